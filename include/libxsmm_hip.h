@@ -1,0 +1,98 @@
+/*
+ * libxsmm_hip.h -- the GPU-side additions to the LIBXSMM dispatch/param API.
+ *
+ * Nothing in here exists in the reference: the reference executes one tiny kernel per
+ * synchronous call on host pointers and leaves batching/threading to the caller's
+ * OpenMP loop [ref: documentation/libxsmm_mm.md:95-107].  A GPU needs the caller's
+ * loop *inside* one launch, a stream to order work on, and device memory.  These entry
+ * points provide exactly that and nothing else; every one of them is plain C ABI
+ * (pointers and sizes, no HIP or torch types in the signatures).
+ *
+ * Semantics of the batched launchers -- the contract the parity tests check:
+ *
+ *   libxsmm_hip_gemm_batch_strided(f, p, count, sa, sb, sc)
+ *     ==  for (i = 0; i < count; ++i) { q = *p;
+ *            q.a.primary = (char*)p->a.primary + i*sa;
+ *            q.b.primary = (char*)p->b.primary + i*sb;
+ *            q.c.primary = (char*)p->c.primary + i*sc;  f(&q); }
+ *
+ * i.e. the caller's loop over independent (BR)GEMMs, with byte strides applied to the
+ * `primary` slots (a stride of 0 shares the operand across the batch, e.g. weights).
+ * In BATCH_REDUCE_ADDRESS mode a/b.primary are pointer arrays, so sa/sb step through
+ * those arrays (sa = br_count*sizeof(void*) gives each batch element its own list).
+ * op.tertiary (br_count), a/b.secondary (offset arrays) are shared by all elements.
+ */
+#ifndef LIBXSMM_HIP_H
+#define LIBXSMM_HIP_H
+
+#if !defined(LIBXSMM_H)
+# error include libxsmm.h, not libxsmm_hip.h
+#endif
+
+/* ---- device, stream and synchronisation policy (state is per host thread) --------- */
+/** Number of visible HIP devices (0 if none: every dispatch then returns NULL). */
+LIBXSMM_API int libxsmm_hip_device_count(void);
+/** Select the device used by the calling thread for subsequent dispatch/launches. */
+LIBXSMM_API int libxsmm_hip_set_device(int device);
+LIBXSMM_API int libxsmm_hip_get_device(void);
+/**
+ * Launch on the given hipStream_t (passed as void*; NULL = the legacy default stream) and
+ * switch the calling thread to stream-ordered (asynchronous) execution: a kernel call
+ * returns after enqueueing, results are valid in stream order.
+ */
+LIBXSMM_API void libxsmm_hip_set_stream(void* hip_stream);
+LIBXSMM_API void* libxsmm_hip_get_stream(void);
+/**
+ * 0 (default, also LIBXSMM_HIP_SYNC=1): every kernel call blocks until C is valid, which
+ * is the reference's semantics.  1: stream-ordered.  LIBXSMM_HIP_ASYNC=1 presets it.
+ */
+LIBXSMM_API void libxsmm_hip_set_async(int enable);
+LIBXSMM_API int libxsmm_hip_get_async(void);
+/** Block until all work enqueued by the calling thread's stream has finished. */
+LIBXSMM_API void libxsmm_hip_sync(void);
+/** Sticky error state of the calling thread (0 = none); kernels have no error channel. */
+LIBXSMM_API int libxsmm_hip_get_last_error(void);
+LIBXSMM_API const char* libxsmm_hip_get_last_error_string(void);
+LIBXSMM_API void libxsmm_hip_clear_last_error(void);
+
+/* ---- device memory for C callers that do not want to include HIP headers ----------- */
+LIBXSMM_API void* libxsmm_hip_malloc(size_t nbytes);
+LIBXSMM_API void libxsmm_hip_free(void* device_ptr);
+LIBXSMM_API int libxsmm_hip_memcpy_h2d(void* device_dst, const void* host_src, size_t nbytes);
+LIBXSMM_API int libxsmm_hip_memcpy_d2h(void* host_dst, const void* device_src, size_t nbytes);
+LIBXSMM_API int libxsmm_hip_memset(void* device_dst, int value, size_t nbytes);
+
+/* ---- batched launches: the caller's loop moved into one grid ------------------------ */
+LIBXSMM_API void libxsmm_hip_gemm_batch_strided(libxsmm_gemmfunction kernel, const libxsmm_gemm_param* param,
+  size_t count, long long stride_a, long long stride_b, long long stride_c);
+/** Adds byte strides for d.primary (fused bias) and c.secondary (ReLU bitmask). */
+LIBXSMM_API void libxsmm_hip_gemm_ext_batch_strided(libxsmm_gemmfunction_ext kernel, const libxsmm_gemm_ext_param* param,
+  size_t count, long long stride_a, long long stride_b, long long stride_c, long long stride_d, long long stride_mask);
+/**
+ * Pointer-list batch: element i uses a_list[i], b_list[i], c_list[i] as its `primary`
+ * slots.  The three lists themselves must be device-accessible arrays of `count` pointers.
+ */
+LIBXSMM_API void libxsmm_hip_gemm_batch_pointers(libxsmm_gemmfunction kernel, const libxsmm_gemm_param* param,
+  size_t count, const void* const* a_list, const void* const* b_list, void* const* c_list);
+LIBXSMM_API void libxsmm_hip_meltw_unary_batch_strided(libxsmm_meltwfunction_unary kernel, const libxsmm_meltw_unary_param* param,
+  size_t count, long long stride_in, long long stride_out, long long stride_aux);
+LIBXSMM_API void libxsmm_hip_meltw_binary_batch_strided(libxsmm_meltwfunction_binary kernel, const libxsmm_meltw_binary_param* param,
+  size_t count, long long stride_in0, long long stride_in1, long long stride_out);
+LIBXSMM_API void libxsmm_hip_meltw_ternary_batch_strided(libxsmm_meltwfunction_ternary kernel, const libxsmm_meltw_ternary_param* param,
+  size_t count, long long stride_in0, long long stride_in1, long long stride_in2, long long stride_out);
+
+/* ---- multi-GPU: the batch / packed / N axis is split by contiguous blocks -----------
+ * One process per GPU; no collective on the data path.  Rank r of `world` owns
+ * [begin, end) of a `count`-long axis (first `count % world` ranks get one extra unit),
+ * after rounding shard boundaries to `granule` units (e.g. the packed width's lane tile). */
+LIBXSMM_API void libxsmm_hip_shard_range(size_t count, size_t granule, int world, int rank, size_t* begin, size_t* end);
+
+/* ---- introspection used by the tests and the bench --------------------------------- */
+/** Name of the device kernel a handle launches for single (batch==0) or batched calls. */
+LIBXSMM_API const char* libxsmm_hip_kernel_name(const void* kernel, int batched);
+/** Number of kernel launches issued by the calling thread since the last reset. */
+LIBXSMM_API unsigned long long libxsmm_hip_launch_count(int reset);
+/** 1 if the library was built with the gfx950 code object and a device is present. */
+LIBXSMM_API int libxsmm_hip_available(void);
+
+#endif /* LIBXSMM_HIP_H */

@@ -1,0 +1,237 @@
+/*
+ * oracle_gemm.c -- CPU restatement of the reference GEMM/BRGEMM semantics (test-only).
+ *
+ * Follows  src/generator_gemm_reference_impl.c  of the reference:
+ *   :180-197   batch-reduce addressing (address / offset / stride)
+ *   :375-661   decoding of the run-time param slots
+ *   :1322-1357 f64, :1359-1426 f32, :2127-2170 bf16->f32, :2367-2419 bf16->bf16 loop nests
+ *   :294-372   fused pre-op (column bias) and post-op (ReLU / sigmoid / down-convert)
+ *   :2802-2853 optional C -> VNNI re-layout and the top-level driver
+ * Instead of one loop nest per datatype there is a single nest over (j, i, r, s) that reads
+ * A/B through index helpers; the *order* of the floating-point operations is kept exactly:
+ * per output element, serially over r then s, product rounded then added (no FMA), with the
+ * two halves of a VNNI k-pair consumed high-k first (reference :2144, :2391).
+ */
+#include "oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct br_cursor {            /* where batch-reduce element r lives */
+  const char* a; const char* b;
+} br_cursor;
+
+typedef struct gemm_view {
+  const oracle_gemm_desc* d;
+  const char* a0; const char* b0;     /* primary slots */
+  const long long* offs_a; const long long* offs_b;
+  void* const* addr_a; void* const* addr_b;
+  long long br;
+  int ta, tb, va, vb;
+  int asz, bsz;
+} gemm_view;
+
+/* element sizes from the public X-table (the oracle does not link the product library) */
+static int tsize(int t) {
+  static const unsigned char sizes[] = {
+#define ORACLE_X_(NAME, SIZE) SIZE,
+    LIBXSMM_DATATYPE_TABLE(ORACLE_X_)
+#undef ORACLE_X_
+    0 };
+  return (t >= 0 && t < (int)LIBXSMM_DATATYPE_COUNT_) ? (int)sizes[t] : 0;
+}
+/* VNNI pack factor of the *host* the reference runs on (x86: bf16 -> 2) [ref: src/libxsmm_cpuid_x86.c:775] */
+enum { ORACLE_BF16_PACK = 2 };
+
+static br_cursor br_at(const gemm_view* v, long long r) {
+  br_cursor c;
+  const unsigned int f = v->d->flags;
+  if (f & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS) {        /* :181-185 */
+    c.a = (const char*)v->addr_a[r]; c.b = (const char*)v->addr_b[r];
+  } else if (f & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET) {  /* :186-188 byte offsets */
+    c.a = v->a0 + v->offs_a[r]; c.b = v->b0 + v->offs_b[r];
+  } else if (f & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_STRIDE) {  /* :189-191 */
+    c.a = v->a0 + v->d->br_stride_a * r; c.b = v->b0 + v->d->br_stride_b * r;
+  } else {
+    c.a = v->a0; c.b = v->b0;
+  }
+  return c;
+}
+
+/* element index of A(i, s) / B(s, j) for the flag combination; kb = VNNI pack factor (1 or 2) */
+static long long a_index(const gemm_view* v, int i, int s, int kb) {
+  const long long lda = v->d->lda;
+  if (!v->ta) return (long long)(s / kb) * (lda * kb) + (long long)i * kb + (s % kb);   /* :2149 (kb=1: :1378) */
+  return (long long)i * lda + s;                                                          /* :2151, :1391 */
+}
+static long long b_index(const gemm_view* v, int s, int j, int kb) {
+  const long long ldb = v->d->ldb;
+  if (v->tb && v->vb) return (long long)j * kb + (long long)(s / kb) * (ldb * kb) + (s % kb); /* :2157 */
+  if (v->tb) return (long long)s * ldb + j;                                                      /* :2159, :1403 */
+  return (long long)j * ldb + s;                                                                 /* :2161, :1379 */
+}
+
+static float load_f32(const char* base, long long idx, int type) {
+  if (type == LIBXSMM_DATATYPE_F32) return ((const float*)base)[idx];
+  return oracle_bf16_to_f32(((const unsigned short*)base)[idx]);
+}
+
+/* C (or the f32 scratch) accumulation for f32 / bf16 inputs. acc points at an m x n f32 image with
+ * leading dimension ldacc which already holds the start value (0, C, bias, bias + C). */
+static void contract_f32(const gemm_view* v, float* acc, long long ldacc) {
+  const oracle_gemm_desc* d = v->d;
+  const int kb = (d->a_type == LIBXSMM_DATATYPE_BF16 && v->va) ? ORACLE_BF16_PACK : 1;
+  int i, j, s, k2; long long r;
+  for (j = 0; j < d->n; ++j) {
+    for (i = 0; i < d->m; ++i) {
+      float c = acc[j * ldacc + i];
+      for (r = 0; r < v->br; ++r) {
+        const br_cursor cur = br_at(v, r);
+        for (s = 0; s < d->k / kb; ++s) {
+          for (k2 = kb - 1; k2 >= 0; --k2) {               /* high half of the pair first */
+            const int kk = s * kb + k2;
+            const float av = load_f32(cur.a, a_index(v, i, kk, kb), d->a_type);
+            const float bv = load_f32(cur.b, b_index(v, kk, j, kb), d->b_type);
+            const float prod = av * bv;
+            c = c + prod;
+          }
+        }
+      }
+      acc[j * ldacc + i] = c;
+    }
+  }
+}
+
+static void contract_f64(const gemm_view* v, double* cmat) {
+  const oracle_gemm_desc* d = v->d;
+  int i, j, s; long long r;
+  for (j = 0; j < d->n; ++j) {
+    for (i = 0; i < d->m; ++i) {
+      double c = (d->flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 0.0 : cmat[(long long)j * d->ldc + i];
+      for (r = 0; r < v->br; ++r) {
+        const br_cursor cur = br_at(v, r);
+        for (s = 0; s < d->k; ++s) {
+          const double prod = ((const double*)cur.a)[a_index(v, i, s, 1)] * ((const double*)cur.b)[b_index(v, s, j, 1)];
+          c = c + prod;
+        }
+      }
+      cmat[(long long)j * d->ldc + i] = c;
+    }
+  }
+}
+
+static void setup_view(gemm_view* v, const void* param, const oracle_gemm_desc* d) {
+  /* both param flavours start with {op, a, b, c}: the ext struct only appends slots */
+  const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
+  memset(v, 0, sizeof(*v));
+  v->d = d;
+  v->ta = (d->flags & LIBXSMM_GEMM_FLAG_TRANS_A) ? 1 : 0;
+  v->tb = (d->flags & LIBXSMM_GEMM_FLAG_TRANS_B) ? 1 : 0;
+  v->va = (d->flags & LIBXSMM_GEMM_FLAG_VNNI_A) ? 1 : 0;
+  v->vb = (d->flags & LIBXSMM_GEMM_FLAG_VNNI_B) ? 1 : 0;
+  v->asz = tsize(d->a_type); v->bsz = tsize(d->b_type);
+  v->a0 = (const char*)p->a.primary; v->b0 = (const char*)p->b.primary;
+  v->br = 1;
+  if (d->flags & (LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_STRIDE)) {
+    v->br = (long long)*(const unsigned long long*)p->op.tertiary;        /* :490-492 */
+  }
+  if (d->flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS) {                /* :494-498 */
+    v->addr_a = (void* const*)p->a.primary; v->addr_b = (void* const*)p->b.primary;
+  } else if (d->flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET) {          /* :509-513 */
+    v->offs_a = (const long long*)p->a.secondary; v->offs_b = (const long long*)p->b.secondary;
+  }
+}
+
+static float act_apply(int act, float x) {
+  if (act == 1 || act == 2) return (x <= 0.0f) ? 0.0f : x;                /* mateltwise ref :2148 */
+  if (act == 3) return (tanhf(x / 2.0f) + 1.0f) / 2.0f;                   /* mateltwise ref :18-20 */
+  return x;
+}
+
+/* NORM -> VNNI2 of a 16-bit m x n matrix, in place through a copy [ref: mateltwise ref :532-557] */
+static void c_to_vnni2_16bit(unsigned short* c, int m, int n, int ldc) {
+  const long long nn = n + (n % 2);
+  unsigned short* tmp = (unsigned short*)malloc(sizeof(unsigned short) * (size_t)ldc * (size_t)nn);
+  long long i, j, j2;
+  memset(tmp, 0, sizeof(unsigned short) * (size_t)ldc * (size_t)nn);
+  memcpy(tmp, c, sizeof(unsigned short) * (size_t)ldc * (size_t)n);
+  for (i = 0; i < (long long)ldc * nn; ++i) c[i] = 0;
+  for (j = 0; j < nn / 2; ++j) for (i = 0; i < m; ++i) for (j2 = 0; j2 < 2; ++j2) {
+    c[j * ldc * 2 + i * 2 + j2] = tmp[(j * 2 + j2) * ldc + i];
+  }
+  free(tmp);
+}
+
+void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
+  gemm_view v;
+  const int is_ext = (d->flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) ? 1 : 0;
+  const int beta0 = (d->flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 1 : 0;
+  const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
+  const libxsmm_gemm_ext_param* pe = (const libxsmm_gemm_ext_param*)param;
+  void* cptr = p->c.primary;
+  int i, j;
+  /* tile-config pseudo kernels are no-ops  [:2821-2826] */
+  if (((d->flags & LIBXSMM_GEMM_FLAG_NO_RESET_TILECONFIG) != 0) != ((d->flags & LIBXSMM_GEMM_FLAG_NO_SETUP_TILECONFIG) != 0)) return;
+  setup_view(&v, param, d);
+
+  if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
+
+  {
+    /* f32 working image: C itself for f32 output, otherwise a scratch of ldc x n floats [:262-272] */
+    const int c_is_f32 = (d->c_type == LIBXSMM_DATATYPE_F32);
+    const long long ldacc = d->ldc;
+    float* acc = c_is_f32 ? (float*)cptr : (float*)malloc(sizeof(float) * (size_t)d->ldc * (size_t)d->n);
+    const int colbias = is_ext ? d->colbias : 0;
+    const int act = is_ext ? d->act : 0;
+    /* start value  [:294-332] */
+    for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+      float start = 0.0f;
+      if (!beta0) start = load_f32((const char*)cptr, (long long)j * d->ldc + i, d->c_type);
+      if (colbias) {
+        const float bias = load_f32((const char*)pe->d.primary, i, d->c_type);   /* D has C's type */
+        start = beta0 ? bias : (bias + start);
+      }
+      acc[j * ldacc + i] = start;
+    }
+    contract_f32(&v, acc, ldacc);
+    /* post-op + store  [:335-372] */
+    if (act != 0 || !c_is_f32) {
+      const long long mask_ld = LIBXSMM_UPDIV(d->ldc, 16) * 16;             /* mateltwise ref :2142 */
+      unsigned char* mask = (act == 2) ? (unsigned char*)pe->c.secondary : NULL;
+      for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+        const float x = acc[j * ldacc + i];
+        const float y = act_apply(act, x);
+        if (c_is_f32) ((float*)cptr)[(long long)j * d->ldc + i] = y;
+        else ((unsigned short*)cptr)[(long long)j * d->ldc + i] = oracle_f32_to_bf16_rne(y);
+        if (mask) {
+          unsigned char* byte = mask + i / 8 + j * (mask_ld / 8);
+          const unsigned char bit = (unsigned char)(1u << (i % 8));
+          if (x <= 0.0f) *byte = (unsigned char)(*byte & ~bit); else *byte = (unsigned char)(*byte | bit);
+        }
+      }
+    }
+    if (!c_is_f32) free(acc);
+    if ((d->flags & LIBXSMM_GEMM_FLAG_VNNI_C) && d->c_type == LIBXSMM_DATATYPE_BF16) {
+      c_to_vnni2_16bit((unsigned short*)cptr, d->m, d->n, d->ldc);          /* :2802-2815 */
+    }
+  }
+}
+
+/* k-ordered fmaf chain: what a v_mfma_f32_32x32x2_f32 accumulation computes when k is
+ * consumed in natural order; used to cross-check kernels more tightly than the tolerance. */
+void oracle_gemm_f32_fma(const void* param, const oracle_gemm_desc* d) {
+  gemm_view v; int i, j, s; long long r;
+  const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
+  float* c = (float*)p->c.primary;
+  setup_view(&v, param, d);
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    float acc = (d->flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 0.0f : c[(long long)j * d->ldc + i];
+    for (r = 0; r < v.br; ++r) {
+      const br_cursor cur = br_at(&v, r);
+      for (s = 0; s < d->k; ++s) {
+        acc = fmaf(((const float*)cur.a)[a_index(&v, i, s, 1)], ((const float*)cur.b)[b_index(&v, s, j, 1)], acc);
+      }
+    }
+    c[(long long)j * d->ldc + i] = acc;
+  }
+}

@@ -1,0 +1,155 @@
+/*
+ * ref_shim.c -- builds the REAL reference (libxsmm/libxsmm under /root/reference) into
+ * oracle/_ref/libxsmm_ref.so so that tests can (1) pin the restatement in oracle_*.c against
+ * it and (2) time the reference's own CPU JIT path as bench.py's cpu_baseline("reference").
+ *
+ * TEST INFRASTRUCTURE ONLY -- never linked into libxsmm_amd.  No reference source is copied:
+ * this translation unit #includes the reference's header-only entry point from where it lies
+ * (the include path is given by oracle/Makefile) and re-exports a handful of its functions
+ * under an `xref_` prefix so both libraries can live in one process.
+ *
+ * Struct layouts/enums are the reference's own here (its headers are in scope), which is also
+ * what makes this shim a layout check for include/libxsmm.h: tests compare sizeof()s.
+ */
+#include <libxsmm_source.h>
+
+#define XREF __attribute__((visibility("default")))
+
+XREF void xref_init(void) { libxsmm_init(); }
+XREF void xref_finalize(void) { libxsmm_finalize(); }
+XREF const char* xref_get_target_arch(void) { return libxsmm_get_target_arch(); }
+XREF void xref_set_target_arch(const char* arch) { libxsmm_set_target_arch(arch); }
+
+/* layout probe: sizes the GPU library's header must reproduce */
+XREF void xref_struct_sizes(size_t* out, int n) {
+  const size_t sizes[] = {
+    sizeof(libxsmm_gemm_param), sizeof(libxsmm_gemm_ext_param), sizeof(libxsmm_matrix_arg), sizeof(libxsmm_matrix_op_arg),
+    sizeof(libxsmm_meltw_unary_param), sizeof(libxsmm_meltw_binary_param), sizeof(libxsmm_meltw_ternary_param),
+    sizeof(libxsmm_gemm_shape), sizeof(libxsmm_gemm_batch_reduce_config), sizeof(libxsmm_gemm_ext_unary_argops),
+    sizeof(libxsmm_gemm_ext_binary_postops), sizeof(libxsmm_meltw_unary_shape), sizeof(libxsmm_meltw_binary_shape),
+    sizeof(libxsmm_meltw_ternary_shape), sizeof(libxsmm_spgemm_config), sizeof(libxsmm_kernel_info),
+    sizeof(libxsmm_mmkernel_info), sizeof(libxsmm_descriptor_blob)
+  };
+  int i; for (i = 0; i < n && i < (int)(sizeof(sizes) / sizeof(*sizes)); ++i) out[i] = sizes[i];
+}
+
+/* --- the reference's C reference implementations (the parity oracle proper) ------------- */
+XREF int xref_reference_gemm(const void* param, libxsmm_gemm_shape shape, libxsmm_bitfield flags,
+  libxsmm_bitfield prefetch, libxsmm_gemm_batch_reduce_config brcfg)
+{
+  libxsmm_descriptor_blob blob;
+  const libxsmm_gemm_descriptor* desc = libxsmm_gemm_descriptor_init_brgemm(&blob, shape, flags, prefetch, brcfg);
+  if (NULL == desc) return -1;
+  libxsmm_reference_gemm((void*)param, desc);
+  return 0;
+}
+XREF int xref_reference_gemm_ext(const void* param, libxsmm_gemm_shape shape, libxsmm_bitfield flags,
+  libxsmm_bitfield prefetch, libxsmm_gemm_batch_reduce_config brcfg,
+  libxsmm_gemm_ext_unary_argops argops, libxsmm_gemm_ext_binary_postops postops)
+{
+  libxsmm_descriptor_blob blob;
+  const libxsmm_gemm_descriptor* desc = libxsmm_gemm_descriptor_init_brgemm_ext(&blob, shape, flags, prefetch, brcfg, argops, postops);
+  if (NULL == desc) return -1;
+  libxsmm_reference_gemm((void*)param, desc);
+  return 0;
+}
+XREF int xref_reference_meltw_unary(const void* param, libxsmm_meltw_unary_type type, libxsmm_meltw_unary_shape s, libxsmm_bitfield flags) {
+  libxsmm_descriptor_blob blob;
+  const libxsmm_meltw_descriptor* desc = libxsmm_meltw_descriptor_init2(&blob, s.in0_type, LIBXSMM_DATATYPE_UNSUPPORTED,
+    LIBXSMM_DATATYPE_UNSUPPORTED, s.comp_type, s.out_type, s.m, s.n, s.ldi, s.ldo, 0, 0,
+    (unsigned short)flags, (unsigned short)type, LIBXSMM_MELTW_OPERATION_UNARY);
+  libxsmm_reference_elementwise((void*)param, desc);
+  return 0;
+}
+XREF int xref_reference_meltw_binary(const void* param, libxsmm_meltw_binary_type type, libxsmm_meltw_binary_shape s, libxsmm_bitfield flags) {
+  libxsmm_descriptor_blob blob;
+  const libxsmm_meltw_descriptor* desc = libxsmm_meltw_descriptor_init2(&blob, s.in0_type, s.in1_type,
+    LIBXSMM_DATATYPE_UNSUPPORTED, s.comp_type, s.out_type, s.m, s.n, s.ldi, s.ldo, s.ldi2, 0,
+    (unsigned short)flags, (unsigned short)type, LIBXSMM_MELTW_OPERATION_BINARY);
+  libxsmm_reference_elementwise((void*)param, desc);
+  return 0;
+}
+XREF int xref_reference_meltw_ternary(const void* param, libxsmm_meltw_ternary_type type, libxsmm_meltw_ternary_shape s, libxsmm_bitfield flags) {
+  libxsmm_descriptor_blob blob;
+  const libxsmm_meltw_descriptor* desc = libxsmm_meltw_descriptor_init2(&blob, s.in0_type, s.in1_type, s.in2_type,
+    s.comp_type, s.out_type, s.m, s.n, s.ldi, s.ldo, s.ldi2, s.ldi3,
+    (unsigned short)flags, (unsigned short)type, LIBXSMM_MELTW_OPERATION_TERNARY);
+  libxsmm_reference_elementwise((void*)param, desc);
+  return 0;
+}
+
+/* --- the reference's CPU JIT dispatch (CPU baseline + second opinion) ----------------------- */
+XREF libxsmm_gemmfunction xref_dispatch_gemm(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch) {
+  return libxsmm_dispatch_gemm(shape, flags, prefetch);
+}
+XREF libxsmm_gemmfunction xref_dispatch_brgemm(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch,
+  libxsmm_gemm_batch_reduce_config brcfg) {
+  return libxsmm_dispatch_brgemm(shape, flags, prefetch, brcfg);
+}
+XREF libxsmm_gemmfunction_ext xref_dispatch_brgemm_ext(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch,
+  libxsmm_gemm_batch_reduce_config brcfg, libxsmm_gemm_ext_unary_argops argops, libxsmm_gemm_ext_binary_postops postops) {
+  return libxsmm_dispatch_brgemm_ext(shape, flags, prefetch, brcfg, argops, postops);
+}
+XREF libxsmm_meltwfunction_unary xref_dispatch_meltw_unary(libxsmm_meltw_unary_type t, libxsmm_meltw_unary_shape s, libxsmm_bitfield f) {
+  return libxsmm_dispatch_meltw_unary(t, s, f);
+}
+XREF libxsmm_meltwfunction_binary xref_dispatch_meltw_binary(libxsmm_meltw_binary_type t, libxsmm_meltw_binary_shape s, libxsmm_bitfield f) {
+  return libxsmm_dispatch_meltw_binary(t, s, f);
+}
+XREF libxsmm_meltwfunction_ternary xref_dispatch_meltw_ternary(libxsmm_meltw_ternary_type t, libxsmm_meltw_ternary_shape s, libxsmm_bitfield f) {
+  return libxsmm_dispatch_meltw_ternary(t, s, f);
+}
+XREF libxsmm_gemmfunction xref_create_packed_spgemm_csr(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch,
+  libxsmm_blasint packed_width, const unsigned int* row_ptr, const unsigned int* column_idx, const void* values) {
+  return libxsmm_create_packed_spgemm_csr(shape, flags, prefetch, packed_width, row_ptr, column_idx, values);
+}
+XREF libxsmm_gemmfunction xref_create_packed_spgemm_csc(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch,
+  libxsmm_blasint packed_width, const unsigned int* column_ptr, const unsigned int* row_idx, const void* values) {
+  return libxsmm_create_packed_spgemm_csc(shape, flags, prefetch, packed_width, column_ptr, row_idx, values);
+}
+XREF libxsmm_gemmfunction xref_create_packed_spgemm_bcsc(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch,
+  libxsmm_spgemm_config cfg) {
+  return libxsmm_create_packed_spgemm_bcsc(shape, flags, prefetch, cfg);
+}
+XREF void xref_release_kernel(const void* kernel) { libxsmm_release_kernel(kernel); }
+XREF int xref_get_kernel_info(const void* kernel, libxsmm_kernel_info* info) { return libxsmm_get_kernel_info(kernel, info); }
+
+XREF libxsmm_fsspmdm* xref_fsspmdm_create(libxsmm_datatype datatype, libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K,
+  libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc, const void* alpha, const void* beta, const void* a_dense,
+  int c_is_nt, libxsmm_timer_tickint (*timer_tick)(void)) {
+  return libxsmm_fsspmdm_create(datatype, M, N, K, lda, ldb, ldc, alpha, beta, a_dense, c_is_nt, timer_tick);
+}
+XREF void xref_fsspmdm_execute(const libxsmm_fsspmdm* handle, const void* B, void* C) { libxsmm_fsspmdm_execute(handle, B, C); }
+XREF void xref_fsspmdm_destroy(libxsmm_fsspmdm* handle) { libxsmm_fsspmdm_destroy(handle); }
+
+/* --- small helpers the pin tests use ------------------------------------------------------------ */
+XREF unsigned short xref_convert_f32_to_bf16_rne(float x) { return libxsmm_convert_f32_to_bf16_rne(x); }
+XREF unsigned short xref_convert_f32_to_bf16_truncate(float x) { return libxsmm_convert_f32_to_bf16_truncate(x); }
+XREF float xref_convert_bf16_to_f32(unsigned short x) { return libxsmm_convert_bf16_to_f32(x); }
+XREF int xref_cpuid_dot_pack_factor(libxsmm_datatype t) { return libxsmm_cpuid_dot_pack_factor(t); }
+XREF double xref_matdiff_normf_rel(libxsmm_datatype t, libxsmm_blasint m, libxsmm_blasint n, const void* ref, const void* tst) {
+  libxsmm_matdiff_info info; libxsmm_matdiff_clear(&info);
+  if (EXIT_SUCCESS != libxsmm_matdiff(&info, t, m, n, ref, tst, NULL, NULL)) return -1.0;
+  return info.normf_rel;
+}
+
+/* Time `reps` back-to-back calls of a JIT'ed (BR)GEMM over `count` independent problems laid out
+ * with byte strides -- the caller's loop of the reference (documentation/libxsmm_mm.md:95-107),
+ * single-threaded.  Returns seconds.  Used only by bench.py's cpu_baseline leg. */
+XREF double xref_time_gemm_batch(libxsmm_gemmfunction kernel, const libxsmm_gemm_param* param, size_t count,
+  long long sa, long long sb, long long sc, int reps)
+{
+  libxsmm_timer_tickint t0, t1; int r; size_t i;
+  libxsmm_gemm_param q = *param;
+  t0 = libxsmm_timer_tick();
+  for (r = 0; r < reps; ++r) {
+    for (i = 0; i < count; ++i) {
+      q.a.primary = (char*)param->a.primary + (long long)i * sa;
+      q.b.primary = (char*)param->b.primary + (long long)i * sb;
+      q.c.primary = (char*)param->c.primary + (long long)i * sc;
+      kernel(&q);
+    }
+  }
+  t1 = libxsmm_timer_tick();
+  return libxsmm_timer_duration(t0, t1);
+}
