@@ -1,0 +1,194 @@
+// frontend.cpp -- FsSpMDM (fixed-size sparse matrix x dense matrix) on top of the sparse panel
+// kernel, plus the host-side helpers the reference's sample drivers link against (allocator,
+// timer, RNG, bf16 conversions, matdiff).  The helpers run on the CPU by nature (they prepare and
+// compare test data); no compute of the hot path lives here.
+//
+// FsSpMDM [ref: src/libxsmm_fsspmdm.c:24-560]: row-major C[MxN] = alpha*A*B + beta*C with a dense A
+// that is sparsified at creation (alpha folded into the values), beta in {0,1}, N a multiple of the
+// 64-byte "vector length" of the reference's AVX-512 host (kept so that the same inputs are accepted
+// and rejected).  The reference builds up to three register-blocked sparse kernels plus a dense
+// fallback and optionally auto-tunes between them; on the GPU there is one kernel -- lanes along N,
+// the operator staged as scalars -- so the tuning knobs (timer_tick, LIBXSMM_FSSPMDM_HINT) are accepted
+// and ignored.
+#include <hip/hip_runtime_api.h>
+#include "internal.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+using namespace xamd;
+
+struct libxsmm_fsspmdm {
+  libxsmm_gemmfunction kernel;
+  libxsmm_datatype datatype;
+  int M, N, K, ldb, ldc;
+};
+
+extern "C" {
+
+LIBXSMM_API libxsmm_fsspmdm* libxsmm_fsspmdm_create(libxsmm_datatype datatype, libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K,
+  libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc, const void* alpha, const void* beta, const void* a_dense, int c_is_nt,
+  libxsmm_timer_tickint (*timer_tick)(void))
+{
+  (void)c_is_nt; (void)timer_tick;
+  if (!a_dense || !runtime_ready()) return nullptr;                                          // [ref: fsspmdm.c:47-54]
+  if (datatype != LIBXSMM_DATATYPE_F32 && datatype != LIBXSMM_DATATYPE_F64) return nullptr;
+  const int typesz = (datatype == LIBXSMM_DATATYPE_F64) ? 8 : 4;
+  const int vl = 64 / typesz;                                                                  // [ref: fsspmdm.c:58-62]
+  const double fbeta = beta ? (datatype == LIBXSMM_DATATYPE_F64 ? *(const double*)beta : (double)*(const float*)beta) : 1.0;
+  const double falpha = alpha ? (datatype == LIBXSMM_DATATYPE_F64 ? *(const double*)alpha : (double)*(const float*)alpha) : 1.0;
+  if (M <= 0 || N <= 0 || K <= 0 || (N % vl) != 0 || !(fbeta == 1.0 || fbeta == 0.0) || lda < K || ldc < N || ldb < N) return nullptr;   // [ref: fsspmdm.c:83-85]
+  // dense -> CSR with alpha folded in; entries that become exactly zero are dropped [ref: fsspmdm.c:196-236]
+  std::vector<unsigned int> rowptr((size_t)M + 1, 0), colidx;
+  std::vector<double> values;
+  for (int i = 0; i < M; ++i) {
+    rowptr[i] = (unsigned int)values.size();
+    for (int j = 0; j < K; ++j) {
+      double v;
+      if (datatype == LIBXSMM_DATATYPE_F64) v = falpha * ((const double*)a_dense)[(size_t)i * lda + j];
+      else v = (double)((float)falpha * ((const float*)a_dense)[(size_t)i * lda + j]);
+      if (v != 0.0) { values.push_back(v); colidx.push_back((unsigned int)j); }
+    }
+  }
+  rowptr[M] = (unsigned int)values.size();
+  if (values.empty()) return nullptr;                                                          // empty matrix [ref: fsspmdm.c:133-141]
+  const libxsmm_gemm_shape shape = libxsmm_create_gemm_shape(M, N, K, 0, ldb, ldc, datatype, datatype, datatype, datatype);
+  const libxsmm_bitfield flags = (fbeta == 0.0) ? LIBXSMM_GEMM_FLAG_BETA_0 : 0;
+  libxsmm_gemmfunction kernel = libxsmm_create_spgemm_csr_areg(shape, flags, LIBXSMM_GEMM_PREFETCH_NONE, N, rowptr.data(), colidx.data(), values.data());
+  if (!kernel) return nullptr;
+  libxsmm_fsspmdm* h = new libxsmm_fsspmdm();
+  h->kernel = kernel; h->datatype = datatype; h->M = M; h->N = N; h->K = K; h->ldb = ldb; h->ldc = ldc;
+  return h;
+}
+LIBXSMM_API libxsmm_dfsspmdm* libxsmm_dfsspmdm_create(libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K, libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc,
+  double alpha, double beta, const double* a_dense, int c_is_nt, libxsmm_timer_tickint (*timer_tick)(void)) {
+  return libxsmm_fsspmdm_create(LIBXSMM_DATATYPE_F64, M, N, K, lda, ldb, ldc, &alpha, &beta, a_dense, c_is_nt, timer_tick);
+}
+LIBXSMM_API libxsmm_sfsspmdm* libxsmm_sfsspmdm_create(libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K, libxsmm_blasint lda, libxsmm_blasint ldb, libxsmm_blasint ldc,
+  float alpha, float beta, const float* a_dense, int c_is_nt, libxsmm_timer_tickint (*timer_tick)(void)) {
+  return libxsmm_fsspmdm_create(LIBXSMM_DATATYPE_F32, M, N, K, lda, ldb, ldc, &alpha, &beta, a_dense, c_is_nt, timer_tick);
+}
+LIBXSMM_API void libxsmm_fsspmdm_execute(const libxsmm_fsspmdm* h, const void* B, void* C) {   // [ref: fsspmdm.c:491-514]
+  if (!h) return;
+  libxsmm_gemm_param p; std::memset(&p, 0, sizeof(p));
+  p.b.primary = const_cast<void*>(B); p.c.primary = C;
+  h->kernel(&p);
+}
+LIBXSMM_API void libxsmm_dfsspmdm_execute(const libxsmm_dfsspmdm* h, const double* B, double* C) { libxsmm_fsspmdm_execute(h, B, C); }
+LIBXSMM_API void libxsmm_sfsspmdm_execute(const libxsmm_sfsspmdm* h, const float* B, float* C) { libxsmm_fsspmdm_execute(h, B, C); }
+LIBXSMM_API void libxsmm_fsspmdm_destroy(libxsmm_fsspmdm* h) {
+  if (!h) return;
+  libxsmm_release_kernel((const void*)h->kernel);
+  delete h;
+}
+LIBXSMM_API void libxsmm_dfsspmdm_destroy(libxsmm_dfsspmdm* h) { libxsmm_fsspmdm_destroy(h); }
+LIBXSMM_API void libxsmm_sfsspmdm_destroy(libxsmm_sfsspmdm* h) { libxsmm_fsspmdm_destroy(h); }
+
+// ---- allocator: pinned, device-visible host memory so unmodified drivers keep working ------------
+LIBXSMM_API void* libxsmm_aligned_malloc(size_t size, size_t alignment) {
+  (void)alignment;   // hipHostMalloc returns page-aligned memory
+  void* p = nullptr;
+  if (libxsmm_hip_device_count() > 0) {
+    if (hipHostMalloc(&p, size ? size : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+  }
+  if (posix_memalign(&p, 64, size ? size : 1) != 0) return nullptr;
+  return p;
+}
+LIBXSMM_API void* libxsmm_malloc(size_t size) { return libxsmm_aligned_malloc(size, 64); }
+LIBXSMM_API void libxsmm_free(const void* memory) {
+  if (!memory) return;
+  if (libxsmm_hip_device_count() > 0) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, memory) == hipSuccess && attr.type == hipMemoryTypeHost) { (void)hipHostFree(const_cast<void*>(memory)); return; }
+    (void)hipGetLastError();
+  }
+  std::free(const_cast<void*>(memory));
+}
+
+// ---- timer / rng -----------------------------------------------------------------------------------------
+LIBXSMM_API libxsmm_timer_tickint libxsmm_timer_tick(void) {
+  return (libxsmm_timer_tickint)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+LIBXSMM_API double libxsmm_timer_duration(libxsmm_timer_tickint t0, libxsmm_timer_tickint t1) { return (t1 >= t0 ? (double)(t1 - t0) : 0.0) * 1e-9; }
+
+static unsigned long long g_rng_state = 0x9E3779B97F4A7C15ull;
+static unsigned long long rng_next() {   // splitmix64
+  unsigned long long z = (g_rng_state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+LIBXSMM_API void libxsmm_rng_set_seed(unsigned int seed) { g_rng_state = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)seed << 17); }
+LIBXSMM_API double libxsmm_rng_f64(void) { return (double)(rng_next() >> 11) * (1.0 / 9007199254740992.0); }
+LIBXSMM_API unsigned int libxsmm_rng_u32(unsigned int n) { return n ? (unsigned int)(rng_next() % n) : 0; }
+
+// ---- bf16 conversions [ref: src/libxsmm_math.c:640-704] ------------------------------------------------
+static unsigned int f2u(float f) { unsigned int u; std::memcpy(&u, &f, 4); return u; }
+LIBXSMM_API float libxsmm_convert_bf16_to_f32(libxsmm_bfloat16 in) { const unsigned int u = (unsigned int)in << 16; float f; std::memcpy(&f, &u, 4); return f; }
+static unsigned int bf16_front(unsigned int u, bool* special) {
+  if ((u & 0x7f800000u) == 0) u &= 0x80000000u;
+  *special = (u & 0x7f800000u) == 0x7f800000u;
+  if (*special && (u & 0x007fffffu)) u |= 0x00400000u;
+  return u;
+}
+LIBXSMM_API libxsmm_bfloat16 libxsmm_convert_f32_to_bf16_rne(float in) {
+  bool sp; unsigned int u = bf16_front(f2u(in), &sp);
+  if (!sp) u += 0x00007fffu + ((u >> 16) & 1u);
+  return (libxsmm_bfloat16)(u >> 16);
+}
+LIBXSMM_API libxsmm_bfloat16 libxsmm_convert_f32_to_bf16_truncate(float in) { bool sp; return (libxsmm_bfloat16)(bf16_front(f2u(in), &sp) >> 16); }
+LIBXSMM_API void libxsmm_rne_convert_fp32_bf16(const float* in, libxsmm_bfloat16* out, unsigned int n) { for (unsigned int i = 0; i < n; ++i) out[i] = libxsmm_convert_f32_to_bf16_rne(in[i]); }
+LIBXSMM_API void libxsmm_truncate_convert_f32_bf16(const float* in, libxsmm_bfloat16* out, unsigned int n) { for (unsigned int i = 0; i < n; ++i) out[i] = libxsmm_convert_f32_to_bf16_truncate(in[i]); }
+LIBXSMM_API void libxsmm_convert_bf16_f32(const libxsmm_bfloat16* in, float* out, unsigned int n) { for (unsigned int i = 0; i < n; ++i) out[i] = libxsmm_convert_bf16_to_f32(in[i]); }
+
+// ---- matdiff: the subset of statistics the drivers read [ref: src/libxsmm_matdiff.h; libxsmm_math.c:35-300] ----
+LIBXSMM_API void libxsmm_matdiff_clear(libxsmm_matdiff_info* info) {
+  if (!info) return;
+  std::memset(info, 0, sizeof(*info));
+  info->min_ref = info->min_tst = INFINITY; info->max_ref = info->max_tst = -INFINITY;
+}
+static double md_load(libxsmm_datatype t, const void* p, size_t i) {
+  switch (t) {
+    case LIBXSMM_DATATYPE_F64: return ((const double*)p)[i];
+    case LIBXSMM_DATATYPE_F32: return ((const float*)p)[i];
+    case LIBXSMM_DATATYPE_BF16: return libxsmm_convert_bf16_to_f32(((const libxsmm_bfloat16*)p)[i]);
+    case LIBXSMM_DATATYPE_I32: return ((const int*)p)[i];
+    case LIBXSMM_DATATYPE_I16: return ((const short*)p)[i];
+    case LIBXSMM_DATATYPE_I8: return ((const signed char*)p)[i];
+    default: return NAN;
+  }
+}
+LIBXSMM_API int libxsmm_matdiff(libxsmm_matdiff_info* info, libxsmm_datatype datatype, libxsmm_blasint m, libxsmm_blasint n,
+  const void* ref, const void* tst, const libxsmm_blasint* ldref, const libxsmm_blasint* ldtst) {
+  if (!info || !ref || m < 0 || n < 0) return EXIT_FAILURE;
+  const size_t ldr = ldref ? (size_t)*ldref : (size_t)m, ldt = ldtst ? (size_t)*ldtst : (size_t)m;
+  libxsmm_matdiff_clear(info);
+  double l2_abs = 0, normfr = 0, l1_ref = 0, l1_tst = 0; size_t cnt = 0;
+  for (libxsmm_blasint j = 0; j < n; ++j) for (libxsmm_blasint i = 0; i < m; ++i) {
+    const double r = md_load(datatype, ref, j * ldr + i), t = tst ? md_load(datatype, tst, j * ldt + i) : 0.0;
+    if (std::isnan(r) && std::isnan(t)) continue;
+    const double d = std::fabs(r - t), ra = std::fabs(r), ta = std::fabs(t);
+    if (r < info->min_ref) info->min_ref = r; if (r > info->max_ref) info->max_ref = r;
+    if (t < info->min_tst) info->min_tst = t; if (t > info->max_tst) info->max_tst = t;
+    if (d > info->linf_abs || std::isnan(d)) { info->linf_abs = d; info->v_ref = r; info->v_tst = t; info->m = i; info->n = j; }
+    const double rel = ra > 0 ? d / ra : (ta > 0 ? d / ta : 0.0);
+    if (rel > info->linf_rel) info->linf_rel = rel;
+    l2_abs += d * d; normfr += r * r; l1_ref += ra; l1_tst += ta; ++cnt;
+  }
+  info->l1_ref = l1_ref; info->l1_tst = l1_tst;
+  if (cnt) { info->avg_ref = l1_ref / cnt; info->avg_tst = l1_tst / cnt; }
+  info->normf_rel = std::sqrt(normfr > 0 ? l2_abs / normfr : l2_abs);
+  double ss_tot = 0;
+  for (libxsmm_blasint j = 0; j < n; ++j) for (libxsmm_blasint i = 0; i < m; ++i) { const double r = md_load(datatype, ref, j * ldr + i) - info->avg_ref; ss_tot += r * r; }
+  info->var_ref = ss_tot; info->rsq = ss_tot > 0 ? std::max(0.0, 1.0 - l2_abs / ss_tot) : (l2_abs > 0 ? 0.0 : 1.0);
+  info->norm1_abs = info->normi_abs = info->linf_abs; info->norm1_rel = info->normi_rel = info->linf_rel;
+  return EXIT_SUCCESS;
+}
+LIBXSMM_API double libxsmm_matdiff_epsilon(const libxsmm_matdiff_info* in) {
+  if (!in) return 0.0;
+  if (in->rsq > 0) return std::min(in->normf_rel, in->linf_abs) / in->rsq;   // [ref: libxsmm_math.c:322-332]
+  return std::max(in->linf_abs, in->normf_rel);
+}
+
+}  // extern "C"

@@ -1,0 +1,567 @@
+// gemm_kernels.hip -- dense GEMM / BRGEMM kernels for gfx950 (MI355X, CDNA4).
+//
+// Semantics restated from the reference [ref: src/generator_gemm_reference_impl.c:1359-1426 (f32),
+// :2127-2170 / :2367-2419 (bf16), :294-372 (fused bias / ReLU / sigmoid), :180-197 (BR addressing)]:
+//   C[m x n] = act( bcast_col(D) + beta*C + sum_{r<br} A_r * B_r ),  alpha == 1, beta in {0,1}
+// all matrices column-major ("m fastest").  One *wavefront* owns one output tile for the whole
+// (batch-reduce, K) reduction; the batch axis of the batched launchers is simply more tiles.
+//
+// Kernel families
+//   gemm_mfma_f32   v_mfma_f32_32x32x2_f32.  The product is formed TRANSPOSED (D' = B^T A^T): the
+//                   MFMA result then has lanes running along GEMM-i, the contiguous dimension of
+//                   C, so C is read/written with fully coalesced 128-byte rows and the A operand
+//                   (m contiguous) is loaded straight into its fragment layout with coalesced
+//                   dword loads -- no LDS round trip.  The k-contiguous operand (B, or A under
+//                   TRANS_A) is fetched with 16-byte loads and put into natural k order with
+//                   v_permlane32_swap, so the accumulation is the k-ordered fmaf chain.
+//   gemm_mfma_f32_t16  v_mfma_f32_16x16x4_f32 for m,n multiples of 16 (the 16^3 headline shape).
+//   gemm_mfma_bf16  v_mfma_f32_32x32x16_bf16, A in VNNI-2 layout, fp32 accumulate, one RNE at store.
+//   gemm_generic    one thread per C element, no FMA contraction, every dtype/flag combination the
+//                   library accepts (f64, flat/transposed bf16, VNNI_B, VNNI_C ...): the semantic
+//                   backstop, bit-identical to the reference's serial loops.
+// All four are HBM-bound for the small shapes this library exists for (32^3 f32: 5.3 flop/byte),
+// so they are organised as streaming kernels: many independent waves, each with its whole tile
+// (8-24 KiB) of loads in flight, no barriers, no LDS.
+#include <hip/hip_runtime.h>
+#include "internal.hpp"
+
+// a*b+c below means two roundings unless fma()/MFMA is spelled out: parity with the reference's C
+// loops (built without FMA contraction) depends on it.
+#pragma clang fp contract(off)
+
+namespace xamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(unsigned short x) { return __uint_as_float((unsigned int)x << 16); }
+// RNE with denormals-are-zero and NaN quieting [ref: src/libxsmm_math.c:684-704]
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7f800000u) == 0u) u &= 0x80000000u;
+  if ((u & 0x7f800000u) == 0x7f800000u) { if (u & 0x007fffffu) u |= 0x00400000u; }
+  else u += 0x00007fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float act_apply(int act, float x) {
+  if (act == 1 || act == 2) return (x <= 0.0f) ? 0.0f : x;
+  if (act == 3) return (tanhf(x * 0.5f) + 1.0f) * 0.5f;   // [ref: mateltwise ref :18-20]
+  return x;
+}
+
+struct BatchPtrs { const char* a; const char* b; char* c; const char* d; unsigned char* mask; };
+__device__ __forceinline__ BatchPtrs batch_ptrs(const GemmArgs& p, unsigned int bidx) {
+  BatchPtrs q;
+  if (p.list_a) { q.a = (const char*)p.list_a[bidx]; q.b = (const char*)p.list_b[bidx]; q.c = (char*)p.list_c[bidx]; }
+  else { q.a = p.a + (long long)bidx * p.bs_a; q.b = p.b + (long long)bidx * p.bs_b; q.c = p.c + (long long)bidx * p.bs_c; }
+  q.d = p.d ? p.d + (long long)bidx * p.bs_d : nullptr;
+  q.mask = p.relu_mask ? p.relu_mask + (long long)bidx * p.bs_mask : nullptr;
+  return q;
+}
+// base of batch-reduce element r [ref: gemm ref :180-197]
+__device__ __forceinline__ void br_base(const GemmArgs& p, const BatchPtrs& q, unsigned long long r, const char*& a, const char*& b) {
+  if (p.br_mode == 1) { a = (const char*)((const void* const*)q.a)[r]; b = (const char*)((const void* const*)q.b)[r]; }
+  else if (p.br_mode == 2) { a = q.a + p.offs_a[r]; b = q.b + p.offs_b[r]; }
+  else if (p.br_mode == 3) { a = q.a + p.br_stride_a * (long long)r; b = q.b + p.br_stride_b * (long long)r; }
+  else { a = q.a; b = q.b; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic kernel: one thread per C element
+// ------------------------------------------------------------------------------------------------
+// Under `#pragma clang fp contract(off)` a product followed by a sum is two correctly rounded
+// operations (the HIP __fmul_rn/__fadd_rn helpers are plain operators compiled with the header's
+// own contraction setting and DO get fused, so they are not used).
+template <typename T> __device__ __forceinline__ T mul_rn(T a, T b) { return a * b; }
+template <typename T> __device__ __forceinline__ T add_rn(T a, T b) { return a + b; }
+
+__device__ __forceinline__ float load_as_f32(const char* base, long long idx, int type) {
+  return (type == LIBXSMM_DATATYPE_F32) ? ((const float*)base)[idx] : bf16_to_f32(((const unsigned short*)base)[idx]);
+}
+
+// block = (64, 4): x walks i (so a wave is 64 consecutive rows of one column, which makes the
+// ReLU bitmask a ballot), y walks j.
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
+  const int tiles_i = (p.m + 63) / 64, tiles_j = (p.n + 3) / 4;
+  const long long per_gemm = (long long)tiles_i * tiles_j;
+  const long long blk = blockIdx.x;
+  const unsigned int bidx = (unsigned int)(blk / per_gemm);
+  const int t = (int)(blk % per_gemm);
+  const int i = (t % tiles_i) * 64 + threadIdx.x;
+  const int j = (t / tiles_i) * 4 + threadIdx.y;
+  const bool valid = (i < p.m) && (j < p.n);
+  const BatchPtrs q = batch_ptrs(p, bidx);
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  const bool ta = (p.flags & LIBXSMM_GEMM_FLAG_TRANS_A) != 0, tb = (p.flags & LIBXSMM_GEMM_FLAG_TRANS_B) != 0;
+  const bool va = (p.flags & LIBXSMM_GEMM_FLAG_VNNI_A) != 0, vb = (p.flags & LIBXSMM_GEMM_FLAG_VNNI_B) != 0;
+
+  if (p.a_type == LIBXSMM_DATATYPE_F64) {
+    if (!valid) return;
+    double* c = (double*)q.c + (long long)j * p.ldc + i;
+    double acc = beta0 ? 0.0 : *c;
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      const char *ar, *br; br_base(p, q, r, ar, br);
+      const double* a = (const double*)ar; const double* b = (const double*)br;
+      for (int s = 0; s < p.k; ++s) {
+        const double av = ta ? a[(long long)i * p.lda + s] : a[(long long)s * p.lda + i];
+        const double bv = tb ? b[(long long)s * p.ldb + j] : b[(long long)j * p.ldb + s];
+        acc = add_rn(acc, mul_rn(av, bv));
+      }
+    }
+    *c = acc;
+    return;
+  }
+
+  float acc = 0.0f;
+  if (valid) {
+    const int kb = (p.a_type == LIBXSMM_DATATYPE_BF16 && va) ? 2 : 1;
+    if (!beta0) acc = load_as_f32(q.c, (long long)j * p.ldc + i, p.c_type);
+    if (p.colbias) {
+      const float bias = load_as_f32(q.d, i, p.c_type);
+      acc = beta0 ? bias : add_rn(bias, acc);
+    }
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      const char *ar, *br; br_base(p, q, r, ar, br);
+      for (int s = 0; s < p.k / kb; ++s) {
+        for (int k2 = kb - 1; k2 >= 0; --k2) {          // VNNI pair: high k first [ref: gemm ref :2144]
+          const int kk = s * kb + k2;
+          const long long ai = ta ? ((long long)i * p.lda + kk)
+                                  : ((long long)(kk / kb) * ((long long)p.lda * kb) + (long long)i * kb + (kk % kb));
+          const long long bi = (tb && vb) ? ((long long)j * kb + (long long)(kk / kb) * ((long long)p.ldb * kb) + (kk % kb))
+                              : tb ? ((long long)kk * p.ldb + j) : ((long long)j * p.ldb + kk);
+          acc = add_rn(acc, mul_rn(load_as_f32(ar, ai, p.a_type), load_as_f32(br, bi, p.b_type)));
+        }
+      }
+    }
+  }
+  const float y = act_apply(p.act, acc);
+  if (p.act == 2 && q.mask) {   // bit i%8 of byte i/8 + j*(mask_ld/8) [ref: mateltwise ref :150-157, :2142]
+    const unsigned long long ballot = __ballot(valid && !(acc <= 0.0f));
+    const unsigned long long vmask = __ballot(valid);
+    const int lane = threadIdx.x;   // blockDim.x == 64: lane within the wave
+    if ((lane & 7) == 0 && valid) {
+      const long long mask_ld = ((p.ldc + 15) / 16) * 16;
+      unsigned char* byte = q.mask + i / 8 + (long long)j * (mask_ld / 8);
+      const unsigned char vm = (unsigned char)((vmask >> lane) & 0xffu);
+      const unsigned char nb = (unsigned char)((ballot >> lane) & 0xffu);
+      *byte = (unsigned char)((*byte & ~vm) | (nb & vm));
+    }
+  }
+  if (!valid) return;
+  if (p.vnni_c && p.c_type == LIBXSMM_DATATYPE_BF16) {
+    // NORM -> VNNI2 of the result [ref: gemm ref :2802-2815]; the pad column of an odd n is zero-filled
+    unsigned short* c = (unsigned short*)q.c;
+    c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + (j % 2)] = f32_to_bf16_rne(y);
+    if ((p.n & 1) && j == p.n - 1) c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + 1] = 0;
+  } else if (p.c_type == LIBXSMM_DATATYPE_F32) {
+    ((float*)q.c)[(long long)j * p.ldc + i] = y;
+  } else {
+    ((unsigned short*)q.c)[(long long)j * p.ldc + i] = f32_to_bf16_rne(y);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA building blocks.  "X" operand: free index contiguous in memory, element (f,k) at base[f + k*ld]
+// (A normal, B under TRANS_B).  "Y" operand: k contiguous, element (f,k) at base[k + f*ld] (B normal,
+// A under TRANS_A).  Both deliver w[s] = op(f = lane&31, k = k0 + 2s + (lane>>5)), s = 0..15, the
+// operand layout of v_mfma_f32_32x32x2_f32 in natural k order.
+// ------------------------------------------------------------------------------------------------
+template <bool EXACT>
+__device__ __forceinline__ void load_x_f32(float (&w)[16], const float* base, long long ld, int f, bool fvalid, int k0, int K, int h) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = k0 + 2 * s + h;
+    w[s] = (EXACT || (fvalid && k < K)) ? base[f + (long long)k * ld] : 0.0f;
+  }
+}
+template <bool EXACT>
+__device__ __forceinline__ void load_y_f32(float (&w)[16], const float* base, long long ld, int f, bool fvalid, int k0, int K, int h) {
+  const float* col = base + (long long)f * ld + k0 + 16 * h;   // this lane's 16 consecutive k
+  float v[16];
+  // wave-uniform alignment test: 16-byte loads need ld % 4 == 0 and a 16-byte aligned base
+  const bool vec = ((((unsigned long long)(size_t)base) & 15ull) == 0ull) && ((ld & 3) == 0) && ((k0 & 3) == 0);
+  if (EXACT && vec) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 t = *(const f32x4*)(col + 4 * q);
+      v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = (EXACT || (fvalid && (k0 + 16 * h + e) < K)) ? col[e] : 0.0f;
+  }
+  // lanes 0-31 hold k0..k0+15, lanes 32-63 hold k0+16..k0+31; one half-wave exchange per register
+  // pair interleaves them: afterwards lane half h owns k0 + 2s + h.
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * s]), __float_as_uint(v[2 * s + 1]), false, false);
+    w[s] = __uint_as_float(r[0]);       // [lower.v[2s]   | lower.v[2s+1]]   -> k0 + 2s + h
+    w[s + 8] = __uint_as_float(r[1]);   // [upper.v[2s]   | upper.v[2s+1]]   -> k0 + 16 + 2s + h
+  }
+}
+
+// Epilogue shared by all MFMA kernels.  `acc` is in transposed-product layout: lane&31 = i (row of
+// C), register r of half h = column j_local(r,h) = (r&3) + 8*(r>>2) + 4*h.
+struct TileCtx { int i; int j0; int h; bool ivalid; };
+__device__ __forceinline__ int jl_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <bool EXACT>
+__device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  float bias = 0.0f;
+  if (p.colbias && (EXACT || t.ivalid)) bias = load_as_f32(q.d, t.i, p.c_type);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = t.j0 + jl_of(r, t.h);
+    float start = 0.0f;
+    if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_as_f32(q.c, (long long)j * p.ldc + t.i, p.c_type);
+    acc[r] = p.colbias ? (beta0 ? bias : bias + start) : start;
+  }
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void tile_store(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
+  const int lane = threadIdx.x & 63;
+  const long long mask_ld = ((p.ldc + 15) / 16) * 16;
+  const bool out_f32 = (p.c_type == LIBXSMM_DATATYPE_F32);
+  // bf16 fast path: neighbouring lanes (i, i+1) pair up so every lane writes one full dword per
+  // two registers instead of one short per register (needs even ldc and a 4-byte aligned C).
+  const bool pack2 = EXACT && !out_f32 && ((p.ldc & 1) == 0) && ((((unsigned long long)(size_t)q.c) & 3ull) == 0ull);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = t.j0 + jl_of(r, t.h);
+    const bool ok = EXACT || (t.ivalid && j < p.n);
+    const float x = acc[r];
+    const float y = act_apply(p.act, x);
+    if (p.act == 2 && q.mask) {
+      const unsigned long long pos = __ballot(ok && !(x <= 0.0f));
+      const unsigned long long val = __ballot(ok);
+      if ((lane & 7) == 0 && ok) {
+        unsigned char* byte = q.mask + t.i / 8 + (long long)j * (mask_ld / 8);
+        const unsigned char vm = (unsigned char)((val >> lane) & 0xffu), nb = (unsigned char)((pos >> lane) & 0xffu);
+        *byte = EXACT ? nb : (unsigned char)((*byte & ~vm) | (nb & vm));
+      }
+    }
+    if (out_f32) {
+      if (ok) ((float*)q.c)[(long long)j * p.ldc + t.i] = y;
+    } else if (!pack2) {
+      if (ok) ((unsigned short*)q.c)[(long long)j * p.ldc + t.i] = f32_to_bf16_rne(y);
+    } else if ((r & 1) == 1) {
+      // registers (r-1, r): even lanes keep column j(r-1), odd lanes keep column j(r)
+      const float y0 = act_apply(p.act, acc[r - 1]);
+      const bool odd = (lane & 1) != 0;
+      const unsigned int mine0 = f32_to_bf16_rne(y0), mine1 = f32_to_bf16_rne(y);
+      const unsigned int send = odd ? mine0 : mine1;
+      const unsigned int recv = (unsigned int)__shfl_xor((int)send, 1);
+      const unsigned int word = odd ? ((recv & 0xffffu) | (mine1 << 16)) : ((mine0 & 0xffffu) | (recv << 16));
+      const int jj = odd ? j : (t.j0 + jl_of(r - 1, t.h));
+      *(unsigned int*)((unsigned short*)q.c + (long long)jj * p.ldc + (t.i & ~1)) = word;
+    }
+  }
+}
+
+// wave -> (batch element, tile) decomposition shared by the MFMA kernels
+struct WaveJob { unsigned int bidx; int i0, j0; bool active; };
+__device__ __forceinline__ WaveJob wave_job(const GemmArgs& p, int tile_m, int tile_n) {
+  const int tiles_m = (p.m + tile_m - 1) / tile_m, tiles_n = (p.n + tile_n - 1) / tile_n;
+  const long long per_gemm = (long long)tiles_m * tiles_n;
+  const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  WaveJob w;
+  w.active = wid < per_gemm * (long long)p.nbatch;
+  w.bidx = (unsigned int)(wid / per_gemm);
+  const int t = (int)(wid % per_gemm);
+  w.i0 = (t % tiles_m) * tile_m; w.j0 = (t / tiles_m) * tile_n;
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32, 32x32 MFMA tiles, MT x NT tiles per wave
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, bool TA, bool TB, bool EXACT>
+__global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs p) {
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  f32x16 acc[MT][NT];
+  TileCtx tc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h;
+      tc[mt][nt].ivalid = tc[mt][nt].i < p.m;
+      tile_init<EXACT>(acc[mt][nt], p, q, tc[mt][nt]);
+    }
+  const int kchunks = (p.k + 31) / 32;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    const char *ar, *br; br_base(p, q, r, ar, br);
+    const float* A = (const float*)ar; const float* B = (const float*)br;
+    for (int kc = 0; kc < kchunks; ++kc) {
+      const int k0 = kc * 32;
+      float af[MT][16], bf[NT][16];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int i = job.i0 + 32 * mt + li;
+        if (TA) load_y_f32<EXACT>(af[mt], A, p.lda, i, i < p.m, k0, p.k, h);
+        else load_x_f32<EXACT>(af[mt], A, p.lda, i, i < p.m, k0, p.k, h);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int j = job.j0 + 32 * nt + li;
+        if (TB) load_x_f32<EXACT>(bf[nt], B, p.ldb, j, j < p.n, k0, p.k, h);
+        else load_y_f32<EXACT>(bf[nt], B, p.ldb, j, j < p.n, k0, p.k, h);
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) tile_store<EXACT>(acc[mt][nt], p, q, tc[mt][nt]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32, 16x16 tiles (v_mfma_f32_16x16x4_f32), NN layout, exact multiples of 16 only.
+// lane = (x = lane&15, g = lane>>4).  Transposed product: operand 1 = B(k, j=x), operand 2 = A(i=x, k);
+// result lane x = i, register q -> j = 4g + q.  k is consumed as 4g + s (not natural order).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_mfma_f32_t16_kernel(GemmArgs p) {
+  const WaveJob job = wave_job(p, 16, 16);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, x = lane & 15, g = lane >> 4;
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  const int i = job.i0 + x;
+  f32x4 acc;
+  float* C = (float*)q.c;
+  const float bias = p.colbias ? ((const float*)q.d)[i] : 0.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = job.j0 + 4 * g + e;
+    const float start = beta0 ? 0.0f : C[(long long)j * p.ldc + i];
+    acc[e] = p.colbias ? (beta0 ? bias : bias + start) : start;
+  }
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    const char *ar, *br; br_base(p, q, r, ar, br);
+    const float* A = (const float*)ar; const float* B = (const float*)br;
+    for (int k0 = 0; k0 < p.k; k0 += 16) {
+      float af[4]; f32x4 bv;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) af[s] = A[i + (long long)(k0 + 4 * g + s) * p.lda];
+      const float* bcol = B + (long long)(job.j0 + x) * p.ldb + k0 + 4 * g;
+      if (((((unsigned long long)(size_t)B) & 15ull) == 0ull) && ((p.ldb & 3) == 0)) bv = *(const f32x4*)bcol;
+      else { bv[0] = bcol[0]; bv[1] = bcol[1]; bv[2] = bcol[2]; bv[3] = bcol[3]; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], af[s], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = job.j0 + 4 * g + e;
+    const float xv = acc[e];
+    if (p.act == 2 && q.mask) {
+      const unsigned long long pos = __ballot(!(xv <= 0.0f));
+      if ((lane & 7) == 0) q.mask[i / 8 + (long long)j * ((((p.ldc + 15) / 16) * 16) / 8)] = (unsigned char)((pos >> lane) & 0xffu);
+    }
+    C[(long long)j * p.ldc + i] = act_apply(p.act, xv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 x bf16 -> fp32 accumulate, 32x32x16 MFMA; A in VNNI-2 layout [K/2][lda][2], B flat [n][ldb].
+// Per K-chunk of 32 (two MFMA steps) lane (f = lane&31, h = lane>>5) owns k = k0 + 16h + 8s + e:
+//   A: four dwords (k-pairs) per step, lanes contiguous along i  -> coalesced 128-byte rows
+//   B: sixteen contiguous bytes per step (32 per chunk) at column j
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, bool EXACT>
+__global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  f32x16 acc[MT][NT];
+  TileCtx tc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h;
+      tc[mt][nt].ivalid = tc[mt][nt].i < p.m;
+      tile_init<EXACT>(acc[mt][nt], p, q, tc[mt][nt]);
+    }
+  const int kchunks = (p.k + 31) / 32;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    const char *ar, *br; br_base(p, q, r, ar, br);
+    const unsigned int* A2 = (const unsigned int*)ar;          // one dword = (k even, k odd) of one row
+    const unsigned short* B = (const unsigned short*)br;
+    const bool bvec = ((((unsigned long long)(size_t)B) & 15ull) == 0ull) && ((p.ldb & 7) == 0);
+    for (int kc = 0; kc < kchunks; ++kc) {
+      const int k0 = kc * 32;
+      u32x4 af[MT][2], bfr[NT][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int kb = k0 + 16 * h + 8 * s;                    // first k of this lane's 8
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int i = job.i0 + 32 * mt + li;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kp = kb / 2 + e;                          // k-pair index
+            af[mt][s][e] = (EXACT || (i < p.m && 2 * kp < p.k)) ? A2[(long long)kp * p.lda + i] : 0u;
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int j = job.j0 + 32 * nt + li;
+          const unsigned short* col = B + (long long)j * p.ldb + kb;
+          if (EXACT && bvec) {
+            bfr[nt][s] = *(const u32x4*)col;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned int lo = (EXACT || (j < p.n && kb + 2 * e < p.k)) ? col[2 * e] : 0u;
+              const unsigned int hi = (EXACT || (j < p.n && kb + 2 * e + 1 < p.k)) ? col[2 * e + 1] : 0u;
+              bfr[nt][s][e] = lo | (hi << 16);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) tile_store<EXACT>(acc[mt][nt], p, q, tc[mt][nt]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side selection
+// ------------------------------------------------------------------------------------------------
+bool gemm_supported(const libxsmm_gemm_descriptor& d) {
+  const bool f32 = d.a_type == LIBXSMM_DATATYPE_F32 && d.b_type == LIBXSMM_DATATYPE_F32 && d.c_type == LIBXSMM_DATATYPE_F32;
+  const bool f64 = d.a_type == LIBXSMM_DATATYPE_F64 && d.b_type == LIBXSMM_DATATYPE_F64 && d.c_type == LIBXSMM_DATATYPE_F64;
+  const bool bf16 = d.a_type == LIBXSMM_DATATYPE_BF16 && d.b_type == LIBXSMM_DATATYPE_BF16 &&
+                    (d.c_type == LIBXSMM_DATATYPE_F32 || d.c_type == LIBXSMM_DATATYPE_BF16);
+  if (!(f32 || f64 || bf16)) return false;
+  if (f32 && d.comp_type != LIBXSMM_DATATYPE_F32) return false;
+  if (f64 && d.comp_type != LIBXSMM_DATATYPE_F64) return false;
+  if (bf16 && d.comp_type != LIBXSMM_DATATYPE_F32) return false;
+  const unsigned int fl = d.flags;
+  const bool ta = fl & LIBXSMM_GEMM_FLAG_TRANS_A, tb = fl & LIBXSMM_GEMM_FLAG_TRANS_B;
+  const bool va = fl & LIBXSMM_GEMM_FLAG_VNNI_A, vb = fl & LIBXSMM_GEMM_FLAG_VNNI_B, vc = fl & LIBXSMM_GEMM_FLAG_VNNI_C;
+  if (!bf16 && (va || vb || vc)) return false;
+  if (bf16 && va && ta) return false;                 // [ref: src/generator_gemm.c:1010-1013]
+  if (bf16 && va && (d.k & 1)) return false;
+  if (bf16 && vb && !tb) return false;                // VNNI_B only defined together with TRANS_B [ref: gemm ref :2156-2163]
+  if (bf16 && vb && (d.k & 1)) return false;
+  if (vc && d.c_type != LIBXSMM_DATATYPE_BF16) return false;
+  if (fl & (LIBXSMM_GEMM_FLAG_USE_COL_VEC_SCF | LIBXSMM_GEMM_FLAG_USE_COL_VEC_ZPT | LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT |
+            LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK | LIBXSMM_GEMM_FLAG_USE_MxK_ZPT | LIBXSMM_GEMM_FLAG_USE_MxK_SCF)) return false;
+  // leading dimensions [ref: src/generator_gemm.c:990-1040]; VNNI-2 A keeps lda >= m (in k-pairs)
+  if (ta ? (d.lda < d.k) : (d.lda < d.m)) return false;
+  if (tb ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
+  if (d.ldc < d.m) return false;
+  if (f64 && (d.bin_type != 0 || d.cp_type != 0)) return false;
+  return true;
+}
+
+enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2 };
+struct GemmPlan { GemmPath path; bool exact; };
+
+static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, int c_type, int vnni_c) {
+  GemmPlan pl{P_GENERIC, false};
+  const bool ta = flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = flags & LIBXSMM_GEMM_FLAG_TRANS_B;
+  const bool va = flags & LIBXSMM_GEMM_FLAG_VNNI_A, vb = flags & LIBXSMM_GEMM_FLAG_VNNI_B;
+  (void)c_type;
+  if (vnni_c || k <= 0) return pl;
+  if (a_type == LIBXSMM_DATATYPE_F32) {
+    const bool ex32 = (m % 32 == 0) && (n % 32 == 0) && (k % 32 == 0);
+    if (!ex32 && !ta && !tb && (m % 16 == 0) && (n % 16 == 0) && (k % 16 == 0) && m <= 48 && n <= 48) { pl.path = P_F32_T16; pl.exact = true; return pl; }
+    pl.exact = ex32;
+    pl.path = (m > 32 && n > 32) ? P_F32_2x2 : P_F32_1x1;
+    if (pl.path == P_F32_2x2) pl.exact = (m % 64 == 0) && (n % 64 == 0) && (k % 32 == 0);
+    return pl;
+  }
+  if (a_type == LIBXSMM_DATATYPE_BF16 && va && !ta && !tb && !vb) {
+    pl.path = (m > 32 && n > 32) ? P_BF16_2x2 : P_BF16_1x1;
+    const int t = (pl.path == P_BF16_2x2) ? 64 : 32;
+    pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
+    return pl;
+  }
+  return pl;
+}
+
+static const char* path_name(GemmPath p) {
+  switch (p) {
+    case P_F32_T16: return "gemm_mfma_f32_t16_kernel";
+    case P_F32_1x1: return "gemm_mfma_f32_kernel<1,1>";
+    case P_F32_2x2: return "gemm_mfma_f32_kernel<2,2>";
+    case P_BF16_1x1: return "gemm_mfma_bf16_kernel<1,1>";
+    case P_BF16_2x2: return "gemm_mfma_bf16_kernel<2,2>";
+    default: return "gemm_generic_kernel";
+  }
+}
+
+const char* gemm_kernel_name(const libxsmm_gemm_descriptor& d, bool) {
+  return path_name(plan_gemm((int)d.m, (int)d.n, (int)d.k, d.flags, d.a_type, d.c_type, (d.flags & LIBXSMM_GEMM_FLAG_VNNI_C) != 0).path);
+}
+
+template <int MT, int NT, bool EXACT>
+static void launch_f32(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, false, false, EXACT>), grid, dim3(256), 0, st, a);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, true, false, EXACT>), grid, dim3(256), 0, st, a);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, false, true, EXACT>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, true, true, EXACT>), grid, dim3(256), 0, st, a);
+}
+
+int launch_gemm(const GemmArgs& a, void* stream, const char** kernel_name) {
+  hipStream_t st = (hipStream_t)stream;
+  if (a.nbatch == 0 || a.m <= 0 || a.n <= 0) { if (kernel_name) *kernel_name = "(empty)"; return 0; }
+  const GemmPlan pl = plan_gemm(a.m, a.n, a.k, a.flags, a.a_type, a.c_type, a.vnni_c);
+  if (kernel_name) *kernel_name = path_name(pl.path);
+  auto wave_grid = [&](int tm, int tn) {
+    const long long tiles = (long long)((a.m + tm - 1) / tm) * ((a.n + tn - 1) / tn) * (long long)a.nbatch;
+    return dim3((unsigned int)((tiles + 3) / 4));
+  };
+  switch (pl.path) {
+    case P_F32_T16: hipLaunchKernelGGL(gemm_mfma_f32_t16_kernel, wave_grid(16, 16), dim3(256), 0, st, a); break;
+    case P_F32_1x1: if (pl.exact) launch_f32<1, 1, true>(a, wave_grid(32, 32), st); else launch_f32<1, 1, false>(a, wave_grid(32, 32), st); break;
+    case P_F32_2x2: if (pl.exact) launch_f32<2, 2, true>(a, wave_grid(64, 64), st); else launch_f32<2, 2, false>(a, wave_grid(64, 64), st); break;
+    case P_BF16_1x1:
+      if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true>), wave_grid(32, 32), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), wave_grid(32, 32), dim3(256), 0, st, a);
+      break;
+    case P_BF16_2x2:
+      if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), wave_grid(64, 64), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), wave_grid(64, 64), dim3(256), 0, st, a);
+      break;
+    default: {
+      const long long blocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
+      hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)blocks), dim3(64, 4), 0, st, a);
+    }
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace xamd

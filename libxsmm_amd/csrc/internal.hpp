@@ -1,0 +1,158 @@
+// internal.hpp -- shared between the host runtime (dispatch.cpp, frontend.cpp) and the
+// device translation units (*.hip).  Nothing in here is visible to users of include/libxsmm.h.
+//
+// Design in one paragraph: a dispatch call normalises its arguments into one of the two
+// opaque descriptors below, looks the descriptor bytes up in the registry and returns a
+// *trampoline*: one of N ahead-of-time instantiated C functions `tramp<I>` whose only job is
+// to call `invoke(I, param)`.  That is how a plain `void(*)(const libxsmm_gemm_param*)` can
+// carry per-kernel state without JIT-emitting x86 thunks (the reference's closure trick,
+// src/generator_x86_reference.c:25-98).  `invoke` decodes the param struct on the host
+// (slots the reference's kernels read inside machine code), builds a by-value argument
+// block and launches the matching hand-written gfx950 kernel on the calling thread's stream.
+#pragma once
+
+#include "../../include/libxsmm.h"
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---- opaque descriptors (users only ever hold pointers into a libxsmm_descriptor_blob) ----
+// Own layout; only the *behaviour* of the reference's init functions is reproduced
+// [ref: src/libxsmm_generator.c:36-321].  Both fit LIBXSMM_DESCRIPTOR_MAXSIZE and are
+// fully initialised (no padding garbage) because their bytes are the registry key.
+struct libxsmm_gemm_descriptor {
+  uint32_t m, n, k, lda, ldb, ldc;
+  uint32_t flags;
+  uint8_t prefetch, a_type, b_type, c_type, comp_type, d_type, br_unroll, store_mask;  // store_mask: bit0 ap, bit1 bp, bit2 cp
+  int64_t br_stride_a, br_stride_b;        // bytes, stride mode only
+  uint32_t ldd;
+  uint16_t bin_type, bin_flags;            // fused binary post-op on C (d operand)
+  uint16_t ap_type, bp_type, cp_type;      // fused unary ops
+  uint16_t ap_flags, bp_flags, cp_flags;
+  uint32_t ldap, ldbp, ldcp;
+  uint32_t reserved;
+};
+static_assert(sizeof(libxsmm_gemm_descriptor) <= LIBXSMM_DESCRIPTOR_MAXSIZE, "gemm descriptor too large");
+
+struct libxsmm_meltw_descriptor {
+  uint32_t m, n, ldi, ldo, ldi2, ldi3;
+  uint8_t in0_type, in1_type, in2_type, comp_type, out_type, operation;
+  uint16_t flags, param;
+  uint32_t reserved;
+};
+static_assert(sizeof(libxsmm_meltw_descriptor) <= LIBXSMM_DESCRIPTOR_MAXSIZE, "meltw descriptor too large");
+
+namespace xamd {
+
+// ---- kernel kinds ---------------------------------------------------------------------------
+enum Kind : int {
+  K_GEMM = 0,            // dense (BR)GEMM, optional fused epilogue
+  K_TILECFG,             // AMX tile-config handles: no-ops on this backend
+  K_MELTW,               // unary / binary / ternary TPP
+  K_SPMM_ASPARSE,        // packed CSR, A sparse (also the FsSpMDM inner kernel)
+  K_SPMM_BSPARSE,        // packed CSR/CSC, B sparse
+  K_BCSC                 // block-sparse B, pattern at run time
+};
+
+// ---- device argument blocks (passed by value as kernel arguments) ---------------------------
+struct GemmArgs {
+  const char* a; const char* b; char* c;            // `primary` slots of batch element 0
+  const char* d; unsigned char* relu_mask;          // fused bias operand, ReLU bitmask output
+  const long long* offs_a; const long long* offs_b; // OFFSET mode (bytes), shared by the batch
+  const void* const* list_a; const void* const* list_b; void* const* list_c;  // pointer-list batch
+  long long bs_a, bs_b, bs_c, bs_d, bs_mask;        // batch byte strides
+  long long br_stride_a, br_stride_b;               // bytes
+  unsigned long long br_count;
+  unsigned int nbatch;
+  int m, n, k, lda, ldb, ldc;
+  unsigned int flags;                               // libxsmm_gemm_flags
+  int br_mode;                                      // 0 none, 1 address, 2 offset, 3 stride
+  int a_type, b_type, c_type;
+  int colbias, act;                                 // act: 0 none, 1 relu, 2 relu+bitmask, 3 sigmoid
+  int vnni_c;
+};
+
+struct MeltwArgs {
+  const char* in0; const char* in1; const char* in2; char* out;
+  const void* aux_in; void* aux_out;                // secondary slots (masks, indices, offsets)
+  long long bs_in0, bs_in1, bs_in2, bs_out, bs_aux; // batch byte strides
+  unsigned long long scalar_u64;                    // op.primary payloads read on the host
+  float scalar_f32;
+  unsigned int nbatch;
+  int m, n, ldi, ldi1, ldi2, ldo;
+  int in0_type, in1_type, in2_type, out_type, comp_type;
+  unsigned int flags;
+  int type, operation;
+};
+
+// sparse operator S (rows x inner) applied to a packed panel:
+//   Y[r][q] (+)= sum_z val[z] * X[idx[z]][q],   q = 0..ncols-1 contiguous, for `nouter` slabs
+struct SpmmArgs {
+  const unsigned int* ptr; const unsigned int* idx;   // device copies of the pattern
+  const void* vals;                                   // run-time values (device-accessible)
+  const unsigned int* vmap;                           // optional: value position of pattern entry z
+  const char* x; char* y;
+  long long ld_x, ld_y;                               // row strides in elements
+  long long outer_x, outer_y;                         // slab strides in elements
+  long long ncols; int rows, inner, nouter;
+  int dtype, beta0, skip_empty, vals_are_f64;
+};
+
+struct BcscArgs {
+  const char* a; const char* bvals; char* c;
+  const unsigned int* colptr; const unsigned int* rowidx;
+  int M, N, K, m_blocks, bk, bn, nblk_n;
+  int a_type, c_type, vnni_a, beta0;
+};
+
+// ---- host-side kernel context ------------------------------------------------------------------
+struct KernelCtx {
+  int slot = -1;
+  Kind kind = K_GEMM;
+  bool registered = false;          // owned by the registry (dispatch_*) vs caller-owned (create_*)
+  libxsmm_gemm_descriptor g{};
+  libxsmm_meltw_descriptor e{};
+  unsigned int nflops = 0;
+  // sparse creators
+  int packed_width = 0, bk = 0, bn = 0;
+  int sp_rows = 0, sp_inner = 0; unsigned int sp_nnz = 0;
+  unsigned int* d_ptr = nullptr; unsigned int* d_idx = nullptr; void* d_vals = nullptr;  // device pattern (+ baked values)
+  unsigned int* d_vmap = nullptr;   // value position per pattern entry (B-sparse CSR regrouped by column)
+  int sp_ncols = 0, sp_skip_empty = 0;
+  int device = 0;
+  const char* kname_single = "";
+  const char* kname_batched = "";
+};
+
+// ---- per-thread execution state -----------------------------------------------------------------
+struct ThreadState {
+  void* stream = nullptr;     // hipStream_t
+  int async = -1;             // -1: not initialised from the environment yet
+  int device = -1;
+  int last_error = 0;
+  std::string last_error_msg;
+  unsigned long long launches = 0;
+};
+ThreadState& tls();
+void set_error(int code, const char* fmt, ...);
+
+// ---- launch entry points implemented in the .hip translation units ------------------------------
+// Each returns a HIP error code (0 == success) and the name of the kernel it picked.
+int launch_gemm(const GemmArgs& args, void* stream, const char** kernel_name);
+const char* gemm_kernel_name(const libxsmm_gemm_descriptor& d, bool batched);
+bool gemm_supported(const libxsmm_gemm_descriptor& d);
+int launch_meltw(const MeltwArgs& args, void* stream, const char** kernel_name);
+bool meltw_supported(const libxsmm_meltw_descriptor& d);
+int launch_spmm(const SpmmArgs& args, void* stream, const char** kernel_name);
+int launch_bcsc(const BcscArgs& args, void* stream, const char** kernel_name);
+
+// ---- runtime services (dispatch.cpp) ---------------------------------------------------------------
+KernelCtx* ctx_from_handle(const void* fn);
+const void* handle_for_slot(int slot);
+void invoke(int slot, const void* param);
+bool runtime_ready();              // library initialised and a device is present
+int typesize(int t);
+
+}  // namespace xamd

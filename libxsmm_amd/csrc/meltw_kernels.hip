@@ -1,0 +1,603 @@
+// meltw_kernels.hip -- element-wise Tensor Processing Primitives (unary / binary / ternary) for gfx950.
+//
+// Semantics restated from the reference [ref: src/generator_mateltwise_reference_impl.c]:
+//   out[i + j*ldo] = f(in0[idx0(i,j)], in1[idx1(i,j)], ...)  over an m x n column-major matrix, with
+//   ROW / COL / SCALAR broadcast of any input (:241-272), fp32 compute for F32/BF16 data and one
+//   RNE-with-DAZ rounding at a bf16 store (:299-324); pure data movement (copy, transpose, VNNI
+//   re-layouts, gather/scatter, ZIP/UNZIP) is bit-exact on 1/2/4/8-byte payloads.
+// All of these are HBM-bound streaming kernels: lanes run along i (the contiguous dimension), the
+// batch axis of the batched launchers is the outermost grid dimension, and the contiguous f32/bf16
+// case uses 16-byte (f32x4 / bf16x8) accesses.  The op is a run-time switch: the arithmetic is
+// irrelevant next to the memory traffic.
+#include <hip/hip_runtime.h>
+#include "internal.hpp"
+
+// a*b+c below means two roundings unless fma()/MFMA is spelled out: parity with the reference's C
+// loops (built without FMA contraction) depends on it.
+#pragma clang fp contract(off)
+
+namespace xamd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float mw_bf2f(unsigned short x) { return __uint_as_float((unsigned int)x << 16); }
+__device__ __forceinline__ unsigned short mw_f2bf(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7f800000u) == 0u) u &= 0x80000000u;
+  if ((u & 0x7f800000u) == 0x7f800000u) { if (u & 0x007fffffu) u |= 0x00400000u; }
+  else u += 0x00007fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float mw_load(const char* p, long long idx, int type) {
+  return (type == LIBXSMM_DATATYPE_F32) ? ((const float*)p)[idx] : mw_bf2f(((const unsigned short*)p)[idx]);
+}
+__device__ __forceinline__ void mw_store(char* p, long long idx, int type, float v) {
+  if (type == LIBXSMM_DATATYPE_F32) ((float*)p)[idx] = v; else ((unsigned short*)p)[idx] = mw_f2bf(v);
+}
+
+enum { BC_NONE = 0, BC_ROW = 1, BC_COL = 2, BC_SCALAR = 3 };
+// broadcast kind of operand `op` [ref: :241-260]
+__host__ __device__ inline int bcast_kind(int operation, int type, unsigned int f, int op) {
+  if (operation == LIBXSMM_MELTW_OPERATION_UNARY) {
+    if (op != 0) return BC_NONE;
+    if (f & LIBXSMM_MELTW_FLAG_UNARY_BCAST_ROW) return BC_ROW;
+    if ((f & LIBXSMM_MELTW_FLAG_UNARY_BCAST_COL) || type == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR) return BC_COL;
+    if (f & LIBXSMM_MELTW_FLAG_UNARY_BCAST_SCALAR) return BC_SCALAR;
+  } else if (operation == LIBXSMM_MELTW_OPERATION_BINARY) {
+    if (op > 1) return BC_NONE;
+    if (f & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_ROW_IN_0 << op)) return BC_ROW;
+    if (f & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_COL_IN_0 << op)) return BC_COL;
+    if (f & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_SCALAR_IN_0 << op)) return BC_SCALAR;
+  } else {
+    if (op > 2) return BC_NONE;
+    if (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_ROW_IN_0 << op)) return BC_ROW;
+    if (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_COL_IN_0 << op)) return BC_COL;
+    if (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_SCALAR_IN_0 << op)) return BC_SCALAR;
+  }
+  return BC_NONE;
+}
+__device__ __forceinline__ long long bc_index(int kind, long long i, long long j, long long ld) {
+  return kind == BC_ROW ? j * ld : kind == BC_COL ? i : kind == BC_SCALAR ? 0 : i + j * ld;
+}
+
+__device__ __forceinline__ float sigmoid_ref(float x) { return (tanhf(x * 0.5f) + 1.0f) * 0.5f; }
+__device__ float unary_math(int type, float x, float alpha) {   // [ref: :83-127, :2148-2152]
+  switch (type) {
+    case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR: return x;
+    case LIBXSMM_MELTW_TYPE_UNARY_XOR: return 0.0f;
+    case LIBXSMM_MELTW_TYPE_UNARY_X2: return x * x;
+    case LIBXSMM_MELTW_TYPE_UNARY_SQRT: return sqrtf(x);
+    case LIBXSMM_MELTW_TYPE_UNARY_RELU: return (x <= 0.0f) ? 0.0f : x;
+    case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: return (x <= 0.0f) ? alpha * x : x;
+    case LIBXSMM_MELTW_TYPE_UNARY_ELU: return (x <= 0.0f) ? alpha * (expf(x) - 1.0f) : x;
+    case LIBXSMM_MELTW_TYPE_UNARY_TANH: return tanhf(x);
+    case LIBXSMM_MELTW_TYPE_UNARY_TANH_INV: { const float t = tanhf(x); return 1.0f - t * t; }
+    case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID: return sigmoid_ref(x);
+    case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID_INV: { const float s = sigmoid_ref(x); return s * (1.0f - s); }
+    case LIBXSMM_MELTW_TYPE_UNARY_GELU: return (erff(x / sqrtf(2.0f)) + 1.0f) * 0.5f * x;
+    case LIBXSMM_MELTW_TYPE_UNARY_GELU_INV:
+      return 0.5f + 0.5f * erff(x / sqrtf(2.0f)) + x / sqrtf(2.0f * 3.14159265358979323846f) * expf(-0.5f * x * x);
+    case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: return -1.0f * x;
+    case LIBXSMM_MELTW_TYPE_UNARY_INC: return x + 1.0f;
+    case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL: return 1.0f / x;
+    case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT: return 1.0f / sqrtf(x);
+    case LIBXSMM_MELTW_TYPE_UNARY_EXP: return expf(x);
+    default: return x;
+  }
+}
+__device__ double unary_math_f64(int type, double x) {          // [ref: :129-152]
+  switch (type) {
+    case LIBXSMM_MELTW_TYPE_UNARY_XOR: return 0.0;
+    case LIBXSMM_MELTW_TYPE_UNARY_X2: return x * x;
+    case LIBXSMM_MELTW_TYPE_UNARY_SQRT: return sqrt(x);
+    case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: return -1.0 * x;
+    case LIBXSMM_MELTW_TYPE_UNARY_INC: return x + 1.0;
+    case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL: return 1.0 / x;
+    case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT: return 1.0 / sqrt(x);
+    default: return x;
+  }
+}
+__device__ float binary_math(int type, float a, float b, float prev) {   // [ref: :181-214]
+  switch (type) {
+    case LIBXSMM_MELTW_TYPE_BINARY_ADD: return a + b;
+    case LIBXSMM_MELTW_TYPE_BINARY_SUB: return a - b;
+    case LIBXSMM_MELTW_TYPE_BINARY_MUL: return a * b;
+    case LIBXSMM_MELTW_TYPE_BINARY_DIV: return a / b;
+    case LIBXSMM_MELTW_TYPE_BINARY_MULADD: { const float prod = a * b; return prev + prod; }
+    case LIBXSMM_MELTW_TYPE_BINARY_MAX: return (a > b) ? a : b;
+    case LIBXSMM_MELTW_TYPE_BINARY_MIN: return (a > b) ? b : a;
+    case LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GT: return (a > b) ? 1.0f : 0.0f;
+    case LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GE: return (a >= b) ? 1.0f : 0.0f;
+    case LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_LT: return (a < b) ? 1.0f : 0.0f;
+    case LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_LE: return (a <= b) ? 1.0f : 0.0f;
+    case LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_EQ: return (a == b) ? 1.0f : 0.0f;
+    case LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_NE: return (a != b) ? 1.0f : 0.0f;
+    default: return a;
+  }
+}
+
+// A tile of 64 (i) x 4 (j): one wave = 64 consecutive rows of one column so bitmask bytes are ballots.
+struct EwJob { unsigned int bidx; int i, j; bool valid; };
+__device__ __forceinline__ EwJob ew_job(const MeltwArgs& p, int m, int n) {
+  const int tiles_i = (m + 63) / 64, tiles_j = (n + 3) / 4;
+  const long long per = (long long)tiles_i * tiles_j;
+  const long long blk = blockIdx.x;
+  EwJob e; e.bidx = (unsigned int)(blk / per);
+  const int t = (int)(blk % per);
+  e.i = (t % tiles_i) * 64 + threadIdx.x; e.j = (t / tiles_i) * 4 + threadIdx.y;
+  e.valid = e.i < m && e.j < n;
+  return e;
+}
+// write bit `on` for element (i,j) into a bit matrix with leading dimension ld_bits; ballot-combined
+__device__ __forceinline__ void put_bits(unsigned char* bits, int i, int j, long long ld_bits, bool valid, bool on) {
+  const int lane = threadIdx.x;
+  const unsigned long long pos = __ballot(valid && on), val = __ballot(valid);
+  if ((lane & 7) == 0 && valid) {
+    unsigned char* byte = bits + i / 8 + (long long)j * (ld_bits / 8);
+    const unsigned char vm = (unsigned char)((val >> lane) & 0xffu), nb = (unsigned char)((pos >> lane) & 0xffu);
+    *byte = (unsigned char)((*byte & ~vm) | (nb & vm));
+  }
+}
+__device__ __forceinline__ int get_bit(const unsigned char* bits, int i, int j, long long ld_bits) {
+  return (bits[i / 8 + (long long)j * (ld_bits / 8)] >> (i % 8)) & 1;
+}
+
+__global__ __launch_bounds__(256) void meltw_unary_kernel(MeltwArgs p) {
+  const int n_eff = (p.type == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR) ? (int)p.scalar_u64 : p.n;
+  const EwJob e = ew_job(p, p.m, n_eff);
+  const char* in = p.in0 + (long long)e.bidx * p.bs_in0;
+  char* out = p.out + (long long)e.bidx * p.bs_out;
+  const int bc = bcast_kind(p.operation, p.type, p.flags, 0);
+  const bool bitm = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) != 0;
+  const int i = e.i, j = e.j;
+  if (p.in0_type == LIBXSMM_DATATYPE_F64) {
+    if (e.valid) ((double*)out)[i + (long long)j * p.ldo] = unary_math_f64(p.type, ((const double*)in)[bc_index(bc, i, j, p.ldi)]);
+    return;
+  }
+  switch (p.type) {
+    case LIBXSMM_MELTW_TYPE_UNARY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_ELU: {
+      const float x = e.valid ? mw_load(in, bc_index(bc, i, j, p.ldi), p.in0_type) : 0.0f;
+      if (e.valid) mw_store(out, i + (long long)j * p.ldo, p.out_type, unary_math(p.type, x, p.scalar_f32));
+      if (bitm) put_bits((unsigned char*)p.aux_out + (long long)e.bidx * p.bs_aux, i, j, ((p.ldo + 15) / 16) * 16, e.valid, !(x <= 0.0f));
+      return;
+    }
+    case LIBXSMM_MELTW_TYPE_UNARY_RELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_ELU_INV: {
+      if (!e.valid) return;
+      const float x = mw_load(in, bc_index(bc, i, j, p.ldi), p.in0_type);
+      const char* aux = (const char*)p.aux_in + (long long)e.bidx * p.bs_aux;
+      float y;
+      if (p.type == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) {
+        const float fwd = mw_load(aux, bc_index(bc, i, j, p.ldi), p.in0_type);
+        y = (fwd > 0.0f) ? x : x * (fwd + p.scalar_f32);
+      } else {
+        const int bit = get_bit((const unsigned char*)aux, i, j, ((p.ldi + 15) / 16) * 16);
+        y = (p.type == LIBXSMM_MELTW_TYPE_UNARY_RELU_INV) ? (bit ? x : 0.0f) : (bit ? x : p.scalar_f32 * x);
+      }
+      mw_store(out, i + (long long)j * p.ldo, p.out_type, y);
+      return;
+    }
+    case LIBXSMM_MELTW_TYPE_UNARY_UNZIP: {                      // [ref: :2419-2432]
+      if (!e.valid) return;
+      const unsigned int u = ((const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
+      ((unsigned short*)out)[i + (long long)j * p.ldo] = (unsigned short)(u & 0xffffu);
+      ((unsigned short*)(out + p.scalar_u64))[i + (long long)j * p.ldo] = (unsigned short)(u >> 16);
+      return;
+    }
+    default: break;
+  }
+  if (!e.valid) return;
+  // pure copies / zero fill of same-width types stay bit-exact (no float round trip)
+  if (p.in0_type == p.out_type && (p.type == LIBXSMM_MELTW_TYPE_UNARY_IDENTITY || p.type == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR)) {
+    if (p.in0_type == LIBXSMM_DATATYPE_F32) ((unsigned int*)out)[i + (long long)j * p.ldo] = ((const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
+    else ((unsigned short*)out)[i + (long long)j * p.ldo] = ((const unsigned short*)in)[bc_index(bc, i, j, p.ldi)];
+    return;
+  }
+  const float x = mw_load(in, bc_index(bc, i, j, p.ldi), p.in0_type);
+  mw_store(out, i + (long long)j * p.ldo, p.out_type, unary_math(p.type, x, p.scalar_f32));
+}
+
+// contiguous fast path (no broadcast, f32 or bf16 in == out type, m % 4 == 0, lds % 4 == 0, aligned):
+// one thread = four consecutive rows.  Covers copy/zero/relu/... of the streaming TPPs.
+template <typename VT, bool BF16>
+__global__ __launch_bounds__(256) void meltw_unary_vec4_kernel(MeltwArgs p) {
+  const int m4 = p.m / 4;
+  const long long per = (long long)m4 * p.n;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= per * p.nbatch) return;
+  const unsigned int bidx = (unsigned int)(gid / per);
+  const long long t = gid % per;
+  const int i = (int)(t % m4) * 4, j = (int)(t / m4);
+  const char* in = p.in0 + (long long)bidx * p.bs_in0;
+  char* out = p.out + (long long)bidx * p.bs_out;
+  float x[4];
+  if (BF16) { const u16x4 v = *(const u16x4*)((const unsigned short*)in + i + (long long)j * p.ldi); for (int e = 0; e < 4; ++e) x[e] = mw_bf2f(v[e]); }
+  else { const f32x4 v = *(const f32x4*)((const float*)in + i + (long long)j * p.ldi); for (int e = 0; e < 4; ++e) x[e] = v[e]; }
+  if (BF16) { u16x4 o; for (int e = 0; e < 4; ++e) o[e] = mw_f2bf(unary_math(p.type, x[e], p.scalar_f32)); *(u16x4*)((unsigned short*)out + i + (long long)j * p.ldo) = o; }
+  else { f32x4 o; for (int e = 0; e < 4; ++e) o[e] = unary_math(p.type, x[e], p.scalar_f32); *(f32x4*)((float*)out + i + (long long)j * p.ldo) = o; }
+}
+
+__global__ __launch_bounds__(256) void meltw_binary_kernel(MeltwArgs p) {
+  const EwJob e = ew_job(p, p.m, p.n);
+  const char* in0 = p.in0 + (long long)e.bidx * p.bs_in0;
+  const char* in1 = p.in1 + (long long)e.bidx * p.bs_in1;
+  char* out = p.out + (long long)e.bidx * p.bs_out;
+  const int bc0 = bcast_kind(p.operation, p.type, p.flags, 0), bc1 = bcast_kind(p.operation, p.type, p.flags, 1);
+  const int i = e.i, j = e.j;
+  const bool cmp = p.type >= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GT && p.type <= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_NE;
+  if (p.type == LIBXSMM_MELTW_TYPE_BINARY_ZIP) {                // [ref: :2543-2556]
+    if (!e.valid) return;
+    const unsigned int lo = ((const unsigned short*)in0)[bc_index(bc0, i, j, p.ldi)];
+    const unsigned int hi = ((const unsigned short*)in1)[bc_index(bc1, i, j, p.ldi1)];
+    ((unsigned int*)out)[i + (long long)j * p.ldo] = lo | (hi << 16);
+    return;
+  }
+  if (p.in0_type == LIBXSMM_DATATYPE_F64) {
+    if (!e.valid) return;
+    const double a = ((const double*)in0)[bc_index(bc0, i, j, p.ldi)], b = ((const double*)in1)[bc_index(bc1, i, j, p.ldi1)];
+    double* o = (double*)out + i + (long long)j * p.ldo;
+    switch (p.type) {
+      case LIBXSMM_MELTW_TYPE_BINARY_ADD: *o = a + b; break;
+      case LIBXSMM_MELTW_TYPE_BINARY_SUB: *o = a - b; break;
+      case LIBXSMM_MELTW_TYPE_BINARY_MUL: *o = a * b; break;
+      case LIBXSMM_MELTW_TYPE_BINARY_DIV: *o = a / b; break;
+      case LIBXSMM_MELTW_TYPE_BINARY_MULADD: { const double prod = a * b; *o = *o + prod; } break;
+      case LIBXSMM_MELTW_TYPE_BINARY_MAX: *o = (a > b) ? a : b; break;
+      default: *o = (a > b) ? b : a; break;
+    }
+    return;
+  }
+  float a = 0.0f, b = 0.0f;
+  if (e.valid) { a = mw_load(in0, bc_index(bc0, i, j, p.ldi), p.in0_type); b = mw_load(in1, bc_index(bc1, i, j, p.ldi1), p.in1_type); }
+  if (cmp) {   // result is a bit matrix, ld rounded up to 16 [ref: :2575-2584]
+    put_bits((unsigned char*)out, i, j, ((p.ldo + 15) / 16) * 16, e.valid, binary_math(p.type, a, b, 0.0f) > 0.1f);
+    return;
+  }
+  if (!e.valid) return;
+  const float prev = (p.type == LIBXSMM_MELTW_TYPE_BINARY_MULADD) ? mw_load(out, i + (long long)j * p.ldo, p.out_type) : 0.0f;
+  mw_store(out, i + (long long)j * p.ldo, p.out_type, binary_math(p.type, a, b, prev));
+}
+
+__global__ __launch_bounds__(256) void meltw_ternary_kernel(MeltwArgs p) {
+  const EwJob e = ew_job(p, p.m, p.n);
+  if (!e.valid) return;
+  const char* in0 = p.in0 + (long long)e.bidx * p.bs_in0;
+  const char* in1 = p.in1 + (long long)e.bidx * p.bs_in1;
+  const char* in2 = p.in2 + (long long)e.bidx * p.bs_in2;
+  char* out = p.out + (long long)e.bidx * p.bs_out;
+  const int bc0 = bcast_kind(p.operation, p.type, p.flags, 0), bc1 = bcast_kind(p.operation, p.type, p.flags, 1), bc2 = bcast_kind(p.operation, p.type, p.flags, 2);
+  const int i = e.i, j = e.j;
+  if (p.type == LIBXSMM_MELTW_TYPE_TERNARY_SELECT) {            // [ref: :2617-2640]
+    const int bit = get_bit((const unsigned char*)in2, i, j, ((p.ldi2 + 15) / 16) * 16);
+    if (p.in0_type == LIBXSMM_DATATYPE_F64) {
+      const double a = ((const double*)in0)[bc_index(bc0, i, j, p.ldi)], b = ((const double*)in1)[bc_index(bc1, i, j, p.ldi1)];
+      ((double*)out)[i + (long long)j * p.ldo] = bit ? b : a;
+    } else {
+      const float a = mw_load(in0, bc_index(bc0, i, j, p.ldi), p.in0_type), b = mw_load(in1, bc_index(bc1, i, j, p.ldi1), p.in1_type);
+      mw_store(out, i + (long long)j * p.ldo, p.out_type, bit ? b : a);
+    }
+    return;
+  }
+  const float a = mw_load(in0, bc_index(bc0, i, j, p.ldi), p.in0_type);
+  const float b = mw_load(in1, bc_index(bc1, i, j, p.ldi1), p.in1_type);
+  const float c = mw_load(in2, bc_index(bc2, i, j, p.ldi2), p.in2_type);
+  const float prod = (p.type == LIBXSMM_MELTW_TYPE_TERNARY_MULADD) ? a * b : a * c;
+  const float r = (p.type == LIBXSMM_MELTW_TYPE_TERNARY_MULADD) ? c + prod : b - prod;   // [ref: :2641-2655]
+  mw_store(out, i + (long long)j * p.ldo, p.out_type, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// data-movement kernels on S-byte payloads (bit-exact)
+// ------------------------------------------------------------------------------------------------
+template <int S> struct Payload;
+template <> struct Payload<1> { typedef unsigned char type; };
+template <> struct Payload<2> { typedef unsigned short type; };
+template <> struct Payload<4> { typedef unsigned int type; };
+template <> struct Payload<8> { typedef unsigned long long type; };
+
+// out[j*ldo + i] = in[i*ldi + j] for i < n, j < m (in is m x n, out is n x m) [ref: :376-424].
+// 32x32 tile through LDS so that both the read and the write are coalesced.
+template <int S>
+__global__ __launch_bounds__(256) void transpose_kernel(MeltwArgs p) {
+  typedef typename Payload<S>::type T;
+  __shared__ T tile[32][33];
+  const int tm = (p.m + 31) / 32, tn = (p.n + 31) / 32;
+  const long long per = (long long)tm * tn;
+  const unsigned int bidx = (unsigned int)(blockIdx.x / per);
+  const int t = (int)(blockIdx.x % per);
+  const int r0 = (t % tm) * 32, c0 = (t / tm) * 32;       // r: index along m (contiguous in `in`), c: along n
+  const T* in = (const T*)(p.in0 + (long long)bidx * p.bs_in0);
+  T* out = (T*)(p.out + (long long)bidx * p.bs_out);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int cc = ty; cc < 32; cc += 8) {
+    const int r = r0 + tx, c = c0 + cc;
+    if (r < p.m && c < p.n) tile[cc][tx] = in[(long long)c * p.ldi + r];
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int c = c0 + tx, r = r0 + rr;
+    if (r < p.m && c < p.n) out[(long long)r * p.ldo + c] = tile[tx][rr];
+  }
+}
+
+// generic index-remapping transforms: one thread per OUTPUT element of the padded extent;
+// `mode` encodes the reference loop nest being restated.
+enum XformMode { XF_NORM_TO_VNNI = 1, XF_VNNI_TO_VNNIT, XF_NORM_TO_VNNIT, XF_VNNIT_TO_NORM, XF_VNNI4_TO_NORM, XF_VNNI4_TO_VNNI2, XF_PAD };
+template <int S>
+__global__ __launch_bounds__(256) void xform_kernel(MeltwArgs p, int mode, int v, int pad_m, int pad_n) {
+  typedef typename Payload<S>::type T;
+  const T* in = (const T*)(p.in0 + (long long)blockIdx.y * p.bs_in0);
+  T* out = (T*)(p.out + (long long)blockIdx.y * p.bs_out);
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long M = p.m, N = p.n, ldi = p.ldi, ldo = p.ldo;
+  switch (mode) {
+    case XF_NORM_TO_VNNI: {   // out[(j*ldo*v) + i*v + j2] = in[(j*v+j2)*ldi + i]; zero fill of ldo*Nn first [ref: :532-557]
+      const long long Nn = ((N + v - 1) / v) * v, total = ldo * Nn;
+      if (gid >= total) return;
+      const long long jb = gid / (ldo * v), rem = gid % (ldo * v), i = rem / v, j2 = rem % v, jsrc = jb * v + j2;
+      out[gid] = (i < M && jsrc < N) ? in[jsrc * ldi + i] : (T)0;
+      return;
+    }
+    case XF_VNNI_TO_VNNIT: {  // [ref: :427-446] out[j*ldo*v + j2 + (i*v+i2)*v] = in[i*ldi*v + i2 + (j*v+j2)*v]
+      const long long total = (M / v) * (N / v) * v * v;
+      if (gid >= total) return;
+      const long long i2 = gid % v, j2 = (gid / v) % v, i = (gid / (v * v)) % (N / v), j = gid / (v * v * (N / v));
+      out[j * ldo * v + j2 + (i * v + i2) * v] = in[i * ldi * v + i2 + (j * v + j2) * v];
+      return;
+    }
+    case XF_NORM_TO_VNNIT: {  // [ref: :560-578] out[i*ldo*v + j*v + i2] = in[j*ldi + i*v + i2]
+      const long long total = (M / v) * N * v;
+      if (gid >= total) return;
+      const long long i2 = gid % v, j = (gid / v) % N, i = gid / (v * N);
+      out[i * ldo * v + j * v + i2] = in[j * ldi + i * v + i2];
+      return;
+    }
+    case XF_VNNIT_TO_NORM: {  // [ref: :581-640] (m and n swap roles) out[j*ldo + i*v + i2] = in[i*ldi*v + j*v + i2]
+      const long long Mm = N, Nn = M, total = (Mm / v) * Nn * v;
+      if (gid >= total) return;
+      const long long i2 = gid % v, j = (gid / v) % Nn, i = gid / (v * Nn);
+      out[j * ldo + i * v + i2] = in[i * ldi * v + j * v + i2];
+      return;
+    }
+    case XF_VNNI4_TO_NORM: {  // [ref: :788-804] out[i*ldo + j] = in[(i/4)*ldi*4 + j*4 + i%4]
+      if (gid >= M * N) return;
+      const long long j = gid % M, i = gid / M;
+      out[i * ldo + j] = in[(i / 4) * ldi * 4 + j * 4 + (i % 4)];
+      return;
+    }
+    case XF_VNNI4_TO_VNNI2: { // [ref: :807-823]
+      if (gid >= M * N) return;
+      const long long j = gid % M, i = gid / M;
+      out[(i / 2) * ldo * 2 + j * 2 + (i % 2)] = in[(i / 4) * ldi * 4 + j * 4 + (i % 4)];
+      return;
+    }
+    default: {                // XF_PAD [ref: :826-964]: zero ldo x pad_n, copy m x n
+      const long long total = ldo * (long long)pad_n;
+      if (gid >= total) return;
+      const long long i = gid % ldo, j = gid / ldo;
+      out[gid] = (i < M && j < N) ? in[j * ldi + i] : (T)0;
+      (void)pad_m;
+      return;
+    }
+  }
+}
+
+// gather / scatter [ref: :1444-1790]; lanes along the contiguous (i) axis where there is one
+template <int S>
+__global__ __launch_bounds__(256) void gather_scatter_kernel(MeltwArgs p) {
+  typedef typename Payload<S>::type T;
+  const T* in = (const T*)(p.in0 + (long long)blockIdx.y * p.bs_in0);
+  T* out = (T*)(p.out + (long long)blockIdx.y * p.bs_out);
+  const bool gather = (p.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER);
+  const void* idxp = gather ? p.aux_in : (const void*)p.aux_out;
+  const bool idx64 = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_8BYTES) != 0;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long long)p.m * p.n) return;
+  const long long i = gid % p.m, j = gid / p.m;
+#define XIDX(q) (idx64 ? (long long)((const unsigned long long*)idxp)[q] : (long long)((const unsigned int*)idxp)[q])
+  if (p.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_COLS) {
+    if (gather) out[i + j * p.ldo] = in[i + XIDX(j) * p.ldi]; else out[i + XIDX(j) * p.ldo] = in[i + j * p.ldi];
+  } else if (p.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_ROWS) {
+    if (gather) out[i + j * p.ldo] = in[XIDX(i) + j * p.ldi]; else out[XIDX(i) + j * p.ldo] = in[i + j * p.ldi];
+  } else {
+    if (gather) out[i + j * p.ldo] = in[XIDX(i + j * p.m)]; else out[XIDX(i + j * p.m)] = in[i + j * p.ldi];
+  }
+#undef XIDX
+}
+
+// reductions over rows (collapse i: one wave per column, shuffle tree) or columns (collapse j:
+// one thread per row, serial over j -- reads stay coalesced along i) [ref: :1065-1441]
+__global__ __launch_bounds__(256) void reduce_kernel(MeltwArgs p) {
+  const bool rows = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
+  const bool init_acc = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_INIT_ACC) != 0;
+  const int type = p.type;
+  const bool want_x = type != LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD;
+  const bool want_x2 = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD || type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD;
+  const bool is_add = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD || want_x2;
+  const char* in = p.in0 + (long long)blockIdx.y * p.bs_in0;
+  char* out = p.out + (long long)blockIdx.y * p.bs_out;
+  const long long result_size = rows ? p.n : p.ldo;
+  char* out2 = (want_x && want_x2) ? out + result_size * ((p.out_type == LIBXSMM_DATATYPE_F32) ? 4 : 2) : out;
+  const float ident = (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) ? -3.402823466e+38f : (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN) ? 3.402823466e+38f : 0.0f;
+  auto combine = [&](float a, float x) {
+    if (is_add) return a + x;
+    if (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) return (a < x) ? x : a;
+    if (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN) return (a > x) ? x : a;
+    return fmaxf(fabsf(a), fabsf(x));
+  };
+  if (rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= p.n) return;
+    float sx = ident, sx2 = 0.0f;
+    for (int i = lane; i < p.m; i += 64) {
+      const float x = mw_load(in, i + (long long)j * p.ldi, p.in0_type);
+      sx = combine(sx, x); sx2 += x * x;
+    }
+    for (int off = 32; off > 0; off >>= 1) { sx = combine(sx, __shfl_xor(sx, off)); sx2 += __shfl_xor(sx2, off); }
+    if (lane == 0) {
+      if (is_add && init_acc) { if (want_x) sx += mw_load(out, j, p.out_type); if (want_x2) sx2 += mw_load(out2, j, p.out_type); }
+      if (want_x) mw_store(out, j, p.out_type, sx);
+      if (want_x2) mw_store(out2, j, p.out_type, sx2);
+    }
+  } else {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.m) return;
+    float sx = ident, sx2 = 0.0f;
+    for (int j = 0; j < p.n; ++j) {
+      const float x = mw_load(in, i + (long long)j * p.ldi, p.in0_type);
+      sx = combine(sx, x); sx2 += x * x;
+    }
+    if (is_add && init_acc) { if (want_x) sx += mw_load(out, i, p.out_type); if (want_x2) sx2 += mw_load(out2, i, p.out_type); }
+    if (want_x) mw_store(out, i, p.out_type, sx);
+    if (want_x2) mw_store(out2, i, p.out_type, sx2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side selection
+// ------------------------------------------------------------------------------------------------
+static int payload_size(int t) { return typesize(t); }
+
+static bool is_float_type(int t) { return t == LIBXSMM_DATATYPE_F32 || t == LIBXSMM_DATATYPE_BF16; }
+
+static int xform_mode(int type, int* v) {
+  switch (type) {
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_VNNI2: case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_VNNI2_PAD: *v = 2; return XF_NORM_TO_VNNI;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_VNNI4: case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_VNNI4_PAD: *v = 4; return XF_NORM_TO_VNNI;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_VNNI8: case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_VNNI8_PAD: *v = 8; return XF_NORM_TO_VNNI;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_VNNI2_TO_VNNI2T: *v = 2; return XF_VNNI_TO_VNNIT;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_VNNI4_TO_VNNI4T: *v = 4; return XF_VNNI_TO_VNNIT;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_VNNI8_TO_VNNI8T: *v = 8; return XF_VNNI_TO_VNNIT;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_VNNI2T: *v = 2; return XF_NORM_TO_VNNIT;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_VNNI4T: *v = 4; return XF_NORM_TO_VNNIT;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_VNNI8T: *v = 8; return XF_NORM_TO_VNNIT;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_VNNI2T_TO_NORM: *v = 2; return XF_VNNIT_TO_NORM;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_VNNI4T_TO_NORM: *v = 4; return XF_VNNIT_TO_NORM;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_VNNI8T_TO_NORM: *v = 8; return XF_VNNIT_TO_NORM;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_VNNI4_TO_NORM: *v = 4; return XF_VNNI4_TO_NORM;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_VNNI4_TO_VNNI2: *v = 4; return XF_VNNI4_TO_VNNI2;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_PADM_MOD2: case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_PADM_MOD4: *v = 1; return XF_PAD;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_PADN_MOD2: case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_PADNM_MOD2: *v = 2; return XF_PAD;
+    case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_PADN_MOD4: case LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_PADNM_MOD4: *v = 4; return XF_PAD;
+    default: *v = 0; return 0;
+  }
+}
+static bool is_reduce_type(int t) {
+  return t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD ||
+         t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX;
+}
+
+bool meltw_supported(const libxsmm_meltw_descriptor& d) {
+  const int t = d.param;
+  const bool f64 = d.in0_type == LIBXSMM_DATATYPE_F64 && d.out_type == LIBXSMM_DATATYPE_F64;
+  if (d.operation == LIBXSMM_MELTW_OPERATION_UNARY) {
+    int v; const int sz = payload_size(d.in0_type);
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT || xform_mode(t, &v) != 0 ||
+        t == LIBXSMM_MELTW_TYPE_UNARY_GATHER || t == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) return sz == 1 || sz == 2 || sz == 4 || sz == 8;
+    if (is_reduce_type(t)) return is_float_type(d.in0_type) && is_float_type(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP));
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) return d.in0_type == LIBXSMM_DATATYPE_F32 && d.out_type == LIBXSMM_DATATYPE_BF16;
+    if (f64) {
+      switch (t) {
+        case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_XOR: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT:
+        case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: case LIBXSMM_MELTW_TYPE_UNARY_INC: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT: return true;
+        default: return false;
+      }
+    }
+    if (!is_float_type(d.in0_type) || !is_float_type(d.out_type)) return false;
+    if (d.flags & LIBXSMM_MELTW_FLAG_UNARY_STOCHASTIC_ROUND) return false;
+    switch (t) {
+      case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_XOR: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT:
+      case LIBXSMM_MELTW_TYPE_UNARY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_RELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_TANH: case LIBXSMM_MELTW_TYPE_UNARY_TANH_INV:
+      case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID: case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID_INV: case LIBXSMM_MELTW_TYPE_UNARY_GELU: case LIBXSMM_MELTW_TYPE_UNARY_GELU_INV:
+      case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: case LIBXSMM_MELTW_TYPE_UNARY_INC: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT:
+      case LIBXSMM_MELTW_TYPE_UNARY_EXP: case LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV:
+      case LIBXSMM_MELTW_TYPE_UNARY_ELU: case LIBXSMM_MELTW_TYPE_UNARY_ELU_INV: return true;
+      default: return false;
+    }
+  }
+  if (d.operation == LIBXSMM_MELTW_OPERATION_BINARY) {
+    if (t == LIBXSMM_MELTW_TYPE_BINARY_ZIP) return d.in0_type == LIBXSMM_DATATYPE_BF16 || d.in0_type == LIBXSMM_DATATYPE_U16 || d.in0_type == LIBXSMM_DATATYPE_I16;
+    const bool arith = t == LIBXSMM_MELTW_TYPE_BINARY_ADD || t == LIBXSMM_MELTW_TYPE_BINARY_MUL || t == LIBXSMM_MELTW_TYPE_BINARY_SUB || t == LIBXSMM_MELTW_TYPE_BINARY_DIV ||
+                       t == LIBXSMM_MELTW_TYPE_BINARY_MULADD || t == LIBXSMM_MELTW_TYPE_BINARY_MAX || t == LIBXSMM_MELTW_TYPE_BINARY_MIN;
+    const bool cmp = t >= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GT && t <= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_NE;
+    if (d.flags & LIBXSMM_MELTW_FLAG_BINARY_STOCHASTIC_ROUND) return false;
+    if (f64) return arith && d.in1_type == LIBXSMM_DATATYPE_F64;
+    if (!is_float_type(d.in0_type) || !is_float_type(d.in1_type)) return false;
+    if (cmp) return true;
+    return arith && is_float_type(d.out_type);
+  }
+  if (d.operation == LIBXSMM_MELTW_OPERATION_TERNARY) {
+    if (d.flags & LIBXSMM_MELTW_FLAG_TERNARY_STOCHASTIC_ROUND) return false;
+    if (t == LIBXSMM_MELTW_TYPE_TERNARY_SELECT) return f64 ? d.in1_type == LIBXSMM_DATATYPE_F64 : (is_float_type(d.in0_type) && is_float_type(d.in1_type) && is_float_type(d.out_type));
+    if (t == LIBXSMM_MELTW_TYPE_TERNARY_MULADD || t == LIBXSMM_MELTW_TYPE_TERNARY_NMULADD)
+      return is_float_type(d.in0_type) && is_float_type(d.in1_type) && is_float_type(d.in2_type) && is_float_type(d.out_type);
+    return false;
+  }
+  return false;
+}
+
+template <template <int> class K> struct SizeSwitch;
+
+#define LAUNCH_BY_SIZE(KERNEL, SZ, GRID, BLOCK, ST, ...)                                          \
+  do { switch (SZ) {                                                                              \
+      case 1: hipLaunchKernelGGL((KERNEL<1>), GRID, BLOCK, 0, ST, __VA_ARGS__); break;             \
+      case 2: hipLaunchKernelGGL((KERNEL<2>), GRID, BLOCK, 0, ST, __VA_ARGS__); break;             \
+      case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, BLOCK, 0, ST, __VA_ARGS__); break;             \
+      default: hipLaunchKernelGGL((KERNEL<8>), GRID, BLOCK, 0, ST, __VA_ARGS__); break; } } while (0)
+
+int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
+  hipStream_t st = (hipStream_t)stream;
+  if (a.nbatch == 0 || a.m <= 0 || a.n <= 0) { if (name) *name = "(empty)"; return 0; }
+  const int sz = payload_size(a.in0_type);
+  if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY) {
+    int v = 0; const int mode = xform_mode(a.type, &v);
+    if (a.type == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT) {
+      const long long tiles = (long long)((a.m + 31) / 32) * ((a.n + 31) / 32) * a.nbatch;
+      LAUNCH_BY_SIZE(transpose_kernel, sz, dim3((unsigned int)tiles), dim3(256), st, a);
+      if (name) *name = "transpose_kernel";
+    } else if (mode != 0) {
+      long long total; int pad_n = a.n;
+      if (mode == XF_NORM_TO_VNNI) total = (long long)a.ldo * (((a.n + v - 1) / v) * v);
+      else if (mode == XF_PAD) { pad_n = ((a.n + v - 1) / v) * v; total = (long long)a.ldo * pad_n; }
+      else total = (long long)a.m * a.n;
+      LAUNCH_BY_SIZE(xform_kernel, sz, dim3((unsigned int)((total + 255) / 256), a.nbatch), dim3(256), st, a, mode, v, 0, pad_n);
+      if (name) *name = "xform_kernel";
+    } else if (a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER || a.type == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) {
+      const long long total = (long long)a.m * a.n;
+      LAUNCH_BY_SIZE(gather_scatter_kernel, sz, dim3((unsigned int)((total + 255) / 256), a.nbatch), dim3(256), st, a);
+      if (name) *name = "gather_scatter_kernel";
+    } else if (is_reduce_type(a.type)) {
+      const bool rows = (a.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
+      const unsigned int gx = rows ? (unsigned int)((a.n + 3) / 4) : (unsigned int)((a.m + 255) / 256);
+      hipLaunchKernelGGL(reduce_kernel, dim3(gx, a.nbatch), dim3(256), 0, st, a);
+      if (name) *name = "reduce_kernel";
+    } else {
+      const int bc = bcast_kind(a.operation, a.type, a.flags, 0);
+      const bool simple = bc == BC_NONE && a.in0_type == a.out_type && is_float_type(a.in0_type) && (a.m % 4 == 0) && (a.ldi % 4 == 0) && (a.ldo % 4 == 0) &&
+        !(a.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && a.type != LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR &&
+        a.type != LIBXSMM_MELTW_TYPE_UNARY_RELU_INV && a.type != LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV && a.type != LIBXSMM_MELTW_TYPE_UNARY_ELU_INV &&
+        a.type != LIBXSMM_MELTW_TYPE_UNARY_UNZIP;
+      const int esz = (a.in0_type == LIBXSMM_DATATYPE_F32) ? 4 : 2;
+      const bool aligned = (((size_t)a.in0 | (size_t)a.out | (size_t)a.bs_in0 | (size_t)a.bs_out) % (size_t)(4 * esz)) == 0;
+      if (simple && aligned) {
+        const long long total = (long long)(a.m / 4) * a.n * a.nbatch;
+        if (esz == 4) hipLaunchKernelGGL((meltw_unary_vec4_kernel<f32x4, false>), dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((meltw_unary_vec4_kernel<u16x4, true>), dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, st, a);
+        if (name) *name = "meltw_unary_vec4_kernel";
+      } else {
+        const int n_eff = (a.type == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR) ? (int)a.scalar_u64 : a.n;
+        const long long blocks = (long long)((a.m + 63) / 64) * ((n_eff + 3) / 4) * a.nbatch;
+        if (blocks > 0) hipLaunchKernelGGL(meltw_unary_kernel, dim3((unsigned int)blocks), dim3(64, 4), 0, st, a);
+        if (name) *name = "meltw_unary_kernel";
+      }
+    }
+  } else {
+    const long long blocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * a.nbatch;
+    if (a.operation == LIBXSMM_MELTW_OPERATION_BINARY) { hipLaunchKernelGGL(meltw_binary_kernel, dim3((unsigned int)blocks), dim3(64, 4), 0, st, a); if (name) *name = "meltw_binary_kernel"; }
+    else { hipLaunchKernelGGL(meltw_ternary_kernel, dim3((unsigned int)blocks), dim3(64, 4), 0, st, a); if (name) *name = "meltw_ternary_kernel"; }
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace xamd

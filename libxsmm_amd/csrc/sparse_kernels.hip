@@ -1,0 +1,167 @@
+// sparse_kernels.hip -- packed / sparse kernels for gfx950.
+//
+// One device kernel serves the three "fixed sparse operator times a dense packed panel" entry
+// points of the reference:
+//   libxsmm_create_packed_spgemm_csr (A sparse)  C[m][n][p] (+)= sum_z a[z] * B[col[z]][n][p]
+//       [ref: src/generator_packed_spgemm_csr_asparse_avx_avx2_avx512.c:336-470]
+//   libxsmm_create_packed_spgemm_csc / _csr (B sparse)  C[m][n][p] (+)= sum_z A[m][row[z]][p] * b[z]
+//       [ref: samples/xgemm_norm_packed/bsparse_packed_csc.c:133-150]
+//   libxsmm_fsspmdm / libxsmm_create_spgemm_csr_areg  C[i][j] = sum_z a[z] * B[col[z]][j] (+ C)
+//       [ref: src/libxsmm_fsspmdm.c:491-514; samples/xgemm_sparse_Ainregs/pyfr_driver_asp_reg.c:351-375]
+// All of them are  Y[r][q] (+)= sum_{z in row r} val[z] * X[idx[z]][q]  with q running over a long
+// contiguous axis (packed width P, or n*P, or the N of FsSpMDM): lanes run along q, so every
+// global access is a coalesced row segment, the sparsity pattern and the values are wave-uniform
+// (scalar loads), and each X element is read from HBM exactly once per slab: the block stages its
+// column slice of X (inner x width) in LDS, then walks the pattern out of LDS.  These kernels are
+// HBM-bound (flops/byte ~ nnz/(K+M)/4); the roofline is bytes = (K + M(1+[beta=1])) * ncols * size.
+//
+// The block-sparse BCSC kernel keeps its pattern at run time (colptr/rowidx arrive with every call)
+// [ref: samples/xgemm_sparse/spmm_kernel.c:423-456].
+#include <hip/hip_runtime.h>
+#include "internal.hpp"
+
+namespace xamd {
+
+template <typename T, int VEC> struct VecOf;
+template <> struct VecOf<float, 1> { typedef float type; };
+template <> struct VecOf<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecOf<double, 1> { typedef double type; };
+template <> struct VecOf<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+
+template <typename T> __device__ __forceinline__ T load_val(const void* vals, unsigned int z, int vals_are_f64) {
+  return vals_are_f64 ? (T)((const double*)vals)[z] : ((const T*)vals)[z];
+}
+
+// grid: x = column blocks, y = slabs.  Dynamic LDS: inner * blockDim.x * VEC elements when STAGE.
+template <typename T, int VEC, bool STAGE>
+__global__ void spmm_panel_kernel(SpmmArgs p) {
+  typedef typename VecOf<T, VEC>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  vec_t* tile = (vec_t*)smem;                                  // [inner][blockDim.x]
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const long long q0 = ((long long)blockIdx.x * nthr + tid) * VEC;
+  const bool active = q0 < p.ncols;                            // ncols % VEC == 0 by construction
+  const T* x = (const T*)p.x + (long long)blockIdx.y * p.outer_x;
+  T* y = (T*)p.y + (long long)blockIdx.y * p.outer_y;
+  if (STAGE) {
+    // each thread copies its own column(s): no other thread reads them -> no barrier needed
+    if (active) for (int k = 0; k < p.inner; ++k) tile[(long long)k * nthr + tid] = *(const vec_t*)(x + (long long)k * p.ld_x + q0);
+  }
+  if (!active) return;
+  for (int r = 0; r < p.rows; ++r) {
+    const unsigned int z0 = p.ptr[r], z1 = p.ptr[r + 1];
+    if (z0 == z1 && (p.skip_empty || !p.beta0)) continue;      // untouched row
+    vec_t acc;
+    vec_t* yp = (vec_t*)(y + (long long)r * p.ld_y + q0);
+    if (p.beta0) { for (int v = 0; v < VEC; ++v) ((T*)&acc)[v] = (T)0; } else acc = *yp;
+    for (unsigned int z = z0; z < z1; ++z) {
+      const T a = load_val<T>(p.vals, p.vmap ? p.vmap[z] : z, p.vals_are_f64);
+      const unsigned int k = p.idx[z];
+      const vec_t xv = STAGE ? tile[(long long)k * nthr + tid] : *(const vec_t*)(x + (long long)k * p.ld_x + q0);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) ((T*)&acc)[v] = fma(a, ((const T*)&xv)[v], ((T*)&acc)[v]);
+    }
+    *yp = acc;
+  }
+}
+
+template <typename T, int VEC>
+static int launch_spmm_t(const SpmmArgs& a, hipStream_t st, const char** name) {
+  // pick the block width so that the staged slice fits a 64 KiB LDS budget (>= 2 blocks per CU)
+  int nthr = 256;
+  const size_t per_thread = (size_t)a.inner * VEC * sizeof(T);
+  while (nthr > 64 && per_thread * nthr > 65536) nthr >>= 1;
+  const bool stage = per_thread * nthr <= 65536;
+  const long long cols_per_block = (long long)nthr * VEC;
+  dim3 grid((unsigned int)((a.ncols + cols_per_block - 1) / cols_per_block), (unsigned int)a.nouter);
+  if (stage) {
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)spmm_panel_kernel<T, VEC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
+    hipLaunchKernelGGL((spmm_panel_kernel<T, VEC, true>), grid, dim3(nthr), per_thread * nthr, st, a);
+    if (name) *name = "spmm_panel_kernel<lds>";
+  } else {
+    hipLaunchKernelGGL((spmm_panel_kernel<T, VEC, false>), grid, dim3(nthr), 0, st, a);
+    if (name) *name = "spmm_panel_kernel<direct>";
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_spmm(const SpmmArgs& a, void* stream, const char** name) {
+  hipStream_t st = (hipStream_t)stream;
+  if (a.ncols <= 0 || a.rows <= 0 || a.nouter <= 0) { if (name) *name = "(empty)"; return 0; }
+  const int sz = (a.dtype == LIBXSMM_DATATYPE_F64) ? 8 : 4;
+  // widest vector such that every row segment start stays aligned
+  auto aligned = [&](int vec) {
+    const unsigned long long bytes = (unsigned long long)vec * sz;
+    return (a.ncols % vec == 0) && (a.ld_x % vec == 0) && (a.ld_y % vec == 0) && (a.outer_x % vec == 0) && (a.outer_y % vec == 0) &&
+           ((unsigned long long)(size_t)a.x % bytes == 0) && ((unsigned long long)(size_t)a.y % bytes == 0);
+  };
+  if (a.dtype == LIBXSMM_DATATYPE_F64) {
+    if (aligned(2)) return launch_spmm_t<double, 2>(a, st, name);
+    return launch_spmm_t<double, 1>(a, st, name);
+  }
+  if (aligned(4)) return launch_spmm_t<float, 4>(a, st, name);
+  if (aligned(2)) return launch_spmm_t<float, 2>(a, st, name);
+  return launch_spmm_t<float, 1>(a, st, name);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BCSC: C[mb][n][i] = beta*C + sum_{blk in block-column n/bn} sum_dk A[mb][k0+dk][i] * Bv[blk][n%bn][dk]
+// generic form: one thread per (i, n) of one M-block; lanes along i (contiguous in A and C).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(unsigned short x) { return __uint_as_float((unsigned int)x << 16); }
+__device__ __forceinline__ unsigned short f2bf_rne(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7f800000u) == 0u) u &= 0x80000000u;
+  if ((u & 0x7f800000u) == 0x7f800000u) { if (u & 0x007fffffu) u |= 0x00400000u; }
+  else u += 0x00007fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void bcsc_generic_kernel(BcscArgs p) {
+  const int tiles_i = (p.M + 63) / 64;
+  const long long per_block = (long long)tiles_i * p.N;
+  const long long blk = blockIdx.x * 4LL + threadIdx.y;
+  if (blk >= per_block * p.m_blocks) return;
+  const int mb = (int)(blk / per_block);
+  const int t = (int)(blk % per_block);
+  const int i = (t % tiles_i) * 64 + threadIdx.x;
+  const int n = t / tiles_i;
+  if (i >= p.M) return;
+  const int nb = n / p.bn, dn = n % p.bn;
+  const long long cidx = (long long)mb * p.N * p.M + (long long)n * p.M + i;
+  const bool f32 = (p.a_type == LIBXSMM_DATATYPE_F32);
+  float acc = 0.0f;
+  if (!p.beta0) acc = (p.c_type == LIBXSMM_DATATYPE_F32) ? ((const float*)p.c)[cidx] : bf2f(((const unsigned short*)p.c)[cidx]);
+  const long long abase = (long long)mb * p.K * p.M;
+  for (unsigned int b = p.colptr[nb]; b < p.colptr[nb + 1]; ++b) {
+    const int k0 = (int)p.rowidx[b] * p.bk;
+    const long long boff = ((long long)b * p.bn + dn) * p.bk;
+    for (int dk = 0; dk < p.bk; ++dk) {
+      const int k = k0 + dk;
+      float av, bv;
+      if (f32) {
+        av = ((const float*)p.a)[abase + (long long)k * p.M + i];
+        bv = ((const float*)p.bvals)[boff + dk];
+      } else {
+        const long long ai = p.vnni_a ? ((long long)(k / 2) * (p.M * 2) + (long long)i * 2 + (k % 2)) : ((long long)k * p.M + i);
+        av = bf2f(((const unsigned short*)p.a)[abase + ai]);
+        bv = bf2f(((const unsigned short*)p.bvals)[boff + dk]);
+      }
+      acc = fmaf(av, bv, acc);
+    }
+  }
+  if (p.c_type == LIBXSMM_DATATYPE_F32) ((float*)p.c)[cidx] = acc; else ((unsigned short*)p.c)[cidx] = f2bf_rne(acc);
+}
+
+int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
+  hipStream_t st = (hipStream_t)stream;
+  if (a.m_blocks <= 0 || a.M <= 0 || a.N <= 0) { if (name) *name = "(empty)"; return 0; }
+  const long long blocks = (long long)((a.M + 63) / 64) * a.N * a.m_blocks;
+  hipLaunchKernelGGL(bcsc_generic_kernel, dim3((unsigned int)((blocks + 3) / 4)), dim3(64, 4), 0, st, a);
+  if (name) *name = "bcsc_generic_kernel";
+  return (int)hipGetLastError();
+}
+
+}  // namespace xamd

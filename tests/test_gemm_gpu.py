@@ -1,0 +1,238 @@
+"""GPU parity tests for the dense GEMM/BRGEMM path, through the C-ABI (libxsmm_dispatch_* handles and
+the batched launchers), against the CPU oracle on the same seeded inputs.
+
+Bars (the reference's own, samples/xgemm/gemm_kernel.c:5312-5414): normf_rel < 1.2e-5 for f32/f64
+output, < 5e-3 for bf16 output; the ReLU bitmask must match bit for bit wherever the pre-activation is
+not within rounding of zero.  Two stronger statements are also checked:
+  * kernels that do not use MFMA (gemm_generic_kernel) are BIT-IDENTICAL to the oracle;
+  * the f32 MFMA kernels are BIT-IDENTICAL to the k-ordered fmaf restatement (oracle_gemm_f32_fma).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import GemmCase, TOL_BF16, TOL_F32, TOL_F64, normf_rel
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, GEMM_FLAG
+
+pytestmark = pytest.mark.gpu
+F = GEMM_FLAG
+
+
+def _tol(case):
+    return {DT.BF16: TOL_BF16, DT.F64: TOL_F64}.get(case.c_type, TOL_F32)
+
+
+def _check(case, batched=True, expect_kernel=None):
+    api = capi.load()
+    got, gmask, handle = case.run_gpu(batched=batched)
+    ref, rmask = case.run_oracle()
+    name = api.hip_kernel_name(handle, 1).decode()
+    if expect_kernel is not None:
+        assert expect_kernel in name, f"expected {expect_kernel}, library picked {name}"
+    err = normf_rel(case.valid_region(ref), case.valid_region(got), case.c_type)
+    assert err < _tol(case), f"{name}: normf_rel={err}"
+    if "generic" in name:
+        assert np.array_equal(case.valid_region(ref), case.valid_region(got)), "generic kernel must be bit-identical to the oracle"
+    if rmask is not None:
+        rb, gb = case.valid_mask_bits(rmask), case.valid_mask_bits(gmask)
+        # the test data (multiples of 0.1) produces many pre-activations that are zero up to rounding; the
+        # bit is only defined away from that: take the oracle's pre-activation and compare where |x| > 1e-5
+        act = case.act
+        case.act = 0
+        pre, _ = case.run_oracle()
+        case.act = act
+        pre = case.valid_region(pre)
+        pre = pre.astype(np.float64) if case.c_type != DT.BF16 else (pre.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        decided = np.abs(pre) > (1e-2 if case.c_type == DT.BF16 else 1e-5)
+        assert decided.mean() > 0.5
+        assert np.array_equal(rb[decided], gb[decided])
+    return name
+
+
+SHAPES_F32 = [
+    dict(m=32, n=32, k=32),
+    dict(m=32, n=32, k=32, beta=1),
+    dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=8),
+    dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=3, beta=1),
+    dict(m=32, n=32, k=32, br_type=capi.BR_OFFSET, br_count=5),
+    dict(m=32, n=32, k=32, br_type=capi.BR_ADDRESS, br_count=4, beta=1),
+    dict(m=64, n=64, k=64, br_type=capi.BR_STRIDE, br_count=2),
+    dict(m=64, n=32, k=96, beta=1),
+    dict(m=16, n=16, k=16),
+    dict(m=16, n=16, k=16, br_type=capi.BR_STRIDE, br_count=4, beta=1),
+    dict(m=48, n=16, k=32),
+    dict(m=128, n=96, k=64),
+    dict(m=23, n=23, k=23),                       # BASELINE config #1
+    dict(m=17, n=9, k=31, lda=20, ldb=33, ldc=19, beta=1),
+    dict(m=100, n=71, k=5),
+    dict(m=1, n=1, k=1),
+    dict(m=33, n=65, k=34, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=32, n=32, k=32, flags=F.TRANS_A),
+    dict(m=32, n=32, k=32, flags=F.TRANS_B, beta=1),
+    dict(m=64, n=64, k=32, flags=F.TRANS_A | F.TRANS_B),
+    dict(m=13, n=7, k=5, flags=F.TRANS_A),
+    dict(m=13, n=7, k=5, flags=F.TRANS_B, beta=1),
+    dict(m=10, n=12, k=14, flags=F.TRANS_A | F.TRANS_B),
+    dict(m=32, n=32, k=32, ldb=36, lda=40, ldc=48),   # unaligned-for-16B B columns -> scalar operand loads
+    dict(m=32, n=32, k=32, ldb=33),
+]
+
+
+@pytest.mark.parametrize("kw", SHAPES_F32, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_f32_gemm_matches_oracle(kw):
+    _check(GemmCase(seed=555, batch=3, **kw))
+
+
+@pytest.mark.parametrize("kw", SHAPES_F32, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_f32_mfma_is_bitwise_the_k_ordered_fma_chain(kw):
+    case = GemmCase(seed=11, batch=2, **kw)
+    api = capi.load()
+    got, _, handle = case.run_gpu()
+    name = api.hip_kernel_name(handle, 1).decode()
+    if "mfma_f32_kernel" not in name:
+        pytest.skip(f"{name} does not promise natural k order")
+    ref, _ = case.run_oracle(fma=True)
+    assert np.array_equal(case.valid_region(ref), case.valid_region(got))
+
+
+def test_headline_shape_uses_mfma_tile_kernel():
+    name = _check(GemmCase(32, 32, 32, br_type=capi.BR_STRIDE, br_count=1, batch=64, seed=1), expect_kernel="gemm_mfma_f32_kernel<1,1>")
+    assert "mfma" in name
+    _check(GemmCase(16, 16, 16, batch=64, seed=2), expect_kernel="t16")
+    _check(GemmCase(64, 64, 64, batch=8, seed=3), expect_kernel="gemm_mfma_f32_kernel<2,2>")
+
+
+SHAPES_BF16 = [
+    dict(m=64, n=64, k=64, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=4),
+    dict(m=64, n=64, k=64, c_type=DT.F32, flags=F.VNNI_A, beta=1),
+    dict(m=32, n=32, k=32, c_type=DT.BF16, flags=F.VNNI_A, beta=1),
+    dict(m=32, n=32, k=64, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=3),
+    dict(m=64, n=64, k=32, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_ADDRESS, br_count=2),
+    dict(m=33, n=17, k=18, c_type=DT.BF16, flags=F.VNNI_A, beta=1, ldc=40),
+    dict(m=96, n=70, k=50, c_type=DT.F32, flags=F.VNNI_A),
+    dict(m=64, n=64, k=64, c_type=DT.BF16, flags=F.VNNI_A, ldb=72, ldc=66),
+    dict(m=12, n=10, k=9, c_type=DT.BF16),                                           # flat A -> generic
+    dict(m=12, n=10, k=8, c_type=DT.F32, flags=F.TRANS_B),
+    dict(m=12, n=10, k=8, c_type=DT.BF16, flags=F.VNNI_A | F.TRANS_B | F.VNNI_B),
+    dict(m=12, n=10, k=8, c_type=DT.BF16, flags=F.TRANS_A, beta=1),
+]
+
+
+@pytest.mark.parametrize("kw", SHAPES_BF16, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_bf16_gemm_matches_oracle(kw):
+    _check(GemmCase(seed=777, batch=3, a_type=DT.BF16, **kw))
+
+
+def test_f64_gemm_is_bit_identical():
+    for kw in (dict(m=9, n=11, k=13, beta=1, br_type=capi.BR_STRIDE, br_count=2), dict(m=32, n=32, k=32), dict(m=7, n=5, k=3, flags=F.TRANS_A | F.TRANS_B)):
+        _check(GemmCase(seed=5, batch=2, a_type=DT.F64, **kw), expect_kernel="generic")
+
+
+FUSED = [
+    dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=4, colbias=True, act=1),   # config #5
+    dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2),
+    dict(m=32, n=24, k=16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2, beta=1),
+    dict(m=32, n=32, k=32, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, act=3),
+    dict(m=32, n=32, k=32, colbias=True, act=2),
+    dict(m=32, n=32, k=32, colbias=True, act=1, beta=1),
+    dict(m=20, n=12, k=16, colbias=True, act=2),
+    dict(m=20, n=12, k=16, act=3, beta=1),
+    dict(m=16, n=16, k=16, colbias=True, act=2),
+    dict(m=64, n=64, k=32, colbias=True),
+]
+
+
+@pytest.mark.parametrize("kw", FUSED, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_fused_epilogue_matches_oracle(kw):
+    _check(GemmCase(seed=99, batch=3, **kw))
+
+
+def test_vnni_c_output():
+    case = GemmCase(16, 6, 8, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A | F.VNNI_C, seed=3)
+    got, _, _ = case.run_gpu()
+    ref, _ = case.run_oracle()
+    assert np.array_equal(ref[: case.ldc * case.n], got[: case.ldc * case.n])
+
+
+def test_batched_launch_equals_loop_of_single_calls():
+    """The contract of libxsmm_hip_gemm_batch_strided (include/libxsmm_hip.h)."""
+    for kw in (dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=2), dict(m=23, n=17, k=9, beta=1),
+               dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2)):
+        case = GemmCase(seed=21, batch=5, **kw)
+        one, m1, _ = case.run_gpu(batched=True)
+        two, m2, _ = case.run_gpu(batched=False)
+        assert np.array_equal(one, two)
+        if m1 is not None:
+            assert np.array_equal(m1, m2)
+
+
+def test_shared_operand_and_pointer_list_batches():
+    import torch
+    api = capi.load()
+    case = GemmCase(32, 32, 32, batch=7, seed=8, shared_b=True)        # stride_b == 0: B shared by the batch
+    got, _, handle = case.run_gpu(batched=True)
+    ref, _ = case.run_oracle()
+    assert normf_rel(ref, got, DT.F32) < TOL_F32
+    # pointer-list form over the same buffers, in reversed order
+    dev = torch.device("cuda:0")
+    A, B = torch.from_numpy(case.A).to(dev), torch.from_numpy(case.B).to(dev)
+    Cbuf = torch.from_numpy(case.C0.copy()).to(dev)
+    order = list(reversed(range(case.batch)))
+    la = torch.tensor([A.data_ptr() + b * case.bs_a for b in order], dtype=torch.int64, device=dev)
+    lb = torch.tensor([B.data_ptr() for _ in order], dtype=torch.int64, device=dev)
+    lc = torch.tensor([Cbuf.data_ptr() + b * case.bs_c for b in order], dtype=torch.int64, device=dev)
+    p = capi.GemmParam()
+    api.hip_gemm_batch_pointers(handle, C.byref(p), case.batch, la.data_ptr(), lb.data_ptr(), lc.data_ptr())
+    api.hip_sync(); api.check()
+    assert np.array_equal(Cbuf.cpu().numpy(), got)
+
+
+def test_full_size_batch_linearity_property():
+    """BASELINE config #2 at full size (batch 4096): parity through a size-independent property --
+    C(A, B1 + B2) == C(A, B1) + C(A, B2) up to fp32 rounding, and a strided sample against the oracle."""
+    import torch
+    api = capi.load()
+    batch, m = 4096, 32
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = (torch.randint(-4, 6, (batch, m, m), generator=g).float() / 10).to(dev)
+    B1 = (torch.randint(-4, 6, (batch, m, m), generator=g).float() / 10).to(dev)
+    B2 = (torch.randint(-4, 6, (batch, m, m), generator=g).float() / 10).to(dev)
+    shape = capi.gemm_shape(m, m, m, m, m, m, DT.F32, DT.F32, DT.F32, DT.F32)
+    h = api.dispatch_brgemm(shape, F.BETA_0, 0, capi.br_config(capi.BR_STRIDE, m * m * 4, m * m * 4, 0))
+    assert h
+    cnt = C.c_ulonglong(1)
+
+    def run(Bt):
+        Ct = torch.empty_like(A)
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = A.data_ptr(), Bt.data_ptr(), Ct.data_ptr(), C.addressof(cnt)
+        api.hip_gemm_batch_strided(h, C.byref(p), batch, m * m * 4, m * m * 4, m * m * 4)
+        api.hip_sync(); api.check()
+        return Ct
+    c1, c2, c12 = run(B1), run(B2), run(B1 + B2)
+    assert torch.allclose(c12, c1 + c2, rtol=0, atol=2e-5)
+    # column-major semantics: C[b] (as [n][m]) == (A_colmajor @ B_colmajor): with row-major views C^T = B^T-view @ A^T-view
+    ref = torch.matmul(B1.double(), A.double())           # [b][n][k] @ [b][k][m] -> [b][n][m]
+    assert torch.allclose(c1.double(), ref, rtol=0, atol=1e-5)
+
+
+def test_illegal_descriptors_return_null():
+    api = capi.load()
+    s = capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F32, DT.F32, DT.F32, DT.F32)
+    assert api.dispatch_gemm(s, F.NO_RESET_TILECONFIG, 0) is None                       # half-set tile config
+    assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 16, 32, 32, DT.F32, DT.F32, DT.F32, DT.F32), 0, 0) is None   # lda < m
+    assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.I8, DT.I8, DT.I32, DT.I32), 0, 0) is None    # unsupported types
+    assert api.dispatch_gemm(capi.gemm_shape(32, 32, 31, 32, 32, 32, DT.BF16, DT.BF16, DT.BF16, DT.F32), F.VNNI_A, 0) is None   # odd k with VNNI
+    # same descriptor -> same handle (registry), different descriptor -> different handle
+    h1, h2 = api.dispatch_gemm(s, 0, 0), api.dispatch_gemm(s, 0, 0)
+    assert h1 and h1 == h2 and api.dispatch_gemm(s, F.BETA_0, 0) != h1
+    info = capi.KernelInfo()
+    assert api.get_kernel_info(h1, C.byref(info)) == 0 and info.is_reference_kernel == 0 and info.nflops == 2 * 32 ** 3
+    mm = capi.MmKernelInfo()
+    assert api.get_mmkernel_info(h1, C.byref(mm)) == 0 and (mm.m, mm.n, mm.k, mm.lda) == (32, 32, 32, 32)
+    # tile-config handles exist and are callable no-ops
+    t = api.dispatch_tilecfg_gemm(s, F.NO_RESET_TILECONFIG)
+    assert t

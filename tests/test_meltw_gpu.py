@@ -1,0 +1,295 @@
+"""GPU parity tests for the element-wise TPPs (libxsmm_dispatch_meltw_unary/binary/ternary) against the
+oracle restatement of src/generator_mateltwise_reference_impl.c.
+
+Bars: data movement (copy, zero, transposes, VNNI re-layouts, padding, gather/scatter, ZIP/UNZIP) and
+comparison/select are BIT-EXACT; arithmetic on f32/bf16 is bit-exact for exactly-rounded ops and within
+the reference's bounds for transcendental ones (7e-4 f32 / 7e-3 bf16, eltwise_unary_simple.c:570-591);
+reductions 1e-5 (summation order differs).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import NP_OF, normf_rel, rand_values
+from libxsmm_amd import capi
+from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, TERNARY, TERNARY_FLAG, UNARY, UNARY_FLAG
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+OP_UNARY, OP_BINARY, OP_TERNARY = 1, 2, 3
+
+
+def _dev(x):
+    import torch
+    v = {np.uint16: np.int16, np.uint32: np.int32, np.uint64: np.int64}.get(x.dtype.type)
+    return torch.from_numpy(np.ascontiguousarray(x.view(v) if v else x)).to("cuda:0")
+
+
+def _back(t, like):
+    return t.cpu().numpy().view(like.dtype)
+
+
+def run_unary(typ, m, n, ldi, ldo, in_dt, out_dt, flags=0, seed=0, batch=1, aux_in=None, aux_out_bytes=0, op_primary=None,
+              in_elems=None, out_elems=None, out_secondary_val=None, inp=None):
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(seed)
+    in_elems = in_elems if in_elems is not None else ldi * max(n, 1)
+    out_elems = out_elems if out_elems is not None else ldo * max(n, 1)
+    X = inp if inp is not None else rand_values(rng, batch * in_elems, in_dt)
+    Y0 = rand_values(rng, batch * out_elems, out_dt)
+    comp = DT.F64 if in_dt == DT.F64 else DT.F32
+    desc = pyoracle.MeltwDesc(m, n, ldi, ldo, 0, 0, in_dt, DT.UNSUPPORTED, DT.UNSUPPORTED, comp, out_dt, flags, typ, OP_UNARY)
+    in_sz, out_sz = capi.DT_SIZE[in_dt], capi.DT_SIZE[out_dt]
+    ref = Y0.copy()
+    aux_ref = np.zeros(batch * aux_out_bytes, dtype=np.uint8) if aux_out_bytes else None
+    keep = []
+
+    def fill(p, xin, yout, aux_i, aux_o, b):
+        p.in_.primary = xin + b * in_elems * in_sz
+        p.out.primary = yout + b * out_elems * out_sz
+        if aux_i is not None:
+            p.in_.secondary = aux_i
+        if aux_o is not None:
+            p.out.secondary = aux_o + b * aux_out_bytes
+        if out_secondary_val is not None:
+            v = C.c_ulonglong(out_secondary_val); keep.append(v); p.out.secondary = C.addressof(v)
+        if op_primary is not None:
+            keep.append(op_primary); p.op.primary = C.addressof(op_primary)
+    for b in range(batch):
+        p = capi.UnaryParam()
+        fill(p, X.ctypes.data, ref.ctypes.data, aux_in.ctypes.data if aux_in is not None else None,
+             aux_ref.ctypes.data if aux_ref is not None else None, b)
+        orc.meltw(p, desc)
+    shape = capi.UnaryShape(m, n, ldi, ldo, in_dt, out_dt, comp)
+    h = api.dispatch_meltw_unary(typ, shape, flags)
+    assert h, "dispatch returned NULL"
+    dX, dY = _dev(X), _dev(Y0.copy())
+    d_aux_in = _dev(aux_in) if aux_in is not None else None
+    d_aux_out = _dev(np.zeros(batch * aux_out_bytes, dtype=np.uint8)) if aux_out_bytes else None
+    p = capi.UnaryParam()
+    fill(p, dX.data_ptr(), dY.data_ptr(), d_aux_in.data_ptr() if d_aux_in is not None else None,
+         d_aux_out.data_ptr() if d_aux_out is not None else None, 0)
+    if batch == 1:
+        capi.Api.call(h, p)
+    else:
+        api.hip_meltw_unary_batch_strided(h, C.byref(p), batch, in_elems * in_sz, out_elems * out_sz, aux_out_bytes)
+    api.hip_sync(); api.check()
+    got = _back(dY, Y0)
+    return ref, got, aux_ref, (d_aux_out.cpu().numpy() if d_aux_out is not None else None)
+
+
+EXACT_UNARY = [UNARY.IDENTITY, UNARY.XOR, UNARY.X2, UNARY.NEGATE, UNARY.INC, UNARY.RELU, UNARY.SQRT, UNARY.RECIPROCAL]
+APPROX_UNARY = [UNARY.TANH, UNARY.SIGMOID, UNARY.GELU, UNARY.EXP, UNARY.RECIPROCAL_SQRT, UNARY.TANH_INV, UNARY.SIGMOID_INV, UNARY.GELU_INV]
+
+
+@pytest.mark.parametrize("typ", EXACT_UNARY + APPROX_UNARY)
+@pytest.mark.parametrize("in_dt,out_dt", [(DT.F32, DT.F32), (DT.BF16, DT.BF16), (DT.F32, DT.BF16), (DT.BF16, DT.F32)])
+@pytest.mark.parametrize("m,n,ldi,ldo,batch", [(64, 64, 64, 64, 1), (33, 7, 40, 35, 3), (128, 16, 128, 128, 4)])
+def test_unary_math(typ, in_dt, out_dt, m, n, ldi, ldo, batch):
+    rng = np.random.default_rng(5)
+    inp = None
+    if typ in (UNARY.SQRT, UNARY.RECIPROCAL_SQRT, UNARY.RECIPROCAL):
+        v = (rng.random(batch * ldi * n) + 0.25).astype(np.float32)
+        inp = v if in_dt == DT.F32 else (v.view(np.uint32) >> 16).astype(np.uint16)
+    ref, got, _, _ = run_unary(typ, m, n, ldi, ldo, in_dt, out_dt, batch=batch, inp=inp)
+    if typ in EXACT_UNARY and typ not in (UNARY.SQRT, UNARY.RECIPROCAL):
+        assert np.array_equal(ref, got)
+    else:
+        assert normf_rel(ref, got, out_dt) < (7e-3 if out_dt == DT.BF16 else 7e-4)
+
+
+@pytest.mark.parametrize("flag", [UNARY_FLAG.BCAST_ROW, UNARY_FLAG.BCAST_COL, UNARY_FLAG.BCAST_SCALAR])
+def test_unary_broadcast(flag):
+    ref, got, _, _ = run_unary(UNARY.IDENTITY, 37, 11, 40, 37, DT.F32, DT.BF16, flags=flag)
+    assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16])
+def test_relu_with_bitmask_and_inverse(dt):
+    m, n, ld = 70, 9, 72
+    mask_bytes = (((ld + 15) // 16) * 16 // 8) * n
+    ref, got, mref, mgot = run_unary(UNARY.RELU, m, n, ld, ld, dt, dt, flags=UNARY_FLAG.BITMASK_2BYTEMULT, aux_out_bytes=mask_bytes, batch=2)
+    assert np.array_equal(ref, got)
+    bits = lambda a: np.unpackbits(a.reshape(2, n, -1), axis=2, bitorder="little")[:, :, :m]
+    assert np.array_equal(bits(mref), bits(mgot))
+    r2, g2, _, _ = run_unary(UNARY.RELU_INV, m, n, ld, ld, dt, dt, flags=UNARY_FLAG.BITMASK_2BYTEMULT, aux_in=mref[:mask_bytes].copy())
+    assert np.array_equal(r2, g2)
+    alpha = C.c_float(0.3)
+    r3, g3, _, _ = run_unary(UNARY.LEAKY_RELU, m, n, ld, ld, dt, dt, op_primary=alpha)
+    assert np.array_equal(r3, g3)
+    r4, g4, _, _ = run_unary(UNARY.ELU, m, n, ld, ld, dt, dt, op_primary=alpha)
+    assert normf_rel(r4, g4, dt) < 7e-3
+
+
+def test_f64_unary():
+    for typ in (UNARY.IDENTITY, UNARY.X2, UNARY.NEGATE, UNARY.INC):
+        ref, got, _, _ = run_unary(typ, 19, 5, 20, 19, DT.F64, DT.F64)
+        assert np.array_equal(ref, got)
+
+
+TRANSFORMS = [
+    (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F32, 37, 19, 40, 19), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.BF16, 64, 64, 64, 64),
+    (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F64, 5, 70, 8, 71), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.I8, 33, 34, 33, 34),
+    (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 32, 16, 32, 32), (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 13, 8, 16, 14),
+    (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.BF16, 16, 8, 16, 16), (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.I8, 20, 12, 24, 20),
+    (UNARY.TRANSFORM_VNNI2_TO_VNNI2T, DT.BF16, 16, 8, 8, 16), (UNARY.TRANSFORM_NORM_TO_VNNI2T, DT.BF16, 16, 6, 16, 6),
+    (UNARY.TRANSFORM_VNNI4_TO_VNNI4T, DT.I8, 16, 8, 8, 16), (UNARY.TRANSFORM_NORM_TO_VNNI4T, DT.BF16, 16, 6, 16, 6),
+    (UNARY.TRANSFORM_VNNI4_TO_NORM, DT.I8, 12, 8, 12, 12), (UNARY.TRANSFORM_VNNI4_TO_VNNI2, DT.I8, 12, 8, 12, 12),
+    (UNARY.TRANSFORM_PADN_MOD2, DT.BF16, 9, 5, 10, 12), (UNARY.TRANSFORM_PADM_MOD2, DT.BF16, 9, 6, 10, 12),
+    (UNARY.TRANSFORM_PADNM_MOD4, DT.I8, 9, 6, 10, 12),
+]
+
+
+@pytest.mark.parametrize("typ,dt,m,n,ldi,ldo", TRANSFORMS)
+def test_transforms_bit_exact(typ, dt, m, n, ldi, ldo):
+    # generous buffers: VNNI layouts interleave rows, padded variants write beyond n columns
+    elems = 4 * max(ldi, ldo) * (max(m, n) + 8)
+    ref, got, _, _ = run_unary(typ, m, n, ldi, ldo, dt, dt, in_elems=elems, out_elems=elems, batch=2)
+    assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16, DT.I8])
+@pytest.mark.parametrize("mode", [UNARY_FLAG.GS_COLS, UNARY_FLAG.GS_ROWS, UNARY_FLAG.GS_OFFS])
+@pytest.mark.parametrize("idx8", [0, 1])
+def test_gather_scatter_bit_exact(dt, mode, idx8):
+    m, n, big = 24, 10, 40
+    rng = np.random.default_rng(9)
+    idt = np.uint64 if idx8 else np.uint32
+    flags = mode | (UNARY_FLAG.IDX_SIZE_8BYTES if idx8 else UNARY_FLAG.IDX_SIZE_4BYTES)
+    if mode == UNARY_FLAG.GS_COLS:
+        idx = rng.choice(big, size=n, replace=False).astype(idt)
+    elif mode == UNARY_FLAG.GS_ROWS:
+        idx = rng.choice(big, size=m, replace=False).astype(idt)
+    else:
+        idx = rng.choice(big * big, size=m * n, replace=False).astype(idt)
+    # gather: big source -> compact m x n ; scatter: compact -> big destination
+    ref, got, _, _ = run_unary(UNARY.GATHER, m, n, big, m, dt, dt, flags=flags, aux_in=idx, in_elems=big * big, out_elems=m * n)
+    assert np.array_equal(ref, got)
+    api, orc = capi.load(), pyoracle.oracle()
+    X, Y0 = rand_values(rng, m * n, dt), rand_values(rng, big * big, dt)
+    desc = pyoracle.MeltwDesc(m, n, m, big, 0, 0, dt, DT.UNSUPPORTED, DT.UNSUPPORTED, DT.F32, dt, flags, UNARY.SCATTER, OP_UNARY)
+    refs = Y0.copy()
+    p = capi.UnaryParam(); p.in_.primary, p.out.primary, p.out.secondary = X.ctypes.data, refs.ctypes.data, idx.ctypes.data
+    orc.meltw(p, desc)
+    h = api.dispatch_meltw_unary(UNARY.SCATTER, capi.UnaryShape(m, n, m, big, dt, dt, DT.F32), flags)
+    assert h
+    dX, dY, dI = _dev(X), _dev(Y0.copy()), _dev(idx)
+    p = capi.UnaryParam(); p.in_.primary, p.out.primary, p.out.secondary = dX.data_ptr(), dY.data_ptr(), dI.data_ptr()
+    capi.Api.call(h, p); api.hip_sync(); api.check()
+    assert np.array_equal(refs, _back(dY, Y0))
+
+
+@pytest.mark.parametrize("typ", [UNARY.REDUCE_X_OP_ADD, UNARY.REDUCE_X2_OP_ADD, UNARY.REDUCE_X_X2_OP_ADD, UNARY.REDUCE_X_OP_MAX, UNARY.REDUCE_X_OP_MIN, UNARY.REDUCE_X_OP_ABSMAX])
+@pytest.mark.parametrize("rows", [0, 1])
+@pytest.mark.parametrize("in_dt", [DT.F32, DT.BF16])
+def test_reductions(typ, rows, in_dt):
+    m, n, ldi = 75, 33, 80
+    res = n if rows else m
+    flags = UNARY_FLAG.REDUCE_ROWS if rows else UNARY_FLAG.REDUCE_COLS
+    ref, got, _, _ = run_unary(typ, m, n, ldi, res, in_dt, DT.F32, flags=flags, out_elems=2 * res, batch=2)
+    r, g = ref.reshape(2, -1), got.reshape(2, -1)
+    used = 2 * res if typ == UNARY.REDUCE_X_X2_OP_ADD else res
+    if typ in (UNARY.REDUCE_X_OP_MAX, UNARY.REDUCE_X_OP_MIN, UNARY.REDUCE_X_OP_ABSMAX):
+        assert np.array_equal(r[:, :used], g[:, :used])
+    else:
+        assert normf_rel(r[:, :used], g[:, :used], DT.F32) < 1e-5
+
+
+def run_binary(typ, m, n, ldi, ldi1, ldo, dts, flags=0, seed=0, batch=1, out_is_bits=False):
+    api, orc = capi.load(), pyoracle.oracle()
+    in0_dt, in1_dt, out_dt = dts
+    rng = np.random.default_rng(seed)
+    X0, X1 = rand_values(rng, batch * ldi * n, in0_dt), rand_values(rng, batch * ldi1 * n, in1_dt)
+    if typ == BINARY.DIV:
+        X1 = (X1.astype(np.float32) * 0 + 0.75).astype(X1.dtype) if in1_dt == DT.F32 else X1
+    out_bytes = ((((ldo + 15) // 16) * 16) // 8) * n if out_is_bits else ldo * n * capi.DT_SIZE[out_dt]
+    Y0 = np.zeros(batch * out_bytes, dtype=np.uint8) if out_is_bits else rand_values(rng, batch * ldo * n, out_dt)
+    comp = DT.F64 if in0_dt == DT.F64 else DT.F32
+    desc = pyoracle.MeltwDesc(m, n, ldi, ldo, ldi1, 0, in0_dt, in1_dt, DT.UNSUPPORTED, comp, out_dt, flags, typ, OP_BINARY)
+    ref = Y0.copy()
+    s0, s1 = ldi * n * capi.DT_SIZE[in0_dt], ldi1 * n * capi.DT_SIZE[in1_dt]
+    for b in range(batch):
+        p = capi.BinaryParam()
+        p.in0.primary, p.in1.primary, p.out.primary = X0.ctypes.data + b * s0, X1.ctypes.data + b * s1, ref.ctypes.data + b * out_bytes
+        orc.meltw(p, desc)
+    h = api.dispatch_meltw_binary(typ, capi.BinaryShape(m, n, ldi, ldi1, ldo, in0_dt, in1_dt, out_dt, comp), flags)
+    assert h
+    d0, d1, dY = _dev(X0), _dev(X1), _dev(Y0.copy())
+    p = capi.BinaryParam()
+    p.in0.primary, p.in1.primary, p.out.primary = d0.data_ptr(), d1.data_ptr(), dY.data_ptr()
+    if batch == 1:
+        capi.Api.call(h, p)
+    else:
+        api.hip_meltw_binary_batch_strided(h, C.byref(p), batch, s0, s1, out_bytes)
+    api.hip_sync(); api.check()
+    return ref, _back(dY, Y0)
+
+
+@pytest.mark.parametrize("typ", [BINARY.ADD, BINARY.MUL, BINARY.SUB, BINARY.DIV, BINARY.MULADD, BINARY.MAX, BINARY.MIN])
+@pytest.mark.parametrize("dts", [(DT.F32, DT.F32, DT.F32), (DT.BF16, DT.BF16, DT.BF16), (DT.BF16, DT.F32, DT.F32)])
+def test_binary_arith_bit_exact(typ, dts):
+    ref, got = run_binary(typ, 45, 13, 48, 45, 50, dts, batch=3)
+    assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("flags", [BINARY_FLAG.BCAST_COL_IN_0, BINARY_FLAG.BCAST_ROW_IN_1, BINARY_FLAG.BCAST_SCALAR_IN_0, BINARY_FLAG.BCAST_COL_IN_0 | BINARY_FLAG.BCAST_ROW_IN_1])
+def test_binary_broadcast_bias_add(flags):
+    ref, got = run_binary(BINARY.ADD, 64, 64, 64, 64, 64, (DT.BF16, DT.BF16, DT.BF16), flags=flags)   # config #5's bias-add as a stand-alone TPP
+    assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("typ", [BINARY.CMP_OP_GT, BINARY.CMP_OP_GE, BINARY.CMP_OP_LT, BINARY.CMP_OP_LE, BINARY.CMP_OP_EQ, BINARY.CMP_OP_NE])
+def test_binary_compare_bitmask(typ):
+    m, n, ld = 70, 6, 72
+    ref, got = run_binary(typ, m, n, ld, ld, ld, (DT.F32, DT.F32, DT.F32), out_is_bits=True)
+    bits = lambda a: np.unpackbits(a.reshape(n, -1), axis=1, bitorder="little")[:, :m]
+    assert np.array_equal(bits(ref), bits(got))
+
+
+def test_zip_unzip_roundtrip_bit_exact():
+    api = capi.load()
+    m, n = 48, 20
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal(m * n).astype(np.float32)
+    off = m * n * 2
+    ref, got, _, _ = run_unary(UNARY.UNZIP, m, n, m, m, DT.F32, DT.BF16, inp=X, out_elems=2 * m * n, out_secondary_val=off)
+    assert np.array_equal(ref, got)
+    lo, hi = got[: m * n].copy(), got[m * n:].copy()
+    h = api.dispatch_meltw_binary(BINARY.ZIP, capi.BinaryShape(m, n, m, m, m, DT.U16, DT.U16, DT.F32, DT.F32), 0)
+    assert h
+    d0, d1, dY = _dev(lo), _dev(hi), _dev(np.zeros(m * n, dtype=np.float32))
+    p = capi.BinaryParam(); p.in0.primary, p.in1.primary, p.out.primary = d0.data_ptr(), d1.data_ptr(), dY.data_ptr()
+    capi.Api.call(h, p); api.hip_sync(); api.check()
+    assert np.array_equal(dY.cpu().numpy().view(np.uint32), X.view(np.uint32))
+
+
+@pytest.mark.parametrize("typ", [TERNARY.SELECT, TERNARY.MULADD, TERNARY.NMULADD])
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16])
+def test_ternary(typ, dt):
+    api, orc = capi.load(), pyoracle.oracle()
+    m, n, ld = 40, 9, 48
+    rng = np.random.default_rng(6)
+    X0, X1 = rand_values(rng, ld * n, dt), rand_values(rng, ld * n, dt)
+    if typ == TERNARY.SELECT:
+        X2 = rng.integers(0, 256, size=(((ld + 15) // 16) * 16 // 8) * n, dtype=np.uint8); in2_dt = DT.IMPLICIT
+    else:
+        X2 = rand_values(rng, ld * n, dt); in2_dt = dt
+    Y0 = rand_values(rng, ld * n, dt)
+    desc = pyoracle.MeltwDesc(m, n, ld, ld, ld, ld, dt, dt, in2_dt, DT.F32, dt, 0, typ, OP_TERNARY)
+    ref = Y0.copy()
+    p = capi.TernaryParam(); p.in0.primary, p.in1.primary, p.in2.primary, p.out.primary = X0.ctypes.data, X1.ctypes.data, X2.ctypes.data, ref.ctypes.data
+    orc.meltw(p, desc)
+    h = api.dispatch_meltw_ternary(typ, capi.TernaryShape(m, n, ld, ld, ld, ld, dt, dt, in2_dt if typ != TERNARY.SELECT else dt, dt, DT.F32), 0)
+    assert h
+    d0, d1, d2, dY = _dev(X0), _dev(X1), _dev(X2), _dev(Y0.copy())
+    p = capi.TernaryParam(); p.in0.primary, p.in1.primary, p.in2.primary, p.out.primary = d0.data_ptr(), d1.data_ptr(), d2.data_ptr(), dY.data_ptr()
+    capi.Api.call(h, p); api.hip_sync(); api.check()
+    assert np.array_equal(ref, _back(dY, Y0))
+
+
+def test_unsupported_tpps_return_null():
+    api = capi.load()
+    assert api.dispatch_meltw_unary(UNARY.DROPOUT, capi.UnaryShape(8, 8, 8, 8, DT.F32, DT.F32, DT.F32), 0) is None
+    assert api.dispatch_meltw_unary(UNARY.IDENTITY, capi.UnaryShape(8, 8, 8, 8, DT.I8, DT.F32, DT.F32), 0) is None
+    assert api.dispatch_meltw_binary(BINARY.MATMUL, capi.BinaryShape(8, 8, 8, 8, 8, DT.F32, DT.F32, DT.F32, DT.F32), 0) is None

@@ -1,0 +1,86 @@
+"""Pins the CPU restatement (oracle/oracle_*.c) against the REAL reference built from
+/root/reference (oracle/_ref/libxsmm_ref.so): bit-exact against the reference's C reference
+kernels (libxsmm_reference_gemm / libxsmm_reference_elementwise), and within the reference's own
+tolerances against its CPU JIT.  Skipped where the reference .so is not available; the committed
+fixtures in tests/golden/ (test_golden.py) cover that situation.
+"""
+import numpy as np
+import pytest
+
+from helpers import GemmCase, TOL_BF16, TOL_F32, normf_rel
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, GEMM_FLAG
+
+F = GEMM_FLAG
+GEMM_CASES = [
+    # m, n, k, a_type, c_type, flags, br_type, br_count, colbias, act, beta, ld pads
+    dict(m=23, n=23, k=23),                                                     # BASELINE config #1
+    dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=8),                 # config #2 shape
+    dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=3, beta=1),
+    dict(m=17, n=9, k=31, lda=20, ldb=33, ldc=19, beta=1),
+    dict(m=16, n=16, k=16, br_type=capi.BR_OFFSET, br_count=5),
+    dict(m=64, n=64, k=64, br_type=capi.BR_ADDRESS, br_count=4, beta=1),
+    dict(m=13, n=7, k=5, flags=F.TRANS_A),
+    dict(m=13, n=7, k=5, flags=F.TRANS_B, beta=1),
+    dict(m=10, n=12, k=14, flags=F.TRANS_A | F.TRANS_B),
+    dict(m=9, n=11, k=13, a_type=DT.F64, beta=1, br_type=capi.BR_STRIDE, br_count=2),
+    dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=4),
+    dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, beta=1),
+    dict(m=33, n=17, k=18, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, beta=1, ldc=40),
+    dict(m=12, n=10, k=9, a_type=DT.BF16, c_type=DT.BF16),                     # flat bf16 A
+    dict(m=12, n=10, k=8, a_type=DT.BF16, c_type=DT.F32, flags=F.TRANS_B),
+    dict(m=12, n=10, k=8, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A | F.TRANS_B | F.VNNI_B),
+    # fused ext ABI (config #5 epilogue): column bias, ReLU (+bitmask), sigmoid
+    dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=4, colbias=True, act=1),
+    dict(m=32, n=24, k=16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2, beta=1),
+    dict(m=20, n=12, k=16, colbias=True, act=2),
+    dict(m=20, n=12, k=16, colbias=False, act=3, beta=1),
+    dict(m=32, n=32, k=32, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, act=3),
+]
+
+
+@pytest.mark.parametrize("kw", GEMM_CASES, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_gemm_restatement_is_bit_identical_to_reference_c_kernel(kw, reference):
+    case = GemmCase(seed=555, **kw)
+    c_or, m_or = case.run_oracle()
+    c_rf, m_rf = case.run_reference(jit=False)
+    assert np.array_equal(case.valid_region(c_or), case.valid_region(c_rf))
+    if m_or is not None:
+        assert np.array_equal(case.valid_mask_bits(m_or), case.valid_mask_bits(m_rf))
+
+
+@pytest.mark.parametrize("kw", [c for c in GEMM_CASES if not (c.get("a_type") == DT.BF16 and not (c.get("flags", 0) & F.VNNI_A))][:16],
+                         ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_gemm_restatement_within_reference_tolerance_of_its_cpu_jit(kw, reference):
+    case = GemmCase(seed=7, **kw)
+    c_or, _ = case.run_oracle()
+    c_jit, _ = case.run_reference(jit=True)
+    if c_jit is None:
+        pytest.skip("reference JIT refused this descriptor on this host")
+    tol = TOL_BF16 if case.c_type == DT.BF16 else TOL_F32
+    assert normf_rel(case.valid_region(c_or), case.valid_region(c_jit), case.c_type) < tol
+
+
+def test_bf16_conversion_matches_reference(reference, oracle):
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.standard_normal(2000).astype(np.float32) * 10.0 ** rng.integers(-40, 38, 2000),
+                           np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-40, 3.4e38, 1.0 + 2 ** -8, 1.0 + 3 * 2 ** -9], dtype=np.float32)])
+    for v in vals.astype(np.float32):
+        assert oracle.lib.oracle_f32_to_bf16_rne(float(v)) == reference.lib.xref_convert_f32_to_bf16_rne(float(v))
+        assert oracle.lib.oracle_f32_to_bf16_trunc(float(v)) == reference.lib.xref_convert_f32_to_bf16_truncate(float(v))
+
+
+def test_struct_layouts_match_reference(reference):
+    import ctypes as C
+    ours = [C.sizeof(t) for t in capi.LAYOUT_PROBE]
+    assert ours == reference.struct_sizes(len(ours))
+
+
+def test_normf_rel_matches_reference_matdiff(reference, oracle):
+    rng = np.random.default_rng(2)
+    r = rng.standard_normal(37 * 11).astype(np.float32)
+    t = (r + 1e-3 * rng.standard_normal(r.size)).astype(np.float32)
+    a = oracle.lib.oracle_normf_rel(DT.F32, r.size, r.ctypes.data, t.ctypes.data)
+    b = reference.lib.xref_matdiff_normf_rel(DT.F32, 37, 11, r.ctypes.data, t.ctypes.data)
+    assert abs(a - b) <= 1e-12 * max(1.0, b)
+    assert abs(a - normf_rel(r, t, DT.F32)) <= 1e-12

@@ -1,0 +1,272 @@
+"""Pins the TPP and sparse parts of the CPU restatement against the REAL reference
+(oracle/_ref/libxsmm_ref.so; skipped when it is not available):
+  * oracle_meltw_{unary,binary,ternary}  ==  libxsmm_reference_elementwise     (bit for bit)
+  * oracle_packed_spgemm_*, oracle_fsspmdm  ~  the reference's own JIT kernels   (its drivers' bounds)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import normf_rel, rand_values
+from libxsmm_amd import capi
+from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, GEMM_FLAG, TERNARY, UNARY, UNARY_FLAG
+from oracle import pyoracle
+from sparse_helpers import csr_to_csc, make_bcsc, pack_vnni2, random_csr
+
+OP_UNARY, OP_BINARY, OP_TERNARY = 1, 2, 3
+NP = {DT.F32: np.float32, DT.F64: np.float64}
+
+
+def both_unary(reference, typ, m, n, ldi, ldo, in_dt, out_dt, flags=0, aux_in=None, aux_out_bytes=0, op_primary=None,
+               in_elems=None, out_elems=None, out_secondary_val=None, seed=0, inp=None):
+    orc = pyoracle.oracle()
+    rng = np.random.default_rng(seed)
+    X = inp if inp is not None else rand_values(rng, in_elems or ldi * n, in_dt)
+    Y0 = rand_values(rng, out_elems or ldo * n, out_dt)
+    comp = DT.F64 if in_dt == DT.F64 else DT.F32
+    outs, auxs = [], []
+    for who in ("oracle", "reference"):
+        y = Y0.copy()
+        aux = np.zeros(aux_out_bytes, dtype=np.uint8) if aux_out_bytes else None
+        p = capi.UnaryParam()
+        p.in_.primary, p.out.primary = X.ctypes.data, y.ctypes.data
+        keep = []
+        if aux_in is not None:
+            p.in_.secondary = aux_in.ctypes.data
+        if aux is not None:
+            p.out.secondary = aux.ctypes.data
+        if out_secondary_val is not None:
+            v = C.c_ulonglong(out_secondary_val); keep.append(v); p.out.secondary = C.addressof(v)
+        if op_primary is not None:
+            p.op.primary = C.addressof(op_primary)
+        if who == "oracle":
+            orc.meltw(p, pyoracle.MeltwDesc(m, n, ldi, ldo, 0, 0, in_dt, DT.UNSUPPORTED, DT.UNSUPPORTED, comp, out_dt, flags, typ, OP_UNARY))
+        else:
+            reference.lib.xref_reference_meltw_unary(C.byref(p), typ, capi.UnaryShape(m, n, ldi, ldo, in_dt, out_dt, comp), flags)
+        outs.append(y); auxs.append(aux)
+    return outs, auxs
+
+
+UNARY_OPS = [UNARY.IDENTITY, UNARY.XOR, UNARY.X2, UNARY.NEGATE, UNARY.INC, UNARY.RELU, UNARY.SQRT, UNARY.RECIPROCAL, UNARY.TANH, UNARY.SIGMOID,
+             UNARY.GELU, UNARY.EXP, UNARY.RECIPROCAL_SQRT, UNARY.TANH_INV, UNARY.SIGMOID_INV, UNARY.GELU_INV]
+
+
+@pytest.mark.parametrize("typ", UNARY_OPS)
+@pytest.mark.parametrize("in_dt,out_dt", [(DT.F32, DT.F32), (DT.BF16, DT.BF16), (DT.F32, DT.BF16), (DT.BF16, DT.F32)])
+def test_unary_math_bit_identical(reference, typ, in_dt, out_dt):
+    rng = np.random.default_rng(5)
+    inp = None
+    if typ in (UNARY.SQRT, UNARY.RECIPROCAL_SQRT, UNARY.RECIPROCAL):
+        v = (rng.random(40 * 7) + 0.25).astype(np.float32)
+        inp = v if in_dt == DT.F32 else (v.view(np.uint32) >> 16).astype(np.uint16)
+    (a, b), _ = both_unary(reference, typ, 33, 7, 40, 35, in_dt, out_dt, inp=inp)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("flag", [UNARY_FLAG.BCAST_ROW, UNARY_FLAG.BCAST_COL, UNARY_FLAG.BCAST_SCALAR])
+def test_unary_broadcast_bit_identical(reference, flag):
+    (a, b), _ = both_unary(reference, UNARY.IDENTITY, 37, 11, 40, 37, DT.F32, DT.BF16, flags=flag)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16])
+def test_relu_family_bit_identical(reference, dt):
+    m, n, ld = 70, 9, 72
+    mask_bytes = (((ld + 15) // 16) * 16 // 8) * n
+    (a, b), (ma, mb) = both_unary(reference, UNARY.RELU, m, n, ld, ld, dt, dt, flags=UNARY_FLAG.BITMASK_2BYTEMULT, aux_out_bytes=mask_bytes)
+    assert np.array_equal(a, b)
+    bits = lambda x: np.unpackbits(x.reshape(n, -1), axis=1, bitorder="little")[:, :m]
+    assert np.array_equal(bits(ma), bits(mb))
+    (a, b), _ = both_unary(reference, UNARY.RELU_INV, m, n, ld, ld, dt, dt, flags=UNARY_FLAG.BITMASK_2BYTEMULT, aux_in=ma)
+    assert np.array_equal(a, b)
+    alpha = C.c_float(0.3)
+    for typ in (UNARY.LEAKY_RELU, UNARY.ELU):
+        (a, b), _ = both_unary(reference, typ, m, n, ld, ld, dt, dt, op_primary=alpha)
+        assert np.array_equal(a, b)
+
+
+TRANSFORMS = [
+    (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F32, 37, 19, 40, 19), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.BF16, 64, 64, 64, 64),
+    (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F64, 5, 70, 8, 71), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.I8, 33, 34, 33, 34),
+    (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 32, 16, 32, 32), (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 13, 8, 16, 14),
+    (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.BF16, 16, 8, 16, 16), (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.I8, 20, 12, 24, 20),
+    (UNARY.TRANSFORM_VNNI2_TO_VNNI2T, DT.BF16, 16, 8, 8, 16), (UNARY.TRANSFORM_NORM_TO_VNNI2T, DT.BF16, 16, 6, 16, 6),
+    (UNARY.TRANSFORM_VNNI4_TO_VNNI4T, DT.I8, 16, 8, 8, 16), (UNARY.TRANSFORM_NORM_TO_VNNI4T, DT.BF16, 16, 6, 16, 6),
+    (UNARY.TRANSFORM_VNNI4_TO_NORM, DT.I8, 12, 8, 12, 12), (UNARY.TRANSFORM_VNNI4_TO_VNNI2, DT.I8, 12, 8, 12, 12),
+    (UNARY.TRANSFORM_PADN_MOD2, DT.BF16, 9, 5, 10, 12), (UNARY.TRANSFORM_PADM_MOD2, DT.BF16, 9, 6, 10, 12),
+    (UNARY.TRANSFORM_PADNM_MOD4, DT.I8, 9, 6, 10, 12),
+]
+
+
+@pytest.mark.parametrize("typ,dt,m,n,ldi,ldo", TRANSFORMS)
+def test_transforms_bit_identical(reference, typ, dt, m, n, ldi, ldo):
+    elems = 4 * max(ldi, ldo) * (max(m, n) + 8)
+    (a, b), _ = both_unary(reference, typ, m, n, ldi, ldo, dt, dt, in_elems=elems, out_elems=elems)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16, DT.I8])
+@pytest.mark.parametrize("mode", [UNARY_FLAG.GS_COLS, UNARY_FLAG.GS_ROWS, UNARY_FLAG.GS_OFFS])
+@pytest.mark.parametrize("idx8", [0, 1])
+def test_gather_bit_identical(reference, dt, mode, idx8):
+    m, n, big = 24, 10, 40
+    rng = np.random.default_rng(9)
+    idt = np.uint64 if idx8 else np.uint32
+    flags = mode | (UNARY_FLAG.IDX_SIZE_8BYTES if idx8 else UNARY_FLAG.IDX_SIZE_4BYTES)
+    cnt = {UNARY_FLAG.GS_COLS: n, UNARY_FLAG.GS_ROWS: m}.get(mode, m * n)
+    idx = rng.choice(big if mode != UNARY_FLAG.GS_OFFS else big * big, size=cnt, replace=False).astype(idt)
+    (a, b), _ = both_unary(reference, UNARY.GATHER, m, n, big, m, dt, dt, flags=flags, aux_in=idx, in_elems=big * big, out_elems=m * n)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("typ", [UNARY.REDUCE_X_OP_ADD, UNARY.REDUCE_X2_OP_ADD, UNARY.REDUCE_X_X2_OP_ADD, UNARY.REDUCE_X_OP_MAX, UNARY.REDUCE_X_OP_MIN, UNARY.REDUCE_X_OP_ABSMAX])
+@pytest.mark.parametrize("rows", [0, 1])
+@pytest.mark.parametrize("in_dt", [DT.F32, DT.BF16])
+def test_reductions_bit_identical(reference, typ, rows, in_dt):
+    m, n, ldi = 75, 33, 80
+    res = n if rows else m
+    flags = UNARY_FLAG.REDUCE_ROWS if rows else UNARY_FLAG.REDUCE_COLS
+    (a, b), _ = both_unary(reference, typ, m, n, ldi, res, in_dt, DT.F32, flags=flags, out_elems=2 * res)
+    used = 2 * res if typ == UNARY.REDUCE_X_X2_OP_ADD else res
+    assert np.array_equal(a[:used], b[:used])
+
+
+@pytest.mark.parametrize("typ", [BINARY.ADD, BINARY.MUL, BINARY.SUB, BINARY.DIV, BINARY.MULADD, BINARY.MAX, BINARY.MIN, BINARY.CMP_OP_GT, BINARY.CMP_OP_LE, BINARY.CMP_OP_EQ])
+@pytest.mark.parametrize("dts", [(DT.F32, DT.F32, DT.F32), (DT.BF16, DT.BF16, DT.BF16), (DT.BF16, DT.F32, DT.F32)])
+@pytest.mark.parametrize("flags", [0, BINARY_FLAG.BCAST_COL_IN_0, BINARY_FLAG.BCAST_ROW_IN_1 | BINARY_FLAG.BCAST_SCALAR_IN_0])
+def test_binary_bit_identical(reference, typ, dts, flags):
+    orc = pyoracle.oracle()
+    m, n, ld = 45, 13, 48
+    rng = np.random.default_rng(3)
+    X0, X1 = rand_values(rng, ld * n, dts[0]), rand_values(rng, ld * n, dts[1])
+    cmp_ = typ >= BINARY.CMP_OP_GT
+    Y0 = np.zeros((((ld + 15) // 16) * 16 // 8) * n, dtype=np.uint8) if cmp_ else rand_values(rng, ld * n, dts[2])
+    outs = []
+    for who in ("oracle", "reference"):
+        y = Y0.copy()
+        p = capi.BinaryParam(); p.in0.primary, p.in1.primary, p.out.primary = X0.ctypes.data, X1.ctypes.data, y.ctypes.data
+        if who == "oracle":
+            orc.meltw(p, pyoracle.MeltwDesc(m, n, ld, ld, ld, 0, dts[0], dts[1], DT.UNSUPPORTED, DT.F32, dts[2], flags, typ, OP_BINARY))
+        else:
+            reference.lib.xref_reference_meltw_binary(C.byref(p), typ, capi.BinaryShape(m, n, ld, ld, ld, dts[0], dts[1], dts[2], DT.F32), flags)
+        outs.append(y)
+    if cmp_:
+        bits = lambda x: np.unpackbits(x.reshape(n, -1), axis=1, bitorder="little")[:, :m]
+        assert np.array_equal(bits(outs[0]), bits(outs[1]))
+    else:
+        assert outs[0].tobytes() == outs[1].tobytes()     # raw bytes: 0/0 -> NaN must match too
+
+
+@pytest.mark.parametrize("typ", [TERNARY.SELECT, TERNARY.MULADD, TERNARY.NMULADD])
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16])
+def test_ternary_bit_identical(reference, typ, dt):
+    orc = pyoracle.oracle()
+    m, n, ld = 40, 9, 48
+    rng = np.random.default_rng(6)
+    X0, X1 = rand_values(rng, ld * n, dt), rand_values(rng, ld * n, dt)
+    X2 = rng.integers(0, 256, size=(((ld + 15) // 16) * 16 // 8) * n, dtype=np.uint8) if typ == TERNARY.SELECT else rand_values(rng, ld * n, dt)
+    Y0 = rand_values(rng, ld * n, dt)
+    outs = []
+    for who in ("oracle", "reference"):
+        y = Y0.copy()
+        p = capi.TernaryParam(); p.in0.primary, p.in1.primary, p.in2.primary, p.out.primary = X0.ctypes.data, X1.ctypes.data, X2.ctypes.data, y.ctypes.data
+        if who == "oracle":
+            orc.meltw(p, pyoracle.MeltwDesc(m, n, ld, ld, ld, ld, dt, dt, dt, DT.F32, dt, 0, typ, OP_TERNARY))
+        else:
+            reference.lib.xref_reference_meltw_ternary(C.byref(p), typ, capi.TernaryShape(m, n, ld, ld, ld, ld, dt, dt, dt, dt, DT.F32), 0)
+        outs.append(y)
+    assert np.array_equal(outs[0], outs[1])
+
+
+# ---- sparse: restated gold loops vs the reference's own JIT kernels -------------------------------------
+@pytest.mark.parametrize("dt", [DT.F32, DT.F64])
+@pytest.mark.parametrize("M,N,K,P,density,beta0", [(35, 16, 35, 16, 0.09, 0), (9, 10, 9, 8, 0.4, 0), (20, 3, 50, 16, 0.1, 0)])
+def test_packed_csr_asparse_vs_reference_jit(reference, dt, M, N, K, P, density, beta0):
+    orc = pyoracle.oracle()
+    rng = np.random.default_rng(42)
+    rowptr, colidx = random_csr(rng, M, K, density)
+    vals = rand_values(rng, len(colidx), dt) + NP[dt](0.05)
+    B, C0 = rand_values(rng, K * N * P, dt), rand_values(rng, M * N * P, dt)
+    ref_c, jit_c = C0.copy(), C0.copy()
+    orc.lib.oracle_packed_spgemm_csr_asparse(dt, M, N, K, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, B.ctypes.data, N, ref_c.ctypes.data, N, beta0)
+    h = reference.create_packed_spgemm_csr(capi.gemm_shape(M, N, K, 0, N, N, dt, dt, dt, dt), GEMM_FLAG.BETA_0 if beta0 else 0, 0, P,
+                                           rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data)
+    if not h:
+        pytest.skip("reference JIT refused")
+    p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = vals.ctypes.data, B.ctypes.data, jit_c.ctypes.data
+    capi.Api.call(h, p)
+    assert normf_rel(ref_c, jit_c, dt) <= (1e-5 if dt == DT.F32 else 1e-12)
+    reference.release_kernel(h)
+
+
+@pytest.mark.parametrize("dt", [DT.F32, DT.F64])
+def test_packed_csc_bsparse_vs_reference_jit(reference, dt):
+    orc = pyoracle.oracle()
+    M, N, K, P = 9, 20, 35, 16
+    rng = np.random.default_rng(7)
+    rowptr, colidx = random_csr(rng, K, N, 0.2)
+    vals = rand_values(rng, len(colidx), dt) + NP[dt](0.05)
+    colptr, rowidx, cvals = csr_to_csc(rowptr, colidx, vals, K, N)
+    A, C0 = rand_values(rng, M * K * P, dt), rand_values(rng, M * N * P, dt)
+    ref_c, ref2_c, jit_c = C0.copy(), C0.copy(), C0.copy()
+    orc.lib.oracle_packed_spgemm_csc_bsparse(dt, M, N, K, P, colptr.ctypes.data, rowidx.ctypes.data, cvals.ctypes.data, A.ctypes.data, K, ref_c.ctypes.data, N, 0)
+    orc.lib.oracle_packed_spgemm_csr_bsparse(dt, M, N, K, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, A.ctypes.data, K, ref2_c.ctypes.data, N, 0)
+    assert np.array_equal(ref_c, ref2_c)          # the CSR and CSC restatements agree bit for bit
+    h = reference.create_packed_spgemm_csc(capi.gemm_shape(M, N, K, K, 0, N, dt, dt, dt, dt), 0, 0, P, colptr.ctypes.data, rowidx.ctypes.data, cvals.ctypes.data)
+    if not h:
+        pytest.skip("reference JIT refused")
+    p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = A.ctypes.data, cvals.ctypes.data, jit_c.ctypes.data
+    capi.Api.call(h, p)
+    assert normf_rel(ref_c, jit_c, dt) <= (1e-5 if dt == DT.F32 else 1e-12)
+    reference.release_kernel(h)
+
+
+@pytest.mark.parametrize("dt", [DT.F32, DT.F64])
+@pytest.mark.parametrize("beta", [0.0, 1.0])
+def test_fsspmdm_vs_reference(reference, dt, beta):
+    orc = pyoracle.oracle()
+    M, N, K = 35, 96, 35
+    rng = np.random.default_rng(3)
+    rowptr, colidx = random_csr(rng, M, K, 0.15)
+    vals = rand_values(rng, len(colidx), dt) + NP[dt](0.05)
+    a_dense = np.zeros((M, K), dtype=NP[dt])
+    for i in range(M):
+        a_dense[i, colidx[rowptr[i]:rowptr[i + 1]]] = vals[rowptr[i]:rowptr[i + 1]]
+    B, C0 = rand_values(rng, K * N, dt), rand_values(rng, M * N, dt)
+    ref_c, lib_c = C0.copy(), C0.copy()
+    alpha = NP[dt](1.5)
+    sv = (alpha * vals).astype(NP[dt])
+    orc.lib.oracle_fsspmdm(dt, M, N, K, rowptr.ctypes.data, colidx.ctypes.data, sv.ctypes.data, B.ctypes.data, N, ref_c.ctypes.data, N, int(beta == 0.0))
+    ct = C.c_double if dt == DT.F64 else C.c_float
+    cal, cbe = ct(float(alpha)), ct(beta)
+    h = reference.fsspmdm_create(dt, M, N, K, K, N, N, C.addressof(cal), C.addressof(cbe), a_dense.ctypes.data, 0, None)
+    assert h
+    reference.fsspmdm_execute(h, B.ctypes.data, lib_c.ctypes.data)
+    assert normf_rel(ref_c, lib_c, dt) <= (1e-5 if dt == DT.F32 else 1e-12)
+    reference.fsspmdm_destroy(h)
+
+
+@pytest.mark.parametrize("a_type,c_type,vnni,bk,bn", [(DT.F32, DT.F32, 0, 8, 8), (DT.BF16, DT.BF16, 1, 32, 32), (DT.BF16, DT.F32, 1, 32, 16)])
+@pytest.mark.parametrize("beta0", [0, 1])
+def test_bcsc_vs_reference_jit(reference, a_type, c_type, vnni, bk, bn, beta0):
+    orc = pyoracle.oracle()
+    M, N, K, mb = 64, 64, 256, 4
+    rng = np.random.default_rng(11)
+    colptr, rowidx, bvals = make_bcsc(rng, K, N, bk, bn, 0.25, a_type)
+    A = rand_values(rng, mb * K * M, a_type)
+    A_run = pack_vnni2(A, mb, K, M) if vnni else A
+    C0 = rand_values(rng, mb * N * M, c_type)
+    ref_c, jit_c = C0.copy(), C0.copy()
+    orc.lib.oracle_packed_spgemm_bcsc(a_type, c_type, M, N, K, mb, bk, bn, vnni, A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref_c.ctypes.data, beta0)
+    flags = (GEMM_FLAG.BETA_0 if beta0 else 0) | (GEMM_FLAG.VNNI_A if vnni else 0)
+    h = reference.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, a_type, a_type, c_type, DT.F32), flags, 0, capi.SpgemmConfig(M, bk, bn))
+    if not h:
+        pytest.skip("reference JIT refused this BCSC configuration on this host")
+    nblk = C.c_ulonglong(N // bn)
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = \
+        A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, C.addressof(nblk), jit_c.ctypes.data
+    capi.Api.call(h, p)
+    assert normf_rel(ref_c, jit_c, c_type) <= (5e-3 if c_type == DT.BF16 else 1e-4)
+    reference.release_kernel(h)
