@@ -31,6 +31,13 @@
 
 namespace xamd {
 
+// Pointers that arrive inside the by-value argument block are "generic" to the compiler and would be
+// accessed with flat_load/flat_store (slower, and they tie the LDS and VMEM wait counters together).
+// Everything the kernels dereference is global memory: say so explicitly.
+#define GM __attribute__((address_space(1)))
+typedef GM const char* gcptr;
+typedef GM char* gptr;
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -48,25 +55,41 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
   else u += 0x00007fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+// sigmoid(x) = (tanh(x/2) + 1) / 2 [ref: mateltwise ref :18-20], evaluated as 1 / (1 + e^-x) with the hardware
+// exp/rcp: ~1e-6 relative, inside the reference's own 7e-4 bound for fused sigmoid (gemm_kernel.c:5396) and a
+// small fraction of the code of an inlined tanhf (the epilogue is instantiated 16x per tile).
 __device__ __forceinline__ float act_apply(int act, float x) {
   if (act == 1 || act == 2) return (x <= 0.0f) ? 0.0f : x;
-  if (act == 3) return (tanhf(x * 0.5f) + 1.0f) * 0.5f;   // [ref: mateltwise ref :18-20]
+  if (act == 3) return __frcp_rn(1.0f + __expf(-x));
   return x;
 }
 
-struct BatchPtrs { const char* a; const char* b; char* c; const char* d; unsigned char* mask; };
+struct BatchPtrs { gcptr a; gcptr b; gptr c; gcptr d; GM unsigned char* mask; };
+// A value every lane of the wave agrees on, made provably uniform (SGPR pair) for the compiler: anything
+// loaded through a vector-memory load is "divergent" to it and would drag all address math into VGPRs.
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ gcptr list_entry(const void* list, unsigned long long i) {
+  return (gcptr)(size_t)uniform_u64(((GM const unsigned long long*)list)[i]);
+}
 __device__ __forceinline__ BatchPtrs batch_ptrs(const GemmArgs& p, unsigned int bidx) {
   BatchPtrs q;
-  if (p.list_a) { q.a = (const char*)p.list_a[bidx]; q.b = (const char*)p.list_b[bidx]; q.c = (char*)p.list_c[bidx]; }
-  else { q.a = p.a + (long long)bidx * p.bs_a; q.b = p.b + (long long)bidx * p.bs_b; q.c = p.c + (long long)bidx * p.bs_c; }
-  q.d = p.d ? p.d + (long long)bidx * p.bs_d : nullptr;
-  q.mask = p.relu_mask ? p.relu_mask + (long long)bidx * p.bs_mask : nullptr;
+  if (p.list_a) { q.a = list_entry(p.list_a, bidx); q.b = list_entry(p.list_b, bidx); q.c = (gptr)list_entry(p.list_c, bidx); }
+  else { q.a = (gcptr)p.a + (long long)bidx * p.bs_a; q.b = (gcptr)p.b + (long long)bidx * p.bs_b; q.c = (gptr)p.c + (long long)bidx * p.bs_c; }
+  q.d = p.d ? (gcptr)p.d + (long long)bidx * p.bs_d : nullptr;
+  q.mask = p.relu_mask ? (GM unsigned char*)p.relu_mask + (long long)bidx * p.bs_mask : nullptr;
   return q;
 }
 // base of batch-reduce element r [ref: gemm ref :180-197]
-__device__ __forceinline__ void br_base(const GemmArgs& p, const BatchPtrs& q, unsigned long long r, const char*& a, const char*& b) {
-  if (p.br_mode == 1) { a = (const char*)((const void* const*)q.a)[r]; b = (const char*)((const void* const*)q.b)[r]; }
-  else if (p.br_mode == 2) { a = q.a + p.offs_a[r]; b = q.b + p.offs_b[r]; }
+__device__ __forceinline__ void br_base(const GemmArgs& p, const BatchPtrs& q, unsigned long long r, gcptr& a, gcptr& b) {
+  if (p.br_mode == 1) { a = list_entry((const void*)(size_t)q.a, r); b = list_entry((const void*)(size_t)q.b, r); }
+  else if (p.br_mode == 2) {
+    a = q.a + (long long)uniform_u64((unsigned long long)((GM const long long*)p.offs_a)[r]);
+    b = q.b + (long long)uniform_u64((unsigned long long)((GM const long long*)p.offs_b)[r]);
+  }
   else if (p.br_mode == 3) { a = q.a + p.br_stride_a * (long long)r; b = q.b + p.br_stride_b * (long long)r; }
   else { a = q.a; b = q.b; }
 }
@@ -80,8 +103,8 @@ __device__ __forceinline__ void br_base(const GemmArgs& p, const BatchPtrs& q, u
 template <typename T> __device__ __forceinline__ T mul_rn(T a, T b) { return a * b; }
 template <typename T> __device__ __forceinline__ T add_rn(T a, T b) { return a + b; }
 
-__device__ __forceinline__ float load_as_f32(const char* base, long long idx, int type) {
-  return (type == LIBXSMM_DATATYPE_F32) ? ((const float*)base)[idx] : bf16_to_f32(((const unsigned short*)base)[idx]);
+__device__ __forceinline__ float load_as_f32(gcptr base, long long idx, int type) {
+  return (type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)base)[idx] : bf16_to_f32(((GM const unsigned short*)base)[idx]);
 }
 
 // block = (64, 4): x walks i (so a wave is 64 consecutive rows of one column, which makes the
@@ -102,11 +125,11 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
 
   if (p.a_type == LIBXSMM_DATATYPE_F64) {
     if (!valid) return;
-    double* c = (double*)q.c + (long long)j * p.ldc + i;
+    GM double* c = (GM double*)q.c + (long long)j * p.ldc + i;
     double acc = beta0 ? 0.0 : *c;
     for (unsigned long long r = 0; r < p.br_count; ++r) {
-      const char *ar, *br; br_base(p, q, r, ar, br);
-      const double* a = (const double*)ar; const double* b = (const double*)br;
+      gcptr ar, br; br_base(p, q, r, ar, br);
+      GM const double* a = (GM const double*)ar; GM const double* b = (GM const double*)br;
       for (int s = 0; s < p.k; ++s) {
         const double av = ta ? a[(long long)i * p.lda + s] : a[(long long)s * p.lda + i];
         const double bv = tb ? b[(long long)s * p.ldb + j] : b[(long long)j * p.ldb + s];
@@ -126,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
       acc = beta0 ? bias : add_rn(bias, acc);
     }
     for (unsigned long long r = 0; r < p.br_count; ++r) {
-      const char *ar, *br; br_base(p, q, r, ar, br);
+      gcptr ar, br; br_base(p, q, r, ar, br);
       for (int s = 0; s < p.k / kb; ++s) {
         for (int k2 = kb - 1; k2 >= 0; --k2) {          // VNNI pair: high k first [ref: gemm ref :2144]
           const int kk = s * kb + k2;
@@ -146,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     const int lane = threadIdx.x;   // blockDim.x == 64: lane within the wave
     if ((lane & 7) == 0 && valid) {
       const long long mask_ld = ((p.ldc + 15) / 16) * 16;
-      unsigned char* byte = q.mask + i / 8 + (long long)j * (mask_ld / 8);
+      GM unsigned char* byte = q.mask + i / 8 + (long long)j * (mask_ld / 8);
       const unsigned char vm = (unsigned char)((vmask >> lane) & 0xffu);
       const unsigned char nb = (unsigned char)((ballot >> lane) & 0xffu);
       *byte = (unsigned char)((*byte & ~vm) | (nb & vm));
@@ -155,13 +178,13 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
   if (!valid) return;
   if (p.vnni_c && p.c_type == LIBXSMM_DATATYPE_BF16) {
     // NORM -> VNNI2 of the result [ref: gemm ref :2802-2815]; the pad column of an odd n is zero-filled
-    unsigned short* c = (unsigned short*)q.c;
+    GM unsigned short* c = (GM unsigned short*)q.c;
     c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + (j % 2)] = f32_to_bf16_rne(y);
     if ((p.n & 1) && j == p.n - 1) c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + 1] = 0;
   } else if (p.c_type == LIBXSMM_DATATYPE_F32) {
-    ((float*)q.c)[(long long)j * p.ldc + i] = y;
+    ((GM float*)q.c)[(long long)j * p.ldc + i] = y;
   } else {
-    ((unsigned short*)q.c)[(long long)j * p.ldc + i] = f32_to_bf16_rne(y);
+    ((GM unsigned short*)q.c)[(long long)j * p.ldc + i] = f32_to_bf16_rne(y);
   }
 }
 
@@ -172,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
 // operand layout of v_mfma_f32_32x32x2_f32 in natural k order.
 // ------------------------------------------------------------------------------------------------
 template <bool EXACT>
-__device__ __forceinline__ void load_x_f32(float (&w)[16], const float* base, long long ld, int f, bool fvalid, int k0, int K, int h) {
+__device__ __forceinline__ void load_x_f32(float (&w)[16], GM const float* base, long long ld, int f, bool fvalid, int k0, int K, int h) {
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const int k = k0 + 2 * s + h;
@@ -180,15 +203,15 @@ __device__ __forceinline__ void load_x_f32(float (&w)[16], const float* base, lo
   }
 }
 template <bool EXACT>
-__device__ __forceinline__ void load_y_f32(float (&w)[16], const float* base, long long ld, int f, bool fvalid, int k0, int K, int h) {
-  const float* col = base + (long long)f * ld + k0 + 16 * h;   // this lane's 16 consecutive k
+__device__ __forceinline__ void load_y_f32(float (&w)[16], GM const float* base, long long ld, int f, bool fvalid, int k0, int K, int h) {
+  GM const float* col = base + (long long)f * ld + k0 + 16 * h;   // this lane's 16 consecutive k
   float v[16];
   // wave-uniform alignment test: 16-byte loads need ld % 4 == 0 and a 16-byte aligned base
   const bool vec = ((((unsigned long long)(size_t)base) & 15ull) == 0ull) && ((ld & 3) == 0) && ((k0 & 3) == 0);
   if (EXACT && vec) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 t = *(const f32x4*)(col + 4 * q);
+      const f32x4 t = *(GM const f32x4*)(col + 4 * q);
       v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
     }
   } else {
@@ -205,88 +228,165 @@ __device__ __forceinline__ void load_y_f32(float (&w)[16], const float* base, lo
   }
 }
 
+// Coalesced variant for exact tiles (measured with tools/gemm_probe.hip: +15% at batch 4096, equal to a
+// plain copy kernel at large batches): a 32x32 f32 operand tile is fetched with four fully coalesced
+// 16-byte-per-lane loads (whole 128-byte rows), parked in a wave-private 4 KiB LDS image and read back in
+// MFMA fragment order.  No barrier: the image is written and read by the same wave.
+//   KCONTIG == false (free index contiguous): image [k][f] linear, fragment = 16 conflict-free ds_read_b32.
+//   KCONTIG == true  (k contiguous): image [f][8 chunks of 4 k], chunk index XOR-swizzled with (f>>1)&7 so that
+//   the per-column ds_read_b128 is conflict free; v_permlane32_swap then interleaves the two k halves.
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_gload(f32x4 (&g)[4], GM const float* base, long long ld, int f0, int k0, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = lane + 64 * q, hi = t >> 3, lo = (t & 7) * 4;
+    GM const float* src = KCONTIG ? base + (long long)(f0 + hi) * ld + k0 + lo : base + (long long)(k0 + hi) * ld + f0 + lo;
+    g[q] = *(GM const f32x4*)src;
+  }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_to_frag(float (&w)[16], const f32x4 (&g)[4], float* lds, int lane) {
+  const int li = lane & 31, h = lane >> 5;
+  if (!KCONTIG) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ((f32x4*)lds)[lane + 64 * q] = g[q];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w[s] = lds[(2 * s + h) * 32 + li];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = lane + 64 * q, f = t >> 3, c = (t & 7) ^ ((f >> 1) & 7);
+      ((f32x4*)lds)[f * 8 + c] = g[q];
+    }
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 x = ((const f32x4*)lds)[li * 8 + ((4 * h + q) ^ ((li >> 1) & 7))];
+      v[4 * q + 0] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * s]), __float_as_uint(v[2 * s + 1]), false, false);
+      w[s] = __uint_as_float(r[0]); w[s + 8] = __uint_as_float(r[1]);
+    }
+  }
+}
+__device__ __forceinline__ bool aligned16(const void* p, long long ld_elems) {
+  return ((((unsigned long long)(size_t)p) & 15ull) == 0ull) && ((ld_elems & 3) == 0);
+}
+
 // Epilogue shared by all MFMA kernels.  `acc` is in transposed-product layout: lane&31 = i (row of
 // C), register r of half h = column j_local(r,h) = (r&3) + 8*(r>>2) + 4*h.
 struct TileCtx { int i; int j0; int h; bool ivalid; };
 __device__ __forceinline__ int jl_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <bool EXACT>
+// CF32: the C (and bias) datatype is known to be f32 at compile time (f32 kernels) -- drops the bf16 paths
+template <bool EXACT, bool CF32>
 __device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
   const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  const int c_type = CF32 ? (int)LIBXSMM_DATATYPE_F32 : p.c_type;
+  if (beta0 && !p.colbias) {          // the streaming case: nothing to read
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    return;
+  }
   float bias = 0.0f;
-  if (p.colbias && (EXACT || t.ivalid)) bias = load_as_f32(q.d, t.i, p.c_type);
+  if (p.colbias && (EXACT || t.ivalid)) bias = load_as_f32(q.d, t.i, c_type);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int j = t.j0 + jl_of(r, t.h);
     float start = 0.0f;
-    if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_as_f32(q.c, (long long)j * p.ldc + t.i, p.c_type);
+    if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_as_f32(q.c, (long long)j * p.ldc + t.i, c_type);
     acc[r] = p.colbias ? (beta0 ? bias : bias + start) : start;
   }
 }
 
-template <bool EXACT>
-__device__ __forceinline__ void tile_store(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
+// One output element group: registers (r-1, r) of a bf16 tile are written as packed dwords (neighbouring
+// lanes (i, i+1) exchange one value so that every lane stores a full dword), everything else element-wise.
+template <bool EXACT, bool CF32, bool ACT>
+__device__ __forceinline__ void tile_store_impl(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
   const int lane = threadIdx.x & 63;
   const long long mask_ld = ((p.ldc + 15) / 16) * 16;
-  const bool out_f32 = (p.c_type == LIBXSMM_DATATYPE_F32);
-  // bf16 fast path: neighbouring lanes (i, i+1) pair up so every lane writes one full dword per
-  // two registers instead of one short per register (needs even ldc and a 4-byte aligned C).
+  const bool out_f32 = CF32 || (p.c_type == LIBXSMM_DATATYPE_F32);
+  const int act = ACT ? p.act : 0;
+  // bf16 fast path needs an even ldc and a 4-byte aligned C
   const bool pack2 = EXACT && !out_f32 && ((p.ldc & 1) == 0) && ((((unsigned long long)(size_t)q.c) & 3ull) == 0ull);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int j = t.j0 + jl_of(r, t.h);
     const bool ok = EXACT || (t.ivalid && j < p.n);
     const float x = acc[r];
-    const float y = act_apply(p.act, x);
-    if (p.act == 2 && q.mask) {
+    const float y = ACT ? act_apply(act, x) : x;
+    if (ACT && act == 2 && q.mask) {
       const unsigned long long pos = __ballot(ok && !(x <= 0.0f));
       const unsigned long long val = __ballot(ok);
       if ((lane & 7) == 0 && ok) {
-        unsigned char* byte = q.mask + t.i / 8 + (long long)j * (mask_ld / 8);
+        GM unsigned char* byte = q.mask + t.i / 8 + (long long)j * (mask_ld / 8);
         const unsigned char vm = (unsigned char)((val >> lane) & 0xffu), nb = (unsigned char)((pos >> lane) & 0xffu);
         *byte = EXACT ? nb : (unsigned char)((*byte & ~vm) | (nb & vm));
       }
     }
     if (out_f32) {
-      if (ok) ((float*)q.c)[(long long)j * p.ldc + t.i] = y;
+      if (ok) ((GM float*)q.c)[(long long)j * p.ldc + t.i] = y;
     } else if (!pack2) {
-      if (ok) ((unsigned short*)q.c)[(long long)j * p.ldc + t.i] = f32_to_bf16_rne(y);
+      if (ok) ((GM unsigned short*)q.c)[(long long)j * p.ldc + t.i] = f32_to_bf16_rne(y);
     } else if ((r & 1) == 1) {
-      // registers (r-1, r): even lanes keep column j(r-1), odd lanes keep column j(r)
-      const float y0 = act_apply(p.act, acc[r - 1]);
+      const float y0 = ACT ? act_apply(act, acc[r - 1]) : acc[r - 1];
       const bool odd = (lane & 1) != 0;
       const unsigned int mine0 = f32_to_bf16_rne(y0), mine1 = f32_to_bf16_rne(y);
       const unsigned int send = odd ? mine0 : mine1;
       const unsigned int recv = (unsigned int)__shfl_xor((int)send, 1);
       const unsigned int word = odd ? ((recv & 0xffffu) | (mine1 << 16)) : ((mine0 & 0xffffu) | (recv << 16));
       const int jj = odd ? j : (t.j0 + jl_of(r - 1, t.h));
-      *(unsigned int*)((unsigned short*)q.c + (long long)jj * p.ldc + (t.i & ~1)) = word;
+      *(GM unsigned int*)((GM unsigned short*)q.c + (long long)jj * p.ldc + (t.i & ~1)) = word;
     }
   }
+}
+// The plain store (no activation) is the streaming hot path and is kept free of the activation / bitmask
+// code: a wave-uniform branch picks the compact variant.
+template <bool EXACT, bool CF32>
+__device__ __forceinline__ void tile_store(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
+  if (p.act == 0) tile_store_impl<EXACT, CF32, false>(acc, p, q, t);
+  else tile_store_impl<EXACT, CF32, true>(acc, p, q, t);
 }
 
 // wave -> (batch element, tile) decomposition shared by the MFMA kernels
 struct WaveJob { unsigned int bidx; int i0, j0; bool active; };
 __device__ __forceinline__ WaveJob wave_job(const GemmArgs& p, int tile_m, int tile_n) {
-  const int tiles_m = (p.m + tile_m - 1) / tile_m, tiles_n = (p.n + tile_n - 1) / tile_n;
-  const long long per_gemm = (long long)tiles_m * tiles_n;
-  const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // The wave index is uniform but not provably so to the compiler: readfirstlane moves the whole tile/batch
+  // address computation to the scalar unit.  Index math is 32-bit and division-free in the common case of
+  // one tile per problem (launch_gemm guarantees tiles * nbatch < 2^31).
+  const unsigned int wid = blockIdx.x * (blockDim.x >> 6) + (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int per_gemm = (unsigned int)(p.tiles_m * p.tiles_n);
   WaveJob w;
-  w.active = wid < per_gemm * (long long)p.nbatch;
-  w.bidx = (unsigned int)(wid / per_gemm);
-  const int t = (int)(wid % per_gemm);
-  w.i0 = (t % tiles_m) * tile_m; w.j0 = (t / tiles_m) * tile_n;
+  w.active = wid < per_gemm * p.nbatch;
+  if (per_gemm == 1) { w.bidx = wid; w.i0 = 0; w.j0 = 0; }
+  else {
+    w.bidx = wid / per_gemm;
+    const unsigned int t = wid - w.bidx * per_gemm;
+    const unsigned int tn = t / (unsigned int)p.tiles_m;
+    w.i0 = (int)(t - tn * (unsigned int)p.tiles_m) * tile_m; w.j0 = (int)tn * tile_n;
+  }
   return w;
 }
 
 // ------------------------------------------------------------------------------------------------
 // f32, 32x32 MFMA tiles, MT x NT tiles per wave
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, bool TA, bool TB, bool EXACT>
+// MODE 0: arbitrary m/n/k (masked loads/stores); 1: exact tiles, operands fetched straight into fragment
+// layout (any alignment); 2: exact tiles with 16-byte aligned operands, staged through LDS (fastest).
+enum { GM_MASKED = 0, GM_EXACT = 1, GM_STAGED = 2 };
+template <int MT, int NT, bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs p) {
+  constexpr bool EXACT = MODE != GM_MASKED;
+  constexpr bool STAGED = MODE == GM_STAGED;
+  // wave-private staging images for the coalesced path: (MT + NT) tiles of 4 KiB per wave
+  constexpr int kLdsFloats = STAGED ? (MT + NT) * 1024 : 4;
+  __shared__ __attribute__((aligned(16))) float lds_all[4][kLdsFloats];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  float* lds = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
   const BatchPtrs q = batch_ptrs(p, job.bidx);
   f32x16 acc[MT][NT];
   TileCtx tc[MT][NT];
@@ -296,15 +396,27 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs p) {
     for (int nt = 0; nt < NT; ++nt) {
       tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h;
       tc[mt][nt].ivalid = tc[mt][nt].i < p.m;
-      tile_init<EXACT>(acc[mt][nt], p, q, tc[mt][nt]);
+      tile_init<EXACT, true>(acc[mt][nt], p, q, tc[mt][nt]);
     }
   const int kchunks = (p.k + 31) / 32;
   for (unsigned long long r = 0; r < p.br_count; ++r) {
-    const char *ar, *br; br_base(p, q, r, ar, br);
-    const float* A = (const float*)ar; const float* B = (const float*)br;
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    GM const float* A = (GM const float*)ar; GM const float* B = (GM const float*)br;
     for (int kc = 0; kc < kchunks; ++kc) {
       const int k0 = kc * 32;
       float af[MT][16], bf[NT][16];
+      if constexpr (STAGED) {
+        // all global loads of the chunk are issued before the first LDS access
+        f32x4 ga[MT][4], gb[NT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) tile_gload<TA>(ga[mt], A, p.lda, job.i0 + 32 * mt, k0, lane);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) tile_gload<!TB>(gb[nt], B, p.ldb, job.j0 + 32 * nt, k0, lane);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) tile_to_frag<TA>(af[mt], ga[mt], lds + 1024 * mt, lane);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) tile_to_frag<!TB>(bf[nt], gb[nt], lds + 1024 * (MT + nt), lane);
+      } else {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int i = job.i0 + 32 * mt + li;
@@ -316,6 +428,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs p) {
         const int j = job.j0 + 32 * nt + li;
         if (TB) load_x_f32<EXACT>(bf[nt], B, p.ldb, j, j < p.n, k0, p.k, h);
         else load_y_f32<EXACT>(bf[nt], B, p.ldb, j, j < p.n, k0, p.k, h);
+      }
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s)
@@ -329,7 +442,94 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) tile_store<EXACT>(acc[mt][nt], p, q, tc[mt][nt]);
+    for (int nt = 0; nt < NT; ++nt) tile_store<EXACT, true>(acc[mt][nt], p, q, tc[mt][nt]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 streaming kernel: the hot path for exact 32x32 tiles with 16-byte aligned operands (the batched
+// small-GEMM case).  Same algorithm as gemm_mfma_f32_kernel<1,1,.,.,GM_STAGED>, written for minimum
+// instruction count because one launch is a single round of waves that all run their prologue and
+// epilogue at the same time (issue-bound, not latency-bound: 4 waves per SIMD x instructions per wave):
+//   * all tile bases are wave-uniform SGPR pointers, lanes only carry a 32-bit byte offset
+//     (global_load/store saddr + voffset form, no 64-bit VALU address math),
+//   * one flattened loop over (batch-reduce element, 32-deep K chunk),
+//   * the epilogue variants (beta / bias / activation / bitmask) sit behind wave-uniform branches.
+// Measured with tools/gemm_probe.hip; PMC: 86 VALU + 5 SALU instructions per wave for the probe kernel.
+// ------------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_stream_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds_all[4][2048];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = blockIdx.x * 4u + wave;
+  const unsigned int per_gemm = (unsigned int)(p.tiles_m * p.tiles_n);
+  if (wid >= per_gemm * p.nbatch) return;
+  unsigned int bidx = wid, i0 = 0, j0 = 0;
+  if (per_gemm != 1) {
+    bidx = wid / per_gemm;
+    const unsigned int t = wid - bidx * per_gemm, tn = t / (unsigned int)p.tiles_m;
+    i0 = (t - tn * (unsigned int)p.tiles_m) * 32u; j0 = tn * 32u;
+  }
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  float* lds = lds_all[wave];
+  const BatchPtrs q = batch_ptrs(p, bidx);
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb, ldc = (unsigned int)p.ldc;
+  // per-lane byte offsets inside a 32x32 operand tile for the four 16-byte loads (rows 8q + lane/8)
+  const unsigned int offA = ((lane >> 3) * lda + (lane & 7u) * 4u) * 4u;
+  const unsigned int offB = ((lane >> 3) * ldb + (lane & 7u) * 4u) * 4u;
+  const unsigned long long stepA = 32ull * lda, stepB = 32ull * ldb;          // bytes per 8 rows
+  // origin of this wave's operand tiles inside A_r / B_r (bytes), per K chunk add kstepX
+  const unsigned long long orgA = TA ? 4ull * i0 * lda : 4ull * i0, kstepA = TA ? 128ull : 128ull * lda;
+  const unsigned long long orgB = TB ? 4ull * j0 : 4ull * j0 * ldb, kstepB = TB ? 128ull * ldb : 128ull;
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  gptr ctile = q.c + 4ull * ((unsigned long long)j0 * ldc + i0);
+  const unsigned int offC = (4u * h * ldc + li) * 4u;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  if (!beta0 || p.colbias) {
+    const float bias = p.colbias ? ((GM const float*)q.d)[i0 + li] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float start = beta0 ? 0.0f : *(GM const float*)(ctile + (unsigned long long)(((r & 3) + 8 * (r >> 2)) * ldc) * 4ull + offC);
+      acc[r] = p.colbias ? (beta0 ? bias : bias + start) : start;
+    }
+  }
+  const unsigned int kchunks = (unsigned int)p.k >> 5;
+  unsigned long long r = 0; unsigned int kc = 0;
+  gcptr ar, br;
+  if (p.br_count != 0) br_base(p, q, 0, ar, br);
+  const unsigned long long total = p.br_count * kchunks;
+  for (unsigned long long t = 0; t < total; ++t) {
+    gcptr au = ar + orgA + kc * kstepA, bu = br + orgB + kc * kstepB;      // wave-uniform
+    f32x4 ga[4], gb[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) ga[x] = *(GM const f32x4*)(au + x * stepA + offA);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) gb[x] = *(GM const f32x4*)(bu + x * stepB + offB);
+    float af[16], bf[16];
+    tile_to_frag<TA>(af, ga, lds, (int)lane);
+    tile_to_frag<!TB>(bf, gb, lds + 1024, (int)lane);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc, 0, 0, 0);
+    if (++kc == kchunks) { kc = 0; if (++r < p.br_count) br_base(p, q, r, ar, br); }
+  }
+  if (p.act == 0) {
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2)
+      *(GM float*)(ctile + (unsigned long long)(((r2 & 3) + 8 * (r2 >> 2)) * ldc) * 4ull + offC) = acc[r2];
+  } else {
+    const unsigned int mask_row = (((ldc + 15u) / 16u) * 16u) / 8u;
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) {
+      const unsigned int jr = (r2 & 3) + 8 * (r2 >> 2);
+      const float x = acc[r2];
+      *(GM float*)(ctile + (unsigned long long)(jr * ldc) * 4ull + offC) = act_apply(p.act, x);
+      if (p.act == 2 && q.mask) {
+        const unsigned long long pos = __ballot(!(x <= 0.0f));
+        if ((lane & 7u) == 0u) q.mask[(i0 + li) / 8u + (unsigned long long)(j0 + jr + 4u * h) * mask_row] = (unsigned char)((pos >> lane) & 0xffu);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,8 +545,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_t16_kernel(GemmArgs p) {
   const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
   const int i = job.i0 + x;
   f32x4 acc;
-  float* C = (float*)q.c;
-  const float bias = p.colbias ? ((const float*)q.d)[i] : 0.0f;
+  GM float* C = (GM float*)q.c;
+  const float bias = p.colbias ? ((GM const float*)q.d)[i] : 0.0f;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int j = job.j0 + 4 * g + e;
@@ -354,14 +554,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_t16_kernel(GemmArgs p) {
     acc[e] = p.colbias ? (beta0 ? bias : bias + start) : start;
   }
   for (unsigned long long r = 0; r < p.br_count; ++r) {
-    const char *ar, *br; br_base(p, q, r, ar, br);
-    const float* A = (const float*)ar; const float* B = (const float*)br;
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    GM const float* A = (GM const float*)ar; GM const float* B = (GM const float*)br;
     for (int k0 = 0; k0 < p.k; k0 += 16) {
       float af[4]; f32x4 bv;
 #pragma unroll
       for (int s = 0; s < 4; ++s) af[s] = A[i + (long long)(k0 + 4 * g + s) * p.lda];
-      const float* bcol = B + (long long)(job.j0 + x) * p.ldb + k0 + 4 * g;
-      if (((((unsigned long long)(size_t)B) & 15ull) == 0ull) && ((p.ldb & 3) == 0)) bv = *(const f32x4*)bcol;
+      GM const float* bcol = B + (long long)(job.j0 + x) * p.ldb + k0 + 4 * g;
+      if (((((unsigned long long)(size_t)B) & 15ull) == 0ull) && ((p.ldb & 3) == 0)) bv = *(GM const f32x4*)bcol;
       else { bv[0] = bcol[0]; bv[1] = bcol[1]; bv[2] = bcol[2]; bv[3] = bcol[3]; }
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], af[s], acc, 0, 0, 0);
@@ -399,13 +599,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
     for (int nt = 0; nt < NT; ++nt) {
       tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h;
       tc[mt][nt].ivalid = tc[mt][nt].i < p.m;
-      tile_init<EXACT>(acc[mt][nt], p, q, tc[mt][nt]);
+      tile_init<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]);
     }
   const int kchunks = (p.k + 31) / 32;
   for (unsigned long long r = 0; r < p.br_count; ++r) {
-    const char *ar, *br; br_base(p, q, r, ar, br);
-    const unsigned int* A2 = (const unsigned int*)ar;          // one dword = (k even, k odd) of one row
-    const unsigned short* B = (const unsigned short*)br;
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    GM const unsigned int* A2 = (GM const unsigned int*)ar;    // one dword = (k even, k odd) of one row
+    GM const unsigned short* B = (GM const unsigned short*)br;
     const bool bvec = ((((unsigned long long)(size_t)B) & 15ull) == 0ull) && ((p.ldb & 7) == 0);
     for (int kc = 0; kc < kchunks; ++kc) {
       const int k0 = kc * 32;
@@ -425,9 +625,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int j = job.j0 + 32 * nt + li;
-          const unsigned short* col = B + (long long)j * p.ldb + kb;
+          GM const unsigned short* col = B + (long long)j * p.ldb + kb;
           if (EXACT && bvec) {
-            bfr[nt][s] = *(const u32x4*)col;
+            bfr[nt][s] = *(GM const u32x4*)col;
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -451,7 +651,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) tile_store<EXACT>(acc[mt][nt], p, q, tc[mt][nt]);
+    for (int nt = 0; nt < NT; ++nt) tile_store<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -526,35 +726,69 @@ const char* gemm_kernel_name(const libxsmm_gemm_descriptor& d, bool) {
   return path_name(plan_gemm((int)d.m, (int)d.n, (int)d.k, d.flags, d.a_type, d.c_type, (d.flags & LIBXSMM_GEMM_FLAG_VNNI_C) != 0).path);
 }
 
-template <int MT, int NT, bool EXACT>
+template <int MT, int NT, int MODE>
 static void launch_f32(const GemmArgs& a, dim3 grid, hipStream_t st) {
   const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
-  if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, false, false, EXACT>), grid, dim3(256), 0, st, a);
-  else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, true, false, EXACT>), grid, dim3(256), 0, st, a);
-  else if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, false, true, EXACT>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, true, true, EXACT>), grid, dim3(256), 0, st, a);
+  if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, false, false, MODE>), grid, dim3(256), 0, st, a);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, true, false, MODE>), grid, dim3(256), 0, st, a);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, false, true, MODE>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_mfma_f32_kernel<MT, NT, true, true, MODE>), grid, dim3(256), 0, st, a);
+}
+// The staged path needs every operand tile 16-byte aligned.  That is decidable on the host for the
+// strided forms; pointer lists / offset arrays live on the device and take the direct-load kernel.
+static bool operands_aligned16(const GemmArgs& a, int elem_size) {
+  if (a.list_a || a.br_mode == 1 || a.br_mode == 2) return false;
+  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a |
+    (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) |
+    (unsigned long long)((long long)a.lda * elem_size) | (unsigned long long)((long long)a.ldb * elem_size);
+  return (bits & 15ull) == 0ull;
 }
 
-int launch_gemm(const GemmArgs& a, void* stream, const char** kernel_name) {
+int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
+  const GemmArgs& a0 = a_in;
   hipStream_t st = (hipStream_t)stream;
-  if (a.nbatch == 0 || a.m <= 0 || a.n <= 0) { if (kernel_name) *kernel_name = "(empty)"; return 0; }
-  const GemmPlan pl = plan_gemm(a.m, a.n, a.k, a.flags, a.a_type, a.c_type, a.vnni_c);
+  if (a0.nbatch == 0 || a0.m <= 0 || a0.n <= 0) { if (kernel_name) *kernel_name = "(empty)"; return 0; }
+  const GemmPlan pl = plan_gemm(a0.m, a0.n, a0.k, a0.flags, a0.a_type, a0.c_type, a0.vnni_c);
+  if ((long long)((a0.m + 15) / 16) * ((a0.n + 15) / 16) * (long long)a0.nbatch >= (1ll << 31)) return (int)hipErrorInvalidValue;
   if (kernel_name) *kernel_name = path_name(pl.path);
+  GemmArgs a = a_in;
   auto wave_grid = [&](int tm, int tn) {
-    const long long tiles = (long long)((a.m + tm - 1) / tm) * ((a.n + tn - 1) / tn) * (long long)a.nbatch;
+    a.tiles_m = (a.m + tm - 1) / tm; a.tiles_n = (a.n + tn - 1) / tn;
+    const long long tiles = (long long)a.tiles_m * a.tiles_n * (long long)a.nbatch;
     return dim3((unsigned int)((tiles + 3) / 4));
   };
+  dim3 grid;
   switch (pl.path) {
-    case P_F32_T16: hipLaunchKernelGGL(gemm_mfma_f32_t16_kernel, wave_grid(16, 16), dim3(256), 0, st, a); break;
-    case P_F32_1x1: if (pl.exact) launch_f32<1, 1, true>(a, wave_grid(32, 32), st); else launch_f32<1, 1, false>(a, wave_grid(32, 32), st); break;
-    case P_F32_2x2: if (pl.exact) launch_f32<2, 2, true>(a, wave_grid(64, 64), st); else launch_f32<2, 2, false>(a, wave_grid(64, 64), st); break;
+    case P_F32_T16: grid = wave_grid(16, 16); hipLaunchKernelGGL(gemm_mfma_f32_t16_kernel, grid, dim3(256), 0, st, a); break;
+    case P_F32_1x1:
+      grid = wave_grid(32, 32);
+      if (pl.exact && operands_aligned16(a, 4) && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22)) {
+        const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
+        if (kernel_name) *kernel_name = "gemm_f32_stream_kernel";
+        if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_stream_kernel<false, false>), grid, dim3(256), 0, st, a);
+        else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_stream_kernel<true, false>), grid, dim3(256), 0, st, a);
+        else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_stream_kernel<false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_f32_stream_kernel<true, true>), grid, dim3(256), 0, st, a);
+      }
+      else if (pl.exact && operands_aligned16(a, 4)) launch_f32<1, 1, GM_STAGED>(a, grid, st);
+      else if (pl.exact) launch_f32<1, 1, GM_EXACT>(a, grid, st);
+      else launch_f32<1, 1, GM_MASKED>(a, grid, st);
+      break;
+    case P_F32_2x2:
+      grid = wave_grid(64, 64);
+      if (pl.exact && operands_aligned16(a, 4)) launch_f32<2, 2, GM_STAGED>(a, grid, st);
+      else if (pl.exact) launch_f32<2, 2, GM_EXACT>(a, grid, st);
+      else launch_f32<2, 2, GM_MASKED>(a, grid, st);
+      break;
     case P_BF16_1x1:
-      if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true>), wave_grid(32, 32), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), wave_grid(32, 32), dim3(256), 0, st, a);
+      grid = wave_grid(32, 32);
+      if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), grid, dim3(256), 0, st, a);
       break;
     case P_BF16_2x2:
-      if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), wave_grid(64, 64), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), wave_grid(64, 64), dim3(256), 0, st, a);
+      grid = wave_grid(64, 64);
+      if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
       break;
     default: {
       const long long blocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;

@@ -72,6 +72,7 @@ struct GemmArgs {
   int a_type, b_type, c_type;
   int colbias, act;                                 // act: 0 none, 1 relu, 2 relu+bitmask, 3 sigmoid
   int vnni_c;
+  int tiles_m, tiles_n;                             // set by launch_gemm for the tile size of the chosen kernel
 };
 
 struct MeltwArgs {

@@ -18,6 +18,9 @@
 
 namespace xamd {
 
+// kernel-argument-block pointers are generic to the compiler; everything dereferenced here is global memory
+#define GM __attribute__((address_space(1)))
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
@@ -29,11 +32,13 @@ __device__ __forceinline__ unsigned short mw_f2bf(float f) {
   else u += 0x00007fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ float mw_load(const char* p, long long idx, int type) {
-  return (type == LIBXSMM_DATATYPE_F32) ? ((const float*)p)[idx] : mw_bf2f(((const unsigned short*)p)[idx]);
+typedef GM const char* gcptr;
+typedef GM char* gptr;
+__device__ __forceinline__ float mw_load(gcptr p, long long idx, int type) {
+  return (type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)p)[idx] : mw_bf2f(((GM const unsigned short*)p)[idx]);
 }
-__device__ __forceinline__ void mw_store(char* p, long long idx, int type, float v) {
-  if (type == LIBXSMM_DATATYPE_F32) ((float*)p)[idx] = v; else ((unsigned short*)p)[idx] = mw_f2bf(v);
+__device__ __forceinline__ void mw_store(gptr p, long long idx, int type, float v) {
+  if (type == LIBXSMM_DATATYPE_F32) ((GM float*)p)[idx] = v; else ((GM unsigned short*)p)[idx] = mw_f2bf(v);
 }
 
 enum { BC_NONE = 0, BC_ROW = 1, BC_COL = 2, BC_SCALAR = 3 };
@@ -130,48 +135,48 @@ __device__ __forceinline__ EwJob ew_job(const MeltwArgs& p, int m, int n) {
   return e;
 }
 // write bit `on` for element (i,j) into a bit matrix with leading dimension ld_bits; ballot-combined
-__device__ __forceinline__ void put_bits(unsigned char* bits, int i, int j, long long ld_bits, bool valid, bool on) {
+__device__ __forceinline__ void put_bits(GM unsigned char* bits, int i, int j, long long ld_bits, bool valid, bool on) {
   const int lane = threadIdx.x;
   const unsigned long long pos = __ballot(valid && on), val = __ballot(valid);
   if ((lane & 7) == 0 && valid) {
-    unsigned char* byte = bits + i / 8 + (long long)j * (ld_bits / 8);
+    GM unsigned char* byte = bits + i / 8 + (long long)j * (ld_bits / 8);
     const unsigned char vm = (unsigned char)((val >> lane) & 0xffu), nb = (unsigned char)((pos >> lane) & 0xffu);
     *byte = (unsigned char)((*byte & ~vm) | (nb & vm));
   }
 }
-__device__ __forceinline__ int get_bit(const unsigned char* bits, int i, int j, long long ld_bits) {
+__device__ __forceinline__ int get_bit(GM const unsigned char* bits, int i, int j, long long ld_bits) {
   return (bits[i / 8 + (long long)j * (ld_bits / 8)] >> (i % 8)) & 1;
 }
 
 __global__ __launch_bounds__(256) void meltw_unary_kernel(MeltwArgs p) {
   const int n_eff = (p.type == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR) ? (int)p.scalar_u64 : p.n;
   const EwJob e = ew_job(p, p.m, n_eff);
-  const char* in = p.in0 + (long long)e.bidx * p.bs_in0;
-  char* out = p.out + (long long)e.bidx * p.bs_out;
+  gcptr in = (gcptr)p.in0 + (long long)e.bidx * p.bs_in0;
+  gptr out = (gptr)p.out + (long long)e.bidx * p.bs_out;
   const int bc = bcast_kind(p.operation, p.type, p.flags, 0);
   const bool bitm = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) != 0;
   const int i = e.i, j = e.j;
   if (p.in0_type == LIBXSMM_DATATYPE_F64) {
-    if (e.valid) ((double*)out)[i + (long long)j * p.ldo] = unary_math_f64(p.type, ((const double*)in)[bc_index(bc, i, j, p.ldi)]);
+    if (e.valid) ((GM double*)out)[i + (long long)j * p.ldo] = unary_math_f64(p.type, ((GM const double*)in)[bc_index(bc, i, j, p.ldi)]);
     return;
   }
   switch (p.type) {
     case LIBXSMM_MELTW_TYPE_UNARY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_ELU: {
       const float x = e.valid ? mw_load(in, bc_index(bc, i, j, p.ldi), p.in0_type) : 0.0f;
       if (e.valid) mw_store(out, i + (long long)j * p.ldo, p.out_type, unary_math(p.type, x, p.scalar_f32));
-      if (bitm) put_bits((unsigned char*)p.aux_out + (long long)e.bidx * p.bs_aux, i, j, ((p.ldo + 15) / 16) * 16, e.valid, !(x <= 0.0f));
+      if (bitm) put_bits((GM unsigned char*)p.aux_out + (long long)e.bidx * p.bs_aux, i, j, ((p.ldo + 15) / 16) * 16, e.valid, !(x <= 0.0f));
       return;
     }
     case LIBXSMM_MELTW_TYPE_UNARY_RELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_ELU_INV: {
       if (!e.valid) return;
       const float x = mw_load(in, bc_index(bc, i, j, p.ldi), p.in0_type);
-      const char* aux = (const char*)p.aux_in + (long long)e.bidx * p.bs_aux;
+      gcptr aux = (gcptr)p.aux_in + (long long)e.bidx * p.bs_aux;
       float y;
       if (p.type == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) {
         const float fwd = mw_load(aux, bc_index(bc, i, j, p.ldi), p.in0_type);
         y = (fwd > 0.0f) ? x : x * (fwd + p.scalar_f32);
       } else {
-        const int bit = get_bit((const unsigned char*)aux, i, j, ((p.ldi + 15) / 16) * 16);
+        const int bit = get_bit((GM const unsigned char*)aux, i, j, ((p.ldi + 15) / 16) * 16);
         y = (p.type == LIBXSMM_MELTW_TYPE_UNARY_RELU_INV) ? (bit ? x : 0.0f) : (bit ? x : p.scalar_f32 * x);
       }
       mw_store(out, i + (long long)j * p.ldo, p.out_type, y);
@@ -179,9 +184,9 @@ __global__ __launch_bounds__(256) void meltw_unary_kernel(MeltwArgs p) {
     }
     case LIBXSMM_MELTW_TYPE_UNARY_UNZIP: {                      // [ref: :2419-2432]
       if (!e.valid) return;
-      const unsigned int u = ((const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
-      ((unsigned short*)out)[i + (long long)j * p.ldo] = (unsigned short)(u & 0xffffu);
-      ((unsigned short*)(out + p.scalar_u64))[i + (long long)j * p.ldo] = (unsigned short)(u >> 16);
+      const unsigned int u = ((GM const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
+      ((GM unsigned short*)out)[i + (long long)j * p.ldo] = (unsigned short)(u & 0xffffu);
+      ((GM unsigned short*)(out + p.scalar_u64))[i + (long long)j * p.ldo] = (unsigned short)(u >> 16);
       return;
     }
     default: break;
@@ -189,8 +194,8 @@ __global__ __launch_bounds__(256) void meltw_unary_kernel(MeltwArgs p) {
   if (!e.valid) return;
   // pure copies / zero fill of same-width types stay bit-exact (no float round trip)
   if (p.in0_type == p.out_type && (p.type == LIBXSMM_MELTW_TYPE_UNARY_IDENTITY || p.type == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR)) {
-    if (p.in0_type == LIBXSMM_DATATYPE_F32) ((unsigned int*)out)[i + (long long)j * p.ldo] = ((const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
-    else ((unsigned short*)out)[i + (long long)j * p.ldo] = ((const unsigned short*)in)[bc_index(bc, i, j, p.ldi)];
+    if (p.in0_type == LIBXSMM_DATATYPE_F32) ((GM unsigned int*)out)[i + (long long)j * p.ldo] = ((GM const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
+    else ((GM unsigned short*)out)[i + (long long)j * p.ldo] = ((GM const unsigned short*)in)[bc_index(bc, i, j, p.ldi)];
     return;
   }
   const float x = mw_load(in, bc_index(bc, i, j, p.ldi), p.in0_type);
@@ -208,34 +213,34 @@ __global__ __launch_bounds__(256) void meltw_unary_vec4_kernel(MeltwArgs p) {
   const unsigned int bidx = (unsigned int)(gid / per);
   const long long t = gid % per;
   const int i = (int)(t % m4) * 4, j = (int)(t / m4);
-  const char* in = p.in0 + (long long)bidx * p.bs_in0;
-  char* out = p.out + (long long)bidx * p.bs_out;
+  gcptr in = (gcptr)p.in0 + (long long)bidx * p.bs_in0;
+  gptr out = (gptr)p.out + (long long)bidx * p.bs_out;
   float x[4];
-  if (BF16) { const u16x4 v = *(const u16x4*)((const unsigned short*)in + i + (long long)j * p.ldi); for (int e = 0; e < 4; ++e) x[e] = mw_bf2f(v[e]); }
-  else { const f32x4 v = *(const f32x4*)((const float*)in + i + (long long)j * p.ldi); for (int e = 0; e < 4; ++e) x[e] = v[e]; }
-  if (BF16) { u16x4 o; for (int e = 0; e < 4; ++e) o[e] = mw_f2bf(unary_math(p.type, x[e], p.scalar_f32)); *(u16x4*)((unsigned short*)out + i + (long long)j * p.ldo) = o; }
-  else { f32x4 o; for (int e = 0; e < 4; ++e) o[e] = unary_math(p.type, x[e], p.scalar_f32); *(f32x4*)((float*)out + i + (long long)j * p.ldo) = o; }
+  if (BF16) { const u16x4 v = *(GM const u16x4*)((GM const unsigned short*)in + i + (long long)j * p.ldi); for (int e = 0; e < 4; ++e) x[e] = mw_bf2f(v[e]); }
+  else { const f32x4 v = *(GM const f32x4*)((GM const float*)in + i + (long long)j * p.ldi); for (int e = 0; e < 4; ++e) x[e] = v[e]; }
+  if (BF16) { u16x4 o; for (int e = 0; e < 4; ++e) o[e] = mw_f2bf(unary_math(p.type, x[e], p.scalar_f32)); *(GM u16x4*)((GM unsigned short*)out + i + (long long)j * p.ldo) = o; }
+  else { f32x4 o; for (int e = 0; e < 4; ++e) o[e] = unary_math(p.type, x[e], p.scalar_f32); *(GM f32x4*)((GM float*)out + i + (long long)j * p.ldo) = o; }
 }
 
 __global__ __launch_bounds__(256) void meltw_binary_kernel(MeltwArgs p) {
   const EwJob e = ew_job(p, p.m, p.n);
-  const char* in0 = p.in0 + (long long)e.bidx * p.bs_in0;
-  const char* in1 = p.in1 + (long long)e.bidx * p.bs_in1;
-  char* out = p.out + (long long)e.bidx * p.bs_out;
+  gcptr in0 = (gcptr)p.in0 + (long long)e.bidx * p.bs_in0;
+  gcptr in1 = (gcptr)p.in1 + (long long)e.bidx * p.bs_in1;
+  gptr out = (gptr)p.out + (long long)e.bidx * p.bs_out;
   const int bc0 = bcast_kind(p.operation, p.type, p.flags, 0), bc1 = bcast_kind(p.operation, p.type, p.flags, 1);
   const int i = e.i, j = e.j;
   const bool cmp = p.type >= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GT && p.type <= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_NE;
   if (p.type == LIBXSMM_MELTW_TYPE_BINARY_ZIP) {                // [ref: :2543-2556]
     if (!e.valid) return;
-    const unsigned int lo = ((const unsigned short*)in0)[bc_index(bc0, i, j, p.ldi)];
-    const unsigned int hi = ((const unsigned short*)in1)[bc_index(bc1, i, j, p.ldi1)];
-    ((unsigned int*)out)[i + (long long)j * p.ldo] = lo | (hi << 16);
+    const unsigned int lo = ((GM const unsigned short*)in0)[bc_index(bc0, i, j, p.ldi)];
+    const unsigned int hi = ((GM const unsigned short*)in1)[bc_index(bc1, i, j, p.ldi1)];
+    ((GM unsigned int*)out)[i + (long long)j * p.ldo] = lo | (hi << 16);
     return;
   }
   if (p.in0_type == LIBXSMM_DATATYPE_F64) {
     if (!e.valid) return;
-    const double a = ((const double*)in0)[bc_index(bc0, i, j, p.ldi)], b = ((const double*)in1)[bc_index(bc1, i, j, p.ldi1)];
-    double* o = (double*)out + i + (long long)j * p.ldo;
+    const double a = ((GM const double*)in0)[bc_index(bc0, i, j, p.ldi)], b = ((GM const double*)in1)[bc_index(bc1, i, j, p.ldi1)];
+    GM double* o = (GM double*)out + i + (long long)j * p.ldo;
     switch (p.type) {
       case LIBXSMM_MELTW_TYPE_BINARY_ADD: *o = a + b; break;
       case LIBXSMM_MELTW_TYPE_BINARY_SUB: *o = a - b; break;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void meltw_binary_kernel(MeltwArgs p) {
   float a = 0.0f, b = 0.0f;
   if (e.valid) { a = mw_load(in0, bc_index(bc0, i, j, p.ldi), p.in0_type); b = mw_load(in1, bc_index(bc1, i, j, p.ldi1), p.in1_type); }
   if (cmp) {   // result is a bit matrix, ld rounded up to 16 [ref: :2575-2584]
-    put_bits((unsigned char*)out, i, j, ((p.ldo + 15) / 16) * 16, e.valid, binary_math(p.type, a, b, 0.0f) > 0.1f);
+    put_bits((GM unsigned char*)out, i, j, ((p.ldo + 15) / 16) * 16, e.valid, binary_math(p.type, a, b, 0.0f) > 0.1f);
     return;
   }
   if (!e.valid) return;
@@ -261,17 +266,17 @@ __global__ __launch_bounds__(256) void meltw_binary_kernel(MeltwArgs p) {
 __global__ __launch_bounds__(256) void meltw_ternary_kernel(MeltwArgs p) {
   const EwJob e = ew_job(p, p.m, p.n);
   if (!e.valid) return;
-  const char* in0 = p.in0 + (long long)e.bidx * p.bs_in0;
-  const char* in1 = p.in1 + (long long)e.bidx * p.bs_in1;
-  const char* in2 = p.in2 + (long long)e.bidx * p.bs_in2;
-  char* out = p.out + (long long)e.bidx * p.bs_out;
+  gcptr in0 = (gcptr)p.in0 + (long long)e.bidx * p.bs_in0;
+  gcptr in1 = (gcptr)p.in1 + (long long)e.bidx * p.bs_in1;
+  gcptr in2 = (gcptr)p.in2 + (long long)e.bidx * p.bs_in2;
+  gptr out = (gptr)p.out + (long long)e.bidx * p.bs_out;
   const int bc0 = bcast_kind(p.operation, p.type, p.flags, 0), bc1 = bcast_kind(p.operation, p.type, p.flags, 1), bc2 = bcast_kind(p.operation, p.type, p.flags, 2);
   const int i = e.i, j = e.j;
   if (p.type == LIBXSMM_MELTW_TYPE_TERNARY_SELECT) {            // [ref: :2617-2640]
-    const int bit = get_bit((const unsigned char*)in2, i, j, ((p.ldi2 + 15) / 16) * 16);
+    const int bit = get_bit((GM const unsigned char*)in2, i, j, ((p.ldi2 + 15) / 16) * 16);
     if (p.in0_type == LIBXSMM_DATATYPE_F64) {
-      const double a = ((const double*)in0)[bc_index(bc0, i, j, p.ldi)], b = ((const double*)in1)[bc_index(bc1, i, j, p.ldi1)];
-      ((double*)out)[i + (long long)j * p.ldo] = bit ? b : a;
+      const double a = ((GM const double*)in0)[bc_index(bc0, i, j, p.ldi)], b = ((GM const double*)in1)[bc_index(bc1, i, j, p.ldi1)];
+      ((GM double*)out)[i + (long long)j * p.ldo] = bit ? b : a;
     } else {
       const float a = mw_load(in0, bc_index(bc0, i, j, p.ldi), p.in0_type), b = mw_load(in1, bc_index(bc1, i, j, p.ldi1), p.in1_type);
       mw_store(out, i + (long long)j * p.ldo, p.out_type, bit ? b : a);
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(MeltwArgs p) {
   const unsigned int bidx = (unsigned int)(blockIdx.x / per);
   const int t = (int)(blockIdx.x % per);
   const int r0 = (t % tm) * 32, c0 = (t / tm) * 32;       // r: index along m (contiguous in `in`), c: along n
-  const T* in = (const T*)(p.in0 + (long long)bidx * p.bs_in0);
-  T* out = (T*)(p.out + (long long)bidx * p.bs_out);
+  GM const T* in = (GM const T*)((gcptr)p.in0 + (long long)bidx * p.bs_in0);
+  GM T* out = (GM T*)((gptr)p.out + (long long)bidx * p.bs_out);
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int cc = ty; cc < 32; cc += 8) {
     const int r = r0 + tx, c = c0 + cc;
@@ -326,8 +331,8 @@ enum XformMode { XF_NORM_TO_VNNI = 1, XF_VNNI_TO_VNNIT, XF_NORM_TO_VNNIT, XF_VNN
 template <int S>
 __global__ __launch_bounds__(256) void xform_kernel(MeltwArgs p, int mode, int v, int pad_m, int pad_n) {
   typedef typename Payload<S>::type T;
-  const T* in = (const T*)(p.in0 + (long long)blockIdx.y * p.bs_in0);
-  T* out = (T*)(p.out + (long long)blockIdx.y * p.bs_out);
+  GM const T* in = (GM const T*)((gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0);
+  GM T* out = (GM T*)((gptr)p.out + (long long)blockIdx.y * p.bs_out);
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long M = p.m, N = p.n, ldi = p.ldi, ldo = p.ldo;
   switch (mode) {
@@ -386,15 +391,15 @@ __global__ __launch_bounds__(256) void xform_kernel(MeltwArgs p, int mode, int v
 template <int S>
 __global__ __launch_bounds__(256) void gather_scatter_kernel(MeltwArgs p) {
   typedef typename Payload<S>::type T;
-  const T* in = (const T*)(p.in0 + (long long)blockIdx.y * p.bs_in0);
-  T* out = (T*)(p.out + (long long)blockIdx.y * p.bs_out);
+  GM const T* in = (GM const T*)((gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0);
+  GM T* out = (GM T*)((gptr)p.out + (long long)blockIdx.y * p.bs_out);
   const bool gather = (p.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER);
   const void* idxp = gather ? p.aux_in : (const void*)p.aux_out;
   const bool idx64 = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_8BYTES) != 0;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long long)p.m * p.n) return;
   const long long i = gid % p.m, j = gid / p.m;
-#define XIDX(q) (idx64 ? (long long)((const unsigned long long*)idxp)[q] : (long long)((const unsigned int*)idxp)[q])
+#define XIDX(q) (idx64 ? (long long)((GM const unsigned long long*)idxp)[q] : (long long)((GM const unsigned int*)idxp)[q])
   if (p.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_COLS) {
     if (gather) out[i + j * p.ldo] = in[i + XIDX(j) * p.ldi]; else out[i + XIDX(j) * p.ldo] = in[i + j * p.ldi];
   } else if (p.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_ROWS) {
@@ -414,10 +419,10 @@ __global__ __launch_bounds__(256) void reduce_kernel(MeltwArgs p) {
   const bool want_x = type != LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD;
   const bool want_x2 = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD || type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD;
   const bool is_add = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD || want_x2;
-  const char* in = p.in0 + (long long)blockIdx.y * p.bs_in0;
-  char* out = p.out + (long long)blockIdx.y * p.bs_out;
+  gcptr in = (gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0;
+  gptr out = (gptr)p.out + (long long)blockIdx.y * p.bs_out;
   const long long result_size = rows ? p.n : p.ldo;
-  char* out2 = (want_x && want_x2) ? out + result_size * ((p.out_type == LIBXSMM_DATATYPE_F32) ? 4 : 2) : out;
+  gptr out2 = (want_x && want_x2) ? out + result_size * ((p.out_type == LIBXSMM_DATATYPE_F32) ? 4 : 2) : out;
   const float ident = (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) ? -3.402823466e+38f : (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN) ? 3.402823466e+38f : 0.0f;
   auto combine = [&](float a, float x) {
     if (is_add) return a + x;

@@ -255,6 +255,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   }
   const char* kname = nullptr;
   const int err = launch_gemm(a, tls().stream, &kname);
+  if (kname) { if (b.count > 1 || b.la) k->kname_batched = kname; else k->kname_single = kname; }   // what actually ran
   finish_launch(err, kname);
 }
 

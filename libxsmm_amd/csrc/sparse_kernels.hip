@@ -22,6 +22,9 @@
 
 namespace xamd {
 
+// kernel-argument-block pointers are generic to the compiler; everything dereferenced here is global memory
+#define GM __attribute__((address_space(1)))
+
 template <typename T, int VEC> struct VecOf;
 template <> struct VecOf<float, 1> { typedef float type; };
 template <> struct VecOf<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
@@ -30,7 +33,7 @@ template <> struct VecOf<double, 1> { typedef double type; };
 template <> struct VecOf<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
 
 template <typename T> __device__ __forceinline__ T load_val(const void* vals, unsigned int z, int vals_are_f64) {
-  return vals_are_f64 ? (T)((const double*)vals)[z] : ((const T*)vals)[z];
+  return vals_are_f64 ? (T)((GM const double*)vals)[z] : ((GM const T*)vals)[z];
 }
 
 // grid: x = column blocks, y = slabs.  Dynamic LDS: inner * blockDim.x * VEC elements when STAGE.
@@ -42,23 +45,26 @@ __global__ void spmm_panel_kernel(SpmmArgs p) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   const long long q0 = ((long long)blockIdx.x * nthr + tid) * VEC;
   const bool active = q0 < p.ncols;                            // ncols % VEC == 0 by construction
-  const T* x = (const T*)p.x + (long long)blockIdx.y * p.outer_x;
-  T* y = (T*)p.y + (long long)blockIdx.y * p.outer_y;
+  GM const T* x = (GM const T*)p.x + (long long)blockIdx.y * p.outer_x;
+  GM T* y = (GM T*)p.y + (long long)blockIdx.y * p.outer_y;
+  GM const unsigned int* ptr = (GM const unsigned int*)p.ptr;
+  GM const unsigned int* idx = (GM const unsigned int*)p.idx;
+  GM const unsigned int* vmap = (GM const unsigned int*)p.vmap;
   if (STAGE) {
     // each thread copies its own column(s): no other thread reads them -> no barrier needed
-    if (active) for (int k = 0; k < p.inner; ++k) tile[(long long)k * nthr + tid] = *(const vec_t*)(x + (long long)k * p.ld_x + q0);
+    if (active) for (int k = 0; k < p.inner; ++k) tile[(long long)k * nthr + tid] = *(GM const vec_t*)(x + (long long)k * p.ld_x + q0);
   }
   if (!active) return;
   for (int r = 0; r < p.rows; ++r) {
-    const unsigned int z0 = p.ptr[r], z1 = p.ptr[r + 1];
+    const unsigned int z0 = ptr[r], z1 = ptr[r + 1];
     if (z0 == z1 && (p.skip_empty || !p.beta0)) continue;      // untouched row
     vec_t acc;
-    vec_t* yp = (vec_t*)(y + (long long)r * p.ld_y + q0);
+    GM vec_t* yp = (GM vec_t*)(y + (long long)r * p.ld_y + q0);
     if (p.beta0) { for (int v = 0; v < VEC; ++v) ((T*)&acc)[v] = (T)0; } else acc = *yp;
     for (unsigned int z = z0; z < z1; ++z) {
-      const T a = load_val<T>(p.vals, p.vmap ? p.vmap[z] : z, p.vals_are_f64);
-      const unsigned int k = p.idx[z];
-      const vec_t xv = STAGE ? tile[(long long)k * nthr + tid] : *(const vec_t*)(x + (long long)k * p.ld_x + q0);
+      const T a = load_val<T>(p.vals, vmap ? vmap[z] : z, p.vals_are_f64);
+      const unsigned int k = idx[z];
+      const vec_t xv = STAGE ? tile[(long long)k * nthr + tid] : *(GM const vec_t*)(x + (long long)k * p.ld_x + q0);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) ((T*)&acc)[v] = fma(a, ((const T*)&xv)[v], ((T*)&acc)[v]);
     }
@@ -133,26 +139,28 @@ __global__ __launch_bounds__(256) void bcsc_generic_kernel(BcscArgs p) {
   const long long cidx = (long long)mb * p.N * p.M + (long long)n * p.M + i;
   const bool f32 = (p.a_type == LIBXSMM_DATATYPE_F32);
   float acc = 0.0f;
-  if (!p.beta0) acc = (p.c_type == LIBXSMM_DATATYPE_F32) ? ((const float*)p.c)[cidx] : bf2f(((const unsigned short*)p.c)[cidx]);
+  if (!p.beta0) acc = (p.c_type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)p.c)[cidx] : bf2f(((GM const unsigned short*)p.c)[cidx]);
   const long long abase = (long long)mb * p.K * p.M;
-  for (unsigned int b = p.colptr[nb]; b < p.colptr[nb + 1]; ++b) {
-    const int k0 = (int)p.rowidx[b] * p.bk;
+  GM const unsigned int* colptr = (GM const unsigned int*)p.colptr;
+  GM const unsigned int* rowidx = (GM const unsigned int*)p.rowidx;
+  for (unsigned int b = colptr[nb]; b < colptr[nb + 1]; ++b) {
+    const int k0 = (int)rowidx[b] * p.bk;
     const long long boff = ((long long)b * p.bn + dn) * p.bk;
     for (int dk = 0; dk < p.bk; ++dk) {
       const int k = k0 + dk;
       float av, bv;
       if (f32) {
-        av = ((const float*)p.a)[abase + (long long)k * p.M + i];
-        bv = ((const float*)p.bvals)[boff + dk];
+        av = ((GM const float*)p.a)[abase + (long long)k * p.M + i];
+        bv = ((GM const float*)p.bvals)[boff + dk];
       } else {
         const long long ai = p.vnni_a ? ((long long)(k / 2) * (p.M * 2) + (long long)i * 2 + (k % 2)) : ((long long)k * p.M + i);
-        av = bf2f(((const unsigned short*)p.a)[abase + ai]);
-        bv = bf2f(((const unsigned short*)p.bvals)[boff + dk]);
+        av = bf2f(((GM const unsigned short*)p.a)[abase + ai]);
+        bv = bf2f(((GM const unsigned short*)p.bvals)[boff + dk]);
       }
       acc = fmaf(av, bv, acc);
     }
   }
-  if (p.c_type == LIBXSMM_DATATYPE_F32) ((float*)p.c)[cidx] = acc; else ((unsigned short*)p.c)[cidx] = f2bf_rne(acc);
+  if (p.c_type == LIBXSMM_DATATYPE_F32) ((GM float*)p.c)[cidx] = acc; else ((GM unsigned short*)p.c)[cidx] = f2bf_rne(acc);
 }
 
 int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
