@@ -8,8 +8,8 @@ header stays the single source of truth.
 
 The binding is deliberately library-agnostic: `Api(path, prefix)` binds any shared object
 that exports the LIBXSMM entry points under `prefix` -- the product library
-(libxsmm_amd.so, prefix "libxsmm_") or, in the test-suite only, the reference itself built
-by oracle/Makefile (oracle/_ref/libxsmm_ref.so, prefix "xref_").  There is NO fallback:
+(libxsmm_amd.so, prefix "libxsmm_"); the test-suite re-uses the class to drive the reference
+build through the same structs (a different prefix, from test code only).  There is NO fallback:
 if libxsmm_amd.so is missing `load()` raises, it never substitutes a CPU path.
 """
 from __future__ import annotations

@@ -1,0 +1,48 @@
+"""Multi-GPU side of the hot path: the batch / packed / N axis is embarrassingly parallel, so the
+only distributed logic is (1) who owns which contiguous block of the axis and (2) an optional gather of the
+results.  One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI; "gloo" in the CPU tests);
+there is no collective on the data path.
+
+The shard arithmetic is the C-ABI's libxsmm_hip_shard_range so that C callers and Python agree bit for bit.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+from . import capi
+
+
+def shard_range(count: int, world: int, rank: int, granule: int = 1) -> Tuple[int, int]:
+    """[begin, end) of a `count`-long axis owned by `rank`; boundaries fall on multiples of `granule`."""
+    b, e = C.c_size_t(), C.c_size_t()
+    capi.load().hip_shard_range(count, granule, world, rank, C.byref(b), C.byref(e))
+    return int(b.value), int(e.value)
+
+
+def shard_sizes(count: int, world: int, granule: int = 1) -> List[int]:
+    return [e - b for b, e in (shard_range(count, world, r, granule) for r in range(world))]
+
+
+def gather_shards(local, count: int, granule: int = 1, group=None):
+    """All ranks receive the full axis: `local` holds this rank's [begin, end) slice along dim 0.
+
+    Uneven shards are padded to the largest one for the collective (all_gather needs equal sizes) and trimmed
+    afterwards.  On MI355X the ring all-gather is bound by one xGMI link per hop; callers that only need the
+    result on one rank should prefer torch.distributed.gather or leave C sharded.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(count, world, granule)
+    biggest = max(sizes)
+    pad = biggest - local.shape[0]
+    buf = local if pad == 0 else torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], dim=0)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf.contiguous(), group=group)
+    return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
+
+
+def byte_offsets(begin: int, strides: Sequence[int]) -> List[int]:
+    """Byte offsets to add to the `primary` slots so that a batched launch starts at problem `begin`."""
+    return [begin * s for s in strides]
