@@ -260,7 +260,7 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"stride-BRGEMM {args.dtype} m=n=k={args.m}, batch={args.batch} independent problems per GPU, br={args.br}, beta={args.beta}"
                                    + (", fused colbias+ReLU" if args.fused else ""),
-                       "kernel": work.kernel, "input_sets_rotated": work.nsets, "per_gpu_batch": args.batch},
+                       "kernel": work.api.hip_kernel_name(work.handle, 1).decode(), "input_sets_rotated": work.nsets, "per_gpu_batch": args.batch},
             "pct_mfma_peak": round(100.0 * value / world / 1e3 / peak_tf, 2),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
