@@ -87,6 +87,15 @@ LIBXSMM_API void libxsmm_hip_meltw_ternary_batch_strided(libxsmm_meltwfunction_t
  * after rounding shard boundaries to `granule` units (e.g. the packed width's lane tile). */
 LIBXSMM_API void libxsmm_hip_shard_range(size_t count, size_t granule, int world, int rank, size_t* begin, size_t* end);
 
+/* ---- run-time specialisation of the fixed-pattern sparse kernels ---------------------
+ * libxsmm_create_packed_spgemm_csr/_csc, libxsmm_create_spgemm_csr_areg and libxsmm_fsspmdm_create can compile a
+ * kernel with the sparsity pattern unrolled into the instruction stream (hiprtc), as the reference's JIT does
+ * [ref: src/generator_packed_spgemm_csr_asparse_avx_avx2_avx512.c:336-470].  mode 0: never (precompiled LDS-staged
+ * kernels), 1: when one call is large enough to repay the compile time (default), 2: always.
+ * LIBXSMM_HIP_JIT=0|1|2 presets it.  Applies to kernels created afterwards. */
+LIBXSMM_API void libxsmm_hip_set_jit(int mode);
+LIBXSMM_API int libxsmm_hip_get_jit(void);
+
 /* ---- introspection used by the tests and the bench --------------------------------- */
 /** Name of the device kernel a handle launches for single (batch==0) or batched calls. */
 LIBXSMM_API const char* libxsmm_hip_kernel_name(const void* kernel, int batched);

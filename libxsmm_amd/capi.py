@@ -228,6 +228,8 @@ class Api:
             self.hip_clear_last_error = f("hip_clear_last_error", None, [])
             self.hip_kernel_name = f("hip_kernel_name", C.c_char_p, [vp, C.c_int])
             self.hip_launch_count = f("hip_launch_count", C.c_ulonglong, [C.c_int])
+            self.hip_set_jit = f("hip_set_jit", None, [C.c_int])
+            self.hip_get_jit = f("hip_get_jit", C.c_int, [])
             ll = C.c_longlong
             self.hip_gemm_batch_strided = f("hip_gemm_batch_strided", None, [vp, C.POINTER(GemmParam), C.c_size_t, ll, ll, ll])
             self.hip_gemm_ext_batch_strided = f("hip_gemm_ext_batch_strided", None, [vp, C.POINTER(GemmExtParam), C.c_size_t, ll, ll, ll, ll, ll])

@@ -97,7 +97,7 @@ struct SpmmArgs {
   const char* x; char* y;
   long long ld_x, ld_y;                               // row strides in elements
   long long outer_x, outer_y;                         // slab strides in elements
-  long long ncols; int rows, inner, nouter;
+  long long ncols; int rows, inner, nouter; unsigned int nnz;
   int dtype, beta0, skip_empty, vals_are_f64;
 };
 
@@ -107,6 +107,20 @@ struct BcscArgs {
   int M, N, K, m_blocks, bk, bn, nblk_n;
   int a_type, c_type, vnni_a, beta0;
 };
+
+// ---- run-time specialised sparse kernels (jit.cpp) ------------------------------------------------------
+struct SpmmJitSpec {              // everything the generated kernel bakes in; pointers are HOST arrays
+  int dtype, rows, inner, nouter, beta0, skip_empty;
+  const unsigned int* ptr; const unsigned int* idx; const unsigned int* vmap;
+  long long ld_x, ld_y, outer_x, outer_y, ncols;   // elements
+};
+struct JitKernel;
+JitKernel* jit_spmm_create(const SpmmJitSpec& spec, std::string* why);
+bool jit_spmm_usable(const JitKernel* k, const void* x, const void* y);
+int jit_spmm_launch(JitKernel* k, const void* vals, const void* x, void* y, void* stream);
+void jit_release(JitKernel* k);
+const char* jit_name(const JitKernel* k);
+size_t jit_code_size(const JitKernel* k);
 
 // ---- host-side kernel context ------------------------------------------------------------------
 struct KernelCtx {
@@ -122,6 +136,7 @@ struct KernelCtx {
   unsigned int* d_ptr = nullptr; unsigned int* d_idx = nullptr; void* d_vals = nullptr;  // device pattern (+ baked values)
   unsigned int* d_vmap = nullptr;   // value position per pattern entry (B-sparse CSR regrouped by column)
   int sp_ncols = 0, sp_skip_empty = 0;
+  JitKernel* jit = nullptr;         // pattern-specialised kernel (nullptr: precompiled kernels serve)
   int device = 0;
   const char* kname_single = "";
   const char* kname_batched = "";

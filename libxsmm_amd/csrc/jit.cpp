@@ -1,0 +1,247 @@
+// jit.cpp -- run-time specialisation of the fixed-pattern sparse kernels.
+//
+// The reference is a JIT: libxsmm_create_packed_spgemm_csr/_csc and libxsmm_create_spgemm_csr_areg emit machine code
+// with the sparsity pattern unrolled into the instruction stream [ref: src/generator_packed_spgemm_csr_asparse_avx_
+// avx2_avx512.c:336-470 (one FMA per non-zero, B rows addressed by immediate), src/generator_spgemm_csr_asparse_reg.c].
+// The gfx950 analogue: generate HIP source for exactly this pattern and geometry, compile it with hiprtc for the
+// device's ISA and load it as a module.  What specialisation buys on this machine:
+//   * every X row a lane needs is fetched by ONE vector load into registers, all of them in flight at once
+//     (the pattern tells which rows are touched; untouched rows are never read);
+//   * a non-zero costs exactly one v_(pk_)fma: the X operand is a register picked at code-generation time, the
+//     value is a scalar register filled by batched s_load_dwordx16 from the run-time values array;
+//   * no LDS, no index loads, no loop: the kernel is a straight line of loads, FMAs and coalesced stores, so the
+//     hardware streams X in and Y out at HBM rate.
+// Shapes that do not fit the register budget fall back to the precompiled LDS-staged kernels (sparse_kernels.hip).
+// hiprtc is bound with dlopen so that the library loads on hosts without it (the precompiled kernels then serve).
+#include <hip/hip_runtime_api.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "internal.hpp"
+
+namespace xamd {
+
+struct JitKernel {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  int device = -1;
+  long long total_threads = 0;
+  int vec = 1, elem = 4;
+  size_t code_size = 0;
+  int refs = 1;
+  std::string key, name;
+};
+
+namespace {
+
+struct Rtc {
+  void* lib = nullptr;
+  decltype(&hiprtcCreateProgram) create = nullptr;
+  decltype(&hiprtcCompileProgram) compile = nullptr;
+  decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+  decltype(&hiprtcGetProgramLog) log = nullptr;
+  decltype(&hiprtcGetCodeSize) code_size = nullptr;
+  decltype(&hiprtcGetCode) code = nullptr;
+  decltype(&hiprtcDestroyProgram) destroy = nullptr;
+  bool tried = false, ok = false;
+};
+Rtc g_rtc;
+std::mutex g_jit_lock;
+std::unordered_map<std::string, JitKernel*> g_jit_cache;
+
+bool rtc_ready() {
+  if (g_rtc.tried) return g_rtc.ok;
+  g_rtc.tried = true;
+  const char* names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+  for (const char* n : names) { g_rtc.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rtc.lib) break; }
+  if (!g_rtc.lib) return false;
+#define BIND_(field, sym) g_rtc.field = (decltype(g_rtc.field))dlsym(g_rtc.lib, sym)
+  BIND_(create, "hiprtcCreateProgram"); BIND_(compile, "hiprtcCompileProgram"); BIND_(log_size, "hiprtcGetProgramLogSize");
+  BIND_(log, "hiprtcGetProgramLog"); BIND_(code_size, "hiprtcGetCodeSize"); BIND_(code, "hiprtcGetCode"); BIND_(destroy, "hiprtcDestroyProgram");
+#undef BIND_
+  g_rtc.ok = g_rtc.create && g_rtc.compile && g_rtc.log_size && g_rtc.log && g_rtc.code_size && g_rtc.code && g_rtc.destroy;
+  return g_rtc.ok;
+}
+
+void append(std::string& s, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+void append(std::string& s, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt);
+  const int n = std::vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (n > 0) s.append(buf, (size_t)(n < (int)sizeof(buf) ? n : (int)sizeof(buf) - 1));
+}
+
+// Pick the widest per-lane vector that (a) keeps every row segment aligned, (b) keeps the touched X rows in registers,
+// and (c) still leaves enough waves to cover the chip when the column axis is short.
+int choose_vec(const SpmmJitSpec& s, int touched, int elem) {
+  const int words = elem / 4;
+  const int cands[3] = {16 / elem, 8 / elem, 1};
+  int best = 0;
+  for (int ci = 0; ci < 3; ++ci) {
+    const int e = cands[ci];
+    if (e < 1 || (ci > 0 && e == cands[ci - 1])) continue;
+    if (s.ncols % e || s.ld_x % e || s.ld_y % e || s.outer_x % e || s.outer_y % e) continue;
+    if ((long long)touched * e * words > 176) continue;
+    if (!best) best = e;
+    const long long waves = (s.ncols / e) * (long long)s.nouter / 64;
+    if (waves >= 2048) return e;           // enough parallelism at this width
+  }
+  if (!best) return 0;
+  // short axis: the narrowest admissible width maximises the number of waves
+  for (int ci = 2; ci >= 0; --ci) {
+    const int e = cands[ci];
+    if (e < 1) continue;
+    if (s.ncols % e || s.ld_x % e || s.ld_y % e || s.outer_x % e || s.outer_y % e) continue;
+    if ((long long)touched * e * words > 176) continue;
+    return e;
+  }
+  return best;
+}
+
+std::string generate_spmm(const SpmmJitSpec& s, int vec, long long* total_threads) {
+  const bool f64 = (s.dtype == LIBXSMM_DATATYPE_F64);
+  const char* T = f64 ? "double" : "float";
+  const unsigned int nnz = s.ptr[s.rows];
+  std::vector<char> touched((size_t)s.inner, 0);
+  for (unsigned int z = 0; z < nnz; ++z) touched[s.idx[z]] = 1;
+  const long long tpo = s.ncols / vec;
+  *total_threads = tpo * s.nouter;
+  std::string src;
+  src.reserve(4096 + (size_t)nnz * 64);
+  append(src, "// generated by libxsmm_amd: rows=%d inner=%d nnz=%u ncols=%lld outer=%d vec=%d %s beta0=%d\n", s.rows, s.inner, nnz, s.ncols, s.nouter, vec, T, s.beta0);
+  append(src, "typedef %s T;\n", T);
+  if (vec > 1) append(src, "typedef T V __attribute__((ext_vector_type(%d)));\n", vec); else src += "typedef T V;\n";
+  src += "#define GM __attribute__((address_space(1)))\n#define CM __attribute__((address_space(4)))\n";
+  src += "extern \"C\" __global__ __launch_bounds__(256) void spmm_jit(const void* vals_, const void* x_, void* y_) {\n";
+  append(src, "  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n  if (t >= %lldLL) return;\n", *total_threads);
+  if (s.nouter > 1) {
+    append(src, "  const long long o = t / %lldLL, c = t - o * %lldLL;\n", tpo, tpo);
+    append(src, "  GM const T* x = (GM const T*)x_ + o * %lldLL + c * %d;\n  GM T* y = (GM T*)y_ + o * %lldLL + c * %d;\n", s.outer_x, vec, s.outer_y, vec);
+  } else {
+    append(src, "  GM const T* x = (GM const T*)x_ + t * %d;\n  GM T* y = (GM T*)y_ + t * %d;\n", vec, vec);
+  }
+  src += "  CM const T* v = (CM const T*)vals_;\n";
+  for (int k = 0; k < s.inner; ++k) if (touched[k]) append(src, "  const V x%d = *(GM const V*)(x + %lldLL);\n", k, (long long)k * s.ld_x);
+  // rows that are written: non-empty ones, and empty ones when beta=0 demands zeros [ref: asparse generator :336-345 skips them]
+  std::vector<int> live;
+  for (int r = 0; r < s.rows; ++r) {
+    const bool empty = s.ptr[r] == s.ptr[r + 1];
+    if (empty && (s.skip_empty || !s.beta0)) continue;
+    live.push_back(r);
+  }
+  const int ahead = 6;                       // beta=1: old C rows are requested this many rows before they are needed
+  if (!s.beta0) for (size_t i = 0; i < live.size() && i < (size_t)ahead; ++i) append(src, "  V c%d = *(GM const V*)(y + %lldLL);\n", live[i], (long long)live[i] * s.ld_y);
+  src += "  V acc;\n";
+  for (size_t i = 0; i < live.size(); ++i) {
+    const int r = live[i];
+    if (!s.beta0 && i + ahead < live.size()) append(src, "  V c%d = *(GM const V*)(y + %lldLL);\n", live[i + ahead], (long long)live[i + ahead] * s.ld_y);
+    const unsigned int z0 = s.ptr[r], z1 = s.ptr[r + 1];
+    if (!s.beta0) append(src, "  acc = c%d;\n", r);
+    else if (z0 == z1) src += "  acc = (V)(T)0;\n";
+    for (unsigned int z = z0; z < z1; ++z) {
+      const unsigned int vz = s.vmap ? s.vmap[z] : z;
+      if (s.beta0 && z == z0) append(src, "  acc = (V)v[%u] * x%u;\n", vz, s.idx[z]);
+      else append(src, "  acc = __builtin_elementwise_fma((V)v[%u], x%u, acc);\n", vz, s.idx[z]);
+    }
+    append(src, "  *(GM V*)(y + %lldLL) = acc;\n", (long long)r * s.ld_y);
+  }
+  src += "}\n";
+  return src;
+}
+
+}  // namespace
+
+JitKernel* jit_spmm_create(const SpmmJitSpec& s, std::string* why) {
+  auto fail = [&](const char* msg) -> JitKernel* { if (why) *why = msg; return nullptr; };
+  const unsigned int nnz = s.ptr[s.rows];
+  if (nnz == 0 || nnz > 16384u || s.rows > 4096) return fail("pattern outside the JIT envelope");
+  const int elem = (s.dtype == LIBXSMM_DATATYPE_F64) ? 8 : 4;
+  std::vector<char> seen((size_t)s.inner, 0); int touched = 0;
+  for (unsigned int z = 0; z < nnz; ++z) if (!seen[s.idx[z]]) { seen[s.idx[z]] = 1; ++touched; }
+  const int vec = choose_vec(s, touched, elem);
+  if (vec == 0) return fail("touched X rows exceed the register budget");
+  std::lock_guard<std::mutex> guard(g_jit_lock);
+  if (!rtc_ready()) return fail("hiprtc is not available");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail("no current device");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("device properties unavailable");
+  long long total = 0;
+  const std::string src = generate_spmm(s, vec, &total);
+  if ((total + 255) / 256 >= (1ll << 31)) return fail("grid too large");
+  const std::string key = std::to_string(dev) + ":" + src;
+  auto it = g_jit_cache.find(key);
+  if (it != g_jit_cache.end()) { ++it->second->refs; return it->second; }
+  const auto t_start = std::chrono::steady_clock::now();
+  hiprtcProgram prog = nullptr;
+  if (g_rtc.create(&prog, src.c_str(), "spmm_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail("hiprtcCreateProgram failed");
+  const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+  const char* opts[] = {arch.c_str(), "-O3", "-ffp-contract=off"};
+  const hiprtcResult rc = g_rtc.compile(prog, 3, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0; (void)g_rtc.log_size(prog, &n);
+    std::string log(n, '\0'); if (n) (void)g_rtc.log(prog, &log[0]);
+    if (why) *why = "hiprtc compile failed: " + log;
+    (void)g_rtc.destroy(&prog);
+    return nullptr;
+  }
+  const auto t_compiled = std::chrono::steady_clock::now();
+  size_t csz = 0; (void)g_rtc.code_size(prog, &csz);
+  std::vector<char> code(csz);
+  (void)g_rtc.code(prog, code.data());
+  (void)g_rtc.destroy(&prog);
+  JitKernel* k = new JitKernel();
+  if (hipModuleLoadData(&k->mod, code.data()) != hipSuccess || hipModuleGetFunction(&k->fn, k->mod, "spmm_jit") != hipSuccess) {
+    (void)hipGetLastError();
+    if (k->mod) (void)hipModuleUnload(k->mod);
+    delete k;
+    return fail("hipModuleLoadData failed");
+  }
+  if (libxsmm_verbosity >= 3 || libxsmm_verbosity < 0) {
+    const auto t_loaded = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "LIBXSMM-AMD: hiprtc %.0f ms, module load %.0f ms, %zu bytes of source\n", std::chrono::duration<double, std::milli>(t_compiled - t_start).count(),
+                 std::chrono::duration<double, std::milli>(t_loaded - t_compiled).count(), src.size());
+  }
+  k->device = dev; k->total_threads = total; k->vec = vec; k->elem = elem; k->code_size = csz; k->key = key;
+  k->name = std::string("spmm_jit<") + (elem == 8 ? "f64" : "f32") + ",vec" + std::to_string(vec) + ",nnz" + std::to_string(nnz) + ">";
+  g_jit_cache.emplace(key, k);
+  return k;
+}
+
+bool jit_spmm_usable(const JitKernel* k, const void* x, const void* y) {
+  if (!k) return false;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != k->device) return false;
+  const size_t mask = (size_t)k->vec * k->elem - 1;
+  return (((size_t)x | (size_t)y) & mask) == 0;
+}
+
+int jit_spmm_launch(JitKernel* k, const void* vals, const void* x, void* y, void* stream) {
+  void* args[3] = {(void*)&vals, (void*)&x, (void*)&y};
+  const unsigned int grid = (unsigned int)((k->total_threads + 255) / 256);
+  return (int)hipModuleLaunchKernel(k->fn, grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+}
+
+void jit_release(JitKernel* k) {
+  if (!k) return;
+  std::lock_guard<std::mutex> guard(g_jit_lock);
+  if (--k->refs > 0) return;
+  g_jit_cache.erase(k->key);
+  (void)hipModuleUnload(k->mod);
+  delete k;
+}
+
+const char* jit_name(const JitKernel* k) { return k ? k->name.c_str() : ""; }
+size_t jit_code_size(const JitKernel* k) { return k ? k->code_size : 0; }
+
+}  // namespace xamd

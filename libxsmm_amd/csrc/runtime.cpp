@@ -132,6 +132,7 @@ void free_ctx_locked(KernelCtx* c) {
   if (c->d_idx) (void)hipFree(c->d_idx);
   if (c->d_vals) (void)hipFree(c->d_vals);
   if (c->d_vmap) (void)hipFree(c->d_vmap);
+  if (c->jit) jit_release(c->jit);
   g_slots[c->slot] = nullptr; g_free_slots.push_back(c->slot);
   delete c;
 }
@@ -303,29 +304,39 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
   finish_launch(err, kname);
 }
 
-void run_spmm(KernelCtx* k, const void* param) {
-  const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
+// geometry of the generic  Y[r][q] (+)= sum val * X[idx][q]  form for a sparse context (shared by run_spmm and the JIT)
+static void spmm_geometry(const KernelCtx* k, SpmmArgs& a) {
   const libxsmm_gemm_descriptor& d = k->g;
   const long long P = k->packed_width;
-  SpmmArgs a{};
-  a.ptr = k->d_ptr; a.idx = k->d_idx; a.vmap = k->d_vmap;
-  a.dtype = d.a_type; a.beta0 = (d.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 1 : 0;
-  a.rows = k->sp_rows; a.inner = k->sp_inner;
   if (k->kind == K_SPMM_ASPARSE) {
-    if (k->d_vals) { a.vals = k->d_vals; a.vals_are_f64 = (d.a_type == LIBXSMM_DATATYPE_F32) ? 1 : 0; }   // baked (areg / FsSpMDM)
-    else a.vals = p->a.primary;                                                                                 // run-time values
-    a.x = (const char*)p->b.primary; a.y = (char*)p->c.primary;
     a.ld_x = (long long)d.ldb * P; a.ld_y = (long long)d.ldc * P; a.ncols = (long long)k->sp_ncols * P;
-    a.nouter = 1; a.skip_empty = k->sp_skip_empty;
+    a.outer_x = a.outer_y = 0; a.nouter = 1; a.skip_empty = k->sp_skip_empty;
   } else {   // B sparse: one slab per row m of the packed A/C
-    a.vals = p->b.primary;
-    a.x = (const char*)p->a.primary; a.y = (char*)p->c.primary;
     a.ld_x = P; a.ld_y = P; a.ncols = P; a.outer_x = (long long)d.lda * P; a.outer_y = (long long)d.ldc * P;
     a.nouter = (int)d.m; a.skip_empty = 0;
   }
+  a.dtype = d.a_type; a.beta0 = (d.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 1 : 0;
+  a.rows = k->sp_rows; a.inner = k->sp_inner; a.nnz = k->sp_nnz;
+}
+
+void run_spmm(KernelCtx* k, const void* param) {
+  const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
+  SpmmArgs a{};
+  spmm_geometry(k, a);
+  a.ptr = k->d_ptr; a.idx = k->d_idx; a.vmap = k->d_vmap;
+  if (k->kind == K_SPMM_ASPARSE) {
+    a.vals = k->d_vals ? k->d_vals : p->a.primary;        // baked (areg / FsSpMDM) or run-time values
+    a.x = (const char*)p->b.primary; a.y = (char*)p->c.primary;
+  } else {
+    a.vals = p->b.primary;
+    a.x = (const char*)p->a.primary; a.y = (char*)p->c.primary;
+  }
   if (!a.vals || !a.x || !a.y) { set_error(-2, "sparse kernel called with a NULL operand"); return; }
   const char* kname = nullptr;
-  const int err = launch_spmm(a, tls().stream, &kname);
+  int err;
+  if (jit_spmm_usable(k->jit, a.x, a.y)) { kname = jit_name(k->jit); err = jit_spmm_launch(k->jit, a.vals, a.x, a.y, tls().stream); }
+  else err = launch_spmm(a, tls().stream, &kname);
+  if (kname) k->kname_single = k->kname_batched = kname;
   finish_launch(err, kname);
 }
 
@@ -341,14 +352,21 @@ void run_bcsc(KernelCtx* k, const void* param) {
   a.a = (const char*)p->a.primary; a.bvals = (const char*)p->b.primary; a.c = (char*)p->c.primary;
   a.colptr = (const unsigned int*)device_visible(p->b.secondary, (size_t)(nblk_n + 1) * sizeof(unsigned int));
   if (!a.colptr) { set_error(-2, "BCSC kernel needs colptr in b.secondary"); return; }
-  // number of stored blocks = colptr[nblk_n]: only known on the device side for device arrays; stage a generous host read otherwise
+  // rowidx: a device array is used in place (no size needed, no host round trip -> capturable in a hipGraph); a host
+  // array is staged, its length colptr[nblk_n] being host-readable in that case
   {
-    hipPointerAttribute_t attr; unsigned int nnzb = 0;
-    const bool host_readable = !(hipPointerGetAttributes(&attr, p->b.secondary) == hipSuccess && attr.type == hipMemoryTypeDevice);
+    hipPointerAttribute_t attr;
+    const bool idx_on_device = (hipPointerGetAttributes(&attr, p->b.tertiary) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged));
     (void)hipGetLastError();
-    if (host_readable) nnzb = ((const unsigned int*)p->b.secondary)[nblk_n];
-    else { (void)hipMemcpyAsync(&nnzb, (const unsigned int*)p->b.secondary + nblk_n, sizeof(nnzb), hipMemcpyDeviceToHost, cur_stream()); (void)hipStreamSynchronize(cur_stream()); }
-    a.rowidx = (const unsigned int*)device_visible(p->b.tertiary, (size_t)std::max(1u, nnzb) * sizeof(unsigned int));
+    if (idx_on_device) a.rowidx = (const unsigned int*)p->b.tertiary;
+    else {
+      const bool ptr_on_device = (hipPointerGetAttributes(&attr, p->b.secondary) == hipSuccess && attr.type == hipMemoryTypeDevice);
+      (void)hipGetLastError();
+      unsigned int nnzb = 0;
+      if (!ptr_on_device) nnzb = ((const unsigned int*)p->b.secondary)[nblk_n];
+      else { (void)hipMemcpyAsync(&nnzb, (const unsigned int*)p->b.secondary + nblk_n, sizeof(nnzb), hipMemcpyDeviceToHost, cur_stream()); (void)hipStreamSynchronize(cur_stream()); }
+      a.rowidx = (const unsigned int*)device_visible(p->b.tertiary, (size_t)std::max(1u, nnzb) * sizeof(unsigned int));
+    }
   }
   if (!a.a || !a.bvals || !a.c || !a.rowidx) { set_error(-2, "BCSC kernel called with a NULL operand"); return; }
   const char* kname = nullptr;
@@ -640,9 +658,31 @@ static bool upload_pattern(KernelCtx* c, int rows, int inner, const unsigned int
   const unsigned int nnz = ptr[rows];
   for (unsigned int z = 0; z < nnz; ++z) if ((int)idx[z] >= inner) return false;
   c->sp_rows = rows; c->sp_inner = inner; c->sp_nnz = nnz;
+  c->kname_single = c->kname_batched = "spmm_stream_kernel";
   c->d_ptr = to_device(ptr, (size_t)rows + 1); c->d_idx = to_device(idx, nnz);
   if (vmap) c->d_vmap = to_device(vmap, nnz);
   return c->d_ptr && c->d_idx && (!vmap || c->d_vmap);
+}
+
+// specialise the kernel for this pattern.  Mode (libxsmm_hip_set_jit / LIBXSMM_HIP_JIT): 0 never, 1 auto (default: only when
+// one call covers enough columns to repay ~0.1 s of hiprtc), 2 always.  Failure is not an error: precompiled kernels serve.
+static int g_jit_mode = -1;
+static int jit_mode() {
+  if (g_jit_mode < 0) { const char* e = getenv("LIBXSMM_HIP_JIT"); g_jit_mode = (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : 1; }
+  return g_jit_mode;
+}
+static void attach_jit(KernelCtx* c, const unsigned int* ptr, const unsigned int* idx, const unsigned int* vmap) {
+  const int mode = jit_mode();
+  if (mode == 0) return;
+  SpmmArgs a{}; spmm_geometry(c, a);
+  if (mode == 1 && a.ncols * a.nouter < 4096) return;    // ~0.1 s of hiprtc is not repaid by launch-bound toy sizes
+  SpmmJitSpec s{};
+  s.dtype = a.dtype; s.rows = a.rows; s.inner = a.inner; s.nouter = a.nouter; s.beta0 = a.beta0; s.skip_empty = a.skip_empty;
+  s.ptr = ptr; s.idx = idx; s.vmap = vmap; s.ld_x = a.ld_x; s.ld_y = a.ld_y; s.outer_x = a.outer_x; s.outer_y = a.outer_y; s.ncols = a.ncols;
+  std::string why;
+  c->jit = jit_spmm_create(s, &why);
+  if (c->jit) { c->kname_single = c->kname_batched = jit_name(c->jit); vlog(2, "JIT %s (%zu bytes of code)", jit_name(c->jit), jit_code_size(c->jit)); }
+  else vlog(2, "sparse kernel not specialised: %s", why.c_str());
 }
 
 LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_csr(libxsmm_gemm_shape s, libxsmm_bitfield flags, libxsmm_bitfield prefetch,
@@ -661,6 +701,7 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_csr(libxsmm_gemm_s
     c = new_unregistered(K_SPMM_ASPARSE, d); if (!c) return nullptr;
     c->packed_width = packed_width; c->sp_ncols = s.n; c->sp_skip_empty = 1;
     ok = upload_pattern(c, s.m, s.k, row_ptr, column_idx, nullptr);
+    if (ok) attach_jit(c, row_ptr, column_idx, nullptr);
     c->nflops = (unsigned int)(2ull * row_ptr[s.m] * s.n * packed_width);   // [ref: libxsmm_main.c:2356-2359]
   } else if (s.ldb == 0 && s.lda > 0 && s.ldc > 0) {   // B sparse, CSR over rows k -> regroup by output column n
     if (s.lda < s.k || s.ldc < s.n) return nullptr;
@@ -673,10 +714,10 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_csr(libxsmm_gemm_s
     c = new_unregistered(K_SPMM_BSPARSE, d); if (!c) return nullptr;
     c->packed_width = packed_width;
     ok = upload_pattern(c, s.n, s.k, cptr.data(), ridx.data(), vmap.data());
+    if (ok) attach_jit(c, cptr.data(), ridx.data(), vmap.data());
     c->nflops = (unsigned int)(2ull * nnz * s.m * packed_width);
   } else return nullptr;                                 // C sparse: not on the hot path
   if (!ok) { drop_unregistered(c); return nullptr; }
-  c->kname_single = c->kname_batched = "spmm_panel_kernel";
   return (libxsmm_gemmfunction)handle_for_slot(c->slot);
 }
 
@@ -694,8 +735,8 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_csc(libxsmm_gemm_s
   KernelCtx* c = new_unregistered(K_SPMM_BSPARSE, d); if (!c) return nullptr;
   c->packed_width = packed_width;
   if (!upload_pattern(c, s.n, s.k, column_ptr, row_idx, nullptr)) { drop_unregistered(c); return nullptr; }
+  attach_jit(c, column_ptr, row_idx, nullptr);
   c->nflops = (unsigned int)(2ull * column_ptr[s.n] * s.m * packed_width);
-  c->kname_single = c->kname_batched = "spmm_panel_kernel";
   return (libxsmm_gemmfunction)handle_for_slot(c->slot);
 }
 
@@ -739,10 +780,14 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_spgemm_csr_areg(libxsmm_gemm_sha
   KernelCtx* c = new_unregistered(K_SPMM_ASPARSE, d); if (!c) return nullptr;
   c->packed_width = 1; c->sp_ncols = max_N; c->sp_skip_empty = 0;
   bool ok = upload_pattern(c, s.m, s.k, row_ptr, column_idx, nullptr);
-  if (ok) { c->d_vals = to_device(values, row_ptr[s.m]); ok = c->d_vals != nullptr; }
+  if (ok) {   // values arrive as double whatever the kernel's type: convert once, here
+    if (s.a_in_type == LIBXSMM_DATATYPE_F32) { std::vector<float> v32(values, values + row_ptr[s.m]); c->d_vals = to_device(v32.data(), v32.size()); }
+    else c->d_vals = to_device(values, row_ptr[s.m]);
+    ok = c->d_vals != nullptr;
+  }
   if (!ok) { drop_unregistered(c); return nullptr; }
+  attach_jit(c, row_ptr, column_idx, nullptr);
   c->nflops = (unsigned int)(2ull * row_ptr[s.m] * max_N);
-  c->kname_single = c->kname_batched = "spmm_panel_kernel";
   return (libxsmm_gemmfunction)handle_for_slot(c->slot);
 }
 
@@ -786,6 +831,8 @@ LIBXSMM_API int libxsmm_get_registry_info(libxsmm_registry_info* info) {
 
 // ---- libxsmm_hip.h ---------------------------------------------------------------------------------------------------
 LIBXSMM_API int libxsmm_hip_device_count(void) { if (libxsmm_ninit < 2) libxsmm_init(); return g_device_count > 0 ? g_device_count : 0; }
+LIBXSMM_API void libxsmm_hip_set_jit(int mode) { g_jit_mode = (mode < 0 || mode > 2) ? 1 : mode; }
+LIBXSMM_API int libxsmm_hip_get_jit(void) { return jit_mode(); }
 LIBXSMM_API int libxsmm_hip_available(void) { return libxsmm_hip_device_count() > 0 ? 1 : 0; }
 LIBXSMM_API int libxsmm_hip_set_device(int device) {
   if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return -1;

@@ -18,6 +18,7 @@
 // The block-sparse BCSC kernel keeps its pattern at run time (colptr/rowidx arrive with every call)
 // [ref: samples/xgemm_sparse/spmm_kernel.c:423-456].
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "internal.hpp"
 
 namespace xamd {
@@ -93,6 +94,114 @@ static int launch_spmm_t(const SpmmArgs& a, hipStream_t st, const char** name) {
   return (int)hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Streaming form of the same operation (the hot path).  One wave per workgroup owns a slab of
+// 64*E consecutive columns; it
+//   1. fires `inner` LDS-DMA loads (global_load_lds: global -> LDS without touching VGPRs, GL bytes
+//      per lane, NL loads per row) so the whole K x slab slice of X is in flight at once,
+//   2. (first slab only, under the shadow of 1.) copies the pattern into LDS as (k*RB, value) pairs
+//      so that the walk below never waits on a dependent global/scalar load,
+//   3. walks the rows: per non-zero one broadcast ds_read of the pair, one ds_read of its own
+//      column(s), E FMAs; per row one coalesced store.
+// X is read from HBM exactly once and Y written once; nothing is shared between waves, so there is
+// no barrier, and occupancy (160 KiB LDS / (inner*RB + pattern)) supplies the load/compute overlap.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct PatPair;
+template <> struct PatPair<float> { unsigned int koff; float v; };
+template <> struct __attribute__((aligned(16))) PatPair<double> { unsigned int koff; unsigned int pad; double v; };
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int GL> __device__ __forceinline__ void glds(GM const char* src, char* lds_dst);   // lane-linear LDS destination
+template <> __device__ __forceinline__ void glds<4>(GM const char* src, char* lds_dst) { __builtin_amdgcn_global_load_lds((GM const void*)src, (lds_ptr_t)lds_dst, 4, 0, 0); }
+template <> __device__ __forceinline__ void glds<16>(GM const char* src, char* lds_dst) { __builtin_amdgcn_global_load_lds((GM const void*)src, (lds_ptr_t)lds_dst, 16, 0, 0); }
+
+template <typename T, int GL, int NL>
+__global__ __launch_bounds__(64) void spmm_stream_kernel(SpmmArgs p, unsigned int slabs_per_outer, unsigned int total_slabs) {
+  constexpr int RB = 64 * GL * NL;                         // staged bytes per X row
+  constexpr int E = GL * NL / (int)sizeof(T);              // columns per lane
+  typedef T vec_t __attribute__((ext_vector_type(E)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile = smem;                                                        // [inner][RB]
+  PatPair<T>* pairs = (PatPair<T>*)(smem + (size_t)p.inner * RB);            // [nnz]
+  unsigned int* rp = (unsigned int*)(pairs + p.nnz);                         // [rows + 1]
+  const int lane = threadIdx.x;
+  const long long ldx_b = p.ld_x * (long long)sizeof(T), ldy = p.ld_y;
+  bool first = true;
+  for (unsigned int s = blockIdx.x; s < total_slabs; s += gridDim.x) {
+    const unsigned int outer = s / slabs_per_outer, cs = s - outer * slabs_per_outer;
+    const long long q0 = (long long)cs * (64 * E);
+    const long long left = p.ncols - q0;                                     // > 0
+    const int valid_b = (int)(left * (long long)sizeof(T) < (long long)RB ? left * (long long)sizeof(T) : (long long)RB);
+    GM const char* xb = (GM const char*)p.x + ((long long)outer * p.outer_x + q0) * (long long)sizeof(T) + lane * GL;
+    for (int k = 0; k < p.inner; ++k) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        if (j * 64 * GL + lane * GL < valid_b)
+          glds<GL>(xb + (long long)k * ldx_b + j * 64 * GL, tile + k * RB + j * 64 * GL);
+      }
+    }
+    if (first) {
+      first = false;
+      GM const unsigned int* ptr = (GM const unsigned int*)p.ptr;
+      GM const unsigned int* idx = (GM const unsigned int*)p.idx;
+      GM const unsigned int* vmap = (GM const unsigned int*)p.vmap;
+      for (unsigned int z = lane; z < p.nnz; z += 64) {
+        PatPair<T> pr;
+        pr.koff = idx[z] * (unsigned int)RB;
+        pr.v = load_val<T>(p.vals, vmap ? vmap[z] : z, p.vals_are_f64);
+        pairs[z] = pr;
+      }
+      for (int r = lane; r <= p.rows; r += 64) rp[r] = ptr[r];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const bool active = (long long)lane * E < left;                          // ncols % E == 0 by construction
+    GM T* yb = (GM T*)p.y + (long long)outer * p.outer_y + q0 + lane * E;
+    const char* mine = tile + lane * (E * (int)sizeof(T));
+    for (int r = 0; r < p.rows; ++r) {
+      const unsigned int z0 = rp[r], z1 = rp[r + 1];
+      if (z0 == z1 && (p.skip_empty || !p.beta0)) continue;                  // untouched row
+      GM vec_t* yp = (GM vec_t*)(yb + (long long)r * ldy);
+      vec_t old;
+      if (!p.beta0 && active) old = *yp;
+      vec_t acc = (vec_t)(T)0;
+#pragma unroll 4
+      for (unsigned int z = z0; z < z1; ++z) {
+        const PatPair<T> pr = pairs[z];
+        const vec_t xv = *(const vec_t*)(mine + pr.koff);
+        acc = __builtin_elementwise_fma((vec_t)pr.v, xv, acc);
+      }
+      if (active) { if (!p.beta0) acc += old; *yp = acc; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // every LDS read retired before the tile is refilled
+  }
+}
+
+static int g_num_cus = 0;
+template <typename T, int GL, int NL>
+static int launch_spmm_stream(const SpmmArgs& a, hipStream_t st, const char** name, const char* label) {
+  constexpr int RB = 64 * GL * NL;
+  constexpr int E = GL * NL / (int)sizeof(T);
+  const size_t lds = (size_t)a.inner * RB + (size_t)a.nnz * sizeof(PatPair<T>) + ((size_t)a.rows + 1) * sizeof(unsigned int);
+  if (lds > 160 * 1024) return -1;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)spmm_stream_kernel<T, GL, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  if (g_num_cus == 0) {
+    int dev = 0, cus = 0; (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    g_num_cus = cus;
+  }
+  const long long per_outer = (a.ncols + 64 * E - 1) / (64 * E);
+  const long long total = per_outer * a.nouter;
+  if (per_outer >= (1ll << 31) || total >= (1ll << 31)) return -1;
+  long long resident = (long long)(160 * 1024 / lds); if (resident > 32) resident = 32;
+  long long grid = (long long)g_num_cus * resident;
+  if (grid > total) grid = total;
+  hipLaunchKernelGGL((spmm_stream_kernel<T, GL, NL>), dim3((unsigned int)grid), dim3(64), lds, st, a, (unsigned int)per_outer, (unsigned int)total);
+  if (name) *name = label;
+  return (int)hipGetLastError();
+}
+
 int launch_spmm(const SpmmArgs& a, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
   if (a.ncols <= 0 || a.rows <= 0 || a.nouter <= 0) { if (name) *name = "(empty)"; return 0; }
@@ -103,6 +212,21 @@ int launch_spmm(const SpmmArgs& a, void* stream, const char** name) {
     return (a.ncols % vec == 0) && (a.ld_x % vec == 0) && (a.ld_y % vec == 0) && (a.outer_x % vec == 0) && (a.outer_y % vec == 0) &&
            ((unsigned long long)(size_t)a.x % bytes == 0) && ((unsigned long long)(size_t)a.y % bytes == 0);
   };
+  // streaming kernel first (pattern + K x slab slice in LDS); the panel kernel below takes what does not fit
+  {
+    static const int variant = []() { const char* e = getenv("LIBXSMM_HIP_SPMM_VARIANT"); return e ? atoi(e) : 0; }();
+    int rc = -1;
+    if (variant >= 0 && a.nnz > 0) {
+      if (a.dtype == LIBXSMM_DATATYPE_F64) {
+        if (variant == 1 && aligned(2)) rc = launch_spmm_stream<double, 16, 1>(a, st, name, "spmm_stream_kernel<f64,16x1>");
+        if (rc < 0) rc = launch_spmm_stream<double, 4, 2>(a, st, name, "spmm_stream_kernel<f64,4x2>");
+      } else {
+        if (variant == 1 && aligned(4)) rc = launch_spmm_stream<float, 16, 1>(a, st, name, "spmm_stream_kernel<f32,16x1>");
+        if (rc < 0) rc = launch_spmm_stream<float, 4, 1>(a, st, name, "spmm_stream_kernel<f32,4x1>");
+      }
+      if (rc >= 0) return rc;
+    }
+  }
   if (a.dtype == LIBXSMM_DATATYPE_F64) {
     if (aligned(2)) return launch_spmm_t<double, 2>(a, st, name);
     return launch_spmm_t<double, 1>(a, st, name);

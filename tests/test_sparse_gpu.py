@@ -21,6 +21,16 @@ pytestmark = pytest.mark.gpu
 NP = {DT.F32: np.float32, DT.F64: np.float64}
 
 
+@pytest.fixture(params=[0, 2], ids=["precompiled", "jit"])
+def jit_mode(request):
+    """Both implementations of the fixed-pattern kernels: the precompiled LDS-staged kernels (0) and the
+    pattern-specialised hiprtc kernels (2: always)."""
+    api = capi.load()
+    api.hip_set_jit(request.param)
+    yield request.param
+    api.hip_set_jit(1)
+
+
 def _dev(x):
     import torch
     if x.dtype == np.uint16:
@@ -42,7 +52,7 @@ def _host(t, dtype):
     (20, 3, 50, 33, 0.1, 1),           # odd packed width -> scalar lanes
     (192, 4, 96, 64, 0.02, 0),         # has empty rows: C rows must stay untouched even with beta=0
 ])
-def test_packed_csr_asparse(dt, M, N, K, P, density, beta0):
+def test_packed_csr_asparse(dt, M, N, K, P, density, beta0, jit_mode):
     api, orc = capi.load(), pyoracle.oracle()
     rng = np.random.default_rng(42)
     rowptr, colidx = random_csr(rng, M, K, density)
@@ -67,13 +77,15 @@ def test_packed_csr_asparse(dt, M, N, K, P, density, beta0):
         assert np.array_equal(got.reshape(M, N * P)[r], C0.reshape(M, N * P)[r])
     info = capi.KernelInfo()
     assert api.get_kernel_info(h, C.byref(info)) == 0 and info.nflops == 2 * len(colidx) * N * P
+    name = api.hip_kernel_name(h, 0).decode()
+    assert name.startswith("spmm_jit") == (jit_mode == 2), name
     api.release_kernel(h)
 
 
 @pytest.mark.parametrize("fmt", ["csc", "csr"])
 @pytest.mark.parametrize("dt", [DT.F32, DT.F64])
 @pytest.mark.parametrize("M,N,K,P,density,beta0", [(9, 35, 20, 64, 0.2, 0), (9, 4, 84, 16, 0.1, 1), (5, 12, 7, 10, 0.5, 0)])
-def test_packed_bsparse(fmt, dt, M, N, K, P, density, beta0):
+def test_packed_bsparse(fmt, dt, M, N, K, P, density, beta0, jit_mode):
     api, orc = capi.load(), pyoracle.oracle()
     rng = np.random.default_rng(7)
     rowptr, colidx = random_csr(rng, K, N, density)              # B is K x N
@@ -104,7 +116,7 @@ def test_packed_bsparse(fmt, dt, M, N, K, P, density, beta0):
 
 @pytest.mark.parametrize("dt", [DT.F32, DT.F64])
 @pytest.mark.parametrize("M,N,K,density,beta", [(35, 4800, 35, 0.15, 0.0), (192, 480, 96, 0.03, 1.0), (28, 64, 49, 0.14, 0.0)])
-def test_fsspmdm(dt, M, N, K, density, beta):
+def test_fsspmdm(dt, M, N, K, density, beta, jit_mode):
     api, orc = capi.load(), pyoracle.oracle()
     rng = np.random.default_rng(3)
     rowptr, colidx = random_csr(rng, M, K, density)

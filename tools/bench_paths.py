@@ -1,0 +1,240 @@
+#!/usr/bin/env python
+"""Roofline measurements for every hot-path row of SURVEY.md section 8 other than the headline config
+(which bench.py owns).  One JSON line per workload; same timing method as bench.py (hipGraph of K launches,
+HIP events on the launch stream, inputs rotated so that every launch streams from HBM).
+Usage: python tools/bench_paths.py [--only csr,fsspmdm,bcsc,fused,meltw,gemm] [--steps K]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from libxsmm_amd import capi  # noqa: E402
+from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, GEMM_FLAG, UNARY, UNARY_FLAG  # noqa: E402
+from sparse_helpers import pack_vnni2, structured_2_of_8  # noqa: E402
+
+L3 = 256 * 2 ** 20
+DEV = None
+
+
+def dev(x):
+    v = {np.uint16: np.int16, np.uint32: np.int32, np.uint64: np.int64}.get(x.dtype.type)
+    return torch.from_numpy(np.ascontiguousarray(x.view(v) if v else x)).to(DEV)
+
+
+def rnd(n, dtype=torch.float32):
+    v = torch.randint(-4, 6, (n,), device=DEV).to(torch.float32) / 10
+    if dtype == "bf16":
+        return (v.view(torch.int32) >> 16).to(torch.int16)
+    return v.to(dtype)
+
+
+class Work:
+    """step(i) launches once on input set i % nsets."""
+    def __init__(self, api, name, flops, alg_bytes, nsets, step, kernel=lambda: ""):
+        self.api, self.name, self.flops, self.alg_bytes, self.nsets, self._step, self.kernel = api, name, flops, alg_bytes, nsets, step, kernel
+
+    def step(self, i):
+        self._step(i % self.nsets)
+
+
+def nsets_for(set_bytes, cap_bytes=24 * 2 ** 30):
+    return int(max(2, min(np.ceil(2.2 * L3 / set_bytes), cap_bytes // set_bytes)))
+
+
+def random_pattern(M, K, nnz, seed=555):
+    rng = np.random.default_rng(seed)
+    pos = np.sort(rng.choice(M * K, size=nnz, replace=False))
+    rows, cols = pos // K, pos % K
+    rowptr = np.zeros(M + 1, dtype=np.uint32)
+    np.add.at(rowptr, rows + 1, 1)
+    return np.cumsum(rowptr).astype(np.uint32), cols.astype(np.uint32), ((rng.integers(-4, 6, nnz)) / 10.0)
+
+
+def csr_asparse(api, P, density, N=35, dtype=DT.F32):
+    M = K = 35
+    nnz = int(round(M * K * density))
+    rowptr, colidx, vals = random_pattern(M, K, nnz)
+    es, tdt, npdt = (4, torch.float32, np.float32) if dtype == DT.F32 else (8, torch.float64, np.float64)
+    h = api.create_packed_spgemm_csr(capi.gemm_shape(M, N, K, 0, N, N, dtype, dtype, dtype, dtype), GEMM_FLAG.BETA_0, 0, P,
+                                     rowptr.ctypes.data, colidx.ctypes.data, vals.astype(npdt).ctypes.data)
+    assert h
+    kt, mne = len(set(colidx.tolist())), int((np.diff(rowptr.astype(np.int64)) > 0).sum())
+    set_bytes = (K + M) * N * P * es
+    ns = nsets_for(set_bytes)
+    dv = dev(vals.astype(npdt))
+    Bs = [rnd(K * N * P, tdt) for _ in range(ns)]
+    Cs = [torch.zeros(M * N * P, dtype=tdt, device=DEV) for _ in range(ns)]
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = dv.data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(); ps.append(p)
+    w = Work(api, f"packed_spgemm_csr A-sparse {M}x{K} nnz={nnz} ({100*density:.0f}%) N={N} P={P} {'f32' if es == 4 else 'f64'} beta=0",
+             2.0 * nnz * N * P, float((kt * N + mne * N) * P * es + nnz * es), ns, lambda s: capi.Api.call(h, ps[s]), lambda: api.hip_kernel_name(h, 0).decode())
+    w.keep = (dv, Bs, Cs, ps, rowptr, colidx)
+    return w
+
+
+def fsspmdm(api, N, density, dtype=DT.F64, beta=0.0):
+    M = K = 35
+    nnz = int(round(M * K * density))
+    rowptr, colidx, vals = random_pattern(M, K, nnz)
+    a = np.zeros((M, K))
+    for i in range(M):
+        a[i, colidx[rowptr[i]:rowptr[i + 1]]] = vals[rowptr[i]:rowptr[i + 1]]
+    es, tdt, npdt, ct = (4, torch.float32, np.float32, C.c_float) if dtype == DT.F32 else (8, torch.float64, np.float64, C.c_double)
+    a = np.ascontiguousarray(a.astype(npdt))
+    al, be = ct(1.0), ct(beta)
+    h = api.fsspmdm_create(dtype, M, N, K, K, N, N, C.addressof(al), C.addressof(be), a.ctypes.data, 0, None)
+    assert h
+    set_bytes = (K + M) * N * es
+    ns = nsets_for(set_bytes)
+    Bs = [rnd(K * N, tdt) for _ in range(ns)]
+    Cs = [torch.zeros(M * N, dtype=tdt, device=DEV) for _ in range(ns)]
+    w = Work(api, f"fsspmdm {M}x{K} nnz={nnz} ({100*density:.0f}%) N={N} {'f32' if es == 4 else 'f64'} beta={beta:g}",
+             2.0 * nnz * N, float(es * (K * N + M * N * (1 + (beta != 0)))), ns,
+             lambda s: api.fsspmdm_execute(h, Bs[s].data_ptr(), Cs[s].data_ptr()))
+    w.keep = (Bs, Cs, a)
+    return w
+
+
+def bcsc(api, m_blocks=8192, M=64, K=256, N=64, bk=32, bn=16):
+    colptr, rowidx = structured_2_of_8(K, N, bk, bn)
+    nnzb = len(rowidx)
+    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(m_blocks, 0, K, K, 0, N, DT.BF16, DT.BF16, DT.BF16, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    set_bytes = m_blocks * M * (K + N) * 2
+    ns = nsets_for(set_bytes)
+    As = [rnd(m_blocks * K * M, "bf16") for _ in range(ns)]
+    Cs = [torch.zeros(m_blocks * N * M, dtype=torch.int16, device=DEV) for _ in range(ns)]
+    bv, dcp, dri = rnd(nnzb * bk * bn, "bf16"), dev(colptr), dev(rowidx)
+    nblk = C.c_ulonglong(N // bn)
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = As[s].data_ptr(), bv.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), Cs[s].data_ptr()
+        ps.append(p)
+    w = Work(api, f"packed_spgemm_bcsc bf16 2:8 M={M} K={K} N={N} bk={bk} bn={bn} m_blocks={m_blocks} beta=0",
+             2.0 * M * m_blocks * bk * bn * nnzb, float(m_blocks * M * (K * 2 + N * 2) + nnzb * bk * bn * 2), ns, lambda s: capi.Api.call(h, ps[s]),
+             lambda: api.hip_kernel_name(h, 0).decode())
+    w.dense_equiv_flops = 2.0 * M * m_blocks * N * K
+    w.keep = (As, Cs, bv, dcp, dri, nblk, ps)
+    return w
+
+
+def brgemm(api, m, dtype, batch, fused=0, br=1, beta=0):
+    a = argparse.Namespace(m=m, dtype=dtype, batch=batch, br=br, beta=beta, fused=fused, sets=0)
+    bw = bench.Workload(a, DEV)
+    set_bytes = batch * (2 * br + 1) * bw.a_bytes
+    if set_bytes * bw.nsets > 40 * 2 ** 30:
+        raise RuntimeError("too large")
+    w = Work(api, f"stride-BRGEMM {dtype} m=n=k={m} batch={batch} br={br} beta={beta}" + (" + colbias+ReLU (ext)" if fused else ""),
+             bw.flops_per_step, bw.alg_bytes_per_step, bw.nsets, bw.step, lambda: api.hip_kernel_name(bw.handle, 1).decode())
+    w.keep = bw
+    return w
+
+
+def meltw_relu_tiles(api, batch=2 ** 17, m=64):
+    """config #5 un-fused: bias-add (binary, col-bcast) then ReLU (unary) over bf16 64x64 tiles."""
+    hb = api.dispatch_meltw_binary(BINARY.ADD, capi.BinaryShape(m, m, m, m, m, DT.BF16, DT.BF16, DT.BF16, DT.F32), BINARY_FLAG.BCAST_COL_IN_0)
+    hu = api.dispatch_meltw_unary(UNARY.RELU, capi.UnaryShape(m, m, m, m, DT.BF16, DT.BF16, DT.F32), 0)
+    assert hb and hu
+    tile = m * m * 2
+    ns = nsets_for(batch * tile * 2)
+    X = [rnd(batch * m * m, "bf16") for _ in range(ns)]
+    Y = [torch.zeros(batch * m * m, dtype=torch.int16, device=DEV) for _ in range(ns)]
+    bias = rnd(m, "bf16")
+    pb, pu = [], []
+    for s in range(ns):
+        p = capi.BinaryParam(); p.in0.primary, p.in1.primary, p.out.primary = bias.data_ptr(), X[s].data_ptr(), Y[s].data_ptr(); pb.append(p)
+        q = capi.UnaryParam(); q.in_.primary, q.out.primary = X[s].data_ptr(), Y[s].data_ptr(); pu.append(q)
+    wb = Work(api, f"meltw binary ADD bcast-col bias bf16 {m}x{m} tiles x{batch}", float(batch * m * m), float(batch * tile * 2 + m * 2), ns,
+              lambda s: api.hip_meltw_binary_batch_strided(hb, C.byref(pb[s]), batch, 0, tile, tile))
+    wu = Work(api, f"meltw unary RELU bf16 {m}x{m} tiles x{batch}", float(batch * m * m), float(batch * tile * 2), ns,
+              lambda s: api.hip_meltw_unary_batch_strided(hu, C.byref(pu[s]), batch, tile, tile, 0))
+    wb.keep = wu.keep = (X, Y, bias, pb, pu)
+    return [wb, wu]
+
+
+def meltw_big(api, typ, name, m=4096, n=8192, in_dt=DT.F32, out_dt=DT.F32, flags=0):
+    h = api.dispatch_meltw_unary(typ, capi.UnaryShape(m, n, m, n if typ == UNARY.TRANSFORM_NORM_TO_NORMT else m, in_dt, out_dt, DT.F32), flags)
+    assert h, name
+    si, so = (2 if in_dt == DT.BF16 else 4), (2 if out_dt == DT.BF16 else 4)
+    ns = nsets_for(m * n * (si + so))
+    X = [rnd(m * n, "bf16" if si == 2 else torch.float32) for _ in range(ns)]
+    Y = [torch.zeros(m * n, dtype=torch.int16 if so == 2 else torch.float32, device=DEV) for _ in range(ns)]
+    ps = []
+    for s in range(ns):
+        q = capi.UnaryParam(); q.in_.primary, q.out.primary = X[s].data_ptr(), Y[s].data_ptr(); ps.append(q)
+    w = Work(api, f"meltw unary {name} {m}x{n}", float(m * n), float(m * n * (si + so)), ns, lambda s: capi.Api.call(h, ps[s]))
+    w.keep = (X, Y, ps)
+    return w
+
+
+def measure(w, steps):
+    for i in range(5):
+        w.step(i)
+    torch.cuda.synchronize(); w.api.check()
+    _, us = bench.timed(w, steps, lambda: None, rotate=True)
+    w.api.check()
+    gbs = w.alg_bytes / (us * 1e-6) / 1e9
+    out = {"workload": w.name, "kernel": w.kernel(), "kernel_us": round(us, 2), "GFLOP/s": round(w.flops / us / 1e3, 1),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / bench.HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": int(w.alg_bytes)}, "input_sets_rotated": w.nsets, "steps": steps}
+    if hasattr(w, "dense_equiv_flops"):
+        out["dense_equiv_GFLOP/s"] = round(w.dense_equiv_flops / us / 1e3, 1)
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    global DEV
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="gemm,csr,fsspmdm,bcsc,fused,meltw")
+    ap.add_argument("--steps", type=int, default=50)
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    DEV = torch.device("cuda", 0)
+    api = capi.load()
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    only = set(args.only.split(","))
+    makers = []
+    if "gemm" in only:
+        makers += [lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 65536), lambda: brgemm(api, 64, "f32", 16384),
+                   lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8),
+                   lambda: brgemm(api, 32, "bf16", 65536), lambda: brgemm(api, 64, "bf16", 32768)]
+    if "fused" in only:
+        makers += [lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
+    if "csr" in only:
+        makers += [lambda: csr_asparse(api, 4096, 0.15), lambda: csr_asparse(api, 65536, 0.15), lambda: csr_asparse(api, 65536, 0.10),
+                   lambda: csr_asparse(api, 65536, 0.15, dtype=DT.F64)]
+    if "fsspmdm" in only:
+        makers += [lambda: fsspmdm(api, 4800, 0.15), lambda: fsspmdm(api, 2 ** 20, 0.15), lambda: fsspmdm(api, 2 ** 20, 0.15, DT.F32),
+                   lambda: fsspmdm(api, 2 ** 20, 0.15, DT.F64, 1.0)]
+    if "bcsc" in only:
+        makers += [lambda: bcsc(api), lambda: bcsc(api, bk=32, bn=32)]
+    if "meltw" in only:
+        makers += [lambda: meltw_relu_tiles(api), lambda: meltw_big(api, UNARY.IDENTITY, "IDENTITY f32"),
+                   lambda: meltw_big(api, UNARY.IDENTITY, "IDENTITY f32->bf16", out_dt=DT.BF16),
+                   lambda: meltw_big(api, UNARY.TRANSFORM_NORM_TO_NORMT, "TRANSPOSE f32"),
+                   lambda: meltw_big(api, UNARY.TRANSFORM_NORM_TO_VNNI2, "NORM_TO_VNNI2 bf16", in_dt=DT.BF16, out_dt=DT.BF16)]
+    for mk in makers:
+        try:
+            ws = mk()
+        except Exception as e:   # a workload that cannot be built is reported, not hidden
+            print(json.dumps({"error": repr(e)}), flush=True)
+            continue
+        for w in (ws if isinstance(ws, list) else [ws]):
+            measure(w, args.steps)
+        del ws
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
