@@ -23,6 +23,8 @@
 // so they are organised as streaming kernels: many independent waves, each with its whole tile
 // (8-24 KiB) of loads in flight, no barriers, no LDS.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <utility>
 #include "internal.hpp"
 
 // a*b+c below means two roundings unless fma()/MFMA is spelled out: parity with the reference's C
@@ -42,6 +44,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: the body sees its index as a constant (no reliance on #pragma unroll, which the optimizer
+// declines for bodies with convergent operations -- a dynamic index into an accumulator array means scratch memory)
+template <typename F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -301,53 +308,77 @@ __device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const 
   }
 }
 
-// One output element group: registers (r-1, r) of a bf16 tile are written as packed dwords (neighbouring
-// lanes (i, i+1) exchange one value so that every lane stores a full dword), everything else element-wise.
-template <bool EXACT, bool CF32, bool ACT>
+// Hardware RNE conversion of two f32 to a packed bf16 pair (v_cvt_pk_bf16_f32).  Differs from the reference's
+// software rounding [ref: src/libxsmm_math.c:684-704] only for f32 denormal inputs (|x| < 1.2e-38 is not flushed
+// to zero first) and in the payload of NaNs; used in GEMM epilogues, whose parity bar is a norm, not bit equality.
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwbf16x2));
+}
+template <int ACT> __device__ __forceinline__ float act_fixed(float x) {
+  if (ACT == 1 || ACT == 2) return (x <= 0.0f) ? 0.0f : x;
+  if (ACT == 3) return __frcp_rn(1.0f + __expf(-x));
+  return x;
+}
+
+// Tile store.  ACT is the fused activation (0 none, 1 ReLU, 2 ReLU + bitmask, 3 sigmoid), fixed at compile time so the
+// streaming variants carry no activation code.  bf16 output of exact tiles goes out as packed dwords: registers
+// (2g, 2g+1) hold rows (j, j+1) of column i; one v_cvt_pk_bf16_f32 packs them, one DPP quad swap fetches the
+// neighbouring lane's pair and one v_perm_b32 (lane-parity dependent selector) forms (i, i+1) of row j in even
+// lanes and of row j+1 in odd lanes: 3 VALU + 1 dword store per two values.
+template <bool EXACT, bool CF32, int ACT>
 __device__ __forceinline__ void tile_store_impl(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
   const int lane = threadIdx.x & 63;
   const long long mask_ld = ((p.ldc + 15) / 16) * 16;
   const bool out_f32 = CF32 || (p.c_type == LIBXSMM_DATATYPE_F32);
-  const int act = ACT ? p.act : 0;
   // bf16 fast path needs an even ldc and a 4-byte aligned C
   const bool pack2 = EXACT && !out_f32 && ((p.ldc & 1) == 0) && ((((unsigned long long)(size_t)q.c) & 3ull) == 0ull);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int j = t.j0 + jl_of(r, t.h);
-    const bool ok = EXACT || (t.ivalid && j < p.n);
-    const float x = acc[r];
-    const float y = ACT ? act_apply(act, x) : x;
-    if (ACT && act == 2 && q.mask) {
-      const unsigned long long pos = __ballot(ok && !(x <= 0.0f));
-      const unsigned long long val = __ballot(ok);
-      if ((lane & 7) == 0 && ok) {
-        GM unsigned char* byte = q.mask + t.i / 8 + (long long)j * (mask_ld / 8);
-        const unsigned char vm = (unsigned char)((val >> lane) & 0xffu), nb = (unsigned char)((pos >> lane) & 0xffu);
-        *byte = EXACT ? nb : (unsigned char)((*byte & ~vm) | (nb & vm));
-      }
-    }
-    if (out_f32) {
-      if (ok) ((GM float*)q.c)[(long long)j * p.ldc + t.i] = y;
-    } else if (!pack2) {
-      if (ok) ((GM unsigned short*)q.c)[(long long)j * p.ldc + t.i] = f32_to_bf16_rne(y);
-    } else if ((r & 1) == 1) {
-      const float y0 = ACT ? act_apply(act, acc[r - 1]) : acc[r - 1];
-      const bool odd = (lane & 1) != 0;
-      const unsigned int mine0 = f32_to_bf16_rne(y0), mine1 = f32_to_bf16_rne(y);
-      const unsigned int send = odd ? mine0 : mine1;
-      const unsigned int recv = (unsigned int)__shfl_xor((int)send, 1);
-      const unsigned int word = odd ? ((recv & 0xffffu) | (mine1 << 16)) : ((mine0 & 0xffffu) | (recv << 16));
-      const int jj = odd ? j : (t.j0 + jl_of(r - 1, t.h));
-      *(GM unsigned int*)((GM unsigned short*)q.c + (long long)jj * p.ldc + (t.i & ~1)) = word;
+  if (ACT == 2) {
+    if (q.mask) {
+      static_for<16>([&](auto rc) {
+        constexpr int r = rc.value;
+        const int j = t.j0 + jl_of(r, t.h);
+        const bool ok = EXACT || (t.ivalid && j < p.n);
+        const unsigned long long pos = __ballot(ok && !(acc[r] <= 0.0f));
+        const unsigned long long val = __ballot(ok);
+        if ((lane & 7) == 0 && ok) {
+          GM unsigned char* byte = q.mask + t.i / 8 + (long long)j * (mask_ld / 8);
+          const unsigned char vm = (unsigned char)((val >> lane) & 0xffu), nb = (unsigned char)((pos >> lane) & 0xffu);
+          *byte = EXACT ? nb : (unsigned char)((*byte & ~vm) | (nb & vm));
+        }
+      });
     }
   }
+  if (!CF32 && pack2) {
+    const bool odd = (lane & 1) != 0;
+    const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
+    GM unsigned short* base = (GM unsigned short*)q.c + (long long)(t.j0 + 4 * t.h + (odd ? 1 : 0)) * p.ldc + (t.i & ~1);
+    static_for<8>([&](auto gc) {
+      constexpr int g = gc.value, r0 = 2 * g, jr = (r0 & 3) + 8 * (r0 >> 2);
+      const unsigned int w = cvt_pk_bf16(act_fixed<ACT>(acc[r0]), act_fixed<ACT>(acc[r0 + 1]));
+      const unsigned int n = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+      *(GM unsigned int*)(base + (long long)jr * p.ldc) = __builtin_amdgcn_perm(n, w, sel);
+    });
+    return;
+  }
+  static_for<16>([&](auto rc) {
+    constexpr int r = rc.value;
+    const int j = t.j0 + jl_of(r, t.h);
+    const bool ok = EXACT || (t.ivalid && j < p.n);
+    const float y = act_fixed<ACT>(acc[r]);
+    if (out_f32) { if (ok) ((GM float*)q.c)[(long long)j * p.ldc + t.i] = y; }
+    else if (ok) ((GM unsigned short*)q.c)[(long long)j * p.ldc + t.i] = f32_to_bf16_rne(y);
+  });
 }
-// The plain store (no activation) is the streaming hot path and is kept free of the activation / bitmask
-// code: a wave-uniform branch picks the compact variant.
+// wave-uniform dispatch on the activation
 template <bool EXACT, bool CF32>
 __device__ __forceinline__ void tile_store(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
-  if (p.act == 0) tile_store_impl<EXACT, CF32, false>(acc, p, q, t);
-  else tile_store_impl<EXACT, CF32, true>(acc, p, q, t);
+  if (p.act == 0) tile_store_impl<EXACT, CF32, 0>(acc, p, q, t);
+  else if (p.act == 1) tile_store_impl<EXACT, CF32, 1>(acc, p, q, t);
+  else if (p.act == 2) tile_store_impl<EXACT, CF32, 2>(acc, p, q, t);
+  else tile_store_impl<EXACT, CF32, 3>(acc, p, q, t);
 }
 
 // wave -> (batch element, tile) decomposition shared by the MFMA kernels
@@ -648,10 +679,86 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
               __builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0);
     }
   }
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]); });
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 streaming kernel: exact tiles, VNNI-2 A, flat B with 16-byte aligned columns.  Same arithmetic as
+// gemm_mfma_bf16_kernel<MT,NT,true>; what differs is how B reaches the matrix core.  The MFMA operand wants
+// 8 consecutive k of ONE column per lane, i.e. lanes 128 bytes apart in memory: fetched directly, every load
+// instruction touches 32 cache lines for 16 bytes each and the tile is re-fetched from L2 several times.
+// Here the 32-deep K chunk of the B tile is brought in with LDS-DMA (global_load_lds_dwordx4: four lanes
+// cover the 64 bytes of one column, whole rows per instruction, no VGPRs), the 16-byte slots XOR-swizzled on
+// the SOURCE side (the DMA destination is lane-linear) so that the per-column ds_read_b128 is conflict free.
+// A (VNNI-2: a dword = two k of one row, rows contiguous) is already coalesced and goes straight to VGPRs.
+// The LDS image is wave-private: no barrier, only s_waitcnt.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_vptr;
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  char* lds = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  f32x16 acc[MT][NT];
+  TileCtx tc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) tile_store<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]);
+    for (int nt = 0; nt < NT; ++nt) {
+      tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h;
+      tc[mt][nt].ivalid = true;
+      tile_init<true, false>(acc[mt][nt], p, q, tc[mt][nt]);
+    }
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  // DMA: LDS slot L = lane + 64x holds column f = L>>2, 16-byte piece (L&3) ^ ((f>>1)&3) of the chunk's 64 bytes
+  unsigned int offB[NT * 2];
+#pragma unroll
+  for (int x = 0; x < NT * 2; ++x) {
+    const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
+    offB[x] = (f * ldb) * 2u + pc * 16u;
+  }
+  const unsigned int offA = ((8u * h) * lda + (unsigned int)li) * 4u;      // dword (k-pair 8h, row li); + e*lda*4 + s*4*lda*4
+  const int kchunks = p.k >> 5;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    gcptr bu = br + 2ull * (unsigned long long)job.j0 * ldb;                 // wave-uniform
+    gcptr au = ar + 4ull * (unsigned long long)job.i0;
+    for (int kc = 0; kc < kchunks; ++kc) {
+#pragma unroll
+      for (int x = 0; x < NT * 2; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(bu + 64ull * kc + offB[x]), (lds_vptr)(lds + 1024 * x), 16, 0, 0);
+      u32x4 af[MT][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            af[mt][s][e] = *(GM const unsigned int*)(au + (unsigned long long)(16 * kc + 4 * s + e) * lda * 4ull + 128ull * mt + offA);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      u32x4 bfr[NT][2];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int f = 32 * nt + li;
+          bfr[nt][s] = *(const u32x4*)(lds + f * 64 + (((2 * h + s) ^ ((f >> 1) & 3)) * 16));
+        }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // LDS reads retired before the image is refilled
+    }
+  }
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<true, false>(acc[mt][nt], p, q, tc[mt][nt]); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -744,6 +851,18 @@ static bool operands_aligned16(const GemmArgs& a, int elem_size) {
   return (bits & 15ull) == 0ull;
 }
 
+// B columns 16-byte aligned, A rows dword aligned (always), every offset inside one tile below 4 GiB
+static bool bf16_stream_ok(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_STREAM"); return e && e[0] == '0'; }();
+  if (off || a.list_a || a.br_mode == 1 || a.br_mode == 2) return false;
+  const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) |
+    (unsigned long long)((long long)a.ldb * 2);
+  if (bits & 15ull) return false;
+  const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0);
+  if (abits & 3ull) return false;
+  return (long long)a.lda * a.k * 2 < (1ll << 31) && (long long)a.ldb * a.n * 2 < (1ll << 31);
+}
+
 int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   const GemmArgs& a0 = a_in;
   hipStream_t st = (hipStream_t)stream;
@@ -782,12 +901,14 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_BF16_1x1:
       grid = wave_grid(32, 32);
-      if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true>), grid, dim3(256), 0, st, a);
+      if (pl.exact && bf16_stream_ok(a)) { if (kernel_name) *kernel_name = "gemm_bf16_stream_kernel<1,1>"; hipLaunchKernelGGL((gemm_bf16_stream_kernel<1, 1>), grid, dim3(256), 0, st, a); }
+      else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), grid, dim3(256), 0, st, a);
       break;
     case P_BF16_2x2:
       grid = wave_grid(64, 64);
-      if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
+      if (pl.exact && bf16_stream_ok(a)) { if (kernel_name) *kernel_name = "gemm_bf16_stream_kernel<2,2>"; hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2>), grid, dim3(256), 0, st, a); }
+      else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
       break;
     default: {
