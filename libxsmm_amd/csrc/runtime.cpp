@@ -371,6 +371,7 @@ void run_bcsc(KernelCtx* k, const void* param) {
   if (!a.a || !a.bvals || !a.c || !a.rowidx) { set_error(-2, "BCSC kernel called with a NULL operand"); return; }
   const char* kname = nullptr;
   const int err = launch_bcsc(a, tls().stream, &kname);
+  if (kname) k->kname_single = k->kname_batched = kname;
   finish_launch(err, kname);
 }
 

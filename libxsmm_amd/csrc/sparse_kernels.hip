@@ -19,6 +19,7 @@
 // [ref: samples/xgemm_sparse/spmm_kernel.c:423-456].
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <utility>
 #include "internal.hpp"
 
 namespace xamd {
@@ -287,9 +288,157 @@ __global__ __launch_bounds__(256) void bcsc_generic_kernel(BcscArgs p) {
   if (p.c_type == LIBXSMM_DATATYPE_F32) ((GM float*)p.c)[cidx] = acc; else ((GM unsigned short*)p.c)[cidx] = f2bf_rne(acc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// BCSC on the matrix cores (bf16, VNNI-2 A, bk % 32 == 0, bn in {16,32,64}, M % 16 == 0).
+// One wave owns (M-block mb, 64 rows i, 64 columns n) of C and keeps it in 64 accumulator VGPRs
+// (up to 4 x 4 tiles of v_mfma_f32_16x16x32_bf16, D[i][n]: lane = column n, registers = 4 consecutive i,
+// so a lane stores 4 consecutive i of one C column as one 8/16-byte access).
+// The pattern arrives with the call, so the wave first inverts it: a wave-private LDS table
+// tbl[n-block][k-block] = block id (or none) plus a bitmask of the k-blocks that matter.  The main loop then
+// runs k-block OUTER: the A operand of a k-block (the only big stream: m_blocks*M*K*2 bytes) is fetched once,
+// straight into MFMA operand registers (VNNI dwords, lanes along i), while the next one is already in flight;
+// the B blocks (k contiguous: a 16 x 32 block is one contiguous 1 KiB load) stay L2 resident.
+// [ref semantics: samples/xgemm_sparse/spmm_kernel.c:74-217]
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef short bf16x8v __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 hwbf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int cvt2(float lo, float hi) {
+  const f32x2v v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwbf16x2v));
+}
+template <typename F, int... Is> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int kBcscTbl = 1024;     // table entries per wave (n-blocks per wave x k-blocks)
+
+template <int BN16>                // bn / 16
+__global__ __launch_bounds__(256) void bcsc_mfma_bf16_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int total) {
+  constexpr int NBL = 4 / BN16;    // n-blocks per wave (64 columns)
+  __shared__ unsigned int tbl_all[4][kBcscTbl];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = blockIdx.x * 4u + wave;
+  if (wid >= total) return;
+  unsigned int* tbl = tbl_all[wave];
+  const unsigned int tn = wid % tiles_n, tmp = wid / tiles_n, ti = tmp % tiles_i, mb = tmp / tiles_i;
+  const int lane = threadIdx.x & 63, lx = lane & 15, kg = lane >> 4;
+  const int i0 = (int)ti * 64, n0 = (int)tn * 64;
+  const int mt = (p.M - i0 >= 64) ? 4 : (p.M - i0) / 16;                  // i-tiles of this wave
+  const int nbl_cnt = ((p.N - n0 >= 64) ? 64 : (p.N - n0)) / (16 * BN16);  // n-blocks of this wave
+  const int nb0 = n0 / (16 * BN16);
+  const int nkb = p.K / p.bk, steps = p.bk / 32;
+  GM const unsigned int* colptr = (GM const unsigned int*)p.colptr;
+  GM const unsigned int* rowidx = (GM const unsigned int*)p.rowidx;
+  // ---- invert the pattern for this wave's columns ----
+  for (int e = lane; e < nbl_cnt * nkb; e += 64) tbl[e] = 0xffffffffu;
+  for (int nbl = 0; nbl < nbl_cnt; ++nbl) {
+    const unsigned int c0 = colptr[nb0 + nbl], c1 = colptr[nb0 + nbl + 1];
+    for (unsigned int b = c0 + lane; b < c1; b += 64) tbl[nbl * nkb + rowidx[b]] = b;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // ---- accumulators ----
+  f32x4v acc[4][4];                                                        // [n-tile][i-tile]
+  const bool c_f32 = (p.c_type == LIBXSMM_DATATYPE_F32);
+  GM char* cbase = (GM char*)p.c + ((long long)mb * p.N * p.M) * (c_f32 ? 4 : 2);
+  sfor<16>([&](auto ic) {
+    constexpr int nt = ic.value / 4, it = ic.value % 4;
+    acc[nt][it] = (f32x4v)0.0f;
+    if (!p.beta0 && it < mt && nt < nbl_cnt * BN16) {
+      const long long e = (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg;
+      if (c_f32) acc[nt][it] = *(GM const f32x4v*)(cbase + e * 4);
+      else {
+        const u32x2v v = *(GM const u32x2v*)(cbase + e * 2);
+        acc[nt][it][0] = __uint_as_float(v[0] << 16); acc[nt][it][1] = __uint_as_float(v[0] & 0xffff0000u);
+        acc[nt][it][2] = __uint_as_float(v[1] << 16); acc[nt][it][3] = __uint_as_float(v[1] & 0xffff0000u);
+      }
+    }
+  });
+  // ---- A operand of chunk (k-block kb, step): lane (row i = lx, k group kg) holds 8 consecutive k = 4 VNNI dwords ----
+  GM const unsigned int* A2 = (GM const unsigned int*)p.a + (long long)mb * (p.K / 2) * p.M + i0 + lx;
+  auto load_a = [&](u32x4v (&dst)[4], int kb, int st) {
+    const long long kp0 = (long long)kb * (p.bk / 2) + 16 * st + 4 * kg;
+    sfor<4>([&](auto tc) {
+      constexpr int t = tc.value;
+      if (t < mt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[t][e] = A2[(kp0 + e) * p.M + 16 * t];
+      }
+    });
+  };
+  GM const char* bv = (GM const char*)p.bvals;
+  u32x4v a_cur[4], a_nxt[4];
+  for (int kgp = 0; kgp < nkb; kgp += 64) {
+    // k-blocks of this group that any of the wave's n-blocks uses
+    bool used = false;
+    const int kb_l = kgp + lane;
+    if (kb_l < nkb) for (int nbl = 0; nbl < nbl_cnt; ++nbl) used = used || (tbl[nbl * nkb + kb_l] != 0xffffffffu);
+    unsigned long long mask = __ballot(used);
+    if (mask == 0ull) continue;
+    int kb = kgp + (int)__builtin_ctzll(mask); mask &= mask - 1ull;
+    int st = 0;
+    load_a(a_cur, kb, 0);
+    for (;;) {
+      // next chunk: next step of this k-block, else the next used k-block
+      int kb_n = kb, st_n = st + 1; bool more = true;
+      if (st_n == steps) { st_n = 0; if (mask != 0ull) { kb_n = kgp + (int)__builtin_ctzll(mask); mask &= mask - 1ull; } else more = false; }
+      if (more) load_a(a_nxt, kb_n, st_n);
+      sfor<NBL>([&](auto nc) {
+        constexpr int nbl = nc.value;
+        if (nbl < nbl_cnt) {
+          const unsigned int blk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tbl[nbl * nkb + kb]);
+          if (blk != 0xffffffffu) {
+            sfor<BN16>([&](auto sc) {
+              constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
+              const u32x4v bfrag = *(GM const u32x4v*)(bv + (((long long)blk * (16 * BN16) + 16 * s2 + lx) * p.bk + 32 * st + 8 * kg) * 2);
+              sfor<4>([&](auto tc) {
+                constexpr int t = tc.value;
+                if (t < mt) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a_cur[t]), __builtin_bit_cast(bf16x8v, bfrag), acc[nt][t], 0, 0, 0);
+              });
+            });
+          }
+        }
+      });
+      if (!more) break;
+      sfor<4>([&](auto tc) { a_cur[tc.value] = a_nxt[tc.value]; });
+      kb = kb_n; st = st_n;
+    }
+  }
+  // ---- store: lane = column n, 4 consecutive i per accumulator ----
+  sfor<16>([&](auto ic) {
+    constexpr int nt = ic.value / 4, it = ic.value % 4;
+    if (it < mt && nt < nbl_cnt * BN16) {
+      const long long e = (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg;
+      if (c_f32) *(GM f32x4v*)(cbase + e * 4) = acc[nt][it];
+      else { u32x2v v; v[0] = cvt2(acc[nt][it][0], acc[nt][it][1]); v[1] = cvt2(acc[nt][it][2], acc[nt][it][3]); *(GM u32x2v*)(cbase + e * 2) = v; }
+    }
+  });
+}
+
 int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
   if (a.m_blocks <= 0 || a.M <= 0 || a.N <= 0) { if (name) *name = "(empty)"; return 0; }
+  // matrix-core path: bf16 with VNNI-2 A, 32-deep k steps, 16-wide n sub-tiles, 16-row i tiles, 8-byte aligned C columns
+  {
+    static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_MFMA"); return e && e[0] == '0'; }();
+    const int nbl_per_wave = (a.bn > 0 && 64 % a.bn == 0) ? 64 / a.bn : 0;
+    const bool shape_ok = a.a_type == LIBXSMM_DATATYPE_BF16 && a.vnni_a && a.bk % 32 == 0 && (a.bn == 16 || a.bn == 32 || a.bn == 64) && a.M % 16 == 0 &&
+      (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTbl && ((size_t)a.a % 4 == 0) && ((size_t)a.bvals % 16 == 0) && ((size_t)a.c % 16 == 0);
+    if (!off && shape_ok) {
+      const unsigned int tiles_i = (unsigned int)((a.M + 63) / 64), tiles_n = (unsigned int)((a.N + 63) / 64);
+      const long long total = (long long)tiles_i * tiles_n * a.m_blocks;
+      if (total < (1ll << 31)) {
+        const dim3 grid((unsigned int)((total + 3) / 4));
+        if (a.bn == 16) hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<1>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
+        else if (a.bn == 32) hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
+        else hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
+        if (name) *name = "bcsc_mfma_bf16_kernel";
+        return (int)hipGetLastError();
+      }
+    }
+  }
   const long long blocks = (long long)((a.M + 63) / 64) * a.N * a.m_blocks;
   hipLaunchKernelGGL(bcsc_generic_kernel, dim3((unsigned int)((blocks + 3) / 4)), dim3(64, 4), 0, st, a);
   if (name) *name = "bcsc_generic_kernel";

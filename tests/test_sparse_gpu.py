@@ -147,7 +147,8 @@ def test_fsspmdm(dt, M, N, K, density, beta, jit_mode):
 
 
 @pytest.mark.parametrize("a_type,c_type,vnni", [(DT.F32, DT.F32, 0), (DT.BF16, DT.BF16, 1), (DT.BF16, DT.F32, 1), (DT.BF16, DT.BF16, 0)])
-@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep,beta0", [(64, 64, 256, 6, 32, 16, 0.25, 1), (64, 64, 256, 3, 32, 32, 0.25, 0), (16, 24, 40, 4, 8, 8, 0.5, 1), (32, 32, 64, 2, 16, 4, 0.42, 0)])
+@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep,beta0", [(64, 64, 256, 6, 32, 16, 0.25, 1), (64, 64, 256, 3, 32, 32, 0.25, 0), (16, 24, 40, 4, 8, 8, 0.5, 1), (32, 32, 64, 2, 16, 4, 0.42, 0),
+                                                       (48, 80, 128, 3, 64, 16, 0.3, 0), (64, 128, 128, 2, 32, 64, 0.5, 1), (80, 96, 96, 5, 32, 32, 0.34, 1)])
 def test_bcsc(a_type, c_type, vnni, M, N, K, mb, bk, bn, keep, beta0):
     api, orc = capi.load(), pyoracle.oracle()
     rng = np.random.default_rng(11)
