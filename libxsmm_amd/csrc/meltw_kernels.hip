@@ -10,6 +10,7 @@
 // case uses 16-byte (f32x4 / bf16x8) accesses.  The op is a run-time switch: the arithmetic is
 // irrelevant next to the memory traffic.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "internal.hpp"
 
 // a*b+c below means two roundings unless fma()/MFMA is spelled out: parity with the reference's C
@@ -220,6 +221,129 @@ __global__ __launch_bounds__(256) void meltw_unary_vec4_kernel(MeltwArgs p) {
   else { const f32x4 v = *(GM const f32x4*)((GM const float*)in + i + (long long)j * p.ldi); for (int e = 0; e < 4; ++e) x[e] = v[e]; }
   if (BF16) { u16x4 o; for (int e = 0; e < 4; ++e) o[e] = mw_f2bf(unary_math(p.type, x[e], p.scalar_f32)); *(GM u16x4*)((GM unsigned short*)out + i + (long long)j * p.ldo) = o; }
   else { f32x4 o; for (int e = 0; e < 4; ++e) o[e] = unary_math(p.type, x[e], p.scalar_f32); *(GM f32x4*)((GM float*)out + i + (long long)j * p.ldo) = o; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming form of the element-wise TPPs: one thread = 8 consecutive rows of one column (16 bytes of bf16,
+// 32 bytes of f32 per operand), f32/bf16 operands in any mix, every broadcast kind, unary / binary / ternary
+// arithmetic (no bit-matrix in or out).  The per-element arithmetic is the same unary_math / binary_math as the
+// general kernels, so results are bit-identical to them; the f32 -> bf16 store uses v_cvt_pk_bf16_f32, which
+// equals the reference's rounding for every input except f32 denormals (probed over all 2^32 patterns,
+// tools/cvt_probe.hip) -- those are flushed first (DAZ) [ref: src/libxsmm_math.c:684-704].
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+typedef __bf16 mwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float mwf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float mw_daz(float x) { return ((__float_as_uint(x) & 0x7f800000u) == 0u) ? __uint_as_float(__float_as_uint(x) & 0x80000000u) : x; }
+__device__ __forceinline__ unsigned int mw_f2bf_pk(float lo, float hi) {
+  const mwf32x2 v = {mw_daz(lo), mw_daz(hi)};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, mwbf16x2));
+}
+__device__ __forceinline__ void ew8_load(float (&x)[8], gcptr base, int type, int kind, long long i, long long j, long long ld) {
+  if (kind == BC_ROW || kind == BC_SCALAR) {
+    const float v = mw_load(base, kind == BC_ROW ? j * ld : 0, type);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = v;
+    return;
+  }
+  const long long idx = (kind == BC_COL) ? i : i + j * ld;
+  if (type == LIBXSMM_DATATYPE_F32) {
+    const f32x4 a = *(GM const f32x4*)((GM const float*)base + idx), b = *(GM const f32x4*)((GM const float*)base + idx + 4);
+    x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
+  } else {
+    const u32x4e v = *(GM const u32x4e*)((GM const unsigned short*)base + idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(v[e] << 16); x[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+  }
+}
+__device__ __forceinline__ void ew8_store(gptr base, int type, long long idx, const float (&y)[8]) {
+  if (type == LIBXSMM_DATATYPE_F32) {
+    f32x4 a, b; a[0] = y[0]; a[1] = y[1]; a[2] = y[2]; a[3] = y[3]; b[0] = y[4]; b[1] = y[5]; b[2] = y[6]; b[3] = y[7];
+    *(GM f32x4*)((GM float*)base + idx) = a; *(GM f32x4*)((GM float*)base + idx + 4) = b;
+  } else {
+    u32x4e v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = mw_f2bf_pk(y[2 * e], y[2 * e + 1]);
+    *(GM u32x4e*)((GM unsigned short*)base + idx) = v;
+  }
+}
+template <int NIN>
+__global__ __launch_bounds__(256) void meltw_ew8_kernel(MeltwArgs p, unsigned int m8, unsigned int total) {
+  const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= total) return;
+  const unsigned int i8 = gid % m8, t = gid / m8, j = t % (unsigned int)p.n, bidx = t / (unsigned int)p.n;
+  const long long i = 8ll * i8;
+  gptr out = (gptr)p.out + (long long)bidx * p.bs_out;
+  const long long oidx = i + (long long)j * p.ldo;
+  float x0[8], x1[8], x2[8], y[8];
+  ew8_load(x0, (gcptr)p.in0 + (long long)bidx * p.bs_in0, p.in0_type, bcast_kind(p.operation, p.type, p.flags, 0), i, j, p.ldi);
+  if (NIN >= 2) ew8_load(x1, (gcptr)p.in1 + (long long)bidx * p.bs_in1, p.in1_type, bcast_kind(p.operation, p.type, p.flags, 1), i, j, p.ldi1);
+  if (NIN >= 3) ew8_load(x2, (gcptr)p.in2 + (long long)bidx * p.bs_in2, p.in2_type, bcast_kind(p.operation, p.type, p.flags, 2), i, j, p.ldi2);
+  if (NIN == 1) {
+    if (p.type == LIBXSMM_MELTW_TYPE_UNARY_IDENTITY) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = x0[e];
+    } else if (p.type == LIBXSMM_MELTW_TYPE_UNARY_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (x0[e] <= 0.0f) ? 0.0f : x0[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = unary_math(p.type, x0[e], p.scalar_f32);
+    }
+  } else if (NIN == 2) {
+    if (p.type == LIBXSMM_MELTW_TYPE_BINARY_ADD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = x0[e] + x1[e];
+    } else if (p.type == LIBXSMM_MELTW_TYPE_BINARY_MUL) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = x0[e] * x1[e];
+    } else {
+      float prev[8];
+      if (p.type == LIBXSMM_MELTW_TYPE_BINARY_MULADD) ew8_load(prev, (gcptr)out, p.out_type, BC_NONE, i, j, p.ldo);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = binary_math(p.type, x0[e], x1[e], p.type == LIBXSMM_MELTW_TYPE_BINARY_MULADD ? prev[e] : 0.0f);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float prod = (p.type == LIBXSMM_MELTW_TYPE_TERNARY_MULADD) ? x0[e] * x1[e] : x0[e] * x2[e];
+      y[e] = (p.type == LIBXSMM_MELTW_TYPE_TERNARY_MULADD) ? x2[e] + prod : x1[e] - prod;
+    }
+  }
+  ew8_store(out, p.out_type, oidx, y);
+}
+
+static bool is_float_type(int t) { return t == LIBXSMM_DATATYPE_F32 || t == LIBXSMM_DATATYPE_BF16; }
+// is this TPP eligible for meltw_ew8_kernel?
+static bool ew8_ok(const MeltwArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_EW8"); return e && e[0] == '0'; }();
+  if (off || a.m % 8 != 0 || a.ldo % 8 != 0) return false;
+  const int nin = a.operation == LIBXSMM_MELTW_OPERATION_UNARY ? 1 : a.operation == LIBXSMM_MELTW_OPERATION_BINARY ? 2 : 3;
+  if (!is_float_type(a.out_type) || ((size_t)a.out % 16) || ((size_t)a.bs_out % 16)) return false;
+  const void* ptrs[3] = {a.in0, a.in1, a.in2}; const long long lds[3] = {a.ldi, a.ldi1, a.ldi2}; const long long bss[3] = {a.bs_in0, a.bs_in1, a.bs_in2};
+  const int types[3] = {a.in0_type, a.in1_type, a.in2_type};
+  for (int o = 0; o < nin; ++o) {
+    if (!is_float_type(types[o])) return false;
+    const int k = bcast_kind(a.operation, a.type, a.flags, o);
+    if (k == BC_NONE && lds[o] % 8 != 0) return false;
+    if ((k == BC_NONE || k == BC_COL) && (((size_t)ptrs[o] % 16) || ((size_t)bss[o] % 16))) return false;
+  }
+  if ((long long)(a.m / 8) * a.n * (long long)a.nbatch >= (1ll << 32) - 256) return false;
+  if (nin == 1) {
+    switch (a.type) {   // arithmetic TPPs without side channels
+      case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_XOR: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT:
+      case LIBXSMM_MELTW_TYPE_UNARY_TANH: case LIBXSMM_MELTW_TYPE_UNARY_TANH_INV: case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID: case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID_INV:
+      case LIBXSMM_MELTW_TYPE_UNARY_GELU: case LIBXSMM_MELTW_TYPE_UNARY_GELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: case LIBXSMM_MELTW_TYPE_UNARY_INC:
+      case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT: case LIBXSMM_MELTW_TYPE_UNARY_EXP:
+        return true;
+      case LIBXSMM_MELTW_TYPE_UNARY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_ELU:
+        return !(a.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT);
+      default: return false;
+    }
+  }
+  if (nin == 2) return a.type == LIBXSMM_MELTW_TYPE_BINARY_ADD || a.type == LIBXSMM_MELTW_TYPE_BINARY_SUB || a.type == LIBXSMM_MELTW_TYPE_BINARY_MUL ||
+                       a.type == LIBXSMM_MELTW_TYPE_BINARY_DIV || a.type == LIBXSMM_MELTW_TYPE_BINARY_MULADD || a.type == LIBXSMM_MELTW_TYPE_BINARY_MAX || a.type == LIBXSMM_MELTW_TYPE_BINARY_MIN;
+  return a.type == LIBXSMM_MELTW_TYPE_TERNARY_MULADD || a.type == LIBXSMM_MELTW_TYPE_TERNARY_NMULADD;
 }
 
 __global__ __launch_bounds__(256) void meltw_binary_kernel(MeltwArgs p) {
@@ -464,7 +588,6 @@ __global__ __launch_bounds__(256) void reduce_kernel(MeltwArgs p) {
 // ------------------------------------------------------------------------------------------------
 static int payload_size(int t) { return typesize(t); }
 
-static bool is_float_type(int t) { return t == LIBXSMM_DATATYPE_F32 || t == LIBXSMM_DATATYPE_BF16; }
 
 static int xform_mode(int type, int* v) {
   switch (type) {
@@ -555,6 +678,15 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
   if (a.nbatch == 0 || a.m <= 0 || a.n <= 0) { if (name) *name = "(empty)"; return 0; }
   const int sz = payload_size(a.in0_type);
+  if (ew8_ok(a)) {
+    const unsigned int m8 = (unsigned int)(a.m / 8), total = m8 * (unsigned int)a.n * (unsigned int)a.nbatch;
+    const dim3 grid((total + 255u) / 256u);
+    if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY) hipLaunchKernelGGL((meltw_ew8_kernel<1>), grid, dim3(256), 0, st, a, m8, total);
+    else if (a.operation == LIBXSMM_MELTW_OPERATION_BINARY) hipLaunchKernelGGL((meltw_ew8_kernel<2>), grid, dim3(256), 0, st, a, m8, total);
+    else hipLaunchKernelGGL((meltw_ew8_kernel<3>), grid, dim3(256), 0, st, a, m8, total);
+    if (name) *name = "meltw_ew8_kernel";
+    return (int)hipGetLastError();
+  }
   if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY) {
     int v = 0; const int mode = xform_mode(a.type, &v);
     if (a.type == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT) {
