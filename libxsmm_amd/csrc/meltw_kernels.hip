@@ -449,6 +449,65 @@ __global__ __launch_bounds__(256) void transpose_kernel(MeltwArgs p) {
   }
 }
 
+// Vector form of the transpose: 64x64 tiles, 16-byte global accesses on both sides (VEC = 16/S elements per thread
+// access), the element shuffle happens in LDS (row pitch padded by one dword).  Needs m, n, ldi, ldo multiples of VEC
+// and 16-byte aligned bases; tiles at the matrix edge are guarded per vector.
+template <int S>
+__global__ __launch_bounds__(256) void transpose_vec_kernel(MeltwArgs p, unsigned int tm, unsigned int tn) {
+  typedef typename Payload<S>::type T;
+  constexpr int VEC = 16 / S, PITCH = 64 + 4 / S, VPR = 64 / VEC;      // vectors per tile row
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  __shared__ T tile[64 * PITCH];
+  const unsigned int per = tm * tn, bidx = blockIdx.x / per, t = blockIdx.x % per;
+  const int r0 = (int)(t % tm) * 64, c0 = (int)(t / tm) * 64;           // r: along m (contiguous in `in`), c: along n
+  GM const T* in = (GM const T*)((gcptr)p.in0 + (long long)bidx * p.bs_in0);
+  GM T* out = (GM T*)((gptr)p.out + (long long)bidx * p.bs_out);
+#pragma unroll
+  for (int q = 0; q < 64 * VPR / 256; ++q) {
+    const int v = threadIdx.x + 256 * q, cc = v / VPR, rr = (v % VPR) * VEC;
+    if (r0 + rr < p.m && c0 + cc < p.n) {
+      const vec_t x = *(GM const vec_t*)(in + (long long)(c0 + cc) * p.ldi + r0 + rr);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) tile[cc * PITCH + rr + e] = x[e];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 64 * VPR / 256; ++q) {
+    const int v = threadIdx.x + 256 * q, rr = v / VPR, cc = (v % VPR) * VEC;
+    if (r0 + rr < p.m && c0 + cc < p.n) {
+      vec_t y;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) y[e] = tile[(cc + e) * PITCH + rr];
+      *(GM vec_t*)(out + (long long)(r0 + rr) * p.ldo + c0 + cc) = y;
+    }
+  }
+}
+
+// NORM -> VNNI2 of 16-bit payloads without LDS: a thread reads 8 consecutive i of rows 2jp and 2jp+1 (16 bytes each)
+// and writes the 8 interleaved pairs (32 contiguous bytes); i in [m, ldo) and the odd-n pad row are zero filled as the
+// reference does [ref: mateltwise ref :532-557].  Needs m, ldi, ldo multiples of 8 and 16-byte aligned bases.
+__global__ __launch_bounds__(256) void vnni2_vec_kernel(MeltwArgs p, unsigned int o8, unsigned int total) {
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= total) return;
+  const unsigned int np = (unsigned int)(p.n + 1) / 2u;
+  const unsigned int i8 = gid % o8, t = gid / o8, jp = t % np, bidx = t / np;
+  GM const unsigned short* in = (GM const unsigned short*)((gcptr)p.in0 + (long long)bidx * p.bs_in0);
+  GM unsigned int* out = (GM unsigned int*)((gptr)p.out + (long long)bidx * p.bs_out);
+  const long long i = 8ll * i8;
+  u16x8 a = (u16x8)(unsigned short)0, b = (u16x8)(unsigned short)0;
+  if (i < p.m) {
+    a = *(GM const u16x8*)(in + (long long)(2 * jp) * p.ldi + i);
+    if ((int)(2 * jp + 1) < p.n) b = *(GM const u16x8*)(in + (long long)(2 * jp + 1) * p.ldi + i);
+  }
+  u32x4e lo, hi;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { lo[e] = (unsigned int)a[e] | ((unsigned int)b[e] << 16); hi[e] = (unsigned int)a[4 + e] | ((unsigned int)b[4 + e] << 16); }
+  GM unsigned int* dst = out + (long long)jp * p.ldo + i;
+  *(GM u32x4e*)dst = lo; *(GM u32x4e*)(dst + 4) = hi;
+}
+
 // generic index-remapping transforms: one thread per OUTPUT element of the padded extent;
 // `mode` encodes the reference loop nest being restated.
 enum XformMode { XF_NORM_TO_VNNI = 1, XF_VNNI_TO_VNNIT, XF_NORM_TO_VNNIT, XF_VNNIT_TO_NORM, XF_VNNI4_TO_NORM, XF_VNNI4_TO_VNNI2, XF_PAD };
@@ -689,7 +748,20 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
   }
   if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY) {
     int v = 0; const int mode = xform_mode(a.type, &v);
-    if (a.type == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT) {
+    static const bool xvec_off = []() { const char* e = getenv("LIBXSMM_HIP_XFORM_VEC"); return e && e[0] == '0'; }();
+    const bool base16 = ((((size_t)a.in0 | (size_t)a.out | (size_t)a.bs_in0 | (size_t)a.bs_out) & 15) == 0);
+    const int vec = 16 / (sz > 0 ? sz : 1);
+    if (a.type == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT && !xvec_off && base16 && a.m % vec == 0 && a.n % vec == 0 && a.ldi % vec == 0 && a.ldo % vec == 0 &&
+        (long long)((a.m + 63) / 64) * ((a.n + 63) / 64) * a.nbatch < (1ll << 31)) {
+      const unsigned int tm = (unsigned int)((a.m + 63) / 64), tn = (unsigned int)((a.n + 63) / 64);
+      LAUNCH_BY_SIZE(transpose_vec_kernel, sz, dim3(tm * tn * (unsigned int)a.nbatch), dim3(256), st, a, tm, tn);
+      if (name) *name = "transpose_vec_kernel";
+    } else if (mode == XF_NORM_TO_VNNI && v == 2 && sz == 2 && !xvec_off && base16 && a.m % 8 == 0 && a.ldi % 8 == 0 && a.ldo % 8 == 0 &&
+               (long long)(a.ldo / 8) * ((a.n + 1) / 2) * a.nbatch < (1ll << 32) - 256) {
+      const unsigned int o8 = (unsigned int)(a.ldo / 8), total = o8 * (unsigned int)((a.n + 1) / 2) * (unsigned int)a.nbatch;
+      hipLaunchKernelGGL(vnni2_vec_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, a, o8, total);
+      if (name) *name = "vnni2_vec_kernel";
+    } else if (a.type == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT) {
       const long long tiles = (long long)((a.m + 31) / 32) * ((a.n + 31) / 32) * a.nbatch;
       LAUNCH_BY_SIZE(transpose_kernel, sz, dim3((unsigned int)tiles), dim3(256), st, a);
       if (name) *name = "transpose_kernel";

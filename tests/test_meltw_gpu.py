@@ -138,6 +138,10 @@ TRANSFORMS = [
     (UNARY.TRANSFORM_VNNI4_TO_NORM, DT.I8, 12, 8, 12, 12), (UNARY.TRANSFORM_VNNI4_TO_VNNI2, DT.I8, 12, 8, 12, 12),
     (UNARY.TRANSFORM_PADN_MOD2, DT.BF16, 9, 5, 10, 12), (UNARY.TRANSFORM_PADM_MOD2, DT.BF16, 9, 6, 10, 12),
     (UNARY.TRANSFORM_PADNM_MOD4, DT.I8, 9, 6, 10, 12),
+    # vector kernels (16-byte accesses): full and edge tiles, every payload width, odd n with zero-filled pad row
+    (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F32, 128, 96, 128, 96), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F32, 68, 200, 72, 208),
+    (UNARY.TRANSFORM_NORM_TO_NORMT, DT.BF16, 72, 40, 80, 48), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F64, 66, 10, 66, 12), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.I8, 80, 32, 96, 32),
+    (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 64, 7, 64, 72), (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 136, 130, 144, 136),
 ]
 
 
