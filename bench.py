@@ -249,6 +249,20 @@ def main():
     eager_us = eager_kernel_us(work, min(args.steps, 100))
 
     if rank == 0:
+        # HBM traffic per launch from the TCC counters: rocprofv3 --pmc cannot run inside this process, so the number
+        # comes from the committed PMC summary of the same workload (tools/profile_paths.sh, separate FETCH_SIZE /
+        # WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction) -- null when no entry matches.
+        traffic, traffic_src = None, None
+        for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                for w in json.load(open(f))["workloads"]:
+                    if w["algorithmic_bytes_per_launch"] == int(work.alg_bytes_per_step) and w["kernel"].replace(" ", "") == api.hip_kernel_name(work.handle, 1).decode().replace(" ", ""):
+                        traffic, traffic_src = w["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                        break
+            except Exception:
+                continue
+            if traffic is not None:
+                break
         total_flops = work.flops_per_step * args.steps * world
         value = total_flops / elapsed / 1e9
         gbs = work.alg_bytes_per_step / (kernel_us * 1e-6) / 1e9
@@ -263,7 +277,7 @@ def main():
                        "kernel": work.api.hip_kernel_name(work.handle, 1).decode(), "input_sets_rotated": work.nsets, "per_gpu_batch": args.batch},
             "pct_mfma_peak": round(100.0 * value / world / 1e3 / peak_tf, 2),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_us": round(kernel_us, 3), "kernel_us_eager_event_pairs": round(eager_us, 3),
                          "algorithmic_bytes_per_launch": int(work.alg_bytes_per_step),
                          "note": "kernel_us = HIP-event time of the timed region / steps (includes the ~1.5 us inter-kernel boundary)"},

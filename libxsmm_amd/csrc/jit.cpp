@@ -108,7 +108,7 @@ int choose_vec(const SpmmJitSpec& s, int touched, int elem) {
   return best;
 }
 
-std::string generate_spmm(const SpmmJitSpec& s, int vec, long long* total_threads) {
+std::string generate_spmm(const SpmmJitSpec& s, int vec, long long* total_threads, const std::string& fname) {
   const bool f64 = (s.dtype == LIBXSMM_DATATYPE_F64);
   const char* T = f64 ? "double" : "float";
   const unsigned int nnz = s.ptr[s.rows];
@@ -122,7 +122,7 @@ std::string generate_spmm(const SpmmJitSpec& s, int vec, long long* total_thread
   append(src, "typedef %s T;\n", T);
   if (vec > 1) append(src, "typedef T V __attribute__((ext_vector_type(%d)));\n", vec); else src += "typedef T V;\n";
   src += "#define GM __attribute__((address_space(1)))\n#define CM __attribute__((address_space(4)))\n";
-  src += "extern \"C\" __global__ __launch_bounds__(256) void spmm_jit(const void* vals_, const void* x_, void* y_) {\n";
+  src += "extern \"C\" __global__ __launch_bounds__(256) void " + fname + "(const void* vals_, const void* x_, void* y_) {\n";
   append(src, "  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n  if (t >= %lldLL) return;\n", *total_threads);
   if (s.nouter > 1) {
     append(src, "  const long long o = t / %lldLL, c = t - o * %lldLL;\n", tpo, tpo);
@@ -177,7 +177,10 @@ JitKernel* jit_spmm_create(const SpmmJitSpec& s, std::string* why) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("device properties unavailable");
   long long total = 0;
-  const std::string src = generate_spmm(s, vec, &total);
+  // the symbol carries the specialisation so that profiles tell the kernels apart
+  const std::string fname = std::string("spmm_jit_") + (elem == 8 ? "f64" : "f32") + "_v" + std::to_string(vec) + "_r" + std::to_string(s.rows) + "_k" + std::to_string(s.inner) +
+                            "_z" + std::to_string(nnz) + "_b" + std::to_string(s.beta0 ? 0 : 1);
+  const std::string src = generate_spmm(s, vec, &total, fname);
   if ((total + 255) / 256 >= (1ll << 31)) return fail("grid too large");
   const std::string key = std::to_string(dev) + ":" + src;
   auto it = g_jit_cache.find(key);
@@ -201,7 +204,7 @@ JitKernel* jit_spmm_create(const SpmmJitSpec& s, std::string* why) {
   (void)g_rtc.code(prog, code.data());
   (void)g_rtc.destroy(&prog);
   JitKernel* k = new JitKernel();
-  if (hipModuleLoadData(&k->mod, code.data()) != hipSuccess || hipModuleGetFunction(&k->fn, k->mod, "spmm_jit") != hipSuccess) {
+  if (hipModuleLoadData(&k->mod, code.data()) != hipSuccess || hipModuleGetFunction(&k->fn, k->mod, fname.c_str()) != hipSuccess) {
     (void)hipGetLastError();
     if (k->mod) (void)hipModuleUnload(k->mod);
     delete k;
@@ -213,7 +216,7 @@ JitKernel* jit_spmm_create(const SpmmJitSpec& s, std::string* why) {
                  std::chrono::duration<double, std::milli>(t_loaded - t_compiled).count(), src.size());
   }
   k->device = dev; k->total_threads = total; k->vec = vec; k->elem = elem; k->code_size = csz; k->key = key;
-  k->name = std::string("spmm_jit<") + (elem == 8 ? "f64" : "f32") + ",vec" + std::to_string(vec) + ",nnz" + std::to_string(nnz) + ">";
+  k->name = fname;
   g_jit_cache.emplace(key, k);
   return k;
 }

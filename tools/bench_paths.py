@@ -100,7 +100,8 @@ def fsspmdm(api, N, density, dtype=DT.F64, beta=0.0):
     Cs = [torch.zeros(M * N, dtype=tdt, device=DEV) for _ in range(ns)]
     w = Work(api, f"fsspmdm {M}x{K} nnz={nnz} ({100*density:.0f}%) N={N} {'f32' if es == 4 else 'f64'} beta={beta:g}",
              2.0 * nnz * N, float(es * (K * N + M * N * (1 + (beta != 0)))), ns,
-             lambda s: api.fsspmdm_execute(h, Bs[s].data_ptr(), Cs[s].data_ptr()))
+             lambda s: api.fsspmdm_execute(h, Bs[s].data_ptr(), Cs[s].data_ptr()),
+             lambda: api.hip_kernel_name(C.cast(h, C.POINTER(C.c_void_p))[0], 0).decode())     # first member of the handle = the kernel
     w.keep = (Bs, Cs, a)
     return w
 
@@ -178,10 +179,16 @@ def meltw_big(api, typ, name, m=4096, n=8192, in_dt=DT.F32, out_dt=DT.F32, flags
     return w
 
 
-def measure(w, steps):
+def measure(w, steps, eager=0):
     for i in range(5):
         w.step(i)
     torch.cuda.synchronize(); w.api.check()
+    if eager:          # profiling mode (rocprofv3 --pmc): plain launches, no graph, no timing
+        for i in range(eager):
+            w.step(i)
+        torch.cuda.synchronize(); w.api.check()
+        print(json.dumps({"workload": w.name, "kernel": w.kernel(), "eager_launches": eager + 5, "algorithmic_bytes_per_launch": int(w.alg_bytes)}), flush=True)
+        return
     _, us = bench.timed(w, steps, lambda: None, rotate=True)
     w.api.check()
     gbs = w.alg_bytes / (us * 1e-6) / 1e9
@@ -198,6 +205,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="gemm,csr,fsspmdm,bcsc,fused,meltw")
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--eager", type=int, default=0, help="profiling mode: this many plain launches per workload, no timing")
+    ap.add_argument("--headline", action="store_true", help="only the BASELINE configs (#2..#5), one workload each")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     DEV = torch.device("cuda", 0)
@@ -205,6 +214,10 @@ def main():
     api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
     only = set(args.only.split(","))
     makers = []
+    if args.headline:
+        only = set()
+        makers = [lambda: brgemm(api, 32, "f32", 4096), lambda: csr_asparse(api, 65536, 0.15), lambda: csr_asparse(api, 65536, 0.10), lambda: fsspmdm(api, 2 ** 20, 0.15),
+                  lambda: bcsc(api), lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
     if "gemm" in only:
         makers += [lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 65536), lambda: brgemm(api, 64, "f32", 16384),
                    lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8),
@@ -231,7 +244,7 @@ def main():
             print(json.dumps({"error": repr(e)}), flush=True)
             continue
         for w in (ws if isinstance(ws, list) else [ws]):
-            measure(w, args.steps)
+            measure(w, args.steps, args.eager)
         del ws
         torch.cuda.empty_cache()
 
