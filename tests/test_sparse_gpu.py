@@ -78,7 +78,8 @@ def test_packed_csr_asparse(dt, M, N, K, P, density, beta0, jit_mode):
     info = capi.KernelInfo()
     assert api.get_kernel_info(h, C.byref(info)) == 0 and info.nflops == 2 * len(colidx) * N * P
     name = api.hip_kernel_name(h, 0).decode()
-    assert name.startswith("spmm_jit") == (jit_mode == 2), name
+    fits = K * (2 if dt == DT.F64 else 1) <= 176          # touched B rows must fit the register budget of the generated kernel
+    assert name.startswith("spmm_jit") == (jit_mode == 2 and fits), name
     api.release_kernel(h)
 
 
