@@ -44,6 +44,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vptr;
 
 // compile-time loop: the body sees its index as a constant (no reliance on #pragma unroll, which the optimizer
 // declines for bodies with convergent operations -- a dynamic index into an accumulator array means scratch memory)
@@ -564,6 +565,101 @@ __global__ __launch_bounds__(256) void gemm_f32_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// f32 streaming kernel, LDS-DMA form (MT x NT tiles of 32x32 per wave).  Same arithmetic as gemm_f32_stream_kernel;
+// the operand tiles of a 32-deep K chunk travel global -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no
+// ds_write), in the same two LDS images (linear [k][f] for the operand whose free index is contiguous, XOR-swizzled
+// [f][8 x 16 B] for the k-contiguous one -- the swizzle is applied to the SOURCE address because the DMA destination
+// is lane-linear).  Per chunk: wait for the DMA, read the fragments into registers, immediately start the DMA of the
+// NEXT chunk into the same image, then run the MFMAs: the matrix core hides the fetch latency without a second
+// buffer.  That is what lifts the 64x64 tile (two chunks per problem, 64 MFMAs per chunk) off its latency floor.
+// ------------------------------------------------------------------------------------------------
+template <bool KCONTIG>
+__device__ __forceinline__ void frag_read(float (&w)[16], const float* lds, int lane) {
+  const int li = lane & 31, h = lane >> 5;
+  if (!KCONTIG) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w[s] = lds[(2 * s + h) * 32 + li];
+  } else {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 x = ((const f32x4*)lds)[li * 8 + ((4 * h + q) ^ ((li >> 1) & 7))];
+      v[4 * q + 0] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * s]), __float_as_uint(v[2 * s + 1]), false, false);
+      w[s] = __uint_as_float(r[0]); w[s + 8] = __uint_as_float(r[1]);
+    }
+  }
+}
+template <int MT, int NT, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds_all[4][(MT + NT) * 1024];
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  float* lds = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  f32x16 acc[MT][NT];
+  TileCtx tc[MT][NT];
+  static_for<MT * NT>([&](auto idx) {
+    constexpr int mt = idx.value / NT, nt = idx.value % NT;
+    tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h; tc[mt][nt].ivalid = true;
+    tile_init<true, true>(acc[mt][nt], p, q, tc[mt][nt]);
+  });
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  // per-lane byte offset of the 16-byte piece that lands in LDS slot (lane + 64x) of a tile image
+  unsigned int offA[4], offB[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const unsigned int L = (unsigned int)lane + 64u * x, hi = L >> 3, lo = L & 7u;
+    offA[x] = TA ? (hi * lda + ((lo ^ ((hi >> 1) & 7u)) * 4u)) * 4u : (hi * lda + lo * 4u) * 4u;       // TA: k contiguous (swizzled image)
+    offB[x] = TB ? (hi * ldb + lo * 4u) * 4u : (hi * ldb + ((lo ^ ((hi >> 1) & 7u)) * 4u)) * 4u;
+  }
+  // origin of tile (mt / nt) and step per K chunk, bytes
+  const unsigned long long orgA = TA ? 4ull * job.i0 * lda : 4ull * job.i0, tileA = TA ? 128ull * lda : 128ull, kstepA = TA ? 128ull : 128ull * lda;
+  const unsigned long long orgB = TB ? 4ull * job.j0 : 4ull * job.j0 * ldb, tileB = TB ? 128ull : 128ull * ldb, kstepB = TB ? 128ull * ldb : 128ull;
+  const unsigned int kchunks = (unsigned int)p.k >> 5;
+  const unsigned long long total = p.br_count * kchunks;
+  unsigned long long r = 0; unsigned int kc = 0;
+  gcptr ar, br;
+  if (p.br_count != 0) br_base(p, q, 0, ar, br);
+  auto issue = [&](gcptr a0, gcptr b0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(a0 + mt * tileA + offA[x]), (lds_vptr)((char*)lds + 4096 * mt + 1024 * x), 16, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(b0 + nt * tileB + offB[x]), (lds_vptr)((char*)lds + 4096 * (MT + nt) + 1024 * x), 16, 0, 0);
+  };
+  if (total != 0) issue(ar + orgA, br + orgB);
+  for (unsigned long long t = 0; t < total; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float af[MT][16], bf[NT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) frag_read<TA>(af[mt], lds + 1024 * mt, lane);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) frag_read<!TB>(bf[nt], lds + 1024 * (MT + nt), lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (++kc == kchunks) { kc = 0; if (++r < p.br_count) br_base(p, q, r, ar, br); }
+    if (t + 1 < total) issue(ar + orgA + kc * kstepA, br + orgB + kc * kstepB);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0);
+  }
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<true, true>(acc[mt][nt], p, q, tc[mt][nt]); });
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32, 16x16 tiles (v_mfma_f32_16x16x4_f32), NN layout, exact multiples of 16 only.
 // lane = (x = lane&15, g = lane>>4).  Transposed product: operand 1 = B(k, j=x), operand 2 = A(i=x, k);
 // result lane x = i, register q -> j = 4g + q.  k is consumed as 4g + s (not natural order).
@@ -693,7 +789,6 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
 // A (VNNI-2: a dword = two k of one row, rows contiguous) is already coalesced and goes straight to VGPRs.
 // The LDS image is wave-private: no barrier, only s_waitcnt.
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_vptr;
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
@@ -851,6 +946,10 @@ static bool operands_aligned16(const GemmArgs& a, int elem_size) {
   return (bits & 15ull) == 0ull;
 }
 
+static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
+  static const int mode = []() { const char* e = getenv("LIBXSMM_HIP_F32_DMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
+  return mode;
+}
 // B columns 16-byte aligned, A rows dword aligned (always), every offset inside one tile below 4 GiB
 static bool bf16_stream_ok(const GemmArgs& a) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_STREAM"); return e && e[0] == '0'; }();
@@ -881,7 +980,15 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     case P_F32_T16: grid = wave_grid(16, 16); hipLaunchKernelGGL(gemm_mfma_f32_t16_kernel, grid, dim3(256), 0, st, a); break;
     case P_F32_1x1:
       grid = wave_grid(32, 32);
-      if (pl.exact && operands_aligned16(a, 4) && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22)) {
+      if (pl.exact && operands_aligned16(a, 4) && f32_dma_mode() >= 2 && a.lda < (1 << 22) && a.ldb < (1 << 22)) {
+        const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
+        if (kernel_name) *kernel_name = "gemm_f32_dma_kernel<1,1>";
+        if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<1, 1, false, false>), grid, dim3(256), 0, st, a);
+        else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<1, 1, true, false>), grid, dim3(256), 0, st, a);
+        else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<1, 1, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_f32_dma_kernel<1, 1, true, true>), grid, dim3(256), 0, st, a);
+      }
+      else if (pl.exact && operands_aligned16(a, 4) && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22)) {
         const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
         if (kernel_name) *kernel_name = "gemm_f32_stream_kernel";
         if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_stream_kernel<false, false>), grid, dim3(256), 0, st, a);
@@ -895,7 +1002,15 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_F32_2x2:
       grid = wave_grid(64, 64);
-      if (pl.exact && operands_aligned16(a, 4)) launch_f32<2, 2, GM_STAGED>(a, grid, st);
+      if (pl.exact && operands_aligned16(a, 4) && f32_dma_mode() >= 1 && a.lda < (1 << 22) && a.ldb < (1 << 22)) {
+        const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
+        if (kernel_name) *kernel_name = "gemm_f32_dma_kernel<2,2>";
+        if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, false, false>), grid, dim3(256), 0, st, a);
+        else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, true, false>), grid, dim3(256), 0, st, a);
+        else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, true, true>), grid, dim3(256), 0, st, a);
+      }
+      else if (pl.exact && operands_aligned16(a, 4)) launch_f32<2, 2, GM_STAGED>(a, grid, st);
       else if (pl.exact) launch_f32<2, 2, GM_EXACT>(a, grid, st);
       else launch_f32<2, 2, GM_MASKED>(a, grid, st);
       break;

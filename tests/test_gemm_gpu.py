@@ -101,7 +101,8 @@ def test_headline_shape_uses_mfma_tile_kernel():
     name = _check(GemmCase(32, 32, 32, br_type=capi.BR_STRIDE, br_count=1, batch=64, seed=1), expect_kernel="gemm_f32_stream_kernel")      # the lean MFMA 32x32 streaming kernel
     _check(GemmCase(32, 32, 32, lda=33, batch=64, seed=1), expect_kernel="gemm_mfma_f32_kernel<1,1>")
     _check(GemmCase(16, 16, 16, batch=64, seed=2), expect_kernel="t16")
-    _check(GemmCase(64, 64, 64, batch=8, seed=3), expect_kernel="gemm_mfma_f32_kernel<2,2>")
+    _check(GemmCase(64, 64, 64, batch=8, seed=3), expect_kernel="gemm_f32_dma_kernel<2,2>")     # LDS-DMA staged 64x64 tile
+    _check(GemmCase(64, 64, 64, lda=65, batch=8, seed=3), expect_kernel="gemm_mfma_f32_kernel<2,2>")
 
 
 SHAPES_BF16 = [

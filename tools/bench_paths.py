@@ -219,9 +219,11 @@ def main():
         makers = [lambda: brgemm(api, 32, "f32", 4096), lambda: csr_asparse(api, 65536, 0.15), lambda: csr_asparse(api, 65536, 0.10), lambda: fsspmdm(api, 2 ** 20, 0.15),
                   lambda: bcsc(api), lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
     if "gemm" in only:
-        makers += [lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 65536), lambda: brgemm(api, 64, "f32", 16384),
-                   lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8),
-                   lambda: brgemm(api, 32, "bf16", 65536), lambda: brgemm(api, 64, "bf16", 32768)]
+        # steady state: ~1.5 GB per input set for every shape (launch ramp/drain amortised), plus small-launch cases
+        makers += [lambda: brgemm(api, 16, "f32", 2 ** 19), lambda: brgemm(api, 32, "f32", 2 ** 17), lambda: brgemm(api, 64, "f32", 2 ** 15),
+                   lambda: brgemm(api, 32, "bf16", 2 ** 18), lambda: brgemm(api, 64, "bf16", 2 ** 16),
+                   lambda: brgemm(api, 32, "f32", 2 ** 17, beta=1), lambda: brgemm(api, 32, "f32", 2 ** 14, br=8),
+                   lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8)]
     if "fused" in only:
         makers += [lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
     if "csr" in only:
