@@ -490,4 +490,19 @@ LIBXSMM_API double libxsmm_matdiff_epsilon(const libxsmm_matdiff_info* input);
 
 #include "libxsmm_hip.h"
 
-#endif /* LIBXSMM_H */
+#endif /* LIBXSMM_H *//**
+ * Dense packed GEMMs (SOA layouts, packed width fastest); caller owned, release with libxsmm_release_kernel.
+ * packed:  A [K][lda][P], B [N][ldb][P], C [N][ldc][P]:  C[n][m][p] (+)= sum_k A[k][m][p] * B[n][k][p]
+ * ac_rm:   A [M][lda][P], B row-major [K][ldb] (not packed), C [M][ldc][P]:  C[m][n][p] (+)= sum_k A[m][k][p] * B[k][n]
+ * bc_rm:   A row-major [M][lda] (not packed), B [K][ldb][P], C [M][ldc][P]:  C[m][n][p] (+)= sum_k A[m][k] * B[k][n][p]
+ * F32 / F64.  [ref: include/libxsmm.h:190-214; src/libxsmm_main.c:3733-3840; gold loops in
+ * samples/xgemm_packed/gemm_packed_kernel.c:35-72, samples/xgemm_norm_packed/dense_packedacrm.c:20-58, dense_packedbcrm.c:20-58]
+ */
+LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_gemm(libxsmm_gemm_shape gemm_shape,
+  libxsmm_bitfield gemm_flags, libxsmm_bitfield prefetch_flags, libxsmm_blasint packed_width);
+LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_gemm_ac_rm(libxsmm_gemm_shape gemm_shape,
+  libxsmm_bitfield gemm_flags, libxsmm_bitfield prefetch_flags, libxsmm_blasint packed_width);
+LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_gemm_bc_rm(libxsmm_gemm_shape gemm_shape,
+  libxsmm_bitfield gemm_flags, libxsmm_bitfield prefetch_flags, libxsmm_blasint packed_width);
+
+

@@ -206,6 +206,9 @@ class Api:
         self.dispatch_meltw_ternary = f("dispatch_meltw_ternary", vp, [C.c_int, TernaryShape, C.c_uint])
         self.create_packed_spgemm_csr = f("create_packed_spgemm_csr", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int, vp, vp, vp])
         self.create_packed_spgemm_csc = f("create_packed_spgemm_csc", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int, vp, vp, vp])
+        self.create_packed_gemm = f("create_packed_gemm", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int])
+        self.create_packed_gemm_ac_rm = f("create_packed_gemm_ac_rm", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int])
+        self.create_packed_gemm_bc_rm = f("create_packed_gemm_bc_rm", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int])
         self.create_packed_spgemm_bcsc = f("create_packed_spgemm_bcsc", vp, [GemmShape, C.c_uint, C.c_uint, SpgemmConfig])
         self.release_kernel = f("release_kernel", None, [vp])
         self.get_kernel_info = f("get_kernel_info", C.c_int, [vp, C.POINTER(KernelInfo)])

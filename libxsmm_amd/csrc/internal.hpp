@@ -53,7 +53,8 @@ enum Kind : int {
   K_MELTW,               // unary / binary / ternary TPP
   K_SPMM_ASPARSE,        // packed CSR, A sparse (also the FsSpMDM inner kernel)
   K_SPMM_BSPARSE,        // packed CSR/CSC, B sparse
-  K_BCSC                 // block-sparse B, pattern at run time
+  K_BCSC,                // block-sparse B, pattern at run time
+  K_PGEMM                // dense packed GEMM (A, B and C in SOA layout)
 };
 
 // ---- device argument blocks (passed by value as kernel arguments) ---------------------------
@@ -101,6 +102,13 @@ struct SpmmArgs {
   int dtype, beta0, skip_empty, vals_are_f64;
 };
 
+// C[n][m][p] (+)= sum_k A[k][m][p] * B[n][k][p]; leading dimensions in packed elements
+struct PgemmArgs {
+  const char* a; const char* b; char* c;
+  int M, N, K, lda, ldb, ldc, dtype, beta0;
+  long long P;
+};
+
 struct BcscArgs {
   const char* a; const char* bvals; char* c;
   const unsigned int* colptr; const unsigned int* rowidx;
@@ -116,7 +124,9 @@ struct SpmmJitSpec {              // everything the generated kernel bakes in; p
 };
 struct JitKernel;
 JitKernel* jit_spmm_create(const SpmmJitSpec& spec, std::string* why);
+JitKernel* jit_pgemm_create(const PgemmArgs& geometry, std::string* why);   // pointers of `geometry` are ignored
 bool jit_spmm_usable(const JitKernel* k, const void* x, const void* y);
+bool jit_pgemm_usable(const JitKernel* k, const void* a, const void* b, const void* c);
 int jit_spmm_launch(JitKernel* k, const void* vals, const void* x, void* y, void* stream);
 void jit_release(JitKernel* k);
 const char* jit_name(const JitKernel* k);
@@ -163,6 +173,7 @@ int launch_meltw(const MeltwArgs& args, void* stream, const char** kernel_name);
 bool meltw_supported(const libxsmm_meltw_descriptor& d);
 int launch_spmm(const SpmmArgs& args, void* stream, const char** kernel_name);
 int launch_bcsc(const BcscArgs& args, void* stream, const char** kernel_name);
+int launch_pgemm(const PgemmArgs& args, void* stream, const char** kernel_name);
 
 // ---- runtime services (dispatch.cpp) ---------------------------------------------------------------
 KernelCtx* ctx_from_handle(const void* fn);

@@ -161,33 +161,22 @@ std::string generate_spmm(const SpmmJitSpec& s, int vec, long long* total_thread
 
 }  // namespace
 
-JitKernel* jit_spmm_create(const SpmmJitSpec& s, std::string* why) {
+// compile `src` (entry point `fname`) for the current device and load it; cached by (device, source)
+static JitKernel* build_module(const std::string& src, const std::string& fname, long long total, int vec, int elem, std::string* why) {
   auto fail = [&](const char* msg) -> JitKernel* { if (why) *why = msg; return nullptr; };
-  const unsigned int nnz = s.ptr[s.rows];
-  if (nnz == 0 || nnz > 16384u || s.rows > 4096) return fail("pattern outside the JIT envelope");
-  const int elem = (s.dtype == LIBXSMM_DATATYPE_F64) ? 8 : 4;
-  std::vector<char> seen((size_t)s.inner, 0); int touched = 0;
-  for (unsigned int z = 0; z < nnz; ++z) if (!seen[s.idx[z]]) { seen[s.idx[z]] = 1; ++touched; }
-  const int vec = choose_vec(s, touched, elem);
-  if (vec == 0) return fail("touched X rows exceed the register budget");
+  if ((total + 255) / 256 >= (1ll << 31)) return fail("grid too large");
   std::lock_guard<std::mutex> guard(g_jit_lock);
   if (!rtc_ready()) return fail("hiprtc is not available");
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return fail("no current device");
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("device properties unavailable");
-  long long total = 0;
-  // the symbol carries the specialisation so that profiles tell the kernels apart
-  const std::string fname = std::string("spmm_jit_") + (elem == 8 ? "f64" : "f32") + "_v" + std::to_string(vec) + "_r" + std::to_string(s.rows) + "_k" + std::to_string(s.inner) +
-                            "_z" + std::to_string(nnz) + "_b" + std::to_string(s.beta0 ? 0 : 1);
-  const std::string src = generate_spmm(s, vec, &total, fname);
-  if ((total + 255) / 256 >= (1ll << 31)) return fail("grid too large");
   const std::string key = std::to_string(dev) + ":" + src;
   auto it = g_jit_cache.find(key);
   if (it != g_jit_cache.end()) { ++it->second->refs; return it->second; }
   const auto t_start = std::chrono::steady_clock::now();
   hiprtcProgram prog = nullptr;
-  if (g_rtc.create(&prog, src.c_str(), "spmm_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail("hiprtcCreateProgram failed");
+  if (g_rtc.create(&prog, src.c_str(), "libxsmm_amd_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail("hiprtcCreateProgram failed");
   const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
   const char* opts[] = {arch.c_str(), "-O3", "-ffp-contract=off"};
   const hiprtcResult rc = g_rtc.compile(prog, 3, opts);
@@ -215,12 +204,79 @@ JitKernel* jit_spmm_create(const SpmmJitSpec& s, std::string* why) {
     std::fprintf(stderr, "LIBXSMM-AMD: hiprtc %.0f ms, module load %.0f ms, %zu bytes of source\n", std::chrono::duration<double, std::milli>(t_compiled - t_start).count(),
                  std::chrono::duration<double, std::milli>(t_loaded - t_compiled).count(), src.size());
   }
-  k->device = dev; k->total_threads = total; k->vec = vec; k->elem = elem; k->code_size = csz; k->key = key;
-  k->name = fname;
+  k->device = dev; k->total_threads = total; k->vec = vec; k->elem = elem; k->code_size = csz; k->key = key; k->name = fname;
   g_jit_cache.emplace(key, k);
   return k;
 }
 
+JitKernel* jit_spmm_create(const SpmmJitSpec& s, std::string* why) {
+  auto fail = [&](const char* msg) -> JitKernel* { if (why) *why = msg; return nullptr; };
+  const unsigned int nnz = s.ptr[s.rows];
+  if (nnz == 0 || nnz > 16384u || s.rows > 4096) return fail("pattern outside the JIT envelope");
+  const int elem = (s.dtype == LIBXSMM_DATATYPE_F64) ? 8 : 4;
+  std::vector<char> seen((size_t)s.inner, 0); int touched = 0;
+  for (unsigned int z = 0; z < nnz; ++z) if (!seen[s.idx[z]]) { seen[s.idx[z]] = 1; ++touched; }
+  const int vec = choose_vec(s, touched, elem);
+  if (vec == 0) return fail("touched X rows exceed the register budget");
+  long long total = 0;
+  // the symbol carries the specialisation so that profiles tell the kernels apart
+  const std::string fname = std::string("spmm_jit_") + (elem == 8 ? "f64" : "f32") + "_v" + std::to_string(vec) + "_r" + std::to_string(s.rows) + "_k" + std::to_string(s.inner) +
+                            "_z" + std::to_string(nnz) + "_b" + std::to_string(s.beta0 ? 0 : 1);
+  const std::string src = generate_spmm(s, vec, &total, fname);
+  return build_module(src, fname, total, vec, elem, why);
+}
+
+// Dense packed GEMM  C[n][m][p] (+)= sum_k A[k][m][p] * B[n][k][p]  [ref: src/generator_packed_gemm_avx_avx512.c; gold
+// samples/xgemm_packed/gemm_packed_kernel.c:35-72]: a lane owns `vec` packed positions, fetches its K*M + N*K operand
+// vectors once (all loads in flight) and produces the M*N results from registers.
+JitKernel* jit_pgemm_create(const PgemmArgs& g, std::string* why) {
+  auto fail = [&](const char* msg) -> JitKernel* { if (why) *why = msg; return nullptr; };
+  const int elem = (g.dtype == LIBXSMM_DATATYPE_F64) ? 8 : 4, words = elem / 4;
+  const long long operands = (long long)g.K * g.M + (long long)g.N * g.K;
+  if (operands <= 0 || (long long)g.M * g.N > 4096) return fail("shape outside the JIT envelope");
+  int vec = 0;
+  for (int e = 16 / elem; e >= 1; e >>= 1) {
+    if (g.P % e) continue;
+    if (operands * e * words > 176) continue;
+    vec = e;
+    if ((g.P / e) / 64 >= 2048) break;          // enough waves at this width; otherwise keep narrowing for parallelism
+  }
+  if (vec == 0) return fail("operands exceed the register budget");
+  const char* T = elem == 8 ? "double" : "float";
+  const long long total = g.P / vec;
+  const std::string fname = std::string("pgemm_jit_") + (elem == 8 ? "f64" : "f32") + "_v" + std::to_string(vec) + "_m" + std::to_string(g.M) + "_n" + std::to_string(g.N) +
+                            "_k" + std::to_string(g.K) + "_b" + std::to_string(g.beta0 ? 0 : 1);
+  std::string src;
+  append(src, "// generated by libxsmm_amd: packed GEMM m=%d n=%d k=%d lda=%d ldb=%d ldc=%d P=%lld vec=%d %s beta0=%d\n", g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.P, vec, T, g.beta0);
+  append(src, "typedef %s T;\n", T);
+  if (vec > 1) append(src, "typedef T V __attribute__((ext_vector_type(%d)));\n", vec); else src += "typedef T V;\n";
+  src += "#define GM __attribute__((address_space(1)))\n";
+  src += "extern \"C\" __global__ __launch_bounds__(256) void " + fname + "(const void* a_, const void* b_, void* c_) {\n";
+  append(src, "  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n  if (t >= %lldLL) return;\n", total);
+  append(src, "  GM const T* a = (GM const T*)a_ + t * %d;\n  GM const T* b = (GM const T*)b_ + t * %d;\n  GM T* c = (GM T*)c_ + t * %d;\n", vec, vec, vec);
+  for (int k = 0; k < g.K; ++k) for (int m = 0; m < g.M; ++m) append(src, "  const V a%d_%d = *(GM const V*)(a + %lldLL);\n", k, m, ((long long)k * g.lda + m) * g.P);
+  for (int n = 0; n < g.N; ++n) for (int k = 0; k < g.K; ++k) append(src, "  const V b%d_%d = *(GM const V*)(b + %lldLL);\n", n, k, ((long long)n * g.ldb + k) * g.P);
+  const int ahead = 6, outs = g.M * g.N;
+  auto coff = [&](int o) { const int n = o / g.M, m = o % g.M; return ((long long)n * g.ldc + m) * g.P; };
+  if (!g.beta0) for (int o = 0; o < outs && o < ahead; ++o) append(src, "  V c%d = *(GM const V*)(c + %lldLL);\n", o, coff(o));
+  src += "  V acc;\n";
+  for (int o = 0; o < outs; ++o) {
+    const int n = o / g.M, m = o % g.M;
+    if (!g.beta0 && o + ahead < outs) append(src, "  V c%d = *(GM const V*)(c + %lldLL);\n", o + ahead, coff(o + ahead));
+    if (!g.beta0) append(src, "  acc = c%d;\n", o);
+    for (int k = 0; k < g.K; ++k) {
+      if (g.beta0 && k == 0) append(src, "  acc = a%d_%d * b%d_%d;\n", k, m, n, k);
+      else append(src, "  acc = __builtin_elementwise_fma(a%d_%d, b%d_%d, acc);\n", k, m, n, k);
+    }
+    append(src, "  *(GM V*)(c + %lldLL) = acc;\n", coff(o));
+  }
+  src += "}\n";
+  return build_module(src, fname, total, vec, elem, why);
+}
+
+bool jit_pgemm_usable(const JitKernel* k, const void* a, const void* b, const void* c) {
+  return jit_spmm_usable(k, a, b) && jit_spmm_usable(k, b, c);
+}
 bool jit_spmm_usable(const JitKernel* k, const void* x, const void* y) {
   if (!k) return false;
   int dev = -1;

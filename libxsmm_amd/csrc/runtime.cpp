@@ -340,6 +340,25 @@ void run_spmm(KernelCtx* k, const void* param) {
   finish_launch(err, kname);
 }
 
+static void pgemm_geometry(const KernelCtx* k, PgemmArgs& a) {
+  const libxsmm_gemm_descriptor& d = k->g;
+  a.M = (int)d.m; a.N = (int)d.n; a.K = (int)d.k; a.lda = (int)d.lda; a.ldb = (int)d.ldb; a.ldc = (int)d.ldc;
+  a.dtype = d.a_type; a.beta0 = (d.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 1 : 0; a.P = k->packed_width;
+}
+void run_pgemm(KernelCtx* k, const void* param) {
+  const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
+  PgemmArgs a{};
+  pgemm_geometry(k, a);
+  a.a = (const char*)p->a.primary; a.b = (const char*)p->b.primary; a.c = (char*)p->c.primary;
+  if (!a.a || !a.b || !a.c) { set_error(-2, "packed GEMM called with a NULL operand"); return; }
+  const char* kname = nullptr;
+  int err;
+  if (jit_pgemm_usable(k->jit, a.a, a.b, a.c)) { kname = jit_name(k->jit); err = jit_spmm_launch(k->jit, a.a, a.b, a.c, tls().stream); }
+  else err = launch_pgemm(a, tls().stream, &kname);
+  if (kname) k->kname_single = k->kname_batched = kname;
+  finish_launch(err, kname);
+}
+
 void run_bcsc(KernelCtx* k, const void* param) {
   const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
   const libxsmm_gemm_descriptor& d = k->g;
@@ -382,6 +401,7 @@ void run_any(KernelCtx* k, const void* param, const BatchSpec& b) {
     case K_MELTW: run_meltw(k, param, b); break;
     case K_SPMM_ASPARSE: case K_SPMM_BSPARSE: run_spmm(k, param); break;
     case K_BCSC: run_bcsc(k, param); break;
+    case K_PGEMM: run_pgemm(k, param); break;
     case K_TILECFG: break;   // AMX tile configuration has no meaning here [ref: gemm ref :2821-2826]
   }
 }
@@ -764,6 +784,66 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_bcsc(libxsmm_gemm_
 LIBXSMM_API libxsmm_tilecfgfunction libxsmm_create_tilecfg_packed_spgemm_bcsc(libxsmm_gemm_shape s, libxsmm_bitfield flags, libxsmm_spgemm_config cfg) {
   (void)cfg;
   return libxsmm_dispatch_tilecfg_gemm(s, flags);
+}
+
+// ---- dense packed GEMMs [ref: libxsmm_main.c:3733-3840] -----------------------------------------------------------
+static libxsmm_gemm_descriptor* packed_descriptor(libxsmm_descriptor_blob* blob, const libxsmm_gemm_shape& s, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_blasint packed_width) {
+  if (!runtime_ready() || packed_width <= 0) return nullptr;
+  if (s.a_in_type != s.b_in_type || (s.a_in_type != LIBXSMM_DATATYPE_F32 && s.a_in_type != LIBXSMM_DATATYPE_F64) || s.out_type != s.a_in_type) return nullptr;
+  if (tilecfg_halfset((unsigned int)flags) || (flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B))) return nullptr;
+  if (s.m <= 0 || s.n <= 0 || s.k <= 0) return nullptr;
+  return libxsmm_gemm_descriptor_init(blob, s.a_in_type, s.b_in_type, s.comp_type, s.out_type, s.m, s.n, s.k, s.lda, s.ldb, s.ldc,
+    (int)(flags | LIBXSMM_GEMM_FLAG_USE_XGEMM_ABI), (int)prefetch);
+}
+LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_gemm(libxsmm_gemm_shape s, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_blasint packed_width) {
+  libxsmm_descriptor_blob blob;
+  libxsmm_gemm_descriptor* d = packed_descriptor(&blob, s, flags, prefetch, packed_width);
+  if (!d || s.lda < s.m || s.ldb < s.k || s.ldc < s.m) return nullptr;            // column-major, every element P wide
+  KernelCtx* c = new_unregistered(K_PGEMM, d); if (!c) return nullptr;
+  c->packed_width = packed_width;
+  c->nflops = (unsigned int)(2ull * s.m * s.n * s.k * packed_width);
+  c->kname_single = c->kname_batched = "pgemm_generic_kernel";
+  if (jit_mode() != 0) {
+    PgemmArgs g{}; pgemm_geometry(c, g);
+    std::string why;
+    c->jit = jit_pgemm_create(g, &why);
+    if (c->jit) { c->kname_single = c->kname_batched = jit_name(c->jit); vlog(2, "JIT %s (%zu bytes of code)", jit_name(c->jit), jit_code_size(c->jit)); }
+    else vlog(2, "packed GEMM not specialised: %s", why.c_str());
+  }
+  return (libxsmm_gemmfunction)handle_for_slot(c->slot);
+}
+// A and C packed, B a plain row-major K x N matrix: the fixed-pattern kernel with a dense pattern whose values are
+// read from B at run time (value of (n, k) at B[k*ldb + n])
+LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_gemm_ac_rm(libxsmm_gemm_shape s, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_blasint packed_width) {
+  libxsmm_descriptor_blob blob;
+  libxsmm_gemm_descriptor* d = packed_descriptor(&blob, s, flags, prefetch, packed_width);
+  if (!d || s.lda < s.k || s.ldb < s.n || s.ldc < s.n) return nullptr;
+  if ((long long)s.n * s.k >= (1ll << 28)) return nullptr;
+  std::vector<unsigned int> ptr((size_t)s.n + 1), idx((size_t)s.n * s.k), vmap((size_t)s.n * s.k);
+  for (int n = 0; n <= s.n; ++n) ptr[n] = (unsigned int)((long long)n * s.k);
+  for (int n = 0; n < s.n; ++n) for (int k = 0; k < s.k; ++k) { idx[(size_t)n * s.k + k] = (unsigned int)k; vmap[(size_t)n * s.k + k] = (unsigned int)((long long)k * s.ldb + n); }
+  KernelCtx* c = new_unregistered(K_SPMM_BSPARSE, d); if (!c) return nullptr;
+  c->packed_width = packed_width;
+  if (!upload_pattern(c, s.n, s.k, ptr.data(), idx.data(), vmap.data())) { drop_unregistered(c); return nullptr; }
+  attach_jit(c, ptr.data(), idx.data(), vmap.data());
+  c->nflops = (unsigned int)(2ull * s.m * s.n * s.k * packed_width);
+  return (libxsmm_gemmfunction)handle_for_slot(c->slot);
+}
+// B and C packed, A a plain row-major M x K matrix (value of (m, k) at A[m*lda + k])
+LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_gemm_bc_rm(libxsmm_gemm_shape s, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_blasint packed_width) {
+  libxsmm_descriptor_blob blob;
+  libxsmm_gemm_descriptor* d = packed_descriptor(&blob, s, flags, prefetch, packed_width);
+  if (!d || s.lda < s.k || s.ldb < s.n || s.ldc < s.n) return nullptr;
+  if ((long long)s.m * s.k >= (1ll << 28)) return nullptr;
+  std::vector<unsigned int> ptr((size_t)s.m + 1), idx((size_t)s.m * s.k), vmap((size_t)s.m * s.k);
+  for (int m = 0; m <= s.m; ++m) ptr[m] = (unsigned int)((long long)m * s.k);
+  for (int m = 0; m < s.m; ++m) for (int k = 0; k < s.k; ++k) { idx[(size_t)m * s.k + k] = (unsigned int)k; vmap[(size_t)m * s.k + k] = (unsigned int)((long long)m * s.lda + k); }
+  KernelCtx* c = new_unregistered(K_SPMM_ASPARSE, d); if (!c) return nullptr;
+  c->packed_width = packed_width; c->sp_ncols = s.n; c->sp_skip_empty = 0;
+  if (!upload_pattern(c, s.m, s.k, ptr.data(), idx.data(), vmap.data())) { drop_unregistered(c); return nullptr; }
+  attach_jit(c, ptr.data(), idx.data(), vmap.data());
+  c->nflops = (unsigned int)(2ull * s.m * s.n * s.k * packed_width);
+  return (libxsmm_gemmfunction)handle_for_slot(c->slot);
 }
 
 LIBXSMM_API libxsmm_gemmfunction libxsmm_create_spgemm_csr_areg(libxsmm_gemm_shape s, libxsmm_bitfield flags, libxsmm_bitfield prefetch,

@@ -445,4 +445,31 @@ int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense packed GEMM, general form (the specialised kernel comes from jit.cpp): one thread per C element,
+// lanes along the packed axis.  [ref: samples/xgemm_packed/gemm_packed_kernel.c:35-72]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pgemm_generic_kernel(PgemmArgs p) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = p.P * p.M;
+  if (gid >= per * p.N) return;
+  const long long n = gid / per, rem = gid - n * per, m = rem / p.P, l = rem - m * p.P;
+  GM const T* a = (GM const T*)p.a; GM const T* b = (GM const T*)p.b; GM T* c = (GM T*)p.c + (n * p.ldc + m) * p.P + l;
+  T acc = p.beta0 ? (T)0 : *c;
+  for (int k = 0; k < p.K; ++k) acc = fma(a[((long long)k * p.lda + m) * p.P + l], b[(n * p.ldb + k) * p.P + l], acc);
+  *c = acc;
+}
+int launch_pgemm(const PgemmArgs& a, void* stream, const char** name) {
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = a.P * a.M * a.N;
+  if (total <= 0) { if (name) *name = "(empty)"; return 0; }
+  if ((total + 255) / 256 >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  const dim3 grid((unsigned int)((total + 255) / 256));
+  if (a.dtype == LIBXSMM_DATATYPE_F64) hipLaunchKernelGGL(pgemm_generic_kernel<double>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(pgemm_generic_kernel<float>, grid, dim3(256), 0, st, a);
+  if (name) *name = "pgemm_generic_kernel";
+  return (int)hipGetLastError();
+}
+
 }  // namespace xamd

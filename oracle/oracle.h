@@ -87,6 +87,13 @@ void oracle_packed_spgemm_bcsc(int a_type, int c_type, int M, int N, int K, int 
 void oracle_fsspmdm(int dtype, int M, int N, int K, const unsigned int* row_ptr, const unsigned int* col_idx,
   const void* a_vals, const void* B, int ldb, void* C, int ldc, int beta0);
 
+/* Dense packed GEMMs [ref: samples/xgemm_norm_packed/dense_packedacrm.c:20-58, dense_packedbcrm.c:20-58,
+ * samples/xgemm_packed/gemm_packed_kernel.c:35-72].  ac_rm: C[m][n][p] (+)= sum_k A[m][k][p] * B[k][n];
+ * bc_rm: C[m][n][p] (+)= sum_k A[m][k] * B[k][n][p]; packed: C[n][m][p] (+)= sum_k A[k][m][p] * B[n][k][p]. */
+void oracle_packed_gemm_ac_rm(int dtype, int M, int N, int K, int P, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int beta0);
+void oracle_packed_gemm_bc_rm(int dtype, int M, int N, int K, int P, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int beta0);
+void oracle_packed_gemm(int dtype, int M, int N, int K, int P, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int beta0);
+
 /* ---- low-precision conversions  [ref: src/libxsmm_math.c:640-704] --------------------- */
 unsigned short oracle_f32_to_bf16_rne(float x);   /* RNE with DAZ and NaN quieting */
 unsigned short oracle_f32_to_bf16_trunc(float x);

@@ -144,3 +144,48 @@ void oracle_fsspmdm(int dtype, int M, int N, int K, const unsigned int* row_ptr,
   if (dtype == LIBXSMM_DATATYPE_F64) REAL_LOOP(double, BODY); else REAL_LOOP(float, BODY);
 #undef BODY
 }
+
+/* ---- dense packed GEMMs (SOA layouts, P = packed width fastest) --------------------------------
+ * [ref: samples/xgemm_norm_packed/dense_packedacrm.c:20-58 (matMulFusedAC), dense_packedbcrm.c:20-58 (matMulFusedBC),
+ *  samples/xgemm_packed/gemm_packed_kernel.c:35-72].  k is the outermost loop of the gold code; the order of the
+ *  additions into one C element is therefore k = 0..K-1, which is what is restated here per element. */
+void oracle_packed_gemm_ac_rm(int dtype, int M, int N, int K, int P, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int beta0)
+{
+  long long m, n, k, p;
+#define BODY \
+  const real* a = (const real*)A; const real* b = (const real*)B; real* c = (real*)C; \
+  for (m = 0; m < M; ++m) for (n = 0; n < N; ++n) for (p = 0; p < P; ++p) { \
+    real acc = beta0 ? (real)0 : c[(m * ldc + n) * P + p]; \
+    for (k = 0; k < K; ++k) { const real prod = a[(m * lda + k) * P + p] * b[k * ldb + n]; acc = acc + prod; } \
+    c[(m * ldc + n) * P + p] = acc; \
+  }
+  if (dtype == LIBXSMM_DATATYPE_F64) REAL_LOOP(double, BODY); else REAL_LOOP(float, BODY);
+#undef BODY
+}
+void oracle_packed_gemm_bc_rm(int dtype, int M, int N, int K, int P, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int beta0)
+{
+  long long m, n, k, p;
+#define BODY \
+  const real* a = (const real*)A; const real* b = (const real*)B; real* c = (real*)C; \
+  for (m = 0; m < M; ++m) for (n = 0; n < N; ++n) for (p = 0; p < P; ++p) { \
+    real acc = beta0 ? (real)0 : c[(m * ldc + n) * P + p]; \
+    for (k = 0; k < K; ++k) { const real prod = a[m * lda + k] * b[(k * ldb + n) * P + p]; acc = acc + prod; } \
+    c[(m * ldc + n) * P + p] = acc; \
+  }
+  if (dtype == LIBXSMM_DATATYPE_F64) REAL_LOOP(double, BODY); else REAL_LOOP(float, BODY);
+#undef BODY
+}
+/* all three packed, column-major: C[n][m][p] (+)= sum_k A[k][m][p] * B[n][k][p] */
+void oracle_packed_gemm(int dtype, int M, int N, int K, int P, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int beta0)
+{
+  long long m, n, k, p;
+#define BODY \
+  const real* a = (const real*)A; const real* b = (const real*)B; real* c = (real*)C; \
+  for (m = 0; m < M; ++m) for (n = 0; n < N; ++n) for (p = 0; p < P; ++p) { \
+    real acc = beta0 ? (real)0 : c[(n * ldc + m) * P + p]; \
+    for (k = 0; k < K; ++k) { const real prod = a[(k * lda + m) * P + p] * b[(n * ldb + k) * P + p]; acc = acc + prod; } \
+    c[(n * ldc + m) * P + p] = acc; \
+  }
+  if (dtype == LIBXSMM_DATATYPE_F64) REAL_LOOP(double, BODY); else REAL_LOOP(float, BODY);
+#undef BODY
+}

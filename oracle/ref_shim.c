@@ -153,3 +153,13 @@ XREF double xref_time_gemm_batch(libxsmm_gemmfunction kernel, const libxsmm_gemm
   t1 = libxsmm_timer_tick();
   return libxsmm_timer_duration(t0, t1);
 }
+
+XREF libxsmm_gemmfunction xref_create_packed_gemm(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_blasint packed_width) {
+  return libxsmm_create_packed_gemm(shape, flags, prefetch, packed_width);
+}
+XREF libxsmm_gemmfunction xref_create_packed_gemm_ac_rm(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_blasint packed_width) {
+  return libxsmm_create_packed_gemm_ac_rm(shape, flags, prefetch, packed_width);
+}
+XREF libxsmm_gemmfunction xref_create_packed_gemm_bc_rm(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_blasint packed_width) {
+  return libxsmm_create_packed_gemm_bc_rm(shape, flags, prefetch, packed_width);
+}

@@ -270,3 +270,39 @@ def test_bcsc_vs_reference_jit(reference, a_type, c_type, vnni, bk, bn, beta0):
     capi.Api.call(h, p)
     assert normf_rel(ref_c, jit_c, c_type) <= (5e-3 if c_type == DT.BF16 else 1e-4)
     reference.release_kernel(h)
+
+
+# ---- dense packed GEMMs: restatement vs the reference's JIT kernels -------------------------------------------------
+PACKED_GEMM = [(9, 9, 9, 16, 0), (4, 7, 5, 8, 1), (20, 9, 20, 16, 1), (35, 9, 35, 8, 0)]
+
+
+@pytest.mark.parametrize("dt", [DT.F32, DT.F64])
+@pytest.mark.parametrize("kind", ["packed", "ac_rm", "bc_rm"])
+@pytest.mark.parametrize("M,N,K,P,beta0", PACKED_GEMM)
+def test_packed_gemm_vs_reference_jit(reference, kind, dt, M, N, K, P, beta0):
+    npdt = np.float32 if dt == DT.F32 else np.float64
+    rng = np.random.default_rng(17)
+    orc = pyoracle.oracle()
+    flags = GEMM_FLAG.BETA_0 if beta0 else 0
+    if kind == "packed":      # column-major, all packed: A [K][lda=M], B [N][ldb=K], C [N][ldc=M]
+        A, B, C0 = (rng.random(K * M * P) - 0.5).astype(npdt), (rng.random(N * K * P) - 0.5).astype(npdt), (rng.random(N * M * P) - 0.5).astype(npdt)
+        shape, fn, ofn = capi.gemm_shape(M, N, K, M, K, M, dt, dt, dt, dt), reference.create_packed_gemm, orc.lib.oracle_packed_gemm
+        lda, ldb, ldc = M, K, M
+    elif kind == "ac_rm":     # A [M][lda=K][P], B [K][ldb=N], C [M][ldc=N][P]
+        A, B, C0 = (rng.random(M * K * P) - 0.5).astype(npdt), (rng.random(K * N) - 0.5).astype(npdt), (rng.random(M * N * P) - 0.5).astype(npdt)
+        shape, fn, ofn = capi.gemm_shape(M, N, K, K, N, N, dt, dt, dt, dt), reference.create_packed_gemm_ac_rm, orc.lib.oracle_packed_gemm_ac_rm
+        lda, ldb, ldc = K, N, N
+    else:                     # A [M][lda=K], B [K][ldb=N][P], C [M][ldc=N][P]
+        A, B, C0 = (rng.random(M * K) - 0.5).astype(npdt), (rng.random(K * N * P) - 0.5).astype(npdt), (rng.random(M * N * P) - 0.5).astype(npdt)
+        shape, fn, ofn = capi.gemm_shape(M, N, K, K, N, N, dt, dt, dt, dt), reference.create_packed_gemm_bc_rm, orc.lib.oracle_packed_gemm_bc_rm
+        lda, ldb, ldc = K, N, N
+    mine = C0.copy()
+    ofn(dt, M, N, K, P, A.ctypes.data, lda, B.ctypes.data, ldb, mine.ctypes.data, ldc, beta0)
+    h = fn(shape, flags, 0, P)
+    if not h:
+        pytest.skip("the reference JIT declines this packed GEMM on this host")
+    theirs = C0.copy()
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.c.primary = A.ctypes.data, B.ctypes.data, theirs.ctypes.data
+    capi.Api.call(h, p)
+    assert normf_rel(theirs, mine, dt) <= (1e-5 if dt == DT.F32 else 1e-12)

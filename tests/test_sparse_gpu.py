@@ -180,3 +180,41 @@ def test_bcsc(a_type, c_type, vnni, M, N, K, mb, bk, bn, keep, beta0):
     api.hip_sync(); api.check()
     assert np.array_equal(_host(dC2, got.dtype), got)
     api.release_kernel(h)
+
+
+# ---- dense packed GEMMs --------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [DT.F32, DT.F64])
+@pytest.mark.parametrize("kind", ["packed", "ac_rm", "bc_rm"])
+@pytest.mark.parametrize("M,N,K,P,beta0", [(9, 9, 9, 64, 0), (4, 7, 5, 24, 1), (20, 9, 20, 16, 1), (35, 9, 35, 1024, 0), (3, 2, 4, 7, 0)])
+def test_packed_gemm(kind, dt, M, N, K, P, beta0, jit_mode):
+    api, orc = capi.load(), pyoracle.oracle()
+    npdt = NP[dt]
+    rng = np.random.default_rng(23)
+    flags = GEMM_FLAG.BETA_0 if beta0 else 0
+    if kind == "packed":
+        sizes, (lda, ldb, ldc) = (K * M * P, N * K * P, N * M * P), (M, K, M)
+        shape, fn, ofn = capi.gemm_shape(M, N, K, M, K, M, dt, dt, dt, dt), api.create_packed_gemm, orc.lib.oracle_packed_gemm
+    elif kind == "ac_rm":
+        sizes, (lda, ldb, ldc) = (M * K * P, K * N, M * N * P), (K, N, N)
+        shape, fn, ofn = capi.gemm_shape(M, N, K, K, N, N, dt, dt, dt, dt), api.create_packed_gemm_ac_rm, orc.lib.oracle_packed_gemm_ac_rm
+    else:
+        sizes, (lda, ldb, ldc) = (M * K, K * N * P, M * N * P), (K, N, N)
+        shape, fn, ofn = capi.gemm_shape(M, N, K, K, N, N, dt, dt, dt, dt), api.create_packed_gemm_bc_rm, orc.lib.oracle_packed_gemm_bc_rm
+    A, B, C0 = (rand_values(rng, n, dt) for n in sizes)
+    ref = C0.copy()
+    ofn(dt, M, N, K, P, A.ctypes.data, lda, B.ctypes.data, ldb, ref.ctypes.data, ldc, beta0)
+    h = fn(shape, flags, 0, P)
+    assert h
+    dA, dB, dC = _dev(A), _dev(B), _dev(C0.copy())
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.c.primary = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    assert normf_rel(ref, _host(dC, npdt), dt) <= (1e-5 if dt == DT.F32 else 1e-12), api.hip_kernel_name(h, 0)
+    info = capi.KernelInfo()
+    assert api.get_kernel_info(h, C.byref(info)) == 0 and info.nflops == 2 * M * N * K * P
+    api.release_kernel(h)
+    # illegal leading dimensions / types are refused
+    bad = capi.gemm_shape(M, N, K, 0, 0, 0, dt, dt, dt, dt)
+    assert fn(bad, flags, 0, P) is None
+    assert fn(capi.gemm_shape(M, N, K, lda, ldb, ldc, DT.BF16, DT.BF16, DT.BF16, DT.F32), flags, 0, P) is None
