@@ -102,6 +102,34 @@ __device__ __forceinline__ void br_base(const GemmArgs& p, const BatchPtrs& q, u
   else { a = q.a; b = q.b; }
 }
 
+// activation, ReLU bitmask, output conversion / VNNI-C of one element (block = 64 x 4: a wave is 64 rows of one column)
+__device__ __forceinline__ void generic_epilogue(const GemmArgs& p, const BatchPtrs& q, int i, int j, bool valid, float acc) {
+  const float y = act_apply(p.act, acc);
+  if (p.act == 2 && q.mask) {   // bit i%8 of byte i/8 + j*(mask_ld/8) [ref: mateltwise ref :150-157, :2142]
+    const unsigned long long ballot = __ballot(valid && !(acc <= 0.0f));
+    const unsigned long long vmask = __ballot(valid);
+    const int lane = threadIdx.x;   // blockDim.x == 64: lane within the wave
+    if ((lane & 7) == 0 && valid) {
+      const long long mask_ld = ((p.ldc + 15) / 16) * 16;
+      GM unsigned char* byte = q.mask + i / 8 + (long long)j * (mask_ld / 8);
+      const unsigned char vm = (unsigned char)((vmask >> lane) & 0xffu);
+      const unsigned char nb = (unsigned char)((ballot >> lane) & 0xffu);
+      *byte = (unsigned char)((*byte & ~vm) | (nb & vm));
+    }
+  }
+  if (!valid) return;
+  if (p.vnni_c && p.c_type == LIBXSMM_DATATYPE_BF16) {
+    // NORM -> VNNI2 of the result [ref: gemm ref :2802-2815]; the pad column of an odd n is zero-filled
+    GM unsigned short* c = (GM unsigned short*)q.c;
+    c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + (j % 2)] = f32_to_bf16_rne(y);
+    if ((p.n & 1) && j == p.n - 1) c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + 1] = 0;
+  } else if (p.c_type == LIBXSMM_DATATYPE_F32) {
+    ((GM float*)q.c)[(long long)j * p.ldc + i] = y;
+  } else {
+    ((GM unsigned short*)q.c)[(long long)j * p.ldc + i] = f32_to_bf16_rne(y);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic kernel: one thread per C element
 // ------------------------------------------------------------------------------------------------
@@ -170,30 +198,45 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
       }
     }
   }
-  const float y = act_apply(p.act, acc);
-  if (p.act == 2 && q.mask) {   // bit i%8 of byte i/8 + j*(mask_ld/8) [ref: mateltwise ref :150-157, :2142]
-    const unsigned long long ballot = __ballot(valid && !(acc <= 0.0f));
-    const unsigned long long vmask = __ballot(valid);
-    const int lane = threadIdx.x;   // blockDim.x == 64: lane within the wave
-    if ((lane & 7) == 0 && valid) {
-      const long long mask_ld = ((p.ldc + 15) / 16) * 16;
-      GM unsigned char* byte = q.mask + i / 8 + (long long)j * (mask_ld / 8);
-      const unsigned char vm = (unsigned char)((vmask >> lane) & 0xffu);
-      const unsigned char nb = (unsigned char)((ballot >> lane) & 0xffu);
-      *byte = (unsigned char)((*byte & ~vm) | (nb & vm));
-    }
+  generic_epilogue(p, q, i, j, valid, acc);
+}
+
+// One long batch-reduce chain split over the chip: `nsplit` partial C tiles (f32, [split][n][m]) were produced by the
+// tile kernels; this pass adds them up in split order on top of beta*C (+ bias) and applies the epilogue of the
+// original descriptor.  [the reference runs the chain serially, gemm ref :490-530; partial sums change the rounding
+// order only]
+// block = (64, 16): x walks i, the 16 y-slices share the splits of one column j (fixed, deterministic order: slice y
+// sums splits y, y+16, ... with four independent chains; the slices are then added in y order through LDS)
+__global__ __launch_bounds__(1024) void brsplit_reduce_kernel(GemmArgs p, const float* partial, int nsplit) {
+  __shared__ float part[16][64];
+  const int tiles_i = (p.m + 63) / 64;
+  const int t = (int)blockIdx.x;
+  const int i = (t % tiles_i) * 64 + threadIdx.x;
+  const int j = t / tiles_i;
+  const bool valid = (i < p.m) && (j < p.n);
+  float sum = 0.0f;
+  if (valid) {
+    GM const float* w = (GM const float*)partial + (long long)j * p.m + i;
+    const long long stride = (long long)p.m * p.n;
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    int s = threadIdx.y;
+    for (; s + 48 < nsplit; s += 64) { c0 += w[s * stride]; c1 += w[(s + 16) * stride]; c2 += w[(s + 32) * stride]; c3 += w[(s + 48) * stride]; }
+    for (; s < nsplit; s += 16) c0 += w[s * stride];
+    sum = (c0 + c1) + (c2 + c3);
   }
-  if (!valid) return;
-  if (p.vnni_c && p.c_type == LIBXSMM_DATATYPE_BF16) {
-    // NORM -> VNNI2 of the result [ref: gemm ref :2802-2815]; the pad column of an odd n is zero-filled
-    GM unsigned short* c = (GM unsigned short*)q.c;
-    c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + (j % 2)] = f32_to_bf16_rne(y);
-    if ((p.n & 1) && j == p.n - 1) c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + 1] = 0;
-  } else if (p.c_type == LIBXSMM_DATATYPE_F32) {
-    ((GM float*)q.c)[(long long)j * p.ldc + i] = y;
-  } else {
-    ((GM unsigned short*)q.c)[(long long)j * p.ldc + i] = f32_to_bf16_rne(y);
+  part[threadIdx.y][threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.y != 0) return;
+  const BatchPtrs q = batch_ptrs(p, 0);
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  float acc = 0.0f;
+  if (valid) {
+    if (!beta0) acc = load_as_f32(q.c, (long long)j * p.ldc + i, p.c_type);
+    if (p.colbias) { const float bias = load_as_f32(q.d, i, p.c_type); acc = beta0 ? bias : add_rn(bias, acc); }
+#pragma unroll
+    for (int y = 0; y < 16; ++y) acc = add_rn(acc, part[y][threadIdx.x]);
   }
+  generic_epilogue(p, q, i, j, valid, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -960,6 +1003,12 @@ static bool bf16_stream_ok(const GemmArgs& a) {
   const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0);
   if (abits & 3ull) return false;
   return (long long)a.lda * a.k * 2 < (1ll << 31) && (long long)a.ldb * a.n * 2 < (1ll << 31);
+}
+
+int launch_brsplit_reduce(const GemmArgs& a, const float* partial, int nsplit, void* stream) {
+  const long long blocks = (long long)((a.m + 63) / 64) * a.n;
+  hipLaunchKernelGGL(brsplit_reduce_kernel, dim3((unsigned int)blocks), dim3(64, 16), 0, (hipStream_t)stream, a, partial, nsplit);
+  return (int)hipGetLastError();
 }
 
 int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {

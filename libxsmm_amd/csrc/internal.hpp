@@ -171,6 +171,7 @@ const char* gemm_kernel_name(const libxsmm_gemm_descriptor& d, bool batched);
 bool gemm_supported(const libxsmm_gemm_descriptor& d);
 int launch_meltw(const MeltwArgs& args, void* stream, const char** kernel_name);
 bool meltw_supported(const libxsmm_meltw_descriptor& d);
+int launch_brsplit_reduce(const GemmArgs& args, const float* partial, int nsplit, void* stream);
 int launch_spmm(const SpmmArgs& args, void* stream, const char** kernel_name);
 int launch_bcsc(const BcscArgs& args, void* stream, const char** kernel_name);
 int launch_pgemm(const PgemmArgs& args, void* stream, const char** kernel_name);

@@ -105,7 +105,20 @@ const void* device_visible(const void* p, size_t nbytes) {
   if (!hip_ok(hipMemcpyAsync(dst, p, nbytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpyAsync(index array)")) return nullptr;
   return dst;
 }
-void scratch_reset() { t_scratch.used = 0; }   // stream order protects data of the previous call
+void scratch_reset() { t_scratch.used = 0; }
+// per-thread device workspace for partial results; grows monotonically, reused in stream order
+struct Workspace { void* base = nullptr; size_t cap = 0; };
+thread_local Workspace t_workspace;
+void* workspace(size_t nbytes) {
+  Workspace& w = t_workspace;
+  if (nbytes > w.cap) {
+    if (w.base) { (void)hipStreamSynchronize(cur_stream()); (void)hipFree(w.base); w.base = nullptr; w.cap = 0; }
+    const size_t ncap = std::max<size_t>(nbytes, 4u << 20);
+    if (!hip_ok(hipMalloc(&w.base, ncap), "hipMalloc(workspace)")) { w.base = nullptr; return nullptr; }
+    w.cap = ncap;
+  }
+  return w.base;
+}   // stream order protects data of the previous call
 
 std::string make_key(int kind, const void* desc, size_t n) {
   std::string k; k.reserve(n + 1); k.push_back((char)kind); k.append((const char*)desc, n); return k;
@@ -255,6 +268,37 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     } else if (d.cp_type == LIBXSMM_MELTW_TYPE_UNARY_SIGMOID) a.act = 3;
   }
   const char* kname = nullptr;
+  // One (or very few) problems with a long STRIDE batch-reduce chain would run on a handful of waves: split the chain
+  // into `nsplit` segments that run as a batch of partial products (f32 tiles in a workspace), then add them up and
+  // apply beta / bias / activation in a second pass (SURVEY 8(d) config #2 variant B: one BRGEMM with br = 4096).
+  static const bool split_off = []() { const char* e = getenv("LIBXSMM_HIP_BRSPLIT"); return e && e[0] == '0'; }();
+  const long long tiles = (long long)((a.m + 31) / 32) * ((a.n + 31) / 32);
+  if (!split_off && a.br_mode == 3 && a.nbatch == 1 && !a.list_a && a.br_count >= 16 && tiles * 8 <= 1024 && a.a_type != LIBXSMM_DATATYPE_F64 && a.m > 0 && a.n > 0) {
+    unsigned long long nsplit = std::min<unsigned long long>(a.br_count / 4, (unsigned long long)(2048 / tiles));
+    const unsigned long long chunk = (a.br_count + nsplit - 1) / nsplit;
+    const unsigned long long nfull = a.br_count / chunk, tail = a.br_count - nfull * chunk;
+    nsplit = nfull + (tail ? 1 : 0);
+    const size_t tile_bytes = (size_t)a.m * a.n * sizeof(float);
+    float* ws = (float*)workspace(nsplit * tile_bytes);
+    if (ws) {
+      GemmArgs pa = a;
+      pa.c = (char*)ws; pa.ldc = a.m; pa.c_type = LIBXSMM_DATATYPE_F32; pa.vnni_c = 0;
+      pa.flags = (a.flags | LIBXSMM_GEMM_FLAG_BETA_0) & ~(unsigned int)LIBXSMM_GEMM_FLAG_VNNI_C;
+      pa.d = nullptr; pa.relu_mask = nullptr; pa.colbias = 0; pa.act = 0;
+      pa.br_count = chunk; pa.nbatch = (unsigned int)nfull;
+      pa.bs_a = (long long)chunk * a.br_stride_a; pa.bs_b = (long long)chunk * a.br_stride_b; pa.bs_c = (long long)tile_bytes; pa.bs_d = 0; pa.bs_mask = 0;
+      int err = launch_gemm(pa, tls().stream, &kname);
+      if (err == 0 && tail) {
+        pa.a = a.a + (long long)nfull * pa.bs_a; pa.b = a.b + (long long)nfull * pa.bs_b; pa.c = (char*)ws + nfull * tile_bytes;
+        pa.br_count = tail; pa.nbatch = 1;
+        err = launch_gemm(pa, tls().stream, nullptr);
+      }
+      if (err == 0) err = launch_brsplit_reduce(a, ws, (int)nsplit, tls().stream);
+      if (kname) k->kname_single = kname;
+      finish_launch(err, kname);
+      return;
+    }
+  }
   const int err = launch_gemm(a, tls().stream, &kname);
   if (kname) { if (b.count > 1 || b.la) k->kname_batched = kname; else k->kname_single = kname; }   // what actually ran
   finish_launch(err, kname);

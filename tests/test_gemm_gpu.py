@@ -237,3 +237,27 @@ def test_illegal_descriptors_return_null():
     # tile-config handles exist and are callable no-ops
     t = api.dispatch_tilecfg_gemm(s, F.NO_RESET_TILECONFIG)
     assert t
+
+
+# SURVEY 8(d) config #2 variant B: ONE strided BRGEMM with a long reduction chain -> split over the chip, partial tiles
+# added up in a second pass.  Same tolerance as every MFMA kernel (only the summation order differs from the oracle).
+@pytest.mark.parametrize("kw", [
+    dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=4096),
+    dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=1000, beta=1),                       # ragged tail segment
+    dict(m=64, n=64, k=64, br_type=capi.BR_STRIDE, br_count=300, beta=1, colbias=True, act=2),   # epilogue applied once, after the sum
+    dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=512, colbias=True, act=1),
+    dict(m=23, n=23, k=23, br_type=capi.BR_STRIDE, br_count=77),                                  # generic kernel underneath
+])
+def test_long_reduction_chain_is_split_and_matches_oracle(kw):
+    api = capi.load()
+    case = GemmCase(seed=11, **kw)
+    n0 = api.hip_launch_count(1)
+    got, gmask, handle = case.run_gpu(batched=False)
+    launches = api.hip_launch_count(0)
+    ref, rmask = case.run_oracle()
+    tol = _tol(case) * (4 if case.c_type == DT.F32 else 1)        # thousands of terms of magnitude 0.1 cancel: looser norm bound
+    assert normf_rel(case.valid_region(ref), case.valid_region(got), case.c_type) < tol
+    if rmask is not None:
+        rb, gb = case.valid_mask_bits(rmask), case.valid_mask_bits(gmask)
+        assert (rb != gb).mean() < 0.02        # bits can only differ where the pre-activation is ~0
+    assert api.hip_get_last_error() == 0 and launches >= 0 and n0 >= 0

@@ -223,7 +223,8 @@ def main():
         makers += [lambda: brgemm(api, 16, "f32", 2 ** 19), lambda: brgemm(api, 32, "f32", 2 ** 17), lambda: brgemm(api, 64, "f32", 2 ** 15),
                    lambda: brgemm(api, 32, "bf16", 2 ** 18), lambda: brgemm(api, 64, "bf16", 2 ** 16),
                    lambda: brgemm(api, 32, "f32", 2 ** 17, beta=1), lambda: brgemm(api, 32, "f32", 2 ** 14, br=8),
-                   lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8)]
+                   lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8),
+                   lambda: brgemm(api, 32, "f32", 1, br=4096), lambda: brgemm(api, 64, "bf16", 1, br=4096)]     # config #2 variant B: one long chain
     if "fused" in only:
         makers += [lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
     if "csr" in only:
