@@ -117,6 +117,10 @@ class Reference(capi.Api):
         L.xref_matdiff_normf_rel.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]; L.xref_matdiff_normf_rel.restype = C.c_double
         L.xref_time_gemm_batch.argtypes = [vp, C.POINTER(capi.GemmParam), C.c_size_t, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]
         L.xref_time_gemm_batch.restype = C.c_double
+        L.xref_time_gemm_ext_batch.argtypes = [vp, C.POINTER(capi.GemmExtParam), C.c_size_t, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]
+        L.xref_time_gemm_ext_batch.restype = C.c_double
+        L.xref_time_fsspmdm.argtypes = [vp, vp, vp, C.c_int]
+        L.xref_time_fsspmdm.restype = C.c_double
         L.xref_get_target_arch.restype = C.c_char_p
         self.init()
 

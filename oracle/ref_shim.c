@@ -163,3 +163,30 @@ XREF libxsmm_gemmfunction xref_create_packed_gemm_ac_rm(libxsmm_gemm_shape shape
 XREF libxsmm_gemmfunction xref_create_packed_gemm_bc_rm(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_blasint packed_width) {
   return libxsmm_create_packed_gemm_bc_rm(shape, flags, prefetch, packed_width);
 }
+
+/* Timing helpers for the CPU-baseline legs of tools/bench_paths.py (single thread, back-to-back calls). */
+XREF double xref_time_gemm_ext_batch(libxsmm_gemmfunction_ext kernel, const libxsmm_gemm_ext_param* param, size_t count,
+  long long sa, long long sb, long long sc, int reps)
+{
+  libxsmm_timer_tickint t0, t1; int r; size_t i;
+  libxsmm_gemm_ext_param q = *param;
+  t0 = libxsmm_timer_tick();
+  for (r = 0; r < reps; ++r) {
+    for (i = 0; i < count; ++i) {
+      q.a.primary = (char*)param->a.primary + (long long)i * sa;
+      q.b.primary = (char*)param->b.primary + (long long)i * sb;
+      q.c.primary = (char*)param->c.primary + (long long)i * sc;
+      kernel(&q);
+    }
+  }
+  t1 = libxsmm_timer_tick();
+  return libxsmm_timer_duration(t0, t1);
+}
+XREF double xref_time_fsspmdm(const libxsmm_fsspmdm* handle, const void* B, void* C, int reps)
+{
+  libxsmm_timer_tickint t0, t1; int r;
+  t0 = libxsmm_timer_tick();
+  for (r = 0; r < reps; ++r) libxsmm_fsspmdm_execute(handle, B, C);
+  t1 = libxsmm_timer_tick();
+  return libxsmm_timer_duration(t0, t1);
+}

@@ -179,6 +179,84 @@ def meltw_big(api, typ, name, m=4096, n=8192, in_dt=DT.F32, out_dt=DT.F32, flags
     return w
 
 
+# ---- CPU legs: the reference's own JIT kernels (oracle/_ref) on ONE host core, bounded samples --------------------
+def _cpu_time(fn_time, flops_per_call, seconds, what):
+    t1 = fn_time(3)
+    reps = max(3, int(seconds / max(t1 / 3, 1e-9)))
+    dt = fn_time(reps)
+    return {"value": round(flops_per_call * reps / dt / 1e9, 2), "unit": "GFLOP/s", "cores": 1, "kind": "reference", "sample": f"{what}, {reps} reps, 1 thread, {dt:.1f} s"}
+
+
+def cpu_csr(P, density, seconds=3.0):
+    from oracle import pyoracle
+    ref = pyoracle.reference()
+    M = K = N = 35
+    nnz = int(round(M * K * density))
+    rowptr, colidx, vals = random_pattern(M, K, nnz)
+    vals = vals.astype(np.float32)
+    h = ref.create_packed_spgemm_csr(capi.gemm_shape(M, N, K, 0, N, N, DT.F32, DT.F32, DT.F32, DT.F32), GEMM_FLAG.BETA_0, 0, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data)
+    if not h:
+        return None
+    B, Cc = np.random.default_rng(1).random(K * N * P).astype(np.float32), np.zeros(M * N * P, dtype=np.float32)
+    p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = vals.ctypes.data, B.ctypes.data, Cc.ctypes.data
+    return _cpu_time(lambda r: ref.lib.xref_time_gemm_batch(h, C.byref(p), 1, 0, 0, 0, r), 2.0 * nnz * N * P, seconds,
+                     f"reference JIT ({ref.lib.xref_get_target_arch().decode()}) packed CSR {M}x{K} nnz={nnz} N={N} P={P} f32")
+
+
+def cpu_fsspmdm(N, density, seconds=3.0):
+    from oracle import pyoracle
+    ref = pyoracle.reference()
+    M = K = 35
+    nnz = int(round(M * K * density))
+    rowptr, colidx, vals = random_pattern(M, K, nnz)
+    a = np.zeros((M, K))
+    for i in range(M):
+        a[i, colidx[rowptr[i]:rowptr[i + 1]]] = vals[rowptr[i]:rowptr[i + 1]]
+    a = np.ascontiguousarray(a)
+    al, be = C.c_double(1.0), C.c_double(0.0)
+    h = ref.fsspmdm_create(DT.F64, M, N, K, K, N, N, C.addressof(al), C.addressof(be), a.ctypes.data, 0, None)
+    if not h:
+        return None
+    B, Cc = np.random.default_rng(1).random(K * N), np.zeros(M * N)
+    return _cpu_time(lambda r: ref.lib.xref_time_fsspmdm(h, B.ctypes.data, Cc.ctypes.data, r), 2.0 * nnz * N, seconds,
+                     f"reference FsSpMDM ({ref.lib.xref_get_target_arch().decode()}) {M}x{K} nnz={nnz} N={N} f64")
+
+
+def cpu_bcsc(m_blocks=64, M=64, K=256, N=64, bk=32, bn=16, seconds=3.0):
+    from oracle import pyoracle
+    ref = pyoracle.reference()
+    colptr, rowidx = structured_2_of_8(K, N, bk, bn)
+    nnzb = len(rowidx)
+    h = ref.create_packed_spgemm_bcsc(capi.gemm_shape(m_blocks, 0, K, K, 0, N, DT.BF16, DT.BF16, DT.BF16, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    if not h:
+        return None
+    rng = np.random.default_rng(1)
+    bf = lambda n: (rng.random(n).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    A, bv, Cc = bf(m_blocks * K * M), bf(nnzb * bk * bn), np.zeros(m_blocks * N * M, dtype=np.uint16)
+    nblk = C.c_ulonglong(N // bn)
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = A.ctypes.data, bv.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, C.addressof(nblk), Cc.ctypes.data
+    return _cpu_time(lambda r: ref.lib.xref_time_gemm_batch(h, C.byref(p), 1, 0, 0, 0, r), 2.0 * M * m_blocks * bk * bn * nnzb, seconds,
+                     f"reference JIT ({ref.lib.xref_get_target_arch().decode()}) BCSC bf16 2:8 m_blocks={m_blocks} (effective flops)")
+
+
+def cpu_fused(batch=256, m=64, seconds=3.0):
+    from oracle import pyoracle
+    ref = pyoracle.reference()
+    sh = capi.gemm_shape(m, m, m, m, m, m, DT.BF16, DT.BF16, DT.BF16, DT.F32)
+    h = ref.dispatch_brgemm_ext(sh, GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.br_config(capi.BR_STRIDE, m * m * 2, m * m * 2, 0), capi.argops_cp(m, UNARY.RELU), capi.postops_colbias(m, DT.BF16))
+    if not h:
+        return None
+    rng = np.random.default_rng(1)
+    bf = lambda n: (rng.random(n).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    A, B, Cc, D = bf(batch * m * m), bf(batch * m * m), np.zeros(batch * m * m, dtype=np.uint16), bf(m)
+    brc = C.c_ulonglong(1)
+    p = capi.GemmExtParam()
+    p.a.primary, p.b.primary, p.c.primary, p.d.primary, p.op.tertiary = A.ctypes.data, B.ctypes.data, Cc.ctypes.data, D.ctypes.data, C.addressof(brc)
+    return _cpu_time(lambda r: ref.lib.xref_time_gemm_ext_batch(h, C.byref(p), batch, m * m * 2, m * m * 2, m * m * 2, r), 2.0 * m ** 3 * batch, seconds,
+                     f"reference JIT ({ref.lib.xref_get_target_arch().decode()}) bf16 64^3 BRGEMM_ext colbias + ReLU, {batch} problems")
+
+
 def measure(w, steps, eager=0):
     for i in range(5):
         w.step(i)
@@ -197,6 +275,11 @@ def measure(w, steps, eager=0):
                         "algorithmic_bytes_per_launch": int(w.alg_bytes)}, "input_sets_rotated": w.nsets, "steps": steps}
     if hasattr(w, "dense_equiv_flops"):
         out["dense_equiv_GFLOP/s"] = round(w.dense_equiv_flops / us / 1e3, 1)
+    if getattr(w, "cpu", None) is not None:
+        try:
+            out["cpu_baseline"] = w.cpu()
+        except Exception as e:      # the CPU leg must never take the GPU measurement down
+            out["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
 
 
@@ -206,6 +289,7 @@ def main():
     ap.add_argument("--only", default="gemm,csr,fsspmdm,bcsc,fused,meltw")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--eager", type=int, default=0, help="profiling mode: this many plain launches per workload, no timing")
+    ap.add_argument("--cpu", action="store_true", help="with --headline: time the reference's CPU kernel (oracle/_ref, 1 core) beside each GPU measurement")
     ap.add_argument("--headline", action="store_true", help="only the BASELINE configs (#2..#5), one workload each")
     args = ap.parse_args()
     torch.cuda.set_device(0)
@@ -216,8 +300,14 @@ def main():
     makers = []
     if args.headline:
         only = set()
-        makers = [lambda: brgemm(api, 32, "f32", 4096), lambda: csr_asparse(api, 65536, 0.15), lambda: csr_asparse(api, 65536, 0.10), lambda: fsspmdm(api, 2 ** 20, 0.15),
-                  lambda: bcsc(api), lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
+        def with_cpu(w, fn):
+            if args.cpu and not args.eager:
+                w.cpu = fn
+            return w
+        makers = [lambda: with_cpu(brgemm(api, 32, "f32", 4096), lambda: bench.cpu_baseline(argparse.Namespace(m=32, br=1, batch=4096, dtype="f32", beta=0), 3.0)),
+                  lambda: with_cpu(csr_asparse(api, 65536, 0.15), lambda: cpu_csr(1024, 0.15)), lambda: with_cpu(csr_asparse(api, 65536, 0.10), lambda: cpu_csr(1024, 0.10)),
+                  lambda: with_cpu(fsspmdm(api, 2 ** 20, 0.15), lambda: cpu_fsspmdm(49152, 0.15)),
+                  lambda: with_cpu(bcsc(api), cpu_bcsc), lambda: with_cpu(brgemm(api, 64, "bf16", 2 ** 17, fused=1), cpu_fused)]
     if "gemm" in only:
         # steady state: ~1.5 GB per input set for every shape (launch ramp/drain amortised), plus small-launch cases
         makers += [lambda: brgemm(api, 16, "f32", 2 ** 19), lambda: brgemm(api, 32, "f32", 2 ** 17), lambda: brgemm(api, 64, "f32", 2 ** 15),
