@@ -422,6 +422,44 @@ LIBXSMM_API libxsmm_meltwfunction_binary libxsmm_dispatch_meltw_binary(libxsmm_m
 LIBXSMM_API libxsmm_meltwfunction_ternary libxsmm_dispatch_meltw_ternary(libxsmm_meltw_ternary_type ternary_type,
   libxsmm_meltw_ternary_shape ternary_shape, libxsmm_bitfield ternary_flags);
 
+/* ---- matrix equations: trees of TPPs evaluated as one kernel handle
+ * [ref: include/libxsmm.h:149-162; include/libxsmm_typedefs.h:586-591,617-657,683-694; src/libxsmm_matrixeqn.c;
+ *  semantics = src/generator_matequation_reference_impl.c:105-227: the tree is evaluated bottom-up, every op node is the
+ *  TPP of its type with comp/out type = the op's dtype, intermediate shape per libxsmm_matrixeqn.c:869-936, the root
+ *  writes `out_shape`].  Ops are pushed in pre-order (an op, then its operands left to right). ------------------- */
+typedef struct libxsmm_meqn_arg_shape { libxsmm_blasint m, n, ld; libxsmm_datatype type; } libxsmm_meqn_arg_shape;
+typedef enum libxsmm_matrix_arg_type { LIBXSMM_MATRIX_ARG_TYPE_SINGULAR = 0, LIBXSMM_MATRIX_ARG_TYPE_SET = 1 } libxsmm_matrix_arg_type;
+typedef enum libxsmm_matrix_arg_set_type {
+  LIBXSMM_MATRIX_ARG_SET_TYPE_NONE = 0, LIBXSMM_MATRIX_ARG_SET_TYPE_ABS_ADDRESS = 1,
+  LIBXSMM_MATRIX_ARG_SET_TYPE_OFFSET_BASE = 2, LIBXSMM_MATRIX_ARG_SET_TYPE_STRIDE_BASE = 3
+} libxsmm_matrix_arg_set_type;
+typedef struct libxsmm_matrix_arg_attributes {
+  libxsmm_matrix_arg_type type; libxsmm_matrix_arg_set_type set_type; libxsmm_blasint set_cardinality_hint, set_stride_hint;
+} libxsmm_matrix_arg_attributes;
+typedef struct libxsmm_meqn_op_metadata { libxsmm_blasint eqn_idx, op_arg_pos; } libxsmm_meqn_op_metadata;
+typedef struct libxsmm_meqn_arg_metadata { libxsmm_blasint eqn_idx, in_arg_pos; } libxsmm_meqn_arg_metadata;
+typedef struct libxsmm_meqn_param {
+  const libxsmm_matrix_op_arg* ops_args;   /* per-op state (e.g. alpha of LEAKY_RELU), indexed by op_arg_pos */
+  const libxsmm_matrix_arg* inputs;        /* inputs[in_arg_pos].primary: device-accessible */
+  libxsmm_matrix_arg output;
+} libxsmm_meqn_param;
+typedef void (*libxsmm_meqn_function)(const libxsmm_meqn_param*);
+
+LIBXSMM_API libxsmm_blasint libxsmm_meqn_create(void);
+LIBXSMM_API libxsmm_meqn_arg_shape libxsmm_create_meqn_arg_shape(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint ld, libxsmm_datatype type);
+LIBXSMM_API libxsmm_matrix_arg_attributes libxsmm_create_matrix_arg_attributes(libxsmm_matrix_arg_type type, libxsmm_matrix_arg_set_type set_type,
+  libxsmm_blasint set_cardinality_hint, libxsmm_blasint set_stride_hint);
+LIBXSMM_API libxsmm_meqn_arg_metadata libxsmm_create_meqn_arg_metadata(libxsmm_blasint eqn_idx, libxsmm_blasint in_arg_pos);
+LIBXSMM_API libxsmm_meqn_op_metadata libxsmm_create_meqn_op_metadata(libxsmm_blasint eqn_idx, libxsmm_blasint op_arg_pos);
+LIBXSMM_API int libxsmm_meqn_push_back_arg(libxsmm_meqn_arg_metadata arg_metadata, libxsmm_meqn_arg_shape arg_shape, libxsmm_matrix_arg_attributes arg_attr);
+LIBXSMM_API int libxsmm_meqn_push_back_unary_op(libxsmm_meqn_op_metadata op_metadata, libxsmm_meltw_unary_type type, libxsmm_datatype dtype, libxsmm_bitfield flags);
+LIBXSMM_API int libxsmm_meqn_push_back_binary_op(libxsmm_meqn_op_metadata op_metadata, libxsmm_meltw_binary_type type, libxsmm_datatype dtype, libxsmm_bitfield flags);
+LIBXSMM_API int libxsmm_meqn_push_back_ternary_op(libxsmm_meqn_op_metadata op_metadata, libxsmm_meltw_ternary_type type, libxsmm_datatype dtype, libxsmm_bitfield flags);
+LIBXSMM_API void libxsmm_meqn_tree_print(libxsmm_blasint idx);
+LIBXSMM_API void libxsmm_meqn_rpn_print(libxsmm_blasint idx);
+/** NULL if the tree is incomplete or contains an op outside this backend (matmul/brgemm nodes, gather, dump, argument sets). */
+LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, libxsmm_meqn_arg_shape out_shape);
+
 /* ---- packed / sparse creators (caller-owned, release with libxsmm_release_kernel)
  * [ref: include/libxsmm.h:164-223; src/libxsmm_main.c:3553-3883] --------------------- */
 LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_csr(libxsmm_gemm_shape gemm_shape,

@@ -82,6 +82,10 @@ class MatrixOpArg(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("primary", "secondary", "tertiary", "quaternary")]
 
 
+class MeqnParam(C.Structure):
+    _fields_ = [("ops_args", C.POINTER(MatrixOpArg)), ("inputs", C.POINTER(MatrixArg)), ("output", MatrixArg)]
+
+
 class GemmParam(C.Structure):
     _fields_ = [("op", MatrixOpArg), ("a", MatrixArg), ("b", MatrixArg), ("c", MatrixArg)]
 
@@ -126,6 +130,18 @@ class ExtBinaryPostops(C.Structure):
     _fields_ = [("ldd", C.c_int), ("d_in_type", C.c_int), ("d_binary_type", C.c_int), ("d_binary_flags", C.c_uint)]
 
 
+class MeqnArgShape(C.Structure):
+    _fields_ = [("m", C.c_int), ("n", C.c_int), ("ld", C.c_int), ("type", C.c_int)]
+
+
+class MatrixArgAttributes(C.Structure):
+    _fields_ = [("type", C.c_int), ("set_type", C.c_int), ("set_cardinality_hint", C.c_int), ("set_stride_hint", C.c_int)]
+
+
+class MeqnMetadata(C.Structure):      # libxsmm_meqn_op_metadata and libxsmm_meqn_arg_metadata share this layout
+    _fields_ = [("eqn_idx", C.c_int), ("pos", C.c_int)]
+
+
 class UnaryShape(C.Structure):
     _fields_ = [("m", C.c_int), ("n", C.c_int), ("ldi", C.c_int), ("ldo", C.c_int),
                 ("in0_type", C.c_int), ("out_type", C.c_int), ("comp_type", C.c_int)]
@@ -159,6 +175,7 @@ GEMM_EXT_FN = C.CFUNCTYPE(None, C.POINTER(GemmExtParam))
 UNARY_FN = C.CFUNCTYPE(None, C.POINTER(UnaryParam))
 BINARY_FN = C.CFUNCTYPE(None, C.POINTER(BinaryParam))
 TERNARY_FN = C.CFUNCTYPE(None, C.POINTER(TernaryParam))
+MEQN_FN = C.CFUNCTYPE(None, C.POINTER(MeqnParam))
 
 # every symbol include/libxsmm.h and libxsmm_hip.h declare (checked by tests/test_capi_symbols.py)
 _DECL_RE = re.compile(r"LIBXSMM_API\s+[^;(]*?\b(libxsmm_\w+)\s*\(")
@@ -204,6 +221,13 @@ class Api:
         self.dispatch_meltw_unary = f("dispatch_meltw_unary", vp, [C.c_int, UnaryShape, C.c_uint])
         self.dispatch_meltw_binary = f("dispatch_meltw_binary", vp, [C.c_int, BinaryShape, C.c_uint])
         self.dispatch_meltw_ternary = f("dispatch_meltw_ternary", vp, [C.c_int, TernaryShape, C.c_uint])
+        # matrix equations
+        self.meqn_create = f("meqn_create", C.c_int, [])
+        self.meqn_push_back_arg = f("meqn_push_back_arg", C.c_int, [MeqnMetadata, MeqnArgShape, MatrixArgAttributes])
+        self.meqn_push_back_unary_op = f("meqn_push_back_unary_op", C.c_int, [MeqnMetadata, C.c_int, C.c_int, C.c_uint])
+        self.meqn_push_back_binary_op = f("meqn_push_back_binary_op", C.c_int, [MeqnMetadata, C.c_int, C.c_int, C.c_uint])
+        self.meqn_push_back_ternary_op = f("meqn_push_back_ternary_op", C.c_int, [MeqnMetadata, C.c_int, C.c_int, C.c_uint])
+        self.dispatch_meqn = f("dispatch_meqn", vp, [C.c_int, MeqnArgShape])
         self.create_packed_spgemm_csr = f("create_packed_spgemm_csr", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int, vp, vp, vp])
         self.create_packed_spgemm_csc = f("create_packed_spgemm_csc", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int, vp, vp, vp])
         self.create_packed_gemm = f("create_packed_gemm", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int])
@@ -248,7 +272,7 @@ class Api:
         if not handle:
             raise RuntimeError("NULL kernel handle (dispatch refused the descriptor or no HIP device is present)")
         if fntype is None:
-            fntype = {GemmParam: GEMM_FN, GemmExtParam: GEMM_EXT_FN, UnaryParam: UNARY_FN, BinaryParam: BINARY_FN, TernaryParam: TERNARY_FN}[type(param)]
+            fntype = {GemmParam: GEMM_FN, GemmExtParam: GEMM_EXT_FN, UnaryParam: UNARY_FN, BinaryParam: BINARY_FN, TernaryParam: TERNARY_FN, MeqnParam: MEQN_FN}[type(param)]
         fntype(handle)(C.byref(param))
 
     def check(self):

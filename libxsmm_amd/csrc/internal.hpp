@@ -54,7 +54,8 @@ enum Kind : int {
   K_SPMM_ASPARSE,        // packed CSR, A sparse (also the FsSpMDM inner kernel)
   K_SPMM_BSPARSE,        // packed CSR/CSC, B sparse
   K_BCSC,                // block-sparse B, pattern at run time
-  K_PGEMM                // dense packed GEMM (A, B and C in SOA layout)
+  K_PGEMM,               // dense packed GEMM (A, B and C in SOA layout)
+  K_MEQN                 // matrix equation (tree of TPPs)
 };
 
 // ---- device argument blocks (passed by value as kernel arguments) ---------------------------
@@ -147,10 +148,21 @@ struct KernelCtx {
   unsigned int* d_vmap = nullptr;   // value position per pattern entry (B-sparse CSR regrouped by column)
   int sp_ncols = 0, sp_skip_empty = 0;
   JitKernel* jit = nullptr;         // pattern-specialised kernel (nullptr: precompiled kernels serve)
+  struct EqnPlan* eqn = nullptr;    // K_MEQN: the evaluation plan (meqn.cpp)
   int device = 0;
   const char* kname_single = "";
   const char* kname_batched = "";
 };
+
+// ---- matrix equations (meqn.cpp) and the runtime services they use (runtime.cpp) ------------------------
+struct EqnPlan;
+void run_meqn(EqnPlan* plan, const void* param);
+void free_meqn_plan(EqnPlan* plan);
+const void* rt_new_meqn_handle(EqnPlan* plan);   // caller-independent handle owned by the equation registry
+void rt_finish_launch(int err, const char* kernel_name);
+void* rt_workspace(size_t nbytes);
+bool rt_ready();
+void* rt_stream();
 
 // ---- per-thread execution state -----------------------------------------------------------------
 struct ThreadState {

@@ -146,6 +146,7 @@ void free_ctx_locked(KernelCtx* c) {
   if (c->d_vals) (void)hipFree(c->d_vals);
   if (c->d_vmap) (void)hipFree(c->d_vmap);
   if (c->jit) jit_release(c->jit);
+  if (c->eqn) free_meqn_plan(c->eqn);
   g_slots[c->slot] = nullptr; g_free_slots.push_back(c->slot);
   delete c;
 }
@@ -446,6 +447,7 @@ void run_any(KernelCtx* k, const void* param, const BatchSpec& b) {
     case K_SPMM_ASPARSE: case K_SPMM_BSPARSE: run_spmm(k, param); break;
     case K_BCSC: run_bcsc(k, param); break;
     case K_PGEMM: run_pgemm(k, param); break;
+    case K_MEQN: scratch_reset(); run_meqn(k->eqn, param); break;
     case K_TILECFG: break;   // AMX tile configuration has no meaning here [ref: gemm ref :2821-2826]
   }
 }
@@ -453,6 +455,18 @@ void run_any(KernelCtx* k, const void* param, const BatchSpec& b) {
 }  // namespace
 
 namespace xamd {
+const void* rt_new_meqn_handle(EqnPlan* plan) {
+  std::lock_guard<std::mutex> guard(g_lock);
+  KernelCtx* c = new_ctx_locked(K_MEQN);
+  if (!c) return nullptr;
+  c->registered = true; c->eqn = plan; c->kname_single = c->kname_batched = "meqn";
+  return handle_for_slot(c->slot);
+}
+void rt_finish_launch(int err, const char* kernel_name) { finish_launch(err, kernel_name); }
+void* rt_workspace(size_t nbytes) { return workspace(nbytes); }
+bool rt_ready() { return runtime_ready(); }
+void* rt_stream() { return tls().stream; }
+
 void invoke(int slot, const void* param) {
   KernelCtx* k = g_slots[slot];
   if (!k) { set_error(-3, "call through a released kernel handle"); return; }

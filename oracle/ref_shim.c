@@ -190,3 +190,17 @@ XREF double xref_time_fsspmdm(const libxsmm_fsspmdm* handle, const void* B, void
   t1 = libxsmm_timer_tick();
   return libxsmm_timer_duration(t0, t1);
 }
+
+/* matrix equations [ref: include/libxsmm.h:149-162] */
+XREF libxsmm_blasint xref_meqn_create(void) { return libxsmm_meqn_create(); }
+XREF libxsmm_meqn_arg_shape xref_create_meqn_arg_shape(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint ld, libxsmm_datatype type) { return libxsmm_create_meqn_arg_shape(m, n, ld, type); }
+XREF libxsmm_matrix_arg_attributes xref_create_matrix_arg_attributes(libxsmm_matrix_arg_type type, libxsmm_matrix_arg_set_type set_type, libxsmm_blasint card, libxsmm_blasint stride) {
+  return libxsmm_create_matrix_arg_attributes(type, set_type, card, stride);
+}
+XREF libxsmm_meqn_arg_metadata xref_create_meqn_arg_metadata(libxsmm_blasint eqn_idx, libxsmm_blasint in_arg_pos) { return libxsmm_create_meqn_arg_metadata(eqn_idx, in_arg_pos); }
+XREF libxsmm_meqn_op_metadata xref_create_meqn_op_metadata(libxsmm_blasint eqn_idx, libxsmm_blasint op_arg_pos) { return libxsmm_create_meqn_op_metadata(eqn_idx, op_arg_pos); }
+XREF int xref_meqn_push_back_arg(libxsmm_meqn_arg_metadata md, libxsmm_meqn_arg_shape shape, libxsmm_matrix_arg_attributes attr) { return libxsmm_meqn_push_back_arg(md, shape, attr); }
+XREF int xref_meqn_push_back_unary_op(libxsmm_meqn_op_metadata md, libxsmm_meltw_unary_type type, libxsmm_datatype dtype, libxsmm_bitfield flags) { return libxsmm_meqn_push_back_unary_op(md, type, dtype, flags); }
+XREF int xref_meqn_push_back_binary_op(libxsmm_meqn_op_metadata md, libxsmm_meltw_binary_type type, libxsmm_datatype dtype, libxsmm_bitfield flags) { return libxsmm_meqn_push_back_binary_op(md, type, dtype, flags); }
+XREF int xref_meqn_push_back_ternary_op(libxsmm_meqn_op_metadata md, libxsmm_meltw_ternary_type type, libxsmm_datatype dtype, libxsmm_bitfield flags) { return libxsmm_meqn_push_back_ternary_op(md, type, dtype, flags); }
+XREF libxsmm_meqn_function xref_dispatch_meqn(libxsmm_blasint idx, libxsmm_meqn_arg_shape out_shape) { return libxsmm_dispatch_meqn(idx, out_shape); }
