@@ -130,6 +130,10 @@ bool jit_spmm_usable(const JitKernel* k, const void* x, const void* y);
 bool jit_pgemm_usable(const JitKernel* k, const void* a, const void* b, const void* c);
 int jit_spmm_launch(JitKernel* k, const void* vals, const void* x, void* y, void* stream);
 void jit_release(JitKernel* k);
+JitKernel* jit_compile(const std::string& src, const std::string& fname, long long total_threads, int align_bytes, std::string* why);
+int jit_launch(JitKernel* k, void** args, void* stream);
+bool jit_on_current_device(const JitKernel* k);
+int rt_jit_mode();
 const char* jit_name(const JitKernel* k);
 size_t jit_code_size(const JitKernel* k);
 
@@ -158,6 +162,7 @@ struct KernelCtx {
 struct EqnPlan;
 void run_meqn(EqnPlan* plan, const void* param);
 void free_meqn_plan(EqnPlan* plan);
+const char* meqn_plan_name(const EqnPlan* plan);
 const void* rt_new_meqn_handle(EqnPlan* plan);   // caller-independent handle owned by the equation registry
 void rt_finish_launch(int err, const char* kernel_name);
 void* rt_workspace(size_t nbytes);

@@ -274,6 +274,18 @@ JitKernel* jit_pgemm_create(const PgemmArgs& g, std::string* why) {
   return build_module(src, fname, total, vec, elem, why);
 }
 
+JitKernel* jit_compile(const std::string& src, const std::string& fname, long long total_threads, int align_bytes, std::string* why) {
+  return build_module(src, fname, total_threads, align_bytes, 1, why);     // vec*elem = required pointer alignment
+}
+int jit_launch(JitKernel* k, void** args, void* stream) {
+  const unsigned int grid = (unsigned int)((k->total_threads + 255) / 256);
+  return (int)hipModuleLaunchKernel(k->fn, grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+}
+bool jit_on_current_device(const JitKernel* k) {
+  int dev = -1;
+  return k && hipGetDevice(&dev) == hipSuccess && dev == k->device;
+}
+
 bool jit_pgemm_usable(const JitKernel* k, const void* a, const void* b, const void* c) {
   return jit_spmm_usable(k, a, b) && jit_spmm_usable(k, b, c);
 }

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "internal.hpp"
@@ -41,6 +42,9 @@ struct Equation {
 
 struct EqnStep { MeltwArgs args; int src[3]; int node; int alpha_from_op; };   // src: >=0 input position, < 0: -(slot+1)
 struct EqnPlan {
+  JitKernel* fused = nullptr;       // whole tree as ONE generated kernel (element-wise trees), else the step chain below
+  std::vector<int> fused_inputs;    // input positions in kernel-argument order
+  std::vector<int> fused_alphas;    // op_arg positions of scalar op arguments, in kernel-argument order
   std::vector<EqnStep> steps;
   std::vector<int> slot_of;         // per node: workspace slot (-1: none)
   size_t slot_bytes = 0; int nslots = 0;
@@ -134,13 +138,176 @@ void print_rpn(const Equation& e, int id) {
   if (nd.kind == EQ_ARG) std::printf("ARG%d ", nd.in_pos); else std::printf("%s%d ", nd.kind == EQ_UNARY ? "U" : nd.kind == EQ_BINARY ? "B" : "T", nd.op);
 }
 
+
+// ---- whole-tree fusion for element-wise equations ---------------------------------------------------------------------
+// Conditions: every op is element-wise arithmetic with an f32 op type, every broadcast operand is an argument, all full
+// operands share the output's m x n, m and every leading dimension are multiples of 8.  One thread = 8 consecutive rows
+// of one column; the expression is emitted in post-order on 8-element register arrays with the SAME per-element
+// formulas as meltw_kernels.hip (contraction off), so the result is bit-identical to the step chain.
+const char* kFusedPrelude = R"SRC(
+#define GM __attribute__((address_space(1)))
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float daz(float x) { return ((__float_as_uint(x) & 0x7f800000u) == 0u) ? __uint_as_float(__float_as_uint(x) & 0x80000000u) : x; }
+__device__ __forceinline__ unsigned int f2bf_pk(float lo, float hi) { const f32x2 v = {daz(lo), daz(hi)}; return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ void ld_f32(float (&x)[8], GM const float* p) { const f32x4 a = *(GM const f32x4*)p, b = *(GM const f32x4*)(p + 4);
+  x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3]; }
+__device__ __forceinline__ void ld_bf16(float (&x)[8], GM const unsigned short* p) { const u32x4 v = *(GM const u32x4*)p;
+  _Pragma("unroll") for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(v[e] << 16); x[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); } }
+__device__ __forceinline__ void st_f32(GM float* p, const float (&y)[8]) { f32x4 a, b; a[0] = y[0]; a[1] = y[1]; a[2] = y[2]; a[3] = y[3]; b[0] = y[4]; b[1] = y[5]; b[2] = y[6]; b[3] = y[7];
+  *(GM f32x4*)p = a; *(GM f32x4*)(p + 4) = b; }
+__device__ __forceinline__ void st_bf16(GM unsigned short* p, const float (&y)[8]) { u32x4 v; _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = f2bf_pk(y[2 * e], y[2 * e + 1]); *(GM u32x4*)p = v; }
+__device__ __forceinline__ float sigm(float x) { return (tanhf(x * 0.5f) + 1.0f) * 0.5f; }
+)SRC";
+
+const char* unary_expr(int t) {     // %s = operand, A = alpha  [same formulas as unary_math in meltw_kernels.hip]
+  switch (t) {
+    case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: return "X";
+    case LIBXSMM_MELTW_TYPE_UNARY_X2: return "X * X";
+    case LIBXSMM_MELTW_TYPE_UNARY_SQRT: return "sqrtf(X)";
+    case LIBXSMM_MELTW_TYPE_UNARY_RELU: return "(X <= 0.0f) ? 0.0f : X";
+    case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: return "(X <= 0.0f) ? A * X : X";
+    case LIBXSMM_MELTW_TYPE_UNARY_TANH: return "tanhf(X)";
+    case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID: return "sigm(X)";
+    case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: return "-1.0f * X";
+    case LIBXSMM_MELTW_TYPE_UNARY_INC: return "X + 1.0f";
+    case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL: return "1.0f / X";
+    case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT: return "1.0f / sqrtf(X)";
+    case LIBXSMM_MELTW_TYPE_UNARY_EXP: return "expf(X)";
+    default: return nullptr;
+  }
+}
+const char* binary_expr(int t) {
+  switch (t) {
+    case LIBXSMM_MELTW_TYPE_BINARY_ADD: return "X + Y";
+    case LIBXSMM_MELTW_TYPE_BINARY_SUB: return "X - Y";
+    case LIBXSMM_MELTW_TYPE_BINARY_MUL: return "X * Y";
+    case LIBXSMM_MELTW_TYPE_BINARY_DIV: return "X / Y";
+    case LIBXSMM_MELTW_TYPE_BINARY_MAX: return "(X > Y) ? X : Y";
+    case LIBXSMM_MELTW_TYPE_BINARY_MIN: return "(X > Y) ? Y : X";
+    default: return nullptr;
+  }
+}
+std::string subst(const char* tmpl, const std::string& x, const std::string& y, const std::string& alpha) {
+  std::string out;
+  for (const char* c = tmpl; *c; ++c) { if (*c == 'X') out += x; else if (*c == 'Y') out += y; else if (*c == 'A' && (c == tmpl || c[-1] == ' ') ) out += alpha; else out += *c; }
+  return out;
+}
+
+int bcast_of(const EqnNode& parent, int operand) {   // 0 none, 1 row, 2 col, 3 scalar
+  const unsigned int f = parent.flags;
+  if (parent.kind == EQ_UNARY) { if (f & LIBXSMM_MELTW_FLAG_UNARY_BCAST_ROW) return 1; if (f & LIBXSMM_MELTW_FLAG_UNARY_BCAST_COL) return 2; if (f & LIBXSMM_MELTW_FLAG_UNARY_BCAST_SCALAR) return 3; return 0; }
+  if (parent.kind == EQ_BINARY) {
+    if (f & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_ROW_IN_0 << operand)) return 1; if (f & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_COL_IN_0 << operand)) return 2;
+    if (f & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_SCALAR_IN_0 << operand)) return 3; return 0;
+  }
+  if (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_ROW_IN_0 << operand)) return 1; if (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_COL_IN_0 << operand)) return 2;
+  if (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_SCALAR_IN_0 << operand)) return 3; return 0;
+}
+
+// returns false when the tree is not fusable; on success `src` holds the kernel source
+bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eqn_idx, std::string& src, std::string& fname, EqnPlan& plan, long long& total) {
+  const EqnNode& root = e.nodes[0];
+  const int M = root.m, N = root.n;
+  if (M % 8 != 0 || out.ld % 8 != 0 || (out.type != LIBXSMM_DATATYPE_F32 && out.type != LIBXSMM_DATATYPE_BF16)) return false;
+  std::vector<int> order; postorder(e, 0, order);
+  std::string body;
+  char buf[512];
+  std::map<int, int> arg_slot;                     // input position -> kernel argument index
+  std::vector<std::pair<int, int> > arg_types;     // (input position, datatype)
+  auto operand = [&](const EqnNode& parent, int c, std::string& name) -> bool {
+    const EqnNode& ch = e.nodes[parent.child[c]];
+    const int bc = bcast_of(parent, c);
+    if (ch.kind != EQ_ARG) {
+      if (bc != 0 || ch.m != M || ch.n != N) return false;
+      name = "v" + std::to_string(parent.child[c]);
+      return true;
+    }
+    if (ch.type != LIBXSMM_DATATYPE_F32 && ch.type != LIBXSMM_DATATYPE_BF16) return false;
+    if (bc == 0 && (ch.m != M || ch.n != N || ch.ld % 8 != 0)) return false;
+    if (bc == 2 && ch.m != M) return false;
+    if (arg_slot.find(ch.in_pos) == arg_slot.end()) { arg_slot[ch.in_pos] = (int)arg_types.size(); arg_types.push_back({ch.in_pos, ch.type}); }
+    else if (arg_types[arg_slot[ch.in_pos]].second != ch.type) return false;
+    const int k = arg_slot[ch.in_pos];
+    name = "a" + std::to_string(parent.child[c]);
+    const char* T = ch.type == LIBXSMM_DATATYPE_F32 ? "float" : "unsigned short";
+    const char* LD = ch.type == LIBXSMM_DATATYPE_F32 ? "ld_f32" : "ld_bf16";
+    if (bc == 0 || bc == 2) {
+      std::snprintf(buf, sizeof(buf), "  float %s[8]; %s(%s, (GM const %s*)in%d + i%s);\n", name.c_str(), LD, name.c_str(), T, k,
+                    bc == 0 ? (" + j * " + std::to_string(ch.ld) + "LL").c_str() : "");
+    } else {
+      const std::string idx = bc == 1 ? ("j * " + std::to_string(ch.ld) + "LL") : std::string("0");
+      if (ch.type == LIBXSMM_DATATYPE_F32) std::snprintf(buf, sizeof(buf), "  float %s[8]; { const float s = ((GM const float*)in%d)[%s]; _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) %s[e] = s; }\n", name.c_str(), k, idx.c_str(), name.c_str());
+      else std::snprintf(buf, sizeof(buf), "  float %s[8]; { const float s = __uint_as_float((unsigned int)((GM const unsigned short*)in%d)[%s] << 16); _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) %s[e] = s; }\n", name.c_str(), k, idx.c_str(), name.c_str());
+    }
+    body += buf;
+    return true;
+  };
+  for (int id : order) {
+    const EqnNode& nd = e.nodes[id];
+    if (nd.dtype != LIBXSMM_DATATYPE_F32 || nd.m != M || nd.n != N) return false;
+    std::string x, y, z, alpha = "0.0f";
+    const std::string v = "v" + std::to_string(id);
+    if (nd.kind == EQ_UNARY) {
+      const char* t = unary_expr(nd.op);
+      if (!t || (nd.flags & ~(unsigned int)(LIBXSMM_MELTW_FLAG_UNARY_BCAST_ROW | LIBXSMM_MELTW_FLAG_UNARY_BCAST_COL | LIBXSMM_MELTW_FLAG_UNARY_BCAST_SCALAR))) return false;
+      if (!operand(nd, 0, x)) return false;
+      if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU) { if (nd.op_arg_pos < 0 || plan.fused_alphas.size() >= 8) return false; alpha = "alpha" + std::to_string(plan.fused_alphas.size()); plan.fused_alphas.push_back(nd.op_arg_pos); }
+      body += "  float " + v + "[8];\n  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + v + "[e] = " + subst(t, x + "[e]", "", alpha) + ";\n";
+    } else if (nd.kind == EQ_BINARY) {
+      const char* t = binary_expr(nd.op);
+      if (!t || !operand(nd, 0, x) || !operand(nd, 1, y)) return false;
+      body += "  float " + v + "[8];\n  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + v + "[e] = " + subst(t, x + "[e]", y + "[e]", alpha) + ";\n";
+    } else {
+      if (nd.op != LIBXSMM_MELTW_TYPE_TERNARY_MULADD && nd.op != LIBXSMM_MELTW_TYPE_TERNARY_NMULADD) return false;
+      if (!operand(nd, 0, x) || !operand(nd, 1, y) || !operand(nd, 2, z)) return false;
+      body += "  float " + v + "[8];\n  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) { const float prod = " + x + "[e] * " + (nd.op == LIBXSMM_MELTW_TYPE_TERNARY_MULADD ? y : z) + "[e]; " + v + "[e] = " +
+              (nd.op == LIBXSMM_MELTW_TYPE_TERNARY_MULADD ? z + "[e] + prod" : y + "[e] - prod") + "; }\n";
+    }
+  }
+  if (arg_types.empty() || arg_types.size() > 24) return false;
+  total = (long long)(M / 8) * N;
+  fname = "meqn_jit_e" + std::to_string(eqn_idx) + "_" + std::to_string(M) + "x" + std::to_string(N) + "_o" + std::to_string((int)out.type);
+  src = kFusedPrelude;
+  src += "extern \"C\" __global__ __launch_bounds__(256) void " + fname + "(";
+  for (size_t k = 0; k < arg_types.size(); ++k) src += "const void* in" + std::to_string(k) + ", ";
+  src += "void* out";
+  for (size_t k = 0; k < plan.fused_alphas.size(); ++k) src += ", float alpha" + std::to_string(k);
+  src += ") {\n";
+  std::snprintf(buf, sizeof(buf), "  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n  if (t >= %lldLL) return;\n  const long long j = t / %d, i = (t - j * %d) * 8;\n", total, M / 8, M / 8);
+  src += buf;
+  src += body;
+  std::snprintf(buf, sizeof(buf), "  %s((GM %s*)out + i + j * %dLL, v0);\n}\n", out.type == LIBXSMM_DATATYPE_F32 ? "st_f32" : "st_bf16", out.type == LIBXSMM_DATATYPE_F32 ? "float" : "unsigned short", (int)out.ld);
+  src += buf;
+  for (auto& a : arg_types) plan.fused_inputs.push_back(a.first);
+  return true;
+}
+
 }  // namespace
 
-void free_meqn_plan(EqnPlan* plan) { delete plan; }
+const char* meqn_plan_name(const EqnPlan* plan) { return (plan && plan->fused) ? jit_name(plan->fused) : "meqn_tpp_chain"; }
+void free_meqn_plan(EqnPlan* plan) { if (plan && plan->fused) jit_release(plan->fused); delete plan; }
 
 void run_meqn(EqnPlan* plan, const void* param) {
   const libxsmm_meqn_param* p = (const libxsmm_meqn_param*)param;
   if (!p->inputs || !p->output.primary) { set_error(-2, "matrix equation called without inputs / output"); return; }
+  if (plan->fused && jit_on_current_device(plan->fused)) {
+    const void* ptrs[24]; float alphas[8]; void* args[33]; int na = 0; bool ok = true;
+    for (size_t i = 0; i < plan->fused_inputs.size(); ++i) {
+      ptrs[i] = p->inputs[plan->fused_inputs[i]].primary;
+      ok = ok && ptrs[i] && (((size_t)ptrs[i]) & 15) == 0;
+      args[na++] = (void*)&ptrs[i];
+    }
+    void* outp = p->output.primary; ok = ok && (((size_t)outp) & 15) == 0;
+    args[na++] = (void*)&outp;
+    for (size_t i = 0; i < plan->fused_alphas.size() && ok; ++i) {
+      if (!p->ops_args || !p->ops_args[plan->fused_alphas[i]].primary) { set_error(-2, "matrix equation: op argument %d is NULL", plan->fused_alphas[i]); return; }
+      alphas[i] = *(const float*)p->ops_args[plan->fused_alphas[i]].primary; args[na++] = (void*)&alphas[i];
+    }
+    if (ok) { rt_finish_launch(jit_launch(plan->fused, args, rt_stream()), "meqn_jit"); return; }
+  }
   char* ws = nullptr;
   if (plan->nslots > 0) { ws = (char*)rt_workspace(plan->slot_bytes * (size_t)plan->nslots); if (!ws) return; }
   const char* kname = nullptr;
@@ -271,7 +438,9 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       if ((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER || nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER ||
           nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP || nd.op == LIBXSMM_MELTW_TYPE_UNARY_DUMP || nd.op == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR ||
           nd.op == LIBXSMM_MELTW_TYPE_UNARY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) d = nullptr;
-      if (st.alpha_from_op < 0 && (nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || nd.op == LIBXSMM_MELTW_TYPE_UNARY_ELU)) d = nullptr;
+      // parameterised activations: the reference's equation generators do not apply ops_args to them (its CPU JIT leaves the
+      // negative side unscaled), so there is no behaviour to be compatible with: refuse instead of guessing
+      if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || nd.op == LIBXSMM_MELTW_TYPE_UNARY_ELU) d = nullptr;
     } else if (nd.kind == EQ_BINARY) {
       a.operation = LIBXSMM_MELTW_OPERATION_BINARY; a.m = nd.m; a.n = nd.n;
       a.in1_type = ch[1]->type; a.ldi1 = ch[1]->ld;
@@ -288,6 +457,15 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
     if (!d || !meltw_supported(*d)) { delete plan; return nullptr; }
     // the broadcast flags of an op refer to operands that really are vectors / scalars of the result
     plan->steps.push_back(st);
+  }
+  if (rt_jit_mode() != 0) {     // element-wise trees: one generated kernel instead of one launch per node
+    std::string src, fname; long long total = 0;
+    EqnPlan probe;
+    if (generate_fused(*e, out, idx, src, fname, probe, total)) {
+      std::string why;
+      plan->fused = jit_compile(src, fname, total, 16, &why);
+      if (plan->fused) { plan->fused_inputs = probe.fused_inputs; plan->fused_alphas = probe.fused_alphas; }
+    }
   }
   const void* h = rt_new_meqn_handle(plan);
   if (!h) { delete plan; return nullptr; }

@@ -18,6 +18,8 @@
 
 using namespace xamd;
 
+static int jit_mode();   // LIBXSMM_HIP_JIT / libxsmm_hip_set_jit, defined with the sparse creators
+
 // ---- exported global state [ref: include/libxsmm_generator.h:213-222] ---------------------------
 extern "C" {
 __attribute__((visibility("default"))) unsigned int libxsmm_ninit = 0;
@@ -459,13 +461,14 @@ const void* rt_new_meqn_handle(EqnPlan* plan) {
   std::lock_guard<std::mutex> guard(g_lock);
   KernelCtx* c = new_ctx_locked(K_MEQN);
   if (!c) return nullptr;
-  c->registered = true; c->eqn = plan; c->kname_single = c->kname_batched = "meqn";
+  c->registered = true; c->eqn = plan; c->kname_single = c->kname_batched = meqn_plan_name(plan);
   return handle_for_slot(c->slot);
 }
 void rt_finish_launch(int err, const char* kernel_name) { finish_launch(err, kernel_name); }
 void* rt_workspace(size_t nbytes) { return workspace(nbytes); }
 bool rt_ready() { return runtime_ready(); }
 void* rt_stream() { return tls().stream; }
+int rt_jit_mode() { return jit_mode(); }
 
 void invoke(int slot, const void* param) {
   KernelCtx* k = g_slots[slot];
