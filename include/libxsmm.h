@@ -422,6 +422,15 @@ LIBXSMM_API libxsmm_meltwfunction_binary libxsmm_dispatch_meltw_binary(libxsmm_m
 LIBXSMM_API libxsmm_meltwfunction_ternary libxsmm_dispatch_meltw_ternary(libxsmm_meltw_ternary_type ternary_type,
   libxsmm_meltw_ternary_shape ternary_shape, libxsmm_bitfield ternary_flags);
 
+/* ---- BLAS-style small GEMM (column-major; alpha is taken as 1, beta as 0 or 1, NULL n/k/ld* default as in BLAS-less LIBXSMM)
+ * [ref: src/libxsmm_main.c:3933-3949, src/libxsmm_main.h:215-240] ------------------- */
+LIBXSMM_API void libxsmm_dgemm(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const double* alpha, const double* a, const libxsmm_blasint* lda, const double* b, const libxsmm_blasint* ldb,
+  const double* beta, double* c, const libxsmm_blasint* ldc);
+LIBXSMM_API void libxsmm_sgemm(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb,
+  const float* beta, float* c, const libxsmm_blasint* ldc);
+
 /* ---- matrix equations: trees of TPPs evaluated as one kernel handle
  * [ref: include/libxsmm.h:149-162; include/libxsmm_typedefs.h:586-591,617-657,683-694; src/libxsmm_matrixeqn.c;
  *  semantics = src/generator_matequation_reference_impl.c:105-227: the tree is evaluated bottom-up, every op node is the

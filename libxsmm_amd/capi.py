@@ -221,6 +221,9 @@ class Api:
         self.dispatch_meltw_unary = f("dispatch_meltw_unary", vp, [C.c_int, UnaryShape, C.c_uint])
         self.dispatch_meltw_binary = f("dispatch_meltw_binary", vp, [C.c_int, BinaryShape, C.c_uint])
         self.dispatch_meltw_ternary = f("dispatch_meltw_ternary", vp, [C.c_int, TernaryShape, C.c_uint])
+        ip = C.POINTER(C.c_int)
+        self.sgemm = f("sgemm", None, [C.c_char_p, C.c_char_p, ip, ip, ip, vp, vp, ip, vp, ip, vp, vp, ip])
+        self.dgemm = f("dgemm", None, [C.c_char_p, C.c_char_p, ip, ip, ip, vp, vp, ip, vp, ip, vp, vp, ip])
         # matrix equations
         self.meqn_create = f("meqn_create", C.c_int, [])
         self.meqn_push_back_arg = f("meqn_push_back_arg", C.c_int, [MeqnMetadata, MeqnArgShape, MatrixArgAttributes])

@@ -26,6 +26,25 @@ struct libxsmm_fsspmdm {
   int M, N, K, ldb, ldc;
 };
 
+template <typename T>
+static void xgemm(libxsmm_datatype dt, const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const T* a, const libxsmm_blasint* lda, const T* b, const libxsmm_blasint* ldb, const T* beta, T* c, const libxsmm_blasint* ldc)
+{
+  if (!m) return;
+  const bool ta = transa && (*transa == 'T' || *transa == 't' || *transa == 'C' || *transa == 'c');
+  const bool tb = transb && (*transb == 'T' || *transb == 't' || *transb == 'C' || *transb == 'c');
+  const T fbeta = beta ? *beta : (T)1;
+  const libxsmm_blasint kk = k ? *k : *m, nn = n ? *n : kk;
+  const libxsmm_blasint la = std::max<libxsmm_blasint>(lda ? *lda : (ta ? kk : *m), 1), lb = std::max<libxsmm_blasint>(ldb ? *ldb : (tb ? nn : kk), 1);
+  const libxsmm_blasint lc = std::max<libxsmm_blasint>(ldc ? *ldc : *m, 1);
+  const libxsmm_bitfield flags = (ta ? LIBXSMM_GEMM_FLAG_TRANS_A : 0) | (tb ? LIBXSMM_GEMM_FLAG_TRANS_B : 0) | (fbeta != (T)0 ? 0 : LIBXSMM_GEMM_FLAG_BETA_0);
+  const libxsmm_gemmfunction f = libxsmm_dispatch_gemm(libxsmm_create_gemm_shape(*m, nn, kk, la, lb, lc, dt, dt, dt, dt), flags, LIBXSMM_GEMM_PREFETCH_NONE);
+  if (!f) { std::printf("LIBXSMM_GEMM failed\n"); return; }
+  libxsmm_gemm_param p; std::memset(&p, 0, sizeof(p));
+  p.a.primary = const_cast<T*>(a); p.b.primary = const_cast<T*>(b); p.c.primary = c;
+  f(&p);
+}
+
 extern "C" {
 
 LIBXSMM_API libxsmm_fsspmdm* libxsmm_fsspmdm_create(libxsmm_datatype datatype, libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K,
@@ -85,6 +104,17 @@ LIBXSMM_API void libxsmm_fsspmdm_destroy(libxsmm_fsspmdm* h) {
 }
 LIBXSMM_API void libxsmm_dfsspmdm_destroy(libxsmm_dfsspmdm* h) { libxsmm_fsspmdm_destroy(h); }
 LIBXSMM_API void libxsmm_sfsspmdm_destroy(libxsmm_sfsspmdm* h) { libxsmm_fsspmdm_destroy(h); }
+
+// ---- BLAS-style entry points: alpha is taken as 1, beta as 0 or 1, exactly like LIBXSMM_XGEMM
+// [ref: src/libxsmm_main.h:215-240, src/libxsmm_main.c:3933-3949] -------------------------------------------
+LIBXSMM_API void libxsmm_dgemm(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const double* alpha, const double* a, const libxsmm_blasint* lda, const double* b, const libxsmm_blasint* ldb, const double* beta, double* c, const libxsmm_blasint* ldc) {
+  (void)alpha; xgemm<double>(LIBXSMM_DATATYPE_F64, transa, transb, m, n, k, a, lda, b, ldb, beta, c, ldc);
+}
+LIBXSMM_API void libxsmm_sgemm(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb, const float* beta, float* c, const libxsmm_blasint* ldc) {
+  (void)alpha; xgemm<float>(LIBXSMM_DATATYPE_F32, transa, transb, m, n, k, a, lda, b, ldb, beta, c, ldc);
+}
 
 // ---- allocator: pinned, device-visible host memory so unmodified drivers keep working ------------
 LIBXSMM_API void* libxsmm_aligned_malloc(size_t size, size_t alignment) {

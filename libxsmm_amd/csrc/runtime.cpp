@@ -85,6 +85,11 @@ void finish_launch(int err, const char* kname) {
 
 // Index arrays (BR offsets / address lists, BCSC pattern) are dereferenced on the device.  Arrays in
 // plain host memory are staged through a per-thread device scratch; device-visible ones pass through.
+// Device blocks that were outgrown are RETIRED, not freed: a captured hipGraph (or a kernel still in flight on another
+// stream) may hold their address.  They are released at libxsmm_finalize.
+std::mutex g_retired_lock;
+std::vector<void*> g_retired;
+void retire_block(void* p) { if (p) { std::lock_guard<std::mutex> guard(g_retired_lock); g_retired.push_back(p); } }
 struct Scratch { char* base = nullptr; size_t cap = 0, used = 0; };
 thread_local Scratch t_scratch;
 const void* device_visible(const void* p, size_t nbytes) {
@@ -100,7 +105,7 @@ const void* device_visible(const void* p, size_t nbytes) {
     const size_t ncap = std::max<size_t>((s.used + need) * 2, 1 << 20);
     char* nb = nullptr;
     if (!hip_ok(hipMalloc((void**)&nb, ncap), "hipMalloc(scratch)")) return nullptr;
-    if (s.base) { (void)hipStreamSynchronize(cur_stream()); (void)hipMemcpy(nb, s.base, s.used, hipMemcpyDeviceToDevice); (void)hipFree(s.base); }
+    if (s.base) { (void)hipStreamSynchronize(cur_stream()); (void)hipMemcpy(nb, s.base, s.used, hipMemcpyDeviceToDevice); retire_block(s.base); }
     s.base = nb; s.cap = ncap;
   }
   char* dst = s.base + s.used; s.used += need;
@@ -114,7 +119,7 @@ thread_local Workspace t_workspace;
 void* workspace(size_t nbytes) {
   Workspace& w = t_workspace;
   if (nbytes > w.cap) {
-    if (w.base) { (void)hipStreamSynchronize(cur_stream()); (void)hipFree(w.base); w.base = nullptr; w.cap = 0; }
+    if (w.base) { retire_block(w.base); w.base = nullptr; w.cap = 0; }
     const size_t ncap = std::max<size_t>(nbytes, 4u << 20);
     if (!hip_ok(hipMalloc(&w.base, ncap), "hipMalloc(workspace)")) { w.base = nullptr; return nullptr; }
     w.cap = ncap;
@@ -504,6 +509,7 @@ LIBXSMM_API void libxsmm_finalize(void) {
   if (libxsmm_verbosity != 0) std::fprintf(stderr, "LIBXSMM-AMD: registry holds %zu kernels at exit\n", g_registry.size());
   for (auto& kv : g_registry) free_ctx_locked(kv.second);
   g_registry.clear();
+  { std::lock_guard<std::mutex> g2(g_retired_lock); for (void* p : g_retired) (void)hipFree(p); g_retired.clear(); }
 }
 
 LIBXSMM_API int libxsmm_get_target_archid(void) { return libxsmm_target_archid; }

@@ -204,3 +204,12 @@ XREF int xref_meqn_push_back_unary_op(libxsmm_meqn_op_metadata md, libxsmm_meltw
 XREF int xref_meqn_push_back_binary_op(libxsmm_meqn_op_metadata md, libxsmm_meltw_binary_type type, libxsmm_datatype dtype, libxsmm_bitfield flags) { return libxsmm_meqn_push_back_binary_op(md, type, dtype, flags); }
 XREF int xref_meqn_push_back_ternary_op(libxsmm_meqn_op_metadata md, libxsmm_meltw_ternary_type type, libxsmm_datatype dtype, libxsmm_bitfield flags) { return libxsmm_meqn_push_back_ternary_op(md, type, dtype, flags); }
 XREF libxsmm_meqn_function xref_dispatch_meqn(libxsmm_blasint idx, libxsmm_meqn_arg_shape out_shape) { return libxsmm_dispatch_meqn(idx, out_shape); }
+
+XREF void xref_dgemm(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const double* alpha, const double* a, const libxsmm_blasint* lda, const double* b, const libxsmm_blasint* ldb, const double* beta, double* c, const libxsmm_blasint* ldc) {
+  libxsmm_dgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
+}
+XREF void xref_sgemm(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,
+  const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb, const float* beta, float* c, const libxsmm_blasint* ldc) {
+  libxsmm_sgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
+}

@@ -261,3 +261,29 @@ def test_long_reduction_chain_is_split_and_matches_oracle(kw):
         rb, gb = case.valid_mask_bits(rmask), case.valid_mask_bits(gmask)
         assert (rb != gb).mean() < 0.02        # bits can only differ where the pre-activation is ~0
     assert api.hip_get_last_error() == 0 and launches >= 0 and n0 >= 0
+
+
+@pytest.mark.parametrize("ta,tb", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+def test_blas_style_sgemm_dgemm(ta, tb):
+    """libxsmm_sgemm / libxsmm_dgemm [ref: src/libxsmm_main.c:3933-3949]: column-major, alpha = 1, beta in {0, 1}."""
+    import torch
+    api = capi.load()
+    rng = np.random.default_rng(3)
+    m, n, k = 48, 24, 40
+    for npdt, fn in ((np.float32, api.sgemm), (np.float64, api.dgemm)):
+        A = rng.random((k, m) if ta == "N" else (m, k)).astype(npdt)        # numpy row-major == column-major transposed
+        B = rng.random((n, k) if tb == "N" else (k, n)).astype(npdt)
+        Cm = rng.random((n, m)).astype(npdt)
+        a_cm = A.T if ta == "N" else A                                       # the m x k matrix
+        b_cm = B.T if tb == "N" else B                                       # the k x n matrix
+        for beta in (0.0, 1.0):
+            ref = (a_cm.astype(np.float64) @ b_cm.astype(np.float64)).T + beta * Cm
+            dA, dB, dC = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), torch.from_numpy(Cm.copy()).cuda()
+            one, be = (C.c_float(1), C.c_float(beta)) if npdt == np.float32 else (C.c_double(1), C.c_double(beta))
+            im, in_, ik = C.c_int(m), C.c_int(n), C.c_int(k)
+            lda, ldb, ldc = C.c_int(A.shape[1]), C.c_int(B.shape[1]), C.c_int(m)
+            fn(ta.encode(), tb.encode(), C.byref(im), C.byref(in_), C.byref(ik), C.addressof(one), dA.data_ptr(), C.byref(lda), dB.data_ptr(), C.byref(ldb),
+               C.addressof(be), dC.data_ptr(), C.byref(ldc))
+            api.hip_sync(); api.check()
+            got = dC.cpu().numpy()
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < (1e-5 if npdt == np.float32 else 1e-13)
