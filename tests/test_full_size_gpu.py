@@ -1,0 +1,152 @@
+"""Parity at BASELINE.json's FULL sizes for configs #3, #4, #5 (config #2 lives in test_gemm_gpu.py).  Where the oracle
+finishes in seconds the whole result is compared; otherwise a size-independent property (each batch element of the big
+launch equals the oracle on that element alone, for a strided sample that includes the first and last element, plus
+linearity in the streamed operand) carries the claim."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import normf_rel
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, GEMM_FLAG
+from oracle import pyoracle
+from sparse_helpers import structured_2_of_8
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_bits(x):       # torch float tensor (values exactly representable) -> int16 tensor of bf16 bits
+    import torch
+    return (x.contiguous().view(torch.int32) >> 16).to(torch.int16)
+
+
+def _pattern(M, K, nnz, seed=555):
+    rng = np.random.default_rng(seed)
+    pos = np.sort(rng.choice(M * K, size=nnz, replace=False))
+    rowptr = np.zeros(M + 1, dtype=np.uint32)
+    np.add.at(rowptr, pos // K + 1, 1)
+    return np.cumsum(rowptr).astype(np.uint32), (pos % K).astype(np.uint32), (rng.integers(-4, 6, nnz) / 10.0 + 0.05)
+
+
+@pytest.mark.parametrize("density", [0.15, 0.10])
+def test_config3_packed_csr_full_width(density):
+    """35x35 operator, N = 35, P = 65536 (f32): the gold loop [ref: asparse_packed_csr.c:113-130] over all 80M outputs."""
+    import torch
+    api, orc = capi.load(), pyoracle.oracle()
+    M = K = N = 35; P = 65536
+    rowptr, colidx, vals = _pattern(M, K, int(round(M * K * density)))
+    vals = vals.astype(np.float32)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    B = (torch.randint(-4, 6, (K * N * P,), generator=g).float() / 10)
+    h = api.create_packed_spgemm_csr(capi.gemm_shape(M, N, K, 0, N, N, DT.F32, DT.F32, DT.F32, DT.F32), GEMM_FLAG.BETA_0, 0, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data)
+    assert h
+    dB, dC, dv = B.cuda(), torch.full((M * N * P,), 7.0, device="cuda"), torch.from_numpy(vals).cuda()
+    p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = dv.data_ptr(), dB.data_ptr(), dC.data_ptr()
+    capi.Api.call(h, p); api.hip_sync(); api.check()
+    ref = np.full(M * N * P, 7.0, dtype=np.float32)
+    Bn = B.numpy()
+    orc.lib.oracle_packed_spgemm_csr_asparse(DT.F32, M, N, K, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, Bn.ctypes.data, N, ref.ctypes.data, N, 1)
+    got = dC.cpu().numpy()
+    assert normf_rel(ref, got, DT.F32) <= 1e-5
+    empty = np.where(np.diff(rowptr.astype(np.int64)) == 0)[0]
+    for r in empty:
+        assert np.all(got.reshape(M, N * P)[r] == 7.0)            # rows without non-zeros stay untouched
+    api.release_kernel(h)
+
+
+def test_config3_fsspmdm_full_width():
+    """FsSpMDM, N = 2^20 columns, f64, beta = 1 [ref: pyfr_driver_asp_reg.c:351-375]."""
+    import torch
+    api, orc = capi.load(), pyoracle.oracle()
+    M = K = 35; N = 2 ** 20
+    rowptr, colidx, vals = _pattern(M, K, 184)
+    a = np.zeros((M, K))
+    for i in range(M):
+        a[i, colidx[rowptr[i]:rowptr[i + 1]]] = vals[rowptr[i]:rowptr[i + 1]]
+    a = np.ascontiguousarray(a)
+    al, be = C.c_double(2.0), C.c_double(1.0)
+    h = api.fsspmdm_create(DT.F64, M, N, K, K, N, N, C.addressof(al), C.addressof(be), a.ctypes.data, 0, None)
+    assert h
+    rng = np.random.default_rng(2)
+    B, C0 = rng.integers(-4, 6, K * N) / 10.0, rng.integers(-4, 6, M * N) / 10.0
+    dB, dC = torch.from_numpy(B).cuda(), torch.from_numpy(C0.copy()).cuda()
+    api.fsspmdm_execute(h, dB.data_ptr(), dC.data_ptr()); api.hip_sync(); api.check()
+    ref, sv = C0.copy(), (2.0 * vals)
+    orc.lib.oracle_fsspmdm(DT.F64, M, N, K, rowptr.ctypes.data, colidx.ctypes.data, sv.ctypes.data, B.ctypes.data, N, ref.ctypes.data, N, 0)
+    assert normf_rel(ref, dC.cpu().numpy(), DT.F64) <= 1e-12
+    api.fsspmdm_destroy(h)
+
+
+def test_config4_bcsc_full_batch():
+    """bf16 BCSC, 2:8 structured, M=64 K=256 N=64, m_blocks = 8192: every 127th M-block (and the last one) against the
+    gold loop on that block alone [ref: spmm_kernel.c:74-217]; the other blocks through linearity in A."""
+    import torch
+    api, orc = capi.load(), pyoracle.oracle()
+    M, K, N, mb, bk, bn = 64, 256, 64, 8192, 32, 16
+    colptr, rowidx = structured_2_of_8(K, N, bk, bn)
+    nnzb = len(rowidx)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rnd = lambda *s: torch.randint(-4, 6, s, generator=g).float() / 8          # eighths: exact in bf16
+    A1, A2, Bv = rnd(mb, K // 2, M, 2), rnd(mb, K // 2, M, 2), rnd(nnzb * bn * bk)
+    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, DT.BF16, DT.BF16, DT.F32, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    dBv, dcp, dri = _bf16_bits(Bv).cuda(), torch.from_numpy(colptr.view(np.int32)).cuda(), torch.from_numpy(rowidx.view(np.int32)).cuda()
+    nblk = C.c_ulonglong(N // bn)
+
+    def run(A):
+        dA, dC = _bf16_bits(A).cuda(), torch.empty(mb * N * M, dtype=torch.float32, device="cuda")
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = dA.data_ptr(), dBv.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), dC.data_ptr()
+        capi.Api.call(h, p); api.hip_sync(); api.check()
+        return dC
+    c1, c2, c12 = run(A1), run(A2), run(A1 + A2)                                  # sums of eighths up to 10/8 stay exact in bf16
+    assert torch.allclose(c12, c1 + c2, rtol=0, atol=1e-4)
+    sample = sorted(set(list(range(0, mb, 127)) + [mb - 1]))
+    As = _bf16_bits(A1[sample]).numpy().view(np.uint16).reshape(-1).copy()
+    bv_bits = _bf16_bits(Bv).numpy().view(np.uint16).copy()
+    ref = np.zeros(len(sample) * N * M, dtype=np.float32)
+    orc.lib.oracle_packed_spgemm_bcsc(DT.BF16, DT.F32, M, N, K, len(sample), bk, bn, 1, As.ctypes.data, bv_bits.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, 1)
+    got = c1.view(mb, N * M)[sample].reshape(-1).cpu().numpy()
+    assert normf_rel(ref, got, DT.F32) <= 1e-5
+    api.release_kernel(h)
+
+
+def test_config5_fused_bf16_brgemm_full_shard():
+    """bf16 64^3 + column bias + ReLU, the per-GPU shard of config #5 (2^17 problems): a strided sample of problems
+    against the oracle [ref: gemm ref :2367-2419, :294-372], and every problem through the batch == loop property on a
+    second launch with shuffled batch order."""
+    import torch
+    from helpers import TOL_BF16
+    api, orc = capi.load(), pyoracle.oracle()
+    m, batch = 64, 2 ** 17
+    g = torch.Generator(device="cpu").manual_seed(4)
+    rnd = lambda *s: torch.randint(-4, 6, s, generator=g).float() / 8
+    A, B, D = rnd(batch, m // 2, m, 2), rnd(batch, m, m), rnd(m)
+    dA, dB, dD = _bf16_bits(A).cuda(), _bf16_bits(B).cuda(), _bf16_bits(D).cuda()
+    sh = capi.gemm_shape(m, m, m, m, m, m, DT.BF16, DT.BF16, DT.BF16, DT.F32)
+    h = api.dispatch_brgemm_ext(sh, GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.br_config(capi.BR_STRIDE, m * m * 2, m * m * 2, 0),
+                                capi.argops_cp(m, capi.UNARY.RELU), capi.postops_colbias(m, DT.BF16))
+    assert h
+    cnt = C.c_ulonglong(1)
+    dC = torch.empty(batch * m * m, dtype=torch.int16, device="cuda")
+    p = capi.GemmExtParam()
+    p.a.primary, p.b.primary, p.c.primary, p.d.primary, p.op.tertiary = dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), dD.data_ptr(), C.addressof(cnt)
+    api.hip_gemm_ext_batch_strided(h, C.byref(p), batch, m * m * 2, m * m * 2, m * m * 2, 0, 0)
+    api.hip_sync(); api.check()
+    sample = sorted(set(list(range(0, batch, 4099)) + [batch - 1]))
+    from helpers import GemmCase
+    got = dC.view(batch, m * m)[sample].cpu().numpy().view(np.uint16)
+    a_bits, b_bits, d_bits = (_bf16_bits(x).numpy().view(np.uint16) for x in (A[sample], B[sample], D))
+    case = GemmCase(m, m, m, a_type=DT.BF16, c_type=DT.BF16, flags=GEMM_FLAG.VNNI_A, colbias=True, act=1, batch=len(sample), seed=0)
+    case.A, case.B, case.D = a_bits.reshape(-1).copy(), b_bits.reshape(-1).copy(), np.tile(d_bits, len(sample))
+    ref, _ = case.run_oracle()
+    assert normf_rel(case.valid_region(ref), got.reshape(-1), DT.BF16) < TOL_BF16
+    # the same kernel on a permuted batch order gives the permuted result, bit for bit (no cross-problem state)
+    perm = torch.randperm(batch, generator=g)
+    dA2, dB2 = dA.view(batch, -1)[perm.cuda()].contiguous(), dB.view(batch, -1)[perm.cuda()].contiguous()
+    dC2 = torch.empty_like(dC)
+    p.a.primary, p.b.primary, p.c.primary = dA2.data_ptr(), dB2.data_ptr(), dC2.data_ptr()
+    api.hip_gemm_ext_batch_strided(h, C.byref(p), batch, m * m * 2, m * m * 2, m * m * 2, 0, 0)
+    api.hip_sync(); api.check()
+    assert torch.equal(dC2.view(batch, -1), dC.view(batch, -1)[perm.cuda()])
