@@ -340,6 +340,8 @@ typedef struct libxsmm_registry_info { size_t capacity, size, nbytes, nstatic, n
 LIBXSMM_EXTERN unsigned int libxsmm_ninit;
 LIBXSMM_EXTERN int libxsmm_verbosity;
 LIBXSMM_EXTERN int libxsmm_target_archid;
+LIBXSMM_EXTERN int libxsmm_stdio_handle;
+LIBXSMM_EXTERN int libxsmm_se;
 LIBXSMM_API void libxsmm_init(void);
 LIBXSMM_API void libxsmm_finalize(void);
 LIBXSMM_API int libxsmm_get_target_archid(void);
@@ -525,7 +527,7 @@ LIBXSMM_API void libxsmm_convert_bf16_f32(const libxsmm_bfloat16* in, float* out
 /* Matrix comparison in the style of libxsmm_matdiff [ref: include/libxsmm_math.h:60-110;
  * src/libxsmm_matdiff.h:141-142]: normf_rel is the metric the reference's tests bound. */
 typedef struct libxsmm_matdiff_info {
-  double norm1_abs, norm1_rel, normi_abs, normi_rel, normf_rel, linf_abs, linf_rel, rsq;
+  double norm1_abs, norm1_rel, normi_abs, normi_rel, normf_rel, linf_abs, linf_rel, l2_abs, l2_rel, rsq;
   double l1_ref, min_ref, max_ref, avg_ref, var_ref, l1_tst, min_tst, max_tst, avg_tst, var_tst;
   double v_ref, v_tst;
   libxsmm_blasint m, n, i, r;
@@ -533,6 +535,8 @@ typedef struct libxsmm_matdiff_info {
 LIBXSMM_API int libxsmm_matdiff(libxsmm_matdiff_info* info, libxsmm_datatype datatype, libxsmm_blasint m, libxsmm_blasint n,
   const void* ref, const void* tst, const libxsmm_blasint* ldref, const libxsmm_blasint* ldtst);
 LIBXSMM_API void libxsmm_matdiff_clear(libxsmm_matdiff_info* info);
+/** Combines the result of one comparison into a running worst case [ref: src/libxsmm_math.c:386-446]. */
+LIBXSMM_API void libxsmm_matdiff_reduce(libxsmm_matdiff_info* output, const libxsmm_matdiff_info* input);
 LIBXSMM_API double libxsmm_matdiff_epsilon(const libxsmm_matdiff_info* input);
 
 #include "libxsmm_hip.h"

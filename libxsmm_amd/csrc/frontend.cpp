@@ -213,7 +213,25 @@ LIBXSMM_API int libxsmm_matdiff(libxsmm_matdiff_info* info, libxsmm_datatype dat
   for (libxsmm_blasint j = 0; j < n; ++j) for (libxsmm_blasint i = 0; i < m; ++i) { const double r = md_load(datatype, ref, j * ldr + i) - info->avg_ref; ss_tot += r * r; }
   info->var_ref = ss_tot; info->rsq = ss_tot > 0 ? std::max(0.0, 1.0 - l2_abs / ss_tot) : (l2_abs > 0 ? 0.0 : 1.0);
   info->norm1_abs = info->normi_abs = info->linf_abs; info->norm1_rel = info->normi_rel = info->linf_rel;
+  info->l2_abs = std::sqrt(l2_abs); info->l2_rel = normfr > 0 ? std::sqrt(l2_abs / normfr) : info->l2_abs;
   return EXIT_SUCCESS;
+}
+// running worst case over repeated comparisons [ref: src/libxsmm_math.c:386-446]
+LIBXSMM_API void libxsmm_matdiff_reduce(libxsmm_matdiff_info* out, const libxsmm_matdiff_info* in) {
+  if (!out || !in) { libxsmm_matdiff_clear(out); return; }
+  const double eps_in = libxsmm_matdiff_epsilon(in), eps_out = libxsmm_matdiff_epsilon(out);
+  if (out->linf_abs <= in->linf_abs) { out->linf_abs = in->linf_abs; out->linf_rel = in->linf_rel; }
+  if (out->norm1_abs <= in->norm1_abs) { out->norm1_abs = in->norm1_abs; out->norm1_rel = in->norm1_rel; }
+  if (out->normi_abs <= in->normi_abs) { out->normi_abs = in->normi_abs; out->normi_rel = in->normi_rel; }
+  if (out->l2_abs <= in->l2_abs) { out->l2_abs = in->l2_abs; out->l2_rel = in->l2_rel; }
+  out->normf_rel = std::max(out->normf_rel, in->normf_rel);
+  out->var_ref = std::max(out->var_ref, in->var_ref); out->var_tst = std::max(out->var_tst, in->var_tst);
+  out->max_ref = std::max(out->max_ref, in->max_ref); out->max_tst = std::max(out->max_tst, in->max_tst);
+  out->min_ref = std::min(out->min_ref, in->min_ref); out->min_tst = std::min(out->min_tst, in->min_tst);
+  if (eps_out < eps_in) { out->rsq = in->rsq; out->v_ref = in->v_ref; out->v_tst = in->v_tst; out->m = in->m; out->n = in->n; out->i = in->r; }
+  out->avg_ref = 0.5 * (out->avg_ref + in->avg_ref); out->avg_tst = 0.5 * (out->avg_tst + in->avg_tst);
+  out->l1_ref += in->l1_ref; out->l1_tst += in->l1_tst;
+  ++out->r;
 }
 LIBXSMM_API double libxsmm_matdiff_epsilon(const libxsmm_matdiff_info* in) {
   if (!in) return 0.0;

@@ -25,6 +25,8 @@ extern "C" {
 __attribute__((visibility("default"))) unsigned int libxsmm_ninit = 0;
 __attribute__((visibility("default"))) int libxsmm_verbosity = 0;
 __attribute__((visibility("default"))) int libxsmm_target_archid = LIBXSMM_TARGET_ARCH_GENERIC;
+__attribute__((visibility("default"))) int libxsmm_stdio_handle = 0;   // [ref: include/libxsmm_generator.h:214] 0: no user lock on I/O
+__attribute__((visibility("default"))) int libxsmm_se = 0;             // security-enhanced environment: never the case here
 }
 
 namespace {

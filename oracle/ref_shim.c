@@ -12,6 +12,7 @@
  * what makes this shim a layout check for include/libxsmm.h: tests compare sizeof()s.
  */
 #include <libxsmm_source.h>
+#include <stddef.h>
 
 #define XREF __attribute__((visibility("default")))
 
@@ -28,7 +29,10 @@ XREF void xref_struct_sizes(size_t* out, int n) {
     sizeof(libxsmm_gemm_shape), sizeof(libxsmm_gemm_batch_reduce_config), sizeof(libxsmm_gemm_ext_unary_argops),
     sizeof(libxsmm_gemm_ext_binary_postops), sizeof(libxsmm_meltw_unary_shape), sizeof(libxsmm_meltw_binary_shape),
     sizeof(libxsmm_meltw_ternary_shape), sizeof(libxsmm_spgemm_config), sizeof(libxsmm_kernel_info),
-    sizeof(libxsmm_mmkernel_info), sizeof(libxsmm_descriptor_blob)
+    sizeof(libxsmm_mmkernel_info), sizeof(libxsmm_descriptor_blob),
+    sizeof(libxsmm_matdiff_info), offsetof(libxsmm_matdiff_info, rsq), offsetof(libxsmm_matdiff_info, v_ref), offsetof(libxsmm_matdiff_info, m),
+    sizeof(libxsmm_meqn_param), sizeof(libxsmm_meqn_arg_shape), sizeof(libxsmm_matrix_arg_attributes), sizeof(libxsmm_meqn_op_metadata),
+    sizeof(libxsmm_meltwkernel_info), sizeof(libxsmm_registry_info), offsetof(libxsmm_gemm_ext_param, d), offsetof(libxsmm_meqn_param, output)
   };
   int i; for (i = 0; i < n && i < (int)(sizeof(sizes) / sizeof(*sizes)); ++i) out[i] = sizes[i];
 }

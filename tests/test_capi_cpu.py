@@ -2,10 +2,13 @@
 declare, keeps the reference's calling conventions (shapes by value, NULL on illegal input), and FAILS LOUDLY
 rather than computing on the host when no HIP device is present."""
 import ctypes as C
+import os
 import subprocess
 import sys
 
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from libxsmm_amd import capi
 from libxsmm_amd.capi import DT, GEMM_FLAG
@@ -75,3 +78,34 @@ def test_product_package_does_not_touch_the_oracle():
                 assert "pyoracle" not in text and "liboracle" not in text and "libxsmm_ref" not in text, f
     out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_public_header_struct_layouts_match_reference_when_compiled_as_c(reference, tmp_path):
+    """sizeof / offsetof of the public structs as a C compiler sees include/libxsmm.h == the reference's own
+    (first 18 entries = the ctypes probe list, then matdiff / meqn / info structs and two offsets)."""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text(r'''
+#include <libxsmm.h>
+#include <stddef.h>
+#include <stdio.h>
+int main(void) {
+  const size_t s[] = {
+    sizeof(libxsmm_gemm_param), sizeof(libxsmm_gemm_ext_param), sizeof(libxsmm_matrix_arg), sizeof(libxsmm_matrix_op_arg),
+    sizeof(libxsmm_meltw_unary_param), sizeof(libxsmm_meltw_binary_param), sizeof(libxsmm_meltw_ternary_param),
+    sizeof(libxsmm_gemm_shape), sizeof(libxsmm_gemm_batch_reduce_config), sizeof(libxsmm_gemm_ext_unary_argops),
+    sizeof(libxsmm_gemm_ext_binary_postops), sizeof(libxsmm_meltw_unary_shape), sizeof(libxsmm_meltw_binary_shape),
+    sizeof(libxsmm_meltw_ternary_shape), sizeof(libxsmm_spgemm_config), sizeof(libxsmm_kernel_info),
+    sizeof(libxsmm_mmkernel_info), sizeof(libxsmm_descriptor_blob),
+    sizeof(libxsmm_matdiff_info), offsetof(libxsmm_matdiff_info, rsq), offsetof(libxsmm_matdiff_info, v_ref), offsetof(libxsmm_matdiff_info, m),
+    sizeof(libxsmm_meqn_param), sizeof(libxsmm_meqn_arg_shape), sizeof(libxsmm_matrix_arg_attributes), sizeof(libxsmm_meqn_op_metadata),
+    sizeof(libxsmm_meltwkernel_info), sizeof(libxsmm_registry_info), offsetof(libxsmm_gemm_ext_param, d), offsetof(libxsmm_meqn_param, output) };
+  size_t i; for (i = 0; i < sizeof(s) / sizeof(*s); ++i) printf("%zu\n", s[i]);
+  return 0;
+}
+''')
+    exe = tmp_path / "sizes"
+    r = subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ours = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
+    assert ours == reference.struct_sizes(len(ours))
