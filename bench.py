@@ -142,20 +142,29 @@ def capture(work, steps, rotate):
 
 def timed(work, steps, barrier, rotate=True):
     """Exactly `steps` steps between two (barrier + synchronize) pairs.  Returns (wall seconds, mean
-    microseconds per launch from HIP events recorded on the launch stream around the region)."""
-    graph = capture(work, steps, rotate)
-    graph.replay()                                # untimed: first replay uploads the graph
+    microseconds per launch from HIP events recorded on the launch stream around the region).
+    The steps are replayed from hipGraphs of at most 500 launches (a full chunk graph + a remainder graph)."""
+    chunk = min(steps, 500)
+    full, rem = divmod(steps, chunk)
+    g_full = capture(work, chunk, rotate)
+    g_rem = capture(work, rem, rotate) if rem else None
+    g_full.replay()                               # untimed: first replay uploads the graph
+    if g_rem is not None:
+        g_rem.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e0.record()
-    graph.replay()
+    for _ in range(full):
+        g_full.replay()
+    if g_rem is not None:
+        g_rem.replay()
     e1.record()
     torch.cuda.synchronize()
+    t1 = time.perf_counter()                      # this rank's K steps are complete here; MAX over ranks is taken by the caller
     barrier()
-    t1 = time.perf_counter()
     return t1 - t0, e0.elapsed_time(e1) * 1e3 / steps
 
 
