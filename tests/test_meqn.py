@@ -11,7 +11,7 @@ import pytest
 
 from helpers import normf_rel, rand_values
 from libxsmm_amd import capi
-from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, TERNARY, UNARY, UNARY_FLAG
+from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, TERNARY, TERNARY_FLAG, UNARY, UNARY_FLAG
 from oracle import pyoracle
 
 NPDT = {DT.F32: np.float32, DT.BF16: np.uint16}
@@ -95,6 +95,10 @@ CASES = {
     "ternary_muladd": (("t", TERNARY.MULADD, 0, A(0), ("u", UNARY.NEGATE, 0, A(1)), A(2)),
                        [(M, N, LD, DT.F32), (M, N, M, DT.F32), (M, N, LD, DT.F32)], (M, N, LD, DT.F32)),
     "tanh_sigmoid_chain": (("u", UNARY.TANH, 0, ("b", BINARY.MUL, 0, ("u", UNARY.SIGMOID, 0, A(0)), A(1))), [(M, N, LD, DT.F32), (M, N, LD, DT.F32)], (M, N, LD, DT.F32)),
+    # equation_simple_layernorm.c:85-106: ((x * s + b) * gamma + beta) with the mean/variance factors as broadcast scalars
+    "layernorm_affine": (("t", TERNARY.MULADD, TERNARY_FLAG.REUSE_IN_2_AS_OUT,
+                          ("t", TERNARY.MULADD, TERNARY_FLAG.BCAST_SCALAR_IN_1 | TERNARY_FLAG.BCAST_SCALAR_IN_2 | TERNARY_FLAG.REUSE_IN_2_AS_OUT, A(0), A(1), A(2)), A(3), A(4)),
+                         [(64, 32, 64, DT.BF16), (1, 1, 1, DT.F32), (1, 1, 1, DT.F32), (64, 32, 64, DT.BF16), (64, 32, 64, DT.BF16)], (64, 32, 64, DT.BF16)),
     "mixed_precision": (("b", BINARY.SUB, 0, ("u", UNARY.X2, 0, A(0)), ("b", BINARY.MUL, BINARY_FLAG.BCAST_SCALAR_IN_1, A(1), A(2))),
                         [(M, N, LD, DT.BF16), (M, N, M, DT.F32), (1, 1, 1, DT.F32)], (M, N, LD, DT.BF16)),
 }
@@ -145,7 +149,7 @@ def test_incomplete_and_unsupported_equations_return_null(api):
     assert api.dispatch_meqn(idx, capi.MeqnArgShape(8, 8, 8, DT.F32)) is None          # second operand missing
 
 
-FUSABLE = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain"}     # no reduction inside
+FUSABLE = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain", "layernorm_affine"}     # no reduction inside
 
 
 @pytest.mark.gpu
