@@ -176,6 +176,31 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     return;
   }
 
+  if (p.a_type == LIBXSMM_DATATYPE_I8 || p.a_type == LIBXSMM_DATATYPE_U8) {
+    // 8-bit integer GEMM, i32 accumulation [ref: gemm ref :1452-1683]; A VNNI-4 (always for f32 output), B flat
+    if (!valid) return;
+    const bool ua = p.a_type == LIBXSMM_DATATYPE_U8, ub = p.b_type == LIBXSMM_DATATYPE_U8, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+    const int kb4 = (c_f32 || va) ? 4 : 1;
+    int acc = 0;
+    if (!c_f32 && !beta0) acc = ((GM const int*)q.c)[(long long)j * p.ldc + i];
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      gcptr ar, br; br_base(p, q, r, ar, br);
+      for (int s = 0; s < p.k; ++s) {
+        const long long ai = (long long)(s / kb4) * ((long long)p.lda * kb4) + (long long)i * kb4 + (s % kb4), bi = (long long)j * p.ldb + s;
+        const int av = ua ? (int)((GM const unsigned char*)ar)[ai] : (int)((GM const signed char*)ar)[ai];
+        const int bv = ub ? (int)((GM const unsigned char*)br)[bi] : (int)((GM const signed char*)br)[bi];
+        acc += av * bv;
+      }
+    }
+    if (c_f32) {
+      GM float* c = (GM float*)q.c + (long long)j * p.ldc + i;
+      float f = mul_rn((float)acc, p.scf);
+      if (!beta0) f = add_rn(f, *c);
+      *c = f;
+    } else ((GM int*)q.c)[(long long)j * p.ldc + i] = acc;
+    return;
+  }
+
   float acc = 0.0f;
   if (valid) {
     const int kb = (p.a_type == LIBXSMM_DATATYPE_BF16 && va) ? 2 : 1;
@@ -900,6 +925,93 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8-bit integer streaming kernel (v_mfma_i32_32x32x32_i8): exact tiles, VNNI-4 A, flat B with 16-byte aligned columns,
+// k % 64 == 0.  Structure = gemm_bf16_stream_kernel: B through LDS-DMA with source-side swizzle, A straight into
+// operand registers.  The matrix core multiplies SIGNED bytes; an unsigned operand u is fed as (u ^ 0x80) = u - 128 and
+// the missing 128 * sum_k(other operand) comes from one more MFMA against an all-ones operand (exact integer
+// arithmetic): (a'+128) b = a'b + 128 sum b,  a (b'+128) = a b' + 128 sum a,  both: + 128*128*K as well.
+// ------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+template <int MT, int NT, bool UA, bool UB>
+__global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  char* lds = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  i32x16 acc[MT][NT], sum_b[NT], sum_a[MT];         // sum_b[nt]: 32x32 tile whose every column i holds sum_k b'(j,k); sum_a likewise per row
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; acc[mt][nt] = (i32x16)0; });
+  static_for<NT>([&](auto idx) { sum_b[idx.value] = (i32x16)0; });
+  static_for<MT>([&](auto idx) { sum_a[idx.value] = (i32x16)0; });
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  unsigned int offB[NT * 2];
+#pragma unroll
+  for (int x = 0; x < NT * 2; ++x) {
+    const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
+    offB[x] = f * ldb + pc * 16u;
+  }
+  const unsigned int offA = ((4u * h) * lda + (unsigned int)li) * 4u;      // dword (k-quad 4h, row li)
+  const i32x4 ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+  const int kchunks = p.k >> 6;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    gcptr bu = br + (unsigned long long)job.j0 * ldb;
+    gcptr au = ar + 4ull * (unsigned long long)job.i0;
+    for (int kc = 0; kc < kchunks; ++kc) {
+#pragma unroll
+      for (int x = 0; x < NT * 2; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(bu + 64ull * kc + offB[x]), (lds_vptr)(lds + 1024 * x), 16, 0, 0);
+      i32x4 af[MT][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int v = *(GM const int*)(au + (unsigned long long)(16 * kc + 8 * s + e) * lda * 4ull + 128ull * mt + offA);
+            af[mt][s][e] = UA ? (v ^ (int)0x80808080) : v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      i32x4 bfr[NT][2];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int f = 32 * nt + li;
+          i32x4 v = *(const i32x4*)(lds + f * 64 + (((2 * s + h) ^ ((f >> 1) & 3)) * 16));
+          if (UB) v ^= (i32x4)(int)0x80808080;
+          bfr[nt][s] = v;
+        }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+          acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0); });
+        if (UA) static_for<NT>([&](auto idx) { sum_b[idx.value] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr[idx.value][s], ones, sum_b[idx.value], 0, 0, 0); });
+        if (UB) static_for<MT>([&](auto idx) { sum_a[idx.value] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ones, af[idx.value][s], sum_a[idx.value], 0, 0, 0); });
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+  const int kconst = (UA && UB) ? 16384 * (int)(p.br_count * (unsigned long long)p.k) : 0;
+  static_for<MT * NT>([&](auto idx) {
+    constexpr int mt = idx.value / NT, nt = idx.value % NT;
+    GM char* ctile = (GM char*)q.c + 4ull * ((unsigned long long)(job.j0 + 32 * nt + 4 * h) * (unsigned int)p.ldc + job.i0 + 32 * mt + li);
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) {
+      int v = acc[mt][nt][r2] + kconst;
+      if (UA) v += 128 * sum_b[nt][r2];
+      if (UB) v += 128 * sum_a[mt][r2];
+      GM char* cp = ctile + 4ull * (unsigned long long)(((r2 & 3) + 8 * (r2 >> 2)) * p.ldc);
+      if (c_f32) { float f = (float)v * p.scf; if (!beta0) f = f + *(GM const float*)cp; *(GM float*)cp = f; }
+      else { if (!beta0) v += *(GM const int*)cp; *(GM int*)cp = v; }
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side selection
 // ------------------------------------------------------------------------------------------------
 bool gemm_supported(const libxsmm_gemm_descriptor& d) {
@@ -907,6 +1019,18 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d) {
   const bool f64 = d.a_type == LIBXSMM_DATATYPE_F64 && d.b_type == LIBXSMM_DATATYPE_F64 && d.c_type == LIBXSMM_DATATYPE_F64;
   const bool bf16 = d.a_type == LIBXSMM_DATATYPE_BF16 && d.b_type == LIBXSMM_DATATYPE_BF16 &&
                     (d.c_type == LIBXSMM_DATATYPE_F32 || d.c_type == LIBXSMM_DATATYPE_BF16);
+  const bool i8 = (d.a_type == LIBXSMM_DATATYPE_I8 || d.a_type == LIBXSMM_DATATYPE_U8) && (d.b_type == LIBXSMM_DATATYPE_I8 || d.b_type == LIBXSMM_DATATYPE_U8) &&
+                  (d.c_type == LIBXSMM_DATATYPE_I32 || d.c_type == LIBXSMM_DATATYPE_F32);
+  if (i8) {   // [ref: gemm ref :1452-1683]: i32 accumulation; no transposes, no fused ops, f32 output needs VNNI-4 A
+    const unsigned int fl8 = d.flags;
+    if (d.comp_type != LIBXSMM_DATATYPE_I32) return false;
+    if (fl8 & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) return false;
+    const bool va8 = (fl8 & LIBXSMM_GEMM_FLAG_VNNI_A) != 0;
+    if (d.c_type == LIBXSMM_DATATYPE_F32 && !va8) return false;
+    if (va8 && (d.k & 3)) return false;
+    if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    return d.lda >= d.m && d.ldb >= d.k && d.ldc >= d.m;
+  }
   if (!(f32 || f64 || bf16)) return false;
   if (f32 && d.comp_type != LIBXSMM_DATATYPE_F32) return false;
   if (f64 && d.comp_type != LIBXSMM_DATATYPE_F64) return false;
@@ -930,7 +1054,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d) {
   return true;
 }
 
-enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2 };
+enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2 };
 struct GemmPlan { GemmPath path; bool exact; };
 
 static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, int c_type, int vnni_c) {
@@ -945,6 +1069,13 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     pl.exact = ex32;
     pl.path = (m > 32 && n > 32) ? P_F32_2x2 : P_F32_1x1;
     if (pl.path == P_F32_2x2) pl.exact = (m % 64 == 0) && (n % 64 == 0) && (k % 32 == 0);
+    return pl;
+  }
+  if ((a_type == LIBXSMM_DATATYPE_I8 || a_type == LIBXSMM_DATATYPE_U8) && va && !ta && !tb && !vb) {
+    pl.path = (m > 32 && n > 32) ? P_I8_2x2 : P_I8_1x1;
+    const int t = (pl.path == P_I8_2x2) ? 64 : 32;
+    pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
+    if (!pl.exact) pl.path = P_GENERIC;
     return pl;
   }
   if (a_type == LIBXSMM_DATATYPE_BF16 && va && !ta && !tb && !vb) {
@@ -963,6 +1094,8 @@ static const char* path_name(GemmPath p) {
     case P_F32_2x2: return "gemm_mfma_f32_kernel<2,2>";
     case P_BF16_1x1: return "gemm_mfma_bf16_kernel<1,1>";
     case P_BF16_2x2: return "gemm_mfma_bf16_kernel<2,2>";
+    case P_I8_1x1: return "gemm_i8_stream_kernel<1,1>";
+    case P_I8_2x2: return "gemm_i8_stream_kernel<2,2>";
     default: return "gemm_generic_kernel";
   }
 }
@@ -1075,6 +1208,26 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
       break;
+    case P_I8_1x1: case P_I8_2x2: {
+      // same alignment contract as the bf16 streaming kernel (element size 1): B columns 16-byte aligned, A dword aligned
+      const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)a.ldb;
+      const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0) | (unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c;
+      const bool ok = !a.list_a && a.br_mode != 1 && a.br_mode != 2 && (bits & 15ull) == 0 && (abits & 3ull) == 0 && (long long)a.lda * a.k < (1ll << 31) && (long long)a.ldb * a.n < (1ll << 31);
+      if (ok) {
+        const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8, big = pl.path == P_I8_2x2;
+        grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
+#define LAUNCH_I8_(MT_, NT_) do { \
+          if (!ua && !ub) hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, false, false>), grid, dim3(256), 0, st, a); \
+          else if (ua && !ub) hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, true, false>), grid, dim3(256), 0, st, a); \
+          else if (!ua && ub) hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, false, true>), grid, dim3(256), 0, st, a); \
+          else hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, true, true>), grid, dim3(256), 0, st, a); } while (0)
+        if (big) LAUNCH_I8_(2, 2); else LAUNCH_I8_(1, 1);
+#undef LAUNCH_I8_
+        break;
+      }
+      if (kernel_name) *kernel_name = "gemm_generic_kernel";
+    }
+    // fallthrough
     default: {
       const long long blocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
       hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)blocks), dim3(64, 4), 0, st, a);

@@ -75,6 +75,7 @@ struct GemmArgs {
   int colbias, act;                                 // act: 0 none, 1 relu, 2 relu+bitmask, 3 sigmoid
   int vnni_c;
   int tiles_m, tiles_n;                             // set by launch_gemm for the tile size of the chosen kernel
+  float scf;                                        // 8-bit GEMM with f32 output: scale read from c.tertiary on the host
 };
 
 struct MeltwArgs {

@@ -265,6 +265,10 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   } else if (d.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_STRIDE) {
     a.br_mode = 3; a.br_stride_a = d.br_stride_a; a.br_stride_b = d.br_stride_b;
   }
+  if ((d.a_type == LIBXSMM_DATATYPE_I8 || d.a_type == LIBXSMM_DATATYPE_U8) && d.c_type == LIBXSMM_DATATYPE_F32) {
+    if (!p->c.tertiary) { set_error(-2, "8-bit GEMM with f32 output needs the scale in c.tertiary"); return; }   // [ref: gemm ref :591-592]
+    a.scf = *(const float*)p->c.tertiary;
+  }
   if (ext) {
     // fused epilogue decoded as the reference does [ref: gemm ref :404-428]
     if (d.bin_type == LIBXSMM_MELTW_TYPE_BINARY_ADD &&
@@ -283,7 +287,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   // apply beta / bias / activation in a second pass (SURVEY 8(d) config #2 variant B: one BRGEMM with br = 4096).
   static const bool split_off = []() { const char* e = getenv("LIBXSMM_HIP_BRSPLIT"); return e && e[0] == '0'; }();
   const long long tiles = (long long)((a.m + 31) / 32) * ((a.n + 31) / 32);
-  if (!split_off && a.br_mode == 3 && a.nbatch == 1 && !a.list_a && a.br_count >= 16 && tiles * 8 <= 1024 && a.a_type != LIBXSMM_DATATYPE_F64 && a.m > 0 && a.n > 0) {
+  if (!split_off && a.br_mode == 3 && a.nbatch == 1 && !a.list_a && a.br_count >= 16 && tiles * 8 <= 1024 && (a.a_type == LIBXSMM_DATATYPE_F32 || a.a_type == LIBXSMM_DATATYPE_BF16) && a.m > 0 && a.n > 0) {
     unsigned long long nsplit = std::min<unsigned long long>(a.br_count / 4, (unsigned long long)(2048 / tiles));
     const unsigned long long chunk = (a.br_count + nsplit - 1) / nsplit;
     const unsigned long long nfull = a.br_count / chunk, tail = a.br_count - nfull * chunk;

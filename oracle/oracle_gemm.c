@@ -162,6 +162,39 @@ static void c_to_vnni2_16bit(unsigned short* c, int m, int n, int ldc) {
   free(tmp);
 }
 
+/* 8-bit integer GEMM: A and B i8/u8 (signedness in the datatype), i32 accumulation over all (r, k).
+ * A is VNNI-4 [k/4][lda][4] under VNNI_A (flat [k][lda] otherwise, i32 output only), B flat [n][ldb].
+ * C i32: C = beta*C + sum [ref: :1452-1555]; C f32: C = float(sum) * scf (+ C), scf = *(float*)c.tertiary,
+ * A always VNNI-4 [ref: :1556-1683, scf :591-592]. */
+static int is_int8(int t) { return t == LIBXSMM_DATATYPE_I8 || t == LIBXSMM_DATATYPE_U8; }
+static void contract_int8(const gemm_view* v, const libxsmm_gemm_param* p, void* cptr, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const int ua = (d->a_type == LIBXSMM_DATATYPE_U8), ub = (d->b_type == LIBXSMM_DATATYPE_U8);
+  const int c_f32 = (d->c_type == LIBXSMM_DATATYPE_F32);
+  const long long kb = (c_f32 || v->va) ? 4 : 1;
+  const float scf = c_f32 ? *(const float*)p->c.tertiary : 1.0f;
+  long long i, j, r, s, k2;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    int acc = 0;
+    if (!c_f32 && !beta0) acc = ((int*)cptr)[j * d->ldc + i];
+    for (r = 0; r < v->br; ++r) {
+      const br_cursor cur = br_at(v, r);
+      for (s = 0; s < d->k / kb; ++s) for (k2 = 0; k2 < kb; ++k2) {
+        const long long ai = s * ((long long)d->lda * kb) + i * kb + k2, bi = j * (long long)d->ldb + s * kb + k2;
+        const int av = ua ? (int)((const unsigned char*)cur.a)[ai] : (int)((const signed char*)cur.a)[ai];
+        const int bv = ub ? (int)((const unsigned char*)cur.b)[bi] : (int)((const signed char*)cur.b)[bi];
+        acc += av * bv;
+      }
+    }
+    if (c_f32) {
+      float f = (float)acc;
+      f *= scf;
+      if (!beta0) f += ((float*)cptr)[j * d->ldc + i];
+      ((float*)cptr)[j * d->ldc + i] = f;
+    } else ((int*)cptr)[j * d->ldc + i] = acc;
+  }
+}
+
 void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   gemm_view v;
   const int is_ext = (d->flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) ? 1 : 0;
@@ -175,6 +208,7 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   setup_view(&v, param, d);
 
   if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
+  if (is_int8(d->a_type) && is_int8(d->b_type)) { contract_int8(&v, p, cptr, beta0); return; }
 
   {
     /* f32 working image: C itself for f32 output, otherwise a scratch of ldc x n floats [:262-272] */

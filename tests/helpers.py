@@ -46,6 +46,10 @@ def as_float(x: np.ndarray, dt: int) -> np.ndarray:
 
 
 def rand_values(rng: np.random.Generator, count: int, dt: int) -> np.ndarray:
+    if dt in (DT.I8, DT.I16, DT.I32):
+        return rng.integers(-9, 10, count).astype(NP_OF[dt])
+    if dt in (DT.U8, DT.U16, DT.U32):
+        return rng.integers(0, 19, count).astype(NP_OF[dt])
     v = (np.floor(rng.random(count) * 10.0) - 4.0) / 10.0
     if dt == DT.BF16:
         return f32_to_bf16_trunc(v.astype(np.float32))
@@ -72,12 +76,14 @@ class GemmCase:
     """One (BR)GEMM problem: descriptor inputs + host buffers."""
 
     def __init__(self, m, n, k, a_type=DT.F32, c_type=None, lda=None, ldb=None, ldc=None, flags=0,
-                 br_type=capi.BR_NONE, br_count=1, colbias=False, act=0, batch=1, seed=0, beta=0, shared_b=False):
+                 br_type=capi.BR_NONE, br_count=1, colbias=False, act=0, batch=1, seed=0, beta=0, shared_b=False, b_type=None, scf=None):
         rng = np.random.default_rng(seed)
         self.m, self.n, self.k = m, n, k
         self.a_type = a_type
+        self.b_type = a_type if b_type is None else b_type
         self.c_type = a_type if c_type is None else c_type
-        self.comp_type = DT.F64 if a_type == DT.F64 else DT.F32
+        self.comp_type = DT.F64 if a_type == DT.F64 else (DT.I32 if a_type in (DT.I8, DT.U8) else DT.F32)
+        self.scf = None if scf is None else C.c_float(scf)           # 8-bit GEMM with f32 output: scale read from c.tertiary
         ta, tb = bool(flags & GEMM_FLAG.TRANS_A), bool(flags & GEMM_FLAG.TRANS_B)
         self.lda = lda if lda is not None else (k if ta else m)
         self.ldb = ldb if ldb is not None else (n if tb else k)
@@ -94,7 +100,7 @@ class GemmCase:
         self.nbr = nbr
         # every batch element owns nbr A blocks and nbr B blocks (B optionally shared across the batch)
         self.A = rand_values(rng, batch * nbr * self.a_elems, a_type)
-        self.B = rand_values(rng, (1 if shared_b else batch) * nbr * self.b_elems, a_type)
+        self.B = rand_values(rng, (1 if shared_b else batch) * nbr * self.b_elems, self.b_type)
         self.C0 = rand_values(rng, batch * self.c_elems, self.c_type)
         self.D = rand_values(rng, batch * m, self.c_type) if colbias else None
         self.mask_ld = ((self.ldc + 15) // 16) * 16
@@ -112,7 +118,7 @@ class GemmCase:
 
     # ---- descriptor pieces ------------------------------------------------------------------
     def shape(self) -> capi.GemmShape:
-        return capi.gemm_shape(self.m, self.n, self.k, self.lda, self.ldb, self.ldc, self.a_type, self.a_type, self.c_type, self.comp_type)
+        return capi.gemm_shape(self.m, self.n, self.k, self.lda, self.ldb, self.ldc, self.a_type, self.b_type, self.c_type, self.comp_type)
 
     def brcfg(self) -> capi.BrConfig:
         if self.br_type == capi.BR_STRIDE:
@@ -133,7 +139,7 @@ class GemmCase:
         f |= {capi.BR_ADDRESS: GEMM_FLAG.BATCH_REDUCE_ADDRESS, capi.BR_OFFSET: GEMM_FLAG.BATCH_REDUCE_OFFSET,
               capi.BR_STRIDE: GEMM_FLAG.BATCH_REDUCE_STRIDE}.get(self.br_type, 0)
         f |= GEMM_FLAG.USE_XGEMM_EXT_ABI if self.ext else GEMM_FLAG.USE_XGEMM_ABI
-        return pyoracle.GemmDesc(self.m, self.n, self.k, self.lda, self.ldb, self.ldc, self.a_type, self.a_type, self.c_type,
+        return pyoracle.GemmDesc(self.m, self.n, self.k, self.lda, self.ldb, self.ldc, self.a_type, self.b_type, self.c_type,
                                  self.comp_type, f, self.br_stride_a, self.br_stride_b, int(self.colbias), self.act)
 
     # ---- param construction over arbitrary buffers ----------------------------------------------
@@ -157,6 +163,8 @@ class GemmCase:
             keep.append(cnt)
             p.op.tertiary = C.addressof(cnt)
         p.c.primary = ptr(Cbuf) + batch_index * self.bs_c
+        if self.scf is not None:
+            p.c.tertiary = C.addressof(self.scf)
         if self.ext:
             if self.colbias:
                 p.d.primary = ptr(D) + batch_index * self.bs_d

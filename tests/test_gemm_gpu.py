@@ -287,3 +287,32 @@ def test_blas_style_sgemm_dgemm(ta, tb):
             api.hip_sync(); api.check()
             got = dC.cpu().numpy()
             assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < (1e-5 if npdt == np.float32 else 1e-13)
+
+
+# 8-bit integer GEMMs: integer arithmetic -> bit-exact whatever the summation order
+SHAPES_I8 = [
+    dict(m=32, n=32, k=64, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3, batch=5),
+    dict(m=32, n=32, k=128, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, beta=1, batch=3),
+    dict(m=64, n=64, k=64, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, batch=4),
+    dict(m=64, n=64, k=192, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2, beta=1, batch=2),
+    dict(m=64, n=32, k=64, a_type=DT.U8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.0625, beta=1, batch=3),
+    dict(m=32, n=64, k=64, a_type=DT.I8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.5, batch=2),
+    dict(m=17, n=9, k=12, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, beta=1, ldc=20),     # generic kernel
+    dict(m=12, n=10, k=7, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32),                                        # flat A
+    dict(m=32, n=32, k=32, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A),                       # k % 64 != 0 -> generic
+]
+
+
+@pytest.mark.parametrize("kw", SHAPES_I8, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_int8_gemm_is_bit_identical(kw):
+    api = capi.load()
+    case = GemmCase(seed=21, **kw)
+    got, _, handle = case.run_gpu(batched=True)
+    ref, _ = case.run_oracle()
+    name = api.hip_kernel_name(handle, 1 if case.batch > 1 else 0).decode()
+    assert np.array_equal(case.valid_region(ref), case.valid_region(got)), name
+    exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 64 == 0 and (kw.get("flags", 0) & F.VNNI_A)
+    assert ("gemm_i8_stream_kernel" in name) == bool(exact), name
+    # unsupported combinations return NULL like the reference's dispatcher
+    assert api.dispatch_gemm(capi.gemm_shape(32, 32, 64, 32, 64, 32, DT.I8, DT.I8, DT.I32, DT.I32), F.VNNI_A | F.TRANS_A, 0) is None
+    assert api.dispatch_gemm(capi.gemm_shape(32, 32, 64, 32, 64, 32, DT.I8, DT.I8, DT.F32, DT.I32), 0, 0) is None      # f32 output needs VNNI-4 A

@@ -36,6 +36,14 @@ GEMM_CASES = [
     dict(m=20, n=12, k=16, colbias=True, act=2),
     dict(m=20, n=12, k=16, colbias=False, act=3, beta=1),
     dict(m=32, n=32, k=32, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, act=3),
+    # 8-bit integer GEMMs: every signedness combination, i32 and scaled f32 output
+    dict(m=32, n=32, k=64, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=32, n=32, k=64, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, beta=1),
+    dict(m=17, n=9, k=12, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, beta=1, ldc=20),
+    dict(m=16, n=16, k=32, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A),
+    dict(m=12, n=10, k=7, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32),                           # flat A
+    dict(m=32, n=32, k=32, a_type=DT.U8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.0625, beta=1),
+    dict(m=24, n=20, k=16, a_type=DT.I8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.5),
 ]
 
 

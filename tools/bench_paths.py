@@ -142,6 +142,25 @@ def brgemm(api, m, dtype, batch, fused=0, br=1, beta=0):
     return w
 
 
+def brgemm_i8(api, m, batch, ua=True):
+    """u8 x i8 -> i32 (VNNI-4 A), m = n = k: algorithmic bytes = 2*m*m (A, B) + 4*m*m (C) per problem."""
+    at = DT.U8 if ua else DT.I8
+    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, at, DT.I8, DT.I32, DT.I32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.br_config(capi.BR_STRIDE, m * m, m * m, 0))
+    assert h
+    ns = nsets_for(batch * 6 * m * m)
+    As = [torch.randint(0, 16, (batch * m * m,), device=DEV, dtype=torch.uint8) for _ in range(ns)]
+    Bs = [torch.randint(-8, 8, (batch * m * m,), device=DEV, dtype=torch.int8) for _ in range(ns)]
+    Cs = [torch.zeros(batch * m * m, device=DEV, dtype=torch.int32) for _ in range(ns)]
+    brc = C.c_ulonglong(1)
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc); ps.append(p)
+    w = Work(api, f"stride-BRGEMM {'u8' if ua else 'i8'} x i8 -> i32 m=n=k={m} batch={batch} br=1 beta=0", 2.0 * m ** 3 * batch, float(batch * 6 * m * m), ns,
+             lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, m * m, m * m, 4 * m * m), lambda: api.hip_kernel_name(h, 1).decode())
+    w.keep = (As, Bs, Cs, ps, brc)
+    return w
+
+
 def meltw_relu_tiles(api, batch=2 ** 17, m=64):
     """config #5 un-fused: bias-add (binary, col-bcast) then ReLU (unary) over bf16 64x64 tiles."""
     hb = api.dispatch_meltw_binary(BINARY.ADD, capi.BinaryShape(m, m, m, m, m, DT.BF16, DT.BF16, DT.BF16, DT.F32), BINARY_FLAG.BCAST_COL_IN_0)
@@ -314,7 +333,8 @@ def main():
                    lambda: brgemm(api, 32, "bf16", 2 ** 18), lambda: brgemm(api, 64, "bf16", 2 ** 16),
                    lambda: brgemm(api, 32, "f32", 2 ** 17, beta=1), lambda: brgemm(api, 32, "f32", 2 ** 14, br=8),
                    lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8),
-                   lambda: brgemm(api, 32, "f32", 1, br=4096), lambda: brgemm(api, 64, "bf16", 1, br=4096)]     # config #2 variant B: one long chain
+                   lambda: brgemm(api, 32, "f32", 1, br=4096), lambda: brgemm(api, 64, "bf16", 1, br=4096),
+                   lambda: brgemm_i8(api, 64, 2 ** 17, ua=True), lambda: brgemm_i8(api, 64, 2 ** 17, ua=False)]     # config #2 variant B: one long chain
     if "fused" in only:
         makers += [lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
     if "csr" in only:
