@@ -116,6 +116,7 @@ struct BcscArgs {
   const unsigned int* colptr; const unsigned int* rowidx;
   int M, N, K, m_blocks, bk, bn, nblk_n;
   int a_type, c_type, vnni_a, beta0;
+  void* table;                        // workspace for the inverted pattern: nblk_n * (K / bk) words (may be NULL)
 };
 
 // ---- run-time specialised sparse kernels (jit.cpp) ------------------------------------------------------

@@ -446,6 +446,7 @@ void run_bcsc(KernelCtx* k, const void* param) {
     }
   }
   if (!a.a || !a.bvals || !a.c || !a.rowidx) { set_error(-2, "BCSC kernel called with a NULL operand"); return; }
+  if (a.bk > 0 && a.K % a.bk == 0) a.table = workspace((size_t)std::max(1, a.nblk_n) * (size_t)(a.K / a.bk) * sizeof(unsigned int));
   const char* kname = nullptr;
   const int err = launch_bcsc(a, tls().stream, &kname);
   if (kname) k->kname_single = k->kname_batched = kname;

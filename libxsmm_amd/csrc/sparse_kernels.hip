@@ -314,6 +314,7 @@ template <typename F, int... Is> __device__ __forceinline__ void sfor_impl(F&& f
 template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int kBcscTbl = 1024;     // table entries per wave (n-blocks per wave x k-blocks)
+constexpr int kBcscTblDma = 256;   // same for the LDS-DMA kernel, which spends its LDS on the A ring instead
 
 template <int BN16>                // bn / 16
 __global__ __launch_bounds__(256) void bcsc_mfma_bf16_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int total) {
@@ -417,6 +418,157 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_kernel(BcscArgs p, unsigne
   });
 }
 
+// Inverts the BCSC pattern once per call: table[n-block][k-block] = block id (0xffffffff: none).  Every wave of the main
+// kernel needs the same rows of it; building it there costs each wave three dependent global round trips up front.
+__global__ void bcsc_invert_kernel(const unsigned int* colptr_, const unsigned int* rowidx_, unsigned int* table, int nblk_n, int nkb) {
+  GM const unsigned int* colptr = (GM const unsigned int*)colptr_; GM const unsigned int* rowidx = (GM const unsigned int*)rowidx_;
+  GM unsigned int* t = (GM unsigned int*)table;
+  const int nb = blockIdx.x;
+  if (nb >= nblk_n) return;
+  for (int e = threadIdx.x; e < nkb; e += blockDim.x) t[(long long)nb * nkb + e] = 0xffffffffu;
+  __syncthreads();
+  for (unsigned int b = colptr[nb] + threadIdx.x; b < colptr[nb + 1]; b += blockDim.x) t[(long long)nb * nkb + rowidx[b]] = b;
+}
+
+// Same algorithm with the A operand staged by LDS-DMA: a k-chunk of A for the wave's 64 rows ([16 k-pairs][64 i] dwords,
+// 4 KiB) arrives with four fully coalesced global_load_lds_dwordx4 (whole 256-byte rows instead of 64-byte dword
+// segments), the MFMA operand is then read with conflict-free ds_read_b32 (rows of odd k-groups are rotated by 16 words
+// on the SOURCE side so that the two k-groups of a half-wave hit different banks).  Per chunk: wait, read the operand
+// registers, fetch the B fragments of this chunk, start the DMA of the NEXT chunk into the same image, run the MFMAs.
+template <int BN16>
+__global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int total, const unsigned int* gtable) {
+  constexpr int NBL = 4 / BN16;
+  __shared__ unsigned int tbl_all[4][kBcscTblDma];
+  __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][3][1024];     // ring of three 4 KiB chunk images per wave
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = blockIdx.x * 4u + wave;
+  if (wid >= total) return;
+  unsigned int* tbl = tbl_all[wave];
+  unsigned int (*abuf)[1024] = abuf_all[wave];
+  const unsigned int tn = wid % tiles_n, tmp = wid / tiles_n, ti = tmp % tiles_i, mb = tmp / tiles_i;
+  const int lane = threadIdx.x & 63, lx = lane & 15, kg = lane >> 4;
+  const int i0 = (int)ti * 64, n0 = (int)tn * 64;
+  const int mt = (p.M - i0 >= 64) ? 4 : (p.M - i0) / 16;
+  const int nbl_cnt = ((p.N - n0 >= 64) ? 64 : (p.N - n0)) / (16 * BN16);
+  const int nb0 = n0 / (16 * BN16);
+  const int nkb = p.K / p.bk, steps = p.bk / 32;
+  {   // this wave's rows of the inverted pattern: one coalesced read
+    GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb;
+    for (int e = lane; e < nbl_cnt * nkb; e += 64) tbl[e] = gt[e];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  f32x4v acc[4][4];
+  const bool c_f32 = (p.c_type == LIBXSMM_DATATYPE_F32);
+  GM char* cbase = (GM char*)p.c + ((long long)mb * p.N * p.M) * (c_f32 ? 4 : 2);
+  sfor<16>([&](auto ic) {
+    constexpr int nt = ic.value / 4, it = ic.value % 4;
+    acc[nt][it] = (f32x4v)0.0f;
+    if (!p.beta0 && it < mt && nt < nbl_cnt * BN16) {
+      const long long e = (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg;
+      if (c_f32) acc[nt][it] = *(GM const f32x4v*)(cbase + e * 4);
+      else {
+        const u32x2v v = *(GM const u32x2v*)(cbase + e * 2);
+        acc[nt][it][0] = __uint_as_float(v[0] << 16); acc[nt][it][1] = __uint_as_float(v[0] & 0xffff0000u);
+        acc[nt][it][2] = __uint_as_float(v[1] << 16); acc[nt][it][3] = __uint_as_float(v[1] & 0xffff0000u);
+      }
+    }
+  });
+  // DMA source of LDS slot (lane + 64x): row kp_l = slot >> 4, the 16-byte group that lands there = (slot & 15) rotated back
+  GM const unsigned int* A2 = (GM const unsigned int*)p.a + (long long)mb * (p.K / 2) * p.M + i0;
+  unsigned int src_off[4]; bool src_ok[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const unsigned int S = (unsigned int)lane + 64u * x, kp_l = S >> 4, g = ((S & 15u) - 4u * ((kp_l >> 2) & 1u)) & 15u;
+    src_ok[x] = (int)(4u * g) < 16 * mt;                                  // groups beyond the wave's rows re-read group 0 (never consumed):
+    src_off[x] = kp_l * (unsigned int)p.M + (src_ok[x] ? 4u * g : 0u);    // every DMA instruction always issues -> the wait below can count
+  }
+  auto issue_a = [&](int kb, int st, int slot) {
+    GM const unsigned int* rowbase = A2 + ((long long)kb * (p.bk / 2) + 16 * st) * p.M;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)((char*)abuf[slot] + 1024 * x), 16, 0, 0);
+  };
+  // chunk sequence of this k-group: (k-block, step) pairs in order; `next_chunk` advances a cursor
+  auto next_chunk = [&](int& kb, int& st, unsigned long long& m, int kgp) -> bool {
+    if (st + 1 < steps) { ++st; return true; }
+    if (m == 0ull) return false;
+    st = 0; kb = kgp + (int)__builtin_ctzll(m); m &= m - 1ull;
+    return true;
+  };
+  // operand read: lane (row i = 16t + lx, k group kg) takes dwords of rows 4kg + e at word (i + 16*(kg & 1)) % 64
+  const int rot = 16 * (kg & 1);
+  GM const char* bv = (GM const char*)p.bvals;
+  for (int kgp = 0; kgp < nkb; kgp += 64) {
+    bool used = false;
+    const int kb_l = kgp + lane;
+    if (kb_l < nkb) for (int nbl = 0; nbl < nbl_cnt; ++nbl) used = used || (tbl[nbl * nkb + kb_l] != 0xffffffffu);
+    unsigned long long mask = __ballot(used);
+    if (mask == 0ull) continue;
+    // cursors: c0 = chunk being consumed, c1 = c0 + 1, c2 = c0 + 2 (the DMA runs two chunks ahead, the B fragments one)
+    int kb0 = kgp + (int)__builtin_ctzll(mask), st0 = 0; mask &= mask - 1ull;
+    int kb1 = kb0, st1 = st0; unsigned long long m1 = mask; const bool has1 = next_chunk(kb1, st1, m1, kgp);
+    int kb2 = kb1, st2 = st1; unsigned long long m2 = m1; bool has2 = has1 && next_chunk(kb2, st2, m2, kgp);
+    bool more1 = has1;
+    unsigned int blk_cur[NBL], blk_nxt[NBL]; u32x4v bf_cur[NBL][BN16], bf_nxt[NBL][BN16];
+    auto fetch_b = [&](unsigned int (&blk)[NBL], u32x4v (&bf)[NBL][BN16], int kb_, int st_) {
+      sfor<NBL>([&](auto nc) {
+        constexpr int nbl = nc.value;
+        blk[nbl] = 0xffffffffu;
+        if (nbl < nbl_cnt) {
+          blk[nbl] = (unsigned int)__builtin_amdgcn_readfirstlane((int)tbl[nbl * nkb + kb_]);
+          if (blk[nbl] != 0xffffffffu)
+            sfor<BN16>([&](auto sc) { constexpr int s2 = sc.value;
+              bf[nbl][s2] = *(GM const u32x4v*)(bv + (((long long)blk[nbl] * (16 * BN16) + 16 * s2 + lx) * p.bk + 32 * st_ + 8 * kg) * 2); });
+        }
+      });
+    };
+    int slot = 0;
+    issue_a(kb0, st0, 0);
+    fetch_b(blk_cur, bf_cur, kb0, st0);
+    if (more1) issue_a(kb1, st1, 1);
+    for (;;) {
+      // chunk c0 (image `slot`) and its B fragments must have landed; the 4 DMA instructions of chunk c1 may stay in flight
+      if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      u32x4v a_cur[4];
+      sfor<4>([&](auto tc) {
+        constexpr int t = tc.value;
+        if (t < mt) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a_cur[t][e] = abuf[slot][(4 * kg + e) * 64 + ((16 * t + lx + rot) & 63)];
+        }
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (more1) fetch_b(blk_nxt, bf_nxt, kb1, st1);                              // B of c1: older than the DMA of c2 queued next
+      if (has2) issue_a(kb2, st2, (slot + 2) % 3);                                // image of c0 - 1, whose reads retired last iteration
+      sfor<NBL>([&](auto nc) {
+        constexpr int nbl = nc.value;
+        if (nbl < nbl_cnt && blk_cur[nbl] != 0xffffffffu) {
+          sfor<BN16>([&](auto sc) {
+            constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
+            sfor<4>([&](auto tc) {
+              constexpr int t = tc.value;
+              if (t < mt) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a_cur[t]), __builtin_bit_cast(bf16x8v, bf_cur[nbl][s2]), acc[nt][t], 0, 0, 0);
+            });
+          });
+        }
+      });
+      if (!more1) break;
+      sfor<NBL>([&](auto nc) { constexpr int nbl = nc.value; blk_cur[nbl] = blk_nxt[nbl]; sfor<BN16>([&](auto sc) { bf_cur[nbl][sc.value] = bf_nxt[nbl][sc.value]; }); });
+      slot = (slot + 1) % 3;
+      kb1 = kb2; st1 = st2; more1 = has2;
+      if (has2) has2 = next_chunk(kb2, st2, m2, kgp);
+    }
+  }
+  sfor<16>([&](auto ic) {
+    constexpr int nt = ic.value / 4, it = ic.value % 4;
+    if (it < mt && nt < nbl_cnt * BN16) {
+      const long long e = (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg;
+      if (c_f32) *(GM f32x4v*)(cbase + e * 4) = acc[nt][it];
+      else { u32x2v v; v[0] = cvt2(acc[nt][it][0], acc[nt][it][1]); v[1] = cvt2(acc[nt][it][2], acc[nt][it][3]); *(GM u32x2v*)(cbase + e * 2) = v; }
+    }
+  });
+}
+
 int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
   if (a.m_blocks <= 0 || a.M <= 0 || a.N <= 0) { if (name) *name = "(empty)"; return 0; }
@@ -431,6 +583,18 @@ int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
       const long long total = (long long)tiles_i * tiles_n * a.m_blocks;
       if (total < (1ll << 31)) {
         const dim3 grid((unsigned int)((total + 3) / 4));
+        static const bool dma = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_DMA"); return !(e && e[0] == '0'); }();
+        const bool dma_ok = dma && a.table != nullptr && (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTblDma && ((size_t)a.a % 16 == 0) && (a.M % 4 == 0) && ((long long)(a.K / 2) * a.M < (1ll << 30));
+        if (dma_ok) {
+          const int nkb = a.K / a.bk;
+          const unsigned int* table = (const unsigned int*)a.table;
+          hipLaunchKernelGGL(bcsc_invert_kernel, dim3((unsigned int)a.nblk_n), dim3(64), 0, st, a.colptr, a.rowidx, (unsigned int*)a.table, a.nblk_n, nkb);
+          if (a.bn == 16) hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<1>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table);
+          else if (a.bn == 32) hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table);
+          else hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table);
+          if (name) *name = "bcsc_mfma_bf16_dma_kernel";
+          return (int)hipGetLastError();
+        }
         if (a.bn == 16) hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<1>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
         else if (a.bn == 32) hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
         else hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
