@@ -183,6 +183,27 @@ __global__ __launch_bounds__(256) void meltw_unary_kernel(MeltwArgs p) {
       mw_store(out, i + (long long)j * p.ldo, p.out_type, y);
       return;
     }
+    case LIBXSMM_MELTW_TYPE_UNARY_QUANT: {                      // f32 -> i8 / i16 / i32, round to nearest even [ref: :2195-2240]
+      if (!e.valid) return;
+      const bool sat = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_SIGN_SAT_QUANT) != 0;
+      float t = rintf(((GM const float*)in)[bc_index(bc, i, j, p.ldi)] * p.scalar_f32);
+      const long long o = i + (long long)j * p.ldo;
+      if (p.out_type == LIBXSMM_DATATYPE_I8) {
+        if (sat) { t = t < -128.0f ? -128.0f : t; t = t > 127.0f ? 127.0f : t; }
+        ((GM signed char*)out)[o] = (signed char)(0xff & (int)t);
+      } else if (p.out_type == LIBXSMM_DATATYPE_I16) {
+        if (sat) { t = t < -32768.0f ? -32768.0f : t; t = t > 32767.0f ? 32767.0f : t; }
+        ((GM short*)out)[o] = (short)(0xffff & (int)t);
+      } else ((GM int*)out)[o] = (int)t;
+      return;
+    }
+    case LIBXSMM_MELTW_TYPE_UNARY_DEQUANT: {                    // i8 / i16 / i32 -> f32 [ref: :2330-2360]
+      if (!e.valid) return;
+      const long long idx = bc_index(bc, i, j, p.ldi);
+      const float v = p.in0_type == LIBXSMM_DATATYPE_I8 ? (float)((GM const signed char*)in)[idx] : p.in0_type == LIBXSMM_DATATYPE_I16 ? (float)((GM const short*)in)[idx] : (float)((GM const int*)in)[idx];
+      ((GM float*)out)[i + (long long)j * p.ldo] = v * p.scalar_f32;
+      return;
+    }
     case LIBXSMM_MELTW_TYPE_UNARY_UNZIP: {                      // [ref: :2419-2432]
       if (!e.valid) return;
       const unsigned int u = ((GM const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
@@ -684,6 +705,9 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
         t == LIBXSMM_MELTW_TYPE_UNARY_GATHER || t == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) return sz == 1 || sz == 2 || sz == 4 || sz == 8;
     if (is_reduce_type(t)) return is_float_type(d.in0_type) && is_float_type(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP));
     if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) return d.in0_type == LIBXSMM_DATATYPE_F32 && d.out_type == LIBXSMM_DATATYPE_BF16;
+    const auto is_qint = [](int x) { return x == LIBXSMM_DATATYPE_I8 || x == LIBXSMM_DATATYPE_I16 || x == LIBXSMM_DATATYPE_I32; };
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT) return d.in0_type == LIBXSMM_DATATYPE_F32 && is_qint(d.out_type);       // [ref: :2195-2240]
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_DEQUANT) return is_qint(d.in0_type) && d.out_type == LIBXSMM_DATATYPE_F32;     // [ref: :2330-2360]
     if (f64) {
       switch (t) {
         case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_XOR: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT:

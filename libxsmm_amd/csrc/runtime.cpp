@@ -336,6 +336,14 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     if (t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || t == LIBXSMM_MELTW_TYPE_UNARY_ELU || t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || t == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) {
       if (!p->op.primary) { set_error(-2, "unary TPP needs alpha in op.primary"); return; }
       a.scalar_f32 = *(const float*)p->op.primary;
+    } else if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT || t == LIBXSMM_MELTW_TYPE_UNARY_DEQUANT) {
+      // the scale is a host scalar behind in.secondary [ref: mateltwise ref :2200, :2333]
+      a.scalar_f32 = 1.0f;
+      if (!(d.flags & LIBXSMM_MELTW_FLAG_UNARY_NO_SCF_QUANT)) {
+        if (!p->in.secondary) { set_error(-2, "QUANT/DEQUANT needs the scale in in.secondary"); return; }
+        a.scalar_f32 = *(const float*)p->in.secondary;
+      }
+      a.aux_in = nullptr;
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR) {
       if (!p->op.primary) { set_error(-2, "REPLICATE_COL_VAR needs the column count in op.primary"); return; }
       a.scalar_u64 = *(const unsigned long long*)p->op.primary;

@@ -309,6 +309,34 @@ void oracle_meltw_unary(const libxsmm_meltw_unary_param* p, const oracle_meltw_d
       }
       return;
     }
+    case LIBXSMM_MELTW_TYPE_UNARY_QUANT: {          /* f32 -> i8 / i16 / i32, round to nearest even  [:2195-2240] */
+      const float scf = (d->flags & LIBXSMM_MELTW_FLAG_UNARY_NO_SCF_QUANT) ? 1.0f : *(const float*)p->in.secondary;
+      const int sat = (d->flags & LIBXSMM_MELTW_FLAG_UNARY_SIGN_SAT_QUANT) ? 1 : 0;
+      for (j = 0; j < N; ++j) for (i = 0; i < M; ++i) {
+        const float x = ((const float*)p->in.primary)[elem_index(bc, i, j, ldi)];
+        float t = nearbyintf(x * scf);
+        if (d->out_type == LIBXSMM_DATATYPE_I8) {
+          if (sat) { if (t < -128) t = -128.0f; if (t > 127) t = 127.0f; ((signed char*)p->out.primary)[i + j * ldo] = (signed char)t; }
+          else ((signed char*)p->out.primary)[i + j * ldo] = (signed char)(0x000000ff & (int)t);
+        } else if (d->out_type == LIBXSMM_DATATYPE_I16) {
+          if (sat) { if (t < -32768) t = -32768.0f; if (t > 32767) t = 32767.0f; ((short*)p->out.primary)[i + j * ldo] = (short)t; }
+          else ((short*)p->out.primary)[i + j * ldo] = (short)(0x0000ffff & (int)t);
+        } else ((int*)p->out.primary)[i + j * ldo] = (int)t;
+      }
+      return;
+    }
+    case LIBXSMM_MELTW_TYPE_UNARY_DEQUANT: {        /* i8 / i16 / i32 -> f32  [:2330-2360] */
+      const float scf = (d->flags & LIBXSMM_MELTW_FLAG_UNARY_NO_SCF_QUANT) ? 1.0f : *(const float*)p->in.secondary;
+      for (j = 0; j < N; ++j) for (i = 0; i < M; ++i) {
+        const long long idx = elem_index(bc, i, j, ldi);
+        float v;
+        if (d->in0_type == LIBXSMM_DATATYPE_I8) v = (float)((const signed char*)p->in.primary)[idx];
+        else if (d->in0_type == LIBXSMM_DATATYPE_I16) v = (float)((const short*)p->in.primary)[idx];
+        else v = (float)((const int*)p->in.primary)[idx];
+        ((float*)p->out.primary)[i + j * ldo] = v * scf;
+      }
+      return;
+    }
     case LIBXSMM_MELTW_TYPE_UNARY_RELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_ELU_INV: {   /* [:2168-2194] */
       const long long mask_ld = LIBXSMM_UPDIV(ldi, 16) * 16;
       const float alpha = (d->type == LIBXSMM_MELTW_TYPE_UNARY_RELU_INV) ? 1.0f : *(const float*)p->op.primary;

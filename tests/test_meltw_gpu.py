@@ -297,3 +297,47 @@ def test_unsupported_tpps_return_null():
     assert api.dispatch_meltw_unary(UNARY.DROPOUT, capi.UnaryShape(8, 8, 8, 8, DT.F32, DT.F32, DT.F32), 0) is None
     assert api.dispatch_meltw_unary(UNARY.IDENTITY, capi.UnaryShape(8, 8, 8, 8, DT.I8, DT.F32, DT.F32), 0) is None
     assert api.dispatch_meltw_binary(BINARY.MATMUL, capi.BinaryShape(8, 8, 8, 8, 8, DT.F32, DT.F32, DT.F32, DT.F32), 0) is None
+
+
+# ---- QUANT / DEQUANT: integer results -> bit-exact; the scale is a host scalar behind in.secondary ----
+@pytest.mark.parametrize("out_dt,flags", [(DT.I8, UNARY_FLAG.SIGN_SAT_QUANT), (DT.I8, 0), (DT.I16, UNARY_FLAG.SIGN_SAT_QUANT), (DT.I32, 0),
+                                          (DT.I8, UNARY_FLAG.NO_SCF_QUANT | UNARY_FLAG.SIGN_SAT_QUANT)])
+def test_quant_dequant_roundtrip_bit_exact(out_dt, flags):
+    import torch
+    api, orc = capi.load(), pyoracle.oracle()
+    m, n, ldi, ldo, batch = 72, 21, 80, 76, 3
+    rng = np.random.default_rng(4)
+    x = ((rng.random(batch * ldi * n) - 0.5) * (40.0 if flags & UNARY_FLAG.SIGN_SAT_QUANT and not flags & UNARY_FLAG.NO_SCF_QUANT else 30.0)).astype(np.float32)
+    x[:6] = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5]
+    if not (flags & UNARY_FLAG.SIGN_SAT_QUANT):
+        x = np.clip(x, -15.0, 15.0)
+    scf, inv = C.c_float(7.5), C.c_float(1.0 / 7.5)
+    npq = {DT.I8: np.int8, DT.I16: np.int16, DT.I32: np.int32}[out_dt]
+    qref = np.zeros(batch * ldo * n, dtype=npq)
+    dq = pyoracle.MeltwDesc(m, n, ldi, ldo, 0, 0, DT.F32, DT.UNSUPPORTED, DT.UNSUPPORTED, DT.F32, out_dt, flags, UNARY.QUANT, OP_UNARY)
+    for b in range(batch):
+        p = capi.UnaryParam(); p.in_.primary, p.in_.secondary, p.out.primary = x.ctypes.data + 4 * b * ldi * n, C.addressof(scf), qref.ctypes.data + qref.itemsize * b * ldo * n
+        orc.meltw(p, dq)
+    hq = api.dispatch_meltw_unary(UNARY.QUANT, capi.UnaryShape(m, n, ldi, ldo, DT.F32, out_dt, DT.F32), flags)
+    assert hq
+    dX, dQ = torch.from_numpy(x).cuda(), torch.zeros(batch * ldo * n, dtype={DT.I8: torch.int8, DT.I16: torch.int16, DT.I32: torch.int32}[out_dt], device="cuda")
+    p = capi.UnaryParam(); p.in_.primary, p.in_.secondary, p.out.primary = dX.data_ptr(), C.addressof(scf), dQ.data_ptr()
+    api.hip_meltw_unary_batch_strided(hq, C.byref(p), batch, 4 * ldi * n, qref.itemsize * ldo * n, 0)
+    api.hip_sync(); api.check()
+    valid = lambda a, ld: a.reshape(batch, n, ld)[:, :, :m]
+    assert np.array_equal(valid(dQ.cpu().numpy(), ldo), valid(qref, ldo))
+    # and back: DEQUANT of the quantised matrix (ldi/ldo swapped roles)
+    fref = np.zeros(batch * ldi * n, dtype=np.float32)
+    dd = pyoracle.MeltwDesc(m, n, ldo, ldi, 0, 0, out_dt, DT.UNSUPPORTED, DT.UNSUPPORTED, DT.F32, DT.F32, flags & UNARY_FLAG.NO_SCF_QUANT, UNARY.DEQUANT, OP_UNARY)
+    for b in range(batch):
+        p = capi.UnaryParam(); p.in_.primary, p.in_.secondary, p.out.primary = qref.ctypes.data + qref.itemsize * b * ldo * n, C.addressof(inv), fref.ctypes.data + 4 * b * ldi * n
+        orc.meltw(p, dd)
+    hd = api.dispatch_meltw_unary(UNARY.DEQUANT, capi.UnaryShape(m, n, ldo, ldi, out_dt, DT.F32, DT.F32), flags & UNARY_FLAG.NO_SCF_QUANT)
+    assert hd
+    dF = torch.zeros(batch * ldi * n, dtype=torch.float32, device="cuda")
+    p = capi.UnaryParam(); p.in_.primary, p.in_.secondary, p.out.primary = dQ.data_ptr(), C.addressof(inv), dF.data_ptr()
+    api.hip_meltw_unary_batch_strided(hd, C.byref(p), batch, qref.itemsize * ldo * n, 4 * ldi * n, 0)
+    api.hip_sync(); api.check()
+    assert np.array_equal(valid(dF.cpu().numpy(), ldi), valid(fref, ldi))
+    # QUANT to a float type or DEQUANT from one is not a thing
+    assert api.dispatch_meltw_unary(UNARY.QUANT, capi.UnaryShape(m, n, ldi, ldo, DT.F32, DT.BF16, DT.F32), 0) is None

@@ -306,3 +306,28 @@ def test_packed_gemm_vs_reference_jit(reference, kind, dt, M, N, K, P, beta0):
     p.a.primary, p.b.primary, p.c.primary = A.ctypes.data, B.ctypes.data, theirs.ctypes.data
     capi.Api.call(h, p)
     assert normf_rel(theirs, mine, dt) <= (1e-5 if dt == DT.F32 else 1e-12)
+
+
+# ---- QUANT / DEQUANT TPPs ----------------------------------------------------------------------------
+QUANT_CASES = [(DT.I8, UNARY_FLAG.SIGN_SAT_QUANT), (DT.I8, 0), (DT.I16, UNARY_FLAG.SIGN_SAT_QUANT), (DT.I32, 0), (DT.I8, UNARY_FLAG.NO_SCF_QUANT | UNARY_FLAG.SIGN_SAT_QUANT)]
+
+
+@pytest.mark.parametrize("out_dt,flags", QUANT_CASES)
+def test_quant_bit_identical(reference, out_dt, flags):
+    rng = np.random.default_rng(9)
+    x = ((rng.random(40 * 9) - 0.5) * 40.0).astype(np.float32)          # |x * 7.5| reaches 150: saturation is exercised
+    x[:8] = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 126.6, -127.4]            # ties go to even
+    scf = np.array([7.5], dtype=np.float32)
+    if flags & UNARY_FLAG.NO_SCF_QUANT or not (flags & UNARY_FLAG.SIGN_SAT_QUANT):
+        x = np.clip(x, -15.0, 15.0)                                      # the wrapping forms are only defined inside the target range
+        x[:6] = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5]
+    (a, b), _ = both_unary(reference, UNARY.QUANT, 33, 9, 40, 36, DT.F32, out_dt, flags=flags, aux_in=scf, inp=x)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("in_dt", [DT.I8, DT.I16, DT.I32])
+@pytest.mark.parametrize("flags", [0, UNARY_FLAG.NO_SCF_QUANT])
+def test_dequant_bit_identical(reference, in_dt, flags):
+    scf = np.array([0.125], dtype=np.float32)
+    (a, b), _ = both_unary(reference, UNARY.DEQUANT, 33, 9, 40, 36, in_dt, DT.F32, flags=flags, aux_in=scf)
+    assert np.array_equal(a, b)
