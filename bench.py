@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--sets", type=int, default=0, help="distinct input sets to rotate over (0: auto, > 2x L3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the all-core CPU leg (-1: one per physical core, 0/1: skip)")
     return ap.parse_args()
 
 
@@ -177,6 +178,23 @@ def eager_kernel_us(work, steps, rotate=True):
     return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e3
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota (containers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // pr))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(args, seconds):
     """Reference JIT (or C restatement) on this box's host cores, single thread, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -206,8 +224,38 @@ def cpu_baseline(args, seconds):
             t1 = ref.lib.xref_time_gemm_batch(h, C.byref(p), batch, sa, sa, sc, 5)
             reps = max(5, int(seconds / max(t1 / 5, 1e-9)))
             dt = ref.lib.xref_time_gemm_batch(h, C.byref(p), batch, sa, sa, sc, reps)
-            return {"value": round(flops * reps / dt / 1e9, 2), "unit": "GFLOP/s", "cores": 1, "kind": "reference",
-                    "sample": f"reference JIT ({ref.lib.xref_get_target_arch().decode()}) kernel, {batch} problems x {reps} reps, private operands, 1 thread, {dt:.1f} s"}
+            out = {"value": round(flops * reps / dt / 1e9, 2), "unit": "GFLOP/s", "cores": 1, "kind": "reference",
+                   "sample": f"reference JIT ({ref.lib.xref_get_target_arch().decode()}) kernel, {batch} problems x {reps} reps, private operands, 1 thread, {dt:.1f} s"}
+            # the same kernel on every physical core at once (one thread per core, private operands): the caller's OpenMP loop of the
+            # reference [samples/xgemm/gemm_kernel.c:4063-4066]; ctypes releases the GIL for the duration of each timing call
+            nthreads = getattr(args, "cpu_threads", 0)
+            if nthreads > 1:
+                import threading
+                sets = []
+                for _ in range(nthreads):
+                    a_, b_, c_ = A.copy(), B.copy(), Cc.copy()
+                    q = capi.GemmParam()
+                    q.a.primary, q.b.primary, q.c.primary, q.op.tertiary = a_.ctypes.data, b_.ctypes.data, c_.ctypes.data, C.addressof(brc)
+                    sets.append((a_, b_, c_, q))
+                def run_all(r):
+                    times = [0.0] * nthreads
+
+                    def work(i):
+                        times[i] = ref.lib.xref_time_gemm_batch(h, C.byref(sets[i][3]), batch, sa, sa, sc, r)
+                    ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+                    t0 = time.perf_counter()
+                    for th in ths:
+                        th.start()
+                    for th in ths:
+                        th.join()
+                    return max(times), time.perf_counter() - t0
+                pilot = max(2, reps // 100)                       # bounded whatever the container's CPU quota turns out to be
+                _, wall_p = run_all(pilot)
+                reps_mt = max(pilot, min(reps, int(pilot * 4.0 / max(wall_p, 1e-6))))      # aim at ~4 s of wall clock
+                slowest, wall = run_all(reps_mt)
+                out["all_cores"] = {"value": round(flops * reps_mt * nthreads / wall / 1e9, 1), "unit": "GFLOP/s", "cores": nthreads,
+                                    "sample": f"{nthreads} threads (usable CPUs of this container) x {batch} private problems x {reps_mt} reps, wall {wall:.1f} s"}
+            return out
     # port: the C restatement (scalar loops); a much smaller sample keeps it bounded
     from helpers import GemmCase
     case = GemmCase(m, m, m, a_type=t, c_type=t, flags=GEMM_FLAG.VNNI_A if bf16 else 0, br_type=capi.BR_STRIDE, br_count=br, batch=64, seed=1)
@@ -295,6 +343,8 @@ def main():
                             "achieved_GBs": round(work.alg_bytes_per_step / (l3_kernel_us * 1e-6) / 1e9, 1)},
         }
         if not args.no_cpu_baseline and world == 1:
+            if args.cpu_threads < 0:
+                args.cpu_threads = usable_cpus()
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         print(json.dumps(out))
     if dist is not None:
