@@ -139,8 +139,21 @@ __device__ __forceinline__ void generic_epilogue(const GemmArgs& p, const BatchP
 template <typename T> __device__ __forceinline__ T mul_rn(T a, T b) { return a * b; }
 template <typename T> __device__ __forceinline__ T add_rn(T a, T b) { return a + b; }
 
+// 8-bit floats [ref: src/libxsmm_math.c:546-585]: BF8 (E5M2) is the upper byte of an IEEE half; HF8 (E4M3, bias 7, no infinities)
+__device__ __forceinline__ float bf8_to_f32(unsigned char x) { return (float)__builtin_bit_cast(_Float16, (unsigned short)((unsigned short)x << 8)); }
+__device__ __forceinline__ float hf8_to_f32(unsigned char in) {
+  const unsigned int s = (unsigned int)(in & 0x80u) << 24, e = (in & 0x78u) >> 3;
+  unsigned int m = in & 0x07u, e_norm = e + 120u;
+  if (e == 0u && m != 0u) { unsigned int lz = 2u; lz = (m > 1u) ? 1u : lz; lz = (m > 3u) ? 0u : lz; e_norm -= lz; m = (m << (lz + 1u)) & 7u; }
+  else if (e == 0u && m == 0u) e_norm = 0u;
+  else if (e == 15u && m == 7u) { e_norm = 255u; m = 4u; }
+  return __uint_as_float((e_norm << 23) | (m << 20) | s);
+}
 __device__ __forceinline__ float load_as_f32(gcptr base, long long idx, int type) {
-  return (type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)base)[idx] : bf16_to_f32(((GM const unsigned short*)base)[idx]);
+  if (type == LIBXSMM_DATATYPE_F32) return ((GM const float*)base)[idx];
+  if (type == LIBXSMM_DATATYPE_BF8) return bf8_to_f32(((GM const unsigned char*)base)[idx]);
+  if (type == LIBXSMM_DATATYPE_HF8) return hf8_to_f32(((GM const unsigned char*)base)[idx]);
+  return bf16_to_f32(((GM const unsigned short*)base)[idx]);
 }
 
 // block = (64, 4): x walks i (so a wave is 64 consecutive rows of one column, which makes the
@@ -203,7 +216,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
 
   float acc = 0.0f;
   if (valid) {
-    const int kb = (p.a_type == LIBXSMM_DATATYPE_BF16 && va) ? 2 : 1;
+    const bool fp8 = (p.a_type == LIBXSMM_DATATYPE_BF8 || p.a_type == LIBXSMM_DATATYPE_HF8);
+    const int kb = fp8 ? (va ? 4 : 1) : ((p.a_type == LIBXSMM_DATATYPE_BF16 && va) ? 2 : 1);
     if (!beta0) acc = load_as_f32(q.c, (long long)j * p.ldc + i, p.c_type);
     if (p.colbias) {
       const float bias = load_as_f32(q.d, i, p.c_type);
@@ -212,7 +226,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     for (unsigned long long r = 0; r < p.br_count; ++r) {
       gcptr ar, br; br_base(p, q, r, ar, br);
       for (int s = 0; s < p.k / kb; ++s) {
-        for (int k2 = kb - 1; k2 >= 0; --k2) {          // VNNI pair: high k first [ref: gemm ref :2144]
+        for (int q2 = 0; q2 < kb; ++q2) {               // bf16 VNNI pair: high k first [ref: gemm ref :2144]; fp8 quad: ascending [:2436]
+          const int k2 = fp8 ? q2 : kb - 1 - q2;
           const int kk = s * kb + k2;
           const long long ai = ta ? ((long long)i * p.lda + kk)
                                   : ((long long)(kk / kb) * ((long long)p.lda * kb) + (long long)i * kb + (kk % kb));
@@ -1012,6 +1027,72 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8-bit float streaming kernel (v_mfma_f32_32x32x16_bf8_bf8 / _fp8_fp8; CDNA4's fp8 = OCP E4M3 = the reference's HF8, bf8 =
+// E5M2 = BF8): exact tiles, VNNI-4 A, flat B with 16-byte aligned columns, k % 64 == 0, f32 accumulate and output.
+// Structure = gemm_i8_stream_kernel; an MFMA consumes 16 k (8 bytes per lane and operand), four steps per 64-deep chunk.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, bool HF8>
+__global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  char* lds = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  f32x16 acc[MT][NT];
+  TileCtx tc[MT][NT];
+  static_for<MT * NT>([&](auto idx) {
+    constexpr int mt = idx.value / NT, nt = idx.value % NT;
+    tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h; tc[mt][nt].ivalid = true;
+    tile_init<true, true>(acc[mt][nt], p, q, tc[mt][nt]);
+  });
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  unsigned int offB[NT * 2];
+#pragma unroll
+  for (int x = 0; x < NT * 2; ++x) {
+    const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
+    offB[x] = f * ldb + pc * 16u;
+  }
+  const unsigned int offA = ((2u * h) * lda + (unsigned int)li) * 4u;      // dword (k-quad 2h, row li)
+  const int kchunks = p.k >> 6;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    gcptr bu = br + (unsigned long long)job.j0 * ldb;
+    gcptr au = ar + 4ull * (unsigned long long)job.i0;
+    for (int kc = 0; kc < kchunks; ++kc) {
+#pragma unroll
+      for (int x = 0; x < NT * 2; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(bu + 64ull * kc + offB[x]), (lds_vptr)(lds + 1024 * x), 16, 0, 0);
+      long af[MT][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const unsigned int lo = *(GM const unsigned int*)(au + (unsigned long long)(16 * kc + 4 * s) * lda * 4ull + 128ull * mt + offA);
+          const unsigned int hi = *(GM const unsigned int*)(au + (unsigned long long)(16 * kc + 4 * s + 1) * lda * 4ull + 128ull * mt + offA);
+          af[mt][s] = (long)(((unsigned long long)hi << 32) | lo);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      long bfr[NT][4];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int f = 32 * nt + li;
+          bfr[nt][s] = *(const long*)(lds + f * 64 + ((s ^ ((f >> 1) & 3)) * 16) + 8 * h);
+        }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+          if (HF8) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(bfr[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0);
+          else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(bfr[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<true, true>(acc[mt][nt], p, q, tc[mt][nt]); });
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side selection
 // ------------------------------------------------------------------------------------------------
 bool gemm_supported(const libxsmm_gemm_descriptor& d) {
@@ -1030,6 +1111,17 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d) {
     if (va8 && (d.k & 3)) return false;
     if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
     return d.lda >= d.m && d.ldb >= d.k && d.ldc >= d.m;
+  }
+  const bool fp8 = (d.a_type == LIBXSMM_DATATYPE_BF8 || d.a_type == LIBXSMM_DATATYPE_HF8) && d.b_type == d.a_type && d.c_type == LIBXSMM_DATATYPE_F32;
+  if (fp8) {   // [ref: gemm ref :2420-2510]: f32 accumulate and output, VNNI-4 A optional, no fused ops
+    const unsigned int fl8 = d.flags;
+    if (d.comp_type != LIBXSMM_DATATYPE_F32) return false;
+    const bool ta8 = fl8 & LIBXSMM_GEMM_FLAG_TRANS_A, tb8 = fl8 & LIBXSMM_GEMM_FLAG_TRANS_B, va8 = fl8 & LIBXSMM_GEMM_FLAG_VNNI_A, vb8 = fl8 & LIBXSMM_GEMM_FLAG_VNNI_B;
+    if ((fl8 & LIBXSMM_GEMM_FLAG_VNNI_C) || (va8 && ta8) || (vb8 && !tb8) || ((va8 || vb8) && (d.k & 3))) return false;
+    if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    if (ta8 ? (d.lda < d.k) : (d.lda < d.m)) return false;
+    if (tb8 ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
+    return d.ldc >= d.m;
   }
   if (!(f32 || f64 || bf16)) return false;
   if (f32 && d.comp_type != LIBXSMM_DATATYPE_F32) return false;
@@ -1054,7 +1146,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d) {
   return true;
 }
 
-enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2 };
+enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2 };
 struct GemmPlan { GemmPath path; bool exact; };
 
 static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, int c_type, int vnni_c) {
@@ -1069,6 +1161,13 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     pl.exact = ex32;
     pl.path = (m > 32 && n > 32) ? P_F32_2x2 : P_F32_1x1;
     if (pl.path == P_F32_2x2) pl.exact = (m % 64 == 0) && (n % 64 == 0) && (k % 32 == 0);
+    return pl;
+  }
+  if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && va && !ta && !tb && !vb) {
+    pl.path = (m > 32 && n > 32) ? P_FP8_2x2 : P_FP8_1x1;
+    const int t = (pl.path == P_FP8_2x2) ? 64 : 32;
+    pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
+    if (!pl.exact) pl.path = P_GENERIC;
     return pl;
   }
   if ((a_type == LIBXSMM_DATATYPE_I8 || a_type == LIBXSMM_DATATYPE_U8) && va && !ta && !tb && !vb) {
@@ -1094,6 +1193,8 @@ static const char* path_name(GemmPath p) {
     case P_F32_2x2: return "gemm_mfma_f32_kernel<2,2>";
     case P_BF16_1x1: return "gemm_mfma_bf16_kernel<1,1>";
     case P_BF16_2x2: return "gemm_mfma_bf16_kernel<2,2>";
+    case P_FP8_1x1: return "gemm_fp8_stream_kernel<1,1>";
+    case P_FP8_2x2: return "gemm_fp8_stream_kernel<2,2>";
     case P_I8_1x1: return "gemm_i8_stream_kernel<1,1>";
     case P_I8_2x2: return "gemm_i8_stream_kernel<2,2>";
     default: return "gemm_generic_kernel";
@@ -1208,6 +1309,22 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
       break;
+    case P_FP8_1x1: case P_FP8_2x2: {
+      const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)a.ldb;
+      const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0);
+      const bool ok = !a.list_a && a.br_mode != 1 && a.br_mode != 2 && (bits & 15ull) == 0 && (abits & 3ull) == 0 && (long long)a.lda * a.k < (1ll << 31) && (long long)a.ldb * a.n < (1ll << 31);
+      if (ok) {
+        const bool hf8 = a.a_type == LIBXSMM_DATATYPE_HF8, big = pl.path == P_FP8_2x2;
+        grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
+        if (big) { if (hf8) hipLaunchKernelGGL((gemm_fp8_stream_kernel<2, 2, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_fp8_stream_kernel<2, 2, false>), grid, dim3(256), 0, st, a); }
+        else { if (hf8) hipLaunchKernelGGL((gemm_fp8_stream_kernel<1, 1, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_fp8_stream_kernel<1, 1, false>), grid, dim3(256), 0, st, a); }
+        break;
+      }
+      if (kernel_name) *kernel_name = "gemm_generic_kernel";
+      const long long gblocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
+      hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)gblocks), dim3(64, 4), 0, st, a);
+      break;
+    }
     case P_I8_1x1: case P_I8_2x2: {
       // same alignment contract as the bf16 streaming kernel (element size 1): B columns 16-byte aligned, A dword aligned
       const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)a.ldb;

@@ -287,7 +287,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   // apply beta / bias / activation in a second pass (SURVEY 8(d) config #2 variant B: one BRGEMM with br = 4096).
   static const bool split_off = []() { const char* e = getenv("LIBXSMM_HIP_BRSPLIT"); return e && e[0] == '0'; }();
   const long long tiles = (long long)((a.m + 31) / 32) * ((a.n + 31) / 32);
-  if (!split_off && a.br_mode == 3 && a.nbatch == 1 && !a.list_a && a.br_count >= 16 && tiles * 8 <= 1024 && (a.a_type == LIBXSMM_DATATYPE_F32 || a.a_type == LIBXSMM_DATATYPE_BF16) && a.m > 0 && a.n > 0) {
+  if (!split_off && a.br_mode == 3 && a.nbatch == 1 && !a.list_a && a.br_count >= 16 && tiles * 8 <= 1024 && (a.a_type == LIBXSMM_DATATYPE_F32 || a.a_type == LIBXSMM_DATATYPE_BF16) && a.b_type == a.a_type && a.m > 0 && a.n > 0) {
     unsigned long long nsplit = std::min<unsigned long long>(a.br_count / 4, (unsigned long long)(2048 / tiles));
     const unsigned long long chunk = (a.br_count + nsplit - 1) / nsplit;
     const unsigned long long nfull = a.br_count / chunk, tail = a.br_count - nfull * chunk;

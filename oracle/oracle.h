@@ -98,6 +98,8 @@ void oracle_packed_gemm(int dtype, int M, int N, int K, int P, const void* A, in
 unsigned short oracle_f32_to_bf16_rne(float x);   /* RNE with DAZ and NaN quieting */
 unsigned short oracle_f32_to_bf16_trunc(float x);
 float oracle_bf16_to_f32(unsigned short x);
+float oracle_bf8_to_f32(unsigned char x);    /* E5M2  [ref: src/libxsmm_math.c:546-551] */
+float oracle_hf8_to_f32(unsigned char x);    /* E4M3  [ref: src/libxsmm_math.c:553-585] */
 
 /* ---- comparison metric  [ref: src/libxsmm_matdiff.h:141-142 normf_rel] ---------------- */
 double oracle_normf_rel(int dtype, long long count, const void* ref, const void* tst);

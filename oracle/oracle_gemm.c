@@ -102,6 +102,30 @@ static void contract_f32(const gemm_view* v, float* acc, long long ldacc) {
   }
 }
 
+/* 8-bit float GEMM (BF8 = E5M2, HF8 = E4M3), f32 accumulate and output; A VNNI-4 under VNNI_A, k consumed in ascending
+ * order inside a quad [ref: :2420-2470 (BF8), :2471-2510 (HF8)] */
+static int is_fp8(int t) { return t == LIBXSMM_DATATYPE_BF8 || t == LIBXSMM_DATATYPE_HF8; }
+static float load_fp8(const char* base, long long idx, int type) {
+  const unsigned char x = ((const unsigned char*)base)[idx];
+  return type == LIBXSMM_DATATYPE_BF8 ? oracle_bf8_to_f32(x) : oracle_hf8_to_f32(x);
+}
+static void contract_fp8(const gemm_view* v, float* cmat, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const int kb = v->va ? 4 : 1;
+  int i, j, s; long long r;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    float c = beta0 ? 0.0f : cmat[(long long)j * d->ldc + i];
+    for (r = 0; r < v->br; ++r) {
+      const br_cursor cur = br_at(v, r);
+      for (s = 0; s < d->k; ++s) {
+        const float prod = load_fp8(cur.a, a_index(v, i, s, kb), d->a_type) * load_fp8(cur.b, b_index(v, s, j, kb), d->b_type);
+        c = c + prod;
+      }
+    }
+    cmat[(long long)j * d->ldc + i] = c;
+  }
+}
+
 static void contract_f64(const gemm_view* v, double* cmat) {
   const oracle_gemm_desc* d = v->d;
   int i, j, s; long long r;
@@ -209,6 +233,7 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
 
   if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
   if (is_int8(d->a_type) && is_int8(d->b_type)) { contract_int8(&v, p, cptr, beta0); return; }
+  if (is_fp8(d->a_type) && d->b_type == d->a_type && d->c_type == LIBXSMM_DATATYPE_F32) { contract_fp8(&v, (float*)cptr, beta0); return; }
 
   {
     /* f32 working image: C itself for f32 output, otherwise a scratch of ldc x n floats [:262-272] */

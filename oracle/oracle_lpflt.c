@@ -49,3 +49,33 @@ double oracle_normf_rel(int dtype, long long count, const void* ref, const void*
   if (den <= 0.0) return sqrt(num);
   return sqrt(num / den);
 }
+
+/* ---- 8-bit floats  [ref: src/libxsmm_math.c:546-585] ---------------------------------------
+ * BF8 = E5M2 = the upper byte of an IEEE half; HF8 = E4M3 (bias 7, no infinities, S.1111.111 = NaN). */
+static float half_bits_to_f32(unsigned short h) {
+  const unsigned int s = (unsigned int)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  union { unsigned int u; float f; } r;
+  if (e == 0) {
+    if (m == 0) r.u = s;
+    else {                                   /* subnormal half: value = m * 2^-24 (exact in f32) */
+      r.f = (float)m * 5.9604644775390625e-08f;
+      r.u |= s;
+    }
+  } else if (e == 31) r.u = s | 0x7f800000u | (m << 13);
+  else r.u = s | ((e + 112u) << 23) | (m << 13);
+  return r.f;
+}
+float oracle_bf8_to_f32(unsigned char x) { return half_bits_to_f32((unsigned short)((unsigned short)x << 8)); }
+float oracle_hf8_to_f32(unsigned char in) {
+  const unsigned int s = (unsigned int)(in & 0x80u) << 24, e = (in & 0x78u) >> 3;
+  unsigned int m = in & 0x07u, e_norm = e + (127u - 7u);
+  union { unsigned int u; float f; } r;
+  if (e == 0 && m != 0) {                    /* subnormal: renormalise */
+    unsigned int lz = 2;
+    lz = (m > 0x1u) ? 1 : lz; lz = (m > 0x3u) ? 0 : lz;
+    e_norm -= lz; m = (m << (lz + 1)) & 0x07u;
+  } else if (e == 0 && m == 0) e_norm = 0;
+  else if (e == 0xfu && m == 0x7u) { e_norm = 0xffu; m = 0x4u; }
+  r.u = (e_norm << 23) | (m << 20) | s;
+  return r.f;
+}

@@ -25,7 +25,9 @@ from libxsmm_amd.capi import DT, GEMM_FLAG  # noqa: E402
 from oracle import pyoracle  # noqa: E402
 
 NP_OF = {DT.F32: np.float32, DT.F64: np.float64, DT.BF16: np.uint16, DT.I32: np.int32, DT.U32: np.uint32,
-         DT.I16: np.int16, DT.U16: np.uint16, DT.I8: np.int8, DT.U8: np.uint8, DT.I64: np.int64, DT.U64: np.uint64}
+         DT.I16: np.int16, DT.U16: np.uint16, DT.I8: np.int8, DT.U8: np.uint8, DT.I64: np.int64, DT.U64: np.uint64, DT.BF8: np.uint8, DT.HF8: np.uint8}
+
+FP8_WIDE = False      # tests flip this to draw 8-bit floats over (almost) the whole exponent range
 
 # the reference's own acceptance bounds [samples/xgemm/gemm_kernel.c:5312-5414]
 TOL_F32 = 1.2e-5
@@ -50,6 +52,13 @@ def rand_values(rng: np.random.Generator, count: int, dt: int) -> np.ndarray:
         return rng.integers(-9, 10, count).astype(NP_OF[dt])
     if dt in (DT.U8, DT.U16, DT.U32):
         return rng.integers(0, 19, count).astype(NP_OF[dt])
+    if dt in (DT.BF8, DT.HF8):              # finite 8-bit floats in [1/8, 2) with random sign, plus a few zeros: the magnitude range of the
+        bias, mbits = (15, 2) if dt == DT.BF8 else (7, 3)     # reference driver's data (multiples of 0.1 in [-0.5, 0.5]); FP8_WIDE widens it
+        lo = max(-14 if FP8_WIDE else -3, -bias)           # exponent field 0 = subnormals / zero
+        e = rng.integers(bias + lo, bias + (4 if FP8_WIDE else 1), count)
+        v = ((rng.integers(0, 2, count) << 7) | (e << mbits) | rng.integers(0, 1 << mbits, count)).astype(np.uint8)
+        v[rng.random(count) < 0.05] = 0
+        return v
     v = (np.floor(rng.random(count) * 10.0) - 4.0) / 10.0
     if dt == DT.BF16:
         return f32_to_bf16_trunc(v.astype(np.float32))
@@ -82,7 +91,7 @@ class GemmCase:
         self.a_type = a_type
         self.b_type = a_type if b_type is None else b_type
         self.c_type = a_type if c_type is None else c_type
-        self.comp_type = DT.F64 if a_type == DT.F64 else (DT.I32 if a_type in (DT.I8, DT.U8) else DT.F32)
+        self.comp_type = DT.F64 if a_type == DT.F64 else (DT.I32 if a_type in (DT.I8, DT.U8) else DT.F32)   # fp8: f32
         self.scf = None if scf is None else C.c_float(scf)           # 8-bit GEMM with f32 output: scale read from c.tertiary
         ta, tb = bool(flags & GEMM_FLAG.TRANS_A), bool(flags & GEMM_FLAG.TRANS_B)
         self.lda = lda if lda is not None else (k if ta else m)

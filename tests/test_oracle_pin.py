@@ -44,6 +44,12 @@ GEMM_CASES = [
     dict(m=12, n=10, k=7, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32),                           # flat A
     dict(m=32, n=32, k=32, a_type=DT.U8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.0625, beta=1),
     dict(m=24, n=20, k=16, a_type=DT.I8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.5),
+    # 8-bit floats (BF8 = E5M2, HF8 = E4M3), f32 output
+    dict(m=32, n=32, k=64, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2),
+    dict(m=17, n=9, k=12, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, ldc=20),
+    dict(m=12, n=10, k=7, a_type=DT.BF8, c_type=DT.F32),
+    dict(m=32, n=32, k=64, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1),
+    dict(m=13, n=11, k=8, a_type=DT.HF8, c_type=DT.F32, flags=F.TRANS_B),
 ]
 
 
