@@ -1160,7 +1160,10 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     if (!ex32 && !ta && !tb && (m % 16 == 0) && (n % 16 == 0) && (k % 16 == 0) && m <= 48 && n <= 48) { pl.path = P_F32_T16; pl.exact = true; return pl; }
     pl.exact = ex32;
     pl.path = (m > 32 && n > 32) ? P_F32_2x2 : P_F32_1x1;
-    if (pl.path == P_F32_2x2) pl.exact = (m % 64 == 0) && (n % 64 == 0) && (k % 32 == 0);
+    if (pl.path == P_F32_2x2) {
+      pl.exact = (m % 64 == 0) && (n % 64 == 0) && (k % 32 == 0);
+      if (!pl.exact && ex32) { pl.path = P_F32_1x1; pl.exact = true; }     // e.g. 96^3: exact 32x32 tiles beat masked 64x64 tiles
+    }
     return pl;
   }
   if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && va && !ta && !tb && !vb) {
@@ -1181,6 +1184,7 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     pl.path = (m > 32 && n > 32) ? P_BF16_2x2 : P_BF16_1x1;
     const int t = (pl.path == P_BF16_2x2) ? 64 : 32;
     pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
+    if (!pl.exact && pl.path == P_BF16_2x2 && (m % 32 == 0) && (n % 32 == 0) && (k % 32 == 0)) { pl.path = P_BF16_1x1; pl.exact = true; }
     return pl;
   }
   return pl;
