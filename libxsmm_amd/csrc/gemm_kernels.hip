@@ -743,6 +743,50 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// f32 "blob" kernel for the odd small shapes LIBXSMM is known for (23x23x23 ...): one masked 32x32 tile, m, n, k, lda, ldb
+// <= 32, no transposes.  A_r (k*lda floats) and B_r (n*ldb floats) are contiguous blobs whatever the shape, so they are
+// brought in as FLAT dword streams with LDS-DMA (global_load_lds_dword: 256 contiguous bytes per instruction, no VGPRs, lanes
+// past the end switched off) instead of per-row / per-column masked loads; the MFMA fragments are then picked out of the
+// LDS images with shape-aware indexing (out-of-range operands read as zero).  Natural k order: bitwise the k-ordered
+// fmaf chain like the other f32 MFMA kernels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_blob_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds_all[4][2048];
+  const WaveJob job = wave_job(p, 32, 32);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  float* la = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  float* lb = la + 1024;
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  TileCtx tc; tc.i = li; tc.j0 = 0; tc.h = h; tc.ivalid = li < p.m;
+  f32x16 acc;
+  tile_init<false, true>(acc, p, q, tc);
+  const int na = p.k * p.lda, nb = p.n * p.ldb;           // dwords per blob (<= 1024 each)
+  const bool iv = li < p.m, jv = li < p.n;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+#pragma unroll 1
+    for (int d0 = 0; d0 < na; d0 += 64)
+      if (d0 + lane < na) __builtin_amdgcn_global_load_lds((GM const void*)(ar + 4ll * (d0 + lane)), (lds_vptr)(la + d0), 4, 0, 0);
+#pragma unroll 1
+    for (int d0 = 0; d0 < nb; d0 += 64)
+      if (d0 + lane < nb) __builtin_amdgcn_global_load_lds((GM const void*)(br + 4ll * (d0 + lane)), (lds_vptr)(lb + d0), 4, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float af[16], bf[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int k = 2 * s + h;
+      af[s] = (iv && k < p.k) ? la[li + k * p.lda] : 0.0f;
+      bf[s] = (jv && k < p.k) ? lb[k + li * p.ldb] : 0.0f;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  tile_store<false, true>(acc, p, q, tc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32, 16x16 tiles (v_mfma_f32_16x16x4_f32), NN layout, exact multiples of 16 only.
 // lane = (x = lane&15, g = lane>>4).  Transposed product: operand 1 = B(k, j=x), operand 2 = A(i=x, k);
 // result lane x = i, register q -> j = 4g + q.  k is consumed as 4g + s (not natural order).
@@ -1227,6 +1271,12 @@ static bool operands_aligned16(const GemmArgs& a, int elem_size) {
   return (bits & 15ull) == 0ull;
 }
 
+// one masked tile, blobs of at most 1024 dwords, dword-aligned operands, no transposes
+static bool f32_blob_ok(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOB"); return e && e[0] == '0'; }();
+  if (off || (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B))) return false;
+  return a.m <= 32 && a.n <= 32 && a.k <= 32 && a.lda <= 32 && a.ldb <= 32 && a.k * a.lda <= 1024 && a.n * a.ldb <= 1024;
+}
 static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
   static const int mode = []() { const char* e = getenv("LIBXSMM_HIP_F32_DMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
   return mode;
@@ -1285,6 +1335,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       }
       else if (pl.exact && operands_aligned16(a, 4)) launch_f32<1, 1, GM_STAGED>(a, grid, st);
       else if (pl.exact) launch_f32<1, 1, GM_EXACT>(a, grid, st);
+      else if (f32_blob_ok(a)) { if (kernel_name) *kernel_name = "gemm_f32_blob_kernel"; hipLaunchKernelGGL(gemm_f32_blob_kernel, grid, dim3(256), 0, st, a); }
       else launch_f32<1, 1, GM_MASKED>(a, grid, st);
       break;
     case P_F32_2x2:
