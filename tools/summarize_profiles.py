@@ -27,10 +27,10 @@ def ours(name):
 
 
 def copy_stats(sub, out):
-    files = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+    files = sorted(glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if not files:
         return
-    rows = list(csv.reader(open(files[0])))
+    rows = list(csv.reader(open(files[-1])))          # the newest run (earlier collections may still lie around)
     with open(os.path.join(dst, out), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(rows[0])
@@ -48,7 +48,8 @@ if os.path.exists(bj) and os.path.getsize(bj):
 
 def counters(sub):
     acc = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:                              # newest collection only
         for r in csv.DictReader(open(f)):
             acc[r["Kernel_Name"].replace(" ", "")].append(float(r["Counter_Value"]))
     return acc
