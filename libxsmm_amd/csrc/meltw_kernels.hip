@@ -663,6 +663,87 @@ __global__ __launch_bounds__(256) void reduce_kernel(MeltwArgs p) {
   }
 }
 
+// Vector form of the reductions (m % 4 == 0, ldi % 4 == 0, 16-byte (f32) / 8-byte (bf16) aligned input).
+//   REDUCE_ROWS (one result per column): a group of G = min(64, pow2(m/4)) lanes owns a column, every lane adds 4-element
+//     vectors with stride G, the group is folded with xor-shuffles; a wave covers 64/G columns (small m keeps all lanes busy).
+//   REDUCE_COLS (one result per 4 rows): a thread owns 4 consecutive rows and, when n >= 256, one of 16 column slices
+//     (columns slice, slice+16, ...); the 16 partial vectors are combined in slice order through LDS.  For n < 256 there is
+//     one slice and the sum runs in column order, bit-identical to the general kernel and the oracle.
+template <bool BF16IN>
+__device__ __forceinline__ void red_load4(float (&x)[4], gcptr in, long long idx) {
+  if (BF16IN) { const u16x4 v = *(GM const u16x4*)((GM const unsigned short*)in + idx); for (int e = 0; e < 4; ++e) x[e] = mw_bf2f(v[e]); }
+  else { const f32x4 v = *(GM const f32x4*)((GM const float*)in + idx); for (int e = 0; e < 4; ++e) x[e] = v[e]; }
+}
+template <bool BF16IN>
+__global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int slices) {
+  __shared__ float part[2][16][16][4];
+  const bool rows = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
+  const bool init_acc = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_INIT_ACC) != 0;
+  const int type = p.type;
+  const bool want_x = type != LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD;
+  const bool want_x2 = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD || type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD;
+  const bool is_add = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD || want_x2;
+  gcptr in = (gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0;
+  gptr out = (gptr)p.out + (long long)blockIdx.y * p.bs_out;
+  const long long result_size = rows ? p.n : p.ldo;
+  gptr out2 = (want_x && want_x2) ? out + result_size * ((p.out_type == LIBXSMM_DATATYPE_F32) ? 4 : 2) : out;
+  const float ident = (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) ? -3.402823466e+38f : (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN) ? 3.402823466e+38f : 0.0f;
+  auto combine = [&](float a, float x) {
+    if (is_add) return a + x;
+    if (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) return (a < x) ? x : a;
+    if (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN) return (a > x) ? x : a;
+    return fmaxf(fabsf(a), fabsf(x));
+  };
+  const int m4 = p.m / 4;
+  if (rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane % G, cpw = 64 / G;
+    const int j = (blockIdx.x * 4 + wave) * cpw + lane / G;
+    float sx = ident, sx2 = 0.0f;
+    if (j < p.n) {
+      for (int i4 = l; i4 < m4; i4 += G) {
+        float x[4]; red_load4<BF16IN>(x, in, 4ll * i4 + (long long)j * p.ldi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sx = combine(sx, x[e]); sx2 += x[e] * x[e]; }
+      }
+    }
+    for (int off = G >> 1; off > 0; off >>= 1) { sx = combine(sx, __shfl_xor(sx, off)); sx2 += __shfl_xor(sx2, off); }
+    if (l == 0 && j < p.n) {
+      if (is_add && init_acc) { if (want_x) sx += mw_load(out, j, p.out_type); if (want_x2) sx2 += mw_load(out2, j, p.out_type); }
+      if (want_x) mw_store(out, j, p.out_type, sx);
+      if (want_x2) mw_store(out2, j, p.out_type, sx2);
+    }
+  } else {
+    const int rg_l = threadIdx.x & 15, sl = threadIdx.x >> 4;            // 16 row groups x 16 slices per block
+    const int rg = blockIdx.x * 16 + rg_l;
+    float sx[4] = {ident, ident, ident, ident}, sx2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (rg < m4 && sl < slices) {
+      for (int j = sl; j < p.n; j += slices) {
+        float x[4]; red_load4<BF16IN>(x, in, 4ll * rg + (long long)j * p.ldi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sx[e] = combine(sx[e], x[e]); sx2[e] += x[e] * x[e]; }
+      }
+    }
+    if (slices > 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { part[0][sl][rg_l][e] = sx[e]; part[1][sl][rg_l][e] = sx2[e]; }
+      __syncthreads();
+      if (sl != 0) return;
+      for (int s2 = 1; s2 < slices; ++s2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sx[e] = combine(sx[e], part[0][s2][rg_l][e]); sx2[e] += part[1][s2][rg_l][e]; }
+    } else if (sl != 0) return;
+    if (rg >= m4) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long i = 4ll * rg + e;
+      float a = sx[e], b = sx2[e];
+      if (is_add && init_acc) { if (want_x) a += mw_load(out, i, p.out_type); if (want_x2) b += mw_load(out2, i, p.out_type); }
+      if (want_x) mw_store(out, i, p.out_type, a);
+      if (want_x2) mw_store(out2, i, p.out_type, b);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side selection
 // ------------------------------------------------------------------------------------------------
@@ -802,9 +883,21 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       if (name) *name = "gather_scatter_kernel";
     } else if (is_reduce_type(a.type)) {
       const bool rows = (a.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
-      const unsigned int gx = rows ? (unsigned int)((a.n + 3) / 4) : (unsigned int)((a.m + 255) / 256);
-      hipLaunchKernelGGL(reduce_kernel, dim3(gx, a.nbatch), dim3(256), 0, st, a);
-      if (name) *name = "reduce_kernel";
+      const bool bf = a.in0_type == LIBXSMM_DATATYPE_BF16;
+      static const bool rvec_off = []() { const char* e = getenv("LIBXSMM_HIP_REDUCE_VEC"); return e && e[0] == '0'; }();
+      const size_t al = bf ? 8 : 16;
+      if (!rvec_off && a.m % 4 == 0 && a.ldi % 4 == 0 && (((size_t)a.in0 | (size_t)a.bs_in0) % al) == 0 && a.nbatch < 65536) {
+        int G = 1; while (G < 64 && G < a.m / 4) G <<= 1;
+        const int slices = (!rows && a.n >= 256) ? 16 : 1;
+        const unsigned int gx = rows ? (unsigned int)((a.n + 4 * (64 / G) - 1) / (4 * (64 / G))) : (unsigned int)((a.m / 4 + 15) / 16);
+        if (bf) hipLaunchKernelGGL((reduce_vec_kernel<true>), dim3(gx, a.nbatch), dim3(256), 0, st, a, G, slices);
+        else hipLaunchKernelGGL((reduce_vec_kernel<false>), dim3(gx, a.nbatch), dim3(256), 0, st, a, G, slices);
+        if (name) *name = "reduce_vec_kernel";
+      } else {
+        const unsigned int gx = rows ? (unsigned int)((a.n + 3) / 4) : (unsigned int)((a.m + 255) / 256);
+        hipLaunchKernelGGL(reduce_kernel, dim3(gx, a.nbatch), dim3(256), 0, st, a);
+        if (name) *name = "reduce_kernel";
+      }
     } else {
       const int bc = bcast_kind(a.operation, a.type, a.flags, 0);
       const bool simple = bc == BC_NONE && a.in0_type == a.out_type && is_float_type(a.in0_type) && (a.m % 4 == 0) && (a.ldi % 4 == 0) && (a.ldo % 4 == 0) &&

@@ -200,6 +200,23 @@ def test_reductions(typ, rows, in_dt):
         assert normf_rel(r[:, :used], g[:, :used], DT.F32) < 1e-5
 
 
+@pytest.mark.parametrize("typ", [UNARY.REDUCE_X_OP_ADD, UNARY.REDUCE_X_X2_OP_ADD, UNARY.REDUCE_X_OP_MAX, UNARY.REDUCE_X_OP_ABSMAX])
+@pytest.mark.parametrize("rows", [0, 1])
+@pytest.mark.parametrize("in_dt", [DT.F32, DT.BF16])
+@pytest.mark.parametrize("m,n,ldi", [(64, 20, 64), (256, 300, 260), (8, 40, 8), (1024, 7, 1024)])
+def test_reductions_vector_kernel(typ, rows, in_dt, m, n, ldi):
+    """m % 4 == 0 and aligned: reduce_vec_kernel (lane groups per column / 16 column slices per row group when n >= 256)."""
+    res = n if rows else m
+    flags = UNARY_FLAG.REDUCE_ROWS if rows else UNARY_FLAG.REDUCE_COLS
+    ref, got, _, _ = run_unary(typ, m, n, ldi, res, in_dt, DT.F32, flags=flags, out_elems=2 * res, batch=2)
+    r, g = ref.reshape(2, -1), got.reshape(2, -1)
+    used = 2 * res if typ == UNARY.REDUCE_X_X2_OP_ADD else res
+    if typ in (UNARY.REDUCE_X_OP_MAX, UNARY.REDUCE_X_OP_ABSMAX):
+        assert np.array_equal(r[:, :used], g[:, :used])
+    else:
+        assert normf_rel(r[:, :used], g[:, :used], DT.F32) < 1e-5
+
+
 def run_binary(typ, m, n, ldi, ldi1, ldo, dts, flags=0, seed=0, batch=1, out_is_bits=False):
     api, orc = capi.load(), pyoracle.oracle()
     in0_dt, in1_dt, out_dt = dts

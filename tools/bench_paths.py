@@ -276,6 +276,24 @@ def cpu_fused(batch=256, m=64, seconds=3.0):
                      f"reference JIT ({ref.lib.xref_get_target_arch().decode()}) bf16 64^3 BRGEMM_ext colbias + ReLU, {batch} problems")
 
 
+def meltw_reduce(api, rows, m=4096, n=8192, batch=1):
+    """REDUCE_X_OP_ADD over rows (one result per column) or over columns (one result per row)."""
+    flag = UNARY_FLAG.REDUCE_ROWS if rows else UNARY_FLAG.REDUCE_COLS
+    res = n if rows else m
+    h = api.dispatch_meltw_unary(UNARY.REDUCE_X_OP_ADD, capi.UnaryShape(m, n, m, res, DT.F32, DT.F32, DT.F32), flag)
+    assert h
+    ns = nsets_for(batch * m * n * 4)
+    X = [rnd(batch * m * n) for _ in range(ns)]
+    Y = [torch.zeros(batch * res, device=DEV) for _ in range(ns)]
+    ps = []
+    for s in range(ns):
+        q = capi.UnaryParam(); q.in_.primary, q.out.primary = X[s].data_ptr(), Y[s].data_ptr(); ps.append(q)
+    step = (lambda s: capi.Api.call(h, ps[s])) if batch == 1 else (lambda s: api.hip_meltw_unary_batch_strided(h, C.byref(ps[s]), batch, m * n * 4, res * 4, 0))
+    w = Work(api, f"meltw unary REDUCE_X_OP_ADD over {'rows' if rows else 'cols'} f32 {m}x{n} x{batch}", float(batch * m * n), float(batch * (m * n + res) * 4), ns, step)
+    w.keep = (X, Y, ps)
+    return w
+
+
 def measure(w, steps, eager=0):
     for i in range(5):
         w.step(i)
@@ -349,7 +367,8 @@ def main():
         makers += [lambda: meltw_relu_tiles(api), lambda: meltw_big(api, UNARY.IDENTITY, "IDENTITY f32"),
                    lambda: meltw_big(api, UNARY.IDENTITY, "IDENTITY f32->bf16", out_dt=DT.BF16),
                    lambda: meltw_big(api, UNARY.TRANSFORM_NORM_TO_NORMT, "TRANSPOSE f32"),
-                   lambda: meltw_big(api, UNARY.TRANSFORM_NORM_TO_VNNI2, "NORM_TO_VNNI2 bf16", in_dt=DT.BF16, out_dt=DT.BF16)]
+                   lambda: meltw_big(api, UNARY.TRANSFORM_NORM_TO_VNNI2, "NORM_TO_VNNI2 bf16", in_dt=DT.BF16, out_dt=DT.BF16),
+                   lambda: meltw_reduce(api, True), lambda: meltw_reduce(api, False), lambda: meltw_reduce(api, True, 64, 1024, 512), lambda: meltw_reduce(api, False, 64, 1024, 512)]
     for mk in makers:
         try:
             ws = mk()
