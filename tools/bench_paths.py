@@ -276,6 +276,28 @@ def cpu_fused(batch=256, m=64, seconds=3.0):
                      f"reference JIT ({ref.lib.xref_get_target_arch().decode()}) bf16 64^3 BRGEMM_ext colbias + ReLU, {batch} problems")
 
 
+def packed_gemm(api, kind, M=9, N=9, K=9, P=2 ** 20, dtype=DT.F32):
+    """Dense packed GEMMs (EDGE-style small operators over a long packed axis): bytes = every packed operand once + C once."""
+    es, tdt = (4, torch.float32) if dtype == DT.F32 else (8, torch.float64)
+    if kind == "packed":
+        sizes, shape, fn = (K * M * P, N * K * P, N * M * P), capi.gemm_shape(M, N, K, M, K, M, dtype, dtype, dtype, dtype), api.create_packed_gemm
+    elif kind == "ac_rm":
+        sizes, shape, fn = (M * K * P, K * N, M * N * P), capi.gemm_shape(M, N, K, K, N, N, dtype, dtype, dtype, dtype), api.create_packed_gemm_ac_rm
+    else:
+        sizes, shape, fn = (M * K, K * N * P, M * N * P), capi.gemm_shape(M, N, K, K, N, N, dtype, dtype, dtype, dtype), api.create_packed_gemm_bc_rm
+    h = fn(shape, GEMM_FLAG.BETA_0, 0, P)
+    assert h
+    ns = nsets_for(sum(sizes) * es)
+    bufs = [[rnd(n, tdt) for n in sizes] for _ in range(ns)]
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = (b.data_ptr() for b in bufs[s]); ps.append(p)
+    w = Work(api, f"packed_gemm {kind} {M}x{N}x{K} P={P} {'f32' if es == 4 else 'f64'} beta=0", 2.0 * M * N * K * P, float(sum(sizes) * es), ns,
+             lambda s: capi.Api.call(h, ps[s]), lambda: api.hip_kernel_name(h, 0).decode())
+    w.keep = (bufs, ps)
+    return w
+
+
 def meltw_reduce(api, rows, m=4096, n=8192, batch=1):
     """REDUCE_X_OP_ADD over rows (one result per column) or over columns (one result per row)."""
     flag = UNARY_FLAG.REDUCE_ROWS if rows else UNARY_FLAG.REDUCE_COLS
@@ -323,7 +345,7 @@ def measure(w, steps, eager=0):
 def main():
     global DEV
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="gemm,csr,fsspmdm,bcsc,fused,meltw")
+    ap.add_argument("--only", default="gemm,csr,fsspmdm,bcsc,fused,meltw,packed")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--eager", type=int, default=0, help="profiling mode: this many plain launches per workload, no timing")
     ap.add_argument("--cpu", action="store_true", help="with --headline: time the reference's CPU kernel (oracle/_ref, 1 core) beside each GPU measurement")
@@ -358,6 +380,8 @@ def main():
     if "csr" in only:
         makers += [lambda: csr_asparse(api, 4096, 0.15), lambda: csr_asparse(api, 65536, 0.15), lambda: csr_asparse(api, 65536, 0.10),
                    lambda: csr_asparse(api, 65536, 0.15, dtype=DT.F64)]
+    if "packed" in only:
+        makers += [lambda: packed_gemm(api, "packed"), lambda: packed_gemm(api, "ac_rm"), lambda: packed_gemm(api, "bc_rm"), lambda: packed_gemm(api, "packed", 4, 4, 4, 2 ** 22)]
     if "fsspmdm" in only:
         makers += [lambda: fsspmdm(api, 4800, 0.15), lambda: fsspmdm(api, 2 ** 20, 0.15), lambda: fsspmdm(api, 2 ** 20, 0.15, DT.F32),
                    lambda: fsspmdm(api, 2 ** 20, 0.15, DT.F64, 1.0)]
