@@ -87,6 +87,7 @@ struct MeltwArgs {
   unsigned int nbatch;
   int m, n, ldi, ldi1, ldi2, ldo;
   int in0_type, in1_type, in2_type, out_type, comp_type;
+  void* ws; size_t ws_bytes;                          // device workspace for two-pass kernels (may be NULL)
   unsigned int flags;
   int type, operation;
 };

@@ -10,6 +10,7 @@
 // case uses 16-byte (f32x4 / bf16x8) accesses.  The op is a run-time switch: the arithmetic is
 // irrelevant next to the memory traffic.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include "internal.hpp"
 
@@ -675,7 +676,7 @@ __device__ __forceinline__ void red_load4(float (&x)[4], gcptr in, long long idx
   else { const f32x4 v = *(GM const f32x4*)((GM const float*)in + idx); for (int e = 0; e < 4; ++e) x[e] = v[e]; }
 }
 template <bool BF16IN>
-__global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int slices) {
+__global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int slices, int chunk, float* partial) {
   __shared__ float part[2][16][16][4];
   const bool rows = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
   const bool init_acc = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_INIT_ACC) != 0;
@@ -716,8 +717,10 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
     const int rg_l = threadIdx.x & 15, sl = threadIdx.x >> 4;            // 16 row groups x 16 slices per block
     const int rg = blockIdx.x * 16 + rg_l;
     float sx[4] = {ident, ident, ident, ident}, sx2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // two-pass form (partial != NULL): blockIdx.z owns columns [z*chunk, (z+1)*chunk) and writes raw partial sums
+    const int jbeg = partial ? (int)blockIdx.z * chunk : 0, jend = partial ? ((jbeg + chunk < p.n) ? jbeg + chunk : p.n) : p.n;
     if (rg < m4 && sl < slices) {
-      for (int j = sl; j < p.n; j += slices) {
+      for (int j = jbeg + sl; j < jend; j += slices) {
         float x[4]; red_load4<BF16IN>(x, in, 4ll * rg + (long long)j * p.ldi);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sx[e] = combine(sx[e], x[e]); sx2[e] += x[e] * x[e]; }
@@ -733,6 +736,12 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
         for (int e = 0; e < 4; ++e) { sx[e] = combine(sx[e], part[0][s2][rg_l][e]); sx2[e] += part[1][s2][rg_l][e]; }
     } else if (sl != 0) return;
     if (rg >= m4) return;
+    if (partial) {
+      GM float* px = (GM float*)partial + ((long long)blockIdx.z * 2) * p.m + 4ll * rg;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { px[e] = sx[e]; px[p.m + e] = sx2[e]; }
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const long long i = 4ll * rg + e;
@@ -742,6 +751,29 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
       if (want_x2) mw_store(out2, i, p.out_type, b);
     }
   }
+}
+
+// second pass of the two-pass column reduction: partial[z][2][m] -> out (chunks combined in order z = 0, 1, ...)
+__global__ __launch_bounds__(256) void reduce_combine_kernel(MeltwArgs p, const float* partial, int nchunks) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.m) return;
+  const bool init_acc = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_INIT_ACC) != 0;
+  const int type = p.type;
+  const bool want_x = type != LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD;
+  const bool want_x2 = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD || type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD;
+  const bool is_add = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD || want_x2;
+  GM const float* px = (GM const float*)partial + i;
+  float a = px[0], b = px[p.m];
+  for (int z = 1; z < nchunks; ++z) {
+    const float x = px[(long long)z * 2 * p.m], x2 = px[((long long)z * 2 + 1) * p.m];
+    if (is_add) a += x; else if (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) a = (a < x) ? x : a; else if (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN) a = (a > x) ? x : a; else a = fmaxf(fabsf(a), fabsf(x));
+    b += x2;
+  }
+  gptr out = (gptr)p.out;
+  gptr out2 = (want_x && want_x2) ? out + (long long)p.ldo * ((p.out_type == LIBXSMM_DATATYPE_F32) ? 4 : 2) : out;
+  if (is_add && init_acc) { if (want_x) a += mw_load(out, i, p.out_type); if (want_x2) b += mw_load(out2, i, p.out_type); }
+  if (want_x) mw_store(out, i, p.out_type, a);
+  if (want_x2) mw_store(out2, i, p.out_type, b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -890,9 +922,24 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
         int G = 1; while (G < 64 && G < a.m / 4) G <<= 1;
         const int slices = (!rows && a.n >= 256) ? 16 : 1;
         const unsigned int gx = rows ? (unsigned int)((a.n + 4 * (64 / G) - 1) / (4 * (64 / G))) : (unsigned int)((a.m / 4 + 15) / 16);
-        if (bf) hipLaunchKernelGGL((reduce_vec_kernel<true>), dim3(gx, a.nbatch), dim3(256), 0, st, a, G, slices);
-        else hipLaunchKernelGGL((reduce_vec_kernel<false>), dim3(gx, a.nbatch), dim3(256), 0, st, a, G, slices);
-        if (name) *name = "reduce_vec_kernel";
+        // one big matrix over its columns: too few row groups to fill the chip -> split the columns over blockIdx.z (two passes)
+        int nchunks = 1;
+        if (!rows && a.ws && a.nbatch == 1 && gx < 512) {
+          nchunks = (int)std::min<long long>(64, std::min<long long>(a.n / 256, 2048 / (gx ? gx : 1)));
+          if ((size_t)nchunks * 2 * (size_t)a.m * sizeof(float) > a.ws_bytes) nchunks = 1;
+        }
+        if (nchunks > 1) {
+          const int chunk = (a.n + nchunks - 1) / nchunks;
+          nchunks = (a.n + chunk - 1) / chunk;
+          if (bf) hipLaunchKernelGGL((reduce_vec_kernel<true>), dim3(gx, 1, nchunks), dim3(256), 0, st, a, G, slices, chunk, (float*)a.ws);
+          else hipLaunchKernelGGL((reduce_vec_kernel<false>), dim3(gx, 1, nchunks), dim3(256), 0, st, a, G, slices, chunk, (float*)a.ws);
+          hipLaunchKernelGGL(reduce_combine_kernel, dim3((unsigned int)((a.m + 255) / 256)), dim3(256), 0, st, a, (const float*)a.ws, nchunks);
+          if (name) *name = "reduce_vec_kernel+combine";
+        } else {
+          if (bf) hipLaunchKernelGGL((reduce_vec_kernel<true>), dim3(gx, a.nbatch), dim3(256), 0, st, a, G, slices, 0, (float*)nullptr);
+          else hipLaunchKernelGGL((reduce_vec_kernel<false>), dim3(gx, a.nbatch), dim3(256), 0, st, a, G, slices, 0, (float*)nullptr);
+          if (name) *name = "reduce_vec_kernel";
+        }
       } else {
         const unsigned int gx = rows ? (unsigned int)((a.n + 3) / 4) : (unsigned int)((a.m + 255) / 256);
         hipLaunchKernelGGL(reduce_kernel, dim3(gx, a.nbatch), dim3(256), 0, st, a);

@@ -217,6 +217,19 @@ def test_reductions_vector_kernel(typ, rows, in_dt, m, n, ldi):
         assert normf_rel(r[:, :used], g[:, :used], DT.F32) < 1e-5
 
 
+@pytest.mark.parametrize("typ", [UNARY.REDUCE_X_OP_ADD, UNARY.REDUCE_X_X2_OP_ADD, UNARY.REDUCE_X_OP_MAX])
+@pytest.mark.parametrize("m,n", [(64, 2500), (256, 4096)])
+def test_column_reduction_of_one_big_matrix_two_pass(typ, m, n):
+    """One matrix, few rows, thousands of columns: the columns are split over the grid and combined in a second pass."""
+    api = capi.load()
+    ref, got, _, _ = run_unary(typ, m, n, m, m, DT.F32, DT.F32, flags=UNARY_FLAG.REDUCE_COLS, out_elems=2 * m, batch=1)
+    used = 2 * m if typ == UNARY.REDUCE_X_X2_OP_ADD else m
+    if typ == UNARY.REDUCE_X_OP_MAX:
+        assert np.array_equal(ref[:used], got[:used])
+    else:
+        assert normf_rel(ref[:used], got[:used], DT.F32) < 1e-5
+
+
 def run_binary(typ, m, n, ldi, ldi1, ldo, dts, flags=0, seed=0, batch=1, out_is_bits=False):
     api, orc = capi.load(), pyoracle.oracle()
     in0_dt, in1_dt, out_dt = dts
