@@ -615,6 +615,23 @@ __global__ __launch_bounds__(256) void gather_scatter_kernel(MeltwArgs p) {
 #undef XIDX
 }
 
+// whole-column gather / scatter (GS_COLS) with 16-byte accesses: a thread moves 16 bytes of one column; the column index is
+// read once per thread (same address across the lanes of a column segment -> broadcast).  Needs (m * S) % 16 == 0, 16-byte
+// aligned bases and leading dimensions that keep every column 16-byte aligned.
+__global__ __launch_bounds__(256) void gather_cols_vec_kernel(MeltwArgs p, int elem_size, unsigned int vpc, unsigned int total) {
+  const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= total) return;
+  const unsigned int v = gid % vpc, j = gid / vpc;
+  gcptr in = (gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0;
+  gptr out = (gptr)p.out + (long long)blockIdx.y * p.bs_out;
+  const bool gather = (p.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER);
+  const void* idxp = gather ? p.aux_in : (const void*)p.aux_out;
+  const long long c = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_8BYTES) ? (long long)((GM const unsigned long long*)idxp)[j] : (long long)((GM const unsigned int*)idxp)[j];
+  const long long src = (gather ? c * p.ldi : (long long)j * p.ldi) * elem_size + 16ll * v;
+  const long long dst = (gather ? (long long)j * p.ldo : c * p.ldo) * elem_size + 16ll * v;
+  *(GM u32x4e*)(out + dst) = *(GM const u32x4e*)(in + src);
+}
+
 // reductions over rows (collapse i: one wave per column, shuffle tree) or columns (collapse j:
 // one thread per row, serial over j -- reads stay coalesced along i) [ref: :1065-1441]
 __global__ __launch_bounds__(256) void reduce_kernel(MeltwArgs p) {
@@ -911,8 +928,16 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       if (name) *name = "xform_kernel";
     } else if (a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER || a.type == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) {
       const long long total = (long long)a.m * a.n;
-      LAUNCH_BY_SIZE(gather_scatter_kernel, sz, dim3((unsigned int)((total + 255) / 256), a.nbatch), dim3(256), st, a);
-      if (name) *name = "gather_scatter_kernel";
+      const long long colbytes = (long long)a.m * sz;
+      if ((a.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_COLS) && !xvec_off && colbytes % 16 == 0 && ((long long)a.ldi * sz) % 16 == 0 && ((long long)a.ldo * sz) % 16 == 0 &&
+          ((((size_t)a.in0 | (size_t)a.out | (size_t)a.bs_in0 | (size_t)a.bs_out) & 15) == 0) && (colbytes / 16) * a.n < (1ll << 32) - 256 && a.nbatch < 65536) {
+        const unsigned int vpc = (unsigned int)(colbytes / 16), tot = vpc * (unsigned int)a.n;
+        hipLaunchKernelGGL(gather_cols_vec_kernel, dim3((tot + 255u) / 256u, a.nbatch), dim3(256), 0, st, a, sz, vpc, tot);
+        if (name) *name = "gather_cols_vec_kernel";
+      } else {
+        LAUNCH_BY_SIZE(gather_scatter_kernel, sz, dim3((unsigned int)((total + 255) / 256), a.nbatch), dim3(256), st, a);
+        if (name) *name = "gather_scatter_kernel";
+      }
     } else if (is_reduce_type(a.type)) {
       const bool rows = (a.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
       const bool bf = a.in0_type == LIBXSMM_DATATYPE_BF16;

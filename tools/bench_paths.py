@@ -298,6 +298,23 @@ def packed_gemm(api, kind, M=9, N=9, K=9, P=2 ** 20, dtype=DT.F32):
     return w
 
 
+def meltw_gather_cols(api, m=4096, n=8192, src_cols=16384):
+    """GATHER of whole columns (out[:, j] = in[:, idx[j]]), 4-byte indices: bytes = gathered columns read + written + indices."""
+    flags = UNARY_FLAG.GS_COLS | UNARY_FLAG.IDX_SIZE_4BYTES
+    h = api.dispatch_meltw_unary(UNARY.GATHER, capi.UnaryShape(m, n, m, m, DT.F32, DT.F32, DT.F32), flags)
+    assert h
+    ns = nsets_for((src_cols + n) * m * 4, cap_bytes=20 * 2 ** 30)
+    X = [rnd(m * src_cols) for _ in range(ns)]
+    Y = [torch.zeros(m * n, device=DEV) for _ in range(ns)]
+    idx = torch.randperm(src_cols, device=DEV)[:n].to(torch.int32)
+    ps = []
+    for s in range(ns):
+        q = capi.UnaryParam(); q.in_.primary, q.in_.secondary, q.out.primary = X[s].data_ptr(), idx.data_ptr(), Y[s].data_ptr(); ps.append(q)
+    w = Work(api, f"meltw unary GATHER columns f32 {m}x{n} out of {src_cols}", float(m * n), float(2 * m * n * 4 + n * 4), ns, lambda s: capi.Api.call(h, ps[s]))
+    w.keep = (X, Y, idx, ps)
+    return w
+
+
 def meltw_reduce(api, rows, m=4096, n=8192, batch=1):
     """REDUCE_X_OP_ADD over rows (one result per column) or over columns (one result per row)."""
     flag = UNARY_FLAG.REDUCE_ROWS if rows else UNARY_FLAG.REDUCE_COLS
@@ -392,7 +409,7 @@ def main():
                    lambda: meltw_big(api, UNARY.IDENTITY, "IDENTITY f32->bf16", out_dt=DT.BF16),
                    lambda: meltw_big(api, UNARY.TRANSFORM_NORM_TO_NORMT, "TRANSPOSE f32"),
                    lambda: meltw_big(api, UNARY.TRANSFORM_NORM_TO_VNNI2, "NORM_TO_VNNI2 bf16", in_dt=DT.BF16, out_dt=DT.BF16),
-                   lambda: meltw_reduce(api, True), lambda: meltw_reduce(api, False), lambda: meltw_reduce(api, True, 64, 1024, 512), lambda: meltw_reduce(api, False, 64, 1024, 512)]
+                   lambda: meltw_gather_cols(api), lambda: meltw_reduce(api, True), lambda: meltw_reduce(api, False), lambda: meltw_reduce(api, True, 64, 1024, 512), lambda: meltw_reduce(api, False, 64, 1024, 512)]
     for mk in makers:
         try:
             ws = mk()
