@@ -21,6 +21,12 @@
  * In BATCH_REDUCE_ADDRESS mode a/b.primary are pointer arrays, so sa/sb step through
  * those arrays (sa = br_count*sizeof(void*) gives each batch element its own list).
  * op.tertiary (br_count), a/b.secondary (offset arrays) are shared by all elements.
+ *
+ * The same call accepts a packed sparse handle (libxsmm_create_packed_spgemm_csr/_csc, _spgemm_csr_areg, FsSpMDM kernels):
+ * the loop over element-local packed tensors an application like EDGE runs around one small operator
+ * [ref: samples/edge]. The sparse operand's values are shared, so its stride must be 0 (anything else is an error);
+ * the dense operand and C step by sb/sa and sc.  A kernel whose single call was too small to specialise is
+ * specialised by the first eager batched launch that covers enough columns.
  */
 #ifndef LIBXSMM_HIP_H
 #define LIBXSMM_HIP_H

@@ -132,6 +132,8 @@ JitKernel* jit_pgemm_create(const PgemmArgs& geometry, std::string* why);   // p
 bool jit_spmm_usable(const JitKernel* k, const void* x, const void* y);
 bool jit_pgemm_usable(const JitKernel* k, const void* a, const void* b, const void* c);
 int jit_spmm_launch(JitKernel* k, const void* vals, const void* x, void* y, void* stream);
+int jit_spmm_launch_slabs(JitKernel* k, const void* vals, const void* x, void* y, long long batch, long long bslabs,
+                          long long outer_x, long long outer_y, long long batch_x, long long batch_y, void* stream);
 void jit_release(JitKernel* k);
 JitKernel* jit_compile(const std::string& src, const std::string& fname, long long total_threads, int align_bytes, std::string* why);
 int jit_launch(JitKernel* k, void** args, void* stream);
@@ -155,6 +157,7 @@ struct KernelCtx {
   unsigned int* d_vmap = nullptr;   // value position per pattern entry (B-sparse CSR regrouped by column)
   int sp_ncols = 0, sp_skip_empty = 0;
   JitKernel* jit = nullptr;         // pattern-specialised kernel (nullptr: precompiled kernels serve)
+  std::vector<unsigned int> h_ptr, h_idx, h_vmap;   // host pattern kept while specialisation is deferred to the first batched launch
   struct EqnPlan* eqn = nullptr;    // K_MEQN: the evaluation plan (meqn.cpp)
   int device = 0;
   const char* kname_single = "";

@@ -115,21 +115,19 @@ std::string generate_spmm(const SpmmJitSpec& s, int vec, long long* total_thread
   std::vector<char> touched((size_t)s.inner, 0);
   for (unsigned int z = 0; z < nnz; ++z) touched[s.idx[z]] = 1;
   const long long tpo = s.ncols / vec;
-  *total_threads = tpo * s.nouter;
+  *total_threads = tpo;                       // per slab; the launch multiplies by the slab count
   std::string src;
   src.reserve(4096 + (size_t)nnz * 64);
   append(src, "// generated by libxsmm_amd: rows=%d inner=%d nnz=%u ncols=%lld outer=%d vec=%d %s beta0=%d\n", s.rows, s.inner, nnz, s.ncols, s.nouter, vec, T, s.beta0);
   append(src, "typedef %s T;\n", T);
   if (vec > 1) append(src, "typedef T V __attribute__((ext_vector_type(%d)));\n", vec); else src += "typedef T V;\n";
   src += "#define GM __attribute__((address_space(1)))\n#define CM __attribute__((address_space(4)))\n";
-  src += "extern \"C\" __global__ __launch_bounds__(256) void " + fname + "(const void* vals_, const void* x_, void* y_) {\n";
-  append(src, "  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n  if (t >= %lldLL) return;\n", *total_threads);
-  if (s.nouter > 1) {
-    append(src, "  const long long o = t / %lldLL, c = t - o * %lldLL;\n", tpo, tpo);
-    append(src, "  GM const T* x = (GM const T*)x_ + o * %lldLL + c * %d;\n  GM T* y = (GM T*)y_ + o * %lldLL + c * %d;\n", s.outer_x, vec, s.outer_y, vec);
-  } else {
-    append(src, "  GM const T* x = (GM const T*)x_ + t * %d;\n  GM T* y = (GM T*)y_ + t * %d;\n", vec, vec);
-  }
+  // the slab (outer) count and strides are run-time arguments: a batched launch (libxsmm_hip_gemm_batch_strided on a packed
+  // kernel) reuses the same code with the caller's element loop as the slab axis; bslabs = slabs per batch element
+  src += "extern \"C\" __global__ __launch_bounds__(256) void " + fname + "(const void* vals_, const void* x_, void* y_, long long nslab, long long bslabs, long long outer_x, long long outer_y, long long batch_x, long long batch_y) {\n";
+  append(src, "  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n  if (t >= %lldLL * nslab) return;\n", tpo);
+  append(src, "  const long long o = t / %lldLL, c = t - o * %lldLL, ob = o / bslabs, oi = o - ob * bslabs;\n", tpo, tpo);
+  append(src, "  GM const T* x = (GM const T*)x_ + ob * batch_x + oi * outer_x + c * %d;\n  GM T* y = (GM T*)y_ + ob * batch_y + oi * outer_y + c * %d;\n", vec, vec);
   src += "  CM const T* v = (CM const T*)vals_;\n";
   for (int k = 0; k < s.inner; ++k) if (touched[k]) append(src, "  const V x%d = *(GM const V*)(x + %lldLL);\n", k, (long long)k * s.ld_x);
   // rows that are written: non-empty ones, and empty ones when beta=0 demands zeros [ref: asparse generator :336-345 skips them]
@@ -297,10 +295,19 @@ bool jit_spmm_usable(const JitKernel* k, const void* x, const void* y) {
   return (((size_t)x | (size_t)y) & mask) == 0;
 }
 
-int jit_spmm_launch(JitKernel* k, const void* vals, const void* x, void* y, void* stream) {
+int jit_spmm_launch(JitKernel* k, const void* vals, const void* x, void* y, void* stream) {     // packed GEMM kernels: three pointers
   void* args[3] = {(void*)&vals, (void*)&x, (void*)&y};
   const unsigned int grid = (unsigned int)((k->total_threads + 255) / 256);
   return (int)hipModuleLaunchKernel(k->fn, grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+}
+// fixed-pattern kernels: `batch` elements of `bslabs` slabs each; strides in elements.  total_threads holds threads per slab.
+int jit_spmm_launch_slabs(JitKernel* k, const void* vals, const void* x, void* y, long long batch, long long bslabs,
+                          long long outer_x, long long outer_y, long long batch_x, long long batch_y, void* stream) {
+  long long nslab = batch * bslabs;
+  void* args[9] = {(void*)&vals, (void*)&x, (void*)&y, (void*)&nslab, (void*)&bslabs, (void*)&outer_x, (void*)&outer_y, (void*)&batch_x, (void*)&batch_y};
+  const long long blocks = (k->total_threads * nslab + 255) / 256;
+  if (blocks >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  return (int)hipModuleLaunchKernel(k->fn, (unsigned int)blocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr);
 }
 
 void jit_release(JitKernel* k) {

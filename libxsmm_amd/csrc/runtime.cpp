@@ -221,6 +221,7 @@ const void* handle_for_slot(int slot) { return (const void*)g_tramps[slot]; }
 // =====================================================================================================
 // invocation: param struct -> argument block -> launch
 // =====================================================================================================
+static void attach_jit(KernelCtx* c, const unsigned int* ptr, const unsigned int* idx, const unsigned int* vmap, long long batch = 1);
 namespace {
 
 struct BatchSpec {
@@ -388,12 +389,13 @@ static void spmm_geometry(const KernelCtx* k, SpmmArgs& a) {
   a.rows = k->sp_rows; a.inner = k->sp_inner; a.nnz = k->sp_nnz;
 }
 
-void run_spmm(KernelCtx* k, const void* param) {
+void run_spmm(KernelCtx* k, const void* param, const BatchSpec& b) {
   const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
   SpmmArgs a{};
   spmm_geometry(k, a);
   a.ptr = k->d_ptr; a.idx = k->d_idx; a.vmap = k->d_vmap;
-  if (k->kind == K_SPMM_ASPARSE) {
+  const bool asp = (k->kind == K_SPMM_ASPARSE);
+  if (asp) {
     a.vals = k->d_vals ? k->d_vals : p->a.primary;        // baked (areg / FsSpMDM) or run-time values
     a.x = (const char*)p->b.primary; a.y = (char*)p->c.primary;
   } else {
@@ -401,10 +403,37 @@ void run_spmm(KernelCtx* k, const void* param) {
     a.x = (const char*)p->a.primary; a.y = (char*)p->c.primary;
   }
   if (!a.vals || !a.x || !a.y) { set_error(-2, "sparse kernel called with a NULL operand"); return; }
+  // batched launch = the caller's loop over elements: the dense operand and C step by byte strides, the sparse operand's values are
+  // shared (its stride must be 0) [include/libxsmm_hip.h]
+  const long long esz = (a.dtype == LIBXSMM_DATATYPE_F64) ? 8 : 4;
+  const long long sx = asp ? b.s[1] : b.s[0], sy = b.s[2], sv = asp ? b.s[0] : b.s[1];
+  const long long count = (long long)b.count;
+  if (count > 1 && (sv != 0 || sx % esz != 0 || sy % esz != 0)) { set_error(-3, "batched packed kernel: the value stride must be 0 and operand strides multiples of the element size"); return; }
   const char* kname = nullptr;
-  int err;
-  if (jit_spmm_usable(k->jit, a.x, a.y)) { kname = jit_name(k->jit); err = jit_spmm_launch(k->jit, a.vals, a.x, a.y, tls().stream); }
-  else err = launch_spmm(a, tls().stream, &kname);
+  int err = 0;
+  const long long bslabs = a.nouter;
+  if (count > 1 && !k->jit && !k->h_ptr.empty()) {       // specialisation deferred at creation (one call too small to repay hiprtc)
+    static std::mutex mu; std::lock_guard<std::mutex> lk(mu);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;     // loading a module is not a capturable operation: wait for an eager launch
+    if (tls().stream) (void)hipStreamIsCapturing((hipStream_t)tls().stream, &cs);
+    if (cs == hipStreamCaptureStatusNone && !k->jit && !k->h_ptr.empty() && a.ncols * a.nouter * count >= 4096) {
+      ::attach_jit(k, k->h_ptr.data(), k->h_idx.data(), k->h_vmap.empty() ? nullptr : k->h_vmap.data(), count);
+      k->h_ptr.clear(); k->h_ptr.shrink_to_fit();        // one attempt
+    }
+  }
+  if (jit_spmm_usable(k->jit, a.x, a.y) && (count == 1 || jit_spmm_usable(k->jit, a.x + sx, a.y + sy))) {   // base and stride aligned to the kernel's vector width
+    kname = jit_name(k->jit);
+    err = jit_spmm_launch_slabs(k->jit, a.vals, a.x, a.y, count, bslabs, a.outer_x, a.outer_y, sx / esz, sy / esz, tls().stream);
+  } else if (count == 1) err = launch_spmm(a, tls().stream, &kname);
+  else if (asp) {              // precompiled kernels: the slab axis of the A-sparse form is free -> one launch
+    a.nouter = (int)count; a.outer_x = sx / esz; a.outer_y = sy / esz;
+    err = launch_spmm(a, tls().stream, &kname);
+  } else {                     // B-sparse already uses the slab axis for the rows of A: one launch per element
+    for (long long e = 0; e < count && err == 0; ++e) {
+      SpmmArgs ae = a; ae.x = a.x + e * sx; ae.y = a.y + e * sy;
+      err = launch_spmm(ae, tls().stream, &kname);
+    }
+  }
   if (kname) k->kname_single = k->kname_batched = kname;
   finish_launch(err, kname);
 }
@@ -469,7 +498,7 @@ void run_any(KernelCtx* k, const void* param, const BatchSpec& b) {
   switch (k->kind) {
     case K_GEMM: run_gemm(k, param, b); break;
     case K_MELTW: run_meltw(k, param, b); break;
-    case K_SPMM_ASPARSE: case K_SPMM_BSPARSE: run_spmm(k, param); break;
+    case K_SPMM_ASPARSE: case K_SPMM_BSPARSE: run_spmm(k, param, b); break;
     case K_BCSC: run_bcsc(k, param); break;
     case K_PGEMM: run_pgemm(k, param); break;
     case K_MEQN: scratch_reset(); run_meqn(k->eqn, param); break;
@@ -777,13 +806,19 @@ static int jit_mode() {
   if (g_jit_mode < 0) { const char* e = getenv("LIBXSMM_HIP_JIT"); g_jit_mode = (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : 1; }
   return g_jit_mode;
 }
-static void attach_jit(KernelCtx* c, const unsigned int* ptr, const unsigned int* idx, const unsigned int* vmap) {
+static void attach_jit(KernelCtx* c, const unsigned int* ptr, const unsigned int* idx, const unsigned int* vmap, long long batch) {
   const int mode = jit_mode();
   if (mode == 0) return;
   SpmmArgs a{}; spmm_geometry(c, a);
-  if (mode == 1 && a.ncols * a.nouter < 4096) return;    // ~0.1 s of hiprtc is not repaid by launch-bound toy sizes
+  if (mode == 1 && a.ncols * a.nouter * batch < 4096) {  // ~0.1 s of hiprtc is not repaid by launch-bound toy sizes ...
+    if (batch == 1 && c->h_ptr.empty()) {                // ... unless a batched launch later covers enough columns: keep the pattern
+      c->h_ptr.assign(ptr, ptr + a.rows + 1); c->h_idx.assign(idx, idx + ptr[a.rows]);
+      if (vmap) c->h_vmap.assign(vmap, vmap + ptr[a.rows]);
+    }
+    return;
+  }
   SpmmJitSpec s{};
-  s.dtype = a.dtype; s.rows = a.rows; s.inner = a.inner; s.nouter = a.nouter; s.beta0 = a.beta0; s.skip_empty = a.skip_empty;
+  s.dtype = a.dtype; s.rows = a.rows; s.inner = a.inner; s.nouter = (int)std::min<long long>(a.nouter * batch, 1 << 30); s.beta0 = a.beta0; s.skip_empty = a.skip_empty;
   s.ptr = ptr; s.idx = idx; s.vmap = vmap; s.ld_x = a.ld_x; s.ld_y = a.ld_y; s.outer_x = a.outer_x; s.outer_y = a.outer_y; s.ncols = a.ncols;
   std::string why;
   c->jit = jit_spmm_create(s, &why);
@@ -807,7 +842,7 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_csr(libxsmm_gemm_s
     c = new_unregistered(K_SPMM_ASPARSE, d); if (!c) return nullptr;
     c->packed_width = packed_width; c->sp_ncols = s.n; c->sp_skip_empty = 1;
     ok = upload_pattern(c, s.m, s.k, row_ptr, column_idx, nullptr);
-    if (ok) attach_jit(c, row_ptr, column_idx, nullptr);
+    if (ok) attach_jit(c, row_ptr, column_idx, nullptr, 1);
     c->nflops = (unsigned int)(2ull * row_ptr[s.m] * s.n * packed_width);   // [ref: libxsmm_main.c:2356-2359]
   } else if (s.ldb == 0 && s.lda > 0 && s.ldc > 0) {   // B sparse, CSR over rows k -> regroup by output column n
     if (s.lda < s.k || s.ldc < s.n) return nullptr;
@@ -820,7 +855,7 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_csr(libxsmm_gemm_s
     c = new_unregistered(K_SPMM_BSPARSE, d); if (!c) return nullptr;
     c->packed_width = packed_width;
     ok = upload_pattern(c, s.n, s.k, cptr.data(), ridx.data(), vmap.data());
-    if (ok) attach_jit(c, cptr.data(), ridx.data(), vmap.data());
+    if (ok) attach_jit(c, cptr.data(), ridx.data(), vmap.data(), 1);
     c->nflops = (unsigned int)(2ull * nnz * s.m * packed_width);
   } else return nullptr;                                 // C sparse: not on the hot path
   if (!ok) { drop_unregistered(c); return nullptr; }
@@ -841,7 +876,7 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_csc(libxsmm_gemm_s
   KernelCtx* c = new_unregistered(K_SPMM_BSPARSE, d); if (!c) return nullptr;
   c->packed_width = packed_width;
   if (!upload_pattern(c, s.n, s.k, column_ptr, row_idx, nullptr)) { drop_unregistered(c); return nullptr; }
-  attach_jit(c, column_ptr, row_idx, nullptr);
+  attach_jit(c, column_ptr, row_idx, nullptr, 1);
   c->nflops = (unsigned int)(2ull * column_ptr[s.n] * s.m * packed_width);
   return (libxsmm_gemmfunction)handle_for_slot(c->slot);
 }
@@ -1031,9 +1066,13 @@ static KernelCtx* batch_ctx(const void* fn, Kind want) {
   return c;
 }
 LIBXSMM_API void libxsmm_hip_gemm_batch_strided(libxsmm_gemmfunction kernel, const libxsmm_gemm_param* param, size_t count, long long sa, long long sb, long long sc) {
-  KernelCtx* c = batch_ctx((const void*)kernel, K_GEMM); if (!c || !param || count == 0) return;
-  if (c->g.flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) { set_error(-3, "use libxsmm_hip_gemm_ext_batch_strided for ext kernels"); return; }
+  KernelCtx* c = ctx_from_handle((const void*)kernel);
+  if (!c) { set_error(-3, "batched launch through an unknown kernel handle"); return; }
+  if (!param || count == 0) return;
   BatchSpec b; b.count = count; b.s[0] = sa; b.s[1] = sb; b.s[2] = sc;
+  if (c->kind == K_SPMM_ASPARSE || c->kind == K_SPMM_BSPARSE) { run_spmm(c, param, b); return; }     // packed sparse kernels: the element loop
+  if (c->kind != K_GEMM) { set_error(-3, "batched launch: handle is not a (BR)GEMM or packed sparse kernel"); return; }
+  if (c->g.flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) { set_error(-3, "use libxsmm_hip_gemm_ext_batch_strided for ext kernels"); return; }
   run_gemm(c, param, b);
 }
 LIBXSMM_API void libxsmm_hip_gemm_ext_batch_strided(libxsmm_gemmfunction_ext kernel, const libxsmm_gemm_ext_param* param, size_t count,

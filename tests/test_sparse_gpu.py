@@ -116,6 +116,88 @@ def test_packed_bsparse(fmt, dt, M, N, K, P, density, beta0, jit_mode):
 
 
 @pytest.mark.parametrize("dt", [DT.F32, DT.F64])
+@pytest.mark.parametrize("side,M,N,K,P,count", [("a", 35, 16, 35, 16, 37), ("a", 9, 7, 9, 8, 5), ("a", 20, 3, 50, 33, 4), ("b", 9, 35, 20, 64, 6), ("b", 5, 12, 7, 10, 3)])
+def test_packed_sparse_batched(dt, side, M, N, K, P, count, jit_mode):
+    """libxsmm_hip_gemm_batch_strided on a packed sparse handle == the caller's loop of single calls (the EDGE usage:
+    one small operator applied to many element-local packed tensors), bit for bit, and both match the oracle."""
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(11)
+    esz = np.dtype(NP[dt]).itemsize
+    if side == "a":
+        rowptr, colidx = random_csr(rng, M, K, 0.15)
+        dense_elems, ld = K * N * P, (0, N, N)
+    else:
+        rowptr, colidx = random_csr(rng, K, N, 0.2)
+        dense_elems, ld = M * K * P, (K, 0, N)
+    vals = rand_values(rng, len(colidx), dt) + NP[dt](0.05)
+    X = rand_values(rng, dense_elems * count, dt)
+    C0 = rand_values(rng, M * N * P * count, dt)
+    ref = C0.copy()
+    fn = orc.lib.oracle_packed_spgemm_csr_asparse if side == "a" else orc.lib.oracle_packed_spgemm_csr_bsparse
+    for e in range(count):
+        xe, ce = X[e * dense_elems:], ref[e * M * N * P:]
+        fn(dt, M, N, K, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, xe.ctypes.data, N if side == "a" else K, ce.ctypes.data, N, 0)
+    shape = capi.gemm_shape(M, N, K, ld[0], ld[1], ld[2], dt, dt, dt, dt)
+    h = api.create_packed_spgemm_csr(shape, 0, 0, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data)
+    assert h
+    dv, dX, dC, dL = _dev(vals), _dev(X), _dev(C0.copy()), _dev(C0.copy())
+    p = capi.GemmParam()
+    sx, sc = dense_elems * esz, M * N * P * esz
+    if side == "a":
+        p.a.primary, p.b.primary, p.c.primary = dv.data_ptr(), dX.data_ptr(), dC.data_ptr()
+        api.hip_gemm_batch_strided(h, C.byref(p), count, 0, sx, sc)
+    else:
+        p.a.primary, p.b.primary, p.c.primary = dX.data_ptr(), dv.data_ptr(), dC.data_ptr()
+        api.hip_gemm_batch_strided(h, C.byref(p), count, sx, 0, sc)
+    api.hip_sync(); api.check()
+    for e in range(count):                      # the loop the batched call replaces
+        q = capi.GemmParam()
+        if side == "a":
+            q.a.primary, q.b.primary, q.c.primary = dv.data_ptr(), dX.data_ptr() + e * sx, dL.data_ptr() + e * sc
+        else:
+            q.a.primary, q.b.primary, q.c.primary = dX.data_ptr() + e * sx, dv.data_ptr(), dL.data_ptr() + e * sc
+        capi.Api.call(h, q)
+    api.hip_sync(); api.check()
+    got, loop = _host(dC, NP[dt]), _host(dL, NP[dt])
+    assert np.array_equal(got.view(np.uint8), loop.view(np.uint8))
+    assert normf_rel(ref, got, dt) <= (1e-5 if dt == DT.F32 else 1e-12)
+    # a value stride is refused (the operator is shared by construction)
+    api.hip_gemm_batch_strided(h, C.byref(p), 2, 8 if side == "a" else sx, sx if side == "a" else 8, sc)
+    assert api.hip_get_last_error() != 0
+    api.hip_clear_last_error()
+    api.release_kernel(h)
+
+
+def test_packed_sparse_batched_deferred_specialisation():
+    """Auto mode (default): a packed kernel whose single call is too small to repay hiprtc is specialised by the first batched
+    launch that covers enough columns; the result still matches the oracle."""
+    api, orc = capi.load(), pyoracle.oracle()
+    api.hip_set_jit(1)
+    dt, M, N, K, P, count = DT.F32, 35, 9, 35, 16, 64
+    rng = np.random.default_rng(5)
+    rowptr, colidx = random_csr(rng, M, K, 0.09)
+    vals = rand_values(rng, len(colidx), dt) + np.float32(0.05)
+    X, C0 = rand_values(rng, K * N * P * count, dt), rand_values(rng, M * N * P * count, dt)
+    ref = C0.copy()
+    for e in range(count):
+        orc.lib.oracle_packed_spgemm_csr_asparse(dt, M, N, K, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data,
+                                                 X[e * K * N * P:].ctypes.data, N, ref[e * M * N * P:].ctypes.data, N, 1)
+    h = api.create_packed_spgemm_csr(capi.gemm_shape(M, N, K, 0, N, N, dt, dt, dt, dt), GEMM_FLAG.BETA_0, 0, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data)
+    assert h and not api.hip_kernel_name(h, 0).decode().startswith("spmm_jit")
+    dv, dX, dC = _dev(vals), _dev(X), _dev(C0.copy())
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.c.primary = dv.data_ptr(), dX.data_ptr(), dC.data_ptr()
+    api.hip_gemm_batch_strided(h, C.byref(p), count, 0, K * N * P * 4, M * N * P * 4)
+    api.hip_sync(); api.check()
+    assert api.hip_kernel_name(h, 1).decode().startswith("spmm_jit")
+    got = _host(dC, np.float32)
+    assert normf_rel(ref, got, dt) <= 1e-5
+    empty = np.where(np.diff(rowptr) == 0)[0]
+    assert all(np.array_equal(got.reshape(count, M, N * P)[:, r], C0.reshape(count, M, N * P)[:, r]) for r in empty)
+    api.release_kernel(h)
+
+
+@pytest.mark.parametrize("dt", [DT.F32, DT.F64])
 @pytest.mark.parametrize("M,N,K,density,beta", [(35, 4800, 35, 0.15, 0.0), (192, 480, 96, 0.03, 1.0), (28, 64, 49, 0.14, 0.0)])
 def test_fsspmdm(dt, M, N, K, density, beta, jit_mode):
     api, orc = capi.load(), pyoracle.oracle()

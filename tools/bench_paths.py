@@ -82,6 +82,32 @@ def csr_asparse(api, P, density, N=35, dtype=DT.F32):
     return w
 
 
+def csr_asparse_batched(api, count=65536, density=0.09, N=9, P=16, dtype=DT.F32):
+    """EDGE-style use: one small operator applied to `count` element-local packed tensors (N quantities x P fused runs) in ONE
+    launch (libxsmm_hip_gemm_batch_strided on the packed handle) instead of `count` calls."""
+    M = K = 35
+    nnz = int(round(M * K * density))
+    rowptr, colidx, vals = random_pattern(M, K, nnz)
+    es, tdt, npdt = (4, torch.float32, np.float32) if dtype == DT.F32 else (8, torch.float64, np.float64)
+    h = api.create_packed_spgemm_csr(capi.gemm_shape(M, N, K, 0, N, N, dtype, dtype, dtype, dtype), GEMM_FLAG.BETA_0, 0, P,
+                                     rowptr.ctypes.data, colidx.ctypes.data, vals.astype(npdt).ctypes.data)
+    assert h
+    kt, mne = len(set(colidx.tolist())), int((np.diff(rowptr.astype(np.int64)) > 0).sum())
+    sx, sc = K * N * P * es, M * N * P * es
+    ns = nsets_for((sx + sc) * count)
+    dv = dev(vals.astype(npdt))
+    Bs = [rnd(K * N * P * count, tdt) for _ in range(ns)]
+    Cs = [torch.zeros(M * N * P * count, dtype=tdt, device=DEV) for _ in range(ns)]
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = dv.data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(); ps.append(p)
+    w = Work(api, f"packed_spgemm_csr A-sparse {M}x{K} nnz={nnz} ({100*density:.0f}%) N={N} P={P} x {count} elements/launch {'f32' if es == 4 else 'f64'}",
+             2.0 * nnz * N * P * count, float(((kt * N + mne * N) * P * es) * count + nnz * es), ns,
+             lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), count, 0, sx, sc), lambda: api.hip_kernel_name(h, 1).decode() or api.hip_kernel_name(h, 0).decode())
+    w.keep = (dv, Bs, Cs, ps, rowptr, colidx)
+    return w
+
+
 def fsspmdm(api, N, density, dtype=DT.F64, beta=0.0):
     M = K = 35
     nnz = int(round(M * K * density))
@@ -396,7 +422,7 @@ def main():
         makers += [lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
     if "csr" in only:
         makers += [lambda: csr_asparse(api, 4096, 0.15), lambda: csr_asparse(api, 65536, 0.15), lambda: csr_asparse(api, 65536, 0.10),
-                   lambda: csr_asparse(api, 65536, 0.15, dtype=DT.F64)]
+                   lambda: csr_asparse(api, 65536, 0.15, dtype=DT.F64), lambda: csr_asparse_batched(api)]
     if "packed" in only:
         makers += [lambda: packed_gemm(api, "packed"), lambda: packed_gemm(api, "ac_rm"), lambda: packed_gemm(api, "bc_rm"), lambda: packed_gemm(api, "packed", 4, 4, 4, 2 ** 22)]
     if "fsspmdm" in only:
