@@ -21,6 +21,8 @@
  * In BATCH_REDUCE_ADDRESS mode a/b.primary are pointer arrays, so sa/sb step through
  * those arrays (sa = br_count*sizeof(void*) gives each batch element its own list).
  * op.tertiary (br_count), a/b.secondary (offset arrays) are shared by all elements.
+ * MXFP4 weights: the E8M0 scales in a.tertiary step with A -- by sa*2/32 bytes (one scale byte per 32 weights; sa must be
+ * a multiple of 16), or by sa through the list of per-block scale pointers in BATCH_REDUCE_ADDRESS mode.
  *
  * The same call accepts a packed sparse handle (libxsmm_create_packed_spgemm_csr/_csc, _spgemm_csr_areg, FsSpMDM kernels):
  * the loop over element-local packed tensors an application like EDGE runs around one small operator

@@ -102,6 +102,21 @@ __device__ __forceinline__ void br_base(const GemmArgs& p, const BatchPtrs& q, u
   else { a = q.a; b = q.b; }
 }
 
+// MXFP4 A: base of the E8M0 scales of batch-reduce element r [ref: gemm ref :200-222] -- one byte per (32-deep k-block, row):
+// pointer list / byte offset of A * 2 / 32 / byte stride of A * 2 / 32
+__device__ __forceinline__ gcptr mx_scale_base(const GemmArgs& p, unsigned int bidx, unsigned long long r) {
+  gcptr base = (gcptr)p.a_scf + (long long)bidx * p.bs_scf;
+  if (p.br_mode == 1) return list_entry((const void*)(size_t)base, r);
+  if (p.br_mode == 2) return base + ((long long)uniform_u64((unsigned long long)((GM const long long*)p.offs_a)[r]) * 2) / 32;
+  if (p.br_mode == 3) return base + ((p.br_stride_a * 2) / 32) * (long long)r;
+  return base;
+}
+__device__ __forceinline__ float e2m1_to_f32(unsigned int c) {     // [ref: gemm ref :60-64]
+  const unsigned int m = c & 7u;
+  const unsigned int bits = (m == 0u) ? 0u : (m == 1u) ? 0x3f000000u : (((m >> 1) + 126u) << 23) | ((m & 1u) << 22);
+  return __uint_as_float(bits | ((c & 8u) << 28));
+}
+
 // activation, ReLU bitmask, output conversion / VNNI-C of one element (block = 64 x 4: a wave is 64 rows of one column)
 __device__ __forceinline__ void generic_epilogue(const GemmArgs& p, const BatchPtrs& q, int i, int j, bool valid, float acc) {
   const float y = act_apply(p.act, acc);
@@ -211,6 +226,31 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
       if (!beta0) f = add_rn(f, *c);
       *c = f;
     } else ((GM int*)q.c)[(long long)j * p.ldc + i] = acc;
+    return;
+  }
+
+  if (p.a_type == LIBXSMM_DATATYPE_MXFP4X2) {
+    // MXFP4 weights x bf16/f32 activations [ref: gemm ref :949-1008]: packed E2M1 pairs [k/2][lda] (low nibble = even k), value * scale
+    // is exact, products summed serially from 0 (unfused), C = (beta ? C : 0) + sum with one RNE for bf16 output
+    if (!valid) return;
+    float acc = 0.0f;
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      gcptr ar, br; br_base(p, q, r, ar, br);
+      gcptr sr = mx_scale_base(p, bidx, r);
+      for (int s = 0; s < p.k / 32; ++s) {
+        const float scf = __uint_as_float((unsigned int)((GM const unsigned char*)sr)[(long long)s * p.lda + i] << 23);
+        for (int k2 = 0; k2 < 32; k2 += 2) {
+          const unsigned int pk = ((GM const unsigned char*)ar)[(long long)(s * 32 + k2) * p.lda / 2 + i];
+          const long long bi = (long long)j * p.ldb + s * 32 + k2;
+          acc = add_rn(acc, mul_rn(mul_rn(e2m1_to_f32(pk & 15u), scf), load_as_f32(br, bi, p.b_type)));
+          acc = add_rn(acc, mul_rn(mul_rn(e2m1_to_f32(pk >> 4), scf), load_as_f32(br, bi + 1, p.b_type)));
+        }
+      }
+    }
+    const long long ci = (long long)j * p.ldc + i;
+    const float base = beta0 ? 0.0f : load_as_f32(q.c, ci, p.c_type);
+    const float y = add_rn(base, acc);
+    if (p.c_type == LIBXSMM_DATATYPE_F32) ((GM float*)q.c)[ci] = y; else ((GM unsigned short*)q.c)[ci] = f32_to_bf16_rne(y);
     return;
   }
 
@@ -1137,6 +1177,87 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// MXFP4 weight streaming kernel: A = packed E2M1 pairs + one E8M0 scale per (32-deep k-block, row), B bf16, exact tiles.
+// Structure = gemm_bf16_stream_kernel (B through LDS-DMA).  In this operand order a lane owns ONE row i of A, so the scale
+// of a k-block is one value per lane: v_cvt_scalef32_pk_bf16_fp4 turns a byte (two k of row i) into a scaled bf16 pair
+// in one instruction (value * 2^e is exact in bf16), i.e. the MFMA consumes exactly what the reference multiplies
+// [ref: gemm ref :976-982]; only the summation order differs (matrix-core tree instead of a serial chain).
+// HBM bytes per 64^3 problem: A 2 KiB + scales 128 B instead of 8 KiB of bf16 weights.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gemm_mxfp4_stream_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  char* lds = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  f32x16 acc[MT][NT];
+  TileCtx tc[MT][NT];
+  static_for<MT * NT>([&](auto idx) {
+    constexpr int mt = idx.value / NT, nt = idx.value % NT;
+    tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h; tc[mt][nt].ivalid = true;
+    tile_init<true, false>(acc[mt][nt], p, q, tc[mt][nt]);
+  });
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  unsigned int offB[NT * 2];
+#pragma unroll
+  for (int x = 0; x < NT * 2; ++x) {
+    const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
+    offB[x] = (f * ldb) * 2u + pc * 16u;
+  }
+  const unsigned int offA = (8u * h) * lda + (unsigned int)li;              // byte (k-pair 8h, row li); + (4s + e) * lda -- k = 16h + 8s + 2e, as B's pieces
+  const int kchunks = p.k >> 5;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    gcptr bu = br + 2ull * (unsigned long long)job.j0 * ldb;
+    gcptr au = ar + (unsigned long long)job.i0;
+    gcptr su = mx_scale_base(p, job.bidx, r) + (unsigned long long)job.i0 + (unsigned int)li;
+    for (int kc = 0; kc < kchunks; ++kc) {
+#pragma unroll
+      for (int x = 0; x < NT * 2; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(bu + 64ull * kc + offB[x]), (lds_vptr)(lds + 1024 * x), 16, 0, 0);
+      unsigned int raw[MT][2][4], sc[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) sc[mt] = *(GM const unsigned char*)(su + (unsigned long long)kc * lda + 32ull * mt);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            raw[mt][s][e] = *(GM const unsigned char*)(au + (unsigned long long)(16 * kc + 4 * s + e) * lda + 32ull * mt + offA);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      u32x4 af[MT][2];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float scale = __uint_as_float(sc[mt] << 23);                    // the instruction reads only the exponent field: byte 0 acts as 2^-127
+                                                                              // (reference: 0.0f) -- at most 6 * 2^-127 per weight, far below f32 resolution
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            af[mt][s][e] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(raw[mt][s][e], scale, 0));
+      }
+      u32x4 bfr[NT][2];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int f = 32 * nt + li;
+          bfr[nt][s] = *(const u32x4*)(lds + f * 64 + (((2 * h + s) ^ ((f >> 1) & 3)) * 16));
+        }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<true, false>(acc[mt][nt], p, q, tc[mt][nt]); });
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side selection
 // ------------------------------------------------------------------------------------------------
 bool gemm_supported(const libxsmm_gemm_descriptor& d) {
@@ -1167,6 +1288,17 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d) {
     if (tb8 ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
     return d.ldc >= d.m;
   }
+  if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {   // MXFP4 weights x bf16/f32 activations [ref: gemm ref :457-465, :949-1008; names libxsmm_main.c:1829-1848]
+    const unsigned int flx = d.flags;
+    const bool okt = (d.b_type == LIBXSMM_DATATYPE_BF16 && (d.c_type == LIBXSMM_DATATYPE_BF16 || d.c_type == LIBXSMM_DATATYPE_F32)) ||
+                     (d.b_type == LIBXSMM_DATATYPE_F32 && d.c_type == LIBXSMM_DATATYPE_F32);
+    if (!okt || d.comp_type != LIBXSMM_DATATYPE_F32) return false;
+    if (!(flx & LIBXSMM_GEMM_FLAG_VNNI_A) || (flx & (LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT | LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B |
+        LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C))) return false;
+    if ((d.k % 32) != 0 || (d.lda & 1)) return false;                       // one scale per 32-deep k-block; k*lda/2 bytes per block
+    if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    return d.lda >= d.m && d.ldb >= d.k && d.ldc >= d.m;
+  }
   if (!(f32 || f64 || bf16)) return false;
   if (f32 && d.comp_type != LIBXSMM_DATATYPE_F32) return false;
   if (f64 && d.comp_type != LIBXSMM_DATATYPE_F64) return false;
@@ -1190,15 +1322,21 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d) {
   return true;
 }
 
-enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2 };
+enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2, P_MX4_1x1, P_MX4_2x2 };
 struct GemmPlan { GemmPath path; bool exact; };
 
-static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, int c_type, int vnni_c) {
+static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, int b_type, int c_type, int vnni_c) {
   GemmPlan pl{P_GENERIC, false};
   const bool ta = flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = flags & LIBXSMM_GEMM_FLAG_TRANS_B;
   const bool va = flags & LIBXSMM_GEMM_FLAG_VNNI_A, vb = flags & LIBXSMM_GEMM_FLAG_VNNI_B;
   (void)c_type;
   if (vnni_c || k <= 0) return pl;
+  if (a_type == LIBXSMM_DATATYPE_MXFP4X2) {
+    if (b_type != LIBXSMM_DATATYPE_BF16 || (m % 32) || (n % 32) || (k % 32)) return pl;
+    pl.exact = true;
+    pl.path = ((m % 64) == 0 && (n % 64) == 0) ? P_MX4_2x2 : P_MX4_1x1;
+    return pl;
+  }
   if (a_type == LIBXSMM_DATATYPE_F32) {
     const bool ex32 = (m % 32 == 0) && (n % 32 == 0) && (k % 32 == 0);
     if (!ex32 && !ta && !tb && (m % 16 == 0) && (n % 16 == 0) && (k % 16 == 0) && m <= 48 && n <= 48) { pl.path = P_F32_T16; pl.exact = true; return pl; }
@@ -1245,12 +1383,14 @@ static const char* path_name(GemmPath p) {
     case P_FP8_2x2: return "gemm_fp8_stream_kernel<2,2>";
     case P_I8_1x1: return "gemm_i8_stream_kernel<1,1>";
     case P_I8_2x2: return "gemm_i8_stream_kernel<2,2>";
+    case P_MX4_1x1: return "gemm_mxfp4_stream_kernel<1,1>";
+    case P_MX4_2x2: return "gemm_mxfp4_stream_kernel<2,2>";
     default: return "gemm_generic_kernel";
   }
 }
 
 const char* gemm_kernel_name(const libxsmm_gemm_descriptor& d, bool) {
-  return path_name(plan_gemm((int)d.m, (int)d.n, (int)d.k, d.flags, d.a_type, d.c_type, (d.flags & LIBXSMM_GEMM_FLAG_VNNI_C) != 0).path);
+  return path_name(plan_gemm((int)d.m, (int)d.n, (int)d.k, d.flags, d.a_type, d.b_type, d.c_type, (d.flags & LIBXSMM_GEMM_FLAG_VNNI_C) != 0).path);
 }
 
 template <int MT, int NT, int MODE>
@@ -1303,7 +1443,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   const GemmArgs& a0 = a_in;
   hipStream_t st = (hipStream_t)stream;
   if (a0.nbatch == 0 || a0.m <= 0 || a0.n <= 0) { if (kernel_name) *kernel_name = "(empty)"; return 0; }
-  const GemmPlan pl = plan_gemm(a0.m, a0.n, a0.k, a0.flags, a0.a_type, a0.c_type, a0.vnni_c);
+  const GemmPlan pl = plan_gemm(a0.m, a0.n, a0.k, a0.flags, a0.a_type, a0.b_type, a0.c_type, a0.vnni_c);
   if ((long long)((a0.m + 15) / 16) * ((a0.n + 15) / 16) * (long long)a0.nbatch >= (1ll << 31)) return (int)hipErrorInvalidValue;
   if (kernel_name) *kernel_name = path_name(pl.path);
   GemmArgs a = a_in;
@@ -1364,6 +1504,20 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
       break;
+    case P_MX4_1x1: case P_MX4_2x2: {
+      // B columns 16-byte aligned (LDS-DMA); A and the scales are read byte-wise (any alignment); offsets inside a tile < 4 GiB
+      const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)((long long)a.ldb * 2);
+      const bool ok = !a.list_a && a.br_mode != 1 && a.br_mode != 2 && (bits & 15ull) == 0 && (long long)a.lda * a.k < (1ll << 31) && (long long)a.ldb * a.n * 2 < (1ll << 31);
+      if (ok) {
+        if (pl.path == P_MX4_2x2) { grid = wave_grid(64, 64); hipLaunchKernelGGL((gemm_mxfp4_stream_kernel<2, 2>), grid, dim3(256), 0, st, a); }
+        else { grid = wave_grid(32, 32); hipLaunchKernelGGL((gemm_mxfp4_stream_kernel<1, 1>), grid, dim3(256), 0, st, a); }
+        break;
+      }
+      if (kernel_name) *kernel_name = "gemm_generic_kernel";
+      const long long gblocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
+      hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)gblocks), dim3(64, 4), 0, st, a);
+      break;
+    }
     case P_FP8_1x1: case P_FP8_2x2: {
       const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)a.ldb;
       const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0);

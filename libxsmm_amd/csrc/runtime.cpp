@@ -270,6 +270,20 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     if (!p->c.tertiary) { set_error(-2, "8-bit GEMM with f32 output needs the scale in c.tertiary"); return; }   // [ref: gemm ref :591-592]
     a.scf = *(const float*)p->c.tertiary;
   }
+  if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {
+    // E8M0 scales of the MXFP4 weights travel in a.tertiary (a list of per-block pointers in ADDRESS mode) [ref: gemm ref :565-569].
+    // A batched launch steps them like A: the pointer list by sa, the scale bytes by sa * 2 / 32 (one byte per 32 weights).
+    if (!p->a.tertiary) { set_error(-2, "MXFP4 GEMM needs the E8M0 scales in a.tertiary"); return; }
+    if (b.la) { set_error(-3, "MXFP4 GEMM: pointer-list batches carry no scale list; use the strided batch"); return; }
+    if (a.br_mode == 1) {
+      const size_t span = (size_t)a.br_count * sizeof(void*) + (size_t)(b.count - 1) * (size_t)std::max<long long>(b.s[0], 0);
+      a.a_scf = (const char*)device_visible(p->a.tertiary, span); a.bs_scf = b.s[0];
+      if (!a.a_scf) return;
+    } else {
+      if (b.count > 1 && (b.s[0] % 16) != 0) { set_error(-3, "MXFP4 GEMM: the batch stride of A must cover whole 32-weight scale blocks (multiple of 16 bytes)"); return; }
+      a.a_scf = (const char*)p->a.tertiary; a.bs_scf = b.s[0] / 16;
+    }
+  }
   if (ext) {
     // fused epilogue decoded as the reference does [ref: gemm ref :404-428]
     if (d.bin_type == LIBXSMM_MELTW_TYPE_BINARY_ADD &&

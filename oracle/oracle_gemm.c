@@ -219,6 +219,55 @@ static void contract_int8(const gemm_view* v, const libxsmm_gemm_param* p, void*
   }
 }
 
+/* MXFP4 weights: A = packed E2M1 pairs [k/2][lda] bytes (low nibble = even k) with one E8M0 scale per (32-deep k-block, row)
+ * in a.tertiary ([k/32][lda] bytes; per batch-reduce element: pointer array / offset*2/32 / stride*2/32); B bf16 or f32 flat;
+ * C f32 or bf16; C = (beta ? C : 0) + sum, one RNE for bf16 C [ref: :949-1008, scale :200-222, LUT :60-64, slots :565-569].
+ * A scale byte of 0 decodes to 0.0f (bits << 23), not 2^-127, exactly like the reference. */
+static float mxfp4_value(unsigned char x) {
+  static const float lut[16] = {0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f, -0.0f, -0.5f, -1.0f, -1.5f, -2.0f, -3.0f, -4.0f, -6.0f};
+  return lut[x & 15];
+}
+static float mxfp4_scale(const gemm_view* v, const libxsmm_gemm_param* p, long long r, long long s, long long i) {
+  const oracle_gemm_desc* d = v->d;
+  const unsigned char* base = (const unsigned char*)p->a.tertiary;
+  union { unsigned int u; float f; } cv;
+  if (d->flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS) base = ((const unsigned char* const*)p->a.tertiary)[r];
+  else if (d->flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET) base += (v->offs_a[r] * 2) / 32;
+  else if (d->flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_STRIDE) base += ((d->br_stride_a * 2) / 32) * r;
+  cv.u = ((unsigned int)base[s * d->lda + i]) << 23;
+  return cv.f;
+}
+static void contract_mxfp4(const gemm_view* v, const libxsmm_gemm_param* p, void* cptr, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const int b_bf16 = (d->b_type == LIBXSMM_DATATYPE_BF16), c_f32 = (d->c_type == LIBXSMM_DATATYPE_F32);
+  long long i, j, r, s, k2;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    float acc = 0.0f;
+    for (r = 0; r < v->br; ++r) {
+      const br_cursor cur = br_at(v, r);
+      for (s = 0; s < d->k / 32; ++s) {
+        const float scf = mxfp4_scale(v, p, r, s, i);
+        for (k2 = 0; k2 < 32; k2 += 2) {
+          const unsigned char pk = ((const unsigned char*)cur.a)[(s * 32 + k2) * (long long)d->lda / 2 + i];
+          const float ev = mxfp4_value(pk & 15) * scf, od = mxfp4_value(pk >> 4) * scf;
+          const long long bi = j * (long long)d->ldb + s * 32 + k2;
+          const float b0 = b_bf16 ? oracle_bf16_to_f32(((const unsigned short*)cur.b)[bi]) : ((const float*)cur.b)[bi];
+          const float b1 = b_bf16 ? oracle_bf16_to_f32(((const unsigned short*)cur.b)[bi + 1]) : ((const float*)cur.b)[bi + 1];
+          float prod = ev * b0; acc = acc + prod;
+          prod = od * b1; acc = acc + prod;
+        }
+      }
+    }
+    if (c_f32) { float* c = (float*)cptr + j * d->ldc + i; float base = beta0 ? 0.0f : *c; *c = base + acc; }
+    else {
+      unsigned short* c = (unsigned short*)cptr + j * d->ldc + i;
+      float base = beta0 ? 0.0f : oracle_bf16_to_f32(*c);
+      base = base + acc;
+      *c = oracle_f32_to_bf16_rne(base);
+    }
+  }
+}
+
 void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   gemm_view v;
   const int is_ext = (d->flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) ? 1 : 0;
@@ -234,6 +283,7 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
   if (is_int8(d->a_type) && is_int8(d->b_type)) { contract_int8(&v, p, cptr, beta0); return; }
   if (is_fp8(d->a_type) && d->b_type == d->a_type && d->c_type == LIBXSMM_DATATYPE_F32) { contract_fp8(&v, (float*)cptr, beta0); return; }
+  if (d->a_type == LIBXSMM_DATATYPE_MXFP4X2) { contract_mxfp4(&v, p, cptr, beta0); return; }
 
   {
     /* f32 working image: C itself for f32 output, otherwise a scratch of ldc x n floats [:262-272] */

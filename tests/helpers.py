@@ -52,6 +52,8 @@ def rand_values(rng: np.random.Generator, count: int, dt: int) -> np.ndarray:
         return rng.integers(-9, 10, count).astype(NP_OF[dt])
     if dt in (DT.U8, DT.U16, DT.U32):
         return rng.integers(0, 19, count).astype(NP_OF[dt])
+    if dt == DT.MXFP4X2:                    # two E2M1 codes per byte, all 256 combinations
+        return rng.integers(0, 256, count).astype(np.uint8)
     if dt in (DT.BF8, DT.HF8):              # finite 8-bit floats in [1/8, 2) with random sign, plus a few zeros: the magnitude range of the
         bias, mbits = (15, 2) if dt == DT.BF8 else (7, 3)     # reference driver's data (multiples of 0.1 in [-0.5, 0.5]); FP8_WIDE widens it
         lo = max(-14 if FP8_WIDE else -3, -bias)           # exponent field 0 = subnormals / zero
@@ -102,9 +104,14 @@ class GemmCase:
         self.colbias, self.act = colbias, act
         self.ext = colbias or act != 0
         self.a_elems = self.lda * (m if ta else k)
+        self.mx = a_type == DT.MXFP4X2          # packed E2M1 pairs: lda bytes per k-pair, one E8M0 scale per (32 k, row)
+        if self.mx:
+            assert k % 32 == 0 and not ta
+            self.a_elems = self.lda * k // 2
+            self.s_elems = self.lda * (k // 32)
         self.b_elems = self.ldb * (k if tb else n)
         self.c_elems = self.ldc * (n + (n % 2 if flags & GEMM_FLAG.VNNI_C else 0))
-        asz, csz = capi.DT_SIZE[a_type], capi.DT_SIZE[self.c_type]
+        asz, csz, bsz = capi.DT_SIZE[a_type], capi.DT_SIZE[self.c_type], capi.DT_SIZE[self.b_type]
         nbr = br_count if br_type != capi.BR_NONE else 1
         self.nbr = nbr
         # every batch element owns nbr A blocks and nbr B blocks (B optionally shared across the batch)
@@ -115,11 +122,15 @@ class GemmCase:
         self.mask_ld = ((self.ldc + 15) // 16) * 16
         self.mask_bytes = (self.mask_ld // 8) * n
         self.bs_a = nbr * self.a_elems * asz
-        self.bs_b = 0 if shared_b else nbr * self.b_elems * asz
+        self.bs_b = 0 if shared_b else nbr * self.b_elems * bsz
         self.bs_c = self.c_elems * csz
         self.bs_d = m * csz if colbias else 0
         self.br_stride_a = self.a_elems * asz
-        self.br_stride_b = self.b_elems * asz
+        if self.mx:                             # scales in a narrow band around 1.0 with a few exact zeros (scale byte 0 decodes to 0.0f)
+            self.S = rng.integers(124, 131, batch * nbr * self.s_elems).astype(np.uint8)
+            self.S[rng.random(self.S.size) < 0.02] = 0
+            self.bs_s = nbr * self.s_elems
+        self.br_stride_b = self.b_elems * bsz
         # OFFSET mode: a permutation of the nbr blocks (byte offsets), shared by the batch
         perm = rng.permutation(nbr)
         self.offs_a = (perm * self.br_stride_a).astype(np.int64)
@@ -152,14 +163,20 @@ class GemmCase:
                                  self.comp_type, f, self.br_stride_a, self.br_stride_b, int(self.colbias), self.act)
 
     # ---- param construction over arbitrary buffers ----------------------------------------------
-    def make_param(self, A, B, Cbuf, D=None, mask=None, offs=None, addr=None, brc=None, batch_index=0):
+    def make_param(self, A, B, Cbuf, D=None, mask=None, offs=None, addr=None, brc=None, batch_index=0, S=None):
         """A, B, Cbuf, D, mask: numpy arrays or torch tensors; returns (param, keepalive)."""
         p = capi.GemmExtParam() if self.ext else capi.GemmParam()
         keep = []
+        if self.mx:                             # a.tertiary: the scales, or (ADDRESS mode) a list of per-block scale pointers
+            sc = self.S if S is None else S
+            if self.br_type == capi.BR_ADDRESS:
+                p.a.tertiary = ptr(addr[2]) + batch_index * self.nbr * 8
+            else:
+                p.a.tertiary = ptr(sc) + batch_index * self.bs_s
         pa = ptr(A) + batch_index * self.bs_a
         pb = ptr(B) + batch_index * self.bs_b
         if self.br_type == capi.BR_ADDRESS:
-            la, lb = addr
+            la, lb = addr[0], addr[1]
             p.a.primary = ptr(la) + batch_index * self.nbr * 8
             p.b.primary = ptr(lb) + batch_index * self.nbr * 8
         else:
@@ -181,15 +198,18 @@ class GemmCase:
                 p.c.secondary = ptr(mask) + batch_index * self.mask_bytes
         return p, keep
 
-    def host_address_lists(self, A: np.ndarray, B: np.ndarray):
+    def host_address_lists(self, A: np.ndarray, B: np.ndarray, S=None):
         """Pointer lists for ADDRESS mode over host (or device, given base addresses) buffers."""
         la = np.zeros(self.batch * self.nbr, dtype=np.uint64)
         lb = np.zeros(self.batch * self.nbr, dtype=np.uint64)
+        ls = np.zeros(self.batch * self.nbr, dtype=np.uint64)
         for b in range(self.batch):
             for r in range(self.nbr):
                 la[b * self.nbr + r] = ptr(A) + b * self.bs_a + r * self.br_stride_a
                 lb[b * self.nbr + r] = ptr(B) + b * self.bs_b + (self.nbr - 1 - r) * self.br_stride_b
-        return la, lb
+                if self.mx:
+                    ls[b * self.nbr + r] = ptr(self.S if S is None else S) + b * self.bs_s + r * self.s_elems
+        return (la, lb, ls) if self.mx else (la, lb)
 
     # ---- executors ---------------------------------------------------------------------------------
     def run_oracle(self, fma=False):
@@ -244,16 +264,17 @@ class GemmCase:
         def up(x):
             return None if x is None else torch.from_numpy(x.view(np.int16) if x.dtype == np.uint16 else x).to(dev)
         A, B, Cbuf, D = up(self.A), up(self.B), up(self.C0.copy()), up(self.D)
+        S = up(self.S) if self.mx else None
         mask = torch.zeros(self.batch * self.mask_bytes, dtype=torch.uint8, device=dev) if self.act == 2 else None
         offs = (up(self.offs_a), up(self.offs_b))
         addr = None
         if self.br_type == capi.BR_ADDRESS:
-            la, lb = self.host_address_lists(A, B)
-            addr = (up(la.view(np.int64)), up(lb.view(np.int64)))
+            lists = self.host_address_lists(A, B, S)
+            addr = tuple(up(x.view(np.int64)) for x in lists)
         handle = self.dispatch(api)
         assert handle, "dispatch returned NULL"
         if batched and self.batch > 1:
-            p, keep = self.make_param(A, B, Cbuf, D, mask, offs, addr)
+            p, keep = self.make_param(A, B, Cbuf, D, mask, offs, addr, S=S)
             sa = self.nbr * 8 if self.br_type == capi.BR_ADDRESS else self.bs_a
             sb = (self.nbr * 8 if self.br_type == capi.BR_ADDRESS else self.bs_b)
             if self.ext:
@@ -262,7 +283,7 @@ class GemmCase:
                 api.hip_gemm_batch_strided(handle, C.byref(p), self.batch, sa, sb, self.bs_c)
         else:
             for b in range(self.batch):
-                p, keep = self.make_param(A, B, Cbuf, D, mask, offs, addr, batch_index=b)
+                p, keep = self.make_param(A, B, Cbuf, D, mask, offs, addr, batch_index=b, S=S)
                 capi.Api.call(handle, p)
         api.hip_sync()
         api.check()

@@ -365,3 +365,50 @@ def test_fp8_mfma_with_wide_exponent_range_data():
             assert np.array_equal(case.valid_region(ref), case.valid_region(got))
     finally:
         helpers.FP8_WIDE = False
+
+
+# MXFP4 weights (packed E2M1 pairs, one E8M0 scale per 32-deep k-block and row) x bf16 / f32 activations
+SHAPES_MXFP4 = [
+    dict(m=64, n=64, k=64, b_type=DT.BF16, c_type=DT.BF16, batch=5),                                                  # the weight-only-quantised hot case
+    dict(m=64, n=64, k=128, b_type=DT.BF16, c_type=DT.F32, beta=1, batch=3),
+    dict(m=32, n=96, k=64, b_type=DT.BF16, c_type=DT.F32, br_type=capi.BR_STRIDE, br_count=3, batch=4),
+    dict(m=96, n=32, k=32, b_type=DT.BF16, c_type=DT.BF16, br_type=capi.BR_STRIDE, br_count=2, beta=1, batch=2, lda=100, ldc=98),
+    dict(m=32, n=32, k=64, b_type=DT.BF16, c_type=DT.F32, br_type=capi.BR_OFFSET, br_count=4, batch=2),              # device-side lists: generic kernel
+    dict(m=32, n=32, k=32, b_type=DT.BF16, c_type=DT.BF16, br_type=capi.BR_ADDRESS, br_count=3, batch=3, beta=1),
+    dict(m=17, n=9, k=64, b_type=DT.F32, c_type=DT.F32, lda=20, ldc=24, beta=1, batch=2),
+    dict(m=33, n=5, k=32, b_type=DT.BF16, c_type=DT.BF16, lda=34),
+    dict(m=64, n=64, k=64, b_type=DT.F32, c_type=DT.F32, batch=2),
+]
+
+
+@pytest.mark.parametrize("kw", SHAPES_MXFP4, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+@pytest.mark.parametrize("batched", [True, False], ids=["batched", "loop"])
+def test_mxfp4_gemm_matches_oracle(kw, batched):
+    api = capi.load()
+    case = GemmCase(seed=41, a_type=DT.MXFP4X2, flags=F.VNNI_A, **kw)
+    got, _, handle = case.run_gpu(batched=batched)
+    ref, _ = case.run_oracle()
+    name = api.hip_kernel_name(handle, 1 if (case.batch > 1 and batched) else 0).decode()
+    fast = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["b_type"] == DT.BF16 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
+    assert ("gemm_mxfp4_stream_kernel" in name) == bool(fast), name
+    if fast:      # value * scale and the bf16 products are exact; only the f32 summation order differs from the serial chain
+        tol = TOL_BF16 if case.c_type == DT.BF16 else TOL_F32
+        assert normf_rel(case.valid_region(ref), case.valid_region(got), case.c_type) < tol, name
+    else:         # the generic kernel follows the reference's operation order: bit-identical
+        assert np.array_equal(case.valid_region(ref), case.valid_region(got)), name
+
+
+def test_mxfp4_dispatch_rules():
+    api = capi.load()
+    sh = lambda b, c, k=64, lda=32: capi.gemm_shape(32, 32, k, lda, k, 32, DT.MXFP4X2, b, c, DT.F32)   # noqa: E731
+    assert api.dispatch_gemm(sh(DT.BF16, DT.BF16), F.VNNI_A, 0)
+    assert api.dispatch_gemm(sh(DT.BF16, DT.F32), 0, 0) is None                  # the packed pair layout IS the VNNI_A format
+    assert api.dispatch_gemm(sh(DT.BF16, DT.F32, k=48), F.VNNI_A, 0) is None     # whole 32-deep scale blocks only
+    assert api.dispatch_gemm(sh(DT.F32, DT.BF16), F.VNNI_A, 0) is None           # [ref: libxsmm_main.c:1829-1848] f32 B -> f32 C
+    assert api.dispatch_gemm(sh(DT.BF16, DT.F32), F.VNNI_A | F.TRANS_B, 0) is None
+    h = api.dispatch_gemm(sh(DT.BF16, DT.F32), F.VNNI_A, 0)
+    p = capi.GemmParam()
+    p.a.primary = p.b.primary = p.c.primary = 16                                  # never dereferenced: the missing scales are caught first
+    capi.Api.call(h, p)
+    assert api.hip_get_last_error() != 0 and b"a.tertiary" in api.hip_get_last_error_string()
+    api.hip_clear_last_error()

@@ -50,6 +50,13 @@ GEMM_CASES = [
     dict(m=12, n=10, k=7, a_type=DT.BF8, c_type=DT.F32),
     dict(m=32, n=32, k=64, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1),
     dict(m=13, n=11, k=8, a_type=DT.HF8, c_type=DT.F32, flags=F.TRANS_B),
+    # MXFP4 weights (packed E2M1 pairs + E8M0 scale per 32-deep k-block and row) times bf16 / f32 activations
+    dict(m=32, n=32, k=64, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A),
+    dict(m=32, n=16, k=32, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, beta=1),
+    dict(m=17, n=9, k=64, a_type=DT.MXFP4X2, b_type=DT.F32, c_type=DT.F32, flags=F.VNNI_A, lda=20, ldc=24, beta=1),
+    dict(m=32, n=32, k=32, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=16, n=8, k=64, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=4),
+    dict(m=16, n=8, k=32, a_type=DT.MXFP4X2, b_type=DT.F32, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_ADDRESS, br_count=2),
 ]
 
 
@@ -63,7 +70,7 @@ def test_gemm_restatement_is_bit_identical_to_reference_c_kernel(kw, reference):
         assert np.array_equal(case.valid_mask_bits(m_or), case.valid_mask_bits(m_rf))
 
 
-@pytest.mark.parametrize("kw", [c for c in GEMM_CASES if not (c.get("a_type") == DT.BF16 and not (c.get("flags", 0) & F.VNNI_A))][:16],
+@pytest.mark.parametrize("kw", [c for c in GEMM_CASES if not (c.get("a_type") == DT.BF16 and not (c.get("flags", 0) & F.VNNI_A))][:16] + GEMM_CASES[-6:],
                          ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_gemm_restatement_within_reference_tolerance_of_its_cpu_jit(kw, reference):
     case = GemmCase(seed=7, **kw)

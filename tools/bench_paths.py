@@ -2,7 +2,7 @@
 """Roofline measurements for every hot-path row of SURVEY.md section 8 other than the headline config
 (which bench.py owns).  One JSON line per workload; same timing method as bench.py (hipGraph of K launches,
 HIP events on the launch stream, inputs rotated so that every launch streams from HBM).
-Usage: python tools/bench_paths.py [--only csr,fsspmdm,bcsc,fused,meltw,gemm] [--steps K]"""
+Usage: python tools/bench_paths.py [--only gemm,mx,csr,fsspmdm,bcsc,fused,meltw,packed] [--steps K]"""
 import argparse
 import ctypes as C
 import json
@@ -184,6 +184,30 @@ def brgemm_i8(api, m, batch, ua=True):
     w = Work(api, f"stride-BRGEMM {'u8' if ua else 'i8'} x i8 -> i32 m=n=k={m} batch={batch} br=1 beta=0", 2.0 * m ** 3 * batch, float(batch * 6 * m * m), ns,
              lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, m * m, m * m, 4 * m * m), lambda: api.hip_kernel_name(h, 1).decode())
     w.keep = (As, Bs, Cs, ps, brc)
+    return w
+
+
+def brgemm_mxfp4(api, m, batch, c_dt=DT.BF16):
+    """MXFP4 weights (packed E2M1 pairs + E8M0 scale per 32-deep k-block and row) x bf16 activations, m = n = k, every problem
+    with its own weights: algorithmic bytes = m*m/2 + m*m/32 (A, scales) + 2*m*m (B) + s_C*m*m (C) per problem."""
+    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, DT.MXFP4X2, DT.BF16, c_dt, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0,
+                            capi.br_config(capi.BR_STRIDE, m * m // 2, 2 * m * m, 0))
+    assert h
+    cs = 2 if c_dt == DT.BF16 else 4
+    per = m * m // 2 + m * m // 32 + (2 + cs) * m * m
+    ns = nsets_for(batch * per)
+    As = [torch.randint(0, 256, (batch * m * m // 2,), device=DEV, dtype=torch.uint8) for _ in range(ns)]
+    Ss = [torch.randint(124, 131, (batch * m * m // 32,), device=DEV, dtype=torch.uint8) for _ in range(ns)]
+    Bs = [rnd(batch * m * m, "bf16") for _ in range(ns)]
+    Cs = [torch.zeros(batch * m * m * cs // 2, device=DEV, dtype=torch.int16) for _ in range(ns)]
+    brc = C.c_ulonglong(1)
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc)
+        p.a.tertiary = Ss[s].data_ptr(); ps.append(p)
+    w = Work(api, f"stride-BRGEMM mxfp4 x bf16 -> {'bf16' if cs == 2 else 'f32'} m=n=k={m} batch={batch} br=1 beta=0", 2.0 * m ** 3 * batch, float(batch * per), ns,
+             lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, m * m // 2, 2 * m * m, cs * m * m), lambda: api.hip_kernel_name(h, 1).decode())
+    w.keep = (As, Ss, Bs, Cs, ps, brc)
     return w
 
 
@@ -388,7 +412,7 @@ def measure(w, steps, eager=0):
 def main():
     global DEV
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="gemm,csr,fsspmdm,bcsc,fused,meltw,packed")
+    ap.add_argument("--only", default="gemm,mx,csr,fsspmdm,bcsc,fused,meltw,packed")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--eager", type=int, default=0, help="profiling mode: this many plain launches per workload, no timing")
     ap.add_argument("--cpu", action="store_true", help="with --headline: time the reference's CPU kernel (oracle/_ref, 1 core) beside each GPU measurement")
@@ -418,6 +442,8 @@ def main():
                    lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8),
                    lambda: brgemm(api, 32, "f32", 1, br=4096), lambda: brgemm(api, 64, "bf16", 1, br=4096),
                    lambda: brgemm_i8(api, 64, 2 ** 17, ua=True), lambda: brgemm_i8(api, 64, 2 ** 17, ua=False)]     # config #2 variant B: one long chain
+    if "mx" in only:
+        makers += [lambda: brgemm_mxfp4(api, 64, 2 ** 17), lambda: brgemm_mxfp4(api, 32, 2 ** 18, c_dt=DT.F32)]
     if "fused" in only:
         makers += [lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
     if "csr" in only:
