@@ -102,6 +102,11 @@ __device__ __forceinline__ void br_base(const GemmArgs& p, const BatchPtrs& q, u
   else { a = q.a; b = q.b; }
 }
 
+// raw buffer resource over a wave-uniform base (gfx9 word 3: 32-bit raw data format); offsets are checked against 4 GiB only
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(gcptr base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(size_t)uniform_u64((unsigned long long)(size_t)base), (short)0, -1, 0x00020000);
+}
+
 // MXFP4 A: base of the E8M0 scales of batch-reduce element r [ref: gemm ref :200-222] -- one byte per (32-deep k-block, row):
 // pointer list / byte offset of A * 2 / 32 / byte stride of A * 2 / 32
 __device__ __forceinline__ gcptr mx_scale_base(const GemmArgs& p, unsigned int bidx, unsigned long long r) {
@@ -169,6 +174,11 @@ __device__ __forceinline__ float load_as_f32(gcptr base, long long idx, int type
   if (type == LIBXSMM_DATATYPE_BF8) return bf8_to_f32(((GM const unsigned char*)base)[idx]);
   if (type == LIBXSMM_DATATYPE_HF8) return hf8_to_f32(((GM const unsigned char*)base)[idx]);
   return bf16_to_f32(((GM const unsigned short*)base)[idx]);
+}
+
+// C and bias operands are f32 or bf16 only (keeps the 8-bit decoders out of every tile prologue)
+__device__ __forceinline__ float load_c_f32(gcptr base, long long idx, int type) {
+  return (type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)base)[idx] : bf16_to_f32(((GM const unsigned short*)base)[idx]);
 }
 
 // block = (64, 4): x walks i (so a wave is 64 consecutive rows of one column, which makes the
@@ -242,13 +252,13 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
         for (int k2 = 0; k2 < 32; k2 += 2) {
           const unsigned int pk = ((GM const unsigned char*)ar)[(long long)(s * 32 + k2) * p.lda / 2 + i];
           const long long bi = (long long)j * p.ldb + s * 32 + k2;
-          acc = add_rn(acc, mul_rn(mul_rn(e2m1_to_f32(pk & 15u), scf), load_as_f32(br, bi, p.b_type)));
-          acc = add_rn(acc, mul_rn(mul_rn(e2m1_to_f32(pk >> 4), scf), load_as_f32(br, bi + 1, p.b_type)));
+          acc = add_rn(acc, mul_rn(mul_rn(e2m1_to_f32(pk & 15u), scf), load_c_f32(br, bi, p.b_type)));
+          acc = add_rn(acc, mul_rn(mul_rn(e2m1_to_f32(pk >> 4), scf), load_c_f32(br, bi + 1, p.b_type)));
         }
       }
     }
     const long long ci = (long long)j * p.ldc + i;
-    const float base = beta0 ? 0.0f : load_as_f32(q.c, ci, p.c_type);
+    const float base = beta0 ? 0.0f : load_c_f32(q.c, ci, p.c_type);
     const float y = add_rn(base, acc);
     if (p.c_type == LIBXSMM_DATATYPE_F32) ((GM float*)q.c)[ci] = y; else ((GM unsigned short*)q.c)[ci] = f32_to_bf16_rne(y);
     return;
@@ -258,9 +268,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
   if (valid) {
     const bool fp8 = (p.a_type == LIBXSMM_DATATYPE_BF8 || p.a_type == LIBXSMM_DATATYPE_HF8);
     const int kb = fp8 ? (va ? 4 : 1) : ((p.a_type == LIBXSMM_DATATYPE_BF16 && va) ? 2 : 1);
-    if (!beta0) acc = load_as_f32(q.c, (long long)j * p.ldc + i, p.c_type);
+    if (!beta0) acc = load_c_f32(q.c, (long long)j * p.ldc + i, p.c_type);
     if (p.colbias) {
-      const float bias = load_as_f32(q.d, i, p.c_type);
+      const float bias = load_c_f32(q.d, i, p.c_type);
       acc = beta0 ? bias : add_rn(bias, acc);
     }
     for (unsigned long long r = 0; r < p.br_count; ++r) {
@@ -311,8 +321,8 @@ __global__ __launch_bounds__(1024) void brsplit_reduce_kernel(GemmArgs p, const 
   const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
   float acc = 0.0f;
   if (valid) {
-    if (!beta0) acc = load_as_f32(q.c, (long long)j * p.ldc + i, p.c_type);
-    if (p.colbias) { const float bias = load_as_f32(q.d, i, p.c_type); acc = beta0 ? bias : add_rn(bias, acc); }
+    if (!beta0) acc = load_c_f32(q.c, (long long)j * p.ldc + i, p.c_type);
+    if (p.colbias) { const float bias = load_c_f32(q.d, i, p.c_type); acc = beta0 ? bias : add_rn(bias, acc); }
 #pragma unroll
     for (int y = 0; y < 16; ++y) acc = add_rn(acc, part[y][threadIdx.x]);
   }
@@ -422,12 +432,12 @@ __device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const 
     return;
   }
   float bias = 0.0f;
-  if (p.colbias && (EXACT || t.ivalid)) bias = load_as_f32(q.d, t.i, c_type);
+  if (p.colbias && (EXACT || t.ivalid)) bias = load_c_f32(q.d, t.i, c_type);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int j = t.j0 + jl_of(r, t.h);
     float start = 0.0f;
-    if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_as_f32(q.c, (long long)j * p.ldc + t.i, c_type);
+    if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_c_f32(q.c, (long long)j * p.ldc + t.i, c_type);
     acc[r] = p.colbias ? (beta0 ? bias : bias + start) : start;
   }
 }
@@ -982,16 +992,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
     const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
     offB[x] = (f * ldb) * 2u + pc * 16u;
   }
-  const unsigned int offA = ((8u * h) * lda + (unsigned int)li) * 4u;      // dword (k-pair 8h, row li); + e*lda*4 + s*4*lda*4
+  // buffer addressing (wave-uniform 4-SGPR resources, loop-invariant 32-bit lane offsets, scalar k-chunk offset): no 64-bit
+  // address VGPRs and no per-iteration address arithmetic
+  unsigned int voffA[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) voffA[s][e] = ((8u * h + 4u * s + e) * lda + (unsigned int)li) * 4u;     // dword (k-pair 8h + 4s + e, row li)
   const int kchunks = p.k >> 5;
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
-    gcptr bu = br + 2ull * (unsigned long long)job.j0 * ldb;                 // wave-uniform
-    gcptr au = ar + 4ull * (unsigned long long)job.i0;
+    const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + 2ull * (unsigned long long)job.j0 * ldb);
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)job.i0);
     for (int kc = 0; kc < kchunks; ++kc) {
 #pragma unroll
       for (int x = 0; x < NT * 2; ++x)
-        __builtin_amdgcn_global_load_lds((GM const void*)(bu + 64ull * kc + offB[x]), (lds_vptr)(lds + 1024 * x), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
       u32x4 af[MT][2];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -999,7 +1015,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            af[mt][s][e] = *(GM const unsigned int*)(au + (unsigned long long)(16 * kc + 4 * s + e) * lda * 4ull + 128ull * mt + offA);
+            af[mt][s][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)voffA[s][e] + 128 * mt, 64 * kc * (int)lda, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       u32x4 bfr[NT][2];
 #pragma unroll
@@ -1056,12 +1072,12 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
   const int kchunks = p.k >> 6;
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
-    gcptr bu = br + (unsigned long long)job.j0 * ldb;
-    gcptr au = ar + 4ull * (unsigned long long)job.i0;
+    const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + (unsigned long long)job.j0 * ldb);     // buffer addressing, see gemm_bf16_stream_kernel
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)job.i0);
     for (int kc = 0; kc < kchunks; ++kc) {
 #pragma unroll
       for (int x = 0; x < NT * 2; ++x)
-        __builtin_amdgcn_global_load_lds((GM const void*)(bu + 64ull * kc + offB[x]), (lds_vptr)(lds + 1024 * x), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
       i32x4 af[MT][2];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -1069,7 +1085,7 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int v = *(GM const int*)(au + (unsigned long long)(16 * kc + 8 * s + e) * lda * 4ull + 128ull * mt + offA);
+            const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (8u * s + e) * lda * 4u) + 128 * mt, 64 * kc * (int)lda, 0);
             af[mt][s][e] = UA ? (v ^ (int)0x80808080) : v;
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1141,19 +1157,19 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
   const int kchunks = p.k >> 6;
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
-    gcptr bu = br + (unsigned long long)job.j0 * ldb;
-    gcptr au = ar + 4ull * (unsigned long long)job.i0;
+    const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + (unsigned long long)job.j0 * ldb);     // buffer addressing, see gemm_bf16_stream_kernel
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)job.i0);
     for (int kc = 0; kc < kchunks; ++kc) {
 #pragma unroll
       for (int x = 0; x < NT * 2; ++x)
-        __builtin_amdgcn_global_load_lds((GM const void*)(bu + 64ull * kc + offB[x]), (lds_vptr)(lds + 1024 * x), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
       long af[MT][4];
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const unsigned int lo = *(GM const unsigned int*)(au + (unsigned long long)(16 * kc + 4 * s) * lda * 4ull + 128ull * mt + offA);
-          const unsigned int hi = *(GM const unsigned int*)(au + (unsigned long long)(16 * kc + 4 * s + 1) * lda * 4ull + 128ull * mt + offA);
+          const unsigned int lo = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (4u * s) * lda * 4u) + 128 * mt, 64 * kc * (int)lda, 0);
+          const unsigned int hi = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (4u * s + 1u) * lda * 4u) + 128 * mt, 64 * kc * (int)lda, 0);
           af[mt][s] = (long)(((unsigned long long)hi << 32) | lo);
         }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1206,27 +1222,33 @@ __global__ __launch_bounds__(256) void gemm_mxfp4_stream_kernel(GemmArgs p) {
     const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
     offB[x] = (f * ldb) * 2u + pc * 16u;
   }
-  const unsigned int offA = (8u * h) * lda + (unsigned int)li;              // byte (k-pair 8h, row li); + (4s + e) * lda -- k = 16h + 8s + 2e, as B's pieces
+  // Buffer addressing: every base is wave-uniform (a 4-SGPR resource per operand and batch-reduce element), lanes contribute
+  // loop-invariant 32-bit offsets and the k-chunk is a scalar offset -- no 64-bit address VGPRs, no per-iteration address math.
+  unsigned int voffA[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) voffA[s][e] = (8u * h + 4u * s + e) * lda + (unsigned int)li;   // k-pair row 8h + 4s + e: k = 16h + 8s + 2e, as B's pieces
   const int kchunks = p.k >> 5;
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
-    gcptr bu = br + 2ull * (unsigned long long)job.j0 * ldb;
-    gcptr au = ar + (unsigned long long)job.i0;
-    gcptr su = mx_scale_base(p, job.bidx, r) + (unsigned long long)job.i0 + (unsigned int)li;
+    const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + 2ull * (unsigned long long)job.j0 * ldb);
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + (unsigned long long)job.i0);
+    const __amdgpu_buffer_rsrc_t rs = wave_rsrc(mx_scale_base(p, job.bidx, r) + (unsigned long long)job.i0);
     for (int kc = 0; kc < kchunks; ++kc) {
 #pragma unroll
       for (int x = 0; x < NT * 2; ++x)
-        __builtin_amdgcn_global_load_lds((GM const void*)(bu + 64ull * kc + offB[x]), (lds_vptr)(lds + 1024 * x), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
       unsigned int raw[MT][2][4], sc[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) sc[mt] = *(GM const unsigned char*)(su + (unsigned long long)kc * lda + 32ull * mt);
+      for (int mt = 0; mt < MT; ++mt) sc[mt] = __builtin_amdgcn_raw_buffer_load_b8(rs, li + 32 * mt, kc * (int)lda, 0);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            raw[mt][s][e] = *(GM const unsigned char*)(au + (unsigned long long)(16 * kc + 4 * s + e) * lda + 32ull * mt + offA);
+            raw[mt][s][e] = __builtin_amdgcn_raw_buffer_load_b8(ra, (int)voffA[s][e] + 32 * mt, 16 * kc * (int)lda, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       u32x4 af[MT][2];
 #pragma unroll
