@@ -183,7 +183,7 @@ _DECL_RE = re.compile(r"LIBXSMM_API\s+[^;(]*?\b(libxsmm_\w+)\s*\(")
 
 def declared_symbols():
     names = []
-    for h in ("libxsmm.h", "libxsmm_hip.h"):
+    for h in ("libxsmm.h", "libxsmm_hip.h", "libxsmm_utils.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         names += _DECL_RE.findall(text)
     return sorted(set(names))

@@ -168,9 +168,9 @@ LIBXSMM_API libxsmm_bfloat16 libxsmm_convert_f32_to_bf16_rne(float in) {
   return (libxsmm_bfloat16)(u >> 16);
 }
 LIBXSMM_API libxsmm_bfloat16 libxsmm_convert_f32_to_bf16_truncate(float in) { bool sp; return (libxsmm_bfloat16)(bf16_front(f2u(in), &sp) >> 16); }
-LIBXSMM_API void libxsmm_rne_convert_fp32_bf16(const float* in, libxsmm_bfloat16* out, unsigned int n) { for (unsigned int i = 0; i < n; ++i) out[i] = libxsmm_convert_f32_to_bf16_rne(in[i]); }
-LIBXSMM_API void libxsmm_truncate_convert_f32_bf16(const float* in, libxsmm_bfloat16* out, unsigned int n) { for (unsigned int i = 0; i < n; ++i) out[i] = libxsmm_convert_f32_to_bf16_truncate(in[i]); }
-LIBXSMM_API void libxsmm_convert_bf16_f32(const libxsmm_bfloat16* in, float* out, unsigned int n) { for (unsigned int i = 0; i < n; ++i) out[i] = libxsmm_convert_bf16_to_f32(in[i]); }
+LIBXSMM_API void libxsmm_rne_convert_fp32_bf16(const float* in, libxsmm_bfloat16* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = libxsmm_convert_f32_to_bf16_rne(in[i]); }
+LIBXSMM_API void libxsmm_truncate_convert_f32_bf16(const float* in, libxsmm_bfloat16* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = libxsmm_convert_f32_to_bf16_truncate(in[i]); }
+LIBXSMM_API void libxsmm_convert_bf16_f32(const libxsmm_bfloat16* in, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = libxsmm_convert_bf16_to_f32(in[i]); }
 
 // ---- matdiff: the subset of statistics the drivers read [ref: src/libxsmm_matdiff.h; libxsmm_math.c:35-300] ----
 LIBXSMM_API void libxsmm_matdiff_clear(libxsmm_matdiff_info* info) {

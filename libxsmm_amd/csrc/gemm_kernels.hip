@@ -968,11 +968,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
+  __shared__ __attribute__((aligned(16))) char lds_all[4][2][NT * 2048];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-  char* lds = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  char* lds = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0];
   const BatchPtrs q = batch_ptrs(p, job.bidx);
   f32x16 acc[MT][NT];
   TileCtx tc[MT][NT];
@@ -1000,40 +1000,54 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) voffA[s][e] = ((8u * h + 4u * s + e) * lda + (unsigned int)li) * 4u;     // dword (k-pair 8h + 4s + e, row li)
   const int kchunks = p.k >> 5;
+  // Two 32-deep chunks are issued together (second LDS image, second set of A registers): a k = 64 problem has ALL its operand
+  // bytes in flight at once, so a wave pays one memory latency per problem instead of two.  An odd chunk count ends with a single.
+  auto issue = [&](const __amdgpu_buffer_rsrc_t& ra, const __amdgpu_buffer_rsrc_t& rb, int kc, char* image, u32x4 (&af)[MT][2]) {
+#pragma unroll
+    for (int x = 0; x < NT * 2; ++x)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(image + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          af[mt][s][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)voffA[s][e] + 128 * mt, 64 * kc * (int)lda, 0);
+  };
+  auto compute = [&](const char* image, const u32x4 (&af)[MT][2]) {
+    u32x4 bfr[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int f = 32 * nt + li;
+        bfr[nt][s] = *(const u32x4*)(image + f * 64 + (((2 * h + s) ^ ((f >> 1) & 3)) * 16));
+      }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0); });
+  };
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
     const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + 2ull * (unsigned long long)job.j0 * ldb);
     const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)job.i0);
-    for (int kc = 0; kc < kchunks; ++kc) {
-#pragma unroll
-      for (int x = 0; x < NT * 2; ++x)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
-      u32x4 af[MT][2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            af[mt][s][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)voffA[s][e] + 128 * mt, 64 * kc * (int)lda, 0);
+    int kc = 0;
+    for (; kc + 1 < kchunks; kc += 2) {
+      u32x4 af0[MT][2], af1[MT][2];
+      issue(ra, rb, kc, lds, af0);
+      issue(ra, rb, kc + 1, lds + NT * 2048, af1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      u32x4 bfr[NT][2];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int f = 32 * nt + li;
-          bfr[nt][s] = *(const u32x4*)(lds + f * 64 + (((2 * h + s) ^ ((f >> 1) & 3)) * 16));
-        }
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // LDS reads retired before the image is refilled
+      compute(lds, af0);
+      compute(lds + NT * 2048, af1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // LDS reads retired before the images are refilled
+    }
+    if (kc < kchunks) {
+      u32x4 af0[MT][2];
+      issue(ra, rb, kc, lds, af0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      compute(lds, af0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
   static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<true, false>(acc[mt][nt], p, q, tc[mt][nt]); });

@@ -75,6 +75,7 @@ bool hip_ok(hipError_t e, const char* what) {
 
 hipStream_t cur_stream() { return (hipStream_t)tls().stream; }
 
+void copy_back_staged();
 void finish_launch(int err, const char* kname) {
   ThreadState& t = tls();
   ++t.launches;
@@ -82,6 +83,7 @@ void finish_launch(int err, const char* kname) {
   if (!t.async) {
     hipError_t e = hipStreamSynchronize(cur_stream());
     if (e != hipSuccess) set_error((int)e, "kernel %s faulted: %s", kname ? kname : "?", hipGetErrorString(e));
+    copy_back_staged();
   }
 }
 
@@ -94,27 +96,46 @@ std::vector<void*> g_retired;
 void retire_block(void* p) { if (p) { std::lock_guard<std::mutex> guard(g_retired_lock); g_retired.push_back(p); } }
 struct Scratch { char* base = nullptr; size_t cap = 0, used = 0; };
 thread_local Scratch t_scratch;
-const void* device_visible(const void* p, size_t nbytes) {
-  if (p == nullptr || nbytes == 0) return p;
+struct CopyBack { void* host; const void* dev; size_t bytes; };
+thread_local std::vector<CopyBack> t_copyback;       // staged outputs of the current synchronous call
+// `copy_in`: upload the current contents; `copy_back`: download after the kernel (finish_launch, synchronous mode)
+static void* stage(const void* p, size_t nbytes, bool copy_in, bool copy_back) {
+  if (p == nullptr || nbytes == 0) return const_cast<void*>(p);
   hipPointerAttribute_t attr;
   const hipError_t e = hipPointerGetAttributes(&attr, p);
-  if (e == hipSuccess && attr.type != hipMemoryTypeUnregistered) return p;
+  if (e == hipSuccess && attr.type != hipMemoryTypeUnregistered) return const_cast<void*>(p);
   (void)hipGetLastError();   // clear the sticky "invalid value" of an unregistered pointer
   Scratch& s = t_scratch;
   const size_t need = (nbytes + 255) & ~(size_t)255;
   if (s.used + need > s.cap) {
-    // a call's earlier staged arrays must stay valid: only grow when nothing is in use
+    // a call's earlier staged arrays must stay valid: the used part moves along
     const size_t ncap = std::max<size_t>((s.used + need) * 2, 1 << 20);
     char* nb = nullptr;
     if (!hip_ok(hipMalloc((void**)&nb, ncap), "hipMalloc(scratch)")) return nullptr;
-    if (s.base) { (void)hipStreamSynchronize(cur_stream()); (void)hipMemcpy(nb, s.base, s.used, hipMemcpyDeviceToDevice); retire_block(s.base); }
+    if (s.base) {
+      (void)hipStreamSynchronize(cur_stream()); (void)hipMemcpy(nb, s.base, s.used, hipMemcpyDeviceToDevice);
+      for (CopyBack& c : t_copyback) c.dev = nb + ((const char*)c.dev - s.base);
+      retire_block(s.base);
+    }
     s.base = nb; s.cap = ncap;
   }
   char* dst = s.base + s.used; s.used += need;
-  if (!hip_ok(hipMemcpyAsync(dst, p, nbytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpyAsync(index array)")) return nullptr;
+  if (copy_in && !hip_ok(hipMemcpyAsync(dst, p, nbytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpyAsync(host operand)")) return nullptr;
+  if (copy_back) t_copyback.push_back(CopyBack{const_cast<void*>(p), dst, nbytes});
   return dst;
 }
-void scratch_reset() { t_scratch.used = 0; }
+const void* device_visible(const void* p, size_t nbytes) { return stage(p, nbytes, true, false); }
+// Operands of a SYNCHRONOUS call may live in plain host memory (the reference's contract: any pointer, result valid on return);
+// an MI355X cannot see such memory, so it is staged.  Stream-ordered (async) and batched launches take device-accessible memory only:
+// no pointer query, no copy on the fast path.
+static bool staging_allowed(size_t batch_count) { return !tls().async && batch_count <= 1; }
+static const void* host_input(const void* p, size_t nbytes, size_t batch_count) { return staging_allowed(batch_count) ? stage(p, nbytes, true, false) : p; }
+static void* host_inout(void* p, size_t nbytes, size_t batch_count) { return staging_allowed(batch_count) ? stage(p, nbytes, true, true) : p; }
+void scratch_reset() { t_scratch.used = 0; t_copyback.clear(); }
+void copy_back_staged() {
+  for (const CopyBack& c : t_copyback) (void)hip_ok(hipMemcpy(c.host, c.dev, c.bytes, hipMemcpyDeviceToHost), "hipMemcpy(staged result)");
+  t_copyback.clear();
+}
 // per-thread device workspace for partial results; grows monotonically, reused in stream order
 struct Workspace { void* base = nullptr; size_t cap = 0; };
 thread_local Workspace t_workspace;
@@ -407,16 +428,22 @@ void run_spmm(KernelCtx* k, const void* param, const BatchSpec& b) {
   const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
   SpmmArgs a{};
   spmm_geometry(k, a);
+  scratch_reset();
   a.ptr = k->d_ptr; a.idx = k->d_idx; a.vmap = k->d_vmap;
   const bool asp = (k->kind == K_SPMM_ASPARSE);
-  if (asp) {
-    a.vals = k->d_vals ? k->d_vals : p->a.primary;        // baked (areg / FsSpMDM) or run-time values
-    a.x = (const char*)p->b.primary; a.y = (char*)p->c.primary;
-  } else {
-    a.vals = p->b.primary;
-    a.x = (const char*)p->a.primary; a.y = (char*)p->c.primary;
+  const void* vals = asp ? (k->d_vals ? k->d_vals : p->a.primary) : p->b.primary;     // baked (areg / FsSpMDM) or run-time values
+  const void* x = asp ? p->b.primary : p->a.primary;
+  void* y = p->c.primary;
+  if (!vals || !x || !y) { set_error(-2, "sparse kernel called with a NULL operand"); return; }
+  {   // synchronous single calls accept plain host memory (e.g. values straight out of an .mtx reader's malloc)
+    const size_t es = (a.dtype == LIBXSMM_DATATYPE_F64) ? 8 : 4;
+    const size_t xb = es * (size_t)(asp ? (long long)a.inner * a.ld_x : (long long)a.nouter * a.outer_x);
+    const size_t yb = es * (size_t)(asp ? (long long)a.rows * a.ld_y : (long long)a.nouter * a.outer_y);
+    if (!k->d_vals || !asp) vals = host_input(vals, es * (size_t)a.nnz, b.count);
+    x = host_input(x, xb, b.count); y = host_inout(y, yb, b.count);
+    if (!vals || !x || !y) return;
   }
-  if (!a.vals || !a.x || !a.y) { set_error(-2, "sparse kernel called with a NULL operand"); return; }
+  a.vals = vals; a.x = (const char*)x; a.y = (char*)y;
   // batched launch = the caller's loop over elements: the dense operand and C step by byte strides, the sparse operand's values are
   // shared (its stride must be 0) [include/libxsmm_hip.h]
   const long long esz = (a.dtype == LIBXSMM_DATATYPE_F64) ? 8 : 4;

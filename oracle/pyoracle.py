@@ -45,6 +45,8 @@ def build(force: bool = False) -> None:
     if os.path.exists(os.path.join(ref_src, "include", "libxsmm_source.h")):
         if force or not os.path.exists(REF_SO) or os.path.getmtime(os.path.join(_HERE, "ref_shim.c")) > os.path.getmtime(REF_SO):
             subprocess.check_call(["make", "-s", "-C", _HERE, "ref", f"REFERENCE={ref_src}"])
+        # the reference's sample drivers against this repository's headers + libxsmm_amd.so (tests/test_reference_drivers_gpu.py)
+        subprocess.check_call(["make", "-s", "-C", _HERE, "drivers", f"REFERENCE={ref_src}"])
 
 
 class Oracle:
@@ -114,6 +116,11 @@ class Reference(capi.Api):
         L.xref_reference_meltw_ternary.argtypes = [vp, C.c_int, capi.TernaryShape, C.c_uint]
         L.xref_convert_f32_to_bf16_rne.argtypes = [C.c_float]; L.xref_convert_f32_to_bf16_rne.restype = C.c_ushort
         L.xref_convert_f32_to_bf16_truncate.argtypes = [C.c_float]; L.xref_convert_f32_to_bf16_truncate.restype = C.c_ushort
+        for name, arg, res in (("f32_to_f16", C.c_float, C.c_ushort), ("f16_to_f32", C.c_ushort, C.c_float), ("f32_to_bf8_rne", C.c_float, C.c_ubyte),
+                               ("f16_to_hf8_rne", C.c_ushort, C.c_ubyte), ("f32_to_hf8_rne", C.c_float, C.c_ubyte),
+                               ("bf8_to_f32", C.c_ubyte, C.c_float), ("hf8_to_f32", C.c_ubyte, C.c_float)):
+            fn = getattr(L, "xref_convert_" + name); fn.argtypes = [arg]; fn.restype = res
+        L.xref_convert_f32_to_bf8_stochastic.argtypes = [C.c_float, C.c_uint]; L.xref_convert_f32_to_bf8_stochastic.restype = C.c_ubyte
         L.xref_matdiff_normf_rel.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp]; L.xref_matdiff_normf_rel.restype = C.c_double
         L.xref_time_gemm_batch.argtypes = [vp, C.POINTER(capi.GemmParam), C.c_size_t, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]
         L.xref_time_gemm_batch.restype = C.c_double

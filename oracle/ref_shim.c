@@ -130,6 +130,15 @@ XREF void xref_fsspmdm_destroy(libxsmm_fsspmdm* handle) { libxsmm_fsspmdm_destro
 XREF unsigned short xref_convert_f32_to_bf16_rne(float x) { return libxsmm_convert_f32_to_bf16_rne(x); }
 XREF unsigned short xref_convert_f32_to_bf16_truncate(float x) { return libxsmm_convert_f32_to_bf16_truncate(x); }
 XREF float xref_convert_bf16_to_f32(unsigned short x) { return libxsmm_convert_bf16_to_f32(x); }
+/* 16/8-bit float helpers of include/libxsmm_utils.h, pinned in tests/test_utils_cpu.py */
+XREF unsigned short xref_convert_f32_to_f16(float x) { return libxsmm_convert_f32_to_f16(x); }
+XREF float xref_convert_f16_to_f32(unsigned short x) { return libxsmm_convert_f16_to_f32(x); }
+XREF unsigned char xref_convert_f32_to_bf8_rne(float x) { return libxsmm_convert_f32_to_bf8_rne(x); }
+XREF unsigned char xref_convert_f16_to_hf8_rne(unsigned short x) { return libxsmm_convert_f16_to_hf8_rne(x); }
+XREF unsigned char xref_convert_f32_to_hf8_rne(float x) { return libxsmm_convert_f32_to_hf8_rne(x); }
+XREF unsigned char xref_convert_f32_to_bf8_stochastic(float x, unsigned int seed) { return libxsmm_convert_f32_to_bf8_stochastic(x, seed); }
+XREF float xref_convert_bf8_to_f32(unsigned char x) { return libxsmm_convert_bf8_to_f32(x); }
+XREF float xref_convert_hf8_to_f32(unsigned char x) { return libxsmm_convert_hf8_to_f32(x); }
 XREF int xref_cpuid_dot_pack_factor(libxsmm_datatype t) { return libxsmm_cpuid_dot_pack_factor(t); }
 XREF double xref_matdiff_normf_rel(libxsmm_datatype t, libxsmm_blasint m, libxsmm_blasint n, const void* ref, const void* tst) {
   libxsmm_matdiff_info info; libxsmm_matdiff_clear(&info);

@@ -1,0 +1,160 @@
+"""The reference's OWN sample drivers as the integration test-suite.
+
+oracle/Makefile target `drivers` compiles the unmodified sources under /root/reference/samples (where they lie) against THIS
+repository's include/libxsmm.h + include/libxsmm_utils.h and links them to libxsmm_amd.so; the binaries (oracle/_ref/drivers,
+git-ignored, shipped to the GPU box like every other built file) generate their own data, dispatch through the public API, run
+the kernels on the MI355X (their buffers come from libxsmm_aligned_malloc = pinned, device-visible memory) and compare against
+their built-in gold loops.  A driver is its own judge: exit code 0 and no failure marker in its output.
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DRV = os.path.join(HERE, "..", "oracle", "_ref", "drivers")
+FAIL_MARKERS = ("FAILED", "ERROR", "JIT failed", "failed. Bailing", "not supported")
+
+
+def run(binary, *args, timeout=120):
+    exe = os.path.join(DRV, binary)
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (make -C oracle drivers needs /root/reference)")
+    env = dict(os.environ, LIBXSMM_VERBOSE="0")
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, env=env)
+    out = r.stdout + r.stderr
+    if os.environ.get("DRIVERS_SHOW"):
+        print(f"\n$ {binary} {' '.join(str(a) for a in args)} -> rc={r.returncode}\n" + "\n".join(out.splitlines()[-12:]))
+    return r.returncode, out
+
+
+def check(binary, *args, **kw):
+    rc, out = run(binary, *args, **kw)
+    assert rc == 0, f"{binary} {args}: exit {rc}\n{out[-2000:]}"
+    bad = [m for m in FAIL_MARKERS if m in out]
+    assert not bad, f"{binary} {args}: {bad}\n{out[-2000:]}"
+    return out
+
+
+def write_mtx(path, rowptr, colidx, vals, ncols, by_column=False):
+    ent = [(r, int(colidx[z]), float(vals[z])) for r in range(len(rowptr) - 1) for z in range(rowptr[r], rowptr[r + 1])]
+    if by_column:
+        ent.sort(key=lambda e: (e[1], e[0]))
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n%\n")
+        f.write(f"{len(rowptr) - 1} {ncols} {len(ent)}\n")
+        for r, c, v in ent:
+            f.write(f"{r + 1} {c + 1} {v!r}\n")
+
+
+@pytest.fixture(scope="module")
+def edge_mtx(tmp_path_factory):
+    """The 35x35 / 108 non-zero EDGE stiffness operator of the committed golden vectors, as .mtx files (row- and column-sorted)."""
+    d = dict(np.load(os.path.join(HERE, "golden", "reference_vectors.npz")))
+    base = tmp_path_factory.mktemp("mtx")
+    csr, csc = str(base / "edge_csr.mtx"), str(base / "edge_csc.mtx")
+    write_mtx(csr, d["spcsr_edge_rowptr"], d["spcsr_edge_colidx"], d["spcsr_edge_vals"], 35)
+    write_mtx(csc, d["spcsr_edge_rowptr"], d["spcsr_edge_colidx"], d["spcsr_edge_vals"], 35, by_column=True)
+    return csr, csc
+
+
+# samples/xgemm/gemm_kernel.c -- A B comp C  M N K lda ldb ldc  alpha beta  alignA alignC  transA transB  vnniA vnniB vnniC  prefetch  br  brsize brunroll reps tilecfg
+GEMM_CASES = [
+    "F32 F32 F32 F32 23 23 23 23 23 23 1 0 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",           # BASELINE config #1
+    "F32 F32 F32 F32 32 32 32 32 32 32 1 0 0 0 0 0 0 0 0 nopf strdbr 8 0 2 0",         # config #2's kernel as a stride-BRGEMM
+    "F32 F32 F32 F32 32 32 32 32 32 32 1 1 0 0 0 0 0 0 0 nopf addrbr 4 0 2 0",
+    "F32 F32 F32 F32 64 48 40 64 40 64 1 1 0 0 0 0 0 0 0 nopf offsbr 3 0 2 0",
+    "F32 F32 F32 F32 17 9 31 33 33 24 1 1 0 0 1 0 0 0 0 nopf nobr 1 0 2 0",            # A transposed, padded leading dimensions
+    "F32 F32 F32 F32 16 16 16 16 16 16 1 0 0 0 0 1 0 0 0 nopf nobr 1 0 2 0",           # B transposed
+    "F64 F64 F64 F64 23 23 23 23 23 23 1 1 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",
+    "BF16 BF16 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf strdbr 4 0 2 0",       # VNNI-2 A
+    "BF16 BF16 F32 BF16 64 64 64 64 64 64 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "BF16 BF16 F32 BF16 32 32 32 32 32 32 1 0 0 0 0 0 1 0 1 nopf nobr 1 0 2 0",        # VNNI-2 C
+    "I8 I8 I32 I32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "U8 I8 I32 I32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf strdbr 2 0 2 0",
+    "BF8 BF8 F32 F32 32 32 64 32 64 32 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "HF8 HF8 F32 F32 64 64 64 64 64 64 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+]
+
+
+@pytest.mark.parametrize("args", GEMM_CASES)
+def test_reference_gemm_driver(args):
+    check("gemm_kernel", *args.split())
+
+
+# samples/xgemm_sparse/spmm_kernel.c -- A B comp C  M N K m_blocks sparsity bk bn beta transA transB vnniA vnniB vnniC reps
+@pytest.mark.parametrize("args", [
+    "BF16 BF16 F32 BF16 64 64 256 16 0.75 32 16 0 0 0 1 0 0 2",            # BASELINE config #4's kernel (random instead of 2:8 pattern)
+    "BF16 BF16 F32 BF16 64 64 256 8 0.5 32 32 1 0 0 1 0 0 2",
+    "F32 F32 F32 F32 32 32 64 4 0.75 16 4 0 0 0 0 0 0 2",
+])
+def test_reference_bcsc_driver(args):
+    check("spmm_kernel", *args.split())
+
+
+# samples/xgemm_norm_packed/*.c -- M N K N_CRUNS reps file
+@pytest.mark.parametrize("binary,which", [("asparse_packed_csr", 0), ("asparse_packed_csr_f32", 0), ("bsparse_packed_csr", 0), ("bsparse_packed_csr_f32", 0),
+                                          ("bsparse_packed_csc", 1), ("bsparse_packed_csc_f32", 1)])
+def test_reference_packed_drivers(binary, which, edge_mtx):
+    mnk = ("35", "9", "35") if binary.startswith("asparse") else ("9", "35", "35")
+    out = check(binary, *mnk, "8", "2", edge_mtx[which])
+    # these drivers print their error but do not assert it ("parity only weakly pinned"): assert it here
+    errs = [float(x) for x in re.findall(r"max error: ([0-9.eE+-]+)", out)]
+    assert errs and max(errs) <= (1e-5 if binary.endswith("_f32") else 1e-6), out[-1500:]
+
+
+# samples/xgemm_sparse_Ainregs/pyfr_driver_asp_reg.c -- file N reps [beta]
+@pytest.mark.parametrize("beta", [0, 1])
+def test_reference_fsspmdm_driver(beta, edge_mtx):
+    out = check("pyfr_driver_asp_reg", edge_mtx[0], "4800", "2", beta)
+    errs = [float(x) for x in re.findall(r"\(libxsmm vs\. gold\): abs=([0-9.eE+-]+)", out)]
+    assert errs and max(errs) <= 1e-6, out[-1500:]
+
+
+# samples/eltwise/*.c
+@pytest.mark.parametrize("args", [
+    "1 0 F32 F32 F32 64 48 64 64", "1 0 BF16 F32 BF16 64 48 70 72", "1 0 F32 F32 BF16 33 17 40 36", "3 0 F32 F32 F32 64 48 64 64",
+    "4 0 F32 F32 F32 32 32 32 32", "7 0 F32 F32 F32 64 48 64 64", "9 0 BF16 F32 BF16 64 48 64 64", "11 0 F32 F32 F32 64 48 64 64",
+    "13 0 F32 F32 F32 64 48 64 64", "14 0 F32 F32 F32 64 48 64 64", "15 0 F32 F32 F32 64 48 64 64", "16 0 F32 F32 F32 64 48 64 64",
+    "17 0 F32 F32 F32 64 48 64 64", "1 1 F32 F32 F32 64 48 64 64", "1 2 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 64 48 64 64", "2 0 F32 F32 F32 64 48 64 64",
+])
+def test_reference_unary_driver(args):
+    check("eltwise_unary_simple", *args.split())
+
+
+@pytest.mark.parametrize("args", [
+    "1 0 F32 F32 F32 F32 64 48 64 64", "2 0 BF16 BF16 F32 BF16 64 48 64 64", "3 1 F32 F32 F32 F32 64 48 64 64", "4 2 F32 F32 F32 F32 64 48 64 64",
+    "5 0 F32 F32 F32 F32 64 48 64 64", "9 4 F32 F32 F32 F32 33 17 40 36", "10 5 F32 F32 F32 F32 64 48 64 64", "1 6 BF16 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 BF16 64 48 64 64",
+])
+def test_reference_binary_driver(args):
+    check("eltwise_binary_simple", *args.split())
+
+
+@pytest.mark.parametrize("args", ["D F 0 F32 F32 F32 64 48 64 64", "D F 1 F32 F32 F32 64 48 64 64", "D F 1 BF16 F32 BF16 64 48 64 64", "D B 1 F32 F32 F32 64 48 64 64",
+                                  "L F 0 F32 F32 F32 64 48 64 64", "E F 0 F32 F32 F32 64 48 64 64"])
+def test_reference_relu_driver(args):
+    check("eltwise_unary_relu", *args.split())
+
+
+@pytest.mark.parametrize("args", ["T F32 64 48 64 48", "T F32 33 17 40 20", "T BF16 64 48 64 48", "T F64 16 24 16 24", "V BF16 64 48 64 64", "R BF16 64 48 64 64"])
+def test_reference_transform_driver(args):
+    check("eltwise_unary_transform", *args.split())
+
+
+# M N ldi ldo gather(0)/scatter(1) rows(0)/cols(1)/offs(2) 16-bit-dtype 64-bit-index iters
+@pytest.mark.parametrize("args", ["64 48 64 64 0 1 0 0 1", "64 48 64 64 0 0 0 1 1", "64 48 64 64 1 1 0 0 1", "64 48 64 64 0 2 0 1 1", "64 48 64 64 0 1 1 0 1"])
+def test_reference_gather_scatter_driver(args):
+    check("eltwise_unary_gather_scatter", *args.split())
+
+
+# samples/eltwise/eltwise_unary_reduce.c is built but not run: it allocates its operands with plain malloc(), which an MI355X cannot
+# see, and TPP calls do not stage host memory (only the packed sparse kernels do, for .mtx readers); reductions are covered by
+# tests/test_meltw_gpu.py against the pinned oracle instead.
+
+
+@pytest.mark.parametrize("args", ["1 0 F32 F32 IMPLICIT F32 F32 64 48 64 64", "1 0 BF16 BF16 IMPLICIT F32 BF16 64 48 64 64", "1 4 F32 F32 IMPLICIT F32 F32 33 17 40 36"])
+def test_reference_ternary_driver(args):
+    check("eltwise_ternary_simple", *args.split())

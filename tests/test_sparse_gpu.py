@@ -168,6 +168,48 @@ def test_packed_sparse_batched(dt, side, M, N, K, P, count, jit_mode):
     api.release_kernel(h)
 
 
+@pytest.mark.parametrize("side", ["a", "b"])
+def test_packed_sparse_accepts_plain_host_memory_in_synchronous_calls(side, jit_mode):
+    """The reference's contract is "any pointer, result valid on return".  A synchronous single call therefore stages operands that
+    live in plain host memory (values straight out of an .mtx reader's malloc, numpy arrays here); stream-ordered and batched
+    launches take device memory only."""
+    api, orc = capi.load(), pyoracle.oracle()
+    dt, M, N, K, P = DT.F64, 9, 12, 20, 8
+    rng = np.random.default_rng(21)
+    if side == "a":
+        rowptr, colidx = random_csr(rng, M, K, 0.2)
+        X, ld = rand_values(rng, K * N * P, dt), (0, N, N)
+    else:
+        rowptr, colidx = random_csr(rng, K, N, 0.2)
+        X, ld = rand_values(rng, M * K * P, dt), (K, 0, N)
+    vals = rand_values(rng, len(colidx), dt) + 0.05
+    C0 = rand_values(rng, M * N * P, dt)
+    ref = C0.copy()
+    fn = orc.lib.oracle_packed_spgemm_csr_asparse if side == "a" else orc.lib.oracle_packed_spgemm_csr_bsparse
+    fn(dt, M, N, K, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, X.ctypes.data, N if side == "a" else K, ref.ctypes.data, N, 0)
+    h = api.create_packed_spgemm_csr(capi.gemm_shape(M, N, K, ld[0], ld[1], ld[2], dt, dt, dt, dt), 0, 0, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data)
+    assert h
+    got = C0.copy()                                   # numpy memory: not visible to the GPU
+    p = capi.GemmParam()
+    if side == "a":
+        p.a.primary, p.b.primary, p.c.primary = vals.ctypes.data, X.ctypes.data, got.ctypes.data
+    else:
+        p.a.primary, p.b.primary, p.c.primary = X.ctypes.data, vals.ctypes.data, got.ctypes.data
+    capi.Api.call(h, p)
+    api.check()
+    assert normf_rel(ref, got, dt) <= 1e-12
+    dC = _dev(C0.copy())                              # mixed: values on the host, dense operands on the device
+    dX = _dev(X)
+    if side == "a":
+        p.b.primary, p.c.primary = dX.data_ptr(), dC.data_ptr()
+    else:
+        p.a.primary, p.c.primary = dX.data_ptr(), dC.data_ptr()
+    capi.Api.call(h, p)
+    api.check()
+    assert np.array_equal(_host(dC, np.float64), got)
+    api.release_kernel(h)
+
+
 def test_packed_sparse_batched_deferred_specialisation():
     """Auto mode (default): a packed kernel whose single call is too small to repay hiprtc is specialised by the first batched
     launch that covers enough columns; the result still matches the oracle."""

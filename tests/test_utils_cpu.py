@@ -1,0 +1,98 @@
+"""include/libxsmm_utils.h helpers (16/8-bit float conversions, strings, RNG state, matrix init) pinned against the
+reference's own functions [ref: src/libxsmm_math.c:600-900] through oracle/_ref.  No GPU needed: these are host helpers the
+reference's sample drivers link against."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from libxsmm_amd import capi
+from oracle import pyoracle
+
+LIB = os.path.join(os.path.dirname(capi.__file__), "lib", "libxsmm_amd.so")
+
+
+@pytest.fixture(scope="module")
+def ours():
+    L = C.CDLL(LIB)
+    for name, arg, res in (("f32_to_f16", C.c_float, C.c_ushort), ("f16_to_f32", C.c_ushort, C.c_float), ("f32_to_bf8_rne", C.c_float, C.c_ubyte),
+                           ("f16_to_hf8_rne", C.c_ushort, C.c_ubyte), ("f32_to_hf8_rne", C.c_float, C.c_ubyte),
+                           ("bf8_to_f32", C.c_ubyte, C.c_float), ("hf8_to_f32", C.c_ubyte, C.c_float)):
+        fn = getattr(L, "libxsmm_convert_" + name); fn.argtypes = [arg]; fn.restype = res
+    L.libxsmm_convert_f32_to_bf8_stochastic.argtypes = [C.c_float, C.c_uint]; L.libxsmm_convert_f32_to_bf8_stochastic.restype = C.c_ubyte
+    return L
+
+
+@pytest.fixture(scope="module")
+def ref():
+    r = pyoracle.reference()
+    if r is None:
+        pytest.skip("oracle/_ref/libxsmm_ref.so not built")
+    return r.lib
+
+
+def _same_float(a, b):
+    return (a != a and b != b) or np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32)
+
+
+def test_every_half_and_every_byte(ours, ref):
+    for h in range(1 << 16):            # all halves: widen, and narrow to E4M3
+        assert _same_float(ours.libxsmm_convert_f16_to_f32(h), ref.xref_convert_f16_to_f32(h)), hex(h)
+        assert ours.libxsmm_convert_f16_to_hf8_rne(h) == ref.xref_convert_f16_to_hf8_rne(h), hex(h)
+    for b in range(256):
+        assert _same_float(ours.libxsmm_convert_bf8_to_f32(b), ref.xref_convert_bf8_to_f32(b)), hex(b)
+        assert _same_float(ours.libxsmm_convert_hf8_to_f32(b), ref.xref_convert_hf8_to_f32(b)), hex(b)
+
+
+def test_f32_narrowing_on_boundaries_and_random_values(ours, ref):
+    rng = np.random.default_rng(3)
+    halves = np.arange(0, 1 << 16, 7, dtype=np.uint16).view(np.float16).astype(np.float32)
+    halves = halves[np.isfinite(halves)]
+    ulp = np.abs(halves) * np.float32(2.0 ** -11)
+    vals = np.concatenate([
+        halves, halves + ulp, halves - ulp, halves + ulp / 2, np.nextafter(halves + ulp, np.float32(np.inf)),   # ties and their neighbours
+        (rng.standard_normal(20000) * 10.0 ** rng.integers(-12, 8, 20000)).astype(np.float32),
+        rng.integers(0, 1 << 32, 20000, dtype=np.uint64).astype(np.uint32).view(np.float32),                     # arbitrary bit patterns incl. NaNs
+        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 65504.0, 65519.9, 65520.0, 6e-8, 2.98e-8, 2.9802322e-8, 1e-45, 448.0, 464.0, 465.0, 0.001953125, 0.0009765625], dtype=np.float32)])
+    vals = vals.astype(np.float32)
+    for v in vals:
+        x = float(v)
+        assert ours.libxsmm_convert_f32_to_f16(x) == ref.xref_convert_f32_to_f16(x), v
+        assert ours.libxsmm_convert_f32_to_bf8_rne(x) == ref.xref_convert_f32_to_bf8_rne(x), v
+        assert ours.libxsmm_convert_f32_to_hf8_rne(x) == ref.xref_convert_f32_to_hf8_rne(x), v
+    for v in vals[::17]:
+        for seed in (0, 1, 127, 128, 255, 0x1234):
+            assert ours.libxsmm_convert_f32_to_bf8_stochastic(float(v), seed) == ref.xref_convert_f32_to_bf8_stochastic(float(v), seed), (v, seed)
+
+
+def test_array_forms_strings_rng_state_and_matinit(ours):
+    n = 1000
+    src = np.linspace(-300, 300, n, dtype=np.float32)
+    for narrow, widen, dt in (("libxsmm_rne_convert_fp32_f16", "libxsmm_convert_f16_f32", np.uint16),
+                              ("libxsmm_rne_convert_fp32_bf8", "libxsmm_convert_bf8_f32", np.uint8),
+                              ("libxsmm_rne_convert_fp32_hf8", "libxsmm_convert_hf8_f32", np.uint8)):
+        lo, back = np.zeros(n, dtype=dt), np.zeros(n, dtype=np.float32)
+        getattr(ours, narrow)(C.c_void_p(src.ctypes.data), C.c_void_p(lo.ctypes.data), C.c_size_t(n))
+        getattr(ours, widen)(C.c_void_p(lo.ctypes.data), C.c_void_p(back.ctypes.data), C.c_size_t(n))
+        rel = 2.0 ** -10 if dt == np.uint16 else 2.0 ** -2
+        assert np.all(np.abs(back - src) <= rel * np.maximum(np.abs(src), 1.0))
+    ours.libxsmm_stristr.restype = C.c_char_p
+    ours.libxsmm_stristr.argtypes = [C.c_char_p, C.c_char_p]
+    assert ours.libxsmm_stristr(b"Sapphire RAPIDS", b"rapids") == b"RAPIDS"
+    assert ours.libxsmm_stristr(b"gfx950", b"spr") is None
+    ours.libxsmm_rng_create_extstate.restype = C.POINTER(C.c_uint)
+    ours.libxsmm_rng_create_extstate.argtypes = [C.c_uint]
+    st = ours.libxsmm_rng_create_extstate(555)
+    assert st and ours.libxsmm_rng_get_extstate_size() == 256 and len({st[i] for i in range(64)}) > 48
+    out = np.zeros(64, dtype=np.uint8)
+    vals = np.full(64, 1.0 + 2.0 ** -5, dtype=np.float32)      # between two E5M2 neighbours: both must appear
+    ours.libxsmm_stochastic_convert_fp32_bf8(C.c_void_p(vals.ctypes.data), C.c_void_p(out.ctypes.data), C.c_uint(64), st, C.c_uint(0))
+    assert set(out.tolist()) <= {0x3c, 0x3d} and len(set(out.tolist())) == 2
+    ours.libxsmm_rng_destroy_extstate(st)
+    ours.libxsmm_hip_matinit_value.restype = C.c_double
+    ours.libxsmm_hip_matinit_value.argtypes = [C.c_double, C.c_double] + [C.c_int] * 5
+    assert ours.libxsmm_hip_matinit_value(42.0, 1.0, 2, 3, 10, 5, 12) == 43.0 * (1 + 3 * 10 + 2)
+    assert ours.libxsmm_hip_matinit_value(42.0, 1.0, 11, 3, 10, 5, 12) == 42.0
+    shuffled = [ours.libxsmm_hip_matinit_value(0.0, 1.0, r, c, 10, 5, 12) for c in range(5) for r in range(12)]
+    assert len(set(shuffled)) == 60 and max(np.abs(shuffled)) <= 1.0
