@@ -27,6 +27,12 @@
 #define LIBXSMM_ABS(A) (0 <= (A) ? (A) : -(A))
 #define LIBXSMM_NEQ(A, B) ((A) != (B))
 #define LIBXSMM_FABS(A) fabs(A)
+#define LIBXSMM_FABSF(A) fabsf(A)
+#define LIBXSMM_POWF(A, B) powf(A, B)
+#define LIBXSMM_LOGF(A) logf(A)
+#define LIBXSMM_FLOORF(A) floorf(A)
+#define LIBXSMM_ROUNDF(A) roundf(A)
+#define LIBXSMM_FREXPF(A, B) frexpf(A, B)
 #define LIBXSMM_EXPF(A) expf(A)
 #define LIBXSMM_TANHF(A) tanhf(A)
 #define LIBXSMM_SQRTF(A) sqrtf(A)

@@ -158,3 +158,10 @@ def test_reference_gather_scatter_driver(args):
 @pytest.mark.parametrize("args", ["1 0 F32 F32 IMPLICIT F32 F32 64 48 64 64", "1 0 BF16 BF16 IMPLICIT F32 BF16 64 48 64 64", "1 4 F32 F32 IMPLICIT F32 F32 33 17 40 36"])
 def test_reference_ternary_driver(args):
     check("eltwise_ternary_simple", *args.split())
+
+
+# samples/equation/equation_simple.c -- M N ld datatype_mode(0 f32, 1 bf16) iters: five-argument element-wise + reduce/broadcast trees
+# (the other equation samples need node kinds this back end refuses: bitmask ReLU inside a tree, ZIP/UNZIP, DUMP, REUSE_IN_2_AS_OUT)
+@pytest.mark.parametrize("args", ["64 48 64 0 2", "64 48 64 1 2", "33 17 40 0 2"])
+def test_reference_equation_driver(args):
+    check("equation_simple", *args.split())
