@@ -328,7 +328,7 @@ typedef struct libxsmm_kernel_info {
 typedef struct libxsmm_registry_info { size_t capacity, size, nbytes, nstatic, ncache; } libxsmm_registry_info;
 
 /* ---- target "architecture" ids  [ref: include/libxsmm_cpuid.h:23-39] --------------
- * This backend reports a generic id below LIBXSMM_X86_AVX512_SPR so that callers do
+ * This backend reports LIBXSMM_X86_GENERIC (the reference's id for LIBXSMM_TARGET=generic), below LIBXSMM_X86_AVX512_SPR, so that callers do
  * not hoist AMX tile configuration. */
 #define LIBXSMM_TARGET_ARCH_UNKNOWN 0
 #define LIBXSMM_TARGET_ARCH_GENERIC 1

@@ -24,7 +24,7 @@ static int jit_mode();   // LIBXSMM_HIP_JIT / libxsmm_hip_set_jit, defined with 
 extern "C" {
 __attribute__((visibility("default"))) unsigned int libxsmm_ninit = 0;
 __attribute__((visibility("default"))) int libxsmm_verbosity = 0;
-__attribute__((visibility("default"))) int libxsmm_target_archid = LIBXSMM_TARGET_ARCH_GENERIC;
+__attribute__((visibility("default"))) int libxsmm_target_archid = LIBXSMM_X86_GENERIC;
 __attribute__((visibility("default"))) int libxsmm_stdio_handle = 0;   // [ref: include/libxsmm_generator.h:214] 0: no user lock on I/O
 __attribute__((visibility("default"))) int libxsmm_se = 0;             // security-enhanced environment: never the case here
 }
@@ -585,7 +585,8 @@ LIBXSMM_API void libxsmm_init(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { n = 0; (void)hipGetLastError(); }
   g_device_count = n;
-  libxsmm_target_archid = LIBXSMM_TARGET_ARCH_GENERIC;   // below SPR: callers must not hoist AMX tile config
+  libxsmm_target_archid = LIBXSMM_X86_GENERIC;   // what the reference reports for LIBXSMM_TARGET=generic: below SPR (callers must not hoist AMX tile
+                                                 // config) and the id its drivers test for when they pick plain-C gold code
   vlog(1, "initialised: %d HIP device(s), target gfx950", n);
   libxsmm_ninit = 2;
 }

@@ -85,6 +85,21 @@ def test_reference_gemm_driver(args):
     check("gemm_kernel", *args.split())
 
 
+# the same source built with -DUSE_GEMM_EXT_FRONTEND (the reference's gemm_kernel_fused): ... reps tilecfg binary_postop(1 = column bias add)
+# unary_postop(1 ReLU, 2 ReLU + bitmask, 3 sigmoid)
+@pytest.mark.parametrize("args", [
+    "BF16 BF16 F32 BF16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf strdbr 4 0 2 0 1 1",     # BASELINE config #5's kernel: bias + ReLU fused
+    "BF16 BF16 F32 BF16 64 64 64 64 64 64 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0 1 2",       # ReLU with bitmask output
+    "BF16 BF16 F32 BF16 32 32 32 32 32 32 1 0 0 0 0 0 1 0 0 nopf addrbr 3 0 2 0 0 3",     # sigmoid
+    "F32 F32 F32 F32 64 48 40 64 40 64 1 1 0 0 0 0 0 0 0 nopf strdbr 3 0 2 0 1 1",
+    "F32 F32 F32 F32 23 23 23 23 23 23 1 0 0 0 0 0 0 0 0 nopf nobr 1 0 2 0 1 2",
+    "F32 F32 F32 F32 32 32 32 32 32 32 1 0 0 0 0 0 0 0 0 nopf offsbr 4 0 2 0 0 3",
+    "BF16 BF16 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0 1 0",
+])
+def test_reference_fused_gemm_driver(args):
+    check("gemm_kernel_fused", *args.split())
+
+
 # samples/xgemm_sparse/spmm_kernel.c -- A B comp C  M N K m_blocks sparsity bk bn beta transA transB vnniA vnniB vnniC reps
 @pytest.mark.parametrize("args", [
     "BF16 BF16 F32 BF16 64 64 256 16 0.75 32 16 0 0 0 1 0 0 2",            # BASELINE config #4's kernel (random instead of 2:8 pattern)
