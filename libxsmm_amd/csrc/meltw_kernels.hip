@@ -718,7 +718,18 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
     const int j = (blockIdx.x * 4 + wave) * cpw + lane / G;
     float sx = ident, sx2 = 0.0f;
     if (j < p.n) {
-      for (int i4 = l; i4 < m4; i4 += G) {
+      // four independent loads in flight per lane; the values are folded in the order of the plain loop (same rounding)
+      int i4 = l;
+      for (; i4 + 3 * G < m4; i4 += 4 * G) {
+        float x[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) red_load4<BF16IN>(x[u], in, 4ll * (i4 + u * G) + (long long)j * p.ldi);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sx = combine(sx, x[u][e]); sx2 += x[u][e] * x[u][e]; }
+      }
+      for (; i4 < m4; i4 += G) {
         float x[4]; red_load4<BF16IN>(x, in, 4ll * i4 + (long long)j * p.ldi);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sx = combine(sx, x[e]); sx2 += x[e] * x[e]; }
@@ -731,13 +742,23 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
       if (want_x2) mw_store(out2, j, p.out_type, sx2);
     }
   } else {
-    const int rg_l = threadIdx.x & 15, sl = threadIdx.x >> 4;            // 16 row groups x 16 slices per block
+    const int rg_l = threadIdx.x & 15, sl = threadIdx.x >> 4;            // 16 row groups x 16 slices per block (64 x 4 measured 1.5x slower)
     const int rg = blockIdx.x * 16 + rg_l;
     float sx[4] = {ident, ident, ident, ident}, sx2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     // two-pass form (partial != NULL): blockIdx.z owns columns [z*chunk, (z+1)*chunk) and writes raw partial sums
     const int jbeg = partial ? (int)blockIdx.z * chunk : 0, jend = partial ? ((jbeg + chunk < p.n) ? jbeg + chunk : p.n) : p.n;
     if (rg < m4 && sl < slices) {
-      for (int j = jbeg + sl; j < jend; j += slices) {
+      int j = jbeg + sl;
+      for (; j + 3 * slices < jend; j += 4 * slices) {       // four columns in flight, folded in column order
+        float x[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) red_load4<BF16IN>(x[u], in, 4ll * rg + (long long)(j + u * slices) * p.ldi);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sx[e] = combine(sx[e], x[u][e]); sx2[e] += x[u][e] * x[u][e]; }
+      }
+      for (; j < jend; j += slices) {
         float x[4]; red_load4<BF16IN>(x, in, 4ll * rg + (long long)j * p.ldi);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sx[e] = combine(sx[e], x[e]); sx2[e] += x[e] * x[e]; }
@@ -950,7 +971,7 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
         // one big matrix over its columns: too few row groups to fill the chip -> split the columns over blockIdx.z (two passes)
         int nchunks = 1;
         if (!rows && a.ws && a.nbatch == 1 && gx < 512) {
-          nchunks = (int)std::min<long long>(64, std::min<long long>(a.n / 256, 2048 / (gx ? gx : 1)));
+          nchunks = (int)std::min<long long>(128, std::min<long long>(a.n / 64, 2048 / (gx ? gx : 1)));
           if ((size_t)nchunks * 2 * (size_t)a.m * sizeof(float) > a.ws_bytes) nchunks = 1;
         }
         if (nchunks > 1) {

@@ -369,7 +369,7 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     a.bs_in0 = b.s[0]; a.bs_out = b.s[1]; a.bs_aux = b.s[2];
     const int t = d.param;
     if ((d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_COLS) && d.n >= 2048 && b.count == 1) {   // one big matrix reduced over its columns: two passes
-      a.ws_bytes = (size_t)64 * 2 * (size_t)d.m * sizeof(float); a.ws = workspace(a.ws_bytes);
+      a.ws_bytes = (size_t)128 * 2 * (size_t)d.m * sizeof(float); a.ws = workspace(a.ws_bytes);
     }
     // scalars the reference reads through op.primary / out.secondary are read here, on the host
     if (t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || t == LIBXSMM_MELTW_TYPE_UNARY_ELU || t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || t == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) {
