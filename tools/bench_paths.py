@@ -433,7 +433,8 @@ def main():
         makers = [lambda: with_cpu(brgemm(api, 32, "f32", 4096), lambda: bench.cpu_baseline(argparse.Namespace(m=32, br=1, batch=4096, dtype="f32", beta=0), 3.0)),
                   lambda: with_cpu(csr_asparse(api, 65536, 0.15), lambda: cpu_csr(1024, 0.15)), lambda: with_cpu(csr_asparse(api, 65536, 0.10), lambda: cpu_csr(1024, 0.10)),
                   lambda: with_cpu(fsspmdm(api, 2 ** 20, 0.15), lambda: cpu_fsspmdm(49152, 0.15)),
-                  lambda: with_cpu(bcsc(api), cpu_bcsc), lambda: with_cpu(brgemm(api, 64, "bf16", 2 ** 17, fused=1), cpu_fused)]
+                  lambda: with_cpu(bcsc(api), cpu_bcsc), lambda: with_cpu(brgemm(api, 64, "bf16", 2 ** 17, fused=1), cpu_fused),
+                  lambda: brgemm_mxfp4(api, 64, 2 ** 17), lambda: csr_asparse_batched(api)]     # widened rows: no CPU leg
     if "gemm" in only:
         # steady state: ~1.5 GB per input set for every shape (launch ramp/drain amortised), plus small-launch cases
         makers += [lambda: brgemm(api, 16, "f32", 2 ** 19), lambda: brgemm(api, 32, "f32", 2 ** 17), lambda: brgemm(api, 64, "f32", 2 ** 15),
