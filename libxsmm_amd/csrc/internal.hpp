@@ -174,6 +174,7 @@ const void* rt_new_meqn_handle(EqnPlan* plan);   // caller-independent handle ow
 void rt_finish_launch(int err, const char* kernel_name);
 void* rt_workspace(size_t nbytes);
 bool rt_ready();
+void rt_note(const char* what, int a, int b, int c);      // verbosity >= 1: why a request was refused
 void* rt_stream();
 
 // ---- per-thread execution state -----------------------------------------------------------------

@@ -399,7 +399,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
   const std::array<int, 4> key = {out.m, out.n, out.ld, (int)out.type};
   auto hit = e->handles.find(key);
   if (hit != e->handles.end()) return (libxsmm_meqn_function)hit->second;
-  if (!infer(*e, 0)) return nullptr;
+  if (!infer(*e, 0)) { rt_note("equation refused: shapes/types of the tree cannot be inferred", idx, 0, 0); return nullptr; }
   std::vector<int> order;
   postorder(*e, 0, order);
   EqnPlan* plan = new EqnPlan();
@@ -411,7 +411,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
     EqnNode nd = e->nodes[id];
     const bool root = (id == 0);
     if (root) {   // the head writes the caller's output [ref: matequation ref :28-29; dispatch out shape]
-      if (out.m != nd.m || out.n != nd.n || out.ld < out.m) { delete plan; return nullptr; }
+      if (out.m != nd.m || out.n != nd.n || out.ld < out.m) { rt_note("equation refused: output shape differs from the head node (m, n, ld)", out.m, out.n, out.ld); delete plan; return nullptr; }
       nd.ld = out.ld; nd.type = out.type;
     } else plan->slot_of[id] = plan->nslots++;
     EqnStep st; std::memset(&st.args, 0, sizeof(st.args));
@@ -454,7 +454,11 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
         (libxsmm_datatype)nd.type, a.m, a.n, a.ldi, a.ldo, a.ldi1, a.ldi2, (unsigned short)nd.flags, (unsigned short)nd.op, LIBXSMM_MELTW_OPERATION_TERNARY);
       if (nd.op == LIBXSMM_MELTW_TYPE_TERNARY_SELECT) d = nullptr;
     }
-    if (!d || !meltw_supported(*d)) { delete plan; return nullptr; }
+    if (!d || !meltw_supported(*d)) {
+      rt_note("equation refused: node kind/op/flags not available inside a tree", (int)nd.kind, (int)nd.op, (int)nd.flags);
+      rt_note("  operand types in0/in1/in2", a.in0_type, a.in1_type, a.in2_type); rt_note("  compute/out type, descriptor built", (int)nd.dtype, (int)nd.type, d != nullptr);
+      delete plan; return nullptr;
+    }
     // the broadcast flags of an op refer to operands that really are vectors / scalars of the result
     plan->steps.push_back(st);
   }
