@@ -109,11 +109,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(gcptr base) {
 
 // MXFP4 A: base of the E8M0 scales of batch-reduce element r [ref: gemm ref :200-222] -- one byte per (32-deep k-block, row):
 // pointer list / byte offset of A * 2 / 32 / byte stride of A * 2 / 32
-__device__ __forceinline__ gcptr mx_scale_base(const GemmArgs& p, unsigned int bidx, unsigned long long r) {
-  gcptr base = (gcptr)p.a_scf + (long long)bidx * p.bs_scf;
+__device__ __forceinline__ bool is_mx_type(int t) { return t == LIBXSMM_DATATYPE_MXFP4X2 || t == LIBXSMM_DATATYPE_MXBF8 || t == LIBXSMM_DATATYPE_MXHF8; }
+// scales of A (of_b = false) or B: one byte per 32 elements, so a byte distance D of the operand is D * (elements per byte) / 32 here
+__device__ __forceinline__ gcptr mx_scale_base(const GemmArgs& p, unsigned int bidx, unsigned long long r, bool of_b) {
+  gcptr base = of_b ? (gcptr)p.b_scf + (long long)bidx * p.bs_bscf : (gcptr)p.a_scf + (long long)bidx * p.bs_scf;
+  const long long epb = ((of_b ? p.b_type : p.a_type) == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
   if (p.br_mode == 1) return list_entry((const void*)(size_t)base, r);
-  if (p.br_mode == 2) return base + ((long long)uniform_u64((unsigned long long)((GM const long long*)p.offs_a)[r]) * 2) / 32;
-  if (p.br_mode == 3) return base + ((p.br_stride_a * 2) / 32) * (long long)r;
+  if (p.br_mode == 2) return base + ((long long)uniform_u64((unsigned long long)((GM const long long*)(of_b ? p.offs_b : p.offs_a))[r]) * epb) / 32;
+  if (p.br_mode == 3) return base + (((of_b ? p.br_stride_b : p.br_stride_a) * epb) / 32) * (long long)r;
   return base;
 }
 __device__ __forceinline__ float e2m1_to_f32(unsigned int c) {     // [ref: gemm ref :60-64]
@@ -239,6 +242,44 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     return;
   }
 
+  if (is_mx_type(p.a_type) && p.b_type == p.a_type) {
+    // MX x MX [ref: gemm ref :2620-2665 (fp8), :2731-2785 (fp4)]: A and B as a dword per (row, k-group), E8M0 scales per (32 k, row) in
+    // a/b.tertiary; partial sums per k-group (fp8: 4 products, high k first; fp4: 8 products ascending) times scale_a times scale_b
+    if (!valid) return;
+    const bool fp4 = p.a_type == LIBXSMM_DATATYPE_MXFP4X2, hf8 = p.a_type == LIBXSMM_DATATYPE_MXHF8;
+    float acc = 0.0f;
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      gcptr ar, br; br_base(p, q, r, ar, br);
+      GM const unsigned char* sa = (GM const unsigned char*)mx_scale_base(p, bidx, r, false);
+      GM const unsigned char* sb = (GM const unsigned char*)mx_scale_base(p, bidx, r, true);
+      if (fp4) {
+        for (int s = 0; s < p.k / 32; ++s) {
+          const float sca = __uint_as_float((unsigned int)sa[(long long)s * p.lda + i] << 23), scb = __uint_as_float((unsigned int)sb[(long long)s * p.ldb + j] << 23);
+          for (int g = 0; g < 4; ++g) {
+            float tmp = 0.0f;
+            const unsigned int wa = *(GM const unsigned int*)(ar + ((long long)(s * 4 + g) * p.lda + i) * 4), wb = *(GM const unsigned int*)(br + ((long long)(s * 4 + g) * p.ldb + j) * 4);
+            for (int k2 = 0; k2 < 8; ++k2) tmp = add_rn(tmp, mul_rn(e2m1_to_f32((wa >> (4 * k2)) & 15u), e2m1_to_f32((wb >> (4 * k2)) & 15u)));
+            acc = add_rn(acc, mul_rn(mul_rn(tmp, sca), scb));
+          }
+        }
+      } else {
+        for (int s = 0; s < p.k / 4; ++s) {
+          const float sca = __uint_as_float((unsigned int)sa[(long long)(s / 8) * p.lda + i] << 23), scb = __uint_as_float((unsigned int)sb[(long long)(s / 8) * p.ldb + j] << 23);
+          const unsigned int wa = *(GM const unsigned int*)(ar + ((long long)s * p.lda + i) * 4), wb = *(GM const unsigned int*)(br + ((long long)s * p.ldb + j) * 4);
+          float tmp = 0.0f;
+          for (int k2 = 3; k2 >= 0; --k2) {
+            const unsigned char xa = (unsigned char)(wa >> (8 * k2)), xb = (unsigned char)(wb >> (8 * k2));
+            tmp = add_rn(tmp, mul_rn(hf8 ? hf8_to_f32(xa) : bf8_to_f32(xa), hf8 ? hf8_to_f32(xb) : bf8_to_f32(xb)));
+          }
+          acc = add_rn(acc, mul_rn(mul_rn(tmp, sca), scb));
+        }
+      }
+    }
+    GM float* c = (GM float*)q.c + (long long)j * p.ldc + i;
+    *c = add_rn(beta0 ? 0.0f : *c, acc);
+    return;
+  }
+
   if (p.a_type == LIBXSMM_DATATYPE_MXFP4X2) {
     // MXFP4 weights x bf16/f32 activations [ref: gemm ref :949-1008]: packed E2M1 pairs [k/2][lda] (low nibble = even k), value * scale
     // is exact, products summed serially from 0 (unfused), C = (beta ? C : 0) + sum with one RNE for bf16 output
@@ -246,7 +287,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     float acc = 0.0f;
     for (unsigned long long r = 0; r < p.br_count; ++r) {
       gcptr ar, br; br_base(p, q, r, ar, br);
-      gcptr sr = mx_scale_base(p, bidx, r);
+      gcptr sr = mx_scale_base(p, bidx, r, false);
       for (int s = 0; s < p.k / 32; ++s) {
         const float scf = __uint_as_float((unsigned int)((GM const unsigned char*)sr)[(long long)s * p.lda + i] << 23);
         for (int k2 = 0; k2 < 32; k2 += 2) {
@@ -1248,7 +1289,7 @@ __global__ __launch_bounds__(256) void gemm_mxfp4_stream_kernel(GemmArgs p) {
     gcptr ar, br; br_base(p, q, r, ar, br);
     const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + 2ull * (unsigned long long)job.j0 * ldb);
     const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + (unsigned long long)job.i0);
-    const __amdgpu_buffer_rsrc_t rs = wave_rsrc(mx_scale_base(p, job.bidx, r) + (unsigned long long)job.i0);
+    const __amdgpu_buffer_rsrc_t rs = wave_rsrc(mx_scale_base(p, job.bidx, r, false) + (unsigned long long)job.i0);
     for (int kc = 0; kc < kchunks; ++kc) {
 #pragma unroll
       for (int x = 0; x < NT * 2; ++x)
@@ -1294,6 +1335,67 @@ __global__ __launch_bounds__(256) void gemm_mxfp4_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// MX x MX streaming kernel (v_mfma_scale_f32_32x32x64_f8f6f4): the OCP microscaling GEMM is what this instruction computes -- a lane
+// supplies 32 consecutive k of ONE row (lane & 31) of its operand for the k-half (lane >> 5), plus that block's E8M0 scale byte; the
+// matrix core applies 2^(sa-127) * 2^(sb-127) to the block's partial product.  A and B arrive in the reference's k-grouped layout
+// (a dword per row and k-group: 4 x fp8 or 8 x fp4), which is already coalesced along the rows: both go straight to operand
+// registers through buffer loads, no LDS.  FMT: 0 = E4M3 (MXHF8), 1 = E5M2 (MXBF8), 4 = E2M1 (MXFP4).  Exact tiles, k % 64 == 0.
+// HBM bytes per 64^3 fp4 problem: 2 x 2 KiB operands + 256 B of scales + 16 KiB of f32 C.
+// ------------------------------------------------------------------------------------------------
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int MT, int NT, int FMT>
+__global__ __launch_bounds__(256) void gemm_mx_stream_kernel(GemmArgs p) {
+  constexpr int NDW = (FMT == 4) ? 4 : 8;                  // dwords (k-groups) per lane and 64-deep step
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  f32x16 acc[MT][NT];
+  TileCtx tc[MT][NT];
+  static_for<MT * NT>([&](auto idx) {
+    constexpr int mt = idx.value / NT, nt = idx.value % NT;
+    tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h; tc[mt][nt].ivalid = true;
+    tile_init<true, true>(acc[mt][nt], p, q, tc[mt][nt]);
+  });
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  unsigned int voffA[NDW], voffB[NDW];
+#pragma unroll
+  for (int e = 0; e < NDW; ++e) {
+    // k-group (one dword) held in operand register e of this lane.  4-bit: the lane half h owns the whole 32-deep block h (4 dwords).
+    // 8-bit: registers 0-3 belong to block 0 and 4-7 to block 1, each half of the wave holding 16 k of either block (measured: with
+    // per-block scales, "all 32 k of block h in lane half h" gives wrong sums); the scale of block b still comes from lane half b.
+    const unsigned int kg = (FMT == 4) ? (unsigned int)(4 * h + e) : (unsigned int)(8 * (e >> 2) + 4 * h + (e & 3));
+    voffA[e] = (kg * lda + (unsigned int)li) * 4u; voffB[e] = (kg * ldb + (unsigned int)li) * 4u;
+  }
+  const int ksteps = p.k >> 6;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)job.i0), rb = wave_rsrc(br + 4ull * (unsigned long long)job.j0);
+    const __amdgpu_buffer_rsrc_t rsa = wave_rsrc(mx_scale_base(p, job.bidx, r, false) + (unsigned long long)job.i0);
+    const __amdgpu_buffer_rsrc_t rsb = wave_rsrc(mx_scale_base(p, job.bidx, r, true) + (unsigned long long)job.j0);
+    for (int kc = 0; kc < ksteps; ++kc) {
+      i32x8 af[MT], bf[NT];
+      int sa[MT], sb[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        sa[mt] = (int)__builtin_amdgcn_raw_buffer_load_b8(rsa, h * (int)lda + li + 32 * mt, 2 * kc * (int)lda, 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[mt][e] = (e < NDW) ? (int)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)voffA[e < NDW ? e : 0] + 128 * mt, 2 * NDW * kc * (int)lda * 4, 0) : 0;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        sb[nt] = (int)__builtin_amdgcn_raw_buffer_load_b8(rsb, h * (int)ldb + li + 32 * nt, 2 * kc * (int)ldb, 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bf[nt][e] = (e < NDW) ? (int)__builtin_amdgcn_raw_buffer_load_b32(rb, (int)voffB[e < NDW ? e : 0] + 128 * nt, 2 * NDW * kc * (int)ldb * 4, 0) : 0;
+      }
+      static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bf[nt], af[mt], acc[mt][nt], FMT, FMT, 0, sb[nt], 0, sa[mt]); });
+    }
+  }
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<true, true>(acc[mt][nt], p, q, tc[mt][nt]); });
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side selection
 // ------------------------------------------------------------------------------------------------
 bool gemm_supported(const libxsmm_gemm_descriptor& d) {
@@ -1323,6 +1425,16 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d) {
     if (ta8 ? (d.lda < d.k) : (d.lda < d.m)) return false;
     if (tb8 ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
     return d.ldc >= d.m;
+  }
+  if ((d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8) && d.b_type == d.a_type) {
+    // MX x MX -> f32 [ref: gemm ref :2620-2790]: A in VNNI, B in VNNI and transposed, no address/offset batch-reduce, no fused ops [:836-855]
+    const unsigned int flx = d.flags;
+    if (d.c_type != LIBXSMM_DATATYPE_F32 || d.comp_type != LIBXSMM_DATATYPE_F32) return false;      // MX-typed outputs are not built
+    const unsigned int need = LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_TRANS_B;
+    if ((flx & need) != need || (flx & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_VNNI_C | LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT |
+        LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET))) return false;
+    if ((d.k % 32) != 0 || d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    return d.lda >= d.m && d.ldb >= d.n && d.ldc >= d.m;
   }
   if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {   // MXFP4 weights x bf16/f32 activations [ref: gemm ref :457-465, :949-1008; names libxsmm_main.c:1829-1848]
     const unsigned int flx = d.flags;
@@ -1358,7 +1470,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d) {
   return true;
 }
 
-enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2, P_MX4_1x1, P_MX4_2x2 };
+enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2, P_MX4_1x1, P_MX4_2x2, P_MXMX_1x1, P_MXMX_2x2 };
 struct GemmPlan { GemmPath path; bool exact; };
 
 static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, int b_type, int c_type, int vnni_c) {
@@ -1367,6 +1479,12 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
   const bool va = flags & LIBXSMM_GEMM_FLAG_VNNI_A, vb = flags & LIBXSMM_GEMM_FLAG_VNNI_B;
   (void)c_type;
   if (vnni_c || k <= 0) return pl;
+  if ((a_type == LIBXSMM_DATATYPE_MXFP4X2 || a_type == LIBXSMM_DATATYPE_MXBF8 || a_type == LIBXSMM_DATATYPE_MXHF8) && b_type == a_type) {
+    if ((m % 32) || (n % 32) || (k % 64)) return pl;
+    pl.exact = true;
+    pl.path = ((m % 64) == 0 && (n % 64) == 0) ? P_MXMX_2x2 : P_MXMX_1x1;
+    return pl;
+  }
   if (a_type == LIBXSMM_DATATYPE_MXFP4X2) {
     if (b_type != LIBXSMM_DATATYPE_BF16 || (m % 32) || (n % 32) || (k % 32)) return pl;
     pl.exact = true;
@@ -1421,6 +1539,8 @@ static const char* path_name(GemmPath p) {
     case P_I8_2x2: return "gemm_i8_stream_kernel<2,2>";
     case P_MX4_1x1: return "gemm_mxfp4_stream_kernel<1,1>";
     case P_MX4_2x2: return "gemm_mxfp4_stream_kernel<2,2>";
+    case P_MXMX_1x1: return "gemm_mx_stream_kernel<1,1>";
+    case P_MXMX_2x2: return "gemm_mx_stream_kernel<2,2>";
     default: return "gemm_generic_kernel";
   }
 }
@@ -1540,6 +1660,28 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
       break;
+    case P_MXMX_1x1: case P_MXMX_2x2: {
+      // operands are read as dwords, scales as bytes: any alignment of the leading dimensions works; bases dword aligned; offsets < 4 GiB
+      const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
+        (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0);
+      const bool ok = !a.list_a && (bits & 3ull) == 0 && (long long)a.lda * a.k < (1ll << 31) && (long long)a.ldb * a.k < (1ll << 31);
+      if (ok) {
+        const int fmt = a.a_type == LIBXSMM_DATATYPE_MXFP4X2 ? 4 : (a.a_type == LIBXSMM_DATATYPE_MXBF8 ? 1 : 0);
+        const bool big = pl.path == P_MXMX_2x2;
+        grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
+#define LAUNCH_MX_(MT_, NT_) do { \
+          if (fmt == 4) hipLaunchKernelGGL((gemm_mx_stream_kernel<MT_, NT_, 4>), grid, dim3(256), 0, st, a); \
+          else if (fmt == 1) hipLaunchKernelGGL((gemm_mx_stream_kernel<MT_, NT_, 1>), grid, dim3(256), 0, st, a); \
+          else hipLaunchKernelGGL((gemm_mx_stream_kernel<MT_, NT_, 0>), grid, dim3(256), 0, st, a); } while (0)
+        if (big) LAUNCH_MX_(2, 2); else LAUNCH_MX_(1, 1);
+#undef LAUNCH_MX_
+        break;
+      }
+      if (kernel_name) *kernel_name = "gemm_generic_kernel";
+      const long long gblocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
+      hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)gblocks), dim3(64, 4), 0, st, a);
+      break;
+    }
     case P_MX4_1x1: case P_MX4_2x2: {
       // B columns 16-byte aligned (LDS-DMA); A and the scales are read byte-wise (any alignment); offsets inside a tile < 4 GiB
       const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)((long long)a.ldb * 2);

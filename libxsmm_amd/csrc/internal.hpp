@@ -77,6 +77,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;                             // set by launch_gemm for the tile size of the chosen kernel
   float scf;                                        // 8-bit GEMM with f32 output: scale read from c.tertiary on the host
   const char* a_scf; long long bs_scf;              // MXFP4 A: E8M0 scales (a.tertiary; a pointer list in ADDRESS mode) and their batch stride
+  const char* b_scf; long long bs_bscf;             // MX x MX: the scales of B (b.tertiary)
 };
 
 struct MeltwArgs {

@@ -291,7 +291,16 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     if (!p->c.tertiary) { set_error(-2, "8-bit GEMM with f32 output needs the scale in c.tertiary"); return; }   // [ref: gemm ref :591-592]
     a.scf = *(const float*)p->c.tertiary;
   }
-  if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {
+  if ((d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8) && d.b_type == d.a_type) {
+    // MX x MX: scales of A in a.tertiary, of B in b.tertiary [ref: gemm ref :577-583]; a batched launch steps them with their operand:
+    // one scale byte per 32 elements
+    if (!p->a.tertiary || !p->b.tertiary) { set_error(-2, "MX x MX GEMM needs the E8M0 scales in a.tertiary and b.tertiary"); return; }
+    if (b.la) { set_error(-3, "MX x MX GEMM: pointer-list batches carry no scale lists; use the strided batch"); return; }
+    const long long epb = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
+    if (b.count > 1 && (((b.s[0] | b.s[1]) * epb) % 32) != 0) { set_error(-3, "MX x MX GEMM: batch strides must cover whole 32-element scale blocks"); return; }
+    a.a_scf = (const char*)p->a.tertiary; a.bs_scf = b.s[0] * epb / 32;
+    a.b_scf = (const char*)p->b.tertiary; a.bs_bscf = b.s[1] * epb / 32;
+  } else if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {
     // E8M0 scales of the MXFP4 weights travel in a.tertiary (a list of per-block pointers in ADDRESS mode) [ref: gemm ref :565-569].
     // A batched launch steps them like A: the pointer list by sa, the scale bytes by sa * 2 / 32 (one byte per 32 weights).
     if (!p->a.tertiary) { set_error(-2, "MXFP4 GEMM needs the E8M0 scales in a.tertiary"); return; }

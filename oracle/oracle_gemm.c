@@ -268,6 +268,59 @@ static void contract_mxfp4(const gemm_view* v, const libxsmm_gemm_param* p, void
   }
 }
 
+/* MX x MX GEMM (OCP microscaling, E8M0 scale per 32 k and row): A and B in the SAME k-grouped layout -- a dword per (row, k-group):
+ * MXFP8 (MXBF8 = E5M2, MXHF8 = E4M3) [k/4][ld][4 bytes], MXFP4 [k/8][ld][4 bytes = 8 nibbles, low nibble first]; B is "VNNI and
+ * transposed", i.e. indexed by the column j with ldb >= n.  Scales: a.tertiary [k/32][lda], b.tertiary [k/32][ldb].  C f32 =
+ * (beta ? C : 0) + sum over (r, 32-blocks) of partial * scale_a * scale_b, where fp8 adds the 4 products of a k-group high k
+ * first and fp4 adds 8 products ascending; batch-reduce elements are contiguous blocks (r * ld * k elements), the reference's
+ * MX x MX path knows no other addressing [ref: gemm ref :2620-2665 (fp8), :2731-2785 (fp4), :836-845]. */
+static int is_mxmx(const oracle_gemm_desc* d) {
+  return d->b_type == d->a_type && (d->a_type == LIBXSMM_DATATYPE_MXFP4X2 || d->a_type == LIBXSMM_DATATYPE_MXBF8 || d->a_type == LIBXSMM_DATATYPE_MXHF8);
+}
+static float e8m0(unsigned char s) { union { unsigned int u; float f; } cv; cv.u = ((unsigned int)s) << 23; return cv.f; }
+static void contract_mxmx(const gemm_view* v, const libxsmm_gemm_param* p, float* cmat, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const unsigned char* a = (const unsigned char*)p->a.primary; const unsigned char* b = (const unsigned char*)p->b.primary;
+  const unsigned char* sa = (const unsigned char*)p->a.tertiary; const unsigned char* sb = (const unsigned char*)p->b.tertiary;
+  const long long lda = d->lda, ldb = d->ldb, k = d->k;
+  const int fp4 = (d->a_type == LIBXSMM_DATATYPE_MXFP4X2), hf8 = (d->a_type == LIBXSMM_DATATYPE_MXHF8);
+  long long i, j, r, s, g, k2;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    float acc = 0.0f;
+    float* c = cmat + j * d->ldc + i;
+    if (beta0) *c = 0.0f;
+    for (r = 0; r < v->br; ++r) {
+      if (fp4) {
+        for (s = 0; s < k / 32; ++s) {
+          const float sca = e8m0(sa[r * lda * (k / 32) + s * lda + i]), scb = e8m0(sb[r * ldb * (k / 32) + s * ldb + j]);
+          for (g = 0; g < 4; ++g) {
+            float tmp = 0.0f;
+            for (k2 = 0; k2 < 8; ++k2) {
+              const long long kblk = s * 4 + g, byte = k2 / 2;
+              const unsigned char ba = a[r * lda * (k / 2) + kblk * lda * 4 + i * 4 + byte], bb = b[r * ldb * (k / 2) + kblk * ldb * 4 + j * 4 + byte];
+              const float prod = mxfp4_value((k2 & 1) ? (ba >> 4) : (ba & 15)) * mxfp4_value((k2 & 1) ? (bb >> 4) : (bb & 15));
+              tmp = tmp + prod;
+            }
+            { float t2 = tmp * sca; t2 = t2 * scb; acc = acc + t2; }
+          }
+        }
+      } else {
+        for (s = 0; s < k / 4; ++s) {
+          const float sca = e8m0(sa[r * lda * (k / 32) + (s / 8) * lda + i]), scb = e8m0(sb[r * ldb * (k / 32) + (s / 8) * ldb + j]);
+          float tmp = 0.0f;
+          for (k2 = 3; k2 >= 0; --k2) {
+            const unsigned char ba = a[r * lda * k + s * lda * 4 + i * 4 + k2], bb = b[r * ldb * k + s * ldb * 4 + j * 4 + k2];
+            const float prod = (hf8 ? oracle_hf8_to_f32(ba) : oracle_bf8_to_f32(ba)) * (hf8 ? oracle_hf8_to_f32(bb) : oracle_bf8_to_f32(bb));
+            tmp = tmp + prod;
+          }
+          { float t2 = tmp * sca; t2 = t2 * scb; acc = acc + t2; }
+        }
+      }
+    }
+    *c = *c + acc;
+  }
+}
+
 void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   gemm_view v;
   const int is_ext = (d->flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) ? 1 : 0;
@@ -283,6 +336,7 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
   if (is_int8(d->a_type) && is_int8(d->b_type)) { contract_int8(&v, p, cptr, beta0); return; }
   if (is_fp8(d->a_type) && d->b_type == d->a_type && d->c_type == LIBXSMM_DATATYPE_F32) { contract_fp8(&v, (float*)cptr, beta0); return; }
+  if (is_mxmx(d) && d->c_type == LIBXSMM_DATATYPE_F32) { contract_mxmx(&v, p, (float*)cptr, beta0); return; }
   if (d->a_type == LIBXSMM_DATATYPE_MXFP4X2) { contract_mxfp4(&v, p, cptr, beta0); return; }
 
   {

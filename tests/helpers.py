@@ -54,6 +54,8 @@ def rand_values(rng: np.random.Generator, count: int, dt: int) -> np.ndarray:
         return rng.integers(0, 19, count).astype(NP_OF[dt])
     if dt == DT.MXFP4X2:                    # two E2M1 codes per byte, all 256 combinations
         return rng.integers(0, 256, count).astype(np.uint8)
+    if dt in (DT.MXBF8, DT.MXHF8):          # the element encodings are plain E5M2 / E4M3
+        return rand_values(rng, count, DT.BF8 if dt == DT.MXBF8 else DT.HF8)
     if dt in (DT.BF8, DT.HF8):              # finite 8-bit floats in [1/8, 2) with random sign, plus a few zeros: the magnitude range of the
         bias, mbits = (15, 2) if dt == DT.BF8 else (7, 3)     # reference driver's data (multiples of 0.1 in [-0.5, 0.5]); FP8_WIDE widens it
         lo = max(-14 if FP8_WIDE else -3, -bias)           # exponent field 0 = subnormals / zero
@@ -104,12 +106,17 @@ class GemmCase:
         self.colbias, self.act = colbias, act
         self.ext = colbias or act != 0
         self.a_elems = self.lda * (m if ta else k)
-        self.mx = a_type == DT.MXFP4X2          # packed E2M1 pairs: lda bytes per k-pair, one E8M0 scale per (32 k, row)
-        if self.mx:
+        self.mxmx = a_type in (DT.MXFP4X2, DT.MXBF8, DT.MXHF8) and self.b_type == a_type     # both operands microscaled
+        self.mx = a_type == DT.MXFP4X2 and not self.mxmx   # packed E2M1 pairs: lda bytes per k-pair, one E8M0 scale per (32 k, row)
+        if self.mx or self.mxmx:
             assert k % 32 == 0 and not ta
-            self.a_elems = self.lda * k // 2
+            self.a_elems = self.lda * k // (2 if a_type == DT.MXFP4X2 else 1)
             self.s_elems = self.lda * (k // 32)
         self.b_elems = self.ldb * (k if tb else n)
+        if self.mxmx:                           # B in A's layout, indexed by the column: [k-group][ldb][4 bytes]
+            assert tb and self.ldb >= n
+            self.b_elems = self.ldb * k // (2 if a_type == DT.MXFP4X2 else 1)
+            self.sb_elems = self.ldb * (k // 32)
         self.c_elems = self.ldc * (n + (n % 2 if flags & GEMM_FLAG.VNNI_C else 0))
         asz, csz, bsz = capi.DT_SIZE[a_type], capi.DT_SIZE[self.c_type], capi.DT_SIZE[self.b_type]
         nbr = br_count if br_type != capi.BR_NONE else 1
@@ -126,10 +133,14 @@ class GemmCase:
         self.bs_c = self.c_elems * csz
         self.bs_d = m * csz if colbias else 0
         self.br_stride_a = self.a_elems * asz
-        if self.mx:                             # scales in a narrow band around 1.0 with a few exact zeros (scale byte 0 decodes to 0.0f)
+        if self.mx or self.mxmx:                # scales in a narrow band around 1.0 with a few exact zeros (scale byte 0 decodes to 0.0f)
             self.S = rng.integers(124, 131, batch * nbr * self.s_elems).astype(np.uint8)
-            self.S[rng.random(self.S.size) < 0.02] = 0
+            if self.mx:
+                self.S[rng.random(self.S.size) < 0.02] = 0
             self.bs_s = nbr * self.s_elems
+        if self.mxmx:
+            self.SB = rng.integers(124, 131, (1 if shared_b else batch) * nbr * self.sb_elems).astype(np.uint8)
+            self.bs_sb = 0 if shared_b else nbr * self.sb_elems
         self.br_stride_b = self.b_elems * bsz
         # OFFSET mode: a permutation of the nbr blocks (byte offsets), shared by the batch
         perm = rng.permutation(nbr)
@@ -163,10 +174,13 @@ class GemmCase:
                                  self.comp_type, f, self.br_stride_a, self.br_stride_b, int(self.colbias), self.act)
 
     # ---- param construction over arbitrary buffers ----------------------------------------------
-    def make_param(self, A, B, Cbuf, D=None, mask=None, offs=None, addr=None, brc=None, batch_index=0, S=None):
+    def make_param(self, A, B, Cbuf, D=None, mask=None, offs=None, addr=None, brc=None, batch_index=0, S=None, SB=None):
         """A, B, Cbuf, D, mask: numpy arrays or torch tensors; returns (param, keepalive)."""
         p = capi.GemmExtParam() if self.ext else capi.GemmParam()
         keep = []
+        if self.mxmx:
+            p.a.tertiary = ptr(self.S if S is None else S) + batch_index * self.bs_s
+            p.b.tertiary = ptr(self.SB if SB is None else SB) + batch_index * self.bs_sb
         if self.mx:                             # a.tertiary: the scales, or (ADDRESS mode) a list of per-block scale pointers
             sc = self.S if S is None else S
             if self.br_type == capi.BR_ADDRESS:
@@ -264,7 +278,8 @@ class GemmCase:
         def up(x):
             return None if x is None else torch.from_numpy(x.view(np.int16) if x.dtype == np.uint16 else x).to(dev)
         A, B, Cbuf, D = up(self.A), up(self.B), up(self.C0.copy()), up(self.D)
-        S = up(self.S) if self.mx else None
+        S = up(self.S) if (self.mx or self.mxmx) else None
+        SB = up(self.SB) if self.mxmx else None
         mask = torch.zeros(self.batch * self.mask_bytes, dtype=torch.uint8, device=dev) if self.act == 2 else None
         offs = (up(self.offs_a), up(self.offs_b))
         addr = None
@@ -274,7 +289,7 @@ class GemmCase:
         handle = self.dispatch(api)
         assert handle, "dispatch returned NULL"
         if batched and self.batch > 1:
-            p, keep = self.make_param(A, B, Cbuf, D, mask, offs, addr, S=S)
+            p, keep = self.make_param(A, B, Cbuf, D, mask, offs, addr, S=S, SB=SB)
             sa = self.nbr * 8 if self.br_type == capi.BR_ADDRESS else self.bs_a
             sb = (self.nbr * 8 if self.br_type == capi.BR_ADDRESS else self.bs_b)
             if self.ext:
@@ -283,7 +298,7 @@ class GemmCase:
                 api.hip_gemm_batch_strided(handle, C.byref(p), self.batch, sa, sb, self.bs_c)
         else:
             for b in range(self.batch):
-                p, keep = self.make_param(A, B, Cbuf, D, mask, offs, addr, batch_index=b, S=S)
+                p, keep = self.make_param(A, B, Cbuf, D, mask, offs, addr, batch_index=b, S=S, SB=SB)
                 capi.Api.call(handle, p)
         api.hip_sync()
         api.check()

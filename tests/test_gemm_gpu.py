@@ -412,3 +412,44 @@ def test_mxfp4_dispatch_rules():
     capi.Api.call(h, p)
     assert api.hip_get_last_error() != 0 and b"a.tertiary" in api.hip_get_last_error_string()
     api.hip_clear_last_error()
+
+
+# MX x MX GEMMs: both operands microscaled (E2M1 / E5M2 / E4M3 elements, E8M0 scale per 32 k and row), f32 output
+MXMX = F.VNNI_A | F.VNNI_B | F.TRANS_B
+SHAPES_MXMX = [
+    dict(m=64, n=64, k=64, a_type=DT.MXFP4X2, batch=5),
+    dict(m=64, n=64, k=128, a_type=DT.MXFP4X2, beta=1, batch=3, br_type=capi.BR_STRIDE, br_count=2),
+    dict(m=32, n=96, k=64, a_type=DT.MXBF8, batch=4, lda=40, ldb=100, ldc=36),
+    dict(m=96, n=32, k=192, a_type=DT.MXHF8, br_type=capi.BR_STRIDE, br_count=2, beta=1, batch=2),
+    dict(m=64, n=64, k=64, a_type=DT.MXHF8, batch=3),
+    dict(m=32, n=32, k=32, a_type=DT.MXFP4X2, batch=2),                    # k not a multiple of 64: generic kernel, bit-identical
+    dict(m=17, n=9, k=64, a_type=DT.MXBF8, lda=20, ldb=12, ldc=24, beta=1, batch=2),
+    dict(m=33, n=5, k=32, a_type=DT.MXHF8, lda=34),
+]
+
+
+@pytest.mark.parametrize("kw", SHAPES_MXMX, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+@pytest.mark.parametrize("batched", [True, False], ids=["batched", "loop"])
+def test_mxmx_gemm_matches_oracle(kw, batched):
+    api = capi.load()
+    case = GemmCase(seed=43, b_type=kw["a_type"], c_type=DT.F32, flags=MXMX, **kw)
+    got, _, handle = case.run_gpu(batched=batched)
+    ref, _ = case.run_oracle()
+    name = api.hip_kernel_name(handle, 1 if (case.batch > 1 and batched) else 0).decode()
+    fast = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 64 == 0
+    assert ("gemm_mx_stream_kernel" in name) == bool(fast), name
+    if fast:      # element products and block scales are exact in f32; the matrix core sums a 32-deep block in its own order
+        assert normf_rel(case.valid_region(ref), case.valid_region(got), DT.F32) < TOL_F32, name
+    else:
+        assert np.array_equal(case.valid_region(ref), case.valid_region(got)), name
+
+
+def test_mxmx_dispatch_rules():
+    api = capi.load()
+    sh = lambda t, c=DT.F32, k=64: capi.gemm_shape(32, 32, k, 32, 32, 32, t, t, c, DT.F32)   # noqa: E731
+    for t in (DT.MXFP4X2, DT.MXBF8, DT.MXHF8):
+        assert api.dispatch_gemm(sh(t), MXMX, 0)
+        assert api.dispatch_gemm(sh(t), F.VNNI_A | F.VNNI_B, 0) is None            # B must be in A's layout (VNNI and transposed)
+        assert api.dispatch_gemm(sh(t, k=48), MXMX, 0) is None
+        assert api.dispatch_brgemm(sh(t), MXMX, 0, capi.br_config(capi.BR_ADDRESS, 0, 0, 0)) is None      # [ref: gemm ref :836-845]
+    assert api.dispatch_gemm(sh(DT.MXFP4X2, c=DT.MXFP4X2), MXMX, 0) is None        # MX-typed outputs: not built

@@ -57,6 +57,11 @@ GEMM_CASES = [
     dict(m=32, n=32, k=32, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3),
     dict(m=16, n=8, k=64, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=4),
     dict(m=16, n=8, k=32, a_type=DT.MXFP4X2, b_type=DT.F32, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_ADDRESS, br_count=2),
+    # MX x MX (both operands microscaled: E2M1, E5M2, E4M3 elements with E8M0 block scales), f32 output
+    dict(m=32, n=32, k=64, a_type=DT.MXFP4X2, b_type=DT.MXFP4X2, c_type=DT.F32, flags=F.VNNI_A | F.VNNI_B | F.TRANS_B),
+    dict(m=17, n=9, k=32, a_type=DT.MXFP4X2, b_type=DT.MXFP4X2, c_type=DT.F32, flags=F.VNNI_A | F.VNNI_B | F.TRANS_B, lda=20, ldb=12, ldc=24, beta=1),
+    dict(m=32, n=32, k=64, a_type=DT.MXBF8, b_type=DT.MXBF8, c_type=DT.F32, flags=F.VNNI_A | F.VNNI_B | F.TRANS_B, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=16, n=24, k=32, a_type=DT.MXHF8, b_type=DT.MXHF8, c_type=DT.F32, flags=F.VNNI_A | F.VNNI_B | F.TRANS_B, beta=1, lda=18, ldb=30),
 ]
 
 
@@ -70,7 +75,7 @@ def test_gemm_restatement_is_bit_identical_to_reference_c_kernel(kw, reference):
         assert np.array_equal(case.valid_mask_bits(m_or), case.valid_mask_bits(m_rf))
 
 
-@pytest.mark.parametrize("kw", [c for c in GEMM_CASES if not (c.get("a_type") == DT.BF16 and not (c.get("flags", 0) & F.VNNI_A))][:16] + GEMM_CASES[-6:],
+@pytest.mark.parametrize("kw", [c for c in GEMM_CASES if not (c.get("a_type") == DT.BF16 and not (c.get("flags", 0) & F.VNNI_A))][:16] + GEMM_CASES[-10:-4],
                          ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_gemm_restatement_within_reference_tolerance_of_its_cpu_jit(kw, reference):
     case = GemmCase(seed=7, **kw)

@@ -211,6 +211,33 @@ def brgemm_mxfp4(api, m, batch, c_dt=DT.BF16):
     return w
 
 
+def brgemm_mxmx(api, m, batch, dt=None):
+    """MX x MX -> f32 (both operands microscaled, every problem with its own operands), m = n = k: algorithmic bytes per problem =
+    2 * (m*m*bits/8 + m*m/32) (operands + scales) + 4*m*m (C)."""
+    dt = DT.MXFP4X2 if dt is None else dt
+    epb = 2 if dt == DT.MXFP4X2 else 1
+    ob, sb = m * m // epb, m * m // 32
+    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, dt, dt, DT.F32, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A | GEMM_FLAG.VNNI_B | GEMM_FLAG.TRANS_B, 0,
+                            capi.br_config(capi.BR_STRIDE, ob, ob, 0))
+    assert h
+    per = 2 * (ob + sb) + 4 * m * m
+    ns = nsets_for(batch * per)
+    mk = lambda n, lo, hi: torch.randint(lo, hi, (n,), device=DEV, dtype=torch.uint8)   # noqa: E731
+    As, Bs = [mk(batch * ob, 0, 256 if epb == 2 else 120) for _ in range(ns)], [mk(batch * ob, 0, 256 if epb == 2 else 120) for _ in range(ns)]
+    Sa, Sb = [mk(batch * sb, 124, 131) for _ in range(ns)], [mk(batch * sb, 124, 131) for _ in range(ns)]
+    Cs = [torch.zeros(batch * m * m, device=DEV, dtype=torch.float32) for _ in range(ns)]
+    brc = C.c_ulonglong(1)
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc)
+        p.a.tertiary, p.b.tertiary = Sa[s].data_ptr(), Sb[s].data_ptr(); ps.append(p)
+    name = {DT.MXFP4X2: "mxfp4", DT.MXBF8: "mxbf8", DT.MXHF8: "mxhf8"}[dt]
+    w = Work(api, f"stride-BRGEMM {name} x {name} -> f32 m=n=k={m} batch={batch} br=1 beta=0", 2.0 * m ** 3 * batch, float(batch * per), ns,
+             lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, ob, ob, 4 * m * m), lambda: api.hip_kernel_name(h, 1).decode())
+    w.keep = (As, Bs, Sa, Sb, Cs, ps, brc)
+    return w
+
+
 def meltw_relu_tiles(api, batch=2 ** 17, m=64):
     """config #5 un-fused: bias-add (binary, col-bcast) then ReLU (unary) over bf16 64x64 tiles."""
     hb = api.dispatch_meltw_binary(BINARY.ADD, capi.BinaryShape(m, m, m, m, m, DT.BF16, DT.BF16, DT.BF16, DT.F32), BINARY_FLAG.BCAST_COL_IN_0)
@@ -444,7 +471,8 @@ def main():
                    lambda: brgemm(api, 32, "f32", 1, br=4096), lambda: brgemm(api, 64, "bf16", 1, br=4096),
                    lambda: brgemm_i8(api, 64, 2 ** 17, ua=True), lambda: brgemm_i8(api, 64, 2 ** 17, ua=False)]     # config #2 variant B: one long chain
     if "mx" in only:
-        makers += [lambda: brgemm_mxfp4(api, 64, 2 ** 17), lambda: brgemm_mxfp4(api, 32, 2 ** 18, c_dt=DT.F32)]
+        makers += [lambda: brgemm_mxfp4(api, 64, 2 ** 17), lambda: brgemm_mxfp4(api, 32, 2 ** 18, c_dt=DT.F32),
+                   lambda: brgemm_mxmx(api, 64, 2 ** 17), lambda: brgemm_mxmx(api, 64, 2 ** 16, DT.MXHF8), lambda: brgemm_mxmx(api, 128, 2 ** 15)]
     if "fused" in only:
         makers += [lambda: brgemm(api, 64, "bf16", 2 ** 17, fused=1)]
     if "csr" in only:
