@@ -205,6 +205,13 @@ __global__ __launch_bounds__(256) void meltw_unary_kernel(MeltwArgs p) {
       ((GM float*)out)[i + (long long)j * p.ldo] = v * p.scalar_f32;
       return;
     }
+    case LIBXSMM_MELTW_TYPE_UNARY_DUMP: {                       // identity that also lands in out.secondary, same ldo and type [ref: :2478-2494]
+      if (!e.valid) return;
+      const float x = mw_load(in, bc_index(bc, i, j, p.ldi), p.in0_type);
+      mw_store(out, i + (long long)j * p.ldo, p.out_type, x);
+      mw_store((gptr)p.aux_out + (long long)e.bidx * p.bs_aux, i + (long long)j * p.ldo, p.out_type, x);
+      return;
+    }
     case LIBXSMM_MELTW_TYPE_UNARY_UNZIP: {                      // [ref: :2419-2432]
       if (!e.valid) return;
       const unsigned int u = ((GM const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
@@ -874,7 +881,7 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
       case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID: case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID_INV: case LIBXSMM_MELTW_TYPE_UNARY_GELU: case LIBXSMM_MELTW_TYPE_UNARY_GELU_INV:
       case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: case LIBXSMM_MELTW_TYPE_UNARY_INC: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT:
       case LIBXSMM_MELTW_TYPE_UNARY_EXP: case LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV:
-      case LIBXSMM_MELTW_TYPE_UNARY_ELU: case LIBXSMM_MELTW_TYPE_UNARY_ELU_INV: return true;
+      case LIBXSMM_MELTW_TYPE_UNARY_ELU: case LIBXSMM_MELTW_TYPE_UNARY_ELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_DUMP: return true;
       default: return false;
     }
   }
@@ -996,7 +1003,7 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       const bool simple = bc == BC_NONE && a.in0_type == a.out_type && is_float_type(a.in0_type) && (a.m % 4 == 0) && (a.ldi % 4 == 0) && (a.ldo % 4 == 0) &&
         !(a.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && a.type != LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR &&
         a.type != LIBXSMM_MELTW_TYPE_UNARY_RELU_INV && a.type != LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV && a.type != LIBXSMM_MELTW_TYPE_UNARY_ELU_INV &&
-        a.type != LIBXSMM_MELTW_TYPE_UNARY_UNZIP;
+        a.type != LIBXSMM_MELTW_TYPE_UNARY_UNZIP && a.type != LIBXSMM_MELTW_TYPE_UNARY_DUMP;
       const int esz = (a.in0_type == LIBXSMM_DATATYPE_F32) ? 4 : 2;
       const bool aligned = (((size_t)a.in0 | (size_t)a.out | (size_t)a.bs_in0 | (size_t)a.bs_out) % (size_t)(4 * esz)) == 0;
       if (simple && aligned) {

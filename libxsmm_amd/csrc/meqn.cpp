@@ -40,7 +40,7 @@ struct Equation {
   std::map<std::array<int, 4>, const void*> handles;   // dispatched (m, n, ld, type) -> handle
 };
 
-struct EqnStep { MeltwArgs args; int src[3]; int node; int alpha_from_op; };   // src: >=0 input position, < 0: -(slot+1)
+struct EqnStep { MeltwArgs args; int src[3]; int node; int alpha_from_op; int dump_from_op; };   // src: >=0 input position, < 0: -(slot+1)
 struct EqnPlan {
   JitKernel* fused = nullptr;       // whole tree as ONE generated kernel (element-wise trees), else the step chain below
   std::vector<int> fused_inputs;    // input positions in kernel-argument order
@@ -327,6 +327,10 @@ void run_meqn(EqnPlan* plan, const void* param) {
       if (!p->ops_args || !p->ops_args[st.alpha_from_op].primary) { set_error(-2, "matrix equation: op argument %d is NULL", st.alpha_from_op); return; }
       a.scalar_f32 = *(const float*)p->ops_args[st.alpha_from_op].primary;
     }
+    if (st.dump_from_op >= 0) {
+      if (!p->ops_args || !p->ops_args[st.dump_from_op].primary) { set_error(-2, "matrix equation: DUMP destination (op argument %d) is NULL", st.dump_from_op); return; }
+      a.aux_out = p->ops_args[st.dump_from_op].primary;
+    }
     err = launch_meltw(a, rt_stream(), &kname);
   }
   rt_finish_launch(err, kname ? kname : "meqn");
@@ -415,7 +419,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       nd.ld = out.ld; nd.type = out.type;
     } else plan->slot_of[id] = plan->nslots++;
     EqnStep st; std::memset(&st.args, 0, sizeof(st.args));
-    st.node = id; st.alpha_from_op = -1; st.src[0] = st.src[1] = st.src[2] = INT32_MIN;
+    st.node = id; st.alpha_from_op = -1; st.dump_from_op = -1; st.src[0] = st.src[1] = st.src[2] = INT32_MIN;
     MeltwArgs& a = st.args;
     a.nbatch = 1; a.flags = nd.flags; a.type = nd.op; a.comp_type = nd.dtype; a.out_type = nd.type; a.ldo = nd.ld;
     a.in0_type = a.in1_type = a.in2_type = LIBXSMM_DATATYPE_UNSUPPORTED;
@@ -432,11 +436,12 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       a.operation = LIBXSMM_MELTW_OPERATION_UNARY;
       if (is_reduce(nd.op)) { a.m = ch[0]->m; a.n = ch[0]->n; } else { a.m = nd.m; a.n = nd.n; }     // [ref: matequation ref :121-125]
       if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || nd.op == LIBXSMM_MELTW_TYPE_UNARY_ELU) st.alpha_from_op = nd.op_arg_pos;
+      if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_DUMP) st.dump_from_op = nd.op_arg_pos;       // second destination: ops_args[pos].primary [ref: matequation ref :58-60]
       d = libxsmm_meltw_descriptor_init2(&blob, (libxsmm_datatype)a.in0_type, LIBXSMM_DATATYPE_UNSUPPORTED, LIBXSMM_DATATYPE_UNSUPPORTED, (libxsmm_datatype)nd.dtype,
         (libxsmm_datatype)nd.type, a.m, a.n, a.ldi, a.ldo, 0, 0, (unsigned short)nd.flags, (unsigned short)nd.op, LIBXSMM_MELTW_OPERATION_UNARY);
       // ops with side channels only make sense as standalone TPPs here
       if ((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER || nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER ||
-          nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP || nd.op == LIBXSMM_MELTW_TYPE_UNARY_DUMP || nd.op == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR ||
+          nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP || (nd.op == LIBXSMM_MELTW_TYPE_UNARY_DUMP && nd.op_arg_pos < 0) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR ||
           nd.op == LIBXSMM_MELTW_TYPE_UNARY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) d = nullptr;
       // parameterised activations: the reference's equation generators do not apply ops_args to them (its CPU JIT leaves the
       // negative side unscaled), so there is no behaviour to be compatible with: refuse instead of guessing

@@ -395,6 +395,8 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR) {
       if (!p->op.primary) { set_error(-2, "REPLICATE_COL_VAR needs the column count in op.primary"); return; }
       a.scalar_u64 = *(const unsigned long long*)p->op.primary;
+    } else if (t == LIBXSMM_MELTW_TYPE_UNARY_DUMP) {
+      if (!p->out.secondary) { set_error(-2, "DUMP needs the second destination in out.secondary"); return; }
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) {
       if (!p->out.secondary) { set_error(-2, "UNZIP needs the byte offset in out.secondary"); return; }
       a.scalar_u64 = *(const unsigned long long*)p->out.secondary;

@@ -192,3 +192,42 @@ def test_gpu_meqn_matches_oracle_composition(name, jit):
         assert normf_rel(_valid(ref2, out_shape), _valid(got2, out_shape), out_shape[3]) < 1e-6
     else:
         assert np.array_equal(_valid(got2, out_shape), _valid(ref2, out_shape))
+
+
+@pytest.mark.gpu
+def test_gpu_meqn_dump_writes_the_intermediate_to_the_op_argument():
+    """UNARY_DUMP inside a tree = identity whose value also lands in ops_args[op_arg_pos].primary (the intermediate's own
+    leading dimension and type) [ref: src/generator_matequation_reference_impl.c:58-60, mateltwise ref :2478-2494] -- the
+    mechanism equation_softmax.c uses to keep exp(x - max) for the backward pass."""
+    import torch
+    api = capi.load()
+    shapes, out_shape = [(M, N, LD, DT.F32), (M, N, LD, DT.F32)], (M, N, LD, DT.F32)
+    arrays = _inputs(shapes, 11)
+    idx = api.meqn_create()
+    assert api.meqn_push_back_binary_op(capi.MeqnMetadata(idx, -1), BINARY.MUL, DT.F32, 0) == 0
+    assert api.meqn_push_back_unary_op(capi.MeqnMetadata(idx, 1), UNARY.DUMP, DT.F32, 0) == 0
+    assert api.meqn_push_back_unary_op(capi.MeqnMetadata(idx, -1), UNARY.X2, DT.F32, 0) == 0
+    assert api.meqn_push_back_arg(capi.MeqnMetadata(idx, 0), capi.MeqnArgShape(*shapes[0]), SINGULAR) == 0
+    assert api.meqn_push_back_arg(capi.MeqnMetadata(idx, 1), capi.MeqnArgShape(*shapes[1]), SINGULAR) == 0
+    h = api.dispatch_meqn(idx, capi.MeqnArgShape(*out_shape))
+    assert h
+    dev = [torch.from_numpy(a.copy()).to("cuda:0") for a in arrays]
+    out = torch.zeros(LD * N, dtype=torch.float32, device="cuda:0")
+    dump = torch.full((M * N,), -7.0, dtype=torch.float32, device="cuda:0")          # the intermediate is M x N with ld = M
+    inputs = (capi.MatrixArg * 2)()
+    inputs[0].primary, inputs[1].primary = dev[0].data_ptr(), dev[1].data_ptr()
+    ops = (capi.MatrixOpArg * 2)()
+    ops[1].primary = dump.data_ptr()
+    p = capi.MeqnParam()
+    p.inputs, p.ops_args = inputs, ops
+    p.output.primary = out.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    a0, a1 = _valid(arrays[0], shapes[0]), _valid(arrays[1], shapes[1])
+    sq = a0 * a0
+    assert np.array_equal(dump.cpu().numpy().reshape(N, M), sq)
+    assert np.array_equal(_valid(out.cpu().numpy(), out_shape), sq * a1)
+    ops[1].primary = None                                                            # a missing destination is an error, not a fault
+    capi.Api.call(h, p)
+    assert api.hip_get_last_error() != 0
+    api.hip_clear_last_error()

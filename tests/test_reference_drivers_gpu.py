@@ -176,7 +176,17 @@ def test_reference_ternary_driver(args):
 
 
 # samples/equation/equation_simple.c -- M N ld datatype_mode(0 f32, 1 bf16) iters: five-argument element-wise + reduce/broadcast trees
-# (the other equation samples need node kinds this back end refuses: bitmask ReLU inside a tree, ZIP/UNZIP, DUMP, REUSE_IN_2_AS_OUT)
+# (equation_relu / _splitSGD / _bf16_x3_split need node kinds this back end refuses inside a tree: bitmask ReLU, ZIP/UNZIP; _simple_layernorm is BF8-only)
 @pytest.mark.parametrize("args", ["64 48 64 0 2", "64 48 64 1 2", "33 17 40 0 2"])
 def test_reference_equation_driver(args):
     check("equation_simple", *args.split())
+
+
+# samples/equation/equation_softmax.c -- S1 S2 S3 datatype_mode(0 f32, 1 bf16) pass(1 fwd, 2 bwd, 3 both) iters: reductions to a scalar, scalar
+# broadcasts, exp, reciprocal and UNARY_DUMP (the forward keeps exp(x - max) for the backward) in one tree.  The driver prints its norms
+# without judging them: the check-norm (relative L2 against its intrinsics implementation) is asserted here.
+@pytest.mark.parametrize("args,bound", [("4 8 16 0 3 2", 1e-5), ("8 16 32 0 1 2", 1e-5), ("8 16 32 1 1 2", 2e-2), ("4 8 16 1 2 2", 2e-2)])
+def test_reference_softmax_equation_driver(args, bound):
+    out = check("equation_softmax", *args.split())
+    norms = [float(x) for x in re.findall(r"Check-norm\s*:\s*([0-9.eE+-]+)", out)]
+    assert norms and max(norms) <= bound, out[-2000:]
