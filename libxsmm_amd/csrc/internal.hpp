@@ -175,6 +175,8 @@ const void* rt_new_meqn_handle(EqnPlan* plan);   // caller-independent handle ow
 void rt_finish_launch(int err, const char* kernel_name);
 void* rt_workspace(size_t nbytes);
 bool rt_ready();
+const void* rt_small_host_input(const void* p, size_t nbytes);   // tiny operands (scalars) may live in host memory: staged if they do
+void rt_scratch_reset();
 void rt_note(const char* what, int a, int b, int c);      // verbosity >= 1: why a request was refused
 void* rt_stream();
 

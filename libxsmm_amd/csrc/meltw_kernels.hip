@@ -862,7 +862,7 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
     if (t == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT || xform_mode(t, &v) != 0 ||
         t == LIBXSMM_MELTW_TYPE_UNARY_GATHER || t == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) return sz == 1 || sz == 2 || sz == 4 || sz == 8;
     if (is_reduce_type(t)) return is_float_type(d.in0_type) && is_float_type(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP));
-    if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) return d.in0_type == LIBXSMM_DATATYPE_F32 && d.out_type == LIBXSMM_DATATYPE_BF16;
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) return d.in0_type == LIBXSMM_DATATYPE_F32 && (d.out_type == LIBXSMM_DATATYPE_BF16 || d.out_type == LIBXSMM_DATATYPE_U16 || d.out_type == LIBXSMM_DATATYPE_I16);
     const auto is_qint = [](int x) { return x == LIBXSMM_DATATYPE_I8 || x == LIBXSMM_DATATYPE_I16 || x == LIBXSMM_DATATYPE_I32; };
     if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT) return d.in0_type == LIBXSMM_DATATYPE_F32 && is_qint(d.out_type);       // [ref: :2195-2240]
     if (t == LIBXSMM_MELTW_TYPE_UNARY_DEQUANT) return is_qint(d.in0_type) && d.out_type == LIBXSMM_DATATYPE_F32;     // [ref: :2330-2360]

@@ -40,10 +40,11 @@ struct Equation {
   std::map<std::array<int, 4>, const void*> handles;   // dispatched (m, n, ld, type) -> handle
 };
 
-struct EqnStep { MeltwArgs args; int src[3]; int node; int alpha_from_op; int dump_from_op; };   // src: >=0 input position, < 0: -(slot+1)
+struct EqnStep { MeltwArgs args; int src[3]; int node; int alpha_from_op; int dump_from_op; int root_side; bool scalar_arg[3]; };   // root_side: 1 bitmask, 2 UNZIP offset from output.secondary   // src: >=0 input position, < 0: -(slot+1)
 struct EqnPlan {
   JitKernel* fused = nullptr;       // whole tree as ONE generated kernel (element-wise trees), else the step chain below
   std::vector<int> fused_inputs;    // input positions in kernel-argument order
+  std::vector<char> fused_scalar;   // ... and whether that argument is a 1 x 1 scalar (may live in host memory)
   std::vector<int> fused_alphas;    // op_arg positions of scalar op arguments, in kernel-argument order
   std::vector<EqnStep> steps;
   std::vector<int> slot_of;         // per node: workspace slot (-1: none)
@@ -109,6 +110,7 @@ bool infer(Equation& e, int id) {
   } else if (nd.kind == EQ_BINARY) {
     const EqnNode& r = e.nodes[nd.child[1]];
     nd.m = std::max(l.m, r.m); nd.n = std::max(l.n, r.n); nd.ld = nd.m;
+    if (nd.op == LIBXSMM_MELTW_TYPE_BINARY_ZIP) nd.type = LIBXSMM_DATATYPE_F32;       // two 16-bit halves -> one f32 [ref: mateltwise ref ZIP]
   } else {
     const EqnNode& r = e.nodes[nd.child[1]]; const EqnNode& r2 = e.nodes[nd.child[2]];
     nd.m = std::max(r2.m, std::max(l.m, r.m)); nd.n = std::max(r2.n, std::max(l.n, r.n)); nd.ld = nd.m;
@@ -281,7 +283,12 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
   src += body;
   std::snprintf(buf, sizeof(buf), "  %s((GM %s*)out + i + j * %dLL, v0);\n}\n", out.type == LIBXSMM_DATATYPE_F32 ? "st_f32" : "st_bf16", out.type == LIBXSMM_DATATYPE_F32 ? "float" : "unsigned short", (int)out.ld);
   src += buf;
-  for (auto& a : arg_types) plan.fused_inputs.push_back(a.first);
+  for (auto& a : arg_types) {
+    plan.fused_inputs.push_back(a.first);
+    char scalar = 0;
+    for (const EqnNode& nd : e.nodes) if (nd.kind == EQ_ARG && nd.in_pos == a.first && nd.m == 1 && nd.n == 1) scalar = 1;
+    plan.fused_scalar.push_back(scalar);
+  }
   return true;
 }
 
@@ -295,9 +302,11 @@ void run_meqn(EqnPlan* plan, const void* param) {
   if (!p->inputs || !p->output.primary) { set_error(-2, "matrix equation called without inputs / output"); return; }
   if (plan->fused && jit_on_current_device(plan->fused)) {
     const void* ptrs[24]; float alphas[8]; void* args[33]; int na = 0; bool ok = true;
+    rt_scratch_reset();
     for (size_t i = 0; i < plan->fused_inputs.size(); ++i) {
       ptrs[i] = p->inputs[plan->fused_inputs[i]].primary;
-      ok = ok && ptrs[i] && (((size_t)ptrs[i]) & 15) == 0;
+      if (ptrs[i] && plan->fused_scalar[i]) ptrs[i] = rt_small_host_input(ptrs[i], 8);
+      ok = ok && ptrs[i] && (plan->fused_scalar[i] || (((size_t)ptrs[i]) & 15) == 0);
       args[na++] = (void*)&ptrs[i];
     }
     void* outp = p->output.primary; ok = ok && (((size_t)outp) & 15) == 0;
@@ -308,6 +317,7 @@ void run_meqn(EqnPlan* plan, const void* param) {
     }
     if (ok) { rt_finish_launch(jit_launch(plan->fused, args, rt_stream()), "meqn_jit"); return; }
   }
+  rt_scratch_reset();
   char* ws = nullptr;
   if (plan->nslots > 0) { ws = (char*)rt_workspace(plan->slot_bytes * (size_t)plan->nslots); if (!ws) return; }
   const char* kname = nullptr;
@@ -320,12 +330,21 @@ void run_meqn(EqnPlan* plan, const void* param) {
       if (st.src[c] == INT32_MIN) continue;
       src[c] = st.src[c] >= 0 ? (const char*)p->inputs[st.src[c]].primary : ws + plan->slot_bytes * (size_t)(-st.src[c] - 1);
       if (!src[c]) { set_error(-2, "matrix equation: input %d is NULL", st.src[c]); return; }
+      // a 1 x 1 argument is a scalar the caller typically keeps on its stack (learning rate, mean, ...): staged when it is host memory
+      if (st.src[c] >= 0 && st.scalar_arg[c]) { src[c] = (const char*)rt_small_host_input(src[c], 8); if (!src[c]) return; }
     }
     a.in0 = src[0]; a.in1 = src[1]; a.in2 = src[2];
     a.out = (s + 1 == plan->steps.size()) ? (char*)p->output.primary : ws + plan->slot_bytes * (size_t)plan->slot_of[st.node];
     if (st.alpha_from_op >= 0) {
       if (!p->ops_args || !p->ops_args[st.alpha_from_op].primary) { set_error(-2, "matrix equation: op argument %d is NULL", st.alpha_from_op); return; }
       a.scalar_f32 = *(const float*)p->ops_args[st.alpha_from_op].primary;
+    }
+    if (st.root_side == 1) {
+      if (!p->output.secondary) { set_error(-2, "matrix equation: the head is a ReLU with bitmask but output.secondary is NULL"); return; }
+      a.aux_out = p->output.secondary;
+    } else if (st.root_side == 2) {
+      if (!p->output.secondary) { set_error(-2, "matrix equation: the head is UNZIP but output.secondary (byte offset of the upper halves) is NULL"); return; }
+      a.scalar_u64 = *(const unsigned long long*)p->output.secondary;
     }
     if (st.dump_from_op >= 0) {
       if (!p->ops_args || !p->ops_args[st.dump_from_op].primary) { set_error(-2, "matrix equation: DUMP destination (op argument %d) is NULL", st.dump_from_op); return; }
@@ -419,7 +438,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       nd.ld = out.ld; nd.type = out.type;
     } else plan->slot_of[id] = plan->nslots++;
     EqnStep st; std::memset(&st.args, 0, sizeof(st.args));
-    st.node = id; st.alpha_from_op = -1; st.dump_from_op = -1; st.src[0] = st.src[1] = st.src[2] = INT32_MIN;
+    st.node = id; st.alpha_from_op = -1; st.dump_from_op = -1; st.root_side = 0; st.scalar_arg[0] = st.scalar_arg[1] = st.scalar_arg[2] = false; st.src[0] = st.src[1] = st.src[2] = INT32_MIN;
     MeltwArgs& a = st.args;
     a.nbatch = 1; a.flags = nd.flags; a.type = nd.op; a.comp_type = nd.dtype; a.out_type = nd.type; a.ldo = nd.ld;
     a.in0_type = a.in1_type = a.in2_type = LIBXSMM_DATATYPE_UNSUPPORTED;
@@ -427,6 +446,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
     for (int c = 0; c < arity(nd.kind); ++c) {
       ch[c] = &e->nodes[nd.child[c]];
       st.src[c] = ch[c]->kind == EQ_ARG ? ch[c]->in_pos : -(plan->slot_of[nd.child[c]] + 1);
+      st.scalar_arg[c] = ch[c]->kind == EQ_ARG && ch[c]->m == 1 && ch[c]->n == 1;
       if (ch[c]->kind == EQ_ARG && ch[c]->in_pos < 0) { delete plan; return nullptr; }
     }
     a.in0_type = ch[0]->type; a.ldi = ch[0]->ld;
@@ -440,8 +460,12 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       d = libxsmm_meltw_descriptor_init2(&blob, (libxsmm_datatype)a.in0_type, LIBXSMM_DATATYPE_UNSUPPORTED, LIBXSMM_DATATYPE_UNSUPPORTED, (libxsmm_datatype)nd.dtype,
         (libxsmm_datatype)nd.type, a.m, a.n, a.ldi, a.ldo, 0, 0, (unsigned short)nd.flags, (unsigned short)nd.op, LIBXSMM_MELTW_OPERATION_UNARY);
       // ops with side channels only make sense as standalone TPPs here
-      if ((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER || nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER ||
-          nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP || (nd.op == LIBXSMM_MELTW_TYPE_UNARY_DUMP && nd.op_arg_pos < 0) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR ||
+      // side channels through output.secondary exist for the head of the tree only [ref: matequation ref :40-55]: the ReLU bitmask,
+      // the byte offset of UNZIP's second half
+      if ((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && nd.op == LIBXSMM_MELTW_TYPE_UNARY_RELU && root) st.root_side = 1;
+      if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP && root) st.root_side = 2;
+      if (((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && st.root_side != 1) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER || nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER ||
+          (nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP && st.root_side != 2) || (nd.op == LIBXSMM_MELTW_TYPE_UNARY_DUMP && nd.op_arg_pos < 0) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR ||
           nd.op == LIBXSMM_MELTW_TYPE_UNARY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) d = nullptr;
       // parameterised activations: the reference's equation generators do not apply ops_args to them (its CPU JIT leaves the
       // negative side unscaled), so there is no behaviour to be compatible with: refuse instead of guessing
@@ -451,7 +475,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       a.in1_type = ch[1]->type; a.ldi1 = ch[1]->ld;
       d = libxsmm_meltw_descriptor_init2(&blob, (libxsmm_datatype)a.in0_type, (libxsmm_datatype)a.in1_type, LIBXSMM_DATATYPE_UNSUPPORTED, (libxsmm_datatype)nd.dtype,
         (libxsmm_datatype)nd.type, a.m, a.n, a.ldi, a.ldo, a.ldi1, 0, (unsigned short)nd.flags, (unsigned short)nd.op, LIBXSMM_MELTW_OPERATION_BINARY);
-      if (nd.op == LIBXSMM_MELTW_TYPE_BINARY_ZIP || (nd.op >= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GT && nd.op <= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_NE)) d = nullptr;
+      if (nd.op >= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GT && nd.op <= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_NE) d = nullptr;
     } else {
       a.operation = LIBXSMM_MELTW_OPERATION_TERNARY; a.m = nd.m; a.n = nd.n;
       a.in1_type = ch[1]->type; a.ldi1 = ch[1]->ld; a.in2_type = ch[2]->type; a.ldi2 = ch[2]->ld;
@@ -473,7 +497,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
     if (generate_fused(*e, out, idx, src, fname, probe, total)) {
       std::string why;
       plan->fused = jit_compile(src, fname, total, 16, &why);
-      if (plan->fused) { plan->fused_inputs = probe.fused_inputs; plan->fused_alphas = probe.fused_alphas; }
+      if (plan->fused) { plan->fused_inputs = probe.fused_inputs; plan->fused_scalar = probe.fused_scalar; plan->fused_alphas = probe.fused_alphas; }
     }
   }
   const void* h = rt_new_meqn_handle(plan);

@@ -571,6 +571,8 @@ const void* rt_new_meqn_handle(EqnPlan* plan) {
 void rt_finish_launch(int err, const char* kernel_name) { finish_launch(err, kernel_name); }
 void* rt_workspace(size_t nbytes) { return workspace(nbytes); }
 bool rt_ready() { return runtime_ready(); }
+const void* rt_small_host_input(const void* p, size_t nbytes) { return device_visible(p, nbytes); }
+void rt_scratch_reset() { scratch_reset(); }
 void rt_note(const char* what, int a, int b, int c) { vlog(1, "%s (%d, %d, %d)", what, a, b, c); }
 void* rt_stream() { return tls().stream; }
 int rt_jit_mode() { return jit_mode(); }

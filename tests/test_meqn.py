@@ -231,3 +231,28 @@ def test_gpu_meqn_dump_writes_the_intermediate_to_the_op_argument():
     capi.Api.call(h, p)
     assert api.hip_get_last_error() != 0
     api.hip_clear_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", [0, 2], ids=["tpp_chain", "fused_jit"])
+def test_gpu_meqn_scalar_arguments_may_live_in_host_memory(jit):
+    """1 x 1 arguments (a learning rate, a mean) are usually stack variables of the caller (samples/equation/equation_splitSGD.c:
+    arg_array[2].primary = &lr): both evaluation paths stage them instead of faulting."""
+    import torch
+    api = capi.load()
+    api.hip_set_jit(jit)
+    tree, shapes, out_shape = CASES["mixed_precision"]
+    arrays = _inputs(shapes, 13)
+    ref = evaluate(tree, shapes, arrays, out_shape)
+    idx = build(api, tree, shapes)
+    h = api.dispatch_meqn(idx, capi.MeqnArgShape(*out_shape))
+    api.hip_set_jit(1)
+    assert h
+    view = lambda a: a.view(np.int16) if a.dtype == np.uint16 else a   # noqa: E731
+    dev = [torch.from_numpy(view(a).copy()).to("cuda:0") for a in arrays[:2]]
+    scalar = C.c_float(float(arrays[2][0]))                                        # plain host memory
+    out = torch.zeros(out_shape[2] * out_shape[1], dtype=torch.int16, device="cuda:0")
+    for _ in range(3):                                                             # the staging scratch is recycled call after call
+        _call(api, h, [dev[0].data_ptr(), dev[1].data_ptr(), C.addressof(scalar)], out.data_ptr())
+    api.hip_sync(); api.check()
+    assert np.array_equal(_valid(out.cpu().numpy().view(np.uint16), out_shape), _valid(ref, out_shape))
