@@ -45,6 +45,8 @@
 #define LIBXSMM_SNPRINTF(S, N, ...) snprintf(S, N, __VA_ARGS__)
 #define LIBXSMM_PUTENV(A) putenv(A)
 #define LIBXSMM_PRAGMA_SIMD
+#define LIBXSMM_OMP_VAR(A) (void)(A)
+#define LIBXSMM_CONST_VOID_PTR(A) ((const void*)(A))
 #if defined(_OPENMP)
 # define LIBXSMM_OMP_MASKED _Pragma("omp master")
 #else

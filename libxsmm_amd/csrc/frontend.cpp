@@ -14,6 +14,7 @@
 #include "internal.hpp"
 
 #include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -176,7 +177,9 @@ LIBXSMM_API void libxsmm_convert_bf16_f32(const libxsmm_bfloat16* in, float* out
 LIBXSMM_API void libxsmm_matdiff_clear(libxsmm_matdiff_info* info) {
   if (!info) return;
   std::memset(info, 0, sizeof(*info));
+  info->m = info->n = info->i = -1;                            // no location with a difference yet
   info->min_ref = info->min_tst = INFINITY; info->max_ref = info->max_tst = -INFINITY;
+  info->rsq = INFINITY;                                        // invalid rather than 1.0 [ref: libxsmm_math.c:456-466]
 }
 static double md_load(libxsmm_datatype t, const void* p, size_t i) {
   switch (t) {
@@ -189,34 +192,91 @@ static double md_load(libxsmm_datatype t, const void* p, size_t i) {
     default: return NAN;
   }
 }
+// Statistics as the reference defines them [behaviour: src/libxsmm_matdiff.h, src/libxsmm_math.c:35-300; pinned by the reference's own
+// tests/matdiff.c, run by tests/test_reference_drivers_gpu.py]: element (i, j) = x[j * ld + i]; a single column is looked at as a row;
+//   linf_abs / linf_rel  largest |r - t| (with its location and values) / largest |r - t| / |r|   (|t| when r = 0, else the difference itself)
+//   normi_abs            max over j of sum_i |r - t|   (one contiguous line), normi_rel = that over the same norm of the reference
+//   norm1_abs            max over i of sum_j |r - t|   (across the lines),    norm1_rel likewise
+//   l2_abs, l2_rel       sqrt(sum d^2), sqrt(sum (d / |r|)^2);  normf_rel = sqrt(sum d^2 / sum r^2);  l1_ref / l1_tst = sum |r|, sum |t|
+//   rsq                  max(0, 1 - sum d^2 / sum (r - avg_ref)^2), avg = l1 / count;  var = that sum / count
+// A NaN or infinity in the test set (that the reference does not share) ends the scan: every error statistic becomes infinity.
 LIBXSMM_API int libxsmm_matdiff(libxsmm_matdiff_info* info, libxsmm_datatype datatype, libxsmm_blasint m, libxsmm_blasint n,
   const void* ref, const void* tst, const libxsmm_blasint* ldref, const libxsmm_blasint* ldtst) {
-  if (!info || !ref || m < 0 || n < 0) return EXIT_FAILURE;
-  const size_t ldr = ldref ? (size_t)*ldref : (size_t)m, ldt = ldtst ? (size_t)*ldtst : (size_t)m;
+  bool swapped = false;
+  if (!ref && tst) { ref = tst; tst = nullptr; swapped = true; }
+  size_t ldr = ldref ? (size_t)*ldref : (size_t)m, ldt = ldtst ? (size_t)*ldtst : (size_t)m;
+  if (!info || !ref || m < 0 || n < 0 || (size_t)m > ldr || (size_t)m > ldt || typesize((int)datatype) == 0) return EXIT_FAILURE;
+  long long rows = m, lines = n;
+  if (n == 1) { rows = 1; lines = m; ldr = ldt = 1; }          // a column vector is treated as a row vector (same statistics for both)
   libxsmm_matdiff_clear(info);
-  double l2_abs = 0, normfr = 0, l1_ref = 0, l1_tst = 0; size_t cnt = 0;
-  for (libxsmm_blasint j = 0; j < n; ++j) for (libxsmm_blasint i = 0; i < m; ++i) {
-    const double r = md_load(datatype, ref, j * ldr + i), t = tst ? md_load(datatype, tst, j * ldt + i) : 0.0;
-    if (std::isnan(r) && std::isnan(t)) continue;
-    const double d = std::fabs(r - t), ra = std::fabs(r), ta = std::fabs(t);
-    if (r < info->min_ref) info->min_ref = r; if (r > info->max_ref) info->max_ref = r;
-    if (t < info->min_tst) info->min_tst = t; if (t > info->max_tst) info->max_tst = t;
-    if (d > info->linf_abs || std::isnan(d)) { info->linf_abs = d; info->v_ref = r; info->v_tst = t; info->m = i; info->n = j; }
-    const double rel = ra > 0 ? d / ra : (ta > 0 ? d / ta : 0.0);
-    if (rel > info->linf_rel) info->linf_rel = rel;
-    l2_abs += d * d; normfr += r * r; l1_ref += ra; l1_tst += ta; ++cnt;
+  const double inf = info->min_ref;                            // clear() leaves +infinity here
+  const size_t count = (size_t)m * (size_t)n;
+  const auto div_or = [](double num, double den, double fallback) { return den > 0 ? num / den : fallback; };
+  double sum_d2 = 0, sum_r2 = 0, sum_t2 = 0, sum_rel2 = 0, l1_ref = 0, l1_tst = 0, line_ref_max = 0, line_tst_max = 0;
+  int bad = 0;                                                 // 1: test value not finite, 2: reference value not finite
+  for (long long j = 0; j < lines && !bad; ++j) {
+    double line_d = 0, line_r = 0, line_t = 0;
+    for (long long i = 0; i < rows; ++i) {
+      const double r = md_load(datatype, ref, (size_t)j * ldr + (size_t)i), t = tst ? md_load(datatype, tst, (size_t)j * ldt + (size_t)i) : 0.0;
+      const double ra = std::fabs(r), ta = std::fabs(t);
+      if (r < info->min_ref) info->min_ref = r;
+      if (r > info->max_ref) info->max_ref = r;
+      if (t == t && (ta < inf || t == r)) {
+        const double d = tst ? std::fabs(r - t) : 0.0, rel = div_or(d, ra, ta);
+        if (t < info->min_tst) info->min_tst = t;
+        if (t > info->max_tst) info->max_tst = t;
+        if (info->linf_abs < d) { info->linf_abs = d; info->v_ref = r; info->v_tst = t; info->m = (libxsmm_blasint)i; info->n = (libxsmm_blasint)j; }
+        if (info->linf_rel < rel) info->linf_rel = rel;
+        if (rel * rel < inf) sum_rel2 += rel * rel;
+        line_r += ra; line_t += ta; line_d += d;
+        sum_r2 += r * r; sum_t2 += t * t;
+        if (d * d < inf) sum_d2 += d * d;
+      } else {
+        bad = (r == r && ra < inf) ? 1 : 2;
+        info->m = (libxsmm_blasint)i; info->n = (libxsmm_blasint)j; info->v_ref = r; info->v_tst = t;
+        break;
+      }
+    }
+    if (bad) break;
+    l1_ref += line_r; l1_tst += line_t;
+    if (info->normi_abs < line_d) info->normi_abs = line_d;
+    if (line_ref_max < line_r) line_ref_max = line_r;
+    if (line_tst_max < line_t) line_tst_max = line_t;
   }
   info->l1_ref = l1_ref; info->l1_tst = l1_tst;
-  if (cnt) { info->avg_ref = l1_ref / cnt; info->avg_tst = l1_tst / cnt; }
-  info->normf_rel = std::sqrt(normfr > 0 ? l2_abs / normfr : l2_abs);
-  double ss_tot = 0;
-  for (libxsmm_blasint j = 0; j < n; ++j) for (libxsmm_blasint i = 0; i < m; ++i) { const double r = md_load(datatype, ref, j * ldr + i) - info->avg_ref; ss_tot += r * r; }
-  info->var_ref = ss_tot; info->rsq = ss_tot > 0 ? std::max(0.0, 1.0 - l2_abs / ss_tot) : (l2_abs > 0 ? 0.0 : 1.0);
-  info->norm1_abs = info->normi_abs = info->linf_abs; info->norm1_rel = info->normi_rel = info->linf_rel;
-  info->l2_abs = std::sqrt(l2_abs); info->l2_rel = normfr > 0 ? std::sqrt(l2_abs / normfr) : info->l2_abs;
+  if (!bad) {
+    if (count) { info->avg_ref = l1_ref / (double)count; info->avg_tst = l1_tst / (double)count; }
+    info->normi_rel = div_or(info->normi_abs, line_ref_max, line_tst_max);
+    info->normf_rel = std::sqrt(div_or(sum_d2, sum_r2, std::min(sum_t2 * sum_t2, sum_d2)));
+    double cross_ref_max = 0, var_r = 0, var_t = 0;
+    for (long long i = 0; i < rows; ++i) {
+      double cross_d = 0, cross_r = 0;
+      for (long long j = 0; j < lines; ++j) {
+        const double r = md_load(datatype, ref, (size_t)j * ldr + (size_t)i), t = tst ? md_load(datatype, tst, (size_t)j * ldt + (size_t)i) : 0.0;
+        const double rd = r - info->avg_ref, td = t - info->avg_tst;
+        var_r += rd * rd; var_t += td * td;
+        cross_r += std::fabs(r); cross_d += tst ? std::fabs(r - t) : 0.0;
+      }
+      if (info->norm1_abs < cross_d) info->norm1_abs = cross_d;
+      if (cross_ref_max < cross_r) cross_ref_max = cross_r;
+    }
+    info->norm1_rel = div_or(info->norm1_abs, cross_ref_max, info->norm1_abs);
+    info->rsq = std::max(0.0, 1.0 - div_or(sum_d2, var_r, sum_d2));
+    info->var_ref = count ? var_r / (double)count : var_r; info->var_tst = count ? var_t / (double)count : var_t;
+    info->l2_abs = std::sqrt(sum_d2); info->l2_rel = std::sqrt(sum_rel2);
+  } else {
+    info->norm1_abs = info->norm1_rel = info->normi_abs = info->normi_rel = info->normf_rel = info->linf_abs = info->linf_rel = info->l2_abs = info->l2_rel = inf;
+    if (bad == 1) { info->l1_tst = info->var_tst = inf; info->avg_tst = info->v_tst; info->min_tst = inf; info->max_tst = -inf; }
+    else { info->l1_ref = info->var_ref = inf; info->avg_ref = info->v_ref; info->min_ref = inf; info->max_ref = -inf; }
+  }
+  if (n == 1) std::swap(info->m, info->n);
+  if (swapped) {
+    info->min_tst = info->min_ref; info->min_ref = 0; info->max_tst = info->max_ref; info->max_ref = 0; info->avg_tst = info->avg_ref; info->avg_ref = 0;
+    info->var_tst = info->var_ref; info->var_ref = 0; info->l1_tst = info->l1_ref; info->l1_ref = 0; info->v_tst = info->v_ref; info->v_ref = 0;
+  }
   return EXIT_SUCCESS;
 }
-// running worst case over repeated comparisons [ref: src/libxsmm_math.c:386-446]
+
 LIBXSMM_API void libxsmm_matdiff_reduce(libxsmm_matdiff_info* out, const libxsmm_matdiff_info* in) {
   if (!out || !in) { libxsmm_matdiff_clear(out); return; }
   const double eps_in = libxsmm_matdiff_epsilon(in), eps_out = libxsmm_matdiff_epsilon(out);
@@ -236,7 +296,7 @@ LIBXSMM_API void libxsmm_matdiff_reduce(libxsmm_matdiff_info* out, const libxsmm
 LIBXSMM_API double libxsmm_matdiff_epsilon(const libxsmm_matdiff_info* in) {
   if (!in) return 0.0;
   if (in->rsq > 0) return std::min(in->normf_rel, in->linf_abs) / in->rsq;   // [ref: libxsmm_math.c:322-332]
-  return std::max(in->linf_abs, in->normf_rel);
+  return std::max(std::min(in->norm1_abs, in->normi_abs), std::max(in->linf_abs, in->l2_abs));
 }
 
 }  // extern "C"

@@ -326,6 +326,27 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
       if (a.act == 2) { a.relu_mask = (unsigned char*)pe->c.secondary; if (!a.relu_mask) { set_error(-2, "ReLU bitmask requested but c.secondary is NULL"); return; } }
     } else if (d.cp_type == LIBXSMM_MELTW_TYPE_UNARY_SIGMOID) a.act = 3;
   }
+  // A synchronous single call may be handed plain host memory (the reference's hello-world mallocs its matrices): operands whose
+  // extent follows from the descriptor alone (no pointer lists, no offset arrays) are staged.  One pointer query per operand.
+  if (staging_allowed(b.count) && !a.list_a && (a.br_mode == 0 || a.br_mode == 3) && a.br_count >= 1) {
+    const bool ta = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_A) != 0, tb = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_B) != 0;
+    const bool mxmx = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8) && d.b_type == d.a_type;
+    const auto bytes_of = [](int type, size_t elems) { return type == LIBXSMM_DATATYPE_MXFP4X2 ? elems / 2 : elems * (size_t)typesize(type); };
+    const size_t ea = bytes_of(d.a_type, (size_t)a.lda * (size_t)(ta ? a.m : a.k));
+    const size_t eb = bytes_of(d.b_type, (size_t)a.ldb * (size_t)((tb || mxmx) ? a.k : a.n));
+    const size_t ec = (size_t)a.ldc * (size_t)(a.n + (a.vnni_c ? (a.n & 1) : 0)) * (size_t)typesize(d.c_type);
+    const size_t span = (a.br_mode == 3) ? (size_t)(a.br_count - 1) : 0;
+    if (a.br_mode != 3 || (a.br_stride_a >= 0 && a.br_stride_b >= 0)) {
+      a.a = (const char*)stage(a.a, span * (size_t)a.br_stride_a + ea, true, false);
+      a.b = (const char*)stage(a.b, span * (size_t)a.br_stride_b + eb, true, false);
+      a.c = (char*)stage(a.c, ec, true, true);
+      if (a.d) a.d = (const char*)stage(a.d, (size_t)a.m * (size_t)typesize(d.c_type), true, false);
+      if (a.relu_mask) a.relu_mask = (unsigned char*)stage(a.relu_mask, (size_t)(((a.ldc + 15) / 16) * 16 / 8) * (size_t)a.n, true, true);
+      if (a.a_scf && a.br_mode == 0) a.a_scf = (const char*)stage(a.a_scf, (size_t)a.lda * (size_t)(a.k / 32), true, false);
+      if (a.b_scf && a.br_mode == 0) a.b_scf = (const char*)stage(a.b_scf, (size_t)a.ldb * (size_t)(a.k / 32), true, false);
+      if (!a.a || !a.b || !a.c) return;
+    }
+  }
   const char* kname = nullptr;
   // One (or very few) problems with a long STRIDE batch-reduce chain would run on a handful of waves: split the chain
   // into `nsplit` segments that run as a batch of partial products (f32 tiles in a workspace), then add them up and

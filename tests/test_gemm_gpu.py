@@ -453,3 +453,26 @@ def test_mxmx_dispatch_rules():
         assert api.dispatch_gemm(sh(t, k=48), MXMX, 0) is None
         assert api.dispatch_brgemm(sh(t), MXMX, 0, capi.br_config(capi.BR_ADDRESS, 0, 0, 0)) is None      # [ref: gemm ref :836-845]
     assert api.dispatch_gemm(sh(DT.MXFP4X2, c=DT.MXFP4X2), MXMX, 0) is None        # MX-typed outputs: not built
+
+
+@pytest.mark.parametrize("kw", [dict(m=13, n=5, k=7, a_type=DT.F64, beta=1), dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=3),
+                                dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2)],
+                         ids=["hello_f64", "f32_strdbr", "bf16_bias_relumask"])
+def test_synchronous_gemm_accepts_plain_host_memory(kw):
+    """The reference's contract is "any pointer, C valid on return" (its hello-world mallocs A, B and C).  A synchronous single call
+    stages operands that live in plain host memory (numpy arrays here), including the bias and the ReLU bitmask; asynchronous and
+    batched launches take device memory only."""
+    api = capi.load()
+    case = GemmCase(seed=77, **kw)
+    ref, ref_mask = case.run_oracle()
+    Cbuf = case.C0.copy()
+    mask = np.zeros(case.mask_bytes, dtype=np.uint8) if case.act == 2 else None
+    handle = case.dispatch(api)
+    assert handle
+    p, keep = case.make_param(case.A, case.B, Cbuf, case.D, mask)          # numpy memory: not visible to the GPU
+    capi.Api.call(handle, p)
+    api.check()
+    tol = TOL_F64 if case.a_type == DT.F64 else (TOL_BF16 if case.c_type == DT.BF16 else TOL_F32)
+    assert normf_rel(case.valid_region(ref), case.valid_region(Cbuf), case.c_type) < tol
+    if mask is not None:
+        assert np.array_equal(case.valid_mask_bits(mask), case.valid_mask_bits(ref_mask))

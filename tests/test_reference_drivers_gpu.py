@@ -201,3 +201,41 @@ def test_reference_side_channel_equation_drivers(binary, args):
     out = check(binary, *args.split())
     norms = [float(x) for x in re.findall(r"Check-norm\s*:\s*([0-9.eE+-]+)", out)]
     assert norms and max(norms) == 0.0, out[-2000:]
+
+
+# samples/xgemm_norm_packed/dense_packed{ac,bc}rm.c (the reference's tests/packed.sh) -- M N K beta reps: libxsmm_create_packed_gemm_ac_rm / _bc_rm
+@pytest.mark.parametrize("binary", ["dense_packedacrm", "dense_packedacrm_f32", "dense_packedbcrm", "dense_packedbcrm_f32"])
+@pytest.mark.parametrize("args", ["9 81 35 0.0 2", "9 81 35 1.0 2", "9 35 81 1.0 2"])
+def test_reference_dense_packed_drivers(binary, args):
+    out = check(binary, *args.split())
+    errs = [float(x) for x in re.findall(r"max\. error: ([0-9.eE+-]+)", out)]
+    assert errs and max(errs) <= (1e-4 if binary.endswith("_f32") else 1e-6), out[-1500:]
+
+
+# samples/xgemm_packed/gemm_packed_kernel.c -- A B comp C  M N K lda ldb ldc  R  alpha beta  transA transB  reps: libxsmm_create_packed_gemm
+@pytest.mark.parametrize("args", ["F32 F32 F32 F32 9 9 9 9 9 9 64 1 0 0 0 2", "F32 F32 F32 F32 4 7 5 4 5 4 24 1 1 0 0 2", "F64 F64 F64 F64 9 9 9 9 9 9 16 1 1 0 0 2"])
+def test_reference_packed_gemm_driver(args):
+    check("gemm_packed_kernel", *args.split())
+
+
+def test_reference_hello_world():
+    """samples/hello/hello.c: 1000 f64 13x5x7 products accumulated into one C, every matrix from plain malloc() -- synchronous GEMM
+    calls stage host operands, so LIBXSMM's first example runs as it is."""
+    check("hello")
+
+
+def test_reference_threadsafety_test():
+    """tests/threadsafety.c: concurrent dispatch of random shapes from all OpenMP threads, registry queries, init/finalize cycles."""
+    env_threads = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = "8"
+    try:
+        check("threadsafety", timeout=300)
+    finally:
+        if env_threads is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = env_threads
+
+
+def test_reference_matdiff_test():
+    check("matdiff")

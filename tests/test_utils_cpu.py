@@ -96,3 +96,13 @@ def test_array_forms_strings_rng_state_and_matinit(ours):
     assert ours.libxsmm_hip_matinit_value(42.0, 1.0, 11, 3, 10, 5, 12) == 42.0
     shuffled = [ours.libxsmm_hip_matinit_value(0.0, 1.0, r, c, 10, 5, 12) for c in range(5) for r in range(12)]
     assert len(set(shuffled)) == 60 and max(np.abs(shuffled)) <= 1.0
+
+
+def test_reference_matdiff_unit_test_passes_on_this_library():
+    """tests/matdiff.c of the reference (every statistic of libxsmm_matdiff, its reduction and epsilon on LAPACK's textbook example),
+    built unmodified against this repository's headers by `make -C oracle drivers`; it needs no GPU."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "drivers", "matdiff")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/drivers/matdiff not built (needs /root/reference)")
+    assert subprocess.run([exe], capture_output=True, timeout=60).returncode == 0
