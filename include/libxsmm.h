@@ -231,6 +231,14 @@ typedef enum libxsmm_basic_gemm_flags {
   (('n' == (TRANSA) || 'N' == (TRANSA)) ? 0 : LIBXSMM_GEMM_FLAG_TRANS_A) | \
   (('n' == (TRANSB) || 'N' == (TRANSB)) ? 0 : LIBXSMM_GEMM_FLAG_TRANS_B)))
 
+/* transposes given by address: a NULL request falls back to what DEFAULT says; all other bits of DEFAULT are kept */
+#define LIBXSMM_GEMM_PFLAGS(TRANSA, TRANSB, DEFAULT) ((int)(LIBXSMM_GEMM_FLAGS( \
+  (0 != ((const void*)(TRANSA)) ? *((const char*)(TRANSA)) : ((0 != (LIBXSMM_GEMM_FLAG_TRANS_A & (DEFAULT))) ? 't' : 'n')), \
+  (0 != ((const void*)(TRANSB)) ? *((const char*)(TRANSB)) : ((0 != (LIBXSMM_GEMM_FLAG_TRANS_B & (DEFAULT))) ? 't' : 'n'))) \
+  | ((DEFAULT) & ~(LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B))))
+#define LIBXSMM_GEMM_VNNI_FLAGS(TRANSA, TRANSB, VNNIA, VNNIB) ((libxsmm_bitfield)(LIBXSMM_GEMM_FLAGS(TRANSA, TRANSB) | \
+  (('n' == (VNNIA) || 'N' == (VNNIA)) ? 0 : LIBXSMM_GEMM_FLAG_VNNI_A) | (('n' == (VNNIB) || 'N' == (VNNIB)) ? 0 : LIBXSMM_GEMM_FLAG_VNNI_B)))
+
 typedef enum libxsmm_gemm_prefetch_type {
   LIBXSMM_GEMM_PREFETCH_NONE = 0, LIBXSMM_GEMM_PREFETCH_AL2 = 1, LIBXSMM_GEMM_PREFETCH_BL2 = 2
 } libxsmm_gemm_prefetch_type;

@@ -98,11 +98,12 @@ def test_array_forms_strings_rng_state_and_matinit(ours):
     assert len(set(shuffled)) == 60 and max(np.abs(shuffled)) <= 1.0
 
 
-def test_reference_matdiff_unit_test_passes_on_this_library():
-    """tests/matdiff.c of the reference (every statistic of libxsmm_matdiff, its reduction and epsilon on LAPACK's textbook example),
-    built unmodified against this repository's headers by `make -C oracle drivers`; it needs no GPU."""
+@pytest.mark.parametrize("name", ["matdiff", "gemmflags"])
+def test_reference_host_side_unit_tests_pass_on_this_library(name):
+    """tests/matdiff.c (every statistic of libxsmm_matdiff, its reduction and epsilon on LAPACK's textbook example) and tests/gemmflags.c
+    (transpose-flag macros) of the reference, built unmodified against this repository's headers by `make -C oracle drivers`; no GPU needed."""
     import subprocess
-    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "drivers", "matdiff")
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "drivers", name)
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/drivers/matdiff not built (needs /root/reference)")
+        pytest.skip(f"oracle/_ref/drivers/{name} not built (needs /root/reference)")
     assert subprocess.run([exe], capture_output=True, timeout=60).returncode == 0
