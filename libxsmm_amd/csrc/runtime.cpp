@@ -436,6 +436,53 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     a.in0 = (const char*)p->in0.primary; a.in1 = (const char*)p->in1.primary; a.in2 = (const char*)p->in2.primary; a.out = (char*)p->out.primary;
     a.bs_in0 = b.s[0]; a.bs_in1 = b.s[1]; a.bs_in2 = b.s[2]; a.bs_out = b.s[3];
   }
+  // Synchronous single calls of the plain element-wise / reduction TPPs accept host memory too (extents follow from the descriptor);
+  // TPPs with index arrays, bit masks as inputs or re-laid-out outputs (gather/scatter, transforms, *_INV, SELECT, ZIP/UNZIP, ...)
+  // take device-visible operands only.
+  if (staging_allowed(b.count)) {
+    const int t = d.param;
+    const auto bc = [&](int op) -> int {            // 0 none, 1 row (one value per column), 2 column vector, 3 scalar
+      const unsigned int f = d.flags;
+      if (d.operation == LIBXSMM_MELTW_OPERATION_UNARY) return op ? 0 : (f & LIBXSMM_MELTW_FLAG_UNARY_BCAST_ROW) ? 1 : (f & LIBXSMM_MELTW_FLAG_UNARY_BCAST_COL) ? 2 : (f & LIBXSMM_MELTW_FLAG_UNARY_BCAST_SCALAR) ? 3 : 0;
+      if (d.operation == LIBXSMM_MELTW_OPERATION_BINARY) return (f & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_ROW_IN_0 << op)) ? 1 : (f & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_COL_IN_0 << op)) ? 2 : (f & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_SCALAR_IN_0 << op)) ? 3 : 0;
+      return (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_ROW_IN_0 << op)) ? 1 : (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_COL_IN_0 << op)) ? 2 : (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_SCALAR_IN_0 << op)) ? 3 : 0;
+    };
+    const auto extent = [&](int kind, long long ld, int type) -> size_t {
+      const long long elems = kind == 1 ? ld * (a.n - 1) + 1 : kind == 2 ? a.m : kind == 3 ? 1 : ld * (a.n - 1) + a.m;
+      return (size_t)std::max<long long>(elems, 0) * (size_t)typesize(type);
+    };
+    bool plain = false, reduce = false;
+    if (d.operation == LIBXSMM_MELTW_OPERATION_UNARY) {
+      switch (t) {
+        case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_XOR: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT:
+        case LIBXSMM_MELTW_TYPE_UNARY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_TANH: case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID: case LIBXSMM_MELTW_TYPE_UNARY_GELU:
+        case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: case LIBXSMM_MELTW_TYPE_UNARY_INC: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT:
+        case LIBXSMM_MELTW_TYPE_UNARY_EXP: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_ELU: plain = true; break;
+        case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD:
+        case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX:
+          reduce = (d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS | LIBXSMM_MELTW_FLAG_UNARY_REDUCE_COLS)) != 0 && !(d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP); break;
+        default: break;
+      }
+    } else if (d.operation == LIBXSMM_MELTW_OPERATION_BINARY) {
+      plain = t == LIBXSMM_MELTW_TYPE_BINARY_ADD || t == LIBXSMM_MELTW_TYPE_BINARY_MUL || t == LIBXSMM_MELTW_TYPE_BINARY_SUB || t == LIBXSMM_MELTW_TYPE_BINARY_DIV ||
+              t == LIBXSMM_MELTW_TYPE_BINARY_MULADD || t == LIBXSMM_MELTW_TYPE_BINARY_MAX || t == LIBXSMM_MELTW_TYPE_BINARY_MIN;
+    } else plain = t == LIBXSMM_MELTW_TYPE_TERNARY_MULADD || t == LIBXSMM_MELTW_TYPE_TERNARY_NMULADD;
+    if (plain || reduce) {
+      a.in0 = (const char*)stage(a.in0, extent(bc(0), a.ldi, a.in0_type), true, false);
+      if (a.in1) a.in1 = (const char*)stage(a.in1, extent(bc(1), a.ldi1, a.in1_type), true, false);
+      if (a.in2) a.in2 = (const char*)stage(a.in2, extent(bc(2), a.ldi2, a.in2_type), true, false);
+      size_t out_bytes = extent(0, a.ldo, a.out_type);
+      if (reduce) {
+        const bool rows = (d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
+        const long long len = rows ? a.n : a.m, apart = rows ? a.n : a.ldo;      // the X2 half of X_X2 starts `apart` elements after X
+        out_bytes = (size_t)(t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD ? apart + len : len) * (size_t)typesize(a.out_type);
+      }
+      a.out = (char*)stage(a.out, out_bytes, true, true);
+      if (plain && d.operation == LIBXSMM_MELTW_OPERATION_UNARY && (d.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && a.aux_out)
+        a.aux_out = stage(a.aux_out, (size_t)(((a.ldo + 15) / 16) * 16 / 8) * (size_t)a.n, true, true);
+      if (!a.in0 || !a.out) return;
+    }
+  }
   const char* kname = nullptr;
   const int err = launch_meltw(a, tls().stream, &kname);
   finish_launch(err, kname);

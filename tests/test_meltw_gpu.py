@@ -371,3 +371,61 @@ def test_quant_dequant_roundtrip_bit_exact(out_dt, flags):
     assert np.array_equal(valid(dF.cpu().numpy(), ldi), valid(fref, ldi))
     # QUANT to a float type or DEQUANT from one is not a thing
     assert api.dispatch_meltw_unary(UNARY.QUANT, capi.UnaryShape(m, n, ldi, ldo, DT.F32, DT.BF16, DT.F32), 0) is None
+
+
+@pytest.mark.parametrize("what", ["unary_bf16", "binary_bcast", "ternary", "reduce_rows_x_x2", "reduce_cols", "relu_bitmask"])
+def test_synchronous_tpp_calls_accept_plain_host_memory(what):
+    """Plain element-wise TPPs and reductions called synchronously stage operands that live in host memory (numpy arrays here), like the
+    reference's samples/eltwise/eltwise_unary_reduce.c, which mallocs everything; results equal the device-memory path bit for bit."""
+    import torch
+    api = capi.load()
+    rng = np.random.default_rng(91)
+    m, n, ld = 40, 24, 48
+
+    def both(handle, param_type, slots, out_key, out_elems, out_dtype, extra=None):
+        host = {k: v.copy() for k, v in slots.items()}
+        dev = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else v).to("cuda:0") for k, v in slots.items()}
+        outs = []
+        for side in (host, dev):
+            p = param_type()
+            for k, v in side.items():
+                getattr(p, k).primary = v.ctypes.data if isinstance(v, np.ndarray) else v.data_ptr()
+            if extra:
+                extra(p, side is host)
+            capi.Api.call(handle, p)
+            api.hip_sync(); api.check()
+            o = side[out_key]
+            outs.append(o.copy() if isinstance(o, np.ndarray) else o.cpu().numpy().view(out_dtype))
+        assert np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8))
+        return outs[0]
+
+    f32 = lambda k: rand_values(rng, k, DT.F32)     # noqa: E731
+    if what == "unary_bf16":
+        h = api.dispatch_meltw_unary(UNARY.SIGMOID, capi.UnaryShape(m, n, ld, ld, DT.BF16, DT.BF16, DT.F32), 0)
+        both(h, capi.UnaryParam, {"in_": rand_values(rng, ld * n, DT.BF16), "out": np.zeros(ld * n, np.uint16)}, "out", ld * n, np.uint16)
+    elif what == "binary_bcast":
+        h = api.dispatch_meltw_binary(BINARY.ADD, capi.BinaryShape(m, n, ld, ld, ld, DT.F32, DT.F32, DT.F32, DT.F32), BINARY_FLAG.BCAST_COL_IN_0)
+        both(h, capi.BinaryParam, {"in0": f32(m), "in1": f32(ld * n), "out": np.zeros(ld * n, np.float32)}, "out", ld * n, np.float32)
+    elif what == "ternary":
+        h = api.dispatch_meltw_ternary(TERNARY.MULADD, capi.TernaryShape(m, n, ld, ld, ld, ld, DT.F32, DT.F32, DT.F32, DT.F32, DT.F32), 0)
+        both(h, capi.TernaryParam, {"in0": f32(ld * n), "in1": f32(ld * n), "in2": f32(ld * n), "out": np.zeros(ld * n, np.float32)}, "out", ld * n, np.float32)
+    elif what == "reduce_rows_x_x2":
+        h = api.dispatch_meltw_unary(UNARY.REDUCE_X_X2_OP_ADD, capi.UnaryShape(m, n, ld, n, DT.F32, DT.F32, DT.F32), UNARY_FLAG.REDUCE_ROWS)
+        x = f32(ld * n)
+        out = both(h, capi.UnaryParam, {"in_": x, "out": np.zeros(2 * n, np.float32)}, "out", 2 * n, np.float32)
+        cols = x.reshape(n, ld)[:, :m].astype(np.float64)
+        assert np.allclose(out[:n], cols.sum(axis=1), rtol=1e-5, atol=1e-5) and np.allclose(out[n:], (cols ** 2).sum(axis=1), rtol=1e-5, atol=1e-5)
+    elif what == "reduce_cols":
+        h = api.dispatch_meltw_unary(UNARY.REDUCE_X_OP_MAX, capi.UnaryShape(m, n, ld, m, DT.F32, DT.F32, DT.F32), UNARY_FLAG.REDUCE_COLS)
+        x = f32(ld * n)
+        out = both(h, capi.UnaryParam, {"in_": x, "out": np.zeros(m, np.float32)}, "out", m, np.float32)
+        assert np.array_equal(out, x.reshape(n, ld)[:, :m].max(axis=0))
+    else:
+        h = api.dispatch_meltw_unary(UNARY.RELU, capi.UnaryShape(m, n, ld, ld, DT.F32, DT.F32, DT.F32), UNARY_FLAG.BITMASK_2BYTEMULT)
+        mask_bytes = ((ld + 15) // 16) * 16 // 8 * n
+        masks = [np.zeros(mask_bytes, np.uint8), torch.zeros(mask_bytes, dtype=torch.uint8, device="cuda:0")]
+
+        def extra(p, is_host):
+            p.out.secondary = masks[0].ctypes.data if is_host else masks[1].data_ptr()
+        both(h, capi.UnaryParam, {"in_": f32(ld * n), "out": np.zeros(ld * n, np.float32)}, "out", ld * n, np.float32, extra)
+        assert np.array_equal(masks[0], masks[1].cpu().numpy()) and masks[0].any()

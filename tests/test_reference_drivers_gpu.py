@@ -165,9 +165,12 @@ def test_reference_gather_scatter_driver(args):
     check("eltwise_unary_gather_scatter", *args.split())
 
 
-# samples/eltwise/eltwise_unary_reduce.c is built but not run: it allocates its operands with plain malloc(), which an MI355X cannot
-# see, and TPP calls do not stage host memory (only the packed sparse kernels do, for .mtx readers); reductions are covered by
-# tests/test_meltw_gpu.py against the pinned oracle instead.
+# samples/eltwise/eltwise_unary_reduce.c allocates with plain malloc(): synchronous reductions stage host operands
+# M N ldi reduce_x reduce_x2 reduce_rows op(0 add, 1 max) dtype n_cols_idx idx_type record_idx reduce_on_outputs iters
+@pytest.mark.parametrize("args", ["64 48 64 1 0 1 0 F32 0 0 0 0 1", "64 48 64 1 0 0 0 F32 0 0 0 0 1", "64 48 64 1 1 1 0 F32 0 0 0 0 1", "64 48 64 1 0 1 1 F32 0 0 0 0 1",
+                                  "64 48 64 1 0 0 0 BF16 0 0 0 0 1", "33 17 40 1 1 0 0 F32 0 0 0 0 1"])
+def test_reference_reduce_driver(args):
+    check("eltwise_unary_reduce", *args.split())
 
 
 @pytest.mark.parametrize("args", ["1 0 F32 F32 IMPLICIT F32 F32 64 48 64 64", "1 0 BF16 BF16 IMPLICIT F32 BF16 64 48 64 64", "1 4 F32 F32 IMPLICIT F32 F32 33 17 40 36"])
