@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "internal.hpp"
+#include "lowp.hpp"
 
 // a*b+c below means two roundings unless fma()/MFMA is spelled out: parity with the reference's C
 // loops (built without FMA contraction) depends on it.
@@ -36,11 +37,27 @@ __device__ __forceinline__ unsigned short mw_f2bf(float f) {
 }
 typedef GM const char* gcptr;
 typedef GM char* gptr;
+// element access of the general kernels: f32, bf16 and -- through lowp.hpp, bit-identical to the reference's conversions -- f16, bf8, hf8
+__device__ __forceinline__ int mw_size(int type) {
+  return type == LIBXSMM_DATATYPE_F32 ? 4 : (type == LIBXSMM_DATATYPE_BF8 || type == LIBXSMM_DATATYPE_HF8) ? 1 : 2;
+}
 __device__ __forceinline__ float mw_load(gcptr p, long long idx, int type) {
-  return (type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)p)[idx] : mw_bf2f(((GM const unsigned short*)p)[idx]);
+  switch (type) {
+    case LIBXSMM_DATATYPE_F32: return ((GM const float*)p)[idx];
+    case LIBXSMM_DATATYPE_F16: return lowp::f16_to_f32(((GM const unsigned short*)p)[idx]);
+    case LIBXSMM_DATATYPE_BF8: return lowp::bf8_to_f32(((GM const unsigned char*)p)[idx]);
+    case LIBXSMM_DATATYPE_HF8: return lowp::hf8_to_f32(((GM const unsigned char*)p)[idx]);
+    default: return mw_bf2f(((GM const unsigned short*)p)[idx]);
+  }
 }
 __device__ __forceinline__ void mw_store(gptr p, long long idx, int type, float v) {
-  if (type == LIBXSMM_DATATYPE_F32) ((GM float*)p)[idx] = v; else ((GM unsigned short*)p)[idx] = mw_f2bf(v);
+  switch (type) {
+    case LIBXSMM_DATATYPE_F32: ((GM float*)p)[idx] = v; break;
+    case LIBXSMM_DATATYPE_F16: ((GM unsigned short*)p)[idx] = lowp::f32_to_f16(v); break;
+    case LIBXSMM_DATATYPE_BF8: ((GM unsigned char*)p)[idx] = lowp::f16_to_bf8_rne(lowp::f32_to_f16(v)); break;
+    case LIBXSMM_DATATYPE_HF8: ((GM unsigned char*)p)[idx] = lowp::f16_to_hf8_rne(lowp::f32_to_f16(v)); break;
+    default: ((GM unsigned short*)p)[idx] = mw_f2bf(v);
+  }
 }
 
 enum { BC_NONE = 0, BC_ROW = 1, BC_COL = 2, BC_SCALAR = 3 };
@@ -224,8 +241,10 @@ __global__ __launch_bounds__(256) void meltw_unary_kernel(MeltwArgs p) {
   if (!e.valid) return;
   // pure copies / zero fill of same-width types stay bit-exact (no float round trip)
   if (p.in0_type == p.out_type && (p.type == LIBXSMM_MELTW_TYPE_UNARY_IDENTITY || p.type == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR)) {
-    if (p.in0_type == LIBXSMM_DATATYPE_F32) ((GM unsigned int*)out)[i + (long long)j * p.ldo] = ((GM const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
-    else ((GM unsigned short*)out)[i + (long long)j * p.ldo] = ((GM const unsigned short*)in)[bc_index(bc, i, j, p.ldi)];
+    const int sz = mw_size(p.in0_type);
+    if (sz == 4) ((GM unsigned int*)out)[i + (long long)j * p.ldo] = ((GM const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
+    else if (sz == 2) ((GM unsigned short*)out)[i + (long long)j * p.ldo] = ((GM const unsigned short*)in)[bc_index(bc, i, j, p.ldi)];
+    else ((GM unsigned char*)out)[i + (long long)j * p.ldo] = ((GM const unsigned char*)in)[bc_index(bc, i, j, p.ldi)];
     return;
   }
   const float x = mw_load(in, bc_index(bc, i, j, p.ldi), p.in0_type);
@@ -342,7 +361,9 @@ __global__ __launch_bounds__(256) void meltw_ew8_kernel(MeltwArgs p, unsigned in
   ew8_store(out, p.out_type, oidx, y);
 }
 
-static bool is_float_type(int t) { return t == LIBXSMM_DATATYPE_F32 || t == LIBXSMM_DATATYPE_BF16; }
+static bool is_float_type(int t) { return t == LIBXSMM_DATATYPE_F32 || t == LIBXSMM_DATATYPE_BF16; }      // the types the vector kernels know
+// ... and the ones the general kernels convert element by element [ref: mateltwise ref :262-324: F16, BF8, HF8 in and out]
+static bool is_tpp_float(int t) { return is_float_type(t) || t == LIBXSMM_DATATYPE_F16 || t == LIBXSMM_DATATYPE_BF8 || t == LIBXSMM_DATATYPE_HF8; }
 // is this TPP eligible for meltw_ew8_kernel?
 static bool ew8_ok(const MeltwArgs& a) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_EW8"); return e && e[0] == '0'; }();
@@ -651,7 +672,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(MeltwArgs p) {
   gcptr in = (gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0;
   gptr out = (gptr)p.out + (long long)blockIdx.y * p.bs_out;
   const long long result_size = rows ? p.n : p.ldo;
-  gptr out2 = (want_x && want_x2) ? out + result_size * ((p.out_type == LIBXSMM_DATATYPE_F32) ? 4 : 2) : out;
+  gptr out2 = (want_x && want_x2) ? out + result_size * mw_size(p.out_type) : out;
   const float ident = (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) ? -3.402823466e+38f : (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN) ? 3.402823466e+38f : 0.0f;
   auto combine = [&](float a, float x) {
     if (is_add) return a + x;
@@ -711,7 +732,7 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
   gcptr in = (gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0;
   gptr out = (gptr)p.out + (long long)blockIdx.y * p.bs_out;
   const long long result_size = rows ? p.n : p.ldo;
-  gptr out2 = (want_x && want_x2) ? out + result_size * ((p.out_type == LIBXSMM_DATATYPE_F32) ? 4 : 2) : out;
+  gptr out2 = (want_x && want_x2) ? out + result_size * mw_size(p.out_type) : out;
   const float ident = (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) ? -3.402823466e+38f : (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN) ? 3.402823466e+38f : 0.0f;
   auto combine = [&](float a, float x) {
     if (is_add) return a + x;
@@ -815,7 +836,7 @@ __global__ __launch_bounds__(256) void reduce_combine_kernel(MeltwArgs p, const 
     b += x2;
   }
   gptr out = (gptr)p.out;
-  gptr out2 = (want_x && want_x2) ? out + (long long)p.ldo * ((p.out_type == LIBXSMM_DATATYPE_F32) ? 4 : 2) : out;
+  gptr out2 = (want_x && want_x2) ? out + (long long)p.ldo * mw_size(p.out_type) : out;
   if (is_add && init_acc) { if (want_x) a += mw_load(out, i, p.out_type); if (want_x2) b += mw_load(out2, i, p.out_type); }
   if (want_x) mw_store(out, i, p.out_type, a);
   if (want_x2) mw_store(out2, i, p.out_type, b);
@@ -861,7 +882,7 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
     int v; const int sz = payload_size(d.in0_type);
     if (t == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT || xform_mode(t, &v) != 0 ||
         t == LIBXSMM_MELTW_TYPE_UNARY_GATHER || t == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) return sz == 1 || sz == 2 || sz == 4 || sz == 8;
-    if (is_reduce_type(t)) return is_float_type(d.in0_type) && is_float_type(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP));
+    if (is_reduce_type(t)) return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP));
     if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) return d.in0_type == LIBXSMM_DATATYPE_F32 && (d.out_type == LIBXSMM_DATATYPE_BF16 || d.out_type == LIBXSMM_DATATYPE_U16 || d.out_type == LIBXSMM_DATATYPE_I16);
     const auto is_qint = [](int x) { return x == LIBXSMM_DATATYPE_I8 || x == LIBXSMM_DATATYPE_I16 || x == LIBXSMM_DATATYPE_I32; };
     if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT) return d.in0_type == LIBXSMM_DATATYPE_F32 && is_qint(d.out_type);       // [ref: :2195-2240]
@@ -873,7 +894,7 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
         default: return false;
       }
     }
-    if (!is_float_type(d.in0_type) || !is_float_type(d.out_type)) return false;
+    if (!is_tpp_float(d.in0_type) || !is_tpp_float(d.out_type)) return false;
     if (d.flags & LIBXSMM_MELTW_FLAG_UNARY_STOCHASTIC_ROUND) return false;
     switch (t) {
       case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_XOR: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT:
@@ -892,15 +913,15 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
     const bool cmp = t >= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GT && t <= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_NE;
     if (d.flags & LIBXSMM_MELTW_FLAG_BINARY_STOCHASTIC_ROUND) return false;
     if (f64) return arith && d.in1_type == LIBXSMM_DATATYPE_F64;
-    if (!is_float_type(d.in0_type) || !is_float_type(d.in1_type)) return false;
+    if (!is_tpp_float(d.in0_type) || !is_tpp_float(d.in1_type)) return false;
     if (cmp) return true;
-    return arith && is_float_type(d.out_type);
+    return arith && is_tpp_float(d.out_type);
   }
   if (d.operation == LIBXSMM_MELTW_OPERATION_TERNARY) {
     if (d.flags & LIBXSMM_MELTW_FLAG_TERNARY_STOCHASTIC_ROUND) return false;
-    if (t == LIBXSMM_MELTW_TYPE_TERNARY_SELECT) return f64 ? d.in1_type == LIBXSMM_DATATYPE_F64 : (is_float_type(d.in0_type) && is_float_type(d.in1_type) && is_float_type(d.out_type));
+    if (t == LIBXSMM_MELTW_TYPE_TERNARY_SELECT) return f64 ? d.in1_type == LIBXSMM_DATATYPE_F64 : (is_tpp_float(d.in0_type) && is_tpp_float(d.in1_type) && is_tpp_float(d.out_type));
     if (t == LIBXSMM_MELTW_TYPE_TERNARY_MULADD || t == LIBXSMM_MELTW_TYPE_TERNARY_NMULADD)
-      return is_float_type(d.in0_type) && is_float_type(d.in1_type) && is_float_type(d.in2_type) && is_float_type(d.out_type);
+      return is_tpp_float(d.in0_type) && is_tpp_float(d.in1_type) && is_tpp_float(d.in2_type) && is_tpp_float(d.out_type);
     return false;
   }
   return false;
@@ -971,7 +992,7 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       const bool bf = a.in0_type == LIBXSMM_DATATYPE_BF16;
       static const bool rvec_off = []() { const char* e = getenv("LIBXSMM_HIP_REDUCE_VEC"); return e && e[0] == '0'; }();
       const size_t al = bf ? 8 : 16;
-      if (!rvec_off && a.m % 4 == 0 && a.ldi % 4 == 0 && (((size_t)a.in0 | (size_t)a.bs_in0) % al) == 0 && a.nbatch < 65536) {
+      if (!rvec_off && is_float_type(a.in0_type) && a.m % 4 == 0 && a.ldi % 4 == 0 && (((size_t)a.in0 | (size_t)a.bs_in0) % al) == 0 && a.nbatch < 65536) {
         int G = 1; while (G < 64 && G < a.m / 4) G <<= 1;
         const int slices = (!rows && a.n >= 256) ? 16 : 1;
         const unsigned int gx = rows ? (unsigned int)((a.n + 4 * (64 / G) - 1) / (4 * (64 / G))) : (unsigned int)((a.m / 4 + 15) / 16);

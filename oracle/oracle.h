@@ -100,6 +100,11 @@ unsigned short oracle_f32_to_bf16_trunc(float x);
 float oracle_bf16_to_f32(unsigned short x);
 float oracle_bf8_to_f32(unsigned char x);    /* E5M2  [ref: src/libxsmm_math.c:546-551] */
 float oracle_hf8_to_f32(unsigned char x);    /* E4M3  [ref: src/libxsmm_math.c:553-585] */
+float oracle_f16_to_f32(unsigned short h);
+unsigned short oracle_f32_to_f16(float x);
+unsigned char oracle_f32_to_bf8_rne(float x);
+unsigned char oracle_f16_to_hf8_rne(unsigned short h);
+unsigned char oracle_f32_to_hf8_rne(float x);
 
 /* ---- comparison metric  [ref: src/libxsmm_matdiff.h:141-142 normf_rel] ---------------- */
 double oracle_normf_rel(int dtype, long long count, const void* ref, const void* tst);

@@ -79,3 +79,55 @@ float oracle_hf8_to_f32(unsigned char in) {
   r.u = (e_norm << 23) | (m << 20) | s;
   return r.f;
 }
+
+/* ---- IEEE half and the narrowing conversions of the 8-bit floats  [ref: src/libxsmm_math.c:600-636 (f16 -> f32), :824-900 (f32 -> f16),
+ * :731-746 (f32 -> bf8), :749-821 (f16 -> hf8)] ------------------------------------------------------------------------------------
+ * Restated case by case like the reference: special values, overflow, flush below half of the smallest subnormal, subnormal results
+ * with a sticky bit, normal results; RNE by adding (half ulp - 1 + lsb) to the bit pattern. */
+float oracle_f16_to_f32(unsigned short h) {
+  union { unsigned int u; float f; } r;
+  const unsigned int s = (unsigned int)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu;
+  if (e == 31u) { const unsigned int m = h & 0x3ffu; r.u = s | 0x7f800000u | ((m ? (m | 0x200u) : 0u) << 13); return r.f; }   /* NaNs quieted [:629-632] */
+  return half_bits_to_f32(h);
+}
+unsigned short oracle_f32_to_f16(float x) {
+  unsigned int u = f2u(x), s, e32, m32, e, m, fix;
+  if ((u & 0x7f800000u) == 0) u &= 0x80000000u;                                   /* DAZ [:835-838] */
+  s = (u & 0x80000000u) >> 16; e32 = (u & 0x7f800000u) >> 23; m32 = u & 0x007fffffu;
+  if (e32 == 0xffu) { e = 0x1fu; m = (m32 == 0) ? 0 : ((m32 >> 13) | 0x200u); }  /* inf / NaN [:845-848] */
+  else if (e32 > 127u + 15u) { e = 0x1fu; m = 0; }                               /* overflow -> inf */
+  else if (e32 < 127u - 15u - 10u) { e = 0; m = 0; }                             /* < 2^-25 -> 0 */
+  else if (e32 <= 127u - 15u) {                                                  /* subnormal half [:857-868] */
+    m = (m32 | 0x00800000u) >> ((127u - 15u) + 1u - e32);
+    m |= ((m32 & 0x1fffu) + 0x1fffu) >> 13;                                      /* sticky */
+    fix = (m >> 13) & 1u; m = (m + 0x0fffu + fix) >> 13; e = 0;
+  } else {                                                                       /* normal [:877-885] */
+    fix = (m32 >> 13) & 1u; u = u + 0x0fffu + fix;
+    e = ((u & 0x7f800000u) >> 23) - (127u - 15u); m = (u & 0x007fffffu) >> 13;
+  }
+  return (unsigned short)(s | (e << 10) | m);
+}
+unsigned char oracle_f32_to_bf8_rne(float x) {
+  unsigned short h = oracle_f32_to_f16(x);
+  const unsigned int fix = (h >> 8) & 1u;
+  if ((h & 0x7c00u) == 0x7c00u) h = (unsigned short)((h & 0x03ffu) == 0 ? h : (h | 0x0200u));   /* no rounding of inf / NaN [:740-742] */
+  else h = (unsigned short)(h + 0x007fu + fix);
+  return (unsigned char)(h >> 8);
+}
+unsigned char oracle_f16_to_hf8_rne(unsigned short in) {
+  const unsigned int s = (in & 0x8000u) >> 8, e16 = (in & 0x7c00u) >> 10, m16 = in & 0x03ffu;
+  unsigned int e, m, fix;
+  if (e16 == 0x1fu || e16 > 15u - 7u + 15u || (e16 == 15u - 7u + 15u && m16 > 0x0340u)) { e = 0xfu; m = 0x7u; }   /* specials, overflow -> NaN [:762-771] */
+  else if (e16 < 15u - 7u - 3u) { e = 0; m = 0; }
+  else if (e16 <= 15u - 7u) {                                                    /* subnormal [:777-789] */
+    m = (m16 | 0x0400u) >> ((15u - 7u) + 1u - e16);
+    m |= ((m16 & 0x007fu) + 0x007fu) >> 7;
+    fix = (m >> 7) & 1u; m = (m + 0x003fu + fix) >> 7; e = 0;
+  } else {                                                                       /* normal [:792-801] */
+    unsigned int h = in;
+    fix = (m16 >> 7) & 1u; h = (h + 0x003fu + fix) & 0xffffu;
+    e = ((h & 0x7c00u) >> 10) - (15u - 7u); m = (h & 0x03ffu) >> 7;
+  }
+  return (unsigned char)(s | (e << 3) | m);
+}
+unsigned char oracle_f32_to_hf8_rne(float x) { return oracle_f16_to_hf8_rne(oracle_f32_to_f16(x)); }

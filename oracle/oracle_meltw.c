@@ -58,11 +58,17 @@ static long long elem_index(int kind, long long i, long long j, long long ld) { 
 static float get_f32(const void* p, long long idx, int type) {                     /* [:274-297] */
   if (type == LIBXSMM_DATATYPE_F32) return ((const float*)p)[idx];
   if (type == LIBXSMM_DATATYPE_BF16) return oracle_bf16_to_f32(((const unsigned short*)p)[idx]);
+  if (type == LIBXSMM_DATATYPE_F16) return oracle_f16_to_f32(((const unsigned short*)p)[idx]);
+  if (type == LIBXSMM_DATATYPE_BF8) return oracle_bf8_to_f32(((const unsigned char*)p)[idx]);
+  if (type == LIBXSMM_DATATYPE_HF8) return oracle_hf8_to_f32(((const unsigned char*)p)[idx]);
   ORACLE_DIE("unsupported input datatype"); return 0.0f;
 }
 static void put_f32(void* p, long long idx, int type, float v) {                   /* [:299-324] */
   if (type == LIBXSMM_DATATYPE_F32) ((float*)p)[idx] = v;
   else if (type == LIBXSMM_DATATYPE_BF16) ((unsigned short*)p)[idx] = oracle_f32_to_bf16_rne(v);
+  else if (type == LIBXSMM_DATATYPE_F16) ((unsigned short*)p)[idx] = oracle_f32_to_f16(v);
+  else if (type == LIBXSMM_DATATYPE_BF8) ((unsigned char*)p)[idx] = oracle_f32_to_bf8_rne(v);
+  else if (type == LIBXSMM_DATATYPE_HF8) ((unsigned char*)p)[idx] = oracle_f32_to_hf8_rne(v);
   else ORACLE_DIE("unsupported output datatype");
 }
 static void bit_put(unsigned char* bits, long long i, long long j, long long ld_bits, int on) {   /* [:150-166] */

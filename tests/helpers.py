@@ -64,6 +64,8 @@ def rand_values(rng: np.random.Generator, count: int, dt: int) -> np.ndarray:
         v[rng.random(count) < 0.05] = 0
         return v
     v = (np.floor(rng.random(count) * 10.0) - 4.0) / 10.0
+    if dt == DT.F16:
+        return v.astype(np.float16).view(np.uint16)
     if dt == DT.BF16:
         return f32_to_bf16_trunc(v.astype(np.float32))
     return v.astype(NP_OF[dt])

@@ -429,3 +429,51 @@ def test_synchronous_tpp_calls_accept_plain_host_memory(what):
             p.out.secondary = masks[0].ctypes.data if is_host else masks[1].data_ptr()
         both(h, capi.UnaryParam, {"in_": f32(ld * n), "out": np.zeros(ld * n, np.float32)}, "out", ld * n, np.float32, extra)
         assert np.array_equal(masks[0], masks[1].cpu().numpy()) and masks[0].any()
+
+
+LOWP_PAIRS = [(DT.F16, DT.F16), (DT.BF8, DT.BF8), (DT.HF8, DT.HF8), (DT.F32, DT.F16), (DT.F16, DT.F32), (DT.F32, DT.BF8), (DT.F32, DT.HF8), (DT.BF16, DT.HF8), (DT.BF8, DT.BF16)]
+
+
+@pytest.mark.parametrize("typ", [UNARY.IDENTITY, UNARY.X2, UNARY.NEGATE, UNARY.INC, UNARY.RELU, UNARY.SIGMOID, UNARY.EXP])
+@pytest.mark.parametrize("in_dt,out_dt", LOWP_PAIRS, ids=lambda x: str(int(x)))
+def test_unary_16_and_8_bit_floats(typ, in_dt, out_dt):
+    """F16 / BF8 / HF8 operands of the TPPs (device conversions = libxsmm_amd/csrc/lowp.hpp, the code pinned against the reference on the
+    host): exact ops are bit-identical to the oracle; exp / sigmoid may land on the neighbouring code where the device's expf differs by an ulp."""
+    ref, got, _, _ = run_unary(typ, 33, 7, 40, 35, in_dt, out_dt, batch=3)
+    if typ in (UNARY.SIGMOID, UNARY.EXP):
+        diff = np.abs(ref.astype(np.int64) - got.astype(np.int64)) if out_dt != DT.F32 else np.abs(ref.view(np.int32).astype(np.int64) - got.view(np.int32).astype(np.int64))
+        assert diff.max() <= (1 if out_dt != DT.F32 else 64) and (out_dt == DT.F32 or (diff != 0).mean() < 0.05)
+    else:
+        assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("out_dt", [DT.F16, DT.BF8, DT.HF8])
+def test_device_narrowing_on_rounding_boundaries(out_dt):
+    halves = np.arange(0, 1 << 16, 3, dtype=np.uint16).view(np.float16).astype(np.float32)
+    halves = halves[np.isfinite(halves)]
+    ulp = np.abs(halves) * np.float32(2.0 ** -11)
+    with np.errstate(all="ignore"):
+        vals = np.concatenate([halves, halves + ulp, halves - ulp, halves + ulp / 2, halves * np.float32(1.0625),
+                               np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 65504.0, 65519.9, 65520.0, 6e-8, 2.98e-8, 2.9802322e-8, 1e-45, 448.0, 464.0, 465.0, 0.001953125, 0.0009765625], dtype=np.float32)]).astype(np.float32)
+    n = 64
+    m = (vals.size + n - 1) // n
+    inp = np.zeros(m * n, dtype=np.float32); inp[:vals.size] = vals
+    ref, got, _, _ = run_unary(UNARY.IDENTITY, m, n, m, m, DT.F32, out_dt, inp=inp)
+    assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("dts", [(DT.F16, DT.F16, DT.F16), (DT.BF8, DT.F32, DT.HF8), (DT.HF8, DT.HF8, DT.F32), (DT.F16, DT.BF16, DT.BF8)])
+@pytest.mark.parametrize("typ", [BINARY.ADD, BINARY.MUL, BINARY.MAX])
+def test_binary_16_and_8_bit_floats_bit_exact(typ, dts):
+    ref, got = run_binary(typ, 45, 13, 48, 45, 50, dts, batch=2)
+    assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("in_dt", [DT.F16, DT.BF8, DT.HF8])
+@pytest.mark.parametrize("rows", [0, 1])
+def test_reductions_16_and_8_bit_floats(in_dt, rows):
+    flags = UNARY_FLAG.REDUCE_ROWS if rows else UNARY_FLAG.REDUCE_COLS
+    m, n, ld = 40, 24, 48
+    out_elems = n if rows else m
+    ref, got, _, _ = run_unary(UNARY.REDUCE_X_OP_ADD, m, n, ld, out_elems, in_dt, DT.F32, flags=flags, out_elems=out_elems)
+    assert np.allclose(ref, got, rtol=1e-5, atol=1e-5)

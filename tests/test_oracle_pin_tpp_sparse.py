@@ -64,6 +64,37 @@ def test_unary_math_bit_identical(reference, typ, in_dt, out_dt):
     assert np.array_equal(a, b)
 
 
+LOWP_PAIRS = [(DT.F16, DT.F16), (DT.BF8, DT.BF8), (DT.HF8, DT.HF8), (DT.F32, DT.F16), (DT.F16, DT.F32), (DT.F32, DT.BF8), (DT.F32, DT.HF8), (DT.BF16, DT.HF8), (DT.BF8, DT.BF16)]
+
+
+@pytest.mark.parametrize("typ", [UNARY.IDENTITY, UNARY.X2, UNARY.NEGATE, UNARY.INC, UNARY.RELU, UNARY.SIGMOID, UNARY.EXP, UNARY.RECIPROCAL])
+@pytest.mark.parametrize("in_dt,out_dt", LOWP_PAIRS, ids=lambda x: str(int(x)))
+def test_unary_16_and_8_bit_floats_bit_identical(reference, typ, in_dt, out_dt):
+    """F16 / BF8 / HF8 in and out [ref: mateltwise ref :262-324]: the restated conversions round exactly like the reference's."""
+    inp = None
+    if typ == UNARY.RECIPROCAL:
+        v = (np.random.default_rng(6).random(40 * 7) + 0.25).astype(np.float32)
+        inp = {DT.F32: v, DT.F16: v.astype(np.float16).view(np.uint16), DT.BF16: (v.view(np.uint32) >> 16).astype(np.uint16)}.get(in_dt)
+    (a, b), _ = both_unary(reference, typ, 33, 7, 40, 35, in_dt, out_dt, inp=inp)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("out_dt", [DT.F16, DT.BF8, DT.HF8])
+def test_narrowing_on_rounding_boundaries_bit_identical(reference, out_dt):
+    """IDENTITY f32 -> narrow type over every half value, its neighbours and ties, overflow / underflow thresholds, NaN and infinities."""
+    halves = np.arange(0, 1 << 16, 3, dtype=np.uint16).view(np.float16).astype(np.float32)
+    halves = halves[np.isfinite(halves)]
+    ulp = np.abs(halves) * np.float32(2.0 ** -11)
+    with np.errstate(all="ignore"):
+        vals = np.concatenate([halves, halves + ulp, halves - ulp, halves + ulp / 2, halves * np.float32(1.0625), halves * np.float32(0.96875),
+                               np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 65504.0, 65519.9, 65520.0, 6e-8, 2.98e-8, 2.9802322e-8, 1e-45, 448.0, 464.0, 465.0, 0.001953125, 0.0009765625, 57344.0, 61440.0, 61439.9], dtype=np.float32)]).astype(np.float32)
+    n = 64
+    m = (vals.size + n - 1) // n
+    inp = np.zeros(m * n, dtype=np.float32); inp[:vals.size] = vals
+    (a, b), _ = both_unary(reference, UNARY.IDENTITY, m, n, m, m, DT.F32, out_dt, inp=inp)
+    assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("flag", [UNARY_FLAG.BCAST_ROW, UNARY_FLAG.BCAST_COL, UNARY_FLAG.BCAST_SCALAR])
 def test_unary_broadcast_bit_identical(reference, flag):
     (a, b), _ = both_unary(reference, UNARY.IDENTITY, 37, 11, 40, 37, DT.F32, DT.BF16, flags=flag)
