@@ -12,6 +12,7 @@
 // and ignored.
 #include <hip/hip_runtime_api.h>
 #include "internal.hpp"
+#include "lowp.hpp"
 
 #include <chrono>
 #include <algorithm>
@@ -189,6 +190,13 @@ static double md_load(libxsmm_datatype t, const void* p, size_t i) {
     case LIBXSMM_DATATYPE_I32: return ((const int*)p)[i];
     case LIBXSMM_DATATYPE_I16: return ((const short*)p)[i];
     case LIBXSMM_DATATYPE_I8: return ((const signed char*)p)[i];
+    case LIBXSMM_DATATYPE_I64: return (double)((const long long*)p)[i];
+    case LIBXSMM_DATATYPE_U32: return ((const unsigned int*)p)[i];
+    case LIBXSMM_DATATYPE_U16: return ((const unsigned short*)p)[i];
+    case LIBXSMM_DATATYPE_U8: return ((const unsigned char*)p)[i];
+    case LIBXSMM_DATATYPE_F16: return lowp::f16_to_f32(((const unsigned short*)p)[i]);      // [ref: libxsmm_math.c matdiff type switch]
+    case LIBXSMM_DATATYPE_BF8: return lowp::bf8_to_f32(((const unsigned char*)p)[i]);
+    case LIBXSMM_DATATYPE_HF8: return lowp::hf8_to_f32(((const unsigned char*)p)[i]);
     default: return NAN;
   }
 }

@@ -134,7 +134,8 @@ def test_reference_fsspmdm_driver(beta, edge_mtx):
     "1 0 F32 F32 F32 64 48 64 64", "1 0 BF16 F32 BF16 64 48 70 72", "1 0 F32 F32 BF16 33 17 40 36", "3 0 F32 F32 F32 64 48 64 64",
     "4 0 F32 F32 F32 32 32 32 32", "7 0 F32 F32 F32 64 48 64 64", "9 0 BF16 F32 BF16 64 48 64 64", "11 0 F32 F32 F32 64 48 64 64",
     "13 0 F32 F32 F32 64 48 64 64", "14 0 F32 F32 F32 64 48 64 64", "15 0 F32 F32 F32 64 48 64 64", "16 0 F32 F32 F32 64 48 64 64",
-    "17 0 F32 F32 F32 64 48 64 64", "1 1 F32 F32 F32 64 48 64 64", "1 2 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 64 48 64 64", "2 0 F32 F32 F32 64 48 64 64",
+    "17 0 F32 F32 F32 64 48 64 64", "1 0 F16 F32 F16 64 48 64 64", "13 0 BF8 F32 BF8 64 48 64 64", "3 0 HF8 F32 HF8 33 17 40 36", "1 0 F32 F32 HF8 64 48 64 64",
+    "9 0 F16 F32 F16 64 48 64 64", "1 1 F32 F32 F32 64 48 64 64", "1 2 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 64 48 64 64", "2 0 F32 F32 F32 64 48 64 64",
 ])
 def test_reference_unary_driver(args):
     check("eltwise_unary_simple", *args.split())
@@ -142,7 +143,7 @@ def test_reference_unary_driver(args):
 
 @pytest.mark.parametrize("args", [
     "1 0 F32 F32 F32 F32 64 48 64 64", "2 0 BF16 BF16 F32 BF16 64 48 64 64", "3 1 F32 F32 F32 F32 64 48 64 64", "4 2 F32 F32 F32 F32 64 48 64 64",
-    "5 0 F32 F32 F32 F32 64 48 64 64", "9 4 F32 F32 F32 F32 33 17 40 36", "10 5 F32 F32 F32 F32 64 48 64 64", "1 6 BF16 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 BF16 64 48 64 64",
+    "5 0 F32 F32 F32 F32 64 48 64 64", "1 0 F16 F16 F32 F16 64 48 64 64", "2 0 BF8 BF8 F32 BF8 64 48 64 64", "1 2 HF8 HF8 F32 HF8 33 17 40 36", "9 4 F32 F32 F32 F32 33 17 40 36", "10 5 F32 F32 F32 F32 64 48 64 64", "1 6 BF16 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 BF16 64 48 64 64",
 ])
 def test_reference_binary_driver(args):
     check("eltwise_binary_simple", *args.split())
