@@ -46,3 +46,16 @@ def gather_shards(local, count: int, granule: int = 1, group=None):
 def byte_offsets(begin: int, strides: Sequence[int]) -> List[int]:
     """Byte offsets to add to the `primary` slots so that a batched launch starts at problem `begin`."""
     return [begin * s for s in strides]
+
+
+def reduce_chain_partials(partial, beta_c=None, group=None):
+    """BRGEMM variant B across GPUs: ONE long batch-reduce chain is split by `shard_range(br_count, world, rank)`; every
+    rank runs its slice with beta = 0 into its own f32 m x n tile (`partial`, a torch tensor on its device) and the tiles are summed
+    with a single all-reduce -- the path's only exchange step, m*n*4 bytes (latency-bound on xGMI, negligible next to the chain).
+    `beta_c` (the caller's C for beta = 1) is added once, after the reduction.  Returns the full C on every rank.
+
+    The summation order differs from the serial chain (sum of per-rank partial sums), exactly like the single-GPU split-chain path."""
+    import torch.distributed as dist
+    total = partial.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return total if beta_c is None else total + beta_c
