@@ -46,6 +46,9 @@
 #define LIBXSMM_PUTENV(A) putenv(A)
 #define LIBXSMM_PRAGMA_SIMD
 #define LIBXSMM_OMP_VAR(A) (void)(A)
+#define LIBXSMM_ELIDE_RESULT(TYPE, EXPR) do { const TYPE libxsmm_elide_result_ = (EXPR); (void)libxsmm_elide_result_; } while (0)
+#define LIBXSMM_ROUND(A) round(A)
+#define LIBXSMM_DELTA(T0, T1) ((T0) < (T1) ? ((T1) - (T0)) : ((T0) - (T1)))
 #define LIBXSMM_CONST_VOID_PTR(A) ((const void*)(A))
 #if defined(_OPENMP)
 # define LIBXSMM_OMP_MASKED _Pragma("omp master")
@@ -135,6 +138,17 @@ LIBXSMM_API void libxsmm_stochastic_convert_fp32_bf8(const float* in, libxsmm_bf
 LIBXSMM_API unsigned int* libxsmm_rng_create_extstate(unsigned int seed);
 LIBXSMM_API unsigned int libxsmm_rng_get_extstate_size(void);
 LIBXSMM_API void libxsmm_rng_destroy_extstate(unsigned int* stateptr);
+
+/* ---- small math helpers the quantisation samples use [ref: include/utils/libxsmm_math.h:40-54, include/libxsmm_math.h:257-267] ------ */
+/** 2^x for 8-bit exponents, exact in single precision (a power of two, or 0 / infinity beyond the f32 range). */
+LIBXSMM_API float libxsmm_sexp2_u8(unsigned char x);
+LIBXSMM_API float libxsmm_sexp2_i8(signed char x);
+LIBXSMM_API float libxsmm_sexp2_i8i(int x);
+/** round to the nearest integer, ties to even (the current rounding mode of the host is the default one) */
+LIBXSMM_API double libxsmm_nearbyint(double x);
+LIBXSMM_API float libxsmm_nearbyintf(float x);
+LIBXSMM_API double libxsmm_dsqrt(double x);
+LIBXSMM_API float libxsmm_ssqrt(float x);
 
 /* ---- strings [ref: include/libxsmm_memory.h:102-103] ------------------------------------- */
 LIBXSMM_API const char* libxsmm_stristrn(const char a[], const char b[], size_t maxlen);

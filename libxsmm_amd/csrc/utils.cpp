@@ -5,6 +5,7 @@
 #include "../../include/libxsmm_utils.h"
 #include "lowp.hpp"
 #include <cctype>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 
@@ -69,6 +70,14 @@ LIBXSMM_API unsigned int* libxsmm_rng_create_extstate(unsigned int seed) {
 }
 LIBXSMM_API unsigned int libxsmm_rng_get_extstate_size(void) { return (unsigned int)(64 * sizeof(unsigned int)); }
 LIBXSMM_API void libxsmm_rng_destroy_extstate(unsigned int* stateptr) { libxsmm_free(stateptr); }
+
+LIBXSMM_API float libxsmm_sexp2_i8(signed char x) { return std::ldexp(1.0f, (int)x); }
+LIBXSMM_API float libxsmm_sexp2_u8(unsigned char x) { return std::ldexp(1.0f, (int)x); }       // 2^128 and above: +infinity, like the f32 range demands
+LIBXSMM_API float libxsmm_sexp2_i8i(int x) { return libxsmm_sexp2_i8((signed char)x); }
+LIBXSMM_API double libxsmm_nearbyint(double x) { return std::nearbyint(x); }
+LIBXSMM_API float libxsmm_nearbyintf(float x) { return std::nearbyintf(x); }
+LIBXSMM_API double libxsmm_dsqrt(double x) { return std::sqrt(x); }
+LIBXSMM_API float libxsmm_ssqrt(float x) { return std::sqrt(x); }
 
 LIBXSMM_API const char* libxsmm_stristrn(const char a[], const char b[], size_t maxlen) {
   if (!a || !b || !*a || !*b || maxlen == 0) return nullptr;

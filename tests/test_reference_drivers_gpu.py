@@ -243,3 +243,10 @@ def test_reference_threadsafety_test():
 
 def test_reference_matdiff_test():
     check("matdiff")
+
+
+# samples/eltwise/eltwise_unary_quantization.c -- F32 I8|I16|I32 M N ldi ldo skip_scf_cvt signed_sat: QUANT and DEQUANT TPPs
+@pytest.mark.parametrize("args", ["F32 I8 64 48 64 64 0 0", "F32 I8 64 48 64 64 0 1", "F32 I16 33 17 40 36 0 1", "F32 I32 64 48 64 64 1 0", "F32 I8 64 48 64 64 1 1"])
+def test_reference_quantization_driver(args):
+    out = check("eltwise_unary_quantization", *args.split())
+    assert out.count("SUCCESS") == 2, out[-1500:]
