@@ -109,3 +109,18 @@ int main(void) {
     assert r.returncode == 0, r.stderr
     ours = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
     assert ours == reference.struct_sizes(len(ours))
+
+
+@pytest.mark.parametrize("header", ["libxsmm.h", "libxsmm_utils.h", "libxsmm_source.h", "libxsmm_macros.h", "libxsmm_math.h"])
+@pytest.mark.parametrize("compiler,std", [("gcc", "-std=c99"), ("g++", "-std=c++11")])
+def test_public_headers_are_clean_c99_and_cxx11(header, compiler, std, tmp_path):
+    """A drop-in header is included by other people's C and C++ code: no warnings under -Wall -Wextra -pedantic."""
+    import shutil
+    import subprocess
+    if not shutil.which(compiler):
+        pytest.skip(f"{compiler} not installed")
+    src = tmp_path / ("t.c" if compiler == "gcc" else "t.cpp")
+    src.write_text(f"#include <{header}>\nint main(void) {{ return 0; }}\n")
+    inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include")
+    r = subprocess.run([compiler, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
