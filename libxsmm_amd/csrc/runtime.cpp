@@ -342,8 +342,10 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
       a.c = (char*)stage(a.c, ec, true, true);
       if (a.d) a.d = (const char*)stage(a.d, (size_t)a.m * (size_t)typesize(d.c_type), true, false);
       if (a.relu_mask) a.relu_mask = (unsigned char*)stage(a.relu_mask, (size_t)(((a.ldc + 15) / 16) * 16 / 8) * (size_t)a.n, true, true);
-      if (a.a_scf && a.br_mode == 0) a.a_scf = (const char*)stage(a.a_scf, (size_t)a.lda * (size_t)(a.k / 32), true, false);
-      if (a.b_scf && a.br_mode == 0) a.b_scf = (const char*)stage(a.b_scf, (size_t)a.ldb * (size_t)(a.k / 32), true, false);
+      // E8M0 scales: one byte per 32 elements, so a batch-reduce element is (stride * elements-per-byte / 32) bytes further on
+      const size_t epb_a = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1, epb_b = (d.b_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
+      if (a.a_scf) a.a_scf = (const char*)stage(a.a_scf, span * ((size_t)a.br_stride_a * epb_a / 32) + (size_t)a.lda * (size_t)(a.k / 32), true, false);
+      if (a.b_scf) a.b_scf = (const char*)stage(a.b_scf, span * ((size_t)a.br_stride_b * epb_b / 32) + (size_t)a.ldb * (size_t)(a.k / 32), true, false);
       if (!a.a || !a.b || !a.c) return;
     }
   }

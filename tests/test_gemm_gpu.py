@@ -456,8 +456,10 @@ def test_mxmx_dispatch_rules():
 
 
 @pytest.mark.parametrize("kw", [dict(m=13, n=5, k=7, a_type=DT.F64, beta=1), dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=3),
-                                dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2)],
-                         ids=["hello_f64", "f32_strdbr", "bf16_bias_relumask"])
+                                dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2),
+                                dict(m=32, n=32, k=64, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2),
+                                dict(m=32, n=32, k=64, a_type=DT.MXHF8, b_type=DT.MXHF8, c_type=DT.F32, flags=F.VNNI_A | F.VNNI_B | F.TRANS_B, beta=1)],
+                         ids=["hello_f64", "f32_strdbr", "bf16_bias_relumask", "mxfp4_weights_strdbr", "mxhf8_mxhf8"])
 def test_synchronous_gemm_accepts_plain_host_memory(kw):
     """The reference's contract is "any pointer, C valid on return" (its hello-world mallocs A, B and C).  A synchronous single call
     stages operands that live in plain host memory (numpy arrays here), including the bias and the ReLU bitmask; asynchronous and
