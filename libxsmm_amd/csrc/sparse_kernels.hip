@@ -559,6 +559,27 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, uns
       if (has2) has2 = next_chunk(kb2, st2, m2, kgp);
     }
   }
+  if (!c_f32 && mt == 4 && nbl_cnt * BN16 == 4 && (p.M % 8) == 0 && ((((size_t)cbase) & 15) == 0)) {
+    // Full 64 x 64 bf16 tile: a lane holds 4 consecutive rows of one column, so a direct store writes 32-byte pieces of sixteen 128-byte
+    // lines.  Pass the tile through the (now idle) A ring instead -- 8-byte slots XOR-swizzled by the column so that neither side has
+    // bank conflicts -- and write every column's 64 rows as one full line: 8 lanes x 16 bytes.
+    unsigned int* tile = &abuf[0][0];                                               // 64 columns x 128 bytes
+    sfor<16>([&](auto ic) {
+      constexpr int nt = ic.value / 4, it = ic.value % 4;
+      const int n = 16 * nt + lx;
+      u32x2v v; v[0] = cvt2(acc[nt][it][0], acc[nt][it][1]); v[1] = cvt2(acc[nt][it][2], acc[nt][it][3]);
+      *(u32x2v*)(tile + n * 32 + 2 * ((4 * it + kg) ^ (n & 15))) = v;
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int n = 8 * r + (lane >> 3), j = lane & 7, x = n & 15;
+      u32x4v w = *(const u32x4v*)(tile + n * 32 + 4 * (j ^ (x >> 1)));
+      if (x & 1) { const unsigned int t0 = w[0], t1 = w[1]; w[0] = w[2]; w[1] = w[3]; w[2] = t0; w[3] = t1; }
+      *(GM u32x4v*)(cbase + ((long long)(n0 + n) * p.M + i0) * 2 + 16 * j) = w;
+    }
+    return;
+  }
   sfor<16>([&](auto ic) {
     constexpr int nt = ic.value / 4, it = ic.value % 4;
     if (it < mt && nt < nbl_cnt * BN16) {
