@@ -547,9 +547,7 @@ LIBXSMM_API void libxsmm_matdiff_clear(libxsmm_matdiff_info* info);
 LIBXSMM_API void libxsmm_matdiff_reduce(libxsmm_matdiff_info* output, const libxsmm_matdiff_info* input);
 LIBXSMM_API double libxsmm_matdiff_epsilon(const libxsmm_matdiff_info* input);
 
-#include "libxsmm_hip.h"
-
-#endif /* LIBXSMM_H *//**
+/**
  * Dense packed GEMMs (SOA layouts, packed width fastest); caller owned, release with libxsmm_release_kernel.
  * packed:  A [K][lda][P], B [N][ldb][P], C [N][ldc][P]:  C[n][m][p] (+)= sum_k A[k][m][p] * B[n][k][p]
  * ac_rm:   A [M][lda][P], B row-major [K][ldb] (not packed), C [M][ldc][P]:  C[m][n][p] (+)= sum_k A[m][k][p] * B[k][n]
@@ -564,4 +562,6 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_gemm_ac_rm(libxsmm_gemm_s
 LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_gemm_bc_rm(libxsmm_gemm_shape gemm_shape,
   libxsmm_bitfield gemm_flags, libxsmm_bitfield prefetch_flags, libxsmm_blasint packed_width);
 
+#include "libxsmm_hip.h"
 
+#endif /* LIBXSMM_H */
