@@ -140,6 +140,13 @@ XREF unsigned char xref_convert_f32_to_bf8_stochastic(float x, unsigned int seed
 XREF float xref_convert_bf8_to_f32(unsigned char x) { return libxsmm_convert_bf8_to_f32(x); }
 XREF float xref_convert_hf8_to_f32(unsigned char x) { return libxsmm_convert_hf8_to_f32(x); }
 XREF int xref_cpuid_dot_pack_factor(libxsmm_datatype t) { return libxsmm_cpuid_dot_pack_factor(t); }
+/* the whole statistics record, for tests/test_utils_cpu.py (same struct layout on both sides, checked by test_capi_cpu.py) */
+XREF int xref_matdiff(void* info, libxsmm_datatype t, libxsmm_blasint m, libxsmm_blasint n, const void* ref, const void* tst, const libxsmm_blasint* ldref, const libxsmm_blasint* ldtst) {
+  return libxsmm_matdiff((libxsmm_matdiff_info*)info, t, m, n, ref, tst, ldref, ldtst);
+}
+XREF void xref_matdiff_reduce(void* out, const void* in) { libxsmm_matdiff_reduce((libxsmm_matdiff_info*)out, (const libxsmm_matdiff_info*)in); }
+XREF void xref_matdiff_clear(void* info) { libxsmm_matdiff_clear((libxsmm_matdiff_info*)info); }
+XREF double xref_matdiff_epsilon(const void* info) { return libxsmm_matdiff_epsilon((const libxsmm_matdiff_info*)info); }
 XREF double xref_matdiff_normf_rel(libxsmm_datatype t, libxsmm_blasint m, libxsmm_blasint n, const void* ref, const void* tst) {
   libxsmm_matdiff_info info; libxsmm_matdiff_clear(&info);
   if (EXIT_SUCCESS != libxsmm_matdiff(&info, t, m, n, ref, tst, NULL, NULL)) return -1.0;

@@ -107,3 +107,53 @@ def test_reference_host_side_unit_tests_pass_on_this_library(name):
     if not os.path.exists(exe):
         pytest.skip(f"oracle/_ref/drivers/{name} not built (needs /root/reference)")
     assert subprocess.run([exe], capture_output=True, timeout=60).returncode == 0
+
+
+class _MatdiffInfo(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("norm1_abs norm1_rel normi_abs normi_rel normf_rel linf_abs linf_rel l2_abs l2_rel rsq "
+                                           "l1_ref min_ref max_ref avg_ref var_ref l1_tst min_tst max_tst avg_tst var_tst v_ref v_tst").split()] + \
+               [(k, C.c_int) for k in ("m", "n", "i", "r")]
+
+
+def _same_record(a, b):
+    for name, _ in _MatdiffInfo._fields_:
+        x, y = getattr(a, name), getattr(b, name)
+        if isinstance(x, float):
+            if not ((x != x and y != y) or x == y or abs(x - y) <= 1e-12 * max(abs(x), abs(y))):
+                return name
+        elif x != y:
+            return name
+    return None
+
+
+@pytest.mark.parametrize("dt,npdt", [(1, np.float32), (0, np.float64)], ids=["f32", "f64"])
+def test_matdiff_record_matches_reference_field_by_field(ours, ref, dt, npdt):
+    """libxsmm_matdiff / _reduce / _epsilon against the reference on random matrices with padded leading dimensions, vectors, exact
+    equality, zeros in the reference and a NaN / an infinity in the test set."""
+    from libxsmm_amd.capi import DT
+    dtype = DT.F32 if npdt == np.float32 else DT.F64
+    rng = np.random.default_rng(17)
+    acc_o, acc_r = _MatdiffInfo(), _MatdiffInfo()
+    ours.libxsmm_matdiff_clear(C.byref(acc_o)); ref.xref_matdiff_clear(C.byref(acc_r))
+    ours.libxsmm_matdiff_epsilon.restype = C.c_double; ref.xref_matdiff_epsilon.restype = C.c_double
+    cases = [(13, 7, 16, 13, "plain"), (1, 9, 1, 1, "row"), (9, 1, 9, 9, "col"), (8, 8, 8, 8, "equal"), (6, 5, 6, 8, "zeros"), (7, 4, 9, 7, "nan"), (7, 4, 7, 7, "inf")]
+    for m, n, ldr, ldt, kind in cases:
+        r = (rng.standard_normal(ldr * n) * 3).astype(npdt)
+        t = np.zeros(ldt * n, dtype=npdt)
+        t.reshape(n, ldt)[:, :m] = r.reshape(n, ldr)[:, :m] + (0 if kind == "equal" else 1e-3) * rng.standard_normal((n, m)).astype(npdt)
+        if kind == "zeros":
+            r.reshape(n, ldr)[:, ::2] = 0
+        if kind == "nan":
+            t.reshape(n, ldt)[2, 3] = np.nan
+        if kind == "inf":
+            t.reshape(n, ldt)[1, 2] = np.inf
+        io, ir = _MatdiffInfo(), _MatdiffInfo()
+        lr, lt = C.c_int(ldr), C.c_int(ldt)
+        args = (int(dtype), m, n, C.c_void_p(r.ctypes.data), C.c_void_p(t.ctypes.data), C.byref(lr), C.byref(lt))
+        assert ours.libxsmm_matdiff(C.byref(io), *args) == ref.xref_matdiff(C.byref(ir), *args) == 0
+        assert _same_record(io, ir) is None, (kind, _same_record(io, ir))
+        eo, er = ours.libxsmm_matdiff_epsilon(C.byref(io)), ref.xref_matdiff_epsilon(C.byref(ir))
+        assert (eo != eo and er != er) or eo == er or abs(eo - er) <= 1e-12 * abs(er), kind
+        if kind not in ("nan", "inf"):
+            ours.libxsmm_matdiff_reduce(C.byref(acc_o), C.byref(io)); ref.xref_matdiff_reduce(C.byref(acc_r), C.byref(ir))
+            assert _same_record(acc_o, acc_r) is None, ("reduce after " + kind, _same_record(acc_o, acc_r))
