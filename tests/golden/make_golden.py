@@ -30,6 +30,7 @@ from sparse_helpers import pack_vnni2, read_mtx, structured_2_of_8  # noqa: E402
 
 REF = os.environ.get("LIBXSMM_REFERENCE", "/root/reference")
 F = GEMM_FLAG
+MXMX = F.VNNI_A | F.VNNI_B | F.TRANS_B
 
 GEMM = {
     "cfg1_f32_23": dict(m=23, n=23, k=23),
@@ -43,6 +44,17 @@ GEMM = {
     "bf16_bias_relumask_beta1": dict(m=32, n=24, k=16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2, beta=1),
     "bf16_f32out": dict(m=33, n=17, k=18, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, beta=1),
     "f32_sigmoid": dict(m=20, n=12, k=16, act=3, beta=1),
+    # low-precision variants: libxsmm_reference_gemm's int8 / fp8 / microscaling branches, src/generator_gemm_reference_impl.c:949-1320,1452-1790,2171-2800
+    "i8_vnni4_strd": dict(m=32, n=32, k=64, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3, batch=2),
+    "u8i8_f32_scf_beta1": dict(m=64, n=32, k=64, a_type=DT.U8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.0625, beta=1),
+    "i8u8_generic": dict(m=17, n=9, k=12, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, beta=1, ldc=20),
+    "bf8_strd": dict(m=32, n=32, k=64, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3, batch=2),
+    "hf8_beta1": dict(m=64, n=64, k=64, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1),
+    "mxfp4_bf16": dict(m=64, n=64, k=64, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=2),
+    "mxfp4_f32_generic": dict(m=17, n=9, k=64, a_type=DT.MXFP4X2, b_type=DT.F32, c_type=DT.F32, flags=F.VNNI_A, lda=20, ldc=24, beta=1),
+    "mxfp4_mxfp4_strd": dict(m=64, n=64, k=128, a_type=DT.MXFP4X2, b_type=DT.MXFP4X2, c_type=DT.F32, flags=MXMX, beta=1, br_type=capi.BR_STRIDE, br_count=2),
+    "mxhf8_mxhf8": dict(m=32, n=32, k=64, a_type=DT.MXHF8, b_type=DT.MXHF8, c_type=DT.F32, flags=MXMX),
+    "mxbf8_generic": dict(m=17, n=9, k=64, a_type=DT.MXBF8, b_type=DT.MXBF8, c_type=DT.F32, flags=MXMX, lda=20, ldb=12, ldc=24, beta=1),
 }
 
 
