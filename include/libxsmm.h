@@ -525,6 +525,8 @@ LIBXSMM_API double libxsmm_timer_duration(libxsmm_timer_tickint tick0, libxsmm_t
 LIBXSMM_API void libxsmm_rng_set_seed(unsigned int seed);
 LIBXSMM_API double libxsmm_rng_f64(void);
 LIBXSMM_API unsigned int libxsmm_rng_u32(unsigned int n);
+LIBXSMM_API void libxsmm_rng_seq(void* data, size_t nbytes);
+LIBXSMM_API void libxsmm_rng_f32_seq(float* rngs, libxsmm_blasint count);
 LIBXSMM_API float libxsmm_convert_bf16_to_f32(libxsmm_bfloat16 in);
 LIBXSMM_API libxsmm_bfloat16 libxsmm_convert_f32_to_bf16_rne(float in);
 LIBXSMM_API libxsmm_bfloat16 libxsmm_convert_f32_to_bf16_truncate(float in);

@@ -58,14 +58,33 @@
 
 /* multi-dimensional views over flat buffers (C99 variably modified types): NDIMS is a literal 1..6,
  * DECL lists the initial pointer followed by the NDIMS-1 inner bounds, ACCESS the NDIMS indices followed by the same bounds */
-#define LIBXSMM_VLA_DECL(NDIMS, ELEMENT_TYPE, ARRAY_VAR, ...) LIBXSMM_VLA_DECL_##NDIMS(ELEMENT_TYPE, ARRAY_VAR, __VA_ARGS__)
+#if !defined(LIBXSMM_ASSERT)
+# include <assert.h>
+# define LIBXSMM_ASSERT(EXPR) assert(EXPR)
+# define LIBXSMM_ASSERT_MSG(EXPR, MSG) assert((EXPR) && *(MSG))
+#endif
+/* linear (row-major) index of I0..In-1 under the bounds S1..Sn-1, and untyped / typed element addresses computed from it
+ * [ref: include/libxsmm_macros.h:751-819]; arrays declared by LIBXSMM_VLA_DECL are real C99 VLAs here, so their name carries no postfix */
+#define LIBXSMM_VLA
+#define LIBXSMM_VLA_POSTFIX
+#define LIBXSMM_INDEX1(NDIMS, ...) LIBXSMM_CONCATENATE(LIBXSMM_INDEX1_, NDIMS)(__VA_ARGS__)
+#define LIBXSMM_INDEX1_1(I0) ((size_t)(I0))
+#define LIBXSMM_INDEX1_2(I0, I1, S1) (LIBXSMM_INDEX1_1(I0) * (size_t)(S1) + (size_t)(I1))
+#define LIBXSMM_INDEX1_3(I0, I1, I2, S1, S2) (LIBXSMM_INDEX1_2(I0, I1, S1) * (size_t)(S2) + (size_t)(I2))
+#define LIBXSMM_INDEX1_4(I0, I1, I2, I3, S1, S2, S3) (LIBXSMM_INDEX1_3(I0, I1, I2, S1, S2) * (size_t)(S3) + (size_t)(I3))
+#define LIBXSMM_INDEX1_5(I0, I1, I2, I3, I4, S1, S2, S3, S4) (LIBXSMM_INDEX1_4(I0, I1, I2, I3, S1, S2, S3) * (size_t)(S4) + (size_t)(I4))
+#define LIBXSMM_INDEX1_6(I0, I1, I2, I3, I4, I5, S1, S2, S3, S4, S5) (LIBXSMM_INDEX1_5(I0, I1, I2, I3, I4, S1, S2, S3, S4) * (size_t)(S5) + (size_t)(I5))
+#define LIBXSMM_ACCESS_RO(NDIMS, TYPESIZE, ARRAY, ...) ((const void*)((const char*)(ARRAY) + (size_t)(TYPESIZE) * LIBXSMM_INDEX1(NDIMS, __VA_ARGS__)))
+#define LIBXSMM_ACCESS_RW(NDIMS, TYPESIZE, ARRAY, ...) ((void*)((char*)(ARRAY) + (size_t)(TYPESIZE) * LIBXSMM_INDEX1(NDIMS, __VA_ARGS__)))
+#define LIBXSMM_ACCESS(NDIMS, TYPE, ARRAY, ...) ((TYPE*)(ARRAY) + LIBXSMM_INDEX1(NDIMS, __VA_ARGS__))
+#define LIBXSMM_VLA_DECL(NDIMS, ELEMENT_TYPE, ARRAY_VAR, ...) LIBXSMM_CONCATENATE(LIBXSMM_VLA_DECL_, NDIMS)(ELEMENT_TYPE, ARRAY_VAR, __VA_ARGS__)
 #define LIBXSMM_VLA_DECL_1(T, V, INIT) T* V = (T*)(INIT)
 #define LIBXSMM_VLA_DECL_2(T, V, INIT, S1) T (*V)[S1] = (T (*)[S1])(INIT)
 #define LIBXSMM_VLA_DECL_3(T, V, INIT, S1, S2) T (*V)[S1][S2] = (T (*)[S1][S2])(INIT)
 #define LIBXSMM_VLA_DECL_4(T, V, INIT, S1, S2, S3) T (*V)[S1][S2][S3] = (T (*)[S1][S2][S3])(INIT)
 #define LIBXSMM_VLA_DECL_5(T, V, INIT, S1, S2, S3, S4) T (*V)[S1][S2][S3][S4] = (T (*)[S1][S2][S3][S4])(INIT)
 #define LIBXSMM_VLA_DECL_6(T, V, INIT, S1, S2, S3, S4, S5) T (*V)[S1][S2][S3][S4][S5] = (T (*)[S1][S2][S3][S4][S5])(INIT)
-#define LIBXSMM_VLA_ACCESS(NDIMS, ARRAY, ...) LIBXSMM_VLA_ACCESS_##NDIMS(ARRAY, __VA_ARGS__)
+#define LIBXSMM_VLA_ACCESS(NDIMS, ARRAY, ...) LIBXSMM_CONCATENATE(LIBXSMM_VLA_ACCESS_, NDIMS)(ARRAY, __VA_ARGS__)
 #define LIBXSMM_VLA_ACCESS_1(A, I0) ((A)[I0])
 #define LIBXSMM_VLA_ACCESS_2(A, I0, I1, S1) ((A)[I0][I1])
 #define LIBXSMM_VLA_ACCESS_3(A, I0, I1, I2, S1, S2) ((A)[I0][I1][I2])

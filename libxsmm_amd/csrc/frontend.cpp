@@ -146,14 +146,24 @@ LIBXSMM_API libxsmm_timer_tickint libxsmm_timer_tick(void) {
 }
 LIBXSMM_API double libxsmm_timer_duration(libxsmm_timer_tickint t0, libxsmm_timer_tickint t1) { return (t1 >= t0 ? (double)(t1 - t0) : 0.0) * 1e-9; }
 
-static unsigned long long g_rng_state = 0x9E3779B97F4A7C15ull;
-static unsigned long long rng_next() {   // splitmix64
-  unsigned long long z = (g_rng_state += 0x9E3779B97F4A7C15ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+// The scalar generators are the C library's 48-bit LCG (lrand48 / drand48), seeded by libxsmm_rng_set_seed -- a driver seeded with 555
+// therefore builds the same matrices on both libraries [ref: src/libxsmm_utils.c:20-87].  libxsmm_rng_u32 draws uniformly in [0, n) by
+// rejecting the incomplete tail of the 31-bit range.
+LIBXSMM_API double libxsmm_rng_f64(void) { return drand48(); }
+LIBXSMM_API unsigned int libxsmm_rng_u32(unsigned int n) {
+  if (n < 2) return 0;
+  const unsigned int range = 1u << 31, lim = n < range ? n : range, usable = (range / lim) * lim;
+  unsigned int r;
+  do r = (unsigned int)lrand48(); while (r >= usable);
+  return n <= lim ? r % lim : (unsigned int)(((double)n / lim) * r + 0.5);     // n beyond the generator's 31 bits: stretched
 }
-LIBXSMM_API void libxsmm_rng_set_seed(unsigned int seed) { g_rng_state = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)seed << 17); }
-LIBXSMM_API double libxsmm_rng_f64(void) { return (double)(rng_next() >> 11) * (1.0 / 9007199254740992.0); }
-LIBXSMM_API unsigned int libxsmm_rng_u32(unsigned int n) { return n ? (unsigned int)(rng_next() % n) : 0; }
+LIBXSMM_API void libxsmm_rng_seq(void* data, size_t nbytes) {                   // consecutive lrand48 words, the tail from one more draw
+  unsigned char* dst = (unsigned char*)data;
+  for (size_t done = 0; done < nbytes; done += 4) {
+    const unsigned int r = (unsigned int)lrand48();
+    std::memcpy(dst + done, &r, nbytes - done < 4 ? nbytes - done : 4);
+  }
+}
 
 // ---- bf16 conversions [ref: src/libxsmm_math.c:640-704] ------------------------------------------------
 static unsigned int f2u(float f) { unsigned int u; std::memcpy(&u, &f, 4); return u; }

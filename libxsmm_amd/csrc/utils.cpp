@@ -7,6 +7,7 @@
 #include <cctype>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -61,12 +62,38 @@ LIBXSMM_API void libxsmm_stochastic_convert_fp32_bf8(const float* in, libxsmm_bf
   }
 }
 
+// 16 xoshiro128 lanes, word w of lane l seeded with seed + 100 w + 31 - l, each lane then moved 2^64 draws ahead with the generator's
+// published jump polynomial (Blackman / Vigna) so that the lanes never overlap [ref: src/libxsmm_rng.c:30-60,172-197]
+static void seed_lanes(uint32_t* st, unsigned int seed) {
+  static const uint32_t jump_poly[4] = { 0x8764000bu, 0xf542d2d3u, 0x6fa035c3u, 0x77f2db5bu };
+  for (unsigned int w = 0; w < 4; ++w) for (unsigned int l = 0; l < 16; ++l) st[16 * w + l] = seed + 100u * w + 31u - l;
+  for (unsigned int l = 0; l < 16; ++l) {
+    uint32_t acc[4] = { 0, 0, 0, 0 };
+    for (unsigned int bit = 0; bit < 128; ++bit) {
+      if ((jump_poly[bit >> 5] >> (bit & 31)) & 1u) for (unsigned int w = 0; w < 4; ++w) acc[w] ^= st[16 * w + l];
+      (void)xoshiro_lane(st, l);
+    }
+    for (unsigned int w = 0; w < 4; ++w) st[16 * w + l] = acc[w];
+  }
+}
 LIBXSMM_API unsigned int* libxsmm_rng_create_extstate(unsigned int seed) {
   unsigned int* st = (unsigned int*)libxsmm_aligned_malloc(64 * sizeof(unsigned int), 64);
-  if (!st) return nullptr;
-  for (unsigned int w = 0; w < 4; ++w) for (unsigned int l = 0; l < 16; ++l) st[16 * w + l] = seed + 100u * w + 31u - l;
-  for (unsigned int l = 0; l < 16; ++l) for (int warm = 0; warm < 64; ++warm) (void)xoshiro_lane(st, l);   // decorrelate the lanes
+  if (st) seed_lanes(st, seed);
   return st;
+}
+
+// the library's own lane state: libxsmm_rng_set_seed (re)seeds it together with the C library's generators; libxsmm_rng_f32_seq hands
+// element i the next draw of lane i % 16, 23 random mantissa bits mapped to [0, 1) [ref: src/libxsmm_rng.c:62-119,211-260]
+static uint32_t g_lanes[64];
+LIBXSMM_API void libxsmm_rng_set_seed(unsigned int seed) { seed_lanes(g_lanes, seed); srand48((long)seed); srand(seed); }
+LIBXSMM_API void libxsmm_rng_f32_seq(float* rngs, libxsmm_blasint count) {
+  for (libxsmm_blasint i = 0; i < count; ++i) {
+    const unsigned int l = (unsigned int)i & 15u;
+    const uint32_t bits = 0x3f800000u | ((g_lanes[l] + g_lanes[48 + l]) >> 9);
+    (void)xoshiro_lane(g_lanes, l);
+    float f; std::memcpy(&f, &bits, 4);
+    rngs[i] = f - 1.0f;
+  }
 }
 LIBXSMM_API unsigned int libxsmm_rng_get_extstate_size(void) { return (unsigned int)(64 * sizeof(unsigned int)); }
 LIBXSMM_API void libxsmm_rng_destroy_extstate(unsigned int* stateptr) { libxsmm_free(stateptr); }

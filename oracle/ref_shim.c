@@ -140,6 +140,15 @@ XREF unsigned char xref_convert_f32_to_bf8_stochastic(float x, unsigned int seed
 XREF float xref_convert_bf8_to_f32(unsigned char x) { return libxsmm_convert_bf8_to_f32(x); }
 XREF float xref_convert_hf8_to_f32(unsigned char x) { return libxsmm_convert_hf8_to_f32(x); }
 XREF int xref_cpuid_dot_pack_factor(libxsmm_datatype t) { return libxsmm_cpuid_dot_pack_factor(t); }
+/* the seeded generators the drivers build their data with (tests/test_utils_cpu.py) */
+XREF void xref_rng_set_seed(unsigned int seed) { libxsmm_rng_set_seed(seed); }
+XREF double xref_rng_f64(void) { return libxsmm_rng_f64(); }
+XREF unsigned int xref_rng_u32(unsigned int n) { return libxsmm_rng_u32(n); }
+XREF void xref_rng_seq(void* data, size_t nbytes) { libxsmm_rng_seq(data, nbytes); }
+XREF void xref_rng_f32_seq(float* r, int count) { libxsmm_rng_f32_seq(r, count); }
+XREF unsigned int* xref_rng_create_extstate(unsigned int seed) { return libxsmm_rng_create_extstate(seed); }
+XREF void xref_rng_destroy_extstate(unsigned int* st) { libxsmm_rng_destroy_extstate(st); }
+XREF void xref_stochastic_convert_fp32_bf8(const float* in, unsigned char* out, unsigned int n, void* st, unsigned int start) { libxsmm_stochastic_convert_fp32_bf8(in, out, n, st, start); }
 /* the whole statistics record, for tests/test_utils_cpu.py (same struct layout on both sides, checked by test_capi_cpu.py) */
 XREF int xref_matdiff(void* info, libxsmm_datatype t, libxsmm_blasint m, libxsmm_blasint n, const void* ref, const void* tst, const libxsmm_blasint* ldref, const libxsmm_blasint* ldtst) {
   return libxsmm_matdiff((libxsmm_matdiff_info*)info, t, m, n, ref, tst, ldref, ldtst);

@@ -98,10 +98,10 @@ def test_array_forms_strings_rng_state_and_matinit(ours):
     assert len(set(shuffled)) == 60 and max(np.abs(shuffled)) <= 1.0
 
 
-@pytest.mark.parametrize("name", ["matdiff", "gemmflags"])
+@pytest.mark.parametrize("name", ["matdiff", "gemmflags", "rng", "vla"])
 def test_reference_host_side_unit_tests_pass_on_this_library(name):
     """tests/matdiff.c (every statistic of libxsmm_matdiff, its reduction and epsilon on LAPACK's textbook example) and tests/gemmflags.c
-    (transpose-flag macros) of the reference, built unmodified against this repository's headers by `make -C oracle drivers`; no GPU needed."""
+    (transpose-flag macros) , tests/rng.c (moments of the seeded generators) and tests/vla.c (multi-dimensional index macros) of the reference, built unmodified against this repository's headers by `make -C oracle drivers`; no GPU needed."""
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "drivers", name)
     if not os.path.exists(exe):
@@ -157,3 +157,42 @@ def test_matdiff_record_matches_reference_field_by_field(ours, ref, dt, npdt):
         if kind not in ("nan", "inf"):
             ours.libxsmm_matdiff_reduce(C.byref(acc_o), C.byref(io)); ref.xref_matdiff_reduce(C.byref(acc_r), C.byref(ir))
             assert _same_record(acc_o, acc_r) is None, ("reduce after " + kind, _same_record(acc_o, acc_r))
+
+
+@pytest.mark.parametrize("seed", [555, 1, 0, 20260923])
+def test_seeded_generators_reproduce_the_reference_streams(ours, ref, seed):
+    """libxsmm_rng_set_seed / _f64 / _u32 / _seq / _f32_seq and the external lane state: the same seed yields the same numbers as the
+    reference, so a driver seeded with 555 builds identical matrices on both libraries (src/libxsmm_utils.c:20-87, src/libxsmm_rng.c)."""
+    ours.libxsmm_rng_f64.restype = C.c_double; ref.xref_rng_f64.restype = C.c_double
+    ours.libxsmm_rng_u32.restype = C.c_uint; ref.xref_rng_u32.restype = C.c_uint
+    ours.libxsmm_rng_set_seed(C.c_uint(seed)); ref.xref_rng_set_seed(C.c_uint(seed))
+    # the two libraries share this process's C library generator: interleave draw-by-draw after re-seeding each side
+    mine, theirs = [], []
+    for side, f64, u32, out in ((ours.libxsmm_rng_set_seed, ours.libxsmm_rng_f64, ours.libxsmm_rng_u32, mine),
+                                (ref.xref_rng_set_seed, ref.xref_rng_f64, ref.xref_rng_u32, theirs)):
+        side(C.c_uint(seed))
+        out += [f64() for _ in range(50)]
+        out += [u32(C.c_uint(n)) for n in (0, 1, 2, 3, 10, 35, 1000, 1 << 20, (1 << 31) - 1, 1 << 31, 3000000000, 0xffffffff) for _ in range(8)]
+        buf = (C.c_ubyte * 23)()
+        (ours.libxsmm_rng_seq if out is mine else ref.xref_rng_seq)(buf, C.c_size_t(23))
+        out += list(buf)
+    assert mine == theirs
+    for count in (7, 16, 100, 1000, 4099):                    # below and above the reference's SIMD threshold, ragged tails
+        a, b = np.zeros(count, np.float32), np.zeros(count, np.float32)
+        ours.libxsmm_rng_set_seed(C.c_uint(seed)); ref.xref_rng_set_seed(C.c_uint(seed))
+        for _ in range(2):                                    # the second call continues the lanes
+            ours.libxsmm_rng_f32_seq(a.ctypes.data_as(C.c_void_p), count); ref.xref_rng_f32_seq(b.ctypes.data_as(C.c_void_p), count)
+            assert np.array_equal(a, b) and a.min() >= 0 and a.max() < 1, count
+    ours.libxsmm_rng_create_extstate.restype = C.c_void_p; ref.xref_rng_create_extstate.restype = C.c_void_p
+    so, sr = ours.libxsmm_rng_create_extstate(C.c_uint(seed)), ref.xref_rng_create_extstate(C.c_uint(seed))
+    try:
+        assert C.string_at(so, 256) == C.string_at(sr, 256)
+        x = (np.random.default_rng(seed).standard_normal(333) * 4).astype(np.float32)
+        yo, yr = np.zeros(333, np.uint8), np.zeros(333, np.uint8)
+        for start in (0, 5):
+            ours.libxsmm_stochastic_convert_fp32_bf8(x.ctypes.data_as(C.c_void_p), yo.ctypes.data_as(C.c_void_p), 333, C.c_void_p(so), start)
+            ref.xref_stochastic_convert_fp32_bf8(x.ctypes.data_as(C.c_void_p), yr.ctypes.data_as(C.c_void_p), 333, C.c_void_p(sr), start)
+            assert np.array_equal(yo, yr), start
+            assert C.string_at(so, 256) == C.string_at(sr, 256)
+    finally:
+        ours.libxsmm_rng_destroy_extstate(C.c_void_p(so)); ref.xref_rng_destroy_extstate(C.c_void_p(sr))
