@@ -476,7 +476,10 @@ LIBXSMM_API int libxsmm_meqn_push_back_binary_op(libxsmm_meqn_op_metadata op_met
 LIBXSMM_API int libxsmm_meqn_push_back_ternary_op(libxsmm_meqn_op_metadata op_metadata, libxsmm_meltw_ternary_type type, libxsmm_datatype dtype, libxsmm_bitfield flags);
 LIBXSMM_API void libxsmm_meqn_tree_print(libxsmm_blasint idx);
 LIBXSMM_API void libxsmm_meqn_rpn_print(libxsmm_blasint idx);
-/** NULL if the tree is incomplete or contains an op outside this backend (matmul/brgemm nodes, gather, dump, argument sets). */
+/** NULL if the tree is incomplete or contains an op outside this backend (LIBXSMM_VERBOSE >= 1 names the node).  MATMUL / BRGEMM nodes run the
+ * dense GEMM kernels (BRGEMM: A and B are STRIDE_BASE argument sets, the block count is read from ops_args[op_arg_pos].tertiary; the ternary
+ * forms need REUSE_IN_2_AS_OUT and accumulate into their third operand in place); a GATHER node directly above an argument reads its index
+ * list from inputs[pos].secondary; DUMP writes to ops_args[op_arg_pos].primary. */
 LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, libxsmm_meqn_arg_shape out_shape);
 
 /* ---- packed / sparse creators (caller-owned, release with libxsmm_release_kernel)

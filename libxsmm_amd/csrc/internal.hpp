@@ -174,6 +174,7 @@ const char* meqn_plan_name(const EqnPlan* plan);
 const void* rt_new_meqn_handle(EqnPlan* plan);   // caller-independent handle owned by the equation registry
 void rt_finish_launch(int err, const char* kernel_name);
 void* rt_workspace(size_t nbytes);
+void rt_workspace_reserve(size_t nbytes);   // nested workspace() requests are placed behind this many bytes (0: off)
 bool rt_ready();
 const void* rt_small_host_input(const void* p, size_t nbytes);   // tiny operands (scalars) may live in host memory: staged if they do
 void rt_scratch_reset();

@@ -28,7 +28,7 @@ enum { EQ_NONE = 0, EQ_ARG = 1, EQ_UNARY = 2, EQ_BINARY = 3, EQ_TERNARY = 4 };
 struct EqnNode {
   int kind = EQ_NONE;
   int op = 0, dtype = 0; unsigned int flags = 0; int op_arg_pos = -1;   // op nodes
-  int in_pos = -1, set = 0;                                             // arg nodes
+  int in_pos = -1, set = 0, set_type = 0; long long set_stride = 0;     // arg nodes (set: a strided block list feeding a BRGEMM node)
   int child[3] = {-1, -1, -1}, up = -1;
   int m = 0, n = 0, ld = 0, type = 0;                                   // result shape / datatype of this node
 };
@@ -40,7 +40,8 @@ struct Equation {
   std::map<std::array<int, 4>, const void*> handles;   // dispatched (m, n, ld, type) -> handle
 };
 
-struct EqnStep { MeltwArgs args; int src[3]; int node; int alpha_from_op; int dump_from_op; int root_side; bool scalar_arg[3]; };   // root_side: 1 bitmask, 2 UNZIP offset from output.secondary   // src: >=0 input position, < 0: -(slot+1)
+struct EqnStep { MeltwArgs args; int src[3]; int node; int alpha_from_op; int dump_from_op; int idx_from_input; int root_side; bool scalar_arg[3];
+  const void* gemm; int br_from_op; int out_loc; };   // gemm: dispatched (BR)GEMM handle of a MATMUL / BRGEMM node; out_loc: like src, INT32_MIN = the caller's output   // idx_from_input: GATHER reads its indices from inputs[pos].secondary   // root_side: 1 bitmask, 2 UNZIP offset from output.secondary   // src: >=0 input position, < 0: -(slot+1)
 struct EqnPlan {
   JitKernel* fused = nullptr;       // whole tree as ONE generated kernel (element-wise trees), else the step chain below
   std::vector<int> fused_inputs;    // input positions in kernel-argument order
@@ -49,6 +50,7 @@ struct EqnPlan {
   std::vector<EqnStep> steps;
   std::vector<int> slot_of;         // per node: workspace slot (-1: none)
   size_t slot_bytes = 0; int nslots = 0;
+  bool has_gemm = false;            // a MATMUL / BRGEMM step: room for the GEMM kernel's partial sums is reserved behind the slots
 };
 
 namespace {
@@ -61,6 +63,24 @@ int arity(int kind) { return kind == EQ_UNARY ? 1 : kind == EQ_BINARY ? 2 : kind
 bool is_reduce(int t) {
   return t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX ||
          t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MUL || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD;
+}
+
+// MATMUL / BRGEMM nodes [ref: src/libxsmm_matrixeqn.c:1421-1441,1468-1488; semantics: samples/equation/equation_matmul.c:37-62]: the eight
+// variants of a family come in the order plain, B_TRANS, A_TRANS, A_TRANS_B_TRANS, A_VNNI, A_VNNI_B_TRANS, A_VNNI_TRANS, A_VNNI_TRANS_B_TRANS
+struct GemmNode { bool is_gemm, br, ta, tb, vnni; };
+GemmNode gemm_node(int kind, int op) {
+  int v = -1; bool br = false;
+  if (kind == EQ_BINARY) {
+    if (op == LIBXSMM_MELTW_TYPE_BINARY_MATMUL) v = 0;
+    else if (op >= LIBXSMM_MELTW_TYPE_BINARY_MATMUL_B_TRANS && op <= LIBXSMM_MELTW_TYPE_BINARY_MATMUL_A_VNNI_TRANS_B_TRANS) v = op - LIBXSMM_MELTW_TYPE_BINARY_MATMUL_B_TRANS + 1;
+    else if (op >= LIBXSMM_MELTW_TYPE_BINARY_BRGEMM && op <= LIBXSMM_MELTW_TYPE_BINARY_BRGEMM_A_VNNI_TRANS_B_TRANS) { v = op - LIBXSMM_MELTW_TYPE_BINARY_BRGEMM; br = true; }
+  } else if (kind == EQ_TERNARY) {
+    if (op == LIBXSMM_MELTW_TYPE_TERNARY_MATMUL) v = 0;
+    else if (op >= LIBXSMM_MELTW_TYPE_TERNARY_MATMUL_B_TRANS && op <= LIBXSMM_MELTW_TYPE_TERNARY_MATMUL_A_VNNI_TRANS_B_TRANS) v = op - LIBXSMM_MELTW_TYPE_TERNARY_MATMUL_B_TRANS + 1;
+    else if (op >= LIBXSMM_MELTW_TYPE_TERNARY_BRGEMM && op <= LIBXSMM_MELTW_TYPE_TERNARY_BRGEMM_A_VNNI_TRANS_B_TRANS) { v = op - LIBXSMM_MELTW_TYPE_TERNARY_BRGEMM; br = true; }
+  }
+  if (v < 0) return GemmNode{false, false, false, false, false};
+  return GemmNode{true, br, ((v >> 1) & 1) != 0, (v & 1) != 0, v >= 4};
 }
 
 // add a node under `cur` and advance `cur` the way libxsmm_meqn_trv_head does: an op takes the next push itself, an
@@ -97,8 +117,28 @@ Equation* get(int idx) { return (idx >= 0 && idx < (int)g_eqns.size()) ? g_eqns[
 // result shape / type of every node, children first [ref: libxsmm_matrixeqn.c:869-936, :289-311]
 bool infer(Equation& e, int id) {
   EqnNode& nd = e.nodes[id];
-  if (nd.kind == EQ_ARG) return nd.m > 0 && nd.n > 0 && nd.ld >= nd.m && nd.set == 0;
+  if (nd.kind == EQ_ARG) {   // a strided set only makes sense as the A / B operand of a BRGEMM node
+    if (nd.set != 0) {
+      const EqnNode* up = nd.up >= 0 ? &e.nodes[nd.up] : nullptr;
+      const GemmNode g = up ? gemm_node(up->kind, up->op) : GemmNode{false, false, false, false, false};
+      if (!g.is_gemm || !g.br || nd.set_type != LIBXSMM_MATRIX_ARG_SET_TYPE_STRIDE_BASE || up->child[2] == id) return false;
+    }
+    return nd.m > 0 && nd.n > 0 && nd.ld >= nd.m;
+  }
   for (int c = 0; c < arity(nd.kind); ++c) if (nd.child[c] < 0 || !infer(e, nd.child[c])) return false;
+  const GemmNode g = gemm_node(nd.kind, nd.op);
+  if (g.is_gemm) {   // op(A) is m x k, op(B) is k x n; a ternary node accumulates into (and is stored in) its third operand
+    const EqnNode& A = e.nodes[nd.child[0]]; const EqnNode& B = e.nodes[nd.child[1]];
+    const int m = g.ta ? A.n : A.m, k = g.ta ? A.m : A.n, n = g.tb ? B.m : B.n, kb = g.tb ? B.n : B.m;
+    if (k != kb || (g.vnni && g.ta)) return false;
+    nd.m = m; nd.n = n; nd.ld = m; nd.type = nd.dtype;
+    if (nd.kind == EQ_TERNARY) {
+      const EqnNode& Cn = e.nodes[nd.child[2]];
+      if (!(nd.flags & LIBXSMM_MELTW_FLAG_TERNARY_REUSE_IN_2_AS_OUT) || Cn.m != m || Cn.n != n) return false;
+      nd.ld = Cn.ld; nd.type = Cn.type;
+    }
+    return true;
+  }
   const EqnNode& l = e.nodes[nd.child[0]];
   nd.type = nd.dtype;
   if (nd.kind == EQ_UNARY) {
@@ -319,7 +359,7 @@ void run_meqn(EqnPlan* plan, const void* param) {
   }
   rt_scratch_reset();
   char* ws = nullptr;
-  if (plan->nslots > 0) { ws = (char*)rt_workspace(plan->slot_bytes * (size_t)plan->nslots); if (!ws) return; }
+  if (plan->nslots > 0) { ws = (char*)rt_workspace(plan->slot_bytes * (size_t)plan->nslots + (plan->has_gemm ? ((size_t)8 << 20) : 0)); if (!ws) return; }
   const char* kname = nullptr;
   int err = 0;
   for (size_t s = 0; s < plan->steps.size() && err == 0; ++s) {
@@ -334,7 +374,21 @@ void run_meqn(EqnPlan* plan, const void* param) {
       if (st.src[c] >= 0 && st.scalar_arg[c]) { src[c] = (const char*)rt_small_host_input(src[c], 8); if (!src[c]) return; }
     }
     a.in0 = src[0]; a.in1 = src[1]; a.in2 = src[2];
-    a.out = (s + 1 == plan->steps.size()) ? (char*)p->output.primary : ws + plan->slot_bytes * (size_t)plan->slot_of[st.node];
+    a.out = st.out_loc == INT32_MIN ? (char*)p->output.primary : (st.out_loc >= 0 ? (char*)p->inputs[st.out_loc].primary : ws + plan->slot_bytes * (size_t)(-st.out_loc - 1));
+    if (st.gemm) {   // a MATMUL / BRGEMM node: the dense kernel, called like any other handle (its own launch bookkeeping included)
+      libxsmm_gemm_param gp; std::memset(&gp, 0, sizeof(gp));
+      unsigned long long blocks = 1;
+      gp.a.primary = (void*)src[0]; gp.b.primary = (void*)src[1]; gp.c.primary = a.out;
+      if (st.br_from_op >= 0) {
+        if (!p->ops_args || !p->ops_args[st.br_from_op].tertiary) { set_error(-2, "matrix equation: BRGEMM block count (op argument %d, tertiary) is NULL", st.br_from_op); return; }
+        blocks = *(const unsigned long long*)p->ops_args[st.br_from_op].tertiary; gp.op.tertiary = &blocks;
+      }
+      rt_workspace_reserve(plan->slot_bytes * (size_t)plan->nslots);     // the kernel's own partial-sum workspace goes behind the slots
+      ((libxsmm_gemmfunction)st.gemm)(&gp);
+      rt_workspace_reserve(0);
+      kname = nullptr;
+      continue;
+    }
     if (st.alpha_from_op >= 0) {
       if (!p->ops_args || !p->ops_args[st.alpha_from_op].primary) { set_error(-2, "matrix equation: op argument %d is NULL", st.alpha_from_op); return; }
       a.scalar_f32 = *(const float*)p->ops_args[st.alpha_from_op].primary;
@@ -345,6 +399,10 @@ void run_meqn(EqnPlan* plan, const void* param) {
     } else if (st.root_side == 2) {
       if (!p->output.secondary) { set_error(-2, "matrix equation: the head is UNZIP but output.secondary (byte offset of the upper halves) is NULL"); return; }
       a.scalar_u64 = *(const unsigned long long*)p->output.secondary;
+    }
+    if (st.idx_from_input >= 0) {
+      if (!p->inputs[st.idx_from_input].secondary) { set_error(-2, "matrix equation: GATHER needs its index list in inputs[%d].secondary", st.idx_from_input); return; }
+      a.aux_in = p->inputs[st.idx_from_input].secondary;
     }
     if (st.dump_from_op >= 0) {
       if (!p->ops_args || !p->ops_args[st.dump_from_op].primary) { set_error(-2, "matrix equation: DUMP destination (op argument %d) is NULL", st.dump_from_op); return; }
@@ -384,7 +442,7 @@ LIBXSMM_API int libxsmm_meqn_push_back_arg(libxsmm_meqn_arg_metadata md, libxsmm
   Equation* e = get(md.eqn_idx);
   if (!e) return 1;
   EqnNode nd; nd.kind = EQ_ARG; nd.in_pos = md.in_arg_pos; nd.m = shape.m; nd.n = shape.n; nd.ld = shape.ld; nd.type = shape.type;
-  nd.set = (attr.type == LIBXSMM_MATRIX_ARG_TYPE_SET) ? 1 : 0;
+  nd.set = (attr.type == LIBXSMM_MATRIX_ARG_TYPE_SET) ? 1 : 0; nd.set_type = (int)attr.set_type; nd.set_stride = attr.set_stride_hint;
   return push(*e, nd);
 }
 static int push_op(libxsmm_meqn_op_metadata md, int kind, int type, libxsmm_datatype dtype, libxsmm_bitfield flags) {
@@ -430,24 +488,57 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
   size_t max_elems = 1;
   for (int id : order) max_elems = std::max(max_elems, (size_t)e->nodes[id].ld * (size_t)e->nodes[id].n);
   plan->slot_bytes = (max_elems * 8 + 255) & ~(size_t)255;
+  // where the result of a node lives: >= 0 an input position (arguments; a ternary GEMM node accumulating into an argument),
+  // < 0 the workspace slot -(loc + 1); INT32_MIN: the caller's output (the head)
+  std::vector<int> loc(e->nodes.size(), INT32_MIN);
+  for (size_t i = 0; i < e->nodes.size(); ++i) if (e->nodes[i].kind == EQ_ARG) loc[i] = e->nodes[i].in_pos;
   for (int id : order) {
     EqnNode nd = e->nodes[id];
     const bool root = (id == 0);
+    const GemmNode g = gemm_node(nd.kind, nd.op);
+    const bool accumulates = g.is_gemm && nd.kind == EQ_TERNARY;       // result = third operand, in place
     if (root) {   // the head writes the caller's output [ref: matequation ref :28-29; dispatch out shape]
-      if (out.m != nd.m || out.n != nd.n || out.ld < out.m) { rt_note("equation refused: output shape differs from the head node (m, n, ld)", out.m, out.n, out.ld); delete plan; return nullptr; }
+      // the head keeps its own inferred extent; the caller's shape contributes the leading dimension and the type, as in the reference
+      // (src/libxsmm_matrixeqn.c:868-936: samples/equation/equation_gather_dot.c declares an M x 1 output for a head that reduces to 1 x 1)
+      const bool reducing_head = nd.kind == EQ_UNARY && is_reduce(nd.op);
+      if (((out.m != nd.m || out.n != nd.n) && !(reducing_head && out.m >= nd.m && out.n >= nd.n)) || out.ld < nd.m) {
+        rt_note("equation refused: output shape differs from the head node (m, n, ld)", out.m, out.n, out.ld); delete plan; return nullptr;
+      }
+      if (accumulates) { rt_note("equation refused: a MATMUL / BRGEMM node that accumulates into its third operand cannot be the head", nd.op, 0, 0); delete plan; return nullptr; }
       nd.ld = out.ld; nd.type = out.type;
-    } else plan->slot_of[id] = plan->nslots++;
+    } else if (accumulates) {
+      loc[id] = loc[nd.child[2]];
+      if (loc[id] < 0 && loc[id] != INT32_MIN) plan->slot_of[id] = -loc[id] - 1;
+    } else { plan->slot_of[id] = plan->nslots++; loc[id] = -(plan->slot_of[id] + 1); }
     EqnStep st; std::memset(&st.args, 0, sizeof(st.args));
-    st.node = id; st.alpha_from_op = -1; st.dump_from_op = -1; st.root_side = 0; st.scalar_arg[0] = st.scalar_arg[1] = st.scalar_arg[2] = false; st.src[0] = st.src[1] = st.src[2] = INT32_MIN;
+    st.node = id; st.alpha_from_op = -1; st.dump_from_op = -1; st.idx_from_input = -1; st.root_side = 0; st.scalar_arg[0] = st.scalar_arg[1] = st.scalar_arg[2] = false; st.src[0] = st.src[1] = st.src[2] = INT32_MIN;
+    st.gemm = nullptr; st.br_from_op = -1; st.out_loc = loc[id];
     MeltwArgs& a = st.args;
     a.nbatch = 1; a.flags = nd.flags; a.type = nd.op; a.comp_type = nd.dtype; a.out_type = nd.type; a.ldo = nd.ld;
     a.in0_type = a.in1_type = a.in2_type = LIBXSMM_DATATYPE_UNSUPPORTED;
     const EqnNode* ch[3] = {nullptr, nullptr, nullptr};
     for (int c = 0; c < arity(nd.kind); ++c) {
       ch[c] = &e->nodes[nd.child[c]];
-      st.src[c] = ch[c]->kind == EQ_ARG ? ch[c]->in_pos : -(plan->slot_of[nd.child[c]] + 1);
+      st.src[c] = loc[nd.child[c]];
       st.scalar_arg[c] = ch[c]->kind == EQ_ARG && ch[c]->m == 1 && ch[c]->n == 1;
-      if (ch[c]->kind == EQ_ARG && ch[c]->in_pos < 0) { delete plan; return nullptr; }
+      if ((ch[c]->kind == EQ_ARG && ch[c]->in_pos < 0) || st.src[c] == INT32_MIN) { delete plan; return nullptr; }
+    }
+    if (g.is_gemm) {   // one (batch-reduce) GEMM of the dense path: op(A) m x k times op(B) k x n, f32 accumulation
+      const EqnNode& A = *ch[0]; const EqnNode& B = *ch[1];
+      const int k = g.ta ? A.m : A.n;
+      const libxsmm_gemm_shape sh = libxsmm_create_gemm_shape(nd.m, nd.n, k, A.ld, B.ld, nd.ld, (libxsmm_datatype)A.type, (libxsmm_datatype)B.type, (libxsmm_datatype)nd.type, LIBXSMM_DATATYPE_F32);
+      const libxsmm_bitfield fl = (g.ta ? LIBXSMM_GEMM_FLAG_TRANS_A : 0) | (g.tb ? LIBXSMM_GEMM_FLAG_TRANS_B : 0) | (g.vnni ? LIBXSMM_GEMM_FLAG_VNNI_A : 0) |
+                                  (accumulates ? 0 : LIBXSMM_GEMM_FLAG_BETA_0);
+      libxsmm_gemmfunction fn = nullptr;
+      if (g.br) {   // the blocks of A and B lie set_stride bytes apart; the count arrives per call in ops_args[op_arg_pos].tertiary
+        if (nd.op_arg_pos < 0 || A.kind != EQ_ARG || B.kind != EQ_ARG || A.set == 0 || B.set == 0) { rt_note("equation refused: BRGEMM node without strided argument sets / op argument", nd.op, nd.op_arg_pos, 0); delete plan; return nullptr; }
+        fn = libxsmm_dispatch_brgemm(sh, fl, LIBXSMM_GEMM_PREFETCH_NONE, libxsmm_create_gemm_batch_reduce_config(LIBXSMM_GEMM_BATCH_REDUCE_STRIDE, A.set_stride, B.set_stride, 0));
+        st.br_from_op = nd.op_arg_pos;
+      } else fn = libxsmm_dispatch_gemm(sh, fl, LIBXSMM_GEMM_PREFETCH_NONE);
+      if (!fn) { rt_note("equation refused: no GEMM kernel for a MATMUL / BRGEMM node (a, b, c type)", A.type, B.type, nd.type); delete plan; return nullptr; }
+      st.gemm = (const void*)fn; plan->has_gemm = true;
+      plan->steps.push_back(st);
+      continue;
     }
     a.in0_type = ch[0]->type; a.ldi = ch[0]->ld;
     libxsmm_descriptor_blob blob;
@@ -464,7 +555,9 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       // the byte offset of UNZIP's second half
       if ((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && nd.op == LIBXSMM_MELTW_TYPE_UNARY_RELU && root) st.root_side = 1;
       if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP && root) st.root_side = 2;
-      if (((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && st.root_side != 1) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER || nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER ||
+      // a GATHER directly above an argument takes its index list from that argument's secondary slot [ref: samples/equation/equation_gather_reduce.c:150-166]
+      if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER && ch[0]->kind == EQ_ARG) st.idx_from_input = ch[0]->in_pos;
+      if (((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && st.root_side != 1) || (nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER && st.idx_from_input < 0) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER ||
           (nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP && st.root_side != 2) || (nd.op == LIBXSMM_MELTW_TYPE_UNARY_DUMP && nd.op_arg_pos < 0) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR ||
           nd.op == LIBXSMM_MELTW_TYPE_UNARY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) d = nullptr;
       // parameterised activations: the reference's equation generators do not apply ops_args to them (its CPU JIT leaves the

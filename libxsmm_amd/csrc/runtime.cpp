@@ -139,15 +139,17 @@ void copy_back_staged() {
 // per-thread device workspace for partial results; grows monotonically, reused in stream order
 struct Workspace { void* base = nullptr; size_t cap = 0; };
 thread_local Workspace t_workspace;
-void* workspace(size_t nbytes) {
+thread_local size_t t_ws_reserved = 0;   // front part owned by an enclosing call (the slots of a matrix equation around a GEMM node)
+void* workspace(size_t nbytes_wanted) {
   Workspace& w = t_workspace;
+  const size_t nbytes = nbytes_wanted + t_ws_reserved;
   if (nbytes > w.cap) {
     if (w.base) { retire_block(w.base); w.base = nullptr; w.cap = 0; }
     const size_t ncap = std::max<size_t>(nbytes, 4u << 20);
     if (!hip_ok(hipMalloc(&w.base, ncap), "hipMalloc(workspace)")) { w.base = nullptr; return nullptr; }
     w.cap = ncap;
   }
-  return w.base;
+  return (char*)w.base + t_ws_reserved;
 }   // stream order protects data of the previous call
 
 std::string make_key(int kind, const void* desc, size_t n) {
@@ -640,6 +642,7 @@ const void* rt_new_meqn_handle(EqnPlan* plan) {
 }
 void rt_finish_launch(int err, const char* kernel_name) { finish_launch(err, kernel_name); }
 void* rt_workspace(size_t nbytes) { return workspace(nbytes); }
+void rt_workspace_reserve(size_t nbytes) { t_ws_reserved = (nbytes + 255) & ~(size_t)255; }
 bool rt_ready() { return runtime_ready(); }
 const void* rt_small_host_input(const void* p, size_t nbytes) { return device_visible(p, nbytes); }
 void rt_scratch_reset() { scratch_reset(); }

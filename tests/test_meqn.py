@@ -256,3 +256,153 @@ def test_gpu_meqn_scalar_arguments_may_live_in_host_memory(jit):
         _call(api, h, [dev[0].data_ptr(), dev[1].data_ptr(), C.addressof(scalar)], out.data_ptr())
     api.hip_sync(); api.check()
     assert np.array_equal(_valid(out.cpu().numpy().view(np.uint16), out_shape), _valid(ref, out_shape))
+
+
+# ---- MATMUL / BRGEMM and GATHER nodes (samples/equation/equation_matmul.c, equation_gather_reduce.c) ------------------------------
+def _f32(bits_or_f32, dt):
+    return bits_or_f32 if dt == DT.F32 else (bits_or_f32.astype(np.uint32) << 16).view(np.float32)
+
+
+def _mat(x, m, n, ld, dt, blocks=1):
+    return _f32(x, dt).reshape(blocks, n, ld)[:, :, :m].astype(np.float64)      # [block][col][row]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16], ids=["f32", "bf16"])
+def test_gpu_meqn_matmul_node(dt):
+    """out = tanh(C x D) * (A + B): a BINARY_MATMUL node below element-wise nodes (equation 0 of samples/equation/equation_matmul.c)."""
+    import torch
+    api = capi.load()
+    m, n, k = 48, 24, 40
+    shapes = [(m, n, m + 8, dt), (m, n, m, dt), (m, k, m + 4, dt), (k, n, k + 2, dt)]
+    out_shape = (m, n, m + 8, dt)
+    arrays = _inputs(shapes, 5)
+    idx = api.meqn_create()
+    md = lambda pos=-1: capi.MeqnMetadata(idx, pos)    # noqa: E731
+    assert api.meqn_push_back_binary_op(md(), BINARY.MUL, DT.F32, 0) == 0
+    assert api.meqn_push_back_unary_op(md(), UNARY.TANH, DT.F32, 0) == 0
+    assert api.meqn_push_back_binary_op(md(), BINARY.MATMUL, DT.F32, 0) == 0
+    assert api.meqn_push_back_arg(md(2), capi.MeqnArgShape(*shapes[2]), SINGULAR) == 0
+    assert api.meqn_push_back_arg(md(3), capi.MeqnArgShape(*shapes[3]), SINGULAR) == 0
+    assert api.meqn_push_back_binary_op(md(), BINARY.ADD, DT.F32, 0) == 0
+    assert api.meqn_push_back_arg(md(0), capi.MeqnArgShape(*shapes[0]), SINGULAR) == 0
+    assert api.meqn_push_back_arg(md(1), capi.MeqnArgShape(*shapes[1]), SINGULAR) == 0
+    h = api.dispatch_meqn(idx, capi.MeqnArgShape(*out_shape))
+    assert h
+    dev = [torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to("cuda:0") for a in arrays]
+    out = torch.zeros(out_shape[2] * n, dtype=torch.float32 if dt == DT.F32 else torch.int16, device="cuda:0")
+    _call(api, h, [d.data_ptr() for d in dev], out.data_ptr())
+    api.hip_sync(); api.check()
+    A, B, Cm, D = (_mat(arrays[i], *shapes[i])[0] for i in range(4))
+    gold = np.tanh(D @ Cm) * (A + B)                                              # [col][row] storage: (C x D)^T = D^T-major product
+    got = _mat(out.cpu().numpy().view(NPDT[dt]), *out_shape)[0]
+    assert np.sqrt(((got - gold) ** 2).sum() / (gold ** 2).sum()) < (2e-5 if dt == DT.F32 else 8e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["binary", "ternary_arg", "ternary_tmp", "vnni_bf16"])
+def test_gpu_meqn_brgemm_node(variant):
+    """BRGEMM nodes: A and B are strided sets of `blocks` matrices, the count arrives in ops_args[pos].tertiary; the ternary form
+    accumulates into its third operand in place -- an argument (equation 1 of equation_matmul.c: that input is overwritten) or an
+    intermediate (equation 3); A_VNNI takes bf16 A blocks in VNNI-2 layout."""
+    import torch
+    api = capi.load()
+    m, n, k, blocks = 32, 16, 24, 5
+    dt = DT.BF16 if variant == "vnni_bf16" else DT.F32
+    es = 2 if dt == DT.BF16 else 4
+    shapes = [(m, n, m, dt), (m, n, m + 4, DT.F32), (m, k, m, dt), (k, n, k, dt)]
+    rng = np.random.default_rng(9)
+    arrays = [rand_values(rng, shapes[0][2] * n, dt), rand_values(rng, shapes[1][2] * n, DT.F32),
+              rand_values(rng, m * k * blocks, dt), rand_values(rng, k * n * blocks, dt)]
+    set_a = capi.MatrixArgAttributes(1, 3, blocks, m * k * es)                   # TYPE_SET, STRIDE_BASE, cardinality, byte stride
+    set_b = capi.MatrixArgAttributes(1, 3, blocks, k * n * es)
+    idx = api.meqn_create()
+    md = lambda pos=-1: capi.MeqnMetadata(idx, pos)    # noqa: E731
+    out_shape = (m, n, m, dt)
+    assert api.meqn_push_back_binary_op(md(), BINARY.ADD, DT.F32, 0) == 0
+    assert api.meqn_push_back_arg(md(0), capi.MeqnArgShape(*shapes[0]), SINGULAR) == 0
+    if variant in ("binary", "vnni_bf16"):
+        assert api.meqn_push_back_binary_op(md(3), BINARY.BRGEMM_A_VNNI if variant == "vnni_bf16" else BINARY.BRGEMM, DT.F32, 0) == 0
+    else:
+        assert api.meqn_push_back_ternary_op(md(3), TERNARY.BRGEMM, DT.F32, TERNARY_FLAG.REUSE_IN_2_AS_OUT) == 0
+    assert api.meqn_push_back_arg(md(2), capi.MeqnArgShape(*shapes[2]), set_a) == 0
+    assert api.meqn_push_back_arg(md(3), capi.MeqnArgShape(*shapes[3]), set_b) == 0
+    if variant == "ternary_arg":
+        assert api.meqn_push_back_arg(md(1), capi.MeqnArgShape(*shapes[1]), SINGULAR) == 0
+    elif variant == "ternary_tmp":
+        assert api.meqn_push_back_unary_op(md(), UNARY.X2, DT.F32, 0) == 0
+        assert api.meqn_push_back_arg(md(1), capi.MeqnArgShape(*shapes[1]), SINGULAR) == 0
+    h = api.dispatch_meqn(idx, capi.MeqnArgShape(*out_shape))
+    assert h
+    A0, Cacc = _mat(arrays[0], *shapes[0])[0], _mat(arrays[1], *shapes[1])[0]
+    Ab, Bb = _mat(arrays[2], m, k, m, dt, blocks), _mat(arrays[3], k, n, k, dt, blocks)
+    prod = sum(Bb[r] @ Ab[r] for r in range(blocks))                             # [col][row] storage
+    a_dev = arrays[2]
+    if variant == "vnni_bf16":                                                   # [block][k/2][m][2] from [block][k][m]
+        a_dev = np.ascontiguousarray(arrays[2].reshape(blocks, k // 2, 2, m).transpose(0, 1, 3, 2)).reshape(-1)
+    host = [arrays[0], arrays[1], a_dev, arrays[3]]
+    dev = [torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a.copy()).to("cuda:0") for a in host]
+    out = torch.zeros(out_shape[2] * n, dtype=torch.float32 if dt == DT.F32 else torch.int16, device="cuda:0")
+    inputs = (capi.MatrixArg * 4)()
+    for i, d in enumerate(dev):
+        inputs[i].primary = d.data_ptr()
+    count = C.c_ulonglong(blocks)
+    ops = (capi.MatrixOpArg * 4)()
+    ops[3].tertiary = C.addressof(count)
+    p = capi.MeqnParam()
+    p.inputs, p.ops_args = inputs, ops
+    p.output.primary = out.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    gold = A0 + {"binary": prod, "vnni_bf16": prod, "ternary_arg": Cacc + prod, "ternary_tmp": Cacc * Cacc + prod}[variant]
+    got = _mat(out.cpu().numpy().view(NPDT[dt]), *out_shape)[0]
+    assert np.sqrt(((got - gold) ** 2).sum() / (gold ** 2).sum()) < (2e-6 if dt == DT.F32 else 8e-3)
+    after = _mat(dev[1].cpu().numpy(), *shapes[1])[0]
+    if variant == "ternary_arg":                                                 # the accumulator argument now holds C + sum A_r x B_r
+        assert np.sqrt((((Cacc + prod) - after) ** 2).sum() / ((Cacc + prod) ** 2).sum()) < 2e-6
+    else:
+        assert np.array_equal(after, Cacc)
+    ops[3].tertiary = None                                                       # a missing block count is an error, not a fault
+    capi.Api.call(h, p)
+    assert api.hip_get_last_error() != 0
+    api.hip_clear_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx_bytes", [4, 8])
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16], ids=["f32", "bf16"])
+def test_gpu_meqn_gather_node_above_an_argument(dt, idx_bytes):
+    """reduce_cols_add(gather_cols(X, idx)): the GATHER node reads its column indices from inputs[pos].secondary
+    (samples/equation/equation_gather_reduce.c:146-166)."""
+    import torch
+    api = capi.load()
+    m, n, ld, big_n = 37, 21, 40, 21 * 5
+    rng = np.random.default_rng(3)
+    X = rand_values(rng, ld * big_n, dt)
+    cols = rng.permutation(big_n)[:n].astype(np.uint32 if idx_bytes == 4 else np.uint64)
+    idx = api.meqn_create()
+    md = capi.MeqnMetadata(idx, -1)
+    gflags = UNARY_FLAG.GS_COLS | (UNARY_FLAG.IDX_SIZE_4BYTES if idx_bytes == 4 else UNARY_FLAG.IDX_SIZE_8BYTES)
+    assert api.meqn_push_back_unary_op(md, UNARY.REDUCE_X_OP_ADD, dt, UNARY_FLAG.REDUCE_COLS) == 0
+    assert api.meqn_push_back_unary_op(md, UNARY.GATHER, dt, gflags) == 0
+    assert api.meqn_push_back_arg(capi.MeqnMetadata(idx, 0), capi.MeqnArgShape(m, n, ld, dt), SINGULAR) == 0
+    h = api.dispatch_meqn(idx, capi.MeqnArgShape(m, 1, ld, dt))
+    assert h
+    xd = torch.from_numpy(X.view(np.int16) if X.dtype == np.uint16 else X).to("cuda:0")
+    idd = torch.from_numpy(cols.view(np.int32 if idx_bytes == 4 else np.int64)).to("cuda:0")
+    out = torch.zeros(ld, dtype=torch.float32 if dt == DT.F32 else torch.int16, device="cuda:0")
+    inputs = (capi.MatrixArg * 1)()
+    inputs[0].primary, inputs[0].secondary = xd.data_ptr(), idd.data_ptr()
+    p = capi.MeqnParam()
+    p.inputs = inputs
+    p.output.primary = out.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    Xf = _f32(X, dt).reshape(big_n, ld)[:, :m].astype(np.float64)
+    gold = Xf[cols.astype(np.int64)].sum(axis=0)
+    got = _f32(out.cpu().numpy().view(NPDT[dt]), dt)[:m].astype(np.float64)
+    assert np.sqrt(((got - gold) ** 2).sum() / (gold ** 2).sum()) < (1e-6 if dt == DT.F32 else 8e-3)
+    inputs[0].secondary = None
+    capi.Api.call(h, p)
+    assert api.hip_get_last_error() != 0
+    api.hip_clear_last_error()

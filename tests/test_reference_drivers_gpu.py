@@ -181,7 +181,7 @@ def test_reference_ternary_driver(args):
 
 # samples/equation/equation_simple.c -- M N ld datatype_mode(0 f32, 1 bf16) iters: five-argument element-wise + reduce/broadcast trees
 # (not run: equation_simple_layernorm is BF8-only; equation_bf16_x3_split_f32 reads, as arguments, buffers that DUMP nodes of the same tree
-# write -- its result depends on the reference's node scheduling; the gather / matmul samples need node kinds this back end refuses)
+# write -- its result depends on the reference's node scheduling; equation_layernorm needs the x86 intrinsics header)
 @pytest.mark.parametrize("args", ["64 48 64 0 2", "64 48 64 1 2", "33 17 40 0 2"])
 def test_reference_equation_driver(args):
     check("equation_simple", *args.split())
@@ -250,3 +250,31 @@ def test_reference_matdiff_test():
 def test_reference_quantization_driver(args):
     out = check("eltwise_unary_quantization", *args.split())
     assert out.count("SUCCESS") == 2, out[-1500:]
+
+
+# samples/equation/equation_gather_reduce.c -- M N ld datatype_mode idx_type(0: 32-bit, 1: 64-bit) iters: reduce_cols(gather_cols(X)) as one
+# equation, the GATHER node reading its indices from inputs[0].secondary (argument lists of equation_test/equation_gather_reduce.sh)
+@pytest.mark.parametrize("args", ["37 21 40 0 0 2", "64 32 64 0 1 2", "64 32 64 1 0 2", "17 5 20 1 1 2"])
+def test_reference_gather_reduce_equation_driver(args):
+    check("equation_gather_reduce", *args.split())
+
+
+# samples/equation/equation_gather_dot.c, equation_gather_bcstmul_add.c -- cols M numidx idxblk iters (equation_test/*.sh: "<cols> <M> 256 16 0"):
+# KV-cache style look-ups as TPP sequences, a two-vector dot-product equation whose head reduces to 1 x 1, gather + GEMM
+@pytest.mark.parametrize("exe", ["equation_gather_dot", "equation_gather_bcstmul_add"])
+@pytest.mark.parametrize("args", ["1024 48 256 16 0", "2048 80 64 16 2"])
+def test_reference_gather_kvcache_equation_drivers(exe, args):
+    check(exe, *args.split())
+
+
+# samples/equation/equation_matmul.c -- n_tensors {m n ld blocks} x n_tensors datatype_mode(0 f32, 1 bf16) fusion(0 none, 1 relu, 2 sigmoid) iters:
+# MATMUL / BRGEMM nodes below and above element-wise nodes (binary and accumulate-in-place ternary forms, strided argument sets, bf16 A in
+# VNNI layout, bias + activation on top of a BRGEMM).  The driver prints its norms without judging them: asserted here.
+# (the driver sizes the scratch of its own gold code as m_C * m_D BYTES for m_C * n_D floats -- equation_matmul.c:345 -- so the shapes keep k >= 4 n)
+@pytest.mark.parametrize("args,bound", [("5 32 16 32 1 32 16 32 1 32 64 32 4 64 16 64 4 32 16 32 1 0 0 2", 1e-5),
+                                        ("5 32 16 32 1 32 16 32 1 32 64 32 4 64 16 64 4 32 16 32 1 0 2 2", 1e-5),
+                                        ("5 64 16 64 1 64 16 64 1 64 64 64 3 64 16 64 3 64 16 64 1 1 1 2", 1e-2)])
+def test_reference_matmul_equation_driver(args, bound):
+    out = check("equation_matmul", *args.split())
+    norms = [float(x) for x in re.findall(r"Check-norm\s*:\s*([0-9.eE+-]+)", out)]
+    assert len(norms) >= 3 and max(norms) <= bound, out[-3000:]
