@@ -11,7 +11,7 @@ import pytest
 
 from helpers import normf_rel, rand_values
 from libxsmm_amd import capi
-from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, TERNARY, TERNARY_FLAG, UNARY, UNARY_FLAG
+from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, GEMM_FLAG, TERNARY, TERNARY_FLAG, UNARY, UNARY_FLAG
 from oracle import pyoracle
 
 NPDT = {DT.F32: np.float32, DT.BF16: np.uint16}
@@ -19,7 +19,7 @@ SINGULAR = capi.MatrixArgAttributes(0, 0, 0, 0)
 ALPHA = C.c_float(0.125)
 
 
-# tree notation: ("arg", pos) | ("u", type, flags, child) | ("b", type, flags, l, r) | ("t", type, flags, a, b, c)
+# tree notation: ("arg", pos) | ("u", type, flags, child) | ("b", type, flags, l, r) | ("t", type, flags, a, b, c) | ("mm", BINARY.MATMUL, 0, A, B)
 def build(api, tree, arg_shapes, comp=DT.F32):
     idx = api.meqn_create()
 
@@ -30,7 +30,7 @@ def build(api, tree, arg_shapes, comp=DT.F32):
         elif t[0] == "u":
             assert api.meqn_push_back_unary_op(capi.MeqnMetadata(idx, 0 if t[1] == UNARY.LEAKY_RELU else -1), t[1], comp, t[2]) == 0
             walk(t[3])
-        elif t[0] == "b":
+        elif t[0] in ("b", "mm"):
             assert api.meqn_push_back_binary_op(capi.MeqnMetadata(idx, -1), t[1], comp, t[2]) == 0
             walk(t[3]); walk(t[4])
         else:
@@ -53,6 +53,14 @@ def evaluate(tree, arg_shapes, arrays, out_shape, comp=DT.F32):
             return arrays[t[1]], (m, n, ld, dt)
         kids = [ev(c, False) for c in t[3:]]
         (x0, (m0, n0, ld0, dt0)) = kids[0]
+        if t[0] == "mm":       # A (m x k) times B (k x n) through the pinned GEMM restatement, beta = 0 (samples/equation/equation_matmul.c:37-62)
+            (x1, (m1, n1, ld1, dt1)) = kids[1]
+            assert n0 == m1
+            ld, odt = (out_shape[2], out_shape[3]) if root else (m0, comp)
+            out = np.zeros(ld * n1, dtype=NPDT[odt])
+            p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = x0.ctypes.data, x1.ctypes.data, out.ctypes.data
+            orc.gemm(p, pyoracle.GemmDesc(m0, n1, n0, ld0, ld1, ld, dt0, dt1, odt, DT.F32, GEMM_FLAG.BETA_0 | GEMM_FLAG.USE_XGEMM_ABI | (GEMM_FLAG.VNNI_A if t[1] == BINARY.MATMUL_A_VNNI else 0), 0, 0, 0, 0))
+            return out, (m0, n1, ld, odt)
         if t[0] == "u":
             if t[1] in REDUCES:
                 m, n = ((n0, 1) if t[2] & UNARY_FLAG.REDUCE_ROWS else (m0, 1)); dm, dn = m0, n0
@@ -99,6 +107,12 @@ CASES = {
     "layernorm_affine": (("t", TERNARY.MULADD, TERNARY_FLAG.REUSE_IN_2_AS_OUT,
                           ("t", TERNARY.MULADD, TERNARY_FLAG.BCAST_SCALAR_IN_1 | TERNARY_FLAG.BCAST_SCALAR_IN_2 | TERNARY_FLAG.REUSE_IN_2_AS_OUT, A(0), A(1), A(2)), A(3), A(4)),
                          [(64, 32, 64, DT.BF16), (1, 1, 1, DT.F32), (1, 1, 1, DT.F32), (64, 32, 64, DT.BF16), (64, 32, 64, DT.BF16)], (64, 32, 64, DT.BF16)),
+    # equation 0 of equation_matmul.c without the transcendentals: (C x D) * (A + B), the product as a BINARY_MATMUL node
+    "matmul_mul": (("b", BINARY.MUL, 0, ("mm", BINARY.MATMUL, 0, A(2), A(3)), ("b", BINARY.ADD, 0, A(0), A(1))),
+                   [(48, 24, 56, DT.F32), (48, 24, 48, DT.F32), (48, 40, 52, DT.F32), (40, 24, 42, DT.F32)], (48, 24, 56, DT.F32)),
+    # a bf16 product at the head, A in VNNI-2 layout (what the reference's AMX / AVX-512 bf16 kernels take), relu on top
+    "matmul_vnni_bf16": (("u", UNARY.RELU, 0, ("mm", BINARY.MATMUL_A_VNNI, 0, A(0), A(1))),
+                         [(32, 16, 32, DT.BF16), (16, 24, 16, DT.BF16)], (32, 24, 40, DT.BF16)),
     "mixed_precision": (("b", BINARY.SUB, 0, ("u", UNARY.X2, 0, A(0)), ("b", BINARY.MUL, BINARY_FLAG.BCAST_SCALAR_IN_1, A(1), A(2))),
                         [(M, N, LD, DT.BF16), (M, N, M, DT.F32), (1, 1, 1, DT.F32)], (M, N, LD, DT.BF16)),
 }
@@ -128,6 +142,8 @@ def _valid(x, shape):
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_oracle_composition_matches_reference_meqn(reference, name):
+    if name == "matmul_vnni_bf16":
+        pytest.skip("the reference's CPU JIT corrupts the heap on this bf16 MATMUL tree on this host (NaN output, glibc abort): GPU-vs-oracle only")
     tree, shapes, out_shape = CASES[name]
     arrays = _inputs(shapes, 5)
     mine = evaluate(tree, shapes, arrays, out_shape)
@@ -149,6 +165,7 @@ def test_incomplete_and_unsupported_equations_return_null(api):
     assert api.dispatch_meqn(idx, capi.MeqnArgShape(8, 8, 8, DT.F32)) is None          # second operand missing
 
 
+BY_NORM = {"tanh_sigmoid_chain": 1e-6, "matmul_mul": 1e-6, "matmul_vnni_bf16": 8e-3}     # device tanhf / the matrix core's summation order: not bit-identical
 FUSABLE = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain", "layernorm_affine"}     # no reduction inside
 
 
@@ -177,8 +194,8 @@ def test_gpu_meqn_matches_oracle_composition(name, jit):
     got = out.cpu().numpy().view(NPDT[out_shape[3]])
     # every node is a TPP kernel that is bit-identical to its oracle -> so is the composition (device tanhf differs from
     # the host's by ulps: the transcendental case is compared in norm)
-    if name == "tanh_sigmoid_chain":
-        assert normf_rel(_valid(ref, out_shape), _valid(got, out_shape), out_shape[3]) < 1e-6
+    if name in BY_NORM:
+        assert normf_rel(_valid(ref, out_shape), _valid(got, out_shape), out_shape[3]) < BY_NORM[name]
     else:
         assert np.array_equal(_valid(got, out_shape), _valid(ref, out_shape))
     # a second call with other inputs reuses handle and workspace
@@ -188,8 +205,8 @@ def test_gpu_meqn_matches_oracle_composition(name, jit):
     _call(api, h, [d.data_ptr() for d in dev2], out.data_ptr())
     api.hip_sync(); api.check()
     got2 = out.cpu().numpy().view(NPDT[out_shape[3]])
-    if name == "tanh_sigmoid_chain":
-        assert normf_rel(_valid(ref2, out_shape), _valid(got2, out_shape), out_shape[3]) < 1e-6
+    if name in BY_NORM:
+        assert normf_rel(_valid(ref2, out_shape), _valid(got2, out_shape), out_shape[3]) < BY_NORM[name]
     else:
         assert np.array_equal(_valid(got2, out_shape), _valid(ref2, out_shape))
 
