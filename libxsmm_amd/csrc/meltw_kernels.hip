@@ -845,6 +845,76 @@ __global__ __launch_bounds__(256) void reduce_combine_kernel(MeltwArgs p, const 
 // ------------------------------------------------------------------------------------------------
 // host-side selection
 // ------------------------------------------------------------------------------------------------
+
+// ---- QUANT to a microscaling type: 32 consecutive rows of a column share one E8M0 scale byte ---------------------------------
+// [ref: samples/eltwise/eltwise_unary_quantization_to_mxfp4.c:20-105 and _to_mxbf8.c:22-71 (the drivers' gold code for the
+//  reference's bf16 -> MXFP4X2 / MXBF8 QUANT TPP)]: amax over the block (NaN sticks), scale exponent = exponent(amax) - emax_elem
+// (2 for E2M1, 15 for E5M2) clamped at 0, an inf / NaN block stores scale 0xFF and max-normal elements; otherwise every element
+// is divided by 2^(scale - 127) -- an exact rescaling -- and rounded to nearest even into its format.  out.primary: the elements
+// (MXFP4X2: two per byte, even row in the low nibble, ldo / 2 bytes per column; MXBF8: ldo bytes per column), out.secondary: the
+// scales, ldo / 32 per column.  One thread per block: 64 B (bf16) in, 16 or 32 B + 1 B out.
+__device__ __forceinline__ unsigned int e2m1_rne(float a) {        // |value| -> 3-bit code of {0, .5, 1, 1.5, 2, 3, 4, 6}, ties to even codes
+  if (a != a || a > 5.0f) return 7u;
+  if (a >= 3.5f) return 6u;
+  if (a > 2.5f) return 5u;
+  if (a >= 1.75f) return 4u;
+  if (a > 1.25f) return 3u;
+  if (a >= 0.75f) return 2u;
+  if (a > 0.25f) return 1u;
+  return 0u;
+}
+template <bool FP4>
+__global__ __launch_bounds__(256) void mx_quant_kernel(MeltwArgs p, unsigned int mblk, unsigned int total) {
+  const unsigned int t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= total) return;
+  const unsigned int b = t % mblk, j = (t / mblk) % (unsigned int)p.n, z = t / (mblk * (unsigned int)p.n);
+  gcptr in = (gcptr)p.in0 + (long long)z * p.bs_in0;
+  float x[32]; float amax = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 32; ++e) {
+    x[e] = mw_load(in, (long long)j * p.ldi + (long long)b * 32 + e, p.in0_type);
+    const float a = fabsf(x[e]);
+    if (a > amax || a != a) amax = a;
+  }
+  int se = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  const bool special = se == 0xff;
+  se -= FP4 ? 2 : 15;
+  if (special) se = 0xff;
+  if (se < 0) se = 0;
+  ((GM unsigned char*)p.aux_out)[(long long)z * p.bs_aux + (long long)j * (p.ldo / 32) + b] = (unsigned char)se;
+  unsigned int w[8];
+  if (FP4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned int word = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = x[8 * q + e];
+        const unsigned int code = special ? 7u : (((__float_as_uint(v) >> 31) << 3) | e2m1_rne(fabsf(ldexpf(v, 127 - se))));
+        word |= code << (4 * e);
+      }
+      w[q] = word;
+    }
+    GM unsigned int* o = (GM unsigned int*)((GM char*)p.out + (long long)z * p.bs_out + (long long)j * (p.ldo / 2) + (long long)b * 16);
+    if ((((size_t)o) & 3) == 0) { for (int q = 0; q < 4; ++q) o[q] = w[q]; }
+    else { GM unsigned char* ob = (GM unsigned char*)o; for (int q = 0; q < 16; ++q) ob[q] = (unsigned char)(w[q >> 2] >> (8 * (q & 3))); }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      unsigned int word = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned int code = special ? 0x7bu : (unsigned int)lowp::f16_to_bf8_rne(lowp::f32_to_f16(ldexpf(x[4 * q + e], 127 - se)));
+        word |= code << (8 * e);
+      }
+      w[q] = word;
+    }
+    GM unsigned int* o = (GM unsigned int*)((GM char*)p.out + (long long)z * p.bs_out + (long long)j * p.ldo + (long long)b * 32);
+    if ((((size_t)o) & 3) == 0) { for (int q = 0; q < 8; ++q) o[q] = w[q]; }
+    else { GM unsigned char* ob = (GM unsigned char*)o; for (int q = 0; q < 32; ++q) ob[q] = (unsigned char)(w[q >> 2] >> (8 * (q & 3))); }
+  }
+}
+
 static int payload_size(int t) { return typesize(t); }
 
 
@@ -885,6 +955,8 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
     if (is_reduce_type(t)) return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP));
     if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) return d.in0_type == LIBXSMM_DATATYPE_F32 && (d.out_type == LIBXSMM_DATATYPE_BF16 || d.out_type == LIBXSMM_DATATYPE_U16 || d.out_type == LIBXSMM_DATATYPE_I16);
     const auto is_qint = [](int x) { return x == LIBXSMM_DATATYPE_I8 || x == LIBXSMM_DATATYPE_I16 || x == LIBXSMM_DATATYPE_I32; };
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT && (d.out_type == LIBXSMM_DATATYPE_MXFP4X2 || d.out_type == LIBXSMM_DATATYPE_MXBF8))     // block-scaled outputs
+      return (d.in0_type == LIBXSMM_DATATYPE_BF16 || d.in0_type == LIBXSMM_DATATYPE_F32) && d.m % 32 == 0 && d.ldo % 32 == 0 && d.ldo >= d.m && d.ldi >= d.m;
     if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT) return d.in0_type == LIBXSMM_DATATYPE_F32 && is_qint(d.out_type);       // [ref: :2195-2240]
     if (t == LIBXSMM_MELTW_TYPE_UNARY_DEQUANT) return is_qint(d.in0_type) && d.out_type == LIBXSMM_DATATYPE_F32;     // [ref: :2330-2360]
     if (f64) {
@@ -947,6 +1019,13 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
     else if (a.operation == LIBXSMM_MELTW_OPERATION_BINARY) hipLaunchKernelGGL((meltw_ew8_kernel<2>), grid, dim3(256), 0, st, a, m8, total);
     else hipLaunchKernelGGL((meltw_ew8_kernel<3>), grid, dim3(256), 0, st, a, m8, total);
     if (name) *name = "meltw_ew8_kernel";
+    return (int)hipGetLastError();
+  }
+  if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_QUANT && (a.out_type == LIBXSMM_DATATYPE_MXFP4X2 || a.out_type == LIBXSMM_DATATYPE_MXBF8)) {
+    const unsigned int mblk = (unsigned int)(a.m / 32), total = mblk * (unsigned int)a.n * (unsigned int)a.nbatch;
+    if (a.out_type == LIBXSMM_DATATYPE_MXFP4X2) hipLaunchKernelGGL((mx_quant_kernel<true>), dim3((total + 255u) / 256u), dim3(256), 0, st, a, mblk, total);
+    else hipLaunchKernelGGL((mx_quant_kernel<false>), dim3((total + 255u) / 256u), dim3(256), 0, st, a, mblk, total);
+    if (name) *name = "mx_quant_kernel";
     return (int)hipGetLastError();
   }
   if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY) {

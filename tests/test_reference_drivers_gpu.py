@@ -278,3 +278,12 @@ def test_reference_matmul_equation_driver(args, bound):
     out = check("equation_matmul", *args.split())
     norms = [float(x) for x in re.findall(r"Check-norm\s*:\s*([0-9.eE+-]+)", out)]
     assert len(norms) >= 3 and max(norms) <= bound, out[-3000:]
+
+
+# samples/eltwise/eltwise_unary_quantization_to_mxfp4.c / _to_mxbf8.c -- M N ldi ldo: bf16 -> block-scaled 4-bit / 8-bit floats with E8M0
+# scales in out.secondary, compared byte by byte with the drivers' gold code (data and scales)
+@pytest.mark.parametrize("exe", ["eltwise_unary_quantization_to_mxfp4", "eltwise_unary_quantization_to_mxbf8"])
+@pytest.mark.parametrize("args", ["64 16 64 64", "128 33 160 256", "1024 64 1024 1024"])
+def test_reference_mx_quantization_drivers(exe, args):
+    out = check(exe, *args.split())
+    assert out.count("SUCCESS") == 2 and "FAILURE" not in out, out[-1500:]
