@@ -915,6 +915,71 @@ __global__ __launch_bounds__(256) void mx_quant_kernel(MeltwArgs p, unsigned int
   }
 }
 
+
+// ---- QUANT to NVFP4X2: 16 consecutive rows share one E4M3 scale byte, all intermediate arithmetic rounded to bf16 ---------------
+// [ref: samples/eltwise/eltwise_unary_quantization_to_nvfp4.c:43-266 (the driver's gold code of the reference's bf16 -> NVFP4X2 QUANT TPP);
+//  src/generator_mateltwise_reference_impl.c:1947, :2274-2300]: scale = E4M3(bf16(bf16(amax) * bf16(1/6))), a saturating E4M3 whose top
+// code is 0x78; elements = E2M1(bf16(x * bf16(1 / scale))) with the sign of x; a zero scale stores zeros.
+__device__ __forceinline__ float nv_bf16(float x) { return mw_bf2f(mw_f2bf(x)); }
+__device__ __forceinline__ unsigned int nv_e4m3_of(float val) {
+  const unsigned int u = __float_as_uint(val), sign = u >> 31, fe = (u >> 23) & 0xffu, fm = u & 0x7fffffu;
+  if (fe == 0xffu && fm != 0u) return (sign << 7) | 0x7fu;
+  if (fe == 0xffu || fabsf(val) > 448.0f) return (sign << 7) | 0x78u;
+  if (fe == 0u) return sign << 7;                                   // zero and f32 subnormals
+  const int ub = (int)fe - 127;
+  if (ub > 8) return (sign << 7) | 0x78u;
+  if (ub < -9) return sign << 7;
+  if (ub >= -6) {                                                    // normal: 23 -> 3 mantissa bits, nearest even
+    unsigned int e = (unsigned int)(ub + 7), tm = fm >> 20;
+    if (((fm >> 19) & 1u) && ((fm & 0x7ffffu) || (tm & 1u))) ++tm;
+    if (tm >= 8u) { tm = 0u; ++e; }
+    return e >= 0xfu ? ((sign << 7) | 0x78u) : ((sign << 7) | (e << 3) | tm);
+  }
+  const int shift = -6 - ub;                                         // subnormal: 1.mmm shifted right, nearest even
+  if (shift >= 4) return sign << 7;
+  const unsigned int full = 8u | ((fm >> 20) & 7u);
+  unsigned int tm = full >> shift;
+  const unsigned int rb = (full >> (shift - 1)) & 1u, sticky = ((full & ((1u << (shift - 1)) - 1u)) || (fm & 0xfffffu)) ? 1u : 0u;
+  if (rb && (sticky || (tm & 1u))) ++tm;
+  return tm >= 8u ? ((sign << 7) | 8u) : ((sign << 7) | (tm & 7u));
+}
+__device__ __forceinline__ float nv_e4m3_value(unsigned int b) {
+  const unsigned int sign = (b >> 7) & 1u, ex = (b >> 3) & 0xfu, mant = b & 7u;
+  float v;
+  if (ex == 0u) v = (float)mant * (1.0f / 512.0f);
+  else if (ex == 0xfu && mant != 0u) return __uint_as_float(0x7fc00000u);
+  else v = ldexpf(1.0f + (float)mant * 0.125f, (int)ex - 7);
+  return sign ? -v : v;
+}
+__global__ __launch_bounds__(256) void nvfp4_quant_kernel(MeltwArgs p, unsigned int mblk, unsigned int total) {
+  const unsigned int t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= total) return;
+  const unsigned int b = t % mblk, j = (t / mblk) % (unsigned int)p.n, z = t / (mblk * (unsigned int)p.n);
+  gcptr in = (gcptr)p.in0 + (long long)z * p.bs_in0;
+  float x[16]; float amax = 0.0f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    x[e] = mw_load(in, (long long)j * p.ldi + (long long)b * 16 + e, p.in0_type);
+    const float a = fabsf(x[e]);
+    if (a > amax || a != a) amax = a;
+  }
+  unsigned int sb = 0u; float sf = 0.0f;
+  if (amax != 0.0f) { sb = nv_e4m3_of(nv_bf16(nv_bf16(amax) * __uint_as_float(0x3e2a0000u))); sf = nv_e4m3_value(sb); }
+  ((GM unsigned char*)p.aux_out)[(long long)z * p.bs_aux + (long long)j * (p.ldo / 16) + b] = (unsigned char)sb;
+  unsigned int w[2] = {0u, 0u};
+  if (sf != 0.0f) {
+    const float rcp = nv_bf16(1.0f / nv_bf16(sf));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const unsigned int code = ((__float_as_uint(x[e]) >> 31) << 3) | e2m1_rne(fabsf(nv_bf16(x[e] * rcp)));
+      w[e >> 3] |= code << (4 * (e & 7));
+    }
+  }
+  GM unsigned int* o = (GM unsigned int*)((GM char*)p.out + (long long)z * p.bs_out + (long long)j * (p.ldo / 2) + (long long)b * 8);
+  if ((((size_t)o) & 3) == 0) { o[0] = w[0]; o[1] = w[1]; }
+  else { GM unsigned char* ob = (GM unsigned char*)o; for (int q = 0; q < 8; ++q) ob[q] = (unsigned char)(w[q >> 2] >> (8 * (q & 3))); }
+}
+
 static int payload_size(int t) { return typesize(t); }
 
 
@@ -955,6 +1020,8 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
     if (is_reduce_type(t)) return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP));
     if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) return d.in0_type == LIBXSMM_DATATYPE_F32 && (d.out_type == LIBXSMM_DATATYPE_BF16 || d.out_type == LIBXSMM_DATATYPE_U16 || d.out_type == LIBXSMM_DATATYPE_I16);
     const auto is_qint = [](int x) { return x == LIBXSMM_DATATYPE_I8 || x == LIBXSMM_DATATYPE_I16 || x == LIBXSMM_DATATYPE_I32; };
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT && d.out_type == LIBXSMM_DATATYPE_NVFP4X2)      // 16-row blocks, E4M3 scales
+      return (d.in0_type == LIBXSMM_DATATYPE_BF16 || d.in0_type == LIBXSMM_DATATYPE_F32) && d.m % 16 == 0 && d.ldo % 16 == 0 && d.ldo >= d.m && d.ldi >= d.m;
     if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT && (d.out_type == LIBXSMM_DATATYPE_MXFP4X2 || d.out_type == LIBXSMM_DATATYPE_MXBF8))     // block-scaled outputs
       return (d.in0_type == LIBXSMM_DATATYPE_BF16 || d.in0_type == LIBXSMM_DATATYPE_F32) && d.m % 32 == 0 && d.ldo % 32 == 0 && d.ldo >= d.m && d.ldi >= d.m;
     if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT) return d.in0_type == LIBXSMM_DATATYPE_F32 && is_qint(d.out_type);       // [ref: :2195-2240]
@@ -1019,6 +1086,12 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
     else if (a.operation == LIBXSMM_MELTW_OPERATION_BINARY) hipLaunchKernelGGL((meltw_ew8_kernel<2>), grid, dim3(256), 0, st, a, m8, total);
     else hipLaunchKernelGGL((meltw_ew8_kernel<3>), grid, dim3(256), 0, st, a, m8, total);
     if (name) *name = "meltw_ew8_kernel";
+    return (int)hipGetLastError();
+  }
+  if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_QUANT && a.out_type == LIBXSMM_DATATYPE_NVFP4X2) {
+    const unsigned int mblk = (unsigned int)(a.m / 16), total = mblk * (unsigned int)a.n * (unsigned int)a.nbatch;
+    hipLaunchKernelGGL(nvfp4_quant_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, a, mblk, total);
+    if (name) *name = "nvfp4_quant_kernel";
     return (int)hipGetLastError();
   }
   if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_QUANT && (a.out_type == LIBXSMM_DATATYPE_MXFP4X2 || a.out_type == LIBXSMM_DATATYPE_MXBF8)) {

@@ -409,8 +409,8 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     if (t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || t == LIBXSMM_MELTW_TYPE_UNARY_ELU || t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || t == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) {
       if (!p->op.primary) { set_error(-2, "unary TPP needs alpha in op.primary"); return; }
       a.scalar_f32 = *(const float*)p->op.primary;
-    } else if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT && (d.out_type == LIBXSMM_DATATYPE_MXFP4X2 || d.out_type == LIBXSMM_DATATYPE_MXBF8)) {
-      // block-scaled output: the E8M0 scales (ldo / 32 per column) go to out.secondary [ref: samples/eltwise/eltwise_unary_quantization_to_mxfp4.c:198-201]
+    } else if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT && (d.out_type == LIBXSMM_DATATYPE_MXFP4X2 || d.out_type == LIBXSMM_DATATYPE_MXBF8 || d.out_type == LIBXSMM_DATATYPE_NVFP4X2)) {
+      // block-scaled output: the scales (E8M0, ldo / 32 per column; NVFP4: E4M3, ldo / 16 per column) go to out.secondary [ref: samples/eltwise/eltwise_unary_quantization_to_mxfp4.c:198-201]
       if (!p->out.secondary) { set_error(-2, "QUANT to a microscaling type needs the scale array in out.secondary"); return; }
       a.aux_out = p->out.secondary;
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT || t == LIBXSMM_MELTW_TYPE_UNARY_DEQUANT) {

@@ -287,3 +287,9 @@ def test_reference_matmul_equation_driver(args, bound):
 def test_reference_mx_quantization_drivers(exe, args):
     out = check(exe, *args.split())
     assert out.count("SUCCESS") == 2 and "FAILURE" not in out, out[-1500:]
+
+
+# samples/eltwise/eltwise_unary_quantization_to_nvfp4.c -- M N ldi ldo: bf16 -> NVFP4X2 (16-row blocks, E4M3 scales, bf16-rounded arithmetic)
+def test_reference_nvfp4_quantization_driver():
+    out = check("eltwise_unary_quantization_to_nvfp4", "128", "33", "160", "256")
+    assert out.count("SUCCESS") == 2 and "FAILURE" not in out, out[-1500:]
