@@ -2,7 +2,7 @@
 """Roofline measurements for every hot-path row of SURVEY.md section 8 other than the headline config
 (which bench.py owns).  One JSON line per workload; same timing method as bench.py (hipGraph of K launches,
 HIP events on the launch stream, inputs rotated so that every launch streams from HBM).
-Usage: python tools/bench_paths.py [--only gemm,mx,csr,fsspmdm,bcsc,fused,meltw,packed] [--steps K]"""
+Usage: python tools/bench_paths.py [--only gemm,mx,csr,fsspmdm,bcsc,fused,meltw,packed,quant] [--steps K]"""
 import argparse
 import ctypes as C
 import json
@@ -275,6 +275,24 @@ def meltw_big(api, typ, name, m=4096, n=8192, in_dt=DT.F32, out_dt=DT.F32, flags
     return w
 
 
+def meltw_block_quant(api, out_dt, name, m=4096, n=8192):
+    """bf16 -> MXFP4X2 / MXBF8 / NVFP4X2 (block scales to out.secondary).  Not part of the default list: `--only quant`."""
+    blk = 16 if out_dt == DT.NVFP4X2 else 32
+    out_bytes = m * n if out_dt == DT.MXBF8 else m * n // 2
+    h = api.dispatch_meltw_unary(UNARY.QUANT, capi.UnaryShape(m, n, m, m, DT.BF16, out_dt, DT.BF16), 0)
+    assert h, name
+    ns = nsets_for(m * n * 2 + out_bytes + m * n // blk)
+    X = [rnd(m * n, "bf16") for _ in range(ns)]
+    Y = [torch.zeros(out_bytes, dtype=torch.uint8, device=DEV) for _ in range(ns)]
+    S = [torch.zeros(m * n // blk, dtype=torch.uint8, device=DEV) for _ in range(ns)]
+    ps = []
+    for s in range(ns):
+        q = capi.UnaryParam(); q.in_.primary, q.out.primary, q.out.secondary = X[s].data_ptr(), Y[s].data_ptr(), S[s].data_ptr(); ps.append(q)
+    w = Work(api, f"meltw QUANT bf16->{name} {m}x{n}", float(m * n), float(m * n * 2 + out_bytes + m * n // blk), ns, lambda s: capi.Api.call(h, ps[s]))
+    w.keep = (X, Y, S, ps)
+    return w
+
+
 # ---- CPU legs: the reference's own JIT kernels (oracle/_ref) on ONE host core, bounded samples --------------------
 def _cpu_time(fn_time, flops_per_call, seconds, what):
     t1 = fn_time(3)
@@ -485,6 +503,8 @@ def main():
                    lambda: fsspmdm(api, 2 ** 20, 0.15, DT.F64, 1.0)]
     if "bcsc" in only:
         makers += [lambda: bcsc(api), lambda: bcsc(api, bk=32, bn=32)]
+    if "quant" in only:
+        makers += [lambda: meltw_block_quant(api, DT.MXFP4X2, "mxfp4"), lambda: meltw_block_quant(api, DT.MXBF8, "mxbf8"), lambda: meltw_block_quant(api, DT.NVFP4X2, "nvfp4")]
     if "meltw" in only:
         makers += [lambda: meltw_relu_tiles(api), lambda: meltw_big(api, UNARY.IDENTITY, "IDENTITY f32"),
                    lambda: meltw_big(api, UNARY.IDENTITY, "IDENTITY f32->bf16", out_dt=DT.BF16),
