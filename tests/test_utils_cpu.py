@@ -196,3 +196,32 @@ def test_seeded_generators_reproduce_the_reference_streams(ours, ref, seed):
             assert C.string_at(so, 256) == C.string_at(sr, 256)
     finally:
         ours.libxsmm_rng_destroy_extstate(C.c_void_p(so)); ref.xref_rng_destroy_extstate(C.c_void_p(sr))
+
+
+@pytest.mark.parametrize("name", ["BF16", "F16", "BF8", "HF8", "I32", "I16", "I8", "U8"])
+def test_matdiff_record_on_narrow_types_matches_reference(ours, ref, name):
+    """libxsmm_matdiff decodes 16- and 8-bit floats and integers itself (the eltwise drivers judge low-precision outputs with it): same record
+    as the reference for every element type both sides accept."""
+    from libxsmm_amd.capi import DT
+    dt = getattr(DT, name)
+    rng = np.random.default_rng(23)
+    m, n, ld = 19, 6, 24
+    if name in ("BF16", "F16"):
+        ebits = 8 if name == "BF16" else 5
+        mk = lambda: ((rng.integers(0, 2, ld * n) << 15) | (rng.integers(1, (1 << ebits) - 1, ld * n) << (15 - ebits)) | rng.integers(0, 1 << (15 - ebits), ld * n)).astype(np.uint16)   # noqa: E731
+    elif name in ("BF8", "HF8"):
+        ebits = 5 if name == "BF8" else 4
+        mk = lambda: ((rng.integers(0, 2, ld * n) << 7) | (rng.integers(1, (1 << ebits) - 1, ld * n) << (7 - ebits)) | rng.integers(0, 1 << (7 - ebits), ld * n)).astype(np.uint8)       # noqa: E731
+    else:
+        npdt = {"I32": np.int32, "I16": np.int16, "I8": np.int8, "U8": np.uint8}[name]
+        mk = lambda: rng.integers(0 if name == "U8" else -100, 100, ld * n).astype(npdt)      # noqa: E731
+    r, t = mk(), mk()
+    t[: ld * 3] = r[: ld * 3]                                   # partly equal
+    io, ir = _MatdiffInfo(), _MatdiffInfo()
+    l1, l2 = C.c_int(ld), C.c_int(ld)
+    args = (int(dt), m, n, C.c_void_p(r.ctypes.data), C.c_void_p(t.ctypes.data), C.byref(l1), C.byref(l2))
+    rc_o, rc_r = ours.libxsmm_matdiff(C.byref(io), *args), ref.xref_matdiff(C.byref(ir), *args)
+    if rc_r != 0:
+        pytest.skip(f"the reference's libxsmm_matdiff does not take {name}")
+    assert rc_o == 0
+    assert _same_record(io, ir) is None, _same_record(io, ir)
