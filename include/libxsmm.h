@@ -70,7 +70,12 @@ typedef unsigned char      libxsmm_hfloat8;
 typedef union libxsmm_float_uint   { float f; unsigned int u; } libxsmm_float_uint;
 typedef union libxsmm_bfloat16_f32 { libxsmm_bfloat16 i[2]; float f; } libxsmm_bfloat16_f32;
 
-typedef struct libxsmm_descriptor_blob { char data[LIBXSMM_DESCRIPTOR_MAXSIZE]; } libxsmm_descriptor_blob;
+/* Same size as the reference's blob; 8-byte aligned because this library's descriptors hold 64-bit strides. */
+#if defined(__GNUC__)
+typedef struct libxsmm_descriptor_blob { char data[LIBXSMM_DESCRIPTOR_MAXSIZE]; } __attribute__((aligned(8))) libxsmm_descriptor_blob;
+#else
+typedef struct libxsmm_descriptor_blob { union { char data[LIBXSMM_DESCRIPTOR_MAXSIZE]; long long align_[LIBXSMM_DESCRIPTOR_MAXSIZE / 8]; }; } libxsmm_descriptor_blob;
+#endif
 typedef struct libxsmm_gemm_descriptor  libxsmm_gemm_descriptor;   /* opaque */
 typedef struct libxsmm_meltw_descriptor libxsmm_meltw_descriptor;  /* opaque */
 

@@ -33,7 +33,7 @@ struct libxsmm_gemm_descriptor {
   uint16_t ap_flags, bp_flags, cp_flags;
   uint32_t ldap, ldbp, ldcp;
   uint32_t reserved;
-};
+} __attribute__((packed));   // packed + byte-aligned: a caller's blob may sit at any address (the reference's descriptors are packed too)
 static_assert(sizeof(libxsmm_gemm_descriptor) <= LIBXSMM_DESCRIPTOR_MAXSIZE, "gemm descriptor too large");
 
 struct libxsmm_meltw_descriptor {
@@ -41,7 +41,7 @@ struct libxsmm_meltw_descriptor {
   uint8_t in0_type, in1_type, in2_type, comp_type, out_type, operation;
   uint16_t flags, param;
   uint32_t reserved;
-};
+} __attribute__((packed));
 static_assert(sizeof(libxsmm_meltw_descriptor) <= LIBXSMM_DESCRIPTOR_MAXSIZE, "meltw descriptor too large");
 
 namespace xamd {
@@ -162,7 +162,7 @@ struct KernelCtx {
   std::vector<unsigned int> h_ptr, h_idx, h_vmap;   // host pattern kept while specialisation is deferred to the first batched launch
   struct EqnPlan* eqn = nullptr;    // K_MEQN: the evaluation plan (meqn.cpp)
   int device = 0;
-  const char* kname_single = "";
+  const char* kname_single = "";                 // static strings or strings owned by a never-shrinking table
   const char* kname_batched = "";
 };
 
@@ -170,6 +170,7 @@ struct KernelCtx {
 struct EqnPlan;
 void run_meqn(EqnPlan* plan, const void* param);
 void free_meqn_plan(EqnPlan* plan);
+void free_meqn_equations();                      // libxsmm_finalize: drop every equation object
 const char* meqn_plan_name(const EqnPlan* plan);
 const void* rt_new_meqn_handle(EqnPlan* plan);   // caller-independent handle owned by the equation registry
 void rt_finish_launch(int err, const char* kernel_name);

@@ -336,6 +336,12 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
 
 const char* meqn_plan_name(const EqnPlan* plan) { return (plan && plan->fused) ? jit_name(plan->fused) : "meqn_tpp_chain"; }
 void free_meqn_plan(EqnPlan* plan) { if (plan && plan->fused) jit_release(plan->fused); delete plan; }
+// libxsmm_finalize: the equation objects (and their handle caches, whose handles the runtime has just released) go with the registry
+void free_meqn_equations() {
+  std::lock_guard<std::mutex> guard(g_eqn_lock);
+  for (Equation* e : g_eqns) delete e;
+  g_eqns.clear();
+}
 
 void run_meqn(EqnPlan* plan, const void* param) {
   const libxsmm_meqn_param* p = (const libxsmm_meqn_param*)param;

@@ -8,7 +8,11 @@
 #include <hip/hip_runtime_api.h>
 #include "internal.hpp"
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <array>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -31,23 +35,91 @@ __attribute__((visibility("default"))) int libxsmm_se = 0;             // securi
 
 namespace {
 
-constexpr int kSlots = 8192;
+// ---- handle table ------------------------------------------------------------------------------------
+// A handle is a plain C function pointer that must carry per-kernel state.  The reference gets that closure by
+// JIT-emitting the whole kernel; here a handle is a 32-byte x86-64 THUNK in an executable pool that loads its slot
+// number and tail-calls xamd_invoke(slot, param) -- the same trick the reference plays for its C reference kernels
+// [ref: src/generator_x86_reference.c:52-96].  Slot <-> handle is pure address arithmetic in both directions.
+// Capacity follows the reference's registry [ref: src/libxsmm_main.h:18-22]: 131072 REGISTERED kernels (dispatch_*),
+// plus as many caller-owned ones (create_*).  Thunk pages are written once, 128 thunks at a time, then flipped to
+// read+execute (W^X).  If the process may not map executable memory (hardened kernels; the reference cannot JIT there
+// either) a small table of ahead-of-time instantiated trampolines serves instead.
+constexpr int kRegistryCapacity = 131072;
+constexpr int kSlots = 2 * kRegistryCapacity;
+constexpr int kStaticSlots = 256;
+constexpr size_t kThunkBytes = 32, kThunkPage = 4096, kThunksPerPage = kThunkPage / kThunkBytes;
 std::mutex g_lock;
 KernelCtx* g_slots[kSlots];
 std::vector<int> g_free_slots;
 int g_next_slot = 0;
-std::unordered_map<std::string, KernelCtx*> g_registry;
+int g_slot_limit = kSlots;            // LIBXSMM_HIP_MAX_HANDLES lowers it (tests of the exhaustion path)
+int g_registered_limit = kRegistryCapacity;
 int g_device_count = -1;
 bool g_warned_nodevice = false;
+bool g_dryrun = false;                // LIBXSMM_HIP_DRYRUN=1: dispatch works without a device (registry tests); calling a kernel is an error
+std::atomic<unsigned int> g_generation{1};   // bumped by libxsmm_finalize: invalidates every thread's dispatch cache
 
-// ---- trampolines: tramp<I> is the C function a handle points to -----------------------------------
+unsigned char* g_thunk_pool = nullptr;       // kSlots * kThunkBytes, nullptr: static trampolines only
+std::vector<bool> g_thunk_page_ready;
+
 template <int I> void tramp(const void* param) { xamd::invoke(I, param); }
 using tramp_fn = void (*)(const void*);
 template <int... Is> constexpr std::array<tramp_fn, sizeof...(Is)> make_tramps(std::integer_sequence<int, Is...>) {
   return {{&tramp<Is>...}};
 }
-const std::array<tramp_fn, kSlots> g_tramps = make_tramps(std::make_integer_sequence<int, kSlots>{});
-std::unordered_map<const void*, int> g_handle_to_slot;   // built once in libxsmm_init
+const std::array<tramp_fn, kStaticSlots> g_tramps = make_tramps(std::make_integer_sequence<int, kStaticSlots>{});
+
+extern "C" void xamd_invoke_thunk(int slot, const void* param) { xamd::invoke(slot, param); }
+
+void thunk_pool_init_locked() {
+  if (g_thunk_pool) return;
+#if defined(__x86_64__)
+  const char* off = std::getenv("LIBXSMM_HIP_THUNKS");
+  if (off && off[0] == '0') return;
+  void* p = mmap(nullptr, (size_t)kSlots * kThunkBytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) return;
+  // probe once that a page may become executable at all
+  if (mprotect(p, kThunkPage, PROT_READ | PROT_EXEC) != 0) { munmap(p, (size_t)kSlots * kThunkBytes); return; }
+  (void)mprotect(p, kThunkPage, PROT_READ | PROT_WRITE);
+  g_thunk_pool = (unsigned char*)p;
+  g_thunk_page_ready.assign(((size_t)kSlots + kThunksPerPage - 1) / kThunksPerPage, false);
+#endif
+}
+// make the thunk of `slot` callable; false if its page could not be made executable
+bool thunk_ready_locked(int slot) {
+  if (!g_thunk_pool) return slot < kStaticSlots;
+  const size_t page = (size_t)slot / kThunksPerPage;
+  if (g_thunk_page_ready[page]) return true;
+  unsigned char* base = g_thunk_pool + page * kThunkPage;
+  const unsigned long long target = (unsigned long long)(size_t)&xamd_invoke_thunk;
+  for (size_t t = 0; t < kThunksPerPage; ++t) {
+    unsigned char* c = base + t * kThunkBytes;
+    const unsigned int id = (unsigned int)(page * kThunksPerPage + t);
+    size_t o = 0;
+    c[o++] = 0x48; c[o++] = 0x89; c[o++] = 0xfe;                                   // mov rsi, rdi   (param -> 2nd argument)
+    c[o++] = 0xbf; std::memcpy(c + o, &id, 4); o += 4;                             // mov edi, slot
+    c[o++] = 0x48; c[o++] = 0xb8; std::memcpy(c + o, &target, 8); o += 8;          // movabs rax, &xamd_invoke_thunk
+    c[o++] = 0xff; c[o++] = 0xe0;                                                  // jmp rax
+    while (o < kThunkBytes) c[o++] = 0xcc;                                         // int3 padding
+  }
+  if (mprotect(base, kThunkPage, PROT_READ | PROT_EXEC) != 0) return false;
+  g_thunk_page_ready[page] = true;
+  return true;
+}
+
+// ---- registry key: kind + the zero-padded descriptor bytes; hashed once per dispatch, never heap-allocated ----------
+struct RegKey {
+  unsigned long long w[(LIBXSMM_DESCRIPTOR_MAXSIZE + 7) / 8 + 1];   // [0] = kind, [1..] = descriptor bytes
+  bool operator==(const RegKey& o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+};
+inline unsigned long long hash_key(const RegKey& k) {
+  unsigned long long h = 0x9e3779b97f4a7c15ull;
+  for (unsigned long long x : k.w) { h ^= x; h *= 0xff51afd7ed558ccdull; h ^= h >> 29; }
+  return h ^ (h >> 32);
+}
+struct RegKeyHash { size_t operator()(const RegKey& k) const { return (size_t)hash_key(k); } };
+std::unordered_map<RegKey, KernelCtx*, RegKeyHash> g_registry;
+std::vector<KernelCtx*> g_meqn_ctxs;         // equation handles: registry-owned, freed at finalize
 
 const char* const kTypeNames[] = {
 #define X_(NAME, SIZE) #NAME,
@@ -94,7 +166,8 @@ void finish_launch(int err, const char* kname) {
 std::mutex g_retired_lock;
 std::vector<void*> g_retired;
 void retire_block(void* p) { if (p) { std::lock_guard<std::mutex> guard(g_retired_lock); g_retired.push_back(p); } }
-struct Scratch { char* base = nullptr; size_t cap = 0, used = 0; };
+static int cur_device() { const int d = tls().device; return d < 0 ? 0 : d; }
+struct Scratch { char* base = nullptr; size_t cap = 0, used = 0; int device = 0; };
 thread_local Scratch t_scratch;
 struct CopyBack { void* host; const void* dev; size_t bytes; };
 thread_local std::vector<CopyBack> t_copyback;       // staged outputs of the current synchronous call
@@ -107,17 +180,16 @@ static void* stage(const void* p, size_t nbytes, bool copy_in, bool copy_back) {
   (void)hipGetLastError();   // clear the sticky "invalid value" of an unregistered pointer
   Scratch& s = t_scratch;
   const size_t need = (nbytes + 255) & ~(size_t)255;
+  if (s.base && s.device != cur_device()) { retire_block(s.base); s.base = nullptr; s.cap = s.used = 0; }   // the thread switched device
   if (s.used + need > s.cap) {
-    // a call's earlier staged arrays must stay valid: the used part moves along
+    // Pointers handed out earlier in this call (staged operands already written into the argument block, pending copy-backs)
+    // must stay valid, so the old block is neither moved nor freed: it is RETIRED (released at libxsmm_finalize) and the
+    // overflowing request starts a fresh, larger block.  Growth is geometric, so a thread retires O(log size) blocks.
     const size_t ncap = std::max<size_t>((s.used + need) * 2, 1 << 20);
     char* nb = nullptr;
     if (!hip_ok(hipMalloc((void**)&nb, ncap), "hipMalloc(scratch)")) return nullptr;
-    if (s.base) {
-      (void)hipStreamSynchronize(cur_stream()); (void)hipMemcpy(nb, s.base, s.used, hipMemcpyDeviceToDevice);
-      for (CopyBack& c : t_copyback) c.dev = nb + ((const char*)c.dev - s.base);
-      retire_block(s.base);
-    }
-    s.base = nb; s.cap = ncap;
+    if (s.base) retire_block(s.base);
+    s.base = nb; s.cap = ncap; s.used = 0; s.device = cur_device();
   }
   char* dst = s.base + s.used; s.used += need;
   if (copy_in && !hip_ok(hipMemcpyAsync(dst, p, nbytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpyAsync(host operand)")) return nullptr;
@@ -137,36 +209,35 @@ void copy_back_staged() {
   t_copyback.clear();
 }
 // per-thread device workspace for partial results; grows monotonically, reused in stream order
-struct Workspace { void* base = nullptr; size_t cap = 0; };
+struct Workspace { void* base = nullptr; size_t cap = 0; int device = 0; };
 thread_local Workspace t_workspace;
 thread_local size_t t_ws_reserved = 0;   // front part owned by an enclosing call (the slots of a matrix equation around a GEMM node)
 void* workspace(size_t nbytes_wanted) {
   Workspace& w = t_workspace;
   const size_t nbytes = nbytes_wanted + t_ws_reserved;
+  if (w.base && w.device != cur_device()) { retire_block(w.base); w.base = nullptr; w.cap = 0; }
   if (nbytes > w.cap) {
     if (w.base) { retire_block(w.base); w.base = nullptr; w.cap = 0; }
     const size_t ncap = std::max<size_t>(nbytes, 4u << 20);
     if (!hip_ok(hipMalloc(&w.base, ncap), "hipMalloc(workspace)")) { w.base = nullptr; return nullptr; }
-    w.cap = ncap;
+    w.cap = ncap; w.device = cur_device();
   }
   return (char*)w.base + t_ws_reserved;
 }   // stream order protects data of the previous call
 
-std::string make_key(int kind, const void* desc, size_t n) {
-  std::string k; k.reserve(n + 1); k.push_back((char)kind); k.append((const char*)desc, n); return k;
-}
-
 int alloc_slot_locked() {
-  if (!g_free_slots.empty()) { const int s = g_free_slots.back(); g_free_slots.pop_back(); return s; }
-  if (g_next_slot < kSlots) return g_next_slot++;
-  return -1;
+  int slot = -1;
+  if (!g_free_slots.empty()) { slot = g_free_slots.back(); g_free_slots.pop_back(); }
+  else if (g_next_slot < std::min(g_slot_limit, g_thunk_pool ? kSlots : kStaticSlots)) slot = g_next_slot++;
+  if (slot >= 0 && !thunk_ready_locked(slot)) { g_free_slots.push_back(slot); return -1; }
+  return slot;
 }
 
 KernelCtx* new_ctx_locked(Kind kind) {
   const int slot = alloc_slot_locked();
-  if (slot < 0) { vlog(1, "out of kernel handles (%d)", kSlots); return nullptr; }
+  if (slot < 0) { vlog(1, "out of kernel handles (%d in use)", g_next_slot - (int)g_free_slots.size()); return nullptr; }
   KernelCtx* c = new KernelCtx();
-  c->slot = slot; c->kind = kind; c->device = tls().device < 0 ? 0 : tls().device;
+  c->slot = slot; c->kind = kind; c->device = cur_device();
   g_slots[slot] = c;
   return c;
 }
@@ -223,7 +294,7 @@ int typesize(int t) { return (t >= 0 && t < (int)LIBXSMM_DATATYPE_COUNT_) ? (int
 
 bool runtime_ready() {
   if (libxsmm_ninit < 2) libxsmm_init();
-  if (g_device_count > 0) return true;
+  if (g_device_count > 0 || g_dryrun) return true;
   if (!g_warned_nodevice) {
     g_warned_nodevice = true;
     std::fprintf(stderr, "LIBXSMM-AMD ERROR: no HIP device visible -- this backend has no CPU path; every dispatch returns NULL\n");
@@ -231,13 +302,21 @@ bool runtime_ready() {
   return false;
 }
 
+static int slot_from_handle(const void* fn) {
+  if (g_thunk_pool) {
+    const size_t off = (size_t)((const unsigned char*)fn - g_thunk_pool);
+    if ((const unsigned char*)fn >= g_thunk_pool && off < (size_t)kSlots * kThunkBytes && off % kThunkBytes == 0) return (int)(off / kThunkBytes);
+    return -1;
+  }
+  for (int i = 0; i < kStaticSlots; ++i) if ((const void*)g_tramps[i] == fn) return i;
+  return -1;
+}
 KernelCtx* ctx_from_handle(const void* fn) {
   if (!fn) return nullptr;
-  auto it = g_handle_to_slot.find(fn);
-  if (it == g_handle_to_slot.end()) return nullptr;
-  return g_slots[it->second];
+  const int slot = slot_from_handle(fn);
+  return slot >= 0 ? g_slots[slot] : nullptr;
 }
-const void* handle_for_slot(int slot) { return (const void*)g_tramps[slot]; }
+const void* handle_for_slot(int slot) { return g_thunk_pool ? (const void*)(g_thunk_pool + (size_t)slot * kThunkBytes) : (const void*)g_tramps[slot]; }
 
 }  // namespace xamd
 
@@ -493,6 +572,7 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
   }
   const char* kname = nullptr;
   const int err = launch_meltw(a, tls().stream, &kname);
+  if (kname) { if (b.count > 1) k->kname_batched = kname; else k->kname_single = kname; }   // the device kernel that actually ran
   finish_launch(err, kname);
 }
 
@@ -514,6 +594,8 @@ static void spmm_geometry(const KernelCtx* k, SpmmArgs& a) {
 void run_spmm(KernelCtx* k, const void* param, const BatchSpec& b) {
   const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
   SpmmArgs a{};
+  // the pattern arrays (and the JIT module) live on the device the kernel was created on
+  if (k->device != cur_device()) { set_error(-3, "packed sparse kernel was created on device %d but is called on device %d", k->device, cur_device()); return; }
   spmm_geometry(k, a);
   scratch_reset();
   a.ptr = k->d_ptr; a.idx = k->d_idx; a.vmap = k->d_vmap;
@@ -623,6 +705,7 @@ void run_bcsc(KernelCtx* k, const void* param) {
 
 void run_any(KernelCtx* k, const void* param, const BatchSpec& b) {
   if (!param && k->kind != K_TILECFG) { set_error(-2, "kernel called with a NULL parameter struct"); return; }
+  if (g_device_count <= 0 && k->kind != K_TILECFG) { set_error(-4, "no HIP device: kernel not launched (this backend has no CPU path)"); return; }
   switch (k->kind) {
     case K_GEMM: run_gemm(k, param, b); break;
     case K_MELTW: run_meltw(k, param, b); break;
@@ -642,6 +725,7 @@ const void* rt_new_meqn_handle(EqnPlan* plan) {
   KernelCtx* c = new_ctx_locked(K_MEQN);
   if (!c) return nullptr;
   c->registered = true; c->eqn = plan; c->kname_single = c->kname_batched = meqn_plan_name(plan);
+  g_meqn_ctxs.push_back(c);            // registry-owned like the reference's equation kernels: released by libxsmm_finalize
   return handle_for_slot(c->slot);
 }
 void rt_finish_launch(int err, const char* kernel_name) { finish_launch(err, kernel_name); }
@@ -672,30 +756,52 @@ LIBXSMM_API void libxsmm_init(void) {
   libxsmm_ninit = 1;
   const char* v = std::getenv("LIBXSMM_VERBOSE");
   if (v) libxsmm_verbosity = std::atoi(v);
-  for (int i = 0; i < kSlots; ++i) g_handle_to_slot.emplace((const void*)g_tramps[i], i);
+  thunk_pool_init_locked();
+  if (const char* cap = std::getenv("LIBXSMM_HIP_MAX_HANDLES")) { const int n = std::atoi(cap); if (n > 0) { g_slot_limit = std::min(n, kSlots); g_registered_limit = std::min(g_registered_limit, g_slot_limit); } }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { n = 0; (void)hipGetLastError(); }
   g_device_count = n;
+  { const char* dry = std::getenv("LIBXSMM_HIP_DRYRUN"); g_dryrun = (n <= 0 && dry && dry[0] == '1'); }
   libxsmm_target_archid = LIBXSMM_X86_GENERIC;   // what the reference reports for LIBXSMM_TARGET=generic: below SPR (callers must not hoist AMX tile
                                                  // config) and the id its drivers test for when they pick plain-C gold code
-  vlog(1, "initialised: %d HIP device(s), target gfx950", n);
+  vlog(1, "initialised: %d HIP device(s), target gfx950, %s handles", n, g_thunk_pool ? "thunk-pool" : "static-trampoline");
   libxsmm_ninit = 2;
 }
 
+// Releases everything the registry owns (dispatched kernels, equation kernels, retired staging blocks) and returns the library to its
+// un-initialised state: a later dispatch re-initialises, as the reference's init/finalize cycles do [ref: src/libxsmm_main.c:1503-1640].
+// Caller-owned kernels (create_*) stay valid until libxsmm_release_kernel.  Every thread's dispatch cache is invalidated by the generation.
 LIBXSMM_API void libxsmm_finalize(void) {
   std::lock_guard<std::mutex> guard(g_lock);
   if (libxsmm_ninit < 2) return;
-  (void)hipDeviceSynchronize();
-  if (libxsmm_verbosity != 0) std::fprintf(stderr, "LIBXSMM-AMD: registry holds %zu kernels at exit\n", g_registry.size());
+  if (g_device_count > 0) (void)hipDeviceSynchronize();
+  if (libxsmm_verbosity != 0) std::fprintf(stderr, "LIBXSMM-AMD: registry holds %zu kernels at exit\n", g_registry.size() + g_meqn_ctxs.size());
   for (auto& kv : g_registry) free_ctx_locked(kv.second);
   g_registry.clear();
+  for (KernelCtx* c : g_meqn_ctxs) free_ctx_locked(c);
+  g_meqn_ctxs.clear();
+  free_meqn_equations();
   { std::lock_guard<std::mutex> g2(g_retired_lock); for (void* p : g_retired) (void)hipFree(p); g_retired.clear(); }
+  g_generation.fetch_add(1, std::memory_order_release);
+  libxsmm_ninit = 0;
 }
 
 LIBXSMM_API int libxsmm_get_target_archid(void) { return libxsmm_target_archid; }
-LIBXSMM_API void libxsmm_set_target_archid(int id) { (void)id; }
+// There is one code path (gfx950); the id callers can observe stays at or below X86_GENERIC so that they never hoist AMX tile
+// configuration [ref: samples/xgemm/gemm_kernel.c:3813-3824].  Requests are clamped like the reference clamps to the CPUID level
+// [ref: src/libxsmm_main.c:1770-1800] and a request for something else is said out loud at LIBXSMM_VERBOSE >= 1.
+LIBXSMM_API void libxsmm_set_target_archid(int id) {
+  if (id > LIBXSMM_X86_GENERIC) { vlog(1, "libxsmm_set_target_archid(%d): this backend only runs gfx950 kernels; id stays %d (generic)", id, (int)LIBXSMM_X86_GENERIC); id = LIBXSMM_X86_GENERIC; }
+  if (id < LIBXSMM_TARGET_ARCH_GENERIC) id = LIBXSMM_TARGET_ARCH_GENERIC;
+  libxsmm_target_archid = id;
+}
 LIBXSMM_API const char* libxsmm_get_target_arch(void) { return "gfx950"; }
-LIBXSMM_API void libxsmm_set_target_arch(const char* arch) { (void)arch; }
+LIBXSMM_API void libxsmm_set_target_arch(const char* arch) {
+  if (!arch) return;
+  if (std::strcmp(arch, "gfx950") != 0 && std::strcmp(arch, "generic") != 0 && std::strcmp(arch, "0") != 0)
+    vlog(1, "libxsmm_set_target_arch(\"%s\"): ignored, kernels are built for gfx950 only", arch);
+  if (std::strcmp(arch, "0") == 0) libxsmm_target_archid = LIBXSMM_TARGET_ARCH_GENERIC; else libxsmm_target_archid = LIBXSMM_X86_GENERIC;
+}
 LIBXSMM_API const char* libxsmm_get_typename(libxsmm_datatype t) { return ((int)t >= 0 && t < LIBXSMM_DATATYPE_COUNT_) ? kTypeNames[t] : "void"; }
 LIBXSMM_API unsigned char libxsmm_typesize(libxsmm_datatype t) { return (unsigned char)typesize((int)t); }
 LIBXSMM_API int libxsmm_get_verbosity(void) { return libxsmm_verbosity; }
@@ -816,17 +922,37 @@ LIBXSMM_API libxsmm_meltw_descriptor* libxsmm_meltw_descriptor_init(libxsmm_desc
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------
-static const void* find_or_build(Kind kind, const void* desc, size_t size) {
-  // thread-local last-hit cache in front of the locked registry [ref: libxsmm_main.c:2739-2763]
-  struct Last { std::string key; const void* fn = nullptr; };
-  thread_local Last last[4]; thread_local unsigned int rr = 0;
-  const std::string key = make_key(kind, desc, size);
-  for (auto& l : last) if (l.fn && l.key == key) return l.fn;
+}  // extern "C" (the dispatch cache below is C++)
+
+// Thread-local dispatch cache in front of the locked registry [ref: libxsmm_main.c:2739-2763, 16 entries like LIBXSMM_CACHE_MAXSIZE].
+// The hit path touches no heap and takes no lock: build the fixed-size key, hash it, compare one direct-mapped entry.
+struct DispatchCacheEntry { RegKey key; const void* fn; unsigned int generation; };
+static inline void make_key(RegKey& key, Kind kind, const void* desc, size_t size) {
+  std::memset(key.w, 0, sizeof(key.w));
+  key.w[0] = (unsigned long long)kind;
+  std::memcpy(&key.w[1], desc, std::min(size, (size_t)LIBXSMM_DESCRIPTOR_MAXSIZE));
+}
+static inline const void* cache_lookup(const RegKey& key, unsigned long long h, DispatchCacheEntry*& entry) {
+  thread_local DispatchCacheEntry cache[16];
+  entry = &cache[h & 15u];
+  if (entry->fn && entry->generation == g_generation.load(std::memory_order_acquire) && entry->key == key) return entry->fn;
+  return nullptr;
+}
+static const char* meltw_label(const libxsmm_meltw_descriptor& e);
+// `supported`: evaluated on a miss only -- a cached descriptor has passed it before
+template <typename Supported>
+static const void* find_or_build(Kind kind, const void* desc, size_t size, Supported&& supported) {
+  RegKey key; make_key(key, kind, desc, size);
+  const unsigned long long h = hash_key(key);
+  DispatchCacheEntry* entry = nullptr;
+  if (const void* hit = cache_lookup(key, h, entry)) return hit;
+  if (!supported()) return nullptr;
   std::lock_guard<std::mutex> guard(g_lock);
   auto it = g_registry.find(key);
   KernelCtx* c = nullptr;
   if (it != g_registry.end()) c = it->second;
   else {
+    if ((int)g_registry.size() >= g_registered_limit) { vlog(1, "registry is full (%d kernels)", g_registered_limit); return nullptr; }
     c = new_ctx_locked(kind);
     if (!c) return nullptr;
     c->registered = true;
@@ -837,23 +963,40 @@ static const void* find_or_build(Kind kind, const void* desc, size_t size) {
     } else {
       std::memcpy(&c->e, desc, sizeof(c->e));
       c->nflops = c->e.m * c->e.n;
-      c->kname_single = c->kname_batched = "meltw";
+      c->kname_single = c->kname_batched = meltw_label(c->e);     // replaced by the device kernel's name at the first launch
     }
     g_registry.emplace(key, c);
     vlog(2, "built kernel #%d kind=%d", c->slot, (int)kind);
   }
   const void* fn = handle_for_slot(c->slot);
-  Last& l = last[rr++ & 3]; l.key = key; l.fn = fn;
+  entry->key = key; entry->fn = fn; entry->generation = g_generation.load(std::memory_order_acquire);
   return fn;
 }
+// TPP handles are told apart before their first launch by operation and type: "meltw_unary#RELU" is not available without the
+// enum's names, so the label carries the numeric type as the reference's own kernel names do [ref: src/libxsmm_main.c:2420-2440].
+static const char* meltw_label(const libxsmm_meltw_descriptor& e) {
+  static std::mutex lock; static std::unordered_map<unsigned int, std::string> names;
+  const unsigned int id = ((unsigned int)e.operation << 16) | e.param;
+  std::lock_guard<std::mutex> guard(lock);
+  auto it = names.find(id);
+  if (it == names.end()) {
+    const char* op = e.operation == LIBXSMM_MELTW_OPERATION_UNARY ? "unary" : e.operation == LIBXSMM_MELTW_OPERATION_BINARY ? "binary" : "ternary";
+    it = names.emplace(id, std::string("meltw_") + op + "_type" + std::to_string((int)e.param)).first;
+  }
+  return it->second.c_str();    // node-based map: the string never moves
+}
+
+extern "C" {
 
 LIBXSMM_API libxsmm_xmmfunction libxsmm_xmmdispatch(const libxsmm_gemm_descriptor* d) {
   libxsmm_xmmfunction r; r.ptr_const = nullptr;
   if (!d || !runtime_ready()) return r;
   const bool a = (d->flags & LIBXSMM_GEMM_FLAG_NO_RESET_TILECONFIG) != 0, b = (d->flags & LIBXSMM_GEMM_FLAG_NO_SETUP_TILECONFIG) != 0;
-  if (a != b) { r.ptr_const = find_or_build(K_TILECFG, d, sizeof(*d)); return r; }
-  if (!gemm_supported(*d)) { vlog(1, "unsupported GEMM descriptor (types %s/%s/%s, flags 0x%x)", kTypeNames[d->a_type], kTypeNames[d->b_type], kTypeNames[d->c_type], d->flags); return r; }
-  r.ptr_const = find_or_build(K_GEMM, d, sizeof(*d));
+  if (a != b) { r.ptr_const = find_or_build(K_TILECFG, d, sizeof(*d), []() { return true; }); return r; }
+  r.ptr_const = find_or_build(K_GEMM, d, sizeof(*d), [d]() {
+    if (gemm_supported(*d)) return true;
+    vlog(1, "unsupported GEMM descriptor (types %s/%s/%s, flags 0x%x)", kTypeNames[d->a_type], kTypeNames[d->b_type], kTypeNames[d->c_type], d->flags);
+    return false; });
   return r;
 }
 LIBXSMM_API libxsmm_gemmfunction libxsmm_dispatch_gemm(libxsmm_gemm_shape s, libxsmm_bitfield flags, libxsmm_bitfield prefetch) {
@@ -885,15 +1028,17 @@ LIBXSMM_API libxsmm_tilecfgfunction libxsmm_dispatch_tilecfg_gemm(libxsmm_gemm_s
   libxsmm_gemm_descriptor* d = libxsmm_gemm_descriptor_init(&blob, s.a_in_type, s.b_in_type, s.comp_type, s.out_type, s.m, s.n, s.k, s.lda, s.ldb, s.ldc,
     (int)(flags | LIBXSMM_GEMM_FLAG_USE_XGEMM_ABI), 0);
   if (!d) return nullptr;
-  libxsmm_xmmfunction r; r.ptr_const = find_or_build(K_TILECFG, d, sizeof(*d));
+  libxsmm_xmmfunction r; r.ptr_const = find_or_build(K_TILECFG, d, sizeof(*d), []() { return true; });
   return r.tilecfg;
 }
 
 LIBXSMM_API libxsmm_xmeltwfunction libxsmm_dispatch_meltw(const libxsmm_meltw_descriptor* d) {
   libxsmm_xmeltwfunction r; r.xmeltw = nullptr;
   if (!d || !runtime_ready()) return r;
-  if (!meltw_supported(*d)) { vlog(1, "unsupported TPP (operation %d, type %d, in %s, out %s)", d->operation, d->param, kTypeNames[d->in0_type], kTypeNames[d->out_type]); return r; }
-  r.xmeltw = (void (*)(const void*))find_or_build(K_MELTW, d, sizeof(*d));
+  r.xmeltw = (void (*)(const void*))find_or_build(K_MELTW, d, sizeof(*d), [d]() {
+    if (meltw_supported(*d)) return true;
+    vlog(1, "unsupported TPP (operation %d, type %d, in %s, out %s)", d->operation, d->param, kTypeNames[d->in0_type], kTypeNames[d->out_type]);
+    return false; });
   return r;
 }
 LIBXSMM_API libxsmm_meltwfunction_unary libxsmm_dispatch_meltw_unary(libxsmm_meltw_unary_type t, libxsmm_meltw_unary_shape s, libxsmm_bitfield f) {
@@ -1159,7 +1304,7 @@ LIBXSMM_API int libxsmm_get_registry_info(libxsmm_registry_info* info) {
   if (!info) return EXIT_FAILURE;
   std::lock_guard<std::mutex> guard(g_lock);
   std::memset(info, 0, sizeof(*info));
-  info->capacity = kSlots; info->size = g_registry.size(); info->nbytes = g_registry.size() * sizeof(KernelCtx);
+  info->capacity = (size_t)g_registered_limit; info->size = g_registry.size(); info->nbytes = g_registry.size() * sizeof(KernelCtx);
   return EXIT_SUCCESS;
 }
 
