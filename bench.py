@@ -1,31 +1,33 @@
 #!/usr/bin/env python
-"""bench.py -- the headline metric of BASELINE.json on MI355X.
+"""bench.py -- the headline metric of BASELINE.json on MI355X, plus the sweep the metric names.
 
-Workload (BASELINE.json configs[1]): strided BRGEMM, fp32, m=n=k=32, batch=4096 -- 4096 independent
-(A_i, B_i, C_i) problems (the data-parallel batch axis of north_star) launched through ONE
-libxsmm_dispatch_brgemm(STRIDE) handle with libxsmm_hip_gemm_batch_strided; every problem reduces
-`--br` consecutive (A, B) pairs (default 1).  One "step" = one such launch over one batch.
+Headline (the `value`): BASELINE.json configs[1] -- strided BRGEMM, fp32, m=n=k=32, batch=4096 independent
+(A_i, B_i, C_i) problems launched through ONE libxsmm_dispatch_brgemm(STRIDE) handle with
+libxsmm_hip_gemm_batch_strided.  One "step" = one such launch over one batch.
 
-Honest-roofline details:
-  * inputs are resident in HBM before the timed region; the timed loop ROTATES over enough distinct
-    input sets (default: > 2x the 256 MiB Infinity Cache) that every step streams from HBM and not
-    from L3.  The L3-resident rate (same set every step) is reported separately as `l3_resident`.
-  * the K steps of the timed region are captured once into a hipGraph (K kernel nodes, one per step) and
-    replayed between the two barrier+synchronize pairs: the GPU sees K back-to-back launches and the Python
-    interpreter is out of the loop.
-  * roofline.achieved = algorithmic bytes per launch (br*(m*k*sA + k*n*sB) + m*n*sC*(1+[beta=1])
-    per problem, times the batch) / mean launch duration = HIP-event time of the timed region (events recorded
-    on the launch stream) / K.  It therefore includes the inter-kernel boundary and is a lower bound of what
-    rocprofv3's per-kernel duration gives.
-  * cpu_baseline: the reference's own JIT kernel (oracle/_ref, kind "reference") or, if that library is not
-    present, the C restatement (kind "port"), single thread, on a bounded sample of the same workload.
+What the one JSON line carries (all measured in this process, on this GPU):
+  * value / ms_per_step: the timed region is a hipGraph of back-to-back launches (a multiple of --steps), replayed until
+    it lasts >= --min-seconds (0.5 s): `steps` echoes the flag, `steps_timed` is what was really timed.  Inputs are
+    resident in HBM and ROTATE over enough distinct sets (> 2x the 256 MiB Infinity Cache) that every step streams from HBM.
+  * roofline: algorithmic bytes (br*(m*k*sA + k*n*sB) + m*n*sC*(1+[beta=1]) per problem) / HIP-event time per launch.
+    `traffic` = TCC-counter bytes per launch from the committed PMC pass of this same command (profiles/), null if none.
+  * verified: after the timed region a strided sample of C is compared with the oracle (oracle/liboracle.so) on the same inputs.
+  * sweep: m in {16,32,64} x {f32,bf16}, streaming regime, at batch 4096 and 65536: GFLOP/s, frac of HBM roofline, % of MFMA peak.
+  * reuse: the operand-reuse regimes -- B shared by the whole batch (stride_b = 0) and a blocked GEMM built from BRGEMM tiles
+    (2-D batch, chain br = K/m, operands cache-resident): the only regime in which a percentage of MFMA peak is the binding roofline.
+  * mfma_busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMDs) per workload from the committed PMC pass (profiles/), null if none.
+  * cpu_baseline: the reference's own JIT kernel (oracle/_ref, kind "reference") or the C restatement (kind "port") on this box's host cores.
 
-N > 1 (launched by torch.distributed.run): one process per GPU, every rank owns its own batch (weak scaling,
-no data-path collective); time = max over ranks between two barriers; value = total flops / time.
+N > 1 (launched by torch.distributed.run): one process per GPU, every rank owns its own batch (weak scaling, no data-path
+collective); time = max over ranks between two barriers; value = total flops / time.
+`--config 5`: BASELINE configs[4] instead -- 2^20 bf16 64^3 problems with fused column-bias + ReLU, split over the ranks with
+libxsmm_hip_shard_range (strong scaling), compute leg and (with --gather) the result gather to rank 0 timed separately.
 """
 import argparse
 import ctypes as C
+import glob
 import json
+import math
 import os
 import sys
 import time
@@ -41,6 +43,7 @@ from libxsmm_amd.capi import DT, GEMM_FLAG  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0}
+L3_BYTES = 256 * 2 ** 20
 
 
 def parse():
@@ -48,134 +51,239 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5], help="BASELINE config: 2 = f32 32^3 batch 4096 (headline), 5 = bf16 64^3 fused, 2^20 problems sharded")
     ap.add_argument("--m", type=int, default=32, help="m = n = k")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--br", type=int, default=1, help="batch-reduce count of every problem")
     ap.add_argument("--beta", type=int, default=0, choices=[0, 1])
-    ap.add_argument("--fused", type=int, default=0, help="1: bf16 column-bias + ReLU epilogue (config #5)")
+    ap.add_argument("--fused", type=int, default=0, help="1: bf16 column-bias + ReLU epilogue")
     ap.add_argument("--sets", type=int, default=0, help="distinct input sets to rotate over (0: auto, > 2x L3)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of the timed region")
+    ap.add_argument("--total", type=int, default=1 << 20, help="--config 5: problems over all ranks")
+    ap.add_argument("--gather", action="store_true", help="--config 5: also time the gather of C to rank 0 (RCCL)")
+    ap.add_argument("--no-sweep", action="store_true", help="headline only (profiling passes)")
+    ap.add_argument("--no-l3", action="store_true", help="skip the Infinity-Cache-resident secondary leg")
+    ap.add_argument("--eager", action="store_true", help="plain launches instead of hipGraph replays in the timed regions (counter-collection passes)")
+    ap.add_argument("--manifest", default="", help="write the execution order of the launches (label, kernel, counts) to this JSON file")
+    ap.add_argument("--only", default="", help="measure only this sweep/reuse entry (profiling passes), e.g. reuse:f32_m32_blocked")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the all-core CPU leg (-1: one per physical core, 0/1: skip)")
+    ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the all-core CPU leg (-1: one per usable core, 0/1: skip)")
     return ap.parse_args()
 
 
+def gen_values(n, bf16, dev, gen):
+    """Reference-style data [samples/xgemm/gemm_kernel.c:837-865]: multiples of 0.1 in [-0.4, 0.5]; bf16 by truncation."""
+    out = torch.empty(n, dtype=torch.int16 if bf16 else torch.float32, device=dev)
+    step = 1 << 26
+    for o in range(0, n, step):
+        c = min(step, n - o)
+        v = torch.randint(-4, 6, (c,), generator=gen, device=dev, dtype=torch.int32).float() / 10
+        out[o:o + c] = (v.view(torch.int32) >> 16).to(torch.int16) if bf16 else v
+    return out
+
+
 class Workload:
-    def __init__(self, args, dev):
-        self.args = args
-        m, br, batch = args.m, args.br, args.batch
-        self.bf16 = args.dtype == "bf16"
+    """mode 'stream': `batch` independent problems, each with its own A/B chain of `br` blocks and its own C.
+    mode 'shared_b': the same, but one B chain shared by the whole batch (stride_b = 0).
+    mode 'blocked': a blocked GEMM -- grid (ni, nj) of C tiles, C(i,j) = sum_r A(i,r) B(r,j), one 2-D batched launch."""
+
+    def __init__(self, api, dev, dtype="f32", m=32, batch=4096, br=1, beta=0, fused=0, mode="stream", grid=None, nsets=0, seed=555):
+        self.api, self.dev, self.dtype, self.m, self.br, self.beta, self.fused, self.mode = api, dev, dtype, m, br, beta, fused, mode
+        self.bf16 = dtype == "bf16"
         es = 2 if self.bf16 else 4
         self.es = es
-        tdt = torch.int16 if self.bf16 else torch.float32
-        self.a_bytes = m * m * es
-        self.flops_per_step = 2.0 * m * m * m * br * batch
-        self.alg_bytes_per_step = float(batch) * (br * 2 * self.a_bytes + m * m * es * (1 + args.beta)) + (m * es if args.fused else 0)
-        set_bytes = batch * (2 * br + 1) * self.a_bytes
-        self.nsets = args.sets if args.sets > 0 else max(2, int(np.ceil(2.2 * 256 * 2 ** 20 / set_bytes)))
-        g = torch.Generator(device="cpu").manual_seed(555)
-
-        def values(n):   # reference-style data: multiples of 0.1 in [-0.4, 0.5]; bf16 by truncation
-            v = torch.randint(-4, 6, (n,), generator=g).float() / 10
-            if self.bf16:
-                return (v.view(torch.int32) >> 16).to(torch.int16)
-            return v
-        n_ab = batch * br * m * m
-        self.A = [values(n_ab).to(dev) for _ in range(self.nsets)]
-        self.B = [values(n_ab).to(dev) for _ in range(self.nsets)]
-        self.C = [torch.zeros(batch * m * m, dtype=tdt, device=dev) for _ in range(self.nsets)]
-        self.D = values(m).to(dev) if args.fused else None
-        api = capi.load()
-        self.api = api
-        t = DT.BF16 if self.bf16 else DT.F32
-        flags = (0 if args.beta else GEMM_FLAG.BETA_0) | (GEMM_FLAG.VNNI_A if self.bf16 else 0)
-        shape = capi.gemm_shape(m, m, m, m, m, m, t, t, t, DT.F32)
-        cfg = capi.br_config(capi.BR_STRIDE, self.a_bytes, self.a_bytes, 0)
-        self.shape, self.flags, self.cfg = shape, flags, cfg
-        if args.fused:
-            self.handle = api.dispatch_brgemm_ext(shape, flags, 0, cfg, capi.argops_cp(m, capi.UNARY.RELU, 0), capi.postops_colbias(m, t))
+        blk = m * m * es
+        self.blk = blk
+        if mode == "blocked":
+            self.ni, self.nj = grid
+            batch = self.ni * self.nj
+            na, nb = self.ni * br, self.nj * br
         else:
-            self.handle = api.dispatch_brgemm(shape, flags, 0, cfg)
+            na, nb = batch * br, (br if mode == "shared_b" else batch * br)
+        self.batch = batch
+        self.flops_per_step = 2.0 * m * m * m * br * batch
+        self.alg_bytes_per_step = float(na + nb) * blk + float(batch) * blk * (1 + beta) + (m * es if fused else 0)
+        set_bytes = (na + nb + batch) * blk
+        if nsets <= 0:
+            nsets = 1 if mode == "blocked" else max(2, int(math.ceil(2.2 * L3_BYTES / set_bytes)))
+        self.nsets = nsets
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        tdt = torch.int16 if self.bf16 else torch.float32
+        self.A = [gen_values(na * m * m, self.bf16, dev, gen) for _ in range(nsets)]
+        self.B = [gen_values(nb * m * m, self.bf16, dev, gen) for _ in range(nsets)]
+        self.C = [torch.zeros(batch * m * m, dtype=tdt, device=dev) for _ in range(nsets)]
+        self.D = gen_values(m, self.bf16, dev, gen) if fused else None
+        t = DT.BF16 if self.bf16 else DT.F32
+        self.t = t
+        self.flags = (0 if beta else GEMM_FLAG.BETA_0) | (GEMM_FLAG.VNNI_A if self.bf16 else 0)
+        self.shape = capi.gemm_shape(m, m, m, m, m, m, t, t, t, DT.F32)
+        self.cfg = capi.br_config(capi.BR_STRIDE, blk, blk, 0)
+        if fused:
+            self.handle = api.dispatch_brgemm_ext(self.shape, self.flags, 0, self.cfg, capi.argops_cp(m, capi.UNARY.RELU, 0), capi.postops_colbias(m, t))
+        else:
+            self.handle = api.dispatch_brgemm(self.shape, self.flags, 0, self.cfg)
         if not self.handle:
             raise RuntimeError("dispatch returned NULL")
         self.brc = C.c_ulonglong(br)
         self.params = []
-        for s in range(self.nsets):
-            p = capi.GemmExtParam() if args.fused else capi.GemmParam()
+        for s in range(nsets):
+            p = capi.GemmExtParam() if fused else capi.GemmParam()
             p.a.primary, p.b.primary, p.c.primary = self.A[s].data_ptr(), self.B[s].data_ptr(), self.C[s].data_ptr()
             p.op.tertiary = C.addressof(self.brc)
-            if args.fused:
+            if fused:
                 p.d.primary = self.D.data_ptr()
             self.params.append(p)
-        self.sa = br * self.a_bytes
-        self.sc = m * m * es
-        self.kernel = api.hip_kernel_name(self.handle, 1).decode()
+        self.sa = br * blk
+        self.sb = 0 if mode == "shared_b" else br * blk
+        self.sc = blk
 
     def step(self, s):
         p = self.params[s % self.nsets]
-        if self.args.fused:
-            self.api.hip_gemm_ext_batch_strided(self.handle, C.byref(p), self.args.batch, self.sa, self.sa, self.sc, 0, 0)
+        if self.mode == "blocked":
+            self.api.hip_gemm_batch_strided_2d(self.handle, C.byref(p), self.ni, self.nj, self.sa, self.sb, self.sc, self.ni * self.sc)
+        elif self.fused:
+            self.api.hip_gemm_ext_batch_strided(self.handle, C.byref(p), self.batch, self.sa, self.sb, self.sc, 0, 0)
         else:
-            self.api.hip_gemm_batch_strided(self.handle, C.byref(p), self.args.batch, self.sa, self.sa, self.sc)
+            self.api.hip_gemm_batch_strided(self.handle, C.byref(p), self.batch, self.sa, self.sb, self.sc)
+
+    def kernel(self):
+        return self.api.hip_kernel_name(self.handle, 1).decode()
+
+    def label(self):
+        return f"{self.dtype}_m{self.m}_" + (f"b{self.batch}" if self.mode == "stream" else (f"sharedB_b{self.batch}" if self.mode == "shared_b" else "blocked"))
+
+    # ---- the oracle as the checker: a strided sample of the batch, same inputs -----------------------------------
+    def verify(self, s=0, samples=32):
+        from oracle import pyoracle
+        orc = pyoracle.oracle()
+        m, br, mm = self.m, self.br, self.m * self.m
+        npdt = np.uint16 if self.bf16 else np.float32
+        idx = sorted(set(int(x) for x in np.linspace(0, self.batch - 1, samples)))
+        A, B, Cg = self.A[s], self.B[s], self.C[s]
+        flags = self.flags | GEMM_FLAG.BATCH_REDUCE_STRIDE | (GEMM_FLAG.USE_XGEMM_EXT_ABI if self.fused else GEMM_FLAG.USE_XGEMM_ABI)
+        desc = pyoracle.GemmDesc(m, m, m, m, m, m, self.t, self.t, self.t, DT.F32, flags, self.blk, self.blk, 1 if self.fused else 0, 1 if self.fused else 0)
+        d_host = self.D.cpu().numpy().view(npdt) if self.fused else None
+        worst = 0.0
+        for e in idx:
+            ia, ib = (e % self.ni, e // self.ni) if self.mode == "blocked" else (e, 0 if self.mode == "shared_b" else e)
+            a = A[ia * br * mm:(ia + 1) * br * mm].cpu().numpy().view(npdt).copy()
+            b = B[ib * br * mm:(ib + 1) * br * mm].cpu().numpy().view(npdt).copy()
+            got = Cg[e * mm:(e + 1) * mm].cpu().numpy().view(npdt)
+            ref = np.zeros(mm, dtype=npdt)          # beta = 1 accumulates over the steps: only beta = 0 workloads are verified
+            p = capi.GemmExtParam() if self.fused else capi.GemmParam()
+            brc = C.c_ulonglong(br)
+            p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = a.ctypes.data, b.ctypes.data, ref.ctypes.data, C.addressof(brc)
+            if self.fused:
+                p.d.primary = d_host.ctypes.data
+            orc.gemm(p, desc)
+            if self.bf16:
+                r = (ref.astype(np.uint32) << 16).view(np.float32).astype(np.float64); g = (got.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+            else:
+                r = ref.astype(np.float64); g = got.astype(np.float64)
+            den = float(np.sum(r * r)); num = float(np.sum((r - g) ** 2))
+            worst = max(worst, math.sqrt(num / den) if den > 0 else math.sqrt(num))
+        tol = 5e-3 if self.bf16 else 1.2e-5          # the reference driver's own bounds [samples/xgemm/gemm_kernel.c:5312-5414]
+        return worst < tol, worst, len(idx)
 
 
-def capture(work, steps, rotate):
-    """Capture `steps` launches (one per step) into a hipGraph on a side stream; the timed region replays it,
-    so the measurement sees K back-to-back kernel launches instead of K trips through the Python interpreter."""
+def capture(work, launches):
+    """`launches` back-to-back steps (rotating over the input sets) in one hipGraph, captured on a side stream."""
     api = work.api
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         api.hip_set_stream(side.cuda_stream)
-        for i in range(3):                      # warm the capture stream
-            work.step(i if rotate else 0)
+        for i in range(2):
+            work.step(i)
         side.synchronize()
         g.capture_begin()
-        for i in range(steps):
-            work.step(i if rotate else 0)
+        for i in range(launches):
+            work.step(i)
         g.capture_end()
     torch.cuda.current_stream().wait_stream(side)
     api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
     return g
 
 
-def timed(work, steps, barrier, rotate=True):
-    """Exactly `steps` steps between two (barrier + synchronize) pairs.  Returns (wall seconds, mean
-    microseconds per launch from HIP events recorded on the launch stream around the region).
-    The steps are replayed from hipGraphs of at most 500 launches (a full chunk graph + a remainder graph)."""
-    chunk = min(steps, 500)
-    full, rem = divmod(steps, chunk)
-    g_full = capture(work, chunk, rotate)
-    g_rem = capture(work, rem, rotate) if rem else None
-    g_full.replay()                               # untimed: first replay uploads the graph
-    if g_rem is not None:
-        g_rem.replay()
-    torch.cuda.synchronize()
+def estimate_step_seconds(work, n=8):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    for i in range(3):
+        work.step(i)
     e0.record()
-    for _ in range(full):
-        g_full.replay()
-    if g_rem is not None:
-        g_rem.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()                      # this rank's K steps are complete here; MAX over ranks is taken by the caller
-    barrier()
-    return t1 - t0, e0.elapsed_time(e1) * 1e3 / steps
+    for i in range(n):
+        work.step(i)
+    e1.record(); torch.cuda.synchronize()
+    return max(e0.elapsed_time(e1) * 1e-3 / n, 1e-6)
 
 
-def eager_kernel_us(work, steps, rotate=True):
-    """Secondary view: every launch bracketed by its own event pair, issued eagerly from Python."""
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    for i in range(steps):
-        evs[i][0].record(); work.step(i if rotate else 0); evs[i][1].record()
-    torch.cuda.synchronize()
-    return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e3
+EAGER = False
+MANIFEST = []      # execution order of the library launches, for tools/summarize_profiles.py (splits a kernel trace by workload)
+
+
+def timed(work, steps, min_seconds, barrier=lambda: None, label=None):
+    """A graph of G launches (G = a multiple of `steps` and of the rotation length) replayed R times so that the region lasts
+    >= min_seconds, between two (barrier + synchronize) pairs.  Returns (wall seconds, launches timed, us per launch from HIP
+    events recorded on the launch stream)."""
+    t_step = estimate_step_seconds(work)
+    unit = steps * work.nsets // math.gcd(steps, work.nsets)
+    per_graph = unit * max(1, min(int(0.02 / t_step) // unit, max(1, 2000 // unit)))
+    while per_graph > 4000 and per_graph > steps:       # very long rotations: keep the graph bounded
+        per_graph //= 2
+    per_graph = max(per_graph, 1)
+    replays = max(1, int(math.ceil(min_seconds / (per_graph * t_step))))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if EAGER:
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(per_graph * replays):
+            work.step(i)
+        e1.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        n = per_graph * replays
+        executed = int(work.api.hip_launch_count(1))
+    else:
+        g = capture(work, per_graph)
+        g.replay(); torch.cuda.synchronize()              # untimed: the first replay uploads the graph
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(replays):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        n = per_graph * replays
+        # launches the GPU executed for this workload since the last manifest entry: the eager ones + the first (untimed) replay + the
+        # timed replays; the capture itself went through the launch counter once without executing
+        executed = int(work.api.hip_launch_count(1)) + n
+    MANIFEST.append({"label": label or work.label(), "kernel": work.kernel(), "launches_executed": executed, "launches_timed": n,
+                     "algorithmic_bytes_per_launch": int(work.alg_bytes_per_step), "flops_per_launch": work.flops_per_step, "dtype": work.dtype,
+                     "us_per_launch_events": e0.elapsed_time(e1) * 1e3 / n})
+    return t1 - t0, n, e0.elapsed_time(e1) * 1e3 / n
+
+
+def entry(work, steps, min_seconds, verify=True):
+    """One sweep / reuse line."""
+    for i in range(3):
+        work.step(i)
+    torch.cuda.synchronize(); work.api.check()
+    wall, n, us = timed(work, steps, min_seconds)
+    work.api.check()
+    tf = work.flops_per_step / (us * 1e-6) / 1e12
+    gbs = work.alg_bytes_per_step / (us * 1e-6) / 1e9
+    out = {"kernel": work.kernel(), "us_per_launch": round(us, 3), "GFLOP/s": round(tf * 1e3, 1), "GB/s": round(gbs, 1),
+           "frac_hbm": round(gbs / HBM_PEAK_GBS, 4), "pct_mfma_peak": round(100.0 * tf / MFMA_PEAK_TF[work.dtype], 2), "launches_timed": n}
+    if verify:
+        ok, err, cnt = work.verify(0)
+        out["verified"] = bool(ok); out["normf_rel"] = float(f"{err:.3g}")
+    return out
 
 
 def usable_cpus():
@@ -195,53 +303,63 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(args, seconds):
-    """Reference JIT (or C restatement) on this box's host cores, single thread, bounded sample."""
+def cpu_baseline(m, dtype, br, beta, fused, seconds, nthreads):
+    """Reference JIT (or C restatement) on this box's host cores: one thread, and every usable core at once; bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import pyoracle
-    m, br = args.m, args.br
-    bf16 = args.dtype == "bf16"
+    bf16 = dtype == "bf16"
     es = 2 if bf16 else 4
     t = DT.BF16 if bf16 else DT.F32
-    batch = min(args.batch, 1024)                       # private operands, streamed like the GPU run
+    batch = 1024                                        # private operands, streamed like the GPU run
     rng = np.random.default_rng(555)
     raw = ((np.floor(rng.random(batch * br * m * m * 2) * 10) - 4) / 10).astype(np.float32)
     ab = (raw.view(np.uint32) >> 16).astype(np.uint16) if bf16 else raw
     A, B = ab[: batch * br * m * m].copy(), ab[batch * br * m * m:].copy()
     Cc = np.zeros(batch * m * m, dtype=np.uint16 if bf16 else np.float32)
-    flags = (0 if args.beta else GEMM_FLAG.BETA_0) | (GEMM_FLAG.VNNI_A if bf16 else 0)
+    Dd = ab[:m].copy()
+    flags = (0 if beta else GEMM_FLAG.BETA_0) | (GEMM_FLAG.VNNI_A if bf16 else 0)
     shape = capi.gemm_shape(m, m, m, m, m, m, t, t, t, DT.F32)
     cfg = capi.br_config(capi.BR_STRIDE, m * m * es, m * m * es, 0)
     brc = C.c_ulonglong(br)
-    p = capi.GemmParam()
-    p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = A.ctypes.data, B.ctypes.data, Cc.ctypes.data, C.addressof(brc)
+    ptype = capi.GemmExtParam if fused else capi.GemmParam
+
+    def make_param(a_, b_, c_):
+        q = ptype()
+        q.a.primary, q.b.primary, q.c.primary, q.op.tertiary = a_.ctypes.data, b_.ctypes.data, c_.ctypes.data, C.addressof(brc)
+        if fused:
+            q.d.primary = Dd.ctypes.data
+        return q
+    p = make_param(A, B, Cc)
     flops = 2.0 * m * m * m * br * batch
     if pyoracle.have_reference():
         ref = pyoracle.reference()
-        h = ref.dispatch_brgemm(shape, flags, 0, cfg)
+        if fused:
+            h = ref.dispatch_brgemm_ext(shape, flags, 0, cfg, capi.argops_cp(m, capi.UNARY.RELU, 0), capi.postops_colbias(m, t))
+            tfn = ref.lib.xref_time_gemm_ext_batch
+        else:
+            h = ref.dispatch_brgemm(shape, flags, 0, cfg)
+            tfn = ref.lib.xref_time_gemm_batch
         if h:
             sa, sc = br * m * m * es, m * m * es
-            t1 = ref.lib.xref_time_gemm_batch(h, C.byref(p), batch, sa, sa, sc, 5)
+            t1 = tfn(h, C.byref(p), batch, sa, sa, sc, 5)
             reps = max(5, int(seconds / max(t1 / 5, 1e-9)))
-            dt = ref.lib.xref_time_gemm_batch(h, C.byref(p), batch, sa, sa, sc, reps)
+            dt = tfn(h, C.byref(p), batch, sa, sa, sc, reps)
             out = {"value": round(flops * reps / dt / 1e9, 2), "unit": "GFLOP/s", "cores": 1, "kind": "reference",
                    "sample": f"reference JIT ({ref.lib.xref_get_target_arch().decode()}) kernel, {batch} problems x {reps} reps, private operands, 1 thread, {dt:.1f} s"}
-            # the same kernel on every physical core at once (one thread per core, private operands): the caller's OpenMP loop of the
+            # the same kernel on every usable core at once (one thread per core, private operands): the caller's OpenMP loop of the
             # reference [samples/xgemm/gemm_kernel.c:4063-4066]; ctypes releases the GIL for the duration of each timing call
-            nthreads = getattr(args, "cpu_threads", 0)
             if nthreads > 1:
                 import threading
                 sets = []
                 for _ in range(nthreads):
                     a_, b_, c_ = A.copy(), B.copy(), Cc.copy()
-                    q = capi.GemmParam()
-                    q.a.primary, q.b.primary, q.c.primary, q.op.tertiary = a_.ctypes.data, b_.ctypes.data, c_.ctypes.data, C.addressof(brc)
-                    sets.append((a_, b_, c_, q))
+                    sets.append((a_, b_, c_, make_param(a_, b_, c_)))
+
                 def run_all(r):
                     times = [0.0] * nthreads
 
                     def work(i):
-                        times[i] = ref.lib.xref_time_gemm_batch(h, C.byref(sets[i][3]), batch, sa, sa, sc, r)
+                        times[i] = tfn(h, C.byref(sets[i][3]), batch, sa, sa, sc, r)
                     ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
                     t0 = time.perf_counter()
                     for th in ths:
@@ -252,7 +370,7 @@ def cpu_baseline(args, seconds):
                 pilot = max(2, reps // 100)                       # bounded whatever the container's CPU quota turns out to be
                 _, wall_p = run_all(pilot)
                 reps_mt = max(pilot, min(reps, int(pilot * 4.0 / max(wall_p, 1e-6))))      # aim at ~4 s of wall clock
-                slowest, wall = run_all(reps_mt)
+                _, wall = run_all(reps_mt)
                 agg = flops * reps_mt * nthreads / wall / 1e9
                 out["all_cores"] = {"value": round(agg, 1), "unit": "GFLOP/s", "cores": nthreads, "speedup_vs_1_thread": round(agg / max(out["value"], 1e-9), 1),
                                     "sample": f"{nthreads} threads (usable CPUs of this container) x {batch} private problems x {reps_mt} reps, wall {wall:.1f} s"}
@@ -268,8 +386,98 @@ def cpu_baseline(args, seconds):
             "sample": f"C restatement (oracle/), 64 problems x {n} reps, 1 thread, {dt:.1f} s"}
 
 
+def committed_counters(kernel, alg_bytes, label):
+    """HBM traffic and MFMA-busy for this workload from the committed PMC passes (rocprofv3 --pmc cannot run inside this process:
+    tools/profile_paths.sh runs THIS command under it in separate passes, tools/summarize_profiles.py distils profiles/)."""
+    traffic = src = busy = busy_src = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            for w in json.load(open(f))["workloads"]:
+                if w["algorithmic_bytes_per_launch"] == int(alg_bytes) and w["kernel"].replace(" ", "") == kernel.replace(" ", ""):
+                    traffic, src = w["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    break
+        except Exception:
+            continue
+        if traffic is not None:
+            break
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_busy.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if label in d.get("workloads", {}):
+                busy, busy_src = d["workloads"], os.path.relpath(f, ROOT)
+                break
+        except Exception:
+            continue
+    return traffic, src, busy, busy_src
+
+
+SWEEP = [(dt, m, b) for dt in ("f32", "bf16") for m in (16, 32, 64) for b in (4096, 65536)]
+# blocked GEMMs: (dtype, m, ni, nj, br) -- 2048^3 out of 16^3 / 32^3 tiles, 4096^3 out of 64^3 tiles
+BLOCKED = [("f32", 16, 128, 128, 128), ("f32", 32, 64, 64, 64), ("f32", 64, 64, 64, 64),
+           ("bf16", 16, 128, 128, 128), ("bf16", 32, 64, 64, 64), ("bf16", 64, 64, 64, 64)]
+SHARED_B = [(dt, m, 65536) for dt in ("f32", "bf16") for m in (16, 32, 64)]
+
+
+def run_config5(args, api, dev, rank, world, dist, barrier):
+    """BASELINE configs[4]: 2^20 bf16 64^3 BRGEMMs with fused column-bias + ReLU, problems split by batch index."""
+    b, e = C.c_size_t(0), C.c_size_t(0)
+    api.hip_shard_range(args.total, 1, world, rank, C.byref(b), C.byref(e))
+    mine = e.value - b.value
+    work = Workload(api, dev, "bf16", 64, mine, br=1, beta=0, fused=1, mode="stream", nsets=1 if mine * 24576 > 2.2 * L3_BYTES else 0, seed=555 + rank)
+    for i in range(max(1, min(args.warmup, 5))):
+        work.step(i)
+    torch.cuda.synchronize(); api.check()
+    elapsed, n, us = timed(work, args.steps, args.min_seconds, barrier)
+    api.check()
+    ok, err, cnt = work.verify(0)
+    gather_ms = None
+    if args.gather and dist is not None:
+        # the only collective of the path: the final result gather (RCCL over xGMI), timed on its own
+        shard = work.C[0]
+        sizes = [0] * world
+        for r in range(world):
+            bb, ee = C.c_size_t(0), C.c_size_t(0)
+            api.hip_shard_range(args.total, 1, world, r, C.byref(bb), C.byref(ee)); sizes[r] = (ee.value - bb.value) * 64 * 64
+        outs = [torch.empty(sz, dtype=shard.dtype, device=dev) for sz in sizes] if rank == 0 else None
+        for _ in range(2):
+            dist.gather(shard, outs, dst=0)
+        torch.cuda.synchronize(); barrier()
+        t0 = time.perf_counter()
+        dist.gather(shard, outs, dst=0)
+        torch.cuda.synchronize(); barrier()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+    if dist is not None:
+        t = torch.tensor([elapsed, float(n), 0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed, bad = float(tmax[0].item()), float(tmax[2].item())
+        tmin = t.clone(); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        n = int(tmin[1].item())            # every rank times the same number of launches unless its estimate differed: count the fewest
+        ok = bad == 0.0
+    if rank != 0:
+        return None
+    flops = 2.0 * 64 ** 3 * args.total * n
+    value = flops / elapsed / 1e9
+    per_gpu_bytes = work.alg_bytes_per_step
+    gbs = per_gpu_bytes / (us * 1e-6) / 1e9
+    out = {"metric": "GFLOP/s, batched stride-BRGEMM m=n=k=64 bf16 + fused colbias+ReLU (BASELINE config 5)", "value": round(value, 1), "unit": "GFLOP/s",
+           "n_gpus": world, "steps": args.steps, "steps_timed": n, "warmup": args.warmup, "ms_per_step": round(elapsed / n * 1e3, 5), "timed_region_s": round(elapsed, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"stride-BRGEMM bf16 m=n=k=64 br=1 beta=0 + column bias + ReLU, {args.total} problems split over {world} rank(s) by libxsmm_hip_shard_range",
+                      "kernel": work.kernel(), "problems_per_gpu_rank0": mine, "parallelism": f"batch-split x{world}, no data-path collective"},
+           "rccl_ranks": world if dist is not None else 0, "verified": bool(ok), "verify_normf_rel": float(f"{err:.3g}"),
+           "pct_mfma_peak": round(100.0 * value / world / 1e3 / MFMA_PEAK_TF["bf16"], 2),
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel_us": round(us, 3), "algorithmic_bytes_per_launch": int(per_gpu_bytes), "note": "rank 0's launch; every rank runs the same shard size +-1"}}
+    if gather_ms is not None:
+        out["gather_ms"] = round(gather_ms, 3)
+        out["gather_GBs_into_root"] = round((args.total - mine) * 8192 / (gather_ms * 1e-3) / 1e9, 1)
+    return out
+
+
 def main():
+    global EAGER
     args = parse()
+    EAGER = args.eager
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -288,66 +496,116 @@ def main():
     api = capi.load()
     api.hip_set_device(local)
     api.hip_set_stream(torch.cuda.current_stream().cuda_stream)      # stream-ordered launches on torch's stream
-    work = Workload(args, dev)
+    nthreads = usable_cpus() if args.cpu_threads < 0 else args.cpu_threads
 
+    if args.config == 5:
+        out = run_config5(args, api, dev, rank, world, dist, barrier)
+        if rank == 0:
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(64, "bf16", 1, 0, 1, args.cpu_seconds, nthreads)
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
+    only = args.only
+    if only:                 # one sweep / reuse entry under a profiler: no headline, no CPU leg
+        kind, label = only.split(":")
+        found = None
+        if kind == "sweep":
+            for dt, m, b in SWEEP:
+                w = (dt, m, b)
+                if f"{dt}_m{m}_b{b}" == label:
+                    found = Workload(api, dev, dt, m, b)
+        else:
+            for dt, m, b in SHARED_B:
+                if f"{dt}_m{m}_sharedB_b{b}" == label:
+                    found = Workload(api, dev, dt, m, b, mode="shared_b")
+            for dt, m, ni, nj, br in BLOCKED:
+                if f"{dt}_m{m}_blocked" == label:
+                    found = Workload(api, dev, dt, m, 0, br=br, mode="blocked", grid=(ni, nj))
+        if found is None:
+            raise SystemExit(f"unknown entry {only}")
+        api.hip_launch_count(1)
+        res = entry(found, args.steps, args.min_seconds)
+        print(json.dumps({"only": only, **res}))
+        if args.manifest:
+            json.dump({"command": " ".join(sys.argv), "entries": MANIFEST}, open(args.manifest, "w"), indent=1)
+        return
+
+    work = Workload(api, dev, args.dtype, args.m, args.batch, br=args.br, beta=args.beta, fused=args.fused, nsets=args.sets)
+    api.hip_launch_count(1)
     for i in range(args.warmup):
         work.step(i)
     torch.cuda.synchronize()
     api.check()
-    elapsed, kernel_us = timed(work, args.steps, barrier, rotate=True)
+    elapsed, n_timed, kernel_us = timed(work, args.steps, args.min_seconds, barrier)
     api.check()
+    verified, verr, vcnt = (work.verify(0) if args.beta == 0 else (None, 0.0, 0))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, -float(n_timed), 0.0 if verified in (True, None) else 1.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, n_timed = float(t[0].item()), int(-t[1].item())
+        if verified is not None:
+            verified = t[2].item() == 0.0
     # secondary measurement: the same set every step (Infinity-Cache resident), not the headline
-    for i in range(min(args.warmup, 10)):
-        work.step(0)
-    l3_elapsed, l3_kernel_us = timed(work, args.steps, barrier, rotate=False)
-    eager_us = eager_kernel_us(work, min(args.steps, 100))
+    l3_us = None
+    if not args.no_l3:
+        l3 = Workload(api, dev, args.dtype, args.m, args.batch, br=args.br, beta=args.beta, fused=args.fused, nsets=1)
+        l3_elapsed, l3_n, l3_us = timed(l3, args.steps, min(args.min_seconds, 0.2), label=work.label() + "_l3resident")
+        del l3
+
+    sweep, reuse = {}, {}
+    if rank == 0 and not args.no_sweep:
+        quick = min(args.min_seconds, 0.15)
+        for dt, m, b in SWEEP:
+            w = Workload(api, dev, dt, m, b)
+            sweep[w.label()] = entry(w, args.steps, quick)
+            del w; torch.cuda.empty_cache()
+        for dt, m, b in SHARED_B:
+            w = Workload(api, dev, dt, m, b, mode="shared_b")
+            reuse[w.label()] = entry(w, args.steps, quick)
+            del w; torch.cuda.empty_cache()
+        for dt, m, ni, nj, br in BLOCKED:
+            w = Workload(api, dev, dt, m, 0, br=br, mode="blocked", grid=(ni, nj))
+            r = entry(w, args.steps, quick)
+            r["gemm"] = f"{ni * m}x{nj * m}x{br * m} as {ni}x{nj} tiles of {m}^3, br={br}"
+            reuse[w.label()] = r
+            del w; torch.cuda.empty_cache()
+    if dist is not None:
+        dist.barrier()
 
     if rank == 0:
-        # HBM traffic per launch from the TCC counters: rocprofv3 --pmc cannot run inside this process, so the number
-        # comes from the committed PMC summary of the same workload (tools/profile_paths.sh, separate FETCH_SIZE /
-        # WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction) -- null when no entry matches.
-        traffic, traffic_src = None, None
-        for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-            try:
-                for w in json.load(open(f))["workloads"]:
-                    if w["algorithmic_bytes_per_launch"] == int(work.alg_bytes_per_step) and w["kernel"].replace(" ", "") == api.hip_kernel_name(work.handle, 1).decode().replace(" ", ""):
-                        traffic, traffic_src = w["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
-                        break
-            except Exception:
-                continue
-            if traffic is not None:
-                break
-        total_flops = work.flops_per_step * args.steps * world
-        value = total_flops / elapsed / 1e9
+        traffic, traffic_src, busy, busy_src = committed_counters(work.kernel(), work.alg_bytes_per_step, work.label())
+        value = work.flops_per_step * n_timed * world / elapsed / 1e9
         gbs = work.alg_bytes_per_step / (kernel_us * 1e-6) / 1e9
         peak_tf = MFMA_PEAK_TF[args.dtype]
         out = {
             "metric": f"GFLOP/s, batched stride-BRGEMM m=n=k={args.m} {args.dtype}",
-            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "steps_timed": n_timed, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / n_timed * 1e3, 5), "timed_region_s": round(elapsed, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"stride-BRGEMM {args.dtype} m=n=k={args.m}, batch={args.batch} independent problems per GPU, br={args.br}, beta={args.beta}"
                                    + (", fused colbias+ReLU" if args.fused else ""),
-                       "kernel": work.api.hip_kernel_name(work.handle, 1).decode(), "input_sets_rotated": work.nsets, "per_gpu_batch": args.batch},
+                       "kernel": work.kernel(), "input_sets_rotated": work.nsets, "per_gpu_batch": args.batch},
+            "verified": verified, "verify": {"checker": "oracle/liboracle.so (oracle_gemm) on the same inputs", "problems_sampled": vcnt, "normf_rel_max": float(f"{verr:.3g}")},
             "pct_mfma_peak": round(100.0 * value / world / 1e3 / peak_tf, 2),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_us": round(kernel_us, 3), "kernel_us_eager_event_pairs": round(eager_us, 3),
-                         "algorithmic_bytes_per_launch": int(work.alg_bytes_per_step),
-                         "note": "kernel_us = HIP-event time of the timed region / steps (includes the ~1.5 us inter-kernel boundary)"},
-            "l3_resident": {"value": round(work.flops_per_step * args.steps * world / l3_elapsed / 1e9, 1), "unit": "GFLOP/s",
-                            "kernel_us": round(l3_kernel_us, 3),
-                            "achieved_GBs": round(work.alg_bytes_per_step / (l3_kernel_us * 1e-6) / 1e9, 1)},
+                         "kernel_us": round(kernel_us, 3), "algorithmic_bytes_per_launch": int(work.alg_bytes_per_step),
+                         "note": "kernel_us = HIP-event time of the timed region / launches (back-to-back launches from a hipGraph, includes the inter-kernel boundary)"},
+            "l3_resident": None if l3_us is None else {"value": round(work.flops_per_step / (l3_us * 1e-6) / 1e9, 1), "unit": "GFLOP/s", "kernel_us": round(l3_us, 3),
+                                                       "achieved_GBs": round(work.alg_bytes_per_step / (l3_us * 1e-6) / 1e9, 1)},
+            "mfma_busy": busy, "mfma_busy_source": busy_src,
         }
-        if not args.no_cpu_baseline and world == 1:
-            if args.cpu_threads < 0:
-                args.cpu_threads = usable_cpus()
-            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        if sweep:
+            out["sweep"] = sweep
+            out["reuse"] = reuse
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.m, args.dtype, args.br, args.beta, args.fused, args.cpu_seconds, nthreads)
         print(json.dumps(out))
+        if args.manifest:
+            json.dump({"command": " ".join(sys.argv), "entries": MANIFEST}, open(args.manifest, "w"), indent=1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -77,6 +77,20 @@ LIBXSMM_API void libxsmm_hip_gemm_batch_strided(libxsmm_gemmfunction kernel, con
 LIBXSMM_API void libxsmm_hip_gemm_ext_batch_strided(libxsmm_gemmfunction_ext kernel, const libxsmm_gemm_ext_param* param,
   size_t count, long long stride_a, long long stride_b, long long stride_c, long long stride_d, long long stride_mask);
 /**
+ * 2-D strided batch -- the two nested loops a caller runs to build a blocked GEMM out of (BR)GEMM tiles
+ * [ref: the loop nests around the kernel in samples/xgemm/gemm_kernel.c:3186-3226 and the DL drivers built on BRGEMM]:
+ *   for (j = 0; j < count_j; ++j) for (i = 0; i < count_i; ++i) { q = *p;
+ *     q.a.primary = (char*)p->a.primary + i*stride_a_i;  q.b.primary = (char*)p->b.primary + j*stride_b_j;
+ *     q.c.primary = (char*)p->c.primary + i*stride_c_i + j*stride_c_j;  f(&q); }
+ * A is re-used by every j and B by every i: the launch deals contiguous bands of j to the eight XCDs so that the re-use
+ * happens in their L2s.  The ext form steps d.primary (column bias) with i and c.secondary (ReLU bitmask) with both.
+ * MXFP4 / MX scales step with their operand as in the 1-D form.
+ */
+LIBXSMM_API void libxsmm_hip_gemm_batch_strided_2d(libxsmm_gemmfunction kernel, const libxsmm_gemm_param* param, size_t count_i, size_t count_j,
+  long long stride_a_i, long long stride_b_j, long long stride_c_i, long long stride_c_j);
+LIBXSMM_API void libxsmm_hip_gemm_ext_batch_strided_2d(libxsmm_gemmfunction_ext kernel, const libxsmm_gemm_ext_param* param, size_t count_i, size_t count_j,
+  long long stride_a_i, long long stride_b_j, long long stride_c_i, long long stride_c_j, long long stride_d_i, long long stride_mask_i, long long stride_mask_j);
+/**
  * Pointer-list batch: element i uses a_list[i], b_list[i], c_list[i] as its `primary`
  * slots.  The three lists themselves must be device-accessible arrays of `count` pointers.
  */

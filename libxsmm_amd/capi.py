@@ -263,6 +263,8 @@ class Api:
             ll = C.c_longlong
             self.hip_gemm_batch_strided = f("hip_gemm_batch_strided", None, [vp, C.POINTER(GemmParam), C.c_size_t, ll, ll, ll])
             self.hip_gemm_ext_batch_strided = f("hip_gemm_ext_batch_strided", None, [vp, C.POINTER(GemmExtParam), C.c_size_t, ll, ll, ll, ll, ll])
+            self.hip_gemm_batch_strided_2d = f("hip_gemm_batch_strided_2d", None, [vp, C.POINTER(GemmParam), C.c_size_t, C.c_size_t, ll, ll, ll, ll])
+            self.hip_gemm_ext_batch_strided_2d = f("hip_gemm_ext_batch_strided_2d", None, [vp, C.POINTER(GemmExtParam), C.c_size_t, C.c_size_t, ll, ll, ll, ll, ll, ll, ll])
             self.hip_gemm_batch_pointers = f("hip_gemm_batch_pointers", None, [vp, C.POINTER(GemmParam), C.c_size_t, vp, vp, vp])
             self.hip_meltw_unary_batch_strided = f("hip_meltw_unary_batch_strided", None, [vp, C.POINTER(UnaryParam), C.c_size_t, ll, ll, ll])
             self.hip_meltw_binary_batch_strided = f("hip_meltw_binary_batch_strided", None, [vp, C.POINTER(BinaryParam), C.c_size_t, ll, ll, ll])

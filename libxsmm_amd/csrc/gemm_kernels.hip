@@ -85,11 +85,27 @@ __device__ __forceinline__ gcptr list_entry(const void* list, unsigned long long
 }
 __device__ __forceinline__ BatchPtrs batch_ptrs(const GemmArgs& p, unsigned int bidx) {
   BatchPtrs q;
+  if (p.batch_inner) {     // 2-D batch: (i, j) = (bidx % inner, bidx / inner); wave-uniform, one 32-bit division per wave
+    const unsigned int bj = bidx / p.batch_inner, bi = bidx - bj * p.batch_inner;
+    q.a = (gcptr)p.a + (long long)bi * p.bs_a; q.b = (gcptr)p.b + (long long)bj * p.bs_b;
+    q.c = (gptr)p.c + (long long)bi * p.bs_c + (long long)bj * p.bs_c2;
+    q.d = p.d ? (gcptr)p.d + (long long)bi * p.bs_d : nullptr;
+    q.mask = p.relu_mask ? (GM unsigned char*)p.relu_mask + (long long)bi * p.bs_mask + (long long)bj * p.bs_mask2 : nullptr;
+    return q;
+  }
   if (p.list_a) { q.a = list_entry(p.list_a, bidx); q.b = list_entry(p.list_b, bidx); q.c = (gptr)list_entry(p.list_c, bidx); }
   else { q.a = (gcptr)p.a + (long long)bidx * p.bs_a; q.b = (gcptr)p.b + (long long)bidx * p.bs_b; q.c = (gptr)p.c + (long long)bidx * p.bs_c; }
   q.d = p.d ? (gcptr)p.d + (long long)bidx * p.bs_d : nullptr;
   q.mask = p.relu_mask ? (GM unsigned char*)p.relu_mask + (long long)bidx * p.bs_mask : nullptr;
   return q;
+}
+// Workgroup -> logical block.  A 2-D batch re-uses operands between elements (A along j, B along i): hardware block b runs on
+// XCD b % 8, so the grid is re-dealt to give every XCD (its own L2) one contiguous eighth of the element range -- a band of j
+// whose B panels stay in that L2 while A streams through it once per XCD.  1-D batches have no reuse: identity.
+__device__ __forceinline__ unsigned int logical_block(const GemmArgs& p) {
+  const unsigned int b = blockIdx.x, nb = gridDim.x;
+  if (p.batch_inner && (nb & 7u) == 0u) return (b & 7u) * (nb >> 3) + (b >> 3);
+  return b;
 }
 // base of batch-reduce element r [ref: gemm ref :180-197]
 __device__ __forceinline__ void br_base(const GemmArgs& p, const BatchPtrs& q, unsigned long long r, gcptr& a, gcptr& b) {
@@ -120,6 +136,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(gcptr base) {
 __device__ __forceinline__ bool is_mx_type(int t) { return t == LIBXSMM_DATATYPE_MXFP4X2 || t == LIBXSMM_DATATYPE_MXBF8 || t == LIBXSMM_DATATYPE_MXHF8; }
 // scales of A (of_b = false) or B: one byte per 32 elements, so a byte distance D of the operand is D * (elements per byte) / 32 here
 __device__ __forceinline__ gcptr mx_scale_base(const GemmArgs& p, unsigned int bidx, unsigned long long r, bool of_b) {
+  if (p.batch_inner) bidx = of_b ? bidx / p.batch_inner : bidx % p.batch_inner;      // the scales step with their operand
   gcptr base = of_b ? (gcptr)p.b_scf + (long long)bidx * p.bs_bscf : (gcptr)p.a_scf + (long long)bidx * p.bs_scf;
   const long long epb = ((of_b ? p.b_type : p.a_type) == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
   if (p.br_mode == 1) return list_entry((const void*)(size_t)base, r);
@@ -570,7 +587,7 @@ __device__ __forceinline__ WaveJob wave_job(const GemmArgs& p, int tile_m, int t
   // The wave index is uniform but not provably so to the compiler: readfirstlane moves the whole tile/batch
   // address computation to the scalar unit.  Index math is 32-bit and division-free in the common case of
   // one tile per problem (launch_gemm guarantees tiles * nbatch < 2^31).
-  const unsigned int wid = blockIdx.x * (blockDim.x >> 6) + (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = logical_block(p) * (blockDim.x >> 6) + (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int per_gemm = (unsigned int)(p.tiles_m * p.tiles_n);
   WaveJob w;
   w.active = wid < per_gemm * p.nbatch;
@@ -674,7 +691,7 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds_all[4][2048];
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned int wid = blockIdx.x * 4u + wave;
+  const unsigned int wid = logical_block(p) * 4u + wave;
   const unsigned int per_gemm = (unsigned int)(p.tiles_m * p.tiles_n);
   if (wid >= per_gemm * p.nbatch) return;
   unsigned int bidx = wid, i0 = 0, j0 = 0;
@@ -713,19 +730,32 @@ __global__ __launch_bounds__(256) void gemm_f32_stream_kernel(GemmArgs p) {
   gcptr ar, br;
   if (p.br_count != 0) br_base(p, q, 0, ar, br);
   const unsigned long long total = p.br_count * kchunks;
-  for (unsigned long long t = 0; t < total; ++t) {
-    gcptr au = ar + orgA + kc * kstepA, bu = br + orgB + kc * kstepB;      // wave-uniform
-    f32x4 ga[4], gb[4];
+  // Software pipeline over the (batch-reduce element, K chunk) sequence: the global loads of chunk t+1 are issued as soon as chunk t
+  // has been parked in LDS, i.e. BEFORE the 16 MFMAs of chunk t (1024 cycles of matrix pipe) -- with operands that other waves
+  // have already pulled into L2 (2-D batches, long chains) the wave then never waits for memory.  One chunk (br = 1, k = 32:
+  // the streaming headline) runs the same instruction sequence as before.
+  f32x4 ga[4], gb[4];
+  if (total != 0) {
+    gcptr au = ar + orgA, bu = br + orgB;                                   // wave-uniform
 #pragma unroll
     for (int x = 0; x < 4; ++x) ga[x] = *(GM const f32x4*)(au + x * stepA + offA);
 #pragma unroll
     for (int x = 0; x < 4; ++x) gb[x] = *(GM const f32x4*)(bu + x * stepB + offB);
+  }
+  for (unsigned long long t = 0; t < total; ++t) {
     float af[16], bf[16];
     tile_to_frag<TA>(af, ga, lds, (int)lane);
     tile_to_frag<!TB>(bf, gb, lds + 1024, (int)lane);
+    if (++kc == kchunks) { kc = 0; if (++r < p.br_count) br_base(p, q, r, ar, br); }
+    if (t + 1 < total) {
+      gcptr au = ar + orgA + kc * kstepA, bu = br + orgB + kc * kstepB;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) ga[x] = *(GM const f32x4*)(au + x * stepA + offA);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) gb[x] = *(GM const f32x4*)(bu + x * stepB + offB);
+    }
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc, 0, 0, 0);
-    if (++kc == kchunks) { kc = 0; if (++r < p.br_count) br_base(p, q, r, ar, br); }
   }
   if (p.act == 0) {
 #pragma unroll

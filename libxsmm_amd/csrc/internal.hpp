@@ -65,6 +65,10 @@ struct GemmArgs {
   const long long* offs_a; const long long* offs_b; // OFFSET mode (bytes), shared by the batch
   const void* const* list_a; const void* const* list_b; void* const* list_c;  // pointer-list batch
   long long bs_a, bs_b, bs_c, bs_d, bs_mask;        // batch byte strides
+  // 2-D strided batch (blocked GEMM out of BRGEMM tiles): element e = (i, j), i = e % batch_inner fastest;
+  // A steps with i (bs_a), B with j (bs_b), C / the bitmask with both (bs_c, bs_mask along i; bs_c2, bs_mask2 along j), the bias with i.
+  unsigned int batch_inner;                         // 0: 1-D batch
+  long long bs_c2, bs_mask2;
   long long br_stride_a, br_stride_b;               // bytes
   unsigned long long br_count;
   unsigned int nbatch;

@@ -329,6 +329,7 @@ namespace {
 struct BatchSpec {
   size_t count = 1;
   long long s[5] = {0, 0, 0, 0, 0};                 // kind specific byte strides
+  size_t inner = 0; long long c2 = 0, mask2 = 0;    // 2-D GEMM batch: count = inner * outer, second strides of C / bitmask
   const void* const* la = nullptr; const void* const* lb = nullptr; void* const* lc = nullptr;
 };
 
@@ -343,6 +344,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   a.list_a = b.la; a.list_b = b.lb; a.list_c = b.lc;
   a.bs_a = b.s[0]; a.bs_b = b.s[1]; a.bs_c = b.s[2]; a.bs_d = b.s[3]; a.bs_mask = b.s[4];
   a.nbatch = (unsigned int)b.count;
+  a.batch_inner = (unsigned int)b.inner; a.bs_c2 = b.c2; a.bs_mask2 = b.mask2;
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.lda = (int)d.lda; a.ldb = (int)d.ldb; a.ldc = (int)d.ldc;
   a.flags = d.flags; a.a_type = d.a_type; a.b_type = d.b_type; a.c_type = d.c_type;
   a.vnni_c = (d.flags & LIBXSMM_GEMM_FLAG_VNNI_C) ? 1 : 0;
@@ -1358,6 +1360,25 @@ LIBXSMM_API void libxsmm_hip_gemm_ext_batch_strided(libxsmm_gemmfunction_ext ker
   KernelCtx* c = batch_ctx((const void*)kernel, K_GEMM); if (!c || !param || count == 0) return;
   if (!(c->g.flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI)) { set_error(-3, "handle was not dispatched with libxsmm_dispatch_brgemm_ext"); return; }
   BatchSpec b; b.count = count; b.s[0] = sa; b.s[1] = sb; b.s[2] = sc; b.s[3] = sd; b.s[4] = smask;
+  run_gemm(c, param, b);
+}
+LIBXSMM_API void libxsmm_hip_gemm_batch_strided_2d(libxsmm_gemmfunction kernel, const libxsmm_gemm_param* param, size_t count_i, size_t count_j,
+  long long stride_a_i, long long stride_b_j, long long stride_c_i, long long stride_c_j) {
+  KernelCtx* c = batch_ctx((const void*)kernel, K_GEMM); if (!c || !param || count_i == 0 || count_j == 0) return;
+  if (c->g.flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) { set_error(-3, "use libxsmm_hip_gemm_ext_batch_strided_2d for ext kernels"); return; }
+  if (c->g.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS) { set_error(-3, "2-D batches take STRIDE / OFFSET / plain kernels (a pointer list per element has no 2-D form)"); return; }
+  if (count_i * count_j >= (1ull << 31)) { set_error(-3, "2-D batch too large"); return; }
+  BatchSpec b; b.count = count_i * count_j; b.inner = count_i; b.s[0] = stride_a_i; b.s[1] = stride_b_j; b.s[2] = stride_c_i; b.c2 = stride_c_j;
+  run_gemm(c, param, b);
+}
+LIBXSMM_API void libxsmm_hip_gemm_ext_batch_strided_2d(libxsmm_gemmfunction_ext kernel, const libxsmm_gemm_ext_param* param, size_t count_i, size_t count_j,
+  long long stride_a_i, long long stride_b_j, long long stride_c_i, long long stride_c_j, long long stride_d_i, long long stride_mask_i, long long stride_mask_j) {
+  KernelCtx* c = batch_ctx((const void*)kernel, K_GEMM); if (!c || !param || count_i == 0 || count_j == 0) return;
+  if (!(c->g.flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI)) { set_error(-3, "handle was not dispatched with libxsmm_dispatch_brgemm_ext"); return; }
+  if (c->g.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS) { set_error(-3, "2-D batches take STRIDE / OFFSET / plain kernels (a pointer list per element has no 2-D form)"); return; }
+  if (count_i * count_j >= (1ull << 31)) { set_error(-3, "2-D batch too large"); return; }
+  BatchSpec b; b.count = count_i * count_j; b.inner = count_i; b.s[0] = stride_a_i; b.s[1] = stride_b_j; b.s[2] = stride_c_i; b.c2 = stride_c_j;
+  b.s[3] = stride_d_i; b.s[4] = stride_mask_i; b.mask2 = stride_mask_j;
   run_gemm(c, param, b);
 }
 LIBXSMM_API void libxsmm_hip_gemm_batch_pointers(libxsmm_gemmfunction kernel, const libxsmm_gemm_param* param, size_t count,

@@ -477,3 +477,35 @@ def test_reductions_16_and_8_bit_floats(in_dt, rows):
     out_elems = n if rows else m
     ref, got, _, _ = run_unary(UNARY.REDUCE_X_OP_ADD, m, n, ld, out_elems, in_dt, DT.F32, flags=flags, out_elems=out_elems)
     assert np.allclose(ref, got, rtol=1e-5, atol=1e-5)
+
+
+def test_staging_scratch_growth_keeps_earlier_staged_pointers_valid():
+    """A synchronous host-memory call whose LAST staged operand overflows the per-thread device scratch: in0 (512 KiB) sizes the first block
+    at 1 MiB, `out` fills it exactly, the 16 KiB bitmask forces a second block.  The pointers already handed to the argument block must stay
+    valid (the old block is retired, not moved).  A fresh host thread has a fresh scratch, so the scenario is reproducible inside a session."""
+    import threading
+    import torch
+    api = capi.load()
+    m, n = 512, 256
+    rng = np.random.default_rng(17)
+    x = rand_values(rng, m * n, DT.F32)
+    h = api.dispatch_meltw_unary(UNARY.RELU, capi.UnaryShape(m, n, m, m, DT.F32, DT.F32, DT.F32), UNARY_FLAG.BITMASK_2BYTEMULT)
+    assert h
+    out = np.full(m * n, -7.0, np.float32)
+    mask = np.zeros((m // 8) * n, np.uint8)
+    err = []
+
+    def body():
+        try:
+            api.hip_set_device(0); api.hip_set_async(0)
+            p = capi.UnaryParam()
+            p.in_.primary, p.out.primary, p.out.secondary = x.ctypes.data, out.ctypes.data, mask.ctypes.data
+            capi.Api.call(h, p)
+            api.check()
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+    t = threading.Thread(target=body); t.start(); t.join()
+    assert not err, err
+    assert np.array_equal(out, np.maximum(x, 0.0)), "staged output did not come back"
+    bits = np.unpackbits(mask.reshape(n, m // 8), axis=1, bitorder="little")
+    assert np.array_equal(bits.astype(bool), (x.reshape(n, m) > 0))

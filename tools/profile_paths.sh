@@ -1,17 +1,39 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for the hot-path kernels on the GPU box (run through gpurun from the repo root):
-#   1. kernel-trace stats of bench.py (the headline command),
-#   2. kernel-trace stats of the BASELINE configs #2..#5 (tools/bench_paths.py --headline, eager launches),
-#   3. HBM traffic counters, FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), no other trace domains.
-# Output: gpurun_out/prof_<tag>/...csv ; summaries are distilled by tools/summarize_profiles.py into profiles/.
+# Collects the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
+#   1. kernel trace of `python bench.py` (headline + sweep + reuse; bench.py writes a manifest = execution order of its
+#      launches, so the trace can be split per workload: rotated / L3-resident / every sweep entry),
+#   2. HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), plain launches (--eager), no other trace domains,
+#   3. matrix-core occupancy: SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE in one pass (SQ + GRBM slots),
+#   4. kernel trace of tools/headline_probe (copy floor of the headline footprint + launch-geometry variants),
+#   5. kernel trace of tools/bench_paths.py --headline (BASELINE configs #2..#5), as in round 1.
+# The raw CSVs stay under gpurun_out/prof_<tag>/ (scratch, gzipped); tools/summarize_profiles.py <tag> distils them into
+# gpurun_out/prof_<tag>/summary/, which is what gets copied to profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+WHAT=${2:-all}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/paths_trace -- python $ROOT/tools/bench_paths.py --headline --eager 20 > $OUT/paths_trace.jsonl 2> $OUT/paths_trace.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/paths_fetch -- python $ROOT/tools/bench_paths.py --headline --eager 10 > $OUT/paths_fetch.jsonl 2> $OUT/paths_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/paths_write -- python $ROOT/tools/bench_paths.py --headline --eager 10 > $OUT/paths_write.jsonl 2> $OUT/paths_write.err
-find $OUT -name "*.csv" | head -40
+B="python $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5"
+if [ "$WHAT" = all ] || [ "$WHAT" = trace ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- $B --min-seconds 0.05 --manifest $OUT/bench_trace_manifest.json > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
+  rocprofv3 -L 2>/dev/null | grep -iE "MFMA|GRBM_GUI|FETCH_SIZE|WRITE_SIZE|SQ_BUSY|SQ_WAVE_CYCLES|SQ_WAIT" | head -60 > $OUT/counters_available.txt
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/bench_fetch -- $B --eager --no-l3 --min-seconds 0.002 --manifest $OUT/bench_fetch_manifest.json > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/bench_write -- $B --eager --no-l3 --min-seconds 0.002 --manifest $OUT/bench_write_manifest.json > $OUT/bench_write.json 2> $OUT/bench_write.err
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/bench_mfma -- $B --eager --no-l3 --min-seconds 0.002 --manifest $OUT/bench_mfma_manifest.json > $OUT/bench_mfma.json 2> $OUT/bench_mfma.err
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = probe ]; then
+  if [ -x $ROOT/tools/headline_probe ]; then
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/probe_trace -- $ROOT/tools/headline_probe 4096 6 1 > $OUT/probe_trace.txt 2> $OUT/probe_trace.err
+  fi
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = paths ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/paths_trace -- python $ROOT/tools/bench_paths.py --headline --eager 20 > $OUT/paths_trace.jsonl 2> $OUT/paths_trace.err
+fi
+cd $ROOT && python tools/summarize_profiles.py $TAG > $OUT/summary.txt 2>&1
+find $OUT -name "*_kernel_trace.csv" -size +2M -exec gzip -f {} \;
+find $OUT -name "*_counter_collection.csv" -size +2M -exec gzip -f {} \;
+tail -40 $OUT/summary.txt

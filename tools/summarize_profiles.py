@@ -1,79 +1,176 @@
 #!/usr/bin/env python
-"""Distils gpurun_out/prof_<tag>/ (written by tools/profile_paths.sh on the GPU box) into the small, tracked
-files under profiles/:
-  <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python bench.py` (library kernels only)
+"""Distils gpurun_out/prof_<tag>/ (written by tools/profile_paths.sh on the GPU box) into small files under
+gpurun_out/prof_<tag>/summary/ (copied to profiles/ and committed):
+  <tag>_bench_kernel_stats.csv   per WORKLOAD of `python bench.py`: rocprofv3 kernel durations of its timed launches.  bench.py's manifest
+                                 gives the execution order of the library's launches, so the rotated (HBM-streaming) launches, the
+                                 L3-resident leg and every sweep / reuse entry are reported separately -- never mixed in one average.
   <tag>_bench_under_rocprof.json the bench line printed by that same run
-  <tag>_paths_kernel_stats.csv   same for the BASELINE configs #2..#5 (tools/bench_paths.py --headline --eager)
-  <tag>_pmc_traffic.json         HBM traffic per launch from the TCC counters: FETCH_SIZE and WRITE_SIZE collected in
-                                 separate passes; FETCH_SIZE doubled (gfx950 counts the 128-byte requests of wide
-                                 coalesced reads at 64 bytes, MI355X_MICROARCH.md "HBM"); both are reported in KiB.
-bench.py reads <tag>_pmc_traffic.json to fill roofline.traffic for the workload it matches."""
+  <tag>_pmc_traffic.json         HBM traffic per launch per workload from the TCC counters: FETCH_SIZE and WRITE_SIZE collected in separate
+                                 passes; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes,
+                                 MI355X_MICROARCH.md "HBM"); both are reported in KiB.
+  <tag>_mfma_busy.json           SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CU_CYCLES and GRBM_GUI_ACTIVE per launch per workload, and the derived
+                                 matrix-core busy fraction.
+  <tag>_copy_floor.csv           kernel durations of tools/headline_probe (copy kernels of the headline footprint, launch-geometry variants)
+  <tag>_paths_kernel_stats.csv   rocprofv3 --stats of tools/bench_paths.py --headline (BASELINE configs #2..#5)
+bench.py reads <tag>_pmc_traffic.json and <tag>_mfma_busy.json to fill roofline.traffic and mfma_busy for the workloads it matches."""
 import collections
 import csv
 import glob
+import gzip
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-dst = os.path.join(ROOT, "profiles")
+dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
+HBM_PEAK = 8000.0e9
+SIMDS = 1024
 
 
 def ours(name):
-    return "xamd::" in name or name.startswith("spmm_jit")
+    return "xamd::" in name or name.startswith("spmm_jit") or name.startswith("pgemm_jit") or name.startswith("meqn_")
 
 
-def copy_stats(sub, out):
-    files = sorted(glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
-    if not files:
-        return
-    rows = list(csv.reader(open(files[-1])))          # the newest run (earlier collections may still lie around)
-    with open(os.path.join(dst, out), "w", newline="") as f:
+def newest(sub, pattern):
+    files = sorted(glob.glob(os.path.join(src, sub, "*", pattern)) + glob.glob(os.path.join(src, sub, "*", pattern + ".gz")), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def rows_of(path):
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rt", newline="") as f:
+        yield from csv.DictReader(f)
+
+
+def library_dispatches(path, value_of):
+    """Library launches of a trace / counter file in execution order: list of (kernel name, value)."""
+    out = []
+    for r in rows_of(path):
+        if ours(r["Kernel_Name"]):
+            out.append((int(r["Dispatch_Id"]), r["Kernel_Name"], value_of(r)))
+    out.sort(key=lambda x: x[0])
+    return out
+
+
+def split_by_manifest(disp, manifest):
+    """Walks the dispatches in order and hands each manifest entry its `launches_executed` rows; returns label -> rows of the TIMED launches."""
+    res, pos = {}, 0
+    for e in manifest["entries"]:
+        n, nt = e["launches_executed"], e["launches_timed"]
+        seg = disp[pos:pos + n]
+        pos += n
+        if len(seg) < n:
+            print(f"  !! manifest entry {e['label']}: trace holds {len(seg)} of {n} launches")
+        res[e["label"]] = (e, seg[-nt:] if nt <= len(seg) else seg)
+    if pos != len(disp):
+        print(f"  !! {len(disp) - pos} library launches after the last manifest entry")
+    return res
+
+
+# ---- 1. kernel durations per workload -------------------------------------------------------------------------------------
+stats_rows = []
+kt = newest("bench_trace", "*_kernel_trace.csv")
+mf = os.path.join(src, "bench_trace_manifest.json")
+if kt and os.path.exists(mf):
+    disp = library_dispatches(kt, lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    per = split_by_manifest(disp, json.load(open(mf)))
+    with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(rows[0])
-        for r in rows[1:]:
-            if ours(r[0]):
-                w.writerow(r)
-
-
-copy_stats("bench_trace", f"{tag}_bench_kernel_stats.csv")
-copy_stats("paths_trace", f"{tag}_paths_kernel_stats.csv")
+        w.writerow(["workload", "kernel", "timed_launches", "avg_us", "min_us", "max_us", "algorithmic_bytes_per_launch", "GB/s", "frac_hbm", "GFLOP/s", "events_us_in_process"])
+        for label, (e, seg) in per.items():
+            if not seg:
+                continue
+            d = [x[2] for x in seg]
+            avg = sum(d) / len(d)
+            names = collections.Counter(x[1].split("(")[0].replace("void xamd::", "") for x in seg)
+            gbs = e["algorithmic_bytes_per_launch"] / (avg * 1e-6)
+            w.writerow([label, names.most_common(1)[0][0], len(d), f"{avg:.3f}", f"{min(d):.3f}", f"{max(d):.3f}", e["algorithmic_bytes_per_launch"],
+                        f"{gbs / 1e9:.1f}", f"{gbs / HBM_PEAK:.4f}", f"{e['flops_per_launch'] / (avg * 1e-6) / 1e9:.1f}", f"{e['us_per_launch_events']:.3f}"])
+            print(f"{label:28s} {names.most_common(1)[0][0][:44]:44s} n={len(d):6d} avg {avg:9.3f} us  frac_hbm {gbs / HBM_PEAK:.3f}")
 bj = os.path.join(src, "bench_trace.json")
 if os.path.exists(bj) and os.path.getsize(bj):
     open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(open(bj).read())
 
 
-def counters(sub):
-    acc = collections.defaultdict(list)
-    files = sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
-    for f in files[-1:]:                              # newest collection only
-        for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"].replace(" ", "")].append(float(r["Counter_Value"]))
-    return acc
+# ---- 2. HBM traffic -------------------------------------------------------------------------------------------------------------
+def counter_pass(sub, names):
+    f = newest(sub, "*_counter_collection.csv")
+    m = os.path.join(src, sub + "_manifest.json")
+    if not f or not os.path.exists(m):
+        return {}
+    acc = collections.defaultdict(dict)      # dispatch id -> {counter: value}, kernel name
+    kn = {}
+    for r in rows_of(f):
+        if ours(r["Kernel_Name"]) and r["Counter_Name"] in names:
+            d = int(r["Dispatch_Id"])
+            acc[d][r["Counter_Name"]] = acc[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            kn[d] = r["Kernel_Name"]
+    disp = [(d, kn[d], acc[d]) for d in sorted(acc)]
+    return split_by_manifest(disp, json.load(open(m)))
 
 
-fetch, write = counters("paths_fetch"), counters("paths_write")
-out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile_paths.sh {tag}",
-       "correction": "FETCH_SIZE x2 (gfx950: 128-byte requests of 16-byte-per-lane reads are tallied at 64 bytes); WRITE_SIZE as reported; both KiB",
-       "workloads": []}
-lines = [json.loads(l) for l in open(os.path.join(src, "paths_fetch.jsonl")) if l.strip().startswith("{")]
-for w in lines:
-    if "kernel" not in w:
-        continue
-    key = w["kernel"].replace(" ", "")
-    f = [v for k, v in fetch.items() if key in k]
-    wr = [v for k, v in write.items() if key in k]
-    if not f or not wr:
-        continue
-    fkb = sum(f[0]) / len(f[0]); wkb = sum(wr[0]) / len(wr[0])
-    traffic = int((2 * fkb + wkb) * 1024)
-    out["workloads"].append({"workload": w["workload"], "kernel": w["kernel"], "launches_averaged": len(f[0]),
-                             "FETCH_SIZE_KiB_avg": round(fkb, 1), "WRITE_SIZE_KiB_avg": round(wkb, 1),
-                             "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": w["algorithmic_bytes_per_launch"],
-                             "traffic_over_algorithmic": round(traffic / w["algorithmic_bytes_per_launch"], 3)})
-json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-for w in out["workloads"]:
-    print(f"{w['workload'][:80]:80s} {w['kernel'][:34]:34s} traffic/alg = {w['traffic_over_algorithmic']}")
+fetch, write = counter_pass("bench_fetch", ["FETCH_SIZE"]), counter_pass("bench_write", ["WRITE_SIZE"])
+if fetch and write:
+    out = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --eager`, tools/profile_paths.sh {tag}",
+           "correction": "FETCH_SIZE x2 (gfx950: 128-byte requests of 16-byte-per-lane reads are tallied at 64 bytes); WRITE_SIZE as reported; both KiB",
+           "workloads": []}
+    for label, (e, seg) in fetch.items():
+        if label not in write or not seg or not write[label][1]:
+            continue
+        fkb = sum(x[2].get("FETCH_SIZE", 0.0) for x in seg) / len(seg)
+        ws = write[label][1]
+        wkb = sum(x[2].get("WRITE_SIZE", 0.0) for x in ws) / len(ws)
+        traffic = int((2 * fkb + wkb) * 1024)
+        out["workloads"].append({"workload": label, "kernel": e["kernel"], "launches_averaged": len(seg), "FETCH_SIZE_KiB_avg": round(fkb, 1), "WRITE_SIZE_KiB_avg": round(wkb, 1),
+                                 "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
+                                 "traffic_over_algorithmic": round(traffic / e["algorithmic_bytes_per_launch"], 3)})
+        print(f"{label:28s} traffic/alg = {traffic / e['algorithmic_bytes_per_launch']:.3f}")
+    json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+
+# ---- 3. matrix-core busy ----------------------------------------------------------------------------------------------------------
+mfma = counter_pass("bench_mfma", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"])
+if mfma:
+    out = {"source": f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of `python bench.py --eager`, tools/profile_paths.sh {tag}",
+           "definition": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs): the share of SIMD-cycles of the launch in which the matrix pipe was busy "
+                         "(the gfx94x MfmaUtil formula; GRBM_GUI_ACTIVE = cycles the GPU was active for the dispatch).  expected_mfma_cycles = the launch's MFMA instructions x their issue "
+                         "cycles (f32 32x32x2: 64, 16x16x4: 32; bf16 32x32x16: 32 per SIMD), a cross-check of the counter's unit.",
+           "workloads": {}}
+    for label, (e, seg) in mfma.items():
+        if not seg:
+            continue
+        n = len(seg)
+        busy = sum(x[2].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for x in seg) / n
+        cu = sum(x[2].get("SQ_BUSY_CU_CYCLES", 0.0) for x in seg) / n
+        gui = sum(x[2].get("GRBM_GUI_ACTIVE", 0.0) for x in seg) / n
+        flops = e["flops_per_launch"]
+        per_mfma_flops, cyc = (4096.0, 64.0) if e["dtype"] == "f32" else (32768.0, 32.0)
+        expected = flops / per_mfma_flops * cyc
+        out["workloads"][label] = {"kernel": e["kernel"], "launches_averaged": n, "SQ_VALU_MFMA_BUSY_CYCLES": round(busy, 1), "SQ_BUSY_CU_CYCLES": round(cu, 1), "GRBM_GUI_ACTIVE": round(gui, 1),
+                                   "mfma_busy_frac": round(busy / (gui * SIMDS), 4) if gui > 0 else None, "expected_mfma_cycles": round(expected, 1),
+                                   "counter_over_expected": round(busy / expected, 3) if expected > 0 else None}
+        print(f"{label:28s} mfma busy {busy:14.0f}  gui {gui:10.0f}  frac {busy / (gui * SIMDS) if gui > 0 else 0:.4f}  counter/expected {busy / expected if expected else 0:.3f}")
+    json.dump(out, open(os.path.join(dst, f"{tag}_mfma_busy.json"), "w"), indent=1)
+
+
+# ---- 4./5. plain --stats tables ---------------------------------------------------------------------------------------------------------
+def copy_stats(sub, outname, keep):
+    f = newest(sub, "*_kernel_stats.csv")
+    if not f:
+        return
+    rows = list(csv.reader(open(f)))
+    with open(os.path.join(dst, outname), "w", newline="") as fo:
+        w = csv.writer(fo)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if keep(r[0]):
+                w.writerow(r)
+
+
+copy_stats("probe_trace", f"{tag}_copy_floor.csv", lambda n: "copy_" in n or "gemm_" in n)
+copy_stats("paths_trace", f"{tag}_paths_kernel_stats.csv", ours)
+pt = os.path.join(src, "probe_trace.txt")
+if os.path.exists(pt):
+    open(os.path.join(dst, f"{tag}_headline_probe.txt"), "w").write(open(pt).read())
