@@ -89,7 +89,7 @@ class Workload:
     mode 'shared_b': the same, but one B chain shared by the whole batch (stride_b = 0).
     mode 'blocked': a blocked GEMM -- grid (ni, nj) of C tiles, C(i,j) = sum_r A(i,r) B(r,j), one 2-D batched launch."""
 
-    def __init__(self, api, dev, dtype="f32", m=32, batch=4096, br=1, beta=0, fused=0, mode="stream", grid=None, nsets=0, seed=555):
+    def __init__(self, api, dev, dtype="f32", m=32, batch=4096, br=1, beta=0, fused=0, mode="stream", grid=None, nsets=0, seed=555, hint=None):
         self.api, self.dev, self.dtype, self.m, self.br, self.beta, self.fused, self.mode = api, dev, dtype, m, br, beta, fused, mode
         self.bf16 = dtype == "bf16"
         es = 2 if self.bf16 else 4
@@ -109,6 +109,9 @@ class Workload:
         if nsets <= 0:
             nsets = 1 if mode == "blocked" else max(2, int(math.ceil(2.2 * L3_BYTES / set_bytes)))
         self.nsets = nsets
+        # libxsmm_hip_set_streaming_hint for this workload's launches: a rotation over more input sets than the Infinity Cache holds IS
+        # "operands read once from HBM" (2) and says so; everything else leaves the decision to the library (0)
+        self.hint = hint if hint is not None else (2 if (mode == "stream" and nsets > 1 and nsets * set_bytes > 2 * L3_BYTES) else 0)
         gen = torch.Generator(device=dev).manual_seed(seed)
         tdt = torch.int16 if self.bf16 else torch.float32
         self.A = [gen_values(na * m * m, self.bf16, dev, gen) for _ in range(nsets)]
@@ -227,6 +230,7 @@ def timed(work, steps, min_seconds, barrier=lambda: None, label=None):
     """A graph of G launches (G = a multiple of `steps` and of the rotation length) replayed R times so that the region lasts
     >= min_seconds, between two (barrier + synchronize) pairs.  Returns (wall seconds, launches timed, us per launch from HIP
     events recorded on the launch stream)."""
+    work.api.hip_set_streaming_hint(work.hint)
     t_step = estimate_step_seconds(work)
     unit = steps * work.nsets // math.gcd(steps, work.nsets)
     per_graph = unit * max(1, min(int(0.02 / t_step) // unit, max(1, 2000 // unit)))
@@ -263,7 +267,8 @@ def timed(work, steps, min_seconds, barrier=lambda: None, label=None):
         # launches the GPU executed for this workload since the last manifest entry: the eager ones + the first (untimed) replay + the
         # timed replays; the capture itself went through the launch counter once without executing
         executed = int(work.api.hip_launch_count(1)) + n
-    MANIFEST.append({"label": label or work.label(), "kernel": work.kernel(), "launches_executed": executed, "launches_timed": n,
+    work.api.hip_set_streaming_hint(0)
+    MANIFEST.append({"label": label or work.label(), "kernel": work.kernel(), "launches_executed": executed, "launches_timed": n, "streaming_hint": work.hint,
                      "algorithmic_bytes_per_launch": int(work.alg_bytes_per_step), "flops_per_launch": work.flops_per_step, "dtype": work.dtype,
                      "us_per_launch_events": e0.elapsed_time(e1) * 1e3 / n})
     return t1 - t0, n, e0.elapsed_time(e1) * 1e3 / n
@@ -271,6 +276,7 @@ def timed(work, steps, min_seconds, barrier=lambda: None, label=None):
 
 def entry(work, steps, min_seconds, verify=True):
     """One sweep / reuse line."""
+    work.api.hip_set_streaming_hint(work.hint)
     for i in range(3):
         work.step(i)
     torch.cuda.synchronize(); work.api.check()
@@ -278,7 +284,7 @@ def entry(work, steps, min_seconds, verify=True):
     work.api.check()
     tf = work.flops_per_step / (us * 1e-6) / 1e12
     gbs = work.alg_bytes_per_step / (us * 1e-6) / 1e9
-    out = {"kernel": work.kernel(), "us_per_launch": round(us, 3), "GFLOP/s": round(tf * 1e3, 1), "GB/s": round(gbs, 1),
+    out = {"kernel": work.kernel(), "streaming_hint": work.hint, "us_per_launch": round(us, 3), "GFLOP/s": round(tf * 1e3, 1), "GB/s": round(gbs, 1),
            "frac_hbm": round(gbs / HBM_PEAK_GBS, 4), "pct_mfma_peak": round(100.0 * tf / MFMA_PEAK_TF[work.dtype], 2), "launches_timed": n}
     if verify:
         ok, err, cnt = work.verify(0)
@@ -412,8 +418,8 @@ def committed_counters(kernel, alg_bytes, label):
 
 
 SWEEP = [(dt, m, b) for dt in ("f32", "bf16") for m in (16, 32, 64) for b in (4096, 65536)]
-# blocked GEMMs: (dtype, m, ni, nj, br) -- 2048^3 out of 16^3 / 32^3 tiles, 4096^3 out of 64^3 tiles
-BLOCKED = [("f32", 16, 128, 128, 128), ("f32", 32, 64, 64, 64), ("f32", 64, 64, 64, 64),
+# blocked GEMMs: (dtype, m, ni, nj, br) -- 2048^3 out of 16^3 tiles, 4096 x 4096 x 2048 out of f32 32^3 tiles, 2048^3 out of bf16 32^3 tiles, 4096^3 out of 64^3 tiles
+BLOCKED = [("f32", 16, 128, 128, 128), ("f32", 32, 128, 128, 64), ("f32", 64, 64, 64, 64),
            ("bf16", 16, 128, 128, 128), ("bf16", 32, 64, 64, 64), ("bf16", 64, 64, 64, 64)]
 SHARED_B = [(dt, m, 65536) for dt in ("f32", "bf16") for m in (16, 32, 64)]
 
@@ -509,38 +515,42 @@ def main():
         return
 
     only = args.only
-    if only:                 # one sweep / reuse entry under a profiler: no headline, no CPU leg
-        kind, label = only.split(":")
-        found = None
-        if kind == "sweep":
-            for dt, m, b in SWEEP:
-                w = (dt, m, b)
-                if f"{dt}_m{m}_b{b}" == label:
-                    found = Workload(api, dev, dt, m, b)
-        else:
-            for dt, m, b in SHARED_B:
-                if f"{dt}_m{m}_sharedB_b{b}" == label:
-                    found = Workload(api, dev, dt, m, b, mode="shared_b")
-            for dt, m, ni, nj, br in BLOCKED:
-                if f"{dt}_m{m}_blocked" == label:
-                    found = Workload(api, dev, dt, m, 0, br=br, mode="blocked", grid=(ni, nj))
-        if found is None:
-            raise SystemExit(f"unknown entry {only}")
+    if only:                 # selected sweep / reuse entries under a profiler: no headline, no CPU leg
         api.hip_launch_count(1)
-        res = entry(found, args.steps, args.min_seconds)
-        print(json.dumps({"only": only, **res}))
+        results = {}
+        for item in only.split(","):
+            kind, label = item.split(":")
+            found = None
+            if kind == "sweep":
+                for dt, m, b in SWEEP:
+                    if f"{dt}_m{m}_b{b}" == label:
+                        found = Workload(api, dev, dt, m, b)
+            else:
+                for dt, m, b in SHARED_B:
+                    if f"{dt}_m{m}_sharedB_b{b}" == label:
+                        found = Workload(api, dev, dt, m, b, mode="shared_b")
+                for dt, m, ni, nj, br in BLOCKED:
+                    if f"{dt}_m{m}_blocked" == label:
+                        found = Workload(api, dev, dt, m, 0, br=br, mode="blocked", grid=(ni, nj))
+            if found is None:
+                raise SystemExit(f"unknown entry {item}")
+            results[label] = entry(found, args.steps, args.min_seconds)
+            del found; torch.cuda.empty_cache()
+        print(json.dumps({"only": only, "results": results}))
         if args.manifest:
             json.dump({"command": " ".join(sys.argv), "entries": MANIFEST}, open(args.manifest, "w"), indent=1)
         return
 
     work = Workload(api, dev, args.dtype, args.m, args.batch, br=args.br, beta=args.beta, fused=args.fused, nsets=args.sets)
     api.hip_launch_count(1)
+    api.hip_set_streaming_hint(work.hint)
     for i in range(args.warmup):
         work.step(i)
     torch.cuda.synchronize()
     api.check()
     elapsed, n_timed, kernel_us = timed(work, args.steps, args.min_seconds, barrier)
     api.check()
+    headline_kernel, headline_hint = work.kernel(), work.hint
     verified, verr, vcnt = (work.verify(0) if args.beta == 0 else (None, 0.0, 0))
     if dist is not None:
         t = torch.tensor([elapsed, -float(n_timed), 0.0 if verified in (True, None) else 1.0], dtype=torch.float64, device=dev)
@@ -549,8 +559,11 @@ def main():
         if verified is not None:
             verified = t[2].item() == 0.0
     # secondary measurement: the same set every step (Infinity-Cache resident), not the headline
-    l3_us = None
+    l3_us = auto_us = None
     if not args.no_l3:
+        # the same rotation without the declaration (hint 0: the library decides by launch size -> cacheable loads for 48 MiB)
+        work.hint = 0
+        _, _, auto_us = timed(work, args.steps, min(args.min_seconds, 0.2), label=work.label() + "_hint0")
         l3 = Workload(api, dev, args.dtype, args.m, args.batch, br=args.br, beta=args.beta, fused=args.fused, nsets=1)
         l3_elapsed, l3_n, l3_us = timed(l3, args.steps, min(args.min_seconds, 0.2), label=work.label() + "_l3resident")
         del l3
@@ -576,7 +589,7 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        traffic, traffic_src, busy, busy_src = committed_counters(work.kernel(), work.alg_bytes_per_step, work.label())
+        traffic, traffic_src, busy, busy_src = committed_counters(headline_kernel, work.alg_bytes_per_step, work.label())
         value = work.flops_per_step * n_timed * world / elapsed / 1e9
         gbs = work.alg_bytes_per_step / (kernel_us * 1e-6) / 1e9
         peak_tf = MFMA_PEAK_TF[args.dtype]
@@ -587,7 +600,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"stride-BRGEMM {args.dtype} m=n=k={args.m}, batch={args.batch} independent problems per GPU, br={args.br}, beta={args.beta}"
                                    + (", fused colbias+ReLU" if args.fused else ""),
-                       "kernel": work.kernel(), "input_sets_rotated": work.nsets, "per_gpu_batch": args.batch},
+                       "kernel": headline_kernel, "input_sets_rotated": work.nsets, "per_gpu_batch": args.batch,
+                       "streaming_hint": headline_hint},
             "verified": verified, "verify": {"checker": "oracle/liboracle.so (oracle_gemm) on the same inputs", "problems_sampled": vcnt, "normf_rel_max": float(f"{verr:.3g}")},
             "pct_mfma_peak": round(100.0 * value / world / 1e3 / peak_tf, 2),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -596,6 +610,8 @@ def main():
                          "note": "kernel_us = HIP-event time of the timed region / launches (back-to-back launches from a hipGraph, includes the inter-kernel boundary)"},
             "l3_resident": None if l3_us is None else {"value": round(work.flops_per_step / (l3_us * 1e-6) / 1e9, 1), "unit": "GFLOP/s", "kernel_us": round(l3_us, 3),
                                                        "achieved_GBs": round(work.alg_bytes_per_step / (l3_us * 1e-6) / 1e9, 1)},
+            "without_streaming_hint": None if auto_us is None else {"kernel_us": round(auto_us, 3), "frac": round(work.alg_bytes_per_step / (auto_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                                     "note": "same rotation, libxsmm_hip_set_streaming_hint(0): cacheable operand loads (what a caller whose 48 MiB working set may be cache resident gets)"},
             "mfma_busy": busy, "mfma_busy_source": busy_src,
         }
         if sweep:

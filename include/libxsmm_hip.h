@@ -56,6 +56,18 @@ LIBXSMM_API void* libxsmm_hip_get_stream(void);
  */
 LIBXSMM_API void libxsmm_hip_set_async(int enable);
 LIBXSMM_API int libxsmm_hip_get_async(void);
+/**
+ * What the calling thread's next launches should assume about their dense operands -- the read-side counterpart of the reference's
+ * non-temporal-store hint for C [ref: include/libxsmm_typedefs.h LIBXSMM_GEMM_FLAG_ALIGN_C_NTS_HINT]:
+ *   0 (default, also LIBXSMM_HIP_STREAMING=0): decide per launch -- operands of a launch that moves more than the 256 MiB Infinity Cache
+ *     holds are loaded non-temporally (they cannot be resident), smaller launches keep their operands cacheable;
+ *   1: operands are re-read by later launches or were just produced on the device (keep them cacheable, never non-temporal);
+ *   2: operands are read once from HBM (a pass over a working set far larger than the cache): non-temporal loads at every size.
+ * Measured on 4096 f32 32^3 problems: hint 2 is 7 % faster when the operands do come from HBM and 50 % slower when they were
+ * resident in the Infinity Cache, which is why it is a declaration of the caller and not a default.
+ */
+LIBXSMM_API void libxsmm_hip_set_streaming_hint(int mode);
+LIBXSMM_API int libxsmm_hip_get_streaming_hint(void);
 /** Block until all work enqueued by the calling thread's stream has finished. */
 LIBXSMM_API void libxsmm_hip_sync(void);
 /** Sticky error state of the calling thread (0 = none); kernels have no error channel. */

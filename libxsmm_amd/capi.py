@@ -252,6 +252,8 @@ class Api:
             self.hip_set_stream = f("hip_set_stream", None, [vp])
             self.hip_set_async = f("hip_set_async", None, [C.c_int])
             self.hip_get_async = f("hip_get_async", C.c_int, [])
+            self.hip_set_streaming_hint = f("hip_set_streaming_hint", None, [C.c_int])
+            self.hip_get_streaming_hint = f("hip_get_streaming_hint", C.c_int, [])
             self.hip_sync = f("hip_sync", None, [])
             self.hip_get_last_error = f("hip_get_last_error", C.c_int, [])
             self.hip_get_last_error_string = f("hip_get_last_error_string", C.c_char_p, [])

@@ -86,7 +86,18 @@ __device__ __forceinline__ gcptr list_entry(const void* list, unsigned long long
 __device__ __forceinline__ BatchPtrs batch_ptrs(const GemmArgs& p, unsigned int bidx) {
   BatchPtrs q;
   if (p.batch_inner) {     // 2-D batch: (i, j) = (bidx % inner, bidx / inner); wave-uniform, one 32-bit division per wave
-    const unsigned int bj = bidx / p.batch_inner, bi = bidx - bj * p.batch_inner;
+    unsigned int bi, bj;
+    if (p.map2d_shift) {
+      // Locality: hardware workgroup g runs on XCD g % 8 and the workgroups of an XCD start in increasing order.  The element grid is cut into
+      // super-tiles of T x T elements (T = 2^shift); super-tile S goes to XCD S % 8 as T*T/4 consecutive workgroups of that XCD, so the waves
+      // that are resident on one XCD at the same time work on a compact square: every A and B block they touch is shared by T of them
+      // and the per-step working set (2 T blocks) fits the XCD's 4 MiB L2 many times over.  (bidx = 4 * workgroup + wave: one tile per element.)
+      const unsigned int sh = p.map2d_shift, wg = bidx >> 2, x = wg & 7u, k = wg >> 3;
+      const unsigned int wgs_shift = 2u * sh - 2u;                         // log2(workgroups per super-tile)
+      const unsigned int S = x + 8u * (k >> wgs_shift), pl = ((k & ((1u << wgs_shift) - 1u)) << 2) | (bidx & 3u);
+      const unsigned int nsi = p.batch_inner >> sh, sj = S / nsi, si = S - sj * nsi;
+      bi = (si << sh) + (pl & ((1u << sh) - 1u)); bj = (sj << sh) + (pl >> sh);
+    } else { bj = bidx / p.batch_inner; bi = bidx - bj * p.batch_inner; }
     q.a = (gcptr)p.a + (long long)bi * p.bs_a; q.b = (gcptr)p.b + (long long)bj * p.bs_b;
     q.c = (gptr)p.c + (long long)bi * p.bs_c + (long long)bj * p.bs_c2;
     q.d = p.d ? (gcptr)p.d + (long long)bi * p.bs_d : nullptr;
@@ -104,7 +115,7 @@ __device__ __forceinline__ BatchPtrs batch_ptrs(const GemmArgs& p, unsigned int 
 // whose B panels stay in that L2 while A streams through it once per XCD.  1-D batches have no reuse: identity.
 __device__ __forceinline__ unsigned int logical_block(const GemmArgs& p) {
   const unsigned int b = blockIdx.x, nb = gridDim.x;
-  if (p.batch_inner && (nb & 7u) == 0u) return (b & 7u) * (nb >> 3) + (b >> 3);
+  if (p.batch_inner && !p.map2d_shift && (nb & 7u) == 0u) return (b & 7u) * (nb >> 3) + (b >> 3);
   return b;
 }
 // base of batch-reduce element r [ref: gemm ref :180-197]
@@ -136,7 +147,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(gcptr base) {
 __device__ __forceinline__ bool is_mx_type(int t) { return t == LIBXSMM_DATATYPE_MXFP4X2 || t == LIBXSMM_DATATYPE_MXBF8 || t == LIBXSMM_DATATYPE_MXHF8; }
 // scales of A (of_b = false) or B: one byte per 32 elements, so a byte distance D of the operand is D * (elements per byte) / 32 here
 __device__ __forceinline__ gcptr mx_scale_base(const GemmArgs& p, unsigned int bidx, unsigned long long r, bool of_b) {
-  if (p.batch_inner) bidx = of_b ? bidx / p.batch_inner : bidx % p.batch_inner;      // the scales step with their operand
+  if (p.batch_inner) {                                                                // the scales step with their operand
+    if (p.map2d_shift) {
+      const unsigned int sh = p.map2d_shift, wg = bidx >> 2, wgs_shift = 2u * sh - 2u, k = wg >> 3;
+      const unsigned int S = (wg & 7u) + 8u * (k >> wgs_shift), pl = ((k & ((1u << wgs_shift) - 1u)) << 2) | (bidx & 3u), nsi = p.batch_inner >> sh;
+      bidx = of_b ? ((S / nsi) << sh) + (pl >> sh) : ((S % nsi) << sh) + (pl & ((1u << sh) - 1u));
+    } else bidx = of_b ? bidx / p.batch_inner : bidx % p.batch_inner;
+  }
   gcptr base = of_b ? (gcptr)p.b_scf + (long long)bidx * p.bs_bscf : (gcptr)p.a_scf + (long long)bidx * p.bs_scf;
   const long long epb = ((of_b ? p.b_type : p.a_type) == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
   if (p.br_mode == 1) return list_entry((const void*)(size_t)base, r);
@@ -777,6 +794,102 @@ __global__ __launch_bounds__(256) void gemm_f32_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same algorithm for the case the headline benchmark is: a 1-D batch of independent 32x32x(32 br kchunks) problems with 16-byte
+// aligned strided operands, beta = 0 and no fused epilogue.  A launch of 4096 such problems is ONE round of waves that lasts ~10 us, so the
+// time every wave spends before its first load is issued is on the critical path of the whole launch.  The general kernel above reads a
+// 280-byte argument block in several dependent scalar loads, divides by the tile count and walks the batch / batch-reduce / epilogue
+// options; this one takes an 88-byte block (one scalar load round trip), has no option left to test, and in its single-chunk form (br = 1,
+// k = 32) has no loop either.
+// NTL: non-temporal operand loads.  Measured (tools/headline_probe.hip, profiles/r02_copy_floor.csv): with operands coming from HBM they
+// save 0.5 us of a 9.9 us launch (they do not displace the Infinity Cache's contents), but operands that ARE resident in the 256 MiB
+// Infinity Cache -- the normal case for a 48 MiB batch produced by the previous kernel -- are then not kept there: 8.7 instead of 5.8 us.
+// The launcher therefore asks for them only when one launch moves more than the Infinity Cache holds (they cannot be resident then).
+// ------------------------------------------------------------------------------------------------
+struct LeanF32Args {
+  const char* a; const char* b; char* c;
+  long long bs_a, bs_b, bs_c, brs_a, brs_b;          // batch strides, batch-reduce strides (bytes)
+  unsigned int nbatch, nchunks, kchunks, lda, ldb, ldc;   // nchunks = br_count * kchunks
+};
+// 16-byte operand load through a wave-uniform buffer resource with gfx950 cache-policy bits (aux: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX> __device__ __forceinline__ f32x4 ld16_pol(__amdgpu_buffer_rsrc_t r, unsigned int voffset) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, 0, AUX));
+}
+// POL 0: operands loaded `sc0 sc1`, C leaves as whole 16-byte pieces through the wave's LDS image, non-temporal.  Measured on the headline
+//        footprint (tools/policy_probe.hip, profiles/r02_cache_policy.txt): against plain loads + dword nt stores 9.95 vs 10.88 us with the
+//        operands in HBM AND 6.25 vs 6.7 us with the operands resident in the Infinity Cache -- no trade-off, so it is the default.
+// POL 1: operands loaded `nt`, C as dword nt stores: 9.65 us from HBM but 8.4 us on resident operands (an nt read is not kept in the
+//        Infinity Cache): only for launches that move more than the Infinity Cache holds, whose operands cannot be resident anyway.
+// POL 2: plain loads, dword nt stores (C not 16-byte aligned).
+template <bool TA, bool TB, bool SINGLE, int POL>
+__global__ __launch_bounds__(256) void gemm_f32_stream_kernel_lean(LeanF32Args p) {
+  constexpr int AUX = POL == 0 ? 17 : (POL == 1 ? 2 : 0);
+  __shared__ __attribute__((aligned(16))) float lds_all[4][2048];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int bidx = blockIdx.x * 4u + wave;
+  if (bidx >= p.nbatch) return;
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  float* lds = lds_all[wave];
+  const unsigned int lda = p.lda, ldb = p.ldb, ldc = p.ldc;
+  gcptr ar = (gcptr)p.a + (long long)bidx * p.bs_a, br = (gcptr)p.b + (long long)bidx * p.bs_b;
+  const unsigned int offA = ((lane >> 3) * lda + (lane & 7u) * 4u) * 4u;
+  const unsigned int offB = ((lane >> 3) * ldb + (lane & 7u) * 4u) * 4u;
+  const unsigned int stepA = 32u * lda, stepB = 32u * ldb;          // bytes per 8 rows
+  f32x4 ga[4], gb[4];
+  {
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar), rb = wave_rsrc(br);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) ga[x] = ld16_pol<AUX>(ra, x * stepA + offA);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) gb[x] = ld16_pol<AUX>(rb, x * stepB + offB);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  if (SINGLE) {
+    float af[16], bf[16];
+    tile_to_frag<TA>(af, ga, lds, (int)lane);
+    tile_to_frag<!TB>(bf, gb, lds + 1024, (int)lane);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc, 0, 0, 0);
+  } else {
+    const unsigned long long kstepA = TA ? 128ull : 128ull * lda, kstepB = TB ? 128ull * ldb : 128ull;
+    unsigned int kc = 0;
+    for (unsigned int t = 0; t < p.nchunks; ++t) {
+      float af[16], bf[16];
+      tile_to_frag<TA>(af, ga, lds, (int)lane);
+      tile_to_frag<!TB>(bf, gb, lds + 1024, (int)lane);
+      if (++kc == p.kchunks) { kc = 0; ar += p.brs_a; br += p.brs_b; }
+      if (t + 1 < p.nchunks) {        // chunk t+1 is in flight while the matrix core works on chunk t
+        const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + kc * kstepA), rb = wave_rsrc(br + kc * kstepB);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ga[x] = ld16_pol<AUX>(ra, x * stepA + offA);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) gb[x] = ld16_pol<AUX>(rb, x * stepB + offB);
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], af[s], acc, 0, 0, 0);
+    }
+  }
+  gptr ctile = (gptr)p.c + (long long)bidx * p.bs_c;
+  if (POL == 0) {
+    // C tile -> column-major LDS image (lanes along i: conflict free) -> whole 128-byte columns, 16 bytes per lane
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) lds[li + (unsigned int)jl_of(r2, (int)h) * 32u] = acc[r2];
+    const __amdgpu_buffer_rsrc_t rc = wave_rsrc((gcptr)ctile);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const unsigned int L = lane + 64u * x;
+      __builtin_amdgcn_raw_buffer_store_b128(((const u32x4*)lds)[L], rc, (int)(((L >> 3) * ldc + (L & 7u) * 4u) * 4u), 0, 2);
+    }
+  } else {
+    const unsigned int offC = (4u * h * ldc + li) * 4u;
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2)
+      st_stream((GM float*)(ctile + (unsigned long long)(((r2 & 3) + 8 * (r2 >> 2)) * ldc) * 4ull + offC), acc[r2]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32 streaming kernel, LDS-DMA form (MT x NT tiles of 32x32 per wave).  Same arithmetic as gemm_f32_stream_kernel;
 // the operand tiles of a 32-deep K chunk travel global -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no
 // ds_write), in the same two LDS images (linear [k][f] for the operand whose free index is contiguous, XOR-swizzled
@@ -805,7 +918,7 @@ __device__ __forceinline__ void frag_read(float (&w)[16], const float* lds, int 
     }
   }
 }
-template <int MT, int NT, bool TA, bool TB>
+template <int MT, int NT, bool TA, bool TB, int AUX = 0>
 __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds_all[4][(MT + NT) * 1024];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
@@ -842,12 +955,12 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs p) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int x = 0; x < 4; ++x)
-        __builtin_amdgcn_global_load_lds((GM const void*)(a0 + mt * tileA + offA[x]), (lds_vptr)((char*)lds + 4096 * mt + 1024 * x), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((GM const void*)(a0 + mt * tileA + offA[x]), (lds_vptr)((char*)lds + 4096 * mt + 1024 * x), 16, 0, AUX);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int x = 0; x < 4; ++x)
-        __builtin_amdgcn_global_load_lds((GM const void*)(b0 + nt * tileB + offB[x]), (lds_vptr)((char*)lds + 4096 * (MT + nt) + 1024 * x), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((GM const void*)(b0 + nt * tileB + offB[x]), (lds_vptr)((char*)lds + 4096 * (MT + nt) + 1024 * x), 16, 0, AUX);
   };
   if (total != 0) issue(ar + orgA, br + orgB);
   for (unsigned long long t = 0; t < total; ++t) {
@@ -869,6 +982,96 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs p) {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0);
   }
   static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<true, true>(acc[mt][nt], p, q, tc[mt][nt]); });
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 blocked kernel: the operand-reuse regime (libxsmm_hip_gemm_batch_strided_2d -- a blocked GEMM out of (BR)GEMM tiles).
+// With one tile per wave and wave-private operands every wave pulls its own 8 KiB per 16 matrix instructions out of L2: measured
+// (profiles/r02_wave_breakdown.json) 41-52 % matrix-core busy at 8 TB/s of L2 traffic, the waves stalled on instruction issue.  Here a
+// WORKGROUP owns a 128 x 128 macro tile of C (4 x 4 problems of 32^3, or 2 x 2 of 64^3) and its four waves a 64 x 64 quarter each:
+//   * per 32-deep K step the workgroup brings in 4 A blocks + 4 B blocks (32 KiB) ONCE, by LDS-DMA (global_load_lds_dwordx4: no
+//     staging VGPRs, no ds_write), wave w fetching A block w and B block w, into one half of a 64 KiB double buffer;
+//   * every wave reads the two A and two B fragments it needs (each block is used by two waves), then issues its share of the NEXT
+//     step's DMA into the other half and runs 64 MFMAs (4096 matrix-pipe cycles) on four independent accumulators;
+//   * one workgroup barrier per step: a buffer half is only rewritten after every wave has passed the barrier that follows its last read.
+// L2 -> CU traffic per matrix instruction drops 4x against the one-tile-per-wave kernels; images and fragment order are the same as in
+// gemm_f32_dma_kernel, so results stay bitwise the k-ordered fma chain.  NN layout, STRIDE or no batch-reduce, any epilogue.
+// MB = 32-blocks per problem edge (1: 32^3 problems, 2: 64^3 problems; K any multiple of 32).
+// ------------------------------------------------------------------------------------------------
+template <int MB>
+__global__ __launch_bounds__(256) void gemm_f32_blocked_kernel(GemmArgs p) {
+  constexpr int PPW = 4 / MB;                       // problems per workgroup edge
+  __shared__ __attribute__((aligned(16))) float lds_all[2][8][1024];
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  // macro tile of this workgroup: contiguous bands of macro columns per XCD (hardware workgroup g runs on XCD g % 8)
+  const unsigned int ni = p.batch_inner, nj = p.nbatch / p.batch_inner, MI = ni / PPW;
+  unsigned int g = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) g = (g & 7u) * (gridDim.x >> 3) + (g >> 3);
+  const unsigned int mj = g / MI, mi = g - mj * MI;
+  (void)nj;
+  // --- DMA duty of this wave: A block w (32 rows x 32 k) and B block w (32 k x 32 columns) of the macro tile, every step
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const unsigned int pa = mi * PPW + w / MB, pb = mj * PPW + w / MB;                   // problem that block w belongs to
+  gcptr a_blk = (gcptr)p.a + (long long)pa * p.bs_a + 128ull * (w % MB);               // + 32 rows per sub-block
+  gcptr b_blk = (gcptr)p.b + (long long)pb * p.bs_b + 128ull * ldb * (w % MB);         // + 32 columns per sub-block
+  unsigned int offA[4], offB[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const unsigned int L = lane + 64u * x, hi = L >> 3, lo = L & 7u;
+    offA[x] = (hi * lda + lo * 4u) * 4u;                                         // image [k][i] linear
+    offB[x] = (hi * ldb + ((lo ^ ((hi >> 1) & 7u)) * 4u)) * 4u;                    // image [j][8 x 16 B], chunk XOR-swizzled
+  }
+  const unsigned long long kstepA = 128ull * lda, kstepB = 128ull;
+  const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
+  const unsigned int kchunks = (unsigned int)p.k >> 5;
+  const unsigned long long total = p.br_count * kchunks;
+  auto issue = [&](gcptr a0, gcptr b0, int buf) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(a0 + offA[x]), (lds_vptr)((char*)&lds_all[buf][w][0] + 1024 * x), 16, 0, 0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(b0 + offB[x]), (lds_vptr)((char*)&lds_all[buf][4 + w][0] + 1024 * x), 16, 0, 0);
+  };
+  // --- compute duty: the 64 x 64 quarter (wi, wj) of the macro tile
+  const unsigned int wi = w & 1u, wj = w >> 1;
+  f32x16 acc[2][2];
+  TileCtx tc[2][2];
+  BatchPtrs q[2][2];
+  static_for<4>([&](auto idx) {
+    constexpr int mt = idx.value / 2, nt = idx.value % 2;
+    const unsigned int bi = mi * PPW + (2 * wi + mt) / MB, bj = mj * PPW + (2 * wj + nt) / MB;
+    q[mt][nt].a = nullptr; q[mt][nt].b = nullptr;
+    q[mt][nt].c = (gptr)p.c + (long long)bi * p.bs_c + (long long)bj * p.bs_c2;
+    q[mt][nt].d = p.d ? (gcptr)p.d + (long long)bi * p.bs_d : nullptr;
+    q[mt][nt].mask = p.relu_mask ? (GM unsigned char*)p.relu_mask + (long long)bi * p.bs_mask + (long long)bj * p.bs_mask2 : nullptr;
+    tc[mt][nt].i = (int)(32u * ((2 * wi + mt) % MB) + li); tc[mt][nt].j0 = (int)(32u * ((2 * wj + nt) % MB)); tc[mt][nt].h = (int)h; tc[mt][nt].ivalid = true;
+    tile_init<true, true>(acc[mt][nt], p, q[mt][nt], tc[mt][nt]);
+  });
+  unsigned long long r = 0; unsigned int kc = 0;
+  if (total != 0) issue(a_blk, b_blk, 0);
+  for (unsigned long long t = 0; t < total; ++t) {
+    const int buf = (int)(t & 1ull);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is ordered by the issuing wave's vmcnt only
+    __syncthreads();                                   // ... and by a barrier for the other waves: step t's eight blocks are in LDS
+    float af[2][16], bf[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) frag_read<false>(af[mt], &lds_all[buf][2 * wi + mt][0], (int)lane);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) frag_read<true>(bf[nt], &lds_all[buf][4 + 2 * wj + nt][0], (int)lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (++kc == kchunks) { kc = 0; ++r; }
+    if (t + 1 < total) issue(a_blk + (long long)r * brs_a + kc * kstepA, b_blk + (long long)r * brs_b + kc * kstepB, buf ^ 1);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nt][s2], af[mt][s2], acc[mt][nt], 0, 0, 0);
+  }
+  static_for<4>([&](auto idx) { constexpr int mt = idx.value / 2, nt = idx.value % 2; tile_store<true, true>(acc[mt][nt], p, q[mt][nt], tc[mt][nt]); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1045,7 +1248,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
 // A (VNNI-2: a dword = two k of one row, rows contiguous) is already coalesced and goes straight to VGPRs.
 // The LDS image is wave-private: no barrier, only s_waitcnt.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT>
+// AUX: cache-policy bits of the operand loads (0 default, 2 = nt for launches whose operands cannot be cache resident, see launch_gemm)
+template <int MT, int NT, int AUX>
 __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds_all[4][2][NT * 2048];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
@@ -1084,14 +1288,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
   auto issue = [&](const __amdgpu_buffer_rsrc_t& ra, const __amdgpu_buffer_rsrc_t& rb, int kc, char* image, u32x4 (&af)[MT][2]) {
 #pragma unroll
     for (int x = 0; x < NT * 2; ++x)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(image + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(image + 1024 * x), 16, (int)offB[x], 64 * kc, 0, AUX);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          af[mt][s][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)voffA[s][e] + 128 * mt, 64 * kc * (int)lda, 0);
+          af[mt][s][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)voffA[s][e] + 128 * mt, 64 * kc * (int)lda, AUX);
   };
   auto compute = [&](const char* image, const u32x4 (&af)[MT][2]) {
     u32x4 bfr[NT][2];
@@ -1611,6 +1815,39 @@ static bool f32_blob_ok(const GemmArgs& a) {
   if (off || (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B))) return false;
   return a.m <= 32 && a.n <= 32 && a.k <= 32 && a.lda <= 32 && a.ldb <= 32 && a.k * a.lda <= 1024 && a.n * a.ldb <= 1024;
 }
+// the lean streaming kernel: one 32x32 tile per problem, 1-D strided batch, plain or STRIDE batch-reduce with at least one block,
+// beta = 0, no fused epilogue, every 32-bit offset inside a tile representable
+static bool f32_lean_ok(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_LEAN"); return e && e[0] == '0'; }();
+  if (off || a.m != 32 || a.n != 32 || a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.br_count < 1) return false;
+  if (!(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) || a.colbias || a.act || a.vnni_c) return false;
+  if ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c) & 3ull) != 0) return false;
+  return a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22) && a.br_count * (unsigned long long)(a.k >> 5) < (1ull << 31);
+}
+// the workgroup-cooperative blocked kernel: 2-D batch whose grid divides into 128 x 128 macro tiles, square 32^3 / 64^3 problems,
+// no transposes, plain or STRIDE batch-reduce, 16-byte aligned operands, 32-bit offsets inside a block
+static bool f32_blocked_ok(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOCKED"); return e && e[0] == '0'; }();
+  if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3)) return false;
+  if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B)) || a.vnni_c) return false;
+  if (!((a.m == 32 && a.n == 32) || (a.m == 64 && a.n == 64)) || (a.k % 32) != 0 || a.k <= 0) return false;
+  const unsigned int ppw = 4 / (a.m / 32), ni = a.batch_inner, nj = a.nbatch / a.batch_inner;
+  if (ni % ppw || nj % ppw) return false;
+  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
+    (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) | (unsigned long long)((long long)a.lda * 4) | (unsigned long long)((long long)a.ldb * 4);
+  return (bits & 15ull) == 0ull && a.lda < (1 << 22) && a.ldb < (1 << 22);
+}
+// Non-temporal operand loads for the streaming kernels?  The calling thread's hint decides (libxsmm_hip_set_streaming_hint), by default the
+// size of the launch: operands of a launch that moves more than the 256 MiB Infinity Cache holds cannot be resident in it, so nothing is lost
+// by not keeping them (measured: +7..10 % on such launches), while smaller launches keep cacheable operands (nt reads of RESIDENT operands
+// measured 50 % slower).  Operands shared by the batch (stride 0) or re-used by a 2-D batch are always cacheable.
+static int typesize_c(const GemmArgs& a) { return a.c_type == LIBXSMM_DATATYPE_F32 ? 4 : 2; }
+static bool stream_nt(const GemmArgs& a, int elem_bytes_ab, int elem_bytes_c) {
+  if (a.batch_inner || a.list_a || a.bs_a == 0 || a.bs_b == 0 || a.stream_hint == 1) return false;
+  if (a.stream_hint == 2) return true;
+  const unsigned long long per = a.br_count * (unsigned long long)a.k * (unsigned long long)(a.m + a.n) * elem_bytes_ab + (unsigned long long)a.m * a.n * elem_bytes_c;
+  return per * a.nbatch > (256ull << 20);
+}
 static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
   static const int mode = []() { const char* e = getenv("LIBXSMM_HIP_F32_DMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
   return mode;
@@ -1643,10 +1880,27 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   GemmArgs a = a_in;
   auto wave_grid = [&](int tm, int tn) {
     a.tiles_m = (a.m + tm - 1) / tm; a.tiles_n = (a.n + tn - 1) / tn;
+    a.map2d_shift = 0;
+    if (a.batch_inner && a.tiles_m * a.tiles_n == 1) {           // 2-D batch, one tile per element: deal compact super-tiles to the XCDs
+      static const int want = []() { const char* e = getenv("LIBXSMM_HIP_2D_SUPERTILE"); const int v = e ? atoi(e) : 16; return (v == 0 || v == 8 || v == 16 || v == 32) ? v : 16; }();
+      const unsigned int ni = a.batch_inner, nj = a.nbatch / a.batch_inner;
+      for (int t = want; t >= 8 && !a.map2d_shift; t >>= 1)
+        if (ni % t == 0 && nj % t == 0 && ((ni / t) * (nj / t)) % 8 == 0) a.map2d_shift = t == 32 ? 5 : (t == 16 ? 4 : 3);
+    }
     const long long tiles = (long long)a.tiles_m * a.tiles_n * (long long)a.nbatch;
     return dim3((unsigned int)((tiles + 3) / 4));
   };
   dim3 grid;
+  // 2-D batches of exact f32 32^3 / 64^3 problems (K any multiple of 32), NN, strided: the workgroup-cooperative blocked kernel
+  if (a.batch_inner && (pl.path == P_F32_1x1 || pl.path == P_F32_2x2) && f32_blocked_ok(a)) {
+    const int mb = a.m / 32, ppw = 4 / mb;
+    const unsigned int ni = a.batch_inner, nj = a.nbatch / a.batch_inner;
+    a.tiles_m = a.tiles_n = mb; a.map2d_shift = 0;
+    grid = dim3((ni / ppw) * (nj / ppw));
+    if (mb == 1) { if (kernel_name) *kernel_name = "gemm_f32_blocked_kernel<1>"; hipLaunchKernelGGL((gemm_f32_blocked_kernel<1>), grid, dim3(256), 0, st, a); }
+    else { if (kernel_name) *kernel_name = "gemm_f32_blocked_kernel<2>"; hipLaunchKernelGGL((gemm_f32_blocked_kernel<2>), grid, dim3(256), 0, st, a); }
+    return (int)hipGetLastError();
+  }
   switch (pl.path) {
     case P_F32_T16: grid = wave_grid(16, 16); hipLaunchKernelGGL(gemm_mfma_f32_t16_kernel, grid, dim3(256), 0, st, a); break;
     case P_F32_1x1:
@@ -1658,6 +1912,32 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<1, 1, true, false>), grid, dim3(256), 0, st, a);
         else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<1, 1, false, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_f32_dma_kernel<1, 1, true, true>), grid, dim3(256), 0, st, a);
+      }
+      else if (pl.exact && operands_aligned16(a, 4) && f32_lean_ok(a)) {
+        const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
+        LeanF32Args la;
+        la.a = a.a; la.b = a.b; la.c = a.c; la.bs_a = a.bs_a; la.bs_b = a.bs_b; la.bs_c = a.bs_c;
+        la.brs_a = a.br_mode == 3 ? a.br_stride_a : 0; la.brs_b = a.br_mode == 3 ? a.br_stride_b : 0;
+        la.nbatch = a.nbatch; la.kchunks = (unsigned int)a.k >> 5; la.nchunks = (unsigned int)a.br_count * la.kchunks;
+        la.lda = (unsigned int)a.lda; la.ldb = (unsigned int)a.ldb; la.ldc = (unsigned int)a.ldc;
+        if (kernel_name) *kernel_name = "gemm_f32_stream_kernel_lean";
+        // cache policy (see the kernel).  Streaming hint of the calling thread (libxsmm_hip_set_streaming_hint): 2 = operands are read once
+        // from HBM -> nt loads; 1 = operands are re-read / cache resident -> never nt; 0 (default) = decide by size: a launch that moves
+        // more than the Infinity Cache holds cannot have resident operands.  LIBXSMM_HIP_F32_POLICY=0|1|2 forces a kernel variant.
+        static const int pol_env = []() { const char* e = getenv("LIBXSMM_HIP_F32_POLICY"); return e ? atoi(e) : -1; }();
+        const unsigned long long footprint = (unsigned long long)a.nbatch * (a.br_count * (unsigned long long)(a.k) * 256ull + 4096ull);
+        const bool c16 = ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)((long long)a.ldc * 4)) & 15ull) == 0ull);
+        int pol = stream_nt(a, 4, 4) ? 1 : 0;
+        (void)footprint;
+        if (pol_env >= 0 && pol_env <= 2) pol = pol_env;
+        if (pol == 0 && !c16) pol = 2;
+#define LAUNCH_LEAN__(TA_, TB_, S_, P_) hipLaunchKernelGGL((gemm_f32_stream_kernel_lean<TA_, TB_, S_, P_>), grid, dim3(256), 0, st, la)
+#define LAUNCH_LEAN_S_(TA_, TB_, S_) do { if (pol == 0) LAUNCH_LEAN__(TA_, TB_, S_, 0); else if (pol == 1) LAUNCH_LEAN__(TA_, TB_, S_, 1); else LAUNCH_LEAN__(TA_, TB_, S_, 2); } while (0)
+#define LAUNCH_LEAN_(TA_, TB_) do { if (la.nchunks == 1) LAUNCH_LEAN_S_(TA_, TB_, true); else LAUNCH_LEAN_S_(TA_, TB_, false); } while (0)
+        if (!ta && !tb) LAUNCH_LEAN_(false, false); else if (ta && !tb) LAUNCH_LEAN_(true, false); else if (!ta && tb) LAUNCH_LEAN_(false, true); else LAUNCH_LEAN_(true, true);
+#undef LAUNCH_LEAN_S_
+#undef LAUNCH_LEAN__
+#undef LAUNCH_LEAN_
       }
       else if (pl.exact && operands_aligned16(a, 4) && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22)) {
         const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
@@ -1677,7 +1957,8 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       if (pl.exact && operands_aligned16(a, 4) && f32_dma_mode() >= 1 && a.lda < (1 << 22) && a.ldb < (1 << 22)) {
         const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
         if (kernel_name) *kernel_name = "gemm_f32_dma_kernel<2,2>";
-        if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, false, false>), grid, dim3(256), 0, st, a);
+        if (!ta && !tb && stream_nt(a, 4, 4)) hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, false, false, 2>), grid, dim3(256), 0, st, a);
+        else if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, false, false>), grid, dim3(256), 0, st, a);
         else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, true, false>), grid, dim3(256), 0, st, a);
         else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, false, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_f32_dma_kernel<2, 2, true, true>), grid, dim3(256), 0, st, a);
@@ -1688,13 +1969,21 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_BF16_1x1:
       grid = wave_grid(32, 32);
-      if (pl.exact && bf16_stream_ok(a)) { if (kernel_name) *kernel_name = "gemm_bf16_stream_kernel<1,1>"; hipLaunchKernelGGL((gemm_bf16_stream_kernel<1, 1>), grid, dim3(256), 0, st, a); }
+      if (pl.exact && bf16_stream_ok(a)) {
+        if (kernel_name) *kernel_name = "gemm_bf16_stream_kernel<1,1>";
+        if (stream_nt(a, 2, typesize_c(a))) hipLaunchKernelGGL((gemm_bf16_stream_kernel<1, 1, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_stream_kernel<1, 1, 0>), grid, dim3(256), 0, st, a);
+      }
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), grid, dim3(256), 0, st, a);
       break;
     case P_BF16_2x2:
       grid = wave_grid(64, 64);
-      if (pl.exact && bf16_stream_ok(a)) { if (kernel_name) *kernel_name = "gemm_bf16_stream_kernel<2,2>"; hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2>), grid, dim3(256), 0, st, a); }
+      if (pl.exact && bf16_stream_ok(a)) {
+        if (kernel_name) *kernel_name = "gemm_bf16_stream_kernel<2,2>";
+        if (stream_nt(a, 2, typesize_c(a))) hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2, 0>), grid, dim3(256), 0, st, a);
+      }
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
       break;

@@ -68,6 +68,8 @@ struct GemmArgs {
   // 2-D strided batch (blocked GEMM out of BRGEMM tiles): element e = (i, j), i = e % batch_inner fastest;
   // A steps with i (bs_a), B with j (bs_b), C / the bitmask with both (bs_c, bs_mask along i; bs_c2, bs_mask2 along j), the bias with i.
   unsigned int batch_inner;                         // 0: 1-D batch
+  int stream_hint;                                  // libxsmm_hip_set_streaming_hint of the calling thread: 0 auto, 1 operands re-read / cache-resident, 2 read once from HBM
+  unsigned int map2d_shift;                         // set by launch_gemm: 0 = linear element order, s = super-tiles of 2^s x 2^s elements per XCD
   long long bs_c2, bs_mask2;
   long long br_stride_a, br_stride_b;               // bytes
   unsigned long long br_count;
@@ -190,6 +192,7 @@ void* rt_stream();
 struct ThreadState {
   void* stream = nullptr;     // hipStream_t
   int async = -1;             // -1: not initialised from the environment yet
+  int stream_hint = 0;        // libxsmm_hip_set_streaming_hint
   int device = -1;
   int last_error = 0;
   std::string last_error_msg;

@@ -277,6 +277,8 @@ ThreadState& tls() {
     const char* a = std::getenv("LIBXSMM_HIP_ASYNC"); const char* s = std::getenv("LIBXSMM_HIP_SYNC");
     st.async = (a && std::atoi(a) != 0) ? 1 : 0;
     if (s && std::atoi(s) != 0) st.async = 0;
+    const char* h = std::getenv("LIBXSMM_HIP_STREAMING");
+    if (h) { const int v = std::atoi(h); st.stream_hint = (v >= 0 && v <= 2) ? v : 0; }
   }
   return st;
 }
@@ -345,6 +347,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   a.bs_a = b.s[0]; a.bs_b = b.s[1]; a.bs_c = b.s[2]; a.bs_d = b.s[3]; a.bs_mask = b.s[4];
   a.nbatch = (unsigned int)b.count;
   a.batch_inner = (unsigned int)b.inner; a.bs_c2 = b.c2; a.bs_mask2 = b.mask2;
+  a.stream_hint = tls().stream_hint;
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.lda = (int)d.lda; a.ldb = (int)d.ldb; a.ldc = (int)d.ldc;
   a.flags = d.flags; a.a_type = d.a_type; a.b_type = d.b_type; a.c_type = d.c_type;
   a.vnni_c = (d.flags & LIBXSMM_GEMM_FLAG_VNNI_C) ? 1 : 0;
@@ -1323,6 +1326,8 @@ LIBXSMM_API int libxsmm_hip_get_device(void) { int d = 0; if (hipGetDevice(&d) !
 LIBXSMM_API void libxsmm_hip_set_stream(void* s) { tls().stream = s; tls().async = 1; }
 LIBXSMM_API void* libxsmm_hip_get_stream(void) { return tls().stream; }
 LIBXSMM_API void libxsmm_hip_set_async(int enable) { tls().async = enable ? 1 : 0; }
+LIBXSMM_API void libxsmm_hip_set_streaming_hint(int mode) { tls().stream_hint = (mode >= 0 && mode <= 2) ? mode : 0; }
+LIBXSMM_API int libxsmm_hip_get_streaming_hint(void) { return tls().stream_hint; }
 LIBXSMM_API int libxsmm_hip_get_async(void) { return tls().async; }
 LIBXSMM_API void libxsmm_hip_sync(void) { (void)hip_ok(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize"); }
 LIBXSMM_API int libxsmm_hip_get_last_error(void) { return tls().last_error; }

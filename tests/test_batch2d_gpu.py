@@ -82,12 +82,13 @@ def _blocked(dtype, m, ni, nj, br, fused=False, seed=3):
     return api.hip_kernel_name(h, 1).decode()
 
 
-@pytest.mark.parametrize("m,ni,nj,br", [(32, 8, 8, 4), (32, 5, 3, 1), (16, 8, 8, 6), (64, 4, 6, 3), (32, 16, 16, 2)])
+# (32, 16), (64, 32), (16, 64): grids that the launch deals to the XCDs as 8x8 / 16x16 super-tiles; the others take the linear order
+@pytest.mark.parametrize("m,ni,nj,br", [(32, 8, 8, 4), (32, 5, 3, 1), (16, 8, 8, 6), (64, 4, 6, 3), (32, 16, 16, 2), (32, 32, 16, 2), (32, 64, 32, 1), (16, 16, 64, 3), (64, 32, 16, 1)])
 def test_f32_2d_batch_is_the_nested_loop(m, ni, nj, br):
     _blocked(DT.F32, m, ni, nj, br)
 
 
-@pytest.mark.parametrize("m,ni,nj,br", [(32, 8, 8, 4), (64, 8, 4, 3), (64, 3, 5, 1)])
+@pytest.mark.parametrize("m,ni,nj,br", [(32, 8, 8, 4), (64, 8, 4, 3), (64, 3, 5, 1), (32, 32, 16, 2), (64, 16, 32, 2)])
 def test_bf16_2d_batch_is_the_nested_loop(m, ni, nj, br):
     _blocked(DT.BF16, m, ni, nj, br)
 

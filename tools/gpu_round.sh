@@ -5,7 +5,7 @@ TAG=${1:-r02}
 WHAT=${2:-all}
 mkdir -p gpurun_out
 if [ "$WHAT" = all ] || [ "$WHAT" = tests ]; then
-  timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -p no:cacheprovider > gpurun_out/pytest_gpu_$TAG.log 2>&1
+  timeout 900 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/pytest_gpu_$TAG.log 2>&1
   echo "pytest rc=$?"; tail -15 gpurun_out/pytest_gpu_$TAG.log
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then

@@ -25,6 +25,12 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/bench_write -- $B --eager --no-l3 --min-seconds 0.002 --manifest $OUT/bench_write_manifest.json > $OUT/bench_write.json 2> $OUT/bench_write.err
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/bench_mfma -- $B --eager --no-l3 --min-seconds 0.002 --manifest $OUT/bench_mfma_manifest.json > $OUT/bench_mfma.json 2> $OUT/bench_mfma.err
 fi
+if [ "$WHAT" = sq ]; then
+  # where the waves of the operand-reuse kernels spend their time: SQ wave-cycle breakdown and L2 hit rate, two passes over a few entries
+  ONLY=${3:-reuse:f32_m32_blocked,reuse:f32_m64_blocked,reuse:bf16_m32_blocked,reuse:bf16_m64_blocked}
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq_waves -- $B --eager --only $ONLY --min-seconds 0.002 --manifest $OUT/sq_waves_manifest.json > $OUT/sq_waves.json 2> $OUT/sq_waves.err
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $OUT/sq_l2 -- $B --eager --only $ONLY --min-seconds 0.002 --manifest $OUT/sq_l2_manifest.json > $OUT/sq_l2.json 2> $OUT/sq_l2.err
+fi
 if [ "$WHAT" = all ] || [ "$WHAT" = probe ]; then
   if [ -x $ROOT/tools/headline_probe ]; then
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/probe_trace -- $ROOT/tools/headline_probe 4096 6 1 > $OUT/probe_trace.txt 2> $OUT/probe_trace.err

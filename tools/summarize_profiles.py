@@ -27,7 +27,7 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 HBM_PEAK = 8000.0e9
-SIMDS = 1024
+SIMDS = 128        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (8 x the cycles of the launch): 1024 SIMDs / 8
 
 
 def ours(name):
@@ -70,6 +70,7 @@ def split_by_manifest(disp, manifest):
     return res
 
 
+trace_us = {}       # label -> rocprofv3 kernel duration of the un-profiled trace pass
 # ---- 1. kernel durations per workload -------------------------------------------------------------------------------------
 stats_rows = []
 kt = newest("bench_trace", "*_kernel_trace.csv")
@@ -87,6 +88,7 @@ if kt and os.path.exists(mf):
             avg = sum(d) / len(d)
             names = collections.Counter(x[1].split("(")[0].replace("void xamd::", "") for x in seg)
             gbs = e["algorithmic_bytes_per_launch"] / (avg * 1e-6)
+            trace_us[label] = round(avg, 3)
             w.writerow([label, names.most_common(1)[0][0], len(d), f"{avg:.3f}", f"{min(d):.3f}", f"{max(d):.3f}", e["algorithmic_bytes_per_launch"],
                         f"{gbs / 1e9:.1f}", f"{gbs / HBM_PEAK:.4f}", f"{e['flops_per_launch'] / (avg * 1e-6) / 1e9:.1f}", f"{e['us_per_launch_events']:.3f}"])
             print(f"{label:28s} {names.most_common(1)[0][0][:44]:44s} n={len(d):6d} avg {avg:9.3f} us  frac_hbm {gbs / HBM_PEAK:.3f}")
@@ -107,6 +109,7 @@ def counter_pass(sub, names):
         if ours(r["Kernel_Name"]) and r["Counter_Name"] in names:
             d = int(r["Dispatch_Id"])
             acc[d][r["Counter_Name"]] = acc[d].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            acc[d]["_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             kn[d] = r["Kernel_Name"]
     disp = [(d, kn[d], acc[d]) for d in sorted(acc)]
     return split_by_manifest(disp, json.load(open(m)))
@@ -134,8 +137,9 @@ if fetch and write:
 mfma = counter_pass("bench_mfma", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"])
 if mfma:
     out = {"source": f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of `python bench.py --eager`, tools/profile_paths.sh {tag}",
-           "definition": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs): the share of SIMD-cycles of the launch in which the matrix pipe was busy "
-                         "(the gfx94x MfmaUtil formula; GRBM_GUI_ACTIVE = cycles the GPU was active for the dispatch).  expected_mfma_cycles = the launch's MFMA instructions x their issue "
+           "definition": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of SIMD-cycles of the launch in which the matrix pipe was busy "
+                         "(the gfx94x MfmaUtil formula; GRBM_GUI_ACTIVE = cycles the GPU was active for the dispatch, longer than the un-profiled launch because counter collection adds set-up time: "
+                         "mfma_busy_frac_unprofiled rescales the same busy cycles to the kernel duration of the trace pass at the clock observed here).  expected_mfma_cycles = the launch's MFMA instructions x their issue "
                          "cycles (f32 32x32x2: 64, 16x16x4: 32; bf16 32x32x16: 32 per SIMD), a cross-check of the counter's unit.",
            "workloads": {}}
     for label, (e, seg) in mfma.items():
@@ -143,17 +147,49 @@ if mfma:
             continue
         n = len(seg)
         busy = sum(x[2].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for x in seg) / n
-        cu = sum(x[2].get("SQ_BUSY_CU_CYCLES", 0.0) for x in seg) / n
         gui = sum(x[2].get("GRBM_GUI_ACTIVE", 0.0) for x in seg) / n
         flops = e["flops_per_launch"]
         per_mfma_flops, cyc = (4096.0, 64.0) if e["dtype"] == "f32" else (32768.0, 32.0)
         expected = flops / per_mfma_flops * cyc
-        out["workloads"][label] = {"kernel": e["kernel"], "launches_averaged": n, "SQ_VALU_MFMA_BUSY_CYCLES": round(busy, 1), "SQ_BUSY_CU_CYCLES": round(cu, 1), "GRBM_GUI_ACTIVE": round(gui, 1),
-                                   "mfma_busy_frac": round(busy / (gui * SIMDS), 4) if gui > 0 else None, "expected_mfma_cycles": round(expected, 1),
-                                   "counter_over_expected": round(busy / expected, 3) if expected > 0 else None}
+        us_pmc = sum(x[2].get("_us", 0.0) for x in seg) / n
+        clock_ghz = min(2.4, gui / 8.0 / (us_pmc * 1e3)) if us_pmc > 0 else 0.0   # cycles per ns while the counters were on (GUI_ACTIVE also covers the
+                                                                                   # dispatch set-up of a short launch, hence the cap at the 2.4 GHz maximum)
+        us_trace = trace_us.get(label)
+        out["workloads"][label] = {"kernel": e["kernel"], "launches_averaged": n, "SQ_VALU_MFMA_BUSY_CYCLES": round(busy, 1), "GRBM_GUI_ACTIVE": round(gui, 1),
+                                   "kernel_us_with_counters_on": round(us_pmc, 3), "effective_clock_GHz": round(clock_ghz, 3),
+                                   "mfma_busy_frac": round(busy / (gui * SIMDS), 4) if gui > 0 else None,
+                                   "kernel_us_unprofiled": us_trace,
+                                   "mfma_busy_frac_unprofiled": round(busy / (1024.0 * us_trace * 1e3 * clock_ghz), 4) if (us_trace and clock_ghz > 0) else None,
+                                   "expected_mfma_cycles": round(expected, 1), "counter_over_expected": round(busy / expected, 3) if expected > 0 else None}
         print(f"{label:28s} mfma busy {busy:14.0f}  gui {gui:10.0f}  frac {busy / (gui * SIMDS) if gui > 0 else 0:.4f}  counter/expected {busy / expected if expected else 0:.3f}")
     json.dump(out, open(os.path.join(dst, f"{tag}_mfma_busy.json"), "w"), indent=1)
 
+
+# ---- 3b. wave-cycle breakdown / L2 hit rate of selected entries ("sq" mode of profile_paths.sh) -------------------------------------------
+SQN = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+sq, l2 = counter_pass("sq_waves", SQN), counter_pass("sq_l2", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"])
+if sq or l2:
+    out = {"source": f"rocprofv3 --pmc (SQ pass, TCC pass) of `python bench.py --eager --only ...`, tools/profile_paths.sh {tag} sq",
+           "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_ANY count quad-cycles summed over waves; WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = issue stall (matrix pipe busy, dependency)", "workloads": {}}
+    for label in list(sq) + [k for k in l2 if k not in sq]:
+        d = {}
+        if label in sq and sq[label][1]:
+            seg = sq[label][1]
+            for c in SQN:
+                d[c] = round(sum(x[2].get(c, 0.0) for x in seg) / len(seg), 1)
+            wc = d.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+            d["share_wait_any"] = round(d.get("SQ_WAIT_ANY", 0.0) / wc, 3); d["share_wait_inst"] = round(d.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3); d["share_active"] = round(d.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3)
+            if d.get("GRBM_GUI_ACTIVE"):
+                d["mfma_busy_frac"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * 128), 4)
+        if label in l2 and l2[label][1]:
+            seg = l2[label][1]
+            for c in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
+                d[c] = round(sum(x[2].get(c, 0.0) for x in seg) / len(seg), 1)
+            if d["TCC_HIT_sum"] + d["TCC_MISS_sum"] > 0:
+                d["l2_hit_rate"] = round(d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"]), 4)
+        out["workloads"][label] = d
+        print(label, json.dumps(d))
+    json.dump(out, open(os.path.join(dst, f"{tag}_wave_breakdown.json"), "w"), indent=1)
 
 # ---- 4./5. plain --stats tables ---------------------------------------------------------------------------------------------------------
 def copy_stats(sub, outname, keep):
