@@ -124,8 +124,9 @@ struct BcscArgs {
   const char* a; const char* bvals; char* c;
   const unsigned int* colptr; const unsigned int* rowidx;
   int M, N, K, m_blocks, bk, bn, nblk_n;
-  int a_type, c_type, vnni_a, beta0;
+  int a_type, b_type, c_type, vnni_a, beta0;      // 8-bit integers: a_type / b_type in {I8, U8}, exactly one unsigned, c_type I32, A VNNI-4
   void* table;                        // workspace for the inverted pattern: nblk_n * (K / bk) words (may be NULL)
+  int table_ready;                    // the table already holds this call's inverted pattern (host-resident pattern, cached per kernel)
 };
 
 // ---- run-time specialised sparse kernels (jit.cpp) ------------------------------------------------------
@@ -167,6 +168,9 @@ struct KernelCtx {
   JitKernel* jit = nullptr;         // pattern-specialised kernel (nullptr: precompiled kernels serve)
   std::vector<unsigned int> h_ptr, h_idx, h_vmap;   // host pattern kept while specialisation is deferred to the first batched launch
   struct EqnPlan* eqn = nullptr;    // K_MEQN: the evaluation plan (meqn.cpp)
+  // K_BCSC: patterns that arrived in HOST memory, inverted on the host once and kept on the device ([colptr | rowidx | table] per entry)
+  struct BcscCached { std::vector<unsigned int> pattern; unsigned int* d_block = nullptr; };
+  std::vector<BcscCached> bcsc_cache;
   int device = 0;
   const char* kname_single = "";                 // static strings or strings owned by a never-shrinking table
   const char* kname_batched = "";

@@ -250,6 +250,7 @@ void free_ctx_locked(KernelCtx* c) {
   if (c->d_vmap) (void)hipFree(c->d_vmap);
   if (c->jit) jit_release(c->jit);
   if (c->eqn) free_meqn_plan(c->eqn);
+  for (auto& e : c->bcsc_cache) if (e.d_block) (void)hipFree(e.d_block);
   g_slots[c->slot] = nullptr; g_free_slots.push_back(c->slot);
   delete c;
 }
@@ -680,14 +681,55 @@ void run_bcsc(KernelCtx* k, const void* param) {
   if (!p->b.quaternary) { set_error(-2, "BCSC kernel needs the block-column count in b.quaternary"); return; }
   const unsigned long long nblk_n = *(const unsigned long long*)p->b.quaternary;   // [ref: spmm_kernel.c:451-456]
   a.M = k->packed_width; a.N = (int)d.ldc; a.K = (int)d.k; a.m_blocks = (int)d.m; a.bk = k->bk; a.bn = k->bn; a.nblk_n = (int)nblk_n;
-  a.a_type = d.a_type; a.c_type = d.c_type; a.vnni_a = (d.flags & LIBXSMM_GEMM_FLAG_VNNI_A) ? 1 : 0; a.beta0 = (d.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 1 : 0;
+  a.a_type = d.a_type; a.b_type = d.b_type; a.c_type = d.c_type; a.vnni_a = (d.flags & LIBXSMM_GEMM_FLAG_VNNI_A) ? 1 : 0; a.beta0 = (d.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 1 : 0;
   a.a = (const char*)p->a.primary; a.bvals = (const char*)p->b.primary; a.c = (char*)p->c.primary;
+  if (!p->b.secondary || !p->b.tertiary) { set_error(-2, "BCSC kernel needs colptr in b.secondary and rowidx in b.tertiary"); return; }
+  if (k->device != cur_device() && !k->bcsc_cache.empty()) { set_error(-3, "BCSC kernel holds a cached pattern on device %d but is called on device %d", k->device, cur_device()); return; }
+  const int nkb = (a.bk > 0 && a.K % a.bk == 0) ? a.K / a.bk : 0;
+  hipPointerAttribute_t attr;
+  const auto on_host = [&](const void* q) {
+    const hipError_t e = hipPointerGetAttributes(&attr, q);
+    const bool host = (e != hipSuccess) || attr.type == hipMemoryTypeUnregistered || attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return host;
+  };
+  if (nkb > 0 && on_host(p->b.secondary) && on_host(p->b.tertiary)) {
+    // The pattern arrived in HOST memory (the reference's calling convention: plain malloc'd colptr / rowidx [ref: spmm_kernel.c:306-347]).
+    // It is readable here, so it is inverted on the host -- table[n-block][k-block] = block id -- and kept on the device with its key:
+    // a pattern rarely changes between calls, and a call with a known pattern then costs no staging copy and no inversion kernel.
+    const unsigned int* hc = (const unsigned int*)p->b.secondary; const unsigned int* hr = (const unsigned int*)p->b.tertiary;
+    const unsigned int nnzb = hc[nblk_n];
+    std::vector<unsigned int> key; key.reserve(2 + nblk_n + 1 + nnzb);
+    key.push_back((unsigned int)nblk_n); key.push_back((unsigned int)nkb);
+    key.insert(key.end(), hc, hc + nblk_n + 1); key.insert(key.end(), hr, hr + nnzb);
+    static std::mutex cache_lock;
+    std::lock_guard<std::mutex> guard(cache_lock);
+    unsigned int* blockp = nullptr;
+    for (auto& e : k->bcsc_cache) if (e.pattern == key) { blockp = e.d_block; break; }
+    const size_t n_ptr = (size_t)nblk_n + 1, n_idx = std::max<size_t>(1, nnzb), n_tab = std::max<size_t>(1, (size_t)nblk_n * nkb);
+    if (!blockp) {
+      std::vector<unsigned int> img(n_ptr + n_idx + n_tab, 0xffffffffu);
+      std::copy(hc, hc + n_ptr, img.begin()); std::copy(hr, hr + nnzb, img.begin() + n_ptr);
+      for (unsigned long long nb = 0; nb < nblk_n; ++nb) {
+        if (hc[nb] > hc[nb + 1] || hc[nb + 1] > nnzb) { set_error(-2, "BCSC colptr is not monotone"); return; }
+        for (unsigned int b = hc[nb]; b < hc[nb + 1]; ++b) {
+          if (hr[b] >= (unsigned int)nkb) { set_error(-2, "BCSC rowidx[%u] = %u is outside the %d k-blocks", b, hr[b], nkb); return; }
+          img[n_ptr + n_idx + nb * nkb + hr[b]] = b;
+        }
+      }
+      if (!hip_ok(hipMalloc((void**)&blockp, img.size() * sizeof(unsigned int)), "hipMalloc(BCSC pattern)")) return;
+      if (!hip_ok(hipMemcpy(blockp, img.data(), img.size() * sizeof(unsigned int), hipMemcpyHostToDevice), "hipMemcpy(BCSC pattern)")) return;
+      if (k->bcsc_cache.size() >= 4) { retire_block(k->bcsc_cache.front().d_block); k->bcsc_cache.erase(k->bcsc_cache.begin()); }   // a kernel in flight may still read it
+      k->bcsc_cache.push_back(KernelCtx::BcscCached{std::move(key), blockp});
+      k->device = cur_device();
+    }
+    a.colptr = blockp; a.rowidx = blockp + n_ptr; a.table = blockp + n_ptr + n_idx; a.table_ready = 1;
+  } else {
   a.colptr = (const unsigned int*)device_visible(p->b.secondary, (size_t)(nblk_n + 1) * sizeof(unsigned int));
   if (!a.colptr) { set_error(-2, "BCSC kernel needs colptr in b.secondary"); return; }
   // rowidx: a device array is used in place (no size needed, no host round trip -> capturable in a hipGraph); a host
   // array is staged, its length colptr[nblk_n] being host-readable in that case
   {
-    hipPointerAttribute_t attr;
     const bool idx_on_device = (hipPointerGetAttributes(&attr, p->b.tertiary) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged));
     (void)hipGetLastError();
     if (idx_on_device) a.rowidx = (const unsigned int*)p->b.tertiary;
@@ -700,8 +742,9 @@ void run_bcsc(KernelCtx* k, const void* param) {
       a.rowidx = (const unsigned int*)device_visible(p->b.tertiary, (size_t)std::max(1u, nnzb) * sizeof(unsigned int));
     }
   }
+  if (nkb > 0) a.table = workspace((size_t)std::max(1, a.nblk_n) * (size_t)nkb * sizeof(unsigned int));
+  }
   if (!a.a || !a.bvals || !a.c || !a.rowidx) { set_error(-2, "BCSC kernel called with a NULL operand"); return; }
-  if (a.bk > 0 && a.K % a.bk == 0) a.table = workspace((size_t)std::max(1, a.nblk_n) * (size_t)(a.K / a.bk) * sizeof(unsigned int));
   const char* kname = nullptr;
   const int err = launch_bcsc(a, tls().stream, &kname);
   if (kname) k->kname_single = k->kname_batched = kname;
@@ -1169,9 +1212,13 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_bcsc(libxsmm_gemm_
   if (tilecfg_halfset((unsigned int)flags)) return nullptr;                                            // [ref: libxsmm_main.c:3664-3667]
   const bool f32 = s.a_in_type == LIBXSMM_DATATYPE_F32 && s.b_in_type == LIBXSMM_DATATYPE_F32 && s.out_type == LIBXSMM_DATATYPE_F32;
   const bool bf16 = s.a_in_type == LIBXSMM_DATATYPE_BF16 && s.b_in_type == LIBXSMM_DATATYPE_BF16 && (s.out_type == LIBXSMM_DATATYPE_BF16 || s.out_type == LIBXSMM_DATATYPE_F32);
-  if (!(f32 || bf16)) return nullptr;
+  // 8-bit integers: unsigned A x signed B or signed A x unsigned B -> int32, A in VNNI-4 [ref: samples/xgemm_sparse/spmm_kernel.c:851-856, :254-262]
+  const bool i8 = ((s.a_in_type == LIBXSMM_DATATYPE_U8 && s.b_in_type == LIBXSMM_DATATYPE_I8) || (s.a_in_type == LIBXSMM_DATATYPE_I8 && s.b_in_type == LIBXSMM_DATATYPE_U8)) &&
+    s.out_type == LIBXSMM_DATATYPE_I32;
+  if (!(f32 || bf16 || i8)) return nullptr;
   if (flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) return nullptr;
   if (f32 && (flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return nullptr;
+  if (i8 && (!(flags & LIBXSMM_GEMM_FLAG_VNNI_A) || (s.k & 3))) return nullptr;
   if (cfg.packed_width <= 0 || cfg.bk <= 0 || cfg.bn <= 0 || s.k % cfg.bk != 0 || s.ldc % cfg.bn != 0 || s.ldb != 0) return nullptr;
   if (bf16 && (flags & LIBXSMM_GEMM_FLAG_VNNI_A) && (s.k & 1)) return nullptr;
   libxsmm_descriptor_blob blob;

@@ -263,11 +263,27 @@ __global__ __launch_bounds__(256) void bcsc_generic_kernel(BcscArgs p) {
   const int nb = n / p.bn, dn = n % p.bn;
   const long long cidx = (long long)mb * p.N * p.M + (long long)n * p.M + i;
   const bool f32 = (p.a_type == LIBXSMM_DATATYPE_F32);
-  float acc = 0.0f;
-  if (!p.beta0) acc = (p.c_type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)p.c)[cidx] : bf2f(((GM const unsigned short*)p.c)[cidx]);
   const long long abase = (long long)mb * p.K * p.M;
   GM const unsigned int* colptr = (GM const unsigned int*)p.colptr;
   GM const unsigned int* rowidx = (GM const unsigned int*)p.rowidx;
+  if (p.a_type == LIBXSMM_DATATYPE_I8 || p.a_type == LIBXSMM_DATATYPE_U8) {     // 8-bit integers -> int32, exact [ref: spmm_kernel.c:153-217]
+    const bool ua = p.a_type == LIBXSMM_DATATYPE_U8, ub = p.b_type == LIBXSMM_DATATYPE_U8;
+    int iacc = p.beta0 ? 0 : ((GM const int*)p.c)[cidx];
+    for (unsigned int b = colptr[nb]; b < colptr[nb + 1]; ++b) {
+      const int k0 = (int)rowidx[b] * p.bk;
+      const long long boff = ((long long)b * p.bn + dn) * p.bk;
+      for (int dk = 0; dk < p.bk; ++dk) {
+        const int k = k0 + dk;
+        const long long ai = p.vnni_a ? ((long long)(k / 4) * (p.M * 4) + (long long)i * 4 + (k % 4)) : ((long long)k * p.M + i);
+        const unsigned char ab = ((GM const unsigned char*)p.a)[abase + ai], bb = ((GM const unsigned char*)p.bvals)[boff + dk];
+        iacc += (ua ? (int)ab : (int)(signed char)ab) * (ub ? (int)bb : (int)(signed char)bb);
+      }
+    }
+    ((GM int*)p.c)[cidx] = iacc;
+    return;
+  }
+  float acc = 0.0f;
+  if (!p.beta0) acc = (p.c_type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)p.c)[cidx] : bf2f(((GM const unsigned short*)p.c)[cidx]);
   for (unsigned int b = colptr[nb]; b < colptr[nb + 1]; ++b) {
     const int k0 = (int)rowidx[b] * p.bk;
     const long long boff = ((long long)b * p.bn + dn) * p.bk;
@@ -414,6 +430,112 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_kernel(BcscArgs p, unsigne
       const long long e = (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg;
       if (c_f32) *(GM f32x4v*)(cbase + e * 4) = acc[nt][it];
       else { u32x2v v; v[0] = cvt2(acc[nt][it][0], acc[nt][it][1]); v[1] = cvt2(acc[nt][it][2], acc[nt][it][3]); *(GM u32x2v*)(cbase + e * 2) = v; }
+    }
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// BCSC with 8-bit integer operands on the matrix cores (v_mfma_i32_16x16x32_i8): unsigned A x signed B or signed A x unsigned B
+// -> int32, exact.  Structure of bcsc_mfma_bf16_kernel: one wave owns (M-block, 64 rows, 64 columns) of C in 64 accumulator VGPRs,
+// inverts the pattern for its columns, then runs k-block outer with the A operand double-buffered in registers.  A is VNNI-4
+// ([K/4][M][4]: a dword = four k of one row): lane (row lx, k group kg) of a 32-deep step takes the two dwords k = 8 kg .. 8 kg + 7;
+// a B block is [bn][bk] bytes, k contiguous: lane (column lx, kg) takes the matching 8 bytes.
+// The matrix core multiplies SIGNED bytes.  The unsigned operand u is fed as u ^ 0x80 = u - 128 and the missing 128 * sum_k(other
+// operand) comes from one more MFMA per fragment against an all-ones operand, accumulated apart and added once at the end:
+//   unsigned A: + 128 * sum_k b[k][n] (per column tile),   unsigned B: + 128 * sum_k a[i][k] over the k-blocks stored for that n-block.
+// [ref semantics: samples/xgemm_sparse/spmm_kernel.c:153-217]
+// ------------------------------------------------------------------------------------------------
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+template <int BN16, bool UA>       // UA: A unsigned (B signed); else A signed, B unsigned
+__global__ __launch_bounds__(256) void bcsc_mfma_i8_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int total) {
+  constexpr int NBL = 4 / BN16;
+  __shared__ unsigned int tbl_all[4][kBcscTbl];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = blockIdx.x * 4u + wave;
+  if (wid >= total) return;
+  unsigned int* tbl = tbl_all[wave];
+  const unsigned int tn = wid % tiles_n, tmp = wid / tiles_n, ti = tmp % tiles_i, mb = tmp / tiles_i;
+  const int lane = threadIdx.x & 63, lx = lane & 15, kg = lane >> 4;
+  const int i0 = (int)ti * 64, n0 = (int)tn * 64;
+  const int mt = (p.M - i0 >= 64) ? 4 : (p.M - i0) / 16;
+  const int nbl_cnt = ((p.N - n0 >= 64) ? 64 : (p.N - n0)) / (16 * BN16);
+  const int nb0 = n0 / (16 * BN16);
+  const int nkb = p.K / p.bk, steps = p.bk / 32;
+  GM const unsigned int* colptr = (GM const unsigned int*)p.colptr;
+  GM const unsigned int* rowidx = (GM const unsigned int*)p.rowidx;
+  for (int e = lane; e < nbl_cnt * nkb; e += 64) tbl[e] = 0xffffffffu;
+  for (int nbl = 0; nbl < nbl_cnt; ++nbl) {
+    const unsigned int c0 = colptr[nb0 + nbl], c1 = colptr[nb0 + nbl + 1];
+    for (unsigned int b = c0 + lane; b < c1; b += 64) tbl[nbl * nkb + rowidx[b]] = b;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  i32x4v acc[4][4], corr_b[4], corr_a[NBL][4];       // corr_b[n-tile]: sum_k b (unsigned A); corr_a[n-block][i-tile]: sum_k a (unsigned B)
+  GM int* cbase = (GM int*)p.c + (long long)mb * p.N * p.M;
+  sfor<16>([&](auto ic) {
+    constexpr int nt = ic.value / 4, it = ic.value % 4;
+    acc[nt][it] = (i32x4v)0;
+    if (!p.beta0 && it < mt && nt < nbl_cnt * BN16) acc[nt][it] = *(GM const i32x4v*)(cbase + (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg);
+  });
+  sfor<4>([&](auto c) { corr_b[c.value] = (i32x4v)0; });
+  sfor<NBL * 4>([&](auto c) { corr_a[c.value / 4][c.value % 4] = (i32x4v)0; });
+  const long long ones = 0x0101010101010101ll;
+  GM const unsigned int* A4 = (GM const unsigned int*)p.a + (long long)mb * (p.K / 4) * p.M + i0 + lx;
+  auto load_a = [&](long long (&dst)[4], int kb, int st) {
+    const long long kq0 = (long long)kb * (p.bk / 4) + 8 * st + 2 * kg;
+    sfor<4>([&](auto tc) {
+      constexpr int t = tc.value;
+      if (t < mt) {
+        unsigned int lo = A4[kq0 * p.M + 16 * t], hi = A4[(kq0 + 1) * p.M + 16 * t];
+        if (UA) { lo ^= 0x80808080u; hi ^= 0x80808080u; }
+        dst[t] = (long long)(((unsigned long long)hi << 32) | lo);
+      }
+    });
+  };
+  GM const char* bv = (GM const char*)p.bvals;
+  long long a_cur[4], a_nxt[4];
+  for (int kgp = 0; kgp < nkb; kgp += 64) {
+    bool used = false;
+    const int kb_l = kgp + lane;
+    if (kb_l < nkb) for (int nbl = 0; nbl < nbl_cnt; ++nbl) used = used || (tbl[nbl * nkb + kb_l] != 0xffffffffu);
+    unsigned long long mask = __ballot(used);
+    if (mask == 0ull) continue;
+    int kb = kgp + (int)__builtin_ctzll(mask); mask &= mask - 1ull;
+    int st = 0;
+    load_a(a_cur, kb, 0);
+    for (;;) {
+      int kb_n = kb, st_n = st + 1; bool more = true;
+      if (st_n == steps) { st_n = 0; if (mask != 0ull) { kb_n = kgp + (int)__builtin_ctzll(mask); mask &= mask - 1ull; } else more = false; }
+      if (more) load_a(a_nxt, kb_n, st_n);
+      sfor<NBL>([&](auto nc) {
+        constexpr int nbl = nc.value;
+        if (nbl < nbl_cnt) {
+          const unsigned int blk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tbl[nbl * nkb + kb]);
+          if (blk != 0xffffffffu) {
+            sfor<BN16>([&](auto sc) {
+              constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
+              long long bfrag = *(GM const long long*)(bv + ((long long)blk * (16 * BN16) + 16 * s2 + lx) * p.bk + 32 * st + 8 * kg);
+              if (!UA) bfrag ^= (long long)0x8080808080808080ull;
+              sfor<4>([&](auto tc) {
+                constexpr int t = tc.value;
+                if (t < mt) acc[nt][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_cur[t], bfrag, acc[nt][t], 0, 0, 0);
+              });
+              if (UA) corr_b[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(ones, bfrag, corr_b[nt], 0, 0, 0);
+            });
+            if (!UA) sfor<4>([&](auto tc) { constexpr int t = tc.value; if (t < mt) corr_a[nbl][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_cur[t], ones, corr_a[nbl][t], 0, 0, 0); });
+          }
+        }
+      });
+      if (!more) break;
+      sfor<4>([&](auto tc) { a_cur[tc.value] = a_nxt[tc.value]; });
+      kb = kb_n; st = st_n;
+    }
+  }
+  sfor<16>([&](auto ic) {
+    constexpr int nt = ic.value / 4, it = ic.value % 4;
+    if (it < mt && nt < nbl_cnt * BN16) {
+      i32x4v v = acc[nt][it];
+      if (UA) v += corr_b[nt] * 128; else v += corr_a[nt / BN16][it] * 128;
+      *(GM i32x4v*)(cbase + (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg) = v;
     }
   });
 }
@@ -609,7 +731,8 @@ int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
         if (dma_ok) {
           const int nkb = a.K / a.bk;
           const unsigned int* table = (const unsigned int*)a.table;
-          hipLaunchKernelGGL(bcsc_invert_kernel, dim3((unsigned int)a.nblk_n), dim3(64), 0, st, a.colptr, a.rowidx, (unsigned int*)a.table, a.nblk_n, nkb);
+          // the inverted pattern: already in place when the pattern came from host memory (built there, cached per kernel: run_bcsc)
+          if (!a.table_ready) hipLaunchKernelGGL(bcsc_invert_kernel, dim3((unsigned int)a.nblk_n), dim3(64), 0, st, a.colptr, a.rowidx, (unsigned int*)a.table, a.nblk_n, nkb);
           if (a.bn == 16) hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<1>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table);
           else if (a.bn == 32) hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table);
           else hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table);
@@ -620,6 +743,26 @@ int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
         else if (a.bn == 32) hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
         else hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
         if (name) *name = "bcsc_mfma_bf16_kernel";
+        return (int)hipGetLastError();
+      }
+    }
+  }
+  {   // 8-bit integers on the matrix cores: VNNI-4 A, 32-deep k steps, 16-wide n sub-tiles, 16-row i tiles, dword / 8-byte / 16-byte aligned A / B / C
+    const bool i8 = (a.a_type == LIBXSMM_DATATYPE_U8 && a.b_type == LIBXSMM_DATATYPE_I8) || (a.a_type == LIBXSMM_DATATYPE_I8 && a.b_type == LIBXSMM_DATATYPE_U8);
+    static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_MFMA"); return e && e[0] == '0'; }();
+    const int nbl_per_wave = (a.bn > 0 && 64 % a.bn == 0) ? 64 / a.bn : 0;
+    if (!off && i8 && a.c_type == LIBXSMM_DATATYPE_I32 && a.vnni_a && a.bk % 32 == 0 && (a.bn == 16 || a.bn == 32 || a.bn == 64) && a.M % 16 == 0 && a.N % a.bn == 0 &&
+        (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTbl && ((size_t)a.a % 4 == 0) && ((size_t)a.bvals % 8 == 0) && ((size_t)a.c % 16 == 0)) {
+      const unsigned int tiles_i = (unsigned int)((a.M + 63) / 64), tiles_n = (unsigned int)((a.N + 63) / 64);
+      const long long total = (long long)tiles_i * tiles_n * a.m_blocks;
+      if (total < (1ll << 31)) {
+        const dim3 grid((unsigned int)((total + 3) / 4));
+        const bool ua = a.a_type == LIBXSMM_DATATYPE_U8;
+#define LAUNCH_I8_(B_) do { if (ua) hipLaunchKernelGGL((bcsc_mfma_i8_kernel<B_, true>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total); \
+                            else hipLaunchKernelGGL((bcsc_mfma_i8_kernel<B_, false>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total); } while (0)
+        if (a.bn == 16) LAUNCH_I8_(1); else if (a.bn == 32) LAUNCH_I8_(2); else LAUNCH_I8_(4);
+#undef LAUNCH_I8_
+        if (name) *name = "bcsc_mfma_i8_kernel";
         return (int)hipGetLastError();
       }
     }

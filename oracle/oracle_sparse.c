@@ -95,32 +95,45 @@ void oracle_packed_spgemm_bcsc(int a_type, int c_type, int M, int N, int K, int 
   int vnni_a, const void* A, const void* b_vals, const unsigned int* col_ptr, const unsigned int* row_idx,
   void* C, int beta0)
 {
-  /* The driver's gold is a dense GEMM on the sparsified B [spmm_kernel.c:88-109 (f32), :113-151 (bf16)];
+  /* The driver's gold is a dense GEMM on the sparsified B [spmm_kernel.c:88-109 (f32), :113-151 (bf16), :153-217 (8-bit integers)];
    * zero blocks contribute exact zeros, so walking the stored blocks of block-column nb in
-   * ascending block-row order reproduces it.  B block layout: vals[blk][dn][dk], k fastest. */
+   * ascending block-row order reproduces it.  B block layout: vals[blk][dn][dk], k fastest.
+   * 8-bit integers: a_type U8 means unsigned A x signed B, a_type I8 means signed A x unsigned B (the two combinations the
+   * reference accepts [spmm_kernel.c:851-856]); A is VNNI-4 packed [K/4][M][4] when vnni_a [spmm_kernel.c:254-262]; C is int32. */
   long long mb, n, i; unsigned int blk; int dk;
-  const int pack = (a_type == LIBXSMM_DATATYPE_BF16 && vnni_a) ? 2 : 1;
+  const int i8 = (a_type == LIBXSMM_DATATYPE_I8 || a_type == LIBXSMM_DATATYPE_U8);
+  const int pack = !vnni_a ? 1 : (i8 ? 4 : (a_type == LIBXSMM_DATATYPE_BF16 ? 2 : 1));
   for (mb = 0; mb < m_blocks; ++mb) {
     for (n = 0; n < N; ++n) {
       const long long nb = n / bn, dn = n % bn;
       for (i = 0; i < M; ++i) {
-        float acc = 0.0f;
+        float acc = 0.0f; int iacc = 0;
         const long long cidx = mb * (long long)N * M + n * M + i;
-        if (!beta0) acc = (c_type == LIBXSMM_DATATYPE_F32) ? ((const float*)C)[cidx] : oracle_bf16_to_f32(((const unsigned short*)C)[cidx]);
+        if (!beta0) {
+          if (i8) iacc = ((const int*)C)[cidx];
+          else acc = (c_type == LIBXSMM_DATATYPE_F32) ? ((const float*)C)[cidx] : oracle_bf16_to_f32(((const unsigned short*)C)[cidx]);
+        }
         for (blk = col_ptr[nb]; blk < col_ptr[nb + 1]; ++blk) {
           const long long k0 = (long long)row_idx[blk] * bk;
           for (dk = 0; dk < bk; ++dk) {
             const long long k = k0 + dk;
-            /* A per block: [K][M] col-major, or VNNI-2 [K/2][M][2]  [spmm_kernel.c:244-253] */
-            const long long aidx = mb * (long long)K * M + ((pack == 2) ? ((k / 2) * (M * 2) + i * 2 + (k % 2)) : (k * M + i));
+            /* A per block: [K][M] col-major, or VNNI [K/pack][M][pack]  [spmm_kernel.c:244-262] */
+            const long long aidx = mb * (long long)K * M + ((pack > 1) ? ((k / pack) * (M * pack) + i * pack + (k % pack)) : (k * M + i));
             const long long bidx = (long long)blk * bn * bk + dn * bk + dk;
             float av, bv, prod;
+            if (i8) {
+              const int ai = (a_type == LIBXSMM_DATATYPE_U8) ? (int)((const unsigned char*)A)[aidx] : (int)((const signed char*)A)[aidx];
+              const int bi = (a_type == LIBXSMM_DATATYPE_U8) ? (int)((const signed char*)b_vals)[bidx] : (int)((const unsigned char*)b_vals)[bidx];
+              iacc += ai * bi;
+              continue;
+            }
             if (a_type == LIBXSMM_DATATYPE_F32) { av = ((const float*)A)[aidx]; bv = ((const float*)b_vals)[bidx]; }
             else { av = oracle_bf16_to_f32(((const unsigned short*)A)[aidx]); bv = oracle_bf16_to_f32(((const unsigned short*)b_vals)[bidx]); }
             prod = av * bv; acc = acc + prod;
           }
         }
-        if (c_type == LIBXSMM_DATATYPE_F32) ((float*)C)[cidx] = acc; else ((unsigned short*)C)[cidx] = oracle_f32_to_bf16_rne(acc);
+        if (i8) ((int*)C)[cidx] = iacc;
+        else if (c_type == LIBXSMM_DATATYPE_F32) ((float*)C)[cidx] = acc; else ((unsigned short*)C)[cidx] = oracle_f32_to_bf16_rne(acc);
       }
     }
   }

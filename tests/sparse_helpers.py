@@ -57,6 +57,12 @@ def pack_vnni2(A, mb, K, M):
     return np.ascontiguousarray(a.transpose(0, 1, 3, 2)).reshape(-1)
 
 
+def pack_vnni4(A, mb, K, M):
+    """[mb][K][M] (M fastest) -> [mb][K/4][M][4] (8-bit operands, [ref: samples/xgemm_sparse/spmm_kernel.c:254-262])."""
+    a = A.reshape(mb, K // 4, 4, M)
+    return np.ascontiguousarray(a.transpose(0, 1, 3, 2)).reshape(-1)
+
+
 def read_mtx(path):
     """Matrix-Market coordinate file -> dense float64 array (fixtures: sparsity patterns + values)."""
     with open(path) as f:

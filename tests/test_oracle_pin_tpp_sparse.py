@@ -12,7 +12,7 @@ from helpers import normf_rel, rand_values
 from libxsmm_amd import capi
 from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, GEMM_FLAG, TERNARY, UNARY, UNARY_FLAG
 from oracle import pyoracle
-from sparse_helpers import csr_to_csc, make_bcsc, pack_vnni2, random_csr
+from sparse_helpers import csr_to_csc, make_bcsc, pack_vnni2, pack_vnni4, random_csr
 
 OP_UNARY, OP_BINARY, OP_TERNARY = 1, 2, 3
 NP = {DT.F32: np.float32, DT.F64: np.float64}
@@ -300,6 +300,34 @@ def test_bcsc_vs_reference_jit(reference, a_type, c_type, vnni, bk, bn, beta0):
         A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, C.addressof(nblk), jit_c.ctypes.data
     capi.Api.call(h, p)
     assert normf_rel(ref_c, jit_c, c_type) <= (5e-3 if c_type == DT.BF16 else 1e-4)
+    reference.release_kernel(h)
+
+
+@pytest.mark.parametrize("a_type", [DT.U8, DT.I8])
+@pytest.mark.parametrize("bk,bn,beta0", [(32, 16, 0), (32, 32, 1), (8, 8, 0), (16, 4, 1)])
+def test_bcsc_int8_vs_reference_jit(reference, a_type, bk, bn, beta0):
+    """8-bit integer BCSC (unsigned x signed -> int32, VNNI-4 A): the restatement is EQUAL to the reference's JIT kernel."""
+    orc = pyoracle.oracle()
+    M, N, K, mb = 64, 64, 256, 3
+    rng = np.random.default_rng(13)
+    b_type = DT.I8 if a_type == DT.U8 else DT.U8
+    colptr, rowidx, bvals = make_bcsc(rng, K, N, bk, bn, 0.25, b_type)
+    A = rng.integers(0, 256, mb * K * M).astype(np.uint8) if a_type == DT.U8 else rng.integers(-128, 128, mb * K * M).astype(np.int8)
+    bvals = rng.integers(-128, 128, bvals.size).astype(np.int8) if b_type == DT.I8 else rng.integers(0, 256, bvals.size).astype(np.uint8)
+    A_run = pack_vnni4(A, mb, K, M)
+    C0 = rng.integers(-1000, 1000, mb * N * M).astype(np.int32)
+    ref_c, jit_c = C0.copy(), C0.copy()
+    orc.lib.oracle_packed_spgemm_bcsc(a_type, DT.I32, M, N, K, mb, bk, bn, 1, A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref_c.ctypes.data, beta0)
+    flags = (GEMM_FLAG.BETA_0 if beta0 else 0) | GEMM_FLAG.VNNI_A
+    h = reference.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, a_type, b_type, DT.I32, DT.I32), flags, 0, capi.SpgemmConfig(M, bk, bn))
+    if not h:
+        pytest.skip("reference JIT refused this BCSC configuration on this host")
+    nblk = C.c_ulonglong(N // bn)
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = \
+        A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, C.addressof(nblk), jit_c.ctypes.data
+    capi.Api.call(h, p)
+    assert np.array_equal(ref_c, jit_c)
     reference.release_kernel(h)
 
 

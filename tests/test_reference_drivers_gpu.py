@@ -105,6 +105,11 @@ def test_reference_fused_gemm_driver(args):
     "BF16 BF16 F32 BF16 64 64 256 16 0.75 32 16 0 0 0 1 0 0 2",            # BASELINE config #4's kernel (random instead of 2:8 pattern)
     "BF16 BF16 F32 BF16 64 64 256 8 0.5 32 32 1 0 0 1 0 0 2",
     "F32 F32 F32 F32 32 32 64 4 0.75 16 4 0 0 0 0 0 0 2",
+    "U8 I8 I32 I32 64 64 256 16 0.75 32 16 0 0 0 1 0 0 2",                  # 8-bit integers on v_mfma_i32_16x16x32_i8
+    "I8 U8 I32 I32 64 64 256 8 0.5 32 32 1 0 0 1 0 0 2",
+    "U8 I8 I32 I32 32 32 64 4 0.75 8 8 0 0 0 1 0 0 2",                      # small blocks: generic kernel
+    "BF16 BF16 F32 BF16 64 64 256 8192 0.75 32 16 0 0 0 1 0 0 2",            # BASELINE config #4 at full size (m_blocks = 8192)
+    "U8 I8 I32 I32 64 64 256 8192 0.75 32 16 0 0 0 1 0 0 2",
 ])
 def test_reference_bcsc_driver(args):
     check("spmm_kernel", *args.split())

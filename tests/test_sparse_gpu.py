@@ -15,7 +15,7 @@ from helpers import normf_rel, rand_values
 from libxsmm_amd import capi
 from libxsmm_amd.capi import DT, GEMM_FLAG
 from oracle import pyoracle
-from sparse_helpers import random_csr, csr_to_csc, make_bcsc, pack_vnni2
+from sparse_helpers import random_csr, csr_to_csc, make_bcsc, pack_vnni2, pack_vnni4
 
 pytestmark = pytest.mark.gpu
 NP = {DT.F32: np.float32, DT.F64: np.float64}
@@ -304,6 +304,57 @@ def test_bcsc(a_type, c_type, vnni, M, N, K, mb, bk, bn, keep, beta0):
     api.hip_sync(); api.check()
     assert np.array_equal(_host(dC2, got.dtype), got)
     api.release_kernel(h)
+
+
+# 8-bit integers (u8 x i8 -> i32 and i8 x u8 -> i32, A in VNNI-4): exact, so the bar is bit equality
+@pytest.mark.parametrize("a_type", [DT.U8, DT.I8])
+@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep,beta0", [(64, 64, 256, 6, 32, 16, 0.25, 1), (64, 64, 256, 3, 32, 32, 0.25, 0), (16, 24, 40, 4, 8, 8, 0.5, 1), (32, 32, 64, 2, 16, 4, 0.42, 0),
+                                                       (48, 80, 128, 3, 64, 16, 0.3, 0), (64, 128, 128, 2, 32, 64, 0.5, 1), (80, 96, 96, 5, 32, 32, 0.34, 1), (64, 64, 512, 40, 64, 16, 0.25, 0)])
+def test_bcsc_int8(a_type, M, N, K, mb, bk, bn, keep, beta0):
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(12)
+    b_type = DT.I8 if a_type == DT.U8 else DT.U8
+    colptr, rowidx, bvals = make_bcsc(rng, K, N, bk, bn, keep, b_type)
+    # full-range bytes: the unsigned operand over 0..255, the signed one over -128..127
+    A = rng.integers(0, 256, mb * K * M).astype(np.uint8) if a_type == DT.U8 else rng.integers(-128, 128, mb * K * M).astype(np.int8)
+    bvals = rng.integers(-128, 128, bvals.size).astype(np.int8) if b_type == DT.I8 else rng.integers(0, 256, bvals.size).astype(np.uint8)
+    A_run = pack_vnni4(A, mb, K, M)
+    C0 = rng.integers(-1000, 1000, mb * N * M).astype(np.int32)
+    ref = C0.copy()
+    orc.lib.oracle_packed_spgemm_bcsc(a_type, DT.I32, M, N, K, mb, bk, bn, 1, A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, beta0)
+    # the restatement against plain integer algebra on the dense operands
+    dense = np.zeros((K, N), dtype=np.int64)
+    bv = bvals.reshape(-1, bn, bk).astype(np.int64)
+    for nb in range(N // bn):
+        for b in range(colptr[nb], colptr[nb + 1]):
+            dense[rowidx[b] * bk:(rowidx[b] + 1) * bk, nb * bn:(nb + 1) * bn] = bv[b].T
+    want = np.einsum("bkm,kn->bnm", A.reshape(mb, K, M).astype(np.int64), dense) + (0 if beta0 else C0.reshape(mb, N, M))
+    assert np.array_equal(ref.reshape(mb, N, M), want.astype(np.int32))
+    shape = capi.gemm_shape(mb, 0, K, K, 0, N, a_type, b_type, DT.I32, DT.I32)
+    flags = (GEMM_FLAG.BETA_0 if beta0 else 0) | GEMM_FLAG.VNNI_A
+    h = api.create_packed_spgemm_bcsc(shape, flags, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    dA, dB, dC, dcp, dri = _dev(A_run), _dev(bvals), _dev(C0.copy()), _dev(colptr), _dev(rowidx)
+    nblk = C.c_ulonglong(N // bn)
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = \
+        dA.data_ptr(), dB.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), dC.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    assert np.array_equal(_host(dC, np.int32), ref)
+    mfma_ok = bk % 32 == 0 and bn in (16, 32, 64) and M % 16 == 0
+    assert ("mfma_i8" in api.hip_kernel_name(h, 0).decode()) == mfma_ok
+    # host-resident pattern (the reference's convention): inverted on the host, cached with the kernel; the second call hits the cache
+    for _ in range(2):
+        dC2 = _dev(C0.copy())
+        p.b.secondary, p.b.tertiary, p.c.primary = colptr.ctypes.data, rowidx.ctypes.data, dC2.data_ptr()
+        capi.Api.call(h, p)
+        api.hip_sync(); api.check()
+        assert np.array_equal(_host(dC2, np.int32), ref)
+    api.release_kernel(h)
+    # refused like the reference: same signedness on both sides, flat A
+    assert not api.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, DT.I8, DT.I8, DT.I32, DT.I32), flags, 0, capi.SpgemmConfig(M, bk, bn))
+    assert not api.create_packed_spgemm_bcsc(shape, flags & ~GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
 
 
 # ---- dense packed GEMMs --------------------------------------------------------------------
