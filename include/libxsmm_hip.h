@@ -121,6 +121,19 @@ LIBXSMM_API void libxsmm_hip_meltw_ternary_batch_strided(libxsmm_meltwfunction_t
  * after rounding shard boundaries to `granule` units (e.g. the packed width's lane tile). */
 LIBXSMM_API void libxsmm_hip_shard_range(size_t count, size_t granule, int world, int rank, size_t* begin, size_t* end);
 
+/* Result gather onto one GPU without a collective library (one process per GPU on one node).  Every rank exports the device buffer that
+ * holds its shard (libxsmm_hip_ipc_export: LIBXSMM_HIP_IPC_HANDLE_BYTES opaque bytes, to be handed to the root by whatever means the
+ * application has -- MPI, a file, torch.distributed); the root then pulls all shards, each on its own stream: the sources sit behind
+ * different xGMI links of the root, so the copies overlap (up to world - 1 links) where a ring all-gather is bound by one link per hop.
+ *   handles     : world x LIBXSMM_HIP_IPC_HANDLE_BYTES, entry r = what rank r exported (entry self_rank is ignored)
+ *   self_src    : the root's own shard (plain device pointer)
+ *   src_offsets : byte offset of the shard behind each exported pointer (NULL: all 0);  dst_offsets / nbytes: placement and size in dst
+ * Returns 0 on success; the copies are complete on return.  The exporting ranks must keep their buffers alive until then. */
+#define LIBXSMM_HIP_IPC_HANDLE_BYTES 80
+LIBXSMM_API int libxsmm_hip_ipc_export(const void* device_ptr, void* handle);
+LIBXSMM_API int libxsmm_hip_gather_shards(void* dst, int world, int self_rank, const void* handles, const void* self_src,
+  const size_t* src_offsets, const size_t* dst_offsets, const size_t* nbytes);
+
 /* ---- run-time specialisation of the fixed-pattern sparse kernels ---------------------
  * libxsmm_create_packed_spgemm_csr/_csc, libxsmm_create_spgemm_csr_areg and libxsmm_fsspmdm_create can compile a
  * kernel with the sparsity pattern unrolled into the instruction stream (hiprtc), as the reference's JIT does

@@ -1295,7 +1295,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          af[mt][s][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)voffA[s][e] + 128 * mt, 64 * kc * (int)lda, AUX);
+          af[mt][s][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)voffA[s][e] + 128 * mt, 64 * kc * (int)lda, 0);   // dword loads: policy bits cost on sub-16-byte accesses
   };
   auto compute = [&](const char* image, const u32x4 (&af)[MT][2]) {
     u32x4 bfr[NT][2];
@@ -1981,8 +1981,9 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       grid = wave_grid(64, 64);
       if (pl.exact && bf16_stream_ok(a)) {
         if (kernel_name) *kernel_name = "gemm_bf16_stream_kernel<2,2>";
-        if (stream_nt(a, 2, typesize_c(a))) hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2, 2>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2, 0>), grid, dim3(256), 0, st, a);
+        // measured (batch 65536, operands from HBM): nt on the B stream takes the 32^3 kernel from 0.72 to 0.84 of the HBM roofline but the
+        // 64^3 kernel from 0.68 to 0.60 -- so only the <1,1> form asks for it
+        hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2, 0>), grid, dim3(256), 0, st, a);
       }
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);

@@ -126,6 +126,8 @@ struct BcscArgs {
   int M, N, K, m_blocks, bk, bn, nblk_n;
   int a_type, b_type, c_type, vnni_a, beta0;      // 8-bit integers: a_type / b_type in {I8, U8}, exactly one unsigned, c_type I32, A VNNI-4
   void* table;                        // workspace for the inverted pattern: nblk_n * (K / bk) words (may be NULL)
+  int nt_a;                           // stream the A operand with non-temporal loads (set by launch_bcsc: launch larger than the Infinity Cache, or the caller's hint)
+  int stream_hint;                    // libxsmm_hip_set_streaming_hint of the calling thread
   int table_ready;                    // the table already holds this call's inverted pattern (host-resident pattern, cached per kernel)
 };
 

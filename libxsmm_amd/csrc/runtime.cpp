@@ -682,6 +682,7 @@ void run_bcsc(KernelCtx* k, const void* param) {
   const unsigned long long nblk_n = *(const unsigned long long*)p->b.quaternary;   // [ref: spmm_kernel.c:451-456]
   a.M = k->packed_width; a.N = (int)d.ldc; a.K = (int)d.k; a.m_blocks = (int)d.m; a.bk = k->bk; a.bn = k->bn; a.nblk_n = (int)nblk_n;
   a.a_type = d.a_type; a.b_type = d.b_type; a.c_type = d.c_type; a.vnni_a = (d.flags & LIBXSMM_GEMM_FLAG_VNNI_A) ? 1 : 0; a.beta0 = (d.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 1 : 0;
+  a.stream_hint = tls().stream_hint;
   a.a = (const char*)p->a.primary; a.bvals = (const char*)p->b.primary; a.c = (char*)p->c.primary;
   if (!p->b.secondary || !p->b.tertiary) { set_error(-2, "BCSC kernel needs colptr in b.secondary and rowidx in b.tertiary"); return; }
   if (k->device != cur_device() && !k->bcsc_cache.empty()) { set_error(-3, "BCSC kernel holds a cached pattern on device %d but is called on device %d", k->device, cur_device()); return; }
@@ -1454,6 +1455,49 @@ LIBXSMM_API void libxsmm_hip_meltw_ternary_batch_strided(libxsmm_meltwfunction_t
   long long s0, long long s1, long long s2, long long so) {
   KernelCtx* c = batch_ctx((const void*)kernel, K_MELTW); if (!c || !param || count == 0) return;
   BatchSpec b; b.count = count; b.s[0] = s0; b.s[1] = s1; b.s[2] = s2; b.s[3] = so; run_meltw(c, param, b);
+}
+// ---- result gather without a collective library: the root pulls every shard over its own xGMI link ----------------------------
+namespace { struct IpcBlob { hipIpcMemHandle_t h; unsigned long long offset, size; }; }
+LIBXSMM_API int libxsmm_hip_ipc_export(const void* device_ptr, void* handle) {
+  static_assert(sizeof(IpcBlob) == LIBXSMM_HIP_IPC_HANDLE_BYTES, "IPC blob size differs from the C ABI's LIBXSMM_HIP_IPC_HANDLE_BYTES");
+  if (!device_ptr || !handle) return -1;
+  IpcBlob b; std::memset(&b, 0, sizeof(b));
+  // an IPC handle names a whole ALLOCATION; device_ptr may sit inside one (sub-allocating memory pools): carry the offset along
+  hipDeviceptr_t base = nullptr; size_t size = 0;
+  if (!hip_ok(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)const_cast<void*>(device_ptr)), "hipMemGetAddressRange")) return -1;
+  if (!hip_ok(hipIpcGetMemHandle(&b.h, (void*)base), "hipIpcGetMemHandle")) return -1;
+  b.offset = (unsigned long long)((const char*)device_ptr - (const char*)base); b.size = (unsigned long long)size;
+  std::memcpy(handle, &b, sizeof(b));
+  return 0;
+}
+LIBXSMM_API int libxsmm_hip_gather_shards(void* dst, int world, int self_rank, const void* handles, const void* self_src,
+  const size_t* src_offsets, const size_t* dst_offsets, const size_t* nbytes) {
+  if (!dst || world <= 0 || !dst_offsets || !nbytes) return -1;
+  std::vector<void*> opened((size_t)world, nullptr);
+  std::vector<hipStream_t> streams((size_t)world, nullptr);
+  int rc = 0;
+  for (int r = 0; r < world && rc == 0; ++r) {
+    if (nbytes[r] == 0) continue;
+    const char* src = nullptr;
+    if (r == self_rank) src = (const char*)self_src;
+    else {
+      if (!handles) { set_error(-2, "libxsmm_hip_gather_shards: no IPC handle for rank %d", r); rc = -1; break; }
+      IpcBlob b; std::memcpy(&b, (const char*)handles + sizeof(IpcBlob) * (size_t)r, sizeof(b));
+      if (!hip_ok(hipIpcOpenMemHandle(&opened[r], b.h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle")) { rc = -1; break; }
+      if (b.offset + (src_offsets ? src_offsets[r] : 0) + nbytes[r] > b.size) { set_error(-2, "libxsmm_hip_gather_shards: shard of rank %d exceeds the exported allocation", r); rc = -1; break; }
+      src = (const char*)opened[r] + b.offset;
+    }
+    if (!src) { set_error(-2, "libxsmm_hip_gather_shards: NULL source for rank %d", r); rc = -1; break; }
+    if (!hip_ok(hipStreamCreateWithFlags(&streams[r], hipStreamNonBlocking), "hipStreamCreate")) { rc = -1; break; }
+    // one copy per source, each on its own stream: the sources sit behind different xGMI links of the root, so the copies run
+    // concurrently at up to (world - 1) x one link instead of a ring's one link per hop
+    if (!hip_ok(hipMemcpyAsync((char*)dst + dst_offsets[r], src + (src_offsets ? src_offsets[r] : 0), nbytes[r], hipMemcpyDeviceToDevice, streams[r]), "hipMemcpyAsync(peer shard)")) rc = -1;
+  }
+  for (int r = 0; r < world; ++r) {
+    if (streams[r]) { if (hipStreamSynchronize(streams[r]) != hipSuccess) rc = -1; (void)hipStreamDestroy(streams[r]); }
+    if (opened[r]) (void)hipIpcCloseMemHandle(opened[r]);
+  }
+  return rc;
 }
 LIBXSMM_API void libxsmm_hip_shard_range(size_t count, size_t granule, int world, int rank, size_t* begin, size_t* end) {
   if (granule == 0) granule = 1;

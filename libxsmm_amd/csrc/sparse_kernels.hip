@@ -485,7 +485,9 @@ __global__ __launch_bounds__(256) void bcsc_mfma_i8_kernel(BcscArgs p, unsigned 
     sfor<4>([&](auto tc) {
       constexpr int t = tc.value;
       if (t < mt) {
-        unsigned int lo = A4[kq0 * p.M + 16 * t], hi = A4[(kq0 + 1) * p.M + 16 * t];
+        unsigned int lo, hi;
+        if (p.nt_a) { lo = __builtin_nontemporal_load(A4 + kq0 * p.M + 16 * t); hi = __builtin_nontemporal_load(A4 + (kq0 + 1) * p.M + 16 * t); }
+        else { lo = A4[kq0 * p.M + 16 * t]; hi = A4[(kq0 + 1) * p.M + 16 * t]; }
         if (UA) { lo ^= 0x80808080u; hi ^= 0x80808080u; }
         dst[t] = (long long)(((unsigned long long)hi << 32) | lo);
       }
@@ -540,6 +542,101 @@ __global__ __launch_bounds__(256) void bcsc_mfma_i8_kernel(BcscArgs p, unsigned 
   });
 }
 
+// ------------------------------------------------------------------------------------------------
+// BCSC in f32 on the matrix cores (v_mfma_f32_16x16x4_f32), bk % 16 == 0, bn in {16, 32, 64}, M % 16 == 0.  Same tile ownership and
+// pattern handling as the bf16 kernel.  A is [K][M] column-major (rows of M contiguous floats): lane (row lx, group kg) reads the four
+// rows k = 4 kg + s of a 16-deep chunk (64-byte segments per lane group); a B block is [bn][bk] with k contiguous: lane (column lx,
+// group kg) reads its four k = 4 kg .. 4 kg + 3 as ONE 16-byte load.  MFMA step s then multiplies k = 4 kg + s of every group: the
+// k order inside a chunk is group-interleaved, which is a valid summation order (tolerance of the reference's f32 check), not bitwise
+// the oracle's.  f32 matrix rate makes this HBM-bound: A is streamed once, B blocks stay in L2.
+// ------------------------------------------------------------------------------------------------
+template <int BN16>
+__global__ __launch_bounds__(256) void bcsc_mfma_f32_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int total) {
+  constexpr int NBL = 4 / BN16;
+  __shared__ unsigned int tbl_all[4][kBcscTbl];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = blockIdx.x * 4u + wave;
+  if (wid >= total) return;
+  unsigned int* tbl = tbl_all[wave];
+  const unsigned int tn = wid % tiles_n, tmp = wid / tiles_n, ti = tmp % tiles_i, mb = tmp / tiles_i;
+  const int lane = threadIdx.x & 63, lx = lane & 15, kg = lane >> 4;
+  const int i0 = (int)ti * 64, n0 = (int)tn * 64;
+  const int mt = (p.M - i0 >= 64) ? 4 : (p.M - i0) / 16;
+  const int nbl_cnt = ((p.N - n0 >= 64) ? 64 : (p.N - n0)) / (16 * BN16);
+  const int nb0 = n0 / (16 * BN16);
+  const int nkb = p.K / p.bk, steps = p.bk / 16;
+  GM const unsigned int* colptr = (GM const unsigned int*)p.colptr;
+  GM const unsigned int* rowidx = (GM const unsigned int*)p.rowidx;
+  for (int e = lane; e < nbl_cnt * nkb; e += 64) tbl[e] = 0xffffffffu;
+  for (int nbl = 0; nbl < nbl_cnt; ++nbl) {
+    const unsigned int c0 = colptr[nb0 + nbl], c1 = colptr[nb0 + nbl + 1];
+    for (unsigned int b = c0 + lane; b < c1; b += 64) tbl[nbl * nkb + rowidx[b]] = b;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  f32x4v acc[4][4];
+  GM float* cbase = (GM float*)p.c + (long long)mb * p.N * p.M;
+  sfor<16>([&](auto ic) {
+    constexpr int nt = ic.value / 4, it = ic.value % 4;
+    acc[nt][it] = (f32x4v)0.0f;
+    if (!p.beta0 && it < mt && nt < nbl_cnt * BN16) acc[nt][it] = *(GM const f32x4v*)(cbase + (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg);
+  });
+  GM const float* Ab = (GM const float*)p.a + (long long)mb * p.K * p.M + i0 + lx;
+  const bool nta = p.nt_a != 0;                  // wave-uniform
+  auto load_a = [&](f32x4v (&dst)[4], int kb, int st) {
+    const long long k0 = (long long)kb * p.bk + 16 * st + 4 * kg;
+    sfor<4>([&](auto tc) {
+      constexpr int t = tc.value;
+      if (t < mt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[t][e] = nta ? __builtin_nontemporal_load(Ab + (k0 + e) * p.M + 16 * t) : Ab[(k0 + e) * p.M + 16 * t];
+      }
+    });
+  };
+  GM const float* bv = (GM const float*)p.bvals;
+  f32x4v a_cur[4], a_nxt[4];
+  for (int kgp = 0; kgp < nkb; kgp += 64) {
+    bool used = false;
+    const int kb_l = kgp + lane;
+    if (kb_l < nkb) for (int nbl = 0; nbl < nbl_cnt; ++nbl) used = used || (tbl[nbl * nkb + kb_l] != 0xffffffffu);
+    unsigned long long mask = __ballot(used);
+    if (mask == 0ull) continue;
+    int kb = kgp + (int)__builtin_ctzll(mask); mask &= mask - 1ull;
+    int st = 0;
+    load_a(a_cur, kb, 0);
+    for (;;) {
+      int kb_n = kb, st_n = st + 1; bool more = true;
+      if (st_n == steps) { st_n = 0; if (mask != 0ull) { kb_n = kgp + (int)__builtin_ctzll(mask); mask &= mask - 1ull; } else more = false; }
+      if (more) load_a(a_nxt, kb_n, st_n);
+      sfor<NBL>([&](auto nc) {
+        constexpr int nbl = nc.value;
+        if (nbl < nbl_cnt) {
+          const unsigned int blk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tbl[nbl * nkb + kb]);
+          if (blk != 0xffffffffu) {
+            sfor<BN16>([&](auto sc) {
+              constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
+              const f32x4v bfrag = *(GM const f32x4v*)(bv + ((long long)blk * (16 * BN16) + 16 * s2 + lx) * p.bk + 16 * st + 4 * kg);
+              sfor<4>([&](auto tc) {
+                constexpr int t = tc.value;
+                if (t < mt) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[t][e], bfrag[e], acc[nt][t], 0, 0, 0);
+                }
+              });
+            });
+          }
+        }
+      });
+      if (!more) break;
+      sfor<4>([&](auto tc) { a_cur[tc.value] = a_nxt[tc.value]; });
+      kb = kb_n; st = st_n;
+    }
+  }
+  sfor<16>([&](auto ic) {
+    constexpr int nt = ic.value / 4, it = ic.value % 4;
+    if (it < mt && nt < nbl_cnt * BN16) *(GM f32x4v*)(cbase + (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg) = acc[nt][it];
+  });
+}
+
 // Inverts the BCSC pattern once per call: table[n-block][k-block] = block id (0xffffffff: none).  Every wave of the main
 // kernel needs the same rows of it; building it there costs each wave three dependent global round trips up front.
 __global__ void bcsc_invert_kernel(const unsigned int* colptr_, const unsigned int* rowidx_, unsigned int* table, int nblk_n, int nkb) {
@@ -557,7 +654,7 @@ __global__ void bcsc_invert_kernel(const unsigned int* colptr_, const unsigned i
 // segments), the MFMA operand is then read with conflict-free ds_read_b32 (rows of odd k-groups are rotated by 16 words
 // on the SOURCE side so that the two k-groups of a half-wave hit different banks).  Per chunk: wait, read the operand
 // registers, fetch the B fragments of this chunk, start the DMA of the NEXT chunk into the same image, run the MFMAs.
-template <int BN16>
+template <int BN16, int AUX_A = 0>      // AUX_A: cache-policy bits of the A stream (2 = nt when the launch is larger than the Infinity Cache)
 __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int total, const unsigned int* gtable) {
   constexpr int NBL = 4 / BN16;
   __shared__ unsigned int tbl_all[4][kBcscTblDma];
@@ -608,7 +705,7 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, uns
     GM const unsigned int* rowbase = A2 + ((long long)kb * (p.bk / 2) + 16 * st) * p.M;
 #pragma unroll
     for (int x = 0; x < 4; ++x)
-      __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)((char*)abuf[slot] + 1024 * x), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)((char*)abuf[slot] + 1024 * x), 16, 0, AUX_A);
   };
   // chunk sequence of this k-group: (k-block, step) pairs in order; `next_chunk` advances a cursor
   auto next_chunk = [&](int& kb, int& st, unsigned long long& m, int kgp) -> bool {
@@ -712,8 +809,14 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, uns
   });
 }
 
-int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
+int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
+  BcscArgs a = a_in;
+  {
+    const unsigned long long es = a.a_type == LIBXSMM_DATATYPE_F32 ? 4ull : (a.a_type == LIBXSMM_DATATYPE_BF16 ? 2ull : 1ull);
+    const unsigned long long a_bytes = (unsigned long long)std::max(a.m_blocks, 0) * (unsigned long long)std::max(a.M, 0) * (unsigned long long)std::max(a.K, 0) * es;
+    a.nt_a = (a.stream_hint == 2 || (a.stream_hint == 0 && a_bytes > (256ull << 20))) ? 1 : 0;
+  }
   if (a.m_blocks <= 0 || a.M <= 0 || a.N <= 0) { if (name) *name = "(empty)"; return 0; }
   // matrix-core path: bf16 with VNNI-2 A, 32-deep k steps, 16-wide n sub-tiles, 16-row i tiles, 8-byte aligned C columns
   {
@@ -733,9 +836,13 @@ int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
           const unsigned int* table = (const unsigned int*)a.table;
           // the inverted pattern: already in place when the pattern came from host memory (built there, cached per kernel: run_bcsc)
           if (!a.table_ready) hipLaunchKernelGGL(bcsc_invert_kernel, dim3((unsigned int)a.nblk_n), dim3(64), 0, st, a.colptr, a.rowidx, (unsigned int*)a.table, a.nblk_n, nkb);
-          if (a.bn == 16) hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<1>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table);
-          else if (a.bn == 32) hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table);
-          else hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table);
+          // A is read exactly once: stream it non-temporally when it cannot be cache resident anyway (or the caller says so)
+          const unsigned long long a_bytes = (unsigned long long)a.m_blocks * a.M * a.K * 2ull;
+          const bool nta = a.stream_hint == 2 || (a.stream_hint == 0 && a_bytes > (256ull << 20));
+#define LAUNCH_DMA_(B_) do { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<B_, 2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); \
+                             else hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<B_, 0>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); } while (0)
+          if (a.bn == 16) LAUNCH_DMA_(1); else if (a.bn == 32) LAUNCH_DMA_(2); else LAUNCH_DMA_(4);
+#undef LAUNCH_DMA_
           if (name) *name = "bcsc_mfma_bf16_dma_kernel";
           return (int)hipGetLastError();
         }
@@ -743,6 +850,23 @@ int launch_bcsc(const BcscArgs& a, void* stream, const char** name) {
         else if (a.bn == 32) hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
         else hipLaunchKernelGGL((bcsc_mfma_bf16_kernel<4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
         if (name) *name = "bcsc_mfma_bf16_kernel";
+        return (int)hipGetLastError();
+      }
+    }
+  }
+  {   // f32 on the matrix cores: 16-deep k steps, 16-wide n sub-tiles, 16-row i tiles, 16-byte aligned B blocks and C columns
+    static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_MFMA"); return e && e[0] == '0'; }();
+    const int nbl_per_wave = (a.bn > 0 && 64 % a.bn == 0) ? 64 / a.bn : 0;
+    if (!off && a.a_type == LIBXSMM_DATATYPE_F32 && a.c_type == LIBXSMM_DATATYPE_F32 && a.bk % 16 == 0 && (a.bn == 16 || a.bn == 32 || a.bn == 64) && a.M % 16 == 0 && a.N % a.bn == 0 &&
+        (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTbl && ((size_t)a.a % 4 == 0) && ((size_t)a.bvals % 16 == 0) && ((size_t)a.c % 16 == 0) && (a.M % 4 == 0)) {
+      const unsigned int tiles_i = (unsigned int)((a.M + 63) / 64), tiles_n = (unsigned int)((a.N + 63) / 64);
+      const long long total = (long long)tiles_i * tiles_n * a.m_blocks;
+      if (total < (1ll << 31)) {
+        const dim3 grid((unsigned int)((total + 3) / 4));
+        if (a.bn == 16) hipLaunchKernelGGL((bcsc_mfma_f32_kernel<1>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
+        else if (a.bn == 32) hipLaunchKernelGGL((bcsc_mfma_f32_kernel<2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
+        else hipLaunchKernelGGL((bcsc_mfma_f32_kernel<4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
+        if (name) *name = "bcsc_mfma_f32_kernel";
         return (int)hipGetLastError();
       }
     }

@@ -43,6 +43,63 @@ def gather_shards(local, count: int, granule: int = 1, group=None):
     return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
 
 
+def gather_to_root(local, count: int, root: int = 0, granule: int = 1, group=None):
+    """Only `root` receives the full axis (the usual case: the consumer of C sits on one GPU).  Every other rank sends its shard straight to
+    the root (point-to-point: ncclSend / ncclRecv on RCCL, i.e. each source over its own xGMI link, no ring, no padding of uneven shards).
+    Returns the assembled tensor on the root and None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = shard_sizes(count, world, granule)
+    if rank != root:
+        if sizes[rank]:
+            dist.send(local.contiguous(), dst=root, group=group)
+        return None
+    out = torch.empty((count,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    begin, reqs = 0, []
+    for r, n in enumerate(sizes):
+        if r == root:
+            out[begin:begin + n] = local
+        elif n:
+            reqs.append(dist.irecv(out[begin:begin + n], src=r, group=group))
+        begin += n
+    for q in reqs:
+        q.wait()
+    return out
+
+
+def gather_shards_ipc(local, count: int, root: int = 0, granule: int = 1, group=None):
+    """The same gather through the C ABI (libxsmm_hip_ipc_export / libxsmm_hip_gather_shards): the ranks exchange 64-byte IPC handles over
+    the process group, the root pulls every shard with one device copy per source on its own stream.  Device tensors only."""
+    import torch
+    import torch.distributed as dist
+    api = capi.load()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sizes = shard_sizes(count, world, granule)
+    row = local[0].numel() * local.element_size() if local.shape[0] else 0
+    HB = 80                                   # LIBXSMM_HIP_IPC_HANDLE_BYTES
+    handle = (C.c_ubyte * HB)()
+    if local.shape[0] and api.hip_ipc_export(local.data_ptr(), handle) != 0:
+        raise RuntimeError("libxsmm_hip_ipc_export failed")
+    table = [None] * world
+    dist.all_gather_object(table, bytes(handle), group=group)
+    torch.cuda.synchronize()
+    dist.barrier(group)                      # every shard is complete and exported before the root reads
+    out = None
+    if rank == root:
+        out = torch.empty((count,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        blob = (C.c_ubyte * (HB * world)).from_buffer_copy(b"".join(t if t else bytes(HB) for t in table))
+        nbytes = (C.c_size_t * world)(*[n * row for n in sizes])
+        offs, acc = [], 0
+        for n in sizes:
+            offs.append(acc * row); acc += n
+        dst_off = (C.c_size_t * world)(*offs)
+        if api.hip_gather_shards(out.data_ptr(), world, rank, blob, local.data_ptr(), None, dst_off, nbytes) != 0:
+            raise RuntimeError("libxsmm_hip_gather_shards failed")
+    dist.barrier(group)                      # sources keep their buffers alive until the root is done
+    return out
+
+
 def byte_offsets(begin: int, strides: Sequence[int]) -> List[int]:
     """Byte offsets to add to the `primary` slots so that a batched launch starts at problem `begin`."""
     return [begin * s for s in strides]

@@ -40,11 +40,13 @@ def main():
         class W:
             pass
         w = W(); w.api = api
+        w.nsets, w.hint, w.dtype, w.alg_bytes_per_step, w.flops_per_step = nsets, 0, "f32", 5 * m * n * 4, 4.0 * m * n
+        w.label = lambda: label; w.kernel = lambda: api.hip_kernel_name(h, 0).decode()
         w.step = lambda i: capi.Api.call(h, params[i % nsets])
         for i in range(3):
             w.step(i)
         torch.cuda.synchronize(); api.check()
-        _, us = bench.timed(w, 20, lambda: None, rotate=True)
+        _, _, us = bench.timed(w, 20, 0.15)
         alg = 5 * m * n * 4
         print(json.dumps({"workload": f"meqn (a0 + inc(a1)) * (x2(a2) + a3), {m}x{n} f32", "mode": label, "kernel": api.hip_kernel_name(h, 0).decode(),
                           "us": round(us, 1), "algorithmic_GBs": round(alg / us / 1e3, 1), "frac_hbm_peak": round(alg / us / 1e3 / 8000, 3)}), flush=True)

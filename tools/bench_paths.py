@@ -42,8 +42,14 @@ class Work:
     def __init__(self, api, name, flops, alg_bytes, nsets, step, kernel=lambda: ""):
         self.api, self.name, self.flops, self.alg_bytes, self.nsets, self._step, self.kernel = api, name, flops, alg_bytes, nsets, step, kernel
 
+        # what bench.timed() reads of a workload
+        self.hint, self.alg_bytes_per_step, self.flops_per_step, self.dtype = 0, alg_bytes, flops, "f32"
+
     def step(self, i):
         self._step(i % self.nsets)
+
+    def label(self):
+        return self.name
 
 
 def nsets_for(set_bytes, cap_bytes=24 * 2 ** 30):
@@ -132,39 +138,51 @@ def fsspmdm(api, N, density, dtype=DT.F64, beta=0.0):
     return w
 
 
-def bcsc(api, m_blocks=8192, M=64, K=256, N=64, bk=32, bn=16):
+def bcsc(api, m_blocks=8192, M=64, K=256, N=64, bk=32, bn=16, dtype="bf16", host_pattern=False):
+    """BASELINE config #4 (bf16) and its f32 / 8-bit integer siblings; host_pattern: colptr / rowidx in plain host memory like the
+    reference's driver (inverted on the host once and cached with the kernel) instead of device arrays (inverted by a kernel per call)."""
     colptr, rowidx = structured_2_of_8(K, N, bk, bn)
     nnzb = len(rowidx)
-    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(m_blocks, 0, K, K, 0, N, DT.BF16, DT.BF16, DT.BF16, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    at, bt, ct, comp, sa, sc, vn = {"bf16": (DT.BF16, DT.BF16, DT.BF16, DT.F32, 2, 2, GEMM_FLAG.VNNI_A), "f32": (DT.F32, DT.F32, DT.F32, DT.F32, 4, 4, 0),
+                                    "u8i8": (DT.U8, DT.I8, DT.I32, DT.I32, 1, 4, GEMM_FLAG.VNNI_A)}[dtype]
+    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(m_blocks, 0, K, K, 0, N, at, bt, ct, comp), GEMM_FLAG.BETA_0 | vn, 0, capi.SpgemmConfig(M, bk, bn))
     assert h
-    set_bytes = m_blocks * M * (K + N) * 2
+    set_bytes = m_blocks * M * (K * sa + N * sc)
     ns = nsets_for(set_bytes)
-    As = [rnd(m_blocks * K * M, "bf16") for _ in range(ns)]
-    Cs = [torch.zeros(m_blocks * N * M, dtype=torch.int16, device=DEV) for _ in range(ns)]
-    bv, dcp, dri = rnd(nnzb * bk * bn, "bf16"), dev(colptr), dev(rowidx)
+
+    def operand(n):
+        if dtype == "bf16":
+            return rnd(n, "bf16")
+        if dtype == "f32":
+            return rnd(n, torch.float32)
+        return torch.randint(0, 255, (n,), dtype=torch.uint8, device=DEV)
+    As = [operand(m_blocks * K * M) for _ in range(ns)]
+    Cs = [torch.zeros(m_blocks * N * M * sc, dtype=torch.uint8, device=DEV) for _ in range(ns)]
+    bv, dcp, dri = operand(nnzb * bk * bn), dev(colptr), dev(rowidx)
     nblk = C.c_ulonglong(N // bn)
     ps = []
     for s in range(ns):
         p = capi.GemmParam()
-        p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = As[s].data_ptr(), bv.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), Cs[s].data_ptr()
+        p.a.primary, p.b.primary, p.b.quaternary, p.c.primary = As[s].data_ptr(), bv.data_ptr(), C.addressof(nblk), Cs[s].data_ptr()
+        p.b.secondary, p.b.tertiary = (colptr.ctypes.data, rowidx.ctypes.data) if host_pattern else (dcp.data_ptr(), dri.data_ptr())
         ps.append(p)
-    w = Work(api, f"packed_spgemm_bcsc bf16 2:8 M={M} K={K} N={N} bk={bk} bn={bn} m_blocks={m_blocks} beta=0",
-             2.0 * M * m_blocks * bk * bn * nnzb, float(m_blocks * M * (K * 2 + N * 2) + nnzb * bk * bn * 2), ns, lambda s: capi.Api.call(h, ps[s]),
+    w = Work(api, f"packed_spgemm_bcsc {dtype} 2:8 M={M} K={K} N={N} bk={bk} bn={bn} m_blocks={m_blocks} beta=0" + (" host pattern" if host_pattern else ""),
+             2.0 * M * m_blocks * bk * bn * nnzb, float(m_blocks * M * (K * sa + N * sc) + nnzb * bk * bn * sa), ns, lambda s: capi.Api.call(h, ps[s]),
              lambda: api.hip_kernel_name(h, 0).decode())
     w.dense_equiv_flops = 2.0 * M * m_blocks * N * K
-    w.keep = (As, Cs, bv, dcp, dri, nblk, ps)
+    w.keep = (As, Cs, bv, dcp, dri, colptr, rowidx, nblk, ps)
     return w
 
 
 def brgemm(api, m, dtype, batch, fused=0, br=1, beta=0):
-    a = argparse.Namespace(m=m, dtype=dtype, batch=batch, br=br, beta=beta, fused=fused, sets=0)
-    bw = bench.Workload(a, DEV)
-    set_bytes = batch * (2 * br + 1) * bw.a_bytes
+    bw = bench.Workload(api, DEV, dtype, m, batch, br=br, beta=beta, fused=fused)
+    set_bytes = batch * (2 * br + 1) * bw.blk
     if set_bytes * bw.nsets > 40 * 2 ** 30:
         raise RuntimeError("too large")
     w = Work(api, f"stride-BRGEMM {dtype} m=n=k={m} batch={batch} br={br} beta={beta}" + (" + colbias+ReLU (ext)" if fused else ""),
              bw.flops_per_step, bw.alg_bytes_per_step, bw.nsets, bw.step, lambda: api.hip_kernel_name(bw.handle, 1).decode())
     w.keep = bw
+    w.hint = bw.hint          # rotating sets larger than the Infinity Cache: operands read once from HBM, declared like bench.py does
     return w
 
 
@@ -433,12 +451,14 @@ def measure(w, steps, eager=0):
         w.step(i)
     torch.cuda.synchronize(); w.api.check()
     if eager:          # profiling mode (rocprofv3 --pmc): plain launches, no graph, no timing
+        w.api.hip_set_streaming_hint(w.hint)
         for i in range(eager):
             w.step(i)
         torch.cuda.synchronize(); w.api.check()
+        w.api.hip_set_streaming_hint(0)
         print(json.dumps({"workload": w.name, "kernel": w.kernel(), "eager_launches": eager + 5, "algorithmic_bytes_per_launch": int(w.alg_bytes)}), flush=True)
         return
-    _, us = bench.timed(w, steps, lambda: None, rotate=True)
+    _, _, us = bench.timed(w, steps, 0.15)
     w.api.check()
     gbs = w.alg_bytes / (us * 1e-6) / 1e9
     out = {"workload": w.name, "kernel": w.kernel(), "kernel_us": round(us, 2), "GFLOP/s": round(w.flops / us / 1e3, 1),
@@ -475,7 +495,7 @@ def main():
             if args.cpu and not args.eager:
                 w.cpu = fn
             return w
-        makers = [lambda: with_cpu(brgemm(api, 32, "f32", 4096), lambda: bench.cpu_baseline(argparse.Namespace(m=32, br=1, batch=4096, dtype="f32", beta=0), 3.0)),
+        makers = [lambda: with_cpu(brgemm(api, 32, "f32", 4096), lambda: bench.cpu_baseline(32, "f32", 1, 0, 0, 3.0, 0)),
                   lambda: with_cpu(csr_asparse(api, 65536, 0.15), lambda: cpu_csr(1024, 0.15)), lambda: with_cpu(csr_asparse(api, 65536, 0.10), lambda: cpu_csr(1024, 0.10)),
                   lambda: with_cpu(fsspmdm(api, 2 ** 20, 0.15), lambda: cpu_fsspmdm(49152, 0.15)),
                   lambda: with_cpu(bcsc(api), cpu_bcsc), lambda: with_cpu(brgemm(api, 64, "bf16", 2 ** 17, fused=1), cpu_fused),
@@ -502,7 +522,8 @@ def main():
         makers += [lambda: fsspmdm(api, 4800, 0.15), lambda: fsspmdm(api, 2 ** 20, 0.15), lambda: fsspmdm(api, 2 ** 20, 0.15, DT.F32),
                    lambda: fsspmdm(api, 2 ** 20, 0.15, DT.F64, 1.0)]
     if "bcsc" in only:
-        makers += [lambda: bcsc(api), lambda: bcsc(api, bk=32, bn=32)]
+        makers += [lambda: bcsc(api), lambda: bcsc(api, host_pattern=True), lambda: bcsc(api, bk=32, bn=32), lambda: bcsc(api, dtype="f32"), lambda: bcsc(api, dtype="f32", bn=32),
+                   lambda: bcsc(api, dtype="u8i8"), lambda: bcsc(api, dtype="u8i8", host_pattern=True)]
     if "quant" in only:
         makers += [lambda: meltw_block_quant(api, DT.MXFP4X2, "mxfp4"), lambda: meltw_block_quant(api, DT.MXBF8, "mxbf8"), lambda: meltw_block_quant(api, DT.NVFP4X2, "nvfp4")]
     if "meltw" in only:
