@@ -254,6 +254,9 @@ def timed(work, steps, min_seconds, barrier=lambda: None, label=None):
     else:
         g = capture(work, per_graph)
         g.replay(); torch.cuda.synchronize()              # untimed: the first replay uploads the graph
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(); g.replay(); c1.record(); torch.cuda.synchronize()        # untimed calibration: how long one replay really takes
+        replays = max(1, int(math.ceil(min_seconds / max(c0.elapsed_time(c1) * 1e-3, 1e-6) * 1.05)))
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()
@@ -264,9 +267,9 @@ def timed(work, steps, min_seconds, barrier=lambda: None, label=None):
         t1 = time.perf_counter()
         barrier()
         n = per_graph * replays
-        # launches the GPU executed for this workload since the last manifest entry: the eager ones + the first (untimed) replay + the
-        # timed replays; the capture itself went through the launch counter once without executing
-        executed = int(work.api.hip_launch_count(1)) + n
+        # launches the GPU executed for this workload since the last manifest entry: the eager ones + the two untimed replays (upload,
+        # calibration) + the timed replays; the capture itself went through the launch counter once without executing
+        executed = int(work.api.hip_launch_count(1)) + per_graph + n
     work.api.hip_set_streaming_hint(0)
     MANIFEST.append({"label": label or work.label(), "kernel": work.kernel(), "launches_executed": executed, "launches_timed": n, "streaming_hint": work.hint,
                      "algorithmic_bytes_per_launch": int(work.alg_bytes_per_step), "flops_per_launch": work.flops_per_step, "dtype": work.dtype,
