@@ -1075,6 +1075,63 @@ __global__ __launch_bounds__(256) void gemm_f32_blocked_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// f32 64 x 64 x K problems, one problem per WORKGROUP (streaming batches).  gemm_f32_dma_kernel<2,2> gives a wave the whole 64 x 64 tile:
+// 16 KiB of wave-private LDS, 8 waves per CU, 128 dependent-latency-bound MFMAs per problem behind every load round trip -- 0.51 of the
+// HBM roofline at batch 4096.  Here the four waves of a workgroup share the problem: per 32-deep K step the workgroup brings in two A
+// blocks and two B blocks (16 KiB) once by LDS-DMA, wave w fetching block w, and wave (wi, wj) multiplies A block wi with B block wj
+// (16 MFMAs): a quarter of the matrix work per wave, 20 waves per CU, and BOTH steps of a k = 64 problem in flight before the first
+// MFMA (two LDS images; longer chains refill an image two steps ahead, behind a second barrier).
+// NN, exact, 16-byte aligned operands, plain or STRIDE batch-reduce; any batch form and any epilogue (batch_ptrs / tile_init / tile_store).
+// ------------------------------------------------------------------------------------------------
+template <int AUX>
+__global__ __launch_bounds__(256) void gemm_f32_wg64_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds_all[2][4][1024];
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int bidx = logical_block(p);
+  const BatchPtrs q = batch_ptrs(p, bidx);
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  // DMA duty of wave w: blocks 0, 1 = A rows 0..31 / 32..63 (image [k][i] linear), blocks 2, 3 = B columns 0..31 / 32..63 (image [j][8 x 16 B] swizzled)
+  const bool isA = w < 2u;
+  unsigned int off[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const unsigned int L = lane + 64u * x, hi = L >> 3, lo = L & 7u;
+    off[x] = isA ? (hi * lda + lo * 4u) * 4u : (hi * ldb + ((lo ^ ((hi >> 1) & 7u)) * 4u)) * 4u;
+  }
+  const unsigned long long sub = isA ? 128ull * w : 128ull * ldb * (w - 2u), kstep = isA ? 128ull * lda : 128ull;
+  const unsigned int kchunks = (unsigned int)p.k >> 5;
+  const unsigned long long total = p.br_count * kchunks;
+  gcptr ar, br;
+  auto issue = [&](unsigned long long t) {
+    const unsigned int r = (unsigned int)t / kchunks, kc = (unsigned int)t - r * kchunks;          // 32-bit: launch_gemm checks the step count
+    br_base(p, q, r, ar, br);
+    gcptr src = (isA ? ar : br) + sub + kc * kstep;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(src + off[x]), (lds_vptr)((char*)&lds_all[t & 1ull][w][0] + 1024 * x), 16, 0, AUX);
+  };
+  const unsigned int wi = w & 1u, wj = w >> 1;
+  f32x16 acc;
+  TileCtx tc; tc.i = (int)(32u * wi + li); tc.j0 = (int)(32u * wj); tc.h = (int)h; tc.ivalid = true;
+  tile_init<true, true>(acc, p, q, tc);
+  if (total > 0) issue(0);
+  if (total > 1) issue(1);
+  for (unsigned long long t = 0; t < total; ++t) {
+    if (t + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step t landed, step t + 1 may fly
+    __syncthreads();
+    float af[16], bf[16];
+    frag_read<false>(af, &lds_all[t & 1ull][wi][0], (int)lane);
+    frag_read<true>(bf, &lds_all[t & 1ull][2 + wj][0], (int)lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t + 2 < total) { __syncthreads(); issue(t + 2); }       // every wave has read image t & 1: refill it two steps ahead
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s2], af[s2], acc, 0, 0, 0);
+  }
+  tile_store<true, true>(acc, p, q, tc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32 "blob" kernel for the odd small shapes LIBXSMM is known for (23x23x23 ...): one masked 32x32 tile, m, n, k, lda, ldb
 // <= 32, no transposes.  A_r (k*lda floats) and B_r (n*ldb floats) are contiguous blobs whatever the shape, so they are
 // brought in as FLAT dword streams with LDS-DMA (global_load_lds_dword: 256 contiguous bytes per instruction, no VGPRs, lanes
@@ -1162,6 +1219,73 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_t16_kernel(GemmArgs p) {
       if ((lane & 7) == 0) q.mask[i / 8 + (long long)j * ((((p.ldc + 15) / 16) * 16) / 8)] = (unsigned char)((pos >> lane) & 0xffu);
     }
     C[(long long)j * p.ldc + i] = act_apply(p.act, xv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16 x 16 problems (m = n = 16, k a multiple of 16), plain epilogue, PPW problems per wave.  A 16^3 problem is 1.5 KiB (bf16) or 3 KiB
+// (f32): with one problem per wave a launch is bound by the per-wave fixed cost (launch slot, address set-up, one load round trip for
+// five loads).  Here a wave owns PPW consecutive batch elements, issues ALL their operand loads before the first MFMA and keeps one
+// accumulator per problem.  Operand roles: A rows -> MFMA rows, B columns -> MFMA columns, so a lane ends up with four consecutive i of
+// one C column j and stores them as ONE 8- or 16-byte access.
+//   f32 : v_mfma_f32_16x16x4_f32, lane (x = lane & 15, g = lane >> 4) supplies A(i = x, k = k0 + 4 g + s) and B(k0 + 4 g + s, j = x);
+//         k is consumed group-interleaved inside a 16-deep chunk (as in gemm_mfma_f32_t16_kernel), a valid summation order.
+//   bf16: v_mfma_f32_16x16x16_bf16, A in VNNI-2 (two dwords = k 4 g .. 4 g + 3 of row x), B flat (8 contiguous bytes of column x).
+// ------------------------------------------------------------------------------------------------
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <int PPW, bool BF16>
+__global__ __launch_bounds__(256) void gemm_p16_kernel(GemmArgs p) {
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int first = (logical_block(p) * 4u + wave) * PPW;
+  if (first >= p.nbatch) return;
+  const unsigned int lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+  f32x4 acc[PPW];
+  BatchPtrs q[PPW];
+#pragma unroll
+  for (int pp = 0; pp < PPW; ++pp) { acc[pp] = (f32x4)0.0f; q[pp] = batch_ptrs(p, first + pp < p.nbatch ? first + pp : first); }
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const int kchunks = p.k >> 4;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar[PPW], br[PPW];
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) br_base(p, q[pp], r, ar[pp], br[pp]);
+    for (int kc = 0; kc < kchunks; ++kc) {
+      if (BF16) {
+        u32x2 av[PPW], bv[PPW];
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+          GM const unsigned int* A2 = (GM const unsigned int*)ar[pp] + (unsigned long long)(8u * kc + 2u * g) * lda + x;      // dword (k-pair, row)
+          av[pp][0] = A2[0]; av[pp][1] = A2[lda];
+          bv[pp] = *(GM const u32x2*)((GM const unsigned short*)br[pp] + (unsigned long long)x * ldb + 16u * kc + 4u * g);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp)
+          acc[pp] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4, av[pp]), __builtin_bit_cast(bf16x4, bv[pp]), acc[pp], 0, 0, 0);
+      } else {
+        float af[PPW][4]; f32x4 bv[PPW];
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+          GM const float* A = (GM const float*)ar[pp] + (unsigned long long)(16u * kc + 4u * g) * lda + x;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) af[pp][s2] = A[(unsigned long long)s2 * lda];
+          bv[pp] = *(GM const f32x4*)((GM const float*)br[pp] + (unsigned long long)x * ldb + 16u * kc + 4u * g);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pp][s2], bv[pp][s2], acc[pp], 0, 0, 0);
+      }
+    }
+  }
+  const bool c_f32 = !BF16 || p.c_type == LIBXSMM_DATATYPE_F32;
+#pragma unroll
+  for (int pp = 0; pp < PPW; ++pp) {
+    if (first + pp < p.nbatch) {
+      if (c_f32) st_stream((GM f32x4*)((GM float*)q[pp].c + (unsigned long long)x * (unsigned int)p.ldc + 4u * g), acc[pp]);
+      else { u32x2 v; v[0] = cvt_pk_bf16(acc[pp][0], acc[pp][1]); v[1] = cvt_pk_bf16(acc[pp][2], acc[pp][3]);
+             st_stream((GM u32x2*)((GM unsigned short*)q[pp].c + (unsigned long long)x * (unsigned int)p.ldc + 4u * g), v); }
+    }
   }
 }
 
@@ -1848,6 +1972,30 @@ static bool stream_nt(const GemmArgs& a, int elem_bytes_ab, int elem_bytes_c) {
   const unsigned long long per = a.br_count * (unsigned long long)a.k * (unsigned long long)(a.m + a.n) * elem_bytes_ab + (unsigned long long)a.m * a.n * elem_bytes_c;
   return per * a.nbatch > (256ull << 20);
 }
+// the four-problems-per-wave kernel for 16 x 16 problems: m = n = 16, k % 16 == 0, no transposes, beta = 0, no fused epilogue, operands whose
+// vector loads are aligned (B columns and C columns 16 bytes for f32, 8 bytes for bf16; bf16 A in VNNI-2 with dword-aligned rows)
+static bool p16_ok(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_P16"); return e && e[0] == '0'; }();
+  if (off || a.m != 16 || a.n != 16 || a.k <= 0 || (a.k % 16) != 0 || a.vnni_c || a.colbias || a.act) return false;
+  if (!(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) || (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B))) return false;
+  if (a.br_mode == 1 || a.br_mode == 2 || a.list_a) return false;            // strided forms only: alignment is decidable on the host
+  const bool f32 = a.a_type == LIBXSMM_DATATYPE_F32 && a.b_type == LIBXSMM_DATATYPE_F32 && a.c_type == LIBXSMM_DATATYPE_F32 && !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A);
+  const bool bf16 = a.a_type == LIBXSMM_DATATYPE_BF16 && a.b_type == LIBXSMM_DATATYPE_BF16 && (a.flags & LIBXSMM_GEMM_FLAG_VNNI_A) &&
+    (a.c_type == LIBXSMM_DATATYPE_BF16 || a.c_type == LIBXSMM_DATATYPE_F32);
+  if (!f32 && !bf16) return false;
+  const unsigned long long brs = a.br_mode == 3 ? (unsigned long long)(a.br_stride_a | a.br_stride_b) : 0ull;
+  const unsigned long long eb = f32 ? 4ull : 2ull, ec = a.c_type == LIBXSMM_DATATYPE_F32 ? 4ull : 2ull;
+  const unsigned long long bbits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (a.br_mode == 3 ? (unsigned long long)a.br_stride_b : 0ull) | (unsigned long long)a.ldb * eb;
+  const unsigned long long cbits = (unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2 | (unsigned long long)a.ldc * ec;
+  const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | brs;
+  if (f32) return (bbits & 15ull) == 0 && (cbits & 15ull) == 0 && (abits & 3ull) == 0;
+  return (bbits & 7ull) == 0 && (cbits & (ec == 4 ? 15ull : 7ull)) == 0 && (abits & 3ull) == 0;
+}
+static bool f32_wg64_ok(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_WG64"); return e && e[0] == '0'; }();
+  if (off || (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B)) || a.list_a || (a.br_mode != 0 && a.br_mode != 3)) return false;
+  return a.lda < (1 << 22) && a.ldb < (1 << 22) && a.k >= 32 && a.br_count * (unsigned long long)(a.k >> 5) < (1ull << 31);
+}
 static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
   static const int mode = []() { const char* e = getenv("LIBXSMM_HIP_F32_DMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
   return mode;
@@ -1891,6 +2039,18 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     return dim3((unsigned int)((tiles + 3) / 4));
   };
   dim3 grid;
+  // 16 x 16 problems with a plain epilogue: four problems per wave
+  if (p16_ok(a)) {
+    const bool bf16 = a.a_type == LIBXSMM_DATATYPE_BF16;
+    a.tiles_m = a.tiles_n = 1; a.map2d_shift = 0;
+    // small launches are bound by their own latency: keep one problem per wave there (4x the waves), four per wave from 16384 problems on
+    const bool four = a.nbatch >= 16384u;
+    grid = dim3((unsigned int)((a.nbatch + (four ? 15u : 3u)) / (four ? 16u : 4u)));
+    if (kernel_name) *kernel_name = bf16 ? "gemm_bf16_p16_kernel" : "gemm_f32_p16_kernel";
+    if (bf16) { if (four) hipLaunchKernelGGL((gemm_p16_kernel<4, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_p16_kernel<1, true>), grid, dim3(256), 0, st, a); }
+    else { if (four) hipLaunchKernelGGL((gemm_p16_kernel<4, false>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_p16_kernel<1, false>), grid, dim3(256), 0, st, a); }
+    return (int)hipGetLastError();
+  }
   // 2-D batches of exact f32 32^3 / 64^3 problems (K any multiple of 32), NN, strided: the workgroup-cooperative blocked kernel
   if (a.batch_inner && (pl.path == P_F32_1x1 || pl.path == P_F32_2x2) && f32_blocked_ok(a)) {
     const int mb = a.m / 32, ppw = 4 / mb;
@@ -1954,6 +2114,14 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_F32_2x2:
       grid = wave_grid(64, 64);
+      if (pl.exact && a.m == 64 && a.n == 64 && f32_wg64_ok(a) && operands_aligned16(a, 4)) {
+        a.map2d_shift = 0;                                  // one problem per workgroup: the super-tile dealing counts four problems per workgroup
+        grid = dim3(a.nbatch);
+        if (kernel_name) *kernel_name = "gemm_f32_wg64_kernel";
+        if (stream_nt(a, 4, 4)) hipLaunchKernelGGL((gemm_f32_wg64_kernel<2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_f32_wg64_kernel<0>), grid, dim3(256), 0, st, a);
+        break;
+      }
       if (pl.exact && operands_aligned16(a, 4) && f32_dma_mode() >= 1 && a.lda < (1 << 22) && a.ldb < (1 << 22)) {
         const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
         if (kernel_name) *kernel_name = "gemm_f32_dma_kernel<2,2>";
