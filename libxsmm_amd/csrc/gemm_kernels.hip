@@ -1461,6 +1461,65 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 64 x 64 x K problems (VNNI-2 A, flat B), one problem per WORKGROUP: the bf16 sibling of gemm_f32_wg64_kernel and the kernel of
+// BASELINE config #5.  gemm_bf16_stream_kernel<2,2> gives a wave the whole 64 x 64 tile and fetches A as 32 dword loads per lane; here the
+// four waves share the problem, BOTH operands of a 32-deep K step arrive by LDS-DMA (A: [16 k-pairs][64 rows] dwords = 4 KiB, linear;
+// B: [64 columns][32 k] = 4 KiB, 16-byte pieces XOR-swizzled on the source side), two DMA instructions per wave and step, and wave
+// (wi, wj) runs its two 32x32x16 MFMAs from conflict-free LDS reads.  Two images: a k = 64 problem has all its operand bytes in flight
+// before the first MFMA.  Any batch form, any epilogue (batch_ptrs / tile_init / tile_store).
+// ------------------------------------------------------------------------------------------------
+template <int AUX>
+__global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned int lds_all[2][2048];       // per image: A dwords [16][64], then B bytes [64][64]
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int bidx = logical_block(p);
+  const BatchPtrs q = batch_ptrs(p, bidx);
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  // DMA pieces of this wave: L = lane + 64 w of the A image (row kp = L >> 4, dwords 4 (L & 15) ..) and of the B image (column f = L >> 2,
+  // 16-byte piece (L & 3) ^ ((f >> 1) & 3) of the chunk's 64 bytes)
+  const unsigned int L = lane + 64u * w;
+  const unsigned int offA = ((L >> 4) * lda + 4u * (L & 15u)) * 4u;
+  const unsigned int fB = L >> 2, offB = fB * ldb * 2u + (((L & 3u) ^ ((fB >> 1) & 3u)) * 16u);
+  const unsigned int kchunks = (unsigned int)p.k >> 5;
+  const unsigned long long total = p.br_count * kchunks;
+  gcptr ar, br;
+  auto issue = [&](unsigned long long t) {
+    const unsigned int r = (unsigned int)t / kchunks, kc = (unsigned int)t - r * kchunks;
+    br_base(p, q, r, ar, br);
+    unsigned int* img = lds_all[t & 1ull];
+    __builtin_amdgcn_global_load_lds((GM const void*)(ar + (unsigned long long)kc * 64ull * lda + offA), (lds_vptr)((char*)img + 1024 * w), 16, 0, AUX);
+    __builtin_amdgcn_global_load_lds((GM const void*)(br + 64ull * kc + offB), (lds_vptr)((char*)img + 4096 + 1024 * w), 16, 0, AUX);
+  };
+  const unsigned int wi = w & 1u, wj = w >> 1;
+  f32x16 acc;
+  TileCtx tc; tc.i = (int)(32u * wi + li); tc.j0 = (int)(32u * wj); tc.h = (int)h; tc.ivalid = true;
+  tile_init<true, false>(acc, p, q, tc);
+  if (total > 0) issue(0);
+  if (total > 1) issue(1);
+  for (unsigned long long t = 0; t < total; ++t) {
+    if (t + 1 < total) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned int* img = lds_all[t & 1ull];
+    u32x4 af[2], bfr[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      // A operand of MFMA step s2: row i = 32 wi + li, k = 16 s2 + 8 h .. + 7 = k-pairs 8 s2 + 4 h + e
+#pragma unroll
+      for (int e = 0; e < 4; ++e) af[s2][e] = img[(8u * s2 + 4u * h + e) * 64u + 32u * wi + li];
+      const unsigned int f = 32u * wj + li;
+      bfr[s2] = *(const u32x4*)((const char*)img + 4096 + f * 64u + (((2u * s2 + h) ^ ((f >> 1) & 3u)) * 16u));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t + 2 < total) { __syncthreads(); issue(t + 2); }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[s2]), __builtin_bit_cast(bf16x8, af[s2]), acc, 0, 0, 0);
+  }
+  tile_store<true, false>(acc, p, q, tc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 8-bit integer streaming kernel (v_mfma_i32_32x32x32_i8): exact tiles, VNNI-4 A, flat B with 16-byte aligned columns,
 // k % 64 == 0.  Structure = gemm_bf16_stream_kernel: B through LDS-DMA with source-side swizzle, A straight into
 // operand registers.  The matrix core multiplies SIGNED bytes; an unsigned operand u is fed as (u ^ 0x80) = u - 128 and
@@ -1967,6 +2026,9 @@ static bool f32_blocked_ok(const GemmArgs& a) {
 // measured 50 % slower).  Operands shared by the batch (stride 0) or re-used by a 2-D batch are always cacheable.
 static int typesize_c(const GemmArgs& a) { return a.c_type == LIBXSMM_DATATYPE_F32 ? 4 : 2; }
 static bool stream_nt(const GemmArgs& a, int elem_bytes_ab, int elem_bytes_c) {
+  static const int force = []() { const char* e = getenv("LIBXSMM_HIP_NT"); return e ? atoi(e) : -1; }();      // experiments: 0 never, 1 always
+  if (force == 0) return false;
+  if (force == 1) return true;
   if (a.batch_inner || a.list_a || a.bs_a == 0 || a.bs_b == 0 || a.stream_hint == 1) return false;
   if (a.stream_hint == 2) return true;
   const unsigned long long per = a.br_count * (unsigned long long)a.k * (unsigned long long)(a.m + a.n) * elem_bytes_ab + (unsigned long long)a.m * a.n * elem_bytes_c;
@@ -1995,6 +2057,15 @@ static bool f32_wg64_ok(const GemmArgs& a) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_WG64"); return e && e[0] == '0'; }();
   if (off || (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B)) || a.list_a || (a.br_mode != 0 && a.br_mode != 3)) return false;
   return a.lda < (1 << 22) && a.ldb < (1 << 22) && a.k >= 32 && a.br_count * (unsigned long long)(a.k >> 5) < (1ull << 31);
+}
+// bf16 64 x 64 problems, one per workgroup: VNNI-2 A with 16-byte aligned rows (lda % 4 == 0), flat B with 16-byte aligned columns, strided forms
+static bool bf16_wg64_ok(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_WG64"); return e && e[0] == '0'; }();
+  if (off || a.list_a || (a.br_mode != 0 && a.br_mode != 3)) return false;
+  const unsigned long long brs = a.br_mode == 3 ? (unsigned long long)(a.br_stride_a | a.br_stride_b) : 0ull;
+  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b | brs |
+    (unsigned long long)((long long)a.lda * 4) | (unsigned long long)((long long)a.ldb * 2);
+  return (bits & 15ull) == 0 && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.k >= 32 && a.br_count * (unsigned long long)(a.k >> 5) < (1ull << 31);
 }
 static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
   static const int mode = []() { const char* e = getenv("LIBXSMM_HIP_F32_DMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
@@ -2147,6 +2218,14 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_BF16_2x2:
       grid = wave_grid(64, 64);
+      if (pl.exact && a.m == 64 && a.n == 64 && !a.batch_inner && bf16_wg64_ok(a)) {
+        a.map2d_shift = 0;
+        grid = dim3(a.nbatch);
+        if (kernel_name) *kernel_name = "gemm_bf16_wg64_kernel";
+        // cacheable loads whatever the size: non-temporal loads measured slower on this kernel (batch 65536 from HBM: 0.71 vs 0.75; batch 4096: 0.59 vs 0.61)
+        hipLaunchKernelGGL((gemm_bf16_wg64_kernel<0>), grid, dim3(256), 0, st, a);
+        break;
+      }
       if (pl.exact && bf16_stream_ok(a)) {
         if (kernel_name) *kernel_name = "gemm_bf16_stream_kernel<2,2>";
         // measured (batch 65536, operands from HBM): nt on the B stream takes the 32^3 kernel from 0.72 to 0.84 of the HBM roofline but the
