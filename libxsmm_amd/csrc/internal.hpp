@@ -53,6 +53,7 @@ enum Kind : int {
   K_MELTW,               // unary / binary / ternary TPP
   K_SPMM_ASPARSE,        // packed CSR, A sparse (also the FsSpMDM inner kernel)
   K_SPMM_BSPARSE,        // packed CSR/CSC, B sparse
+  K_SPMM_CSPARSE,        // packed CSC with a sparse C: the packed axis is reduced
   K_BCSC,                // block-sparse B, pattern at run time
   K_PGEMM,               // dense packed GEMM (A, B and C in SOA layout)
   K_MEQN                 // matrix equation (tree of TPPs)
@@ -118,6 +119,13 @@ struct PgemmArgs {
   const char* a; const char* b; char* c;
   int M, N, K, lda, ldb, ldc, dtype, beta0;
   long long P;
+};
+
+// C_val[z] (+)= sum_k sum_p A[(k*lda + rows[z])*P + p] * B[(k*ldb + cols[z])*P + p]
+struct CsparseArgs {
+  const char* a; const char* b; char* c;
+  const unsigned int* rows; const unsigned int* cols;
+  unsigned int nnz; int K, lda, ldb, beta0; long long P;
 };
 
 struct BcscArgs {
@@ -217,6 +225,7 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d);
 int launch_brsplit_reduce(const GemmArgs& args, const float* partial, int nsplit, void* stream);
 int launch_spmm(const SpmmArgs& args, void* stream, const char** kernel_name);
 int launch_bcsc(const BcscArgs& args, void* stream, const char** kernel_name);
+int launch_csparse(const CsparseArgs& args, void* stream, const char** kernel_name);
 int launch_pgemm(const PgemmArgs& args, void* stream, const char** kernel_name);
 
 // ---- runtime services (dispatch.cpp) ---------------------------------------------------------------

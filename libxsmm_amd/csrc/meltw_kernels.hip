@@ -558,6 +558,32 @@ __global__ __launch_bounds__(256) void vnni2_vec_kernel(MeltwArgs p, unsigned in
   *(GM u32x4e*)dst = lo; *(GM u32x4e*)(dst + 4) = hi;
 }
 
+// NORM -> VNNI4 of 8-bit payloads without LDS (the producer side of the 8-bit GEMMs / BCSC): a thread reads 4 consecutive i of the four
+// rows 4jq .. 4jq+3 (one dword each: a wave reads whole 256-byte row segments) and writes the 4 x 4 byte transpose as 16 contiguous
+// bytes (out[(jq*ldo + i)*4 + j2] = in[(4jq + j2)*ldi + i]); i in [m, ldo) and the rows past n are zero filled as the reference does
+// [ref: mateltwise ref :532-557 with v = 4].  Needs m, ldi, ldo multiples of 4 and 16-byte aligned bases.
+__global__ __launch_bounds__(256) void vnni4_vec_kernel(MeltwArgs p, unsigned int o4, unsigned int total) {
+  const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= total) return;
+  const unsigned int nq = (unsigned int)(p.n + 3) / 4u;
+  const unsigned int i4 = gid % o4, t = gid / o4, jq = t % nq, bidx = t / nq;
+  GM const unsigned char* in = (GM const unsigned char*)((gcptr)p.in0 + (long long)bidx * p.bs_in0);
+  GM unsigned int* out = (GM unsigned int*)((gptr)p.out + (long long)bidx * p.bs_out);
+  const long long i = 4ll * i4;
+  unsigned int r[4] = {0u, 0u, 0u, 0u};
+  if (i < p.m) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if ((int)(4 * jq + c) < p.n) r[c] = *(GM const unsigned int*)(in + (long long)(4 * jq + c) * p.ldi + i);
+  }
+  // byte e of r[c] = element (row 4jq + c, i + e)  ->  output dword e = bytes (c = 0..3) of column i + e
+  const unsigned int t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);   // (r0.b0 r1.b0 r0.b1 r1.b1), (r0.b2 r1.b2 r0.b3 r1.b3)
+  const unsigned int t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+  u32x4e o;
+  o[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); o[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+  o[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); o[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+  *(GM u32x4e*)(out + (long long)jq * p.ldo + i) = o;
+}
+
 // generic index-remapping transforms: one thread per OUTPUT element of the padded extent;
 // `mode` encodes the reference loop nest being restated.
 enum XformMode { XF_NORM_TO_VNNI = 1, XF_VNNI_TO_VNNIT, XF_NORM_TO_VNNIT, XF_VNNIT_TO_NORM, XF_VNNI4_TO_NORM, XF_VNNI4_TO_VNNI2, XF_PAD };
@@ -658,6 +684,39 @@ __global__ __launch_bounds__(256) void gather_cols_vec_kernel(MeltwArgs p, int e
   const long long src = (gather ? c * p.ldi : (long long)j * p.ldi) * elem_size + 16ll * v;
   const long long dst = (gather ? (long long)j * p.ldo : c * p.ldo) * elem_size + 16ll * v;
   *(GM u32x4e*)(out + dst) = *(GM const u32x4e*)(in + src);
+}
+
+// Row gather / scatter (GS_ROWS) through LDS: the direct form reads (gather) or writes (scatter) one random 4-byte word per lane -- 64
+// cache lines per wave instruction, 0.20 of the HBM roofline.  Here a workgroup stages one whole source (gather) or destination (scatter)
+// column in LDS with coalesced 16-byte accesses and does the random indexing THERE: HBM sees two streams.
+//   gather : lds[0 .. ldi) = in[.. + j*ldi];  out[i + j*ldo] = lds[idx[i]]
+//   scatter: lds = out column j (read-modify-write: rows that no index names keep their value);  lds[idx[i]] = in[i + j*ldi];  column written back
+// `rows` = staged extent (ldi for gather, ldo for scatter), a multiple of 16 / S elements; used when at least half of the staged rows are touched.
+template <int S>
+__global__ __launch_bounds__(256) void gs_rows_lds_kernel(MeltwArgs p, int rows) {
+  typedef typename Payload<S>::type T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gs_lds[];
+  T* col = (T*)gs_lds;
+  GM const T* in = (GM const T*)((gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0);
+  GM T* out = (GM T*)((gptr)p.out + (long long)blockIdx.y * p.bs_out);
+  const bool gather = (p.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER);
+  const void* idxp = gather ? p.aux_in : (const void*)p.aux_out;
+  const bool idx64 = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_8BYTES) != 0;
+  const long long j = blockIdx.x;
+  const int nvec = rows * S / 16;
+  GM const u32x4e* src = gather ? (GM const u32x4e*)(in + j * p.ldi) : (GM const u32x4e*)(out + j * p.ldo);
+  for (int v = threadIdx.x; v < nvec; v += 256) ((u32x4e*)col)[v] = src[v];
+  __syncthreads();
+#define XIDX(q) (idx64 ? (long long)((GM const unsigned long long*)idxp)[q] : (long long)((GM const unsigned int*)idxp)[q])
+  if (gather) {
+    for (int i = threadIdx.x; i < p.m; i += 256) out[i + j * p.ldo] = col[XIDX(i)];
+  } else {
+    for (int i = threadIdx.x; i < p.m; i += 256) col[XIDX(i)] = in[i + j * p.ldi];
+    __syncthreads();
+    GM u32x4e* dst = (GM u32x4e*)(out + j * p.ldo);
+    for (int v = threadIdx.x; v < nvec; v += 256) dst[v] = ((const u32x4e*)col)[v];
+  }
+#undef XIDX
 }
 
 // reductions over rows (collapse i: one wave per column, shuffle tree) or columns (collapse j:
@@ -1075,6 +1134,17 @@ template <template <int> class K> struct SizeSwitch;
       case 4: hipLaunchKernelGGL((KERNEL<4>), GRID, BLOCK, 0, ST, __VA_ARGS__); break;             \
       default: hipLaunchKernelGGL((KERNEL<8>), GRID, BLOCK, 0, ST, __VA_ARGS__); break; } } while (0)
 
+// row gather / scatter through an LDS-staged column: the staged extent (the side that is indexed) is the leading dimension of that side, must be
+// 16-byte granular and aligned, fit 64 KiB, and be at least half used (m >= rows / 2) -- otherwise the direct kernel moves fewer bytes.
+// The index values must lie inside the staged extent: true by the TPP's contract (an index beyond the leading dimension would alias the next column).
+static bool gs_rows_lds_ok(const MeltwArgs& a, int sz) {
+  const bool gather = a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER;
+  const long long rows = gather ? a.ldi : a.ldo;
+  if (rows <= 0 || (rows * sz) % 16 != 0 || rows * sz > 65536 || 2ll * a.m < rows || a.n <= 0 || a.n > 65535 * 16 || a.nbatch >= 65536) return false;
+  const size_t base = gather ? ((size_t)a.in0 | (size_t)a.bs_in0) : ((size_t)a.out | (size_t)a.bs_out);
+  return (base & 15) == 0;
+}
+
 int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
   if (a.nbatch == 0 || a.m <= 0 || a.n <= 0) { if (name) *name = "(empty)"; return 0; }
@@ -1116,6 +1186,11 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       const unsigned int o8 = (unsigned int)(a.ldo / 8), total = o8 * (unsigned int)((a.n + 1) / 2) * (unsigned int)a.nbatch;
       hipLaunchKernelGGL(vnni2_vec_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, a, o8, total);
       if (name) *name = "vnni2_vec_kernel";
+    } else if (mode == XF_NORM_TO_VNNI && v == 4 && sz == 1 && !xvec_off && base16 && a.m % 4 == 0 && a.ldi % 4 == 0 && a.ldo % 4 == 0 &&
+               (long long)(a.ldo / 4) * ((a.n + 3) / 4) * a.nbatch < (1ll << 32) - 256) {
+      const unsigned int o4 = (unsigned int)(a.ldo / 4), total = o4 * (unsigned int)((a.n + 3) / 4) * (unsigned int)a.nbatch;
+      hipLaunchKernelGGL(vnni4_vec_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, a, o4, total);
+      if (name) *name = "vnni4_vec_kernel";
     } else if (a.type == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT) {
       const long long tiles = (long long)((a.m + 31) / 32) * ((a.n + 31) / 32) * a.nbatch;
       LAUNCH_BY_SIZE(transpose_kernel, sz, dim3((unsigned int)tiles), dim3(256), st, a);
@@ -1135,6 +1210,16 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
         const unsigned int vpc = (unsigned int)(colbytes / 16), tot = vpc * (unsigned int)a.n;
         hipLaunchKernelGGL(gather_cols_vec_kernel, dim3((tot + 255u) / 256u, a.nbatch), dim3(256), 0, st, a, sz, vpc, tot);
         if (name) *name = "gather_cols_vec_kernel";
+      } else if ((a.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_ROWS) && !xvec_off && gs_rows_lds_ok(a, sz)) {
+        const int rows = a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER ? a.ldi : a.ldo;
+        const size_t lds_bytes = (size_t)rows * sz;
+        switch (sz) {
+          case 1: hipLaunchKernelGGL((gs_rows_lds_kernel<1>), dim3((unsigned int)a.n, a.nbatch), dim3(256), lds_bytes, st, a, rows); break;
+          case 2: hipLaunchKernelGGL((gs_rows_lds_kernel<2>), dim3((unsigned int)a.n, a.nbatch), dim3(256), lds_bytes, st, a, rows); break;
+          case 4: hipLaunchKernelGGL((gs_rows_lds_kernel<4>), dim3((unsigned int)a.n, a.nbatch), dim3(256), lds_bytes, st, a, rows); break;
+          default: hipLaunchKernelGGL((gs_rows_lds_kernel<8>), dim3((unsigned int)a.n, a.nbatch), dim3(256), lds_bytes, st, a, rows); break;
+        }
+        if (name) *name = "gs_rows_lds_kernel";
       } else {
         LAUNCH_BY_SIZE(gather_scatter_kernel, sz, dim3((unsigned int)((total + 255) / 256), a.nbatch), dim3(256), st, a);
         if (name) *name = "gather_scatter_kernel";

@@ -490,6 +490,12 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     if ((d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_COLS) && d.n >= 2048 && b.count == 1) {   // one big matrix reduced over its columns: two passes
       a.ws_bytes = (size_t)128 * 2 * (size_t)d.m * sizeof(float); a.ws = workspace(a.ws_bytes);
     }
+    if (d.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) {       // a missing mask pointer would be a device fault: say so instead
+      const bool fwd = t == LIBXSMM_MELTW_TYPE_UNARY_RELU || t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || t == LIBXSMM_MELTW_TYPE_UNARY_ELU;
+      const bool inv = t == LIBXSMM_MELTW_TYPE_UNARY_RELU_INV || t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || t == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV;
+      if (fwd && !p->out.secondary) { set_error(-2, "unary TPP with BITMASK_2BYTEMULT needs the mask destination in out.secondary"); return; }
+      if (inv && !p->in.secondary) { set_error(-2, "unary *_INV TPP with BITMASK_2BYTEMULT needs the mask in in.secondary"); return; }
+    }
     // scalars the reference reads through op.primary / out.secondary are read here, on the host
     if (t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || t == LIBXSMM_MELTW_TYPE_UNARY_ELU || t == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || t == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) {
       if (!p->op.primary) { set_error(-2, "unary TPP needs alpha in op.primary"); return; }
@@ -752,6 +758,24 @@ void run_bcsc(KernelCtx* k, const void* param) {
   finish_launch(err, kname);
 }
 
+void run_csparse(KernelCtx* k, const void* param) {
+  const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
+  const libxsmm_gemm_descriptor& d = k->g;
+  if (k->device != cur_device()) { set_error(-3, "packed sparse kernel was created on device %d but is called on device %d", k->device, cur_device()); return; }
+  scratch_reset();
+  CsparseArgs a{};
+  a.rows = k->d_idx; a.cols = k->d_vmap; a.nnz = k->sp_nnz; a.K = (int)d.k; a.lda = (int)d.lda; a.ldb = (int)d.ldb; a.P = k->packed_width;
+  a.beta0 = (d.flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 1 : 0;
+  // a synchronous call may be handed host memory like the other packed kernels: extents follow from the descriptor
+  a.a = (const char*)host_input(p->a.primary, (size_t)d.k * d.lda * (size_t)a.P * 4, 1);
+  a.b = (const char*)host_input(p->b.primary, (size_t)d.k * d.ldb * (size_t)a.P * 4, 1);
+  a.c = (char*)host_inout(p->c.primary, (size_t)std::max(1u, a.nnz) * 4, 1);
+  if (!a.a || !a.b || !a.c) { set_error(-2, "packed C-sparse kernel called with a NULL operand"); return; }
+  const char* kname = nullptr;
+  const int err = launch_csparse(a, tls().stream, &kname);
+  finish_launch(err, kname);
+}
+
 void run_any(KernelCtx* k, const void* param, const BatchSpec& b) {
   if (!param && k->kind != K_TILECFG) { set_error(-2, "kernel called with a NULL parameter struct"); return; }
   if (g_device_count <= 0 && k->kind != K_TILECFG) { set_error(-4, "no HIP device: kernel not launched (this backend has no CPU path)"); return; }
@@ -760,6 +784,7 @@ void run_any(KernelCtx* k, const void* param, const BatchSpec& b) {
     case K_MELTW: run_meltw(k, param, b); break;
     case K_SPMM_ASPARSE: case K_SPMM_BSPARSE: run_spmm(k, param, b); break;
     case K_BCSC: run_bcsc(k, param); break;
+    case K_SPMM_CSPARSE: run_csparse(k, param); break;
     case K_PGEMM: run_pgemm(k, param); break;
     case K_MEQN: scratch_reset(); run_meqn(k->eqn, param); break;
     case K_TILECFG: break;   // AMX tile configuration has no meaning here [ref: gemm ref :2821-2826]
@@ -1195,7 +1220,29 @@ LIBXSMM_API libxsmm_gemmfunction libxsmm_create_packed_spgemm_csc(libxsmm_gemm_s
   if (s.a_in_type != s.b_in_type || !column_ptr || !row_idx || !values) return nullptr;               // [ref: libxsmm_main.c:3611-3616]
   if ((s.a_in_type != LIBXSMM_DATATYPE_F32 && s.a_in_type != LIBXSMM_DATATYPE_F64) || s.out_type != s.a_in_type) return nullptr;
   if (packed_width <= 0 || tilecfg_halfset((unsigned int)flags) || (flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B))) return nullptr;
-  if (!(s.ldb == 0 && s.lda >= s.k && s.ldc >= s.n)) return nullptr;                                  // B sparse only
+  if (s.lda > 0 && s.ldb > 0 && s.ldc == 0) {
+    // C sparse [ref: src/generator_packed_spgemm.c:81-94]: f32 only [ref: generator_packed_spgemm_csc_csparse_avx_avx2_avx512.c:614-630], ldb >= n;
+    // the pattern (column_ptr over n, row_idx) is C's, the values array is not read at creation
+    if (s.a_in_type != LIBXSMM_DATATYPE_F32 || s.ldb < s.n || s.lda < s.m) return nullptr;
+    libxsmm_descriptor_blob blob;
+    libxsmm_gemm_descriptor* d = libxsmm_gemm_descriptor_init(&blob, s.a_in_type, s.b_in_type, s.comp_type, s.out_type, s.m, s.n, s.k, s.lda, s.ldb, s.ldc,
+      (int)(flags | LIBXSMM_GEMM_FLAG_USE_XGEMM_ABI), (int)prefetch);
+    if (!d) return nullptr;
+    const unsigned int nnz = column_ptr[s.n];
+    std::vector<unsigned int> cols(std::max(1u, nnz));
+    for (libxsmm_blasint n = 0; n < s.n; ++n) {
+      if (column_ptr[n] > column_ptr[n + 1] || column_ptr[n + 1] > nnz) return nullptr;
+      for (unsigned int z = column_ptr[n]; z < column_ptr[n + 1]; ++z) { if ((libxsmm_blasint)row_idx[z] >= s.m) return nullptr; cols[z] = (unsigned int)n; }
+    }
+    KernelCtx* c = new_unregistered(K_SPMM_CSPARSE, d); if (!c) return nullptr;
+    c->packed_width = packed_width; c->sp_nnz = nnz;
+    c->d_idx = to_device(row_idx, nnz); c->d_vmap = to_device(cols.data(), nnz);
+    if (!c->d_idx || !c->d_vmap) { drop_unregistered(c); return nullptr; }
+    c->nflops = (unsigned int)(2ull * nnz * s.k * packed_width);
+    c->kname_single = c->kname_batched = "csparse_kernel";
+    return (libxsmm_gemmfunction)handle_for_slot(c->slot);
+  }
+  if (!(s.ldb == 0 && s.lda >= s.k && s.ldc >= s.n)) return nullptr;                                  // otherwise: B sparse
   libxsmm_descriptor_blob blob;
   libxsmm_gemm_descriptor* d = libxsmm_gemm_descriptor_init(&blob, s.a_in_type, s.b_in_type, s.comp_type, s.out_type, s.m, s.n, s.k, s.lda, s.ldb, s.ldc,
     (int)(flags | LIBXSMM_GEMM_FLAG_USE_XGEMM_ABI), (int)prefetch);

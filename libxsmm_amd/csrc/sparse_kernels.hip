@@ -924,4 +924,41 @@ int launch_pgemm(const PgemmArgs& a, void* stream, const char** name) {
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Packed SpGEMM with a sparse C (libxsmm_create_packed_spgemm_csc with ldc == 0): for every stored entry (m, n) of C
+//   C_val[z] (+)= sum_k sum_p A[k][m][p] * B[k][n][p]          [ref: src/generator_packed_spgemm_csc_csparse_avx_avx2_avx512.c:17-195]
+// -- the packed axis is REDUCED (a sampled dense-dense product).  One wave per stored entry, lanes along p, a wave reduction at the end.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csparse_kernel(CsparseArgs p) {
+  const unsigned int z = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (z >= p.nnz) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned int m = ((GM const unsigned int*)p.rows)[z], n = ((GM const unsigned int*)p.cols)[z];
+  GM const float* a = (GM const float*)p.a + (long long)m * p.P;
+  GM const float* b = (GM const float*)p.b + (long long)n * p.P;
+  const long long sa = (long long)p.lda * p.P, sb = (long long)p.ldb * p.P;
+  float acc = 0.0f;
+  const bool vec = (p.P % 4 == 0) && ((((size_t)p.a | (size_t)p.b) & 15) == 0);
+  for (int k = 0; k < p.K; ++k) {
+    GM const float* ak = a + k * sa; GM const float* bk = b + k * sb;
+    if (vec) {
+      for (long long q = 4ll * lane; q < p.P; q += 256) {
+        const f32x4v x = *(GM const f32x4v*)(ak + q), y = *(GM const f32x4v*)(bk + q);
+        acc = fmaf(x[0], y[0], acc); acc = fmaf(x[1], y[1], acc); acc = fmaf(x[2], y[2], acc); acc = fmaf(x[3], y[3], acc);
+      }
+    } else {
+      for (long long q = lane; q < p.P; q += 64) acc = fmaf(ak[q], bk[q], acc);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) { GM float* c = (GM float*)p.c + z; *c = p.beta0 ? acc : *c + acc; }
+}
+int launch_csparse(const CsparseArgs& a, void* stream, const char** name) {
+  if (name) *name = "csparse_kernel";
+  if (a.nnz == 0 || a.K <= 0 || a.P <= 0) return 0;
+  hipLaunchKernelGGL(csparse_kernel, dim3((a.nnz + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 }  // namespace xamd

@@ -76,6 +76,9 @@ void oracle_packed_spgemm_csc_bsparse(int dtype, int M, int N, int K, int P,
 void oracle_packed_spgemm_csr_bsparse(int dtype, int M, int N, int K, int P,
   const unsigned int* row_ptr, const unsigned int* col_idx, const void* b_vals,
   const void* A, int lda, void* C, int ldc, int beta0);
+/* sparse C (ldc == 0) variant of the packed CSC kernel: the packed axis is reduced [ref: src/generator_packed_spgemm.c:81-94] */
+void oracle_packed_spgemm_csc_csparse(int N, int K, int P, const unsigned int* col_ptr, const unsigned int* row_idx,
+  const float* A, int lda, const float* B, int ldb, float* Cvals, int beta0);
 /* Block-sparse B (BCSC), per M-block:  C[mb][n][m] = beta*C + sum_k A[mb][k][m]*B[k][n].
  * a_type/c_type in {F32, BF16}; bf16 A is VNNI-2 packed [K/2][M][2] when vnni_a != 0.
  * [ref: samples/xgemm_sparse/spmm_kernel.c:74-217 (gold), :219-375 (layouts)] */

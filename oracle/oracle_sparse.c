@@ -139,6 +139,22 @@ void oracle_packed_spgemm_bcsc(int a_type, int c_type, int M, int N, int K, int 
   }
 }
 
+/* Packed CSC with a SPARSE C (ldc == 0): C_val[z] (+)= sum_k sum_p A[k][row[z]][p] * B[k][n][p] for every stored entry z of column n.
+ * The reference has no gold loop for it; this restates what its generator emits
+ * [src/generator_packed_spgemm_csc_csparse_avx_avx2_avx512.c:17-195: per entry an accumulator over (k, packed chunks), horizontal add,
+ *  beta handling on the scalar] with the accumulation in (k, p) order; pinned against the reference's JIT kernel within f32 summation-order tolerance. */
+void oracle_packed_spgemm_csc_csparse(int N, int K, int P, const unsigned int* col_ptr, const unsigned int* row_idx,
+  const float* A, int lda, const float* B, int ldb, float* Cvals, int beta0)
+{
+  int n, k; long long p; unsigned int z;
+  for (n = 0; n < N; ++n) for (z = col_ptr[n]; z < col_ptr[n + 1]; ++z) {
+    double acc = 0.0;
+    for (k = 0; k < K; ++k) for (p = 0; p < P; ++p)
+      acc += (double)A[((long long)k * lda + row_idx[z]) * P + p] * (double)B[((long long)k * ldb + n) * P + p];
+    Cvals[z] = beta0 ? (float)acc : (float)((double)Cvals[z] + acc);
+  }
+}
+
 void oracle_fsspmdm(int dtype, int M, int N, int K, const unsigned int* row_ptr, const unsigned int* col_idx,
   const void* a_vals, const void* B, int ldb, void* C, int ldc, int beta0)
 {

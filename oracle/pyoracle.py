@@ -65,6 +65,7 @@ class Oracle:
         L.oracle_packed_spgemm_csr_bsparse.argtypes = [i, i, i, i, i, vp, vp, vp, vp, i, vp, i, i]
         L.oracle_packed_spgemm_bcsc.argtypes = [i, i, i, i, i, i, i, i, i, vp, vp, vp, vp, vp, i]
         L.oracle_fsspmdm.argtypes = [i, i, i, i, vp, vp, vp, vp, i, vp, i, i]
+        L.oracle_packed_spgemm_csc_csparse.argtypes = [i, i, i, vp, vp, vp, i, vp, i, vp, i]; L.oracle_packed_spgemm_csc_csparse.restype = None
         for n in ("oracle_packed_gemm", "oracle_packed_gemm_ac_rm", "oracle_packed_gemm_bc_rm"):
             getattr(L, n).argtypes = [i, i, i, i, i, vp, i, vp, i, vp, i, i]; getattr(L, n).restype = None
         for n in ("oracle_packed_spgemm_csr_asparse", "oracle_packed_spgemm_csc_bsparse", "oracle_packed_spgemm_csr_bsparse",

@@ -142,6 +142,9 @@ TRANSFORMS = [
     (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F32, 128, 96, 128, 96), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F32, 68, 200, 72, 208),
     (UNARY.TRANSFORM_NORM_TO_NORMT, DT.BF16, 72, 40, 80, 48), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F64, 66, 10, 66, 12), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.I8, 80, 32, 96, 32),
     (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 64, 7, 64, 72), (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 136, 130, 144, 136),
+    # NORM -> VNNI4 of 8-bit payloads, vector kernel: n a multiple of 4, n with 1 / 2 / 3 rows missing (zero-filled), ldo > m (zero-filled columns)
+    (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.I8, 64, 16, 64, 64), (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.I8, 132, 13, 136, 140), (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.I8, 16, 6, 16, 16),
+    (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.BF8, 256, 35, 256, 260), (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.HF8, 20, 12, 24, 20),
 ]
 
 

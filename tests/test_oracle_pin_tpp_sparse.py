@@ -331,6 +331,46 @@ def test_bcsc_int8_vs_reference_jit(reference, a_type, bk, bn, beta0):
     reference.release_kernel(h)
 
 
+@pytest.mark.parametrize("M,N,K,P,density,beta0", [(9, 9, 9, 16, 0.3, 0), (35, 35, 4, 32, 0.1, 0), (20, 9, 7, 64, 0.5, 0)])
+def test_packed_csc_csparse_vs_reference_jit(reference, M, N, K, P, density, beta0):
+    """The C-sparse variant of the packed CSC kernel (ldc == 0) has no gold loop in the reference: the restatement is pinned against the
+    reference's JIT kernel itself (summation order differs: 1e-5 of the norm).  Pinned for beta = 1 only: with LIBXSMM_GEMM_FLAG_BETA_0 the
+    reference's AVX-512 kernel returns values that are NOT sum_k sum_p A*B for columns with more than two stored entries (observed here on
+    9x9 / 24 entries: off by O(1), while the same call with beta = 1 agrees to 3e-7) -- for beta = 0 the restatement is checked against plain
+    algebra instead (test_packed_csc_csparse_beta0_is_the_plain_sum)."""
+    orc = pyoracle.oracle()
+    rng = np.random.default_rng(17)
+    rowptr, colidx = random_csr(rng, N, M, density)                       # CSR of C^T == CSC of C: pointer over n, indices = rows m
+    nnz = int(rowptr[-1])
+    A = rand_values(rng, K * M * P, DT.F32); B = rand_values(rng, K * N * P, DT.F32)
+    C0 = rand_values(rng, max(1, nnz), DT.F32)
+    ref_c, jit_c = C0.copy(), C0.copy()
+    orc.lib.oracle_packed_spgemm_csc_csparse(N, K, P, rowptr.ctypes.data, colidx.ctypes.data, A.ctypes.data, M, B.ctypes.data, N, ref_c.ctypes.data, beta0)
+    h = reference.create_packed_spgemm_csc(capi.gemm_shape(M, N, K, M, N, 0, DT.F32, DT.F32, DT.F32, DT.F32), GEMM_FLAG.BETA_0 if beta0 else 0, 0, P,
+                                           rowptr.ctypes.data, colidx.ctypes.data, C0.ctypes.data)
+    if not h:
+        pytest.skip("reference JIT refused the C-sparse configuration on this host")
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.c.primary = A.ctypes.data, B.ctypes.data, jit_c.ctypes.data
+    capi.Api.call(h, p)
+    assert normf_rel(ref_c, jit_c, DT.F32) <= 1e-5
+    reference.release_kernel(h)
+
+
+def test_packed_csc_csparse_beta0_is_the_plain_sum():
+    orc = pyoracle.oracle()
+    rng = np.random.default_rng(18)
+    M, N, K, P = 9, 9, 9, 16
+    rowptr, colidx = random_csr(rng, N, M, 0.3)
+    nnz = int(rowptr[-1])
+    A = rand_values(rng, K * M * P, DT.F32); B = rand_values(rng, K * N * P, DT.F32)
+    got = rand_values(rng, nnz, DT.F32)
+    orc.lib.oracle_packed_spgemm_csc_csparse(N, K, P, rowptr.ctypes.data, colidx.ctypes.data, A.ctypes.data, M, B.ctypes.data, N, got.ctypes.data, 1)
+    A3, B3 = A.reshape(K, M, P).astype(np.float64), B.reshape(K, N, P).astype(np.float64)
+    want = np.array([(A3[:, colidx[z], :] * B3[:, n, :]).sum() for n in range(N) for z in range(rowptr[n], rowptr[n + 1])])
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
 # ---- dense packed GEMMs: restatement vs the reference's JIT kernels -------------------------------------------------
 PACKED_GEMM = [(9, 9, 9, 16, 0), (4, 7, 5, 8, 1), (20, 9, 20, 16, 1), (35, 9, 35, 8, 0)]
 

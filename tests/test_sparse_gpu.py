@@ -306,6 +306,38 @@ def test_bcsc(a_type, c_type, vnni, M, N, K, mb, bk, bn, keep, beta0):
     api.release_kernel(h)
 
 
+@pytest.mark.parametrize("M,N,K,P,density,beta0", [(9, 9, 9, 16, 0.3, 1), (9, 9, 9, 16, 0.3, 0), (35, 35, 4, 32, 0.1, 0), (20, 9, 7, 64, 0.5, 1), (35, 35, 20, 4096, 0.09, 1), (12, 7, 3, 10, 0.4, 0)])
+def test_packed_csc_csparse(M, N, K, P, density, beta0):
+    """libxsmm_create_packed_spgemm_csc with ldc == 0: C sparse, the packed axis reduced [ref: src/generator_packed_spgemm.c:81-94]."""
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(19)
+    rowptr, colidx = random_csr(rng, N, M, density)                       # CSC of C: pointer over n, row indices m
+    nnz = int(rowptr[-1])
+    A = rand_values(rng, K * M * P, DT.F32); B = rand_values(rng, K * N * P, DT.F32)
+    C0 = rand_values(rng, max(1, nnz), DT.F32)
+    ref = C0.copy()
+    orc.lib.oracle_packed_spgemm_csc_csparse(N, K, P, rowptr.ctypes.data, colidx.ctypes.data, A.ctypes.data, M, B.ctypes.data, N, ref.ctypes.data, beta0)
+    h = api.create_packed_spgemm_csc(capi.gemm_shape(M, N, K, M, N, 0, DT.F32, DT.F32, DT.F32, DT.F32), GEMM_FLAG.BETA_0 if beta0 else 0, 0, P,
+                                     rowptr.ctypes.data, colidx.ctypes.data, C0.ctypes.data)
+    assert h
+    assert api.hip_kernel_name(h, 0).decode() == "csparse_kernel"
+    dA, dB, dC = _dev(A), _dev(B), _dev(C0.copy())
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.c.primary = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    assert normf_rel(ref[:nnz], _host(dC, np.float32)[:nnz], DT.F32) <= 1e-5
+    # plain host memory is staged for a synchronous call, like the other packed kernels
+    hc = C0.copy()
+    p.a.primary, p.b.primary, p.c.primary = A.ctypes.data, B.ctypes.data, hc.ctypes.data
+    capi.Api.call(h, p)
+    api.check()
+    assert normf_rel(ref[:nnz], hc[:nnz], DT.F32) <= 1e-5
+    api.release_kernel(h)
+    # f64 and a row index outside m are refused (the reference: f32 only)
+    assert not api.create_packed_spgemm_csc(capi.gemm_shape(M, N, K, M, N, 0, DT.F64, DT.F64, DT.F64, DT.F64), 0, 0, P, rowptr.ctypes.data, colidx.ctypes.data, C0.ctypes.data)
+
+
 # 8-bit integers (SURVEY 8 row a9: u8 x i8 -> i32 and i8 x u8 -> i32, A in VNNI-4): exact, so the bar is bit equality
 @pytest.mark.parametrize("a_type", [DT.U8, DT.I8])
 @pytest.mark.parametrize("M,N,K,mb,bk,bn,keep,beta0", [(64, 64, 256, 6, 32, 16, 0.25, 1), (64, 64, 256, 3, 32, 32, 0.25, 0), (16, 24, 40, 4, 8, 8, 0.5, 1), (32, 32, 64, 2, 16, 4, 0.42, 0),

@@ -293,6 +293,53 @@ def meltw_big(api, typ, name, m=4096, n=8192, in_dt=DT.F32, out_dt=DT.F32, flags
     return w
 
 
+def meltw_gs(api, kind, m=4096, n=8192):
+    """Row / offset gathers and the column scatter (f32): the general one-element-per-thread kernels' cases."""
+    if kind == "gather_rows":       # out[i, j] = in[idx[i], j]: m indices
+        flags, typ, cnt = UNARY_FLAG.GS_ROWS | UNARY_FLAG.IDX_SIZE_4BYTES, UNARY.GATHER, m
+    elif kind == "gather_offs":     # out[i, j] = in[off[i + j*m]]: one linear offset per element
+        flags, typ, cnt = UNARY_FLAG.GS_OFFS | UNARY_FLAG.IDX_SIZE_4BYTES, UNARY.GATHER, m * n
+    else:                           # scatter of whole columns: out[:, idx[j]] = in[:, j]
+        flags, typ, cnt = UNARY_FLAG.GS_COLS | UNARY_FLAG.IDX_SIZE_4BYTES, UNARY.SCATTER, n
+    h = api.dispatch_meltw_unary(typ, capi.UnaryShape(m, n, m, m, DT.F32, DT.F32, DT.F32), flags)
+    assert h, kind
+    ns = nsets_for(2 * m * n * 4 + cnt * 4)
+    X = [rnd(m * n) for _ in range(ns)]
+    Y = [torch.zeros(m * n, device=DEV) for _ in range(ns)]
+    if kind == "gather_rows":
+        idx = torch.randperm(m, device=DEV).to(torch.int32)
+    elif kind == "gather_offs":
+        idx = (torch.randperm(m * n // 16, device=DEV).to(torch.int64).repeat_interleave(16) * 16 + torch.arange(16, device=DEV).repeat(m * n // 16)).to(torch.int32)   # 64-byte runs
+    else:
+        idx = torch.randperm(n, device=DEV).to(torch.int32)
+    ps = []
+    for s2 in range(ns):
+        q = capi.UnaryParam(); q.in_.primary, q.out.primary = X[s2].data_ptr(), Y[s2].data_ptr()
+        if typ == UNARY.GATHER:
+            q.in_.secondary = idx.data_ptr()
+        else:
+            q.out.secondary = idx.data_ptr()
+        ps.append(q)
+    w = Work(api, f"meltw unary {kind} f32 {m}x{n}", float(m * n), float(2 * m * n * 4 + cnt * 4), ns, lambda s2: capi.Api.call(h, ps[s2]), lambda: api.hip_kernel_name(h, 0).decode())
+    w.keep = (X, Y, idx, ps)
+    return w
+
+
+def meltw_xform8(api, typ, name, m=4096, n=8192):
+    """8-bit layout transforms (NORM -> VNNI4 and back): the producer side of the 8-bit GEMMs."""
+    h = api.dispatch_meltw_unary(typ, capi.UnaryShape(m, n, m, m, DT.I8, DT.I8, DT.I8), 0)
+    assert h, name
+    ns = nsets_for(2 * m * n)
+    X = [torch.randint(0, 255, (m * n,), dtype=torch.uint8, device=DEV) for _ in range(ns)]
+    Y = [torch.zeros(m * n, dtype=torch.uint8, device=DEV) for _ in range(ns)]
+    ps = []
+    for s2 in range(ns):
+        q = capi.UnaryParam(); q.in_.primary, q.out.primary = X[s2].data_ptr(), Y[s2].data_ptr(); ps.append(q)
+    w = Work(api, f"meltw unary {name} i8 {m}x{n}", float(m * n), float(2 * m * n), ns, lambda s2: capi.Api.call(h, ps[s2]), lambda: api.hip_kernel_name(h, 0).decode())
+    w.keep = (X, Y, ps)
+    return w
+
+
 def meltw_block_quant(api, out_dt, name, m=4096, n=8192):
     """bf16 -> MXFP4X2 / MXBF8 / NVFP4X2 (block scales to out.secondary).  Not part of the default list: `--only quant`."""
     blk = 16 if out_dt == DT.NVFP4X2 else 32
@@ -524,6 +571,10 @@ def main():
     if "bcsc" in only:
         makers += [lambda: bcsc(api), lambda: bcsc(api, host_pattern=True), lambda: bcsc(api, bk=32, bn=32), lambda: bcsc(api, dtype="f32"), lambda: bcsc(api, dtype="f32", bn=32),
                    lambda: bcsc(api, dtype="u8i8"), lambda: bcsc(api, dtype="u8i8", host_pattern=True)]
+    if "tpp2" in only:       # the general (one element per thread) TPP kernels
+        makers += [lambda: meltw_gs(api, "gather_rows"), lambda: meltw_gs(api, "gather_offs"), lambda: meltw_gs(api, "scatter_cols"),
+                   lambda: meltw_xform8(api, UNARY.TRANSFORM_NORM_TO_VNNI4, "NORM_TO_VNNI4"), lambda: meltw_big(api, UNARY.TRANSFORM_NORM_TO_VNNI2, "NORM_TO_VNNI2 bf16 (odd ld)", m=4090, in_dt=DT.BF16, out_dt=DT.BF16),
+]
     if "quant" in only:
         makers += [lambda: meltw_block_quant(api, DT.MXFP4X2, "mxfp4"), lambda: meltw_block_quant(api, DT.MXBF8, "mxbf8"), lambda: meltw_block_quant(api, DT.NVFP4X2, "nvfp4")]
     if "meltw" in only:
