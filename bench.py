@@ -442,17 +442,13 @@ def run_config5(args, api, dev, rank, world, dist, barrier):
     gather_ms = None
     if args.gather and dist is not None:
         # the only collective of the path: the final result gather (RCCL over xGMI), timed on its own
-        shard = work.C[0]
-        sizes = [0] * world
-        for r in range(world):
-            bb, ee = C.c_size_t(0), C.c_size_t(0)
-            api.hip_shard_range(args.total, 1, world, r, C.byref(bb), C.byref(ee)); sizes[r] = (ee.value - bb.value) * 64 * 64
-        outs = [torch.empty(sz, dtype=shard.dtype, device=dev) for sz in sizes] if rank == 0 else None
+        from libxsmm_amd import parallel
+        shard = work.C[0].view(torch.uint8).view(mine, -1)              # bytes: RCCL has no 16-bit integer type; one row per problem
         for _ in range(2):
-            dist.gather(shard, outs, dst=0)
+            parallel.gather_to_root(shard, args.total, root=0)          # point-to-point: every source straight to rank 0 over its own link
         torch.cuda.synchronize(); barrier()
         t0 = time.perf_counter()
-        dist.gather(shard, outs, dst=0)
+        parallel.gather_to_root(shard, args.total, root=0)
         torch.cuda.synchronize(); barrier()
         gather_ms = (time.perf_counter() - t0) * 1e3
     if dist is not None:
@@ -493,7 +489,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":      # BENCH_FORCE_DIST: exercise the RCCL code path with one rank (1-GPU boxes)
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=dev)
