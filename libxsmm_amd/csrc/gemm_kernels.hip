@@ -1075,6 +1075,99 @@ __global__ __launch_bounds__(256) void gemm_f32_blocked_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The blocked kernel for 16 x 16 x K tiles (K a multiple of 16, plain epilogue): same workgroup structure as gemm_f32_blocked_kernel -- a
+// 128 x 128 macro tile (8 x 8 problems), eight 32 x 32 x 32 operand blocks per step by LDS-DMA into a double buffer, wave = 64 x 64 on the
+// 32x32x2 MFMA -- only the addressing differs: a 32 x 32 operand block is 2 x 2 SUB-blocks, (problem 2b / 2b+1) x (16-deep sub-step 2t / 2t+1
+// of the flattened (batch-reduce element, 16-deep K chunk) sequence), and a 32 x 32 accumulator tile is 2 x 2 problems of C.
+//   A image [32 k][32 i]: DMA instruction x covers k = 8x .. 8x+7 -> sub-step x >> 1 is uniform per instruction; lanes pick the problem.
+//   B image [32 j][8 x 16 B] swizzled: a lane's 16-byte piece belongs to sub-step (source chunk) >> 2 -> selected per lane.
+// One tile per wave (gemm_p16_kernel / t16) reaches 37 % of the f32 matrix peak on this regime; this form is the one that is matrix-bound.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_blocked16_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds_all[2][8][1024];
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int ni = p.batch_inner, MI = ni / 8u;
+  unsigned int g = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) g = (g & 7u) * (gridDim.x >> 3) + (g >> 3);
+  const unsigned int mj = g / MI, mi = g - mj * MI;
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
+  const unsigned int kch = (unsigned int)p.k >> 4;                         // 16-deep sub-steps per batch-reduce element
+  const unsigned int total = ((unsigned int)p.br_count * kch) >> 1;        // 32-deep steps (launch_gemm guarantees an even sub-step count)
+  // --- DMA duty: A block w = problems pa0, pa0 + 1 (rows 0..15 / 16..31 of the block); B block w = problems pb0, pb0 + 1 (columns)
+  const unsigned int pa0 = mi * 8u + 2u * w, pb0 = mj * 8u + 2u * w;
+  gcptr a_base = (gcptr)p.a + (long long)pa0 * p.bs_a, b_base = (gcptr)p.b + (long long)pb0 * p.bs_b;
+  long long offA[4], offB[4]; unsigned int subB[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const unsigned int L = lane + 64u * x, hi = L >> 3, lo = L & 7u;
+    // A piece: image row k = hi (sub-step hi >> 4 == x >> 1), 16-byte column group lo: problem lo >> 2, rows 4 (lo & 3) ..
+    offA[x] = (long long)(lo >> 2) * p.bs_a + (long long)(((hi & 15u) * lda + (lo & 3u) * 4u) * 4u);
+    // B piece: image column j = hi (problem hi >> 4, local column hi & 15), slot lo holds source chunk cs = lo ^ swizzle: k = 4 cs .. 4 cs + 3
+    const unsigned int cs = lo ^ ((hi >> 1) & 7u);
+    subB[x] = cs >> 2;
+    offB[x] = (long long)(hi >> 4) * p.bs_b + (long long)(((hi & 15u) * ldb + (cs & 3u) * 4u) * 4u);
+  }
+  auto issue = [&](unsigned int t, int buf) {
+    // the two 16-deep sub-steps of step t: flattened index 2t and 2t + 1 -> (batch-reduce element, K chunk)
+    long long sa[2], sb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const unsigned int q = 2u * t + u, r = q / kch, kc = q - r * kch;
+      sa[u] = (long long)r * brs_a + (long long)kc * 64ll * lda;           // 16 k columns of A = 16 * lda floats
+      sb[u] = (long long)r * brs_b + (long long)kc * 64ll;                 // 16 k rows of B = 64 bytes down every column
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(a_base + sa[x >> 1] + offA[x]), (lds_vptr)((char*)&lds_all[buf][w][0] + 1024 * x), 16, 0, 0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(b_base + (subB[x] ? sb[1] : sb[0]) + offB[x]), (lds_vptr)((char*)&lds_all[buf][4 + w][0] + 1024 * x), 16, 0, 0);
+  };
+  const unsigned int wi = w & 1u, wj = w >> 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+  if (total != 0) issue(0, 0);
+  for (unsigned int t = 0; t < total; ++t) {
+    const int buf = (int)(t & 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float af[2][16], bf[2][16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) frag_read<false>(af[mt], &lds_all[buf][2 * wi + mt][0], (int)lane);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) frag_read<true>(bf[nt], &lds_all[buf][4 + 2 * wj + nt][0], (int)lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t + 1 < total) issue(t + 1, buf ^ 1);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nt][s2], af[mt][s2], acc[mt][nt], 0, 0, 0);
+  }
+  // C: accumulator tile (mt, nt) covers problems (bi0 + (li >> 4), bj0 + (j >> 4)); lane = row li, register r = column jl_of(r, h)
+  const unsigned int ldc = (unsigned int)p.ldc;
+  static_for<4>([&](auto idx) {
+    constexpr int mt = idx.value / 2, nt = idx.value % 2;
+    const unsigned int bi = mi * 8u + 2u * (2u * wi + mt) + (li >> 4), bj0 = mj * 8u + 2u * (2u * wj + nt);
+    gptr crow = (gptr)p.c + (long long)bi * p.bs_c + (long long)((li & 15u) * 4u);
+    static_for<16>([&](auto rc) {
+      constexpr int r = rc.value;
+      const unsigned int j = (unsigned int)jl_of(r, (int)h);                 // 0..31 inside the tile
+      st_stream((GM float*)(crow + (long long)(bj0 + (j >> 4)) * p.bs_c2 + (long long)((j & 15u) * ldc) * 4ll), acc[mt][nt][r]);
+    });
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32 64 x 64 x K problems, one problem per WORKGROUP (streaming batches).  gemm_f32_dma_kernel<2,2> gives a wave the whole 64 x 64 tile:
 // 16 KiB of wave-private LDS, 8 waves per CU, 128 dependent-latency-bound MFMAs per problem behind every load round trip -- 0.51 of the
 // HBM roofline at batch 4096.  Here the four waves of a workgroup share the problem: per 32-deep K step the workgroup brings in two A
@@ -2009,6 +2102,20 @@ static bool f32_lean_ok(const GemmArgs& a) {
 }
 // the workgroup-cooperative blocked kernel: 2-D batch whose grid divides into 128 x 128 macro tiles, square 32^3 / 64^3 problems,
 // no transposes, plain or STRIDE batch-reduce, 16-byte aligned operands, 32-bit offsets inside a block
+// the blocked kernel on 16 x 16 x K tiles: grid divisible into 8 x 8 problems, an even number of 16-deep sub-steps, plain epilogue, f32, NN, strided
+static bool f32_blocked16_ok(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOCKED"); return e && e[0] == '0'; }();
+  if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.a_type != LIBXSMM_DATATYPE_F32 || a.b_type != LIBXSMM_DATATYPE_F32 || a.c_type != LIBXSMM_DATATYPE_F32) return false;
+  if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B)) || a.vnni_c || !(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) || a.colbias || a.act) return false;
+  if (a.m != 16 || a.n != 16 || a.k <= 0 || (a.k % 16) != 0) return false;
+  const unsigned long long subs = a.br_count * (unsigned long long)(a.k / 16);
+  if (subs == 0 || (subs & 1ull) || subs >= (1ull << 31)) return false;
+  const unsigned int ni = a.batch_inner, nj = a.nbatch / a.batch_inner;
+  if (ni % 8u || nj % 8u) return false;
+  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
+    (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) | (unsigned long long)((long long)a.lda * 4) | (unsigned long long)((long long)a.ldb * 4);
+  return (bits & 15ull) == 0ull && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22);
+}
 static bool f32_blocked_ok(const GemmArgs& a) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOCKED"); return e && e[0] == '0'; }();
   if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3)) return false;
@@ -2110,6 +2217,14 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     return dim3((unsigned int)((tiles + 3) / 4));
   };
   dim3 grid;
+  // 2-D batches of f32 16 x 16 x K tiles with a plain epilogue: the blocked kernel on 2 x 2 sub-blocks
+  if (a.batch_inner && f32_blocked16_ok(a)) {
+    a.tiles_m = a.tiles_n = 1; a.map2d_shift = 0;
+    grid = dim3((a.batch_inner / 8u) * ((a.nbatch / a.batch_inner) / 8u));
+    if (kernel_name) *kernel_name = "gemm_f32_blocked16_kernel";
+    hipLaunchKernelGGL(gemm_f32_blocked16_kernel, grid, dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+  }
   // 16 x 16 problems with a plain epilogue: four problems per wave
   if (p16_ok(a)) {
     const bool bf16 = a.a_type == LIBXSMM_DATATYPE_BF16;

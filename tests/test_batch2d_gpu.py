@@ -63,7 +63,12 @@ def _blocked(dtype, m, ni, nj, br, fused=False, seed=3):
             capi.Api.call(h, q)
     api.hip_sync(); api.check()
     got2, got1 = C2.cpu().numpy().view(npdt), C1.cpu().numpy().view(npdt)
-    assert np.array_equal(got2, got1), "2-D batch differs from the loop of single calls"
+    if m == 16 and dtype == DT.F32:
+        # single 16^3 calls run on the 16x16x4 MFMA (k summed in a lane-group-interleaved order), the blocked 2-D form on 32x32x2 in natural
+        # order: the same products, a different but equally valid f32 summation order -- equal to rounding, both pinned to the oracle below
+        assert normf_rel(got1, got2, dtype) < 1e-6
+    else:
+        assert np.array_equal(got2, got1), "2-D batch differs from the loop of single calls"
     # the oracle, tile by tile
     orc = pyoracle.oracle()
     want = np.zeros(ni * nj * mm, dtype=npdt)
@@ -83,9 +88,13 @@ def _blocked(dtype, m, ni, nj, br, fused=False, seed=3):
 
 
 # (32, 16), (64, 32), (16, 64): grids that the launch deals to the XCDs as 8x8 / 16x16 super-tiles; the others take the linear order
-@pytest.mark.parametrize("m,ni,nj,br", [(32, 8, 8, 4), (32, 5, 3, 1), (16, 8, 8, 6), (64, 4, 6, 3), (32, 16, 16, 2), (32, 32, 16, 2), (32, 64, 32, 1), (16, 16, 64, 3), (64, 32, 16, 1)])
+@pytest.mark.parametrize("m,ni,nj,br", [(32, 8, 8, 4), (32, 5, 3, 1), (16, 8, 8, 6), (64, 4, 6, 3), (32, 16, 16, 2), (32, 32, 16, 2), (32, 64, 32, 1), (16, 16, 64, 3), (64, 32, 16, 1), (16, 16, 24, 2), (16, 64, 64, 8), (16, 8, 16, 5)])
 def test_f32_2d_batch_is_the_nested_loop(m, ni, nj, br):
-    _blocked(DT.F32, m, ni, nj, br)
+    name = _blocked(DT.F32, m, ni, nj, br)
+    if m == 16 and ni % 8 == 0 and nj % 8 == 0 and br % 2 == 0:
+        assert name == "gemm_f32_blocked16_kernel", name
+    if m in (32, 64) and ni % (128 // m) == 0 and nj % (128 // m) == 0:
+        assert name.startswith("gemm_f32_blocked_kernel"), name
 
 
 @pytest.mark.parametrize("m,ni,nj,br", [(32, 8, 8, 4), (64, 8, 4, 3), (64, 3, 5, 1), (32, 32, 16, 2), (64, 16, 32, 2)])

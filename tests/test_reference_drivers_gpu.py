@@ -126,10 +126,18 @@ def test_reference_packed_drivers(binary, which, edge_mtx):
     assert errs and max(errs) <= (1e-5 if binary.endswith("_f32") else 1e-6), out[-1500:]
 
 
+# BASELINE config #3 at its full sizes: the 35 x 35 operator, N = 35 quantities, packed width P = 4096 and 65 536
+@pytest.mark.parametrize("binary,P", [("asparse_packed_csr_f32", 4096), ("asparse_packed_csr_f32", 65536), ("asparse_packed_csr", 4096)])
+def test_reference_packed_driver_at_baseline_size(binary, P, edge_mtx):
+    out = check(binary, "35", "35", "35", str(P), "2", edge_mtx[0])
+    errs = [float(x) for x in re.findall(r"max error: ([0-9.eE+-]+)", out)]
+    assert errs and max(errs) <= (1e-5 if binary.endswith("_f32") else 1e-6), out[-1500:]
+
+
 # samples/xgemm_sparse_Ainregs/pyfr_driver_asp_reg.c -- file N reps [beta]
-@pytest.mark.parametrize("beta", [0, 1])
-def test_reference_fsspmdm_driver(beta, edge_mtx):
-    out = check("pyfr_driver_asp_reg", edge_mtx[0], "4800", "2", beta)
+@pytest.mark.parametrize("beta,N", [(0, 4800), (1, 4800), (0, 1 << 20)])
+def test_reference_fsspmdm_driver(beta, N, edge_mtx):
+    out = check("pyfr_driver_asp_reg", edge_mtx[0], str(N), "2", beta)
     errs = [float(x) for x in re.findall(r"\(libxsmm vs\. gold\): abs=([0-9.eE+-]+)", out)]
     assert errs and max(errs) <= 1e-6, out[-1500:]
 
