@@ -134,6 +134,19 @@ LIBXSMM_API int libxsmm_hip_ipc_export(const void* device_ptr, void* handle);
 LIBXSMM_API int libxsmm_hip_gather_shards(void* dst, int world, int self_rank, const void* handles, const void* self_src,
   const size_t* src_offsets, const size_t* dst_offsets, const size_t* nbytes);
 
+/* ---- input preparation (the reference keeps these in its samples) ----------------------------------------
+ * libxsmm_hip_mtx_read: Matrix-Market coordinate file -> CSR (by_column = 0: ptr over rows, idx = columns) or CSC (by_column = 1), values as
+ * F32 or F64, entries in any order, empty rows / columns allowed [ref: samples/xgemm_norm_packed/common_edge_proxy.h:29-320].
+ * libxsmm_hip_bcsc_from_dense: dense K x N operand stored as the reference's BCSC driver stores it (B[n*K + k]) -> colptr / rowidx / block values
+ * [blk][bn][bk], all-zero blocks dropped [ref: samples/xgemm_sparse/spmm_kernel.c:306-347].
+ * Every output array comes from libxsmm_aligned_malloc (device-visible pinned memory when a device is present): pattern arrays can be passed to
+ * libxsmm_create_packed_spgemm_* / the BCSC call and value arrays to a.primary / b.primary as they are; release them with libxsmm_free.
+ * Return EXIT_SUCCESS or EXIT_FAILURE (unreadable file, inconsistent header, index out of range, block sizes that do not divide). */
+LIBXSMM_API int libxsmm_hip_mtx_read(const char* path, int by_column, libxsmm_datatype value_type, unsigned int** ptr, unsigned int** idx, void** values,
+  unsigned int* rows, unsigned int* cols, unsigned int* nnz);
+LIBXSMM_API int libxsmm_hip_bcsc_from_dense(libxsmm_datatype type, const void* dense, int K, int N, int bk, int bn,
+  unsigned int** colptr, unsigned int** rowidx, void** values, unsigned int* nnzb);
+
 /* ---- run-time specialisation of the fixed-pattern sparse kernels ---------------------
  * libxsmm_create_packed_spgemm_csr/_csc, libxsmm_create_spgemm_csr_areg and libxsmm_fsspmdm_create can compile a
  * kernel with the sparsity pattern unrolled into the instruction stream (hiprtc), as the reference's JIT does

@@ -271,6 +271,10 @@ class Api:
             self.hip_meltw_unary_batch_strided = f("hip_meltw_unary_batch_strided", None, [vp, C.POINTER(UnaryParam), C.c_size_t, ll, ll, ll])
             self.hip_meltw_binary_batch_strided = f("hip_meltw_binary_batch_strided", None, [vp, C.POINTER(BinaryParam), C.c_size_t, ll, ll, ll])
             self.hip_meltw_ternary_batch_strided = f("hip_meltw_ternary_batch_strided", None, [vp, C.POINTER(TernaryParam), C.c_size_t, ll, ll, ll, ll])
+            pu = C.POINTER(C.POINTER(C.c_uint))
+            self.hip_mtx_read = f("hip_mtx_read", C.c_int, [C.c_char_p, C.c_int, C.c_int, pu, pu, C.POINTER(vp), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
+            self.hip_bcsc_from_dense = f("hip_bcsc_from_dense", C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, pu, pu, C.POINTER(vp), C.POINTER(C.c_uint)])
+            self.free = f("free", None, [vp])
             self.hip_ipc_export = f("hip_ipc_export", C.c_int, [vp, vp])
             self.hip_gather_shards = f("hip_gather_shards", C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp])
             self.hip_shard_range = f("hip_shard_range", None, [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)])

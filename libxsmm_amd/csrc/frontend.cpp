@@ -140,6 +140,93 @@ LIBXSMM_API void libxsmm_free(const void* memory) {
   std::free(const_cast<void*>(memory));
 }
 
+// ---- input preparation: Matrix-Market readers and the BCSC builder -------------------------------------------------
+// The reference keeps these in its samples [samples/xgemm_norm_packed/common_edge_proxy.h:29-320 (CSR / CSC readers),
+// samples/xgemm_sparse/spmm_kernel.c:306-347 (dense -> BCSC)]; here they are library calls whose outputs live in device-visible memory
+// (libxsmm_aligned_malloc: pinned host memory when a device is present), so that pattern arrays go straight to libxsmm_create_* / the BCSC
+// call and value arrays straight into a.primary / b.primary without staging.  Entries may come in any order (the reference's reader
+// needs them sorted by row); rows / columns without entries get empty ranges.
+LIBXSMM_API int libxsmm_hip_mtx_read(const char* path, int by_column, libxsmm_datatype value_type, unsigned int** ptr, unsigned int** idx, void** values,
+  unsigned int* rows, unsigned int* cols, unsigned int* nnz) {
+  if (!path || !ptr || !idx || !values || !rows || !cols || !nnz || (value_type != LIBXSMM_DATATYPE_F32 && value_type != LIBXSMM_DATATYPE_F64)) return EXIT_FAILURE;
+  *ptr = *idx = nullptr; *values = nullptr; *rows = *cols = *nnz = 0;
+  FILE* f = std::fopen(path, "r");
+  if (!f) return EXIT_FAILURE;
+  char line[512];
+  unsigned int r = 0, c = 0, n = 0; bool header = false;
+  std::vector<unsigned int> er, ec; std::vector<double> ev;
+  while (std::fgets(line, sizeof(line), f)) {
+    if (line[0] == '%' || line[0] == '\n') continue;
+    if (!header) {
+      if (std::sscanf(line, "%u %u %u", &r, &c, &n) != 3 || r == 0 || c == 0) { std::fclose(f); return EXIT_FAILURE; }
+      header = true; er.reserve(n); ec.reserve(n); ev.reserve(n);
+      continue;
+    }
+    unsigned int i, j; double v = 1.0;
+    const int got = std::sscanf(line, "%u %u %lf", &i, &j, &v);
+    if (got < 2 || i == 0 || j == 0 || i > r || j > c) { std::fclose(f); return EXIT_FAILURE; }     // pattern files carry no value: 1.0
+    er.push_back(i - 1); ec.push_back(j - 1); ev.push_back(got == 3 ? v : 1.0);
+  }
+  std::fclose(f);
+  if (!header || er.size() != n) return EXIT_FAILURE;
+  const unsigned int outer = by_column ? c : r;
+  const std::vector<unsigned int>& ko = by_column ? ec : er; const std::vector<unsigned int>& ki = by_column ? er : ec;
+  const size_t es = value_type == LIBXSMM_DATATYPE_F32 ? 4 : 8;
+  unsigned int* p = (unsigned int*)libxsmm_aligned_malloc(sizeof(unsigned int) * ((size_t)outer + 1), 64);
+  unsigned int* x = (unsigned int*)libxsmm_aligned_malloc(sizeof(unsigned int) * std::max<size_t>(n, 1), 64);
+  void* v = libxsmm_aligned_malloc(es * std::max<size_t>(n, 1), 64);
+  if (!p || !x || !v) { libxsmm_free(p); libxsmm_free(x); libxsmm_free(v); return EXIT_FAILURE; }
+  std::fill(p, p + outer + 1, 0u);
+  for (unsigned int z = 0; z < n; ++z) ++p[ko[z] + 1];
+  for (unsigned int o = 0; o < outer; ++o) p[o + 1] += p[o];
+  std::vector<unsigned int> pos(p, p + outer);
+  std::vector<unsigned int> order(n);
+  for (unsigned int z = 0; z < n; ++z) order[pos[ko[z]]++] = z;            // stable counting sort by the outer index ...
+  for (unsigned int o = 0; o < outer; ++o)                                  // ... then by the inner index inside every row / column
+    std::sort(order.begin() + p[o], order.begin() + p[o + 1], [&](unsigned int a, unsigned int b) { return ki[a] < ki[b]; });
+  for (unsigned int z = 0; z < n; ++z) {
+    x[z] = ki[order[z]];
+    if (es == 4) ((float*)v)[z] = (float)ev[order[z]]; else ((double*)v)[z] = ev[order[z]];
+  }
+  *ptr = p; *idx = x; *values = v; *rows = r; *cols = c; *nnz = n;
+  return EXIT_SUCCESS;
+}
+
+// Dense K x N operand in the reference driver's layout (column n = K contiguous values: B[n*K + k]) -> BCSC with bk x bn blocks: blocks that are
+// entirely zero are dropped; values[blk][dn][dk] (k fastest), colptr over the N / bn block columns, rowidx = k-block.  `type` gives the element
+// size only (F32, BF16, I8 / U8 ...).
+LIBXSMM_API int libxsmm_hip_bcsc_from_dense(libxsmm_datatype type, const void* dense, int K, int N, int bk, int bn,
+  unsigned int** colptr, unsigned int** rowidx, void** values, unsigned int* nnzb) {
+  const size_t es = libxsmm_typesize(type);
+  if (!dense || !colptr || !rowidx || !values || !nnzb || es == 0 || bk <= 0 || bn <= 0 || K <= 0 || N <= 0 || K % bk || N % bn) return EXIT_FAILURE;
+  const int nkb = K / bk, nnb = N / bn;
+  const unsigned char* d = (const unsigned char*)dense;
+  std::vector<unsigned int> cp(1, 0u), ri;
+  for (int nb = 0; nb < nnb; ++nb) {
+    for (int kb = 0; kb < nkb; ++kb) {
+      bool nz = false;
+      for (int dn = 0; dn < bn && !nz; ++dn) {
+        const unsigned char* row = d + ((size_t)(nb * bn + dn) * K + (size_t)kb * bk) * es;
+        for (size_t q = 0; q < (size_t)bk * es; ++q) if (row[q] != 0) { nz = true; break; }      // any set bit keeps the block (so does -0.0)
+      }
+      if (nz) ri.push_back((unsigned int)kb);
+    }
+    cp.push_back((unsigned int)ri.size());
+  }
+  unsigned int* p = (unsigned int*)libxsmm_aligned_malloc(sizeof(unsigned int) * cp.size(), 64);
+  unsigned int* x = (unsigned int*)libxsmm_aligned_malloc(sizeof(unsigned int) * std::max<size_t>(ri.size(), 1), 64);
+  unsigned char* v = (unsigned char*)libxsmm_aligned_malloc(es * (size_t)bk * bn * std::max<size_t>(ri.size(), 1), 64);
+  if (!p || !x || !v) { libxsmm_free(p); libxsmm_free(x); libxsmm_free(v); return EXIT_FAILURE; }
+  std::copy(cp.begin(), cp.end(), p); std::copy(ri.begin(), ri.end(), x);
+  size_t blk = 0;
+  for (int nb = 0; nb < nnb; ++nb)
+    for (unsigned int b = cp[nb]; b < cp[nb + 1]; ++b, ++blk)
+      for (int dn = 0; dn < bn; ++dn)
+        std::memcpy(v + ((blk * bn + dn) * bk) * es, d + ((size_t)(nb * bn + dn) * K + (size_t)ri[b] * bk) * es, (size_t)bk * es);
+  *colptr = p; *rowidx = x; *values = v; *nnzb = (unsigned int)ri.size();
+  return EXIT_SUCCESS;
+}
+
 // ---- timer / rng -----------------------------------------------------------------------------------------
 LIBXSMM_API libxsmm_timer_tickint libxsmm_timer_tick(void) {
   return (libxsmm_timer_tickint)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();

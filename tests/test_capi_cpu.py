@@ -124,3 +124,89 @@ def test_public_headers_are_clean_c99_and_cxx11(header, compiler, std, tmp_path)
     inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include")
     r = subprocess.run([compiler, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+# ---- input preparation: host code, runs without a GPU -------------------------------------------------------------------
+def _mtx(tmp_path, rows, cols, entries, name="a.mtx"):
+    path = tmp_path / name
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% comment\n")
+        f.write(f"{rows} {cols} {len(entries)}\n")
+        for r, c, v in entries:
+            f.write(f"{r + 1} {c + 1} {v!r}\n")
+    return str(path).encode()
+
+
+@pytest.mark.parametrize("by_column", [0, 1])
+@pytest.mark.parametrize("vt", ["F32", "F64"])
+def test_mtx_reader_builds_csr_and_csc_from_unsorted_entries(tmp_path, by_column, vt):
+    import ctypes as C
+    import numpy as np
+    from libxsmm_amd import capi
+    from libxsmm_amd.capi import DT
+    api = capi.load()
+    rng = np.random.default_rng(4)
+    rows, cols = 35, 20
+    pos = rng.choice(rows * cols, size=90, replace=False)
+    pos = pos[(pos // cols != 7) & (pos % cols != 3)]                    # an empty row and an empty column
+    rng.shuffle(pos)                                                     # entries in no particular order
+    ent = [(int(q // cols), int(q % cols), float(np.round(rng.random() - 0.5, 3))) for q in pos]
+    path = _mtx(tmp_path, rows, cols, ent)
+    ptr, idx, val = C.POINTER(C.c_uint)(), C.POINTER(C.c_uint)(), C.c_void_p()
+    r, c, n = C.c_uint(), C.c_uint(), C.c_uint()
+    dt = DT.F32 if vt == "F32" else DT.F64
+    assert api.hip_mtx_read(path, by_column, dt, C.byref(ptr), C.byref(idx), C.byref(val), C.byref(r), C.byref(c), C.byref(n)) == 0
+    assert (r.value, c.value, n.value) == (rows, cols, len(ent))
+    outer = cols if by_column else rows
+    p = np.ctypeslib.as_array(ptr, (outer + 1,)).copy(); x = np.ctypeslib.as_array(idx, (n.value,)).copy()
+    v = np.ctypeslib.as_array(C.cast(val, C.POINTER(C.c_float if vt == "F32" else C.c_double)), (n.value,)).copy()
+    dense = np.zeros((rows, cols))
+    for a, b, w in ent:
+        dense[a, b] = w
+    want = dense.T if by_column else dense
+    assert p[0] == 0 and p[-1] == len(ent) and np.all(np.diff(p.astype(np.int64)) >= 0)
+    got = np.zeros_like(want)
+    for o in range(outer):
+        seg = x[p[o]:p[o + 1]]
+        assert np.all(np.diff(seg.astype(np.int64)) > 0)                # inner indices ascending, no duplicates
+        got[o, seg] = v[p[o]:p[o + 1]]
+    assert np.allclose(got, want, rtol=1e-6 if vt == "F32" else 0, atol=0)
+    for q in (ptr, idx):
+        api.free(C.cast(q, C.c_void_p))
+    api.free(val)
+    # failure modes: missing file, index outside the header's shape
+    assert api.hip_mtx_read(b"/nonexistent.mtx", 0, dt, C.byref(ptr), C.byref(idx), C.byref(val), C.byref(r), C.byref(c), C.byref(n)) != 0
+    bad = _mtx(tmp_path, 3, 3, [(0, 0, 1.0), (5, 1, 2.0)], "bad.mtx")
+    assert api.hip_mtx_read(bad, 0, dt, C.byref(ptr), C.byref(idx), C.byref(val), C.byref(r), C.byref(c), C.byref(n)) != 0
+
+
+@pytest.mark.parametrize("npdt,dtname", [("float32", "F32"), ("uint16", "BF16"), ("int8", "I8")])
+def test_bcsc_builder_drops_zero_blocks_and_keeps_the_reference_layout(npdt, dtname):
+    import ctypes as C
+    import numpy as np
+    from libxsmm_amd import capi
+    from libxsmm_amd.capi import DT
+    api = capi.load()
+    rng = np.random.default_rng(5)
+    K, N, bk, bn = 64, 48, 16, 8
+    dense = rng.integers(1, 100, size=(N, K)).astype(npdt)              # B[n*K + k]
+    keep = rng.random((N // bn, K // bk)) < 0.4
+    keep[2, :] = False                                                   # an empty block column
+    for nb in range(N // bn):
+        for kb in range(K // bk):
+            if not keep[nb, kb]:
+                dense[nb * bn:(nb + 1) * bn, kb * bk:(kb + 1) * bk] = 0
+    cp, ri, val, nn = C.POINTER(C.c_uint)(), C.POINTER(C.c_uint)(), C.c_void_p(), C.c_uint()
+    assert api.hip_bcsc_from_dense(getattr(DT, dtname), dense.ctypes.data, K, N, bk, bn, C.byref(cp), C.byref(ri), C.byref(val), C.byref(nn)) == 0
+    assert nn.value == int(keep.sum())
+    colptr = np.ctypeslib.as_array(cp, (N // bn + 1,)); rowidx = np.ctypeslib.as_array(ri, (max(1, nn.value),))
+    vals = np.frombuffer((C.c_char * (nn.value * bk * bn * dense.itemsize)).from_address(val.value), dtype=npdt).reshape(nn.value, bn, bk)
+    b = 0
+    for nb in range(N // bn):
+        assert colptr[nb] == b
+        for kb in range(K // bk):
+            if keep[nb, kb]:
+                assert rowidx[b] == kb and np.array_equal(vals[b], dense[nb * bn:(nb + 1) * bn, kb * bk:(kb + 1) * bk])
+                b += 1
+    assert colptr[-1] == b
+    assert api.hip_bcsc_from_dense(getattr(DT, dtname), dense.ctypes.data, K, N, 24, bn, C.byref(cp), C.byref(ri), C.byref(val), C.byref(nn)) != 0   # bk does not divide K
