@@ -169,15 +169,19 @@ void retire_block(void* p) { if (p) { std::lock_guard<std::mutex> guard(g_retire
 static int cur_device() { const int d = tls().device; return d < 0 ? 0 : d; }
 struct Scratch { char* base = nullptr; size_t cap = 0, used = 0; int device = 0; };
 thread_local Scratch t_scratch;
-struct CopyBack { void* host; const void* dev; size_t bytes; };
+struct CopyBack { void* host; const void* dev; size_t width, height, pitch; };   // height rows of `width` bytes, `pitch` bytes apart (height 1: plain)
 thread_local std::vector<CopyBack> t_copyback;       // staged outputs of the current synchronous call
-// `copy_in`: upload the current contents; `copy_back`: download after the kernel (finish_launch, synchronous mode)
-static void* stage(const void* p, size_t nbytes, bool copy_in, bool copy_back) {
-  if (p == nullptr || nbytes == 0) return const_cast<void*>(p);
+// Stages a host-resident operand: `height` rows of `width` bytes that lie `pitch` bytes apart (a panel of a wider matrix: only the bytes the
+// kernel touches are copied, in either direction -- the rows' gaps belong to the caller).  The device image keeps the pitch, so kernels see
+// the caller's leading dimension.  `copy_in`: upload the current contents; `copy_back`: download after the kernel (finish_launch, synchronous mode).
+static void* stage2d(const void* p, size_t width, size_t height, size_t pitch, bool copy_in, bool copy_back) {
+  if (p == nullptr || width == 0 || height == 0) return const_cast<void*>(p);
   hipPointerAttribute_t attr;
   const hipError_t e = hipPointerGetAttributes(&attr, p);
   if (e == hipSuccess && attr.type != hipMemoryTypeUnregistered) return const_cast<void*>(p);
   (void)hipGetLastError();   // clear the sticky "invalid value" of an unregistered pointer
+  if (height == 1 || pitch == width) { width *= height; height = 1; pitch = width; }
+  const size_t nbytes = (height - 1) * pitch + width;
   Scratch& s = t_scratch;
   const size_t need = (nbytes + 255) & ~(size_t)255;
   if (s.base && s.device != cur_device()) { retire_block(s.base); s.base = nullptr; s.cap = s.used = 0; }   // the thread switched device
@@ -192,10 +196,15 @@ static void* stage(const void* p, size_t nbytes, bool copy_in, bool copy_back) {
     s.base = nb; s.cap = ncap; s.used = 0; s.device = cur_device();
   }
   char* dst = s.base + s.used; s.used += need;
-  if (copy_in && !hip_ok(hipMemcpyAsync(dst, p, nbytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpyAsync(host operand)")) return nullptr;
-  if (copy_back) t_copyback.push_back(CopyBack{const_cast<void*>(p), dst, nbytes});
+  if (copy_in) {
+    const hipError_t ce = height == 1 ? hipMemcpyAsync(dst, p, width, hipMemcpyHostToDevice, cur_stream())
+                                      : hipMemcpy2DAsync(dst, pitch, p, pitch, width, height, hipMemcpyHostToDevice, cur_stream());
+    if (!hip_ok(ce, "hipMemcpyAsync(host operand)")) return nullptr;
+  }
+  if (copy_back) t_copyback.push_back(CopyBack{const_cast<void*>(p), dst, width, height, pitch});
   return dst;
 }
+static void* stage(const void* p, size_t nbytes, bool copy_in, bool copy_back) { return stage2d(p, nbytes, 1, nbytes, copy_in, copy_back); }
 const void* device_visible(const void* p, size_t nbytes) { return stage(p, nbytes, true, false); }
 // Operands of a SYNCHRONOUS call may live in plain host memory (the reference's contract: any pointer, result valid on return);
 // an MI355X cannot see such memory, so it is staged.  Stream-ordered (async) and batched launches take device-accessible memory only:
@@ -205,7 +214,9 @@ static const void* host_input(const void* p, size_t nbytes, size_t batch_count) 
 static void* host_inout(void* p, size_t nbytes, size_t batch_count) { return staging_allowed(batch_count) ? stage(p, nbytes, true, true) : p; }
 void scratch_reset() { t_scratch.used = 0; t_copyback.clear(); }
 void copy_back_staged() {
-  for (const CopyBack& c : t_copyback) (void)hip_ok(hipMemcpy(c.host, c.dev, c.bytes, hipMemcpyDeviceToHost), "hipMemcpy(staged result)");
+  for (const CopyBack& c : t_copyback)
+    (void)hip_ok(c.height == 1 ? hipMemcpy(c.host, c.dev, c.width, hipMemcpyDeviceToHost) : hipMemcpy2D(c.host, c.pitch, c.dev, c.pitch, c.width, c.height, hipMemcpyDeviceToHost),
+                 "hipMemcpy(staged result)");
   t_copyback.clear();
 }
 // per-thread device workspace for partial results; grows monotonically, reused in stream order
@@ -618,10 +629,18 @@ void run_spmm(KernelCtx* k, const void* param, const BatchSpec& b) {
   if (!vals || !x || !y) { set_error(-2, "sparse kernel called with a NULL operand"); return; }
   {   // synchronous single calls accept plain host memory (e.g. values straight out of an .mtx reader's malloc)
     const size_t es = (a.dtype == LIBXSMM_DATATYPE_F64) ? 8 : 4;
-    const size_t xb = es * (size_t)(asp ? (long long)a.inner * a.ld_x : (long long)a.nouter * a.outer_x);
-    const size_t yb = es * (size_t)(asp ? (long long)a.rows * a.ld_y : (long long)a.nouter * a.outer_y);
     if (!k->d_vals || !asp) vals = host_input(vals, es * (size_t)a.nnz, b.count);
-    x = host_input(x, xb, b.count); y = host_inout(y, yb, b.count);
+    if (staging_allowed(b.count)) {
+      // the dense operand and C may be PANELS of wider host matrices (PyFR hands column blocks of B and C with ldb = ldc = the full width
+      // [ref: samples/xgemm_sparse_Ainregs/pyfr_driver_asp_reg.c:379-393]): only the touched bytes of every row / slab move, never the gaps
+      if (asp) {
+        x = stage2d(x, es * (size_t)a.ncols, (size_t)a.inner, es * (size_t)a.ld_x, true, false);
+        y = stage2d(y, es * (size_t)a.ncols, (size_t)a.rows, es * (size_t)a.ld_y, true, true);
+      } else {
+        x = stage2d(x, es * (size_t)a.inner * (size_t)a.ld_x, (size_t)a.nouter, es * (size_t)a.outer_x, true, false);
+        y = stage2d(y, es * (size_t)a.rows * (size_t)a.ld_y, (size_t)a.nouter, es * (size_t)a.outer_y, true, true);
+      }
+    }
     if (!vals || !x || !y) return;
   }
   a.vals = vals; a.x = (const char*)x; a.y = (char*)y;

@@ -271,6 +271,43 @@ def test_fsspmdm(dt, M, N, K, density, beta, jit_mode):
     assert api.fsspmdm_create(dt, M, N, K, K, N, N, C.addressof(cal), C.addressof(bad), a_dense.ctypes.data, 0, None) is None
 
 
+@pytest.mark.parametrize("dt", [DT.F32, DT.F64])
+@pytest.mark.parametrize("beta", [0.0, 1.0])
+def test_fsspmdm_host_column_panels(dt, beta):
+    """PyFR's calling pattern with PAGEABLE host operands: the handle covers an N-block, ldb = ldc = the full width, and the caller walks
+    column panels B + z, C + z [ref: samples/xgemm_sparse_Ainregs/pyfr_driver_asp_reg.c:379-393].  The last panel's last row ends on the
+    array's last element: staging must move the panel's rows only -- neither read nor write the gaps (the canary columns stay intact)."""
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(9)
+    M, K, NB, W = 35, 35, 64, 64 * 5
+    rowptr, colidx = random_csr(rng, M, K, 0.15)
+    vals = rand_values(rng, len(colidx), dt) + NP[dt](0.05)
+    a_dense = np.zeros((M, K), dtype=NP[dt])
+    for i in range(M):
+        for z in range(rowptr[i], rowptr[i + 1]):
+            a_dense[i, colidx[z]] = vals[z]
+    B = rand_values(rng, K * W, dt)
+    C0 = rand_values(rng, M * W, dt)
+    ref = C0.copy()
+    orc.lib.oracle_fsspmdm(dt, M, W, K, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, B.ctypes.data, W, ref.ctypes.data, W, int(beta == 0.0))
+    one = (C.c_double if dt == DT.F64 else C.c_float)(1.0)
+    cbe = (C.c_double if dt == DT.F64 else C.c_float)(beta)
+    h = api.fsspmdm_create(dt, M, NB, K, K, W, W, C.addressof(one), C.addressof(cbe), a_dense.ctypes.data, 0, None)
+    assert h
+    got = C0.copy()
+    es = got.itemsize
+    skip = 2                                                   # panel 2 is left out: its columns of C must come back untouched
+    for z in range(0, W, NB):
+        if z // NB != skip:
+            api.fsspmdm_execute(h, B.ctypes.data + z * es, got.ctypes.data + z * es)
+    api.hip_sync(); api.check()
+    g2, r2, c2 = got.reshape(M, W), ref.reshape(M, W), C0.reshape(M, W)
+    keep = np.ones(W, dtype=bool); keep[skip * NB:(skip + 1) * NB] = False
+    assert normf_rel(r2[:, keep], g2[:, keep], dt) <= (1e-5 if dt == DT.F32 else 1e-12)
+    assert np.array_equal(g2[:, ~keep], c2[:, ~keep])
+    api.fsspmdm_destroy(h)
+
+
 @pytest.mark.parametrize("a_type,c_type,vnni", [(DT.F32, DT.F32, 0), (DT.BF16, DT.BF16, 1), (DT.BF16, DT.F32, 1), (DT.BF16, DT.BF16, 0)])
 @pytest.mark.parametrize("M,N,K,mb,bk,bn,keep,beta0", [(64, 64, 256, 6, 32, 16, 0.25, 1), (64, 64, 256, 3, 32, 32, 0.25, 0), (16, 24, 40, 4, 8, 8, 0.5, 1), (32, 32, 64, 2, 16, 4, 0.42, 0),
                                                        (48, 80, 128, 3, 64, 16, 0.3, 0), (64, 128, 128, 2, 32, 64, 0.5, 1), (80, 96, 96, 5, 32, 32, 0.34, 1)])
