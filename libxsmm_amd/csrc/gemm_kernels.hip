@@ -23,6 +23,7 @@
 // so they are organised as streaming kernels: many independent waves, each with its whole tile
 // (8-24 KiB) of loads in flight, no barriers, no LDS.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include <utility>
 #include "internal.hpp"
@@ -135,6 +136,16 @@ __device__ __forceinline__ void br_base(const GemmArgs& p, const BatchPtrs& q, u
 // Non-temporal stores in the BCSC and TPP kernels measured slower (0.57 -> 0.47, 0.78 -> 0.76) and were not kept.
 template <bool NT = true, typename T> __device__ __forceinline__ void st_stream(GM T* p, T v) {
   if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+// Workgroup barrier WITHOUT the memory fence of __syncthreads().  The fence makes the compiler drain every outstanding vector-memory
+// operation ("s_waitcnt vmcnt(0)" in front of s_barrier), which ends an LDS-DMA prefetch that is deliberately left in flight across the
+// barrier.  What the pipelines here need is: this wave's LDS traffic is complete (lgkmcnt), its landed DMA is accounted for by the explicit
+// vmcnt wait in front of the call, and nobody proceeds before everybody arrived.
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 }
 
 // raw buffer resource over a wave-uniform base (gfx9 word 3: 32-bit raw data format); offsets are checked against 4 GiB only
@@ -1212,12 +1223,12 @@ __global__ __launch_bounds__(256) void gemm_f32_wg64_kernel(GemmArgs p) {
   if (total > 1) issue(1);
   for (unsigned long long t = 0; t < total; ++t) {
     if (t + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // step t landed, step t + 1 may fly
-    __syncthreads();
+    wg_barrier();
     float af[16], bf[16];
     frag_read<false>(af, &lds_all[t & 1ull][wi][0], (int)lane);
     frag_read<true>(bf, &lds_all[t & 1ull][2 + wj][0], (int)lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (t + 2 < total) { __syncthreads(); issue(t + 2); }       // every wave has read image t & 1: refill it two steps ahead
+    if (t + 2 < total) { wg_barrier(); issue(t + 2); }       // every wave has read image t & 1: refill it two steps ahead
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s2], af[s2], acc, 0, 0, 0);
   }
@@ -1266,6 +1277,255 @@ __global__ __launch_bounds__(256) void gemm_f32_blob_kernel(GemmArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   tile_store<false, true>(acc, p, q, tc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 "ragged" kernel: the odd small shapes LIBXSMM exists for (23^3 is BASELINE config #1; 13^3, 40^3, 50^3, 72^3 ...), NN, plain
+// epilogue (beta 0 or 1), any leading dimensions, every batch form.  ONE WORKGROUP OF W WAVES PER PROBLEM (W = 1 up to 32 x 32, else 4);
+// a problem is a sequence of CHUNKS (batch-reduce block, k-range of at most kc), usually one.
+// Such problems are a few KB each: what bounds the kernel is the number of instructions per byte, then the bytes in flight.
+//   * NO PER-ELEMENT ARITHMETIC.  A thread's place in a block is fixed once: for A (and C) thread t takes row i = t % m of column t / m
+//     of every ROUND of cpr = 64 W / m columns; for B it takes k = t % kc of column t / kc.  A round is then one buffer load "lane
+//     constant + scalar round offset" (columns a leading dimension apart cost nothing) and one LDS write "running lane pointer"; the
+//     resource ends with the block, so rounds that run past it (k tail, last columns) and idle lanes read 0 and their stores are
+//     dropped by the bounds check: no predicates.  m = 23: 46 of 64 lanes busy, 184 contiguous bytes per instruction.
+//   * The landing zone is the REGISTER FILE (R2 dwords per thread and operand): all loads of a chunk are in flight at once, and in a
+//     problem of several chunks the next one is requested before the current one is multiplied and waits in registers.
+//   * The product is formed on v_mfma_f32_16x16x4_f32 tiles, transposed (rows = j, columns = i) so that a lane holds C(i, 4 consecutive
+//     j): ceil(m/16) x ceil(n/16) tiles instead of padding to 32 / 64.  A wave owns up to NP vertical tile PAIRS (two i-tiles of one
+//     j-tile share the B fragment).  Lanes of rows i >= m / columns j >= n read a clamped address: what they compute never leaves the
+//     registers (an output depends on its own row and column only); only the k tail is selected to zero.
+//     k is consumed in natural order (MFMA s takes k = 4 s + lane group): bitwise the k-ordered fmaf chain.
+//   * C leaves through an LDS image [j][16 ceil(m/16)] and the same round scheme (buffer stores).
+// History, measured on 23^3 x 131072 (fraction of the 8 TB/s HBM peak; the bare access pattern copies at 0.74, tools/width_probe.hip):
+// flat dword LDS-DMA with per-element div/mod 0.57 -> the same in a persistent, double-buffered loop 0.57 (the counters said VALU-bound:
+// 50 % VALU + 27 % MFMA busy, waves waiting for an issue slot half of the time) -> lane-constant rounds, persistent 0.58 (more resident
+// waves did not help, fewer hurt) -> lane-constant rounds, one short-lived workgroup per problem 0.73.
+// Barriers (W = 4) are raw s_barrier: the fence of __syncthreads() would make the compiler drain loads in flight in front of it.
+// ------------------------------------------------------------------------------------------------
+struct RaggedCfg {
+  unsigned int kc, kchunks;             // k-chunk depth held in LDS, chunks per K
+  unsigned int cpr_a, cpr_b;            // columns per round: 64 W / m (A, C), 64 W / kc (B)
+  unsigned int pb, pc;                  // LDS pitches: of a B column (k contiguous), of a C column (i contiguous); A columns are m apart
+  unsigned int off_b, off_ci, off_co, spare;   // LDS dword offsets: B image, incoming C image (beta = 1), outgoing C image, 64 W spare dwords
+  unsigned int tpi, npairs;             // tile pairs along i, tile pairs in total
+};
+// waves per SIMD the register allocator is held to (registers, not LDS, bound the bytes in flight): the stage is (2 or 3) R2 registers
+constexpr int ragged_waves_per_simd(int W, int NP, int R2, bool BETA1, bool SINGLE) {
+  if (SINGLE) return 1;                                            // the stage is dead once placed: the allocator needs no help
+  const int regs = (BETA1 ? 3 : 2) * R2 + 8 * NP + 44 + ((W == 1 && NP == 2) ? 8 : 0) + (BETA1 ? 8 : 0);     // stage + accumulators + the rest, as measured: no scratch
+  return regs <= 64 ? 8 : regs <= 72 ? 7 : regs <= 80 ? 6 : regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : 2;
+}
+// SINGLE: the problem is one chunk (K fits, one batch-reduce block): straight-line -- fetch, place, multiply, write.  Measured on the bare
+// access pattern (tools/width_probe.hip): one short-lived wave per 23^2 block streams at 0.74 of the HBM peak, resident waves looping
+// over the same blocks at 0.64-0.67 -- the hardware dispatcher sweeps memory in order and refills a CU the moment a wave retires.
+// !SINGLE: the loop over the problem's chunks (written for a stride of problems per workgroup; launched with one problem each).
+template <int W, int NP, int R2, bool BETA1, bool SINGLE>
+__global__ __launch_bounds__(64 * W, ragged_waves_per_simd(W, NP, R2, BETA1, SINGLE)) void gemm_f32_ragged_kernel(GemmArgs p, RaggedCfg c) {
+  extern __shared__ __attribute__((aligned(16))) float rg_lds[];
+  const unsigned int tid = threadIdx.x, lane = tid & 63u;
+  const unsigned int w = (W == 1) ? 0u : (unsigned int)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const unsigned int x = lane & 15u, g = lane >> 4;
+  const unsigned int m = (unsigned int)p.m, n = (unsigned int)p.n, K = (unsigned int)p.k;
+  const unsigned int nprob = p.nbatch, stride = gridDim.x;
+  const unsigned long long nbr = p.br_count;
+  const unsigned int lda4 = 4u * (unsigned int)p.lda, ldb4 = 4u * (unsigned int)p.ldb, ldc4 = 4u * (unsigned int)p.ldc;
+  auto block_rsrc = [&](gcptr base, unsigned int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(size_t)uniform_u64((unsigned long long)(size_t)base), (short)0, (int)bytes, 0x00020000);
+  };
+  constexpr unsigned int kIdle = 0x7ffffff0u;                      // lane offset behind every block (round offsets stay below 2^31)
+  // ---- a thread's place in a round, fixed for the life of the kernel
+  const unsigned int sub_a = tid / m, i_a = tid - sub_a * m, sub_b = tid / c.kc, k_b = tid - sub_b * c.kc;
+  const bool act_a = sub_a < c.cpr_a, act_b = sub_b < c.cpr_b;
+  const unsigned int vo_a = act_a ? sub_a * lda4 + 4u * i_a : kIdle, vo_b = act_b ? sub_b * ldb4 + 4u * k_b : kIdle, vo_c = act_a ? sub_a * ldc4 + 4u * i_a : kIdle;
+  // LDS (dword indices): where the thread's element of round 0 goes, and how far the next round is (idle lanes stay on a spare dword)
+  const unsigned int spare = c.spare + tid;                        // idle lanes: a dword of their own behind the images
+  const unsigned int ls_a = act_a ? sub_a * m + i_a : spare, st_a = act_a ? c.cpr_a * m : 0u;
+  const unsigned int ls_b = act_b ? c.off_b + sub_b * c.pb + k_b : spare, st_b = act_b ? c.cpr_b * c.pb : 0u;
+  const unsigned int ls_ci = act_a ? c.off_ci + sub_a * c.pc + i_a : spare, ls_co = act_a ? c.off_co + sub_a * c.pc + i_a : spare, st_c = act_a ? c.cpr_a * c.pc : 0u;
+  if (nbr == 0) {                                                  // no blocks: C = beta * C
+    if (!BETA1)
+      for (unsigned int prob = blockIdx.x; prob < nprob; prob += stride) {
+        const __amdgpu_buffer_rsrc_t RC = block_rsrc((gcptr)batch_ptrs(p, prob).c, (n - 1u) * ldc4 + 4u * m);
+        for (unsigned int j0 = 0; j0 < n; j0 += c.cpr_a) __builtin_amdgcn_raw_buffer_store_b32(0u, RC, (int)vo_c, (int)(j0 * ldc4), 0);
+      }
+    return;
+  }
+  unsigned int prob = blockIdx.x;
+  if (prob >= nprob) return;
+  // (tile pair PI of this wave) -> lane coordinates; the pair index is wave-uniform
+  auto pair_of = [&](int PI, unsigned int& tj, unsigned int& tp) -> bool {
+    const unsigned int pair = w + (unsigned int)PI * W;
+    if (pair >= c.npairs) return false;
+    tj = (c.tpi == 1u) ? pair : pair / c.tpi; tp = pair - tj * c.tpi;
+    return true;
+  };
+  // ---- the staged chunk: R2 rounds of A, R2 of B, (beta = 1) R2 of C, one dword per thread and round
+  constexpr int RS = (BETA1 ? 3 : 2) * R2;
+  unsigned int stage[RS];
+  unsigned int st_kcur = 0; bool st_withc = false;
+  auto fetch = [&](const BatchPtrs& q, unsigned long long r, unsigned int kci) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    const unsigned int kc0 = kci * c.kc, kcur = min(c.kc, K - kc0);
+    const __amdgpu_buffer_rsrc_t RA = block_rsrc(ar + (unsigned long long)kc0 * lda4, (kcur - 1u) * lda4 + 4u * m);
+    const __amdgpu_buffer_rsrc_t RB = block_rsrc(br + 4ull * kc0, (n - 1u) * ldb4 + 4u * kcur);
+    static_for<R2>([&](auto IT) { stage[IT] = __builtin_amdgcn_raw_buffer_load_b32(RA, (int)vo_a, (int)((unsigned int)IT * c.cpr_a * lda4), 0); });
+    static_for<R2>([&](auto IT) { stage[R2 + IT] = __builtin_amdgcn_raw_buffer_load_b32(RB, (int)vo_b, (int)((unsigned int)IT * c.cpr_b * ldb4), 0); });
+    const bool withc = BETA1 && r == 0 && kci == 0;
+    if constexpr (BETA1) {
+      if (withc) {
+        const __amdgpu_buffer_rsrc_t RC = block_rsrc((gcptr)q.c, (n - 1u) * ldc4 + 4u * m);
+        static_for<R2>([&](auto IT) { stage[2 * R2 + IT] = __builtin_amdgcn_raw_buffer_load_b32(RC, (int)vo_c, (int)((unsigned int)IT * c.cpr_a * ldc4), 0); });
+      }
+    }
+    st_kcur = kcur; st_withc = withc;
+  };
+  const unsigned int rounds_c = (n + c.cpr_a - 1u) / c.cpr_a;
+  auto spill = [&]() {                                             // registers -> LDS images
+    unsigned int* lds = (unsigned int*)rg_lds;
+    unsigned int pa_ = ls_a, pb_ = ls_b;
+    asm volatile("" : "+v"(pa_), "+v"(pb_));                       // the R2 addresses per image are loop invariant: recompute (one add each), do not park them in registers
+    // every round is placed, also those behind an operand's last one (they hold zeros: a skip per round measured 2-5 % slower than the
+    // LDS it saves is worth; the images are sized for R2 rounds)
+    static_for<R2>([&](auto IT) { lds[pa_] = stage[IT]; pa_ += st_a; });
+    static_for<R2>([&](auto IT) { lds[pb_] = stage[R2 + IT]; pb_ += st_b; });
+    if constexpr (BETA1) {
+      if (st_withc) { unsigned int pc_ = ls_ci; asm volatile("" : "+v"(pc_)); static_for<R2>([&](auto IT) { lds[pc_] = stage[2 * R2 + IT]; pc_ += st_c; }); }
+    }
+  };
+  f32x4 acc[NP][2];
+  float* const la = rg_lds; float* const lb = rg_lds + c.off_b; float* const lo = rg_lds + c.off_co;
+  auto init_acc = [&]() {                                          // a new problem: accumulators start from 0 or from C
+    const float* lc = rg_lds + c.off_ci;
+    static_for<NP>([&](auto PI) {
+      unsigned int tj, tp;
+      acc[PI][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[PI][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (BETA1 && pair_of(PI, tj, tp)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned int i = 32u * tp + 16u * h + x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const unsigned int j = 16u * tj + 4u * g + e; acc[PI][h][e] = (i < m && j < n) ? lc[j * c.pc + i] : 0.0f; }
+        }
+      }
+    });
+  };
+  auto multiply = [&](unsigned int kcur) {                         // acc += A image x B image, kcur deep
+    const unsigned int full = kcur >> 2;
+    static_for<NP>([&](auto PI) {
+      unsigned int tj, tp;
+      if (pair_of(PI, tj, tp)) {
+        const unsigned int i0 = 32u * tp + x, j = 16u * tj + x;
+        const bool two = 32u * tp + 16u < m;                       // wave-uniform: the pair's second tile exists
+        // rows i >= m and columns j >= n compute from a clamped (valid) address: their results stay in registers nobody stores
+        const float* pa = la + g * m + (i0 < m ? i0 : 0u);
+        const float* pa1 = la + g * m + (i0 + 16u < m ? i0 + 16u : 0u);
+        const float* pbq = lb + (j < n ? j : 0u) * c.pb + g;
+        const unsigned int m4 = 4u * m;
+        f32x4 c0 = acc[PI][0], c1 = acc[PI][1];
+        unsigned int s = 0;
+        if (two) {
+          for (; s + 2u <= full; s += 2u) {                        // two groups of four k per trip: six fragment reads, then four MFMAs
+            const float a0 = pa[0], a1 = pa1[0], a2 = pa[m4], a3 = pa1[m4], b = pbq[0], b2 = pbq[4];
+            pa += 2u * m4; pa1 += 2u * m4; pbq += 8;
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a1, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b2, a2, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b2, a3, c1, 0, 0, 0);
+          }
+          if (s < full) {
+            const float a0 = pa[0], a1 = pa1[0], b = pbq[0];
+            pa += m4; pa1 += m4; pbq += 4;
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a1, c1, 0, 0, 0);
+          }
+        } else {
+          for (; s + 2u <= full; s += 2u) {
+            const float a0 = pa[0], a2 = pa[m4], b = pbq[0], b2 = pbq[4];
+            pa += 2u * m4; pbq += 8;
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a0, c0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b2, a2, c0, 0, 0, 0);
+          }
+          if (s < full) {
+            const float a0 = pa[0], b = pbq[0];
+            pa += m4; pa1 += m4; pbq += 4;
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a0, c0, 0, 0, 0);
+          }
+        }
+        if (kcur & 3u) {                                           // the last, partial group of four k: both operands zero behind the depth
+          const bool kv = 4u * full + g < kcur;
+          const float a0 = kv ? pa[0] : 0.0f, a1 = (two && kv) ? pa1[0] : 0.0f, b = kv ? pbq[0] : 0.0f;
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a0, c0, 0, 0, 0);
+          if (two) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a1, c1, 0, 0, 0);
+        }
+        acc[PI][0] = c0; acc[PI][1] = c1;
+      }
+    });
+  };
+  auto write_image = [&]() {                                       // registers -> C image [j][pc]
+    static_for<NP>([&](auto PI) {
+      unsigned int tj, tp;
+      if (pair_of(PI, tj, tp)) {
+        const unsigned int j0 = 16u * tj + 4u * g;
+        if (j0 < n) {                                              // whole groups of four columns behind n are skipped; rows behind m land in the pitch
+          float* dst = lo + j0 * c.pc + 32u * tp + x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { dst[e * c.pc] = acc[PI][0][e]; if (32u * tp + 16u < m) dst[e * c.pc + 16u] = acc[PI][1][e]; }
+        }
+      }
+    });
+  };
+  auto flush = [&](unsigned int which) {                           // C image -> memory, a round of columns per store
+    const __amdgpu_buffer_rsrc_t RC = block_rsrc((gcptr)batch_ptrs(p, which).c, (n - 1u) * ldc4 + 4u * m);
+    const unsigned int* src = (const unsigned int*)rg_lds;
+    unsigned int pc_ = ls_co, so = 0;
+    asm volatile("" : "+v"(pc_));
+#pragma unroll 2
+    for (unsigned int r = 0; r < rounds_c; ++r) {
+      __builtin_amdgcn_raw_buffer_store_b32(src[pc_], RC, (int)vo_c, (int)so, 2);
+      pc_ += st_c; so += c.cpr_a * ldc4;
+    }
+  };
+  if constexpr (SINGLE) {                                          // one problem, one chunk: straight through (the C image takes the operands' place)
+    fetch(batch_ptrs(p, prob), 0, 0);
+    spill();
+    if (W > 1) wg_barrier();
+    init_acc();
+    multiply(K);
+    if (W > 1) wg_barrier();
+    write_image();
+    if (W > 1) wg_barrier();
+    flush(prob);
+    return;
+  }
+  // One loop trip = "place the staged chunk, request the one after it, multiply the placed one".  The first trip has nothing staged
+  // yet and only requests (one fetch site, one spill site: the kernel is register-bound, code duplicated by inlining costs occupancy).
+  // C of a finished problem is written one trip LATE, right before the next request: the wait for a staged chunk (vmcnt, in order) then
+  // never has younger stores in front of it -- written right after the product, their acknowledgements would be waited for every trip.
+  unsigned long long cur_r = 0, st_r = 0; unsigned int cur_k = 0, st_k = 0, st_prob = prob, out_prob = 0;
+  bool placed = false, staged = false, more = true, out_pending = false;
+  for (;;) {
+    unsigned int kcur = 0;
+    placed = staged;
+    if (staged) {
+      spill();                                                     // the chunk that waited in registers becomes the current one
+      kcur = st_kcur; prob = st_prob; cur_r = st_r; cur_k = st_k;
+      if (W > 1) wg_barrier();
+      // the chunk after it
+      if (++st_k == c.kchunks) { st_k = 0; if (++st_r == nbr) { st_r = 0; st_prob += stride; } }
+      more = st_prob < nprob;
+    }
+    if (out_pending) { flush(out_prob); out_pending = false; }
+    if (more) { const BatchPtrs qn = batch_ptrs(p, st_prob); fetch(qn, st_r, st_k); }
+    staged = more;
+    if (!placed) continue;
+    if (cur_r == 0 && cur_k == 0) init_acc();
+    multiply(kcur);
+    if (cur_k + 1u == c.kchunks && cur_r + 1ull == nbr) { write_image(); out_pending = true; out_prob = prob; }     // complete: into its own LDS region
+    if (!staged) break;
+    if (W > 1) wg_barrier();                                       // everybody is done with the images before the next chunk replaces them
+  }
+  if (out_pending) { if (W > 1) wg_barrier(); flush(out_prob); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1592,7 +1852,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
   if (total > 1) issue(1);
   for (unsigned long long t = 0; t < total; ++t) {
     if (t + 1 < total) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wg_barrier();
     const unsigned int* img = lds_all[t & 1ull];
     u32x4 af[2], bfr[2];
 #pragma unroll
@@ -1604,7 +1864,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
       bfr[s2] = *(const u32x4*)((const char*)img + 4096 + f * 64u + (((2u * s2 + h) ^ ((f >> 1) & 3u)) * 16u));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (t + 2 < total) { __syncthreads(); issue(t + 2); }
+    if (t + 2 < total) { wg_barrier(); issue(t + 2); }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[s2]), __builtin_bit_cast(bf16x8, af[s2]), acc, 0, 0, 0);
@@ -2174,6 +2434,74 @@ static bool bf16_wg64_ok(const GemmArgs& a) {
     (unsigned long long)((long long)a.lda * 4) | (unsigned long long)((long long)a.ldb * 2);
   return (bits & 15ull) == 0 && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.k >= 32 && a.br_count * (unsigned long long)(a.k >> 5) < (1ull << 31);
 }
+// rounds per operand of the instantiation that serves (waves, tile pairs per wave, rounds needed) -- see the dispatch in launch_gemm
+static unsigned int ragged_rounds_cap(int waves, int np, unsigned int rounds) {
+  if (waves == 1) return (np == 1 && rounds <= 4u) ? 4u : (rounds <= 8u ? 8u : (rounds <= 12u ? 12u : 17u));
+  if (np == 2 && rounds <= 7u) return 7u;
+  if (np <= 4 && rounds <= 10u) return 10u;
+  return rounds <= 14u ? 14u : 24u;
+}
+// the ragged kernel: f32 NN with a plain epilogue, 2 <= m <= 128, n <= 128, at most 24 tile pairs; fills in the chunk plan
+static bool f32_ragged_plan(const GemmArgs& a, RaggedCfg& c, int& waves, int& np, int& rounds, unsigned int& lds_bytes, bool& single) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_RAGGED"); return e && e[0] == '0'; }();
+  if (off || a.a_type != LIBXSMM_DATATYPE_F32 || a.b_type != LIBXSMM_DATATYPE_F32 || a.c_type != LIBXSMM_DATATYPE_F32) return false;
+  if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B)) || a.vnni_c || a.colbias || a.act) return false;
+  // leading dimensions below 2^20: every round offset (columns x leading dimension x 4 bytes) stays below 2^31
+  if (a.m < 2 || a.m > 128 || a.n < 1 || a.n > 128 || a.k < 1 || a.lda >= (1 << 20) || a.ldb >= (1 << 20) || a.ldc >= (1 << 20)) return false;
+  const unsigned int m = (unsigned int)a.m, n = (unsigned int)a.n, K = (unsigned int)a.k;
+  const unsigned int ti = (m + 15u) / 16u, tj = (n + 15u) / 16u;
+  c.tpi = (ti + 1u) / 2u; c.npairs = c.tpi * tj;
+  if (c.npairs > 24u) return false;
+  waves = (m <= 32u && n <= 32u) ? 1 : 4;
+  const unsigned int per_wave = (c.npairs + (unsigned int)waves - 1u) / (unsigned int)waves;
+  np = waves == 1 ? (per_wave <= 1u ? 1 : 2) : (per_wave <= 2u ? 2 : (per_wave <= 4u ? 4 : 6));
+  const bool beta0 = (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  const unsigned int T = 64u * (unsigned int)waves, rmax = waves == 1 ? 17u : 24u;
+  c.cpr_a = T / m;                                                  // columns of A / C per round
+  if (c.cpr_a == 0 || (n + c.cpr_a - 1u) / c.cpr_a > rmax) return false;      // C (beta = 1 in, always out) in at most rmax rounds
+  // depth of a chunk: A in at most rmax rounds (kc <= rmax * cpr_a), B too (columns per round T / kc >= n / rmax)
+  unsigned int kmax = std::min(rmax * c.cpr_a, T / ((n + rmax - 1u) / rmax));
+  if (kmax >= K) { c.kc = K; c.kchunks = 1; }
+  else {
+    kmax &= ~3u;
+    if (kmax == 0) return false;
+    c.kchunks = (K + kmax - 1u) / kmax; c.kc = (((K + c.kchunks - 1u) / c.kchunks) + 3u) & ~3u; c.kchunks = (K + c.kc - 1u) / c.kc;
+  }
+  c.cpr_b = T / c.kc;
+  const unsigned int ra = (c.kc + c.cpr_a - 1u) / c.cpr_a, rb = (n + c.cpr_b - 1u) / c.cpr_b, rcn = (n + c.cpr_a - 1u) / c.cpr_a;
+  rounds = (int)std::max(ra, std::max(rb, beta0 ? 0u : rcn));
+  if (rounds > (int)rmax) return false;
+  const unsigned int k4 = (c.kc + 3u) & ~3u;
+  c.pb = (k4 & 1u) ? k4 : k4 + 2u;                                  // B column pitch == 2 (mod 4): the 16 columns of a fragment read hit different banks
+  c.pc = 16u * ti;
+  // LDS images: every round of the chosen instantiation is written (rows / columns behind the block receive zeros)
+  const unsigned int rcap = ragged_rounds_cap(waves, np, (unsigned int)rounds);
+  const unsigned int rows_a = std::max(rcap * c.cpr_a, k4), cols_b = rcap * c.cpr_b, cols_c = std::max(rcap * c.cpr_a, (n + 3u) & ~3u);
+  // every scalar round offset below 2^31 bytes
+  if ((unsigned long long)rcap * c.cpr_a * a.lda * 4ull >= (1ull << 31) || (unsigned long long)rcap * c.cpr_b * a.ldb * 4ull >= (1ull << 31) || (unsigned long long)rcap * c.cpr_a * a.ldc * 4ull >= (1ull << 31)) return false;
+  single = c.kchunks == 1 && a.br_count == 1;                      // one chunk per problem: one workgroup per problem, the C image in place of the operands
+  c.off_b = rows_a * m;
+  c.off_ci = c.off_b + cols_b * c.pb;
+  const unsigned int operands = c.off_ci + (beta0 ? 0u : cols_c * c.pc);
+  c.off_co = single ? 0u : operands;
+  c.spare = single ? std::max(operands, cols_c * c.pc) : operands + cols_c * c.pc;
+  rounds = (int)rcap;
+  lds_bytes = 4u * ((c.spare + T + 3u) & ~3u);
+  return lds_bytes <= 65536u;
+}
+template <int W, int NP, int R2>
+static void launch_ragged(const GemmArgs& a, const RaggedCfg& c, unsigned int lds_bytes, bool single, hipStream_t st) {
+  const bool beta0 = (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  if (single) {
+    if (beta0) hipLaunchKernelGGL((gemm_f32_ragged_kernel<W, NP, R2, false, true>), dim3(a.nbatch), dim3(64 * W), lds_bytes, st, a, c);
+    else hipLaunchKernelGGL((gemm_f32_ragged_kernel<W, NP, R2, true, true>), dim3(a.nbatch), dim3(64 * W), lds_bytes, st, a, c);
+  }
+  // several chunks per problem: the chunk loop with its register prefetch, still one workgroup per problem (a grid of resident
+  // workgroups striding over the problems measured slower: 0.59 against 0.62 on 23^3 x 8 blocks, and a workgroup that does not fit
+  // next to the others at launch waits for a whole stride of problems)
+  else if (beta0) hipLaunchKernelGGL((gemm_f32_ragged_kernel<W, NP, R2, false, false>), dim3(a.nbatch), dim3(64 * W), lds_bytes, st, a, c);
+  else hipLaunchKernelGGL((gemm_f32_ragged_kernel<W, NP, R2, true, false>), dim3(a.nbatch), dim3(64 * W), lds_bytes, st, a, c);
+}
 static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
   static const int mode = []() { const char* e = getenv("LIBXSMM_HIP_F32_DMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
   return mode;
@@ -2246,6 +2574,30 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     if (mb == 1) { if (kernel_name) *kernel_name = "gemm_f32_blocked_kernel<1>"; hipLaunchKernelGGL((gemm_f32_blocked_kernel<1>), grid, dim3(256), 0, st, a); }
     else { if (kernel_name) *kernel_name = "gemm_f32_blocked_kernel<2>"; hipLaunchKernelGGL((gemm_f32_blocked_kernel<2>), grid, dim3(256), 0, st, a); }
     return (int)hipGetLastError();
+  }
+  // f32 shapes that are not whole 32 / 64 tiles, plain epilogue: persistent workgroups, operands staged in registers, 16 x 16 MFMA tiles
+  if ((pl.path == P_F32_1x1 || pl.path == P_F32_2x2) && !pl.exact) {
+    RaggedCfg rc; int waves = 1, np = 1, rounds = 0; unsigned int lds_bytes = 0; bool single = false;
+    if (f32_ragged_plan(a, rc, waves, np, rounds, lds_bytes, single)) {
+      a.tiles_m = a.tiles_n = 1; a.map2d_shift = 0;
+      if (kernel_name) *kernel_name = "gemm_f32_ragged_kernel";
+      if (waves == 1) {                                      // rounds == ragged_rounds_cap(...): the LDS plan is sized for exactly this instantiation
+        if (rounds == 4) launch_ragged<1, 1, 4>(a, rc, lds_bytes, single, st);
+        else if (rounds == 8 && np == 1) launch_ragged<1, 1, 8>(a, rc, lds_bytes, single, st);
+        else if (rounds == 8) launch_ragged<1, 2, 8>(a, rc, lds_bytes, single, st);
+        else if (rounds == 12) launch_ragged<1, 2, 12>(a, rc, lds_bytes, single, st);
+        else launch_ragged<1, 2, 17>(a, rc, lds_bytes, single, st);
+      } else {
+        if (rounds == 7) launch_ragged<4, 2, 7>(a, rc, lds_bytes, single, st);
+        else if (rounds == 10 && np == 2) launch_ragged<4, 2, 10>(a, rc, lds_bytes, single, st);
+        else if (rounds == 10) launch_ragged<4, 4, 10>(a, rc, lds_bytes, single, st);
+        else if (rounds == 14 && np <= 4) launch_ragged<4, 4, 14>(a, rc, lds_bytes, single, st);
+        else if (rounds == 14) launch_ragged<4, 6, 14>(a, rc, lds_bytes, single, st);
+        else if (np <= 4) launch_ragged<4, 4, 24>(a, rc, lds_bytes, single, st);
+        else launch_ragged<4, 6, 24>(a, rc, lds_bytes, single, st);
+      }
+      return (int)hipGetLastError();
+    }
   }
   switch (pl.path) {
     case P_F32_T16: grid = wave_grid(16, 16); hipLaunchKernelGGL(gemm_mfma_f32_t16_kernel, grid, dim3(256), 0, st, a); break;

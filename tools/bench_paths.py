@@ -2,7 +2,7 @@
 """Roofline measurements for every hot-path row of SURVEY.md section 8 other than the headline config
 (which bench.py owns).  One JSON line per workload; same timing method as bench.py (hipGraph of K launches,
 HIP events on the launch stream, inputs rotated so that every launch streams from HBM).
-Usage: python tools/bench_paths.py [--only gemm,mx,csr,fsspmdm,bcsc,fused,meltw,packed,quant] [--steps K]"""
+Usage: python tools/bench_paths.py [--only gemm,ragged,mx,csr,fsspmdm,bcsc,fused,meltw,packed,quant] [--steps K]"""
 import argparse
 import ctypes as C
 import json
@@ -555,6 +555,10 @@ def main():
                    lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8),
                    lambda: brgemm(api, 32, "f32", 1, br=4096), lambda: brgemm(api, 64, "bf16", 1, br=4096),
                    lambda: brgemm_i8(api, 64, 2 ** 17, ua=True), lambda: brgemm_i8(api, 64, 2 ** 17, ua=False)]     # config #2 variant B: one long chain
+    if "ragged" in only:     # the odd small shapes (BASELINE config #1 is 23^3), steady state and a 4096-problem launch
+        makers += [lambda: brgemm(api, 13, "f32", 2 ** 18), lambda: brgemm(api, 23, "f32", 2 ** 17), lambda: brgemm(api, 23, "f32", 4096),
+                   lambda: brgemm(api, 40, "f32", 2 ** 15), lambda: brgemm(api, 50, "f32", 2 ** 15), lambda: brgemm(api, 72, "f32", 2 ** 14),
+                   lambda: brgemm(api, 23, "f32", 2 ** 17, beta=1), lambda: brgemm(api, 23, "f32", 2 ** 14, br=8)]
     if "mx" in only:
         makers += [lambda: brgemm_mxfp4(api, 64, 2 ** 17), lambda: brgemm_mxfp4(api, 32, 2 ** 18, c_dt=DT.F32),
                    lambda: brgemm_mxmx(api, 64, 2 ** 17), lambda: brgemm_mxmx(api, 64, 2 ** 16, DT.MXHF8), lambda: brgemm_mxmx(api, 128, 2 ** 15)]
