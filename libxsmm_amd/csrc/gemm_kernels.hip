@@ -1873,6 +1873,187 @@ __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 blocked kernel: the operand-reuse regime for bf16 (libxsmm_hip_gemm_batch_strided_2d on 64 x 64 x K problems, VNNI-2 A, flat B,
+// plain epilogue).  The bf16 matrix pipe does a 32 x 32 x 16 step in 32 cycles, 8 x the f32 rate per operand byte: with the f32 blocked
+// kernel's 128 x 128 macro tile (64 x 64 per wave) the fragment reads plus the LDS-DMA writes would need 190 bytes per cycle of an LDS
+// that delivers 128.  Here a workgroup owns 256 x 256 of C (4 x 4 problems) and every wave 128 x 128 of it -- 16 accumulators of
+// 32 x 32, 256 AGPRs -- so a fragment is used by four MFMAs: 94 bytes per cycle.
+//   * K advances in stages of 32: A as [16 k-pairs][256 rows] dwords (16 KiB), B as [256 columns][64 bytes] (16 KiB, 16-byte chunks
+//     XOR-swizzled by the column so that the b128 fragment reads are conflict free), three stages in a 96 KiB ring.  All of it arrives
+//     by LDS-DMA (8 instructions per wave and stage: wave w brings k-pairs 4 w .. 4 w + 3 of all four A problems and the B problem
+//     column w), two stages ahead of the one being multiplied.
+//   * One wave per SIMD cannot hide anything behind another wave: the loop is software-pipelined on k-steps of 16 -- the fragments of
+//     step u + 1 are requested before the 16 MFMAs of step u are issued -- with ONE workgroup barrier per stage.
+// Accumulation order per output = the k order of the single-problem kernels: bitwise the same results.
+// ------------------------------------------------------------------------------------------------
+// FORM of the C stores (decided by the host): 0 f32, 1 bf16 as packed dwords (even ldc, 4-byte aligned tiles), 2 bf16 element by element
+template <int FORM>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int bb_lds[];
+  constexpr unsigned int STAGE = 8192;                             // dwords per stage: A 4096 | B 4096
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int ni = p.batch_inner, MI = ni / 4u;
+  unsigned int g = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) g = (g & 7u) * (gridDim.x >> 3) + (g >> 3);      // a contiguous band of macro tiles per XCD (its own L2)
+  const unsigned int mj = g / MI, mi = g - mj * MI;
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  // --- DMA duty.  A: instruction x brings k-pair 4 w + x of the stage, lane (problem ib = lane / 16, rows 4 (lane % 16) .. + 3).
+  //     B: instruction x brings columns 16 x .. 16 x + 15 of problem column w, lane (column lane / 4, chunk slot lane % 4).
+  // Addresses are "wave-uniform base (SGPR pair) + 32-bit lane offset": no VALU per request (launch_gemm checks that 3 bs_a fits 32 bits).
+  gcptr a_wave = (gcptr)p.a + (long long)(mi * 4u) * p.bs_a + 4ull * (4u * w) * lda;
+  const unsigned int offA = (lane >> 4) * (unsigned int)p.bs_a + 16u * (lane & 15u);
+  gcptr b_wave = (gcptr)p.b + (long long)(mj * 4u + w) * p.bs_b;
+  unsigned int offB[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const unsigned int cin = 16u * x + (lane >> 2), col = 64u * w + cin;
+    offB[x] = cin * ldb * 2u + 16u * ((lane & 3u) ^ ((col >> 1) & 3u));
+  }
+  const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
+  const unsigned int kchunks = (unsigned int)p.k >> 5;
+  const unsigned int total = (unsigned int)p.br_count * kchunks;
+  unsigned int is_r = 0, is_kc = 0;                                // the stage the next DMA request is for
+  auto issue = [&](unsigned int slot) {
+    gcptr a0 = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)(a_wave + is_r * brs_a + 64ull * is_kc * lda));      // 16 k-pairs x lda x 4 bytes per stage
+    gcptr b0 = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)(b_wave + is_r * brs_b + 64ull * is_kc));
+    unsigned int* dst = bb_lds + slot * STAGE + 1024u * w;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(a0 + 4ull * x * lda + (unsigned long long)offA), (lds_vptr)(dst + 256 * x), 16, 0, 0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(b0 + (unsigned long long)offB[x]), (lds_vptr)(dst + 4096 + 256 * x), 16, 0, 0);
+    if (++is_kc == kchunks) { is_kc = 0; ++is_r; }
+  };
+  // --- compute duty: the 128 x 128 quarter (wi, wj)
+  const unsigned int wi = w & 1u, wj = w >> 1;
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
+  if (total == 0) return;                                          // (launch_gemm sends br_count == 0 elsewhere)
+  // fragment addresses inside a stage (dwords): A row 128 wi + li, k-pair 4 h; B column 128 wj + li, chunk (2 s2 + h) ^ swizzle
+  const unsigned int fa = 1024u * h + 128u * wi + li;
+  const unsigned int sw = (li >> 1) & 3u;
+  const unsigned int fb0 = 4096u + (128u * wj + li) * 16u + 4u * (h ^ sw), fb1 = 4096u + (128u * wj + li) * 16u + 4u * ((2u + h) ^ sw);
+  struct Frags { u32x4 a[4]; u32x4 b[4]; };
+  auto read = [&](Frags& f, unsigned int slot, int s2) {
+    const unsigned int* st = bb_lds + slot * STAGE;
+    const unsigned int* pa = st + fa + 2048u * s2;
+    const unsigned int* pb = st + (s2 ? fb1 : fb0);
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) {
+      // an address register per fragment: its four k-pairs (256 dwords apart) then pair up as ds_read2st64 and land in consecutive
+      // registers; left to itself the compiler pairs the same k-pair of two fragments (32 dwords apart) and needs moves -- and a
+      // full LDS wait in front of them -- to build the operand
+      unsigned int ot = 32u * ti;
+      asm volatile("" : "+v"(ot));                                 // (an opaque OFFSET: laundering the pointer itself would lose its LDS address space)
+      const unsigned int* pt = pa + ot;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f.a[ti][e] = pt[256 * e];
+    }
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) f.b[tj] = *(const u32x4*)(pb + 512 * tj);
+  };
+  auto mfma16 = [&](const Frags& f) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[tj]), __builtin_bit_cast(bf16x8, f.a[ti]), acc[ti][tj], 0, 0, 0);
+  };
+  auto wait_landed = [&](unsigned int younger) {                   // this wave's DMA of a stage is complete when at most `younger` stages are behind it
+    if (younger >= 2u) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (younger == 1u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  const unsigned int pre = total < 3u ? total : 3u;
+  for (unsigned int t = 0; t < pre; ++t) issue(t);
+  wait_landed(pre - 1u);
+  wg_barrier();
+  Frags f0, f1;
+  read(f0, 0, 0);
+  unsigned int slot = 0, t = 0;
+  // Steady state (stages t + 1 .. t + 3 all exist): two straight-line regions per stage, split by the one barrier.  A single wave per SIMD
+  // issues in order, so whatever is not an MFMA has to sit BETWEEN MFMAs in program order to run in their shadow (32 cycles each):
+  // the group barriers ask the scheduler for "one MFMA, one LDS read" / "one MFMA, one DMA request" pairs instead of its default
+  // (all loads first, then 16 MFMAs back to back, the matrix pipe idle during the loads).
+  for (; t + 3u < total; ++t) {
+    read(f1, slot, 1);
+    mfma16(f0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // stage t + 1 has landed (stage t + 2 may fly)
+    wg_barrier();                                                  // ... for every wave, and every wave has read all of stage t
+    const unsigned int nslot = slot == 2u ? 0u : slot + 1u;
+    issue(slot);                                                   // stage t + 3 takes the place of stage t
+    read(f0, nslot, 0);
+    mfma16(f1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    slot = nslot;
+  }
+  for (; t < total; ++t) {                                         // the last stages: the same steps behind their conditions
+    read(f1, slot, 1);
+    mfma16(f0);
+    const unsigned int nslot = slot == 2u ? 0u : slot + 1u;
+    if (t + 1u < total) {
+      wait_landed(t + 2u < total ? 1u : 0u);                       // stage t + 1 (stage t + 2 may still fly, stage t + 3 is not requested yet)
+      wg_barrier();
+      if (t + 3u < total) issue(slot);
+      read(f0, nslot, 0);
+    }
+    mfma16(f1);
+    slot = nslot;
+  }
+  // --- C: tile (ti, tj) of the quarter is tile (ti % 2, tj % 2) of problem (2 wi + ti / 2, 2 wj + tj / 2) of the macro tile.  Same three
+  // store forms (and conversions) as tile_store_impl; the form is a template parameter because a run-time choice behind the loop makes
+  // the compiler unpack all 256 accumulators from the AGPRs at the loop exit (and spill what the loop needs to make room).
+  const bool odd = (lane & 1u) != 0;
+  const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
+  auto tile_base = [&](int ti, int tj) -> gptr {
+    const unsigned int bi = mi * 4u + 2u * wi + (unsigned int)(ti / 2), bj = mj * 4u + 2u * wj + (unsigned int)(tj / 2);
+    return (gptr)p.c + (long long)bi * p.bs_c + (long long)bj * p.bs_c2;
+  };
+  if constexpr (FORM == 0) {
+    static_for<16>([&](auto idx) {
+      constexpr int ti = idx.value / 4, tj = idx.value % 4;
+      GM float* base = (GM float*)tile_base(ti, tj) + (long long)(32 * (tj % 2) + 4 * (int)h) * p.ldc + (int)(32u * (ti % 2) + li);
+      static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream(base + (long long)((r & 3) + 8 * (r >> 2)) * p.ldc, acc[ti][tj][r]); });
+      asm volatile("" ::: "memory");
+    });
+  } else if constexpr (FORM == 1) {
+    static_for<16>([&](auto idx) {
+      constexpr int ti = idx.value / 4, tj = idx.value % 4;
+      const int i = (int)(32u * (ti % 2) + li);
+      GM unsigned short* base = (GM unsigned short*)tile_base(ti, tj) + (long long)(32 * (tj % 2) + 4 * (int)h + (odd ? 1 : 0)) * p.ldc + (i & ~1);
+      static_for<8>([&](auto gc) {
+        constexpr int r0 = 2 * gc.value, jr = (r0 & 3) + 8 * (r0 >> 2);
+        const unsigned int wv = cvt_pk_bf16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]);
+        const unsigned int nv = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)wv, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+        st_stream((GM unsigned int*)(base + (long long)jr * p.ldc), (unsigned int)__builtin_amdgcn_perm(nv, wv, sel));
+      });
+      asm volatile("" ::: "memory");
+    });
+  } else {
+    static_for<16>([&](auto idx) {
+      constexpr int ti = idx.value / 4, tj = idx.value % 4;
+      GM unsigned short* base = (GM unsigned short*)tile_base(ti, tj) + (long long)(32 * (tj % 2) + 4 * (int)h) * p.ldc + (int)(32u * (ti % 2) + li);
+      static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream(base + (long long)((r & 3) + 8 * (r >> 2)) * p.ldc, f32_to_bf16_rne(acc[ti][tj][r])); });
+      asm volatile("" ::: "memory");
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 8-bit integer streaming kernel (v_mfma_i32_32x32x32_i8): exact tiles, VNNI-4 A, flat B with 16-byte aligned columns,
 // k % 64 == 0.  Structure = gemm_bf16_stream_kernel: B through LDS-DMA with source-side swizzle, A straight into
 // operand registers.  The matrix core multiplies SIGNED bytes; an unsigned operand u is fed as (u ^ 0x80) = u - 128 and
@@ -2502,6 +2683,22 @@ static void launch_ragged(const GemmArgs& a, const RaggedCfg& c, unsigned int ld
   else if (beta0) hipLaunchKernelGGL((gemm_f32_ragged_kernel<W, NP, R2, false, false>), dim3(a.nbatch), dim3(64 * W), lds_bytes, st, a, c);
   else hipLaunchKernelGGL((gemm_f32_ragged_kernel<W, NP, R2, true, false>), dim3(a.nbatch), dim3(64 * W), lds_bytes, st, a, c);
 }
+// the bf16 blocked kernel: 2-D batch of 64 x 64 x K problems (K % 32 == 0) whose grid divides into 4 x 4 problems, VNNI-2 A, flat B, plain
+// epilogue, beta = 0, strided forms, 16-byte aligned rows / columns, at least one block
+static bool bf16_blocked_ok(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_BLOCKED"); return e && e[0] == '0'; }();
+  if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.br_count == 0) return false;
+  if (a.a_type != LIBXSMM_DATATYPE_BF16 || a.b_type != LIBXSMM_DATATYPE_BF16 || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
+  if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || a.vnni_c || a.colbias || a.act || !(a.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false;
+  if (a.c_type != LIBXSMM_DATATYPE_BF16 && a.c_type != LIBXSMM_DATATYPE_F32) return false;
+  if (a.m != 64 || a.n != 64 || a.k <= 0 || (a.k % 32) != 0) return false;
+  const unsigned int ni = a.batch_inner, nj = a.nbatch / a.batch_inner;
+  if (ni % 4u || nj % 4u || a.br_count * (unsigned long long)(a.k >> 5) >= (1ull << 31)) return false;
+  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
+    (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) | (unsigned long long)((long long)a.lda * 4) | (unsigned long long)((long long)a.ldb * 2);
+  if (a.bs_a < 0 || 3ull * (unsigned long long)a.bs_a + 1024ull >= (1ull << 32) || 64ull * (unsigned long long)a.ldb * 2ull >= (1ull << 32)) return false;
+  return (bits & 15ull) == 0ull && a.lda < (1 << 20) && a.ldb < (1 << 20);
+}
 static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
   static const int mode = []() { const char* e = getenv("LIBXSMM_HIP_F32_DMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
   return mode;
@@ -2564,6 +2761,24 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     if (bf16) { if (four) hipLaunchKernelGGL((gemm_p16_kernel<4, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_p16_kernel<1, true>), grid, dim3(256), 0, st, a); }
     else { if (four) hipLaunchKernelGGL((gemm_p16_kernel<4, false>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_p16_kernel<1, false>), grid, dim3(256), 0, st, a); }
     return (int)hipGetLastError();
+  }
+  // 2-D batches of bf16 64 x 64 x K problems, plain epilogue: the 256 x 256 macro-tile kernel
+  if (a.batch_inner && pl.path == P_BF16_2x2 && pl.exact && bf16_blocked_ok(a)) {
+    static const bool lds_ok = []() {
+      return hipFuncSetAttribute((const void*)gemm_bf16_blocked_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) == hipSuccess &&
+             hipFuncSetAttribute((const void*)gemm_bf16_blocked_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) == hipSuccess &&
+             hipFuncSetAttribute((const void*)gemm_bf16_blocked_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) == hipSuccess; }();
+    if (lds_ok) {
+      a.tiles_m = a.tiles_n = 2; a.map2d_shift = 0;
+      grid = dim3((a.batch_inner / 4u) * ((a.nbatch / a.batch_inner) / 4u));
+      if (kernel_name) *kernel_name = "gemm_bf16_blocked_kernel";
+      const bool pack2 = ((a.ldc & 1) == 0) && ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 3ull) == 0ull);
+      if (a.c_type == LIBXSMM_DATATYPE_F32) hipLaunchKernelGGL(gemm_bf16_blocked_kernel<0>, grid, dim3(256), 98304, st, a);
+      else if (pack2) hipLaunchKernelGGL(gemm_bf16_blocked_kernel<1>, grid, dim3(256), 98304, st, a);
+      else hipLaunchKernelGGL(gemm_bf16_blocked_kernel<2>, grid, dim3(256), 98304, st, a);
+      return (int)hipGetLastError();
+    }
+    (void)hipGetLastError();
   }
   // 2-D batches of exact f32 32^3 / 64^3 problems (K any multiple of 32), NN, strided: the workgroup-cooperative blocked kernel
   if (a.batch_inner && (pl.path == P_F32_1x1 || pl.path == P_F32_2x2) && f32_blocked_ok(a)) {
