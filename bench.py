@@ -423,7 +423,7 @@ def committed_counters(kernel, alg_bytes, label):
 SWEEP = [(dt, m, b) for dt in ("f32", "bf16") for m in (16, 32, 64) for b in (4096, 65536)]
 # blocked GEMMs: (dtype, m, ni, nj, br) -- 2048^3 out of 16^3 tiles, 4096 x 4096 x 2048 out of f32 32^3 tiles, 2048^3 out of bf16 32^3 tiles, 4096^3 out of 64^3 tiles
 BLOCKED = [("f32", 16, 128, 128, 128), ("f32", 32, 128, 128, 64), ("f32", 64, 64, 64, 64),
-           ("bf16", 16, 128, 128, 128), ("bf16", 32, 64, 64, 64), ("bf16", 64, 64, 64, 64)]
+           ("bf16", 16, 128, 128, 128), ("bf16", 32, 128, 128, 128), ("bf16", 64, 64, 64, 64)]
 SHARED_B = [(dt, m, 65536) for dt in ("f32", "bf16") for m in (16, 32, 64)]
 
 

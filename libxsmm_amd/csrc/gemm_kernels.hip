@@ -1879,36 +1879,47 @@ __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
 // that delivers 128.  Here a workgroup owns 256 x 256 of C (4 x 4 problems) and every wave 128 x 128 of it -- 16 accumulators of
 // 32 x 32, 256 AGPRs -- so a fragment is used by four MFMAs: 94 bytes per cycle.
 //   * K advances in stages of 32: A as [16 k-pairs][256 rows] dwords (16 KiB), B as [256 columns][64 bytes] (16 KiB, 16-byte chunks
-//     XOR-swizzled by the column so that the b128 fragment reads are conflict free), three stages in a 96 KiB ring.  All of it arrives
+//     XOR-swizzled by the column so that the b128 fragment reads are conflict free), four stages in a 128 KiB ring.  All of it arrives
 //     by LDS-DMA (8 instructions per wave and stage: wave w brings k-pairs 4 w .. 4 w + 3 of all four A problems and the B problem
-//     column w), two stages ahead of the one being multiplied.
+//     column w), three stages ahead of the one being multiplied.
 //   * One wave per SIMD cannot hide anything behind another wave: the loop is software-pipelined on k-steps of 16 -- the fragments of
 //     step u + 1 are requested before the 16 MFMAs of step u are issued -- with ONE workgroup barrier per stage.
 // Accumulation order per output = the k order of the single-problem kernels: bitwise the same results.
 // ------------------------------------------------------------------------------------------------
 // FORM of the C stores (decided by the host): 0 f32, 1 bf16 as packed dwords (even ldc, 4-byte aligned tiles), 2 bf16 element by element
-template <int FORM>
+// MB = 32-blocks per problem edge: 2 = 64 x 64 x K problems (4 x 4 per macro tile), 1 = 32 x 32 x K problems (8 x 8 per macro tile)
+template <int FORM, int MB>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
+  constexpr unsigned int PPM = 8 / MB, PE = 32 * MB;                // problems per macro-tile edge, problem edge
   extern __shared__ __attribute__((aligned(16))) unsigned int bb_lds[];
   constexpr unsigned int STAGE = 8192;                             // dwords per stage: A 4096 | B 4096
+  constexpr unsigned int NSLOT = 4;                                // stages in the ring (128 KiB): the DMA runs NSLOT - 1 stages ahead
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
-  const unsigned int ni = p.batch_inner, MI = ni / 4u;
-  unsigned int g = blockIdx.x;
-  if ((gridDim.x & 7u) == 0u) g = (g & 7u) * (gridDim.x >> 3) + (g >> 3);      // a contiguous band of macro tiles per XCD (its own L2)
-  const unsigned int mj = g / MI, mi = g - mj * MI;
+  const unsigned int ni = p.batch_inner, MI = ni / PPM, MJ = (p.nbatch / ni) / PPM;
+  // Hardware workgroup g runs on XCD g % 8 (its own 4 MiB L2).  The macro-tile grid is cut 4 x 2 so that every XCD owns a compact
+  // rectangle -- 16 x 16 macro tiles: 4 x 8 per XCD, an A panel shared by 8 of its workgroups and a B panel by 4 -- or, when the grid does
+  // not divide that way, a contiguous band of macro columns.
+  unsigned int g = blockIdx.x, mi, mj;
+  if ((MI & 3u) == 0u && (MJ & 1u) == 0u) {
+    const unsigned int x = g & 7u, k = g >> 3, RI = MI >> 2, rj = k / RI, ri = k - rj * RI;
+    mi = (x & 3u) * RI + ri; mj = (x >> 2) * (MJ >> 1) + rj;
+  } else {
+    if ((gridDim.x & 7u) == 0u) g = (g & 7u) * (gridDim.x >> 3) + (g >> 3);
+    mj = g / MI; mi = g - mj * MI;
+  }
   const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
-  // --- DMA duty.  A: instruction x brings k-pair 4 w + x of the stage, lane (problem ib = lane / 16, rows 4 (lane % 16) .. + 3).
-  //     B: instruction x brings columns 16 x .. 16 x + 15 of problem column w, lane (column lane / 4, chunk slot lane % 4).
-  // Addresses are "wave-uniform base (SGPR pair) + 32-bit lane offset": no VALU per request (launch_gemm checks that 3 bs_a fits 32 bits).
-  gcptr a_wave = (gcptr)p.a + (long long)(mi * 4u) * p.bs_a + 4ull * (4u * w) * lda;
-  const unsigned int offA = (lane >> 4) * (unsigned int)p.bs_a + 16u * (lane & 15u);
-  gcptr b_wave = (gcptr)p.b + (long long)(mj * 4u + w) * p.bs_b;
+  // --- DMA duty.  A: instruction x brings k-pair 4 w + x of the stage, lane (problem ib = 4 lane / PE, rows 4 lane % PE .. + 3).
+  //     B: instruction x brings columns 64 w + 16 x .. + 15 of the macro tile, lane (column lane / 4, chunk slot lane % 4).
+  // Addresses are "wave-uniform base (SGPR pair) + 32-bit lane offset": no VALU per request (launch_gemm checks that the offsets fit).
+  gcptr a_wave = (gcptr)p.a + (long long)(mi * PPM) * p.bs_a + 4ull * (4u * w) * lda;
+  const unsigned int offA = ((4u * lane) / PE) * (unsigned int)p.bs_a + 4u * ((4u * lane) % PE);
+  gcptr b_wave = (gcptr)p.b + (long long)(mj * PPM) * p.bs_b;
   unsigned int offB[4];
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
-    const unsigned int cin = 16u * x + (lane >> 2), col = 64u * w + cin;
-    offB[x] = cin * ldb * 2u + 16u * ((lane & 3u) ^ ((col >> 1) & 3u));
+    const unsigned int col = 64u * w + 16u * x + (lane >> 2);
+    offB[x] = (col / PE) * (unsigned int)p.bs_b + (col % PE) * ldb * 2u + 16u * ((lane & 3u) ^ ((col >> 1) & 3u));
   }
   const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
   const unsigned int kchunks = (unsigned int)p.k >> 5;
@@ -1967,31 +1978,32 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[tj]), __builtin_bit_cast(bf16x8, f.a[ti]), acc[ti][tj], 0, 0, 0);
   };
   auto wait_landed = [&](unsigned int younger) {                   // this wave's DMA of a stage is complete when at most `younger` stages are behind it
-    if (younger >= 2u) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (younger >= 3u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (younger == 2u) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (younger == 1u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  const unsigned int pre = total < 3u ? total : 3u;
+  const unsigned int pre = total < NSLOT ? total : NSLOT;
   for (unsigned int t = 0; t < pre; ++t) issue(t);
   wait_landed(pre - 1u);
   wg_barrier();
   Frags f0, f1;
   read(f0, 0, 0);
   unsigned int slot = 0, t = 0;
-  // Steady state (stages t + 1 .. t + 3 all exist): two straight-line regions per stage, split by the one barrier.  A single wave per SIMD
+  // Steady state (stages t + 1 .. t + NSLOT all exist): two straight-line regions per stage, split by the one barrier.  A single wave per SIMD
   // issues in order, so whatever is not an MFMA has to sit BETWEEN MFMAs in program order to run in their shadow (32 cycles each):
   // the group barriers ask the scheduler for "one MFMA, one LDS read" / "one MFMA, one DMA request" pairs instead of its default
   // (all loads first, then 16 MFMAs back to back, the matrix pipe idle during the loads).
-  for (; t + 3u < total; ++t) {
+  for (; t + NSLOT < total; ++t) {
     read(f1, slot, 1);
     mfma16(f0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // stage t + 1 has landed (stage t + 2 may fly)
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");              // stage t + 1 has landed (stages t + 2, t + 3 may fly)
     wg_barrier();                                                  // ... for every wave, and every wave has read all of stage t
-    const unsigned int nslot = slot == 2u ? 0u : slot + 1u;
-    issue(slot);                                                   // stage t + 3 takes the place of stage t
+    const unsigned int nslot = slot == NSLOT - 1u ? 0u : slot + 1u;
+    issue(slot);                                                   // stage t + NSLOT takes the place of stage t
     read(f0, nslot, 0);
     mfma16(f1);
 #pragma unroll
@@ -2004,11 +2016,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
   for (; t < total; ++t) {                                         // the last stages: the same steps behind their conditions
     read(f1, slot, 1);
     mfma16(f0);
-    const unsigned int nslot = slot == 2u ? 0u : slot + 1u;
+    const unsigned int nslot = slot == NSLOT - 1u ? 0u : slot + 1u;
     if (t + 1u < total) {
-      wait_landed(t + 2u < total ? 1u : 0u);                       // stage t + 1 (stage t + 2 may still fly, stage t + 3 is not requested yet)
+      wait_landed(total - t - 2u < NSLOT - 2u ? total - t - 2u : NSLOT - 2u);     // stage t + 1; stages t + 2 .. t + NSLOT - 1 may still fly
       wg_barrier();
-      if (t + 3u < total) issue(slot);
+      if (t + NSLOT < total) issue(slot);
       read(f0, nslot, 0);
     }
     mfma16(f1);
@@ -2019,22 +2031,25 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
   // the compiler unpack all 256 accumulators from the AGPRs at the loop exit (and spill what the loop needs to make room).
   const bool odd = (lane & 1u) != 0;
   const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
+  // tile (ti, tj) of the quarter = 32 x 32 block at rows 128 wi + 32 ti, columns 128 wj + 32 tj of the macro tile
   auto tile_base = [&](int ti, int tj) -> gptr {
-    const unsigned int bi = mi * 4u + 2u * wi + (unsigned int)(ti / 2), bj = mj * 4u + 2u * wj + (unsigned int)(tj / 2);
-    return (gptr)p.c + (long long)bi * p.bs_c + (long long)bj * p.bs_c2;
+    const unsigned int row = 128u * wi + 32u * (unsigned int)ti, col = 128u * wj + 32u * (unsigned int)tj;
+    return (gptr)p.c + (long long)(mi * PPM + row / PE) * p.bs_c + (long long)(mj * PPM + col / PE) * p.bs_c2;
   };
+  auto tile_i = [&](int ti) { return (int)((128u * wi + 32u * (unsigned int)ti) % PE + li); };
+  auto tile_j = [&](int tj) { return (int)((128u * wj + 32u * (unsigned int)tj) % PE); };
   if constexpr (FORM == 0) {
     static_for<16>([&](auto idx) {
       constexpr int ti = idx.value / 4, tj = idx.value % 4;
-      GM float* base = (GM float*)tile_base(ti, tj) + (long long)(32 * (tj % 2) + 4 * (int)h) * p.ldc + (int)(32u * (ti % 2) + li);
+      GM float* base = (GM float*)tile_base(ti, tj) + (long long)(tile_j(tj) + 4 * (int)h) * p.ldc + tile_i(ti);
       static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream(base + (long long)((r & 3) + 8 * (r >> 2)) * p.ldc, acc[ti][tj][r]); });
       asm volatile("" ::: "memory");
     });
   } else if constexpr (FORM == 1) {
     static_for<16>([&](auto idx) {
       constexpr int ti = idx.value / 4, tj = idx.value % 4;
-      const int i = (int)(32u * (ti % 2) + li);
-      GM unsigned short* base = (GM unsigned short*)tile_base(ti, tj) + (long long)(32 * (tj % 2) + 4 * (int)h + (odd ? 1 : 0)) * p.ldc + (i & ~1);
+      const int i = tile_i(ti);
+      GM unsigned short* base = (GM unsigned short*)tile_base(ti, tj) + (long long)(tile_j(tj) + 4 * (int)h + (odd ? 1 : 0)) * p.ldc + (i & ~1);
       static_for<8>([&](auto gc) {
         constexpr int r0 = 2 * gc.value, jr = (r0 & 3) + 8 * (r0 >> 2);
         const unsigned int wv = cvt_pk_bf16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]);
@@ -2046,7 +2061,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
   } else {
     static_for<16>([&](auto idx) {
       constexpr int ti = idx.value / 4, tj = idx.value % 4;
-      GM unsigned short* base = (GM unsigned short*)tile_base(ti, tj) + (long long)(32 * (tj % 2) + 4 * (int)h) * p.ldc + (int)(32u * (ti % 2) + li);
+      GM unsigned short* base = (GM unsigned short*)tile_base(ti, tj) + (long long)(tile_j(tj) + 4 * (int)h) * p.ldc + tile_i(ti);
       static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream(base + (long long)((r & 3) + 8 * (r >> 2)) * p.ldc, f32_to_bf16_rne(acc[ti][tj][r])); });
       asm volatile("" ::: "memory");
     });
@@ -2691,12 +2706,12 @@ static bool bf16_blocked_ok(const GemmArgs& a) {
   if (a.a_type != LIBXSMM_DATATYPE_BF16 || a.b_type != LIBXSMM_DATATYPE_BF16 || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
   if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || a.vnni_c || a.colbias || a.act || !(a.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false;
   if (a.c_type != LIBXSMM_DATATYPE_BF16 && a.c_type != LIBXSMM_DATATYPE_F32) return false;
-  if (a.m != 64 || a.n != 64 || a.k <= 0 || (a.k % 32) != 0) return false;
-  const unsigned int ni = a.batch_inner, nj = a.nbatch / a.batch_inner;
-  if (ni % 4u || nj % 4u || a.br_count * (unsigned long long)(a.k >> 5) >= (1ull << 31)) return false;
+  if (!((a.m == 64 && a.n == 64) || (a.m == 32 && a.n == 32)) || a.k <= 0 || (a.k % 32) != 0) return false;
+  const unsigned int ni = a.batch_inner, nj = a.nbatch / a.batch_inner, ppm = 256u / (unsigned int)a.m;
+  if (ni % ppm || nj % ppm || a.br_count * (unsigned long long)(a.k >> 5) >= (1ull << 31)) return false;
   const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
     (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) | (unsigned long long)((long long)a.lda * 4) | (unsigned long long)((long long)a.ldb * 2);
-  if (a.bs_a < 0 || 3ull * (unsigned long long)a.bs_a + 1024ull >= (1ull << 32) || 64ull * (unsigned long long)a.ldb * 2ull >= (1ull << 32)) return false;
+  if (a.bs_a < 0 || a.bs_b < 0 || 8ull * (unsigned long long)a.bs_a + 1024ull >= (1ull << 32) || 8ull * (unsigned long long)a.bs_b + 64ull * (unsigned long long)a.ldb * 2ull >= (1ull << 32)) return false;
   return (bits & 15ull) == 0ull && a.lda < (1 << 20) && a.ldb < (1 << 20);
 }
 static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
@@ -2762,22 +2777,26 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     else { if (four) hipLaunchKernelGGL((gemm_p16_kernel<4, false>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_p16_kernel<1, false>), grid, dim3(256), 0, st, a); }
     return (int)hipGetLastError();
   }
-  // 2-D batches of bf16 64 x 64 x K problems, plain epilogue: the 256 x 256 macro-tile kernel
-  if (a.batch_inner && pl.path == P_BF16_2x2 && pl.exact && bf16_blocked_ok(a)) {
+  // 2-D batches of bf16 64 x 64 x K or 32 x 32 x K problems, plain epilogue: the 256 x 256 macro-tile kernel
+  if (a.batch_inner && (pl.path == P_BF16_2x2 || pl.path == P_BF16_1x1) && pl.exact && bf16_blocked_ok(a)) {
+#define BB_FORMS_(MB_) do { if (a.c_type == LIBXSMM_DATATYPE_F32) hipLaunchKernelGGL((gemm_bf16_blocked_kernel<0, MB_>), grid, dim3(256), 131072, st, a); \
+      else if (pack2) hipLaunchKernelGGL((gemm_bf16_blocked_kernel<1, MB_>), grid, dim3(256), 131072, st, a); \
+      else hipLaunchKernelGGL((gemm_bf16_blocked_kernel<2, MB_>), grid, dim3(256), 131072, st, a); } while (0)
     static const bool lds_ok = []() {
-      return hipFuncSetAttribute((const void*)gemm_bf16_blocked_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) == hipSuccess &&
-             hipFuncSetAttribute((const void*)gemm_bf16_blocked_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) == hipSuccess &&
-             hipFuncSetAttribute((const void*)gemm_bf16_blocked_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304) == hipSuccess; }();
+      const void* ks[6] = {(const void*)gemm_bf16_blocked_kernel<0, 1>, (const void*)gemm_bf16_blocked_kernel<1, 1>, (const void*)gemm_bf16_blocked_kernel<2, 1>,
+                           (const void*)gemm_bf16_blocked_kernel<0, 2>, (const void*)gemm_bf16_blocked_kernel<1, 2>, (const void*)gemm_bf16_blocked_kernel<2, 2>};
+      for (const void* kf : ks) if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) return false;
+      return true; }();
     if (lds_ok) {
-      a.tiles_m = a.tiles_n = 2; a.map2d_shift = 0;
-      grid = dim3((a.batch_inner / 4u) * ((a.nbatch / a.batch_inner) / 4u));
+      const unsigned int ppm = 256u / (unsigned int)a.m;
+      a.tiles_m = a.tiles_n = a.m / 32; a.map2d_shift = 0;
+      grid = dim3((a.batch_inner / ppm) * ((a.nbatch / a.batch_inner) / ppm));
       if (kernel_name) *kernel_name = "gemm_bf16_blocked_kernel";
       const bool pack2 = ((a.ldc & 1) == 0) && ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 3ull) == 0ull);
-      if (a.c_type == LIBXSMM_DATATYPE_F32) hipLaunchKernelGGL(gemm_bf16_blocked_kernel<0>, grid, dim3(256), 98304, st, a);
-      else if (pack2) hipLaunchKernelGGL(gemm_bf16_blocked_kernel<1>, grid, dim3(256), 98304, st, a);
-      else hipLaunchKernelGGL(gemm_bf16_blocked_kernel<2>, grid, dim3(256), 98304, st, a);
+      if (a.m == 64) BB_FORMS_(2); else BB_FORMS_(1);
       return (int)hipGetLastError();
     }
+#undef BB_FORMS_
     (void)hipGetLastError();
   }
   // 2-D batches of exact f32 32^3 / 64^3 problems (K any multiple of 32), NN, strided: the workgroup-cooperative blocked kernel
