@@ -10,6 +10,9 @@
 // case uses 16-byte (f32x4 / bf16x8) accesses.  The op is a run-time switch: the arithmetic is
 // irrelevant next to the memory traffic.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 #include <algorithm>
 #include <cstdlib>
 #include "internal.hpp"
@@ -878,6 +881,139 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Reduction over a LIST of columns -- REDUCE_COLS_IDX_OP_ADD / MAX / MIN: out[i] = op over jj < n_cols of in(i, idx[jj]) (an embedding
+// bag: gather + reduce in one pass) -- and the column reductions MAX / ABSMAX / MIN that record the column of the extremum
+// (REDUCE_RECORD_ARGOP) [ref: mateltwise ref :1346-1430].  One thread per row i, the listed columns in the caller's order (the sum is
+// the reference's serial f32 sum; a later equal extremum wins like there); a wave reads 64 consecutive rows of a column: 256 bytes.
+// p.scalar_u64 = number of listed columns (0: all p.n columns in order), p.aux_in = the list, p.aux_out = the recorded columns.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_cols_listed_kernel(MeltwArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.m) return;
+  const unsigned int b = blockIdx.y;
+  gcptr in = (gcptr)p.in0 + (long long)b * p.bs_in0;
+  gptr out = (gptr)p.out + (long long)b * p.bs_out;
+  const bool idx4 = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_4BYTES) != 0, record = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP) != 0;
+  const bool listed = p.type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_ADD || p.type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MAX || p.type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MIN;
+  const int op = (p.type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_ADD) ? 0
+               : (p.type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MAX || p.type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) ? 1
+               : (p.type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX) ? 3 : 2;
+  const unsigned long long n_cols = listed ? p.scalar_u64 : (unsigned long long)p.n;
+  GM const unsigned int* idx32 = (GM const unsigned int*)((gcptr)p.aux_in + (long long)b * p.bs_aux);
+  GM const unsigned long long* idx64 = (GM const unsigned long long*)((gcptr)p.aux_in + (long long)b * p.bs_aux);
+  float acc = (op == 0) ? 0.0f : (op == 1) ? -3.402823466e+38f : (op == 3) ? 0.0f : 3.402823466e+38f;
+  unsigned long long arg = 0; bool found = false;
+  for (unsigned long long jj = 0; jj < n_cols; ++jj) {
+    const unsigned long long j = listed ? (idx4 ? (unsigned long long)idx32[jj] : idx64[jj]) : jj;     // wave-uniform: one scalar load
+    float x = mw_load(in, (long long)i + (long long)j * p.ldi, p.in0_type);
+    if (op == 0) { acc += x; continue; }
+    if (op == 3) x = fabsf(x);
+    if (op == 1 || op == 3) {
+      if (record) { if (x >= acc) { acc = x; arg = j; found = true; } }
+      else acc = (x < acc) ? acc : x;
+    } else {
+      if (record) { if (x <= acc) { acc = x; arg = j; found = true; } }
+      else acc = (x < acc) ? x : acc;
+    }
+  }
+  mw_store(out, i, p.out_type, acc);
+  if (record && found) {          // (no listed column qualified -- all NaN -- : the entry keeps its old value, like the reference)
+    if (idx4) ((GM unsigned int*)p.aux_out)[i] = (unsigned int)arg; else ((GM unsigned long long*)p.aux_out)[i] = arg;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DROPOUT [ref: mateltwise ref :2361-2407, generator :43-72].  The reference keeps 16 xoshiro128+ streams side by side (state word s of
+// stream l at state[l + 16 s]) and draws for 16 rows at a time (the AVX-512 width; the width is part of the semantics):
+// row i of column j of batch element b gets draw number g = (b * n + j) * ceil(m / 16) + i / 16 of stream i % 16, and every draw
+// advances all 16 streams, also in a column's ragged tail.  A stream is a linear map over GF(2): draw g needs T^g state, and T^(2^k) is
+// a 128 x 128 bit matrix that the host builds once (jump[k][bit] = T^(2^k) e_bit, 64 KiB).  So the draws are cut into SEGMENTS of L
+// consecutive g: 16 threads (one per stream) jump to the segment's first draw -- one matrix-vector product per set bit of g -- and
+// step through it; the segment that ends the launch writes the advanced state back, exactly the reference's state after its last draw.
+// The bitmask comes from a wave ballot: the 16 streams of a segment are 16 adjacent lanes = two mask bytes.
+// p.aux_in = the 64-dword state, p.aux_out = the mask (BITMASK_2BYTEMULT), p.scalar_f32 = the dropout probability.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void dropout_kernel(MeltwArgs p, const u32x4m* jump_tables, unsigned long long L) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+  const unsigned int l = (unsigned int)(t & 15ull);
+  const unsigned long long seg = t >> 4;
+  const unsigned long long cpr = (unsigned long long)((p.m + 15) / 16), C = (unsigned long long)p.n * cpr, total = C * p.nbatch;
+  const unsigned long long g0 = seg * L;
+  if (g0 >= total) return;
+  const unsigned long long g1 = (g0 + L < total) ? g0 + L : total;
+  GM unsigned int* st = (GM unsigned int*)p.aux_in;
+  GM const u32x4m* jump = (GM const u32x4m*)jump_tables;
+  u32x4m s = {st[l], st[l + 16], st[l + 32], st[l + 48]};
+  for (int k = 0; k < 64 && (g0 >> k) != 0ull; ++k) {              // s = T^g0 s
+    if (!((g0 >> k) & 1ull)) continue;
+    GM const u32x4m* col = jump + 128 * k;
+    u32x4m acc = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      unsigned int bits = s[w];
+      while (bits) { const int b = __builtin_ctz(bits); bits &= bits - 1u; acc ^= col[32 * w + b]; }
+    }
+    s = acc;
+  }
+  const float pn = 1.0f - p.scalar_f32, pi = 1.0f / pn;
+  const bool bitm = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) != 0;
+  const long long mask_ld8 = (((long long)p.ldo + 15) / 16) * 2;    // mask bytes per column
+  const unsigned int shift = (threadIdx.x & 63u) & ~15u;             // this segment's 16 lanes inside the wave
+  for (unsigned long long g = g0; g < g1; ++g) {
+    const float draw = __uint_as_float(0x3f800000u | ((s[3] + s[0]) >> 9)) - 1.0f;
+    { const unsigned int t0 = s[1] << 9; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t0; s[3] = (s[3] << 11) | (s[3] >> 21); }
+    const unsigned long long b = g / C, c = g - b * C, j = c / cpr, ic = c - j * cpr;
+    const long long i = (long long)(ic * 16ull + l);
+    const bool valid = i < p.m, keep = draw < pn;
+    if (valid) {
+      const float x = mw_load((gcptr)p.in0 + (long long)b * p.bs_in0, i + (long long)j * p.ldi, p.in0_type);
+      mw_store((gptr)p.out + (long long)b * p.bs_out, i + (long long)j * p.ldo, p.out_type, keep ? pi * x : 0.0f);
+    }
+    if (bitm) {
+      const unsigned int kept = (unsigned int)((__ballot(valid && keep) >> shift) & 0xffffull), have = (unsigned int)((__ballot(valid) >> shift) & 0xffffull);
+      if (l == 0) {
+        GM unsigned char* mb = (GM unsigned char*)p.aux_out + (long long)b * p.bs_aux + (long long)j * mask_ld8 + (long long)ic * 2;
+        if (have & 0x00ffu) mb[0] = (unsigned char)((mb[0] & ~(have & 0xffu)) | (kept & 0xffu));
+        if (have & 0xff00u) mb[1] = (unsigned char)((mb[1] & ~(have >> 8)) | (kept >> 8));
+      }
+    }
+  }
+  if (g1 == total) { st[l] = s[0]; st[l + 16] = s[1]; st[l + 32] = s[2]; st[l + 48] = s[3]; }
+}
+// DROPOUT_INV [ref: :2408-2424]: out = mask bit ? in / (1 - p) : 0, the mask from in.secondary
+__global__ __launch_bounds__(256) void dropout_inv_kernel(MeltwArgs p) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x, per = (long long)p.m * p.n;
+  if (e >= per * p.nbatch) return;
+  const long long b = e / per, r = e - b * per, j = r / p.m, i = r - j * p.m;
+  const bool bitm = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) != 0;
+  const long long mask_ld8 = bitm ? (((long long)p.ldi + 15) / 16) * 2 : p.ldi / 8;
+  const float pi = 1.0f / (1.0f - p.scalar_f32);
+  GM const unsigned char* mb = (GM const unsigned char*)p.aux_in + b * p.bs_aux;
+  const int bit = (mb[i / 8 + j * mask_ld8] >> (i % 8)) & 1;
+  const float x = mw_load((gcptr)p.in0 + b * p.bs_in0, i + j * p.ldi, p.in0_type) * pi;
+  mw_store((gptr)p.out + b * p.bs_out, i + j * p.ldo, p.out_type, bit ? x : 0.0f);
+}
+// T^(2^k) as 128 columns each, k < 64, on the current device (built once per device)
+static const u32x4m* dropout_jump_tables() {
+  static std::mutex mu; static std::unordered_map<int, const u32x4m*> per_device;
+  int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = per_device.find(dev);
+  if (it != per_device.end()) return it->second;
+  struct S { unsigned int w[4]; };
+  auto step = [](S s) { const unsigned int t0 = s.w[1] << 9; s.w[2] ^= s.w[0]; s.w[3] ^= s.w[1]; s.w[1] ^= s.w[2]; s.w[0] ^= s.w[3]; s.w[2] ^= t0; s.w[3] = (s.w[3] << 11) | (s.w[3] >> 21); return s; };
+  std::vector<S> tab(64 * 128);
+  for (int b = 0; b < 128; ++b) { S e{{0, 0, 0, 0}}; e.w[b / 32] = 1u << (b % 32); tab[b] = step(e); }      // T
+  auto apply = [&](const S* cols, S v) { S a{{0, 0, 0, 0}}; for (int b = 0; b < 128; ++b) if ((v.w[b / 32] >> (b % 32)) & 1u) for (int q = 0; q < 4; ++q) a.w[q] ^= cols[b].w[q]; return a; };
+  for (int k = 1; k < 64; ++k) for (int b = 0; b < 128; ++b) tab[128 * k + b] = apply(&tab[128 * (k - 1)], tab[128 * (k - 1) + b]);     // T^(2^k) = (T^(2^(k-1)))^2
+  void* d = nullptr;
+  if (hipMalloc(&d, tab.size() * sizeof(S)) != hipSuccess || hipMemcpy(d, tab.data(), tab.size() * sizeof(S), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  per_device[dev] = (const u32x4m*)d;
+  return (const u32x4m*)d;
+}
+
 // second pass of the two-pass column reduction: partial[z][2][m] -> out (chunks combined in order z = 0, 1, ...)
 __global__ __launch_bounds__(256) void reduce_combine_kernel(MeltwArgs p, const float* partial, int nchunks) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1069,6 +1205,10 @@ static bool is_reduce_type(int t) {
          t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX;
 }
 
+static bool is_reduce_cols_idx_type(int t) {
+  return t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_ADD || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MAX || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MIN;
+}
+
 bool meltw_supported(const libxsmm_meltw_descriptor& d) {
   const int t = d.param;
   const bool f64 = d.in0_type == LIBXSMM_DATATYPE_F64 && d.out_type == LIBXSMM_DATATYPE_F64;
@@ -1076,7 +1216,13 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
     int v; const int sz = payload_size(d.in0_type);
     if (t == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT || xform_mode(t, &v) != 0 ||
         t == LIBXSMM_MELTW_TYPE_UNARY_GATHER || t == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) return sz == 1 || sz == 2 || sz == 4 || sz == 8;
-    if (is_reduce_type(t)) return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP));
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT || t == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT_INV)      // no broadcasts; 16 rows per draw
+      return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_BCAST_ROW | LIBXSMM_MELTW_FLAG_UNARY_BCAST_COL | LIBXSMM_MELTW_FLAG_UNARY_BCAST_SCALAR | LIBXSMM_MELTW_FLAG_UNARY_STOCHASTIC_ROUND));
+    if (is_reduce_cols_idx_type(t)) return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type);
+    if (is_reduce_type(t) && (d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP))       // recorded for MAX / ABSMAX / MIN over columns [ref: :1376-1424]
+      return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type) && !(d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) &&
+             (t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX);
+    if (is_reduce_type(t)) return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type);
     if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) return d.in0_type == LIBXSMM_DATATYPE_F32 && (d.out_type == LIBXSMM_DATATYPE_BF16 || d.out_type == LIBXSMM_DATATYPE_U16 || d.out_type == LIBXSMM_DATATYPE_I16);
     const auto is_qint = [](int x) { return x == LIBXSMM_DATATYPE_I8 || x == LIBXSMM_DATATYPE_I16 || x == LIBXSMM_DATATYPE_I32; };
     if (t == LIBXSMM_MELTW_TYPE_UNARY_QUANT && d.out_type == LIBXSMM_DATATYPE_NVFP4X2)      // 16-row blocks, E4M3 scales
@@ -1158,6 +1304,24 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
     if (name) *name = "meltw_ew8_kernel";
     return (int)hipGetLastError();
   }
+  if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT) {
+    const u32x4m* jt = dropout_jump_tables();
+    if (!jt) return (int)hipErrorOutOfMemory;
+    const unsigned long long total = (unsigned long long)a.n * (unsigned long long)((a.m + 15) / 16) * a.nbatch;
+    unsigned long long segs = std::min<unsigned long long>((total + 7ull) / 8ull, 16384ull);      // at least 8 draws per thread, at most 256 Ki threads
+    if (segs == 0) segs = 1;
+    const unsigned long long L = (total + segs - 1ull) / segs;
+    segs = (total + L - 1ull) / L;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned int)((segs * 16ull + 255ull) / 256ull)), dim3(256), 0, st, a, jt, L);
+    if (name) *name = "dropout_kernel";
+    return (int)hipGetLastError();
+  }
+  if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT_INV) {
+    const unsigned long long total = (unsigned long long)a.m * a.n * a.nbatch;
+    hipLaunchKernelGGL(dropout_inv_kernel, dim3((unsigned int)((total + 255ull) / 256ull)), dim3(256), 0, st, a);
+    if (name) *name = "dropout_inv_kernel";
+    return (int)hipGetLastError();
+  }
   if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_QUANT && a.out_type == LIBXSMM_DATATYPE_NVFP4X2) {
     const unsigned int mblk = (unsigned int)(a.m / 16), total = mblk * (unsigned int)a.n * (unsigned int)a.nbatch;
     hipLaunchKernelGGL(nvfp4_quant_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, a, mblk, total);
@@ -1224,6 +1388,9 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
         LAUNCH_BY_SIZE(gather_scatter_kernel, sz, dim3((unsigned int)((total + 255) / 256), a.nbatch), dim3(256), st, a);
         if (name) *name = "gather_scatter_kernel";
       }
+    } else if (is_reduce_cols_idx_type(a.type) || (is_reduce_type(a.type) && (a.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP))) {
+      hipLaunchKernelGGL(reduce_cols_listed_kernel, dim3((unsigned int)((a.m + 255) / 256), a.nbatch), dim3(256), 0, st, a);
+      if (name) *name = "reduce_cols_listed_kernel";
     } else if (is_reduce_type(a.type)) {
       const bool rows = (a.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
       const bool bf = a.in0_type == LIBXSMM_DATATYPE_BF16;

@@ -531,6 +531,25 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) {
       if (!p->out.secondary) { set_error(-2, "UNZIP needs the byte offset in out.secondary"); return; }
       a.scalar_u64 = *(const unsigned long long*)p->out.secondary;
+    } else if (t == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT || t == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT_INV) {
+      // the probability is a host scalar behind op.primary; DROPOUT advances the generator state (64 dwords) behind op.secondary and
+      // writes the mask to out.secondary, DROPOUT_INV reads the mask from in.secondary [ref: mateltwise ref :2091, :2361-2424]
+      if (!p->op.primary) { set_error(-2, "DROPOUT needs the probability in op.primary"); return; }
+      a.scalar_f32 = *(const float*)p->op.primary;
+      const bool bitm = (d.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) != 0;
+      if (t == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT) {
+        if (!p->op.secondary) { set_error(-2, "DROPOUT needs the generator state in op.secondary"); return; }
+        if (bitm && !p->out.secondary) { set_error(-2, "DROPOUT with BITMASK_2BYTEMULT needs the mask destination in out.secondary"); return; }
+        a.aux_in = staging_allowed(b.count) ? stage(p->op.secondary, 256, true, true) : p->op.secondary;
+        if (!a.aux_in) return;
+      } else if (!p->in.secondary) { set_error(-2, "DROPOUT_INV needs the mask in in.secondary"); return; }
+    } else if (t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_ADD || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MAX || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MIN) {
+      // the number of listed columns is a host scalar behind in.tertiary, the list itself sits behind in.secondary [ref: mateltwise ref :1121-1138, :1076]
+      if (!p->in.tertiary || !p->in.secondary) { set_error(-2, "REDUCE_COLS_IDX needs the column list in in.secondary and its length in in.tertiary"); return; }
+      a.scalar_u64 = *(const unsigned long long*)p->in.tertiary;
+      const size_t isz = (d.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_4BYTES) ? 4 : 8;
+      a.aux_in = device_visible(p->in.secondary, (size_t)a.scalar_u64 * isz);
+      if (a.scalar_u64 && !a.aux_in) return;
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_GATHER || t == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) {
       const size_t isz = (d.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_8BYTES) ? 8 : 4;
       const size_t cnt = (d.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_COLS) ? d.n : (d.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_ROWS) ? d.m : (size_t)d.m * d.n;
@@ -545,6 +564,13 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     const libxsmm_meltw_ternary_param* p = (const libxsmm_meltw_ternary_param*)param;
     a.in0 = (const char*)p->in0.primary; a.in1 = (const char*)p->in1.primary; a.in2 = (const char*)p->in2.primary; a.out = (char*)p->out.primary;
     a.bs_in0 = b.s[0]; a.bs_in1 = b.s[1]; a.bs_in2 = b.s[2]; a.bs_out = b.s[3];
+  }
+  if (d.operation == LIBXSMM_MELTW_OPERATION_UNARY && (d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP)) {
+    // the recorded columns go to out.secondary: one index per row [ref: mateltwise ref :1078-1083]
+    if (!a.aux_out) { set_error(-2, "REDUCE_RECORD_ARGOP needs the index destination in out.secondary"); return; }
+    if (b.count > 1) { set_error(-2, "REDUCE_RECORD_ARGOP is not available in batched launches"); return; }
+    const size_t isz = (d.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_4BYTES) ? 4 : 8;
+    if (staging_allowed(b.count)) { a.aux_out = stage(a.aux_out, (size_t)a.m * isz, true, true); if (!a.aux_out) return; }
   }
   // Synchronous single calls of the plain element-wise / reduction TPPs accept host memory too (extents follow from the descriptor);
   // TPPs with index arrays, bit masks as inputs or re-laid-out outputs (gather/scatter, transforms, *_INV, SELECT, ZIP/UNZIP, ...)
@@ -567,10 +593,10 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
         case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_XOR: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT:
         case LIBXSMM_MELTW_TYPE_UNARY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_TANH: case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID: case LIBXSMM_MELTW_TYPE_UNARY_GELU:
         case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: case LIBXSMM_MELTW_TYPE_UNARY_INC: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT:
-        case LIBXSMM_MELTW_TYPE_UNARY_EXP: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_ELU: plain = true; break;
+        case LIBXSMM_MELTW_TYPE_UNARY_EXP: case LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_ELU: case LIBXSMM_MELTW_TYPE_UNARY_DROPOUT: plain = true; break;
         case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD:
         case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX:
-          reduce = (d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS | LIBXSMM_MELTW_FLAG_UNARY_REDUCE_COLS)) != 0 && !(d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP); break;
+          reduce = (d.flags & (LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS | LIBXSMM_MELTW_FLAG_UNARY_REDUCE_COLS)) != 0; break;
         default: break;
       }
     } else if (d.operation == LIBXSMM_MELTW_OPERATION_BINARY) {

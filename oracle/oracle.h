@@ -55,6 +55,8 @@ typedef struct oracle_meltw_desc {
 } oracle_meltw_desc;
 
 /* [ref: src/generator_mateltwise_reference_impl.c:2074 / 2505 / 2596 / 2663] */
+/* DROPOUT: rows per draw of the generator = the 32-bit vector length of the CPU the reference runs on (default 16) */
+void oracle_set_rng_width(int w);
 void oracle_meltw_unary(const libxsmm_meltw_unary_param* param, const oracle_meltw_desc* desc);
 void oracle_meltw_binary(const libxsmm_meltw_binary_param* param, const oracle_meltw_desc* desc);
 void oracle_meltw_ternary(const libxsmm_meltw_ternary_param* param, const oracle_meltw_desc* desc);

@@ -245,6 +245,10 @@ static void gather_scatter(const libxsmm_meltw_unary_param* p, const oracle_melt
 #undef IDX
 }
 
+/* rows per draw of the DROPOUT generator (see there) */
+static long long oracle_rng_width = 16;
+void oracle_set_rng_width(int w) { oracle_rng_width = (w >= 1 && w <= 16) ? w : 16; }
+
 /* ---- reductions  [:1065-1441], f32 compute ------------------------------------------------ */
 static int is_reduce(int t) {
   switch (t) {
@@ -252,6 +256,42 @@ static int is_reduce(int t) {
     case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX:
     case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN: case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX: return 1;
     default: return 0;
+  }
+}
+/* Reduction over a LIST of columns (REDUCE_COLS_IDX_OP_ADD / MAX / MIN: out[i] = op_jj in(i, idx[jj]), jj < *in.tertiary) and the
+ * column reductions MAX / ABSMAX / MIN that record WHERE the extremum was found (REDUCE_RECORD_ARGOP: the column index goes to
+ * out.secondary; a later equal value wins) [:1346-1430].  Indices are 4 bytes with IDX_SIZE_4BYTES, else 8 [:1088]. */
+static int is_reduce_cols_idx(int t) {
+  return t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_ADD || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MAX || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MIN;
+}
+static void reduce_cols_listed(const libxsmm_meltw_unary_param* p, const oracle_meltw_desc* d) {
+  const long long m = d->m, ldi = d->ldi;
+  const int idx4 = (d->flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_4BYTES) ? 1 : 0;
+  const int record = (d->flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP) ? 1 : 0;
+  const int listed = is_reduce_cols_idx(d->type);
+  const unsigned long long n_cols = listed ? *(const unsigned long long*)p->in.tertiary : (unsigned long long)d->n;
+  const unsigned int* idx32 = (const unsigned int*)p->in.secondary; const unsigned long long* idx64 = (const unsigned long long*)p->in.secondary;
+  unsigned int* arg32 = (unsigned int*)p->out.secondary; unsigned long long* arg64 = (unsigned long long*)p->out.secondary;
+  const int op = (d->type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_ADD) ? 0
+               : (d->type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MAX || d->type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) ? 1
+               : (d->type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX) ? 3 : 2;
+  long long i; unsigned long long jj;
+  for (i = 0; i < m; ++i) {
+    float acc = (op == 0) ? 0.0f : (op == 1) ? -FLT_MAX : (op == 3) ? 0.0f : FLT_MAX;
+    for (jj = 0; jj < n_cols; ++jj) {
+      const unsigned long long j = listed ? (idx4 ? (unsigned long long)idx32[jj] : idx64[jj]) : jj;
+      float x = get_f32(p->in.primary, i + (long long)j * ldi, d->in0_type);
+      if (op == 0) { acc = acc + x; continue; }
+      if (op == 3) x = fabsf(x);
+      if (op == 1 || op == 3) {
+        if (record) { if (x >= acc) { acc = x; if (idx4) arg32[i] = (unsigned int)j; else arg64[i] = j; } }
+        else acc = (x < acc) ? acc : x;                                      /* LIBXSMM_MAX(in_val, acc) */
+      } else {
+        if (record) { if (x <= acc) { acc = x; if (idx4) arg32[i] = (unsigned int)j; else arg64[i] = j; } }
+        else acc = (x < acc) ? x : acc;                                      /* LIBXSMM_MIN(in_val, acc) */
+      }
+    }
+    put_f32(p->out.primary, i, d->out_type, acc);
   }
 }
 static void reduce(const libxsmm_meltw_unary_param* p, const oracle_meltw_desc* d) {
@@ -296,6 +336,11 @@ void oracle_meltw_unary(const libxsmm_meltw_unary_param* p, const oracle_meltw_d
   const long long N = (d->type == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR) ? (long long)*(const unsigned long long*)p->op.primary : d->n;
   const int bc = bcast_kind(d, 0);
   long long i, j;
+  if (is_reduce_cols_idx(d->type)) { reduce_cols_listed(p, d); return; }
+  if (is_reduce(d->type) && (d->flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP) && !(d->flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) &&
+      (d->type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX || d->type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN || d->type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX)) {
+    reduce_cols_listed(p, d); return;
+  }
   if (is_reduce(d->type)) { reduce(p, d); return; }
   if (d->type == LIBXSMM_MELTW_TYPE_UNARY_GATHER || d->type == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) { gather_scatter(p, d); return; }
   if (is_transform(d->type)) { transform(p, d); return; }
@@ -312,6 +357,46 @@ void oracle_meltw_unary(const libxsmm_meltw_unary_param* p, const oracle_meltw_d
         else y = (x <= 0.0f) ? alpha * (expf(x) - 1.0f) : x;
         put_f32(p->out.primary, i + j * ldo, d->out_type, y);
         if (bitm) bit_put((unsigned char*)p->out.secondary, i, j, mask_ld, !(x <= 0.0f));
+      }
+      return;
+    }
+    case LIBXSMM_MELTW_TYPE_UNARY_DROPOUT: {        /* [:2361-2407]; the generator of [:43-72] */
+      /* 16 independent xoshiro128+ streams side by side (state word s of stream l at rng_state[l + 16 s], op.secondary).  The reference
+       * draws for `w` rows at a time, w = the 32-bit vector length of the CPU it runs on: row i of column j gets draw number
+       * j * ceil(M / w) + i / w of stream i % w.  The width is therefore part of the semantics: oracle_set_rng_width (default 16, the
+       * AVX-512 width, which is what the device library implements). */
+      const int bitm = (d->flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) ? 1 : 0;
+      const long long mask_ld = bitm ? LIBXSMM_UPDIV(ldo, 16) * 16 : ldo;
+      const float prob = *(const float*)p->op.primary, pn = 1 - prob, pi = 1 / pn;
+      unsigned int* st = (unsigned int*)p->op.secondary;
+      const long long w = oracle_rng_width;
+      float draw[16];
+      long long l;
+      for (j = 0; j < N; ++j) for (i = 0; i < M; i += w) {
+        for (l = 0; l < w; ++l) {                                       /* one step of every stream [:43-72] */
+          unsigned int s0 = st[l], s1 = st[l + 16], s2 = st[l + 32], s3 = st[l + 48], t0;
+          union { unsigned int u; float f; } r;
+          r.u = 0x3f800000u | ((s3 + s0) >> 9);
+          draw[l] = r.f - 1.0f;
+          t0 = s1 << 9; s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t0; s3 = (s3 << 11) | (s3 >> 21);
+          st[l] = s0; st[l + 16] = s1; st[l + 32] = s2; st[l + 48] = s3;
+        }
+        for (l = 0; l < w && i + l < M; ++l) {
+          const float x = get_f32(p->in.primary, elem_index(bc, i + l, j, ldi), d->in0_type);
+          const int keep = draw[l] < pn;
+          put_f32(p->out.primary, (i + l) + j * ldo, d->out_type, keep ? pi * x : 0.0f);
+          if (bitm) bit_put((unsigned char*)p->out.secondary, i + l, j, mask_ld, keep);
+        }
+      }
+      return;
+    }
+    case LIBXSMM_MELTW_TYPE_UNARY_DROPOUT_INV: {    /* [:2408-2424] */
+      const int bitm = (d->flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) ? 1 : 0;
+      const long long mask_ld = bitm ? LIBXSMM_UPDIV(ldi, 16) * 16 : ldi;
+      const float prob = *(const float*)p->op.primary, pn = 1.0f - prob, pi = 1.0f / pn;
+      for (j = 0; j < N; ++j) for (i = 0; i < M; ++i) {
+        const float x = get_f32(p->in.primary, elem_index(bc, i, j, ldi), d->in0_type) * pi;
+        put_f32(p->out.primary, i + j * ldo, d->out_type, bit_get((const unsigned char*)p->in.secondary, i, j, mask_ld) ? x : 0.0f);
       }
       return;
     }

@@ -65,6 +65,8 @@ XREF int xref_reference_meltw_unary(const void* param, libxsmm_meltw_unary_type 
   libxsmm_reference_elementwise((void*)param, desc);
   return 0;
 }
+/* rows per draw of the DROPOUT generator = the reference's 32-bit vector length on this CPU [ref: mateltwise ref :2369] */
+XREF int xref_vlen32(void) { return libxsmm_cpuid_vlen32(libxsmm_get_target_archid()); }
 XREF int xref_reference_meltw_binary(const void* param, libxsmm_meltw_binary_type type, libxsmm_meltw_binary_shape s, libxsmm_bitfield flags) {
   libxsmm_descriptor_blob blob;
   const libxsmm_meltw_descriptor* desc = libxsmm_meltw_descriptor_init2(&blob, s.in0_type, s.in1_type,

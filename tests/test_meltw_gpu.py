@@ -31,7 +31,7 @@ def _back(t, like):
 
 
 def run_unary(typ, m, n, ldi, ldo, in_dt, out_dt, flags=0, seed=0, batch=1, aux_in=None, aux_out_bytes=0, op_primary=None,
-              in_elems=None, out_elems=None, out_secondary_val=None, inp=None):
+              in_elems=None, out_elems=None, out_secondary_val=None, inp=None, in_tertiary_val=None):
     api, orc = capi.load(), pyoracle.oracle()
     rng = np.random.default_rng(seed)
     in_elems = in_elems if in_elems is not None else ldi * max(n, 1)
@@ -56,6 +56,8 @@ def run_unary(typ, m, n, ldi, ldo, in_dt, out_dt, flags=0, seed=0, batch=1, aux_
             v = C.c_ulonglong(out_secondary_val); keep.append(v); p.out.secondary = C.addressof(v)
         if op_primary is not None:
             keep.append(op_primary); p.op.primary = C.addressof(op_primary)
+        if in_tertiary_val is not None:
+            tv = C.c_ulonglong(in_tertiary_val); keep.append(tv); p.in_.tertiary = C.addressof(tv)
     for b in range(batch):
         p = capi.UnaryParam()
         fill(p, X.ctypes.data, ref.ctypes.data, aux_in.ctypes.data if aux_in is not None else None,
@@ -203,6 +205,61 @@ def test_reductions(typ, rows, in_dt):
         assert normf_rel(r[:, :used], g[:, :used], DT.F32) < 1e-5
 
 
+@pytest.mark.parametrize("typ", [UNARY.REDUCE_COLS_IDX_OP_ADD, UNARY.REDUCE_COLS_IDX_OP_MAX, UNARY.REDUCE_COLS_IDX_OP_MIN])
+@pytest.mark.parametrize("in_dt,out_dt", [(DT.F32, DT.F32), (DT.BF16, DT.BF16), (DT.BF16, DT.F32)])
+@pytest.mark.parametrize("idx8", [0, 1])
+@pytest.mark.parametrize("record", [0, 1])
+@pytest.mark.parametrize("m,big,ldi,ncols", [(45, 60, 48, 17), (256, 1000, 256, 64), (3, 5, 3, 1)])
+def test_reduce_over_listed_columns_bit_exact(typ, in_dt, out_dt, idx8, record, m, big, ldi, ncols):
+    """REDUCE_COLS_IDX_OP_*: the listed columns in the caller's order, the serial sum / the later equal extremum of the reference:
+    bit-exact, and so are the recorded columns."""
+    if record and typ == UNARY.REDUCE_COLS_IDX_OP_ADD:
+        pytest.skip("nothing to record for a sum")
+    rng = np.random.default_rng(31)
+    idx = rng.integers(0, big, size=ncols).astype(np.uint64 if idx8 else np.uint32)
+    flags = UNARY_FLAG.REDUCE_COLS | (0 if idx8 else UNARY_FLAG.IDX_SIZE_4BYTES) | (UNARY_FLAG.REDUCE_RECORD_ARGOP if record else 0)
+    ref, got, aref, agot = run_unary(typ, m, big, ldi, m, in_dt, out_dt, flags=flags, aux_in=idx, in_elems=ldi * big, out_elems=m,
+                                     in_tertiary_val=ncols, aux_out_bytes=m * (8 if idx8 else 4) if record else 0)
+    assert np.array_equal(ref, got)
+    if record:
+        assert np.array_equal(aref, agot)
+
+
+@pytest.mark.parametrize("typ", [UNARY.REDUCE_X_OP_MAX, UNARY.REDUCE_X_OP_MIN, UNARY.REDUCE_X_OP_ABSMAX])
+@pytest.mark.parametrize("idx8", [0, 1])
+def test_column_reduction_records_the_extremum(typ, idx8):
+    m, n, ldi = 70, 33, 72
+    flags = UNARY_FLAG.REDUCE_COLS | UNARY_FLAG.REDUCE_RECORD_ARGOP | (0 if idx8 else UNARY_FLAG.IDX_SIZE_4BYTES)
+    ref, got, aref, agot = run_unary(typ, m, n, ldi, m, DT.F32, DT.F32, flags=flags, out_elems=m, aux_out_bytes=m * (8 if idx8 else 4))
+    assert np.array_equal(ref, got) and np.array_equal(aref, agot)
+
+
+def test_listed_column_sum_batched_embedding_bags():
+    """hip_meltw_unary_batch_strided over bags: every bag its own index list (aux stride), one table."""
+    api, orc = capi.load(), pyoracle.oracle()
+    m, rows, bag, nb = 64, 500, 12, 37
+    rng = np.random.default_rng(5)
+    table = rand_values(rng, m * rows, DT.F32)
+    idx = rng.integers(0, rows, size=nb * bag).astype(np.uint32)
+    flags = UNARY_FLAG.REDUCE_COLS | UNARY_FLAG.IDX_SIZE_4BYTES
+    desc = pyoracle.MeltwDesc(m, rows, m, m, 0, 0, DT.F32, DT.UNSUPPORTED, DT.UNSUPPORTED, DT.F32, DT.F32, flags, UNARY.REDUCE_COLS_IDX_OP_ADD, OP_UNARY)
+    ref = np.zeros(nb * m, dtype=np.float32)
+    cnt = C.c_ulonglong(bag)
+    for b in range(nb):
+        p = capi.UnaryParam()
+        p.in_.primary, p.in_.secondary, p.in_.tertiary, p.out.primary = table.ctypes.data, idx.ctypes.data + 4 * bag * b, C.addressof(cnt), ref.ctypes.data + 4 * m * b
+        orc.meltw(p, desc)
+    h = api.dispatch_meltw_unary(UNARY.REDUCE_COLS_IDX_OP_ADD, capi.UnaryShape(m, rows, m, m, DT.F32, DT.F32, DT.F32), flags)
+    assert h
+    dT, dI, dO = _dev(table), _dev(idx), _dev(np.zeros(nb * m, dtype=np.float32))
+    p = capi.UnaryParam()
+    p.in_.primary, p.in_.secondary, p.in_.tertiary, p.out.primary = dT.data_ptr(), dI.data_ptr(), C.addressof(cnt), dO.data_ptr()
+    api.hip_meltw_unary_batch_strided(h, C.byref(p), nb, 0, 4 * m, 4 * bag)
+    api.hip_sync(); api.check()
+    assert np.array_equal(ref, dO.cpu().numpy())
+    assert api.hip_kernel_name(h, 1).decode() == "reduce_cols_listed_kernel"
+
+
 @pytest.mark.parametrize("typ", [UNARY.REDUCE_X_OP_ADD, UNARY.REDUCE_X_X2_OP_ADD, UNARY.REDUCE_X_OP_MAX, UNARY.REDUCE_X_OP_ABSMAX])
 @pytest.mark.parametrize("rows", [0, 1])
 @pytest.mark.parametrize("in_dt", [DT.F32, DT.BF16])
@@ -325,9 +382,75 @@ def test_ternary(typ, dt):
     assert np.array_equal(ref, _back(dY, Y0))
 
 
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16])
+@pytest.mark.parametrize("m,n,ld,batch", [(70, 9, 72, 1), (16, 4, 16, 1), (5, 3, 8, 1), (1000, 300, 1000, 1), (64, 64, 64, 37), (33, 7, 40, 5)])
+@pytest.mark.parametrize("bitm", [0, 1])
+def test_dropout_bit_exact(dt, m, n, ld, batch, bitm):
+    """DROPOUT: the reference's 16 xoshiro128+ streams, 16 rows per draw.  The device cuts the draw sequence into segments and jumps
+    (T^g by 128 x 128 bit matrices): output, mask AND the advanced generator state are the oracle's bit for bit, also when a batched
+    launch runs many tiles through the same state; DROPOUT_INV replays the mask."""
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(8)
+    X, Y0 = rand_values(rng, batch * ld * n, dt), rand_values(rng, batch * ld * n, dt)
+    state0 = rng.integers(1, 2 ** 32, size=64, dtype=np.uint64).astype(np.uint32)
+    prob = C.c_float(0.3)
+    flags = UNARY_FLAG.BITMASK_2BYTEMULT if bitm else 0
+    mask_bytes = (((ld + 15) // 16) * 16 // 8) * n
+    es = capi.DT_SIZE[dt]
+    desc = pyoracle.MeltwDesc(m, n, ld, ld, 0, 0, dt, DT.UNSUPPORTED, DT.UNSUPPORTED, DT.F32, dt, flags, UNARY.DROPOUT, OP_UNARY)
+    ref, st_ref, mask_ref = Y0.copy(), state0.copy(), np.zeros(batch * mask_bytes, dtype=np.uint8)
+    for b in range(batch):
+        p = capi.UnaryParam()
+        p.in_.primary, p.out.primary, p.op.primary, p.op.secondary = X.ctypes.data + b * ld * n * es, ref.ctypes.data + b * ld * n * es, C.addressof(prob), st_ref.ctypes.data
+        p.out.secondary = mask_ref.ctypes.data + b * mask_bytes
+        orc.meltw(p, desc)
+    shape = capi.UnaryShape(m, n, ld, ld, dt, dt, DT.F32)
+    h = api.dispatch_meltw_unary(UNARY.DROPOUT, shape, flags)
+    assert h
+    dX, dY, dS, dM = _dev(X), _dev(Y0.copy()), _dev(state0.copy()), _dev(np.zeros(batch * mask_bytes, dtype=np.uint8))
+    p = capi.UnaryParam()
+    p.in_.primary, p.out.primary, p.out.secondary, p.op.primary, p.op.secondary = dX.data_ptr(), dY.data_ptr(), dM.data_ptr(), C.addressof(prob), dS.data_ptr()
+    if batch == 1:
+        capi.Api.call(h, p)
+    else:
+        api.hip_meltw_unary_batch_strided(h, C.byref(p), batch, ld * n * es, ld * n * es, mask_bytes)
+    api.hip_sync(); api.check()
+    valid = lambda y: y.reshape(batch * n, ld)[:, :m]
+    assert np.array_equal(valid(ref), valid(_back(dY, Y0)))
+    assert np.array_equal(st_ref, dS.cpu().numpy().view(np.uint32))
+    if bitm:
+        bits = lambda x: np.unpackbits(x.reshape(batch * n, -1), axis=1, bitorder="little")[:, :m]
+        got_mask = dM.cpu().numpy()
+        assert np.array_equal(bits(mask_ref), bits(got_mask))
+        refi, goti, _, _ = run_unary(UNARY.DROPOUT_INV, m, n, ld, ld, dt, dt, flags=flags, aux_in=mask_ref[:mask_bytes].copy(), op_primary=prob)
+        assert np.array_equal(refi.reshape(n, ld)[:, :m], goti.reshape(n, ld)[:, :m])
+
+
+def test_dropout_single_call_with_host_memory_advances_the_callers_state():
+    api, orc = capi.load(), pyoracle.oracle()
+    m, n = 40, 6
+    rng = np.random.default_rng(2)
+    X = rand_values(rng, m * n, DT.F32)
+    st0 = rng.integers(1, 2 ** 32, size=64, dtype=np.uint64).astype(np.uint32)
+    prob = C.c_float(0.5)
+    outs = []
+    for who in ("oracle", "device"):
+        y, st = np.zeros(m * n, dtype=np.float32), st0.copy()
+        p = capi.UnaryParam()
+        p.in_.primary, p.out.primary, p.op.primary, p.op.secondary = X.ctypes.data, y.ctypes.data, C.addressof(prob), st.ctypes.data
+        if who == "oracle":
+            orc.meltw(p, pyoracle.MeltwDesc(m, n, m, m, 0, 0, DT.F32, DT.UNSUPPORTED, DT.UNSUPPORTED, DT.F32, DT.F32, 0, UNARY.DROPOUT, OP_UNARY))
+        else:
+            capi.Api.call(api.dispatch_meltw_unary(UNARY.DROPOUT, capi.UnaryShape(m, n, m, m, DT.F32, DT.F32, DT.F32), 0), p)
+            api.check()
+        outs.append((y, st))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert not np.array_equal(outs[1][1], st0)
+
+
 def test_unsupported_tpps_return_null():
     api = capi.load()
-    assert api.dispatch_meltw_unary(UNARY.DROPOUT, capi.UnaryShape(8, 8, 8, 8, DT.F32, DT.F32, DT.F32), 0) is None
+    assert api.dispatch_meltw_unary(UNARY.DROPOUT, capi.UnaryShape(8, 8, 8, 8, DT.F32, DT.F32, DT.F32), UNARY_FLAG.BCAST_ROW) is None
     assert api.dispatch_meltw_unary(UNARY.IDENTITY, capi.UnaryShape(8, 8, 8, 8, DT.I8, DT.F32, DT.F32), 0) is None
     assert api.dispatch_meltw_binary(BINARY.MATMUL, capi.BinaryShape(8, 8, 8, 8, 8, DT.F32, DT.F32, DT.F32, DT.F32), 0) is None
 

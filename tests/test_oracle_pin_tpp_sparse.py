@@ -19,7 +19,7 @@ NP = {DT.F32: np.float32, DT.F64: np.float64}
 
 
 def both_unary(reference, typ, m, n, ldi, ldo, in_dt, out_dt, flags=0, aux_in=None, aux_out_bytes=0, op_primary=None,
-               in_elems=None, out_elems=None, out_secondary_val=None, seed=0, inp=None):
+               in_elems=None, out_elems=None, out_secondary_val=None, seed=0, inp=None, in_tertiary_val=None):
     orc = pyoracle.oracle()
     rng = np.random.default_rng(seed)
     X = inp if inp is not None else rand_values(rng, in_elems or ldi * n, in_dt)
@@ -40,6 +40,8 @@ def both_unary(reference, typ, m, n, ldi, ldo, in_dt, out_dt, flags=0, aux_in=No
             v = C.c_ulonglong(out_secondary_val); keep.append(v); p.out.secondary = C.addressof(v)
         if op_primary is not None:
             p.op.primary = C.addressof(op_primary)
+        if in_tertiary_val is not None:
+            tv = C.c_ulonglong(in_tertiary_val); keep.append(tv); p.in_.tertiary = C.addressof(tv)
         if who == "oracle":
             orc.meltw(p, pyoracle.MeltwDesc(m, n, ldi, ldo, 0, 0, in_dt, DT.UNSUPPORTED, DT.UNSUPPORTED, comp, out_dt, flags, typ, OP_UNARY))
         else:
@@ -161,6 +163,77 @@ def test_reductions_bit_identical(reference, typ, rows, in_dt):
     (a, b), _ = both_unary(reference, typ, m, n, ldi, res, in_dt, DT.F32, flags=flags, out_elems=2 * res)
     used = 2 * res if typ == UNARY.REDUCE_X_X2_OP_ADD else res
     assert np.array_equal(a[:used], b[:used])
+
+
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16])
+@pytest.mark.parametrize("m,n,ld", [(70, 9, 72), (16, 4, 16), (5, 3, 8)])
+@pytest.mark.parametrize("bitm", [0, 1])
+def test_dropout_bit_identical(reference, dt, m, n, ld, bitm):
+    """DROPOUT draws from 16 xoshiro128+ streams, `w` rows per draw with w = the reference CPU's 32-bit vector length: the oracle is told
+    that width (its default, and the device library's, is 16 = AVX-512).  Output, mask and the advanced generator state must match;
+    DROPOUT_INV replays the mask."""
+    orc = pyoracle.oracle()
+    ref_w = int(reference.lib.xref_vlen32())
+    assert 1 <= ref_w <= 16
+    orc.lib.oracle_set_rng_width(ref_w)
+    try:
+        rng = np.random.default_rng(8)
+        X, Y0 = rand_values(rng, ld * n, dt), rand_values(rng, ld * n, dt)
+        state0 = rng.integers(1, 2 ** 32, size=64, dtype=np.uint64).astype(np.uint32)
+        prob = C.c_float(0.3)
+        flags = UNARY_FLAG.BITMASK_2BYTEMULT if bitm else 0
+        mask_bytes = (((ld + 15) // 16) * 16 // 8) * n
+        res = []
+        for who in ("oracle", "reference"):
+            y, st, mask = Y0.copy(), state0.copy(), np.zeros(mask_bytes, dtype=np.uint8)
+            p = capi.UnaryParam()
+            p.in_.primary, p.out.primary, p.out.secondary, p.op.primary, p.op.secondary = X.ctypes.data, y.ctypes.data, mask.ctypes.data, C.addressof(prob), st.ctypes.data
+            if who == "oracle":
+                orc.meltw(p, pyoracle.MeltwDesc(m, n, ld, ld, 0, 0, dt, DT.UNSUPPORTED, DT.UNSUPPORTED, DT.F32, dt, flags, UNARY.DROPOUT, OP_UNARY))
+            else:
+                reference.lib.xref_reference_meltw_unary(C.byref(p), UNARY.DROPOUT, capi.UnaryShape(m, n, ld, ld, dt, dt, DT.F32), flags)
+            res.append((y, st, mask))
+        (ya, sa, ma), (yb, sb, mb) = res
+        valid = lambda y: y.reshape(n, ld)[:, :m]
+        assert np.array_equal(valid(ya), valid(yb)) and np.array_equal(sa, sb)
+        kept = (valid(ya).view(np.uint16 if dt == DT.BF16 else np.uint32) != 0).mean()
+        assert m * n < 100 or 0.5 < kept < 0.9                       # p = 0.3: about 70 % survive
+        if bitm:
+            bits = lambda x: np.unpackbits(x.reshape(n, -1), axis=1, bitorder="little")[:, :m]
+            assert np.array_equal(bits(ma), bits(mb))
+            (a, b), _ = both_unary(reference, UNARY.DROPOUT_INV, m, n, ld, ld, dt, dt, flags=flags, aux_in=ma, op_primary=prob)
+            assert np.array_equal(a.reshape(n, ld)[:, :m], b.reshape(n, ld)[:, :m])
+    finally:
+        orc.lib.oracle_set_rng_width(16)
+
+
+@pytest.mark.parametrize("typ", [UNARY.REDUCE_COLS_IDX_OP_ADD, UNARY.REDUCE_COLS_IDX_OP_MAX, UNARY.REDUCE_COLS_IDX_OP_MIN])
+@pytest.mark.parametrize("in_dt", [DT.F32, DT.BF16])
+@pytest.mark.parametrize("idx8", [0, 1])
+@pytest.mark.parametrize("record", [0, 1])
+def test_reduce_over_listed_columns_bit_identical(reference, typ, in_dt, idx8, record):
+    """out[i] = op over the listed columns (an embedding bag); MAX / MIN optionally record the winning column [ref: mateltwise ref :1346-1430]."""
+    if record and typ == UNARY.REDUCE_COLS_IDX_OP_ADD:
+        pytest.skip("nothing to record for a sum")
+    m, big, ldi, ncols = 45, 60, 48, 17
+    rng = np.random.default_rng(21)
+    idt = np.uint64 if idx8 else np.uint32
+    idx = rng.integers(0, big, size=ncols).astype(idt)                      # repeats allowed
+    flags = UNARY_FLAG.REDUCE_COLS | (0 if idx8 else UNARY_FLAG.IDX_SIZE_4BYTES) | (UNARY_FLAG.REDUCE_RECORD_ARGOP if record else 0)
+    (a, b), (xa, xb) = both_unary(reference, typ, m, big, ldi, m, in_dt, DT.F32, flags=flags, aux_in=idx, in_elems=ldi * big, out_elems=m,
+                                  in_tertiary_val=ncols, aux_out_bytes=m * (8 if idx8 else 4) if record else 0)
+    assert np.array_equal(a, b)
+    if record:
+        assert np.array_equal(xa, xb)
+
+
+@pytest.mark.parametrize("typ", [UNARY.REDUCE_X_OP_MAX, UNARY.REDUCE_X_OP_MIN, UNARY.REDUCE_X_OP_ABSMAX])
+@pytest.mark.parametrize("idx8", [0, 1])
+def test_column_reduction_records_the_extremum_bit_identical(reference, typ, idx8):
+    m, n, ldi = 45, 33, 48
+    flags = UNARY_FLAG.REDUCE_COLS | UNARY_FLAG.REDUCE_RECORD_ARGOP | (0 if idx8 else UNARY_FLAG.IDX_SIZE_4BYTES)
+    (a, b), (xa, xb) = both_unary(reference, typ, m, n, ldi, m, DT.F32, DT.F32, flags=flags, out_elems=m, aux_out_bytes=m * (8 if idx8 else 4))
+    assert np.array_equal(a, b) and np.array_equal(xa, xb)
 
 
 @pytest.mark.parametrize("typ", [BINARY.ADD, BINARY.MUL, BINARY.SUB, BINARY.DIV, BINARY.MULADD, BINARY.MAX, BINARY.MIN, BINARY.CMP_OP_GT, BINARY.CMP_OP_LE, BINARY.CMP_OP_EQ])
