@@ -54,6 +54,8 @@
 #define LIBXSMM_MIN(A, B) ((A) < (B) ? (A) : (B))
 #define LIBXSMM_MAX(A, B) ((A) < (B) ? (B) : (A))
 #define LIBXSMM_UPDIV(N, D) (((N) + (D) - 1) / (D))
+#define LIBXSMM_LO2(N, NPOT) ((N) & ~((NPOT) - 1))          /* round down / up to a multiple of a power of two [ref: include/libxsmm_macros.h:630-631] */
+#define LIBXSMM_UP2(N, NPOT) LIBXSMM_LO2((N) + ((NPOT) - 1), NPOT)
 #define LIBXSMM_UP(N, D) (LIBXSMM_UPDIV(N, D) * (D))
 #define LIBXSMM_UNUSED(X) (void)(X)
 #define LIBXSMM_CONCATENATE_(A, B) A##B
@@ -367,6 +369,7 @@ LIBXSMM_API void libxsmm_set_verbosity(int level);
 LIBXSMM_API int libxsmm_cpuid(void* info);
 LIBXSMM_API int libxsmm_cpuid_dot_pack_factor(libxsmm_datatype datatype);   /* bf16: 2, i8: 4 */
 LIBXSMM_API int libxsmm_cpuid_vlen(int id);                                /* bytes: 64 */
+LIBXSMM_API int libxsmm_cpuid_vlen32(int id);                              /* 32-bit lanes: 16 (rows per DROPOUT draw) [ref: include/libxsmm_cpuid.h:123] */
 
 /* ---- kernel introspection / lifetime  [ref: include/libxsmm.h:94-104,226-229] ----- */
 LIBXSMM_API int libxsmm_get_mmkernel_info(libxsmm_xmmfunction kernel, libxsmm_mmkernel_info* info);

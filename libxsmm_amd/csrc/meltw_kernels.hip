@@ -1293,8 +1293,14 @@ static bool gs_rows_lds_ok(const MeltwArgs& a, int sz) {
 
 int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
-  if (a.nbatch == 0 || a.m <= 0 || a.n <= 0) { if (name) *name = "(empty)"; return 0; }
+  const bool listed = a.operation == LIBXSMM_MELTW_OPERATION_UNARY && is_reduce_cols_idx_type(a.type);      // the shape's n does not matter there (the reference's driver passes 0)
+  if (a.nbatch == 0 || a.m <= 0 || (a.n <= 0 && !listed)) { if (name) *name = "(empty)"; return 0; }
   const int sz = payload_size(a.in0_type);
+  if (listed) {
+    hipLaunchKernelGGL(reduce_cols_listed_kernel, dim3((unsigned int)((a.m + 255) / 256), a.nbatch), dim3(256), 0, st, a);
+    if (name) *name = "reduce_cols_listed_kernel";
+    return (int)hipGetLastError();
+  }
   if (ew8_ok(a)) {
     const unsigned int m8 = (unsigned int)(a.m / 8), total = m8 * (unsigned int)a.n * (unsigned int)a.nbatch;
     const dim3 grid((total + 255u) / 256u);

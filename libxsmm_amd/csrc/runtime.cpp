@@ -548,6 +548,18 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
       if (!p->in.tertiary || !p->in.secondary) { set_error(-2, "REDUCE_COLS_IDX needs the column list in in.secondary and its length in in.tertiary"); return; }
       a.scalar_u64 = *(const unsigned long long*)p->in.tertiary;
       const size_t isz = (d.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_4BYTES) ? 4 : 8;
+      // A synchronous call may hand plain host memory (the reference's driver does, with n = 0 in the shape: the table's width is only
+      // known through the list): the list is then host memory too, its largest entry bounds the table.
+      hipPointerAttribute_t attr;
+      const bool host_table = staging_allowed(b.count) && (hipPointerGetAttributes(&attr, p->in.primary) != hipSuccess || attr.type == hipMemoryTypeUnregistered);
+      (void)hipGetLastError();
+      if (host_table) {
+        unsigned long long top = 0;
+        for (unsigned long long jj = 0; jj < a.scalar_u64; ++jj) top = std::max(top, isz == 4 ? (unsigned long long)((const unsigned int*)p->in.secondary)[jj] : ((const unsigned long long*)p->in.secondary)[jj]);
+        a.in0 = (const char*)stage(a.in0, ((size_t)top * (size_t)a.ldi + (size_t)a.m) * (size_t)typesize(a.in0_type), true, false);
+        a.out = (char*)stage(a.out, (size_t)a.m * (size_t)typesize(a.out_type), true, true);
+        if (!a.in0 || !a.out) return;
+      }
       a.aux_in = device_visible(p->in.secondary, (size_t)a.scalar_u64 * isz);
       if (a.scalar_u64 && !a.aux_in) return;
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_GATHER || t == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) {
@@ -931,6 +943,8 @@ LIBXSMM_API int libxsmm_cpuid_dot_pack_factor(libxsmm_datatype t) {
   switch (t) { case LIBXSMM_DATATYPE_BF16: case LIBXSMM_DATATYPE_F16: return 2; case LIBXSMM_DATATYPE_I8: case LIBXSMM_DATATYPE_U8: case LIBXSMM_DATATYPE_BF8: case LIBXSMM_DATATYPE_HF8: return 4; default: return 1; }
 }
 LIBXSMM_API int libxsmm_cpuid_vlen(int id) { (void)id; return 64; }
+// 32-bit lanes per "vector": the rows DROPOUT draws for at a time (the reference's gold loops ask this too) [ref: src/libxsmm_cpuid_x86.c:670]
+LIBXSMM_API int libxsmm_cpuid_vlen32(int id) { (void)id; return 16; }
 
 // ---- shapes / configs -----------------------------------------------------------------------------------
 LIBXSMM_API libxsmm_gemm_shape libxsmm_create_gemm_shape(libxsmm_blasint m, libxsmm_blasint n, libxsmm_blasint k,

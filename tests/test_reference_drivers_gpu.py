@@ -183,10 +183,18 @@ def test_reference_gather_scatter_driver(args):
     check("eltwise_unary_gather_scatter", *args.split())
 
 
+# samples/eltwise/eltwise_unary_dropout.c -- F/B bitmask prec_in prec_out M N ldi ldo: its gold loop draws libxsmm_cpuid_vlen32() rows at a time
+@pytest.mark.parametrize("args", ["F 1 F32 F32 64 64 64 64", "F 0 F32 F32 40 13 48 40", "F 1 BF16 BF16 64 48 64 64", "F 1 F32 BF16 33 17 40 36", "B 1 F32 F32 64 64 64 64", "B 1 BF16 BF16 50 20 56 52"])
+def test_reference_dropout_driver(args):
+    check("eltwise_unary_dropout", *args.split())
+
+
 # samples/eltwise/eltwise_unary_reduce.c allocates with plain malloc(): synchronous reductions stage host operands
 # M N ldi reduce_x reduce_x2 reduce_rows op(0 add, 1 max) dtype n_cols_idx idx_type record_idx reduce_on_outputs iters
 @pytest.mark.parametrize("args", ["64 48 64 1 0 1 0 F32 0 0 0 0 1", "64 48 64 1 0 0 0 F32 0 0 0 0 1", "64 48 64 1 1 1 0 F32 0 0 0 0 1", "64 48 64 1 0 1 1 F32 0 0 0 0 1",
-                                  "64 48 64 1 0 0 0 BF16 0 0 0 0 1", "33 17 40 1 1 0 0 F32 0 0 0 0 1"])
+                                  "64 48 64 1 0 0 0 BF16 0 0 0 0 1", "33 17 40 1 1 0 0 F32 0 0 0 0 1",
+                                  "64 48 64 1 0 0 0 F32 12 0 0 0 1", "64 48 64 1 0 0 1 F32 12 1 1 0 1", "64 48 64 1 0 0 2 F32 12 0 1 0 1", "64 48 64 1 0 0 1 BF16 9 1 0 0 1",
+                                  "64 48 64 1 0 0 1 F32 0 0 1 0 1"])          # listed columns (n_cols_idx), 4 / 8-byte indices, recorded arg-max / arg-min
 def test_reference_reduce_driver(args):
     check("eltwise_unary_reduce", *args.split())
 
