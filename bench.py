@@ -425,6 +425,8 @@ SWEEP = [(dt, m, b) for dt in ("f32", "bf16") for m in (16, 32, 64) for b in (40
 BLOCKED = [("f32", 16, 128, 128, 128), ("f32", 32, 128, 128, 64), ("f32", 64, 64, 64, 64),
            ("bf16", 16, 128, 128, 128), ("bf16", 32, 128, 128, 128), ("bf16", 64, 64, 64, 64)]
 SHARED_B = [(dt, m, 65536) for dt in ("f32", "bf16") for m in (16, 32, 64)]
+# the odd shapes LIBXSMM is known for (BASELINE configs[0] is one 23^3 f32 GEMM): same streaming regime, problems that are not whole tiles
+RAGGED = [("f32", 23, 131072), ("f32", 23, 4096), ("f32", 13, 262144), ("f32", 40, 32768), ("f32", 72, 16384)]
 
 
 def run_config5(args, api, dev, rank, world, dist, barrier):
@@ -567,9 +569,13 @@ def main():
         l3_elapsed, l3_n, l3_us = timed(l3, args.steps, min(args.min_seconds, 0.2), label=work.label() + "_l3resident")
         del l3
 
-    sweep, reuse = {}, {}
+    sweep, reuse, ragged = {}, {}, {}
     if rank == 0 and not args.no_sweep:
         quick = min(args.min_seconds, 0.15)
+        for dt, m, b in RAGGED:
+            w = Workload(api, dev, dt, m, b)
+            ragged[w.label()] = entry(w, args.steps, quick)
+            del w; torch.cuda.empty_cache()
         for dt, m, b in SWEEP:
             w = Workload(api, dev, dt, m, b)
             sweep[w.label()] = entry(w, args.steps, quick)
@@ -616,6 +622,7 @@ def main():
         if sweep:
             out["sweep"] = sweep
             out["reuse"] = reuse
+            out["ragged"] = ragged
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.m, args.dtype, args.br, args.beta, args.fused, args.cpu_seconds, nthreads)
         print(json.dumps(out))
