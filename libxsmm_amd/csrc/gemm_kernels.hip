@@ -270,6 +270,33 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     return;
   }
 
+  if (p.a_type == LIBXSMM_DATATYPE_F16) {
+    // IEEE half GEMM, f32 accumulation [ref: gemm ref :2025-2124]: k ascending (also inside a VNNI-2 pair), beta * C added AFTER the sum,
+    // an f32 C rounded to f16 on the way in
+    if (!valid) return;
+    const int kb = va ? 2 : 1;
+    float acc = 0.0f;
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      gcptr ar, br; br_base(p, q, r, ar, br);
+      for (int s = 0; s < p.k; ++s) {
+        const long long ai = (long long)(s / kb) * ((long long)p.lda * kb) + (long long)i * kb + (s % kb);
+        const long long bi = tb ? (long long)s * p.ldb + j : (long long)j * p.ldb + s;
+        const float av = (float)__builtin_bit_cast(_Float16, ((GM const unsigned short*)ar)[ai]), bv = (float)__builtin_bit_cast(_Float16, ((GM const unsigned short*)br)[bi]);
+        acc = add_rn(acc, mul_rn(av, bv));
+      }
+    }
+    if (p.c_type == LIBXSMM_DATATYPE_F32) {
+      GM float* c = (GM float*)q.c + (long long)j * p.ldc + i;
+      if (!beta0) acc = add_rn(acc, (float)(_Float16)*c);
+      *c = acc;
+    } else {
+      GM unsigned short* c = (GM unsigned short*)q.c + (long long)j * p.ldc + i;
+      if (!beta0) acc = add_rn(acc, (float)__builtin_bit_cast(_Float16, *c));
+      *c = __builtin_bit_cast(unsigned short, (_Float16)acc);
+    }
+    return;
+  }
+
   if (p.a_type == LIBXSMM_DATATYPE_I8 || p.a_type == LIBXSMM_DATATYPE_U8) {
     // 8-bit integer GEMM, i32 accumulation [ref: gemm ref :1452-1683]; A VNNI-4 (always for f32 output), B flat
     if (!valid) return;
@@ -1648,7 +1675,10 @@ __global__ __launch_bounds__(256) void gemm_p16_kernel(GemmArgs p) {
 //   A: four dwords (k-pairs) per step, lanes contiguous along i  -> coalesced 128-byte rows
 //   B: sixteen contiguous bytes per step (32 per chunk) at column j
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, bool EXACT>
+// F16 = true: the same kernel on IEEE halves (v_mfma_f32_32x32x16_f16; plain epilogue only) with the reference's F16 rules: the
+// accumulators start at 0, beta * C is added after the sum, an f32 C is rounded to f16 on the way in [ref: gemm ref :2025-2124].
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int MT, int NT, bool EXACT, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
@@ -1662,7 +1692,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
     for (int nt = 0; nt < NT; ++nt) {
       tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h;
       tc[mt][nt].ivalid = tc[mt][nt].i < p.m;
-      tile_init<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]);
+      if (F16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+      }
+      else tile_init<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]);
     }
   const int kchunks = (p.k + 31) / 32;
   for (unsigned long long r = 0; r < p.br_count; ++r) {
@@ -1707,9 +1741,33 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bfr[nt][s]), __builtin_bit_cast(f16x8, af[mt][s]), acc[mt][nt], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0);
     }
+  }
+  if (F16) {
+    const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+    static_for<MT * NT>([&](auto idx) {
+      constexpr int mt = idx.value / NT, nt = idx.value % NT;
+      const TileCtx& t = tc[mt][nt];
+      static_for<16>([&](auto rc) {
+        constexpr int r = rc.value;
+        const int j = t.j0 + jl_of(r, t.h);
+        if (EXACT || (t.ivalid && j < p.n)) {
+          float v = acc[mt][nt][r];
+          if (c_f32) {
+            GM float* c = (GM float*)q.c + (long long)j * p.ldc + t.i;
+            if (!beta0) v += (float)(_Float16)*c;
+            st_stream(c, v);
+          } else {
+            GM unsigned short* c = (GM unsigned short*)q.c + (long long)j * p.ldc + t.i;
+            if (!beta0) v += (float)__builtin_bit_cast(_Float16, *c);
+            st_stream(c, __builtin_bit_cast(unsigned short, (_Float16)v));
+          }
+        }
+      });
+    });
+    return;
   }
   static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]); });
 }
@@ -2389,6 +2447,16 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d) {
     if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
     return d.lda >= d.m && d.ldb >= d.k && d.ldc >= d.m;
   }
+  if (d.a_type == LIBXSMM_DATATYPE_F16 && d.b_type == LIBXSMM_DATATYPE_F16) {   // [ref: gemm ref :2025-2124]: f32 accumulation, F16 or F32 out, VNNI-2 A optional, B may be transposed, no fused ops
+    const unsigned int fl = d.flags;
+    if (d.c_type != LIBXSMM_DATATYPE_F16 && d.c_type != LIBXSMM_DATATYPE_F32) return false;
+    if (d.comp_type != LIBXSMM_DATATYPE_F32) return false;                       // comp F16 (a rounding after every product) is not built
+    if (fl & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) return false;
+    if ((fl & LIBXSMM_GEMM_FLAG_VNNI_A) && (d.k & 1)) return false;
+    if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    if ((fl & LIBXSMM_GEMM_FLAG_TRANS_B) ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
+    return d.lda >= d.m && d.ldc >= d.m;
+  }
   const bool fp8 = (d.a_type == LIBXSMM_DATATYPE_BF8 || d.a_type == LIBXSMM_DATATYPE_HF8) && d.b_type == d.a_type && d.c_type == LIBXSMM_DATATYPE_F32;
   if (fp8) {   // [ref: gemm ref :2420-2510]: f32 accumulate and output, VNNI-4 A optional, no fused ops
     const unsigned int fl8 = d.flags;
@@ -2490,7 +2558,7 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     if (!pl.exact) pl.path = P_GENERIC;
     return pl;
   }
-  if (a_type == LIBXSMM_DATATYPE_BF16 && va && !ta && !tb && !vb) {
+  if ((a_type == LIBXSMM_DATATYPE_BF16 || (a_type == LIBXSMM_DATATYPE_F16 && b_type == LIBXSMM_DATATYPE_F16)) && va && !ta && !tb && !vb) {
     pl.path = (m > 32 && n > 32) ? P_BF16_2x2 : P_BF16_1x1;
     const int t = (pl.path == P_BF16_2x2) ? 64 : 32;
     pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
@@ -2909,6 +2977,12 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_BF16_1x1:
       grid = wave_grid(32, 32);
+      if (a.a_type == LIBXSMM_DATATYPE_F16) {
+        if (kernel_name) *kernel_name = "gemm_mfma_f16_kernel<1,1>";
+        if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false, true>), grid, dim3(256), 0, st, a);
+        break;
+      }
       if (pl.exact && bf16_stream_ok(a)) {
         if (kernel_name) *kernel_name = "gemm_bf16_stream_kernel<1,1>";
         if (stream_nt(a, 2, typesize_c(a))) hipLaunchKernelGGL((gemm_bf16_stream_kernel<1, 1, 2>), grid, dim3(256), 0, st, a);
@@ -2919,6 +2993,12 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_BF16_2x2:
       grid = wave_grid(64, 64);
+      if (a.a_type == LIBXSMM_DATATYPE_F16) {
+        if (kernel_name) *kernel_name = "gemm_mfma_f16_kernel<2,2>";
+        if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false, true>), grid, dim3(256), 0, st, a);
+        break;
+      }
       if (pl.exact && a.m == 64 && a.n == 64 && !a.batch_inner && bf16_wg64_ok(a)) {
         a.map2d_shift = 0;
         grid = dim3(a.nbatch);

@@ -126,6 +126,36 @@ static void contract_fp8(const gemm_view* v, float* cmat, int beta0) {
   }
 }
 
+/* F16 x F16 -> F16 or F32, f32 accumulation [ref: :2025-2124].  Unlike bf16: the pair of a VNNI-2 A is consumed LOW k first, the start
+ * value is 0 and beta * C is added AFTER the sum, and an f32 C is rounded to f16 on the way in.  (comp_type F16 -- a rounding to f16 after
+ * every product, what AVX512-FP16 hosts do for IMPLICIT -- is not restated: the device library computes in f32.) */
+static void contract_f16(const gemm_view* v, void* cmat, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const int kb = v->va ? 2 : 1;
+  int i, j, s; long long r;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    float c = 0.0f;
+    for (r = 0; r < v->br; ++r) {
+      const br_cursor cur = br_at(v, r);
+      for (s = 0; s < d->k; ++s) {
+        const float av = oracle_f16_to_f32(((const unsigned short*)cur.a)[a_index(v, i, s, kb)]);
+        const float bv = oracle_f16_to_f32(((const unsigned short*)cur.b)[b_index(v, s, j, kb)]);
+        const float prod = av * bv;
+        c = c + prod;
+      }
+    }
+    if (d->c_type == LIBXSMM_DATATYPE_F32) {
+      float* cf = (float*)cmat + (long long)j * d->ldc + i;
+      if (!beta0) c = c + oracle_f16_to_f32(oracle_f32_to_f16(*cf));
+      *cf = c;
+    } else {
+      unsigned short* ch = (unsigned short*)cmat + (long long)j * d->ldc + i;
+      if (!beta0) c = c + oracle_f16_to_f32(*ch);
+      *ch = oracle_f32_to_f16(c);
+    }
+  }
+}
+
 static void contract_f64(const gemm_view* v, double* cmat) {
   const oracle_gemm_desc* d = v->d;
   int i, j, s; long long r;
@@ -336,6 +366,9 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
   if (is_int8(d->a_type) && is_int8(d->b_type)) { contract_int8(&v, p, cptr, beta0); return; }
   if (is_fp8(d->a_type) && d->b_type == d->a_type && d->c_type == LIBXSMM_DATATYPE_F32) { contract_fp8(&v, (float*)cptr, beta0); return; }
+  if (d->a_type == LIBXSMM_DATATYPE_F16 && d->b_type == LIBXSMM_DATATYPE_F16 && (d->c_type == LIBXSMM_DATATYPE_F16 || d->c_type == LIBXSMM_DATATYPE_F32)) {
+    contract_f16(&v, cptr, beta0); return;
+  }
   if (is_mxmx(d) && d->c_type == LIBXSMM_DATATYPE_F32) { contract_mxmx(&v, p, (float*)cptr, beta0); return; }
   if (d->a_type == LIBXSMM_DATATYPE_MXFP4X2) { contract_mxfp4(&v, p, cptr, beta0); return; }
 

@@ -44,6 +44,8 @@ def bf16_to_f32(x: np.ndarray) -> np.ndarray:
 
 
 def as_float(x: np.ndarray, dt: int) -> np.ndarray:
+    if dt == DT.F16:
+        return np.ascontiguousarray(x).view(np.float16).astype(np.float64) if x.dtype in (np.uint16, np.int16) else x.astype(np.float64)
     return bf16_to_f32(x).astype(np.float64) if dt == DT.BF16 else x.astype(np.float64)
 
 
@@ -305,7 +307,7 @@ class GemmCase:
         api.hip_sync()
         api.check()
         out = Cbuf.cpu().numpy()
-        if self.c_type == DT.BF16:
+        if self.c_type in (DT.BF16, DT.F16):
             out = out.view(np.uint16)
         return out, (mask.cpu().numpy() if mask is not None else None), handle
 

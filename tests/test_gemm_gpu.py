@@ -136,6 +136,42 @@ def test_bf16_gemm_matches_oracle(kw):
     _check(GemmCase(seed=777, batch=3, a_type=DT.BF16, **kw))
 
 
+SHAPES_F16 = [
+    dict(m=64, n=64, k=64, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=4),
+    dict(m=64, n=64, k=64, c_type=DT.F32, flags=F.VNNI_A, beta=1),
+    dict(m=32, n=32, k=32, c_type=DT.F16, flags=F.VNNI_A, beta=1),
+    dict(m=32, n=32, k=64, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=3),
+    dict(m=64, n=64, k=32, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_ADDRESS, br_count=2),
+    dict(m=33, n=17, k=18, c_type=DT.F16, flags=F.VNNI_A, beta=1, ldc=40),
+    dict(m=96, n=70, k=50, c_type=DT.F32, flags=F.VNNI_A),
+    dict(m=64, n=64, k=64, c_type=DT.F16, flags=F.VNNI_A, ldb=72, ldc=66),
+    dict(m=12, n=10, k=9, c_type=DT.F16),                                            # flat A -> generic
+    dict(m=12, n=10, k=8, c_type=DT.F32, flags=F.TRANS_B, beta=1),
+    dict(m=12, n=10, k=8, c_type=DT.F16, flags=F.VNNI_A | F.TRANS_B),
+]
+
+
+@pytest.mark.parametrize("kw", SHAPES_F16, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_f16_gemm_matches_oracle(kw):
+    """IEEE half operands, f32 accumulation on v_mfma_f32_32x32x16_f16 [ref: gemm ref :2025-2124]; half output within 1e-3 (one rounding of
+    sums that differ in their last f32 bits), f32 output within the f32 bound."""
+    api = capi.load()
+    case = GemmCase(seed=777, batch=3, a_type=DT.F16, **kw)
+    got, _, handle = case.run_gpu(batched=True)
+    ref, _ = case.run_oracle()
+    name = api.hip_kernel_name(handle, 1).decode()
+    err = normf_rel(case.valid_region(ref), case.valid_region(got), case.c_type)
+    assert err < (1e-3 if case.c_type == DT.F16 else TOL_F32), f"{name}: normf_rel={err}"
+    if "generic" in name:
+        assert np.array_equal(case.valid_region(ref), case.valid_region(got)), "generic kernel must be bit-identical to the oracle"
+    elif kw.get("flags", 0) == F.VNNI_A:
+        assert "f16" in name, name
+    # what the library does not build for halves: fused epilogues, a transposed A
+    assert api.dispatch_brgemm_ext(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F16, DT.F16, DT.F16, DT.F32), F.VNNI_A | F.BETA_0, 0, capi.br_config(capi.BR_NONE, 0, 0, 0),
+                                   capi.argops_cp(32, capi.UNARY.RELU, 0), capi.postops_colbias(32, DT.F16)) is None
+    assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F16, DT.F16, DT.F16, DT.F32), F.TRANS_A | F.BETA_0, 0) is None
+
+
 def test_f64_gemm_is_bit_identical():
     for kw in (dict(m=9, n=11, k=13, beta=1, br_type=capi.BR_STRIDE, br_count=2), dict(m=32, n=32, k=32), dict(m=7, n=5, k=3, flags=F.TRANS_A | F.TRANS_B)):
         _check(GemmCase(seed=5, batch=2, a_type=DT.F64, **kw), expect_kernel="generic")

@@ -50,6 +50,13 @@ GEMM_CASES = [
     dict(m=12, n=10, k=7, a_type=DT.BF8, c_type=DT.F32),
     dict(m=32, n=32, k=64, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1),
     dict(m=13, n=11, k=8, a_type=DT.HF8, c_type=DT.F32, flags=F.TRANS_B),
+    # IEEE half GEMMs, f32 accumulation (F16 or F32 out)
+    dict(m=32, n=32, k=32, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=64, n=64, k=64, a_type=DT.F16, c_type=DT.F32, flags=F.VNNI_A, beta=1),
+    dict(m=33, n=17, k=18, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, beta=1, ldc=40),
+    dict(m=12, n=10, k=9, a_type=DT.F16, c_type=DT.F16),                       # flat A
+    dict(m=12, n=10, k=8, a_type=DT.F16, c_type=DT.F32, flags=F.TRANS_B, beta=1),
+    dict(m=16, n=8, k=16, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=4),
     # MXFP4 weights (packed E2M1 pairs + E8M0 scale per 32-deep k-block and row) times bf16 / f32 activations
     dict(m=32, n=32, k=64, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A),
     dict(m=32, n=16, k=32, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, beta=1),

@@ -73,6 +73,8 @@ GEMM_CASES = [
     "BF16 BF16 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf strdbr 4 0 2 0",       # VNNI-2 A
     "BF16 BF16 F32 BF16 64 64 64 64 64 64 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     "BF16 BF16 F32 BF16 32 32 32 32 32 32 1 0 0 0 0 0 1 0 1 nopf nobr 1 0 2 0",        # VNNI-2 C
+    "F16 F16 F32 F16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf strdbr 4 0 2 0",        # IEEE halves, f32 accumulation
+    "F16 F16 F32 F32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     "I8 I8 I32 I32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     "U8 I8 I32 I32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf strdbr 2 0 2 0",
     "BF8 BF8 F32 F32 32 32 64 32 64 32 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
