@@ -995,6 +995,51 @@ __global__ __launch_bounds__(256) void dropout_inv_kernel(MeltwArgs p) {
   const float x = mw_load((gcptr)p.in0 + b * p.bs_in0, i + j * p.ldi, p.in0_type) * pi;
   mw_store((gptr)p.out + b * p.bs_out, i + j * p.ldo, p.out_type, bit ? x : 0.0f);
 }
+// ------------------------------------------------------------------------------------------------
+// Stochastic rounding to BF8 (UNARY / BINARY / TERNARY_STOCHASTIC_ROUND) [ref: src/libxsmm_lpflt_quant.c:303-365; mateltwise ref
+// :2485-2486].  Element e (column-major order of the m x n result) of a call takes one xoshiro128++ draw of stream e % 16 of the same
+// 16-stream state DROPOUT uses; every call of a batched launch starts again at e = 0 and continues the streams.  So stream l makes
+// cnt(l) = |{e < m n : e % 16 == l}| draws per call and draw d of stream l belongs to call d / cnt(l), element 16 (d % cnt(l)) + l.
+// The TPP itself ran into an f32 workspace (p.in0, [call][n][m] dense); this pass jumps every thread to its segment of draws (as in
+// dropout_kernel) and rounds; the thread that makes a stream's last draw writes that stream's state back.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stochastic_bf8_kernel(MeltwArgs p, const u32x4m* jump_tables, unsigned long long L) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+  const unsigned int l = (unsigned int)(t & 15ull);
+  const unsigned long long seg = t >> 4, mn = (unsigned long long)p.m * p.n;
+  if (l >= mn) return;
+  const unsigned long long cnt = (mn - 1ull - l) / 16ull + 1ull, total = cnt * p.nbatch;
+  const unsigned long long d0 = seg * L;
+  if (d0 >= total) return;
+  const unsigned long long d1 = (d0 + L < total) ? d0 + L : total;
+  GM unsigned int* st = (GM unsigned int*)p.aux_in;
+  GM const u32x4m* jump = (GM const u32x4m*)jump_tables;
+  u32x4m s = {st[l], st[l + 16], st[l + 32], st[l + 48]};
+  for (int k = 0; k < 64 && (d0 >> k) != 0ull; ++k) {
+    if (!((d0 >> k) & 1ull)) continue;
+    GM const u32x4m* col = jump + 128 * k;
+    u32x4m acc = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      unsigned int bits = s[w];
+      while (bits) { const int b = __builtin_ctz(bits); bits &= bits - 1u; acc ^= col[32 * w + b]; }
+    }
+    s = acc;
+  }
+  for (unsigned long long d = d0; d < d1; ++d) {
+    const unsigned int sum = s[0] + s[3], vrng = ((sum << 7) | (sum >> 25)) + s[0];
+    { const unsigned int t0 = s[1] << 9; s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t0; s[3] = (s[3] << 11) | (s[3] >> 21); }
+    const unsigned long long b = d / cnt, e = 16ull * (d - b * cnt) + l, j = e / (unsigned long long)p.m, i = e - j * (unsigned long long)p.m;
+    const float x = ((GM const float*)p.in0)[b * mn + e];
+    unsigned short h = __builtin_bit_cast(unsigned short, (_Float16)x);
+    const unsigned short rnd = (unsigned short)((vrng >> 24) & 0xffu), fixup = (unsigned short)((h >> 8) & 1u);
+    if ((h & 0x7c00u) == 0x7c00u) h = ((h & 0x03ffu) == 0) ? h : (unsigned short)(h | 0x0200u);
+    else if ((h & 0x7c00u) == 0) h = (unsigned short)(h + 0x007fu + fixup);
+    else h = (unsigned short)(h + rnd);
+    ((GM unsigned char*)p.out)[(long long)b * p.bs_out + (long long)j * p.ldo + (long long)i] = (unsigned char)(h >> 8);
+  }
+  if (d1 == total) { st[l] = s[0]; st[l + 16] = s[1]; st[l + 32] = s[2]; st[l + 48] = s[3]; }
+}
 // T^(2^k) as 128 columns each, k < 64, on the current device (built once per device)
 static const u32x4m* dropout_jump_tables() {
   static std::mutex mu; static std::unordered_map<int, const u32x4m*> per_device;
@@ -1239,7 +1284,16 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
       }
     }
     if (!is_tpp_float(d.in0_type) || !is_tpp_float(d.out_type)) return false;
-    if (d.flags & LIBXSMM_MELTW_FLAG_UNARY_STOCHASTIC_ROUND) return false;
+    if (d.flags & LIBXSMM_MELTW_FLAG_UNARY_STOCHASTIC_ROUND) {      // BF8 output, the ops of the reference's generic loop [ref: :311-316, :2469-2497]
+      if (d.out_type != LIBXSMM_DATATYPE_BF8 || (d.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT)) return false;
+      switch (t) {
+        case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT: case LIBXSMM_MELTW_TYPE_UNARY_TANH:
+        case LIBXSMM_MELTW_TYPE_UNARY_TANH_INV: case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID: case LIBXSMM_MELTW_TYPE_UNARY_SIGMOID_INV: case LIBXSMM_MELTW_TYPE_UNARY_GELU:
+        case LIBXSMM_MELTW_TYPE_UNARY_GELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_NEGATE: case LIBXSMM_MELTW_TYPE_UNARY_INC: case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL:
+        case LIBXSMM_MELTW_TYPE_UNARY_RECIPROCAL_SQRT: case LIBXSMM_MELTW_TYPE_UNARY_EXP: return true;
+        default: return false;
+      }
+    }
     switch (t) {
       case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_XOR: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT:
       case LIBXSMM_MELTW_TYPE_UNARY_RELU: case LIBXSMM_MELTW_TYPE_UNARY_RELU_INV: case LIBXSMM_MELTW_TYPE_UNARY_TANH: case LIBXSMM_MELTW_TYPE_UNARY_TANH_INV:
@@ -1255,14 +1309,15 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
     const bool arith = t == LIBXSMM_MELTW_TYPE_BINARY_ADD || t == LIBXSMM_MELTW_TYPE_BINARY_MUL || t == LIBXSMM_MELTW_TYPE_BINARY_SUB || t == LIBXSMM_MELTW_TYPE_BINARY_DIV ||
                        t == LIBXSMM_MELTW_TYPE_BINARY_MULADD || t == LIBXSMM_MELTW_TYPE_BINARY_MAX || t == LIBXSMM_MELTW_TYPE_BINARY_MIN;
     const bool cmp = t >= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GT && t <= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_NE;
-    if (d.flags & LIBXSMM_MELTW_FLAG_BINARY_STOCHASTIC_ROUND) return false;
+    if (d.flags & LIBXSMM_MELTW_FLAG_BINARY_STOCHASTIC_ROUND)       // (MULADD reads its BF8 output as an input: not through the two-pass scheme)
+      return arith && t != LIBXSMM_MELTW_TYPE_BINARY_MULADD && !f64 && d.out_type == LIBXSMM_DATATYPE_BF8 && is_tpp_float(d.in0_type) && is_tpp_float(d.in1_type);
     if (f64) return arith && d.in1_type == LIBXSMM_DATATYPE_F64;
     if (!is_tpp_float(d.in0_type) || !is_tpp_float(d.in1_type)) return false;
     if (cmp) return true;
     return arith && is_tpp_float(d.out_type);
   }
   if (d.operation == LIBXSMM_MELTW_OPERATION_TERNARY) {
-    if (d.flags & LIBXSMM_MELTW_FLAG_TERNARY_STOCHASTIC_ROUND) return false;
+    if ((d.flags & LIBXSMM_MELTW_FLAG_TERNARY_STOCHASTIC_ROUND) && (f64 || d.out_type != LIBXSMM_DATATYPE_BF8)) return false;
     if (t == LIBXSMM_MELTW_TYPE_TERNARY_SELECT) return f64 ? d.in1_type == LIBXSMM_DATATYPE_F64 : (is_tpp_float(d.in0_type) && is_tpp_float(d.in1_type) && is_tpp_float(d.out_type));
     if (t == LIBXSMM_MELTW_TYPE_TERNARY_MULADD || t == LIBXSMM_MELTW_TYPE_TERNARY_NMULADD)
       return is_tpp_float(d.in0_type) && is_tpp_float(d.in1_type) && is_tpp_float(d.in2_type) && is_tpp_float(d.out_type);
@@ -1289,6 +1344,20 @@ static bool gs_rows_lds_ok(const MeltwArgs& a, int sz) {
   if (rows <= 0 || (rows * sz) % 16 != 0 || rows * sz > 65536 || 2ll * a.m < rows || a.n <= 0 || a.n > 65535 * 16 || a.nbatch >= 65536) return false;
   const size_t base = gather ? ((size_t)a.in0 | (size_t)a.bs_in0) : ((size_t)a.out | (size_t)a.bs_out);
   return (base & 15) == 0;
+}
+
+static const u32x4m* dropout_jump_tables();
+// second pass of a TPP with stochastic rounding: `a.in0` = the f32 results [call][n][m], `a.out` = the BF8 destination, a.aux_in = the state
+int launch_stochastic_bf8(const MeltwArgs& a, void* stream) {
+  const u32x4m* jt = dropout_jump_tables();
+  if (!jt) return (int)hipErrorOutOfMemory;
+  const unsigned long long mn = (unsigned long long)a.m * a.n, per_stream = ((mn + 15ull) / 16ull) * a.nbatch;
+  unsigned long long segs = std::min<unsigned long long>((per_stream + 7ull) / 8ull, 16384ull);
+  if (segs == 0) segs = 1;
+  const unsigned long long L = (per_stream + segs - 1ull) / segs;
+  segs = (per_stream + L - 1ull) / L;
+  hipLaunchKernelGGL(stochastic_bf8_kernel, dim3((unsigned int)((segs * 16ull + 255ull) / 256ull)), dim3(256), 0, (hipStream_t)stream, a, jt, L);
+  return (int)hipGetLastError();
 }
 
 int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {

@@ -632,6 +632,29 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     }
   }
   const char* kname = nullptr;
+  const bool stoch = a.out_type == LIBXSMM_DATATYPE_BF8 &&
+    ((d.operation == LIBXSMM_MELTW_OPERATION_UNARY && (d.flags & LIBXSMM_MELTW_FLAG_UNARY_STOCHASTIC_ROUND)) ||
+     (d.operation == LIBXSMM_MELTW_OPERATION_BINARY && (d.flags & LIBXSMM_MELTW_FLAG_BINARY_STOCHASTIC_ROUND)) ||
+     (d.operation == LIBXSMM_MELTW_OPERATION_TERNARY && (d.flags & LIBXSMM_MELTW_FLAG_TERNARY_STOCHASTIC_ROUND)));
+  if (stoch) {
+    // Stochastic rounding needs one draw per element IN ELEMENT ORDER from the caller's generator state (op.secondary, every param struct
+    // starts with `op`): the TPP runs into a dense f32 workspace, a second kernel draws and rounds [ref: mateltwise ref :2091, :2485].
+    const void* state = ((const libxsmm_matrix_op_arg*)param)->secondary;
+    if (!state) { set_error(-2, "a TPP with STOCHASTIC_ROUND needs the generator state in op.secondary"); return; }
+    MeltwArgs second = a;
+    const size_t tile = (size_t)a.m * (size_t)a.n * sizeof(float);
+    float* ws = (float*)workspace(tile * (size_t)a.nbatch);
+    if (!ws) return;
+    a.out = (char*)ws; a.out_type = LIBXSMM_DATATYPE_F32; a.ldo = a.m; a.bs_out = (long long)tile;
+    int err = launch_meltw(a, tls().stream, &kname);
+    second.in0 = (const char*)ws;
+    second.aux_in = staging_allowed(b.count) ? stage(state, 256, true, true) : state;
+    if (err == 0 && !second.aux_in) return;
+    if (err == 0) err = launch_stochastic_bf8(second, tls().stream);
+    if (kname) { if (b.count > 1) k->kname_batched = kname; else k->kname_single = kname; }
+    finish_launch(err, kname);
+    return;
+  }
   const int err = launch_meltw(a, tls().stream, &kname);
   if (kname) { if (b.count > 1) k->kname_batched = kname; else k->kname_single = kname; }   // the device kernel that actually ran
   finish_launch(err, kname);

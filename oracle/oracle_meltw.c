@@ -80,6 +80,27 @@ static int bit_get(const unsigned char* bits, long long i, long long j, long lon
   return (bits[i / 8 + j * (ld_bits / 8)] >> (i % 8)) & 1;
 }
 
+/* f32 -> BF8 with stochastic rounding [ref: src/libxsmm_lpflt_quant.c:303-365]: the value goes through f16, a normal number gets a random
+ * byte added below the kept bits (one xoshiro128++ draw of stream `lane` of the 16-stream state), subnormals round to nearest even,
+ * infinities stay, NaNs are quieted.  Element number e of a TPP call uses stream e % 16 [mateltwise ref :2095, :2485-2486]. */
+static unsigned char f32_to_bf8_stochastic(float x, unsigned int* st, unsigned int lane) {
+  unsigned short h = oracle_f32_to_f16(x);
+  unsigned int s0 = st[lane], s1 = st[lane + 16], s2 = st[lane + 32], s3 = st[lane + 48], t0;
+  const unsigned int sum = s0 + s3, vrng = ((sum << 7) | (sum >> 25)) + s0;
+  const unsigned short rnd = (unsigned short)((vrng >> 24) & 0xffu), fixup = (unsigned short)((h >> 8) & 1u);
+  t0 = s1 << 9; s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t0; s3 = (s3 << 11) | (s3 >> 21);
+  st[lane] = s0; st[lane + 16] = s1; st[lane + 32] = s2; st[lane + 48] = s3;
+  if ((h & 0x7c00u) == 0x7c00u) h = ((h & 0x03ffu) == 0) ? h : (unsigned short)(h | 0x0200u);
+  else if ((h & 0x7c00u) == 0) h = (unsigned short)(h + 0x007fu + fixup);
+  else h = (unsigned short)(h + rnd);
+  return (unsigned char)(h >> 8);
+}
+/* store of the generic element-wise loops: stochastic only for BF8 output with the flag set [:299-320] */
+static void put_elem(void* out, long long idx, int type, float v, int stoch, void* state, unsigned int seed_idx) {
+  if (stoch && type == LIBXSMM_DATATYPE_BF8) ((unsigned char*)out)[idx] = f32_to_bf8_stochastic(v, (unsigned int*)state, seed_idx % 16u);
+  else put_f32(out, idx, type, v);
+}
+
 static float sigmoidf_ref(float x) { return (tanhf(x / 2.0f) + 1.0f) / 2.0f; }     /* [:18-20] */
 static float unary_f32(int type, float x) {                                       /* [:83-127] */
   switch (type) {
@@ -463,7 +484,7 @@ void oracle_meltw_unary(const libxsmm_meltw_unary_param* p, const oracle_meltw_d
       ((double*)p->out.primary)[i + j * ldo] = unary_f64(d->type, ((const double*)p->in.primary)[elem_index(bc, i, j, ldi)]);
     } else {
       const float x = get_f32(p->in.primary, elem_index(bc, i, j, ldi), d->in0_type);
-      put_f32(p->out.primary, i + j * ldo, d->out_type, unary_f32(d->type, x));
+      put_elem(p->out.primary, i + j * ldo, d->out_type, unary_f32(d->type, x), (d->flags & LIBXSMM_MELTW_FLAG_UNARY_STOCHASTIC_ROUND) != 0, p->op.secondary, (unsigned int)(j * M + i));
     }
   }
 }
@@ -523,7 +544,7 @@ void oracle_meltw_binary(const libxsmm_meltw_binary_param* p, const oracle_meltw
         bit_put((unsigned char*)p->out.primary, i, j, LIBXSMM_UPDIV(ldo, 16) * 16, binary_f32(d->type, a, b, 0.0f) > 0.1f);
       } else {
         const float prev = (d->type == LIBXSMM_MELTW_TYPE_BINARY_MULADD) ? get_f32(p->out.primary, i + j * ldo, d->out_type) : 0.0f;
-        put_f32(p->out.primary, i + j * ldo, d->out_type, binary_f32(d->type, a, b, prev));
+        put_elem(p->out.primary, i + j * ldo, d->out_type, binary_f32(d->type, a, b, prev), (d->flags & LIBXSMM_MELTW_FLAG_BINARY_STOCHASTIC_ROUND) != 0, p->op.secondary, (unsigned int)(j * M + i));
       }
     }
   }
@@ -543,7 +564,7 @@ void oracle_meltw_ternary(const libxsmm_meltw_ternary_param* p, const oracle_mel
       } else {
         const float a = get_f32(p->in0.primary, elem_index(bc0, i, j, ldi), d->in0_type);
         const float b = get_f32(p->in1.primary, elem_index(bc1, i, j, ldi1), d->in1_type);
-        put_f32(p->out.primary, i + j * ldo, d->out_type, bit ? b : a);
+        put_elem(p->out.primary, i + j * ldo, d->out_type, bit ? b : a, (d->flags & LIBXSMM_MELTW_FLAG_TERNARY_STOCHASTIC_ROUND) != 0, p->op.secondary, (unsigned int)(j * M + i));
       }
     } else if (d->type == LIBXSMM_MELTW_TYPE_TERNARY_MULADD || d->type == LIBXSMM_MELTW_TYPE_TERNARY_NMULADD) {   /* [:2641-2655] */
       const float a = get_f32(p->in0.primary, elem_index(bc0, i, j, ldi), d->in0_type);
@@ -552,7 +573,7 @@ void oracle_meltw_ternary(const libxsmm_meltw_ternary_param* p, const oracle_mel
       float prod, r;
       if (d->type == LIBXSMM_MELTW_TYPE_TERNARY_MULADD) { prod = a * b; r = c + prod; }
       else { prod = a * c; r = b - prod; }
-      put_f32(p->out.primary, i + j * ldo, d->out_type, r);
+      put_elem(p->out.primary, i + j * ldo, d->out_type, r, (d->flags & LIBXSMM_MELTW_FLAG_TERNARY_STOCHASTIC_ROUND) != 0, p->op.secondary, (unsigned int)(j * M + i));
     } else {
       ORACLE_DIE("unsupported ternary op");
     }

@@ -448,6 +448,67 @@ def test_dropout_single_call_with_host_memory_advances_the_callers_state():
     assert not np.array_equal(outs[1][1], st0)
 
 
+def _wide_f32(rng, count):
+    v = (rng.standard_normal(count) * 2.0 ** rng.integers(-18, 15, count)).astype(np.float32)
+    v[:8] = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 65504.0, 1e-7, -3e-6], dtype=np.float32)
+    return v
+
+
+@pytest.mark.parametrize("what", ["unary_identity", "unary_x2", "binary_add", "ternary_muladd"])
+@pytest.mark.parametrize("m,n,ld,batch", [(70, 9, 72, 1), (5, 3, 8, 1), (16, 16, 16, 1), (300, 200, 304, 1), (33, 7, 40, 6), (64, 64, 64, 19)])
+def test_stochastic_rounding_bit_exact(what, m, n, ld, batch):
+    """f32 -> BF8 with stochastic rounding: bytes AND advanced generator state equal to the oracle, single calls, big tiles (segments with
+    jump-ahead) and batched launches (every call restarts at element 0 and continues the 16 streams)."""
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(4)
+    per = ld * n
+    X = [_wide_f32(rng, batch * per) for _ in range(3)]
+    state0 = rng.integers(1, 2 ** 32, size=64, dtype=np.uint64).astype(np.uint32)
+    unary = what.startswith("unary")
+    typ = {"unary_identity": UNARY.IDENTITY, "unary_x2": UNARY.X2, "binary_add": BINARY.ADD, "ternary_muladd": TERNARY.MULADD}[what]
+    if unary:
+        flags, desc = UNARY_FLAG.STOCHASTIC_ROUND, None
+        desc = pyoracle.MeltwDesc(m, n, ld, ld, 0, 0, DT.F32, DT.UNSUPPORTED, DT.UNSUPPORTED, DT.F32, DT.BF8, flags, typ, OP_UNARY)
+        h = api.dispatch_meltw_unary(typ, capi.UnaryShape(m, n, ld, ld, DT.F32, DT.BF8, DT.F32), flags)
+    elif what == "binary_add":
+        flags = BINARY_FLAG.STOCHASTIC_ROUND
+        desc = pyoracle.MeltwDesc(m, n, ld, ld, ld, 0, DT.F32, DT.F32, DT.UNSUPPORTED, DT.F32, DT.BF8, flags, typ, OP_BINARY)
+        h = api.dispatch_meltw_binary(typ, capi.BinaryShape(m, n, ld, ld, ld, DT.F32, DT.F32, DT.BF8, DT.F32), flags)
+    else:
+        flags = TERNARY_FLAG.STOCHASTIC_ROUND
+        desc = pyoracle.MeltwDesc(m, n, ld, ld, ld, ld, DT.F32, DT.F32, DT.F32, DT.F32, DT.BF8, flags, typ, OP_TERNARY)
+        h = api.dispatch_meltw_ternary(typ, capi.TernaryShape(m, n, ld, ld, ld, ld, DT.F32, DT.F32, DT.F32, DT.BF8, DT.F32), flags)
+    assert h
+
+    def param(x0, x1, x2, y, st, b):
+        if unary:
+            p = capi.UnaryParam(); p.in_.primary = x0 + 4 * per * b
+        elif what == "binary_add":
+            p = capi.BinaryParam(); p.in0.primary, p.in1.primary = x0 + 4 * per * b, x1 + 4 * per * b
+        else:
+            p = capi.TernaryParam(); p.in0.primary, p.in1.primary, p.in2.primary = x0 + 4 * per * b, x1 + 4 * per * b, x2 + 4 * per * b
+        p.out.primary, p.op.secondary = y + per * b, st
+        return p
+    ref, st_ref = np.zeros(batch * per, dtype=np.uint8), state0.copy()
+    for b in range(batch):
+        orc.meltw(param(X[0].ctypes.data, X[1].ctypes.data, X[2].ctypes.data, ref.ctypes.data, st_ref.ctypes.data, b), desc)
+    dX = [_dev(x) for x in X]
+    dY, dS = _dev(np.zeros(batch * per, dtype=np.uint8)), _dev(state0.copy())
+    p = param(dX[0].data_ptr(), dX[1].data_ptr(), dX[2].data_ptr(), dY.data_ptr(), dS.data_ptr(), 0)
+    if batch == 1:
+        capi.Api.call(h, p)
+    elif unary:
+        api.hip_meltw_unary_batch_strided(h, C.byref(p), batch, 4 * per, per, 0)
+    elif what == "binary_add":
+        api.hip_meltw_binary_batch_strided(h, C.byref(p), batch, 4 * per, 4 * per, per)
+    else:
+        api.hip_meltw_ternary_batch_strided(h, C.byref(p), batch, 4 * per, 4 * per, 4 * per, per)
+    api.hip_sync(); api.check()
+    valid = lambda y: y.reshape(batch * n, ld)[:, :m]
+    assert np.array_equal(valid(ref), valid(dY.cpu().numpy()))
+    assert np.array_equal(st_ref, dS.cpu().numpy().view(np.uint32))
+
+
 def test_unsupported_tpps_return_null():
     api = capi.load()
     assert api.dispatch_meltw_unary(UNARY.DROPOUT, capi.UnaryShape(8, 8, 8, 8, DT.F32, DT.F32, DT.F32), UNARY_FLAG.BCAST_ROW) is None

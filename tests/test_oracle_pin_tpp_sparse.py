@@ -10,7 +10,7 @@ import pytest
 
 from helpers import normf_rel, rand_values
 from libxsmm_amd import capi
-from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, GEMM_FLAG, TERNARY, UNARY, UNARY_FLAG
+from libxsmm_amd.capi import BINARY, BINARY_FLAG, DT, GEMM_FLAG, TERNARY, TERNARY_FLAG, UNARY, UNARY_FLAG
 from oracle import pyoracle
 from sparse_helpers import csr_to_csc, make_bcsc, pack_vnni2, pack_vnni4, random_csr
 
@@ -205,6 +205,49 @@ def test_dropout_bit_identical(reference, dt, m, n, ld, bitm):
             assert np.array_equal(a.reshape(n, ld)[:, :m], b.reshape(n, ld)[:, :m])
     finally:
         orc.lib.oracle_set_rng_width(16)
+
+
+def _wide_f32(rng, count):
+    """values over many binades, with specials: what a rounding to E5M2 has to be tried on"""
+    v = (rng.standard_normal(count) * 2.0 ** rng.integers(-18, 15, count)).astype(np.float32)
+    v[:8] = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 65504.0, 1e-7, -3e-6], dtype=np.float32)
+    return v
+
+
+@pytest.mark.parametrize("what", ["unary_identity", "unary_x2", "binary_add", "ternary_muladd"])
+@pytest.mark.parametrize("m,n,ld", [(70, 9, 72), (5, 3, 8), (16, 16, 16)])
+def test_stochastic_rounding_bit_identical(reference, what, m, n, ld):
+    """*_STOCHASTIC_ROUND to BF8: one xoshiro128++ draw per element, stream = element number % 16, from the state behind op.secondary
+    [ref: src/libxsmm_lpflt_quant.c:303-365].  Bytes and the advanced state must match the reference."""
+    orc = pyoracle.oracle()
+    rng = np.random.default_rng(4)
+    X0, X1, X2 = _wide_f32(rng, ld * n), _wide_f32(rng, ld * n), _wide_f32(rng, ld * n)
+    state0 = rng.integers(1, 2 ** 32, size=64, dtype=np.uint64).astype(np.uint32)
+    res = []
+    for who in ("oracle", "reference"):
+        y, st = np.zeros(ld * n, dtype=np.uint8), state0.copy()
+        if what.startswith("unary"):
+            typ = UNARY.IDENTITY if what == "unary_identity" else UNARY.X2
+            p = capi.UnaryParam(); p.in_.primary, p.out.primary, p.op.secondary = X0.ctypes.data, y.ctypes.data, st.ctypes.data
+            if who == "oracle":
+                orc.meltw(p, pyoracle.MeltwDesc(m, n, ld, ld, 0, 0, DT.F32, DT.UNSUPPORTED, DT.UNSUPPORTED, DT.F32, DT.BF8, UNARY_FLAG.STOCHASTIC_ROUND, typ, OP_UNARY))
+            else:
+                reference.lib.xref_reference_meltw_unary(C.byref(p), typ, capi.UnaryShape(m, n, ld, ld, DT.F32, DT.BF8, DT.F32), UNARY_FLAG.STOCHASTIC_ROUND)
+        elif what == "binary_add":
+            p = capi.BinaryParam(); p.in0.primary, p.in1.primary, p.out.primary, p.op.secondary = X0.ctypes.data, X1.ctypes.data, y.ctypes.data, st.ctypes.data
+            if who == "oracle":
+                orc.meltw(p, pyoracle.MeltwDesc(m, n, ld, ld, ld, 0, DT.F32, DT.F32, DT.UNSUPPORTED, DT.F32, DT.BF8, BINARY_FLAG.STOCHASTIC_ROUND, BINARY.ADD, OP_BINARY))
+            else:
+                reference.lib.xref_reference_meltw_binary(C.byref(p), BINARY.ADD, capi.BinaryShape(m, n, ld, ld, ld, DT.F32, DT.F32, DT.BF8, DT.F32), BINARY_FLAG.STOCHASTIC_ROUND)
+        else:
+            p = capi.TernaryParam(); p.in0.primary, p.in1.primary, p.in2.primary, p.out.primary, p.op.secondary = X0.ctypes.data, X1.ctypes.data, X2.ctypes.data, y.ctypes.data, st.ctypes.data
+            if who == "oracle":
+                orc.meltw(p, pyoracle.MeltwDesc(m, n, ld, ld, ld, ld, DT.F32, DT.F32, DT.F32, DT.F32, DT.BF8, TERNARY_FLAG.STOCHASTIC_ROUND, TERNARY.MULADD, OP_TERNARY))
+            else:
+                reference.lib.xref_reference_meltw_ternary(C.byref(p), TERNARY.MULADD, capi.TernaryShape(m, n, ld, ld, ld, ld, DT.F32, DT.F32, DT.F32, DT.BF8, DT.F32), TERNARY_FLAG.STOCHASTIC_ROUND)
+        res.append((y.reshape(n, ld)[:, :m].copy(), st))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert not np.array_equal(res[0][1], state0)
 
 
 @pytest.mark.parametrize("typ", [UNARY.REDUCE_COLS_IDX_OP_ADD, UNARY.REDUCE_COLS_IDX_OP_MAX, UNARY.REDUCE_COLS_IDX_OP_MIN])
