@@ -198,6 +198,7 @@ void* rt_workspace(size_t nbytes);
 void rt_workspace_reserve(size_t nbytes);   // nested workspace() requests are placed behind this many bytes (0: off)
 bool rt_ready();
 const void* rt_small_host_input(const void* p, size_t nbytes);   // tiny operands (scalars) may live in host memory: staged if they do
+void* rt_small_host_output(void* p, size_t nbytes);              // ... and so may a 1 x 1 result: staged and copied back when the call is synchronous
 void rt_scratch_reset();
 void rt_note(const char* what, int a, int b, int c);      // verbosity >= 1: why a request was refused
 void* rt_stream();

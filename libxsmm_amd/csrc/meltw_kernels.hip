@@ -1059,6 +1059,26 @@ static const u32x4m* dropout_jump_tables() {
   return (const u32x4m*)d;
 }
 
+// BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD: out[0] = sum_ij in0(i, j) * in1(i, j) [ref: mateltwise ref :2523-2542] -- the dot product the
+// layernorm-backward equations end in.  One workgroup per batch element: 1024 partial sums (element e goes to thread e % 1024), folded
+// pairwise in LDS: deterministic, a different (tree) order than the reference's serial sum.
+__global__ __launch_bounds__(1024) void mul_reduce_scalar_kernel(MeltwArgs p) {
+  __shared__ float part[1024];
+  const unsigned int b = blockIdx.x;
+  gcptr in0 = (gcptr)p.in0 + (long long)b * p.bs_in0; gcptr in1 = (gcptr)p.in1 + (long long)b * p.bs_in1;
+  const int bc0 = bcast_kind(p.operation, p.type, p.flags, 0), bc1 = bcast_kind(p.operation, p.type, p.flags, 1);
+  const long long total = (long long)p.m * p.n;
+  float acc = 0.0f;
+  for (long long e = threadIdx.x; e < total; e += 1024) {
+    const long long j = e / p.m, i = e - j * p.m;
+    acc += mw_load(in0, bc_index(bc0, i, j, p.ldi), p.in0_type) * mw_load(in1, bc_index(bc1, i, j, p.ldi1), p.in1_type);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) { if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) mw_store((gptr)p.out + (long long)b * p.bs_out, 0, p.out_type, part[0]);
+}
+
 // second pass of the two-pass column reduction: partial[z][2][m] -> out (chunks combined in order z = 0, 1, ...)
 __global__ __launch_bounds__(256) void reduce_combine_kernel(MeltwArgs p, const float* partial, int nchunks) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1309,6 +1329,8 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
     const bool arith = t == LIBXSMM_MELTW_TYPE_BINARY_ADD || t == LIBXSMM_MELTW_TYPE_BINARY_MUL || t == LIBXSMM_MELTW_TYPE_BINARY_SUB || t == LIBXSMM_MELTW_TYPE_BINARY_DIV ||
                        t == LIBXSMM_MELTW_TYPE_BINARY_MULADD || t == LIBXSMM_MELTW_TYPE_BINARY_MAX || t == LIBXSMM_MELTW_TYPE_BINARY_MIN;
     const bool cmp = t >= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_GT && t <= LIBXSMM_MELTW_TYPE_BINARY_CMP_OP_NE;
+    if (t == LIBXSMM_MELTW_TYPE_BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD)
+      return !f64 && !(d.flags & LIBXSMM_MELTW_FLAG_BINARY_STOCHASTIC_ROUND) && is_tpp_float(d.in0_type) && is_tpp_float(d.in1_type) && is_tpp_float(d.out_type);
     if (d.flags & LIBXSMM_MELTW_FLAG_BINARY_STOCHASTIC_ROUND)       // (MULADD reads its BF8 output as an input: not through the two-pass scheme)
       return arith && t != LIBXSMM_MELTW_TYPE_BINARY_MULADD && !f64 && d.out_type == LIBXSMM_DATATYPE_BF8 && is_tpp_float(d.in0_type) && is_tpp_float(d.in1_type);
     if (f64) return arith && d.in1_type == LIBXSMM_DATATYPE_F64;
@@ -1377,6 +1399,11 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
     else if (a.operation == LIBXSMM_MELTW_OPERATION_BINARY) hipLaunchKernelGGL((meltw_ew8_kernel<2>), grid, dim3(256), 0, st, a, m8, total);
     else hipLaunchKernelGGL((meltw_ew8_kernel<3>), grid, dim3(256), 0, st, a, m8, total);
     if (name) *name = "meltw_ew8_kernel";
+    return (int)hipGetLastError();
+  }
+  if (a.operation == LIBXSMM_MELTW_OPERATION_BINARY && a.type == LIBXSMM_MELTW_TYPE_BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD) {
+    hipLaunchKernelGGL(mul_reduce_scalar_kernel, dim3(a.nbatch), dim3(1024), 0, st, a);
+    if (name) *name = "mul_reduce_scalar_kernel";
     return (int)hipGetLastError();
   }
   if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT) {

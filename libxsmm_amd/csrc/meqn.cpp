@@ -43,6 +43,8 @@ struct Equation {
 struct EqnStep { MeltwArgs args; int src[3]; int node; int alpha_from_op; int dump_from_op; int idx_from_input; int root_side; bool scalar_arg[3];
   const void* gemm; int br_from_op; int out_loc; };   // gemm: dispatched (BR)GEMM handle of a MATMUL / BRGEMM node; out_loc: like src, INT32_MIN = the caller's output   // idx_from_input: GATHER reads its indices from inputs[pos].secondary   // root_side: 1 bitmask, 2 UNZIP offset from output.secondary   // src: >=0 input position, < 0: -(slot+1)
 struct EqnPlan {
+  bool out_scalar = false;          // a 1 x 1 result (a dot product, a full reduction): callers keep it on their stack -> staged like scalar inputs
+  size_t out_scalar_bytes = 4;
   JitKernel* fused = nullptr;       // whole tree as ONE generated kernel (element-wise trees), else the step chain below
   std::vector<int> fused_inputs;    // input positions in kernel-argument order
   std::vector<char> fused_scalar;   // ... and whether that argument is a 1 x 1 scalar (may live in host memory)
@@ -151,6 +153,10 @@ bool infer(Equation& e, int id) {
     const EqnNode& r = e.nodes[nd.child[1]];
     nd.m = std::max(l.m, r.m); nd.n = std::max(l.n, r.n); nd.ld = nd.m;
     if (nd.op == LIBXSMM_MELTW_TYPE_BINARY_ZIP) nd.type = LIBXSMM_DATATYPE_F32;       // two 16-bit halves -> one f32 [ref: mateltwise ref ZIP]
+    if (nd.op == LIBXSMM_MELTW_TYPE_BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD) {          // a dot product: one value [ref: mateltwise ref :2523-2542]
+      if (l.m != r.m || l.n != r.n) return false;
+      nd.m = nd.n = nd.ld = 1;
+    }
   } else {
     const EqnNode& r = e.nodes[nd.child[1]]; const EqnNode& r2 = e.nodes[nd.child[2]];
     nd.m = std::max(r2.m, std::max(l.m, r.m)); nd.n = std::max(r2.n, std::max(l.n, r.n)); nd.ld = nd.m;
@@ -252,8 +258,12 @@ int bcast_of(const EqnNode& parent, int operand) {   // 0 none, 1 row, 2 col, 3 
 // returns false when the tree is not fusable; on success `src` holds the kernel source
 bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eqn_idx, std::string& src, std::string& fname, EqnPlan& plan, long long& total) {
   const EqnNode& root = e.nodes[0];
-  const int M = root.m, N = root.n;
-  if (M % 8 != 0 || out.ld % 8 != 0 || (out.type != LIBXSMM_DATATYPE_F32 && out.type != LIBXSMM_DATATYPE_BF16)) return false;
+  // a head that folds its two element-wise operands into one number (the ds / db sums of a layernorm backward pass): the operand trees are
+  // evaluated in registers exactly as below and never written; one workgroup walks the units and folds 256 partial sums in LDS
+  const bool dot_root = root.kind == EQ_BINARY && root.op == LIBXSMM_MELTW_TYPE_BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD;
+  const int M = dot_root ? e.nodes[root.child[0]].m : root.m, N = dot_root ? e.nodes[root.child[0]].n : root.n;
+  if (M % 8 != 0 || (!dot_root && out.ld % 8 != 0) || (out.type != LIBXSMM_DATATYPE_F32 && out.type != LIBXSMM_DATATYPE_BF16)) return false;
+  if (dot_root && (root.flags != 0 || root.dtype != LIBXSMM_DATATYPE_F32)) return false;
   std::vector<int> order; postorder(e, 0, order);
   std::string body;
   char buf[512];
@@ -289,8 +299,13 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
   };
   for (int id : order) {
     const EqnNode& nd = e.nodes[id];
-    if (nd.dtype != LIBXSMM_DATATYPE_F32 || nd.m != M || nd.n != N) return false;
     std::string x, y, z, alpha = "0.0f";
+    if (dot_root && id == 0) {
+      if (!operand(nd, 0, x) || !operand(nd, 1, y)) return false;
+      body += "  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) { const float prod = " + x + "[e] * " + y + "[e]; acc = acc + prod; }\n";
+      continue;
+    }
+    if (nd.dtype != LIBXSMM_DATATYPE_F32 || nd.m != M || nd.n != N) return false;
     const std::string v = "v" + std::to_string(id);
     if (nd.kind == EQ_UNARY) {
       const char* t = unary_expr(nd.op);
@@ -311,18 +326,29 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
   }
   if (arg_types.empty() || arg_types.size() > 24) return false;
   total = (long long)(M / 8) * N;
-  fname = "meqn_jit_e" + std::to_string(eqn_idx) + "_" + std::to_string(M) + "x" + std::to_string(N) + "_o" + std::to_string((int)out.type);
+  fname = std::string(dot_root ? "meqn_jit_dot_e" : "meqn_jit_e") + std::to_string(eqn_idx) + "_" + std::to_string(M) + "x" + std::to_string(N) + "_o" + std::to_string((int)out.type);
   src = kFusedPrelude;
   src += "extern \"C\" __global__ __launch_bounds__(256) void " + fname + "(";
   for (size_t k = 0; k < arg_types.size(); ++k) src += "const void* in" + std::to_string(k) + ", ";
   src += "void* out";
   for (size_t k = 0; k < plan.fused_alphas.size(); ++k) src += ", float alpha" + std::to_string(k);
   src += ") {\n";
+  if (dot_root) {
+    std::snprintf(buf, sizeof(buf), "  __shared__ float part[256];\n  float acc = 0.0f;\n  for (long long t = threadIdx.x; t < %lldLL; t += 256) {\n  const long long j = t / %d, i = (t - j * %d) * 8;\n", total, M / 8, M / 8);
+    src += buf;
+    src += body;
+    src += "  }\n  part[threadIdx.x] = acc;\n  __syncthreads();\n"
+           "  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) part[threadIdx.x] = part[threadIdx.x] + part[threadIdx.x + s]; __syncthreads(); }\n";
+    src += out.type == LIBXSMM_DATATYPE_F32 ? "  if (threadIdx.x == 0) *(GM float*)out = part[0];\n}\n"
+                                            : "  if (threadIdx.x == 0) *(GM unsigned short*)out = (unsigned short)(f2bf_pk(part[0], 0.0f) & 0xffffu);\n}\n";
+    total = 256;      // one workgroup
+  } else {
   std::snprintf(buf, sizeof(buf), "  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n  if (t >= %lldLL) return;\n  const long long j = t / %d, i = (t - j * %d) * 8;\n", total, M / 8, M / 8);
   src += buf;
   src += body;
   std::snprintf(buf, sizeof(buf), "  %s((GM %s*)out + i + j * %dLL, v0);\n}\n", out.type == LIBXSMM_DATATYPE_F32 ? "st_f32" : "st_bf16", out.type == LIBXSMM_DATATYPE_F32 ? "float" : "unsigned short", (int)out.ld);
   src += buf;
+  }
   for (auto& a : arg_types) {
     plan.fused_inputs.push_back(a.first);
     char scalar = 0;
@@ -355,7 +381,9 @@ void run_meqn(EqnPlan* plan, const void* param) {
       ok = ok && ptrs[i] && (plan->fused_scalar[i] || (((size_t)ptrs[i]) & 15) == 0);
       args[na++] = (void*)&ptrs[i];
     }
-    void* outp = p->output.primary; ok = ok && (((size_t)outp) & 15) == 0;
+    void* outp = p->output.primary;
+    if (plan->out_scalar) { outp = rt_small_host_output(outp, plan->out_scalar_bytes); if (!outp) return; }
+    else ok = ok && (((size_t)outp) & 15) == 0;
     args[na++] = (void*)&outp;
     for (size_t i = 0; i < plan->fused_alphas.size() && ok; ++i) {
       if (!p->ops_args || !p->ops_args[plan->fused_alphas[i]].primary) { set_error(-2, "matrix equation: op argument %d is NULL", plan->fused_alphas[i]); return; }
@@ -364,6 +392,8 @@ void run_meqn(EqnPlan* plan, const void* param) {
     if (ok) { rt_finish_launch(jit_launch(plan->fused, args, rt_stream()), "meqn_jit"); return; }
   }
   rt_scratch_reset();
+  char* const out_primary = plan->out_scalar ? (char*)rt_small_host_output(p->output.primary, plan->out_scalar_bytes) : (char*)p->output.primary;
+  if (!out_primary) return;
   char* ws = nullptr;
   if (plan->nslots > 0) { ws = (char*)rt_workspace(plan->slot_bytes * (size_t)plan->nslots + (plan->has_gemm ? ((size_t)8 << 20) : 0)); if (!ws) return; }
   const char* kname = nullptr;
@@ -380,7 +410,7 @@ void run_meqn(EqnPlan* plan, const void* param) {
       if (st.src[c] >= 0 && st.scalar_arg[c]) { src[c] = (const char*)rt_small_host_input(src[c], 8); if (!src[c]) return; }
     }
     a.in0 = src[0]; a.in1 = src[1]; a.in2 = src[2];
-    a.out = st.out_loc == INT32_MIN ? (char*)p->output.primary : (st.out_loc >= 0 ? (char*)p->inputs[st.out_loc].primary : ws + plan->slot_bytes * (size_t)(-st.out_loc - 1));
+    a.out = st.out_loc == INT32_MIN ? out_primary : (st.out_loc >= 0 ? (char*)p->inputs[st.out_loc].primary : ws + plan->slot_bytes * (size_t)(-st.out_loc - 1));
     if (st.gemm) {   // a MATMUL / BRGEMM node: the dense kernel, called like any other handle (its own launch bookkeeping included)
       libxsmm_gemm_param gp; std::memset(&gp, 0, sizeof(gp));
       unsigned long long blocks = 1;
@@ -512,6 +542,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       }
       if (accumulates) { rt_note("equation refused: a MATMUL / BRGEMM node that accumulates into its third operand cannot be the head", nd.op, 0, 0); delete plan; return nullptr; }
       nd.ld = out.ld; nd.type = out.type;
+      plan->out_scalar = (nd.m == 1 && nd.n == 1); plan->out_scalar_bytes = (size_t)std::max(1, typesize((int)out.type));
     } else if (accumulates) {
       loc[id] = loc[nd.child[2]];
       if (loc[id] < 0 && loc[id] != INT32_MIN) plan->slot_of[id] = -loc[id] - 1;
@@ -571,6 +602,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || nd.op == LIBXSMM_MELTW_TYPE_UNARY_ELU) d = nullptr;
     } else if (nd.kind == EQ_BINARY) {
       a.operation = LIBXSMM_MELTW_OPERATION_BINARY; a.m = nd.m; a.n = nd.n;
+      if (nd.op == LIBXSMM_MELTW_TYPE_BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD) { a.m = ch[0]->m; a.n = ch[0]->n; }     // the extent of the operands, not of the (1 x 1) result
       a.in1_type = ch[1]->type; a.ldi1 = ch[1]->ld;
       d = libxsmm_meltw_descriptor_init2(&blob, (libxsmm_datatype)a.in0_type, (libxsmm_datatype)a.in1_type, LIBXSMM_DATATYPE_UNSUPPORTED, (libxsmm_datatype)nd.dtype,
         (libxsmm_datatype)nd.type, a.m, a.n, a.ldi, a.ldo, a.ldi1, 0, (unsigned short)nd.flags, (unsigned short)nd.op, LIBXSMM_MELTW_OPERATION_BINARY);

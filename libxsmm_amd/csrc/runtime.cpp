@@ -887,6 +887,7 @@ void* rt_workspace(size_t nbytes) { return workspace(nbytes); }
 void rt_workspace_reserve(size_t nbytes) { t_ws_reserved = (nbytes + 255) & ~(size_t)255; }
 bool rt_ready() { return runtime_ready(); }
 const void* rt_small_host_input(const void* p, size_t nbytes) { return device_visible(p, nbytes); }
+void* rt_small_host_output(void* p, size_t nbytes) { return host_inout(p, nbytes, 1); }
 void rt_scratch_reset() { scratch_reset(); }
 void rt_note(const char* what, int a, int b, int c) { vlog(1, "%s (%d, %d, %d)", what, a, b, c); }
 void* rt_stream() { return tls().stream; }

@@ -522,6 +522,15 @@ void oracle_meltw_binary(const libxsmm_meltw_binary_param* p, const oracle_meltw
     }
     return;
   }
+  if (d->type == LIBXSMM_MELTW_TYPE_BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD) {           /* a dot product into out[0], serial f32 sum [:2523-2542] */
+    float acc = 0.0f;
+    for (j = 0; j < N; ++j) for (i = 0; i < M; ++i) {
+      const float prod = get_f32(p->in0.primary, elem_index(bc0, i, j, ldi), d->in0_type) * get_f32(p->in1.primary, elem_index(bc1, i, j, ldi1), d->in1_type);
+      acc = acc + prod;
+    }
+    put_f32(p->out.primary, 0, d->out_type, acc);
+    return;
+  }
   for (j = 0; j < N; ++j) for (i = 0; i < M; ++i) {                                   /* [:2558-2590] */
     if (d->in0_type == LIBXSMM_DATATYPE_F64 && d->out_type == LIBXSMM_DATATYPE_F64) {
       const double a = ((const double*)p->in0.primary)[elem_index(bc0, i, j, ldi)];

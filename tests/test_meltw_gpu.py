@@ -327,6 +327,20 @@ def test_binary_arith_bit_exact(typ, dts):
     assert np.array_equal(ref, got)
 
 
+@pytest.mark.parametrize("dts", [(DT.F32, DT.F32, DT.F32), (DT.BF16, DT.BF16, DT.F32), (DT.BF16, DT.F32, DT.BF16)])
+@pytest.mark.parametrize("m,n,ld,batch", [(45, 13, 48, 1), (64, 16, 64, 5), (1, 1, 1, 1), (768, 64, 768, 2)])
+def test_dot_product_to_scalar(dts, m, n, ld, batch):
+    """BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD: the device folds 1024 partial sums pairwise, the reference adds serially -- equal to f32
+    summation error (|terms| <= 1, so either order is within count * 2^-24 * count of the exact sum; the bound below is far inside that)"""
+    ref, got = run_binary(BINARY.MUL_AND_REDUCE_TO_SCALAR_OP_ADD, m, n, ld, ld, 1, dts, batch=batch)
+    from helpers import as_float
+    stride = n                                     # run_binary lays one (ldo = 1) x n output per batch element; element 0 is the result
+    for b in range(batch):
+        r, g = float(as_float(ref[b * stride:b * stride + 1], dts[2])[0]), float(as_float(got[b * stride:b * stride + 1], dts[2])[0])
+        assert abs(r - g) <= m * n * 2.0 ** -22 + (abs(r) * 2.0 ** -7 if dts[2] == DT.BF16 else 0.0), (b, r, g)
+        assert np.array_equal(ref[b * stride + 1:(b + 1) * stride], got[b * stride + 1:(b + 1) * stride])    # nothing else written
+
+
 @pytest.mark.parametrize("flags", [BINARY_FLAG.BCAST_COL_IN_0, BINARY_FLAG.BCAST_ROW_IN_1, BINARY_FLAG.BCAST_SCALAR_IN_0, BINARY_FLAG.BCAST_COL_IN_0 | BINARY_FLAG.BCAST_ROW_IN_1])
 def test_binary_broadcast_bias_add(flags):
     ref, got = run_binary(BINARY.ADD, 64, 64, 64, 64, 64, (DT.BF16, DT.BF16, DT.BF16), flags=flags)   # config #5's bias-add as a stand-alone TPP

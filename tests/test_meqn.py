@@ -66,6 +66,8 @@ def evaluate(tree, arg_shapes, arrays, out_shape, comp=DT.F32):
                 m, n = ((n0, 1) if t[2] & UNARY_FLAG.REDUCE_ROWS else (m0, 1)); dm, dn = m0, n0
             else:
                 m, n = m0, n0; dm, dn = m0, n0
+        elif t[0] == "b" and t[1] == BINARY.MUL_AND_REDUCE_TO_SCALAR_OP_ADD:
+            m, n = 1, 1; dm, dn = m0, n0          # a dot product over the operands' extent [ref: mateltwise ref :2523-2542]
         else:
             m = max(k[1][0] for k in kids); n = max(k[1][1] for k in kids); dm, dn = m, n
         ld, odt = (out_shape[2], out_shape[3]) if root else (m, comp)
@@ -113,6 +115,11 @@ CASES = {
     # a bf16 product at the head, A in VNNI-2 layout (what the reference's AMX / AVX-512 bf16 kernels take), relu on top
     "matmul_vnni_bf16": (("u", UNARY.RELU, 0, ("mm", BINARY.MATMUL_A_VNNI, 0, A(0), A(1))),
                          [(32, 16, 32, DT.BF16), (16, 24, 16, DT.BF16)], (32, 24, 40, DT.BF16)),
+    # equation_layernorm.c:966-998: the db and ds sums of the backward pass, dot products that end in one number
+    "dot_to_scalar": (("b", BINARY.MUL_AND_REDUCE_TO_SCALAR_OP_ADD, 0, A(0), A(1)),
+                      [(64, 12, 128, DT.BF16), (64, 12, 64, DT.BF16)], (1, 1, 1, DT.F32)),
+    "mul_dot_to_scalar": (("b", BINARY.MUL_AND_REDUCE_TO_SCALAR_OP_ADD, 0, ("b", BINARY.MUL, 0, A(0), A(1)), A(2)),
+                          [(M, N, LD, DT.F32), (M, N, M, DT.F32), (M, N, LD, DT.F32)], (1, 1, 1, DT.F32)),
     "mixed_precision": (("b", BINARY.SUB, 0, ("u", UNARY.X2, 0, A(0)), ("b", BINARY.MUL, BINARY_FLAG.BCAST_SCALAR_IN_1, A(1), A(2))),
                         [(M, N, LD, DT.BF16), (M, N, M, DT.F32), (1, 1, 1, DT.F32)], (M, N, LD, DT.BF16)),
 }
@@ -165,8 +172,9 @@ def test_incomplete_and_unsupported_equations_return_null(api):
     assert api.dispatch_meqn(idx, capi.MeqnArgShape(8, 8, 8, DT.F32)) is None          # second operand missing
 
 
-BY_NORM = {"tanh_sigmoid_chain": 1e-6, "matmul_mul": 1e-6, "matmul_vnni_bf16": 8e-3}     # device tanhf / the matrix core's summation order: not bit-identical
-FUSABLE = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain", "layernorm_affine"}     # no reduction inside
+# device tanhf / the matrix core's summation order / the tree-shaped sum of a dot product: not bit-identical
+BY_NORM = {"tanh_sigmoid_chain": 1e-6, "matmul_mul": 1e-6, "matmul_vnni_bf16": 8e-3, "dot_to_scalar": 2e-5, "mul_dot_to_scalar": 2e-5}
+FUSABLE = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain", "layernorm_affine", "dot_to_scalar", "mul_dot_to_scalar"}     # no reduction below the head
 
 
 @pytest.mark.gpu

@@ -305,6 +305,26 @@ def test_binary_bit_identical(reference, typ, dts, flags):
         assert outs[0].tobytes() == outs[1].tobytes()     # raw bytes: 0/0 -> NaN must match too
 
 
+@pytest.mark.parametrize("dts", [(DT.F32, DT.F32, DT.F32), (DT.BF16, DT.BF16, DT.F32), (DT.BF16, DT.F32, DT.BF16)])
+@pytest.mark.parametrize("m,n,ld", [(45, 13, 48), (64, 4, 64), (1, 1, 1), (7, 300, 9)])
+def test_dot_product_to_scalar_bit_identical(reference, dts, m, n, ld):
+    """BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD [ref: generator_mateltwise_reference_impl.c:2523-2542]: the serial f32 sum in the reference's order"""
+    orc = pyoracle.oracle()
+    rng = np.random.default_rng(31)
+    X0, X1 = rand_values(rng, ld * n, dts[0]), rand_values(rng, ld * n, dts[1])
+    typ = BINARY.MUL_AND_REDUCE_TO_SCALAR_OP_ADD
+    outs = []
+    for who in ("oracle", "reference"):
+        y = rand_values(np.random.default_rng(5), 4, dts[2])
+        p = capi.BinaryParam(); p.in0.primary, p.in1.primary, p.out.primary = X0.ctypes.data, X1.ctypes.data, y.ctypes.data
+        if who == "oracle":
+            orc.meltw(p, pyoracle.MeltwDesc(m, n, ld, 1, ld, 0, dts[0], dts[1], DT.UNSUPPORTED, DT.F32, dts[2], 0, typ, OP_BINARY))
+        else:
+            reference.lib.xref_reference_meltw_binary(C.byref(p), typ, capi.BinaryShape(m, n, ld, ld, 1, dts[0], dts[1], dts[2], DT.F32), 0)
+        outs.append(y)
+    assert outs[0][:1].tobytes() == outs[1][:1].tobytes()
+
+
 @pytest.mark.parametrize("typ", [TERNARY.SELECT, TERNARY.MULADD, TERNARY.NMULADD])
 @pytest.mark.parametrize("dt", [DT.F32, DT.BF16])
 def test_ternary_bit_identical(reference, typ, dt):

@@ -208,7 +208,7 @@ def test_reference_ternary_driver(args):
 
 # samples/equation/equation_simple.c -- M N ld datatype_mode(0 f32, 1 bf16) iters: five-argument element-wise + reduce/broadcast trees
 # (not run: equation_simple_layernorm is BF8-only; equation_bf16_x3_split_f32 reads, as arguments, buffers that DUMP nodes of the same tree
-# write -- its result depends on the reference's node scheduling; equation_layernorm needs the x86 intrinsics header)
+# write -- its result depends on the reference's node scheduling)
 @pytest.mark.parametrize("args", ["64 48 64 0 2", "64 48 64 1 2", "33 17 40 0 2"])
 def test_reference_equation_driver(args):
     check("equation_simple", *args.split())
@@ -222,6 +222,18 @@ def test_reference_softmax_equation_driver(args, bound):
     out = check("equation_softmax", *args.split())
     norms = [float(x) for x in re.findall(r"Check-norm\s*:\s*([0-9.eE+-]+)", out)]
     assert norms and max(norms) <= bound, out[-2000:]
+
+
+# samples/equation/equation_layernorm.c -- S1 S2 S3 datatype_mode(0 f32, 1 bf16) pass(1 fwd, 2 bwd, 3 both) iters: per row block, X / X^2 column
+# reductions + a row reduction as plain TPPs, then six equations -- the affine forward, dgamma / dbeta accumulated in place, the ds / db dot
+# products (BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD heads, results on the caller's stack) and din.  Mean, variance and the scalar factors live on
+# the driver's stack: every call is synchronous.  The driver judges itself (check-norm against its scalar loops, bound 0.007).  S3 = 20: rows that
+# are no multiple of 8, the TPP chain instead of the generated kernels.
+@pytest.mark.parametrize("args", ["4 8 64 0 3 1", "4 8 64 1 3 1", "2 5 48 0 3 1", "3 4 20 0 3 1", "3 4 20 1 3 1", "8 3 256 1 2 1"])
+def test_reference_layernorm_equation_driver(args):
+    out = check("equation_layernorm", *args.split())
+    norms = [float(x) for x in re.findall(r"Check-norm\s*:\s*([0-9.eE+-]+)", out)]
+    assert len(norms) >= (1 if args.split()[4] == "1" else 3) and max(norms) <= 0.007, out[-2000:]
 
 
 # equation_relu.c (M N ld datatype_mode): ReLU with bitmask as the HEAD of a tree (mask through output.secondary); equation_splitSGD.c
