@@ -13,7 +13,9 @@
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -49,6 +51,7 @@ struct EqnPlan {
   std::vector<int> fused_inputs;    // input positions in kernel-argument order
   std::vector<char> fused_scalar;   // ... and whether that argument is a 1 x 1 scalar (may live in host memory)
   std::vector<int> fused_alphas;    // op_arg positions of scalar op arguments, in kernel-argument order
+  std::vector<int> fused_dumps;     // op_arg positions of DUMP destinations (device pointers), behind the alphas
   std::vector<EqnStep> steps;
   std::vector<int> slot_of;         // per node: workspace slot (-1: none)
   size_t slot_bytes = 0; int nslots = 0;
@@ -255,35 +258,79 @@ int bcast_of(const EqnNode& parent, int operand) {   // 0 none, 1 row, 2 col, 3 
   if (f & (LIBXSMM_MELTW_FLAG_TERNARY_BCAST_SCALAR_IN_0 << operand)) return 3; return 0;
 }
 
-// returns false when the tree is not fusable; on success `src` holds the kernel source
+// A reduction (one node, or a REDUCE_COLS / REDUCE_ROWS pair) that folds an element-wise M x N operand into ONE number: the max and the sum
+// of a softmax, the sum of a softmax backward pass [ref: samples/equation/equation_softmax.c:527-538,676-688]
+struct ScalarReduce { int src; int fold; bool square; };     // fold: 0 add, 1 max, 2 min
+bool scalar_reduce(const Equation& e, int id, int M, int N, ScalarReduce& r) {
+  const EqnNode& nd = e.nodes[id];
+  const auto kind = [](int op, int& fold, bool& sq) {
+    switch (op) {
+      case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD: fold = 0; sq = false; return true;
+      case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD: fold = 0; sq = true; return true;
+      case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX: fold = 1; sq = false; return true;
+      case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN: fold = 2; sq = false; return true;
+      default: return false;
+    }
+  };
+  const unsigned int dirs = LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS | LIBXSMM_MELTW_FLAG_UNARY_REDUCE_COLS;
+  if (nd.kind != EQ_UNARY || nd.m != 1 || nd.n != 1 || nd.dtype != LIBXSMM_DATATYPE_F32 || !kind(nd.op, r.fold, r.square) || (nd.flags & ~dirs) || !(nd.flags & dirs)) return false;
+  r.src = nd.child[0];
+  const EqnNode& c = e.nodes[nd.child[0]];
+  if (c.kind == EQ_UNARY && is_reduce(c.op)) {
+    int f2 = 0; bool s2 = false;
+    if (c.dtype != LIBXSMM_DATATYPE_F32 || !kind(c.op, f2, s2) || f2 != r.fold || r.square || (c.flags & ~dirs) || !(c.flags & dirs)) return false;
+    r.square = s2; r.src = c.child[0];
+  }
+  return e.nodes[r.src].m == M && e.nodes[r.src].n == N;
+}
+
+// returns false when the tree is not fusable; on success `src` holds the kernel source.
+// Two forms.  Element-wise trees: a grid of threads, one 8-row unit each.  Trees with reductions to ONE number inside (or as the head): one
+// workgroup of 256 threads that walks the units once per reduction ("phase"), folds its partial results in LDS and carries the number in a
+// register into the phases that broadcast it -- the operand trees are re-evaluated from the (cache-resident) arguments, never written.  Unit t
+// belongs to thread t % 256 in every phase, so what a DUMP node wrote is read back (as an argument) by the thread that wrote it.
 bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eqn_idx, std::string& src, std::string& fname, EqnPlan& plan, long long& total) {
   const EqnNode& root = e.nodes[0];
-  // a head that folds its two element-wise operands into one number (the ds / db sums of a layernorm backward pass): the operand trees are
-  // evaluated in registers exactly as below and never written; one workgroup walks the units and folds 256 partial sums in LDS
-  const bool dot_root = root.kind == EQ_BINARY && root.op == LIBXSMM_MELTW_TYPE_BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD;
-  const int M = dot_root ? e.nodes[root.child[0]].m : root.m, N = dot_root ? e.nodes[root.child[0]].n : root.n;
-  if (M % 8 != 0 || (!dot_root && out.ld % 8 != 0) || (out.type != LIBXSMM_DATATYPE_F32 && out.type != LIBXSMM_DATATYPE_BF16)) return false;
-  if (dot_root && (root.flags != 0 || root.dtype != LIBXSMM_DATATYPE_F32)) return false;
-  std::vector<int> order; postorder(e, 0, order);
-  std::string body;
-  char buf[512];
+  const bool scalar_root = root.m == 1 && root.n == 1;
+  int M = root.m, N = root.n;                      // the extent of the element-wise part: the head's, or (a head that is one number) the operands'
+  if (scalar_root) for (const EqnNode& nd : e.nodes) { M = std::max(M, nd.m); N = std::max(N, nd.n); }
+  if (M % 8 != 0 || (out.type != LIBXSMM_DATATYPE_F32 && out.type != LIBXSMM_DATATYPE_BF16)) return false;
+  if (!scalar_root && (root.m != M || root.n != N || out.ld % 8 != 0)) return false;
+  const long long units = (long long)(M / 8) * N;
+  char buf[768];
+  std::string phases;
   std::map<int, int> arg_slot;                     // input position -> kernel argument index
   std::vector<std::pair<int, int> > arg_types;     // (input position, datatype)
-  auto operand = [&](const EqnNode& parent, int c, std::string& name) -> bool {
-    const EqnNode& ch = e.nodes[parent.child[c]];
-    const int bc = bcast_of(parent, c);
+  const auto slot_of_arg = [&](const EqnNode& ch) -> int {
+    if (ch.type != LIBXSMM_DATATYPE_F32 && ch.type != LIBXSMM_DATATYPE_BF16) return -1;
+    if (arg_slot.find(ch.in_pos) == arg_slot.end()) { arg_slot[ch.in_pos] = (int)arg_types.size(); arg_types.push_back({ch.in_pos, ch.type}); }
+    else if (arg_types[arg_slot[ch.in_pos]].second != ch.type) return -1;
+    return arg_slot[ch.in_pos];
+  };
+  std::function<bool(int, int, std::string&, std::string&)> value;     // (node, broadcast kind, name, code of the enclosing unit loop)
+  std::function<bool(int, std::string&)> elem, scalar_value;           // element-wise op node -> v<id>[8]; one-number subtree -> s<id>
+  const auto operand = [&](const EqnNode& parent, int c, std::string& name, std::string& body) -> bool { return value(parent.child[c], bcast_of(parent, c), name, body); };
+  const std::string unit_loop = "  for (long long t = threadIdx.x; t < " + std::to_string(units) + "LL; t += 256) {\n  const long long j = t / " + std::to_string(M / 8) + ", i = (t - j * " + std::to_string(M / 8) + ") * 8;\n";
+
+  value = [&](int id, int bc, std::string& name, std::string& body) -> bool {
+    const EqnNode& ch = e.nodes[id];
     if (ch.kind != EQ_ARG) {
-      if (bc != 0 || ch.m != M || ch.n != N) return false;
-      name = "v" + std::to_string(parent.child[c]);
+      if (ch.m == 1 && ch.n == 1) {     // a number computed by an earlier phase, broadcast
+        std::string s;
+        if (bc != 3 || !scalar_value(id, s)) return false;
+        name = "b" + std::to_string(id);
+        body += "  float " + name + "[8]; _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + name + "[e] = " + s + ";\n";
+        return true;
+      }
+      if (bc != 0 || ch.m != M || ch.n != N || !elem(id, body)) return false;
+      name = "v" + std::to_string(id);
       return true;
     }
-    if (ch.type != LIBXSMM_DATATYPE_F32 && ch.type != LIBXSMM_DATATYPE_BF16) return false;
     if (bc == 0 && (ch.m != M || ch.n != N || ch.ld % 8 != 0)) return false;
     if (bc == 2 && ch.m != M) return false;
-    if (arg_slot.find(ch.in_pos) == arg_slot.end()) { arg_slot[ch.in_pos] = (int)arg_types.size(); arg_types.push_back({ch.in_pos, ch.type}); }
-    else if (arg_types[arg_slot[ch.in_pos]].second != ch.type) return false;
-    const int k = arg_slot[ch.in_pos];
-    name = "a" + std::to_string(parent.child[c]);
+    const int k = slot_of_arg(ch);
+    if (k < 0) return false;
+    name = "a" + std::to_string(id);
     const char* T = ch.type == LIBXSMM_DATATYPE_F32 ? "float" : "unsigned short";
     const char* LD = ch.type == LIBXSMM_DATATYPE_F32 ? "ld_f32" : "ld_bf16";
     if (bc == 0 || bc == 2) {
@@ -297,57 +344,112 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
     body += buf;
     return true;
   };
-  for (int id : order) {
+
+  elem = [&](int id, std::string& body) -> bool {
     const EqnNode& nd = e.nodes[id];
-    std::string x, y, z, alpha = "0.0f";
-    if (dot_root && id == 0) {
-      if (!operand(nd, 0, x) || !operand(nd, 1, y)) return false;
-      body += "  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) { const float prod = " + x + "[e] * " + y + "[e]; acc = acc + prod; }\n";
-      continue;
-    }
     if (nd.dtype != LIBXSMM_DATATYPE_F32 || nd.m != M || nd.n != N) return false;
+    std::string x, y, z, alpha = "0.0f";
     const std::string v = "v" + std::to_string(id);
     if (nd.kind == EQ_UNARY) {
+      if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_DUMP) {      // identity that also lands in ops_args[pos].primary: an f32 M x N image, ld = M, below the head [ref: matequation ref :58-60]
+        if (id == 0 || nd.flags != 0 || nd.op_arg_pos < 0 || plan.fused_dumps.size() >= 4 || !operand(nd, 0, x, body)) return false;
+        const std::string d = "dump" + std::to_string(plan.fused_dumps.size());
+        plan.fused_dumps.push_back(nd.op_arg_pos);
+        body += "  float " + v + "[8];\n  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + v + "[e] = " + x + "[e];\n  st_f32((GM float*)" + d + " + i + j * " + std::to_string(M) + "LL, " + v + ");\n";
+        return true;
+      }
       const char* t = unary_expr(nd.op);
       if (!t || (nd.flags & ~(unsigned int)(LIBXSMM_MELTW_FLAG_UNARY_BCAST_ROW | LIBXSMM_MELTW_FLAG_UNARY_BCAST_COL | LIBXSMM_MELTW_FLAG_UNARY_BCAST_SCALAR))) return false;
-      if (!operand(nd, 0, x)) return false;
+      if (!operand(nd, 0, x, body)) return false;
       if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU) { if (nd.op_arg_pos < 0 || plan.fused_alphas.size() >= 8) return false; alpha = "alpha" + std::to_string(plan.fused_alphas.size()); plan.fused_alphas.push_back(nd.op_arg_pos); }
       body += "  float " + v + "[8];\n  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + v + "[e] = " + subst(t, x + "[e]", "", alpha) + ";\n";
     } else if (nd.kind == EQ_BINARY) {
       const char* t = binary_expr(nd.op);
-      if (!t || !operand(nd, 0, x) || !operand(nd, 1, y)) return false;
+      if (!t || !operand(nd, 0, x, body) || !operand(nd, 1, y, body)) return false;
       body += "  float " + v + "[8];\n  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + v + "[e] = " + subst(t, x + "[e]", y + "[e]", alpha) + ";\n";
     } else {
       if (nd.op != LIBXSMM_MELTW_TYPE_TERNARY_MULADD && nd.op != LIBXSMM_MELTW_TYPE_TERNARY_NMULADD) return false;
-      if (!operand(nd, 0, x) || !operand(nd, 1, y) || !operand(nd, 2, z)) return false;
+      if (!operand(nd, 0, x, body) || !operand(nd, 1, y, body) || !operand(nd, 2, z, body)) return false;
       body += "  float " + v + "[8];\n  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) { const float prod = " + x + "[e] * " + (nd.op == LIBXSMM_MELTW_TYPE_TERNARY_MULADD ? y : z) + "[e]; " + v + "[e] = " +
               (nd.op == LIBXSMM_MELTW_TYPE_TERNARY_MULADD ? z + "[e] + prod" : y + "[e] - prod") + "; }\n";
     }
-  }
+    return true;
+  };
+
+  scalar_value = [&](int id, std::string& name) -> bool {
+    const EqnNode& nd = e.nodes[id];
+    name = "s" + std::to_string(id);
+    if (nd.m != 1 || nd.n != 1) return false;
+    if (nd.kind == EQ_ARG) {
+      const int k = slot_of_arg(nd);
+      if (k < 0) return false;
+      phases += nd.type == LIBXSMM_DATATYPE_F32 ? "  const float " + name + " = ((GM const float*)in" + std::to_string(k) + ")[0];\n"
+                                                : "  const float " + name + " = __uint_as_float((unsigned int)((GM const unsigned short*)in" + std::to_string(k) + ")[0] << 16);\n";
+      return true;
+    }
+    if (nd.dtype != LIBXSMM_DATATYPE_F32) return false;
+    ScalarReduce r; r.src = -1; r.fold = 0; r.square = false;
+    const bool dot = nd.kind == EQ_BINARY && nd.op == LIBXSMM_MELTW_TYPE_BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD && nd.flags == 0;
+    if (dot || scalar_reduce(e, id, M, N, r)) {
+      std::string body, x, y, fold;
+      if (dot) {
+        if (e.nodes[nd.child[0]].m != M || e.nodes[nd.child[0]].n != N || !value(nd.child[0], 0, x, body) || !value(nd.child[1], 0, y, body)) return false;
+        fold = "{ const float prod = " + x + "[e] * " + y + "[e]; acc = acc + prod; }";
+      } else {
+        if (!value(r.src, 0, x, body)) return false;
+        fold = r.fold == 1 ? "acc = (acc < " + x + "[e]) ? " + x + "[e] : acc;" : r.fold == 2 ? "acc = (acc > " + x + "[e]) ? " + x + "[e] : acc;"
+             : r.square ? "{ const float sq = " + x + "[e] * " + x + "[e]; acc = acc + sq; }" : "acc = acc + " + x + "[e];";
+      }
+      const char* init = r.fold == 1 ? "-3.402823466e+38f" : r.fold == 2 ? "3.402823466e+38f" : "0.0f";      // [ref: mateltwise ref :1386,:1415]
+      const char* combine = r.fold == 1 ? "(acc < o) ? o : acc" : r.fold == 2 ? "(acc > o) ? o : acc" : "acc + o";
+      phases += "  float " + name + ";\n  { float acc = " + init + ";\n" + unit_loop + body + "  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + fold + "\n  }\n"
+                "  part[threadIdx.x] = acc; __syncthreads();\n"
+                "  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) { const float o = part[threadIdx.x + s]; acc = " + combine + "; part[threadIdx.x] = acc; } __syncthreads(); }\n"
+                "  " + name + " = part[0]; __syncthreads(); }\n";
+      return true;
+    }
+    // arithmetic on numbers (the reciprocal of a sum, ...): every operand is a number itself, broadcast flags say nothing new
+    std::string x, y, z;
+    if (nd.kind == EQ_UNARY) {
+      const char* t = unary_expr(nd.op);
+      if (!t || nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU || !scalar_value(nd.child[0], x)) return false;
+      phases += "  const float " + name + " = " + subst(t, x, "", "0.0f") + ";\n";
+    } else if (nd.kind == EQ_BINARY) {
+      const char* t = binary_expr(nd.op);
+      if (!t || !scalar_value(nd.child[0], x) || !scalar_value(nd.child[1], y)) return false;
+      phases += "  const float " + name + " = " + subst(t, x, y, "0.0f") + ";\n";
+    } else {
+      if ((nd.op != LIBXSMM_MELTW_TYPE_TERNARY_MULADD && nd.op != LIBXSMM_MELTW_TYPE_TERNARY_NMULADD) || !scalar_value(nd.child[0], x) || !scalar_value(nd.child[1], y) || !scalar_value(nd.child[2], z)) return false;
+      phases += nd.op == LIBXSMM_MELTW_TYPE_TERNARY_MULADD ? "  const float " + name + " = " + z + " + " + x + " * " + y + ";\n" : "  const float " + name + " = " + y + " - " + x + " * " + z + ";\n";
+    }
+    return true;
+  };
+
+  std::string body, head;
+  if (scalar_root) { if (M == 1 && N == 1) return false; if (!scalar_value(0, head)) return false; }
+  else if (!elem(0, body)) return false;
+  const bool phased = scalar_root || !phases.empty();
+  if (phased && units > 256 * 64) return false;      // one workgroup: beyond ~10^5 elements the chain of full-grid kernels is the faster form
   if (arg_types.empty() || arg_types.size() > 24) return false;
-  total = (long long)(M / 8) * N;
-  fname = std::string(dot_root ? "meqn_jit_dot_e" : "meqn_jit_e") + std::to_string(eqn_idx) + "_" + std::to_string(M) + "x" + std::to_string(N) + "_o" + std::to_string((int)out.type);
+  total = phased ? 256 : units;
+  fname = std::string(phased ? "meqn_jit_r" : "meqn_jit_e") + std::to_string(eqn_idx) + "_" + std::to_string(M) + "x" + std::to_string(N) + "_o" + std::to_string((int)out.type);
   src = kFusedPrelude;
   src += "extern \"C\" __global__ __launch_bounds__(256) void " + fname + "(";
   for (size_t k = 0; k < arg_types.size(); ++k) src += "const void* in" + std::to_string(k) + ", ";
   src += "void* out";
   for (size_t k = 0; k < plan.fused_alphas.size(); ++k) src += ", float alpha" + std::to_string(k);
+  for (size_t k = 0; k < plan.fused_dumps.size(); ++k) src += ", void* dump" + std::to_string(k);
   src += ") {\n";
-  if (dot_root) {
-    std::snprintf(buf, sizeof(buf), "  __shared__ float part[256];\n  float acc = 0.0f;\n  for (long long t = threadIdx.x; t < %lldLL; t += 256) {\n  const long long j = t / %d, i = (t - j * %d) * 8;\n", total, M / 8, M / 8);
-    src += buf;
-    src += body;
-    src += "  }\n  part[threadIdx.x] = acc;\n  __syncthreads();\n"
-           "  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) part[threadIdx.x] = part[threadIdx.x] + part[threadIdx.x + s]; __syncthreads(); }\n";
-    src += out.type == LIBXSMM_DATATYPE_F32 ? "  if (threadIdx.x == 0) *(GM float*)out = part[0];\n}\n"
-                                            : "  if (threadIdx.x == 0) *(GM unsigned short*)out = (unsigned short)(f2bf_pk(part[0], 0.0f) & 0xffffu);\n}\n";
-    total = 256;      // one workgroup
+  const std::string store = std::string("  ") + (out.type == LIBXSMM_DATATYPE_F32 ? "st_f32((GM float*)" : "st_bf16((GM unsigned short*)") + "out + i + j * " + std::to_string((int)out.ld) + "LL, v0);\n";
+  if (phased) {
+    src += "  __shared__ float part[256];\n" + phases;
+    if (scalar_root) src += out.type == LIBXSMM_DATATYPE_F32 ? "  if (threadIdx.x == 0) *(GM float*)out = " + head + ";\n}\n"
+                                                             : "  if (threadIdx.x == 0) *(GM unsigned short*)out = (unsigned short)(f2bf_pk(" + head + ", 0.0f) & 0xffffu);\n}\n";
+    else src += unit_loop + body + store + "  }\n}\n";
   } else {
-  std::snprintf(buf, sizeof(buf), "  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n  if (t >= %lldLL) return;\n  const long long j = t / %d, i = (t - j * %d) * 8;\n", total, M / 8, M / 8);
-  src += buf;
-  src += body;
-  std::snprintf(buf, sizeof(buf), "  %s((GM %s*)out + i + j * %dLL, v0);\n}\n", out.type == LIBXSMM_DATATYPE_F32 ? "st_f32" : "st_bf16", out.type == LIBXSMM_DATATYPE_F32 ? "float" : "unsigned short", (int)out.ld);
-  src += buf;
+    std::snprintf(buf, sizeof(buf), "  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n  if (t >= %lldLL) return;\n  const long long j = t / %d, i = (t - j * %d) * 8;\n", units, M / 8, M / 8);
+    src += buf;
+    src += body + store + "}\n";
   }
   for (auto& a : arg_types) {
     plan.fused_inputs.push_back(a.first);
@@ -373,7 +475,7 @@ void run_meqn(EqnPlan* plan, const void* param) {
   const libxsmm_meqn_param* p = (const libxsmm_meqn_param*)param;
   if (!p->inputs || !p->output.primary) { set_error(-2, "matrix equation called without inputs / output"); return; }
   if (plan->fused && jit_on_current_device(plan->fused)) {
-    const void* ptrs[24]; float alphas[8]; void* args[33]; int na = 0; bool ok = true;
+    const void* ptrs[24]; float alphas[8]; void* args[37]; int na = 0; bool ok = true;
     rt_scratch_reset();
     for (size_t i = 0; i < plan->fused_inputs.size(); ++i) {
       ptrs[i] = p->inputs[plan->fused_inputs[i]].primary;
@@ -388,6 +490,11 @@ void run_meqn(EqnPlan* plan, const void* param) {
     for (size_t i = 0; i < plan->fused_alphas.size() && ok; ++i) {
       if (!p->ops_args || !p->ops_args[plan->fused_alphas[i]].primary) { set_error(-2, "matrix equation: op argument %d is NULL", plan->fused_alphas[i]); return; }
       alphas[i] = *(const float*)p->ops_args[plan->fused_alphas[i]].primary; args[na++] = (void*)&alphas[i];
+    }
+    void* dumps[4];
+    for (size_t i = 0; i < plan->fused_dumps.size() && ok; ++i) {
+      if (!p->ops_args || !p->ops_args[plan->fused_dumps[i]].primary) { set_error(-2, "matrix equation: DUMP destination (op argument %d) is NULL", plan->fused_dumps[i]); return; }
+      dumps[i] = p->ops_args[plan->fused_dumps[i]].primary; ok = ok && (((size_t)dumps[i]) & 15) == 0; args[na++] = (void*)&dumps[i];
     }
     if (ok) { rt_finish_launch(jit_launch(plan->fused, args, rt_stream()), "meqn_jit"); return; }
   }
@@ -628,7 +735,8 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
     if (generate_fused(*e, out, idx, src, fname, probe, total)) {
       std::string why;
       plan->fused = jit_compile(src, fname, total, 16, &why);
-      if (plan->fused) { plan->fused_inputs = probe.fused_inputs; plan->fused_scalar = probe.fused_scalar; plan->fused_alphas = probe.fused_alphas; }
+      if (!plan->fused && std::getenv("LIBXSMM_HIP_JIT_VERBOSE")) std::fprintf(stderr, "libxsmm_amd: generated equation kernel did not compile: %s\n%s\n", why.c_str(), src.c_str());
+      if (plan->fused) { plan->fused_inputs = probe.fused_inputs; plan->fused_scalar = probe.fused_scalar; plan->fused_alphas = probe.fused_alphas; plan->fused_dumps = probe.fused_dumps; }
     }
   }
   const void* h = rt_new_meqn_handle(plan);

@@ -120,6 +120,19 @@ CASES = {
                       [(64, 12, 128, DT.BF16), (64, 12, 64, DT.BF16)], (1, 1, 1, DT.F32)),
     "mul_dot_to_scalar": (("b", BINARY.MUL_AND_REDUCE_TO_SCALAR_OP_ADD, 0, ("b", BINARY.MUL, 0, A(0), A(1)), A(2)),
                           [(M, N, LD, DT.F32), (M, N, M, DT.F32), (M, N, LD, DT.F32)], (1, 1, 1, DT.F32)),
+    # equation_softmax.c:527-538 without the DUMP: exp(x - max x) / sum exp(x - max x), both reductions (COLS then ROWS) to one number inside the tree
+    "softmax_fwd": (("b", BINARY.MUL, BINARY_FLAG.BCAST_SCALAR_IN_1,
+                     ("u", UNARY.EXP, 0, ("b", BINARY.SUB, BINARY_FLAG.BCAST_SCALAR_IN_1, A(0), ("u", UNARY.REDUCE_X_OP_MAX, UNARY_FLAG.REDUCE_ROWS, ("u", UNARY.REDUCE_X_OP_MAX, UNARY_FLAG.REDUCE_COLS, A(0))))),
+                     ("u", UNARY.RECIPROCAL, 0, ("u", UNARY.REDUCE_X_OP_ADD, UNARY_FLAG.REDUCE_ROWS, ("u", UNARY.REDUCE_X_OP_ADD, UNARY_FLAG.REDUCE_COLS,
+                      ("u", UNARY.EXP, 0, ("b", BINARY.SUB, BINARY_FLAG.BCAST_SCALAR_IN_1, A(0), ("u", UNARY.REDUCE_X_OP_MAX, UNARY_FLAG.REDUCE_ROWS, ("u", UNARY.REDUCE_X_OP_MAX, UNARY_FLAG.REDUCE_COLS, A(0))))))))),
+                    [(64, 12, 128, DT.BF16)], (64, 12, 64, DT.BF16)),
+    # equation_softmax.c:676-688: a1 - (sum a0) * a0... as NMULADD with the sum broadcast into operand 0
+    "softmax_bwd": (("t", TERNARY.NMULADD, TERNARY_FLAG.BCAST_SCALAR_IN_0 | TERNARY_FLAG.REUSE_IN_2_AS_OUT,
+                     ("u", UNARY.REDUCE_X_OP_ADD, UNARY_FLAG.REDUCE_ROWS, ("u", UNARY.REDUCE_X_OP_ADD, UNARY_FLAG.REDUCE_COLS, A(0))), A(0), A(1)),
+                    [(M, N, M, DT.F32), (M, N, LD, DT.F32)], (M, N, LD, DT.F32)),
+    # the sum of squares of an expression as the head: one number out
+    "sum_of_squares": (("u", UNARY.REDUCE_X_OP_ADD, UNARY_FLAG.REDUCE_ROWS, ("u", UNARY.REDUCE_X2_OP_ADD, UNARY_FLAG.REDUCE_COLS, ("b", BINARY.SUB, 0, A(0), A(1)))),
+                       [(M, N, LD, DT.F32), (M, N, M, DT.F32)], (1, 1, 1, DT.F32)),
     "mixed_precision": (("b", BINARY.SUB, 0, ("u", UNARY.X2, 0, A(0)), ("b", BINARY.MUL, BINARY_FLAG.BCAST_SCALAR_IN_1, A(1), A(2))),
                         [(M, N, LD, DT.BF16), (M, N, M, DT.F32), (1, 1, 1, DT.F32)], (M, N, LD, DT.BF16)),
 }
@@ -173,8 +186,11 @@ def test_incomplete_and_unsupported_equations_return_null(api):
 
 
 # device tanhf / the matrix core's summation order / the tree-shaped sum of a dot product: not bit-identical
-BY_NORM = {"tanh_sigmoid_chain": 1e-6, "matmul_mul": 1e-6, "matmul_vnni_bf16": 8e-3, "dot_to_scalar": 2e-5, "mul_dot_to_scalar": 2e-5}
-FUSABLE = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain", "layernorm_affine", "dot_to_scalar", "mul_dot_to_scalar"}     # no reduction below the head
+BY_NORM = {"tanh_sigmoid_chain": 1e-6, "matmul_mul": 1e-6, "matmul_vnni_bf16": 8e-3, "dot_to_scalar": 2e-5, "mul_dot_to_scalar": 2e-5,
+           "softmax_fwd": 8e-3, "softmax_bwd": 1e-5, "sum_of_squares": 1e-5}
+# reductions only where they end in ONE number (a phase of the one-workgroup kernel); vector-valued reductions inside a tree stay a chain
+FUSABLE = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain", "layernorm_affine", "dot_to_scalar", "mul_dot_to_scalar",
+           "softmax_fwd", "softmax_bwd", "sum_of_squares"}
 
 
 @pytest.mark.gpu
@@ -220,7 +236,8 @@ def test_gpu_meqn_matches_oracle_composition(name, jit):
 
 
 @pytest.mark.gpu
-def test_gpu_meqn_dump_writes_the_intermediate_to_the_op_argument():
+@pytest.mark.parametrize("jit", [0, 2], ids=["tpp_chain", "fused_jit"])
+def test_gpu_meqn_dump_writes_the_intermediate_to_the_op_argument(jit):
     """UNARY_DUMP inside a tree = identity whose value also lands in ops_args[op_arg_pos].primary (the intermediate's own
     leading dimension and type) [ref: src/generator_matequation_reference_impl.c:58-60, mateltwise ref :2478-2494] -- the
     mechanism equation_softmax.c uses to keep exp(x - max) for the backward pass."""
@@ -234,8 +251,11 @@ def test_gpu_meqn_dump_writes_the_intermediate_to_the_op_argument():
     assert api.meqn_push_back_unary_op(capi.MeqnMetadata(idx, -1), UNARY.X2, DT.F32, 0) == 0
     assert api.meqn_push_back_arg(capi.MeqnMetadata(idx, 0), capi.MeqnArgShape(*shapes[0]), SINGULAR) == 0
     assert api.meqn_push_back_arg(capi.MeqnMetadata(idx, 1), capi.MeqnArgShape(*shapes[1]), SINGULAR) == 0
+    api.hip_set_jit(jit)
     h = api.dispatch_meqn(idx, capi.MeqnArgShape(*out_shape))
+    api.hip_set_jit(1)
     assert h
+    assert api.hip_kernel_name(h, 0).decode().startswith("meqn_jit") == (jit == 2)      # the generated kernel stores the second image itself
     dev = [torch.from_numpy(a.copy()).to("cuda:0") for a in arrays]
     out = torch.zeros(LD * N, dtype=torch.float32, device="cuda:0")
     dump = torch.full((M * N,), -7.0, dtype=torch.float32, device="cuda:0")          # the intermediate is M x N with ld = M
@@ -284,6 +304,59 @@ def test_gpu_meqn_scalar_arguments_may_live_in_host_memory(jit):
 
 
 # ---- MATMUL / BRGEMM and GATHER nodes (samples/equation/equation_matmul.c, equation_gather_reduce.c) ------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("jit", [0, 2], ids=["tpp_chain", "fused_jit"])
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16], ids=["f32", "bf16"])
+def test_gpu_meqn_softmax_forward_reads_back_what_its_dump_node_wrote(dt, jit):
+    """The forward tree of samples/equation/equation_softmax.c:527-538 as the driver builds it: the head multiplies ARGUMENT 0 -- the very buffer
+    the DUMP node below the sum writes exp(x - max) to -- with the reciprocal of the sum.  One generated kernel: a max phase, a phase that
+    writes the exponentials and sums them, and the scaling phase in which every thread reads back its own units."""
+    import torch
+    api = capi.load()
+    m, n, ld = 64, 12, 128
+    x = rand_values(np.random.default_rng(21), ld * n, dt)
+    idx = api.meqn_create()
+    OP, DUMP_AT = capi.MeqnMetadata(idx, -1), capi.MeqnMetadata(idx, 31)
+    rows, cols = UNARY_FLAG.REDUCE_ROWS, UNARY_FLAG.REDUCE_COLS
+    assert api.meqn_push_back_binary_op(OP, BINARY.MUL, DT.F32, BINARY_FLAG.BCAST_SCALAR_IN_1) == 0
+    assert api.meqn_push_back_arg(capi.MeqnMetadata(idx, 0), capi.MeqnArgShape(m, n, m, DT.F32), SINGULAR) == 0
+    assert api.meqn_push_back_unary_op(OP, UNARY.RECIPROCAL, DT.F32, 0) == 0
+    assert api.meqn_push_back_unary_op(OP, UNARY.REDUCE_X_OP_ADD, DT.F32, rows) == 0
+    assert api.meqn_push_back_unary_op(OP, UNARY.REDUCE_X_OP_ADD, DT.F32, cols) == 0
+    assert api.meqn_push_back_unary_op(DUMP_AT, UNARY.DUMP, DT.F32, 0) == 0
+    assert api.meqn_push_back_unary_op(OP, UNARY.EXP, DT.F32, 0) == 0
+    assert api.meqn_push_back_binary_op(OP, BINARY.SUB, DT.F32, BINARY_FLAG.BCAST_SCALAR_IN_1) == 0
+    assert api.meqn_push_back_arg(capi.MeqnMetadata(idx, 1), capi.MeqnArgShape(m, n, ld, dt), SINGULAR) == 0
+    assert api.meqn_push_back_unary_op(OP, UNARY.REDUCE_X_OP_MAX, DT.F32, rows) == 0
+    assert api.meqn_push_back_unary_op(OP, UNARY.REDUCE_X_OP_MAX, DT.F32, cols) == 0
+    assert api.meqn_push_back_arg(capi.MeqnMetadata(idx, 1), capi.MeqnArgShape(m, n, ld, dt), SINGULAR) == 0
+    api.hip_set_jit(jit)
+    h = api.dispatch_meqn(idx, capi.MeqnArgShape(m, n, ld, dt))
+    api.hip_set_jit(1)
+    assert h
+    assert api.hip_kernel_name(h, 0).decode().startswith("meqn_jit_r") == (jit == 2)
+    view = lambda a: a.view(np.int16) if a.dtype == np.uint16 else a
+    dx = torch.from_numpy(view(x).copy()).to("cuda:0")
+    kept = torch.zeros(m * n, dtype=torch.float32, device="cuda:0")
+    out = torch.zeros(ld * n, dtype=torch.int16 if dt == DT.BF16 else torch.float32, device="cuda:0")
+    inputs = (capi.MatrixArg * 2)()
+    inputs[0].primary, inputs[1].primary = kept.data_ptr(), dx.data_ptr()
+    ops = (capi.MatrixOpArg * 32)()
+    ops[31].primary = kept.data_ptr()
+    p = capi.MeqnParam()
+    p.inputs, p.ops_args = inputs, ops
+    p.output.primary = out.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    xf = _valid(_f32(x, dt), (m, n, ld, dt)).astype(np.float64)
+    ex = np.exp(xf - xf.max())
+    want = ex / ex.sum()
+    got = _valid(_f32(out.cpu().numpy().view(NPDT[dt]), dt), (m, n, ld, dt))
+    assert np.abs(kept.cpu().numpy().reshape(n, m) - ex).max() < 1e-6 * ex.max()
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < (4e-3 if dt == DT.BF16 else 1e-6)
+    assert abs(float(got.sum()) - 1.0) < (2e-2 if dt == DT.BF16 else 1e-5)
+
+
 def _f32(bits_or_f32, dt):
     return bits_or_f32 if dt == DT.F32 else (bits_or_f32.astype(np.uint32) << 16).view(np.float32)
 
