@@ -809,6 +809,157 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, uns
   });
 }
 
+// 8-bit integers with the A operand on an LDS-DMA ring (the structure of bcsc_mfma_bf16_dma_kernel, re-cut for bytes).  A chunk is 32 k of the
+// wave's 64 rows: [8 k-quads][64 i] dwords = 2 KiB = two global_load_lds_dwordx4; rows of odd k-groups are rotated by 16 words on the source
+// side, so the operand reads (lane (row, kg): rows 2 kg and 2 kg + 1) are conflict-free ds_read_b32.  The used k-blocks of a k-group are
+// compacted into a list first, which makes "chunk c" addressable: the ring runs D chunks ahead and the B
+// fragments travel with it in a register ring.  s_waitcnt counts in order, so every chunk issues the SAME number of memory instructions --
+// absent blocks load one (wave-uniform) dummy address -- and the wait before chunk c is the static (4 + NI) x (chunks still in flight behind it).
+// Full 64 x 64 tiles leave through the idle ring: a lane holds 4 rows of one column (16-byte pieces of 64 different lines); transposed in
+// LDS, 16 lanes write one column's 256 bytes.
+template <int BN16, bool UA, int AUX_A, int D, int WPS, int RT>     // RT: 16-row tiles per wave (4: 64 x 64 of C per wave, 2: 32 x 64)
+__global__ __launch_bounds__(256, WPS) void bcsc_mfma_i8_dma_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int total, const unsigned int* gtable) {
+  constexpr int NBL = 4 / BN16, W = 16 * RT, SPR = 4 * RT, NI = RT / 2;      // W: words per image row, SPR: 16-byte slots per row, NI: DMA instructions per chunk
+  __shared__ unsigned int tbl_all[4][kBcscTblDma];
+  __shared__ unsigned int klist_all[4][64];
+  __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][D][8 * W];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = blockIdx.x * 4u + wave;
+  if (wid >= total) return;
+  unsigned int* tbl = tbl_all[wave];
+  unsigned int* klist = klist_all[wave];
+  unsigned int (*abuf)[8 * W] = abuf_all[wave];
+  const unsigned int tn = wid % tiles_n, tmp = wid / tiles_n, ti = tmp % tiles_i, mb = tmp / tiles_i;
+  const int lane = threadIdx.x & 63, lx = lane & 15, kg = lane >> 4;
+  const int i0 = (int)ti * (16 * RT), n0 = (int)tn * 64;
+  const int mt = (p.M - i0 >= 16 * RT) ? RT : (p.M - i0) / 16;
+  const int nbl_cnt = ((p.N - n0 >= 64) ? 64 : (p.N - n0)) / (16 * BN16);
+  const int nb0 = n0 / (16 * BN16);
+  const int nkb = p.K / p.bk, steps = p.bk / 32;
+  {
+    GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb;
+    for (int e = lane; e < nbl_cnt * nkb; e += 64) tbl[e] = gt[e];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  i32x4v acc[4][RT], corr_b[4], corr_a[NBL][RT];
+  GM int* cbase = (GM int*)p.c + (long long)mb * p.N * p.M;
+  sfor<4 * RT>([&](auto ic) {
+    constexpr int nt = ic.value / RT, it = ic.value % RT;
+    acc[nt][it] = (i32x4v)0;
+    if (!p.beta0 && it < mt && nt < nbl_cnt * BN16) acc[nt][it] = *(GM const i32x4v*)(cbase + (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg);
+  });
+  sfor<4>([&](auto c) { corr_b[c.value] = (i32x4v)0; });
+  sfor<NBL * RT>([&](auto c) { corr_a[c.value / RT][c.value % RT] = (i32x4v)0; });
+  const long long ones = 0x0101010101010101ll;
+  // DMA source of LDS slot (lane + 64x): k-quad row = slot >> 4, the 16-byte group that lands there = (slot & 15) rotated back
+  GM const unsigned int* A4 = (GM const unsigned int*)p.a + (long long)mb * (p.K / 4) * p.M + i0;
+  unsigned int src_off[NI];
+#pragma unroll
+  for (int x = 0; x < NI; ++x) {
+    const unsigned int S = (unsigned int)lane + 64u * x, row = S / SPR, g = ((S % SPR) - 4u * ((row >> 1) & 1u)) & (unsigned int)(SPR - 1);
+    src_off[x] = row * (unsigned int)p.M + (((int)(4u * g) < 16 * mt) ? 4u * g : 0u);       // groups beyond the wave's rows re-read group 0 (never consumed)
+  }
+  const int rot = 16 * (kg & 1);
+  GM const char* bv = (GM const char*)p.bvals;
+  for (int kgp = 0; kgp < nkb; kgp += 64) {
+    bool used = false;
+    const int kb_l = kgp + lane;
+    if (kb_l < nkb) for (int nbl = 0; nbl < nbl_cnt; ++nbl) used = used || (tbl[nbl * nkb + kb_l] != 0xffffffffu);
+    const unsigned long long mask = __ballot(used);
+    if (mask == 0ull) continue;
+    if (used) klist[__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (unsigned int)kb_l;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int nch = __builtin_popcountll(mask) * steps;
+    unsigned int blk_r[D][NBL]; long long bf_r[D][NBL][BN16];
+    auto issue = [&](auto uc, int c) {        // chunk c -> ring position u: its B fragments first (older), then the two DMA instructions
+      constexpr int u = decltype(uc)::value;
+      const int q = c / steps, st_ = c - q * steps;
+      const int kb_ = __builtin_amdgcn_readfirstlane((int)klist[q]);
+      sfor<NBL>([&](auto nc) {
+        constexpr int nbl = nc.value;
+        blk_r[u][nbl] = (nbl < nbl_cnt) ? (unsigned int)__builtin_amdgcn_readfirstlane((int)tbl[nbl * nkb + kb_]) : 0xffffffffu;
+        sfor<BN16>([&](auto sc) { constexpr int s2 = sc.value;
+          GM const char* src = (blk_r[u][nbl] != 0xffffffffu) ? bv + ((long long)blk_r[u][nbl] * (16 * BN16) + 16 * s2 + lx) * p.bk + 32 * st_ + 8 * kg : bv;
+          bf_r[u][nbl][s2] = *(GM const long long*)src; });
+      });
+      GM const unsigned int* rowbase = A4 + ((long long)kb_ * (p.bk / 4) + 8 * st_) * p.M;
+#pragma unroll
+      for (int x = 0; x < NI; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)((char*)abuf[u] + 1024 * x), 16, 0, AUX_A);
+    };
+    sfor<D>([&](auto uc) { if (uc.value < nch) issue(uc, uc.value); });
+    for (int c0 = 0; c0 < nch; c0 += D) {
+      sfor<D>([&](auto uc) {
+        constexpr int u = uc.value;
+        const int c = c0 + u;
+        if (c < nch) {
+          const int behind = (nch - 1 - c < D - 1) ? nch - 1 - c : D - 1;          // chunks issued after c: each is 4 / BN16 * BN16 = 4 loads + NI DMA
+          if (D > 3 && behind == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (4 + NI)) : "memory");
+          else if (D > 2 && behind == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (4 + NI)) : "memory");
+          else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + NI) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          long long a_cur[RT];
+          sfor<RT>([&](auto tc) {
+            constexpr int t = tc.value;
+            if (t < mt) {
+              unsigned int lo = abuf[u][(2 * kg) * W + ((16 * t + lx + rot) & (W - 1))], hi = abuf[u][(2 * kg + 1) * W + ((16 * t + lx + rot) & (W - 1))];
+              if (UA) { lo ^= 0x80808080u; hi ^= 0x80808080u; }
+              a_cur[t] = (long long)(((unsigned long long)hi << 32) | lo);
+            }
+          });
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          unsigned int blk_c[NBL]; long long bf_c[NBL][BN16];
+          sfor<NBL>([&](auto nc) { blk_c[nc.value] = blk_r[u][nc.value]; sfor<BN16>([&](auto sc) { bf_c[nc.value][sc.value] = bf_r[u][nc.value][sc.value]; }); });
+          if (c + D < nch) issue(uc, c + D);                                          // the image just read is free again
+          sfor<NBL>([&](auto nc) {
+            constexpr int nbl = nc.value;
+            if (blk_c[nbl] != 0xffffffffu) {
+              sfor<BN16>([&](auto sc) {
+                constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
+                long long bfrag = bf_c[nbl][s2];
+                if (!UA) bfrag ^= (long long)0x8080808080808080ull;
+                sfor<RT>([&](auto tc) { constexpr int t = tc.value; if (t < mt) acc[nt][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_cur[t], bfrag, acc[nt][t], 0, 0, 0); });
+                if (UA) corr_b[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(ones, bfrag, corr_b[nt], 0, 0, 0);
+              });
+              if (!UA) sfor<RT>([&](auto tc) { constexpr int t = tc.value; if (t < mt) corr_a[nbl][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_cur[t], ones, corr_a[nbl][t], 0, 0, 0); });
+            }
+          });
+        }
+      });
+    }
+  }
+  if (mt == RT && nbl_cnt * BN16 == 4 && (p.M % 4) == 0) {
+    static_assert(D >= 2, "the C tile passes through two chunk images");
+    unsigned int* tile = &abuf[0][0];                       // 16 columns x 16 RT rows of int32 per pass (two chunk images)
+    sfor<4>([&](auto nc) {
+      constexpr int nt = nc.value;
+      sfor<RT>([&](auto tc) {
+        constexpr int it = tc.value;
+        i32x4v v = acc[nt][it];
+        if (UA) v += corr_b[nt] * 128; else v += corr_a[nt / BN16][it] * 128;
+        *(i32x4v*)(tile + lx * W + 4 * ((4 * it + kg) ^ (lx & (SPR - 1)))) = v;
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {                         // SPR lanes write one column's 16 RT rows as whole lines
+        const int n = (64 / SPR) * r + lane / SPR, j = lane % SPR;
+        const i32x4v w = *(const i32x4v*)(tile + n * W + 4 * (j ^ (n & (SPR - 1))));
+        *(GM i32x4v*)(cbase + (long long)(n0 + 16 * nt + n) * p.M + i0 + 4 * j) = w;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+    return;
+  }
+  sfor<4 * RT>([&](auto ic) {
+    constexpr int nt = ic.value / RT, it = ic.value % RT;
+    if (it < mt && nt < nbl_cnt * BN16) {
+      i32x4v v = acc[nt][it];
+      if (UA) v += corr_b[nt] * 128; else v += corr_a[nt / BN16][it] * 128;
+      *(GM i32x4v*)(cbase + (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg) = v;
+    }
+  });
+}
+
 int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
   BcscArgs a = a_in;
@@ -882,6 +1033,24 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
       if (total < (1ll << 31)) {
         const dim3 grid((unsigned int)((total + 3) / 4));
         const bool ua = a.a_type == LIBXSMM_DATATYPE_U8;
+        static const bool dma = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_DMA"); return !(e && e[0] == '0'); }();
+        if (dma && a.table != nullptr && (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTblDma && ((size_t)a.a % 16 == 0) && (a.M % 4 == 0) && ((long long)(a.K / 4) * a.M < (1ll << 30))) {
+          const int nkb = a.K / a.bk;
+          const unsigned int* table = (const unsigned int*)a.table;
+          if (!a.table_ready) hipLaunchKernelGGL(bcsc_invert_kernel, dim3((unsigned int)a.nblk_n), dim3(64), 0, st, a.colptr, a.rowidx, (unsigned int*)a.table, a.nblk_n, nkb);
+#define LAUNCH_I8D_(B_) do { \
+    if (ua) { if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, true, 2, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); \
+              else hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, true, 0, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); } \
+    else { if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, false, 2, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); \
+           else hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, false, 0, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); } } while (0)
+          // ring depth 2, three waves per SIMD (141 VGPRs), 64 rows per wave -- measured on 8192 M-blocks of 64 x 256 (2:8, bn = 16): depth 2 / 3 / 4 at two waves
+          // per SIMD 60.5 / 61.2 / 61.2 us, three waves per SIMD 56.0 us; 32 rows per wave (104 VGPRs, four waves per SIMD) 60.5 us: twice the B loads and
+          // per-wave set-up outweigh the occupancy (profiles/r02_bcsc_counters.txt)
+          if (a.bn == 16) LAUNCH_I8D_(1); else if (a.bn == 32) LAUNCH_I8D_(2); else LAUNCH_I8D_(4);
+#undef LAUNCH_I8D_
+          if (name) *name = "bcsc_mfma_i8_dma_kernel";
+          return (int)hipGetLastError();
+        }
 #define LAUNCH_I8_(B_) do { if (ua) hipLaunchKernelGGL((bcsc_mfma_i8_kernel<B_, true>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total); \
                             else hipLaunchKernelGGL((bcsc_mfma_i8_kernel<B_, false>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total); } while (0)
         if (a.bn == 16) LAUNCH_I8_(1); else if (a.bn == 32) LAUNCH_I8_(2); else LAUNCH_I8_(4);

@@ -378,7 +378,8 @@ def test_packed_csc_csparse(M, N, K, P, density, beta0):
 # 8-bit integers (u8 x i8 -> i32 and i8 x u8 -> i32, A in VNNI-4): exact, so the bar is bit equality
 @pytest.mark.parametrize("a_type", [DT.U8, DT.I8])
 @pytest.mark.parametrize("M,N,K,mb,bk,bn,keep,beta0", [(64, 64, 256, 6, 32, 16, 0.25, 1), (64, 64, 256, 3, 32, 32, 0.25, 0), (16, 24, 40, 4, 8, 8, 0.5, 1), (32, 32, 64, 2, 16, 4, 0.42, 0),
-                                                       (48, 80, 128, 3, 64, 16, 0.3, 0), (64, 128, 128, 2, 32, 64, 0.5, 1), (80, 96, 96, 5, 32, 32, 0.34, 1), (64, 64, 512, 40, 64, 16, 0.25, 0)])
+                                                       (48, 80, 128, 3, 64, 16, 0.3, 0), (64, 128, 128, 2, 32, 64, 0.5, 1), (80, 96, 96, 5, 32, 32, 0.34, 1), (64, 64, 512, 40, 64, 16, 0.25, 0),
+                                                       (64, 64, 2560, 2, 32, 64, 0.3, 0), (64, 128, 256, 3, 32, 16, 0.06, 1), (128, 64, 1024, 2, 128, 32, 0.4, 0)])
 def test_bcsc_int8(a_type, M, N, K, mb, bk, bn, keep, beta0):
     api, orc = capi.load(), pyoracle.oracle()
     rng = np.random.default_rng(12)
