@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 ONLY=${1:-bcsc}
 O=$R/gpurun_out/${2:-pmc_paths}
 rm -rf $O; mkdir -p $O
-B="python $R/tools/bench_paths.py --only $ONLY --steps 3"
+B="python $R/tools/bench_paths.py --only $ONLY --eager 3"   # --eager: a few plain launches per workload (the timed replay loop under counter collection takes minutes)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/p1 -- $B > $O/p1.out 2> $O/p1.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAVES --kernel-trace --output-format csv -d $O/p2 -- $B > $O/p2.out 2> $O/p2.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/p3 -- $B > $O/p3.out 2> $O/p3.err
