@@ -2430,7 +2430,23 @@ __global__ __launch_bounds__(256) void gemm_mx_stream_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 // host-side selection
 // ------------------------------------------------------------------------------------------------
-bool gemm_supported(const libxsmm_gemm_descriptor& d) {
+bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
+  libxsmm_gemm_descriptor d = d_in;
+  if (d.flags & LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) {
+    // A arrives as (non-zeros, one bit per element) [ref: gemm ref :857-948]: one plain GEMM (no batch-reduce, no transposes, no fused
+    // operators), f32 or 16-bit operands; the 16-bit image is the VNNI-2 one whatever the flag says, and its leading dimension is m.
+    // Expanded on the device into a dense image, then the dense kernel of the equivalent descriptor runs.
+    const bool f32x = d.a_type == LIBXSMM_DATATYPE_F32 && d.b_type == LIBXSMM_DATATYPE_F32 && d.c_type == LIBXSMM_DATATYPE_F32;
+    const bool h16 = (d.a_type == LIBXSMM_DATATYPE_BF16 || d.a_type == LIBXSMM_DATATYPE_F16) && d.b_type == d.a_type && (d.c_type == d.a_type || d.c_type == LIBXSMM_DATATYPE_F32);
+    if (!f32x && !h16) return false;
+    if (d.flags & (LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_STRIDE |
+                   LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) return false;
+    const int kb = f32x ? 1 : 2;
+    if ((d.k % kb) != 0 || (((long long)d.m * kb) & 7) != 0 || (long long)d.m * d.k >= (1ll << 31)) return false;
+    d.flags &= ~(unsigned int)LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK;
+    if (h16) d.flags |= LIBXSMM_GEMM_FLAG_VNNI_A;
+    d.lda = d.m;
+  }
   const bool f32 = d.a_type == LIBXSMM_DATATYPE_F32 && d.b_type == LIBXSMM_DATATYPE_F32 && d.c_type == LIBXSMM_DATATYPE_F32;
   const bool f64 = d.a_type == LIBXSMM_DATATYPE_F64 && d.b_type == LIBXSMM_DATATYPE_F64 && d.c_type == LIBXSMM_DATATYPE_F64;
   const bool bf16 = d.a_type == LIBXSMM_DATATYPE_BF16 && d.b_type == LIBXSMM_DATATYPE_BF16 &&
@@ -2796,6 +2812,70 @@ static bool bf16_stream_ok(const GemmArgs& a) {
   const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0);
   if (abits & 3ull) return false;
   return (long long)a.lda * a.k * 2 < (1ll << 31) && (long long)a.ldb * a.n * 2 < (1ll << 31);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK: A = (non-zeros in memory order, one bit per element).  Row s of the bit matrix (the
+// k-group s: m * kb elements) starts at byte s * row_bytes.  Three small passes expand it to the dense image the dense kernels read:
+// set bits per row -> exclusive scan over the rows -> one workgroup per row places its values (or zeros).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void bitmask_row_count_kernel(const unsigned char* bitmap_, unsigned int* count, int row_bytes) {
+  GM const unsigned char* row = (GM const unsigned char*)bitmap_ + (long long)blockIdx.x * row_bytes;
+  unsigned int c = 0;
+  for (int b = threadIdx.x; b < row_bytes; b += 64) c += (unsigned int)__builtin_popcount((unsigned int)row[b]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (threadIdx.x == 0) ((GM unsigned int*)count)[blockIdx.x] = c;
+}
+__global__ __launch_bounds__(1024) void bitmask_row_scan_kernel(const unsigned int* count_, unsigned int* start_, int rows) {
+  __shared__ unsigned int part[1024];
+  GM const unsigned int* count = (GM const unsigned int*)count_; GM unsigned int* start = (GM unsigned int*)start_;
+  const int per = (rows + 1023) / 1024, r0 = (int)threadIdx.x * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+  unsigned int sum = 0;
+  for (int r = r0; r < r1; ++r) sum += count[r];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                     // inclusive scan of the 1024 partial sums
+    const unsigned int v = (threadIdx.x >= (unsigned int)o) ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned int at = part[threadIdx.x] - sum;
+  for (int r = r0; r < r1; ++r) { start[r] = at; at += count[r]; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bitmask_expand_kernel(const unsigned char* bitmap_, const T* vals_, T* dense_, const unsigned int* start_, int row_bytes) {
+  __shared__ unsigned int part[256];
+  GM const unsigned char* row = (GM const unsigned char*)bitmap_ + (long long)blockIdx.x * row_bytes;
+  GM const T* vals = (GM const T*)vals_ + ((GM const unsigned int*)start_)[blockIdx.x];
+  GM T* out = (GM T*)dense_ + (long long)blockIdx.x * row_bytes * 8;
+  const int per = (row_bytes + 255) / 256, b0 = (int)threadIdx.x * per, b1 = (b0 + per < row_bytes) ? b0 + per : row_bytes;
+  unsigned int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += (unsigned int)__builtin_popcount((unsigned int)row[b]);
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned int v = (threadIdx.x >= (unsigned int)o) ? part[threadIdx.x - o] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned int at = part[threadIdx.x] - sum;
+  for (int b = b0; b < b1; ++b) {
+    const unsigned int bits = row[b];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { T v = (T)0; if ((bits >> e) & 1u) v = vals[at++]; out[(long long)b * 8 + e] = v; }
+  }
+}
+int launch_bitmask_expand(const void* bitmap, const void* vals, void* dense, unsigned int* rows_scratch, int rows, int row_bytes, int elem_size, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  unsigned int* count = rows_scratch; unsigned int* start = rows_scratch + rows;
+  hipLaunchKernelGGL(bitmask_row_count_kernel, dim3((unsigned int)rows), dim3(64), 0, st, (const unsigned char*)bitmap, count, row_bytes);
+  hipLaunchKernelGGL(bitmask_row_scan_kernel, dim3(1), dim3(1024), 0, st, count, start, rows);
+  if (elem_size == 4) hipLaunchKernelGGL(bitmask_expand_kernel<unsigned int>, dim3((unsigned int)rows), dim3(256), 0, st, (const unsigned char*)bitmap, (const unsigned int*)vals, (unsigned int*)dense, start, row_bytes);
+  else hipLaunchKernelGGL(bitmask_expand_kernel<unsigned short>, dim3((unsigned int)rows), dim3(256), 0, st, (const unsigned char*)bitmap, (const unsigned short*)vals, (unsigned short*)dense, start, row_bytes);
+  return (int)hipGetLastError();
 }
 
 int launch_brsplit_reduce(const GemmArgs& a, const float* partial, int nsplit, void* stream) {

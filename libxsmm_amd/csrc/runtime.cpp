@@ -347,8 +347,57 @@ struct BatchSpec {
   const void* const* la = nullptr; const void* const* lb = nullptr; void* const* lc = nullptr;
 };
 
+// LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK [ref: gemm ref :535-556,857-948]: a.primary = the non-zeros of A, a.secondary = one bit per element.
+// The dense image is rebuilt in the workspace (three small launches), then the dense kernel of the equivalent descriptor runs on it.
+static void run_gemm_bitmask(KernelCtx* k, const libxsmm_gemm_param* p, const BatchSpec& b) {
+  const libxsmm_gemm_descriptor& d = k->g;
+  if (b.count != 1 || b.la) { set_error(-2, "a GEMM with bitmask-compressed A cannot be batched (its operand size differs per problem)"); return; }
+  if (!p->a.primary || !p->a.secondary || !p->b.primary || !p->c.primary) { set_error(-2, "GEMM with bitmask-compressed A: a.primary / a.secondary / b.primary / c.primary is NULL"); return; }
+  scratch_reset();
+  const int es = typesize(d.a_type), kb = (d.a_type == LIBXSMM_DATATYPE_F32) ? 1 : 2;
+  const int rows = (int)d.k / kb, row_bytes = (int)d.m * kb / 8;
+  const size_t bitmap_bytes = (size_t)rows * (size_t)row_bytes, dense_bytes = bitmap_bytes * 8 * (size_t)es;
+  GemmArgs a{};
+  const void* bitmap = p->a.secondary; const void* vals = p->a.primary;
+  a.b = (const char*)p->b.primary; a.c = (char*)p->c.primary;
+  if (staging_allowed(1)) {
+    hipPointerAttribute_t attr;
+    const bool host_bits = hipPointerGetAttributes(&attr, bitmap) != hipSuccess || attr.type == hipMemoryTypeUnregistered;
+    (void)hipGetLastError();
+    if (host_bits) {     // plain host memory: the length of the value array is the number of set bits, countable right here
+      size_t nnz = 0;
+      const unsigned char* hb = (const unsigned char*)bitmap;
+      for (size_t i = 0; i < bitmap_bytes; ++i) nnz += (size_t)__builtin_popcount(hb[i]);
+      bitmap = stage(bitmap, bitmap_bytes, true, false);
+      vals = stage(vals, std::max<size_t>(nnz, 1) * (size_t)es, true, false);
+    }
+    a.b = (const char*)stage(a.b, (size_t)d.ldb * (size_t)d.n * (size_t)typesize(d.b_type), true, false);
+    a.c = (char*)stage(a.c, (size_t)d.ldc * (size_t)d.n * (size_t)typesize(d.c_type), true, true);
+    if (!bitmap || !vals || !a.b || !a.c) return;
+  }
+  const size_t scratch_bytes = ((size_t)rows * 2 * sizeof(unsigned int) + 255) & ~(size_t)255;
+  char* ws = (char*)workspace(scratch_bytes + dense_bytes);
+  if (!ws) return;
+  int err = launch_bitmask_expand(bitmap, vals, ws + scratch_bytes, (unsigned int*)ws, rows, row_bytes, es, tls().stream);
+  const char* kname = nullptr;
+  if (err == 0) {
+    a.a = ws + scratch_bytes;
+    a.nbatch = 1; a.stream_hint = tls().stream_hint;
+    a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.lda = (int)d.m; a.ldb = (int)d.ldb; a.ldc = (int)d.ldc;
+    a.flags = (d.flags & ~(unsigned int)LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) | (kb == 2 ? (unsigned int)LIBXSMM_GEMM_FLAG_VNNI_A : 0u);
+    a.a_type = d.a_type; a.b_type = d.b_type; a.c_type = d.c_type;
+    a.br_count = 1; a.br_mode = 0;
+    rt_workspace_reserve(scratch_bytes + dense_bytes);     // a kernel that needs partial sums of its own places them behind the dense image
+    err = launch_gemm(a, tls().stream, &kname);
+    rt_workspace_reserve(0);
+  }
+  if (kname) k->kname_single = kname;
+  finish_launch(err, kname ? kname : "bitmask_expand");
+}
+
 void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   const libxsmm_gemm_descriptor& d = k->g;
+  if (d.flags & LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) { run_gemm_bitmask(k, (const libxsmm_gemm_param*)param, b); return; }
   const bool ext = (d.flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) != 0;
   const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;          // {op,a,b,c} prefix is common
   const libxsmm_gemm_ext_param* pe = (const libxsmm_gemm_ext_param*)param;

@@ -351,6 +351,50 @@ static void contract_mxmx(const gemm_view* v, const libxsmm_gemm_param* p, float
   }
 }
 
+/* A compressed by bitmask (LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) [ref: generator_gemm_reference_impl.c:857-948]: a.primary holds only the
+ * non-zeros, in the order k-group s, row i, k inside the group (= memory order of the VNNI image for 16-bit types); a.secondary holds one bit
+ * per element, row s of the bit matrix being m * kb bits (bit order: LSB first, mateltwise ref :170-178).  Products are added in that order,
+ * k ascending inside a pair -- NOT the high-half-first order of the dense 16-bit loop. */
+static void contract_spmm(const oracle_gemm_desc* d, const libxsmm_gemm_param* p, int beta0) {
+  const int m = d->m, n = d->n, k = d->k;
+  const int kb = (d->a_type == LIBXSMM_DATATYPE_F32) ? 1 : ORACLE_BF16_PACK;
+  const unsigned char* bitmap = (const unsigned char*)p->a.secondary;
+  const int c_f32 = (d->c_type == LIBXSMM_DATATYPE_F32);
+  float* scratch = c_f32 ? NULL : (float*)malloc(sizeof(float) * (size_t)m * (size_t)n);
+  unsigned long long at = 0;
+  int i, j, s, k2;
+  for (s = 0; s < k / kb; ++s) for (i = 0; i < m; ++i) {
+    if (s == 0) for (j = 0; j < n; ++j) {
+      if (c_f32) { if (beta0) ((float*)p->c.primary)[(long long)j * d->ldc + i] = 0.0f; }
+      else scratch[(long long)j * m + i] = beta0 ? 0.0f : (d->c_type == LIBXSMM_DATATYPE_BF16 ? oracle_bf16_to_f32(((const unsigned short*)p->c.primary)[(long long)j * d->ldc + i])
+                                                                                              : oracle_f16_to_f32(((const unsigned short*)p->c.primary)[(long long)j * d->ldc + i]));
+    }
+    for (k2 = 0; k2 < kb; ++k2) {
+      const long long q = (long long)i * kb + k2;
+      if ((bitmap[q / 8 + (long long)s * ((long long)m * kb / 8)] >> (q % 8)) & 1) {
+        const float av = d->a_type == LIBXSMM_DATATYPE_F32 ? ((const float*)p->a.primary)[at]
+                       : d->a_type == LIBXSMM_DATATYPE_BF16 ? oracle_bf16_to_f32(((const unsigned short*)p->a.primary)[at]) : oracle_f16_to_f32(((const unsigned short*)p->a.primary)[at]);
+        for (j = 0; j < n; ++j) {
+          const long long bi = (long long)j * d->ldb + (long long)s * kb + k2;
+          const float bv = d->b_type == LIBXSMM_DATATYPE_F32 ? ((const float*)p->b.primary)[bi]
+                         : d->b_type == LIBXSMM_DATATYPE_BF16 ? oracle_bf16_to_f32(((const unsigned short*)p->b.primary)[bi]) : oracle_f16_to_f32(((const unsigned short*)p->b.primary)[bi]);
+          const float prod = av * bv;
+          float* c = c_f32 ? (float*)p->c.primary + (long long)j * d->ldc + i : scratch + (long long)j * m + i;
+          *c = *c + prod;
+        }
+        ++at;
+      }
+    }
+  }
+  if (!c_f32) {
+    for (i = 0; i < m; ++i) for (j = 0; j < n; ++j) {
+      const float y = scratch[(long long)j * m + i];
+      ((unsigned short*)p->c.primary)[(long long)j * d->ldc + i] = d->c_type == LIBXSMM_DATATYPE_BF16 ? oracle_f32_to_bf16_rne(y) : oracle_f32_to_f16(y);
+    }
+    free(scratch);
+  }
+}
+
 void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   gemm_view v;
   const int is_ext = (d->flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) ? 1 : 0;
@@ -363,6 +407,7 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   if (((d->flags & LIBXSMM_GEMM_FLAG_NO_RESET_TILECONFIG) != 0) != ((d->flags & LIBXSMM_GEMM_FLAG_NO_SETUP_TILECONFIG) != 0)) return;
   setup_view(&v, param, d);
 
+  if (d->flags & LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) { contract_spmm(d, p, beta0); return; }
   if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
   if (is_int8(d->a_type) && is_int8(d->b_type)) { contract_int8(&v, p, cptr, beta0); return; }
   if (is_fp8(d->a_type) && d->b_type == d->a_type && d->c_type == LIBXSMM_DATATYPE_F32) { contract_fp8(&v, (float*)cptr, beta0); return; }

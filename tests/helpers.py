@@ -319,3 +319,20 @@ class GemmCase:
     def valid_mask_bits(self, mask: np.ndarray) -> np.ndarray:
         bits = np.unpackbits(mask.reshape(self.batch, self.n, self.mask_ld // 8), axis=2, bitorder="little")
         return bits[:, :, : self.m]
+
+
+def compress_by_bitmask(a_mem: np.ndarray):
+    """LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK operands from a dense A in MEMORY order (f32: [k][m]; 16-bit: the VNNI image [k/2][m][2]):
+    (non-zeros in that order, one bit per element LSB first) -- what samples/xgemm/gemm_kernel.c:107-212 builds.  -0.0 counts as zero there
+    (the driver compares the VALUE with 0) and so it does here."""
+    if a_mem.dtype == np.float32:
+        nz = a_mem != 0.0
+    else:
+        nz = (a_mem & 0x7fff) != 0
+    return np.ascontiguousarray(a_mem[nz]), np.packbits(nz, bitorder="little")
+
+
+def sparsify(rng: np.random.Generator, a_mem: np.ndarray, frac: float) -> np.ndarray:
+    out = a_mem.copy()
+    out[rng.random(out.size) < frac] = 0
+    return out

@@ -537,3 +537,53 @@ def test_synchronous_gemm_accepts_plain_host_memory(kw):
     assert normf_rel(case.valid_region(ref), case.valid_region(Cbuf), case.c_type) < tol
     if mask is not None:
         assert np.array_equal(case.valid_mask_bits(mask), case.valid_mask_bits(ref_mask))
+
+
+# LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK [ref: gemm ref :857-948, samples/xgemm/gemm_kernel.c "spmm"]: only the non-zeros of A travel, with one
+# bit per element; the device rebuilds the dense image and runs the dense kernel.  Device and (synchronous) plain host memory.
+@pytest.mark.parametrize("where", ["device", "host"])
+@pytest.mark.parametrize("a_type,c_type", [(DT.F32, DT.F32), (DT.BF16, DT.F32), (DT.BF16, DT.BF16), (DT.F16, DT.F16)])
+@pytest.mark.parametrize("m,n,k,ldb,ldc,frac,beta", [(64, 48, 64, 64, 64, 0.5, 0), (32, 17, 48, 50, 40, 0.9, 1), (16, 8, 16, 16, 16, 0.0, 1), (48, 5, 32, 32, 48, 1.0, 0),
+                                                     (512, 64, 1024, 1024, 512, 0.75, 0), (1000, 33, 266, 270, 1000, 0.3, 1)])
+def test_gemm_with_bitmask_compressed_a(where, a_type, c_type, m, n, k, ldb, ldc, frac, beta):
+    import ctypes as C
+    import torch
+    from helpers import compress_by_bitmask, rand_values, sparsify
+    from oracle import pyoracle
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(17)
+    a_mem = sparsify(rng, rand_values(rng, m * k, a_type), frac)
+    vals, bits = compress_by_bitmask(a_mem)
+    if vals.size == 0:
+        vals = np.zeros(1, dtype=a_mem.dtype)
+    B = rand_values(rng, ldb * n, a_type)
+    C0 = rand_values(rng, ldc * n, c_type)
+    flags = F.DECOMPRESS_A_VIA_BITMASK | (0 if beta else F.BETA_0) | (0 if a_type == DT.F32 else F.VNNI_A)
+    ref = C0.copy()
+    p = capi.GemmParam()
+    p.a.primary, p.a.secondary, p.b.primary, p.c.primary = vals.ctypes.data, bits.ctypes.data, B.ctypes.data, ref.ctypes.data
+    orc.gemm(p, pyoracle.GemmDesc(m, n, k, m, ldb, ldc, a_type, a_type, c_type, DT.F32, flags | F.USE_XGEMM_ABI, 0, 0, 0, 0))
+    h = api.dispatch_gemm(capi.gemm_shape(m, n, k, m, ldb, ldc, a_type, a_type, c_type, DT.F32), flags, 0)
+    assert h
+    view = lambda x: x.view(np.int16) if x.dtype == np.uint16 else x
+    if where == "device":
+        dv, db, dB, dC = (torch.from_numpy(view(x).copy()).to("cuda:0") for x in (vals, bits, B, C0))
+        p.a.primary, p.a.secondary, p.b.primary, p.c.primary = dv.data_ptr(), db.data_ptr(), dB.data_ptr(), dC.data_ptr()
+        capi.Api.call(h, p)
+        api.hip_sync(); api.check()
+        got = dC.cpu().numpy().view(C0.dtype)
+    else:
+        got = C0.copy()
+        p.c.primary = got.ctypes.data
+        capi.Api.call(h, p)
+        api.check()
+    sel = lambda x: x.reshape(n, ldc)[:, :m]
+    assert np.array_equal(got.reshape(n, ldc)[:, m:], C0.reshape(n, ldc)[:, m:])                      # the padding of C is untouched
+    err = normf_rel(sel(ref), sel(got), c_type)
+    assert err < (TOL_BF16 if c_type in (DT.BF16, DT.F16) else TOL_F32), err
+    if frac == 1.0 and not beta:
+        assert not np.any(sel(got))
+    # batching such a kernel is refused: the operand size differs per problem
+    api.hip_gemm_batch_strided(h, C.byref(p), 2, 0, 0, 0)
+    assert api.hip_get_last_error() != 0
+    api.hip_clear_last_error()

@@ -7,7 +7,9 @@ fixtures in tests/golden/ (test_golden.py) cover that situation.
 import numpy as np
 import pytest
 
-from helpers import GemmCase, TOL_BF16, TOL_F32, normf_rel
+import ctypes as C
+
+from helpers import GemmCase, TOL_BF16, TOL_F32, compress_by_bitmask, normf_rel, rand_values, sparsify
 from libxsmm_amd import capi
 from libxsmm_amd.capi import DT, GEMM_FLAG
 
@@ -92,6 +94,35 @@ def test_gemm_restatement_within_reference_tolerance_of_its_cpu_jit(kw, referenc
         pytest.skip("reference JIT refused this descriptor on this host")
     tol = TOL_BF16 if case.c_type == DT.BF16 else TOL_F32
     assert normf_rel(case.valid_region(c_or), case.valid_region(c_jit), case.c_type) < tol
+
+
+# A compressed by bitmask [ref: generator_gemm_reference_impl.c:857-948]: only the non-zeros of A travel, a.secondary says where they go
+@pytest.mark.parametrize("a_type,c_type", [(DT.F32, DT.F32), (DT.BF16, DT.F32), (DT.BF16, DT.BF16), (DT.F16, DT.F16), (DT.F16, DT.F32)])
+@pytest.mark.parametrize("m,n,k,ldb,ldc,frac,beta", [(64, 48, 64, 64, 64, 0.5, 0), (32, 17, 48, 50, 40, 0.9, 1), (16, 8, 16, 16, 16, 0.0, 1), (48, 5, 32, 32, 48, 1.0, 0)])
+def test_bitmask_compressed_a_restatement_is_bit_identical_to_reference_c_kernel(reference, oracle, a_type, c_type, m, n, k, ldb, ldc, frac, beta):
+    rng = np.random.default_rng(99)
+    a_mem = sparsify(rng, rand_values(rng, m * k, a_type), frac)
+    vals, bits = compress_by_bitmask(a_mem)
+    if vals.size == 0:
+        vals = np.zeros(1, dtype=a_mem.dtype)
+    B = rand_values(rng, ldb * n, a_type)
+    C0 = rand_values(rng, ldc * n, c_type)
+    flags = F.DECOMPRESS_A_VIA_BITMASK | (0 if beta else F.BETA_0) | (0 if a_type == DT.F32 else F.VNNI_A)
+    shape = capi.gemm_shape(m, n, k, m, ldb, ldc, a_type, a_type, c_type, DT.F32)
+    outs = []
+    for who in ("oracle", "reference"):
+        c = C0.copy()
+        p = capi.GemmParam()
+        p.a.primary, p.a.secondary, p.b.primary, p.c.primary = vals.ctypes.data, bits.ctypes.data, B.ctypes.data, c.ctypes.data
+        if who == "oracle":
+            from oracle import pyoracle
+            oracle.gemm(p, pyoracle.GemmDesc(m, n, k, m, ldb, ldc, a_type, a_type, c_type, DT.F32, flags | F.USE_XGEMM_ABI, 0, 0, 0, 0))
+        else:
+            assert reference.lib.xref_reference_gemm(C.byref(p), shape, flags, 0, capi.br_config(capi.BR_NONE, 0, 0, 0)) == 0
+        outs.append(c)
+    assert outs[0].tobytes() == outs[1].tobytes()
+    if frac == 1.0 and not beta:
+        assert not np.any(outs[0].reshape(n, ldc)[:, :m])          # an all-zero A: C = 0
 
 
 def test_bf16_conversion_matches_reference(reference, oracle):

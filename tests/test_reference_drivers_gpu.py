@@ -79,6 +79,11 @@ GEMM_CASES = [
     "U8 I8 I32 I32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf strdbr 2 0 2 0",
     "BF8 BF8 F32 F32 32 32 64 32 64 32 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     "HF8 HF8 F32 F32 64 64 64 64 64 64 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    # "spmm": A sparsified to the given fraction and handed over as (non-zeros, bitmask) -- LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK
+    "F32 F32 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf spmm 0.5 0 2 0",
+    "F32 F32 F32 F32 128 48 256 128 256 128 1 1 0 0 0 0 0 0 0 nopf spmm 0.9 0 2 0",
+    "BF16 BF16 F32 BF16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf spmm 0.5 0 2 0",
+    "BF16 BF16 F32 F32 128 32 128 128 128 128 1 1 0 0 0 0 1 0 0 nopf spmm 0.75 0 2 0",
 ]
 
 
