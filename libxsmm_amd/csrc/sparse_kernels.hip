@@ -809,6 +809,164 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, uns
   });
 }
 
+// bf16 BCSC with waves that STREAM over M-blocks.  The one-tile-per-wave kernels above spend most of a wave's life in its set-up chain (pattern
+// rows -> first DMA -> first operands; profiles/r02_bcsc_counters.txt: 51 % of the wave cycles wait on a memory counter) because a tile is only
+// ~5 chunks of work.  Here a wave keeps its (i-tile, n-tile), reads the pattern rows and compacts the used k-blocks ONCE, and then walks the
+// M-blocks g, g + MBG, g + 2 MBG, ... as one flat sequence of chunks: the LDS-DMA ring and the B-fragment register ring run ahead across tile
+// boundaries, so the next tile's first operands are in flight while this tile's C leaves (through an LDS image of its own, not the ring).
+// s_waitcnt counts loads and stores in issue order: the wait before a chunk allows for the younger chunk and for the stores of a tile that
+// ended since the chunk was issued (only the 8-store LDS epilogue is counted; the direct epilogue just makes the next waits stricter).
+// beta = 0 only (a C read would sit in the middle of the counted sequence); one k-group (K / bk <= 64).
+template <int BN16, int AUX_A = 0>
+__global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
+  constexpr int NBL = 4 / BN16, D = 2;
+  __shared__ unsigned int tbl_all[4][kBcscTblDma];
+  __shared__ unsigned int klist_all[4][64];
+  __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][D][1024];
+  __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][1024];       // 32 columns x 128 bytes: C leaves in two halves
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = blockIdx.x * 4u + wave;
+  if (wid >= total_waves) return;
+  unsigned int* tbl = tbl_all[wave];
+  unsigned int* klist = klist_all[wave];
+  unsigned int (*abuf)[1024] = abuf_all[wave];
+  unsigned int* tile = ctile_all[wave];
+  const unsigned int tt_count = tiles_i * tiles_n, tt = wid % tt_count, g0 = wid / tt_count;
+  const unsigned int tn = tt % tiles_n, ti = tt / tiles_n;
+  const int lane = threadIdx.x & 63, lx = lane & 15, kg = lane >> 4;
+  const int i0 = (int)ti * 64, n0 = (int)tn * 64;
+  const int mt = (p.M - i0 >= 64) ? 4 : (p.M - i0) / 16;
+  const int nbl_cnt = ((p.N - n0 >= 64) ? 64 : (p.N - n0)) / (16 * BN16);
+  const int nb0 = n0 / (16 * BN16);
+  const int nkb = p.K / p.bk, steps = p.bk / 32;
+  {
+    GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb;
+    for (int e = lane; e < nbl_cnt * nkb; e += 64) tbl[e] = gt[e];
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  bool used = false;
+  if (lane < nkb) for (int nbl = 0; nbl < nbl_cnt; ++nbl) used = used || (tbl[nbl * nkb + lane] != 0xffffffffu);
+  const unsigned long long mask = __ballot(used);
+  if (used) klist[__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (unsigned int)lane;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int nch = __builtin_popcountll(mask) * steps;
+  const int nmb = ((unsigned int)p.m_blocks > g0) ? (int)(((unsigned int)p.m_blocks - g0 + mbg - 1u) / mbg) : 0;
+  const bool c_f32 = (p.c_type == LIBXSMM_DATATYPE_F32);
+  const long long c_mb_bytes = (long long)p.N * p.M * (c_f32 ? 4 : 2);
+  const bool lds_store = !c_f32 && mt == 4 && nbl_cnt * BN16 == 4 && (p.M % 8) == 0 && ((((size_t)p.c) & 15) == 0);
+  f32x4v acc[4][4];
+  sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
+  auto store_tile = [&](unsigned int mb) __attribute__((always_inline)) {        // C of M-block mb leaves; the accumulators restart at zero
+    GM char* cbase = (GM char*)p.c + (long long)mb * c_mb_bytes;
+    if (lds_store) {
+      sfor<2>([&](auto hc) {
+        constexpr int h = hc.value;
+        sfor<8>([&](auto ic) {
+          constexpr int nt = 2 * h + ic.value / 4, it = ic.value % 4;
+          const int n = 16 * (nt - 2 * h) + lx;
+          u32x2v v; v[0] = cvt2(acc[nt][it][0], acc[nt][it][1]); v[1] = cvt2(acc[nt][it][2], acc[nt][it][3]);
+          *(u32x2v*)(tile + n * 32 + 2 * ((4 * it + kg) ^ (n & 15))) = v;
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = 8 * r + (lane >> 3), j = lane & 7, x = n & 15;
+          u32x4v w = *(const u32x4v*)(tile + n * 32 + 4 * (j ^ (x >> 1)));
+          if (x & 1) { const unsigned int t0 = w[0], t1 = w[1]; w[0] = w[2]; w[1] = w[3]; w[2] = t0; w[3] = t1; }
+          *(GM u32x4v*)(cbase + ((long long)(n0 + 32 * h + n) * p.M + i0) * 2 + 16 * j) = w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      });
+    } else {
+      sfor<16>([&](auto ic) {
+        constexpr int nt = ic.value / 4, it = ic.value % 4;
+        if (it < mt && nt < nbl_cnt * BN16) {
+          const long long e = (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg;
+          if (c_f32) *(GM f32x4v*)(cbase + e * 4) = acc[nt][it];
+          else { u32x2v v; v[0] = cvt2(acc[nt][it][0], acc[nt][it][1]); v[1] = cvt2(acc[nt][it][2], acc[nt][it][3]); *(GM u32x2v*)(cbase + e * 2) = v; }
+        }
+      });
+    }
+    sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
+  };
+  if (nch == 0) { for (int j = 0; j < nmb; ++j) store_tile(g0 + (unsigned int)j * mbg); return; }     // no block in these columns: C = 0
+  // DMA source of LDS slot (lane + 64x): row kp_l = slot >> 4, the 16-byte group that lands there = (slot & 15) rotated back
+  GM const unsigned int* A2 = (GM const unsigned int*)p.a + i0;
+  const long long a_mb_words = (long long)(p.K / 2) * p.M;
+  unsigned int src_off[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const unsigned int S = (unsigned int)lane + 64u * x, kp_l = S >> 4, g = ((S & 15u) - 4u * ((kp_l >> 2) & 1u)) & 15u;
+    src_off[x] = kp_l * (unsigned int)p.M + (((int)(4u * g) < 16 * mt) ? 4u * g : 0u);
+  }
+  const int rot = 16 * (kg & 1);
+  GM const char* bv = (GM const char*)p.bvals;
+  const int total_f = nmb * nch;
+  unsigned int blk_r[D][NBL]; u32x4v bf_r[D][NBL][BN16];
+  // flat chunk f = (tile j, chunk c): cursor advanced by `advance`; `issue` sends chunk (j, c) to ring position u
+  int ij = 0, ic_ = 0;                              // the NEXT chunk to issue
+  auto issue = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    const int q = ic_ / steps, st_ = ic_ - q * steps;
+    const int kb_ = __builtin_amdgcn_readfirstlane((int)klist[q]);
+    sfor<NBL>([&](auto nc) {
+      constexpr int nbl = nc.value;
+      blk_r[u][nbl] = (nbl < nbl_cnt) ? (unsigned int)__builtin_amdgcn_readfirstlane((int)tbl[nbl * nkb + kb_]) : 0xffffffffu;
+      sfor<BN16>([&](auto sc) { constexpr int s2 = sc.value;
+        GM const char* src = (blk_r[u][nbl] != 0xffffffffu) ? bv + (((long long)blk_r[u][nbl] * (16 * BN16) + 16 * s2 + lx) * p.bk + 32 * st_ + 8 * kg) * 2 : bv;
+        bf_r[u][nbl][s2] = *(GM const u32x4v*)src; });
+    });
+    GM const unsigned int* rowbase = A2 + (long long)(g0 + (unsigned int)ij * mbg) * a_mb_words + ((long long)kb_ * (p.bk / 2) + 16 * st_) * p.M;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)((char*)abuf[u] + 1024 * x), 16, 0, AUX_A);
+    if (++ic_ == nch) { ic_ = 0; ++ij; }
+  };
+  sfor<D>([&](auto uc) { if (uc.value < total_f) issue(uc); });
+  int cj = 0, cc = 0;                               // the chunk being consumed
+  for (int f0 = 0; f0 < total_f; f0 += D) {
+    sfor<D>([&](auto uc) {
+      constexpr int u = uc.value;
+      const int f = f0 + u;
+      if (f < total_f) {
+        // chunk f must have landed.  Younger than its loads: the chunk issued one step later (4 + 4, if there is one) and -- when a tile ended
+        // within the last D chunks -- the 8 stores of that tile's C (loads and stores retire this counter in issue order on gfx9)
+        const int behind = (total_f - 1 - f < D - 1) ? total_f - 1 - f : D - 1;
+        const int allowed = behind + ((lds_store && cj > 0 && cc < D) ? 1 : 0);       // in units of 8 instructions
+        if (allowed >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (allowed == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (allowed == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        u32x4v a_cur[4];
+        sfor<4>([&](auto tc) {
+          constexpr int t = tc.value;
+          if (t < mt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a_cur[t][e] = abuf[u][(4 * kg + e) * 64 + ((16 * t + lx + rot) & 63)];
+          }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unsigned int blk_c[NBL]; u32x4v bf_c[NBL][BN16];
+        sfor<NBL>([&](auto nc) { blk_c[nc.value] = blk_r[u][nc.value]; sfor<BN16>([&](auto sc) { bf_c[nc.value][sc.value] = bf_r[u][nc.value][sc.value]; }); });
+        if (f + D < total_f) issue(uc);
+        sfor<NBL>([&](auto nc) {
+          constexpr int nbl = nc.value;
+          if (blk_c[nbl] != 0xffffffffu) {
+            sfor<BN16>([&](auto sc) {
+              constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
+              sfor<4>([&](auto tc) {
+                constexpr int t = tc.value;
+                if (t < mt) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a_cur[t]), __builtin_bit_cast(bf16x8v, bf_c[nbl][s2]), acc[nt][t], 0, 0, 0);
+              });
+            });
+          }
+        });
+        if (++cc == nch) { store_tile(g0 + (unsigned int)cj * mbg); cc = 0; ++cj; }
+      }
+    });
+  }
+}
+
 // 8-bit integers with the A operand on an LDS-DMA ring (the structure of bcsc_mfma_bf16_dma_kernel, re-cut for bytes).  A chunk is 32 k of the
 // wave's 64 rows: [8 k-quads][64 i] dwords = 2 KiB = two global_load_lds_dwordx4; rows of odd k-groups are rotated by 16 words on the source
 // side, so the operand reads (lane (row, kg): rows 2 kg and 2 kg + 1) are conflict-free ds_read_b32.  The used k-blocks of a k-group are
@@ -990,6 +1148,23 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
           // A is read exactly once: stream it non-temporally when it cannot be cache resident anyway (or the caller says so)
           const unsigned long long a_bytes = (unsigned long long)a.m_blocks * a.M * a.K * 2ull;
           const bool nta = a.stream_hint == 2 || (a.stream_hint == 0 && a_bytes > (256ull << 20));
+          // many M-blocks per (i-tile, n-tile): waves that stream over M-blocks (two per SIMD: 2048 on the chip), each taking every mbg-th block
+          static const int stream_mode = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_STREAM"); return e ? atoi(e) : 1; }();
+          const long long tt_count = (long long)tiles_i * tiles_n;
+          if (stream_mode != 0 && a.beta0 && nkb <= 64 && tt_count <= 2048 && ((long long)a.m_blocks * tt_count >= 4096 || stream_mode == 2) && ((long long)(a.K / 2) * a.M) * (long long)a.m_blocks < (1ll << 40)) {
+            const long long slots = 2048;      // two waves per SIMD (245 VGPRs); three (168 VGPRs) spill inside the chunk loop: 105 instead of 61 us
+            long long mbg = std::min<long long>(a.m_blocks, std::max<long long>(1, slots / tt_count));
+            const long long per = (a.m_blocks + mbg - 1) / mbg;
+            mbg = (a.m_blocks + per - 1) / per;
+            const long long waves = mbg * tt_count;
+            const dim3 sgrid((unsigned int)((waves + 3) / 4));
+#define LAUNCH_STREAM_(B_) do { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 2>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+                                else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 0>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
+            if (a.bn == 16) LAUNCH_STREAM_(1); else if (a.bn == 32) LAUNCH_STREAM_(2); else LAUNCH_STREAM_(4);
+#undef LAUNCH_STREAM_
+            if (name) *name = "bcsc_mfma_bf16_stream_kernel";
+            return (int)hipGetLastError();
+          }
 #define LAUNCH_DMA_(B_) do { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<B_, 2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); \
                              else hipLaunchKernelGGL((bcsc_mfma_bf16_dma_kernel<B_, 0>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); } while (0)
           if (a.bn == 16) LAUNCH_DMA_(1); else if (a.bn == 32) LAUNCH_DMA_(2); else LAUNCH_DMA_(4);

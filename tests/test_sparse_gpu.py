@@ -375,6 +375,42 @@ def test_packed_csc_csparse(M, N, K, P, density, beta0):
     assert not api.create_packed_spgemm_csc(capi.gemm_shape(M, N, K, M, N, 0, DT.F64, DT.F64, DT.F64, DT.F64), 0, 0, P, rowptr.ctypes.data, colidx.ctypes.data, C0.ctypes.data)
 
 
+# many M-blocks per tile: waves that keep their (i-tile, n-tile) and stream over the M-blocks (bcsc_mfma_bf16_stream_kernel); ragged tiles in both
+# directions, every wave with a different number of M-blocks, bf16 (C through LDS) and f32 (direct) output, one n-tile without any block
+@pytest.mark.parametrize("c_type", [DT.BF16, DT.F32])
+@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep", [(80, 96, 128, 1100, 32, 32, 0.34), (64, 64, 256, 4099, 32, 16, 0.25), (64, 128, 64, 2050, 64, 64, 0.5)])
+def test_bcsc_bf16_waves_streaming_over_m_blocks(c_type, M, N, K, mb, bk, bn, keep):
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(13)
+    colptr, rowidx, bvals = make_bcsc(rng, K, N, bk, bn, keep, DT.BF16)
+    if N == 128:                                   # the second n-tile loses all its blocks: its C must become zero
+        keep_blocks = int(colptr[1])
+        colptr = np.array([0, keep_blocks, keep_blocks], dtype=colptr.dtype); rowidx = rowidx[:keep_blocks].copy(); bvals = bvals[:keep_blocks * bn * bk].copy()
+    A = rand_values(rng, mb * K * M, DT.BF16)
+    A_run = pack_vnni2(A, mb, K, M)
+    C0 = rand_values(rng, mb * N * M, c_type)
+    ref = C0.copy()
+    orc.lib.oracle_packed_spgemm_bcsc(DT.BF16, c_type, M, N, K, mb, bk, bn, 1, A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, 1)
+    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, DT.BF16, DT.BF16, c_type, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    dA, dB, dC, dcp, dri = _dev(A_run), _dev(bvals), _dev(C0.copy()), _dev(colptr), _dev(rowidx)
+    nblk = C.c_ulonglong(N // bn)
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = dA.data_ptr(), dB.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), dC.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_bf16_stream_kernel"
+    got = _host(dC, np.uint16 if c_type == DT.BF16 else np.float32)
+    assert normf_rel(ref, got, c_type) <= (5e-3 if c_type == DT.BF16 else 1e-4)
+    # block by block: no M-block may be skipped or written twice with another block's data
+    rb, gb = ref.reshape(mb, -1), got.reshape(mb, -1)
+    worst = max(normf_rel(rb[b], gb[b], c_type) for b in list(range(0, mb, 97)) + [mb - 1, mb - 2, mb // 2])
+    assert worst <= (8e-3 if c_type == DT.BF16 else 1e-4)
+    if N == 128:
+        assert not np.any(gb.reshape(mb, N, M)[:, 64:, :])
+    api.release_kernel(h)
+
+
 # 8-bit integers (u8 x i8 -> i32 and i8 x u8 -> i32, A in VNNI-4): exact, so the bar is bit equality
 @pytest.mark.parametrize("a_type", [DT.U8, DT.I8])
 @pytest.mark.parametrize("M,N,K,mb,bk,bn,keep,beta0", [(64, 64, 256, 6, 32, 16, 0.25, 1), (64, 64, 256, 3, 32, 32, 0.25, 0), (16, 24, 40, 4, 8, 8, 0.5, 1), (32, 32, 64, 2, 16, 4, 0.42, 0),
