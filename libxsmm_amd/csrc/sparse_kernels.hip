@@ -1220,7 +1220,8 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
            else hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, false, 0, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); } } while (0)
           // ring depth 2, three waves per SIMD (141 VGPRs), 64 rows per wave -- measured on 8192 M-blocks of 64 x 256 (2:8, bn = 16): depth 2 / 3 / 4 at two waves
           // per SIMD 60.5 / 61.2 / 61.2 us, three waves per SIMD 56.0 us; 32 rows per wave (104 VGPRs, four waves per SIMD) 60.5 us: twice the B loads and
-          // per-wave set-up outweigh the occupancy (profiles/r02_bcsc_counters.txt)
+          // per-wave set-up outweigh the occupancy (profiles/r02_bcsc_counters.txt).  Waves streaming over M-blocks (the bf16 kernel's +9 %): 55.9 us here,
+          // no gain -- half of this kernel's traffic is the int32 C it writes, not the operand stream the scheme keeps busy -- so it was not kept.
           if (a.bn == 16) LAUNCH_I8D_(1); else if (a.bn == 32) LAUNCH_I8D_(2); else LAUNCH_I8D_(4);
 #undef LAUNCH_I8D_
           if (name) *name = "bcsc_mfma_i8_dma_kernel";
