@@ -1152,7 +1152,8 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
           static const int stream_mode = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_STREAM"); return e ? atoi(e) : 1; }();
           const long long tt_count = (long long)tiles_i * tiles_n;
           if (stream_mode != 0 && a.beta0 && nkb <= 64 && tt_count <= 2048 && ((long long)a.m_blocks * tt_count >= 4096 || stream_mode == 2) && ((long long)(a.K / 2) * a.M) * (long long)a.m_blocks < (1ll << 40)) {
-            const long long slots = 2048;      // two waves per SIMD (245 VGPRs); three (168 VGPRs) spill inside the chunk loop: 105 instead of 61 us
+            static const long long slots_env = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_SLOTS"); return e ? atoll(e) : 0ll; }();
+            const long long slots = slots_env > 0 ? slots_env : 2048;      // two waves per SIMD (245 VGPRs); three (168 VGPRs) spill inside the chunk loop: 105 instead of 61 us
             long long mbg = std::min<long long>(a.m_blocks, std::max<long long>(1, slots / tt_count));
             const long long per = (a.m_blocks + mbg - 1) / mbg;
             mbg = (a.m_blocks + per - 1) / per;
