@@ -817,25 +817,25 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, uns
 // s_waitcnt counts loads and stores in issue order: the wait before a chunk allows for the younger chunk and for the stores of a tile that
 // ended since the chunk was issued (only the 8-store LDS epilogue is counted; the direct epilogue just makes the next waits stricter).
 // beta = 0 only (a C read would sit in the middle of the counted sequence); one k-group (K / bk <= 64).
-template <int BN16, int AUX_A = 0>
-__global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
-  constexpr int NBL = 4 / BN16, D = 2;
+template <int BN16, int AUX_A = 0, int RT = 4, int WPS = 2>     // RT: 16-row tiles per wave (4: 64 rows, 2: 32 rows -> half the accumulators, more waves per SIMD)
+__global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
+  constexpr int NBL = 4 / BN16, D = 2, W = 16 * RT, SPR = 4 * RT, NI = RT;     // W words per image row, SPR 16-byte slots per row, NI DMA instructions per chunk
   __shared__ unsigned int tbl_all[4][kBcscTblDma];
   __shared__ unsigned int klist_all[4][64];
-  __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][D][1024];
+  __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][D][16 * W];
   __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][1024];       // 32 columns x 128 bytes: C leaves in two halves
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int wid = blockIdx.x * 4u + wave;
   if (wid >= total_waves) return;
   unsigned int* tbl = tbl_all[wave];
   unsigned int* klist = klist_all[wave];
-  unsigned int (*abuf)[1024] = abuf_all[wave];
+  unsigned int (*abuf)[16 * W] = abuf_all[wave];
   unsigned int* tile = ctile_all[wave];
   const unsigned int tt_count = tiles_i * tiles_n, tt = wid % tt_count, g0 = wid / tt_count;
   const unsigned int tn = tt % tiles_n, ti = tt / tiles_n;
   const int lane = threadIdx.x & 63, lx = lane & 15, kg = lane >> 4;
-  const int i0 = (int)ti * 64, n0 = (int)tn * 64;
-  const int mt = (p.M - i0 >= 64) ? 4 : (p.M - i0) / 16;
+  const int i0 = (int)ti * (16 * RT), n0 = (int)tn * 64;
+  const int mt = (p.M - i0 >= 16 * RT) ? RT : (p.M - i0) / 16;
   const int nbl_cnt = ((p.N - n0 >= 64) ? 64 : (p.N - n0)) / (16 * BN16);
   const int nb0 = n0 / (16 * BN16);
   const int nkb = p.K / p.bk, steps = p.bk / 32;
@@ -853,12 +853,13 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_kernel(BcscArgs 
   const int nmb = ((unsigned int)p.m_blocks > g0) ? (int)(((unsigned int)p.m_blocks - g0 + mbg - 1u) / mbg) : 0;
   const bool c_f32 = (p.c_type == LIBXSMM_DATATYPE_F32);
   const long long c_mb_bytes = (long long)p.N * p.M * (c_f32 ? 4 : 2);
-  const bool lds_store = !c_f32 && mt == 4 && nbl_cnt * BN16 == 4 && (p.M % 8) == 0 && ((((size_t)p.c) & 15) == 0);
-  f32x4v acc[4][4];
-  sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
+  const bool lds_store = !c_f32 && mt == RT && nbl_cnt * BN16 == 4 && (p.M % 8) == 0 && ((((size_t)p.c) & 15) == 0);
+  f32x4v acc[4][RT];
+  sfor<4 * RT>([&](auto ic) { acc[ic.value / RT][ic.value % RT] = (f32x4v)0.0f; });
   auto store_tile = [&](unsigned int mb) __attribute__((always_inline)) {        // C of M-block mb leaves; the accumulators restart at zero
     GM char* cbase = (GM char*)p.c + (long long)mb * c_mb_bytes;
     if (lds_store) {
+      if constexpr (RT == 4) {
       sfor<2>([&](auto hc) {
         constexpr int h = hc.value;
         sfor<8>([&](auto ic) {
@@ -877,9 +878,26 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_kernel(BcscArgs 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       });
+      } else {           // 32 rows: a column is 64 bytes, four lanes write it; one pass over all 64 columns
+        sfor<8>([&](auto ic) {
+          constexpr int nt = ic.value / 2, it = ic.value % 2;
+          const int n = 16 * nt + lx;
+          u32x2v v; v[0] = cvt2(acc[nt][it][0], acc[nt][it][1]); v[1] = cvt2(acc[nt][it][2], acc[nt][it][3]);
+          *(u32x2v*)(tile + n * 16 + 2 * ((4 * it + kg) ^ (n & 7))) = v;
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = 16 * r + (lane >> 2), j = lane & 3, x = n & 7;
+          u32x4v w = *(const u32x4v*)(tile + n * 16 + 4 * (j ^ (x >> 1)));
+          if (x & 1) { const unsigned int t0 = w[0], t1 = w[1]; w[0] = w[2]; w[1] = w[3]; w[2] = t0; w[3] = t1; }
+          *(GM u32x4v*)(cbase + ((long long)(n0 + n) * p.M + i0) * 2 + 16 * j) = w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     } else {
-      sfor<16>([&](auto ic) {
-        constexpr int nt = ic.value / 4, it = ic.value % 4;
+      sfor<4 * RT>([&](auto ic) {
+        constexpr int nt = ic.value / RT, it = ic.value % RT;
         if (it < mt && nt < nbl_cnt * BN16) {
           const long long e = (long long)(n0 + 16 * nt + lx) * p.M + i0 + 16 * it + 4 * kg;
           if (c_f32) *(GM f32x4v*)(cbase + e * 4) = acc[nt][it];
@@ -887,16 +905,16 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_kernel(BcscArgs 
         }
       });
     }
-    sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
+    sfor<4 * RT>([&](auto ic) { acc[ic.value / RT][ic.value % RT] = (f32x4v)0.0f; });
   };
   if (nch == 0) { for (int j = 0; j < nmb; ++j) store_tile(g0 + (unsigned int)j * mbg); return; }     // no block in these columns: C = 0
   // DMA source of LDS slot (lane + 64x): row kp_l = slot >> 4, the 16-byte group that lands there = (slot & 15) rotated back
   GM const unsigned int* A2 = (GM const unsigned int*)p.a + i0;
   const long long a_mb_words = (long long)(p.K / 2) * p.M;
-  unsigned int src_off[4];
+  unsigned int src_off[NI];
 #pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    const unsigned int S = (unsigned int)lane + 64u * x, kp_l = S >> 4, g = ((S & 15u) - 4u * ((kp_l >> 2) & 1u)) & 15u;
+  for (int x = 0; x < NI; ++x) {
+    const unsigned int S = (unsigned int)lane + 64u * x, kp_l = S / SPR, g = ((S % SPR) - 4u * ((kp_l >> 2) & 1u)) & (unsigned int)(SPR - 1);
     src_off[x] = kp_l * (unsigned int)p.M + (((int)(4u * g) < 16 * mt) ? 4u * g : 0u);
   }
   const int rot = 16 * (kg & 1);
@@ -918,7 +936,7 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_kernel(BcscArgs 
     });
     GM const unsigned int* rowbase = A2 + (long long)(g0 + (unsigned int)ij * mbg) * a_mb_words + ((long long)kb_ * (p.bk / 2) + 16 * st_) * p.M;
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < NI; ++x)
       __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)((char*)abuf[u] + 1024 * x), 16, 0, AUX_A);
     if (++ic_ == nch) { ic_ = 0; ++ij; }
   };
@@ -931,18 +949,19 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_kernel(BcscArgs 
       if (f < total_f) {
         // chunk f must have landed.  Younger than its loads: the chunk issued one step later (4 + 4, if there is one) and -- when a tile ended
         // within the last D chunks -- the 8 stores of that tile's C (loads and stores retire this counter in issue order on gfx9)
-        const int behind = (total_f - 1 - f < D - 1) ? total_f - 1 - f : D - 1;
-        const int allowed = behind + ((lds_store && cj > 0 && cc < D) ? 1 : 0);       // in units of 8 instructions
-        if (allowed >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (allowed == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (allowed == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        static_assert(D == 2, "the wait table below is written for one chunk in flight behind the consumed one");
+        constexpr int PER = 4 + NI, NS = (RT == 4) ? 8 : 4;           // instructions per chunk (4 B loads + the DMA), stores of one tile's LDS epilogue
+        const bool behind = total_f - 1 - f >= 1, stored = lds_store && cj > 0 && cc < D;
+        if (behind && stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER + NS) : "memory");
+        else if (behind) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+        else if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        u32x4v a_cur[4];
-        sfor<4>([&](auto tc) {
+        u32x4v a_cur[RT];
+        sfor<RT>([&](auto tc) {
           constexpr int t = tc.value;
           if (t < mt) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a_cur[t][e] = abuf[u][(4 * kg + e) * 64 + ((16 * t + lx + rot) & 63)];
+            for (int e = 0; e < 4; ++e) a_cur[t][e] = abuf[u][(4 * kg + e) * W + ((16 * t + lx + rot) & (W - 1))];
           }
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -954,7 +973,7 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_kernel(BcscArgs 
           if (blk_c[nbl] != 0xffffffffu) {
             sfor<BN16>([&](auto sc) {
               constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
-              sfor<4>([&](auto tc) {
+              sfor<RT>([&](auto tc) {
                 constexpr int t = tc.value;
                 if (t < mt) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a_cur[t]), __builtin_bit_cast(bf16x8v, bf_c[nbl][s2]), acc[nt][t], 0, 0, 0);
               });
@@ -1153,6 +1172,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
           const long long tt_count = (long long)tiles_i * tiles_n;
           if (stream_mode != 0 && a.beta0 && nkb <= 64 && tt_count <= 2048 && ((long long)a.m_blocks * tt_count >= 4096 || stream_mode == 2) && ((long long)(a.K / 2) * a.M) * (long long)a.m_blocks < (1ll << 40)) {
             static const long long slots_env = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_SLOTS"); return e ? atoll(e) : 0ll; }();
+            // 32 rows per wave (RT = 2: 161 VGPRs, three waves per SIMD) measured 72 us against 61 us: every B fragment then feeds two MFMAs instead of four
             const long long slots = slots_env > 0 ? slots_env : 2048;      // two waves per SIMD (245 VGPRs); three (168 VGPRs) spill inside the chunk loop: 105 instead of 61 us
             long long mbg = std::min<long long>(a.m_blocks, std::max<long long>(1, slots / tt_count));
             const long long per = (a.m_blocks + mbg - 1) / mbg;
