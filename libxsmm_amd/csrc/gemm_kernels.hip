@@ -155,7 +155,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(gcptr base) {
 
 // MXFP4 A: base of the E8M0 scales of batch-reduce element r [ref: gemm ref :200-222] -- one byte per (32-deep k-block, row):
 // pointer list / byte offset of A * 2 / 32 / byte stride of A * 2 / 32
-__device__ __forceinline__ bool is_mx_type(int t) { return t == LIBXSMM_DATATYPE_MXFP4X2 || t == LIBXSMM_DATATYPE_MXBF8 || t == LIBXSMM_DATATYPE_MXHF8; }
+__device__ __forceinline__ bool is_mx_type(int t) { return t == LIBXSMM_DATATYPE_MXFP4X2 || t == LIBXSMM_DATATYPE_MXBF8 || t == LIBXSMM_DATATYPE_MXHF8 || t == LIBXSMM_DATATYPE_MXBF6 || t == LIBXSMM_DATATYPE_MXHF6; }
+__device__ __forceinline__ bool is_fp6_type(int t) { return t == LIBXSMM_DATATYPE_MXBF6 || t == LIBXSMM_DATATYPE_MXHF6; }
+// E2M3 / E3M2 (MXHF6 / MXBF6) -> f32, exact [ref: gemm ref :70-92 via E4M3]
+__device__ __forceinline__ float fp6_to_f32(unsigned int v, bool e3m2) {
+  const unsigned int e = e3m2 ? ((v >> 2) & 7u) : ((v >> 3) & 3u), m = e3m2 ? (v & 3u) : (v & 7u);
+  float mag;
+  if (e3m2) mag = (e == 0u) ? (float)m * 0.0625f : (1.0f + (float)m * 0.25f) * (float)(1u << e) * 0.125f;
+  else mag = (e == 0u) ? (float)m * 0.125f : (1.0f + (float)m * 0.125f) * (float)(1u << e) * 0.5f;
+  return ((v >> 5) & 1u) ? -mag : mag;
+}
 // scales of A (of_b = false) or B: one byte per 32 elements, so a byte distance D of the operand is D * (elements per byte) / 32 here
 __device__ __forceinline__ gcptr mx_scale_base(const GemmArgs& p, unsigned int bidx, unsigned long long r, bool of_b) {
   if (p.batch_inner) {                                                                // the scales step with their operand
@@ -169,6 +178,7 @@ __device__ __forceinline__ gcptr mx_scale_base(const GemmArgs& p, unsigned int b
   const long long epb = ((of_b ? p.b_type : p.a_type) == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
   if (p.br_mode == 1) return list_entry((const void*)(size_t)base, r);
   if (p.br_mode == 2) return base + ((long long)uniform_u64((unsigned long long)((GM const long long*)(of_b ? p.offs_b : p.offs_a))[r]) * epb) / 32;
+  if (p.br_mode == 3 && is_fp6_type(of_b ? p.b_type : p.a_type)) return base + (((of_b ? p.br_stride_b : p.br_stride_a) * 4 / 3) / 32) * (long long)r;     // four elements in three bytes
   if (p.br_mode == 3) return base + (((of_b ? p.br_stride_b : p.br_stride_a) * epb) / 32) * (long long)r;
   return base;
 }
@@ -341,6 +351,16 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
             for (int k2 = 0; k2 < 8; ++k2) tmp = add_rn(tmp, mul_rn(e2m1_to_f32((wa >> (4 * k2)) & 15u), e2m1_to_f32((wb >> (4 * k2)) & 15u)));
             acc = add_rn(acc, mul_rn(mul_rn(tmp, sca), scb));
           }
+        }
+      } else if (is_fp6_type(p.a_type)) {      // [ref: gemm ref :2680-2727]: [k/4][ld][3 bytes], four 6-bit values per row and k-group, high k first
+        const bool e3m2 = p.a_type == LIBXSMM_DATATYPE_MXBF6;
+        for (int s = 0; s < p.k / 4; ++s) {
+          const float sca = __uint_as_float((unsigned int)sa[(long long)(s / 8) * p.lda + i] << 23), scb = __uint_as_float((unsigned int)sb[(long long)(s / 8) * p.ldb + j] << 23);
+          GM const unsigned char* pa = (GM const unsigned char*)ar + ((long long)s * p.lda + i) * 3; GM const unsigned char* pb = (GM const unsigned char*)br + ((long long)s * p.ldb + j) * 3;
+          const unsigned int wa = (unsigned int)pa[0] | ((unsigned int)pa[1] << 8) | ((unsigned int)pa[2] << 16), wb = (unsigned int)pb[0] | ((unsigned int)pb[1] << 8) | ((unsigned int)pb[2] << 16);
+          float tmp = 0.0f;
+          for (int k2 = 3; k2 >= 0; --k2) tmp = add_rn(tmp, mul_rn(fp6_to_f32((wa >> (6 * k2)) & 63u, e3m2), fp6_to_f32((wb >> (6 * k2)) & 63u, e3m2)));
+          acc = add_rn(acc, mul_rn(mul_rn(tmp, sca), scb));
         }
       } else {
         for (int s = 0; s < p.k / 4; ++s) {
@@ -2484,7 +2504,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     if (tb8 ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
     return d.ldc >= d.m;
   }
-  if ((d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8) && d.b_type == d.a_type) {
+  if ((d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8 || d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6) && d.b_type == d.a_type) {
     // MX x MX -> f32 [ref: gemm ref :2620-2790]: A in VNNI, B in VNNI and transposed, no address/offset batch-reduce, no fused ops [:836-855]
     const unsigned int flx = d.flags;
     if (d.c_type != LIBXSMM_DATATYPE_F32 || d.comp_type != LIBXSMM_DATATYPE_F32) return false;      // MX-typed outputs are not built
@@ -2492,6 +2512,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     if ((flx & need) != need || (flx & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_VNNI_C | LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT |
         LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET))) return false;
     if ((d.k % 32) != 0 || d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    if ((d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6) && (((d.lda * 6) % 8) != 0 || ((d.ldb * 6) % 8) != 0)) return false;   // a k-group row of the image is ld * 6 / 8 bytes
     return d.lda >= d.m && d.ldb >= d.n && d.ldc >= d.m;
   }
   if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {   // MXFP4 weights x bf16/f32 activations [ref: gemm ref :457-465, :949-1008; names libxsmm_main.c:1829-1848]

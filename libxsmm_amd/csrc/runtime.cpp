@@ -438,15 +438,16 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     if (!p->c.tertiary) { set_error(-2, "8-bit GEMM with f32 output needs the scale in c.tertiary"); return; }   // [ref: gemm ref :591-592]
     a.scf = *(const float*)p->c.tertiary;
   }
-  if ((d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8) && d.b_type == d.a_type) {
+  const bool a_fp6 = d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6;
+  if ((d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8 || a_fp6) && d.b_type == d.a_type) {
     // MX x MX: scales of A in a.tertiary, of B in b.tertiary [ref: gemm ref :577-583]; a batched launch steps them with their operand:
     // one scale byte per 32 elements
     if (!p->a.tertiary || !p->b.tertiary) { set_error(-2, "MX x MX GEMM needs the E8M0 scales in a.tertiary and b.tertiary"); return; }
     if (b.la) { set_error(-3, "MX x MX GEMM: pointer-list batches carry no scale lists; use the strided batch"); return; }
     const long long epb = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
-    if (b.count > 1 && (((b.s[0] | b.s[1]) * epb) % 32) != 0) { set_error(-3, "MX x MX GEMM: batch strides must cover whole 32-element scale blocks"); return; }
-    a.a_scf = (const char*)p->a.tertiary; a.bs_scf = b.s[0] * epb / 32;
-    a.b_scf = (const char*)p->b.tertiary; a.bs_bscf = b.s[1] * epb / 32;
+    if (b.count > 1 && (a_fp6 ? (((b.s[0] | b.s[1]) % 24) != 0) : ((((b.s[0] | b.s[1]) * epb) % 32) != 0))) { set_error(-3, "MX x MX GEMM: batch strides must cover whole 32-element scale blocks"); return; }
+    a.a_scf = (const char*)p->a.tertiary; a.bs_scf = a_fp6 ? b.s[0] / 24 : b.s[0] * epb / 32;       // 6-bit: 32 elements are 24 bytes
+    a.b_scf = (const char*)p->b.tertiary; a.bs_bscf = a_fp6 ? b.s[1] / 24 : b.s[1] * epb / 32;
   } else if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {
     // E8M0 scales of the MXFP4 weights travel in a.tertiary (a list of per-block pointers in ADDRESS mode) [ref: gemm ref :565-569].
     // A batched launch steps them like A: the pointer list by sa, the scale bytes by sa * 2 / 32 (one byte per 32 weights).
@@ -477,8 +478,9 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   // extent follows from the descriptor alone (no pointer lists, no offset arrays) are staged.  One pointer query per operand.
   if (staging_allowed(b.count) && !a.list_a && (a.br_mode == 0 || a.br_mode == 3) && a.br_count >= 1) {
     const bool ta = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_A) != 0, tb = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_B) != 0;
-    const bool mxmx = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8) && d.b_type == d.a_type;
-    const auto bytes_of = [](int type, size_t elems) { return type == LIBXSMM_DATATYPE_MXFP4X2 ? elems / 2 : elems * (size_t)typesize(type); };
+    const bool fp6 = d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6;
+    const bool mxmx = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8 || fp6) && d.b_type == d.a_type;
+    const auto bytes_of = [](int type, size_t elems) { return type == LIBXSMM_DATATYPE_MXFP4X2 ? elems / 2 : (type == LIBXSMM_DATATYPE_MXBF6 || type == LIBXSMM_DATATYPE_MXHF6) ? elems * 3 / 4 : elems * (size_t)typesize(type); };
     const size_t ea = bytes_of(d.a_type, (size_t)a.lda * (size_t)(ta ? a.m : a.k));
     const size_t eb = bytes_of(d.b_type, (size_t)a.ldb * (size_t)((tb || mxmx) ? a.k : a.n));
     const size_t ec = (size_t)a.ldc * (size_t)(a.n + (a.vnni_c ? (a.n & 1) : 0)) * (size_t)typesize(d.c_type);
@@ -491,8 +493,9 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
       if (a.relu_mask) a.relu_mask = (unsigned char*)stage(a.relu_mask, (size_t)(((a.ldc + 15) / 16) * 16 / 8) * (size_t)a.n, true, true);
       // E8M0 scales: one byte per 32 elements, so a batch-reduce element is (stride * elements-per-byte / 32) bytes further on
       const size_t epb_a = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1, epb_b = (d.b_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
-      if (a.a_scf) a.a_scf = (const char*)stage(a.a_scf, span * ((size_t)a.br_stride_a * epb_a / 32) + (size_t)a.lda * (size_t)(a.k / 32), true, false);
-      if (a.b_scf) a.b_scf = (const char*)stage(a.b_scf, span * ((size_t)a.br_stride_b * epb_b / 32) + (size_t)a.ldb * (size_t)(a.k / 32), true, false);
+      const size_t sc_step_a = fp6 ? (size_t)a.br_stride_a / 24 : (size_t)a.br_stride_a * epb_a / 32, sc_step_b = fp6 ? (size_t)a.br_stride_b / 24 : (size_t)a.br_stride_b * epb_b / 32;
+      if (a.a_scf) a.a_scf = (const char*)stage(a.a_scf, span * sc_step_a + (size_t)a.lda * (size_t)(a.k / 32), true, false);
+      if (a.b_scf) a.b_scf = (const char*)stage(a.b_scf, span * sc_step_b + (size_t)a.ldb * (size_t)(a.k / 32), true, false);
       if (!a.a || !a.b || !a.c) return;
     }
   }

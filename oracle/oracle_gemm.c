@@ -305,7 +305,18 @@ static void contract_mxfp4(const gemm_view* v, const libxsmm_gemm_param* p, void
  * first and fp4 adds 8 products ascending; batch-reduce elements are contiguous blocks (r * ld * k elements), the reference's
  * MX x MX path knows no other addressing [ref: gemm ref :2620-2665 (fp8), :2731-2785 (fp4), :836-845]. */
 static int is_mxmx(const oracle_gemm_desc* d) {
-  return d->b_type == d->a_type && (d->a_type == LIBXSMM_DATATYPE_MXFP4X2 || d->a_type == LIBXSMM_DATATYPE_MXBF8 || d->a_type == LIBXSMM_DATATYPE_MXHF8);
+  return d->b_type == d->a_type && (d->a_type == LIBXSMM_DATATYPE_MXFP4X2 || d->a_type == LIBXSMM_DATATYPE_MXBF8 || d->a_type == LIBXSMM_DATATYPE_MXHF8 ||
+                                    d->a_type == LIBXSMM_DATATYPE_MXBF6 || d->a_type == LIBXSMM_DATATYPE_MXHF6);
+}
+/* 6-bit floats of the MX formats (no infinities, no NaNs): E2M3 ("HF6": bias 1, subnormals m / 8) and E3M2 ("BF6": bias 3, subnormals m / 16).
+ * The reference goes through E4M3 with two look-up tables [ref: gemm ref :70-92]; every 6-bit value is exact there, so this is the same number. */
+static float fp6_value(unsigned int v, int e3m2) {
+  const unsigned int sign = (v >> 5) & 1u;
+  const unsigned int e = e3m2 ? ((v >> 2) & 7u) : ((v >> 3) & 3u), m = e3m2 ? (v & 3u) : (v & 7u);
+  float mag;
+  if (e3m2) mag = (e == 0) ? (float)m * 0.0625f : (1.0f + (float)m * 0.25f) * (float)(1u << e) * 0.125f;
+  else mag = (e == 0) ? (float)m * 0.125f : (1.0f + (float)m * 0.125f) * (float)(1u << e) * 0.5f;
+  return sign ? -mag : mag;
 }
 static float e8m0(unsigned char s) { union { unsigned int u; float f; } cv; cv.u = ((unsigned int)s) << 23; return cv.f; }
 static void contract_mxmx(const gemm_view* v, const libxsmm_gemm_param* p, float* cmat, int beta0) {
@@ -333,6 +344,22 @@ static void contract_mxmx(const gemm_view* v, const libxsmm_gemm_param* p, float
             }
             { float t2 = tmp * sca; t2 = t2 * scb; acc = acc + t2; }
           }
+        }
+      } else if (d->a_type == LIBXSMM_DATATYPE_MXBF6 || d->a_type == LIBXSMM_DATATYPE_MXHF6) {
+        /* four 6-bit values of a row's k-group in three bytes, [k/4][ld][3]; a batch-reduce element is (ld * 6 / 8) * k bytes [ref: :2680-2727] */
+        const int e3m2 = (d->a_type == LIBXSMM_DATATYPE_MXBF6);
+        const long long slab_a = ((lda * 6) / 8) * k, slab_b = ((ldb * 6) / 8) * k;
+        for (s = 0; s < k / 4; ++s) {
+          const float sca = e8m0(sa[r * lda * (k / 32) + (s / 8) * lda + i]), scb = e8m0(sb[r * ldb * (k / 32) + (s / 8) * ldb + j]);
+          const unsigned char* pa = a + r * slab_a + s * lda * 3 + i * 3; const unsigned char* pb = b + r * slab_b + s * ldb * 3 + j * 3;
+          const unsigned int va = (unsigned int)pa[0] | ((unsigned int)pa[1] << 8) | ((unsigned int)pa[2] << 16);
+          const unsigned int vb = (unsigned int)pb[0] | ((unsigned int)pb[1] << 8) | ((unsigned int)pb[2] << 16);
+          float tmp = 0.0f;
+          for (k2 = 3; k2 >= 0; --k2) {
+            const float prod = fp6_value((va >> (6 * k2)) & 0x3f, e3m2) * fp6_value((vb >> (6 * k2)) & 0x3f, e3m2);
+            tmp = tmp + prod;
+          }
+          { float t2 = tmp * sca; t2 = t2 * scb; acc = acc + t2; }
         }
       } else {
         for (s = 0; s < k / 4; ++s) {

@@ -336,3 +336,10 @@ def sparsify(rng: np.random.Generator, a_mem: np.ndarray, frac: float) -> np.nda
     out = a_mem.copy()
     out[rng.random(out.size) < frac] = 0
     return out
+
+
+def mx6_operands(rng: np.random.Generator, k: int, ld: int, nbr: int):
+    """An MXBF6 / MXHF6 operand: nbr blocks of [k/4][ld][3 bytes] (four 6-bit values of a row per k-group; every bit pattern is a number) and
+    its E8M0 scales [k/32][ld] in a narrow band around 1 [ref: generator_gemm_reference_impl.c:2680-2727]."""
+    assert k % 32 == 0 and (ld * 6) % 8 == 0
+    return rng.integers(0, 256, nbr * (k // 4) * ld * 3).astype(np.uint8), rng.integers(124, 131, nbr * (k // 32) * ld).astype(np.uint8)

@@ -9,7 +9,7 @@ import pytest
 
 import ctypes as C
 
-from helpers import GemmCase, TOL_BF16, TOL_F32, compress_by_bitmask, normf_rel, rand_values, sparsify
+from helpers import GemmCase, TOL_BF16, TOL_F32, compress_by_bitmask, mx6_operands, normf_rel, rand_values, sparsify
 from libxsmm_amd import capi
 from libxsmm_amd.capi import DT, GEMM_FLAG
 
@@ -123,6 +123,33 @@ def test_bitmask_compressed_a_restatement_is_bit_identical_to_reference_c_kernel
     assert outs[0].tobytes() == outs[1].tobytes()
     if frac == 1.0 and not beta:
         assert not np.any(outs[0].reshape(n, ldc)[:, :m])          # an all-zero A: C = 0
+
+
+# 6-bit MX formats (E3M2 = MXBF6, E2M3 = MXHF6) x the same, E8M0 block scales, f32 out [ref: generator_gemm_reference_impl.c:2680-2727]
+@pytest.mark.parametrize("dt", [DT.MXBF6, DT.MXHF6])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta", [(32, 32, 64, 32, 32, 32, 1, 0), (17, 9, 32, 20, 12, 24, 1, 1), (32, 16, 64, 32, 16, 32, 3, 0), (8, 12, 96, 8, 12, 8, 2, 1)])
+def test_mx6_gemm_restatement_is_bit_identical_to_reference_c_kernel(reference, oracle, dt, m, n, k, lda, ldb, ldc, br, beta):
+    from oracle import pyoracle
+    rng = np.random.default_rng(61)
+    A, SA = mx6_operands(rng, k, lda, br)
+    B, SB = mx6_operands(rng, k, ldb, br)
+    C0 = rand_values(rng, ldc * n, DT.F32)
+    flags = F.VNNI_A | F.VNNI_B | F.TRANS_B | (0 if beta else F.BETA_0) | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    sa_bytes, sb_bytes = (lda * 6 // 8) * k, (ldb * 6 // 8) * k
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, dt, dt, DT.F32, DT.F32)
+    cnt = C.c_ulonglong(br)
+    outs = []
+    for who in ("oracle", "reference"):
+        c = C0.copy()
+        p = capi.GemmParam()
+        p.a.primary, p.a.tertiary, p.b.primary, p.b.tertiary, p.c.primary, p.op.tertiary = A.ctypes.data, SA.ctypes.data, B.ctypes.data, SB.ctypes.data, c.ctypes.data, C.addressof(cnt)
+        if who == "oracle":
+            oracle.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, dt, dt, DT.F32, DT.F32, flags | F.USE_XGEMM_ABI, sa_bytes, sb_bytes, 0, 0))
+        else:
+            cfg = capi.br_config(capi.BR_STRIDE, sa_bytes, sb_bytes, 0) if br > 1 else capi.br_config(capi.BR_NONE, 0, 0, 0)
+            assert reference.lib.xref_reference_gemm(C.byref(p), shape, flags, 0, cfg) == 0
+        outs.append(c)
+    assert outs[0].tobytes() == outs[1].tobytes()
 
 
 def test_bf16_conversion_matches_reference(reference, oracle):
