@@ -2507,7 +2507,11 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
   if ((d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8 || d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6) && d.b_type == d.a_type) {
     // MX x MX -> f32 [ref: gemm ref :2620-2790]: A in VNNI, B in VNNI and transposed, no address/offset batch-reduce, no fused ops [:836-855]
     const unsigned int flx = d.flags;
-    if (d.c_type != LIBXSMM_DATATYPE_F32 || d.comp_type != LIBXSMM_DATATYPE_F32) return false;      // MX-typed outputs are not built
+    // C: f32, or the operands' own MX type for E2M1 / E5M2 (quantised in 32-row blocks, scales to c.tertiary; beta = 0 only: the reference
+    // accumulates into an uninitialised buffer otherwise) [ref: gemm ref :2624-2678, :2731-2798]
+    const bool mx_out = d.c_type == d.a_type && (d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8);
+    if ((d.c_type != LIBXSMM_DATATYPE_F32 && !mx_out) || d.comp_type != LIBXSMM_DATATYPE_F32) return false;
+    if (mx_out && (!(flx & LIBXSMM_GEMM_FLAG_BETA_0) || (d.m % 32) != 0 || (d.ldc % 32) != 0 || (flx & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI))) return false;
     const unsigned int need = LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_TRANS_B;
     if ((flx & need) != need || (flx & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_VNNI_C | LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT |
         LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET))) return false;

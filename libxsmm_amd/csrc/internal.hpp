@@ -222,6 +222,7 @@ int launch_gemm(const GemmArgs& args, void* stream, const char** kernel_name);
 const char* gemm_kernel_name(const libxsmm_gemm_descriptor& d, bool batched);
 bool gemm_supported(const libxsmm_gemm_descriptor& d);
 int launch_meltw(const MeltwArgs& args, void* stream, const char** kernel_name);
+int launch_mx_out_quant(const float* src, void* dst, void* scf, int m, int n, int ldc, int fp4, unsigned int nbatch, long long bs_dst, long long bs_scf, void* stream);
 int launch_bitmask_expand(const void* bitmap, const void* vals, void* dense, unsigned int* rows_scratch, int rows, int row_bytes, int elem_size, void* stream);
 int launch_stochastic_bf8(const MeltwArgs& args, void* stream);     // second pass of a TPP with *_STOCHASTIC_ROUND: f32 results -> BF8
 bool meltw_supported(const libxsmm_meltw_descriptor& d);

@@ -1368,6 +1368,60 @@ static bool gs_rows_lds_ok(const MeltwArgs& a, int sz) {
   return (base & 15) == 0;
 }
 
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+// MX-typed C of an MX x MX GEMM [ref: gemm ref :661-817]: the f32 result [batch][n][ldc] is quantised in blocks of 32 consecutive rows --
+// the reference's bf16-flavoured pipeline (inputs, scale, reciprocal and every scaled value pass through bf16), NOT the QUANT TPP's exact one.
+// One thread per block: 128 bytes in, 16 (E2M1 pairs) or 32 (E5M2) bytes + one scale byte out.
+__global__ __launch_bounds__(256) void mx_out_quant_kernel(const float* src_, unsigned char* dst_, unsigned char* scf_, int m, int n, int ldc, int fp4,
+                                                           unsigned int nbatch, long long bs_dst, long long bs_scf, unsigned int total) {
+  const unsigned int t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= total) return;
+  const unsigned int mblk = (unsigned int)m / 32u, per = mblk * (unsigned int)n;
+  const unsigned int b = t / per, r = t - b * per, j = r / mblk, i = (r - j * mblk) * 32u;
+  GM const float* in = (GM const float*)src_ + ((long long)b * n + j) * ldc + i;
+  float x[32], amax = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { const f32x4m v = *(GM const f32x4m*)(in + 4 * q); x[4 * q] = nv_bf16(v[0]); x[4 * q + 1] = nv_bf16(v[1]); x[4 * q + 2] = nv_bf16(v[2]); x[4 * q + 3] = nv_bf16(v[3]); }
+#pragma unroll
+  for (int e = 0; e < 32; ++e) { const float a = fabsf(x[e]); if (a > amax || a != a) amax = a; }
+  int se = (amax == 0.0f) ? 0 : (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  se -= fp4 ? 2 : 15;
+  se = se < 0 ? 0 : (se > 254 ? 254 : se);
+  ((GM unsigned char*)scf_)[(long long)b * bs_scf + (long long)j * (ldc / 32) + i / 32u] = (unsigned char)se;
+  const float scale = nv_bf16(__uint_as_float(((unsigned int)se << 23) | (se == 0 ? (1u << 22) : 0u)));
+  const float rcp = nv_bf16(1.0f / scale);
+  if (fp4) {
+    GM unsigned char* out = (GM unsigned char*)dst_ + (long long)b * bs_dst + (long long)j * (ldc / 2) + i / 2u;
+    unsigned int w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const float a = fabsf(nv_bf16(x[e] * rcp));
+      const unsigned int code = (a != a) ? 7u : (a > 5.0f) ? 7u : (a >= 3.5f) ? 6u : (a > 2.5f) ? 5u : (a >= 1.75f) ? 4u : (a > 1.25f) ? 3u : (a >= 0.75f) ? 2u : (a > 0.25f) ? 1u : 0u;
+      w[e / 8] |= (((__float_as_uint(x[e]) >> 31) << 3) | code) << (4 * (e % 8));
+    }
+    u32x4m o; o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3];
+    *(GM u32x4m*)out = o;
+  } else {
+    GM unsigned char* out = (GM unsigned char*)dst_ + (long long)b * bs_dst + (long long)j * ldc + i;
+    unsigned int w[8];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      unsigned int c = (unsigned int)lowp::f16_to_bf8_rne(lowp::f32_to_f16(nv_bf16(x[e] * rcp)));
+      if ((c & 0x7cu) == 0x7cu) c = (c & 0x80u) | 0x7bu;
+      if (e % 4 == 0) w[e / 4] = c; else w[e / 4] |= c << (8 * (e % 4));
+    }
+    u32x4m o0, o1; o0[0] = w[0]; o0[1] = w[1]; o0[2] = w[2]; o0[3] = w[3]; o1[0] = w[4]; o1[1] = w[5]; o1[2] = w[6]; o1[3] = w[7];
+    *(GM u32x4m*)out = o0; *(GM u32x4m*)(out + 16) = o1;
+  }
+}
+int launch_mx_out_quant(const float* src, void* dst, void* scf, int m, int n, int ldc, int fp4, unsigned int nbatch, long long bs_dst, long long bs_scf, void* stream) {
+  const unsigned long long total = (unsigned long long)(m / 32) * (unsigned long long)n * nbatch;
+  if (total == 0 || total >= (1ull << 32)) return total == 0 ? 0 : (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mx_out_quant_kernel, dim3((unsigned int)((total + 255ull) / 256ull)), dim3(256), 0, (hipStream_t)stream, src, (unsigned char*)dst, (unsigned char*)scf, m, n, ldc, fp4,
+                     nbatch, bs_dst, bs_scf, (unsigned int)total);
+  return (int)hipGetLastError();
+}
+
 static const u32x4m* dropout_jump_tables();
 // second pass of a TPP with stochastic rounding: `a.in0` = the f32 results [call][n][m], `a.out` = the BF8 destination, a.aux_in = the state
 int launch_stochastic_bf8(const MeltwArgs& a, void* stream) {

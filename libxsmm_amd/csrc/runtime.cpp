@@ -439,6 +439,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     a.scf = *(const float*)p->c.tertiary;
   }
   const bool a_fp6 = d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6;
+  char* c_scf = nullptr;                       // MX-typed C: where its block scales go
   if ((d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8 || a_fp6) && d.b_type == d.a_type) {
     // MX x MX: scales of A in a.tertiary, of B in b.tertiary [ref: gemm ref :577-583]; a batched launch steps them with their operand:
     // one scale byte per 32 elements
@@ -446,6 +447,11 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     if (b.la) { set_error(-3, "MX x MX GEMM: pointer-list batches carry no scale lists; use the strided batch"); return; }
     const long long epb = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
     if (b.count > 1 && (a_fp6 ? (((b.s[0] | b.s[1]) % 24) != 0) : ((((b.s[0] | b.s[1]) * epb) % 32) != 0))) { set_error(-3, "MX x MX GEMM: batch strides must cover whole 32-element scale blocks"); return; }
+    if (d.c_type == d.a_type && (d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8)) {
+      if (!p->c.tertiary) { set_error(-2, "MX-typed C needs room for its E8M0 scales in c.tertiary"); return; }
+      if (b.la || b.inner) { set_error(-3, "MX-typed C: strided batches only"); return; }
+      c_scf = (char*)p->c.tertiary;
+    }
     a.a_scf = (const char*)p->a.tertiary; a.bs_scf = a_fp6 ? b.s[0] / 24 : b.s[0] * epb / 32;       // 6-bit: 32 elements are 24 bytes
     a.b_scf = (const char*)p->b.tertiary; a.bs_bscf = a_fp6 ? b.s[1] / 24 : b.s[1] * epb / 32;
   } else if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {
@@ -483,7 +489,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     const auto bytes_of = [](int type, size_t elems) { return type == LIBXSMM_DATATYPE_MXFP4X2 ? elems / 2 : (type == LIBXSMM_DATATYPE_MXBF6 || type == LIBXSMM_DATATYPE_MXHF6) ? elems * 3 / 4 : elems * (size_t)typesize(type); };
     const size_t ea = bytes_of(d.a_type, (size_t)a.lda * (size_t)(ta ? a.m : a.k));
     const size_t eb = bytes_of(d.b_type, (size_t)a.ldb * (size_t)((tb || mxmx) ? a.k : a.n));
-    const size_t ec = (size_t)a.ldc * (size_t)(a.n + (a.vnni_c ? (a.n & 1) : 0)) * (size_t)typesize(d.c_type);
+    const size_t ec = bytes_of(d.c_type, (size_t)a.ldc * (size_t)(a.n + (a.vnni_c ? (a.n & 1) : 0)));
     const size_t span = (a.br_mode == 3) ? (size_t)(a.br_count - 1) : 0;
     if (a.br_mode != 3 || (a.br_stride_a >= 0 && a.br_stride_b >= 0)) {
       a.a = (const char*)stage(a.a, span * (size_t)a.br_stride_a + ea, true, false);
@@ -496,10 +502,29 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
       const size_t sc_step_a = fp6 ? (size_t)a.br_stride_a / 24 : (size_t)a.br_stride_a * epb_a / 32, sc_step_b = fp6 ? (size_t)a.br_stride_b / 24 : (size_t)a.br_stride_b * epb_b / 32;
       if (a.a_scf) a.a_scf = (const char*)stage(a.a_scf, span * sc_step_a + (size_t)a.lda * (size_t)(a.k / 32), true, false);
       if (a.b_scf) a.b_scf = (const char*)stage(a.b_scf, span * sc_step_b + (size_t)a.ldb * (size_t)(a.k / 32), true, false);
+      if (c_scf) c_scf = (char*)stage(c_scf, (size_t)(a.ldc / 32) * (size_t)a.n, true, true);     // copied in as well: the entries of padded rows stay the caller's
       if (!a.a || !a.b || !a.c) return;
     }
   }
   const char* kname = nullptr;
+  if (c_scf) {
+    // MX-typed C [ref: gemm ref :2666-2678, :2787-2798]: the product goes to an f32 image in the workspace, a second kernel quantises it in
+    // 32-row blocks (data to c.primary, E8M0 scales to c.tertiary); a batched launch steps the scales with C (one byte per 32 elements)
+    const bool fp4 = d.c_type == LIBXSMM_DATATYPE_MXFP4X2;
+    const size_t img = (size_t)a.ldc * (size_t)a.n * sizeof(float);
+    float* ws = (float*)workspace(img * a.nbatch);
+    if (!ws) return;
+    if (a.nbatch > 1 && ((a.bs_c * (fp4 ? 2 : 1)) % 32) != 0) { set_error(-3, "MX-typed C: the batch stride must cover whole 32-element scale blocks"); return; }
+    GemmArgs pa = a;
+    pa.c = (char*)ws; pa.c_type = LIBXSMM_DATATYPE_F32; pa.bs_c = (long long)img; pa.bs_c2 = 0; pa.batch_inner = 0; pa.list_c = nullptr;
+    rt_workspace_reserve(img * a.nbatch);
+    int err = launch_gemm(pa, tls().stream, &kname);
+    rt_workspace_reserve(0);
+    if (err == 0) err = launch_mx_out_quant(ws, a.c, c_scf, a.m, a.n, a.ldc, fp4 ? 1 : 0, a.nbatch, a.bs_c, a.bs_c * (fp4 ? 2 : 1) / 32, tls().stream);
+    if (kname) { if (b.count > 1) k->kname_batched = kname; else k->kname_single = kname; }
+    finish_launch(err, kname);
+    return;
+  }
   // One (or very few) problems with a long STRIDE batch-reduce chain would run on a handful of waves: split the chain
   // into `nsplit` segments that run as a batch of partial products (f32 tiles in a workspace), then add them up and
   // apply beta / bias / activation in a second pass (SURVEY 8(d) config #2 variant B: one BRGEMM with br = 4096).

@@ -378,6 +378,44 @@ static void contract_mxmx(const gemm_view* v, const libxsmm_gemm_param* p, float
   }
 }
 
+/* MX-typed C of an MX x MX GEMM [ref: gemm ref :661-817]: 32 consecutive rows of a column share one E8M0 scale.  The reference mimics its JIT,
+ * which works in bf16: inputs rounded to bf16, shared exponent = exponent(amax) - emax_elem (2 for E2M1, 15 for E5M2) clamped to 0..254 (NaN
+ * sticks in amax), scale and reciprocal are powers of two passed through bf16, every scaled value is rounded to bf16 again and then encoded
+ * (E2M1 by thresholds with the sign of the input; E5M2 by RNE, infinities and NaNs saturate to the largest normal). */
+static unsigned char e2m1_abs_code(float a) {
+  return (a != a) ? 7 : (a > 5.0f) ? 7 : (a >= 3.5f) ? 6 : (a > 2.5f) ? 5 : (a >= 1.75f) ? 4 : (a > 1.25f) ? 3 : (a >= 0.75f) ? 2 : (a > 0.25f) ? 1 : 0;
+}
+static void mx_out_block(const float* in, unsigned char* out, unsigned char* out_scale, int fp4) {
+  union { float f; unsigned int u; } cv;
+  float x[32], amax = 0.0f, scale, rcp;
+  int i, e;
+  for (i = 0; i < 32; ++i) x[i] = oracle_bf16_to_f32(oracle_f32_to_bf16_rne(in[i]));
+  for (i = 0; i < 32; ++i) { const float a = fabsf(x[i]); if (a > amax || a != a) amax = a; }
+  cv.f = amax;
+  e = (amax == 0.0f) ? 0 : (int)((cv.u >> 23) & 0xffu);
+  e -= fp4 ? 2 : 15;
+  if (e < 0) e = 0;
+  if (e > 254) e = 254;
+  *out_scale = (unsigned char)e;
+  cv.u = ((unsigned int)e << 23) | (e == 0 ? (1u << 22) : 0u);
+  scale = oracle_bf16_to_f32(oracle_f32_to_bf16_rne(cv.f));
+  rcp = 1.0f / scale;
+  rcp = oracle_bf16_to_f32(oracle_f32_to_bf16_rne(rcp));
+  for (i = 0; i < 32; ++i) {
+    float v = x[i] * rcp;
+    v = oracle_bf16_to_f32(oracle_f32_to_bf16_rne(v));
+    if (fp4) {
+      cv.f = x[i];
+      { const unsigned char code = (unsigned char)(((cv.u >> 31) ? 8u : 0u) | e2m1_abs_code(fabsf(v)));
+        if (i & 1) out[i / 2] = (unsigned char)((out[i / 2] & 0x0f) | (code << 4)); else out[i / 2] = code; }
+    } else {
+      unsigned char b = oracle_f32_to_bf8_rne(v);
+      if ((b & 0x7c) == 0x7c) b = (unsigned char)((b & 0x80) | 0x7b);
+      out[i] = b;
+    }
+  }
+}
+
 /* A compressed by bitmask (LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) [ref: generator_gemm_reference_impl.c:857-948]: a.primary holds only the
  * non-zeros, in the order k-group s, row i, k inside the group (= memory order of the VNNI image for 16-bit types); a.secondary holds one bit
  * per element, row s of the bit matrix being m * kb bits (bit order: LSB first, mateltwise ref :170-178).  Products are added in that order,
@@ -442,6 +480,21 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
     contract_f16(&v, cptr, beta0); return;
   }
   if (is_mxmx(d) && d->c_type == LIBXSMM_DATATYPE_F32) { contract_mxmx(&v, p, (float*)cptr, beta0); return; }
+  if (is_mxmx(d) && d->c_type == d->a_type && (d->a_type == LIBXSMM_DATATYPE_MXFP4X2 || d->a_type == LIBXSMM_DATATYPE_MXBF8) && beta0) {
+    /* C of the operands' MX type: the f32 result is quantised block by block, data to c.primary, scales to c.tertiary [ref: :2666-2678, :2787-2798] */
+    const int fp4 = (d->a_type == LIBXSMM_DATATYPE_MXFP4X2);
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)d->ldc * (size_t)d->n);
+    oracle_gemm_desc df = *d;
+    gemm_view vf;
+    df.c_type = LIBXSMM_DATATYPE_F32;
+    setup_view(&vf, param, &df);
+    contract_mxmx(&vf, p, tmp, 1);
+    for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; i += 32)
+      mx_out_block(tmp + (long long)j * d->ldc + i, (unsigned char*)cptr + (fp4 ? ((long long)j * (d->ldc / 2) + i / 2) : ((long long)j * d->ldc + i)),
+                   (unsigned char*)p->c.tertiary + (long long)j * (d->ldc / 32) + i / 32, fp4);
+    free(tmp);
+    return;
+  }
   if (d->a_type == LIBXSMM_DATATYPE_MXFP4X2) { contract_mxfp4(&v, p, cptr, beta0); return; }
 
   {

@@ -634,3 +634,64 @@ def test_mx6_gemm_bit_exact(dt, m, n, k, lda, ldb, ldc, br, beta, batch):
         assert np.array_equal(got, ref)
     # what the 6-bit formats do not have here: other output types, missing scales
     assert api.dispatch_gemm(capi.gemm_shape(m, n, k, lda, ldb, ldc, dt, dt, DT.BF16, DT.F32), flags, 0) is None
+
+
+# MX-typed C of an MX x MX GEMM [ref: gemm ref :661-817,2666-2678,2787-2798]: the f32 product is quantised in 32-row blocks, E8M0 scales to c.tertiary.
+# k = 32 / 96 run the generic kernel, whose f32 image is bit-identical to the oracle's: the bytes must be too.  k = 64 / 128 run the matrix cores
+# (another summation order): a value that sits on a rounding boundary may take the neighbouring code, nothing else may differ.
+@pytest.mark.parametrize("dt", [DT.MXFP4X2, DT.MXBF8])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,batch", [(32, 32, 32, 32, 32, 32, 1, 1), (64, 9, 96, 64, 12, 96, 2, 1), (32, 16, 32, 32, 16, 64, 1, 6), (64, 64, 64, 64, 64, 64, 1, 1), (64, 32, 128, 64, 32, 64, 2, 9)])
+def test_mx_typed_gemm_output(dt, m, n, k, lda, ldb, ldc, br, batch):
+    import torch
+    from oracle import pyoracle
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(72)
+    fp4 = dt == DT.MXFP4X2
+    epb = 2 if fp4 else 1
+    A = rng.integers(0, 256, batch * br * lda * k // epb).astype(np.uint8); B = rng.integers(0, 256, batch * br * ldb * k // epb).astype(np.uint8)
+    if not fp4:
+        A[(A & 0x7c) == 0x7c] &= 0x83; B[(B & 0x7c) == 0x7c] &= 0x83
+    SA = rng.integers(110, 140, batch * br * (k // 32) * lda).astype(np.uint8); SB = rng.integers(110, 140, batch * br * (k // 32) * ldb).astype(np.uint8)
+    flags = F.VNNI_A | F.VNNI_B | F.TRANS_B | F.BETA_0
+    sa_b, sb_b, c_b, cs_b = lda * k // epb, ldb * k // epb, ldc * n // epb, (ldc // 32) * n
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, dt, dt, dt, DT.F32)
+    cnt = C.c_ulonglong(br)
+    ref_c = np.full(batch * c_b, 0x5a, dtype=np.uint8); ref_s = np.full(batch * cs_b, 0x5a, dtype=np.uint8)
+    oflags = flags | F.USE_XGEMM_ABI | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    for b in range(batch):
+        p = capi.GemmParam()
+        p.a.primary, p.a.tertiary = A.ctypes.data + b * br * sa_b, SA.ctypes.data + b * br * (k // 32) * lda
+        p.b.primary, p.b.tertiary = B.ctypes.data + b * br * sb_b, SB.ctypes.data + b * br * (k // 32) * ldb
+        p.c.primary, p.c.tertiary, p.op.tertiary = ref_c.ctypes.data + b * c_b, ref_s.ctypes.data + b * cs_b, C.addressof(cnt)
+        orc.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, dt, dt, dt, DT.F32, oflags, sa_b, sb_b, 0, 0))
+    h = api.dispatch_brgemm(shape, flags, 0, capi.br_config(capi.BR_STRIDE, sa_b, sb_b, 0)) if br > 1 else api.dispatch_gemm(shape, flags, 0)
+    assert h
+    dA, dSA, dB, dSB = (torch.from_numpy(x.copy()).to("cuda:0") for x in (A, SA, B, SB))
+    dC = torch.full((batch * c_b,), 0x5a, dtype=torch.uint8, device="cuda:0"); dS = torch.full((batch * cs_b,), 0x5a, dtype=torch.uint8, device="cuda:0")
+    p = capi.GemmParam()
+    p.a.primary, p.a.tertiary, p.b.primary, p.b.tertiary, p.c.primary, p.c.tertiary, p.op.tertiary = \
+        dA.data_ptr(), dSA.data_ptr(), dB.data_ptr(), dSB.data_ptr(), dC.data_ptr(), dS.data_ptr(), C.addressof(cnt)
+    if batch == 1:
+        capi.Api.call(h, p)
+    else:
+        api.hip_gemm_batch_strided(h, C.byref(p), batch, br * sa_b, br * sb_b, c_b)
+    api.hip_sync(); api.check()
+    got_c, got_s = dC.cpu().numpy(), dS.cpu().numpy()
+    rows = lambda x, w: x.reshape(batch * n, w)[:, :w * m // ldc]
+    rc, gc, rs, gs = rows(ref_c, ldc // epb), rows(got_c, ldc // epb), rows(ref_s, ldc // 32), rows(got_s, ldc // 32)
+    assert np.array_equal(rows(got_c, ldc // epb)[:, :0], rc[:, :0]) and np.array_equal(got_c.reshape(batch * n, -1)[:, (ldc // epb) * m // ldc:], ref_c.reshape(batch * n, -1)[:, (ldc // epb) * m // ldc:])   # padding untouched
+    if k % 64 != 0:
+        assert "generic" in api.hip_kernel_name(h, 1 if batch > 1 else 0).decode()
+        assert np.array_equal(gs, rs) and np.array_equal(gc, rc)
+    else:
+        assert np.mean(gs == rs) > 0.98
+        same_block = np.repeat(gs == rs, 32 // epb, axis=1)                       # compare codes only where the shared scale agrees
+        assert np.mean((gc == rc)[same_block]) > 0.97
+    if batch == 1:                                # plain host memory
+        hc, hs = np.full(c_b, 0x5a, dtype=np.uint8), np.full(cs_b, 0x5a, dtype=np.uint8)
+        p.a.primary, p.a.tertiary, p.b.primary, p.b.tertiary, p.c.primary, p.c.tertiary = A.ctypes.data, SA.ctypes.data, B.ctypes.data, SB.ctypes.data, hc.ctypes.data, hs.ctypes.data
+        capi.Api.call(h, p)
+        api.check()
+        assert np.array_equal(hc, got_c) and np.array_equal(hs, got_s)
+    # beta = 1 into an MX-typed C is refused (the reference accumulates into an uninitialised buffer there)
+    assert api.dispatch_gemm(shape, flags & ~F.BETA_0, 0) is None

@@ -152,6 +152,41 @@ def test_mx6_gemm_restatement_is_bit_identical_to_reference_c_kernel(reference, 
     assert outs[0].tobytes() == outs[1].tobytes()
 
 
+# MX-typed C of an MX x MX GEMM [ref: generator_gemm_reference_impl.c:661-817,2666-2678,2787-2798]: data to c.primary, E8M0 scales to c.tertiary
+@pytest.mark.parametrize("dt", [DT.MXFP4X2, DT.MXBF8])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,wide", [(32, 32, 64, 32, 32, 32, 1, 0), (64, 9, 32, 64, 12, 96, 1, 1), (32, 16, 64, 32, 16, 64, 3, 0), (96, 5, 128, 96, 8, 96, 2, 1)])
+def test_mx_typed_gemm_output_is_bit_identical_to_reference_c_kernel(reference, oracle, dt, m, n, k, lda, ldb, ldc, br, wide):
+    from oracle import pyoracle
+    rng = np.random.default_rng(71)
+    fp4 = dt == DT.MXFP4X2
+    epb = 2 if fp4 else 1
+    A = rng.integers(0, 256, br * lda * k // epb).astype(np.uint8); B = rng.integers(0, 256, br * ldb * k // epb).astype(np.uint8)
+    if not fp4:                                   # E5M2 operands: no infinities / NaNs among the inputs (exponent field 31)
+        A[(A & 0x7c) == 0x7c] &= 0x83; B[(B & 0x7c) == 0x7c] &= 0x83
+    lo, hi = (100, 150) if wide else (124, 131)   # wide: results from the subnormal range up to overflowing blocks
+    SA = rng.integers(lo, hi, br * (k // 32) * lda).astype(np.uint8); SB = rng.integers(lo, hi, br * (k // 32) * ldb).astype(np.uint8)
+    flags = F.VNNI_A | F.VNNI_B | F.TRANS_B | F.BETA_0 | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    sa_bytes, sb_bytes = lda * k // epb, ldb * k // epb
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, dt, dt, dt, DT.F32)
+    cnt = C.c_ulonglong(br)
+    outs = []
+    for who in ("oracle", "reference"):
+        c = np.full(ldc * n // epb, 0x5a, dtype=np.uint8); sc = np.full((ldc // 32) * n, 0x5a, dtype=np.uint8)
+        p = capi.GemmParam()
+        p.a.primary, p.a.tertiary, p.b.primary, p.b.tertiary, p.c.primary, p.c.tertiary, p.op.tertiary = \
+            A.ctypes.data, SA.ctypes.data, B.ctypes.data, SB.ctypes.data, c.ctypes.data, sc.ctypes.data, C.addressof(cnt)
+        if who == "oracle":
+            oracle.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, dt, dt, dt, DT.F32, flags | F.USE_XGEMM_ABI, sa_bytes, sb_bytes, 0, 0))
+        else:
+            cfg = capi.br_config(capi.BR_STRIDE, sa_bytes, sb_bytes, 0) if br > 1 else capi.br_config(capi.BR_NONE, 0, 0, 0)
+            assert reference.lib.xref_reference_gemm(C.byref(p), shape, flags, 0, cfg) == 0
+        outs.append((c, sc))
+    rows = lambda x, w: x.reshape(n, w)[:, :w * m // ldc]
+    assert np.array_equal(rows(outs[0][0], ldc // epb), rows(outs[1][0], ldc // epb))
+    assert np.array_equal(rows(outs[0][1], ldc // 32), rows(outs[1][1], ldc // 32))
+    assert len(np.unique(outs[0][1])) > 1
+
+
 def test_bf16_conversion_matches_reference(reference, oracle):
     rng = np.random.default_rng(1)
     vals = np.concatenate([rng.standard_normal(2000).astype(np.float32) * 10.0 ** rng.integers(-40, 38, 2000),
