@@ -307,6 +307,38 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     return;
   }
 
+  if (p.a_type == LIBXSMM_DATATYPE_I1X8 || p.a_type == LIBXSMM_DATATYPE_I2X4) {
+    // 1-bit (+-1) and 2-bit (0, +1, -1) weights x 8-bit activations -> i32 [ref: gemm ref :1100-1300]; layouts as in oracle_gemm.c contract_lowbit
+    if (!valid) return;
+    const bool ub = p.b_type == LIBXSMM_DATATYPE_U8, one_bit = p.a_type == LIBXSMM_DATATYPE_I1X8;
+    const int mq = p.m / 4;
+    GM int* c = (GM int*)q.c + (long long)j * p.ldc + i;
+    int acc = beta0 ? 0 : *c;
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      gcptr ar, br; br_base(p, q, r, ar, br);
+      GM const unsigned char* a = (GM const unsigned char*)ar;
+      for (int s = 0; s < p.k / 4; ++s) {
+        const unsigned int bw = *(GM const unsigned int*)(br + (long long)j * p.ldb + 4 * s);      // four k of the column (k % 4 == 0, ldb % 4 == 0, base 4-byte aligned: launch checks)
+        if (one_bit) {
+          const unsigned int nib = ((unsigned int)a[((long long)s * p.lda) / 2 + i / 2] >> (4 * (i & 1))) & 15u;
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) { const int bv = ub ? (int)((bw >> (8 * k2)) & 255u) : (int)(signed char)(bw >> (8 * k2)); acc += ((nib >> k2) & 1u) ? -bv : bv; }
+        } else {
+          const unsigned int aw = *(GM const unsigned int*)(ar + (long long)s * p.lda + 4 * (i % mq));
+          const int sh = 2 * (i / mq);
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) {
+            const unsigned int code = (aw >> (8 * k2 + sh)) & 3u;
+            const int bv = ub ? (int)((bw >> (8 * k2)) & 255u) : (int)(signed char)(bw >> (8 * k2));
+            acc += (code == 0u) ? 0 : (code == 1u) ? bv : -bv;
+          }
+        }
+      }
+    }
+    *c = acc;
+    return;
+  }
+
   if (p.a_type == LIBXSMM_DATATYPE_I8 || p.a_type == LIBXSMM_DATATYPE_U8) {
     // 8-bit integer GEMM, i32 accumulation [ref: gemm ref :1452-1683]; A VNNI-4 (always for f32 output), B flat
     if (!valid) return;
@@ -2473,6 +2505,16 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
                     (d.c_type == LIBXSMM_DATATYPE_F32 || d.c_type == LIBXSMM_DATATYPE_BF16);
   const bool i8 = (d.a_type == LIBXSMM_DATATYPE_I8 || d.a_type == LIBXSMM_DATATYPE_U8) && (d.b_type == LIBXSMM_DATATYPE_I8 || d.b_type == LIBXSMM_DATATYPE_U8) &&
                   (d.c_type == LIBXSMM_DATATYPE_I32 || d.c_type == LIBXSMM_DATATYPE_F32);
+  if ((d.a_type == LIBXSMM_DATATYPE_I1X8 || d.a_type == LIBXSMM_DATATYPE_I2X4) && (d.b_type == LIBXSMM_DATATYPE_I8 || d.b_type == LIBXSMM_DATATYPE_U8)) {
+    // [ref: gemm ref :480-486, :1100-1300]: packed 1- / 2-bit weights (VNNI; the 2-bit form interleaved) x 8-bit activations -> i32
+    const unsigned int fl = d.flags;
+    if (d.c_type != LIBXSMM_DATATYPE_I32 || d.comp_type != LIBXSMM_DATATYPE_I32 || !(fl & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
+    if (((fl & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) != 0) != (d.a_type == LIBXSMM_DATATYPE_I2X4)) return false;
+    if (fl & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C | LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI)) return false;
+    if ((d.k & 3) || (d.ldb & 3) || (d.m % (d.a_type == LIBXSMM_DATATYPE_I2X4 ? 4 : 2)) || (d.lda & (d.a_type == LIBXSMM_DATATYPE_I2X4 ? 3 : 1))) return false;
+    if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    return d.lda >= d.m && d.ldb >= d.k && d.ldc >= d.m;
+  }
   if (i8) {   // [ref: gemm ref :1452-1683]: i32 accumulation; no transposes, no fused ops, f32 output needs VNNI-4 A
     const unsigned int fl8 = d.flags;
     if (d.comp_type != LIBXSMM_DATATYPE_I32) return false;

@@ -486,7 +486,8 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     const bool ta = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_A) != 0, tb = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_B) != 0;
     const bool fp6 = d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6;
     const bool mxmx = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8 || fp6) && d.b_type == d.a_type;
-    const auto bytes_of = [](int type, size_t elems) { return type == LIBXSMM_DATATYPE_MXFP4X2 ? elems / 2 : (type == LIBXSMM_DATATYPE_MXBF6 || type == LIBXSMM_DATATYPE_MXHF6) ? elems * 3 / 4 : elems * (size_t)typesize(type); };
+    const auto bytes_of = [](int type, size_t elems) { return type == LIBXSMM_DATATYPE_MXFP4X2 ? elems / 2 : (type == LIBXSMM_DATATYPE_MXBF6 || type == LIBXSMM_DATATYPE_MXHF6) ? elems * 3 / 4 :
+                                                             type == LIBXSMM_DATATYPE_I1X8 ? elems / 8 : type == LIBXSMM_DATATYPE_I2X4 ? elems / 4 : elems * (size_t)typesize(type); };
     const size_t ea = bytes_of(d.a_type, (size_t)a.lda * (size_t)(ta ? a.m : a.k));
     const size_t eb = bytes_of(d.b_type, (size_t)a.ldb * (size_t)((tb || mxmx) ? a.k : a.n));
     const size_t ec = bytes_of(d.c_type, (size_t)a.ldc * (size_t)(a.n + (a.vnni_c ? (a.n & 1) : 0)));

@@ -249,6 +249,40 @@ static void contract_int8(const gemm_view* v, const libxsmm_gemm_param* p, void*
   }
 }
 
+/* 1-bit and 2-bit weights times 8-bit activations -> i32 [ref: gemm ref :1100-1300].
+ * I1X8: a byte holds four k of two rows -- bit (k % 4) of the low nibble for the even row, of the high nibble for the odd row, 0 = +1, 1 = -1 --
+ *       at (k / 4) * lda / 2 + i / 2.
+ * I2X4 (interleaved): the m rows form four groups of m / 4; the byte at (k / 4) * lda + 4 * (i % (m / 4)) + k % 4 holds that k of row
+ *       i % (m / 4) of every group, group g in bits 2 g, 2 g + 1: 0 -> 0, 1 -> +1, 2 and 3 -> -1. */
+static int is_lowbit_a(int t) { return t == LIBXSMM_DATATYPE_I1X8 || t == LIBXSMM_DATATYPE_I2X4; }
+static void contract_lowbit(const gemm_view* v, void* cptr, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const int ub = (d->b_type == LIBXSMM_DATATYPE_U8), one_bit = (d->a_type == LIBXSMM_DATATYPE_I1X8);
+  const long long mq = d->m / 4;
+  long long i, j, r, kk;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    int acc = beta0 ? 0 : ((int*)cptr)[j * d->ldc + i];
+    for (r = 0; r < v->br; ++r) {
+      const br_cursor cur = br_at(v, r);
+      for (kk = 0; kk < d->k; ++kk) {
+        const long long bi = j * (long long)d->ldb + kk;
+        const int bv = ub ? (int)((const unsigned char*)cur.b)[bi] : (int)((const signed char*)cur.b)[bi];
+        int w;
+        if (one_bit) {
+          const unsigned int byte = ((const unsigned char*)cur.a)[((kk / 4) * (long long)d->lda) / 2 + i / 2];
+          w = ((byte >> (4 * (i & 1) + (kk & 3))) & 1u) ? -1 : 1;
+        } else {
+          const unsigned int byte = ((const unsigned char*)cur.a)[(kk / 4) * (long long)d->lda + 4 * (i % mq) + (kk & 3)];
+          const unsigned int code = (byte >> (2 * (i / mq))) & 3u;
+          w = (code == 0) ? 0 : (code == 1) ? 1 : -1;
+        }
+        acc += w * bv;
+      }
+    }
+    ((int*)cptr)[j * d->ldc + i] = acc;
+  }
+}
+
 /* MXFP4 weights: A = packed E2M1 pairs [k/2][lda] bytes (low nibble = even k) with one E8M0 scale per (32-deep k-block, row)
  * in a.tertiary ([k/32][lda] bytes; per batch-reduce element: pointer array / offset*2/32 / stride*2/32); B bf16 or f32 flat;
  * C f32 or bf16; C = (beta ? C : 0) + sum, one RNE for bf16 C [ref: :949-1008, scale :200-222, LUT :60-64, slots :565-569].
@@ -475,6 +509,7 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   if (d->flags & LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) { contract_spmm(d, p, beta0); return; }
   if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
   if (is_int8(d->a_type) && is_int8(d->b_type)) { contract_int8(&v, p, cptr, beta0); return; }
+  if (is_lowbit_a(d->a_type) && is_int8(d->b_type) && d->c_type == LIBXSMM_DATATYPE_I32) { contract_lowbit(&v, cptr, beta0); return; }
   if (is_fp8(d->a_type) && d->b_type == d->a_type && d->c_type == LIBXSMM_DATATYPE_F32) { contract_fp8(&v, (float*)cptr, beta0); return; }
   if (d->a_type == LIBXSMM_DATATYPE_F16 && d->b_type == LIBXSMM_DATATYPE_F16 && (d->c_type == LIBXSMM_DATATYPE_F16 || d->c_type == LIBXSMM_DATATYPE_F32)) {
     contract_f16(&v, cptr, beta0); return;

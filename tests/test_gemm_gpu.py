@@ -695,3 +695,46 @@ def test_mx_typed_gemm_output(dt, m, n, k, lda, ldb, ldc, br, batch):
         assert np.array_equal(hc, got_c) and np.array_equal(hs, got_s)
     # beta = 1 into an MX-typed C is refused (the reference accumulates into an uninitialised buffer there)
     assert api.dispatch_gemm(shape, flags & ~F.BETA_0, 0) is None
+
+
+# 1-bit (+-1) and 2-bit (0, +1, -1, interleaved) weights x 8-bit activations -> i32 [ref: gemm ref :1100-1300]: exact, so bit equality
+@pytest.mark.parametrize("a_type", [DT.I1X8, DT.I2X4])
+@pytest.mark.parametrize("b_type", [DT.I8, DT.U8])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (24, 7, 16, 28, 20, 30, 1, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0, 1), (128, 32, 256, 128, 256, 128, 2, 1, 11)])
+def test_low_bit_weight_gemm_bit_exact(a_type, b_type, m, n, k, lda, ldb, ldc, br, beta, batch):
+    import torch
+    from oracle import pyoracle
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(82)
+    a_b, b_b, c_b = lda * k // (8 if a_type == DT.I1X8 else 4), ldb * n, ldc * n * 4
+    A = rng.integers(0, 256, batch * br * a_b).astype(np.uint8)
+    B = rng.integers(0, 256, batch * br * b_b).astype(np.uint8)
+    C0 = rng.integers(-1000, 1000, batch * ldc * n).astype(np.int32)
+    flags = F.VNNI_A | (F.INTLV_A_FORMAT if a_type == DT.I2X4 else 0) | (0 if beta else F.BETA_0)
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, a_type, b_type, DT.I32, DT.I32)
+    cnt = C.c_ulonglong(br)
+    ref = C0.copy()
+    oflags = flags | F.USE_XGEMM_ABI | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    for b in range(batch):
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = A.ctypes.data + b * br * a_b, B.ctypes.data + b * br * b_b, ref.ctypes.data + b * c_b, C.addressof(cnt)
+        orc.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, a_type, b_type, DT.I32, DT.I32, oflags, a_b, b_b, 0, 0))
+    h = api.dispatch_brgemm(shape, flags, 0, capi.br_config(capi.BR_STRIDE, a_b, b_b, 0)) if br > 1 else api.dispatch_gemm(shape, flags, 0)
+    assert h
+    dA, dB, dC = (torch.from_numpy(x.copy()).to("cuda:0") for x in (A, B, C0))
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), C.addressof(cnt)
+    if batch == 1:
+        capi.Api.call(h, p)
+    else:
+        api.hip_gemm_batch_strided(h, C.byref(p), batch, br * a_b, br * b_b, c_b)
+    api.hip_sync(); api.check()
+    assert np.array_equal(dC.cpu().numpy(), ref)
+    if batch == 1:
+        got = C0.copy()
+        p.a.primary, p.b.primary, p.c.primary = A.ctypes.data, B.ctypes.data, got.ctypes.data
+        capi.Api.call(h, p)
+        api.check()
+        assert np.array_equal(got, ref)
+    # the flags are part of the format: 2-bit weights exist interleaved only, 1-bit weights not
+    assert api.dispatch_gemm(shape, flags ^ F.INTLV_A_FORMAT, 0) is None

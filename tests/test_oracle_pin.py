@@ -187,6 +187,35 @@ def test_mx_typed_gemm_output_is_bit_identical_to_reference_c_kernel(reference, 
     assert len(np.unique(outs[0][1])) > 1
 
 
+# 1-bit (+-1) and 2-bit (0, +1, -1; interleaved) weights x 8-bit activations -> i32 [ref: generator_gemm_reference_impl.c:1100-1300]
+@pytest.mark.parametrize("a_type", [DT.I1X8, DT.I2X4])
+@pytest.mark.parametrize("b_type", [DT.I8, DT.U8])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta", [(32, 16, 32, 32, 32, 32, 1, 0), (24, 7, 16, 28, 20, 30, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0), (8, 5, 8, 8, 8, 8, 2, 1)])
+def test_low_bit_weight_gemm_restatement_is_bit_identical_to_reference_c_kernel(reference, oracle, a_type, b_type, m, n, k, lda, ldb, ldc, br, beta):
+    from oracle import pyoracle
+    rng = np.random.default_rng(81)
+    a_bytes = lda * k // (8 if a_type == DT.I1X8 else 4)
+    A = rng.integers(0, 256, br * a_bytes).astype(np.uint8)
+    B = rng.integers(0, 256, br * ldb * n).astype(np.uint8)
+    C0 = rng.integers(-1000, 1000, ldc * n).astype(np.int32)
+    flags = F.VNNI_A | (F.INTLV_A_FORMAT if a_type == DT.I2X4 else 0) | (0 if beta else F.BETA_0) | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, a_type, b_type, DT.I32, DT.I32)
+    cnt = C.c_ulonglong(br)
+    outs = []
+    for who in ("oracle", "reference"):
+        c = C0.copy()
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = A.ctypes.data, B.ctypes.data, c.ctypes.data, C.addressof(cnt)
+        if who == "oracle":
+            oracle.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, a_type, b_type, DT.I32, DT.I32, flags | F.USE_XGEMM_ABI, a_bytes, ldb * n, 0, 0))
+        else:
+            cfg = capi.br_config(capi.BR_STRIDE, a_bytes, ldb * n, 0) if br > 1 else capi.br_config(capi.BR_NONE, 0, 0, 0)
+            assert reference.lib.xref_reference_gemm(C.byref(p), shape, flags, 0, cfg) == 0
+        outs.append(c)
+    assert np.array_equal(outs[0].reshape(n, ldc)[:, :m], outs[1].reshape(n, ldc)[:, :m])
+    assert np.array_equal(outs[0].reshape(n, ldc)[:, m:], C0.reshape(n, ldc)[:, m:])
+
+
 def test_bf16_conversion_matches_reference(reference, oracle):
     rng = np.random.default_rng(1)
     vals = np.concatenate([rng.standard_normal(2000).astype(np.float32) * 10.0 ** rng.integers(-40, 38, 2000),
