@@ -307,6 +307,51 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     return;
   }
 
+  if ((p.flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && (p.a_type == LIBXSMM_DATATYPE_I4X2 || p.a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
+    // interleaved 4-bit weights x 8-bit activations [ref: gemm ref :1009-1088, :1272-1330]; layouts and orders as in oracle_gemm.c contract_i4_intlv
+    if (!valid) return;
+    const bool mx = p.a_type == LIBXSMM_DATATYPE_MXFP4X2;
+    int iacc = 0; float facc = 0.0f;
+    if (!mx && !beta0) iacc = ((GM const int*)q.c)[(long long)j * p.ldc + i];
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      gcptr ar, br; br_base(p, q, r, ar, br);
+      const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
+      if (!mx) {
+        const int zpt = ((GM const unsigned char*)p.a_scf)[(long long)bidx * p.bs_scf + ((brs_a * 2) / p.k) * (long long)r + i];
+        for (int o = 0; o < p.k / 8; ++o) {
+          const unsigned int aw = *(GM const unsigned int*)(ar + ((long long)o * p.lda + i) * 4);
+          const unsigned int b0 = *(GM const unsigned int*)(br + (long long)j * p.ldb + 8 * o), b1 = *(GM const unsigned int*)(br + (long long)j * p.ldb + 8 * o + 4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int lo = (int)(signed char)((int)((aw >> (8 * t)) & 15u) - zpt), hi = (int)(signed char)((int)((aw >> (8 * t + 4)) & 15u) - zpt);
+            iacc += lo * (int)((b0 >> (8 * t)) & 255u) + hi * (int)((b1 >> (8 * t)) & 255u);
+          }
+        }
+      } else {
+        GM const unsigned char* sa = (GM const unsigned char*)p.a_scf + (long long)bidx * p.bs_scf + ((brs_a * 2) / 32) * (long long)r;
+        GM const float* sb = (GM const float*)(p.b_scf + (long long)bidx * p.bs_bscf) + (brs_b / 32) * (long long)r + (long long)j * (p.ldb / 32);
+        for (int s = 0; s < p.k / 32; ++s) {
+          int tmp = 0;
+          for (int o = 4 * s; o < 4 * s + 4; ++o) {
+            const unsigned int aw = *(GM const unsigned int*)(ar + ((long long)o * p.lda + i) * 4);
+            const unsigned int b0 = *(GM const unsigned int*)(br + (long long)j * p.ldb + 8 * o), b1 = *(GM const unsigned int*)(br + (long long)j * p.ldb + 8 * o + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const unsigned int cl = (aw >> (8 * t)) & 15u, ch = (aw >> (8 * t + 4)) & 15u;
+              const int ml = (int)((0x7f55402a20150b00ull >> (8 * (cl & 7u))) & 255ull), mh = (int)((0x7f55402a20150b00ull >> (8 * (ch & 7u))) & 255ull);   // {0,11,21,32,42,64,85,127}
+              tmp += ((cl & 8u) ? -ml : ml) * (int)(signed char)(b0 >> (8 * t)) + ((ch & 8u) ? -mh : mh) * (int)(signed char)(b1 >> (8 * t));
+            }
+          }
+          facc = add_rn(facc, mul_rn(mul_rn((float)tmp, __uint_as_float((unsigned int)sa[(long long)s * p.lda + i] << 23)), sb[s]));
+        }
+      }
+    }
+    if (!mx) ((GM int*)q.c)[(long long)j * p.ldc + i] = iacc;
+    else if (p.c_type == LIBXSMM_DATATYPE_F32) { GM float* c = (GM float*)q.c + (long long)j * p.ldc + i; *c = add_rn(beta0 ? 0.0f : *c, facc); }
+    else { GM unsigned short* c = (GM unsigned short*)q.c + (long long)j * p.ldc + i; *c = f32_to_bf16_rne(add_rn(beta0 ? 0.0f : bf16_to_f32(*c), facc)); }
+    return;
+  }
+
   if (p.a_type == LIBXSMM_DATATYPE_I1X8 || p.a_type == LIBXSMM_DATATYPE_I2X4) {
     // 1-bit (+-1) and 2-bit (0, +1, -1) weights x 8-bit activations -> i32 [ref: gemm ref :1100-1300]; layouts as in oracle_gemm.c contract_lowbit
     if (!valid) return;
@@ -2560,6 +2605,20 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     if ((d.k % 32) != 0 || d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
     if ((d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6) && (((d.lda * 6) % 8) != 0 || ((d.ldb * 6) % 8) != 0)) return false;   // a k-group row of the image is ld * 6 / 8 bytes
     return d.lda >= d.m && d.ldb >= d.n && d.ldc >= d.m;
+  }
+  if ((d.flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && (d.a_type == LIBXSMM_DATATYPE_I4X2 || d.a_type == LIBXSMM_DATATYPE_MXFP4X2) &&
+      (d.b_type == LIBXSMM_DATATYPE_I8 || d.b_type == LIBXSMM_DATATYPE_U8)) {
+    // interleaved 4-bit weights x 8-bit activations [ref: gemm ref :467-477, :1009-1088, :1272-1330]: I4X2 (minus a zero point per row,
+    // a.quaternary; B read as unsigned bytes) -> i32; MXFP4 (integer table, E8M0 scales in a.tertiary, f32 scales of B in b.tertiary) -> f32 / bf16
+    const unsigned int fl = d.flags;
+    const bool mx = d.a_type == LIBXSMM_DATATYPE_MXFP4X2;
+    if (mx ? !((d.c_type == LIBXSMM_DATATYPE_F32 || d.c_type == LIBXSMM_DATATYPE_BF16) && d.comp_type == LIBXSMM_DATATYPE_F32 && d.b_type == LIBXSMM_DATATYPE_I8)
+           : !(d.c_type == LIBXSMM_DATATYPE_I32 && d.comp_type == LIBXSMM_DATATYPE_I32)) return false;
+    if (!(fl & LIBXSMM_GEMM_FLAG_VNNI_A) || (fl & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C |
+        LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET))) return false;
+    if ((d.k % (mx ? 32 : 8)) != 0 || (d.ldb & 3) || (mx && (d.ldb % 32) != 0)) return false;
+    if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    return d.lda >= d.m && d.ldb >= d.k && d.ldc >= d.m;
   }
   if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {   // MXFP4 weights x bf16/f32 activations [ref: gemm ref :457-465, :949-1008; names libxsmm_main.c:1829-1848]
     const unsigned int flx = d.flags;

@@ -283,6 +283,50 @@ static void contract_lowbit(const gemm_view* v, void* cptr, int beta0) {
   }
 }
 
+/* 4-bit weights in the INTERLEAVED layout times 8-bit activations [ref: gemm ref :1009-1088 (MXFP4), :1272-1330 (I4X2)]: a dword holds eight k of
+ * one row, [k/8][lda][4 bytes]; byte b carries k = 8 o + b in its low and k = 8 o + 4 + b in its high nibble.  No batch-reduce or stride mode.
+ * I4X2 x u8 -> i32: weight = nibble - zero point of the row (a.quaternary, one byte per row and block); B is read as UNSIGNED bytes.
+ * MXFP4 x i8 -> f32 / bf16: E2M1 codes become integers through the table {0, 11, 21, 32, 42, 64, 85, 127} (sign in bit 3), the integer sum of a
+ *   32-deep block is scaled by 2^(sa - 127) (a.tertiary, [k/32][lda] bytes) and by an f32 per (column, block) (b.tertiary, [n][ldb/32]). */
+static float e8m0(unsigned char s);
+static const signed char kFp4AsInt[16] = {0, 11, 21, 32, 42, 64, 85, 127, 0, -11, -21, -32, -42, -64, -85, -127};
+static void contract_i4_intlv(const gemm_view* v, const libxsmm_gemm_param* p, void* cptr, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const int mx = (d->a_type == LIBXSMM_DATATYPE_MXFP4X2);
+  const long long lda = d->lda, ldb = d->ldb, k = d->k;
+  long long i, j, r, s, kk;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    int iacc = (mx || beta0) ? 0 : ((int*)cptr)[j * d->ldc + i];
+    float facc = 0.0f;
+    for (r = 0; r < v->br; ++r) {
+      const br_cursor cur = br_at(v, r);
+      const unsigned char* a = (const unsigned char*)cur.a;
+      if (!mx) {
+        const int zpt = ((const unsigned char*)p->a.quaternary)[((d->br_stride_a * 2) / k) * r + i];
+        for (kk = 0; kk < k; ++kk) {
+          const unsigned int byte = a[(kk / 8) * lda * 4 + i * 4 + (kk & 3)];
+          const int w = (int)((kk & 4) ? (byte >> 4) : (byte & 15u)) - zpt;
+          iacc += (int)(signed char)w * (int)((const unsigned char*)cur.b)[j * ldb + kk];
+        }
+      } else {
+        for (s = 0; s < k / 32; ++s) {
+          const float sca = e8m0(((const unsigned char*)p->a.tertiary)[((d->br_stride_a * 2) / 32) * r + s * lda + i]);
+          const float scb = ((const float*)p->b.tertiary)[(d->br_stride_b / 32) * r + j * (ldb / 32) + s];
+          int tmp = 0;
+          for (kk = 32 * s; kk < 32 * s + 32; ++kk) {
+            const unsigned int byte = a[(kk / 8) * lda * 4 + i * 4 + (kk & 3)];
+            tmp += (int)kFp4AsInt[(kk & 4) ? (byte >> 4) : (byte & 15u)] * (int)((const signed char*)cur.b)[j * ldb + kk];
+          }
+          { float t2 = (float)tmp * sca; t2 = t2 * scb; facc = facc + t2; }
+        }
+      }
+    }
+    if (!mx) ((int*)cptr)[j * d->ldc + i] = iacc;
+    else if (d->c_type == LIBXSMM_DATATYPE_F32) { float* c = (float*)cptr + j * d->ldc + i; *c = (beta0 ? 0.0f : *c) + facc; }
+    else { unsigned short* c = (unsigned short*)cptr + j * d->ldc + i; *c = oracle_f32_to_bf16_rne((beta0 ? 0.0f : oracle_bf16_to_f32(*c)) + facc); }
+  }
+}
+
 /* MXFP4 weights: A = packed E2M1 pairs [k/2][lda] bytes (low nibble = even k) with one E8M0 scale per (32-deep k-block, row)
  * in a.tertiary ([k/32][lda] bytes; per batch-reduce element: pointer array / offset*2/32 / stride*2/32); B bf16 or f32 flat;
  * C f32 or bf16; C = (beta ? C : 0) + sum, one RNE for bf16 C [ref: :949-1008, scale :200-222, LUT :60-64, slots :565-569].
@@ -510,6 +554,9 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
   if (is_int8(d->a_type) && is_int8(d->b_type)) { contract_int8(&v, p, cptr, beta0); return; }
   if (is_lowbit_a(d->a_type) && is_int8(d->b_type) && d->c_type == LIBXSMM_DATATYPE_I32) { contract_lowbit(&v, cptr, beta0); return; }
+  if ((d->flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && is_int8(d->b_type) && (d->a_type == LIBXSMM_DATATYPE_I4X2 || d->a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
+    contract_i4_intlv(&v, p, cptr, beta0); return;
+  }
   if (is_fp8(d->a_type) && d->b_type == d->a_type && d->c_type == LIBXSMM_DATATYPE_F32) { contract_fp8(&v, (float*)cptr, beta0); return; }
   if (d->a_type == LIBXSMM_DATATYPE_F16 && d->b_type == LIBXSMM_DATATYPE_F16 && (d->c_type == LIBXSMM_DATATYPE_F16 || d->c_type == LIBXSMM_DATATYPE_F32)) {
     contract_f16(&v, cptr, beta0); return;

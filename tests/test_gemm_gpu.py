@@ -738,3 +738,60 @@ def test_low_bit_weight_gemm_bit_exact(a_type, b_type, m, n, k, lda, ldb, ldc, b
         assert np.array_equal(got, ref)
     # the flags are part of the format: 2-bit weights exist interleaved only, 1-bit weights not
     assert api.dispatch_gemm(shape, flags ^ F.INTLV_A_FORMAT, 0) is None
+
+
+# interleaved 4-bit weights x 8-bit activations [ref: gemm ref :1009-1088, :1272-1330]: I4X2 minus a zero point per row -> i32 (exact);
+# MXFP4 through the integer table with E8M0 scales of A and f32 scales of B -> f32 / bf16 (the reference's order: bit-identical)
+@pytest.mark.parametrize("a_type,c_type", [(DT.I4X2, DT.I32), (DT.MXFP4X2, DT.F32), (DT.MXFP4X2, DT.BF16)])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (17, 7, 64, 20, 96, 24, 1, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0, 1), (128, 32, 256, 128, 256, 128, 2, 1, 9)])
+def test_interleaved_4bit_weight_gemm_bit_exact(a_type, c_type, m, n, k, lda, ldb, ldc, br, beta, batch):
+    import torch
+    from helpers import rand_values
+    from oracle import pyoracle
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(84)
+    mx = a_type == DT.MXFP4X2
+    a_b, b_b = lda * k // 2, ldb * n
+    A = rng.integers(0, 256, batch * br * a_b).astype(np.uint8)
+    B = rng.integers(0, 256, batch * br * b_b).astype(np.uint8)
+    ZPT = rng.integers(0, 16, batch * br * lda).astype(np.uint8)
+    SA = rng.integers(120, 134, batch * br * (k // 32) * lda).astype(np.uint8)
+    SB = (rng.random(batch * br * (ldb // 32) * n).astype(np.float32) + 0.5) / 64
+    C0 = rand_values(rng, batch * ldc * n, c_type) if mx else rng.integers(-1000, 1000, batch * ldc * n).astype(np.int32)
+    b_type, comp = (DT.I8, DT.F32) if mx else (DT.U8, DT.I32)
+    flags = F.VNNI_A | F.INTLV_A_FORMAT | (0 if beta else F.BETA_0)
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, a_type, b_type, c_type, comp)
+    cnt = C.c_ulonglong(br)
+    esz = C0.itemsize
+    ref = C0.copy()
+    oflags = flags | F.USE_XGEMM_ABI | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+
+    def fill(p, a, b, c, zp, sa, sb, e):
+        p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = a + e * br * a_b, b + e * br * b_b, c + e * ldc * n * esz, C.addressof(cnt)
+        if mx:
+            p.a.tertiary, p.b.tertiary = sa + e * br * (k // 32) * lda, sb + e * br * (ldb // 32) * n * 4
+        else:
+            p.a.quaternary = zp + e * br * lda
+    for e in range(batch):
+        p = capi.GemmParam()
+        fill(p, A.ctypes.data, B.ctypes.data, ref.ctypes.data, ZPT.ctypes.data, SA.ctypes.data, SB.ctypes.data, e)
+        orc.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, a_type, b_type, c_type, comp, oflags, a_b, b_b, 0, 0))
+    h = api.dispatch_brgemm(shape, flags, 0, capi.br_config(capi.BR_STRIDE, a_b, b_b, 0)) if br > 1 else api.dispatch_gemm(shape, flags, 0)
+    assert h
+    view = lambda x: x.view(np.int16) if x.dtype == np.uint16 else x
+    dA, dB, dZ, dSA, dSB, dC = (torch.from_numpy(view(x).copy()).to("cuda:0") for x in (A, B, ZPT, SA, SB, C0))
+    p = capi.GemmParam()
+    fill(p, dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), dZ.data_ptr(), dSA.data_ptr(), dSB.data_ptr(), 0)
+    if batch == 1:
+        capi.Api.call(h, p)
+    else:
+        api.hip_gemm_batch_strided(h, C.byref(p), batch, br * a_b, br * b_b, ldc * n * esz)
+    api.hip_sync(); api.check()
+    assert dC.cpu().numpy().view(C0.dtype).tobytes() == ref.tobytes()
+    if batch == 1:
+        got = C0.copy()
+        p = capi.GemmParam()
+        fill(p, A.ctypes.data, B.ctypes.data, got.ctypes.data, ZPT.ctypes.data, SA.ctypes.data, SB.ctypes.data, 0)
+        capi.Api.call(h, p)
+        api.check()
+        assert got.tobytes() == ref.tobytes()

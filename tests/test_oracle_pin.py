@@ -216,6 +216,43 @@ def test_low_bit_weight_gemm_restatement_is_bit_identical_to_reference_c_kernel(
     assert np.array_equal(outs[0].reshape(n, ldc)[:, m:], C0.reshape(n, ldc)[:, m:])
 
 
+# 4-bit weights, interleaved layout, x 8-bit activations [ref: generator_gemm_reference_impl.c:1009-1088 (MXFP4 -> f32 / bf16), :1272-1330 (I4X2 - zero point -> i32)]
+@pytest.mark.parametrize("a_type,c_type", [(DT.I4X2, DT.I32), (DT.MXFP4X2, DT.F32), (DT.MXFP4X2, DT.BF16)])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta", [(32, 16, 32, 32, 32, 32, 1, 0), (17, 7, 64, 20, 96, 24, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0), (8, 5, 32, 8, 32, 8, 2, 1)])
+def test_interleaved_4bit_weight_gemm_restatement_is_bit_identical_to_reference_c_kernel(reference, oracle, a_type, c_type, m, n, k, lda, ldb, ldc, br, beta):
+    from oracle import pyoracle
+    rng = np.random.default_rng(83)
+    mx = a_type == DT.MXFP4X2
+    a_b, b_b = lda * k // 2, ldb * n
+    A = rng.integers(0, 256, br * a_b).astype(np.uint8)
+    B = rng.integers(0, 256, br * b_b).astype(np.uint8)
+    ZPT = rng.integers(0, 16, br * lda).astype(np.uint8)
+    SA = rng.integers(120, 134, br * (k // 32) * lda).astype(np.uint8)
+    SB = (rng.random(br * (ldb // 32) * n).astype(np.float32) + 0.5) / 64
+    C0 = rand_values(rng, ldc * n, c_type) if mx else rng.integers(-1000, 1000, ldc * n).astype(np.int32)
+    b_type = DT.I8 if mx else DT.U8
+    flags = F.VNNI_A | F.INTLV_A_FORMAT | (0 if beta else F.BETA_0) | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, a_type, b_type, c_type, DT.F32 if mx else DT.I32)
+    cnt = C.c_ulonglong(br)
+    outs = []
+    for who in ("oracle", "reference"):
+        c = C0.copy()
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = A.ctypes.data, B.ctypes.data, c.ctypes.data, C.addressof(cnt)
+        if mx:
+            p.a.tertiary, p.b.tertiary = SA.ctypes.data, SB.ctypes.data
+        else:
+            p.a.quaternary = ZPT.ctypes.data
+        if who == "oracle":
+            oracle.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, a_type, b_type, c_type, DT.F32 if mx else DT.I32, flags | F.USE_XGEMM_ABI, a_b, b_b, 0, 0))
+        else:
+            cfg = capi.br_config(capi.BR_STRIDE, a_b, b_b, 0) if br > 1 else capi.br_config(capi.BR_NONE, 0, 0, 0)
+            assert reference.lib.xref_reference_gemm(C.byref(p), shape, flags, 0, cfg) == 0
+        outs.append(c)
+    assert outs[0].tobytes() == outs[1].tobytes()
+    assert not np.array_equal(outs[0], C0)
+
+
 def test_bf16_conversion_matches_reference(reference, oracle):
     rng = np.random.default_rng(1)
     vals = np.concatenate([rng.standard_normal(2000).astype(np.float32) * 10.0 ** rng.integers(-40, 38, 2000),
