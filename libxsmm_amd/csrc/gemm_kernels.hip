@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     return;
   }
 
-  if ((p.flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && (p.a_type == LIBXSMM_DATATYPE_I4X2 || p.a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
+  if ((p.flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && (p.a_type == LIBXSMM_DATATYPE_I4X2 || p.a_type == LIBXSMM_DATATYPE_U4X2 || p.a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
     // interleaved 4-bit weights x 8-bit activations [ref: gemm ref :1009-1088, :1272-1330]; layouts and orders as in oracle_gemm.c contract_i4_intlv
     if (!valid) return;
     const bool mx = p.a_type == LIBXSMM_DATATYPE_MXFP4X2;
@@ -2606,7 +2606,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     if ((d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6) && (((d.lda * 6) % 8) != 0 || ((d.ldb * 6) % 8) != 0)) return false;   // a k-group row of the image is ld * 6 / 8 bytes
     return d.lda >= d.m && d.ldb >= d.n && d.ldc >= d.m;
   }
-  if ((d.flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && (d.a_type == LIBXSMM_DATATYPE_I4X2 || d.a_type == LIBXSMM_DATATYPE_MXFP4X2) &&
+  if ((d.flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && (d.a_type == LIBXSMM_DATATYPE_I4X2 || d.a_type == LIBXSMM_DATATYPE_U4X2 || d.a_type == LIBXSMM_DATATYPE_MXFP4X2) &&
       (d.b_type == LIBXSMM_DATATYPE_I8 || d.b_type == LIBXSMM_DATATYPE_U8)) {
     // interleaved 4-bit weights x 8-bit activations [ref: gemm ref :467-477, :1009-1088, :1272-1330]: I4X2 (minus a zero point per row,
     // a.quaternary; B read as unsigned bytes) -> i32; MXFP4 (integer table, E8M0 scales in a.tertiary, f32 scales of B in b.tertiary) -> f32 / bf16

@@ -455,12 +455,12 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     }
     a.a_scf = (const char*)p->a.tertiary; a.bs_scf = a_fp6 ? b.s[0] / 24 : b.s[0] * epb / 32;       // 6-bit: 32 elements are 24 bytes
     a.b_scf = (const char*)p->b.tertiary; a.bs_bscf = a_fp6 ? b.s[1] / 24 : b.s[1] * epb / 32;
-  } else if ((d.flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && (d.a_type == LIBXSMM_DATATYPE_I4X2 || d.a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
+  } else if ((d.flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && (d.a_type == LIBXSMM_DATATYPE_I4X2 || d.a_type == LIBXSMM_DATATYPE_U4X2 || d.a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
     // interleaved 4-bit weights x 8-bit activations [ref: gemm ref :565-575, :1009-1088, :1272-1330].  I4X2: one zero point per row in
     // a.quaternary.  MXFP4: E8M0 scales of A in a.tertiary, one f32 per (column, 32-deep block) of B in b.tertiary.  Batches step them with A / B.
     intlv4 = true;
     if (b.la) { set_error(-3, "interleaved 4-bit GEMM: strided batches only"); return; }
-    if (d.a_type == LIBXSMM_DATATYPE_I4X2) {
+    if (d.a_type != LIBXSMM_DATATYPE_MXFP4X2) {
       if (!p->a.quaternary) { set_error(-2, "I4X2 GEMM needs the zero points in a.quaternary"); return; }
       a.a_scf = (const char*)p->a.quaternary; a.bs_scf = b.s[0] * 2 / std::max<long long>(d.k, 1);
     } else {
@@ -501,7 +501,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     const bool ta = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_A) != 0, tb = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_B) != 0;
     const bool fp6 = d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6;
     const bool mxmx = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8 || fp6) && d.b_type == d.a_type;
-    const auto bytes_of = [](int type, size_t elems) { return (type == LIBXSMM_DATATYPE_MXFP4X2 || type == LIBXSMM_DATATYPE_I4X2) ? elems / 2 : (type == LIBXSMM_DATATYPE_MXBF6 || type == LIBXSMM_DATATYPE_MXHF6) ? elems * 3 / 4 :
+    const auto bytes_of = [](int type, size_t elems) { return (type == LIBXSMM_DATATYPE_MXFP4X2 || type == LIBXSMM_DATATYPE_I4X2 || type == LIBXSMM_DATATYPE_U4X2) ? elems / 2 : (type == LIBXSMM_DATATYPE_MXBF6 || type == LIBXSMM_DATATYPE_MXHF6) ? elems * 3 / 4 :
                                                              type == LIBXSMM_DATATYPE_I1X8 ? elems / 8 : type == LIBXSMM_DATATYPE_I2X4 ? elems / 4 : elems * (size_t)typesize(type); };
     const size_t ea = bytes_of(d.a_type, (size_t)a.lda * (size_t)(ta ? a.m : a.k));
     const size_t eb = bytes_of(d.b_type, (size_t)a.ldb * (size_t)((tb || mxmx) ? a.k : a.n));
@@ -516,7 +516,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
       // E8M0 scales: one byte per 32 elements, so a batch-reduce element is (stride * elements-per-byte / 32) bytes further on
       const size_t epb_a = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1, epb_b = (d.b_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
       const size_t sc_step_a = fp6 ? (size_t)a.br_stride_a / 24 : (size_t)a.br_stride_a * epb_a / 32, sc_step_b = fp6 ? (size_t)a.br_stride_b / 24 : (size_t)a.br_stride_b * epb_b / 32;
-      if (intlv4 && d.a_type == LIBXSMM_DATATYPE_I4X2) a.a_scf = (const char*)stage(a.a_scf, span * ((size_t)a.br_stride_a * 2 / (size_t)a.k) + (size_t)a.lda, true, false);
+      if (intlv4 && d.a_type != LIBXSMM_DATATYPE_MXFP4X2) a.a_scf = (const char*)stage(a.a_scf, span * ((size_t)a.br_stride_a * 2 / (size_t)a.k) + (size_t)a.lda, true, false);
       else if (intlv4) {
         a.a_scf = (const char*)stage(a.a_scf, span * ((size_t)a.br_stride_a / 16) + (size_t)a.lda * (size_t)(a.k / 32), true, false);
         a.b_scf = (const char*)stage(a.b_scf, (span * ((size_t)a.br_stride_b / 32) + (size_t)(a.ldb / 32) * (size_t)a.n) * sizeof(float), true, false);

@@ -554,7 +554,7 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   if (d->a_type == LIBXSMM_DATATYPE_F64) { contract_f64(&v, (double*)cptr); return; }
   if (is_int8(d->a_type) && is_int8(d->b_type)) { contract_int8(&v, p, cptr, beta0); return; }
   if (is_lowbit_a(d->a_type) && is_int8(d->b_type) && d->c_type == LIBXSMM_DATATYPE_I32) { contract_lowbit(&v, cptr, beta0); return; }
-  if ((d->flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && is_int8(d->b_type) && (d->a_type == LIBXSMM_DATATYPE_I4X2 || d->a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
+  if ((d->flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && is_int8(d->b_type) && (d->a_type == LIBXSMM_DATATYPE_I4X2 || d->a_type == LIBXSMM_DATATYPE_U4X2 || d->a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
     contract_i4_intlv(&v, p, cptr, beta0); return;
   }
   if (is_fp8(d->a_type) && d->b_type == d->a_type && d->c_type == LIBXSMM_DATATYPE_F32) { contract_fp8(&v, (float*)cptr, beta0); return; }

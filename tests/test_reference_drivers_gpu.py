@@ -79,6 +79,12 @@ GEMM_CASES = [
     "U8 I8 I32 I32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf strdbr 2 0 2 0",
     "BF8 BF8 F32 F32 32 32 64 32 64 32 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     "HF8 HF8 F32 F32 64 64 64 64 64 64 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    # low-bit weights x 8-bit activations: 4-bit minus zero points (interleaved), 2-bit (interleaved), 1-bit
+    "U4 U8 I32 I32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "I2 U8 I32 I32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "I2 I8 I32 I32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "I1 I8 I32 I32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "I1 U8 I32 I32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf strdbr 3 0 2 0",
     # "spmm": A sparsified to the given fraction and handed over as (non-zeros, bitmask) -- LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK
     "F32 F32 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf spmm 0.5 0 2 0",
     "F32 F32 F32 F32 128 48 256 128 256 128 1 1 0 0 0 0 0 0 0 nopf spmm 0.9 0 2 0",
