@@ -2612,7 +2612,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     // a.quaternary; B read as unsigned bytes) -> i32; MXFP4 (integer table, E8M0 scales in a.tertiary, f32 scales of B in b.tertiary) -> f32 / bf16
     const unsigned int fl = d.flags;
     const bool mx = d.a_type == LIBXSMM_DATATYPE_MXFP4X2;
-    if (mx ? !((d.c_type == LIBXSMM_DATATYPE_F32 || d.c_type == LIBXSMM_DATATYPE_BF16) && d.comp_type == LIBXSMM_DATATYPE_F32 && d.b_type == LIBXSMM_DATATYPE_I8)
+    if (mx ? !((d.c_type == LIBXSMM_DATATYPE_F32 || d.c_type == LIBXSMM_DATATYPE_BF16) && (d.comp_type == LIBXSMM_DATATYPE_F32 || d.comp_type == LIBXSMM_DATATYPE_I32) && d.b_type == LIBXSMM_DATATYPE_I8)
            : !(d.c_type == LIBXSMM_DATATYPE_I32 && d.comp_type == LIBXSMM_DATATYPE_I32)) return false;
     if (!(fl & LIBXSMM_GEMM_FLAG_VNNI_A) || (fl & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C |
         LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET))) return false;

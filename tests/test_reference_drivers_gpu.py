@@ -85,6 +85,18 @@ GEMM_CASES = [
     "I2 I8 I32 I32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     "I1 I8 I32 I32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     "I1 U8 I32 I32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf strdbr 3 0 2 0",
+    # microscaling formats: both operands MX (E2M1, E5M2, E4M3, the 6-bit E3M2 / E2M3) with f32 or MX-typed C (the driver checks C's data AND scales),
+    # MXFP4 weights x bf16, MXFP4 weights (interleaved) x i8
+    "MXFP4 MXFP4 F32 F32 64 64 64 64 64 64 1 0 0 0 0 1 1 1 0 nopf nobr 1 0 2 0",
+    "MXFP4 MXFP4 F32 MXFP4 64 64 64 64 64 64 1 0 0 0 0 1 1 1 0 nopf nobr 1 0 2 0",
+    "MXBF8 MXBF8 F32 F32 64 64 64 64 64 64 1 0 0 0 0 1 1 1 0 nopf nobr 1 0 2 0",
+    "MXBF8 MXBF8 F32 MXBF8 64 64 64 64 64 64 1 0 0 0 0 1 1 1 0 nopf nobr 1 0 2 0",
+    "MXHF8 MXHF8 F32 F32 32 32 64 32 32 32 1 1 0 0 0 1 1 1 0 nopf strdbr 2 0 2 0",
+    "MXBF6 MXBF6 F32 F32 64 64 64 64 64 64 1 0 0 0 0 1 1 1 0 nopf nobr 1 0 2 0",
+    "MXHF6 MXHF6 F32 F32 32 32 64 32 32 32 1 1 0 0 0 1 1 1 0 nopf nobr 1 0 2 0",
+    "MXFP4 BF16 F32 BF16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "MXFP4 I8 I32 F32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "MXFP4 I8 I32 BF16 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     # "spmm": A sparsified to the given fraction and handed over as (non-zeros, bitmask) -- LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK
     "F32 F32 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf spmm 0.5 0 2 0",
     "F32 F32 F32 F32 128 48 256 128 256 128 1 1 0 0 0 0 0 0 0 nopf spmm 0.9 0 2 0",
