@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <utility>
 #include "internal.hpp"
+#include "lowp.hpp"
 
 // a*b+c below means two roundings unless fma()/MFMA is spelled out: parity with the reference's C
 // loops (built without FMA contraction) depends on it.
@@ -237,6 +238,7 @@ __device__ __forceinline__ float hf8_to_f32(unsigned char in) {
 }
 __device__ __forceinline__ float load_as_f32(gcptr base, long long idx, int type) {
   if (type == LIBXSMM_DATATYPE_F32) return ((GM const float*)base)[idx];
+  if (type == LIBXSMM_DATATYPE_BF32) return bf16_to_f32(f32_to_bf16_rne(((GM const float*)base)[idx]));      // f32 storage, bf16 precision [ref: gemm ref :1366,:1384-1389]
   if (type == LIBXSMM_DATATYPE_BF8) return bf8_to_f32(((GM const unsigned char*)base)[idx]);
   if (type == LIBXSMM_DATATYPE_HF8) return hf8_to_f32(((GM const unsigned char*)base)[idx]);
   return bf16_to_f32(((GM const unsigned short*)base)[idx]);
@@ -384,6 +386,37 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     return;
   }
 
+  if (p.a_type == LIBXSMM_DATATYPE_I16) {       // 16-bit integers -> i32, A optionally VNNI-2 [ref: gemm ref :1427-1450]
+    if (!valid) return;
+    const int kb = va ? 2 : 1;
+    GM int* c = (GM int*)q.c + (long long)j * p.ldc + i;
+    int acc = beta0 ? 0 : *c;
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      gcptr ar, br; br_base(p, q, r, ar, br);
+      for (int s = 0; s < p.k; ++s)
+        acc += (int)((GM const short*)ar)[(long long)(s / kb) * ((long long)p.lda * kb) + (long long)i * kb + (s % kb)] * (int)((GM const short*)br)[(long long)j * p.ldb + s];
+    }
+    *c = acc;
+    return;
+  }
+  if (p.a_type == LIBXSMM_DATATYPE_I8 && p.b_type == LIBXSMM_DATATYPE_BF16) {
+    // i8 weights with one f32 scale per row (a.tertiary) x bf16 activations [ref: gemm ref :1684-1730]: the scaled weight is rounded to bf16, the
+    // products are summed from 0 in k order, beta * C comes last
+    if (!valid) return;
+    const float scf = ((GM const float*)(p.a_scf + (long long)bidx * p.bs_scf))[i];
+    float acc = 0.0f;
+    for (unsigned long long r = 0; r < p.br_count; ++r) {
+      gcptr ar, br; br_base(p, q, r, ar, br);
+      for (int s = 0; s < p.k; ++s) {
+        const float a_use = bf16_to_f32(f32_to_bf16_rne(mul_rn((float)(int)((GM const signed char*)ar)[(long long)s * p.lda + i], scf)));
+        acc = add_rn(acc, mul_rn(a_use, bf16_to_f32(((GM const unsigned short*)br)[(long long)j * p.ldb + s])));
+      }
+    }
+    if (p.c_type == LIBXSMM_DATATYPE_BF16) { GM unsigned short* c = (GM unsigned short*)q.c + (long long)j * p.ldc + i; if (!beta0) acc = add_rn(acc, bf16_to_f32(*c)); *c = f32_to_bf16_rne(acc); }
+    else { GM float* c = (GM float*)q.c + (long long)j * p.ldc + i; if (!beta0) acc = add_rn(acc, *c); *c = acc; }
+    return;
+  }
+
   if (p.a_type == LIBXSMM_DATATYPE_I8 || p.a_type == LIBXSMM_DATATYPE_U8) {
     // 8-bit integer GEMM, i32 accumulation [ref: gemm ref :1452-1683]; A VNNI-4 (always for f32 output), B flat
     if (!valid) return;
@@ -484,9 +517,11 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
 
   float acc = 0.0f;
   if (valid) {
-    const bool fp8 = (p.a_type == LIBXSMM_DATATYPE_BF8 || p.a_type == LIBXSMM_DATATYPE_HF8);
-    const int kb = fp8 ? (va ? 4 : 1) : ((p.a_type == LIBXSMM_DATATYPE_BF16 && va) ? 2 : 1);
-    if (!beta0) acc = load_c_f32(q.c, (long long)j * p.ldc + i, p.c_type);
+    // 8-bit floats x themselves: VNNI-4, k ascending; 8-bit float weights x bf16 run the bf16 loop (pairs, high k first) [ref: gemm ref :2171-2366]
+    const bool fp8 = (p.a_type == LIBXSMM_DATATYPE_BF8 || p.a_type == LIBXSMM_DATATYPE_HF8) && p.b_type == p.a_type;
+    const bool fp8w = (p.a_type == LIBXSMM_DATATYPE_BF8 || p.a_type == LIBXSMM_DATATYPE_HF8) && p.b_type == LIBXSMM_DATATYPE_BF16;
+    const int kb = fp8 ? (va ? 4 : 1) : (((p.a_type == LIBXSMM_DATATYPE_BF16 || fp8w) && va) ? 2 : 1);
+    if (!beta0) acc = (p.c_type == LIBXSMM_DATATYPE_BF8 || p.c_type == LIBXSMM_DATATYPE_HF8) ? load_as_f32(q.c, (long long)j * p.ldc + i, p.c_type) : load_c_f32(q.c, (long long)j * p.ldc + i, p.c_type);
     if (p.colbias) {
       const float bias = load_c_f32(q.d, i, p.c_type);
       acc = beta0 ? bias : add_rn(bias, acc);
@@ -505,6 +540,10 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
         }
       }
     }
+  }
+  if (p.c_type == LIBXSMM_DATATYPE_BF8 || p.c_type == LIBXSMM_DATATYPE_HF8) {     // C in the operands' 8-bit type [ref: gemm ref :2511-2619]: one RNE at the end
+    if (valid) ((GM unsigned char*)q.c)[(long long)j * p.ldc + i] = p.c_type == LIBXSMM_DATATYPE_BF8 ? lowp::f16_to_bf8_rne(lowp::f32_to_f16(acc)) : lowp::f16_to_hf8_rne(lowp::f32_to_f16(acc));
+    return;
   }
   generic_epilogue(p, q, i, j, valid, acc);
 }
@@ -2560,6 +2599,20 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
     return d.lda >= d.m && d.ldb >= d.k && d.ldc >= d.m;
   }
+  {   // the dense loop in further types: all on the exact generic kernel, plain ABI, no fused operators
+    const unsigned int fl = d.flags;
+    const bool plain = !(fl & (LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) && d.bin_type == 0 && d.cp_type == 0 && d.ap_type == 0 && d.bp_type == 0;
+    const bool ta_ = fl & LIBXSMM_GEMM_FLAG_TRANS_A, tb_ = fl & LIBXSMM_GEMM_FLAG_TRANS_B, va_ = fl & LIBXSMM_GEMM_FLAG_VNNI_A;
+    const bool lds_ok = (ta_ ? d.lda >= d.k : d.lda >= d.m) && (tb_ ? d.ldb >= d.n : d.ldb >= d.k) && d.ldc >= d.m;
+    if (d.a_type == LIBXSMM_DATATYPE_BF32 || d.b_type == LIBXSMM_DATATYPE_BF32)      // f32 storage, operands rounded to bf16 [ref: gemm ref :1359-1426]
+      return d.a_type == d.b_type && d.c_type == LIBXSMM_DATATYPE_F32 && d.comp_type == LIBXSMM_DATATYPE_F32 && plain && !va_ && lds_ok;
+    if (d.a_type == LIBXSMM_DATATYPE_I16 || d.b_type == LIBXSMM_DATATYPE_I16)        // [ref: gemm ref :1427-1450]
+      return d.a_type == d.b_type && d.c_type == LIBXSMM_DATATYPE_I32 && d.comp_type == LIBXSMM_DATATYPE_I32 && plain && !ta_ && !tb_ && !(va_ && (d.k & 1)) && lds_ok;
+    if (d.a_type == LIBXSMM_DATATYPE_I8 && d.b_type == LIBXSMM_DATATYPE_BF16)       // row-scaled i8 weights x bf16 [ref: gemm ref :1684-1730]
+      return (d.c_type == LIBXSMM_DATATYPE_BF16 || d.c_type == LIBXSMM_DATATYPE_F32) && d.comp_type == LIBXSMM_DATATYPE_F32 && plain && !ta_ && !tb_ && !va_ && lds_ok;
+    if ((d.a_type == LIBXSMM_DATATYPE_BF8 || d.a_type == LIBXSMM_DATATYPE_HF8) && d.b_type == LIBXSMM_DATATYPE_BF16)      // 8-bit float weights x bf16 [ref: gemm ref :2171-2366]
+      return (d.c_type == LIBXSMM_DATATYPE_BF16 || d.c_type == LIBXSMM_DATATYPE_F32) && d.comp_type == LIBXSMM_DATATYPE_F32 && plain && !ta_ && !tb_ && !(va_ && (d.k & 1)) && lds_ok;
+  }
   if (i8) {   // [ref: gemm ref :1452-1683]: i32 accumulation; no transposes, no fused ops, f32 output needs VNNI-4 A
     const unsigned int fl8 = d.flags;
     if (d.comp_type != LIBXSMM_DATATYPE_I32) return false;
@@ -2580,7 +2633,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     if ((fl & LIBXSMM_GEMM_FLAG_TRANS_B) ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
     return d.lda >= d.m && d.ldc >= d.m;
   }
-  const bool fp8 = (d.a_type == LIBXSMM_DATATYPE_BF8 || d.a_type == LIBXSMM_DATATYPE_HF8) && d.b_type == d.a_type && d.c_type == LIBXSMM_DATATYPE_F32;
+  const bool fp8 = (d.a_type == LIBXSMM_DATATYPE_BF8 || d.a_type == LIBXSMM_DATATYPE_HF8) && d.b_type == d.a_type && (d.c_type == LIBXSMM_DATATYPE_F32 || d.c_type == d.a_type);      // C f32 or the operands' type [ref: :2511-2619]
   if (fp8) {   // [ref: gemm ref :2420-2510]: f32 accumulate and output, VNNI-4 A optional, no fused ops
     const unsigned int fl8 = d.flags;
     if (d.comp_type != LIBXSMM_DATATYPE_F32) return false;
@@ -2686,6 +2739,7 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     }
     return pl;
   }
+  if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && (b_type != a_type || c_type != LIBXSMM_DATATYPE_F32)) return pl;      // mixed operands / 8-bit C: generic kernel
   if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && va && !ta && !tb && !vb) {
     pl.path = (m > 32 && n > 32) ? P_FP8_2x2 : P_FP8_1x1;
     const int t = (pl.path == P_FP8_2x2) ? 64 : 32;

@@ -434,12 +434,13 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   } else if (d.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_STRIDE) {
     a.br_mode = 3; a.br_stride_a = d.br_stride_a; a.br_stride_b = d.br_stride_b;
   }
-  if ((d.a_type == LIBXSMM_DATATYPE_I8 || d.a_type == LIBXSMM_DATATYPE_U8) && d.c_type == LIBXSMM_DATATYPE_F32) {
+  if ((d.a_type == LIBXSMM_DATATYPE_I8 || d.a_type == LIBXSMM_DATATYPE_U8) && (d.b_type == LIBXSMM_DATATYPE_I8 || d.b_type == LIBXSMM_DATATYPE_U8) && d.c_type == LIBXSMM_DATATYPE_F32) {
     if (!p->c.tertiary) { set_error(-2, "8-bit GEMM with f32 output needs the scale in c.tertiary"); return; }   // [ref: gemm ref :591-592]
     a.scf = *(const float*)p->c.tertiary;
   }
   const bool a_fp6 = d.a_type == LIBXSMM_DATATYPE_MXBF6 || d.a_type == LIBXSMM_DATATYPE_MXHF6;
   char* c_scf = nullptr;                       // MX-typed C: where its block scales go
+  bool i8_rows = false;                        // i8 weights x bf16: a_scf = one f32 per row
   bool intlv4 = false;                         // interleaved 4-bit weights x 8-bit activations: a_scf = zero points or E8M0 scales, b_scf = f32 scales
   if ((d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8 || d.a_type == LIBXSMM_DATATYPE_MXHF8 || a_fp6) && d.b_type == d.a_type) {
     // MX x MX: scales of A in a.tertiary, of B in b.tertiary [ref: gemm ref :577-583]; a batched launch steps them with their operand:
@@ -469,6 +470,12 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
       a.a_scf = (const char*)p->a.tertiary; a.bs_scf = b.s[0] / 16;
       a.b_scf = (const char*)p->b.tertiary; a.bs_bscf = b.s[1] / 8;            // one f32 per 32 bytes of B
     }
+  } else if (d.a_type == LIBXSMM_DATATYPE_I8 && d.b_type == LIBXSMM_DATATYPE_BF16) {
+    // one f32 scale per row of the i8 weights in a.tertiary [ref: gemm ref :1684-1730]; a strided batch steps them with A (lda floats per k * lda weights)
+    if (!p->a.tertiary) { set_error(-2, "I8 x BF16 GEMM needs the row scales in a.tertiary"); return; }
+    if (b.la) { set_error(-3, "I8 x BF16 GEMM: strided batches only"); return; }
+    a.a_scf = (const char*)p->a.tertiary; a.bs_scf = (b.s[0] / std::max<long long>(d.k, 1)) * 4;
+    i8_rows = true;
   } else if (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) {
     // E8M0 scales of the MXFP4 weights travel in a.tertiary (a list of per-block pointers in ADDRESS mode) [ref: gemm ref :565-569].
     // A batched launch steps them like A: the pointer list by sa, the scale bytes by sa * 2 / 32 (one byte per 32 weights).
@@ -516,7 +523,8 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
       // E8M0 scales: one byte per 32 elements, so a batch-reduce element is (stride * elements-per-byte / 32) bytes further on
       const size_t epb_a = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1, epb_b = (d.b_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
       const size_t sc_step_a = fp6 ? (size_t)a.br_stride_a / 24 : (size_t)a.br_stride_a * epb_a / 32, sc_step_b = fp6 ? (size_t)a.br_stride_b / 24 : (size_t)a.br_stride_b * epb_b / 32;
-      if (intlv4 && d.a_type != LIBXSMM_DATATYPE_MXFP4X2) a.a_scf = (const char*)stage(a.a_scf, span * ((size_t)a.br_stride_a * 2 / (size_t)a.k) + (size_t)a.lda, true, false);
+      if (i8_rows) a.a_scf = (const char*)stage(a.a_scf, (size_t)a.lda * sizeof(float), true, false);
+      else if (intlv4 && d.a_type != LIBXSMM_DATATYPE_MXFP4X2) a.a_scf = (const char*)stage(a.a_scf, span * ((size_t)a.br_stride_a * 2 / (size_t)a.k) + (size_t)a.lda, true, false);
       else if (intlv4) {
         a.a_scf = (const char*)stage(a.a_scf, span * ((size_t)a.br_stride_a / 16) + (size_t)a.lda * (size_t)(a.k / 32), true, false);
         a.b_scf = (const char*)stage(a.b_scf, (span * ((size_t)a.br_stride_b / 32) + (size_t)(a.ldb / 32) * (size_t)a.n) * sizeof(float), true, false);
@@ -1063,7 +1071,13 @@ LIBXSMM_API void libxsmm_set_verbosity(int level) { libxsmm_verbosity = level; }
 LIBXSMM_API int libxsmm_cpuid(void* info) { (void)info; return LIBXSMM_TARGET_ARCH_GENERIC; }
 /* drivers pre-pack bf16 A with this factor; it stays the x86 value [ref: src/libxsmm_cpuid_x86.c:775] */
 LIBXSMM_API int libxsmm_cpuid_dot_pack_factor(libxsmm_datatype t) {
-  switch (t) { case LIBXSMM_DATATYPE_BF16: case LIBXSMM_DATATYPE_F16: return 2; case LIBXSMM_DATATYPE_I8: case LIBXSMM_DATATYPE_U8: case LIBXSMM_DATATYPE_BF8: case LIBXSMM_DATATYPE_HF8: return 4; default: return 1; }
+  switch (t) {      // [ref: src/libxsmm_cpuid_x86.c:775-797]
+    case LIBXSMM_DATATYPE_BF16: case LIBXSMM_DATATYPE_F16: case LIBXSMM_DATATYPE_I16: case LIBXSMM_DATATYPE_U16: return 2;
+    case LIBXSMM_DATATYPE_I8: case LIBXSMM_DATATYPE_U8: case LIBXSMM_DATATYPE_BF8: case LIBXSMM_DATATYPE_HF8:
+    case LIBXSMM_DATATYPE_MXBF8: case LIBXSMM_DATATYPE_MXHF8: case LIBXSMM_DATATYPE_MXBF6: case LIBXSMM_DATATYPE_MXHF6: return 4;
+    case LIBXSMM_DATATYPE_MXFP4X2: return 8;
+    default: return 1;
+  }
 }
 LIBXSMM_API int libxsmm_cpuid_vlen(int id) { (void)id; return 64; }
 // 32-bit lanes per "vector": the rows DROPOUT draws for at a time (the reference's gold loops ask this too) [ref: src/libxsmm_cpuid_x86.c:670]

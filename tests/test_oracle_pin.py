@@ -253,6 +253,72 @@ def test_interleaved_4bit_weight_gemm_restatement_is_bit_identical_to_reference_
     assert not np.array_equal(outs[0], C0)
 
 
+# more operand / result types of the dense loop [ref: generator_gemm_reference_impl.c]: BF32 (f32 storage, bf16 precision, :1359-1426), I16 -> I32
+# (:1427-1450), 8-bit floats with a result of their own type (:2511-2619), 8-bit float weights x bf16 (:2171-2366), i8 weights with row scales x bf16 (:1684-1730)
+MORE_TYPES = [
+    dict(a=DT.BF32, b=DT.BF32, c=DT.F32, comp=DT.F32, flags=0),
+    dict(a=DT.BF32, b=DT.BF32, c=DT.F32, comp=DT.F32, flags=F.TRANS_A),
+    dict(a=DT.BF32, b=DT.BF32, c=DT.F32, comp=DT.F32, flags=F.TRANS_B),
+    dict(a=DT.I16, b=DT.I16, c=DT.I32, comp=DT.I32, flags=0),
+    dict(a=DT.I16, b=DT.I16, c=DT.I32, comp=DT.I32, flags=F.VNNI_A),
+    dict(a=DT.BF8, b=DT.BF8, c=DT.BF8, comp=DT.F32, flags=F.VNNI_A),
+    dict(a=DT.HF8, b=DT.HF8, c=DT.HF8, comp=DT.F32, flags=F.VNNI_A),
+    dict(a=DT.HF8, b=DT.HF8, c=DT.HF8, comp=DT.F32, flags=0),
+    dict(a=DT.BF8, b=DT.BF16, c=DT.F32, comp=DT.F32, flags=F.VNNI_A),
+    dict(a=DT.BF8, b=DT.BF16, c=DT.BF16, comp=DT.F32, flags=F.VNNI_A),
+    dict(a=DT.HF8, b=DT.BF16, c=DT.F32, comp=DT.F32, flags=F.VNNI_A),
+    dict(a=DT.HF8, b=DT.BF16, c=DT.BF16, comp=DT.F32, flags=0),
+    dict(a=DT.I8, b=DT.BF16, c=DT.BF16, comp=DT.F32, flags=0),
+    dict(a=DT.I8, b=DT.BF16, c=DT.F32, comp=DT.F32, flags=0),
+]
+
+
+def more_types_case(rng, t, m, n, k, lda, ldb, ldc, br):
+    """operands for one MORE_TYPES entry: (A, B, C0, SCF, a_block_elems, b_block_elems)"""
+    ta, tb = bool(t["flags"] & F.TRANS_A), bool(t["flags"] & F.TRANS_B)
+    a_e, b_e = lda * (m if ta else k), ldb * (k if tb else n)
+    def vals(dt, count):
+        if dt == DT.BF32:
+            return (rng.random(count).astype(np.float32) - 0.5) * 1.37          # not bf16-representable: the rounding of the operands matters
+        if dt == DT.I16:
+            return rng.integers(-3000, 3000, count).astype(np.int16)
+        if dt == DT.I32:
+            return rng.integers(-1000, 1000, count).astype(np.int32)
+        if dt == DT.I8:
+            return rng.integers(-128, 128, count).astype(np.int8)
+        return rand_values(rng, count, dt)
+    return vals(t["a"], br * a_e), vals(t["b"], br * b_e), vals(t["c"], ldc * n), (rng.random(lda).astype(np.float32) + 0.5) / 16, a_e, b_e
+
+
+@pytest.mark.parametrize("t", MORE_TYPES, ids=lambda t: f"{int(t['a'])}x{int(t['b'])}to{int(t['c'])}f{t['flags']}")
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta", [(32, 16, 32, 32, 32, 32, 1, 0), (17, 7, 16, 20, 24, 24, 1, 1), (8, 5, 8, 8, 8, 8, 3, 1)])
+def test_more_gemm_types_restatement_is_bit_identical_to_reference_c_kernel(reference, oracle, t, m, n, k, lda, ldb, ldc, br, beta):
+    from oracle import pyoracle
+    rng = np.random.default_rng(91)
+    if t["flags"] & F.TRANS_A:
+        lda = max(lda, k)
+    if t["flags"] & F.TRANS_B:
+        ldb = max(ldb, n)
+    A, B, C0, SCF, a_e, b_e = more_types_case(rng, t, m, n, k, lda, ldb, ldc, br)
+    flags = t["flags"] | (0 if beta else F.BETA_0) | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    sa, sb = a_e * A.itemsize, b_e * B.itemsize
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, t["a"], t["b"], t["c"], t["comp"])
+    cnt = C.c_ulonglong(br)
+    outs = []
+    for who in ("oracle", "reference"):
+        c = C0.copy()
+        p = capi.GemmParam()
+        p.a.primary, p.a.tertiary, p.b.primary, p.c.primary, p.op.tertiary = A.ctypes.data, SCF.ctypes.data, B.ctypes.data, c.ctypes.data, C.addressof(cnt)
+        if who == "oracle":
+            oracle.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, t["a"], t["b"], t["c"], t["comp"], flags | F.USE_XGEMM_ABI, sa, sb, 0, 0))
+        else:
+            cfg = capi.br_config(capi.BR_STRIDE, sa, sb, 0) if br > 1 else capi.br_config(capi.BR_NONE, 0, 0, 0)
+            assert reference.lib.xref_reference_gemm(C.byref(p), shape, flags, 0, cfg) == 0
+        outs.append(c)
+    assert outs[0].tobytes() == outs[1].tobytes()
+    assert outs[0].tobytes() != C0.tobytes()
+
+
 def test_bf16_conversion_matches_reference(reference, oracle):
     rng = np.random.default_rng(1)
     vals = np.concatenate([rng.standard_normal(2000).astype(np.float32) * 10.0 ** rng.integers(-40, 38, 2000),

@@ -97,6 +97,16 @@ GEMM_CASES = [
     "MXFP4 BF16 F32 BF16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     "MXFP4 I8 I32 F32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
     "MXFP4 I8 I32 BF16 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    # further types of the dense loop: BF32 (f32 storage, bf16 precision), 16-bit integers, 8-bit floats with a result of their own type,
+    # 8-bit float weights x bf16, row-scaled i8 weights x bf16
+    "BF32 BF32 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",
+    "I16 I16 I32 I32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "BF8 BF8 F32 BF8 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "HF8 HF8 F32 HF8 64 64 64 64 64 64 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "BF8 BF16 F32 BF16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",
+    "HF8 BF16 F32 F32 64 64 64 64 64 64 1 1 0 0 0 0 1 0 0 nopf strdbr 2 0 2 0",
+    "I8 BF16 F32 BF16 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",
+    "I8 BF16 F32 F32 64 64 64 64 64 64 1 1 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",
     # "spmm": A sparsified to the given fraction and handed over as (non-zeros, bitmask) -- LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK
     "F32 F32 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf spmm 0.5 0 2 0",
     "F32 F32 F32 F32 128 48 256 128 256 128 1 1 0 0 0 0 0 0 0 nopf spmm 0.9 0 2 0",
