@@ -1439,7 +1439,10 @@ int launch_stochastic_bf8(const MeltwArgs& a, void* stream) {
 int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
   const bool listed = a.operation == LIBXSMM_MELTW_OPERATION_UNARY && is_reduce_cols_idx_type(a.type);      // the shape's n does not matter there (the reference's driver passes 0)
-  if (a.nbatch == 0 || a.m <= 0 || (a.n <= 0 && !listed)) { if (name) *name = "(empty)"; return 0; }
+  // the extent along n may come with the call instead of the descriptor: the listed reductions (their column list), REPLICATE_COL_VAR (op.primary) --
+  // the reference's drivers dispatch those with n = 0
+  const bool n_by_call = listed || (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR && a.scalar_u64 > 0);
+  if (a.nbatch == 0 || a.m <= 0 || (a.n <= 0 && !n_by_call)) { if (name) *name = "(empty)"; return 0; }
   const int sz = payload_size(a.in0_type);
   if (listed) {
     hipLaunchKernelGGL(reduce_cols_listed_kernel, dim3((unsigned int)((a.m + 255) / 256), a.nbatch), dim3(256), 0, st, a);

@@ -187,7 +187,8 @@ def test_reference_fsspmdm_driver(beta, N, edge_mtx):
     "4 0 F32 F32 F32 32 32 32 32", "7 0 F32 F32 F32 64 48 64 64", "9 0 BF16 F32 BF16 64 48 64 64", "11 0 F32 F32 F32 64 48 64 64",
     "13 0 F32 F32 F32 64 48 64 64", "14 0 F32 F32 F32 64 48 64 64", "15 0 F32 F32 F32 64 48 64 64", "16 0 F32 F32 F32 64 48 64 64",
     "17 0 F32 F32 F32 64 48 64 64", "1 0 F16 F32 F16 64 48 64 64", "13 0 BF8 F32 BF8 64 48 64 64", "3 0 HF8 F32 HF8 33 17 40 36", "1 0 F32 F32 HF8 64 48 64 64",
-    "9 0 F16 F32 F16 64 48 64 64", "1 1 F32 F32 F32 64 48 64 64", "1 2 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 64 48 64 64", "2 0 F32 F32 F32 64 48 64 64",
+    "9 0 F16 F32 F16 64 48 64 64", "8 0 F32 F32 F32 64 48 64 64", "10 0 F32 F32 F32 64 48 64 64", "12 0 F32 F32 F32 64 48 64 64", "27 0 F32 F32 F32 64 48 64 64", "27 0 BF16 F32 BF16 64 48 64 64",
+    "7 0 BF16 F32 BF16 64 48 64 64", "11 0 BF16 F32 BF16 64 48 64 64", "17 0 BF8 F32 BF8 64 48 64 64", "15 0 HF8 F32 HF8 64 48 64 64", "1 1 F32 F32 F32 64 48 64 64", "1 2 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 64 48 64 64", "2 0 F32 F32 F32 64 48 64 64",
 ])
 def test_reference_unary_driver(args):
     check("eltwise_unary_simple", *args.split())
@@ -195,7 +196,8 @@ def test_reference_unary_driver(args):
 
 @pytest.mark.parametrize("args", [
     "1 0 F32 F32 F32 F32 64 48 64 64", "2 0 BF16 BF16 F32 BF16 64 48 64 64", "3 1 F32 F32 F32 F32 64 48 64 64", "4 2 F32 F32 F32 F32 64 48 64 64",
-    "5 0 F32 F32 F32 F32 64 48 64 64", "1 0 F16 F16 F32 F16 64 48 64 64", "2 0 BF8 BF8 F32 BF8 64 48 64 64", "1 2 HF8 HF8 F32 HF8 33 17 40 36", "9 4 F32 F32 F32 F32 33 17 40 36", "10 5 F32 F32 F32 F32 64 48 64 64", "1 6 BF16 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 BF16 64 48 64 64",
+    "5 0 F32 F32 F32 F32 64 48 64 64", "1 0 F16 F16 F32 F16 64 48 64 64", "2 0 BF8 BF8 F32 BF8 64 48 64 64", "1 2 HF8 HF8 F32 HF8 33 17 40 36", "9 4 F32 F32 F32 F32 33 17 40 36", "10 5 F32 F32 F32 F32 64 48 64 64", "27 0 F32 F32 F32 F32 64 48 64 64", "28 0 F32 F32 F32 F32 64 48 64 64", "29 0 BF16 BF16 F32 BF16 64 48 64 64",
+    "30 0 F32 F32 F32 F32 64 48 64 64", "31 0 F32 F32 F32 F32 64 48 64 64", "32 0 F32 F32 F32 F32 64 48 64 64", "5 3 BF16 BF16 F32 BF16 64 48 64 64", "4 0 F16 F16 F32 F16 64 48 64 64", "1 6 BF16 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 BF16 64 48 64 64",
 ])
 def test_reference_binary_driver(args):
     check("eltwise_binary_simple", *args.split())
