@@ -204,12 +204,21 @@ def test_reference_binary_driver(args):
 
 
 @pytest.mark.parametrize("args", ["D F 0 F32 F32 F32 64 48 64 64", "D F 1 F32 F32 F32 64 48 64 64", "D F 1 BF16 F32 BF16 64 48 64 64", "D B 1 F32 F32 F32 64 48 64 64",
-                                  "L F 0 F32 F32 F32 64 48 64 64", "E F 0 F32 F32 F32 64 48 64 64"])
+                                  "L F 0 F32 F32 F32 64 48 64 64", "E F 0 F32 F32 F32 64 48 64 64", "L F 1 F32 F32 F32 64 48 64 64", "L B 1 F32 F32 F32 64 48 64 64",
+                                  "E F 0 BF16 F32 BF16 64 48 64 64", "E B 0 F32 F32 F32 64 48 64 64", "D B 1 BF16 F32 BF16 64 48 64 64", "D F 1 F16 F32 F16 64 48 64 64",
+                                  "D F 0 BF8 F32 BF8 64 48 64 64", "D F 1 HF8 F32 HF8 64 48 64 64", "L F 1 BF16 F32 BF16 64 48 64 64"])
 def test_reference_relu_driver(args):
     check("eltwise_unary_relu", *args.split())
 
 
-@pytest.mark.parametrize("args", ["T F32 64 48 64 48", "T F32 33 17 40 20", "T BF16 64 48 64 48", "T F64 16 24 16 24", "V BF16 64 48 64 64", "R BF16 64 48 64 64"])
+# every transform letter of the driver (T transpose; R / S / F / V / W / G / Q / H / B / C / D / I / N / M the NORM <-> VNNI2 / VNNI4 / VNNI8 and VNNI <-> VNNI-T
+# forms; X / Y / Z the padded ones), in each element width it accepts
+@pytest.mark.parametrize("args", ["T F32 64 48 64 48", "T F32 33 17 40 20", "T BF16 64 48 64 48", "T F64 16 24 16 24", "V BF16 64 48 64 64", "R BF16 64 48 64 64",
+                                  "T I8 64 48 64 48", "T BF8 64 48 64 48", "T I16 64 48 64 48", "T F16 64 48 64 48", "T I32 64 48 64 48", "T I64 64 48 64 48", "R F16 64 48 64 64",
+                                  "S I8 64 48 64 64", "S BF16 64 48 64 64", "F I8 64 48 64 64", "F BF16 64 48 64 64", "V I16 64 48 64 64", "W I8 64 48 64 64", "W BF16 64 48 64 64",
+                                  "G I8 64 48 64 64", "G BF16 64 48 64 64", "Q BF16 64 48 64 64", "H BF16 64 48 64 64", "B BF16 64 48 64 64", "C BF16 64 48 64 64", "D BF16 64 48 64 64",
+                                  "I BF16 64 48 64 64", "N I8 64 48 64 64", "M I8 64 48 64 64", "X BF16 64 48 64 64", "Y BF16 64 48 64 64", "Z BF16 64 48 64 64", "X I8 64 48 64 64",
+                                  "Y I8 64 48 64 64", "Z I8 64 48 64 64"])
 def test_reference_transform_driver(args):
     check("eltwise_unary_transform", *args.split())
 
@@ -221,7 +230,8 @@ def test_reference_gather_scatter_driver(args):
 
 
 # samples/eltwise/eltwise_unary_dropout.c -- F/B bitmask prec_in prec_out M N ldi ldo: its gold loop draws libxsmm_cpuid_vlen32() rows at a time
-@pytest.mark.parametrize("args", ["F 1 F32 F32 64 64 64 64", "F 0 F32 F32 40 13 48 40", "F 1 BF16 BF16 64 48 64 64", "F 1 F32 BF16 33 17 40 36", "B 1 F32 F32 64 64 64 64", "B 1 BF16 BF16 50 20 56 52"])
+@pytest.mark.parametrize("args", ["F 1 F32 F32 64 64 64 64", "F 0 F32 F32 40 13 48 40", "F 1 BF16 BF16 64 48 64 64", "F 1 F32 BF16 33 17 40 36", "B 1 F32 F32 64 64 64 64", "B 1 BF16 BF16 50 20 56 52",
+                                  "F 1 F16 F16 64 48 64 64", "F 1 BF8 BF8 64 48 64 64", "B 1 HF8 HF8 64 48 64 64", "F 0 BF16 F32 64 48 64 64"])
 def test_reference_dropout_driver(args):
     check("eltwise_unary_dropout", *args.split())
 
@@ -231,7 +241,9 @@ def test_reference_dropout_driver(args):
 @pytest.mark.parametrize("args", ["64 48 64 1 0 1 0 F32 0 0 0 0 1", "64 48 64 1 0 0 0 F32 0 0 0 0 1", "64 48 64 1 1 1 0 F32 0 0 0 0 1", "64 48 64 1 0 1 1 F32 0 0 0 0 1",
                                   "64 48 64 1 0 0 0 BF16 0 0 0 0 1", "33 17 40 1 1 0 0 F32 0 0 0 0 1",
                                   "64 48 64 1 0 0 0 F32 12 0 0 0 1", "64 48 64 1 0 0 1 F32 12 1 1 0 1", "64 48 64 1 0 0 2 F32 12 0 1 0 1", "64 48 64 1 0 0 1 BF16 9 1 0 0 1",
-                                  "64 48 64 1 0 0 1 F32 0 0 1 0 1"])          # listed columns (n_cols_idx), 4 / 8-byte indices, recorded arg-max / arg-min
+                                  "64 48 64 1 0 0 1 F32 0 0 1 0 1", "64 48 64 0 1 1 0 F32 0 0 0 0 1", "64 48 64 0 1 0 0 F32 0 0 0 0 1", "64 48 64 1 0 1 1 BF16 0 0 0 0 1",
+                                  "64 48 64 1 0 0 2 F32 0 0 0 0 1", "64 48 64 1 0 1 2 F32 0 0 0 0 1", "64 48 64 1 0 0 0 F16 0 0 0 0 1", "64 48 64 1 0 0 0 BF8 0 0 0 0 1",
+                                  "64 48 64 1 0 0 0 F32 0 0 0 1 1", "64 48 64 1 1 1 0 F32 0 0 0 1 1"])          # listed columns (n_cols_idx), 4 / 8-byte indices, recorded arg-max / arg-min
 def test_reference_reduce_driver(args):
     check("eltwise_unary_reduce", *args.split())
 
