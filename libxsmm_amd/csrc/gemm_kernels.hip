@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
         const long long bi = tb ? (long long)s * p.ldb + j : (long long)j * p.ldb + s;
         const float av = (float)__builtin_bit_cast(_Float16, ((GM const unsigned short*)ar)[ai]), bv = (float)__builtin_bit_cast(_Float16, ((GM const unsigned short*)br)[bi]);
         acc = add_rn(acc, mul_rn(av, bv));
+        if (p.comp_f16) acc = (float)(_Float16)acc;             // comp_type F16 [ref: gemm ref :2042,:2059-2062]
       }
     }
     if (p.c_type == LIBXSMM_DATATYPE_F32) {
@@ -2626,7 +2627,9 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
   if (d.a_type == LIBXSMM_DATATYPE_F16 && d.b_type == LIBXSMM_DATATYPE_F16) {   // [ref: gemm ref :2025-2124]: f32 accumulation, F16 or F32 out, VNNI-2 A optional, B may be transposed, no fused ops
     const unsigned int fl = d.flags;
     if (d.c_type != LIBXSMM_DATATYPE_F16 && d.c_type != LIBXSMM_DATATYPE_F32) return false;
-    if (d.comp_type != LIBXSMM_DATATYPE_F32) return false;                       // comp F16 (a rounding after every product) is not built
+    // comp F32, F16 (the running sum rounded to f16 after every product: generic kernel) or IMPLICIT (= F32 here; the reference means F16 by it on
+    // AVX512-FP16 hosts only)
+    if (d.comp_type != LIBXSMM_DATATYPE_F32 && d.comp_type != LIBXSMM_DATATYPE_F16 && d.comp_type != LIBXSMM_DATATYPE_IMPLICIT) return false;
     if (fl & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) return false;
     if ((fl & LIBXSMM_GEMM_FLAG_VNNI_A) && (d.k & 1)) return false;
     if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
@@ -3068,7 +3071,9 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   const GemmArgs& a0 = a_in;
   hipStream_t st = (hipStream_t)stream;
   if (a0.nbatch == 0 || a0.m <= 0 || a0.n <= 0) { if (kernel_name) *kernel_name = "(empty)"; return 0; }
-  const GemmPlan pl = plan_gemm(a0.m, a0.n, a0.k, a0.flags, a0.a_type, a0.b_type, a0.c_type, a0.vnni_c);
+  GemmPlan pl_ = plan_gemm(a0.m, a0.n, a0.k, a0.flags, a0.a_type, a0.b_type, a0.c_type, a0.vnni_c);
+  if (a0.comp_f16) pl_ = GemmPlan{P_GENERIC, false};              // a rounding after every product: only the generic kernel does that
+  const GemmPlan pl = pl_;
   if ((long long)((a0.m + 15) / 16) * ((a0.n + 15) / 16) * (long long)a0.nbatch >= (1ll << 31)) return (int)hipErrorInvalidValue;
   if (kernel_name) *kernel_name = path_name(pl.path);
   GemmArgs a = a_in;

@@ -82,6 +82,7 @@ struct GemmArgs {
   int colbias, act;                                 // act: 0 none, 1 relu, 2 relu+bitmask, 3 sigmoid
   int vnni_c;
   int tiles_m, tiles_n;                             // set by launch_gemm for the tile size of the chosen kernel
+  int comp_f16;                                     // F16 GEMM with comp_type F16: the running sum is rounded to f16 after every product (generic kernel)
   float scf;                                        // 8-bit GEMM with f32 output: scale read from c.tertiary on the host
   const char* a_scf; long long bs_scf;              // MXFP4 A: E8M0 scales (a.tertiary; a pointer list in ADDRESS mode) and their batch stride
   const char* b_scf; long long bs_bscf;             // MX x MX: the scales of B (b.tertiary)

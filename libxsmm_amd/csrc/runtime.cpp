@@ -412,6 +412,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.lda = (int)d.lda; a.ldb = (int)d.ldb; a.ldc = (int)d.ldc;
   a.flags = d.flags; a.a_type = d.a_type; a.b_type = d.b_type; a.c_type = d.c_type;
   a.vnni_c = (d.flags & LIBXSMM_GEMM_FLAG_VNNI_C) ? 1 : 0;
+  a.comp_f16 = (d.a_type == LIBXSMM_DATATYPE_F16 && d.comp_type == LIBXSMM_DATATYPE_F16) ? 1 : 0;
   a.br_count = 1; a.br_mode = 0;
   if (d.flags & (LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_STRIDE)) {
     // the count is re-read on every call [ref: gemm ref :490-492; SURVEY Appendix B.4]

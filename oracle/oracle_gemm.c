@@ -179,8 +179,8 @@ static void contract_i8_bf16(const gemm_view* v, const libxsmm_gemm_param* p, vo
 }
 
 /* F16 x F16 -> F16 or F32, f32 accumulation [ref: :2025-2124].  Unlike bf16: the pair of a VNNI-2 A is consumed LOW k first, the start
- * value is 0 and beta * C is added AFTER the sum, and an f32 C is rounded to f16 on the way in.  (comp_type F16 -- a rounding to f16 after
- * every product, what AVX512-FP16 hosts do for IMPLICIT -- is not restated: the device library computes in f32.) */
+ * value is 0 and beta * C is added AFTER the sum, and an f32 C is rounded to f16 on the way in.  (comp_type F16: the running sum is rounded to f16 after
+ * every product; IMPLICIT means that on AVX512-FP16 hosts only -- restated, like the device library, as f32.) */
 static void contract_f16(const gemm_view* v, void* cmat, int beta0) {
   const oracle_gemm_desc* d = v->d;
   const int kb = v->va ? 2 : 1;
@@ -194,6 +194,7 @@ static void contract_f16(const gemm_view* v, void* cmat, int beta0) {
         const float bv = oracle_f16_to_f32(((const unsigned short*)cur.b)[b_index(v, s, j, kb)]);
         const float prod = av * bv;
         c = c + prod;
+        if (d->comp_type == LIBXSMM_DATATYPE_F16) c = oracle_f16_to_f32(oracle_f32_to_f16(c));      /* comp F16: the running sum lives in a half [ref: :2042,:2059-2062] */
       }
     }
     if (d->c_type == LIBXSMM_DATATYPE_F32) {

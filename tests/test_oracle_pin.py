@@ -270,6 +270,10 @@ MORE_TYPES = [
     dict(a=DT.HF8, b=DT.BF16, c=DT.BF16, comp=DT.F32, flags=0),
     dict(a=DT.I8, b=DT.BF16, c=DT.BF16, comp=DT.F32, flags=0),
     dict(a=DT.I8, b=DT.BF16, c=DT.F32, comp=DT.F32, flags=0),
+    # IEEE halves with comp_type F16: the running sum is rounded to f16 after every product (:2042, :2059-2062)
+    dict(a=DT.F16, b=DT.F16, c=DT.F16, comp=DT.F16, flags=F.VNNI_A),
+    dict(a=DT.F16, b=DT.F16, c=DT.F32, comp=DT.F16, flags=0),
+    dict(a=DT.F16, b=DT.F16, c=DT.F16, comp=DT.F16, flags=F.TRANS_B),
 ]
 
 

@@ -107,6 +107,9 @@ GEMM_CASES = [
     "HF8 BF16 F32 F32 64 64 64 64 64 64 1 1 0 0 0 0 1 0 0 nopf strdbr 2 0 2 0",
     "I8 BF16 F32 BF16 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",
     "I8 BF16 F32 F32 64 64 64 64 64 64 1 1 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",
+    "F16 F16 F16 F16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",          # comp_type F16: a rounding after every product
+    "F16 F16 F16 F32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf strdbr 2 0 2 0",
+    "F16 F16 IMPLICIT F16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",     # IMPLICIT = f32 sums here (the driver asks this library's libxsmm_cpuid)
     # "spmm": A sparsified to the given fraction and handed over as (non-zeros, bitmask) -- LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK
     "F32 F32 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf spmm 0.5 0 2 0",
     "F32 F32 F32 F32 128 48 256 128 256 128 1 1 0 0 0 0 0 0 0 nopf spmm 0.9 0 2 0",
