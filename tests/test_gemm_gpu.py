@@ -285,7 +285,8 @@ def test_illegal_descriptors_return_null():
     assert api.dispatch_gemm(s, F.NO_RESET_TILECONFIG, 0) is None                       # half-set tile config
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 16, 32, 32, DT.F32, DT.F32, DT.F32, DT.F32), 0, 0) is None   # lda < m
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F64, DT.F32, DT.F32, DT.F32), 0, 0) is None  # unsupported type mix
-    assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F16, DT.F16, DT.F16, DT.F16), 0, 0) is None  # halves accumulate in f32 here (comp F16 is not built)
+    assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F16, DT.F16, DT.BF16, DT.F32), 0, 0) is None  # halves produce halves or f32, nothing else
+    assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F16, DT.F16, DT.F16, DT.BF16), 0, 0) is None  # ... and accumulate in f32 or f16
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.I8, DT.I8, DT.I32, DT.F32), 0, 0) is None    # 8-bit integers accumulate in i32
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 31, 32, 32, 32, DT.BF16, DT.BF16, DT.BF16, DT.F32), F.VNNI_A, 0) is None   # odd k with VNNI
     # same descriptor -> same handle (registry), different descriptor -> different handle
