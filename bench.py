@@ -507,12 +507,9 @@ def main():
 
     if args.config == 5:
         out = run_config5(args, api, dev, rank, world, dist, barrier)
-        if rank == 0:
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(64, "bf16", 1, 0, 1, args.cpu_seconds, nthreads)
-            print(json.dumps(out))
-        if dist is not None:
-            dist.barrier(); dist.destroy_process_group()
+        if rank == 0 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(64, "bf16", 1, 0, 1, args.cpu_seconds, nthreads)
+        finish(dist, out if rank == 0 else None)
         return
 
     only = args.only
@@ -625,12 +622,29 @@ def main():
             out["ragged"] = ragged
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.m, args.dtype, args.br, args.beta, args.fused, args.cpu_seconds, nthreads)
-        print(json.dumps(out))
         if args.manifest:
             json.dump({"command": " ".join(sys.argv), "entries": MANIFEST}, open(args.manifest, "w"), indent=1)
+    finish(dist, out if rank == 0 else None)
+
+
+def finish(dist, out):
+    """Tear the process group down FIRST, then print the one JSON line as the last thing this process writes to stdout: RCCL announces itself
+    on stdout through C stdio ("Librccl path : ..."), whose buffer would otherwise be flushed after Python's at exit and push that text behind
+    the JSON line."""
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if out is None:
+        return
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # whatever C libraries still hold goes out before the line, not after it
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+    if dist is not None:
+        os._exit(0)                             # nothing (an exit handler of the collective library, ...) writes behind the line
 
 
 if __name__ == "__main__":
