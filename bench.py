@@ -631,20 +631,22 @@ def finish(dist, out):
     """Tear the process group down FIRST, then print the one JSON line as the last thing this process writes to stdout: RCCL announces itself
     on stdout through C stdio ("Librccl path : ..."), whose buffer would otherwise be flushed after Python's at exit and push that text behind
     the JSON line."""
+    def flush_all():
+        try:
+            C.CDLL(None).fflush(None)           # whatever C libraries still hold goes out now ...
+        except Exception:
+            pass
+        sys.stdout.flush(); sys.stderr.flush()
+    flush_all()                                 # ... on EVERY rank, before the barrier: the launcher merges the ranks' stdout
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if out is None:
-        return
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)          # whatever C libraries still hold goes out before the line, not after it
-    except Exception:
-        pass
-    sys.stdout.write(json.dumps(out) + "\n")
-    sys.stdout.flush()
+        flush_all()
+    if out is not None:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
     if dist is not None:
-        os._exit(0)                             # nothing (an exit handler of the collective library, ...) writes behind the line
+        os._exit(0)                             # no exit handler (of the collective library, ...) writes behind the line, on any rank
 
 
 if __name__ == "__main__":
