@@ -84,3 +84,58 @@ def test_dispatcher_accepts_and_refuses_what_the_documentation_says():
     wrong = {k: v for k, v in got.items() if v == k.startswith("no:")}
     assert not wrong, f"accepted / refused against the table: {wrong}"
     assert sum(1 for k in got if not k.startswith("no:")) >= 30
+
+
+TPP_CHILD = r"""
+import json, sys
+sys.path.insert(0, %r)
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, UNARY, UNARY_FLAG as UF, BINARY, BINARY_FLAG as BF, TERNARY, TERNARY_FLAG as TF
+api = capi.load()
+U = lambda i, o, m=64, n=48, ldi=64, ldo=64: capi.UnaryShape(m, n, ldi, ldo, i, o, DT.F32)
+B = lambda i0, i1, o, m=64, n=48: capi.BinaryShape(m, n, 64, 64, 64, i0, i1, o, DT.F32)
+out = {}
+def u(name, typ, shape, flags=0): out[name] = bool(api.dispatch_meltw_unary(typ, shape, flags))
+def b(name, typ, shape, flags=0): out[name] = bool(api.dispatch_meltw_binary(typ, shape, flags))
+u("identity_f32_bf16", UNARY.IDENTITY, U(DT.F32, DT.BF16))
+u("tanh_bf16", UNARY.TANH, U(DT.BF16, DT.BF16))
+u("gelu_inv", UNARY.GELU_INV, U(DT.F32, DT.F32))
+u("relu_bitmask", UNARY.RELU, U(DT.F32, DT.F32), UF.BITMASK_2BYTEMULT)
+u("exp_hf8", UNARY.EXP, U(DT.HF8, DT.HF8))
+u("transpose_f64", UNARY.TRANSFORM_NORM_TO_NORMT, capi.UnaryShape(16, 24, 16, 24, DT.F64, DT.F64, DT.F64))
+u("norm_to_vnni4_i8", UNARY.TRANSFORM_NORM_TO_VNNI4, U(DT.I8, DT.I8))
+u("reduce_cols_add", UNARY.REDUCE_X_OP_ADD, U(DT.F32, DT.F32), UF.REDUCE_COLS)
+u("reduce_x_x2_rows", UNARY.REDUCE_X_X2_OP_ADD, U(DT.BF16, DT.F32), UF.REDUCE_ROWS)
+u("reduce_listed_cols_max", UNARY.REDUCE_COLS_IDX_OP_MAX, U(DT.F32, DT.F32), UF.IDX_SIZE_4BYTES)
+u("dropout", UNARY.DROPOUT, U(DT.F32, DT.F32), UF.BITMASK_2BYTEMULT)
+u("dropout_inv", UNARY.DROPOUT_INV, U(DT.BF16, DT.BF16), UF.BITMASK_2BYTEMULT)
+u("stochastic_bf8", UNARY.IDENTITY, U(DT.F32, DT.BF8), UF.STOCHASTIC_ROUND)
+u("quant_i8", UNARY.QUANT, U(DT.F32, DT.I8))
+u("quant_mxfp4", UNARY.QUANT, U(DT.F32, DT.MXFP4X2))
+u("quant_nvfp4", UNARY.QUANT, U(DT.BF16, DT.NVFP4X2))
+u("dequant_i16", UNARY.DEQUANT, U(DT.I16, DT.F32))
+u("gather_cols", UNARY.GATHER, U(DT.F32, DT.F32), UF.GS_COLS | UF.IDX_SIZE_4BYTES)
+u("replicate_col_var_n0", UNARY.REPLICATE_COL_VAR, U(DT.F32, DT.F32, n=0))
+b("add_bcast_col", BINARY.ADD, B(DT.BF16, DT.BF16, DT.BF16), BF.BCAST_COL_IN_0)
+b("cmp_gt_bitmask", BINARY.CMP_OP_GT, B(DT.F32, DT.F32, DT.F32), BF.BITMASK_2BYTEMULT)
+b("zip", BINARY.ZIP, B(DT.U16, DT.U16, DT.F32))
+b("dot_to_scalar", BINARY.MUL_AND_REDUCE_TO_SCALAR_OP_ADD, B(DT.BF16, DT.F32, DT.F32))
+b("add_stochastic_bf8", BINARY.ADD, B(DT.F32, DT.F32, DT.BF8), BF.STOCHASTIC_ROUND)
+out["select"] = bool(api.dispatch_meltw_ternary(TERNARY.SELECT, capi.TernaryShape(64, 48, 64, 64, 64, 64, DT.F32, DT.F32, DT.IMPLICIT, DT.F32, DT.F32), TF.BITMASK_2BYTEMULT))
+out["muladd"] = bool(api.dispatch_meltw_ternary(TERNARY.MULADD, capi.TernaryShape(64, 48, 64, 64, 64, 64, DT.BF16, DT.BF16, DT.BF16, DT.BF16, DT.F32), 0))
+# refused on purpose
+b("no:matmul_as_a_tpp", BINARY.MATMUL, B(DT.F32, DT.F32, DT.F32, m=8, n=8))
+u("no:stochastic_to_bf16", UNARY.IDENTITY, U(DT.F32, DT.BF16), UF.STOCHASTIC_ROUND)
+u("no:dropout_with_broadcast", UNARY.DROPOUT, U(DT.F32, DT.F32), UF.BITMASK_2BYTEMULT | UF.BCAST_COL)
+b("no:dot_to_scalar_f64", BINARY.MUL_AND_REDUCE_TO_SCALAR_OP_ADD, capi.BinaryShape(64, 48, 64, 64, 64, DT.F64, DT.F64, DT.F64, DT.F64))
+print(json.dumps(out))
+"""
+
+
+def test_tpp_dispatcher_accepts_and_refuses_what_the_documentation_says():
+    env = dict(os.environ, LIBXSMM_HIP_DRYRUN="1", LIBXSMM_VERBOSE="0")
+    r = subprocess.run([sys.executable, "-c", TPP_CHILD % ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    wrong = {k: v for k, v in got.items() if v == k.startswith("no:")}
+    assert not wrong, f"accepted / refused against the table: {wrong}"
