@@ -1237,12 +1237,14 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
 #define LAUNCH_I8D_(B_) do { \
     if (ua) { if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, true, 2, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); \
               else hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, true, 0, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); } \
-    else { if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, false, 2, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); \
-           else hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, false, 0, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); } } while (0)
+    else { if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, false, 2, 2, (B_ == 1 ? 2 : 3), 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); \
+           else hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, false, 0, 2, (B_ == 1 ? 2 : 3), 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); } } while (0)
           // ring depth 2, three waves per SIMD (141 VGPRs), 64 rows per wave -- measured on 8192 M-blocks of 64 x 256 (2:8, bn = 16): depth 2 / 3 / 4 at two waves
           // per SIMD 60.5 / 61.2 / 61.2 us, three waves per SIMD 56.0 us; 32 rows per wave (104 VGPRs, four waves per SIMD) 60.5 us: twice the B loads and
           // per-wave set-up outweigh the occupancy (profiles/r02_bcsc_counters.txt).  Waves streaming over M-blocks (the bf16 kernel's +9 %): 55.9 us here,
           // no gain -- half of this kernel's traffic is the int32 C it writes, not the operand stream the scheme keeps busy -- so it was not kept.
+          // Signed A (i8 x u8) at bn = 16 carries 64 more correction accumulators (one set per N-block): under the three-waves cap (168 registers) the
+          // compiler spilled 74 of them to scratch inside the loop (tools/kernel_resources.py), so that one variant is compiled for two waves per SIMD.
           if (a.bn == 16) LAUNCH_I8D_(1); else if (a.bn == 32) LAUNCH_I8D_(2); else LAUNCH_I8D_(4);
 #undef LAUNCH_I8D_
           if (name) *name = "bcsc_mfma_i8_dma_kernel";

@@ -1,0 +1,80 @@
+"""Register / scratch budget of the compiled gfx950 kernels, read from the code objects inside libxsmm_amd.so (no GPU needed).
+
+A kernel that needs scratch has spilled registers or keeps its argument block in memory: for the streaming kernels of this library that is a
+performance bug (round 2 found two of them this way: the M-block streaming BCSC kernel before its lambdas were force-inlined, and the signed-A
+int8 BCSC variant under the three-waves register cap).  The table itself is committed as profiles/r02_kernel_resources.txt."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources as kr   # noqa: E402
+
+LIB = os.path.join(ROOT, "libxsmm_amd", "lib", "libxsmm_amd.so")
+pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.path.join(kr.LLVM, "llvm-readelf"))),
+                                reason="needs the built library and the ROCm LLVM tools")
+
+# two spilled registers live across the main loop of the 512-register blocked bf16 kernel (stored before it, reloaded in the epilogue)
+SCRATCH_ALLOWED = {r"xamd::gemm_bf16_blocked_kernel<[02], [12]>": 12}
+
+# kernel family -> least waves per SIMD that DESIGN.md's occupancy statements rely on (registers and static LDS together)
+OCCUPANCY = {
+    r"xamd::gemm_f32_stream_kernel_lean<.*>": 4,                 # headline: four workgroups of 32 KiB LDS per CU
+    r"xamd::gemm_f32_stream_kernel<.*>": 4,
+    r"xamd::gemm_f32_wg64_kernel<.*>": 4,
+    r"xamd::gemm_bf16_wg64_kernel<.*>": 4,
+    r"xamd::gemm_p16_kernel<1, .*>": 8,
+    r"xamd::bcsc_mfma_bf16_stream_kernel<.*>": 2,                # 2048 waves = one round at two waves per SIMD
+    r"xamd::bcsc_mfma_bf16_dma_kernel<.*>": 3,
+    r"xamd::bcsc_mfma_i8_dma_kernel<., true, .*>": 3,
+    r"xamd::bcsc_mfma_i8_dma_kernel<., false, .*>": 2,
+    r"xamd::bcsc_mfma_f32_kernel<.*>": 4,
+    r"xamd::spmm_stream_kernel<.*>": 8,
+}
+
+
+@pytest.fixture(scope="module")
+def table():
+    return kr.collect(LIB)
+
+
+def test_every_translation_unit_is_found(table):
+    names = {t["name"] for t in table}
+    assert len(table) > 200
+    for family in ("xamd::gemm_f32_stream_kernel_lean", "xamd::bcsc_mfma_bf16_stream_kernel", "xamd::spmm_stream_kernel", "xamd::mx_out_quant_kernel"):
+        assert any(n.startswith(family) for n in names), family          # gemm_kernels.hip, sparse_kernels.hip, meltw_kernels.hip
+
+
+def test_no_kernel_spills_to_scratch(table):
+    bad = {}
+    for t in table:
+        allowed = max([v for k, v in SCRATCH_ALLOWED.items() if re.fullmatch(k, t["name"])], default=0)
+        if t["scratch"] > allowed:
+            bad[t["name"]] = (t["scratch"], t["spills"])
+    assert not bad, f"kernels with scratch (bytes, spilled registers): {bad}"
+
+
+def test_hot_kernels_keep_their_occupancy(table):
+    low, seen = {}, set()
+    for t in table:
+        for pattern, least in OCCUPANCY.items():
+            if re.fullmatch(pattern, t["name"]):
+                seen.add(pattern)
+                if t["waves"] < least:
+                    low[t["name"]] = (t["waves"], least, t["vgpr"], t["lds"])
+    assert seen == set(OCCUPANCY), f"no kernel matches {set(OCCUPANCY) - seen}"
+    assert not low, f"(waves per SIMD, expected at least, registers, LDS bytes): {low}"
+
+
+def test_committed_table_is_current(table):
+    """profiles/r02_kernel_resources.txt is the table of THIS build (regenerate with tools/kernel_resources.py --out ...)."""
+    path = os.path.join(ROOT, "profiles", "r02_kernel_resources.txt")
+    committed = {}
+    for line in open(path).read().splitlines()[2:]:
+        cols = line.split(None, 8)
+        committed[cols[8]] = (int(cols[3]), int(cols[4]))                 # static LDS and scratch; register counts may move with the compiler
+    built = {t["name"]: (t["lds"], t["scratch"]) for t in table}
+    assert committed == built
