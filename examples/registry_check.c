@@ -8,12 +8,16 @@
  *   registry_check hit <reps>                            ns per libxsmm_dispatch_brgemm hit (thread-local cache)
  *   registry_check cycle                                 finalize invalidates the per-thread cache; re-dispatch is valid
  *   registry_check info                                  libxsmm_get_registry_info / kernel info / kernel names
+ *   registry_check threads <threads> <n>                 every thread dispatches the same n descriptors, each in its own order, while the
+ *                                                        others do: one handle per descriptor whoever got there first (the reference's
+ *                                                        tests/threadsafety.c), registry size n, every handle describes its descriptor
  */
 #include <libxsmm.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <pthread.h>
 
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
@@ -101,12 +105,54 @@ static int run_info(void) {
   return 0;
 }
 
+typedef struct worker_t { int id, n, threads; size_t* handles; int failed; } worker_t;
+
+static void* worker_main(void* arg) {
+  worker_t* w = (worker_t*)arg;
+  int r, i;
+  for (r = 0; r < 3; ++r) {                  /* first pass registers (racing with the others), later passes hit */
+    for (i = 0; i < w->n; ++i) {
+      const int d = (int)(((long)i * (2 * w->id + 1) + 7919L * w->id + r) % w->n);      /* a thread-specific walk over all descriptors */
+      const size_t h = (size_t)unary_of(d);
+      if (!h) { w->failed = 1; return NULL; }
+      if (w->handles[d] == 0) w->handles[d] = h; else if (w->handles[d] != h) { w->failed = 2; return NULL; }
+    }
+  }
+  for (i = 0; i < w->n; ++i) if (w->handles[i] == 0) w->handles[i] = (size_t)unary_of(i);   /* walks with a common factor skip some: fill in */
+  return NULL;
+}
+
+static int run_threads(int threads, int n) {
+  pthread_t* tid = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+  worker_t* w = (worker_t*)calloc((size_t)threads, sizeof(worker_t));
+  int t, i;
+  for (t = 0; t < threads; ++t) {
+    w[t].id = t; w[t].n = n; w[t].threads = threads; w[t].handles = (size_t*)calloc((size_t)n, sizeof(size_t));
+    if (pthread_create(&tid[t], NULL, worker_main, &w[t]) != 0) { printf("FAIL: pthread_create\n"); return 1; }
+  }
+  for (t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+  for (t = 0; t < threads; ++t) if (w[t].failed) { printf("FAIL: thread %d: %s\n", t, w[t].failed == 1 ? "NULL handle" : "two handles for one descriptor"); return 1; }
+  for (i = 0; i < n; ++i) {
+    libxsmm_xmeltwfunction x; libxsmm_meltwkernel_info mi;
+    for (t = 1; t < threads; ++t) if (w[t].handles[i] != w[0].handles[i]) { printf("FAIL: descriptor %d has different handles in threads 0 and %d\n", i, t); return 1; }
+    x.meltw_unary = (libxsmm_meltwfunction_unary)w[0].handles[i];
+    if (libxsmm_get_meltwkernel_info(x, &mi) != EXIT_SUCCESS || (int)mi.m != 1 + (i % 512) || (int)mi.n != 1 + (i / 512) % 512) {
+      printf("FAIL: handle of descriptor %d describes m=%u n=%u\n", i, mi.m, mi.n); return 1;
+    }
+  }
+  { libxsmm_registry_info info;
+    if (libxsmm_get_registry_info(&info) != EXIT_SUCCESS || (int)info.size != n) { printf("FAIL: registry size %d, expected %d\n", (int)info.size, n); return 1; } }
+  printf("ok threads: %d threads x %d descriptors, one handle each\n", threads, n);
+  return 0;
+}
+
 int main(int argc, char* argv[]) {
   libxsmm_init();
   if (argc >= 4 && strcmp(argv[1], "capacity") == 0) return run_capacity(atoi(argv[2]), atoi(argv[3]));
   if (argc >= 3 && strcmp(argv[1], "hit") == 0) return run_hit(atol(argv[2]));
   if (argc >= 2 && strcmp(argv[1], "cycle") == 0) return run_cycle();
   if (argc >= 2 && strcmp(argv[1], "info") == 0) return run_info();
-  printf("usage: registry_check capacity <n> <expected_ok> | hit <reps> | cycle | info\n");
+  if (argc >= 4 && strcmp(argv[1], "threads") == 0) return run_threads(atoi(argv[2]), atoi(argv[3]));
+  printf("usage: registry_check capacity <n> <expected_ok> | hit <reps> | cycle | info | threads <threads> <n>\n");
   return 2;
 }

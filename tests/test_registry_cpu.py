@@ -18,7 +18,7 @@ LIBDIR = os.path.join(ROOT, "libxsmm_amd", "lib")
 def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("reg") / "registry_check")
     cmd = ["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "registry_check.c"), "-L" + LIBDIR, "-lxsmm_amd", "-Wl,-rpath," + LIBDIR, "-o", out]
+           os.path.join(ROOT, "examples", "registry_check.c"), "-L" + LIBDIR, "-lxsmm_amd", "-Wl,-rpath," + LIBDIR, "-lpthread", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return out
@@ -46,6 +46,14 @@ def test_slot_exhaustion_returns_null_and_keeps_earlier_handles(exe):
 def test_static_trampolines_serve_when_executable_memory_is_unavailable(exe):
     r = run(exe, "capacity", 300, 256, LIBXSMM_HIP_THUNKS=0)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_concurrent_dispatch_gives_one_handle_per_descriptor(exe):
+    """Eight threads register and hit the same 20 000 descriptors in different orders [ref: tests/threadsafety.c]; the same run under
+    ThreadSanitizer is part of tools/sanitize_host.sh."""
+    r = run(exe, "threads", 8, 20000)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok threads" in r.stdout
 
 
 def test_dispatch_hit_is_allocation_free_and_fast(exe):

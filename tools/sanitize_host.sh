@@ -3,7 +3,7 @@
 # (device code is left alone: -fno-gpu-sanitize), swaps it in for the duration of the CPU test-suite and of examples/registry_check.c in
 # dry-run mode (capacity, exhaustion, hit path, init / finalize cycles; with leak detection), and restores the real library afterwards.
 # Round 2: 720 CPU tests and the registry program ran without a report (the few CPU tests that start children with a cleaned environment or
-# link a C program with gcc cannot preload the sanitizer runtime and are not counted).
+# link a C program with gcc cannot preload the sanitizer runtime and are not counted); the threaded dispatch check under ThreadSanitizer: clean.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-/tmp/libxsmm_amd_asan}
@@ -35,4 +35,17 @@ export ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:log_path=$OUT/asan UBSAN_OPTI
 LIBXSMM_HIP_MAX_HANDLES=500 "$OUT/registry_check" capacity 700 500 | tail -1
 LIBXSMM_HIP_THUNKS=0 "$OUT/registry_check" capacity 300 256 | tail -1
 unset LD_PRELOAD
-echo "sanitizer reports:"; ls "$OUT"/asan.* "$OUT"/ubsan.* 2>/dev/null || echo "  none"
+
+# the registry's miss path (lock), hit path (thread cache) and thunk pool under ThreadSanitizer: eight threads, the same descriptors
+TS="$OUT/tsan"; mkdir -p "$TS/obj" "$TS/lib"
+TFLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fvisibility=hidden -I$ROOT/include -fsanitize=thread -fno-gpu-sanitize"
+cd "$ROOT/libxsmm_amd/csrc" || exit 1
+for f in runtime.cpp frontend.cpp utils.cpp jit.cpp meqn.cpp; do /opt/rocm/bin/hipcc $TFLAGS -x hip -c $f -o "$TS/obj/$f.o" & done
+for f in gemm_kernels.hip sparse_kernels.hip meltw_kernels.hip; do /opt/rocm/bin/hipcc $TFLAGS -c $f -o "$TS/obj/$f.o" & done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=thread -fno-gpu-sanitize "$TS"/obj/*.o -ldl -o "$TS/lib/libxsmm_amd.so" || exit 1
+gcc -std=c99 -D_POSIX_C_SOURCE=200809L -O1 -g -I"$ROOT/include" "$ROOT/examples/registry_check.c" -L"$TS/lib" -lxsmm_amd -Wl,-rpath,"$TS/lib" \
+  -Wl,--allow-shlib-undefined -lpthread -o "$TS/registry_check" || exit 1
+TSAN_OPTIONS=halt_on_error=0:log_path=$OUT/tsan_report LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | head -1) \
+  LIBXSMM_HIP_DRYRUN=1 "$TS/registry_check" threads 8 5000 | tail -1
+echo "sanitizer reports:"; ls "$OUT"/asan.* "$OUT"/ubsan.* "$OUT"/tsan_report.* 2>/dev/null || echo "  none"
