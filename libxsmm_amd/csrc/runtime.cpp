@@ -163,11 +163,11 @@ void finish_launch(int err, const char* kname) {
 // plain host memory are staged through a per-thread device scratch; device-visible ones pass through.
 // Device blocks that were outgrown are RETIRED, not freed: a captured hipGraph (or a kernel still in flight on another
 // stream) may hold their address.  They are released at libxsmm_finalize.
-std::mutex g_retired_lock;
-std::vector<void*> g_retired;
-void retire_block(void* p) { if (p) { std::lock_guard<std::mutex> guard(g_retired_lock); g_retired.push_back(p); } }
+struct Retired { std::mutex lock; std::vector<void*> blocks; };
+Retired& retired() { static Retired* r = new Retired(); return *r; }   // never destroyed: a thread may still retire its blocks while the process exits
+void retire_block(void* p) { if (p) { Retired& r = retired(); std::lock_guard<std::mutex> guard(r.lock); r.blocks.push_back(p); } }
 static int cur_device() { const int d = tls().device; return d < 0 ? 0 : d; }
-struct Scratch { char* base = nullptr; size_t cap = 0, used = 0; int device = 0; };
+struct Scratch { char* base = nullptr; size_t cap = 0, used = 0; int device = 0; ~Scratch() { retire_block(base); } };   // a thread that exits hands its block to finalize
 thread_local Scratch t_scratch;
 struct CopyBack { void* host; const void* dev; size_t width, height, pitch; };   // height rows of `width` bytes, `pitch` bytes apart (height 1: plain)
 thread_local std::vector<CopyBack> t_copyback;       // staged outputs of the current synchronous call
@@ -220,7 +220,7 @@ void copy_back_staged() {
   t_copyback.clear();
 }
 // per-thread device workspace for partial results; grows monotonically, reused in stream order
-struct Workspace { void* base = nullptr; size_t cap = 0; int device = 0; };
+struct Workspace { void* base = nullptr; size_t cap = 0; int device = 0; ~Workspace() { retire_block(base); } };
 thread_local Workspace t_workspace;
 thread_local size_t t_ws_reserved = 0;   // front part owned by an enclosing call (the slots of a matrix equation around a GEMM node)
 void* workspace(size_t nbytes_wanted) {
@@ -1044,7 +1044,7 @@ LIBXSMM_API void libxsmm_finalize(void) {
   for (KernelCtx* c : g_meqn_ctxs) free_ctx_locked(c);
   g_meqn_ctxs.clear();
   free_meqn_equations();
-  { std::lock_guard<std::mutex> g2(g_retired_lock); for (void* p : g_retired) (void)hipFree(p); g_retired.clear(); }
+  { Retired& r = retired(); std::lock_guard<std::mutex> g2(r.lock); for (void* p : r.blocks) (void)hipFree(p); r.blocks.clear(); }
   g_generation.fetch_add(1, std::memory_order_release);
   libxsmm_ninit = 0;
 }
