@@ -159,6 +159,7 @@ JitKernel* jit_compile(const std::string& src, const std::string& fname, long lo
 int jit_launch(JitKernel* k, void** args, void* stream);
 bool jit_on_current_device(const JitKernel* k);
 int rt_jit_mode();
+bool rt_dryrun();            // LIBXSMM_HIP_DRYRUN=1 and no device: dispatch / code generation work, nothing can be launched
 const char* jit_name(const JitKernel* k);
 size_t jit_code_size(const JitKernel* k);
 

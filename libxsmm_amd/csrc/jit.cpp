@@ -19,6 +19,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <mutex>
@@ -169,17 +170,24 @@ static JitKernel* build_module(const std::string& src, const std::string& fname,
   if ((total + 255) / 256 >= (1ll << 31)) return fail("grid too large");
   std::lock_guard<std::mutex> guard(g_jit_lock);
   if (!rtc_ready()) return fail("hiprtc is not available");
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return fail("no current device");
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("device properties unavailable");
+  // Dry run (LIBXSMM_HIP_DRYRUN=1, no device): the source is compiled for gfx950 and kept (optionally dumped), never loaded or launched --
+  // the CPU test-suite compiles what the generators emit and reads the code objects' register / scratch budget.
+  const bool dry = rt_dryrun();
+  int dev = dry ? -1 : 0;
+  std::string arch_name = "gfx950";
+  if (!dry) {
+    if (hipGetDevice(&dev) != hipSuccess) return fail("no current device");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("device properties unavailable");
+    arch_name = prop.gcnArchName;
+  }
   const std::string key = std::to_string(dev) + ":" + src;
   auto it = g_jit_cache.find(key);
   if (it != g_jit_cache.end()) { ++it->second->refs; return it->second; }
   const auto t_start = std::chrono::steady_clock::now();
   hiprtcProgram prog = nullptr;
   if (g_rtc.create(&prog, src.c_str(), "libxsmm_amd_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail("hiprtcCreateProgram failed");
-  const std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+  const std::string arch = std::string("--offload-arch=") + arch_name;
   const char* opts[] = {arch.c_str(), "-O3", "-ffp-contract=off"};
   const hiprtcResult rc = g_rtc.compile(prog, 3, opts);
   if (rc != HIPRTC_SUCCESS) {
@@ -194,7 +202,17 @@ static JitKernel* build_module(const std::string& src, const std::string& fname,
   std::vector<char> code(csz);
   (void)g_rtc.code(prog, code.data());
   (void)g_rtc.destroy(&prog);
+  if (const char* dump = std::getenv("LIBXSMM_HIP_JIT_DUMP")) {          // <dir>/<kernel>.hip and .co of everything that is generated
+    const std::string base = std::string(dump) + "/" + fname;
+    if (FILE* f = std::fopen((base + ".hip").c_str(), "wb")) { std::fwrite(src.data(), 1, src.size(), f); std::fclose(f); }
+    if (FILE* f = std::fopen((base + ".co").c_str(), "wb")) { std::fwrite(code.data(), 1, code.size(), f); std::fclose(f); }
+  }
   JitKernel* k = new JitKernel();
+  if (dry) {
+    k->device = -1; k->total_threads = total; k->vec = vec; k->elem = elem; k->code_size = csz; k->key = key; k->name = fname;
+    g_jit_cache.emplace(key, k);
+    return k;
+  }
   if (hipModuleLoadData(&k->mod, code.data()) != hipSuccess || hipModuleGetFunction(&k->fn, k->mod, fname.c_str()) != hipSuccess) {
     (void)hipGetLastError();
     if (k->mod) (void)hipModuleUnload(k->mod);
@@ -319,7 +337,7 @@ void jit_release(JitKernel* k) {
   std::lock_guard<std::mutex> guard(g_jit_lock);
   if (--k->refs > 0) return;
   g_jit_cache.erase(k->key);
-  (void)hipModuleUnload(k->mod);
+  if (k->mod) (void)hipModuleUnload(k->mod);
   delete k;
 }
 

@@ -253,12 +253,11 @@ KernelCtx* new_ctx_locked(Kind kind) {
   return c;
 }
 
+// Dry run (no device): pattern "uploads" are host copies (to_device below), released accordingly.
+void dev_free(void* p) { if (!p) return; if (g_dryrun) std::free(p); else (void)hipFree(p); }
 void free_ctx_locked(KernelCtx* c) {
   if (!c) return;
-  if (c->d_ptr) (void)hipFree(c->d_ptr);
-  if (c->d_idx) (void)hipFree(c->d_idx);
-  if (c->d_vals) (void)hipFree(c->d_vals);
-  if (c->d_vmap) (void)hipFree(c->d_vmap);
+  dev_free(c->d_ptr); dev_free(c->d_idx); dev_free(c->d_vals); dev_free(c->d_vmap);
   if (c->jit) jit_release(c->jit);
   if (c->eqn) free_meqn_plan(c->eqn);
   for (auto& e : c->bcsc_cache) if (e.d_block) (void)hipFree(e.d_block);
@@ -271,8 +270,10 @@ bool tilecfg_halfset(unsigned int f) {   // [ref: src/libxsmm_generator.c:154-15
   return a != b;
 }
 
+// Dry run (no device): pattern "uploads" are host copies, so that the creators get as far as code generation (compiled, never launched).
 template <typename T> T* to_device(const T* host, size_t count) {
   if (count == 0) count = 1;
+  if (g_dryrun) { T* h = (T*)std::calloc(count, sizeof(T)); if (h && host) std::memcpy(h, host, count * sizeof(T)); return h; }
   T* d = nullptr;
   if (hipMalloc((void**)&d, count * sizeof(T)) != hipSuccess) return nullptr;
   if (host && hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
@@ -1000,6 +1001,7 @@ void rt_scratch_reset() { scratch_reset(); }
 void rt_note(const char* what, int a, int b, int c) { vlog(1, "%s (%d, %d, %d)", what, a, b, c); }
 void* rt_stream() { return tls().stream; }
 int rt_jit_mode() { return jit_mode(); }
+bool rt_dryrun() { return g_dryrun; }
 
 void invoke(int slot, const void* param) {
   KernelCtx* k = g_slots[slot];

@@ -82,8 +82,11 @@ def waves_per_simd_lds(lds_bytes, wg_size):
 
 
 def collect(lib):
+    """`lib`: a shared library with embedded offload bundles, or a bare gfx950 code object (what hiprtc returns: LIBXSMM_HIP_JIT_DUMP)."""
     rows = []
-    for image in code_objects(lib):
+    head = open(lib, "rb").read(64)
+    images = [open(lib, "rb").read()] if (lib.endswith(".co") and head[:4] == b"\x7fELF" and MAGIC not in head) else code_objects(lib)
+    for image in images:
         rows.extend(kernels_of(image))
     pretty = demangle([r[".name"] for r in rows])
     table = []
