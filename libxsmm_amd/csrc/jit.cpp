@@ -92,6 +92,10 @@ int choose_vec(const SpmmJitSpec& s, int touched, int elem) {
   const int words = elem / 4;
   const int cands[3] = {16 / elem, 8 / elem, 1};
   int best = 0;
+  // LIBXSMM_HIP_JIT_VEC=<elements per lane>: experiments on the register budget / occupancy trade (taken if the geometry admits it)
+  static const int forced = []() { const char* e = getenv("LIBXSMM_HIP_JIT_VEC"); return e ? atoi(e) : 0; }();
+  if (forced >= 1 && forced * elem <= 16 && !(s.ncols % forced || s.ld_x % forced || s.ld_y % forced || s.outer_x % forced || s.outer_y % forced) &&
+      (long long)touched * forced * words <= 176) return forced;
   for (int ci = 0; ci < 3; ++ci) {
     const int e = cands[ci];
     if (e < 1 || (ci > 0 && e == cands[ci - 1])) continue;
