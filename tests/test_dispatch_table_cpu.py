@@ -139,3 +139,74 @@ def test_tpp_dispatcher_accepts_and_refuses_what_the_documentation_says():
     got = json.loads(r.stdout.strip().splitlines()[-1])
     wrong = {k: v for k, v in got.items() if v == k.startswith("no:")}
     assert not wrong, f"accepted / refused against the table: {wrong}"
+
+
+CREATOR_CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, GEMM_FLAG as F
+api = capi.load()
+rowptr = np.array([0, 2, 3, 3, 5], dtype=np.uint32); colidx = np.array([0, 2, 1, 0, 3], dtype=np.uint32)
+v32, v64 = np.ones(5, dtype=np.float32), np.ones(5, dtype=np.float64)
+P = 64
+out = {}
+
+def csr(name, dt_a, dt_b, dt_c, lda, ldb, ldc, flags=0, pw=P, vals=v32, rp=rowptr, ci=colidx, fn=None):
+    shape = capi.gemm_shape(4, 4, 4, lda, ldb, ldc, dt_a, dt_b, dt_c, dt_a)
+    fn = fn or api.create_packed_spgemm_csr
+    out[name] = bool(fn(shape, flags, 0, pw, rp.ctypes.data if rp is not None else None, ci.ctypes.data if ci is not None else None, vals.ctypes.data if vals is not None else None))
+
+# packed CSR / CSC: A-sparse (lda = 0), B-sparse (ldb = 0), C-sparse (ldc = 0) [ref: src/libxsmm_main.c:3553-3640, generator_packed_spgemm.c:27-81]
+csr("csr_asparse_f32", DT.F32, DT.F32, DT.F32, 0, 4, 4)
+csr("csr_asparse_f64", DT.F64, DT.F64, DT.F64, 0, 4, 4, vals=v64)
+csr("csr_bsparse_f32", DT.F32, DT.F32, DT.F32, 4, 0, 4)
+csr("no:csr_csparse_f32", DT.F32, DT.F32, DT.F32, 4, 4, 0)                                  # C-sparse exists for CSC only, as in the reference
+csr("csc_csparse_f32", DT.F32, DT.F32, DT.F32, 4, 4, 0, fn=api.create_packed_spgemm_csc)
+csr("csc_bsparse_f32", DT.F32, DT.F32, DT.F32, 4, 0, 4, fn=api.create_packed_spgemm_csc)
+csr("no:csr_bf16", DT.BF16, DT.BF16, DT.BF16, 0, 4, 4)
+csr("no:csr_mixed_types", DT.F32, DT.F64, DT.F32, 0, 4, 4)
+csr("no:csr_f32_to_f64", DT.F32, DT.F32, DT.F64, 0, 4, 4)
+csr("no:csr_width_0", DT.F32, DT.F32, DT.F32, 0, 4, 4, pw=0)
+csr("no:csr_trans_a", DT.F32, DT.F32, DT.F32, 0, 4, 4, flags=F.TRANS_A)
+csr("no:csr_null_values", DT.F32, DT.F32, DT.F32, 0, 4, 4, vals=None)
+csr("no:csr_null_rowptr", DT.F32, DT.F32, DT.F32, 0, 4, 4, rp=None)
+csr("no:csr_all_dense", DT.F32, DT.F32, DT.F32, 4, 4, 4)
+csr("no:csr_two_sparse", DT.F32, DT.F32, DT.F32, 0, 0, 4)
+csr("no:csr_ldb_below_n", DT.F32, DT.F32, DT.F32, 0, 2, 4)
+csr("no:csr_half_tilecfg", DT.F32, DT.F32, DT.F32, 0, 4, 4, flags=F.NO_RESET_TILECONFIG)
+
+def bcsc(name, dt_a, dt_b, dt_c, comp, flags, K=256, N=64, bk=32, bn=16, pw=64, ldb=0):
+    shape = capi.gemm_shape(8, 0, K, K, ldb, N, dt_a, dt_b, dt_c, comp)
+    out[name] = bool(api.create_packed_spgemm_bcsc(shape, flags, 0, capi.SpgemmConfig(pw, bk, bn)))
+
+# BCSC [ref: src/libxsmm_main.c:3640-3700, samples/xgemm_sparse/spmm_kernel.c:423-456]: BASELINE configs[3] in its three precisions
+bcsc("bcsc_bf16", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A)
+bcsc("bcsc_bf16_flat", DT.BF16, DT.BF16, DT.BF16, DT.F32, 0)
+bcsc("bcsc_bf16_f32out", DT.BF16, DT.BF16, DT.F32, DT.F32, F.VNNI_A)
+bcsc("bcsc_f32", DT.F32, DT.F32, DT.F32, DT.F32, 0)
+bcsc("bcsc_u8_i8", DT.U8, DT.I8, DT.I32, DT.I32, F.VNNI_A)
+bcsc("bcsc_i8_u8", DT.I8, DT.U8, DT.I32, DT.I32, F.VNNI_A)
+bcsc("bcsc_bf16_bn32", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A, bn=32)
+bcsc("no:bcsc_f32_vnni", DT.F32, DT.F32, DT.F32, DT.F32, F.VNNI_A)
+bcsc("no:bcsc_i8_flat", DT.U8, DT.I8, DT.I32, DT.I32, 0)
+bcsc("no:bcsc_f16", DT.F16, DT.F16, DT.F16, DT.F32, F.VNNI_A)
+bcsc("no:bcsc_trans_b", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A | F.TRANS_B)
+bcsc("no:bcsc_k_not_blocks", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A, K=250)
+bcsc("no:bcsc_n_not_blocks", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A, N=72)
+bcsc("no:bcsc_width_0", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A, pw=0)
+bcsc("no:bcsc_ldb_set", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A, ldb=64)
+print("TABLE " + json.dumps(out))
+"""
+
+
+def test_sparse_creators_accept_and_refuse_what_the_documentation_says():
+    env = dict(os.environ, LIBXSMM_HIP_DRYRUN="1", LIBXSMM_HIP_JIT="0")
+    env.pop("LIBXSMM_VERBOSE", None)
+    r = subprocess.run([sys.executable, "-c", CREATOR_CHILD % ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    table = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("TABLE ")][-1][6:])
+    wrong = {k: v for k, v in table.items() if v == k.startswith("no:")}
+    assert not wrong, f"accepted / refused against the table: {wrong}"
+    assert len(table) == 32
