@@ -210,3 +210,44 @@ def test_sparse_creators_accept_and_refuse_what_the_documentation_says():
     wrong = {k: v for k, v in table.items() if v == k.startswith("no:")}
     assert not wrong, f"accepted / refused against the table: {wrong}"
     assert len(table) == 32
+
+
+MEQN_CHILD = r"""
+import json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from libxsmm_amd import capi
+from libxsmm_amd.capi import BINARY, DT, UNARY
+import test_meqn as tm
+api = capi.load()
+out = {}
+for name, (tree, shapes, oshape) in sorted(tm.CASES.items()):
+    h = api.dispatch_meqn(tm.build(api, tree, shapes), capi.MeqnArgShape(*oshape))
+    out[name] = api.hip_kernel_name(h, 0).decode() if h else None
+# an operator whose second operand was never pushed [ref: src/libxsmm_matrixeqn.c: the tree must be complete at dispatch]
+idx = api.meqn_create()
+api.meqn_push_back_binary_op(capi.MeqnMetadata(idx, -1), BINARY.ADD, DT.F32, 0)
+api.meqn_push_back_arg(capi.MeqnMetadata(idx, 0), capi.MeqnArgShape(8, 8, 8, DT.F32), tm.SINGULAR)
+out["no:incomplete"] = bool(api.dispatch_meqn(idx, capi.MeqnArgShape(8, 8, 8, DT.F32)))
+out["no:unknown_equation"] = bool(api.dispatch_meqn(12345, capi.MeqnArgShape(8, 8, 8, DT.F32)))
+print("TABLE " + json.dumps(out))
+"""
+
+
+def test_equations_dispatch_and_fuse_as_documented():
+    """Every tree of tests/test_meqn.py dispatches without a device; with LIBXSMM_HIP_JIT=2 exactly the documented set becomes ONE generated kernel
+    (element-wise: meqn_jit_e..., with reductions to one number: meqn_jit_r...), the rest stays a chain of TPP / GEMM launches."""
+    env = dict(os.environ, LIBXSMM_HIP_DRYRUN="1", LIBXSMM_HIP_JIT="2")
+    env.pop("LIBXSMM_VERBOSE", None)
+    r = subprocess.run([sys.executable, "-c", MEQN_CHILD % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    table = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("TABLE ")][-1][6:])
+    assert table.pop("no:incomplete") is False and table.pop("no:unknown_equation") is False
+    assert all(table.values()), {k: v for k, v in table.items() if not v}
+    elementwise = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain", "layernorm_affine"}
+    phased = {"dot_to_scalar", "mul_dot_to_scalar", "softmax_fwd", "softmax_bwd", "sum_of_squares"}
+    for name, kernel in table.items():
+        expected = "meqn_jit_e" if name in elementwise else "meqn_jit_r" if name in phased else None
+        if expected:
+            assert kernel.startswith(expected), (name, kernel)
+        else:
+            assert not kernel.startswith("meqn_jit"), (name, kernel)          # vector-valued reductions, MATMUL nodes: a chain of launches
