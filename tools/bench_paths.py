@@ -144,7 +144,7 @@ def bcsc(api, m_blocks=8192, M=64, K=256, N=64, bk=32, bn=16, dtype="bf16", host
     colptr, rowidx = structured_2_of_8(K, N, bk, bn)
     nnzb = len(rowidx)
     at, bt, ct, comp, sa, sc, vn = {"bf16": (DT.BF16, DT.BF16, DT.BF16, DT.F32, 2, 2, GEMM_FLAG.VNNI_A), "f32": (DT.F32, DT.F32, DT.F32, DT.F32, 4, 4, 0),
-                                    "u8i8": (DT.U8, DT.I8, DT.I32, DT.I32, 1, 4, GEMM_FLAG.VNNI_A)}[dtype]
+                                    "u8i8": (DT.U8, DT.I8, DT.I32, DT.I32, 1, 4, GEMM_FLAG.VNNI_A), "i8u8": (DT.I8, DT.U8, DT.I32, DT.I32, 1, 4, GEMM_FLAG.VNNI_A)}[dtype]
     h = api.create_packed_spgemm_bcsc(capi.gemm_shape(m_blocks, 0, K, K, 0, N, at, bt, ct, comp), GEMM_FLAG.BETA_0 | vn, 0, capi.SpgemmConfig(M, bk, bn))
     assert h
     set_bytes = m_blocks * M * (K * sa + N * sc)
@@ -575,6 +575,8 @@ def main():
     if "bcsc" in only:
         makers += [lambda: bcsc(api), lambda: bcsc(api, host_pattern=True), lambda: bcsc(api, bk=32, bn=32), lambda: bcsc(api, dtype="f32"), lambda: bcsc(api, dtype="f32", bn=32),
                    lambda: bcsc(api, dtype="u8i8"), lambda: bcsc(api, dtype="u8i8", host_pattern=True)]
+    if "bcsc_i8u8" in only:  # signed A: the variant compiled for two waves per SIMD since round 2 (not in the default list: first measured in round 3)
+        makers += [lambda: bcsc(api, dtype="i8u8"), lambda: bcsc(api, dtype="i8u8", bn=32), lambda: bcsc(api, dtype="u8i8"), lambda: bcsc(api, dtype="u8i8", bn=32)]
     if "tpp2" in only:       # the general (one element per thread) TPP kernels
         makers += [lambda: meltw_gs(api, "gather_rows"), lambda: meltw_gs(api, "gather_offs"), lambda: meltw_gs(api, "scatter_cols"),
                    lambda: meltw_xform8(api, UNARY.TRANSFORM_NORM_TO_VNNI4, "NORM_TO_VNNI4"), lambda: meltw_big(api, UNARY.TRANSFORM_NORM_TO_VNNI2, "NORM_TO_VNNI2 bf16 (odd ld)", m=4090, in_dt=DT.BF16, out_dt=DT.BF16),
