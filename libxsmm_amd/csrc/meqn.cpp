@@ -309,6 +309,12 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
   };
   std::function<bool(int, int, std::string&, std::string&)> value;     // (node, broadcast kind, name, code of the enclosing unit loop)
   std::function<bool(int, std::string&)> elem, scalar_value;           // element-wise op node -> v<id>[8]; one-number subtree -> s<id>
+  std::function<bool(int, std::string&)> vector_value;                 // REDUCE_COLS subtree (one number per row) -> LDS array w<id>[M]
+  // Vector-valued reductions inside a tree (a sum over the columns, broadcast back along them): generated and checked on the CPU
+  // (tests/test_jit_emulated_cpu.py), OFF by default until measured on the device: LIBXSMM_HIP_MEQN_VECRED=1.
+  static const bool vecred = []() { const char* v = getenv("LIBXSMM_HIP_MEQN_VECRED"); return v && v[0] == '1'; }();
+  std::string lds_decl;
+  int n_vec = 0;
   const auto operand = [&](const EqnNode& parent, int c, std::string& name, std::string& body) -> bool { return value(parent.child[c], bcast_of(parent, c), name, body); };
   const std::string unit_loop = "  for (long long t = threadIdx.x; t < " + std::to_string(units) + "LL; t += 256) {\n  const long long j = t / " + std::to_string(M / 8) + ", i = (t - j * " + std::to_string(M / 8) + ") * 8;\n";
 
@@ -320,6 +326,13 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
         if (bc != 3 || !scalar_value(id, s)) return false;
         name = "b" + std::to_string(id);
         body += "  float " + name + "[8]; _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + name + "[e] = " + s + ";\n";
+        return true;
+      }
+      if (bc == 2 && vecred && ch.m == M && ch.n == 1 && N > 1) {     // one number per row from an earlier phase, broadcast along the columns
+        std::string w;
+        if (!vector_value(id, w)) return false;
+        name = "b" + std::to_string(id);
+        body += "  float " + name + "[8]; _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + name + "[e] = " + w + "[i + e];\n";
         return true;
       }
       if (bc != 0 || ch.m != M || ch.n != N || !elem(id, body)) return false;
@@ -425,6 +438,38 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
     return true;
   };
 
+  // REDUCE_COLS of an element-wise M x N operand (ADD, X2-ADD, MAX, MIN): thread r owns the 8-row blocks r, r + 256, ... and walks the columns in
+  // ascending order -- the reference's order [ref: mateltwise ref :1065-1130], so a plain sum is the same chain of additions -- then parks its
+  // 8 results in LDS; one barrier makes them visible to the phases that broadcast them.
+  vector_value = [&](int id, std::string& name) -> bool {
+    const EqnNode& nd = e.nodes[id];
+    name = "w" + std::to_string(id);
+    if (nd.kind != EQ_UNARY || nd.dtype != LIBXSMM_DATATYPE_F32 || nd.m != M || nd.n != 1 || nd.flags != LIBXSMM_MELTW_FLAG_UNARY_REDUCE_COLS) return false;
+    int fold = 0; bool sq = false;
+    switch (nd.op) {
+      case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD: break;
+      case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD: sq = true; break;
+      case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX: fold = 1; break;
+      case LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN: fold = 2; break;
+      default: return false;
+    }
+    const EqnNode& srcn = e.nodes[nd.child[0]];
+    if (srcn.m != M || srcn.n != N || M > 2048 || n_vec >= 4) return false;
+    std::string body, x;
+    const size_t dumps_before = plan.fused_dumps.size();
+    if (!value(nd.child[0], 0, x, body)) return false;
+    if (plan.fused_dumps.size() != dumps_before) return false;      // a DUMP image written here would be read back by another thread later
+    ++n_vec;
+    lds_decl += "  __shared__ float " + name + "[" + std::to_string(M) + "];\n";
+    const char* init = fold == 1 ? "-3.402823466e+38f" : fold == 2 ? "3.402823466e+38f" : "0.0f";
+    const std::string step = fold == 1 ? "acc[e] = (acc[e] < " + x + "[e]) ? " + x + "[e] : acc[e];" : fold == 2 ? "acc[e] = (acc[e] > " + x + "[e]) ? " + x + "[e] : acc[e];"
+                           : sq ? "{ const float sq = " + x + "[e] * " + x + "[e]; acc[e] = acc[e] + sq; }" : "acc[e] = acc[e] + " + x + "[e];";
+    phases += "  for (long long ib = threadIdx.x; ib < " + std::to_string(M / 8) + "LL; ib += 256) {\n  const long long i = ib * 8;\n  float acc[8]; _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) acc[e] = " + init + ";\n"
+              "  for (long long j = 0; j < " + std::to_string(N) + "LL; ++j) {\n" + body + "  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + step + "\n  }\n"
+              "  _Pragma(\"unroll\") for (int e = 0; e < 8; ++e) " + name + "[i + e] = acc[e];\n  }\n  __syncthreads();\n";
+    return true;
+  };
+
   std::string body, head;
   if (scalar_root) { if (M == 1 && N == 1) return false; if (!scalar_value(0, head)) return false; }
   else if (!elem(0, body)) return false;
@@ -442,7 +487,7 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
   src += ") {\n";
   const std::string store = std::string("  ") + (out.type == LIBXSMM_DATATYPE_F32 ? "st_f32((GM float*)" : "st_bf16((GM unsigned short*)") + "out + i + j * " + std::to_string((int)out.ld) + "LL, v0);\n";
   if (phased) {
-    src += "  __shared__ float part[256];\n" + phases;
+    src += "  __shared__ float part[256];\n" + lds_decl + phases;
     if (scalar_root) src += out.type == LIBXSMM_DATATYPE_F32 ? "  if (threadIdx.x == 0) *(GM float*)out = " + head + ";\n}\n"
                                                              : "  if (threadIdx.x == 0) *(GM unsigned short*)out = (unsigned short)(f2bf_pk(" + head + ", 0.0f) & 0xffffu);\n}\n";
     else src += unit_loop + body + store + "  }\n}\n";

@@ -10,3 +10,5 @@ for v in 1 2 4; do
   LIBXSMM_HIP_JIT_VEC=$v timeout 300 python tools/bench_paths.py --only csr,fsspmdm --steps 50 > gpurun_out/sweep_csr_vec$v.jsonl 2> gpurun_out/sweep_csr_vec$v.err
   echo "csr vec=$v rc=$?"; cat gpurun_out/sweep_csr_vec$v.jsonl
 done
+# 4. vector-valued reductions inside generated equation kernels (generated and CPU-checked in round 2, off by default): the equation tests with the switch on
+LIBXSMM_HIP_MEQN_VECRED=1 timeout 600 python -m pytest tests/test_meqn.py -m gpu -q -p no:cacheprovider -k "reduce_bcast" > gpurun_out/sweep_vecred.log 2>&1; echo "vecred rc=$?"; tail -5 gpurun_out/sweep_vecred.log
