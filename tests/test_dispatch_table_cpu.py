@@ -197,6 +197,13 @@ bcsc("no:bcsc_k_not_blocks", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A, K=250)
 bcsc("no:bcsc_n_not_blocks", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A, N=72)
 bcsc("no:bcsc_width_0", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A, pw=0)
 bcsc("no:bcsc_ldb_set", DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A, ldb=64)
+# a handle created without a device cannot compute anything: calling it is a loud error and leaves C alone (no CPU path)
+shape = capi.gemm_shape(4, 4, 4, 0, 4, 4, DT.F32, DT.F32, DT.F32, DT.F32)
+h = api.create_packed_spgemm_csr(shape, 0, 0, P, rowptr.ctypes.data, colidx.ctypes.data, v32.ctypes.data)
+B, Cm = np.ones(4 * 4 * P, dtype=np.float32), np.zeros(4 * 4 * P, dtype=np.float32)
+p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = v32.ctypes.data, B.ctypes.data, Cm.ctypes.data
+capi.Api.call(h, p)
+print("CALL " + json.dumps({"error": int(api.hip_get_last_error()), "c_sum": float(Cm.sum())}))
 print("TABLE " + json.dumps(out))
 """
 
@@ -210,6 +217,8 @@ def test_sparse_creators_accept_and_refuse_what_the_documentation_says():
     wrong = {k: v for k, v in table.items() if v == k.startswith("no:")}
     assert not wrong, f"accepted / refused against the table: {wrong}"
     assert len(table) == 32
+    call = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("CALL ")][-1][5:])
+    assert call["error"] != 0 and call["c_sum"] == 0.0 and "no HIP device: kernel not launched" in r.stderr
 
 
 MEQN_CHILD = r"""
