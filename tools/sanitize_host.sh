@@ -2,7 +2,7 @@
 # Host code of libxsmm_amd.so under AddressSanitizer + UBSan, no GPU needed: builds an instrumented copy of the library under /tmp
 # (device code is left alone: -fno-gpu-sanitize), swaps it in for the duration of the CPU test-suite and of examples/registry_check.c in
 # dry-run mode (capacity, exhaustion, hit path, init / finalize cycles; with leak detection), and restores the real library afterwards.
-# Round 2: 720 CPU tests and the registry program ran without a report (the few CPU tests that start children with a cleaned environment or
+# Round 2: 766 CPU tests (incl. the dry-run code generators) and the registry program ran without a report (the few CPU tests that start children with a cleaned environment or
 # link a C program with gcc cannot preload the sanitizer runtime and are not counted); the threaded dispatch check under ThreadSanitizer: clean.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -27,13 +27,14 @@ ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:log_path=$OUT/asan UBSAN_OPTIONS=pri
 
 gcc -std=c99 -D_POSIX_C_SOURCE=200809L -O1 -g -I"$ROOT/include" "$ROOT/examples/registry_check.c" -L"$OUT/lib" -lxsmm_amd -Wl,-rpath,"$OUT/lib" \
   -Wl,--allow-shlib-undefined -o "$OUT/registry_check" || exit 1
-export ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:log_path=$OUT/asan UBSAN_OPTIONS=print_stacktrace=1:log_path=$OUT/ubsan LD_PRELOAD=$RT LIBXSMM_HIP_DRYRUN=1
-"$OUT/registry_check" capacity 136072 131072 | tail -1
-"$OUT/registry_check" hit 200000 | tail -1
-"$OUT/registry_check" cycle | tail -1
-"$OUT/registry_check" info | tail -1
-LIBXSMM_HIP_MAX_HANDLES=500 "$OUT/registry_check" capacity 700 500 | tail -1
-LIBXSMM_HIP_THUNKS=0 "$OUT/registry_check" capacity 300 256 | tail -1
+export ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:log_path=$OUT/asan UBSAN_OPTIONS=print_stacktrace=1:log_path=$OUT/ubsan LIBXSMM_HIP_DRYRUN=1
+run() { env LD_PRELOAD=$RT "$@" | tail -1; }          # the preload (and its leak check) for the program only, not for the pipeline's tail
+run "$OUT/registry_check" capacity 136072 131072
+run "$OUT/registry_check" hit 200000
+run "$OUT/registry_check" cycle
+run "$OUT/registry_check" info
+LIBXSMM_HIP_MAX_HANDLES=500 run "$OUT/registry_check" capacity 700 500
+LIBXSMM_HIP_THUNKS=0 run "$OUT/registry_check" capacity 300 256
 unset LD_PRELOAD
 
 # the registry's miss path (lock), hit path (thread cache) and thunk pool under ThreadSanitizer: eight threads, the same descriptors
