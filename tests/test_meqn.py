@@ -191,6 +191,8 @@ BY_NORM = {"tanh_sigmoid_chain": 1e-6, "matmul_mul": 1e-6, "matmul_vnni_bf16": 8
 # reductions only where they end in ONE number (a phase of the one-workgroup kernel); vector-valued reductions inside a tree stay a chain
 FUSABLE = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain", "layernorm_affine", "dot_to_scalar", "mul_dot_to_scalar",
            "softmax_fwd", "softmax_bwd", "sum_of_squares"}
+if __import__("os").environ.get("LIBXSMM_HIP_MEQN_VECRED") == "1":      # the switch of the vector-valued reduction phases (off by default, tools/sweep_next.sh)
+    FUSABLE = FUSABLE | {"reduce_bcast"}
 
 
 @pytest.mark.gpu
