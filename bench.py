@@ -5,7 +5,11 @@ Headline (the `value`): BASELINE.json configs[1] -- strided BRGEMM, fp32, m=n=k=
 (A_i, B_i, C_i) problems launched through ONE libxsmm_dispatch_brgemm(STRIDE) handle with
 libxsmm_hip_gemm_batch_strided.  One "step" = one such launch over one batch.
 
-What the one JSON line carries (all measured in this process, on this GPU):
+Output contract: the LAST stdout line is one compact JSON object (< 3 KB: the driver keeps an 8 KB tail) with the headline, its roofline,
+the CPU baseline and one or two numbers per secondary workload; the full record of the run (every kernel name, time, verification norm,
+CPU sample description) goes to bench_detail.json next to this file and to stderr BEFORE that line.
+
+What the record carries (all measured in this process, on this GPU):
   * value / ms_per_step: the timed region is a hipGraph of back-to-back launches (a multiple of --steps), replayed until
     it lasts >= --min-seconds (0.5 s): `steps` echoes the flag, `steps_timed` is what was really timed.  Inputs are
     resident in HBM and ROTATE over enough distinct sets (> 2x the 256 MiB Infinity Cache) that every step streams from HBM.
@@ -17,6 +21,9 @@ What the one JSON line carries (all measured in this process, on this GPU):
     (2-D batch, chain br = K/m, operands cache-resident): the only regime in which a percentage of MFMA peak is the binding roofline.
   * mfma_busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMDs) per workload from the committed PMC pass (profiles/), null if none.
   * cpu_baseline: the reference's own JIT kernel (oracle/_ref, kind "reference") or the C restatement (kind "port") on this box's host cores.
+  * configs: BASELINE configs #3 (packed CSR A-sparse 35x35 @15 % and @10 %, FsSpMDM), #4 (bf16 BCSC 2:8) and #5 (bf16 64^3 + bias + ReLU, one
+    GPU's shard of 2^17 problems), each as [fraction of the HBM roofline, GFLOP/s of the reference's CPU kernel on one host core], every GPU
+    result checked against the oracle; variantB: config #2 as ONE BRGEMM with br = 4096.
 
 N > 1 (launched by torch.distributed.run): one process per GPU, every rank owns its own batch (weak scaling, no data-path
 collective); time = max over ranks between two barriers; value = total flops / time.
@@ -68,6 +75,8 @@ def parse():
     ap.add_argument("--manifest", default="", help="write the execution order of the launches (label, kernel, counts) to this JSON file")
     ap.add_argument("--only", default="", help="measure only this sweep/reuse entry (profiling passes), e.g. reuse:f32_m32_blocked")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs #3 / #4 / #5 legs")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), help="where the full record goes (the stdout line is the compact one)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the all-core CPU leg (-1: one per usable core, 0/1: skip)")
     return ap.parse_args()
@@ -429,6 +438,95 @@ SHARED_B = [(dt, m, 65536) for dt in ("f32", "bf16") for m in (16, 32, 64)]
 RAGGED = [("f32", 23, 131072), ("f32", 23, 4096), ("f32", 13, 262144), ("f32", 40, 32768), ("f32", 72, 16384)]
 
 
+def run_configs(api, dev, steps, min_seconds, cpu_seconds, with_cpu):
+    """BASELINE configs #3, #4, #5 (one GPU) and config #2's variant B, measured like the headline (hipGraph replays, HIP events on the launch
+    stream, inputs rotated past the Infinity Cache), every result checked against the oracle, the reference's CPU kernel timed beside each."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import workloads as wl
+    wl.set_device(dev)
+    cs = max(1.0, min(3.0, cpu_seconds))
+    specs = [
+        ("c3_csr15", lambda: wl.csr_asparse(api, 65536, 0.15), lambda: wl.cpu_csr(1024, 0.15, cs)),
+        ("c3_csr10", lambda: wl.csr_asparse(api, 65536, 0.10), lambda: wl.cpu_csr(1024, 0.10, cs)),
+        ("c3_fsspmdm", lambda: wl.fsspmdm(api, 2 ** 20, 0.15), lambda: wl.cpu_fsspmdm(49152, 0.15, cs)),
+        ("c4_bcsc_bf16", lambda: wl.bcsc(api, host_pattern=True), lambda: wl.cpu_bcsc(seconds=cs)),
+        ("c5_fused", lambda: Workload(api, dev, "bf16", 64, 2 ** 17, fused=1), lambda: wl.cpu_fused(seconds=cs)),
+        ("variantB_f32_m32_br4096", lambda: Workload(api, dev, "f32", 32, 1, br=4096, nsets=18), None),
+    ]
+    out = {}
+    for label, make, cpu in specs:
+        try:
+            w = make()
+            for i in range(3):
+                w.step(i)
+            torch.cuda.synchronize(); api.check()
+            _, n, us = timed(w, steps, min_seconds, label=label)
+            api.check()
+            gbs = w.alg_bytes_per_step / (us * 1e-6) / 1e9
+            r = {"workload": getattr(w, "name", None) or w.label(), "kernel": w.kernel(), "us_per_launch": round(us, 3), "GFLOP/s": round(w.flops_per_step / us / 1e3, 1),
+                 "GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(w.alg_bytes_per_step), "launches_timed": n,
+                 "input_sets_rotated": w.nsets}
+            if hasattr(w, "dense_equiv_flops"):
+                r["dense_equiv_GFLOP/s"] = round(w.dense_equiv_flops / us / 1e3, 1)
+            v = w.verify() if hasattr(w, "verify") else None
+            if v is not None:
+                r["verified"] = bool(v[0]); r["normf_rel"] = float(f"{v[1]:.3g}")
+            if cpu is not None and with_cpu:
+                try:
+                    from oracle import pyoracle
+                    r["cpu_baseline"] = cpu() if pyoracle.have_reference() else None
+                except Exception as e:          # the CPU leg must never take the GPU measurement down
+                    r["cpu_baseline"] = {"error": repr(e)}
+            out[label] = r
+            del w
+        except Exception as e:                  # a workload that cannot be built or run is reported, not hidden
+            out[label] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    return out
+
+
+def compact_line(full, detail_path):
+    """The driver keeps an 8 KB tail of stdout: the line it parses carries the contract fields and ONE OR TWO numbers per secondary workload
+    ([frac of HBM roofline, % of MFMA peak] for sweep / reuse / ragged, [frac, CPU GFLOP/s on one core] for the BASELINE configs)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "steps_timed", "warmup", "ms_per_step", "timed_region_s", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "verified", "pct_mfma_peak", "rccl_ranks", "gather_ms", "gather_GBs_into_root")
+    line = {k: full[k] for k in keep if k in full}
+    cfg = full.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "kernel", "per_gpu_batch", "problems_per_gpu_rank0", "input_sets_rotated", "streaming_hint", "parallelism") if k in cfg}
+    rf = full.get("roofline")
+    if rf:
+        line["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_us", "algorithmic_bytes_per_launch")}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:110]
+        if "all_cores" in cb:
+            line["cpu_baseline"]["all_cores"] = {"value": cb["all_cores"]["value"], "cores": cb["all_cores"]["cores"]}
+    if full.get("configs"):
+        line["configs"] = {}
+        ok = True
+        for k, r in full["configs"].items():
+            if "error" in r:
+                line["configs"][k] = None; ok = False
+                continue
+            cpu = r.get("cpu_baseline") or {}
+            line["configs"][k] = [r["frac_hbm"], cpu.get("value")]
+            ok = ok and r.get("verified", True)
+        line["configs_verified"] = bool(ok)
+        line["configs_fields"] = "[frac_hbm, cpu_GFLOPs_1core]"
+    for grp in ("sweep", "reuse", "ragged"):
+        if full.get(grp):
+            line[grp] = {k: [round(r["frac_hbm"], 3), round(r["pct_mfma_peak"], 1)] for k, r in full[grp].items()}
+    if any(full.get(g) for g in ("sweep", "reuse", "ragged")):
+        line["sweep_fields"] = "[frac_hbm, pct_mfma_peak]"
+        line["sweep_verified"] = all(r.get("verified", True) for g in ("sweep", "reuse", "ragged") for r in (full.get(g) or {}).values())
+    for k in ("pipelined", "l3_resident_us", "without_streaming_hint_us"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    return line
+
+
 def run_config5(args, api, dev, rank, world, dist, barrier):
     """BASELINE configs[4]: 2^20 bf16 64^3 BRGEMMs with fused column-bias + ReLU, problems split by batch index."""
     b, e = C.c_size_t(0), C.c_size_t(0)
@@ -507,9 +605,9 @@ def main():
 
     if args.config == 5:
         out = run_config5(args, api, dev, rank, world, dist, barrier)
-        if rank == 0 and not args.no_cpu_baseline:
+        if rank == 0 and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(64, "bf16", 1, 0, 1, args.cpu_seconds, nthreads)
-        finish(dist, out if rank == 0 else None)
+        finish(dist, out if rank == 0 else None, args.detail)
         return
 
     only = args.only
@@ -567,7 +665,7 @@ def main():
         del l3
 
     sweep, reuse, ragged = {}, {}, {}
-    if rank == 0 and not args.no_sweep:
+    if rank == 0 and world == 1 and not args.no_sweep:
         quick = min(args.min_seconds, 0.15)
         for dt, m, b in RAGGED:
             w = Workload(api, dev, dt, m, b)
@@ -587,11 +685,17 @@ def main():
             r["gemm"] = f"{ni * m}x{nj * m}x{br * m} as {ni}x{nj} tiles of {m}^3, br={br}"
             reuse[w.label()] = r
             del w; torch.cuda.empty_cache()
+    configs = {}
+    if rank == 0 and world == 1 and not args.no_sweep and not args.no_configs:
+        configs = run_configs(api, dev, args.steps, min(args.min_seconds, 0.15), args.cpu_seconds, not args.no_cpu_baseline)
     if dist is not None:
         dist.barrier()
 
     if rank == 0:
         traffic, traffic_src, busy, busy_src = committed_counters(headline_kernel, work.alg_bytes_per_step, work.label())
+        if traffic is None:
+            print(f"bench.py: WARNING: no committed PMC pass (profiles/r*_pmc_traffic.json) matches kernel {headline_kernel!r} with "
+                  f"{int(work.alg_bytes_per_step)} algorithmic bytes per launch: roofline.traffic is null (re-run tools/profile_paths.sh)", file=sys.stderr)
         value = work.flops_per_step * n_timed * world / elapsed / 1e9
         gbs = work.alg_bytes_per_step / (kernel_us * 1e-6) / 1e9
         peak_tf = MFMA_PEAK_TF[args.dtype]
@@ -616,18 +720,24 @@ def main():
                                                                      "note": "same rotation, libxsmm_hip_set_streaming_hint(0): cacheable operand loads (what a caller whose 48 MiB working set may be cache resident gets)"},
             "mfma_busy": busy, "mfma_busy_source": busy_src,
         }
+        if l3_us is not None:
+            out["l3_resident_us"] = round(l3_us, 3)
+        if auto_us is not None:
+            out["without_streaming_hint_us"] = round(auto_us, 3)
+        if configs:
+            out["configs"] = configs
         if sweep:
             out["sweep"] = sweep
             out["reuse"] = reuse
             out["ragged"] = ragged
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.m, args.dtype, args.br, args.beta, args.fused, args.cpu_seconds, nthreads)
         if args.manifest:
             json.dump({"command": " ".join(sys.argv), "entries": MANIFEST}, open(args.manifest, "w"), indent=1)
-    finish(dist, out if rank == 0 else None)
+    finish(dist, out if rank == 0 else None, args.detail)
 
 
-def finish(dist, out):
+def finish(dist, out, detail_path=None):
     """Tear the process group down FIRST, then print the one JSON line as the last thing this process writes to stdout: RCCL announces itself
     on stdout through C stdio ("Librccl path : ..."), whose buffer would otherwise be flushed after Python's at exit and push that text behind
     the JSON line."""
@@ -643,7 +753,15 @@ def finish(dist, out):
         dist.destroy_process_group()
         flush_all()
     if out is not None:
-        sys.stdout.write(json.dumps(out) + "\n")
+        # the full record first (file + stderr), then the compact line as the LAST thing on stdout
+        if detail_path:
+            try:
+                with open(detail_path, "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError as e:
+                print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+        sys.stderr.write("bench.py full record: " + json.dumps(out) + "\n"); sys.stderr.flush()
+        sys.stdout.write(json.dumps(compact_line(out, detail_path), separators=(",", ":")) + "\n")
         sys.stdout.flush()
     if dist is not None:
         os._exit(0)                             # no exit handler (of the collective library, ...) writes behind the line, on any rank

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 
 using namespace xamd;
@@ -152,13 +153,21 @@ LIBXSMM_API int libxsmm_hip_mtx_read(const char* path, int by_column, libxsmm_da
   *ptr = *idx = nullptr; *values = nullptr; *rows = *cols = *nnz = 0;
   FILE* f = std::fopen(path, "r");
   if (!f) return EXIT_FAILURE;
+  // nothing may leave through the extern "C" boundary: a header that claims an absurd entry count ends in bad_alloc / length_error otherwise
+  try {
+  long fsize = 0;
+  if (std::fseek(f, 0, SEEK_END) == 0) { fsize = std::ftell(f); std::rewind(f); }
   char line[512];
   unsigned int r = 0, c = 0, n = 0; bool header = false;
   std::vector<unsigned int> er, ec; std::vector<double> ev;
   while (std::fgets(line, sizeof(line), f)) {
+    const size_t len = std::strlen(line);
+    if (len + 1 == sizeof(line) && line[len - 1] != '\n') { std::fclose(f); return EXIT_FAILURE; }      // a longer line would be split and parsed as two entries
     if (line[0] == '%' || line[0] == '\n') continue;
     if (!header) {
       if (std::sscanf(line, "%u %u %u", &r, &c, &n) != 3 || r == 0 || c == 0) { std::fclose(f); return EXIT_FAILURE; }
+      // an entry is at least "i j\n" = 4 bytes: a count the file cannot hold is a broken header, not a reason to reserve gigabytes
+      if (fsize > 0 && (unsigned long long)n > (unsigned long long)fsize / 4ull) { std::fclose(f); return EXIT_FAILURE; }
       header = true; er.reserve(n); ec.reserve(n); ev.reserve(n);
       continue;
     }
@@ -167,11 +176,12 @@ LIBXSMM_API int libxsmm_hip_mtx_read(const char* path, int by_column, libxsmm_da
     if (got < 2 || i == 0 || j == 0 || i > r || j > c) { std::fclose(f); return EXIT_FAILURE; }     // pattern files carry no value: 1.0
     er.push_back(i - 1); ec.push_back(j - 1); ev.push_back(got == 3 ? v : 1.0);
   }
-  std::fclose(f);
+  std::fclose(f); f = nullptr;
   if (!header || er.size() != n) return EXIT_FAILURE;
   const unsigned int outer = by_column ? c : r;
   const std::vector<unsigned int>& ko = by_column ? ec : er; const std::vector<unsigned int>& ki = by_column ? er : ec;
   const size_t es = value_type == LIBXSMM_DATATYPE_F32 ? 4 : 8;
+  std::vector<unsigned int> pos((size_t)outer), order(n);       // everything that may throw comes before the C allocations
   unsigned int* p = (unsigned int*)libxsmm_aligned_malloc(sizeof(unsigned int) * ((size_t)outer + 1), 64);
   unsigned int* x = (unsigned int*)libxsmm_aligned_malloc(sizeof(unsigned int) * std::max<size_t>(n, 1), 64);
   void* v = libxsmm_aligned_malloc(es * std::max<size_t>(n, 1), 64);
@@ -179,8 +189,7 @@ LIBXSMM_API int libxsmm_hip_mtx_read(const char* path, int by_column, libxsmm_da
   std::fill(p, p + outer + 1, 0u);
   for (unsigned int z = 0; z < n; ++z) ++p[ko[z] + 1];
   for (unsigned int o = 0; o < outer; ++o) p[o + 1] += p[o];
-  std::vector<unsigned int> pos(p, p + outer);
-  std::vector<unsigned int> order(n);
+  std::copy(p, p + outer, pos.begin());
   for (unsigned int z = 0; z < n; ++z) order[pos[ko[z]]++] = z;            // stable counting sort by the outer index ...
   for (unsigned int o = 0; o < outer; ++o)                                  // ... then by the inner index inside every row / column
     std::sort(order.begin() + p[o], order.begin() + p[o + 1], [&](unsigned int a, unsigned int b) { return ki[a] < ki[b]; });
@@ -190,6 +199,10 @@ LIBXSMM_API int libxsmm_hip_mtx_read(const char* path, int by_column, libxsmm_da
   }
   *ptr = p; *idx = x; *values = v; *rows = r; *cols = c; *nnz = n;
   return EXIT_SUCCESS;
+  } catch (...) {
+    if (f) std::fclose(f);
+    return EXIT_FAILURE;
+  }
 }
 
 // Dense K x N operand in the reference driver's layout (column n = K contiguous values: B[n*K + k]) -> BCSC with bk x bn blocks: blocks that are

@@ -202,6 +202,7 @@ bool rt_ready();
 const void* rt_small_host_input(const void* p, size_t nbytes);   // tiny operands (scalars) may live in host memory: staged if they do
 void* rt_small_host_output(void* p, size_t nbytes);              // ... and so may a 1 x 1 result: staged and copied back when the call is synchronous
 void rt_scratch_reset();
+void rt_nest(int delta);     // +1 / -1 around a kernel handle invoked from inside another invocation (equation GEMM nodes)
 void rt_note(const char* what, int a, int b, int c);      // verbosity >= 1: why a request was refused
 void* rt_stream();
 

@@ -943,9 +943,12 @@ __global__ __launch_bounds__(256) void dropout_kernel(MeltwArgs p, const u32x4m*
   const unsigned long long g0 = seg * L;
   if (g0 >= total) return;
   const unsigned long long g1 = (g0 + L < total) ? g0 + L : total;
+  // read from the launch's snapshot of the state (p.ws, copied in stream order before the launch), written back to the caller's buffer:
+  // no workgroup can observe the state the stream's last segment has already advanced
   GM unsigned int* st = (GM unsigned int*)p.aux_in;
+  GM const unsigned int* st_in = (GM const unsigned int*)p.ws;
   GM const u32x4m* jump = (GM const u32x4m*)jump_tables;
-  u32x4m s = {st[l], st[l + 16], st[l + 32], st[l + 48]};
+  u32x4m s = {st_in[l], st_in[l + 16], st_in[l + 32], st_in[l + 48]};
   for (int k = 0; k < 64 && (g0 >> k) != 0ull; ++k) {              // s = T^g0 s
     if (!((g0 >> k) & 1ull)) continue;
     GM const u32x4m* col = jump + 128 * k;
@@ -1012,9 +1015,12 @@ __global__ __launch_bounds__(256) void stochastic_bf8_kernel(MeltwArgs p, const 
   const unsigned long long d0 = seg * L;
   if (d0 >= total) return;
   const unsigned long long d1 = (d0 + L < total) ? d0 + L : total;
+  // the state is READ from the launch's snapshot (p.ws, copied in stream order before the launch) and WRITTEN to the caller's buffer: a
+  // workgroup that starts late can never load what the segment ending the stream has already advanced
   GM unsigned int* st = (GM unsigned int*)p.aux_in;
+  GM const unsigned int* st_in = (GM const unsigned int*)p.ws;
   GM const u32x4m* jump = (GM const u32x4m*)jump_tables;
-  u32x4m s = {st[l], st[l + 16], st[l + 32], st[l + 48]};
+  u32x4m s = {st_in[l], st_in[l + 16], st_in[l + 32], st_in[l + 48]};
   for (int k = 0; k < 64 && (d0 >> k) != 0ull; ++k) {
     if (!((d0 >> k) & 1ull)) continue;
     GM const u32x4m* col = jump + 128 * k;
@@ -1432,6 +1438,8 @@ int launch_stochastic_bf8(const MeltwArgs& a, void* stream) {
   if (segs == 0) segs = 1;
   const unsigned long long L = (per_stream + segs - 1ull) / segs;
   segs = (per_stream + L - 1ull) / L;
+  if (!a.ws || a.ws_bytes < 256) return (int)hipErrorInvalidValue;
+  if (hipMemcpyAsync(a.ws, a.aux_in, 256, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
   hipLaunchKernelGGL(stochastic_bf8_kernel, dim3((unsigned int)((segs * 16ull + 255ull) / 256ull)), dim3(256), 0, (hipStream_t)stream, a, jt, L);
   return (int)hipGetLastError();
 }
@@ -1471,6 +1479,8 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
     if (segs == 0) segs = 1;
     const unsigned long long L = (total + segs - 1ull) / segs;
     segs = (total + L - 1ull) / L;
+    if (!a.ws || a.ws_bytes < 256) return (int)hipErrorInvalidValue;
+    if (hipMemcpyAsync(a.ws, a.aux_in, 256, hipMemcpyDeviceToDevice, st) != hipSuccess) return (int)hipGetLastError();      // the kernel reads the snapshot, writes aux_in
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned int)((segs * 16ull + 255ull) / 256ull)), dim3(256), 0, st, a, jt, L);
     if (name) *name = "dropout_kernel";
     return (int)hipGetLastError();

@@ -572,7 +572,9 @@ void run_meqn(EqnPlan* plan, const void* param) {
         blocks = *(const unsigned long long*)p->ops_args[st.br_from_op].tertiary; gp.op.tertiary = &blocks;
       }
       rt_workspace_reserve(plan->slot_bytes * (size_t)plan->nslots);     // the kernel's own partial-sum workspace goes behind the slots
+      rt_nest(+1);          // keeps this call's staged scalars / pending copy-backs alive and defers the sync to the end of the chain
       ((libxsmm_gemmfunction)st.gemm)(&gp);
+      rt_nest(-1);
       rt_workspace_reserve(0);
       kname = nullptr;
       continue;

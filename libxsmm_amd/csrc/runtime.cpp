@@ -148,11 +148,14 @@ bool hip_ok(hipError_t e, const char* what) {
 hipStream_t cur_stream() { return (hipStream_t)tls().stream; }
 
 void copy_back_staged();
+// > 0 while a kernel handle is invoked from inside another invocation (a MATMUL / BRGEMM node of a matrix equation): the nested call must
+// neither rewind the caller's staging scratch (its staged operands and pending copy-backs live there) nor synchronise / copy back early
+thread_local int t_nest = 0;
 void finish_launch(int err, const char* kname) {
   ThreadState& t = tls();
   ++t.launches;
   if (err != 0) { set_error(err, "launch of %s failed: %s", kname ? kname : "?", hipGetErrorString((hipError_t)err)); return; }
-  if (!t.async) {
+  if (!t.async && t_nest == 0) {
     hipError_t e = hipStreamSynchronize(cur_stream());
     if (e != hipSuccess) set_error((int)e, "kernel %s faulted: %s", kname ? kname : "?", hipGetErrorString(e));
     copy_back_staged();
@@ -212,7 +215,7 @@ const void* device_visible(const void* p, size_t nbytes) { return stage(p, nbyte
 static bool staging_allowed(size_t batch_count) { return !tls().async && batch_count <= 1; }
 static const void* host_input(const void* p, size_t nbytes, size_t batch_count) { return staging_allowed(batch_count) ? stage(p, nbytes, true, false) : p; }
 static void* host_inout(void* p, size_t nbytes, size_t batch_count) { return staging_allowed(batch_count) ? stage(p, nbytes, true, true) : p; }
-void scratch_reset() { t_scratch.used = 0; t_copyback.clear(); }
+void scratch_reset() { if (t_nest > 0) return; t_scratch.used = 0; t_copyback.clear(); }
 void copy_back_staged() {
   for (const CopyBack& c : t_copyback)
     (void)hip_ok(c.height == 1 ? hipMemcpy(c.host, c.dev, c.width, hipMemcpyDeviceToHost) : hipMemcpy2D(c.host, c.pitch, c.dev, c.pitch, c.width, c.height, hipMemcpyDeviceToHost),
@@ -237,11 +240,16 @@ void* workspace(size_t nbytes_wanted) {
 }   // stream order protects data of the previous call
 
 int alloc_slot_locked() {
-  int slot = -1;
-  if (!g_free_slots.empty()) { slot = g_free_slots.back(); g_free_slots.pop_back(); }
-  else if (g_next_slot < std::min(g_slot_limit, g_thunk_pool ? kSlots : kStaticSlots)) slot = g_next_slot++;
-  if (slot >= 0 && !thunk_ready_locked(slot)) { g_free_slots.push_back(slot); return -1; }
-  return slot;
+  // A slot whose thunk page cannot be made executable is PARKED (never returned to the free list: every later allocation would pop it
+  // again and fail although other pages work); the search goes on with the next slot.
+  for (;;) {
+    int slot = -1;
+    if (!g_free_slots.empty()) { slot = g_free_slots.back(); g_free_slots.pop_back(); }
+    else if (g_next_slot < std::min(g_slot_limit, g_thunk_pool ? kSlots : kStaticSlots)) slot = g_next_slot++;
+    if (slot < 0) return -1;
+    if (thunk_ready_locked(slot)) return slot;
+    vlog(1, "thunk page of handle slot %d cannot be made executable: slot parked", slot);
+  }
 }
 
 KernelCtx* new_ctx_locked(Kind kind) {
@@ -574,6 +582,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
       pa.c = (char*)ws; pa.ldc = a.m; pa.c_type = LIBXSMM_DATATYPE_F32; pa.vnni_c = 0;
       pa.flags = (a.flags | LIBXSMM_GEMM_FLAG_BETA_0) & ~(unsigned int)LIBXSMM_GEMM_FLAG_VNNI_C;
       pa.d = nullptr; pa.relu_mask = nullptr; pa.colbias = 0; pa.act = 0;
+      pa.batch_inner = 0; pa.bs_c2 = 0; pa.bs_mask2 = 0;      // the partial products are a plain 1-D batch whatever the caller's (1 x 1) batch form was
       pa.br_count = chunk; pa.nbatch = (unsigned int)nfull;
       pa.bs_a = (long long)chunk * a.br_stride_a; pa.bs_b = (long long)chunk * a.br_stride_b; pa.bs_c = (long long)tile_bytes; pa.bs_d = 0; pa.bs_mask = 0;
       int err = launch_gemm(pa, tls().stream, &kname);
@@ -651,6 +660,8 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
         if (bitm && !p->out.secondary) { set_error(-2, "DROPOUT with BITMASK_2BYTEMULT needs the mask destination in out.secondary"); return; }
         a.aux_in = staging_allowed(b.count) ? stage(p->op.secondary, 256, true, true) : p->op.secondary;
         if (!a.aux_in) return;
+        a.ws_bytes = 256; a.ws = workspace(a.ws_bytes);      // read-only snapshot of the state for the launch (see dropout_kernel)
+        if (!a.ws) return;
       } else if (!p->in.secondary) { set_error(-2, "DROPOUT_INV needs the mask in in.secondary"); return; }
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_ADD || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MAX || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_COLS_IDX_OP_MIN) {
       // the number of listed columns is a host scalar behind in.tertiary, the list itself sits behind in.secondary [ref: mateltwise ref :1121-1138, :1076]
@@ -752,11 +763,12 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     if (!state) { set_error(-2, "a TPP with STOCHASTIC_ROUND needs the generator state in op.secondary"); return; }
     MeltwArgs second = a;
     const size_t tile = (size_t)a.m * (size_t)a.n * sizeof(float);
-    float* ws = (float*)workspace(tile * (size_t)a.nbatch);
+    const size_t img = ((tile * (size_t)a.nbatch) + 255) & ~(size_t)255;
+    float* ws = (float*)workspace(img + 256);             // + a read-only snapshot of the generator state (see launch_stochastic_bf8)
     if (!ws) return;
     a.out = (char*)ws; a.out_type = LIBXSMM_DATATYPE_F32; a.ldo = a.m; a.bs_out = (long long)tile;
     int err = launch_meltw(a, tls().stream, &kname);
-    second.in0 = (const char*)ws;
+    second.in0 = (const char*)ws; second.ws = (char*)ws + img; second.ws_bytes = 256;
     second.aux_in = staging_allowed(b.count) ? stage(state, 256, true, true) : state;
     if (err == 0 && !second.aux_in) return;
     if (err == 0) err = launch_stochastic_bf8(second, tls().stream);
@@ -998,6 +1010,7 @@ bool rt_ready() { return runtime_ready(); }
 const void* rt_small_host_input(const void* p, size_t nbytes) { return device_visible(p, nbytes); }
 void* rt_small_host_output(void* p, size_t nbytes) { return host_inout(p, nbytes, 1); }
 void rt_scratch_reset() { scratch_reset(); }
+void rt_nest(int delta) { t_nest += delta; }
 void rt_note(const char* what, int a, int b, int c) { vlog(1, "%s (%d, %d, %d)", what, a, b, c); }
 void* rt_stream() { return tls().stream; }
 int rt_jit_mode() { return jit_mode(); }

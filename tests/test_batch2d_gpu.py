@@ -104,6 +104,13 @@ def test_bf16_2d_batch_is_the_nested_loop(m, ni, nj, br):
         assert name == "gemm_bf16_blocked_kernel", name          # 256 x 256 macro tiles
 
 
+@pytest.mark.parametrize("dtype,m,br", [(DT.F32, 32, 64), (DT.F32, 32, 16), (DT.BF16, 64, 48), (DT.F32, 16, 40)])
+def test_1x1_2d_batch_with_a_long_chain(dtype, m, br):
+    """count_i = count_j = 1 with br >= 16 reaches the chain-split path (partial products as a batch, then a reduce): the partial batch is a
+    plain 1-D one whatever the caller's batch form was (round-2 advisor finding, csrc/runtime.cpp)."""
+    _blocked(dtype, m, 1, 1, br)
+
+
 def test_bf16_fused_2d_batch_steps_the_bias_with_i():
     _blocked(DT.BF16, 64, 4, 4, 2, fused=True)
 

@@ -178,6 +178,13 @@ def test_mtx_reader_builds_csr_and_csc_from_unsorted_entries(tmp_path, by_column
     assert api.hip_mtx_read(b"/nonexistent.mtx", 0, dt, C.byref(ptr), C.byref(idx), C.byref(val), C.byref(r), C.byref(c), C.byref(n)) != 0
     bad = _mtx(tmp_path, 3, 3, [(0, 0, 1.0), (5, 1, 2.0)], "bad.mtx")
     assert api.hip_mtx_read(bad, 0, dt, C.byref(ptr), C.byref(idx), C.byref(val), C.byref(r), C.byref(c), C.byref(n)) != 0
+    # a header that claims more entries than the file can hold (round-2 advisor: reserve(n) threw through the C boundary), an over-long line
+    huge = tmp_path / "huge.mtx"
+    huge.write_text("%%MatrixMarket matrix coordinate real general\n3 3 4000000000\n1 1 1.0\n")
+    assert api.hip_mtx_read(str(huge).encode(), 0, dt, C.byref(ptr), C.byref(idx), C.byref(val), C.byref(r), C.byref(c), C.byref(n)) != 0
+    longline = tmp_path / "long.mtx"
+    longline.write_text("%%MatrixMarket matrix coordinate real general\n3 3 1\n1 1 " + "0" * 600 + "1.0\n")
+    assert api.hip_mtx_read(str(longline).encode(), 0, dt, C.byref(ptr), C.byref(idx), C.byref(val), C.byref(r), C.byref(c), C.byref(n)) != 0
 
 
 @pytest.mark.parametrize("npdt,dtname", [("float32", "F32"), ("uint16", "BF16"), ("int8", "I8")])

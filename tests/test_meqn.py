@@ -133,6 +133,10 @@ CASES = {
     # the sum of squares of an expression as the head: one number out
     "sum_of_squares": (("u", UNARY.REDUCE_X_OP_ADD, UNARY_FLAG.REDUCE_ROWS, ("u", UNARY.REDUCE_X2_OP_ADD, UNARY_FLAG.REDUCE_COLS, ("b", BINARY.SUB, 0, A(0), A(1)))),
                        [(M, N, LD, DT.F32), (M, N, M, DT.F32)], (1, 1, 1, DT.F32)),
+    # a product reduced to ONE number: sum over all elements of (A0 x A1) -- a GEMM node below a 1 x 1 head (round-2 advisor: the nested
+    # GEMM call used to rewind the staging scratch that holds a host-resident 1 x 1 result)
+    "matmul_sum_to_scalar": (("u", UNARY.REDUCE_X_OP_ADD, UNARY_FLAG.REDUCE_ROWS, ("u", UNARY.REDUCE_X_OP_ADD, UNARY_FLAG.REDUCE_COLS, ("mm", BINARY.MATMUL, 0, A(0), A(1)))),
+                             [(48, 40, 52, DT.F32), (40, 24, 42, DT.F32)], (1, 1, 1, DT.F32)),
     "mixed_precision": (("b", BINARY.SUB, 0, ("u", UNARY.X2, 0, A(0)), ("b", BINARY.MUL, BINARY_FLAG.BCAST_SCALAR_IN_1, A(1), A(2))),
                         [(M, N, LD, DT.BF16), (M, N, M, DT.F32), (1, 1, 1, DT.F32)], (M, N, LD, DT.BF16)),
 }
@@ -187,7 +191,7 @@ def test_incomplete_and_unsupported_equations_return_null(api):
 
 # device tanhf / the matrix core's summation order / the tree-shaped sum of a dot product: not bit-identical
 BY_NORM = {"tanh_sigmoid_chain": 1e-6, "matmul_mul": 1e-6, "matmul_vnni_bf16": 8e-3, "dot_to_scalar": 2e-5, "mul_dot_to_scalar": 2e-5,
-           "softmax_fwd": 8e-3, "softmax_bwd": 1e-5, "sum_of_squares": 1e-5}
+           "softmax_fwd": 8e-3, "softmax_bwd": 1e-5, "sum_of_squares": 1e-5, "matmul_sum_to_scalar": 1e-5}
 # reductions only where they end in ONE number (a phase of the one-workgroup kernel); vector-valued reductions inside a tree stay a chain
 FUSABLE = {"simple", "bias_relu_bf16", "ternary_muladd", "mixed_precision", "tanh_sigmoid_chain", "layernorm_affine", "dot_to_scalar", "mul_dot_to_scalar",
            "softmax_fwd", "softmax_bwd", "sum_of_squares"}
@@ -303,6 +307,26 @@ def test_gpu_meqn_scalar_arguments_may_live_in_host_memory(jit):
         _call(api, h, [dev[0].data_ptr(), dev[1].data_ptr(), C.addressof(scalar)], out.data_ptr())
     api.hip_sync(); api.check()
     assert np.array_equal(_valid(out.cpu().numpy().view(np.uint16), out_shape), _valid(ref, out_shape))
+
+
+@pytest.mark.gpu
+def test_gpu_meqn_gemm_node_below_a_scalar_head_in_host_memory():
+    """sum(A0 x A1) with the 1 x 1 result on the caller's stack (synchronous mode): the MATMUL step is a nested handle invocation and must
+    not rewind the staging scratch or drop the pending copy-back of the staged scalar (round-2 advisor finding, csrc/meqn.cpp)."""
+    import torch
+    api = capi.load()
+    tree, shapes, out_shape = CASES["matmul_sum_to_scalar"]
+    idx = build(api, tree, shapes)
+    h = api.dispatch_meqn(idx, capi.MeqnArgShape(*out_shape))
+    assert h
+    for seed in (21, 22, 23):                                     # repeated calls: the scratch is recycled call after call
+        arrays = _inputs(shapes, seed)
+        ref = evaluate(tree, shapes, arrays, out_shape)
+        dev = [torch.from_numpy(a.copy()).to("cuda:0") for a in arrays]
+        result = C.c_float(-12345.0)                              # plain host memory
+        _call(api, h, [d.data_ptr() for d in dev], C.addressof(result))
+        api.check()
+        assert abs(result.value - float(ref[0])) <= 1e-5 * max(1.0, abs(float(ref[0]))), (seed, result.value, float(ref[0]))
 
 
 # ---- MATMUL / BRGEMM and GATHER nodes (samples/equation/equation_matmul.c, equation_gather_reduce.c) ------------------------------
