@@ -2083,7 +2083,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 // FORM of the C stores (decided by the host): 0 f32, 1 bf16 as packed dwords (even ldc, 4-byte aligned tiles), 2 bf16 element by element
 // MB = 32-blocks per problem edge: 2 = 64 x 64 x K problems (4 x 4 per macro tile), 1 = 32 x 32 x K problems (8 x 8 per macro tile)
-template <int FORM, int MB>
+// ABL (experiments only, tools/bb_ablate.sh): 1 no workgroup barrier in the steady loop, 2 no DMA requests in the steady loop, 4 no C stores,
+// 8 the round-2 swizzle -- wrong results by construction, timing only
+template <int FORM, int MB, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
   constexpr unsigned int PPM = 8 / MB, PE = 32 * MB;                // problems per macro-tile edge, problem edge
   extern __shared__ __attribute__((aligned(16))) unsigned int bb_lds[];
@@ -2114,7 +2116,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
     const unsigned int col = 64u * w + 16u * x + (lane >> 2);
-    offB[x] = (col / PE) * (unsigned int)p.bs_b + (col % PE) * ldb * 2u + 16u * ((lane & 3u) ^ ((col >> 1) & 3u));
+    // chunk swizzle by bits 3..4 of the column: a ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), and the
+    // four lanes of a group whose columns agree mod 4 (same 16 banks) are li / 4 in {0, 3, 5, 6} or {1, 2, 4, 7}: (li >> 3) & 3 tells them apart.
+    // (Round 2 swizzled by bits 1..2 -- right for contiguous groups of 8, two-way conflicts on every B read here: SQ_LDS_BANK_CONFLICT = 25 %.)
+    const unsigned int swz = (ABL & 8) ? ((col >> 1) & 3u) : ((col >> 3) & 3u);
+    offB[x] = (col / PE) * (unsigned int)p.bs_b + (col % PE) * ldb * 2u + 16u * ((lane & 3u) ^ swz);
   }
   const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
   const unsigned int kchunks = (unsigned int)p.k >> 5;
@@ -2144,7 +2150,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
   if (total == 0) return;                                          // (launch_gemm sends br_count == 0 elsewhere)
   // fragment addresses inside a stage (dwords): A row 128 wi + li, k-pair 4 h; B column 128 wj + li, chunk (2 s2 + h) ^ swizzle
   const unsigned int fa = 1024u * h + 128u * wi + li;
-  const unsigned int sw = (li >> 1) & 3u;
+  const unsigned int sw = (ABL & 8) ? ((li >> 1) & 3u) : ((li >> 3) & 3u);
   const unsigned int fb0 = 4096u + (128u * wj + li) * 16u + 4u * (h ^ sw), fb1 = 4096u + (128u * wj + li) * 16u + 4u * ((2u + h) ^ sw);
   struct Frags { u32x4 a[4]; u32x4 b[4]; };
   auto read = [&](Frags& f, unsigned int slot, int s2) {
@@ -2195,10 +2201,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");              // stage t + 1 has landed (stages t + 2, t + 3 may fly)
-    wg_barrier();                                                  // ... for every wave, and every wave has read all of stage t
+    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");              // stage t + 1 has landed (stages t + 2, t + 3 may fly)
+    if constexpr (!(ABL & 1)) wg_barrier();                        // ... for every wave, and every wave has read all of stage t
     const unsigned int nslot = slot == NSLOT - 1u ? 0u : slot + 1u;
-    issue(slot);                                                   // stage t + NSLOT takes the place of stage t
+    if constexpr (!(ABL & 2)) issue(slot);                         // stage t + NSLOT takes the place of stage t
     read(f0, nslot, 0);
     mfma16(f1);
 #pragma unroll
@@ -2224,6 +2230,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
   // --- C: tile (ti, tj) of the quarter is tile (ti % 2, tj % 2) of problem (2 wi + ti / 2, 2 wj + tj / 2) of the macro tile.  Same three
   // store forms (and conversions) as tile_store_impl; the form is a template parameter because a run-time choice behind the loop makes
   // the compiler unpack all 256 accumulators from the AGPRs at the loop exit (and spill what the loop needs to make room).
+  if constexpr ((ABL & 4) != 0) {        // keep the accumulators alive without the stores: one dword per wave
+    float sink = 0.0f;
+    static_for<16>([&](auto idx) { constexpr int ti = idx.value / 4, tj = idx.value % 4; static_for<16>([&](auto rc) { sink += acc[ti][tj][rc.value]; }); });
+    if (sink == 123.456f) st_stream((GM float*)p.c, sink);
+    return;
+  }
   const bool odd = (lane & 1u) != 0;
   const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
   // tile (ti, tj) of the quarter = 32 x 32 block at rows 128 wi + 32 ti, columns 128 wj + 32 tj of the macro tile
@@ -2261,6 +2273,233 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
       asm volatile("" ::: "memory");
     });
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 macro-tile kernel, second generation (round 3): the same 256 x 256 macro tile / 128 x 128 per wave / 4-stage LDS-DMA ring as
+// gemm_bf16_blocked_kernel, rebuilt around what the round-3 ablation of that kernel measured (tools/bb_ablate.sh, 4096 x 4096 x 16384:
+// 0.726 us per stage; without the workgroup barrier 0.723; without the DMA requests 0.614; without both and without stores 0.608;
+// the bank-conflict-free swizzle alone: no change): the one barrier per stage is free, the 8 DMA requests per wave and stage cost 15 %
+// -- each came with a 64-bit VALU address, the stage base was rebuilt with scalar multiplies every stage (54 SALU + 36 VALU per 32 MFMAs).
+//   * requests are raw BUFFER loads to LDS: one resource per operand panel, the per-lane offsets are eight loop-invariant VGPRs, the stage
+//     offset is ONE SGPR per operand advanced by an add; a request is "s_add m0 ; buffer_load_dwordx4 ... lds", nothing else;
+//   * the stage loop is unrolled over the four ring slots, so every LDS fragment address is "loop-invariant VGPR + immediate";
+//   * problems of 16 x 16 x 16 (PE = 16, K16: a stage is two consecutive batch-reduce blocks), 32 x 32 x K and 64 x 64 x K tiles.
+// Accumulation order per output = the k order of the single-problem kernels: bitwise the same results.
+// ------------------------------------------------------------------------------------------------
+// Wave layout: NW waves (4: one per SIMD, or 8: two per SIMD), each TI x TJ accumulator tiles of 32 x 32 (NW * TI * TJ = 64 tiles = 256 x 256).
+// ABL: timing-only experiments (wrong results): 1 no A requests, 2 no B requests.
+// The other instructions of a region (fragment reads, requests) are written in the order they are to issue and the group barriers place them one
+// by one behind the region's MFMAs: bm_item_is_vmem(TI, TJ, RA, idx) = type of the idx-th of them (see the emission loops in the kernel).
+__host__ __device__ constexpr bool bm_item_is_vmem(int TI, int TJ, int RA, int idx) {
+  const int Q = TI > TJ ? TI : TJ;
+  int n = 0;
+  for (int q = 0; q < Q; ++q) {
+    if (q < TI) { if (idx == n || idx == n + 1) return false; n += 2; }      // an A fragment = two ds_read2st64_b32
+    if (q < TJ) { if (idx == n) return false; n += 1; }                      // a B fragment = one ds_read_b128
+    if (q < RA) { if (idx == n) return true; n += 1; }                       // one request
+  }
+  return false;
+}
+template <int TI, int TJ, int RA> __device__ __forceinline__ void bm_region_schedule() {
+  constexpr int M = TI * TJ, N = 2 * TI + TJ + RA;
+  static_for<M>([&](auto ic) {
+    constexpr int i = ic.value, lo = i * N / M, hi = (i + 1) * N / M;
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    static_for<hi - lo>([&](auto jc) {
+      if constexpr (bm_item_is_vmem(TI, TJ, RA, lo + jc.value)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    });
+  });
+}
+template <int FORM, int PE, bool K16, int NW = 4, int TI = 4, int TJ = 4, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, 1) void gemm_bf16_macro_kernel(GemmArgs p) {
+  static_assert(NW * TI * TJ == 64 && (NW == 4 || NW == 8), "256 x 256 macro tile");
+  constexpr unsigned int PPM = 256 / PE;                           // problems per macro-tile edge
+  constexpr int RA = 16 / NW;                                      // requests per wave for each half (A, B) of a stage
+  constexpr unsigned int WI = 8 / TI;                              // waves along i
+  extern __shared__ __attribute__((aligned(16))) unsigned int bm_lds[];
+  constexpr unsigned int STAGE = 8192;                             // dwords per stage: A [16 k-pairs][256 rows] | B [256 columns][16 dwords]
+  constexpr unsigned int NSLOT = 4;
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int ni = p.batch_inner, MI = ni / PPM, MJ = (p.nbatch / ni) / PPM;
+  unsigned int g = blockIdx.x, mi, mj;                             // XCD-aware macro-tile order: see gemm_bf16_blocked_kernel
+  if ((MI & 3u) == 0u && (MJ & 1u) == 0u) {
+    const unsigned int x = g & 7u, k = g >> 3, RI = MI >> 2, rj = k / RI, ri = k - rj * RI;
+    mi = (x & 3u) * RI + ri; mj = (x >> 2) * (MJ >> 1) + rj;
+  } else {
+    if ((gridDim.x & 7u) == 0u) g = (g & 7u) * (gridDim.x >> 3) + (g >> 3);
+    mj = g / MI; mi = g - mj * MI;
+  }
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const unsigned int brs_a = p.br_mode == 3 ? (unsigned int)p.br_stride_a : 0u, brs_b = p.br_mode == 3 ? (unsigned int)p.br_stride_b : 0u;
+  const __amdgpu_buffer_rsrc_t ra = wave_rsrc((gcptr)p.a + (long long)(mi * PPM) * p.bs_a);
+  const __amdgpu_buffer_rsrc_t rb = wave_rsrc((gcptr)p.b + (long long)(mj * PPM) * p.bs_b);
+  // --- DMA duty (launch_gemm checks that every offset below fits 32 bits).  A: request x brings k-pair RA w + x of the stage, lane = (problem
+  // 4 lane / PE, rows 4 lane % PE .. + 3).  B: request x brings columns 16 (RA w + x) .. + 15, lane = (column lane / 4, chunk slot lane % 4); the
+  // 16-byte chunk that lands in slot s of column c is chunk s ^ ((c >> 3) & 3) of the stage's 64 bytes: a ds_read_b128 is serviced in the lane
+  // groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), and the four lanes of a group whose columns agree mod 4 (same 16 banks) are li / 4 in
+  // {0, 3, 5, 6} or {1, 2, 4, 7}: (li >> 3) & 3 tells them apart.  K16: k-pairs 8 .. 15 and chunks 2, 3 belong to the stage's second block.
+  unsigned int voffA[RA], voffB[RA];
+#pragma unroll
+  for (int x = 0; x < RA; ++x) {
+    const unsigned int kp = (unsigned int)RA * w + (unsigned int)x;
+    voffA[x] = ((4u * lane) / PE) * (unsigned int)p.bs_a + 4u * ((4u * lane) % PE) + (K16 ? (kp >> 3) * brs_a + (kp & 7u) * lda * 4u : kp * lda * 4u);
+    const unsigned int col = 16u * kp + (lane >> 2), c = (lane & 3u) ^ ((col >> 3) & 3u);
+    voffB[x] = (col / PE) * (unsigned int)p.bs_b + (col % PE) * ldb * 2u + (K16 ? (c >> 1) * brs_b + (c & 1u) * 16u : c * 16u);
+  }
+  const unsigned int kchunks = K16 ? 1u : ((unsigned int)p.k >> 5);
+  const unsigned int total = K16 ? (unsigned int)(p.br_count >> 1) : (unsigned int)p.br_count * kchunks;
+  // stage offsets (SGPRs): within a block a stage is 16 k-pairs of A (64 lda bytes) and 64 bytes of every B column
+  const unsigned int stepA = K16 ? 2u * brs_a : 64u * lda, stepB = K16 ? 2u * brs_b : 64u;
+  const unsigned int wrapA = brs_a - kchunks * 64u * lda, wrapB = brs_b - kchunks * 64u;       // (unsigned wrap-around is fine: added modulo 2^32)
+  // Requests are written in HALVES of a stage (A half, B half; order A0 B0 A1 B1 ...), one request at a time between the fragment reads: the
+  // compiler must see requests and reads in the order they are to issue (a request writes LDS, so it never moves across an LDS read).
+  unsigned int sA = 0, sB = 0, kcA = 0, kcB = 0, nA = 0, nB = 0;    // nA / nB: stages whose A / B half has been requested
+  auto reqA = [&](unsigned int slot, int x) {
+    if (!(ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(bm_lds + slot * STAGE + 256u * ((unsigned int)RA * w + (unsigned int)x)), 16, (int)voffA[x], (int)sA, 0, 0);
+    if (x == RA - 1) { sA += stepA; ++nA; if (!K16) { if (++kcA == kchunks) { kcA = 0; sA += wrapA; } } }
+  };
+  auto reqB = [&](unsigned int slot, int x) {
+    if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(bm_lds + slot * STAGE + 4096u + 256u * ((unsigned int)RA * w + (unsigned int)x)), 16, (int)voffB[x], (int)sB, 0, 0);
+    if (x == RA - 1) { sB += stepB; ++nB; if (!K16) { if (++kcB == kchunks) { kcB = 0; sB += wrapB; } } }
+  };
+  auto issueA = [&](unsigned int slot) { static_for<RA>([&](auto xc) { reqA(slot, xc.value); }); };
+  auto issueB = [&](unsigned int slot) { static_for<RA>([&](auto xc) { reqB(slot, xc.value); }); };
+  // every request up to and including the B half of stage `s` has landed when at most (nA + nB - 2 s - 2) halves are behind it
+  auto wait_stage = [&](unsigned int s_) {
+    const unsigned int behind = nA + nB - 2u * s_ - 2u;
+    if (RA == 4) {
+      if (behind >= 4u) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (behind == 3u) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (behind == 2u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (behind == 1u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (behind >= 4u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (behind == 3u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (behind == 2u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (behind == 1u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  // --- compute duty: the (32 TI) x (32 TJ) part (wi, wj)
+  const unsigned int wi = w % WI, wj = w / WI;
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
+  if (total == 0) return;
+  // fragment addresses inside a stage (dwords): A row 32 TI wi + 32 ti + li, k-pairs 8 s2 + 4 h + e (256 dwords apart); B column
+  // 32 TJ wj + 32 tj + li, chunk (2 s2 + h) ^ ((li >> 3) & 3).  One opaque base per A fragment: its four k-pairs then pair up as
+  // ds_read2st64_b32 into consecutive registers (see the first-generation kernel); everything else is an immediate.
+  unsigned int fa[TI];
+#pragma unroll
+  for (int ti = 0; ti < TI; ++ti) { fa[ti] = 1024u * h + 32u * (unsigned int)TI * wi + 32u * (unsigned int)ti + li; asm volatile("" : "+v"(fa[ti])); }
+  const unsigned int sw = (li >> 3) & 3u;
+  unsigned int fb[2] = {4096u + (32u * (unsigned int)TJ * wj + li) * 16u + 4u * (h ^ sw), 4096u + (32u * (unsigned int)TJ * wj + li) * 16u + 4u * ((2u + h) ^ sw)};
+  asm volatile("" : "+v"(fb[0])); asm volatile("" : "+v"(fb[1]));
+  struct Frags { u32x4 a[TI]; u32x4 b[TJ]; };
+  constexpr int Q = TI > TJ ? TI : TJ;
+  // quarter q of a region's other work, in issue order: A fragment q, B fragment q, request q
+  auto read_q = [&](Frags& f, unsigned int slot, int s2, int q) {
+    const unsigned int* st = bm_lds + slot * STAGE;
+    if (q < TI) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f.a[q][e] = st[fa[q] + 2048u * (unsigned int)s2 + 256u * (unsigned int)e];
+    }
+    if (q < TJ) f.b[q] = *(const u32x4*)(st + fb[s2] + 512 * q);
+  };
+  auto read = [&](Frags& f, unsigned int slot, int s2) { static_for<Q>([&](auto qc) { read_q(f, slot, s2, qc.value); }); };
+  auto mfmas = [&](const Frags& f) {
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < TJ; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[tj]), __builtin_bit_cast(bf16x8, f.a[ti]), acc[ti][tj], 0, 0, 0);
+  };
+  // prologue: stages 0 .. 2 and the A half of stage 3 (as far as they exist)
+  for (unsigned int u = 0; u < NSLOT; ++u) {
+    if (u < total) issueA(u);
+    if (u < total && u + 1u < NSLOT) issueB(u);
+  }
+  wait_stage(0);
+  wg_barrier();
+  Frags f0, f1;
+  read(f0, 0, 0);
+  unsigned int t = 0;
+  // Steady state, four stages per trip (slot = compile-time).  Per stage two straight-line regions split by the one barrier:
+  //   region 1: the MFMAs of k-step 0, the fragment reads of k-step 1, the B half of stage t + 3 (slot freed by the previous barrier)
+  //   region 2: the MFMAs of k-step 1, the fragment reads of the next stage's k-step 0, the A half of stage t + 4 (slot freed by this barrier)
+  for (; t + NSLOT + 3u < total; t += 4u) {
+    static_for<4>([&](auto sc) {
+      constexpr unsigned int S = (unsigned int)sc.value, SN = (S + 1u) & 3u;
+      static_for<Q>([&](auto qc) { read_q(f1, S, 1, qc.value); if constexpr (qc.value < RA) reqB((S + 3u) & 3u, qc.value); });       // B half of stage t + 3
+      mfmas(f0);
+      bm_region_schedule<TI, TJ, RA>();
+      __builtin_amdgcn_sched_barrier(0);                           // nothing moves across the region boundary (the unrolled stages are one basic block)
+      if constexpr ((ABL & 3) == 0) { if (RA == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   // stage t + 1 has landed
+      else if constexpr ((ABL & 3) != 3) { if (RA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      wg_barrier();                                                // ... for every wave, and every wave has read all of stage t
+      static_for<Q>([&](auto qc) { read_q(f0, SN, 0, qc.value); if constexpr (qc.value < RA) reqA(S, qc.value); });                  // A half of stage t + 4 takes stage t's place
+      mfmas(f1);
+      bm_region_schedule<TI, TJ, RA>();
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  unsigned int slot = 0;                                           // t % 4 == 0 here
+  for (; t < total; ++t) {                                         // the last stages (fewer than eight): the same steps behind their conditions
+    read(f1, slot, 1);
+    if (nB < total) issueB(nB & 3u);
+    mfmas(f0);
+    const unsigned int nslot = slot == NSLOT - 1u ? 0u : slot + 1u;
+    if (t + 1u < total) {
+      wait_stage(t + 1u);
+      wg_barrier();
+      read(f0, nslot, 0);
+      if (nA < total) issueA(nA & 3u);
+    }
+    mfmas(f1);
+    slot = nslot;
+  }
+  // --- C.  Element (row, col) of the macro tile belongs to problem (row / PE, col / PE); a 32 x 32 accumulator tile lies inside one problem
+  // for PE >= 32 and covers 2 x 2 problems for PE = 16 (the lane's row picks the problem row, the register's column the problem column).
+  const bool odd = (lane & 1u) != 0;
+  const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
+  constexpr int ES = FORM == 0 ? 4 : 2;
+  auto row_off = [&](int ti, unsigned int sub) -> long long {     // byte offset of this lane's row (minus `sub` rows) inside C
+    const unsigned int row = 32u * (unsigned int)TI * wi + 32u * (unsigned int)ti + li - sub;
+    return (long long)(mi * PPM + row / PE) * p.bs_c + (long long)(row % PE) * ES;
+  };
+  auto col_off = [&](unsigned int col) -> long long {
+    return (long long)(mj * PPM + col / PE) * p.bs_c2 + (long long)(col % PE) * p.ldc * ES;
+  };
+  static_for<TI * TJ>([&](auto idx) {
+    constexpr int ti = idx.value / TJ, tj = idx.value % TJ;
+    const unsigned int col0 = 32u * (unsigned int)TJ * wj + 32u * (unsigned int)tj + 4u * h;
+    if constexpr (FORM == 0) {
+      GM char* base = (GM char*)p.c + row_off(ti, 0u);
+      static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream((GM float*)(base + col_off(col0 + (unsigned int)((r & 3) + 8 * (r >> 2)))), acc[ti][tj][r]); });
+    } else if constexpr (FORM == 1) {
+      // lanes (2q, 2q + 1) hold rows (2q, 2q + 1) of a column: the even lane stores the packed pair of the even register's column, the odd lane
+      // that of the odd register's column (rows 2q, 2q + 1 both times): see tile_store_impl
+      GM char* base = (GM char*)p.c + row_off(ti, odd ? 1u : 0u);
+      static_for<8>([&](auto gc) {
+        constexpr int r0 = 2 * gc.value, jr = (r0 & 3) + 8 * (r0 >> 2);
+        const unsigned int wv = cvt_pk_bf16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]);
+        const unsigned int nv = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)wv, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+        st_stream((GM unsigned int*)(base + col_off(col0 + (unsigned int)jr + (odd ? 1u : 0u))), (unsigned int)__builtin_amdgcn_perm(nv, wv, sel));
+      });
+    } else {
+      GM char* base = (GM char*)p.c + row_off(ti, 0u);
+      static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream((GM unsigned short*)(base + col_off(col0 + (unsigned int)((r & 3) + 8 * (r >> 2)))), f32_to_bf16_rne(acc[ti][tj][r])); });
+    }
+    asm volatile("" ::: "memory");
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2826,6 +3065,29 @@ static bool f32_lean_ok(const GemmArgs& a) {
 // the workgroup-cooperative blocked kernel: 2-D batch whose grid divides into 128 x 128 macro tiles, square 32^3 / 64^3 problems,
 // no transposes, plain or STRIDE batch-reduce, 16-byte aligned operands, 32-bit offsets inside a block
 // the blocked kernel on 16 x 16 x K tiles: grid divisible into 8 x 8 problems, an even number of 16-deep sub-steps, plain epilogue, f32, NN, strided
+// second-generation macro-tile kernel (gemm_bf16_macro_kernel): 16 / 32 / 64 tiles; every request offset (lane part + stage part) must fit 32 bits
+static bool bf16_macro_ok(const GemmArgs& a, bool& k16) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BB_V"); return e && e[0] == '1'; }();      // 1: the first-generation kernel (A/B runs)
+  if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.br_count == 0) return false;
+  if (a.a_type != LIBXSMM_DATATYPE_BF16 || a.b_type != LIBXSMM_DATATYPE_BF16 || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
+  if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || a.vnni_c || a.colbias || a.act || !(a.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false;
+  if (a.c_type != LIBXSMM_DATATYPE_BF16 && a.c_type != LIBXSMM_DATATYPE_F32) return false;
+  if (a.m != a.n || (a.m != 64 && a.m != 32 && a.m != 16) || a.k <= 0) return false;
+  k16 = (a.k % 32) != 0;
+  if (k16 && (a.k != 16 || (a.br_count & 1ull) || a.br_mode != 3)) return false;       // a stage of 32 k = two consecutive blocks of 16
+  const unsigned int ni = a.batch_inner, nj = a.nbatch / a.batch_inner, ppm = 256u / (unsigned int)a.m;
+  const unsigned long long stages = k16 ? a.br_count / 2ull : a.br_count * (unsigned long long)(a.k >> 5);
+  if (ni % ppm || nj % ppm || stages >= (1ull << 31)) return false;
+  const unsigned long long bra = a.br_mode == 3 ? (unsigned long long)a.br_stride_a : 0ull, brb = a.br_mode == 3 ? (unsigned long long)a.br_stride_b : 0ull;
+  if (a.bs_a < 0 || a.bs_b < 0 || (a.br_mode == 3 && (a.br_stride_a < 0 || a.br_stride_b < 0))) return false;
+  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b | bra | brb |
+    (unsigned long long)((long long)a.lda * 4) | (unsigned long long)((long long)a.ldb * 2);
+  if ((bits & 15ull) != 0ull || a.lda >= (1 << 20) || a.ldb >= (1 << 20)) return false;
+  // largest byte offset a request can form inside the macro tile's operand panel: (ppm - 1) problems + the whole chain + one stage
+  const unsigned long long spanA = (unsigned long long)(ppm - 1u) * (unsigned long long)a.bs_a + a.br_count * bra + (unsigned long long)a.k * (unsigned long long)a.lda * 2ull + 4096ull;
+  const unsigned long long spanB = (unsigned long long)(ppm - 1u) * (unsigned long long)a.bs_b + a.br_count * brb + (unsigned long long)a.m * (unsigned long long)a.ldb * 2ull + 4096ull;
+  return spanA < (1ull << 32) && spanB < (1ull << 32);
+}
 static bool f32_blocked16_ok(const GemmArgs& a) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOCKED"); return e && e[0] == '0'; }();
   if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.a_type != LIBXSMM_DATATYPE_F32 || a.b_type != LIBXSMM_DATATYPE_F32 || a.c_type != LIBXSMM_DATATYPE_F32) return false;
@@ -3098,6 +3360,45 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     hipLaunchKernelGGL(gemm_f32_blocked16_kernel, grid, dim3(256), 0, st, a);
     return (int)hipGetLastError();
   }
+  // 2-D batches of bf16 16^3 / 32 x 32 x K / 64 x 64 x K problems, plain epilogue: the 256 x 256 macro-tile kernel (second generation)
+  { bool k16 = false;
+    if (a.batch_inner && bf16_macro_ok(a, k16)) {
+      const bool f32c = a.c_type == LIBXSMM_DATATYPE_F32;
+      const bool pack2 = ((a.ldc & 1) == 0) && ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 3ull) == 0ull);
+      const int form = f32c ? 0 : (pack2 ? 1 : 2);
+      using kfn = void (*)(GemmArgs);
+#define BM_(F_) { gemm_bf16_macro_kernel<F_, 64, false>, gemm_bf16_macro_kernel<F_, 32, false>, gemm_bf16_macro_kernel<F_, 16, false>, gemm_bf16_macro_kernel<F_, 16, true> }
+      static const kfn table[3][4] = { BM_(0), BM_(1), BM_(2) };
+#undef BM_
+      static const bool lds_ok = []() {
+        for (int f = 0; f < 3; ++f) for (int v = 0; v < 4; ++v)
+          if (hipFuncSetAttribute((const void*)table[f][v], hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) return false;
+        return true; }();
+      if (lds_ok) {
+        const unsigned int ppm = 256u / (unsigned int)a.m;
+        a.tiles_m = a.tiles_n = 1; a.map2d_shift = 0;
+        const dim3 mgrid((a.batch_inner / ppm) * ((a.nbatch / a.batch_inner) / ppm));
+        if (kernel_name) *kernel_name = "gemm_bf16_macro_kernel";
+        const int v = a.m == 64 ? 0 : (a.m == 32 ? 1 : (k16 ? 3 : 2));
+        static const int abl = []() { const char* e = getenv("LIBXSMM_HIP_BB_ABL"); return e ? atoi(e) : 0; }();      // timing experiments (wrong results)
+        static const int shape = []() { const char* e = getenv("LIBXSMM_HIP_BM_SHAPE"); return e ? atoi(e) : 0; }();   // experiments: 824 = 8 waves of 2 x 4 tiles, 842 = 4 x 2
+        if ((abl || shape) && form == 1 && v == 0) {
+#define BM_VAR_(NW_, TI_, TJ_, V_) { static const bool ok = hipFuncSetAttribute((const void*)gemm_bf16_macro_kernel<1, 64, false, NW_, TI_, TJ_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess; \
+            if (ok) { hipLaunchKernelGGL((gemm_bf16_macro_kernel<1, 64, false, NW_, TI_, TJ_, V_>), mgrid, dim3(64 * NW_), 131072, st, a); return (int)hipGetLastError(); } }
+          if (shape == 824 && abl == 0) BM_VAR_(8, 2, 4, 0)
+          else if (shape == 842 && abl == 0) BM_VAR_(8, 4, 2, 0)
+          else if (shape == 824 && abl == 3) BM_VAR_(8, 2, 4, 3)
+          else if (shape == 0 && abl == 1) BM_VAR_(4, 4, 4, 1)
+          else if (shape == 0 && abl == 2) BM_VAR_(4, 4, 4, 2)
+          else if (shape == 0 && abl == 3) BM_VAR_(4, 4, 4, 3)
+#undef BM_VAR_
+        }
+        hipLaunchKernelGGL(table[form][v], mgrid, dim3(256), 131072, st, a);
+        return (int)hipGetLastError();
+      }
+      (void)hipGetLastError();
+    }
+  }
   // 16 x 16 problems with a plain epilogue: four problems per wave
   if (p16_ok(a)) {
     const bool bf16 = a.a_type == LIBXSMM_DATATYPE_BF16;
@@ -3126,6 +3427,13 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       grid = dim3((a.batch_inner / ppm) * ((a.nbatch / a.batch_inner) / ppm));
       if (kernel_name) *kernel_name = "gemm_bf16_blocked_kernel";
       const bool pack2 = ((a.ldc & 1) == 0) && ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 3ull) == 0ull);
+      static const int abl = []() { const char* e = getenv("LIBXSMM_HIP_BB_ABL"); return e ? atoi(e) : 0; }();      // timing experiments (wrong results), tools/bb_ablate.sh
+      if (abl && pack2 && a.m == 64) {
+#define BB_ABL_(V_) case V_: { static const bool ok = hipFuncSetAttribute((const void*)gemm_bf16_blocked_kernel<1, 2, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess; \
+          if (ok) { hipLaunchKernelGGL((gemm_bf16_blocked_kernel<1, 2, V_>), grid, dim3(256), 131072, st, a); return (int)hipGetLastError(); } } break;
+        switch (abl) { BB_ABL_(1) BB_ABL_(2) BB_ABL_(3) BB_ABL_(4) BB_ABL_(7) BB_ABL_(8) default: break; }
+#undef BB_ABL_
+      }
       if (a.m == 64) BB_FORMS_(2); else BB_FORMS_(1);
       return (int)hipGetLastError();
     }

@@ -97,11 +97,13 @@ def test_f32_2d_batch_is_the_nested_loop(m, ni, nj, br):
         assert name.startswith("gemm_f32_blocked_kernel"), name
 
 
-@pytest.mark.parametrize("m,ni,nj,br", [(32, 8, 8, 4), (64, 8, 4, 3), (64, 3, 5, 1), (32, 32, 16, 2), (64, 16, 32, 2), (64, 4, 4, 1), (64, 12, 8, 5), (64, 32, 32, 7), (32, 16, 8, 3), (32, 64, 64, 5)])
+@pytest.mark.parametrize("m,ni,nj,br", [(32, 8, 8, 4), (64, 8, 4, 3), (64, 3, 5, 1), (32, 32, 16, 2), (64, 16, 32, 2), (64, 4, 4, 1), (64, 12, 8, 5), (64, 32, 32, 7), (32, 16, 8, 3), (32, 64, 64, 5),
+                                        (64, 4, 4, 9), (64, 8, 8, 16), (32, 8, 8, 13), (16, 16, 16, 2), (16, 32, 16, 6), (16, 16, 48, 22), (16, 16, 16, 3), (16, 8, 16, 4)])
 def test_bf16_2d_batch_is_the_nested_loop(m, ni, nj, br):
     name = _blocked(DT.BF16, m, ni, nj, br)
-    if (m == 64 and ni % 4 == 0 and nj % 4 == 0) or (m == 32 and ni % 8 == 0 and nj % 8 == 0):
-        assert name == "gemm_bf16_blocked_kernel", name          # 256 x 256 macro tiles
+    ppm = 256 // m
+    if ni % ppm == 0 and nj % ppm == 0 and (m != 16 or br % 2 == 0):
+        assert name == "gemm_bf16_macro_kernel", name            # 256 x 256 macro tiles (16^3 tiles: a stage is two blocks of the chain)
 
 
 @pytest.mark.parametrize("dtype,m,br", [(DT.F32, 32, 64), (DT.F32, 32, 16), (DT.BF16, 64, 48), (DT.F32, 16, 40)])
