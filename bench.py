@@ -98,8 +98,8 @@ class Workload:
     mode 'shared_b': the same, but one B chain shared by the whole batch (stride_b = 0).
     mode 'blocked': a blocked GEMM -- grid (ni, nj) of C tiles, C(i,j) = sum_r A(i,r) B(r,j), one 2-D batched launch."""
 
-    def __init__(self, api, dev, dtype="f32", m=32, batch=4096, br=1, beta=0, fused=0, mode="stream", grid=None, nsets=0, seed=555, hint=None):
-        self.api, self.dev, self.dtype, self.m, self.br, self.beta, self.fused, self.mode = api, dev, dtype, m, br, beta, fused, mode
+    def __init__(self, api, dev, dtype="f32", m=32, batch=4096, br=1, beta=0, fused=0, mode="stream", grid=None, nsets=0, seed=555, hint=None, tag=""):
+        self.api, self.dev, self.dtype, self.m, self.br, self.beta, self.fused, self.mode, self.tag = api, dev, dtype, m, br, beta, fused, mode, tag
         self.bf16 = dtype == "bf16"
         es = 2 if self.bf16 else 4
         self.es = es
@@ -164,7 +164,7 @@ class Workload:
         return self.api.hip_kernel_name(self.handle, 1).decode()
 
     def label(self):
-        return f"{self.dtype}_m{self.m}_" + (f"b{self.batch}" if self.mode == "stream" else (f"sharedB_b{self.batch}" if self.mode == "shared_b" else "blocked"))
+        return f"{self.dtype}_m{self.m}_" + (f"b{self.batch}" if self.mode == "stream" else (f"sharedB_b{self.batch}" if self.mode == "shared_b" else "blocked" + self.tag))
 
     # ---- the oracle as the checker: a strided sample of the batch, same inputs -----------------------------------
     def verify(self, s=0, samples=32):
@@ -430,12 +430,34 @@ def committed_counters(kernel, alg_bytes, label):
 
 
 SWEEP = [(dt, m, b) for dt in ("f32", "bf16") for m in (16, 32, 64) for b in (4096, 65536)]
-# blocked GEMMs: (dtype, m, ni, nj, br) -- 2048^3 out of 16^3 tiles, 4096 x 4096 x 2048 out of f32 32^3 tiles, 2048^3 out of bf16 32^3 tiles, 4096^3 out of 64^3 tiles
-BLOCKED = [("f32", 16, 128, 128, 128), ("f32", 32, 128, 128, 64), ("f32", 64, 64, 64, 64),
-           ("bf16", 16, 128, 128, 128), ("bf16", 32, 128, 128, 128), ("bf16", 64, 64, 64, 64)]
+# blocked GEMMs: (dtype, m, ni, nj, br, tag) -- f32: 2048^3 out of 16^3 tiles, 4096 x 4096 x 2048 out of 32^3 tiles, 4096^3 out of 64^3 tiles (macro tile 128 x 128:
+# 256 .. 1024 workgroups); bf16 (macro tile 256 x 256): 4096^3 out of 16^3 / 32^3 / 64^3 tiles = ONE round of 256 workgroups, and 8192^3 out of 64^3 tiles = four rounds
+BLOCKED = [("f32", 16, 128, 128, 128, ""), ("f32", 32, 128, 128, 64, ""), ("f32", 64, 64, 64, 64, ""),
+           ("bf16", 16, 256, 256, 256, ""), ("bf16", 32, 128, 128, 128, ""), ("bf16", 64, 64, 64, 64, ""), ("bf16", 64, 128, 128, 128, "_8192")]
 SHARED_B = [(dt, m, 65536) for dt in ("f32", "bf16") for m in (16, 32, 64)]
 # the odd shapes LIBXSMM is known for (BASELINE configs[0] is one 23^3 f32 GEMM): same streaming regime, problems that are not whole tiles
 RAGGED = [("f32", 23, 131072), ("f32", 23, 4096), ("f32", 13, 262144), ("f32", 40, 32768), ("f32", 72, 16384)]
+
+
+def mfma_roof(api, dev):
+    """What the matrix pipe of THIS chip sustains on the bench's operand values with nothing but MFMAs (libxsmm_hip_probe_mfma: register operands, one wave
+    per SIMD, no LDS, no memory): the roof a blocked GEMM on the same data cannot exceed -- the chip clocks to its power budget, and the 2.5 PF bf16 figure
+    assumes 2.4 GHz.  TFLOP/s per data type."""
+    out = {}
+    gen = torch.Generator(device=dev).manual_seed(555)
+    for name, t, iters in (("bf16", DT.BF16, 6000), ("f32", DT.F32, 3000)):
+        ops = gen_values(32768 if name == "bf16" else 16384, name == "bf16", dev, gen)       # 64 KiB of the bench's value distribution
+        flop = C.c_double(0.0)
+        for _ in range(2):
+            api.hip_probe_mfma(t, ops.data_ptr(), iters, C.byref(flop))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            api.hip_probe_mfma(t, ops.data_ptr(), iters, C.byref(flop))
+        e1.record(); torch.cuda.synchronize(); api.check()
+        out[name] = round(5 * flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+    return out
 
 
 def run_configs(api, dev, steps, min_seconds, cpu_seconds, with_cpu):
@@ -520,7 +542,7 @@ def compact_line(full, detail_path):
     if any(full.get(g) for g in ("sweep", "reuse", "ragged")):
         line["sweep_fields"] = "[frac_hbm, pct_mfma_peak]"
         line["sweep_verified"] = all(r.get("verified", True) for g in ("sweep", "reuse", "ragged") for r in (full.get(g) or {}).values())
-    for k in ("pipelined", "l3_resident_us", "without_streaming_hint_us"):
+    for k in ("pipelined", "l3_resident_us", "without_streaming_hint_us", "mfma_power_roof_TF"):
         if full.get(k) is not None:
             line[k] = full[k]
     line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
@@ -625,9 +647,9 @@ def main():
                 for dt, m, b in SHARED_B:
                     if f"{dt}_m{m}_sharedB_b{b}" == label:
                         found = Workload(api, dev, dt, m, b, mode="shared_b")
-                for dt, m, ni, nj, br in BLOCKED:
-                    if f"{dt}_m{m}_blocked" == label:
-                        found = Workload(api, dev, dt, m, 0, br=br, mode="blocked", grid=(ni, nj))
+                for dt, m, ni, nj, br, tag in BLOCKED:
+                    if f"{dt}_m{m}_blocked{tag}" == label:
+                        found = Workload(api, dev, dt, m, 0, br=br, mode="blocked", grid=(ni, nj), tag=tag)
             if found is None:
                 raise SystemExit(f"unknown entry {item}")
             results[label] = entry(found, args.steps, args.min_seconds)
@@ -679,15 +701,21 @@ def main():
             w = Workload(api, dev, dt, m, b, mode="shared_b")
             reuse[w.label()] = entry(w, args.steps, quick)
             del w; torch.cuda.empty_cache()
-        for dt, m, ni, nj, br in BLOCKED:
-            w = Workload(api, dev, dt, m, 0, br=br, mode="blocked", grid=(ni, nj))
+        for dt, m, ni, nj, br, tag in BLOCKED:
+            w = Workload(api, dev, dt, m, 0, br=br, mode="blocked", grid=(ni, nj), tag=tag)
             r = entry(w, args.steps, quick)
             r["gemm"] = f"{ni * m}x{nj * m}x{br * m} as {ni}x{nj} tiles of {m}^3, br={br}"
             reuse[w.label()] = r
             del w; torch.cuda.empty_cache()
-    configs = {}
+    configs, roof = {}, None
     if rank == 0 and world == 1 and not args.no_sweep and not args.no_configs:
         configs = run_configs(api, dev, args.steps, min(args.min_seconds, 0.15), args.cpu_seconds, not args.no_cpu_baseline)
+    if rank == 0 and world == 1 and not args.no_sweep:
+        roof = mfma_roof(api, dev)
+        for r in reuse.values():           # blocked entries next to what the pipe sustains on this data, on this chip, today
+            if "gemm" in r:
+                dt = "bf16" if r["kernel"].startswith("gemm_bf16") else "f32"
+                r["pct_of_power_roof"] = round(100.0 * r["GFLOP/s"] / 1e3 / roof[dt], 1)
     if dist is not None:
         dist.barrier()
 
@@ -726,6 +754,10 @@ def main():
             out["without_streaming_hint_us"] = round(auto_us, 3)
         if configs:
             out["configs"] = configs
+        if roof:
+            out["mfma_power_roof_TF"] = roof
+            out["mfma_power_roof_note"] = ("libxsmm_hip_probe_mfma: MFMAs back to back on register operands of the bench's value distribution (no LDS, no memory), "
+                                           "one wave per SIMD; MFMA_PEAK_TF is the nominal 2.4 GHz figure, this is what the power budget allows on this data")
         if sweep:
             out["sweep"] = sweep
             out["reuse"] = reuse

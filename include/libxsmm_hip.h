@@ -161,6 +161,12 @@ LIBXSMM_API int libxsmm_hip_get_jit(void);
 LIBXSMM_API const char* libxsmm_hip_kernel_name(const void* kernel, int batched);
 /** Number of kernel launches issued by the calling thread since the last reset. */
 LIBXSMM_API unsigned long long libxsmm_hip_launch_count(int reset);
+/** Diagnostic: what the matrix pipe of THIS chip sustains under its power budget.  Every wave (one per SIMD on every CU, 16 accumulators) issues
+ * `iterations` x 16 MFMAs back to back on REGISTER operands taken from `operands` (device memory, 64 KiB of bf16 or f32 values) -- no LDS, no memory
+ * traffic -- on the calling thread's stream.  datatype BF16: v_mfma_f32_32x32x16_bf16, F32: v_mfma_f32_32x32x2_f32.  *flop receives the floating-point
+ * operations of the launch; time it with events.  The rate depends on the operand VALUES (zeros: 99 % of the 2.5 PF bf16 figure at 2.36 GHz; the reference
+ * drivers' value distribution: 73 % at 1.75 GHz, profiles/r03_bf16_macro_ablation.txt): the roof a GEMM on the same data cannot exceed. */
+LIBXSMM_API int libxsmm_hip_probe_mfma(libxsmm_datatype datatype, const void* operands, int iterations, double* flop);
 /** 1 if the library was built with the gfx950 code object and a device is present. */
 LIBXSMM_API int libxsmm_hip_available(void);
 

@@ -2068,225 +2068,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16 blocked kernel: the operand-reuse regime for bf16 (libxsmm_hip_gemm_batch_strided_2d on 64 x 64 x K problems, VNNI-2 A, flat B,
-// plain epilogue).  The bf16 matrix pipe does a 32 x 32 x 16 step in 32 cycles, 8 x the f32 rate per operand byte: with the f32 blocked
-// kernel's 128 x 128 macro tile (64 x 64 per wave) the fragment reads plus the LDS-DMA writes would need 190 bytes per cycle of an LDS
-// that delivers 128.  Here a workgroup owns 256 x 256 of C (4 x 4 problems) and every wave 128 x 128 of it -- 16 accumulators of
-// 32 x 32, 256 AGPRs -- so a fragment is used by four MFMAs: 94 bytes per cycle.
-//   * K advances in stages of 32: A as [16 k-pairs][256 rows] dwords (16 KiB), B as [256 columns][64 bytes] (16 KiB, 16-byte chunks
-//     XOR-swizzled by the column so that the b128 fragment reads are conflict free), four stages in a 128 KiB ring.  All of it arrives
-//     by LDS-DMA (8 instructions per wave and stage: wave w brings k-pairs 4 w .. 4 w + 3 of all four A problems and the B problem
-//     column w), three stages ahead of the one being multiplied.
-//   * One wave per SIMD cannot hide anything behind another wave: the loop is software-pipelined on k-steps of 16 -- the fragments of
-//     step u + 1 are requested before the 16 MFMAs of step u are issued -- with ONE workgroup barrier per stage.
+// bf16 macro-tile kernel: the operand-reuse regime for bf16 (libxsmm_hip_gemm_batch_strided_2d on 16^3 / 32 x 32 x K / 64 x 64 x K problems, VNNI-2 A,
+// flat B, plain epilogue).  The bf16 matrix pipe does a 32 x 32 x 16 step in 32 cycles, 8 x the f32 rate per operand byte: with the f32 blocked
+// kernel's 128 x 128 macro tile (64 x 64 per wave) the fragment reads plus the LDS-DMA writes would need 190 bytes per cycle of LDS.  Here a
+// workgroup owns 256 x 256 of C (4 x 4 problems of 64, 8 x 8 of 32, 16 x 16 of 16) and every wave 128 x 128 of it -- 16 accumulators of 32 x 32,
+// 256 AGPRs, one wave per SIMD -- so a fragment is used by four MFMAs.
+//   * K advances in stages of 32: A as [16 k-pairs][256 rows] dwords (16 KiB), B as [256 columns][64 bytes] (16 KiB, 16-byte chunks XOR-swizzled
+//     by the column so that the b128 fragment reads are conflict free), four stages in a 128 KiB ring, all of it by LDS-DMA three stages ahead.
+//   * One wave per SIMD hides nothing behind another wave: the loop is software-pipelined on k-steps of 16 (the fragments of step u + 1 are read
+//     while the 16 MFMAs of step u issue), ONE workgroup barrier per stage, and exactly one other instruction is placed behind each MFMA.
+//   * Round 3 (profiles/r03_bf16_macro_ablation.txt): the round-2 kernel spent 15 % of a stage on its 8 requests -- each came with a 64-bit VALU
+//     address and the stage base was rebuilt with scalar multiplies (54 SALU + 36 VALU per 32 MFMAs); barrier and bank conflicts cost nothing.  Now a
+//     request is a raw BUFFER load to LDS: one resource per operand panel, the per-lane offsets are eight loop-invariant VGPRs, the stage offset is
+//     ONE SGPR per operand advanced by an add; the stage loop is unrolled over the four ring slots, so every LDS fragment address is
+//     "loop-invariant VGPR + immediate".  0.726 -> 0.68 us per stage; what remains is the issue cost of a request itself (about 55 cycles against the
+//     32-cycle shadow of an MFMA, wherever it is placed and also with two waves per SIMD) on top of a body that runs at the chip's POWER roof: bare
+//     MFMAs on register operands with these operand values sustain 73 % of the 2.5 PF figure (1.75 GHz), this kernel without requests 70 %.
+//   * 16 x 16 x 16 problems (PE = 16, K16): a stage is two consecutive batch-reduce blocks.
 // Accumulation order per output = the k order of the single-problem kernels: bitwise the same results.
 // ------------------------------------------------------------------------------------------------
-// FORM of the C stores (decided by the host): 0 f32, 1 bf16 as packed dwords (even ldc, 4-byte aligned tiles), 2 bf16 element by element
-// MB = 32-blocks per problem edge: 2 = 64 x 64 x K problems (4 x 4 per macro tile), 1 = 32 x 32 x K problems (8 x 8 per macro tile)
-// ABL (experiments only, tools/bb_ablate.sh): 1 no workgroup barrier in the steady loop, 2 no DMA requests in the steady loop, 4 no C stores,
-// 8 the round-2 swizzle -- wrong results by construction, timing only
-template <int FORM, int MB, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_blocked_kernel(GemmArgs p) {
-  constexpr unsigned int PPM = 8 / MB, PE = 32 * MB;                // problems per macro-tile edge, problem edge
-  extern __shared__ __attribute__((aligned(16))) unsigned int bb_lds[];
-  constexpr unsigned int STAGE = 8192;                             // dwords per stage: A 4096 | B 4096
-  constexpr unsigned int NSLOT = 4;                                // stages in the ring (128 KiB): the DMA runs NSLOT - 1 stages ahead
-  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
-  const unsigned int ni = p.batch_inner, MI = ni / PPM, MJ = (p.nbatch / ni) / PPM;
-  // Hardware workgroup g runs on XCD g % 8 (its own 4 MiB L2).  The macro-tile grid is cut 4 x 2 so that every XCD owns a compact
-  // rectangle -- 16 x 16 macro tiles: 4 x 8 per XCD, an A panel shared by 8 of its workgroups and a B panel by 4 -- or, when the grid does
-  // not divide that way, a contiguous band of macro columns.
-  unsigned int g = blockIdx.x, mi, mj;
-  if ((MI & 3u) == 0u && (MJ & 1u) == 0u) {
-    const unsigned int x = g & 7u, k = g >> 3, RI = MI >> 2, rj = k / RI, ri = k - rj * RI;
-    mi = (x & 3u) * RI + ri; mj = (x >> 2) * (MJ >> 1) + rj;
-  } else {
-    if ((gridDim.x & 7u) == 0u) g = (g & 7u) * (gridDim.x >> 3) + (g >> 3);
-    mj = g / MI; mi = g - mj * MI;
-  }
-  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
-  // --- DMA duty.  A: instruction x brings k-pair 4 w + x of the stage, lane (problem ib = 4 lane / PE, rows 4 lane % PE .. + 3).
-  //     B: instruction x brings columns 64 w + 16 x .. + 15 of the macro tile, lane (column lane / 4, chunk slot lane % 4).
-  // Addresses are "wave-uniform base (SGPR pair) + 32-bit lane offset": no VALU per request (launch_gemm checks that the offsets fit).
-  gcptr a_wave = (gcptr)p.a + (long long)(mi * PPM) * p.bs_a + 4ull * (4u * w) * lda;
-  const unsigned int offA = ((4u * lane) / PE) * (unsigned int)p.bs_a + 4u * ((4u * lane) % PE);
-  gcptr b_wave = (gcptr)p.b + (long long)(mj * PPM) * p.bs_b;
-  unsigned int offB[4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    const unsigned int col = 64u * w + 16u * x + (lane >> 2);
-    // chunk swizzle by bits 3..4 of the column: a ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), and the
-    // four lanes of a group whose columns agree mod 4 (same 16 banks) are li / 4 in {0, 3, 5, 6} or {1, 2, 4, 7}: (li >> 3) & 3 tells them apart.
-    // (Round 2 swizzled by bits 1..2 -- right for contiguous groups of 8, two-way conflicts on every B read here: SQ_LDS_BANK_CONFLICT = 25 %.)
-    const unsigned int swz = (ABL & 8) ? ((col >> 1) & 3u) : ((col >> 3) & 3u);
-    offB[x] = (col / PE) * (unsigned int)p.bs_b + (col % PE) * ldb * 2u + 16u * ((lane & 3u) ^ swz);
-  }
-  const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
-  const unsigned int kchunks = (unsigned int)p.k >> 5;
-  const unsigned int total = (unsigned int)p.br_count * kchunks;
-  unsigned int is_r = 0, is_kc = 0;                                // the stage the next DMA request is for
-  auto issue = [&](unsigned int slot) {
-    gcptr a0 = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)(a_wave + is_r * brs_a + 64ull * is_kc * lda));      // 16 k-pairs x lda x 4 bytes per stage
-    gcptr b0 = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)(b_wave + is_r * brs_b + 64ull * is_kc));
-    unsigned int* dst = bb_lds + slot * STAGE + 1024u * w;
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-      __builtin_amdgcn_global_load_lds((GM const void*)(a0 + 4ull * x * lda + (unsigned long long)offA), (lds_vptr)(dst + 256 * x), 16, 0, 0);
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-      __builtin_amdgcn_global_load_lds((GM const void*)(b0 + (unsigned long long)offB[x]), (lds_vptr)(dst + 4096 + 256 * x), 16, 0, 0);
-    if (++is_kc == kchunks) { is_kc = 0; ++is_r; }
-  };
-  // --- compute duty: the 128 x 128 quarter (wi, wj)
-  const unsigned int wi = w & 1u, wj = w >> 1;
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.0f;
-  if (total == 0) return;                                          // (launch_gemm sends br_count == 0 elsewhere)
-  // fragment addresses inside a stage (dwords): A row 128 wi + li, k-pair 4 h; B column 128 wj + li, chunk (2 s2 + h) ^ swizzle
-  const unsigned int fa = 1024u * h + 128u * wi + li;
-  const unsigned int sw = (ABL & 8) ? ((li >> 1) & 3u) : ((li >> 3) & 3u);
-  const unsigned int fb0 = 4096u + (128u * wj + li) * 16u + 4u * (h ^ sw), fb1 = 4096u + (128u * wj + li) * 16u + 4u * ((2u + h) ^ sw);
-  struct Frags { u32x4 a[4]; u32x4 b[4]; };
-  auto read = [&](Frags& f, unsigned int slot, int s2) {
-    const unsigned int* st = bb_lds + slot * STAGE;
-    const unsigned int* pa = st + fa + 2048u * s2;
-    const unsigned int* pb = st + (s2 ? fb1 : fb0);
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
-      // an address register per fragment: its four k-pairs (256 dwords apart) then pair up as ds_read2st64 and land in consecutive
-      // registers; left to itself the compiler pairs the same k-pair of two fragments (32 dwords apart) and needs moves -- and a
-      // full LDS wait in front of them -- to build the operand
-      unsigned int ot = 32u * ti;
-      asm volatile("" : "+v"(ot));                                 // (an opaque OFFSET: laundering the pointer itself would lose its LDS address space)
-      const unsigned int* pt = pa + ot;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) f.a[ti][e] = pt[256 * e];
-    }
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj) f.b[tj] = *(const u32x4*)(pb + 512 * tj);
-  };
-  auto mfma16 = [&](const Frags& f) {
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj)
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[tj]), __builtin_bit_cast(bf16x8, f.a[ti]), acc[ti][tj], 0, 0, 0);
-  };
-  auto wait_landed = [&](unsigned int younger) {                   // this wave's DMA of a stage is complete when at most `younger` stages are behind it
-    if (younger >= 3u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (younger == 2u) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (younger == 1u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  const unsigned int pre = total < NSLOT ? total : NSLOT;
-  for (unsigned int t = 0; t < pre; ++t) issue(t);
-  wait_landed(pre - 1u);
-  wg_barrier();
-  Frags f0, f1;
-  read(f0, 0, 0);
-  unsigned int slot = 0, t = 0;
-  // Steady state (stages t + 1 .. t + NSLOT all exist): two straight-line regions per stage, split by the one barrier.  A single wave per SIMD
-  // issues in order, so whatever is not an MFMA has to sit BETWEEN MFMAs in program order to run in their shadow (32 cycles each):
-  // the group barriers ask the scheduler for "one MFMA, one LDS read" / "one MFMA, one DMA request" pairs instead of its default
-  // (all loads first, then 16 MFMAs back to back, the matrix pipe idle during the loads).
-  for (; t + NSLOT < total; ++t) {
-    read(f1, slot, 1);
-    mfma16(f0);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-    if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");              // stage t + 1 has landed (stages t + 2, t + 3 may fly)
-    if constexpr (!(ABL & 1)) wg_barrier();                        // ... for every wave, and every wave has read all of stage t
-    const unsigned int nslot = slot == NSLOT - 1u ? 0u : slot + 1u;
-    if constexpr (!(ABL & 2)) issue(slot);                         // stage t + NSLOT takes the place of stage t
-    read(f0, nslot, 0);
-    mfma16(f1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-    slot = nslot;
-  }
-  for (; t < total; ++t) {                                         // the last stages: the same steps behind their conditions
-    read(f1, slot, 1);
-    mfma16(f0);
-    const unsigned int nslot = slot == NSLOT - 1u ? 0u : slot + 1u;
-    if (t + 1u < total) {
-      wait_landed(total - t - 2u < NSLOT - 2u ? total - t - 2u : NSLOT - 2u);     // stage t + 1; stages t + 2 .. t + NSLOT - 1 may still fly
-      wg_barrier();
-      if (t + NSLOT < total) issue(slot);
-      read(f0, nslot, 0);
-    }
-    mfma16(f1);
-    slot = nslot;
-  }
-  // --- C: tile (ti, tj) of the quarter is tile (ti % 2, tj % 2) of problem (2 wi + ti / 2, 2 wj + tj / 2) of the macro tile.  Same three
-  // store forms (and conversions) as tile_store_impl; the form is a template parameter because a run-time choice behind the loop makes
-  // the compiler unpack all 256 accumulators from the AGPRs at the loop exit (and spill what the loop needs to make room).
-  if constexpr ((ABL & 4) != 0) {        // keep the accumulators alive without the stores: one dword per wave
-    float sink = 0.0f;
-    static_for<16>([&](auto idx) { constexpr int ti = idx.value / 4, tj = idx.value % 4; static_for<16>([&](auto rc) { sink += acc[ti][tj][rc.value]; }); });
-    if (sink == 123.456f) st_stream((GM float*)p.c, sink);
-    return;
-  }
-  const bool odd = (lane & 1u) != 0;
-  const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
-  // tile (ti, tj) of the quarter = 32 x 32 block at rows 128 wi + 32 ti, columns 128 wj + 32 tj of the macro tile
-  auto tile_base = [&](int ti, int tj) -> gptr {
-    const unsigned int row = 128u * wi + 32u * (unsigned int)ti, col = 128u * wj + 32u * (unsigned int)tj;
-    return (gptr)p.c + (long long)(mi * PPM + row / PE) * p.bs_c + (long long)(mj * PPM + col / PE) * p.bs_c2;
-  };
-  auto tile_i = [&](int ti) { return (int)((128u * wi + 32u * (unsigned int)ti) % PE + li); };
-  auto tile_j = [&](int tj) { return (int)((128u * wj + 32u * (unsigned int)tj) % PE); };
-  if constexpr (FORM == 0) {
-    static_for<16>([&](auto idx) {
-      constexpr int ti = idx.value / 4, tj = idx.value % 4;
-      GM float* base = (GM float*)tile_base(ti, tj) + (long long)(tile_j(tj) + 4 * (int)h) * p.ldc + tile_i(ti);
-      static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream(base + (long long)((r & 3) + 8 * (r >> 2)) * p.ldc, acc[ti][tj][r]); });
-      asm volatile("" ::: "memory");
-    });
-  } else if constexpr (FORM == 1) {
-    static_for<16>([&](auto idx) {
-      constexpr int ti = idx.value / 4, tj = idx.value % 4;
-      const int i = tile_i(ti);
-      GM unsigned short* base = (GM unsigned short*)tile_base(ti, tj) + (long long)(tile_j(tj) + 4 * (int)h + (odd ? 1 : 0)) * p.ldc + (i & ~1);
-      static_for<8>([&](auto gc) {
-        constexpr int r0 = 2 * gc.value, jr = (r0 & 3) + 8 * (r0 >> 2);
-        const unsigned int wv = cvt_pk_bf16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]);
-        const unsigned int nv = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)wv, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-        st_stream((GM unsigned int*)(base + (long long)jr * p.ldc), (unsigned int)__builtin_amdgcn_perm(nv, wv, sel));
-      });
-      asm volatile("" ::: "memory");
-    });
-  } else {
-    static_for<16>([&](auto idx) {
-      constexpr int ti = idx.value / 4, tj = idx.value % 4;
-      GM unsigned short* base = (GM unsigned short*)tile_base(ti, tj) + (long long)(tile_j(tj) + 4 * (int)h) * p.ldc + tile_i(ti);
-      static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream(base + (long long)((r & 3) + 8 * (r >> 2)) * p.ldc, f32_to_bf16_rne(acc[ti][tj][r])); });
-      asm volatile("" ::: "memory");
-    });
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16 macro-tile kernel, second generation (round 3): the same 256 x 256 macro tile / 128 x 128 per wave / 4-stage LDS-DMA ring as
-// gemm_bf16_blocked_kernel, rebuilt around what the round-3 ablation of that kernel measured (tools/bb_ablate.sh, 4096 x 4096 x 16384:
-// 0.726 us per stage; without the workgroup barrier 0.723; without the DMA requests 0.614; without both and without stores 0.608;
-// the bank-conflict-free swizzle alone: no change): the one barrier per stage is free, the 8 DMA requests per wave and stage cost 15 %
-// -- each came with a 64-bit VALU address, the stage base was rebuilt with scalar multiplies every stage (54 SALU + 36 VALU per 32 MFMAs).
-//   * requests are raw BUFFER loads to LDS: one resource per operand panel, the per-lane offsets are eight loop-invariant VGPRs, the stage
-//     offset is ONE SGPR per operand advanced by an add; a request is "s_add m0 ; buffer_load_dwordx4 ... lds", nothing else;
-//   * the stage loop is unrolled over the four ring slots, so every LDS fragment address is "loop-invariant VGPR + immediate";
-//   * problems of 16 x 16 x 16 (PE = 16, K16: a stage is two consecutive batch-reduce blocks), 32 x 32 x K and 64 x 64 x K tiles.
-// Accumulation order per output = the k order of the single-problem kernels: bitwise the same results.
-// ------------------------------------------------------------------------------------------------
+// FORM of the C stores (decided by the host): 0 f32, 1 bf16 as packed dwords (even ldc, 4-byte aligned tiles), 2 bf16 element by element.
 // Wave layout: NW waves (4: one per SIMD, or 8: two per SIMD), each TI x TJ accumulator tiles of 32 x 32 (NW * TI * TJ = 64 tiles = 256 x 256).
 // ABL: timing-only experiments (wrong results): 1 no A requests, 2 no B requests.
 // The other instructions of a region (fragment reads, requests) are written in the order they are to issue and the group barriers place them one
@@ -2324,7 +2125,10 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_bf16_macro_kernel(GemmArgs p)
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
   const unsigned int ni = p.batch_inner, MI = ni / PPM, MJ = (p.nbatch / ni) / PPM;
-  unsigned int g = blockIdx.x, mi, mj;                             // XCD-aware macro-tile order: see gemm_bf16_blocked_kernel
+  // Hardware workgroup g runs on XCD g % 8 (its own 4 MiB L2).  The macro-tile grid is cut 4 x 2 so that every XCD owns a compact rectangle --
+  // 16 x 16 macro tiles: 4 x 8 per XCD, an A panel shared by 8 of its workgroups and a B panel by 4 -- or, when the grid does not divide that
+  // way, a contiguous band of macro columns.
+  unsigned int g = blockIdx.x, mi, mj;
   if ((MI & 3u) == 0u && (MJ & 1u) == 0u) {
     const unsigned int x = g & 7u, k = g >> 3, RI = MI >> 2, rj = k / RI, ri = k - rj * RI;
     mi = (x & 3u) * RI + ri; mj = (x >> 2) * (MJ >> 1) + rj;
@@ -2396,7 +2200,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_bf16_macro_kernel(GemmArgs p)
   if (total == 0) return;
   // fragment addresses inside a stage (dwords): A row 32 TI wi + 32 ti + li, k-pairs 8 s2 + 4 h + e (256 dwords apart); B column
   // 32 TJ wj + 32 tj + li, chunk (2 s2 + h) ^ ((li >> 3) & 3).  One opaque base per A fragment: its four k-pairs then pair up as
-  // ds_read2st64_b32 into consecutive registers (see the first-generation kernel); everything else is an immediate.
+  // ds_read2st64_b32 into consecutive registers (left to itself the compiler pairs the same k-pair of two fragments and needs moves -- and a full LDS wait -- to build the operand); everything else is an immediate.
   unsigned int fa[TI];
 #pragma unroll
   for (int ti = 0; ti < TI; ++ti) { fa[ti] = 1024u * h + 32u * (unsigned int)TI * wi + 32u * (unsigned int)ti + li; asm volatile("" : "+v"(fa[ti])); }
@@ -3065,9 +2869,9 @@ static bool f32_lean_ok(const GemmArgs& a) {
 // the workgroup-cooperative blocked kernel: 2-D batch whose grid divides into 128 x 128 macro tiles, square 32^3 / 64^3 problems,
 // no transposes, plain or STRIDE batch-reduce, 16-byte aligned operands, 32-bit offsets inside a block
 // the blocked kernel on 16 x 16 x K tiles: grid divisible into 8 x 8 problems, an even number of 16-deep sub-steps, plain epilogue, f32, NN, strided
-// second-generation macro-tile kernel (gemm_bf16_macro_kernel): 16 / 32 / 64 tiles; every request offset (lane part + stage part) must fit 32 bits
+// macro-tile kernel (gemm_bf16_macro_kernel): 16 / 32 / 64 tiles; every request offset (lane part + stage part) must fit 32 bits
 static bool bf16_macro_ok(const GemmArgs& a, bool& k16) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BB_V"); return e && e[0] == '1'; }();      // 1: the first-generation kernel (A/B runs)
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_BLOCKED"); return e && e[0] == '0'; }();
   if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.br_count == 0) return false;
   if (a.a_type != LIBXSMM_DATATYPE_BF16 || a.b_type != LIBXSMM_DATATYPE_BF16 || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
   if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || a.vnni_c || a.colbias || a.act || !(a.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false;
@@ -3229,20 +3033,6 @@ static void launch_ragged(const GemmArgs& a, const RaggedCfg& c, unsigned int ld
 }
 // the bf16 blocked kernel: 2-D batch of 64 x 64 x K problems (K % 32 == 0) whose grid divides into 4 x 4 problems, VNNI-2 A, flat B, plain
 // epilogue, beta = 0, strided forms, 16-byte aligned rows / columns, at least one block
-static bool bf16_blocked_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_BLOCKED"); return e && e[0] == '0'; }();
-  if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.br_count == 0) return false;
-  if (a.a_type != LIBXSMM_DATATYPE_BF16 || a.b_type != LIBXSMM_DATATYPE_BF16 || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
-  if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || a.vnni_c || a.colbias || a.act || !(a.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false;
-  if (a.c_type != LIBXSMM_DATATYPE_BF16 && a.c_type != LIBXSMM_DATATYPE_F32) return false;
-  if (!((a.m == 64 && a.n == 64) || (a.m == 32 && a.n == 32)) || a.k <= 0 || (a.k % 32) != 0) return false;
-  const unsigned int ni = a.batch_inner, nj = a.nbatch / a.batch_inner, ppm = 256u / (unsigned int)a.m;
-  if (ni % ppm || nj % ppm || a.br_count * (unsigned long long)(a.k >> 5) >= (1ull << 31)) return false;
-  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
-    (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) | (unsigned long long)((long long)a.lda * 4) | (unsigned long long)((long long)a.ldb * 2);
-  if (a.bs_a < 0 || a.bs_b < 0 || 8ull * (unsigned long long)a.bs_a + 1024ull >= (1ull << 32) || 8ull * (unsigned long long)a.bs_b + 64ull * (unsigned long long)a.ldb * 2ull >= (1ull << 32)) return false;
-  return (bits & 15ull) == 0ull && a.lda < (1 << 20) && a.ldb < (1 << 20);
-}
 static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
   static const int mode = []() { const char* e = getenv("LIBXSMM_HIP_F32_DMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
   return mode;
@@ -3323,6 +3113,45 @@ int launch_bitmask_expand(const void* bitmap, const void* vals, void* dense, uns
   return (int)hipGetLastError();
 }
 
+// libxsmm_hip_probe_mfma: the matrix pipe alone (register operands, 16 accumulators per wave, one wave per SIMD): the power roof of a data set
+template <bool BF16>
+__global__ __launch_bounds__(256, 1) void mfma_probe_kernel(const void* operands, float* sink, int iterations) {
+  f32x16 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  GM const u32x4* ops = (GM const u32x4*)operands;                 // 4096 x 16 bytes
+  u32x4 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = ops[(threadIdx.x + 256 * i + 37 * blockIdx.x) & 4095]; b[i] = ops[(threadIdx.x + 256 * (i + 4) + 37 * blockIdx.x) & 4095]; }
+  for (int it = 0; it < iterations; ++it) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        if constexpr (BF16) acc[ti * 4 + tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[tj]), __builtin_bit_cast(bf16x8, a[ti]), acc[ti * 4 + tj], 0, 0, 0);
+        else acc[ti * 4 + tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(b[tj][0]), __uint_as_float(a[ti][0]), acc[ti * 4 + tj], 0, 0, 0);
+      }
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) sink[0] = s;                                // keeps the accumulators alive; never true for finite sums of this size in practice
+}
+int launch_mfma_probe(int bf16, const void* operands, int iterations, void* stream, double* flop) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  static float* sink = nullptr;
+  if (!sink && hipMalloc((void**)&sink, 256) != hipSuccess) return (int)hipGetLastError();
+  if (bf16) hipLaunchKernelGGL(mfma_probe_kernel<true>, dim3((unsigned int)cus), dim3(256), 0, (hipStream_t)stream, operands, sink, iterations);
+  else hipLaunchKernelGGL(mfma_probe_kernel<false>, dim3((unsigned int)cus), dim3(256), 0, (hipStream_t)stream, operands, sink, iterations);
+  if (flop) *flop = (double)cus * 4.0 * 16.0 * (double)iterations * (bf16 ? 32768.0 : 4096.0);
+  return (int)hipGetLastError();
+}
+
 int launch_brsplit_reduce(const GemmArgs& a, const float* partial, int nsplit, void* stream) {
   const long long blocks = (long long)((a.m + 63) / 64) * a.n;
   hipLaunchKernelGGL(brsplit_reduce_kernel, dim3((unsigned int)blocks), dim3(64, 16), 0, (hipStream_t)stream, a, partial, nsplit);
@@ -3360,7 +3189,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     hipLaunchKernelGGL(gemm_f32_blocked16_kernel, grid, dim3(256), 0, st, a);
     return (int)hipGetLastError();
   }
-  // 2-D batches of bf16 16^3 / 32 x 32 x K / 64 x 64 x K problems, plain epilogue: the 256 x 256 macro-tile kernel (second generation)
+  // 2-D batches of bf16 16^3 / 32 x 32 x K / 64 x 64 x K problems, plain epilogue: the 256 x 256 macro-tile kernel
   { bool k16 = false;
     if (a.batch_inner && bf16_macro_ok(a, k16)) {
       const bool f32c = a.c_type == LIBXSMM_DATATYPE_F32;
@@ -3380,6 +3209,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         const dim3 mgrid((a.batch_inner / ppm) * ((a.nbatch / a.batch_inner) / ppm));
         if (kernel_name) *kernel_name = "gemm_bf16_macro_kernel";
         const int v = a.m == 64 ? 0 : (a.m == 32 ? 1 : (k16 ? 3 : 2));
+#ifdef LIBXSMM_HIP_EXPERIMENTS      // make -C libxsmm_amd/csrc EXPERIMENTS=1: the ablations / wave layouts of profiles/r03_bf16_macro_ablation.txt (tools/bb_ablate.sh)
         static const int abl = []() { const char* e = getenv("LIBXSMM_HIP_BB_ABL"); return e ? atoi(e) : 0; }();      // timing experiments (wrong results)
         static const int shape = []() { const char* e = getenv("LIBXSMM_HIP_BM_SHAPE"); return e ? atoi(e) : 0; }();   // experiments: 824 = 8 waves of 2 x 4 tiles, 842 = 4 x 2
         if ((abl || shape) && form == 1 && v == 0) {
@@ -3393,6 +3223,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
           else if (shape == 0 && abl == 3) BM_VAR_(4, 4, 4, 3)
 #undef BM_VAR_
         }
+#endif
         hipLaunchKernelGGL(table[form][v], mgrid, dim3(256), 131072, st, a);
         return (int)hipGetLastError();
       }
@@ -3410,35 +3241,6 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     if (bf16) { if (four) hipLaunchKernelGGL((gemm_p16_kernel<4, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_p16_kernel<1, true>), grid, dim3(256), 0, st, a); }
     else { if (four) hipLaunchKernelGGL((gemm_p16_kernel<4, false>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_p16_kernel<1, false>), grid, dim3(256), 0, st, a); }
     return (int)hipGetLastError();
-  }
-  // 2-D batches of bf16 64 x 64 x K or 32 x 32 x K problems, plain epilogue: the 256 x 256 macro-tile kernel
-  if (a.batch_inner && (pl.path == P_BF16_2x2 || pl.path == P_BF16_1x1) && pl.exact && bf16_blocked_ok(a)) {
-#define BB_FORMS_(MB_) do { if (a.c_type == LIBXSMM_DATATYPE_F32) hipLaunchKernelGGL((gemm_bf16_blocked_kernel<0, MB_>), grid, dim3(256), 131072, st, a); \
-      else if (pack2) hipLaunchKernelGGL((gemm_bf16_blocked_kernel<1, MB_>), grid, dim3(256), 131072, st, a); \
-      else hipLaunchKernelGGL((gemm_bf16_blocked_kernel<2, MB_>), grid, dim3(256), 131072, st, a); } while (0)
-    static const bool lds_ok = []() {
-      const void* ks[6] = {(const void*)gemm_bf16_blocked_kernel<0, 1>, (const void*)gemm_bf16_blocked_kernel<1, 1>, (const void*)gemm_bf16_blocked_kernel<2, 1>,
-                           (const void*)gemm_bf16_blocked_kernel<0, 2>, (const void*)gemm_bf16_blocked_kernel<1, 2>, (const void*)gemm_bf16_blocked_kernel<2, 2>};
-      for (const void* kf : ks) if (hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) return false;
-      return true; }();
-    if (lds_ok) {
-      const unsigned int ppm = 256u / (unsigned int)a.m;
-      a.tiles_m = a.tiles_n = a.m / 32; a.map2d_shift = 0;
-      grid = dim3((a.batch_inner / ppm) * ((a.nbatch / a.batch_inner) / ppm));
-      if (kernel_name) *kernel_name = "gemm_bf16_blocked_kernel";
-      const bool pack2 = ((a.ldc & 1) == 0) && ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 3ull) == 0ull);
-      static const int abl = []() { const char* e = getenv("LIBXSMM_HIP_BB_ABL"); return e ? atoi(e) : 0; }();      // timing experiments (wrong results), tools/bb_ablate.sh
-      if (abl && pack2 && a.m == 64) {
-#define BB_ABL_(V_) case V_: { static const bool ok = hipFuncSetAttribute((const void*)gemm_bf16_blocked_kernel<1, 2, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess; \
-          if (ok) { hipLaunchKernelGGL((gemm_bf16_blocked_kernel<1, 2, V_>), grid, dim3(256), 131072, st, a); return (int)hipGetLastError(); } } break;
-        switch (abl) { BB_ABL_(1) BB_ABL_(2) BB_ABL_(3) BB_ABL_(4) BB_ABL_(7) BB_ABL_(8) default: break; }
-#undef BB_ABL_
-      }
-      if (a.m == 64) BB_FORMS_(2); else BB_FORMS_(1);
-      return (int)hipGetLastError();
-    }
-#undef BB_FORMS_
-    (void)hipGetLastError();
   }
   // 2-D batches of exact f32 32^3 / 64^3 problems (K any multiple of 32), NN, strided: the workgroup-cooperative blocked kernel
   if (a.batch_inner && (pl.path == P_F32_1x1 || pl.path == P_F32_2x2) && f32_blocked_ok(a)) {

@@ -229,6 +229,7 @@ int launch_mx_out_quant(const float* src, void* dst, void* scf, int m, int n, in
 int launch_bitmask_expand(const void* bitmap, const void* vals, void* dense, unsigned int* rows_scratch, int rows, int row_bytes, int elem_size, void* stream);
 int launch_stochastic_bf8(const MeltwArgs& args, void* stream);     // second pass of a TPP with *_STOCHASTIC_ROUND: f32 results -> BF8
 bool meltw_supported(const libxsmm_meltw_descriptor& d);
+int launch_mfma_probe(int bf16, const void* operands, int iterations, void* stream, double* flop);
 int launch_brsplit_reduce(const GemmArgs& args, const float* partial, int nsplit, void* stream);
 int launch_spmm(const SpmmArgs& args, void* stream, const char** kernel_name);
 int launch_bcsc(const BcscArgs& args, void* stream, const char** kernel_name);

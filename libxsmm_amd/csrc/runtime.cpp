@@ -1645,6 +1645,12 @@ LIBXSMM_API void libxsmm_hip_free(void* p) { if (p) (void)hipFree(p); }
 LIBXSMM_API int libxsmm_hip_memcpy_h2d(void* d, const void* s, size_t n) { return hip_ok(hipMemcpy(d, s, n, hipMemcpyHostToDevice), "hipMemcpy(H2D)") ? 0 : -1; }
 LIBXSMM_API int libxsmm_hip_memcpy_d2h(void* d, const void* s, size_t n) { return hip_ok(hipMemcpy(d, s, n, hipMemcpyDeviceToHost), "hipMemcpy(D2H)") ? 0 : -1; }
 LIBXSMM_API int libxsmm_hip_memset(void* d, int v, size_t n) { return hip_ok(hipMemset(d, v, n), "hipMemset") ? 0 : -1; }
+LIBXSMM_API int libxsmm_hip_probe_mfma(libxsmm_datatype datatype, const void* operands, int iterations, double* flop) {
+  if (!runtime_ready() || g_dryrun || !operands || iterations <= 0 || (datatype != LIBXSMM_DATATYPE_BF16 && datatype != LIBXSMM_DATATYPE_F32)) return EXIT_FAILURE;
+  const int err = launch_mfma_probe(datatype == LIBXSMM_DATATYPE_BF16 ? 1 : 0, operands, iterations, tls().stream, flop);
+  if (err != 0) { set_error(err, "launch of mfma_probe_kernel failed: %s", hipGetErrorString((hipError_t)err)); return EXIT_FAILURE; }
+  return EXIT_SUCCESS;
+}
 LIBXSMM_API unsigned long long libxsmm_hip_launch_count(int reset) { const unsigned long long n = tls().launches; if (reset) tls().launches = 0; return n; }
 LIBXSMM_API const char* libxsmm_hip_kernel_name(const void* kernel, int batched) {
   KernelCtx* c = ctx_from_handle(kernel);

@@ -2,7 +2,7 @@
 
 A kernel that needs scratch has spilled registers or keeps its argument block in memory: for the streaming kernels of this library that is a
 performance bug (round 2 found two of them this way: the M-block streaming BCSC kernel before its lambdas were force-inlined, and the signed-A
-int8 BCSC variant under the three-waves register cap).  The table itself is committed as profiles/r02_kernel_resources.txt."""
+int8 BCSC variant under the three-waves register cap).  The table itself is committed as profiles/r03_kernel_resources.txt."""
 import os
 import re
 import sys
@@ -17,8 +17,9 @@ LIB = os.path.join(ROOT, "libxsmm_amd", "lib", "libxsmm_amd.so")
 pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.path.join(kr.LLVM, "llvm-readelf"))),
                                 reason="needs the built library and the ROCm LLVM tools")
 
-# two spilled registers live across the main loop of the 512-register blocked bf16 kernel (stored before it, reloaded in the epilogue)
-SCRATCH_ALLOWED = {r"xamd::gemm_bf16_blocked_kernel<[02], [12]>": 12}
+# the 512-register bf16 macro-tile kernel, f32 / element-wise bf16 C stores of 64-tiles only: a few registers of the EPILOGUE's 64-bit address
+# arithmetic are spilled after the main loop and reloaded inside the epilogue (nothing inside the loop; the packed-bf16 form has no scratch)
+SCRATCH_ALLOWED = {r"xamd::gemm_bf16_macro_kernel<[02], 64, false, 4, 4, 4, 0>": 72}
 
 # kernel family -> least waves per SIMD that DESIGN.md's occupancy statements rely on (registers and static LDS together)
 OCCUPANCY = {
@@ -70,8 +71,8 @@ def test_hot_kernels_keep_their_occupancy(table):
 
 
 def test_committed_table_is_current(table):
-    """profiles/r02_kernel_resources.txt is the table of THIS build (regenerate with tools/kernel_resources.py --out ...)."""
-    path = os.path.join(ROOT, "profiles", "r02_kernel_resources.txt")
+    """profiles/r03_kernel_resources.txt is the table of THIS build (regenerate with tools/kernel_resources.py --out ...)."""
+    path = os.path.join(ROOT, "profiles", "r03_kernel_resources.txt")
     committed = {}
     for line in open(path).read().splitlines()[2:]:
         cols = line.split(None, 8)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Blocked GEMMs out of BRGEMM tiles (libxsmm_hip_gemm_batch_strided_2d) at chosen sizes: M x N x K from m^3 tiles, one JSON line each.
 Usage: python tools/bb_sweep.py [--dtype bf16] [--m 64] [--sizes 4096x4096x4096,4096x4096x16384,8192x8192x8192] [--no-verify]
-LIBXSMM_HIP_BB_ABL=<bits> selects a timing-only ablation of the bf16 kernel (see gemm_bf16_blocked_kernel)."""
+LIBXSMM_HIP_BB_ABL=<bits> selects a timing-only ablation of the bf16 kernel (experiment build only, see tools/bb_ablate.sh)."""
 import argparse
 import json
 import os
