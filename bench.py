@@ -200,8 +200,9 @@ class Workload:
         return worst < tol, worst, len(idx)
 
 
-def capture(work, launches):
-    """`launches` back-to-back steps (rotating over the input sets) in one hipGraph, captured on a side stream."""
+def capture(work, launches, lanes=0):
+    """`launches` back-to-back steps (rotating over the input sets) in one hipGraph, captured on a side stream.  lanes > 1: the steps are issued inside a
+    pipeline section (libxsmm_hip_pipeline_begin / _end: the caller declares them independent), i.e. as `lanes` parallel branches of the graph."""
     api = work.api
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
@@ -212,8 +213,12 @@ def capture(work, launches):
             work.step(i)
         side.synchronize()
         g.capture_begin()
+        if lanes > 1:
+            assert api.hip_pipeline_begin(lanes) == 0
         for i in range(launches):
             work.step(i)
+        if lanes > 1:
+            assert api.hip_pipeline_end() == 0
         g.capture_end()
     torch.cuda.current_stream().wait_stream(side)
     api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
@@ -235,7 +240,7 @@ EAGER = False
 MANIFEST = []      # execution order of the library launches, for tools/summarize_profiles.py (splits a kernel trace by workload)
 
 
-def timed(work, steps, min_seconds, barrier=lambda: None, label=None):
+def timed(work, steps, min_seconds, barrier=lambda: None, label=None, lanes=0):
     """A graph of G launches (G = a multiple of `steps` and of the rotation length) replayed R times so that the region lasts
     >= min_seconds, between two (barrier + synchronize) pairs.  Returns (wall seconds, launches timed, us per launch from HIP
     events recorded on the launch stream)."""
@@ -261,7 +266,7 @@ def timed(work, steps, min_seconds, barrier=lambda: None, label=None):
         n = per_graph * replays
         executed = int(work.api.hip_launch_count(1))
     else:
-        g = capture(work, per_graph)
+        g = capture(work, per_graph, lanes)
         g.replay(); torch.cuda.synchronize()              # untimed: the first replay uploads the graph
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record(); g.replay(); c1.record(); torch.cuda.synchronize()        # untimed calibration: how long one replay really takes
@@ -460,6 +465,37 @@ def mfma_roof(api, dev):
     return out
 
 
+PIPELINED = [("f32", 32, 4096), ("f32", 16, 4096), ("bf16", 16, 4096), ("bf16", 32, 4096), ("f32", 23, 4096), ("f32", 64, 4096), ("bf16", 64, 4096)]
+
+
+def run_pipelined(api, dev, steps, min_seconds, lanes=4):
+    """The small-launch regime with INDEPENDENT consecutive launches allowed to overlap (libxsmm_hip_pipeline_begin / _end, `lanes` internal streams,
+    captured as parallel branches of the graph): a launch of 4096 small problems is one round of waves, a third of it fill and drain.  The strict
+    one-launch-after-the-other figures stay the headline / sweep numbers; this is what a caller gets who declares the independence it has."""
+    out = {"lanes": lanes}
+    for dt, m, b in PIPELINED:
+        try:
+            set_bytes = 3 * b * m * m * (2 if dt == "bf16" else 4)
+            nsets = max(2, int(math.ceil(2.2 * L3_BYTES / set_bytes)))
+            nsets = (nsets + lanes - 1) // lanes * lanes          # launch k and launch k + nsets write the same C: they land on the same lane (ordered)
+            w = Workload(api, dev, dt, m, b, nsets=nsets)
+            api.hip_set_streaming_hint(w.hint)
+            for i in range(3):
+                w.step(i)
+            torch.cuda.synchronize(); api.check()
+            _, n, us = timed(w, steps, min_seconds, label=w.label() + f"_pipelined{lanes}", lanes=lanes)
+            api.check()
+            ok, err, _ = w.verify(0)
+            gbs = w.alg_bytes_per_step / (us * 1e-6) / 1e9
+            out[w.label()] = {"kernel": w.kernel(), "us_per_launch": round(us, 3), "GFLOP/s": round(w.flops_per_step / us / 1e3, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                              "launches_timed": n, "input_sets_rotated": nsets, "verified": bool(ok)}
+            del w
+        except Exception as e:
+            out[f"{dt}_m{m}_b{b}"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    return out
+
+
 def run_configs(api, dev, steps, min_seconds, cpu_seconds, with_cpu):
     """BASELINE configs #3, #4, #5 (one GPU) and config #2's variant B, measured like the headline (hipGraph replays, HIP events on the launch
     stream, inputs rotated past the Infinity Cache), every result checked against the oracle, the reference's CPU kernel timed beside each."""
@@ -542,7 +578,11 @@ def compact_line(full, detail_path):
     if any(full.get(g) for g in ("sweep", "reuse", "ragged")):
         line["sweep_fields"] = "[frac_hbm, pct_mfma_peak]"
         line["sweep_verified"] = all(r.get("verified", True) for g in ("sweep", "reuse", "ragged") for r in (full.get(g) or {}).values())
-    for k in ("pipelined", "l3_resident_us", "without_streaming_hint_us", "mfma_power_roof_TF"):
+    if full.get("pipelined"):
+        pl = full["pipelined"]
+        line["pipelined"] = {k: (v if not isinstance(v, dict) else (round(v["frac_hbm"], 3) if "frac_hbm" in v else None)) for k, v in pl.items()}
+        line["pipelined_verified"] = all(v.get("verified", False) for v in pl.values() if isinstance(v, dict))
+    for k in ("l3_resident_us", "without_streaming_hint_us", "mfma_power_roof_TF"):
         if full.get(k) is not None:
             line[k] = full[k]
     line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
@@ -710,7 +750,9 @@ def main():
     configs, roof = {}, None
     if rank == 0 and world == 1 and not args.no_sweep and not args.no_configs:
         configs = run_configs(api, dev, args.steps, min(args.min_seconds, 0.15), args.cpu_seconds, not args.no_cpu_baseline)
+    pipelined = None
     if rank == 0 and world == 1 and not args.no_sweep:
+        pipelined = run_pipelined(api, dev, args.steps, min(args.min_seconds, 0.15), lanes=int(os.environ.get("BENCH_LANES", "4")))
         roof = mfma_roof(api, dev)
         for r in reuse.values():           # blocked entries next to what the pipe sustains on this data, on this chip, today
             if "gemm" in r:
@@ -754,6 +796,8 @@ def main():
             out["without_streaming_hint_us"] = round(auto_us, 3)
         if configs:
             out["configs"] = configs
+        if pipelined:
+            out["pipelined"] = pipelined
         if roof:
             out["mfma_power_roof_TF"] = roof
             out["mfma_power_roof_note"] = ("libxsmm_hip_probe_mfma: MFMAs back to back on register operands of the bench's value distribution (no LDS, no memory), "

@@ -70,6 +70,15 @@ LIBXSMM_API void libxsmm_hip_set_streaming_hint(int mode);
 LIBXSMM_API int libxsmm_hip_get_streaming_hint(void);
 /** Block until all work enqueued by the calling thread's stream has finished. */
 LIBXSMM_API void libxsmm_hip_sync(void);
+/** Pipeline section: the calling thread DECLARES that the kernel launches it issues between _begin and _end are mutually independent (no launch reads
+ * what another one of the section writes) and may overlap on the device.  A launch of a few thousand small problems is one round of waves: a third of
+ * its time is filling and draining the chip (the headline launch sits on the copy floor of its footprint), and back-to-back launches on one
+ * stream cannot overlap that.  Inside a section consecutive launches rotate over `lanes` (2..8) internal streams: _begin forks them off the thread's stream
+ * (they wait for everything issued to it before), _end joins them back (the thread's stream waits for every lane); everything is stream-ordered, so a
+ * section may be captured into a hipGraph (the lanes become parallel branches).  Needs stream-ordered launches (libxsmm_hip_set_stream / _set_async);
+ * libxsmm_hip_sync and libxsmm_hip_set_stream close an open section.  Each lane has its own partial-result workspace. */
+LIBXSMM_API int libxsmm_hip_pipeline_begin(int lanes);
+LIBXSMM_API int libxsmm_hip_pipeline_end(void);
 /** Sticky error state of the calling thread (0 = none); kernels have no error channel. */
 LIBXSMM_API int libxsmm_hip_get_last_error(void);
 LIBXSMM_API const char* libxsmm_hip_get_last_error_string(void);
@@ -146,6 +155,14 @@ LIBXSMM_API int libxsmm_hip_mtx_read(const char* path, int by_column, libxsmm_da
   unsigned int* rows, unsigned int* cols, unsigned int* nnz);
 LIBXSMM_API int libxsmm_hip_bcsc_from_dense(libxsmm_datatype type, const void* dense, int K, int N, int bk, int bn,
   unsigned int** colptr, unsigned int** rowidx, void** values, unsigned int* nnzb);
+
+/** BCSC kernels take their block pattern with every call (b.secondary = colptr, b.tertiary = rowidx, b.quaternary -> block-column count
+ * [ref: samples/xgemm_sparse/spmm_kernel.c:423-456]) and need it inverted (block id per (block column, k-block)).  A pattern in HOST memory -- the
+ * reference's convention -- is recognised by content and its inverted image cached with the kernel (no allocation, no lock on a hit).  A pattern in
+ * DEVICE memory cannot be compared without a host round trip: by default it is inverted by a small kernel in front of every call; this function
+ * lets the caller promise that the two device arrays do not change until the binding is replaced (NULL, NULL unbinds), so the table is built once,
+ * stream-ordered on the calling thread's stream, and calls that pass exactly these pointers launch the GEMM kernel alone. */
+LIBXSMM_API int libxsmm_hip_bcsc_bind_pattern(libxsmm_gemmfunction kernel, const unsigned int* colptr, const unsigned int* rowidx, unsigned long long n_block_columns);
 
 /* ---- run-time specialisation of the fixed-pattern sparse kernels ---------------------
  * libxsmm_create_packed_spgemm_csr/_csc, libxsmm_create_spgemm_csr_areg and libxsmm_fsspmdm_create can compile a

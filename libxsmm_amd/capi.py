@@ -260,6 +260,9 @@ class Api:
             self.hip_clear_last_error = f("hip_clear_last_error", None, [])
             self.hip_kernel_name = f("hip_kernel_name", C.c_char_p, [vp, C.c_int])
             self.hip_launch_count = f("hip_launch_count", C.c_ulonglong, [C.c_int])
+            self.hip_bcsc_bind_pattern = f("hip_bcsc_bind_pattern", C.c_int, [vp, vp, vp, C.c_ulonglong])
+            self.hip_pipeline_begin = f("hip_pipeline_begin", C.c_int, [C.c_int])
+            self.hip_pipeline_end = f("hip_pipeline_end", C.c_int, [])
             self.hip_probe_mfma = f("hip_probe_mfma", C.c_int, [C.c_int, vp, C.c_int, C.POINTER(C.c_double)])
             self.hip_set_jit = f("hip_set_jit", None, [C.c_int])
             self.hip_get_jit = f("hip_get_jit", C.c_int, [])

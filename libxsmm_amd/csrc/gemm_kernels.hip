@@ -1065,6 +1065,73 @@ __global__ __launch_bounds__(256) void gemm_f32_stream_kernel_lean(LeanF32Args p
 }
 
 // ------------------------------------------------------------------------------------------------
+// ONE long STRIDE batch-reduce chain (SURVEY 8(d) config #2 variant B: a single BRGEMM with br = 4096): the chain is cut into slices, a workgroup
+// of EIGHT waves takes 8 * chunk consecutive blocks of one 32 x 32 output tile (wave w: blocks w * chunk .. + chunk - 1 of the slice, the loop of
+// gemm_f32_stream_kernel), adds the eight accumulators up through LDS in wave order and writes ONE partial tile; brsplit_reduce_kernel adds the
+// partial tiles in slice order.  Round 2 ran the chain as 1024 waves of 4 blocks with one partial tile per wave (0.21 of the HBM roofline: a
+// quarter of the waves the chip wants, 4 MiB of partial sums written and read back); here br = 4096 is 4096 waves and 512 partial tiles.
+// f32, NN, whole 32 x 32 tiles, k % 32 == 0.  partial: [slice][n][m] f32.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_f32_brchain_kernel(GemmArgs p, float* partial, unsigned int chunk, unsigned int nslices) {
+  __shared__ __attribute__((aligned(16))) float lds_all[8][2048];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int per_gemm = (unsigned int)(p.tiles_m * p.tiles_n);
+  const unsigned int slice = blockIdx.x / per_gemm, t = blockIdx.x - slice * per_gemm, tn = t / (unsigned int)p.tiles_m;
+  const unsigned int i0 = (t - tn * (unsigned int)p.tiles_m) * 32u, j0 = tn * 32u;
+  float* lds = lds_all[wave];
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const unsigned int offA = ((lane >> 3) * lda + (lane & 7u) * 4u) * 4u, offB = ((lane >> 3) * ldb + (lane & 7u) * 4u) * 4u;
+  const unsigned long long stepA = 32ull * lda, stepB = 32ull * ldb, orgA = 4ull * i0, kstepA = 128ull * lda, orgB = 4ull * j0 * ldb, kstepB = 128ull;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const unsigned int kchunks = (unsigned int)p.k >> 5;
+  const unsigned long long first = ((unsigned long long)slice * 8ull + wave) * chunk;
+  const unsigned long long last = first + chunk < p.br_count ? first + chunk : p.br_count;           // (first >= br_count: nothing to do, the wave contributes zeros)
+  if (first < last) {
+    gcptr ar = (gcptr)p.a + p.br_stride_a * (long long)first, br = (gcptr)p.b + p.br_stride_b * (long long)first;
+    const unsigned long long total = (last - first) * kchunks;
+    unsigned int kc = 0;
+    f32x4 ga[4], gb[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) ga[x] = *(GM const f32x4*)(ar + orgA + x * stepA + offA);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) gb[x] = *(GM const f32x4*)(br + orgB + x * stepB + offB);
+    for (unsigned long long u = 0; u < total; ++u) {
+      float af[16], bf[16];
+      tile_to_frag<false>(af, ga, lds, (int)lane);
+      tile_to_frag<true>(bf, gb, lds + 1024, (int)lane);
+      if (++kc == kchunks) { kc = 0; ar += p.br_stride_a; br += p.br_stride_b; }
+      if (u + 1 < total) {
+        gcptr au = ar + orgA + kc * kstepA, bu = br + orgB + kc * kstepB;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ga[x] = *(GM const f32x4*)(au + x * stepA + offA);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) gb[x] = *(GM const f32x4*)(bu + x * stepB + offB);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s2], af[s2], acc, 0, 0, 0);
+    }
+  }
+  // the eight accumulators -> one partial tile: register r of lane l goes to word r * 64 + l of the wave's image (the operand images are done with)
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lds[r * 64 + (int)lane] = acc[r];
+  __syncthreads();
+  float* tile = partial + (unsigned long long)slice * (unsigned long long)p.m * (unsigned long long)p.n;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const unsigned int r = 2u * wave + (unsigned int)rr;
+    float sum = lds_all[0][r * 64 + lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 8; ++w2) sum += lds_all[w2][r * 64 + lane];              // wave order: deterministic
+    const unsigned int j = j0 + (r & 3u) + 8u * (r >> 2) + 4u * h;
+    tile[(unsigned long long)j * (unsigned int)p.m + i0 + li] = sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32 streaming kernel, LDS-DMA form (MT x NT tiles of 32x32 per wave).  Same arithmetic as gemm_f32_stream_kernel;
 // the operand tiles of a 32-deep K chunk travel global -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no
 // ds_write), in the same two LDS images (linear [k][f] for the operand whose free index is contiguous, XOR-swizzled
@@ -3149,6 +3216,28 @@ int launch_mfma_probe(int bf16, const void* operands, int iterations, void* stre
   if (bf16) hipLaunchKernelGGL(mfma_probe_kernel<true>, dim3((unsigned int)cus), dim3(256), 0, (hipStream_t)stream, operands, sink, iterations);
   else hipLaunchKernelGGL(mfma_probe_kernel<false>, dim3((unsigned int)cus), dim3(256), 0, (hipStream_t)stream, operands, sink, iterations);
   if (flop) *flop = (double)cus * 4.0 * 16.0 * (double)iterations * (bf16 ? 32768.0 : 4096.0);
+  return (int)hipGetLastError();
+}
+
+// the partial products of one long f32 chain (see gemm_f32_brchain_kernel); *nslices = partial tiles written; 0 slices = shape not taken
+int launch_brchain_f32(const GemmArgs& a_in, float* partial, size_t partial_capacity_tiles, int* nslices, void* stream, const char** kernel_name) {
+  *nslices = 0;
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BRCHAIN"); return e && e[0] == '0'; }();
+  if (off || a_in.a_type != LIBXSMM_DATATYPE_F32 || a_in.b_type != LIBXSMM_DATATYPE_F32 || a_in.br_mode != 3 || (a_in.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B))) return 0;
+  if ((a_in.m % 32) || (a_in.n % 32) || (a_in.k % 32) || a_in.k <= 0 || a_in.m <= 0 || a_in.n <= 0) return 0;
+  const unsigned long long bits = (unsigned long long)(size_t)a_in.a | (unsigned long long)(size_t)a_in.b | (unsigned long long)a_in.br_stride_a | (unsigned long long)a_in.br_stride_b |
+    (unsigned long long)((long long)a_in.lda * 4) | (unsigned long long)((long long)a_in.ldb * 4);
+  if (bits & 15ull) return 0;                                  // 16-byte operand loads
+  GemmArgs a = a_in;
+  a.tiles_m = a.m / 32; a.tiles_n = a.n / 32;
+  const unsigned long long tiles = (unsigned long long)a.tiles_m * a.tiles_n;
+  // about 8192 waves over the chip: chunk blocks per wave, 8 waves per slice
+  unsigned long long chunk = (tiles * a.br_count + 8191ull) / 8192ull; if (chunk == 0) chunk = 1;
+  const unsigned long long slices = (a.br_count + 8ull * chunk - 1ull) / (8ull * chunk);
+  if (slices > partial_capacity_tiles || slices * tiles >= (1ull << 31)) return 0;
+  hipLaunchKernelGGL(gemm_f32_brchain_kernel, dim3((unsigned int)(slices * tiles)), dim3(512), 0, (hipStream_t)stream, a, partial, (unsigned int)chunk, (unsigned int)slices);
+  if (kernel_name) *kernel_name = "gemm_f32_brchain_kernel";
+  *nslices = (int)slices;
   return (int)hipGetLastError();
 }
 

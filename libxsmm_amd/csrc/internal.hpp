@@ -15,6 +15,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -181,8 +182,14 @@ struct KernelCtx {
   std::vector<unsigned int> h_ptr, h_idx, h_vmap;   // host pattern kept while specialisation is deferred to the first batched launch
   struct EqnPlan* eqn = nullptr;    // K_MEQN: the evaluation plan (meqn.cpp)
   // K_BCSC: patterns that arrived in HOST memory, inverted on the host once and kept on the device ([colptr | rowidx | table] per entry)
+  // Entries are immutable once published and live until the kernel is released: the hit path reads `bcsc_last` without a lock.
   struct BcscCached { std::vector<unsigned int> pattern; unsigned int* d_block = nullptr; };
-  std::vector<BcscCached> bcsc_cache;
+  std::vector<BcscCached*> bcsc_cache;            // guarded by the cache lock (miss path only); at most 4 current entries, evicted ones go to bcsc_old
+  std::vector<BcscCached*> bcsc_old;
+  std::atomic<const BcscCached*> bcsc_last{nullptr};
+  // libxsmm_hip_bcsc_bind_pattern: a DEVICE-resident pattern the caller promises not to change: its inverted table is built once
+  struct BcscBound { const void* colptr = nullptr; const void* rowidx = nullptr; unsigned long long nblk_n = 0; unsigned int* d_table = nullptr; int nkb = 0; };
+  BcscBound bcsc_bound;
   int device = 0;
   const char* kname_single = "";                 // static strings or strings owned by a never-shrinking table
   const char* kname_batched = "";
@@ -215,6 +222,11 @@ struct ThreadState {
   int last_error = 0;
   std::string last_error_msg;
   unsigned long long launches = 0;
+  // libxsmm_hip_pipeline_begin / _end: launches between the two are declared independent and rotate over `pipe_lanes` internal streams
+  int pipe_lanes = 0, pipe_cur = 0, pipe_device = -1;
+  void* pipe_user = nullptr;             // the caller's stream while a pipeline section is open
+  void* pipe_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* pipe_event[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [8]: the fork point
 };
 ThreadState& tls();
 void set_error(int code, const char* fmt, ...);
@@ -230,9 +242,11 @@ int launch_bitmask_expand(const void* bitmap, const void* vals, void* dense, uns
 int launch_stochastic_bf8(const MeltwArgs& args, void* stream);     // second pass of a TPP with *_STOCHASTIC_ROUND: f32 results -> BF8
 bool meltw_supported(const libxsmm_meltw_descriptor& d);
 int launch_mfma_probe(int bf16, const void* operands, int iterations, void* stream, double* flop);
+int launch_brchain_f32(const GemmArgs& args, float* partial, size_t partial_capacity_tiles, int* nslices, void* stream, const char** kernel_name);
 int launch_brsplit_reduce(const GemmArgs& args, const float* partial, int nsplit, void* stream);
 int launch_spmm(const SpmmArgs& args, void* stream, const char** kernel_name);
 int launch_bcsc(const BcscArgs& args, void* stream, const char** kernel_name);
+int launch_bcsc_invert(const unsigned int* colptr, const unsigned int* rowidx, unsigned int* table, int nblk_n, int nkb, void* stream);
 int launch_csparse(const CsparseArgs& args, void* stream, const char** kernel_name);
 int launch_pgemm(const PgemmArgs& args, void* stream, const char** kernel_name);
 

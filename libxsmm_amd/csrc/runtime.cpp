@@ -154,6 +154,10 @@ thread_local int t_nest = 0;
 void finish_launch(int err, const char* kname) {
   ThreadState& t = tls();
   ++t.launches;
+  if (t.pipe_lanes > 1 && t_nest == 0) {           // an open pipeline section: the next independent launch goes to the next lane
+    t.pipe_cur = (t.pipe_cur + 1) % t.pipe_lanes;
+    t.stream = t.pipe_stream[t.pipe_cur];
+  }
   if (err != 0) { set_error(err, "launch of %s failed: %s", kname ? kname : "?", hipGetErrorString((hipError_t)err)); return; }
   if (!t.async && t_nest == 0) {
     hipError_t e = hipStreamSynchronize(cur_stream());
@@ -224,10 +228,10 @@ void copy_back_staged() {
 }
 // per-thread device workspace for partial results; grows monotonically, reused in stream order
 struct Workspace { void* base = nullptr; size_t cap = 0; int device = 0; ~Workspace() { retire_block(base); } };
-thread_local Workspace t_workspace;
+thread_local Workspace t_workspace[8];    // one per pipeline lane: launches that overlap must not share partial-result buffers ([0] outside a section)
 thread_local size_t t_ws_reserved = 0;   // front part owned by an enclosing call (the slots of a matrix equation around a GEMM node)
 void* workspace(size_t nbytes_wanted) {
-  Workspace& w = t_workspace;
+  Workspace& w = t_workspace[tls().pipe_lanes > 1 ? tls().pipe_cur : 0];
   const size_t nbytes = nbytes_wanted + t_ws_reserved;
   if (w.base && w.device != cur_device()) { retire_block(w.base); w.base = nullptr; w.cap = 0; }
   if (nbytes > w.cap) {
@@ -268,7 +272,9 @@ void free_ctx_locked(KernelCtx* c) {
   dev_free(c->d_ptr); dev_free(c->d_idx); dev_free(c->d_vals); dev_free(c->d_vmap);
   if (c->jit) jit_release(c->jit);
   if (c->eqn) free_meqn_plan(c->eqn);
-  for (auto& e : c->bcsc_cache) if (e.d_block) (void)hipFree(e.d_block);
+  for (auto* e : c->bcsc_cache) { if (e->d_block) (void)hipFree(e->d_block); delete e; }
+  for (auto* e : c->bcsc_old) { if (e->d_block) (void)hipFree(e->d_block); delete e; }
+  if (c->bcsc_bound.d_table) (void)hipFree(c->bcsc_bound.d_table);
   g_slots[c->slot] = nullptr; g_free_slots.push_back(c->slot);
   delete c;
 }
@@ -571,11 +577,28 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   static const bool split_off = []() { const char* e = getenv("LIBXSMM_HIP_BRSPLIT"); return e && e[0] == '0'; }();
   const long long tiles = (long long)((a.m + 31) / 32) * ((a.n + 31) / 32);
   if (!split_off && a.br_mode == 3 && a.nbatch == 1 && !a.list_a && a.br_count >= 16 && tiles * 8 <= 1024 && (a.a_type == LIBXSMM_DATATYPE_F32 || a.a_type == LIBXSMM_DATATYPE_BF16) && a.b_type == a.a_type && a.m > 0 && a.n > 0) {
-    unsigned long long nsplit = std::min<unsigned long long>(a.br_count / 4, (unsigned long long)(2048 / tiles));
+    const size_t tile_bytes = (size_t)a.m * a.n * sizeof(float);
+    // f32 chains of whole 32 x 32 tiles: eight waves per slice add their accumulators up on chip (one partial tile per 8 * chunk blocks)
+    {
+      const size_t cap = (size_t)((a.br_count + 7) / 8);
+      float* ws8 = (float*)workspace(cap * tile_bytes);
+      if (ws8) {
+        int nslices = 0;
+        int err = launch_brchain_f32(a, ws8, cap, &nslices, tls().stream, &kname);
+        if (nslices > 0) {
+          if (err == 0) err = launch_brsplit_reduce(a, ws8, nslices, tls().stream);
+          if (kname) k->kname_single = kname;
+          finish_launch(err, kname);
+          return;
+        }
+      }
+    }
+    // everything else (bf16, transposes, ragged tiles): the chain as a batch of partial products on the tile kernels, as many waves as a launch of
+    // 4096 problems has (round 2 stopped at 2048 / tiles segments of >= 4 blocks: a quarter of the chip's waves)
+    unsigned long long nsplit = std::min<unsigned long long>(a.br_count / 2, (unsigned long long)(4096 / tiles));
     const unsigned long long chunk = (a.br_count + nsplit - 1) / nsplit;
     const unsigned long long nfull = a.br_count / chunk, tail = a.br_count - nfull * chunk;
     nsplit = nfull + (tail ? 1 : 0);
-    const size_t tile_bytes = (size_t)a.m * a.n * sizeof(float);
     float* ws = (float*)workspace(nsplit * tile_bytes);
     if (ws) {
       GemmArgs pa = a;
@@ -907,30 +930,46 @@ void run_bcsc(KernelCtx* k, const void* param) {
     // a pattern rarely changes between calls, and a call with a known pattern then costs no staging copy and no inversion kernel.
     const unsigned int* hc = (const unsigned int*)p->b.secondary; const unsigned int* hr = (const unsigned int*)p->b.tertiary;
     const unsigned int nnzb = hc[nblk_n];
-    std::vector<unsigned int> key; key.reserve(2 + nblk_n + 1 + nnzb);
-    key.push_back((unsigned int)nblk_n); key.push_back((unsigned int)nkb);
-    key.insert(key.end(), hc, hc + nblk_n + 1); key.insert(key.end(), hr, hr + nnzb);
-    static std::mutex cache_lock;
-    std::lock_guard<std::mutex> guard(cache_lock);
-    unsigned int* blockp = nullptr;
-    for (auto& e : k->bcsc_cache) if (e.pattern == key) { blockp = e.d_block; break; }
     const size_t n_ptr = (size_t)nblk_n + 1, n_idx = std::max<size_t>(1, nnzb), n_tab = std::max<size_t>(1, (size_t)nblk_n * nkb);
-    if (!blockp) {
-      std::vector<unsigned int> img(n_ptr + n_idx + n_tab, 0xffffffffu);
-      std::copy(hc, hc + n_ptr, img.begin()); std::copy(hr, hr + nnzb, img.begin() + n_ptr);
-      for (unsigned long long nb = 0; nb < nblk_n; ++nb) {
-        if (hc[nb] > hc[nb + 1] || hc[nb + 1] > nnzb) { set_error(-2, "BCSC colptr is not monotone"); return; }
-        for (unsigned int b = hc[nb]; b < hc[nb + 1]; ++b) {
-          if (hr[b] >= (unsigned int)nkb) { set_error(-2, "BCSC rowidx[%u] = %u is outside the %d k-blocks", b, hr[b], nkb); return; }
-          img[n_ptr + n_idx + nb * nkb + hr[b]] = b;
+    // key = [nblk_n, nkb, colptr..., rowidx...]; compared in place against the caller's arrays: the hit path neither allocates nor locks
+    const auto matches = [&](const KernelCtx::BcscCached* e) {
+      return e && e->pattern.size() == 2 + n_ptr + nnzb && e->pattern[0] == (unsigned int)nblk_n && e->pattern[1] == (unsigned int)nkb &&
+             std::memcmp(e->pattern.data() + 2, hc, n_ptr * sizeof(unsigned int)) == 0 &&
+             (nnzb == 0 || std::memcmp(e->pattern.data() + 2 + n_ptr, hr, (size_t)nnzb * sizeof(unsigned int)) == 0);
+    };
+    const KernelCtx::BcscCached* hit = k->bcsc_last.load(std::memory_order_acquire);
+    if (!matches(hit)) {
+      static std::mutex cache_lock;
+      std::lock_guard<std::mutex> guard(cache_lock);
+      hit = nullptr;
+      for (const auto* e : k->bcsc_cache) if (matches(e)) { hit = e; break; }
+      if (!hit) {
+        std::vector<unsigned int> img(n_ptr + n_idx + n_tab, 0xffffffffu);
+        std::copy(hc, hc + n_ptr, img.begin()); std::copy(hr, hr + nnzb, img.begin() + n_ptr);
+        for (unsigned long long nb = 0; nb < nblk_n; ++nb) {
+          if (hc[nb] > hc[nb + 1] || hc[nb + 1] > nnzb) { set_error(-2, "BCSC colptr is not monotone"); return; }
+          for (unsigned int b = hc[nb]; b < hc[nb + 1]; ++b) {
+            if (hr[b] >= (unsigned int)nkb) { set_error(-2, "BCSC rowidx[%u] = %u is outside the %d k-blocks", b, hr[b], nkb); return; }
+            img[n_ptr + n_idx + nb * nkb + hr[b]] = b;
+          }
         }
+        unsigned int* blockp = nullptr;
+        if (!hip_ok(hipMalloc((void**)&blockp, img.size() * sizeof(unsigned int)), "hipMalloc(BCSC pattern)")) return;
+        if (!hip_ok(hipMemcpy(blockp, img.data(), img.size() * sizeof(unsigned int), hipMemcpyHostToDevice), "hipMemcpy(BCSC pattern)")) return;
+        KernelCtx::BcscCached* fresh = new KernelCtx::BcscCached();
+        fresh->pattern.reserve(2 + n_ptr + nnzb);
+        fresh->pattern.push_back((unsigned int)nblk_n); fresh->pattern.push_back((unsigned int)nkb);
+        fresh->pattern.insert(fresh->pattern.end(), hc, hc + n_ptr); fresh->pattern.insert(fresh->pattern.end(), hr, hr + nnzb);
+        fresh->d_block = blockp;
+        // an evicted entry stays alive until the kernel is released: another thread may be past its lock-free hit, a launch may still read its table
+        if (k->bcsc_cache.size() >= 4) { k->bcsc_old.push_back(k->bcsc_cache.front()); k->bcsc_cache.erase(k->bcsc_cache.begin()); }
+        k->bcsc_cache.push_back(fresh);
+        k->device = cur_device();
+        hit = fresh;
       }
-      if (!hip_ok(hipMalloc((void**)&blockp, img.size() * sizeof(unsigned int)), "hipMalloc(BCSC pattern)")) return;
-      if (!hip_ok(hipMemcpy(blockp, img.data(), img.size() * sizeof(unsigned int), hipMemcpyHostToDevice), "hipMemcpy(BCSC pattern)")) return;
-      if (k->bcsc_cache.size() >= 4) { retire_block(k->bcsc_cache.front().d_block); k->bcsc_cache.erase(k->bcsc_cache.begin()); }   // a kernel in flight may still read it
-      k->bcsc_cache.push_back(KernelCtx::BcscCached{std::move(key), blockp});
-      k->device = cur_device();
+      k->bcsc_last.store(hit, std::memory_order_release);
     }
+    unsigned int* blockp = hit->d_block;
     a.colptr = blockp; a.rowidx = blockp + n_ptr; a.table = blockp + n_ptr + n_idx; a.table_ready = 1;
   } else {
   a.colptr = (const unsigned int*)device_visible(p->b.secondary, (size_t)(nblk_n + 1) * sizeof(unsigned int));
@@ -950,7 +989,10 @@ void run_bcsc(KernelCtx* k, const void* param) {
       a.rowidx = (const unsigned int*)device_visible(p->b.tertiary, (size_t)std::max(1u, nnzb) * sizeof(unsigned int));
     }
   }
-  if (nkb > 0) a.table = workspace((size_t)std::max(1, a.nblk_n) * (size_t)nkb * sizeof(unsigned int));
+  const KernelCtx::BcscBound& bd = k->bcsc_bound;
+  if (nkb > 0 && bd.d_table && bd.colptr == p->b.secondary && bd.rowidx == p->b.tertiary && bd.nblk_n == nblk_n && bd.nkb == nkb) {
+    a.table = bd.d_table; a.table_ready = 1;        // libxsmm_hip_bcsc_bind_pattern: inverted once, no inversion kernel per call
+  } else if (nkb > 0) a.table = workspace((size_t)std::max(1, a.nblk_n) * (size_t)nkb * sizeof(unsigned int));
   }
   if (!a.a || !a.bvals || !a.c || !a.rowidx) { set_error(-2, "BCSC kernel called with a NULL operand"); return; }
   const char* kname = nullptr;
@@ -1630,13 +1672,78 @@ LIBXSMM_API int libxsmm_hip_set_device(int device) {
   tls().device = device; return 0;
 }
 LIBXSMM_API int libxsmm_hip_get_device(void) { int d = 0; if (hipGetDevice(&d) != hipSuccess) return -1; return d; }
-LIBXSMM_API void libxsmm_hip_set_stream(void* s) { tls().stream = s; tls().async = 1; }
+LIBXSMM_API void libxsmm_hip_set_stream(void* s) { if (tls().pipe_lanes > 1) libxsmm_hip_pipeline_end(); tls().stream = s; tls().async = 1; }
 LIBXSMM_API void* libxsmm_hip_get_stream(void) { return tls().stream; }
 LIBXSMM_API void libxsmm_hip_set_async(int enable) { tls().async = enable ? 1 : 0; }
 LIBXSMM_API void libxsmm_hip_set_streaming_hint(int mode) { tls().stream_hint = (mode >= 0 && mode <= 2) ? mode : 0; }
 LIBXSMM_API int libxsmm_hip_get_streaming_hint(void) { return tls().stream_hint; }
 LIBXSMM_API int libxsmm_hip_get_async(void) { return tls().async; }
-LIBXSMM_API void libxsmm_hip_sync(void) { (void)hip_ok(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize"); }
+LIBXSMM_API void libxsmm_hip_sync(void) {
+  if (tls().pipe_lanes > 1) libxsmm_hip_pipeline_end();          // a synchronisation closes an open pipeline section
+  (void)hip_ok(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
+}
+// Pipeline sections: see include/libxsmm_hip.h.  Fork = an event on the caller's stream that every lane waits for; join = one event per lane that
+// the caller's stream waits for.  All of it is stream-ordered (no host synchronisation), so a section can be captured into a hipGraph: the lanes
+// become parallel branches of the graph.
+LIBXSMM_API int libxsmm_hip_bcsc_bind_pattern(libxsmm_gemmfunction kernel, const unsigned int* colptr, const unsigned int* rowidx, unsigned long long n_block_columns) {
+  KernelCtx* c = ctx_from_handle((const void*)kernel);
+  if (!c || c->kind != K_BCSC) { set_error(-3, "libxsmm_hip_bcsc_bind_pattern: not a packed BCSC kernel"); return EXIT_FAILURE; }
+  std::lock_guard<std::mutex> guard(g_lock);
+  if (c->bcsc_bound.d_table) { retire_block(c->bcsc_bound.d_table); c->bcsc_bound = KernelCtx::BcscBound(); }       // a launch in flight may still read the old table
+  if (!colptr || !rowidx) return EXIT_SUCCESS;                                                                       // unbind
+  const int nkb = (c->bk > 0 && (int)c->g.k % c->bk == 0) ? (int)c->g.k / c->bk : 0;
+  if (nkb <= 0 || n_block_columns == 0 || n_block_columns >= (1ull << 31)) { set_error(-3, "libxsmm_hip_bcsc_bind_pattern: this kernel's block shape has no inverted table"); return EXIT_FAILURE; }
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, colptr) != hipSuccess || attr.type != hipMemoryTypeDevice || hipPointerGetAttributes(&attr, rowidx) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+    (void)hipGetLastError();
+    set_error(-3, "libxsmm_hip_bcsc_bind_pattern takes DEVICE arrays (host-resident patterns are recognised and cached by the call itself)");
+    return EXIT_FAILURE;
+  }
+  unsigned int* table = nullptr;
+  if (!hip_ok(hipMalloc((void**)&table, (size_t)n_block_columns * (size_t)nkb * sizeof(unsigned int)), "hipMalloc(BCSC table)")) return EXIT_FAILURE;
+  const int err = launch_bcsc_invert(colptr, rowidx, table, (int)n_block_columns, nkb, tls().stream);       // stream-ordered before the calls that follow on this stream
+  if (err != 0) { (void)hipFree(table); set_error(err, "launch of bcsc_invert_kernel failed: %s", hipGetErrorString((hipError_t)err)); return EXIT_FAILURE; }
+  if (!tls().async) (void)hipStreamSynchronize(cur_stream());
+  c->bcsc_bound.colptr = colptr; c->bcsc_bound.rowidx = rowidx; c->bcsc_bound.nblk_n = n_block_columns; c->bcsc_bound.d_table = table; c->bcsc_bound.nkb = nkb;
+  c->device = cur_device();
+  return EXIT_SUCCESS;
+}
+LIBXSMM_API int libxsmm_hip_pipeline_begin(int lanes) {
+  ThreadState& t = tls();
+  if (!runtime_ready() || g_dryrun) return EXIT_FAILURE;
+  if (t.pipe_lanes > 1) { set_error(-3, "libxsmm_hip_pipeline_begin: a pipeline section is already open on this thread"); return EXIT_FAILURE; }
+  if (!t.async) { set_error(-3, "libxsmm_hip_pipeline_begin needs stream-ordered launches (libxsmm_hip_set_stream / libxsmm_hip_set_async)"); return EXIT_FAILURE; }
+  lanes = std::max(1, std::min(lanes, 8));
+  if (lanes == 1) return EXIT_SUCCESS;
+  if (t.pipe_device != cur_device()) {           // (re)create the lanes of this thread on the current device
+    for (int i = 0; i < 8; ++i) if (t.pipe_stream[i]) { (void)hipStreamDestroy((hipStream_t)t.pipe_stream[i]); t.pipe_stream[i] = nullptr; }
+    for (int i = 0; i < 9; ++i) if (t.pipe_event[i]) { (void)hipEventDestroy((hipEvent_t)t.pipe_event[i]); t.pipe_event[i] = nullptr; }
+    t.pipe_device = cur_device();
+  }
+  for (int i = 0; i < lanes; ++i) {
+    if (!t.pipe_stream[i] && !hip_ok(hipStreamCreateWithFlags((hipStream_t*)&t.pipe_stream[i], hipStreamNonBlocking), "hipStreamCreate(pipeline lane)")) return EXIT_FAILURE;
+    if (!t.pipe_event[i] && !hip_ok(hipEventCreateWithFlags((hipEvent_t*)&t.pipe_event[i], hipEventDisableTiming), "hipEventCreate(pipeline lane)")) return EXIT_FAILURE;
+  }
+  if (!t.pipe_event[8] && !hip_ok(hipEventCreateWithFlags((hipEvent_t*)&t.pipe_event[8], hipEventDisableTiming), "hipEventCreate(pipeline fork)")) return EXIT_FAILURE;
+  t.pipe_user = t.stream;
+  if (!hip_ok(hipEventRecord((hipEvent_t)t.pipe_event[8], (hipStream_t)t.pipe_user), "hipEventRecord(pipeline fork)")) return EXIT_FAILURE;
+  for (int i = 0; i < lanes; ++i)
+    if (!hip_ok(hipStreamWaitEvent((hipStream_t)t.pipe_stream[i], (hipEvent_t)t.pipe_event[8], 0), "hipStreamWaitEvent(pipeline fork)")) return EXIT_FAILURE;
+  t.pipe_lanes = lanes; t.pipe_cur = 0; t.stream = t.pipe_stream[0];
+  return EXIT_SUCCESS;
+}
+LIBXSMM_API int libxsmm_hip_pipeline_end(void) {
+  ThreadState& t = tls();
+  if (t.pipe_lanes <= 1) return EXIT_SUCCESS;
+  const int lanes = t.pipe_lanes;
+  t.pipe_lanes = 0; t.pipe_cur = 0; t.stream = t.pipe_user;
+  bool ok = true;
+  for (int i = 0; i < lanes; ++i) {
+    ok = hip_ok(hipEventRecord((hipEvent_t)t.pipe_event[i], (hipStream_t)t.pipe_stream[i]), "hipEventRecord(pipeline join)") && ok;
+    ok = hip_ok(hipStreamWaitEvent((hipStream_t)t.pipe_user, (hipEvent_t)t.pipe_event[i], 0), "hipStreamWaitEvent(pipeline join)") && ok;
+  }
+  return ok ? EXIT_SUCCESS : EXIT_FAILURE;
+}
 LIBXSMM_API int libxsmm_hip_get_last_error(void) { return tls().last_error; }
 LIBXSMM_API const char* libxsmm_hip_get_last_error_string(void) { return tls().last_error_msg.c_str(); }
 LIBXSMM_API void libxsmm_hip_clear_last_error(void) { tls().last_error = 0; tls().last_error_msg.clear(); }

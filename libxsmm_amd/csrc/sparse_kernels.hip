@@ -649,6 +649,11 @@ __global__ void bcsc_invert_kernel(const unsigned int* colptr_, const unsigned i
   for (unsigned int b = colptr[nb] + threadIdx.x; b < colptr[nb + 1]; b += blockDim.x) t[(long long)nb * nkb + rowidx[b]] = b;
 }
 
+int launch_bcsc_invert(const unsigned int* colptr, const unsigned int* rowidx, unsigned int* table, int nblk_n, int nkb, void* stream) {
+  hipLaunchKernelGGL(bcsc_invert_kernel, dim3((unsigned int)nblk_n), dim3(64), 0, (hipStream_t)stream, colptr, rowidx, table, nblk_n, nkb);
+  return (int)hipGetLastError();
+}
+
 // Same algorithm with the A operand staged by LDS-DMA: a k-chunk of A for the wave's 64 rows ([16 k-pairs][64 i] dwords,
 // 4 KiB) arrives with four fully coalesced global_load_lds_dwordx4 (whole 256-byte rows instead of 64-byte dword
 // segments), the MFMA operand is then read with conflict-free ds_read_b32 (rows of odd k-groups are rotated by 16 words

@@ -50,7 +50,8 @@ def test_line_fits_the_driver_tail(detail, line):
                                ("c3_csr15", "c3_csr10", "c3_fsspmdm", "c4_bcsc_bf16", "c5_fused", "variantB_f32_m32_br4096")})
     fat["cpu_baseline"] = dict(fat.get("cpu_baseline") or {"value": 1.0, "unit": "GFLOP/s", "cores": 1, "kind": "reference"}, sample="x" * 500)
     fat["config"] = dict(fat["config"], kernel="k" * 120, workload="w" * 200)
-    fat["pipelined"] = {"streams": 4, "kernel_us": 7.123, "frac": 0.8812, "f32_m16_b4096": 0.512, "bf16_m16_b4096": 0.501}
+    fat["pipelined"] = dict({"lanes": 4}, **{f"{dt}_m{m}_b4096": {"frac_hbm": 0.87654, "verified": True} for dt in ("f32", "bf16") for m in (16, 23, 32, 64)})
+    fat["mfma_power_roof_TF"] = {"bf16": 1692.8, "f32": 143.9}
     text = json.dumps(bench.compact_line(fat, os.path.join(ROOT, "bench_detail.json")), separators=(",", ":"))
     assert len(text) < 4096, len(text)
 
@@ -114,3 +115,16 @@ def test_baseline_configs_are_in_the_line(detail, line):
         assert line["configs"][key][0] == pytest.approx(e["frac_hbm"], abs=1e-4)
         assert e["frac_hbm"] == pytest.approx(e["algorithmic_bytes_per_launch"] / e["us_per_launch"] * 1e-3 / 8000.0, rel=2e-3)
     assert line["configs_verified"] is True
+
+
+def test_gpus_1_is_the_plain_run(monkeypatch):
+    """SCALE's N = 1 point is `bench.py --gpus 1 ...`, BENCH's is the same command: the flag changes nothing -- ranks come from the launcher's environment
+    (WORLD_SIZE), the workload from the other flags -- so the two lines differ by run-to-run noise only."""
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "20", "--warmup", "5"])
+    plain = vars(bench.parse())
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5"])
+    one = vars(bench.parse())
+    assert plain == one
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "args.gpus" not in src                    # nothing in the run depends on the flag: WORLD_SIZE / RANK / LOCAL_RANK decide

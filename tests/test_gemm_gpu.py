@@ -309,6 +309,9 @@ def test_illegal_descriptors_return_null():
     dict(m=64, n=64, k=64, br_type=capi.BR_STRIDE, br_count=300, beta=1, colbias=True, act=2),   # epilogue applied once, after the sum
     dict(m=64, n=64, k=64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=512, colbias=True, act=1),
     dict(m=23, n=23, k=23, br_type=capi.BR_STRIDE, br_count=77),                                  # generic kernel underneath
+    dict(m=96, n=64, k=64, br_type=capi.BR_STRIDE, br_count=100),                                 # six tiles, slices of eight waves with a ragged last one
+    dict(m=32, n=32, k=96, br_type=capi.BR_STRIDE, br_count=17, beta=1),                          # three k-chunks per block, 17 = 2 slices + 1 wave
+    dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=70000),                               # chunk > 1: nine blocks per wave
 ])
 def test_long_reduction_chain_is_split_and_matches_oracle(kw):
     api = capi.load()
@@ -323,6 +326,8 @@ def test_long_reduction_chain_is_split_and_matches_oracle(kw):
         rb, gb = case.valid_mask_bits(rmask), case.valid_mask_bits(gmask)
         assert (rb != gb).mean() < 0.02        # bits can only differ where the pre-activation is ~0
     assert api.hip_get_last_error() == 0 and launches >= 0 and n0 >= 0
+    if case.a_type == DT.F32 and kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0:
+        assert api.hip_kernel_name(handle, 0).decode() == "gemm_f32_brchain_kernel"             # eight waves per slice, reduced on chip
 
 
 @pytest.mark.parametrize("ta,tb", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])

@@ -159,3 +159,91 @@ def test_two_rank_chain_split_and_allreduce(br):
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(2))
     assert results == {0: True, 1: True}
+
+
+# ---- the other shard axes of SURVEY 8(e): the packed width P of the fixed-pattern sparse kernels, the M-blocks of BCSC, the columns of FsSpMDM ----
+def _axis_worker(rank, world, port, kind, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pyoracle
+        from libxsmm_amd.capi import DT
+        from sparse_helpers import make_bcsc, pack_vnni2, random_csr
+        orc = pyoracle.oracle()
+        rng = np.random.default_rng(17)                                   # same inputs on every rank
+        ok = True
+        if kind == "csr_p":
+            # packed CSR A-sparse: C[m][n][p] = sum_nz A[m][k] B[k][n][p]; the packed axis P (fastest in memory) is split in granules of 16:
+            # a rank holds B[:, :, b:e] and C[:, :, b:e] as its own dense packed tensors (what the caller's element loop hands a GPU)
+            M = K = 35; N = 9; P = 112
+            rowptr, colidx = random_csr(rng, M, K, 0.15)
+            vals = rng.standard_normal(len(colidx)).astype(np.float32)
+            B = rng.standard_normal((K, N, P)).astype(np.float32)
+            b, e = parallel.shard_range(P, world, rank, granule=16)
+            assert b % 16 == 0 and (e % 16 == 0 or e == P)
+            Bl = np.ascontiguousarray(B[:, :, b:e]); Cl = np.zeros((M, N, e - b), dtype=np.float32)
+            if e > b:
+                orc.lib.oracle_packed_spgemm_csr_asparse(int(DT.F32), M, N, K, e - b, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, Bl.ctypes.data, N, Cl.ctypes.data, N, 1)
+            rows = torch.from_numpy(np.ascontiguousarray(Cl.transpose(2, 0, 1)).reshape(e - b, M * N))      # one row per packed position: the gather axis
+            got = parallel.gather_to_root(rows, P, root=0, granule=16)
+            count = P
+            if rank == 0:
+                full = np.zeros((M, N, P), dtype=np.float32)
+                orc.lib.oracle_packed_spgemm_csr_asparse(int(DT.F32), M, N, K, P, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, B.ctypes.data, N, full.ctypes.data, N, 1)
+                ok = bool(np.array_equal(got.numpy().reshape(P, M, N).transpose(1, 2, 0), full))
+        elif kind == "bcsc_mb":
+            # BCSC: C[mb][n][m]; the M-blocks are independent: rank r owns blocks [b, e) of A and C, the pattern and the B blocks are replicated
+            M, N, K, mb, bk, bn = 64, 64, 128, 5, 32, 16
+            colptr, rowidx, bvals = make_bcsc(rng, K, N, bk, bn, 0.3, DT.BF16)
+            A = ((rng.integers(-4, 6, mb * K * M) / 10).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+            A_run = pack_vnni2(A, mb, K, M)
+            b, e = parallel.shard_range(mb, world, rank)
+            Cl = np.zeros((e - b, N * M), dtype=np.uint16)
+            if e > b:
+                orc.lib.oracle_packed_spgemm_bcsc(int(DT.BF16), int(DT.BF16), M, N, K, e - b, bk, bn, 1, A_run[b * K * M:].ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, Cl.ctypes.data, 1)
+            got = parallel.gather_to_root(torch.from_numpy(Cl.view(np.int16)), mb, root=0)
+            count = mb
+            if rank == 0:
+                full = np.zeros((mb, N * M), dtype=np.uint16)
+                orc.lib.oracle_packed_spgemm_bcsc(int(DT.BF16), int(DT.BF16), M, N, K, mb, bk, bn, 1, A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, full.ctypes.data, 1)
+                ok = bool(np.array_equal(got.numpy().view(np.uint16), full))
+        else:
+            # FsSpMDM: row-major C[M x N] = A B; the columns N are split in granules of the handle's N-block (column panels of B and C)
+            M = K = 35; N = 200; nb = 48
+            rowptr, colidx = random_csr(rng, M, K, 0.15)
+            vals = rng.standard_normal(len(colidx))
+            B = rng.standard_normal((K, N))
+            b, e = parallel.shard_range(N, world, rank, granule=nb)
+            Bl = np.ascontiguousarray(B[:, b:e]); Cl = np.zeros((M, e - b))
+            if e > b:
+                orc.lib.oracle_fsspmdm(int(DT.F64), M, e - b, K, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, Bl.ctypes.data, e - b, Cl.ctypes.data, e - b, 1)
+            got = parallel.gather_to_root(torch.from_numpy(np.ascontiguousarray(Cl.T)), N, root=0, granule=nb)     # one row per column of C
+            count = N
+            if rank == 0:
+                full = np.zeros((M, N))
+                orc.lib.oracle_fsspmdm(int(DT.F64), M, N, K, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, B.ctypes.data, N, full.ctypes.data, N, 1)
+                ok = bool(np.array_equal(got.numpy().T, full))
+        if rank != 0:
+            ok = ok and got is None
+        t = torch.tensor([float(e - b)])
+        dist.all_reduce(t)                                                # every unit of the axis owned exactly once
+        q.put((rank, bool(ok) and int(t.item()) == count))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["csr_p", "bcsc_mb", "fsspmdm_n"])
+def test_two_rank_split_of_the_packed_axes(kind):
+    """packed CSR splits the packed width P, BCSC its M-blocks, FsSpMDM its columns; each rank computes its slice only (oracle on
+    CPU), no data-path collective, the optional result gather goes straight to the consumer."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000) + len(kind)
+    procs = [ctx.Process(target=_axis_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=10) for _ in range(2))
+    assert results == {0: True, 1: True}

@@ -1,0 +1,99 @@
+"""libxsmm_hip_pipeline_begin / _end (include/libxsmm_hip.h): launches the caller declares independent rotate over internal streams and may overlap.
+By definition the result equals the same launches issued one after the other; a section is stream-ordered end to end (fork / join by events), so it
+can be captured into a hipGraph, and launches that need partial-result workspaces (a long batch-reduce chain split over the chip) get one per lane."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from libxsmm_amd import capi  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dtype, m, batch, br, nsets):
+    import torch
+    import bench
+    api = capi.load()
+    dev = torch.device("cuda:0")
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    w = bench.Workload(api, dev, dtype, m, batch, br=br, nsets=nsets, hint=0)
+    return api, w
+
+
+@pytest.mark.parametrize("dtype,m,batch,br", [("f32", 32, 512, 1), ("bf16", 64, 128, 2), ("f32", 16, 1024, 1), ("f32", 32, 1, 256)])
+@pytest.mark.parametrize("lanes", [2, 4, 8])
+def test_section_equals_the_serial_launches(dtype, m, batch, br, lanes):
+    import torch
+    api, w = _setup(dtype, m, batch, br, nsets=8)
+    for s in range(8):
+        w.step(s)
+    api.hip_sync(); api.check()
+    serial = [c.clone() for c in w.C]
+    for c in w.C:
+        c.fill_(7)
+    torch.cuda.synchronize()
+    assert api.hip_pipeline_begin(lanes) == 0
+    for s in range(8):
+        w.step(s)                    # eight independent launches: every set has its own A, B and C
+    assert api.hip_pipeline_end() == 0
+    api.hip_sync(); api.check()
+    for s in range(8):
+        assert torch.equal(w.C[s], serial[s]), s
+    ok, err, _ = w.verify(3)
+    assert ok, err
+
+
+def test_section_inside_a_graph_capture():
+    import torch
+    api, w = _setup("f32", 32, 4096, 1, nsets=8)
+    for s in range(8):
+        w.step(s)
+    api.hip_sync(); api.check()
+    serial = [c.clone() for c in w.C]
+    for c in w.C:
+        c.zero_()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        api.hip_set_stream(side.cuda_stream)
+        assert api.hip_pipeline_begin(4) == 0        # lanes are created here, outside the capture
+        w.step(0)
+        assert api.hip_pipeline_end() == 0
+        side.synchronize()
+        w.C[0].zero_()
+        side.synchronize()
+        g.capture_begin()
+        assert api.hip_pipeline_begin(4) == 0
+        for s in range(8):
+            w.step(s)
+        assert api.hip_pipeline_end() == 0
+        g.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(); api.check()
+    for s in range(8):
+        assert torch.equal(w.C[s], serial[s]), s
+
+
+def test_section_rules():
+    import torch
+    api = capi.load()
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    assert api.hip_pipeline_begin(1) == 0 and api.hip_pipeline_end() == 0          # one lane: nothing to do
+    assert api.hip_pipeline_begin(3) == 0
+    assert api.hip_pipeline_begin(2) != 0                                          # no nesting
+    api.hip_clear_last_error()
+    api.hip_sync()                                                                 # a synchronisation closes the section
+    assert api.hip_pipeline_begin(2) == 0 and api.hip_pipeline_end() == 0
+    api.hip_set_async(0)
+    assert api.hip_pipeline_begin(2) != 0                                          # synchronous calls cannot overlap
+    api.hip_clear_last_error()
+    api.hip_set_async(1)

@@ -340,6 +340,53 @@ def test_bcsc(a_type, c_type, vnni, M, N, K, mb, bk, bn, keep, beta0):
     capi.Api.call(h, p)
     api.hip_sync(); api.check()
     assert np.array_equal(_host(dC2, got.dtype), got)
+    # a bound device pattern (libxsmm_hip_bcsc_bind_pattern): the table is inverted once, calls with exactly these pointers launch the GEMM kernel alone
+    if K % bk == 0:
+        assert api.hip_bcsc_bind_pattern(h, dcp.data_ptr(), dri.data_ptr(), N // bn) == 0
+        for _ in range(2):
+            dC3 = _dev(C0.copy())
+            p.b.secondary, p.b.tertiary, p.c.primary = dcp.data_ptr(), dri.data_ptr(), dC3.data_ptr()
+            capi.Api.call(h, p)
+            api.hip_sync(); api.check()
+            assert np.array_equal(_host(dC3, got.dtype), got)
+        # other pointers fall back to the per-call inversion; a host pattern in between is still recognised by content
+        dcp2, dri2, dC4 = _dev(colptr), _dev(rowidx), _dev(C0.copy())
+        p.b.secondary, p.b.tertiary, p.c.primary = dcp2.data_ptr(), dri2.data_ptr(), dC4.data_ptr()
+        capi.Api.call(h, p)
+        api.hip_sync(); api.check()
+        assert np.array_equal(_host(dC4, got.dtype), got)
+        assert api.hip_bcsc_bind_pattern(h, None, None, 0) == 0                       # unbind
+        assert api.hip_bcsc_bind_pattern(h, colptr.ctypes.data, rowidx.ctypes.data, N // bn) != 0     # host arrays are not bound (they are cached by content)
+        api.hip_clear_last_error()
+    api.release_kernel(h)
+
+
+def test_bcsc_host_pattern_cache_keeps_several_patterns_and_survives_eviction():
+    """The host-pattern cache of a BCSC kernel: hit = the caller's arrays compared in place against the last entry (no allocation, no lock);
+    six different patterns through one handle exceed its four entries; every call must use ITS pattern, also when an evicted one returns."""
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(21)
+    M, N, K, mb, bk, bn = 64, 64, 256, 3, 32, 16
+    A = rand_values(rng, mb * K * M, DT.BF16)
+    A_run = pack_vnni2(A, mb, K, M)
+    dA = _dev(A_run)
+    shape = capi.gemm_shape(mb, 0, K, K, 0, N, DT.BF16, DT.BF16, DT.BF16, DT.F32)
+    h = api.create_packed_spgemm_bcsc(shape, GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    pats = [make_bcsc(np.random.default_rng(100 + i), K, N, bk, bn, 0.2 + 0.1 * i, DT.BF16) for i in range(6)]
+    nblk = C.c_ulonglong(N // bn)
+    for order in (range(6), (0, 5, 0, 1, 4, 4, 2)):                                      # the second pass revisits evicted and cached patterns
+        for i in order:
+            colptr, rowidx, bvals = pats[i]
+            ref = np.zeros(mb * N * M, dtype=np.uint16)
+            orc.lib.oracle_packed_spgemm_bcsc(DT.BF16, DT.BF16, M, N, K, mb, bk, bn, 1, A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, 1)
+            dB, dC = _dev(bvals), _dev(np.zeros(mb * N * M, dtype=np.uint16))
+            p = capi.GemmParam()
+            p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = \
+                dA.data_ptr(), dB.data_ptr(), colptr.ctypes.data, rowidx.ctypes.data, C.addressof(nblk), dC.data_ptr()
+            capi.Api.call(h, p)
+            api.hip_sync(); api.check()
+            assert normf_rel(ref, _host(dC, np.uint16), DT.BF16) <= 5e-3, i
     api.release_kernel(h)
 
 
