@@ -49,7 +49,7 @@ from libxsmm_amd import capi  # noqa: E402
 from libxsmm_amd.capi import DT, GEMM_FLAG  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0}
+MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}
 L3_BYTES = 256 * 2 ** 20
 
 
@@ -83,13 +83,16 @@ def parse():
 
 
 def gen_values(n, bf16, dev, gen):
-    """Reference-style data [samples/xgemm/gemm_kernel.c:837-865]: multiples of 0.1 in [-0.4, 0.5]; bf16 by truncation."""
+    """Reference-style data [samples/xgemm/gemm_kernel.c:837-865]: multiples of 0.1 in [-0.4, 0.5]; bf16 by truncation (bf16 = "f16": IEEE halves, RNE)."""
     out = torch.empty(n, dtype=torch.int16 if bf16 else torch.float32, device=dev)
     step = 1 << 26
     for o in range(0, n, step):
         c = min(step, n - o)
         v = torch.randint(-4, 6, (c,), generator=gen, device=dev, dtype=torch.int32).float() / 10
-        out[o:o + c] = (v.view(torch.int32) >> 16).to(torch.int16) if bf16 else v
+        if bf16 == "f16":
+            out[o:o + c] = v.to(torch.float16).view(torch.int16)
+        else:
+            out[o:o + c] = (v.view(torch.int32) >> 16).to(torch.int16) if bf16 else v
     return out
 
 
@@ -100,7 +103,7 @@ class Workload:
 
     def __init__(self, api, dev, dtype="f32", m=32, batch=4096, br=1, beta=0, fused=0, mode="stream", grid=None, nsets=0, seed=555, hint=None, tag=""):
         self.api, self.dev, self.dtype, self.m, self.br, self.beta, self.fused, self.mode, self.tag = api, dev, dtype, m, br, beta, fused, mode, tag
-        self.bf16 = dtype == "bf16"
+        self.bf16 = "f16" if dtype == "f16" else dtype == "bf16"       # truthy: 16-bit operands in VNNI-2 layout
         es = 2 if self.bf16 else 4
         self.es = es
         blk = m * m * es
@@ -127,7 +130,7 @@ class Workload:
         self.B = [gen_values(nb * m * m, self.bf16, dev, gen) for _ in range(nsets)]
         self.C = [torch.zeros(batch * m * m, dtype=tdt, device=dev) for _ in range(nsets)]
         self.D = gen_values(m, self.bf16, dev, gen) if fused else None
-        t = DT.BF16 if self.bf16 else DT.F32
+        t = DT.F16 if dtype == "f16" else (DT.BF16 if self.bf16 else DT.F32)
         self.t = t
         self.flags = (0 if beta else GEMM_FLAG.BETA_0) | (GEMM_FLAG.VNNI_A if self.bf16 else 0)
         self.shape = capi.gemm_shape(m, m, m, m, m, m, t, t, t, DT.F32)
@@ -190,7 +193,9 @@ class Workload:
             if self.fused:
                 p.d.primary = d_host.ctypes.data
             orc.gemm(p, desc)
-            if self.bf16:
+            if self.dtype == "f16":
+                r = ref.view(np.float16).astype(np.float64); g = got.view(np.float16).astype(np.float64)
+            elif self.bf16:
                 r = (ref.astype(np.uint32) << 16).view(np.float32).astype(np.float64); g = (got.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
             else:
                 r = ref.astype(np.float64); g = got.astype(np.float64)

@@ -709,6 +709,19 @@ __device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
   const f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwbf16x2));
 }
+// the same for IEEE halves (RNE, the conversion the reference's f32 -> f16 helper performs [ref: src/libxsmm_math.c libxsmm_convert_f32_to_f16])
+typedef _Float16 hwf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int cvt_pk_f16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwf16x2));
+}
+__device__ __forceinline__ unsigned int cvt_pk_16(bool f16, float lo, float hi) { return f16 ? cvt_pk_f16(lo, hi) : cvt_pk_bf16(lo, hi); }
+// one 32 x 32 x 16 step on 16-bit operands: bf16 or (F16) IEEE halves -- same operand layout, same rate
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <bool F16> __device__ __forceinline__ f32x16 mfma_16bit(const u32x4& b, const u32x4& a, const f32x16& acc) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), acc, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
 template <int ACT> __device__ __forceinline__ float act_fixed(float x) {
   if (ACT == 1 || ACT == 2) return (x <= 0.0f) ? 0.0f : x;
   if (ACT == 3) return __frcp_rn(1.0f + __expf(-x));
@@ -743,13 +756,14 @@ __device__ __forceinline__ void tile_store_impl(const f32x16& acc, const GemmArg
       });
     }
   }
+  const bool c_f16 = p.c_type == LIBXSMM_DATATYPE_F16;            // wave-uniform: the 16-bit output is bf16 or IEEE half
   if (!CF32 && pack2) {
     const bool odd = (lane & 1) != 0;
     const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
     GM unsigned short* base = (GM unsigned short*)q.c + (long long)(t.j0 + 4 * t.h + (odd ? 1 : 0)) * p.ldc + (t.i & ~1);
     static_for<8>([&](auto gc) {
       constexpr int g = gc.value, r0 = 2 * g, jr = (r0 & 3) + 8 * (r0 >> 2);
-      const unsigned int w = cvt_pk_bf16(act_fixed<ACT>(acc[r0]), act_fixed<ACT>(acc[r0 + 1]));
+      const unsigned int w = cvt_pk_16(c_f16, act_fixed<ACT>(acc[r0]), act_fixed<ACT>(acc[r0 + 1]));
       const unsigned int n = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
       st_stream<NT>((GM unsigned int*)(base + (long long)jr * p.ldc), (unsigned int)__builtin_amdgcn_perm(n, w, sel));
     });
@@ -761,7 +775,7 @@ __device__ __forceinline__ void tile_store_impl(const f32x16& acc, const GemmArg
     const bool ok = EXACT || (t.ivalid && j < p.n);
     const float y = act_fixed<ACT>(acc[r]);
     if (out_f32) { if (ok) st_stream<NT>((GM float*)q.c + (long long)j * p.ldc + t.i, y); }
-    else if (ok) st_stream<NT>((GM unsigned short*)q.c + (long long)j * p.ldc + t.i, f32_to_bf16_rne(y));
+    else if (ok) st_stream<NT>((GM unsigned short*)q.c + (long long)j * p.ldc + t.i, c_f16 ? __builtin_bit_cast(unsigned short, (_Float16)y) : f32_to_bf16_rne(y));
   });
 }
 // wave-uniform dispatch on the activation
@@ -1988,7 +2002,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
 // The LDS image is wave-private: no barrier, only s_waitcnt.
 // ------------------------------------------------------------------------------------------------
 // AUX: cache-policy bits of the operand loads (0 default, 2 = nt for launches whose operands cannot be cache resident, see launch_gemm)
-template <int MT, int NT, int AUX>
+template <int MT, int NT, int AUX, bool F16 = false>      // F16: IEEE halves (beta = 0, plain epilogue: launch_gemm), same layouts
 __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds_all[4][2][NT * 2048];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
@@ -2048,7 +2062,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
       static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0); });
+        acc[mt][nt] = mfma_16bit<F16>(bfr[nt][s], af[mt][s], acc[mt][nt]); });
   };
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
@@ -2083,7 +2097,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
 // (wi, wj) runs its two 32x32x16 MFMAs from conflict-free LDS reads.  Two images: a k = 64 problem has all its operand bytes in flight
 // before the first MFMA.  Any batch form, any epilogue (batch_ptrs / tile_init / tile_store).
 // ------------------------------------------------------------------------------------------------
-template <int AUX>
+template <int AUX, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned int lds_all[2][2048];       // per image: A dwords [16][64], then B bytes [64][64]
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2129,7 +2143,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
     if (t + 2 < total) { wg_barrier(); issue(t + 2); }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[s2]), __builtin_bit_cast(bf16x8, af[s2]), acc, 0, 0, 0);
+      acc = mfma_16bit<F16>(bfr[s2], af[s2], acc);
   }
   tile_store<true, false>(acc, p, q, tc);
 }
@@ -2180,7 +2194,7 @@ template <int TI, int TJ, int RA> __device__ __forceinline__ void bm_region_sche
     });
   });
 }
-template <int FORM, int PE, bool K16, int NW = 4, int TI = 4, int TJ = 4, int ABL = 0>
+template <int FORM, int PE, bool K16, int NW = 4, int TI = 4, int TJ = 4, int ABL = 0, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, 1) void gemm_bf16_macro_kernel(GemmArgs p) {
   static_assert(NW * TI * TJ == 64 && (NW == 4 || NW == 8), "256 x 256 macro tile");
   constexpr unsigned int PPM = 256 / PE;                           // problems per macro-tile edge
@@ -2291,7 +2305,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_bf16_macro_kernel(GemmArgs p)
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
       for (int tj = 0; tj < TJ; ++tj)
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[tj]), __builtin_bit_cast(bf16x8, f.a[ti]), acc[ti][tj], 0, 0, 0);
+        acc[ti][tj] = mfma_16bit<F16>(f.b[tj], f.a[ti], acc[ti][tj]);
   };
   // prologue: stages 0 .. 2 and the A half of stage 3 (as far as they exist)
   for (unsigned int u = 0; u < NSLOT; ++u) {
@@ -2361,13 +2375,14 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_bf16_macro_kernel(GemmArgs p)
       GM char* base = (GM char*)p.c + row_off(ti, odd ? 1u : 0u);
       static_for<8>([&](auto gc) {
         constexpr int r0 = 2 * gc.value, jr = (r0 & 3) + 8 * (r0 >> 2);
-        const unsigned int wv = cvt_pk_bf16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]);
+        const unsigned int wv = F16 ? cvt_pk_f16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]) : cvt_pk_bf16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]);
         const unsigned int nv = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)wv, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
         st_stream((GM unsigned int*)(base + col_off(col0 + (unsigned int)jr + (odd ? 1u : 0u))), (unsigned int)__builtin_amdgcn_perm(nv, wv, sel));
       });
     } else {
       GM char* base = (GM char*)p.c + row_off(ti, 0u);
-      static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream((GM unsigned short*)(base + col_off(col0 + (unsigned int)((r & 3) + 8 * (r >> 2)))), f32_to_bf16_rne(acc[ti][tj][r])); });
+      static_for<16>([&](auto rc) { constexpr int r = rc.value; st_stream((GM unsigned short*)(base + col_off(col0 + (unsigned int)((r & 3) + 8 * (r >> 2)))),
+                                                                            F16 ? __builtin_bit_cast(unsigned short, (_Float16)acc[ti][tj][r]) : f32_to_bf16_rne(acc[ti][tj][r])); });
     }
     asm volatile("" ::: "memory");
   });
@@ -2940,9 +2955,11 @@ static bool f32_lean_ok(const GemmArgs& a) {
 static bool bf16_macro_ok(const GemmArgs& a, bool& k16) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_BLOCKED"); return e && e[0] == '0'; }();
   if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.br_count == 0) return false;
-  if (a.a_type != LIBXSMM_DATATYPE_BF16 || a.b_type != LIBXSMM_DATATYPE_BF16 || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
+  const bool f16 = a.a_type == LIBXSMM_DATATYPE_F16;            // IEEE halves: same layouts, v_mfma_f32_32x32x16_f16 (64 / 32 tiles, f32 accumulation only)
+  if ((a.a_type != LIBXSMM_DATATYPE_BF16 && !f16) || a.b_type != a.a_type || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
   if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || a.vnni_c || a.colbias || a.act || !(a.flags & LIBXSMM_GEMM_FLAG_BETA_0)) return false;
-  if (a.c_type != LIBXSMM_DATATYPE_BF16 && a.c_type != LIBXSMM_DATATYPE_F32) return false;
+  if (a.c_type != a.a_type && a.c_type != LIBXSMM_DATATYPE_F32) return false;
+  if (f16 && (a.comp_f16 || a.m == 16)) return false;
   if (a.m != a.n || (a.m != 64 && a.m != 32 && a.m != 16) || a.k <= 0) return false;
   k16 = (a.k % 32) != 0;
   if (k16 && (a.k != 16 || (a.br_count & 1ull) || a.br_mode != 3)) return false;       // a stage of 32 k = two consecutive blocks of 16
@@ -3298,6 +3315,20 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         const dim3 mgrid((a.batch_inner / ppm) * ((a.nbatch / a.batch_inner) / ppm));
         if (kernel_name) *kernel_name = "gemm_bf16_macro_kernel";
         const int v = a.m == 64 ? 0 : (a.m == 32 ? 1 : (k16 ? 3 : 2));
+        if (a.a_type == LIBXSMM_DATATYPE_F16) {       // packed f16 or f32 C (element-wise f16 stores: the single-problem kernels)
+          if (form == 2) goto no_macro;
+          using k16fn = void (*)(GemmArgs);
+          static const k16fn f16_table[2][2] = {{gemm_bf16_macro_kernel<0, 64, false, 4, 4, 4, 0, true>, gemm_bf16_macro_kernel<0, 32, false, 4, 4, 4, 0, true>},
+                                                {gemm_bf16_macro_kernel<1, 64, false, 4, 4, 4, 0, true>, gemm_bf16_macro_kernel<1, 32, false, 4, 4, 4, 0, true>}};
+          static const bool f16_ok = []() {
+            for (int f = 0; f < 2; ++f)
+              for (int w = 0; w < 2; ++w) { if (hipFuncSetAttribute((const void*)f16_table[f][w], hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) return false; }
+            return true; }();
+          if (!f16_ok) { (void)hipGetLastError(); goto no_macro; }
+          if (kernel_name) *kernel_name = "gemm_f16_macro_kernel";
+          hipLaunchKernelGGL(f16_table[form][v], mgrid, dim3(256), 131072, st, a);
+          return (int)hipGetLastError();
+        }
 #ifdef LIBXSMM_HIP_EXPERIMENTS      // make -C libxsmm_amd/csrc EXPERIMENTS=1: the ablations / wave layouts of profiles/r03_bf16_macro_ablation.txt (tools/bb_ablate.sh)
         static const int abl = []() { const char* e = getenv("LIBXSMM_HIP_BB_ABL"); return e ? atoi(e) : 0; }();      // timing experiments (wrong results)
         static const int shape = []() { const char* e = getenv("LIBXSMM_HIP_BM_SHAPE"); return e ? atoi(e) : 0; }();   // experiments: 824 = 8 waves of 2 x 4 tiles, 842 = 4 x 2
@@ -3319,6 +3350,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       (void)hipGetLastError();
     }
   }
+  no_macro:
   // 16 x 16 problems with a plain epilogue: four problems per wave
   if (p16_ok(a)) {
     const bool bf16 = a.a_type == LIBXSMM_DATATYPE_BF16;
@@ -3365,6 +3397,10 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       return (int)hipGetLastError();
     }
   }
+  // IEEE halves take the bf16 fast paths when nothing but the product is asked for: beta = 0 (the reference adds beta * C AFTER the sum for halves),
+  // f32 accumulation, f16 or f32 C, no fused operator
+  const bool f16_fast = a.a_type == LIBXSMM_DATATYPE_F16 && a.b_type == LIBXSMM_DATATYPE_F16 && !a.comp_f16 && (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && !a.colbias && !a.act && !a.vnni_c &&
+    (a.c_type == LIBXSMM_DATATYPE_F16 || a.c_type == LIBXSMM_DATATYPE_F32);
   switch (pl.path) {
     case P_F32_T16: grid = wave_grid(16, 16); hipLaunchKernelGGL(gemm_mfma_f32_t16_kernel, grid, dim3(256), 0, st, a); break;
     case P_F32_1x1:
@@ -3441,6 +3477,12 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_BF16_1x1:
       grid = wave_grid(32, 32);
+      if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && bf16_stream_ok(a)) {       // the bf16 streaming kernel on IEEE halves
+        if (kernel_name) *kernel_name = "gemm_f16_stream_kernel<1,1>";
+        if (stream_nt(a, 2, typesize_c(a))) hipLaunchKernelGGL((gemm_bf16_stream_kernel<1, 1, 2, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_stream_kernel<1, 1, 0, true>), grid, dim3(256), 0, st, a);
+        break;
+      }
       if (a.a_type == LIBXSMM_DATATYPE_F16) {
         if (kernel_name) *kernel_name = "gemm_mfma_f16_kernel<1,1>";
         if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true, true>), grid, dim3(256), 0, st, a);
@@ -3457,6 +3499,18 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_BF16_2x2:
       grid = wave_grid(64, 64);
+      if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && a.m == 64 && a.n == 64 && !a.batch_inner && bf16_wg64_ok(a)) {
+        a.map2d_shift = 0;
+        grid = dim3(a.nbatch);
+        if (kernel_name) *kernel_name = "gemm_f16_wg64_kernel";
+        hipLaunchKernelGGL((gemm_bf16_wg64_kernel<0, true>), grid, dim3(256), 0, st, a);
+        break;
+      }
+      if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && bf16_stream_ok(a)) {
+        if (kernel_name) *kernel_name = "gemm_f16_stream_kernel<2,2>";
+        hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2, 0, true>), grid, dim3(256), 0, st, a);
+        break;
+      }
       if (a.a_type == LIBXSMM_DATATYPE_F16) {
         if (kernel_name) *kernel_name = "gemm_mfma_f16_kernel<2,2>";
         if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true, true>), grid, dim3(256), 0, st, a);

@@ -18,7 +18,7 @@ def _blocked(dtype, m, ni, nj, br, fused=False, seed=3):
     import torch
     api = capi.load()
     dev = torch.device("cuda:0")
-    bf16 = dtype == DT.BF16
+    bf16 = dtype in (DT.BF16, DT.F16)          # "16-bit, VNNI-2 A"
     es = 2 if bf16 else 4
     rng = np.random.default_rng(seed)
     mm = m * m
@@ -63,7 +63,11 @@ def _blocked(dtype, m, ni, nj, br, fused=False, seed=3):
             capi.Api.call(h, q)
     api.hip_sync(); api.check()
     got2, got1 = C2.cpu().numpy().view(npdt), C1.cpu().numpy().view(npdt)
-    if m == 16 and dtype == DT.F32:
+    if dtype == DT.F16:
+        # the macro-tile kernel feeds an MFMA step k 0..15 of a 32-deep chunk, the streaming kernel k {0..7, 16..23}: products of halves carry 22
+        # significant bits, so the two f32 summation orders differ in the last bits (bf16 products carry 16: those sums are exact on this data)
+        assert normf_rel(got1, got2, dtype) < 1e-3
+    elif m == 16 and dtype == DT.F32:
         # single 16^3 calls run on the 16x16x4 MFMA (k summed in a lane-group-interleaved order), the blocked 2-D form on 32x32x2 in natural
         # order: the same products, a different but equally valid f32 summation order -- equal to rounding, both pinned to the oracle below
         assert normf_rel(got1, got2, dtype) < 1e-6
@@ -111,6 +115,11 @@ def test_1x1_2d_batch_with_a_long_chain(dtype, m, br):
     """count_i = count_j = 1 with br >= 16 reaches the chain-split path (partial products as a batch, then a reduce): the partial batch is a
     plain 1-D one whatever the caller's batch form was (round-2 advisor finding, csrc/runtime.cpp)."""
     _blocked(dtype, m, 1, 1, br)
+
+
+@pytest.mark.parametrize("m,ni,nj,br", [(64, 4, 4, 3), (32, 8, 8, 4), (64, 8, 4, 9)])
+def test_f16_2d_batch_runs_on_the_macro_tile_kernel(m, ni, nj, br):
+    assert _blocked(DT.F16, m, ni, nj, br) == "gemm_f16_macro_kernel"
 
 
 def test_bf16_fused_2d_batch_steps_the_bias_with_i():

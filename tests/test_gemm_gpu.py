@@ -172,6 +172,26 @@ def test_f16_gemm_matches_oracle(kw):
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F16, DT.F16, DT.F16, DT.F32), F.TRANS_A | F.BETA_0, 0) is None
 
 
+@pytest.mark.parametrize("kw,kernel", [
+    (dict(m=32, n=32, k=32, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3), "gemm_f16_stream_kernel<1,1>"),
+    (dict(m=32, n=32, k=96, c_type=DT.F32, flags=F.VNNI_A), "gemm_f16_stream_kernel<1,1>"),
+    (dict(m=64, n=64, k=64, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2), "gemm_f16_wg64_kernel"),
+    (dict(m=64, n=64, k=128, c_type=DT.F32, flags=F.VNNI_A), "gemm_f16_wg64_kernel"),
+    (dict(m=128, n=64, k=64, c_type=DT.F16, flags=F.VNNI_A), "gemm_f16_stream_kernel<2,2>"),
+    (dict(m=64, n=64, k=64, c_type=DT.F16, flags=F.VNNI_A, ldc=65), "gemm_f16_wg64_kernel"),          # odd ldc: element-wise half stores
+])
+def test_f16_takes_the_bf16_fast_paths(kw, kernel):
+    """beta = 0 halves run on the streaming / one-problem-per-workgroup kernels of bf16 (same VNNI-2 layout, v_mfma_f32_32x32x16_f16, one RNE to f16)."""
+    api = capi.load()
+    case = GemmCase(seed=778, batch=37, a_type=DT.F16, **kw)
+    got, _, handle = case.run_gpu(batched=True)
+    ref, _ = case.run_oracle()
+    name = api.hip_kernel_name(handle, 1).decode()
+    assert name == kernel, name
+    err = normf_rel(case.valid_region(ref), case.valid_region(got), case.c_type)
+    assert err < (1e-3 if case.c_type == DT.F16 else TOL_F32), f"{name}: normf_rel={err}"
+
+
 def test_f64_gemm_is_bit_identical():
     for kw in (dict(m=9, n=11, k=13, beta=1, br_type=capi.BR_STRIDE, br_count=2), dict(m=32, n=32, k=32), dict(m=7, n=5, k=3, flags=F.TRANS_A | F.TRANS_B)):
         _check(GemmCase(seed=5, batch=2, a_type=DT.F64, **kw), expect_kernel="generic")

@@ -332,6 +332,8 @@ def main():
                    lambda: brgemm(api, 16, "f32", 16384), lambda: brgemm(api, 32, "f32", 4096, beta=1), lambda: brgemm(api, 32, "f32", 1024, br=8),
                    lambda: brgemm(api, 32, "f32", 1, br=4096), lambda: brgemm(api, 64, "bf16", 1, br=4096),
                    lambda: brgemm_i8(api, 64, 2 ** 17, ua=True), lambda: brgemm_i8(api, 64, 2 ** 17, ua=False)]     # config #2 variant B: one long chain
+    if "f16" in only:        # IEEE halves on the bf16 fast paths (round 3): streaming 32^3 / 64^3, fused none, and the blocked form through tools/bb_sweep.py --dtype f16
+        makers += [lambda: brgemm(api, 32, "f16", 2 ** 18), lambda: brgemm(api, 64, "f16", 2 ** 16), lambda: brgemm(api, 32, "f16", 4096), lambda: brgemm(api, 64, "f16", 4096)]
     if "ragged" in only:     # the odd small shapes (BASELINE config #1 is 23^3), steady state and a 4096-problem launch
         makers += [lambda: brgemm(api, 13, "f32", 2 ** 18), lambda: brgemm(api, 23, "f32", 2 ** 17), lambda: brgemm(api, 23, "f32", 4096),
                    lambda: brgemm(api, 40, "f32", 2 ** 15), lambda: brgemm(api, 50, "f32", 2 ** 15), lambda: brgemm(api, 72, "f32", 2 ** 14),
