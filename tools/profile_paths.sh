@@ -9,7 +9,7 @@
 # The raw CSVs stay under gpurun_out/prof_<tag>/ (scratch, gzipped); tools/summarize_profiles.py <tag> distils them into
 # gpurun_out/prof_<tag>/summary/, which is what gets copied to profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 WHAT=${2:-all}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG

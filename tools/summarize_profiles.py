@@ -22,7 +22,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
@@ -31,6 +31,8 @@ SIMDS = 128        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (8 x the 
 
 
 def ours(name):
+    if "mfma_probe_kernel" in name:          # libxsmm_hip_probe_mfma: a diagnostic outside the launch manifest
+        return False
     return "xamd::" in name or name.startswith("spmm_jit") or name.startswith("pgemm_jit") or name.startswith("meqn_")
 
 
@@ -59,12 +61,22 @@ def split_by_manifest(disp, manifest):
     """Walks the dispatches in order and hands each manifest entry its `launches_executed` rows; returns label -> rows of the TIMED launches."""
     res, pos = {}, 0
     for e in manifest["entries"]:
-        n, nt = e["launches_executed"], e["launches_timed"]
+        k = int(e.get("kernels_per_launch", 1))          # a library call may be several kernels (a split chain: partial products + reduction)
+        n, nt = e["launches_executed"] * k, e["launches_timed"] * k
         seg = disp[pos:pos + n]
         pos += n
         if len(seg) < n:
             print(f"  !! manifest entry {e['label']}: trace holds {len(seg)} of {n} launches")
-        res[e["label"]] = (e, seg[-nt:] if nt <= len(seg) else seg)
+        seg = seg[-nt:] if nt <= len(seg) else seg
+        if k > 1:                                        # one row per call: the first kernel's name, the values of its k kernels added up
+            merged = []
+            for i in range(0, len(seg) - k + 1, k):
+                grp = seg[i:i + k]
+                v0 = grp[0][2]
+                val = sum(g[2] for g in grp) if not isinstance(v0, dict) else {c: sum(g[2].get(c, 0.0) for g in grp) for c in set().union(*[g[2].keys() for g in grp])}
+                merged.append((grp[0][0], grp[0][1], val))
+            seg = merged
+        res[e["label"]] = (e, seg)
     if pos != len(disp):
         print(f"  !! {len(disp) - pos} library launches after the last manifest entry")
     return res
