@@ -310,9 +310,13 @@ bool generate_fused(const Equation& e, const libxsmm_meqn_arg_shape& out, int eq
   std::function<bool(int, int, std::string&, std::string&)> value;     // (node, broadcast kind, name, code of the enclosing unit loop)
   std::function<bool(int, std::string&)> elem, scalar_value;           // element-wise op node -> v<id>[8]; one-number subtree -> s<id>
   std::function<bool(int, std::string&)> vector_value;                 // REDUCE_COLS subtree (one number per row) -> LDS array w<id>[M]
-  // Vector-valued reductions inside a tree (a sum over the columns, broadcast back along them): generated and checked on the CPU
-  // (tests/test_jit_emulated_cpu.py), OFF by default until measured on the device: LIBXSMM_HIP_MEQN_VECRED=1.
-  static const bool vecred = []() { const char* v = getenv("LIBXSMM_HIP_MEQN_VECRED"); return v && v[0] == '1'; }();
+  // Vector-valued reductions inside a tree (a sum over the columns, broadcast back along them) as a phase of the one-workgroup kernel.  Measured in
+  // round 3 (tools/bench_meqn_vecred.py, profiles/r03_meqn_vecred.jsonl): x * colsum(x^2) and a column softmax as ONE kernel against the chain of TPP
+  // launches -- 64 x 128: 7.9 vs 19.4 us and 58 vs 109 us (the launches of the chain dominate); 64 x 1024: 56 vs 14.6 us and 457 vs 81 us, 256 x 512:
+  // 40 vs 10.8 us (one workgroup walks what the chain spreads over the chip).  So: on up to 2^14 elements by default;
+  // LIBXSMM_HIP_MEQN_VECRED=1 always, =0 never.
+  static const int vecred_mode = []() { const char* v = getenv("LIBXSMM_HIP_MEQN_VECRED"); return (v && (v[0] == '0' || v[0] == '1')) ? v[0] - '0' : 2; }();
+  const bool vecred = vecred_mode == 1 || (vecred_mode == 2 && (long long)M * (long long)N <= (1ll << 14));
   std::string lds_decl;
   int n_vec = 0;
   const auto operand = [&](const EqnNode& parent, int c, std::string& name, std::string& body) -> bool { return value(parent.child[c], bcast_of(parent, c), name, body); };
