@@ -782,9 +782,12 @@ __device__ __forceinline__ void red_load4(float (&x)[4], gcptr in, long long idx
   if (BF16IN) { const u16x4 v = *(GM const u16x4*)((GM const unsigned short*)in + idx); for (int e = 0; e < 4; ++e) x[e] = mw_bf2f(v[e]); }
   else { const f32x4 v = *(GM const f32x4*)((GM const float*)in + idx); for (int e = 0; e < 4; ++e) x[e] = v[e]; }
 }
-template <bool BF16IN>
+// RGL: row groups per block of the REDUCE_COLS form (16: 16 column slices per block, tiles; 64: 4 slices, whole 1 KiB row segments per wave -- the
+// two-pass form over one big matrix).  CPG: columns a lane group of the REDUCE_ROWS form handles per trip (4 when a column is ONE vector per lane).
+template <bool BF16IN, int RGL = 16, int CPG = 1>
 __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int slices, int chunk, float* partial) {
-  __shared__ float part[2][16][16][4];
+  constexpr int NSL = 256 / RGL;
+  __shared__ float part[2][NSL][RGL][4];
   const bool rows = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
   const bool init_acc = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_INIT_ACC) != 0;
   const int type = p.type;
@@ -805,6 +808,32 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
   const int m4 = p.m / 4;
   if (rows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane % G, cpw = 64 / G;
+    if constexpr (CPG > 1) {
+      // short columns (m / 4 <= G: one vector per lane and column): CPG columns per lane group with all their loads in flight, then CPG folds
+      const int j0 = ((blockIdx.x * 4 + wave) * cpw + lane / G) * CPG;
+      float x[CPG][4];
+#pragma unroll
+      for (int u = 0; u < CPG; ++u) {
+        if (j0 + u < p.n && l < m4) red_load4<BF16IN>(x[u], in, 4ll * l + (long long)(j0 + u) * p.ldi);
+        else { x[u][0] = x[u][1] = x[u][2] = x[u][3] = ident; }
+      }
+#pragma unroll
+      for (int u = 0; u < CPG; ++u) {
+        float sx = ident, sx2 = 0.0f;
+        if (l < m4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sx = combine(sx, x[u][e]); sx2 += x[u][e] * x[u][e]; }
+        }
+        for (int off = G >> 1; off > 0; off >>= 1) { sx = combine(sx, __shfl_xor(sx, off)); sx2 += __shfl_xor(sx2, off); }
+        const int j = j0 + u;
+        if (l == 0 && j < p.n) {
+          if (is_add && init_acc) { if (want_x) sx += mw_load(out, j, p.out_type); if (want_x2) sx2 += mw_load(out2, j, p.out_type); }
+          if (want_x) mw_store(out, j, p.out_type, sx);
+          if (want_x2) mw_store(out2, j, p.out_type, sx2);
+        }
+      }
+      return;
+    }
     const int j = (blockIdx.x * 4 + wave) * cpw + lane / G;
     float sx = ident, sx2 = 0.0f;
     if (j < p.n) {
@@ -832,8 +861,8 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
       if (want_x2) mw_store(out2, j, p.out_type, sx2);
     }
   } else {
-    const int rg_l = threadIdx.x & 15, sl = threadIdx.x >> 4;            // 16 row groups x 16 slices per block (64 x 4 measured 1.5x slower)
-    const int rg = blockIdx.x * 16 + rg_l;
+    const int rg_l = threadIdx.x % RGL, sl = threadIdx.x / RGL;          // RGL row groups x NSL slices per block (tiles: 64 x 4 measured 1.5x slower than 16 x 16)
+    const int rg = blockIdx.x * RGL + rg_l;
     float sx[4] = {ident, ident, ident, ident}, sx2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     // two-pass form (partial != NULL): blockIdx.z owns columns [z*chunk, (z+1)*chunk) and writes raw partial sums
     const int jbeg = partial ? (int)blockIdx.z * chunk : 0, jend = partial ? ((jbeg + chunk < p.n) ? jbeg + chunk : p.n) : p.n;
@@ -1571,11 +1600,18 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
         const unsigned int gx = rows ? (unsigned int)((a.n + 4 * (64 / G) - 1) / (4 * (64 / G))) : (unsigned int)((a.m / 4 + 15) / 16);
         // one big matrix over its columns: too few row groups to fill the chip -> split the columns over blockIdx.z (two passes)
         int nchunks = 1;
+        // measured on one 4096 x 8192 f32 matrix (round 3): 2048 blocks 38.9 us, 1024 34.7, 512 32.1, 384 31.6, 256 36.9, 128 60.4 -- few, long-running blocks win;
+        // 64 or 32 row groups per block (whole 1 KiB / 512-byte row segments per wave, 4 / 8 column slices) were SLOWER at every block count (42 - 62 us)
         if (!rows && a.ws && a.nbatch == 1 && gx < 512) {
-          nchunks = (int)std::min<long long>(128, std::min<long long>(a.n / 64, 2048 / (gx ? gx : 1)));
+          nchunks = (int)std::min<long long>(128, std::min<long long>(a.n / 64, 512 / (gx ? gx : 1)));
           if ((size_t)nchunks * 2 * (size_t)a.m * sizeof(float) > a.ws_bytes) nchunks = 1;
         }
-        if (nchunks > 1) {
+        if (rows && a.m / 4 <= G && a.n >= 64) {     // short columns: four per lane group and trip
+          const unsigned int gx4 = (unsigned int)((a.n + 16 * (64 / G) - 1) / (16 * (64 / G)));
+          if (bf) hipLaunchKernelGGL((reduce_vec_kernel<true, 16, 4>), dim3(gx4, a.nbatch), dim3(256), 0, st, a, G, slices, 0, (float*)nullptr);
+          else hipLaunchKernelGGL((reduce_vec_kernel<false, 16, 4>), dim3(gx4, a.nbatch), dim3(256), 0, st, a, G, slices, 0, (float*)nullptr);
+          if (name) *name = "reduce_vec_kernel";
+        } else if (nchunks > 1) {
           const int chunk = (a.n + nchunks - 1) / nchunks;
           nchunks = (a.n + chunk - 1) / chunk;
           if (bf) hipLaunchKernelGGL((reduce_vec_kernel<true>), dim3(gx, 1, nchunks), dim3(256), 0, st, a, G, slices, chunk, (float*)a.ws);
