@@ -2397,7 +2397,14 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_bf16_macro_kernel(GemmArgs p)
 // ------------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
-template <int MT, int NT, bool UA, bool UB>
+// I4 (round 3): interleaved 4-bit weights [ref: gemm ref :467-477, :1009-1088] -- a dword of A holds eight k of one row (byte t: low nibble k 8o + t, high
+// nibble k 8o + 4 + t), every weight minus the row's zero point (one byte per row, a.quaternary) wrapped to a signed byte, B read as UNSIGNED bytes
+// (UB = true).  Two dwords of A per lane and MFMA step become the four operand dwords: (w & 0x0f0f0f0f) and ((w >> 4) & 0x0f0f0f0f) are k 8o..8o+3 and
+// 8o+4..8o+7 in order; the zero point is subtracted from all four bytes at once (byte-wise subtraction modulo 256 without borrows across bytes).
+__device__ __forceinline__ int sub_bytes(unsigned int x, unsigned int y) {
+  return (int)((((x | 0x80808080u) - (y & 0x7f7f7f7fu))) ^ ((x ^ ~y) & 0x80808080u));
+}
+template <int MT, int NT, bool UA, bool UB, bool I4 = false>
 __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
@@ -2416,18 +2423,37 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
     const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
     offB[x] = f * ldb + pc * 16u;
   }
-  const unsigned int offA = ((4u * h) * lda + (unsigned int)li) * 4u;      // dword (k-quad 4h, row li)
+  const unsigned int offA = ((I4 ? 2u * h : 4u * h) * lda + (unsigned int)li) * 4u;      // dword (k-quad 4h, row li); I4: dword (k-group-of-8 2h, row li)
   const i32x4 ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
   const int kchunks = p.k >> 6;
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
     const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + (unsigned long long)job.j0 * ldb);     // buffer addressing, see gemm_bf16_stream_kernel
     const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)job.i0);
+    unsigned int zz[MT];
+    if (I4) {       // the zero points of this lane's rows for batch-reduce block r: one byte per row, stepped with A [run_gemm: bs_scf, (br_stride_a * 2) / k per block]
+      const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0;
+      GM const unsigned char* zp = (GM const unsigned char*)p.a_scf + (long long)job.bidx * p.bs_scf + ((brs_a * 2) / p.k) * (long long)r + job.i0 + li;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) zz[mt] = (unsigned int)zp[32 * mt] * 0x01010101u;
+    }
     for (int kc = 0; kc < kchunks; ++kc) {
 #pragma unroll
       for (int x = 0; x < NT * 2; ++x)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
       i32x4 af[MT][2];
+      if constexpr (I4) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const unsigned int w = (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (4u * s + e) * lda * 4u) + 128 * mt, 32 * kc * (int)lda, 0);
+              af[mt][s][2 * e] = sub_bytes(w & 0x0f0f0f0fu, zz[mt]);
+              af[mt][s][2 * e + 1] = sub_bytes((w >> 4) & 0x0f0f0f0fu, zz[mt]);
+            }
+      } else
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -2871,6 +2897,15 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
   if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && va && !ta && !tb && !vb) {
     pl.path = (m > 32 && n > 32) ? P_FP8_2x2 : P_FP8_1x1;
     const int t = (pl.path == P_FP8_2x2) ? 64 : 32;
+    pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
+    if (!pl.exact) pl.path = P_GENERIC;
+    return pl;
+  }
+  if ((a_type == LIBXSMM_DATATYPE_I4X2 || a_type == LIBXSMM_DATATYPE_U4X2) && (flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && va && !ta && !tb && !vb &&
+      (b_type == LIBXSMM_DATATYPE_I8 || b_type == LIBXSMM_DATATYPE_U8) && c_type == LIBXSMM_DATATYPE_I32) {
+    // interleaved 4-bit weights: the int8 streaming kernel with the nibbles expanded (and the row's zero point subtracted) in registers
+    pl.path = (m > 32 && n > 32) ? P_I8_2x2 : P_I8_1x1;
+    const int t = (pl.path == P_I8_2x2) ? 64 : 32;
     pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
     if (!pl.exact) pl.path = P_GENERIC;
     return pl;
@@ -3591,7 +3626,16 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)a.ldb;
       const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0) | (unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c;
       const bool ok = !a.list_a && a.br_mode != 1 && a.br_mode != 2 && (bits & 15ull) == 0 && (abits & 3ull) == 0 && (long long)a.lda * a.k < (1ll << 31) && (long long)a.ldb * a.n < (1ll << 31);
-      if (ok) {
+      const bool i4 = a.a_type == LIBXSMM_DATATYPE_I4X2 || a.a_type == LIBXSMM_DATATYPE_U4X2;
+      if (ok && i4) {
+        const bool big = pl.path == P_I8_2x2;
+        grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
+        if (kernel_name) *kernel_name = big ? "gemm_i4_stream_kernel<2,2>" : "gemm_i4_stream_kernel<1,1>";
+        if (big) hipLaunchKernelGGL((gemm_i8_stream_kernel<2, 2, false, true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_i8_stream_kernel<1, 1, false, true, true>), grid, dim3(256), 0, st, a);
+        break;
+      }
+      if (ok && !i4) {
         const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8, big = pl.path == P_I8_2x2;
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
 #define LAUNCH_I8_(MT_, NT_) do { \

@@ -769,7 +769,8 @@ def test_low_bit_weight_gemm_bit_exact(a_type, b_type, m, n, k, lda, ldb, ldc, b
 # interleaved 4-bit weights x 8-bit activations [ref: gemm ref :1009-1088, :1272-1330]: I4X2 minus a zero point per row -> i32 (exact);
 # MXFP4 through the integer table with E8M0 scales of A and f32 scales of B -> f32 / bf16 (the reference's order: bit-identical)
 @pytest.mark.parametrize("a_type,c_type", [(DT.I4X2, DT.I32), (DT.MXFP4X2, DT.F32), (DT.MXFP4X2, DT.BF16)])
-@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (17, 7, 64, 20, 96, 24, 1, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0, 1), (128, 32, 256, 128, 256, 128, 2, 1, 9)])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (17, 7, 64, 20, 96, 24, 1, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0, 1), (128, 32, 256, 128, 256, 128, 2, 1, 9),
+                                                             (64, 64, 128, 64, 128, 64, 3, 0, 5), (32, 32, 64, 32, 64, 32, 1, 0, 1), (64, 128, 64, 72, 96, 64, 1, 1, 33)])
 def test_interleaved_4bit_weight_gemm_bit_exact(a_type, c_type, m, n, k, lda, ldb, ldc, br, beta, batch):
     import torch
     from helpers import rand_values
@@ -814,6 +815,9 @@ def test_interleaved_4bit_weight_gemm_bit_exact(a_type, c_type, m, n, k, lda, ld
         api.hip_gemm_batch_strided(h, C.byref(p), batch, br * a_b, br * b_b, ldc * n * esz)
     api.hip_sync(); api.check()
     assert dC.cpu().numpy().view(C0.dtype).tobytes() == ref.tobytes()
+    if a_type == DT.I4X2 and m % 32 == 0 and n % 32 == 0 and k % 64 == 0:
+        # whole tiles: the int8 matrix-core kernel with the nibbles expanded in registers (round 3); everything else the exact generic kernel
+        assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode().startswith("gemm_i4_stream_kernel"), api.hip_kernel_name(h, 1 if batch > 1 else 0)
     if batch == 1:
         got = C0.copy()
         p = capi.GemmParam()
