@@ -2502,6 +2502,111 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Interleaved MXFP4 weights x signed 8-bit activations -> f32 / bf16 (round 3) [ref: gemm ref :467-477, :1009-1088]: a dword of A holds eight k of one row
+// (byte t: low nibble k 8o + t, high nibble k 8o + 4 + t) as E2M1 codes that the reference maps to the INTEGER table {0, 11, 21, 32, 42, 64, 85, 127} with
+// sign; the integer sum of a 32-deep block is scaled by the E8M0 scale of (row, block) and an f32 of (column, block) and added to the f32 result, block by
+// block.  One v_mfma_i32_32x32x32_i8 IS one block: the accumulator starts at zero for every MFMA, its 16 integers are converted, scaled with the two
+// multiplies and added in the reference's order -- bit-identical to the reference loop.  The codes are expanded in registers: v_perm_b32 looks four
+// magnitudes up at once in the 8-byte table, the sign is applied byte-wise.  B through the LDS-DMA path of the int8 kernel; the f32 column scales of
+// a 64-deep chunk (two blocks x 32 columns per tile) through a wave-private LDS image, read back as four 16-byte pieces per block.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mx4_codes_to_bytes(unsigned int codes) {       // four E2M1 codes (one per byte) -> four signed bytes of the reference's integer table
+  const unsigned int mag = (unsigned int)__builtin_amdgcn_perm(0x7f55402au, 0x20150b00u, codes & 0x07070707u);
+  const unsigned int sm = ((codes >> 3) & 0x01010101u) * 0xffu;
+  return sub_bytes(mag ^ sm, sm);
+}
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void gemm_mx4i8_stream_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048 + NT * 256];
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  char* lds = lds_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  float* lds_sb = (float*)(lds + NT * 2048);                       // [nt][block of the chunk][32 columns]
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  float facc[MT][NT][16];
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) facc[mt][nt][r2] = 0.0f; });
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  unsigned int offB[NT * 2];
+#pragma unroll
+  for (int x = 0; x < NT * 2; ++x) {
+    const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
+    offB[x] = f * ldb + pc * 16u;
+  }
+  const unsigned int offA = ((2u * h) * lda + (unsigned int)li) * 4u;      // dword (k-group-of-8 2h, row li)
+  const int kchunks = p.k >> 6;
+  const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
+  const int nsb = p.ldb / 32;                                      // f32 scales per column of B
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + (unsigned long long)job.j0 * ldb);
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)job.i0);
+    // scales of this block of the chain [run_gemm: one E8M0 byte per (32 k, row) of A, stepped by (br_stride_a * 2) / 32 per block; one f32 per (column, 32 k) of B]
+    GM const unsigned char* sa = (GM const unsigned char*)p.a_scf + (long long)job.bidx * p.bs_scf + ((brs_a * 2) / 32) * (long long)r + job.i0 + li;
+    GM const float* sb = (GM const float*)(p.b_scf + (long long)job.bidx * p.bs_bscf) + (brs_b / 32) * (long long)r + (long long)job.j0 * nsb;
+    for (int kc = 0; kc < kchunks; ++kc) {
+#pragma unroll
+      for (int x = 0; x < NT * 2; ++x)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
+      i32x4 af[MT][2];
+      float rs[MT][2];                                             // 2^(scale - 127) of (this lane's row, block 2 kc + s)
+      float colsc[NT];                                             // this lane's contribution to the column-scale image: column li, block h of the chunk
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) colsc[nt] = sb[(long long)(32 * nt + li) * nsb + 2 * kc + h];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          rs[mt][s] = __uint_as_float((unsigned int)sa[(long long)(2 * kc + s) * lda + 32 * mt] << 23);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const unsigned int w = (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (4u * s + e) * lda * 4u) + 128 * mt, 32 * kc * (int)lda, 0);
+            af[mt][s][2 * e] = mx4_codes_to_bytes(w & 0x0f0f0f0fu);
+            af[mt][s][2 * e + 1] = mx4_codes_to_bytes((w >> 4) & 0x0f0f0f0fu);
+          }
+        }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) lds_sb[64 * nt + 32 * h + li] = colsc[nt];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        i32x4 bfr[NT];
+        f32x4 cs[NT][4];                                           // column scales of registers 4 g .. 4 g + 3: columns 8 g + 4 h .. + 3
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int f = 32 * nt + li;
+          bfr[nt] = *(const i32x4*)(lds + f * 64 + (((2 * s + h) ^ ((f >> 1) & 3)) * 16));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) cs[nt][g] = *(const f32x4*)(lds_sb + 64 * nt + 32 * s + 8 * g + 4 * h);
+        }
+        static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+          const i32x16 t = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr[nt], af[mt][s], (i32x16)0, 0, 0, 0);
+#pragma unroll
+          for (int r2 = 0; r2 < 16; ++r2)
+            facc[mt][nt][r2] = add_rn(facc[mt][nt][r2], mul_rn(mul_rn((float)t[r2], rs[mt][s]), cs[nt][r2 >> 2][r2 & 3]));
+        });
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  static_for<MT * NT>([&](auto idx) {
+    constexpr int mt = idx.value / NT, nt = idx.value % NT;
+    const unsigned long long e0 = (unsigned long long)(job.j0 + 32 * nt + 4 * h) * (unsigned int)p.ldc + job.i0 + 32 * mt + li;
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) {
+      const unsigned long long e = e0 + (unsigned long long)(((r2 & 3) + 8 * (r2 >> 2)) * p.ldc);
+      if (c_f32) { GM float* c = (GM float*)q.c + e; *c = add_rn(beta0 ? 0.0f : *c, facc[mt][nt][r2]); }
+      else { GM unsigned short* c = (GM unsigned short*)q.c + e; *c = f32_to_bf16_rne(add_rn(beta0 ? 0.0f : bf16_to_f32(*c), facc[mt][nt][r2])); }
+    }
+  });
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // 8-bit float streaming kernel (v_mfma_f32_32x32x16_bf8_bf8 / _fp8_fp8; CDNA4's fp8 = OCP E4M3 = the reference's HF8, bf8 =
 // E5M2 = BF8): exact tiles, VNNI-4 A, flat B with 16-byte aligned columns, k % 64 == 0, f32 accumulate and output.
 // Structure = gemm_i8_stream_kernel; an MFMA consumes 16 k (8 bytes per lane and operand), four steps per 64-deep chunk.
@@ -2861,7 +2966,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
   return true;
 }
 
-enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2, P_MX4_1x1, P_MX4_2x2, P_MXMX_1x1, P_MXMX_2x2 };
+enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2, P_MX4_1x1, P_MX4_2x2, P_MXMX_1x1, P_MXMX_2x2, P_MX4I8_1x1, P_MX4I8_2x2 };
 struct GemmPlan { GemmPath path; bool exact; };
 
 static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, int b_type, int c_type, int vnni_c) {
@@ -2874,6 +2979,15 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     if ((m % 32) || (n % 32) || (k % 64)) return pl;
     pl.exact = true;
     pl.path = ((m % 64) == 0 && (n % 64) == 0) ? P_MXMX_2x2 : P_MXMX_1x1;
+    return pl;
+  }
+  if (a_type == LIBXSMM_DATATYPE_MXFP4X2 && (flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && b_type == LIBXSMM_DATATYPE_I8 && va && !ta && !tb && !vb) {
+    // interleaved MXFP4 x i8: one int8 MFMA per 32-deep block, scaled and added block by block (gemm_mx4i8_stream_kernel)
+    if ((m % 32) || (n % 32) || (k % 64)) return pl;
+    pl.exact = true;
+    // 2 x 2 tiles per wave need 320 registers (64 f32 sums + the MFMA results in flight): one wave per SIMD, 0.17 of the HBM roofline on 64^3 problems;
+    // one tile per wave (120 registers, four waves per SIMD) re-reads operands from L2 and runs several times faster
+    pl.path = P_MX4I8_1x1;
     return pl;
   }
   if (a_type == LIBXSMM_DATATYPE_MXFP4X2) {
@@ -2936,6 +3050,8 @@ static const char* path_name(GemmPath p) {
     case P_BF16_2x2: return "gemm_mfma_bf16_kernel<2,2>";
     case P_FP8_1x1: return "gemm_fp8_stream_kernel<1,1>";
     case P_FP8_2x2: return "gemm_fp8_stream_kernel<2,2>";
+    case P_MX4I8_1x1: return "gemm_mx4i8_stream_kernel<1,1>";
+    case P_MX4I8_2x2: return "gemm_mx4i8_stream_kernel<2,2>";
     case P_I8_1x1: return "gemm_i8_stream_kernel<1,1>";
     case P_I8_2x2: return "gemm_i8_stream_kernel<2,2>";
     case P_MX4_1x1: return "gemm_mxfp4_stream_kernel<1,1>";
@@ -3619,6 +3735,22 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       if (kernel_name) *kernel_name = "gemm_generic_kernel";
       const long long gblocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
       hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)gblocks), dim3(64, 4), 0, st, a);
+      break;
+    }
+    case P_MX4I8_1x1: case P_MX4I8_2x2: {
+      const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)a.ldb;
+      const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0) |
+        (unsigned long long)(size_t)a.b_scf | (unsigned long long)a.bs_bscf;
+      const bool ok = !a.list_a && a.br_mode != 1 && a.br_mode != 2 && (bits & 15ull) == 0 && (abits & 3ull) == 0 && (long long)a.lda * a.k < (1ll << 31) && (long long)a.ldb * a.n < (1ll << 31) &&
+        (a.c_type == LIBXSMM_DATATYPE_F32 || a.c_type == LIBXSMM_DATATYPE_BF16) && a.a_scf && a.b_scf;
+      if (ok) {
+        grid = wave_grid(32, 32);
+        hipLaunchKernelGGL((gemm_mx4i8_stream_kernel<1, 1>), grid, dim3(256), 0, st, a);
+        break;
+      }
+      if (kernel_name) *kernel_name = "gemm_generic_kernel";
+      const long long gblocks2 = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
+      hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)gblocks2), dim3(64, 4), 0, st, a);
       break;
     }
     case P_I8_1x1: case P_I8_2x2: {

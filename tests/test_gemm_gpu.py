@@ -818,6 +818,9 @@ def test_interleaved_4bit_weight_gemm_bit_exact(a_type, c_type, m, n, k, lda, ld
     if a_type == DT.I4X2 and m % 32 == 0 and n % 32 == 0 and k % 64 == 0:
         # whole tiles: the int8 matrix-core kernel with the nibbles expanded in registers (round 3); everything else the exact generic kernel
         assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode().startswith("gemm_i4_stream_kernel"), api.hip_kernel_name(h, 1 if batch > 1 else 0)
+    if mx and m % 32 == 0 and n % 32 == 0 and k % 64 == 0:
+        # one int8 MFMA per 32-deep block, scaled and added block by block in the reference's order: still bit-identical
+        assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode().startswith("gemm_mx4i8_stream_kernel"), api.hip_kernel_name(h, 1 if batch > 1 else 0)
     if batch == 1:
         got = C0.copy()
         p = capi.GemmParam()

@@ -82,6 +82,31 @@ def brgemm_i4(api, m, batch):
     return w
 
 
+def brgemm_mx4i8(api, m, batch, c_dt=DT.BF16):
+    """interleaved MXFP4 weights (E8M0 scale per 32 k and row) x signed bytes (one f32 scale per column and 32 k) -> bf16 / f32, m = n = k: algorithmic bytes per
+    problem = m*m/2 + m*m/32 (A, its scales) + m*m + 4*m*m/32 (B, its scales) + s_C*m*m."""
+    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, DT.MXFP4X2, DT.I8, c_dt, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A | GEMM_FLAG.INTLV_A_FORMAT, 0,
+                            capi.br_config(capi.BR_STRIDE, m * m // 2, m * m, 0))
+    assert h
+    cs = 2 if c_dt == DT.BF16 else 4
+    per = m * m // 2 + m * m // 32 + m * m + 4 * m * m // 32 + cs * m * m
+    ns = nsets_for(batch * per)
+    As = [torch.randint(0, 256, (batch * m * m // 2,), device=DEV, dtype=torch.uint8) for _ in range(ns)]
+    Sa = [torch.randint(124, 131, (batch * m * m // 32,), device=DEV, dtype=torch.uint8) for _ in range(ns)]
+    Bs = [torch.randint(-128, 128, (batch * m * m,), device=DEV, dtype=torch.int8) for _ in range(ns)]
+    Sb = [torch.rand(batch * m * m // 32, device=DEV) / 64 + 0.01 for _ in range(ns)]
+    Cs = [torch.zeros(batch * m * m * cs // 2, device=DEV, dtype=torch.int16) for _ in range(ns)]
+    brc = C.c_ulonglong(1)
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc)
+        p.a.tertiary, p.b.tertiary = Sa[s].data_ptr(), Sb[s].data_ptr(); ps.append(p)
+    w = Work(api, f"stride-BRGEMM mxfp4 (interleaved) x i8 -> {'bf16' if cs == 2 else 'f32'} m=n=k={m} batch={batch} br=1 beta=0", 2.0 * m ** 3 * batch, float(batch * per), ns,
+             lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, m * m // 2, m * m, cs * m * m), lambda: api.hip_kernel_name(h, 1).decode())
+    w.keep = (As, Sa, Bs, Sb, Cs, ps, brc)
+    return w
+
+
 def brgemm_mxfp4(api, m, batch, c_dt=DT.BF16):
     """MXFP4 weights (packed E2M1 pairs + E8M0 scale per 32-deep k-block and row) x bf16 activations, m = n = k, every problem
     with its own weights: algorithmic bytes = m*m/2 + m*m/32 (A, scales) + 2*m*m (B) + s_C*m*m (C) per problem."""
@@ -356,7 +381,7 @@ def main():
                    lambda: brgemm(api, 32, "f32", 1, br=4096), lambda: brgemm(api, 64, "bf16", 1, br=4096),
                    lambda: brgemm_i8(api, 64, 2 ** 17, ua=True), lambda: brgemm_i8(api, 64, 2 ** 17, ua=False)]     # config #2 variant B: one long chain
     if "lowbit" in only:     # the (f4) forms moved onto the matrix cores in round 3
-        makers += [lambda: brgemm_i4(api, 64, 2 ** 17), lambda: brgemm_i4(api, 32, 2 ** 18)]
+        makers += [lambda: brgemm_i4(api, 64, 2 ** 17), lambda: brgemm_i4(api, 32, 2 ** 18), lambda: brgemm_mx4i8(api, 64, 2 ** 17), lambda: brgemm_mx4i8(api, 64, 2 ** 17, DT.F32)]
     if "f16" in only:        # IEEE halves on the bf16 fast paths (round 3): streaming 32^3 / 64^3, fused none, and the blocked form through tools/bb_sweep.py --dtype f16
         makers += [lambda: brgemm(api, 32, "f16", 2 ** 18), lambda: brgemm(api, 64, "f16", 2 ** 16), lambda: brgemm(api, 32, "f16", 4096), lambda: brgemm(api, 64, "f16", 4096)]
     if "ragged" in only:     # the odd small shapes (BASELINE config #1 is 23^3), steady state and a 4096-problem launch
