@@ -464,7 +464,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
     if (!p->a.tertiary || !p->b.tertiary) { set_error(-2, "MX x MX GEMM needs the E8M0 scales in a.tertiary and b.tertiary"); return; }
     if (b.la) { set_error(-3, "MX x MX GEMM: pointer-list batches carry no scale lists; use the strided batch"); return; }
     const long long epb = (d.a_type == LIBXSMM_DATATYPE_MXFP4X2) ? 2 : 1;
-    if (b.count > 1 && (a_fp6 ? (((b.s[0] | b.s[1]) % 24) != 0) : ((((b.s[0] | b.s[1]) * epb) % 32) != 0))) { set_error(-3, "MX x MX GEMM: batch strides must cover whole 32-element scale blocks"); return; }
+    if (b.count > 1 && (a_fp6 ? ((b.s[0] % 24) != 0 || (b.s[1] % 24) != 0) : ((((b.s[0] | b.s[1]) * epb) % 32) != 0))) { set_error(-3, "MX x MX GEMM: batch strides must cover whole 32-element scale blocks"); return; }
     if (d.c_type == d.a_type && (d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_MXBF8)) {
       if (!p->c.tertiary) { set_error(-2, "MX-typed C needs room for its E8M0 scales in c.tertiary"); return; }
       if (b.la || b.inner) { set_error(-3, "MX-typed C: strided batches only"); return; }

@@ -616,10 +616,12 @@ def test_gemm_with_bitmask_compressed_a(where, a_type, c_type, m, n, k, ldb, ldc
     api.hip_clear_last_error()
 
 
-# 6-bit MX formats [ref: gemm ref :2680-2727]: [k/4][ld][3 bytes] operands with E8M0 scales per 32 k; the device runs the reference's order
-# (k descending inside a group, unfused) in the generic kernel: bit-identical to the oracle.  Single, batch-reduce, strided batch, host memory.
+# 6-bit MX formats [ref: gemm ref :2680-2727]: [k/4][ld][3 bytes] operands with E8M0 scales per 32 k.  Whole 32 x 32 x 64 tiles run on the matrix cores
+# (the eight 3-byte groups of a block ARE the instruction's 192-bit operand image); everything else runs the reference's order (k descending inside a
+# group, unfused) in the generic kernel: bit-identical to the oracle.  Single, batch-reduce, strided batch, host memory.
 @pytest.mark.parametrize("dt", [DT.MXBF6, DT.MXHF6])
-@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 32, 64, 32, 32, 32, 1, 0, 1), (17, 9, 32, 20, 12, 24, 1, 1, 1), (32, 16, 64, 32, 16, 32, 3, 0, 1), (64, 64, 128, 64, 64, 64, 2, 1, 5), (8, 12, 96, 8, 12, 8, 1, 0, 7)])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 32, 64, 32, 32, 32, 1, 0, 1), (17, 9, 32, 20, 12, 24, 1, 1, 1), (32, 16, 64, 32, 16, 32, 3, 0, 1), (64, 64, 128, 64, 64, 64, 2, 1, 5), (8, 12, 96, 8, 12, 8, 1, 0, 7),
+                                                             (32, 64, 192, 36, 68, 40, 1, 0, 3), (96, 32, 64, 96, 32, 96, 3, 1, 2)])
 def test_mx6_gemm_bit_exact(dt, m, n, k, lda, ldb, ldc, br, beta, batch):
     import torch
     from helpers import mx6_operands, rand_values
@@ -651,13 +653,23 @@ def test_mx6_gemm_bit_exact(dt, m, n, k, lda, ldb, ldc, br, beta, batch):
     else:
         api.hip_gemm_batch_strided(h, C.byref(p), batch, br * sa_b, br * sb_b, ldc * n * 4)
     api.hip_sync(); api.check()
-    assert np.array_equal(dC.cpu().numpy(), ref)
+    # whole tiles of E2M3: v_mfma_scale_f32_32x32x64_f8f6f4 takes the format natively (round 3); E3M2 stays exact (the core's aligned sum measures 2e-5 on it,
+    # above the 1.2e-5 the reference's driver accepts)
+    on_mfma = dt == DT.MXHF6 and m % 32 == 0 and n % 32 == 0 and k % 64 == 0
+    name = api.hip_kernel_name(h, 1 if batch > 1 else 0).decode()
+    assert name.startswith("gemm_mx6_stream_kernel") == on_mfma, name
+
+    def same(x):
+        if on_mfma:                               # the matrix core sums a 32-deep block in its own order: the f32 bound of the MX x MX kernels
+            return normf_rel(ref, x, DT.F32) < 2e-6     # E2M3 products and their sums are exact in the matrix core (measured 0 .. 3e-8)
+        return np.array_equal(x, ref)             # generic kernel: the reference's order, bit-identical
+    assert same(dC.cpu().numpy())
     if batch == 1:                                # plain host memory through the synchronous call
         got = C0.copy()
         p.a.primary, p.a.tertiary, p.b.primary, p.b.tertiary, p.c.primary = A.ctypes.data, SA.ctypes.data, B.ctypes.data, SB.ctypes.data, got.ctypes.data
         capi.Api.call(h, p)
         api.check()
-        assert np.array_equal(got, ref)
+        assert same(got)
     # what the 6-bit formats do not have here: other output types, missing scales
     assert api.dispatch_gemm(capi.gemm_shape(m, n, k, lda, ldb, ldc, dt, dt, DT.BF16, DT.F32), flags, 0) is None
 

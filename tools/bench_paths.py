@@ -136,7 +136,7 @@ def brgemm_mxmx(api, m, batch, dt=None):
     2 * (m*m*bits/8 + m*m/32) (operands + scales) + 4*m*m (C)."""
     dt = DT.MXFP4X2 if dt is None else dt
     epb = 2 if dt == DT.MXFP4X2 else 1
-    ob, sb = m * m // epb, m * m // 32
+    ob, sb = (m * m * 3 // 4 if dt in (DT.MXHF6, DT.MXBF6) else m * m // epb), m * m // 32
     h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, dt, dt, DT.F32, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A | GEMM_FLAG.VNNI_B | GEMM_FLAG.TRANS_B, 0,
                             capi.br_config(capi.BR_STRIDE, ob, ob, 0))
     assert h
@@ -151,7 +151,7 @@ def brgemm_mxmx(api, m, batch, dt=None):
     for s in range(ns):
         p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc)
         p.a.tertiary, p.b.tertiary = Sa[s].data_ptr(), Sb[s].data_ptr(); ps.append(p)
-    name = {DT.MXFP4X2: "mxfp4", DT.MXBF8: "mxbf8", DT.MXHF8: "mxhf8"}[dt]
+    name = {DT.MXFP4X2: "mxfp4", DT.MXBF8: "mxbf8", DT.MXHF8: "mxhf8", DT.MXHF6: "mxhf6", DT.MXBF6: "mxbf6"}[dt]
     w = Work(api, f"stride-BRGEMM {name} x {name} -> f32 m=n=k={m} batch={batch} br=1 beta=0", 2.0 * m ** 3 * batch, float(batch * per), ns,
              lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, ob, ob, 4 * m * m), lambda: api.hip_kernel_name(h, 1).decode())
     w.keep = (As, Bs, Sa, Sb, Cs, ps, brc)
@@ -381,7 +381,8 @@ def main():
                    lambda: brgemm(api, 32, "f32", 1, br=4096), lambda: brgemm(api, 64, "bf16", 1, br=4096),
                    lambda: brgemm_i8(api, 64, 2 ** 17, ua=True), lambda: brgemm_i8(api, 64, 2 ** 17, ua=False)]     # config #2 variant B: one long chain
     if "lowbit" in only:     # the (f4) forms moved onto the matrix cores in round 3
-        makers += [lambda: brgemm_i4(api, 64, 2 ** 17), lambda: brgemm_i4(api, 32, 2 ** 18), lambda: brgemm_mx4i8(api, 64, 2 ** 17), lambda: brgemm_mx4i8(api, 64, 2 ** 17, DT.F32)]
+        makers += [lambda: brgemm_i4(api, 64, 2 ** 17), lambda: brgemm_i4(api, 32, 2 ** 18), lambda: brgemm_mx4i8(api, 64, 2 ** 17), lambda: brgemm_mx4i8(api, 64, 2 ** 17, DT.F32),
+                   lambda: brgemm_mxmx(api, 64, 2 ** 17, DT.MXHF6), lambda: brgemm_mxmx(api, 128, 2 ** 15, DT.MXHF6)]
     if "f16" in only:        # IEEE halves on the bf16 fast paths (round 3): streaming 32^3 / 64^3, fused none, and the blocked form through tools/bb_sweep.py --dtype f16
         makers += [lambda: brgemm(api, 32, "f16", 2 ** 18), lambda: brgemm(api, 64, "f16", 2 ** 16), lambda: brgemm(api, 32, "f16", 4096), lambda: brgemm(api, 64, "f16", 4096)]
     if "ragged" in only:     # the odd small shapes (BASELINE config #1 is 23^3), steady state and a 4096-problem launch
