@@ -112,6 +112,48 @@ def test_config4_bcsc_full_batch():
     api.release_kernel(h)
 
 
+@pytest.mark.parametrize("pattern_on", ["device", "host", "bound"])
+def test_config4_bcsc_full_batch_bf16_c(pattern_on):
+    """BASELINE configs[3] as written (`spmm_kernel BF16 BF16 F32 BF16 64 64 256 8192 ...`: bf16 C) at full size: EVERY one of the 8192 M-blocks against the
+    gold loop [ref: spmm_kernel.c:74-217] (the oracle takes a few seconds for all of them), with the pattern in device memory (inverted per call), in host
+    memory (the reference's convention: inverted on the host once, cached with the kernel) and bound (libxsmm_hip_bcsc_bind_pattern)."""
+    import torch
+    api, orc = capi.load(), pyoracle.oracle()
+    M, K, N, mb, bk, bn = 64, 256, 64, 8192, 32, 16
+    colptr, rowidx = structured_2_of_8(K, N, bk, bn)
+    nnzb = len(rowidx)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: torch.randint(-4, 6, s, generator=g).float() / 8          # eighths: exact in bf16
+    A, Bv = rnd(mb, K // 2, M, 2), rnd(nnzb * bn * bk)
+    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, DT.BF16, DT.BF16, DT.BF16, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    dA, dBv = _bf16_bits(A).cuda(), _bf16_bits(Bv).cuda()
+    dcp, dri = torch.from_numpy(colptr.view(np.int32)).cuda(), torch.from_numpy(rowidx.view(np.int32)).cuda()
+    dC = torch.full((mb * N * M,), 0x5a5a, dtype=torch.int16, device="cuda")
+    nblk = C.c_ulonglong(N // bn)
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.b.quaternary, p.c.primary = dA.data_ptr(), dBv.data_ptr(), C.addressof(nblk), dC.data_ptr()
+    if pattern_on == "host":
+        p.b.secondary, p.b.tertiary = colptr.ctypes.data, rowidx.ctypes.data
+    else:
+        p.b.secondary, p.b.tertiary = dcp.data_ptr(), dri.data_ptr()
+        if pattern_on == "bound":
+            assert api.hip_bcsc_bind_pattern(h, dcp.data_ptr(), dri.data_ptr(), N // bn) == 0
+    for _ in range(2):                                                          # the second call takes the cached / bound table
+        capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_bf16_stream_kernel"
+    a_bits = _bf16_bits(A).numpy().view(np.uint16).reshape(-1).copy()
+    bv_bits = _bf16_bits(Bv).numpy().view(np.uint16).copy()
+    ref = np.zeros(mb * N * M, dtype=np.uint16)
+    orc.lib.oracle_packed_spgemm_bcsc(DT.BF16, DT.BF16, M, N, K, mb, bk, bn, 1, a_bits.ctypes.data, bv_bits.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, 1)
+    got = dC.cpu().numpy().view(np.uint16)
+    assert normf_rel(ref, got, DT.BF16) <= 5e-3
+    # sums of at most 64 products of eighths are exact in f32 and the bf16 rounding is the same RNE: in fact every value must agree
+    assert np.array_equal(got, ref)
+    api.release_kernel(h)
+
+
 def test_config5_fused_bf16_brgemm_full_shard():
     """bf16 64^3 + column bias + ReLU, the per-GPU shard of config #5 (2^17 problems): a strided sample of problems
     against the oracle [ref: gemm ref :2367-2419, :294-372], and every problem through the batch == loop property on a
