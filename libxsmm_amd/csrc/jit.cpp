@@ -90,7 +90,10 @@ void append(std::string& s, const char* fmt, ...) {
 static bool nt_stores() { static const bool on = []() { const char* e = getenv("LIBXSMM_HIP_JIT_NT"); return !(e && e[0] == '0'); }(); return on; }
 int choose_vec(const SpmmJitSpec& s, int touched, int elem) {
   const int words = elem / 4;
-  const int cands[3] = {16 / elem, 8 / elem, 1};
+  // f64: ONE double per lane.  Round-3 sweep (profiles/r03_csr_width_sweep.jsonl, LIBXSMM_HIP_JIT_VEC): FsSpMDM f64 N = 2^20 108 us at one double per lane against
+  // 117-123 us at two (beta = 1: 181 vs 193 us), packed CSR f64 the same either way (221 vs 221-226 us); f32 keeps four floats per lane (FsSpMDM 53.8 us vs
+  // 57.2 / 62.3 at one / two; CSR @10 % 109 vs 114 us).
+  const int cands[3] = {elem == 8 ? 1 : 16 / elem, elem == 8 ? 1 : 8 / elem, 1};
   int best = 0;
   // LIBXSMM_HIP_JIT_VEC=<elements per lane>: experiments on the register budget / occupancy trade (taken if the geometry admits it)
   static const int forced = []() { const char* e = getenv("LIBXSMM_HIP_JIT_VEC"); return e ? atoi(e) : 0; }();

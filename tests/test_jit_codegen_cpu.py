@@ -95,7 +95,9 @@ def test_every_generator_emits_code_that_compiles(generated):
     for label, kernel in jitted.items():
         assert kernel in table, (label, kernel, sorted(table))
         assert os.path.getsize(os.path.join(dump, kernel + ".hip")) > 100
-    assert len(table) > len(set(jitted.values()))          # FsSpMDM's own kernel (an opaque handle) is in the dump directory as well
+    # FsSpMDM's own kernel (an opaque handle) is in the dump directory as well -- under its own name or, since f64 kernels keep one double per lane
+    # (round 3), as the very kernel the packed CSR creator of the same pattern generated (cached by source)
+    assert len(table) >= len(set(jitted.values()))
 
 
 def test_generated_kernels_need_no_scratch(generated):
