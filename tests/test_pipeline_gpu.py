@@ -15,6 +15,18 @@ from libxsmm_amd import capi  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _restore_the_threads_launch_mode():
+    """These tests switch the calling thread to stream-ordered launches on torch's stream; the rest of the suite relies on the library's default
+    (synchronous calls on the null stream, host operands staged): put it back."""
+    yield
+    api = capi.load()
+    api.hip_sync()
+    api.hip_clear_last_error()
+    api.hip_set_stream(None)
+    api.hip_set_async(0)
+
+
 def _setup(dtype, m, batch, br, nsets):
     import torch
     import bench
