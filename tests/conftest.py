@@ -33,3 +33,23 @@ def reference():
 def api():
     from libxsmm_amd import capi
     return capi.load()
+
+
+@pytest.fixture(autouse=True)
+def _default_launch_mode(request):
+    """GPU tests share one process and the library keeps its launch mode per THREAD: a test that switches to stream-ordered launches (libxsmm_hip_set_stream /
+    _set_async, a pipeline section) must not leak that into the next one, whose host-memory operands are only staged by SYNCHRONOUS calls.  After every GPU
+    test: close an open section, drain, clear the sticky error, back to synchronous calls on the null stream."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    try:
+        from libxsmm_amd import capi
+        api = capi.load()
+        if api.hip_available() == 1:
+            api.hip_sync()
+            api.hip_set_stream(None)
+            api.hip_set_async(0)
+            api.hip_set_streaming_hint(0)
+    except Exception:
+        pass
