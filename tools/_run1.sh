@@ -1,3 +1,18 @@
-mkdir -p gpurun_out
-BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --gpus 1 --config 5 --gather --steps 10 --warmup 2 --cpu-seconds 3 --detail gpurun_out/bench_c5_detail.json 2> gpurun_out/bench_c5.err | tail -1 > gpurun_out/bench_c5_line.json; echo rc=$?; cat gpurun_out/bench_c5_line.json
-BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-sweep --cpu-seconds 3 --detail gpurun_out/bench_dist1_detail.json 2> gpurun_out/bench_dist1.err | tail -1 > gpurun_out/bench_dist1_line.json; echo rc=$?; cat gpurun_out/bench_dist1_line.json
+python - <<'PY'
+import sys, json, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tools"); sys.path.insert(0, "tests")
+import bench, workloads as wl
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT
+api = capi.load(); dev = torch.device("cuda:0"); torch.cuda.set_device(0)
+api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+wl.set_device(dev)
+for N in (2 ** 20, 2 ** 20 + 2048, 2 ** 20 + 8192 + 512, 1000000, 3 * 2 ** 18):
+    for dt in (DT.F64, DT.F32):
+        w = wl.fsspmdm(api, N, 0.15, dt)
+        for i in range(3): w.step(i)
+        torch.cuda.synchronize()
+        _, _, us = bench.timed(w, 20, 0.15)
+        print(N, "f64" if dt == DT.F64 else "f32", round(us, 2), round(w.alg_bytes / us / 1e3 / 8000, 4), flush=True)
+        del w; torch.cuda.empty_cache()
+PY
