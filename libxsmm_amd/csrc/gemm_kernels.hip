@@ -893,7 +893,15 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs p) {
 //   * the epilogue variants (beta / bias / activation / bitmask) sit behind wave-uniform branches.
 // Measured with tools/gemm_probe.hip; PMC: 86 VALU + 5 SALU instructions per wave for the probe kernel.
 // ------------------------------------------------------------------------------------------------
-template <bool TA, bool TB>
+// BF32 (round 3): f32 storage whose operands the reference rounds to bf16 before multiplying [ref: gemm ref :1366, :1384-1389] -- the loaded vectors are
+// rounded in registers (the reference's RNE: software, so denormals and NaNs agree too); products of two bf16 values are exact in f32, so the MFMA's
+// k-ordered chain equals the reference's loop bit for bit.
+__device__ __forceinline__ f32x4 round_to_bf16(f32x4 v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = __uint_as_float((unsigned int)f32_to_bf16_rne(v[e]) << 16);
+  return v;
+}
+template <bool TA, bool TB, bool BF32 = false>
 __global__ __launch_bounds__(256) void gemm_f32_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds_all[4][2048];
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -950,6 +958,10 @@ __global__ __launch_bounds__(256) void gemm_f32_stream_kernel(GemmArgs p) {
   }
   for (unsigned long long t = 0; t < total; ++t) {
     float af[16], bf[16];
+    if constexpr (BF32) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { ga[x] = round_to_bf16(ga[x]); gb[x] = round_to_bf16(gb[x]); }
+    }
     tile_to_frag<TA>(af, ga, lds, (int)lane);
     tile_to_frag<!TB>(bf, gb, lds + 1024, (int)lane);
     if (++kc == kchunks) { kc = 0; if (++r < p.br_count) br_base(p, q, r, ar, br); }
@@ -3475,6 +3487,20 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     return dim3((unsigned int)((tiles + 3) / 4));
   };
   dim3 grid;
+  // BF32 on whole 32 x 32 x 32 tiles: the f32 streaming kernel with the operands rounded to bf16 in registers (bit-identical to the reference loop)
+  if (a.a_type == LIBXSMM_DATATYPE_BF32 && a.b_type == LIBXSMM_DATATYPE_BF32 && a.c_type == LIBXSMM_DATATYPE_F32 && (a.m % 32) == 0 && (a.n % 32) == 0 && (a.k % 32) == 0 && a.k > 0 &&
+      !a.colbias && !a.act && !a.vnni_c && !(a.flags & (LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B)) && operands_aligned16(a, 4) &&
+      a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22) &&
+      ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 3ull) == 0ull)) {
+    const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
+    grid = wave_grid(32, 32);
+    if (kernel_name) *kernel_name = "gemm_bf32_stream_kernel";
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_stream_kernel<false, false, true>), grid, dim3(256), 0, st, a);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_stream_kernel<true, false, true>), grid, dim3(256), 0, st, a);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_stream_kernel<false, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f32_stream_kernel<true, true, true>), grid, dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+  }
   // 2-D batches of f32 16 x 16 x K tiles with a plain epilogue: the blocked kernel on 2 x 2 sub-blocks
   if (a.batch_inner && f32_blocked16_ok(a)) {
     a.tiles_m = a.tiles_n = 1; a.map2d_shift = 0;

@@ -850,7 +850,7 @@ def _more_types():
 
 
 @pytest.mark.parametrize("t", _more_types(), ids=lambda t: f"{int(t['a'])}x{int(t['b'])}to{int(t['c'])}f{t['flags']}")
-@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (17, 7, 16, 20, 24, 24, 1, 1, 1), (64, 32, 64, 64, 64, 64, 3, 1, 5)])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (17, 7, 16, 20, 24, 24, 1, 1, 1), (64, 32, 64, 64, 64, 64, 3, 1, 5), (32, 32, 32, 32, 32, 32, 1, 0, 1), (96, 64, 32, 96, 96, 100, 1, 0, 3)])
 def test_more_gemm_types_bit_exact(t, m, n, k, lda, ldb, ldc, br, beta, batch):
     import torch
     from test_oracle_pin import more_types_case
@@ -891,6 +891,9 @@ def test_more_gemm_types_bit_exact(t, m, n, k, lda, ldb, ldc, br, beta, batch):
     if t["a"] == DT.I8 and batch > 1 and br > 1:
         return                                    # scales step with the batch stride of A, which here spans br blocks: not the layout of this test
     assert got.tobytes() == ref.tobytes()
+    if t["a"] == DT.BF32 and m % 32 == 0 and n % 32 == 0 and k % 32 == 0:
+        # whole tiles: the f32 matrix-core streaming kernel with the operands rounded to bf16 in registers (round 3) -- still bit-identical
+        assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode() == "gemm_bf32_stream_kernel"
     if batch == 1:
         hc = C0.copy()
         p.a.primary, p.a.tertiary, p.b.primary, p.c.primary = A.ctypes.data, SCF.ctypes.data, B.ctypes.data, hc.ctypes.data
