@@ -672,6 +672,32 @@ __global__ __launch_bounds__(256) void gather_scatter_kernel(MeltwArgs p) {
 #undef XIDX
 }
 
+// GS_OFFS (one linear offset per element), four consecutive elements per thread (round 3): the four offsets arrive as one vector load, the four random
+// accesses are in flight together, the contiguous side moves as one vector.  m % 4 == 0, 4-byte offsets 16-byte aligned, contiguous side 4 * S aligned.
+template <int S>
+__global__ __launch_bounds__(256) void gs_offs_vec4_kernel(MeltwArgs p, unsigned int m4, unsigned int total) {
+  typedef typename Payload<S>::type T;
+  typedef T T4 __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4i __attribute__((ext_vector_type(4)));
+  const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= total) return;
+  const unsigned int j = gid / m4, i = (gid - j * m4) * 4u;
+  GM const T* in = (GM const T*)((gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0);
+  GM T* out = (GM T*)((gptr)p.out + (long long)blockIdx.y * p.bs_out);
+  const bool gather = (p.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER);
+  const u32x4i off = *(GM const u32x4i*)((GM const unsigned int*)(gather ? p.aux_in : (const void*)p.aux_out) + (long long)j * p.m + i);
+  if (gather) {
+    T4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = in[off[e]];
+    *(GM T4*)(out + i + (long long)j * p.ldo) = v;
+  } else {
+    const T4 v = *(GM const T4*)(in + i + (long long)j * p.ldi);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[off[e]] = v[e];
+  }
+}
+
 // whole-column gather / scatter (GS_COLS) with 16-byte accesses: a thread moves 16 bytes of one column; the column index is
 // read once per thread (same address across the lanes of a column segment -> broadcast).  Needs (m * S) % 16 == 0, 16-byte
 // aligned bases and leading dimensions that keep every column 16-byte aligned.
@@ -1582,6 +1608,15 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
           default: hipLaunchKernelGGL((gs_rows_lds_kernel<8>), dim3((unsigned int)a.n, a.nbatch), dim3(256), lds_bytes, st, a, rows); break;
         }
         if (name) *name = "gs_rows_lds_kernel";
+      } else if (!(a.flags & (LIBXSMM_MELTW_FLAG_UNARY_GS_COLS | LIBXSMM_MELTW_FLAG_UNARY_GS_ROWS | LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_8BYTES)) && !xvec_off && (sz == 4 || sz == 2) &&
+                 a.m % 4 == 0 && (long long)a.m * a.n / 4 < (1ll << 31) &&
+                 ((size_t)(a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER ? a.aux_in : (const void*)a.aux_out) % 16) == 0 &&
+                 (a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER ? (((size_t)a.out | (size_t)a.bs_out) % (4 * sz) == 0 && ((long long)a.ldo * sz) % (4 * sz) == 0)
+                                                             : (((size_t)a.in0 | (size_t)a.bs_in0) % (4 * sz) == 0 && ((long long)a.ldi * sz) % (4 * sz) == 0))) {
+        const unsigned int m4 = (unsigned int)(a.m / 4), tot4 = m4 * (unsigned int)a.n;
+        if (sz == 4) hipLaunchKernelGGL((gs_offs_vec4_kernel<4>), dim3((tot4 + 255u) / 256u, a.nbatch), dim3(256), 0, st, a, m4, tot4);
+        else hipLaunchKernelGGL((gs_offs_vec4_kernel<2>), dim3((tot4 + 255u) / 256u, a.nbatch), dim3(256), 0, st, a, m4, tot4);
+        if (name) *name = "gs_offs_vec4_kernel";
       } else {
         LAUNCH_BY_SIZE(gather_scatter_kernel, sz, dim3((unsigned int)((total + 255) / 256), a.nbatch), dim3(256), st, a);
         if (name) *name = "gather_scatter_kernel";
