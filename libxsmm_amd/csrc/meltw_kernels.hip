@@ -649,6 +649,23 @@ __global__ __launch_bounds__(256) void xform_kernel(MeltwArgs p, int mode, int v
   }
 }
 
+// NORM -> VNNI2 of 16-bit elements with any leading dimensions (round 3; the 16-byte kernel above needs multiples of 8): a thread owns ONE output dword =
+// rows (2 jb, 2 jb + 1) of column position i, two 2-byte loads (coalesced along i) and one dword store; positions beyond m and a missing odd row are zero
+// like the reference's fill [ref: :532-557].  32-bit index arithmetic, no division per element beyond one per thread.
+__global__ __launch_bounds__(256) void vnni2_pair_kernel(MeltwArgs p, unsigned int per_batch) {
+  const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= per_batch) return;
+  const unsigned int ldo = (unsigned int)p.ldo, jb = gid / ldo, i = gid - jb * ldo;
+  GM const unsigned short* in = (GM const unsigned short*)((gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0);
+  GM unsigned int* out = (GM unsigned int*)((gptr)p.out + (long long)blockIdx.y * p.bs_out);
+  unsigned int lo = 0, hi = 0;
+  if (i < (unsigned int)p.m) {
+    lo = in[(long long)(2u * jb) * p.ldi + i];
+    if (2u * jb + 1u < (unsigned int)p.n) hi = in[(long long)(2u * jb + 1u) * p.ldi + i];
+  }
+  out[gid] = lo | (hi << 16);
+}
+
 // gather / scatter [ref: :1444-1790]; lanes along the contiguous (i) axis where there is one
 template <int S>
 __global__ __launch_bounds__(256) void gather_scatter_kernel(MeltwArgs p) {
@@ -1574,6 +1591,10 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       const unsigned int o8 = (unsigned int)(a.ldo / 8), total = o8 * (unsigned int)((a.n + 1) / 2) * (unsigned int)a.nbatch;
       hipLaunchKernelGGL(vnni2_vec_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, a, o8, total);
       if (name) *name = "vnni2_vec_kernel";
+    } else if (mode == XF_NORM_TO_VNNI && v == 2 && sz == 2 && !xvec_off && (((size_t)a.out | (size_t)a.bs_out) % 4) == 0 && (long long)a.ldo * ((a.n + 1) / 2) < (1ll << 31) && a.nbatch < 65536) {
+      const unsigned int per_batch = (unsigned int)a.ldo * (unsigned int)((a.n + 1) / 2);
+      hipLaunchKernelGGL(vnni2_pair_kernel, dim3((per_batch + 255u) / 256u, a.nbatch), dim3(256), 0, st, a, per_batch);
+      if (name) *name = "vnni2_pair_kernel";
     } else if (mode == XF_NORM_TO_VNNI && v == 4 && sz == 1 && !xvec_off && base16 && a.m % 4 == 0 && a.ldi % 4 == 0 && a.ldo % 4 == 0 &&
                (long long)(a.ldo / 4) * ((a.n + 3) / 4) * a.nbatch < (1ll << 32) - 256) {
       const unsigned int o4 = (unsigned int)(a.ldo / 4), total = o4 * (unsigned int)((a.n + 3) / 4) * (unsigned int)a.nbatch;
