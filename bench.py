@@ -242,6 +242,7 @@ def estimate_step_seconds(work, n=8):
 
 
 EAGER = False
+REPLAY_SYNC = None  # N > 1: every rank replays its graph the SAME number of times (the largest any rank calibrated), so that "K steps" means one thing
 MANIFEST = []      # execution order of the library launches, for tools/summarize_profiles.py (splits a kernel trace by workload)
 
 
@@ -276,6 +277,8 @@ def timed(work, steps, min_seconds, barrier=lambda: None, label=None, lanes=0):
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record(); g.replay(); c1.record(); torch.cuda.synchronize()        # untimed calibration: how long one replay really takes
         replays = max(1, int(math.ceil(min_seconds / max(c0.elapsed_time(c1) * 1e-3, 1e-6) * 1.05)))
+        if REPLAY_SYNC is not None:
+            replays = REPLAY_SYNC(replays)
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()
@@ -681,6 +684,14 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    if dist is not None:
+        def _same_replays(r):
+            t = torch.tensor([float(r)], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return int(t.item())
+        global REPLAY_SYNC
+        REPLAY_SYNC = _same_replays
 
     api = capi.load()
     api.hip_set_device(local)
