@@ -43,7 +43,7 @@ struct Equation {
 };
 
 struct EqnStep { MeltwArgs args; int src[3]; int node; int alpha_from_op; int dump_from_op; int idx_from_input; int root_side; bool scalar_arg[3];
-  const void* gemm; int br_from_op; int out_loc; };   // gemm: dispatched (BR)GEMM handle of a MATMUL / BRGEMM node; out_loc: like src, INT32_MIN = the caller's output   // idx_from_input: GATHER reads its indices from inputs[pos].secondary   // root_side: 1 bitmask, 2 UNZIP offset from output.secondary   // src: >=0 input position, < 0: -(slot+1)
+  const void* gemm; int br_from_op; int out_loc; bool skip_if_in_place; };   // gemm: dispatched (BR)GEMM handle of a MATMUL / BRGEMM node; out_loc: like src, INT32_MIN = the caller's output   // idx_from_input: GATHER reads its indices from inputs[pos].secondary   // root_side: 1 bitmask, 2 UNZIP offset from output.secondary   // src: >=0 input position, < 0: -(slot+1)
 struct EqnPlan {
   bool out_scalar = false;          // a 1 x 1 result (a dot product, a full reduction): callers keep it on their stack -> staged like scalar inputs
   size_t out_scalar_bytes = 4;
@@ -567,6 +567,7 @@ void run_meqn(EqnPlan* plan, const void* param) {
     }
     a.in0 = src[0]; a.in1 = src[1]; a.in2 = src[2];
     a.out = st.out_loc == INT32_MIN ? out_primary : (st.out_loc >= 0 ? (char*)p->inputs[st.out_loc].primary : ws + plan->slot_bytes * (size_t)(-st.out_loc - 1));
+    if (st.skip_if_in_place && (const char*)a.out == src[0]) continue;     // C += A * B with the accumulator passed as the output: nothing to copy
     if (st.gemm) {   // a MATMUL / BRGEMM node: the dense kernel, called like any other handle (its own launch bookkeeping included)
       libxsmm_gemm_param gp; std::memset(&gp, 0, sizeof(gp));
       unsigned long long blocks = 1;
@@ -593,6 +594,9 @@ void run_meqn(EqnPlan* plan, const void* param) {
     } else if (st.root_side == 2) {
       if (!p->output.secondary) { set_error(-2, "matrix equation: the head is UNZIP but output.secondary (byte offset of the upper halves) is NULL"); return; }
       a.scalar_u64 = *(const unsigned long long*)p->output.secondary;
+    } else if (st.root_side == 3) {
+      if (!p->output.secondary) { set_error(-2, "matrix equation: the head is SCATTER but output.secondary (the index list) is NULL"); return; }
+      a.aux_out = p->output.secondary;
     }
     if (st.idx_from_input >= 0) {
       if (!p->inputs[st.idx_from_input].secondary) { set_error(-2, "matrix equation: GATHER needs its index list in inputs[%d].secondary", st.idx_from_input); return; }
@@ -695,10 +699,12 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       // the head keeps its own inferred extent; the caller's shape contributes the leading dimension and the type, as in the reference
       // (src/libxsmm_matrixeqn.c:868-936: samples/equation/equation_gather_dot.c declares an M x 1 output for a head that reduces to 1 x 1)
       const bool reducing_head = nd.kind == EQ_UNARY && is_reduce(nd.op);
-      if (((out.m != nd.m || out.n != nd.n) && !(reducing_head && out.m >= nd.m && out.n >= nd.n)) || out.ld < nd.m) {
+      // a SCATTER head spreads its operand over the caller's (larger) output: only the leading dimension is the caller's business
+      // [ref: generator_matequation_reference_impl.c:41-56: SCATTER exists as the head only, its index list is output.secondary]
+      const bool scatter_head = nd.kind == EQ_UNARY && nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER;
+      if (((out.m != nd.m || out.n != nd.n) && !(reducing_head && out.m >= nd.m && out.n >= nd.n) && !scatter_head) || (out.ld < nd.m && !scatter_head) || out.ld < 1) {
         rt_note("equation refused: output shape differs from the head node (m, n, ld)", out.m, out.n, out.ld); delete plan; return nullptr;
       }
-      if (accumulates) { rt_note("equation refused: a MATMUL / BRGEMM node that accumulates into its third operand cannot be the head", nd.op, 0, 0); delete plan; return nullptr; }
       nd.ld = out.ld; nd.type = out.type;
       plan->out_scalar = (nd.m == 1 && nd.n == 1); plan->out_scalar_bytes = (size_t)std::max(1, typesize((int)out.type));
     } else if (accumulates) {
@@ -707,7 +713,7 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
     } else { plan->slot_of[id] = plan->nslots++; loc[id] = -(plan->slot_of[id] + 1); }
     EqnStep st; std::memset(&st.args, 0, sizeof(st.args));
     st.node = id; st.alpha_from_op = -1; st.dump_from_op = -1; st.idx_from_input = -1; st.root_side = 0; st.scalar_arg[0] = st.scalar_arg[1] = st.scalar_arg[2] = false; st.src[0] = st.src[1] = st.src[2] = INT32_MIN;
-    st.gemm = nullptr; st.br_from_op = -1; st.out_loc = loc[id];
+    st.gemm = nullptr; st.br_from_op = -1; st.out_loc = loc[id]; st.skip_if_in_place = false;
     MeltwArgs& a = st.args;
     a.nbatch = 1; a.flags = nd.flags; a.type = nd.op; a.comp_type = nd.dtype; a.out_type = nd.type; a.ldo = nd.ld;
     a.in0_type = a.in1_type = a.in2_type = LIBXSMM_DATATYPE_UNSUPPORTED;
@@ -732,6 +738,21 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       } else fn = libxsmm_dispatch_gemm(sh, fl, LIBXSMM_GEMM_PREFETCH_NONE);
       if (!fn) { rt_note("equation refused: no GEMM kernel for a MATMUL / BRGEMM node (a, b, c type)", A.type, B.type, nd.type); delete plan; return nullptr; }
       st.gemm = (const void*)fn; plan->has_gemm = true;
+      if (root && accumulates) {
+        // the head accumulates into its third operand but the result belongs in the caller's output: the operand is copied (and converted) there
+        // first, unless the caller passed the very same matrix as input and output -- the usual C += A * B call -- which is checked per call
+        const EqnNode& Cn = *ch[2];
+        EqnStep cp = st; cp.gemm = nullptr; cp.br_from_op = -1; cp.skip_if_in_place = true;
+        cp.src[0] = st.src[2]; cp.src[1] = cp.src[2] = INT32_MIN; cp.scalar_arg[0] = cp.scalar_arg[1] = cp.scalar_arg[2] = false;
+        MeltwArgs& c = cp.args;
+        c.operation = LIBXSMM_MELTW_OPERATION_UNARY; c.type = LIBXSMM_MELTW_TYPE_UNARY_IDENTITY; c.flags = 0; c.comp_type = LIBXSMM_DATATYPE_F32;
+        c.m = nd.m; c.n = nd.n; c.in0_type = Cn.type; c.ldi = Cn.ld; c.out_type = nd.type; c.ldo = nd.ld;
+        libxsmm_descriptor_blob cb;
+        const libxsmm_meltw_descriptor* cd = libxsmm_meltw_descriptor_init2(&cb, (libxsmm_datatype)c.in0_type, LIBXSMM_DATATYPE_UNSUPPORTED, LIBXSMM_DATATYPE_UNSUPPORTED, LIBXSMM_DATATYPE_F32,
+          (libxsmm_datatype)c.out_type, c.m, c.n, c.ldi, c.ldo, 0, 0, 0, (unsigned short)LIBXSMM_MELTW_TYPE_UNARY_IDENTITY, LIBXSMM_MELTW_OPERATION_UNARY);
+        if (!cd || !meltw_supported(*cd)) { rt_note("equation refused: the accumulator of the head GEMM cannot be copied to the output (in type, out type)", Cn.type, nd.type, 0); delete plan; return nullptr; }
+        plan->steps.push_back(cp);
+      }
       plan->steps.push_back(st);
       continue;
     }
@@ -749,10 +770,11 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       // side channels through output.secondary exist for the head of the tree only [ref: matequation ref :40-55]: the ReLU bitmask,
       // the byte offset of UNZIP's second half
       if ((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && nd.op == LIBXSMM_MELTW_TYPE_UNARY_RELU && root) st.root_side = 1;
+      if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER && root) st.root_side = 3;
       if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP && root) st.root_side = 2;
       // a GATHER directly above an argument takes its index list from that argument's secondary slot [ref: samples/equation/equation_gather_reduce.c:150-166]
       if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER && ch[0]->kind == EQ_ARG) st.idx_from_input = ch[0]->in_pos;
-      if (((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && st.root_side != 1) || (nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER && st.idx_from_input < 0) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER ||
+      if (((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && st.root_side != 1) || (nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER && st.idx_from_input < 0) || (nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER && st.root_side != 3) ||
           (nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP && st.root_side != 2) || (nd.op == LIBXSMM_MELTW_TYPE_UNARY_DUMP && nd.op_arg_pos < 0) || nd.op == LIBXSMM_MELTW_TYPE_UNARY_REPLICATE_COL_VAR ||
           nd.op == LIBXSMM_MELTW_TYPE_UNARY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_LEAKY_RELU_INV || nd.op == LIBXSMM_MELTW_TYPE_UNARY_ELU_INV) d = nullptr;
       // parameterised activations: the reference's equation generators do not apply ops_args to them (its CPU JIT leaves the

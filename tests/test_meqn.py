@@ -530,3 +530,78 @@ def test_gpu_meqn_gather_node_above_an_argument(dt, idx_bytes):
     capi.Api.call(h, p)
     assert api.hip_get_last_error() != 0
     api.hip_clear_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_place", [True, False], ids=["in_place", "separate_output"])
+def test_gpu_meqn_accumulating_gemm_as_the_head(in_place):
+    """C += A x B as the WHOLE equation: a TERNARY_MATMUL head with REUSE_IN_2_AS_OUT.  Its result belongs in the caller's output: with the accumulator
+    passed as input 2 AND as the output nothing is copied; with a separate output the accumulator is copied there first and stays untouched."""
+    import torch
+    api = capi.load()
+    m, n, k = 32, 48, 24
+    shapes = [(m, k, m, DT.F32), (k, n, k + 2, DT.F32), (m, n, m + 4, DT.F32)]
+    arrays = _inputs(shapes, 11)
+    idx = api.meqn_create()
+    md = lambda pos=-1: capi.MeqnMetadata(idx, pos)    # noqa: E731
+    assert api.meqn_push_back_ternary_op(md(), TERNARY.MATMUL, DT.F32, TERNARY_FLAG.REUSE_IN_2_AS_OUT) == 0
+    for i in range(3):
+        assert api.meqn_push_back_arg(md(i), capi.MeqnArgShape(*shapes[i]), SINGULAR) == 0
+    out_shape = shapes[2] if in_place else (m, n, m + 8, DT.F32)
+    h = api.dispatch_meqn(idx, capi.MeqnArgShape(*out_shape))
+    assert h
+    dev = [torch.from_numpy(a.copy()).to("cuda:0") for a in arrays]
+    out = dev[2] if in_place else torch.zeros(out_shape[2] * n, dtype=torch.float32, device="cuda:0")
+    _call(api, h, [d.data_ptr() for d in dev], out.data_ptr())
+    api.hip_sync(); api.check()
+    A, B, Cacc = (_mat(arrays[i], *shapes[i])[0] for i in range(3))
+    gold = Cacc + B @ A                                                          # [col][row] storage
+    got = _mat(out.cpu().numpy(), *out_shape)[0]
+    assert np.sqrt(((got - gold) ** 2).sum() / (gold ** 2).sum()) < 2e-6
+    if not in_place:
+        assert np.array_equal(dev[2].cpu().numpy(), arrays[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16], ids=["f32", "bf16"])
+def test_gpu_meqn_scatter_as_the_head(dt):
+    """scatter_cols(A + B, idx): SCATTER exists as the head of an equation only and takes its index list from output.secondary
+    (generator_matequation_reference_impl.c:41-56); the columns that no index names keep what the output held."""
+    import torch
+    api = capi.load()
+    m, n, ld, big_n = 40, 13, 48, 40
+    shapes = [(m, n, ld, dt), (m, n, m, dt)]
+    arrays = _inputs(shapes, 13)
+    rng = np.random.default_rng(4)
+    cols = rng.permutation(big_n)[:n].astype(np.uint32)
+    idx = api.meqn_create()
+    md = lambda pos=-1: capi.MeqnMetadata(idx, pos)    # noqa: E731
+    assert api.meqn_push_back_unary_op(md(), UNARY.SCATTER, dt, UNARY_FLAG.GS_COLS | UNARY_FLAG.IDX_SIZE_4BYTES) == 0
+    assert api.meqn_push_back_binary_op(md(), BINARY.ADD, DT.F32, 0) == 0
+    assert api.meqn_push_back_arg(md(0), capi.MeqnArgShape(*shapes[0]), SINGULAR) == 0
+    assert api.meqn_push_back_arg(md(1), capi.MeqnArgShape(*shapes[1]), SINGULAR) == 0
+    h = api.dispatch_meqn(idx, capi.MeqnArgShape(m, big_n, ld, dt))
+    assert h
+    dev = [torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to("cuda:0") for a in arrays]
+    before = rand_values(rng, ld * big_n, dt)
+    out = torch.from_numpy(before.view(np.int16) if before.dtype == np.uint16 else before.copy()).to("cuda:0")
+    idd = torch.from_numpy(cols.view(np.int32)).to("cuda:0")
+    inputs = (capi.MatrixArg * 2)()
+    for i, d in enumerate(dev):
+        inputs[i].primary = d.data_ptr()
+    p = capi.MeqnParam()
+    p.inputs = inputs
+    p.output.primary, p.output.secondary = out.data_ptr(), idd.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    A, B = (_mat(arrays[i], *shapes[i])[0] for i in range(2))
+    gold = _mat(before, m, big_n, ld, dt)[0].copy()
+    gold[cols.astype(np.int64)] = A + B
+    got = _mat(out.cpu().numpy().view(NPDT[dt]), m, big_n, ld, dt)[0]
+    untouched = np.setdiff1d(np.arange(big_n), cols)
+    assert np.array_equal(got[untouched], gold[untouched])
+    assert np.sqrt(((got - gold) ** 2).sum() / (gold ** 2).sum()) < (1e-6 if dt == DT.F32 else 8e-3)
+    p.output.secondary = None
+    capi.Api.call(h, p)
+    assert api.hip_get_last_error() != 0
+    api.hip_clear_last_error()
