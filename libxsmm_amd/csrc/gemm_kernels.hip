@@ -709,6 +709,16 @@ __device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
   const f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwbf16x2));
 }
+// The reference's conversion EXACTLY (denormal inputs become signed zeros first), on the hardware instruction: ~4 vector instructions per element instead of the ~12
+// (and a divergent branch) of f32_to_bf16_rne.  NaNs are the one input whose result the instruction may encode differently: `nan_seen` collects them so that the
+// caller can send a wave that holds one through the software conversion.
+__device__ __forceinline__ unsigned int cvt_pk_bf16_dazexact(float lo, float hi, bool& nan_seen) {
+  const unsigned int ul = __float_as_uint(lo), uh = __float_as_uint(hi);
+  const float fl = __builtin_amdgcn_class(lo, 0x090) ? __uint_as_float(ul & 0x80000000u) : lo;      // class bits 4 / 7: negative / positive denormal
+  const float fh = __builtin_amdgcn_class(hi, 0x090) ? __uint_as_float(uh & 0x80000000u) : hi;
+  nan_seen = nan_seen || __builtin_amdgcn_class(lo, 0x003) || __builtin_amdgcn_class(hi, 0x003);   // class bits 0 / 1: signalling / quiet NaN
+  return cvt_pk_bf16(fl, fh);
+}
 // the same for IEEE halves (RNE, the conversion the reference's f32 -> f16 helper performs [ref: src/libxsmm_math.c libxsmm_convert_f32_to_f16])
 typedef _Float16 hwf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int cvt_pk_f16(float lo, float hi) {
@@ -2416,8 +2426,12 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int sub_bytes(unsigned int x, unsigned int y) {
   return (int)((((x | 0x80808080u) - (y & 0x7f7f7f7fu))) ^ ((x ^ ~y) & 0x80808080u));
 }
-template <int MT, int NT, bool UA, bool UB, bool I4 = false>
+// LB (round 3): the packed low-bit weights expanded to signed bytes in registers -- 1: interleaved 4-bit minus a zero point per row (I4X2); 2: interleaved 2-bit codes
+// 0 / +1 / -1 / -1, the rows in four groups of m / 4 sharing a byte (I2X4: one dword per k-quad and lane, the lane's group selects the bit pair, v_perm_b32 maps the
+// four codes at once); 3: 1-bit signs, a byte = four k of two rows (I1X8: one byte per k-quad and lane, the nibble spread to one bit per byte by a multiply).
+template <int MT, int NT, bool UA, bool UB, int LB = 0>
 __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
+  constexpr bool I4 = LB == 1;
   __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
@@ -2442,6 +2456,7 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
     gcptr ar, br; br_base(p, q, r, ar, br);
     const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + (unsigned long long)job.j0 * ldb);     // buffer addressing, see gemm_bf16_stream_kernel
     const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)job.i0);
+    const __amdgpu_buffer_rsrc_t ra0 = wave_rsrc(ar);          // LB 2 / 3: the lane's row decides where in a k-quad's bytes its bits sit
     unsigned int zz[MT];
     if (I4) {       // the zero points of this lane's rows for batch-reduce block r: one byte per row, stepped with A [run_gemm: bs_scf, (br_stride_a * 2) / k per block]
       const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0;
@@ -2465,6 +2480,31 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
               af[mt][s][2 * e] = sub_bytes(w & 0x0f0f0f0fu, zz[mt]);
               af[mt][s][2 * e + 1] = sub_bytes((w >> 4) & 0x0f0f0f0fu, zz[mt]);
             }
+      } else if constexpr (LB == 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const unsigned int i = (unsigned int)(job.i0 + 32 * mt + li), mq = (unsigned int)p.m >> 2, g = i / mq, rr = i - g * mq;
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned int w = (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(ra0, (int)((8u * s + 4u * h + e) * lda + 4u * rr), 16 * kc * (int)lda, 0);
+              af[mt][s][e] = (int)__builtin_amdgcn_perm(0u, 0xffff0100u, (w >> (2u * g)) & 0x03030303u);
+            }
+        }
+      } else if constexpr (LB == 3) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const unsigned int i = (unsigned int)(job.i0 + 32 * mt + li);
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned int b = (unsigned int)__builtin_amdgcn_raw_buffer_load_b8(ra0, (int)((8u * s + 4u * h + e) * (lda >> 1) + (i >> 1)), 16 * kc * (int)(lda >> 1), 0) & 0xffu;
+              const unsigned int x = ((((b >> (4u * (i & 1u))) & 0xfu) * 0x00204081u) & 0x01010101u);
+              af[mt][s][e] = (int)((x * 0xfeu) | 0x01010101u);
+            }
+        }
       } else
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -2523,9 +2563,12 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
 // a 64-deep chunk (two blocks x 32 columns per tile) through a wave-private LDS image, read back as four 16-byte pieces per block.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int mx4_codes_to_bytes(unsigned int codes) {       // four E2M1 codes (one per byte) -> four signed bytes of the reference's integer table
-  const unsigned int mag = (unsigned int)__builtin_amdgcn_perm(0x7f55402au, 0x20150b00u, codes & 0x07070707u);
+  // one look-up in the table {0, 11, 21, 32, 42, 64, 85, 127}, one in its negation, the sign bit of each code selects (v_bfi_b32): 7 instructions for four codes
+  const unsigned int sel = codes & 0x07070707u;
+  const unsigned int pos = (unsigned int)__builtin_amdgcn_perm(0x7f55402au, 0x20150b00u, sel);
+  const unsigned int neg = (unsigned int)__builtin_amdgcn_perm(0x81abc0d6u, 0xe0ebf500u, sel);
   const unsigned int sm = ((codes >> 3) & 0x01010101u) * 0xffu;
-  return sub_bytes(mag ^ sm, sm);
+  return (int)((neg & sm) | (pos & ~sm));
 }
 // Four waves per SIMD (118 registers instead of 152): the kernel is bound by the latency of one short wave per tile, not by its instructions -- 0.30 / 0.33 ->
 // 0.38 / 0.46 (bf16 / f32 C); five waves per SIMD spill 19 registers and halve the speed.
@@ -2617,6 +2660,157 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       else { GM unsigned short* c = (GM unsigned short*)q.c + e; *c = f32_to_bf16_rne(add_rn(beta0 ? 0.0f : bf16_to_f32(*c), facc[mt][nt][r2])); }
     }
   });
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The same arithmetic with waves that walk G consecutive tiles (round 3).  gemm_mx4i8_stream_kernel is one short wave per 32 x 32 tile: a load round trip,
+// two MFMAs, sixteen 2- or 4-byte stores per lane -- 5 us of wave lifetime for 5 KiB, and 16 + 9 vector-memory instructions whose addresses the texture unit
+// works through at a quarter wave per clock.  Here (a) the chunks of the wave's tiles form ONE flat sequence and the operands of chunk f + 1 are requested
+// before chunk f is multiplied (all through registers: B fragments are 16 contiguous bytes of a column, which is what the MFMA wants, so no LDS image and
+// no hand-counted waits -- the compiler tracks every load), (b) with beta = 0 a finished tile leaves through a column-major LDS image as whole columns:
+// 2 (bf16) or 4 (f32) 16-byte stores per lane instead of 16 element stores.  Bit-identical to the one-tile kernel (same sums in the same order).
+// ------------------------------------------------------------------------------------------------
+struct Mx4i8Tile { BatchPtrs q; unsigned int bidx; int i0, j0; };
+__device__ __forceinline__ Mx4i8Tile mx4i8_tile(const GemmArgs& p, unsigned int id) {
+  Mx4i8Tile t;
+  const unsigned int per_gemm = (unsigned int)(p.tiles_m * p.tiles_n);
+  t.bidx = per_gemm == 1 ? id : id / per_gemm;
+  const unsigned int r = id - t.bidx * per_gemm, tn = r / (unsigned int)p.tiles_m;
+  t.i0 = (int)(r - tn * (unsigned int)p.tiles_m) * 32; t.j0 = (int)tn * 32;
+  t.q = batch_ptrs(p, t.bidx);
+  return t;
+}
+struct Mx4i8Chunk { u32x4 b[2]; unsigned int a[4]; unsigned int sa[2]; float cs; };
+template <int D>          // chunks in flight per wave (the ring): one round trip of ~2.5 us against ~0.3 us of work per chunk wants about ten per SIMD
+__global__ __launch_bounds__(256) void gemm_mx4i8_pipe_kernel(GemmArgs p, unsigned int per_wave, unsigned int total_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds_all[4][1024 + 64];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int first = (blockIdx.x * 4u + wave) * per_wave;
+  if (first >= total_tiles) return;
+  const unsigned int ntiles = total_tiles - first < per_wave ? total_tiles - first : per_wave;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  float* lds = lds_all[wave];
+  float* lds_sb = lds + 1024;                                      // [block of the chunk][32 columns]
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const unsigned int offA = ((2u * h) * lda + (unsigned int)li) * 4u, offB = (unsigned int)li * ldb + 16u * h;
+  const unsigned int kchunks = (unsigned int)p.k >> 6;
+  const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
+  const int nsb = p.ldb / 32;
+  const unsigned long long per_tile = p.br_count * kchunks, total = per_tile * ntiles;
+  // the chunk the NEXT request goes to
+  Mx4i8Tile nx = mx4i8_tile(p, first);
+  unsigned int n_tile = 0, n_kc = 0; unsigned long long n_r = 0;
+  auto request = [&](Mx4i8Chunk& c) __attribute__((always_inline)) {
+    gcptr ar, br; br_base(p, nx.q, n_r, ar, br);
+    const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + (unsigned long long)nx.j0 * ldb);
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)nx.i0);
+    GM const unsigned char* sa = (GM const unsigned char*)p.a_scf + (long long)nx.bidx * p.bs_scf + ((brs_a * 2) / 32) * (long long)n_r + nx.i0 + li;
+    GM const float* sb = (GM const float*)(p.b_scf + (long long)nx.bidx * p.bs_bscf) + (brs_b / 32) * (long long)n_r + (long long)nx.j0 * nsb;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) c.b[s2] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(offB + 32u * s2), 64 * (int)n_kc, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) c.a[2 * s2 + e] = (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (4u * s2 + e) * lda * 4u), 32 * (int)n_kc * (int)lda, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) c.sa[s2] = sa[(long long)(2 * n_kc + s2) * lda];
+    c.cs = sb[(long long)li * nsb + 2 * n_kc + h];
+    if (++n_kc == kchunks) { n_kc = 0; if (++n_r == p.br_count) { n_r = 0; if (++n_tile < ntiles) nx = mx4i8_tile(p, first + n_tile); } }
+  };
+  Mx4i8Chunk ring[D];
+  static_for<D>([&](auto uc) { if ((unsigned long long)uc.value < total) request(ring[uc.value]); });
+  Mx4i8Tile cur = mx4i8_tile(p, first);                            // the tile whose chunks are being multiplied
+  unsigned int c_tile = 0;
+  typedef float f32x2p __attribute__((ext_vector_type(2)));
+  f32x2p facc2[8];
+#pragma unroll
+  for (int r2 = 0; r2 < 8; ++r2) facc2[r2] = (f32x2p)0.0f;
+  unsigned long long left_in_tile = per_tile;
+  for (unsigned long long f0 = 0; f0 < total; f0 += D) {
+    static_for<D>([&](auto uc) {
+      constexpr int u = uc.value;
+      const unsigned long long f = f0 + u;
+      if (f < total) {
+        const Mx4i8Chunk c = ring[u];
+        if (f + D < total) request(ring[u]);
+        i32x4 af[2]; float rs[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          rs[s2] = __uint_as_float(c.sa[s2] << 23);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            af[s2][2 * e] = mx4_codes_to_bytes(c.a[2 * s2 + e] & 0x0f0f0f0fu);
+            af[s2][2 * e + 1] = mx4_codes_to_bytes((c.a[2 * s2 + e] >> 4) & 0x0f0f0f0fu);
+          }
+        }
+        lds_sb[32 * h + li] = c.cs;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          f32x4 cs[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) cs[g] = *(const f32x4*)(lds_sb + 32 * s2 + 8 * g + 4 * h);
+          const i32x16 t = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, c.b[s2]), af[s2], (i32x16)0, 0, 0, 0);
+          // two elements per instruction (v_pk_mul_f32 / v_pk_add_f32: each lane of the pair rounds like the scalar operation; contraction is off in this file)
+          const f32x2p rs2 = {rs[s2], rs[s2]};
+#pragma unroll
+          for (int r2 = 0; r2 < 8; ++r2) {
+            const f32x2p tv = {(float)t[2 * r2], (float)t[2 * r2 + 1]};
+            const f32x2p c2 = {cs[r2 >> 1][2 * (r2 & 1)], cs[r2 >> 1][2 * (r2 & 1) + 1]};
+            facc2[r2] = add_rn(facc2[r2], mul_rn(mul_rn(tv, rs2), c2));
+          }
+        }
+        if (--left_in_tile == 0) {
+          left_in_tile = per_tile;
+          const unsigned int ldc = (unsigned int)p.ldc;
+          float facc[16];
+#pragma unroll
+          for (int r2 = 0; r2 < 16; ++r2) facc[r2] = facc2[r2 >> 1][r2 & 1];
+          if (beta0) {
+            // column-major image [j][i] (lanes along i: conflict free), then whole columns: 64 (bf16) / 128 (f32) contiguous bytes from 4 / 8 lanes
+            const __amdgpu_buffer_rsrc_t rc = wave_rsrc((gcptr)cur.q.c + ((unsigned long long)cur.j0 * ldc + (unsigned long long)cur.i0) * (c_f32 ? 4ull : 2ull));
+            if (c_f32) {
+#pragma unroll
+              for (int r2 = 0; r2 < 16; ++r2) lds[li + jl_of(r2, h) * 32] = add_rn(0.0f, facc[r2]);
+#pragma unroll
+              for (int x = 0; x < 4; ++x) {
+                const unsigned int L = (unsigned int)lane + 64u * x;
+                __builtin_amdgcn_raw_buffer_store_b128(((const u32x4*)lds)[L], rc, (int)(((L >> 3) * ldc + (L & 7u) * 4u) * 4u), 0, 0);
+              }
+            } else {
+              unsigned short* l16 = (unsigned short*)lds;
+              unsigned int pk[8]; bool nan_seen = false;
+#pragma unroll
+              for (int r2 = 0; r2 < 8; ++r2) pk[r2] = cvt_pk_bf16_dazexact(add_rn(0.0f, facc[2 * r2]), add_rn(0.0f, facc[2 * r2 + 1]), nan_seen);
+              if (__builtin_amdgcn_ballot_w64(nan_seen) != 0ull) {          // a NaN somewhere in the tile: the reference's conversion in software for all of it
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) pk[r2] = (unsigned int)f32_to_bf16_rne(add_rn(0.0f, facc[2 * r2])) | ((unsigned int)f32_to_bf16_rne(add_rn(0.0f, facc[2 * r2 + 1])) << 16);
+              }
+#pragma unroll
+              for (int r2 = 0; r2 < 8; ++r2) { l16[li + jl_of(2 * r2, h) * 32] = (unsigned short)pk[r2]; l16[li + jl_of(2 * r2 + 1, h) * 32] = (unsigned short)(pk[r2] >> 16); }
+#pragma unroll
+              for (int x = 0; x < 2; ++x) {
+                const unsigned int L = (unsigned int)lane + 64u * x;
+                __builtin_amdgcn_raw_buffer_store_b128(((const u32x4*)lds)[L], rc, (int)(((L >> 2) * ldc + (L & 3u) * 8u) * 2u), 0, 0);
+              }
+            }
+          } else {
+            const unsigned long long e0 = (unsigned long long)(cur.j0 + 4 * h) * ldc + cur.i0 + li;
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+              const unsigned long long e = e0 + (unsigned long long)(((r2 & 3) + 8 * (r2 >> 2)) * p.ldc);
+              if (c_f32) { GM float* cp = (GM float*)cur.q.c + e; *cp = add_rn(*cp, facc[r2]); }
+              else { GM unsigned short* cp = (GM unsigned short*)cur.q.c + e; *cp = f32_to_bf16_rne(add_rn(bf16_to_f32(*cp), facc[r2])); }
+            }
+          }
+#pragma unroll
+          for (int r2 = 0; r2 < 8; ++r2) facc2[r2] = (f32x2p)0.0f;
+          if (++c_tile < ntiles) cur = mx4i8_tile(p, first + c_tile);
+        }
+      }
+    });
+  }
 }
 
 
@@ -2788,9 +2982,12 @@ template <int MT, int NT, int FMT, int FP6MAP = 0>
 __global__ __launch_bounds__(256) void gemm_mx_stream_kernel(GemmArgs p) {
   constexpr bool FP6 = FMT == 2 || FMT == 3;
   constexpr int NDW = (FMT == 4) ? 4 : 8;                  // dwords (k-groups) per lane and 64-deep step
+  constexpr int kImgA = FP6 ? ((MT * 1536 + 1023) / 1024) * 1024 : 0, kImgB = FP6 ? ((NT * 1536 + 1023) / 1024) * 1024 : 0;     // 6-bit operand images of a chunk, whole requests
+  __shared__ __attribute__((aligned(16))) char lds6_all[4][kImgA + kImgB + 16];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  char* lds6 = lds6_all[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
   const BatchPtrs q = batch_ptrs(p, job.bidx);
   f32x16 acc[MT][NT];
   TileCtx tc[MT][NT];
@@ -2822,6 +3019,7 @@ __global__ __launch_bounds__(256) void gemm_mx_stream_kernel(GemmArgs p) {
       ra6 = __builtin_amdgcn_make_buffer_rsrc((void*)(size_t)uniform_u64((unsigned long long)(size_t)(ar + 3ull * (unsigned long long)job.i0)), (short)0, (int)bytes_a, 0x00020000);
       rb6 = __builtin_amdgcn_make_buffer_rsrc((void*)(size_t)uniform_u64((unsigned long long)(size_t)(br + 3ull * (unsigned long long)job.j0)), (short)0, (int)bytes_b, 0x00020000);
     }
+    const bool stage6 = FP6 && !(p.tune & 1) && ((uniform_u64((unsigned long long)(size_t)ar) | uniform_u64((unsigned long long)(size_t)br)) & 15ull) == 0 && (lda & 15u) == 0 && (ldb & 15u) == 0;
     for (int kc = 0; kc < ksteps; ++kc) {
       i32x8 af[MT], bf[NT];
       int sa[MT], sb[NT];
@@ -2843,10 +3041,50 @@ __global__ __launch_bounds__(256) void gemm_mx_stream_kernel(GemmArgs p) {
           out[3] = (int)(v[4] | (v[5] << 24)); out[4] = (int)((v[5] >> 8) | (v[6] << 16)); out[5] = (int)((v[6] >> 16) | (v[7] << 8));
           out[6] = 0; out[7] = 0;
         };
+        // Round 3, second step: with 16-byte aligned operands the 16 groups x (32 MT rows x 3 bytes) of a chunk travel global -> LDS as whole 16-byte pieces
+        // (3 requests per 64-row operand instead of 16 two-dword gathers per lane) into a packed image [group][row][3 bytes]; a lane then picks its groups
+        // out of the image with the same two-dwords-around-the-group reads.
+        if (stage6) {
+          auto dma6 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned int ld, auto tiles_c, char* img) __attribute__((always_inline)) {
+            constexpr int T = decltype(tiles_c)::value, P = 6 * T, NI6 = (T * 1536 + 1023) / 1024;
+#pragma unroll
+            for (int x = 0; x < NI6; ++x) {
+              const unsigned int Lx = (unsigned int)lane + 64u * x, g = Lx / (unsigned int)P, piece = Lx - g * (unsigned int)P;
+              const unsigned int voff = g < 16u ? g * ld * 3u + piece * 16u : 0x7ffffff0u;                   // past the image: out of bounds, reads as zero
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr)(img + 1024 * x), 16, (int)voff, 16 * kc * (int)ld * 3, 0, 0);
+            }
+          };
+          auto pick6 = [&](const char* img, int rows_bytes, int tile, i32x8& out) __attribute__((always_inline)) {
+            unsigned int v[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+              const unsigned int off = (unsigned int)((8 * h + g) * rows_bytes + (li + 32 * tile) * 3);
+              const unsigned int* w = (const unsigned int*)(img + (off & ~3u));
+              v[g] = (unsigned int)(((((unsigned long long)w[1]) << 32) | w[0]) >> (8u * (off & 3u))) & 0x00ffffffu;
+            }
+            out[0] = (int)(v[0] | (v[1] << 24)); out[1] = (int)((v[1] >> 8) | (v[2] << 16)); out[2] = (int)((v[2] >> 16) | (v[3] << 8));
+            out[3] = (int)(v[4] | (v[5] << 24)); out[4] = (int)((v[5] >> 8) | (v[6] << 16)); out[5] = (int)((v[6] >> 16) | (v[7] << 8));
+            out[6] = 0; out[7] = 0;
+          };
+          static_assert(FP6MAP == 0, "the staged form is written for lane half h = block h");
+          dma6(ra6, lda, std::integral_constant<int, MT>{}, lds6);
+          dma6(rb6, ldb, std::integral_constant<int, NT>{}, lds6 + kImgA);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) sa[mt] = (int)__builtin_amdgcn_raw_buffer_load_b8(rsa, h * (int)lda + li + 32 * mt, 2 * kc * (int)lda, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) sb[nt] = (int)__builtin_amdgcn_raw_buffer_load_b8(rsb, h * (int)ldb + li + 32 * nt, 2 * kc * (int)ldb, 0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) pick6(lds6, 96 * MT, mt, af[mt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) pick6(lds6 + kImgA, 96 * NT, nt, bf[nt]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the image is free for the next chunk's requests
+        } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { sa[mt] = (int)__builtin_amdgcn_raw_buffer_load_b8(rsa, h * (int)lda + li + 32 * mt, 2 * kc * (int)lda, 0); fetch6(ra6, lda, mt, af[mt]); }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { sb[nt] = (int)__builtin_amdgcn_raw_buffer_load_b8(rsb, h * (int)ldb + li + 32 * nt, 2 * kc * (int)ldb, 0); fetch6(rb6, ldb, nt, bf[nt]); }
+        }
       } else {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -3072,6 +3310,15 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     pl.path = (m > 32 && n > 32) ? P_I8_2x2 : P_I8_1x1;
     const int t = (pl.path == P_I8_2x2) ? 64 : 32;
     pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
+    if (!pl.exact) pl.path = P_GENERIC;
+    return pl;
+  }
+  if ((a_type == LIBXSMM_DATATYPE_I1X8 || a_type == LIBXSMM_DATATYPE_I2X4) && va && !ta && !tb && !vb && (b_type == LIBXSMM_DATATYPE_I8 || b_type == LIBXSMM_DATATYPE_U8) && c_type == LIBXSMM_DATATYPE_I32) {
+    // 1- / 2-bit weights: the int8 streaming kernel with the bits expanded to +-1 / 0 bytes in registers (round 3)
+    pl.path = (m > 32 && n > 32) ? P_I8_2x2 : P_I8_1x1;
+    const int t = (pl.path == P_I8_2x2) ? 64 : 32;
+    pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
+    if (!pl.exact && pl.path == P_I8_2x2 && (m % 32 == 0) && (n % 32 == 0) && (k % 64 == 0)) { pl.path = P_I8_1x1; pl.exact = true; }
     if (!pl.exact) pl.path = P_GENERIC;
     return pl;
   }
@@ -3761,6 +4008,8 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
           const bool big6 = pl.path == P_MXMX_2x2 && !small6;
           const long long lim = (1ll << 31) / 3;
           if ((long long)a.lda * (a.k / 4) < lim && (long long)a.ldb * (a.k / 4) < lim) {
+            static const int gather6 = []() { const char* e = getenv("LIBXSMM_HIP_MX6_STAGE"); return (e && e[0] == '0') ? 1 : 0; }();
+            a.tune = gather6;
             grid = big6 ? wave_grid(64, 64) : wave_grid(32, 32);
             if (kernel_name) *kernel_name = big6 ? "gemm_mx6_stream_kernel<2,2>" : "gemm_mx6_stream_kernel<1,1>";
             if (big6) hipLaunchKernelGGL((gemm_mx_stream_kernel<2, 2, 2>), grid, dim3(256), 0, st, a);
@@ -3825,6 +4074,21 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       const bool ok = !a.list_a && a.br_mode != 1 && a.br_mode != 2 && (bits & 15ull) == 0 && (abits & 3ull) == 0 && (long long)a.lda * a.k < (1ll << 31) && (long long)a.ldb * a.n < (1ll << 31) &&
         (a.c_type == LIBXSMM_DATATYPE_F32 || a.c_type == LIBXSMM_DATATYPE_BF16) && a.a_scf && a.b_scf;
       if (ok) {
+        // waves that walk several consecutive tiles with the next chunk's operands in flight: at least 8 K waves per launch, at most 8 tiles each
+        static const int pipe = []() { const char* e = getenv("LIBXSMM_HIP_MX4I8_PIPE"); return e ? atoi(e) : 8; }();
+        a.tiles_m = a.m / 32; a.tiles_n = a.n / 32; a.map2d_shift = 0;
+        const unsigned long long tiles = (unsigned long long)a.tiles_m * a.tiles_n * a.nbatch;
+        const bool c_ok = (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) == 0 || ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 15ull) == 0 &&
+          ((unsigned long long)a.ldc * (a.c_type == LIBXSMM_DATATYPE_F32 ? 4ull : 2ull)) % 16ull == 0 && !a.list_c);
+        if (pipe > 0 && c_ok && tiles < (1ull << 31) && (a.k >> 6) * a.br_count < (1ull << 31)) {
+          const unsigned int per_wave = (unsigned int)std::min<unsigned long long>((unsigned long long)pipe, std::max<unsigned long long>(1ull, tiles / 8192ull));
+          const unsigned long long waves = (tiles + per_wave - 1) / per_wave;
+          // two chunks in flight per wave at three waves per SIMD; four / six at two waves per SIMD measured the same or worse (the kernel is bound by its
+          // ~300 vector instructions per tile -- code expansion, convert / scale / add of 2 x 16 block sums -- not by the operand round trip any more)
+          hipLaunchKernelGGL((gemm_mx4i8_pipe_kernel<2>), dim3((unsigned int)((waves + 3) / 4)), dim3(256), 0, st, a, per_wave, (unsigned int)tiles);
+          if (kernel_name) *kernel_name = "gemm_mx4i8_pipe_kernel";
+          break;
+        }
         grid = wave_grid(32, 32);
         hipLaunchKernelGGL((gemm_mx4i8_stream_kernel<1, 1>), grid, dim3(256), 0, st, a);
         break;
@@ -3844,11 +4108,23 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         const bool big = pl.path == P_I8_2x2;
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
         if (kernel_name) *kernel_name = big ? "gemm_i4_stream_kernel<2,2>" : "gemm_i4_stream_kernel<1,1>";
-        if (big) hipLaunchKernelGGL((gemm_i8_stream_kernel<2, 2, false, true, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm_i8_stream_kernel<1, 1, false, true, true>), grid, dim3(256), 0, st, a);
+        if (big) hipLaunchKernelGGL((gemm_i8_stream_kernel<2, 2, false, true, 1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_i8_stream_kernel<1, 1, false, true, 1>), grid, dim3(256), 0, st, a);
         break;
       }
-      if (ok && !i4) {
+      const int lowbit = a.a_type == LIBXSMM_DATATYPE_I2X4 ? 2 : (a.a_type == LIBXSMM_DATATYPE_I1X8 ? 3 : 0);
+      if (ok && lowbit) {
+        const bool ub = a.b_type == LIBXSMM_DATATYPE_U8, big = pl.path == P_I8_2x2;
+        grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
+        if (kernel_name) *kernel_name = lowbit == 2 ? (big ? "gemm_i2_stream_kernel<2,2>" : "gemm_i2_stream_kernel<1,1>") : (big ? "gemm_i1_stream_kernel<2,2>" : "gemm_i1_stream_kernel<1,1>");
+#define LAUNCH_LB_(MT_, NT_) do { \
+          if (lowbit == 2) { if (ub) hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, false, true, 2>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, false, false, 2>), grid, dim3(256), 0, st, a); } \
+          else { if (ub) hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, false, true, 3>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, false, false, 3>), grid, dim3(256), 0, st, a); } } while (0)
+        if (big) LAUNCH_LB_(2, 2); else LAUNCH_LB_(1, 1);
+#undef LAUNCH_LB_
+        break;
+      }
+      if (ok && !i4 && !lowbit) {
         const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8, big = pl.path == P_I8_2x2;
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
 #define LAUNCH_I8_(MT_, NT_) do { \

@@ -770,7 +770,8 @@ LIBXSMM_API libxsmm_meqn_function libxsmm_dispatch_meqn(libxsmm_blasint idx, lib
       // side channels through output.secondary exist for the head of the tree only [ref: matequation ref :40-55]: the ReLU bitmask,
       // the byte offset of UNZIP's second half
       if ((nd.flags & LIBXSMM_MELTW_FLAG_UNARY_BITMASK_2BYTEMULT) && nd.op == LIBXSMM_MELTW_TYPE_UNARY_RELU && root) st.root_side = 1;
-      if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER && root) st.root_side = 3;
+      // (a byte copy in the operand's element size, like the reference's: an operand of another width than the output would be written past the columns)
+      if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_SCATTER && root && typesize((int)ch[0]->type) == typesize((int)nd.type)) st.root_side = 3;
       if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_UNZIP && root) st.root_side = 2;
       // a GATHER directly above an argument takes its index list from that argument's secondary slot [ref: samples/equation/equation_gather_reduce.c:150-166]
       if (nd.op == LIBXSMM_MELTW_TYPE_UNARY_GATHER && ch[0]->kind == EQ_ARG) st.idx_from_input = ch[0]->in_pos;

@@ -822,13 +822,16 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, uns
 // s_waitcnt counts loads and stores in issue order: the wait before a chunk allows for the younger chunk and for the stores of a tile that
 // ended since the chunk was issued (only the 8-store LDS epilogue is counted; the direct epilogue just makes the next waits stricter).
 // beta = 0 only (a C read would sit in the middle of the counted sequence); one k-group (K / bk <= 64).
-template <int BN16, int AUX_A = 0, int RT = 4, int WPS = 2>     // RT: 16-row tiles per wave (4: 64 rows, 2: 32 rows -> half the accumulators, more waves per SIMD)
+// F32 (round 3): the same kernel on f32 operands.  A chunk is then 16 k (not 16 k-PAIRS) of the wave's rows -- the LDS image, its rotation and the
+// operand reads are word for word the bf16 ones, a row of the image is one k instead of a VNNI pair --, a B fragment is four consecutive k of a column
+// (again one 16-byte load) and a chunk is four v_mfma_f32_16x16x4_f32 per (n-tile, i-tile), k = 4 kg + e in step e as in bcsc_mfma_f32_kernel.
+template <int BN16, int AUX_A = 0, int RT = 4, int WPS = 2, bool F32 = false>     // RT: 16-row tiles per wave (4: 64 rows, 2: 32 rows -> half the accumulators, more waves per SIMD)
 __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
   constexpr int NBL = 4 / BN16, D = 2, W = 16 * RT, SPR = 4 * RT, NI = RT;     // W words per image row, SPR 16-byte slots per row, NI DMA instructions per chunk
   __shared__ unsigned int tbl_all[4][kBcscTblDma];
   __shared__ unsigned int klist_all[4][64];
   __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][D][16 * W];
-  __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][1024];       // 32 columns x 128 bytes: C leaves in two halves
+  __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][F32 ? 4 : 1024];       // 32 columns x 128 bytes: bf16 C leaves in two halves
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int wid = blockIdx.x * 4u + wave;
   if (wid >= total_waves) return;
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
   const int mt = (p.M - i0 >= 16 * RT) ? RT : (p.M - i0) / 16;
   const int nbl_cnt = ((p.N - n0 >= 64) ? 64 : (p.N - n0)) / (16 * BN16);
   const int nb0 = n0 / (16 * BN16);
-  const int nkb = p.K / p.bk, steps = p.bk / 32;
+  const int nkb = p.K / p.bk, steps = F32 ? p.bk / 16 : p.bk / 32;
   {
     GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb;
     for (int e = lane; e < nbl_cnt * nkb; e += 64) tbl[e] = gt[e];
@@ -856,9 +859,9 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const int nch = __builtin_popcountll(mask) * steps;
   const int nmb = ((unsigned int)p.m_blocks > g0) ? (int)(((unsigned int)p.m_blocks - g0 + mbg - 1u) / mbg) : 0;
-  const bool c_f32 = (p.c_type == LIBXSMM_DATATYPE_F32);
+  const bool c_f32 = F32 || (p.c_type == LIBXSMM_DATATYPE_F32);
   const long long c_mb_bytes = (long long)p.N * p.M * (c_f32 ? 4 : 2);
-  const bool lds_store = !c_f32 && mt == RT && nbl_cnt * BN16 == 4 && (p.M % 8) == 0 && ((((size_t)p.c) & 15) == 0);
+  const bool lds_store = !F32 && !c_f32 && mt == RT && nbl_cnt * BN16 == 4 && (p.M % 8) == 0 && ((((size_t)p.c) & 15) == 0);
   f32x4v acc[4][RT];
   sfor<4 * RT>([&](auto ic) { acc[ic.value / RT][ic.value % RT] = (f32x4v)0.0f; });
   auto store_tile = [&](unsigned int mb) __attribute__((always_inline)) {        // C of M-block mb leaves; the accumulators restart at zero
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
   if (nch == 0) { for (int j = 0; j < nmb; ++j) store_tile(g0 + (unsigned int)j * mbg); return; }     // no block in these columns: C = 0
   // DMA source of LDS slot (lane + 64x): row kp_l = slot >> 4, the 16-byte group that lands there = (slot & 15) rotated back
   GM const unsigned int* A2 = (GM const unsigned int*)p.a + i0;
-  const long long a_mb_words = (long long)(p.K / 2) * p.M;
+  const long long a_mb_words = (long long)(F32 ? p.K : p.K / 2) * p.M;
   unsigned int src_off[NI];
 #pragma unroll
   for (int x = 0; x < NI; ++x) {
@@ -936,10 +939,12 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
       constexpr int nbl = nc.value;
       blk_r[u][nbl] = (nbl < nbl_cnt) ? (unsigned int)__builtin_amdgcn_readfirstlane((int)tbl[nbl * nkb + kb_]) : 0xffffffffu;
       sfor<BN16>([&](auto sc) { constexpr int s2 = sc.value;
-        GM const char* src = (blk_r[u][nbl] != 0xffffffffu) ? bv + (((long long)blk_r[u][nbl] * (16 * BN16) + 16 * s2 + lx) * p.bk + 32 * st_ + 8 * kg) * 2 : bv;
+        GM const char* src = (blk_r[u][nbl] == 0xffffffffu) ? bv :
+          F32 ? bv + (((long long)blk_r[u][nbl] * (16 * BN16) + 16 * s2 + lx) * p.bk + 16 * st_ + 4 * kg) * 4
+              : bv + (((long long)blk_r[u][nbl] * (16 * BN16) + 16 * s2 + lx) * p.bk + 32 * st_ + 8 * kg) * 2;
         bf_r[u][nbl][s2] = *(GM const u32x4v*)src; });
     });
-    GM const unsigned int* rowbase = A2 + (long long)(g0 + (unsigned int)ij * mbg) * a_mb_words + ((long long)kb_ * (p.bk / 2) + 16 * st_) * p.M;
+    GM const unsigned int* rowbase = A2 + (long long)(g0 + (unsigned int)ij * mbg) * a_mb_words + ((long long)kb_ * (F32 ? p.bk : p.bk / 2) + 16 * st_) * p.M;
 #pragma unroll
     for (int x = 0; x < NI; ++x)
       __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)((char*)abuf[u] + 1024 * x), 16, 0, AUX_A);
@@ -956,6 +961,8 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
         // within the last D chunks -- the 8 stores of that tile's C (loads and stores retire this counter in issue order on gfx9)
         static_assert(D == 2, "the wait table below is written for one chunk in flight behind the consumed one");
         constexpr int PER = 4 + NI, NS = (RT == 4) ? 8 : 4;           // instructions per chunk (4 B loads + the DMA), stores of one tile's LDS epilogue
+        // (the 16 direct stores of an f32 tile are NOT counted: the wait is then stricter than needed for two chunks per tile -- measured equal, 119.1 us
+        // either way on config #4's shape in f32 -- and does not depend on how stores retire relative to the loads around them)
         const bool behind = total_f - 1 - f >= 1, stored = lds_store && cj > 0 && cc < D;
         if (behind && stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER + NS) : "memory");
         else if (behind) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
@@ -980,7 +987,15 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
               constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
               sfor<RT>([&](auto tc) {
                 constexpr int t = tc.value;
-                if (t < mt) acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a_cur[t]), __builtin_bit_cast(bf16x8v, bf_c[nbl][s2]), acc[nt][t], 0, 0, 0);
+                if (t < mt) {
+                  if constexpr (F32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {     // (__builtin_bit_cast on a vector ELEMENT reads element 0 whatever e is -- hipcc 7.2: go through scalars)
+                      const unsigned int av = a_cur[t][e], bw = bf_c[nbl][s2][e];
+                      acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av), __uint_as_float(bw), acc[nt][t], 0, 0, 0);
+                    }
+                  } else acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a_cur[t]), __builtin_bit_cast(bf16x8v, bf_c[nbl][s2]), acc[nt][t], 0, 0, 0);
+                }
               });
             });
           }
@@ -1215,6 +1230,28 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
       const long long total = (long long)tiles_i * tiles_n * a.m_blocks;
       if (total < (1ll << 31)) {
         const dim3 grid((unsigned int)((total + 3) / 4));
+        // many M-blocks per (i-tile, n-tile): the bf16 kernel's waves streaming over M-blocks, on f32 operands (round 3; the one-tile-per-wave kernel below
+        // builds its pattern rows in every wave and fetches A one 16-deep step ahead: 0.65 of the HBM roofline on config #4's shape)
+        static const int stream_mode = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_STREAM"); return e ? atoi(e) : 1; }();
+        const int nkb = a.K / a.bk;
+        const long long tt_count = (long long)tiles_i * tiles_n;
+        if (stream_mode != 0 && a.table != nullptr && a.beta0 && nkb <= 64 && (long long)nbl_per_wave * nkb <= kBcscTblDma && ((size_t)a.a % 16 == 0) && (long long)a.K * a.M < (1ll << 30) &&
+            tt_count <= 2048 && ((long long)a.m_blocks * tt_count >= 4096 || stream_mode == 2) && ((long long)a.K * a.M) * (long long)a.m_blocks < (1ll << 40)) {
+          const unsigned int* table = (const unsigned int*)a.table;
+          if (!a.table_ready) hipLaunchKernelGGL(bcsc_invert_kernel, dim3((unsigned int)a.nblk_n), dim3(64), 0, st, a.colptr, a.rowidx, (unsigned int*)a.table, a.nblk_n, nkb);
+          // two waves per SIMD (182 registers); three (168: ten spills) measured 139.7 us against 119.1 us
+          long long mbg = std::min<long long>(a.m_blocks, std::max<long long>(1, 2048 / tt_count));
+          const long long per = (a.m_blocks + mbg - 1) / mbg;
+          mbg = (a.m_blocks + per - 1) / per;
+          const long long waves = mbg * tt_count;
+          const dim3 sgrid((unsigned int)((waves + 3) / 4));
+#define LAUNCH_STREAM_F32_(B_) do { if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 2, 4, 2, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+                                    else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 0, 4, 2, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
+          if (a.bn == 16) LAUNCH_STREAM_F32_(1); else if (a.bn == 32) LAUNCH_STREAM_F32_(2); else LAUNCH_STREAM_F32_(4);
+#undef LAUNCH_STREAM_F32_
+          if (name) *name = "bcsc_mfma_f32_stream_kernel";
+          return (int)hipGetLastError();
+        }
         if (a.bn == 16) hipLaunchKernelGGL((bcsc_mfma_f32_kernel<1>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
         else if (a.bn == 32) hipLaunchKernelGGL((bcsc_mfma_f32_kernel<2>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);
         else hipLaunchKernelGGL((bcsc_mfma_f32_kernel<4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total);

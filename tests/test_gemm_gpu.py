@@ -738,7 +738,8 @@ def test_mx_typed_gemm_output(dt, m, n, k, lda, ldb, ldc, br, batch):
 # 1-bit (+-1) and 2-bit (0, +1, -1, interleaved) weights x 8-bit activations -> i32 [ref: gemm ref :1100-1300]: exact, so bit equality
 @pytest.mark.parametrize("a_type", [DT.I1X8, DT.I2X4])
 @pytest.mark.parametrize("b_type", [DT.I8, DT.U8])
-@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (24, 7, 16, 28, 20, 30, 1, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0, 1), (128, 32, 256, 128, 256, 128, 2, 1, 11)])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (24, 7, 16, 28, 20, 30, 1, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0, 1), (128, 32, 256, 128, 256, 128, 2, 1, 11),
+                                                             (64, 64, 64, 64, 64, 64, 1, 0, 3), (32, 32, 128, 36, 144, 40, 3, 0, 1), (96, 64, 64, 104, 80, 96, 2, 1, 7)])
 def test_low_bit_weight_gemm_bit_exact(a_type, b_type, m, n, k, lda, ldb, ldc, br, beta, batch):
     import torch
     from oracle import pyoracle
@@ -768,6 +769,10 @@ def test_low_bit_weight_gemm_bit_exact(a_type, b_type, m, n, k, lda, ldb, ldc, b
         api.hip_gemm_batch_strided(h, C.byref(p), batch, br * a_b, br * b_b, c_b)
     api.hip_sync(); api.check()
     assert np.array_equal(dC.cpu().numpy(), ref)
+    if m % 32 == 0 and n % 32 == 0 and k % 64 == 0:
+        # whole tiles: the int8 matrix-core kernel with the bits expanded to signed bytes in registers (round 3); everything else the exact generic kernel
+        want = "gemm_i1_stream_kernel" if a_type == DT.I1X8 else "gemm_i2_stream_kernel"
+        assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode().startswith(want), api.hip_kernel_name(h, 1 if batch > 1 else 0)
     if batch == 1:
         got = C0.copy()
         p.a.primary, p.b.primary, p.c.primary = A.ctypes.data, B.ctypes.data, got.ctypes.data
@@ -782,7 +787,9 @@ def test_low_bit_weight_gemm_bit_exact(a_type, b_type, m, n, k, lda, ldb, ldc, b
 # MXFP4 through the integer table with E8M0 scales of A and f32 scales of B -> f32 / bf16 (the reference's order: bit-identical)
 @pytest.mark.parametrize("a_type,c_type", [(DT.I4X2, DT.I32), (DT.MXFP4X2, DT.F32), (DT.MXFP4X2, DT.BF16)])
 @pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (17, 7, 64, 20, 96, 24, 1, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0, 1), (128, 32, 256, 128, 256, 128, 2, 1, 9),
-                                                             (64, 64, 128, 64, 128, 64, 3, 0, 5), (32, 32, 64, 32, 64, 32, 1, 0, 1), (64, 128, 64, 72, 96, 64, 1, 1, 33)])
+                                                             (64, 64, 128, 64, 128, 64, 3, 0, 5), (32, 32, 64, 32, 64, 32, 1, 0, 1), (64, 128, 64, 72, 96, 64, 1, 1, 33),
+                                                             # enough tiles for waves that walk several of them (MXFP4: gemm_mx4i8_pipe_kernel), the last wave with fewer
+                                                             (64, 64, 64, 64, 64, 64, 2, 0, 6200), (32, 32, 64, 32, 64, 40, 1, 1, 20001)])
 def test_interleaved_4bit_weight_gemm_bit_exact(a_type, c_type, m, n, k, lda, ldb, ldc, br, beta, batch):
     import torch
     from helpers import rand_values
@@ -832,7 +839,8 @@ def test_interleaved_4bit_weight_gemm_bit_exact(a_type, c_type, m, n, k, lda, ld
         assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode().startswith("gemm_i4_stream_kernel"), api.hip_kernel_name(h, 1 if batch > 1 else 0)
     if mx and m % 32 == 0 and n % 32 == 0 and k % 64 == 0:
         # one int8 MFMA per 32-deep block, scaled and added block by block in the reference's order: still bit-identical
-        assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode().startswith("gemm_mx4i8_stream_kernel"), api.hip_kernel_name(h, 1 if batch > 1 else 0)
+        # (the waves walk several tiles with the next chunk's operands in flight: gemm_mx4i8_pipe_kernel; ldc not a multiple of 16 bytes: one tile per wave)
+        assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode().startswith("gemm_mx4i8_"), api.hip_kernel_name(h, 1 if batch > 1 else 0)
     if batch == 1:
         got = C0.copy()
         p = capi.GemmParam()

@@ -577,7 +577,7 @@ def test_gpu_meqn_scatter_as_the_head(dt):
     idx = api.meqn_create()
     md = lambda pos=-1: capi.MeqnMetadata(idx, pos)    # noqa: E731
     assert api.meqn_push_back_unary_op(md(), UNARY.SCATTER, dt, UNARY_FLAG.GS_COLS | UNARY_FLAG.IDX_SIZE_4BYTES) == 0
-    assert api.meqn_push_back_binary_op(md(), BINARY.ADD, DT.F32, 0) == 0
+    assert api.meqn_push_back_binary_op(md(), BINARY.ADD, dt, 0) == 0                # SCATTER copies elements of its operand's width: the sum is produced in the output type
     assert api.meqn_push_back_arg(md(0), capi.MeqnArgShape(*shapes[0]), SINGULAR) == 0
     assert api.meqn_push_back_arg(md(1), capi.MeqnArgShape(*shapes[1]), SINGULAR) == 0
     h = api.dispatch_meqn(idx, capi.MeqnArgShape(m, big_n, ld, dt))

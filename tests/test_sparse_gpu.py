@@ -458,6 +458,39 @@ def test_bcsc_bf16_waves_streaming_over_m_blocks(c_type, M, N, K, mb, bk, bn, ke
     api.release_kernel(h)
 
 
+# the same scheme on f32 operands (round 3): a chunk is 16 k, four v_mfma_f32_16x16x4_f32 per tile pair; bk = 16 (one chunk per block) .. 64, ragged tiles,
+# an n-tile without blocks, every wave with a different number of M-blocks
+@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep", [(80, 96, 128, 1100, 32, 32, 0.34), (64, 64, 256, 4099, 32, 16, 0.25), (64, 128, 64, 2050, 64, 64, 0.5), (64, 64, 128, 4100, 16, 16, 0.3)])
+def test_bcsc_f32_waves_streaming_over_m_blocks(M, N, K, mb, bk, bn, keep):
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(14)
+    colptr, rowidx, bvals = make_bcsc(rng, K, N, bk, bn, keep, DT.F32)
+    if N == 128:
+        keep_blocks = int(colptr[1])
+        colptr = np.array([0, keep_blocks, keep_blocks], dtype=colptr.dtype); rowidx = rowidx[:keep_blocks].copy(); bvals = bvals[:keep_blocks * bn * bk].copy()
+    A = rand_values(rng, mb * K * M, DT.F32)
+    C0 = rand_values(rng, mb * N * M, DT.F32)
+    ref = C0.copy()
+    orc.lib.oracle_packed_spgemm_bcsc(DT.F32, DT.F32, M, N, K, mb, bk, bn, 0, A.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, 1)
+    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, DT.F32, DT.F32, DT.F32, DT.F32), GEMM_FLAG.BETA_0, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    dA, dB, dC, dcp, dri = _dev(A), _dev(bvals), _dev(C0.copy()), _dev(colptr), _dev(rowidx)
+    nblk = C.c_ulonglong(N // bn)
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = dA.data_ptr(), dB.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), dC.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_f32_stream_kernel"
+    got = _host(dC, np.float32)
+    assert normf_rel(ref, got, DT.F32) <= 1e-5
+    rb, gb = ref.reshape(mb, -1), got.reshape(mb, -1)
+    worst = max(normf_rel(rb[b], gb[b], DT.F32) for b in list(range(0, mb, 97)) + [mb - 1, mb - 2, mb // 2])
+    assert worst <= 1e-5
+    if N == 128:
+        assert not np.any(gb.reshape(mb, N, M)[:, 64:, :])
+    api.release_kernel(h)
+
+
 # 8-bit integers (u8 x i8 -> i32 and i8 x u8 -> i32, A in VNNI-4): exact, so the bar is bit equality
 @pytest.mark.parametrize("a_type", [DT.U8, DT.I8])
 @pytest.mark.parametrize("M,N,K,mb,bk,bn,keep,beta0", [(64, 64, 256, 6, 32, 16, 0.25, 1), (64, 64, 256, 3, 32, 32, 0.25, 0), (16, 24, 40, 4, 8, 8, 0.5, 1), (32, 32, 64, 2, 16, 4, 0.42, 0),

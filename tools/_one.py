@@ -1,0 +1,23 @@
+"""scratch: time ONE workload expression (env WL, evaluated with bp = tools/bench_paths, wl = tools/workloads) -- used by tools/_run1.sh for A/B runs under different env switches"""
+import os, sys, json, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tools"); sys.path.insert(0, "tests")
+import bench, bench_paths as bp, workloads as wl
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, UNARY  # noqa: F401
+api = capi.load(); dev = torch.device("cuda:0"); torch.cuda.set_device(0)
+api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+wl.set_device(dev); bp.DEV = dev
+for expr in os.environ["WL"].split(";;"):
+    w = eval(expr)
+    for i in range(3):
+        w.step(i)
+    torch.cuda.synchronize()
+    ok = w.verify() if getattr(w, "verify", None) else None
+    if os.environ.get("EAGER"):        # plain launches for counter passes
+        for i in range(6):
+            w.step(i)
+        torch.cuda.synchronize(); us = 1.0
+    else:
+        _, _, us = bench.timed(w, 20, 0.2)
+    print(json.dumps({"tag": os.environ.get("TAG", ""), "workload": w.name, "kernel": w.kernel(), "us": round(us, 2), "frac_hbm": round(w.alg_bytes / us / 1e3 / 8000, 4), "verified": ok}), flush=True)
+    del w; torch.cuda.empty_cache()

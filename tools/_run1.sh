@@ -1,24 +1,6 @@
-python - <<'PY'
-import sys, json, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tools"); sys.path.insert(0, "tests")
-import bench, bench_paths as bp, workloads as wl
-from libxsmm_amd import capi
-from libxsmm_amd.capi import DT, UNARY
-api = capi.load(); dev = torch.device("cuda:0"); torch.cuda.set_device(0)
-api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
-wl.set_device(dev); bp.DEV = dev
-for (m, n) in ((4096, 8192), (4160, 8192), (4096 + 16, 8192), (3840, 8192)):
-    for rows in (False, True):
-        w = bp.meltw_reduce(api, rows, m, n)
-        for i in range(3): w.step(i)
-        torch.cuda.synchronize()
-        _, _, us = bench.timed(w, 20, 0.15)
-        print("reduce", "rows" if rows else "cols", m, n, round(us, 2), round(w.alg_bytes / us / 1e3 / 8000, 4), flush=True)
-        del w; torch.cuda.empty_cache()
-    w = bp.meltw_big(api, UNARY.TRANSFORM_NORM_TO_NORMT, "T", m=m, n=n)
-    for i in range(3): w.step(i)
-    torch.cuda.synchronize()
-    _, _, us = bench.timed(w, 20, 0.15)
-    print("transpose", m, n, round(us, 2), round(w.alg_bytes / us / 1e3 / 8000, 4), flush=True)
-    del w; torch.cuda.empty_cache()
-PY
+set -x
+export PYTHONPATH=.
+timeout 1200 python -m pytest tests/test_gemm_gpu.py -q -m gpu -k "interleaved_4bit" 2>&1 | tail -4
+MX='bp.brgemm_mx4i8(api, 64, 2 ** 17);;bp.brgemm_mx4i8(api, 64, 2 ** 17, DT.F32)'
+TAG=mx4i8_cvt WL="$MX" timeout 300 python tools/_one.py 2>&1 | tail -2
+TAG=mx4i8_old LIBXSMM_HIP_MX4I8_PIPE=0 WL="$MX" timeout 300 python tools/_one.py 2>&1 | tail -2

@@ -82,6 +82,28 @@ def brgemm_i4(api, m, batch):
     return w
 
 
+def brgemm_lowbit(api, m, batch, a_dt):
+    """1-bit (I1X8: signs) or 2-bit (I2X4: 0 / +1 / -1, interleaved) weights x signed bytes -> i32, m = n = k: algorithmic bytes per problem =
+    m*m/8 or m*m/4 (A) + m*m (B) + 4*m*m (C)."""
+    div = 8 if a_dt == DT.I1X8 else 4
+    flags = GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A | (GEMM_FLAG.INTLV_A_FORMAT if a_dt == DT.I2X4 else 0)
+    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, a_dt, DT.I8, DT.I32, DT.I32), flags, 0, capi.br_config(capi.BR_STRIDE, m * m // div, m * m, 0))
+    assert h
+    per = m * m // div + m * m + 4 * m * m
+    ns = nsets_for(batch * per)
+    As = [torch.randint(0, 256, (batch * m * m // div,), device=DEV, dtype=torch.uint8) for _ in range(ns)]
+    Bs = [torch.randint(-128, 128, (batch * m * m,), device=DEV, dtype=torch.int8) for _ in range(ns)]
+    Cs = [torch.zeros(batch * m * m, device=DEV, dtype=torch.int32) for _ in range(ns)]
+    brc = C.c_ulonglong(1)
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc); ps.append(p)
+    w = Work(api, f"stride-BRGEMM {'i1x8' if div == 8 else 'i2x4'} x i8 -> i32 m=n=k={m} batch={batch} br=1 beta=0", 2.0 * m ** 3 * batch, float(batch * per), ns,
+             lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, m * m // div, m * m, 4 * m * m), lambda: api.hip_kernel_name(h, 1).decode())
+    w.keep = (As, Bs, Cs, ps, brc)
+    return w
+
+
 def brgemm_mx4i8(api, m, batch, c_dt=DT.BF16):
     """interleaved MXFP4 weights (E8M0 scale per 32 k and row) x signed bytes (one f32 scale per column and 32 k) -> bf16 / f32, m = n = k: algorithmic bytes per
     problem = m*m/2 + m*m/32 (A, its scales) + m*m + 4*m*m/32 (B, its scales) + s_C*m*m."""
@@ -382,7 +404,8 @@ def main():
                    lambda: brgemm_i8(api, 64, 2 ** 17, ua=True), lambda: brgemm_i8(api, 64, 2 ** 17, ua=False)]     # config #2 variant B: one long chain
     if "lowbit" in only:     # the (f4) forms moved onto the matrix cores in round 3
         makers += [lambda: brgemm_i4(api, 64, 2 ** 17), lambda: brgemm_i4(api, 32, 2 ** 18), lambda: brgemm_mx4i8(api, 64, 2 ** 17), lambda: brgemm_mx4i8(api, 64, 2 ** 17, DT.F32),
-                   lambda: brgemm_mxmx(api, 64, 2 ** 17, DT.MXHF6), lambda: brgemm_mxmx(api, 128, 2 ** 15, DT.MXHF6)]
+                   lambda: brgemm_mxmx(api, 64, 2 ** 17, DT.MXHF6), lambda: brgemm_mxmx(api, 128, 2 ** 15, DT.MXHF6),
+                   lambda: brgemm_lowbit(api, 64, 2 ** 17, DT.I2X4), lambda: brgemm_lowbit(api, 64, 2 ** 17, DT.I1X8)]
     if "f16" in only:        # IEEE halves on the bf16 fast paths (round 3): streaming 32^3 / 64^3, fused none, and the blocked form through tools/bb_sweep.py --dtype f16
         makers += [lambda: brgemm(api, 32, "f16", 2 ** 18), lambda: brgemm(api, 64, "f16", 2 ** 16), lambda: brgemm(api, 32, "f16", 4096), lambda: brgemm(api, 64, "f16", 4096)]
     if "ragged" in only:     # the odd small shapes (BASELINE config #1 is 23^3), steady state and a 4096-problem launch
