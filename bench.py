@@ -530,6 +530,9 @@ def run_configs(api, dev, steps, min_seconds, cpu_seconds, with_cpu):
         # HBM channels and banks (measured: f32 0.56 at 2^20 against 0.74 at 2^20 + 8704, f64 0.64 against 0.66-0.69) -- the caller's leading dimension, not the kernel
         ("c3_fsspmdm_n1e6", lambda: wl.fsspmdm(api, 1000000, 0.15), None),
         ("c4_bcsc_bf16", lambda: wl.bcsc(api, host_pattern=True), lambda: wl.cpu_bcsc(seconds=cs)),
+        # config #4's f32 and 8-bit siblings: the same pattern and shape in the other two operand types of the reference's spmm_kernel driver
+        ("c4_bcsc_f32", lambda: wl.bcsc(api, dtype="f32", host_pattern=True), None),
+        ("c4_bcsc_u8i8", lambda: wl.bcsc(api, dtype="u8i8", host_pattern=True), None),
         ("c5_fused", lambda: Workload(api, dev, "bf16", 64, 2 ** 17, fused=1), lambda: wl.cpu_fused(seconds=cs)),
         ("variantB_f32_m32_br4096", lambda: variant_b(api, dev, 4096), None),
         ("variantB_f32_m32_br65536", lambda: variant_b(api, dev, 65536), None),

@@ -47,7 +47,8 @@ def test_line_fits_the_driver_tail(detail, line):
     # the worst case the code can produce: every optional object present, long kernel names and sample texts
     fat = dict(detail)
     fat.setdefault("configs", {k: {"frac_hbm": 0.7123, "verified": True, "cpu_baseline": {"value": 123456.78}} for k in
-                               ("c3_csr15", "c3_csr10", "c3_fsspmdm", "c4_bcsc_bf16", "c5_fused", "variantB_f32_m32_br4096")})
+                               ("c3_csr15", "c3_csr10", "c3_fsspmdm", "c3_fsspmdm_n1e6", "c4_bcsc_bf16", "c4_bcsc_f32", "c4_bcsc_u8i8", "c5_fused", "variantB_f32_m32_br4096",
+                                "variantB_f32_m32_br65536")})
     fat["cpu_baseline"] = dict(fat.get("cpu_baseline") or {"value": 1.0, "unit": "GFLOP/s", "cores": 1, "kind": "reference"}, sample="x" * 500)
     fat["config"] = dict(fat["config"], kernel="k" * 120, workload="w" * 200)
     fat["pipelined"] = dict({"lanes": 4}, **{f"{dt}_m{m}_b4096": {"frac_hbm": 0.87654, "verified": True} for dt in ("f32", "bf16") for m in (16, 23, 32, 64)})
