@@ -212,6 +212,8 @@ __device__ __forceinline__ void generic_epilogue(const GemmArgs& p, const BatchP
     if ((p.n & 1) && j == p.n - 1) c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + 1] = 0;
   } else if (p.c_type == LIBXSMM_DATATYPE_F32) {
     ((GM float*)q.c)[(long long)j * p.ldc + i] = y;
+  } else if (p.c_type == LIBXSMM_DATATYPE_F16) {        // (the reduce pass of a k-sliced GEMM with IEEE-half C: round 3)
+    ((GM _Float16*)q.c)[(long long)j * p.ldc + i] = (_Float16)y;
   } else {
     ((GM unsigned short*)q.c)[(long long)j * p.ldc + i] = f32_to_bf16_rne(y);
   }
@@ -246,6 +248,7 @@ __device__ __forceinline__ float load_as_f32(gcptr base, long long idx, int type
 
 // C and bias operands are f32 or bf16 only (keeps the 8-bit decoders out of every tile prologue)
 __device__ __forceinline__ float load_c_f32(gcptr base, long long idx, int type) {
+  if (type == LIBXSMM_DATATYPE_F16) return (float)((GM const _Float16*)base)[idx];
   return (type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)base)[idx] : bf16_to_f32(((GM const unsigned short*)base)[idx]);
 }
 
@@ -3644,6 +3647,228 @@ int launch_bitmask_expand(const void* bitmap, const void* vals, void* dense, uns
   if (elem_size == 4) hipLaunchKernelGGL(bitmask_expand_kernel<unsigned int>, dim3((unsigned int)rows), dim3(256), 0, st, (const unsigned char*)bitmap, (const unsigned int*)vals, (unsigned int*)dense, start, row_bytes);
   else hipLaunchKernelGGL(bitmask_expand_kernel<unsigned short>, dim3((unsigned int)rows), dim3(256), 0, st, (const unsigned char*)bitmap, (const unsigned short*)vals, (unsigned short*)dense, start, row_bytes);
   return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bitmask-compressed A WITHOUT the dense image (round 3): 16-bit operands, m % 16 == 0, k % 64 == 0, B columns 16-byte aligned.  What travels from HBM is
+// what the caller stored -- the non-zeros and one bit per element -- so a weight matrix pruned to density d costs (d + 1/16) of its dense bytes instead of
+// (d + 1/16) + 2 (the image written by bitmask_expand_kernel and read back by the dense kernel).
+//   pass 1 (bitmask_tile_prefix_kernel): per (bit row r = k-pair, tile of 128 rows of A): set bits of row r before the tile; per row: its total
+//   pass 2 (bitmask_row_scan_kernel, shared with the expanding path): exclusive scan of the totals = where row r's values start
+//   pass 3 (gemm_bitmask16_kernel): one workgroup per (128 rows of A, 64 columns of C, slice of k).  Per 64-deep chunk (32 bit rows): every wave fetches the
+//     values of its 8 bit rows as ONE 8-byte request per lane and row (an aligned window over <= 256 values) into LDS; thread (bit row kp, dword p of the
+//     row's 8 bitmap dwords) ranks its 32 bits (popcount of the bits below, plus the exclusive prefix over the 8 lanes of its row), picks its values out of
+//     the window and writes 16 VNNI-2 words of the dense chunk image [32 k-pairs][128 rows]; B's chunk [64 columns][64 k] lands in LDS with its 16-byte
+//     pieces XOR-swizzled; wave w multiplies rows 32 w .. + 31 by the 64 columns on v_mfma_f32_32x32x16_bf16 / _f16.  Requests run ahead of the chunk being
+//     multiplied: bitmap dword / value offset / B pieces D + 1 chunks, value windows D chunks (they need the ranks), in a ring of D register sets.
+//   C is small next to A (m x n against m x k), so the chip is filled by slicing k: every slice writes an f32 partial tile, brsplit_reduce_kernel adds the
+//   slices in order and applies beta / the output type (one slice: the kernel writes C itself).  f32 accumulation in the matrix core's order: the
+//   tolerance of the dense kernels, not bitwise the reference's serial chain.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bitmask_tile_prefix_kernel(const unsigned char* bitmap_, unsigned int* tile_prefix_, unsigned int* count_, int row_bytes, int tiles) {
+  __shared__ unsigned int part[256];
+  GM const unsigned char* row = (GM const unsigned char*)bitmap_ + (long long)blockIdx.x * row_bytes;
+  const int t = (int)threadIdx.x;
+  unsigned int c = 0;
+  if (t < tiles) {
+    const int b0 = t * 32, b1 = (b0 + 32 < row_bytes) ? b0 + 32 : row_bytes;        // 128 rows x 2 bits = 32 bytes; row_bytes is a multiple of 4
+    for (int b = b0; b < b1; b += 4) c += (unsigned int)__builtin_popcount(*(GM const unsigned int*)(row + b));
+  }
+  part[t] = c;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned int v = (t >= o) ? part[t - o] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  if (t < tiles) ((GM unsigned int*)tile_prefix_)[(long long)blockIdx.x * tiles + t] = part[t] - c;
+  if (t == 255) ((GM unsigned int*)count_)[blockIdx.x] = part[255];
+}
+
+typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
+template <bool F16, int D, int WGS>
+__global__ __launch_bounds__(256, WGS) void gemm_bitmask16_kernel(GemmArgs p, const unsigned char* bitmap_, const unsigned int* start_, const unsigned int* tile_prefix_, int tiles, int row_bytes,
+                                                                int chunks_per_slice, float* partial) {
+  constexpr int kStageRow = 528;                                            // bytes per staged value window: 64 lanes x 8 bytes (+ 16: rows land in different banks)
+  __shared__ __attribute__((aligned(16))) unsigned int a_img[32 * 128];     // [k-pair][row] VNNI-2 words
+  __shared__ __attribute__((aligned(16))) char b_img[64 * 128];             // [column][64 k], 16-byte pieces XOR-swizzled with the column
+  __shared__ __attribute__((aligned(16))) char stage[32 * kStageRow];
+  __shared__ __attribute__((aligned(16))) u32x2b lut[16];                   // per 4-bit pattern: the byte selectors of the two output words
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  if (tid < 16) {
+    unsigned int selw[2] = {0u, 0u}, rank = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned int bit = ((unsigned int)tid >> e) & 1u;
+      const unsigned int two = bit ? ((2u * rank) | ((2u * rank + 1u) << 8)) : 0x0c0cu;      // source bytes of this half, or two zero bytes
+      selw[e >> 1] |= two << (16 * (e & 1));
+      rank += bit;
+    }
+    lut[tid] = (u32x2b){selw[0], selw[1]};
+  }
+  const int kp_l = tid >> 3, piece = tid & 7;                           // this thread's bit row of the chunk and bitmap dword of the tile
+  const int tm = (int)blockIdx.x, i0 = tm * 128, j0 = (int)blockIdx.y * 64;
+  const bool word_ok = (i0 / 4 + piece * 4) < row_bytes;               // the tile's last dwords may lie past the row (m not a multiple of 128)
+  GM const unsigned char* bitmap = (GM const unsigned char*)bitmap_;
+  GM const unsigned int* start = (GM const unsigned int*)start_; GM const unsigned int* tpre = (GM const unsigned int*)tile_prefix_;
+  const unsigned long long vals0 = (unsigned long long)(size_t)p.a;
+  const int chunks = p.k >> 6;
+  const int cbeg = (int)blockIdx.z * chunks_per_slice, cend = (cbeg + chunks_per_slice < chunks) ? cbeg + chunks_per_slice : chunks;
+  const unsigned int ldb = (unsigned int)p.ldb;
+  // B: thread -> (column f = tid / 4, 16-byte pieces tid % 4 and tid % 4 + 4) of the chunk
+  const int bf_ = tid >> 2, bpc = tid & 3;
+  GM const char* bsrc = (GM const char*)p.b + ((long long)((j0 + bf_ < p.n) ? j0 + bf_ : p.n - 1) * ldb) * 2 + bpc * 16;
+  f32x16 acc[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+  // What is loaded is kept raw until it is consumed one stage later: an operation on a value right behind its load (a select, an add, a copy at the end of a
+  // conditional block) makes the compiler wait there, and every load is unconditional (an address that is always valid instead of a branch around the load):
+  // a load inside divergent control flow makes it wait for ALL outstanding loads at the next use of any of them.  Either would end the requests that run ahead.
+  struct Bits { unsigned int wv, s0, t0; int c; };
+  struct Prep { unsigned int w, before; u32x4 b[2]; u32x2b win[8]; };
+  auto load_bits = [&](int c_in) __attribute__((always_inline)) {
+    Bits x;
+    const int c = c_in < cend ? c_in : cend - 1;                                          // past the slice: the last chunk again (never consumed)
+    const long long r = (long long)c * 32 + kp_l;
+    x.c = c;
+    x.wv = *(GM const unsigned int*)(bitmap + r * row_bytes + (word_ok ? i0 / 4 + piece * 4 : 0));
+    x.s0 = start[r]; x.t0 = tpre[r * tiles + tm];
+    return x;
+  };
+  auto prepare = [&](const Bits& x) __attribute__((always_inline)) {
+    Prep q;
+    q.w = word_ok ? x.wv : 0u;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) q.b[qq] = *(GM const u32x4*)(bsrc + 128ll * x.c + 64 * qq);      // (columns past n read column n - 1: their products are never stored)
+    const unsigned int base = x.s0 + x.t0;
+    // ranks: bits of this row below this thread's dword (exclusive prefix over the 8 lanes of the row); the row's total ends up in its last lane
+    const unsigned int cnt = (unsigned int)__builtin_popcount(q.w);
+    unsigned int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { const unsigned int v = (unsigned int)__shfl_up((int)incl, o, 8); if (piece >= o) incl += v; }
+    q.before = incl - cnt;
+    // the value windows of the wave's eight bit rows start AT the row's first value: 8-byte requests on 2-byte boundaries (the memory pipeline serves unaligned
+    // global accesses), so 64 lanes cover the 256 values a row can have; lanes past the row's values read the start of the value array (always mapped; what
+    // they stage is never picked)
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const unsigned int rbase = (unsigned int)__builtin_amdgcn_readlane((int)base, 8 * rr), rtot = (unsigned int)__builtin_amdgcn_readlane((int)incl, 8 * rr + 7);
+      const unsigned long long from = rtot ? vals0 + 2ull * rbase : vals0;              // wave-uniform base + a 32-bit lane offset: no 64-bit vector arithmetic
+      q.win[rr] = *(GM const u32x2b*)((GM const char*)(size_t)from + (((unsigned int)lane * 4u < rtot) ? (unsigned int)lane * 8u : 0u));
+    }
+    return q;
+  };
+  auto process = [&](const Prep& cur) __attribute__((always_inline)) {
+    wg_barrier();                                                                   // the previous chunk's MFMAs are done with the images (raw barrier: the requests ahead stay in flight)
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) *(u32x2b*)(stage + (8 * wave + rr) * kStageRow + lane * 8) = cur.win[rr];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *(u32x4*)(b_img + bf_ * 128 + (((bpc + 4 * q) ^ (bf_ & 7)) * 16)) = cur.b[q];
+    // Four bits (two VNNI words) at a time: the values of a nibble are <= 4 consecutive halves from rank r on.  Three aligned dwords around them, shifted by
+    // 16 bits when r is odd, are the 8 source bytes of two v_perm_b32 whose selectors -- which source half goes to which half of which word, zero bytes
+    // where the bit is clear -- come from a 16-entry table indexed by the nibble: 15 instructions per four elements instead of ~44 with one pick per element.
+    const char* winb = stage + kp_l * kStageRow;
+    const unsigned int w = cur.w;
+    unsigned int out[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned int nib = (w >> (4 * q)) & 15u;
+      const u32x2b sel = lut[nib];
+      const unsigned int r = cur.before + (unsigned int)__builtin_popcount(w & ((1u << (4 * q)) - 1u));
+      const unsigned int* t = (const unsigned int*)(winb + ((r >> 1) << 2));
+      const unsigned int t0 = t[0], t1 = t[1], t2 = t[2], sh = (r & 1u) << 4;
+      const unsigned int d0 = __builtin_amdgcn_alignbit(t1, t0, sh), d1 = __builtin_amdgcn_alignbit(t2, t1, sh);
+      out[2 * q] = __builtin_amdgcn_perm(d1, d0, sel[0]);
+      out[2 * q + 1] = __builtin_amdgcn_perm(d1, d0, sel[1]);
+    }
+#pragma unroll
+    // image rows are rotated by 4 (row % 8) words: the eight bit rows a wave writes at once would otherwise start in the same bank (a row is 128 words)
+    for (int x = 0; x < 4; ++x) { const u32x4 v = {out[4 * x], out[4 * x + 1], out[4 * x + 2], out[4 * x + 3]}; *(u32x4*)(a_img + kp_l * 128 + ((piece * 16 + 4 * x + 4 * (kp_l & 7)) & 127)) = v; }
+    wg_barrier();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      u32x4 af, bfr[2];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) af[d] = a_img[(8 * s2 + 4 * h + d) * 128 + ((32 * wave + li + 4 * (4 * h + d)) & 127)];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) { const int f = 32 * nt + li; bfr[nt] = *(const u32x4*)(b_img + f * 128 + (((2 * s2 + h) ^ (f & 7)) * 16)); }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[nt] = mfma_16bit<F16>(bfr[nt], af, acc[nt]);
+    }
+  };
+  if (cbeg >= cend) return;                                                              // (cannot happen: the launcher sizes the slices)
+  Prep ring[D]; Bits bits[D];
+  // prologue: windows of the first D chunks, bits of the D after them (indices past the slice repeat its last chunk and are never consumed).  In the loop the
+  // bits of chunk c + 2 D are requested while chunk c is multiplied and turned into window requests D chunks later: both stages are D chunks deep
+  static_for<D>([&](auto uc) { bits[uc.value] = load_bits(cbeg + uc.value); });
+  static_for<D>([&](auto uc) { ring[uc.value] = prepare(bits[uc.value]); bits[uc.value] = load_bits(cbeg + D + uc.value); });
+  int c0 = cbeg;
+  for (; c0 + D <= cend; c0 += D) {
+    static_for<D>([&](auto uc) {
+      constexpr int u = uc.value;
+      const Prep cur = ring[u];
+      ring[u] = prepare(bits[u]);                 // chunk c0 + u + D
+      bits[u] = load_bits(c0 + u + 2 * D);
+      process(cur);
+    });
+  }
+  static_for<D>([&](auto uc) { if (c0 + uc.value < cend) process(ring[uc.value]); });
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  const int i = i0 + 32 * wave + li;
+  if (i >= p.m) return;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) {
+      const int j = j0 + 32 * nt + jl_of(r2, h);
+      if (j >= p.n) continue;
+      const float v = acc[nt][r2];
+      if (partial) { ((GM float*)partial)[((long long)blockIdx.z * p.n + j) * p.m + i] = v; continue; }
+      const long long e = (long long)j * p.ldc + i;
+      if (p.c_type == LIBXSMM_DATATYPE_F32) { GM float* cp = (GM float*)p.c + e; *cp = beta0 ? v : v + *cp; }
+      else if (F16) { GM _Float16* cp = (GM _Float16*)p.c + e; *cp = (_Float16)(beta0 ? v : v + (float)*cp); }
+      else { GM unsigned short* cp = (GM unsigned short*)p.c + e; *cp = f32_to_bf16_rne(beta0 ? v : v + bf16_to_f32(*cp)); }
+    }
+  }
+}
+
+// *taken = 1: launched (the return value is the launch status); 0: shape / alignment not taken (the caller expands A and runs the dense kernel).
+// scratch: rows * (tiles + 2) words of counts / offsets, followed by the f32 partial tiles of the k-slices.
+int launch_gemm_bitmask16(const GemmArgs& a, const void* bitmap, unsigned int* scratch, size_t scratch_bytes, void* stream, const char** name, int* taken) {
+  hipStream_t st = (hipStream_t)stream;
+  *taken = 0;
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BITMASK_FUSED"); return e && e[0] == '0'; }();
+  const bool t16 = (a.a_type == LIBXSMM_DATATYPE_BF16 || a.a_type == LIBXSMM_DATATYPE_F16) && a.b_type == a.a_type;
+  if (off || !t16 || (a.m % 16) || (a.k % 64) || a.m <= 0 || a.n <= 0 || a.k <= 0) return 0;
+  if ((((size_t)a.b) & 15) || (((long long)a.ldb * 2) & 15) || (((size_t)a.a) & 1) || (((size_t)bitmap) & 3)) return 0;
+  const int rows = a.k / 2, row_bytes = a.m / 4, tiles = (a.m + 127) / 128, chunks = a.k / 64;
+  if (tiles > 256 || (long long)a.m * a.k >= (1ll << 31)) return 0;
+  const size_t table_words = ((size_t)rows * (size_t)(tiles + 2) + 63) & ~(size_t)63;
+  // slices of k: about 768 workgroups on the chip (three per CU; 256 ... 4096 measured within 20 % of each other), at least four chunks per slice, the partial tiles inside the scratch
+  const long long wgs = (long long)tiles * ((a.n + 63) / 64);
+  static const long long want = []() { const char* e = getenv("LIBXSMM_HIP_BITMASK_WGS"); return e ? atoll(e) : 768ll; }();
+  long long slices = std::max<long long>(1, std::min<long long>(want / std::max<long long>(wgs, 1), chunks / 4));
+  const size_t tile_bytes = (size_t)a.m * (size_t)a.n * sizeof(float);
+  while (slices > 1 && table_words * 4 + (size_t)slices * tile_bytes > scratch_bytes) --slices;
+  if (table_words * 4 > scratch_bytes) return 0;
+  const int cps = (int)((chunks + slices - 1) / slices);
+  slices = (chunks + cps - 1) / cps;
+  unsigned int* count = scratch; unsigned int* start = scratch + rows; unsigned int* tpre = scratch + 2 * (size_t)rows;
+  float* partial = slices > 1 ? (float*)(scratch + table_words) : nullptr;
+  hipLaunchKernelGGL(bitmask_tile_prefix_kernel, dim3((unsigned int)rows), dim3(256), 0, st, (const unsigned char*)bitmap, tpre, count, row_bytes, tiles);
+  hipLaunchKernelGGL(bitmask_row_scan_kernel, dim3(1), dim3(1024), 0, st, count, start, rows);
+  const dim3 grid((unsigned int)tiles, (unsigned int)((a.n + 63) / 64), (unsigned int)slices);
+  // ring depth 2 at three workgroups per CU (162 registers) measured 81 us against 89 us for depth 3 at two (206 registers) on 8192 x 8192 @50 %, n = 64
+  if (a.a_type == LIBXSMM_DATATYPE_F16) hipLaunchKernelGGL((gemm_bitmask16_kernel<true, 2, 3>), grid, dim3(256), 0, st, a, (const unsigned char*)bitmap, start, tpre, tiles, row_bytes, cps, partial);
+  else hipLaunchKernelGGL((gemm_bitmask16_kernel<false, 2, 3>), grid, dim3(256), 0, st, a, (const unsigned char*)bitmap, start, tpre, tiles, row_bytes, cps, partial);
+  int err = (int)hipGetLastError();
+  if (err == 0 && slices > 1) err = launch_brsplit_reduce(a, partial, (int)slices, st);
+  if (name) *name = "gemm_bitmask16_kernel";
+  *taken = 1;
+  return err;
 }
 
 // libxsmm_hip_probe_mfma: the matrix pipe alone (register operands, 16 accumulators per wave, one wave per SIMD): the power roof of a data set

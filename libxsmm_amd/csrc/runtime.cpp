@@ -390,11 +390,29 @@ static void run_gemm_bitmask(KernelCtx* k, const libxsmm_gemm_param* p, const Ba
     a.c = (char*)stage(a.c, (size_t)d.ldc * (size_t)d.n * (size_t)typesize(d.c_type), true, true);
     if (!bitmap || !vals || !a.b || !a.c) return;
   }
+  const char* kname = nullptr;
+  // 16-bit operands: the fused kernel multiplies straight out of (non-zeros, bitmap): no dense image is written or read (round 3)
+  {
+    // counts / offsets per (bit row, tile of 128 rows), then room for the f32 partial tiles of up to 32 slices of k (fewer slices if the workspace is short)
+    const size_t tiles = ((size_t)d.m + 127) / 128, table_bytes = ((((size_t)rows * (tiles + 2)) + 63) & ~(size_t)63) * sizeof(unsigned int);
+    const size_t part_bytes = (size_t)d.m * (size_t)d.n * sizeof(float);
+    size_t want_bytes = table_bytes + 32 * part_bytes;
+    if (want_bytes > ((size_t)1 << 30)) want_bytes = std::max(table_bytes + 2 * part_bytes, (size_t)1 << 30);
+    unsigned int* fs = (es == 2) ? (unsigned int*)workspace(want_bytes) : nullptr;
+    if (fs) {
+      a.a = (const char*)vals;
+      a.nbatch = 1; a.stream_hint = tls().stream_hint;
+      a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.lda = (int)d.m; a.ldb = (int)d.ldb; a.ldc = (int)d.ldc;
+      a.flags = d.flags; a.a_type = d.a_type; a.b_type = d.b_type; a.c_type = d.c_type; a.br_count = 1; a.br_mode = 0;
+      int taken = 0;
+      const int ferr = launch_gemm_bitmask16(a, bitmap, fs, want_bytes, tls().stream, &kname, &taken);
+      if (taken) { if (kname) k->kname_single = kname; finish_launch(ferr, kname); return; }
+    }
+  }
   const size_t scratch_bytes = ((size_t)rows * 2 * sizeof(unsigned int) + 255) & ~(size_t)255;
   char* ws = (char*)workspace(scratch_bytes + dense_bytes);
   if (!ws) return;
   int err = launch_bitmask_expand(bitmap, vals, ws + scratch_bytes, (unsigned int*)ws, rows, row_bytes, es, tls().stream);
-  const char* kname = nullptr;
   if (err == 0) {
     a.a = ws + scratch_bytes;
     a.nbatch = 1; a.stream_hint = tls().stream_hint;

@@ -571,7 +571,9 @@ def test_synchronous_gemm_accepts_plain_host_memory(kw):
 @pytest.mark.parametrize("where", ["device", "host"])
 @pytest.mark.parametrize("a_type,c_type", [(DT.F32, DT.F32), (DT.BF16, DT.F32), (DT.BF16, DT.BF16), (DT.F16, DT.F16)])
 @pytest.mark.parametrize("m,n,k,ldb,ldc,frac,beta", [(64, 48, 64, 64, 64, 0.5, 0), (32, 17, 48, 50, 40, 0.9, 1), (16, 8, 16, 16, 16, 0.0, 1), (48, 5, 32, 32, 48, 1.0, 0),
-                                                     (512, 64, 1024, 1024, 512, 0.75, 0), (1000, 33, 266, 270, 1000, 0.3, 1)])
+                                                     (512, 64, 1024, 1024, 512, 0.75, 0), (1000, 33, 266, 270, 1000, 0.3, 1),
+                                                     # the fused kernel's tiling: a ragged second tile of 128 rows, several column tiles, slices of k, dense rows (windows that overflow) and nearly empty ones
+                                                     (272, 70, 128, 128, 272, 0.3, 0), (1024, 16, 2048, 2048, 1024, 0.5, 0), (4096, 64, 512, 512, 4096, 0.9, 1), (256, 64, 64, 72, 260, 0.0, 1), (144, 130, 4096, 4096, 144, 0.0, 0)])
 def test_gemm_with_bitmask_compressed_a(where, a_type, c_type, m, n, k, ldb, ldc, frac, beta):
     import ctypes as C
     import torch
@@ -610,6 +612,9 @@ def test_gemm_with_bitmask_compressed_a(where, a_type, c_type, m, n, k, ldb, ldc
     assert err < (TOL_BF16 if c_type in (DT.BF16, DT.F16) else TOL_F32), err
     if frac == 1.0 and not beta:
         assert not np.any(sel(got))
+    if a_type != DT.F32 and m % 16 == 0 and k % 64 == 0 and (ldb * 2) % 16 == 0:
+        # 16-bit operands on whole 64-deep chunks: multiplied straight out of (non-zeros, bitmap), no dense image (round 3)
+        assert api.hip_kernel_name(h, 0).decode() == "gemm_bitmask16_kernel", api.hip_kernel_name(h, 0)
     # batching such a kernel is refused: the operand size differs per problem
     api.hip_gemm_batch_strided(h, C.byref(p), 2, 0, 0, 0)
     assert api.hip_get_last_error() != 0

@@ -82,6 +82,33 @@ def brgemm_i4(api, m, batch):
     return w
 
 
+def bitmask_gemm(api, m, n, k, frac, dt=DT.BF16):
+    """ONE GEMM whose A travels as (non-zeros, one bit per element) [LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK]: a pruned weight matrix m x k times n
+    activations.  Algorithmic bytes = 2 nnz + m k / 8 (A as stored) + 2 k n (B) + 4 m n (C, f32); `frac` = the share of zeros."""
+    import numpy as np
+    flags = GEMM_FLAG.DECOMPRESS_A_VIA_BITMASK | GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A
+    h = api.dispatch_gemm(capi.gemm_shape(m, n, k, m, k, m, dt, dt, DT.F32, DT.F32), flags, 0)
+    assert h
+    rng = np.random.default_rng(5)
+    keep = rng.random(m * k) >= frac
+    bits = np.packbits(keep, bitorder="little")
+    nnz = int(keep.sum())
+    per = 2 * nnz + m * k // 8 + 2 * k * n + 4 * m * n
+    ns = nsets_for(per)
+    Vs = [rnd(max(nnz, 1), "bf16") for _ in range(ns)]
+    Ms = [torch.from_numpy(bits.copy()).to(DEV) for _ in range(ns)]
+    Bs = [rnd(k * n, "bf16") for _ in range(ns)]
+    Cs = [torch.zeros(m * n, device=DEV, dtype=torch.float32) for _ in range(ns)]
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.a.secondary, p.b.primary, p.c.primary = Vs[s].data_ptr(), Ms[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(); ps.append(p)
+    w = Work(api, f"GEMM bf16, A by bitmask ({100 * (1 - frac):.0f} % non-zeros) m={m} n={n} k={k} -> f32", 2.0 * nnz * n, float(per), ns,
+             lambda s: capi.Api.call(h, ps[s]), lambda: api.hip_kernel_name(h, 0).decode())
+    w.dense_equiv_flops = 2.0 * m * n * k
+    w.keep = (Vs, Ms, Bs, Cs, ps)
+    return w
+
+
 def brgemm_lowbit(api, m, batch, a_dt):
     """1-bit (I1X8: signs) or 2-bit (I2X4: 0 / +1 / -1, interleaved) weights x signed bytes -> i32, m = n = k: algorithmic bytes per problem =
     m*m/8 or m*m/4 (A) + m*m (B) + 4*m*m (C)."""
@@ -406,6 +433,9 @@ def main():
         makers += [lambda: brgemm_i4(api, 64, 2 ** 17), lambda: brgemm_i4(api, 32, 2 ** 18), lambda: brgemm_mx4i8(api, 64, 2 ** 17), lambda: brgemm_mx4i8(api, 64, 2 ** 17, DT.F32),
                    lambda: brgemm_mxmx(api, 64, 2 ** 17, DT.MXHF6), lambda: brgemm_mxmx(api, 128, 2 ** 15, DT.MXHF6),
                    lambda: brgemm_lowbit(api, 64, 2 ** 17, DT.I2X4), lambda: brgemm_lowbit(api, 64, 2 ** 17, DT.I1X8)]
+    if "bitmask" in only:    # A compressed by bitmask: a pruned weight matrix times a few activations (round 3: no dense image)
+        makers += [lambda: bitmask_gemm(api, 8192, 16, 8192, 0.5), lambda: bitmask_gemm(api, 8192, 64, 8192, 0.5), lambda: bitmask_gemm(api, 8192, 64, 8192, 0.9),
+                   lambda: bitmask_gemm(api, 4096, 64, 4096, 0.5)]
     if "f16" in only:        # IEEE halves on the bf16 fast paths (round 3): streaming 32^3 / 64^3, fused none, and the blocked form through tools/bb_sweep.py --dtype f16
         makers += [lambda: brgemm(api, 32, "f16", 2 ** 18), lambda: brgemm(api, 64, "f16", 2 ** 16), lambda: brgemm(api, 32, "f16", 4096), lambda: brgemm(api, 64, "f16", 4096)]
     if "ragged" in only:     # the odd small shapes (BASELINE config #1 is 23^3), steady state and a 4096-problem launch
