@@ -1,10 +1,10 @@
-# PMC passes over one workload expression of tools/_one.py: WL='bp.brgemm_mx4i8(api, 64, 2 ** 17)' bash tools/pmc_wl.sh [outdir]
+# PMC passes over one workload expression of tools/time_one.py: WL='bp.brgemm_mx4i8(api, 64, 2 ** 17)' bash tools/pmc_wl.sh [outdir]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-pmc_wl}
 rm -rf $O; mkdir -p $O
 export EAGER=1 PYTHONPATH=$R
-B="python $R/tools/_one.py"
+B="python $R/tools/time_one.py"
 cd $R
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/p1 -- $B > $O/p1.out 2> $O/p1.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $O/p2 -- $B > $O/p2.out 2> $O/p2.err

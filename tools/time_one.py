@@ -1,4 +1,4 @@
-"""scratch: time ONE workload expression (env WL, evaluated with bp = tools/bench_paths, wl = tools/workloads) -- used by tools/_run1.sh for A/B runs under different env switches"""
+"""time ONE workload expression (env WL, evaluated with bp = tools/bench_paths, wl = tools/workloads) -- used by tools/a scratch script for A/B runs under different env switches"""
 import os, sys, json, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tools"); sys.path.insert(0, "tests")
 import bench, bench_paths as bp, workloads as wl
