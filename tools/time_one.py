@@ -1,4 +1,4 @@
-"""time ONE workload expression (env WL, evaluated with bp = tools/bench_paths, wl = tools/workloads) -- used by tools/a scratch script for A/B runs under different env switches"""
+"""time ONE workload expression (env WL, ";;"-separated; evaluated with bp = tools/bench_paths, wl = tools/workloads; EAGER=1: plain launches for counter passes) -- A/B runs under env switches: TAG=x LIBXSMM_HIP_...=1 WL="bp.bcsc(api, dtype=\"f32\")" python tools/time_one.py"""
 import os, sys, json, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tools"); sys.path.insert(0, "tests")
 import bench, bench_paths as bp, workloads as wl
