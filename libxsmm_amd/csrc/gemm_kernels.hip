@@ -3842,7 +3842,8 @@ int launch_gemm_bitmask16(const GemmArgs& a, const void* bitmap, unsigned int* s
   *taken = 0;
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BITMASK_FUSED"); return e && e[0] == '0'; }();
   const bool t16 = (a.a_type == LIBXSMM_DATATYPE_BF16 || a.a_type == LIBXSMM_DATATYPE_F16) && a.b_type == a.a_type;
-  if (off || !t16 || (a.m % 16) || (a.k % 64) || a.m <= 0 || a.n <= 0 || a.k <= 0) return 0;
+  // (every 64-column tile of C expands A again: beyond a few tiles the dense image, built once, is the cheaper form)
+  if (off || !t16 || (a.m % 16) || (a.k % 64) || a.m <= 0 || a.n <= 0 || a.n > 256 || a.k <= 0) return 0;
   if ((((size_t)a.b) & 15) || (((long long)a.ldb * 2) & 15) || (((size_t)a.a) & 1) || (((size_t)bitmap) & 3)) return 0;
   const int rows = a.k / 2, row_bytes = a.m / 4, tiles = (a.m + 127) / 128, chunks = a.k / 64;
   if (tiles > 256 || (long long)a.m * a.k >= (1ll << 31)) return 0;
