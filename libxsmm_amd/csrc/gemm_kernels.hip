@@ -3859,9 +3859,12 @@ int launch_gemm_bitmask16(const GemmArgs& a, const void* bitmap, unsigned int* s
   slices = (chunks + cps - 1) / cps;
   unsigned int* count = scratch; unsigned int* start = scratch + rows; unsigned int* tpre = scratch + 2 * (size_t)rows;
   float* partial = slices > 1 ? (float*)(scratch + table_words) : nullptr;
+  const dim3 grid((unsigned int)tiles, (unsigned int)((a.n + 63) / 64), (unsigned int)slices);
+  // (A second form -- every wave owning 32 rows outright: wave-private stage and image, B fragments straight from global memory, no barrier in the loop, a 16-bit
+  // table per 32-row tile -- was written and measured in round 3: correct, 136 registers, and SLOWER, 118 / 82 us against 81 / 62 us on 8192^2 @50 % x 64 / 16
+  // columns: the barriers are not what bounds this kernel.  Removed.)
   hipLaunchKernelGGL(bitmask_tile_prefix_kernel, dim3((unsigned int)rows), dim3(256), 0, st, (const unsigned char*)bitmap, tpre, count, row_bytes, tiles);
   hipLaunchKernelGGL(bitmask_row_scan_kernel, dim3(1), dim3(1024), 0, st, count, start, rows);
-  const dim3 grid((unsigned int)tiles, (unsigned int)((a.n + 63) / 64), (unsigned int)slices);
   // ring depth 2 at three workgroups per CU (162 registers) measured 81 us against 89 us for depth 3 at two (206 registers) on 8192 x 8192 @50 %, n = 64
   if (a.a_type == LIBXSMM_DATATYPE_F16) hipLaunchKernelGGL((gemm_bitmask16_kernel<true, 2, 3>), grid, dim3(256), 0, st, a, (const unsigned char*)bitmap, start, tpre, tiles, row_bytes, cps, partial);
   else hipLaunchKernelGGL((gemm_bitmask16_kernel<false, 2, 3>), grid, dim3(256), 0, st, a, (const unsigned char*)bitmap, start, tpre, tiles, row_bytes, cps, partial);
