@@ -3688,7 +3688,7 @@ __global__ __launch_bounds__(256) void bitmask_tile_prefix_kernel(const unsigned
 
 typedef unsigned int u32x2b __attribute__((ext_vector_type(2)));
 template <bool F16, int D, int WGS>
-__global__ __launch_bounds__(256, WGS) void gemm_bitmask16_kernel(GemmArgs p, const unsigned char* bitmap_, const unsigned int* start_, const unsigned int* tile_prefix_, int tiles, int row_bytes,
+__global__ __launch_bounds__(256, WGS) void gemm_bitmask16_kernel(GemmArgs p, const unsigned char* bitmap_, const unsigned int* start_, const unsigned int* tile_prefix_, const unsigned int* count_, int tiles, int row_bytes,
                                                                 int chunks_per_slice, float* partial) {
   constexpr int kStageRow = 528;                                            // bytes per staged value window: 64 lanes x 8 bytes (+ 16: rows land in different banks)
   __shared__ __attribute__((aligned(16))) unsigned int a_img[32 * 128];     // [k-pair][row] VNNI-2 words
@@ -3714,6 +3714,11 @@ __global__ __launch_bounds__(256, WGS) void gemm_bitmask16_kernel(GemmArgs p, co
   GM const unsigned int* start = (GM const unsigned int*)start_; GM const unsigned int* tpre = (GM const unsigned int*)tile_prefix_;
   const unsigned long long vals0 = (unsigned long long)(size_t)p.a;
   const int chunks = p.k >> 6;
+  // one past the last non-zero (the tables know), as an offset from the 8-byte boundary at or below the array; the last position an 8-byte request may start at
+  const unsigned long long base0 = vals0 & ~7ull;
+  const unsigned int row_off0 = (unsigned int)(vals0 - base0);
+  const unsigned int end_off = row_off0 + 2u * (start[p.k / 2 - 1] + ((GM const unsigned int*)count_)[p.k / 2 - 1]);
+  const unsigned int last_off = end_off >= 8u ? end_off - 8u : 0u;
   const int cbeg = (int)blockIdx.z * chunks_per_slice, cend = (cbeg + chunks_per_slice < chunks) ? cbeg + chunks_per_slice : chunks;
   const unsigned int ldb = (unsigned int)p.ldb;
   // B: thread -> (column f = tid / 4, 16-byte pieces tid % 4 and tid % 4 + 4) of the chunk
@@ -3728,7 +3733,7 @@ __global__ __launch_bounds__(256, WGS) void gemm_bitmask16_kernel(GemmArgs p, co
   // conditional block) makes the compiler wait there, and every load is unconditional (an address that is always valid instead of a branch around the load):
   // a load inside divergent control flow makes it wait for ALL outstanding loads at the next use of any of them.  Either would end the requests that run ahead.
   struct Bits { unsigned int wv, s0, t0; int c; };
-  struct Prep { unsigned int w, before; u32x4 b[2]; u32x2b win[8]; };
+  struct Prep { unsigned int w, before, shifts; u32x4 b[2]; u32x2b win[8]; };
   auto load_bits = [&](int c_in) __attribute__((always_inline)) {
     Bits x;
     const int c = c_in < cend ? c_in : cend - 1;                                          // past the slice: the last chunk again (never consumed)
@@ -3740,7 +3745,7 @@ __global__ __launch_bounds__(256, WGS) void gemm_bitmask16_kernel(GemmArgs p, co
   };
   auto prepare = [&](const Bits& x) __attribute__((always_inline)) {
     Prep q;
-    q.w = word_ok ? x.wv : 0u;
+    q.w = word_ok ? x.wv : 0u; q.shifts = 0u;
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) q.b[qq] = *(GM const u32x4*)(bsrc + 128ll * x.c + 64 * qq);      // (columns past n read column n - 1: their products are never stored)
     const unsigned int base = x.s0 + x.t0;
@@ -3756,15 +3761,23 @@ __global__ __launch_bounds__(256, WGS) void gemm_bitmask16_kernel(GemmArgs p, co
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const unsigned int rbase = (unsigned int)__builtin_amdgcn_readlane((int)base, 8 * rr), rtot = (unsigned int)__builtin_amdgcn_readlane((int)incl, 8 * rr + 7);
-      const unsigned long long from = rtot ? vals0 + 2ull * rbase : vals0;              // wave-uniform base + a 32-bit lane offset: no 64-bit vector arithmetic
-      q.win[rr] = *(GM const u32x2b*)((GM const char*)(size_t)from + (((unsigned int)lane * 4u < rtot) ? (unsigned int)lane * 8u : 0u));
+      // offsets from the 8-byte boundary at or below the value array (< 4 GiB: m k < 2^31).  A request that would end past the LAST non-zero of the whole
+      // array (only the last non-empty rows can) is moved back to end there and its bytes shifted down: nothing outside the caller's array is ever read,
+      // without a branch (a branch around a load would end the requests that run ahead, see above)
+      const unsigned int want = (rtot ? row_off0 + 2u * rbase : row_off0) + (((unsigned int)lane * 4u < rtot) ? (unsigned int)lane * 8u : 0u);
+      const unsigned int at = want < last_off ? want : last_off;
+      q.win[rr] = *(GM const u32x2b*)((GM const char*)(size_t)base0 + at);              // kept raw: the shift happens where the window is consumed
+      q.shifts |= ((want - at) >> 1) << (2 * rr);                                       // 0 / 2 / 4 / 6 bytes, two bits per row
     }
     return q;
   };
   auto process = [&](const Prep& cur) __attribute__((always_inline)) {
     wg_barrier();                                                                   // the previous chunk's MFMAs are done with the images (raw barrier: the requests ahead stay in flight)
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) *(u32x2b*)(stage + (8 * wave + rr) * kStageRow + lane * 8) = cur.win[rr];
+    for (int rr = 0; rr < 8; ++rr) {
+      const unsigned long long xs = (((unsigned long long)cur.win[rr][1] << 32) | cur.win[rr][0]) >> (16u * ((cur.shifts >> (2 * rr)) & 3u));
+      *(u32x2b*)(stage + (8 * wave + rr) * kStageRow + lane * 8) = (u32x2b){(unsigned int)xs, (unsigned int)(xs >> 32)};
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) *(u32x4*)(b_img + bf_ * 128 + (((bpc + 4 * q) ^ (bf_ & 7)) * 16)) = cur.b[q];
     // Four bits (two VNNI words) at a time: the values of a nibble are <= 4 consecutive halves from rank r on.  Three aligned dwords around them, shifted by
@@ -3812,6 +3825,7 @@ __global__ __launch_bounds__(256, WGS) void gemm_bitmask16_kernel(GemmArgs p, co
       const Prep cur = ring[u];
       ring[u] = prepare(bits[u]);                 // chunk c0 + u + D
       bits[u] = load_bits(c0 + u + 2 * D);
+      __builtin_amdgcn_sched_barrier(0);          // the requests go out BEFORE this chunk's work (left alone the scheduler sinks them below it)
       process(cur);
     });
   }
@@ -3866,8 +3880,8 @@ int launch_gemm_bitmask16(const GemmArgs& a, const void* bitmap, unsigned int* s
   hipLaunchKernelGGL(bitmask_tile_prefix_kernel, dim3((unsigned int)rows), dim3(256), 0, st, (const unsigned char*)bitmap, tpre, count, row_bytes, tiles);
   hipLaunchKernelGGL(bitmask_row_scan_kernel, dim3(1), dim3(1024), 0, st, count, start, rows);
   // ring depth 2 at three workgroups per CU (162 registers) measured 81 us against 89 us for depth 3 at two (206 registers) on 8192 x 8192 @50 %, n = 64
-  if (a.a_type == LIBXSMM_DATATYPE_F16) hipLaunchKernelGGL((gemm_bitmask16_kernel<true, 2, 3>), grid, dim3(256), 0, st, a, (const unsigned char*)bitmap, start, tpre, tiles, row_bytes, cps, partial);
-  else hipLaunchKernelGGL((gemm_bitmask16_kernel<false, 2, 3>), grid, dim3(256), 0, st, a, (const unsigned char*)bitmap, start, tpre, tiles, row_bytes, cps, partial);
+  if (a.a_type == LIBXSMM_DATATYPE_F16) hipLaunchKernelGGL((gemm_bitmask16_kernel<true, 2, 3>), grid, dim3(256), 0, st, a, (const unsigned char*)bitmap, start, tpre, count, tiles, row_bytes, cps, partial);
+  else hipLaunchKernelGGL((gemm_bitmask16_kernel<false, 2, 3>), grid, dim3(256), 0, st, a, (const unsigned char*)bitmap, start, tpre, count, tiles, row_bytes, cps, partial);
   int err = (int)hipGetLastError();
   if (err == 0 && slices > 1) err = launch_brsplit_reduce(a, partial, (int)slices, st);
   if (name) *name = "gemm_bitmask16_kernel";
