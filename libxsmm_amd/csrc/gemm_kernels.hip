@@ -3940,8 +3940,11 @@ int launch_brchain_f32(const GemmArgs& a_in, float* partial, size_t partial_capa
   GemmArgs a = a_in;
   a.tiles_m = a.m / 32; a.tiles_n = a.n / 32;
   const unsigned long long tiles = (unsigned long long)a.tiles_m * a.tiles_n;
-  // about 8192 waves over the chip: chunk blocks per wave, 8 waves per slice
-  unsigned long long chunk = (tiles * a.br_count + 8191ull) / 8192ull; if (chunk == 0) chunk = 1;
+  // about 2048 waves over the chip (one workgroup of 8 per CU), chunk blocks per wave, 8 waves per slice: measured on 32^3 chains (round 3): br = 4096 12.6 us with
+  // 1024 ... 2731 waves against 14.6 us with >= 4096 (twice the partial tiles for the second kernel) and 16.4 us with 512; br = 65 536: 91 - 103 us with 1024 ... 2048,
+  // 102 - 111 us with >= 4096
+  static const unsigned long long want_waves = []() { const char* e = getenv("LIBXSMM_HIP_BRCHAIN_WAVES"); return e ? (unsigned long long)atoll(e) : 2048ull; }();
+  unsigned long long chunk = (tiles * a.br_count + want_waves - 1ull) / want_waves; if (chunk == 0) chunk = 1;
   const unsigned long long slices = (a.br_count + 8ull * chunk - 1ull) / (8ull * chunk);
   if (slices > partial_capacity_tiles || slices * tiles >= (1ull << 31)) return 0;
   hipLaunchKernelGGL(gemm_f32_brchain_kernel, dim3((unsigned int)(slices * tiles)), dim3(512), 0, (hipStream_t)stream, a, partial, (unsigned int)chunk, (unsigned int)slices);
