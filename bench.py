@@ -815,6 +815,7 @@ def main():
                        "kernel": headline_kernel, "input_sets_rotated": work.nsets, "per_gpu_batch": args.batch,
                        "streaming_hint": headline_hint},
             "verified": verified, "verify": {"checker": "oracle/liboracle.so (oracle_gemm) on the same inputs", "problems_sampled": vcnt, "normf_rel_max": float(f"{verr:.3g}")},
+            "rccl_ranks": world if dist is not None else 0,      # ranks of the process group behind the barrier / MAX reduction (0: a single process without one)
             "pct_mfma_peak": round(100.0 * value / world / 1e3 / peak_tf, 2),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
