@@ -261,3 +261,54 @@ def test_equations_dispatch_and_fuse_as_documented():
             assert kernel.startswith(expected), (name, kernel)
         else:
             assert not kernel.startswith("meqn_jit"), (name, kernel)          # MATMUL nodes (and vector-valued reductions above 2^14 elements): a chain of launches
+
+
+MEQN_HEADS_CHILD = r"""
+import json, sys
+sys.path.insert(0, %r)
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, UNARY, UNARY_FLAG as UF, BINARY, TERNARY, TERNARY_FLAG as TF
+api = capi.load()
+SINGULAR = capi.MatrixArgAttributes(0, 0, 0, 0)
+out = {}
+def scatter_head(name, sum_type, out_type):
+    idx = api.meqn_create()
+    md = lambda pos=-1: capi.MeqnMetadata(idx, pos)
+    api.meqn_push_back_unary_op(md(), UNARY.SCATTER, out_type, UF.GS_COLS | UF.IDX_SIZE_4BYTES)
+    api.meqn_push_back_binary_op(md(), BINARY.ADD, sum_type, 0)
+    api.meqn_push_back_arg(md(0), capi.MeqnArgShape(32, 8, 32, out_type), SINGULAR)
+    api.meqn_push_back_arg(md(1), capi.MeqnArgShape(32, 8, 32, out_type), SINGULAR)
+    out[name] = bool(api.dispatch_meqn(idx, capi.MeqnArgShape(32, 24, 32, out_type)))
+scatter_head("scatter_head_f32", DT.F32, DT.F32)
+scatter_head("scatter_head_bf16_sum_bf16", DT.BF16, DT.BF16)
+scatter_head("no:scatter_head_bf16_sum_f32", DT.F32, DT.BF16)          # a 4-byte operand scattered into 2-byte columns would be written past them
+def scatter_inside():
+    idx = api.meqn_create()
+    md = lambda pos=-1: capi.MeqnMetadata(idx, pos)
+    api.meqn_push_back_unary_op(md(), UNARY.TANH, DT.F32, 0)
+    api.meqn_push_back_unary_op(md(), UNARY.SCATTER, DT.F32, UF.GS_COLS | UF.IDX_SIZE_4BYTES)
+    api.meqn_push_back_arg(md(0), capi.MeqnArgShape(32, 8, 32, DT.F32), SINGULAR)
+    out["no:scatter_below_the_head"] = bool(api.dispatch_meqn(idx, capi.MeqnArgShape(32, 8, 32, DT.F32)))
+scatter_inside()
+def gemm_head(name, flags):
+    idx = api.meqn_create()
+    md = lambda pos=-1: capi.MeqnMetadata(idx, pos)
+    api.meqn_push_back_ternary_op(md(), TERNARY.MATMUL, DT.F32, flags)
+    api.meqn_push_back_arg(md(0), capi.MeqnArgShape(32, 16, 32, DT.F32), SINGULAR)
+    api.meqn_push_back_arg(md(1), capi.MeqnArgShape(16, 48, 16, DT.F32), SINGULAR)
+    api.meqn_push_back_arg(md(2), capi.MeqnArgShape(32, 48, 32, DT.F32), SINGULAR)
+    out[name] = bool(api.dispatch_meqn(idx, capi.MeqnArgShape(32, 48, 40, DT.F32)))
+gemm_head("accumulating_matmul_head", TF.REUSE_IN_2_AS_OUT)
+gemm_head("no:ternary_matmul_without_reuse", 0)
+print(json.dumps(out))
+"""
+
+
+def test_equation_heads_accepted_and_refused():
+    """SCATTER exists as the head only and copies elements of its operand's width; a MATMUL that accumulates into its third operand may be the head (round 3)."""
+    env = dict(os.environ, LIBXSMM_HIP_DRYRUN="1", LIBXSMM_VERBOSE="0")
+    r = subprocess.run([sys.executable, "-c", MEQN_HEADS_CHILD % ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    wrong = {k: v for k, v in got.items() if v == k.startswith("no:")}
+    assert not wrong, f"accepted / refused against the table: {wrong}"
