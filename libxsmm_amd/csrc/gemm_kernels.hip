@@ -2446,15 +2446,16 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
   static_for<NT>([&](auto idx) { sum_b[idx.value] = (i32x16)0; });
   static_for<MT>([&](auto idx) { sum_a[idx.value] = (i32x16)0; });
   const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
-  unsigned int offB[NT * 2];
+  unsigned int offB[NT * 2], offBt[NT * 2];
 #pragma unroll
   for (int x = 0; x < NT * 2; ++x) {
     const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
     offB[x] = f * ldb + pc * 16u;
+    offBt[x] = f * ldb + (pc & 1u) * 16u;             // half a chunk (k % 64 == 32): only the first 32 bytes of a column's 64 exist -- the pieces 2 / 3 re-read 0 / 1 and are never used
   }
   const unsigned int offA = ((I4 ? 2u * h : 4u * h) * lda + (unsigned int)li) * 4u;      // dword (k-quad 4h, row li); I4: dword (k-group-of-8 2h, row li)
   const i32x4 ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
-  const int kchunks = p.k >> 6;
+  const int kchunks = p.k >> 6, ktail = (p.k >> 5) & 1;       // whole 64-deep chunks, then one 32-deep half chunk: MFMA step 0 only (round 3: k = 32, 96, ... used to fall to the generic kernel)
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
     const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + (unsigned long long)job.j0 * ldb);     // buffer addressing, see gemm_bf16_stream_kernel
@@ -2467,10 +2468,12 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) zz[mt] = (unsigned int)zp[32 * mt] * 0x01010101u;
     }
-    for (int kc = 0; kc < kchunks; ++kc) {
+    for (int kc = 0; kc < kchunks + ktail; ++kc) {
+      const bool half = kc == kchunks;                 // wave-uniform
+      const unsigned int s1 = half ? 0u : 1u;          // the k-step the "second" operand loads address: in a half chunk they repeat step 0 (in bounds) and are not multiplied
 #pragma unroll
       for (int x = 0; x < NT * 2; ++x)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)(half ? offBt[x] : offB[x]), 64 * kc, 0, 0);
       i32x4 af[MT][2];
       if constexpr (I4) {
 #pragma unroll
@@ -2479,7 +2482,7 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-              const unsigned int w = (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (4u * s + e) * lda * 4u) + 128 * mt, 32 * kc * (int)lda, 0);
+              const unsigned int w = (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (4u * (s ? s1 : 0u) + e) * lda * 4u) + 128 * mt, 32 * kc * (int)lda, 0);
               af[mt][s][2 * e] = sub_bytes(w & 0x0f0f0f0fu, zz[mt]);
               af[mt][s][2 * e + 1] = sub_bytes((w >> 4) & 0x0f0f0f0fu, zz[mt]);
             }
@@ -2491,7 +2494,7 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
           for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const unsigned int w = (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(ra0, (int)((8u * s + 4u * h + e) * lda + 4u * rr), 16 * kc * (int)lda, 0);
+              const unsigned int w = (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(ra0, (int)((8u * (s ? s1 : 0u) + 4u * h + e) * lda + 4u * rr), 16 * kc * (int)lda, 0);
               af[mt][s][e] = (int)__builtin_amdgcn_perm(0u, 0xffff0100u, (w >> (2u * g)) & 0x03030303u);
             }
         }
@@ -2503,7 +2506,7 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
           for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const unsigned int b = (unsigned int)__builtin_amdgcn_raw_buffer_load_b8(ra0, (int)((8u * s + 4u * h + e) * (lda >> 1) + (i >> 1)), 16 * kc * (int)(lda >> 1), 0) & 0xffu;
+              const unsigned int b = (unsigned int)__builtin_amdgcn_raw_buffer_load_b8(ra0, (int)((8u * (s ? s1 : 0u) + 4u * h + e) * (lda >> 1) + (i >> 1)), 16 * kc * (int)(lda >> 1), 0) & 0xffu;
               const unsigned int x = ((((b >> (4u * (i & 1u))) & 0xfu) * 0x00204081u) & 0x01010101u);
               af[mt][s][e] = (int)((x * 0xfeu) | 0x01010101u);
             }
@@ -2515,7 +2518,7 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (8u * s + e) * lda * 4u) + 128 * mt, 64 * kc * (int)lda, 0);
+            const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (8u * (s ? s1 : 0u) + e) * lda * 4u) + 128 * mt, 64 * kc * (int)lda, 0);
             af[mt][s][e] = UA ? (v ^ (int)0x80808080) : v;
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2531,6 +2534,7 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
         }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        if (s == 1 && half) break;
         static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
           acc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0); });
         if (UA) static_for<NT>([&](auto idx) { sum_b[idx.value] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr[idx.value][s], ones, sum_b[idx.value], 0, 0, 0); });
@@ -3312,7 +3316,7 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     // interleaved 4-bit weights: the int8 streaming kernel with the nibbles expanded (and the row's zero point subtracted) in registers
     pl.path = (m > 32 && n > 32) ? P_I8_2x2 : P_I8_1x1;
     const int t = (pl.path == P_I8_2x2) ? 64 : 32;
-    pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
+    pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
     if (!pl.exact) pl.path = P_GENERIC;
     return pl;
   }
@@ -3320,15 +3324,15 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     // 1- / 2-bit weights: the int8 streaming kernel with the bits expanded to +-1 / 0 bytes in registers (round 3)
     pl.path = (m > 32 && n > 32) ? P_I8_2x2 : P_I8_1x1;
     const int t = (pl.path == P_I8_2x2) ? 64 : 32;
-    pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
-    if (!pl.exact && pl.path == P_I8_2x2 && (m % 32 == 0) && (n % 32 == 0) && (k % 64 == 0)) { pl.path = P_I8_1x1; pl.exact = true; }
+    pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
+    if (!pl.exact && pl.path == P_I8_2x2 && (m % 32 == 0) && (n % 32 == 0) && (k % 32 == 0)) { pl.path = P_I8_1x1; pl.exact = true; }
     if (!pl.exact) pl.path = P_GENERIC;
     return pl;
   }
   if ((a_type == LIBXSMM_DATATYPE_I8 || a_type == LIBXSMM_DATATYPE_U8) && va && !ta && !tb && !vb) {
     pl.path = (m > 32 && n > 32) ? P_I8_2x2 : P_I8_1x1;
     const int t = (pl.path == P_I8_2x2) ? 64 : 32;
-    pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
+    pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
     if (!pl.exact) pl.path = P_GENERIC;
     return pl;
   }

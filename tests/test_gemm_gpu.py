@@ -386,7 +386,12 @@ SHAPES_I8 = [
     dict(m=32, n=64, k=64, a_type=DT.I8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.5, batch=2),
     dict(m=17, n=9, k=12, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, beta=1, ldc=20),     # generic kernel
     dict(m=12, n=10, k=7, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32),                                        # flat A
-    dict(m=32, n=32, k=32, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A),                       # k % 64 != 0 -> generic
+    # k % 64 == 32: whole 64-deep chunks and one half chunk (MFMA step 0 only; round 3 -- these shapes ran on the generic kernel before), every signedness
+    dict(m=32, n=32, k=32, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A),
+    dict(m=32, n=32, k=32, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, beta=1, batch=9),
+    dict(m=64, n=64, k=96, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3, batch=4),
+    dict(m=64, n=32, k=160, a_type=DT.I8, b_type=DT.U8, c_type=DT.F32, flags=F.VNNI_A, scf=0.25, beta=1, batch=2, lda=72, ldb=176, ldc=80),
+    dict(m=32, n=32, k=48, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A),                       # k % 32 != 0 -> generic
 ]
 
 
@@ -398,7 +403,7 @@ def test_int8_gemm_is_bit_identical(kw):
     ref, _ = case.run_oracle()
     name = api.hip_kernel_name(handle, 1 if case.batch > 1 else 0).decode()
     assert np.array_equal(case.valid_region(ref), case.valid_region(got)), name
-    exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 64 == 0 and (kw.get("flags", 0) & F.VNNI_A)
+    exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and (kw.get("flags", 0) & F.VNNI_A)
     assert ("gemm_i8_stream_kernel" in name) == bool(exact), name
     # unsupported combinations return NULL like the reference's dispatcher
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 64, 32, 64, 32, DT.I8, DT.I8, DT.I32, DT.I32), F.VNNI_A | F.TRANS_A, 0) is None
@@ -424,7 +429,7 @@ def test_fp8_gemm_matches_oracle(kw):
     got, _, handle = case.run_gpu(batched=True)
     ref, _ = case.run_oracle()
     name = api.hip_kernel_name(handle, 1 if case.batch > 1 else 0).decode()
-    exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 64 == 0 and (kw.get("flags", 0) & F.VNNI_A)
+    exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and (kw.get("flags", 0) & F.VNNI_A)
     assert ("gemm_fp8_stream_kernel" in name) == bool(exact), name
     if exact:     # products of 8-bit floats are exact in f32; the reference's bound for f32 output (gemm_kernel.c:5408) holds
         assert normf_rel(case.valid_region(ref), case.valid_region(got), DT.F32) < TOL_F32, name
@@ -744,7 +749,8 @@ def test_mx_typed_gemm_output(dt, m, n, k, lda, ldb, ldc, br, batch):
 @pytest.mark.parametrize("a_type", [DT.I1X8, DT.I2X4])
 @pytest.mark.parametrize("b_type", [DT.I8, DT.U8])
 @pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (24, 7, 16, 28, 20, 30, 1, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0, 1), (128, 32, 256, 128, 256, 128, 2, 1, 11),
-                                                             (64, 64, 64, 64, 64, 64, 1, 0, 3), (32, 32, 128, 36, 144, 40, 3, 0, 1), (96, 64, 64, 104, 80, 96, 2, 1, 7)])
+                                                             (64, 64, 64, 64, 64, 64, 1, 0, 3), (32, 32, 128, 36, 144, 40, 3, 0, 1), (96, 64, 64, 104, 80, 96, 2, 1, 7),
+                                                             (32, 32, 32, 32, 32, 32, 1, 0, 5), (64, 32, 96, 64, 96, 64, 2, 1, 3)])      # k % 64 == 32: a half chunk at the end
 def test_low_bit_weight_gemm_bit_exact(a_type, b_type, m, n, k, lda, ldb, ldc, br, beta, batch):
     import torch
     from oracle import pyoracle
@@ -774,7 +780,7 @@ def test_low_bit_weight_gemm_bit_exact(a_type, b_type, m, n, k, lda, ldb, ldc, b
         api.hip_gemm_batch_strided(h, C.byref(p), batch, br * a_b, br * b_b, c_b)
     api.hip_sync(); api.check()
     assert np.array_equal(dC.cpu().numpy(), ref)
-    if m % 32 == 0 and n % 32 == 0 and k % 64 == 0:
+    if m % 32 == 0 and n % 32 == 0 and k % 32 == 0:
         # whole tiles: the int8 matrix-core kernel with the bits expanded to signed bytes in registers (round 3); everything else the exact generic kernel
         want = "gemm_i1_stream_kernel" if a_type == DT.I1X8 else "gemm_i2_stream_kernel"
         assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode().startswith(want), api.hip_kernel_name(h, 1 if batch > 1 else 0)
@@ -794,7 +800,8 @@ def test_low_bit_weight_gemm_bit_exact(a_type, b_type, m, n, k, lda, ldb, ldc, b
 @pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta,batch", [(32, 16, 32, 32, 32, 32, 1, 0, 1), (17, 7, 64, 20, 96, 24, 1, 1, 1), (64, 8, 64, 64, 64, 64, 3, 0, 1), (128, 32, 256, 128, 256, 128, 2, 1, 9),
                                                              (64, 64, 128, 64, 128, 64, 3, 0, 5), (32, 32, 64, 32, 64, 32, 1, 0, 1), (64, 128, 64, 72, 96, 64, 1, 1, 33),
                                                              # enough tiles for waves that walk several of them (MXFP4: gemm_mx4i8_pipe_kernel), the last wave with fewer
-                                                             (64, 64, 64, 64, 64, 64, 2, 0, 6200), (32, 32, 64, 32, 64, 40, 1, 1, 20001)])
+                                                             (64, 64, 64, 64, 64, 64, 2, 0, 6200), (32, 32, 64, 32, 64, 40, 1, 1, 20001),
+                                                             (32, 32, 32, 32, 32, 32, 1, 0, 7), (64, 64, 96, 64, 96, 64, 2, 1, 3)])      # k % 64 == 32 (I4X2: a half chunk on the matrix cores; MXFP4: generic)
 def test_interleaved_4bit_weight_gemm_bit_exact(a_type, c_type, m, n, k, lda, ldb, ldc, br, beta, batch):
     import torch
     from helpers import rand_values
@@ -839,7 +846,7 @@ def test_interleaved_4bit_weight_gemm_bit_exact(a_type, c_type, m, n, k, lda, ld
         api.hip_gemm_batch_strided(h, C.byref(p), batch, br * a_b, br * b_b, ldc * n * esz)
     api.hip_sync(); api.check()
     assert dC.cpu().numpy().view(C0.dtype).tobytes() == ref.tobytes()
-    if a_type == DT.I4X2 and m % 32 == 0 and n % 32 == 0 and k % 64 == 0:
+    if a_type == DT.I4X2 and m % 32 == 0 and n % 32 == 0 and k % 32 == 0:
         # whole tiles: the int8 matrix-core kernel with the nibbles expanded in registers (round 3); everything else the exact generic kernel
         assert api.hip_kernel_name(h, 1 if batch > 1 else 0).decode().startswith("gemm_i4_stream_kernel"), api.hip_kernel_name(h, 1 if batch > 1 else 0)
     if mx and m % 32 == 0 and n % 32 == 0 and k % 64 == 0:
