@@ -2842,29 +2842,32 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
     tile_init<true, true>(acc[mt][nt], p, q, tc[mt][nt]);
   });
   const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
-  unsigned int offB[NT * 2];
+  unsigned int offB[NT * 2], offBt[NT * 2];
 #pragma unroll
   for (int x = 0; x < NT * 2; ++x) {
     const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
     offB[x] = f * ldb + pc * 16u;
+    offBt[x] = f * ldb + (pc & 1u) * 16u;             // half a chunk (k % 64 == 32): the pieces 2 / 3 of a column re-read 0 / 1 and are never used
   }
   const unsigned int offA = ((2u * h) * lda + (unsigned int)li) * 4u;      // dword (k-quad 2h, row li)
-  const int kchunks = p.k >> 6;
+  const int kchunks = p.k >> 6, ktail = (p.k >> 5) & 1;       // whole chunks, then one 32-deep half chunk: MFMA steps 0 and 1 only (round 3)
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
     const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + (unsigned long long)job.j0 * ldb);     // buffer addressing, see gemm_bf16_stream_kernel
     const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 4ull * (unsigned long long)job.i0);
-    for (int kc = 0; kc < kchunks; ++kc) {
+    for (int kc = 0; kc < kchunks + ktail; ++kc) {
+      const bool half = kc == kchunks;                 // wave-uniform
 #pragma unroll
       for (int x = 0; x < NT * 2; ++x)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)offB[x], 64 * kc, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(lds + 1024 * x), 16, (int)(half ? offBt[x] : offB[x]), 64 * kc, 0, 0);
       long af[MT][4];
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const unsigned int lo = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (4u * s) * lda * 4u) + 128 * mt, 64 * kc * (int)lda, 0);
-          const unsigned int hi = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (4u * s + 1u) * lda * 4u) + 128 * mt, 64 * kc * (int)lda, 0);
+          const unsigned int sq = (s >= 2 && half) ? 4u * (s - 2) : 4u * s;      // in a half chunk the steps 2 / 3 repeat 0 / 1 (in bounds) and are not multiplied
+          const unsigned int lo = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + sq * lda * 4u) + 128 * mt, 64 * kc * (int)lda, 0);
+          const unsigned int hi = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(offA + (sq + 1u) * lda * 4u) + 128 * mt, 64 * kc * (int)lda, 0);
           af[mt][s] = (long)(((unsigned long long)hi << 32) | lo);
         }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2877,10 +2880,12 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
           bfr[nt][s] = *(const long*)(lds + f * 64 + ((s ^ ((f >> 1) & 3)) * 16) + 8 * h);
         }
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
+        if (s == 2 && half) break;
         static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
           if (HF8) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(bfr[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0);
           else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(bfr[nt][s], af[mt][s], acc[mt][nt], 0, 0, 0); });
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
@@ -3307,7 +3312,7 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
   if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && va && !ta && !tb && !vb) {
     pl.path = (m > 32 && n > 32) ? P_FP8_2x2 : P_FP8_1x1;
     const int t = (pl.path == P_FP8_2x2) ? 64 : 32;
-    pl.exact = (m % t == 0) && (n % t == 0) && (k % 64 == 0);
+    pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
     if (!pl.exact) pl.path = P_GENERIC;
     return pl;
   }

@@ -416,6 +416,10 @@ SHAPES_FP8 = [
     dict(m=64, n=64, k=128, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, batch=3),
     dict(m=64, n=64, k=64, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, batch=4),
     dict(m=32, n=64, k=192, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2, beta=1, batch=2),
+    # k % 64 == 32: whole chunks and a half chunk (MFMA steps 0 and 1; round 3 -- generic kernel before)
+    dict(m=32, n=32, k=32, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, batch=7),
+    dict(m=64, n=64, k=96, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2, beta=1, batch=3),
+    dict(m=64, n=32, k=160, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, batch=2, lda=72, ldb=176, ldc=80),
     dict(m=17, n=9, k=12, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, ldc=20),       # generic kernel: bit-identical
     dict(m=12, n=10, k=7, a_type=DT.HF8, c_type=DT.F32),
     dict(m=13, n=11, k=8, a_type=DT.HF8, c_type=DT.F32, flags=F.TRANS_B),
