@@ -112,6 +112,41 @@ def test_config4_bcsc_full_batch():
     api.release_kernel(h)
 
 
+def test_config4_bcsc_full_batch_f32():
+    """config #4's shape in f32 (`spmm_kernel F32 F32 F32 F32 64 64 256 8192 ...`) at full size on the waves streaming over M-blocks (round 3): every 127th M-block
+    (and the last one) against the gold loop [ref: spmm_kernel.c:74-217], all blocks through linearity in A (eighths: sums stay exact in f32)."""
+    import torch
+    api, orc = capi.load(), pyoracle.oracle()
+    M, K, N, mb, bk, bn = 64, 256, 64, 8192, 32, 16
+    colptr, rowidx = structured_2_of_8(K, N, bk, bn)
+    nnzb = len(rowidx)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    rnd = lambda *s: torch.randint(-4, 6, s, generator=g).float() / 8
+    A1, A2, Bv = rnd(mb, K, M), rnd(mb, K, M), rnd(nnzb * bn * bk)
+    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, DT.F32, DT.F32, DT.F32, DT.F32), GEMM_FLAG.BETA_0, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    dBv, dcp, dri = Bv.cuda(), torch.from_numpy(colptr.view(np.int32)).cuda(), torch.from_numpy(rowidx.view(np.int32)).cuda()
+    nblk = C.c_ulonglong(N // bn)
+
+    def run(A):
+        dA, dC = A.cuda(), torch.full((mb * N * M,), float("nan"), dtype=torch.float32, device="cuda")
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = dA.data_ptr(), dBv.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), dC.data_ptr()
+        capi.Api.call(h, p); api.hip_sync(); api.check()
+        return dC
+    c1, c2, c12 = run(A1), run(A2), run(A1 + A2)
+    assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_f32_stream_kernel"
+    assert torch.equal(c12, c1 + c2)                                             # exact: every term is a multiple of 1/64 far below 2^24
+    sample = sorted(set(list(range(0, mb, 127)) + [mb - 1]))
+    As = A1[sample].numpy().reshape(-1).copy()
+    bv = Bv.numpy().copy()
+    ref = np.zeros(len(sample) * N * M, dtype=np.float32)
+    orc.lib.oracle_packed_spgemm_bcsc(DT.F32, DT.F32, M, N, K, len(sample), bk, bn, 0, As.ctypes.data, bv.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, 1)
+    got = c1.view(mb, N * M)[sample].reshape(-1).cpu().numpy()
+    assert np.array_equal(ref, got)                                              # exact data: any summation order gives the same f32
+    api.release_kernel(h)
+
+
 @pytest.mark.parametrize("pattern_on", ["device", "host", "bound"])
 def test_config4_bcsc_full_batch_bf16_c(pattern_on):
     """BASELINE configs[3] as written (`spmm_kernel BF16 BF16 F32 BF16 64 64 256 8192 ...`: bf16 C) at full size: EVERY one of the 8192 M-blocks against the
