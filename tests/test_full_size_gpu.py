@@ -227,3 +227,34 @@ def test_config5_fused_bf16_brgemm_full_shard():
     api.hip_gemm_ext_batch_strided(h, C.byref(p), batch, m * m * 2, m * m * 2, m * m * 2, 0, 0)
     api.hip_sync(); api.check()
     assert torch.equal(dC2.view(batch, -1), dC.view(batch, -1)[perm.cuda()])
+
+
+def test_bitmask_compressed_a_large_exact():
+    """ONE bf16 GEMM with A = (non-zeros, bitmap) at the size the fused kernel is built for (a pruned 8192 x 8192 weight matrix, half of it zeros, times 16
+    columns): k in 12 slices, 11 chunks each.  Operands are eighths, so every partial sum is exact in f32 whatever its order and the result must equal the
+    reference's serial loop [ref: gemm ref :857-948] BIT FOR BIT."""
+    import torch
+    from helpers import compress_by_bitmask
+    api, orc = capi.load(), pyoracle.oracle()
+    m, n, k = 8192, 16, 8192
+    rng = np.random.default_rng(23)
+    eighths = (rng.integers(-4, 6, m * k).astype(np.float32) / 8)
+    eighths[rng.random(m * k) < 0.5] = 0.0
+    a_mem = (eighths.view(np.uint32) >> 16).astype(np.uint16)                 # exact in bf16; memory order = the VNNI image [k/2][m][2]
+    vals, bits = compress_by_bitmask(a_mem)
+    Bf = rng.integers(-4, 6, k * n).astype(np.float32) / 8
+    B = (Bf.view(np.uint32) >> 16).astype(np.uint16)
+    flags = GEMM_FLAG.DECOMPRESS_A_VIA_BITMASK | GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A
+    ref = np.zeros(m * n, dtype=np.float32)
+    p = capi.GemmParam()
+    p.a.primary, p.a.secondary, p.b.primary, p.c.primary = vals.ctypes.data, bits.ctypes.data, B.ctypes.data, ref.ctypes.data
+    orc.gemm(p, pyoracle.GemmDesc(m, n, k, m, k, m, DT.BF16, DT.BF16, DT.F32, DT.F32, flags | GEMM_FLAG.USE_XGEMM_ABI, 0, 0, 0, 0))
+    h = api.dispatch_gemm(capi.gemm_shape(m, n, k, m, k, m, DT.BF16, DT.BF16, DT.F32, DT.F32), flags, 0)
+    assert h
+    dv, db, dB = (torch.from_numpy(x.view(np.int16) if x.dtype == np.uint16 else x).cuda() for x in (vals, bits, B))
+    dC = torch.full((m * n,), float("nan"), dtype=torch.float32, device="cuda")
+    p.a.primary, p.a.secondary, p.b.primary, p.c.primary = dv.data_ptr(), db.data_ptr(), dB.data_ptr(), dC.data_ptr()
+    capi.Api.call(h, p)
+    api.hip_sync(); api.check()
+    assert api.hip_kernel_name(h, 0).decode() == "gemm_bitmask16_kernel"
+    assert np.array_equal(dC.cpu().numpy(), ref)
