@@ -49,7 +49,7 @@ from libxsmm_amd import capi  # noqa: E402
 from libxsmm_amd.capi import DT, GEMM_FLAG  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}
+MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0, "f64": 78.6}      # f64: v_mfma_f64_16x16x4_f64, 32 flop / clk / SIMD
 L3_BYTES = 256 * 2 ** 20
 
 
@@ -84,10 +84,13 @@ def parse():
 
 def gen_values(n, bf16, dev, gen):
     """Reference-style data [samples/xgemm/gemm_kernel.c:837-865]: multiples of 0.1 in [-0.4, 0.5]; bf16 by truncation (bf16 = "f16": IEEE halves, RNE)."""
-    out = torch.empty(n, dtype=torch.int16 if bf16 else torch.float32, device=dev)
+    out = torch.empty(n, dtype=torch.float64 if bf16 == "f64" else (torch.int16 if bf16 else torch.float32), device=dev)
     step = 1 << 26
     for o in range(0, n, step):
         c = min(step, n - o)
+        if bf16 == "f64":
+            out[o:o + c] = torch.randint(-4, 6, (c,), generator=gen, device=dev, dtype=torch.int32).double() / 10
+            continue
         v = torch.randint(-4, 6, (c,), generator=gen, device=dev, dtype=torch.int32).float() / 10
         if bf16 == "f16":
             out[o:o + c] = v.to(torch.float16).view(torch.int16)
@@ -104,8 +107,10 @@ class Workload:
     def __init__(self, api, dev, dtype="f32", m=32, batch=4096, br=1, beta=0, fused=0, mode="stream", grid=None, nsets=0, seed=555, hint=None, tag=""):
         self.api, self.dev, self.dtype, self.m, self.br, self.beta, self.fused, self.mode, self.tag = api, dev, dtype, m, br, beta, fused, mode, tag
         self.bf16 = "f16" if dtype == "f16" else dtype == "bf16"       # truthy: 16-bit operands in VNNI-2 layout
-        es = 2 if self.bf16 else 4
+        self.f64 = dtype == "f64"
+        es = 2 if self.bf16 else (8 if self.f64 else 4)
         self.es = es
+        kind = "f64" if self.f64 else self.bf16                        # what gen_values makes
         blk = m * m * es
         self.blk = blk
         if mode == "blocked":
@@ -125,15 +130,16 @@ class Workload:
         # "operands read once from HBM" (2) and says so; everything else leaves the decision to the library (0)
         self.hint = hint if hint is not None else (2 if (mode == "stream" and nsets > 1 and nsets * set_bytes > 2 * L3_BYTES) else 0)
         gen = torch.Generator(device=dev).manual_seed(seed)
-        tdt = torch.int16 if self.bf16 else torch.float32
-        self.A = [gen_values(na * m * m, self.bf16, dev, gen) for _ in range(nsets)]
-        self.B = [gen_values(nb * m * m, self.bf16, dev, gen) for _ in range(nsets)]
+        tdt = torch.int16 if self.bf16 else (torch.float64 if self.f64 else torch.float32)
+        self.A = [gen_values(na * m * m, kind, dev, gen) for _ in range(nsets)]
+        self.B = [gen_values(nb * m * m, kind, dev, gen) for _ in range(nsets)]
         self.C = [torch.zeros(batch * m * m, dtype=tdt, device=dev) for _ in range(nsets)]
         self.D = gen_values(m, self.bf16, dev, gen) if fused else None
-        t = DT.F16 if dtype == "f16" else (DT.BF16 if self.bf16 else DT.F32)
+        t = DT.F16 if dtype == "f16" else (DT.BF16 if self.bf16 else (DT.F64 if self.f64 else DT.F32))
         self.t = t
+        self.comp = DT.F64 if self.f64 else DT.F32
         self.flags = (0 if beta else GEMM_FLAG.BETA_0) | (GEMM_FLAG.VNNI_A if self.bf16 else 0)
-        self.shape = capi.gemm_shape(m, m, m, m, m, m, t, t, t, DT.F32)
+        self.shape = capi.gemm_shape(m, m, m, m, m, m, t, t, t, self.comp)
         self.cfg = capi.br_config(capi.BR_STRIDE, blk, blk, 0)
         if fused:
             self.handle = api.dispatch_brgemm_ext(self.shape, self.flags, 0, self.cfg, capi.argops_cp(m, capi.UNARY.RELU, 0), capi.postops_colbias(m, t))
@@ -174,11 +180,11 @@ class Workload:
         from oracle import pyoracle
         orc = pyoracle.oracle()
         m, br, mm = self.m, self.br, self.m * self.m
-        npdt = np.uint16 if self.bf16 else np.float32
+        npdt = np.uint16 if self.bf16 else (np.float64 if self.f64 else np.float32)
         idx = sorted(set(int(x) for x in np.linspace(0, self.batch - 1, samples)))
         A, B, Cg = self.A[s], self.B[s], self.C[s]
         flags = self.flags | GEMM_FLAG.BATCH_REDUCE_STRIDE | (GEMM_FLAG.USE_XGEMM_EXT_ABI if self.fused else GEMM_FLAG.USE_XGEMM_ABI)
-        desc = pyoracle.GemmDesc(m, m, m, m, m, m, self.t, self.t, self.t, DT.F32, flags, self.blk, self.blk, 1 if self.fused else 0, 1 if self.fused else 0)
+        desc = pyoracle.GemmDesc(m, m, m, m, m, m, self.t, self.t, self.t, self.comp, flags, self.blk, self.blk, 1 if self.fused else 0, 1 if self.fused else 0)
         d_host = self.D.cpu().numpy().view(npdt) if self.fused else None
         worst = 0.0
         for e in idx:
@@ -201,7 +207,7 @@ class Workload:
                 r = ref.astype(np.float64); g = got.astype(np.float64)
             den = float(np.sum(r * r)); num = float(np.sum((r - g) ** 2))
             worst = max(worst, math.sqrt(num / den) if den > 0 else math.sqrt(num))
-        tol = 5e-3 if self.bf16 else 1.2e-5          # the reference driver's own bounds [samples/xgemm/gemm_kernel.c:5312-5414]
+        tol = 5e-3 if self.bf16 else (1e-12 if self.f64 else 1.2e-5)          # f64: this repo's own bound (tests/helpers.py); the rest: the reference driver's own bounds [samples/xgemm/gemm_kernel.c:5312-5414]
         return worst < tol, worst, len(idx)
 
 

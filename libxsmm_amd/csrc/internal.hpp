@@ -235,6 +235,8 @@ void set_error(int code, const char* fmt, ...);
 // ---- launch entry points implemented in the .hip translation units ------------------------------
 // Each returns a HIP error code (0 == success) and the name of the kernel it picked.
 int launch_gemm(const GemmArgs& args, void* stream, const char** kernel_name);
+int launch_gemm_f64(const GemmArgs& args, void* stream, const char** kernel_name);     // gemm_f64_kernels.hip: v_mfma_f64_16x16x4_f64
+const char* gemm_f64_kernel_name(const libxsmm_gemm_descriptor& d);
 const char* gemm_kernel_name(const libxsmm_gemm_descriptor& d, bool batched);
 bool gemm_supported(const libxsmm_gemm_descriptor& d);
 int launch_meltw(const MeltwArgs& args, void* stream, const char** kernel_name);

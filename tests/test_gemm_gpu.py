@@ -192,9 +192,11 @@ def test_f16_takes_the_bf16_fast_paths(kw, kernel):
     assert err < (1e-3 if case.c_type == DT.F16 else TOL_F32), f"{name}: normf_rel={err}"
 
 
-def test_f64_gemm_is_bit_identical():
-    for kw in (dict(m=9, n=11, k=13, beta=1, br_type=capi.BR_STRIDE, br_count=2), dict(m=32, n=32, k=32), dict(m=7, n=5, k=3, flags=F.TRANS_A | F.TRANS_B)):
-        _check(GemmCase(seed=5, batch=2, a_type=DT.F64, **kw), expect_kernel="generic")
+def test_f64_gemm_runs_on_the_f64_matrix_cores():
+    """Round 4: no f64 descriptor is left on the VALU backstop (tests/test_gemm_f64_gpu.py has the full matrix)."""
+    for kw, kernel in ((dict(m=9, n=11, k=13, beta=1, br_type=capi.BR_STRIDE, br_count=2), "gemm_f64_ragged_kernel"), (dict(m=32, n=32, k=32), "gemm_f64_stream_kernel"),
+                       (dict(m=7, n=5, k=3, flags=F.TRANS_A | F.TRANS_B), "gemm_f64_ragged_kernel")):
+        _check(GemmCase(seed=5, batch=2, a_type=DT.F64, **kw), expect_kernel=kernel)
 
 
 FUSED = [

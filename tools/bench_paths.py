@@ -36,6 +36,8 @@ def brgemm(api, m, dtype, batch, fused=0, br=1, beta=0):
     w = Work(api, f"stride-BRGEMM {dtype} m=n=k={m} batch={batch} br={br} beta={beta}" + (" + colbias+ReLU (ext)" if fused else ""),
              bw.flops_per_step, bw.alg_bytes_per_step, bw.nsets, bw.step, lambda: api.hip_kernel_name(bw.handle, 1).decode())
     w.keep = bw
+    if beta == 0:
+        w.verify = lambda: bool(bw.verify()[0])          # the oracle on a strided sample of the batch
     w.hint = bw.hint          # rotating sets larger than the Infinity Cache: operands read once from HBM, declared like bench.py does
     return w
 
