@@ -271,6 +271,176 @@ __global__ __launch_bounds__(256) void gemm_f64_ragged_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 16 x 16 x 16 problems, one per wave
+// ------------------------------------------------------------------------------------------------
+// A 16^3 problem is 2 KiB per operand and four MFMAs.  B (k contiguous) comes by LDS-DMA -- two 16-byte requests per lane into a wave-private
+// 2 KiB image [16 columns][8 slots], slot XOR-swizzled by the column on the source side -- and is read back as two ds_read_b128 (the k pairs
+// 8u + 2s, + 1 of column g); A (rows contiguous) is read straight into the k order the B fragments dictate: step (u, h) is k = 8u + 2s + h,
+// 16 lanes = one 128-byte column.  C leaves as 8-byte stores, 128-byte runs (a 16-row column is all there is).  NN, strided operands.
+template <int AUX>
+__global__ __launch_bounds__(256) void gemm_f64_p16_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) f64x2 lds_all[4][128];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int bidx = logical_block(p) * 4u + wave;
+  if (bidx >= p.nbatch) return;
+  const unsigned int lane = threadIdx.x & 63u, g = lane & 15u, s = lane >> 4;
+  f64x2* img = lds_all[wave];
+  const BatchPtrs q = batch_ptrs(p, bidx);
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb, ldc = (unsigned int)p.ldc;
+  const unsigned int o0 = lane >> 3, sl = lane & 7u;
+  const unsigned int vB0 = (o0 * ldb + 2u * (sl ^ (o0 & 7u))) * 8u;                      // columns 0..7; columns 8..15: + 8 ldb (same swizzle: (o + 8) & 7 == o & 7)
+  const unsigned int vA = (2u * s * lda + g) * 8u;
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  const unsigned int kchunks = (unsigned int)p.k >> 4;
+  const unsigned long long total = p.br_count * kchunks;
+  f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+  GM double* c = (GM double*)q.c + ((unsigned long long)s * ldc + g);
+  if (!beta0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = c[(unsigned long long)(4u * r) * ldc];
+  }
+  unsigned long long r = 0; unsigned int kc = 0;
+  for (unsigned long long t = 0; t < total; ++t) {
+    gcptr ar, br;
+    br_base(p, q, r, ar, br);
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar), rb = wave_rsrc(br);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)((char*)img), 16, (int)vB0, (int)(kc * 128u), 0, AUX);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)((char*)img + 1024), 16, (int)vB0, (int)(kc * 128u + 64u * ldb), 0, AUX);
+    double av[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)             // e = 2u + h: k = 8u + 2s + h
+      av[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ra, (int)vA, (int)((kc * 16u + 8u * (e >> 1) + (e & 1)) * 8u * lda), AUX));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f64x2 fb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) fb[u] = img[g * 8u + ((4u * u + s) ^ (g & 7u))];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) acc = mfma_f64(fb[u][h], av[2 * u + h], acc);
+    if (++kc == kchunks) { kc = 0; ++r; }
+  }
+#pragma unroll
+  for (int r2 = 0; r2 < 4; ++r2) st_stream(c + (unsigned long long)(4u * r2) * ldc, acc[r2]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// blocked kernel: 2-D batches of 32^3 / 64^3 tiles (libxsmm_hip_gemm_batch_strided_2d: C(i, j) = sum_r A(i, r) B(r, j)) -- the operand-reuse regime
+// ------------------------------------------------------------------------------------------------
+// The structure of gemm_f32_blocked_kernel on the f64 instruction: a WORKGROUP owns a 128 x 128 macro tile of C (4 x 4 problems of 32^3 or
+// 2 x 2 of 64^3), wave (wi, wj) its 64 x 64 quarter = 4 x 4 MFMA tiles (128 accumulator registers).  K advances in stages of 16: per stage
+// the workgroup brings 4 A blocks (32 rows x 16 k) and 4 B blocks (16 k x 32 columns), 32 KiB, in ONCE by LDS-DMA -- wave w fetches A block w
+// and B block w -- into one half of a 64 KiB double buffer; every wave then reads the fragments of its two A and two B blocks (16
+// ds_read_b128, all conflict free), issues its share of the NEXT stage's requests and runs 64 MFMAs (4096 matrix-pipe cycles).  One barrier
+// per stage.  Two workgroups fit a CU (LDS and registers), so one computes while the other waits at its barrier.
+//   A image [16 k][32 rows]: linear (a request is four k rows); fragment (u, h) = the 16-byte row pair (2g, 2g + 1) of k = 8u + 2s + h
+//   B image [32 columns][8 slots]: slot XOR-swizzled by the column (source side); fragment u = k pair 4u + s of column 16t + g
+// NN, strided 2-D batch, STRIDE or no batch-reduce, K % 16 == 0, 16-byte aligned operands and C.
+template <int MB>
+__global__ __launch_bounds__(256, 2) void gemm_f64_blocked_kernel(GemmArgs p) {
+  constexpr int PPW = 4 / MB;                       // problems per macro-tile edge
+  __shared__ __attribute__((aligned(16))) f64x2 lds_all[2][8][256];
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, g = lane & 15u, s = lane >> 4;
+  // macro tile of this workgroup: contiguous bands of macro columns per XCD (hardware workgroup x runs on XCD x % 8)
+  const unsigned int ni = p.batch_inner, MI = ni / PPW;
+  unsigned int wg = blockIdx.x;
+  if ((gridDim.x & 7u) == 0u) wg = (wg & 7u) * (gridDim.x >> 3) + (wg >> 3);
+  const unsigned int mj = wg / MI, mi = wg - mj * MI;
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb, ldc = (unsigned int)p.ldc;
+  // --- request duty of this wave: A block w and B block w of the macro tile, every stage
+  const unsigned int pa = mi * PPW + w / MB, pb = mj * PPW + w / MB;
+  const __amdgpu_buffer_rsrc_t ra = wave_rsrc((gcptr)p.a + (long long)pa * p.bs_a + 256ull * (w % MB));
+  const __amdgpu_buffer_rsrc_t rb = wave_rsrc((gcptr)p.b + (long long)pb * p.bs_b + 256ull * ldb * (w % MB));
+  const unsigned int vA = (s * lda + 2u * g) * 8u;                                       // request x: k = 4x + s, row pair g
+  const unsigned int ob = lane >> 3, sl = lane & 7u;
+  const unsigned int vB = (ob * ldb + 2u * (sl ^ (ob & 7u))) * 8u;                       // request x: column 8x + ob, slot sl <- k pair sl ^ (column & 7)
+  const long long brs_a = p.br_mode == 3 ? p.br_stride_a : 0, brs_b = p.br_mode == 3 ? p.br_stride_b : 0;
+  const unsigned int kstages = (unsigned int)p.k >> 4;
+  const unsigned long long total = p.br_count * kstages;
+  auto issue = [&](unsigned long long r, unsigned int kc, int buf) {
+    const unsigned int sa = (unsigned int)((long long)r * brs_a) + kc * 128u * lda, sb = (unsigned int)((long long)r * brs_b) + kc * 128u;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)((char*)&lds_all[buf][w][0] + 1024 * x), 16, (int)vA, (int)(sa + 32u * x * lda), 0, 0);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)((char*)&lds_all[buf][4 + w][0] + 1024 * x), 16, (int)vB, (int)(sb + 64u * x * ldb), 0, 0);
+  };
+  // --- compute duty: the 64 x 64 quarter (wi, wj): rows 32 (2 wi + ib) + 2g + par, columns 32 (2 wj + jb) + 16 t + s + 4 r
+  const unsigned int wi = w & 1u, wj = w >> 1;
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  f64x4 acc[2][2][2][2];                           // [ib][par][jb][t]
+  gptr cblk[2][2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const unsigned int bi = mi * PPW + (2 * wi + ib) / MB, bj = mj * PPW + (2 * wj + jb) / MB;
+      cblk[ib][jb] = (gptr)p.c + (long long)bi * p.bs_c + (long long)bj * p.bs_c2 + 8ull * (32ull * ((2 * wi + ib) % MB) + 32ull * ((2 * wj + jb) % MB) * ldc + 2u * g + (unsigned long long)s * ldc);
+    }
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[ib][0][jb][t] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[ib][1][jb][t] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (!beta0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f64x2 v = *(GM const f64x2*)(cblk[ib][jb] + 8ull * (16u * t + 4u * r) * ldc);
+            acc[ib][0][jb][t][r] = v.x; acc[ib][1][jb][t][r] = v.y;
+          }
+        }
+      }
+  unsigned long long r = 0; unsigned int kc = 0;
+  if (total != 0) issue(0, 0, 0);
+  for (unsigned long long t = 0; t < total; ++t) {
+    const int buf = (int)(t & 1ull);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is ordered by the issuing wave's vmcnt only
+    __syncthreads();                                   // ... and by a barrier for the other waves: stage t's eight blocks are in LDS
+    f64x2 fa[2][4], fb[2][2][2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fa[ib][e] = lds_all[buf][2 * wi + ib][(8u * (e >> 1) + 2u * s + (e & 1)) * 16u + g];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) fb[jb][tt][u] = lds_all[buf][4 + 2 * wj + jb][(16u * tt + g) * 8u + ((4u * u + s) ^ (g & 7u))];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (++kc == kstages) { kc = 0; ++r; }
+    if (t + 1 < total) issue(r, kc, buf ^ 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+          for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+                acc[ib][par][jb][tt] = mfma_f64(fb[jb][tt][u][h], fa[ib][2 * u + h][par], acc[ib][par][jb][tt]);
+  }
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2)
+          *(GM f64x2*)(cblk[ib][jb] + 8ull * (16u * tt + 4u * r2) * ldc) = f64x2{acc[ib][0][jb][tt][r2], acc[ib][1][jb][tt][r2]};
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static bool f64_stream_ok(const GemmArgs& a) {
@@ -281,6 +451,35 @@ static bool f64_stream_ok(const GemmArgs& a) {
   if (a.br_mode == 3) bits |= (unsigned long long)a.br_stride_a | (unsigned long long)a.br_stride_b;
   if (bits & 15ull) return false;
   return a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22);            // 32-bit byte offsets inside a chunk
+}
+
+static bool f64_strided_aligned(const GemmArgs& a) {
+  if (a.list_a || a.br_mode == 1 || a.br_mode == 2) return false;
+  unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
+    (unsigned long long)((long long)a.lda * 8) | (unsigned long long)((long long)a.ldb * 8);
+  if (a.br_mode == 3) bits |= (unsigned long long)a.br_stride_a | (unsigned long long)a.br_stride_b;
+  return (bits & 15ull) == 0ull && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22);
+}
+// 16^3 problems: NN, one problem per wave (8-byte accesses of A and C: alignment of B only)
+static bool f64_p16_ok(const GemmArgs& a) {
+  if (a.m != 16 || a.n != 16 || (a.k % 16) || a.k <= 0 || (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B))) return false;
+  if (a.list_a || a.br_mode == 1 || a.br_mode == 2) return false;
+  unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)((long long)a.ldb * 8);
+  if (a.br_mode == 3) bits |= (unsigned long long)a.br_stride_b;
+  return (bits & 15ull) == 0ull && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22);
+}
+// 2-D batches of 32^3 / 64^3 tiles: the blocked kernel (whole macro tiles of 128 x 128, 32-bit request offsets)
+static bool f64_blocked_ok(const GemmArgs& a) {
+  if (!a.batch_inner || a.m != a.n || (a.m != 32 && a.m != 64) || (a.k % 16) || a.k <= 0) return false;
+  if (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B)) return false;
+  if (!f64_strided_aligned(a)) return false;
+  const unsigned int ppw = 128u / (unsigned int)a.m, ni = a.batch_inner, nj = a.nbatch / a.batch_inner;
+  if (ni % ppw || nj % ppw) return false;
+  if ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2 | (unsigned long long)((long long)a.ldc * 8)) & 15ull) != 0ull) return false;
+  const unsigned long long span_a = (a.br_mode == 3 ? (unsigned long long)std::max<long long>(a.br_stride_a, 0) * a.br_count : 0ull) + (unsigned long long)a.lda * a.k * 8ull;
+  const unsigned long long span_b = (a.br_mode == 3 ? (unsigned long long)std::max<long long>(a.br_stride_b, 0) * a.br_count : 0ull) + (unsigned long long)a.ldb * a.n * 8ull;
+  if (a.br_mode == 3 && (a.br_stride_a < 0 || a.br_stride_b < 0)) return false;
+  return span_a < (1ull << 31) && span_b < (1ull << 31);
 }
 
 const char* gemm_f64_kernel_name(const libxsmm_gemm_descriptor& d) {
@@ -297,14 +496,28 @@ int launch_gemm_f64(const GemmArgs& a_in, void* stream, const char** kernel_name
   const long long tiles = (long long)a.tiles_m * a.tiles_n * (long long)a.nbatch;
   if (tiles >= (1ll << 31)) return (int)hipErrorInvalidValue;
   const dim3 grid((unsigned int)((tiles + 3) / 4));
+  static const int pol_env = []() { const char* e = getenv("LIBXSMM_HIP_F64_POLICY"); return e ? atoi(e) : -1; }();
+  // cache policy as for the f32 kernels (DESIGN decision 8): non-temporal requests only when the operands cannot be cache resident -- one launch
+  // moves more than the 256 MiB Infinity Cache holds -- or the caller declared a streaming pass (libxsmm_hip_set_streaming_hint(2)); never with hint 1
+  const unsigned long long moved = (unsigned long long)a.nbatch * ((unsigned long long)a.br_count * (unsigned long long)a.k * (unsigned long long)(a.m + a.n) + (unsigned long long)a.m * a.n) * 8ull;
+  bool nt = a.stream_hint == 2 || (a.stream_hint == 0 && moved > (256ull << 20));
+  if (pol_env == 0) nt = false; else if (pol_env == 1) nt = true;
+  static const bool blocked_off = []() { const char* e = getenv("LIBXSMM_HIP_F64_BLOCKED"); return e && e[0] == '0'; }();
+  if (!blocked_off && f64_blocked_ok(a)) {
+    const unsigned int ppw = 128u / (unsigned int)a.m;
+    const dim3 bgrid((a.batch_inner / ppw) * ((a.nbatch / a.batch_inner) / ppw));
+    if (a.m == 32) { if (kernel_name) *kernel_name = "gemm_f64_blocked_kernel<1>"; hipLaunchKernelGGL((gemm_f64_blocked_kernel<1>), bgrid, dim3(256), 0, st, a); }
+    else { if (kernel_name) *kernel_name = "gemm_f64_blocked_kernel<2>"; hipLaunchKernelGGL((gemm_f64_blocked_kernel<2>), bgrid, dim3(256), 0, st, a); }
+    return (int)hipGetLastError();
+  }
+  if (f64_p16_ok(a)) {
+    if (kernel_name) *kernel_name = "gemm_f64_p16_kernel";
+    const dim3 pgrid((a.nbatch + 3u) / 4u);
+    if (nt) hipLaunchKernelGGL((gemm_f64_p16_kernel<2>), pgrid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_f64_p16_kernel<0>), pgrid, dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+  }
   if (f64_stream_ok(a)) {
     if (kernel_name) *kernel_name = "gemm_f64_stream_kernel";
-    // cache policy as for the f32 kernels (DESIGN decision 8): non-temporal requests only when the operands cannot be cache resident -- one launch
-    // moves more than the 256 MiB Infinity Cache holds -- or the caller declared a streaming pass (libxsmm_hip_set_streaming_hint(2)); never with hint 1
-    const unsigned long long moved = (unsigned long long)a.nbatch * ((unsigned long long)a.br_count * (unsigned long long)a.k * (unsigned long long)(a.m + a.n) + (unsigned long long)a.m * a.n) * 8ull;
-    static const int pol_env = []() { const char* e = getenv("LIBXSMM_HIP_F64_POLICY"); return e ? atoi(e) : -1; }();
-    bool nt = a.stream_hint == 2 || (a.stream_hint == 0 && moved > (256ull << 20));
-    if (pol_env == 0) nt = false; else if (pol_env == 1) nt = true;
 #define LAUNCH_F64S_(TA_, TB_) do { if (nt) hipLaunchKernelGGL((gemm_f64_stream_kernel<TA_, TB_, 2>), grid, dim3(256), 0, st, a); \
                                     else hipLaunchKernelGGL((gemm_f64_stream_kernel<TA_, TB_, 0>), grid, dim3(256), 0, st, a); } while (0)
     if (!ta && !tb) LAUNCH_F64S_(false, false); else if (ta && !tb) LAUNCH_F64S_(true, false); else if (!ta && tb) LAUNCH_F64S_(false, true); else LAUNCH_F64S_(true, true);

@@ -113,24 +113,39 @@ def test_f64_full_size_32cubed_batch_4096():
     _run(case, expect="gemm_f64_stream_kernel")
 
 
-def test_f64_2d_batch_is_the_callers_two_loops():
-    """libxsmm_hip_gemm_batch_strided_2d on f64 tiles: C(i, j) = sum_r A(i, r) B(r, j), a blocked GEMM out of 32^3 BRGEMM tiles, against numpy."""
+@pytest.mark.parametrize("T,K,NI,NJ,NR,beta,kernel", [
+    (32, 32, 4, 8, 3, 0, "gemm_f64_blocked_kernel<1>"),
+    (32, 48, 8, 4, 2, 1, "gemm_f64_blocked_kernel<1>"),          # K = 48: three stages of 16 per block
+    (64, 64, 2, 4, 2, 0, "gemm_f64_blocked_kernel<2>"),
+    (64, 16, 4, 2, 1, 1, "gemm_f64_blocked_kernel<2>"),
+    (32, 32, 3, 5, 2, 0, "gemm_f64_stream_kernel"),              # not whole 128 x 128 macro tiles: one tile per wave
+    (16, 16, 8, 8, 4, 1, "gemm_f64_p16_kernel"),
+])
+def test_f64_2d_batch_is_the_callers_two_loops(T, K, NI, NJ, NR, beta, kernel):
+    """libxsmm_hip_gemm_batch_strided_2d on f64 tiles: C(i, j) (+)= sum_r A(i, r) B(r, j), a blocked GEMM out of BRGEMM tiles, against numpy."""
     import torch
     api = capi.load()
-    T, NI, NJ, NR = 32, 4, 8, 3
     rng = np.random.default_rng(11)
-    # block (i, r) of A at ((i * NR + r) * T * T), column-major T x T blocks; B likewise with (j, r)
-    A = rng.standard_normal((NI, NR, T, T)); B = rng.standard_normal((NJ, NR, T, T))       # [.., k, m] and [.., n, k] in memory order
-    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
-    dC = torch.zeros((NJ, NI, T, T), dtype=torch.float64, device="cuda")
-    blk = T * T * 8
-    h = api.dispatch_brgemm(capi.gemm_shape(T, T, T, T, T, T, DT.F64, DT.F64, DT.F64, DT.F64), F.BETA_0, 0, capi.br_config(capi.BR_STRIDE, blk, blk, 0))
+    # block (i, r) of A: column-major T x K ([k][m] in memory order); block (j, r) of B: K x T ([n][k])
+    A = rng.standard_normal((NI, NR, K, T)); B = rng.standard_normal((NJ, NR, T, K)); C0 = rng.standard_normal((NJ, NI, T, T))
+    dA, dB, dC = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), torch.from_numpy(C0.copy()).cuda()
+    blk_a, blk_b, blk_c = T * K * 8, K * T * 8, T * T * 8
+    h = api.dispatch_brgemm(capi.gemm_shape(T, T, K, T, K, T, DT.F64, DT.F64, DT.F64, DT.F64), 0 if beta else F.BETA_0, 0, capi.br_config(capi.BR_STRIDE, blk_a, blk_b, 0))
     cnt = C.c_ulonglong(NR)
     p = capi.GemmParam()
     p.a.primary, p.b.primary, p.c.primary = dA.data_ptr(), dB.data_ptr(), dC.data_ptr()
     p.op.tertiary = C.addressof(cnt)
-    api.hip_gemm_batch_strided_2d(h, C.byref(p), NI, NJ, NR * blk, NR * blk, blk, NI * blk)
+    api.hip_gemm_batch_strided_2d(h, C.byref(p), NI, NJ, NR * blk_a, NR * blk_b, blk_c, NI * blk_c)
     api.hip_sync(); api.check()
-    ref = np.einsum("irkm,jrnk->jinm", A, B)
+    assert api.hip_kernel_name(h, 1).decode() == kernel
+    ref = np.einsum("irkm,jrnk->jinm", A, B) + (C0 if beta else 0.0)
     got = dC.cpu().numpy()
     assert np.sqrt(((ref - got) ** 2).sum() / (ref ** 2).sum()) < 1e-13
+
+
+P16 = [dict(m=16, n=16, k=16), dict(m=16, n=16, k=16, beta=1), dict(m=16, n=16, k=48, br_type=capi.BR_STRIDE, br_count=3), dict(m=16, n=16, k=16, lda=18, ldb=18, ldc=17, beta=1)]
+
+
+@pytest.mark.parametrize("kw", P16, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_f64_16cubed_problems_one_per_wave(kw):
+    _run(GemmCase(seed=77, batch=37, a_type=DT.F64, **kw), expect="gemm_f64_p16_kernel")

@@ -42,6 +42,17 @@ def brgemm(api, m, dtype, batch, fused=0, br=1, beta=0):
     return w
 
 
+def blocked(api, dtype, m, ni, nj, br):
+    """A blocked GEMM out of BRGEMM tiles (libxsmm_hip_gemm_batch_strided_2d): C(i, j) = sum_r A(i, r) B(r, j), (ni m) x (nj m) x (br m) -- the operand-reuse regime."""
+    bw = bench.Workload(api, DEV, dtype, m, 0, br=br, mode="blocked", grid=(ni, nj))
+    w = Work(api, f"blocked GEMM {dtype} {ni * m} x {nj * m} x {br * m} out of {m}^3 tiles", bw.flops_per_step, bw.alg_bytes_per_step, bw.nsets, bw.step,
+             lambda: api.hip_kernel_name(bw.handle, 1).decode())
+    w.keep = bw
+    w.verify = lambda: bool(bw.verify()[0])
+    w.pct_peak = lambda us: 100.0 * bw.flops_per_step / us / 1e6 / bench.MFMA_PEAK_TF[dtype]
+    return w
+
+
 def brgemm_i8(api, m, batch, ua=True):
     """u8 x i8 -> i32 (VNNI-4 A), m = n = k: algorithmic bytes = 2*m*m (A, B) + 4*m*m (C) per problem."""
     at = DT.U8 if ua else DT.I8

@@ -19,5 +19,6 @@ for expr in os.environ["WL"].split(";;"):
         torch.cuda.synchronize(); us = 1.0
     else:
         _, _, us = bench.timed(w, 20, 0.2)
-    print(json.dumps({"tag": os.environ.get("TAG", ""), "workload": w.name, "kernel": w.kernel(), "us": round(us, 2), "frac_hbm": round(w.alg_bytes / us / 1e3 / 8000, 4), "verified": ok}), flush=True)
+    print(json.dumps({"tag": os.environ.get("TAG", ""), "workload": w.name, "kernel": w.kernel(), "us": round(us, 2), "frac_hbm": round(w.alg_bytes / us / 1e3 / 8000, 4), "TFLOP/s": round(w.flops / us / 1e6, 2),
+                      "pct_mfma_peak": round(w.pct_peak(us), 1) if getattr(w, "pct_peak", None) else None, "verified": ok}), flush=True)
     del w; torch.cuda.empty_cache()
