@@ -190,6 +190,137 @@ __global__ __launch_bounds__(256) void gemm_f64_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// streaming kernel for 64 x 64 tiles: one WAVE per tile, nothing fetched twice
+// ------------------------------------------------------------------------------------------------
+// With 32 x 32 tiles a 64^3 problem is four waves that each fetch half of A and half of B: every operand byte travels L2 -> CU twice.  Here one
+// wave owns the whole 64 x 64 tile -- 4 x 4 MFMA tiles, 128 accumulator registers, the wave of the blocked kernel with private operands -- and
+// walks K in stages of 16: A (two 32-row blocks) as eight 16-byte row-pair requests into registers, re-requested for the next stage right
+// behind the MFMAs that consumed them; B (64 columns x 16 k) by LDS-DMA into a wave-private 8 KiB image [64 columns][8 slots], slot XOR-swizzled
+// by the column, read back as eight ds_read_b128; the next stage's DMA goes out as soon as the fragments are in registers.  64 MFMAs per stage.
+// NN, strided operands, 16-byte aligned; two waves per SIMD.
+template <int AUX>
+__global__ __launch_bounds__(256, 2) void gemm_f64_stream64_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) f64x2 lds_all[4][512];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int nwaves = gridDim.x * 4u;
+  const unsigned int per_gemm = (unsigned int)(p.tiles_m * p.tiles_n), ntiles = per_gemm * p.nbatch;
+  unsigned int tile = logical_block(p) * 4u + wave;
+  if (tile >= ntiles) return;
+  const unsigned int lane = threadIdx.x & 63u, g = lane & 15u, s = lane >> 4;
+  f64x2* img = lds_all[wave];
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb, ldc = (unsigned int)p.ldc;
+  const unsigned int vA = (2u * s * lda + 2u * g) * 8u;                                  // request (ib, e = 2u + h): k = 8u + 2s + h, rows 32 ib + 2g, + 1
+  const unsigned int ob = lane >> 3, sl = lane & 7u;
+  const unsigned int vB = (ob * ldb + 2u * (sl ^ (ob & 7u))) * 8u;                       // request x: column 8x + ob, slot sl <- k pair sl ^ (column & 7)
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  const unsigned int kstages = (unsigned int)p.k >> 4;
+  if (p.br_count * kstages == 0) return;                                                 // (the host does not launch empty chains)
+  // A wave walks the tiles tile, tile + nwaves, ... as ONE sequence of stages: the first stage of the next tile is requested under the last
+  // stage's MFMAs of the current one, so only the very first request of a wave is exposed (0.69 / 0.71 -> 0.71 / 0.72 at batch 4096 / 32768).
+  // Requests TWO stages ahead (a second B image, a second set of A registers, in-order vmcnt counts) measured no better: 0.72 / 0.69.
+  BatchPtrs q; unsigned int i0, j0;
+  auto locate = [&](unsigned int t) {
+    unsigned int bidx = t; i0 = 0; j0 = 0;
+    if (per_gemm != 1) {
+      bidx = t / per_gemm;
+      const unsigned int tt = t - bidx * per_gemm, tn = tt / (unsigned int)p.tiles_m;
+      i0 = (tt - tn * (unsigned int)p.tiles_m) * 64u; j0 = tn * 64u;
+    }
+    q = batch_ptrs(p, bidx);
+  };
+  locate(tile);
+  gcptr ar, br;
+  br_base(p, q, 0, ar, br);
+  __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar + 8ull * i0), rb = wave_rsrc(br + 8ull * j0 * ldb);
+  f64x2 da[2][4];
+  auto request_a = [&](int ib, int e, unsigned int kc) {
+    da[ib][e] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)vA, (int)((kc * 16u + 8u * (e >> 1) + (e & 1)) * 8u * lda + 256u * ib), AUX));
+  };
+  auto request_b = [&](unsigned int kc) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)((char*)img + 1024 * x), 16, (int)vB, (int)(kc * 128u + 64u * x * ldb), 0, AUX);
+  };
+  request_b(0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { request_a(0, e, 0); request_a(1, e, 0); }
+  f64x4 acc[2][2][4];                          // [ib][par][jt]: rows 32 ib + 2g + par, columns 16 jt + s + 4r
+  gptr ctile = q.c + 8ull * ((unsigned long long)j0 * ldc + i0 + 2u * g + (unsigned long long)s * ldc);
+  bool c16 = ((((unsigned long long)(size_t)q.c) | (8ull * ldc)) & 15ull) == 0ull;       // wave-uniform (i0, 2g are even)
+  auto init_acc = [&]() {
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        acc[ib][0][jt] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[ib][1][jt] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (!beta0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            gptr at = ctile + 8ull * (32ull * ib + (16ull * jt + 4ull * r) * ldc);
+            if (c16) { const f64x2 v = *(GM const f64x2*)at; acc[ib][0][jt][r] = v.x; acc[ib][1][jt][r] = v.y; }
+            else { acc[ib][0][jt][r] = *(GM const double*)at; acc[ib][1][jt][r] = *(GM const double*)(at + 8); }
+          }
+        }
+      }
+  };
+  init_acc();
+  unsigned long long r = 0; unsigned int kc = 0;
+  for (;;) {
+    f64x2 fb[4][2];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) fb[jt][u] = img[(16u * jt + g) * 8u + ((4u * u + s) ^ (g & 7u))];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the stage after this one: next k stage, next batch-reduce element, or the first stage of the wave's next tile
+    bool last_of_tile = false, more = true;
+    gptr ctile_now = ctile; const bool c16_now = c16;
+    if (++kc == kstages) {
+      kc = 0;
+      if (++r == p.br_count) {
+        r = 0; last_of_tile = true;
+        tile += nwaves;
+        more = tile < ntiles;
+        if (more) {
+          locate(tile);
+          ctile = q.c + 8ull * ((unsigned long long)j0 * ldc + i0 + 2u * g + (unsigned long long)s * ldc);
+          c16 = ((((unsigned long long)(size_t)q.c) | (8ull * ldc)) & 15ull) == 0ull;
+        }
+      }
+      if (more) { br_base(p, q, r, ar, br); ra = wave_rsrc(ar + 8ull * i0); rb = wave_rsrc(br + 8ull * j0 * ldb); }
+    }
+    if (more) request_b(kc);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+          for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+              acc[ib][par][jt] = mfma_f64(fb[jt][u][h], da[ib][2 * u + h][par], acc[ib][par][jt]);
+        if (more) { request_a(0, 2 * u + h, kc); request_a(1, 2 * u + h, kc); }
+      }
+    if (last_of_tile) {
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+          for (int r2 = 0; r2 < 4; ++r2) {
+            gptr at = ctile_now + 8ull * (32ull * ib + (16ull * jt + 4ull * r2) * ldc);
+            if (c16_now) st_stream((GM f64x2*)at, f64x2{acc[ib][0][jt][r2], acc[ib][1][jt][r2]});
+            else { st_stream((GM double*)at, acc[ib][0][jt][r2]); st_stream((GM double*)(at + 8), acc[ib][1][jt][r2]); }
+          }
+      if (!more) break;
+      init_acc();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // general kernel: any shape, any leading dimensions, any batch / batch-reduce form
 // ------------------------------------------------------------------------------------------------
 // One wave per 32 x 32 tile of C (2 x 2 MFMA tiles; tiles that lie outside the matrix are skipped wave-uniformly).  Natural labels: the
@@ -516,6 +647,21 @@ int launch_gemm_f64(const GemmArgs& a_in, void* stream, const char** kernel_name
     if (nt) hipLaunchKernelGGL((gemm_f64_p16_kernel<2>), pgrid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_f64_p16_kernel<0>), pgrid, dim3(256), 0, st, a);
     return (int)hipGetLastError();
   }
+  static const bool s64_off = []() { const char* e = getenv("LIBXSMM_HIP_F64_STREAM64"); return e && e[0] == '0'; }();
+  if (!s64_off && !ta && !tb && (a.m % 64) == 0 && (a.n % 64) == 0 && f64_stream_ok(a)) {       // 64 x 64 tiles: one wave per tile, no operand byte fetched twice
+    a.tiles_m = a.m / 64; a.tiles_n = a.n / 64;
+    const long long t64 = (long long)a.tiles_m * a.tiles_n * (long long)a.nbatch;
+    if (kernel_name) *kernel_name = "gemm_f64_stream64_kernel";
+    // waves walk several tiles once the launch exceeds what is resident at two waves per SIMD (256 CUs x 8): LIBXSMM_HIP_F64_S64_WAVES overrides the cap
+    static const long long cap = []() { const char* e = getenv("LIBXSMM_HIP_F64_S64_WAVES"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 2048ll; }();
+    const long long per_wave = (t64 + cap - 1) / cap, waves = (t64 + per_wave - 1) / per_wave;
+    if (a.br_count == 0) { if (kernel_name) *kernel_name = "gemm_f64_stream_kernel"; goto f64_small_tiles; }      // beta-only call: the 32 x 32 kernel has that path
+    if (nt) hipLaunchKernelGGL((gemm_f64_stream64_kernel<2>), dim3((unsigned int)((waves + 3) / 4)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f64_stream64_kernel<0>), dim3((unsigned int)((waves + 3) / 4)), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+  }
+  f64_small_tiles:
+  a.tiles_m = (a.m + 31) / 32; a.tiles_n = (a.n + 31) / 32;
   if (f64_stream_ok(a)) {
     if (kernel_name) *kernel_name = "gemm_f64_stream_kernel";
 #define LAUNCH_F64S_(TA_, TB_) do { if (nt) hipLaunchKernelGGL((gemm_f64_stream_kernel<TA_, TB_, 2>), grid, dim3(256), 0, st, a); \

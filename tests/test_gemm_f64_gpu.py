@@ -34,27 +34,32 @@ def _run(case, batched=True, expect=None):
     return name
 
 
+S32, S64 = "gemm_f64_stream_kernel", "gemm_f64_stream64_kernel"
 WHOLE = [
-    dict(m=32, n=32, k=32),
-    dict(m=32, n=32, k=32, beta=1),
-    dict(m=32, n=32, k=64, br_type=capi.BR_STRIDE, br_count=5),
-    dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=3, beta=1),
-    dict(m=64, n=64, k=64),
-    dict(m=64, n=32, k=96, beta=1),
-    dict(m=96, n=64, k=32, lda=98, ldb=34, ldc=100),
-    dict(m=32, n=32, k=32, ldc=33),                       # odd ldc: element-wise C
-    dict(m=32, n=32, k=32, flags=F.TRANS_A),
-    dict(m=64, n=32, k=64, flags=F.TRANS_A, beta=1, br_type=capi.BR_STRIDE, br_count=2),
-    dict(m=32, n=32, k=32, flags=F.TRANS_B),
-    dict(m=32, n=64, k=64, flags=F.TRANS_B, beta=1, br_type=capi.BR_STRIDE, br_count=2),
-    dict(m=32, n=32, k=32, flags=F.TRANS_A | F.TRANS_B),
-    dict(m=64, n=64, k=32, flags=F.TRANS_A | F.TRANS_B, beta=1, lda=34, ldb=66),
+    (dict(m=32, n=32, k=32), S32),
+    (dict(m=32, n=32, k=32, beta=1), S32),
+    (dict(m=32, n=32, k=64, br_type=capi.BR_STRIDE, br_count=5), S32),
+    (dict(m=32, n=32, k=32, br_type=capi.BR_STRIDE, br_count=3, beta=1), S32),
+    (dict(m=64, n=64, k=64), S64),                           # one wave per 64 x 64 tile
+    (dict(m=64, n=64, k=32, beta=1, br_type=capi.BR_STRIDE, br_count=3), S64),
+    (dict(m=128, n=64, k=96, lda=130, ldb=98, ldc=132, beta=1), S64),
+    (dict(m=64, n=64, k=64, ldc=65), S64),                   # odd ldc: element-wise C
+    (dict(m=64, n=32, k=96, beta=1), S32),
+    (dict(m=96, n=64, k=32, lda=98, ldb=34, ldc=100), S32),
+    (dict(m=32, n=32, k=32, ldc=33), S32),
+    (dict(m=32, n=32, k=32, flags=F.TRANS_A), S32),
+    (dict(m=64, n=32, k=64, flags=F.TRANS_A, beta=1, br_type=capi.BR_STRIDE, br_count=2), S32),
+    (dict(m=32, n=32, k=32, flags=F.TRANS_B), S32),
+    (dict(m=32, n=64, k=64, flags=F.TRANS_B, beta=1, br_type=capi.BR_STRIDE, br_count=2), S32),
+    (dict(m=32, n=32, k=32, flags=F.TRANS_A | F.TRANS_B), S32),
+    (dict(m=64, n=64, k=32, flags=F.TRANS_A | F.TRANS_B, beta=1, lda=34, ldb=66), S32),
 ]
 
 
-@pytest.mark.parametrize("kw", WHOLE, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
-def test_f64_whole_tiles_run_on_the_streaming_mfma_kernel(kw):
-    _run(GemmCase(seed=1234, batch=7, a_type=DT.F64, **kw), expect="gemm_f64_stream_kernel")
+@pytest.mark.parametrize("kw,kernel", WHOLE, ids=lambda v: "-".join(f"{k}{x}" for k, x in v.items()) if isinstance(v, dict) else v)
+def test_f64_whole_tiles_run_on_the_streaming_mfma_kernels(kw, kernel):
+    name = _run(GemmCase(seed=1234, batch=7, a_type=DT.F64, **kw))
+    assert name == kernel, name
 
 
 def test_f64_single_synchronous_calls_equal_the_batched_launch():
