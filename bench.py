@@ -345,18 +345,18 @@ def cpu_baseline(m, dtype, br, beta, fused, seconds, nthreads):
     """Reference JIT (or C restatement) on this box's host cores: one thread, and every usable core at once; bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import pyoracle
-    bf16 = dtype == "bf16"
-    es = 2 if bf16 else 4
-    t = DT.BF16 if bf16 else DT.F32
+    bf16, f64 = dtype == "bf16", dtype == "f64"
+    es = 2 if bf16 else (8 if f64 else 4)
+    t = DT.BF16 if bf16 else (DT.F64 if f64 else DT.F32)
     batch = 1024                                        # private operands, streamed like the GPU run
     rng = np.random.default_rng(555)
-    raw = ((np.floor(rng.random(batch * br * m * m * 2) * 10) - 4) / 10).astype(np.float32)
+    raw = ((np.floor(rng.random(batch * br * m * m * 2) * 10) - 4) / 10).astype(np.float64 if f64 else np.float32)
     ab = (raw.view(np.uint32) >> 16).astype(np.uint16) if bf16 else raw
     A, B = ab[: batch * br * m * m].copy(), ab[batch * br * m * m:].copy()
-    Cc = np.zeros(batch * m * m, dtype=np.uint16 if bf16 else np.float32)
+    Cc = np.zeros(batch * m * m, dtype=np.uint16 if bf16 else (np.float64 if f64 else np.float32))
     Dd = ab[:m].copy()
     flags = (0 if beta else GEMM_FLAG.BETA_0) | (GEMM_FLAG.VNNI_A if bf16 else 0)
-    shape = capi.gemm_shape(m, m, m, m, m, m, t, t, t, DT.F32)
+    shape = capi.gemm_shape(m, m, m, m, m, m, t, t, t, DT.F64 if f64 else DT.F32)
     cfg = capi.br_config(capi.BR_STRIDE, m * m * es, m * m * es, 0)
     brc = C.c_ulonglong(br)
     ptype = capi.GemmExtParam if fused else capi.GemmParam
@@ -449,11 +449,12 @@ def committed_counters(kernel, alg_bytes, label):
     return traffic, src, busy, busy_src
 
 
-SWEEP = [(dt, m, b) for dt in ("f32", "bf16") for m in (16, 32, 64) for b in (4096, 65536)]
+SWEEP = [(dt, m, b) for dt in ("f32", "bf16", "f64") for m in (16, 32, 64) for b in (4096, 65536)]      # f64 (round 4): v_mfma_f64_16x16x4_f64
 # blocked GEMMs: (dtype, m, ni, nj, br, tag) -- f32: 2048^3 out of 16^3 tiles, 4096 x 4096 x 2048 out of 32^3 tiles, 4096^3 out of 64^3 tiles (macro tile 128 x 128:
 # 256 .. 1024 workgroups); bf16 (macro tile 256 x 256): 4096^3 out of 16^3 / 32^3 / 64^3 tiles = ONE round of 256 workgroups, and 8192^3 out of 64^3 tiles = four rounds
 BLOCKED = [("f32", 16, 128, 128, 128, ""), ("f32", 32, 128, 128, 64, ""), ("f32", 64, 64, 64, 64, ""),
-           ("bf16", 16, 256, 256, 256, ""), ("bf16", 32, 128, 128, 128, ""), ("bf16", 64, 64, 64, 64, ""), ("bf16", 64, 128, 128, 128, "_8192")]
+           ("bf16", 16, 256, 256, 256, ""), ("bf16", 32, 128, 128, 128, ""), ("bf16", 64, 64, 64, 64, ""), ("bf16", 64, 128, 128, 128, "_8192"),
+           ("f64", 32, 128, 128, 64, ""), ("f64", 64, 64, 64, 64, "")]      # f64: 4096 x 4096 x 2048 out of 32^3 tiles, 4096^3 out of 64^3 tiles (macro tile 128 x 128)
 SHARED_B = [(dt, m, 65536) for dt in ("f32", "bf16") for m in (16, 32, 64)]
 # the odd shapes LIBXSMM is known for (BASELINE configs[0] is one 23^3 f32 GEMM): same streaming regime, problems that are not whole tiles
 RAGGED = [("f32", 23, 131072), ("f32", 23, 4096), ("f32", 13, 262144), ("f32", 40, 32768), ("f32", 72, 16384)]
@@ -594,6 +595,9 @@ def compact_line(full, detail_path):
         line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:110]
         if "all_cores" in cb:
             line["cpu_baseline"]["all_cores"] = {"value": cb["all_cores"]["value"], "cores": cb["all_cores"]["cores"]}
+    cb64 = full.get("cpu_baseline_f64")
+    if cb64:
+        line["cpu_baseline_f64"] = [cb64.get("value"), cb64.get("cores"), cb64.get("kind")]       # [GFLOP/s of the reference's f64 32^3 kernel, cores, kind]
     if full.get("configs"):
         line["configs"] = {}
         ok = True
@@ -798,8 +802,9 @@ def main():
         roof = mfma_roof(api, dev)
         for r in reuse.values():           # blocked entries next to what the pipe sustains on this data, on this chip, today
             if "gemm" in r:
-                dt = "bf16" if r["kernel"].startswith("gemm_bf16") else "f32"
-                r["pct_of_power_roof"] = round(100.0 * r["GFLOP/s"] / 1e3 / roof[dt], 1)
+                dt = "bf16" if r["kernel"].startswith("gemm_bf16") else ("f64" if r["kernel"].startswith("gemm_f64") else "f32")
+                if dt in roof:
+                    r["pct_of_power_roof"] = round(100.0 * r["GFLOP/s"] / 1e3 / roof[dt], 1)
     if dist is not None:
         dist.barrier()
 
@@ -851,6 +856,8 @@ def main():
             out["ragged"] = ragged
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.m, args.dtype, args.br, args.beta, args.fused, args.cpu_seconds, nthreads)
+            if sweep:       # the reference's classic precision: its f64 JIT kernel for the sweep's f64 32^3 entries, one core (a shorter sample: it is a side figure)
+                out["cpu_baseline_f64"] = cpu_baseline(32, "f64", 1, 0, 0, min(args.cpu_seconds, 4.0), 0)
         if args.manifest:
             json.dump({"command": " ".join(sys.argv), "entries": MANIFEST}, open(args.manifest, "w"), indent=1)
     finish(dist, out if rank == 0 else None, args.detail)

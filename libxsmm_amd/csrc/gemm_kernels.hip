@@ -3998,6 +3998,10 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   if (p16_ok(a)) {
     const bool bf16 = a.a_type == LIBXSMM_DATATYPE_BF16;
     a.tiles_m = a.tiles_n = 1; a.map2d_shift = 0;
+    // round 4: A through a wave-private LDS image, one 16-byte request per lane (gemm_small_kernels.hip); needs 16-byte aligned A rows
+    { int taken = 0;
+      const int e16 = launch_gemm_p16w(a, stream_nt(a, bf16 ? 2 : 4, a.c_type == LIBXSMM_DATATYPE_F32 ? 4 : 2), stream, kernel_name, &taken);
+      if (taken) return e16; }
     // small launches are bound by their own latency: keep one problem per wave there (4x the waves), four per wave from 16384 problems on
     const bool four = a.nbatch >= 16384u;
     grid = dim3((unsigned int)((a.nbatch + (four ? 15u : 3u)) / (four ? 16u : 4u)));

@@ -1,0 +1,135 @@
+// gemm_small_kernels.hip -- 16 x 16 x 16 f32 / bf16 problems, round 4: every global access a 16-byte access of a contiguous 1 KiB run.
+//
+// Semantics as gemm_kernels.hip [ref: src/generator_gemm_reference_impl.c:1359-1426 (f32), :2127-2170 / :2367-2419 (bf16)]; NN, beta = 0,
+// plain epilogue, strided operands (launch_gemm's p16_ok).  A 16^3 problem is 3 KiB (f32) or 1.5 KiB (bf16): the round-2 kernel
+// (gemm_p16_kernel) fetched A as dwords straight into MFMA operand order -- four 64-byte runs per instruction -- and measured 0.63 of the
+// HBM roofline at 65 536 problems.  Here A (rows contiguous, the operand whose register layout does not match its memory layout) travels
+// global -> LDS by DMA, ONE 16-byte request per lane for a whole 1 KiB tile (f32: one problem, bf16: two), and is read back in operand order
+// with conflict-free ds_read_b32; B and C were 16- / 8-byte accesses of contiguous tiles already.  The image is wave-private: no barrier.
+//   f32 : v_mfma_f32_16x16x4_f32.  Lane (x = lane & 15, g = lane >> 4) supplies A(i = x, k = 4g + s) and B(k = 4g + s, j = x), s = 0..3 --
+//         the summation order of gemm_p16_kernel, bit for bit.  Image [16 k][16 i] dwords; row k sits at position k ^ ((k >> 2) & 1), so the
+//         two rows a half-wave reads together (k = s and k = 4 + s) fall into different halves of the 32 banks.
+//   bf16: v_mfma_f32_16x16x16_bf16.  A in VNNI-2: image [8 k pairs][16 i] dwords per problem, pair kp at position kp ^ ((kp >> 1) & 1); lanes
+//         0-31 of the request fetch problem 2w, lanes 32-63 problem 2w + 1.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "internal.hpp"
+#include "gemm_device.hpp"
+
+namespace xamd {
+
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int small_cvt_pk_bf16(float lo, float hi) {       // v_cvt_pk_bf16_f32 (RNE), as in gemm_kernels.hip
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwbf16x2_t));
+}
+
+template <int AUX>
+__global__ __launch_bounds__(256) void gemm_f32_p16w_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds_all[4][256];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int bidx = logical_block(p) * 4u + wave;
+  if (bidx >= p.nbatch) return;
+  const unsigned int lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+  float* img = lds_all[wave];
+  const BatchPtrs q = batch_ptrs(p, bidx);
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const unsigned int pos = lane >> 2;                                               // image row this lane's 16 bytes land in
+  const unsigned int vA = ((pos ^ ((pos >> 2) & 1u)) * lda + (lane & 3u) * 4u) * 4u;   // ... which holds k = pos ^ ((pos >> 2) & 1)
+  const unsigned int vB = (x * ldb + 4u * g) * 4u;
+  const unsigned int kchunks = (unsigned int)p.k >> 4;
+  f32x4 acc = (f32x4)0.0f;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br;
+    br_base(p, q, r, ar, br);
+    const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar), rb = wave_rsrc(br);
+    for (unsigned int kc = 0; kc < kchunks; ++kc) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)img, 16, (int)vA, (int)(kc * 64u * lda), 0, AUX);
+      const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)vB, (int)(kc * 64u), AUX));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float af[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) af[s] = img[((4u * g + s) ^ (g & 1u)) * 16u + x];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bv[s], acc, 0, 0, 0);
+    }
+  }
+  st_stream((GM f32x4*)((GM float*)q.c + (unsigned long long)x * (unsigned int)p.ldc + 4u * g), acc);
+}
+
+template <int AUX>
+__global__ __launch_bounds__(256) void gemm_bf16_p16w_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned int lds_all[4][256];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int first = (logical_block(p) * 4u + wave) * 2u;
+  if (first >= p.nbatch) return;
+  const bool two = first + 1u < p.nbatch;                                           // wave-uniform
+  const unsigned int lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+  unsigned int* img = lds_all[wave];
+  BatchPtrs q[2];
+  q[0] = batch_ptrs(p, first); q[1] = batch_ptrs(p, two ? first + 1u : first);
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const unsigned int l5 = lane & 31u, pos = l5 >> 2;
+  const unsigned int vA = ((pos ^ ((pos >> 1) & 1u)) * lda + (l5 & 3u) * 4u) * 4u;     // dword (k pair, row): pair pos ^ ((pos >> 1) & 1), rows 4 (l5 & 3) ..
+  const unsigned int vB = (x * ldb + 4u * g) * 2u;
+  const unsigned int kchunks = (unsigned int)p.k >> 4;
+  f32x4 acc[2] = {(f32x4)0.0f, (f32x4)0.0f};
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar[2], br[2];
+    br_base(p, q[0], r, ar[0], br[0]); br_base(p, q[1], r, ar[1], br[1]);
+    gcptr amine = (lane >> 5) ? ar[1] : ar[0];                                      // per-lane base: the upper half-wave fetches the second problem's A
+    for (unsigned int kc = 0; kc < kchunks; ++kc) {
+      __builtin_amdgcn_global_load_lds((GM const void*)(amine + vA + (unsigned long long)kc * 32ull * lda), (lds_vptr)img, 16, 0, AUX);
+      u32x2_t bv[2];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) bv[pp] = *(GM const u32x2_t*)(br[pp] + vB + kc * 32u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      u32x2_t av[2];
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) av[pp][e] = img[pp * 128u + ((2u * g + e) ^ (g & 1u)) * 16u + x];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+        acc[pp] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4_t, av[pp]), __builtin_bit_cast(bf16x4_t, bv[pp]), acc[pp], 0, 0, 0);
+    }
+  }
+  const bool c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    if (pp == 0 || two) {
+      if (c_f32) st_stream((GM f32x4*)((GM float*)q[pp].c + (unsigned long long)x * (unsigned int)p.ldc + 4u * g), acc[pp]);
+      else { u32x2_t v; v[0] = small_cvt_pk_bf16(acc[pp][0], acc[pp][1]); v[1] = small_cvt_pk_bf16(acc[pp][2], acc[pp][3]);
+             st_stream((GM u32x2_t*)((GM unsigned short*)q[pp].c + (unsigned long long)x * (unsigned int)p.ldc + 4u * g), v); }
+    }
+  }
+}
+
+// 16-byte aligned A rows on top of launch_gemm's p16_ok (B, C and the strided forms are checked there); *taken = 0: the caller's older kernel serves
+int launch_gemm_p16w(const GemmArgs& a, bool nt, void* stream, const char** kernel_name, int* taken) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_P16W"); return e && e[0] == '0'; }();
+  *taken = 0;
+  const bool bf16 = a.a_type == LIBXSMM_DATATYPE_BF16;
+  unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)((long long)a.lda * 4);
+  if (a.br_mode == 3) abits |= (unsigned long long)a.br_stride_a;
+  if (off || (abits & 15ull) || a.lda >= (1 << 22) || a.ldb >= (1 << 22) || a.ldc >= (1 << 22)) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  *taken = 1;
+  if (bf16) {
+    if (kernel_name) *kernel_name = "gemm_bf16_p16w_kernel";
+    const dim3 grid((unsigned int)(((a.nbatch + 1u) / 2u + 3u) / 4u));
+    if (nt) hipLaunchKernelGGL((gemm_bf16_p16w_kernel<2>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_bf16_p16w_kernel<0>), grid, dim3(256), 0, st, a);
+  } else {
+    if (kernel_name) *kernel_name = "gemm_f32_p16w_kernel";
+    const dim3 grid((unsigned int)((a.nbatch + 3u) / 4u));
+    if (nt) hipLaunchKernelGGL((gemm_f32_p16w_kernel<2>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_f32_p16w_kernel<0>), grid, dim3(256), 0, st, a);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace xamd

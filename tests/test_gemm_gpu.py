@@ -102,12 +102,16 @@ def test_f32_mfma_is_bitwise_the_k_ordered_fma_chain(kw):
 def test_headline_shape_uses_mfma_tile_kernel():
     name = _check(GemmCase(32, 32, 32, br_type=capi.BR_STRIDE, br_count=1, batch=64, seed=1), expect_kernel="gemm_f32_stream_kernel")      # the lean MFMA 32x32 streaming kernel
     _check(GemmCase(32, 32, 32, lda=33, batch=64, seed=1), expect_kernel="gemm_mfma_f32_kernel<1,1>")
-    _check(GemmCase(16, 16, 16, batch=64, seed=2), expect_kernel="gemm_f32_p16_kernel")        # four 16^3 problems per wave
+    _check(GemmCase(16, 16, 16, batch=64, seed=2), expect_kernel="gemm_f32_p16w_kernel")       # round 4: one 16^3 problem per wave, A by LDS-DMA (16-byte requests)
+    _check(GemmCase(16, 16, 16, batch=67, seed=2, lda=18), expect_kernel="gemm_f32_p16_kernel")   # A rows not 16-byte aligned: the round-2 kernel (dword loads of A)
     _check(GemmCase(16, 16, 16, batch=64, seed=2, beta=1), expect_kernel="t16")                 # beta = 1: the general 16x16-tile kernel
-    _check(GemmCase(16, 16, 32, batch=67, seed=2, br_type=capi.BR_STRIDE, br_count=3), expect_kernel="gemm_f32_p16_kernel")
-    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=64, seed=2), expect_kernel="gemm_bf16_p16_kernel")
-    _check(GemmCase(16, 16, 48, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, batch=33, seed=3, br_type=capi.BR_STRIDE, br_count=2), expect_kernel="gemm_bf16_p16_kernel")
-    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=5, seed=4, ldc=24), expect_kernel="gemm_bf16_p16_kernel")
+    _check(GemmCase(16, 16, 32, batch=67, seed=2, br_type=capi.BR_STRIDE, br_count=3), expect_kernel="gemm_f32_p16w_kernel")
+    _check(GemmCase(16, 16, 16, batch=70001, seed=2), expect_kernel="gemm_f32_p16w_kernel")
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=64, seed=2), expect_kernel="gemm_bf16_p16w_kernel")     # two problems per wave
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=20001, seed=2), expect_kernel="gemm_bf16_p16w_kernel")  # odd count: the last wave has one
+    _check(GemmCase(16, 16, 48, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, batch=33, seed=3, br_type=capi.BR_STRIDE, br_count=2), expect_kernel="gemm_bf16_p16w_kernel")
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=5, seed=4, ldc=24), expect_kernel="gemm_bf16_p16w_kernel")
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=9, seed=4, lda=18), expect_kernel="gemm_bf16_p16_kernel")
     _check(GemmCase(64, 64, 64, batch=8, seed=3), expect_kernel="gemm_f32_wg64_kernel")         # one 64x64 problem per workgroup, LDS-DMA
     _check(GemmCase(64, 64, 96, batch=5, seed=3, beta=1, br_type=capi.BR_STRIDE, br_count=3), expect_kernel="gemm_f32_wg64_kernel")
     _check(GemmCase(64, 64, 32, batch=3, seed=3, colbias=True, act=2), expect_kernel="gemm_f32_wg64_kernel")
