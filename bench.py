@@ -424,6 +424,26 @@ def cpu_baseline(m, dtype, br, beta, fused, seconds, nthreads):
             "sample": f"C restatement (oracle/), 64 problems x {n} reps, 1 thread, {dt:.1f} s"}
 
 
+def single_call_latency():
+    """The reference's calling pattern -- ONE small GEMM per call, the loop in the caller -- timed by a plain C program (examples/loop_driver.c, built by
+    __graft_entry__.build()): microseconds per f32 32^3 call when every call blocks (the default, the reference's semantics), when calls are stream-ordered,
+    and when consecutive calls are coalesced into one batched launch (libxsmm_hip_set_async(2)); wall clock around a loop of 4096 calls plus the final sync."""
+    exe = os.path.join(ROOT, "libxsmm_amd", "lib", "loop_driver")
+    if not os.path.exists(exe):
+        return None
+    import subprocess
+    out = {}
+    for mode in ("sync", "async", "coalesce"):
+        try:
+            r = subprocess.run([exe, "32", "4096", mode, "3", "f32"], capture_output=True, text=True, timeout=120)
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+            out[mode] = {"us_per_call": rec["us_per_call"], "GFLOP/s": rec["GFLOPs"], "launches_per_4096_calls": rec["launches_per_rep"], "bit_identical_to_batched_launch": rec["bit_identical"]}
+        except Exception as e:                       # a side figure: never fails the bench
+            out[mode] = {"error": str(e)[:100]}
+    out["note"] = "examples/loop_driver.c: for (i < 4096) kernel(&param_i); libxsmm_hip_sync(); f32 32^3, device operands; the GPU is shared with this process while it runs"
+    return out
+
+
 def committed_counters(kernel, alg_bytes, label):
     """HBM traffic and MFMA-busy for this workload from the committed PMC passes (rocprofv3 --pmc cannot run inside this process:
     tools/profile_paths.sh runs THIS command under it in separate passes, tools/summarize_profiles.py distils profiles/)."""
@@ -595,6 +615,9 @@ def compact_line(full, detail_path):
         line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:110]
         if "all_cores" in cb:
             line["cpu_baseline"]["all_cores"] = {"value": cb["all_cores"]["value"], "cores": cb["all_cores"]["cores"]}
+    sc = full.get("single_call_us")
+    if sc:
+        line["single_call_us"] = [sc.get(k, {}).get("us_per_call") for k in ("sync", "async", "coalesce")]       # [blocking, stream-ordered, coalesced] per f32 32^3 call
     cb64 = full.get("cpu_baseline_f64")
     if cb64:
         line["cpu_baseline_f64"] = [cb64.get("value"), cb64.get("cores"), cb64.get("kind")]       # [GFLOP/s of the reference's f64 32^3 kernel, cores, kind]
@@ -856,6 +879,8 @@ def main():
             out["ragged"] = ragged
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.m, args.dtype, args.br, args.beta, args.fused, args.cpu_seconds, nthreads)
+            if sweep:
+                out["single_call_us"] = single_call_latency()
             if sweep:       # the reference's classic precision: its f64 JIT kernel for the sweep's f64 32^3 entries, one core (a shorter sample: it is a side figure)
                 out["cpu_baseline_f64"] = cpu_baseline(32, "f64", 1, 0, 0, min(args.cpu_seconds, 4.0), 0)
         if args.manifest:

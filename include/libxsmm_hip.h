@@ -53,6 +53,13 @@ LIBXSMM_API void* libxsmm_hip_get_stream(void);
 /**
  * 0 (default, also LIBXSMM_HIP_SYNC=1): every kernel call blocks until C is valid, which
  * is the reference's semantics.  1: stream-ordered.  LIBXSMM_HIP_ASYNC=1 presets it.
+ * 2 (LIBXSMM_HIP_ASYNC=2 or LIBXSMM_HIP_COALESCE=1): stream-ordered AND coalescing -- the reference leaves the batch loop to the caller
+ * (one small GEMM per call [ref: documentation/libxsmm_mm.md:95-107]); in this mode consecutive calls through ONE plain GEMM / stride-BRGEMM handle
+ * are queued (three pointers per call, nothing is launched) and leave as ONE pointer-list batch launch when anything else happens: a call through
+ * another handle or kind, another batch-reduce count, libxsmm_hip_sync / _set_stream / _set_async / libxsmm_finalize / libxsmm_release_kernel, 65 536
+ * queued calls, or a call that reads or writes what a queued call writes (or writes what one reads): the caller's dependent sequences keep their
+ * order.  An unmodified `for (i...) kernel(&param_i);` loop followed by libxsmm_hip_sync() thus runs as one batched launch.  Operands must be
+ * device-accessible (as in mode 1); calls with a fused operator, pointer / offset lists or per-call scale operands are not queued (they launch as in mode 1).
  */
 LIBXSMM_API void libxsmm_hip_set_async(int enable);
 LIBXSMM_API int libxsmm_hip_get_async(void);

@@ -576,9 +576,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_blocked_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 static bool f64_stream_ok(const GemmArgs& a) {
   if ((a.m % 32) || (a.n % 32) || (a.k % 32) || a.k <= 0) return false;
-  if (a.list_a || a.br_mode == 1 || a.br_mode == 2) return false;               // pointer / offset lists live on the device: alignment unknown here
-  unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
-    (unsigned long long)((long long)a.lda * 8) | (unsigned long long)((long long)a.ldb * 8);
+  if ((a.list_a && !a.lists_aligned16) || a.br_mode == 1 || a.br_mode == 2) return false;      // pointer / offset lists live on the device: alignment unknown here (unless the library built them)
+  unsigned long long bits = (unsigned long long)((long long)a.lda * 8) | (unsigned long long)((long long)a.ldb * 8);
+  if (!a.list_a) bits |= (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b;
   if (a.br_mode == 3) bits |= (unsigned long long)a.br_stride_a | (unsigned long long)a.br_stride_b;
   if (bits & 15ull) return false;
   return a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22);            // 32-bit byte offsets inside a chunk

@@ -3293,7 +3293,12 @@ static void launch_f32(const GemmArgs& a, dim3 grid, hipStream_t st) {
 // The staged path needs every operand tile 16-byte aligned.  That is decidable on the host for the
 // strided forms; pointer lists / offset arrays live on the device and take the direct-load kernel.
 static bool operands_aligned16(const GemmArgs& a, int elem_size) {
-  if (a.list_a || a.br_mode == 1 || a.br_mode == 2) return false;
+  if (a.br_mode == 1 || a.br_mode == 2) return false;
+  if (a.list_a) {                                   // pointer lists live on the device; lists the library built itself come with their alignment
+    if (!a.lists_aligned16) return false;
+    const unsigned long long lbits = (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) | (unsigned long long)((long long)a.lda * elem_size) | (unsigned long long)((long long)a.ldb * elem_size);
+    return (lbits & 15ull) == 0ull;
+  }
   const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a |
     (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) |
     (unsigned long long)((long long)a.lda * elem_size) | (unsigned long long)((long long)a.ldb * elem_size);

@@ -87,6 +87,7 @@ struct GemmArgs {
   float scf;                                        // 8-bit GEMM with f32 output: scale read from c.tertiary on the host
   const char* a_scf; long long bs_scf;              // MXFP4 A: E8M0 scales (a.tertiary; a pointer list in ADDRESS mode) and their batch stride
   const char* b_scf; long long bs_bscf;             // MX x MX: the scales of B (b.tertiary)
+  int lists_aligned16;                              // pointer-list batch whose every pointer is known to be 16-byte aligned (lists built by the library: the coalescing queue)
   int tune;                                         // experiment switches set by launch_gemm from the environment (bit 0: 6-bit MX operands gathered per lane instead of staged through LDS)
 };
 

@@ -213,13 +213,33 @@ static void* stage2d(const void* p, size_t width, size_t height, size_t pitch, b
 }
 static void* stage(const void* p, size_t nbytes, bool copy_in, bool copy_back) { return stage2d(p, nbytes, 1, nbytes, copy_in, copy_back); }
 const void* device_visible(const void* p, size_t nbytes) { return stage(p, nbytes, true, false); }
+// an array KNOWN to live in plain host memory (the coalescing queue's pointer lists): uploaded into the scratch without the pointer query
+static void* stage_host(const void* p, size_t nbytes) {
+  if (!p || nbytes == 0) return nullptr;
+  Scratch& s = t_scratch;
+  const size_t need = (nbytes + 255) & ~(size_t)255;
+  if (s.base && s.device != cur_device()) { retire_block(s.base); s.base = nullptr; s.cap = s.used = 0; }
+  if (s.used + need > s.cap) {
+    const size_t ncap = std::max<size_t>((s.used + need) * 2, 1 << 20);
+    char* nb = nullptr;
+    if (!hip_ok(hipMalloc((void**)&nb, ncap), "hipMalloc(scratch)")) return nullptr;
+    if (s.base) retire_block(s.base);
+    s.base = nb; s.cap = ncap; s.used = 0; s.device = cur_device();
+  }
+  char* dst = s.base + s.used; s.used += need;
+  if (!hip_ok(hipMemcpyAsync(dst, p, nbytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpyAsync(pointer lists)")) return nullptr;
+  return dst;
+}
 // Operands of a SYNCHRONOUS call may live in plain host memory (the reference's contract: any pointer, result valid on return);
 // an MI355X cannot see such memory, so it is staged.  Stream-ordered (async) and batched launches take device-accessible memory only:
 // no pointer query, no copy on the fast path.
 static bool staging_allowed(size_t batch_count) { return !tls().async && batch_count <= 1; }
 static const void* host_input(const void* p, size_t nbytes, size_t batch_count) { return staging_allowed(batch_count) ? stage(p, nbytes, true, false) : p; }
 static void* host_inout(void* p, size_t nbytes, size_t batch_count) { return staging_allowed(batch_count) ? stage(p, nbytes, true, true) : p; }
-void scratch_reset() { if (t_nest > 0) return; t_scratch.used = 0; t_copyback.clear(); }
+// Rewinds the staging scratch at the start of a call.  NOT inside an open pipeline section: its launches run on different lane streams, so call N + 1's
+// upload of a staged operand (an OFFSET / ADDRESS list, a gather index list, a BCSC pattern) is not ordered behind call N's kernel, which may not have
+// read the same bytes yet -- the scratch keeps growing until the first call after libxsmm_hip_pipeline_end (ordered behind every lane by the join).
+void scratch_reset() { if (t_nest > 0 || tls().pipe_lanes > 1) return; t_scratch.used = 0; t_copyback.clear(); }
 void copy_back_staged() {
   for (const CopyBack& c : t_copyback)
     (void)hip_ok(c.height == 1 ? hipMemcpy(c.host, c.dev, c.width, hipMemcpyDeviceToHost) : hipMemcpy2D(c.host, c.pitch, c.dev, c.pitch, c.width, c.height, hipMemcpyDeviceToHost),
@@ -302,7 +322,8 @@ ThreadState& tls() {
   thread_local ThreadState st;
   if (st.async < 0) {
     const char* a = std::getenv("LIBXSMM_HIP_ASYNC"); const char* s = std::getenv("LIBXSMM_HIP_SYNC");
-    st.async = (a && std::atoi(a) != 0) ? 1 : 0;
+    st.async = (a && std::atoi(a) != 0) ? (std::atoi(a) == 2 ? 2 : 1) : 0;
+    if (const char* co = std::getenv("LIBXSMM_HIP_COALESCE")) { if (std::atoi(co) != 0) st.async = 2; }
     if (s && std::atoi(s) != 0) st.async = 0;
     const char* h = std::getenv("LIBXSMM_HIP_STREAMING");
     if (h) { const int v = std::atoi(h); st.stream_hint = (v >= 0 && v <= 2) ? v : 0; }
@@ -360,10 +381,13 @@ struct BatchSpec {
   long long s[5] = {0, 0, 0, 0, 0};                 // kind specific byte strides
   size_t inner = 0; long long c2 = 0, mask2 = 0;    // 2-D GEMM batch: count = inner * outer, second strides of C / bitmask
   const void* const* la = nullptr; const void* const* lb = nullptr; void* const* lc = nullptr;
+  bool lists_on_host = false;                       // the coalescing queue's lists: plain host vectors, staged without a pointer query
+  bool lists_aligned16 = false;                     // ... and every pointer in them is known to be 16-byte aligned (the fast kernels take pointer lists then)
 };
 
 // LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK [ref: gemm ref :535-556,857-948]: a.primary = the non-zeros of A, a.secondary = one bit per element.
 // The dense image is rebuilt in the workspace (three small launches), then the dense kernel of the equivalent descriptor runs on it.
+void coalesce_flush();       // the coalescing queue (further down): every launch path drains it first, so launches keep the caller's order
 static void run_gemm_bitmask(KernelCtx* k, const libxsmm_gemm_param* p, const BatchSpec& b) {
   const libxsmm_gemm_descriptor& d = k->g;
   if (b.count != 1 || b.la) { set_error(-2, "a GEMM with bitmask-compressed A cannot be batched (its operand size differs per problem)"); return; }
@@ -429,6 +453,7 @@ static void run_gemm_bitmask(KernelCtx* k, const libxsmm_gemm_param* p, const Ba
 }
 
 void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
+  coalesce_flush();
   const libxsmm_gemm_descriptor& d = k->g;
   if (d.flags & LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) { run_gemm_bitmask(k, (const libxsmm_gemm_param*)param, b); return; }
   const bool ext = (d.flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) != 0;
@@ -438,6 +463,12 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   scratch_reset();
   a.a = (const char*)p->a.primary; a.b = (const char*)p->b.primary; a.c = (char*)p->c.primary;
   a.list_a = b.la; a.list_b = b.lb; a.list_c = b.lc;
+  if (b.lists_on_host) {
+    a.list_a = (const void* const*)stage_host(b.la, b.count * sizeof(void*)); a.list_b = (const void* const*)stage_host(b.lb, b.count * sizeof(void*));
+    a.list_c = (void* const*)stage_host(b.lc, b.count * sizeof(void*));
+    if (!a.list_a || !a.list_b || !a.list_c) return;
+  }
+  a.lists_aligned16 = (b.la && b.lists_aligned16) ? 1 : 0;
   a.bs_a = b.s[0]; a.bs_b = b.s[1]; a.bs_c = b.s[2]; a.bs_d = b.s[3]; a.bs_mask = b.s[4];
   a.nbatch = (unsigned int)b.count;
   a.batch_inner = (unsigned int)b.inner; a.bs_c2 = b.c2; a.bs_mask2 = b.mask2;
@@ -644,6 +675,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
 }
 
 void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
+  coalesce_flush();
   const libxsmm_meltw_descriptor& d = k->e;
   MeltwArgs a{};
   scratch_reset();
@@ -838,6 +870,7 @@ static void spmm_geometry(const KernelCtx* k, SpmmArgs& a) {
 }
 
 void run_spmm(KernelCtx* k, const void* param, const BatchSpec& b) {
+  coalesce_flush();
   const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
   SpmmArgs a{};
   // the pattern arrays (and the JIT module) live on the device the kernel was created on
@@ -1037,7 +1070,100 @@ void run_csparse(KernelCtx* k, const void* param) {
   finish_launch(err, kname);
 }
 
+// ---- coalescing launch mode (libxsmm_hip_set_async(2) / LIBXSMM_HIP_COALESCE=1) ---------------------------------------------------------------
+// The reference executes ONE small GEMM per call and leaves the batch loop to the caller [ref: documentation/libxsmm_mm.md:95-107]; on a GPU that
+// is one launch per 65 kflop.  In this mode consecutive calls through ONE plain (BR)GEMM handle are only QUEUED -- three pointers per call -- and
+// leave as ONE pointer-list batch launch when something else happens: a call through another handle or of another kind, a different batch-reduce
+// count, libxsmm_hip_sync / _set_stream / _set_async / finalize, a full queue, or a call that touches what a queued call writes (or writes what a
+// queued call reads): the queue keeps the byte ranges of its operands, so a caller's dependent sequence (C of call i read by call i + 1, two
+// calls accumulating into one C) keeps its order -- the batched launch only ever holds mutually independent calls.  Results are valid after
+// libxsmm_hip_sync(), as in every stream-ordered mode.  Queued: NONE / STRIDE batch-reduce, no fused operator, no per-call scale operands.
+struct CoalesceQueue {
+  KernelCtx* k = nullptr;
+  unsigned long long br_count = 0;
+  std::vector<const void*> a, b; std::vector<void*> c;
+  size_t ea = 0, eb = 0, ec = 0;                        // bytes a call reads through a / b and writes through c
+  uintptr_t cmin = 0, cmax = 0, rmin = 0, rmax = 0;     // hulls of the queued C ranges and of the queued A / B ranges
+  bool c_monotonic = true;                              // every queued C started at or behind the end of the hull so far: no two overlap
+  bool strided = true; long long sa = 0, sb = 0, sc = 0;  // the calls so far step by constant byte strides (the usual loop): they leave as a STRIDED batch
+  uintptr_t low_bits = 0;                               // OR of all queued pointers: alignment of the lists
+};
+thread_local CoalesceQueue t_queue;
+static const size_t kCoalesceCap = 65536;
+
+void coalesce_flush() {
+  CoalesceQueue& q = t_queue;
+  if (q.a.empty()) return;
+  std::vector<const void*> la, lb; std::vector<void*> lc;
+  la.swap(q.a); lb.swap(q.b); lc.swap(q.c);             // the queue is empty before anything is launched: run_gemm's own flush hook finds nothing
+  KernelCtx* k = q.k; q.k = nullptr;
+  libxsmm_gemm_param p; std::memset(&p, 0, sizeof(p));
+  unsigned long long brc = q.br_count;
+  p.op.tertiary = &brc; p.a.primary = const_cast<void*>(la[0]); p.b.primary = const_cast<void*>(lb[0]); p.c.primary = lc[0];
+  BatchSpec bs; bs.count = la.size();
+  if (q.strided && la.size() >= 2) { bs.s[0] = q.sa; bs.s[1] = q.sb; bs.s[2] = q.sc; }       // exactly libxsmm_hip_gemm_batch_strided
+  else if (la.size() >= 2) { bs.la = la.data(); bs.lb = lb.data(); bs.lc = lc.data(); bs.lists_on_host = true; bs.lists_aligned16 = (q.low_bits & 15u) == 0; }
+  run_gemm(k, &p, bs);
+  la.clear(); lb.clear(); lc.clear();
+  q.a.swap(la); q.b.swap(lb); q.c.swap(lc);             // keep the capacity
+}
+static bool ranges_overlap(uintptr_t a0, size_t an, uintptr_t b0, size_t bn) { return a0 < b0 + bn && b0 < a0 + an; }
+// true: the call has been queued
+bool coalesce_try(KernelCtx* k, const void* param) {
+  if (k->kind != K_GEMM || t_nest > 0 || tls().pipe_lanes > 1 || !param) return false;
+  const libxsmm_gemm_descriptor& d = k->g;
+  const unsigned int never = LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI | LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET |
+    LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT | LIBXSMM_GEMM_FLAG_USE_COL_VEC_SCF | LIBXSMM_GEMM_FLAG_USE_COL_VEC_ZPT | LIBXSMM_GEMM_FLAG_USE_MxK_ZPT | LIBXSMM_GEMM_FLAG_USE_MxK_SCF;
+  if (d.flags & never) return false;
+  const auto plain = [](int t) { return t == LIBXSMM_DATATYPE_F32 || t == LIBXSMM_DATATYPE_F64 || t == LIBXSMM_DATATYPE_BF16 || t == LIBXSMM_DATATYPE_F16; };
+  if (!plain(d.a_type) || !plain(d.b_type) || !plain(d.c_type)) return false;          // (8-bit and MX types carry per-call scale operands)
+  const libxsmm_gemm_param* p = (const libxsmm_gemm_param*)param;
+  if (!p->a.primary || !p->b.primary || !p->c.primary) return false;
+  unsigned long long brc = 1;
+  const bool strided = (d.flags & LIBXSMM_GEMM_FLAG_BATCH_REDUCE_STRIDE) != 0;
+  if (strided) { if (!p->op.tertiary) return false; brc = *(const unsigned long long*)p->op.tertiary; if (brc == 0 || d.br_stride_a < 0 || d.br_stride_b < 0) return false; }
+  CoalesceQueue& q = t_queue;
+  if (!q.a.empty() && (q.k != k || q.br_count != brc || q.a.size() >= kCoalesceCap)) coalesce_flush();
+  const bool ta = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_A) != 0, tb = (d.flags & LIBXSMM_GEMM_FLAG_TRANS_B) != 0;
+  const size_t ea = (size_t)(brc - 1) * (size_t)(strided ? d.br_stride_a : 0) + (size_t)d.lda * (size_t)(ta ? d.m : d.k) * (size_t)typesize(d.a_type);
+  const size_t eb = (size_t)(brc - 1) * (size_t)(strided ? d.br_stride_b : 0) + (size_t)d.ldb * (size_t)(tb ? d.k : d.n) * (size_t)typesize(d.b_type);
+  const size_t ec = (size_t)d.ldc * (size_t)(d.n + ((d.flags & LIBXSMM_GEMM_FLAG_VNNI_C) ? (d.n & 1) : 0)) * (size_t)typesize(d.c_type);
+  const uintptr_t pa = (uintptr_t)p->a.primary, pb = (uintptr_t)p->b.primary, pc = (uintptr_t)p->c.primary;
+  if (!q.a.empty()) {
+    // read-after-write: this call's A / B against the queued C ranges; write-after-write / write-after-read: its C against the queued C and A / B ranges
+    bool hazard = false;
+    const bool a_near = ranges_overlap(pa, ea, q.cmin, q.cmax - q.cmin), b_near = ranges_overlap(pb, eb, q.cmin, q.cmax - q.cmin);
+    const bool c_near_c = !(q.c_monotonic && pc >= q.cmax) && ranges_overlap(pc, ec, q.cmin, q.cmax - q.cmin);
+    const bool c_near_r = ranges_overlap(pc, ec, q.rmin, q.rmax - q.rmin);
+    if (a_near || b_near || c_near_c)
+      for (size_t i = 0; i < q.c.size() && !hazard; ++i) {
+        const uintptr_t qc = (uintptr_t)q.c[i];
+        hazard = (a_near && ranges_overlap(pa, ea, qc, q.ec)) || (b_near && ranges_overlap(pb, eb, qc, q.ec)) || (c_near_c && ranges_overlap(pc, ec, qc, q.ec));
+      }
+    if (c_near_r && !hazard)
+      for (size_t i = 0; i < q.a.size() && !hazard; ++i)
+        hazard = ranges_overlap(pc, ec, (uintptr_t)q.a[i], q.ea) || ranges_overlap(pc, ec, (uintptr_t)q.b[i], q.eb);
+    if (hazard) coalesce_flush();
+  }
+  if (q.a.empty()) {
+    q.k = k; q.br_count = brc; q.ea = ea; q.eb = eb; q.ec = ec;
+    q.cmin = pc; q.cmax = pc + ec; q.rmin = std::min(pa, pb); q.rmax = std::max(pa + ea, pb + eb); q.c_monotonic = true;
+    q.strided = true; q.sa = q.sb = q.sc = 0; q.low_bits = 0;
+  } else {
+    const size_t n = q.a.size();
+    if (n == 1) { q.sa = (long long)(pa - (uintptr_t)q.a[0]); q.sb = (long long)(pb - (uintptr_t)q.b[0]); q.sc = (long long)(pc - (uintptr_t)q.c[0]); }
+    else if (q.strided) q.strided = (long long)(pa - (uintptr_t)q.a[n - 1]) == q.sa && (long long)(pb - (uintptr_t)q.b[n - 1]) == q.sb && (long long)(pc - (uintptr_t)q.c[n - 1]) == q.sc;
+    if (pc < q.cmax) q.c_monotonic = false;
+    q.cmin = std::min(q.cmin, pc); q.cmax = std::max(q.cmax, pc + ec);
+    q.rmin = std::min(q.rmin, std::min(pa, pb)); q.rmax = std::max(q.rmax, std::max(pa + ea, pb + eb));
+  }
+  q.low_bits |= pa | pb | pc;
+  q.a.push_back(p->a.primary); q.b.push_back(p->b.primary); q.c.push_back(p->c.primary);
+  return true;
+}
+
 void run_any(KernelCtx* k, const void* param, const BatchSpec& b) {
+  coalesce_flush();                   // whatever launches next is ordered behind the queued calls
   if (!param && k->kind != K_TILECFG) { set_error(-2, "kernel called with a NULL parameter struct"); return; }
   if (g_device_count <= 0 && k->kind != K_TILECFG) { set_error(-4, "no HIP device: kernel not launched (this backend has no CPU path)"); return; }
   switch (k->kind) {
@@ -1079,6 +1205,7 @@ bool rt_dryrun() { return g_dryrun; }
 void invoke(int slot, const void* param) {
   KernelCtx* k = g_slots[slot];
   if (!k) { set_error(-3, "call through a released kernel handle"); return; }
+  if (tls().async == 2 && g_device_count > 0 && coalesce_try(k, param)) return;
   run_any(k, param, BatchSpec{});
 }
 }  // namespace xamd
@@ -1110,6 +1237,7 @@ LIBXSMM_API void libxsmm_init(void) {
 // un-initialised state: a later dispatch re-initialises, as the reference's init/finalize cycles do [ref: src/libxsmm_main.c:1503-1640].
 // Caller-owned kernels (create_*) stay valid until libxsmm_release_kernel.  Every thread's dispatch cache is invalidated by the generation.
 LIBXSMM_API void libxsmm_finalize(void) {
+  coalesce_flush();                        // the calling thread's queued calls (other threads drain theirs at their own libxsmm_hip_sync)
   std::lock_guard<std::mutex> guard(g_lock);
   if (libxsmm_ninit < 2) return;
   if (g_device_count > 0) (void)hipDeviceSynchronize();
@@ -1647,6 +1775,7 @@ LIBXSMM_API void libxsmm_release_kernel(const void* kernel) {
   KernelCtx* c = ctx_from_handle(kernel);
   if (!c) return;
   if (c->registered) { vlog(1, "libxsmm_release_kernel: registered kernels are owned by the registry (no-op)"); return; }   // [ref: libxsmm_main.c:3900-3922]
+  coalesce_flush();
   (void)hipDeviceSynchronize();
   drop_unregistered(c);
 }
@@ -1690,13 +1819,14 @@ LIBXSMM_API int libxsmm_hip_set_device(int device) {
   tls().device = device; return 0;
 }
 LIBXSMM_API int libxsmm_hip_get_device(void) { int d = 0; if (hipGetDevice(&d) != hipSuccess) return -1; return d; }
-LIBXSMM_API void libxsmm_hip_set_stream(void* s) { if (tls().pipe_lanes > 1) libxsmm_hip_pipeline_end(); tls().stream = s; tls().async = 1; }
+LIBXSMM_API void libxsmm_hip_set_stream(void* s) { coalesce_flush(); if (tls().pipe_lanes > 1) libxsmm_hip_pipeline_end(); tls().stream = s; if (tls().async != 2) tls().async = 1; }
 LIBXSMM_API void* libxsmm_hip_get_stream(void) { return tls().stream; }
-LIBXSMM_API void libxsmm_hip_set_async(int enable) { tls().async = enable ? 1 : 0; }
+LIBXSMM_API void libxsmm_hip_set_async(int enable) { coalesce_flush(); tls().async = enable == 2 ? 2 : (enable ? 1 : 0); }
 LIBXSMM_API void libxsmm_hip_set_streaming_hint(int mode) { tls().stream_hint = (mode >= 0 && mode <= 2) ? mode : 0; }
 LIBXSMM_API int libxsmm_hip_get_streaming_hint(void) { return tls().stream_hint; }
 LIBXSMM_API int libxsmm_hip_get_async(void) { return tls().async; }
 LIBXSMM_API void libxsmm_hip_sync(void) {
+  coalesce_flush();
   if (tls().pipe_lanes > 1) libxsmm_hip_pipeline_end();          // a synchronisation closes an open pipeline section
   (void)hip_ok(hipStreamSynchronize(cur_stream()), "hipStreamSynchronize");
 }
@@ -1747,6 +1877,17 @@ LIBXSMM_API int libxsmm_hip_pipeline_begin(int lanes) {
   if (!hip_ok(hipEventRecord((hipEvent_t)t.pipe_event[8], (hipStream_t)t.pipe_user), "hipEventRecord(pipeline fork)")) return EXIT_FAILURE;
   for (int i = 0; i < lanes; ++i)
     if (!hip_ok(hipStreamWaitEvent((hipStream_t)t.pipe_stream[i], (hipEvent_t)t.pipe_event[8], 0), "hipStreamWaitEvent(pipeline fork)")) return EXIT_FAILURE;
+  // every lane gets a partial-result workspace as large as the thread's own BEFORE the section opens: a first hipMalloc inside the section would be
+  // illegal while a graph is being captured (warm-up launches outside the section size lane 0)
+  for (int i = 1; i < lanes; ++i) {
+    Workspace& w = t_workspace[i];
+    if (w.base && w.device != cur_device()) { retire_block(w.base); w.base = nullptr; w.cap = 0; }
+    if (w.cap < t_workspace[0].cap) {
+      void* nb = nullptr;
+      if (hipMalloc(&nb, t_workspace[0].cap) == hipSuccess) { if (w.base) retire_block(w.base); w.base = nb; w.cap = t_workspace[0].cap; w.device = cur_device(); }
+      else (void)hipGetLastError();          // (e.g. under capture: the section still works for kernels that need no workspace)
+    }
+  }
   t.pipe_lanes = lanes; t.pipe_cur = 0; t.stream = t.pipe_stream[0];
   return EXIT_SUCCESS;
 }
@@ -1768,7 +1909,7 @@ LIBXSMM_API void libxsmm_hip_clear_last_error(void) { tls().last_error = 0; tls(
 LIBXSMM_API void* libxsmm_hip_malloc(size_t n) { void* p = nullptr; if (!hip_ok(hipMalloc(&p, n ? n : 1), "hipMalloc")) return nullptr; return p; }
 LIBXSMM_API void libxsmm_hip_free(void* p) { if (p) (void)hipFree(p); }
 LIBXSMM_API int libxsmm_hip_memcpy_h2d(void* d, const void* s, size_t n) { return hip_ok(hipMemcpy(d, s, n, hipMemcpyHostToDevice), "hipMemcpy(H2D)") ? 0 : -1; }
-LIBXSMM_API int libxsmm_hip_memcpy_d2h(void* d, const void* s, size_t n) { return hip_ok(hipMemcpy(d, s, n, hipMemcpyDeviceToHost), "hipMemcpy(D2H)") ? 0 : -1; }
+LIBXSMM_API int libxsmm_hip_memcpy_d2h(void* d, const void* s, size_t n) { coalesce_flush(); return hip_ok(hipMemcpy(d, s, n, hipMemcpyDeviceToHost), "hipMemcpy(D2H)") ? 0 : -1; }
 LIBXSMM_API int libxsmm_hip_memset(void* d, int v, size_t n) { return hip_ok(hipMemset(d, v, n), "hipMemset") ? 0 : -1; }
 LIBXSMM_API int libxsmm_hip_probe_mfma(libxsmm_datatype datatype, const void* operands, int iterations, double* flop) {
   if (!runtime_ready() || g_dryrun || !operands || iterations <= 0 || (datatype != LIBXSMM_DATATYPE_BF16 && datatype != LIBXSMM_DATATYPE_F32)) return EXIT_FAILURE;

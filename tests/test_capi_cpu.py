@@ -217,3 +217,14 @@ def test_bcsc_builder_drops_zero_blocks_and_keeps_the_reference_layout(npdt, dtn
                 b += 1
     assert colptr[-1] == b
     assert api.hip_bcsc_from_dense(getattr(DT, dtname), dense.ctypes.data, K, N, 24, bn, C.byref(cp), C.byref(ri), C.byref(val), C.byref(nn)) != 0   # bk does not divide K
+
+
+def test_launch_modes_round_trip_without_a_device():
+    """0 blocking (the reference's semantics), 1 stream-ordered, 2 stream-ordered + coalescing (include/libxsmm_hip.h); anything else non-zero is 1."""
+    api = capi.load()
+    try:
+        for want, got in ((0, 0), (1, 1), (2, 2), (7, 1), (0, 0)):
+            api.hip_set_async(want)
+            assert api.hip_get_async() == got
+    finally:
+        api.hip_set_async(0)

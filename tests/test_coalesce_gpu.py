@@ -1,0 +1,111 @@
+"""The coalescing launch mode (libxsmm_hip_set_async(2), include/libxsmm_hip.h): the reference's calling pattern -- one small GEMM per call, the batch
+loop in the caller [ref: documentation/libxsmm_mm.md:95-107] -- runs as ONE batched launch, and a caller's dependent sequences keep their order."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, GEMM_FLAG as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "libxsmm_amd", "lib")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def loop_driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("loop") / "loop_driver")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "loop_driver.c"),
+           "-L" + LIBDIR, "-lxsmm_amd", "-lm", "-Wl,-rpath," + LIBDIR, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_the_callers_loop_over_4096_problems_is_one_launch_and_bit_identical(loop_driver, dtype):
+    out = {}
+    for mode in ("sync", "async", "coalesce"):
+        r = subprocess.run([loop_driver, "32", "4096", mode, "3", dtype], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out[mode]["bit_identical"] is True and out[mode]["error"] == 0
+    assert out["sync"]["launches_per_rep"] == 4096 and out["async"]["launches_per_rep"] == 4096
+    assert out["coalesce"]["launches_per_rep"] == 1
+    assert out["coalesce"]["us_per_call"] < out["async"]["us_per_call"] < out["sync"]["us_per_call"]
+    print(json.dumps(out))
+
+
+def _gemm(api, m, beta=0):
+    return api.dispatch_gemm(capi.gemm_shape(m, m, m, m, m, m, DT.F32, DT.F32, DT.F32, DT.F32), 0 if beta else F.BETA_0, 0)
+
+
+def _call(h, a, b, c):
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.c.primary = a, b, c
+    capi.Api.call(h, p)
+
+
+def test_dependent_calls_keep_their_order():
+    """C1 = A B; C2 = C1 B (reads what the queued call writes); C2 += A B twice (two calls into one C); a call through another handle in between."""
+    import torch
+    api = capi.load()
+    m = 32
+    rng = np.random.default_rng(5)
+    A = torch.from_numpy(rng.standard_normal((m, m)).astype(np.float32)).cuda()      # memory order [k][m]: a column-major m x k matrix
+    B = torch.from_numpy(rng.standard_normal((m, m)).astype(np.float32)).cuda()
+    C1 = torch.zeros((m, m), dtype=torch.float32, device="cuda"); C2 = torch.zeros_like(C1); C3 = torch.zeros_like(C1)
+    h0, h1 = _gemm(api, m, 0), _gemm(api, m, 1)
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    api.hip_set_async(2)
+    n0 = api.hip_launch_count(1)
+    _call(h0, A.data_ptr(), B.data_ptr(), C1.data_ptr())          # queued
+    _call(h0, C1.data_ptr(), B.data_ptr(), C2.data_ptr())         # reads C1: the queue is flushed first
+    _call(h1, A.data_ptr(), B.data_ptr(), C2.data_ptr())          # another handle, and it accumulates into C2
+    _call(h1, A.data_ptr(), B.data_ptr(), C2.data_ptr())          # the same C again: must not join the previous call's launch
+    _call(h0, A.data_ptr(), B.data_ptr(), C3.data_ptr())
+    _call(h0, A.data_ptr(), C3.data_ptr(), C3.data_ptr())         # reads and overwrites C3
+    api.hip_sync(); api.check()
+    assert api.hip_launch_count(0) == 6                           # nothing could be merged
+    Ad, Bd = A.cpu().numpy().astype(np.float64), B.cpu().numpy().astype(np.float64)
+    mm = lambda a, b: b @ a                                        # noqa: E731  column-major C = A B  <=>  memory-order (C^T) = (B^T)(A^T)
+    c1 = mm(Ad, Bd); c2 = mm(c1, Bd) + 2 * mm(Ad, Bd); c3 = mm(Ad, mm(Ad, Bd))
+    for got, ref in ((C1, c1), (C2, c2), (C3, c3)):
+        assert np.allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=1e-3)
+    api.hip_set_async(0); api.hip_set_stream(None)
+
+
+def test_independent_calls_merge_and_other_kernels_flush():
+    import torch
+    api = capi.load()
+    m, n = 16, 1000
+    rng = np.random.default_rng(6)
+    A = torch.from_numpy(rng.standard_normal((n, m, m)).astype(np.float32)).cuda()
+    B = torch.from_numpy(rng.standard_normal((n, m, m)).astype(np.float32)).cuda()
+    Cq = torch.zeros((n, m, m), dtype=torch.float32, device="cuda"); Cb = torch.zeros_like(Cq)
+    h = _gemm(api, m, 0)
+    p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = A.data_ptr(), B.data_ptr(), Cb.data_ptr()
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    api.hip_gemm_batch_strided(h, C.byref(p), n, m * m * 4, m * m * 4, m * m * 4)
+    api.hip_sync()
+    api.hip_set_async(2)
+    api.hip_launch_count(1)
+    order = rng.permutation(n)                                     # C in random order: no two overlap, they still merge
+    for i in order[: n // 2]:
+        _call(h, A[i].data_ptr(), B[i].data_ptr(), Cq[i].data_ptr())
+    # a TPP through another handle drains the queue (it may consume what the queued calls produce)
+    relu = api.dispatch_meltw_unary(capi.UNARY.RELU, capi.UnaryShape(m, m, m, m, DT.F32, DT.F32, DT.F32), 0)
+    up = capi.UnaryParam(); scratch = torch.zeros((m, m), dtype=torch.float32, device="cuda")
+    up.in_.primary, up.out.primary = Cq[int(order[0])].data_ptr(), scratch.data_ptr()
+    capi.Api.call(relu, up)
+    for i in order[n // 2:]:
+        _call(h, A[i].data_ptr(), B[i].data_ptr(), Cq[i].data_ptr())
+    api.hip_sync(); api.check()
+    assert api.hip_launch_count(0) == 3                            # two batched launches around the TPP
+    assert torch.equal(Cq, Cb)
+    assert torch.equal(scratch, torch.relu(Cb[int(order[0])]))
+    api.hip_set_async(0); api.hip_set_stream(None)

@@ -109,3 +109,49 @@ def test_section_rules():
     assert api.hip_pipeline_begin(2) != 0                                          # synchronous calls cannot overlap
     api.hip_clear_last_error()
     api.hip_set_async(1)
+
+
+def test_staged_host_lists_of_overlapping_launches_do_not_share_scratch():
+    """Advisor, round 3: the staging scratch for host-resident index arrays was rewound at every call, also inside a section -- launch N + 1 on lane 1 then
+    uploaded ITS offset list over the bytes launch N's kernel on lane 0 might not have read yet.  Eight OFFSET-BRGEMMs with eight DIFFERENT host offset
+    lists (plain numpy memory), issued back to back inside a section, must each use their own list."""
+    import torch
+    api = capi.load()
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    m, nbr, nblocks, launches = 32, 6, 64, 8
+    rng = np.random.default_rng(17)
+    blk = m * m * 4
+    A = torch.from_numpy(rng.standard_normal(nblocks * m * m).astype(np.float32)).cuda()
+    B = torch.from_numpy(rng.standard_normal(nblocks * m * m).astype(np.float32)).cuda()
+    Cs = [torch.zeros(m * m, dtype=torch.float32, device="cuda") for _ in range(launches)]
+    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, capi.DT.F32, capi.DT.F32, capi.DT.F32, capi.DT.F32), capi.GEMM_FLAG.BETA_0, 0, capi.br_config(capi.BR_OFFSET, 0, 0, 0))
+    assert h
+    offs = [((rng.permutation(nblocks)[:nbr]) * blk).astype(np.int64) for _ in range(launches)]      # host memory: staged by the library
+    offs_b = [((rng.permutation(nblocks)[:nbr]) * blk).astype(np.int64) for _ in range(launches)]
+    cnt = C.c_ulonglong(nbr)
+
+    def run(sectioned):
+        for c in Cs:
+            c.zero_()
+        torch.cuda.synchronize()
+        if sectioned:
+            assert api.hip_pipeline_begin(8) == 0
+        for i in range(launches):
+            p = capi.GemmParam()
+            p.a.primary, p.b.primary, p.c.primary = A.data_ptr(), B.data_ptr(), Cs[i].data_ptr()
+            p.a.secondary, p.b.secondary = offs[i].ctypes.data, offs_b[i].ctypes.data
+            p.op.tertiary = C.addressof(cnt)
+            capi.Api.call(h, p)
+        if sectioned:
+            assert api.hip_pipeline_end() == 0
+        api.hip_sync(); api.check()
+        return [c.cpu().numpy().copy() for c in Cs]
+    serial = run(False)
+    Ah, Bh = A.cpu().numpy().reshape(nblocks, m, m), B.cpu().numpy().reshape(nblocks, m, m)      # [k][m] and [n][k] in memory order
+    for i in range(launches):
+        ref = sum(Bh[offs_b[i][r] // blk].astype(np.float64) @ Ah[offs[i][r] // blk].astype(np.float64) for r in range(nbr))     # C^T[n][m] = B[n][k] A[k][m]
+        assert np.allclose(serial[i].reshape(m, m), ref, rtol=1e-4, atol=1e-4), i
+    for rep in range(20):                       # a race needs several tries to show
+        got = run(True)
+        for i in range(launches):
+            assert np.array_equal(got[i], serial[i]), (rep, i)
