@@ -667,13 +667,18 @@ def run_config5(args, api, dev, rank, world, dist, barrier):
         # the only collective of the path: the final result gather (RCCL over xGMI), timed on its own
         from libxsmm_amd import parallel
         shard = work.C[0].view(torch.uint8).view(mine, -1)              # bytes: RCCL has no 16-bit integer type; one row per problem
+        # RCCL: point-to-point, every source straight to rank 0 over its own link; any other backend (the one-GPU plumbing test under gloo): the C ABI's
+        # IPC gather (libxsmm_hip_ipc_export / libxsmm_hip_gather_shards) -- the root pulls every shard with one device copy per source
+        gather = parallel.gather_to_root if dist.get_backend() == "nccl" else parallel.gather_shards_ipc
         for _ in range(2):
-            parallel.gather_to_root(shard, args.total, root=0)          # point-to-point: every source straight to rank 0 over its own link
+            gather(shard, args.total, root=0)
         torch.cuda.synchronize(); barrier()
         t0 = time.perf_counter()
-        parallel.gather_to_root(shard, args.total, root=0)
+        full_c = gather(shard, args.total, root=0)
         torch.cuda.synchronize(); barrier()
         gather_ms = (time.perf_counter() - t0) * 1e3
+        if rank == 0:                                                   # the assembled result carries this rank's shard where shard_range says it lies
+            ok = ok and full_c is not None and full_c.shape[0] == args.total and bool(torch.equal(full_c[b.value:e.value], shard))
     if dist is not None:
         t = torch.tensor([elapsed, float(n), 0.0 if ok else 1.0], dtype=torch.float64, device=dev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -709,13 +714,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # One process per GPU: LOCAL_RANK is the device.  BENCH_DEVICE / BENCH_BACKEND exist for the plumbing test on a ONE-GPU box (tests/test_parallel_gloo.py:
+    # two ranks share device 0 behind a gloo group -- RCCL refuses two ranks on one device -- and the result gather goes through the C ABI's IPC gather).
+    devidx = int(os.environ.get("BENCH_DEVICE", local))
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(devidx)
+    dev = torch.device("cuda", devidx)
+    local = devidx
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":      # BENCH_FORCE_DIST: exercise the RCCL code path with one rank (1-GPU boxes)
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if dist is not None:

@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from helpers import GemmCase
 from libxsmm_amd import capi, parallel
 
@@ -247,3 +249,28 @@ def test_two_rank_split_of_the_packed_axes(kind):
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(2))
     assert results == {0: True, 1: True}
+
+
+@pytest.mark.gpu
+def test_bench_config5_two_ranks_end_to_end_on_one_device():
+    """The command the driver will run on an 8-GPU node -- `python -m torch.distributed.run ... bench.py --gpus N --config 5 --gather` -- end to end with
+    N = 2 on a ONE-GPU box: both ranks on device 0 behind a gloo group (BENCH_DEVICE / BENCH_BACKEND: RCCL refuses two ranks on one device), the result
+    gather through the C ABI's IPC gather.  What it pins: rank -> shard arithmetic (2 x 4096 of 8192 problems), the barrier + MAX-over-ranks timing,
+    ONE parseable compact line on stdout from rank 0 only, the gather fields, and that the assembled C carries rank 0's shard where shard_range puts it."""
+    import json
+    import subprocess
+    import sys
+    port = 34500 + (os.getpid() % 2000)
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--gather", "--total", "8192", "--steps", "3", "--warmup", "1", "--min-seconds", "0.05",
+           "--no-cpu-baseline", "--detail", ""]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 only, one line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "strong" and line["verified"] is True
+    assert line["config"]["problems_per_gpu_rank0"] == 4096 and "x2" in line["config"]["parallelism"]
+    assert line["gather_ms"] > 0 and line["gather_GBs_into_root"] > 0
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0
