@@ -444,6 +444,34 @@ def single_call_latency():
     return out
 
 
+def stale_profile_rows(measured):
+    """Every workload of this run against the committed rocprofv3 kernel-duration table (profiles/rNN_bench_kernel_stats.csv, the latest round): a row that is
+    missing, names another kernel, or whose average duration is more than 15 % away from what this run measured is reported -- the driver line's numbers must be
+    reproducible from profiles/ (round 3 shipped a variant-B row that predated the kernel's last change).  `measured`: {label: (kernel, us_per_launch)}."""
+    import csv
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    rows = {}
+    try:
+        for r in csv.DictReader(open(files[-1])):
+            rows[r["workload"]] = (r["kernel"], float(r["avg_us"]), float(r.get("events_us_in_process") or 0.0))
+    except Exception:
+        return None
+    stale = []
+    for label, (kernel, us) in measured.items():
+        if label not in rows:
+            stale.append(f"{label}: no row"); continue
+        k, avg, ev = rows[label]
+        base = lambda n: n.replace("xamd::", "").split("<")[0].split("(")[0].strip()      # noqa: E731
+        if base(k) != base(kernel):
+            stale.append(f"{label}: row is {base(k)}, ran {base(kernel)}"); continue
+        ref = ev if ev > 0 else avg                    # event time of the profiled run where the table has it (several kernels per launch: their sum)
+        if us > 0 and abs(ref - us) / us > 0.15:
+            stale.append(f"{label}: row {ref:.2f} us, measured {us:.2f} us")
+    return {"table": os.path.relpath(files[-1], ROOT), "stale": stale}
+
+
 def committed_counters(kernel, alg_bytes, label):
     """HBM traffic and MFMA-busy for this workload from the committed PMC passes (rocprofv3 --pmc cannot run inside this process:
     tools/profile_paths.sh runs THIS command under it in separate passes, tools/summarize_profiles.py distils profiles/)."""
@@ -618,6 +646,8 @@ def compact_line(full, detail_path):
     sc = full.get("single_call_us")
     if sc:
         line["single_call_us"] = [sc.get(k, {}).get("us_per_call") for k in ("sync", "async", "coalesce")]       # [blocking, stream-ordered, coalesced] per f32 32^3 call
+    if full.get("profiles_check"):
+        line["profiles_stale_rows"] = len(full["profiles_check"]["stale"])            # workloads whose committed rocprofv3 row does not reproduce this run (0 = all do)
     cb64 = full.get("cpu_baseline_f64")
     if cb64:
         line["cpu_baseline_f64"] = [cb64.get("value"), cb64.get("cores"), cb64.get("kind")]       # [GFLOP/s of the reference's f64 32^3 kernel, cores, kind]
@@ -890,6 +920,17 @@ def main():
             out["sweep"] = sweep
             out["reuse"] = reuse
             out["ragged"] = ragged
+        if sweep:
+            measured = {work.label(): (headline_kernel, kernel_us)}
+            for grp in (sweep, reuse, ragged, configs):
+                for k, r in grp.items():
+                    if isinstance(r, dict) and "us_per_launch" in r:
+                        measured[k] = (r.get("kernel", ""), r["us_per_launch"])
+            chk = stale_profile_rows(measured)
+            if chk is not None:
+                out["profiles_check"] = chk
+                for msg in chk["stale"]:
+                    print(f"bench.py: WARNING: {chk['table']} does not reproduce this run -- {msg} (re-run tools/profile_paths.sh)", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.m, args.dtype, args.br, args.beta, args.fused, args.cpu_seconds, nthreads)
             if sweep:

@@ -152,7 +152,7 @@ if mfma:
            "definition": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of SIMD-cycles of the launch in which the matrix pipe was busy "
                          "(the gfx94x MfmaUtil formula; GRBM_GUI_ACTIVE = cycles the GPU was active for the dispatch, longer than the un-profiled launch because counter collection adds set-up time: "
                          "mfma_busy_frac_unprofiled rescales the same busy cycles to the kernel duration of the trace pass at the clock observed here).  expected_mfma_cycles = the launch's MFMA instructions x their issue "
-                         "cycles (f32 32x32x2: 64, 16x16x4: 32; bf16 32x32x16: 32 per SIMD), a cross-check of the counter's unit.",
+                         "cycles (f32 32x32x2: 64, 16x16x4: 32; f64 16x16x4: 64; bf16 32x32x16: 32 = 16x16x32: 16 per SIMD; chosen by the kernel's name), a cross-check of the counter's unit.",
            "workloads": {}}
     for label, (e, seg) in mfma.items():
         if not seg:
@@ -161,8 +161,12 @@ if mfma:
         busy = sum(x[2].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for x in seg) / n
         gui = sum(x[2].get("GRBM_GUI_ACTIVE", 0.0) for x in seg) / n
         flops = e["flops_per_launch"]
-        per_mfma_flops, cyc = (4096.0, 64.0) if e["dtype"] == "f32" else (32768.0, 32.0)
-        expected = flops / per_mfma_flops * cyc
+        # flop per matrix-pipe cycle and SIMD by the KERNEL's MFMA (the manifest's dtype field defaults to f32 for the config workloads: round 3 priced the
+        # bf16 BCSC kernel's 16x16x32 MFMAs at the f32 rate and reported counter / expected = 0.062): f32 64, f64 32, bf16 / f16 1024 (32x32x16 in 32 cycles =
+        # 16x16x32 in 16), 8-bit 2048
+        kname = e.get("kernel", "")
+        rate = 32.0 if "f64" in kname else (2048.0 if ("i8" in kname or "fp8" in kname) else (1024.0 if ("bf16" in kname or "f16" in kname or e["dtype"] in ("bf16", "f16")) else 64.0))
+        expected = flops / rate
         us_pmc = sum(x[2].get("_us", 0.0) for x in seg) / n
         clock_ghz = min(2.4, gui / 8.0 / (us_pmc * 1e3)) if us_pmc > 0 else 0.0   # cycles per ns while the counters were on (GUI_ACTIVE also covers the
                                                                                    # dispatch set-up of a short launch, hence the cap at the 2.4 GHz maximum)
