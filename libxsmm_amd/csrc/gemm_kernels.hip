@@ -2028,6 +2028,110 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 GEMM in the OTHER operand forms the dense loop accepts [ref: gemm ref :2127-2170 (the loop), :2149-2161 (transposed / VNNI addressing), :2803-2815 (C in
+// VNNI)]: A flat (i contiguous, A[k * lda + i]) or transposed (k contiguous, A[i * lda + k]) instead of VNNI-2; B transposed (j contiguous, B[k * ldb + j]) or
+// transposed in VNNI-2 (dword (k pair, j) at [kp * ldb + j]) instead of flat; C optionally written in VNNI-2.  Until round 4 all of these ran on the exact VALU
+// kernel at 0.003 - 0.007 of the HBM roofline (measured: profiles/r04_forms_before.jsonl) against 0.74 for the VNNI-A / flat-B form.
+// One wave per 32 x 32 tile.  Per 32-deep chunk both operand tiles (2 KiB each) are fetched AS THEY LIE IN MEMORY -- whole 64- or 128-byte rows, 16 bytes per lane --
+// and parked in a wave-private LDS image of the same shape; the re-layout happens on the way OUT of the image, where it is free: a lane assembles its MFMA operand
+// (eight consecutive k of its row / column) with the access the form asks for
+//     k contiguous in the image (A transposed, B flat):      one ds_read_b128; the 16-byte slots of a row are XOR-swizzled by (row >> 2) & 3 (conflict free)
+//     VNNI-2 dwords (A VNNI, B transposed VNNI):             four ds_read_b32 down a column of the image (lanes along the row: conflict free)
+//     outer index contiguous (A flat, B transposed):         eight ds_read_u16 down a column, packed in pairs
+// No barrier (wave-private images); the next chunk's global loads are issued before the chunk's two MFMAs.  Any batch form, batch-reduce mode and epilogue of the
+// VNNI-A kernels (tile_init / tile_store); C in VNNI-2 with a plain epilogue.  m, n, k multiples of 32, 16-byte aligned rows.
+// ------------------------------------------------------------------------------------------------
+enum { AF_VNNI = 0, AF_FLAT = 1, AF_TRANS = 2, BF_FLAT = 0, BF_TRANS = 1, BF_TVNNI = 2 };
+// operand tile in its memory shape: FORM 0 = [32 outer][32 k] halves, k contiguous; 1 = [32 k][32 outer] halves, outer contiguous; 2 = [16 k pairs][32 outer] dwords
+template <int FORM> struct FormsTile {
+  static constexpr unsigned int row_bytes = FORM == 2 ? 128u : 64u, ppr = row_bytes / 16u;          // 16-byte pieces per row
+  __device__ static __forceinline__ unsigned int ld_bytes(unsigned int ld) { return FORM == 2 ? ld * 4u : ld * 2u; }
+  // byte offsets of the wave's tile inside the operand block: outer origin o0, chunk kc
+  __device__ static __forceinline__ unsigned long long origin(unsigned int ld, unsigned int o0, unsigned int kc) {
+    return FORM == 0 ? 2ull * o0 * ld + 64ull * kc : (FORM == 1 ? 2ull * o0 + 64ull * kc * ld : 4ull * o0 + 64ull * kc * ld);
+  }
+  __device__ static __forceinline__ void lane_offsets(unsigned int lane, unsigned int ld, unsigned int (&goff)[2], unsigned int (&loff)[2]) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const unsigned int P = lane + 64u * x, row = P / ppr, c16 = P % ppr;
+      goff[x] = row * ld_bytes(ld) + c16 * 16u;
+      loff[x] = row * row_bytes + ((FORM == 0 ? (c16 ^ ((row >> 2) & 3u)) : c16) * 16u);
+    }
+  }
+  // eight consecutive k (16 s + 8 h ..) of outer index o as the MFMA's 16-byte operand
+  __device__ static __forceinline__ u32x4 fragment(const char* img, unsigned int o, unsigned int s, unsigned int h) {
+    u32x4 f;
+    if constexpr (FORM == 0) f = *(const u32x4*)(img + o * 64u + (((2u * s + h) ^ ((o >> 2) & 3u)) * 16u));
+    else if constexpr (FORM == 2) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) f[d] = *(const unsigned int*)(img + (8u * s + 4u * h + d) * 128u + o * 4u);
+    } else {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned int k = 16u * s + 8u * h + 2u * d;
+        const unsigned int lo = *(const unsigned short*)(img + k * 64u + o * 2u), hi = *(const unsigned short*)(img + (k + 1u) * 64u + o * 2u);
+        f[d] = lo | (hi << 16);
+      }
+    }
+    return f;
+  }
+};
+template <int AF, int BF, bool VNNI_C>
+__global__ __launch_bounds__(256) void gemm_bf16_forms_kernel(GemmArgs p) {
+  // A forms -> tile shapes: VNNI = dword rows (2), flat = outer contiguous (1), transposed = k contiguous (0); B: flat = k contiguous (0), transposed = (1), transposed VNNI = (2)
+  using TA_ = FormsTile<AF == AF_VNNI ? 2 : (AF == AF_FLAT ? 1 : 0)>;
+  using TB_ = FormsTile<BF == BF_FLAT ? 0 : (BF == BF_TRANS ? 1 : 2)>;
+  __shared__ __attribute__((aligned(16))) char lds_all[4][2][2048];
+  const WaveJob job = wave_job(p, 32, 32);
+  if (!job.active) return;
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  char* ia = lds_all[wave][0]; char* ib = lds_all[wave][1];
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  f32x16 acc;
+  TileCtx tc; tc.i = job.i0 + (int)li; tc.j0 = job.j0; tc.h = (int)h; tc.ivalid = true;
+  if constexpr (VNNI_C) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  } else tile_init<true, false>(acc, p, q, tc);
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  unsigned int ga[2], la[2], gb[2], lb[2];
+  TA_::lane_offsets(lane, lda, ga, la); TB_::lane_offsets(lane, ldb, gb, lb);
+  const unsigned int kchunks = (unsigned int)p.k >> 5;
+  const unsigned long long total = p.br_count * kchunks;
+  gcptr ar = nullptr, br = nullptr;
+  if (p.br_count != 0) br_base(p, q, 0, ar, br);
+  u32x4 va[2], vb[2];
+  auto request = [&](unsigned int kc) {
+    gcptr at = ar + TA_::origin(lda, (unsigned int)job.i0, kc), bt = br + TB_::origin(ldb, (unsigned int)job.j0, kc);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { va[x] = *(GM const u32x4*)(at + ga[x]); vb[x] = *(GM const u32x4*)(bt + gb[x]); }
+  };
+  if (total != 0) request(0);
+  unsigned long long r = 0; unsigned int kc = 0;
+  for (unsigned long long t = 0; t < total; ++t) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) { *(u32x4*)(ia + la[x]) = va[x]; *(u32x4*)(ib + lb[x]) = vb[x]; }
+    u32x4 fa[2], fb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { fa[s] = TA_::fragment(ia, li, (unsigned int)s, h); fb[s] = TB_::fragment(ib, li, (unsigned int)s, h); }
+    if (++kc == kchunks) { kc = 0; if (++r < p.br_count) br_base(p, q, r, ar, br); }
+    if (t + 1 < total) request(kc);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc = mfma_16bit<false>(fb[s], fa[s], acc);
+  }
+  if constexpr (VNNI_C) {
+    // C in VNNI-2 [ref: gemm ref :2803-2815]: dword (j / 2, i) = (C(i, j), C(i, j + 1)); registers (2g, 2g + 1) of a lane are columns (j, j + 1), j even
+    GM unsigned int* c32 = (GM unsigned int*)q.c;
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) {
+      const unsigned int j = (unsigned int)job.j0 + (unsigned int)jl_of(2 * g2, (int)h);
+      st_stream(c32 + (unsigned long long)(j >> 1) * (unsigned int)p.ldc + (unsigned int)tc.i, cvt_pk_bf16(acc[2 * g2], acc[2 * g2 + 1]));
+    }
+  } else tile_store<true, false>(acc, p, q, tc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 64 x 64 x K problems (VNNI-2 A, flat B), one problem per WORKGROUP: the bf16 sibling of gemm_f32_wg64_kernel and the kernel of
 // BASELINE config #5.  gemm_bf16_stream_kernel<2,2> gives a wave the whole 64 x 64 tile and fetches A as 32 dword loads per lane; here the
 // four waves share the problem, BOTH operands of a 32-deep K step arrive by LDS-DMA (A: [16 k-pairs][64 rows] dwords = 4 KiB, linear;
@@ -3502,6 +3606,33 @@ static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64
   return mode;
 }
 // B columns 16-byte aligned, A rows dword aligned (always), every offset inside one tile below 4 GiB
+// the bf16 forms kernel: whole 32-tiles, every row of both operand tiles a 16-byte aligned 64- / 128-byte run, strided forms (alignment decidable here)
+static bool bf16_forms_ok(const GemmArgs& a, int& af, int& bf) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_FORMS"); return e && e[0] == '0'; }();
+  if (off || a.a_type != LIBXSMM_DATATYPE_BF16 || a.b_type != LIBXSMM_DATATYPE_BF16 || (a.c_type != LIBXSMM_DATATYPE_BF16 && a.c_type != LIBXSMM_DATATYPE_F32)) return false;
+  if ((a.m % 32) || (a.n % 32) || (a.k % 32) || a.k <= 0 || a.comp_f16) return false;
+  const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B, va = a.flags & LIBXSMM_GEMM_FLAG_VNNI_A, vb = a.flags & LIBXSMM_GEMM_FLAG_VNNI_B;
+  if ((va && ta) || (vb && !tb)) return false;
+  // (the reference packs k by A's VNNI factor: with a non-VNNI A the VNNI_B flag changes nothing, B is plainly transposed [ref: gemm ref :2134, :2157])
+  af = va ? AF_VNNI : (ta ? AF_TRANS : AF_FLAT); bf = !tb ? BF_FLAT : ((vb && va) ? BF_TVNNI : BF_TRANS);
+  if (a.vnni_c && (a.c_type != LIBXSMM_DATATYPE_BF16 || !(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) || a.colbias || a.act)) return false;
+  if (af == AF_VNNI && bf == BF_FLAT && !a.vnni_c) return false;                  // the fast form has its own kernels
+  if ((a.list_a && !a.lists_aligned16) || a.br_mode == 1 || a.br_mode == 2) return false;
+  unsigned long long bits = (unsigned long long)((long long)a.lda * (af == AF_VNNI ? 4 : 2)) | (unsigned long long)((long long)a.ldb * (bf == BF_TVNNI ? 4 : 2));
+  if (!a.list_a) bits |= (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b;
+  if (a.br_mode == 3) bits |= (unsigned long long)a.br_stride_a | (unsigned long long)a.br_stride_b;
+  if (bits & 15ull) return false;
+  if (a.vnni_c && ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 3ull) != 0)) return false;
+  return a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22);
+}
+template <int AF, int BF> static void launch_bf16_forms_b(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  if (a.vnni_c) hipLaunchKernelGGL((gemm_bf16_forms_kernel<AF, BF, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_bf16_forms_kernel<AF, BF, false>), grid, dim3(256), 0, st, a);
+}
+template <int AF> static void launch_bf16_forms_a(const GemmArgs& a, int bf, dim3 grid, hipStream_t st) {
+  if (bf == BF_FLAT) launch_bf16_forms_b<AF, BF_FLAT>(a, grid, st); else if (bf == BF_TRANS) launch_bf16_forms_b<AF, BF_TRANS>(a, grid, st); else launch_bf16_forms_b<AF, BF_TVNNI>(a, grid, st);
+}
+
 static bool bf16_stream_ok(const GemmArgs& a) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_STREAM"); return e && e[0] == '0'; }();
   if (off || a.list_a || a.br_mode == 1 || a.br_mode == 2) return false;
@@ -4057,6 +4188,14 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       return (int)hipGetLastError();
     }
   }
+  // bf16 in the other operand forms (flat / transposed A, transposed / VNNI B, VNNI C): operands re-laid out on the way out of a wave-private LDS image (round 4)
+  { int af = 0, bf = 0;
+    if (bf16_forms_ok(a, af, bf)) {
+      grid = wave_grid(32, 32);
+      if (kernel_name) *kernel_name = "gemm_bf16_forms_kernel";
+      if (af == AF_VNNI) launch_bf16_forms_a<AF_VNNI>(a, bf, grid, st); else if (af == AF_FLAT) launch_bf16_forms_a<AF_FLAT>(a, bf, grid, st); else launch_bf16_forms_a<AF_TRANS>(a, bf, grid, st);
+      return (int)hipGetLastError();
+    } }
   // IEEE halves take the bf16 fast paths when nothing but the product is asked for: beta = 0 (the reference adds beta * C AFTER the sum for halves),
   // f32 accumulation, f16 or f32 C, no fused operator
   const bool f16_fast = a.a_type == LIBXSMM_DATATYPE_F16 && a.b_type == LIBXSMM_DATATYPE_F16 && !a.comp_f16 && (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && !a.colbias && !a.act && !a.vnni_c &&

@@ -53,6 +53,34 @@ def blocked(api, dtype, m, ni, nj, br):
     return w
 
 
+def brgemm_form(api, m, batch, flags=0, a_dt=DT.BF16, c_dt=DT.BF16, name=""):
+    """The other operand forms the dense loop accepts [ref: src/generator_gemm_reference_impl.c:2127-2170, :2149-2161, :2803-2815]: bf16 with a flat (non-VNNI) or
+    transposed A, a transposed / VNNI B, a VNNI C; 8-bit floats with a result of their own type.  m = n = k, one problem per batch element, beta = 0;
+    algorithmic bytes = every operand and C once."""
+    es = capi.DT_SIZE[a_dt]
+    cs = capi.DT_SIZE[c_dt]
+    comp = DT.F32
+    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, a_dt, a_dt, c_dt, comp), flags | GEMM_FLAG.BETA_0, 0, capi.br_config(capi.BR_STRIDE, m * m * es, m * m * es, 0))
+    assert h, name
+    per = 2 * m * m * es + m * m * cs
+    ns = nsets_for(batch * per)
+    if es == 2:
+        mk = lambda n: rnd(n, "bf16")                                                       # noqa: E731
+    else:
+        mk = lambda n: torch.randint(0x30, 0x48, (n,), device=DEV, dtype=torch.uint8)       # noqa: E731  finite 8-bit floats of moderate size
+    As = [mk(batch * m * m) for _ in range(ns)]
+    Bs = [mk(batch * m * m) for _ in range(ns)]
+    Cs = [torch.zeros(batch * m * m * cs, device=DEV, dtype=torch.uint8) for _ in range(ns)]
+    brc = C.c_ulonglong(1)
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc); ps.append(p)
+    w = Work(api, f"stride-BRGEMM {name} m=n=k={m} batch={batch} br=1 beta=0", 2.0 * m ** 3 * batch, float(batch * per), ns,
+             lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, m * m * es, m * m * es, m * m * cs), lambda: api.hip_kernel_name(h, 1).decode())
+    w.keep = (As, Bs, Cs, ps, brc)
+    return w
+
+
 def brgemm_i8(api, m, batch, ua=True):
     """u8 x i8 -> i32 (VNNI-4 A), m = n = k: algorithmic bytes = 2*m*m (A, B) + 4*m*m (C) per problem."""
     at = DT.U8 if ua else DT.I8
@@ -446,6 +474,21 @@ def main():
         makers += [lambda: brgemm_i4(api, 64, 2 ** 17), lambda: brgemm_i4(api, 32, 2 ** 18), lambda: brgemm_mx4i8(api, 64, 2 ** 17), lambda: brgemm_mx4i8(api, 64, 2 ** 17, DT.F32),
                    lambda: brgemm_mxmx(api, 64, 2 ** 17, DT.MXHF6), lambda: brgemm_mxmx(api, 128, 2 ** 15, DT.MXHF6),
                    lambda: brgemm_lowbit(api, 64, 2 ** 17, DT.I2X4), lambda: brgemm_lowbit(api, 64, 2 ** 17, DT.I1X8)]
+    if "forms" in only:      # round 4: the remaining accepted dense forms, measured before / after they left the exact VALU kernel
+        F = GEMM_FLAG
+        nb = 2 ** 17
+        makers += [lambda: brgemm_form(api, 64, nb, F.VNNI_A, name="bf16 VNNI-A (the fast form)"),
+                   lambda: brgemm_form(api, 64, nb, 0, name="bf16 flat A"),
+                   lambda: brgemm_form(api, 64, nb, F.TRANS_A, name="bf16 TRANS_A"),
+                   lambda: brgemm_form(api, 64, nb, F.VNNI_A | F.TRANS_B, name="bf16 VNNI-A TRANS_B"),
+                   lambda: brgemm_form(api, 64, nb, F.VNNI_A | F.TRANS_B | F.VNNI_B, name="bf16 VNNI-A TRANS_B+VNNI_B"),
+                   lambda: brgemm_form(api, 64, nb, F.TRANS_A | F.TRANS_B, name="bf16 TRANS_A TRANS_B"),
+                   lambda: brgemm_form(api, 64, nb, F.VNNI_A | F.VNNI_C, name="bf16 VNNI-A VNNI_C"),
+                   lambda: brgemm_form(api, 64, nb, 0, c_dt=DT.F32, name="bf16 flat A -> f32"),
+                   lambda: brgemm_form(api, 64, nb, F.VNNI_A, a_dt=DT.BF8, c_dt=DT.BF8, name="bf8 -> bf8"),
+                   lambda: brgemm_form(api, 64, nb, F.VNNI_A, a_dt=DT.HF8, c_dt=DT.HF8, name="hf8 -> hf8"),
+                   lambda: brgemm_form(api, 40, nb * 2, F.VNNI_A, a_dt=DT.BF8, c_dt=DT.F32, name="bf8 -> f32 (40^3)"),
+                   lambda: brgemm_i8(api, 40, nb * 2, ua=True)]
     if "bitmask" in only:    # A compressed by bitmask: a pruned weight matrix times a few activations (round 3: no dense image)
         makers += [lambda: bitmask_gemm(api, 8192, 16, 8192, 0.5), lambda: bitmask_gemm(api, 8192, 64, 8192, 0.5), lambda: bitmask_gemm(api, 8192, 64, 8192, 0.9),
                    lambda: bitmask_gemm(api, 4096, 64, 4096, 0.5)]
