@@ -2843,7 +2843,13 @@ __global__ __launch_bounds__(256) void gemm_mx4i8_pipe_kernel(GemmArgs p, unsign
 // E5M2 = BF8): exact tiles, VNNI-4 A, flat B with 16-byte aligned columns, k % 64 == 0, f32 accumulate and output.
 // Structure = gemm_i8_stream_kernel; an MFMA consumes 16 k (8 bytes per lane and operand), four steps per 64-deep chunk.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, bool HF8>
+// C8: C in the operands' 8-bit type [ref: gemm ref :2511-2619]: beta * C comes in through the type, the f32 sum leaves through the reference's two-step
+// conversion f32 -> IEEE half (v_cvt_f16_f32: RNE; f32 denormals vanish either way) -> E5M2 / E4M3 (lowp.hpp, bit-identical to the reference's helpers).
+__device__ __forceinline__ unsigned char f32_to_fp8_ref(float x, bool hf8) {
+  const unsigned short hbits = __builtin_bit_cast(unsigned short, (_Float16)x);
+  return hf8 ? lowp::f16_to_hf8_rne(hbits) : lowp::f16_to_bf8_rne(hbits);
+}
+template <int MT, int NT, bool HF8, bool C8 = false>
 __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
@@ -2856,7 +2862,14 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
   static_for<MT * NT>([&](auto idx) {
     constexpr int mt = idx.value / NT, nt = idx.value % NT;
     tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h; tc[mt][nt].ivalid = true;
-    tile_init<true, true>(acc[mt][nt], p, q, tc[mt][nt]);
+    if constexpr (C8) {
+      const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long e = (long long)(tc[mt][nt].j0 + jl_of(r, h)) * p.ldc + tc[mt][nt].i;
+        acc[mt][nt][r] = beta0 ? 0.0f : (HF8 ? hf8_to_f32(((GM const unsigned char*)q.c)[e]) : bf8_to_f32(((GM const unsigned char*)q.c)[e]));
+      }
+    } else tile_init<true, true>(acc[mt][nt], p, q, tc[mt][nt]);
   });
   const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
   unsigned int offB[NT * 2], offBt[NT * 2];
@@ -2906,7 +2919,29 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
-  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<true, true>(acc[mt][nt], p, q, tc[mt][nt]); });
+  if constexpr (C8) {
+    // byte results through the wave's LDS image [32 NT columns][32 MT rows] and out as 16-byte pieces (64 byte stores per lane measured 0.27 of the roofline on
+    // 64^3 bf8 problems: the store instructions, not the bytes, were the bound); columns that are not 16-byte aligned in memory leave byte by byte
+    constexpr unsigned int pitch = 32u * MT;
+    static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ((unsigned char*)lds)[(32u * nt + (unsigned int)jl_of(r, h)) * pitch + 32u * mt + (unsigned int)li] = f32_to_fp8_ref(acc[mt][nt][r], HF8); });
+    GM unsigned char* ct = (GM unsigned char*)q.c + (long long)job.j0 * p.ldc + job.i0;
+    const bool wide = ((((unsigned long long)(size_t)ct) | (unsigned long long)p.ldc) & 15ull) == 0ull;        // wave-uniform
+    if (wide) {
+#pragma unroll
+      for (int x = 0; x < MT * NT; ++x) {
+        const unsigned int P = (unsigned int)lane + 64u * x, j = P / (pitch / 16u), c16 = P % (pitch / 16u);
+        *(GM u32x4*)(ct + (long long)j * p.ldc + c16 * 16u) = *(const u32x4*)(lds + j * pitch + c16 * 16u);
+      }
+    } else {
+      static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const unsigned int j = 32u * nt + (unsigned int)jl_of(r, h), i = 32u * mt + (unsigned int)li; ct[(long long)j * p.ldc + i] = ((const unsigned char*)lds)[j * pitch + i]; } });
+    }
+  } else {
+    static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<true, true>(acc[mt][nt], p, q, tc[mt][nt]); });
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3325,7 +3360,7 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     }
     return pl;
   }
-  if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && (b_type != a_type || c_type != LIBXSMM_DATATYPE_F32)) return pl;      // mixed operands / 8-bit C: generic kernel
+  if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && (b_type != a_type || (c_type != LIBXSMM_DATATYPE_F32 && c_type != a_type))) return pl;      // mixed operands: generic kernel (C of the operands' type: round 4)
   if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && va && !ta && !tb && !vb) {
     pl.path = (m > 32 && n > 32) ? P_FP8_2x2 : P_FP8_1x1;
     const int t = (pl.path == P_FP8_2x2) ? 64 : 32;
@@ -4394,10 +4429,18 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       if (ok) {
         const bool hf8 = a.a_type == LIBXSMM_DATATYPE_HF8, big = pl.path == P_FP8_2x2;
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
+        if (a.c_type != LIBXSMM_DATATYPE_F32) {            // C in the operands' type: plain epilogue only
+          if (a.colbias || a.act || a.vnni_c) goto fp8_generic;
+          if (kernel_name) *kernel_name = big ? "gemm_fp8c8_stream_kernel<2,2>" : "gemm_fp8c8_stream_kernel<1,1>";
+          if (big) { if (hf8) hipLaunchKernelGGL((gemm_fp8_stream_kernel<2, 2, true, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_fp8_stream_kernel<2, 2, false, true>), grid, dim3(256), 0, st, a); }
+          else { if (hf8) hipLaunchKernelGGL((gemm_fp8_stream_kernel<1, 1, true, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_fp8_stream_kernel<1, 1, false, true>), grid, dim3(256), 0, st, a); }
+          break;
+        }
         if (big) { if (hf8) hipLaunchKernelGGL((gemm_fp8_stream_kernel<2, 2, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_fp8_stream_kernel<2, 2, false>), grid, dim3(256), 0, st, a); }
         else { if (hf8) hipLaunchKernelGGL((gemm_fp8_stream_kernel<1, 1, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_fp8_stream_kernel<1, 1, false>), grid, dim3(256), 0, st, a); }
         break;
       }
+      fp8_generic:
       if (kernel_name) *kernel_name = "gemm_generic_kernel";
       const long long gblocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
       hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)gblocks), dim3(64, 4), 0, st, a);
