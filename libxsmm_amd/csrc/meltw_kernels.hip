@@ -318,6 +318,10 @@ __device__ __forceinline__ void ew8_store(gptr base, int type, long long idx, co
     *(GM u32x4e*)((GM unsigned short*)base + idx) = v;
   }
 }
+// Round 4, measured and NOT adopted (4096 x 8192 f32 copy 0.66, bf16 ReLU tiles 0.77 with this kernel): (a) four chunks per thread a grid apart with all loads
+// issued first, 16 bytes per lane for f32-only TPPs (whole-line accesses instead of two half-line ones): 0.60 / 0.70 -- fewer, longer-lived waves lose, as in the
+// ragged GEMM kernels (DESIGN decision 11); (b) the f32 transpose as 4 x 4 register blocks with 16-byte LDS traffic only (8 LDS instructions per thread instead
+// of 32): 0.595 against 0.604 -- LDS is not what holds the transposes at 0.9 of the copy's rate.
 template <int NIN>
 __global__ __launch_bounds__(256) void meltw_ew8_kernel(MeltwArgs p, unsigned int m8, unsigned int total) {
   const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
