@@ -474,19 +474,14 @@ __global__ __launch_bounds__(1024) void brsplit_reduce_kernel(GemmArgs p, const 
   if (valid) {
     GM const float* w = (GM const float*)partial + (long long)j * p.m + i;
     const long long stride = (long long)p.m * p.n;
-    // sixteen slabs per thread and trip, all their loads in flight before the first add; fixed order: deterministic.  (Round 4, rocprofv3 kernel trace of
-    // variant B at br = 4096: this kernel lasts 4.8 us on 256 slabs of 4 KiB whatever the load schedule -- four dependent rounds of four loads measured the
-    // same -- which is what ANY dependent kernel of a few workgroups costs behind a kernel boundary here (a 16-workgroup launch of 16^3 problems: 3.3 - 4.2 us).)
-    for (int s0 = threadIdx.y; s0 < nsplit; s0 += 256) {
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) { const int s = s0 + 16 * u; v[u] = s < nsplit ? w[s * stride] : 0.0f; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] += v[u + 8];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] += v[u + 4];
-      sum += (v[0] + v[2]) + (v[1] + v[3]);
-    }
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    int s = threadIdx.y;
+    for (; s + 48 < nsplit; s += 64) { c0 += w[s * stride]; c1 += w[(s + 16) * stride]; c2 += w[(s + 32) * stride]; c3 += w[(s + 48) * stride]; }
+    for (; s < nsplit; s += 16) c0 += w[s * stride];
+    sum = (c0 + c1) + (c2 + c3);
+    // (Round 4, rocprofv3 kernel trace of variant B at br = 4096: this kernel lasts 4.8 us on 256 slabs of 4 KiB; a form with sixteen slab loads in flight per
+    // thread measured the same there and slower on few large slabs -- 4.8 us is what ANY dependent kernel of a few workgroups costs behind a kernel
+    // boundary here: a 16-workgroup launch of 16^3 problems lasts 3.3 - 4.2 us.)
   }
   part[threadIdx.y][threadIdx.x] = sum;
   __syncthreads();

@@ -245,6 +245,8 @@ int launch_meltw(const MeltwArgs& args, void* stream, const char** kernel_name);
 int launch_mx_out_quant(const float* src, void* dst, void* scf, int m, int n, int ldc, int fp4, unsigned int nbatch, long long bs_dst, long long bs_scf, void* stream);
 int launch_bitmask_expand(const void* bitmap, const void* vals, void* dense, unsigned int* rows_scratch, int rows, int row_bytes, int elem_size, void* stream);
 int launch_gemm_bitmask16(const GemmArgs& args, const void* bitmap, unsigned int* scratch, size_t scratch_bytes, void* stream, const char** kernel_name, int* taken);
+size_t gemm_bitmask_reg_workspace(const GemmArgs& args);      // gemm_bitmask_kernels.hip (round 4): bytes of workspace of the register-expanding bitmask GEMM, 0 = shape not taken
+int launch_gemm_bitmask_reg(const GemmArgs& args, const void* bitmap, void* ws, size_t ws_bytes, void* stream, const char** kernel_name, int* taken);
 int launch_stochastic_bf8(const MeltwArgs& args, void* stream);     // second pass of a TPP with *_STOCHASTIC_ROUND: f32 results -> BF8
 bool meltw_supported(const libxsmm_meltw_descriptor& d);
 int launch_mfma_probe(int bf16, const void* operands, int iterations, void* stream, double* flop);

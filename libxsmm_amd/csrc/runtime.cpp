@@ -250,6 +250,20 @@ void copy_back_staged() {
 struct Workspace { void* base = nullptr; size_t cap = 0; int device = 0; ~Workspace() { retire_block(base); } };
 thread_local Workspace t_workspace[8];    // one per pipeline lane: launches that overlap must not share partial-result buffers ([0] outside a section)
 thread_local size_t t_ws_reserved = 0;   // front part owned by an enclosing call (the slots of a matrix equation around a GEMM node)
+void* workspace(size_t nbytes_wanted);
+// an OPTIONAL workspace (a fast path that has a fallback): a failed allocation is not an error of the call
+void* workspace_try(size_t nbytes_wanted) {
+  ThreadState& t = tls();
+  const int e0 = t.last_error; const std::string m0 = t.last_error_msg;
+  Workspace& w = t_workspace[t.pipe_lanes > 1 ? t.pipe_cur : 0];
+  if (nbytes_wanted + t_ws_reserved <= w.cap && w.device == cur_device()) return (char*)w.base + t_ws_reserved;
+  void* nb = nullptr;
+  const size_t ncap = std::max<size_t>(nbytes_wanted + t_ws_reserved, 4u << 20);
+  if (hipMalloc(&nb, ncap) != hipSuccess) { (void)hipGetLastError(); t.last_error = e0; t.last_error_msg = m0; return nullptr; }
+  if (w.base) retire_block(w.base);
+  w.base = nb; w.cap = ncap; w.device = cur_device();
+  return (char*)w.base + t_ws_reserved;
+}
 void* workspace(size_t nbytes_wanted) {
   Workspace& w = t_workspace[tls().pipe_lanes > 1 ? tls().pipe_cur : 0];
   const size_t nbytes = nbytes_wanted + t_ws_reserved;
@@ -415,6 +429,21 @@ static void run_gemm_bitmask(KernelCtx* k, const libxsmm_gemm_param* p, const Ba
     if (!bitmap || !vals || !a.b || !a.c) return;
   }
   const char* kname = nullptr;
+  // round 4: the expansion in registers (gemm_bitmask_kernels.hip).  The shape decides first, then exactly the workspace that shape needs is requested;
+  // an allocation that fails only loses the fast path (no sticky error: the other paths follow)
+  {
+    GemmArgs q{};
+    q.a = (const char*)vals; q.b = a.b; q.c = a.c;
+    q.nbatch = 1; q.m = (int)d.m; q.n = (int)d.n; q.k = (int)d.k; q.lda = (int)d.m; q.ldb = (int)d.ldb; q.ldc = (int)d.ldc;
+    q.flags = d.flags; q.a_type = d.a_type; q.b_type = d.b_type; q.c_type = d.c_type; q.br_count = 1; q.br_mode = 0;
+    const size_t need = gemm_bitmask_reg_workspace(q);
+    void* rws = need ? workspace_try(need) : nullptr;
+    if (rws) {
+      int taken = 0;
+      const int ferr = launch_gemm_bitmask_reg(q, bitmap, rws, need, tls().stream, &kname, &taken);
+      if (taken) { if (kname) k->kname_single = kname; finish_launch(ferr, kname); return; }
+    }
+  }
   // 16-bit operands: the fused kernel multiplies straight out of (non-zeros, bitmap): no dense image is written or read (round 3)
   {
     // counts / offsets per (bit row, tile of 128 rows), then room for the f32 partial tiles of up to 32 slices of k (fewer slices if the workspace is short)

@@ -256,5 +256,5 @@ def test_bitmask_compressed_a_large_exact():
     p.a.primary, p.a.secondary, p.b.primary, p.c.primary = dv.data_ptr(), db.data_ptr(), dB.data_ptr(), dC.data_ptr()
     capi.Api.call(h, p)
     api.hip_sync(); api.check()
-    assert api.hip_kernel_name(h, 0).decode() == "gemm_bitmask16_kernel"
+    assert api.hip_kernel_name(h, 0).decode() == "gemm_bitmask_reg_kernel"
     assert np.array_equal(dC.cpu().numpy(), ref)

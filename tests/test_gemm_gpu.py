@@ -629,7 +629,10 @@ def test_gemm_with_bitmask_compressed_a(where, a_type, c_type, m, n, k, ldb, ldc
         assert not np.any(sel(got))
     if a_type != DT.F32 and m % 16 == 0 and k % 64 == 0 and (ldb * 2) % 16 == 0:
         # 16-bit operands on whole 64-deep chunks: multiplied straight out of (non-zeros, bitmap), no dense image (round 3)
-        assert api.hip_kernel_name(h, 0).decode().startswith("gemm_bitmask16"), api.hip_kernel_name(h, 0)
+        name = api.hip_kernel_name(h, 0).decode()
+        assert name.startswith(("gemm_bitmask16", "gemm_bitmask_reg")), name
+        if m % 32 == 0 and k >= 256 and k % 16 == 0:            # round 4: expanded in registers (wave ballots), sixteen k-slices per workgroup
+            assert name == "gemm_bitmask_reg_kernel", name
     # batching such a kernel is refused: the operand size differs per problem
     api.hip_gemm_batch_strided(h, C.byref(p), 2, 0, 0, 0)
     assert api.hip_get_last_error() != 0
