@@ -1908,7 +1908,9 @@ LIBXSMM_API int libxsmm_hip_pipeline_begin(int lanes) {
     if (!hip_ok(hipStreamWaitEvent((hipStream_t)t.pipe_stream[i], (hipEvent_t)t.pipe_event[8], 0), "hipStreamWaitEvent(pipeline fork)")) return EXIT_FAILURE;
   // every lane gets a partial-result workspace as large as the thread's own BEFORE the section opens: a first hipMalloc inside the section would be
   // illegal while a graph is being captured (warm-up launches outside the section size lane 0)
-  for (int i = 1; i < lanes; ++i) {
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)t.pipe_user, &cap_status) != hipSuccess) { (void)hipGetLastError(); cap_status = hipStreamCaptureStatusNone; }
+  for (int i = 1; i < lanes && cap_status == hipStreamCaptureStatusNone; ++i) {        // (an allocation under capture would invalidate the capture: open a section once outside it to size the lanes)
     Workspace& w = t_workspace[i];
     if (w.base && w.device != cur_device()) { retire_block(w.base); w.base = nullptr; w.cap = 0; }
     if (w.cap < t_workspace[0].cap) {
