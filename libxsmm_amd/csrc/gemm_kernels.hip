@@ -2940,6 +2940,128 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8-bit operands of ANY shape on the matrix cores (round 4): what the two streaming kernels above refuse -- m / n that are not whole tiles (40^3 ...),
+// k % 32 != 0 (k % 4 == 0: a VNNI-4 quad of A is whole), operands that are not 16-byte aligned, pointer and offset lists.  These ran on the
+// one-element-per-thread kernel (0.006 / 0.02 of the HBM roofline on 40^3 problems).
+// KIND 0: u8 / i8 -> i32 on v_mfma_i32_32x32x32_i8 (integer sums: bit-exact in any order), 1: BF8, 2: HF8 on v_mfma_f32_32x32x16 (f32 sums).
+// Per 32-deep chunk a lane fetches four dwords (= four k-quads) of its row of A -- lanes run along i, so a load instruction covers whole 128-byte
+// rows of the VNNI-4 image -- and four dwords of its column of B.  A quad at or beyond k, a row beyond m, a column beyond n reads as ZERO, and the
+// unsigned -> signed shift of the integer kernel (see gemm_i8_stream_kernel) is applied to real elements only, so padding adds nothing to any sum.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int load_u32_any(gcptr p4) {          // a dword at any byte alignment
+  if ((((unsigned long long)(size_t)p4) & 3ull) == 0ull) return *(GM const unsigned int*)p4;
+  GM const unsigned char* b = (GM const unsigned char*)p4;
+  return (unsigned int)b[0] | ((unsigned int)b[1] << 8) | ((unsigned int)b[2] << 16) | ((unsigned int)b[3] << 24);
+}
+template <int MT, int NT, int KIND, bool UA, bool UB>
+__global__ __launch_bounds__(256) void gemm_mfma_8bit_kernel(GemmArgs p) {
+  constexpr bool INT = KIND == 0, HF8 = KIND == 2;
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  const bool c8 = !INT && p.c_type != LIBXSMM_DATATYPE_F32;          // 8-bit float C: wave-uniform
+  i32x16 iacc[INT ? MT : 1][INT ? NT : 1], sum_b[(INT && UA) ? NT : 1], sum_a[(INT && UB) ? MT : 1];
+  f32x16 facc[INT ? 1 : MT][INT ? 1 : NT];
+  TileCtx tc[MT][NT];
+  static_for<MT * NT>([&](auto idx) {
+    constexpr int mt = idx.value / NT, nt = idx.value % NT;
+    tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h; tc[mt][nt].ivalid = tc[mt][nt].i < p.m;
+    if constexpr (INT) iacc[mt][nt] = (i32x16)0;
+    else {
+      if (c8) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = tc[mt][nt].j0 + jl_of(r, h);
+          float v = 0.0f;
+          if (!beta0 && tc[mt][nt].ivalid && j < p.n) { const unsigned char x = ((GM const unsigned char*)q.c)[(long long)j * p.ldc + tc[mt][nt].i]; v = HF8 ? hf8_to_f32(x) : bf8_to_f32(x); }
+          facc[mt][nt][r] = v;
+        }
+      } else tile_init<false, true>(facc[mt][nt], p, q, tc[mt][nt]);
+    }
+  });
+  if constexpr (INT && UA) static_for<NT>([&](auto idx) { sum_b[idx.value] = (i32x16)0; });
+  if constexpr (INT && UB) static_for<MT>([&](auto idx) { sum_a[idx.value] = (i32x16)0; });
+  const i32x4 ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+  const int kquads = p.k >> 2, kchunks = (p.k + 31) >> 5;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    for (int kc = 0; kc < kchunks; ++kc) {
+      unsigned int aw[MT][4], bw[NT][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int kq = INT ? 8 * kc + 4 * h + e : 8 * kc + 4 * (e >> 1) + 2 * h + (e & 1);       // the k-quad of operand dword e (fp8: MFMA step e / 2)
+        const bool kok = kq < kquads;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int i = job.i0 + 32 * mt + li;
+          unsigned int v = 0u;
+          if (kok && i < p.m) { v = load_u32_any(ar + ((long long)kq * p.lda + i) * 4); if (INT && UA) v ^= 0x80808080u; }
+          aw[mt][e] = v;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int j = job.j0 + 32 * nt + li;
+          unsigned int v = 0u;
+          if (kok && j < p.n) { v = load_u32_any(br + (long long)j * p.ldb + 4ll * kq); if (INT && UB) v ^= 0x80808080u; }
+          bw[nt][e] = v;
+        }
+      }
+      if constexpr (INT) {
+        i32x4 af[MT], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = i32x4{(int)aw[mt][0], (int)aw[mt][1], (int)aw[mt][2], (int)aw[mt][3]};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = i32x4{(int)bw[nt][0], (int)bw[nt][1], (int)bw[nt][2], (int)bw[nt][3]};
+        static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+          iacc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[nt], af[mt], iacc[mt][nt], 0, 0, 0); });
+        if constexpr (UA) static_for<NT>([&](auto idx) { sum_b[idx.value] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[idx.value], ones, sum_b[idx.value], 0, 0, 0); });
+        if constexpr (UB) static_for<MT>([&](auto idx) { sum_a[idx.value] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ones, af[idx.value], sum_a[idx.value], 0, 0, 0); });
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+            const long a8 = (long)(((unsigned long long)aw[mt][2 * s + 1] << 32) | aw[mt][2 * s]), b8 = (long)(((unsigned long long)bw[nt][2 * s + 1] << 32) | bw[nt][2 * s]);
+            if (HF8) facc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b8, a8, facc[mt][nt], 0, 0, 0);
+            else facc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(b8, a8, facc[mt][nt], 0, 0, 0); });
+      }
+    }
+  }
+  if constexpr (INT) {
+    const bool c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+    const int kconst = (UA && UB) ? 16384 * (int)(p.br_count * (unsigned long long)p.k) : 0;
+    static_for<MT * NT>([&](auto idx) {
+      constexpr int mt = idx.value / NT, nt = idx.value % NT;
+      const TileCtx& t = tc[mt][nt];
+#pragma unroll
+      for (int r2 = 0; r2 < 16; ++r2) {
+        const int j = t.j0 + jl_of(r2, h);
+        if (!(t.ivalid && j < p.n)) continue;
+        int v = iacc[mt][nt][r2] + kconst;
+        if constexpr (UA) v += 128 * sum_b[nt][r2];
+        if constexpr (UB) v += 128 * sum_a[mt][r2];
+        GM char* cp = (GM char*)q.c + 4ll * ((long long)j * p.ldc + t.i);
+        if (c_f32) { float f = mul_rn((float)v, p.scf); if (!beta0) f = add_rn(f, *(GM const float*)cp); *(GM float*)cp = f; }
+        else { if (!beta0) v += *(GM const int*)cp; *(GM int*)cp = v; }
+      }
+    });
+  } else if (c8) {
+    static_for<MT * NT>([&](auto idx) {
+      constexpr int mt = idx.value / NT, nt = idx.value % NT;
+      const TileCtx& t = tc[mt][nt];
+#pragma unroll
+      for (int r2 = 0; r2 < 16; ++r2) {
+        const int j = t.j0 + jl_of(r2, h);
+        if (t.ivalid && j < p.n) ((GM unsigned char*)q.c)[(long long)j * p.ldc + t.i] = f32_to_fp8_ref(facc[mt][nt][r2], HF8);
+      }
+    });
+  } else {
+    static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<false, true>(facc[mt][nt], p, q, tc[mt][nt]); });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MXFP4 weight streaming kernel: A = packed E2M1 pairs + one E8M0 scale per (32-deep k-block, row), B bf16, exact tiles.
 // Structure = gemm_bf16_stream_kernel (B through LDS-DMA).  In this operand order a lane owns ONE row i of A, so the scale
 // of a k-block is one value per lane: v_cvt_scalef32_pk_bf16_fp4 turns a byte (two k of row i) into a scaled bf16 pair
@@ -3311,7 +3433,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
   return true;
 }
 
-enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2, P_MX4_1x1, P_MX4_2x2, P_MXMX_1x1, P_MXMX_2x2, P_MX4I8_1x1, P_MX4I8_2x2 };
+enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2, P_MX4_1x1, P_MX4_2x2, P_MXMX_1x1, P_MXMX_2x2, P_MX4I8_1x1, P_MX4I8_2x2, P_M8_1x1, P_M8_2x2 };
 struct GemmPlan { GemmPath path; bool exact; };
 
 static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, int b_type, int c_type, int vnni_c) {
@@ -3360,7 +3482,8 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     pl.path = (m > 32 && n > 32) ? P_FP8_2x2 : P_FP8_1x1;
     const int t = (pl.path == P_FP8_2x2) ? 64 : 32;
     pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
-    if (!pl.exact) pl.path = P_GENERIC;
+    if (!pl.exact && pl.path == P_FP8_2x2 && (m % 32 == 0) && (n % 32 == 0) && (k % 32 == 0)) { pl.path = P_FP8_1x1; pl.exact = true; }      // e.g. 96 x 64: whole 32 x 32 tiles
+    if (!pl.exact) pl.path = (k % 4 == 0) ? (pl.path == P_FP8_2x2 ? P_M8_2x2 : P_M8_1x1) : P_GENERIC;        // any shape with whole k-quads: the masked matrix-core kernel (round 4)
     return pl;
   }
   if ((a_type == LIBXSMM_DATATYPE_I4X2 || a_type == LIBXSMM_DATATYPE_U4X2) && (flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && va && !ta && !tb && !vb &&
@@ -3382,10 +3505,12 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     return pl;
   }
   if ((a_type == LIBXSMM_DATATYPE_I8 || a_type == LIBXSMM_DATATYPE_U8) && va && !ta && !tb && !vb) {
+    if (b_type != LIBXSMM_DATATYPE_I8 && b_type != LIBXSMM_DATATYPE_U8) return pl;
     pl.path = (m > 32 && n > 32) ? P_I8_2x2 : P_I8_1x1;
     const int t = (pl.path == P_I8_2x2) ? 64 : 32;
     pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
-    if (!pl.exact) pl.path = P_GENERIC;
+    if (!pl.exact && pl.path == P_I8_2x2 && (m % 32 == 0) && (n % 32 == 0) && (k % 32 == 0)) { pl.path = P_I8_1x1; pl.exact = true; }
+    if (!pl.exact) pl.path = (k % 4 == 0) ? (pl.path == P_I8_2x2 ? P_M8_2x2 : P_M8_1x1) : P_GENERIC;         // any shape with whole k-quads: the masked matrix-core kernel (round 4)
     return pl;
   }
   if ((a_type == LIBXSMM_DATATYPE_BF16 || (a_type == LIBXSMM_DATATYPE_F16 && b_type == LIBXSMM_DATATYPE_F16)) && va && !ta && !tb && !vb) {
@@ -3415,6 +3540,8 @@ static const char* path_name(GemmPath p) {
     case P_MX4_2x2: return "gemm_mxfp4_stream_kernel<2,2>";
     case P_MXMX_1x1: return "gemm_mx_stream_kernel<1,1>";
     case P_MXMX_2x2: return "gemm_mx_stream_kernel<2,2>";
+    case P_M8_1x1: return "gemm_mfma_8bit_kernel<1,1>";
+    case P_M8_2x2: return "gemm_mfma_8bit_kernel<2,2>";
     default: return "gemm_generic_kernel";
   }
 }
@@ -4230,7 +4357,34 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   // f32 accumulation, f16 or f32 C, no fused operator
   const bool f16_fast = a.a_type == LIBXSMM_DATATYPE_F16 && a.b_type == LIBXSMM_DATATYPE_F16 && !a.comp_f16 && (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && !a.colbias && !a.act && !a.vnni_c &&
     (a.c_type == LIBXSMM_DATATYPE_F16 || a.c_type == LIBXSMM_DATATYPE_F32);
+  // 8-bit operands on the masked matrix-core kernel: any shape with whole k-quads, any alignment, any batch-reduce form.  Returns false for what it does not
+  // take (C of an 8-bit float type together with a fused operator; more than 2^31 bytes inside one operand).
+  auto launch_m8 = [&](bool big) -> bool {
+    const bool fp8 = a.a_type == LIBXSMM_DATATYPE_BF8 || a.a_type == LIBXSMM_DATATYPE_HF8;
+    if (fp8 && a.c_type != LIBXSMM_DATATYPE_F32 && (a.colbias || a.act || a.vnni_c)) return false;
+    if ((a.k & 3) || a.k <= 0) return false;
+    grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
+    if (kernel_name) *kernel_name = big ? "gemm_mfma_8bit_kernel<2,2>" : "gemm_mfma_8bit_kernel<1,1>";
+    const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8;
+#define LAUNCH_M8_(MT_, NT_) do { \
+      if (fp8) { if (a.a_type == LIBXSMM_DATATYPE_HF8) hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 2, false, false>), grid, dim3(256), 0, st, a); \
+                 else hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 1, false, false>), grid, dim3(256), 0, st, a); } \
+      else if (!ua && !ub) hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 0, false, false>), grid, dim3(256), 0, st, a); \
+      else if (ua && !ub) hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 0, true, false>), grid, dim3(256), 0, st, a); \
+      else if (!ua && ub) hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 0, false, true>), grid, dim3(256), 0, st, a); \
+      else hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 0, true, true>), grid, dim3(256), 0, st, a); } while (0)
+    if (big) LAUNCH_M8_(2, 2); else LAUNCH_M8_(1, 1);
+#undef LAUNCH_M8_
+    return true;
+  };
   switch (pl.path) {
+    case P_M8_1x1: case P_M8_2x2: {
+      if (launch_m8(pl.path == P_M8_2x2)) break;
+      if (kernel_name) *kernel_name = "gemm_generic_kernel";
+      const long long gblocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
+      hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)gblocks), dim3(64, 4), 0, st, a);
+      break;
+    }
     case P_F32_T16: grid = wave_grid(16, 16); hipLaunchKernelGGL(gemm_mfma_f32_t16_kernel, grid, dim3(256), 0, st, a); break;
     case P_F32_1x1:
       grid = wave_grid(32, 32);
@@ -4436,6 +4590,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         break;
       }
       fp8_generic:
+      if (launch_m8(pl.path == P_FP8_2x2)) break;            // unaligned operands, pointer / offset lists: the masked matrix-core kernel
       if (kernel_name) *kernel_name = "gemm_generic_kernel";
       const long long gblocks = (long long)((a.m + 63) / 64) * ((a.n + 3) / 4) * (long long)a.nbatch;
       hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned int)gblocks), dim3(64, 4), 0, st, a);
@@ -4510,6 +4665,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
 #undef LAUNCH_I8_
         break;
       }
+      if (!i4 && !lowbit && launch_m8(pl.path == P_I8_2x2)) break;       // unaligned operands, pointer / offset lists: the masked matrix-core kernel
       if (kernel_name) *kernel_name = "gemm_generic_kernel";
     }
     // fallthrough

@@ -397,7 +397,17 @@ SHAPES_I8 = [
     dict(m=32, n=32, k=32, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, beta=1, batch=9),
     dict(m=64, n=64, k=96, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3, batch=4),
     dict(m=64, n=32, k=160, a_type=DT.I8, b_type=DT.U8, c_type=DT.F32, flags=F.VNNI_A, scf=0.25, beta=1, batch=2, lda=72, ldb=176, ldc=80),
-    dict(m=32, n=32, k=48, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A),                       # k % 32 != 0 -> generic
+    dict(m=32, n=32, k=48, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A),                       # k % 32 != 0: masked matrix-core kernel (round 4)
+    # round 4: shapes that are not whole tiles, operands that are not 16-byte aligned and pointer / offset lists on the masked matrix-core kernel, every signedness
+    dict(m=40, n=40, k=40, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, batch=7),
+    dict(m=40, n=40, k=40, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, beta=1, batch=5),
+    dict(m=40, n=40, k=40, a_type=DT.I8, b_type=DT.U8, c_type=DT.F32, flags=F.VNNI_A, scf=0.125, beta=1, batch=5),
+    dict(m=40, n=40, k=40, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3, batch=4),
+    dict(m=23, n=37, k=20, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, beta=1, lda=25, ldb=21, ldc=29, batch=3),        # B columns at odd byte addresses
+    dict(m=70, n=33, k=100, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, ldb=102, batch=2),
+    dict(m=32, n=32, k=64, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_ADDRESS, br_count=3, batch=1),
+    dict(m=64, n=64, k=64, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=4, beta=1, batch=1),
+    dict(m=32, n=32, k=64, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, ldb=68, batch=3),                                  # whole tiles, B columns 4-byte aligned only
 ]
 
 
@@ -409,8 +419,10 @@ def test_int8_gemm_is_bit_identical(kw):
     ref, _ = case.run_oracle()
     name = api.hip_kernel_name(handle, 1 if case.batch > 1 else 0).decode()
     assert np.array_equal(case.valid_region(ref), case.valid_region(got)), name
-    exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and (kw.get("flags", 0) & F.VNNI_A)
+    vnni = bool(kw.get("flags", 0) & F.VNNI_A)
+    exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and vnni and kw.get("ldb", 0) % 16 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
     assert ("gemm_i8_stream_kernel" in name) == bool(exact), name
+    assert ("gemm_mfma_8bit_kernel" in name) == bool(vnni and not exact and kw["k"] % 4 == 0), name          # nothing with whole k-quads is left on the one-element-per-thread kernel
     # unsupported combinations return NULL like the reference's dispatcher
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 64, 32, 64, 32, DT.I8, DT.I8, DT.I32, DT.I32), F.VNNI_A | F.TRANS_A, 0) is None
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 64, 32, 64, 32, DT.I8, DT.I8, DT.F32, DT.I32), 0, 0) is None      # f32 output needs VNNI-4 A
@@ -426,7 +438,13 @@ SHAPES_FP8 = [
     dict(m=32, n=32, k=32, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, batch=7),
     dict(m=64, n=64, k=96, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2, beta=1, batch=3),
     dict(m=64, n=32, k=160, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, batch=2, lda=72, ldb=176, ldc=80),
-    dict(m=17, n=9, k=12, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, ldc=20),       # generic kernel: bit-identical
+    dict(m=17, n=9, k=12, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, ldc=20),       # masked matrix-core kernel (round 4)
+    dict(m=40, n=40, k=40, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, batch=7),
+    dict(m=40, n=40, k=40, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, br_type=capi.BR_STRIDE, br_count=3, batch=4),
+    dict(m=23, n=37, k=20, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, lda=25, ldb=21, ldc=29, batch=3),
+    dict(m=70, n=33, k=100, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, ldb=102, batch=2),
+    dict(m=32, n=32, k=64, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_ADDRESS, br_count=3, batch=1),
+    dict(m=64, n=64, k=64, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=4, beta=1, batch=1),
     dict(m=12, n=10, k=7, a_type=DT.HF8, c_type=DT.F32),
     dict(m=13, n=11, k=8, a_type=DT.HF8, c_type=DT.F32, flags=F.TRANS_B),
 ]
@@ -439,9 +457,12 @@ def test_fp8_gemm_matches_oracle(kw):
     got, _, handle = case.run_gpu(batched=True)
     ref, _ = case.run_oracle()
     name = api.hip_kernel_name(handle, 1 if case.batch > 1 else 0).decode()
-    exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and (kw.get("flags", 0) & F.VNNI_A)
+    vnni = bool(kw.get("flags", 0) & F.VNNI_A)
+    exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and vnni and kw.get("ldb", 0) % 16 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
     assert ("gemm_fp8_stream_kernel" in name) == bool(exact), name
-    if exact:     # products of 8-bit floats are exact in f32; the reference's bound for f32 output (gemm_kernel.c:5408) holds
+    masked = vnni and not exact and kw["k"] % 4 == 0
+    assert ("gemm_mfma_8bit_kernel" in name) == bool(masked), name
+    if exact or masked:     # products of 8-bit floats are exact in f32; the reference's bound for f32 output (gemm_kernel.c:5408) holds
         assert normf_rel(case.valid_region(ref), case.valid_region(got), DT.F32) < TOL_F32, name
     else:
         assert np.array_equal(case.valid_region(ref), case.valid_region(got)), name
@@ -924,7 +945,7 @@ def test_more_gemm_types_bit_exact(t, m, n, k, lda, ldb, ldc, br, beta, batch):
     if t["a"] == DT.I8 and batch > 1 and br > 1:
         return                                    # scales step with the batch stride of A, which here spans br blocks: not the layout of this test
     name = api.hip_kernel_name(h, 1 if batch > 1 else 0).decode()
-    if name.startswith("gemm_fp8c8_stream_kernel"):
+    if name.startswith("gemm_fp8c8_stream_kernel") or (name.startswith("gemm_mfma_8bit_kernel") and t["c"] in (DT.BF8, DT.HF8)):
         # round 4: 8-bit floats with a result of their own type on the matrix cores (whole tiles).  The f32 sum is formed in the matrix core's order (the 16
         # products of a step are aligned before they are added), so a sum that sits on a rounding boundary of the 8-bit type may land on the neighbouring code
         key = lambda x: np.where(x.astype(np.int32) & 0x80, -(x.astype(np.int32) & 0x7f), x.astype(np.int32) & 0x7f)      # noqa: E731  sign-magnitude -> monotonic
