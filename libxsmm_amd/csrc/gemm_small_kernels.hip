@@ -110,6 +110,128 @@ __global__ __launch_bounds__(256) void gemm_bf16_p16w_kernel(GemmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Waves that WALK several problems (round 4, second form): the kernels above are one-shot waves -- pointers, one round trip to memory, a handful of
+// MFMAs, a store, exit -- so at 65 536 problems the chip launches 16 - 32 K waves that each spend their life waiting for ONE latency (0.76 / 0.68 of the
+// HBM roofline, f32 / bf16).  Here a wave owns `per_wave` consecutive steps (f32: a problem, bf16: a pair of problems) and runs them as a two-deep
+// software pipeline: the requests of step t + 1 (A by LDS-DMA into the other half of a two-slot image, B into the other register set) are issued
+// BEFORE the wait for step t, so a wave always has the next step's 1.5 - 3 KiB in flight while it multiplies and stores.  s_waitcnt counts this
+// wave's loads and stores in issue order: behind the loads of step t are the stores of step t - 1 and the loads of step t + 1.
+// One k-chunk and one batch-reduce block per problem (k == 16, br_count == 1): everything else keeps the one-shot kernels.
+// ------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// B travels by LDS-DMA as well: a load with a register destination inside the loop makes the compiler place its own (conservative: vmcnt(0) at the loop
+// head) wait in front of the MFMA, which ends the overlap.  With both operands in LDS every wait in the loop is the explicit one.
+// f32 : B image [16 columns][64 bytes]; the 16-byte piece g of column c sits in slot g ^ 2 (c >> 3): the four lanes of a ds_read_b128 lane group that
+//       share c mod 4 (same 16 banks) then read four different slots.
+// bf16: B image [16 columns][32 bytes] per problem; the 8-byte piece g of column c at byte (8 g) ^ 16 (c >> 3): lanes 0-31 of a ds_read_b64 hit 64 banks.
+template <int AUX>
+__global__ __launch_bounds__(256) void gemm_f32_p16s_kernel(GemmArgs p, unsigned int per_wave) {
+  __shared__ __attribute__((aligned(16))) float lds_all[4][2][512];                // per wave and slot: A image (1 KiB) | B image (1 KiB)
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int t0 = (blockIdx.x * 4u + wave) * per_wave;
+  if (t0 >= p.nbatch) return;
+  const unsigned int np = (p.nbatch - t0 < per_wave) ? p.nbatch - t0 : per_wave;
+  const unsigned int lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const unsigned int pos = lane >> 2;
+  const unsigned int vA = ((pos ^ ((pos >> 2) & 1u)) * lda + (lane & 3u) * 4u) * 4u;
+  const unsigned int vB = (pos * ldb + 4u * ((lane & 3u) ^ ((pos >> 3) << 1))) * 4u;     // DMA lane = (column pos, slot lane & 3)
+  const unsigned int rB = 256u + x * 16u + 4u * (g ^ ((x >> 3) << 1));                    // dword index of this lane's B operand inside a slot
+  const unsigned long long vC = ((unsigned long long)x * (unsigned int)p.ldc + 4u * g) * 4ull;
+  gptr cq[2];
+  auto issue = [&](auto sc, unsigned int t) __attribute__((always_inline)) {
+    constexpr int S = decltype(sc)::value;
+    const long long e = (long long)(t0 + t);                                        // plain strided 1-D batch, one block per problem (the launcher checks)
+    __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.a + e * p.bs_a + vA), (lds_vptr)lds_all[wave][S], 16, 0, AUX);
+    __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.b + e * p.bs_b + vB), (lds_vptr)(lds_all[wave][S] + 256), 16, 0, AUX);
+    cq[S] = (gptr)p.c + e * p.bs_c;
+  };
+  auto step = [&](auto sc, unsigned int t) __attribute__((always_inline)) {
+    constexpr int S = decltype(sc)::value;
+    const bool more = t + 1u < np;
+    if (more) issue(std::integral_constant<int, S ^ 1>{}, t + 1u);
+    // younger than this step's two requests: the store of the step before and the next step's two requests
+    if (t == 0u) { if (more) wait_vm<2>(); else wait_vm<0>(); }
+    else { if (more) wait_vm<3>(); else wait_vm<1>(); }
+    const float* img = lds_all[wave][S];
+    float af[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) af[s] = img[((4u * g + s) ^ (g & 1u)) * 16u + x];
+    const f32x4 bv = *(const f32x4*)(img + rB);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x4 acc = (f32x4)0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bv[s], acc, 0, 0, 0);
+    st_stream((GM f32x4*)(cq[S] + vC), acc);
+  };
+  issue(std::integral_constant<int, 0>{}, 0u);
+  for (unsigned int t = 0; t < np; t += 2u) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t + 1u < np) step(std::integral_constant<int, 1>{}, t + 1u);
+  }
+}
+
+template <int AUX>
+__global__ __launch_bounds__(256) void gemm_bf16_p16s_kernel(GemmArgs p, unsigned int per_wave) {
+  __shared__ __attribute__((aligned(16))) unsigned int lds_all[4][2][512];         // per wave and slot: A images of the pair (2 x 512 B) | B images (2 x 512 B)
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int npairs = (p.nbatch + 1u) / 2u;
+  const unsigned int t0 = (blockIdx.x * 4u + wave) * per_wave;                      // in pairs of problems
+  if (t0 >= npairs) return;
+  const unsigned int np = (npairs - t0 < per_wave) ? npairs - t0 : per_wave;
+  const unsigned int lane = threadIdx.x & 63u, x = lane & 15u, g = lane >> 4;
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const unsigned int l5 = lane & 31u, pos = l5 >> 2, col = l5 >> 1;
+  const unsigned int vA = ((pos ^ ((pos >> 1) & 1u)) * lda + (l5 & 3u) * 4u) * 4u;
+  const unsigned int vB = col * ldb * 2u + 16u * ((l5 & 1u) ^ (col >> 3));             // DMA lane = (problem lane >> 5, column col, half l5 & 1)
+  const unsigned int rB = 256u + x * 8u + ((2u * g) ^ (4u * (x >> 3)));                // dword index of this lane's 8 bytes of B inside a slot (problem 0)
+  const bool c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+  const unsigned long long vC = ((unsigned long long)x * (unsigned int)p.ldc + 4u * g) * (c_f32 ? 4ull : 2ull);
+  gptr cq[2][2]; bool two[2];
+  auto issue = [&](auto sc, unsigned int t) __attribute__((always_inline)) {
+    constexpr int S = decltype(sc)::value;
+    const unsigned int first = 2u * (t0 + t);
+    two[S] = first + 1u < p.nbatch;
+    const long long e0 = (long long)first, e1 = (long long)(two[S] ? first + 1u : first);     // plain strided 1-D batch, one block per problem (the launcher checks)
+    const long long emine = (lane >> 5) ? e1 : e0;                                  // the upper half-wave fetches the pair's second problem
+    __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.a + emine * p.bs_a + vA), (lds_vptr)lds_all[wave][S], 16, 0, AUX);
+    __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.b + emine * p.bs_b + vB), (lds_vptr)(lds_all[wave][S] + 256), 16, 0, AUX);
+    cq[S][0] = (gptr)p.c + e0 * p.bs_c; cq[S][1] = (gptr)p.c + e1 * p.bs_c;
+  };
+  auto step = [&](auto sc, unsigned int t) __attribute__((always_inline)) {
+    constexpr int S = decltype(sc)::value;
+    const bool more = t + 1u < np;
+    if (more) issue(std::integral_constant<int, S ^ 1>{}, t + 1u);
+    // younger than this step's two requests: the two stores of the step before (a pair that is not the last one is always whole) and the next step's two requests
+    if (t == 0u) { if (more) wait_vm<2>(); else wait_vm<0>(); }
+    else { if (more) wait_vm<4>(); else wait_vm<2>(); }
+    const unsigned int* img = lds_all[wave][S];
+    u32x2_t av[2], bv[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) av[pp][e] = img[pp * 128u + ((2u * g + e) ^ (g & 1u)) * 16u + x];
+      bv[pp] = *(const u32x2_t*)(img + rB + pp * 128u);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4_t, av[pp]), __builtin_bit_cast(bf16x4_t, bv[pp]), (f32x4)0.0f, 0, 0, 0);
+      if (pp == 0 || two[S]) {
+        if (c_f32) st_stream((GM f32x4*)(cq[S][pp] + vC), acc);
+        else { u32x2_t v; v[0] = small_cvt_pk_bf16(acc[0], acc[1]); v[1] = small_cvt_pk_bf16(acc[2], acc[3]); st_stream((GM u32x2_t*)(cq[S][pp] + vC), v); }
+      }
+    }
+  };
+  issue(std::integral_constant<int, 0>{}, 0u);
+  for (unsigned int t = 0; t < np; t += 2u) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t + 1u < np) step(std::integral_constant<int, 1>{}, t + 1u);
+  }
+}
+
 // 16-byte aligned A rows on top of launch_gemm's p16_ok (B, C and the strided forms are checked there); *taken = 0: the caller's older kernel serves
 int launch_gemm_p16w(const GemmArgs& a, bool nt, void* stream, const char** kernel_name, int* taken) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_P16W"); return e && e[0] == '0'; }();
@@ -120,6 +242,25 @@ int launch_gemm_p16w(const GemmArgs& a, bool nt, void* stream, const char** kern
   if (off || (abits & 15ull) || a.lda >= (1 << 22) || a.ldb >= (1 << 22) || a.ldc >= (1 << 22)) return 0;
   hipStream_t st = (hipStream_t)stream;
   *taken = 1;
+  // waves that walk `per_wave` steps (a problem / a pair of problems) as a two-deep pipeline: single-block 16^3 problems, launches that keep at least ~8 K waves
+  // (LIBXSMM_HIP_P16_PW = 0 switches the form off, N forces N steps per wave)
+  static const int pw_env = []() { const char* e = getenv("LIBXSMM_HIP_P16_PW"); return e ? atoi(e) : -1; }();
+  const unsigned long long bbits16 = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)((long long)a.ldb * (bf16 ? 2 : 4));
+  if (pw_env != 0 && a.k == 16 && a.br_count == 1 && !a.batch_inner && !a.list_a && (bbits16 & 15ull) == 0) {
+    const unsigned int steps = bf16 ? (a.nbatch + 1u) / 2u : a.nbatch;
+    unsigned int pw = pw_env > 0 ? (unsigned int)pw_env : (steps >= 65536u ? 8u : steps >= 32768u ? 4u : steps >= 16384u ? 2u : 1u);
+    if (pw > 1u) {
+      const dim3 grid((unsigned int)(((steps + pw - 1u) / pw + 3u) / 4u));
+      if (bf16) {
+        if (kernel_name) *kernel_name = "gemm_bf16_p16s_kernel";
+        if (nt) hipLaunchKernelGGL((gemm_bf16_p16s_kernel<2>), grid, dim3(256), 0, st, a, pw); else hipLaunchKernelGGL((gemm_bf16_p16s_kernel<0>), grid, dim3(256), 0, st, a, pw);
+      } else {
+        if (kernel_name) *kernel_name = "gemm_f32_p16s_kernel";
+        if (nt) hipLaunchKernelGGL((gemm_f32_p16s_kernel<2>), grid, dim3(256), 0, st, a, pw); else hipLaunchKernelGGL((gemm_f32_p16s_kernel<0>), grid, dim3(256), 0, st, a, pw);
+      }
+      return (int)hipGetLastError();
+    }
+  }
   if (bf16) {
     if (kernel_name) *kernel_name = "gemm_bf16_p16w_kernel";
     const dim3 grid((unsigned int)(((a.nbatch + 1u) / 2u + 3u) / 4u));

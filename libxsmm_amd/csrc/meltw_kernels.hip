@@ -670,6 +670,49 @@ __global__ __launch_bounds__(256) void vnni2_pair_kernel(MeltwArgs p, unsigned i
   out[gid] = lo | (hi << 16);
 }
 
+// The same transform, FOUR output dwords per thread (round 4): the pair kernel moves 4 bytes per memory instruction (0.37 of the HBM roofline on 4090 x 8192);
+// here a thread owns positions i0 .. i0 + 3 of one row pair and uses the widest access the addresses allow -- the even row of a pair starts 4-byte aligned
+// whatever ldi is (2 * 2 jb * ldi bytes), the odd row when ldi is even; 8-byte loads when the row offset allows; the four output dwords leave as one 16-byte,
+// two 8-byte or four 4-byte stores.  The alignment cases are the same for all lanes of a row, so the branches are (nearly) wave-uniform.
+__device__ __forceinline__ void load4_u16(GM const unsigned short* src, unsigned int valid, unsigned int (&v)[4]) {
+  v[0] = v[1] = v[2] = v[3] = 0u;
+  if (valid == 0u) return;
+  const unsigned long long a = (unsigned long long)(size_t)src;
+  if (valid >= 4u && (a & 7ull) == 0ull) {
+    const unsigned long long w = *(GM const unsigned long long*)src;
+    v[0] = (unsigned int)(w & 0xffffu); v[1] = (unsigned int)((w >> 16) & 0xffffu); v[2] = (unsigned int)((w >> 32) & 0xffffu); v[3] = (unsigned int)(w >> 48);
+  } else if (valid >= 4u && (a & 3ull) == 0ull) {
+    const unsigned int w0 = ((GM const unsigned int*)src)[0], w1 = ((GM const unsigned int*)src)[1];
+    v[0] = w0 & 0xffffu; v[1] = w0 >> 16; v[2] = w1 & 0xffffu; v[3] = w1 >> 16;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if ((unsigned int)e < valid) v[e] = src[e];
+  }
+}
+__global__ __launch_bounds__(256) void vnni2_quad_kernel(MeltwArgs p, unsigned int q4, unsigned int per_batch) {
+  typedef unsigned int u32x2q __attribute__((ext_vector_type(2)));
+  const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= per_batch) return;
+  const unsigned int jb = gid / q4, i0 = (gid - jb * q4) * 4u, ldo = (unsigned int)p.ldo, m = (unsigned int)p.m;
+  GM const unsigned short* in = (GM const unsigned short*)((gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0);
+  GM unsigned int* out = (GM unsigned int*)((gptr)p.out + (long long)blockIdx.y * p.bs_out) + (long long)jb * ldo + i0;
+  const unsigned int valid = i0 < m ? (m - i0 < 4u ? m - i0 : 4u) : 0u;
+  unsigned int lo[4], hi[4];
+  load4_u16(in + (long long)(2u * jb) * p.ldi + i0, valid, lo);
+  load4_u16(in + (long long)(2u * jb + 1u) * p.ldi + i0, (2u * jb + 1u < (unsigned int)p.n) ? valid : 0u, hi);
+  u32x4e o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = lo[e] | (hi[e] << 16);
+  const unsigned int nout = ldo - i0 < 4u ? ldo - i0 : 4u;
+  const unsigned long long oa = (unsigned long long)(size_t)out;
+  if (nout == 4u && (oa & 15ull) == 0ull) *(GM u32x4e*)out = o;
+  else if (nout == 4u && (oa & 7ull) == 0ull) { u32x2q a2 = {o[0], o[1]}, b2 = {o[2], o[3]}; *(GM u32x2q*)out = a2; *(GM u32x2q*)(out + 2) = b2; }
+  else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if ((unsigned int)e < nout) out[e] = o[e];
+  }
+}
+
 // gather / scatter [ref: :1444-1790]; lanes along the contiguous (i) axis where there is one
 template <int S>
 __global__ __launch_bounds__(256) void gather_scatter_kernel(MeltwArgs p) {
@@ -1596,9 +1639,16 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       hipLaunchKernelGGL(vnni2_vec_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, a, o8, total);
       if (name) *name = "vnni2_vec_kernel";
     } else if (mode == XF_NORM_TO_VNNI && v == 2 && sz == 2 && !xvec_off && (((size_t)a.out | (size_t)a.bs_out) % 4) == 0 && (long long)a.ldo * ((a.n + 1) / 2) < (1ll << 31) && a.nbatch < 65536) {
+      static const bool quad_off = []() { const char* e = getenv("LIBXSMM_HIP_VNNI2_QUAD"); return e && e[0] == '0'; }();
+      if (!quad_off && a.ldo >= 16 && (((size_t)a.in0 | (size_t)a.bs_in0) % 2) == 0) {          // four positions per thread (rows of at least a few threads)
+        const unsigned int q4 = ((unsigned int)a.ldo + 3u) / 4u, per_q = q4 * (unsigned int)((a.n + 1) / 2);
+        hipLaunchKernelGGL(vnni2_quad_kernel, dim3((per_q + 255u) / 256u, a.nbatch), dim3(256), 0, st, a, q4, per_q);
+        if (name) *name = "vnni2_quad_kernel";
+      } else {
       const unsigned int per_batch = (unsigned int)a.ldo * (unsigned int)((a.n + 1) / 2);
       hipLaunchKernelGGL(vnni2_pair_kernel, dim3((per_batch + 255u) / 256u, a.nbatch), dim3(256), 0, st, a, per_batch);
       if (name) *name = "vnni2_pair_kernel";
+      }
     } else if (mode == XF_NORM_TO_VNNI && v == 4 && sz == 1 && !xvec_off && base16 && a.m % 4 == 0 && a.ldi % 4 == 0 && a.ldo % 4 == 0 &&
                (long long)(a.ldo / 4) * ((a.n + 3) / 4) * a.nbatch < (1ll << 32) - 256) {
       const unsigned int o4 = (unsigned int)(a.ldo / 4), total = o4 * (unsigned int)((a.n + 3) / 4) * (unsigned int)a.nbatch;

@@ -106,7 +106,15 @@ def test_headline_shape_uses_mfma_tile_kernel():
     _check(GemmCase(16, 16, 16, batch=67, seed=2, lda=18), expect_kernel="gemm_f32_p16_kernel")   # A rows not 16-byte aligned: the round-2 kernel (dword loads of A)
     _check(GemmCase(16, 16, 16, batch=64, seed=2, beta=1), expect_kernel="t16")                 # beta = 1: the general 16x16-tile kernel
     _check(GemmCase(16, 16, 32, batch=67, seed=2, br_type=capi.BR_STRIDE, br_count=3), expect_kernel="gemm_f32_p16w_kernel")
-    _check(GemmCase(16, 16, 16, batch=70001, seed=2), expect_kernel="gemm_f32_p16w_kernel")
+    _check(GemmCase(16, 16, 16, batch=16001, seed=2), expect_kernel="gemm_f32_p16w_kernel")
+    # round 4, second form: from 16 384 steps on a wave walks several problems as a two-deep pipeline (both operands by LDS-DMA); odd counts leave short last waves
+    _check(GemmCase(16, 16, 16, batch=70001, seed=2), expect_kernel="gemm_f32_p16s_kernel")        # 8 problems per wave
+    _check(GemmCase(16, 16, 16, batch=16387, seed=5, ldb=20, ldc=24), expect_kernel="gemm_f32_p16s_kernel")      # 2 per wave, padded B / C columns
+    _check(GemmCase(16, 16, 16, batch=40003, seed=6, lda=20), expect_kernel="gemm_f32_p16s_kernel")              # 4 per wave, padded A rows
+    _check(GemmCase(16, 16, 16, batch=16390, seed=7, ldb=18), expect_kernel="gemm_f32_p16w_kernel")              # B columns not 16-byte aligned: one-shot waves
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=131073, seed=2), expect_kernel="gemm_bf16_p16s_kernel")   # 8 pairs per wave, the last pair a single problem
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, batch=32771, seed=8, ldb=24, ldc=20), expect_kernel="gemm_bf16_p16s_kernel")
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=70002, seed=9, lda=20), expect_kernel="gemm_bf16_p16s_kernel")
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=64, seed=2), expect_kernel="gemm_bf16_p16w_kernel")     # two problems per wave
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=20001, seed=2), expect_kernel="gemm_bf16_p16w_kernel")  # odd count: the last wave has one
     _check(GemmCase(16, 16, 48, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, batch=33, seed=3, br_type=capi.BR_STRIDE, br_count=2), expect_kernel="gemm_bf16_p16w_kernel")

@@ -144,6 +144,10 @@ TRANSFORMS = [
     (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F32, 128, 96, 128, 96), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F32, 68, 200, 72, 208),
     (UNARY.TRANSFORM_NORM_TO_NORMT, DT.BF16, 72, 40, 80, 48), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.F64, 66, 10, 66, 12), (UNARY.TRANSFORM_NORM_TO_NORMT, DT.I8, 80, 32, 96, 32),
     (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 64, 7, 64, 72), (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 136, 130, 144, 136),
+    # any leading dimensions, four positions per thread (round 4): ldi even / odd (odd rows 4- / 2-byte aligned), ldo % 4 in 0..3 (16- / 8- / 4-byte stores, short last
+    # thread of a row), m < ldo (zero-filled positions), odd n (zero-filled pad row)
+    (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 70, 9, 74, 78), (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 61, 10, 63, 67), (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 33, 5, 36, 37),
+    (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 100, 12, 100, 100), (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 47, 6, 47, 50), (UNARY.TRANSFORM_NORM_TO_VNNI2, DT.BF16, 18, 4, 19, 21),
     # NORM -> VNNI4 of 8-bit payloads, vector kernel: n a multiple of 4, n with 1 / 2 / 3 rows missing (zero-filled), ldo > m (zero-filled columns)
     (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.I8, 64, 16, 64, 64), (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.I8, 132, 13, 136, 140), (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.I8, 16, 6, 16, 16),
     (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.BF8, 256, 35, 256, 260), (UNARY.TRANSFORM_NORM_TO_VNNI4, DT.HF8, 20, 12, 24, 20),
