@@ -2840,10 +2840,20 @@ __global__ __launch_bounds__(256) void gemm_mx4i8_pipe_kernel(GemmArgs p, unsign
 // ------------------------------------------------------------------------------------------------
 // C8: C in the operands' 8-bit type [ref: gemm ref :2511-2619]: beta * C comes in through the type, the f32 sum leaves through the reference's two-step
 // conversion f32 -> IEEE half (v_cvt_f16_f32: RNE; f32 denormals vanish either way) -> E5M2 / E4M3 (lowp.hpp, bit-identical to the reference's helpers).
-__device__ __forceinline__ unsigned char f32_to_fp8_ref(float x, bool hf8) {
-  const unsigned short hbits = __builtin_bit_cast(unsigned short, (_Float16)x);
-  return hf8 ? lowp::f16_to_hf8_rne(hbits) : lowp::f16_to_bf8_rne(hbits);
+// Round 4 (tools/fp8_cvt_probe.hip, all 65 536 halves): v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32 fed with the half widened back to f32 give the reference's byte for EVERY
+// half that is not a NaN -- ties, subnormal results, overflow (E4M3: 0x7f, E5M2: infinity) and infinities included; a NaN comes out with its sign bit set, the
+// reference's without: those lanes take the software rounding.  Two results per conversion instruction instead of ~25 vector instructions per element.
+__device__ __forceinline__ unsigned int f32x2_to_fp8_ref(float x0, float x1, bool hf8) {      // byte 0: x0, byte 1: x1
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+  const float f0 = (float)h0, f1 = (float)h1;
+  unsigned int r = (unsigned int)(hf8 ? __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false) : __builtin_amdgcn_cvt_pk_bf8_f32(f0, f1, 0, false)) & 0xffffu;
+  if (__builtin_expect((x0 != x0) || (x1 != x1), 0)) {
+    const unsigned short b0 = __builtin_bit_cast(unsigned short, h0), b1 = __builtin_bit_cast(unsigned short, h1);
+    r = hf8 ? ((unsigned int)lowp::f16_to_hf8_rne(b0) | ((unsigned int)lowp::f16_to_hf8_rne(b1) << 8)) : ((unsigned int)lowp::f16_to_bf8_rne(b0) | ((unsigned int)lowp::f16_to_bf8_rne(b1) << 8));
+  }
+  return r;
 }
+__device__ __forceinline__ unsigned char f32_to_fp8_ref(float x, bool hf8) { return (unsigned char)(f32x2_to_fp8_ref(x, x, hf8) & 0xffu); }
 template <int MT, int NT, bool HF8, bool C8 = false>
 __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
@@ -2920,7 +2930,11 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
     constexpr unsigned int pitch = 32u * MT;
     static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ((unsigned char*)lds)[(32u * nt + (unsigned int)jl_of(r, h)) * pitch + 32u * mt + (unsigned int)li] = f32_to_fp8_ref(acc[mt][nt][r], HF8); });
+      for (int r = 0; r < 16; r += 2) {
+        const unsigned int two = f32x2_to_fp8_ref(acc[mt][nt][r], acc[mt][nt][r + 1], HF8);
+        ((unsigned char*)lds)[(32u * nt + (unsigned int)jl_of(r, h)) * pitch + 32u * mt + (unsigned int)li] = (unsigned char)two;
+        ((unsigned char*)lds)[(32u * nt + (unsigned int)jl_of(r + 1, h)) * pitch + 32u * mt + (unsigned int)li] = (unsigned char)(two >> 8);
+      } });
     GM unsigned char* ct = (GM unsigned char*)q.c + (long long)job.j0 * p.ldc + job.i0;
     const bool wide = ((((unsigned long long)(size_t)ct) | (unsigned long long)p.ldc) & 15ull) == 0ull;        // wave-uniform
     if (wide) {
@@ -2953,8 +2967,12 @@ __device__ __forceinline__ unsigned int load_u32_any(gcptr p4) {          // a d
   GM const unsigned char* b = (GM const unsigned char*)p4;
   return (unsigned int)b[0] | ((unsigned int)b[1] << 8) | ((unsigned int)b[2] << 16) | ((unsigned int)b[3] << 24);
 }
+// The unsigned -> signed correction terms 128 * sum_k b'(j, k) (unsigned A) and 128 * sum_k a'(i, k) (unsigned B) are plain byte sums of what a lane holds anyway
+// (lane = column j of B, lane = row i of A): one v_dot4_i32_i8 against 0x01010101 per operand dword into ONE register per tile row / column, the two k halves of
+// the wave added at the end; the column sums reach the accumulator layout (column = register) through 16 ds_bpermute per column tile in the epilogue.  (The
+// streaming kernel spends an MFMA and 16 accumulators per tile row / column on them: here that cost a wave per SIMD -- 216 against 152 registers.)
 template <int MT, int NT, int KIND, bool UA, bool UB>
-__global__ __launch_bounds__(256) void gemm_mfma_8bit_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
   constexpr bool INT = KIND == 0, HF8 = KIND == 2;
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
@@ -2962,7 +2980,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_8bit_kernel(GemmArgs p) {
   const BatchPtrs q = batch_ptrs(p, job.bidx);
   const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
   const bool c8 = !INT && p.c_type != LIBXSMM_DATATYPE_F32;          // 8-bit float C: wave-uniform
-  i32x16 iacc[INT ? MT : 1][INT ? NT : 1], sum_b[(INT && UA) ? NT : 1], sum_a[(INT && UB) ? MT : 1];
+  i32x16 iacc[INT ? MT : 1][INT ? NT : 1];
+  int sum_b[NT], sum_a[MT];                                          // this lane's column j / row i, its k half
   f32x16 facc[INT ? 1 : MT][INT ? 1 : NT];
   TileCtx tc[MT][NT];
   static_for<MT * NT>([&](auto idx) {
@@ -2981,10 +3000,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_8bit_kernel(GemmArgs p) {
       } else tile_init<false, true>(facc[mt][nt], p, q, tc[mt][nt]);
     }
   });
-  if constexpr (INT && UA) static_for<NT>([&](auto idx) { sum_b[idx.value] = (i32x16)0; });
-  if constexpr (INT && UB) static_for<MT>([&](auto idx) { sum_a[idx.value] = (i32x16)0; });
-  const i32x4 ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) sum_b[nt] = 0;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) sum_a[mt] = 0;
   const int kquads = p.k >> 2, kchunks = (p.k + 31) >> 5;
+  // (a branch-free form -- every load issued unconditionally at a clamped address, the padding a select afterwards -- measured SLOWER on 40^3 problems: 0.51 -> 0.24
+  // for i8 x i8; the lanes beyond m / n then load for real and the kernel needs 138 instead of 120 registers: three waves per SIMD instead of four)
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
     for (int kc = 0; kc < kchunks; ++kc) {
@@ -3016,8 +3038,18 @@ __global__ __launch_bounds__(256) void gemm_mfma_8bit_kernel(GemmArgs p) {
         for (int nt = 0; nt < NT; ++nt) bf[nt] = i32x4{(int)bw[nt][0], (int)bw[nt][1], (int)bw[nt][2], (int)bw[nt][3]};
         static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
           iacc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[nt], af[mt], iacc[mt][nt], 0, 0, 0); });
-        if constexpr (UA) static_for<NT>([&](auto idx) { sum_b[idx.value] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[idx.value], ones, sum_b[idx.value], 0, 0, 0); });
-        if constexpr (UB) static_for<MT>([&](auto idx) { sum_a[idx.value] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ones, af[idx.value], sum_a[idx.value], 0, 0, 0); });
+        if constexpr (UA) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum_b[nt] = __builtin_amdgcn_sdot4((int)bw[nt][e], 0x01010101, sum_b[nt], false);
+        }
+        if constexpr (UB) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum_a[mt] = __builtin_amdgcn_sdot4((int)aw[mt][e], 0x01010101, sum_a[mt], false);
+        }
       } else {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -3031,16 +3063,24 @@ __global__ __launch_bounds__(256) void gemm_mfma_8bit_kernel(GemmArgs p) {
   if constexpr (INT) {
     const bool c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
     const int kconst = (UA && UB) ? 16384 * (int)(p.br_count * (unsigned long long)p.k) : 0;
+    if constexpr (UA) {       // both k halves of a column: lane j + lane j + 32
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) sum_b[nt] += __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), sum_b[nt]);
+    }
+    if constexpr (UB) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) sum_a[mt] += __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), sum_a[mt]);
+    }
     static_for<MT * NT>([&](auto idx) {
       constexpr int mt = idx.value / NT, nt = idx.value % NT;
       const TileCtx& t = tc[mt][nt];
 #pragma unroll
       for (int r2 = 0; r2 < 16; ++r2) {
-        const int j = t.j0 + jl_of(r2, h);
-        if (!(t.ivalid && j < p.n)) continue;
+        const int jl = jl_of(r2, h), j = t.j0 + jl;
         int v = iacc[mt][nt][r2] + kconst;
-        if constexpr (UA) v += 128 * sum_b[nt][r2];
-        if constexpr (UB) v += 128 * sum_a[mt][r2];
+        if constexpr (UA) v += 128 * __builtin_amdgcn_ds_bpermute(4 * jl, sum_b[nt]);       // the sum of column jl lives in lane jl (all lanes execute the exchange)
+        if constexpr (UB) v += 128 * sum_a[mt];
+        if (!(t.ivalid && j < p.n)) continue;
         GM char* cp = (GM char*)q.c + 4ll * ((long long)j * p.ldc + t.i);
         if (c_f32) { float f = mul_rn((float)v, p.scf); if (!beta0) f = add_rn(f, *(GM const float*)cp); *(GM float*)cp = f; }
         else { if (!beta0) v += *(GM const int*)cp; *(GM int*)cp = v; }
@@ -3051,9 +3091,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_8bit_kernel(GemmArgs p) {
       constexpr int mt = idx.value / NT, nt = idx.value % NT;
       const TileCtx& t = tc[mt][nt];
 #pragma unroll
-      for (int r2 = 0; r2 < 16; ++r2) {
-        const int j = t.j0 + jl_of(r2, h);
-        if (t.ivalid && j < p.n) ((GM unsigned char*)q.c)[(long long)j * p.ldc + t.i] = f32_to_fp8_ref(facc[mt][nt][r2], HF8);
+      for (int r2 = 0; r2 < 16; r2 += 2) {
+        const unsigned int two = f32x2_to_fp8_ref(facc[mt][nt][r2], facc[mt][nt][r2 + 1], HF8);
+        const int j = t.j0 + jl_of(r2, h);                                                                       // registers (2q, 2q + 1) are columns (j, j + 1)
+        if (t.ivalid && j < p.n) ((GM unsigned char*)q.c)[(long long)j * p.ldc + t.i] = (unsigned char)two;
+        if (t.ivalid && j + 1 < p.n) ((GM unsigned char*)q.c)[(long long)(j + 1) * p.ldc + t.i] = (unsigned char)(two >> 8);
       }
     });
   } else {
@@ -4360,6 +4402,8 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   // 8-bit operands on the masked matrix-core kernel: any shape with whole k-quads, any alignment, any batch-reduce form.  Returns false for what it does not
   // take (C of an 8-bit float type together with a fused operator; more than 2^31 bytes inside one operand).
   auto launch_m8 = [&](bool big) -> bool {
+    static const int tile_env = []() { const char* e = getenv("LIBXSMM_HIP_M8_TILE"); return e ? atoi(e) : 0; }();      // experiments: 1 forces 32 x 32 tiles, 2 forces 64 x 64
+    if (tile_env == 1) big = false; else if (tile_env == 2) big = true;
     const bool fp8 = a.a_type == LIBXSMM_DATATYPE_BF8 || a.a_type == LIBXSMM_DATATYPE_HF8;
     if (fp8 && a.c_type != LIBXSMM_DATATYPE_F32 && (a.colbias || a.act || a.vnni_c)) return false;
     if ((a.k & 3) || a.k <= 0) return false;

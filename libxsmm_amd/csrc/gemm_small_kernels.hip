@@ -248,7 +248,9 @@ int launch_gemm_p16w(const GemmArgs& a, bool nt, void* stream, const char** kern
   const unsigned long long bbits16 = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)((long long)a.ldb * (bf16 ? 2 : 4));
   if (pw_env != 0 && a.k == 16 && a.br_count == 1 && !a.batch_inner && !a.list_a && (bbits16 & 15ull) == 0) {
     const unsigned int steps = bf16 ? (a.nbatch + 1u) / 2u : a.nbatch;
-    unsigned int pw = pw_env > 0 ? (unsigned int)pw_env : (steps >= 65536u ? 8u : steps >= 32768u ? 4u : steps >= 16384u ? 2u : 1u);
+    // measured (profiles/r04b_p16s_times.jsonl; f32 / bf16 fractions of the HBM roofline, one-shot waves -> 2 / 4 / 8 / 16 steps per wave): 65 536 problems 0.745 / 0.675 ->
+    // 0.779 / 0.721, 0.761 / 0.719, 0.737 / 0.701, 0.706 / 0.663; 524 288 problems 0.796 / 0.769 -> 0.794 / 0.787, 0.821 / 0.827, 0.743 / 0.787, 0.728 / 0.739
+    unsigned int pw = pw_env > 0 ? (unsigned int)pw_env : (steps >= 131072u ? 4u : steps >= 2048u ? 2u : 1u);        // small launches too: 4096 problems 3.73 / 3.88 -> 3.43 / 2.74 us
     if (pw > 1u) {
       const dim3 grid((unsigned int)(((steps + pw - 1u) / pw + 3u) / 4u));
       if (bf16) {

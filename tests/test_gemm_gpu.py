@@ -106,17 +106,19 @@ def test_headline_shape_uses_mfma_tile_kernel():
     _check(GemmCase(16, 16, 16, batch=67, seed=2, lda=18), expect_kernel="gemm_f32_p16_kernel")   # A rows not 16-byte aligned: the round-2 kernel (dword loads of A)
     _check(GemmCase(16, 16, 16, batch=64, seed=2, beta=1), expect_kernel="t16")                 # beta = 1: the general 16x16-tile kernel
     _check(GemmCase(16, 16, 32, batch=67, seed=2, br_type=capi.BR_STRIDE, br_count=3), expect_kernel="gemm_f32_p16w_kernel")
-    _check(GemmCase(16, 16, 16, batch=16001, seed=2), expect_kernel="gemm_f32_p16w_kernel")
-    # round 4, second form: from 16 384 steps on a wave walks several problems as a two-deep pipeline (both operands by LDS-DMA); odd counts leave short last waves
-    _check(GemmCase(16, 16, 16, batch=70001, seed=2), expect_kernel="gemm_f32_p16s_kernel")        # 8 problems per wave
-    _check(GemmCase(16, 16, 16, batch=16387, seed=5, ldb=20, ldc=24), expect_kernel="gemm_f32_p16s_kernel")      # 2 per wave, padded B / C columns
-    _check(GemmCase(16, 16, 16, batch=40003, seed=6, lda=20), expect_kernel="gemm_f32_p16s_kernel")              # 4 per wave, padded A rows
-    _check(GemmCase(16, 16, 16, batch=16390, seed=7, ldb=18), expect_kernel="gemm_f32_p16w_kernel")              # B columns not 16-byte aligned: one-shot waves
-    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=131073, seed=2), expect_kernel="gemm_bf16_p16s_kernel")   # 8 pairs per wave, the last pair a single problem
+    _check(GemmCase(16, 16, 16, batch=2001, seed=2), expect_kernel="gemm_f32_p16w_kernel")
+    _check(GemmCase(16, 16, 16, batch=16001, seed=2), expect_kernel="gemm_f32_p16s_kernel")
+    # round 4, second form: from 2048 steps on a wave walks several problems as a two-deep pipeline (both operands by LDS-DMA); odd counts leave short last waves
+    _check(GemmCase(16, 16, 16, batch=131075, seed=2), expect_kernel="gemm_f32_p16s_kernel")        # 4 problems per wave
+    _check(GemmCase(16, 16, 16, batch=70001, seed=2), expect_kernel="gemm_f32_p16s_kernel")        # 2 problems per wave
+    _check(GemmCase(16, 16, 16, batch=16387, seed=5, ldb=20, ldc=24), expect_kernel="gemm_f32_p16s_kernel")      # padded B / C columns
+    _check(GemmCase(16, 16, 16, batch=40003, seed=6, lda=20), expect_kernel="gemm_f32_p16s_kernel")              # padded A rows
+    _check(GemmCase(16, 16, 16, batch=16390, seed=7, ldb=20, lda=18), expect_kernel="gemm_f32_p16_kernel")       # A rows not 16-byte aligned: the round-2 kernel
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=262145, seed=2), expect_kernel="gemm_bf16_p16s_kernel")   # 4 pairs per wave, the last pair a single problem
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, batch=32771, seed=8, ldb=24, ldc=20), expect_kernel="gemm_bf16_p16s_kernel")
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=70002, seed=9, lda=20), expect_kernel="gemm_bf16_p16s_kernel")
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=64, seed=2), expect_kernel="gemm_bf16_p16w_kernel")     # two problems per wave
-    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=20001, seed=2), expect_kernel="gemm_bf16_p16w_kernel")  # odd count: the last wave has one
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=20001, seed=2), expect_kernel="gemm_bf16_p16s_kernel")  # odd count: the last wave has one
     _check(GemmCase(16, 16, 48, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, batch=33, seed=3, br_type=capi.BR_STRIDE, br_count=2), expect_kernel="gemm_bf16_p16w_kernel")
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=5, seed=4, ldc=24), expect_kernel="gemm_bf16_p16w_kernel")
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=9, seed=4, lda=18), expect_kernel="gemm_bf16_p16_kernel")
@@ -489,9 +491,14 @@ def test_fp8_mfma_with_wide_exponent_range_data():
             got, _, _ = case.run_gpu(batched=True)
             ref, _ = case.run_oracle()
             assert normf_rel(case.valid_region(ref), case.valid_region(got), DT.F32) < 2e-4
-            case = GemmCase(20, 12, 16, a_type=t, c_type=DT.F32, flags=F.VNNI_A, seed=34)
+            case = GemmCase(20, 12, 16, a_type=t, c_type=DT.F32, flags=F.VNNI_A, seed=34)       # round 4: the masked matrix-core kernel, the same bound
             got, _, _ = case.run_gpu(batched=False)
             ref, _ = case.run_oracle()
+            assert normf_rel(case.valid_region(ref), case.valid_region(got), DT.F32) < 2e-4
+            case = GemmCase(20, 12, 15, a_type=t, c_type=DT.F32, seed=35)                         # flat A: the generic kernel, the reference's order
+            got, _, handle = case.run_gpu(batched=False)
+            ref, _ = case.run_oracle()
+            assert "generic" in capi.load().hip_kernel_name(handle, 0).decode()
             assert np.array_equal(case.valid_region(ref), case.valid_region(got))
     finally:
         helpers.FP8_WIDE = False
