@@ -103,7 +103,8 @@ __device__ __forceinline__ unsigned int keep_where_set(unsigned int x, u64b mask
   return r;
 }
 
-template <bool F16, int NT, int KS>
+// ABL: timing-only experiments (WRONG results; LIBXSMM_HIP_BITMASK_ABL): 1 no value loads, 2 no expansion (ballot ranks / crossbar), 4 no B loads, 8 no MFMA, 16 no meta-data blocks
+template <bool F16, int NT, int KS, int ABL = 0>
 __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p) {
   __shared__ __attribute__((aligned(16))) float red[KS / 2][NT * 1024];
   const unsigned int lane = threadIdx.x & 63u;
@@ -180,19 +181,28 @@ __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p
     auto fetch = [&](auto slotc, auto lanec, const Block& b) __attribute__((always_inline)) {
       constexpr int slot = decltype(slotc)::value, l0 = decltype(lanec)::value;
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        val[slot][e] = (unsigned int)__builtin_amdgcn_raw_buffer_load_b16(rv, (int)vval, (int)(2u * (unsigned int)__builtin_amdgcn_readlane((int)b.off, l0 + e)), 0);
+      for (int e = 0; e < 8; ++e) {
+        if constexpr (ABL & 1) val[slot][e] = vval + (unsigned int)e;
+        else val[slot][e] = (unsigned int)__builtin_amdgcn_raw_buffer_load_b16(rv, (int)vval, (int)(2u * (unsigned int)__builtin_amdgcn_readlane((int)b.off, l0 + e)), 0);
+      }
     };
     auto fetch_b = [&](auto slotc, unsigned int s_in) __attribute__((always_inline)) {
       constexpr int slot = decltype(slotc)::value;
       const unsigned int sc = s_in < s_end ? s_in : s_end - 1u;
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
-        bfr[slot][jt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(vb + 512u * jt), (int)(sc * 2u * (unsigned int)p.n_pad * 16u), 0));
+      for (int jt = 0; jt < NT; ++jt) {
+        if constexpr (ABL & 4) bfr[slot][jt] = u32x4{sc, vb, 0x3f803f80u, 0x3f803f80u};
+        else bfr[slot][jt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(vb + 512u * jt), (int)(sc * 2u * (unsigned int)p.n_pad * 16u), 0));
+      }
     };
     auto expand = [&](auto slotc, auto lanec, const Block& b, u32x4& a4) __attribute__((always_inline)) {
       constexpr int slot = decltype(slotc)::value, l0 = decltype(lanec)::value;
       unsigned int dense[8];
+      if constexpr (ABL & 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a4[q] = val[slot][2 * q] | (val[slot][2 * q + 1] << 16);
+        return;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)b.mlo, l0 + e), hi = (unsigned int)__builtin_amdgcn_readlane((int)b.mhi, l0 + e);
@@ -205,6 +215,7 @@ __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p
     };
     auto mfma = [&](auto slotc, const u32x4& a4) __attribute__((always_inline)) {
       constexpr int slot = decltype(slotc)::value;
+      if constexpr (ABL & 8) { acc[0][0] += __uint_as_float(a4[0] ^ a4[1] ^ a4[2] ^ a4[3] ^ bfr[slot][0][0] ^ bfr[slot][NT - 1][3]); return; }
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) {
         if constexpr (F16) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8b, bfr[slot][jt]), __builtin_bit_cast(f16x8b, a4), acc[jt], 0, 0, 0);
@@ -236,9 +247,11 @@ __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p
           mfma(SlotB{}, a4);
         }
       });
+      if constexpr (!(ABL & 16)) {
       cur = nxt;
       nxt = block_make(pre, 8u * sb + 128u);               // the block after next: its raw data was requested a block ago
       pre = block_load(8u * sb + 192u);
+      }
     }
   }
   // the KS partial tiles, added in wave order through LDS (halving: waves [h, 2h) hand their tile to waves [0, h))
@@ -320,6 +333,25 @@ int launch_gemm_bitmask_reg(const GemmArgs& a, const void* bitmap, void* ws, siz
   const bool f16 = a.a_type == LIBXSMM_DATATYPE_F16;
   const bool two = p.n_pad >= 64;                                   // 64 columns per workgroup where C has them
   const dim3 grid((unsigned int)p.tiles, (unsigned int)(p.n_pad / (two ? 64 : 32)));
+#ifdef LIBXSMM_HIP_EXPERIMENTS
+  static const int abl = []() { const char* e = getenv("LIBXSMM_HIP_BITMASK_ABL"); return e ? atoi(e) : 0; }();
+  if (two && !f16 && abl) {
+    switch (abl) {
+      case 1: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 1>), grid, dim3(64 * KS), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 2>), grid, dim3(64 * KS), 0, st, p); break;
+      case 3: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 3>), grid, dim3(64 * KS), 0, st, p); break;
+      case 4: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 4>), grid, dim3(64 * KS), 0, st, p); break;
+      case 8: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 8>), grid, dim3(64 * KS), 0, st, p); break;
+      case 16: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 16>), grid, dim3(64 * KS), 0, st, p); break;
+      case 7: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 7>), grid, dim3(64 * KS), 0, st, p); break;
+      case 23: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 23>), grid, dim3(64 * KS), 0, st, p); break;
+      default: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 31>), grid, dim3(64 * KS), 0, st, p); break;
+    }
+    if (name) *name = "gemm_bitmask_reg_kernel(ablation)";
+    *taken = 1;
+    return (int)hipGetLastError();
+  }
+#endif
   if (two) { if (f16) hipLaunchKernelGGL((gemm_bitmask_reg_kernel<true, 2, KS>), grid, dim3(64 * KS), 0, st, p); else hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS>), grid, dim3(64 * KS), 0, st, p); }
   else { if (f16) hipLaunchKernelGGL((gemm_bitmask_reg_kernel<true, 1, KS>), grid, dim3(64 * KS), 0, st, p); else hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 1, KS>), grid, dim3(64 * KS), 0, st, p); }
   if (name) *name = "gemm_bitmask_reg_kernel";

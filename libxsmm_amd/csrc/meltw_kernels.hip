@@ -1711,7 +1711,9 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
         // one big matrix over its columns: too few row groups to fill the chip -> split the columns over blockIdx.z (two passes)
         int nchunks = 1;
         // measured on one 4096 x 8192 f32 matrix (round 3): 2048 blocks 38.9 us, 1024 34.7, 512 32.1, 384 31.6, 256 36.9, 128 60.4 -- few, long-running blocks win;
-        // 64 or 32 row groups per block (whole 1 KiB / 512-byte row segments per wave, 4 / 8 column slices) were SLOWER at every block count (42 - 62 us)
+        // 64 or 32 row groups per block (whole 1 KiB / 512-byte row segments per wave, 4 / 8 column slices) were SLOWER at every block count (42 - 62 us);
+        // round 4: 256 row groups per block (one contiguous 4 KiB run of every column, eight columns in flight per thread, 32 - 512 column chunks): 54 - 66 us
+        // (8192 x 8192: 52 -> 66 - 91 us; 1024 x 65536: 60 -> 138 - 392 us) -- the short pieces of many columns at once are what this memory system wants here
         if (!rows && a.ws && a.nbatch == 1 && gx < 512) {
           nchunks = (int)std::min<long long>(128, std::min<long long>(a.n / 64, 512 / (gx ? gx : 1)));
           if ((size_t)nchunks * 2 * (size_t)a.m * sizeof(float) > a.ws_bytes) nchunks = 1;
