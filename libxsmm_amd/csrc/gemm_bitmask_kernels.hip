@@ -22,6 +22,12 @@
 //   * one pre-pass kernel (bitmask_prepass_kernel): per bit row its total and the exclusive prefix per 32-row tile (16-bit entries: 2.5 % of the compressed
 //     bytes), and the re-laid B.  Where a bit row's values start -- the scan over the row totals -- is computed by every wave for its own slice (<= 16 KiB of
 //     totals, L2 resident), not by a third kernel.
+//   * round 4, second session (profiles/r04b_bitmask_ablation.jsonl, timing-only switches in an EXPERIMENTS build): of 72 us the value loads cost 34, the expansion 14,
+//     the meta data 11, B loads and MFMAs nothing; ONE 16-byte request per lane for all eight windows of a step cost what the eight 2-byte loads cost (at any
+//     alignment): the bytes, not the instructions.  Tiles were dealt T -> XCD T % 8, so neighbouring tiles -- which share the lines of every bit row's values and of the
+//     bitmap -- sat behind different L2s.  Now every XCD owns a contiguous eighth of the tiles (72 -> 59 us) and the pre-pass re-lays the masks tile by tile (a
+//     block's 64 masks are 512 contiguous bytes instead of 64 lines 2 KiB apart: 59 -> 56.5 us).  Not adopted: lanes beyond a window's count masked off, B requested
+//     before the values (no change).  What is left: 34 us without any value load, 22 us for the loads (64 MB of values at 3 TB/s) -- the two do not overlap.
 // m % 32 == 0, m <= 32768, k % 16 == 0 with at least 16 steps of 16, 16-bit operands (bf16 / IEEE half), C f32 / bf16 / f16.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -40,6 +46,7 @@ struct BitmaskArgs {
   const unsigned short* vals; const unsigned char* bitmap;     // the caller's operands
   const char* b; char* c;
   unsigned int* tot; unsigned short* tpre; unsigned short* bp;   // workspace: row totals, per-tile exclusive prefixes, the re-laid B
+  unsigned long long* mt;                                         // workspace: the bit rows' masks tile by tile ([tile][bit row]: a block of 64 rows of one tile = 512 contiguous bytes)
   int m, n, k, ldb, ldc, c_type, beta0;
   int rows, row_bytes, tiles, n_pad, steps, steps_per_wave;      // bit rows (k / 2), bytes per bit row (m / 4), 32-row tiles, n rounded up to 32, k / 16
 };
@@ -50,6 +57,7 @@ struct BitmaskArgs {
 __global__ __launch_bounds__(512) void bitmask_prepass_kernel(BitmaskArgs p, unsigned int row_blocks) {
   // table layout: tpre[tile][bit row] -- the eight rows of a step are ONE 16-byte record per tile (a single scalar load in the main kernel)
   __shared__ unsigned short ex[8][64];
+  __shared__ u64b mk[8][64];
   const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (blockIdx.x < row_blocks) {
     const unsigned int r0 = blockIdx.x * 8u, r = r0 + wave;                         // rows is a multiple of 8: every wave has a row
@@ -57,7 +65,9 @@ __global__ __launch_bounds__(512) void bitmask_prepass_kernel(BitmaskArgs p, uns
     unsigned int carry = 0;
     for (unsigned int t0 = 0; t0 < (unsigned int)p.tiles; t0 += 64u) {
       const unsigned int t = t0 + lane;
-      const unsigned int c = t < (unsigned int)p.tiles ? (unsigned int)__builtin_popcountll(row[t]) : 0u;
+      const u64b mword = t < (unsigned int)p.tiles ? row[t] : 0ull;
+      const unsigned int c = (unsigned int)__builtin_popcountll(mword);
+      mk[wave][lane] = mword;
       unsigned int incl = c;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const unsigned int v = (unsigned int)__shfl_up((int)incl, o); if (lane >= (unsigned int)o) incl += v; }
@@ -69,6 +79,10 @@ __global__ __launch_bounds__(512) void bitmask_prepass_kernel(BitmaskArgs p, uns
 #pragma unroll
         for (int q = 0; q < 4; ++q) rec[q] = (unsigned int)ex[2 * q][lane] | ((unsigned int)ex[2 * q + 1][lane] << 16);
         *(GM u32x4*)((GM unsigned short*)p.tpre + (size_t)t * (size_t)p.rows + r0) = rec;
+      }
+      {   // the eight rows' masks of tile t0 + tid / 8 leave as one 64-byte run: thread = (tile tid / 8, row tid % 8)
+        const unsigned int tt = t0 + (threadIdx.x >> 3), q = threadIdx.x & 7u;
+        if (tt < (unsigned int)p.tiles) ((GM u64b*)p.mt)[(size_t)tt * (size_t)p.rows + r0 + q] = mk[q][threadIdx.x >> 3];
       }
       __syncthreads();
     }
@@ -109,7 +123,14 @@ __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p
   __shared__ __attribute__((aligned(16))) float red[KS / 2][NT * 1024];
   const unsigned int lane = threadIdx.x & 63u;
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned int T = blockIdx.x, j0 = blockIdx.y * 32u * NT;
+  // Hardware workgroup g runs on XCD g % 8 (its own L2).  Neighbouring tiles share cache lines -- a bit row's values for tiles T and T + 1 are adjacent in
+  // memory (a window is ~64 of a line's 128 bytes) and a 128-byte line of the bitmap holds the masks of 16 tiles -- so every XCD takes a CONTIGUOUS eighth
+  // of the tiles: what one of its waves over-fetches is what the same wave of the next tile (the next CU of the same XCD, at the same time) needs.
+  // Round 4 ablation (profiles/r04b_bitmask_ablation.jsonl): with tile T on XCD T % 8 the value loads cost 34 of 72 us and ONE 16-byte request per lane for all
+  // eight windows of a step cost the same as the eight 2-byte loads -- the lines, not the instructions.
+  unsigned int T = blockIdx.x;
+  if constexpr (!(ABL & 128)) { if ((gridDim.x & 7u) == 0u) T = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+  const unsigned int j0 = blockIdx.y * 32u * NT;
   const unsigned int s_begin = wave * (unsigned int)p.steps_per_wave;
   const unsigned int s_end = std::min<unsigned int>((unsigned int)p.steps, s_begin + (unsigned int)p.steps_per_wave);
   f32x16 acc[NT];
@@ -143,23 +164,23 @@ __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p
     // use; a step reads its eight rows' values out of the lanes with v_readlane (compile-time lane numbers).  Scalar loads were the first form: their
     // misses (every bit row's mask is another cache line, 2 KiB apart) cannot be requested far enough ahead -- a step's masks are 16 scalar registers -- and
     // while one is in flight every wait for a crossbar result is a full lgkmcnt(0): 2 us per step, 63 us for the kernel (rocprofv3, 8192 x 8192 @50 %).
-    GM const unsigned char* bmv = (GM const unsigned char*)p.bitmap + (size_t)T * 8u;
+    GM const u64b* mtv = (GM const u64b*)p.mt + (size_t)T * (size_t)p.rows;                          // this tile's masks, re-laid by the pre-pass: 64 rows = 512 contiguous bytes
     GM const unsigned short* tpv = (GM const unsigned short*)p.tpre + (size_t)T * (size_t)p.rows;      // this tile's column of the table
     GM const unsigned int* ttv = (GM const unsigned int*)p.tot;
-    struct Block { unsigned int mlo, mhi, off; };               // per lane: bit row (first row of the block + lane): mask, packed offset of its window
+    struct Block { unsigned int mlo, mhi, off, cnt; };               // per lane: bit row (first row of the block + lane): mask, packed offset of its window
     struct Raw { u32x2 m; unsigned int tot; unsigned int pre; };
     const unsigned int r_end = 8u * s_end;
     auto block_load = [&](unsigned int rb0) __attribute__((always_inline)) {
       Raw w;
       const unsigned int r = rb0 + lane < r_end ? rb0 + lane : r_end - 1u;                        // past the slice: the last row again (never used)
-      w.m = *(GM const u32x2*)(bmv + (size_t)r * (size_t)p.row_bytes);
+      w.m = *(GM const u32x2*)(mtv + r);
       w.tot = ttv[r];
       w.pre = tpv[r];
       return w;
     };
     // offsets of a block: running position S + exclusive scan of the row totals + tile prefix; S moves on by the block's total
     auto block_make = [&](const Raw& w, unsigned int rb0) __attribute__((always_inline)) {
-      Block b; b.mlo = w.m[0]; b.mhi = w.m[1];
+      Block b; b.mlo = w.m[0]; b.mhi = w.m[1]; b.cnt = (unsigned int)__builtin_popcount(b.mlo) + (unsigned int)__builtin_popcount(b.mhi);
       const unsigned int t = rb0 + lane < r_end ? w.tot : 0u;
       unsigned int incl = t;
 #pragma unroll
@@ -178,11 +199,32 @@ __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p
     // ds_bpermute and CU) is what bounds the kernel: the counters show no unit above 25 % busy (vector ALU 24 %, LDS 20 %, texture addresser 60 % of the
     // cycles with ONE request in flight or more) and the waves waiting 87 % of their life -- 41 % on a counter, 46 % for an issue slot.
     unsigned int val[4][8]; u32x4 bfr[2][NT];
+#pragma unroll
+    for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+      for (int b_ = 0; b_ < 8; ++b_) val[a_][b_] = 0u;             // (lanes beyond a window's count never load: their registers keep whatever they hold)
     auto fetch = [&](auto slotc, auto lanec, const Block& b) __attribute__((always_inline)) {
       constexpr int slot = decltype(slotc)::value, l0 = decltype(lanec)::value;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if constexpr (ABL & 1) val[slot][e] = vval + (unsigned int)e;
+        else if constexpr (ABL & 32) {      // ONE 2-byte load per step (the other seven rows reuse it)
+          if (e == 0) val[slot][0] = (unsigned int)__builtin_amdgcn_raw_buffer_load_b16(rv, (int)vval, (int)(2u * (unsigned int)__builtin_amdgcn_readlane((int)b.off, l0)), 0);
+          else val[slot][e] = val[slot][0];
+        } else if constexpr (ABL & 64) {    // ONE 16-byte load per step at a 2-byte aligned address: lane = (window lane / 8, piece lane % 8)
+          if (e == 0) {
+            const unsigned int myoff = (unsigned int)__builtin_amdgcn_ds_bpermute((int)((l0 + (lane >> 3)) << 2), (int)b.off);
+            const unsigned int al = (ABL & 1024) ? (myoff & ~7u) : ((ABL & 512) ? (myoff & ~1u) : myoff);      // 16- / 4- / 2-byte aligned requests
+            const u32x4 w4 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(2u * al + 16u * (lane & 7u)), 0, 0));
+            val[slot][0] = w4[0]; val[slot][1] = w4[1]; val[slot][2] = w4[2]; val[slot][3] = w4[3];
+          } else if (e >= 4) val[slot][e] = val[slot][e - 4];
+        }
+        else if constexpr (ABL & 256) {
+          // only the lanes that hold a value of this window ask for one (the others fetch the next tile's values: half of the requested bytes at 50 %): no gain once
+          // the neighbouring tile runs on the same XCD -- 57.3 against 56.4 us
+          const unsigned int cnt = (unsigned int)__builtin_amdgcn_readlane((int)b.cnt, l0 + e);
+          if (lane < cnt) val[slot][e] = (unsigned int)__builtin_amdgcn_raw_buffer_load_b16(rv, (int)vval, (int)(2u * (unsigned int)__builtin_amdgcn_readlane((int)b.off, l0 + e)), 0);
+        }
         else val[slot][e] = (unsigned int)__builtin_amdgcn_raw_buffer_load_b16(rv, (int)vval, (int)(2u * (unsigned int)__builtin_amdgcn_readlane((int)b.off, l0 + e)), 0);
       }
     };
@@ -238,9 +280,10 @@ __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p
         using SlotV = std::integral_constant<int, st & 3>; using SlotB = std::integral_constant<int, st & 1>;
         using NextV = std::integral_constant<int, (st + 2) & 3>; using NextB = std::integral_constant<int, (st + 1) & 1>;
         // requests: the values of step st + 2 (the next block's first steps from `nxt`), the B operands of step st + 1
+        if constexpr (!(ABL & 2048)) fetch_b(NextB{}, sb + st + 1u);       // B first: the counter retires in order, so waiting for this step's B (issued a step ago) then leaves the younger value loads alone
         if constexpr (st + 2 < 8) fetch(NextV{}, std::integral_constant<int, 8 * (st + 2)>{}, cur);
         else fetch(NextV{}, std::integral_constant<int, 8 * (st + 2 - 8)>{}, nxt);
-        fetch_b(NextB{}, sb + st + 1u);
+        if constexpr (ABL & 2048) fetch_b(NextB{}, sb + st + 1u);
         if (sb + st < s_end) {                               // wave-uniform
           u32x4 a4;
           expand(SlotV{}, std::integral_constant<int, 8 * st>{}, cur, a4);
@@ -311,7 +354,7 @@ static bool bitmask_reg_ok(const GemmArgs& a) {
 size_t gemm_bitmask_reg_workspace(const GemmArgs& a) {
   if (!bitmask_reg_ok(a)) return 0;
   const size_t rows = (size_t)a.k / 2, tiles = (size_t)a.m / 32, n_pad = a.n <= 32 ? 32 : ((size_t)a.n + 63) / 64 * 64;
-  return ((rows * 4 + 255) & ~(size_t)255) + ((rows * tiles * 2 + 255) & ~(size_t)255) + (size_t)a.k * n_pad * 2;
+  return ((rows * 4 + 255) & ~(size_t)255) + ((rows * tiles * 2 + 255) & ~(size_t)255) + ((rows * tiles * 8 + 255) & ~(size_t)255) + (size_t)a.k * n_pad * 2;
 }
 int launch_gemm_bitmask_reg(const GemmArgs& a, const void* bitmap, void* ws, size_t ws_bytes, void* stream, const char** name, int* taken) {
   *taken = 0;
@@ -327,6 +370,7 @@ int launch_gemm_bitmask_reg(const GemmArgs& a, const void* bitmap, void* ws, siz
   char* w = (char*)ws;
   p.tot = (unsigned int*)w; w += ((size_t)p.rows * 4 + 255) & ~(size_t)255;
   p.tpre = (unsigned short*)w; w += ((size_t)p.rows * p.tiles * 2 + 255) & ~(size_t)255;
+  p.mt = (unsigned long long*)w; w += ((size_t)p.rows * p.tiles * 8 + 255) & ~(size_t)255;
   p.bp = (unsigned short*)w;
   const unsigned int row_blocks = (unsigned int)p.rows / 8u, b_blocks = ((unsigned int)p.steps * (unsigned int)p.n_pad + 511u) / 512u;
   hipLaunchKernelGGL(bitmask_prepass_kernel, dim3(row_blocks + b_blocks), dim3(512), 0, st, p, row_blocks);
@@ -343,6 +387,16 @@ int launch_gemm_bitmask_reg(const GemmArgs& a, const void* bitmap, void* ws, siz
       case 4: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 4>), grid, dim3(64 * KS), 0, st, p); break;
       case 8: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 8>), grid, dim3(64 * KS), 0, st, p); break;
       case 16: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 16>), grid, dim3(64 * KS), 0, st, p); break;
+      case 32: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 32>), grid, dim3(64 * KS), 0, st, p); break;
+      case 128: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 128>), grid, dim3(64 * KS), 0, st, p); break;
+      case 256: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 256>), grid, dim3(64 * KS), 0, st, p); break;
+      case 129: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 1>), grid, dim3(64 * KS), 0, st, p); break;
+      case 144: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 16>), grid, dim3(64 * KS), 0, st, p); break;
+      case 64: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 64>), grid, dim3(64 * KS), 0, st, p); break;
+      case 2048: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 2048>), grid, dim3(64 * KS), 0, st, p); break;
+      case 576: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 576>), grid, dim3(64 * KS), 0, st, p); break;
+      case 1088: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 1088>), grid, dim3(64 * KS), 0, st, p); break;
+      case 48: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 48>), grid, dim3(64 * KS), 0, st, p); break;
       case 7: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 7>), grid, dim3(64 * KS), 0, st, p); break;
       case 23: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 23>), grid, dim3(64 * KS), 0, st, p); break;
       default: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 31>), grid, dim3(64 * KS), 0, st, p); break;
