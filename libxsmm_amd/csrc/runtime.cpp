@@ -1043,6 +1043,16 @@ void run_bcsc(KernelCtx* k, const void* param) {
         fresh->d_block = blockp;
         // an evicted entry stays alive until the kernel is released: another thread may be past its lock-free hit, a launch may still read its table
         if (k->bcsc_cache.size() >= 4) { k->bcsc_old.push_back(k->bcsc_cache.front()); k->bcsc_cache.erase(k->bcsc_cache.begin()); }
+        // ... but a caller that cycles through many patterns must not grow device memory without bound (advisor, round 3): beyond 64 retired entries that still own a device table the
+        // tables of the oldest 32 are freed after the device has drained (no launch can still read them; a thread would have to sit between its lock-free hit and
+        // its launch across 32 pattern insertions for the pointer to matter).  The small host parts stay until the kernel is released.
+        size_t live_old = 0;
+        for (auto* e : k->bcsc_old) live_old += e->d_block ? 1 : 0;
+        if (live_old > 64) {
+          (void)hipDeviceSynchronize();
+          size_t freed = 0;
+          for (auto* e : k->bcsc_old) { if (freed == 32) break; if (e->d_block) { (void)hipFree(e->d_block); e->d_block = nullptr; ++freed; } }
+        }
         k->bcsc_cache.push_back(fresh);
         k->device = cur_device();
         hit = fresh;

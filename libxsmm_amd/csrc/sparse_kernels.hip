@@ -646,7 +646,8 @@ __global__ void bcsc_invert_kernel(const unsigned int* colptr_, const unsigned i
   if (nb >= nblk_n) return;
   for (int e = threadIdx.x; e < nkb; e += blockDim.x) t[(long long)nb * nkb + e] = 0xffffffffu;
   __syncthreads();
-  for (unsigned int b = colptr[nb] + threadIdx.x; b < colptr[nb + 1]; b += blockDim.x) t[(long long)nb * nkb + rowidx[b]] = b;
+  // (a k-block id beyond K / bk in a device-resident pattern is dropped instead of written past the table: the host-pattern path refuses such patterns up front)
+  for (unsigned int b = colptr[nb] + threadIdx.x; b < colptr[nb + 1]; b += blockDim.x) { const unsigned int kb = rowidx[b]; if (kb < (unsigned int)nkb) t[(long long)nb * nkb + kb] = b; }
 }
 
 int launch_bcsc_invert(const unsigned int* colptr, const unsigned int* rowidx, unsigned int* table, int nblk_n, int nkb, void* stream) {

@@ -390,6 +390,35 @@ def test_bcsc_host_pattern_cache_keeps_several_patterns_and_survives_eviction():
     api.release_kernel(h)
 
 
+def test_bcsc_host_pattern_cache_frees_retired_device_tables():
+    """A caller that cycles through many patterns: beyond 64 retired entries the oldest device tables are freed (after the device drained); every call
+    still computes with ITS pattern, also one that comes back after its table was freed."""
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(22)
+    M, N, K, mb, bk, bn = 64, 64, 256, 2, 32, 16
+    A = rand_values(rng, mb * K * M, DT.BF16)
+    A_run = pack_vnni2(A, mb, K, M)
+    dA = _dev(A_run)
+    shape = capi.gemm_shape(mb, 0, K, K, 0, N, DT.BF16, DT.BF16, DT.BF16, DT.F32)
+    h = api.create_packed_spgemm_bcsc(shape, GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    npat = 110
+    pats = [make_bcsc(np.random.default_rng(500 + i), K, N, bk, bn, 0.3 + 0.004 * i, DT.BF16) for i in range(npat)]
+    nblk = C.c_ulonglong(N // bn)
+    for i in list(range(npat)) + [0, 1, 50, npat - 1]:
+        colptr, rowidx, bvals = pats[i]
+        ref = np.zeros(mb * N * M, dtype=np.uint16)
+        orc.lib.oracle_packed_spgemm_bcsc(DT.BF16, DT.BF16, M, N, K, mb, bk, bn, 1, A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, 1)
+        dB, dC = _dev(bvals), _dev(np.zeros(mb * N * M, dtype=np.uint16))
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = \
+            dA.data_ptr(), dB.data_ptr(), colptr.ctypes.data, rowidx.ctypes.data, C.addressof(nblk), dC.data_ptr()
+        capi.Api.call(h, p)
+        api.hip_sync(); api.check()
+        assert normf_rel(ref, _host(dC, np.uint16), DT.BF16) <= 5e-3, i
+    api.release_kernel(h)
+
+
 @pytest.mark.parametrize("M,N,K,P,density,beta0", [(9, 9, 9, 16, 0.3, 1), (9, 9, 9, 16, 0.3, 0), (35, 35, 4, 32, 0.1, 0), (20, 9, 7, 64, 0.5, 1), (35, 35, 20, 4096, 0.09, 1), (12, 7, 3, 10, 0.4, 0)])
 def test_packed_csc_csparse(M, N, K, P, density, beta0):
     """libxsmm_create_packed_spgemm_csc with ldc == 0: C sparse, the packed axis reduced [ref: src/generator_packed_spgemm.c:81-94]."""
