@@ -2202,6 +2202,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
 //     "loop-invariant VGPR + immediate".  0.726 -> 0.68 us per stage; what remains is the issue cost of a request itself (about 55 cycles against the
 //     32-cycle shadow of an MFMA, wherever it is placed and also with two waves per SIMD) on top of a body that runs at the chip's POWER roof: bare
 //     MFMAs on register operands with these operand values sustain 73 % of the 2.5 PF figure (1.75 GHz), this kernel without requests 70 %.
+//   * Round 4: the four waves run identical code, so all four SIMDs of the CU issue their request behind the same MFMA and could queue behind each other at
+//     the one texture addresser.  Per-wave copies of the steady-state loop with the requests 0 / 1 / 3 / 2 MFMAs earlier (requests behind MFMAs {3,7,11,15},
+//     {2,6,10,14}, {0,4,8,12}, {5,9,13,15} of a region) measured 95.0 / 355.2 / 718.1 us against 94.1 / 353.6 / 712.0 us (4096^3, K = 16 384, 8192^3; verified):
+//     no collision to remove -- not adopted (profiles/r04b_bf16_macro_staggered_requests_not_adopted.jsonl).
 //   * 16 x 16 x 16 problems (PE = 16, K16): a stage is two consecutive batch-reduce blocks.
 // Accumulation order per output = the k order of the single-problem kernels: bitwise the same results.
 // ------------------------------------------------------------------------------------------------
