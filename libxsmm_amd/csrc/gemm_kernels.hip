@@ -942,9 +942,11 @@ template <int AUX> __device__ __forceinline__ f32x4 ld16_pol(__amdgpu_buffer_rsr
 // POL 1: operands loaded `nt`, C as dword nt stores: 9.65 us from HBM but 8.4 us on resident operands (an nt read is not kept in the
 //        Infinity Cache): only for launches that move more than the Infinity Cache holds, whose operands cannot be resident anyway.
 // POL 2: plain loads, dword nt stores (C not 16-byte aligned).
+// POL 3 (round 4): POL 1's nt loads with POL 0's 16-byte stores through the LDS image -- tools/headline_probe: a copy of this footprint with nt loads and 16-byte nt
+//        stores takes 8.99 us where the POL 1 kernel takes 9.99 (dword stores: four times the store instructions).
 template <bool TA, bool TB, bool SINGLE, int POL>
 __global__ __launch_bounds__(256) void gemm_f32_stream_kernel_lean(LeanF32Args p) {
-  constexpr int AUX = POL == 0 ? 17 : (POL == 1 ? 2 : 0);
+  constexpr int AUX = POL == 0 ? 17 : ((POL == 1 || POL == 3) ? 2 : 0);
   __shared__ __attribute__((aligned(16))) float lds_all[4][2048];
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int bidx = blockIdx.x * 4u + wave;
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(256) void gemm_f32_stream_kernel_lean(LeanF32Args p
     }
   }
   gptr ctile = (gptr)p.c + (long long)bidx * p.bs_c;
-  if (POL == 0) {
+  if (POL == 0 || POL == 3) {
     // C tile -> column-major LDS image (lanes along i: conflict free) -> whole 128-byte columns, 16 bytes per lane
 #pragma unroll
     for (int r2 = 0; r2 < 16; ++r2) lds[li + (unsigned int)jl_of(r2, (int)h) * 32u] = acc[r2];
@@ -4460,10 +4462,11 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         const bool c16 = ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)((long long)a.ldc * 4)) & 15ull) == 0ull);
         int pol = stream_nt(a, 4, 4) ? 1 : 0;
         (void)footprint;
-        if (pol_env >= 0 && pol_env <= 2) pol = pol_env;
-        if (pol == 0 && !c16) pol = 2;
+        if (pol == 1 && c16) pol = 3;                        // nt loads AND whole 16-byte stores
+        if (pol_env >= 0 && pol_env <= 3) pol = pol_env;
+        if ((pol == 0 || pol == 3) && !c16) pol = pol == 0 ? 2 : 1;
 #define LAUNCH_LEAN__(TA_, TB_, S_, P_) hipLaunchKernelGGL((gemm_f32_stream_kernel_lean<TA_, TB_, S_, P_>), grid, dim3(256), 0, st, la)
-#define LAUNCH_LEAN_S_(TA_, TB_, S_) do { if (pol == 0) LAUNCH_LEAN__(TA_, TB_, S_, 0); else if (pol == 1) LAUNCH_LEAN__(TA_, TB_, S_, 1); else LAUNCH_LEAN__(TA_, TB_, S_, 2); } while (0)
+#define LAUNCH_LEAN_S_(TA_, TB_, S_) do { if (pol == 0) LAUNCH_LEAN__(TA_, TB_, S_, 0); else if (pol == 1) LAUNCH_LEAN__(TA_, TB_, S_, 1); else if (pol == 3) LAUNCH_LEAN__(TA_, TB_, S_, 3); else LAUNCH_LEAN__(TA_, TB_, S_, 2); } while (0)
 #define LAUNCH_LEAN_(TA_, TB_) do { if (la.nchunks == 1) LAUNCH_LEAN_S_(TA_, TB_, true); else LAUNCH_LEAN_S_(TA_, TB_, false); } while (0)
         if (!ta && !tb) LAUNCH_LEAN_(false, false); else if (ta && !tb) LAUNCH_LEAN_(true, false); else if (!ta && tb) LAUNCH_LEAN_(false, true); else LAUNCH_LEAN_(true, true);
 #undef LAUNCH_LEAN_S_

@@ -38,6 +38,21 @@ __global__ __launch_bounds__(256) void copy_tile(const float* A, const float* B,
 #pragma unroll
   for (int q = 0; q < 4; ++q) st4<NTS>(c + lane + 64 * q, va[q] + vb[q]);
 }
+// round 4: the same with every XCD (hardware workgroup b -> XCD b % 8) owning a CONTIGUOUS eighth of the problems instead of every eighth workgroup's
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void copy_tile_xcd(const float* A, const float* B, float* C, int nb) {
+  const unsigned int b = blockIdx.x, g = gridDim.x;
+  const unsigned int lb = (g & 7u) == 0u ? (b & 7u) * (g >> 3) + (b >> 3) : b;
+  const int wid = (int)(lb * 4u) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wid >= nb) return;
+  const f32x4* a = (const f32x4*)(A + (size_t)wid * 1024); const f32x4* bb = (const f32x4*)(B + (size_t)wid * 1024);
+  f32x4* c = (f32x4*)(C + (size_t)wid * 1024);
+  f32x4 va[4], vb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { va[q] = ld4<NTL>(a + lane + 64 * q); vb[q] = ld4<NTL>(bb + lane + 64 * q); }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) st4<NTS>(c + lane + 64 * q, va[q] + vb[q]);
+}
 // fine-grained: one 16-byte C chunk per thread (2 loads, 1 store), 4x the waves
 __global__ __launch_bounds__(256) void copy_fine(const float* A, const float* B, float* C, int nb) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -215,6 +230,8 @@ int main(int argc, char** argv) {
     {"copy_tile", 256, 8, copy_tile<false, false>, false, 0},
     {"copy_tile_nts", 256, 8, copy_tile<false, true>, false, 0},
     {"copy_tile_ntls", 256, 8, copy_tile<true, true>, false, 0},
+    {"copy_tile_xcd", 256, 8, copy_tile_xcd<false, false>, false, 0},
+    {"copy_tile_xcd_ntls", 256, 8, copy_tile_xcd<true, true>, false, 0},
     {"copy_fine", 256, 2, copy_fine, false, 0},
     {"copy_persist512", 256, 8, copy_persist, false, 512},
     {"copy_persist1024", 256, 8, copy_persist, false, 1024},

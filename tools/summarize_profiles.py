@@ -166,7 +166,20 @@ if mfma:
         # 16x16x32 in 16), 8-bit 2048
         kname = e.get("kernel", "")
         rate = 32.0 if "f64" in kname else (2048.0 if ("i8" in kname or "fp8" in kname) else (1024.0 if ("bf16" in kname or "f16" in kname or e["dtype"] in ("bf16", "f16")) else 64.0))
-        expected = flops / rate
+        # round 4: the 16^3 bf16 kernels multiply with v_mfma_f32_16x16x16_bf16 (8192 flop in 16 cycles: half the rate of the 32x32x16 / 16x16x32 forms); the integer
+        # BCSC kernel with v_mfma_i32_16x16x32_i8 (16 384 operations in 16 cycles) plus one correction MFMA per four (unsigned operand); the ragged f32 kernel pads
+        # m, n to 32 and k to 2: its matrix pipe works on the padded shape
+        work = 1.0
+        if "bf16_p16" in kname or ("gemm_p16_kernel" in kname and e["dtype"] == "bf16"):
+            rate = 512.0
+        if "bcsc_mfma_i8" in kname:
+            rate, work = 1024.0, 1.25
+        import re as _re
+        mm = _re.search(r"_m(\d+)_", label)
+        if "ragged" in kname and mm:
+            m_ = int(mm.group(1)); pad = lambda x, q: (x + q - 1) // q * q      # noqa: E731
+            work = pad(m_, 32) ** 2 * pad(m_, 2) / float(m_ ** 3)
+        expected = flops * work / rate
         us_pmc = sum(x[2].get("_us", 0.0) for x in seg) / n
         clock_ghz = min(2.4, gui / 8.0 / (us_pmc * 1e3)) if us_pmc > 0 else 0.0   # cycles per ns while the counters were on (GUI_ACTIVE also covers the
                                                                                    # dispatch set-up of a short launch, hence the cap at the 2.4 GHz maximum)
