@@ -2563,6 +2563,8 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
   }
   const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
   const int kconst = (UA && UB) ? 16384 * (int)(p.br_count * (unsigned long long)p.k) : 0;
+  // (round 4: the 4-byte results through the wave's LDS image and out as whole 128-byte columns, 16 bytes per lane -- four store instructions per tile instead of
+  //  sixteen, the f32 streaming kernel's epilogue -- measured no gain: u8 x i8 64^3 0.70 against 0.71, 32^3 0.76 against 0.74; not kept)
   static_for<MT * NT>([&](auto idx) {
     constexpr int mt = idx.value / NT, nt = idx.value % NT;
     GM char* ctile = (GM char*)q.c + 4ull * ((unsigned long long)(job.j0 + 32 * nt + 4 * h) * (unsigned int)p.ldc + job.i0 + 32 * mt + li);
