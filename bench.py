@@ -5,7 +5,7 @@ Headline (the `value`): BASELINE.json configs[1] -- strided BRGEMM, fp32, m=n=k=
 (A_i, B_i, C_i) problems launched through ONE libxsmm_dispatch_brgemm(STRIDE) handle with
 libxsmm_hip_gemm_batch_strided.  One "step" = one such launch over one batch.
 
-Output contract: the LAST stdout line is one compact JSON object (< 3 KB: the driver keeps an 8 KB tail) with the headline, its roofline,
+Output contract: the LAST stdout line is one compact JSON object (< 3.5 KB: the driver keeps an 8 KB tail) with the headline, its roofline,
 the CPU baseline and one or two numbers per secondary workload; the full record of the run (every kernel name, time, verification norm,
 CPU sample description) goes to bench_detail.json next to this file and to stderr BEFORE that line.
 
@@ -626,6 +626,42 @@ def run_configs(api, dev, steps, min_seconds, cpu_seconds, with_cpu):
     return out
 
 
+def run_round4(api, dev, steps, min_seconds):
+    """Round-4 workloads outside BASELINE's configs, measured like everything else here (hipGraph replays, HIP events, rotated inputs): 8-bit GEMMs of a shape that is
+    not whole tiles on the masked matrix-core kernel, an 8-bit float GEMM with a result of its own type, the bitmask-compressed-A GEMM and the NORM -> VNNI2
+    transform with leading dimensions that are no multiples of eight.  Parity of each is the GPU test-suite's job (tests/test_gemm_gpu.py: SHAPES_I8 / SHAPES_FP8,
+    test_more_gemm_types_bit_exact; tests/test_full_size_gpu.py: bitmask; tests/test_meltw_gpu.py: TRANSFORMS); here only the clock runs."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_paths as bp
+    import workloads as wl
+    from libxsmm_amd.capi import DT, GEMM_FLAG, UNARY
+    wl.set_device(dev); bp.DEV = dev
+    specs = [
+        ("i8_m40", lambda: bp.brgemm_i8(api, 40, 2 ** 17, ua=False)),
+        ("u8i8_m40", lambda: bp.brgemm_i8(api, 40, 2 ** 17, ua=True)),
+        ("bf8_m40", lambda: bp.brgemm_form(api, 40, 2 ** 17, GEMM_FLAG.VNNI_A, a_dt=DT.BF8, c_dt=DT.F32, name="bf8 -> f32")),
+        ("hf8c8_m64", lambda: bp.brgemm_form(api, 64, 2 ** 16, GEMM_FLAG.VNNI_A, a_dt=DT.HF8, c_dt=DT.HF8, name="hf8 -> hf8")),
+        ("bitmaskA_8192x64", lambda: bp.bitmask_gemm(api, 8192, 64, 8192, 0.5)),
+        ("vnni2_ld4090", lambda: bp.meltw_big(api, UNARY.TRANSFORM_NORM_TO_VNNI2, "NORM_TO_VNNI2 bf16", m=4090, in_dt=DT.BF16, out_dt=DT.BF16)),
+    ]
+    out = {}
+    for label, make in specs:
+        try:
+            w = make()
+            for i in range(3):
+                w.step(i)
+            torch.cuda.synchronize(); api.check()
+            _, n, us = timed(w, steps, min_seconds, label=label)
+            api.check()
+            out[label] = {"workload": w.name, "kernel": w.kernel(), "us_per_launch": round(us, 3), "frac_hbm": round(w.alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                          "algorithmic_bytes_per_launch": int(w.alg_bytes), "launches_timed": n}
+            del w
+        except Exception as e:               # a side group: reported, never fails the bench
+            out[label] = {"error": repr(e)[:120]}
+        torch.cuda.empty_cache()
+    return out
+
+
 def compact_line(full, detail_path):
     """The driver keeps an 8 KB tail of stdout: the line it parses carries the contract fields and ONE OR TWO numbers per secondary workload
     ([frac of HBM roofline, % of MFMA peak] for sweep / reuse / ragged, [frac, CPU GFLOP/s on one core] for the BASELINE configs)."""
@@ -640,7 +676,7 @@ def compact_line(full, detail_path):
     cb = full.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
-        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:110]
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:64]
         if "all_cores" in cb:
             line["cpu_baseline"]["all_cores"] = {"value": cb["all_cores"]["value"], "cores": cb["all_cores"]["cores"]}
     sc = full.get("single_call_us")
@@ -669,6 +705,8 @@ def compact_line(full, detail_path):
     if any(full.get(g) for g in ("sweep", "reuse", "ragged")):
         line["sweep_fields"] = "[frac_hbm, pct_mfma_peak]"
         line["sweep_verified"] = all(r.get("verified", True) for g in ("sweep", "reuse", "ragged") for r in (full.get(g) or {}).values())
+    if full.get("round4"):
+        line["round4"] = {k: r.get("frac_hbm") for k, r in full["round4"].items()}       # fractions of the HBM roofline; shapes / kernels in the detail record
     if full.get("pipelined"):
         pl = full["pipelined"]
         line["pipelined"] = {k: (v if not isinstance(v, dict) else (round(v["frac_hbm"], 3) if "frac_hbm" in v else None)) for k, v in pl.items()}
@@ -862,6 +900,9 @@ def main():
     configs, roof = {}, None
     if rank == 0 and world == 1 and not args.no_sweep and not args.no_configs:
         configs = run_configs(api, dev, args.steps, min(args.min_seconds, 0.15), args.cpu_seconds, not args.no_cpu_baseline)
+    round4 = {}
+    if rank == 0 and world == 1 and not args.no_sweep and not args.no_configs:
+        round4 = run_round4(api, dev, args.steps, min(args.min_seconds, 0.15))
     pipelined = None
     if rank == 0 and world == 1 and not args.no_sweep:
         pipelined = run_pipelined(api, dev, args.steps, min(args.min_seconds, 0.15), lanes=int(os.environ.get("BENCH_LANES", "8")))
@@ -910,6 +951,8 @@ def main():
             out["without_streaming_hint_us"] = round(auto_us, 3)
         if configs:
             out["configs"] = configs
+        if round4:
+            out["round4"] = round4
         if pipelined:
             out["pipelined"] = pipelined
         if roof:
@@ -922,7 +965,7 @@ def main():
             out["ragged"] = ragged
         if sweep:
             measured = {work.label(): (headline_kernel, kernel_us)}
-            for grp in (sweep, reuse, ragged, configs):
+            for grp in (sweep, reuse, ragged, configs, round4):
                 for k, r in grp.items():
                     if isinstance(r, dict) and "us_per_launch" in r:
                         measured[k] = (r.get("kernel", ""), r["us_per_launch"])

@@ -43,7 +43,7 @@ def line(detail):
 
 def test_line_fits_the_driver_tail(detail, line):
     import bench
-    assert len(json.dumps(line, separators=(",", ":"))) < 3072
+    assert len(json.dumps(line, separators=(",", ":"))) < 3584
     # the worst case the code can produce: every optional object present, long kernel names and sample texts
     fat = dict(detail)
     fat.setdefault("configs", {k: {"frac_hbm": 0.7123, "verified": True, "cpu_baseline": {"value": 123456.78}} for k in
