@@ -3107,7 +3107,8 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
       }
     });
   } else {
-    static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<false, true>(facc[mt][nt], p, q, tc[mt][nt]); });
+    // (plain stores: the columns of a ragged C are pieces of cache lines, which non-temporal stores would send to memory one by one)
+    static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<false, true, false>(facc[mt][nt], p, q, tc[mt][nt]); });
   }
 }
 
