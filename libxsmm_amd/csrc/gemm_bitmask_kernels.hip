@@ -27,7 +27,7 @@
 //     alignment): the bytes, not the instructions.  Tiles were dealt T -> XCD T % 8, so neighbouring tiles -- which share the lines of every bit row's values and of the
 //     bitmap -- sat behind different L2s.  Now every XCD owns a contiguous eighth of the tiles (72 -> 59 us) and the pre-pass re-lays the masks tile by tile (a
 //     block's 64 masks are 512 contiguous bytes instead of 64 lines 2 KiB apart: 59 -> 56.5 us).  Not adopted: lanes beyond a window's count masked off, B requested
-//     before the values (no change).  What is left: 34 us without any value load, 22 us for the loads (64 MB of values at 3 TB/s) -- the two do not overlap.
+//     before the values, values requested three steps ahead instead of two (no change each: the kernel is not waiting for a latency).  What is left: 34 us without any value load, 22 us for the loads (64 MB of values at 3 TB/s) -- the two do not overlap.
 // m % 32 == 0, m <= 32768, k % 16 == 0 with at least 16 steps of 16, 16-bit operands (bf16 / IEEE half), C f32 / bf16 / f16.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -273,16 +273,18 @@ __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p
     // values of the block's first two steps, B operands of its first step
     fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, cur);
     fetch(std::integral_constant<int, 1>{}, std::integral_constant<int, 8>{}, cur);
+    if constexpr (ABL & 4096) fetch(std::integral_constant<int, 2>{}, std::integral_constant<int, 16>{}, cur);       // (experiment: values three steps ahead)
     fetch_b(std::integral_constant<int, 0>{}, s_begin);
     for (unsigned int sb = s_begin; sb < s_end; sb += 8u) {
       static_for<8>([&](auto stc) {
         constexpr int st = stc.value;
         using SlotV = std::integral_constant<int, st & 3>; using SlotB = std::integral_constant<int, st & 1>;
-        using NextV = std::integral_constant<int, (st + 2) & 3>; using NextB = std::integral_constant<int, (st + 1) & 1>;
+        constexpr int AH = (ABL & 4096) ? 3 : 2;
+        using NextV = std::integral_constant<int, (st + AH) & 3>; using NextB = std::integral_constant<int, (st + 1) & 1>;
         // requests: the values of step st + 2 (the next block's first steps from `nxt`), the B operands of step st + 1
         if constexpr (!(ABL & 2048)) fetch_b(NextB{}, sb + st + 1u);       // B first: the counter retires in order, so waiting for this step's B (issued a step ago) then leaves the younger value loads alone
-        if constexpr (st + 2 < 8) fetch(NextV{}, std::integral_constant<int, 8 * (st + 2)>{}, cur);
-        else fetch(NextV{}, std::integral_constant<int, 8 * (st + 2 - 8)>{}, nxt);
+        if constexpr (st + AH < 8) fetch(NextV{}, std::integral_constant<int, 8 * (st + AH)>{}, cur);
+        else fetch(NextV{}, std::integral_constant<int, 8 * (st + AH - 8)>{}, nxt);
         if constexpr (ABL & 2048) fetch_b(NextB{}, sb + st + 1u);
         if (sb + st < s_end) {                               // wave-uniform
           u32x4 a4;
@@ -393,6 +395,7 @@ int launch_gemm_bitmask_reg(const GemmArgs& a, const void* bitmap, void* ws, siz
       case 129: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 1>), grid, dim3(64 * KS), 0, st, p); break;
       case 144: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 16>), grid, dim3(64 * KS), 0, st, p); break;
       case 64: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 64>), grid, dim3(64 * KS), 0, st, p); break;
+      case 4096: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 4096>), grid, dim3(64 * KS), 0, st, p); break;
       case 2048: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 2048>), grid, dim3(64 * KS), 0, st, p); break;
       case 576: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 576>), grid, dim3(64 * KS), 0, st, p); break;
       case 1088: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 1088>), grid, dim3(64 * KS), 0, st, p); break;
