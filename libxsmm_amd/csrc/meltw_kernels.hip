@@ -785,6 +785,34 @@ __global__ __launch_bounds__(256) void gather_cols_vec_kernel(MeltwArgs p, int e
 //   gather : lds[0 .. ldi) = in[.. + j*ldi];  out[i + j*ldo] = lds[idx[i]]
 //   scatter: lds = out column j (read-modify-write: rows that no index names keep their value);  lds[idx[i]] = in[i + j*ldi];  column written back
 // `rows` = staged extent (ldi for gather, ldo for scatter), a multiple of 16 / S elements; used when at least half of the staged rows are touched.
+// NC columns per workgroup (round 4; gather only): every workgroup of the one-column form reads the whole index list again -- as many bytes through L1 as the column
+// it stages -- so a workgroup now stages NC columns (NC * rows * S <= 64 KiB) and a thread uses each index it reads for all of them.
+template <int S, int NC>
+__global__ __launch_bounds__(256) void gs_rows_lds_multi_kernel(MeltwArgs p, int rows) {
+  typedef typename Payload<S>::type T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gs_lds[];
+  T* col = (T*)gs_lds;
+  GM const T* in = (GM const T*)((gcptr)p.in0 + (long long)blockIdx.y * p.bs_in0);
+  GM T* out = (GM T*)((gptr)p.out + (long long)blockIdx.y * p.bs_out);
+  const void* idxp = p.aux_in;
+  const bool idx64 = (p.flags & LIBXSMM_MELTW_FLAG_UNARY_IDX_SIZE_8BYTES) != 0;
+  const long long j0 = (long long)blockIdx.x * NC;
+  const int nvec = rows * S / 16;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (j0 + c < p.n) {
+      GM const u32x4e* src = (GM const u32x4e*)(in + (j0 + c) * p.ldi);
+      for (int v = threadIdx.x; v < nvec; v += 256) ((u32x4e*)col)[c * nvec + v] = src[v];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.m; i += 256) {
+    const long long r = idx64 ? (long long)((GM const unsigned long long*)idxp)[i] : (long long)((GM const unsigned int*)idxp)[i];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) if (j0 + c < p.n) out[i + (j0 + c) * p.ldo] = col[(long long)c * rows + r];
+  }
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void gs_rows_lds_kernel(MeltwArgs p, int rows) {
   typedef typename Payload<S>::type T;
@@ -1676,6 +1704,17 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       } else if ((a.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_ROWS) && !xvec_off && gs_rows_lds_ok(a, sz)) {
         const int rows = a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER ? a.ldi : a.ldo;
         const size_t lds_bytes = (size_t)rows * sz;
+        static const int nc_env = []() { const char* e = getenv("LIBXSMM_HIP_GS_ROWS_NC"); return e ? atoi(e) : 2; }();       // columns per workgroup of the gather (1: the older form).  4096 x 8192 / 2048 x 16384 f32: 1 -> 0.550 / 0.601, 2 -> 0.563 / 0.628, 4 (64 KiB of LDS, two workgroups per CU) -> 0.448 / 0.578
+        if (a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER && nc_env > 1 && (sz == 4 || sz == 2) && a.n >= 64 && ((long long)a.ldi * sz) % 16 == 0) {
+          const int nc = (nc_env >= 4 && lds_bytes * 4 <= 65536) ? 4 : ((lds_bytes * 2 <= 65536) ? 2 : 1);
+          if (nc > 1) {
+            const dim3 g((unsigned int)((a.n + nc - 1) / nc), a.nbatch);
+            if (sz == 4) { if (nc == 4) hipLaunchKernelGGL((gs_rows_lds_multi_kernel<4, 4>), g, dim3(256), lds_bytes * 4, st, a, rows); else hipLaunchKernelGGL((gs_rows_lds_multi_kernel<4, 2>), g, dim3(256), lds_bytes * 2, st, a, rows); }
+            else { if (nc == 4) hipLaunchKernelGGL((gs_rows_lds_multi_kernel<2, 4>), g, dim3(256), lds_bytes * 4, st, a, rows); else hipLaunchKernelGGL((gs_rows_lds_multi_kernel<2, 2>), g, dim3(256), lds_bytes * 2, st, a, rows); }
+            if (name) *name = "gs_rows_lds_multi_kernel";
+            return (int)hipGetLastError();
+          }
+        }
         switch (sz) {
           case 1: hipLaunchKernelGGL((gs_rows_lds_kernel<1>), dim3((unsigned int)a.n, a.nbatch), dim3(256), lds_bytes, st, a, rows); break;
           case 2: hipLaunchKernelGGL((gs_rows_lds_kernel<2>), dim3((unsigned int)a.n, a.nbatch), dim3(256), lds_bytes, st, a, rows); break;

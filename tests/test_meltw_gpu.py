@@ -193,6 +193,20 @@ def test_gather_scatter_bit_exact(dt, mode, idx8):
     assert np.array_equal(refs, _back(dY, Y0))
 
 
+@pytest.mark.parametrize("dt", [DT.F32, DT.BF16])
+@pytest.mark.parametrize("idx8", [0, 1])
+@pytest.mark.parametrize("m,n,big", [(500, 70, 512), (1000, 131, 1024), (4096, 65, 4096)])
+def test_row_gather_of_many_columns_bit_exact(dt, idx8, m, n, big):
+    """Row gather with 64 columns or more (round 4): a workgroup stages four (two) source columns in LDS and uses every index it reads for all of them;
+    column counts that leave a short last workgroup."""
+    rng = np.random.default_rng(19)
+    idt = np.uint64 if idx8 else np.uint32
+    flags = UNARY_FLAG.GS_ROWS | (UNARY_FLAG.IDX_SIZE_8BYTES if idx8 else UNARY_FLAG.IDX_SIZE_4BYTES)
+    idx = rng.choice(big, size=m, replace=(m > big)).astype(idt)
+    ref, got, _, _ = run_unary(UNARY.GATHER, m, n, big, m, dt, dt, flags=flags, aux_in=idx, in_elems=big * n, out_elems=m * n)
+    assert np.array_equal(ref, got)
+
+
 @pytest.mark.parametrize("typ", [UNARY.REDUCE_X_OP_ADD, UNARY.REDUCE_X2_OP_ADD, UNARY.REDUCE_X_X2_OP_ADD, UNARY.REDUCE_X_OP_MAX, UNARY.REDUCE_X_OP_MIN, UNARY.REDUCE_X_OP_ABSMAX])
 @pytest.mark.parametrize("rows", [0, 1])
 @pytest.mark.parametrize("in_dt", [DT.F32, DT.BF16])
