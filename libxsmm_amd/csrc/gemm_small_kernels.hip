@@ -250,6 +250,8 @@ int launch_gemm_p16w(const GemmArgs& a, bool nt, void* stream, const char** kern
     const unsigned int steps = bf16 ? (a.nbatch + 1u) / 2u : a.nbatch;
     // measured (profiles/r04b_p16s_times.jsonl; f32 / bf16 fractions of the HBM roofline, one-shot waves -> 2 / 4 / 8 / 16 steps per wave): 65 536 problems 0.745 / 0.675 ->
     // 0.779 / 0.721, 0.761 / 0.719, 0.737 / 0.701, 0.706 / 0.663; 524 288 problems 0.796 / 0.769 -> 0.794 / 0.787, 0.821 / 0.827, 0.743 / 0.787, 0.728 / 0.739
+    // (workgroups of 8 / 16 waves instead of 4 -- fewer workgroups for the dispatcher to start -- measured slower on the small launches: 4096 problems f32 / bf16 3.43 / 2.76 us ->
+    //  3.53 / 2.91 -> 4.17 / 3.59 us, and no better on the large ones: not kept)
     unsigned int pw = pw_env > 0 ? (unsigned int)pw_env : (steps >= 131072u ? 4u : steps >= 2048u ? 2u : 1u);        // small launches too: 4096 problems 3.73 / 3.88 -> 3.43 / 2.74 us
     if (pw > 1u) {
       const dim3 grid((unsigned int)(((steps + pw - 1u) / pw + 3u) / 4u));
