@@ -312,3 +312,51 @@ def test_equation_heads_accepted_and_refused():
     got = json.loads(r.stdout.strip().splitlines()[-1])
     wrong = {k: v for k, v in got.items() if v == k.startswith("no:")}
     assert not wrong, f"accepted / refused against the table: {wrong}"
+
+
+PLAN_CHILD = r"""
+import json, sys
+sys.path.insert(0, %r)
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, GEMM_FLAG as F
+api = capi.load()
+out = {}
+def g(name, m, n, k, a, b, c, comp, flags=0, lda=None, ldb=None, ldc=None):
+    ta, tb = bool(flags & F.TRANS_A), bool(flags & F.TRANS_B)
+    sh = capi.gemm_shape(m, n, k, lda or (k if ta else m), ldb or (n if tb else k), ldc or m, a, b, c, comp)
+    h = api.dispatch_gemm(sh, flags | F.BETA_0, 0)
+    out[name] = api.hip_kernel_name(h, 0).decode() if h else None
+g("f32_32", 32, 32, 32, DT.F32, DT.F32, DT.F32, DT.F32)
+g("f32_23", 23, 23, 23, DT.F32, DT.F32, DT.F32, DT.F32)
+g("f64_32", 32, 32, 32, DT.F64, DT.F64, DT.F64, DT.F64)
+g("f64_23", 23, 23, 23, DT.F64, DT.F64, DT.F64, DT.F64)
+g("bf16_64_vnni", 64, 64, 64, DT.BF16, DT.BF16, DT.BF16, DT.F32, F.VNNI_A)
+g("i8_64", 64, 64, 64, DT.I8, DT.I8, DT.I32, DT.I32, F.VNNI_A)
+g("i8_96x64", 96, 64, 64, DT.U8, DT.I8, DT.I32, DT.I32, F.VNNI_A)
+g("i8_40", 40, 40, 40, DT.U8, DT.I8, DT.I32, DT.I32, F.VNNI_A)
+g("i8_32x32x48", 32, 32, 48, DT.I8, DT.U8, DT.I32, DT.I32, F.VNNI_A)
+g("i8_flat", 12, 10, 7, DT.I8, DT.I8, DT.I32, DT.I32)
+g("bf8_64", 64, 64, 64, DT.BF8, DT.BF8, DT.F32, DT.F32, F.VNNI_A)
+g("hf8_17x9x12", 17, 9, 12, DT.HF8, DT.HF8, DT.F32, DT.F32, F.VNNI_A, ldc=20)
+g("hf8_40_c8", 40, 40, 40, DT.HF8, DT.HF8, DT.HF8, DT.F32, F.VNNI_A)
+g("hf8_flat", 12, 10, 7, DT.HF8, DT.HF8, DT.F32, DT.F32)
+print("TABLE " + json.dumps(out))
+"""
+
+
+def test_dense_plan_names_without_a_device():
+    """Which kernel family the planner names for a descriptor (host logic: LIBXSMM_HIP_DRYRUN=1).  Round 4: nothing with 8-bit operands in VNNI-4 and whole k-quads is
+    left on the one-element-per-thread kernel, no f64 descriptor at all; launch-time refinements (streaming / blocked / lean variants) are the GPU tests' matter."""
+    env = dict(os.environ, LIBXSMM_HIP_DRYRUN="1", LIBXSMM_VERBOSE="0")
+    r = subprocess.run([sys.executable, "-c", PLAN_CHILD % ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    t = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("TABLE ")][-1][6:])
+    assert all(v is not None for v in t.values()), t
+    assert "mfma_f32" in t["f32_32"] and "mfma_f32" in t["f32_23"]
+    assert "f64" in t["f64_32"] and "f64" in t["f64_23"] and "generic" not in t["f64_23"]
+    assert t["bf16_64_vnni"] == "gemm_mfma_bf16_kernel<2,2>"
+    assert t["i8_64"] == "gemm_i8_stream_kernel<2,2>" and t["i8_96x64"] == "gemm_i8_stream_kernel<1,1>"
+    assert t["i8_40"] == "gemm_mfma_8bit_kernel<2,2>" and t["i8_32x32x48"] == "gemm_mfma_8bit_kernel<1,1>"
+    assert t["bf8_64"] == "gemm_fp8_stream_kernel<2,2>"
+    assert t["hf8_17x9x12"] == "gemm_mfma_8bit_kernel<1,1>" and t["hf8_40_c8"] == "gemm_mfma_8bit_kernel<2,2>"
+    assert t["i8_flat"] == "gemm_generic_kernel" and t["hf8_flat"] == "gemm_generic_kernel"
