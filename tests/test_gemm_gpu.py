@@ -479,6 +479,48 @@ def test_fp8_gemm_matches_oracle(kw):
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 64, 32, 64, 32, DT.BF8, DT.HF8, DT.F32, DT.F32), F.VNNI_A, 0) is None     # mixed 8-bit types
 
 
+@pytest.mark.parametrize("t", [DT.BF8, DT.HF8])
+@pytest.mark.parametrize("m,k", [(64, 64), (40, 40)])
+def test_fp8_results_of_their_own_type_with_special_values(t, m, k):
+    """8-bit float results leave through v_cvt_pk_bf8_f32 / v_cvt_pk_fp8_f32 (round 4); a NaN is the one input whose byte the instruction encodes differently from the
+    reference (sign bit), so those lanes take the software rounding: operands with NaNs, infinities (E5M2) and the largest finite values -- sums that are NaN, infinite or
+    overflow the type -- must give the reference's special values wherever the reference's result is not an ordinary finite number."""
+    case = GemmCase(m, m, k, a_type=t, c_type=t, flags=F.VNNI_A, batch=3, seed=41)
+    A = case.A.view(np.uint8); B = case.B.view(np.uint8)
+    rng = np.random.default_rng(42)
+    big = 0x7e if t == DT.HF8 else 0x7b                     # largest finite magnitudes: 448 (E4M3), 57344 (E5M2)
+    nan = 0x7f if t == DT.HF8 else 0x7e
+    touched = []
+    for arr in (A, B):
+        pos = rng.choice(arr.size, size=24, replace=False)
+        arr[pos[:12]] = big; arr[pos[12:14]] = nan; arr[pos[14:16]] = nan | 0x80
+        if t == DT.BF8:
+            arr[pos[16:18]] = 0x7c; arr[pos[18:20]] = 0xfc   # +-infinity
+        touched.append(pos[:20])
+    # rows of A / columns of B that hold one of these: a large operand makes the matrix core drop the small products of its step (it aligns a step's 16 products to the
+    # largest before adding them), so ordinary results in those rows and columns may be many codes away from the serial f32 sum -- only the special results are held there
+    hot = np.zeros((case.batch, m, m), dtype=bool)            # [batch][j][i]
+    for q in touched[0]:
+        hot[q // (case.lda * k), :, (q // 4) % case.lda] = True
+    for q in touched[1]:
+        hot[q // (case.ldb * m), (q % (case.ldb * m)) // case.ldb, :] = True
+    got, _, handle = case.run_gpu(batched=True)
+    ref, _ = case.run_oracle()
+    g, r = case.valid_region(got).view(np.uint8), case.valid_region(ref).view(np.uint8)
+    emask = 0x78 if t == DT.HF8 else 0x7c
+    special = ((r & 0x7f) == 0x7f) if t == DT.HF8 else ((r & emask) == emask)          # NaN (E4M3: the only special) / NaN or infinity (E5M2)
+    assert special.any()
+    # infinities byte for byte; a NaN must be the same NaN code up to its sign bit (the SIGN of a NaN that an inf - inf or 0 x inf produces is the adding hardware's
+    # convention -- the reference's host CPU and the matrix core differ there -- and survives the conversion on both sides)
+    isnan = special if t == DT.HF8 else (special & ((r & 0x03) != 0))
+    assert np.array_equal(g[special & ~isnan], r[special & ~isnan]), capi.load().hip_kernel_name(handle, 1).decode()
+    assert np.array_equal(g[isnan] & 0x7f, r[isnan] & 0x7f), capi.load().hip_kernel_name(handle, 1).decode()
+    key = lambda x: np.where(x.astype(np.int32) & 0x80, -(x.astype(np.int32) & 0x7f), x.astype(np.int32) & 0x7f)      # noqa: E731
+    calm = ~special & ~hot
+    d = np.abs(key(g[calm]) - key(r[calm]))
+    assert calm.sum() > 0.5 * calm.size and d.max() <= 1 and np.mean(d != 0) < 0.05
+
+
 def test_fp8_mfma_with_wide_exponent_range_data():
     """Operands spread over 2^-14 .. 2^3: the fp8 matrix core aligns the 16 products of an instruction to their largest
     exponent before adding them (measured: 4-5e-5 relative on this data against a sequential f32 sum), which the narrow
