@@ -4491,6 +4491,11 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       break;
     case P_F32_2x2:
       grid = wave_grid(64, 64);
+      if (pl.exact && a.m == 64 && a.n == 64 && a.bs_b == 0 && f32_wg64_ok(a) && operands_aligned16(a, 4)) {       // B shared by the batch: persistent workgroups, B's operands in registers
+        int taken = 0;
+        const int e64 = launch_gemm_f32_wg64_sharedb(a, stream_nt(a, 4, 4), stream, kernel_name, &taken);
+        if (taken) return e64;
+      }
       if (pl.exact && a.m == 64 && a.n == 64 && f32_wg64_ok(a) && operands_aligned16(a, 4)) {
         a.map2d_shift = 0;                                  // one problem per workgroup: the super-tile dealing counts four problems per workgroup
         grid = dim3(a.nbatch);

@@ -126,7 +126,8 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // f32 : B image [16 columns][64 bytes]; the 16-byte piece g of column c sits in slot g ^ 2 (c >> 3): the four lanes of a ds_read_b128 lane group that
 //       share c mod 4 (same 16 banks) then read four different slots.
 // bf16: B image [16 columns][32 bytes] per problem; the 8-byte piece g of column c at byte (8 g) ^ 16 (c >> 3): lanes 0-31 of a ds_read_b64 hit 64 banks.
-template <int AUX>
+// SHB: B is ONE tile shared by the whole batch (batch stride 0: the weights of a layer): requested once per wave, kept in the image of slot 0, one request per step.
+template <int AUX, bool SHB = false>
 __global__ __launch_bounds__(256) void gemm_f32_p16s_kernel(GemmArgs p, unsigned int per_wave) {
   __shared__ __attribute__((aligned(16))) float lds_all[4][2][512];                // per wave and slot: A image (1 KiB) | B image (1 KiB)
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -145,27 +146,29 @@ __global__ __launch_bounds__(256) void gemm_f32_p16s_kernel(GemmArgs p, unsigned
     constexpr int S = decltype(sc)::value;
     const long long e = (long long)(t0 + t);                                        // plain strided 1-D batch, one block per problem (the launcher checks)
     __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.a + e * p.bs_a + vA), (lds_vptr)lds_all[wave][S], 16, 0, AUX);
-    __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.b + e * p.bs_b + vB), (lds_vptr)(lds_all[wave][S] + 256), 16, 0, AUX);
+    if constexpr (!SHB) __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.b + e * p.bs_b + vB), (lds_vptr)(lds_all[wave][S] + 256), 16, 0, AUX);
     cq[S] = (gptr)p.c + e * p.bs_c;
   };
+  constexpr int L = SHB ? 1 : 2;                                                     // requests per step
   auto step = [&](auto sc, unsigned int t) __attribute__((always_inline)) {
     constexpr int S = decltype(sc)::value;
     const bool more = t + 1u < np;
     if (more) issue(std::integral_constant<int, S ^ 1>{}, t + 1u);
     // younger than this step's two requests: the store of the step before and the next step's two requests
-    if (t == 0u) { if (more) wait_vm<2>(); else wait_vm<0>(); }
-    else { if (more) wait_vm<3>(); else wait_vm<1>(); }
+    if (t == 0u) { if (more) wait_vm<L>(); else wait_vm<0>(); }
+    else { if (more) wait_vm<L + 1>(); else wait_vm<1>(); }
     const float* img = lds_all[wave][S];
     float af[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) af[s] = img[((4u * g + s) ^ (g & 1u)) * 16u + x];
-    const f32x4 bv = *(const f32x4*)(img + rB);
+    const f32x4 bv = *(const f32x4*)((SHB ? lds_all[wave][0] : img) + rB);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     f32x4 acc = (f32x4)0.0f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bv[s], acc, 0, 0, 0);
     st_stream((GM f32x4*)(cq[S] + vC), acc);
   };
+  if constexpr (SHB) __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.b + vB), (lds_vptr)(lds_all[wave][0] + 256), 16, 0, 0);     // older than every step's request
   issue(std::integral_constant<int, 0>{}, 0u);
   for (unsigned int t = 0; t < np; t += 2u) {
     step(std::integral_constant<int, 0>{}, t);
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_f32_p16s_kernel(GemmArgs p, unsigned
   }
 }
 
-template <int AUX>
+template <int AUX, bool SHB = false>
 __global__ __launch_bounds__(256) void gemm_bf16_p16s_kernel(GemmArgs p, unsigned int per_wave) {
   __shared__ __attribute__((aligned(16))) unsigned int lds_all[4][2][512];         // per wave and slot: A images of the pair (2 x 512 B) | B images (2 x 512 B)
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -197,23 +200,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_p16s_kernel(GemmArgs p, unsigne
     const long long e0 = (long long)first, e1 = (long long)(two[S] ? first + 1u : first);     // plain strided 1-D batch, one block per problem (the launcher checks)
     const long long emine = (lane >> 5) ? e1 : e0;                                  // the upper half-wave fetches the pair's second problem
     __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.a + emine * p.bs_a + vA), (lds_vptr)lds_all[wave][S], 16, 0, AUX);
-    __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.b + emine * p.bs_b + vB), (lds_vptr)(lds_all[wave][S] + 256), 16, 0, AUX);
+    if constexpr (!SHB) __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.b + emine * p.bs_b + vB), (lds_vptr)(lds_all[wave][S] + 256), 16, 0, AUX);
     cq[S][0] = (gptr)p.c + e0 * p.bs_c; cq[S][1] = (gptr)p.c + e1 * p.bs_c;
   };
+  constexpr int L = SHB ? 1 : 2;                                                     // requests per step
   auto step = [&](auto sc, unsigned int t) __attribute__((always_inline)) {
     constexpr int S = decltype(sc)::value;
     const bool more = t + 1u < np;
     if (more) issue(std::integral_constant<int, S ^ 1>{}, t + 1u);
     // younger than this step's two requests: the two stores of the step before (a pair that is not the last one is always whole) and the next step's two requests
-    if (t == 0u) { if (more) wait_vm<2>(); else wait_vm<0>(); }
-    else { if (more) wait_vm<4>(); else wait_vm<2>(); }
+    if (t == 0u) { if (more) wait_vm<L>(); else wait_vm<0>(); }
+    else { if (more) wait_vm<L + 2>(); else wait_vm<2>(); }
     const unsigned int* img = lds_all[wave][S];
     u32x2_t av[2], bv[2];
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) av[pp][e] = img[pp * 128u + ((2u * g + e) ^ (g & 1u)) * 16u + x];
-      bv[pp] = *(const u32x2_t*)(img + rB + pp * 128u);
+      bv[pp] = *(const u32x2_t*)((SHB ? lds_all[wave][0] : img) + rB + pp * 128u);       // (SHB: both halves of the wave requested the same tile: the two images are equal)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_p16s_kernel(GemmArgs p, unsigne
       }
     }
   };
+  if constexpr (SHB) __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)p.b + vB), (lds_vptr)(lds_all[wave][0] + 256), 16, 0, 0);     // older than every step's request
   issue(std::integral_constant<int, 0>{}, 0u);
   for (unsigned int t = 0; t < np; t += 2u) {
     step(std::integral_constant<int, 0>{}, t);
@@ -255,12 +260,15 @@ int launch_gemm_p16w(const GemmArgs& a, bool nt, void* stream, const char** kern
     unsigned int pw = pw_env > 0 ? (unsigned int)pw_env : (steps >= 131072u ? 4u : steps >= 2048u ? 2u : 1u);        // small launches too: 4096 problems 3.73 / 3.88 -> 3.43 / 2.74 us
     if (pw > 1u) {
       const dim3 grid((unsigned int)(((steps + pw - 1u) / pw + 3u) / 4u));
+      const bool shb = a.bs_b == 0;                          // one B tile for the whole batch
       if (bf16) {
         if (kernel_name) *kernel_name = "gemm_bf16_p16s_kernel";
-        if (nt) hipLaunchKernelGGL((gemm_bf16_p16s_kernel<2>), grid, dim3(256), 0, st, a, pw); else hipLaunchKernelGGL((gemm_bf16_p16s_kernel<0>), grid, dim3(256), 0, st, a, pw);
+        if (shb) { if (nt) hipLaunchKernelGGL((gemm_bf16_p16s_kernel<2, true>), grid, dim3(256), 0, st, a, pw); else hipLaunchKernelGGL((gemm_bf16_p16s_kernel<0, true>), grid, dim3(256), 0, st, a, pw); }
+        else { if (nt) hipLaunchKernelGGL((gemm_bf16_p16s_kernel<2>), grid, dim3(256), 0, st, a, pw); else hipLaunchKernelGGL((gemm_bf16_p16s_kernel<0>), grid, dim3(256), 0, st, a, pw); }
       } else {
         if (kernel_name) *kernel_name = "gemm_f32_p16s_kernel";
-        if (nt) hipLaunchKernelGGL((gemm_f32_p16s_kernel<2>), grid, dim3(256), 0, st, a, pw); else hipLaunchKernelGGL((gemm_f32_p16s_kernel<0>), grid, dim3(256), 0, st, a, pw);
+        if (shb) { if (nt) hipLaunchKernelGGL((gemm_f32_p16s_kernel<2, true>), grid, dim3(256), 0, st, a, pw); else hipLaunchKernelGGL((gemm_f32_p16s_kernel<0, true>), grid, dim3(256), 0, st, a, pw); }
+        else { if (nt) hipLaunchKernelGGL((gemm_f32_p16s_kernel<2>), grid, dim3(256), 0, st, a, pw); else hipLaunchKernelGGL((gemm_f32_p16s_kernel<0>), grid, dim3(256), 0, st, a, pw); }
       }
       return (int)hipGetLastError();
     }

@@ -114,6 +114,11 @@ def test_headline_shape_uses_mfma_tile_kernel():
     _check(GemmCase(16, 16, 16, batch=16387, seed=5, ldb=20, ldc=24), expect_kernel="gemm_f32_p16s_kernel")      # padded B / C columns
     _check(GemmCase(16, 16, 16, batch=40003, seed=6, lda=20), expect_kernel="gemm_f32_p16s_kernel")              # padded A rows
     _check(GemmCase(16, 16, 16, batch=16390, seed=7, ldb=20, lda=18), expect_kernel="gemm_f32_p16_kernel")       # A rows not 16-byte aligned: the round-2 kernel
+    # one B tile shared by the whole batch (stride 0: weights): requested once per wave, one request per step
+    _check(GemmCase(16, 16, 16, batch=16391, seed=11, shared_b=True), expect_kernel="gemm_f32_p16s_kernel")
+    _check(GemmCase(16, 16, 16, batch=3001, seed=12, shared_b=True, ldb=20), expect_kernel="gemm_f32_p16s_kernel")
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=32773, seed=13, shared_b=True), expect_kernel="gemm_bf16_p16s_kernel")
+    _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, batch=5001, seed=14, shared_b=True, ldb=24), expect_kernel="gemm_bf16_p16s_kernel")
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=262145, seed=2), expect_kernel="gemm_bf16_p16s_kernel")   # 4 pairs per wave, the last pair a single problem
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, batch=32771, seed=8, ldb=24, ldc=20), expect_kernel="gemm_bf16_p16s_kernel")
     _check(GemmCase(16, 16, 16, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=70002, seed=9, lda=20), expect_kernel="gemm_bf16_p16s_kernel")
@@ -519,6 +524,21 @@ def test_fp8_results_of_their_own_type_with_special_values(t, m, k):
     calm = ~special & ~hot
     d = np.abs(key(g[calm]) - key(r[calm]))
     assert calm.sum() > 0.5 * calm.size and d.max() <= 1 and np.mean(d != 0) < 0.05
+
+
+def test_shared_b_64_cubed_runs_persistent_workgroups_bitwise_like_the_one_problem_kernel():
+    """64^3 f32 problems with ONE B for the whole batch (round 4): persistent workgroups keep B's operands in registers; the k order is gemm_f32_wg64_kernel's,
+    so the results equal the k-ordered fmaf chain bit for bit.  Batch sizes that leave a short last workgroup; padded leading dimensions."""
+    api = capi.load()
+    for kw in (dict(batch=2051), dict(batch=8195, lda=68, ldb=72, ldc=80), dict(batch=40000)):
+        case = GemmCase(64, 64, 64, seed=61, shared_b=True, **kw)
+        got, _, handle = case.run_gpu(batched=True)
+        assert api.hip_kernel_name(handle, 1).decode() == "gemm_f32_wg64_sharedb_kernel"
+        ref, _ = case.run_oracle(fma=True)
+        assert np.array_equal(case.valid_region(ref), case.valid_region(got))
+    case = GemmCase(64, 64, 64, seed=62, shared_b=True, batch=300)             # too few problems: one workgroup per problem
+    got, _, handle = case.run_gpu(batched=True)
+    assert api.hip_kernel_name(handle, 1).decode() == "gemm_f32_wg64_kernel"
 
 
 def test_fp8_mfma_with_wide_exponent_range_data():

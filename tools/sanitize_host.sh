@@ -12,7 +12,7 @@ FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fvisibility=hidden -I$ROOT
 mkdir -p "$OUT/obj" "$OUT/lib"
 cd "$ROOT/libxsmm_amd/csrc" || exit 1
 for f in runtime.cpp frontend.cpp utils.cpp jit.cpp meqn.cpp; do /opt/rocm/bin/hipcc $FLAGS -x hip -c $f -o "$OUT/obj/$f.o" & done
-for f in gemm_kernels.hip gemm_f64_kernels.hip gemm_small_kernels.hip gemm_bitmask_kernels.hip sparse_kernels.hip meltw_kernels.hip; do /opt/rocm/bin/hipcc $FLAGS -c $f -o "$OUT/obj/$f.o" & done
+for f in gemm_kernels.hip gemm_f64_kernels.hip gemm_small_kernels.hip gemm_sharedb_kernels.hip gemm_bitmask_kernels.hip sparse_kernels.hip meltw_kernels.hip; do /opt/rocm/bin/hipcc $FLAGS -c $f -o "$OUT/obj/$f.o" & done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -fno-gpu-sanitize "$OUT"/obj/*.o -ldl -o "$OUT/lib/libxsmm_amd.so" || exit 1
 
@@ -42,7 +42,7 @@ TS="$OUT/tsan"; mkdir -p "$TS/obj" "$TS/lib"
 TFLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fvisibility=hidden -I$ROOT/include -fsanitize=thread -fno-gpu-sanitize"
 cd "$ROOT/libxsmm_amd/csrc" || exit 1
 for f in runtime.cpp frontend.cpp utils.cpp jit.cpp meqn.cpp; do /opt/rocm/bin/hipcc $TFLAGS -x hip -c $f -o "$TS/obj/$f.o" & done
-for f in gemm_kernels.hip gemm_f64_kernels.hip gemm_small_kernels.hip gemm_bitmask_kernels.hip sparse_kernels.hip meltw_kernels.hip; do /opt/rocm/bin/hipcc $TFLAGS -c $f -o "$TS/obj/$f.o" & done
+for f in gemm_kernels.hip gemm_f64_kernels.hip gemm_small_kernels.hip gemm_sharedb_kernels.hip gemm_bitmask_kernels.hip sparse_kernels.hip meltw_kernels.hip; do /opt/rocm/bin/hipcc $TFLAGS -c $f -o "$TS/obj/$f.o" & done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=thread -fno-gpu-sanitize "$TS"/obj/*.o -ldl -o "$TS/lib/libxsmm_amd.so" || exit 1
 gcc -std=c99 -D_POSIX_C_SOURCE=200809L -O1 -g -I"$ROOT/include" "$ROOT/examples/registry_check.c" -L"$TS/lib" -lxsmm_amd -Wl,-rpath,"$TS/lib" \
