@@ -1926,6 +1926,112 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 8-bit WEIGHTS x bf16 activations on the bf16 matrix cores (round 4): BF8 / HF8 weights (A in VNNI-2 byte pairs or flat) [ref: gemm ref :2171-2366] and int8 weights with
+// one f32 scale per row (flat A, the scaled weight rounded to bf16) [ref: gemm ref :1684-1730].  These ran on the one-element-per-thread kernel.  The weights become the
+// bf16 values the reference multiplies with -- an E5M2 / E4M3 number IS a bf16 number (v_cvt_pk_f32_bf8 / _fp8, the upper halves of the two results), the scaled int8
+// weight is rounded with v_cvt_pk_bf16_f32 -- in registers, on the way into the masked bf16 kernel's operand layout (any shape, any leading dimension, any batch-reduce
+// form); sums in the matrix core's order, epilogues as the bf16 kernels.
+// KIND 0 / 1: BF8 / HF8 in VNNI-2 pairs, 2 / 3: BF8 / HF8 flat, 4: scaled int8 flat.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+template <int KIND> __device__ __forceinline__ unsigned int w8_pair_to_bf16(unsigned int two_bytes, float scf) {      // byte 0 = even k, byte 1 = odd k  ->  packed bf16 pair
+  if constexpr (KIND == 4) {
+    const float f0 = (float)(int)(signed char)(two_bytes & 0xffu) * scf, f1 = (float)(int)(signed char)((two_bytes >> 8) & 0xffu) * scf;
+    return cvt_pk_bf16(f0, f1);
+  } else {
+    const f32x2w f = (KIND & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)two_bytes, false) : __builtin_amdgcn_cvt_pk_f32_bf8((int)two_bytes, false);
+    return (__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xffff0000u);        // exact: both formats have at most 3 significand bits
+  }
+}
+// EXACT: whole 32 x 32 x 32 tiles and 16-byte aligned B columns (the host checks): no masks, a step's B operand is ONE 16-byte load.
+template <int MT, int NT, int KIND, bool EXACT>
+__global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
+  constexpr bool PAIRS = KIND < 2;
+  const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
+  if (!job.active) return;
+  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+  const BatchPtrs q = batch_ptrs(p, job.bidx);
+  f32x16 acc[MT][NT];
+  TileCtx tc[MT][NT];
+  float scf[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int i = job.i0 + 32 * mt + li;
+    scf[mt] = (KIND == 4 && (EXACT || i < p.m)) ? ((GM const float*)(p.a_scf + (long long)job.bidx * p.bs_scf))[i] : 1.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      tc[mt][nt].i = i; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h; tc[mt][nt].ivalid = EXACT || i < p.m;
+      tile_init<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]);
+    }
+  }
+  const int kchunks = (p.k + 31) / 32;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    GM const unsigned char* A8 = (GM const unsigned char*)ar;
+    GM const unsigned short* B = (GM const unsigned short*)br;
+    for (int kc = 0; kc < kchunks; ++kc) {
+      const int k0 = kc * 32;
+      u32x4 af[MT][2], bfr[NT][2];
+      unsigned int raw[MT][2][4][2];                           // every load of the chunk is issued before the first conversion (written as one loop the compiler waited after each)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int kb = k0 + 16 * h + 8 * s;                    // first k of this lane's 8
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int i = job.i0 + 32 * mt + li;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ke = kb + 2 * e;                          // even k of the pair
+            raw[mt][s][e][0] = raw[mt][s][e][1] = 0u;
+            if (EXACT || (i < p.m && ke < p.k)) {
+              if constexpr (PAIRS) raw[mt][s][e][0] = *(GM const unsigned short*)(A8 + ((long long)(ke >> 1) * p.lda + i) * 2);       // (k is even for VNNI-2 A: a pair is whole)
+              else {
+                raw[mt][s][e][0] = A8[(long long)ke * p.lda + i];
+                if (EXACT || ke + 1 < p.k) raw[mt][s][e][1] = A8[(long long)(ke + 1) * p.lda + i];
+              }
+            }
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int kb = k0 + 16 * h + 8 * s;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int j = job.j0 + 32 * nt + li;
+          GM const unsigned short* col = B + (long long)j * p.ldb + kb;
+          if constexpr (EXACT) bfr[nt][s] = *(GM const u32x4*)col;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned int lo = (j < p.n && kb + 2 * e < p.k) ? col[2 * e] : 0u;
+              const unsigned int hi = (j < p.n && kb + 2 * e + 1 < p.k) ? col[2 * e + 1] : 0u;
+              bfr[nt][s][e] = lo | (hi << 16);
+            }
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) af[mt][s][e] = w8_pair_to_bf16<KIND>(raw[mt][s][e][0] | (raw[mt][s][e][1] << 8), scf[mt]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0);
+    }
+  }
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]); });
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 streaming kernel: exact tiles, VNNI-2 A, flat B with 16-byte aligned columns.  Same arithmetic as
 // gemm_mfma_bf16_kernel<MT,NT,true>; what differs is how B reaches the matrix core.  The MFMA operand wants
 // 8 consecutive k of ONE column per lane, i.e. lanes 128 bytes apart in memory: fetched directly, every load
@@ -3484,7 +3590,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
   return true;
 }
 
-enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2, P_MX4_1x1, P_MX4_2x2, P_MXMX_1x1, P_MXMX_2x2, P_MX4I8_1x1, P_MX4I8_2x2, P_M8_1x1, P_M8_2x2 };
+enum GemmPath { P_GENERIC, P_F32_T16, P_F32_1x1, P_F32_2x2, P_BF16_1x1, P_BF16_2x2, P_I8_1x1, P_I8_2x2, P_FP8_1x1, P_FP8_2x2, P_MX4_1x1, P_MX4_2x2, P_MXMX_1x1, P_MXMX_2x2, P_MX4I8_1x1, P_MX4I8_2x2, P_M8_1x1, P_M8_2x2, P_W8_1x1, P_W8_2x2 };
 struct GemmPlan { GemmPath path; bool exact; };
 
 static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, int b_type, int c_type, int vnni_c) {
@@ -3526,6 +3632,11 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
       pl.exact = (m % 64 == 0) && (n % 64 == 0) && (k % 32 == 0);
       if (!pl.exact && ex32) { pl.path = P_F32_1x1; pl.exact = true; }     // e.g. 96^3: exact 32x32 tiles beat masked 64x64 tiles
     }
+    return pl;
+  }
+  if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8 || a_type == LIBXSMM_DATATYPE_I8) && b_type == LIBXSMM_DATATYPE_BF16 && !ta && !tb && !vb &&
+      (c_type == LIBXSMM_DATATYPE_F32 || c_type == LIBXSMM_DATATYPE_BF16) && !(a_type == LIBXSMM_DATATYPE_I8 && va)) {
+    pl.path = (m > 32 && n > 32) ? P_W8_2x2 : P_W8_1x1;         // 8-bit weights x bf16 activations: converted in registers, bf16 matrix cores (round 4)
     return pl;
   }
   if ((a_type == LIBXSMM_DATATYPE_BF8 || a_type == LIBXSMM_DATATYPE_HF8) && (b_type != a_type || (c_type != LIBXSMM_DATATYPE_F32 && c_type != a_type))) return pl;      // mixed operands: generic kernel (C of the operands' type: round 4)
@@ -3591,6 +3702,8 @@ static const char* path_name(GemmPath p) {
     case P_MX4_2x2: return "gemm_mxfp4_stream_kernel<2,2>";
     case P_MXMX_1x1: return "gemm_mx_stream_kernel<1,1>";
     case P_MXMX_2x2: return "gemm_mx_stream_kernel<2,2>";
+    case P_W8_1x1: return "gemm_w8_bf16_kernel<1,1>";
+    case P_W8_2x2: return "gemm_w8_bf16_kernel<2,2>";
     case P_M8_1x1: return "gemm_mfma_8bit_kernel<1,1>";
     case P_M8_2x2: return "gemm_mfma_8bit_kernel<2,2>";
     default: return "gemm_generic_kernel";
@@ -4431,6 +4544,23 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     return true;
   };
   switch (pl.path) {
+    case P_W8_1x1: case P_W8_2x2: {
+      const bool big = pl.path == P_W8_2x2, va8 = (a.flags & LIBXSMM_GEMM_FLAG_VNNI_A) != 0;
+      const int kind = a.a_type == LIBXSMM_DATATYPE_I8 ? 4 : ((a.a_type == LIBXSMM_DATATYPE_HF8 ? 1 : 0) + (va8 ? 0 : 2));
+      grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
+      const int tw = big ? 64 : 32;
+      const unsigned long long bbits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)((long long)a.ldb * 2);
+      const bool exact = (a.m % tw) == 0 && (a.n % tw) == 0 && (a.k % 32) == 0 && (bbits & 15ull) == 0 && !a.list_a && a.br_mode != 1 && a.br_mode != 2 &&
+        (kind >= 2 || ((((unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0)) & 1ull) == 0));
+#define LAUNCH_W8K_(MT_, NT_, K_) do { if (exact) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, true>), grid, dim3(256), 0, st, a); \
+                                       else hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, false>), grid, dim3(256), 0, st, a); } while (0)
+#define LAUNCH_W8_(MT_, NT_) do { switch (kind) { case 0: LAUNCH_W8K_(MT_, NT_, 0); break; case 1: LAUNCH_W8K_(MT_, NT_, 1); break; case 2: LAUNCH_W8K_(MT_, NT_, 2); break; \
+                                                  case 3: LAUNCH_W8K_(MT_, NT_, 3); break; default: LAUNCH_W8K_(MT_, NT_, 4); break; } } while (0)
+      if (big) LAUNCH_W8_(2, 2); else LAUNCH_W8_(1, 1);
+#undef LAUNCH_W8_
+#undef LAUNCH_W8K_
+      break;
+    }
     case P_M8_1x1: case P_M8_2x2: {
       if (launch_m8(pl.path == P_M8_2x2)) break;
       if (kernel_name) *kernel_name = "gemm_generic_kernel";

@@ -1029,6 +1029,15 @@ def test_more_gemm_types_bit_exact(t, m, n, k, lda, ldb, ldc, br, beta, batch):
         gk, rk = key(got.view(np.uint8)), key(ref.view(np.uint8))
         assert np.max(np.abs(gk - rk)) <= 1 and np.mean(gk != rk) < 0.03, (int(np.max(np.abs(gk - rk))), float(np.mean(gk != rk)))
         return
+    if name.startswith("gemm_w8_bf16_kernel"):
+        # round 4: 8-bit float / row-scaled int8 WEIGHTS x bf16 on the bf16 matrix cores -- the weights are converted exactly (resp. rounded like the reference) in
+        # registers, the sum is formed in the matrix core's order: the reference's bounds for bf16 GEMMs
+        assert t["b"] == DT.BF16 and t["a"] in (DT.BF8, DT.HF8, DT.I8)
+        cdt = t["c"]
+        view_c = (lambda x: x.view(np.uint16)) if cdt == DT.BF16 else (lambda x: x)      # noqa: E731
+        rows = lambda x: view_c(x).reshape(batch, n, ldc)[:, :, :m]                        # noqa: E731
+        assert normf_rel(rows(ref), rows(got), cdt) < (TOL_BF16 if cdt == DT.BF16 else TOL_F32), name
+        return
     assert got.tobytes() == ref.tobytes()
     if t["a"] == DT.BF32 and m % 32 == 0 and n % 32 == 0 and k % 32 == 0:
         # whole tiles: the f32 matrix-core streaming kernel with the operands rounded to bf16 in registers (round 3) -- still bit-identical

@@ -81,6 +81,37 @@ def brgemm_form(api, m, batch, flags=0, a_dt=DT.BF16, c_dt=DT.BF16, name=""):
     return w
 
 
+def brgemm_w8(api, m, batch, a_dt=DT.BF8, vnni=True, c_dt=DT.BF16):
+    """8-bit WEIGHTS x bf16 activations [ref: src/generator_gemm_reference_impl.c:2171-2366 (BF8 / HF8 weights, VNNI-2 byte pairs or flat), :1684-1730 (int8 weights with one
+    f32 scale per row, flat)]: m = n = k, one problem per batch element, beta = 0; algorithmic bytes = A (1 byte per weight, + 4 m bytes of scales) + B (bf16) + C."""
+    cs = capi.DT_SIZE[c_dt]
+    flags = (GEMM_FLAG.VNNI_A if (vnni and a_dt != DT.I8) else 0) | GEMM_FLAG.BETA_0
+    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, a_dt, DT.BF16, c_dt, DT.F32), flags, 0, capi.br_config(capi.BR_STRIDE, m * m, m * m * 2, 0))
+    assert h
+    per = m * m + 2 * m * m + m * m * cs + (4 * m if a_dt == DT.I8 else 0)
+    ns = nsets_for(batch * per)
+    if a_dt == DT.I8:
+        As = [torch.randint(-100, 100, (batch * m * m,), device=DEV, dtype=torch.int8) for _ in range(ns)]
+        Ss = [(torch.rand(batch * m, device=DEV) + 0.5) / 64 for _ in range(ns)]
+    else:
+        As = [torch.randint(0x30, 0x48, (batch * m * m,), device=DEV, dtype=torch.uint8) for _ in range(ns)]
+        Ss = [None] * ns
+    Bs = [rnd(batch * m * m, "bf16") for _ in range(ns)]
+    Cs = [torch.zeros(batch * m * m * cs, device=DEV, dtype=torch.uint8) for _ in range(ns)]
+    brc = C.c_ulonglong(1)
+    ps = []
+    for s in range(ns):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc)
+        if Ss[s] is not None:
+            p.a.tertiary = Ss[s].data_ptr()
+        ps.append(p)
+    nm = {DT.BF8: "bf8", DT.HF8: "hf8", DT.I8: "i8 (row scales)"}[a_dt]
+    w = Work(api, f"stride-BRGEMM {nm} weights{' VNNI-2' if flags & GEMM_FLAG.VNNI_A else ' flat'} x bf16 -> {'bf16' if cs == 2 else 'f32'} m=n=k={m} batch={batch} br=1 beta=0",
+             2.0 * m ** 3 * batch, float(batch * per), ns, lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, m * m, m * m * 2, m * m * cs), lambda: api.hip_kernel_name(h, 1).decode())
+    w.keep = (As, Bs, Cs, Ss, ps, brc)
+    return w
+
+
 def brgemm_i8(api, m, batch, ua=True):
     """u8 x i8 -> i32 (VNNI-4 A), m = n = k: algorithmic bytes = 2*m*m (A, B) + 4*m*m (C) per problem."""
     at = DT.U8 if ua else DT.I8
@@ -488,7 +519,8 @@ def main():
                    lambda: brgemm_form(api, 64, nb, F.VNNI_A, a_dt=DT.BF8, c_dt=DT.BF8, name="bf8 -> bf8"),
                    lambda: brgemm_form(api, 64, nb, F.VNNI_A, a_dt=DT.HF8, c_dt=DT.HF8, name="hf8 -> hf8"),
                    lambda: brgemm_form(api, 40, nb * 2, F.VNNI_A, a_dt=DT.BF8, c_dt=DT.F32, name="bf8 -> f32 (40^3)"),
-                   lambda: brgemm_i8(api, 40, nb * 2, ua=True)]
+                   lambda: brgemm_i8(api, 40, nb * 2, ua=True),
+                   lambda: brgemm_w8(api, 64, nb, DT.BF8, True), lambda: brgemm_w8(api, 64, nb, DT.HF8, False), lambda: brgemm_w8(api, 64, nb, DT.I8, False, DT.F32)]
     if "bitmask" in only:    # A compressed by bitmask: a pruned weight matrix times a few activations (round 3: no dense image)
         makers += [lambda: bitmask_gemm(api, 8192, 16, 8192, 0.5), lambda: bitmask_gemm(api, 8192, 64, 8192, 0.5), lambda: bitmask_gemm(api, 8192, 64, 8192, 0.9),
                    lambda: bitmask_gemm(api, 4096, 64, 4096, 0.5)]
