@@ -3119,30 +3119,64 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) sum_a[mt] = 0;
   const int kquads = p.k >> 2, kchunks = (p.k + 31) >> 5;
-  // (a branch-free form -- every load issued unconditionally at a clamped address, the padding a select afterwards -- measured SLOWER on 40^3 problems: 0.51 -> 0.24
-  // for i8 x i8; the lanes beyond m / n then load for real and the kernel needs 138 instead of 120 registers: three waves per SIMD instead of four)
+  // Dword-aligned operands (the usual case): every load of a chunk is issued UNCONDITIONALLY -- a lane beyond m / n reads the last real row / column, a quad beyond k the
+  // last real quad: the same addresses its neighbours request, so no byte more is fetched -- and the padding is a select afterwards.  With a branch around every load
+  // (the first form) the compiler waited for each of the sixteen before it issued the next.  (An earlier branch-free attempt clamped to row / column 0 instead: other
+  // cache lines, 0.51 -> 0.24.)  Misaligned operands assemble their dwords byte by byte.
+  long long aoff[MT], boff[NT]; bool iok[MT], jok[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { const int i = job.i0 + 32 * mt + li; iok[mt] = i < p.m; aoff[mt] = 4ll * (iok[mt] ? i : p.m - 1); }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { const int j = job.j0 + 32 * nt + li; jok[nt] = j < p.n; boff[nt] = (long long)(jok[nt] ? j : p.n - 1) * p.ldb; }
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
+    bool b_al = true;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b_al = b_al && ((((unsigned long long)(size_t)(br + boff[nt])) & 3ull) == 0ull);
+    // (measured on 40^3 problems, branch per load -> unconditional loads: bf8 0.29 -> 0.47, u8 x i8 0.34 -> 0.42, hf8 -> hf8 0.15 -> 0.22, but i8 x i8 0.51 -> 0.45: the
+    //  signed-signed variant has no correction code and fits four waves per SIMD only in the branchy form (120 against 140 registers) -- it keeps that form)
+    constexpr bool CLAMPED = !(INT && !UA && !UB);
+    const bool fast = CLAMPED && ((((unsigned long long)(size_t)ar) & 3ull) == 0ull) && (__builtin_amdgcn_ballot_w64(!b_al) == 0ull);       // wave-uniform
     for (int kc = 0; kc < kchunks; ++kc) {
       unsigned int aw[MT][4], bw[NT][4];
+      if (fast) {
+        bool kok[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kq = INT ? 8 * kc + 4 * h + e : 8 * kc + 4 * (e >> 1) + 2 * h + (e & 1);       // the k-quad of operand dword e (fp8: MFMA step e / 2)
+          kok[e] = kq < kquads;
+          const long long kqs = kok[e] ? (long long)kq : (long long)(kquads - 1);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) aw[mt][e] = *(GM const unsigned int*)(ar + kqs * p.lda * 4 + aoff[mt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bw[nt][e] = *(GM const unsigned int*)(br + boff[nt] + 4ll * kqs);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) aw[mt][e] = (kok[e] && iok[mt]) ? ((INT && UA) ? (aw[mt][e] ^ 0x80808080u) : aw[mt][e]) : 0u;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bw[nt][e] = (kok[e] && jok[nt]) ? ((INT && UB) ? (bw[nt][e] ^ 0x80808080u) : bw[nt][e]) : 0u;
+        }
+      } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int kq = INT ? 8 * kc + 4 * h + e : 8 * kc + 4 * (e >> 1) + 2 * h + (e & 1);       // the k-quad of operand dword e (fp8: MFMA step e / 2)
+        const int kq = INT ? 8 * kc + 4 * h + e : 8 * kc + 4 * (e >> 1) + 2 * h + (e & 1);
         const bool kok = kq < kquads;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const int i = job.i0 + 32 * mt + li;
           unsigned int v = 0u;
-          if (kok && i < p.m) { v = load_u32_any(ar + ((long long)kq * p.lda + i) * 4); if (INT && UA) v ^= 0x80808080u; }
+          if (kok && iok[mt]) { v = load_u32_any(ar + (long long)kq * p.lda * 4 + aoff[mt]); if (INT && UA) v ^= 0x80808080u; }
           aw[mt][e] = v;
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const int j = job.j0 + 32 * nt + li;
           unsigned int v = 0u;
-          if (kok && j < p.n) { v = load_u32_any(br + (long long)j * p.ldb + 4ll * kq); if (INT && UB) v ^= 0x80808080u; }
+          if (kok && jok[nt]) { v = load_u32_any(br + boff[nt] + 4ll * kq); if (INT && UB) v ^= 0x80808080u; }
           bw[nt][e] = v;
         }
+      }
       }
       if constexpr (INT) {
         i32x4 af[MT], bf[NT];
