@@ -628,7 +628,7 @@ def run_configs(api, dev, steps, min_seconds, cpu_seconds, with_cpu):
 
 def run_round4(api, dev, steps, min_seconds):
     """Round-4 workloads outside BASELINE's configs, measured like everything else here (hipGraph replays, HIP events, rotated inputs): 8-bit GEMMs of a shape that is
-    not whole tiles on the masked matrix-core kernel, an 8-bit float GEMM with a result of its own type, the bitmask-compressed-A GEMM and the NORM -> VNNI2
+    not whole tiles on the masked matrix-core kernel, an 8-bit float GEMM with a result of its own type, 8-bit weights x bf16 activations, the bitmask-compressed-A GEMM and the NORM -> VNNI2
     transform with leading dimensions that are no multiples of eight.  Parity of each is the GPU test-suite's job (tests/test_gemm_gpu.py: SHAPES_I8 / SHAPES_FP8,
     test_more_gemm_types_bit_exact; tests/test_full_size_gpu.py: bitmask; tests/test_meltw_gpu.py: TRANSFORMS); here only the clock runs."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -641,6 +641,8 @@ def run_round4(api, dev, steps, min_seconds):
         ("u8i8_m40", lambda: bp.brgemm_i8(api, 40, 2 ** 17, ua=True)),
         ("bf8_m40", lambda: bp.brgemm_form(api, 40, 2 ** 17, GEMM_FLAG.VNNI_A, a_dt=DT.BF8, c_dt=DT.F32, name="bf8 -> f32")),
         ("hf8c8_m64", lambda: bp.brgemm_form(api, 64, 2 ** 16, GEMM_FLAG.VNNI_A, a_dt=DT.HF8, c_dt=DT.HF8, name="hf8 -> hf8")),
+        ("w8_bf8_m64", lambda: bp.brgemm_w8(api, 64, 2 ** 16, DT.BF8, True)),                     # 8-bit float weights (VNNI-2 pairs) x bf16 -> bf16
+        ("w8_i8s_m64", lambda: bp.brgemm_w8(api, 64, 2 ** 16, DT.I8, False, DT.F32)),              # int8 weights with row scales x bf16 -> f32
         ("bitmaskA_8192x64", lambda: bp.bitmask_gemm(api, 8192, 64, 8192, 0.5)),
         ("vnni2_ld4090", lambda: bp.meltw_big(api, UNARY.TRANSFORM_NORM_TO_VNNI2, "NORM_TO_VNNI2 bf16", m=4090, in_dt=DT.BF16, out_dt=DT.BF16)),
     ]
