@@ -647,6 +647,7 @@ def run_round4(api, dev, steps, min_seconds):
         ("u8i8_m40", lambda: bp.brgemm_i8(api, 40, 2 ** 17, ua=True)),
         ("bf8_m40", lambda: bp.brgemm_form(api, 40, 2 ** 17, GEMM_FLAG.VNNI_A, a_dt=DT.BF8, c_dt=DT.F32, name="bf8 -> f32")),
         ("hf8c8_m64", lambda: bp.brgemm_form(api, 64, 2 ** 16, GEMM_FLAG.VNNI_A, a_dt=DT.HF8, c_dt=DT.HF8, name="hf8 -> hf8")),
+        ("bf16_m40", lambda: bp.brgemm(api, 40, "bf16", 2 ** 16)),                                  # a ragged bf16 shape on the masked bf16 matrix-core kernel
         ("w8_bf8_m64", lambda: bp.brgemm_w8(api, 64, 2 ** 16, DT.BF8, True)),                     # 8-bit float weights (VNNI-2 pairs) x bf16 -> bf16
         ("w8_i8s_m64", lambda: bp.brgemm_w8(api, 64, 2 ** 16, DT.I8, False, DT.F32)),              # int8 weights with row scales x bf16 -> f32
         ("bitmaskA_8192x64", lambda: bp.bitmask_gemm(api, 8192, 64, 8192, 0.5)),
@@ -661,8 +662,9 @@ def run_round4(api, dev, steps, min_seconds):
             torch.cuda.synchronize(); api.check()
             _, n, us = timed(w, steps, min_seconds, label=label)
             api.check()
-            out[label] = {"workload": w.name, "kernel": w.kernel(), "us_per_launch": round(us, 3), "frac_hbm": round(w.alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                          "algorithmic_bytes_per_launch": int(w.alg_bytes), "launches_timed": n}
+            ab = getattr(w, "alg_bytes", None) or w.alg_bytes_per_step
+            out[label] = {"workload": getattr(w, "name", None) or w.label(), "kernel": w.kernel(), "us_per_launch": round(us, 3), "frac_hbm": round(ab / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                          "algorithmic_bytes_per_launch": int(ab), "launches_timed": n}
             del w
         except Exception as e:               # a side group: reported, never fails the bench
             out[label] = {"error": repr(e)[:120]}

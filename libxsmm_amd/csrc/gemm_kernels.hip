@@ -660,7 +660,8 @@ __device__ __forceinline__ void tile_store_impl(const f32x16& acc, const GemmArg
   const long long mask_ld = ((p.ldc + 15) / 16) * 16;
   const bool out_f32 = CF32 || (p.c_type == LIBXSMM_DATATYPE_F32);
   // bf16 fast path needs an even ldc and a 4-byte aligned C
-  const bool pack2 = EXACT && !out_f32 && ((p.ldc & 1) == 0) && ((((unsigned long long)(size_t)q.c) & 3ull) == 0ull);
+  // (round 4: also for ragged tiles with an even m -- every row pair is whole -- with the store masked by row and column)
+  const bool pack2 = (EXACT || (p.m & 1) == 0) && !out_f32 && ((p.ldc & 1) == 0) && ((((unsigned long long)(size_t)q.c) & 3ull) == 0ull);
   if (ACT == 2) {
     if (q.mask) {
       static_for<16>([&](auto rc) {
@@ -686,7 +687,8 @@ __device__ __forceinline__ void tile_store_impl(const f32x16& acc, const GemmArg
       constexpr int g = gc.value, r0 = 2 * g, jr = (r0 & 3) + 8 * (r0 >> 2);
       const unsigned int w = cvt_pk_16(c_f16, act_fixed<ACT>(acc[r0]), act_fixed<ACT>(acc[r0 + 1]));
       const unsigned int n = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-      st_stream<NT>((GM unsigned int*)(base + (long long)jr * p.ldc), (unsigned int)__builtin_amdgcn_perm(n, w, sel));
+      if (EXACT || (t.ivalid && t.j0 + 4 * t.h + (odd ? 1 : 0) + jr < p.n))
+        st_stream<NT>((GM unsigned int*)(base + (long long)jr * p.ldc), (unsigned int)__builtin_amdgcn_perm(n, w, sel));
     });
     return;
   }
@@ -1857,9 +1859,39 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
     GM const unsigned int* A2 = (GM const unsigned int*)ar;    // one dword = (k even, k odd) of one row
     GM const unsigned short* B = (GM const unsigned short*)br;
     const bool bvec = ((((unsigned long long)(size_t)B) & 15ull) == 0ull) && ((p.ldb & 7) == 0);
+    // ragged shapes (round 4): every load of a chunk is issued UNCONDITIONALLY at its neighbour's address -- a lane beyond m / n reads the last real row / column, a k pair
+    // beyond k the last real pair: the same lines its neighbours request -- and the padding is a select afterwards; written with a condition per load the compiler
+    // waited for each load before it issued the next (40^3: 0.15 of the HBM roofline).  B as dwords (k pairs) when its columns start on dwords, else as halves.
+    const bool bdw = !EXACT && ((((unsigned long long)(size_t)B) & 3ull) == 0ull) && ((p.ldb & 1) == 0);
     for (int kc = 0; kc < kchunks; ++kc) {
       const int k0 = kc * 32;
       u32x4 af[MT][2], bfr[NT][2];
+      if (!EXACT && bdw) {
+        const int kpl = (p.k >> 1) - 1;                         // last real k pair (k is even with a VNNI-2 A)
+        bool kok[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kp = (k0 + 16 * h + 8 * s) / 2 + e;
+            kok[s][e] = kp <= kpl;
+            const long long kps = kok[s][e] ? kp : kpl;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { const int i = job.i0 + 32 * mt + li; af[mt][s][e] = A2[kps * p.lda + (i < p.m ? i : p.m - 1)]; }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { const int j = job.j0 + 32 * nt + li; bfr[nt][s][e] = ((GM const unsigned int*)(B + (long long)(j < p.n ? j : p.n - 1) * p.ldb))[kps]; }
+          }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt][s][e] = (kok[s][e] && job.i0 + 32 * mt + li < p.m) ? af[mt][s][e] : 0u;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[nt][s][e] = (kok[s][e] && job.j0 + 32 * nt + li < p.n) ? bfr[nt][s][e] : 0u;
+          }
+      } else
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int kb = k0 + 16 * h + 8 * s;                    // first k of this lane's 8
@@ -1922,7 +1954,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
     });
     return;
   }
-  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]); });
+  // (ragged tiles: plain stores -- their columns are pieces of cache lines, which non-temporal stores would send to memory one by one)
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false, EXACT>(acc[mt][nt], p, q, tc[mt][nt]); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2028,7 +2061,8 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0);
     }
   }
-  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]); });
+  // (ragged tiles: plain stores -- their columns are pieces of cache lines, which non-temporal stores would send to memory one by one)
+  static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false, EXACT>(acc[mt][nt], p, q, tc[mt][nt]); });
 }
 
 // ------------------------------------------------------------------------------------------------
