@@ -1932,6 +1932,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
   }
   if (F16) {
     const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+    if (beta0) {        // the shared epilogue (halves as packed row pairs when m is even), as the bf16 kernel below
+      static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false, EXACT>(acc[mt][nt], p, q, tc[mt][nt]); });
+      return;
+    }
     static_for<MT * NT>([&](auto idx) {
       constexpr int mt = idx.value / NT, nt = idx.value % NT;
       const TileCtx& t = tc[mt][nt];
@@ -2006,6 +2010,48 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
       const int k0 = kc * 32;
       u32x4 af[MT][2], bfr[NT][2];
       unsigned int raw[MT][2][4][2];                           // every load of the chunk is issued before the first conversion (written as one loop the compiler waited after each)
+      if constexpr (!EXACT) {
+        // ragged shapes: as gemm_mfma_bf16_kernel -- every load unconditional at the neighbour's address (last real row / column / k), the padding a select afterwards
+        const int kl = p.k - 1;
+        unsigned int blo[NT][2][4], bhi[NT][2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ke = k0 + 16 * h + 8 * s + 2 * e;
+            const long long k_lo = ke < kl ? ke : kl, k_hi = ke + 1 < kl ? ke + 1 : kl;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const int i = job.i0 + 32 * mt + li, ic = i < p.m ? i : p.m - 1;
+              if constexpr (PAIRS) { raw[mt][s][e][0] = *(GM const unsigned short*)(A8 + (((ke < kl ? ke : kl - 1) >> 1) * (long long)p.lda + ic) * 2); raw[mt][s][e][1] = 0u; }
+              else { raw[mt][s][e][0] = A8[k_lo * p.lda + ic]; raw[mt][s][e][1] = A8[k_hi * p.lda + ic]; }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int j = job.j0 + 32 * nt + li;
+              GM const unsigned short* col = B + (long long)(j < p.n ? j : p.n - 1) * p.ldb;
+              blo[nt][s][e] = col[k_lo]; bhi[nt][s][e] = col[k_hi];
+            }
+          }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ke = k0 + 16 * h + 8 * s + 2 * e;
+            const bool k0ok = ke < p.k, k1ok = ke + 1 < p.k;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const bool iok = job.i0 + 32 * mt + li < p.m;
+              raw[mt][s][e][0] = (iok && k0ok) ? raw[mt][s][e][0] : 0u; raw[mt][s][e][1] = (iok && k1ok) ? raw[mt][s][e][1] : 0u;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const bool jok = job.j0 + 32 * nt + li < p.n;
+              bfr[nt][s][e] = ((jok && k0ok) ? blo[nt][s][e] : 0u) | (((jok && k1ok) ? bhi[nt][s][e] : 0u) << 16);
+            }
+          }
+      } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int kb = k0 + 16 * h + 8 * s;                    // first k of this lane's 8
@@ -2046,6 +2092,7 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
         }
       }
       asm volatile("" ::: "memory");
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
