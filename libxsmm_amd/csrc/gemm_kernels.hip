@@ -1833,8 +1833,9 @@ __global__ __launch_bounds__(256) void gemm_p16_kernel(GemmArgs p) {
 // F16 = true: the same kernel on IEEE halves (v_mfma_f32_32x32x16_f16; plain epilogue only) with the reference's F16 rules: the
 // accumulators start at 0, beta * C is added after the sum, an f32 C is rounded to f16 on the way in [ref: gemm ref :2025-2124].
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int MT, int NT, bool EXACT, bool F16 = false>
+template <int MT, int NT, bool EXACT, bool F16 = false, bool BL = false>      // BL (ragged shapes, B on dwords: launch_gemm): B through LDS
 __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds_img[4][BL ? NT * 2048 : 16];       // ragged shapes: the wave's B chunk ([32 NT columns][32 k] halves, 16-byte slots swizzled)
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
@@ -1863,6 +1864,64 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
     // beyond k the last real pair: the same lines its neighbours request -- and the padding is a select afterwards; written with a condition per load the compiler
     // waited for each load before it issued the next (40^3: 0.15 of the HBM roofline).  B as dwords (k pairs) when its columns start on dwords, else as halves.
     const bool bdw = !EXACT && ((((unsigned long long)(size_t)B) & 3ull) == 0ull) && ((p.ldb & 1) == 0);
+    if constexpr (BL) {
+      // B through LDS: a lane's MFMA operand is eight k of ONE column, i.e. lanes a whole column apart in memory -- fetched into registers every load instruction
+      // touched 32+ cache lines for 4 bytes each.  Here the chunk's B panel is brought in by LDS-DMA a dword per lane (16 lanes = the 64 bytes of one column's chunk,
+      // 4 columns per instruction, no registers, any ldb), the 16-byte slots XOR-swizzled on the source side as in gemm_bf16_stream_kernel, and read back as one
+      // ds_read_b128 per operand.  A (rows contiguous) stays in registers, buffer-addressed (32-bit offsets: the 64-bit addresses of 32 loads held the kernel at 2 waves).
+      char* image = lds_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+      const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar), rb = wave_rsrc(br);
+      const int kpl = (p.k >> 1) - 1;                           // last real k pair (k is even with a VNNI-2 A)
+      const unsigned int d = (unsigned int)lane & 15u, fb = (unsigned int)lane >> 4;
+      unsigned int icol[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { const int i = job.i0 + 32 * mt + li; icol[mt] = 4u * (unsigned int)(i < p.m ? i : p.m - 1); }
+      for (int kc = 0; kc < kchunks; ++kc) {
+        u32x4 af[MT][2], bfr[NT][2];
+#pragma unroll
+        for (int x = 0; x < NT * 8; ++x) {
+          const unsigned int f = fb + 4u * x, pc = (d >> 2) ^ ((f >> 1) & 3u);          // LDS slot lane + 64 x: column f, 16-byte piece pc of its 64 bytes
+          const int kp = kc * 16 + (int)(pc * 4u + (d & 3u)), jc = job.j0 + (int)f;
+          const unsigned int voff = (unsigned int)(jc < p.n ? jc : p.n - 1) * (unsigned int)p.ldb * 2u + 4u * (unsigned int)(kp < kpl ? kp : kpl);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(image + 256 * x), 4, (int)voff, 0, 0, 0);
+        }
+        bool kok[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kp = kc * 16 + 8 * h + 4 * s + e;
+            kok[s][e] = kp <= kpl;
+            const unsigned int krow = (unsigned int)(kok[s][e] ? kp : kpl) * (unsigned int)p.lda * 4u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt][s][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(krow + icol[mt]), 0, 0);
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int f = 32 * nt + li;
+            bfr[nt][s] = *(const u32x4*)(image + f * 64 + (((2 * h + s) ^ ((f >> 1) & 3)) * 16));
+          }
+        // k beyond the problem: zero on BOTH sides (the clamped loads brought real numbers); rows beyond m / columns beyond n only feed results nobody stores
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt][s][e] = kok[s][e] ? af[mt][s][e] : 0u;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[nt][s][e] = kok[s][e] ? bfr[nt][s][e] : 0u;
+          }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+            acc[mt][nt] = mfma_16bit<F16>(bfr[nt][s], af[mt][s], acc[mt][nt]); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // LDS reads retired before the image is refilled
+      }
+      continue;
+    }
     for (int kc = 0; kc < kchunks; ++kc) {
       const int k0 = kc * 32;
       u32x4 af[MT][2], bfr[NT][2];
@@ -3853,6 +3912,14 @@ static bool operands_aligned16(const GemmArgs& a, int elem_size) {
   return (bits & 15ull) == 0ull;
 }
 
+// ragged bf16 / f16 shapes: every B block and column starts on a dword (strided forms only: the alignment of listed blocks is not known on the host), so that the
+// wave's B panel can be fetched a dword per lane by LDS-DMA (gemm_mfma_bf16_kernel<.., BL = true>); LIBXSMM_HIP_RAGGED16_LDS=0 keeps B in registers (measurement switch)
+static bool ragged16_b_dwords(const GemmArgs& a) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_RAGGED16_LDS"); return e && e[0] == '0'; }();
+  if (off || a.list_a || a.br_mode == 1 || a.br_mode == 2 || (a.ldb & 1)) return false;
+  const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0);
+  return (bits & 3ull) == 0ull && (unsigned long long)a.n * (unsigned long long)a.ldb < (1ull << 30) && (unsigned long long)a.k * (unsigned long long)a.lda < (1ull << 30);
+}
 // one masked tile, blobs of at most 1024 dwords, dword-aligned operands, no transposes
 static bool f32_blob_ok(const GemmArgs& a) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOB"); return e && e[0] == '0'; }();
@@ -4773,6 +4840,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       if (a.a_type == LIBXSMM_DATATYPE_F16) {
         if (kernel_name) *kernel_name = "gemm_mfma_f16_kernel<1,1>";
         if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true, true>), grid, dim3(256), 0, st, a);
+        else if (ragged16_b_dwords(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false, true, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false, true>), grid, dim3(256), 0, st, a);
         break;
       }
@@ -4782,6 +4850,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         else hipLaunchKernelGGL((gemm_bf16_stream_kernel<1, 1, 0>), grid, dim3(256), 0, st, a);
       }
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true>), grid, dim3(256), 0, st, a);
+      else if (ragged16_b_dwords(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false, false, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), grid, dim3(256), 0, st, a);
       break;
     case P_BF16_2x2:
@@ -4801,6 +4870,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       if (a.a_type == LIBXSMM_DATATYPE_F16) {
         if (kernel_name) *kernel_name = "gemm_mfma_f16_kernel<2,2>";
         if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true, true>), grid, dim3(256), 0, st, a);
+        else if (ragged16_b_dwords(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false, true, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false, true>), grid, dim3(256), 0, st, a);
         break;
       }
@@ -4819,6 +4889,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2, 0>), grid, dim3(256), 0, st, a);
       }
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
+      else if (ragged16_b_dwords(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false, false, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
       break;
     case P_MXMX_1x1: case P_MXMX_2x2: {

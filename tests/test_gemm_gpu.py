@@ -21,7 +21,7 @@ F = GEMM_FLAG
 
 
 def _tol(case):
-    return {DT.BF16: TOL_BF16, DT.F64: TOL_F64}.get(case.c_type, TOL_F32)
+    return {DT.BF16: TOL_BF16, DT.F64: TOL_F64, DT.F16: 1e-3}.get(case.c_type, TOL_F32)       # (half output: one rounding of sums that differ in their last f32 bits)
 
 
 def _check(case, batched=True, expect_kernel=None):
@@ -168,6 +168,32 @@ SHAPES_F16 = [
     dict(m=12, n=10, k=8, c_type=DT.F32, flags=F.TRANS_B, beta=1),
     dict(m=12, n=10, k=8, c_type=DT.F16, flags=F.VNNI_A | F.TRANS_B),
 ]
+
+
+RAGGED_16BIT = [
+    dict(m=40, n=40, k=40),                                                   # B on dwords: its panel through LDS (a dword per lane, any ldb)
+    dict(m=24, n=24, k=24, beta=1),
+    dict(m=72, n=72, k=72, br_type=capi.BR_STRIDE, br_count=3),               # nine waves per problem, k tail of 8, strided batch-reduce
+    dict(m=40, n=33, k=200, ldb=202, lda=44, ldc=42),                         # seven chunks, padded columns / rows, odd n
+    dict(m=7, n=5, k=2),                                                      # one k pair
+    dict(m=65, n=31, k=34, c_type=DT.F32, beta=1),
+    dict(m=40, n=40, k=40, ldb=41),                                           # columns on odd halves: B in registers (halves)
+    dict(m=40, n=40, k=38, br_type=capi.BR_ADDRESS, br_count=2),              # listed blocks (alignment unknown on the host): B in registers (dwords, decided per block)
+    dict(m=40, n=40, k=38, br_type=capi.BR_OFFSET, br_count=2),
+]
+
+
+@pytest.mark.parametrize("dt", [DT.BF16, DT.F16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("kw", RAGGED_16BIT, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_ragged_16bit_shapes_on_the_masked_matrix_core_kernel(kw, dt):
+    """Shapes that are not whole tiles (round 4: the wave's B panel by LDS-DMA when B starts on dwords, everything else unconditional neighbour-clamped loads; padding
+    by select: k beyond the problem is zero on both sides, whatever the neighbours hold)."""
+    kw = dict(kw)
+    if dt == DT.F16 and kw.get("beta"):
+        kw.pop("beta")                                                        # (halves with beta = 1: covered by SHAPES_F16; same kernel, its own epilogue)
+    kw.setdefault("c_type", dt)
+    name = _check(GemmCase(a_type=dt, flags=F.VNNI_A, batch=37, seed=77, **kw), expect_kernel="gemm_mfma_bf16_kernel" if dt == DT.BF16 else "gemm_mfma_f16_kernel")
+    assert "mfma" in name
 
 
 @pytest.mark.parametrize("kw", SHAPES_F16, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
