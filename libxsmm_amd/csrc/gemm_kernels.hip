@@ -2040,9 +2040,10 @@ template <int KIND> __device__ __forceinline__ unsigned int w8_pair_to_bf16(unsi
   }
 }
 // EXACT: whole 32 x 32 x 32 tiles and 16-byte aligned B columns (the host checks): no masks, a step's B operand is ONE 16-byte load.
-template <int MT, int NT, int KIND, bool EXACT>
+template <int MT, int NT, int KIND, bool EXACT, bool BL = false>          // BL (ragged shapes, B on dwords, k even: launch_gemm): B through LDS as gemm_mfma_bf16_kernel
 __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
   constexpr bool PAIRS = KIND < 2;
+  __shared__ __attribute__((aligned(16))) char lds_img[4][BL ? NT * 2048 : 16];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
@@ -2072,7 +2073,20 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
       if constexpr (!EXACT) {
         // ragged shapes: as gemm_mfma_bf16_kernel -- every load unconditional at the neighbour's address (last real row / column / k), the padding a select afterwards
         const int kl = p.k - 1;
-        unsigned int blo[NT][2][4], bhi[NT][2][4];
+        unsigned int blo[BL ? 1 : NT][2][4], bhi[BL ? 1 : NT][2][4];
+        char* image = lds_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+        if constexpr (BL) {
+          const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br);
+          const unsigned int d = (unsigned int)lane & 15u, fb = (unsigned int)lane >> 4;
+          const int kpl = (p.k >> 1) - 1;
+#pragma unroll
+          for (int x = 0; x < NT * 8; ++x) {
+            const unsigned int f = fb + 4u * x, pc = (d >> 2) ^ ((f >> 1) & 3u);          // LDS slot lane + 64 x: column f, 16-byte piece pc of its 64 bytes
+            const int kp = kc * 16 + (int)(pc * 4u + (d & 3u)), jc = job.j0 + (int)f;
+            const unsigned int voff = (unsigned int)(jc < p.n ? jc : p.n - 1) * (unsigned int)p.ldb * 2u + 4u * (unsigned int)(kp < kpl ? kp : kpl);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(image + 256 * x), 4, (int)voff, 0, 0, 0);
+          }
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -2085,14 +2099,23 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
               if constexpr (PAIRS) { raw[mt][s][e][0] = *(GM const unsigned short*)(A8 + (((ke < kl ? ke : kl - 1) >> 1) * (long long)p.lda + ic) * 2); raw[mt][s][e][1] = 0u; }
               else { raw[mt][s][e][0] = A8[k_lo * p.lda + ic]; raw[mt][s][e][1] = A8[k_hi * p.lda + ic]; }
             }
+            if constexpr (!BL) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
               const int j = job.j0 + 32 * nt + li;
               GM const unsigned short* col = B + (long long)(j < p.n ? j : p.n - 1) * p.ldb;
               blo[nt][s][e] = col[k_lo]; bhi[nt][s][e] = col[k_hi];
             }
+            }
           }
-        asm volatile("" ::: "memory");
+        if constexpr (BL) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { const int f = 32 * nt + li; bfr[nt][s] = *(const u32x4*)(image + f * 64 + (((2 * h + s) ^ ((f >> 1) & 3)) * 16)); }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // (the image is refilled by the next chunk's requests)
+        } else asm volatile("" ::: "memory");
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -2107,7 +2130,8 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
               const bool jok = job.j0 + 32 * nt + li < p.n;
-              bfr[nt][s][e] = ((jok && k0ok) ? blo[nt][s][e] : 0u) | (((jok && k1ok) ? bhi[nt][s][e] : 0u) << 16);
+              if constexpr (BL) bfr[nt][s][e] = k0ok ? bfr[nt][s][e] : 0u;          // (k even: a pair is whole)
+              else bfr[nt][s][e] = ((jok && k0ok) ? blo[nt][s][e] : 0u) | (((jok && k1ok) ? bhi[nt][s][e] : 0u) << 16);
             }
           }
       } else {
@@ -3225,9 +3249,47 @@ __device__ __forceinline__ unsigned int load_u32_any(gcptr p4) {          // a d
 // (lane = column j of B, lane = row i of A): one v_dot4_i32_i8 against 0x01010101 per operand dword into ONE register per tile row / column, the two k halves of
 // the wave added at the end; the column sums reach the accumulator layout (column = register) through 16 ds_bpermute per column tile in the epilogue.  (The
 // streaming kernel spends an MFMA and 16 accumulators per tile row / column on them: here that cost a wave per SIMD -- 216 against 152 registers.)
+// one 32-deep chunk of products of the masked 8-bit kernel: operand dwords aw / bw (padding already zero) into the accumulators, the byte sums of the unsigned forms
 template <int MT, int NT, int KIND, bool UA, bool UB>
+__device__ __forceinline__ void m8_products(const unsigned int (&aw)[MT][4], const unsigned int (&bw)[NT][4], i32x16 (&iacc)[KIND == 0 ? MT : 1][KIND == 0 ? NT : 1],
+                                            f32x16 (&facc)[KIND == 0 ? 1 : MT][KIND == 0 ? 1 : NT], int (&sum_a)[MT], int (&sum_b)[NT]) {
+  constexpr bool INT = KIND == 0, HF8 = KIND == 2;
+  if constexpr (INT) {
+    i32x4 af[MT], bf[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[mt] = i32x4{(int)aw[mt][0], (int)aw[mt][1], (int)aw[mt][2], (int)aw[mt][3]};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[nt] = i32x4{(int)bw[nt][0], (int)bw[nt][1], (int)bw[nt][2], (int)bw[nt][3]};
+    static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+      iacc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[nt], af[mt], iacc[mt][nt], 0, 0, 0); });
+    if constexpr (UA) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum_b[nt] = __builtin_amdgcn_sdot4((int)bw[nt][e], 0x01010101, sum_b[nt], false);
+    }
+    if constexpr (UB) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum_a[mt] = __builtin_amdgcn_sdot4((int)aw[mt][e], 0x01010101, sum_a[mt], false);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+        const long a8 = (long)(((unsigned long long)aw[mt][2 * s + 1] << 32) | aw[mt][2 * s]), b8 = (long)(((unsigned long long)bw[nt][2 * s + 1] << 32) | bw[nt][2 * s]);
+        if (HF8) facc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b8, a8, facc[mt][nt], 0, 0, 0);
+        else facc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(b8, a8, facc[mt][nt], 0, 0, 0); });
+  }
+}
+// BL (strided forms with dword-aligned blocks and columns: launch_gemm): the wave's B panel of a chunk -- 32 bytes of each of its columns, a whole column apart in
+// memory -- by LDS-DMA a dword per lane (eight lanes = one column, eight columns per instruction, no registers) and back as ONE ds_read_b128 (integers) / two
+// ds_read_b64 (8-bit floats: k-quads 4 s + 2 h + {0, 1}) per column tile, the 64 lanes reading the 2 KiB image end to end; A buffer-addressed (32-bit offsets).
+template <int MT, int NT, int KIND, bool UA, bool UB, bool BL = false>
 __global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
   constexpr bool INT = KIND == 0, HF8 = KIND == 2;
+  __shared__ __attribute__((aligned(16))) char lds_img[4][BL ? NT * 1024 : 16];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
@@ -3270,6 +3332,49 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
   for (int nt = 0; nt < NT; ++nt) { const int j = job.j0 + 32 * nt + li; jok[nt] = j < p.n; boff[nt] = (long long)(jok[nt] ? j : p.n - 1) * p.ldb; }
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     gcptr ar, br; br_base(p, q, r, ar, br);
+    if constexpr (BL) {
+      char* image = lds_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+      const __amdgpu_buffer_rsrc_t ra = wave_rsrc(ar), rb = wave_rsrc(br);
+      const unsigned int dq = (unsigned int)lane & 7u, fb = (unsigned int)lane >> 3;
+      for (int kc = 0; kc < kchunks; ++kc) {
+        unsigned int aw[MT][4], bw[NT][4];
+#pragma unroll
+        for (int x = 0; x < NT * 4; ++x) {                      // LDS slot lane + 64 x: column fb + 8 x, k-quad dq of the chunk
+          const int jc = job.j0 + (int)fb + 8 * x, kq = 8 * kc + (int)dq;
+          const unsigned int voff = (unsigned int)(jc < p.n ? jc : p.n - 1) * (unsigned int)p.ldb + 4u * (unsigned int)(kq < kquads ? kq : kquads - 1);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(image + 256 * x), 4, (int)voff, 0, 0, 0);
+        }
+        bool kok[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kq = INT ? 8 * kc + 4 * h + e : 8 * kc + 4 * (e >> 1) + 2 * h + (e & 1);
+          kok[e] = kq < kquads;
+          const unsigned int krow = (unsigned int)(kok[e] ? kq : kquads - 1) * (unsigned int)p.lda * 4u;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) aw[mt][e] = __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(krow + (unsigned int)aoff[mt]), 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const char* col = image + (32 * nt + li) * 32;
+          if constexpr (INT) { const u32x4 t = *(const u32x4*)(col + 16 * h); bw[nt][0] = t[0]; bw[nt][1] = t[1]; bw[nt][2] = t[2]; bw[nt][3] = t[3]; }
+          else {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) { const u32x2 t = *(const u32x2*)(col + 16 * s2 + 8 * h); bw[nt][2 * s2] = t[0]; bw[nt][2 * s2 + 1] = t[1]; }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) aw[mt][e] = (kok[e] && iok[mt]) ? ((INT && UA) ? (aw[mt][e] ^ 0x80808080u) : aw[mt][e]) : 0u;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bw[nt][e] = (kok[e] && jok[nt]) ? ((INT && UB) ? (bw[nt][e] ^ 0x80808080u) : bw[nt][e]) : 0u;
+        }
+        m8_products<MT, NT, KIND, UA, UB>(aw, bw, iacc, facc, sum_a, sum_b);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // LDS reads retired before the image is refilled
+      }
+      continue;
+    }
     bool b_al = true;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b_al = b_al && ((((unsigned long long)(size_t)(br + boff[nt])) & 3ull) == 0ull);
@@ -3318,34 +3423,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
         }
       }
       }
-      if constexpr (INT) {
-        i32x4 af[MT], bf[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = i32x4{(int)aw[mt][0], (int)aw[mt][1], (int)aw[mt][2], (int)aw[mt][3]};
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = i32x4{(int)bw[nt][0], (int)bw[nt][1], (int)bw[nt][2], (int)bw[nt][3]};
-        static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
-          iacc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[nt], af[mt], iacc[mt][nt], 0, 0, 0); });
-        if constexpr (UA) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sum_b[nt] = __builtin_amdgcn_sdot4((int)bw[nt][e], 0x01010101, sum_b[nt], false);
-        }
-        if constexpr (UB) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sum_a[mt] = __builtin_amdgcn_sdot4((int)aw[mt][e], 0x01010101, sum_a[mt], false);
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
-            const long a8 = (long)(((unsigned long long)aw[mt][2 * s + 1] << 32) | aw[mt][2 * s]), b8 = (long)(((unsigned long long)bw[nt][2 * s + 1] << 32) | bw[nt][2 * s]);
-            if (HF8) facc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b8, a8, facc[mt][nt], 0, 0, 0);
-            else facc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(b8, a8, facc[mt][nt], 0, 0, 0); });
-      }
+      m8_products<MT, NT, KIND, UA, UB>(aw, bw, iacc, facc, sum_a, sum_b);
     }
   }
   if constexpr (INT) {
@@ -4714,15 +4792,23 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
     if (kernel_name) *kernel_name = big ? "gemm_mfma_8bit_kernel<2,2>" : "gemm_mfma_8bit_kernel<1,1>";
     const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8;
+    // strided forms whose blocks, rows and columns start on dwords: B through LDS (see the kernel); LIBXSMM_HIP_M8_LDS=0 keeps B in registers (measurement switch)
+    static const bool lds_off = []() { const char* e = getenv("LIBXSMM_HIP_M8_LDS"); return e && e[0] == '0'; }();
+    const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
+      (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) | (unsigned long long)a.ldb;
+    const bool bl = !lds_off && !a.list_a && a.br_mode != 1 && a.br_mode != 2 && (abits & 3ull) == 0ull &&
+      (unsigned long long)a.n * (unsigned long long)a.ldb < (1ull << 31) && (unsigned long long)a.k * (unsigned long long)a.lda < (1ull << 31);
+#define LAUNCH_M8K_(MT_, NT_, K_, UA_, UB_) do { if (bl) hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, K_, UA_, UB_, true>), grid, dim3(256), 0, st, a); \
+                                                 else hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, K_, UA_, UB_, false>), grid, dim3(256), 0, st, a); } while (0)
 #define LAUNCH_M8_(MT_, NT_) do { \
-      if (fp8) { if (a.a_type == LIBXSMM_DATATYPE_HF8) hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 2, false, false>), grid, dim3(256), 0, st, a); \
-                 else hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 1, false, false>), grid, dim3(256), 0, st, a); } \
-      else if (!ua && !ub) hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 0, false, false>), grid, dim3(256), 0, st, a); \
-      else if (ua && !ub) hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 0, true, false>), grid, dim3(256), 0, st, a); \
-      else if (!ua && ub) hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 0, false, true>), grid, dim3(256), 0, st, a); \
-      else hipLaunchKernelGGL((gemm_mfma_8bit_kernel<MT_, NT_, 0, true, true>), grid, dim3(256), 0, st, a); } while (0)
+      if (fp8) { if (a.a_type == LIBXSMM_DATATYPE_HF8) LAUNCH_M8K_(MT_, NT_, 2, false, false); else LAUNCH_M8K_(MT_, NT_, 1, false, false); } \
+      else if (!ua && !ub) LAUNCH_M8K_(MT_, NT_, 0, false, false); \
+      else if (ua && !ub) LAUNCH_M8K_(MT_, NT_, 0, true, false); \
+      else if (!ua && ub) LAUNCH_M8K_(MT_, NT_, 0, false, true); \
+      else LAUNCH_M8K_(MT_, NT_, 0, true, true); } while (0)
     if (big) LAUNCH_M8_(2, 2); else LAUNCH_M8_(1, 1);
 #undef LAUNCH_M8_
+#undef LAUNCH_M8K_
     return true;
   };
   switch (pl.path) {
@@ -4734,7 +4820,9 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       const unsigned long long bbits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)((long long)a.ldb * 2);
       const bool exact = (a.m % tw) == 0 && (a.n % tw) == 0 && (a.k % 32) == 0 && (bbits & 15ull) == 0 && !a.list_a && a.br_mode != 1 && a.br_mode != 2 &&
         (kind >= 2 || ((((unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0)) & 1ull) == 0));
+      const bool bl = !exact && !(a.k & 1) && ragged16_b_dwords(a);        // ragged shapes with B on dwords: B through LDS
 #define LAUNCH_W8K_(MT_, NT_, K_) do { if (exact) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, true>), grid, dim3(256), 0, st, a); \
+                                       else if (bl) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, false, true>), grid, dim3(256), 0, st, a); \
                                        else hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, false>), grid, dim3(256), 0, st, a); } while (0)
 #define LAUNCH_W8_(MT_, NT_) do { switch (kind) { case 0: LAUNCH_W8K_(MT_, NT_, 0); break; case 1: LAUNCH_W8K_(MT_, NT_, 1); break; case 2: LAUNCH_W8K_(MT_, NT_, 2); break; \
                                                   case 3: LAUNCH_W8K_(MT_, NT_, 3); break; default: LAUNCH_W8K_(MT_, NT_, 4); break; } } while (0)
