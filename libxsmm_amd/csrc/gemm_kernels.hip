@@ -1876,6 +1876,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
       unsigned int icol[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) { const int i = job.i0 + 32 * mt + li; icol[mt] = 4u * (unsigned int)(i < p.m ? i : p.m - 1); }
+      // (measured and not adopted: TWO chunks requested together -- second image, second set of A registers, a counted wait -- as gemm_bf16_stream_kernel does: the
+      //  registers and LDS cost a wave per SIMD and every shape lost, 40^3 0.49 -> 0.40, 24^3 0.60 -> 0.48; the masked 8-bit kernel likewise, u8 x i8 0.52 -> 0.49:
+      //  what these kernels are short of is waves, not requests per wave: profiles/r04b_m8_lds.jsonl, tag "two".  Nor can the fourth wave of the 64 x 64 form be
+      //  had by a register bound: 128 registers spill 13 of them, and the scratch set-up alone costs 0.49 -> 0.34, tag "lb4"; 32 x 32 tiles for 40^3 problems --
+      //  four light waves per problem, operands read twice -- 0.44 against 0.55 on the 8-bit kernel, tag "lb4_tile1")
       for (int kc = 0; kc < kchunks; ++kc) {
         u32x4 af[MT][2], bfr[NT][2];
 #pragma unroll
