@@ -710,6 +710,41 @@ __device__ __forceinline__ void tile_store(const f32x16& acc, const GemmArgs& p,
   else tile_store_impl<EXACT, CF32, 3, NT>(acc, p, q, t);
 }
 
+// The same store through a descriptor that carries the exact extent of the C block (prepared with BND, see gemm_mfma_bf16_kernel; off by default): one lane offset
+// per tile, every column offset scalar; a column beyond n lies beyond the extent and its store is dropped by the address unit, rows beyond m are masked lanes.
+// Plain results only (no bitmask, no VNNI C): f32, or 16-bit as packed row pairs when m and ldc are even and C starts on a dword, else element-wise.
+template <int ACT>
+__device__ __forceinline__ void tile_store_buf_impl(const f32x16& acc, const GemmArgs& p, const __amdgpu_buffer_rsrc_t& rc, bool c_dword, const TileCtx& t) {
+  if (!t.ivalid) return;
+  const unsigned int ldc = (unsigned int)p.ldc, lane = threadIdx.x & 63u;
+  if (p.c_type == LIBXSMM_DATATYPE_F32) {
+    const unsigned int voff = ((4u * (unsigned int)t.h) * ldc + (unsigned int)t.i) * 4u;
+    static_for<16>([&](auto rc_) { constexpr int r = rc_.value;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act_fixed<ACT>(acc[r])), rc, (int)voff, (int)(((unsigned int)t.j0 + (unsigned int)((r & 3) + 8 * (r >> 2))) * ldc * 4u), 0); });
+    return;
+  }
+  const bool c_f16 = p.c_type == LIBXSMM_DATATYPE_F16;
+  if (c_dword && !(p.m & 1) && !(ldc & 1u)) {
+    const bool odd = (lane & 1u) != 0;
+    const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
+    const unsigned int voff = ((4u * (unsigned int)t.h + (odd ? 1u : 0u)) * ldc + ((unsigned int)t.i & ~1u)) * 2u;
+    static_for<8>([&](auto gc) { constexpr int g = gc.value, r0 = 2 * g, jr = (r0 & 3) + 8 * (r0 >> 2);
+      const unsigned int w = cvt_pk_16(c_f16, act_fixed<ACT>(acc[r0]), act_fixed<ACT>(acc[r0 + 1]));
+      const unsigned int n = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+      __builtin_amdgcn_raw_buffer_store_b32((unsigned int)__builtin_amdgcn_perm(n, w, sel), rc, (int)voff, (int)(((unsigned int)t.j0 + (unsigned int)jr) * ldc * 2u), 0); });
+    return;
+  }
+  const unsigned int voff = ((4u * (unsigned int)t.h) * ldc + (unsigned int)t.i) * 2u;
+  static_for<16>([&](auto rc_) { constexpr int r = rc_.value;
+    const float y = act_fixed<ACT>(acc[r]);
+    __builtin_amdgcn_raw_buffer_store_b16(c_f16 ? __builtin_bit_cast(unsigned short, (_Float16)y) : f32_to_bf16_rne(y), rc, (int)voff, (int)(((unsigned int)t.j0 + (unsigned int)((r & 3) + 8 * (r >> 2))) * ldc * 2u), 0); });
+}
+__device__ __forceinline__ void tile_store_buf(const f32x16& acc, const GemmArgs& p, const __amdgpu_buffer_rsrc_t& rc, bool c_dword, const TileCtx& t) {
+  if (p.act == 0) tile_store_buf_impl<0>(acc, p, rc, c_dword, t);
+  else if (p.act == 1) tile_store_buf_impl<1>(acc, p, rc, c_dword, t);
+  else tile_store_buf_impl<3>(acc, p, rc, c_dword, t);
+}
+
 // wave -> (batch element, tile) decomposition shared by the MFMA kernels
 struct WaveJob { unsigned int bidx; int i0, j0; bool active; };
 __device__ __forceinline__ WaveJob wave_job(const GemmArgs& p, int tile_m, int tile_n) {
@@ -1833,9 +1868,14 @@ __global__ __launch_bounds__(256) void gemm_p16_kernel(GemmArgs p) {
 // F16 = true: the same kernel on IEEE halves (v_mfma_f32_32x32x16_f16; plain epilogue only) with the reference's F16 rules: the
 // accumulators start at 0, beta * C is added after the sum, an f32 C is rounded to f16 on the way in [ref: gemm ref :2025-2124].
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int MT, int NT, bool EXACT, bool F16 = false, bool BL = false>      // BL (ragged shapes, B on dwords: launch_gemm): B through LDS
-__global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds_img[4][BL ? NT * 2048 : 16];       // ragged shapes: the wave's B chunk ([32 NT columns][32 k] halves, 16-byte slots swizzled)
+// BND (with BL; prepared in round 4 after the GPU budget was spent: NOT measured, NOT verified on the device, off unless LIBXSMM_HIP_RAGGED16_BOUNDED=1): the
+// operand descriptors carry the exact extent of the block, so a request beyond it (a row of the last k pair beyond m, a k pair beyond k in the last column) is dropped
+// by the address unit instead of being clamped in registers -- every lane offset is loop invariant (two registers for B, eight for A, the rest scalar), which is what
+// the fourth wave per SIMD of the 64 x 64 form needs (see decision 32: these kernels are short of waves).  Rows beyond m and columns beyond n read whatever lies
+// inside the block: they only feed results nobody stores.
+template <int MT, int NT, bool EXACT, bool F16 = false, bool BL = false, bool BND = false>      // BL (ragged shapes, B on dwords: launch_gemm): B through LDS
+__global__ __launch_bounds__(256, BND ? 4 : 1) void gemm_mfma_bf16_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds_img[4][BL ? (BND ? (NT + MT) * 2048 : NT * 2048) : 16];       // ragged shapes: the wave's B chunk ([32 NT columns][32 k] halves, 16-byte slots swizzled); BND: A's too
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
   if (!job.active) return;
   const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
@@ -1848,7 +1888,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
     for (int nt = 0; nt < NT; ++nt) {
       tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h;
       tc[mt][nt].ivalid = tc[mt][nt].i < p.m;
-      if (F16) {
+      if (F16 || BND) {                                         // (BND: beta = 0, no bias -- launch_gemm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
       }
@@ -1864,6 +1904,60 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
     // beyond k the last real pair: the same lines its neighbours request -- and the padding is a select afterwards; written with a condition per load the compiler
     // waited for each load before it issued the next (40^3: 0.15 of the HBM roofline).  B as dwords (k pairs) when its columns start on dwords, else as halves.
     const bool bdw = !EXACT && ((((unsigned long long)(size_t)B) & 3ull) == 0ull) && ((p.ldb & 1) == 0);
+    if constexpr (BL && BND) {
+      // BOTH operand panels of a chunk by LDS-DMA, a dword per lane: nothing in flight occupies a register.  A: instruction x fetches k pair x of the chunk for the wave's
+      // 32 MT rows (lanes beyond them idle) into [16 k pairs][32 MT rows] dwords, read back with ds_read_b32 down a column (lanes along the row: conflict free).
+      char* image = lds_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+      char* image_a = image + NT * 2048;
+      const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+      const int kpl = (p.k >> 1) - 1;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(size_t)uniform_u64((unsigned long long)(size_t)ar), (short)0, (int)(((unsigned int)kpl * lda + (unsigned int)p.m) * 4u), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(size_t)uniform_u64((unsigned long long)(size_t)br), (short)0, (int)(((unsigned int)(p.n - 1) * ldb + (unsigned int)p.k) * 2u), 0x00020000);
+      const unsigned int d = (unsigned int)lane & 15u, fb = (unsigned int)lane >> 4;
+      // LDS slot lane + 64 x holds column f = fb + 4 x, 16-byte piece pc = (d >> 2) ^ ((f >> 1) & 3) of its 64 bytes; (f >> 1) & 3 = (fb >> 1) + 2 (x & 1): two lane offsets
+      unsigned int voffB[2];
+      voffB[0] = fb * ldb * 2u + (((d >> 2) ^ (fb >> 1)) * 16u) + (d & 3u) * 4u;
+      voffB[1] = fb * ldb * 2u + (((d >> 2) ^ (fb >> 1) ^ 2u) * 16u) + (d & 3u) * 4u;
+      // A: MT = 2: lane = row of the wave's 64, one k pair per instruction; MT = 1: lane = (k pair parity, row of 32), two k pairs per instruction
+      const unsigned int voffA = MT == 2 ? (unsigned int)lane * 4u : ((unsigned int)h * lda + (unsigned int)li) * 4u;
+      for (int kc = 0; kc < kchunks; ++kc) {
+        // (the scalar offsets are running sums over steps the compiler cannot see through: hoisted out of the loop, the 16 + 16 of them overflowed the scalar file)
+        unsigned int so_b = (unsigned int)job.j0 * ldb * 2u + 64u * (unsigned int)kc, step_b = ldb * 8u;
+        unsigned int so_a = 16u * (unsigned int)kc * lda * 4u + 4u * (unsigned int)job.i0, step_a = (MT == 2 ? 1u : 2u) * lda * 4u;
+        asm volatile("" : "+s"(step_b), "+s"(step_a));
+#pragma unroll
+        for (int x = 0; x < NT * 8; ++x) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(image + 256 * x), 4, (int)voffB[x & 1], (int)so_b, 0, 0); so_b += step_b; }
+#pragma unroll
+        for (int x = 0; x < MT * 8; ++x) {            // LDS slot lane + 64 x: k pair x (MT = 2) / 2 x + h (MT = 1) of the chunk, row lane (li)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(image_a + 256 * x), 4, (int)voffA, (int)so_a, 0, 0); so_a += step_a; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool tail = 16 * kc + 15 > kpl;                       // the chunk that holds k pairs beyond k (wave-uniform): zero on BOTH sides
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          u32x4 af[MT], bfr[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { const int f = 32 * nt + li; bfr[nt] = *(const u32x4*)(image + f * 64 + (((2 * h + s) ^ ((f >> 1) & 3)) * 16)); }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) af[mt][e] = *(const unsigned int*)(image_a + ((8 * h + 4 * s + e) * (32 * MT) + 32 * mt + li) * 4);
+          if (tail) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool kok = kc * 16 + 8 * h + 4 * s + e <= kpl;
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) af[mt][e] = kok ? af[mt][e] : 0u;
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) bfr[nt][e] = kok ? bfr[nt][e] : 0u;
+            }
+          }
+          static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+            acc[mt][nt] = mfma_16bit<F16>(bfr[nt], af[mt], acc[mt][nt]); });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      continue;
+    }
     if constexpr (BL) {
       // B through LDS: a lane's MFMA operand is eight k of ONE column, i.e. lanes a whole column apart in memory -- fetched into registers every load instruction
       // touched 32+ cache lines for 4 bytes each.  Here the chunk's B panel is brought in by LDS-DMA a dword per lane (16 lanes = the 64 bytes of one column's chunk,
@@ -1993,6 +2087,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(GemmArgs p) {
             acc[mt][nt] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bfr[nt][s]), __builtin_bit_cast(f16x8, af[mt][s]), acc[mt][nt], 0, 0, 0)
                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[nt][s]), __builtin_bit_cast(bf16x8, af[mt][s]), acc[mt][nt], 0, 0, 0);
     }
+  }
+  if constexpr (BND) {
+    const unsigned int esz = p.c_type == LIBXSMM_DATATYPE_F32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(size_t)uniform_u64((unsigned long long)(size_t)q.c), (short)0, (int)(((unsigned int)(p.n - 1) * (unsigned int)p.ldc + (unsigned int)p.m) * esz), 0x00020000);
+    const bool c_dword = (uniform_u64((unsigned long long)(size_t)q.c) & 3ull) == 0ull;
+    static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store_buf(acc[mt][nt], p, rc, c_dword, tc[mt][nt]); });
+    return;
   }
   if (F16) {
     const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
@@ -4003,6 +4104,10 @@ static bool ragged16_b_dwords(const GemmArgs& a) {
   const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0);
   return (bits & 3ull) == 0ull && (unsigned long long)a.n * (unsigned long long)a.ldb < (1ull << 30) && (unsigned long long)a.k * (unsigned long long)a.lda < (1ull << 30);
 }
+static bool ragged16_bounded(const GemmArgs& a) {          // see BND at the kernel: prepared, off by default; plain results (beta = 0, no bias, no bitmask, no VNNI C)
+  static const bool on = []() { const char* e = getenv("LIBXSMM_HIP_RAGGED16_BOUNDED"); return e && e[0] == '1'; }();
+  return on && (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && !a.colbias && a.act != 2 && !a.relu_mask && !a.vnni_c && (unsigned long long)a.n * (unsigned long long)a.ldc < (1ull << 29);
+}
 // one masked tile, blobs of at most 1024 dwords, dword-aligned operands, no transposes
 static bool f32_blob_ok(const GemmArgs& a) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOB"); return e && e[0] == '0'; }();
@@ -4933,6 +5038,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       if (a.a_type == LIBXSMM_DATATYPE_F16) {
         if (kernel_name) *kernel_name = "gemm_mfma_f16_kernel<1,1>";
         if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true, true>), grid, dim3(256), 0, st, a);
+        else if (ragged16_b_dwords(a) && ragged16_bounded(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false, true, true, true>), grid, dim3(256), 0, st, a);
         else if (ragged16_b_dwords(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false, true, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false, true>), grid, dim3(256), 0, st, a);
         break;
@@ -4943,6 +5049,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         else hipLaunchKernelGGL((gemm_bf16_stream_kernel<1, 1, 0>), grid, dim3(256), 0, st, a);
       }
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, true>), grid, dim3(256), 0, st, a);
+      else if (ragged16_b_dwords(a) && ragged16_bounded(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false, false, true, true>), grid, dim3(256), 0, st, a);
       else if (ragged16_b_dwords(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false, false, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), grid, dim3(256), 0, st, a);
       break;
@@ -4963,6 +5070,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       if (a.a_type == LIBXSMM_DATATYPE_F16) {
         if (kernel_name) *kernel_name = "gemm_mfma_f16_kernel<2,2>";
         if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true, true>), grid, dim3(256), 0, st, a);
+        else if (ragged16_b_dwords(a) && ragged16_bounded(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false, true, true, true>), grid, dim3(256), 0, st, a);
         else if (ragged16_b_dwords(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false, true, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false, true>), grid, dim3(256), 0, st, a);
         break;
@@ -4982,6 +5090,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         hipLaunchKernelGGL((gemm_bf16_stream_kernel<2, 2, 0>), grid, dim3(256), 0, st, a);
       }
       else if (pl.exact) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, true>), grid, dim3(256), 0, st, a);
+      else if (ragged16_b_dwords(a) && ragged16_bounded(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false, false, true, true>), grid, dim3(256), 0, st, a);
       else if (ragged16_b_dwords(a)) hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false, false, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<2, 2, false>), grid, dim3(256), 0, st, a);
       break;

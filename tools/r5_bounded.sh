@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5, first GPU call: the prepared BND form of the ragged 16-bit kernel (LIBXSMM_HIP_RAGGED16_BOUNDED=1, see gemm_mfma_bf16_kernel) -- parity first, then A/B timing
+mkdir -p gpurun_out
+LIBXSMM_HIP_RAGGED16_BOUNDED=1 timeout 600 python -m pytest tests/test_gemm_gpu.py -m gpu -q -x -p no:cacheprovider -k "ragged_16bit or bf16_gemm_matches or f16" 2>&1 | tail -5
+WL='bp.brgemm(api, 40, "bf16", 2 ** 16);;bp.brgemm(api, 24, "bf16", 2 ** 17);;bp.brgemm(api, 72, "bf16", 2 ** 14);;bp.brgemm(api, 40, "f16", 2 ** 16)'
+TAG=shipped WL="$WL" timeout 300 python tools/time_one.py 2>&1 | grep -v "^$" | tail -4 | tee -a gpurun_out/r5_bounded.jsonl
+LIBXSMM_HIP_RAGGED16_BOUNDED=1 TAG=bounded WL="$WL" timeout 300 python tools/time_one.py 2>&1 | grep -v "^$" | tail -4 | tee -a gpurun_out/r5_bounded.jsonl
