@@ -715,6 +715,10 @@ def compact_line(full, detail_path):
     if any(full.get(g) for g in ("sweep", "reuse", "ragged")):
         line["sweep_fields"] = "[frac_hbm, pct_mfma_peak]"
         line["sweep_verified"] = all(r.get("verified", True) for g in ("sweep", "reuse", "ragged") for r in (full.get(g) or {}).values())
+    if full.get("reuse"):
+        ppr = {k: r["pct_of_power_roof"] for k, r in full["reuse"].items() if r.get("pct_of_power_roof") is not None}
+        if ppr:
+            line["pct_of_power_roof"] = ppr           # blocked entries: % of what back-to-back MFMAs on the same operand values sustain under the power budget (mfma_power_roof_TF)
     if full.get("round4"):
         line["round4"] = {k: r.get("frac_hbm") for k, r in full["round4"].items()}       # fractions of the HBM roofline; shapes / kernels in the detail record
     if full.get("pipelined"):
