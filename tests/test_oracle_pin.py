@@ -59,6 +59,12 @@ GEMM_CASES = [
     dict(m=12, n=10, k=9, a_type=DT.F16, c_type=DT.F16),                       # flat A
     dict(m=12, n=10, k=8, a_type=DT.F16, c_type=DT.F32, flags=F.TRANS_B, beta=1),
     dict(m=16, n=8, k=16, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=4),
+    # the ragged shapes of the round-4 measurements (tests/test_gemm_gpu.py RAGGED_16BIT, bench.py round4): several k chunks with a tail, padded rows / columns
+    dict(m=40, n=33, k=200, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, lda=44, ldb=202, ldc=42),
+    dict(m=72, n=72, k=72, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=40, n=40, k=40, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A),
+    dict(m=40, n=40, k=40, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, beta=1),
+    dict(m=65, n=31, k=34, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, beta=1),
     # MXFP4 weights (packed E2M1 pairs + E8M0 scale per 32-deep k-block and row) times bf16 / f32 activations
     dict(m=32, n=32, k=64, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A),
     dict(m=32, n=16, k=32, a_type=DT.MXFP4X2, b_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, beta=1),
