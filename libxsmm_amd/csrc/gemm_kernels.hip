@@ -4038,6 +4038,9 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     const int t = (pl.path == P_BF16_2x2) ? 64 : 32;
     pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
     if (!pl.exact && pl.path == P_BF16_2x2 && (m % 32 == 0) && (n % 32 == 0) && (k % 32 == 0)) { pl.path = P_BF16_1x1; pl.exact = true; }
+    // measurement switch (round 5: 72^3-class shapes cover 128 x 128 with 64-tiles, 96 x 96 with 32-tiles): LIBXSMM_HIP_RAGGED16_TILE=1 forces 32 x 32 tiles for ragged shapes
+    static const bool small_tiles = []() { const char* e = getenv("LIBXSMM_HIP_RAGGED16_TILE"); return e && e[0] == '1'; }();
+    if (small_tiles && !pl.exact) pl.path = P_BF16_1x1;
     return pl;
   }
   return pl;

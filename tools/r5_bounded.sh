@@ -5,3 +5,7 @@ LIBXSMM_HIP_RAGGED16_BOUNDED=1 timeout 600 python -m pytest tests/test_gemm_gpu.
 WL='bp.brgemm(api, 40, "bf16", 2 ** 16);;bp.brgemm(api, 24, "bf16", 2 ** 17);;bp.brgemm(api, 72, "bf16", 2 ** 14);;bp.brgemm(api, 40, "f16", 2 ** 16)'
 TAG=shipped WL="$WL" timeout 300 python tools/time_one.py 2>&1 | grep -v "^$" | tail -4 | tee -a gpurun_out/r5_bounded.jsonl
 LIBXSMM_HIP_RAGGED16_BOUNDED=1 TAG=bounded WL="$WL" timeout 300 python tools/time_one.py 2>&1 | grep -v "^$" | tail -4 | tee -a gpurun_out/r5_bounded.jsonl
+# 72^3: four 64 x 64 waves (128 x 128 covered) against nine 32 x 32 waves (96 x 96), both forms
+WL='bp.brgemm(api, 72, "bf16", 2 ** 14);;bp.brgemm(api, 40, "bf16", 2 ** 16)'
+LIBXSMM_HIP_RAGGED16_TILE=1 TAG=tile32 WL="$WL" timeout 300 python tools/time_one.py 2>&1 | grep -v "^$" | tail -2 | tee -a gpurun_out/r5_bounded.jsonl
+LIBXSMM_HIP_RAGGED16_TILE=1 LIBXSMM_HIP_RAGGED16_BOUNDED=1 TAG=tile32_bounded WL="$WL" timeout 300 python tools/time_one.py 2>&1 | grep -v "^$" | tail -2 | tee -a gpurun_out/r5_bounded.jsonl
