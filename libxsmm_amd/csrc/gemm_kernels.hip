@@ -2241,6 +2241,18 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
             }
           }
       } else {
+      char* ximage = lds_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+      if constexpr (EXACT && BL) {
+        // (prepared in round 4, not measured, off unless LIBXSMM_HIP_W8_LDS=1) whole tiles: B as gemm_bf16_stream_kernel fetches it -- 16-byte LDS-DMA requests, four
+        // lanes = the 64 bytes of one column's chunk, slots swizzled on the source side -- instead of 16 bytes per lane from 64 different columns
+        const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + 2ull * (unsigned long long)job.j0 * (unsigned long long)p.ldb);
+#pragma unroll
+        for (int x = 0; x < NT * 2; ++x) {
+          const unsigned int L = (unsigned int)lane + 64u * x, f = L >> 2, pc = (L & 3u) ^ ((f >> 1) & 3u);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_vptr)(ximage + 1024 * x), 16, (int)((f * (unsigned int)p.ldb) * 2u + pc * 16u), 64 * kc, 0, 0);
+        }
+        asm volatile("" ::: "memory");                          // (B's requests first: moved behind A's loads the compiler put a counted wait after each of them)
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int kb = k0 + 16 * h + 8 * s;                    // first k of this lane's 8
@@ -2269,7 +2281,8 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
         for (int nt = 0; nt < NT; ++nt) {
           const int j = job.j0 + 32 * nt + li;
           GM const unsigned short* col = B + (long long)j * p.ldb + kb;
-          if constexpr (EXACT) bfr[nt][s] = *(GM const u32x4*)col;
+          if constexpr (EXACT && BL) { (void)col; }
+          else if constexpr (EXACT) bfr[nt][s] = *(GM const u32x4*)col;
           else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -2280,7 +2293,14 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
           }
         }
       }
-      asm volatile("" ::: "memory");
+      if constexpr (EXACT && BL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) { const int f = 32 * nt + li; bfr[nt][s] = *(const u32x4*)(ximage + f * 64 + (((2 * h + s) ^ ((f >> 1) & 3)) * 16)); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // (the image is refilled by the next chunk's requests)
+      } else asm volatile("" ::: "memory");
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -4934,7 +4954,9 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       const bool exact = (a.m % tw) == 0 && (a.n % tw) == 0 && (a.k % 32) == 0 && (bbits & 15ull) == 0 && !a.list_a && a.br_mode != 1 && a.br_mode != 2 &&
         (kind >= 2 || ((((unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0)) & 1ull) == 0));
       const bool bl = !exact && !(a.k & 1) && ragged16_b_dwords(a);        // ragged shapes with B on dwords: B through LDS
-#define LAUNCH_W8K_(MT_, NT_, K_) do { if (exact) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, true>), grid, dim3(256), 0, st, a); \
+      static const bool xlds = []() { const char* e = getenv("LIBXSMM_HIP_W8_LDS"); return e && e[0] == '1'; }();      // prepared, not measured: whole tiles with B through LDS
+#define LAUNCH_W8K_(MT_, NT_, K_) do { if (exact && xlds) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, true, true>), grid, dim3(256), 0, st, a); \
+                                       else if (exact) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, true>), grid, dim3(256), 0, st, a); \
                                        else if (bl) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, false, true>), grid, dim3(256), 0, st, a); \
                                        else hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, false>), grid, dim3(256), 0, st, a); } while (0)
 #define LAUNCH_W8_(MT_, NT_) do { switch (kind) { case 0: LAUNCH_W8K_(MT_, NT_, 0); break; case 1: LAUNCH_W8K_(MT_, NT_, 1); break; case 2: LAUNCH_W8K_(MT_, NT_, 2); break; \
