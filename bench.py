@@ -25,8 +25,12 @@ What the record carries (all measured in this process, on this GPU):
     GPU's shard of 2^17 problems), each as [fraction of the HBM roofline, GFLOP/s of the reference's CPU kernel on one host core], every GPU
     result checked against the oracle; variantB: config #2 as ONE BRGEMM with br = 4096.
 
-N > 1 (launched by torch.distributed.run): one process per GPU, every rank owns its own batch (weak scaling, no data-path
-collective); time = max over ranks between two barriers; value = total flops / time.
+N > 1: one process per GPU, every rank owns its own batch (weak scaling, no data-path collective); time = max over ranks between
+two barriers; value = total flops / time.  The ranks come from the launcher's environment (torch.distributed.run sets WORLD_SIZE / RANK /
+LOCAL_RANK) -- or, when the plain command `python bench.py --gpus N ...` is run WITHOUT a launcher, bench.py starts N ranks itself
+(spawn_ranks: the same torch.distributed.run command line the driver uses, rendezvous on 127.0.0.1) and relays their output, so
+`--gpus N` means N ranks either way.  BENCH_DRY=1 is the plumbing check of exactly that on a box without GPUs (gloo, no kernel is
+launched, `value` 0, "dry": true): tests/test_bench_contract_cpu.py.
 `--config 5`: BASELINE configs[4] instead -- 2^20 bf16 64^3 problems with fused column-bias + ReLU, split over the ranks with
 libxsmm_hip_shard_range (strong scaling), compute leg and (with --gather) the result gather to rank 0 timed separately.
 """
@@ -80,6 +84,78 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-threads", type=int, default=-1, help="threads of the all-core CPU leg (-1: one per usable core, 0/1: skip)")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run -- the command line the driver itself uses for
+    N > 1 -- relay their output and make sure rank 0's JSON line is the LAST line on stdout.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    if os.environ.get("BENCH_DRY") != "1" and "BENCH_DEVICE" not in os.environ:
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this box has {have} (no rank is started: a rank without a device of its own would "
+                  f"measure nothing; BENCH_DEVICE=0 BENCH_BACKEND=gloo shares one device between the ranks for plumbing checks)", file=sys.stderr)
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for text in proc.stdout:
+        if line is not None:                # something followed the last candidate: it was not the last line, let it through
+            sys.stdout.write(line)
+            line = None
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        else:
+            sys.stdout.write(text)
+    rc = proc.wait()
+    sys.stdout.flush()
+    if line is not None:
+        sys.stdout.write(line if line.endswith("\n") else line + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def dry_main(args):
+    """BENCH_DRY=1: the rank / barrier / max-over-ranks / one-line plumbing of the N > 1 path with NO device and NO kernel (CPU-only boxes: the contract test).
+    Nothing is computed and nothing is measured -- `value` is 0 and the line says "dry": true."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(os.environ.get("BENCH_BACKEND", "gloo"))
+    from libxsmm_amd import parallel
+    total = args.total if args.config == 5 else args.batch * world
+    b, e = parallel.shard_range(total, world, rank) if args.config == 5 else (rank * args.batch, (rank + 1) * args.batch)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass                                 # a step of the dry run launches nothing
+    elapsed = time.perf_counter() - t0
+    owned = float(e - b)
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed, owned], dtype=torch.float64)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        elapsed, owned = float(t[0]), float(t[1])
+    out = None
+    if rank == 0:
+        out = {"metric": f"GFLOP/s, batched stride-BRGEMM m=n=k={args.m} {args.dtype}", "value": 0.0, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 6), "higher_is_better": True, "scaling": "strong" if args.config == 5 else "weak", "vs_baseline": None,
+               "dtype": args.dtype, "data": "none", "dry": True, "problems_owned_by_all_ranks": int(owned), "rccl_ranks": 0,
+               "config": {"workload": "DRY RUN: ranks, barriers and the one-line output only; no device, no kernel, nothing measured", "per_gpu_batch": args.batch}}
+    finish(dist, out, None)
 
 
 def gen_values(n, bf16, dev, gen):
@@ -676,7 +752,7 @@ def compact_line(full, detail_path):
     """The driver keeps an 8 KB tail of stdout: the line it parses carries the contract fields and ONE OR TWO numbers per secondary workload
     ([frac of HBM roofline, % of MFMA peak] for sweep / reuse / ragged, [frac, CPU GFLOP/s on one core] for the BASELINE configs)."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "steps_timed", "warmup", "ms_per_step", "timed_region_s", "higher_is_better", "scaling",
-            "vs_baseline", "dtype", "data", "verified", "pct_mfma_peak", "rccl_ranks", "gather_ms", "gather_GBs_into_root")
+            "vs_baseline", "dtype", "data", "verified", "pct_mfma_peak", "rccl_ranks", "gather_ms", "gather_GBs_into_root", "dry", "problems_owned_by_all_ranks")
     line = {k: full[k] for k in keep if k in full}
     cfg = full.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "kernel", "per_gpu_batch", "problems_per_gpu_rank0", "input_sets_rotated", "streaming_hint", "parallelism") if k in cfg}
@@ -793,6 +869,13 @@ def main():
     global EAGER
     args = parse()
     EAGER = args.eager
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:            # the plain command: no launcher set the ranks up, so bench.py does
+        sys.exit(spawn_ranks(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: WARNING: --gpus {args.gpus} but the launcher started {os.environ['WORLD_SIZE']} rank(s): the launcher decides", file=sys.stderr)
+    if os.environ.get("BENCH_DRY") == "1":
+        dry_main(args)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

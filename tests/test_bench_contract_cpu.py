@@ -118,14 +118,52 @@ def test_baseline_configs_are_in_the_line(detail, line):
     assert line["configs_verified"] is True
 
 
-def test_gpus_1_is_the_plain_run(monkeypatch):
-    """SCALE's N = 1 point is `bench.py --gpus 1 ...`, BENCH's is the same command: the flag changes nothing -- ranks come from the launcher's environment
-    (WORLD_SIZE), the workload from the other flags -- so the two lines differ by run-to-run noise only."""
-    import bench
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "20", "--warmup", "5"])
-    plain = vars(bench.parse())
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5"])
-    one = vars(bench.parse())
-    assert plain == one
+def _run_plain(argv, extra_env=None):
+    """the PLAIN command (no launcher), dry: ranks, barriers and the one JSON line with no device"""
+    import subprocess
+    env = dict(os.environ, BENCH_DRY="1", BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    last = [ln for ln in res.stdout.splitlines() if ln.strip()][-1]
+    return json.loads(last), res
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_gpus_n_starts_n_ranks_by_itself(n):
+    """`python bench.py --gpus N --steps K --warmup W` -- the command shape of BENCH_rNN.json.cmd -- must yield N ranks without an external launcher
+    (round 4: the flag was parsed and dropped, so a scaling curve could not be produced).  Dry: gloo, no kernel."""
+    line, res = _run_plain(["--gpus", str(n), "--steps", "5", "--warmup", "1"])
+    assert line["n_gpus"] == n and line["dry"] is True
+    assert line["problems_owned_by_all_ranks"] == n * 4096            # weak scaling: every rank owns its own batch
+    assert "torch.distributed.run" in res.stderr and f"--nproc-per-node={n}" in res.stderr
+
+
+def test_gpus_n_config5_shards_the_total():
+    line, _ = _run_plain(["--gpus", "2", "--config", "5", "--total", "1001", "--gather"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["problems_owned_by_all_ranks"] == 1001
+
+
+def test_gpus_1_is_one_process():
+    """N = 1 stays the plain single-process run (no launcher, no process group)"""
+    line, res = _run_plain(["--gpus", "1", "--steps", "5", "--warmup", "1"])
+    assert line["n_gpus"] == 1 and "torch.distributed.run" not in res.stderr
+
+
+def test_gpus_n_without_devices_refuses(monkeypatch):
+    """not dry, no GPUs: `--gpus 2` must refuse loudly instead of measuring one device twice"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("box has the devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_DRY", "BENCH_DEVICE")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 2 and "needs 2 visible GPUs" in res.stderr
+
+
+def test_launcher_environment_wins():
+    """under the driver's own launcher (WORLD_SIZE set) bench.py must NOT spawn again"""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "args.gpus" not in src                    # nothing in the run depends on the flag: WORLD_SIZE / RANK / LOCAL_RANK decide
+    assert '"WORLD_SIZE" not in os.environ and args.gpus > 1' in src

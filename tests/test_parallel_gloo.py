@@ -274,3 +274,23 @@ def test_bench_config5_two_ranks_end_to_end_on_one_device():
     assert line["config"]["problems_per_gpu_rank0"] == 4096 and "x2" in line["config"]["parallelism"]
     assert line["gather_ms"] > 0 and line["gather_GBs_into_root"] > 0
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_plain_command_spawns_two_ranks_on_one_device():
+    """`python bench.py --gpus 2 ...` with NO launcher (the command shape of BENCH_rNN.json.cmd): bench.py starts the two ranks itself.  On a one-GPU box both
+    ranks share device 0 behind a gloo group (BENCH_DEVICE / BENCH_BACKEND); on a multi-GPU node the same command runs one rank per device over RCCL."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--min-seconds", "0.05", "--no-sweep", "--no-l3",
+           "--no-cpu-baseline", "--detail", ""]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.strip()][-1]
+    line = json.loads(last)                                         # the LAST stdout line is rank 0's
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak" and line["verified"] is True
+    assert line["value"] > 0 and line["config"]["per_gpu_batch"] == 4096
