@@ -137,6 +137,41 @@ LIBXSMM_API void libxsmm_hip_meltw_ternary_batch_strided(libxsmm_meltwfunction_t
  * after rounding shard boundaries to `granule` units (e.g. the packed width's lane tile). */
 LIBXSMM_API void libxsmm_hip_shard_range(size_t count, size_t granule, int world, int rank, size_t* begin, size_t* end);
 
+/* ---- multi-GPU from ONE process and ONE host thread (C / C++ hosts: no launcher, no Python) ---------------------------------------
+ * The reference scales out through the caller's loop over independent problems [ref: samples/xgemm/gemm_kernel.c:4063-4066,
+ * samples/xgemm_sparse_Ainregs/pyfr_driver_asp_reg.c:379-393]; here that loop is cut into one contiguous block per device.
+ * A shard = what ONE device does: a kernel handle, the param struct whose pointers name operands RESIDENT ON THAT DEVICE (the first
+ * problem of the shard), and either count = 0 (one plain call kernel(param): the P / m_blocks / N splits, where every shard has a
+ * handle of its own shape) or count > 0 (a strided batch exactly as libxsmm_hip_gemm[_ext]_batch_strided / libxsmm_hip_meltw_*_batch_strided:
+ * stride[] = {a, b, c, d, mask} for (BR)GEMM and packed sparse handles, {in, out, aux} / {in0, in1, out} / {in0, in1, in2, out} for TPPs).
+ * libxsmm_hip_launch_shards issues every shard on a stream of its own on the shard's device -- shards overlap, also several on one
+ * device -- each with private staging scratch and partial-result workspaces, and (gather_bytes > 0) follows the shard's kernel with ONE
+ * copy of gather_bytes from gather_src to gather_dst + gather_dst_offset on gather_device: the source device pushes over its own xGMI
+ * link (hipMemcpyPeerAsync), so nshards - 1 links feed the root at once where a ring would be bound by one link per hop.
+ * Blocking thread (default): returns when every shard and copy has finished.  Stream-ordered thread (libxsmm_hip_set_stream / _set_async):
+ * the shards start behind what the thread's stream holds and the thread's stream continues behind them; libxsmm_hip_sync() waits.
+ * Dense dispatch handles run on every device; created sparse kernels (pattern arrays, generated code) belong to the device that was
+ * current at creation (libxsmm_hip_set_device) -- create one per device.  Operands must be device memory.  Returns EXIT_SUCCESS / EXIT_FAILURE
+ * (libxsmm_hip_get_last_error_string says why). */
+typedef struct libxsmm_hip_shard {
+  int device;                          /* HIP device that holds this shard's operands */
+  const void* kernel;                  /* any libxsmm_*function handle */
+  const void* param;                   /* the matching param struct; its pointers are the shard's FIRST problem, in `device`'s memory */
+  size_t count;                        /* 0: kernel(param) once;  > 0: strided batch of `count` problems */
+  long long stride[5];                 /* byte strides of the batch (kind specific, see above) */
+  const void* gather_src;              /* optional result gather: after the kernel, gather_bytes from here ... */
+  size_t gather_bytes, gather_dst_offset;   /* ... to gather_dst + gather_dst_offset on gather_device */
+} libxsmm_hip_shard;
+LIBXSMM_API int libxsmm_hip_launch_shards(const libxsmm_hip_shard* shards, int nshards, int gather_device, void* gather_dst);
+/** The batch axis cut by libxsmm_hip_shard_range(count, 1, nshards, s): shard s owns problems [begin_s, end_s) and runs on devices[s]
+ * (NULL: device s % device_count; a device may appear more than once).  shard_params[s] holds the pointers of problem begin_s in that device's
+ * memory (every device holds only its own block of A / B / C; a shared operand -- stride 0 -- is replicated by the caller).
+ * gather_dst != NULL: C of all shards is assembled at gather_dst + begin_s * stride_c on gather_device. */
+LIBXSMM_API int libxsmm_hip_gemm_batch_strided_sharded(libxsmm_gemmfunction kernel, const libxsmm_gemm_param* shard_params, size_t count,
+  long long stride_a, long long stride_b, long long stride_c, int nshards, const int* devices, int gather_device, void* gather_dst);
+LIBXSMM_API int libxsmm_hip_gemm_ext_batch_strided_sharded(libxsmm_gemmfunction_ext kernel, const libxsmm_gemm_ext_param* shard_params, size_t count,
+  long long stride_a, long long stride_b, long long stride_c, long long stride_d, long long stride_mask, int nshards, const int* devices, int gather_device, void* gather_dst);
+
 /* Result gather onto one GPU without a collective library (one process per GPU on one node).  Every rank exports the device buffer that
  * holds its shard (libxsmm_hip_ipc_export: LIBXSMM_HIP_IPC_HANDLE_BYTES opaque bytes, to be handed to the root by whatever means the
  * application has -- MPI, a file, torch.distributed); the root then pulls all shards, each on its own stream: the sources sit behind

@@ -157,6 +157,11 @@ class TernaryShape(C.Structure):
                 ("in0_type", C.c_int), ("in1_type", C.c_int), ("in2_type", C.c_int), ("out_type", C.c_int), ("comp_type", C.c_int)]
 
 
+class HipShard(C.Structure):           # libxsmm_hip_shard (include/libxsmm_hip.h): what ONE device does in a multi-device launch
+    _fields_ = [("device", C.c_int), ("kernel", C.c_void_p), ("param", C.c_void_p), ("count", C.c_size_t), ("stride", C.c_longlong * 5),
+                ("gather_src", C.c_void_p), ("gather_bytes", C.c_size_t), ("gather_dst_offset", C.c_size_t)]
+
+
 class KernelInfo(C.Structure):
     _fields_ = [("kind", C.c_int), ("nflops", C.c_uint), ("code_size", C.c_size_t), ("is_reference_kernel", C.c_uint)]
 
@@ -281,6 +286,15 @@ class Api:
             self.free = f("free", None, [vp])
             self.hip_ipc_export = f("hip_ipc_export", C.c_int, [vp, vp])
             self.hip_gather_shards = f("hip_gather_shards", C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp])
+            self.hip_malloc = f("hip_malloc", vp, [C.c_size_t])
+            self.hip_free = f("hip_free", None, [vp])
+            self.hip_memcpy_h2d = f("hip_memcpy_h2d", C.c_int, [vp, vp, C.c_size_t])
+            self.hip_memcpy_d2h = f("hip_memcpy_d2h", C.c_int, [vp, vp, C.c_size_t])
+            self.hip_memset = f("hip_memset", C.c_int, [vp, C.c_int, C.c_size_t])
+            self.hip_launch_shards = f("hip_launch_shards", C.c_int, [C.POINTER(HipShard), C.c_int, C.c_int, vp])
+            self.hip_gemm_batch_strided_sharded = f("hip_gemm_batch_strided_sharded", C.c_int, [vp, C.POINTER(GemmParam), C.c_size_t, ll, ll, ll, C.c_int, C.POINTER(C.c_int), C.c_int, vp])
+            self.hip_gemm_ext_batch_strided_sharded = f("hip_gemm_ext_batch_strided_sharded", C.c_int,
+                                                        [vp, C.POINTER(GemmExtParam), C.c_size_t, ll, ll, ll, ll, ll, C.c_int, C.POINTER(C.c_int), C.c_int, vp])
             self.hip_shard_range = f("hip_shard_range", None, [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)])
 
     # ---- calling a handle (a plain C function pointer) --------------------------------

@@ -213,7 +213,14 @@ static void* stage2d(const void* p, size_t width, size_t height, size_t pitch, b
 }
 static void* stage(const void* p, size_t nbytes, bool copy_in, bool copy_back) { return stage2d(p, nbytes, 1, nbytes, copy_in, copy_back); }
 const void* device_visible(const void* p, size_t nbytes) { return stage(p, nbytes, true, false); }
-// an array KNOWN to live in plain host memory (the coalescing queue's pointer lists): uploaded into the scratch without the pointer query
+// an array KNOWN to live in plain host memory (the coalescing queue's pointer lists): uploaded into the scratch without the pointer query.
+// The upload does NOT read the caller's (pageable, soon overwritten) storage asynchronously: the bytes are first copied into a PINNED slot owned by
+// this thread, the device copy leaves from there, and a slot is reused only after the event behind its last upload has completed (two slots, so the
+// host rarely waits).  [advisor, round 4: hipMemcpyAsync straight out of the queue's std::vector is a race once the runtime copies truly asynchronously]
+struct PinnedSlot { char* base = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+struct PinnedRing { PinnedSlot slot[2]; int next = 0;
+  ~PinnedRing() { for (PinnedSlot& p : slot) { if (p.base) (void)hipHostFree(p.base); if (p.done) (void)hipEventDestroy(p.done); } } };
+thread_local PinnedRing t_pinned;
 static void* stage_host(const void* p, size_t nbytes) {
   if (!p || nbytes == 0) return nullptr;
   Scratch& s = t_scratch;
@@ -227,7 +234,19 @@ static void* stage_host(const void* p, size_t nbytes) {
     s.base = nb; s.cap = ncap; s.used = 0; s.device = cur_device();
   }
   char* dst = s.base + s.used; s.used += need;
-  if (!hip_ok(hipMemcpyAsync(dst, p, nbytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpyAsync(pointer lists)")) return nullptr;
+  PinnedSlot& ps = t_pinned.slot[t_pinned.next]; t_pinned.next ^= 1;
+  if (ps.busy) { (void)hipEventSynchronize(ps.done); ps.busy = false; }          // the upload that last used this slot has left it
+  if (ps.cap < nbytes) {
+    if (ps.base) { (void)hipHostFree(ps.base); ps.base = nullptr; ps.cap = 0; }
+    const size_t ncap = std::max<size_t>(nbytes * 2, 64 << 10);
+    if (!hip_ok(hipHostMalloc((void**)&ps.base, ncap, hipHostMallocDefault), "hipHostMalloc(pointer lists)")) { ps.base = nullptr; return nullptr; }
+    ps.cap = ncap;
+  }
+  if (!ps.done && !hip_ok(hipEventCreateWithFlags(&ps.done, hipEventDisableTiming), "hipEventCreate(pointer lists)")) return nullptr;
+  std::memcpy(ps.base, p, nbytes);
+  if (!hip_ok(hipMemcpyAsync(dst, ps.base, nbytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpyAsync(pointer lists)")) return nullptr;
+  if (hip_ok(hipEventRecord(ps.done, cur_stream()), "hipEventRecord(pointer lists)")) ps.busy = true;
+  else (void)hipStreamSynchronize(cur_stream());
   return dst;
 }
 // Operands of a SYNCHRONOUS call may live in plain host memory (the reference's contract: any pointer, result valid on return);
@@ -1150,6 +1169,12 @@ static bool ranges_overlap(uintptr_t a0, size_t an, uintptr_t b0, size_t bn) { r
 // true: the call has been queued
 bool coalesce_try(KernelCtx* k, const void* param) {
   if (k->kind != K_GEMM || t_nest > 0 || tls().pipe_lanes > 1 || !param) return false;
+  {  // a stream that is being CAPTURED records addresses, not contents: a queued call's pointer list would be re-read from whatever the staging slot holds at
+     // replay time.  While capturing, calls launch one by one (mode 1 semantics); what was queued before the capture began has left already (flushed below).
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(cur_stream(), &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs != hipStreamCaptureStatusNone) return false;
+  }
   const libxsmm_gemm_descriptor& d = k->g;
   const unsigned int never = LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI | LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_ADDRESS | LIBXSMM_GEMM_FLAG_BATCH_REDUCE_OFFSET |
     LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT | LIBXSMM_GEMM_FLAG_USE_COL_VEC_SCF | LIBXSMM_GEMM_FLAG_USE_COL_VEC_ZPT | LIBXSMM_GEMM_FLAG_USE_MxK_ZPT | LIBXSMM_GEMM_FLAG_USE_MxK_SCF;
@@ -1174,7 +1199,11 @@ bool coalesce_try(KernelCtx* k, const void* param) {
     const bool a_near = ranges_overlap(pa, ea, q.cmin, q.cmax - q.cmin), b_near = ranges_overlap(pb, eb, q.cmin, q.cmax - q.cmin);
     const bool c_near_c = !(q.c_monotonic && pc >= q.cmax) && ranges_overlap(pc, ec, q.cmin, q.cmax - q.cmin);
     const bool c_near_r = ranges_overlap(pc, ec, q.rmin, q.rmax - q.rmin);
-    if (a_near || b_near || c_near_c)
+    // interleaved layouts ({A_i, B_i, C_i} structs, operands carved alternately from one arena) are "near" on every call: the exact scan is bounded to a few
+    // hundred queued entries -- beyond that a near call simply flushes (a batch of 256+ problems already amortises its launch)
+    const size_t kScanCap = 256;
+    if ((a_near || b_near || c_near_c || c_near_r) && q.c.size() > kScanCap) hazard = true;
+    if ((a_near || b_near || c_near_c) && !hazard)
       for (size_t i = 0; i < q.c.size() && !hazard; ++i) {
         const uintptr_t qc = (uintptr_t)q.c[i];
         hazard = (a_near && ranges_overlap(pa, ea, qc, q.ec)) || (b_near && ranges_overlap(pb, eb, qc, q.ec)) || (c_near_c && ranges_overlap(pc, ec, qc, q.ec));
@@ -1854,6 +1883,7 @@ LIBXSMM_API void libxsmm_hip_set_jit(int mode) { g_jit_mode = (mode < 0 || mode 
 LIBXSMM_API int libxsmm_hip_get_jit(void) { return jit_mode(); }
 LIBXSMM_API int libxsmm_hip_available(void) { return libxsmm_hip_device_count() > 0 ? 1 : 0; }
 LIBXSMM_API int libxsmm_hip_set_device(int device) {
+  coalesce_flush();                     // queued calls belong to the device they were issued for
   if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return -1;
   tls().device = device; return 0;
 }
@@ -1896,6 +1926,7 @@ LIBXSMM_API int libxsmm_hip_bcsc_bind_pattern(libxsmm_gemmfunction kernel, const
   return EXIT_SUCCESS;
 }
 LIBXSMM_API int libxsmm_hip_pipeline_begin(int lanes) {
+  coalesce_flush();                     // calls queued before the section leave BEFORE the fork event: every lane is ordered behind them
   ThreadState& t = tls();
   if (!runtime_ready() || g_dryrun) return EXIT_FAILURE;
   if (t.pipe_lanes > 1) { set_error(-3, "libxsmm_hip_pipeline_begin: a pipeline section is already open on this thread"); return EXIT_FAILURE; }
@@ -1948,10 +1979,24 @@ LIBXSMM_API int libxsmm_hip_get_last_error(void) { return tls().last_error; }
 LIBXSMM_API const char* libxsmm_hip_get_last_error_string(void) { return tls().last_error_msg.c_str(); }
 LIBXSMM_API void libxsmm_hip_clear_last_error(void) { tls().last_error = 0; tls().last_error_msg.clear(); }
 LIBXSMM_API void* libxsmm_hip_malloc(size_t n) { void* p = nullptr; if (!hip_ok(hipMalloc(&p, n ? n : 1), "hipMalloc")) return nullptr; return p; }
-LIBXSMM_API void libxsmm_hip_free(void* p) { if (p) (void)hipFree(p); }
-LIBXSMM_API int libxsmm_hip_memcpy_h2d(void* d, const void* s, size_t n) { return hip_ok(hipMemcpy(d, s, n, hipMemcpyHostToDevice), "hipMemcpy(H2D)") ? 0 : -1; }
-LIBXSMM_API int libxsmm_hip_memcpy_d2h(void* d, const void* s, size_t n) { coalesce_flush(); return hip_ok(hipMemcpy(d, s, n, hipMemcpyDeviceToHost), "hipMemcpy(D2H)") ? 0 : -1; }
-LIBXSMM_API int libxsmm_hip_memset(void* d, int v, size_t n) { return hip_ok(hipMemset(d, v, n), "hipMemset") ? 0 : -1; }
+LIBXSMM_API void libxsmm_hip_free(void* p) { coalesce_flush(); if (p) (void)hipFree(p); }
+// Blocking copies, ORDERED ON THE CALLING THREAD'S STREAM: queued (coalescing mode) and stream-ordered launches issued before the copy have run when it
+// reads or overwrites their operands -- a copy on the legacy default stream would not wait for a non-blocking user stream.
+LIBXSMM_API int libxsmm_hip_memcpy_h2d(void* d, const void* s, size_t n) {
+  coalesce_flush();
+  if (!hip_ok(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, cur_stream()), "hipMemcpy(H2D)")) return -1;
+  return hip_ok(hipStreamSynchronize(cur_stream()), "hipMemcpy(H2D)") ? 0 : -1;
+}
+LIBXSMM_API int libxsmm_hip_memcpy_d2h(void* d, const void* s, size_t n) {
+  coalesce_flush();
+  if (!hip_ok(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, cur_stream()), "hipMemcpy(D2H)")) return -1;
+  return hip_ok(hipStreamSynchronize(cur_stream()), "hipMemcpy(D2H)") ? 0 : -1;
+}
+LIBXSMM_API int libxsmm_hip_memset(void* d, int v, size_t n) {
+  coalesce_flush();
+  if (!hip_ok(hipMemsetAsync(d, v, n, cur_stream()), "hipMemset")) return -1;
+  return hip_ok(hipStreamSynchronize(cur_stream()), "hipMemset") ? 0 : -1;
+}
 LIBXSMM_API int libxsmm_hip_probe_mfma(libxsmm_datatype datatype, const void* operands, int iterations, double* flop) {
   if (!runtime_ready() || g_dryrun || !operands || iterations <= 0 || (datatype != LIBXSMM_DATATYPE_BF16 && datatype != LIBXSMM_DATATYPE_F32)) return EXIT_FAILURE;
   const int err = launch_mfma_probe(datatype == LIBXSMM_DATATYPE_BF16 ? 1 : 0, operands, iterations, tls().stream, flop);
@@ -2027,6 +2072,146 @@ LIBXSMM_API void libxsmm_hip_meltw_ternary_batch_strided(libxsmm_meltwfunction_t
   long long s0, long long s1, long long s2, long long so) {
   KernelCtx* c = batch_ctx((const void*)kernel, K_MELTW); if (!c || !param || count == 0) return;
   BatchSpec b; b.count = count; b.s[0] = s0; b.s[1] = s1; b.s[2] = s2; b.s[3] = so; run_meltw(c, param, b);
+}
+// ---- multi-device launch from ONE host thread (the reference's scale-out axis is the caller's loop,
+// samples/xgemm/gemm_kernel.c:4063-4066) --------------------------------------------------------------------------------------------------------
+// Every shard has a context of its own on the calling thread -- device, a non-blocking stream there, staging scratch, partial-result workspaces -- that is
+// swapped into the thread's state around the shard's launch, so the existing launch paths run unchanged and shards on one device (virtual shards: the
+// one-GPU test) overlap without sharing a byte of scratch.
+namespace {
+struct ShardCtx {
+  int device = -1; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+  Scratch scratch; Workspace ws[8];
+  ~ShardCtx() { if (stream) (void)hipStreamDestroy(stream); if (done) (void)hipEventDestroy(done); }
+};
+struct ShardSet { std::vector<ShardCtx*> ctx; hipEvent_t fork = nullptr; int fork_device = -1;
+  ~ShardSet() { for (ShardCtx* c : ctx) delete c; if (fork) (void)hipEventDestroy(fork); } };
+thread_local ShardSet t_shards;
+// field-wise: a std::swap of the structs would run a destructor on the temporary and retire a live block
+void swap_scratch(Scratch& a, Scratch& b) { std::swap(a.base, b.base); std::swap(a.cap, b.cap); std::swap(a.used, b.used); std::swap(a.device, b.device); }
+void swap_workspace(Workspace& a, Workspace& b) { std::swap(a.base, b.base); std::swap(a.cap, b.cap); std::swap(a.device, b.device); }
+void shard_swap(ShardCtx& sc) { swap_scratch(t_scratch, sc.scratch); for (int i = 0; i < 8; ++i) swap_workspace(t_workspace[i], sc.ws[i]); }
+ShardCtx* shard_ctx(int index, int device) {
+  ShardSet& set = t_shards;
+  if ((size_t)index >= set.ctx.size()) set.ctx.resize((size_t)index + 1, nullptr);
+  ShardCtx*& c = set.ctx[(size_t)index];
+  if (c && c->device != device) { delete c; c = nullptr; }          // the slot moved to another device: its stream belongs to the old one
+  if (!c) {
+    c = new ShardCtx(); c->device = device;
+    if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate(shard)") ||
+        !hip_ok(hipEventCreateWithFlags(&c->done, hipEventDisableTiming), "hipEventCreate(shard)")) { delete c; c = nullptr; }
+  }
+  return c;
+}
+std::mutex g_peer_lock; std::vector<char> g_peer_enabled;     // [from * ndev + to]
+void enable_peer(int from, int to) {       // `from` is the current device
+  if (from == to || g_device_count <= 1) return;
+  std::lock_guard<std::mutex> guard(g_peer_lock);
+  if (g_peer_enabled.empty()) g_peer_enabled.assign((size_t)g_device_count * (size_t)g_device_count, 0);
+  char& done = g_peer_enabled[(size_t)from * (size_t)g_device_count + (size_t)to];
+  if (done) return;
+  int can = 0;
+  if (hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can) { const hipError_t e = hipDeviceEnablePeerAccess(to, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+  else (void)hipGetLastError();          // no direct path: hipMemcpyPeerAsync stages through the host by itself
+  done = 1;
+}
+}  // namespace
+LIBXSMM_API int libxsmm_hip_launch_shards(const libxsmm_hip_shard* shards, int nshards, int gather_device, void* gather_dst) {
+  coalesce_flush();
+  if (!runtime_ready() || g_dryrun || g_device_count <= 0) { set_error(-4, "libxsmm_hip_launch_shards: no HIP device"); return EXIT_FAILURE; }
+  if (!shards || nshards <= 0 || nshards > 64) { set_error(-2, "libxsmm_hip_launch_shards: 1..64 shards"); return EXIT_FAILURE; }
+  ThreadState& t = tls();
+  if (t.pipe_lanes > 1 || t_nest > 0) { set_error(-3, "libxsmm_hip_launch_shards: not inside a pipeline section or a kernel invocation"); return EXIT_FAILURE; }
+  for (int i = 0; i < nshards; ++i) {
+    const libxsmm_hip_shard& sh = shards[i];
+    if (sh.device < 0 || sh.device >= g_device_count) { set_error(-2, "libxsmm_hip_launch_shards: shard %d names device %d, %d visible", i, sh.device, g_device_count); return EXIT_FAILURE; }
+    if (!sh.kernel || !sh.param) { set_error(-2, "libxsmm_hip_launch_shards: shard %d has no kernel / param", i); return EXIT_FAILURE; }
+    if (!ctx_from_handle(sh.kernel)) { set_error(-3, "libxsmm_hip_launch_shards: shard %d: unknown kernel handle", i); return EXIT_FAILURE; }
+    if (sh.gather_bytes && (!gather_dst || !sh.gather_src || gather_device < 0 || gather_device >= g_device_count)) {
+      set_error(-2, "libxsmm_hip_launch_shards: shard %d asks for a gather without source / destination / root device", i); return EXIT_FAILURE; }
+  }
+  const int home_device = t.device, home_async = t.async; void* const home_stream = t.stream;
+  int hip_home = 0; (void)hipGetDevice(&hip_home);
+  const int err0 = t.last_error;
+  bool ok = true;
+  // fork: work already issued to the thread's stream (stream-ordered mode) comes first on every shard
+  ShardSet& set = t_shards;
+  const bool fork = home_async != 0;
+  if (fork) {
+    if (set.fork && set.fork_device != hip_home) { (void)hipEventDestroy(set.fork); set.fork = nullptr; }
+    if (!set.fork) { ok = hip_ok(hipEventCreateWithFlags(&set.fork, hipEventDisableTiming), "hipEventCreate(shard fork)"); set.fork_device = hip_home; }
+    ok = ok && hip_ok(hipEventRecord(set.fork, (hipStream_t)home_stream), "hipEventRecord(shard fork)");
+  }
+  int issued = 0;
+  for (int i = 0; i < nshards && ok; ++i) {
+    const libxsmm_hip_shard& sh = shards[i];
+    if (!hip_ok(hipSetDevice(sh.device), "hipSetDevice(shard)")) { ok = false; break; }
+    ShardCtx* sc = shard_ctx(i, sh.device);
+    if (!sc) { ok = false; break; }
+    if (fork && !hip_ok(hipStreamWaitEvent(sc->stream, set.fork, 0), "hipStreamWaitEvent(shard fork)")) { ok = false; break; }
+    t.device = sh.device; t.stream = sc->stream; t.async = 1;       // the shard's launches are stream-ordered on its own stream
+    shard_swap(*sc);
+    KernelCtx* k = ctx_from_handle(sh.kernel);
+    if (sh.count == 0) run_any(k, sh.param, BatchSpec{});
+    else {
+      BatchSpec b; b.count = sh.count; for (int j = 0; j < 5; ++j) b.s[j] = sh.stride[j];
+      if (k->kind == K_GEMM || k->kind == K_MELTW || k->kind == K_SPMM_ASPARSE || k->kind == K_SPMM_BSPARSE) run_any(k, sh.param, b);
+      else set_error(-3, "libxsmm_hip_launch_shards: shard %d: this kind of kernel has no strided batch (count must be 0)", i);
+    }
+    shard_swap(*sc);
+    if (t.last_error != err0 && t.last_error != 0) ok = false;
+    if (ok && sh.gather_bytes) {
+      char* dst = (char*)gather_dst + sh.gather_dst_offset;
+      if (sh.device == gather_device) ok = hip_ok(hipMemcpyAsync(dst, sh.gather_src, sh.gather_bytes, hipMemcpyDeviceToDevice, sc->stream), "hipMemcpyAsync(shard gather)");
+      else { enable_peer(sh.device, gather_device);      // each source pushes over its own xGMI link into the root: no ring, up to nshards - 1 links at once
+             ok = hip_ok(hipMemcpyPeerAsync(dst, gather_device, sh.gather_src, sh.device, sh.gather_bytes, sc->stream), "hipMemcpyPeerAsync(shard gather)"); }
+    }
+    ok = hip_ok(hipEventRecord(sc->done, sc->stream), "hipEventRecord(shard)") && ok;
+    issued = i + 1;
+  }
+  (void)hipSetDevice(hip_home);
+  t.device = home_device; t.stream = home_stream; t.async = home_async;
+  // join: stream-ordered callers get the shards' completion as a dependency of their stream, blocking callers get results
+  for (int i = 0; i < issued; ++i) {
+    ShardCtx* sc = set.ctx[(size_t)i];
+    if (fork) ok = hip_ok(hipStreamWaitEvent((hipStream_t)home_stream, sc->done, 0), "hipStreamWaitEvent(shard join)") && ok;
+    else { const hipError_t e = hipEventSynchronize(sc->done); if (e != hipSuccess) { set_error((int)e, "shard %d faulted: %s", i, hipGetErrorString(e)); ok = false; } }
+  }
+  return ok ? EXIT_SUCCESS : EXIT_FAILURE;
+}
+static int batch_sharded(const void* kernel, const char* params, size_t param_size, size_t count, const long long* strides, int nstrides, int c_slot_offset,
+                         int nshards, const int* devices, int gather_device, void* gather_dst) {
+  if (nshards <= 0 || nshards > 64 || !params) { set_error(-2, "sharded batch: 1..64 shards and one param per shard"); return EXIT_FAILURE; }
+  const int ndev = libxsmm_hip_device_count();
+  if (ndev <= 0) { set_error(-4, "sharded batch: no HIP device"); return EXIT_FAILURE; }
+  libxsmm_hip_shard sh[64];
+  int n = 0;
+  for (int s = 0; s < nshards; ++s) {
+    size_t b = 0, e = 0;
+    libxsmm_hip_shard_range(count, 1, nshards, s, &b, &e);
+    if (e == b) continue;                                           // more shards than problems
+    libxsmm_hip_shard& x = sh[n++];
+    std::memset(&x, 0, sizeof(x));
+    x.device = devices ? devices[s] : s % ndev;
+    x.kernel = kernel; x.param = params + param_size * (size_t)s; x.count = e - b;
+    for (int j = 0; j < nstrides; ++j) x.stride[j] = strides[j];
+    if (gather_dst) {
+      const long long sc = strides[2];
+      if (sc <= 0) { set_error(-2, "sharded batch: a gather needs a positive C stride"); return EXIT_FAILURE; }
+      x.gather_src = *(void* const*)((const char*)x.param + c_slot_offset); x.gather_bytes = (e - b) * (size_t)sc; x.gather_dst_offset = b * (size_t)sc;
+    }
+  }
+  return n == 0 ? EXIT_SUCCESS : libxsmm_hip_launch_shards(sh, n, gather_device, gather_dst);
+}
+LIBXSMM_API int libxsmm_hip_gemm_batch_strided_sharded(libxsmm_gemmfunction kernel, const libxsmm_gemm_param* shard_params, size_t count,
+  long long stride_a, long long stride_b, long long stride_c, int nshards, const int* devices, int gather_device, void* gather_dst) {
+  const long long st[3] = {stride_a, stride_b, stride_c};
+  return batch_sharded((const void*)kernel, (const char*)shard_params, sizeof(libxsmm_gemm_param), count, st, 3, (int)offsetof(libxsmm_gemm_param, c), nshards, devices, gather_device, gather_dst);
+}
+LIBXSMM_API int libxsmm_hip_gemm_ext_batch_strided_sharded(libxsmm_gemmfunction_ext kernel, const libxsmm_gemm_ext_param* shard_params, size_t count,
+  long long stride_a, long long stride_b, long long stride_c, long long stride_d, long long stride_mask, int nshards, const int* devices, int gather_device, void* gather_dst) {
+  const long long st[5] = {stride_a, stride_b, stride_c, stride_d, stride_mask};
+  return batch_sharded((const void*)kernel, (const char*)shard_params, sizeof(libxsmm_gemm_ext_param), count, st, 5, (int)offsetof(libxsmm_gemm_ext_param, c), nshards, devices, gather_device, gather_dst);
 }
 // ---- result gather without a collective library: the root pulls every shard over its own xGMI link ----------------------------
 namespace { struct IpcBlob { hipIpcMemHandle_t h; unsigned long long offset, size; }; }

@@ -109,3 +109,98 @@ def test_independent_calls_merge_and_other_kernels_flush():
     assert torch.equal(Cq, Cb)
     assert torch.equal(scratch, torch.relu(Cb[int(order[0])]))
     api.hip_set_async(0); api.hip_set_stream(None)
+
+
+def test_queued_calls_leave_before_a_pipeline_section_forks():
+    """[advisor, round 4] calls queued BEFORE libxsmm_hip_pipeline_begin must be launched before the fork event: a launch on lane 1 reads their C."""
+    import torch
+    api = capi.load()
+    m, n = 32, 64
+    rng = np.random.default_rng(8)
+    A = torch.from_numpy(rng.standard_normal((n, m, m)).astype(np.float32)).cuda()
+    B = torch.from_numpy(rng.standard_normal((n, m, m)).astype(np.float32)).cuda()
+    C1 = torch.zeros_like(A); C2 = torch.zeros_like(A); D0 = torch.zeros_like(A); G1 = torch.zeros_like(A); G2 = torch.zeros_like(A)
+    h = _gemm(api, m, 0)
+    blk = m * m * 4
+    p = capi.GemmParam()
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    p.a.primary, p.b.primary, p.c.primary = A.data_ptr(), B.data_ptr(), G1.data_ptr(); api.hip_gemm_batch_strided(h, C.byref(p), n, blk, blk, blk)
+    p.a.primary, p.b.primary, p.c.primary = G1.data_ptr(), B.data_ptr(), G2.data_ptr(); api.hip_gemm_batch_strided(h, C.byref(p), n, blk, blk, blk)
+    api.hip_sync()
+    for _ in range(3):                                             # several rounds: a missing ordering is a race, not a certainty
+        C1.zero_(); C2.zero_()
+        api.hip_set_async(2)
+        for i in range(n):
+            _call(h, A[i].data_ptr(), B[i].data_ptr(), C1[i].data_ptr())      # queued, nothing launched yet
+        assert api.hip_pipeline_begin(2) == 0
+        p.a.primary, p.b.primary, p.c.primary = A.data_ptr(), B.data_ptr(), D0.data_ptr(); api.hip_gemm_batch_strided(h, C.byref(p), n, blk, blk, blk)    # lane 0
+        p.a.primary, p.b.primary, p.c.primary = C1.data_ptr(), B.data_ptr(), C2.data_ptr(); api.hip_gemm_batch_strided(h, C.byref(p), n, blk, blk, blk)   # lane 1 reads the queued C
+        assert api.hip_pipeline_end() == 0
+        api.hip_sync(); api.check()
+        assert torch.equal(C1, G1) and torch.equal(C2, G2)
+    api.hip_set_async(0); api.hip_set_stream(None)
+
+
+def test_h2d_copy_between_queued_calls_is_ordered():
+    """[advisor, round 4] kernel(A -> C1); memcpy_h2d(A, new); kernel(A -> C2): the first GEMM must read the OLD A, the second the new one."""
+    import torch
+    api = capi.load()
+    m = 32
+    rng = np.random.default_rng(9)
+    a_old = rng.standard_normal((m, m)).astype(np.float32); a_new = rng.standard_normal((m, m)).astype(np.float32)
+    A = torch.from_numpy(a_old.copy()).cuda(); B = torch.from_numpy(rng.standard_normal((m, m)).astype(np.float32)).cuda()
+    C1 = torch.zeros_like(A); C2 = torch.zeros_like(A); G1 = torch.zeros_like(A); G2 = torch.zeros_like(A)
+    h = _gemm(api, m, 0)
+    side = torch.cuda.Stream()                                     # a NON-BLOCKING user stream: the legacy default stream would not wait for it
+    torch.cuda.synchronize()
+    api.hip_set_stream(side.cuda_stream)
+    _call(h, A.data_ptr(), B.data_ptr(), G1.data_ptr()); api.hip_sync()
+    A2 = torch.from_numpy(a_new.copy()).cuda(); torch.cuda.synchronize()
+    _call(h, A2.data_ptr(), B.data_ptr(), G2.data_ptr()); api.hip_sync()
+    api.hip_set_async(2)
+    _call(h, A.data_ptr(), B.data_ptr(), C1.data_ptr())           # queued
+    assert api.hip_memcpy_h2d(A.data_ptr(), a_new.ctypes.data, a_new.nbytes) == 0
+    _call(h, A.data_ptr(), B.data_ptr(), C2.data_ptr())
+    api.hip_sync(); api.check()
+    assert torch.equal(C1, G1) and torch.equal(C2, G2)
+    api.hip_set_async(0); api.hip_set_stream(None)
+
+
+def test_coalescing_thread_under_stream_capture_launches_call_by_call():
+    """[advisor, round 4] a captured stream records ADDRESSES: a queued pointer list would be re-read at replay from a recycled staging slot.
+    While the thread's stream is being captured, mode 2 launches call by call; the replayed graph recomputes the right results."""
+    import torch
+    api = capi.load()
+    m, n = 16, 40
+    rng = np.random.default_rng(10)
+    A = torch.from_numpy(rng.standard_normal((n, m, m)).astype(np.float32)).cuda()
+    B = torch.from_numpy(rng.standard_normal((n, m, m)).astype(np.float32)).cuda()
+    Cq = torch.zeros_like(A); G = torch.zeros_like(A)
+    h = _gemm(api, m, 0)
+    p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = A.data_ptr(), B.data_ptr(), G.data_ptr()
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    api.hip_gemm_batch_strided(h, C.byref(p), n, m * m * 4, m * m * 4, m * m * 4); api.hip_sync()
+    order = rng.permutation(n)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        api.hip_set_stream(side.cuda_stream)
+        api.hip_set_async(2)
+        api.hip_launch_count(1)
+        g.capture_begin()
+        for i in order:
+            _call(h, A[i].data_ptr(), B[i].data_ptr(), Cq[i].data_ptr())
+        api.hip_set_async(1)                                       # (flushes: nothing may be left in the queue)
+        g.capture_end()
+        assert api.hip_launch_count(0) == n                        # one launch per call inside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    # churn the staging slots, then replay twice
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream); api.hip_set_async(2)
+    T = torch.zeros_like(A)
+    for i in range(n):
+        _call(h, B[i].data_ptr(), A[i].data_ptr(), T[i].data_ptr())
+    api.hip_sync()
+    for _ in range(2):
+        Cq.zero_(); g.replay(); torch.cuda.synchronize()
+        assert torch.equal(Cq, G)
+    api.hip_set_async(0); api.hip_set_stream(None)
