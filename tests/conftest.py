@@ -53,3 +53,21 @@ def _default_launch_mode(request):
             api.hip_set_streaming_hint(0)
     except Exception:
         pass
+
+
+def pytest_collection_finish(session):
+    """LIBXSMM_TEST_GUARD=end|front (set by tests/test_oob_guard_gpu.py for its pytest SUBPROCESSES): every device operand the parity tests upload through
+    tests/helpers.py (GemmCase.run_gpu) or tests/test_sparse_gpu.py (_dev) is placed flush against unmapped address space (tests/guard.py), so the SAME parity
+    tests also prove that no kernel loads or stores outside its operands -- an access outside page-faults and aborts the subprocess."""
+    side = os.environ.get("LIBXSMM_TEST_GUARD", "")
+    if side not in ("end", "front"):
+        return
+    import tempfile
+    import guard
+    import helpers
+    guard.load(guard.build(tempfile.mkdtemp(prefix="guard_")))
+    helpers.UPLOAD_HOOK = guard.hook(side == "front")
+    for name in ("test_sparse_gpu", "test_gemm_ragged_gpu", "test_gemm_f64_gpu"):
+        mod = sys.modules.get(name)
+        if mod is not None and hasattr(mod, "_dev"):
+            mod._dev = guard.hook(side == "front")

@@ -27,6 +27,7 @@ from oracle import pyoracle  # noqa: E402
 NP_OF = {DT.F32: np.float32, DT.F64: np.float64, DT.BF16: np.uint16, DT.I32: np.int32, DT.U32: np.uint32,
          DT.I16: np.int16, DT.U16: np.uint16, DT.I8: np.int8, DT.U8: np.uint8, DT.I64: np.int64, DT.U64: np.uint64, DT.BF8: np.uint8, DT.HF8: np.uint8}
 
+UPLOAD_HOOK = None    # tests/guard.py: device buffers that touch unmapped address space instead of torch tensors (x -> object with data_ptr() / cpu().numpy())
 FP8_WIDE = False      # tests flip this to draw 8-bit floats over (almost) the whole exponent range
 
 # the reference's own acceptance bounds [samples/xgemm/gemm_kernel.c:5312-5414]
@@ -280,11 +281,13 @@ class GemmCase:
         dev = torch.device("cuda:0")
 
         def up(x):
+            if UPLOAD_HOOK is not None:
+                return None if x is None else UPLOAD_HOOK(x)
             return None if x is None else torch.from_numpy(x.view(np.int16) if x.dtype == np.uint16 else x).to(dev)
         A, B, Cbuf, D = up(self.A), up(self.B), up(self.C0.copy()), up(self.D)
         S = up(self.S) if (self.mx or self.mxmx) else None
         SB = up(self.SB) if self.mxmx else None
-        mask = torch.zeros(self.batch * self.mask_bytes, dtype=torch.uint8, device=dev) if self.act == 2 else None
+        mask = (up(np.zeros(self.batch * self.mask_bytes, dtype=np.uint8)) if UPLOAD_HOOK is not None else torch.zeros(self.batch * self.mask_bytes, dtype=torch.uint8, device=dev)) if self.act == 2 else None
         offs = (up(self.offs_a), up(self.offs_b))
         addr = None
         if self.br_type == capi.BR_ADDRESS:
