@@ -21,6 +21,9 @@ What the record carries (all measured in this process, on this GPU):
     (2-D batch, chain br = K/m, operands cache-resident): the only regime in which a percentage of MFMA peak is the binding roofline.
   * mfma_busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMDs) per workload from the committed PMC pass (profiles/), null if none.
   * cpu_baseline: the reference's own JIT kernel (oracle/_ref, kind "reference") or the C restatement (kind "port") on this box's host cores.
+  * tpp: SURVEY 8 rows a11 (TPPs: copy, transpose, NORM -> VNNI2, config #5's un-fused bias-add + ReLU chain, row / column reductions, column gather), f1 (a five-node
+    matrix equation) and f2 (a dense packed GEMM), each as [fraction of the HBM roofline, GB/s of the reference's CPU kernel on one host core], every GPU result
+    checked against the oracle (tools/tpp_group.py).
   * configs: BASELINE configs #3 (packed CSR A-sparse 35x35 @15 % and @10 %, FsSpMDM), #4 (bf16 BCSC 2:8) and #5 (bf16 64^3 + bias + ReLU, one
     GPU's shard of 2^17 problems), each as [fraction of the HBM roofline, GFLOP/s of the reference's CPU kernel on one host core], every GPU
     result checked against the oracle; variantB: config #2 as ONE BRGEMM with br = 4096.
@@ -797,6 +800,10 @@ def compact_line(full, detail_path):
             line["pct_of_power_roof"] = ppr           # blocked entries: % of what back-to-back MFMAs on the same operand values sustain under the power budget (mfma_power_roof_TF)
     if full.get("round4"):
         line["round4"] = {k: r.get("frac_hbm") for k, r in full["round4"].items()}       # fractions of the HBM roofline; shapes / kernels in the detail record
+    if full.get("tpp"):
+        # [fraction of the HBM roofline, GB/s of the reference's CPU kernel on one host core (null: none)], every entry checked against the oracle
+        line["tpp"] = {k: (None if "error" in r else [r.get("frac_hbm"), (r.get("cpu_baseline") or {}).get("GB/s")]) for k, r in full["tpp"].items()}
+        line["tpp_verified"] = all(("error" not in r) and r.get("verified") is True for r in full["tpp"].values())
     if full.get("pipelined"):
         pl = full["pipelined"]
         line["pipelined"] = {k: (v if not isinstance(v, dict) else (round(v["frac_hbm"], 3) if "frac_hbm" in v else None)) for k, v in pl.items()}
@@ -1000,6 +1007,12 @@ def main():
     round4 = {}
     if rank == 0 and world == 1 and not args.no_sweep and not args.no_configs:
         round4 = run_round4(api, dev, args.steps, min(args.min_seconds, 0.15))
+    tpp = {}
+    if rank == 0 and world == 1 and not args.no_sweep and not args.no_configs:
+        # SURVEY 8 rows a11 / f1 / f2 in the driver-visible line (round-4 review item 4): tools/tpp_group.py -- measured like the headline, verified against the oracle
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import tpp_group
+        tpp = tpp_group.run(api, dev, args.steps, min(args.min_seconds, 0.15), args.cpu_seconds, not args.no_cpu_baseline, timed)
     pipelined = None
     if rank == 0 and world == 1 and not args.no_sweep:
         pipelined = run_pipelined(api, dev, args.steps, min(args.min_seconds, 0.15), lanes=int(os.environ.get("BENCH_LANES", "8")))
@@ -1050,6 +1063,8 @@ def main():
             out["configs"] = configs
         if round4:
             out["round4"] = round4
+        if tpp:
+            out["tpp"] = tpp
         if pipelined:
             out["pipelined"] = pipelined
         if roof:
@@ -1062,7 +1077,7 @@ def main():
             out["ragged"] = ragged
         if sweep:
             measured = {work.label(): (headline_kernel, kernel_us)}
-            for grp in (sweep, reuse, ragged, configs, round4):
+            for grp in (sweep, reuse, ragged, configs, round4, tpp):
                 for k, r in grp.items():
                     if isinstance(r, dict) and "us_per_launch" in r:
                         measured[k] = (r.get("kernel", ""), r["us_per_launch"])

@@ -1868,7 +1868,7 @@ __global__ __launch_bounds__(256) void gemm_p16_kernel(GemmArgs p) {
 // F16 = true: the same kernel on IEEE halves (v_mfma_f32_32x32x16_f16; plain epilogue only) with the reference's F16 rules: the
 // accumulators start at 0, beta * C is added after the sum, an f32 C is rounded to f16 on the way in [ref: gemm ref :2025-2124].
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// BND (with BL; prepared in round 4 after the GPU budget was spent: NOT measured, NOT verified on the device, off unless LIBXSMM_HIP_RAGGED16_BOUNDED=1): the
+// BND (with BL; prepared in round 4, measured and adopted in round 5 for plain results -- ragged16_bounded): the
 // operand descriptors carry the exact extent of the block, so a request beyond it (a row of the last k pair beyond m, a k pair beyond k in the last column) is dropped
 // by the address unit instead of being clamped in registers -- every lane offset is loop invariant (two registers for B, eight for A, the rest scalar), which is what
 // the fourth wave per SIMD of the 64 x 64 form needs (see decision 32: these kernels are short of waves).  Rows beyond m and columns beyond n read whatever lies
@@ -2243,7 +2243,7 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
       } else {
       char* ximage = lds_img[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
       if constexpr (EXACT && BL) {
-        // (prepared in round 4, not measured, off unless LIBXSMM_HIP_W8_LDS=1) whole tiles: B as gemm_bf16_stream_kernel fetches it -- 16-byte LDS-DMA requests, four
+        // (prepared in round 4, adopted in round 5) whole tiles: B as gemm_bf16_stream_kernel fetches it -- 16-byte LDS-DMA requests, four
         // lanes = the 64 bytes of one column's chunk, slots swizzled on the source side -- instead of 16 bytes per lane from 64 different columns
         const __amdgpu_buffer_rsrc_t rb = wave_rsrc(br + 2ull * (unsigned long long)job.j0 * (unsigned long long)p.ldb);
 #pragma unroll
@@ -3952,7 +3952,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
   const unsigned int fl = d.flags;
   const bool ta = fl & LIBXSMM_GEMM_FLAG_TRANS_A, tb = fl & LIBXSMM_GEMM_FLAG_TRANS_B;
   const bool va = fl & LIBXSMM_GEMM_FLAG_VNNI_A, vb = fl & LIBXSMM_GEMM_FLAG_VNNI_B, vc = fl & LIBXSMM_GEMM_FLAG_VNNI_C;
-  if (!bf16 && (va || vb || vc)) return false;
+  if (!bf16 && vc) return false;                      // (VNNI_A / VNNI_B on f32 / f64 operands: accepted and ignored, as the reference does -- run_gemm clears them)
   if (bf16 && va && ta) return false;                 // [ref: src/generator_gemm.c:1010-1013]
   if (bf16 && va && (d.k & 1)) return false;
   if (bf16 && vb && !tb) return false;                // VNNI_B only defined together with TRANS_B [ref: gemm ref :2156-2163]
@@ -4058,9 +4058,8 @@ static GemmPlan plan_gemm(int m, int n, int k, unsigned int flags, int a_type, i
     const int t = (pl.path == P_BF16_2x2) ? 64 : 32;
     pl.exact = (m % t == 0) && (n % t == 0) && (k % 32 == 0);
     if (!pl.exact && pl.path == P_BF16_2x2 && (m % 32 == 0) && (n % 32 == 0) && (k % 32 == 0)) { pl.path = P_BF16_1x1; pl.exact = true; }
-    // measurement switch (round 5: 72^3-class shapes cover 128 x 128 with 64-tiles, 96 x 96 with 32-tiles): LIBXSMM_HIP_RAGGED16_TILE=1 forces 32 x 32 tiles for ragged shapes
-    static const bool small_tiles = []() { const char* e = getenv("LIBXSMM_HIP_RAGGED16_TILE"); return e && e[0] == '1'; }();
-    if (small_tiles && !pl.exact) pl.path = P_BF16_1x1;
+    // (round 5, measured and dropped: 32 x 32 tiles for ragged shapes above 32 -- nine light waves cover 96 x 96 of a 72^3 problem instead of four waves 128 x 128 --
+    //  72^3 0.38 against 0.43, 40^3 0.44 against 0.57, both in the bounded form: profiles/r05_ragged16_switches.jsonl)
     return pl;
   }
   return pl;
@@ -4127,9 +4126,11 @@ static bool ragged16_b_dwords(const GemmArgs& a) {
   const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0);
   return (bits & 3ull) == 0ull && (unsigned long long)a.n * (unsigned long long)a.ldb < (1ull << 30) && (unsigned long long)a.k * (unsigned long long)a.lda < (1ull << 30);
 }
-static bool ragged16_bounded(const GemmArgs& a) {          // see BND at the kernel: prepared, off by default; plain results (beta = 0, no bias, no bitmask, no VNNI C)
-  static const bool on = []() { const char* e = getenv("LIBXSMM_HIP_RAGGED16_BOUNDED"); return e && e[0] == '1'; }();
-  return on && (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && !a.colbias && a.act != 2 && !a.relu_mask && !a.vnni_c && (unsigned long long)a.n * (unsigned long long)a.ldc < (1ull << 29);
+// BND form (round 5: adopted -- bf16 40^3 0.49 -> 0.57, 24^3 0.60 -> 0.70, 72^3 0.35 -> 0.43 of the HBM roofline, profiles/r05_ragged16_switches.jsonl): plain results
+// (beta = 0, no bias, no bitmask, no VNNI C), A blocks on dwords like B's (ragged16_b_dwords), extents that fit a 32-bit buffer resource
+static bool ragged16_bounded(const GemmArgs& a) {
+  const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0);
+  return (abits & 3ull) == 0ull && (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && !a.colbias && a.act != 2 && !a.relu_mask && !a.vnni_c && (unsigned long long)a.n * (unsigned long long)a.ldc < (1ull << 29);
 }
 // one masked tile, blobs of at most 1024 dwords, dword-aligned operands, no transposes
 static bool f32_blob_ok(const GemmArgs& a) {
@@ -4954,7 +4955,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       const bool exact = (a.m % tw) == 0 && (a.n % tw) == 0 && (a.k % 32) == 0 && (bbits & 15ull) == 0 && !a.list_a && a.br_mode != 1 && a.br_mode != 2 &&
         (kind >= 2 || ((((unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)(a.br_mode == 3 ? a.br_stride_a : 0)) & 1ull) == 0));
       const bool bl = !exact && !(a.k & 1) && ragged16_b_dwords(a);        // ragged shapes with B on dwords: B through LDS
-      static const bool xlds = []() { const char* e = getenv("LIBXSMM_HIP_W8_LDS"); return e && e[0] == '1'; }();      // prepared, not measured: whole tiles with B through LDS
+      const bool xlds = true;      // whole tiles: B through LDS by 16-byte requests (round 5: adopted, 64^3 bf8 0.605 -> 0.658, scaled i8 0.628 -> 0.659: profiles/r05_ragged16_switches.jsonl)
 #define LAUNCH_W8K_(MT_, NT_, K_) do { if (exact && xlds) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, true, true>), grid, dim3(256), 0, st, a); \
                                        else if (exact) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, true>), grid, dim3(256), 0, st, a); \
                                        else if (bl) hipLaunchKernelGGL((gemm_w8_bf16_kernel<MT_, NT_, K_, false, true>), grid, dim3(256), 0, st, a); \

@@ -500,6 +500,17 @@ static void run_gemm_bitmask(KernelCtx* k, const libxsmm_gemm_param* p, const Ba
   finish_launch(err, kname ? kname : "bitmask_expand");
 }
 
+// Flags that mean nothing for the descriptor's operand types are IGNORED, as the reference does (its JIT and its C loop alike; tests/test_dispatch_differential_cpu.py):
+// VNNI_A / VNNI_B on f32 / f64 operands (no VNNI layout exists for them [ref: gemm ref :1359-1426]), INTLV_A_FORMAT on types that have no interleaved format
+// (it belongs to 4-bit / 2-bit weights [ref: gemm ref :467-486]).  The handle still reports the caller's flags (libxsmm_get_mmkernel_info).
+unsigned int effective_gemm_flags(const libxsmm_gemm_descriptor& d) {
+  unsigned int f = d.flags;
+  if ((d.a_type == LIBXSMM_DATATYPE_F32 && d.b_type == LIBXSMM_DATATYPE_F32) || (d.a_type == LIBXSMM_DATATYPE_F64 && d.b_type == LIBXSMM_DATATYPE_F64))
+    f &= ~(unsigned int)(LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B);
+  const bool has_intlv = d.a_type == LIBXSMM_DATATYPE_I4X2 || d.a_type == LIBXSMM_DATATYPE_U4X2 || d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_I2X4 || d.a_type == LIBXSMM_DATATYPE_I1X8;
+  if (!has_intlv) f &= ~(unsigned int)LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT;
+  return f;
+}
 void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   coalesce_flush();
   const libxsmm_gemm_descriptor& d = k->g;
@@ -523,6 +534,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   a.stream_hint = tls().stream_hint;
   a.m = (int)d.m; a.n = (int)d.n; a.k = (int)d.k; a.lda = (int)d.lda; a.ldb = (int)d.ldb; a.ldc = (int)d.ldc;
   a.flags = d.flags; a.a_type = d.a_type; a.b_type = d.b_type; a.c_type = d.c_type;
+  a.flags = effective_gemm_flags(d);
   a.vnni_c = (d.flags & LIBXSMM_GEMM_FLAG_VNNI_C) ? 1 : 0;
   a.comp_f16 = (d.a_type == LIBXSMM_DATATYPE_F16 && d.comp_type == LIBXSMM_DATATYPE_F16) ? 1 : 0;
   a.br_count = 1; a.br_mode = 0;
@@ -1145,6 +1157,8 @@ struct CoalesceQueue {
   bool c_monotonic = true;                              // every queued C started at or behind the end of the hull so far: no two overlap
   bool strided = true; long long sa = 0, sb = 0, sc = 0;  // the calls so far step by constant byte strides (the usual loop): they leave as a STRIDED batch
   uintptr_t low_bits = 0;                               // OR of all queued pointers: alignment of the lists
+  std::unordered_map<uintptr_t, uintptr_t> index;       // queued C blocks by address / ec (built lazily, see coalesce_try)
+  bool indexed = false;
 };
 thread_local CoalesceQueue t_queue;
 static const size_t kCoalesceCap = 65536;
@@ -1199,24 +1213,36 @@ bool coalesce_try(KernelCtx* k, const void* param) {
     const bool a_near = ranges_overlap(pa, ea, q.cmin, q.cmax - q.cmin), b_near = ranges_overlap(pb, eb, q.cmin, q.cmax - q.cmin);
     const bool c_near_c = !(q.c_monotonic && pc >= q.cmax) && ranges_overlap(pc, ec, q.cmin, q.cmax - q.cmin);
     const bool c_near_r = ranges_overlap(pc, ec, q.rmin, q.rmax - q.rmin);
-    // interleaved layouts ({A_i, B_i, C_i} structs, operands carved alternately from one arena) are "near" on every call: the exact scan is bounded to a few
-    // hundred queued entries -- beyond that a near call simply flushes (a batch of 256+ problems already amortises its launch)
-    const size_t kScanCap = 256;
-    if ((a_near || b_near || c_near_c || c_near_r) && q.c.size() > kScanCap) hazard = true;
-    if ((a_near || b_near || c_near_c) && !hazard)
-      for (size_t i = 0; i < q.c.size() && !hazard; ++i) {
-        const uintptr_t qc = (uintptr_t)q.c[i];
-        hazard = (a_near && ranges_overlap(pa, ea, qc, q.ec)) || (b_near && ranges_overlap(pb, eb, qc, q.ec)) || (c_near_c && ranges_overlap(pc, ec, qc, q.ec));
-      }
-    if (c_near_r && !hazard)
+    // Exact checks without an O(n) scan per call [advisor, round 4: interleaved layouts ({A_i, B_i, C_i} structs, operands carved alternately from one arena)
+    // are "near" on every call].  Queued C blocks never overlap each other (a write-after-write flushes first) and all have the size ec, so a table keyed by
+    // address / ec holds at most one block start per key: a range query probes (length / ec + 2) keys.  The table is built on the first near call only --
+    // the usual loop over disjoint arrays never pays for it.
+    if (a_near || b_near || c_near_c) {
+      if (!q.indexed) { q.index.clear(); q.index.reserve(q.c.size() * 2 + 64); for (void* c : q.c) q.index.emplace((uintptr_t)c / q.ec, (uintptr_t)c); q.indexed = true; }
+      const auto hits = [&q](uintptr_t x, size_t len) {
+        const uintptr_t k0 = x / q.ec, k1 = (x + len - 1) / q.ec;
+        if (k1 - k0 > 64) return true;                      // a very long read range (a deep batch-reduce chain): not worth probing, order it behind the queue
+        for (uintptr_t key = (k0 > 0 ? k0 - 1 : 0); key <= k1; ++key) {
+          const auto it = q.index.find(key);
+          if (it != q.index.end() && ranges_overlap(x, len, it->second, q.ec)) return true;
+        }
+        return false;
+      };
+      hazard = (a_near && hits(pa, ea)) || (b_near && hits(pb, eb)) || (c_near_c && hits(pc, ec));
+    }
+    // write-after-read (this call's C against what the queued calls READ: two sizes, no common grid): the exact scan is bounded to a few hundred entries,
+    // beyond that a near call simply flushes -- a batch of 256+ problems already amortises its launch
+    if (c_near_r && !hazard) {
+      if (q.a.size() > 256) hazard = true;
       for (size_t i = 0; i < q.a.size() && !hazard; ++i)
         hazard = ranges_overlap(pc, ec, (uintptr_t)q.a[i], q.ea) || ranges_overlap(pc, ec, (uintptr_t)q.b[i], q.eb);
+    }
     if (hazard) coalesce_flush();
   }
   if (q.a.empty()) {
     q.k = k; q.br_count = brc; q.ea = ea; q.eb = eb; q.ec = ec;
     q.cmin = pc; q.cmax = pc + ec; q.rmin = std::min(pa, pb); q.rmax = std::max(pa + ea, pb + eb); q.c_monotonic = true;
-    q.strided = true; q.sa = q.sb = q.sc = 0; q.low_bits = 0;
+    q.strided = true; q.sa = q.sb = q.sc = 0; q.low_bits = 0; q.indexed = false;
   } else {
     const size_t n = q.a.size();
     if (n == 1) { q.sa = (long long)(pa - (uintptr_t)q.a[0]); q.sb = (long long)(pb - (uintptr_t)q.b[0]); q.sc = (long long)(pc - (uintptr_t)q.c[0]); }
@@ -1226,6 +1252,7 @@ bool coalesce_try(KernelCtx* k, const void* param) {
     q.rmin = std::min(q.rmin, std::min(pa, pb)); q.rmax = std::max(q.rmax, std::max(pa + ea, pb + eb));
   }
   q.low_bits |= pa | pb | pc;
+  if (q.indexed) q.index.emplace(pc / q.ec, pc);
   q.a.push_back(p->a.primary); q.b.push_back(p->b.primary); q.c.push_back(p->c.primary);
   return true;
 }
@@ -1501,7 +1528,7 @@ static const void* find_or_build(Kind kind, const void* desc, size_t size, Suppo
     if (kind == K_GEMM || kind == K_TILECFG) {
       std::memcpy(&c->g, desc, sizeof(c->g));
       c->nflops = (unsigned int)(2ull * c->g.m * c->g.n * c->g.k);
-      c->kname_single = gemm_kernel_name(c->g, false); c->kname_batched = gemm_kernel_name(c->g, true);
+      { libxsmm_gemm_descriptor e = c->g; e.flags = effective_gemm_flags(e); c->kname_single = gemm_kernel_name(e, false); c->kname_batched = gemm_kernel_name(e, true); }
     } else {
       std::memcpy(&c->e, desc, sizeof(c->e));
       c->nflops = c->e.m * c->e.n;
@@ -1536,7 +1563,8 @@ LIBXSMM_API libxsmm_xmmfunction libxsmm_xmmdispatch(const libxsmm_gemm_descripto
   const bool a = (d->flags & LIBXSMM_GEMM_FLAG_NO_RESET_TILECONFIG) != 0, b = (d->flags & LIBXSMM_GEMM_FLAG_NO_SETUP_TILECONFIG) != 0;
   if (a != b) { r.ptr_const = find_or_build(K_TILECFG, d, sizeof(*d), []() { return true; }); return r; }
   r.ptr_const = find_or_build(K_GEMM, d, sizeof(*d), [d]() {
-    if (gemm_supported(*d)) return true;
+    libxsmm_gemm_descriptor e = *d; e.flags = effective_gemm_flags(e);
+    if (gemm_supported(e)) return true;
     vlog(1, "unsupported GEMM descriptor (types %s/%s/%s, flags 0x%x)", kTypeNames[d->a_type], kTypeNames[d->b_type], kTypeNames[d->c_type], d->flags);
     return false; });
   return r;
@@ -1858,7 +1886,11 @@ LIBXSMM_API int libxsmm_get_kernel_info(const void* kernel, libxsmm_kernel_info*
 LIBXSMM_API int libxsmm_get_mmkernel_info(libxsmm_xmmfunction kernel, libxsmm_mmkernel_info* info) {
   KernelCtx* c = ctx_from_handle(kernel.ptr_const);
   if (!c || !info || c->kind == K_MELTW) return EXIT_FAILURE;
-  info->iprecision = (libxsmm_datatype)c->g.a_type; info->oprecision = (libxsmm_datatype)c->g.c_type;
+  // the COMMON precision of A and B with the signedness dropped, UNSUPPORTED when they differ beyond that [ref: src/libxsmm_main.c:3057, LIBXSMM_GEMM_GETENUM_AB_COMMON_PREC] --
+  // round 5: found by the differential test (was: A's type as given)
+  const auto sgn = [](int t) { return t == LIBXSMM_DATATYPE_U64 ? LIBXSMM_DATATYPE_I64 : t == LIBXSMM_DATATYPE_U32 ? LIBXSMM_DATATYPE_I32 : t == LIBXSMM_DATATYPE_U16 ? LIBXSMM_DATATYPE_I16 :
+                                  t == LIBXSMM_DATATYPE_U8 ? LIBXSMM_DATATYPE_I8 : t == LIBXSMM_DATATYPE_U4X2 ? LIBXSMM_DATATYPE_I4X2 : t; };
+  info->iprecision = (libxsmm_datatype)(sgn(c->g.a_type) == sgn(c->g.b_type) ? sgn(c->g.a_type) : (int)LIBXSMM_DATATYPE_UNSUPPORTED); info->oprecision = (libxsmm_datatype)c->g.c_type;
   info->prefetch = (libxsmm_gemm_prefetch_type)c->g.prefetch; info->flags = (int)c->g.flags;
   info->lda = c->g.lda; info->ldb = c->g.ldb; info->ldc = c->g.ldc; info->m = c->g.m; info->n = c->g.n; info->k = c->g.k;
   return EXIT_SUCCESS;
@@ -1866,7 +1898,8 @@ LIBXSMM_API int libxsmm_get_mmkernel_info(libxsmm_xmmfunction kernel, libxsmm_mm
 LIBXSMM_API int libxsmm_get_meltwkernel_info(libxsmm_xmeltwfunction kernel, libxsmm_meltwkernel_info* info) {
   KernelCtx* c = ctx_from_handle((const void*)kernel.xmeltw);
   if (!c || !info || c->kind != K_MELTW) return EXIT_FAILURE;
-  info->ldi = c->e.ldi; info->ldo = c->e.ldo; info->m = c->e.m; info->n = c->e.n; info->datatype = c->e.in0_type; info->flags = c->e.flags; info->operation = c->e.param;
+  info->ldi = c->e.ldi; info->ldo = c->e.ldo; info->m = c->e.m; info->n = c->e.n; info->datatype = c->e.in0_type; info->flags = c->e.flags;
+  info->operation = c->e.operation;          // the KIND (unary 1 / binary 2 / ternary 3), as the reference reports it [ref: src/libxsmm_main.c:3106] -- round 5: found by the differential test (was: the TPP type)
   return EXIT_SUCCESS;
 }
 LIBXSMM_API int libxsmm_get_registry_info(libxsmm_registry_info* info) {

@@ -244,3 +244,18 @@ XREF void xref_sgemm(const char* transa, const char* transb, const libxsmm_blasi
   const float* alpha, const float* a, const libxsmm_blasint* lda, const float* b, const libxsmm_blasint* ldb, const float* beta, float* c, const libxsmm_blasint* ldc) {
   libxsmm_sgemm(transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc);
 }
+
+/* --- differential accept / refuse parity (tests/test_dispatch_differential_cpu.py): what the reference's own descriptor initialisers and dispatcher say about a
+ * descriptor, and what its introspection reports for the handle [ref: src/libxsmm_generator.c:36-321, src/libxsmm_main.c:3004-3131] ------------------------------- */
+XREF int xref_gemm_descriptor_ok(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_gemm_batch_reduce_config brcfg) {
+  libxsmm_descriptor_blob blob;
+  return NULL != libxsmm_gemm_descriptor_init_brgemm(&blob, shape, flags, prefetch, brcfg);
+}
+XREF int xref_gemm_ext_descriptor_ok(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch, libxsmm_gemm_batch_reduce_config brcfg,
+  libxsmm_gemm_ext_unary_argops argops, libxsmm_gemm_ext_binary_postops postops) {
+  libxsmm_descriptor_blob blob;
+  return NULL != libxsmm_gemm_descriptor_init_brgemm_ext(&blob, shape, flags, prefetch, brcfg, argops, postops);
+}
+XREF int xref_get_mmkernel_info(const void* kernel, libxsmm_mmkernel_info* info) { libxsmm_xmmfunction f; f.ptr_const = kernel; return libxsmm_get_mmkernel_info(f, info); }
+XREF int xref_get_meltwkernel_info(const void* kernel, libxsmm_meltwkernel_info* info) { libxsmm_xmeltwfunction f; memset(&f, 0, sizeof(f)); memcpy(&f, &kernel, sizeof(kernel)); return libxsmm_get_meltwkernel_info(f, info); }
+XREF libxsmm_tilecfgfunction xref_dispatch_tilecfg_gemm(libxsmm_gemm_shape shape, libxsmm_bitfield flags) { return libxsmm_dispatch_tilecfg_gemm(shape, flags); }

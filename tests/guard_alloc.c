@@ -44,8 +44,15 @@ void* guard_alloc(size_t nbytes, int front) {
   return r->user;
 }
 
+/* guard_free QUARANTINES by default (guard_set_reuse(1) really unmaps -- tools/guard_probe.py measures what that does): a block that is unmapped and released hands its
+ * physical pages -- and usually its virtual range -- to the next guard_alloc of the process, and on this stack the next kernel can then see the PREVIOUS owner's
+ * bytes instead of what a host-to-device copy just wrote there (observed in round 5: the second beta = 1 test of a guarded run read the first test's C).  Parity
+ * tests need memory that holds what was uploaded, so freed blocks stay mapped until the process exits (a granule each: a few GB over a whole guarded run). */
+static int g_reuse = 0;
+void guard_set_reuse(int on) { g_reuse = on; }
 void guard_free(void* user) {
   guard_rec** pp = &g_head;
+  if (!g_reuse) return;
   for (; *pp; pp = &(*pp)->next) if ((*pp)->user == user) {
     guard_rec* r = *pp; size_t gran = (r->reserve - r->mapped) / 2;
     *pp = r->next;

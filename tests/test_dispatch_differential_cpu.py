@@ -1,0 +1,191 @@
+"""Differential accept / refuse parity with the REFERENCE ITSELF (oracle/_ref/libxsmm_ref.so = /root/reference compiled here through oracle/ref_shim.c), not with a
+hand-typed table (round-4 review item 3): a few thousand drawn descriptors -- types x flags x shapes x leading dimensions (also smaller than the extent), odd k with
+VNNI, tile-config flag pairs, batch-reduce kinds, ext argops / postops -- go through
+
+  * this library in dry-run mode (LIBXSMM_HIP_DRYRUN=1: dispatch works without a device),
+  * the reference's descriptor initialisers  [ref: src/libxsmm_generator.c:36-321]  (host independent),
+  * the reference's dispatcher               [ref: src/libxsmm_main.c:3323-3470]    and libxsmm_get_kernel_info(...).is_reference_kernel.
+
+What the reference does with a descriptor has three outcomes: NULL (only the tile-config half pairs, src/libxsmm_generator.c:154-157, and 1- / 2-bit weights with
+m not in {32, 64}, src/libxsmm_main.c:2200-2207), a JIT kernel (the host ISA's generator took it: its dtype allow-list and leading-dimension checks,
+src/generator_gemm.c:195-298, :1017-1040), or -- for EVERYTHING else, including leading dimensions smaller than the extent and type combinations no loop of
+libxsmm_reference_gemm handles -- a trampoline to its C loop (is_reference_kernel = 1, src/libxsmm_main.c:2209-2216).  Checked here:
+
+  1. reference NULL          =>  this library NULL, and the other way round for the tile-config pairs;
+  2. this library non-NULL   =>  reference non-NULL;
+  3. reference JIT kernel    =>  this library non-NULL, EXCEPT the documented refusals D1-D3 and D5 below ("Differences of the dispatcher");
+     D4 is the one place where this library hands out a handle and the reference (on a host whose JIT does not take the descriptor) does not;
+  4. handles both sides hand out report the same libxsmm_get_mmkernel_info / libxsmm_get_meltwkernel_info fields [ref: src/libxsmm_main.c:3043-3131].
+The trampoline class is reported (counts per family) but not asserted: the reference "accepts" there what it cannot compute."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import collections, ctypes as C, json, random, sys
+sys.path.insert(0, %r)
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, GEMM_FLAG as F, UNARY, BINARY
+from oracle import pyoracle
+api = capi.load(); ref = pyoracle.reference(); L = ref.lib; vp = C.c_void_p
+L.xref_gemm_descriptor_ok.argtypes = [capi.GemmShape, C.c_uint, C.c_uint, capi.BrConfig]; L.xref_gemm_descriptor_ok.restype = C.c_int
+L.xref_gemm_ext_descriptor_ok.argtypes = [capi.GemmShape, C.c_uint, C.c_uint, capi.BrConfig, capi.ExtUnaryArgops, capi.ExtBinaryPostops]; L.xref_gemm_ext_descriptor_ok.restype = C.c_int
+L.xref_get_mmkernel_info.argtypes = [vp, C.POINTER(capi.MmKernelInfo)]; L.xref_get_mmkernel_info.restype = C.c_int
+class MeltwInfo(C.Structure):
+    _fields_ = [("ldi", C.c_uint), ("ldo", C.c_uint), ("m", C.c_uint), ("n", C.c_uint), ("datatype", C.c_uint), ("flags", C.c_uint), ("operation", C.c_uint)]   # [ref: include/libxsmm_typedefs.h:809-818]
+L.xref_get_meltwkernel_info.argtypes = [vp, C.POINTER(MeltwInfo)]; L.xref_get_meltwkernel_info.restype = C.c_int
+api.lib.libxsmm_get_meltwkernel_info.argtypes = [vp, C.POINTER(MeltwInfo)]; api.lib.libxsmm_get_meltwkernel_info.restype = C.c_int
+rng = random.Random(20260925)
+TYPES = [("f32", DT.F32, DT.F32, DT.F32, DT.F32), ("f64", DT.F64, DT.F64, DT.F64, DT.F64), ("bf16", DT.BF16, DT.BF16, DT.BF16, DT.F32), ("bf16_f32", DT.BF16, DT.BF16, DT.F32, DT.F32),
+         ("f16", DT.F16, DT.F16, DT.F16, DT.F32), ("f16_f32", DT.F16, DT.F16, DT.F32, DT.F32), ("u8i8", DT.U8, DT.I8, DT.I32, DT.I32), ("i8u8", DT.I8, DT.U8, DT.I32, DT.I32),
+         ("i8i8_f32", DT.I8, DT.I8, DT.F32, DT.I32), ("bf8", DT.BF8, DT.BF8, DT.F32, DT.F32), ("hf8", DT.HF8, DT.HF8, DT.F32, DT.F32), ("bf8_bf8", DT.BF8, DT.BF8, DT.BF8, DT.F32),
+         ("i16", DT.I16, DT.I16, DT.I32, DT.I32), ("bf32", DT.BF32, DT.BF32, DT.F32, DT.F32), ("f64xf32", DT.F64, DT.F32, DT.F32, DT.F32), ("f32_bf16", DT.F32, DT.F32, DT.BF16, DT.F32),
+         ("bf16_i32", DT.BF16, DT.BF16, DT.I32, DT.F32), ("i1", DT.I1X8, DT.I8, DT.I32, DT.I32), ("i2", DT.I2X4, DT.U8, DT.I32, DT.I32)]
+TC = F.NO_RESET_TILECONFIG | F.NO_SETUP_TILECONFIG
+FLAGS = [0, 0, F.TRANS_A, F.TRANS_B, F.TRANS_A | F.TRANS_B, F.VNNI_A, F.VNNI_A, F.VNNI_A | F.TRANS_B | F.VNNI_B, F.VNNI_A | F.VNNI_C, F.VNNI_B, F.NO_RESET_TILECONFIG, F.NO_SETUP_TILECONFIG, TC,
+         F.VNNI_A | F.INTLV_A_FORMAT, F.VNNI_A | F.NO_RESET_TILECONFIG]
+records, stats = [], collections.Counter()
+def kind_of(rh):
+    if not rh: return "null"
+    info = capi.KernelInfo(); ref.get_kernel_info(rh, C.byref(info))
+    return "refk" if info.is_reference_kernel else "jit"
+for it in range(%d):
+    tn, a, b, c, comp = rng.choice(TYPES)
+    m, n, k = rng.choice([1, 7, 16, 23, 32, 33, 64]), rng.choice([1, 5, 16, 32, 48]), rng.choice([1, 2, 3, 4, 8, 16, 31, 32, 64])
+    fl = rng.choice(FLAGS) | (F.BETA_0 if rng.random() < 0.5 else 0)
+    ta, tb = bool(fl & F.TRANS_A), bool(fl & F.TRANS_B)
+    lda = (k if ta else m) + rng.choice([0, 0, 0, 0, 3, 4, -1]); ldb = (n if tb else k) + rng.choice([0, 0, 0, 0, 5, 8, -1]); ldc = m + rng.choice([0, 0, 0, 0, 2, -1])
+    if min(lda, ldb, ldc) < 1: continue
+    brt = rng.choice([capi.BR_NONE, capi.BR_NONE, capi.BR_STRIDE, capi.BR_OFFSET, capi.BR_ADDRESS])
+    brc = capi.br_config(brt, 4096 if brt == capi.BR_STRIDE else 0, 8192 if brt == capi.BR_STRIDE else 0, 0)
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, a, b, c, comp)
+    ext = rng.random() < 0.15
+    fused = 0
+    if ext:
+        has_cp, has_bin = rng.random() < 0.5, rng.random() < 0.6
+        fused = int(has_cp) + 2 * int(has_bin)
+        argops = capi.argops_cp(ldc, capi.UNARY.RELU) if has_cp else capi.no_argops()
+        postops = capi.ExtBinaryPostops(ldc, c, capi.BINARY.ADD, capi.BINARY_FLAG.BCAST_COL_IN_0) if has_bin else capi.ExtBinaryPostops()
+        ours = api.dispatch_brgemm_ext(shape, fl, 0, brc, argops, postops)
+        rdesc = L.xref_gemm_ext_descriptor_ok(shape, fl, 0, brc, argops, postops)
+        rh = ref.dispatch_brgemm_ext(shape, fl, 0, brc, argops, postops)
+    else:
+        ours = api.dispatch_brgemm(shape, fl, 0, brc)
+        rdesc = L.xref_gemm_descriptor_ok(shape, fl, 0, brc)
+        rh = ref.dispatch_brgemm(shape, fl, 0, brc)
+    rk = kind_of(rh)
+    info_equal = None
+    if ours and rh:
+        io, ir = capi.MmKernelInfo(), capi.MmKernelInfo()
+        ro, rr = api.get_mmkernel_info(ours, C.byref(io)), L.xref_get_mmkernel_info(rh, C.byref(ir))
+        info_equal = ro == rr == 0 and all(getattr(io, f) == getattr(ir, f) for f, _ in capi.MmKernelInfo._fields_)
+        if not info_equal:
+            info_equal = {f: (getattr(io, f), getattr(ir, f)) for f, _ in capi.MmKernelInfo._fields_ if getattr(io, f) != getattr(ir, f)}
+    stats[(bool(ours), rk)] += 1
+    records.append(dict(t=tn, a=int(a), b=int(b), c=int(c), m=m, n=n, k=k, lda=lda, ldb=ldb, ldc=ldc, fl=int(fl), br=brt, ext=ext, fused=fused, ours=bool(ours), rdesc=bool(rdesc), ref=rk, info=info_equal))
+# TPP handles: introspection fields
+tpp = []
+US = lambda i, o, m=32, n=24, ldi=40, ldo=36: capi.UnaryShape(m, n, ldi, ldo, i, o, DT.F32)
+for name, typ, shape, flags in [("relu", UNARY.RELU, US(DT.F32, DT.F32), 0), ("identity_bf16", UNARY.IDENTITY, US(DT.BF16, DT.F32), 0), ("tanh", UNARY.TANH, US(DT.F32, DT.BF16), 0),
+                                ("reduce_cols", UNARY.REDUCE_X_OP_ADD, US(DT.F32, DT.F32), capi.UNARY_FLAG.REDUCE_COLS), ("transpose", UNARY.TRANSFORM_NORM_TO_NORMT, US(DT.F32, DT.F32, 32, 24, 32, 24), 0)]:
+    ho, hr = api.dispatch_meltw_unary(typ, shape, flags), ref.dispatch_meltw_unary(typ, shape, flags)
+    io, ir = MeltwInfo(), MeltwInfo()
+    ok = bool(ho) and bool(hr) and api.lib.libxsmm_get_meltwkernel_info(ho, C.byref(io)) == 0 and L.xref_get_meltwkernel_info(hr, C.byref(ir)) == 0
+    tpp.append((name, ok, {f: (getattr(io, f), getattr(ir, f)) for f, _ in MeltwInfo._fields_ if getattr(io, f) != getattr(ir, f)}))
+bs = capi.BinaryShape(32, 24, 40, 44, 36, DT.F32, DT.BF16, DT.F32, DT.F32)
+ho, hr = api.dispatch_meltw_binary(BINARY.ADD, bs, 0), ref.dispatch_meltw_binary(BINARY.ADD, bs, 0)
+io, ir = MeltwInfo(), MeltwInfo()
+ok = bool(ho) and bool(hr) and api.lib.libxsmm_get_meltwkernel_info(ho, C.byref(io)) == 0 and L.xref_get_meltwkernel_info(hr, C.byref(ir)) == 0
+tpp.append(("binary_add", ok, {f: (getattr(io, f), getattr(ir, f)) for f, _ in MeltwInfo._fields_ if getattr(io, f) != getattr(ir, f)}))
+L.xref_get_target_arch.restype = C.c_char_p
+print(json.dumps({"arch": L.xref_get_target_arch().decode(), "records": records, "tpp": tpp, "stats": {f"{k[0]}/{k[1]}": v for k, v in stats.items()}}))
+"""
+
+F_TA, F_TB, F_VA, F_VB, F_VC, F_NORESET, F_NOSETUP = 1, 2, 256, 512, 1024, 64, 128
+I8, U8, F32, BF16, F16, BF8, HF8 = None, None, None, None, None, None, None
+
+
+def _documented_refusal(r, DT):
+    """D1-D3, D5: descriptors the reference's JIT takes on this host and this library refuses ON PURPOSE ("Differences of the dispatcher")."""
+    fl = r["fl"]
+    sixteen = r["a"] in (int(DT.BF16), int(DT.F16), int(DT.I16))
+    eight = r["a"] in (int(DT.I8), int(DT.U8), int(DT.BF8), int(DT.HF8))
+    if r["a"] == int(DT.I8) and r["b"] == int(DT.I8) and r["c"] == int(DT.F32) and not (fl & F_VA):
+        return "D1 i8 x i8 -> f32 with a flat (non-VNNI) A: the scaled-f32 result is defined for VNNI-4 A only [ref: gemm ref :1558-1683]"
+    if (fl & (F_VA | F_VB)) and ((sixteen and r["k"] % 2) or (eight and r["k"] % 4)):
+        return "D2 VNNI operand with a k that is not a whole number of k-groups: the reference's own loop reads k/2 (k/4) groups [ref: gemm ref :2134-2161]"
+    if (fl & F_VC) and r["c"] != int(DT.BF16):
+        return "D3 VNNI_C with a C that is not bf16"
+    if r["fused"] and not (r["a"] == int(DT.F32) or r["a"] == int(DT.BF16)):
+        return "D5 a fused operator (argops / postops of libxsmm_dispatch_brgemm_ext) on operand types other than f32 / bf16"
+    return None
+
+
+@pytest.fixture(scope="module")
+def drawn():
+    sys.path.insert(0, ROOT)
+    from oracle import pyoracle
+    pyoracle.build()
+    if not pyoracle.have_reference():
+        pytest.skip("oracle/_ref/libxsmm_ref.so not built (no /root/reference here)")
+    env = dict(os.environ, LIBXSMM_HIP_DRYRUN="1", LIBXSMM_VERBOSE="0")
+    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, 6000)], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_enough_descriptors_of_every_outcome(drawn):
+    s = drawn["stats"]
+    print("reference target:", drawn["arch"], "| ours/reference:", s)
+    assert len(drawn["records"]) > 4500
+    assert s.get("True/jit", 0) > 300 and s.get("False/null", 0) > 300 and s.get("False/refk", 0) > 300
+
+
+def test_reference_null_is_null_here_and_nothing_else_is_new(drawn):
+    from libxsmm_amd.capi import DT
+    for r in drawn["records"]:
+        half = bool(r["fl"] & F_NORESET) != bool(r["fl"] & F_NOSETUP)
+        assert r["rdesc"] == (not half), r                                       # the initialisers refuse exactly the tile-config half pairs (host independent)
+        lowbit_d4 = r["a"] in (int(DT.I1X8), int(DT.I2X4)) and r["m"] not in (32, 64)      # D4: no C-loop fallback for these in the reference [ref: src/libxsmm_main.c:2200-2207]
+        if r["ref"] == "null":
+            assert half or lowbit_d4, f"a reference NULL of an unknown kind: {r}"
+            assert not r["ours"] or lowbit_d4, f"the reference refuses, this library accepts: {r}"
+        if r["ours"]:
+            assert r["ref"] != "null" or lowbit_d4, r
+
+
+def test_what_the_reference_jits_is_accepted_here_or_documented(drawn):
+    from libxsmm_amd.capi import DT
+    seen = {}
+    for r in drawn["records"]:
+        if r["ref"] == "jit" and not r["ours"]:
+            why = _documented_refusal(r, DT)
+            assert why is not None, f"the reference's JIT ({drawn['arch']}) takes this descriptor, this library refuses it without a documented reason: {r}"
+            seen[why.split()[0]] = seen.get(why.split()[0], 0) + 1
+    print("documented refusals met:", seen)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for tag in ("D1", "D2", "D3", "D4", "D5"):
+        assert f"**{tag}**" in text, f"INTEGRATION.md does not list {tag}"
+
+
+def test_introspection_fields_equal_the_references(drawn):
+    bad = [r for r in drawn["records"] if r["info"] not in (None, True)]
+    assert not bad, bad[:5]
+    assert sum(1 for r in drawn["records"] if r["info"] is True) > 500
+    for name, ok, diff in drawn["tpp"]:
+        assert ok and not diff, (name, diff)
+
+
+def test_trampoline_class_is_reported(drawn):
+    """not asserted: the reference hands out a trampoline to its C loop for everything its JIT refuses -- leading dimensions below the extent, type combinations no loop handles"""
+    import collections
+    refused, taken = collections.Counter(), collections.Counter()
+    for r in drawn["records"]:
+        if r["ref"] == "refk":
+            (taken if r["ours"] else refused)[r["t"]] += 1
+    print("reference falls back to its C loop -- accepted here:", dict(taken), "| refused here:", dict(refused))
