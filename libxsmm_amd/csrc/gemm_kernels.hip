@@ -29,6 +29,7 @@
 #include "internal.hpp"
 #include "lowp.hpp"
 #include "gemm_device.hpp"
+#include "gemm_tile.hpp"
 
 // a*b+c below means two roundings unless fma()/MFMA is spelled out: parity with the reference's C
 // loops (built without FMA contraction) depends on it.
@@ -37,26 +38,6 @@
 namespace xamd {
 
 
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bf16_to_f32(unsigned short x) { return __uint_as_float((unsigned int)x << 16); }
-// RNE with denormals-are-zero and NaN quieting [ref: src/libxsmm_math.c:684-704]
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7f800000u) == 0u) u &= 0x80000000u;
-  if ((u & 0x7f800000u) == 0x7f800000u) { if (u & 0x007fffffu) u |= 0x00400000u; }
-  else u += 0x00007fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-// sigmoid(x) = (tanh(x/2) + 1) / 2 [ref: mateltwise ref :18-20], evaluated as 1 / (1 + e^-x) with the hardware
-// exp/rcp: ~1e-6 relative, inside the reference's own 7e-4 bound for fused sigmoid (gemm_kernel.c:5396) and a
-// small fraction of the code of an inlined tanhf (the epilogue is instantiated 16x per tile).
-__device__ __forceinline__ float act_apply(int act, float x) {
-  if (act == 1 || act == 2) return (x <= 0.0f) ? 0.0f : x;
-  if (act == 3) return __frcp_rn(1.0f + __expf(-x));
-  return x;
-}
 
 
 // MXFP4 A: base of the E8M0 scales of batch-reduce element r [ref: gemm ref :200-222] -- one byte per (32-deep k-block, row):
@@ -133,29 +114,6 @@ __device__ __forceinline__ void generic_epilogue(const GemmArgs& p, const BatchP
 template <typename T> __device__ __forceinline__ T mul_rn(T a, T b) { return a * b; }
 template <typename T> __device__ __forceinline__ T add_rn(T a, T b) { return a + b; }
 
-// 8-bit floats [ref: src/libxsmm_math.c:546-585]: BF8 (E5M2) is the upper byte of an IEEE half; HF8 (E4M3, bias 7, no infinities)
-__device__ __forceinline__ float bf8_to_f32(unsigned char x) { return (float)__builtin_bit_cast(_Float16, (unsigned short)((unsigned short)x << 8)); }
-__device__ __forceinline__ float hf8_to_f32(unsigned char in) {
-  const unsigned int s = (unsigned int)(in & 0x80u) << 24, e = (in & 0x78u) >> 3;
-  unsigned int m = in & 0x07u, e_norm = e + 120u;
-  if (e == 0u && m != 0u) { unsigned int lz = 2u; lz = (m > 1u) ? 1u : lz; lz = (m > 3u) ? 0u : lz; e_norm -= lz; m = (m << (lz + 1u)) & 7u; }
-  else if (e == 0u && m == 0u) e_norm = 0u;
-  else if (e == 15u && m == 7u) { e_norm = 255u; m = 4u; }
-  return __uint_as_float((e_norm << 23) | (m << 20) | s);
-}
-__device__ __forceinline__ float load_as_f32(gcptr base, long long idx, int type) {
-  if (type == LIBXSMM_DATATYPE_F32) return ((GM const float*)base)[idx];
-  if (type == LIBXSMM_DATATYPE_BF32) return bf16_to_f32(f32_to_bf16_rne(((GM const float*)base)[idx]));      // f32 storage, bf16 precision [ref: gemm ref :1366,:1384-1389]
-  if (type == LIBXSMM_DATATYPE_BF8) return bf8_to_f32(((GM const unsigned char*)base)[idx]);
-  if (type == LIBXSMM_DATATYPE_HF8) return hf8_to_f32(((GM const unsigned char*)base)[idx]);
-  return bf16_to_f32(((GM const unsigned short*)base)[idx]);
-}
-
-// C and bias operands are f32 or bf16 only (keeps the 8-bit decoders out of every tile prologue)
-__device__ __forceinline__ float load_c_f32(gcptr base, long long idx, int type) {
-  if (type == LIBXSMM_DATATYPE_F16) return (float)((GM const _Float16*)base)[idx];
-  return (type == LIBXSMM_DATATYPE_F32) ? ((GM const float*)base)[idx] : bf16_to_f32(((GM const unsigned short*)base)[idx]);
-}
 
 // block = (64, 4): x walks i (so a wave is 64 consecutive rows of one column, which makes the
 // ReLU bitmask a ballot), y walks j.
@@ -580,189 +538,6 @@ __device__ __forceinline__ void tile_to_frag(float (&w)[16], const f32x4 (&g)[4]
       w[s] = __uint_as_float(r[0]); w[s + 8] = __uint_as_float(r[1]);
     }
   }
-}
-__device__ __forceinline__ bool aligned16(const void* p, long long ld_elems) {
-  return ((((unsigned long long)(size_t)p) & 15ull) == 0ull) && ((ld_elems & 3) == 0);
-}
-
-// Epilogue shared by all MFMA kernels.  `acc` is in transposed-product layout: lane&31 = i (row of
-// C), register r of half h = column j_local(r,h) = (r&3) + 8*(r>>2) + 4*h.
-struct TileCtx { int i; int j0; int h; bool ivalid; };
-__device__ __forceinline__ int jl_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// CF32: the C (and bias) datatype is known to be f32 at compile time (f32 kernels) -- drops the bf16 paths
-template <bool EXACT, bool CF32>
-__device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
-  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
-  const int c_type = CF32 ? (int)LIBXSMM_DATATYPE_F32 : p.c_type;
-  if (beta0 && !p.colbias) {          // the streaming case: nothing to read
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    return;
-  }
-  float bias = 0.0f;
-  if (p.colbias && (EXACT || t.ivalid)) bias = load_c_f32(q.d, t.i, c_type);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int j = t.j0 + jl_of(r, t.h);
-    float start = 0.0f;
-    if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_c_f32(q.c, (long long)j * p.ldc + t.i, c_type);
-    acc[r] = p.colbias ? (beta0 ? bias : bias + start) : start;
-  }
-}
-
-// Hardware RNE conversion of two f32 to a packed bf16 pair (v_cvt_pk_bf16_f32).  Differs from the reference's
-// software rounding [ref: src/libxsmm_math.c:684-704] only for f32 denormal inputs (|x| < 1.2e-38 is not flushed
-// to zero first) and in the payload of NaNs; used in GEMM epilogues, whose parity bar is a norm, not bit equality.
-typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
-  const f32x2 v = {lo, hi};
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwbf16x2));
-}
-// The reference's conversion EXACTLY (denormal inputs become signed zeros first), on the hardware instruction: ~4 vector instructions per element instead of the ~12
-// (and a divergent branch) of f32_to_bf16_rne.  NaNs are the one input whose result the instruction may encode differently: `nan_seen` collects them so that the
-// caller can send a wave that holds one through the software conversion.
-__device__ __forceinline__ unsigned int cvt_pk_bf16_dazexact(float lo, float hi, bool& nan_seen) {
-  const unsigned int ul = __float_as_uint(lo), uh = __float_as_uint(hi);
-  const float fl = __builtin_amdgcn_class(lo, 0x090) ? __uint_as_float(ul & 0x80000000u) : lo;      // class bits 4 / 7: negative / positive denormal
-  const float fh = __builtin_amdgcn_class(hi, 0x090) ? __uint_as_float(uh & 0x80000000u) : hi;
-  nan_seen = nan_seen || __builtin_amdgcn_class(lo, 0x003) || __builtin_amdgcn_class(hi, 0x003);   // class bits 0 / 1: signalling / quiet NaN
-  return cvt_pk_bf16(fl, fh);
-}
-// the same for IEEE halves (RNE, the conversion the reference's f32 -> f16 helper performs [ref: src/libxsmm_math.c libxsmm_convert_f32_to_f16])
-typedef _Float16 hwf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int cvt_pk_f16(float lo, float hi) {
-  const f32x2 v = {lo, hi};
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwf16x2));
-}
-__device__ __forceinline__ unsigned int cvt_pk_16(bool f16, float lo, float hi) { return f16 ? cvt_pk_f16(lo, hi) : cvt_pk_bf16(lo, hi); }
-// one 32 x 32 x 16 step on 16-bit operands: bf16 or (F16) IEEE halves -- same operand layout, same rate
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-template <bool F16> __device__ __forceinline__ f32x16 mfma_16bit(const u32x4& b, const u32x4& a, const f32x16& acc) {
-  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), acc, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
-}
-template <int ACT> __device__ __forceinline__ float act_fixed(float x) {
-  if (ACT == 1 || ACT == 2) return (x <= 0.0f) ? 0.0f : x;
-  if (ACT == 3) return __frcp_rn(1.0f + __expf(-x));
-  return x;
-}
-
-// Tile store.  ACT is the fused activation (0 none, 1 ReLU, 2 ReLU + bitmask, 3 sigmoid), fixed at compile time so the
-// streaming variants carry no activation code.  bf16 output of exact tiles goes out as packed dwords: registers
-// (2g, 2g+1) hold rows (j, j+1) of column i; one v_cvt_pk_bf16_f32 packs them, one DPP quad swap fetches the
-// neighbouring lane's pair and one v_perm_b32 (lane-parity dependent selector) forms (i, i+1) of row j in even
-// lanes and of row j+1 in odd lanes: 3 VALU + 1 dword store per two values.
-template <bool EXACT, bool CF32, int ACT, bool NT>
-__device__ __forceinline__ void tile_store_impl(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
-  const int lane = threadIdx.x & 63;
-  const long long mask_ld = ((p.ldc + 15) / 16) * 16;
-  const bool out_f32 = CF32 || (p.c_type == LIBXSMM_DATATYPE_F32);
-  // bf16 fast path needs an even ldc and a 4-byte aligned C
-  // (round 4: also for ragged tiles with an even m -- every row pair is whole -- with the store masked by row and column)
-  const bool pack2 = (EXACT || (p.m & 1) == 0) && !out_f32 && ((p.ldc & 1) == 0) && ((((unsigned long long)(size_t)q.c) & 3ull) == 0ull);
-  if (ACT == 2) {
-    if (q.mask) {
-      static_for<16>([&](auto rc) {
-        constexpr int r = rc.value;
-        const int j = t.j0 + jl_of(r, t.h);
-        const bool ok = EXACT || (t.ivalid && j < p.n);
-        const unsigned long long pos = __ballot(ok && !(acc[r] <= 0.0f));
-        const unsigned long long val = __ballot(ok);
-        if ((lane & 7) == 0 && ok) {
-          GM unsigned char* byte = q.mask + t.i / 8 + (long long)j * (mask_ld / 8);
-          const unsigned char vm = (unsigned char)((val >> lane) & 0xffu), nb = (unsigned char)((pos >> lane) & 0xffu);
-          *byte = EXACT ? nb : (unsigned char)((*byte & ~vm) | (nb & vm));
-        }
-      });
-    }
-  }
-  const bool c_f16 = p.c_type == LIBXSMM_DATATYPE_F16;            // wave-uniform: the 16-bit output is bf16 or IEEE half
-  if (!CF32 && pack2) {
-    const bool odd = (lane & 1) != 0;
-    const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
-    GM unsigned short* base = (GM unsigned short*)q.c + (long long)(t.j0 + 4 * t.h + (odd ? 1 : 0)) * p.ldc + (t.i & ~1);
-    static_for<8>([&](auto gc) {
-      constexpr int g = gc.value, r0 = 2 * g, jr = (r0 & 3) + 8 * (r0 >> 2);
-      const unsigned int w = cvt_pk_16(c_f16, act_fixed<ACT>(acc[r0]), act_fixed<ACT>(acc[r0 + 1]));
-      const unsigned int n = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-      if (EXACT || (t.ivalid && t.j0 + 4 * t.h + (odd ? 1 : 0) + jr < p.n))
-        st_stream<NT>((GM unsigned int*)(base + (long long)jr * p.ldc), (unsigned int)__builtin_amdgcn_perm(n, w, sel));
-    });
-    return;
-  }
-  static_for<16>([&](auto rc) {
-    constexpr int r = rc.value;
-    const int j = t.j0 + jl_of(r, t.h);
-    const bool ok = EXACT || (t.ivalid && j < p.n);
-    const float y = act_fixed<ACT>(acc[r]);
-    if (out_f32) { if (ok) st_stream<NT>((GM float*)q.c + (long long)j * p.ldc + t.i, y); }
-    else if (ok) st_stream<NT>((GM unsigned short*)q.c + (long long)j * p.ldc + t.i, c_f16 ? __builtin_bit_cast(unsigned short, (_Float16)y) : f32_to_bf16_rne(y));
-  });
-}
-// wave-uniform dispatch on the activation
-template <bool EXACT, bool CF32, bool NT = true>
-__device__ __forceinline__ void tile_store(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
-  if (p.act == 0) tile_store_impl<EXACT, CF32, 0, NT>(acc, p, q, t);
-  else if (p.act == 1) tile_store_impl<EXACT, CF32, 1, NT>(acc, p, q, t);
-  else if (p.act == 2) tile_store_impl<EXACT, CF32, 2, NT>(acc, p, q, t);
-  else tile_store_impl<EXACT, CF32, 3, NT>(acc, p, q, t);
-}
-
-// The same store through a descriptor that carries the exact extent of the C block (prepared with BND, see gemm_mfma_bf16_kernel; off by default): one lane offset
-// per tile, every column offset scalar; a column beyond n lies beyond the extent and its store is dropped by the address unit, rows beyond m are masked lanes.
-// Plain results only (no bitmask, no VNNI C): f32, or 16-bit as packed row pairs when m and ldc are even and C starts on a dword, else element-wise.
-template <int ACT>
-__device__ __forceinline__ void tile_store_buf_impl(const f32x16& acc, const GemmArgs& p, const __amdgpu_buffer_rsrc_t& rc, bool c_dword, const TileCtx& t) {
-  if (!t.ivalid) return;
-  const unsigned int ldc = (unsigned int)p.ldc, lane = threadIdx.x & 63u;
-  if (p.c_type == LIBXSMM_DATATYPE_F32) {
-    const unsigned int voff = ((4u * (unsigned int)t.h) * ldc + (unsigned int)t.i) * 4u;
-    static_for<16>([&](auto rc_) { constexpr int r = rc_.value;
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(act_fixed<ACT>(acc[r])), rc, (int)voff, (int)(((unsigned int)t.j0 + (unsigned int)((r & 3) + 8 * (r >> 2))) * ldc * 4u), 0); });
-    return;
-  }
-  const bool c_f16 = p.c_type == LIBXSMM_DATATYPE_F16;
-  if (c_dword && !(p.m & 1) && !(ldc & 1u)) {
-    const bool odd = (lane & 1u) != 0;
-    const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
-    const unsigned int voff = ((4u * (unsigned int)t.h + (odd ? 1u : 0u)) * ldc + ((unsigned int)t.i & ~1u)) * 2u;
-    static_for<8>([&](auto gc) { constexpr int g = gc.value, r0 = 2 * g, jr = (r0 & 3) + 8 * (r0 >> 2);
-      const unsigned int w = cvt_pk_16(c_f16, act_fixed<ACT>(acc[r0]), act_fixed<ACT>(acc[r0 + 1]));
-      const unsigned int n = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-      __builtin_amdgcn_raw_buffer_store_b32((unsigned int)__builtin_amdgcn_perm(n, w, sel), rc, (int)voff, (int)(((unsigned int)t.j0 + (unsigned int)jr) * ldc * 2u), 0); });
-    return;
-  }
-  const unsigned int voff = ((4u * (unsigned int)t.h) * ldc + (unsigned int)t.i) * 2u;
-  static_for<16>([&](auto rc_) { constexpr int r = rc_.value;
-    const float y = act_fixed<ACT>(acc[r]);
-    __builtin_amdgcn_raw_buffer_store_b16(c_f16 ? __builtin_bit_cast(unsigned short, (_Float16)y) : f32_to_bf16_rne(y), rc, (int)voff, (int)(((unsigned int)t.j0 + (unsigned int)((r & 3) + 8 * (r >> 2))) * ldc * 2u), 0); });
-}
-__device__ __forceinline__ void tile_store_buf(const f32x16& acc, const GemmArgs& p, const __amdgpu_buffer_rsrc_t& rc, bool c_dword, const TileCtx& t) {
-  if (p.act == 0) tile_store_buf_impl<0>(acc, p, rc, c_dword, t);
-  else if (p.act == 1) tile_store_buf_impl<1>(acc, p, rc, c_dword, t);
-  else tile_store_buf_impl<3>(acc, p, rc, c_dword, t);
-}
-
-// wave -> (batch element, tile) decomposition shared by the MFMA kernels
-struct WaveJob { unsigned int bidx; int i0, j0; bool active; };
-__device__ __forceinline__ WaveJob wave_job(const GemmArgs& p, int tile_m, int tile_n) {
-  // The wave index is uniform but not provably so to the compiler: readfirstlane moves the whole tile/batch
-  // address computation to the scalar unit.  Index math is 32-bit and division-free in the common case of
-  // one tile per problem (launch_gemm guarantees tiles * nbatch < 2^31).
-  const unsigned int wid = logical_block(p) * (blockDim.x >> 6) + (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned int per_gemm = (unsigned int)(p.tiles_m * p.tiles_n);
-  WaveJob w;
-  w.active = wid < per_gemm * p.nbatch;
-  if (per_gemm == 1) { w.bidx = wid; w.i0 = 0; w.j0 = 0; }
-  else {
-    w.bidx = wid / per_gemm;
-    const unsigned int t = wid - w.bidx * per_gemm;
-    const unsigned int tn = t / (unsigned int)p.tiles_m;
-    w.i0 = (int)(t - tn * (unsigned int)p.tiles_m) * tile_m; w.j0 = (int)tn * tile_n;
-  }
-  return w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -5054,6 +4829,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else launch_f32<2, 2, GM_MASKED>(a, grid, st);
       break;
     case P_BF16_1x1:
+      if (!pl.exact) { int taken = 0; const int e = launch_gemm_wgp16(a, stream, kernel_name, &taken); if (taken) return e; }       // gemm_wgp16_kernels.hip (round 5)
       grid = wave_grid(32, 32);
       if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && bf16_stream_ok(a)) {       // the bf16 streaming kernel on IEEE halves
         if (kernel_name) *kernel_name = "gemm_f16_stream_kernel<1,1>";
@@ -5080,6 +4856,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), grid, dim3(256), 0, st, a);
       break;
     case P_BF16_2x2:
+      if (!pl.exact) { int taken = 0; const int e = launch_gemm_wgp16(a, stream, kernel_name, &taken); if (taken) return e; }       // gemm_wgp16_kernels.hip (round 5)
       grid = wave_grid(64, 64);
       if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && a.m == 64 && a.n == 64 && !a.batch_inner && bf16_wg64_ok(a)) {
         a.map2d_shift = 0;

@@ -1,0 +1,160 @@
+// gemm_wgp16_kernels.hip -- ragged 16-bit (bf16 / f16) GEMMs, ONE PROBLEM PER WORKGROUP with the whole problem staged in LDS (round 5).
+//
+// What was wrong with the wave-per-tile kernel on shapes like 40^3 and 72^3 (gemm_mfma_bf16_kernel<2,2>: 0.49 / 0.35 of the HBM roofline, 0.57 / 0.43 in its bounded
+// form): a wave walks its K chunks one after the other -- request a 32-deep panel, wait for it, multiply, request the next -- so a 72^3 problem is three memory
+// round trips per wave with nothing in flight in between, the four waves of a problem fetch overlapping panels, and they cover 128 x 128 with 64 x 64 tiles.
+// The counters said the same: traffic 1.02-1.19 x algorithmic, MFMA work 4 x the problem's (profiles/r04_pmc_traffic.json, r04_mfma_busy.json) -- latency, not bytes.
+//
+// Here the operand BLOCKS of a problem -- A as [k/2][lda] dwords (VNNI-2 pairs), B as [n][ldb] halves: both contiguous in memory -- are brought into LDS as what
+// they are: rows of A and columns of B cut into 16-byte pieces, one piece per lane and request (global -> LDS DMA, no registers, every request a full 16 bytes of a
+// row that is read exactly once), ALL of them issued before the first wait.  One round trip per problem and batch-reduce block.  The four waves then deal the
+// problem's ceil(m/32) x ceil(n/32) tiles of 32 x 32 among themselves (72^3: nine tiles = 96 x 96 covered instead of 128 x 128) and multiply out of LDS:
+//   A fragment of row i, k pairs kp..kp+3:   four ds_read_b32 at (kp + e) * RP + i        (lanes along i: conflict free)
+//   B fragment of column j, 8 consecutive k: one ds_read_b128 at j * CP + 16 * piece      (CP = 16 bytes x pieces per column; odd piece counts are conflict free)
+// Overlap comes from the workgroups a CU holds at once (72^3: 20 KiB of LDS each, five to seven resident; 40^3: 6.4 KiB, eight): while one multiplies the others'
+// requests are in flight.  Results: tile_init / tile_store of gemm_tile.hpp -- any beta, fused column bias / ReLU (+ bitmask) / sigmoid -- in the matrix core's
+// summation order (the same chunking as the wave-per-tile kernel: k in steps of 16, batch-reduce blocks in order).
+//
+// Taken by launch_gemm for 1-D batches (strided or pointer lists are not needed: strided only) when every piece request lies inside its operand block:
+// m % 4 == 0, k % 8 == 0, lda % 4 == 0, ldb % 8 == 0, 16-byte aligned blocks, 2 <= tiles <= 12, LDS image <= 64 KiB.  Everything else keeps the wave-per-tile kernel.
+// [ref: the loop being computed is src/generator_gemm_reference_impl.c:2127-2170 (bf16 -> f32), :2367-2419 (bf16 -> bf16), :2025-2124 (f16)]
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "internal.hpp"
+#include "gemm_device.hpp"
+#include "gemm_tile.hpp"
+
+#pragma clang fp contract(off)
+
+namespace xamd {
+
+struct Wgp16Geo {
+  unsigned int rp;          // dwords per k-pair row of the A image = 4 x pieces per row
+  unsigned int ppr;         // 16-byte pieces per k-pair row of A
+  unsigned int ppc;         // 16-byte pieces per column of B
+  unsigned int a_pieces, b_pieces;      // total pieces of one block
+  unsigned int a_img;       // bytes of the A image (whole 1 KiB request slots)
+};
+
+template <bool F16, int TPW>
+__global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g) {
+  extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int bidx = blockIdx.x;
+  const BatchPtrs q = batch_ptrs(p, bidx);
+  char* const img_a = lds_wgp;
+  char* const img_b = lds_wgp + g.a_img;
+  const unsigned int ntiles = (unsigned int)(p.tiles_m * p.tiles_n);
+  f32x16 acc[TPW];
+  TileCtx tc[TPW];
+  static_for<TPW>([&](auto tt) {
+    constexpr int t = tt.value;
+    const unsigned int id = w + 4u * (unsigned int)t;
+    const unsigned int tj = id / (unsigned int)p.tiles_m, ti = id - tj * (unsigned int)p.tiles_m;
+    tc[t].i = (int)(32u * ti + li); tc[t].j0 = (int)(32u * tj); tc[t].h = (int)h; tc[t].ivalid = tc[t].i < p.m;
+    if (id < ntiles) {
+      if (F16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+      } else tile_init<false, false>(acc[t], p, q, tc[t]);
+    }
+  });
+  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
+  const unsigned int kchunks = ((unsigned int)p.k + 31u) >> 5, kgroups = (unsigned int)p.k >> 3;      // 8-deep k groups (k % 8 == 0)
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    if (r != 0) wg_barrier();                                   // everybody has read the previous block's images
+    // ---- all requests of the block, dealt round-robin to the four waves: request x fills the 1 KiB slot x of its image, lane = piece 64 x + lane
+    for (unsigned int x = w; x * 64u < g.a_pieces; x += 4u) {
+      const unsigned int P = 64u * x + lane;
+      if (P < g.a_pieces) {
+        const unsigned int kp = P / g.ppr, pc = P - kp * g.ppr;
+        __builtin_amdgcn_global_load_lds((GM const void*)(ar + ((unsigned long long)kp * lda + 4u * pc) * 4ull), (lds_vptr)(img_a + 1024u * x), 16, 0, 0);
+      }
+    }
+    for (unsigned int x = w; x * 64u < g.b_pieces; x += 4u) {
+      const unsigned int P = 64u * x + lane;
+      if (P < g.b_pieces) {
+        const unsigned int col = P / g.ppc, pc = P - col * g.ppc;
+        __builtin_amdgcn_global_load_lds((GM const void*)(br + ((unsigned long long)col * ldb + 8u * pc) * 2ull), (lds_vptr)(img_b + 1024u * x), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    // ---- multiply out of LDS: my tiles, K in chunks of 32 (two MFMA steps of 16)
+    static_for<TPW>([&](auto tt) {
+      constexpr int t = tt.value;
+      const unsigned int id = w + 4u * (unsigned int)t;
+      if (id < ntiles) {
+        const unsigned int tj = id / (unsigned int)p.tiles_m, ti = id - tj * (unsigned int)p.tiles_m;
+        const unsigned int* const arow = (const unsigned int*)img_a + 32u * ti + li;              // + kp * rp
+        const char* const bcol = img_b + (size_t)(32u * tj + li) * (g.ppc * 16u);                  // + 16 * piece
+        for (unsigned int kc = 0; kc < kchunks; ++kc) {
+          u32x4 af[2], bfr[2];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const unsigned int kg = 4u * kc + 2u * (unsigned int)s + h;           // this lane's 8-deep k group of the step
+            const bool ok = kg < kgroups;                                         // (k % 8 == 0: a group is whole or absent)
+            const unsigned int kgc = ok ? kg : 0u;                                // absent groups read group 0 (inside the image) and are zeroed
+#pragma unroll
+            for (int e = 0; e < 4; ++e) af[s][e] = arow[(4u * kgc + (unsigned int)e) * g.rp];
+            bfr[s] = *(const u32x4*)(bcol + 16u * kgc);
+            if (!ok) { af[s] = u32x4{0u, 0u, 0u, 0u}; bfr[s] = u32x4{0u, 0u, 0u, 0u}; }
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s) acc[t] = mfma_16bit<F16>(bfr[s], af[s], acc[t]);
+        }
+      }
+    });
+  }
+  static_for<TPW>([&](auto tt) {
+    constexpr int t = tt.value;
+    if (w + 4u * (unsigned int)t < ntiles) tile_store<false, false, false>(acc[t], p, q, tc[t]);
+  });
+}
+
+// rows / columns beyond m / n of a tile read LDS beyond their operand's rows (another k pair's row, the other image, or nothing): they feed results nobody stores,
+// and an LDS read beyond the allocation returns zero by definition -- no fault is possible on that side.
+static bool wgp16_shape_ok(const GemmArgs& a, Wgp16Geo& g, unsigned int& lds_bytes, int& tpw) {
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '0'; }();
+  if (off) return false;
+  if (a.batch_inner || a.list_a || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c) return false;          // 1-D strided batches, plain / STRIDE batch-reduce
+  if (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) return false;
+  if (!(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
+  if ((a.m & 3) || (a.k & 7) || (a.lda & 3) || (a.ldb & 7) || a.k <= 0) return false;
+  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
+    (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0);
+  if (bits & 15ull) return false;
+  const int tiles = ((a.m + 31) / 32) * ((a.n + 31) / 32);
+  if (tiles < 2 || tiles > 12) return false;
+  g.ppr = (unsigned int)a.m / 4u; g.rp = (unsigned int)a.m;
+  g.ppc = (unsigned int)a.k / 8u;
+  g.a_pieces = ((unsigned int)a.k / 2u) * g.ppr; g.b_pieces = (unsigned int)a.n * g.ppc;
+  g.a_img = ((g.a_pieces + 63u) / 64u) * 1024u;
+  lds_bytes = g.a_img + ((g.b_pieces + 63u) / 64u) * 1024u;
+  if (lds_bytes > 64u * 1024u) return false;
+  tpw = (tiles + 3) / 4;
+  return true;
+}
+
+int launch_gemm_wgp16(const GemmArgs& a_in, void* stream, const char** kernel_name, int* taken) {
+  *taken = 0;
+  Wgp16Geo g; unsigned int lds_bytes = 0; int tpw = 0;
+  const bool f16 = a_in.a_type == LIBXSMM_DATATYPE_F16;
+  if (f16 && (!(a_in.flags & LIBXSMM_GEMM_FLAG_BETA_0) || a_in.colbias || a_in.act)) return 0;       // halves: beta * C is added AFTER the sum [ref: gemm ref :2025-2124] -- the wave-per-tile kernel's own epilogue
+  if (!wgp16_shape_ok(a_in, g, lds_bytes, tpw)) return 0;
+  GemmArgs a = a_in;
+  a.tiles_m = (a.m + 31) / 32; a.tiles_n = (a.n + 31) / 32; a.map2d_shift = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(a.nbatch), block(256);
+  *taken = 1;
+  if (kernel_name) *kernel_name = f16 ? "gemm_f16_wgp_kernel" : "gemm_bf16_wgp_kernel";
+#define WGP_(F_, T_) hipLaunchKernelGGL((gemm_wgp16_kernel<F_, T_>), grid, block, lds_bytes, st, a, g)
+  if (f16) { if (tpw == 1) WGP_(true, 1); else if (tpw == 2) WGP_(true, 2); else WGP_(true, 3); }
+  else { if (tpw == 1) WGP_(false, 1); else if (tpw == 2) WGP_(false, 2); else WGP_(false, 3); }
+#undef WGP_
+  return (int)hipGetLastError();
+}
+
+}  // namespace xamd
