@@ -4829,7 +4829,8 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else launch_f32<2, 2, GM_MASKED>(a, grid, st);
       break;
     case P_BF16_1x1:
-      if (!pl.exact) { int taken = 0; const int e = launch_gemm_wgp16(a, stream, kernel_name, &taken); if (taken) return e; }       // gemm_wgp16_kernels.hip (round 5)
+      // gemm_wgp16_kernels.hip (round 5): ragged shapes, and whole 32-tiles that are several tiles per problem (96^3 as nine waves that each fetched their own panels: 0.39)
+      { int taken = 0; const int e = launch_gemm_wgp16(a, stream, kernel_name, &taken); if (taken) return e; }
       grid = wave_grid(32, 32);
       if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && bf16_stream_ok(a)) {       // the bf16 streaming kernel on IEEE halves
         if (kernel_name) *kernel_name = "gemm_f16_stream_kernel<1,1>";

@@ -44,10 +44,12 @@ void* guard_alloc(size_t nbytes, int front) {
   return r->user;
 }
 
-/* guard_free QUARANTINES by default (guard_set_reuse(1) really unmaps -- tools/guard_probe.py measures what that does): a block that is unmapped and released hands its
- * physical pages -- and usually its virtual range -- to the next guard_alloc of the process, and on this stack the next kernel can then see the PREVIOUS owner's
- * bytes instead of what a host-to-device copy just wrote there (observed in round 5: the second beta = 1 test of a guarded run read the first test's C).  Parity
- * tests need memory that holds what was uploaded, so freed blocks stay mapped until the process exits (a granule each: a few GB over a whole guarded run). */
+/* guard_free QUARANTINES by default (guard_set_reuse(1) really unmaps): in the first guarded run of round 5, where freed blocks were unmapped and released at once, the
+ * SECOND and later tests of a process read wrong C values (beta = 1 cases: what the kernel saw of a freshly uploaded C was not what libxsmm_hip_memcpy_h2d had
+ * written) although nothing faulted; with freed blocks kept mapped until the process exits every guarded parity test passes.  tools/guard_probe.py (copy kernel, 20
+ * alloc / upload / free rounds with reuse on) did NOT reproduce it -- profiles/r05_guard_probe.json -- so the cause stays open (candidates: a stale translation or
+ * cache line of a virtual range that is unmapped and re-mapped to other physical pages within microseconds); what matters for the parity tests is that the memory
+ * holds what was uploaded, and quarantined blocks do (a 4 KiB granule each on this stack). */
 static int g_reuse = 0;
 void guard_set_reuse(int on) { g_reuse = on; }
 void guard_free(void* user) {

@@ -171,6 +171,9 @@ SHAPES_F16 = [
 
 
 RAGGED_16BIT = [
+    dict(m=72, n=40, k=48, beta=1, br_type=capi.BR_STRIDE, br_count=4, c_type=DT.F32),      # wgp kernel: six tiles (two per wave), batch-reduce stages, f32 C with beta = 1
+    dict(m=96, n=96, k=96),                                                                  # whole 32-tiles, nine per problem: three per wave
+    dict(m=44, n=100, k=16, ldc=48),                                                         # eight tiles, one short chunk
     dict(m=40, n=40, k=40),                                                   # B on dwords: its panel through LDS (a dword per lane, any ldb)
     dict(m=24, n=24, k=24, beta=1),
     dict(m=72, n=72, k=72, br_type=capi.BR_STRIDE, br_count=3),               # nine waves per problem, k tail of 8, strided batch-reduce
@@ -192,8 +195,15 @@ def test_ragged_16bit_shapes_on_the_masked_matrix_core_kernel(kw, dt):
     if dt == DT.F16 and kw.get("beta"):
         kw.pop("beta")                                                        # (halves with beta = 1: covered by SHAPES_F16; same kernel, its own epilogue)
     kw.setdefault("c_type", dt)
-    name = _check(GemmCase(a_type=dt, flags=F.VNNI_A, batch=37, seed=77, **kw), expect_kernel="gemm_mfma_bf16_kernel" if dt == DT.BF16 else "gemm_mfma_f16_kernel")
-    assert "mfma" in name
+    name = _check(GemmCase(a_type=dt, flags=F.VNNI_A, batch=37, seed=77, **kw))
+    # round 5: shapes whose every 16-byte piece lies inside its operand block run as one problem per workgroup out of LDS (gemm_wgp16_kernels.hip), the rest on the wave-per-tile kernel
+    whole_pieces = kw["m"] % 4 == 0 and kw["k"] % 8 == 0 and kw.get("lda", kw["m"]) % 4 == 0 and kw.get("ldb", kw["k"]) % 8 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
+    tiles = ((kw["m"] + 31) // 32) * ((kw["n"] + 31) // 32)
+    f16_own_epilogue = dt == DT.F16 and kw.get("beta")
+    if whole_pieces and 2 <= tiles <= 12 and not f16_own_epilogue:
+        assert ("gemm_bf16_wgp_kernel" if dt == DT.BF16 else "gemm_f16_wgp_kernel") in name, name
+    else:
+        assert ("gemm_mfma_bf16_kernel" if dt == DT.BF16 else "gemm_mfma_f16_kernel") in name, name
 
 
 @pytest.mark.parametrize("kw", SHAPES_F16, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))

@@ -1,0 +1,80 @@
+"""A host model of the data movement of the one-problem-per-workgroup kernel for ragged 16-bit shapes (libxsmm_amd/csrc/gemm_wgp16_kernels.hip), no GPU.
+
+The kernel brings a problem's two operand blocks into LDS as 16-byte pieces -- piece P of A = k-pair row P / ppr, rows 4 (P % ppr) .. + 3; piece P of B = column P / ppc,
+k 8 (P % ppc) .. + 7 -- with the lane-linear destination of a global -> LDS request (request x fills bytes 1024 x .. of its image, lane l the 16 bytes at 16 l), and
+reads MFMA operands back as `arow[(4 kg + e) * rp]` (A: four k pairs of one row) and `bcol + 16 kg` (B: eight k of one column), kg = the lane's 8-deep k group.
+This model restates exactly that index arithmetic on a byte image whose untouched bytes are NaN patterns, multiplies the fragments the way v_mfma_f32_32x32x16 does
+(lane & 31 = row / column, lane >> 5 = k half) and compares with the plain product: it pins the layout algebra (piece <-> address, image pitch, the zeroing of absent k
+groups, which tiles a wave owns), not the silicon -- the device parity tests are tests/test_gemm_gpu.py::test_ragged_16bit_shapes_*."""
+import numpy as np
+import pytest
+
+
+def _model(m, n, k, lda, ldb, seed=0):
+    assert m % 4 == 0 and k % 8 == 0 and lda % 4 == 0 and ldb % 8 == 0
+    rng = np.random.default_rng(seed)
+    A = rng.integers(-4, 5, (m, k)).astype(np.float64); B = rng.integers(-4, 5, (k, n)).astype(np.float64)
+    # memory images: A VNNI-2 [k/2][lda][2] halves, B [n][ldb] halves; padding = NaN (must never reach a stored result)
+    a_mem = np.full((k // 2) * lda * 2, np.nan); b_mem = np.full(n * ldb, np.nan)
+    for kp in range(k // 2):
+        for i in range(m):
+            a_mem[(kp * lda + i) * 2 + 0] = A[i, 2 * kp]; a_mem[(kp * lda + i) * 2 + 1] = A[i, 2 * kp + 1]
+    for j in range(n):
+        b_mem[j * ldb:j * ldb + k] = B[:, j]
+    ppr, rp, ppc = m // 4, m, k // 8
+    a_pieces, b_pieces = (k // 2) * ppr, n * ppc
+    a_img_halves = ((a_pieces + 63) // 64) * 512; b_img_halves = ((b_pieces + 63) // 64) * 512          # 1 KiB request slots, in halves
+    img_a = np.full(a_img_halves, np.nan); img_b = np.full(b_img_halves, np.nan)
+    for P in range(a_pieces):                                     # request x = P // 64, lane = P % 64: destination = 1024 x + 16 lane = 16 P bytes = 8 P halves
+        kp, pc = divmod(P, ppr)
+        src = (kp * lda + 4 * pc) * 2                             # halves: dword (kp * lda + 4 pc)
+        img_a[8 * P:8 * P + 8] = a_mem[src:src + 8]
+    for P in range(b_pieces):
+        col, pc = divmod(P, ppc)
+        src = col * ldb + 8 * pc
+        img_b[8 * P:8 * P + 8] = b_mem[src:src + 8]
+    tiles_m, tiles_n = (m + 31) // 32, (n + 31) // 32
+    ntiles = tiles_m * tiles_n
+    kchunks, kgroups = (k + 31) // 32, k // 8
+    C = np.full((m, n), np.nan)
+    owners = {}
+    for w in range(4):
+        for t in range((ntiles + 3) // 4):
+            tid = w + 4 * t
+            if tid >= ntiles:
+                continue
+            owners[tid] = owners.get(tid, 0) + 1
+            tj, ti = divmod(tid, tiles_m)
+            acc = np.zeros((32, 32))
+            for kc in range(kchunks):
+                for s in range(2):
+                    for h in range(2):
+                        kg = 4 * kc + 2 * s + h
+                        ok = kg < kgroups
+                        kgc = kg if ok else 0
+                        a_frag = np.zeros((32, 8)); b_frag = np.zeros((32, 8))
+                        for li in range(32):
+                            for e in range(4):                    # dword index arow[(4 kgc + e) * rp], arow = img_a dwords + 32 ti + li
+                                dw = (4 * kgc + e) * rp + 32 * ti + li
+                                pair = img_a[2 * dw:2 * dw + 2] if 2 * dw + 2 <= img_a.size else np.array([0.0, 0.0])      # beyond the allocation: zeros by definition
+                                a_frag[li, 2 * e:2 * e + 2] = pair
+                            off = (32 * tj + li) * (ppc * 8) + 8 * kgc                        # halves: bcol + 16 kgc bytes
+                            b_frag[li] = img_b[off:off + 8] if off + 8 <= img_b.size else 0.0
+                        if not ok:
+                            a_frag[:] = 0.0; b_frag[:] = 0.0
+                        with np.errstate(invalid="ignore"):
+                            acc += a_frag @ b_frag.T              # rows i of the tile x columns j of the tile, over this lane half's eight k
+            for li in range(32):
+                for lj in range(32):
+                    i, j = 32 * ti + li, 32 * tj + lj
+                    if i < m and j < n:
+                        C[i, j] = acc[li, lj]
+    assert sorted(owners) == list(range(ntiles)) and set(owners.values()) == {1}              # every tile has exactly one wave
+    return C, A @ B
+
+
+@pytest.mark.parametrize("m,n,k,lda,ldb", [(40, 40, 40, 40, 40), (72, 72, 72, 72, 72), (24, 40, 8, 24, 8), (96, 96, 96, 96, 96), (44, 100, 16, 48, 24), (72, 40, 48, 76, 56), (128, 96, 32, 128, 32)])
+def test_pieces_land_where_the_fragments_read_them(m, n, k, lda, ldb):
+    got, ref = _model(m, n, k, lda, ldb)
+    assert not np.isnan(got).any(), "padding or untouched LDS reached a stored result"
+    assert np.array_equal(got, ref)
