@@ -117,6 +117,7 @@ template <typename T> __device__ __forceinline__ T add_rn(T a, T b) { return a +
 
 // block = (64, 4): x walks i (so a wave is 64 consecutive rows of one column, which makes the
 // ReLU bitmask a ballot), y walks j.
+#if !defined(XAMD_GEMM_SHARD)      // a plain (non-template) kernel: emitted by the main translation unit only
 __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
   const int tiles_i = (p.m + 63) / 64, tiles_j = (p.n + 3) / 4;
   const long long per_gemm = (long long)tiles_i * tiles_j;
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
   }
   generic_epilogue(p, q, i, j, valid, acc);
 }
+#endif
 
 // One long batch-reduce chain split over the chip: `nsplit` partial C tiles (f32, [split][n][m]) were produced by the
 // tile kernels; this pass adds them up in split order on top of beta*C (+ bias) and applies the epilogue of the
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
 // order only]
 // block = (64, 16): x walks i, the 16 y-slices share the splits of one column j (fixed, deterministic order: slice y
 // sums splits y, y+16, ... with four independent chains; the slices are then added in y order through LDS)
+#if !defined(XAMD_GEMM_SHARD)      // a plain (non-template) kernel: emitted by the main translation unit only
 __global__ __launch_bounds__(1024) void brsplit_reduce_kernel(GemmArgs p, const float* partial, int nsplit) {
   __shared__ float part[16][64];
   const int tiles_i = (p.m + 63) / 64;
@@ -455,6 +458,7 @@ __global__ __launch_bounds__(1024) void brsplit_reduce_kernel(GemmArgs p, const 
   }
   generic_epilogue(p, q, i, j, valid, acc);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // MFMA building blocks.  "X" operand: free index contiguous in memory, element (f,k) at base[f + k*ld]
@@ -833,6 +837,7 @@ __global__ __launch_bounds__(256) void gemm_f32_stream_kernel_lean(LeanF32Args p
 // quarter of the waves the chip wants, 4 MiB of partial sums written and read back); here br = 4096 is 4096 waves and 512 partial tiles.
 // f32, NN, whole 32 x 32 tiles, k % 32 == 0.  partial: [slice][n][m] f32.
 // ------------------------------------------------------------------------------------------------
+#if !defined(XAMD_GEMM_SHARD)      // a plain (non-template) kernel: emitted by the main translation unit only
 __global__ __launch_bounds__(512) void gemm_f32_brchain_kernel(GemmArgs p, float* partial, unsigned int chunk, unsigned int nslices) {
   __shared__ __attribute__((aligned(16))) float lds_all[8][2048];
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -891,6 +896,7 @@ __global__ __launch_bounds__(512) void gemm_f32_brchain_kernel(GemmArgs p, float
     tile[(unsigned long long)j * (unsigned int)p.m + i0 + li] = sum;
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // f32 streaming kernel, LDS-DMA form (MT x NT tiles of 32x32 per wave).  Same arithmetic as gemm_f32_stream_kernel;
@@ -1086,6 +1092,7 @@ __global__ __launch_bounds__(256) void gemm_f32_blocked_kernel(GemmArgs p) {
 //   B image [32 j][8 x 16 B] swizzled: a lane's 16-byte piece belongs to sub-step (source chunk) >> 2 -> selected per lane.
 // One tile per wave (gemm_p16_kernel / t16) reaches 37 % of the f32 matrix peak on this regime; this form is the one that is matrix-bound.
 // ------------------------------------------------------------------------------------------------
+#if !defined(XAMD_GEMM_SHARD)      // a plain (non-template) kernel: emitted by the main translation unit only
 __global__ __launch_bounds__(256) void gemm_f32_blocked16_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds_all[2][8][1024];
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1169,6 +1176,7 @@ __global__ __launch_bounds__(256) void gemm_f32_blocked16_kernel(GemmArgs p) {
     });
   });
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // f32 64 x 64 x K problems, one problem per WORKGROUP (streaming batches).  gemm_f32_dma_kernel<2,2> gives a wave the whole 64 x 64 tile:
@@ -1235,6 +1243,7 @@ __global__ __launch_bounds__(256) void gemm_f32_wg64_kernel(GemmArgs p) {
 // LDS images with shape-aware indexing (out-of-range operands read as zero).  Natural k order: bitwise the k-ordered
 // fmaf chain like the other f32 MFMA kernels.
 // ------------------------------------------------------------------------------------------------
+#if !defined(XAMD_GEMM_SHARD)      // a plain (non-template) kernel: emitted by the main translation unit only
 __global__ __launch_bounds__(256) void gemm_f32_blob_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds_all[4][2048];
   const WaveJob job = wave_job(p, 32, 32);
@@ -1270,6 +1279,7 @@ __global__ __launch_bounds__(256) void gemm_f32_blob_kernel(GemmArgs p) {
   }
   tile_store<false, true>(acc, p, q, tc);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // f32 "ragged" kernel: the odd small shapes LIBXSMM exists for (23^3 is BASELINE config #1; 13^3, 40^3, 50^3, 72^3 ...), NN, plain
@@ -1525,6 +1535,7 @@ __global__ __launch_bounds__(64 * W, ragged_waves_per_simd(W, NP, R2, BETA1, SIN
 // lane = (x = lane&15, g = lane>>4).  Transposed product: operand 1 = B(k, j=x), operand 2 = A(i=x, k);
 // result lane x = i, register q -> j = 4g + q.  k is consumed as 4g + s (not natural order).
 // ------------------------------------------------------------------------------------------------
+#if !defined(XAMD_GEMM_SHARD)      // a plain (non-template) kernel: emitted by the main translation unit only
 __global__ __launch_bounds__(256) void gemm_mfma_f32_t16_kernel(GemmArgs p) {
   const WaveJob job = wave_job(p, 16, 16);
   if (!job.active) return;
@@ -1566,6 +1577,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_t16_kernel(GemmArgs p) {
     C[(long long)j * p.ldc + i] = act_apply(p.act, xv);
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // 16 x 16 problems (m = n = 16, k a multiple of 16), plain epilogue, PPW problems per wave.  A 16^3 problem is 1.5 KiB (bf16) or 3 KiB
@@ -3600,6 +3612,16 @@ __global__ __launch_bounds__(256) void gemm_mx_stream_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 // host-side selection
 // ------------------------------------------------------------------------------------------------
+#if defined(XAMD_GEMM_SHARD)
+// A shard translation unit (Makefile: gemm_shard_<i>.o, tools/gen_gemm_shards.py): the kernel definitions above + the explicit instantiations of this shard, nothing else.
+#include XAMD_GEMM_SHARD_INC
+}  // namespace xamd
+#else
+// The main translation unit generates no code for the kernel templates above: every instantiation launch_gemm uses is declared extern here and defined in a shard.
+#if !defined(XAMD_GEMM_MONO)
+#include "gemm_shards/extern.inc"
+#endif
+
 bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
   libxsmm_gemm_descriptor d = d_in;
   if (d.flags & LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) {
@@ -5059,3 +5081,4 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
 }
 
 }  // namespace xamd
+#endif  // XAMD_GEMM_SHARD

@@ -108,119 +108,15 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
       }
     });
   }
+  // (round 5, measured and not adopted -- profiles/r05_wgp16_c_image_not_adopted.jsonl: the results through an LDS image of C and out as whole 16-byte pieces.  The timing
+  //  ablation had put the element stores at 41 of 147 us on 40^3, but the image costs LDS -- 96^3: 54 instead of 36 KiB per workgroup -- and a second barrier: 40^3 0.54 ->
+  //  0.51, 72^3 0.53 -> 0.47, 96^3 0.65 -> 0.40.  Likewise a wave per problem (no barrier at all, a quarter of the workgroups: 40^3 0.56 -> 0.48, 48^3 0.67 -> 0.36,
+  //  r05_wave_per_problem_not_adopted.jsonl) and persistent workgroups with two images in flight (0.56 -> 0.46, r05_wgp16_forms.jsonl): what these shapes need is many
+  //  short workgroups in different phases, which is exactly what the hardware's own workgroup scheduler provides.)
   static_for<TPW>([&](auto tt) {
     constexpr int t = tt.value;
     if (w + 4u * (unsigned int)t < ntiles) tile_store<false, false, false>(acc[t], p, q, tc[t]);
   });
-}
-
-// PERSISTENT form (the default): the grid is what the chip holds at once (CUs x workgroups per CU), a workgroup walks problems g, g + G, g + 2G, ... and the
-// operand blocks go through TWO LDS images: the requests of stage u + 1 (the next batch-reduce block, or the next problem) are issued BEFORE stage u is multiplied,
-// so every workgroup has a block in flight while it computes and stores -- twice the bytes in flight per CU of the one-shot form -- and nothing pays a workgroup
-// launch, an argument load or a first address computation per problem (40^3: 65 536 four-wave workgroups of ~4 us each were also a launch-rate problem).
-// One workgroup barrier per stage: behind it every wave's requests of stage u have landed (each waited for its own) and every wave has finished reading the other
-// image (stage u - 1), which is the one the new requests overwrite.
-template <bool F16, int TPW>
-__global__ __launch_bounds__(256) void gemm_wgp16_persist_kernel(GemmArgs p, Wgp16Geo g, unsigned int img_bytes) {
-  extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
-  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
-  const unsigned int ntiles = (unsigned int)(p.tiles_m * p.tiles_n);
-  const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
-  const unsigned int kchunks = ((unsigned int)p.k + 31u) >> 5, kgroups = (unsigned int)p.k >> 3;
-  const unsigned int first = blockIdx.x, stride = gridDim.x;
-  if (first >= p.nbatch) return;
-  const unsigned int mine = (p.nbatch - first + stride - 1u) / stride;               // problems of this workgroup
-  const unsigned long long brc = p.br_count;
-  auto issue = [&](unsigned int prob, unsigned long long r, unsigned int slot) {
-    const BatchPtrs q = batch_ptrs(p, prob);
-    gcptr ar, br; br_base(p, q, r, ar, br);
-    char* const img_a = lds_wgp + slot * img_bytes;
-    char* const img_b = img_a + g.a_img;
-    for (unsigned int x = w; x * 64u < g.a_pieces; x += 4u) {
-      const unsigned int P = 64u * x + lane;
-      if (P < g.a_pieces) {
-        const unsigned int kp = P / g.ppr, pc = P - kp * g.ppr;
-        __builtin_amdgcn_global_load_lds((GM const void*)(ar + ((unsigned long long)kp * lda + 4u * pc) * 4ull), (lds_vptr)(img_a + 1024u * x), 16, 0, 0);
-      }
-    }
-    for (unsigned int x = w; x * 64u < g.b_pieces; x += 4u) {
-      const unsigned int P = 64u * x + lane;
-      if (P < g.b_pieces) {
-        const unsigned int col = P / g.ppc, pc = P - col * g.ppc;
-        __builtin_amdgcn_global_load_lds((GM const void*)(br + ((unsigned long long)col * ldb + 8u * pc) * 2ull), (lds_vptr)(img_b + 1024u * x), 16, 0, 0);
-      }
-    }
-  };
-  f32x16 acc[TPW];
-  TileCtx tc[TPW];
-  static_for<TPW>([&](auto tt) {
-    constexpr int t = tt.value;
-    const unsigned int id = w + 4u * (unsigned int)t;
-    const unsigned int tj = id / (unsigned int)p.tiles_m, ti = id - tj * (unsigned int)p.tiles_m;
-    tc[t].i = (int)(32u * ti + li); tc[t].j0 = (int)(32u * tj); tc[t].h = (int)h; tc[t].ivalid = tc[t].i < p.m;
-  });
-  if (brc == 0) {          // an empty chain: C = beta C (+ bias, activation) for my problems
-    for (unsigned int n = 0; n < mine; ++n) {
-      const BatchPtrs q = batch_ptrs(p, first + n * stride);
-      static_for<TPW>([&](auto tt) { constexpr int t = tt.value;
-        if (w + 4u * (unsigned int)t < ntiles) { if (F16) { for (int r2 = 0; r2 < 16; ++r2) acc[t][r2] = 0.0f; } else tile_init<false, false>(acc[t], p, q, tc[t]); tile_store<false, false, false>(acc[t], p, q, tc[t]); } });
-    }
-    return;
-  }
-  issue(first, 0, 0u);
-  unsigned int prob = first, done = 0, slot = 0;
-  unsigned long long r = 0;
-  for (;;) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my requests of this stage have landed (and my stores of the previous problem have left)
-    wg_barrier();
-    // the next stage: the next batch-reduce block of this problem, or block 0 of my next problem
-    const bool last_r = r + 1 == brc;
-    const bool more = !last_r || done + 1u < mine;
-    if (more) issue(last_r ? prob + stride : prob, last_r ? 0ull : r + 1, slot ^ 1u);
-    const BatchPtrs q = batch_ptrs(p, prob);
-    if (r == 0) {
-      static_for<TPW>([&](auto tt) { constexpr int t = tt.value;
-        if (w + 4u * (unsigned int)t < ntiles) {
-          if (F16) {
-#pragma unroll
-            for (int r2 = 0; r2 < 16; ++r2) acc[t][r2] = 0.0f;
-          } else tile_init<false, false>(acc[t], p, q, tc[t]);
-        } });
-    }
-    const char* const img_a = lds_wgp + slot * img_bytes;
-    const char* const img_b = img_a + g.a_img;
-    static_for<TPW>([&](auto tt) {
-      constexpr int t = tt.value;
-      const unsigned int id = w + 4u * (unsigned int)t;
-      if (id < ntiles) {
-        const unsigned int tj = id / (unsigned int)p.tiles_m, ti = id - tj * (unsigned int)p.tiles_m;
-        const unsigned int* const arow = (const unsigned int*)img_a + 32u * ti + li;
-        const char* const bcol = img_b + (size_t)(32u * tj + li) * (g.ppc * 16u);
-        for (unsigned int kc = 0; kc < kchunks; ++kc) {
-          u32x4 af[2], bfr[2];
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const unsigned int kg = 4u * kc + 2u * (unsigned int)s + h;
-            const bool ok = kg < kgroups;
-            const unsigned int kgc = ok ? kg : 0u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) af[s][e] = arow[(4u * kgc + (unsigned int)e) * g.rp];
-            bfr[s] = *(const u32x4*)(bcol + 16u * kgc);
-            if (!ok) { af[s] = u32x4{0u, 0u, 0u, 0u}; bfr[s] = u32x4{0u, 0u, 0u, 0u}; }
-          }
-#pragma unroll
-          for (int s = 0; s < 2; ++s) acc[t] = mfma_16bit<F16>(bfr[s], af[s], acc[t]);
-        }
-      }
-    });
-    if (last_r) {
-      static_for<TPW>([&](auto tt) { constexpr int t = tt.value; if (w + 4u * (unsigned int)t < ntiles) tile_store<false, false, false>(acc[t], p, q, tc[t]); });
-      if (++done == mine) break;
-      prob += stride; r = 0;
-    } else ++r;
-    slot ^= 1u;
-  }
 }
 
 // rows / columns beyond m / n of a tile read LDS beyond their operand's rows (another k pair's row, the other image, or nothing): they feed results nobody stores,
@@ -258,22 +154,6 @@ int launch_gemm_wgp16(const GemmArgs& a_in, void* stream, const char** kernel_na
   hipStream_t st = (hipStream_t)stream;
   const dim3 block(256);
   *taken = 1;
-  // persistent form: as many workgroups as the chip holds at once -- registers allow 8 / 5 / 4 four-wave workgroups per CU for 1 / 2 / 3 tiles per wave
-  // (profiles/r05_kernel_resources.txt), LDS allows 160 KiB / (two images); LIBXSMM_HIP_WGP16=1 keeps the one-shot form (measurement switch)
-  static const bool oneshot = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '1'; }();
-  static const int cus = []() { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
-  const unsigned int by_regs = tpw == 1 ? 8u : (tpw == 2 ? 5u : 4u), by_lds = (160u * 1024u) / (2u * lds_bytes + 256u);
-  const unsigned int per_cu = by_regs < by_lds ? by_regs : by_lds;
-  if (!oneshot && per_cu >= 2u && 2u * lds_bytes <= 64u * 1024u) {
-    const unsigned int resident = (unsigned int)cus * per_cu;
-    const dim3 grid(a.nbatch < resident ? a.nbatch : resident);
-    if (kernel_name) *kernel_name = f16 ? "gemm_f16_wgp_kernel<persistent>" : "gemm_bf16_wgp_kernel<persistent>";
-#define WGPP_(F_, T_) hipLaunchKernelGGL((gemm_wgp16_persist_kernel<F_, T_>), grid, block, 2u * lds_bytes, st, a, g, lds_bytes)
-    if (f16) { if (tpw == 1) WGPP_(true, 1); else if (tpw == 2) WGPP_(true, 2); else WGPP_(true, 3); }
-    else { if (tpw == 1) WGPP_(false, 1); else if (tpw == 2) WGPP_(false, 2); else WGPP_(false, 3); }
-#undef WGPP_
-    return (int)hipGetLastError();
-  }
   const dim3 grid(a.nbatch);
   if (kernel_name) *kernel_name = f16 ? "gemm_f16_wgp_kernel" : "gemm_bf16_wgp_kernel";
 #define WGP_(F_, T_) hipLaunchKernelGGL((gemm_wgp16_kernel<F_, T_>), grid, block, lds_bytes, st, a, g)

@@ -174,6 +174,9 @@ RAGGED_16BIT = [
     dict(m=72, n=40, k=48, beta=1, br_type=capi.BR_STRIDE, br_count=4, c_type=DT.F32),      # wgp kernel: six tiles (two per wave), batch-reduce stages, f32 C with beta = 1
     dict(m=96, n=96, k=96),                                                                  # whole 32-tiles, nine per problem: three per wave
     dict(m=44, n=100, k=16, ldc=48),                                                         # eight tiles, one short chunk
+    dict(m=40, n=24, k=64, c_type=DT.F32),                                                   # f32 C through the LDS image of C
+    dict(m=48, n=40, k=24, ldc=52),                                                          # padded C columns -> element stores (no C image)
+    dict(m=36, n=36, k=8, beta=1),                                                           # beta = 1 (C read by tile_init, written through the image)
     dict(m=40, n=40, k=40),                                                   # B on dwords: its panel through LDS (a dword per lane, any ldb)
     dict(m=24, n=24, k=24, beta=1),
     dict(m=72, n=72, k=72, br_type=capi.BR_STRIDE, br_count=3),               # nine waves per problem, k tail of 8, strided batch-reduce
