@@ -164,6 +164,8 @@ def dry_main(args):
 def gen_values(n, bf16, dev, gen):
     """Reference-style data [samples/xgemm/gemm_kernel.c:837-865]: multiples of 0.1 in [-0.4, 0.5]; bf16 by truncation (bf16 = "f16": IEEE halves, RNE)."""
     out = torch.empty(n, dtype=torch.float64 if bf16 == "f64" else (torch.int16 if bf16 else torch.float32), device=dev)
+    if os.environ.get("BENCH_ZERO_DATA") == "1":      # counter passes only (tools/r5_macro_counters.sh): the same launches on all-zero operands -- what the matrix pipe clocks to without data toggling
+        return out.zero_()
     step = 1 << 26
     for o in range(0, n, step):
         c = min(step, n - o)
@@ -808,6 +810,9 @@ def compact_line(full, detail_path):
         pl = full["pipelined"]
         line["pipelined"] = {k: (v if not isinstance(v, dict) else (round(v["frac_hbm"], 3) if "frac_hbm" in v else None)) for k, v in pl.items()}
         line["pipelined_verified"] = all(v.get("verified", False) for v in pl.values() if isinstance(v, dict))
+    if full.get("effective_clock_GHz"):
+        ec = full["effective_clock_GHz"]
+        line["effective_clock_GHz"] = [ec.get("bf16_m64_blocked_8192"), ec.get("bf16_m64_blocked_8192_on_zeros"), ec.get("mfma_busy_frac")]   # [drivers' data, zeros, matrix pipe busy]: committed rocprofv3 pass
     for k in ("l3_resident_us", "without_streaming_hint_us", "mfma_power_roof_TF"):
         if full.get(k) is not None:
             line[k] = full[k]
@@ -1069,6 +1074,17 @@ def main():
             out["pipelined"] = pipelined
         if roof:
             out["mfma_power_roof_TF"] = roof
+            # the rocprofv3 side of the same statement (committed counter passes of the 8192^3 bf16 launch: tools/r5_macro_counters.sh): GRBM_GUI_ACTIVE / kernel time
+            # = the clock the chip really ran at, on the drivers' operand values and on zeros, with the matrix-pipe-busy share of both
+            try:
+                mc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bf16_macro_counters.json")))[-1]))["counters"]
+                pick = lambda d: max((v for k, v in d.items() if "gemm_bf16_macro_kernel<1, 64" in k), key=lambda v: v["kernel_us_under_counters"])     # noqa: E731  (the 8192^3 launch)
+                dd, zz = pick(mc["drivers_data"]), pick(mc["zeros"])
+                out["effective_clock_GHz"] = {"bf16_m64_blocked_8192": dd["effective_clock_GHz"], "bf16_m64_blocked_8192_on_zeros": zz["effective_clock_GHz"],
+                                              "mfma_busy_frac": dd["mfma_busy_frac"], "mfma_busy_frac_on_zeros": zz["mfma_busy_frac"],
+                                              "source": "profiles/r05_bf16_macro_counters.json (rocprofv3 --pmc GRBM_GUI_ACTIVE ..., the committed pass; not measured in this process)"}
+            except Exception:
+                pass
             out["mfma_power_roof_note"] = ("libxsmm_hip_probe_mfma: MFMAs back to back on register operands of the bench's value distribution (no LDS, no memory), "
                                            "one wave per SIMD; MFMA_PEAK_TF is the nominal 2.4 GHz figure, this is what the power budget allows on this data")
         if sweep:
