@@ -525,6 +525,27 @@ def single_call_latency():
     return out
 
 
+def sharded_c_abi():
+    """SURVEY 8(e) for C hosts: examples/sharded_driver.c (built by __graft_entry__.build()) -- ONE process, ONE thread, the batch cut by libxsmm_hip_shard_range into one
+    block per shard, every shard's operands on the shard's device, one libxsmm_hip_gemm[_ext]_batch_strided_sharded call launches them all and gathers C on device 0.
+    Shard s runs on device s % device_count: on a one-GPU box the four shards are virtual (a stream and scratch each), on an 8-GPU node the same command spreads.
+    Reported: milliseconds per sharded launch INCLUDING the gather, and that the gathered C equals the unsharded launch bit for bit."""
+    exe = os.path.join(ROOT, "libxsmm_amd", "lib", "sharded_driver")
+    if not os.path.exists(exe):
+        return None
+    import subprocess
+    out = {}
+    for key, argv in (("f32_m32_b4096_x4", ["32", "4096", "4", "f32", "20"]), ("c5_bf16fused_m64_b32768_x4", ["64", "32768", "4", "bf16fused", "5"])):
+        try:
+            r = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=300)
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+            out[key] = {"ms_per_sharded_launch_with_gather": rec["ms_per_sharded_launch_with_gather"], "GFLOP/s": rec["GFLOPs"], "shards": rec["shards"], "devices": rec["devices"],
+                        "bit_identical_to_unsharded_launch": rec["bit_identical"], "rc": rec["rc"]}
+        except Exception as e:                       # a side figure: never fails the bench
+            out[key] = {"error": str(e)[:100]}
+    return out
+
+
 def stale_profile_rows(measured):
     """Every workload of this run against the committed rocprofv3 kernel-duration table (profiles/rNN_bench_kernel_stats.csv, the latest round): a row that is
     missing, names another kernel, or whose average duration is more than 15 % away from what this run measured is reported -- the driver line's numbers must be
@@ -773,6 +794,9 @@ def compact_line(full, detail_path):
     sc = full.get("single_call_us")
     if sc:
         line["single_call_us"] = [sc.get(k, {}).get("us_per_call") for k in ("sync", "async", "coalesce")]       # [blocking, stream-ordered, coalesced] per f32 32^3 call
+    sh = full.get("sharded_c_abi")
+    if sh:     # [ms per sharded launch with gather, shards, devices, bit-identical to the unsharded launch] per workload of examples/sharded_driver.c (the C-ABI multi-device launcher)
+        line["sharded_c_abi"] = {k: (None if "error" in v else [v["ms_per_sharded_launch_with_gather"], v["shards"], v["devices"], v["bit_identical_to_unsharded_launch"]]) for k, v in sh.items()}
     if full.get("profiles_check"):
         line["profiles_stale_rows"] = len(full["profiles_check"]["stale"])            # workloads whose committed rocprofv3 row does not reproduce this run (0 = all do)
     cb64 = full.get("cpu_baseline_f64")
@@ -1106,6 +1130,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.m, args.dtype, args.br, args.beta, args.fused, args.cpu_seconds, nthreads)
             if sweep:
                 out["single_call_us"] = single_call_latency()
+                out["sharded_c_abi"] = sharded_c_abi()
             if sweep:       # the reference's classic precision: its f64 JIT kernel for the sweep's f64 32^3 entries, one core (a shorter sample: it is a side figure)
                 out["cpu_baseline_f64"] = cpu_baseline(32, "f64", 1, 0, 0, min(args.cpu_seconds, 4.0), 0)
         if args.manifest:
