@@ -613,7 +613,8 @@ BLOCKED = [("f32", 16, 128, 128, 128, ""), ("f32", 32, 128, 128, 64, ""), ("f32"
            ("f64", 32, 128, 128, 64, ""), ("f64", 64, 64, 64, 64, "")]      # f64: 4096 x 4096 x 2048 out of 32^3 tiles, 4096^3 out of 64^3 tiles (macro tile 128 x 128)
 SHARED_B = [(dt, m, 65536) for dt in ("f32", "bf16") for m in (16, 32, 64)]
 # the odd shapes LIBXSMM is known for (BASELINE configs[0] is one 23^3 f32 GEMM): same streaming regime, problems that are not whole tiles
-RAGGED = [("f32", 23, 131072), ("f32", 23, 4096), ("f32", 13, 262144), ("f32", 40, 32768), ("f32", 72, 16384)]
+RAGGED = [("f32", 23, 131072), ("f32", 23, 4096), ("f32", 13, 262144), ("f32", 40, 32768), ("f32", 72, 16384),
+          ("bf16", 40, 65536), ("bf16", 72, 16384), ("bf16", 96, 8192)]      # round 5: ragged / several-tile 16-bit shapes (one problem per workgroup out of LDS, gemm_wgp16_kernels.hip)
 
 
 def mfma_roof(api, dev):

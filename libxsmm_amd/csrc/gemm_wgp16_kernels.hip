@@ -39,18 +39,20 @@ struct Wgp16Geo {
 template <bool F16, int TPW>
 __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g) {
   extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
+  constexpr unsigned int TS = 4u;                                 // the four waves of the workgroup share the problem
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
   const unsigned int bidx = blockIdx.x;
+  const bool present = true;
   const BatchPtrs q = batch_ptrs(p, bidx);
   char* const img_a = lds_wgp;
-  char* const img_b = lds_wgp + g.a_img;
+  char* const img_b = img_a + g.a_img;
   const unsigned int ntiles = (unsigned int)(p.tiles_m * p.tiles_n);
   f32x16 acc[TPW];
   TileCtx tc[TPW];
   static_for<TPW>([&](auto tt) {
     constexpr int t = tt.value;
-    const unsigned int id = w + 4u * (unsigned int)t;
+    const unsigned int id = w + TS * (unsigned int)t;
     const unsigned int tj = id / (unsigned int)p.tiles_m, ti = id - tj * (unsigned int)p.tiles_m;
     tc[t].i = (int)(32u * ti + li); tc[t].j0 = (int)(32u * tj); tc[t].h = (int)h; tc[t].ivalid = tc[t].i < p.m;
     if (id < ntiles) {
@@ -66,16 +68,16 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
     gcptr ar, br; br_base(p, q, r, ar, br);
     if (r != 0) wg_barrier();                                   // everybody has read the previous block's images
     // ---- all requests of the block, dealt round-robin to the four waves: request x fills the 1 KiB slot x of its image, lane = piece 64 x + lane
-    for (unsigned int x = w; x * 64u < g.a_pieces; x += 4u) {
+    for (unsigned int x = w; x * 64u < g.a_pieces; x += TS) {
       const unsigned int P = 64u * x + lane;
-      if (P < g.a_pieces) {
+      if (P < g.a_pieces && present) {
         const unsigned int kp = P / g.ppr, pc = P - kp * g.ppr;
         __builtin_amdgcn_global_load_lds((GM const void*)(ar + ((unsigned long long)kp * lda + 4u * pc) * 4ull), (lds_vptr)(img_a + 1024u * x), 16, 0, 0);
       }
     }
-    for (unsigned int x = w; x * 64u < g.b_pieces; x += 4u) {
+    for (unsigned int x = w; x * 64u < g.b_pieces; x += TS) {
       const unsigned int P = 64u * x + lane;
-      if (P < g.b_pieces) {
+      if (P < g.b_pieces && present) {
         const unsigned int col = P / g.ppc, pc = P - col * g.ppc;
         __builtin_amdgcn_global_load_lds((GM const void*)(br + ((unsigned long long)col * ldb + 8u * pc) * 2ull), (lds_vptr)(img_b + 1024u * x), 16, 0, 0);
       }
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
     // ---- multiply out of LDS: my tiles, K in chunks of 32 (two MFMA steps of 16)
     static_for<TPW>([&](auto tt) {
       constexpr int t = tt.value;
-      const unsigned int id = w + 4u * (unsigned int)t;
+      const unsigned int id = w + TS * (unsigned int)t;
       if (id < ntiles) {
         const unsigned int tj = id / (unsigned int)p.tiles_m, ti = id - tj * (unsigned int)p.tiles_m;
         const unsigned int* const arow = (const unsigned int*)img_a + 32u * ti + li;              // + kp * rp
@@ -111,11 +113,13 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
   // (round 5, measured and not adopted -- profiles/r05_wgp16_c_image_not_adopted.jsonl: the results through an LDS image of C and out as whole 16-byte pieces.  The timing
   //  ablation had put the element stores at 41 of 147 us on 40^3, but the image costs LDS -- 96^3: 54 instead of 36 KiB per workgroup -- and a second barrier: 40^3 0.54 ->
   //  0.51, 72^3 0.53 -> 0.47, 96^3 0.65 -> 0.40.  Likewise a wave per problem (no barrier at all, a quarter of the workgroups: 40^3 0.56 -> 0.48, 48^3 0.67 -> 0.36,
-  //  r05_wave_per_problem_not_adopted.jsonl) and persistent workgroups with two images in flight (0.56 -> 0.46, r05_wgp16_forms.jsonl): what these shapes need is many
-  //  short workgroups in different phases, which is exactly what the hardware's own workgroup scheduler provides.)
+  //  r05_wave_per_problem_not_adopted.jsonl), persistent workgroups with two images in flight (0.56 -> 0.46, r05_wgp16_forms.jsonl) and two problems per workgroup, two
+  //  waves each (half the workgroups: 0.536 -> 0.542, 48^3 0.65 -> 0.64: nothing, r05_wgp16_two_problems_per_wg_not_adopted.jsonl): what these shapes need is many
+  //  short workgroups in different phases, which is exactly what the hardware's own workgroup scheduler provides.  40^3 stays at 0.54 - 0.57 in EVERY form, the
+  //  wave-per-tile kernel included.)
   static_for<TPW>([&](auto tt) {
     constexpr int t = tt.value;
-    if (w + 4u * (unsigned int)t < ntiles) tile_store<false, false, false>(acc[t], p, q, tc[t]);
+    if (w + TS * (unsigned int)t < ntiles) tile_store<false, false, false>(acc[t], p, q, tc[t]);
   });
 }
 
@@ -154,8 +158,8 @@ int launch_gemm_wgp16(const GemmArgs& a_in, void* stream, const char** kernel_na
   hipStream_t st = (hipStream_t)stream;
   const dim3 block(256);
   *taken = 1;
-  const dim3 grid(a.nbatch);
   if (kernel_name) *kernel_name = f16 ? "gemm_f16_wgp_kernel" : "gemm_bf16_wgp_kernel";
+  const dim3 grid(a.nbatch);
 #define WGP_(F_, T_) hipLaunchKernelGGL((gemm_wgp16_kernel<F_, T_>), grid, block, lds_bytes, st, a, g)
   if (f16) { if (tpw == 1) WGP_(true, 1); else if (tpw == 2) WGP_(true, 2); else WGP_(true, 3); }
   else { if (tpw == 1) WGP_(false, 1); else if (tpw == 2) WGP_(false, 2); else WGP_(false, 3); }
