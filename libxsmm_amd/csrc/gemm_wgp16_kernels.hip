@@ -43,7 +43,6 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
   const unsigned int bidx = blockIdx.x;
-  const bool present = true;
   const BatchPtrs q = batch_ptrs(p, bidx);
   char* const img_a = lds_wgp;
   char* const img_b = img_a + g.a_img;
@@ -70,14 +69,14 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
     // ---- all requests of the block, dealt round-robin to the four waves: request x fills the 1 KiB slot x of its image, lane = piece 64 x + lane
     for (unsigned int x = w; x * 64u < g.a_pieces; x += TS) {
       const unsigned int P = 64u * x + lane;
-      if (P < g.a_pieces && present) {
+      if (P < g.a_pieces) {
         const unsigned int kp = P / g.ppr, pc = P - kp * g.ppr;
         __builtin_amdgcn_global_load_lds((GM const void*)(ar + ((unsigned long long)kp * lda + 4u * pc) * 4ull), (lds_vptr)(img_a + 1024u * x), 16, 0, 0);
       }
     }
     for (unsigned int x = w; x * 64u < g.b_pieces; x += TS) {
       const unsigned int P = 64u * x + lane;
-      if (P < g.b_pieces && present) {
+      if (P < g.b_pieces) {
         const unsigned int col = P / g.ppc, pc = P - col * g.ppc;
         __builtin_amdgcn_global_load_lds((GM const void*)(br + ((unsigned long long)col * ldb + 8u * pc) * 2ull), (lds_vptr)(img_b + 1024u * x), 16, 0, 0);
       }
