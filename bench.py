@@ -564,7 +564,8 @@ def stale_profile_rows(measured):
     # names the library reports for a template instance of another kernel / for a launch of several kernels (the table holds the first symbol of the launch)
     alias = {"bcsc_mfma_f32_stream_kernel": "bcsc_mfma_bf16_stream_kernel", "gemm_fp8c8_stream_kernel": "gemm_fp8_stream_kernel", "gemm_bf32_stream_kernel": "gemm_f32_stream_kernel",
              "gemm_bitmask_reg_kernel": "bitmask_prepass_kernel", "gemm_i4_stream_kernel": "gemm_i8_stream_kernel", "gemm_i2_stream_kernel": "gemm_i8_stream_kernel",
-             "gemm_i1_stream_kernel": "gemm_i8_stream_kernel"}
+             "gemm_i1_stream_kernel": "gemm_i8_stream_kernel", "gemm_bf16_wgp_kernel": "gemm_wgp16_kernel", "gemm_f16_wgp_kernel": "gemm_wgp16_kernel",
+             "reduce_vec_kernel": "reduce_combine_kernel"}        # (the big column reduction is two kernels per call: partial sums, then their combination)
     for label, (kernel, us) in measured.items():
         if label not in rows:
             stale.append(f"{label}: no row"); continue

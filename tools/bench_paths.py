@@ -178,6 +178,7 @@ def bitmask_gemm(api, m, n, k, frac, dt=DT.BF16):
              lambda s: capi.Api.call(h, ps[s]), lambda: api.hip_kernel_name(h, 0).decode())
     w.dense_equiv_flops = 2.0 * m * n * k
     w.keep = (Vs, Ms, Bs, Cs, ps)
+    w.kernels_per_launch = 2          # the pre-pass (row totals, re-laid B) + the GEMM: tools/summarize_profiles.py adds the two up per call
     return w
 
 

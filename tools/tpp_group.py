@@ -74,6 +74,8 @@ class Tpp:
         self.alg_bytes = self.alg_bytes_per_step
         self.flops_per_step = float(flops if flops is not None else count * m * n)
         self.hint, self.dtype = 0, "f32"
+        # the column reduction of ONE big matrix is two kernels per call (partial sums over row groups, then their combination): the trace summary adds them up
+        self.kernels_per_launch = 2 if (op == "unary" and typ == UNARY.REDUCE_X_OP_ADD and (flags & UNARY_FLAG.REDUCE_COLS) and count == 1) else 1
 
     def _param(self, x, y, x1, idx):
         if self.op == "unary":
