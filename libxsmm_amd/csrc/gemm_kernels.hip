@@ -1922,16 +1922,6 @@ __global__ __launch_bounds__(256, BND ? 4 : 1) void gemm_mfma_bf16_kernel(GemmAr
 // form); sums in the matrix core's order, epilogues as the bf16 kernels.
 // KIND 0 / 1: BF8 / HF8 in VNNI-2 pairs, 2 / 3: BF8 / HF8 flat, 4: scaled int8 flat.
 // ------------------------------------------------------------------------------------------------
-typedef float f32x2w __attribute__((ext_vector_type(2)));
-template <int KIND> __device__ __forceinline__ unsigned int w8_pair_to_bf16(unsigned int two_bytes, float scf) {      // byte 0 = even k, byte 1 = odd k  ->  packed bf16 pair
-  if constexpr (KIND == 4) {
-    const float f0 = (float)(int)(signed char)(two_bytes & 0xffu) * scf, f1 = (float)(int)(signed char)((two_bytes >> 8) & 0xffu) * scf;
-    return cvt_pk_bf16(f0, f1);
-  } else {
-    const f32x2w f = (KIND & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)two_bytes, false) : __builtin_amdgcn_cvt_pk_f32_bf8((int)two_bytes, false);
-    return (__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xffff0000u);        // exact: both formats have at most 3 significand bits
-  }
-}
 // EXACT: whole 32 x 32 x 32 tiles and 16-byte aligned B columns (the host checks): no masks, a step's B operand is ONE 16-byte load.
 template <int MT, int NT, int KIND, bool EXACT, bool BL = false>          // BL (ragged shapes, B on dwords, k even: launch_gemm): B through LDS as gemm_mfma_bf16_kernel
 __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
@@ -4746,6 +4736,8 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     case P_W8_1x1: case P_W8_2x2: {
       const bool big = pl.path == P_W8_2x2, va8 = (a.flags & LIBXSMM_GEMM_FLAG_VNNI_A) != 0;
       const int kind = a.a_type == LIBXSMM_DATATYPE_I8 ? 4 : ((a.a_type == LIBXSMM_DATATYPE_HF8 ? 1 : 0) + (va8 ? 0 : 2));
+      // ragged / several-tile shapes with a packed weight block: one problem per workgroup out of LDS (gemm_wgp16_kernels.hip, round 5)
+      if ((a.m % 64) || (a.n % 64) || (a.k % 32)) { int taken = 0; const int e = launch_gemm_wgp16_w8(a, kind, stream, kernel_name, &taken); if (taken) return e; }
       grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
       const int tw = big ? 64 : 32;
       const unsigned long long bbits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)((long long)a.ldb * 2);

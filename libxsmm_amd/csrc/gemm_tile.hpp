@@ -238,4 +238,16 @@ __device__ __forceinline__ WaveJob wave_job(const GemmArgs& p, int tile_m, int t
   return w;
 }
 
+// 8-bit WEIGHTS as the bf16 values the reference multiplies with (gemm_w8_bf16_kernel, gemm_wgp16_kernel<.., AK>): KIND 0 / 1: BF8 / HF8 in VNNI-2 pairs, 2 / 3: flat, 4: int8 x row scale
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+template <int KIND> __device__ __forceinline__ unsigned int w8_pair_to_bf16(unsigned int two_bytes, float scf) {      // byte 0 = even k, byte 1 = odd k  ->  packed bf16 pair
+  if constexpr (KIND == 4) {
+    const float f0 = (float)(int)(signed char)(two_bytes & 0xffu) * scf, f1 = (float)(int)(signed char)((two_bytes >> 8) & 0xffu) * scf;
+    return cvt_pk_bf16(f0, f1);
+  } else {
+    const f32x2w f = (KIND & 1) ? __builtin_amdgcn_cvt_pk_f32_fp8((int)two_bytes, false) : __builtin_amdgcn_cvt_pk_f32_bf8((int)two_bytes, false);
+    return (__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xffff0000u);        // exact: both formats have at most 3 significand bits
+  }
+}
+
 }  // namespace xamd

@@ -36,7 +36,10 @@ struct Wgp16Geo {
   unsigned int a_img;       // bytes of the A image (whole 1 KiB request slots)
 };
 
-template <bool F16, int TPW>
+// AK = -1: 16-bit A (VNNI-2 dwords).  AK = 0..4: 8-bit WEIGHTS x bf16 activations (KIND of gemm_w8_bf16_kernel: 0 / 1 BF8 / HF8 in VNNI-2 byte pairs, 2 / 3 flat, 4 int8 with
+// one f32 scale per row) -- the A block is a BYTE image ([k/2][m][2] or [k][m], lda == m) that comes in as a linear copy (whole 16-byte pieces of the packed block) and is
+// turned into the bf16 pairs the reference multiplies with on the way out of LDS (w8_pair_to_bf16: exact for the 8-bit floats, one rounding for the scaled int8).
+template <bool F16, int TPW, int AK = -1>
 __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g) {
   extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
   constexpr unsigned int TS = 4u;                                 // the four waves of the workgroup share the problem
@@ -61,6 +64,9 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
       } else tile_init<false, false>(acc[t], p, q, tc[t]);
     }
   });
+  float scf[TPW];
+  static_for<TPW>([&](auto tt) { constexpr int t = tt.value;
+    scf[t] = (AK == 4 && tc[t].ivalid) ? ((GM const float*)(p.a_scf + (long long)bidx * p.bs_scf))[tc[t].i] : 1.0f; });
   const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
   const unsigned int kchunks = ((unsigned int)p.k + 31u) >> 5, kgroups = (unsigned int)p.k >> 3;      // 8-deep k groups (k % 8 == 0)
   for (unsigned long long r = 0; r < p.br_count; ++r) {
@@ -70,8 +76,11 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
     for (unsigned int x = w; x * 64u < g.a_pieces; x += TS) {
       const unsigned int P = 64u * x + lane;
       if (P < g.a_pieces) {
-        const unsigned int kp = P / g.ppr, pc = P - kp * g.ppr;
-        __builtin_amdgcn_global_load_lds((GM const void*)(ar + ((unsigned long long)kp * lda + 4u * pc) * 4ull), (lds_vptr)(img_a + 1024u * x), 16, 0, 0);
+        if constexpr (AK >= 0) __builtin_amdgcn_global_load_lds((GM const void*)(ar + 16ull * P), (lds_vptr)(img_a + 1024u * x), 16, 0, 0);      // the packed byte image, piece by piece
+        else {
+          const unsigned int kp = P / g.ppr, pc = P - kp * g.ppr;
+          __builtin_amdgcn_global_load_lds((GM const void*)(ar + ((unsigned long long)kp * lda + 4u * pc) * 4ull), (lds_vptr)(img_a + 1024u * x), 16, 0, 0);
+        }
       }
     }
     for (unsigned int x = w; x * 64u < g.b_pieces; x += TS) {
@@ -98,8 +107,19 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
             const unsigned int kg = 4u * kc + 2u * (unsigned int)s + h;           // this lane's 8-deep k group of the step
             const bool ok = kg < kgroups;                                         // (k % 8 == 0: a group is whole or absent)
             const unsigned int kgc = ok ? kg : 0u;                                // absent groups read group 0 (inside the image) and are zeroed
+            if constexpr (AK < 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) af[s][e] = arow[(4u * kgc + (unsigned int)e) * g.rp];
+              for (int e = 0; e < 4; ++e) af[s][e] = arow[(4u * kgc + (unsigned int)e) * g.rp];
+            } else if constexpr (AK < 2) {        // byte pairs [k/2][m][2]: two bytes of my row per k pair
+#pragma unroll
+              for (int e = 0; e < 4; ++e) af[s][e] = w8_pair_to_bf16<AK>(*((const unsigned short*)img_a + (4u * kgc + (unsigned int)e) * g.rp + 32u * ti + li), 1.0f);
+            } else {                              // flat [k][m]: the even and the odd k of a pair are m bytes apart
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const unsigned char* b0 = (const unsigned char*)img_a + (8u * kgc + 2u * (unsigned int)e) * g.rp + 32u * ti + li;
+                af[s][e] = w8_pair_to_bf16<AK>((unsigned int)b0[0] | ((unsigned int)b0[g.rp] << 8), scf[t]);
+              }
+            }
             bfr[s] = *(const u32x4*)(bcol + 16u * kgc);
             if (!ok) { af[s] = u32x4{0u, 0u, 0u, 0u}; bfr[s] = u32x4{0u, 0u, 0u, 0u}; }
           }
@@ -124,13 +144,14 @@ __global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g)
 
 // rows / columns beyond m / n of a tile read LDS beyond their operand's rows (another k pair's row, the other image, or nothing): they feed results nobody stores,
 // and an LDS read beyond the allocation returns zero by definition -- no fault is possible on that side.
-static bool wgp16_shape_ok(const GemmArgs& a, Wgp16Geo& g, unsigned int& lds_bytes, int& tpw) {
+static bool wgp16_shape_ok(const GemmArgs& a, Wgp16Geo& g, unsigned int& lds_bytes, int& tpw, int ak = -1) {
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '0'; }();
   if (off) return false;
   if (a.batch_inner || a.list_a || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c) return false;          // 1-D strided batches, plain / STRIDE batch-reduce
   if (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) return false;
-  if (!(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
+  if (ak < 0 && !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
   if ((a.m & 3) || (a.k & 7) || (a.lda & 3) || (a.ldb & 7) || a.k <= 0) return false;
+  if (ak >= 0 && (a.lda != a.m || (((long long)a.m * a.k) & 15))) return false;       // 8-bit weights: the packed byte image of the block, whole 16-byte pieces of it
   const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
     (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0);
   if (bits & 15ull) return false;
@@ -138,7 +159,7 @@ static bool wgp16_shape_ok(const GemmArgs& a, Wgp16Geo& g, unsigned int& lds_byt
   if (tiles < 2 || tiles > 12) return false;
   g.ppr = (unsigned int)a.m / 4u; g.rp = (unsigned int)a.m;
   g.ppc = (unsigned int)a.k / 8u;
-  g.a_pieces = ((unsigned int)a.k / 2u) * g.ppr; g.b_pieces = (unsigned int)a.n * g.ppc;
+  g.a_pieces = ak >= 0 ? (unsigned int)(((long long)a.m * a.k) / 16) : ((unsigned int)a.k / 2u) * g.ppr; g.b_pieces = (unsigned int)a.n * g.ppc;
   g.a_img = ((g.a_pieces + 63u) / 64u) * 1024u;
   lds_bytes = g.a_img + ((g.b_pieces + 63u) / 64u) * 1024u;
   if (lds_bytes > 64u * 1024u) return false;
@@ -163,6 +184,27 @@ int launch_gemm_wgp16(const GemmArgs& a_in, void* stream, const char** kernel_na
   if (f16) { if (tpw == 1) WGP_(true, 1); else if (tpw == 2) WGP_(true, 2); else WGP_(true, 3); }
   else { if (tpw == 1) WGP_(false, 1); else if (tpw == 2) WGP_(false, 2); else WGP_(false, 3); }
 #undef WGP_
+  return (int)hipGetLastError();
+}
+
+// 8-bit weights x bf16 activations on ragged / several-tile shapes (kind as in launch_gemm's P_W8 case); plain strided batches, one block per problem or STRIDE chains
+int launch_gemm_wgp16_w8(const GemmArgs& a_in, int kind, void* stream, const char** kernel_name, int* taken) {
+  *taken = 0;
+  Wgp16Geo g; unsigned int lds_bytes = 0; int tpw = 0;
+  if (kind < 0 || kind > 4 || a_in.b_type != LIBXSMM_DATATYPE_BF16) return 0;
+  if (!wgp16_shape_ok(a_in, g, lds_bytes, tpw, kind)) return 0;
+  if (kind == 4 && (!a_in.a_scf || (a_in.bs_scf & 3))) return 0;
+  GemmArgs a = a_in;
+  a.tiles_m = (a.m + 31) / 32; a.tiles_n = (a.n + 31) / 32; a.map2d_shift = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(a.nbatch), block(256);
+  *taken = 1;
+  if (kernel_name) *kernel_name = "gemm_w8_wgp_kernel";
+#define WGPW_(K_, T_) hipLaunchKernelGGL((gemm_wgp16_kernel<false, T_, K_>), grid, block, lds_bytes, st, a, g)
+#define WGPWT_(K_) do { if (tpw == 1) WGPW_(K_, 1); else if (tpw == 2) WGPW_(K_, 2); else WGPW_(K_, 3); } while (0)
+  switch (kind) { case 0: WGPWT_(0); break; case 1: WGPWT_(1); break; case 2: WGPWT_(2); break; case 3: WGPWT_(3); break; default: WGPWT_(4); break; }
+#undef WGPWT_
+#undef WGPW_
   return (int)hipGetLastError();
 }
 

@@ -1068,7 +1068,7 @@ def test_more_gemm_types_bit_exact(t, m, n, k, lda, ldb, ldc, br, beta, batch):
         gk, rk = key(got.view(np.uint8)), key(ref.view(np.uint8))
         assert np.max(np.abs(gk - rk)) <= 1 and np.mean(gk != rk) < 0.03, (int(np.max(np.abs(gk - rk))), float(np.mean(gk != rk)))
         return
-    if name.startswith("gemm_w8_bf16_kernel"):
+    if name.startswith(("gemm_w8_bf16_kernel", "gemm_w8_wgp_kernel")):
         # round 4: 8-bit float / row-scaled int8 WEIGHTS x bf16 on the bf16 matrix cores -- the weights are converted exactly (resp. rounded like the reference) in
         # registers, the sum is formed in the matrix core's order: the reference's bounds for bf16 GEMMs
         assert t["b"] == DT.BF16 and t["a"] in (DT.BF8, DT.HF8, DT.I8)

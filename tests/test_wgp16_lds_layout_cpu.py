@@ -78,3 +78,43 @@ def test_pieces_land_where_the_fragments_read_them(m, n, k, lda, ldb):
     got, ref = _model(m, n, k, lda, ldb)
     assert not np.isnan(got).any(), "padding or untouched LDS reached a stored result"
     assert np.array_equal(got, ref)
+
+
+def _model_w8(m, n, k, flat, seed=1):
+    """8-bit WEIGHTS (gemm_wgp16_kernel<.., AK>): the A block is a packed BYTE image -- pairs [k/2][m][2] (AK 0 / 1) or flat [k][m] (AK 2..4), lda == m -- that comes in as a
+    linear copy (piece P = bytes 16 P .. of the block) and is read back as the two bytes of (row i, k pair): ushort index (4 kg + e) * m + i, resp. bytes (8 kg + 2 e) * m + i
+    and + m.  Values stand for themselves here (the conversion to bf16 is a function of the byte alone)."""
+    assert m % 4 == 0 and k % 8 == 0 and (m * k) % 16 == 0
+    rng = np.random.default_rng(seed)
+    A = rng.integers(1, 100, (m, k)).astype(np.float64)
+    img = np.full(((m * k + 15) // 16) * 16, np.nan)
+    mem = np.zeros(m * k)
+    for kk in range(k):
+        for i in range(m):
+            mem[(kk * m + i) if flat else ((kk // 2) * m + i) * 2 + (kk % 2)] = A[i, kk]
+    for P in range(m * k // 16):
+        img[16 * P:16 * P + 16] = mem[16 * P:16 * P + 16]               # request x = P // 64, lane P % 64 -> LDS byte 16 P
+    got = np.full((m, k), np.nan)
+    tiles_m = (m + 31) // 32
+    for ti in range(tiles_m):
+        for kg in range(k // 8):
+            for li in range(32):
+                i = 32 * ti + li
+                if i >= m:
+                    continue
+                for e in range(4):
+                    if flat:
+                        b0 = (8 * kg + 2 * e) * m + i
+                        lo, hi = img[b0], img[b0 + m]
+                    else:
+                        u = (4 * kg + e) * m + i
+                        lo, hi = img[2 * u], img[2 * u + 1]
+                    got[i, 8 * kg + 2 * e], got[i, 8 * kg + 2 * e + 1] = lo, hi
+    return got, A
+
+
+@pytest.mark.parametrize("flat", [False, True])
+@pytest.mark.parametrize("m,k", [(40, 40), (72, 72), (96, 32), (44, 16)])
+def test_packed_byte_images_of_8bit_weights(m, k, flat):
+    got, ref = _model_w8(m, 8, k, flat)
+    assert np.array_equal(got, ref)
