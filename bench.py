@@ -565,7 +565,7 @@ def stale_profile_rows(measured):
     alias = {"bcsc_mfma_f32_stream_kernel": "bcsc_mfma_bf16_stream_kernel", "gemm_fp8c8_stream_kernel": "gemm_fp8_stream_kernel", "gemm_bf32_stream_kernel": "gemm_f32_stream_kernel",
              "gemm_bitmask_reg_kernel": "bitmask_prepass_kernel", "gemm_i4_stream_kernel": "gemm_i8_stream_kernel", "gemm_i2_stream_kernel": "gemm_i8_stream_kernel",
              "gemm_i1_stream_kernel": "gemm_i8_stream_kernel", "gemm_bf16_wgp_kernel": "gemm_wgp16_kernel", "gemm_f16_wgp_kernel": "gemm_wgp16_kernel",
-             "reduce_vec_kernel": "reduce_combine_kernel"}        # (the big column reduction is two kernels per call: partial sums, then their combination)
+             "gemm_8bit_wgp_kernel": "gemm_wgp8_kernel", "gemm_w8_wgp_kernel": "gemm_wgp16_kernel", "reduce_vec_kernel": "reduce_combine_kernel"}        # (the big column reduction is two kernels per call: partial sums, then their combination)
     for label, (kernel, us) in measured.items():
         if label not in rows:
             stale.append(f"{label}: no row"); continue
@@ -754,6 +754,10 @@ def run_round4(api, dev, steps, min_seconds):
         ("bf16_m40", lambda: bp.brgemm(api, 40, "bf16", 2 ** 16)),                                  # a ragged bf16 shape on the masked bf16 matrix-core kernel
         ("w8_bf8_m64", lambda: bp.brgemm_w8(api, 64, 2 ** 16, DT.BF8, True)),                     # 8-bit float weights (VNNI-2 pairs) x bf16 -> bf16
         ("w8_i8s_m64", lambda: bp.brgemm_w8(api, 64, 2 ** 16, DT.I8, False, DT.F32)),              # int8 weights with row scales x bf16 -> f32
+        # round 5: 72^3 of the 8-bit families -- packed blocks of nine tiles, one problem per workgroup out of LDS (gemm_wgp8_kernel / gemm_wgp16_kernel<.., AK>)
+        ("i8_m72", lambda: bp.brgemm_i8(api, 72, 2 ** 15, ua=False)),
+        ("bf8_m72", lambda: bp.brgemm_form(api, 72, 2 ** 15, GEMM_FLAG.VNNI_A, a_dt=DT.BF8, c_dt=DT.F32, name="bf8 -> f32")),
+        ("w8_bf8_m72", lambda: bp.brgemm_w8(api, 72, 2 ** 14, DT.BF8, True)),
         ("bitmaskA_8192x64", lambda: bp.bitmask_gemm(api, 8192, 64, 8192, 0.5)),
         ("vnni2_ld4090", lambda: bp.meltw_big(api, UNARY.TRANSFORM_NORM_TO_VNNI2, "NORM_TO_VNNI2 bf16", m=4090, in_dt=DT.BF16, out_dt=DT.BF16)),
     ]

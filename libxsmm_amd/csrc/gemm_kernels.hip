@@ -30,6 +30,7 @@
 #include "lowp.hpp"
 #include "gemm_device.hpp"
 #include "gemm_tile.hpp"
+#include "gemm_8bit.hpp"
 
 // a*b+c below means two roundings unless fma()/MFMA is spelled out: parity with the reference's C
 // loops (built without FMA contraction) depends on it.
@@ -111,8 +112,6 @@ __device__ __forceinline__ void generic_epilogue(const GemmArgs& p, const BatchP
 // Under `#pragma clang fp contract(off)` a product followed by a sum is two correctly rounded
 // operations (the HIP __fmul_rn/__fadd_rn helpers are plain operators compiled with the header's
 // own contraction setting and DO get fused, so they are not used).
-template <typename T> __device__ __forceinline__ T mul_rn(T a, T b) { return a * b; }
-template <typename T> __device__ __forceinline__ T add_rn(T a, T b) { return a + b; }
 
 
 // block = (64, 4): x walks i (so a wave is 64 consecutive rows of one column, which makes the
@@ -1590,7 +1589,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_t16_kernel(GemmArgs p) {
 //   bf16: v_mfma_f32_16x16x16_bf16, A in VNNI-2 (two dwords = k 4 g .. 4 g + 3 of row x), B flat (8 contiguous bytes of column x).
 // ------------------------------------------------------------------------------------------------
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 template <int PPW, bool BF16>
 __global__ __launch_bounds__(256) void gemm_p16_kernel(GemmArgs p) {
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2611,8 +2610,6 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_bf16_macro_kernel(GemmArgs p)
 // the missing 128 * sum_k(other operand) comes from one more MFMA against an all-ones operand (exact integer
 // arithmetic): (a'+128) b = a'b + 128 sum b,  a (b'+128) = a b' + 128 sum a,  both: + 128*128*K as well.
 // ------------------------------------------------------------------------------------------------
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
 // I4 (round 3): interleaved 4-bit weights [ref: gemm ref :467-477, :1009-1088] -- a dword of A holds eight k of one row (byte t: low nibble k 8o + t, high
 // nibble k 8o + 4 + t), every weight minus the row's zero point (one byte per row, a.quaternary) wrapped to a signed byte, B read as UNSIGNED bytes
 // (UB = true).  Two dwords of A per lane and MFMA step become the four operand dwords: (w & 0x0f0f0f0f) and ((w >> 4) & 0x0f0f0f0f) are k 8o..8o+3 and
@@ -3024,17 +3021,6 @@ __global__ __launch_bounds__(256) void gemm_mx4i8_pipe_kernel(GemmArgs p, unsign
 // Round 4 (tools/fp8_cvt_probe.hip, all 65 536 halves): v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32 fed with the half widened back to f32 give the reference's byte for EVERY
 // half that is not a NaN -- ties, subnormal results, overflow (E4M3: 0x7f, E5M2: infinity) and infinities included; a NaN comes out with its sign bit set, the
 // reference's without: those lanes take the software rounding.  Two results per conversion instruction instead of ~25 vector instructions per element.
-__device__ __forceinline__ unsigned int f32x2_to_fp8_ref(float x0, float x1, bool hf8) {      // byte 0: x0, byte 1: x1
-  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-  const float f0 = (float)h0, f1 = (float)h1;
-  unsigned int r = (unsigned int)(hf8 ? __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false) : __builtin_amdgcn_cvt_pk_bf8_f32(f0, f1, 0, false)) & 0xffffu;
-  if (__builtin_expect((x0 != x0) || (x1 != x1), 0)) {
-    const unsigned short b0 = __builtin_bit_cast(unsigned short, h0), b1 = __builtin_bit_cast(unsigned short, h1);
-    r = hf8 ? ((unsigned int)lowp::f16_to_hf8_rne(b0) | ((unsigned int)lowp::f16_to_hf8_rne(b1) << 8)) : ((unsigned int)lowp::f16_to_bf8_rne(b0) | ((unsigned int)lowp::f16_to_bf8_rne(b1) << 8));
-  }
-  return r;
-}
-__device__ __forceinline__ unsigned char f32_to_fp8_ref(float x, bool hf8) { return (unsigned char)(f32x2_to_fp8_ref(x, x, hf8) & 0xffu); }
 template <int MT, int NT, bool HF8, bool C8 = false>
 __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds_all[4][NT * 2048];
@@ -3153,42 +3139,6 @@ __device__ __forceinline__ unsigned int load_u32_any(gcptr p4) {          // a d
 // the wave added at the end; the column sums reach the accumulator layout (column = register) through 16 ds_bpermute per column tile in the epilogue.  (The
 // streaming kernel spends an MFMA and 16 accumulators per tile row / column on them: here that cost a wave per SIMD -- 216 against 152 registers.)
 // one 32-deep chunk of products of the masked 8-bit kernel: operand dwords aw / bw (padding already zero) into the accumulators, the byte sums of the unsigned forms
-template <int MT, int NT, int KIND, bool UA, bool UB>
-__device__ __forceinline__ void m8_products(const unsigned int (&aw)[MT][4], const unsigned int (&bw)[NT][4], i32x16 (&iacc)[KIND == 0 ? MT : 1][KIND == 0 ? NT : 1],
-                                            f32x16 (&facc)[KIND == 0 ? 1 : MT][KIND == 0 ? 1 : NT], int (&sum_a)[MT], int (&sum_b)[NT]) {
-  constexpr bool INT = KIND == 0, HF8 = KIND == 2;
-  if constexpr (INT) {
-    i32x4 af[MT], bf[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) af[mt] = i32x4{(int)aw[mt][0], (int)aw[mt][1], (int)aw[mt][2], (int)aw[mt][3]};
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bf[nt] = i32x4{(int)bw[nt][0], (int)bw[nt][1], (int)bw[nt][2], (int)bw[nt][3]};
-    static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
-      iacc[mt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[nt], af[mt], iacc[mt][nt], 0, 0, 0); });
-    if constexpr (UA) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sum_b[nt] = __builtin_amdgcn_sdot4((int)bw[nt][e], 0x01010101, sum_b[nt], false);
-    }
-    if constexpr (UB) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sum_a[mt] = __builtin_amdgcn_sdot4((int)aw[mt][e], 0x01010101, sum_a[mt], false);
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
-        const long a8 = (long)(((unsigned long long)aw[mt][2 * s + 1] << 32) | aw[mt][2 * s]), b8 = (long)(((unsigned long long)bw[nt][2 * s + 1] << 32) | bw[nt][2 * s]);
-        if (HF8) facc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b8, a8, facc[mt][nt], 0, 0, 0);
-        else facc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(b8, a8, facc[mt][nt], 0, 0, 0); });
-  }
-}
-// BL (strided forms with dword-aligned blocks and columns: launch_gemm): the wave's B panel of a chunk -- 32 bytes of each of its columns, a whole column apart in
-// memory -- by LDS-DMA a dword per lane (eight lanes = one column, eight columns per instruction, no registers) and back as ONE ds_read_b128 (integers) / two
-// ds_read_b64 (8-bit floats: k-quads 4 s + 2 h + {0, 1}) per column tile, the 64 lanes reading the 2 KiB image end to end; A buffer-addressed (32-bit offsets).
 template <int MT, int NT, int KIND, bool UA, bool UB, bool BL = false>
 __global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
   constexpr bool INT = KIND == 0, HF8 = KIND == 2;
@@ -4710,9 +4660,12 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     const bool fp8 = a.a_type == LIBXSMM_DATATYPE_BF8 || a.a_type == LIBXSMM_DATATYPE_HF8;
     if (fp8 && a.c_type != LIBXSMM_DATATYPE_F32 && (a.colbias || a.act || a.vnni_c)) return false;
     if ((a.k & 3) || a.k <= 0) return false;
+    const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8;
+    // packed operand blocks of several tiles: one problem per workgroup, whole problem in LDS (gemm_wgp16_kernels.hip, round 5); an error of that launch is left
+    // for the hipGetLastError() behind the switch
+    { int taken = 0; (void)launch_gemm_wgp8(a, fp8 ? (a.a_type == LIBXSMM_DATATYPE_HF8 ? 2 : 1) : 0, ua, ub, stream, kernel_name, &taken); if (taken) return true; }
     grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
     if (kernel_name) *kernel_name = big ? "gemm_mfma_8bit_kernel<2,2>" : "gemm_mfma_8bit_kernel<1,1>";
-    const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8;
     // strided forms whose blocks, rows and columns start on dwords: B through LDS (see the kernel); LIBXSMM_HIP_M8_LDS=0 keeps B in registers (measurement switch)
     static const bool lds_off = []() { const char* e = getenv("LIBXSMM_HIP_M8_LDS"); return e && e[0] == '0'; }();
     const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |

@@ -23,6 +23,7 @@
 #include "internal.hpp"
 #include "gemm_device.hpp"
 #include "gemm_tile.hpp"
+#include "gemm_8bit.hpp"
 
 #pragma clang fp contract(off)
 
@@ -40,7 +41,7 @@ struct Wgp16Geo {
 // one f32 scale per row) -- the A block is a BYTE image ([k/2][m][2] or [k][m], lda == m) that comes in as a linear copy (whole 16-byte pieces of the packed block) and is
 // turned into the bf16 pairs the reference multiplies with on the way out of LDS (w8_pair_to_bf16: exact for the 8-bit floats, one rounding for the scaled int8).
 template <bool F16, int TPW, int AK = -1>
-__global__ __launch_bounds__(256) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g) {
+__global__ __launch_bounds__(256, TPW == 3 ? 5 : 1) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave: 120 registers = four waves per SIMD without the bound)
   extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
   constexpr unsigned int TS = 4u;                                 // the four waves of the workgroup share the problem
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -185,6 +186,147 @@ int launch_gemm_wgp16(const GemmArgs& a_in, void* stream, const char** kernel_na
   else { if (tpw == 1) WGP_(false, 1); else if (tpw == 2) WGP_(false, 2); else WGP_(false, 3); }
 #undef WGP_
   return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// 8-bit x 8-bit GEMMs (KIND 0: u8 / i8 -> i32 or scaled f32 on v_mfma_i32_32x32x32_i8; 1 / 2: BF8 / HF8 -> f32 on v_mfma_f32_32x32x16_*), the same form: one problem per
+// workgroup, both PACKED operand blocks (A in VNNI-4: [k/4][m] dwords, lda == m; B flat: [n][k] bytes, ldb == k) brought in as linear copies, the products and signedness
+// corrections of gemm_mfma_8bit_kernel (m8_products) fed from LDS: A as four ds_read_b32 (the k quads of my row), B as eight-byte reads of my column (k % 8 == 0 keeps
+// them aligned).  A k quad beyond k is zeroed on both sides after the unsigned -> signed shift, exactly as in the wave-per-tile kernel.  C: i32 / f32 (the 8-bit float
+// result types stay with the wave-per-tile kernel).
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+template <int KIND, bool UA, bool UB, int TPW>
+__global__ __launch_bounds__(256, TPW == 3 ? 5 : 1) void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave with an unsigned operand: 132 registers without the bound = three waves per SIMD)
+  constexpr bool INT = KIND == 0;
+  extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
+  constexpr unsigned int TS = 4u;
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int bidx = blockIdx.x;
+  const BatchPtrs q = batch_ptrs(p, bidx);
+  char* const img_a = lds_wgp;
+  char* const img_b = img_a + g.a_img;
+  const unsigned int ntiles = (unsigned int)(p.tiles_m * p.tiles_n);
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  i32x16 iacc[TPW][INT ? 1 : 1][1];
+  f32x16 facc[TPW][1][1];
+  int sum_a[TPW][1], sum_b[TPW][1];
+  TileCtx tc[TPW];
+  static_for<TPW>([&](auto tt) {
+    constexpr int t = tt.value;
+    const unsigned int id = w + TS * (unsigned int)t;
+    const unsigned int tj = id / (unsigned int)p.tiles_m, ti = id - tj * (unsigned int)p.tiles_m;
+    tc[t].i = (int)(32u * ti + li); tc[t].j0 = (int)(32u * tj); tc[t].h = (int)h; tc[t].ivalid = tc[t].i < p.m;
+    iacc[t][0][0] = (i32x16)0; sum_a[t][0] = 0; sum_b[t][0] = 0;
+    if (!INT && id < ntiles) tile_init<false, true>(facc[t][0][0], p, q, tc[t]);
+  });
+  const unsigned int m = (unsigned int)p.m, k = (unsigned int)p.k;
+  const unsigned int kquads = k >> 2, kchunks = (k + 31u) >> 5;
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    if (r != 0) wg_barrier();
+    for (unsigned int x = w; x * 64u < g.a_pieces; x += TS) {
+      const unsigned int P = 64u * x + lane;
+      if (P < g.a_pieces) __builtin_amdgcn_global_load_lds((GM const void*)(ar + 16ull * P), (lds_vptr)(img_a + 1024u * x), 16, 0, 0);
+    }
+    for (unsigned int x = w; x * 64u < g.b_pieces; x += TS) {
+      const unsigned int P = 64u * x + lane;
+      if (P < g.b_pieces) __builtin_amdgcn_global_load_lds((GM const void*)(br + 16ull * P), (lds_vptr)(img_b + 1024u * x), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    static_for<TPW>([&](auto tt) {
+      constexpr int t = tt.value;
+      const unsigned int id = w + TS * (unsigned int)t;
+      if (id < ntiles) {
+        const unsigned int tj = id / (unsigned int)p.tiles_m, ti = id - tj * (unsigned int)p.tiles_m;
+        const unsigned int* const arow = (const unsigned int*)img_a + 32u * ti + li;                 // + kq * m
+        const unsigned int j = 32u * tj + li;
+        const bool iok = tc[t].ivalid, jok = j < (unsigned int)p.n;
+        const unsigned int* const bcol = (const unsigned int*)(img_b + (size_t)(jok ? j : 0u) * k);      // dword q of my column = bytes 4 q .. (k % 8 == 0: 8-byte aligned)
+        for (unsigned int kc = 0; kc < kchunks; ++kc) {
+          unsigned int aw[1][4], bw[1][4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned int kq = INT ? 8u * kc + 4u * h + (unsigned int)e : 8u * kc + 4u * ((unsigned int)e >> 1) + 2u * h + ((unsigned int)e & 1u);
+            const bool kok = kq < kquads;
+            const unsigned int kqc = kok ? kq : 0u;
+            unsigned int av = arow[kqc * m], bv = bcol[kqc];
+            if (INT && UA) av ^= 0x80808080u;
+            if (INT && UB) bv ^= 0x80808080u;
+            aw[0][e] = (kok && iok) ? av : 0u;
+            bw[0][e] = (kok && jok) ? bv : 0u;
+          }
+          m8_products<1, 1, KIND, UA, UB>(aw, bw, iacc[t], facc[t], sum_a[t], sum_b[t]);
+        }
+      }
+    });
+  }
+  if constexpr (INT) {
+    const bool c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+    const int kconst = (UA && UB) ? 16384 * (int)(p.br_count * (unsigned long long)p.k) : 0;
+    static_for<TPW>([&](auto tt) {
+      constexpr int t = tt.value;
+      // (every wave executes the exchanges, also for a tile it does not own: ds_bpermute needs all lanes)
+      int sb = sum_b[t][0], sa = sum_a[t][0];
+      if constexpr (UA) sb += __builtin_amdgcn_ds_bpermute(4 * (int)(lane ^ 32u), sb);           // both k halves of a column: lane j + lane j + 32
+      if constexpr (UB) sa += __builtin_amdgcn_ds_bpermute(4 * (int)(lane ^ 32u), sa);
+      const bool mine = w + TS * (unsigned int)t < ntiles;
+#pragma unroll
+      for (int r2 = 0; r2 < 16; ++r2) {
+        const int jl = jl_of(r2, (int)h), j = tc[t].j0 + jl;
+        int v = iacc[t][0][0][r2] + kconst;
+        if constexpr (UA) v += 128 * __builtin_amdgcn_ds_bpermute(4 * jl, sb);                   // the sum of column jl lives in lane jl
+        if constexpr (UB) v += 128 * sa;
+        if (!(mine && tc[t].ivalid && j < p.n)) continue;
+        GM char* cp = (GM char*)q.c + 4ll * ((long long)j * p.ldc + tc[t].i);
+        if (c_f32) { float f = mul_rn((float)v, p.scf); if (!beta0) f = add_rn(f, *(GM const float*)cp); *(GM float*)cp = f; }
+        else { if (!beta0) v += *(GM const int*)cp; *(GM int*)cp = v; }
+      }
+    });
+  } else {
+    static_for<TPW>([&](auto tt) { constexpr int t = tt.value; if (w + TS * (unsigned int)t < ntiles) tile_store<false, true, false>(facc[t][0][0], p, q, tc[t]); });
+  }
+}
+
+// kind: 0 integers (ua / ub: the operand is unsigned), 1 BF8, 2 HF8 -- launch_gemm's P_M8 case; packed blocks only (lda == m, ldb == k)
+int launch_gemm_wgp8(const GemmArgs& a_in, int kind, bool ua, bool ub, void* stream, const char** kernel_name, int* taken) {
+  *taken = 0;
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '0'; }();
+  const GemmArgs& a = a_in;
+  if (off || kind < 0 || kind > 2) return 0;
+  if (a.batch_inner || a.list_a || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || a.colbias || a.act) return 0;
+  if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return 0;
+  if (a.c_type != LIBXSMM_DATATYPE_F32 && a.c_type != LIBXSMM_DATATYPE_I32) return 0;
+  if ((a.m & 3) || (a.k & 7) || a.lda != a.m || a.ldb != a.k || a.k <= 0) return 0;
+  const long long abytes = (long long)a.m * a.k, bbytes = (long long)a.n * a.k;
+  if ((abytes & 15) || (bbytes & 15)) return 0;
+  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
+    (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0);
+  if (bits & 15ull) return 0;
+  if ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c) & 3ull) != 0ull) return 0;
+  const int tiles = ((a.m + 31) / 32) * ((a.n + 31) / 32);
+  if (tiles < 2 || tiles > 12) return 0;
+  Wgp16Geo g; g.rp = (unsigned int)a.m; g.ppr = 0; g.ppc = 0;
+  g.a_pieces = (unsigned int)(abytes / 16); g.b_pieces = (unsigned int)(bbytes / 16);
+  g.a_img = ((g.a_pieces + 63u) / 64u) * 1024u;
+  const unsigned int lds_bytes = g.a_img + ((g.b_pieces + 63u) / 64u) * 1024u;
+  if (lds_bytes > 64u * 1024u) return 0;
+  const int tpw = (tiles + 3) / 4;
+  GemmArgs b = a_in;
+  b.tiles_m = (a.m + 31) / 32; b.tiles_n = (a.n + 31) / 32; b.map2d_shift = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(a.nbatch), block(256);
+  *taken = 1;
+  if (kernel_name) *kernel_name = "gemm_8bit_wgp_kernel";
+#define WGP8_(K_, UA_, UB_, T_) hipLaunchKernelGGL((gemm_wgp8_kernel<K_, UA_, UB_, T_>), grid, block, lds_bytes, st, b, g)
+#define WGP8T_(K_, UA_, UB_) do { if (tpw == 1) WGP8_(K_, UA_, UB_, 1); else if (tpw == 2) WGP8_(K_, UA_, UB_, 2); else WGP8_(K_, UA_, UB_, 3); } while (0)
+  if (kind == 0) { if (ua && ub) WGP8T_(0, true, true); else if (ua) WGP8T_(0, true, false); else if (ub) WGP8T_(0, false, true); else WGP8T_(0, false, false); }
+  else if (kind == 1) WGP8T_(1, false, false);
+  else WGP8T_(2, false, false);
+#undef WGP8T_
+#undef WGP8_
+  return (int)hipPeekAtLastError();
 }
 
 // 8-bit weights x bf16 activations on ragged / several-tile shapes (kind as in launch_gemm's P_W8 case); plain strided batches, one block per problem or STRIDE chains

@@ -462,6 +462,11 @@ SHAPES_I8 = [
     dict(m=32, n=32, k=64, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_ADDRESS, br_count=3, batch=1),
     dict(m=64, n=64, k=64, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=4, beta=1, batch=1),
     dict(m=32, n=32, k=64, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, ldb=68, batch=3),                                  # whole tiles, B columns 4-byte aligned only
+    # round 5: packed blocks of several tiles, one problem per workgroup out of LDS (gemm_wgp8_kernel): nine tiles, a k tail of 8, every signedness, scaled f32, chains
+    dict(m=72, n=72, k=72, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, batch=9),
+    dict(m=72, n=72, k=72, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, beta=1, br_type=capi.BR_STRIDE, br_count=2, batch=5),
+    dict(m=72, n=40, k=48, a_type=DT.U8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.25, beta=1, batch=6),
+    dict(m=44, n=100, k=16, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, batch=3),
 ]
 
 
@@ -476,7 +481,12 @@ def test_int8_gemm_is_bit_identical(kw):
     vnni = bool(kw.get("flags", 0) & F.VNNI_A)
     exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and vnni and kw.get("ldb", 0) % 16 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
     assert ("gemm_i8_stream_kernel" in name) == bool(exact), name
-    assert ("gemm_mfma_8bit_kernel" in name) == bool(vnni and not exact and kw["k"] % 4 == 0), name          # nothing with whole k-quads is left on the one-element-per-thread kernel
+    # nothing with whole k-quads is left on the one-element-per-thread kernel; round 5: packed blocks of several tiles run as one problem per workgroup out of LDS
+    assert ("gemm_mfma_8bit_kernel" in name or "gemm_8bit_wgp_kernel" in name) == bool(vnni and not exact and kw["k"] % 4 == 0), name
+    packed = kw.get("lda", kw["m"]) == kw["m"] and kw.get("ldb", kw["k"]) == kw["k"] and kw["m"] % 4 == 0 and kw["k"] % 8 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
+    tiles = ((kw["m"] + 31) // 32) * ((kw["n"] + 31) // 32)
+    if vnni and not exact and packed and 2 <= tiles <= 12 and (kw["m"] * kw["k"]) % 16 == 0 and (kw["n"] * kw["k"]) % 16 == 0:
+        assert "gemm_8bit_wgp_kernel" in name, name
     # unsupported combinations return NULL like the reference's dispatcher
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 64, 32, 64, 32, DT.I8, DT.I8, DT.I32, DT.I32), F.VNNI_A | F.TRANS_A, 0) is None
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 64, 32, 64, 32, DT.I8, DT.I8, DT.F32, DT.I32), 0, 0) is None      # f32 output needs VNNI-4 A
@@ -501,6 +511,9 @@ SHAPES_FP8 = [
     dict(m=64, n=64, k=64, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_OFFSET, br_count=4, beta=1, batch=1),
     dict(m=12, n=10, k=7, a_type=DT.HF8, c_type=DT.F32),
     dict(m=13, n=11, k=8, a_type=DT.HF8, c_type=DT.F32, flags=F.TRANS_B),
+    # round 5: packed blocks of several tiles on gemm_wgp8_kernel
+    dict(m=72, n=72, k=72, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, batch=9),
+    dict(m=72, n=40, k=48, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, br_type=capi.BR_STRIDE, br_count=3, batch=5),
 ]
 
 
@@ -515,7 +528,7 @@ def test_fp8_gemm_matches_oracle(kw):
     exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and vnni and kw.get("ldb", 0) % 16 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
     assert ("gemm_fp8_stream_kernel" in name) == bool(exact), name
     masked = vnni and not exact and kw["k"] % 4 == 0
-    assert ("gemm_mfma_8bit_kernel" in name) == bool(masked), name
+    assert ("gemm_mfma_8bit_kernel" in name or "gemm_8bit_wgp_kernel" in name) == bool(masked), name
     if exact or masked:     # products of 8-bit floats are exact in f32; the reference's bound for f32 output (gemm_kernel.c:5408) holds
         assert normf_rel(case.valid_region(ref), case.valid_region(got), DT.F32) < TOL_F32, name
     else:
