@@ -40,8 +40,21 @@ struct Wgp16Geo {
 // AK = -1: 16-bit A (VNNI-2 dwords).  AK = 0..4: 8-bit WEIGHTS x bf16 activations (KIND of gemm_w8_bf16_kernel: 0 / 1 BF8 / HF8 in VNNI-2 byte pairs, 2 / 3 flat, 4 int8 with
 // one f32 scale per row) -- the A block is a BYTE image ([k/2][m][2] or [k][m], lda == m) that comes in as a linear copy (whole 16-byte pieces of the packed block) and is
 // turned into the bf16 pairs the reference multiplies with on the way out of LDS (w8_pair_to_bf16: exact for the 8-bit floats, one rounding for the scaled int8).
+// Register bounds = waves per SIMD the compiler must leave room for (__launch_bounds__' second argument).  LDS never limits these kernels (6-20 KiB per workgroup of
+// 160 KiB); resident workgroups are what hides a problem's single round trip, so every form is bounded to the most waves that compile WITHOUT scratch:
+// one tile per wave 8 (<= 64 registers), two 6 (<= 80), three 5 (<= 96).  Measured: profiles/r05_wgp_bound5.jsonl (three tiles), r05_wgp_waves.jsonl (one / two).
+#ifndef WGP_W1
+#define WGP_W1 8
+#endif
+#ifndef WGP_W2
+#define WGP_W2 6
+#endif
+#ifndef WGP_W3
+#define WGP_W3 5
+#endif
+#define WGP_WAVES(T) ((T) == 3 ? WGP_W3 : (T) == 2 ? WGP_W2 : WGP_W1)
 template <bool F16, int TPW, int AK = -1>
-__global__ __launch_bounds__(256, TPW == 3 ? 5 : 1) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave: 120 registers = four waves per SIMD without the bound)
+__global__ __launch_bounds__(256, WGP_WAVES(TPW)) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave: 120 registers = four waves per SIMD without the bound)
   extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
   constexpr unsigned int TS = 4u;                                 // the four waves of the workgroup share the problem
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -196,7 +209,7 @@ int launch_gemm_wgp16(const GemmArgs& a_in, void* stream, const char** kernel_na
 // result types stay with the wave-per-tile kernel).
 // ------------------------------------------------------------------------------------------------------------------------------------------------------------
 template <int KIND, bool UA, bool UB, int TPW>
-__global__ __launch_bounds__(256, TPW == 3 ? 5 : 1) void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave with an unsigned operand: 132 registers without the bound = three waves per SIMD)
+__global__ __launch_bounds__(256, WGP_WAVES(TPW)) void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave with an unsigned operand: 132 registers without the bound = three waves per SIMD)
   constexpr bool INT = KIND == 0;
   extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
   constexpr unsigned int TS = 4u;
