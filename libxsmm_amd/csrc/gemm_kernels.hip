@@ -4661,7 +4661,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     if (fp8 && a.c_type != LIBXSMM_DATATYPE_F32 && (a.colbias || a.act || a.vnni_c)) return false;
     if ((a.k & 3) || a.k <= 0) return false;
     const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8;
-    // packed operand blocks of several tiles: one problem per workgroup, whole problem in LDS (gemm_wgp16_kernels.hip, round 5); an error of that launch is left
+    // packed operand blocks of several tiles: one problem per workgroup, whole problem in LDS (gemm_wgp8_kernels.hip, round 5); an error of that launch is left
     // for the hipGetLastError() behind the switch
     { int taken = 0; (void)launch_gemm_wgp8(a, fp8 ? (a.a_type == LIBXSMM_DATATYPE_HF8 ? 2 : 1) : 0, ua, ub, stream, kernel_name, &taken); if (taken) return true; }
     grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
@@ -4796,7 +4796,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else launch_f32<2, 2, GM_MASKED>(a, grid, st);
       break;
     case P_BF16_1x1:
-      // gemm_wgp16_kernels.hip (round 5): ragged shapes, and whole 32-tiles that are several tiles per problem (96^3 as nine waves that each fetched their own panels: 0.39)
+      // gemm_wgp.hpp (round 5): ragged shapes, and whole 32-tiles that are several tiles per problem (96^3 as nine waves that each fetched their own panels: 0.39)
       { int taken = 0; const int e = launch_gemm_wgp16(a, stream, kernel_name, &taken); if (taken) return e; }
       grid = wave_grid(32, 32);
       if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && bf16_stream_ok(a)) {       // the bf16 streaming kernel on IEEE halves
@@ -4824,7 +4824,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), grid, dim3(256), 0, st, a);
       break;
     case P_BF16_2x2:
-      if (!pl.exact) { int taken = 0; const int e = launch_gemm_wgp16(a, stream, kernel_name, &taken); if (taken) return e; }       // gemm_wgp16_kernels.hip (round 5)
+      if (!pl.exact) { int taken = 0; const int e = launch_gemm_wgp16(a, stream, kernel_name, &taken); if (taken) return e; }       // gemm_wgp.hpp (round 5)
       grid = wave_grid(64, 64);
       if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && a.m == 64 && a.n == 64 && !a.batch_inner && bf16_wg64_ok(a)) {
         a.map2d_shift = 0;
@@ -4925,6 +4925,8 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       const bool ok = !a.list_a && a.br_mode != 1 && a.br_mode != 2 && (bits & 15ull) == 0 && (abits & 3ull) == 0 && (long long)a.lda * a.k < (1ll << 31) && (long long)a.ldb * a.n < (1ll << 31);
       if (ok) {
         const bool hf8 = a.a_type == LIBXSMM_DATATYPE_HF8, big = pl.path == P_FP8_2x2;
+        // whole 32-tiles, several per problem (96^3: nine): one problem per workgroup out of LDS instead of nine waves that each fetch their own panels (gemm_wgp8_kernels.hip)
+        if (!big && a.m > 32 && a.n > 32) { int taken = 0; (void)launch_gemm_wgp8(a, hf8 ? 2 : 1, false, false, stream, kernel_name, &taken); if (taken) break; }
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
         if (a.c_type != LIBXSMM_DATATYPE_F32) {            // C in the operands' type: plain epilogue only
           if (a.colbias || a.act || a.vnni_c) goto fp8_generic;
@@ -5003,6 +5005,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       }
       if (ok && !i4 && !lowbit) {
         const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8, big = pl.path == P_I8_2x2;
+        if (!big && a.m > 32 && a.n > 32) { int taken = 0; (void)launch_gemm_wgp8(a, 0, ua, ub, stream, kernel_name, &taken); if (taken) break; }      // (as for the 8-bit floats above)
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
 #define LAUNCH_I8_(MT_, NT_) do { \
           if (!ua && !ub) hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, false, false>), grid, dim3(256), 0, st, a); \

@@ -64,23 +64,25 @@ struct TileCtx { int i; int j0; int h; bool ivalid; };
 __device__ __forceinline__ int jl_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // CF32: the C (and bias) datatype is known to be f32 at compile time (f32 kernels) -- drops the bf16 paths
-template <bool EXACT, bool CF32>
+// NOBIAS: the caller adds the column bias itself (gemm_wgp16_kernel: from an LDS image behind its first barrier) -- beta * C only
+template <bool EXACT, bool CF32, bool NOBIAS = false>
 __device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
   const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
   const int c_type = CF32 ? (int)LIBXSMM_DATATYPE_F32 : p.c_type;
-  if (beta0 && !p.colbias) {          // the streaming case: nothing to read
+  const bool colbias = !NOBIAS && p.colbias;
+  if (beta0 && !colbias) {          // the streaming case: nothing to read
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     return;
   }
   float bias = 0.0f;
-  if (p.colbias && (EXACT || t.ivalid)) bias = load_c_f32(q.d, t.i, c_type);
+  if (colbias && (EXACT || t.ivalid)) bias = load_c_f32(q.d, t.i, c_type);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int j = t.j0 + jl_of(r, t.h);
     float start = 0.0f;
     if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_c_f32(q.c, (long long)j * p.ldc + t.i, c_type);
-    acc[r] = p.colbias ? (beta0 ? bias : bias + start) : start;
+    acc[r] = colbias ? (beta0 ? bias : bias + start) : start;
   }
 }
 

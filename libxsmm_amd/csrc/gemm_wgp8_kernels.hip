@@ -1,0 +1,169 @@
+// gemm_wgp8_kernels.hip -- 8-bit x 8-bit GEMMs, one problem per workgroup out of LDS (the form of gemm_wgp.hpp; products and corrections of gemm_8bit.hpp)
+#include "gemm_wgp.hpp"
+
+namespace xamd {
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// 8-bit x 8-bit GEMMs (KIND 0: u8 / i8 -> i32 or scaled f32 on v_mfma_i32_32x32x32_i8; 1 / 2: BF8 / HF8 -> f32 on v_mfma_f32_32x32x16_*), the same form: one problem per
+// workgroup, both PACKED operand blocks (A in VNNI-4: [k/4][m] dwords, lda == m; B flat: [n][k] bytes, ldb == k) brought in as linear copies, the products and signedness
+// corrections of gemm_mfma_8bit_kernel (m8_products) fed from LDS: A as four ds_read_b32 (the k quads of my row), B as eight-byte reads of my column (k % 8 == 0 keeps
+// them aligned).  A k quad beyond k is zeroed on both sides after the unsigned -> signed shift, exactly as in the wave-per-tile kernel.  C: i32 / f32 (the 8-bit float
+// result types stay with the wave-per-tile kernel).
+// ------------------------------------------------------------------------------------------------------------------------------------------------------------
+// DEAL as in gemm_wgp16_kernel; a strip is ONE call of m8_products with MT x NT = 1 x TPW (a tile row: the A quads of my row feed TPW column tiles) or TPW x 1.
+template <int KIND, bool UA, bool UB, int TPW, int DEAL = 0>
+__global__ __launch_bounds__(256, (TPW == 3 && ((KIND == 0 && UA && UB) || (KIND != 0 && DEAL == 2))) ? 4 : WGP_WAVES(TPW))      // (u8 x u8 and column strips of 8-bit floats, three tiles: 2-3 registers short of five waves -- four instead of scratch)
+void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave with an unsigned operand: 132 registers without the bound = three waves per SIMD)
+  constexpr bool INT = KIND == 0;
+  constexpr int G = DEAL == 0 ? TPW : 1, MT = DEAL == 2 ? TPW : 1, NT = DEAL == 1 ? TPW : 1;      // G groups of MT x NT tiles; tile t = (group, mt, nt)
+  constexpr auto gi = [](int t) { return DEAL == 0 ? t : 0; };
+  constexpr auto mi = [](int t) { return DEAL == 2 ? t : 0; };
+  constexpr auto ni = [](int t) { return DEAL == 1 ? t : 0; };
+  extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
+  const unsigned int TS = (DEAL == 0 && TPW > 1) ? 4u : blockDim.x >> 6;
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
+  const unsigned int bidx = blockIdx.x;
+  const BatchPtrs q = batch_ptrs(p, bidx);
+  char* const img_a = lds_wgp;
+  char* const img_b = img_a + g.a_img;
+  const unsigned int tiles_m = (unsigned int)p.tiles_m, tiles_n = (unsigned int)p.tiles_n;
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  i32x16 iacc[G][INT ? MT : 1][INT ? NT : 1];
+  f32x16 facc[G][INT ? 1 : MT][INT ? 1 : NT];
+  int sum_a[G][MT], sum_b[G][NT];
+  TileCtx tc[TPW];
+  bool mine[TPW];
+  static_for<TPW>([&](auto tt) {
+    constexpr int t = tt.value;
+    unsigned int ti, tj;
+    mine[t] = wgp_tile_of<DEAL>(w, TS, (unsigned int)t, tiles_m, tiles_n, ti, tj);
+    tc[t].i = (int)(32u * ti + li); tc[t].j0 = (int)(32u * tj); tc[t].h = (int)h; tc[t].ivalid = tc[t].i < p.m;
+    if constexpr (INT) iacc[gi(t)][mi(t)][ni(t)] = (i32x16)0;
+    sum_a[gi(t)][mi(t)] = 0; sum_b[gi(t)][ni(t)] = 0;
+  });
+  auto init_tiles = [&]() {          // after the first block's requests (gemm_wgp.hpp)
+    static_for<TPW>([&](auto tt) { constexpr int t = tt.value;
+      if (!INT && mine[t]) tile_init<false, true>(facc[gi(t)][INT ? 0 : mi(t)][INT ? 0 : ni(t)], p, q, tc[t]); });
+  };
+  const unsigned int m = (unsigned int)p.m, k = (unsigned int)p.k;
+  const unsigned int kquads = k >> 2, kchunks = (k + 31u) >> 5;
+  auto issue = [&](unsigned long long r) {
+    gcptr ar, br; br_base(p, q, r, ar, br);
+    for (unsigned int x = w; x * 64u < g.a_pieces; x += TS) {
+      const unsigned int P = 64u * x + lane;
+      if (P < g.a_pieces) __builtin_amdgcn_global_load_lds((GM const void*)(ar + 16ull * P), (lds_vptr)(img_a + 1024u * x), 16, 0, 0);
+    }
+    for (unsigned int x = w; x * 64u < g.b_pieces; x += TS) {
+      const unsigned int P = 64u * x + lane;
+      if (P < g.b_pieces) __builtin_amdgcn_global_load_lds((GM const void*)(br + 16ull * P), (lds_vptr)(img_b + 1024u * x), 16, 0, 0);
+    }
+  };
+  if (p.br_count) issue(0);
+  init_tiles();
+  for (unsigned long long r = 0; r < p.br_count; ++r) {
+    if (r != 0) { wg_barrier(); issue(r); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wg_barrier();
+    static_for<G>([&](auto gg) {
+      constexpr int gr = gg.value;                                 // the group's first tile is tile gr (DEAL 0) / tile 0 (a strip)
+      if (mine[gr]) {
+        const unsigned int i0 = (unsigned int)tc[gr].i, j0 = (unsigned int)tc[gr].j0 + li;          // + 32 mt / + 32 nt inside a strip
+        for (unsigned int kc = 0; kc < kchunks; ++kc) {
+          unsigned int aw[MT][4], bw[NT][4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned int kq = INT ? 8u * kc + 4u * h + (unsigned int)e : 8u * kc + 4u * ((unsigned int)e >> 1) + 2u * h + ((unsigned int)e & 1u);
+            const bool kok = kq < kquads;
+            const unsigned int kqc = kok ? kq : 0u;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const unsigned int i = i0 + 32u * (unsigned int)mt;
+              unsigned int av = ((const unsigned int*)img_a)[kqc * m + i];             // k quad kq of my row
+              if (INT && UA) av ^= 0x80808080u;
+              aw[mt][e] = (kok && i < m) ? av : 0u;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const unsigned int j = j0 + 32u * (unsigned int)nt;
+              const bool jok = j < (unsigned int)p.n;
+              unsigned int bv = ((const unsigned int*)(img_b + (size_t)(jok ? j : 0u) * k))[kqc];      // dword q of my column = bytes 4 q .. (k % 8 == 0: 8-byte aligned)
+              if (INT && UB) bv ^= 0x80808080u;
+              bw[nt][e] = (kok && jok) ? bv : 0u;
+            }
+          }
+          m8_products<MT, NT, KIND, UA, UB>(aw, bw, iacc[gr], facc[gr], sum_a[gr], sum_b[gr]);
+        }
+      }
+    });
+  }
+  if constexpr (INT) {
+    const bool c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
+    const int kconst = (UA && UB) ? 16384 * (int)(p.br_count * (unsigned long long)p.k) : 0;
+    static_for<TPW>([&](auto tt) {
+      constexpr int t = tt.value;
+      // (every wave executes the exchanges, also for a tile it does not own: ds_bpermute needs all lanes)
+      int sb = sum_b[gi(t)][ni(t)], sa = sum_a[gi(t)][mi(t)];
+      if constexpr (UA) sb += __builtin_amdgcn_ds_bpermute(4 * (int)(lane ^ 32u), sb);           // both k halves of a column: lane j + lane j + 32
+      if constexpr (UB) sa += __builtin_amdgcn_ds_bpermute(4 * (int)(lane ^ 32u), sa);
+#pragma unroll
+      for (int r2 = 0; r2 < 16; ++r2) {
+        const int jl = jl_of(r2, (int)h), j = tc[t].j0 + jl;
+        int v = iacc[gi(t)][mi(t)][ni(t)][r2] + kconst;
+        if constexpr (UA) v += 128 * __builtin_amdgcn_ds_bpermute(4 * jl, sb);                   // the sum of column jl lives in lane jl
+        if constexpr (UB) v += 128 * sa;
+        if (!(mine[t] && tc[t].ivalid && j < p.n)) continue;
+        GM char* cp = (GM char*)q.c + 4ll * ((long long)j * p.ldc + tc[t].i);
+        if (c_f32) { float f = mul_rn((float)v, p.scf); if (!beta0) f = add_rn(f, *(GM const float*)cp); *(GM float*)cp = f; }
+        else { if (!beta0) v += *(GM const int*)cp; *(GM int*)cp = v; }
+      }
+    });
+  } else {
+    static_for<TPW>([&](auto tt) { constexpr int t = tt.value; if (mine[t]) tile_store<false, true, false>(facc[gi(t)][mi(t)][ni(t)], p, q, tc[t]); });
+  }
+}
+
+// kind: 0 integers (ua / ub: the operand is unsigned), 1 BF8, 2 HF8 -- launch_gemm's P_M8 case; packed blocks only (lda == m, ldb == k)
+int launch_gemm_wgp8(const GemmArgs& a_in, int kind, bool ua, bool ub, void* stream, const char** kernel_name, int* taken) {
+  *taken = 0;
+  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '0'; }();
+  const GemmArgs& a = a_in;
+  if (off || kind < 0 || kind > 2) return 0;
+  if (a.batch_inner || a.list_a || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || a.colbias || a.act) return 0;
+  if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return 0;
+  if (a.c_type != LIBXSMM_DATATYPE_F32 && a.c_type != LIBXSMM_DATATYPE_I32) return 0;
+  if ((a.m & 3) || (a.k & 7) || a.lda != a.m || a.ldb != a.k || a.k <= 0) return 0;
+  const long long abytes = (long long)a.m * a.k, bbytes = (long long)a.n * a.k;
+  if ((abytes & 15) || (bbytes & 15)) return 0;
+  const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
+    (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0);
+  if (bits & 15ull) return 0;
+  if ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c) & 3ull) != 0ull) return 0;
+  const int tiles = ((a.m + 31) / 32) * ((a.n + 31) / 32);
+  if (tiles < 2 || tiles > 12) return 0;
+  Wgp16Geo g; g.rp = (unsigned int)a.m; g.ppr = 0; g.ppc = 0; g.bias_off = 0; g.bias_dw = 0;
+  g.a_pieces = (unsigned int)(abytes / 16); g.b_pieces = (unsigned int)(bbytes / 16);
+  g.a_img = ((g.a_pieces + 63u) / 64u) * 1024u;
+  const unsigned int lds_bytes = g.a_img + ((g.b_pieces + 63u) / 64u) * 1024u;
+  if (lds_bytes > 64u * 1024u) return 0;
+  const int tpw = (tiles + 3) / 4;
+  GemmArgs b = a_in;
+  b.tiles_m = (a.m + 31) / 32; b.tiles_n = (a.n + 31) / 32; b.map2d_shift = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int deal = wgp_deal(b.tiles_m, b.tiles_n, tpw);
+  const dim3 grid(a.nbatch), block(64u * wgp_waves(b.tiles_m, b.tiles_n, deal));
+  *taken = 1;
+  if (kernel_name) *kernel_name = "gemm_8bit_wgp_kernel";
+#define WGP8_(K_, UA_, UB_, T_, D_) hipLaunchKernelGGL((gemm_wgp8_kernel<K_, UA_, UB_, T_, D_>), grid, block, lds_bytes, st, b, g)
+#define WGP8D_(K_, UA_, UB_, T_) do { if (deal == 1) WGP8_(K_, UA_, UB_, T_, 1); else if (deal == 2) WGP8_(K_, UA_, UB_, T_, 2); else WGP8_(K_, UA_, UB_, T_, 0); } while (0)
+#define WGP8T_(K_, UA_, UB_) do { if (tpw == 1) WGP8_(K_, UA_, UB_, 1, 0); else if (tpw == 2) WGP8D_(K_, UA_, UB_, 2); else WGP8D_(K_, UA_, UB_, 3); } while (0)
+  if (kind == 0) { if (ua && ub) WGP8T_(0, true, true); else if (ua) WGP8T_(0, true, false); else if (ub) WGP8T_(0, false, true); else WGP8T_(0, false, false); }
+  else if (kind == 1) WGP8T_(1, false, false);
+  else WGP8T_(2, false, false);
+#undef WGP8T_
+#undef WGP8D_
+#undef WGP8_
+  return (int)hipPeekAtLastError();
+}
+
+}  // namespace xamd

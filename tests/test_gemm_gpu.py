@@ -173,7 +173,10 @@ SHAPES_F16 = [
 RAGGED_16BIT = [
     dict(m=72, n=40, k=48, beta=1, br_type=capi.BR_STRIDE, br_count=4, c_type=DT.F32),      # wgp kernel: six tiles (two per wave), batch-reduce stages, f32 C with beta = 1
     dict(m=96, n=96, k=96),                                                                  # whole 32-tiles, nine per problem: three per wave
-    dict(m=44, n=100, k=16, ldc=48),                                                         # eight tiles, one short chunk
+    dict(m=44, n=100, k=16, ldc=48),                                                         # eight tiles, one short chunk (a tile column per wave)
+    dict(m=128, n=96, k=64, beta=1),                                                         # twelve tiles: four waves, a tile row of three each
+    dict(m=96, n=128, k=40, c_type=DT.F32),                                                  # twelve tiles: four waves, a tile column of three each
+    dict(m=160, n=64, k=32),                                                                 # ten tiles: round robin, three per wave
     dict(m=40, n=24, k=64, c_type=DT.F32),                                                   # f32 C through the LDS image of C
     dict(m=48, n=40, k=24, ldc=52),                                                          # padded C columns -> element stores (no C image)
     dict(m=36, n=36, k=8, beta=1),                                                           # beta = 1 (C read by tile_init, written through the image)
@@ -199,7 +202,7 @@ def test_ragged_16bit_shapes_on_the_masked_matrix_core_kernel(kw, dt):
         kw.pop("beta")                                                        # (halves with beta = 1: covered by SHAPES_F16; same kernel, its own epilogue)
     kw.setdefault("c_type", dt)
     name = _check(GemmCase(a_type=dt, flags=F.VNNI_A, batch=37, seed=77, **kw))
-    # round 5: shapes whose every 16-byte piece lies inside its operand block run as one problem per workgroup out of LDS (gemm_wgp16_kernels.hip), the rest on the wave-per-tile kernel
+    # round 5: shapes whose every 16-byte piece lies inside its operand block run as one problem per workgroup out of LDS (gemm_wgp.hpp), the rest on the wave-per-tile kernel
     whole_pieces = kw["m"] % 4 == 0 and kw["k"] % 8 == 0 and kw.get("lda", kw["m"]) % 4 == 0 and kw.get("ldb", kw["k"]) % 8 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
     tiles = ((kw["m"] + 31) // 32) * ((kw["n"] + 31) // 32)
     f16_own_epilogue = dt == DT.F16 and kw.get("beta")
@@ -268,6 +271,12 @@ FUSED = [
     dict(m=20, n=12, k=16, act=3, beta=1),
     dict(m=16, n=16, k=16, colbias=True, act=2),
     dict(m=64, n=64, k=32, colbias=True),
+    # round 5: several tiles per problem on the workgroup-per-problem kernel (start values fetched behind the first block's requests; tile rows per wave)
+    dict(m=72, n=72, k=72, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=1),
+    dict(m=72, n=72, k=72, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2, beta=1),
+    dict(m=72, n=40, k=48, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, act=3, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=96, n=96, k=96, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=1, beta=1),
+    dict(m=40, n=40, k=40, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2),
 ]
 
 
@@ -467,6 +476,11 @@ SHAPES_I8 = [
     dict(m=72, n=72, k=72, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, beta=1, br_type=capi.BR_STRIDE, br_count=2, batch=5),
     dict(m=72, n=40, k=48, a_type=DT.U8, b_type=DT.I8, c_type=DT.F32, flags=F.VNNI_A, scf=0.25, beta=1, batch=6),
     dict(m=44, n=100, k=16, a_type=DT.I8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, batch=3),
+    # whole 32-tiles, several per problem, m or n not a multiple of 64: the same kernel (tile rows / columns per wave)
+    dict(m=96, n=96, k=96, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, beta=1, batch=5),
+    dict(m=96, n=64, k=64, a_type=DT.I8, b_type=DT.U8, c_type=DT.F32, flags=F.VNNI_A, scf=0.5, br_type=capi.BR_STRIDE, br_count=2, batch=4),
+    dict(m=64, n=96, k=32, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, batch=3),
+    dict(m=128, n=96, k=64, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, batch=3),
 ]
 
 
@@ -480,9 +494,12 @@ def test_int8_gemm_is_bit_identical(kw):
     assert np.array_equal(case.valid_region(ref), case.valid_region(got)), name
     vnni = bool(kw.get("flags", 0) & F.VNNI_A)
     exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and vnni and kw.get("ldb", 0) % 16 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
-    assert ("gemm_i8_stream_kernel" in name) == bool(exact), name
+    several = exact and kw["m"] > 32 and kw["n"] > 32 and (kw["m"] % 64 or kw["n"] % 64) and not kw.get("lda") and not kw.get("ldb")      # packed, 32-tiles, several
+    assert ("gemm_i8_stream_kernel" in name) == bool(exact and not several), name
+    if several:
+        assert name == "gemm_8bit_wgp_kernel", name
     # nothing with whole k-quads is left on the one-element-per-thread kernel; round 5: packed blocks of several tiles run as one problem per workgroup out of LDS
-    assert ("gemm_mfma_8bit_kernel" in name or "gemm_8bit_wgp_kernel" in name) == bool(vnni and not exact and kw["k"] % 4 == 0), name
+    assert ("gemm_mfma_8bit_kernel" in name or "gemm_8bit_wgp_kernel" in name) == bool(vnni and (several or not exact) and kw["k"] % 4 == 0), name
     packed = kw.get("lda", kw["m"]) == kw["m"] and kw.get("ldb", kw["k"]) == kw["k"] and kw["m"] % 4 == 0 and kw["k"] % 8 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
     tiles = ((kw["m"] + 31) // 32) * ((kw["n"] + 31) // 32)
     if vnni and not exact and packed and 2 <= tiles <= 12 and (kw["m"] * kw["k"]) % 16 == 0 and (kw["n"] * kw["k"]) % 16 == 0:
@@ -514,6 +531,8 @@ SHAPES_FP8 = [
     # round 5: packed blocks of several tiles on gemm_wgp8_kernel
     dict(m=72, n=72, k=72, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, batch=9),
     dict(m=72, n=40, k=48, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, br_type=capi.BR_STRIDE, br_count=3, batch=5),
+    dict(m=96, n=96, k=96, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, batch=5),          # whole 32-tiles, nine per problem
+    dict(m=64, n=96, k=64, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2, batch=4),
 ]
 
 
@@ -526,8 +545,11 @@ def test_fp8_gemm_matches_oracle(kw):
     name = api.hip_kernel_name(handle, 1 if case.batch > 1 else 0).decode()
     vnni = bool(kw.get("flags", 0) & F.VNNI_A)
     exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and vnni and kw.get("ldb", 0) % 16 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
-    assert ("gemm_fp8_stream_kernel" in name) == bool(exact), name
-    masked = vnni and not exact and kw["k"] % 4 == 0
+    several = exact and kw["m"] > 32 and kw["n"] > 32 and (kw["m"] % 64 or kw["n"] % 64) and not kw.get("lda") and not kw.get("ldb")
+    assert ("gemm_fp8_stream_kernel" in name) == bool(exact and not several), name
+    if several:
+        assert name == "gemm_8bit_wgp_kernel", name
+    masked = vnni and (several or not exact) and kw["k"] % 4 == 0
     assert ("gemm_mfma_8bit_kernel" in name or "gemm_8bit_wgp_kernel" in name) == bool(masked), name
     if exact or masked:     # products of 8-bit floats are exact in f32; the reference's bound for f32 output (gemm_kernel.c:5408) holds
         assert normf_rel(case.valid_region(ref), case.valid_region(got), DT.F32) < TOL_F32, name

@@ -1,4 +1,4 @@
-"""A host model of the data movement of the one-problem-per-workgroup kernel for ragged 16-bit shapes (libxsmm_amd/csrc/gemm_wgp16_kernels.hip), no GPU.
+"""A host model of the data movement of the one-problem-per-workgroup kernel for ragged 16-bit shapes (libxsmm_amd/csrc/gemm_wgp.hpp), no GPU.
 
 The kernel brings a problem's two operand blocks into LDS as 16-byte pieces -- piece P of A = k-pair row P / ppr, rows 4 (P % ppr) .. + 3; piece P of B = column P / ppc,
 k 8 (P % ppc) .. + 7 -- with the lane-linear destination of a global -> LDS request (request x fills bytes 1024 x .. of its image, lane l the 16 bytes at 16 l), and
@@ -118,3 +118,59 @@ def _model_w8(m, n, k, flat, seed=1):
 def test_packed_byte_images_of_8bit_weights(m, k, flat):
     got, ref = _model_w8(m, 8, k, flat)
     assert np.array_equal(got, ref)
+
+
+# ---- which wave owns which tile (wgp_deal / wgp_waves / wgp_tile_of of gemm_wgp.hpp) ---------------------------------------------------------------------------------
+def _deal(tiles_m, tiles_n, tpw):
+    if tpw < 2:
+        return 0
+    if tiles_m in (3, 4) and tiles_n == tpw:
+        return 1                # a tile row per wave
+    if tiles_n in (3, 4) and tiles_m == tpw:
+        return 2                # a tile column per wave
+    return 0
+
+
+def _waves(tiles_m, tiles_n, deal):
+    n = tiles_m if deal == 1 else tiles_n if deal == 2 else tiles_m * tiles_n
+    return min(n, 4)
+
+
+def _tile_of(deal, w, nw, t, tiles_m, tiles_n):
+    if deal == 1:
+        return (w, t) if w < tiles_m and t < tiles_n else None
+    if deal == 2:
+        return (t, w) if t < tiles_m and w < tiles_n else None
+    tid = w + nw * t
+    return (tid % tiles_m, tid // tiles_m) if tid < tiles_m * tiles_n else None
+
+
+def test_every_tile_has_exactly_one_owner_and_strips_are_never_longer_than_round_robin():
+    for tiles_m in range(1, 13):
+        for tiles_n in range(1, 13):
+            tiles = tiles_m * tiles_n
+            if tiles < 2 or tiles > 12:
+                continue
+            tpw = (tiles + 3) // 4
+            deal = _deal(tiles_m, tiles_n, tpw)
+            nw = _waves(tiles_m, tiles_n, deal)
+            if deal == 0 and tpw > 1:
+                assert nw == 4          # the kernel's compile-time wave count of the round-robin deal with several tiles per wave
+            owners = {}
+            for w in range(nw):
+                mine = [_tile_of(deal, w, nw, t, tiles_m, tiles_n) for t in range(tpw)]
+                assert sum(x is not None for x in mine) <= tpw
+                for x in mine:
+                    if x is not None:
+                        assert x not in owners, (tiles_m, tiles_n, x)
+                        owners[x] = w
+            assert len(owners) == tiles, (tiles_m, tiles_n, deal, nw)
+            if deal:                    # a strip is as long as the round-robin deal's longest wave, and a strip wave has ALL its tpw tiles (the kernels multiply whole strips)
+                assert (tiles_n if deal == 1 else tiles_m) == tpw
+
+
+def test_the_shapes_the_strips_were_measured_on():
+    assert _deal(3, 3, 3) == 1 and _waves(3, 3, 1) == 3           # 72^3, 80^3, 96^3: three waves, a tile row each
+    assert _deal(2, 2, 1) == 0 and _waves(2, 2, 0) == 4           # 40^3 .. 64^3
+    assert _deal(2, 3, 2) == 2 and _waves(2, 3, 2) == 3           # 64 x 96: a tile column per wave
+    assert _deal(4, 3, 3) == 1 and _deal(3, 4, 3) == 2 and _deal(2, 5, 3) == 0
