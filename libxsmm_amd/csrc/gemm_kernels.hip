@@ -4639,6 +4639,11 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       }
       return (int)hipGetLastError();
     }
+    // round 5: what that plan does not hold (72^3 with beta = 1: three images next to the operands; deep K with wide n ...) ran on the wave-per-tile kernel at 0.19 of
+    // the roofline.  When rows of A and columns of B are whole 16-byte pieces: the blocks by LDS-DMA, K in chunks, one problem per workgroup (gemm_wgp_f32_kernels.hip:
+    // 0.43 - 0.48 there).  Where both apply the register-staged kernel is the faster one (72^3 0.51 against 0.41, 40^3 0.66 against 0.56: these shapes are as much
+    // matrix-pipe as memory bound, profiles/r05_wgp_f32.jsonl) and keeps its shapes.
+    { int taken = 0; const int e = launch_gemm_wgp_f32(a, stream, kernel_name, &taken); if (taken) return e; }
   }
   // bf16 in the other operand forms (flat / transposed A, transposed / VNNI B, VNNI C): operands re-laid out on the way out of a wave-private LDS image (round 4)
   { int af = 0, bf = 0;

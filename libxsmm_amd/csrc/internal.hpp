@@ -241,6 +241,7 @@ const char* gemm_f64_kernel_name(const libxsmm_gemm_descriptor& d);
 int launch_gemm_f32_wg64_sharedb(const GemmArgs& args, bool nt, void* stream, const char** kernel_name, int* taken);   // gemm_sharedb_kernels.hip: 64^3 f32, B shared by the batch
 int launch_gemm_p16w(const GemmArgs& args, bool nt, void* stream, const char** kernel_name, int* taken);
 int launch_gemm_wgp16(const GemmArgs& args, void* stream, const char** kernel_name, int* taken);
+int launch_gemm_wgp_f32(const GemmArgs& args, void* stream, const char** kernel_name, int* taken);      // gemm_wgp_f32_kernels.hip
 int launch_gemm_wgp8(const GemmArgs& args, int kind, bool ua, bool ub, void* stream, const char** kernel_name, int* taken);   // 8-bit x 8-bit (integers / BF8 / HF8), packed blocks
 int launch_gemm_wgp16_w8(const GemmArgs& args, int kind, void* stream, const char** kernel_name, int* taken);   // the same form for 8-bit weights x bf16 (kind: gemm_w8_bf16_kernel's KIND)   // gemm_wgp16_kernels.hip: ragged 16-bit shapes, one problem per workgroup, whole problem in LDS   // gemm_small_kernels.hip: 16^3 f32 / bf16, A by LDS-DMA
 const char* gemm_kernel_name(const libxsmm_gemm_descriptor& d, bool batched);
