@@ -835,6 +835,12 @@ __global__ __launch_bounds__(256) void gemm_f32_stream_kernel_lean(LeanF32Args p
 // partial tiles in slice order.  Round 2 ran the chain as 1024 waves of 4 blocks with one partial tile per wave (0.21 of the HBM roofline: a
 // quarter of the waves the chip wants, 4 MiB of partial sums written and read back); here br = 4096 is 4096 waves and 512 partial tiles.
 // f32, NN, whole 32 x 32 tiles, k % 32 == 0.  partial: [slice][n][m] f32.
+// Round 5, built, verified and NOT adopted (the review's "variant B in a single launch"; the patch is profiles/r05_variant_b_single_launch_not_adopted.patch, the numbers
+// profiles/r05_variant_b.jsonl): the sum over the slices in THIS launch -- arrival counters, two deterministic levels (the last workgroup of 16 slices adds the group up, the
+// last group adds the groups up and applies the epilogue), nobody waits.  With device-scope fences (__threadfence: write-back + invalidate of the XCD's whole L2 per
+// workgroup) br = 4096 went from 12.7 to 80 us; with every partial-tile access an agent-scope relaxed atomic (sc1: coherent line by line, no cache maintenance) 27 us; with
+// sixteen such loads in flight 17.3 us (br = 1024: 11.9 against 8.7, br = 65 536: 103 against 101).  Data that crosses the eight L2s inside a launch travels through memory
+// twice per level -- as long as a kernel boundary (4.8 us) -- so the second launch stays.
 // ------------------------------------------------------------------------------------------------
 #if !defined(XAMD_GEMM_SHARD)      // a plain (non-template) kernel: emitted by the main translation unit only
 __global__ __launch_bounds__(512) void gemm_f32_brchain_kernel(GemmArgs p, float* partial, unsigned int chunk, unsigned int nslices) {

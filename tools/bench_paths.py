@@ -42,6 +42,18 @@ def brgemm(api, m, dtype, batch, fused=0, br=1, beta=0):
     return w
 
 
+def variant_b(api, br):
+    """SURVEY 8(d) config #2 variant B: ONE strided f32 32^3 BRGEMM with a chain of `br` blocks (bench.variant_b), as a Work for tools/time_one.py"""
+    bw = bench.variant_b(api, DEV, br)
+    w = Work(api, f"variant B: one stride-BRGEMM f32 m=n=k=32 br={br}", bw.flops_per_step, bw.alg_bytes_per_step, bw.nsets, bw.step, bw.kernel)
+    w.keep = bw
+    w.kernels_per_launch = bw.kernels_per_launch
+    if br <= 8192:
+        w.verify = lambda: bool(bw.verify()[0])
+    w.hint = bw.hint
+    return w
+
+
 def blocked(api, dtype, m, ni, nj, br):
     """A blocked GEMM out of BRGEMM tiles (libxsmm_hip_gemm_batch_strided_2d): C(i, j) = sum_r A(i, r) B(r, j), (ni m) x (nj m) x (br m) -- the operand-reuse regime."""
     bw = bench.Workload(api, DEV, dtype, m, 0, br=br, mode="blocked", grid=(ni, nj))
