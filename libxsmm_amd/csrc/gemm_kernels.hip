@@ -4701,7 +4701,8 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       const bool big = pl.path == P_W8_2x2, va8 = (a.flags & LIBXSMM_GEMM_FLAG_VNNI_A) != 0;
       const int kind = a.a_type == LIBXSMM_DATATYPE_I8 ? 4 : ((a.a_type == LIBXSMM_DATATYPE_HF8 ? 1 : 0) + (va8 ? 0 : 2));
       // ragged / several-tile shapes with a packed weight block: one problem per workgroup out of LDS (gemm_wgp16_kernels.hip, round 5)
-      if ((a.m % 64) || (a.n % 64) || (a.k % 32)) { int taken = 0; const int e = launch_gemm_wgp16_w8(a, kind, stream, kernel_name, &taken); if (taken) return e; }
+      // (8-bit FLOAT weights also as whole 64-tiles: 64^3 0.66 -> 0.74; int8 weights with row scales stay with the LDS-B kernel there: 0.70 against 0.68)
+      if ((a.m % 64) || (a.n % 64) || (a.k % 32) || kind != 4) { int taken = 0; const int e = launch_gemm_wgp16_w8(a, kind, stream, kernel_name, &taken); if (taken) return e; }
       grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
       const int tw = big ? 64 : 32;
       const unsigned long long bbits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) | (unsigned long long)((long long)a.ldb * 2);
@@ -4835,6 +4836,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       else hipLaunchKernelGGL((gemm_mfma_bf16_kernel<1, 1, false>), grid, dim3(256), 0, st, a);
       break;
     case P_BF16_2x2:
+      // (whole 64-tiles stay with the 64^3-per-workgroup kernel: 0.735 against 0.753 at 65 536 problems but 0.61 against 0.53 at 4096, profiles/r05_wgp_pair.jsonl)
       if (!pl.exact) { int taken = 0; const int e = launch_gemm_wgp16(a, stream, kernel_name, &taken); if (taken) return e; }       // gemm_wgp.hpp (round 5)
       grid = wave_grid(64, 64);
       if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && a.m == 64 && a.n == 64 && !a.batch_inner && bf16_wg64_ok(a)) {
@@ -4937,7 +4939,8 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       if (ok) {
         const bool hf8 = a.a_type == LIBXSMM_DATATYPE_HF8, big = pl.path == P_FP8_2x2;
         // whole 32-tiles, several per problem (96^3: nine): one problem per workgroup out of LDS instead of nine waves that each fetch their own panels (gemm_wgp8_kernels.hip)
-        if (!big && a.m > 32 && a.n > 32) { int taken = 0; (void)launch_gemm_wgp8(a, hf8 ? 2 : 1, false, false, stream, kernel_name, &taken); if (taken) break; }
+        // (also whole 64-tiles -- 64^3 was one wave per problem: bf8 0.64 -> 0.76, i8 0.65 -> 0.75, profiles/r05_wgp_pair.jsonl; more than twelve tiles are not taken there)
+        if (a.m > 32 && a.n > 32) { int taken = 0; (void)launch_gemm_wgp8(a, hf8 ? 2 : 1, false, false, stream, kernel_name, &taken); if (taken) break; }
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
         if (a.c_type != LIBXSMM_DATATYPE_F32) {            // C in the operands' type: plain epilogue only
           if (a.colbias || a.act || a.vnni_c) goto fp8_generic;
@@ -5016,7 +5019,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       }
       if (ok && !i4 && !lowbit) {
         const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8, big = pl.path == P_I8_2x2;
-        if (!big && a.m > 32 && a.n > 32) { int taken = 0; (void)launch_gemm_wgp8(a, 0, ua, ub, stream, kernel_name, &taken); if (taken) break; }      // (as for the 8-bit floats above)
+        if (a.m > 32 && a.n > 32) { int taken = 0; (void)launch_gemm_wgp8(a, 0, ua, ub, stream, kernel_name, &taken); if (taken) break; }      // (as for the 8-bit floats above)
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
 #define LAUNCH_I8_(MT_, NT_) do { \
           if (!ua && !ub) hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, false, false>), grid, dim3(256), 0, st, a); \

@@ -296,8 +296,12 @@ static inline unsigned int wgp_waves(int tiles_m, int tiles_n, int deal) {
 }
 
 // strips of tiles (DEAL 1: a tile row per wave, 2: a tile column) when they are as short as the round-robin deal's longest wave
-static inline int wgp_deal(int tiles_m, int tiles_n, int tpw) {
+static inline int wgp_deal(int tiles_m, int tiles_n, int& tpw) {
   static const int forced = []() { const char* e = getenv("LIBXSMM_HIP_WGP_DEAL"); return e ? atoi(e) : -1; }();
+  // 2 x 2 tiles: TWO waves with a tile row each instead of four with a tile each -- half the waves to launch, the A fragment read once for two MFMAs, and a CU holds twelve
+  // problems instead of eight (40^3: bf16 0.60 -> 0.68, i8 0.57 -> 0.65, 8-bit weights 0.50 -> 0.61, profiles/r05_wgp_pair.jsonl; LIBXSMM_HIP_WGP_PAIR=0: four waves)
+  static const bool pair = []() { const char* e = getenv("LIBXSMM_HIP_WGP_PAIR"); return !(e && e[0] == '0'); }();
+  if (pair && tiles_m == 2 && tiles_n == 2 && forced != 0) { tpw = 2; return 1; }
   if (forced == 0 || tpw < 2) return 0;
   if ((tiles_m == 3 || tiles_m == 4) && tiles_n == tpw && forced != 2) return 1;
   if ((tiles_n == 3 || tiles_n == 4) && tiles_m == tpw) return 2;

@@ -1,4 +1,5 @@
 // gemm_wgp8_kernels.hip -- 8-bit x 8-bit GEMMs, one problem per workgroup out of LDS (the form of gemm_wgp.hpp; products and corrections of gemm_8bit.hpp)
+#include <algorithm>
 #include "gemm_wgp.hpp"
 
 namespace xamd {
@@ -42,9 +43,22 @@ void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave wi
     if constexpr (INT) iacc[gi(t)][mi(t)][ni(t)] = (i32x16)0;
     sum_a[gi(t)][mi(t)] = 0; sum_b[gi(t)][ni(t)] = 0;
   });
+  const bool c8 = !INT && p.c_type != LIBXSMM_DATATYPE_F32;       // C in the operands' 8-bit float type [ref: gemm ref :2511-2619] (see gemm_fp8_stream_kernel<.., C8>)
   auto init_tiles = [&]() {          // after the first block's requests (gemm_wgp.hpp)
     static_for<TPW>([&](auto tt) { constexpr int t = tt.value;
-      if (!INT && mine[t]) tile_init<false, true>(facc[gi(t)][INT ? 0 : mi(t)][INT ? 0 : ni(t)], p, q, tc[t]); });
+      if (!INT && mine[t]) {
+        f32x16& acc = facc[gi(t)][INT ? 0 : mi(t)][INT ? 0 : ni(t)];
+        if (!c8) tile_init<false, true>(acc, p, q, tc[t]);
+        else {
+#pragma unroll
+          for (int r2 = 0; r2 < 16; ++r2) {
+            const int j = tc[t].j0 + jl_of(r2, (int)h);
+            float v = 0.0f;
+            if (!beta0 && tc[t].ivalid && j < p.n) { const unsigned char b8 = ((GM const unsigned char*)q.c)[(long long)j * p.ldc + tc[t].i]; v = KIND == 2 ? hf8_to_f32(b8) : bf8_to_f32(b8); }
+            acc[r2] = v;
+          }
+        }
+      } });
   };
   const unsigned int m = (unsigned int)p.m, k = (unsigned int)p.k;
   const unsigned int kquads = k >> 2, kchunks = (k + 31u) >> 5;
@@ -118,8 +132,36 @@ void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave wi
         else { if (!beta0) v += *(GM const int*)cp; *(GM int*)cp = v; }
       }
     });
-  } else {
+  } else if (!c8) {
     static_for<TPW>([&](auto tt) { constexpr int t = tt.value; if (mine[t]) tile_store<false, true, false>(facc[gi(t)][mi(t)][ni(t)], p, q, tc[t]); });
+  } else {
+    // byte results: through an LDS image [n][m] of the whole problem (in place of the operand images) and out as 16-byte pieces of its columns when those are whole and
+    // aligned in memory -- sixteen one-byte stores per tile and lane are the bound otherwise (gemm_fp8_stream_kernel: 0.27 of the roofline that way)
+    const bool wide = !(m & 15u) && ((((unsigned long long)(size_t)q.c) | (unsigned long long)p.ldc) & 15ull) == 0ull;      // workgroup-uniform
+    if (wide) wg_barrier();                                       // everybody has read the operand images
+    static_for<TPW>([&](auto tt) { constexpr int t = tt.value;
+      if (mine[t]) {
+        const f32x16& acc = facc[gi(t)][mi(t)][ni(t)];
+#pragma unroll
+        for (int r2 = 0; r2 < 16; r2 += 2) {
+          const unsigned int two = f32x2_to_fp8_ref(acc[r2], acc[r2 + 1], KIND == 2);
+          const unsigned int ja = (unsigned int)(tc[t].j0 + jl_of(r2, (int)h)), jb = (unsigned int)(tc[t].j0 + jl_of(r2 + 1, (int)h)), i = (unsigned int)tc[t].i;
+          if (wide) {
+            if (i < m) { if (ja < (unsigned int)p.n) ((unsigned char*)lds_wgp)[ja * m + i] = (unsigned char)two; if (jb < (unsigned int)p.n) ((unsigned char*)lds_wgp)[jb * m + i] = (unsigned char)(two >> 8); }
+          } else if (i < m) {
+            if (ja < (unsigned int)p.n) ((GM unsigned char*)q.c)[(long long)ja * p.ldc + i] = (unsigned char)two;
+            if (jb < (unsigned int)p.n) ((GM unsigned char*)q.c)[(long long)jb * p.ldc + i] = (unsigned char)(two >> 8);
+          }
+        }
+      } });
+    if (wide) {
+      wg_barrier();
+      const unsigned int ppc = m >> 4, pieces = (unsigned int)p.n * ppc;
+      for (unsigned int P = threadIdx.x; P < pieces; P += blockDim.x) {
+        const unsigned int j = P / ppc, c16 = P - j * ppc;
+        *(GM u32x4*)((GM unsigned char*)q.c + (long long)j * p.ldc + 16u * c16) = *(const u32x4*)(lds_wgp + (size_t)j * m + 16u * c16);
+      }
+    }
   }
 }
 
@@ -131,22 +173,25 @@ int launch_gemm_wgp8(const GemmArgs& a_in, int kind, bool ua, bool ub, void* str
   if (off || kind < 0 || kind > 2) return 0;
   if (a.batch_inner || a.list_a || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || a.colbias || a.act) return 0;
   if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return 0;
-  if (a.c_type != LIBXSMM_DATATYPE_F32 && a.c_type != LIBXSMM_DATATYPE_I32) return 0;
+  const bool c8 = kind != 0 && a.c_type == a.a_type;              // 8-bit floats with a result of their own type
+  if (a.c_type != LIBXSMM_DATATYPE_F32 && a.c_type != LIBXSMM_DATATYPE_I32 && !c8) return 0;
+  if (kind != 0 && a.c_type == LIBXSMM_DATATYPE_I32) return 0;
   if ((a.m & 3) || (a.k & 7) || a.lda != a.m || a.ldb != a.k || a.k <= 0) return 0;
   const long long abytes = (long long)a.m * a.k, bbytes = (long long)a.n * a.k;
   if ((abytes & 15) || (bbytes & 15)) return 0;
   const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
     (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0);
   if (bits & 15ull) return 0;
-  if ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c) & 3ull) != 0ull) return 0;
+  if (!c8 && (((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c) & 3ull) != 0ull) return 0;
   const int tiles = ((a.m + 31) / 32) * ((a.n + 31) / 32);
   if (tiles < 2 || tiles > 12) return 0;
   Wgp16Geo g; g.rp = (unsigned int)a.m; g.ppr = 0; g.ppc = 0; g.bias_off = 0; g.bias_dw = 0;
   g.a_pieces = (unsigned int)(abytes / 16); g.b_pieces = (unsigned int)(bbytes / 16);
   g.a_img = ((g.a_pieces + 63u) / 64u) * 1024u;
-  const unsigned int lds_bytes = g.a_img + ((g.b_pieces + 63u) / 64u) * 1024u;
+  unsigned int lds_bytes = g.a_img + ((g.b_pieces + 63u) / 64u) * 1024u;
+  if (c8) lds_bytes = std::max(lds_bytes, (unsigned int)(((size_t)a.m * a.n + 15u) & ~(size_t)15u));      // the byte image of C takes the operands' place
   if (lds_bytes > 64u * 1024u) return 0;
-  const int tpw = (tiles + 3) / 4;
+  int tpw = (tiles + 3) / 4;
   GemmArgs b = a_in;
   b.tiles_m = (a.m + 31) / 32; b.tiles_n = (a.n + 31) / 32; b.map2d_shift = 0;
   hipStream_t st = (hipStream_t)stream;
