@@ -1159,6 +1159,10 @@ struct CoalesceQueue {
   uintptr_t low_bits = 0;                               // OR of all queued pointers: alignment of the lists
   std::unordered_map<uintptr_t, uintptr_t> index;       // queued C blocks by address / ec (built lazily, see coalesce_try)
   bool indexed = false;
+  unsigned int gen = 0;                                 // registry generation the queued handle belongs to (libxsmm_finalize on ANOTHER thread frees it)
+  // a thread that ends with calls still queued never launched them: results are defined after libxsmm_hip_sync() only (include/libxsmm_hip.h) -- say so instead of
+  // dropping them silently (no launch from a thread_local destructor: the thread's stream state may be gone already)
+  ~CoalesceQueue() { if (!a.empty() && libxsmm_verbosity != 0) std::fprintf(stderr, "LIBXSMM-AMD: a thread ended with %zu coalesced calls still queued (no libxsmm_hip_sync()): they were never launched\n", a.size()); }
 };
 thread_local CoalesceQueue t_queue;
 static const size_t kCoalesceCap = 65536;
@@ -1169,6 +1173,11 @@ void coalesce_flush() {
   std::vector<const void*> la, lb; std::vector<void*> lc;
   la.swap(q.a); lb.swap(q.b); lc.swap(q.c);             // the queue is empty before anything is launched: run_gemm's own flush hook finds nothing
   KernelCtx* k = q.k; q.k = nullptr;
+  if (q.gen != g_generation.load(std::memory_order_acquire)) {        // the registry (and this handle) was freed by libxsmm_finalize on another thread: nothing to launch through
+    la.clear(); lb.clear(); lc.clear(); q.a.swap(la); q.b.swap(lb); q.c.swap(lc);
+    set_error(-3, "coalesced calls dropped: libxsmm_finalize() ran on another thread while they were queued (libxsmm_hip_sync() first)");
+    return;
+  }
   libxsmm_gemm_param p; std::memset(&p, 0, sizeof(p));
   unsigned long long brc = q.br_count;
   p.op.tertiary = &brc; p.a.primary = const_cast<void*>(la[0]); p.b.primary = const_cast<void*>(lb[0]); p.c.primary = lc[0];
@@ -1240,7 +1249,7 @@ bool coalesce_try(KernelCtx* k, const void* param) {
     if (hazard) coalesce_flush();
   }
   if (q.a.empty()) {
-    q.k = k; q.br_count = brc; q.ea = ea; q.eb = eb; q.ec = ec;
+    q.k = k; q.gen = g_generation.load(std::memory_order_acquire); q.br_count = brc; q.ea = ea; q.eb = eb; q.ec = ec;
     q.cmin = pc; q.cmax = pc + ec; q.rmin = std::min(pa, pb); q.rmax = std::max(pa + ea, pb + eb); q.c_monotonic = true;
     q.strided = true; q.sa = q.sb = q.sc = 0; q.low_bits = 0; q.indexed = false;
   } else {

@@ -204,3 +204,39 @@ def test_coalescing_thread_under_stream_capture_launches_call_by_call():
         Cq.zero_(); g.replay(); torch.cuda.synchronize()
         assert torch.equal(Cq, G)
     api.hip_set_async(0); api.hip_set_stream(None)
+
+
+FINALIZE_CHILD = r"""
+import sys, threading
+sys.path.insert(0, %r)
+import numpy as np, torch
+from libxsmm_amd import capi
+from libxsmm_amd.capi import DT, GEMM_FLAG as F
+api = capi.load()
+m = 32
+A = torch.ones(m * m, dtype=torch.float32, device="cuda"); B = torch.ones(m * m, dtype=torch.float32, device="cuda"); Cs = torch.zeros(4 * m * m, dtype=torch.float32, device="cuda")
+queued, finalized, out = threading.Event(), threading.Event(), {}
+def worker():
+    h = api.dispatch_gemm(capi.gemm_shape(m, m, m, m, m, m, DT.F32, DT.F32, DT.F32, DT.F32), F.BETA_0, 0)
+    api.hip_set_async(2)
+    for i in range(4):
+        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = A.data_ptr(), B.data_ptr(), Cs.data_ptr() + 4 * m * m * i
+        capi.Api.call(h, p)                                  # queued, not launched
+    queued.set(); finalized.wait(30)
+    api.hip_sync()                                           # the flush finds the registry of another generation: the calls are dropped, with an error, without touching freed memory
+    out["error"] = api.hip_get_last_error()
+t = threading.Thread(target=worker); t.start()
+queued.wait(30); api.finalize(); finalized.set(); t.join(60)
+torch.cuda.synchronize()
+print("RESULT", out.get("error"), float(Cs.abs().sum().item()))
+"""
+
+
+def test_finalize_on_another_thread_drops_queued_calls_with_an_error():
+    """advisor (round 4, low): the queue is per thread and holds a raw handle context; libxsmm_finalize on another thread frees it.  The queue remembers the registry
+    generation of its handle and a flush of another generation drops the calls (sticky error -3) instead of launching through freed memory."""
+    import sys
+    r = subprocess.run([sys.executable, "-c", FINALIZE_CHILD % ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+    assert int(line[1]) == -3 and float(line[2]) == 0.0, r.stdout
