@@ -65,7 +65,7 @@ __device__ __forceinline__ int jl_of(int r, int h) { return (r & 3) + 8 * (r >> 
 
 // CF32: the C (and bias) datatype is known to be f32 at compile time (f32 kernels) -- drops the bf16 paths
 // NOBIAS: the caller adds the column bias itself (gemm_wgp16_kernel: from an LDS image behind its first barrier) -- beta * C only
-template <bool EXACT, bool CF32, bool NOBIAS = false>
+template <bool EXACT, bool CF32, bool NOBIAS = false, bool HOIST = false>
 __device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
   const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
   const int c_type = CF32 ? (int)LIBXSMM_DATATYPE_F32 : p.c_type;
@@ -77,12 +77,36 @@ __device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const 
   }
   float bias = 0.0f;
   if (colbias && (EXACT || t.ivalid)) bias = load_c_f32(q.d, t.i, c_type);
+  // HOIST (the workgroup-per-problem kernels): the datatype of C is decided ONCE, outside the loop over the tile's sixteen elements -- a per-element switch puts every load
+  // into a basic block of its own and the sixteen loads become sixteen memory round trips one after the other (bf16 72^3 with beta = 1: 0.28 of the roofline against
+  // 0.66 with beta = 0).  Not for the wave-per-tile kernels: sixteen addresses live at once cost them a third of their occupancy (gemm_bf16_stream_kernel<1,1>: 76 -> 144
+  // registers), also when beta = 0.
+  if constexpr (HOIST) {
+    float start[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int j = t.j0 + jl_of(r, t.h);
-    float start = 0.0f;
-    if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_c_f32(q.c, (long long)j * p.ldc + t.i, c_type);
-    acc[r] = colbias ? (beta0 ? bias : bias + start) : start;
+    for (int r = 0; r < 16; ++r) start[r] = 0.0f;
+    if (!beta0) {
+      if (c_type == LIBXSMM_DATATYPE_F32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int j = t.j0 + jl_of(r, t.h); if (EXACT || (t.ivalid && j < p.n)) start[r] = ((GM const float*)q.c)[(long long)j * p.ldc + t.i]; }
+      } else if (c_type == LIBXSMM_DATATYPE_F16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int j = t.j0 + jl_of(r, t.h); if (EXACT || (t.ivalid && j < p.n)) start[r] = (float)((GM const _Float16*)q.c)[(long long)j * p.ldc + t.i]; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int j = t.j0 + jl_of(r, t.h); if (EXACT || (t.ivalid && j < p.n)) start[r] = bf16_to_f32(((GM const unsigned short*)q.c)[(long long)j * p.ldc + t.i]); }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = colbias ? (beta0 ? bias : bias + start[r]) : start[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = t.j0 + jl_of(r, t.h);
+      float start = 0.0f;
+      if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_c_f32(q.c, (long long)j * p.ldc + t.i, c_type);
+      acc[r] = colbias ? (beta0 ? bias : bias + start) : start;
+    }
   }
 }
 

@@ -38,6 +38,7 @@ struct Wgp16Geo {
   unsigned int a_pieces, b_pieces;      // total pieces of one block
   unsigned int a_img;       // bytes of the A image (whole 1 KiB request slots)
   unsigned int bias_off, bias_dw;      // fused column bias: LDS offset of its image and its dwords (m elements of C's type; 0 = no bias)
+  unsigned int c_off, c_ppc, c_pieces; // beta = 1: LDS offset of the image of C ([n][m] elements, compact), 16-byte pieces per column, pieces in all (0 = C by element loads)
 };
 
 // AK = -1: 16-bit A (VNNI-2 dwords).  AK = 0..4: 8-bit WEIGHTS x bf16 activations (KIND of gemm_w8_bf16_kernel: 0 / 1 BF8 / HF8 in VNNI-2 byte pairs, 2 / 3 flat, 4 int8 with
@@ -59,7 +60,7 @@ struct Wgp16Geo {
 #define WGP_W3S 5
 #endif
 #define WGP_WAVES(T) ((T) == 3 ? WGP_W3 : (T) == 2 ? WGP_W2 : WGP_W1)
-#define WGP_WAVES_D(T, D, AK) ((T) == 3 && (D) == 1 ? ((AK) == 4 ? 6 : WGP_W3S) : WGP_WAVES(T))      // (int8 weights with row scales: six waves with two spilled registers measured faster)
+#define WGP_WAVES_D(T, D, AK) ((T) == 3 && (D) == 1 ? ((AK) == 4 ? 6 : WGP_W3S) : ((T) == 2 && (D) == 0 && (AK) >= 0) ? 5 : WGP_WAVES(T))      // (int8 weights with row scales: six waves with two spilled registers measured faster)
 // Which tiles a wave owns.  DEAL 0: round robin (tile w + 4 t).  DEAL 1: wave w owns tile ROW w, its tiles t are the tile columns -- one A fragment per k step feeds all of
 // them.  DEAL 2: wave w owns tile COLUMN w (one B fragment).  The strips are chosen by the launcher when they do not lengthen the critical path (3 or 4 strips of
 // ceil(tiles / 4) tiles: 72^3 and 96^3 are 3 x 3 -- three waves with a row each instead of 3 + 3 + 2 + 1 tiles with nothing in common).
@@ -103,12 +104,32 @@ __global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_ke
         if (F16) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        } else tile_init<false, false, true>(acc[t], p, q, tc[t]);
+        } else tile_init<false, false, true, true>(acc[t], p, q, tc[t]);
       }
     });
   };
-  auto init_bias = [&]() {                                         // behind the first barrier: bias (+ beta * C), the order of tile_init
-    if (F16 || !g.bias_dw) return;
+  auto init_bias = [&]() {                                         // behind the first barrier: C from its LDS image, bias (+ beta * C) in the order of tile_init
+    if (F16) return;
+    if (g.c_pieces) {
+      const unsigned int m = (unsigned int)p.m;
+      static_for<TPW>([&](auto tt) {
+        constexpr int t = tt.value;
+        if (mine[t]) {
+          const char* img = lds_wgp + g.c_off;
+          if (p.c_type == LIBXSMM_DATATYPE_F32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const unsigned int j = (unsigned int)(tc[t].j0 + jl_of(r, tc[t].h)); acc[t][r] = (tc[t].ivalid && j < (unsigned int)p.n) ? ((const float*)img)[j * m + (unsigned int)tc[t].i] : 0.0f; }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const unsigned int j = (unsigned int)(tc[t].j0 + jl_of(r, tc[t].h)); acc[t][r] = (tc[t].ivalid && j < (unsigned int)p.n) ? bf16_to_f32(((const unsigned short*)img)[j * m + (unsigned int)tc[t].i]) : 0.0f; }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        }
+      });
+    }
+    if (!g.bias_dw) return;
     static_for<TPW>([&](auto tt) {
       constexpr int t = tt.value;
       if (mine[t]) {
@@ -153,7 +174,18 @@ __global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_ke
       if (P < g.bias_dw) __builtin_amdgcn_global_load_lds((GM const void*)(q.d + 4ull * P), (lds_vptr)(lds_wgp + g.bias_off + 256u * x), 4, 0, 0);
     }
   }
-  init_start();
+  // beta = 1: C comes in like the operands -- whole 16-byte pieces of its columns by LDS-DMA (72^3 bf16: ten requests per workgroup instead of 432 two-byte loads, which
+  // kept the address unit busy for three times the kernel's beta = 0 duration: 0.28 of the roofline, profiles/r05_wgp_beta1.jsonl)
+  if (g.c_pieces) {
+    const unsigned int ces = p.c_type == LIBXSMM_DATATYPE_F32 ? 4u : 2u;
+    for (unsigned int x = w; x * 64u < g.c_pieces; x += TS) {
+      const unsigned int P = 64u * x + lane;
+      if (P < g.c_pieces) {
+        const unsigned int col = P / g.c_ppc, pc = P - col * g.c_ppc;
+        __builtin_amdgcn_global_load_lds((GM const void*)((gcptr)q.c + (unsigned long long)col * (unsigned int)p.ldc * ces + 16u * pc), (lds_vptr)(lds_wgp + g.c_off + 1024u * x), 16, 0, 0);
+      }
+    }
+  } else init_start();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wg_barrier();
   init_bias();                                                   // (an empty chain: C = beta * C (+ bias))
@@ -281,6 +313,16 @@ static inline bool wgp16_shape_ok(const GemmArgs& a, Wgp16Geo& g, unsigned int& 
     const unsigned int es = a.c_type == LIBXSMM_DATATYPE_F32 ? 4u : 2u;
     g.bias_off = lds_bytes; g.bias_dw = (unsigned int)a.m * es / 4u;
     lds_bytes += ((g.bias_dw + 63u) / 64u) * 256u;
+  }
+  g.c_off = 0; g.c_ppc = 0; g.c_pieces = 0;
+  if (!(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && (a.c_type == LIBXSMM_DATATYPE_F32 || a.c_type == LIBXSMM_DATATYPE_BF16)) {       // beta = 1: C as whole 16-byte pieces of its columns (else: element loads)
+    const unsigned int ces = a.c_type == LIBXSMM_DATATYPE_F32 ? 4u : 2u;
+    const unsigned long long cbits = (unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.ldc * ces | (unsigned long long)a.m * ces;
+    const unsigned int c_img = ((((unsigned int)a.m * ces / 16u) * (unsigned int)a.n + 63u) / 64u) * 1024u;
+    if (!(cbits & 15ull) && lds_bytes + c_img <= 64u * 1024u) {
+      g.c_off = lds_bytes; g.c_ppc = (unsigned int)a.m * ces / 16u; g.c_pieces = g.c_ppc * (unsigned int)a.n;
+      lds_bytes += c_img;
+    }
   }
   if (lds_bytes > 64u * 1024u) return false;
   tpw = (tiles + 3) / 4;

@@ -185,7 +185,7 @@ int launch_gemm_wgp8(const GemmArgs& a_in, int kind, bool ua, bool ub, void* str
   if (!c8 && (((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c) & 3ull) != 0ull) return 0;
   const int tiles = ((a.m + 31) / 32) * ((a.n + 31) / 32);
   if (tiles < 2 || tiles > 12) return 0;
-  Wgp16Geo g; g.rp = (unsigned int)a.m; g.ppr = 0; g.ppc = 0; g.bias_off = 0; g.bias_dw = 0;
+  Wgp16Geo g; g.rp = (unsigned int)a.m; g.ppr = 0; g.ppc = 0; g.bias_off = 0; g.bias_dw = 0; g.c_off = 0; g.c_ppc = 0; g.c_pieces = 0;
   g.a_pieces = (unsigned int)(abytes / 16); g.b_pieces = (unsigned int)(bbytes / 16);
   g.a_img = ((g.a_pieces + 63u) / 64u) * 1024u;
   unsigned int lds_bytes = g.a_img + ((g.b_pieces + 63u) / 64u) * 1024u;

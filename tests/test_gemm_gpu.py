@@ -177,6 +177,9 @@ RAGGED_16BIT = [
     dict(m=128, n=96, k=64, beta=1),                                                         # twelve tiles: four waves, a tile row of three each
     dict(m=96, n=128, k=40, c_type=DT.F32),                                                  # twelve tiles: four waves, a tile column of three each
     dict(m=160, n=64, k=32),                                                                 # ten tiles: round robin, three per wave
+    dict(m=40, n=40, k=40, beta=1, ldc=48),                                                  # beta = 1: C by 16-byte pieces through an LDS image (padded columns)
+    dict(m=40, n=40, k=40, beta=1, ldc=44),                                                  # ... columns that are not whole pieces in memory: element loads
+    dict(m=72, n=72, k=72, beta=1, br_type=capi.BR_STRIDE, br_count=2),                      # ... nine tiles, a chain
     dict(m=40, n=24, k=64, c_type=DT.F32),                                                   # f32 C through the LDS image of C
     dict(m=48, n=40, k=24, ldc=52),                                                          # padded C columns -> element stores (no C image)
     dict(m=36, n=36, k=8, beta=1),                                                           # beta = 1 (C read by tile_init, written through the image)
