@@ -342,6 +342,7 @@ static inline int wgp_deal(int tiles_m, int tiles_n, int& tpw) {
   static const int forced = []() { const char* e = getenv("LIBXSMM_HIP_WGP_DEAL"); return e ? atoi(e) : -1; }();
   // 2 x 2 tiles: TWO waves with a tile row each instead of four with a tile each -- half the waves to launch, the A fragment read once for two MFMAs, and a CU holds twelve
   // problems instead of eight (40^3: bf16 0.60 -> 0.68, i8 0.57 -> 0.65, 8-bit weights 0.50 -> 0.61, profiles/r05_wgp_pair.jsonl; LIBXSMM_HIP_WGP_PAIR=0: four waves)
+  // (ONE wave with the whole 2 x 2 block, no barrier at all, sixteen problems per CU: measured and not adopted -- 40^3 0.62 against 0.65, 48^3 0.65 against 0.70, same file)
   static const bool pair = []() { const char* e = getenv("LIBXSMM_HIP_WGP_PAIR"); return !(e && e[0] == '0'); }();
   if (pair && tiles_m == 2 && tiles_n == 2 && forced != 0) { tpw = 2; return 1; }
   if (forced == 0 || tpw < 2) return 0;

@@ -135,10 +135,10 @@ void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave wi
   } else if (!c8) {
     static_for<TPW>([&](auto tt) { constexpr int t = tt.value; if (mine[t]) tile_store<false, true, false>(facc[gi(t)][mi(t)][ni(t)], p, q, tc[t]); });
   } else {
-    // byte results: through an LDS image [n][m] of the whole problem (in place of the operand images) and out as 16-byte pieces (or dwords) of its columns when those are
+    // byte results: through an LDS image [n][m] of the whole problem (in place of the operand images) and out as 16-byte pieces of its columns when those are whole and
     // aligned in memory -- sixteen one-byte stores per tile and lane are the bound otherwise (gemm_fp8_stream_kernel: 0.27 of the roofline that way)
-    const unsigned long long cal = ((unsigned long long)(size_t)q.c) | (unsigned long long)p.ldc;
-    const bool wide16 = !(m & 15u) && (cal & 15ull) == 0ull, wide = wide16 || (cal & 3ull) == 0ull;      // workgroup-uniform; m % 4 == 0 always: dwords of a column at least
+    // (columns that are not whole 16-byte pieces -- 72^3 -- leave byte by byte: dwords out of the image measured SLOWER than the byte stores, 0.33 against 0.38, profiles/r05_wgp_pair.jsonl)
+    const bool wide = !(m & 15u) && ((((unsigned long long)(size_t)q.c) | (unsigned long long)p.ldc) & 15ull) == 0ull;      // workgroup-uniform
     if (wide) wg_barrier();                                       // everybody has read the operand images
     static_for<TPW>([&](auto tt) { constexpr int t = tt.value;
       if (mine[t]) {
@@ -157,18 +157,10 @@ void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave wi
       } });
     if (wide) {
       wg_barrier();
-      if (wide16) {
-        const unsigned int ppc = m >> 4, pieces = (unsigned int)p.n * ppc;
-        for (unsigned int P = threadIdx.x; P < pieces; P += blockDim.x) {
-          const unsigned int j = P / ppc, c16 = P - j * ppc;
-          *(GM u32x4*)((GM unsigned char*)q.c + (long long)j * p.ldc + 16u * c16) = *(const u32x4*)(lds_wgp + (size_t)j * m + 16u * c16);
-        }
-      } else {                                                    // (72^3: 18 dwords per column -- seven dword stores per thread instead of 48 byte stores per lane)
-        const unsigned int ppc = m >> 2, pieces = (unsigned int)p.n * ppc;
-        for (unsigned int P = threadIdx.x; P < pieces; P += blockDim.x) {
-          const unsigned int j = P / ppc, c4 = P - j * ppc;
-          *(GM unsigned int*)((GM unsigned char*)q.c + (long long)j * p.ldc + 4u * c4) = *(const unsigned int*)(lds_wgp + (size_t)j * m + 4u * c4);
-        }
+      const unsigned int ppc = m >> 4, pieces = (unsigned int)p.n * ppc;
+      for (unsigned int P = threadIdx.x; P < pieces; P += blockDim.x) {
+        const unsigned int j = P / ppc, c16 = P - j * ppc;
+        *(GM u32x4*)((GM unsigned char*)q.c + (long long)j * p.ldc + 16u * c16) = *(const u32x4*)(lds_wgp + (size_t)j * m + 16u * c16);
       }
     }
   }
