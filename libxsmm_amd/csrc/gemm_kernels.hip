@@ -4623,7 +4623,13 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     return (int)hipGetLastError();
   }
   // f32 shapes that are not whole 32 / 64 tiles, plain epilogue: persistent workgroups, operands staged in registers, 16 x 16 MFMA tiles
-  if ((pl.path == P_F32_1x1 || pl.path == P_F32_2x2) && !pl.exact) {
+  // (round 5: shapes of several WHOLE 16-tiles that are not whole 32-tiles -- 48^3, 32 x 48 ... -- ran a wave per 16-tile, nine waves per 48^3 problem that each fetched
+  //  their own panels: 0.49 of the HBM roofline.  The one-problem-per-workgroup kernel takes them like 40^3 and 56^3: 48^3 0.49 -> 0.73, batch 4096 0.41 -> 0.56, beta = 1
+  //  0.53 -> 0.70 (profiles/r05_t16_ragged.jsonl); LIBXSMM_HIP_T16_RAGGED=0: the wave-per-tile kernel)
+  static const bool t16_ragged = []() { const char* e = getenv("LIBXSMM_HIP_T16_RAGGED"); return !(e && e[0] == '0'); }();
+  // (whole 32-tiles that are several per problem -- 96^3, 128^3 -- stay a wave per tile: on gemm_wgp_f32_kernel 96^3 0.47 -> 0.49, 128^3 0.47 -> 0.37, r05_t16_ragged.jsonl:
+  //  the f32 matrix pipe is as busy as the memory there)
+  if (((pl.path == P_F32_1x1 || pl.path == P_F32_2x2) && !pl.exact) || (t16_ragged && pl.path == P_F32_T16 && (a.m > 16 || a.n > 16))) {
     RaggedCfg rc; int waves = 1, np = 1, rounds = 0; unsigned int lds_bytes = 0; bool single = false;
     if (f32_ragged_plan(a, rc, waves, np, rounds, lds_bytes, single)) {
       a.tiles_m = a.tiles_n = 1; a.map2d_shift = 0;

@@ -75,6 +75,11 @@ SHAPES = [
     dict(m=36, n=100, k=8, br_type=capi.BR_STRIDE, br_count=5, either=True),
     dict(m=64, n=120, k=52, beta=1, either=True),
     dict(m=112, n=112, k=112, wgp=True),
+    # round 5: several WHOLE 16-tiles that are not whole 32-tiles (they ran a wave per 16-tile)
+    dict(m=48, n=48, k=48),
+    dict(m=48, n=48, k=48, beta=1, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=32, n=48, k=16),
+    dict(m=48, n=16, k=64, beta=1),
 ]
 
 
