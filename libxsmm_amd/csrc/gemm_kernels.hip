@@ -4946,7 +4946,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         const bool hf8 = a.a_type == LIBXSMM_DATATYPE_HF8, big = pl.path == P_FP8_2x2;
         // whole 32-tiles, several per problem (96^3: nine): one problem per workgroup out of LDS instead of nine waves that each fetch their own panels (gemm_wgp8_kernels.hip)
         // (also whole 64-tiles -- 64^3 was one wave per problem: bf8 0.64 -> 0.76, i8 0.65 -> 0.75, profiles/r05_wgp_pair.jsonl; more than twelve tiles are not taken there)
-        if (a.m > 32 && a.n > 32) { int taken = 0; (void)launch_gemm_wgp8(a, hf8 ? 2 : 1, false, false, stream, kernel_name, &taken); if (taken) break; }
+        if (a.m > 32 && a.n > 32 && (a.m / 32) * (a.n / 32) <= 12) { int taken = 0; (void)launch_gemm_wgp8(a, hf8 ? 2 : 1, false, false, stream, kernel_name, &taken); if (taken) break; }      // (128^3: 0.66 here against 0.43 there)
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
         if (a.c_type != LIBXSMM_DATATYPE_F32) {            // C in the operands' type: plain epilogue only
           if (a.colbias || a.act || a.vnni_c) goto fp8_generic;
@@ -5025,7 +5025,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       }
       if (ok && !i4 && !lowbit) {
         const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8, big = pl.path == P_I8_2x2;
-        if (a.m > 32 && a.n > 32) { int taken = 0; (void)launch_gemm_wgp8(a, 0, ua, ub, stream, kernel_name, &taken); if (taken) break; }      // (as for the 8-bit floats above)
+        if (a.m > 32 && a.n > 32 && (a.m / 32) * (a.n / 32) <= 12) { int taken = 0; (void)launch_gemm_wgp8(a, 0, ua, ub, stream, kernel_name, &taken); if (taken) break; }      // (as for the 8-bit floats above)
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
 #define LAUNCH_I8_(MT_, NT_) do { \
           if (!ua && !ub) hipLaunchKernelGGL((gemm_i8_stream_kernel<MT_, NT_, false, false>), grid, dim3(256), 0, st, a); \

@@ -59,7 +59,7 @@ struct Wgp16Geo {
 #ifndef WGP_W3S
 #define WGP_W3S 5
 #endif
-#define WGP_WAVES(T) ((T) == 3 ? WGP_W3 : (T) == 2 ? WGP_W2 : WGP_W1)
+#define WGP_WAVES(T) ((T) == 4 ? 4 : (T) == 3 ? WGP_W3 : (T) == 2 ? WGP_W2 : WGP_W1)      // (four tiles per wave: 4 x 4 tiles as four tile rows, <= 128 registers)
 #define WGP_WAVES_D(T, D, AK) ((T) == 3 && (D) == 1 ? ((AK) == 4 ? 6 : WGP_W3S) : ((T) == 2 && (D) == 0 && (AK) >= 0) ? 5 : WGP_WAVES(T))      // (int8 weights with row scales: six waves with two spilled registers measured faster)
 // Which tiles a wave owns.  DEAL 0: round robin (tile w + 4 t).  DEAL 1: wave w owns tile ROW w, its tiles t are the tile columns -- one A fragment per k step feeds all of
 // them.  DEAL 2: wave w owns tile COLUMN w (one B fragment).  The strips are chosen by the launcher when they do not lengthen the critical path (3 or 4 strips of
@@ -301,7 +301,7 @@ static inline bool wgp16_shape_ok(const GemmArgs& a, Wgp16Geo& g, unsigned int& 
     (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0);
   if (bits & 15ull) return false;
   const int tiles = ((a.m + 31) / 32) * ((a.n + 31) / 32);
-  if (tiles < 2 || tiles > 12) return false;
+  if (tiles < 2 || (tiles > 12 && !(tiles == 16 && a.m > 96 && a.n > 96))) return false;      // (sixteen: 4 x 4 tiles only -- a tile row of four per wave)
   g.ppr = (unsigned int)a.m / 4u; g.rp = (unsigned int)a.m;
   g.ppc = (unsigned int)a.k / 8u;
   g.a_pieces = ak >= 0 ? (unsigned int)(((long long)a.m * a.k) / 16) : ((unsigned int)a.k / 2u) * g.ppr; g.b_pieces = (unsigned int)a.n * g.ppc;

@@ -19,7 +19,8 @@ int launch_gemm_wgp16(const GemmArgs& a_in, void* stream, const char** kernel_na
   const dim3 block(64u * wgp_waves(a.tiles_m, a.tiles_n, deal));
 #define WGP_(F_, T_, D_) hipLaunchKernelGGL((gemm_wgp16_kernel<F_, T_, -1, D_>), grid, block, lds_bytes, st, a, g)
 #define WGPD_(F_, T_) do { if (deal == 1) WGP_(F_, T_, 1); else if (deal == 2) WGP_(F_, T_, 2); else WGP_(F_, T_, 0); } while (0)
-  if (f16) { if (tpw == 1) WGP_(true, 1, 0); else if (tpw == 2) WGPD_(true, 2); else WGPD_(true, 3); }
+  if (tpw == 4) { if (f16) WGP_(true, 4, 1); else WGP_(false, 4, 1); }      // (4 x 4 tiles: wgp_deal returns 1)
+  else if (f16) { if (tpw == 1) WGP_(true, 1, 0); else if (tpw == 2) WGPD_(true, 2); else WGPD_(true, 3); }
   else { if (tpw == 1) WGP_(false, 1, 0); else if (tpw == 2) WGPD_(false, 2); else WGPD_(false, 3); }
 #undef WGPD_
 #undef WGP_

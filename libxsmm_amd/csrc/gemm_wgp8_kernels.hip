@@ -185,7 +185,7 @@ int launch_gemm_wgp8(const GemmArgs& a_in, int kind, bool ua, bool ub, void* str
   if (bits & 15ull) return 0;
   if (!c8 && (((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c) & 3ull) != 0ull) return 0;
   const int tiles = ((a.m + 31) / 32) * ((a.n + 31) / 32);
-  if (tiles < 2 || tiles > 12) return 0;
+  if (tiles < 2 || (tiles > 12 && !(tiles == 16 && a.m > 96 && a.n > 96))) return 0;
   Wgp16Geo g; g.rp = (unsigned int)a.m; g.ppr = 0; g.ppc = 0; g.bias_off = 0; g.bias_dw = 0; g.c_off = 0; g.c_ppc = 0; g.c_pieces = 0;
   g.a_pieces = (unsigned int)(abytes / 16); g.b_pieces = (unsigned int)(bbytes / 16);
   g.a_img = ((g.a_pieces + 63u) / 64u) * 1024u;
@@ -202,7 +202,7 @@ int launch_gemm_wgp8(const GemmArgs& a_in, int kind, bool ua, bool ub, void* str
   if (kernel_name) *kernel_name = "gemm_8bit_wgp_kernel";
 #define WGP8_(K_, UA_, UB_, T_, D_) hipLaunchKernelGGL((gemm_wgp8_kernel<K_, UA_, UB_, T_, D_>), grid, block, lds_bytes, st, b, g)
 #define WGP8D_(K_, UA_, UB_, T_) do { if (deal == 1) WGP8_(K_, UA_, UB_, T_, 1); else if (deal == 2) WGP8_(K_, UA_, UB_, T_, 2); else WGP8_(K_, UA_, UB_, T_, 0); } while (0)
-#define WGP8T_(K_, UA_, UB_) do { if (tpw == 1) WGP8_(K_, UA_, UB_, 1, 0); else if (tpw == 2) WGP8D_(K_, UA_, UB_, 2); else WGP8D_(K_, UA_, UB_, 3); } while (0)
+#define WGP8T_(K_, UA_, UB_) do { if (tpw == 4) WGP8_(K_, UA_, UB_, 4, 1); else if (tpw == 1) WGP8_(K_, UA_, UB_, 1, 0); else if (tpw == 2) WGP8D_(K_, UA_, UB_, 2); else WGP8D_(K_, UA_, UB_, 3); } while (0)
   if (kind == 0) { if (ua && ub) WGP8T_(0, true, true); else if (ua) WGP8T_(0, true, false); else if (ub) WGP8T_(0, false, true); else WGP8T_(0, false, false); }
   else if (kind == 1) WGP8T_(1, false, false);
   else WGP8T_(2, false, false);

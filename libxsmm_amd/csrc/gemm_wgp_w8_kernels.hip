@@ -14,7 +14,7 @@ template <>
 int launch_wgp_w8_kind<WGP_W8_KIND>(const GemmArgs& a, const Wgp16Geo& g, unsigned int lds_bytes, int tpw, int deal, dim3 grid, dim3 block, hipStream_t st) {
 #define WGPW_(T_, D_) hipLaunchKernelGGL((gemm_wgp16_kernel<false, T_, WGP_W8_KIND, D_>), grid, block, lds_bytes, st, a, g)
 #define WGPWD_(T_) do { if (deal == 1) WGPW_(T_, 1); else if (deal == 2) WGPW_(T_, 2); else WGPW_(T_, 0); } while (0)
-  if (tpw == 1) WGPW_(1, 0); else if (tpw == 2) WGPWD_(2); else WGPWD_(3);
+  if (tpw == 4) WGPW_(4, 1); else if (tpw == 1) WGPW_(1, 0); else if (tpw == 2) WGPWD_(2); else WGPWD_(3);
 #undef WGPWD_
 #undef WGPW_
   return (int)hipGetLastError();

@@ -177,6 +177,8 @@ RAGGED_16BIT = [
     dict(m=128, n=96, k=64, beta=1),                                                         # twelve tiles: four waves, a tile row of three each
     dict(m=96, n=128, k=40, c_type=DT.F32),                                                  # twelve tiles: four waves, a tile column of three each
     dict(m=160, n=64, k=32),                                                                 # ten tiles: round robin, three per wave
+    dict(m=104, n=120, k=40, beta=1),                                                        # sixteen tiles: four waves, a tile row of four each
+    dict(m=128, n=100, k=24, c_type=DT.F32),
     dict(m=40, n=40, k=40, beta=1, ldc=48),                                                  # beta = 1: C by 16-byte pieces through an LDS image (padded columns)
     dict(m=40, n=40, k=40, beta=1, ldc=44),                                                  # ... columns that are not whole pieces in memory: element loads
     dict(m=72, n=72, k=72, beta=1, br_type=capi.BR_STRIDE, br_count=2),                      # ... nine tiles, a chain
@@ -209,7 +211,7 @@ def test_ragged_16bit_shapes_on_the_masked_matrix_core_kernel(kw, dt):
     whole_pieces = kw["m"] % 4 == 0 and kw["k"] % 8 == 0 and kw.get("lda", kw["m"]) % 4 == 0 and kw.get("ldb", kw["k"]) % 8 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
     tiles = ((kw["m"] + 31) // 32) * ((kw["n"] + 31) // 32)
     f16_own_epilogue = dt == DT.F16 and kw.get("beta")
-    if whole_pieces and 2 <= tiles <= 12 and not f16_own_epilogue:
+    if whole_pieces and (2 <= tiles <= 12 or (tiles == 16 and kw["m"] > 96 and kw["n"] > 96)) and not f16_own_epilogue:
         assert ("gemm_bf16_wgp_kernel" if dt == DT.BF16 else "gemm_f16_wgp_kernel") in name, name
     else:
         assert ("gemm_mfma_bf16_kernel" if dt == DT.BF16 else "gemm_mfma_f16_kernel") in name, name
@@ -484,6 +486,8 @@ SHAPES_I8 = [
     dict(m=96, n=64, k=64, a_type=DT.I8, b_type=DT.U8, c_type=DT.F32, flags=F.VNNI_A, scf=0.5, br_type=capi.BR_STRIDE, br_count=2, batch=4),
     dict(m=64, n=96, k=32, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, batch=3),
     dict(m=128, n=96, k=64, a_type=DT.U8, b_type=DT.U8, c_type=DT.I32, flags=F.VNNI_A, batch=3),
+    dict(m=104, n=120, k=40, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, beta=1, batch=3),       # sixteen tiles: a tile row of four per wave
+    dict(m=128, n=128, k=64, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, batch=3),
 ]
 
 
@@ -497,7 +501,8 @@ def test_int8_gemm_is_bit_identical(kw):
     assert np.array_equal(case.valid_region(ref), case.valid_region(got)), name
     vnni = bool(kw.get("flags", 0) & F.VNNI_A)
     exact = kw["m"] % 32 == 0 and kw["n"] % 32 == 0 and kw["k"] % 32 == 0 and vnni and kw.get("ldb", 0) % 16 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
-    several = exact and kw["m"] > 32 and kw["n"] > 32 and (kw["m"] // 32) * (kw["n"] // 32) <= 12 and not kw.get("lda") and not kw.get("ldb")      # packed, whole tiles, 4 .. 12 of them
+    ntile = (kw["m"] // 32) * (kw["n"] // 32)
+    several = exact and kw["m"] > 32 and kw["n"] > 32 and ntile <= 12 and not kw.get("lda") and not kw.get("ldb")      # packed, whole tiles, 4 .. 12 of them (4 x 4 whole tiles: the streaming kernel)
     assert ("gemm_i8_stream_kernel" in name) == bool(exact and not several), name
     if several:
         assert name == "gemm_8bit_wgp_kernel", name
@@ -505,7 +510,7 @@ def test_int8_gemm_is_bit_identical(kw):
     assert ("gemm_mfma_8bit_kernel" in name or "gemm_8bit_wgp_kernel" in name) == bool(vnni and (several or not exact) and kw["k"] % 4 == 0), name
     packed = kw.get("lda", kw["m"]) == kw["m"] and kw.get("ldb", kw["k"]) == kw["k"] and kw["m"] % 4 == 0 and kw["k"] % 8 == 0 and kw.get("br_type", capi.BR_NONE) in (capi.BR_NONE, capi.BR_STRIDE)
     tiles = ((kw["m"] + 31) // 32) * ((kw["n"] + 31) // 32)
-    if vnni and not exact and packed and 2 <= tiles <= 12 and (kw["m"] * kw["k"]) % 16 == 0 and (kw["n"] * kw["k"]) % 16 == 0:
+    if vnni and not exact and packed and (2 <= tiles <= 12 or (tiles == 16 and kw["m"] > 96 and kw["n"] > 96)) and (kw["m"] * kw["k"]) % 16 == 0 and (kw["n"] * kw["k"]) % 16 == 0:
         assert "gemm_8bit_wgp_kernel" in name, name
     # unsupported combinations return NULL like the reference's dispatcher
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 64, 32, 64, 32, DT.I8, DT.I8, DT.I32, DT.I32), F.VNNI_A | F.TRANS_A, 0) is None
@@ -536,6 +541,7 @@ SHAPES_FP8 = [
     dict(m=72, n=40, k=48, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, br_type=capi.BR_STRIDE, br_count=3, batch=5),
     dict(m=96, n=96, k=96, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, batch=5),          # whole 32-tiles, nine per problem
     dict(m=64, n=96, k=64, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2, batch=4),
+    dict(m=120, n=104, k=48, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, beta=1, batch=3),                       # sixteen tiles
 ]
 
 
