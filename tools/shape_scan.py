@@ -13,7 +13,7 @@ sizes = [int(x) for x in os.environ.get("SIZES", "16,24,32,40,48,56,64,72,80,88,
 for t in types:
     for m in sizes:
         es = 4 if t == "f32" else 2 if t in ("bf16", "w8") else 1
-        batch = max(256, min(2 ** 18, (96 << 20) // (3 * m * m * es)))
+        batch = max(256, min(2 ** 19, (int(os.environ.get("FOOT_MB", "96")) << 20) // (3 * m * m * es)))
         batch = 1 << (batch.bit_length() - 1)
         try:
             if t in ("f32", "bf16"): w = bp.brgemm(api, m, t, batch)
