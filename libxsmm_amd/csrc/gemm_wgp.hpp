@@ -189,6 +189,9 @@ __global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_ke
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wg_barrier();
   init_bias();                                                   // (an empty chain: C = beta * C (+ bias))
+  // (chains with TWO pairs of images -- block r + 1 in flight while block r is multiplied, one barrier per block -- measured and not adopted: the second pair halves the
+  //  workgroups a CU holds; 72^3 x 4 blocks 0.60 -> 0.52, x 16 blocks 0.60 -> 0.45, 40^3 x 4 0.64 -> 0.60, profiles/r05_wgp_chains.jsonl.  Resident workgroups beat overlap
+  //  inside a workgroup, every time it was tried this round.)
   for (unsigned long long r = 0; r < p.br_count; ++r) {
     if (r != 0) {
       wg_barrier();                                              // everybody has read the previous block's images
