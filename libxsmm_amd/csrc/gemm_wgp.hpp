@@ -47,20 +47,26 @@ struct Wgp16Geo {
 // Register bounds = waves per SIMD the compiler must leave room for (__launch_bounds__' second argument).  LDS never limits these kernels (6-20 KiB per workgroup of
 // 160 KiB); resident workgroups are what hides a problem's single round trip, so every form is bounded to the most waves that compile WITHOUT scratch:
 // one tile per wave 8 (<= 64 registers), two 6 (<= 80), three 5 (<= 96).  Measured: profiles/r05_wgp_bound5.jsonl (three tiles), r05_wgp_waves.jsonl (one / two).
+// Round 5, last session: with the problem's base pointers in SGPRs and the store addresses formed behind the multiply loop, three tiles per wave fit 80 registers without
+// scratch (76-79), two fit 64 (57-60), four fit 96: the bounds below.  A variant that does not fit its bound spills -- and scratch costs a third of the kernel -- so
+// tests/test_kernel_resources_cpu.py pins "no scratch" on the built library.
 #ifndef WGP_W1
 #define WGP_W1 8
 #endif
 #ifndef WGP_W2
-#define WGP_W2 6
+#define WGP_W2 8
 #endif
 #ifndef WGP_W3
 #define WGP_W3 5
 #endif
 #ifndef WGP_W3S
-#define WGP_W3S 5
+#define WGP_W3S 6
 #endif
-#define WGP_WAVES(T) ((T) == 4 ? 4 : (T) == 3 ? WGP_W3 : (T) == 2 ? WGP_W2 : WGP_W1)      // (four tiles per wave: 4 x 4 tiles as four tile rows, <= 128 registers)
-#define WGP_WAVES_D(T, D, AK) ((T) == 3 && (D) == 1 ? ((AK) == 4 ? 6 : WGP_W3S) : ((T) == 2 && (D) == 0 && (AK) >= 0) ? 5 : WGP_WAVES(T))      // (int8 weights with row scales: six waves with two spilled registers measured faster)
+#ifndef WGP_W4
+#define WGP_W4 5
+#endif
+#define WGP_WAVES(T) ((T) == 4 ? WGP_W4 : (T) == 3 ? WGP_W3 : (T) == 2 ? WGP_W2 : WGP_W1)      // round-robin deal (three tiles: 83-88 registers)
+#define WGP_WAVES_D(T, D, AK) ((T) == 3 && (D) != 0 ? (((D) == 2 && (AK) >= 2) ? 5 : WGP_W3S) : WGP_WAVES(T))      // strips of three: six waves (column strips of flat 8-bit weights: 81-84 registers, five)
 // Which tiles a wave owns.  DEAL 0: round robin (tile w + 4 t).  DEAL 1: wave w owns tile ROW w, its tiles t are the tile columns -- one A fragment per k step feeds all of
 // them.  DEAL 2: wave w owns tile COLUMN w (one B fragment).  The strips are chosen by the launcher when they do not lengthen the critical path (3 or 4 strips of
 // ceil(tiles / 4) tiles: 72^3 and 96^3 are 3 x 3 -- three waves with a row each instead of 3 + 3 + 2 + 1 tiles with nothing in common).
@@ -78,7 +84,11 @@ __global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_ke
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
   const unsigned int bidx = blockIdx.x;
-  const BatchPtrs q = batch_ptrs(p, bidx);
+  BatchPtrs q = batch_ptrs(p, bidx);
+  // (the problem's five base pointers are wave-uniform but come out of 64-bit vector multiplies: ten VGPRs for the life of the kernel unless they are moved to SGPRs)
+  q.a = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)q.a); q.b = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)q.b);
+  q.c = (gptr)(size_t)uniform_u64((unsigned long long)(size_t)q.c); q.d = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)q.d);
+  q.mask = (GM unsigned char*)(size_t)uniform_u64((unsigned long long)(size_t)q.mask);
   char* const img_a = lds_wgp;
   char* const img_b = img_a + g.a_img;
   const unsigned int tiles_m = (unsigned int)p.tiles_m, tiles_n = (unsigned int)p.tiles_n;
@@ -284,6 +294,10 @@ __global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_ke
   //  waves each (half the workgroups: 0.536 -> 0.542, 48^3 0.65 -> 0.64: nothing, r05_wgp16_two_problems_per_wg_not_adopted.jsonl): what these shapes need is many
   //  short workgroups in different phases, which is exactly what the hardware's own workgroup scheduler provides.  40^3 stays at 0.54 - 0.57 in EVERY form, the
   //  wave-per-tile kernel included.)
+  // (the row index is made opaque here: addresses of the stores must not be formed -- and kept in registers -- in front of the multiply loop, where beta * C's loads
+  //  use the same expressions; two 64-bit values spilled that way were all that stood between three tiles per wave and six waves per SIMD)
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) { int opaque_i = tc[t].i; asm volatile("" : "+v"(opaque_i)); tc[t].i = opaque_i; }
   static_for<TPW>([&](auto tt) {
     constexpr int t = tt.value;
     if (mine[t]) tile_store<false, false, false>(acc[t], p, q, tc[t]);

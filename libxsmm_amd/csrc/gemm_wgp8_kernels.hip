@@ -11,9 +11,13 @@ namespace xamd {
 // them aligned).  A k quad beyond k is zeroed on both sides after the unsigned -> signed shift, exactly as in the wave-per-tile kernel.  C: i32 / f32 (the 8-bit float
 // result types stay with the wave-per-tile kernel).
 // ------------------------------------------------------------------------------------------------------------------------------------------------------------
+#ifndef WGP8_W3S
+#define WGP8_W3S 5
+#endif
+#define WGP8_WAVES(KIND, UA, UB, TPW, DEAL) ((TPW) == 4 ? 4 : (TPW) == 3 ? ((DEAL) != 0 ? WGP8_W3S : WGP_W3) : (TPW) == 2 ? 6 : 8)      // (the correction sums and k-quad masks cost the 8-bit kernels a step against the 16-bit one)
 // DEAL as in gemm_wgp16_kernel; a strip is ONE call of m8_products with MT x NT = 1 x TPW (a tile row: the A quads of my row feed TPW column tiles) or TPW x 1.
 template <int KIND, bool UA, bool UB, int TPW, int DEAL = 0>
-__global__ __launch_bounds__(256, (TPW == 3 && ((KIND == 0 && UA && UB) || (KIND != 0 && DEAL == 2))) ? 4 : WGP_WAVES(TPW))      // (u8 x u8 and column strips of 8-bit floats, three tiles: 2-3 registers short of five waves -- four instead of scratch)
+__global__ __launch_bounds__(256, WGP8_WAVES(KIND, UA, UB, TPW, DEAL))      // (u8 x u8 and column strips of 8-bit floats, three tiles: 2-3 registers short of five waves -- four instead of scratch)
 void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave with an unsigned operand: 132 registers without the bound = three waves per SIMD)
   constexpr bool INT = KIND == 0;
   constexpr int G = DEAL == 0 ? TPW : 1, MT = DEAL == 2 ? TPW : 1, NT = DEAL == 1 ? TPW : 1;      // G groups of MT x NT tiles; tile t = (group, mt, nt)
@@ -25,7 +29,11 @@ void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave wi
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int lane = threadIdx.x & 63u, li = lane & 31u, h = lane >> 5;
   const unsigned int bidx = blockIdx.x;
-  const BatchPtrs q = batch_ptrs(p, bidx);
+  BatchPtrs q = batch_ptrs(p, bidx);
+  // (the problem's five base pointers are wave-uniform but come out of 64-bit vector multiplies: ten VGPRs for the life of the kernel unless they are moved to SGPRs)
+  q.a = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)q.a); q.b = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)q.b);
+  q.c = (gptr)(size_t)uniform_u64((unsigned long long)(size_t)q.c); q.d = (gcptr)(size_t)uniform_u64((unsigned long long)(size_t)q.d);
+  q.mask = (GM unsigned char*)(size_t)uniform_u64((unsigned long long)(size_t)q.mask);
   char* const img_a = lds_wgp;
   char* const img_b = img_a + g.a_img;
   const unsigned int tiles_m = (unsigned int)p.tiles_m, tiles_n = (unsigned int)p.tiles_n;

@@ -19,10 +19,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(os.p
 
 # the 512-register bf16 macro-tile kernel, f32 / element-wise bf16 C stores of 64-tiles only: a few registers of the EPILOGUE's 64-bit address
 # arithmetic are spilled after the main loop and reloaded inside the epilogue (nothing inside the loop; the packed-bf16 form has no scratch)
-SCRATCH_ALLOWED = {r"xamd::gemm_bf16_macro_kernel<[02], 64, false, 4, 4, 4, 0, (false|true)>": 72,
-                   # int8 weights with row scales, a tile row of three per wave: six waves per SIMD with one or two spilled registers measured FASTER than five without
-                   # (72^3: 0.50 against 0.48 of the HBM roofline, profiles/r05_wgp_strips.jsonl)
-                   r"xamd::gemm_wgp16_kernel<false, 3, 4, 1>": 16}
+SCRATCH_ALLOWED = {r"xamd::gemm_bf16_macro_kernel<[02], 64, false, 4, 4, 4, 0, (false|true)>": 72}
 
 # kernel family -> least waves per SIMD that DESIGN.md's occupancy statements rely on (registers and static LDS together)
 OCCUPANCY = {
