@@ -1,4 +1,7 @@
-// gemm_wgp.hpp -- ragged 16-bit (bf16 / f16) GEMMs, ONE PROBLEM PER WORKGROUP with the whole problem staged in LDS (round 5).
+// gemm_wgp.hpp -- 16-bit (bf16 / f16) GEMMs and 8-bit weights x bf16 of SEVERAL TILES, ONE PROBLEM PER WORKGROUP with the whole problem staged in LDS (round 5); the
+// geometry, the tile ownership (wgp_deal / wgp_waves) and the register bounds are shared with the 8-bit x 8-bit kernel (gemm_wgp8_kernels.hip).
+// Where the family stands at the end of round 5 (tools/shape_scan.py, profiles/r05_shape_scan_640MB.jsonl): m = n = k = 40 .. 120 at 0.56-0.72 of the HBM roofline for
+// every 16-bit / 8-bit type -- 80-87 % of what the whole-tile streaming kernels reach (0.83).
 //
 // What was wrong with the wave-per-tile kernel on shapes like 40^3 and 72^3 (gemm_mfma_bf16_kernel<2,2>: 0.49 / 0.35 of the HBM roofline, 0.57 / 0.43 in its bounded
 // form): a wave walks its K chunks one after the other -- request a 32-deep panel, wait for it, multiply, request the next -- so a 72^3 problem is three memory
@@ -16,7 +19,10 @@
 // summation order (the same chunking as the wave-per-tile kernel: k in steps of 16, batch-reduce blocks in order).
 //
 // Taken by launch_gemm for 1-D batches (strided or pointer lists are not needed: strided only) when every piece request lies inside its operand block:
-// m % 4 == 0, k % 8 == 0, lda % 4 == 0, ldb % 8 == 0, 16-byte aligned blocks, 2 <= tiles <= 12, LDS image <= 64 KiB.  Everything else keeps the wave-per-tile kernel.
+// m % 4 == 0, k % 8 == 0, lda % 4 == 0, ldb % 8 == 0, 16-byte aligned blocks, 2 <= tiles <= 12 or 4 x 4 tiles, LDS image <= 64 KiB.  Everything else keeps the wave-per-tile
+// kernel.  What was added after the first form (each step an A/B on the GPU, DESIGN.md decision 34): register bounds = the most waves per SIMD without scratch; STRIPS -- a
+// wave owns a tile row or column and reads the shared fragment once per k step, the workgroup has as many waves as strips (2 x 2 tiles: two waves with a row each; 3 x 3:
+// three; 4 x 4: four); the fused column bias and beta * C through LDS images like the operands; base pointers in SGPRs.
 // [ref: the loop being computed is src/generator_gemm_reference_impl.c:2127-2170 (bf16 -> f32), :2367-2419 (bf16 -> bf16), :2025-2124 (f16)]
 #pragma once
 #include <hip/hip_runtime.h>
@@ -78,7 +84,7 @@ __device__ __forceinline__ bool wgp_tile_of(unsigned int w, unsigned int nw, uns
 }
 
 template <bool F16, int TPW, int AK = -1, int DEAL = 0>
-__global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave: 120 registers = four waves per SIMD without the bound)
+__global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_kernel(GemmArgs p, Wgp16Geo g) {
   extern __shared__ __attribute__((aligned(16))) char lds_wgp[];
   const unsigned int TS = (DEAL == 0 && TPW > 1) ? 4u : blockDim.x >> 6;                        // the waves of the workgroup share the problem: four, or one per strip / tile when those are fewer
   const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
