@@ -176,6 +176,11 @@ void retire_block(void* p) { if (p) { Retired& r = retired(); std::lock_guard<st
 static int cur_device() { const int d = tls().device; return d < 0 ? 0 : d; }
 struct Scratch { char* base = nullptr; size_t cap = 0, used = 0; int device = 0; ~Scratch() { retire_block(base); } };   // a thread that exits hands its block to finalize
 thread_local Scratch t_scratch;
+// Inside a pipeline section every LANE stages into a scratch of its own: a lane's uploads and kernels are ordered on that lane's stream, so the lane's scratch is rewound
+// at the start of each of its calls like the thread's own outside a section.  (Until round 5 a section appended to the one shared scratch -- call N + 1's upload on
+// another lane is not ordered behind call N's kernel -- and a long section grew it, retiring block after block until libxsmm_finalize.)  [advisor, round 4]
+thread_local Scratch t_scratch_lane[8];
+Scratch& cur_scratch();
 struct CopyBack { void* host; const void* dev; size_t width, height, pitch; };   // height rows of `width` bytes, `pitch` bytes apart (height 1: plain)
 thread_local std::vector<CopyBack> t_copyback;       // staged outputs of the current synchronous call
 // Stages a host-resident operand: `height` rows of `width` bytes that lie `pitch` bytes apart (a panel of a wider matrix: only the bytes the
@@ -189,7 +194,7 @@ static void* stage2d(const void* p, size_t width, size_t height, size_t pitch, b
   (void)hipGetLastError();   // clear the sticky "invalid value" of an unregistered pointer
   if (height == 1 || pitch == width) { width *= height; height = 1; pitch = width; }
   const size_t nbytes = (height - 1) * pitch + width;
-  Scratch& s = t_scratch;
+  Scratch& s = cur_scratch();
   const size_t need = (nbytes + 255) & ~(size_t)255;
   if (s.base && s.device != cur_device()) { retire_block(s.base); s.base = nullptr; s.cap = s.used = 0; }   // the thread switched device
   if (s.used + need > s.cap) {
@@ -223,7 +228,7 @@ struct PinnedRing { PinnedSlot slot[2]; int next = 0;
 thread_local PinnedRing t_pinned;
 static void* stage_host(const void* p, size_t nbytes) {
   if (!p || nbytes == 0) return nullptr;
-  Scratch& s = t_scratch;
+  Scratch& s = cur_scratch();
   const size_t need = (nbytes + 255) & ~(size_t)255;
   if (s.base && s.device != cur_device()) { retire_block(s.base); s.base = nullptr; s.cap = s.used = 0; }
   if (s.used + need > s.cap) {
@@ -258,7 +263,12 @@ static void* host_inout(void* p, size_t nbytes, size_t batch_count) { return sta
 // Rewinds the staging scratch at the start of a call.  NOT inside an open pipeline section: its launches run on different lane streams, so call N + 1's
 // upload of a staged operand (an OFFSET / ADDRESS list, a gather index list, a BCSC pattern) is not ordered behind call N's kernel, which may not have
 // read the same bytes yet -- the scratch keeps growing until the first call after libxsmm_hip_pipeline_end (ordered behind every lane by the join).
-void scratch_reset() { if (t_nest > 0 || tls().pipe_lanes > 1) return; t_scratch.used = 0; t_copyback.clear(); }
+Scratch& cur_scratch() { ThreadState& t = tls(); return t.pipe_lanes > 1 ? t_scratch_lane[t.pipe_cur & 7] : t_scratch; }
+void scratch_reset() {
+  if (t_nest > 0) return;
+  if (tls().pipe_lanes > 1) { t_scratch_lane[tls().pipe_cur & 7].used = 0; return; }      // this lane's scratch: its previous call is ahead of this one on the lane's stream
+  t_scratch.used = 0; t_copyback.clear();
+}
 void copy_back_staged() {
   for (const CopyBack& c : t_copyback)
     (void)hip_ok(c.height == 1 ? hipMemcpy(c.host, c.dev, c.width, hipMemcpyDeviceToHost) : hipMemcpy2D(c.host, c.pitch, c.dev, c.pitch, c.width, c.height, hipMemcpyDeviceToHost),

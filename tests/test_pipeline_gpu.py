@@ -155,3 +155,42 @@ def test_staged_host_lists_of_overlapping_launches_do_not_share_scratch():
         got = run(True)
         for i in range(launches):
             assert np.array_equal(got[i], serial[i]), (rep, i)
+
+
+def test_a_lane_reuses_its_scratch_call_after_call():
+    """Advisor, round 4 (low): inside a section the staging scratch was never rewound -- a long section grew it call after call.  Round 5: every lane stages into a scratch
+    of its own and rewinds it at the start of each of its calls (a lane's uploads and kernels are ordered on the lane's stream).  64 OFFSET-BRGEMMs with 64 DIFFERENT host
+    offset lists over FOUR lanes: each lane's scratch is overwritten sixteen times while earlier kernels of other lanes may still be running; every launch must have
+    used its own lists."""
+    import torch
+    api = capi.load()
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    m, nbr, nblocks, launches = 32, 5, 128, 64
+    rng = np.random.default_rng(23)
+    blk = m * m * 4
+    A = torch.from_numpy(rng.standard_normal(nblocks * m * m).astype(np.float32)).cuda()
+    B = torch.from_numpy(rng.standard_normal(nblocks * m * m).astype(np.float32)).cuda()
+    Cs = torch.zeros(launches * m * m, dtype=torch.float32, device="cuda")
+    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, capi.DT.F32, capi.DT.F32, capi.DT.F32, capi.DT.F32), capi.GEMM_FLAG.BETA_0, 0, capi.br_config(capi.BR_OFFSET, 0, 0, 0))
+    assert h
+    offs = [((rng.permutation(nblocks)[:nbr]) * blk).astype(np.int64) for _ in range(launches)]
+    offs_b = [((rng.permutation(nblocks)[:nbr]) * blk).astype(np.int64) for _ in range(launches)]
+    cnt = C.c_ulonglong(nbr)
+
+    def run(lanes):
+        Cs.zero_(); torch.cuda.synchronize()
+        if lanes:
+            assert api.hip_pipeline_begin(lanes) == 0
+        for i in range(launches):
+            p = capi.GemmParam()
+            p.a.primary, p.b.primary, p.c.primary = A.data_ptr(), B.data_ptr(), Cs.data_ptr() + i * blk
+            p.a.secondary, p.b.secondary = offs[i].ctypes.data, offs_b[i].ctypes.data
+            p.op.tertiary = C.addressof(cnt)
+            capi.Api.call(h, p)
+        if lanes:
+            assert api.hip_pipeline_end() == 0
+        api.hip_sync(); api.check()
+        return Cs.cpu().numpy().copy()
+    serial = run(0)
+    for rep in range(10):
+        assert np.array_equal(run(4), serial), rep
