@@ -179,3 +179,55 @@ def test_the_shapes_the_strips_were_measured_on():
     assert _deal(2, 3, 2) == 2 and _waves(2, 3, 2) == 3           # 64 x 96: a tile column per wave
     assert _deal(4, 3, 3) == 1 and _deal(3, 4, 3) == 2 and _deal(2, 5, 3) == 0
     assert _deal(4, 4, 4) == 1 and _waves(4, 4, 1) == 4           # 104^3 .. 120^3: four waves, a tile row of four each
+
+
+# ---- the f32 form (gemm_wgp_f32_kernels.hip): wave grid and K chunks, restated on the host -------------------------------------------------------------------------
+def _f32_grid(tm, tn):
+    best, best_sum, pick = 1 << 30, 1 << 30, (1, 1, 1, 1)
+    for wr, wc in ((2, 2), (1, 4), (4, 1), (1, 3), (3, 1), (1, 2), (2, 1), (1, 1)):
+        if wr > tm or wc > tn:
+            continue
+        a, b = -(-tm // wr), -(-tn // wc)
+        if a > 4 or b > 4:
+            continue
+        if a * b < best or (a * b == best and a + b < best_sum):
+            best, best_sum, pick = a * b, a + b, (wr, wc, a, b)
+    return pick
+
+
+def _f32_img_bytes(m, n, kc):
+    return (-(-(kc * (m // 4)) // 64)) * 1024 + (-(-(n * (kc // 4)) // 64)) * 1024
+
+
+def test_f32_wave_grid_covers_every_tile_with_blocks_of_at_most_four_by_four():
+    for m in range(4, 129, 4):
+        for n in range(1, 129, 7):
+            tm, tn = -(-m // 16), -(-n // 16)
+            wr, wc, rm, rn = _f32_grid(tm, tn)
+            assert wr * wc <= 4 and 1 <= rm <= 4 and 1 <= rn <= 4
+            assert wr * rm >= tm and wc * rn >= tn, (m, n, wr, wc, rm, rn)          # the launcher refuses otherwise; for m, n <= 128 it never has to
+            owners = {}
+            for w in range(wr * wc):
+                r0, c0 = (w // wc) * rm, (w % wc) * rn
+                for a in range(rm):
+                    for b in range(rn):
+                        if r0 + a < tm and c0 + b < tn:
+                            assert (r0 + a, c0 + b) not in owners
+                            owners[(r0 + a, c0 + b)] = w
+            assert len(owners) == tm * tn
+
+
+def test_f32_k_chunks_fit_the_budget_and_cover_k():
+    budget = 48 * 1024
+    for m, n, k in ((72, 72, 72), (128, 120, 200), (96, 96, 52), (112, 112, 112), (24, 128, 300), (128, 128, 1024)):
+        kc, chunks = k, 1
+        if _f32_img_bytes(m, n, k) > budget:
+            for nch in range(2, 17):
+                kc = (-(-k // nch) + 3) & ~3
+                if _f32_img_bytes(m, n, kc) <= budget:
+                    break
+            else:
+                continue                                    # the launcher declines (k too deep for sixteen chunks): another kernel takes the shape
+            chunks = -(-k // kc)
+        assert kc % 4 == 0 and chunks * kc >= k and (chunks - 1) * kc < k
+        assert _f32_img_bytes(m, n, kc) <= budget
