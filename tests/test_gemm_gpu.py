@@ -285,6 +285,24 @@ FUSED = [
 ]
 
 
+@pytest.mark.parametrize("kw", [
+    dict(m=72, n=72, k=72, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A),
+    dict(m=40, n=40, k=40, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, beta=1),
+    dict(m=104, n=104, k=24, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A),
+    dict(m=48, n=48, k=48),
+    dict(m=72, n=72, k=72, beta=1),
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_one_plain_call_of_a_several_tile_problem(kw):
+    """The workgroup-per-problem kernels are reached by ONE call through the handle as well (a batch of one problem: one workgroup), host-resident operands staged."""
+    api = capi.load()
+    case = GemmCase(seed=41, batch=1, **kw)
+    got, _, handle = case.run_gpu(batched=False)
+    ref, _ = case.run_oracle()
+    name = api.hip_kernel_name(handle, 0).decode()
+    assert "wgp" in name or "ragged" in name, name
+    assert normf_rel(case.valid_region(ref), case.valid_region(got), case.c_type) < _tol(case), name
+
+
 @pytest.mark.parametrize("kw", FUSED, ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
 def test_fused_epilogue_matches_oracle(kw):
     _check(GemmCase(seed=99, batch=3, **kw))
