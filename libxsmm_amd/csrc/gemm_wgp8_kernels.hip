@@ -180,7 +180,7 @@ int launch_gemm_wgp8(const GemmArgs& a_in, int kind, bool ua, bool ub, void* str
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '0'; }();
   const GemmArgs& a = a_in;
   if (off || kind < 0 || kind > 2) return 0;
-  if (a.batch_inner || a.list_a || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || a.colbias || a.act) return 0;
+  if (a.batch_inner || (a.list_a && !a.lists_aligned16) || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || a.colbias || a.act) return 0;
   if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return 0;
   const bool c8 = kind != 0 && a.c_type == a.a_type;              // 8-bit floats with a result of their own type
   if (a.c_type != LIBXSMM_DATATYPE_F32 && a.c_type != LIBXSMM_DATATYPE_I32 && !c8) return 0;

@@ -150,7 +150,7 @@ int launch_gemm_wgp_f32(const GemmArgs& a_in, void* stream, const char** kernel_
   static const unsigned int budget = []() { const char* e = getenv("LIBXSMM_HIP_WGP_F32_LDS"); return e ? (unsigned int)atoi(e) * 1024u : 48u * 1024u; }();      // LDS per workgroup (A/B switch)
   const GemmArgs& a = a_in;
   if (off || a.a_type != LIBXSMM_DATATYPE_F32 || a.b_type != LIBXSMM_DATATYPE_F32 || a.c_type != LIBXSMM_DATATYPE_F32) return 0;
-  if (a.batch_inner || a.list_a || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || a.colbias || a.act) return 0;
+  if (a.batch_inner || (a.list_a && !a.lists_aligned16) || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || a.colbias || a.act) return 0;
   if (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B)) return 0;
   if ((a.m & 3) || (a.k & 3) || (a.lda & 3) || (a.ldb & 3) || a.k <= 0 || a.m <= 0 || a.n <= 0 || a.m > 128 || a.n > 128) return 0;
   if (a.m <= 32 && a.n <= 32) return 0;                           // one wave's worth: the register-staged kernel streams those at 0.7

@@ -240,3 +240,32 @@ def test_finalize_on_another_thread_drops_queued_calls_with_an_error():
     assert r.returncode == 0, r.stdout + r.stderr
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
     assert int(line[1]) == -3 and float(line[2]) == 0.0, r.stdout
+
+
+def test_queued_calls_of_a_several_tile_shape_leave_on_the_workgroup_per_problem_kernel():
+    """Round 5: the pointer lists the queue builds are known to be 16-byte aligned, so a loop of single calls over 72^3 bf16 problems in RANDOM order (no constant stride: a
+    pointer-list batch) runs on the one-problem-per-workgroup kernel like the strided launch -- and gives the same bits."""
+    import torch
+    api = capi.load()
+    m, n = 72, 300
+    rng = np.random.default_rng(12)
+    A = torch.from_numpy(rng.integers(0, 1 << 15, (n, m * m), dtype=np.int16)).cuda()        # bf16 patterns (VNNI-2 image): any finite / small values
+    A = (A & 0x3fff) | 0x3c00                                                               # magnitudes in [0.0078, 2)
+    B = ((torch.from_numpy(rng.integers(0, 1 << 15, (n, m * m), dtype=np.int16)).cuda()) & 0x3fff) | 0x3c00
+    Cq = torch.zeros((n, m * m), dtype=torch.int16, device="cuda"); Cb = torch.zeros_like(Cq)
+    h = api.dispatch_gemm(capi.gemm_shape(m, m, m, m, m, m, DT.BF16, DT.BF16, DT.BF16, DT.F32), F.BETA_0 | F.VNNI_A, 0)
+    assert h
+    p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary = A.data_ptr(), B.data_ptr(), Cb.data_ptr()
+    api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+    api.hip_gemm_batch_strided(h, C.byref(p), n, m * m * 2, m * m * 2, m * m * 2)
+    api.hip_sync(); api.check()
+    assert api.hip_kernel_name(h, 1).decode() == "gemm_bf16_wgp_kernel"
+    api.hip_set_async(2)
+    api.hip_launch_count(1)
+    for i in rng.permutation(n):
+        _call(h, A[i].data_ptr(), B[i].data_ptr(), Cq[i].data_ptr())
+    api.hip_sync(); api.check()
+    assert api.hip_launch_count(0) <= 3          # (one batch; more only where the allocator placed C between A and B: the write-after-read scan flushes a long queue then)
+    assert api.hip_kernel_name(h, 1).decode() == "gemm_bf16_wgp_kernel"
+    assert torch.equal(Cq, Cb)
+    api.hip_set_async(0); api.hip_set_stream(None)
