@@ -2738,7 +2738,7 @@ __global__ __launch_bounds__(256) void gemm_i8_stream_kernel(GemmArgs p) {
     }
   }
   const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
-  const int kconst = (UA && UB) ? 16384 * (int)(p.br_count * (unsigned long long)p.k) : 0;
+  const int kconst = (UA && UB) ? (int)(16384u * (unsigned int)(p.br_count * (unsigned long long)p.k)) : 0;      // (mod 2^32 like the i32 sums themselves: unsigned arithmetic, no signed overflow)
   // (round 4: the 4-byte results through the wave's LDS image and out as whole 128-byte columns, 16 bytes per lane -- four store instructions per tile instead of
   //  sixteen, the f32 streaming kernel's epilogue -- measured no gain: u8 x i8 64^3 0.70 against 0.71, 32^3 0.76 against 0.74; not kept)
   static_for<MT * NT>([&](auto idx) {
@@ -3287,7 +3287,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
   }
   if constexpr (INT) {
     const bool c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
-    const int kconst = (UA && UB) ? 16384 * (int)(p.br_count * (unsigned long long)p.k) : 0;
+    const int kconst = (UA && UB) ? (int)(16384u * (unsigned int)(p.br_count * (unsigned long long)p.k)) : 0;      // (mod 2^32 like the i32 sums themselves: unsigned arithmetic, no signed overflow)
     if constexpr (UA) {       // both k halves of a column: lane j + lane j + 32
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) sum_b[nt] += __builtin_amdgcn_ds_bpermute(4 * (lane ^ 32), sum_b[nt]);

@@ -121,7 +121,7 @@ void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave wi
   }
   if constexpr (INT) {
     const bool c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
-    const int kconst = (UA && UB) ? 16384 * (int)(p.br_count * (unsigned long long)p.k) : 0;
+    const int kconst = (UA && UB) ? (int)(16384u * (unsigned int)(p.br_count * (unsigned long long)p.k)) : 0;      // (mod 2^32 like the i32 sums themselves: unsigned arithmetic, no signed overflow)
     static_for<TPW>([&](auto tt) {
       constexpr int t = tt.value;
       // (every wave executes the exchanges, also for a tile it does not own: ds_bpermute needs all lanes)
