@@ -8,8 +8,8 @@ namespace xamd {
 // 8-bit x 8-bit GEMMs (KIND 0: u8 / i8 -> i32 or scaled f32 on v_mfma_i32_32x32x32_i8; 1 / 2: BF8 / HF8 -> f32 on v_mfma_f32_32x32x16_*), the same form: one problem per
 // workgroup, both PACKED operand blocks (A in VNNI-4: [k/4][m] dwords, lda == m; B flat: [n][k] bytes, ldb == k) brought in as linear copies, the products and signedness
 // corrections of gemm_mfma_8bit_kernel (m8_products) fed from LDS: A as four ds_read_b32 (the k quads of my row), B as eight-byte reads of my column (k % 8 == 0 keeps
-// them aligned).  A k quad beyond k is zeroed on both sides after the unsigned -> signed shift, exactly as in the wave-per-tile kernel.  C: i32 / f32 (the 8-bit float
-// result types stay with the wave-per-tile kernel).
+// them aligned).  A k quad beyond k is zeroed on both sides after the unsigned -> signed shift, exactly as in the wave-per-tile kernel.  C: i32 / f32, or the 8-bit float
+// type of the operands (the reference's two-step rounding, bytes through an LDS image of C and out as 16-byte pieces where the columns allow it).  Plain epilogue only.
 // ------------------------------------------------------------------------------------------------------------------------------------------------------------
 #ifndef WGP8_W3S
 #define WGP8_W3S 5
@@ -17,8 +17,8 @@ namespace xamd {
 #define WGP8_WAVES(KIND, UA, UB, TPW, DEAL) ((TPW) == 4 ? 4 : (TPW) == 3 ? ((DEAL) != 0 ? WGP8_W3S : WGP_W3) : (TPW) == 2 ? 6 : 8)      // (the correction sums and k-quad masks cost the 8-bit kernels a step against the 16-bit one)
 // DEAL as in gemm_wgp16_kernel; a strip is ONE call of m8_products with MT x NT = 1 x TPW (a tile row: the A quads of my row feed TPW column tiles) or TPW x 1.
 template <int KIND, bool UA, bool UB, int TPW, int DEAL = 0>
-__global__ __launch_bounds__(256, WGP8_WAVES(KIND, UA, UB, TPW, DEAL))      // (u8 x u8 and column strips of 8-bit floats, three tiles: 2-3 registers short of five waves -- four instead of scratch)
-void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {      // (three tiles per wave with an unsigned operand: 132 registers without the bound = three waves per SIMD)
+__global__ __launch_bounds__(256, WGP8_WAVES(KIND, UA, UB, TPW, DEAL))
+void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {
   constexpr bool INT = KIND == 0;
   constexpr int G = DEAL == 0 ? TPW : 1, MT = DEAL == 2 ? TPW : 1, NT = DEAL == 1 ? TPW : 1;      // G groups of MT x NT tiles; tile t = (group, mt, nt)
   constexpr auto gi = [](int t) { return DEAL == 0 ? t : 0; };
