@@ -99,8 +99,10 @@ __device__ __forceinline__ void generic_epilogue(const GemmArgs& p, const BatchP
     if ((p.n & 1) && j == p.n - 1) c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + 1] = 0;
   } else if (p.c_type == LIBXSMM_DATATYPE_F32) {
     ((GM float*)q.c)[(long long)j * p.ldc + i] = y;
-  } else if (p.c_type == LIBXSMM_DATATYPE_F16) {        // (the reduce pass of a k-sliced GEMM with IEEE-half C: round 3)
+  } else if (p.c_type == LIBXSMM_DATATYPE_F16) {        // (the reduce pass of a k-sliced GEMM with IEEE-half C: round 3; fused IEEE-half GEMMs: round 6)
     ((GM _Float16*)q.c)[(long long)j * p.ldc + i] = (_Float16)y;
+  } else if (p.c_type == LIBXSMM_DATATYPE_BF8 || p.c_type == LIBXSMM_DATATYPE_HF8) {     // C in the operands' 8-bit type [ref: gemm ref :2511-2619, mateltwise ref :310-319]: one two-step RNE at the end
+    ((GM unsigned char*)q.c)[(long long)j * p.ldc + i] = p.c_type == LIBXSMM_DATATYPE_BF8 ? lowp::f16_to_bf8_rne(lowp::f32_to_f16(y)) : lowp::f16_to_hf8_rne(lowp::f32_to_f16(y));
   } else {
     ((GM unsigned short*)q.c)[(long long)j * p.ldc + i] = f32_to_bf16_rne(y);
   }
@@ -151,28 +153,27 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
   if (p.a_type == LIBXSMM_DATATYPE_F16) {
     // IEEE half GEMM, f32 accumulation [ref: gemm ref :2025-2124]: k ascending (also inside a VNNI-2 pair), beta * C added AFTER the sum,
     // an f32 C rounded to f16 on the way in
-    if (!valid) return;
+    // (round 6) fused column bias / activation [ref: gemm ref :294-372]: the start value bias (+ C), formed in f32, takes C's place in that rule
     const int kb = va ? 2 : 1;
     float acc = 0.0f;
-    for (unsigned long long r = 0; r < p.br_count; ++r) {
-      gcptr ar, br; br_base(p, q, r, ar, br);
-      for (int s = 0; s < p.k; ++s) {
-        const long long ai = (long long)(s / kb) * ((long long)p.lda * kb) + (long long)i * kb + (s % kb);
-        const long long bi = tb ? (long long)s * p.ldb + j : (long long)j * p.ldb + s;
-        const float av = (float)__builtin_bit_cast(_Float16, ((GM const unsigned short*)ar)[ai]), bv = (float)__builtin_bit_cast(_Float16, ((GM const unsigned short*)br)[bi]);
-        acc = add_rn(acc, mul_rn(av, bv));
-        if (p.comp_f16) acc = (float)(_Float16)acc;             // comp_type F16 [ref: gemm ref :2042,:2059-2062]
+    if (valid) {
+      for (unsigned long long r = 0; r < p.br_count; ++r) {
+        gcptr ar, br; br_base(p, q, r, ar, br);
+        for (int s = 0; s < p.k; ++s) {
+          const long long ai = (long long)(s / kb) * ((long long)p.lda * kb) + (long long)i * kb + (s % kb);
+          const long long bi = tb ? (long long)s * p.ldb + j : (long long)j * p.ldb + s;
+          const float av = (float)__builtin_bit_cast(_Float16, ((GM const unsigned short*)ar)[ai]), bv = (float)__builtin_bit_cast(_Float16, ((GM const unsigned short*)br)[bi]);
+          acc = add_rn(acc, mul_rn(av, bv));
+          if (p.comp_f16) acc = (float)(_Float16)acc;             // comp_type F16 [ref: gemm ref :2042,:2059-2062]
+        }
+      }
+      if (!beta0 || p.colbias) {
+        float start = beta0 ? 0.0f : load_c_f32(q.c, (long long)j * p.ldc + i, p.c_type);
+        if (p.colbias) { const float bias = load_c_f32(q.d, i, p.c_type); start = beta0 ? bias : add_rn(bias, start); }
+        acc = add_rn(acc, (float)(_Float16)start);
       }
     }
-    if (p.c_type == LIBXSMM_DATATYPE_F32) {
-      GM float* c = (GM float*)q.c + (long long)j * p.ldc + i;
-      if (!beta0) acc = add_rn(acc, (float)(_Float16)*c);
-      *c = acc;
-    } else {
-      GM unsigned short* c = (GM unsigned short*)q.c + (long long)j * p.ldc + i;
-      if (!beta0) acc = add_rn(acc, (float)__builtin_bit_cast(_Float16, *c));
-      *c = __builtin_bit_cast(unsigned short, (_Float16)acc);
-    }
+    generic_epilogue(p, q, i, j, valid, acc);
     return;
   }
 
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
     const int kb = fp8 ? (va ? 4 : 1) : (((p.a_type == LIBXSMM_DATATYPE_BF16 || fp8w) && va) ? 2 : 1);
     if (!beta0) acc = (p.c_type == LIBXSMM_DATATYPE_BF8 || p.c_type == LIBXSMM_DATATYPE_HF8) ? load_as_f32(q.c, (long long)j * p.ldc + i, p.c_type) : load_c_f32(q.c, (long long)j * p.ldc + i, p.c_type);
     if (p.colbias) {
-      const float bias = load_c_f32(q.d, i, p.c_type);
+      const float bias = (p.c_type == LIBXSMM_DATATYPE_BF8 || p.c_type == LIBXSMM_DATATYPE_HF8) ? load_as_f32(q.d, i, p.c_type) : load_c_f32(q.d, i, p.c_type);
       acc = beta0 ? bias : add_rn(bias, acc);
     }
     for (unsigned long long r = 0; r < p.br_count; ++r) {
@@ -407,10 +408,6 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs p) {
         }
       }
     }
-  }
-  if (p.c_type == LIBXSMM_DATATYPE_BF8 || p.c_type == LIBXSMM_DATATYPE_HF8) {     // C in the operands' 8-bit type [ref: gemm ref :2511-2619]: one RNE at the end
-    if (valid) ((GM unsigned char*)q.c)[(long long)j * p.ldc + i] = p.c_type == LIBXSMM_DATATYPE_BF8 ? lowp::f16_to_bf8_rne(lowp::f32_to_f16(acc)) : lowp::f16_to_hf8_rne(lowp::f32_to_f16(acc));
-    return;
   }
   generic_epilogue(p, q, i, j, valid, acc);
 }
@@ -1657,8 +1654,9 @@ __global__ __launch_bounds__(256) void gemm_p16_kernel(GemmArgs p) {
 //   A: four dwords (k-pairs) per step, lanes contiguous along i  -> coalesced 128-byte rows
 //   B: sixteen contiguous bytes per step (32 per chunk) at column j
 // ------------------------------------------------------------------------------------------------
-// F16 = true: the same kernel on IEEE halves (v_mfma_f32_32x32x16_f16; plain epilogue only) with the reference's F16 rules: the
-// accumulators start at 0, beta * C is added after the sum, an f32 C is rounded to f16 on the way in [ref: gemm ref :2025-2124].
+// F16 = true: the same kernel on IEEE halves (v_mfma_f32_32x32x16_f16) with the reference's F16 rule for the start value: beta * C (+ the fused column bias) is rounded
+// to f16 on the way in [ref: gemm ref :2025-2124, :296-317]; the reference adds it after the sum, the matrix core before -- a difference of the f32 summation order only
+// (round 6: any epilogue; until then the accumulators started at 0 and beta * C was added element by element behind the loop).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // BND (with BL; prepared in round 4, measured and adopted in round 5 for plain results -- ragged16_bounded): the
 // operand descriptors carry the exact extent of the block, so a request beyond it (a row of the last k pair beyond m, a k pair beyond k in the last column) is dropped
@@ -1680,11 +1678,11 @@ __global__ __launch_bounds__(256, BND ? 4 : 1) void gemm_mfma_bf16_kernel(GemmAr
     for (int nt = 0; nt < NT; ++nt) {
       tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h;
       tc[mt][nt].ivalid = tc[mt][nt].i < p.m;
-      if (F16 || BND) {                                         // (BND: beta = 0, no bias -- launch_gemm)
+      if (BND) {                                                // (BND: beta = 0, no bias -- launch_gemm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
       }
-      else tile_init<EXACT, false>(acc[mt][nt], p, q, tc[mt][nt]);
+      else tile_init<EXACT, false, false, false, F16>(acc[mt][nt], p, q, tc[mt][nt]);       // (halves: the start value rounded to f16, see tile_init)
     }
   const int kchunks = (p.k + 31) / 32;
   for (unsigned long long r = 0; r < p.br_count; ++r) {
@@ -1887,34 +1885,6 @@ __global__ __launch_bounds__(256, BND ? 4 : 1) void gemm_mfma_bf16_kernel(GemmAr
     static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store_buf(acc[mt][nt], p, rc, c_dword, tc[mt][nt]); });
     return;
   }
-  if (F16) {
-    const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0, c_f32 = p.c_type == LIBXSMM_DATATYPE_F32;
-    if (beta0) {        // the shared epilogue (halves as packed row pairs when m is even), as the bf16 kernel below
-      static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false, EXACT>(acc[mt][nt], p, q, tc[mt][nt]); });
-      return;
-    }
-    static_for<MT * NT>([&](auto idx) {
-      constexpr int mt = idx.value / NT, nt = idx.value % NT;
-      const TileCtx& t = tc[mt][nt];
-      static_for<16>([&](auto rc) {
-        constexpr int r = rc.value;
-        const int j = t.j0 + jl_of(r, t.h);
-        if (EXACT || (t.ivalid && j < p.n)) {
-          float v = acc[mt][nt][r];
-          if (c_f32) {
-            GM float* c = (GM float*)q.c + (long long)j * p.ldc + t.i;
-            if (!beta0) v += (float)(_Float16)*c;
-            st_stream(c, v);
-          } else {
-            GM unsigned short* c = (GM unsigned short*)q.c + (long long)j * p.ldc + t.i;
-            if (!beta0) v += (float)__builtin_bit_cast(_Float16, *c);
-            st_stream(c, __builtin_bit_cast(unsigned short, (_Float16)v));
-          }
-        }
-      });
-    });
-    return;
-  }
   // (ragged tiles: plain stores -- their columns are pieces of cache lines, which non-temporal stores would send to memory one by one)
   static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT; tile_store<EXACT, false, EXACT>(acc[mt][nt], p, q, tc[mt][nt]); });
 }
@@ -2115,7 +2085,7 @@ __global__ __launch_bounds__(256) void gemm_w8_bf16_kernel(GemmArgs p) {
 // The LDS image is wave-private: no barrier, only s_waitcnt.
 // ------------------------------------------------------------------------------------------------
 // AUX: cache-policy bits of the operand loads (0 default, 2 = nt for launches whose operands cannot be cache resident, see launch_gemm)
-template <int MT, int NT, int AUX, bool F16 = false>      // F16: IEEE halves (beta = 0, plain epilogue: launch_gemm), same layouts
+template <int MT, int NT, int AUX, bool F16 = false>      // F16: IEEE halves, same layouts (the start value rounded to f16: tile_init)
 __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds_all[4][2][NT * 2048];
   const WaveJob job = wave_job(p, 32 * MT, 32 * NT);
@@ -2131,7 +2101,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_kernel(GemmArgs p) {
     for (int nt = 0; nt < NT; ++nt) {
       tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h;
       tc[mt][nt].ivalid = true;
-      tile_init<true, false>(acc[mt][nt], p, q, tc[mt][nt]);
+      tile_init<true, false, false, false, F16>(acc[mt][nt], p, q, tc[mt][nt]);
     }
   const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
   // DMA: LDS slot L = lane + 64x holds column f = L>>2, 16-byte piece (L&3) ^ ((f>>1)&3) of the chunk's 64 bytes
@@ -2340,7 +2310,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_wg64_kernel(GemmArgs p) {
   const unsigned int wi = w & 1u, wj = w >> 1;
   f32x16 acc;
   TileCtx tc; tc.i = (int)(32u * wi + li); tc.j0 = (int)(32u * wj); tc.h = (int)h; tc.ivalid = true;
-  tile_init<true, false>(acc, p, q, tc);
+  tile_init<true, false, false, false, F16>(acc, p, q, tc);
   if (total > 0) issue(0);
   if (total > 1) issue(1);
   for (unsigned long long t = 0; t < total; ++t) {
@@ -3040,14 +3010,8 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
   static_for<MT * NT>([&](auto idx) {
     constexpr int mt = idx.value / NT, nt = idx.value % NT;
     tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h; tc[mt][nt].ivalid = true;
-    if constexpr (C8) {
-      const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long e = (long long)(tc[mt][nt].j0 + jl_of(r, h)) * p.ldc + tc[mt][nt].i;
-        acc[mt][nt][r] = beta0 ? 0.0f : (HF8 ? hf8_to_f32(((GM const unsigned char*)q.c)[e]) : bf8_to_f32(((GM const unsigned char*)q.c)[e]));
-      }
-    } else tile_init<true, true>(acc[mt][nt], p, q, tc[mt][nt]);
+    if constexpr (C8) tile_init_c8<true>(acc[mt][nt], p, q, tc[mt][nt], HF8);
+    else tile_init<true, true>(acc[mt][nt], p, q, tc[mt][nt]);
   });
   const unsigned int lda = (unsigned int)p.lda, ldb = (unsigned int)p.ldb;
   unsigned int offB[NT * 2], offBt[NT * 2];
@@ -3102,6 +3066,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_stream_kernel(GemmArgs p) {
     // 64^3 bf8 problems: the store instructions, not the bytes, were the bound); columns that are not 16-byte aligned in memory leave byte by byte
     constexpr unsigned int pitch = 32u * MT;
     static_for<MT * NT>([&](auto idx) { constexpr int mt = idx.value / NT, nt = idx.value % NT;
+      tile_activate<true>(acc[mt][nt], p, q, tc[mt][nt]);          // fused ReLU (+ bitmask) / sigmoid (round 6)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const unsigned int two = f32x2_to_fp8_ref(acc[mt][nt][r], acc[mt][nt][r + 1], HF8);
@@ -3164,15 +3129,8 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
     tc[mt][nt].i = job.i0 + 32 * mt + li; tc[mt][nt].j0 = job.j0 + 32 * nt; tc[mt][nt].h = h; tc[mt][nt].ivalid = tc[mt][nt].i < p.m;
     if constexpr (INT) iacc[mt][nt] = (i32x16)0;
     else {
-      if (c8) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = tc[mt][nt].j0 + jl_of(r, h);
-          float v = 0.0f;
-          if (!beta0 && tc[mt][nt].ivalid && j < p.n) { const unsigned char x = ((GM const unsigned char*)q.c)[(long long)j * p.ldc + tc[mt][nt].i]; v = HF8 ? hf8_to_f32(x) : bf8_to_f32(x); }
-          facc[mt][nt][r] = v;
-        }
-      } else tile_init<false, true>(facc[mt][nt], p, q, tc[mt][nt]);
+      if (c8) tile_init_c8<false>(facc[mt][nt], p, q, tc[mt][nt], HF8);
+      else tile_init<false, true>(facc[mt][nt], p, q, tc[mt][nt]);
     }
   });
 #pragma unroll
@@ -3315,6 +3273,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_8bit_kernel(GemmArgs p) {
     static_for<MT * NT>([&](auto idx) {
       constexpr int mt = idx.value / NT, nt = idx.value % NT;
       const TileCtx& t = tc[mt][nt];
+      tile_activate<false>(facc[mt][nt], p, q, t);               // fused ReLU (+ bitmask) / sigmoid (round 6)
 #pragma unroll
       for (int r2 = 0; r2 < 16; r2 += 2) {
         const unsigned int two = f32x2_to_fp8_ref(facc[mt][nt][r2], facc[mt][nt][r2 + 1], HF8);
@@ -3568,6 +3527,16 @@ __global__ __launch_bounds__(256) void gemm_mx_stream_kernel(GemmArgs p) {
 #include "gemm_shards/extern.inc"
 #endif
 
+// the fused operators of the ext ABI this library implements on every type the reference's loop fuses them on (f32, BF32, bf16, IEEE halves, 8-bit floats):
+// column bias (binary ADD, broadcast column), ReLU (+ bitmask) / sigmoid on C [ref: gemm ref :294-372; the accept list of libxsmm_dispatch_brgemm_ext, runtime.cpp]
+static bool fused_ops_ok(const libxsmm_gemm_descriptor& d) {
+  const bool bin_ok = d.bin_type == LIBXSMM_MELTW_TYPE_BINARY_NONE ||
+    (d.bin_type == LIBXSMM_MELTW_TYPE_BINARY_ADD && (d.bin_flags & (LIBXSMM_MELTW_FLAG_BINARY_BCAST_COL_IN_0 | LIBXSMM_MELTW_FLAG_BINARY_BCAST_COL_IN_1)));
+  const bool cp_ok = d.cp_type == LIBXSMM_MELTW_TYPE_UNARY_NONE || d.cp_type == LIBXSMM_MELTW_TYPE_UNARY_RELU || d.cp_type == LIBXSMM_MELTW_TYPE_UNARY_SIGMOID;
+  if (!bin_ok || !cp_ok || d.ap_type != 0 || d.bp_type != 0) return false;
+  return (d.flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) || (d.bin_type == 0 && d.cp_type == 0);
+}
+
 bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
   libxsmm_gemm_descriptor d = d_in;
   if (d.flags & LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK) {
@@ -3606,8 +3575,8 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     const bool plain = !(fl & (LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) && d.bin_type == 0 && d.cp_type == 0 && d.ap_type == 0 && d.bp_type == 0;
     const bool ta_ = fl & LIBXSMM_GEMM_FLAG_TRANS_A, tb_ = fl & LIBXSMM_GEMM_FLAG_TRANS_B, va_ = fl & LIBXSMM_GEMM_FLAG_VNNI_A;
     const bool lds_ok = (ta_ ? d.lda >= d.k : d.lda >= d.m) && (tb_ ? d.ldb >= d.n : d.ldb >= d.k) && d.ldc >= d.m;
-    if (d.a_type == LIBXSMM_DATATYPE_BF32 || d.b_type == LIBXSMM_DATATYPE_BF32)      // f32 storage, operands rounded to bf16 [ref: gemm ref :1359-1426]
-      return d.a_type == d.b_type && d.c_type == LIBXSMM_DATATYPE_F32 && d.comp_type == LIBXSMM_DATATYPE_F32 && plain && !va_ && lds_ok;
+    if (d.a_type == LIBXSMM_DATATYPE_BF32 || d.b_type == LIBXSMM_DATATYPE_BF32)      // f32 storage, operands rounded to bf16 [ref: gemm ref :1359-1426]; fused operators as f32 (round 6)
+      return d.a_type == d.b_type && d.c_type == LIBXSMM_DATATYPE_F32 && d.comp_type == LIBXSMM_DATATYPE_F32 && !(fl & (LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) && fused_ops_ok(d) && !va_ && lds_ok;
     if (d.a_type == LIBXSMM_DATATYPE_I16 || d.b_type == LIBXSMM_DATATYPE_I16)        // [ref: gemm ref :1427-1450]
       return d.a_type == d.b_type && d.c_type == LIBXSMM_DATATYPE_I32 && d.comp_type == LIBXSMM_DATATYPE_I32 && plain && !ta_ && !tb_ && !(va_ && (d.k & 1)) && lds_ok;
     if (d.a_type == LIBXSMM_DATATYPE_I8 && d.b_type == LIBXSMM_DATATYPE_BF16)       // row-scaled i8 weights x bf16 [ref: gemm ref :1684-1730]
@@ -3625,7 +3594,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
     return d.lda >= d.m && d.ldb >= d.k && d.ldc >= d.m;
   }
-  if (d.a_type == LIBXSMM_DATATYPE_F16 && d.b_type == LIBXSMM_DATATYPE_F16) {   // [ref: gemm ref :2025-2124]: f32 accumulation, F16 or F32 out, VNNI-2 A optional, B may be transposed, no fused ops
+  if (d.a_type == LIBXSMM_DATATYPE_F16 && d.b_type == LIBXSMM_DATATYPE_F16) {   // [ref: gemm ref :2025-2124]: f32 accumulation, F16 or F32 out, VNNI-2 A optional, B may be transposed; fused operators [:294-372] (round 6)
     const unsigned int fl = d.flags;
     if (d.c_type != LIBXSMM_DATATYPE_F16 && d.c_type != LIBXSMM_DATATYPE_F32) return false;
     // comp F32, F16 (the running sum rounded to f16 after every product: generic kernel) or IMPLICIT (= F32 here; the reference means F16 by it on
@@ -3633,17 +3602,17 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     if (d.comp_type != LIBXSMM_DATATYPE_F32 && d.comp_type != LIBXSMM_DATATYPE_F16 && d.comp_type != LIBXSMM_DATATYPE_IMPLICIT) return false;
     if (fl & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) return false;
     if ((fl & LIBXSMM_GEMM_FLAG_VNNI_A) && (d.k & 1)) return false;
-    if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    if (!fused_ops_ok(d)) return false;
     if ((fl & LIBXSMM_GEMM_FLAG_TRANS_B) ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
     return d.lda >= d.m && d.ldc >= d.m;
   }
   const bool fp8 = (d.a_type == LIBXSMM_DATATYPE_BF8 || d.a_type == LIBXSMM_DATATYPE_HF8) && d.b_type == d.a_type && (d.c_type == LIBXSMM_DATATYPE_F32 || d.c_type == d.a_type);      // C f32 or the operands' type [ref: :2511-2619]
-  if (fp8) {   // [ref: gemm ref :2420-2510]: f32 accumulate and output, VNNI-4 A optional, no fused ops
+  if (fp8) {   // [ref: gemm ref :2420-2510]: f32 accumulate and output, VNNI-4 A optional; fused operators [:294-372] (round 6)
     const unsigned int fl8 = d.flags;
     if (d.comp_type != LIBXSMM_DATATYPE_F32) return false;
     const bool ta8 = fl8 & LIBXSMM_GEMM_FLAG_TRANS_A, tb8 = fl8 & LIBXSMM_GEMM_FLAG_TRANS_B, va8 = fl8 & LIBXSMM_GEMM_FLAG_VNNI_A, vb8 = fl8 & LIBXSMM_GEMM_FLAG_VNNI_B;
     if ((fl8 & LIBXSMM_GEMM_FLAG_VNNI_C) || (va8 && ta8) || (vb8 && !tb8) || ((va8 || vb8) && (d.k & 3))) return false;
-    if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
+    if (!fused_ops_ok(d)) return false;
     if (ta8 ? (d.lda < d.k) : (d.lda < d.m)) return false;
     if (tb8 ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
     return d.ldc >= d.m;
@@ -4520,7 +4489,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   dim3 grid;
   // BF32 on whole 32 x 32 x 32 tiles: the f32 streaming kernel with the operands rounded to bf16 in registers (bit-identical to the reference loop)
   if (a.a_type == LIBXSMM_DATATYPE_BF32 && a.b_type == LIBXSMM_DATATYPE_BF32 && a.c_type == LIBXSMM_DATATYPE_F32 && (a.m % 32) == 0 && (a.n % 32) == 0 && (a.k % 32) == 0 && a.k > 0 &&
-      !a.colbias && !a.act && !a.vnni_c && !(a.flags & (LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B)) && operands_aligned16(a, 4) &&
+      !a.vnni_c && !(a.flags & (LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B)) && operands_aligned16(a, 4) && (!a.colbias || ((((unsigned long long)(size_t)a.d | (unsigned long long)a.bs_d) & 3ull) == 0ull)) &&
       a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22) &&
       ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 3ull) == 0ull)) {
     const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B;
@@ -4665,17 +4634,17 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       if (af == AF_VNNI) launch_bf16_forms_a<AF_VNNI>(a, bf, grid, st); else if (af == AF_FLAT) launch_bf16_forms_a<AF_FLAT>(a, bf, grid, st); else launch_bf16_forms_a<AF_TRANS>(a, bf, grid, st);
       return (int)hipGetLastError();
     } }
-  // IEEE halves take the bf16 fast paths when nothing but the product is asked for: beta = 0 (the reference adds beta * C AFTER the sum for halves),
-  // f32 accumulation, f16 or f32 C, no fused operator
-  const bool f16_fast = a.a_type == LIBXSMM_DATATYPE_F16 && a.b_type == LIBXSMM_DATATYPE_F16 && !a.comp_f16 && (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && !a.colbias && !a.act && !a.vnni_c &&
+  // IEEE halves take the bf16 fast paths with f32 accumulation and f16 or f32 C (round 6: any beta and the fused operators too -- the start value is rounded to f16 on
+  // its way into the accumulators, tile_init<.., F16S>)
+  const bool f16_fast = a.a_type == LIBXSMM_DATATYPE_F16 && a.b_type == LIBXSMM_DATATYPE_F16 && !a.comp_f16 && !a.vnni_c &&
     (a.c_type == LIBXSMM_DATATYPE_F16 || a.c_type == LIBXSMM_DATATYPE_F32);
   // 8-bit operands on the masked matrix-core kernel: any shape with whole k-quads, any alignment, any batch-reduce form.  Returns false for what it does not
-  // take (C of an 8-bit float type together with a fused operator; more than 2^31 bytes inside one operand).
+  // take (more than 2^31 bytes inside one operand).
   auto launch_m8 = [&](bool big) -> bool {
     static const int tile_env = []() { const char* e = getenv("LIBXSMM_HIP_M8_TILE"); return e ? atoi(e) : 0; }();      // experiments: 1 forces 32 x 32 tiles, 2 forces 64 x 64
     if (tile_env == 1) big = false; else if (tile_env == 2) big = true;
     const bool fp8 = a.a_type == LIBXSMM_DATATYPE_BF8 || a.a_type == LIBXSMM_DATATYPE_HF8;
-    if (fp8 && a.c_type != LIBXSMM_DATATYPE_F32 && (a.colbias || a.act || a.vnni_c)) return false;
+    if (fp8 && a.c_type != LIBXSMM_DATATYPE_F32 && a.vnni_c) return false;
     if ((a.k & 3) || a.k <= 0) return false;
     const bool ua = a.a_type == LIBXSMM_DATATYPE_U8, ub = a.b_type == LIBXSMM_DATATYPE_U8;
     // packed operand blocks of several tiles: one problem per workgroup, whole problem in LDS (gemm_wgp8_kernels.hip, round 5); an error of that launch is left
@@ -4948,8 +4917,8 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         // (also whole 64-tiles -- 64^3 was one wave per problem: bf8 0.64 -> 0.76, i8 0.65 -> 0.75, profiles/r05_wgp_pair.jsonl; more than twelve tiles are not taken there)
         if (a.m > 32 && a.n > 32 && (a.m / 32) * (a.n / 32) <= 12) { int taken = 0; (void)launch_gemm_wgp8(a, hf8 ? 2 : 1, false, false, stream, kernel_name, &taken); if (taken) break; }      // (128^3: 0.66 here against 0.43 there)
         grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
-        if (a.c_type != LIBXSMM_DATATYPE_F32) {            // C in the operands' type: plain epilogue only
-          if (a.colbias || a.act || a.vnni_c) goto fp8_generic;
+        if (a.c_type != LIBXSMM_DATATYPE_F32) {            // C in the operands' type
+          if (a.vnni_c) goto fp8_generic;
           if (kernel_name) *kernel_name = big ? "gemm_fp8c8_stream_kernel<2,2>" : "gemm_fp8c8_stream_kernel<1,1>";
           if (big) { if (hf8) hipLaunchKernelGGL((gemm_fp8_stream_kernel<2, 2, true, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_fp8_stream_kernel<2, 2, false, true>), grid, dim3(256), 0, st, a); }
           else { if (hf8) hipLaunchKernelGGL((gemm_fp8_stream_kernel<1, 1, true, true>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_fp8_stream_kernel<1, 1, false, true>), grid, dim3(256), 0, st, a); }

@@ -30,6 +30,12 @@ __device__ __forceinline__ float act_apply(int act, float x) {
   return x;
 }
 
+template <int ACT> __device__ __forceinline__ float act_fixed(float x) {
+  if (ACT == 1 || ACT == 2) return (x <= 0.0f) ? 0.0f : x;
+  if (ACT == 3) return __frcp_rn(1.0f + __expf(-x));
+  return x;
+}
+
 // 8-bit floats [ref: src/libxsmm_math.c:546-585]: BF8 (E5M2) is the upper byte of an IEEE half; HF8 (E4M3, bias 7, no infinities)
 __device__ __forceinline__ float bf8_to_f32(unsigned char x) { return (float)__builtin_bit_cast(_Float16, (unsigned short)((unsigned short)x << 8)); }
 __device__ __forceinline__ float hf8_to_f32(unsigned char in) {
@@ -65,7 +71,9 @@ __device__ __forceinline__ int jl_of(int r, int h) { return (r & 3) + 8 * (r >> 
 
 // CF32: the C (and bias) datatype is known to be f32 at compile time (f32 kernels) -- drops the bf16 paths
 // NOBIAS: the caller adds the column bias itself (gemm_wgp16_kernel: from an LDS image behind its first barrier) -- beta * C only
-template <bool EXACT, bool CF32, bool NOBIAS = false, bool HOIST = false>
+// F16S (IEEE-half GEMMs): the start value is rounded to a half on its way in -- the reference's F16 loop adds f16(start) to the finished sum, whatever C's type, and the
+// fused path hands it bias + C as an f32 image [ref: gemm ref :2112-2117 with :296-317].  Identity when the start is one f16 value (C or the bias alone).
+template <bool EXACT, bool CF32, bool NOBIAS = false, bool HOIST = false, bool F16S = false>
 __device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
   const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
   const int c_type = CF32 ? (int)LIBXSMM_DATATYPE_F32 : p.c_type;
@@ -98,15 +106,32 @@ __device__ __forceinline__ void tile_init(f32x16& acc, const GemmArgs& p, const 
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = colbias ? (beta0 ? bias : bias + start[r]) : start[r];
+    for (int r = 0; r < 16; ++r) { const float v = colbias ? (beta0 ? bias : bias + start[r]) : start[r]; acc[r] = F16S ? (float)(_Float16)v : v; }
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = t.j0 + jl_of(r, t.h);
       float start = 0.0f;
       if (!beta0 && (EXACT || (t.ivalid && j < p.n))) start = load_c_f32(q.c, (long long)j * p.ldc + t.i, c_type);
-      acc[r] = colbias ? (beta0 ? bias : bias + start) : start;
+      const float v = colbias ? (beta0 ? bias : bias + start) : start;
+      acc[r] = F16S ? (float)(_Float16)v : v;
     }
+  }
+}
+
+// The same for a C (and bias) of the operands' 8-bit float type (BF8 / HF8 GEMMs with a result of their own type): beta * C and the fused column bias come in through the
+// type [ref: gemm ref :296-317 -- the bias operand has C's type].
+template <bool EXACT>
+__device__ __forceinline__ void tile_init_c8(f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t, bool hf8) {
+  const bool beta0 = (p.flags & LIBXSMM_GEMM_FLAG_BETA_0) != 0;
+  float bias = 0.0f;
+  if (p.colbias && (EXACT || t.ivalid)) { const unsigned char x = ((GM const unsigned char*)q.d)[t.i]; bias = hf8 ? hf8_to_f32(x) : bf8_to_f32(x); }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = t.j0 + jl_of(r, t.h);
+    float v = 0.0f;
+    if (!beta0 && (EXACT || (t.ivalid && j < p.n))) { const unsigned char x = ((GM const unsigned char*)q.c)[(long long)j * p.ldc + t.i]; v = hf8 ? hf8_to_f32(x) : bf8_to_f32(x); }
+    acc[r] = p.colbias ? (beta0 ? bias : bias + v) : v;
   }
 }
 
@@ -142,41 +167,53 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma_16bit(const u32x4& b,
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), acc, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
 }
-template <int ACT> __device__ __forceinline__ float act_fixed(float x) {
-  if (ACT == 1 || ACT == 2) return (x <= 0.0f) ? 0.0f : x;
-  if (ACT == 3) return __frcp_rn(1.0f + __expf(-x));
-  return x;
-}
 
 // Tile store.  ACT is the fused activation (0 none, 1 ReLU, 2 ReLU + bitmask, 3 sigmoid), fixed at compile time so the
 // streaming variants carry no activation code.  bf16 output of exact tiles goes out as packed dwords: registers
 // (2g, 2g+1) hold rows (j, j+1) of column i; one v_cvt_pk_bf16_f32 packs them, one DPP quad swap fetches the
 // neighbouring lane's pair and one v_perm_b32 (lane-parity dependent selector) forms (i, i+1) of row j in even
 // lanes and of row j+1 in odd lanes: 3 VALU + 1 dword store per two values.
+// ReLU bitmask of one tile (bit i % 8 of byte i / 8 + j * mask_ld / 8 [ref: mateltwise ref :150-157, :2142]): a wave ballot per column
+template <bool EXACT>
+__device__ __forceinline__ void tile_relu_mask(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
+  if (!q.mask) return;
+  const int lane = threadIdx.x & 63;
+  const long long mask_ld = ((p.ldc + 15) / 16) * 16;
+  static_for<16>([&](auto rc) {
+    constexpr int r = rc.value;
+    const int j = t.j0 + jl_of(r, t.h);
+    const bool ok = EXACT || (t.ivalid && j < p.n);
+    const unsigned long long pos = __ballot(ok && !(acc[r] <= 0.0f));
+    const unsigned long long val = __ballot(ok);
+    if ((lane & 7) == 0 && ok) {
+      GM unsigned char* byte = q.mask + t.i / 8 + (long long)j * (mask_ld / 8);
+      const unsigned char vm = (unsigned char)((val >> lane) & 0xffu), nb = (unsigned char)((pos >> lane) & 0xffu);
+      *byte = EXACT ? nb : (unsigned char)((*byte & ~vm) | (nb & vm));
+    }
+  });
+}
+// the fused activation of a tile whose store is the kernel's own (8-bit float results): bitmask first (it is taken from the sums), then the activation in place
+template <bool EXACT>
+__device__ __forceinline__ void tile_activate(f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
+  if (p.act == 0) return;                                         // wave-uniform
+  if (p.act == 2) tile_relu_mask<EXACT>(acc, p, q, t);
+  if (p.act == 3) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = act_fixed<3>(acc[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = act_fixed<1>(acc[r]);
+  }
+}
+
 template <bool EXACT, bool CF32, int ACT, bool NT>
 __device__ __forceinline__ void tile_store_impl(const f32x16& acc, const GemmArgs& p, const BatchPtrs& q, const TileCtx& t) {
   const int lane = threadIdx.x & 63;
-  const long long mask_ld = ((p.ldc + 15) / 16) * 16;
   const bool out_f32 = CF32 || (p.c_type == LIBXSMM_DATATYPE_F32);
   // bf16 fast path needs an even ldc and a 4-byte aligned C
   // (round 4: also for ragged tiles with an even m -- every row pair is whole -- with the store masked by row and column)
   const bool pack2 = (EXACT || (p.m & 1) == 0) && !out_f32 && ((p.ldc & 1) == 0) && ((((unsigned long long)(size_t)q.c) & 3ull) == 0ull);
-  if (ACT == 2) {
-    if (q.mask) {
-      static_for<16>([&](auto rc) {
-        constexpr int r = rc.value;
-        const int j = t.j0 + jl_of(r, t.h);
-        const bool ok = EXACT || (t.ivalid && j < p.n);
-        const unsigned long long pos = __ballot(ok && !(acc[r] <= 0.0f));
-        const unsigned long long val = __ballot(ok);
-        if ((lane & 7) == 0 && ok) {
-          GM unsigned char* byte = q.mask + t.i / 8 + (long long)j * (mask_ld / 8);
-          const unsigned char vm = (unsigned char)((val >> lane) & 0xffu), nb = (unsigned char)((pos >> lane) & 0xffu);
-          *byte = EXACT ? nb : (unsigned char)((*byte & ~vm) | (nb & vm));
-        }
-      });
-    }
-  }
+  if (ACT == 2) tile_relu_mask<EXACT>(acc, p, q, t);
   const bool c_f16 = p.c_type == LIBXSMM_DATATYPE_F16;            // wave-uniform: the 16-bit output is bf16 or IEEE half
   if (!CF32 && pack2) {
     const bool odd = (lane & 1) != 0;

@@ -116,16 +116,22 @@ __global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_ke
   auto init_start = [&]() {                                        // beta * C: requested with the first block, no bias yet
     static_for<TPW>([&](auto tt) {
       constexpr int t = tt.value;
-      if (mine[t]) {
-        if (F16) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        } else tile_init<false, false, true, true>(acc[t], p, q, tc[t]);
-      }
+      if (mine[t]) tile_init<false, false, true, true>(acc[t], p, q, tc[t]);
     });
   };
+  // (IEEE halves, round 6: the finished start value -- beta * C, the bias, or their f32 sum -- is rounded to f16, the rule of the reference's F16 loop: tile_init<.., F16S>)
+  auto round_start = [&]() {
+    if constexpr (F16) {
+      if (!beta0 || g.bias_dw) {
+        static_for<TPW>([&](auto tt) { constexpr int t = tt.value;
+          if (mine[t]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = (float)(_Float16)acc[t][r];
+          } });
+      }
+    }
+  };
   auto init_bias = [&]() {                                         // behind the first barrier: C from its LDS image, bias (+ beta * C) in the order of tile_init
-    if (F16) return;
     if (g.c_pieces) {
       const unsigned int m = (unsigned int)p.m;
       static_for<TPW>([&](auto tt) {
@@ -135,6 +141,9 @@ __global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_ke
           if (p.c_type == LIBXSMM_DATATYPE_F32) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const unsigned int j = (unsigned int)(tc[t].j0 + jl_of(r, tc[t].h)); acc[t][r] = (tc[t].ivalid && j < (unsigned int)p.n) ? ((const float*)img)[j * m + (unsigned int)tc[t].i] : 0.0f; }
+          } else if (p.c_type == LIBXSMM_DATATYPE_F16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const unsigned int j = (unsigned int)(tc[t].j0 + jl_of(r, tc[t].h)); acc[t][r] = (tc[t].ivalid && j < (unsigned int)p.n) ? (float)((const _Float16*)img)[j * m + (unsigned int)tc[t].i] : 0.0f; }
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const unsigned int j = (unsigned int)(tc[t].j0 + jl_of(r, tc[t].h)); acc[t][r] = (tc[t].ivalid && j < (unsigned int)p.n) ? bf16_to_f32(((const unsigned short*)img)[j * m + (unsigned int)tc[t].i]) : 0.0f; }
@@ -205,6 +214,7 @@ __global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_ke
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   wg_barrier();
   init_bias();                                                   // (an empty chain: C = beta * C (+ bias))
+  round_start();
   // (chains with TWO pairs of images -- block r + 1 in flight while block r is multiplied, one barrier per block -- measured and not adopted: the second pair halves the
   //  workgroups a CU holds; 72^3 x 4 blocks 0.60 -> 0.52, x 16 blocks 0.60 -> 0.45, 40^3 x 4 0.64 -> 0.60, profiles/r05_wgp_chains.jsonl.  Resident workgroups beat overlap
   //  inside a workgroup, every time it was tried this round.)
@@ -338,7 +348,7 @@ static inline bool wgp16_shape_ok(const GemmArgs& a, Wgp16Geo& g, unsigned int& 
     lds_bytes += ((g.bias_dw + 63u) / 64u) * 256u;
   }
   g.c_off = 0; g.c_ppc = 0; g.c_pieces = 0;
-  if (!(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && (a.c_type == LIBXSMM_DATATYPE_F32 || a.c_type == LIBXSMM_DATATYPE_BF16)) {       // beta = 1: C as whole 16-byte pieces of its columns (else: element loads)
+  if (!(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) && (a.c_type == LIBXSMM_DATATYPE_F32 || a.c_type == LIBXSMM_DATATYPE_BF16 || a.c_type == LIBXSMM_DATATYPE_F16)) {       // beta = 1: C as whole 16-byte pieces of its columns (else: element loads)
     const unsigned int ces = a.c_type == LIBXSMM_DATATYPE_F32 ? 4u : 2u;
     const unsigned long long cbits = (unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.ldc * ces | (unsigned long long)a.m * ces;
     const unsigned int c_img = ((((unsigned int)a.m * ces / 16u) * (unsigned int)a.n + 63u) / 64u) * 1024u;

@@ -7,7 +7,7 @@ int launch_gemm_wgp16(const GemmArgs& a_in, void* stream, const char** kernel_na
   *taken = 0;
   Wgp16Geo g; unsigned int lds_bytes = 0; int tpw = 0;
   const bool f16 = a_in.a_type == LIBXSMM_DATATYPE_F16;
-  if (f16 && (!(a_in.flags & LIBXSMM_GEMM_FLAG_BETA_0) || a_in.colbias || a_in.act)) return 0;       // halves: beta * C is added AFTER the sum [ref: gemm ref :2025-2124] -- the wave-per-tile kernel's own epilogue
+  if (f16 && a_in.comp_f16) return 0;       // (halves with any beta / fused operators: round 6 -- the start value is rounded to f16, gemm_wgp16_kernel round_start)
   if (!wgp16_shape_ok(a_in, g, lds_bytes, tpw)) return 0;
   GemmArgs a = a_in;
   a.tiles_m = (a.m + 31) / 32; a.tiles_n = (a.n + 31) / 32; a.map2d_shift = 0;

@@ -9,7 +9,7 @@ namespace xamd {
 // workgroup, both PACKED operand blocks (A in VNNI-4: [k/4][m] dwords, lda == m; B flat: [n][k] bytes, ldb == k) brought in as linear copies, the products and signedness
 // corrections of gemm_mfma_8bit_kernel (m8_products) fed from LDS: A as four ds_read_b32 (the k quads of my row), B as eight-byte reads of my column (k % 8 == 0 keeps
 // them aligned).  A k quad beyond k is zeroed on both sides after the unsigned -> signed shift, exactly as in the wave-per-tile kernel.  C: i32 / f32, or the 8-bit float
-// type of the operands (the reference's two-step rounding, bytes through an LDS image of C and out as 16-byte pieces where the columns allow it).  Plain epilogue only.
+// type of the operands (the reference's two-step rounding, bytes through an LDS image of C and out as 16-byte pieces where the columns allow it).  8-bit floats: any epilogue.
 // ------------------------------------------------------------------------------------------------------------------------------------------------------------
 #ifndef WGP8_W3S
 #define WGP8_W3S 5
@@ -57,15 +57,7 @@ void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {
       if (!INT && mine[t]) {
         f32x16& acc = facc[gi(t)][INT ? 0 : mi(t)][INT ? 0 : ni(t)];
         if (!c8) tile_init<false, true>(acc, p, q, tc[t]);
-        else {
-#pragma unroll
-          for (int r2 = 0; r2 < 16; ++r2) {
-            const int j = tc[t].j0 + jl_of(r2, (int)h);
-            float v = 0.0f;
-            if (!beta0 && tc[t].ivalid && j < p.n) { const unsigned char b8 = ((GM const unsigned char*)q.c)[(long long)j * p.ldc + tc[t].i]; v = KIND == 2 ? hf8_to_f32(b8) : bf8_to_f32(b8); }
-            acc[r2] = v;
-          }
-        }
+        else tile_init_c8<false>(acc, p, q, tc[t], KIND == 2);
       } });
   };
   const unsigned int m = (unsigned int)p.m, k = (unsigned int)p.k;
@@ -148,9 +140,11 @@ void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {
     // (columns that are not whole 16-byte pieces -- 72^3 -- leave byte by byte: dwords out of the image measured SLOWER than the byte stores, 0.33 against 0.38, profiles/r05_wgp_pair.jsonl)
     const bool wide = !(m & 15u) && ((((unsigned long long)(size_t)q.c) | (unsigned long long)p.ldc) & 15ull) == 0ull;      // workgroup-uniform
     if (wide) wg_barrier();                                       // everybody has read the operand images
+    // (the fused activation's ballots need every lane of a wave, and `mine` is wave-uniform)
     static_for<TPW>([&](auto tt) { constexpr int t = tt.value;
       if (mine[t]) {
-        const f32x16& acc = facc[gi(t)][mi(t)][ni(t)];
+        f32x16& acc = facc[gi(t)][mi(t)][ni(t)];
+        tile_activate<false>(acc, p, q, tc[t]);                   // fused ReLU (+ bitmask) / sigmoid (round 6)
 #pragma unroll
         for (int r2 = 0; r2 < 16; r2 += 2) {
           const unsigned int two = f32x2_to_fp8_ref(acc[r2], acc[r2 + 1], KIND == 2);
@@ -180,7 +174,7 @@ int launch_gemm_wgp8(const GemmArgs& a_in, int kind, bool ua, bool ub, void* str
   static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '0'; }();
   const GemmArgs& a = a_in;
   if (off || kind < 0 || kind > 2) return 0;
-  if (a.batch_inner || (a.list_a && !a.lists_aligned16) || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || a.colbias || a.act) return 0;
+  if (a.batch_inner || (a.list_a && !a.lists_aligned16) || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || (kind == 0 && (a.colbias || a.act))) return 0;      // (fused operators on the 8-bit floats: round 6)
   if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return 0;
   const bool c8 = kind != 0 && a.c_type == a.a_type;              // 8-bit floats with a result of their own type
   if (a.c_type != LIBXSMM_DATATYPE_F32 && a.c_type != LIBXSMM_DATATYPE_I32 && !c8) return 0;

@@ -591,6 +591,55 @@ static void contract_spmm(const oracle_gemm_desc* d, const libxsmm_gemm_param* p
   }
 }
 
+/* Fused column bias / ReLU (+ bitmask) / sigmoid on IEEE-half and 8-bit-float GEMMs [ref: :294-372, :2826-2839].  The reference swaps C for an f32 scratch when C is
+ * not f32 [:255-266], fills it with the bias (of C's type) [+ C] [:296-317] or with C alone when beta = 1 [:320-329], runs the matmul of the (A, B) pair with c_type = F32
+ * and beta = 1 on that image -- so the F16 loop adds the start value AFTER the sum and rounds it to a half on the way in [:2112-2117], the 8-bit float loops start from
+ * it [:2432-2434, :2483-2485] -- and hands the image to the unary TPP that applies the activation and converts to C's type [:335-370, mateltwise ref :303-322]. */
+static void contract_fused_lowp(const gemm_view* v, const libxsmm_gemm_ext_param* pe, int beta0) {
+  const oracle_gemm_desc* d = v->d;
+  const int f16 = (d->a_type == LIBXSMM_DATATYPE_F16);
+  const int kb = v->va ? (f16 ? 2 : 4) : 1;
+  const long long mask_ld = LIBXSMM_UPDIV(d->ldc, 16) * 16;             /* mateltwise ref :2142 */
+  unsigned char* mask = (d->act == 2) ? (unsigned char*)pe->c.secondary : NULL;
+  char* cptr = (char*)pe->c.primary;
+  const int have_start = d->colbias || !beta0;
+  int i, j, s; long long r;
+  for (j = 0; j < d->n; ++j) for (i = 0; i < d->m; ++i) {
+    const long long ci = (long long)j * d->ldc + i;
+    float start = 0.0f, c, y;
+    if (!beta0) start = (d->c_type == LIBXSMM_DATATYPE_F16) ? oracle_f16_to_f32(((const unsigned short*)cptr)[ci]) : load_f32(cptr, ci, d->c_type);
+    if (d->colbias) {
+      const float bias = (d->c_type == LIBXSMM_DATATYPE_F16) ? oracle_f16_to_f32(((const unsigned short*)pe->d.primary)[i]) : load_f32((const char*)pe->d.primary, i, d->c_type);   /* D has C's type */
+      start = beta0 ? bias : (bias + start);
+    }
+    c = (f16 || !have_start) ? 0.0f : start;
+    for (r = 0; r < v->br; ++r) {
+      const br_cursor cur = br_at(v, r);
+      for (s = 0; s < d->k; ++s) {
+        float prod;
+        if (f16) {
+          prod = oracle_f16_to_f32(((const unsigned short*)cur.a)[a_index(v, i, s, kb)]) * oracle_f16_to_f32(((const unsigned short*)cur.b)[b_index(v, s, j, kb)]);
+          c = c + prod;
+          if (d->comp_type == LIBXSMM_DATATYPE_F16) c = oracle_f16_to_f32(oracle_f32_to_f16(c));
+        } else {
+          prod = load_fp8(cur.a, a_index(v, i, s, kb), d->a_type) * load_fp8(cur.b, b_index(v, s, j, kb), d->b_type);
+          c = c + prod;
+        }
+      }
+    }
+    if (f16 && have_start) c = c + oracle_f16_to_f32(oracle_f32_to_f16(start));
+    y = act_apply(d->act, c);
+    if (d->c_type == LIBXSMM_DATATYPE_F32) ((float*)cptr)[ci] = y;
+    else if (d->c_type == LIBXSMM_DATATYPE_F16) ((unsigned short*)cptr)[ci] = oracle_f32_to_f16(y);
+    else ((unsigned char*)cptr)[ci] = d->c_type == LIBXSMM_DATATYPE_BF8 ? oracle_f32_to_bf8_rne(y) : oracle_f32_to_hf8_rne(y);
+    if (mask) {
+      unsigned char* byte = mask + i / 8 + j * (mask_ld / 8);
+      const unsigned char bit = (unsigned char)(1u << (i % 8));
+      if (c <= 0.0f) *byte = (unsigned char)(*byte & ~bit); else *byte = (unsigned char)(*byte | bit);
+    }
+  }
+}
+
 void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   gemm_view v;
   const int is_ext = (d->flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) ? 1 : 0;
@@ -609,6 +658,11 @@ void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
   if (is_lowbit_a(d->a_type) && is_int8(d->b_type) && d->c_type == LIBXSMM_DATATYPE_I32) { contract_lowbit(&v, cptr, beta0); return; }
   if ((d->flags & LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT) && is_int8(d->b_type) && (d->a_type == LIBXSMM_DATATYPE_I4X2 || d->a_type == LIBXSMM_DATATYPE_U4X2 || d->a_type == LIBXSMM_DATATYPE_MXFP4X2)) {
     contract_i4_intlv(&v, p, cptr, beta0); return;
+  }
+  if (is_ext && (d->colbias || d->act) &&
+      ((is_fp8(d->a_type) && d->b_type == d->a_type && (d->c_type == LIBXSMM_DATATYPE_F32 || d->c_type == d->a_type)) ||
+       (d->a_type == LIBXSMM_DATATYPE_F16 && d->b_type == LIBXSMM_DATATYPE_F16 && (d->c_type == LIBXSMM_DATATYPE_F16 || d->c_type == LIBXSMM_DATATYPE_F32)))) {
+    contract_fused_lowp(&v, pe, beta0); return;
   }
   if (is_fp8(d->a_type) && d->b_type == d->a_type && (d->c_type == LIBXSMM_DATATYPE_F32 || d->c_type == d->a_type)) { contract_fp8(&v, cptr, beta0); return; }
   if (d->a_type == LIBXSMM_DATATYPE_I16 && d->b_type == LIBXSMM_DATATYPE_I16 && d->c_type == LIBXSMM_DATATYPE_I32) { contract_i16(&v, (int*)cptr, beta0); return; }

@@ -25,7 +25,7 @@ from libxsmm_amd.capi import DT, GEMM_FLAG  # noqa: E402
 from oracle import pyoracle  # noqa: E402
 
 NP_OF = {DT.F32: np.float32, DT.F64: np.float64, DT.BF16: np.uint16, DT.I32: np.int32, DT.U32: np.uint32,
-         DT.I16: np.int16, DT.U16: np.uint16, DT.I8: np.int8, DT.U8: np.uint8, DT.I64: np.int64, DT.U64: np.uint64, DT.BF8: np.uint8, DT.HF8: np.uint8}
+         DT.I16: np.int16, DT.U16: np.uint16, DT.I8: np.int8, DT.U8: np.uint8, DT.I64: np.int64, DT.U64: np.uint64, DT.BF8: np.uint8, DT.HF8: np.uint8, DT.BF32: np.float32, DT.F16: np.uint16}
 
 UPLOAD_HOOK = None    # tests/guard.py: device buffers that touch unmapped address space instead of torch tensors (x -> object with data_ptr() / cpu().numpy())
 FP8_WIDE = False      # tests flip this to draw 8-bit floats over (almost) the whole exponent range
@@ -44,7 +44,24 @@ def bf16_to_f32(x: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(x, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
 
 
+def _fp8_table(hf8: bool) -> np.ndarray:
+    """value of every byte of E5M2 (BF8: the upper byte of an IEEE half) / E4M3 (HF8: bias 7, no infinities, 0x7f = NaN) [ref: src/libxsmm_math.c:546-585]"""
+    b = np.arange(256, dtype=np.uint16)
+    if not hf8:
+        return (b << 8).view(np.float16).astype(np.float64)
+    sign = np.where(b & 0x80, -1.0, 1.0)
+    e, m = ((b >> 3) & 15).astype(np.int32), (b & 7).astype(np.float64)
+    v = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * 2.0 ** (e - 7.0))
+    v = np.where((e == 15) & ((b & 7) == 7), np.nan, v)
+    return sign * v
+
+
+_FP8_VALUES = {False: _fp8_table(False), True: _fp8_table(True)}
+
+
 def as_float(x: np.ndarray, dt: int) -> np.ndarray:
+    if dt in (DT.BF8, DT.HF8):
+        return _FP8_VALUES[dt == DT.HF8][np.ascontiguousarray(x).view(np.uint8)]
     if dt == DT.F16:
         return np.ascontiguousarray(x).view(np.float16).astype(np.float64) if x.dtype in (np.uint16, np.int16) else x.astype(np.float64)
     return bf16_to_f32(x).astype(np.float64) if dt == DT.BF16 else x.astype(np.float64)
@@ -66,6 +83,8 @@ def rand_values(rng: np.random.Generator, count: int, dt: int) -> np.ndarray:
         v = ((rng.integers(0, 2, count) << 7) | (e << mbits) | rng.integers(0, 1 << mbits, count)).astype(np.uint8)
         v[rng.random(count) < 0.05] = 0
         return v
+    if dt == DT.BF32:                       # f32 storage, not bf16-representable: the rounding of the operands matters
+        return ((rng.random(count).astype(np.float32) - 0.5) * 1.37).astype(np.float32)
     v = (np.floor(rng.random(count) * 10.0) - 4.0) / 10.0
     if dt == DT.F16:
         return v.astype(np.float16).view(np.uint16)
@@ -99,7 +118,7 @@ class GemmCase:
         self.m, self.n, self.k = m, n, k
         self.a_type = a_type
         self.b_type = a_type if b_type is None else b_type
-        self.c_type = a_type if c_type is None else c_type
+        self.c_type = (DT.F32 if a_type == DT.BF32 else a_type) if c_type is None else c_type
         self.comp_type = DT.F64 if a_type == DT.F64 else (DT.I32 if a_type in (DT.I8, DT.U8) else DT.F32)   # fp8: f32
         self.scf = None if scf is None else C.c_float(scf)           # 8-bit GEMM with f32 output: scale read from c.tertiary
         ta, tb = bool(flags & GEMM_FLAG.TRANS_A), bool(flags & GEMM_FLAG.TRANS_B)

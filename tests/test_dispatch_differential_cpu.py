@@ -121,8 +121,8 @@ def _documented_refusal(r, DT):
         return "D2 VNNI operand with a k that is not a whole number of k-groups: the reference's own loop reads k/2 (k/4) groups [ref: gemm ref :2134-2161]"
     if (fl & F_VC) and r["c"] != int(DT.BF16):
         return "D3 VNNI_C with a C that is not bf16"
-    if r["fused"] and not (r["a"] == int(DT.F32) or r["a"] == int(DT.BF16)):
-        return "D5 a fused operator (argops / postops of libxsmm_dispatch_brgemm_ext) on operand types other than f32 / bf16"
+    if r["fused"] and r["a"] not in (int(DT.F32), int(DT.BF16), int(DT.BF32), int(DT.F16), int(DT.BF8), int(DT.HF8)):
+        return "D5 a fused operator (argops / postops of libxsmm_dispatch_brgemm_ext) on operand types the reference's own kernel tests never fuse (integers, f64)"
     return None
 
 

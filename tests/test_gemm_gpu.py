@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from helpers import GemmCase, TOL_BF16, TOL_F32, TOL_F64, normf_rel
+from helpers import GemmCase, TOL_BF16, TOL_F32, TOL_F64, as_float, normf_rel
 from libxsmm_amd import capi
 from libxsmm_amd.capi import DT, GEMM_FLAG
 
@@ -31,9 +31,16 @@ def _check(case, batched=True, expect_kernel=None):
     name = api.hip_kernel_name(handle, 1).decode()
     if expect_kernel is not None:
         assert expect_kernel in name, f"expected {expect_kernel}, library picked {name}"
-    err = normf_rel(case.valid_region(ref), case.valid_region(got), case.c_type)
-    assert err < _tol(case), f"{name}: normf_rel={err}"
-    if "generic" in name:
+    if case.c_type in (DT.BF8, DT.HF8) and "generic" not in name:
+        # 8-bit float results off the matrix cores: the f32 sum is formed in the matrix core's order, so a sum that sits on a rounding boundary of the 8-bit type may land
+        # on the neighbouring code (the bar of test_more_gemm_types_bit_exact)
+        key = lambda x: np.where(x.astype(np.int32) & 0x80, -(x.astype(np.int32) & 0x7f), x.astype(np.int32) & 0x7f)      # noqa: E731  sign-magnitude -> monotonic
+        gk, rk = key(case.valid_region(got).view(np.uint8)), key(case.valid_region(ref).view(np.uint8))
+        assert np.max(np.abs(gk - rk)) <= 1 and np.mean(gk != rk) < 0.03, (name, int(np.max(np.abs(gk - rk))), float(np.mean(gk != rk)))
+    else:
+        err = normf_rel(case.valid_region(ref), case.valid_region(got), case.c_type)
+        assert err < _tol(case), f"{name}: normf_rel={err}"
+    if "generic" in name and case.act != 3:       # (sigmoid: the device evaluates 1 / (1 + e^-x), the reference (tanhf(x / 2) + 1) / 2 with the host's libm -- 1e-6 apart)
         assert np.array_equal(case.valid_region(ref), case.valid_region(got)), "generic kernel must be bit-identical to the oracle"
     if rmask is not None:
         rb, gb = case.valid_mask_bits(rmask), case.valid_mask_bits(gmask)
@@ -44,8 +51,8 @@ def _check(case, batched=True, expect_kernel=None):
         pre, _ = case.run_oracle()
         case.act = act
         pre = case.valid_region(pre)
-        pre = pre.astype(np.float64) if case.c_type != DT.BF16 else (pre.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
-        decided = np.abs(pre) > (1e-2 if case.c_type == DT.BF16 else 1e-5)
+        pre = as_float(pre, case.c_type)
+        decided = np.abs(pre) > (1e-5 if case.c_type in (DT.F32, DT.F64) else 1e-2)
         assert decided.mean() > 0.5
         assert np.array_equal(rb[decided], gb[decided])
     return name
@@ -232,9 +239,9 @@ def test_f16_gemm_matches_oracle(kw):
         assert np.array_equal(case.valid_region(ref), case.valid_region(got)), "generic kernel must be bit-identical to the oracle"
     elif kw.get("flags", 0) == F.VNNI_A:
         assert "f16" in name, name
-    # what the library does not build for halves: fused epilogues, a transposed A
+    # what the library does not build for halves: a transposed A (fused epilogues: round 6, test_fused_epilogue_matches_oracle)
     assert api.dispatch_brgemm_ext(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F16, DT.F16, DT.F16, DT.F32), F.VNNI_A | F.BETA_0, 0, capi.br_config(capi.BR_NONE, 0, 0, 0),
-                                   capi.argops_cp(32, capi.UNARY.RELU, 0), capi.postops_colbias(32, DT.F16)) is None
+                                   capi.argops_cp(32, capi.UNARY.RELU, 0), capi.postops_colbias(32, DT.F16))
     assert api.dispatch_gemm(capi.gemm_shape(32, 32, 32, 32, 32, 32, DT.F16, DT.F16, DT.F16, DT.F32), F.TRANS_A | F.BETA_0, 0) is None
 
 
@@ -282,6 +289,30 @@ FUSED = [
     dict(m=72, n=40, k=48, a_type=DT.BF16, c_type=DT.F32, flags=F.VNNI_A, act=3, br_type=capi.BR_STRIDE, br_count=3),
     dict(m=96, n=96, k=96, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=1, beta=1),
     dict(m=40, n=40, k=40, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, colbias=True, act=2),
+    # round 6: the same epilogues on the other precisions the reference fuses them on (its test generator keeps fusion ON for these: generate_gemm_test_scripts.tpl:77)
+    # -- IEEE halves (the start value rounded to f16), 8-bit floats with f32 or own-type C (bias of C's type), BF32
+    dict(m=64, n=64, k=64, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=4, colbias=True, act=1),     # config #5's shape in halves
+    dict(m=64, n=64, k=64, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, colbias=True, act=2, beta=1),
+    dict(m=32, n=32, k=32, a_type=DT.F16, c_type=DT.F32, flags=F.VNNI_A, colbias=True, act=3, beta=1),
+    dict(m=32, n=24, k=16, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, colbias=True, act=2, beta=1),
+    dict(m=72, n=72, k=72, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, colbias=True, act=1, beta=1),
+    dict(m=40, n=40, k=40, a_type=DT.F16, c_type=DT.F32, flags=F.VNNI_A, colbias=True, act=2),
+    dict(m=12, n=10, k=9, a_type=DT.F16, c_type=DT.F16, act=1, beta=1),                                        # flat A: the exact kernel
+    dict(m=12, n=10, k=8, a_type=DT.F16, c_type=DT.F32, flags=F.TRANS_B, colbias=True),
+    dict(m=64, n=64, k=64, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, colbias=True, act=1),
+    dict(m=64, n=64, k=64, a_type=DT.BF8, c_type=DT.BF8, flags=F.VNNI_A, colbias=True, act=2, beta=1),
+    dict(m=32, n=32, k=64, a_type=DT.HF8, c_type=DT.HF8, flags=F.VNNI_A, colbias=True, act=3, br_type=capi.BR_STRIDE, br_count=2),
+    dict(m=32, n=32, k=64, a_type=DT.HF8, c_type=DT.F32, flags=F.VNNI_A, act=2, beta=1),
+    dict(m=17, n=9, k=12, a_type=DT.BF8, c_type=DT.BF8, flags=F.VNNI_A, colbias=True, act=2, beta=1, ldc=20),   # masked matrix-core kernel
+    dict(m=40, n=40, k=40, a_type=DT.HF8, c_type=DT.HF8, flags=F.VNNI_A, colbias=True, act=1),
+    dict(m=72, n=72, k=72, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, colbias=True, act=2, beta=1),          # workgroup-per-problem kernel
+    dict(m=96, n=96, k=96, a_type=DT.HF8, c_type=DT.HF8, flags=F.VNNI_A, colbias=True, act=2),
+    dict(m=12, n=10, k=7, a_type=DT.BF8, c_type=DT.BF8, act=1),                                                   # flat A: the exact kernel
+    dict(m=13, n=11, k=8, a_type=DT.HF8, c_type=DT.F32, flags=F.TRANS_B, act=2, beta=1),
+    dict(m=32, n=32, k=32, a_type=DT.BF32, colbias=True, act=1),
+    dict(m=64, n=64, k=64, a_type=DT.BF32, colbias=True, act=2, beta=1, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=17, n=9, k=31, a_type=DT.BF32, lda=20, ldb=33, ldc=19, colbias=True, act=2, beta=1),
+    dict(m=13, n=7, k=5, a_type=DT.BF32, flags=F.TRANS_A, act=3),
 ]
 
 

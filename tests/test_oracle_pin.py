@@ -38,6 +38,23 @@ GEMM_CASES = [
     dict(m=20, n=12, k=16, colbias=True, act=2),
     dict(m=20, n=12, k=16, colbias=False, act=3, beta=1),
     dict(m=32, n=32, k=32, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, act=3),
+    # the same fused epilogues on the other precisions the reference's kernel tests keep fusion ON for (samples/xgemm/kernel_test/generate_gemm_test_scripts.tpl:77):
+    # IEEE halves (f32 accumulation), 8-bit floats (f32 or own-type C), BF32 -- bias of C's type, start value / conversion rules of each loop [gemm ref :294-372]
+    dict(m=32, n=32, k=32, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, colbias=True, act=1),
+    dict(m=33, n=17, k=18, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, colbias=True, act=2, beta=1, ldc=40),
+    dict(m=24, n=20, k=16, a_type=DT.F16, c_type=DT.F32, flags=F.VNNI_A, colbias=True, act=3, beta=1, br_type=capi.BR_STRIDE, br_count=3),
+    dict(m=12, n=10, k=9, a_type=DT.F16, c_type=DT.F16, act=1, beta=1),
+    dict(m=12, n=10, k=8, a_type=DT.F16, c_type=DT.F32, flags=F.TRANS_B, colbias=True),
+    dict(m=64, n=64, k=64, a_type=DT.F16, c_type=DT.F16, flags=F.VNNI_A, colbias=True, act=1, br_type=capi.BR_STRIDE, br_count=2),
+    dict(m=32, n=32, k=64, a_type=DT.BF8, c_type=DT.F32, flags=F.VNNI_A, colbias=True, act=1),
+    dict(m=17, n=9, k=12, a_type=DT.BF8, c_type=DT.BF8, flags=F.VNNI_A, colbias=True, act=2, beta=1, ldc=20),
+    dict(m=12, n=10, k=7, a_type=DT.BF8, c_type=DT.BF8, act=1),
+    dict(m=32, n=32, k=64, a_type=DT.HF8, c_type=DT.HF8, flags=F.VNNI_A, colbias=True, act=3, br_type=capi.BR_STRIDE, br_count=2),
+    dict(m=13, n=11, k=8, a_type=DT.HF8, c_type=DT.F32, flags=F.TRANS_B, act=2, beta=1),
+    dict(m=64, n=64, k=64, a_type=DT.HF8, c_type=DT.HF8, flags=F.VNNI_A, colbias=True, act=1, beta=1),
+    dict(m=32, n=32, k=32, a_type=DT.BF32, colbias=True, act=1),
+    dict(m=17, n=9, k=31, a_type=DT.BF32, lda=20, ldb=33, ldc=19, colbias=True, act=2, beta=1),
+    dict(m=13, n=7, k=5, a_type=DT.BF32, flags=F.TRANS_A, act=3),
     # 8-bit integer GEMMs: every signedness combination, i32 and scaled f32 output
     dict(m=32, n=32, k=64, a_type=DT.I8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3),
     dict(m=32, n=32, k=64, a_type=DT.U8, b_type=DT.I8, c_type=DT.I32, flags=F.VNNI_A, beta=1),

@@ -133,6 +133,15 @@ def test_reference_gemm_driver(args):
     "F32 F32 F32 F32 23 23 23 23 23 23 1 0 0 0 0 0 0 0 0 nopf nobr 1 0 2 0 1 2",
     "F32 F32 F32 F32 32 32 32 32 32 32 1 0 0 0 0 0 0 0 0 nopf offsbr 4 0 2 0 0 3",
     "BF16 BF16 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0 1 0",
+    # round 6: the seven further precisions the reference's kernel tests keep fusion ON for (samples/xgemm/kernel_test/generate_gemm_test_scripts.tpl:77)
+    "F16 F16 F32 F16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf strdbr 4 0 2 0 1 1",
+    "F16 F16 F32 F32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf nobr 1 0 2 0 1 2",
+    "BF8 BF8 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0 1 1",
+    "BF8 BF8 F32 BF8 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0 1 2",
+    "HF8 HF8 F32 F32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf strdbr 2 0 2 0 1 3",
+    "HF8 HF8 F32 HF8 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0 1 1",
+    "BF32 BF32 F32 F32 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf nobr 1 0 2 0 1 2",
+    "BF32 BF32 F32 F32 23 23 23 23 23 23 1 1 0 0 0 0 0 0 0 nopf nobr 1 0 2 0 0 3",
 ])
 def test_reference_fused_gemm_driver(args):
     check("gemm_kernel_fused", *args.split())
