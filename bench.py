@@ -212,9 +212,10 @@ class Workload:
         self.hint = hint if hint is not None else (2 if (mode == "stream" and nsets > 1 and nsets * set_bytes > 2 * L3_BYTES) else 0)
         gen = torch.Generator(device=dev).manual_seed(seed)
         tdt = torch.int16 if self.bf16 else (torch.float64 if self.f64 else torch.float32)
+        skew = int(os.environ.get("XAMD_BENCH_SKEW", "0")) // es          # experiment: B / C start `skew` / 2 `skew` bytes into their allocations (channel aliasing of same-sized arrays)
         self.A = [gen_values(na * m * m, kind, dev, gen) for _ in range(nsets)]
-        self.B = [gen_values(nb * m * m, kind, dev, gen) for _ in range(nsets)]
-        self.C = [torch.zeros(batch * m * m, dtype=tdt, device=dev) for _ in range(nsets)]
+        self.B = [gen_values(nb * m * m + skew, kind, dev, gen)[skew:] for _ in range(nsets)]
+        self.C = [torch.zeros(batch * m * m + 2 * skew, dtype=tdt, device=dev)[2 * skew:] for _ in range(nsets)]
         self.D = gen_values(m, self.bf16, dev, gen) if fused else None
         t = DT.F16 if dtype == "f16" else (DT.BF16 if self.bf16 else (DT.F64 if self.f64 else DT.F32))
         self.t = t
@@ -842,7 +843,7 @@ def compact_line(full, detail_path):
         line["pipelined_verified"] = all(v.get("verified", False) for v in pl.values() if isinstance(v, dict))
     if full.get("effective_clock_GHz"):
         ec = full["effective_clock_GHz"]
-        line["effective_clock_GHz"] = [ec.get("bf16_m64_blocked_8192"), ec.get("bf16_m64_blocked_8192_on_zeros"), ec.get("mfma_busy_frac")]   # [drivers' data, zeros, matrix pipe busy]: committed rocprofv3 pass
+        line["effective_clock_GHz_committed_profile"] = [ec.get("bf16_m64_blocked_8192"), ec.get("bf16_m64_blocked_8192_on_zeros"), ec.get("mfma_busy_frac")]   # [drivers' data, zeros, matrix pipe busy]: committed rocprofv3 pass
     for k in ("l3_resident_us", "without_streaming_hint_us", "mfma_power_roof_TF"):
         if full.get(k) is not None:
             line[k] = full[k]

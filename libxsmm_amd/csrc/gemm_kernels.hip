@@ -92,11 +92,16 @@ __device__ __forceinline__ void generic_epilogue(const GemmArgs& p, const BatchP
     }
   }
   if (!valid) return;
-  if (p.vnni_c && p.c_type == LIBXSMM_DATATYPE_BF16) {
+  if (p.vnni_c && (p.c_type == LIBXSMM_DATATYPE_BF16 || p.c_type == LIBXSMM_DATATYPE_F16)) {
     // NORM -> VNNI2 of the result [ref: gemm ref :2802-2815]; the pad column of an odd n is zero-filled
     GM unsigned short* c = (GM unsigned short*)q.c;
-    c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + (j % 2)] = f32_to_bf16_rne(y);
+    c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + (j % 2)] = p.c_type == LIBXSMM_DATATYPE_F16 ? __builtin_bit_cast(unsigned short, (_Float16)y) : f32_to_bf16_rne(y);
     if ((p.n & 1) && j == p.n - 1) c[(long long)(j / 2) * p.ldc * 2 + (long long)i * 2 + 1] = 0;
+  } else if (p.vnni_c && (p.c_type == LIBXSMM_DATATYPE_BF8 || p.c_type == LIBXSMM_DATATYPE_HF8)) {
+    // 8-bit results: NORM -> VNNI4 [ref: gemm ref :2806, mateltwise ref :737-759]; the pad columns up to a multiple of four are zero-filled
+    GM unsigned char* c = (GM unsigned char*)q.c;
+    c[(long long)(j / 4) * p.ldc * 4 + (long long)i * 4 + (j % 4)] = p.c_type == LIBXSMM_DATATYPE_BF8 ? lowp::f16_to_bf8_rne(lowp::f32_to_f16(y)) : lowp::f16_to_hf8_rne(lowp::f32_to_f16(y));
+    if (j == p.n - 1) for (int jj = p.n; (jj & 3) != 0; ++jj) c[(long long)(jj / 4) * p.ldc * 4 + (long long)i * 4 + (jj % 4)] = 0;
   } else if (p.c_type == LIBXSMM_DATATYPE_F32) {
     ((GM float*)q.c)[(long long)j * p.ldc + i] = y;
   } else if (p.c_type == LIBXSMM_DATATYPE_F16) {        // (the reduce pass of a k-sliced GEMM with IEEE-half C: round 3; fused IEEE-half GEMMs: round 6)
@@ -1642,7 +1647,7 @@ __global__ __launch_bounds__(256) void gemm_p16_kernel(GemmArgs p) {
   for (int pp = 0; pp < PPW; ++pp) {
     if (first + pp < p.nbatch) {
       if (c_f32) st_stream((GM f32x4*)((GM float*)q[pp].c + (unsigned long long)x * (unsigned int)p.ldc + 4u * g), acc[pp]);
-      else { u32x2 v; v[0] = cvt_pk_bf16(acc[pp][0], acc[pp][1]); v[1] = cvt_pk_bf16(acc[pp][2], acc[pp][3]);
+      else { u32x2 v; v[0] = bf16_pk_exact(acc[pp][0], acc[pp][1]); v[1] = bf16_pk_exact(acc[pp][2], acc[pp][3]);
              st_stream((GM u32x2*)((GM unsigned short*)q[pp].c + (unsigned long long)x * (unsigned int)p.ldc + 4u * g), v); }
     }
   }
@@ -2271,7 +2276,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_forms_kernel(GemmArgs p) {
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) {
       const unsigned int j = (unsigned int)job.j0 + (unsigned int)jl_of(2 * g2, (int)h);
-      st_stream(c32 + (unsigned long long)(j >> 1) * (unsigned int)p.ldc + (unsigned int)tc.i, cvt_pk_bf16(acc[2 * g2], acc[2 * g2 + 1]));
+      st_stream(c32 + (unsigned long long)(j >> 1) * (unsigned int)p.ldc + (unsigned int)tc.i, bf16_pk_exact(acc[2 * g2], acc[2 * g2 + 1]));
     }
   } else tile_store<true, false>(acc, p, q, tc);
 }
@@ -2566,7 +2571,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_bf16_macro_kernel(GemmArgs p)
       GM char* base = (GM char*)p.c + row_off(ti, odd ? 1u : 0u);
       static_for<8>([&](auto gc) {
         constexpr int r0 = 2 * gc.value, jr = (r0 & 3) + 8 * (r0 >> 2);
-        const unsigned int wv = F16 ? cvt_pk_f16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]) : cvt_pk_bf16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]);
+        const unsigned int wv = F16 ? cvt_pk_f16(acc[ti][tj][r0], acc[ti][tj][r0 + 1]) : bf16_pk_exact(acc[ti][tj][r0], acc[ti][tj][r0 + 1]);
         const unsigned int nv = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)wv, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
         st_stream((GM unsigned int*)(base + col_off(col0 + (unsigned int)jr + (odd ? 1u : 0u))), (unsigned int)__builtin_amdgcn_perm(nv, wv, sel));
       });
@@ -2953,13 +2958,10 @@ __global__ __launch_bounds__(256) void gemm_mx4i8_pipe_kernel(GemmArgs p, unsign
               }
             } else {
               unsigned short* l16 = (unsigned short*)lds;
-              unsigned int pk[8]; bool nan_seen = false;
+              unsigned int pk[8]; float yv[16];
 #pragma unroll
-              for (int r2 = 0; r2 < 8; ++r2) pk[r2] = cvt_pk_bf16_dazexact(add_rn(0.0f, facc[2 * r2]), add_rn(0.0f, facc[2 * r2 + 1]), nan_seen);
-              if (__builtin_amdgcn_ballot_w64(nan_seen) != 0ull) {          // a NaN somewhere in the tile: the reference's conversion in software for all of it
-#pragma unroll
-                for (int r2 = 0; r2 < 8; ++r2) pk[r2] = (unsigned int)f32_to_bf16_rne(add_rn(0.0f, facc[2 * r2])) | ((unsigned int)f32_to_bf16_rne(add_rn(0.0f, facc[2 * r2 + 1])) << 16);
-              }
+              for (int r2 = 0; r2 < 16; ++r2) yv[r2] = add_rn(0.0f, facc[r2]);
+              bf16_pk_exact_n<8>(yv, pk);
 #pragma unroll
               for (int r2 = 0; r2 < 8; ++r2) { l16[li + jl_of(2 * r2, h) * 32] = (unsigned short)pk[r2]; l16[li + jl_of(2 * r2 + 1, h) * 32] = (unsigned short)(pk[r2] >> 16); }
 #pragma unroll
@@ -3588,8 +3590,7 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     const unsigned int fl8 = d.flags;
     if (d.comp_type != LIBXSMM_DATATYPE_I32) return false;
     if (fl8 & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) return false;
-    const bool va8 = (fl8 & LIBXSMM_GEMM_FLAG_VNNI_A) != 0;
-    if (d.c_type == LIBXSMM_DATATYPE_F32 && !va8) return false;
+    const bool va8 = (fl8 & LIBXSMM_GEMM_FLAG_VNNI_A) != 0 || d.c_type == LIBXSMM_DATATYPE_F32;      // f32 result: A is read as VNNI-4 with or without the flag [ref: gemm ref :1556-1683] (effective_gemm_flags)
     if (va8 && (d.k & 3)) return false;
     if (d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0) return false;
     return d.lda >= d.m && d.ldb >= d.k && d.ldc >= d.m;
@@ -3600,7 +3601,9 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     // comp F32, F16 (the running sum rounded to f16 after every product: generic kernel) or IMPLICIT (= F32 here; the reference means F16 by it on
     // AVX512-FP16 hosts only)
     if (d.comp_type != LIBXSMM_DATATYPE_F32 && d.comp_type != LIBXSMM_DATATYPE_F16 && d.comp_type != LIBXSMM_DATATYPE_IMPLICIT) return false;
-    if (fl & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_VNNI_B | LIBXSMM_GEMM_FLAG_VNNI_C)) return false;
+    if (fl & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_VNNI_B)) return false;
+    // VNNI_C: the finished F16 result re-laid as VNNI-2 [ref: gemm ref :2802-2815]; beta = 0, no fused operator (the reference's driver and test generator: gemm_kernel.c:3842, tpl :82)
+    if ((fl & LIBXSMM_GEMM_FLAG_VNNI_C) && (d.c_type != LIBXSMM_DATATYPE_F16 || !(fl & LIBXSMM_GEMM_FLAG_BETA_0) || d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0)) return false;
     if ((fl & LIBXSMM_GEMM_FLAG_VNNI_A) && (d.k & 1)) return false;
     if (!fused_ops_ok(d)) return false;
     if ((fl & LIBXSMM_GEMM_FLAG_TRANS_B) ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
@@ -3611,7 +3614,9 @@ bool gemm_supported(const libxsmm_gemm_descriptor& d_in) {
     const unsigned int fl8 = d.flags;
     if (d.comp_type != LIBXSMM_DATATYPE_F32) return false;
     const bool ta8 = fl8 & LIBXSMM_GEMM_FLAG_TRANS_A, tb8 = fl8 & LIBXSMM_GEMM_FLAG_TRANS_B, va8 = fl8 & LIBXSMM_GEMM_FLAG_VNNI_A, vb8 = fl8 & LIBXSMM_GEMM_FLAG_VNNI_B;
-    if ((fl8 & LIBXSMM_GEMM_FLAG_VNNI_C) || (va8 && ta8) || (vb8 && !tb8) || ((va8 || vb8) && (d.k & 3))) return false;
+    // VNNI_C: a result of the operands' 8-bit type re-laid as VNNI-4 [ref: gemm ref :2802-2815]; beta = 0, no fused operator
+    if ((fl8 & LIBXSMM_GEMM_FLAG_VNNI_C) && (d.c_type != d.a_type || !(fl8 & LIBXSMM_GEMM_FLAG_BETA_0) || d.bin_type != 0 || d.cp_type != 0 || d.ap_type != 0 || d.bp_type != 0)) return false;
+    if ((va8 && ta8) || (vb8 && !tb8) || ((va8 || vb8) && (d.k & 3))) return false;
     if (!fused_ops_ok(d)) return false;
     if (ta8 ? (d.lda < d.k) : (d.lda < d.m)) return false;
     if (tb8 ? (d.ldb < d.n) : (d.ldb < d.k)) return false;
@@ -4814,6 +4819,9 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       // (whole 64-tiles stay with the 64^3-per-workgroup kernel: 0.735 against 0.753 at 65 536 problems but 0.61 against 0.53 at 4096, profiles/r05_wgp_pair.jsonl)
       if (!pl.exact) { int taken = 0; const int e = launch_gemm_wgp16(a, stream, kernel_name, &taken); if (taken) return e; }       // gemm_wgp.hpp (round 5)
       grid = wave_grid(64, 64);
+      if (pl.exact && a.m == 64 && a.n == 64 && !a.batch_inner && (a.a_type != LIBXSMM_DATATYPE_F16 || f16_fast)) {       // gemm_w64_kernels.hip (round 6): 64^3, one problem per wave
+        int taken = 0; const int e = launch_gemm_16bit_w64(a, stream_nt(a, 2, typesize_c(a)), stream, kernel_name, &taken); if (taken) return e;
+      }
       if (a.a_type == LIBXSMM_DATATYPE_F16 && f16_fast && pl.exact && a.m == 64 && a.n == 64 && !a.batch_inner && bf16_wg64_ok(a)) {
         a.map2d_shift = 0;
         grid = dim3(a.nbatch);

@@ -15,17 +15,13 @@
 #include <cstdlib>
 #include "internal.hpp"
 #include "gemm_device.hpp"
+#include "bf16_cvt.hpp"
 
 namespace xamd {
 
 typedef short bf16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int small_cvt_pk_bf16(float lo, float hi) {       // v_cvt_pk_bf16_f32 (RNE), as in gemm_kernels.hip
-  const f32x2_t v = {lo, hi};
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwbf16x2_t));
-}
+__device__ __forceinline__ unsigned int small_cvt_pk_bf16(float lo, float hi) { return bf16_pk_exact(lo, hi); }       // the reference's conversion exactly (bf16_cvt.hpp)
 
 template <int AUX>
 __global__ __launch_bounds__(256) void gemm_f32_p16w_kernel(GemmArgs p) {

@@ -3,6 +3,7 @@
 // form), the 16-bit MFMA step, the wave -> (problem, tile) decomposition.  Semantics of the fused epilogue: [ref: src/generator_gemm_reference_impl.c:294-372].
 #pragma once
 #include "gemm_device.hpp"
+#include "bf16_cvt.hpp"
 
 // a*b+c below means two roundings unless fma()/MFMA is spelled out: parity with the reference's C loops depends on it
 #pragma clang fp contract(off)
@@ -135,32 +136,16 @@ __device__ __forceinline__ void tile_init_c8(f32x16& acc, const GemmArgs& p, con
   }
 }
 
-// Hardware RNE conversion of two f32 to a packed bf16 pair (v_cvt_pk_bf16_f32).  Differs from the reference's
-// software rounding [ref: src/libxsmm_math.c:684-704] only for f32 denormal inputs (|x| < 1.2e-38 is not flushed
-// to zero first) and in the payload of NaNs; used in GEMM epilogues, whose parity bar is a norm, not bit equality.
-typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+// Hardware RNE conversion of two f32 to a packed bf16 pair (v_cvt_pk_bf16_f32): the reference's rounding for everything but f32 denormals -- bf16_cvt.hpp has the exact
+// forms every C store goes through since round 6; this bare one is for values that cannot be denormal (operands being re-laid).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) {
-  const f32x2 v = {lo, hi};
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwbf16x2));
-}
-// The reference's conversion EXACTLY (denormal inputs become signed zeros first), on the hardware instruction: ~4 vector instructions per element instead of the ~12
-// (and a divergent branch) of f32_to_bf16_rne.  NaNs are the one input whose result the instruction may encode differently: `nan_seen` collects them so that the
-// caller can send a wave that holds one through the software conversion.
-__device__ __forceinline__ unsigned int cvt_pk_bf16_dazexact(float lo, float hi, bool& nan_seen) {
-  const unsigned int ul = __float_as_uint(lo), uh = __float_as_uint(hi);
-  const float fl = __builtin_amdgcn_class(lo, 0x090) ? __uint_as_float(ul & 0x80000000u) : lo;      // class bits 4 / 7: negative / positive denormal
-  const float fh = __builtin_amdgcn_class(hi, 0x090) ? __uint_as_float(uh & 0x80000000u) : hi;
-  nan_seen = nan_seen || __builtin_amdgcn_class(lo, 0x003) || __builtin_amdgcn_class(hi, 0x003);   // class bits 0 / 1: signalling / quiet NaN
-  return cvt_pk_bf16(fl, fh);
-}
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float lo, float hi) { return bf16_pk_hw(lo, hi); }
 // the same for IEEE halves (RNE, the conversion the reference's f32 -> f16 helper performs [ref: src/libxsmm_math.c libxsmm_convert_f32_to_f16])
 typedef _Float16 hwf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int cvt_pk_f16(float lo, float hi) {
   const f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwf16x2));
 }
-__device__ __forceinline__ unsigned int cvt_pk_16(bool f16, float lo, float hi) { return f16 ? cvt_pk_f16(lo, hi) : cvt_pk_bf16(lo, hi); }
 // one 32 x 32 x 16 step on 16-bit operands: bf16 or (F16) IEEE halves -- same operand layout, same rate
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 template <bool F16> __device__ __forceinline__ f32x16 mfma_16bit(const u32x4& b, const u32x4& a, const f32x16& acc) {
@@ -219,9 +204,16 @@ __device__ __forceinline__ void tile_store_impl(const f32x16& acc, const GemmArg
     const bool odd = (lane & 1) != 0;
     const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
     GM unsigned short* base = (GM unsigned short*)q.c + (long long)(t.j0 + 4 * t.h + (odd ? 1 : 0)) * p.ldc + (t.i & ~1);
+    float y[16]; unsigned int wp[8];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = act_fixed<ACT>(acc[r]);
+    if (c_f16) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) wp[g] = cvt_pk_f16(y[2 * g], y[2 * g + 1]);
+    } else bf16_pk_exact_n<8>(y, wp);                     // (the reference's conversion exactly: denormal sums are flushed -- bf16_cvt.hpp)
     static_for<8>([&](auto gc) {
       constexpr int g = gc.value, r0 = 2 * g, jr = (r0 & 3) + 8 * (r0 >> 2);
-      const unsigned int w = cvt_pk_16(c_f16, act_fixed<ACT>(acc[r0]), act_fixed<ACT>(acc[r0 + 1]));
+      const unsigned int w = wp[g];
       const unsigned int n = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
       if (EXACT || (t.ivalid && t.j0 + 4 * t.h + (odd ? 1 : 0) + jr < p.n))
         st_stream<NT>((GM unsigned int*)(base + (long long)jr * p.ldc), (unsigned int)__builtin_amdgcn_perm(n, w, sel));
@@ -264,8 +256,15 @@ __device__ __forceinline__ void tile_store_buf_impl(const f32x16& acc, const Gem
     const bool odd = (lane & 1u) != 0;
     const unsigned int sel = odd ? 0x03020706u : 0x05040100u;
     const unsigned int voff = ((4u * (unsigned int)t.h + (odd ? 1u : 0u)) * ldc + ((unsigned int)t.i & ~1u)) * 2u;
+    float y[16]; unsigned int wp[8];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = act_fixed<ACT>(acc[r]);
+    if (c_f16) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) wp[g] = cvt_pk_f16(y[2 * g], y[2 * g + 1]);
+    } else bf16_pk_exact_n<8>(y, wp);
     static_for<8>([&](auto gc) { constexpr int g = gc.value, r0 = 2 * g, jr = (r0 & 3) + 8 * (r0 >> 2);
-      const unsigned int w = cvt_pk_16(c_f16, act_fixed<ACT>(acc[r0]), act_fixed<ACT>(acc[r0 + 1]));
+      const unsigned int w = wp[g];
       const unsigned int n = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
       __builtin_amdgcn_raw_buffer_store_b32((unsigned int)__builtin_amdgcn_perm(n, w, sel), rc, (int)voff, (int)(((unsigned int)t.j0 + (unsigned int)jr) * ldc * 2u), 0); });
     return;

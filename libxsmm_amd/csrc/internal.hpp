@@ -96,6 +96,7 @@ struct MeltwArgs {
   const void* aux_in; void* aux_out;                // secondary slots (masks, indices, offsets)
   long long bs_in0, bs_in1, bs_in2, bs_out, bs_aux; // batch byte strides
   unsigned long long scalar_u64;                    // op.primary payloads read on the host
+  unsigned long long scalar_u64b;                   // a second one (DECOMP_FP32_TO_BF16X3: the byte offset of the third piece)
   float scalar_f32;
   unsigned int nbatch;
   int m, n, ldi, ldi1, ldi2, ldo;
@@ -241,9 +242,10 @@ const char* gemm_f64_kernel_name(const libxsmm_gemm_descriptor& d);
 int launch_gemm_f32_wg64_sharedb(const GemmArgs& args, bool nt, void* stream, const char** kernel_name, int* taken);   // gemm_sharedb_kernels.hip: 64^3 f32, B shared by the batch
 int launch_gemm_p16w(const GemmArgs& args, bool nt, void* stream, const char** kernel_name, int* taken);
 int launch_gemm_wgp16(const GemmArgs& args, void* stream, const char** kernel_name, int* taken);
+int launch_gemm_16bit_w64(const GemmArgs& args, bool nt, void* stream, const char** kernel_name, int* taken);   // gemm_w64_kernels.hip: bf16 / f16 64^3, one problem per wave, whole-line requests
 int launch_gemm_wgp_f32(const GemmArgs& args, void* stream, const char** kernel_name, int* taken);      // gemm_wgp_f32_kernels.hip
 int launch_gemm_wgp8(const GemmArgs& args, int kind, bool ua, bool ub, void* stream, const char** kernel_name, int* taken);   // 8-bit x 8-bit (integers / BF8 / HF8), packed blocks
-int launch_gemm_wgp16_w8(const GemmArgs& args, int kind, void* stream, const char** kernel_name, int* taken);   // the same form for 8-bit weights x bf16 (kind: gemm_w8_bf16_kernel's KIND)   // gemm_wgp16_kernels.hip: ragged 16-bit shapes, one problem per workgroup, whole problem in LDS   // gemm_small_kernels.hip: 16^3 f32 / bf16, A by LDS-DMA
+int launch_gemm_wgp16_w8(const GemmArgs& args, int kind, void* stream, const char** kernel_name, int* taken);   // the same form for 8-bit weights x bf16 (kind: gemm_w8_bf16_kernel's KIND)
 const char* gemm_kernel_name(const libxsmm_gemm_descriptor& d, bool batched);
 bool gemm_supported(const libxsmm_gemm_descriptor& d);
 int launch_meltw(const MeltwArgs& args, void* stream, const char** kernel_name);

@@ -232,6 +232,24 @@ __global__ __launch_bounds__(256) void meltw_unary_kernel(MeltwArgs p) {
       mw_store((gptr)p.aux_out + (long long)e.bidx * p.bs_aux, i + (long long)j * p.ldo, p.out_type, x);
       return;
     }
+    case LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X2: case LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X3: {      // [ref: :2437-2470]
+      // f32 -> a sum of two / three bf16: the leading piece(s) by TRUNCATION (upper 16 bits), the last by RNE of what is left (both subtractions are exact);
+      // the pieces lie strides[0] / strides[1] BYTES behind the first (out.secondary, read on the host)
+      if (!e.valid) return;
+      const float x = ((GM const float*)in)[bc_index(bc, i, j, p.ldi)];
+      const long long o = i + (long long)j * p.ldo;
+      GM unsigned short* o16 = (GM unsigned short*)out;
+      const unsigned int u1 = __float_as_uint(x) & 0xffff0000u;
+      const float r1 = x - __uint_as_float(u1);
+      o16[o] = (unsigned short)(u1 >> 16);
+      if (p.type == LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X3) {
+        const unsigned int u2 = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(u2);
+        o16[o + (long long)(p.scalar_u64 / 2)] = (unsigned short)(u2 >> 16);
+        o16[o + (long long)(p.scalar_u64b / 2)] = mw_f2bf(r2);
+      } else o16[o + (long long)(p.scalar_u64 / 2)] = mw_f2bf(r1);
+      return;
+    }
     case LIBXSMM_MELTW_TYPE_UNARY_UNZIP: {                      // [ref: :2419-2432]
       if (!e.valid) return;
       const unsigned int u = ((GM const unsigned int*)in)[bc_index(bc, i, j, p.ldi)];
@@ -1232,6 +1250,48 @@ __global__ __launch_bounds__(1024) void mul_reduce_scalar_kernel(MeltwArgs p) {
   if (threadIdx.x == 0) mw_store((gptr)p.out + (long long)b * p.bs_out, 0, p.out_type, part[0]);
 }
 
+// UNARY_REDUCE_TO_SCALAR_OP_ADD: out[0] = sum_ij in(i, j) [ref: mateltwise ref :2097-2116] -- the same scheme (1024 partial sums folded pairwise: deterministic, a
+// tree order instead of the reference's serial one); all-f64 descriptors accumulate in double as the reference does.
+template <typename T>
+__global__ __launch_bounds__(1024) void reduce_scalar_kernel(MeltwArgs p) {
+  __shared__ T part[1024];
+  const unsigned int b = blockIdx.x;
+  gcptr in0 = (gcptr)p.in0 + (long long)b * p.bs_in0;
+  const int bc0 = bcast_kind(p.operation, p.type, p.flags, 0);
+  const long long total = (long long)p.m * p.n;
+  T acc = (T)0;
+  for (long long e = threadIdx.x; e < total; e += 1024) {
+    const long long j = e / p.m, i = e - j * p.m;
+    if constexpr (sizeof(T) == 8) acc += ((GM const double*)in0)[bc_index(bc0, i, j, p.ldi)];
+    else acc += mw_load(in0, bc_index(bc0, i, j, p.ldi), p.in0_type);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) { if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    if constexpr (sizeof(T) == 8) ((GM double*)((gptr)p.out + (long long)b * p.bs_out))[0] = part[0];
+    else mw_store((gptr)p.out + (long long)b * p.bs_out, 0, p.out_type, part[0]);
+  }
+}
+
+// UNARY_REDUCE_X_OP_ADD_NCNC_FORMAT [ref: mateltwise ref :2118-2141]: the input is a blocked [N / bn][C / bc][bn][bc] tensor (bc = the shape's m, bn = its n, C = its
+// ldi, N = its ldo); out[c] = sum over all N of channel c, added in the reference's order (blocks of bn rows, rows inside a block) -- one thread per channel, so the
+// sum is BIT-IDENTICAL to the reference's; consecutive threads read consecutive addresses (ic is the innermost index).
+__global__ __launch_bounds__(256) void reduce_ncnc_kernel(MeltwArgs p) {
+  const int bc = p.m, bn = p.n, C = p.ldi, N = p.ldo;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= (C / bc) * bc) return;
+  const unsigned int b = blockIdx.y;
+  gcptr in = (gcptr)p.in0 + (long long)b * p.bs_in0;
+  const int iC = c / bc, ic = c - iC * bc;
+  float tmp = 0.0f;
+  for (int iN = 0; iN < N / bn; ++iN) {
+    const long long base = (long long)iN * C * bn + (long long)iC * bn * bc + ic;
+    for (int i_n = 0; i_n < bn; ++i_n) tmp += mw_load(in, base + (long long)i_n * bc, p.in0_type);
+  }
+  mw_store((gptr)p.out + (long long)b * p.bs_out, c, p.out_type, tmp);
+}
+
 // second pass of the two-pass column reduction: partial[z][2][m] -> out (chunks combined in order z = 0, 1, ...)
 __global__ __launch_bounds__(256) void reduce_combine_kernel(MeltwArgs p, const float* partial, int nchunks) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1437,6 +1497,12 @@ bool meltw_supported(const libxsmm_meltw_descriptor& d) {
     if (t == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT || t == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT_INV)      // no broadcasts; 16 rows per draw
       return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type) && !(d.flags & (LIBXSMM_MELTW_FLAG_UNARY_BCAST_ROW | LIBXSMM_MELTW_FLAG_UNARY_BCAST_COL | LIBXSMM_MELTW_FLAG_UNARY_BCAST_SCALAR | LIBXSMM_MELTW_FLAG_UNARY_STOCHASTIC_ROUND));
     if (is_reduce_cols_idx_type(t)) return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type);
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_TO_SCALAR_OP_ADD)                                  // [ref: :2097-2116] f64 only when input, output and compute all are
+      return (f64 && d.comp_type == LIBXSMM_DATATYPE_F64) || (is_tpp_float(d.in0_type) && is_tpp_float(d.out_type));
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD_NCNC_FORMAT)                              // [ref: :2118-2141] m = bc, n = bn, ldi = C, ldo = N
+      return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type) && d.m > 0 && d.n > 0 && d.ldi >= d.m && d.ldo >= d.n;
+    if (t == LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X2 || t == LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X3)      // [ref: :2437-2470]
+      return d.in0_type == LIBXSMM_DATATYPE_F32 && d.out_type == LIBXSMM_DATATYPE_BF16;
     if (is_reduce_type(t) && (d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_RECORD_ARGOP))       // recorded for MAX / ABSMAX / MIN over columns [ref: :1376-1424]
       return is_tpp_float(d.in0_type) && is_tpp_float(d.out_type) && !(d.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) &&
              (t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN || t == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ABSMAX);
@@ -1616,6 +1682,17 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
   if (a.operation == LIBXSMM_MELTW_OPERATION_BINARY && a.type == LIBXSMM_MELTW_TYPE_BINARY_MUL_AND_REDUCE_TO_SCALAR_OP_ADD) {
     hipLaunchKernelGGL(mul_reduce_scalar_kernel, dim3(a.nbatch), dim3(1024), 0, st, a);
     if (name) *name = "mul_reduce_scalar_kernel";
+    return (int)hipGetLastError();
+  }
+  if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_TO_SCALAR_OP_ADD) {
+    if (a.in0_type == LIBXSMM_DATATYPE_F64) hipLaunchKernelGGL((reduce_scalar_kernel<double>), dim3(a.nbatch), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((reduce_scalar_kernel<float>), dim3(a.nbatch), dim3(1024), 0, st, a);
+    if (name) *name = "reduce_scalar_kernel";
+    return (int)hipGetLastError();
+  }
+  if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD_NCNC_FORMAT) {
+    hipLaunchKernelGGL(reduce_ncnc_kernel, dim3((unsigned int)((a.ldi + 255) / 256), a.nbatch), dim3(256), 0, st, a);
+    if (name) *name = "reduce_ncnc_kernel";
     return (int)hipGetLastError();
   }
   if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY && a.type == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT) {

@@ -220,10 +220,12 @@ static void* stage(const void* p, size_t nbytes, bool copy_in, bool copy_back) {
 const void* device_visible(const void* p, size_t nbytes) { return stage(p, nbytes, true, false); }
 // an array KNOWN to live in plain host memory (the coalescing queue's pointer lists): uploaded into the scratch without the pointer query.
 // The upload does NOT read the caller's (pageable, soon overwritten) storage asynchronously: the bytes are first copied into a PINNED slot owned by
-// this thread, the device copy leaves from there, and a slot is reused only after the event behind its last upload has completed (two slots, so the
-// host rarely waits).  [advisor, round 4: hipMemcpyAsync straight out of the queue's std::vector is a race once the runtime copies truly asynchronously]
-struct PinnedSlot { char* base = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
-struct PinnedRing { PinnedSlot slot[2]; int next = 0;
+// this thread, the device copy leaves from there, and a slot is reused only after the event behind its last upload has completed.  A pointer-list flush
+// stages three lists (A, B, C), so the ring has eight slots: two flushes in flight before the host waits on the oldest [advisor, round 5].  A slot's event belongs
+// to the device it was created on: a thread that moved to another device (libxsmm_hip_set_device) gets a fresh event for the slot, the pinned bytes are portable.
+// [advisor, round 4: hipMemcpyAsync straight out of the queue's std::vector is a race once the runtime copies truly asynchronously]
+struct PinnedSlot { char* base = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; int device = -1; };
+struct PinnedRing { static constexpr int NSLOT = 8; PinnedSlot slot[NSLOT]; int next = 0;
   ~PinnedRing() { for (PinnedSlot& p : slot) { if (p.base) (void)hipHostFree(p.base); if (p.done) (void)hipEventDestroy(p.done); } } };
 thread_local PinnedRing t_pinned;
 static void* stage_host(const void* p, size_t nbytes) {
@@ -239,15 +241,16 @@ static void* stage_host(const void* p, size_t nbytes) {
     s.base = nb; s.cap = ncap; s.used = 0; s.device = cur_device();
   }
   char* dst = s.base + s.used; s.used += need;
-  PinnedSlot& ps = t_pinned.slot[t_pinned.next]; t_pinned.next ^= 1;
+  PinnedSlot& ps = t_pinned.slot[t_pinned.next]; t_pinned.next = (t_pinned.next + 1) % PinnedRing::NSLOT;
   if (ps.busy) { (void)hipEventSynchronize(ps.done); ps.busy = false; }          // the upload that last used this slot has left it
+  if (ps.done && ps.device != cur_device()) { (void)hipEventDestroy(ps.done); ps.done = nullptr; }      // the event of another device cannot be recorded on this one's stream
   if (ps.cap < nbytes) {
     if (ps.base) { (void)hipHostFree(ps.base); ps.base = nullptr; ps.cap = 0; }
     const size_t ncap = std::max<size_t>(nbytes * 2, 64 << 10);
-    if (!hip_ok(hipHostMalloc((void**)&ps.base, ncap, hipHostMallocDefault), "hipHostMalloc(pointer lists)")) { ps.base = nullptr; return nullptr; }
+    if (!hip_ok(hipHostMalloc((void**)&ps.base, ncap, hipHostMallocPortable), "hipHostMalloc(pointer lists)")) { ps.base = nullptr; return nullptr; }
     ps.cap = ncap;
   }
-  if (!ps.done && !hip_ok(hipEventCreateWithFlags(&ps.done, hipEventDisableTiming), "hipEventCreate(pointer lists)")) return nullptr;
+  if (!ps.done) { if (!hip_ok(hipEventCreateWithFlags(&ps.done, hipEventDisableTiming), "hipEventCreate(pointer lists)")) return nullptr; ps.device = cur_device(); }
   std::memcpy(ps.base, p, nbytes);
   if (!hip_ok(hipMemcpyAsync(dst, ps.base, nbytes, hipMemcpyHostToDevice, cur_stream()), "hipMemcpyAsync(pointer lists)")) return nullptr;
   if (hip_ok(hipEventRecord(ps.done, cur_stream()), "hipEventRecord(pointer lists)")) ps.busy = true;
@@ -519,6 +522,9 @@ unsigned int effective_gemm_flags(const libxsmm_gemm_descriptor& d) {
     f &= ~(unsigned int)(LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B);
   const bool has_intlv = d.a_type == LIBXSMM_DATATYPE_I4X2 || d.a_type == LIBXSMM_DATATYPE_U4X2 || d.a_type == LIBXSMM_DATATYPE_MXFP4X2 || d.a_type == LIBXSMM_DATATYPE_I2X4 || d.a_type == LIBXSMM_DATATYPE_I1X8;
   if (!has_intlv) f &= ~(unsigned int)LIBXSMM_GEMM_FLAG_INTLV_A_FORMAT;
+  // 8-bit integers with an f32 result: the reference's loop reads A as VNNI-4 whether or not the caller's flags say so [ref: gemm ref :1556-1683, l_k_block = 4] (round 6)
+  const auto is_i8 = [](int t) { return t == LIBXSMM_DATATYPE_I8 || t == LIBXSMM_DATATYPE_U8; };
+  if (is_i8(d.a_type) && is_i8(d.b_type) && d.c_type == LIBXSMM_DATATYPE_F32) f |= (unsigned int)LIBXSMM_GEMM_FLAG_VNNI_A;
   return f;
 }
 void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
@@ -792,6 +798,12 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_UNZIP) {
       if (!p->out.secondary) { set_error(-2, "UNZIP needs the byte offset in out.secondary"); return; }
       a.scalar_u64 = *(const unsigned long long*)p->out.secondary;
+    } else if (t == LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X2 || t == LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X3) {
+      // the byte offsets of the second (and third) piece: host scalars behind out.secondary [ref: mateltwise ref :2439, :2467-2469]
+      if (!p->out.secondary) { set_error(-2, "DECOMP_FP32_TO_BF16X2/X3 needs the byte offsets of the pieces in out.secondary"); return; }
+      a.scalar_u64 = ((const unsigned long long*)p->out.secondary)[0];
+      a.scalar_u64b = t == LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X3 ? ((const unsigned long long*)p->out.secondary)[1] : 0ull;
+      a.aux_out = nullptr;
     } else if (t == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT || t == LIBXSMM_MELTW_TYPE_UNARY_DROPOUT_INV) {
       // the probability is a host scalar behind op.primary; DROPOUT advances the generator state (64 dwords) behind op.secondary and
       // writes the mask to out.secondary, DROPOUT_INV reads the mask from in.secondary [ref: mateltwise ref :2091, :2361-2424]
@@ -1204,8 +1216,11 @@ bool coalesce_try(KernelCtx* k, const void* param) {
   if (k->kind != K_GEMM || t_nest > 0 || tls().pipe_lanes > 1 || !param) return false;
   {  // a stream that is being CAPTURED records addresses, not contents: a queued call's pointer list would be re-read from whatever the staging slot holds at
      // replay time.  While capturing, calls launch one by one (mode 1 semantics); what was queued before the capture began has left already (flushed below).
+    // Never asked of the NULL stream: it cannot be captured, and the query would invalidate another stream's global-mode capture [advisor, round 5].
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(cur_stream(), &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cur_stream() != nullptr) {
+      if (hipStreamIsCapturing(cur_stream(), &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    }
     if (cs != hipStreamCaptureStatusNone) return false;
   }
   const libxsmm_gemm_descriptor& d = k->g;
@@ -2184,7 +2199,8 @@ LIBXSMM_API int libxsmm_hip_launch_shards(const libxsmm_hip_shard* shards, int n
   }
   const int home_device = t.device, home_async = t.async; void* const home_stream = t.stream;
   int hip_home = 0; (void)hipGetDevice(&hip_home);
-  const int err0 = t.last_error;
+  const int err0 = t.last_error; const std::string msg0 = t.last_error_msg;      // a stale error of the thread must not hide a shard's failure of the same code: cleared for the loop, restored if no shard failed
+  t.last_error = 0;
   bool ok = true;
   // fork: work already issued to the thread's stream (stream-ordered mode) comes first on every shard
   ShardSet& set = t_shards;
@@ -2211,7 +2227,7 @@ LIBXSMM_API int libxsmm_hip_launch_shards(const libxsmm_hip_shard* shards, int n
       else set_error(-3, "libxsmm_hip_launch_shards: shard %d: this kind of kernel has no strided batch (count must be 0)", i);
     }
     shard_swap(*sc);
-    if (t.last_error != err0 && t.last_error != 0) ok = false;
+    if (t.last_error != 0) ok = false;
     if (ok && sh.gather_bytes) {
       char* dst = (char*)gather_dst + sh.gather_dst_offset;
       if (sh.device == gather_device) ok = hip_ok(hipMemcpyAsync(dst, sh.gather_src, sh.gather_bytes, hipMemcpyDeviceToDevice, sc->stream), "hipMemcpyAsync(shard gather)");
@@ -2229,6 +2245,7 @@ LIBXSMM_API int libxsmm_hip_launch_shards(const libxsmm_hip_shard* shards, int n
     if (fork) ok = hip_ok(hipStreamWaitEvent((hipStream_t)home_stream, sc->done, 0), "hipStreamWaitEvent(shard join)") && ok;
     else { const hipError_t e = hipEventSynchronize(sc->done); if (e != hipSuccess) { set_error((int)e, "shard %d faulted: %s", i, hipGetErrorString(e)); ok = false; } }
   }
+  if (ok && t.last_error == 0) { t.last_error = err0; t.last_error_msg = msg0; }
   return ok ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 static int batch_sharded(const void* kernel, const char* params, size_t param_size, size_t count, const long long* strides, int nstrides, int c_slot_offset,

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <utility>
 #include "internal.hpp"
+#include "bf16_cvt.hpp"
 
 namespace xamd {
 
@@ -320,12 +321,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef short bf16x8v __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
-typedef __bf16 hwbf16x2v __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned int cvt2(float lo, float hi) {
-  const f32x2v v = {lo, hi};
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hwbf16x2v));
-}
+__device__ __forceinline__ unsigned int cvt2(float lo, float hi) { return bf16_pk_exact(lo, hi); }      // the reference's conversion exactly (bf16_cvt.hpp)
 template <typename F, int... Is> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
 

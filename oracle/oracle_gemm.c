@@ -269,6 +269,20 @@ static void c_to_vnni2_16bit(unsigned short* c, int m, int n, int ldc) {
   free(tmp);
 }
 
+/* NORM -> VNNI4 of an 8-bit m x n matrix, in place through a copy [ref: mateltwise ref :737-759] */
+static void c_to_vnni4_08bit(unsigned char* c, int m, int n, int ldc) {
+  const long long nn = ((n % 4) == 0) ? n : (n + 4 - n % 4);
+  unsigned char* tmp = (unsigned char*)malloc((size_t)ldc * (size_t)nn);
+  long long i, j, j2;
+  memset(tmp, 0, (size_t)ldc * (size_t)nn);
+  memcpy(tmp, c, (size_t)ldc * (size_t)n);
+  for (i = 0; i < (long long)ldc * nn; ++i) c[i] = 0;
+  for (j = 0; j < nn / 4; ++j) for (i = 0; i < m; ++i) for (j2 = 0; j2 < 4; ++j2) {
+    c[j * ldc * 4 + i * 4 + j2] = tmp[(j * 4 + j2) * ldc + i];
+  }
+  free(tmp);
+}
+
 /* 8-bit integer GEMM: A and B i8/u8 (signedness in the datatype), i32 accumulation over all (r, k).
  * A is VNNI-4 [k/4][lda][4] under VNNI_A (flat [k][lda] otherwise, i32 output only), B flat [n][ldb].
  * C i32: C = beta*C + sum [ref: :1452-1555]; C f32: C = float(sum) * scf (+ C), scf = *(float*)c.tertiary,
@@ -640,7 +654,19 @@ static void contract_fused_lowp(const gemm_view* v, const libxsmm_gemm_ext_param
   }
 }
 
+static void oracle_gemm_plain(const void* param, const oracle_gemm_desc* d);
+/* libxsmm_reference_gemm [:2817-2850]: the contraction, then -- VNNI_C -- the finished C re-laid through the NORM_TO_VNNI TPP [:2802-2815]: VNNI-2 for 16-bit results
+ * (bf16 inside oracle_gemm_plain; IEEE halves here), VNNI-4 for results of an 8-bit float type. */
 void oracle_gemm(const void* param, const oracle_gemm_desc* d) {
+  oracle_gemm_plain(param, d);
+  if (((d->flags & LIBXSMM_GEMM_FLAG_NO_RESET_TILECONFIG) != 0) != ((d->flags & LIBXSMM_GEMM_FLAG_NO_SETUP_TILECONFIG) != 0)) return;
+  if (d->flags & LIBXSMM_GEMM_FLAG_VNNI_C) {
+    void* cptr = ((const libxsmm_gemm_param*)param)->c.primary;
+    if (d->c_type == LIBXSMM_DATATYPE_F16) c_to_vnni2_16bit((unsigned short*)cptr, d->m, d->n, d->ldc);
+    else if (d->c_type == LIBXSMM_DATATYPE_BF8 || d->c_type == LIBXSMM_DATATYPE_HF8) c_to_vnni4_08bit((unsigned char*)cptr, d->m, d->n, d->ldc);
+  }
+}
+static void oracle_gemm_plain(const void* param, const oracle_gemm_desc* d) {
   gemm_view v;
   const int is_ext = (d->flags & LIBXSMM_GEMM_FLAG_USE_XGEMM_EXT_ABI) ? 1 : 0;
   const int beta0 = (d->flags & LIBXSMM_GEMM_FLAG_BETA_0) ? 1 : 0;

@@ -363,6 +363,49 @@ void oracle_meltw_unary(const libxsmm_meltw_unary_param* p, const oracle_meltw_d
     reduce_cols_listed(p, d); return;
   }
   if (is_reduce(d->type)) { reduce(p, d); return; }
+  if (d->type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_TO_SCALAR_OP_ADD) {                /* [:2097-2116] one serial sum over the whole block, column by column */
+    if (d->in0_type == LIBXSMM_DATATYPE_F64 && d->out_type == LIBXSMM_DATATYPE_F64 && d->comp_type == LIBXSMM_DATATYPE_F64) {
+      double acc = 0.0;
+      for (j = 0; j < N; ++j) for (i = 0; i < M; ++i) acc += ((const double*)p->in.primary)[elem_index(bc, i, j, ldi)];
+      ((double*)p->out.primary)[0] = acc;
+    } else {
+      float acc = 0.0f;
+      for (j = 0; j < N; ++j) for (i = 0; i < M; ++i) acc += get_f32(p->in.primary, elem_index(bc, i, j, ldi), d->in0_type);
+      put_f32(p->out.primary, 0, d->out_type, acc);
+    }
+    return;
+  }
+  if (d->type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD_NCNC_FORMAT) {            /* [:2118-2141] blocked [N / bn][C / bc][bn][bc] input: m = bc, n = bn, ldi = C, ldo = N */
+    const long long bc_ = d->m, bn = d->n, C = d->ldi, NN = d->ldo;
+    long long iC, ic, iN, i_n;
+    for (iC = 0; iC < C / bc_; ++iC) for (ic = 0; ic < bc_; ++ic) {
+      float tmp = 0.0f;
+      for (iN = 0; iN < NN / bn; ++iN) for (i_n = 0; i_n < bn; ++i_n)
+        tmp += get_f32(p->in.primary, iN * C * bn + iC * bn * bc_ + i_n * bc_ + ic, d->in0_type);
+      put_f32(p->out.primary, iC * bc_ + ic, d->out_type, tmp);
+    }
+    return;
+  }
+  if (d->type == LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X2 || d->type == LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X3) {   /* [:2437-2470] */
+    /* f32 -> two / three bf16 that add up to it: the leading pieces by truncation, the last by RNE of the remainder; byte offsets of the pieces in out.secondary */
+    const unsigned long long* strides = (const unsigned long long*)p->out.secondary;
+    unsigned short* o16 = (unsigned short*)p->out.primary;
+    for (j = 0; j < N; ++j) for (i = 0; i < M; ++i) {
+      const float x = ((const float*)p->in.primary)[elem_index(bc, i, j, ldi)];
+      unsigned int u; float t, r1;
+      memcpy(&u, &x, 4); u &= 0xffff0000u; memcpy(&t, &u, 4);
+      o16[j * ldo + i] = (unsigned short)(u >> 16);
+      r1 = x - t;
+      if (d->type == LIBXSMM_MELTW_TYPE_UNARY_DECOMP_FP32_TO_BF16X3) {
+        float r2;
+        memcpy(&u, &r1, 4); u &= 0xffff0000u; memcpy(&t, &u, 4);
+        o16[j * ldo + i + (long long)(strides[0] / 2)] = (unsigned short)(u >> 16);
+        r2 = r1 - t;
+        put_f32(o16, j * ldo + i + (long long)(strides[1] / 2), LIBXSMM_DATATYPE_BF16, r2);
+      } else put_f32(o16, j * ldo + i + (long long)(strides[0] / 2), LIBXSMM_DATATYPE_BF16, r1);
+    }
+    return;
+  }
   if (d->type == LIBXSMM_MELTW_TYPE_UNARY_GATHER || d->type == LIBXSMM_MELTW_TYPE_UNARY_SCATTER) { gather_scatter(p, d); return; }
   if (is_transform(d->type)) { transform(p, d); return; }
   switch (d->type) {

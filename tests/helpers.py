@@ -141,7 +141,8 @@ class GemmCase:
             assert tb and self.ldb >= n
             self.b_elems = self.ldb * k // (2 if a_type == DT.MXFP4X2 else 1)
             self.sb_elems = self.ldb * (k // 32)
-        self.c_elems = self.ldc * (n + (n % 2 if flags & GEMM_FLAG.VNNI_C else 0))
+        vf = 4 if capi.DT_SIZE[self.c_type] == 1 else 2                 # VNNI_C re-lays 8-bit results as VNNI-4, 16-bit ones as VNNI-2: room for the pad columns
+        self.c_elems = self.ldc * (((n + vf - 1) // vf) * vf if flags & GEMM_FLAG.VNNI_C else n)
         asz, csz, bsz = capi.DT_SIZE[a_type], capi.DT_SIZE[self.c_type], capi.DT_SIZE[self.b_type]
         nbr = br_count if br_type != capi.BR_NONE else 1
         self.nbr = nbr

@@ -13,7 +13,7 @@ libxsmm_reference_gemm handles -- a trampoline to its C loop (is_reference_kerne
 
   1. reference NULL          =>  this library NULL, and the other way round for the tile-config pairs;
   2. this library non-NULL   =>  reference non-NULL;
-  3. reference JIT kernel    =>  this library non-NULL, EXCEPT the documented refusals D1-D3 and D5 below (INTEGRATION.md, "Differences of the dispatcher");
+  3. reference JIT kernel    =>  this library non-NULL, EXCEPT the documented refusals D2, D3 and D5 below (INTEGRATION.md, "Differences of the dispatcher");
      D4 is the one place where this library hands out a handle and the reference (on a host whose JIT does not take the descriptor) does not;
   4. handles both sides hand out report the same libxsmm_get_mmkernel_info / libxsmm_get_meltwkernel_info fields [ref: src/libxsmm_main.c:3043-3131].
 The trampoline class is reported (counts per family) but not asserted: the reference "accepts" there what it cannot compute."""
@@ -106,21 +106,19 @@ L.xref_get_target_arch.restype = C.c_char_p
 print(json.dumps({"arch": L.xref_get_target_arch().decode(), "records": records, "tpp": tpp, "stats": {f"{k[0]}/{k[1]}": v for k, v in stats.items()}}))
 """
 
-F_TA, F_TB, F_VA, F_VB, F_VC, F_NORESET, F_NOSETUP = 1, 2, 256, 512, 1024, 64, 128
+F_TA, F_TB, F_VA, F_VB, F_VC, F_NORESET, F_NOSETUP, F_BETA0 = 1, 2, 256, 512, 1024, 64, 128, 4
 I8, U8, F32, BF16, F16, BF8, HF8 = None, None, None, None, None, None, None
 
 
 def _documented_refusal(r, DT):
-    """D1-D3, D5: descriptors the reference's JIT takes on this host and this library refuses ON PURPOSE ("Differences of the dispatcher")."""
+    """D2, D3, D5 (D1 was closed in round 6): descriptors the reference's JIT takes on this host and this library refuses ON PURPOSE ("Differences of the dispatcher")."""
     fl = r["fl"]
     sixteen = r["a"] in (int(DT.BF16), int(DT.F16), int(DT.I16))
     eight = r["a"] in (int(DT.I8), int(DT.U8), int(DT.BF8), int(DT.HF8))
-    if r["a"] == int(DT.I8) and r["b"] == int(DT.I8) and r["c"] == int(DT.F32) and not (fl & F_VA):
-        return "D1 i8 x i8 -> f32 with a flat (non-VNNI) A: the scaled-f32 result is defined for VNNI-4 A only [ref: gemm ref :1558-1683]"
     if (fl & (F_VA | F_VB)) and ((sixteen and r["k"] % 2) or (eight and r["k"] % 4)):
         return "D2 VNNI operand with a k that is not a whole number of k-groups: the reference's own loop reads k/2 (k/4) groups [ref: gemm ref :2134-2161]"
-    if (fl & F_VC) and r["c"] != int(DT.BF16):
-        return "D3 VNNI_C with a C that is not bf16"
+    if (fl & F_VC) and (r["c"] not in (int(DT.BF16), int(DT.F16), int(DT.BF8), int(DT.HF8)) or r["c"] != r["a"] or not (fl & F_BETA0) or r["fused"]):
+        return "D3 VNNI_C on a result that the reference's driver does not re-lay: a C type other than the 16-bit / 8-bit float of the operands, beta = 1, a fused operator"
     if r["fused"] and r["a"] not in (int(DT.F32), int(DT.BF16), int(DT.BF32), int(DT.F16), int(DT.BF8), int(DT.HF8)):
         return "D5 a fused operator (argops / postops of libxsmm_dispatch_brgemm_ext) on operand types the reference's own kernel tests never fuse (integers, f64)"
     return None
@@ -171,7 +169,7 @@ def test_what_the_reference_jits_is_accepted_here_or_documented(drawn):
             seen[why.split()[0]] = seen.get(why.split()[0], 0) + 1
     print("documented refusals met:", seen)
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    for tag in ("D1", "D2", "D3", "D4", "D5"):
+    for tag in ("D2", "D3", "D4", "D5"):
         assert f"**{tag}**" in text, f"INTEGRATION.md does not list {tag}"
 
 

@@ -2,7 +2,7 @@
 
 A kernel that needs scratch has spilled registers or keeps its argument block in memory: for the streaming kernels of this library that is a
 performance bug (round 2 found two of them this way: the M-block streaming BCSC kernel before its lambdas were force-inlined, and the signed-A
-int8 BCSC variant under the three-waves register cap).  The table itself is committed as profiles/r05_kernel_resources.txt."""
+int8 BCSC variant under the three-waves register cap).  The table itself is committed as profiles/r06_kernel_resources.txt."""
 import os
 import re
 import sys
@@ -75,8 +75,8 @@ def test_hot_kernels_keep_their_occupancy(table):
 
 
 def test_committed_table_is_current(table):
-    """profiles/r05_kernel_resources.txt is the table of THIS build (regenerate with tools/kernel_resources.py --out ...)."""
-    path = os.path.join(ROOT, "profiles", "r05_kernel_resources.txt")
+    """profiles/r06_kernel_resources.txt is the table of THIS build (regenerate with tools/kernel_resources.py --out ...)."""
+    path = os.path.join(ROOT, "profiles", "r06_kernel_resources.txt")
     committed = {}
     for line in open(path).read().splitlines()[2:]:
         cols = line.split(None, 8)

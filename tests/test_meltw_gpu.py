@@ -53,7 +53,7 @@ def run_unary(typ, m, n, ldi, ldo, in_dt, out_dt, flags=0, seed=0, batch=1, aux_
         if aux_o is not None:
             p.out.secondary = aux_o + b * aux_out_bytes
         if out_secondary_val is not None:
-            v = C.c_ulonglong(out_secondary_val); keep.append(v); p.out.secondary = C.addressof(v)
+            v = (C.c_ulonglong * len(out_secondary_val))(*out_secondary_val) if isinstance(out_secondary_val, (tuple, list)) else C.c_ulonglong(out_secondary_val); keep.append(v); p.out.secondary = C.addressof(v)
         if op_primary is not None:
             keep.append(op_primary); p.op.primary = C.addressof(op_primary)
         if in_tertiary_val is not None:
@@ -388,6 +388,50 @@ def test_zip_unzip_roundtrip_bit_exact():
     p = capi.BinaryParam(); p.in0.primary, p.in1.primary, p.out.primary = d0.data_ptr(), d1.data_ptr(), dY.data_ptr()
     capi.Api.call(h, p); api.hip_sync(); api.check()
     assert np.array_equal(dY.cpu().numpy().view(np.uint32), X.view(np.uint32))
+
+
+# ---- round 6: the three TPP kinds the round-5 review found missing [ref: mateltwise ref :2097-2141, :2437-2470] ----
+@pytest.mark.parametrize("in_dt,out_dt", [(DT.F32, DT.F32), (DT.BF16, DT.BF16), (DT.BF16, DT.F32), (DT.F16, DT.F32), (DT.F64, DT.F64)])
+@pytest.mark.parametrize("m,n,ld,batch", [(45, 13, 48, 1), (64, 64, 64, 3), (1, 1, 1, 1), (7, 300, 9, 2)])
+def test_reduce_to_scalar(in_dt, out_dt, m, n, ld, batch):
+    """REDUCE_TO_SCALAR_OP_ADD: a tree sum on the device against the reference's serial one -- the bound of the reduction tests (f64: 1e-12)"""
+    ref, got, _, _ = run_unary(UNARY.REDUCE_TO_SCALAR_OP_ADD, m, n, ld, 1, in_dt, out_dt, batch=batch, out_elems=4, seed=51)
+    r, g = ref.reshape(batch, 4), got.reshape(batch, 4)
+    assert np.array_equal(r[:, 1:], g[:, 1:])                      # only element 0 of each output is written
+    if in_dt == DT.F64:
+        assert np.allclose(r[:, 0], g[:, 0], rtol=1e-12, atol=1e-12)
+    else:
+        from helpers import as_float
+        rf, gf = as_float(r[:, 0].copy(), out_dt), as_float(g[:, 0].copy(), out_dt)
+        assert np.all(np.abs(rf - gf) <= m * n * 2.0 ** -22 + (np.abs(rf) * 2.0 ** -7 if out_dt == DT.BF16 else 0.0)), (rf, gf)
+
+
+@pytest.mark.parametrize("in_dt,out_dt", [(DT.F32, DT.F32), (DT.BF16, DT.BF16), (DT.BF16, DT.F32), (DT.F32, DT.F16)])
+@pytest.mark.parametrize("bc,bn,C_,N_,batch", [(16, 4, 64, 32, 1), (8, 8, 8, 8, 3), (32, 2, 96, 10, 1), (5, 3, 20, 9, 2), (64, 16, 1024, 256, 1)])
+def test_reduce_ncnc_format_bit_exact(in_dt, out_dt, bc, bn, C_, N_, batch):
+    """REDUCE_X_OP_ADD_NCNC_FORMAT: one thread per channel adds in the reference's order -- bit-exact"""
+    ref, got, _, _ = run_unary(UNARY.REDUCE_X_OP_ADD_NCNC_FORMAT, bc, bn, C_, N_, in_dt, out_dt, batch=batch, in_elems=C_ * N_, out_elems=C_ + 3, seed=52)
+    assert np.array_equal(ref, got)
+
+
+@pytest.mark.parametrize("typ", [UNARY.DECOMP_FP32_TO_BF16X2, UNARY.DECOMP_FP32_TO_BF16X3])
+@pytest.mark.parametrize("m,n,ldi,ldo,batch", [(32, 8, 32, 32, 1), (17, 5, 20, 24, 1), (64, 64, 64, 64, 2)])
+def test_decomp_f32_to_bf16_pieces_bit_exact(typ, m, n, ldi, ldo, batch):
+    """DECOMP_FP32_TO_BF16X2 / X3: bit-exact, and the pieces add up to the input to 2^-16 / 2^-24 relative"""
+    rng = np.random.default_rng(53)
+    X = _wide_f32(rng, batch * ldi * n)
+    piece = ldo * n * 2
+    if batch > 1:            # a batch element owns its three pieces back to back
+        ref, got, _, _ = run_unary(typ, m, n, ldi, ldo, DT.F32, DT.BF16, inp=X, batch=batch, out_elems=3 * ldo * n, out_secondary_val=(piece, 2 * piece))
+    else:
+        ref, got, _, _ = run_unary(typ, m, n, ldi, ldo, DT.F32, DT.BF16, inp=X, out_elems=3 * ldo * n, out_secondary_val=(piece, 2 * piece))
+    assert np.array_equal(ref, got)
+    np_ = 3 if typ == UNARY.DECOMP_FP32_TO_BF16X3 else 2
+    g = got.reshape(batch, 3, n, ldo)[:, :np_, :, :m].astype(np.uint32) << 16
+    total = g.view(np.float32).astype(np.float64).sum(axis=1)
+    x = X.reshape(batch, n, ldi)[:, :, :m].astype(np.float64)
+    ok = np.isfinite(x) & (np.abs(x) > 1e-30)
+    assert np.all(np.abs(total[ok] - x[ok]) <= np.abs(x[ok]) * (2.0 ** -23 if np_ == 3 else 2.0 ** -15))
 
 
 @pytest.mark.parametrize("typ", [TERNARY.SELECT, TERNARY.MULADD, TERNARY.NMULADD])

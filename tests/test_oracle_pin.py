@@ -346,6 +346,75 @@ def test_more_gemm_types_restatement_is_bit_identical_to_reference_c_kernel(refe
     assert outs[0].tobytes() != C0.tobytes()
 
 
+# round 6 -- D3: VNNI_C on the other result types the reference's driver re-lays (IEEE halves as VNNI-2, 8-bit floats as VNNI-4 [ref: gemm ref :2802-2815, gemm_kernel.c:3977,
+# :5054-5062]); D1: 8-bit integers with an f32 result read A as VNNI-4 whether or not the flags say so [ref: gemm ref :1556-1683]
+VNNI_C_TYPES = [
+    dict(a=DT.F16, b=DT.F16, c=DT.F16, comp=DT.F32, flags=F.VNNI_C),
+    dict(a=DT.F16, b=DT.F16, c=DT.F16, comp=DT.F32, flags=F.VNNI_C | F.VNNI_A),
+    dict(a=DT.F16, b=DT.F16, c=DT.F16, comp=DT.F16, flags=F.VNNI_C | F.TRANS_B),
+    dict(a=DT.BF8, b=DT.BF8, c=DT.BF8, comp=DT.F32, flags=F.VNNI_C | F.VNNI_A),
+    dict(a=DT.HF8, b=DT.HF8, c=DT.HF8, comp=DT.F32, flags=F.VNNI_C),
+    dict(a=DT.HF8, b=DT.HF8, c=DT.HF8, comp=DT.F32, flags=F.VNNI_C | F.VNNI_A),
+]
+
+
+@pytest.mark.parametrize("t", VNNI_C_TYPES, ids=lambda t: f"{int(t['a'])}to{int(t['c'])}f{t['flags']}")
+# (n a multiple of the VNNI factor: for other n the reference's TPP reads columns n .. of a scratch that holds ldc * n elements -- its pad columns are undefined;
+#  the restatement and the device zero-fill them)
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br", [(32, 16, 32, 32, 32, 32, 1), (17, 8, 16, 20, 24, 24, 1), (8, 4, 8, 8, 8, 8, 3), (12, 12, 12, 12, 12, 16, 2)])
+def test_vnni_c_of_halves_and_8bit_floats_is_bit_identical_to_reference_c_kernel(reference, oracle, t, m, n, k, lda, ldb, ldc, br):
+    from oracle import pyoracle
+    rng = np.random.default_rng(92)
+    if t["flags"] & F.TRANS_B:
+        ldb = max(ldb, n)
+    A, B, _, SCF, a_e, b_e = more_types_case(rng, t, m, n, k, lda, ldb, ldc, br)
+    C0 = rand_values(rng, ldc * (n + 3), t["c"])                     # room for the pad columns of an n that is not a multiple of the VNNI factor
+    flags = t["flags"] | F.BETA_0 | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    sa, sb = a_e * A.itemsize, b_e * B.itemsize
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, t["a"], t["b"], t["c"], t["comp"])
+    cnt = C.c_ulonglong(br)
+    outs = []
+    for who in ("oracle", "reference"):
+        c = C0.copy()
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = A.ctypes.data, B.ctypes.data, c.ctypes.data, C.addressof(cnt)
+        if who == "oracle":
+            oracle.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, t["a"], t["b"], t["c"], t["comp"], flags | F.USE_XGEMM_ABI, sa, sb, 0, 0))
+        else:
+            cfg = capi.br_config(capi.BR_STRIDE, sa, sb, 0) if br > 1 else capi.br_config(capi.BR_NONE, 0, 0, 0)
+            assert reference.lib.xref_reference_gemm(C.byref(p), shape, flags, 0, cfg) == 0
+        outs.append(c)
+    assert outs[0].tobytes() == outs[1].tobytes()
+    assert outs[0].tobytes() != C0.tobytes()
+
+
+@pytest.mark.parametrize("ua,ub", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,br,beta", [(32, 16, 32, 32, 32, 32, 1, 0), (17, 7, 16, 20, 24, 24, 1, 1), (8, 5, 8, 8, 8, 8, 3, 1)])
+def test_i8_to_f32_reads_a_as_vnni4_without_the_flag(reference, oracle, ua, ub, m, n, k, lda, ldb, ldc, br, beta):
+    """D1 (closed in round 6): the reference's scaled-f32 loop indexes A in groups of four k whatever VNNI_A says [ref: gemm ref :1556-1683]"""
+    from oracle import pyoracle
+    rng = np.random.default_rng(93)
+    ta, tb = (DT.U8 if ua else DT.I8), (DT.U8 if ub else DT.I8)
+    A = rng.integers(0, 256, br * lda * k).astype(np.uint8); B = rng.integers(0, 256, br * ldb * n).astype(np.uint8)
+    C0 = (rng.random(ldc * n).astype(np.float32) - 0.5)
+    scf = C.c_float(0.0137)
+    flags = (0 if beta else F.BETA_0) | (F.BATCH_REDUCE_STRIDE if br > 1 else 0)
+    shape = capi.gemm_shape(m, n, k, lda, ldb, ldc, ta, tb, DT.F32, DT.I32)
+    cnt = C.c_ulonglong(br)
+    outs = []
+    for who in ("oracle", "reference"):
+        c = C0.copy()
+        p = capi.GemmParam()
+        p.a.primary, p.b.primary, p.c.primary, p.c.tertiary, p.op.tertiary = A.ctypes.data, B.ctypes.data, c.ctypes.data, C.addressof(scf), C.addressof(cnt)
+        if who == "oracle":
+            oracle.gemm(p, pyoracle.GemmDesc(m, n, k, lda, ldb, ldc, ta, tb, DT.F32, DT.I32, flags | F.USE_XGEMM_ABI, lda * k, ldb * n, 0, 0))
+        else:
+            cfg = capi.br_config(capi.BR_STRIDE, lda * k, ldb * n, 0) if br > 1 else capi.br_config(capi.BR_NONE, 0, 0, 0)
+            assert reference.lib.xref_reference_gemm(C.byref(p), shape, flags, 0, cfg) == 0
+        outs.append(c)
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
 def test_bf16_conversion_matches_reference(reference, oracle):
     rng = np.random.default_rng(1)
     vals = np.concatenate([rng.standard_normal(2000).astype(np.float32) * 10.0 ** rng.integers(-40, 38, 2000),

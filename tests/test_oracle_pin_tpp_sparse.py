@@ -37,7 +37,7 @@ def both_unary(reference, typ, m, n, ldi, ldo, in_dt, out_dt, flags=0, aux_in=No
         if aux is not None:
             p.out.secondary = aux.ctypes.data
         if out_secondary_val is not None:
-            v = C.c_ulonglong(out_secondary_val); keep.append(v); p.out.secondary = C.addressof(v)
+            v = (C.c_ulonglong * len(out_secondary_val))(*out_secondary_val) if isinstance(out_secondary_val, (tuple, list)) else C.c_ulonglong(out_secondary_val); keep.append(v); p.out.secondary = C.addressof(v)
         if op_primary is not None:
             p.op.primary = C.addressof(op_primary)
         if in_tertiary_val is not None:
@@ -323,6 +323,33 @@ def test_dot_product_to_scalar_bit_identical(reference, dts, m, n, ld):
             reference.lib.xref_reference_meltw_binary(C.byref(p), typ, capi.BinaryShape(m, n, ld, ld, 1, dts[0], dts[1], dts[2], DT.F32), 0)
         outs.append(y)
     assert outs[0][:1].tobytes() == outs[1][:1].tobytes()
+
+
+@pytest.mark.parametrize("in_dt,out_dt", [(DT.F32, DT.F32), (DT.BF16, DT.BF16), (DT.BF16, DT.F32), (DT.F16, DT.F32), (DT.F32, DT.BF8), (DT.F64, DT.F64)])
+@pytest.mark.parametrize("m,n,ld", [(45, 13, 48), (64, 64, 64), (1, 1, 1), (7, 300, 9)])
+def test_reduce_to_scalar_bit_identical(reference, in_dt, out_dt, m, n, ld):
+    """UNARY_REDUCE_TO_SCALAR_OP_ADD [ref: generator_mateltwise_reference_impl.c:2097-2116]: one serial sum over the block, f32 (f64 when all three types are)"""
+    outs, _ = both_unary(reference, UNARY.REDUCE_TO_SCALAR_OP_ADD, m, n, ld, 1, in_dt, out_dt, out_elems=4, seed=41)
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
+@pytest.mark.parametrize("in_dt,out_dt", [(DT.F32, DT.F32), (DT.BF16, DT.BF16), (DT.BF16, DT.F32), (DT.F32, DT.F16)])
+@pytest.mark.parametrize("bc,bn,C_,N_", [(16, 4, 64, 32), (8, 8, 8, 8), (32, 2, 96, 10), (5, 3, 20, 9)])
+def test_reduce_ncnc_format_bit_identical(reference, in_dt, out_dt, bc, bn, C_, N_):
+    """UNARY_REDUCE_X_OP_ADD_NCNC_FORMAT [ref: :2118-2141]: blocked [N / bn][C / bc][bn][bc] input (m = bc, n = bn, ldi = C, ldo = N), one sum per channel"""
+    outs, _ = both_unary(reference, UNARY.REDUCE_X_OP_ADD_NCNC_FORMAT, bc, bn, C_, N_, in_dt, out_dt, in_elems=C_ * N_, out_elems=C_ + 3, seed=42)
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
+@pytest.mark.parametrize("typ", [UNARY.DECOMP_FP32_TO_BF16X2, UNARY.DECOMP_FP32_TO_BF16X3])
+@pytest.mark.parametrize("m,n,ldi,ldo", [(32, 8, 32, 32), (17, 5, 20, 24), (9, 2, 9, 12)])
+def test_decomp_f32_to_bf16_pieces_bit_identical(reference, typ, m, n, ldi, ldo):
+    """DECOMP_FP32_TO_BF16X2 / X3 [ref: :2437-2470]: truncated leading piece(s), RNE of the remainder; wide-exponent data, denormals and specials included"""
+    rng = np.random.default_rng(43)
+    X = _wide_f32(rng, ldi * n)
+    piece = ldo * n * 2
+    outs, _ = both_unary(reference, typ, m, n, ldi, ldo, DT.F32, DT.BF16, inp=X, out_elems=3 * ldo * n, out_secondary_val=(piece, 2 * piece), seed=44)
+    assert outs[0].tobytes() == outs[1].tobytes()
 
 
 @pytest.mark.parametrize("typ", [TERNARY.SELECT, TERNARY.MULADD, TERNARY.NMULADD])

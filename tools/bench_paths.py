@@ -65,14 +65,17 @@ def blocked(api, dtype, m, ni, nj, br):
     return w
 
 
-def brgemm_form(api, m, batch, flags=0, a_dt=DT.BF16, c_dt=DT.BF16, name=""):
+def brgemm_form(api, m, batch, flags=0, a_dt=DT.BF16, c_dt=DT.BF16, name="", fused=0):
     """The other operand forms the dense loop accepts [ref: src/generator_gemm_reference_impl.c:2127-2170, :2149-2161, :2803-2815]: bf16 with a flat (non-VNNI) or
     transposed A, a transposed / VNNI B, a VNNI C; 8-bit floats with a result of their own type.  m = n = k, one problem per batch element, beta = 0;
     algorithmic bytes = every operand and C once."""
     es = capi.DT_SIZE[a_dt]
     cs = capi.DT_SIZE[c_dt]
     comp = DT.F32
-    h = api.dispatch_brgemm(capi.gemm_shape(m, m, m, m, m, m, a_dt, a_dt, c_dt, comp), flags | GEMM_FLAG.BETA_0, 0, capi.br_config(capi.BR_STRIDE, m * m * es, m * m * es, 0))
+    # fused (round 6): column bias of C's type + ReLU through the ext ABI, as config #5 does for bf16 [ref: gemm ref :294-372]
+    shape, cfg = capi.gemm_shape(m, m, m, m, m, m, a_dt, a_dt, c_dt, comp), capi.br_config(capi.BR_STRIDE, m * m * es, m * m * es, 0)
+    h = (api.dispatch_brgemm_ext(shape, flags | GEMM_FLAG.BETA_0, 0, cfg, capi.argops_cp(m, capi.UNARY.RELU, 0), capi.postops_colbias(m, c_dt)) if fused
+         else api.dispatch_brgemm(shape, flags | GEMM_FLAG.BETA_0, 0, cfg))
     assert h, name
     per = 2 * m * m * es + m * m * cs
     ns = nsets_for(batch * per)
@@ -84,12 +87,19 @@ def brgemm_form(api, m, batch, flags=0, a_dt=DT.BF16, c_dt=DT.BF16, name=""):
     Bs = [mk(batch * m * m) for _ in range(ns)]
     Cs = [torch.zeros(batch * m * m * cs, device=DEV, dtype=torch.uint8) for _ in range(ns)]
     brc = C.c_ulonglong(1)
+    D = (rnd(m, "bf16") if cs == 2 else (rnd(m) if cs == 4 else torch.randint(0x30, 0x48, (m,), device=DEV, dtype=torch.uint8))) if fused else None
     ps = []
     for s in range(ns):
-        p = capi.GemmParam(); p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc); ps.append(p)
-    w = Work(api, f"stride-BRGEMM {name} m=n=k={m} batch={batch} br=1 beta=0", 2.0 * m ** 3 * batch, float(batch * per), ns,
-             lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, m * m * es, m * m * es, m * m * cs), lambda: api.hip_kernel_name(h, 1).decode())
-    w.keep = (As, Bs, Cs, ps, brc)
+        p = capi.GemmExtParam() if fused else capi.GemmParam()
+        p.a.primary, p.b.primary, p.c.primary, p.op.tertiary = As[s].data_ptr(), Bs[s].data_ptr(), Cs[s].data_ptr(), C.addressof(brc)
+        if fused:
+            p.d.primary = D.data_ptr()
+        ps.append(p)
+    step = ((lambda s: api.hip_gemm_ext_batch_strided(h, C.byref(ps[s]), batch, m * m * es, m * m * es, m * m * cs, 0, 0)) if fused
+            else (lambda s: api.hip_gemm_batch_strided(h, C.byref(ps[s]), batch, m * m * es, m * m * es, m * m * cs)))
+    w = Work(api, f"stride-BRGEMM {name} m=n=k={m} batch={batch} br=1 beta=0" + (" + colbias+ReLU (ext)" if fused else ""), 2.0 * m ** 3 * batch, float(batch * per + (m * cs if fused else 0)), ns,
+             step, lambda: api.hip_kernel_name(h, 1).decode())
+    w.keep = (As, Bs, Cs, D, ps, brc)
     return w
 
 
