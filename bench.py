@@ -164,7 +164,7 @@ def dry_main(args):
 def gen_values(n, bf16, dev, gen):
     """Reference-style data [samples/xgemm/gemm_kernel.c:837-865]: multiples of 0.1 in [-0.4, 0.5]; bf16 by truncation (bf16 = "f16": IEEE halves, RNE)."""
     out = torch.empty(n, dtype=torch.float64 if bf16 == "f64" else (torch.int16 if bf16 else torch.float32), device=dev)
-    if os.environ.get("BENCH_ZERO_DATA") == "1":      # counter passes only (tools/r5_macro_counters.sh): the same launches on all-zero operands -- what the matrix pipe clocks to without data toggling
+    if os.environ.get("BENCH_ZERO_DATA") == "1":      # counter passes only (tools/macro_counters.sh): the same launches on all-zero operands -- what the matrix pipe clocks to without data toggling
         return out.zero_()
     step = 1 << 26
     for o in range(0, n, step):
@@ -1105,7 +1105,7 @@ def main():
             out["pipelined"] = pipelined
         if roof:
             out["mfma_power_roof_TF"] = roof
-            # the rocprofv3 side of the same statement (committed counter passes of the 8192^3 bf16 launch: tools/r5_macro_counters.sh): GRBM_GUI_ACTIVE / kernel time
+            # the rocprofv3 side of the same statement (committed counter passes of the 8192^3 bf16 launch: tools/macro_counters.sh): GRBM_GUI_ACTIVE / kernel time
             # = the clock the chip really ran at, on the drivers' operand values and on zeros, with the matrix-pipe-busy share of both
             try:
                 mc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bf16_macro_counters.json")))[-1]))["counters"]

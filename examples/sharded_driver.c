@@ -4,6 +4,8 @@
  * call launches all shards (libxsmm_hip_gemm[_ext]_batch_strided_sharded) and gathers C onto device 0 -- each source over its own link.
  *
  *   sharded_driver M BATCH NSHARDS [f32|bf16fused] [REPS]
+ *   sharded_driver 35 P NSHARDS csr  [REPS]      packed CSR (A sparse, 35 x 35 @15 %, N = 9): the packed width P split (round 6: libxsmm_hip_create_packed_spgemm_csr_sharded)
+ *   sharded_driver 64 MB NSHARDS bcsc [REPS]     bf16 BCSC 2:8 (64 x 256 x 64, bk = 32, bn = 16): the MB M-blocks split (libxsmm_hip_create_packed_spgemm_bcsc_sharded)
  *
  * Shard s runs on device s % device_count: on a one-GPU box the shards are VIRTUAL (one device, a stream and scratch of its own each), which is
  * what the parity test uses.  Gold: the whole batch in ONE unsharded launch on device 0; the gathered C must equal it bit for bit.
@@ -27,6 +29,127 @@ static void fill(void* host, size_t elems, int bf16) {
   }
 }
 
+/* created (sparse) kernels: the creator's arguments go to the *_sharded creator, which builds one kernel per shard on the shard's device */
+static int run_sparse(int bcsc, size_t axis, int nshards, int reps) {
+  const int ndev = libxsmm_hip_device_count();
+  enum { M = 35, K = 35, N = 9, BM = 64, BK = 256, BN = 64, bk = 32, bn = 16 };
+  const size_t es = bcsc ? 2 : 4;
+  unsigned int ptr[65], idx[35 * 35 + 16 * 8];
+  float vals[35 * 35];
+  unsigned int nnz = 0;
+  libxsmm_hip_sharded_kernel* set;
+  libxsmm_gemmfunction gold_kernel;
+  libxsmm_gemm_param gp, p[MAX_SHARDS];
+  unsigned long long nblk = BN / bn;
+  size_t x_elems, c_elems, b_elems = 0, i;
+  char *hx, *hb = NULL, *hgold, *hgot, *dx, *dv, *dgold, *dgot, *dcp = NULL, *dri = NULL;
+  char *sx[MAX_SHARDS], *sv[MAX_SHARDS], *sc[MAX_SHARDS], *scp[MAX_SHARDS], *sri[MAX_SHARDS];
+  int devices[MAX_SHARDS], n, s, r, rc = EXIT_SUCCESS, same;
+  libxsmm_timer_tickint t0, t1;
+  libxsmm_gemm_shape shape;
+  libxsmm_spgemm_config cfg;
+  libxsmm_rng_set_seed(777);
+  if (bcsc) {                                                             /* 2 of every 8 K-blocks per block column */
+    unsigned int nb, g;
+    ptr[0] = 0;
+    for (nb = 0; nb < BN / bn; ++nb) { for (g = 0; g < BK / bk; g += 8) { unsigned int a = g + nb % 8, b = g + (nb + 3) % 8; if (a > b) { const unsigned int t = a; a = b; b = t; } idx[nnz++] = a; if (b != a) idx[nnz++] = b; } ptr[nb + 1] = nnz; }
+    shape = libxsmm_create_gemm_shape((libxsmm_blasint)axis, 0, BK, BK, 0, BN, LIBXSMM_DATATYPE_BF16, LIBXSMM_DATATYPE_BF16, LIBXSMM_DATATYPE_BF16, LIBXSMM_DATATYPE_F32);
+    cfg.packed_width = BM; cfg.bk = bk; cfg.bn = bn;
+    x_elems = axis * BK * BM; c_elems = axis * BN * BM; b_elems = (size_t)nnz * bn * bk;
+  }
+  else {
+    int row, col;
+    for (row = 0; row < M; ++row) { ptr[row] = nnz; for (col = 0; col < K; ++col) if (libxsmm_rng_f64() < 0.15) { idx[nnz] = (unsigned int)col; vals[nnz++] = (float)(libxsmm_rng_f64() - 0.5); } }
+    ptr[M] = nnz;
+    shape = libxsmm_create_gemm_shape(M, N, K, 0, N, N, LIBXSMM_DATATYPE_F32, LIBXSMM_DATATYPE_F32, LIBXSMM_DATATYPE_F32, LIBXSMM_DATATYPE_F32);
+    x_elems = (size_t)K * N * axis; c_elems = (size_t)M * N * axis;
+  }
+  hx = (char*)malloc(x_elems * es); hgold = (char*)malloc(c_elems * es); hgot = (char*)malloc(c_elems * es);
+  if (bcsc) { hb = (char*)malloc(b_elems * es); fill(hb, b_elems, 1); }
+  if (!hx || !hgold || !hgot || (bcsc && !hb)) return 3;
+  fill(hx, x_elems, bcsc);
+  for (s = 0; s < nshards; ++s) devices[s] = s % ndev;
+  /* gold: the unsharded kernel on device 0 */
+  libxsmm_hip_set_device(0);
+  dx = (char*)libxsmm_hip_malloc(x_elems * es); dgold = (char*)libxsmm_hip_malloc(c_elems * es); dgot = (char*)libxsmm_hip_malloc(c_elems * es);
+  dv = (char*)libxsmm_hip_malloc(bcsc ? b_elems * es : sizeof(vals));
+  if (!dx || !dgold || !dgot || !dv) return 3;
+  libxsmm_hip_memcpy_h2d(dx, hx, x_elems * es); libxsmm_hip_memcpy_h2d(dv, bcsc ? (const void*)hb : (const void*)vals, bcsc ? b_elems * es : sizeof(vals));
+  libxsmm_hip_memset(dgold, 0xef, c_elems * es); libxsmm_hip_memset(dgot, 0xef, c_elems * es);
+  memset(&gp, 0, sizeof(gp));
+  if (bcsc) {
+    dcp = (char*)libxsmm_hip_malloc(sizeof(ptr)); dri = (char*)libxsmm_hip_malloc(sizeof(idx));
+    libxsmm_hip_memcpy_h2d(dcp, ptr, sizeof(ptr)); libxsmm_hip_memcpy_h2d(dri, idx, sizeof(idx));
+    gold_kernel = libxsmm_create_packed_spgemm_bcsc(shape, LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_VNNI_A, LIBXSMM_GEMM_PREFETCH_NONE, cfg);
+    gp.a.primary = dx; gp.b.primary = dv; gp.b.secondary = dcp; gp.b.tertiary = dri; gp.b.quaternary = &nblk; gp.c.primary = dgold;
+  }
+  else {
+    gold_kernel = libxsmm_create_packed_spgemm_csr(shape, LIBXSMM_GEMM_FLAG_BETA_0, LIBXSMM_GEMM_PREFETCH_NONE, (libxsmm_blasint)axis, ptr, idx, vals);
+    gp.a.primary = dv; gp.b.primary = dx; gp.c.primary = dgold;
+  }
+  if (NULL == gold_kernel) { fprintf(stderr, "the creator returned NULL\n"); return 2; }
+  gold_kernel(&gp);
+  libxsmm_hip_sync();
+  /* the sharded set: same arguments, plus the shard count and the devices */
+  set = bcsc ? libxsmm_hip_create_packed_spgemm_bcsc_sharded(shape, LIBXSMM_GEMM_FLAG_BETA_0 | LIBXSMM_GEMM_FLAG_VNNI_A, LIBXSMM_GEMM_PREFETCH_NONE, cfg, nshards, devices)
+             : libxsmm_hip_create_packed_spgemm_csr_sharded(shape, LIBXSMM_GEMM_FLAG_BETA_0, LIBXSMM_GEMM_PREFETCH_NONE, (libxsmm_blasint)axis, ptr, idx, vals, nshards, devices);
+  if (NULL == set) { fprintf(stderr, "the sharded creator returned NULL\n"); return 2; }
+  n = libxsmm_hip_sharded_count(set);
+  for (s = 0; s < n; ++s) {                                               /* every device holds only its own block, in the shard's own compact layout */
+    int dev; size_t b, e, w, row;
+    libxsmm_hip_sharded_range(set, s, &dev, &b, &e);
+    w = e - b;
+    libxsmm_hip_set_device(dev);
+    memset(&p[s], 0, sizeof(p[s]));
+    if (bcsc) {
+      sx[s] = (char*)libxsmm_hip_malloc(w * BK * BM * es); sc[s] = (char*)libxsmm_hip_malloc(w * BN * BM * es); sv[s] = (char*)libxsmm_hip_malloc(b_elems * es);
+      scp[s] = (char*)libxsmm_hip_malloc(sizeof(ptr)); sri[s] = (char*)libxsmm_hip_malloc(sizeof(idx));
+      if (!sx[s] || !sc[s] || !sv[s] || !scp[s] || !sri[s]) return 3;
+      libxsmm_hip_memcpy_h2d(sx[s], hx + b * BK * BM * es, w * BK * BM * es); libxsmm_hip_memcpy_h2d(sv[s], hb, b_elems * es);
+      libxsmm_hip_memcpy_h2d(scp[s], ptr, sizeof(ptr)); libxsmm_hip_memcpy_h2d(sri[s], idx, sizeof(idx));
+      p[s].a.primary = sx[s]; p[s].b.primary = sv[s]; p[s].b.secondary = scp[s]; p[s].b.tertiary = sri[s]; p[s].b.quaternary = &nblk; p[s].c.primary = sc[s];
+    }
+    else {                                                                /* B [K][N][P] -> the shard's [K][N][P_s] */
+      char* tmp = (char*)malloc((size_t)K * N * w * es);
+      if (!tmp) return 3;
+      for (row = 0; row < (size_t)K * N; ++row) memcpy(tmp + row * w * es, hx + (row * axis + b) * es, w * es);
+      sx[s] = (char*)libxsmm_hip_malloc((size_t)K * N * w * es); sc[s] = (char*)libxsmm_hip_malloc((size_t)M * N * w * es); sv[s] = (char*)libxsmm_hip_malloc(sizeof(vals));
+      scp[s] = sri[s] = NULL;
+      if (!sx[s] || !sc[s] || !sv[s]) return 3;
+      libxsmm_hip_memcpy_h2d(sx[s], tmp, (size_t)K * N * w * es); libxsmm_hip_memcpy_h2d(sv[s], vals, sizeof(vals));
+      libxsmm_hip_memset(sc[s], 0xef, (size_t)M * N * w * es);            /* rows of A without a non-zero leave their rows of C untouched, here as in the gold run */
+      free(tmp);
+      p[s].a.primary = sv[s]; p[s].b.primary = sx[s]; p[s].c.primary = sc[s];
+    }
+  }
+  libxsmm_hip_set_device(0);
+  t0 = libxsmm_timer_tick();
+  for (r = 0; r < reps + 1 && EXIT_SUCCESS == rc; ++r) {
+    if (1 == r) t0 = libxsmm_timer_tick();
+    rc = libxsmm_hip_sharded_launch(set, p, 0, dgot, bcsc ? 0 : axis * es);        /* CSR: every shard's columns land in place inside [M][N][P] */
+  }
+  t1 = libxsmm_timer_tick();
+  libxsmm_hip_memcpy_d2h(hgold, dgold, c_elems * es); libxsmm_hip_memcpy_d2h(hgot, dgot, c_elems * es);
+  same = 0 == memcmp(hgold, hgot, c_elems * es);
+  if (!same) { for (i = 0; i < c_elems * es && hgold[i] == hgot[i]; ++i) {} fprintf(stderr, "first differing byte: %lu of %lu (gold %02x %02x %02x %02x, sharded %02x %02x %02x %02x)\n", (unsigned long)i, (unsigned long)(c_elems * es),
+      (unsigned char)hgold[i & ~(size_t)3], (unsigned char)hgold[(i & ~(size_t)3) + 1], (unsigned char)hgold[(i & ~(size_t)3) + 2], (unsigned char)hgold[(i & ~(size_t)3) + 3],
+      (unsigned char)hgot[i & ~(size_t)3], (unsigned char)hgot[(i & ~(size_t)3) + 1], (unsigned char)hgot[(i & ~(size_t)3) + 2], (unsigned char)hgot[(i & ~(size_t)3) + 3]); }
+  printf("{\"kernel\": \"%s\", \"axis\": %lu, \"shards\": %d, \"non_empty_shards\": %d, \"devices\": %d, \"reps\": %d, \"ms_per_sharded_launch_with_gather\": %.4f, "
+         "\"bit_identical\": %s, \"rc\": %d, \"error\": %d, \"error_string\": \"%s\"}\n",
+         bcsc ? "bcsc" : "csr", (unsigned long)axis, nshards, n, ndev, reps, libxsmm_timer_duration(t0, t1) * 1e3 / reps, same ? "true" : "false", rc,
+         libxsmm_hip_get_last_error(), libxsmm_hip_get_last_error_string());
+  for (s = 0; s < n; ++s) {
+    int dev; libxsmm_hip_sharded_range(set, s, &dev, NULL, NULL); libxsmm_hip_set_device(dev);
+    libxsmm_hip_free(sx[s]); libxsmm_hip_free(sc[s]); libxsmm_hip_free(sv[s]); if (scp[s]) libxsmm_hip_free(scp[s]); if (sri[s]) libxsmm_hip_free(sri[s]);
+  }
+  libxsmm_hip_set_device(0);
+  libxsmm_hip_sharded_destroy(set);
+  libxsmm_release_kernel((const void*)gold_kernel);
+  libxsmm_hip_free(dx); libxsmm_hip_free(dv); libxsmm_hip_free(dgold); libxsmm_hip_free(dgot); if (dcp) libxsmm_hip_free(dcp); if (dri) libxsmm_hip_free(dri);
+  free(hx); free(hgold); free(hgot); free(hb);
+  return (same && EXIT_SUCCESS == rc && 0 == libxsmm_hip_get_last_error()) ? 0 : 1;
+}
+
 int main(int argc, char* argv[]) {
   const int m = argc > 1 ? atoi(argv[1]) : 32;
   const size_t batch = argc > 2 ? (size_t)atol(argv[2]) : 4096;
@@ -48,6 +171,7 @@ int main(int argc, char* argv[]) {
   int s, r, rc = EXIT_SUCCESS, same;
   if (ndev <= 0) { fprintf(stderr, "no HIP device\n"); return 2; }
   if (nshards < 1 || nshards > MAX_SHARDS || (fused && 0 != (m % 2))) return 2;
+  if (argc > 4 && (0 == strcmp(argv[4], "csr") || 0 == strcmp(argv[4], "bcsc"))) return run_sparse(0 == strcmp(argv[4], "bcsc"), batch, nshards, reps);
   if (fused) {
     const libxsmm_gemm_batch_reduce_config brc = libxsmm_create_gemm_batch_reduce_config(LIBXSMM_GEMM_BATCH_REDUCE_STRIDE, (libxsmm_blasint)blk, (libxsmm_blasint)blk, 0);
     const libxsmm_gemm_ext_unary_argops argops = libxsmm_create_gemm_ext_unary_argops(0, LIBXSMM_MELTW_TYPE_UNARY_NONE, LIBXSMM_MELTW_FLAG_UNARY_NONE, 0,

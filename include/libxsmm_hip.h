@@ -161,6 +161,9 @@ typedef struct libxsmm_hip_shard {
   long long stride[5];                 /* byte strides of the batch (kind specific, see above) */
   const void* gather_src;              /* optional result gather: after the kernel, gather_bytes from here ... */
   size_t gather_bytes, gather_dst_offset;   /* ... to gather_dst + gather_dst_offset on gather_device */
+  size_t gather_rows, gather_src_pitch, gather_dst_pitch;   /* gather_rows > 1 (round 6): a PITCHED gather -- gather_rows rows of gather_bytes each, the source rows
+                                          gather_src_pitch bytes apart, the destination rows gather_dst_pitch: a shard's column block of a row-major result (the P
+                                          axis of a packed C, the N axis of an FsSpMDM C) lands in place inside the whole result.  0 / 1: one contiguous copy. */
 } libxsmm_hip_shard;
 LIBXSMM_API int libxsmm_hip_launch_shards(const libxsmm_hip_shard* shards, int nshards, int gather_device, void* gather_dst);
 /** The batch axis cut by libxsmm_hip_shard_range(count, 1, nshards, s): shard s owns problems [begin_s, end_s) and runs on devices[s]
@@ -171,6 +174,36 @@ LIBXSMM_API int libxsmm_hip_gemm_batch_strided_sharded(libxsmm_gemmfunction kern
   long long stride_a, long long stride_b, long long stride_c, int nshards, const int* devices, int gather_device, void* gather_dst);
 LIBXSMM_API int libxsmm_hip_gemm_ext_batch_strided_sharded(libxsmm_gemmfunction_ext kernel, const libxsmm_gemm_ext_param* shard_params, size_t count,
   long long stride_a, long long stride_b, long long stride_c, long long stride_d, long long stride_mask, int nshards, const int* devices, int gather_device, void* gather_dst);
+
+/* ---- created (sparse) kernels, sharded (round 6) ---------------------------------------------------------------------------------------
+ * Created kernels belong to the device they were created on (pattern arrays, generated code), so a C host that splits P / M-blocks / N over several GPUs
+ * needs one handle per device.  These calls do that loop: given the creator's own arguments they cut the parallel axis with libxsmm_hip_shard_range
+ * (granule = whole lane tiles), create one kernel per non-empty shard ON that shard's device (devices[s], NULL: s % device_count; a device may appear
+ * several times -- virtual shards), and keep them together.  Every shard's operands live on its device in the shard's OWN compact layout:
+ *   packed CSR / CSC (axis = the packed width P):   B [K][N][P_s], C [M][N][P_s] (CSR, A sparse);  A [M][K][P_s], C [M][N][P_s] (CSC, B sparse)
+ *   BCSC (axis = the M-blocks = shape.m, as the creator takes them): A and C of the shard's M-blocks; the block-sparse B is replicated by the caller
+ *   FsSpMDM (axis = N):                              B [K][N_s], C [M][N_s]  (leading dimensions = N_s)
+ * libxsmm_hip_sharded_launch: shard_params[i] (i = 0 .. shards - 1, non-empty shards in order) holds shard i's operand pointers exactly as the plain kernel
+ * takes them (FsSpMDM: b.primary, c.primary); all shards are issued by libxsmm_hip_launch_shards (one stream per shard, overlapping).  gather_dst != NULL
+ * assembles C on gather_device: gather_dst_pitch = 0 places the shards' C blocks back to back (a valid packed layout of independent slabs),
+ * gather_dst_pitch > 0 is the byte pitch of one row of the WHOLE result (P * elem for packed C, ldc * elem for FsSpMDM) and every shard's columns land in
+ * place (BCSC: C of an M-block is contiguous, the pitch is ignored).  Returns EXIT_SUCCESS / EXIT_FAILURE like libxsmm_hip_launch_shards. */
+typedef struct libxsmm_hip_sharded_kernel libxsmm_hip_sharded_kernel;
+LIBXSMM_API libxsmm_hip_sharded_kernel* libxsmm_hip_create_packed_spgemm_csr_sharded(libxsmm_gemm_shape gemm_shape, libxsmm_bitfield gemm_flags, libxsmm_bitfield prefetch_flags,
+  libxsmm_blasint packed_width, const unsigned int* row_ptr, const unsigned int* column_idx, const void* values, int nshards, const int* devices);
+LIBXSMM_API libxsmm_hip_sharded_kernel* libxsmm_hip_create_packed_spgemm_csc_sharded(libxsmm_gemm_shape gemm_shape, libxsmm_bitfield gemm_flags, libxsmm_bitfield prefetch_flags,
+  libxsmm_blasint packed_width, const unsigned int* column_ptr, const unsigned int* row_idx, const void* values, int nshards, const int* devices);
+LIBXSMM_API libxsmm_hip_sharded_kernel* libxsmm_hip_create_packed_spgemm_bcsc_sharded(libxsmm_gemm_shape gemm_shape, libxsmm_bitfield gemm_flags, libxsmm_bitfield prefetch_flags,
+  libxsmm_spgemm_config spgemm_config, int nshards, const int* devices);
+LIBXSMM_API libxsmm_hip_sharded_kernel* libxsmm_hip_fsspmdm_create_sharded(libxsmm_datatype datatype, libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K, libxsmm_blasint lda,
+  const void* alpha, const void* beta, const void* a_dense, int nshards, const int* devices);
+/** number of (non-empty) shards; shard i's device, its range [begin, end) of the split axis (P columns, M-blocks, N columns) and its plain handle
+ * (a libxsmm_gemmfunction; owned by the set) */
+LIBXSMM_API int libxsmm_hip_sharded_count(const libxsmm_hip_sharded_kernel* set);
+LIBXSMM_API int libxsmm_hip_sharded_range(const libxsmm_hip_sharded_kernel* set, int shard, int* device, size_t* begin, size_t* end);
+LIBXSMM_API libxsmm_gemmfunction libxsmm_hip_sharded_handle(const libxsmm_hip_sharded_kernel* set, int shard);
+LIBXSMM_API int libxsmm_hip_sharded_launch(libxsmm_hip_sharded_kernel* set, const libxsmm_gemm_param* shard_params, int gather_device, void* gather_dst, size_t gather_dst_pitch);
+LIBXSMM_API void libxsmm_hip_sharded_destroy(libxsmm_hip_sharded_kernel* set);
 
 /* Result gather onto one GPU without a collective library (one process per GPU on one node).  Every rank exports the device buffer that
  * holds its shard (libxsmm_hip_ipc_export: LIBXSMM_HIP_IPC_HANDLE_BYTES opaque bytes, to be handed to the root by whatever means the

@@ -159,7 +159,8 @@ class TernaryShape(C.Structure):
 
 class HipShard(C.Structure):           # libxsmm_hip_shard (include/libxsmm_hip.h): what ONE device does in a multi-device launch
     _fields_ = [("device", C.c_int), ("kernel", C.c_void_p), ("param", C.c_void_p), ("count", C.c_size_t), ("stride", C.c_longlong * 5),
-                ("gather_src", C.c_void_p), ("gather_bytes", C.c_size_t), ("gather_dst_offset", C.c_size_t)]
+                ("gather_src", C.c_void_p), ("gather_bytes", C.c_size_t), ("gather_dst_offset", C.c_size_t),
+                ("gather_rows", C.c_size_t), ("gather_src_pitch", C.c_size_t), ("gather_dst_pitch", C.c_size_t)]
 
 
 class KernelInfo(C.Structure):
@@ -295,6 +296,16 @@ class Api:
             self.hip_gemm_batch_strided_sharded = f("hip_gemm_batch_strided_sharded", C.c_int, [vp, C.POINTER(GemmParam), C.c_size_t, ll, ll, ll, C.c_int, C.POINTER(C.c_int), C.c_int, vp])
             self.hip_gemm_ext_batch_strided_sharded = f("hip_gemm_ext_batch_strided_sharded", C.c_int,
                                                         [vp, C.POINTER(GemmExtParam), C.c_size_t, ll, ll, ll, ll, ll, C.c_int, C.POINTER(C.c_int), C.c_int, vp])
+            pi = C.POINTER(C.c_int)
+            self.hip_create_packed_spgemm_csr_sharded = f("hip_create_packed_spgemm_csr_sharded", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int, vp, vp, vp, C.c_int, pi])
+            self.hip_create_packed_spgemm_csc_sharded = f("hip_create_packed_spgemm_csc_sharded", vp, [GemmShape, C.c_uint, C.c_uint, C.c_int, vp, vp, vp, C.c_int, pi])
+            self.hip_create_packed_spgemm_bcsc_sharded = f("hip_create_packed_spgemm_bcsc_sharded", vp, [GemmShape, C.c_uint, C.c_uint, SpgemmConfig, C.c_int, pi])
+            self.hip_fsspmdm_create_sharded = f("hip_fsspmdm_create_sharded", vp, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, pi])
+            self.hip_sharded_count = f("hip_sharded_count", C.c_int, [vp])
+            self.hip_sharded_range = f("hip_sharded_range", C.c_int, [vp, C.c_int, pi, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)])
+            self.hip_sharded_handle = f("hip_sharded_handle", vp, [vp, C.c_int])
+            self.hip_sharded_launch = f("hip_sharded_launch", C.c_int, [vp, C.POINTER(GemmParam), C.c_int, vp, C.c_size_t])
+            self.hip_sharded_destroy = f("hip_sharded_destroy", None, [vp])
             self.hip_shard_range = f("hip_shard_range", None, [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)])
 
     # ---- calling a handle (a plain C function pointer) --------------------------------

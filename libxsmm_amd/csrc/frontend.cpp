@@ -108,6 +108,118 @@ LIBXSMM_API void libxsmm_fsspmdm_destroy(libxsmm_fsspmdm* h) {
 LIBXSMM_API void libxsmm_dfsspmdm_destroy(libxsmm_dfsspmdm* h) { libxsmm_fsspmdm_destroy(h); }
 LIBXSMM_API void libxsmm_sfsspmdm_destroy(libxsmm_sfsspmdm* h) { libxsmm_fsspmdm_destroy(h); }
 
+// ---- created (sparse) kernels, sharded (round 6; include/libxsmm_hip.h): one handle per shard, created on the shard's device, kept together ---------------
+}  // extern "C"
+struct libxsmm_hip_sharded_kernel {
+  enum Kind { CSR, CSC, BCSC, FSSPMDM } kind;
+  struct Shard { int device; size_t begin, end; libxsmm_gemmfunction kernel; libxsmm_fsspmdm* fs; };
+  std::vector<Shard> shards;
+  size_t elem;                // bytes per element of C
+  size_t rows;                // rows of the row-major result whose columns are split (CSR / CSC: M * N, FsSpMDM: M); BCSC: bytes of one M-block of C
+  size_t axis;                // length of the split axis
+};
+namespace {
+// lane tiles stay whole: sixteen elements cover the widest per-lane vector (four floats) of a quarter wave and every 16-byte alignment rule of the generated kernels
+constexpr size_t kShardGranule = 16;
+template <typename Create>
+libxsmm_hip_sharded_kernel* build_sharded(libxsmm_hip_sharded_kernel::Kind kind, size_t axis, size_t granule, size_t elem, size_t rows, int nshards, const int* devices, Create create) {
+  const int ndev = libxsmm_hip_device_count();
+  if (ndev <= 0 || nshards <= 0 || nshards > 64 || axis == 0) return nullptr;
+  libxsmm_hip_sharded_kernel* set = new libxsmm_hip_sharded_kernel();
+  set->kind = kind; set->elem = elem; set->rows = rows; set->axis = axis;
+  const int home = libxsmm_hip_get_device();
+  bool ok = true;
+  for (int s = 0; s < nshards && ok; ++s) {
+    size_t b = 0, e = 0;
+    libxsmm_hip_shard_range(axis, granule, nshards, s, &b, &e);
+    if (e == b) continue;
+    libxsmm_hip_sharded_kernel::Shard sh; sh.device = devices ? devices[s] : s % ndev; sh.begin = b; sh.end = e; sh.kernel = nullptr; sh.fs = nullptr;
+    if (sh.device < 0 || sh.device >= ndev) { ok = false; break; }
+    libxsmm_hip_set_device(sh.device);
+    ok = create(sh, e - b);
+    if (ok) set->shards.push_back(sh);
+  }
+  libxsmm_hip_set_device(home);
+  if (!ok || set->shards.empty()) { libxsmm_hip_sharded_destroy(set); return nullptr; }
+  return set;
+}
+}  // namespace
+extern "C" {
+LIBXSMM_API libxsmm_hip_sharded_kernel* libxsmm_hip_create_packed_spgemm_csr_sharded(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch,
+  libxsmm_blasint packed_width, const unsigned int* row_ptr, const unsigned int* column_idx, const void* values, int nshards, const int* devices) {
+  if (packed_width <= 0) return nullptr;
+  return build_sharded(libxsmm_hip_sharded_kernel::CSR, (size_t)packed_width, kShardGranule, (size_t)LIBXSMM_TYPESIZE(shape.out_type), (size_t)shape.m * (size_t)shape.n, nshards, devices,
+    [&](libxsmm_hip_sharded_kernel::Shard& sh, size_t width) { sh.kernel = libxsmm_create_packed_spgemm_csr(shape, flags, prefetch, (libxsmm_blasint)width, row_ptr, column_idx, values); return sh.kernel != nullptr; });
+}
+LIBXSMM_API libxsmm_hip_sharded_kernel* libxsmm_hip_create_packed_spgemm_csc_sharded(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch,
+  libxsmm_blasint packed_width, const unsigned int* column_ptr, const unsigned int* row_idx, const void* values, int nshards, const int* devices) {
+  if (packed_width <= 0 || shape.ldc == 0) return nullptr;       // (ldc == 0: C sparse -- the packed axis is a REDUCTION there, not a batch of independent columns: not shardable by this call)
+  return build_sharded(libxsmm_hip_sharded_kernel::CSC, (size_t)packed_width, kShardGranule, (size_t)LIBXSMM_TYPESIZE(shape.out_type), (size_t)shape.m * (size_t)shape.n, nshards, devices,
+    [&](libxsmm_hip_sharded_kernel::Shard& sh, size_t width) { sh.kernel = libxsmm_create_packed_spgemm_csc(shape, flags, prefetch, (libxsmm_blasint)width, column_ptr, row_idx, values); return sh.kernel != nullptr; });
+}
+LIBXSMM_API libxsmm_hip_sharded_kernel* libxsmm_hip_create_packed_spgemm_bcsc_sharded(libxsmm_gemm_shape shape, libxsmm_bitfield flags, libxsmm_bitfield prefetch,
+  libxsmm_spgemm_config cfg, int nshards, const int* devices) {
+  // the BCSC creator's shape [ref: samples/xgemm_sparse/spmm_kernel.c:548-556]: m = the number of M-blocks, packed_width = rows per block, ldc = N; C is [m_blocks][N][packed_width]
+  if (cfg.packed_width <= 0 || shape.m <= 0 || shape.ldc <= 0) return nullptr;
+  return build_sharded(libxsmm_hip_sharded_kernel::BCSC, (size_t)shape.m, 1, (size_t)LIBXSMM_TYPESIZE(shape.out_type), (size_t)shape.ldc * (size_t)cfg.packed_width * (size_t)LIBXSMM_TYPESIZE(shape.out_type), nshards, devices,
+    [&](libxsmm_hip_sharded_kernel::Shard& sh, size_t blocks) {
+      libxsmm_gemm_shape part = shape; part.m = (libxsmm_blasint)blocks;
+      sh.kernel = libxsmm_create_packed_spgemm_bcsc(part, flags, prefetch, cfg); return sh.kernel != nullptr; });
+}
+LIBXSMM_API libxsmm_hip_sharded_kernel* libxsmm_hip_fsspmdm_create_sharded(libxsmm_datatype datatype, libxsmm_blasint M, libxsmm_blasint N, libxsmm_blasint K, libxsmm_blasint lda,
+  const void* alpha, const void* beta, const void* a_dense, int nshards, const int* devices) {
+  if (M <= 0 || N <= 0 || K <= 0) return nullptr;
+  return build_sharded(libxsmm_hip_sharded_kernel::FSSPMDM, (size_t)N, kShardGranule, (size_t)LIBXSMM_TYPESIZE(datatype), (size_t)M, nshards, devices,
+    [&](libxsmm_hip_sharded_kernel::Shard& sh, size_t width) {
+      sh.fs = libxsmm_fsspmdm_create(datatype, M, (libxsmm_blasint)width, K, lda, (libxsmm_blasint)width, (libxsmm_blasint)width, alpha, beta, a_dense, 0, nullptr);
+      if (sh.fs) sh.kernel = sh.fs->kernel;
+      return sh.fs != nullptr; });
+}
+LIBXSMM_API int libxsmm_hip_sharded_count(const libxsmm_hip_sharded_kernel* set) { return set ? (int)set->shards.size() : 0; }
+LIBXSMM_API int libxsmm_hip_sharded_range(const libxsmm_hip_sharded_kernel* set, int shard, int* device, size_t* begin, size_t* end) {
+  if (!set || shard < 0 || (size_t)shard >= set->shards.size()) return EXIT_FAILURE;
+  const libxsmm_hip_sharded_kernel::Shard& sh = set->shards[(size_t)shard];
+  if (device) *device = sh.device;
+  if (begin) *begin = sh.begin;
+  if (end) *end = sh.end;
+  return EXIT_SUCCESS;
+}
+LIBXSMM_API libxsmm_gemmfunction libxsmm_hip_sharded_handle(const libxsmm_hip_sharded_kernel* set, int shard) {
+  return (set && shard >= 0 && (size_t)shard < set->shards.size()) ? set->shards[(size_t)shard].kernel : nullptr;
+}
+LIBXSMM_API int libxsmm_hip_sharded_launch(libxsmm_hip_sharded_kernel* set, const libxsmm_gemm_param* shard_params, int gather_device, void* gather_dst, size_t gather_dst_pitch) {
+  if (!set || !shard_params || set->shards.empty()) return EXIT_FAILURE;
+  libxsmm_hip_shard sh[64];
+  const int n = (int)set->shards.size();
+  for (int i = 0; i < n; ++i) {
+    const libxsmm_hip_sharded_kernel::Shard& s = set->shards[(size_t)i];
+    std::memset(&sh[i], 0, sizeof(sh[i]));
+    sh[i].device = s.device; sh[i].kernel = (const void*)s.kernel; sh[i].param = &shard_params[i]; sh[i].count = 0;
+    if (!gather_dst) continue;
+    sh[i].gather_src = shard_params[i].c.primary;
+    const size_t width = s.end - s.begin;
+    if (set->kind == libxsmm_hip_sharded_kernel::BCSC) { sh[i].gather_bytes = width * set->rows; sh[i].gather_dst_offset = s.begin * set->rows; }       // rows = bytes of one M-block of C
+    else if (gather_dst_pitch == 0) { sh[i].gather_bytes = set->rows * width * set->elem; sh[i].gather_dst_offset = set->rows * s.begin * set->elem; }   // slabs back to back
+    else {
+      sh[i].gather_bytes = width * set->elem; sh[i].gather_rows = set->rows; sh[i].gather_src_pitch = width * set->elem; sh[i].gather_dst_pitch = gather_dst_pitch;
+      sh[i].gather_dst_offset = s.begin * set->elem;
+      if (set->rows == 1) sh[i].gather_rows = 0;
+    }
+  }
+  return libxsmm_hip_launch_shards(sh, n, gather_device, gather_dst);
+}
+LIBXSMM_API void libxsmm_hip_sharded_destroy(libxsmm_hip_sharded_kernel* set) {
+  if (!set) return;
+  const int home = libxsmm_hip_get_device();
+  for (libxsmm_hip_sharded_kernel::Shard& sh : set->shards) {
+    libxsmm_hip_set_device(sh.device);
+    if (sh.fs) libxsmm_fsspmdm_destroy(sh.fs);
+    else if (sh.kernel) libxsmm_release_kernel((const void*)sh.kernel);
+  }
+  libxsmm_hip_set_device(home);
+  delete set;
+}
+
 // ---- BLAS-style entry points: alpha is taken as 1, beta as 0 or 1, exactly like LIBXSMM_XGEMM
 // [ref: src/libxsmm_main.h:215-240, src/libxsmm_main.c:3933-3949] -------------------------------------------
 LIBXSMM_API void libxsmm_dgemm(const char* transa, const char* transb, const libxsmm_blasint* m, const libxsmm_blasint* n, const libxsmm_blasint* k,

@@ -86,7 +86,11 @@ void append(std::string& s, const char* fmt, ...) {
 // and (c) still leaves enough waves to cover the chip when the column axis is short.
 // Results are written once and not read again by the kernel: with beta = 0 they go out as non-temporal stores (measured on the packed CSR /
 // FsSpMDM kernels: +3..6 % at P = 65 536, +19 % at P = 4096; with beta = 1 -- C is read first -- plain stores are slightly better; non-temporal
-// LOADS changed nothing).  LIBXSMM_HIP_JIT_NT=0 switches back.
+// LOADS changed nothing).  LIBXSMM_HIP_JIT_NT=0 switches both policies back.
+static bool nt_stores();
+// Round 6: the packed operand is read once, too -- non-temporal LOADS measured +3 % (packed CSR @10 % / @15 %, P = 65 536: 0.678 -> 0.700, 0.670 -> 0.689), +4 % (FsSpMDM
+// N = 10^6: 0.696 -> 0.725), +1.5 % at P = 4096 (profiles/r06_jit_nt_loads.jsonl); a bare copy of the same footprint gains 7 % from the policy (tools/copy_floor.hip).
+static bool nt_loads() { return nt_stores(); }
 static bool nt_stores() { static const bool on = []() { const char* e = getenv("LIBXSMM_HIP_JIT_NT"); return !(e && e[0] == '0'); }(); return on; }
 int choose_vec(const SpmmJitSpec& s, int touched, int elem) {
   const int words = elem / 4;
@@ -141,7 +145,7 @@ std::string generate_spmm(const SpmmJitSpec& s, int vec, long long* total_thread
   append(src, "  const long long o = t / %lldLL, c = t - o * %lldLL, ob = o / bslabs, oi = o - ob * bslabs;\n", tpo, tpo);
   append(src, "  GM const T* x = (GM const T*)x_ + ob * batch_x + oi * outer_x + c * %d;\n  GM T* y = (GM T*)y_ + ob * batch_y + oi * outer_y + c * %d;\n", vec, vec);
   src += "  CM const T* v = (CM const T*)vals_;\n";
-  for (int k = 0; k < s.inner; ++k) if (touched[k]) append(src, "  const V x%d = *(GM const V*)(x + %lldLL);\n", k, (long long)k * s.ld_x);
+  for (int k = 0; k < s.inner; ++k) if (touched[k]) append(src, nt_loads() ? "  const V x%d = __builtin_nontemporal_load((GM const V*)(x + %lldLL));\n" : "  const V x%d = *(GM const V*)(x + %lldLL);\n", k, (long long)k * s.ld_x);
   // rows that are written: non-empty ones, and empty ones when beta=0 demands zeros [ref: asparse generator :336-345 skips them]
   std::vector<int> live;
   for (int r = 0; r < s.rows; ++r) {
@@ -160,7 +164,9 @@ std::string generate_spmm(const SpmmJitSpec& s, int vec, long long* total_thread
     else if (z0 == z1) src += "  acc = (V)(T)0;\n";
     for (unsigned int z = z0; z < z1; ++z) {
       const unsigned int vz = s.vmap ? s.vmap[z] : z;
-      if (s.beta0 && z == z0) append(src, "  acc = (V)v[%u] * x%u;\n", vz, s.idx[z]);
+      // (beta = 0: the first product is ADDED to +0 as the reference's loop does -- a bare product would keep the sign of a zero product, -0 where the reference has +0;
+      //  one instruction either way)
+      if (s.beta0 && z == z0) append(src, "  acc = __builtin_elementwise_fma((V)v[%u], x%u, (V)(T)0);\n", vz, s.idx[z]);
       else append(src, "  acc = __builtin_elementwise_fma((V)v[%u], x%u, acc);\n", vz, s.idx[z]);
     }
     append(src, (nt_stores() && s.beta0) ? "  __builtin_nontemporal_store(acc, (GM V*)(y + %lldLL));\n" : "  *(GM V*)(y + %lldLL) = acc;\n", (long long)r * s.ld_y);
@@ -292,7 +298,7 @@ JitKernel* jit_pgemm_create(const PgemmArgs& g, std::string* why) {
     if (!g.beta0 && o + ahead < outs) append(src, "  V c%d = *(GM const V*)(c + %lldLL);\n", o + ahead, coff(o + ahead));
     if (!g.beta0) append(src, "  acc = c%d;\n", o);
     for (int k = 0; k < g.K; ++k) {
-      if (g.beta0 && k == 0) append(src, "  acc = a%d_%d * b%d_%d;\n", k, m, n, k);
+      if (g.beta0 && k == 0) append(src, "  acc = __builtin_elementwise_fma(a%d_%d, b%d_%d, (V)(T)0);\n", k, m, n, k);      // (added to +0, as in generate_spmm)
       else append(src, "  acc = __builtin_elementwise_fma(a%d_%d, b%d_%d, acc);\n", k, m, n, k);
     }
     append(src, (nt_stores() && g.beta0) ? "  __builtin_nontemporal_store(acc, (GM V*)(c + %lldLL));\n" : "  *(GM V*)(c + %lldLL) = acc;\n", coff(o));

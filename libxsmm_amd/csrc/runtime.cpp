@@ -2196,6 +2196,8 @@ LIBXSMM_API int libxsmm_hip_launch_shards(const libxsmm_hip_shard* shards, int n
     if (!ctx_from_handle(sh.kernel)) { set_error(-3, "libxsmm_hip_launch_shards: shard %d: unknown kernel handle", i); return EXIT_FAILURE; }
     if (sh.gather_bytes && (!gather_dst || !sh.gather_src || gather_device < 0 || gather_device >= g_device_count)) {
       set_error(-2, "libxsmm_hip_launch_shards: shard %d asks for a gather without source / destination / root device", i); return EXIT_FAILURE; }
+    if (sh.gather_bytes && sh.gather_rows > 1 && (sh.gather_src_pitch < sh.gather_bytes || sh.gather_dst_pitch < sh.gather_bytes)) {
+      set_error(-2, "libxsmm_hip_launch_shards: shard %d: a pitched gather needs pitches of at least one row (gather_bytes)", i); return EXIT_FAILURE; }
   }
   const int home_device = t.device, home_async = t.async; void* const home_stream = t.stream;
   int hip_home = 0; (void)hipGetDevice(&hip_home);
@@ -2230,7 +2232,11 @@ LIBXSMM_API int libxsmm_hip_launch_shards(const libxsmm_hip_shard* shards, int n
     if (t.last_error != 0) ok = false;
     if (ok && sh.gather_bytes) {
       char* dst = (char*)gather_dst + sh.gather_dst_offset;
-      if (sh.device == gather_device) ok = hip_ok(hipMemcpyAsync(dst, sh.gather_src, sh.gather_bytes, hipMemcpyDeviceToDevice, sc->stream), "hipMemcpyAsync(shard gather)");
+      if (sh.gather_rows > 1) {        // pitched (round 6): the shard's column block of a row-major result, in place
+        enable_peer(sh.device, gather_device);
+        ok = hip_ok(hipMemcpy2DAsync(dst, sh.gather_dst_pitch, sh.gather_src, sh.gather_src_pitch, sh.gather_bytes, sh.gather_rows, hipMemcpyDeviceToDevice, sc->stream), "hipMemcpy2DAsync(shard gather)");
+      }
+      else if (sh.device == gather_device) ok = hip_ok(hipMemcpyAsync(dst, sh.gather_src, sh.gather_bytes, hipMemcpyDeviceToDevice, sc->stream), "hipMemcpyAsync(shard gather)");
       else { enable_peer(sh.device, gather_device);      // each source pushes over its own xGMI link into the root: no ring, up to nshards - 1 links at once
              ok = hip_ok(hipMemcpyPeerAsync(dst, gather_device, sh.gather_src, sh.device, sh.gather_bytes, sc->stream), "hipMemcpyPeerAsync(shard gather)"); }
     }

@@ -108,6 +108,12 @@ GEMM_CASES = [
     "I8 BF16 F32 BF16 64 64 64 64 64 64 1 0 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",
     "I8 BF16 F32 F32 64 64 64 64 64 64 1 1 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",
     "F16 F16 F16 F16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",          # comp_type F16: a rounding after every product
+    # round 6: VNNI_C on IEEE-half results (VNNI-2) and on results of the operands' 8-bit float type (VNNI-4); 8-bit integers -> f32 WITHOUT the VNNI_A flag
+    "F16 F16 F32 F16 32 32 32 32 32 32 1 0 0 0 0 0 1 0 1 nopf nobr 1 0 2 0",
+    "BF8 BF8 F32 BF8 32 32 64 32 64 32 1 0 0 0 0 0 1 0 1 nopf nobr 1 0 2 0",
+    "HF8 HF8 F32 HF8 32 16 64 32 64 32 1 0 0 0 0 0 1 0 1 nopf strdbr 2 0 2 0",
+    "I8 I8 I32 F32 32 32 64 32 64 32 1 0 0 0 0 0 0 0 0 nopf nobr 1 0 2 0",
+    "U8 I8 I32 F32 64 32 64 64 64 64 1 1 0 0 0 0 0 0 0 nopf strdbr 2 0 2 0",
     "F16 F16 F16 F32 32 32 64 32 64 32 1 1 0 0 0 0 1 0 0 nopf strdbr 2 0 2 0",
     "F16 F16 IMPLICIT F16 64 64 64 64 64 64 1 0 0 0 0 0 1 0 0 nopf nobr 1 0 2 0",     # IMPLICIT = f32 sums here (the driver asks this library's libxsmm_cpuid)
     # "spmm": A sparsified to the given fraction and handed over as (non-zeros, bitmask) -- LIBXSMM_GEMM_FLAG_DECOMPRESS_A_VIA_BITMASK
@@ -201,6 +207,7 @@ def test_reference_fsspmdm_driver(beta, N, edge_mtx):
     "17 0 F32 F32 F32 64 48 64 64", "1 0 F16 F32 F16 64 48 64 64", "13 0 BF8 F32 BF8 64 48 64 64", "3 0 HF8 F32 HF8 33 17 40 36", "1 0 F32 F32 HF8 64 48 64 64",
     "9 0 F16 F32 F16 64 48 64 64", "8 0 F32 F32 F32 64 48 64 64", "10 0 F32 F32 F32 64 48 64 64", "12 0 F32 F32 F32 64 48 64 64", "27 0 F32 F32 F32 64 48 64 64", "27 0 BF16 F32 BF16 64 48 64 64",
     "7 0 BF16 F32 BF16 64 48 64 64", "11 0 BF16 F32 BF16 64 48 64 64", "17 0 BF8 F32 BF8 64 48 64 64", "15 0 HF8 F32 HF8 64 48 64 64", "1 1 F32 F32 F32 64 48 64 64", "1 2 F32 F32 F32 64 48 64 64", "1 3 F32 F32 F32 64 48 64 64", "2 0 F32 F32 F32 64 48 64 64",
+    "64 0 F32 F32 BF16 64 48 64 64", "65 0 F32 F32 BF16 64 48 64 64", "65 0 F32 F32 BF16 33 17 40 36",      # round 6: DECOMP_FP32_TO_BF16X2 / X3
 ])
 def test_reference_unary_driver(args):
     check("eltwise_unary_simple", *args.split())

@@ -1,0 +1,97 @@
+// copy_floor.hip -- what the memory system gives a kernel that does NOTHING but move a workload's bytes: R read streams and W write streams of a given size, 16 bytes per
+// lane, whole lines, as many bytes in flight as the register file allows.  The fraction of the 8 TB/s figure this reaches is the roof of every streaming kernel with the
+// same read : write mix and footprint (round 6: the configs of BASELINE.json against their own copy floors, profiles/r06_copy_floor.txt).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/copy_floor.hip -o tools/copy_floor
+//   tools/copy_floor  <name> <reads> <writes> <MiB per stream> [<name> ...]      (sets rotate so that at least 1 GiB is touched between two uses of a buffer)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define GM __attribute__((address_space(1)))
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+struct Streams { const u32x4* in[4]; u32x4* out[4]; };
+
+// one workgroup moves consecutive 4 KiB pieces (256 lanes x 16 bytes) of every stream, U pieces per stream in flight; NT: non-temporal loads and stores
+template <int NR, int NW, int U, bool NT>
+__global__ __launch_bounds__(256) void copy_kernel(Streams s, unsigned long long pieces) {
+  const unsigned long long first = (unsigned long long)blockIdx.x * U;
+  if (first >= pieces) return;
+  u32x4 v[NR > 0 ? NR : 1][U];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long p = std::min(first + u, pieces - 1);
+      GM const u32x4* src = (GM const u32x4*)s.in[r] + p * 256ull + threadIdx.x;
+      v[r][u] = NT ? __builtin_nontemporal_load(src) : *src;
+    }
+  if (NW == 0) {            // read only: the loaded values reach a store that never executes
+    u32x4 x = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u) x ^= v[r][u];
+    if (x[0] == 0x12345678u && x[1] == 0x9abcdef0u && x[2] == 0x0fedcba9u) *((GM u32x4*)s.in[0] + threadIdx.x) = x;
+  }
+#pragma unroll
+  for (int w = 0; w < NW; ++w)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (first + u >= pieces) continue;
+      u32x4 x = (u32x4){1u + (unsigned int)w, 2u, 3u, 4u};
+#pragma unroll
+      for (int r = 0; r < NR; ++r) x ^= v[r][u];                 // every read stream reaches a store: none of the loads is dead
+      GM u32x4* dst = (GM u32x4*)s.out[w] + (first + u) * 256ull + threadIdx.x;
+      if (NT) __builtin_nontemporal_store(x, dst); else *dst = x;
+    }
+}
+
+template <int NR, int NW, bool NT> static void launch(const Streams& s, unsigned long long pieces, hipStream_t st) {
+  constexpr int U = 4;
+  hipLaunchKernelGGL((copy_kernel<NR, NW, U, NT>), dim3((unsigned int)((pieces + U - 1) / U)), dim3(256), 0, st, s, pieces);
+}
+static void launch_any(int nr, int nw, bool nt, const Streams& s, unsigned long long pieces, hipStream_t st) {
+#define C_(R_, W_) if (nr == R_ && nw == W_) { if (nt) launch<R_, W_, true>(s, pieces, st); else launch<R_, W_, false>(s, pieces, st); return; }
+  C_(1, 1) C_(2, 1) C_(4, 1) C_(1, 0) C_(0, 1) C_(3, 1)
+#undef C_
+  printf("unsupported mix %d:%d\n", nr, nw); exit(1);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 5 || (argc - 1) % 4) { printf("usage: copy_floor <name> <reads> <writes> <MiB per stream> ...\n"); return 1; }
+  hipStream_t st; CHECK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int a = 1; a + 3 < argc; a += 4) {
+    const char* name = argv[a]; const int nr = atoi(argv[a + 1]), nw = atoi(argv[a + 2]); const double mib = atof(argv[a + 3]);
+    const unsigned long long pieces = (unsigned long long)(mib * 256.0);                       // 4 KiB pieces per stream
+    const size_t bytes = (size_t)pieces * 4096;
+    const size_t per_set = bytes * (size_t)(nr + nw);
+    const int nsets = (int)std::max<size_t>(2, ((size_t)1 << 30) / per_set + 1);
+    std::vector<Streams> sets((size_t)nsets);
+    std::vector<void*> all;
+    for (int q = 0; q < nsets; ++q) {
+      memset(&sets[(size_t)q], 0, sizeof(Streams));
+      for (int r = 0; r < nr; ++r) { void* p; CHECK(hipMalloc(&p, bytes)); CHECK(hipMemset(p, 0x11 * (r + 1), bytes)); sets[(size_t)q].in[r] = (const u32x4*)p; all.push_back(p); }
+      for (int w = 0; w < nw; ++w) { void* p; CHECK(hipMalloc(&p, bytes)); sets[(size_t)q].out[w] = (u32x4*)p; all.push_back(p); }
+    }
+    for (int nt = 0; nt < 2; ++nt) {
+      for (int i = 0; i < 2 * nsets; ++i) launch_any(nr, nw, nt != 0, sets[(size_t)(i % nsets)], pieces, st);
+      CHECK(hipStreamSynchronize(st));
+      const int reps = std::max(3 * nsets, (int)(0.05 / (per_set / 5e12)));
+      CHECK(hipEventRecord(e0, st));
+      for (int i = 0; i < reps; ++i) launch_any(nr, nw, nt != 0, sets[(size_t)(i % nsets)], pieces, st);
+      CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+      float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1e3 / reps, tbs = per_set / us / 1e6;
+      printf("{\"copy_floor\": \"%s\", \"reads\": %d, \"writes\": %d, \"MiB_per_stream\": %.1f, \"sets\": %d, \"policy\": \"%s\", \"us\": %.2f, \"TB/s\": %.3f, \"frac_of_8TBs\": %.4f}\n",
+             name, nr, nw, mib, nsets, nt ? "nt" : "default", us, tbs, tbs / 8.0);
+    }
+    for (void* p : all) CHECK(hipFree(p));
+  }
+  return 0;
+}

@@ -1,10 +1,11 @@
 #!/bin/bash
-# round 5, closing evidence in ONE GPU call: rocprofv3 passes of bench.py (tools/profile_paths.sh r05 all: kernel trace, FETCH / WRITE counters in separate passes, MFMA busy,
+# closing evidence of a round in ONE GPU call (tools/final_evidence.sh <tag>, e.g. r06): rocprofv3 passes of bench.py (tools/profile_paths.sh <tag> all: kernel trace, FETCH / WRITE counters in separate passes, MFMA busy,
 # copy floor, paths), their summaries copied over profiles/ on the box, then bench.py exactly as the driver runs it (so profiles_stale_rows is computed against the
 # summaries of this very build), then the whole GPU suite.
+TAG=${1:-r06}
 mkdir -p gpurun_out
-bash tools/profile_paths.sh r05 all > gpurun_out/prof_r05_tail.txt 2>&1; tail -3 gpurun_out/prof_r05_tail.txt
-cp gpurun_out/prof_r05/summary/* profiles/
+bash tools/profile_paths.sh $TAG all > gpurun_out/prof_${TAG}_tail.txt 2>&1; tail -3 gpurun_out/prof_${TAG}_tail.txt
+cp gpurun_out/prof_$TAG/summary/* profiles/
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --detail gpurun_out/bench_detail.json > gpurun_out/bench_line.json 2> gpurun_out/bench.err; echo "bench rc=$?"
 wc -c gpurun_out/bench_line.json; tail -1 gpurun_out/bench_line.json | cut -c1-600
 if [ -z "$SKIP_SUITE" ]; then timeout 1800 python -m pytest tests/ -m gpu -q -x -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu.log; fi

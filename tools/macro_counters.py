@@ -1,5 +1,5 @@
-"""Distils tools/r5_macro_counters.sh: per blocked-GEMM kernel and operand data (the drivers' values / zeros) the counters of the timed launches ->
-profiles/r05_bf16_macro_counters.{txt,json}.  GRBM_GUI_ACTIVE comes back summed over the 8 XCDs: cycles of the launch = GUI / 8, effective clock = cycles / kernel time
+"""Distils tools/macro_counters.sh: per blocked-GEMM kernel and operand data (the drivers' values / zeros) the counters of the timed launches ->
+profiles/<tag>_bf16_macro_counters.{txt,json}.  GRBM_GUI_ACTIVE comes back summed over the 8 XCDs: cycles of the launch = GUI / 8, effective clock = cycles / kernel time
 (MI355X_MICROARCH.md, "DVFS give-back"); SQ_VALU_MFMA_BUSY_CYCLES / (GUI / 8 x 1024 SIMDs) = share of SIMD-cycles with the matrix pipe busy; the SQ wave counters are
 quad-cycles summed over waves (shares of SQ_WAVE_CYCLES: ACTIVE_INST_ANY issuing, WAIT_INST_ANY issue stall -- matrix pipe busy / dependency --, WAIT_ANY parked)."""
 import csv, glob, gzip, json, os, sys, collections
@@ -55,7 +55,7 @@ def unprofiled(name):
         return {"error": repr(e)}
 
 
-res = {"source": "tools/r5_macro_counters.sh (rocprofv3 --pmc ... --kernel-trace, eager launches) + un-profiled hipGraph timing of the same entries",
+res = {"source": "tools/macro_counters.sh (rocprofv3 --pmc ... --kernel-trace, eager launches) + un-profiled hipGraph timing of the same entries",
        "counters": {"drivers_data": one_pass("data"), "zeros": one_pass("zero")},
        "unprofiled": {"drivers_data": unprofiled("unprofiled_data.json"), "zeros": unprofiled("unprofiled_zero.json")}}
 for data, ks in res["counters"].items():
@@ -63,5 +63,5 @@ for data, ks in res["counters"].items():
         print(f"{data:13s} {k[:64]:64s} us {v['kernel_us_under_counters']:9.2f}  clock {v['effective_clock_GHz']} GHz  mfma busy {v['mfma_busy_frac']}  active {v['share_active_inst']} wait_inst {v['share_wait_inst']} wait_any {v['share_wait_any']}")
 for data, ks in res["unprofiled"].items():
     print(data, json.dumps(ks))
-dst = os.path.join(ROOT, "gpurun_out", "macro_r05")
-json.dump(res, open(os.path.join(dst, "r05_bf16_macro_counters.json"), "w"), indent=1)
+tag = os.path.basename(os.path.normpath(src)).replace("macro_", "") or "r06"      # gpurun_out/macro_<tag>
+json.dump(res, open(os.path.join(src, f"{tag}_bf16_macro_counters.json"), "w"), indent=1)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5, review item 6: rocprofv3 evidence for the power-roof statement about the bf16 macro-tile kernel (4096^3 out of 64^3 tiles) -- for the SAME launches, on the
+# (tools/macro_counters.sh <tag>; round 5, review item 6) rocprofv3 evidence for the power-roof statement about the bf16 macro-tile kernel (4096^3 out of 64^3 tiles) -- for the SAME launches, on the
 # drivers' data and on zeros: GRBM_GUI_ACTIVE / kernel time (effective clock), SQ_VALU_MFMA_BUSY_CYCLES, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY, SQ_WAVE_CYCLES.
 # Counters in their own passes (--pmc with --kernel-trace only); the un-profiled graph-replay timing of the same entries next to them (never compare across the two).
 set -u
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/macro_r05; mkdir -p $OUT
+ROOT=$(pwd); TAG=${1:-r06}; OUT=$ROOT/gpurun_out/macro_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ONLY=reuse:bf16_m64_blocked,reuse:bf16_m64_blocked_8192,reuse:bf16_m32_blocked,reuse:f32_m64_blocked
 B="python $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 --only $ONLY"
