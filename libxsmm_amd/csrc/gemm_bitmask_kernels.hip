@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * KS) void gemm_bitmask_reg_kernel(BitmaskArgs p
 // host side
 // ------------------------------------------------------------------------------------------------
 static bool bitmask_reg_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BITMASK_REG"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   const bool t16 = (a.a_type == LIBXSMM_DATATYPE_BF16 || a.a_type == LIBXSMM_DATATYPE_F16) && a.b_type == a.a_type;
   if (off || !t16 || a.m <= 0 || a.n <= 0 || a.k <= 0 || (a.m % 32) || a.m > 32768 || (a.k % 16) || a.k / 16 < 16) return false;
   if (a.c_type != LIBXSMM_DATATYPE_F32 && a.c_type != a.a_type) return false;
@@ -380,7 +380,7 @@ int launch_gemm_bitmask_reg(const GemmArgs& a, const void* bitmap, void* ws, siz
   const bool two = p.n_pad >= 64;                                   // 64 columns per workgroup where C has them
   const dim3 grid((unsigned int)p.tiles, (unsigned int)(p.n_pad / (two ? 64 : 32)));
 #ifdef LIBXSMM_HIP_EXPERIMENTS
-  static const int abl = []() { const char* e = getenv("LIBXSMM_HIP_BITMASK_ABL"); return e ? atoi(e) : 0; }();
+  constexpr int abl = 0;
   if (two && !f16 && abl) {
     switch (abl) {
       case 1: hipLaunchKernelGGL((gemm_bitmask_reg_kernel<false, 2, KS, 1>), grid, dim3(64 * KS), 0, st, p); break;

@@ -627,13 +627,13 @@ int launch_gemm_f64(const GemmArgs& a_in, void* stream, const char** kernel_name
   const long long tiles = (long long)a.tiles_m * a.tiles_n * (long long)a.nbatch;
   if (tiles >= (1ll << 31)) return (int)hipErrorInvalidValue;
   const dim3 grid((unsigned int)((tiles + 3) / 4));
-  static const int pol_env = []() { const char* e = getenv("LIBXSMM_HIP_F64_POLICY"); return e ? atoi(e) : -1; }();
+  constexpr int pol_env = -1;
   // cache policy as for the f32 kernels (DESIGN decision 8): non-temporal requests only when the operands cannot be cache resident -- one launch
   // moves more than the 256 MiB Infinity Cache holds -- or the caller declared a streaming pass (libxsmm_hip_set_streaming_hint(2)); never with hint 1
   const unsigned long long moved = (unsigned long long)a.nbatch * ((unsigned long long)a.br_count * (unsigned long long)a.k * (unsigned long long)(a.m + a.n) + (unsigned long long)a.m * a.n) * 8ull;
   bool nt = a.stream_hint == 2 || (a.stream_hint == 0 && moved > (256ull << 20));
   if (pol_env == 0) nt = false; else if (pol_env == 1) nt = true;
-  static const bool blocked_off = []() { const char* e = getenv("LIBXSMM_HIP_F64_BLOCKED"); return e && e[0] == '0'; }();
+  constexpr bool blocked_off = false;
   if (!blocked_off && f64_blocked_ok(a)) {
     const unsigned int ppw = 128u / (unsigned int)a.m;
     const dim3 bgrid((a.batch_inner / ppw) * ((a.nbatch / a.batch_inner) / ppw));
@@ -647,13 +647,13 @@ int launch_gemm_f64(const GemmArgs& a_in, void* stream, const char** kernel_name
     if (nt) hipLaunchKernelGGL((gemm_f64_p16_kernel<2>), pgrid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_f64_p16_kernel<0>), pgrid, dim3(256), 0, st, a);
     return (int)hipGetLastError();
   }
-  static const bool s64_off = []() { const char* e = getenv("LIBXSMM_HIP_F64_STREAM64"); return e && e[0] == '0'; }();
+  constexpr bool s64_off = false;
   if (!s64_off && !ta && !tb && (a.m % 64) == 0 && (a.n % 64) == 0 && f64_stream_ok(a)) {       // 64 x 64 tiles: one wave per tile, no operand byte fetched twice
     a.tiles_m = a.m / 64; a.tiles_n = a.n / 64;
     const long long t64 = (long long)a.tiles_m * a.tiles_n * (long long)a.nbatch;
     if (kernel_name) *kernel_name = "gemm_f64_stream64_kernel";
     // waves walk several tiles once the launch exceeds what is resident at two waves per SIMD (256 CUs x 8): LIBXSMM_HIP_F64_S64_WAVES overrides the cap
-    static const long long cap = []() { const char* e = getenv("LIBXSMM_HIP_F64_S64_WAVES"); const long long v = e ? atoll(e) : 0; return v > 0 ? v : 2048ll; }();
+    constexpr long long cap = 2048ll;
     const long long per_wave = (t64 + cap - 1) / cap, waves = (t64 + per_wave - 1) / per_wave;
     if (a.br_count == 0) { if (kernel_name) *kernel_name = "gemm_f64_stream_kernel"; goto f64_small_tiles; }      // beta-only call: the 32 x 32 kernel has that path
     if (nt) hipLaunchKernelGGL((gemm_f64_stream64_kernel<2>), dim3((unsigned int)((waves + 3) / 4)), dim3(256), 0, st, a);

@@ -3838,7 +3838,7 @@ static bool operands_aligned16(const GemmArgs& a, int elem_size) {
 // ragged bf16 / f16 shapes: every B block and column starts on a dword (strided forms only: the alignment of listed blocks is not known on the host), so that the
 // wave's B panel can be fetched a dword per lane by LDS-DMA (gemm_mfma_bf16_kernel<.., BL = true>); LIBXSMM_HIP_RAGGED16_LDS=0 keeps B in registers (measurement switch)
 static bool ragged16_b_dwords(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_RAGGED16_LDS"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || a.list_a || a.br_mode == 1 || a.br_mode == 2 || (a.ldb & 1)) return false;
   const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0);
   return (bits & 3ull) == 0ull && (unsigned long long)a.n * (unsigned long long)a.ldb < (1ull << 30) && (unsigned long long)a.k * (unsigned long long)a.lda < (1ull << 30);
@@ -3851,14 +3851,14 @@ static bool ragged16_bounded(const GemmArgs& a) {
 }
 // one masked tile, blobs of at most 1024 dwords, dword-aligned operands, no transposes
 static bool f32_blob_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOB"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B))) return false;
   return a.m <= 32 && a.n <= 32 && a.k <= 32 && a.lda <= 32 && a.ldb <= 32 && a.k * a.lda <= 1024 && a.n * a.ldb <= 1024;
 }
 // the lean streaming kernel: one 32x32 tile per problem, 1-D strided batch, plain or STRIDE batch-reduce with at least one block,
 // beta = 0, no fused epilogue, every 32-bit offset inside a tile representable
 static bool f32_lean_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_LEAN"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || a.m != 32 || a.n != 32 || a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.br_count < 1) return false;
   if (!(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) || a.colbias || a.act || a.vnni_c) return false;
   if ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c) & 3ull) != 0) return false;
@@ -3869,7 +3869,7 @@ static bool f32_lean_ok(const GemmArgs& a) {
 // the blocked kernel on 16 x 16 x K tiles: grid divisible into 8 x 8 problems, an even number of 16-deep sub-steps, plain epilogue, f32, NN, strided
 // macro-tile kernel (gemm_bf16_macro_kernel): 16 / 32 / 64 tiles; every request offset (lane part + stage part) must fit 32 bits
 static bool bf16_macro_ok(const GemmArgs& a, bool& k16) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_BLOCKED"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.br_count == 0) return false;
   const bool f16 = a.a_type == LIBXSMM_DATATYPE_F16;            // IEEE halves: same layouts, v_mfma_f32_32x32x16_f16 (64 / 32 tiles, f32 accumulation only)
   if ((a.a_type != LIBXSMM_DATATYPE_BF16 && !f16) || a.b_type != a.a_type || !(a.flags & LIBXSMM_GEMM_FLAG_VNNI_A)) return false;
@@ -3893,7 +3893,7 @@ static bool bf16_macro_ok(const GemmArgs& a, bool& k16) {
   return spanA < (1ull << 32) && spanB < (1ull << 32);
 }
 static bool f32_blocked16_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOCKED"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3) || a.a_type != LIBXSMM_DATATYPE_F32 || a.b_type != LIBXSMM_DATATYPE_F32 || a.c_type != LIBXSMM_DATATYPE_F32) return false;
   if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B)) || a.vnni_c || !(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) || a.colbias || a.act) return false;
   if (a.m != 16 || a.n != 16 || a.k <= 0 || (a.k % 16) != 0) return false;
@@ -3906,7 +3906,7 @@ static bool f32_blocked16_ok(const GemmArgs& a) {
   return (bits & 15ull) == 0ull && a.lda < (1 << 22) && a.ldb < (1 << 22) && a.ldc < (1 << 22);
 }
 static bool f32_blocked_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_BLOCKED"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || !a.batch_inner || a.list_a || (a.br_mode != 0 && a.br_mode != 3)) return false;
   if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B)) || a.vnni_c) return false;
   if (!((a.m == 32 && a.n == 32) || (a.m == 64 && a.n == 64)) || (a.k % 32) != 0 || a.k <= 0) return false;
@@ -3933,7 +3933,7 @@ static bool stream_nt(const GemmArgs& a, int elem_bytes_ab, int elem_bytes_c) {
 // the four-problems-per-wave kernel for 16 x 16 problems: m = n = 16, k % 16 == 0, no transposes, beta = 0, no fused epilogue, operands whose
 // vector loads are aligned (B columns and C columns 16 bytes for f32, 8 bytes for bf16; bf16 A in VNNI-2 with dword-aligned rows)
 static bool p16_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_P16"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || a.m != 16 || a.n != 16 || a.k <= 0 || (a.k % 16) != 0 || a.vnni_c || a.colbias || a.act) return false;
   if (!(a.flags & LIBXSMM_GEMM_FLAG_BETA_0) || (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B))) return false;
   if (a.br_mode == 1 || a.br_mode == 2 || a.list_a) return false;            // strided forms only: alignment is decidable on the host
@@ -3950,13 +3950,13 @@ static bool p16_ok(const GemmArgs& a) {
   return (bbits & 7ull) == 0 && (cbits & (ec == 4 ? 15ull : 7ull)) == 0 && (abits & 3ull) == 0;
 }
 static bool f32_wg64_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_WG64"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B)) || a.list_a || (a.br_mode != 0 && a.br_mode != 3)) return false;
   return a.lda < (1 << 22) && a.ldb < (1 << 22) && a.k >= 32 && a.br_count * (unsigned long long)(a.k >> 5) < (1ull << 31);
 }
 // bf16 64 x 64 problems, one per workgroup: VNNI-2 A with 16-byte aligned rows (lda % 4 == 0), flat B with 16-byte aligned columns, strided forms
 static bool bf16_wg64_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_WG64"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || a.list_a || (a.br_mode != 0 && a.br_mode != 3)) return false;
   const unsigned long long brs = a.br_mode == 3 ? (unsigned long long)(a.br_stride_a | a.br_stride_b) : 0ull;
   const unsigned long long bits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b | brs |
@@ -3972,7 +3972,7 @@ static unsigned int ragged_rounds_cap(int waves, int np, unsigned int rounds) {
 }
 // the ragged kernel: f32 NN with a plain epilogue, 2 <= m <= 128, n <= 128, at most 24 tile pairs; fills in the chunk plan
 static bool f32_ragged_plan(const GemmArgs& a, RaggedCfg& c, int& waves, int& np, int& rounds, unsigned int& lds_bytes, bool& single) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_F32_RAGGED"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || a.a_type != LIBXSMM_DATATYPE_F32 || a.b_type != LIBXSMM_DATATYPE_F32 || a.c_type != LIBXSMM_DATATYPE_F32) return false;
   if ((a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_A | LIBXSMM_GEMM_FLAG_VNNI_B)) || a.vnni_c || a.colbias || a.act) return false;
   // leading dimensions below 2^20: every round offset (columns x leading dimension x 4 bytes) stays below 2^31
@@ -4034,13 +4034,13 @@ static void launch_ragged(const GemmArgs& a, const RaggedCfg& c, unsigned int ld
 // the bf16 blocked kernel: 2-D batch of 64 x 64 x K problems (K % 32 == 0) whose grid divides into 4 x 4 problems, VNNI-2 A, flat B, plain
 // epilogue, beta = 0, strided forms, 16-byte aligned rows / columns, at least one block
 static int f32_dma_mode() {   // LIBXSMM_HIP_F32_DMA: 0 never, 1 (default) 64x64 tiles, 2 also 32x32 tiles
-  static const int mode = []() { const char* e = getenv("LIBXSMM_HIP_F32_DMA"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
+  constexpr int mode = 1;
   return mode;
 }
 // B columns 16-byte aligned, A rows dword aligned (always), every offset inside one tile below 4 GiB
 // the bf16 forms kernel: whole 32-tiles, every row of both operand tiles a 16-byte aligned 64- / 128-byte run, strided forms (alignment decidable here)
 static bool bf16_forms_ok(const GemmArgs& a, int& af, int& bf) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_FORMS"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || a.a_type != LIBXSMM_DATATYPE_BF16 || a.b_type != LIBXSMM_DATATYPE_BF16 || (a.c_type != LIBXSMM_DATATYPE_BF16 && a.c_type != LIBXSMM_DATATYPE_F32)) return false;
   if ((a.m % 32) || (a.n % 32) || (a.k % 32) || a.k <= 0 || a.comp_f16) return false;
   const bool ta = a.flags & LIBXSMM_GEMM_FLAG_TRANS_A, tb = a.flags & LIBXSMM_GEMM_FLAG_TRANS_B, va = a.flags & LIBXSMM_GEMM_FLAG_VNNI_A, vb = a.flags & LIBXSMM_GEMM_FLAG_VNNI_B;
@@ -4066,7 +4066,7 @@ template <int AF> static void launch_bf16_forms_a(const GemmArgs& a, int bf, dim
 }
 
 static bool bf16_stream_ok(const GemmArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BF16_STREAM"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || a.list_a || a.br_mode == 1 || a.br_mode == 2) return false;
   const unsigned long long bits = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)(a.br_mode == 3 ? a.br_stride_b : 0) |
     (unsigned long long)((long long)a.ldb * 2);
@@ -4363,7 +4363,7 @@ __global__ __launch_bounds__(256, WGS) void gemm_bitmask16_kernel(GemmArgs p, co
 int launch_gemm_bitmask16(const GemmArgs& a, const void* bitmap, unsigned int* scratch, size_t scratch_bytes, void* stream, const char** name, int* taken) {
   hipStream_t st = (hipStream_t)stream;
   *taken = 0;
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BITMASK_FUSED"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   const bool t16 = (a.a_type == LIBXSMM_DATATYPE_BF16 || a.a_type == LIBXSMM_DATATYPE_F16) && a.b_type == a.a_type;
   // (every 64-column tile of C expands A again: beyond a few tiles the dense image, built once, is the cheaper form)
   if (off || !t16 || (a.m % 16) || (a.k % 64) || a.m <= 0 || a.n <= 0 || a.n > 256 || a.k <= 0) return 0;
@@ -4373,7 +4373,7 @@ int launch_gemm_bitmask16(const GemmArgs& a, const void* bitmap, unsigned int* s
   const size_t table_words = ((size_t)rows * (size_t)(tiles + 2) + 63) & ~(size_t)63;
   // slices of k: about 768 workgroups on the chip (three per CU; 256 ... 4096 measured within 20 % of each other), at least four chunks per slice, the partial tiles inside the scratch
   const long long wgs = (long long)tiles * ((a.n + 63) / 64);
-  static const long long want = []() { const char* e = getenv("LIBXSMM_HIP_BITMASK_WGS"); return e ? atoll(e) : 768ll; }();
+  constexpr long long want = 768ll;
   long long slices = std::max<long long>(1, std::min<long long>(want / std::max<long long>(wgs, 1), chunks / 4));
   const size_t tile_bytes = (size_t)a.m * (size_t)a.n * sizeof(float);
   while (slices > 1 && table_words * 4 + (size_t)slices * tile_bytes > scratch_bytes) --slices;
@@ -4440,7 +4440,7 @@ int launch_mfma_probe(int bf16, const void* operands, int iterations, void* stre
 // the partial products of one long f32 chain (see gemm_f32_brchain_kernel); *nslices = partial tiles written; 0 slices = shape not taken
 int launch_brchain_f32(const GemmArgs& a_in, float* partial, size_t partial_capacity_tiles, int* nslices, void* stream, const char** kernel_name) {
   *nslices = 0;
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BRCHAIN"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || a_in.a_type != LIBXSMM_DATATYPE_F32 || a_in.b_type != LIBXSMM_DATATYPE_F32 || a_in.br_mode != 3 || (a_in.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B))) return 0;
   if ((a_in.m % 32) || (a_in.n % 32) || (a_in.k % 32) || a_in.k <= 0 || a_in.m <= 0 || a_in.n <= 0) return 0;
   const unsigned long long bits = (unsigned long long)(size_t)a_in.a | (unsigned long long)(size_t)a_in.b | (unsigned long long)a_in.br_stride_a | (unsigned long long)a_in.br_stride_b |
@@ -4452,7 +4452,7 @@ int launch_brchain_f32(const GemmArgs& a_in, float* partial, size_t partial_capa
   // about 2048 waves over the chip (one workgroup of 8 per CU), chunk blocks per wave, 8 waves per slice: measured on 32^3 chains (round 3): br = 4096 12.6 us with
   // 1024 ... 2731 waves against 14.6 us with >= 4096 (twice the partial tiles for the second kernel) and 16.4 us with 512; br = 65 536: 91 - 103 us with 1024 ... 2048,
   // 102 - 111 us with >= 4096
-  static const unsigned long long want_waves = []() { const char* e = getenv("LIBXSMM_HIP_BRCHAIN_WAVES"); return e ? (unsigned long long)atoll(e) : 2048ull; }();
+  constexpr unsigned long long want_waves = 2048ull;
   unsigned long long chunk = (tiles * a.br_count + want_waves - 1ull) / want_waves; if (chunk == 0) chunk = 1;
   const unsigned long long slices = (a.br_count + 8ull * chunk - 1ull) / (8ull * chunk);
   if (slices > partial_capacity_tiles || slices * tiles >= (1ull << 31)) return 0;
@@ -4483,7 +4483,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     a.tiles_m = (a.m + tm - 1) / tm; a.tiles_n = (a.n + tn - 1) / tn;
     a.map2d_shift = 0;
     if (a.batch_inner && a.tiles_m * a.tiles_n == 1) {           // 2-D batch, one tile per element: deal compact super-tiles to the XCDs
-      static const int want = []() { const char* e = getenv("LIBXSMM_HIP_2D_SUPERTILE"); const int v = e ? atoi(e) : 16; return (v == 0 || v == 8 || v == 16 || v == 32) ? v : 16; }();
+      constexpr int want = 16;
       const unsigned int ni = a.batch_inner, nj = a.nbatch / a.batch_inner;
       for (int t = want; t >= 8 && !a.map2d_shift; t >>= 1)
         if (ni % t == 0 && nj % t == 0 && ((ni / t) * (nj / t)) % 8 == 0) a.map2d_shift = t == 32 ? 5 : (t == 16 ? 4 : 3);
@@ -4600,7 +4600,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   // (round 5: shapes of several WHOLE 16-tiles that are not whole 32-tiles -- 48^3, 32 x 48 ... -- ran a wave per 16-tile, nine waves per 48^3 problem that each fetched
   //  their own panels: 0.49 of the HBM roofline.  The one-problem-per-workgroup kernel takes them like 40^3 and 56^3: 48^3 0.49 -> 0.73, batch 4096 0.41 -> 0.56, beta = 1
   //  0.53 -> 0.70 (profiles/r05_t16_ragged.jsonl); LIBXSMM_HIP_T16_RAGGED=0: the wave-per-tile kernel)
-  static const bool t16_ragged = []() { const char* e = getenv("LIBXSMM_HIP_T16_RAGGED"); return !(e && e[0] == '0'); }();
+  constexpr bool t16_ragged = true;
   // (whole 32-tiles that are several per problem -- 96^3, 128^3 -- stay a wave per tile: on gemm_wgp_f32_kernel 96^3 0.47 -> 0.49, 128^3 0.47 -> 0.37, r05_t16_ragged.jsonl:
   //  the f32 matrix pipe is as busy as the memory there)
   if (((pl.path == P_F32_1x1 || pl.path == P_F32_2x2) && !pl.exact) || (t16_ragged && pl.path == P_F32_T16 && (a.m > 16 || a.n > 16))) {
@@ -4646,7 +4646,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
   // 8-bit operands on the masked matrix-core kernel: any shape with whole k-quads, any alignment, any batch-reduce form.  Returns false for what it does not
   // take (more than 2^31 bytes inside one operand).
   auto launch_m8 = [&](bool big) -> bool {
-    static const int tile_env = []() { const char* e = getenv("LIBXSMM_HIP_M8_TILE"); return e ? atoi(e) : 0; }();      // experiments: 1 forces 32 x 32 tiles, 2 forces 64 x 64
+    constexpr int tile_env = 0;      // experiments: 1 forces 32 x 32 tiles, 2 forces 64 x 64
     if (tile_env == 1) big = false; else if (tile_env == 2) big = true;
     const bool fp8 = a.a_type == LIBXSMM_DATATYPE_BF8 || a.a_type == LIBXSMM_DATATYPE_HF8;
     if (fp8 && a.c_type != LIBXSMM_DATATYPE_F32 && a.vnni_c) return false;
@@ -4658,7 +4658,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
     grid = big ? wave_grid(64, 64) : wave_grid(32, 32);
     if (kernel_name) *kernel_name = big ? "gemm_mfma_8bit_kernel<2,2>" : "gemm_mfma_8bit_kernel<1,1>";
     // strided forms whose blocks, rows and columns start on dwords: B through LDS (see the kernel); LIBXSMM_HIP_M8_LDS=0 keeps B in registers (measurement switch)
-    static const bool lds_off = []() { const char* e = getenv("LIBXSMM_HIP_M8_LDS"); return e && e[0] == '0'; }();
+    constexpr bool lds_off = false;
     const unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_a | (unsigned long long)a.bs_b |
       (unsigned long long)(a.br_mode == 3 ? (a.br_stride_a | a.br_stride_b) : 0) | (unsigned long long)a.ldb;
     const bool bl = !lds_off && !a.list_a && a.br_mode != 1 && a.br_mode != 2 && (abits & 3ull) == 0ull &&
@@ -4730,7 +4730,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         // cache policy (see the kernel).  Streaming hint of the calling thread (libxsmm_hip_set_streaming_hint): 2 = operands are read once
         // from HBM -> nt loads; 1 = operands are re-read / cache resident -> never nt; 0 (default) = decide by size: a launch that moves
         // more than the Infinity Cache holds cannot have resident operands.  LIBXSMM_HIP_F32_POLICY=0|1|2 forces a kernel variant.
-        static const int pol_env = []() { const char* e = getenv("LIBXSMM_HIP_F32_POLICY"); return e ? atoi(e) : -1; }();
+        constexpr int pol_env = -1;
         const unsigned long long footprint = (unsigned long long)a.nbatch * (a.br_count * (unsigned long long)(a.k) * 256ull + 4096ull);
         const bool c16 = ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)((long long)a.ldc * 4)) & 15ull) == 0ull);
         int pol = stream_nt(a, 4, 4) ? 1 : 0;
@@ -4868,11 +4868,11 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
       const bool ok = !a.list_a && (bits & 3ull) == 0 && (long long)a.lda * a.k < (1ll << 31) && (long long)a.ldb * a.k < (1ll << 31);
       if (ok) {
         if (a.a_type == LIBXSMM_DATATYPE_MXHF6) {           // E2M3 on the matrix cores (the plan sends E3M2 to the exact kernel, see plan_gemm)
-          static const bool small6 = []() { const char* e = getenv("LIBXSMM_HIP_MX6_1x1"); return e && e[0] == '1'; }();
+          constexpr bool small6 = false;
           const bool big6 = pl.path == P_MXMX_2x2 && !small6;
           const long long lim = (1ll << 31) / 3;
           if ((long long)a.lda * (a.k / 4) < lim && (long long)a.ldb * (a.k / 4) < lim) {
-            static const int gather6 = []() { const char* e = getenv("LIBXSMM_HIP_MX6_STAGE"); return (e && e[0] == '0') ? 1 : 0; }();
+            constexpr int gather6 = 0;
             a.tune = gather6;
             grid = big6 ? wave_grid(64, 64) : wave_grid(32, 32);
             if (kernel_name) *kernel_name = big6 ? "gemm_mx6_stream_kernel<2,2>" : "gemm_mx6_stream_kernel<1,1>";
@@ -4951,7 +4951,7 @@ int launch_gemm(const GemmArgs& a_in, void* stream, const char** kernel_name) {
         (a.c_type == LIBXSMM_DATATYPE_F32 || a.c_type == LIBXSMM_DATATYPE_BF16) && a.a_scf && a.b_scf;
       if (ok) {
         // waves that walk several consecutive tiles with the next chunk's operands in flight: at least 8 K waves per launch, at most 8 tiles each
-        static const int pipe = []() { const char* e = getenv("LIBXSMM_HIP_MX4I8_PIPE"); return e ? atoi(e) : 8; }();
+        constexpr int pipe = 8;
         a.tiles_m = a.m / 32; a.tiles_n = a.n / 32; a.map2d_shift = 0;
         const unsigned long long tiles = (unsigned long long)a.tiles_m * a.tiles_n * a.nbatch;
         const bool c_ok = (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) == 0 || ((((unsigned long long)(size_t)a.c | (unsigned long long)a.bs_c | (unsigned long long)a.bs_c2) & 15ull) == 0 &&

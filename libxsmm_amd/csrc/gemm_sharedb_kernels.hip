@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void gemm_f32_wg64_sharedb_kernel(GemmArgs p, 
 
 // *taken = 0: the caller's other kernels serve
 int launch_gemm_f32_wg64_sharedb(const GemmArgs& a, bool nt, void* stream, const char** kernel_name, int* taken) {
-  static const int env = []() { const char* e = getenv("LIBXSMM_HIP_SHAREDB"); return e ? atoi(e) : -1; }();      // 0: off, N: problems per workgroup
+  constexpr int env = -1;      // 0: off, N: problems per workgroup
   *taken = 0;
   if (env == 0) return 0;
   const bool plain = a.m == 64 && a.n == 64 && a.k == 64 && a.br_count == 1 && a.bs_b == 0 && !a.batch_inner && !a.list_a && (a.flags & LIBXSMM_GEMM_FLAG_BETA_0) &&

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_p16s_kernel(GemmArgs p, unsigne
 
 // 16-byte aligned A rows on top of launch_gemm's p16_ok (B, C and the strided forms are checked there); *taken = 0: the caller's older kernel serves
 int launch_gemm_p16w(const GemmArgs& a, bool nt, void* stream, const char** kernel_name, int* taken) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_P16W"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   *taken = 0;
   const bool bf16 = a.a_type == LIBXSMM_DATATYPE_BF16;
   unsigned long long abits = (unsigned long long)(size_t)a.a | (unsigned long long)a.bs_a | (unsigned long long)((long long)a.lda * 4);
@@ -245,7 +245,7 @@ int launch_gemm_p16w(const GemmArgs& a, bool nt, void* stream, const char** kern
   *taken = 1;
   // waves that walk `per_wave` steps (a problem / a pair of problems) as a two-deep pipeline: single-block 16^3 problems, launches that keep at least ~8 K waves
   // (LIBXSMM_HIP_P16_PW = 0 switches the form off, N forces N steps per wave)
-  static const int pw_env = []() { const char* e = getenv("LIBXSMM_HIP_P16_PW"); return e ? atoi(e) : -1; }();
+  constexpr int pw_env = -1;
   const unsigned long long bbits16 = (unsigned long long)(size_t)a.b | (unsigned long long)a.bs_b | (unsigned long long)((long long)a.ldb * (bf16 ? 2 : 4));
   if (pw_env != 0 && a.k == 16 && a.br_count == 1 && !a.batch_inner && !a.list_a && (bbits16 & 15ull) == 0) {
     const unsigned int steps = bf16 ? (a.nbatch + 1u) / 2u : a.nbatch;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))
 
 // *taken = 0: the caller's other kernels serve
 int launch_gemm_16bit_w64(const GemmArgs& a_in, bool nt, void* stream, const char** kernel_name, int* taken) {
-  static const int env = []() { const char* e = getenv("LIBXSMM_HIP_W64"); return e ? atoi(e) : -1; }();      // experiments: 0 off, 1 on / cacheable loads, 2 on / nt loads
+  constexpr int env = -1;      // experiments: 0 off, 1 on / cacheable loads, 2 on / nt loads
   *taken = 0;
   if (env == 0) return 0;
   const GemmArgs& a = a_in;

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, WGP_WAVES_D(TPW, DEAL, AK)) void gemm_wgp16_ke
 // rows / columns beyond m / n of a tile read LDS beyond their operand's rows (another k pair's row, the other image, or nothing): they feed results nobody stores,
 // and an LDS read beyond the allocation returns zero by definition -- no fault is possible on that side.
 static inline bool wgp16_shape_ok(const GemmArgs& a, Wgp16Geo& g, unsigned int& lds_bytes, int& tpw, int ak = -1) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off) return false;
   if (a.batch_inner || (a.list_a && !a.lists_aligned16) || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c) return false;      // 1-D batches: strided, or pointer lists the library built itself (the coalescing queue: every pointer known to be 16-byte aligned); plain / STRIDE batch-reduce
   if (a.flags & (LIBXSMM_GEMM_FLAG_TRANS_A | LIBXSMM_GEMM_FLAG_TRANS_B | LIBXSMM_GEMM_FLAG_VNNI_B)) return false;
@@ -364,7 +364,7 @@ static inline bool wgp16_shape_ok(const GemmArgs& a, Wgp16Geo& g, unsigned int& 
 
 // waves of a workgroup: one per strip, or one per tile when the round-robin deal has fewer than four
 static inline unsigned int wgp_waves(int tiles_m, int tiles_n, int deal) {
-  static const bool four = []() { const char* e = getenv("LIBXSMM_HIP_WGP_WAVES4"); return e && e[0] == '1'; }();
+  constexpr bool four = false;
   if (four) return 4u;
   const int n = deal == 1 ? tiles_m : deal == 2 ? tiles_n : tiles_m * tiles_n;
   return (unsigned int)(n < 4 ? n : 4);
@@ -372,11 +372,11 @@ static inline unsigned int wgp_waves(int tiles_m, int tiles_n, int deal) {
 
 // strips of tiles (DEAL 1: a tile row per wave, 2: a tile column) when they are as short as the round-robin deal's longest wave
 static inline int wgp_deal(int tiles_m, int tiles_n, int& tpw) {
-  static const int forced = []() { const char* e = getenv("LIBXSMM_HIP_WGP_DEAL"); return e ? atoi(e) : -1; }();
+  constexpr int forced = -1;
   // 2 x 2 tiles: TWO waves with a tile row each instead of four with a tile each -- half the waves to launch, the A fragment read once for two MFMAs, and a CU holds twelve
   // problems instead of eight (40^3: bf16 0.60 -> 0.68, i8 0.57 -> 0.65, 8-bit weights 0.50 -> 0.61, profiles/r05_wgp_pair.jsonl; LIBXSMM_HIP_WGP_PAIR=0: four waves)
   // (ONE wave with the whole 2 x 2 block, no barrier at all, sixteen problems per CU: measured and not adopted -- 40^3 0.62 against 0.65, 48^3 0.65 against 0.70, same file)
-  static const bool pair = []() { const char* e = getenv("LIBXSMM_HIP_WGP_PAIR"); return !(e && e[0] == '0'); }();
+  constexpr bool pair = true;
   if (pair && tiles_m == 2 && tiles_n == 2 && forced != 0) { tpw = 2; return 1; }
   if (forced == 0 || tpw < 2) return 0;
   if ((tiles_m == 3 || tiles_m == 4) && tiles_n == tpw && forced != 2) return 1;

@@ -171,7 +171,7 @@ void gemm_wgp8_kernel(GemmArgs p, Wgp16Geo g) {
 // kind: 0 integers (ua / ub: the operand is unsigned), 1 BF8, 2 HF8 -- launch_gemm's P_M8 case; packed blocks only (lda == m, ldb == k)
 int launch_gemm_wgp8(const GemmArgs& a_in, int kind, bool ua, bool ub, void* stream, const char** kernel_name, int* taken) {
   *taken = 0;
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   const GemmArgs& a = a_in;
   if (off || kind < 0 || kind > 2) return 0;
   if (a.batch_inner || (a.list_a && !a.lists_aligned16) || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || (kind == 0 && (a.colbias || a.act))) return 0;      // (fused operators on the 8-bit floats: round 6)

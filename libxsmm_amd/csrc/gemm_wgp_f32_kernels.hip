@@ -146,8 +146,8 @@ static void wgp_f32_grid(int tm, int tn, int& wr, int& wc, int& rm, int& rn) {
 
 int launch_gemm_wgp_f32(const GemmArgs& a_in, void* stream, const char** kernel_name, int* taken) {
   *taken = 0;
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_WGP16"); return e && e[0] == '0'; }();
-  static const unsigned int budget = []() { const char* e = getenv("LIBXSMM_HIP_WGP_F32_LDS"); return e ? (unsigned int)atoi(e) * 1024u : 48u * 1024u; }();      // LDS per workgroup (A/B switch)
+  constexpr bool off = false;
+  constexpr unsigned int budget = 48u * 1024u;      // LDS per workgroup (A/B switch)
   const GemmArgs& a = a_in;
   if (off || a.a_type != LIBXSMM_DATATYPE_F32 || a.b_type != LIBXSMM_DATATYPE_F32 || a.c_type != LIBXSMM_DATATYPE_F32) return 0;
   if (a.batch_inner || (a.list_a && !a.lists_aligned16) || a.br_mode == 1 || a.br_mode == 2 || a.vnni_c || a.colbias || a.act) return 0;

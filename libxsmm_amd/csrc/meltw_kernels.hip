@@ -391,7 +391,7 @@ static bool is_float_type(int t) { return t == LIBXSMM_DATATYPE_F32 || t == LIBX
 static bool is_tpp_float(int t) { return is_float_type(t) || t == LIBXSMM_DATATYPE_F16 || t == LIBXSMM_DATATYPE_BF8 || t == LIBXSMM_DATATYPE_HF8; }
 // is this TPP eligible for meltw_ew8_kernel?
 static bool ew8_ok(const MeltwArgs& a) {
-  static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_EW8"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || a.m % 8 != 0 || a.ldo % 8 != 0) return false;
   const int nin = a.operation == LIBXSMM_MELTW_OPERATION_UNARY ? 1 : a.operation == LIBXSMM_MELTW_OPERATION_BINARY ? 2 : 3;
   if (!is_float_type(a.out_type) || ((size_t)a.out % 16) || ((size_t)a.bs_out % 16)) return false;
@@ -1730,7 +1730,7 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
   }
   if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY) {
     int v = 0; const int mode = xform_mode(a.type, &v);
-    static const bool xvec_off = []() { const char* e = getenv("LIBXSMM_HIP_XFORM_VEC"); return e && e[0] == '0'; }();
+    constexpr bool xvec_off = false;
     const bool base16 = ((((size_t)a.in0 | (size_t)a.out | (size_t)a.bs_in0 | (size_t)a.bs_out) & 15) == 0);
     const int vec = 16 / (sz > 0 ? sz : 1);
     if (a.type == LIBXSMM_MELTW_TYPE_UNARY_TRANSFORM_NORM_TO_NORMT && !xvec_off && base16 && a.m % vec == 0 && a.n % vec == 0 && a.ldi % vec == 0 && a.ldo % vec == 0 &&
@@ -1744,7 +1744,7 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       hipLaunchKernelGGL(vnni2_vec_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, a, o8, total);
       if (name) *name = "vnni2_vec_kernel";
     } else if (mode == XF_NORM_TO_VNNI && v == 2 && sz == 2 && !xvec_off && (((size_t)a.out | (size_t)a.bs_out) % 4) == 0 && (long long)a.ldo * ((a.n + 1) / 2) < (1ll << 31) && a.nbatch < 65536) {
-      static const bool quad_off = []() { const char* e = getenv("LIBXSMM_HIP_VNNI2_QUAD"); return e && e[0] == '0'; }();
+      constexpr bool quad_off = false;
       if (!quad_off && a.ldo >= 16 && (((size_t)a.in0 | (size_t)a.bs_in0) % 2) == 0) {          // four positions per thread (rows of at least a few threads)
         const unsigned int q4 = ((unsigned int)a.ldo + 3u) / 4u, per_q = q4 * (unsigned int)((a.n + 1) / 2);
         hipLaunchKernelGGL(vnni2_quad_kernel, dim3((per_q + 255u) / 256u, a.nbatch), dim3(256), 0, st, a, q4, per_q);
@@ -1781,7 +1781,7 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       } else if ((a.flags & LIBXSMM_MELTW_FLAG_UNARY_GS_ROWS) && !xvec_off && gs_rows_lds_ok(a, sz)) {
         const int rows = a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER ? a.ldi : a.ldo;
         const size_t lds_bytes = (size_t)rows * sz;
-        static const int nc_env = []() { const char* e = getenv("LIBXSMM_HIP_GS_ROWS_NC"); return e ? atoi(e) : 2; }();       // columns per workgroup of the gather (1: the older form).  4096 x 8192 / 2048 x 16384 f32: 1 -> 0.550 / 0.601, 2 -> 0.563 / 0.628, 4 (64 KiB of LDS, two workgroups per CU) -> 0.448 / 0.578
+        constexpr int nc_env = 2;       // columns per workgroup of the gather (1: the older form).  4096 x 8192 / 2048 x 16384 f32: 1 -> 0.550 / 0.601, 2 -> 0.563 / 0.628, 4 (64 KiB of LDS, two workgroups per CU) -> 0.448 / 0.578
         if (a.type == LIBXSMM_MELTW_TYPE_UNARY_GATHER && nc_env > 1 && (sz == 4 || sz == 2) && a.n >= 64 && ((long long)a.ldi * sz) % 16 == 0) {
           const int nc = (nc_env >= 4 && lds_bytes * 4 <= 65536) ? 4 : ((lds_bytes * 2 <= 65536) ? 2 : 1);
           if (nc > 1) {
@@ -1818,7 +1818,7 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
     } else if (is_reduce_type(a.type)) {
       const bool rows = (a.flags & LIBXSMM_MELTW_FLAG_UNARY_REDUCE_ROWS) != 0;
       const bool bf = a.in0_type == LIBXSMM_DATATYPE_BF16;
-      static const bool rvec_off = []() { const char* e = getenv("LIBXSMM_HIP_REDUCE_VEC"); return e && e[0] == '0'; }();
+      constexpr bool rvec_off = false;
       const size_t al = bf ? 8 : 16;
       if (!rvec_off && is_float_type(a.in0_type) && a.m % 4 == 0 && a.ldi % 4 == 0 && (((size_t)a.in0 | (size_t)a.bs_in0) % al) == 0 && a.nbatch < 65536) {
         int G = 1; while (G < 64 && G < a.m / 4) G <<= 1;

@@ -699,7 +699,7 @@ void run_gemm(KernelCtx* k, const void* param, const BatchSpec& b) {
   // One (or very few) problems with a long STRIDE batch-reduce chain would run on a handful of waves: split the chain
   // into `nsplit` segments that run as a batch of partial products (f32 tiles in a workspace), then add them up and
   // apply beta / bias / activation in a second pass (SURVEY 8(d) config #2 variant B: one BRGEMM with br = 4096).
-  static const bool split_off = []() { const char* e = getenv("LIBXSMM_HIP_BRSPLIT"); return e && e[0] == '0'; }();
+  constexpr bool split_off = false;
   const long long tiles = (long long)((a.m + 31) / 32) * ((a.n + 31) / 32);
   if (!split_off && a.br_mode == 3 && a.nbatch == 1 && !a.list_a && a.br_count >= 16 && tiles * 8 <= 1024 && (a.a_type == LIBXSMM_DATATYPE_F32 || a.a_type == LIBXSMM_DATATYPE_BF16) && a.b_type == a.a_type && a.m > 0 && a.n > 0) {
     const size_t tile_bytes = (size_t)a.m * a.n * sizeof(float);

@@ -216,16 +216,10 @@ int launch_spmm(const SpmmArgs& a, void* stream, const char** name) {
   };
   // streaming kernel first (pattern + K x slab slice in LDS); the panel kernel below takes what does not fit
   {
-    static const int variant = []() { const char* e = getenv("LIBXSMM_HIP_SPMM_VARIANT"); return e ? atoi(e) : 0; }();
-    int rc = -1;
-    if (variant >= 0 && a.nnz > 0) {
-      if (a.dtype == LIBXSMM_DATATYPE_F64) {
-        if (variant == 1 && aligned(2)) rc = launch_spmm_stream<double, 16, 1>(a, st, name, "spmm_stream_kernel<f64,16x1>");
-        if (rc < 0) rc = launch_spmm_stream<double, 4, 2>(a, st, name, "spmm_stream_kernel<f64,4x2>");
-      } else {
-        if (variant == 1 && aligned(4)) rc = launch_spmm_stream<float, 16, 1>(a, st, name, "spmm_stream_kernel<f32,16x1>");
-        if (rc < 0) rc = launch_spmm_stream<float, 4, 1>(a, st, name, "spmm_stream_kernel<f32,4x1>");
-      }
+    // (a 16-row x 1 form of the streaming kernel was measured in round 2 and lost; removed in round 6)
+    if (a.nnz > 0) {
+      const int rc = a.dtype == LIBXSMM_DATATYPE_F64 ? launch_spmm_stream<double, 4, 2>(a, st, name, "spmm_stream_kernel<f64,4x2>")
+                                                     : launch_spmm_stream<float, 4, 1>(a, st, name, "spmm_stream_kernel<f32,4x1>");
       if (rc >= 0) return rc;
     }
   }
@@ -1165,7 +1159,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
   if (a.m_blocks <= 0 || a.M <= 0 || a.N <= 0) { if (name) *name = "(empty)"; return 0; }
   // matrix-core path: bf16 with VNNI-2 A, 32-deep k steps, 16-wide n sub-tiles, 16-row i tiles, 8-byte aligned C columns
   {
-    static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_MFMA"); return e && e[0] == '0'; }();
+    constexpr bool off = false;
     const int nbl_per_wave = (a.bn > 0 && 64 % a.bn == 0) ? 64 / a.bn : 0;
     const bool shape_ok = a.a_type == LIBXSMM_DATATYPE_BF16 && a.vnni_a && a.bk % 32 == 0 && (a.bn == 16 || a.bn == 32 || a.bn == 64) && a.M % 16 == 0 &&
       (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTbl && ((size_t)a.a % 4 == 0) && ((size_t)a.bvals % 16 == 0) && ((size_t)a.c % 16 == 0);
@@ -1174,7 +1168,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
       const long long total = (long long)tiles_i * tiles_n * a.m_blocks;
       if (total < (1ll << 31)) {
         const dim3 grid((unsigned int)((total + 3) / 4));
-        static const bool dma = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_DMA"); return !(e && e[0] == '0'); }();
+        constexpr bool dma = true;
         const bool dma_ok = dma && a.table != nullptr && (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTblDma && ((size_t)a.a % 16 == 0) && (a.M % 4 == 0) && ((long long)(a.K / 2) * a.M < (1ll << 30));
         if (dma_ok) {
           const int nkb = a.K / a.bk;
@@ -1185,10 +1179,10 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
           const unsigned long long a_bytes = (unsigned long long)a.m_blocks * a.M * a.K * 2ull;
           const bool nta = a.stream_hint == 2 || (a.stream_hint == 0 && a_bytes > (256ull << 20));
           // many M-blocks per (i-tile, n-tile): waves that stream over M-blocks (two per SIMD: 2048 on the chip), each taking every mbg-th block
-          static const int stream_mode = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_STREAM"); return e ? atoi(e) : 1; }();
+          constexpr int stream_mode = 1;
           const long long tt_count = (long long)tiles_i * tiles_n;
           if (stream_mode != 0 && a.beta0 && nkb <= 64 && tt_count <= 2048 && ((long long)a.m_blocks * tt_count >= 4096 || stream_mode == 2) && ((long long)(a.K / 2) * a.M) * (long long)a.m_blocks < (1ll << 40)) {
-            static const long long slots_env = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_SLOTS"); return e ? atoll(e) : 0ll; }();
+            constexpr long long slots_env = 0ll;
             // 32 rows per wave (RT = 2: 161 VGPRs, three waves per SIMD) measured 72 us against 61 us: every B fragment then feeds two MFMAs instead of four
             const long long slots = slots_env > 0 ? slots_env : 2048;      // two waves per SIMD (245 VGPRs); three (168 VGPRs) spill inside the chunk loop: 105 instead of 61 us
             long long mbg = std::min<long long>(a.m_blocks, std::max<long long>(1, slots / tt_count));
@@ -1219,7 +1213,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
     }
   }
   {   // f32 on the matrix cores: 16-deep k steps, 16-wide n sub-tiles, 16-row i tiles, 16-byte aligned B blocks and C columns
-    static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_MFMA"); return e && e[0] == '0'; }();
+    constexpr bool off = false;
     const int nbl_per_wave = (a.bn > 0 && 64 % a.bn == 0) ? 64 / a.bn : 0;
     if (!off && a.a_type == LIBXSMM_DATATYPE_F32 && a.c_type == LIBXSMM_DATATYPE_F32 && a.bk % 16 == 0 && (a.bn == 16 || a.bn == 32 || a.bn == 64) && a.M % 16 == 0 && a.N % a.bn == 0 &&
         (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTbl && ((size_t)a.a % 4 == 0) && ((size_t)a.bvals % 16 == 0) && ((size_t)a.c % 16 == 0) && (a.M % 4 == 0)) {
@@ -1229,7 +1223,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
         const dim3 grid((unsigned int)((total + 3) / 4));
         // many M-blocks per (i-tile, n-tile): the bf16 kernel's waves streaming over M-blocks, on f32 operands (round 3; the one-tile-per-wave kernel below
         // builds its pattern rows in every wave and fetches A one 16-deep step ahead: 0.65 of the HBM roofline on config #4's shape)
-        static const int stream_mode = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_STREAM"); return e ? atoi(e) : 1; }();
+        constexpr int stream_mode = 1;
         const int nkb = a.K / a.bk;
         const long long tt_count = (long long)tiles_i * tiles_n;
         if (stream_mode != 0 && a.table != nullptr && a.beta0 && nkb <= 64 && (long long)nbl_per_wave * nkb <= kBcscTblDma && ((size_t)a.a % 16 == 0) && (long long)a.K * a.M < (1ll << 30) &&
@@ -1259,7 +1253,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
   }
   {   // 8-bit integers on the matrix cores: VNNI-4 A, 32-deep k steps, 16-wide n sub-tiles, 16-row i tiles, dword / 8-byte / 16-byte aligned A / B / C
     const bool i8 = (a.a_type == LIBXSMM_DATATYPE_U8 && a.b_type == LIBXSMM_DATATYPE_I8) || (a.a_type == LIBXSMM_DATATYPE_I8 && a.b_type == LIBXSMM_DATATYPE_U8);
-    static const bool off = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_MFMA"); return e && e[0] == '0'; }();
+    constexpr bool off = false;
     const int nbl_per_wave = (a.bn > 0 && 64 % a.bn == 0) ? 64 / a.bn : 0;
     if (!off && i8 && a.c_type == LIBXSMM_DATATYPE_I32 && a.vnni_a && a.bk % 32 == 0 && (a.bn == 16 || a.bn == 32 || a.bn == 64) && a.M % 16 == 0 && a.N % a.bn == 0 &&
         (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTbl && ((size_t)a.a % 4 == 0) && ((size_t)a.bvals % 8 == 0) && ((size_t)a.c % 16 == 0)) {
@@ -1268,7 +1262,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
       if (total < (1ll << 31)) {
         const dim3 grid((unsigned int)((total + 3) / 4));
         const bool ua = a.a_type == LIBXSMM_DATATYPE_U8;
-        static const bool dma = []() { const char* e = getenv("LIBXSMM_HIP_BCSC_DMA"); return !(e && e[0] == '0'); }();
+        constexpr bool dma = true;
         if (dma && a.table != nullptr && (long long)nbl_per_wave * (a.K / a.bk) <= kBcscTblDma && ((size_t)a.a % 16 == 0) && (a.M % 4 == 0) && ((long long)(a.K / 4) * a.M < (1ll << 30))) {
           const int nkb = a.K / a.bk;
           const unsigned int* table = (const unsigned int*)a.table;
