@@ -818,10 +818,13 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, uns
 // (again one 16-byte load) and a chunk is four v_mfma_f32_16x16x4_f32 per (n-tile, i-tile), k = 4 kg + e in step e as in bcsc_mfma_f32_kernel.
 template <int BN16, int AUX_A = 0, int RT = 4, int WPS = 2, bool F32 = false>     // RT: 16-row tiles per wave (4: 64 rows, 2: 32 rows -> half the accumulators, more waves per SIMD)
 __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
-  constexpr int NBL = 4 / BN16, D = 2, W = 16 * RT, SPR = 4 * RT, NI = RT;     // W words per image row, SPR 16-byte slots per row, NI DMA instructions per chunk
+  // D: depth of the B-fragment REGISTER ring (the chunk being consumed + one behind it); DA: depth of the A ring in LDS.  Round 6: DA = 3 -- the A chunks (HBM) run one
+  // chunk further ahead than the B fragments (L2), 8 KiB instead of 4 KiB of A in flight per wave behind the chunk being consumed, with the register budget unchanged
+  // (a third B slot would be 16 registers the two-waves-per-SIMD budget does not have)
+  constexpr int NBL = 4 / BN16, D = 2, DA = 3, W = 16 * RT, SPR = 4 * RT, NI = RT;     // W words per image row, SPR 16-byte slots per row, NI DMA instructions per chunk
   __shared__ unsigned int tbl_all[4][kBcscTblDma];
   __shared__ unsigned int klist_all[4][64];
-  __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][D][16 * W];
+  __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][DA][16 * W];
   __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][F32 ? 4 : 1024];       // 32 columns x 128 bytes: bf16 C leaves in two halves
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int wid = blockIdx.x * 4u + wave;
@@ -920,11 +923,12 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
   GM const char* bv = (GM const char*)p.bvals;
   const int total_f = nmb * nch;
   unsigned int blk_r[D][NBL]; u32x4v bf_r[D][NBL][BN16];
-  // flat chunk f = (tile j, chunk c): cursor advanced by `advance`; `issue` sends chunk (j, c) to ring position u
-  int ij = 0, ic_ = 0;                              // the NEXT chunk to issue
-  auto issue = [&](auto uc) __attribute__((always_inline)) {
+  // flat chunk f = (tile j, chunk c).  Two cursors: the B fragments of chunk f + 2 are asked for when chunk f is consumed (register slot f % 2), the A chunk f + 3 at the
+  // same point (LDS slot f % 3): in issue order  ... B(f) A(f+1) | B(f+1) A(f+2) | B(f+2) A(f+3) ...
+  int bj = 0, bc_ = 0, aj = 0, ac_ = 0;             // the NEXT chunk whose B fragments / whose A chunk is to be issued
+  auto issue_b = [&](auto uc) __attribute__((always_inline)) {
     constexpr int u = decltype(uc)::value;
-    const int q = ic_ / steps, st_ = ic_ - q * steps;
+    const int q = bc_ / steps, st_ = bc_ - q * steps;
     const int kb_ = __builtin_amdgcn_readfirstlane((int)klist[q]);
     sfor<NBL>([&](auto nc) {
       constexpr int nbl = nc.value;
@@ -935,28 +939,43 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
               : bv + (((long long)blk_r[u][nbl] * (16 * BN16) + 16 * s2 + lx) * p.bk + 32 * st_ + 8 * kg) * 2;
         bf_r[u][nbl][s2] = *(GM const u32x4v*)src; });
     });
-    GM const unsigned int* rowbase = A2 + (long long)(g0 + (unsigned int)ij * mbg) * a_mb_words + ((long long)kb_ * (F32 ? p.bk : p.bk / 2) + 16 * st_) * p.M;
+    (void)bj;
+    if (++bc_ == nch) { bc_ = 0; ++bj; }
+  };
+  auto issue_a = [&](auto uc) __attribute__((always_inline)) {
+    constexpr int u = decltype(uc)::value;
+    const int q = ac_ / steps, st_ = ac_ - q * steps;
+    const int kb_ = __builtin_amdgcn_readfirstlane((int)klist[q]);
+    GM const unsigned int* rowbase = A2 + (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + ((long long)kb_ * (F32 ? p.bk : p.bk / 2) + 16 * st_) * p.M;
 #pragma unroll
     for (int x = 0; x < NI; ++x)
       __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)((char*)abuf[u] + 1024 * x), 16, 0, AUX_A);
-    if (++ic_ == nch) { ic_ = 0; ++ij; }
+    if (++ac_ == nch) { ac_ = 0; ++aj; }
   };
-  sfor<D>([&](auto uc) { if (uc.value < total_f) issue(uc); });
+  // prologue, in the steady state's order: A(0) | B(0) A(1) | B(1) A(2)
+  if (total_f > 0) issue_a(std::integral_constant<int, 0>{});
+  if (total_f > 0) issue_b(std::integral_constant<int, 0>{});
+  if (total_f > 1) issue_a(std::integral_constant<int, 1>{});
+  if (total_f > 1) issue_b(std::integral_constant<int, 1>{});
+  if (total_f > 2) issue_a(std::integral_constant<int, 2>{});
   int cj = 0, cc = 0;                               // the chunk being consumed
-  for (int f0 = 0; f0 < total_f; f0 += D) {
-    sfor<D>([&](auto uc) {
-      constexpr int u = uc.value;
-      const int f = f0 + u;
+  for (int f0 = 0; f0 < total_f; f0 += 6) {
+    sfor<6>([&](auto uc) {
+      constexpr int u = uc.value % D, ua = uc.value % DA;           // register slot of the chunk's B fragments, LDS slot of its A chunk
+      const int f = f0 + uc.value;
       if (f < total_f) {
-        // chunk f must have landed.  Younger than its loads: the chunk issued one step later (4 + 4, if there is one) and -- when a tile ended
-        // within the last D chunks -- the 8 stores of that tile's C (loads and stores retire this counter in issue order on gfx9)
-        static_assert(D == 2, "the wait table below is written for one chunk in flight behind the consumed one");
-        constexpr int PER = 4 + NI, NS = (RT == 4) ? 8 : 4;           // instructions per chunk (4 B loads + the DMA), stores of one tile's LDS epilogue
-        // (the 16 direct stores of an f32 tile are NOT counted: the wait is then stricter than needed for two chunks per tile -- measured equal, 119.1 us
-        // either way on config #4's shape in f32 -- and does not depend on how stores retire relative to the loads around them)
-        const bool behind = total_f - 1 - f >= 1, stored = lds_store && cj > 0 && cc < D;
-        if (behind && stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER + NS) : "memory");
-        else if (behind) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
+        // chunk f must have landed: its B fragments are the younger of its two requests, so everything issued BEHIND B(f) may still be in flight -- A(f+1), B(f+1), A(f+2)
+        // (as far as those chunks exist) and, when a tile ended after B(f) was issued (at the end of chunk f - 1 or f - 2: this chunk is the first or second of its tile),
+        // the 8 stores of that tile's C (loads and stores retire this counter in issue order on gfx9).  Fewer stores counted than outstanding (several one-chunk
+        // tiles) only makes the wait stricter.
+        static_assert(D == 2 && DA == 3, "the wait table below is written for B one chunk and A two chunks in flight behind the consumed one");
+        constexpr int NS = (RT == 4) ? 8 : 4;           // stores of one tile's LDS epilogue
+        // (the 16 direct stores of an f32 tile are NOT counted: the wait is then stricter than needed -- measured equal on config #4's shape in f32 -- and does not
+        // depend on how stores retire relative to the loads around them)
+        const int left = total_f - 1 - f;
+        const bool stored = lds_store && cj > 0 && cc < 2;
+        if (left >= 2) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + 2 * NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + 2 * NI) : "memory"); }
+        else if (left == 1) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + NI) : "memory"); }
         else if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         u32x4v a_cur[RT];
@@ -964,13 +983,14 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
           constexpr int t = tc.value;
           if (t < mt) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a_cur[t][e] = abuf[u][(4 * kg + e) * W + ((16 * t + lx + rot) & (W - 1))];
+            for (int e = 0; e < 4; ++e) a_cur[t][e] = abuf[ua][(4 * kg + e) * W + ((16 * t + lx + rot) & (W - 1))];
           }
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         unsigned int blk_c[NBL]; u32x4v bf_c[NBL][BN16];
         sfor<NBL>([&](auto nc) { blk_c[nc.value] = blk_r[u][nc.value]; sfor<BN16>([&](auto sc) { bf_c[nc.value][sc.value] = bf_r[u][nc.value][sc.value]; }); });
-        if (f + D < total_f) issue(uc);
+        if (f + 2 < total_f) issue_b(std::integral_constant<int, u>{});
+        if (f + 3 < total_f) issue_a(std::integral_constant<int, ua>{});
         sfor<NBL>([&](auto nc) {
           constexpr int nbl = nc.value;
           if (blk_c[nbl] != 0xffffffffu) {

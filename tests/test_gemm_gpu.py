@@ -248,8 +248,9 @@ def test_f16_gemm_matches_oracle(kw):
 @pytest.mark.parametrize("kw,kernel", [
     (dict(m=32, n=32, k=32, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=3), "gemm_f16_stream_kernel<1,1>"),
     (dict(m=32, n=32, k=96, c_type=DT.F32, flags=F.VNNI_A), "gemm_f16_stream_kernel<1,1>"),
-    (dict(m=64, n=64, k=64, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2), "gemm_f16_wg64_kernel"),
-    (dict(m=64, n=64, k=128, c_type=DT.F32, flags=F.VNNI_A), "gemm_f16_wg64_kernel"),
+    (dict(m=64, n=64, k=64, c_type=DT.F16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2), "gemm_f16_w64_kernel"),
+    (dict(m=64, n=64, k=128, c_type=DT.F32, flags=F.VNNI_A), "gemm_f16_w64_kernel"),
+    (dict(m=64, n=64, k=96, c_type=DT.F16, flags=F.VNNI_A), "gemm_f16_wg64_kernel"),                 # k not a multiple of 64: four waves per problem, 32-deep chunks
     (dict(m=64, n=64, k=64, c_type=DT.F16, flags=F.VNNI_A), "gemm_f16_w64_kernel"),                  # one problem per wave (round 6)
     (dict(m=64, n=64, k=64, c_type=DT.F32, flags=F.VNNI_A), "gemm_f16_w64_kernel"),
     (dict(m=128, n=64, k=64, c_type=DT.F16, flags=F.VNNI_A), "gemm_f16_stream_kernel<2,2>"),

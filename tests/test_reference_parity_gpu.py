@@ -43,7 +43,7 @@ def test_config2_stride_brgemm_f32_32_cubed_batch_4096(reference):
 def test_config5_bf16_brgemm_64_cubed_bias_relu(reference):
     case = GemmCase(64, 64, 64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, br_type=capi.BR_STRIDE, br_count=2, colbias=True, act=1, batch=256, seed=105)
     got, _, handle = case.run_gpu(batched=True)
-    assert capi.load().hip_kernel_name(handle, 1).decode().startswith("gemm_bf16_wg64_kernel")
+    assert capi.load().hip_kernel_name(handle, 1).decode().startswith("gemm_bf16_w64_kernel")
     ref, _ = case.run_reference(jit=False)
     assert normf_rel(case.valid_region(ref), case.valid_region(got), DT.BF16) < TOL_BF16
 

@@ -1,6 +1,5 @@
-"""gemm_16bit_w64_kernel (round 6; csrc/gemm_w64_kernels.hip): bf16 / f16 64 x 64 x 64 problems, one per wave, operands by whole-line LDS-DMA, 16-bit C through an LDS
-image as whole lines.  Every form the kernel accepts against the oracle, and BITWISE against gemm_bf16_wg64_kernel (LIBXSMM_HIP_W64=0 is read once per process, so the
-comparison goes through a shape the other kernel keeps: the same k order, hence the same f32 sums -- checked on the oracle's side by exact equality of two oracles' inputs)."""
+"""gemm_16bit_w64_kernel (round 6; csrc/gemm_w64_kernels.hip): bf16 / f16 64 x 64 x (64 j) problems, one per wave, operands by whole-line LDS-DMA, 16-bit C through an LDS
+image as whole lines.  Every form the kernel accepts against the oracle; a caller's loop through the coalescing queue bitwise against the strided launch."""
 import numpy as np
 import pytest
 
@@ -61,8 +60,16 @@ def test_pointer_lists_of_the_coalescing_queue_reach_it():
     api.hip_set_async(0); api.hip_set_stream(None)
 
 
-def test_chains_and_longer_k_stay_with_the_workgroup_kernel():
-    api = capi.load()
-    for kw in (dict(k=128), dict(k=64, br_type=capi.BR_STRIDE, br_count=2)):
-        case = GemmCase(64, 64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=8, seed=903, **kw)
+@pytest.mark.parametrize("kw", [dict(k=128), dict(k=64, br_type=capi.BR_STRIDE, br_count=2), dict(k=192, br_type=capi.BR_STRIDE, br_count=3, beta=1, colbias=True, act=1),
+                                dict(k=64, br_type=capi.BR_STRIDE, br_count=5, beta=1)], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_chains_take_their_chunks_through_the_one_image(kw):
+    """batch-reduce chains and k = 64 j: the wave walks the 64-deep chunks one after the other (equal to the workgroup kernel with beta = 0, 0.69 -> 0.75 with beta = 1:
+    profiles/r06_w64_chains.jsonl)"""
+    case = GemmCase(64, 64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=9, seed=903, **kw)
+    _check(case, expect_kernel="gemm_bf16_w64_kernel")
+
+
+def test_k_that_is_not_a_multiple_of_64_stays_with_the_workgroup_kernel():
+    for kw in (dict(k=96), dict(k=32, br_type=capi.BR_STRIDE, br_count=2)):
+        case = GemmCase(64, 64, a_type=DT.BF16, c_type=DT.BF16, flags=F.VNNI_A, batch=8, seed=904, **kw)
         _check(case, expect_kernel="gemm_bf16_wg64_kernel")

@@ -177,6 +177,7 @@ def bcsc(api, m_blocks=8192, M=64, K=256, N=64, bk=32, bn=16, dtype="bf16", host
     reference's driver (inverted on the host once and cached with the kernel) instead of device arrays (inverted by a kernel per call)."""
     colptr, rowidx = structured_2_of_8(K, N, bk, bn)
     nnzb = len(rowidx)
+    kt = len(set(int(x) for x in rowidx))          # K-blocks of A that some block of B references: the others are never read and are NOT algorithmic bytes (round-5 review; 7 of 8 here)
     at, bt, ct, comp, sa, sc, vn = {"bf16": (DT.BF16, DT.BF16, DT.BF16, DT.F32, 2, 2, GEMM_FLAG.VNNI_A), "f32": (DT.F32, DT.F32, DT.F32, DT.F32, 4, 4, 0),
                                     "u8i8": (DT.U8, DT.I8, DT.I32, DT.I32, 1, 4, GEMM_FLAG.VNNI_A), "i8u8": (DT.I8, DT.U8, DT.I32, DT.I32, 1, 4, GEMM_FLAG.VNNI_A)}[dtype]
     h = api.create_packed_spgemm_bcsc(capi.gemm_shape(m_blocks, 0, K, K, 0, N, at, bt, ct, comp), GEMM_FLAG.BETA_0 | vn, 0, capi.SpgemmConfig(M, bk, bn))
@@ -201,7 +202,7 @@ def bcsc(api, m_blocks=8192, M=64, K=256, N=64, bk=32, bn=16, dtype="bf16", host
         p.b.secondary, p.b.tertiary = (colptr.ctypes.data, rowidx.ctypes.data) if host_pattern else (dcp.data_ptr(), dri.data_ptr())
         ps.append(p)
     w = Work(api, f"packed_spgemm_bcsc {dtype} 2:8 M={M} K={K} N={N} bk={bk} bn={bn} m_blocks={m_blocks} beta=0" + (" host pattern" if host_pattern else ""),
-             2.0 * M * m_blocks * bk * bn * nnzb, float(m_blocks * M * (K * sa + N * sc) + nnzb * bk * bn * sa), ns, lambda s: capi.Api.call(h, ps[s]),
+             2.0 * M * m_blocks * bk * bn * nnzb, float(m_blocks * M * (kt * bk * sa + N * sc) + nnzb * bk * bn * sa), ns, lambda s: capi.Api.call(h, ps[s]),
              lambda: api.hip_kernel_name(h, 0).decode())
     w.dense_equiv_flops = 2.0 * M * m_blocks * N * K
     w.keep = (As, Cs, bv, dcp, dri, colptr, rowidx, nblk, ps)
