@@ -565,7 +565,7 @@ def stale_profile_rows(measured):
     # names the library reports for a template instance of another kernel / for a launch of several kernels (the table holds the first symbol of the launch)
     alias = {"bcsc_mfma_f32_stream_kernel": "bcsc_mfma_bf16_stream_kernel", "gemm_fp8c8_stream_kernel": "gemm_fp8_stream_kernel", "gemm_bf32_stream_kernel": "gemm_f32_stream_kernel",
              "gemm_bitmask_reg_kernel": "bitmask_prepass_kernel", "gemm_i4_stream_kernel": "gemm_i8_stream_kernel", "gemm_i2_stream_kernel": "gemm_i8_stream_kernel",
-             "gemm_i1_stream_kernel": "gemm_i8_stream_kernel", "gemm_bf16_wgp_kernel": "gemm_wgp16_kernel", "gemm_f16_wgp_kernel": "gemm_wgp16_kernel",
+             "gemm_i1_stream_kernel": "gemm_i8_stream_kernel", "gemm_bf16_wgp_kernel": "gemm_wgp16_kernel", "gemm_f16_wgp_kernel": "gemm_wgp16_kernel", "gemm_bf16_w64_kernel": "gemm_16bit_w64_kernel", "gemm_f16_w64_kernel": "gemm_16bit_w64_kernel",
              "gemm_8bit_wgp_kernel": "gemm_wgp8_kernel", "gemm_w8_wgp_kernel": "gemm_wgp16_kernel", "reduce_vec_kernel": "reduce_combine_kernel"}        # (the big column reduction is two kernels per call: partial sums, then their combination)
     for label, (kernel, us) in measured.items():
         if label not in rows:
@@ -605,6 +605,23 @@ def committed_counters(kernel, alg_bytes, label):
         except Exception:
             continue
     return traffic, src, busy, busy_src
+
+
+def committed_copy_floor():
+    """{name: best fraction of 8 TB/s} of the latest committed tools/copy_floor.hip run (profiles/r*_copy_floor.txt): what a kernel that ONLY moves a config's bytes --
+    same read : write mix, same footprint -- reached on the GPU box of that round.  Not measured in this run (said so in the key that carries it)."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_copy_floor.txt")), reverse=True):
+        best = {}
+        try:
+            for ln in open(f):
+                if ln.startswith("{"):
+                    r = json.loads(ln)
+                    best[r["copy_floor"]] = max(best.get(r["copy_floor"], 0.0), float(r["frac_of_8TBs"]))
+        except Exception:
+            continue
+        if best:
+            return {"source": os.path.relpath(f, ROOT), "frac_of_8TBs": {k: round(v, 3) for k, v in best.items()}}
+    return None
 
 
 SWEEP = [(dt, m, b) for dt in ("f32", "bf16", "f64") for m in (16, 32, 64) for b in (4096, 65536)]      # f64 (round 4): v_mfma_f64_16x16x4_f64
@@ -847,6 +864,9 @@ def compact_line(full, detail_path):
     for k in ("l3_resident_us", "without_streaming_hint_us", "mfma_power_roof_TF"):
         if full.get(k) is not None:
             line[k] = full[k]
+    cf = committed_copy_floor()
+    if cf:
+        line["copy_floor_committed_profile"] = cf
     line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
     return line
 

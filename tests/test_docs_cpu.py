@@ -51,13 +51,13 @@ def test_public_headers_cite_the_reference_interface():
 
 
 def test_design_section5_table_is_the_committed_bench_record():
-    """DESIGN.md's round-5 table is generated (tools/design_table.py) from profiles/r05_bench_detail.json: every row of the generator's output stands in the document, so
+    """DESIGN.md's closing-run table is generated (tools/design_table.py) from profiles/r06_bench_detail.json: every row of the generator's output stands in the document, so
     the numbers a reader sees are the ones of the committed closing run."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import design_table
     doc = open(os.path.join(ROOT, "DESIGN.md")).read()
-    rows = design_table.rows("r05")
+    rows = design_table.rows("r06")
     assert len(rows) > 70
     missing = [r for r in rows if r not in doc]
     assert not missing, missing[:3]

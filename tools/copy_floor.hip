@@ -51,6 +51,23 @@ __global__ __launch_bounds__(256) void copy_kernel(Streams s, unsigned long long
     }
 }
 
+// the packed sparse kernels' pattern: a lane owns 16 bytes of a COLUMN chunk and touches it in every one of R input rows and W output rows (row pitch = the row length):
+// R + W streams a whole row apart instead of 2-3 contiguous ones
+template <int R, int W, bool NT>
+__global__ __launch_bounds__(256) void rows_kernel(const u32x4* in, u32x4* out, unsigned long long row_vec) {
+  const unsigned long long c = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+  if (c >= row_vec) return;
+  u32x4 v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { GM const u32x4* src = (GM const u32x4*)in + (unsigned long long)r * row_vec + c; v[r] = NT ? __builtin_nontemporal_load(src) : *src; }
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    u32x4 x = v[w % R] ^ v[(w + 7) % R];
+    GM u32x4* dst = (GM u32x4*)out + (unsigned long long)w * row_vec + c;
+    if (NT) __builtin_nontemporal_store(x, dst); else *dst = x;
+  }
+}
+
 template <int NR, int NW, bool NT> static void launch(const Streams& s, unsigned long long pieces, hipStream_t st) {
   constexpr int U = 4;
   hipLaunchKernelGGL((copy_kernel<NR, NW, U, NT>), dim3((unsigned int)((pieces + U - 1) / U)), dim3(256), 0, st, s, pieces);
@@ -68,6 +85,30 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   for (int a = 1; a + 3 < argc; a += 4) {
     const char* name = argv[a]; const int nr = atoi(argv[a + 1]), nw = atoi(argv[a + 2]); const double mib = atof(argv[a + 3]);
+    if (nr == 35 && nw == 35) {           // "<name> 35 35 <MiB per row>": the packed CSR / FsSpMDM access pattern (35 rows in, 35 rows out)
+      const unsigned long long row_vec = (unsigned long long)(mib * 65536.0);
+      const size_t row_bytes = (size_t)row_vec * 16, set_bytes = row_bytes * 70;
+      const int ns = (int)std::max<size_t>(2, ((size_t)1 << 30) / set_bytes + 1);
+      std::vector<void*> ins((size_t)ns), outs((size_t)ns);
+      for (int q = 0; q < ns; ++q) { CHECK(hipMalloc(&ins[(size_t)q], row_bytes * 35)); CHECK(hipMemset(ins[(size_t)q], 0x21, row_bytes * 35)); CHECK(hipMalloc(&outs[(size_t)q], row_bytes * 35)); }
+      for (int nt = 0; nt < 2; ++nt) {
+        const dim3 grid((unsigned int)((row_vec + 255) / 256));
+        auto go = [&](int i) { if (nt) hipLaunchKernelGGL((rows_kernel<35, 35, true>), grid, dim3(256), 0, st, (const u32x4*)ins[(size_t)(i % ns)], (u32x4*)outs[(size_t)(i % ns)], row_vec);
+                               else hipLaunchKernelGGL((rows_kernel<35, 35, false>), grid, dim3(256), 0, st, (const u32x4*)ins[(size_t)(i % ns)], (u32x4*)outs[(size_t)(i % ns)], row_vec); };
+        for (int i = 0; i < 2 * ns; ++i) go(i);
+        CHECK(hipStreamSynchronize(st));
+        const int reps = std::max(3 * ns, (int)(0.05 / (set_bytes / 5e12)));
+        CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) go(i);
+        CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+        float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps, tbs = set_bytes / us / 1e6;
+        printf("{\"copy_floor\": \"%s\", \"reads\": 35, \"writes\": 35, \"MiB_per_stream\": %.1f, \"sets\": %d, \"policy\": \"%s\", \"us\": %.2f, \"TB/s\": %.3f, \"frac_of_8TBs\": %.4f}\n",
+               name, mib, ns, nt ? "nt" : "default", us, tbs, tbs / 8.0);
+      }
+      for (int q = 0; q < ns; ++q) { CHECK(hipFree(ins[(size_t)q])); CHECK(hipFree(outs[(size_t)q])); }
+      continue;
+    }
     const unsigned long long pieces = (unsigned long long)(mib * 256.0);                       // 4 KiB pieces per stream
     const size_t bytes = (size_t)pieces * 4096;
     const size_t per_set = bytes * (size_t)(nr + nw);

@@ -27,7 +27,7 @@ def rows(tag):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
     table = rows(tag)
     if "--write" not in sys.argv:
         print("\n".join(table)); return
