@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void copy_kernel(Streams s, unsigned long long
 
 // the packed sparse kernels' pattern: a lane owns 16 bytes of a COLUMN chunk and touches it in every one of R input rows and W output rows (row pitch = the row length):
 // R + W streams a whole row apart instead of 2-3 contiguous ones
-template <int R, int W, bool NT>
-__global__ __launch_bounds__(256) void rows_kernel(const u32x4* in, u32x4* out, unsigned long long row_vec) {
-  const unsigned long long c = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+template <int R, int W, bool NT, int BS = 256>
+__global__ __launch_bounds__(BS) void rows_kernel(const u32x4* in, u32x4* out, unsigned long long row_vec) {
+  const unsigned long long c = (unsigned long long)blockIdx.x * BS + threadIdx.x;
   if (c >= row_vec) return;
   u32x4 v[R];
 #pragma unroll
@@ -92,9 +92,12 @@ int main(int argc, char** argv) {
       std::vector<void*> ins((size_t)ns), outs((size_t)ns);
       for (int q = 0; q < ns; ++q) { CHECK(hipMalloc(&ins[(size_t)q], row_bytes * 35)); CHECK(hipMemset(ins[(size_t)q], 0x21, row_bytes * 35)); CHECK(hipMalloc(&outs[(size_t)q], row_bytes * 35)); }
       for (int nt = 0; nt < 2; ++nt) {
-        const dim3 grid((unsigned int)((row_vec + 255) / 256));
-        auto go = [&](int i) { if (nt) hipLaunchKernelGGL((rows_kernel<35, 35, true>), grid, dim3(256), 0, st, (const u32x4*)ins[(size_t)(i % ns)], (u32x4*)outs[(size_t)(i % ns)], row_vec);
-                               else hipLaunchKernelGGL((rows_kernel<35, 35, false>), grid, dim3(256), 0, st, (const u32x4*)ins[(size_t)(i % ns)], (u32x4*)outs[(size_t)(i % ns)], row_vec); };
+        static const int bs = []() { const char* e = getenv("ROWS_BLOCK"); return e ? atoi(e) : 256; }();      // experiment: threads per workgroup (64 / 256 / 1024)
+        const dim3 grid((unsigned int)((row_vec + bs - 1) / bs));
+        auto go = [&](int i) { const u32x4* a_ = (const u32x4*)ins[(size_t)(i % ns)]; u32x4* o_ = (u32x4*)outs[(size_t)(i % ns)];
+          if (bs == 1024) { if (nt) hipLaunchKernelGGL((rows_kernel<35, 35, true, 1024>), grid, dim3(1024), 0, st, a_, o_, row_vec); else hipLaunchKernelGGL((rows_kernel<35, 35, false, 1024>), grid, dim3(1024), 0, st, a_, o_, row_vec); }
+          else if (bs == 64) { if (nt) hipLaunchKernelGGL((rows_kernel<35, 35, true, 64>), grid, dim3(64), 0, st, a_, o_, row_vec); else hipLaunchKernelGGL((rows_kernel<35, 35, false, 64>), grid, dim3(64), 0, st, a_, o_, row_vec); }
+          else { if (nt) hipLaunchKernelGGL((rows_kernel<35, 35, true>), grid, dim3(256), 0, st, a_, o_, row_vec); else hipLaunchKernelGGL((rows_kernel<35, 35, false>), grid, dim3(256), 0, st, a_, o_, row_vec); } };
         for (int i = 0; i < 2 * ns; ++i) go(i);
         CHECK(hipStreamSynchronize(st));
         const int reps = std::max(3 * ns, (int)(0.05 / (set_bytes / 5e12)));
