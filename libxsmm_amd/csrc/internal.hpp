@@ -104,6 +104,7 @@ struct MeltwArgs {
   void* ws; size_t ws_bytes;                          // device workspace for two-pass kernels (may be NULL)
   unsigned int flags;
   int type, operation;
+  int nt;                                             // round 6: the launch's operands cannot be cache resident (footprint, streaming hint): non-temporal loads and stores in the streaming kernels
 };
 
 // sparse operator S (rows x inner) applied to a packed panel:

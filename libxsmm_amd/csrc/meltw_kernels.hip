@@ -308,102 +308,125 @@ __device__ __forceinline__ unsigned int mw_f2bf_pk(float lo, float hi) {
   const mwf32x2 v = {mw_daz(lo), mw_daz(hi)};
   return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, mwbf16x2));
 }
-__device__ __forceinline__ void ew8_load(float (&x)[8], gcptr base, int type, int kind, long long i, long long j, long long ld) {
+// NT (round 6): non-temporal policy for launches whose operands cannot be cache resident (MeltwArgs::nt) -- a bare copy of this footprint gains 7-10 % from it
+// (tools/copy_floor.hip: 0.72 -> 0.80 of 8 TB/s)
+template <bool NT, typename V> __device__ __forceinline__ V ld_pol(GM const V* p) { if (NT) return __builtin_nontemporal_load(p); else return *p; }
+template <bool NT, typename V> __device__ __forceinline__ void st_pol(GM V* p, V v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+template <bool NT = false, int E = 8>      // E = 4: all operands f32, ONE 16-byte access per lane (a wave covers 1 KiB without gaps)
+__device__ __forceinline__ void ew8_load(float (&x)[E], gcptr base, int type, int kind, long long i, long long j, long long ld) {
   if (kind == BC_ROW || kind == BC_SCALAR) {
     const float v = mw_load(base, kind == BC_ROW ? j * ld : 0, type);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = v;
+    for (int e = 0; e < E; ++e) x[e] = v;
     return;
   }
   const long long idx = (kind == BC_COL) ? i : i + j * ld;
+  if constexpr (E == 4) {
+    const f32x4 a = ld_pol<NT>((GM const f32x4*)((GM const float*)base + idx));
+    x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
+  } else
   if (type == LIBXSMM_DATATYPE_F32) {
-    const f32x4 a = *(GM const f32x4*)((GM const float*)base + idx), b = *(GM const f32x4*)((GM const float*)base + idx + 4);
+    const f32x4 a = ld_pol<NT>((GM const f32x4*)((GM const float*)base + idx)), b = ld_pol<NT>((GM const f32x4*)((GM const float*)base + idx + 4));
     x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3]; x[4] = b[0]; x[5] = b[1]; x[6] = b[2]; x[7] = b[3];
   } else {
-    const u32x4e v = *(GM const u32x4e*)((GM const unsigned short*)base + idx);
+    const u32x4e v = ld_pol<NT>((GM const u32x4e*)((GM const unsigned short*)base + idx));
 #pragma unroll
     for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(v[e] << 16); x[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
   }
 }
-__device__ __forceinline__ void ew8_store(gptr base, int type, long long idx, const float (&y)[8]) {
+template <bool NT = false, int E = 8>
+__device__ __forceinline__ void ew8_store(gptr base, int type, long long idx, const float (&y)[E]) {
+  if constexpr (E == 4) {
+    f32x4 a; a[0] = y[0]; a[1] = y[1]; a[2] = y[2]; a[3] = y[3];
+    st_pol<NT>((GM f32x4*)((GM float*)base + idx), a);
+  } else
   if (type == LIBXSMM_DATATYPE_F32) {
     f32x4 a, b; a[0] = y[0]; a[1] = y[1]; a[2] = y[2]; a[3] = y[3]; b[0] = y[4]; b[1] = y[5]; b[2] = y[6]; b[3] = y[7];
-    *(GM f32x4*)((GM float*)base + idx) = a; *(GM f32x4*)((GM float*)base + idx + 4) = b;
+    st_pol<NT>((GM f32x4*)((GM float*)base + idx), a); st_pol<NT>((GM f32x4*)((GM float*)base + idx + 4), b);
   } else {
     u32x4e v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = mw_f2bf_pk(y[2 * e], y[2 * e + 1]);
-    *(GM u32x4e*)((GM unsigned short*)base + idx) = v;
+    st_pol<NT>((GM u32x4e*)((GM unsigned short*)base + idx), v);
   }
 }
 // Round 4, measured and NOT adopted (4096 x 8192 f32 copy 0.66, bf16 ReLU tiles 0.77 with this kernel): (a) four chunks per thread a grid apart with all loads
 // issued first, 16 bytes per lane for f32-only TPPs (whole-line accesses instead of two half-line ones): 0.60 / 0.70 -- fewer, longer-lived waves lose, as in the
 // ragged GEMM kernels (DESIGN decision 11); (b) the f32 transpose as 4 x 4 register blocks with 16-byte LDS traffic only (8 LDS instructions per thread instead
 // of 32): 0.595 against 0.604 -- LDS is not what holds the transposes at 0.9 of the copy's rate.
-template <int NIN>
+template <int NIN, bool NT = false, int E = 8>
 __global__ __launch_bounds__(256) void meltw_ew8_kernel(MeltwArgs p, unsigned int m8, unsigned int total) {
   const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
   if (gid >= total) return;
   const unsigned int i8 = gid % m8, t = gid / m8, j = t % (unsigned int)p.n, bidx = t / (unsigned int)p.n;
-  const long long i = 8ll * i8;
+  const long long i = (long long)E * i8;
   gptr out = (gptr)p.out + (long long)bidx * p.bs_out;
   const long long oidx = i + (long long)j * p.ldo;
-  float x0[8], x1[8], x2[8], y[8];
-  ew8_load(x0, (gcptr)p.in0 + (long long)bidx * p.bs_in0, p.in0_type, bcast_kind(p.operation, p.type, p.flags, 0), i, j, p.ldi);
-  if (NIN >= 2) ew8_load(x1, (gcptr)p.in1 + (long long)bidx * p.bs_in1, p.in1_type, bcast_kind(p.operation, p.type, p.flags, 1), i, j, p.ldi1);
-  if (NIN >= 3) ew8_load(x2, (gcptr)p.in2 + (long long)bidx * p.bs_in2, p.in2_type, bcast_kind(p.operation, p.type, p.flags, 2), i, j, p.ldi2);
+  float x0[E], x1[E], x2[E], y[E];
+  ew8_load<NT, E>(x0, (gcptr)p.in0 + (long long)bidx * p.bs_in0, p.in0_type, bcast_kind(p.operation, p.type, p.flags, 0), i, j, p.ldi);
+  if (NIN >= 2) ew8_load<NT, E>(x1, (gcptr)p.in1 + (long long)bidx * p.bs_in1, p.in1_type, bcast_kind(p.operation, p.type, p.flags, 1), i, j, p.ldi1);
+  if (NIN >= 3) ew8_load<NT, E>(x2, (gcptr)p.in2 + (long long)bidx * p.bs_in2, p.in2_type, bcast_kind(p.operation, p.type, p.flags, 2), i, j, p.ldi2);
   if (NIN == 1) {
     if (p.type == LIBXSMM_MELTW_TYPE_UNARY_IDENTITY) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = x0[e];
+      for (int e = 0; e < E; ++e) y[e] = x0[e];
     } else if (p.type == LIBXSMM_MELTW_TYPE_UNARY_RELU) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = (x0[e] <= 0.0f) ? 0.0f : x0[e];
+      for (int e = 0; e < E; ++e) y[e] = (x0[e] <= 0.0f) ? 0.0f : x0[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = unary_math(p.type, x0[e], p.scalar_f32);
+      for (int e = 0; e < E; ++e) y[e] = unary_math(p.type, x0[e], p.scalar_f32);
     }
   } else if (NIN == 2) {
     if (p.type == LIBXSMM_MELTW_TYPE_BINARY_ADD) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = x0[e] + x1[e];
+      for (int e = 0; e < E; ++e) y[e] = x0[e] + x1[e];
     } else if (p.type == LIBXSMM_MELTW_TYPE_BINARY_MUL) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = x0[e] * x1[e];
+      for (int e = 0; e < E; ++e) y[e] = x0[e] * x1[e];
     } else {
-      float prev[8];
-      if (p.type == LIBXSMM_MELTW_TYPE_BINARY_MULADD) ew8_load(prev, (gcptr)out, p.out_type, BC_NONE, i, j, p.ldo);
+      float prev[E];
+      if (p.type == LIBXSMM_MELTW_TYPE_BINARY_MULADD) ew8_load<false, E>(prev, (gcptr)out, p.out_type, BC_NONE, i, j, p.ldo);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = binary_math(p.type, x0[e], x1[e], p.type == LIBXSMM_MELTW_TYPE_BINARY_MULADD ? prev[e] : 0.0f);
+      for (int e = 0; e < E; ++e) y[e] = binary_math(p.type, x0[e], x1[e], p.type == LIBXSMM_MELTW_TYPE_BINARY_MULADD ? prev[e] : 0.0f);
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < E; ++e) {
       const float prod = (p.type == LIBXSMM_MELTW_TYPE_TERNARY_MULADD) ? x0[e] * x1[e] : x0[e] * x2[e];
       y[e] = (p.type == LIBXSMM_MELTW_TYPE_TERNARY_MULADD) ? x2[e] + prod : x1[e] - prod;
     }
   }
-  ew8_store(out, p.out_type, oidx, y);
+  ew8_store<NT, E>(out, p.out_type, oidx, y);
 }
 
 static bool is_float_type(int t) { return t == LIBXSMM_DATATYPE_F32 || t == LIBXSMM_DATATYPE_BF16; }      // the types the vector kernels know
 // ... and the ones the general kernels convert element by element [ref: mateltwise ref :262-324: F16, BF8, HF8 in and out]
 static bool is_tpp_float(int t) { return is_float_type(t) || t == LIBXSMM_DATATYPE_F16 || t == LIBXSMM_DATATYPE_BF8 || t == LIBXSMM_DATATYPE_HF8; }
+// elements per thread of meltw_ew8_kernel: eight (16 bytes of bf16); FOUR when every operand and the result are f32 -- eight f32 are two 16-byte accesses 32 bytes apart
+// per lane, each instruction then touches every other 16 bytes of a 2 KiB span (round 6: f32 copy 0.665 -> see DESIGN)
+static int ew_elems(const MeltwArgs& a) {
+  const int nin = a.operation == LIBXSMM_MELTW_OPERATION_UNARY ? 1 : a.operation == LIBXSMM_MELTW_OPERATION_BINARY ? 2 : 3;
+  const int types[3] = {a.in0_type, a.in1_type, a.in2_type};
+  bool f32 = a.out_type == LIBXSMM_DATATYPE_F32;
+  for (int o = 0; o < nin; ++o) f32 = f32 && types[o] == LIBXSMM_DATATYPE_F32;
+  return f32 ? 4 : 8;
+}
 // is this TPP eligible for meltw_ew8_kernel?
 static bool ew8_ok(const MeltwArgs& a) {
-  constexpr bool off = false;
-  if (off || a.m % 8 != 0 || a.ldo % 8 != 0) return false;
   const int nin = a.operation == LIBXSMM_MELTW_OPERATION_UNARY ? 1 : a.operation == LIBXSMM_MELTW_OPERATION_BINARY ? 2 : 3;
+  const int g = ew_elems(a);                 // elements per thread: 4 when every operand is f32, else 8
+  if (a.m % g != 0 || a.ldo % g != 0) return false;
   if (!is_float_type(a.out_type) || ((size_t)a.out % 16) || ((size_t)a.bs_out % 16)) return false;
   const void* ptrs[3] = {a.in0, a.in1, a.in2}; const long long lds[3] = {a.ldi, a.ldi1, a.ldi2}; const long long bss[3] = {a.bs_in0, a.bs_in1, a.bs_in2};
   const int types[3] = {a.in0_type, a.in1_type, a.in2_type};
   for (int o = 0; o < nin; ++o) {
     if (!is_float_type(types[o])) return false;
     const int k = bcast_kind(a.operation, a.type, a.flags, o);
-    if (k == BC_NONE && lds[o] % 8 != 0) return false;
+    if (k == BC_NONE && lds[o] % g != 0) return false;
     if ((k == BC_NONE || k == BC_COL) && (((size_t)ptrs[o] % 16) || ((size_t)bss[o] % 16))) return false;
   }
-  if ((long long)(a.m / 8) * a.n * (long long)a.nbatch >= (1ll << 32) - 256) return false;
+  if ((long long)(a.m / g) * a.n * (long long)a.nbatch >= (1ll << 32) - 256) return false;
   if (nin == 1) {
     switch (a.type) {   // arithmetic TPPs without side channels
       case LIBXSMM_MELTW_TYPE_UNARY_IDENTITY: case LIBXSMM_MELTW_TYPE_UNARY_XOR: case LIBXSMM_MELTW_TYPE_UNARY_X2: case LIBXSMM_MELTW_TYPE_UNARY_SQRT:
@@ -541,7 +564,8 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(MeltwArgs p, unsigne
   for (int q = 0; q < 64 * VPR / 256; ++q) {
     const int v = threadIdx.x + 256 * q, cc = v / VPR, rr = (v % VPR) * VEC;
     if (r0 + rr < p.m && c0 + cc < p.n) {
-      const vec_t x = *(GM const vec_t*)(in + (long long)(c0 + cc) * p.ldi + r0 + rr);
+      GM const vec_t* src = (GM const vec_t*)(in + (long long)(c0 + cc) * p.ldi + r0 + rr);
+      const vec_t x = p.nt ? __builtin_nontemporal_load(src) : *src;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) tile[cc * PITCH + rr + e] = x[e];
     }
@@ -554,7 +578,8 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(MeltwArgs p, unsigne
       vec_t y;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) y[e] = tile[(cc + e) * PITCH + rr];
-      *(GM vec_t*)(out + (long long)(r0 + rr) * p.ldo + c0 + cc) = y;
+      GM vec_t* dst = (GM vec_t*)(out + (long long)(r0 + rr) * p.ldo + c0 + cc);
+      if (p.nt) __builtin_nontemporal_store(y, dst); else *dst = y;
     }
   }
 }
@@ -562,25 +587,34 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(MeltwArgs p, unsigne
 // NORM -> VNNI2 of 16-bit payloads without LDS: a thread reads 8 consecutive i of rows 2jp and 2jp+1 (16 bytes each)
 // and writes the 8 interleaved pairs (32 contiguous bytes); i in [m, ldo) and the odd-n pad row are zero filled as the
 // reference does [ref: mateltwise ref :532-557].  Needs m, ldi, ldo multiples of 8 and 16-byte aligned bases.
+template <int E>      // E positions i per thread: 8 (two 16-byte loads, 32 bytes out) or 4 (round 6: two 8-byte loads, ONE 16-byte store -- a wave's stores are 1 KiB without gaps)
 __global__ __launch_bounds__(256) void vnni2_vec_kernel(MeltwArgs p, unsigned int o8, unsigned int total) {
-  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned short u16xE __attribute__((ext_vector_type(E)));
+  typedef unsigned int u32xH __attribute__((ext_vector_type(E / 2)));
   const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
   if (gid >= total) return;
   const unsigned int np = (unsigned int)(p.n + 1) / 2u;
   const unsigned int i8 = gid % o8, t = gid / o8, jp = t % np, bidx = t / np;
   GM const unsigned short* in = (GM const unsigned short*)((gcptr)p.in0 + (long long)bidx * p.bs_in0);
   GM unsigned int* out = (GM unsigned int*)((gptr)p.out + (long long)bidx * p.bs_out);
-  const long long i = 8ll * i8;
-  u16x8 a = (u16x8)(unsigned short)0, b = (u16x8)(unsigned short)0;
+  const long long i = (long long)E * i8;
+  u16xE a = (u16xE)(unsigned short)0, b = (u16xE)(unsigned short)0;
   if (i < p.m) {
-    a = *(GM const u16x8*)(in + (long long)(2 * jp) * p.ldi + i);
-    if ((int)(2 * jp + 1) < p.n) b = *(GM const u16x8*)(in + (long long)(2 * jp + 1) * p.ldi + i);
+    GM const u16xE* pa = (GM const u16xE*)(in + (long long)(2 * jp) * p.ldi + i);
+    a = p.nt ? __builtin_nontemporal_load(pa) : *pa;
+    if ((int)(2 * jp + 1) < p.n) { GM const u16xE* pb = (GM const u16xE*)(in + (long long)(2 * jp + 1) * p.ldi + i); b = p.nt ? __builtin_nontemporal_load(pb) : *pb; }
   }
-  u32x4e lo, hi;
+  u32xH lo, hi;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { lo[e] = (unsigned int)a[e] | ((unsigned int)b[e] << 16); hi[e] = (unsigned int)a[4 + e] | ((unsigned int)b[4 + e] << 16); }
+  for (int e = 0; e < E / 2; ++e) { lo[e] = (unsigned int)a[e] | ((unsigned int)b[e] << 16); hi[e] = (unsigned int)a[E / 2 + e] | ((unsigned int)b[E / 2 + e] << 16); }
   GM unsigned int* dst = out + (long long)jp * p.ldo + i;
-  *(GM u32x4e*)dst = lo; *(GM u32x4e*)(dst + 4) = hi;
+  if constexpr (E == 4) {
+    u32x4e v; v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    if (p.nt) __builtin_nontemporal_store(v, (GM u32x4e*)dst); else *(GM u32x4e*)dst = v;
+  } else {
+    if (p.nt) { __builtin_nontemporal_store(lo, (GM u32xH*)dst); __builtin_nontemporal_store(hi, (GM u32xH*)(dst + E / 2)); }
+    else { *(GM u32xH*)dst = lo; *(GM u32xH*)(dst + E / 2) = hi; }
+  }
 }
 
 // NORM -> VNNI4 of 8-bit payloads without LDS (the producer side of the 8-bit GEMMs / BCSC): a thread reads 4 consecutive i of the four
@@ -1671,11 +1705,16 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
     return (int)hipGetLastError();
   }
   if (ew8_ok(a)) {
-    const unsigned int m8 = (unsigned int)(a.m / 8), total = m8 * (unsigned int)a.n * (unsigned int)a.nbatch;
+    const int g = ew_elems(a);
+    const unsigned int m8 = (unsigned int)(a.m / g), total = m8 * (unsigned int)a.n * (unsigned int)a.nbatch;
     const dim3 grid((total + 255u) / 256u);
-    if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY) hipLaunchKernelGGL((meltw_ew8_kernel<1>), grid, dim3(256), 0, st, a, m8, total);
-    else if (a.operation == LIBXSMM_MELTW_OPERATION_BINARY) hipLaunchKernelGGL((meltw_ew8_kernel<2>), grid, dim3(256), 0, st, a, m8, total);
-    else hipLaunchKernelGGL((meltw_ew8_kernel<3>), grid, dim3(256), 0, st, a, m8, total);
+#define EW_(N_, T_, E_) hipLaunchKernelGGL((meltw_ew8_kernel<N_, T_, E_>), grid, dim3(256), 0, st, a, m8, total)
+#define EWN_(T_, E_) do { if (a.operation == LIBXSMM_MELTW_OPERATION_UNARY) EW_(1, T_, E_); else if (a.operation == LIBXSMM_MELTW_OPERATION_BINARY) EW_(2, T_, E_); else EW_(3, T_, E_); } while (0)
+    // (non-temporal: f32 copy 4096 x 8192 0.715 -> 0.75; the bf16 tile streams of config #5 lose 1 % with it and stay cacheable -- profiles/r06_tpp_nt.jsonl)
+    if (g == 4) { if (a.nt) EWN_(true, 4); else EWN_(false, 4); }
+    else EWN_(false, 8);
+#undef EWN_
+#undef EW_
     if (name) *name = "meltw_ew8_kernel";
     return (int)hipGetLastError();
   }
@@ -1738,10 +1777,12 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
       const unsigned int tm = (unsigned int)((a.m + 63) / 64), tn = (unsigned int)((a.n + 63) / 64);
       LAUNCH_BY_SIZE(transpose_vec_kernel, sz, dim3(tm * tn * (unsigned int)a.nbatch), dim3(256), st, a, tm, tn);
       if (name) *name = "transpose_vec_kernel";
-    } else if (mode == XF_NORM_TO_VNNI && v == 2 && sz == 2 && !xvec_off && base16 && a.m % 8 == 0 && a.ldi % 8 == 0 && a.ldo % 8 == 0 &&
-               (long long)(a.ldo / 8) * ((a.n + 1) / 2) * a.nbatch < (1ll << 32) - 256) {
-      const unsigned int o8 = (unsigned int)(a.ldo / 8), total = o8 * (unsigned int)((a.n + 1) / 2) * (unsigned int)a.nbatch;
-      hipLaunchKernelGGL(vnni2_vec_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, a, o8, total);
+    } else if (mode == XF_NORM_TO_VNNI && v == 2 && sz == 2 && !xvec_off && base16 && a.m % 4 == 0 && a.ldi % 4 == 0 && a.ldo % 4 == 0 &&
+               (long long)(a.ldo / 4) * ((a.n + 1) / 2) * a.nbatch < (1ll << 32) - 256) {
+      // four positions per thread (8-byte loads, one 16-byte store); the eight-position form stays for what is not 8-byte granular on the input side -- nothing: ldi % 4 == 0
+      // with a 16-byte aligned base makes every row start 8-byte aligned
+      const unsigned int o4 = (unsigned int)(a.ldo / 4), total = o4 * (unsigned int)((a.n + 1) / 2) * (unsigned int)a.nbatch;
+      hipLaunchKernelGGL((vnni2_vec_kernel<4>), dim3((total + 255u) / 256u), dim3(256), 0, st, a, o4, total);
       if (name) *name = "vnni2_vec_kernel";
     } else if (mode == XF_NORM_TO_VNNI && v == 2 && sz == 2 && !xvec_off && (((size_t)a.out | (size_t)a.bs_out) % 4) == 0 && (long long)a.ldo * ((a.n + 1) / 2) < (1ll << 31) && a.nbatch < 65536) {
       constexpr bool quad_off = false;

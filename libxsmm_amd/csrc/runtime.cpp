@@ -906,6 +906,12 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
       if (!a.in0 || !a.out) return;
     }
   }
+  {  // cache policy of the streaming TPP kernels (as stream_nt does for the GEMMs): the caller's hint, else by the bytes one launch moves against the Infinity Cache
+    const int hint = tls().stream_hint;
+    const unsigned long long elems = (unsigned long long)std::max(a.m, 0) * (unsigned long long)std::max(a.n, 0) * (unsigned long long)std::max<size_t>(b.count, 1);
+    const unsigned long long bytes = elems * (unsigned long long)(typesize(a.in0_type) + typesize(a.out_type));
+    a.nt = hint == 2 || (hint == 0 && bytes >= (256ull << 20)) ? 1 : 0;
+  }
   const char* kname = nullptr;
   const bool stoch = a.out_type == LIBXSMM_DATATYPE_BF8 &&
     ((d.operation == LIBXSMM_MELTW_OPERATION_UNARY && (d.flags & LIBXSMM_MELTW_FLAG_UNARY_STOCHASTIC_ROUND)) ||
