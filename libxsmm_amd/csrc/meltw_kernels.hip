@@ -547,6 +547,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(MeltwArgs p) {
   }
 }
 
+// (Round 6, measured and not adopted: 128 x 128 tiles -- 512-byte instead of 256-byte pieces per request, 65 KiB of LDS, two workgroups per CU: f32 4096 x 8192 0.615 -> 0.537;
+//  padded leading dimensions change nothing either: the transposes are not held back by channel aliasing, profiles/r06_transpose_pitch.jsonl)
 // Vector form of the transpose: 64x64 tiles, 16-byte global accesses on both sides (VEC = 16/S elements per thread
 // access), the element shuffle happens in LDS (row pitch padded by one dword).  Needs m, n, ldi, ldo multiples of VEC
 // and 16-byte aligned bases; tiles at the matrix edge are guarded per vector.
