@@ -1119,7 +1119,7 @@ void run_bcsc(KernelCtx* k, const void* param) {
       k->bcsc_last.store(hit, std::memory_order_release);
     }
     unsigned int* blockp = hit->d_block;
-    a.colptr = blockp; a.rowidx = blockp + n_ptr; a.table = blockp + n_ptr + n_idx; a.table_ready = 1;
+    a.colptr = blockp; a.rowidx = blockp + n_ptr; a.table = blockp + n_ptr + n_idx; a.table_ready = 1; a.nnzb = (int)nnzb;
   } else {
   a.colptr = (const unsigned int*)device_visible(p->b.secondary, (size_t)(nblk_n + 1) * sizeof(unsigned int));
   if (!a.colptr) { set_error(-2, "BCSC kernel needs colptr in b.secondary"); return; }

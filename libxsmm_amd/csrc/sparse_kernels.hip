@@ -816,7 +816,8 @@ __global__ __launch_bounds__(256) void bcsc_mfma_bf16_dma_kernel(BcscArgs p, uns
 // F32 (round 3): the same kernel on f32 operands.  A chunk is then 16 k (not 16 k-PAIRS) of the wave's rows -- the LDS image, its rotation and the
 // operand reads are word for word the bf16 ones, a row of the image is one k instead of a VNNI pair --, a B fragment is four consecutive k of a column
 // (again one 16-byte load) and a chunk is four v_mfma_f32_16x16x4_f32 per (n-tile, i-tile), k = 4 kg + e in step e as in bcsc_mfma_f32_kernel.
-template <int BN16, int AUX_A = 0, int RT = 4, int WPS = 2, bool F32 = false>     // RT: 16-row tiles per wave (4: 64 rows, 2: 32 rows -> half the accumulators, more waves per SIMD)
+constexpr int kBcscBLds = 10240;     // bytes of LDS for a copy of the whole B value array (BL): 2 : 8 of 256 x 64 in bf16 is 8 KiB
+template <int BN16, int AUX_A = 0, int RT = 4, int WPS = 2, bool F32 = false, bool BL = false>     // RT: 16-row tiles per wave (4: 64 rows, 2: 32 rows -> half the accumulators, more waves per SIMD)
 __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
   // D: depth of the B-fragment REGISTER ring (the chunk being consumed + one behind it); DA: depth of the A ring in LDS.  Round 6: DA = 3 -- the A chunks (HBM) run one
   // chunk further ahead than the B fragments (L2), 8 KiB instead of 4 KiB of A in flight per wave behind the chunk being consumed, with the register budget unchanged
@@ -826,8 +827,14 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
   __shared__ unsigned int klist_all[4][64];
   __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][DA][16 * W];
   __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][F32 ? 4 : 1024];       // 32 columns x 128 bytes: bf16 C leaves in two halves
+  __shared__ __attribute__((aligned(16))) unsigned int bimg[BL ? kBcscBLds / 4 : 4];       // BL: the whole bf16 value array of B, read by every wave of the workgroup
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int wid = blockIdx.x * 4u + wave;
+  if constexpr (BL) {          // every wave of the workgroup helps to bring B in and meets the others before any of them leaves
+    const unsigned int pieces = (unsigned int)p.nnzb * (unsigned int)(p.bn * p.bk) / 8u;        // 16-byte pieces of the bf16 value array
+    for (unsigned int e = threadIdx.x; e < pieces; e += 256u) ((u32x4v*)bimg)[e] = ((GM const u32x4v*)p.bvals)[e];
+    __syncthreads();
+  }
   if (wid >= total_waves) return;
   unsigned int* tbl = tbl_all[wave];
   unsigned int* klist = klist_all[wave];
@@ -954,9 +961,9 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
   };
   // prologue, in the steady state's order: A(0) | B(0) A(1) | B(1) A(2)
   if (total_f > 0) issue_a(std::integral_constant<int, 0>{});
-  if (total_f > 0) issue_b(std::integral_constant<int, 0>{});
+  if (!BL && total_f > 0) issue_b(std::integral_constant<int, 0>{});
   if (total_f > 1) issue_a(std::integral_constant<int, 1>{});
-  if (total_f > 1) issue_b(std::integral_constant<int, 1>{});
+  if (!BL && total_f > 1) issue_b(std::integral_constant<int, 1>{});
   if (total_f > 2) issue_a(std::integral_constant<int, 2>{});
   int cj = 0, cc = 0;                               // the chunk being consumed
   for (int f0 = 0; f0 < total_f; f0 += 6) {
@@ -972,10 +979,13 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
         constexpr int NS = (RT == 4) ? 8 : 4;           // stores of one tile's LDS epilogue
         // (the 16 direct stores of an f32 tile are NOT counted: the wait is then stricter than needed -- measured equal on config #4's shape in f32 -- and does not
         // depend on how stores retire relative to the loads around them)
+        // BL: no B requests -- the chunk's own A request is what is waited for (A(f+1), A(f+2) behind it), and a tile's stores are younger than it for the first THREE chunks
+        // of the next tile (A(f) was issued three chunks earlier, in front of the stores at the end of chunk f - 3)
+        constexpr int PB = BL ? 0 : 4;
         const int left = total_f - 1 - f;
-        const bool stored = lds_store && cj > 0 && cc < 2;
-        if (left >= 2) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + 2 * NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + 2 * NI) : "memory"); }
-        else if (left == 1) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 + NI) : "memory"); }
+        const bool stored = lds_store && cj > 0 && cc < (BL ? 3 : 2);
+        if (left >= 2) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PB + 2 * NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PB + 2 * NI) : "memory"); }
+        else if (left == 1) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PB + NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PB + NI) : "memory"); }
         else if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         u32x4v a_cur[RT];
@@ -986,10 +996,23 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
             for (int e = 0; e < 4; ++e) a_cur[t][e] = abuf[ua][(4 * kg + e) * W + ((16 * t + lx + rot) & (W - 1))];
           }
         });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         unsigned int blk_c[NBL]; u32x4v bf_c[NBL][BN16];
-        sfor<NBL>([&](auto nc) { blk_c[nc.value] = blk_r[u][nc.value]; sfor<BN16>([&](auto sc) { bf_c[nc.value][sc.value] = bf_r[u][nc.value][sc.value]; }); });
-        if (f + 2 < total_f) issue_b(std::integral_constant<int, u>{});
+        if constexpr (BL) {          // the chunk's B fragments out of the LDS copy of the value array: chunk cc of a tile = 32-deep step cc % steps of the used k-block number cc / steps
+          const int q = cc / steps, st_ = cc - q * steps;
+          const int kb_ = __builtin_amdgcn_readfirstlane((int)klist[q]);
+          sfor<NBL>([&](auto nc) {
+            constexpr int nbl = nc.value;
+            blk_c[nbl] = (nbl < nbl_cnt) ? (unsigned int)__builtin_amdgcn_readfirstlane((int)tbl[nbl * nkb + kb_]) : 0xffffffffu;
+            sfor<BN16>([&](auto sc) { constexpr int s2 = sc.value;
+              const unsigned int b = blk_c[nbl] == 0xffffffffu ? 0u : blk_c[nbl];
+              bf_c[nbl][s2] = *(const u32x4v*)((const char*)bimg + ((b * (16u * BN16) + 16u * s2 + (unsigned int)lx) * (unsigned int)p.bk + 32u * (unsigned int)st_ + 8u * (unsigned int)kg) * 2u); });
+          });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!BL) {
+          sfor<NBL>([&](auto nc) { blk_c[nc.value] = blk_r[u][nc.value]; sfor<BN16>([&](auto sc) { bf_c[nc.value][sc.value] = bf_r[u][nc.value][sc.value]; }); });
+          if (f + 2 < total_f) issue_b(std::integral_constant<int, u>{});
+        }
         if (f + 3 < total_f) issue_a(std::integral_constant<int, ua>{});
         sfor<NBL>([&](auto nc) {
           constexpr int nbl = nc.value;
@@ -1210,7 +1233,12 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
             mbg = (a.m_blocks + per - 1) / per;
             const long long waves = mbg * tt_count;
             const dim3 sgrid((unsigned int)((waves + 3) / 4));
-#define LAUNCH_STREAM_(B_) do { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 2>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+            // one (i-tile, n-tile) per M-block and a value array that fits beside the rings: every workgroup keeps its own LDS copy of B and no wave asks the L2 for a
+            // fragment again (bn = 32: 39.5 -> 35.7 us on 8192 M-blocks of 64 x 256, bn = 16 unchanged; profiles/r06_bcsc_b_in_lds.jsonl)
+            const bool b_lds = tt_count == 1 && a.nnzb > 0 && (long long)a.nnzb * a.bn * a.bk * 2 <= kBcscBLds && ((size_t)a.bvals % 16 == 0);
+#define LAUNCH_STREAM_(B_) do { if (b_lds) { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 2, 4, 2, false, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+                                             else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 0, 4, 2, false, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } \
+                                else if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 2>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
                                 else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 0>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
             if (a.bn == 16) LAUNCH_STREAM_(1); else if (a.bn == 32) LAUNCH_STREAM_(2); else LAUNCH_STREAM_(4);
 #undef LAUNCH_STREAM_

@@ -7,6 +7,8 @@ from libxsmm_amd.capi import DT, UNARY  # noqa: F401
 api = capi.load(); dev = torch.device("cuda:0"); torch.cuda.set_device(0)
 api.hip_set_stream(torch.cuda.current_stream().cuda_stream)
 wl.set_device(dev); bp.DEV = dev
+if os.environ.get("HINT"):             # libxsmm_hip_set_streaming_hint of this thread (0 auto, 1 cache-resident, 2 read once from HBM)
+    api.hip_set_streaming_hint(int(os.environ["HINT"]))
 for expr in os.environ["WL"].split(";;"):
     w = eval(expr)
     for i in range(3):
