@@ -143,7 +143,7 @@ struct BcscArgs {
   int nt_a;                           // stream the A operand with non-temporal loads (set by launch_bcsc: launch larger than the Infinity Cache, or the caller's hint)
   int stream_hint;                    // libxsmm_hip_set_streaming_hint of the calling thread
   int table_ready;                    // the table already holds this call's inverted pattern (host-resident pattern, cached per kernel)
-  int nnzb;                           // number of blocks of B when the host knows it (host-resident or bound pattern), else -1: a B of a few KiB is kept in LDS by the streaming kernel (round 6)
+  int nnzb;                           // number of blocks of B when the host knows it (host-resident or bound pattern), else 0: a B of a few KiB is kept in LDS by the streaming kernel (round 6)
 };
 
 // ---- run-time specialised sparse kernels (jit.cpp) ------------------------------------------------------

@@ -953,7 +953,8 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
     constexpr int u = decltype(uc)::value;
     const int q = ac_ / steps, st_ = ac_ - q * steps;
     const int kb_ = __builtin_amdgcn_readfirstlane((int)klist[q]);
-    GM const unsigned int* rowbase = A2 + (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + ((long long)kb_ * (F32 ? p.bk : p.bk / 2) + 16 * st_) * p.M;
+    const unsigned int mb_a = g0 + (unsigned int)aj * mbg;
+    GM const unsigned int* rowbase = A2 + (long long)mb_a * a_mb_words + ((long long)kb_ * (F32 ? p.bk : p.bk / 2) + 16 * st_) * p.M;
 #pragma unroll
     for (int x = 0; x < NI; ++x)
       __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)((char*)abuf[u] + 1024 * x), 16, 0, AUX_A);
@@ -1037,6 +1038,220 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
         if (++cc == nch) { store_tile(g0 + (unsigned int)cj * mbg); cc = 0; ++cj; }
       }
     });
+  }
+}
+
+// The streaming kernel re-cut for the shape config #4 has: whole 64 x 64 tiles (M and N multiples of 64), bf16 C, the value array of B in LDS.  What bounded the
+// general kernel above was not its operand stream but the chain of dependent steps in front of every chunk -- two integer divisions, five table look-ups in LDS each
+// waited for, a branch around every MFMA for tiles that are not whole (tools: A served from cache it still took 38 of its 61 us, profiles/r06_bcsc_full.jsonl).  Here
+// a wave writes ONE 16-byte record per chunk of its pattern before the loop -- the chunk's offset inside an M-block of A and the LDS offsets of its (up to four) blocks
+// of B, 0xffff for an absent one -- and a chunk is: wait for its A; one batch of LDS reads (A fragments, B fragments, the next chunk's record, the offset of the chunk
+// to request) and one wait; four LDS-DMA requests into the slot just read; the MFMAs.  The ring slot is a run-time index, so the loop is not unrolled over slots.
+// The epilogue's LDS traffic is written as instructions: a ds_write / ds_read the compiler can see gets its s_waitcnt vmcnt(0) -- it cannot tell the C tile from
+// the ring the requests in flight write to -- which would wait for the next tile's first three chunks at every tile end.
+constexpr int kBcscRecs = 64;        // chunk records per wave
+template <int BN16, int AUX_A>
+__global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
+  constexpr int NBL = 4 / BN16, DA = 3, NI = 4, NS = 8;
+  __shared__ __attribute__((aligned(16))) unsigned int recs_all[4][kBcscRecs][4];
+  __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][DA][1024];
+  __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][1024];              // 32 columns x 128 bytes: C leaves in two halves
+  __shared__ __attribute__((aligned(16))) unsigned int bimg[kBcscBLds / 4];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = blockIdx.x * 4u + wave;
+  // Start-up in ONE round trip to the L2 before the first A request leaves: the table rows of this wave's columns and the workgroup's share of B are asked for
+  // together; the records are built from the table (exchanged through the idle C tile, not loaded a second time) and the first three chunks requested; only then is
+  // B written to LDS and the workgroup's barrier passed -- waves beyond the last one take part in the copy and leave after the barrier.
+  const int lane = threadIdx.x & 63, lx = lane & 15, kg = lane >> 4;
+  const bool live = wid < total_waves;
+  unsigned int (*recs)[4] = recs_all[wave];
+  unsigned int* abuf = abuf_all[wave][0];
+  unsigned int* tile = ctile_all[wave];
+  unsigned int tile_lds = (unsigned int)(unsigned long long)(lds_ptr_t)tile;
+  const unsigned int tt_count = tiles_i * tiles_n, tt = live ? wid % tt_count : 0u, g0 = live ? wid / tt_count : 0u;
+  const unsigned int tn = tt % tiles_n, ti = tt / tiles_n;
+  const int i0 = (int)ti * 64, n0 = (int)tn * 64;
+  const int nb0 = n0 / (16 * BN16);
+  const int nkb = p.K / p.bk, steps = p.bk / 32;
+  GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb;
+  unsigned int trow[NBL];
+#pragma unroll
+  for (int nbl = 0; nbl < NBL; ++nbl) trow[nbl] = (lane < nkb) ? gt[nbl * nkb + lane] : 0xffffffffu;
+  constexpr int BP = kBcscBLds / 16 / 256 + 1;          // 16-byte pieces of B per thread
+  const unsigned int pieces = (unsigned int)p.nnzb * (unsigned int)(p.bn * p.bk) / 8u;
+  u32x4v bpiece[BP];
+#pragma unroll
+  for (int e = 0; e < BP; ++e) { const unsigned int x = threadIdx.x + 256u * e; bpiece[e] = ((GM const u32x4v*)p.bvals)[x < pieces ? x : 0u]; }
+  bool used = false;
+#pragma unroll
+  for (int nbl = 0; nbl < NBL; ++nbl) { used = used || (trow[nbl] != 0xffffffffu); tile[64 * (nbl + 1) + lane] = trow[nbl]; }
+  const unsigned long long mask = __ballot(used);
+  if (used) tile[__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (unsigned int)lane;
+  const int nch = __builtin_popcountll(mask) * steps;
+  if (lane < nch) {
+    const int q = lane / steps, st_ = lane - q * steps;
+    const unsigned int kb = tile[q];
+    unsigned int bo[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+#pragma unroll
+    for (int nbl = 0; nbl < NBL; ++nbl) {
+      const unsigned int blk = tile[64 * (nbl + 1) + (int)kb];
+      if (blk != 0xffffffffu) bo[nbl] = (blk * (unsigned int)(16 * BN16) * (unsigned int)p.bk + 32u * (unsigned int)st_) * 2u;
+    }
+    u32x4v r; r[0] = (kb * (unsigned int)(p.bk / 2) + 16u * (unsigned int)st_) * (unsigned int)p.M; r[1] = bo[0] | (bo[1] << 16); r[2] = bo[2] | (bo[3] << 16); r[3] = 0u;
+    *(u32x4v*)recs[lane] = r;
+  }
+  const int nmb = (live && (unsigned int)p.m_blocks > g0) ? (int)(((unsigned int)p.m_blocks - g0 + mbg - 1u) / mbg) : 0;
+  const long long c_mb_bytes = (long long)p.N * p.M * 2;
+  f32x4v acc[4][4];
+  sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
+  auto store_tile = [&](unsigned int mb) __attribute__((always_inline)) {        // C of M-block mb leaves; the accumulators restart at zero
+    GM char* cbase = (GM char*)p.c + (long long)mb * c_mb_bytes;
+    sfor<2>([&](auto hc) {
+      constexpr int h = hc.value;
+      sfor<8>([&](auto ic) {
+        constexpr int nt = 2 * h + ic.value / 4, it = ic.value % 4;
+        const int n = 16 * (nt - 2 * h) + lx;
+        const float x4[4] = {acc[nt][it][0], acc[nt][it][1], acc[nt][it][2], acc[nt][it][3]};
+        unsigned int o2[2];
+        bf16_pk_exact_n<2>(x4, o2);
+        u32x2v v; v[0] = o2[0]; v[1] = o2[1];
+        const unsigned int wad = tile_lds + 4u * (unsigned int)(n * 32 + 2 * ((4 * it + kg) ^ (n & 15)));
+        asm volatile("ds_write_b64 %0, %1" :: "v"(wad), "v"(v) : "memory");
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      u32x4v w4[4]; unsigned int ad[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int n = 8 * r + (lane >> 3), j = lane & 7, x = n & 15; ad[r] = tile_lds + 4u * (unsigned int)(n * 32 + 4 * (j ^ (x >> 1))); }
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(w4[0]), "=&v"(w4[1]), "=&v"(w4[2]), "=&v"(w4[3]) : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]) : "memory");
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 8 * r + (lane >> 3), j = lane & 7, x = n & 15;
+        u32x4v w = w4[r];
+        if (x & 1) { const unsigned int t0 = w[0], t1 = w[1]; w[0] = w[2]; w[1] = w[3]; w[2] = t0; w[3] = t1; }
+        GM u32x4v* dst = (GM u32x4v*)(cbase + ((long long)(n0 + 32 * h + n) * p.M + i0) * 2 + 16 * j);
+        if (AUX_A != 0) __builtin_nontemporal_store(w, dst); else *dst = w;
+      }
+    });
+    sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
+  };
+  // DMA source of LDS slot (lane + 64 x): row kp_l = slot >> 4, the 16-byte group that lands there = (slot & 15) rotated back
+  GM const unsigned int* A2 = (GM const unsigned int*)p.a + i0;
+  const long long a_mb_words = (long long)(p.K / 2) * p.M;
+  unsigned int src_off[NI];
+#pragma unroll
+  for (int x = 0; x < NI; ++x) {
+    const unsigned int S = (unsigned int)lane + 64u * x, kp_l = S >> 4, g = ((S & 15u) - 4u * ((kp_l >> 2) & 1u)) & 15u;
+    src_off[x] = kp_l * (unsigned int)p.M + 4u * g;
+  }
+  const int rot = 16 * (kg & 1);
+  unsigned int a_rd[4];                       // word index of this lane's four A fragments' first element inside a chunk image (row 4 kg, its 16 words of tile t)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a_rd[t] = (unsigned int)((4 * kg) * 64 + ((16 * t + lx + rot) & 63));
+  unsigned int b_rd[BN16];                    // byte offset of this lane's piece inside a block's fragment (sub-tile s2)
+#pragma unroll
+  for (int s2 = 0; s2 < BN16; ++s2) b_rd[s2] = (unsigned int)(((16 * s2 + lx) * p.bk + 8 * kg) * 2);
+  const int total_f = nmb * nch;             // (0 for a wave beyond the last one)
+  int aj = 0, ac_ = 0;                        // the NEXT chunk whose A is to be requested
+  unsigned int a_slot = 0;                    // ... and the ring slot it goes to
+  auto issue_a = [&](unsigned int a_off) __attribute__((always_inline)) {
+#if defined(XAMD_BCSC_A_ALIAS)      // experiment: every M-block reads one of the first eight's A (cache hits) -- what the kernel costs without its operand stream
+    GM const unsigned int* rowbase = A2 + (long long)((g0 + (unsigned int)aj * mbg) & 7u) * a_mb_words + a_off;
+#else
+    GM const unsigned int* rowbase = A2 + (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + a_off;
+#endif
+    char* dst = (char*)abuf + 4096u * a_slot;
+#pragma unroll
+    for (int x = 0; x < NI; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)(dst + 1024 * x), 16, 0, AUX_A);
+    a_slot = (a_slot == 2u) ? 0u : a_slot + 1u;
+    if (++ac_ == nch) { ac_ = 0; ++aj; }
+  };
+  // B arrived with the table (one round trip); it is in LDS before the first A request leaves, and the barrier below is a bare s_barrier: nothing waits for those requests
+  const unsigned int bimg_lds = (unsigned int)(unsigned long long)(lds_ptr_t)bimg;
+#pragma unroll
+  for (int e = 0; e < BP; ++e) {
+    const unsigned int x = threadIdx.x + 256u * e, bad = bimg_lds + 16u * x;
+    if (x < pieces) asm volatile("ds_write_b128 %0, %1" :: "v"(bad), "v"(bpiece[e]) : "memory");
+  }
+  // the first three chunks (a wave with fewer chunks asks for the first bytes of A again, into slots it does not read: one straight line of twelve requests)
+  const unsigned int recs_lds = (unsigned int)(unsigned long long)(lds_ptr_t)&recs[0][0], abuf_lds = (unsigned int)(unsigned long long)(lds_ptr_t)abuf;
+  u32x4v rec_c = *(const u32x4v*)recs[0];
+  long long first[3];                                     // (all three offsets are read before the first request leaves: a read of LDS the compiler can see waits for every request in flight)
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    const bool real = f < total_f;
+    const unsigned int a_off = real ? (unsigned int)__builtin_amdgcn_readfirstlane((int)recs[ac_][0]) : 0u;
+    first[f] = real ? (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + a_off : 0ll;
+    if (real && ++ac_ == nch) { ac_ = 0; ++aj; }
+  }
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+#pragma unroll
+    for (int x = 0; x < NI; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(A2 + first[f] + src_off[x]), (lds_ptr_t)((char*)abuf + 4096 * f + 1024 * x), 16, 0, AUX_A);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (!live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }        // (no request may land in LDS the workgroup has given back)
+  if (nch == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); for (int j = 0; j < nmb; ++j) store_tile(g0 + (unsigned int)j * mbg); return; }     // no block in these columns: C = 0
+  int cj = 0, cc = 0;                         // the chunk being consumed
+  unsigned int c_slot = 0;
+  for (int f = 0; f < total_f; ++f) {
+    // chunk f must have landed; behind it in issue order: A(f+1), A(f+2) as far as they exist, and the 8 stores of the previous tile while this chunk is one of the
+    // first three of its tile (A(f) was requested three chunks earlier, in front of them); loads and stores retire this counter in issue order on gfx9
+    const int left = total_f - 1 - f;
+    const bool stored = cj > 0 && cc < 3;
+    if (left >= 2) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory"); }
+    else if (left == 1) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory"); }
+    else if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int r1 = (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_c[1]), r2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_c[2]);
+    const unsigned int bo[4] = {r1 & 0xffffu, r1 >> 16, r2 & 0xffffu, r2 >> 16};
+    // the chunk's LDS reads in one statement, one wait behind them: the A fragments (lane (row, kg): k pairs 4 kg .. 4 kg + 3 of its row, four image rows), the B
+    // fragments (from offset 0 for an absent block: read, not used), the next chunk's record and the A offset of the chunk to request.  Written as instructions because
+    // the compiler puts s_waitcnt vmcnt(0) in front of a read of LDS it can see while LDS-DMA requests are in flight -- the whole ring would land before every chunk.
+    unsigned int a_ad[4], b_ad[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a_ad[t] = abuf_lds + 4096u * c_slot + 4u * a_rd[t];
+    sfor<NBL>([&](auto nc) {
+      constexpr int nbl = nc.value;
+      const unsigned int b = bo[nbl] == 0xffffu ? 0u : bo[nbl];
+      sfor<BN16>([&](auto sc) { b_ad[nbl * BN16 + sc.value] = bimg_lds + b + b_rd[sc.value]; });
+    });
+    const int cn = (cc + 1 == nch) ? 0 : cc + 1;
+    const unsigned int rec_ad = recs_lds + 16u * (unsigned int)cn, aoff_ad = recs_lds + 16u * (unsigned int)ac_;
+    u32x2v ap[8]; u32x4v bq[4]; u32x4v rec_n; unsigned int a_off_v;
+    asm volatile("ds_read2_b32 %0, %14 offset1:64\n\tds_read2_b32 %1, %14 offset0:128 offset1:192\n\t"
+                 "ds_read2_b32 %2, %15 offset1:64\n\tds_read2_b32 %3, %15 offset0:128 offset1:192\n\t"
+                 "ds_read2_b32 %4, %16 offset1:64\n\tds_read2_b32 %5, %16 offset0:128 offset1:192\n\t"
+                 "ds_read2_b32 %6, %17 offset1:64\n\tds_read2_b32 %7, %17 offset0:128 offset1:192\n\t"
+                 "ds_read_b128 %8, %18\n\tds_read_b128 %9, %19\n\tds_read_b128 %10, %20\n\tds_read_b128 %11, %21\n\t"
+                 "ds_read_b128 %12, %22\n\tds_read_b32 %13, %23\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(ap[0]), "=&v"(ap[1]), "=&v"(ap[2]), "=&v"(ap[3]), "=&v"(ap[4]), "=&v"(ap[5]), "=&v"(ap[6]), "=&v"(ap[7]),
+                   "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(rec_n), "=&v"(a_off_v)
+                 : "v"(a_ad[0]), "v"(a_ad[1]), "v"(a_ad[2]), "v"(a_ad[3]), "v"(b_ad[0]), "v"(b_ad[1]), "v"(b_ad[2]), "v"(b_ad[3]), "v"(rec_ad), "v"(aoff_ad)
+                 : "memory");
+    u32x4v a_cur[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { a_cur[t][0] = ap[2 * t][0]; a_cur[t][1] = ap[2 * t][1]; a_cur[t][2] = ap[2 * t + 1][0]; a_cur[t][3] = ap[2 * t + 1][1]; }
+    u32x4v bf_c[NBL][BN16];
+    sfor<4>([&](auto ic) { bf_c[ic.value / BN16][ic.value % BN16] = bq[ic.value]; });
+    if (left >= 3) issue_a((unsigned int)__builtin_amdgcn_readfirstlane((int)a_off_v));        // into the slot just read
+    sfor<NBL>([&](auto nc) {
+      constexpr int nbl = nc.value;
+      if (bo[nbl] != 0xffffu) {
+        sfor<BN16>([&](auto sc) {
+          constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
+          sfor<4>([&](auto tc) {
+            constexpr int t = tc.value;
+            acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a_cur[t]), __builtin_bit_cast(bf16x8v, bf_c[nbl][s2]), acc[nt][t], 0, 0, 0);
+          });
+        });
+      }
+    });
+    rec_c = rec_n;
+    c_slot = (c_slot == 2u) ? 0u : c_slot + 1u;
+    if (++cc == nch) { store_tile(g0 + (unsigned int)cj * mbg); cc = 0; ++cj; }
   }
 }
 
@@ -1233,9 +1448,19 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
             mbg = (a.m_blocks + per - 1) / per;
             const long long waves = mbg * tt_count;
             const dim3 sgrid((unsigned int)((waves + 3) / 4));
-            // one (i-tile, n-tile) per M-block and a value array that fits beside the rings: every workgroup keeps its own LDS copy of B and no wave asks the L2 for a
+            // a value array that fits beside the rings: every workgroup keeps its own LDS copy of B and no wave asks the L2 for a
             // fragment again (bn = 32: 39.5 -> 35.7 us on 8192 M-blocks of 64 x 256, bn = 16 unchanged; profiles/r06_bcsc_b_in_lds.jsonl)
-            const bool b_lds = tt_count == 1 && a.nnzb > 0 && (long long)a.nnzb * a.bn * a.bk * 2 <= kBcscBLds && ((size_t)a.bvals % 16 == 0);
+            const bool b_lds = a.nnzb > 0 && (long long)a.nnzb * a.bn * a.bk * 2 <= kBcscBLds && ((size_t)a.bvals % 16 == 0);
+            // ... and whole 64 x 64 tiles with bf16 C: the kernel with one record per chunk
+            const bool full = b_lds && a.c_type == LIBXSMM_DATATYPE_BF16 && a.M % 64 == 0 && a.N % 64 == 0 && ((size_t)a.c % 16 == 0) && nkb * (a.bk / 32) <= kBcscRecs;
+            if (full) {
+#define LAUNCH_FULL_(B_) do { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 2>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+                              else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
+              if (a.bn == 16) LAUNCH_FULL_(1); else if (a.bn == 32) LAUNCH_FULL_(2); else LAUNCH_FULL_(4);
+#undef LAUNCH_FULL_
+              if (name) *name = "bcsc_mfma_bf16_stream_full_kernel";
+              return (int)hipGetLastError();
+            }
 #define LAUNCH_STREAM_(B_) do { if (b_lds) { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 2, 4, 2, false, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
                                              else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 0, 4, 2, false, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } \
                                 else if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 2>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \

@@ -453,15 +453,21 @@ def test_packed_csc_csparse(M, N, K, P, density, beta0):
 
 # many M-blocks per tile: waves that keep their (i-tile, n-tile) and stream over the M-blocks (bcsc_mfma_bf16_stream_kernel); ragged tiles in both
 # directions, every wave with a different number of M-blocks, bf16 (C through LDS) and f32 (direct) output, one n-tile without any block
+# host pattern (the reference's convention): the value array of B is known to fit in LDS -- the general kernel with B in LDS, and for whole 64 x 64 tiles with bf16 C the
+# kernel with one record per chunk (bcsc_mfma_bf16_stream_full_kernel): several n-tiles per workgroup, two 32-deep steps per k-block, an n-tile without blocks, a wave
+# with a single chunk, more workgroup slots than waves
+@pytest.mark.parametrize("pattern_on", ["device", "host"])
 @pytest.mark.parametrize("c_type", [DT.BF16, DT.F32])
-@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep", [(80, 96, 128, 1100, 32, 32, 0.34), (64, 64, 256, 4099, 32, 16, 0.25), (64, 128, 64, 2050, 64, 64, 0.5)])
-def test_bcsc_bf16_waves_streaming_over_m_blocks(c_type, M, N, K, mb, bk, bn, keep):
+@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep", [(80, 96, 128, 1100, 32, 32, 0.34), (64, 64, 256, 4099, 32, 16, 0.25), (64, 128, 64, 2050, 64, 64, 0.5), (128, 64, 64, 2049, 32, 32, 0.5),
+                                                 (64, 64, 32, 4101, 32, 64, 1.0), (192, 128, 128, 700, 32, 32, 0.25)])
+def test_bcsc_bf16_waves_streaming_over_m_blocks(c_type, M, N, K, mb, bk, bn, keep, pattern_on):
     api, orc = capi.load(), pyoracle.oracle()
     rng = np.random.default_rng(13)
     colptr, rowidx, bvals = make_bcsc(rng, K, N, bk, bn, keep, DT.BF16)
     if N == 128:                                   # the second n-tile loses all its blocks: its C must become zero
-        keep_blocks = int(colptr[1])
-        colptr = np.array([0, keep_blocks, keep_blocks], dtype=colptr.dtype); rowidx = rowidx[:keep_blocks].copy(); bvals = bvals[:keep_blocks * bn * bk].copy()
+        first = 64 // bn                                                        # block columns of the first n-tile
+        keep_blocks = int(colptr[first])
+        colptr = np.array(list(colptr[:first + 1]) + [keep_blocks] * (N // bn - first), dtype=colptr.dtype); rowidx = rowidx[:keep_blocks].copy(); bvals = bvals[:keep_blocks * bn * bk].copy()
     A = rand_values(rng, mb * K * M, DT.BF16)
     A_run = pack_vnni2(A, mb, K, M)
     C0 = rand_values(rng, mb * N * M, c_type)
@@ -473,9 +479,14 @@ def test_bcsc_bf16_waves_streaming_over_m_blocks(c_type, M, N, K, mb, bk, bn, ke
     nblk = C.c_ulonglong(N // bn)
     p = capi.GemmParam()
     p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = dA.data_ptr(), dB.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), dC.data_ptr()
-    capi.Api.call(h, p)
+    if pattern_on == "host":
+        p.b.secondary, p.b.tertiary = colptr.ctypes.data, rowidx.ctypes.data
+    for _ in range(2):                             # (the second call takes the cached table)
+        capi.Api.call(h, p)
     api.hip_sync(); api.check()
-    assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_bf16_stream_kernel"
+    fits = len(rowidx) * bn * bk * 2 <= 10240
+    full = pattern_on == "host" and fits and c_type == DT.BF16 and M % 64 == 0 and N % 64 == 0
+    assert api.hip_kernel_name(h, 0).decode() == ("bcsc_mfma_bf16_stream_full_kernel" if full else "bcsc_mfma_bf16_stream_kernel")
     got = _host(dC, np.uint16 if c_type == DT.BF16 else np.float32)
     assert normf_rel(ref, got, c_type) <= (5e-3 if c_type == DT.BF16 else 1e-4)
     # block by block: no M-block may be skipped or written twice with another block's data

@@ -1,6 +1,8 @@
 """time ONE workload expression (env WL, ";;"-separated; evaluated with bp = tools/bench_paths, wl = tools/workloads; EAGER=1: plain launches for counter passes) -- A/B runs under env switches: TAG=x LIBXSMM_HIP_...=1 WL="bp.bcsc(api, dtype=\"f32\")" python tools/time_one.py"""
 import os, sys, json, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tools"); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for d in ("", "tools", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, d))
 import bench, bench_paths as bp, workloads as wl
 from libxsmm_amd import capi
 from libxsmm_amd.capi import DT, UNARY  # noqa: F401
