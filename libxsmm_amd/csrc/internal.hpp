@@ -143,6 +143,8 @@ struct BcscArgs {
   int nt_a;                           // stream the A operand with non-temporal loads (set by launch_bcsc: launch larger than the Infinity Cache, or the caller's hint)
   int stream_hint;                    // libxsmm_hip_set_streaming_hint of the calling thread
   int table_ready;                    // the table already holds this call's inverted pattern (host-resident pattern, cached per kernel)
+  unsigned long long kmask0;          // host-resident pattern: bit kb set when some block of the first 64 columns lies in k-block kb (valid when nnzb > 0 and K / bk <= 64) --
+                                      // a kernel whose waves all work on those columns knows its first A requests without a look at the table
   int nnzb;                           // number of blocks of B when the host knows it (host-resident or bound pattern), else 0: a B of a few KiB is kept in LDS by the streaming kernel (round 6)
 };
 
@@ -188,7 +190,7 @@ struct KernelCtx {
   struct EqnPlan* eqn = nullptr;    // K_MEQN: the evaluation plan (meqn.cpp)
   // K_BCSC: patterns that arrived in HOST memory, inverted on the host once and kept on the device ([colptr | rowidx | table] per entry)
   // Entries are immutable once published and live until the kernel is released: the hit path reads `bcsc_last` without a lock.
-  struct BcscCached { std::vector<unsigned int> pattern; unsigned int* d_block = nullptr; };
+  struct BcscCached { std::vector<unsigned int> pattern; unsigned int* d_block = nullptr; unsigned long long kmask0 = 0ull; };
   std::vector<BcscCached*> bcsc_cache;            // guarded by the cache lock (miss path only); at most 4 current entries, evicted ones go to bcsc_old
   std::vector<BcscCached*> bcsc_old;
   std::atomic<const BcscCached*> bcsc_last{nullptr};

@@ -1100,6 +1100,9 @@ void run_bcsc(KernelCtx* k, const void* param) {
         fresh->pattern.push_back((unsigned int)nblk_n); fresh->pattern.push_back((unsigned int)nkb);
         fresh->pattern.insert(fresh->pattern.end(), hc, hc + n_ptr); fresh->pattern.insert(fresh->pattern.end(), hr, hr + nnzb);
         fresh->d_block = blockp;
+        if (nkb <= 64 && a.bn > 0)        // the k-blocks the first 64 columns use (see BcscArgs::kmask0)
+          for (unsigned long long nb = 0; nb < nblk_n && nb * (unsigned long long)a.bn < 64ull; ++nb)
+            for (unsigned int b = hc[nb]; b < hc[nb + 1]; ++b) fresh->kmask0 |= 1ull << hr[b];
         // an evicted entry stays alive until the kernel is released: another thread may be past its lock-free hit, a launch may still read its table
         if (k->bcsc_cache.size() >= 4) { k->bcsc_old.push_back(k->bcsc_cache.front()); k->bcsc_cache.erase(k->bcsc_cache.begin()); }
         // ... but a caller that cycles through many patterns must not grow device memory without bound (advisor, round 3): beyond 64 retired entries that still own a device table the
@@ -1119,7 +1122,7 @@ void run_bcsc(KernelCtx* k, const void* param) {
       k->bcsc_last.store(hit, std::memory_order_release);
     }
     unsigned int* blockp = hit->d_block;
-    a.colptr = blockp; a.rowidx = blockp + n_ptr; a.table = blockp + n_ptr + n_idx; a.table_ready = 1; a.nnzb = (int)nnzb;
+    a.colptr = blockp; a.rowidx = blockp + n_ptr; a.table = blockp + n_ptr + n_idx; a.table_ready = 1; a.nnzb = (int)nnzb; a.kmask0 = hit->kmask0;
   } else {
   a.colptr = (const unsigned int*)device_visible(p->b.secondary, (size_t)(nblk_n + 1) * sizeof(unsigned int));
   if (!a.colptr) { set_error(-2, "BCSC kernel needs colptr in b.secondary"); return; }

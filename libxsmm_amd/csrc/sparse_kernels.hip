@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
 // The epilogue's LDS traffic is written as instructions: a ds_write / ds_read the compiler can see gets its s_waitcnt vmcnt(0) -- it cannot tell the C tile from
 // the ring the requests in flight write to -- which would wait for the next tile's first three chunks at every tile end.
 constexpr int kBcscRecs = 64;        // chunk records per wave
-template <int BN16, int AUX_A>
+template <int BN16, int AUX_A, bool EARLY>     // EARLY: one n-tile and the host's mask of its used k-blocks (BcscArgs::kmask0) -- the first three chunks are requested before anything is loaded
 __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
   constexpr int NBL = 4 / BN16, DA = 3, NI = 4, NS = 8;
   __shared__ __attribute__((aligned(16))) unsigned int recs_all[4][kBcscRecs][4];
@@ -1073,34 +1073,85 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
   const int i0 = (int)ti * 64, n0 = (int)tn * 64;
   const int nb0 = n0 / (16 * BN16);
   const int nkb = p.K / p.bk, steps = p.bk / 32;
-  GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb;
-  unsigned int trow[NBL];
+  const int nmb = (live && (unsigned int)p.m_blocks > g0) ? (int)(((unsigned int)p.m_blocks - g0 + mbg - 1u) / mbg) : 0;
+  // DMA source of LDS slot (lane + 64 x): row kp_l = slot >> 4, the 16-byte group that lands there = (slot & 15) rotated back
+  GM const unsigned int* A2 = (GM const unsigned int*)p.a + i0;
+  const long long a_mb_words = (long long)(p.K / 2) * p.M;
+  unsigned int src_off[NI];
 #pragma unroll
-  for (int nbl = 0; nbl < NBL; ++nbl) trow[nbl] = (lane < nkb) ? gt[nbl * nkb + lane] : 0xffffffffu;
+  for (int x = 0; x < NI; ++x) {
+    const unsigned int S = (unsigned int)lane + 64u * x, kp_l = S >> 4, g = ((S & 15u) - 4u * ((kp_l >> 2) & 1u)) & 15u;
+    src_off[x] = kp_l * (unsigned int)p.M + 4u * g;
+  }
+  // EARLY: the chunk list follows from the host's mask alone -- the first three chunks are requested without a look at the table
+  long long first[3] = {0ll, 0ll, 0ll};
+  if constexpr (EARLY) {
+    const int nch_e = __builtin_popcountll(p.kmask0) * steps, total_e = nmb * nch_e;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+      if (f < total_e) {
+        const int j = f / nch_e, c = f - j * nch_e, q = c / steps, st_ = c - q * steps;
+        unsigned long long m = p.kmask0;
+        for (int z = 0; z < q; ++z) m &= m - 1ull;
+        const unsigned int kb = (unsigned int)__builtin_ctzll(m);
+        first[f] = (long long)(g0 + (unsigned int)j * mbg) * a_mb_words + (long long)((kb * (unsigned int)(p.bk / 2) + 16u * (unsigned int)st_) * (unsigned int)p.M);
+      }
+    }
+  }
+  // The table rows of this wave's columns and this thread's pieces of B, then (EARLY) the twelve requests, then ONE wait that leaves the requests in flight.  The loads
+  // are written as instructions: a register the compiler knows to be loaded is waited for with s_waitcnt vmcnt(0) while LDS-DMA requests are pending, whatever their
+  // place in the queue -- here that would be the first three chunks of A (the wait statement names the registers, so nothing reads them before it).
+  GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb + (lane < nkb ? lane : 0);
   constexpr int BP = kBcscBLds / 16 / 256 + 1;          // 16-byte pieces of B per thread
+  static_assert(BP == 3, "the load statement below asks for three pieces");
   const unsigned int pieces = (unsigned int)p.nnzb * (unsigned int)(p.bn * p.bk) / 8u;
-  u32x4v bpiece[BP];
+  unsigned int trow[4]; u32x4v bpiece[BP];
+  {
+    GM const unsigned int* tp[4]; GM const u32x4v* bp_[BP];
 #pragma unroll
-  for (int e = 0; e < BP; ++e) { const unsigned int x = threadIdx.x + 256u * e; bpiece[e] = ((GM const u32x4v*)p.bvals)[x < pieces ? x : 0u]; }
+    for (int nbl = 0; nbl < 4; ++nbl) tp[nbl] = gt + (nbl < NBL ? nbl : NBL - 1) * nkb;
+#pragma unroll
+    for (int e = 0; e < BP; ++e) { const unsigned int x = threadIdx.x + 256u * e; bp_[e] = (GM const u32x4v*)p.bvals + (x < pieces ? x : 0u); }
+    asm volatile("global_load_dword %0, %7, off\n\tglobal_load_dword %1, %8, off\n\tglobal_load_dword %2, %9, off\n\tglobal_load_dword %3, %10, off\n\t"
+                 "global_load_dwordx4 %4, %11, off\n\tglobal_load_dwordx4 %5, %12, off\n\tglobal_load_dwordx4 %6, %13, off"
+                 : "=&v"(trow[0]), "=&v"(trow[1]), "=&v"(trow[2]), "=&v"(trow[3]), "=&v"(bpiece[0]), "=&v"(bpiece[1]), "=&v"(bpiece[2])
+                 : "v"(tp[0]), "v"(tp[1]), "v"(tp[2]), "v"(tp[3]), "v"(bp_[0]), "v"(bp_[1]), "v"(bp_[2]) : "memory");
+  }
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+#pragma unroll
+      for (int x = 0; x < NI; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(A2 + first[f] + src_off[x]), (lds_ptr_t)((char*)abuf + 4096 * f + 1024 * x), 16, 0, AUX_A);
+    }
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]) :: "memory");
+  } else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]) :: "memory");
+  if (lane >= nkb) { trow[0] = 0xffffffffu; trow[1] = 0xffffffffu; trow[2] = 0xffffffffu; trow[3] = 0xffffffffu; }
+  // one record per chunk, lane c building chunk c's -- without a look at LDS the compiler can see (an LDS access it sees while requests are in flight gets its
+  // s_waitcnt vmcnt(0)): the used k-blocks are bits of a mask, the table row of another lane comes through a cross-lane read, the record leaves as an instruction
   bool used = false;
 #pragma unroll
-  for (int nbl = 0; nbl < NBL; ++nbl) { used = used || (trow[nbl] != 0xffffffffu); tile[64 * (nbl + 1) + lane] = trow[nbl]; }
-  const unsigned long long mask = __ballot(used);
-  if (used) tile[__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (unsigned int)lane;
+  for (int nbl = 0; nbl < NBL; ++nbl) used = used || (trow[nbl] != 0xffffffffu);
+  const unsigned long long mask = EARLY ? p.kmask0 : __ballot(used);
   const int nch = __builtin_popcountll(mask) * steps;
-  if (lane < nch) {
+  const unsigned int recs_lds = (unsigned int)(unsigned long long)(lds_ptr_t)&recs[0][0], abuf_lds = (unsigned int)(unsigned long long)(lds_ptr_t)abuf;
+  u32x4v rec_mine;
+  {
     const int q = lane / steps, st_ = lane - q * steps;
-    const unsigned int kb = tile[q];
+    unsigned long long m = mask;
+    for (int z = 0; z < q; ++z) m &= m - 1ull;                          // (the q-th used k-block: the q-th set bit)
+    const unsigned int kb = m ? (unsigned int)__builtin_ctzll(m) : 0u;
     unsigned int bo[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
 #pragma unroll
     for (int nbl = 0; nbl < NBL; ++nbl) {
-      const unsigned int blk = tile[64 * (nbl + 1) + (int)kb];
+      const unsigned int blk = (unsigned int)__shfl((int)trow[nbl], (int)kb);
       if (blk != 0xffffffffu) bo[nbl] = (blk * (unsigned int)(16 * BN16) * (unsigned int)p.bk + 32u * (unsigned int)st_) * 2u;
     }
-    u32x4v r; r[0] = (kb * (unsigned int)(p.bk / 2) + 16u * (unsigned int)st_) * (unsigned int)p.M; r[1] = bo[0] | (bo[1] << 16); r[2] = bo[2] | (bo[3] << 16); r[3] = 0u;
-    *(u32x4v*)recs[lane] = r;
+    rec_mine[0] = (kb * (unsigned int)(p.bk / 2) + 16u * (unsigned int)st_) * (unsigned int)p.M; rec_mine[1] = bo[0] | (bo[1] << 16); rec_mine[2] = bo[2] | (bo[3] << 16); rec_mine[3] = 0u;
+    const unsigned int rad = recs_lds + 16u * (unsigned int)lane;
+    if (lane < nch) asm volatile("ds_write_b128 %0, %1" :: "v"(rad), "v"(rec_mine) : "memory");
   }
-  const int nmb = (live && (unsigned int)p.m_blocks > g0) ? (int)(((unsigned int)p.m_blocks - g0 + mbg - 1u) / mbg) : 0;
   const long long c_mb_bytes = (long long)p.N * p.M * 2;
   f32x4v acc[4][4];
   sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
@@ -1135,15 +1186,6 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
     });
     sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
   };
-  // DMA source of LDS slot (lane + 64 x): row kp_l = slot >> 4, the 16-byte group that lands there = (slot & 15) rotated back
-  GM const unsigned int* A2 = (GM const unsigned int*)p.a + i0;
-  const long long a_mb_words = (long long)(p.K / 2) * p.M;
-  unsigned int src_off[NI];
-#pragma unroll
-  for (int x = 0; x < NI; ++x) {
-    const unsigned int S = (unsigned int)lane + 64u * x, kp_l = S >> 4, g = ((S & 15u) - 4u * ((kp_l >> 2) & 1u)) & 15u;
-    src_off[x] = kp_l * (unsigned int)p.M + 4u * g;
-  }
   const int rot = 16 * (kg & 1);
   unsigned int a_rd[4];                       // word index of this lane's four A fragments' first element inside a chunk image (row 4 kg, its 16 words of tile t)
 #pragma unroll
@@ -1175,21 +1217,24 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
     if (x < pieces) asm volatile("ds_write_b128 %0, %1" :: "v"(bad), "v"(bpiece[e]) : "memory");
   }
   // the first three chunks (a wave with fewer chunks asks for the first bytes of A again, into slots it does not read: one straight line of twelve requests)
-  const unsigned int recs_lds = (unsigned int)(unsigned long long)(lds_ptr_t)&recs[0][0], abuf_lds = (unsigned int)(unsigned long long)(lds_ptr_t)abuf;
-  u32x4v rec_c = *(const u32x4v*)recs[0];
-  long long first[3];                                     // (all three offsets are read before the first request leaves: a read of LDS the compiler can see waits for every request in flight)
+  u32x4v rec_c;                                           // chunk 0's record: lane 0's
+#pragma unroll
+  for (int e = 0; e < 4; ++e) rec_c[e] = (unsigned int)__builtin_amdgcn_readlane((int)rec_mine[e], 0);
+  // (all three offsets are read before the first request leaves: a read of LDS the compiler can see waits for every request in flight)
 #pragma unroll
   for (int f = 0; f < 3; ++f) {
     const bool real = f < total_f;
-    const unsigned int a_off = real ? (unsigned int)__builtin_amdgcn_readfirstlane((int)recs[ac_][0]) : 0u;
-    first[f] = real ? (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + a_off : 0ll;
+    const unsigned int a_off = real ? (unsigned int)__builtin_amdgcn_readlane((int)rec_mine[0], ac_) : 0u;
+    if constexpr (!EARLY) first[f] = real ? (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + a_off : 0ll;
     if (real && ++ac_ == nch) { ac_ = 0; ++aj; }
   }
+  if constexpr (!EARLY) {
 #pragma unroll
-  for (int f = 0; f < 3; ++f) {
+    for (int f = 0; f < 3; ++f) {
 #pragma unroll
-    for (int x = 0; x < NI; ++x)
-      __builtin_amdgcn_global_load_lds((GM const void*)(A2 + first[f] + src_off[x]), (lds_ptr_t)((char*)abuf + 4096 * f + 1024 * x), 16, 0, AUX_A);
+      for (int x = 0; x < NI; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(A2 + first[f] + src_off[x]), (lds_ptr_t)((char*)abuf + 4096 * f + 1024 * x), 16, 0, AUX_A);
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (!live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }        // (no request may land in LDS the workgroup has given back)
@@ -1454,8 +1499,11 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
             // ... and whole 64 x 64 tiles with bf16 C: the kernel with one record per chunk
             const bool full = b_lds && a.c_type == LIBXSMM_DATATYPE_BF16 && a.M % 64 == 0 && a.N % 64 == 0 && ((size_t)a.c % 16 == 0) && nkb * (a.bk / 32) <= kBcscRecs;
             if (full) {
-#define LAUNCH_FULL_(B_) do { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 2>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
-                              else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
+              const bool early = tiles_n == 1;          // (kmask0 describes the first n-tile)
+#define LAUNCH_FULL_(B_) do { if (early) { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 2, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+                                           else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } \
+                              else if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 2, false>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+                              else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0, false>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
               if (a.bn == 16) LAUNCH_FULL_(1); else if (a.bn == 32) LAUNCH_FULL_(2); else LAUNCH_FULL_(4);
 #undef LAUNCH_FULL_
               if (name) *name = "bcsc_mfma_bf16_stream_full_kernel";

@@ -29,6 +29,7 @@ OCCUPANCY = {
     r"xamd::gemm_bf16_wg64_kernel<.*>": 4,
     r"xamd::gemm_p16_kernel<1, .*>": 8,
     r"xamd::bcsc_mfma_bf16_stream_kernel<.*>": 2,                # 2048 waves = one round at two waves per SIMD
+    r"xamd::bcsc_mfma_bf16_stream_full_kernel<.*>": 2,           # round 6: the same 2048 waves, one record per chunk
     r"xamd::bcsc_mfma_bf16_dma_kernel<.*>": 3,
     r"xamd::bcsc_mfma_i8_dma_kernel<., true, .*>": 3,
     r"xamd::bcsc_mfma_i8_dma_kernel<., false, .*>": 2,
