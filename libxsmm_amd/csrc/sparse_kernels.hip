@@ -1451,13 +1451,23 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_i8_dma_kernel(BcscArgs p, 
   });
 }
 
+// What one launch moves: the k-blocks of A some block of B refers to (known from a host-resident pattern when one n-tile covers all columns: BcscArgs::kmask0;
+// all of A otherwise) and C.  A launch that moves more than the Infinity Cache holds cannot leave anything there for the next one: its A is requested non-temporal
+// (config #4: 7 of 8 k-blocks of 256 MiB + 64 MiB of C -- 52.6 against 56.7 us; the same shape with bn = 32 touches half of A: 192 MiB, cacheable, 34.6 against 36.6 us;
+// profiles/r06_bcsc_full.jsonl).
+static unsigned long long bcsc_launch_bytes(const BcscArgs& a, unsigned long long a_elem, unsigned long long c_elem) {
+  const unsigned long long mb = (unsigned long long)std::max(a.m_blocks, 0), M = (unsigned long long)std::max(a.M, 0);
+  unsigned long long k_used = (unsigned long long)std::max(a.K, 0);
+  if (a.nnzb > 0 && a.N <= 64 && a.bk > 0 && a.K / a.bk <= 64) k_used = (unsigned long long)__builtin_popcountll(a.kmask0) * (unsigned long long)a.bk;
+  return mb * M * (k_used * a_elem + (unsigned long long)std::max(a.N, 0) * c_elem);
+}
+
 int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
   hipStream_t st = (hipStream_t)stream;
   BcscArgs a = a_in;
   {
     const unsigned long long es = a.a_type == LIBXSMM_DATATYPE_F32 ? 4ull : (a.a_type == LIBXSMM_DATATYPE_BF16 ? 2ull : 1ull);
-    const unsigned long long a_bytes = (unsigned long long)std::max(a.m_blocks, 0) * (unsigned long long)std::max(a.M, 0) * (unsigned long long)std::max(a.K, 0) * es;
-    a.nt_a = (a.stream_hint == 2 || (a.stream_hint == 0 && a_bytes > (256ull << 20))) ? 1 : 0;
+    a.nt_a = (a.stream_hint == 2 || (a.stream_hint == 0 && bcsc_launch_bytes(a, es, a.c_type == LIBXSMM_DATATYPE_BF16 ? 2ull : 4ull) > (256ull << 20))) ? 1 : 0;
   }
   if (a.m_blocks <= 0 || a.M <= 0 || a.N <= 0) { if (name) *name = "(empty)"; return 0; }
   // matrix-core path: bf16 with VNNI-2 A, 32-deep k steps, 16-wide n sub-tiles, 16-row i tiles, 8-byte aligned C columns
@@ -1479,8 +1489,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
           // the inverted pattern: already in place when the pattern came from host memory (built there, cached per kernel: run_bcsc)
           if (!a.table_ready) hipLaunchKernelGGL(bcsc_invert_kernel, dim3((unsigned int)a.nblk_n), dim3(64), 0, st, a.colptr, a.rowidx, (unsigned int*)a.table, a.nblk_n, nkb);
           // A is read exactly once: stream it non-temporally when it cannot be cache resident anyway (or the caller says so)
-          const unsigned long long a_bytes = (unsigned long long)a.m_blocks * a.M * a.K * 2ull;
-          const bool nta = a.stream_hint == 2 || (a.stream_hint == 0 && a_bytes > (256ull << 20));
+          const bool nta = a.nt_a != 0;
           // many M-blocks per (i-tile, n-tile): waves that stream over M-blocks (two per SIMD: 2048 on the chip), each taking every mbg-th block
           constexpr int stream_mode = 1;
           const long long tt_count = (long long)tiles_i * tiles_n;
@@ -1500,7 +1509,10 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
             const bool full = b_lds && a.c_type == LIBXSMM_DATATYPE_BF16 && a.M % 64 == 0 && a.N % 64 == 0 && ((size_t)a.c % 16 == 0) && nkb * (a.bk / 32) <= kBcscRecs;
             if (full) {
               const bool early = tiles_n == 1;          // (kmask0 describes the first n-tile)
-#define LAUNCH_FULL_(B_) do { if (early) { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 2, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+#if !defined(XAMD_BCSC_AUX_NT)
+#define XAMD_BCSC_AUX_NT 2          // cache-policy bits of the A requests of a launch that streams (A/B builds: 3, 16, 18, ...)
+#endif
+#define LAUNCH_FULL_(B_) do { if (early) { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, XAMD_BCSC_AUX_NT, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
                                            else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } \
                               else if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 2, false>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
                               else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0, false>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)

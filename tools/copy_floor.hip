@@ -70,7 +70,7 @@ __global__ __launch_bounds__(BS) void rows_kernel(const u32x4* in, u32x4* out, u
 
 // the BCSC streaming kernel's pattern (config #4): `waves` waves; wave w walks M-blocks w, w + waves, ...; an M-block = eight 4 KiB chunks of A of which seven are read
 // (the 2 : 8 pattern touches 7 of 8 K-blocks), three chunks in flight per wave, then 8 KiB of C are written
-template <bool NT>
+template <int NT>          // bit 0: non-temporal loads, bit 1: non-temporal stores
 __global__ __launch_bounds__(256) void bcsc_pattern_kernel(const u32x4* a, u32x4* c, unsigned int m_blocks, unsigned int waves) {
   const unsigned int w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (w >= waves) return;
@@ -81,19 +81,19 @@ __global__ __launch_bounds__(256) void bcsc_pattern_kernel(const u32x4* a, u32x4
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-      for (int x = 0; x < 4; ++x) { GM const u32x4* q = src + (ch * 4 + x) * 64; v[ch][x] = NT ? __builtin_nontemporal_load(q) : *q; }
+      for (int x = 0; x < 4; ++x) { GM const u32x4* q = src + (ch * 4 + x) * 64; v[ch][x] = (NT & 1) ? __builtin_nontemporal_load(q) : *q; }
 #pragma unroll
     for (int ch = 0; ch < 7; ++ch) {
 #pragma unroll
       for (int x = 0; x < 4; ++x) acc ^= v[ch % 3][x];
       if (ch + 3 < 7) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { GM const u32x4* q = src + ((ch + 3) * 4 + x) * 64; v[ch % 3][x] = NT ? __builtin_nontemporal_load(q) : *q; }
+        for (int x = 0; x < 4; ++x) { GM const u32x4* q = src + ((ch + 3) * 4 + x) * 64; v[ch % 3][x] = (NT & 1) ? __builtin_nontemporal_load(q) : *q; }
       }
     }
     GM u32x4* dst = (GM u32x4*)c + (unsigned long long)mb * 512ull + lane;                     // 8 KiB per M-block
 #pragma unroll
-    for (int x = 0; x < 8; ++x) { u32x4 o = acc; o[0] += (unsigned int)x; if (NT) __builtin_nontemporal_store(o, dst + x * 64); else dst[x * 64] = o; }
+    for (int x = 0; x < 8; ++x) { u32x4 o = acc; o[0] += (unsigned int)x; if (NT & 2) __builtin_nontemporal_store(o, dst + x * 64); else dst[x * 64] = o; }
   }
 }
 
@@ -121,10 +121,14 @@ int main(int argc, char** argv) {
       const int ns = (int)std::max<size_t>(2, ((size_t)1 << 30) / (a_bytes + c_bytes) + 1);
       std::vector<void*> as_((size_t)ns), cs_((size_t)ns);
       for (int q = 0; q < ns; ++q) { CHECK(hipMalloc(&as_[(size_t)q], a_bytes)); CHECK(hipMemset(as_[(size_t)q], 0x31, a_bytes)); CHECK(hipMalloc(&cs_[(size_t)q], c_bytes)); }
-      for (unsigned int waves = 2048; waves <= 8192; waves *= 2)
-        for (int nt = 0; nt < 2; ++nt) {
-          auto go = [&](int i) { if (nt) hipLaunchKernelGGL((bcsc_pattern_kernel<true>), dim3(waves / 4), dim3(256), 0, st, (const u32x4*)as_[(size_t)(i % ns)], (u32x4*)cs_[(size_t)(i % ns)], m_blocks, waves);
-                                 else hipLaunchKernelGGL((bcsc_pattern_kernel<false>), dim3(waves / 4), dim3(256), 0, st, (const u32x4*)as_[(size_t)(i % ns)], (u32x4*)cs_[(size_t)(i % ns)], m_blocks, waves); };
+      for (unsigned int waves = 2048; waves <= 2048; waves *= 2)
+        for (int nt = 0; nt < 4; ++nt) {
+          auto go = [&](int i) {
+            const u32x4* ap = (const u32x4*)as_[(size_t)(i % ns)]; u32x4* cp = (u32x4*)cs_[(size_t)(i % ns)];
+            if (nt == 0) hipLaunchKernelGGL((bcsc_pattern_kernel<0>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves);
+            else if (nt == 1) hipLaunchKernelGGL((bcsc_pattern_kernel<1>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves);
+            else if (nt == 2) hipLaunchKernelGGL((bcsc_pattern_kernel<2>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves);
+            else hipLaunchKernelGGL((bcsc_pattern_kernel<3>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves); };
           for (int i = 0; i < 2 * ns; ++i) go(i);
           CHECK(hipStreamSynchronize(st));
           const int reps = std::max(3 * ns, (int)(0.05 / (moved / 5e12)));
@@ -134,7 +138,7 @@ int main(int argc, char** argv) {
           float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
           const double us = ms * 1e3 / reps, tbs = moved / us / 1e6;
           printf("{\"copy_floor\": \"%s\", \"pattern\": \"bcsc 7 of 8 chunks in, 8 KiB out per M-block\", \"m_blocks\": %u, \"waves\": %u, \"sets\": %d, \"policy\": \"%s\", \"us\": %.2f, \"TB/s\": %.3f, \"frac_of_8TBs\": %.4f}\n",
-                 name, m_blocks, waves, ns, nt ? "nt" : "default", us, tbs, tbs / 8.0);
+                 name, m_blocks, waves, ns, nt == 0 ? "default" : nt == 1 ? "nt loads" : nt == 2 ? "nt stores" : "nt", us, tbs, tbs / 8.0);
         }
       for (int q = 0; q < ns; ++q) { CHECK(hipFree(as_[(size_t)q])); CHECK(hipFree(cs_[(size_t)q])); }
       continue;

@@ -13,6 +13,8 @@ if os.environ.get("HINT"):             # libxsmm_hip_set_streaming_hint of this 
     api.hip_set_streaming_hint(int(os.environ["HINT"]))
 for expr in os.environ["WL"].split(";;"):
     w = eval(expr)
+    if os.environ.get("HINT"):
+        w.hint = int(os.environ["HINT"])           # (bench.timed sets the thread's hint from the workload)
     for i in range(3):
         w.step(i)
     torch.cuda.synchronize()
