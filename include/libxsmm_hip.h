@@ -236,7 +236,9 @@ LIBXSMM_API int libxsmm_hip_bcsc_from_dense(libxsmm_datatype type, const void* d
  * reference's convention -- is recognised by content and its inverted image cached with the kernel (no allocation, no lock on a hit).  A pattern in
  * DEVICE memory cannot be compared without a host round trip: by default it is inverted by a small kernel in front of every call; this function
  * lets the caller promise that the two device arrays do not change until the binding is replaced (NULL, NULL unbinds), so the table is built once,
- * stream-ordered on the calling thread's stream, and calls that pass exactly these pointers launch the GEMM kernel alone. */
+ * stream-ordered on the calling thread's stream, and calls that pass exactly these pointers launch the GEMM kernel alone.  Outside a graph capture the
+ * two arrays are also read once (the call then waits for the stream): the number of blocks and the k-blocks in use let the launcher pick the kernels
+ * that keep a small B in LDS, as a host-resident pattern does. */
 LIBXSMM_API int libxsmm_hip_bcsc_bind_pattern(libxsmm_gemmfunction kernel, const unsigned int* colptr, const unsigned int* rowidx, unsigned long long n_block_columns);
 
 /* ---- run-time specialisation of the fixed-pattern sparse kernels ---------------------

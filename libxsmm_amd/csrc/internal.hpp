@@ -195,7 +195,8 @@ struct KernelCtx {
   std::vector<BcscCached*> bcsc_old;
   std::atomic<const BcscCached*> bcsc_last{nullptr};
   // libxsmm_hip_bcsc_bind_pattern: a DEVICE-resident pattern the caller promises not to change: its inverted table is built once
-  struct BcscBound { const void* colptr = nullptr; const void* rowidx = nullptr; unsigned long long nblk_n = 0; unsigned int* d_table = nullptr; int nkb = 0; };
+  struct BcscBound { const void* colptr = nullptr; const void* rowidx = nullptr; unsigned long long nblk_n = 0; unsigned int* d_table = nullptr; int nkb = 0;
+                     int nnzb = 0; unsigned long long kmask0 = 0ull; };      // read back once at bind time (0: not read -- the bind was captured into a graph)
   BcscBound bcsc_bound;
   int device = 0;
   const char* kname_single = "";                 // static strings or strings owned by a never-shrinking table

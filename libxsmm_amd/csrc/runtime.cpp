@@ -1144,6 +1144,7 @@ void run_bcsc(KernelCtx* k, const void* param) {
   const KernelCtx::BcscBound& bd = k->bcsc_bound;
   if (nkb > 0 && bd.d_table && bd.colptr == p->b.secondary && bd.rowidx == p->b.tertiary && bd.nblk_n == nblk_n && bd.nkb == nkb) {
     a.table = bd.d_table; a.table_ready = 1;        // libxsmm_hip_bcsc_bind_pattern: inverted once, no inversion kernel per call
+    a.nnzb = bd.nnzb; a.kmask0 = bd.kmask0;         // ... and read once: the streaming kernels that keep B in LDS apply as for a host-resident pattern
   } else if (nkb > 0) a.table = workspace((size_t)std::max(1, a.nblk_n) * (size_t)nkb * sizeof(unsigned int));
   }
   if (!a.a || !a.bvals || !a.c || !a.rowidx) { set_error(-2, "BCSC kernel called with a NULL operand"); return; }
@@ -1997,6 +1998,30 @@ LIBXSMM_API int libxsmm_hip_bcsc_bind_pattern(libxsmm_gemmfunction kernel, const
   const int err = launch_bcsc_invert(colptr, rowidx, table, (int)n_block_columns, nkb, tls().stream);       // stream-ordered before the calls that follow on this stream
   if (err != 0) { (void)hipFree(table); set_error(err, "launch of bcsc_invert_kernel failed: %s", hipGetErrorString((hipError_t)err)); return EXIT_FAILURE; }
   if (!tls().async) (void)hipStreamSynchronize(cur_stream());
+  // The caller promises not to change the arrays: they are read once here (the number of blocks and the k-blocks the first 64 columns use, what a host-resident
+  // pattern tells the launcher), unless the bind is being captured into a graph.  This waits for the stream, like the first call with a new host pattern does.
+  int nnzb_read = 0; unsigned long long kmask_read = 0ull;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(cur_stream(), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+  if (cap == hipStreamCaptureStatusNone && nkb <= 64 && c->bn > 0 && n_block_columns <= 4096) {
+    std::vector<unsigned int> hc((size_t)n_block_columns + 1);
+    if (hipMemcpyAsync(hc.data(), colptr, hc.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, cur_stream()) == hipSuccess && hipStreamSynchronize(cur_stream()) == hipSuccess &&
+        hc[n_block_columns] > 0 && hc[n_block_columns] <= (1u << 20)) {
+      std::vector<unsigned int> hr(hc[n_block_columns]);
+      if (hipMemcpyAsync(hr.data(), rowidx, hr.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, cur_stream()) == hipSuccess && hipStreamSynchronize(cur_stream()) == hipSuccess) {
+        bool sane = true;
+        for (unsigned long long nb = 0; nb < n_block_columns && sane; ++nb) sane = hc[nb] <= hc[nb + 1] && hc[nb + 1] <= hc[n_block_columns];
+        for (unsigned int b = 0; b < hc[n_block_columns] && sane; ++b) sane = hr[b] < (unsigned int)nkb;
+        if (sane) {
+          nnzb_read = (int)hc[n_block_columns];
+          for (unsigned long long nb = 0; nb < n_block_columns && nb * (unsigned long long)c->bn < 64ull; ++nb)
+            for (unsigned int b = hc[nb]; b < hc[nb + 1]; ++b) kmask_read |= 1ull << hr[b];
+        }
+      }
+    }
+    (void)hipGetLastError();
+  }
+  c->bcsc_bound.nnzb = nnzb_read; c->bcsc_bound.kmask0 = kmask_read;
   c->bcsc_bound.colptr = colptr; c->bcsc_bound.rowidx = rowidx; c->bcsc_bound.nblk_n = n_block_columns; c->bcsc_bound.d_table = table; c->bcsc_bound.nkb = nkb;
   c->device = cur_device();
   return EXIT_SUCCESS;

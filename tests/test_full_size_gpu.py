@@ -177,8 +177,8 @@ def test_config4_bcsc_full_batch_bf16_c(pattern_on):
     for _ in range(2):                                                          # the second call takes the cached / bound table
         capi.Api.call(h, p)
     api.hip_sync(); api.check()
-    # (a host pattern tells the library how large B is: 8 KiB here, kept in LDS by the kernel for whole 64 x 64 tiles)
-    assert api.hip_kernel_name(h, 0).decode() == ("bcsc_mfma_bf16_stream_full_kernel" if pattern_on == "host" else "bcsc_mfma_bf16_stream_kernel")
+    # (a host-resident or bound pattern tells the library how large B is: 8 KiB here, kept in LDS by the kernel for whole 64 x 64 tiles)
+    assert api.hip_kernel_name(h, 0).decode() == ("bcsc_mfma_bf16_stream_kernel" if pattern_on == "device" else "bcsc_mfma_bf16_stream_full_kernel")
     a_bits = _bf16_bits(A).numpy().view(np.uint16).reshape(-1).copy()
     bv_bits = _bf16_bits(Bv).numpy().view(np.uint16).copy()
     ref = np.zeros(mb * N * M, dtype=np.uint16)

@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
       const int ns = (int)std::max<size_t>(2, ((size_t)1 << 30) / (a_bytes + c_bytes) + 1);
       std::vector<void*> as_((size_t)ns), cs_((size_t)ns);
       for (int q = 0; q < ns; ++q) { CHECK(hipMalloc(&as_[(size_t)q], a_bytes)); CHECK(hipMemset(as_[(size_t)q], 0x31, a_bytes)); CHECK(hipMalloc(&cs_[(size_t)q], c_bytes)); }
-      for (unsigned int waves = 2048; waves <= 2048; waves *= 2)
+      for (unsigned int waves = 2048; waves <= 2048; waves *= 2)      // (4096 and 8192 waves measure the same: profiles/r06_copy_floor.txt history)
         for (int nt = 0; nt < 4; ++nt) {
           auto go = [&](int i) {
             const u32x4* ap = (const u32x4*)as_[(size_t)(i % ns)]; u32x4* cp = (u32x4*)cs_[(size_t)(i % ns)];
