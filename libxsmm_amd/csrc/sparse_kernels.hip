@@ -1049,14 +1049,18 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
 // to request) and one wait; four LDS-DMA requests into the slot just read; the MFMAs.  The ring slot is a run-time index, so the loop is not unrolled over slots.
 // The epilogue's LDS traffic is written as instructions: a ds_write / ds_read the compiler can see gets its s_waitcnt vmcnt(0) -- it cannot tell the C tile from
 // the ring the requests in flight write to -- which would wait for the next tile's first three chunks at every tile end.
-constexpr int kBcscRecs = 64;        // chunk records per wave
-template <int BN16, int AUX_A, bool EARLY>     // EARLY: one n-tile and the host's mask of its used k-blocks (BcscArgs::kmask0) -- the first three chunks are requested before anything is loaded
-__global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
-  constexpr int NBL = 4 / BN16, DA = 3, NI = 4, NS = 8;
-  __shared__ __attribute__((aligned(16))) unsigned int recs_all[4][kBcscRecs][4];
+constexpr int kBcscRecs = 64;        // chunk records per wave (ring depth 3; depth 2: half)
+// DA: depth of the A ring.  3: two workgroups per CU (78 KiB each).  2: THREE workgroups per CU -- ring 32 KiB, C leaving in quarters through 2 KiB per wave, B up to 8 KiB,
+// 32 records: 50 KiB -- the same 96 KiB of A in flight per CU spread over twelve waves instead of eight (what a wave does between its waits hides behind two others).
+template <int BN16, int AUX_A, bool EARLY, int DA>     // EARLY: one n-tile and the host's mask of its used k-blocks (BcscArgs::kmask0) -- the first three chunks are requested before anything is loaded
+__global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_full_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
+  static_assert(DA == 2 || DA == 3, "ring depth 2 or 3");
+  constexpr int NBL = 4 / BN16, NI = 4, NS = 8;
+  constexpr int RECS = DA == 2 ? kBcscRecs / 2 : kBcscRecs, BLDS = DA == 2 ? 8192 : kBcscBLds, CPASS = DA == 2 ? 4 : 2, TILEW = 2048 / CPASS;     // C leaves in CPASS passes of 64 / CPASS columns
+  __shared__ __attribute__((aligned(16))) unsigned int recs_all[4][RECS][4];
   __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][DA][1024];
-  __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][1024];              // 32 columns x 128 bytes: C leaves in two halves
-  __shared__ __attribute__((aligned(16))) unsigned int bimg[kBcscBLds / 4];
+  __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][TILEW];             // 64 / CPASS columns x 128 bytes
+  __shared__ __attribute__((aligned(16))) unsigned int bimg[BLDS / 4];
   const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned int wid = blockIdx.x * 4u + wave;
   // Start-up in ONE round trip to the L2 before the first A request leaves: the table rows of this wave's columns and the workgroup's share of B are asked for
@@ -1084,11 +1088,11 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
     src_off[x] = kp_l * (unsigned int)p.M + 4u * g;
   }
   // EARLY: the chunk list follows from the host's mask alone -- the first three chunks are requested without a look at the table
-  long long first[3] = {0ll, 0ll, 0ll};
+  long long first[DA] = {};
   if constexpr (EARLY) {
     const int nch_e = __builtin_popcountll(p.kmask0) * steps, total_e = nmb * nch_e;
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
+    for (int f = 0; f < DA; ++f) {
       if (f < total_e) {
         const int j = f / nch_e, c = f - j * nch_e, q = c / steps, st_ = c - q * steps;
         unsigned long long m = p.kmask0;
@@ -1102,8 +1106,8 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
   // are written as instructions: a register the compiler knows to be loaded is waited for with s_waitcnt vmcnt(0) while LDS-DMA requests are pending, whatever their
   // place in the queue -- here that would be the first three chunks of A (the wait statement names the registers, so nothing reads them before it).
   GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb + (lane < nkb ? lane : 0);
-  constexpr int BP = kBcscBLds / 16 / 256 + 1;          // 16-byte pieces of B per thread
-  static_assert(BP == 3, "the load statement below asks for three pieces");
+  constexpr int BP = 3;          // 16-byte pieces of B per thread
+  static_assert(BP * 256 * 16 >= BLDS, "the load statement below asks for three pieces per thread");
   const unsigned int pieces = (unsigned int)p.nnzb * (unsigned int)(p.bn * p.bk) / 8u;
   unsigned int trow[4]; u32x4v bpiece[BP];
   {
@@ -1119,12 +1123,12 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
   }
   if constexpr (EARLY) {
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
+    for (int f = 0; f < DA; ++f) {
 #pragma unroll
       for (int x = 0; x < NI; ++x)
         __builtin_amdgcn_global_load_lds((GM const void*)(A2 + first[f] + src_off[x]), (lds_ptr_t)((char*)abuf + 4096 * f + 1024 * x), 16, 0, AUX_A);
     }
-    asm volatile("s_waitcnt vmcnt(12)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]) :: "memory");
+    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]) : "n"(DA * NI) : "memory");
   } else
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]) :: "memory");
   if (lane >= nkb) { trow[0] = 0xffffffffu; trow[1] = 0xffffffffu; trow[2] = 0xffffffffu; trow[3] = 0xffffffffu; }
@@ -1157,11 +1161,12 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
   sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
   auto store_tile = [&](unsigned int mb) __attribute__((always_inline)) {        // C of M-block mb leaves; the accumulators restart at zero
     GM char* cbase = (GM char*)p.c + (long long)mb * c_mb_bytes;
-    sfor<2>([&](auto hc) {
+    constexpr int NTP = 4 / CPASS, RD = 4 / CPASS;      // 16-column sub-tiles and 1 KiB stores per pass
+    sfor<CPASS>([&](auto hc) {
       constexpr int h = hc.value;
-      sfor<8>([&](auto ic) {
-        constexpr int nt = 2 * h + ic.value / 4, it = ic.value % 4;
-        const int n = 16 * (nt - 2 * h) + lx;
+      sfor<4 * NTP>([&](auto ic) {
+        constexpr int nt = NTP * h + ic.value / 4, it = ic.value % 4;
+        const int n = 16 * (nt - NTP * h) + lx;
         const float x4[4] = {acc[nt][it][0], acc[nt][it][1], acc[nt][it][2], acc[nt][it][3]};
         unsigned int o2[2];
         bf16_pk_exact_n<2>(x4, o2);
@@ -1170,17 +1175,20 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
         asm volatile("ds_write_b64 %0, %1" :: "v"(wad), "v"(v) : "memory");
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      u32x4v w4[4]; unsigned int ad[4];
+      u32x4v w4[RD]; unsigned int ad[RD];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int n = 8 * r + (lane >> 3), j = lane & 7, x = n & 15; ad[r] = tile_lds + 4u * (unsigned int)(n * 32 + 4 * (j ^ (x >> 1))); }
-      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(w4[0]), "=&v"(w4[1]), "=&v"(w4[2]), "=&v"(w4[3]) : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]) : "memory");
+      for (int r = 0; r < RD; ++r) { const int n = 8 * r + (lane >> 3), j = lane & 7, x = n & 15; ad[r] = tile_lds + 4u * (unsigned int)(n * 32 + 4 * (j ^ (x >> 1))); }
+      if constexpr (RD == 4)
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(w4[0]), "=&v"(w4[1]), "=&v"(w4[2]), "=&v"(w4[3]) : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]) : "memory");
+      else
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w4[0]), "=&v"(w4[1]) : "v"(ad[0]), "v"(ad[1]) : "memory");
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < RD; ++r) {
         const int n = 8 * r + (lane >> 3), j = lane & 7, x = n & 15;
         u32x4v w = w4[r];
         if (x & 1) { const unsigned int t0 = w[0], t1 = w[1]; w[0] = w[2]; w[1] = w[3]; w[2] = t0; w[3] = t1; }
-        GM u32x4v* dst = (GM u32x4v*)(cbase + ((long long)(n0 + 32 * h + n) * p.M + i0) * 2 + 16 * j);
+        GM u32x4v* dst = (GM u32x4v*)(cbase + ((long long)(n0 + 16 * NTP * h + n) * p.M + i0) * 2 + 16 * j);
         if (AUX_A != 0) __builtin_nontemporal_store(w, dst); else *dst = w;
       }
     });
@@ -1206,7 +1214,7 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
 #pragma unroll
     for (int x = 0; x < NI; ++x)
       __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)(dst + 1024 * x), 16, 0, AUX_A);
-    a_slot = (a_slot == 2u) ? 0u : a_slot + 1u;
+    a_slot = (a_slot == (unsigned int)(DA - 1)) ? 0u : a_slot + 1u;
     if (++ac_ == nch) { ac_ = 0; ++aj; }
   };
   // B arrived with the table (one round trip); it is in LDS before the first A request leaves, and the barrier below is a bare s_barrier: nothing waits for those requests
@@ -1222,7 +1230,7 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
   for (int e = 0; e < 4; ++e) rec_c[e] = (unsigned int)__builtin_amdgcn_readlane((int)rec_mine[e], 0);
   // (all three offsets are read before the first request leaves: a read of LDS the compiler can see waits for every request in flight)
 #pragma unroll
-  for (int f = 0; f < 3; ++f) {
+  for (int f = 0; f < DA; ++f) {
     const bool real = f < total_f;
     const unsigned int a_off = real ? (unsigned int)__builtin_amdgcn_readlane((int)rec_mine[0], ac_) : 0u;
     if constexpr (!EARLY) first[f] = real ? (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + a_off : 0ll;
@@ -1230,7 +1238,7 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
   }
   if constexpr (!EARLY) {
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {
+    for (int f = 0; f < DA; ++f) {
 #pragma unroll
       for (int x = 0; x < NI; ++x)
         __builtin_amdgcn_global_load_lds((GM const void*)(A2 + first[f] + src_off[x]), (lds_ptr_t)((char*)abuf + 4096 * f + 1024 * x), 16, 0, AUX_A);
@@ -1242,12 +1250,12 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
   int cj = 0, cc = 0;                         // the chunk being consumed
   unsigned int c_slot = 0;
   for (int f = 0; f < total_f; ++f) {
-    // chunk f must have landed; behind it in issue order: A(f+1), A(f+2) as far as they exist, and the 8 stores of the previous tile while this chunk is one of the
-    // first three of its tile (A(f) was requested three chunks earlier, in front of them); loads and stores retire this counter in issue order on gfx9
+    // chunk f must have landed; behind it in issue order: A(f+1) .. A(f+DA-1) as far as they exist, and the 8 stores of the previous tile while this chunk is one of the
+    // first DA of its tile (A(f) was requested DA chunks earlier, in front of them); loads and stores retire this counter in issue order on gfx9
     const int left = total_f - 1 - f;
-    const bool stored = cj > 0 && cc < 3;
-    if (left >= 2) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NI) : "memory"); }
-    else if (left == 1) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory"); }
+    const bool stored = cj > 0 && cc < DA;
+    if (left >= DA - 1) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DA - 1) * NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DA - 1) * NI) : "memory"); }
+    else if (DA == 3 && left == 1) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory"); }
     else if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned int r1 = (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_c[1]), r2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_c[2]);
@@ -1281,7 +1289,7 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
     for (int t = 0; t < 4; ++t) { a_cur[t][0] = ap[2 * t][0]; a_cur[t][1] = ap[2 * t][1]; a_cur[t][2] = ap[2 * t + 1][0]; a_cur[t][3] = ap[2 * t + 1][1]; }
     u32x4v bf_c[NBL][BN16];
     sfor<4>([&](auto ic) { bf_c[ic.value / BN16][ic.value % BN16] = bq[ic.value]; });
-    if (left >= 3) issue_a((unsigned int)__builtin_amdgcn_readfirstlane((int)a_off_v));        // into the slot just read
+    if (left >= DA) issue_a((unsigned int)__builtin_amdgcn_readfirstlane((int)a_off_v));        // into the slot just read
     sfor<NBL>([&](auto nc) {
       constexpr int nbl = nc.value;
       if (bo[nbl] != 0xffffu) {
@@ -1295,7 +1303,7 @@ __global__ __launch_bounds__(256, 2) void bcsc_mfma_bf16_stream_full_kernel(Bcsc
       }
     });
     rec_c = rec_n;
-    c_slot = (c_slot == 2u) ? 0u : c_slot + 1u;
+    c_slot = (c_slot == (unsigned int)(DA - 1)) ? 0u : c_slot + 1u;
     if (++cc == nch) { store_tile(g0 + (unsigned int)cj * mbg); cc = 0; ++cj; }
   }
 }
@@ -1494,30 +1502,36 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
           constexpr int stream_mode = 1;
           const long long tt_count = (long long)tiles_i * tiles_n;
           if (stream_mode != 0 && a.beta0 && nkb <= 64 && tt_count <= 2048 && ((long long)a.m_blocks * tt_count >= 4096 || stream_mode == 2) && ((long long)(a.K / 2) * a.M) * (long long)a.m_blocks < (1ll << 40)) {
-            constexpr long long slots_env = 0ll;
-            // 32 rows per wave (RT = 2: 161 VGPRs, three waves per SIMD) measured 72 us against 61 us: every B fragment then feeds two MFMAs instead of four
-            const long long slots = slots_env > 0 ? slots_env : 2048;      // two waves per SIMD (245 VGPRs); three (168 VGPRs) spill inside the chunk loop: 105 instead of 61 us
-            long long mbg = std::min<long long>(a.m_blocks, std::max<long long>(1, slots / tt_count));
-            const long long per = (a.m_blocks + mbg - 1) / mbg;
-            mbg = (a.m_blocks + per - 1) / per;
-            const long long waves = mbg * tt_count;
-            const dim3 sgrid((unsigned int)((waves + 3) / 4));
             // a value array that fits beside the rings: every workgroup keeps its own LDS copy of B and no wave asks the L2 for a
             // fragment again (bn = 32: 39.5 -> 35.7 us on 8192 M-blocks of 64 x 256, bn = 16 unchanged; profiles/r06_bcsc_b_in_lds.jsonl)
             const bool b_lds = a.nnzb > 0 && (long long)a.nnzb * a.bn * a.bk * 2 <= kBcscBLds && ((size_t)a.bvals % 16 == 0);
             // ... and whole 64 x 64 tiles with bf16 C: the kernel with one record per chunk
             const bool full = b_lds && a.c_type == LIBXSMM_DATATYPE_BF16 && a.M % 64 == 0 && a.N % 64 == 0 && ((size_t)a.c % 16 == 0) && nkb * (a.bk / 32) <= kBcscRecs;
+            // ... on three workgroups per CU (ring depth 2) when B and the record list fit the smaller LDS plan
+#if !defined(XAMD_BCSC_THREE)
+#define XAMD_BCSC_THREE 1           // (A/B builds: 0 keeps ring depth 3 on two workgroups per CU)
+#endif
+            const bool three = XAMD_BCSC_THREE != 0 && full && (long long)a.nnzb * a.bn * a.bk * 2 <= 8192 && nkb * (a.bk / 32) <= kBcscRecs / 2;
+            // 32 rows per wave (RT = 2: 161 VGPRs, three waves per SIMD) measured 72 us against 61 us: every B fragment then feeds two MFMAs instead of four
+            const long long slots = three ? 3072 : 2048;      // waves per round: two per SIMD (the general kernel: 245 VGPRs; three spill inside the chunk loop: 105 instead of 61 us), three for `three`
+            long long mbg = std::min<long long>(a.m_blocks, std::max<long long>(1, slots / tt_count));
+            const long long per = (a.m_blocks + mbg - 1) / mbg;
+            mbg = (a.m_blocks + per - 1) / per;
+            const long long waves = mbg * tt_count;
+            const dim3 sgrid((unsigned int)((waves + 3) / 4));
             if (full) {
               const bool early = tiles_n == 1;          // (kmask0 describes the first n-tile)
 #if !defined(XAMD_BCSC_AUX_NT)
-#define XAMD_BCSC_AUX_NT 2          // cache-policy bits of the A requests of a launch that streams (A/B builds: 3, 16, 18, ...)
+#define XAMD_BCSC_AUX_NT 2          // cache-policy bits of the A requests of a launch that streams (A/B builds: 3, 16, 18: profiles/r06_bcsc_full.jsonl)
 #endif
-#define LAUNCH_FULL_(B_) do { if (early) { if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, XAMD_BCSC_AUX_NT, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
-                                           else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } \
-                              else if (nta) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 2, false>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
-                              else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0, false>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
+#define LAUNCH_FULL4_(B_, X_, E_, D_) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, X_, E_, D_>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table)
+#define LAUNCH_FULL3_(B_, X_, E_) do { if (three) LAUNCH_FULL4_(B_, X_, E_, 2); else LAUNCH_FULL4_(B_, X_, E_, 3); } while (0)
+#define LAUNCH_FULL_(B_) do { if (early) { if (nta) LAUNCH_FULL3_(B_, XAMD_BCSC_AUX_NT, true); else LAUNCH_FULL3_(B_, 0, true); } \
+                              else if (nta) LAUNCH_FULL3_(B_, XAMD_BCSC_AUX_NT, false); else LAUNCH_FULL3_(B_, 0, false); } while (0)
               if (a.bn == 16) LAUNCH_FULL_(1); else if (a.bn == 32) LAUNCH_FULL_(2); else LAUNCH_FULL_(4);
 #undef LAUNCH_FULL_
+#undef LAUNCH_FULL3_
+#undef LAUNCH_FULL4_
               if (name) *name = "bcsc_mfma_bf16_stream_full_kernel";
               return (int)hipGetLastError();
             }

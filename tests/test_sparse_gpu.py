@@ -453,6 +453,35 @@ def test_packed_csc_csparse(M, N, K, P, density, beta0):
 
 # many M-blocks per tile: waves that keep their (i-tile, n-tile) and stream over the M-blocks (bcsc_mfma_bf16_stream_kernel); ragged tiles in both
 # directions, every wave with a different number of M-blocks, bf16 (C through LDS) and f32 (direct) output, one n-tile without any block
+def test_bcsc_bf16_full_kernel_two_workgroups_per_cu():
+    """A value array of B between 8 and 10 KiB: the full-tile streaming kernel on its first LDS plan (ring depth 3, two workgroups per CU; up to 8 KiB the
+    launcher takes ring depth 2 and three workgroups).  Block columns with 3, 2, 2 and 3 blocks of 32 x 16: ten blocks = 10 KiB, up to three blocks per chunk."""
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(29)
+    M, N, K, mb, bk, bn = 64, 64, 256, 4200, 32, 16
+    rows = [np.sort(rng.choice(K // bk, size=c, replace=False)) for c in (3, 2, 2, 3)]
+    colptr = np.array([0, 3, 5, 7, 10], dtype=np.uint32); rowidx = np.concatenate(rows).astype(np.uint32)
+    bvals = rand_values(rng, 10 * bn * bk, DT.BF16)
+    A_run = pack_vnni2(rand_values(rng, mb * K * M, DT.BF16), mb, K, M)
+    C0 = rand_values(rng, mb * N * M, DT.BF16)
+    ref = C0.copy()
+    orc.lib.oracle_packed_spgemm_bcsc(DT.BF16, DT.BF16, M, N, K, mb, bk, bn, 1, A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, 1)
+    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, DT.BF16, DT.BF16, DT.BF16, DT.F32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    dA, dB, dC = _dev(A_run), _dev(bvals), _dev(C0.copy())
+    nblk = C.c_ulonglong(N // bn)
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = dA.data_ptr(), dB.data_ptr(), colptr.ctypes.data, rowidx.ctypes.data, C.addressof(nblk), dC.data_ptr()
+    for hint in (0, 2):                            # cacheable and non-temporal instance
+        api.hip_set_streaming_hint(hint)
+        capi.Api.call(h, p)
+        api.hip_sync(); api.check()
+        assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_bf16_stream_full_kernel"
+        assert normf_rel(ref, _host(dC, np.uint16), DT.BF16) <= 5e-3
+    api.hip_set_streaming_hint(0)
+    api.release_kernel(h)
+
+
 # host pattern (the reference's convention): the value array of B is known to fit in LDS -- the general kernel with B in LDS, and for whole 64 x 64 tiles with bf16 C the
 # kernel with one record per chunk (bcsc_mfma_bf16_stream_full_kernel): several n-tiles per workgroup, two 32-deep steps per k-block, an n-tile without blocks, a wave
 # with a single chunk, more workgroup slots than waves
