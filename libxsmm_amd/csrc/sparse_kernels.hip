@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
   sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
   auto store_tile = [&](unsigned int mb) __attribute__((always_inline)) {        // C of M-block mb leaves; the accumulators restart at zero
     GM char* cbase = (GM char*)p.c + (long long)mb * c_mb_bytes;
-    constexpr int NTP = 4 / CPASS, RD = 4 / CPASS;      // 16-column sub-tiles and 1 KiB stores per pass
+    constexpr int NTP = 4 / CPASS, RD = 8 / CPASS;      // 16-column sub-tiles and 1 KiB stores per pass
     sfor<CPASS>([&](auto hc) {
       constexpr int h = hc.value;
       sfor<4 * NTP>([&](auto ic) {
@@ -1509,8 +1509,8 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
             const bool full = b_lds && a.c_type == LIBXSMM_DATATYPE_BF16 && a.M % 64 == 0 && a.N % 64 == 0 && ((size_t)a.c % 16 == 0) && nkb * (a.bk / 32) <= kBcscRecs;
             // ... on three workgroups per CU (ring depth 2) when B and the record list fit the smaller LDS plan
 #if !defined(XAMD_BCSC_THREE)
-#define XAMD_BCSC_THREE 1           // (A/B builds: 0 keeps ring depth 3 on two workgroups per CU)
-#endif
+#define XAMD_BCSC_THREE 0           // measured equal to ring depth 3 on two workgroups per CU (config #4 52.1-52.3 against 52.3-52.4 us, 32 768 M-blocks 213.8 against 209.4: the kernel is
+#endif                              // bound by the memory system, not by what a wave does between its waits; profiles/r06_bcsc_three.jsonl) -- not instantiated unless built with -DXAMD_BCSC_THREE=1
             const bool three = XAMD_BCSC_THREE != 0 && full && (long long)a.nnzb * a.bn * a.bk * 2 <= 8192 && nkb * (a.bk / 32) <= kBcscRecs / 2;
             // 32 rows per wave (RT = 2: 161 VGPRs, three waves per SIMD) measured 72 us against 61 us: every B fragment then feeds two MFMAs instead of four
             const long long slots = three ? 3072 : 2048;      // waves per round: two per SIMD (the general kernel: 245 VGPRs; three spill inside the chunk loop: 105 instead of 61 us), three for `three`
@@ -1525,7 +1525,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
 #define XAMD_BCSC_AUX_NT 2          // cache-policy bits of the A requests of a launch that streams (A/B builds: 3, 16, 18: profiles/r06_bcsc_full.jsonl)
 #endif
 #define LAUNCH_FULL4_(B_, X_, E_, D_) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, X_, E_, D_>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table)
-#define LAUNCH_FULL3_(B_, X_, E_) do { if (three) LAUNCH_FULL4_(B_, X_, E_, 2); else LAUNCH_FULL4_(B_, X_, E_, 3); } while (0)
+#define LAUNCH_FULL3_(B_, X_, E_) do { if constexpr (XAMD_BCSC_THREE != 0) { if (three) LAUNCH_FULL4_(B_, X_, E_, 2); else LAUNCH_FULL4_(B_, X_, E_, 3); } else LAUNCH_FULL4_(B_, X_, E_, 3); } while (0)
 #define LAUNCH_FULL_(B_) do { if (early) { if (nta) LAUNCH_FULL3_(B_, XAMD_BCSC_AUX_NT, true); else LAUNCH_FULL3_(B_, 0, true); } \
                               else if (nta) LAUNCH_FULL3_(B_, XAMD_BCSC_AUX_NT, false); else LAUNCH_FULL3_(B_, 0, false); } while (0)
               if (a.bn == 16) LAUNCH_FULL_(1); else if (a.bn == 32) LAUNCH_FULL_(2); else LAUNCH_FULL_(4);
