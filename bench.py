@@ -563,7 +563,7 @@ def stale_profile_rows(measured):
         return None
     stale = []
     # names the library reports for a template instance of another kernel / for a launch of several kernels (the table holds the first symbol of the launch)
-    alias = {"bcsc_mfma_f32_stream_kernel": "bcsc_mfma_bf16_stream_kernel", "gemm_fp8c8_stream_kernel": "gemm_fp8_stream_kernel", "gemm_bf32_stream_kernel": "gemm_f32_stream_kernel",
+    alias = {"bcsc_mfma_f32_stream_kernel": "bcsc_mfma_bf16_stream_kernel", "bcsc_mfma_f32_stream_full_kernel": "bcsc_mfma_bf16_stream_full_kernel", "gemm_fp8c8_stream_kernel": "gemm_fp8_stream_kernel", "gemm_bf32_stream_kernel": "gemm_f32_stream_kernel",
              "gemm_bitmask_reg_kernel": "bitmask_prepass_kernel", "gemm_i4_stream_kernel": "gemm_i8_stream_kernel", "gemm_i2_stream_kernel": "gemm_i8_stream_kernel",
              "gemm_i1_stream_kernel": "gemm_i8_stream_kernel", "gemm_bf16_wgp_kernel": "gemm_wgp16_kernel", "gemm_f16_wgp_kernel": "gemm_wgp16_kernel", "gemm_bf16_w64_kernel": "gemm_16bit_w64_kernel", "gemm_f16_w64_kernel": "gemm_16bit_w64_kernel",
              "gemm_8bit_wgp_kernel": "gemm_wgp8_kernel", "gemm_w8_wgp_kernel": "gemm_wgp16_kernel", "reduce_vec_kernel": "reduce_combine_kernel"}        # (the big column reduction is two kernels per call: partial sums, then their combination)

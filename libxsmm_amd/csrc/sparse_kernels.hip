@@ -1052,11 +1052,14 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
 constexpr int kBcscRecs = 64;        // chunk records per wave (ring depth 3; depth 2: half)
 // DA: depth of the A ring.  3: two workgroups per CU (78 KiB each).  2: THREE workgroups per CU -- ring 32 KiB, C leaving in quarters through 2 KiB per wave, B up to 8 KiB,
 // 32 records: 50 KiB -- the same 96 KiB of A in flight per CU spread over twelve waves instead of eight (what a wave does between its waits hides behind two others).
-template <int BN16, int AUX_A, bool EARLY, int DA>     // EARLY: one n-tile and the host's mask of its used k-blocks (BcscArgs::kmask0) -- the first three chunks are requested before anything is loaded
+// F32: f32 operands and f32 C on v_mfma_f32_16x16x4_f32 -- a chunk is 16 k of 64 rows (the same 4 KiB image, a row is one k instead of a k pair), B up to 16 KiB in LDS,
+// C leaves through LDS eight columns at a time (2 KiB per wave: what is left next to two workgroups' rings)
+template <int BN16, int AUX_A, bool EARLY, int DA, bool F32 = false>     // EARLY: one n-tile and the host's mask of its used k-blocks (BcscArgs::kmask0) -- the first three chunks are requested before anything is loaded
 __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_full_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
   static_assert(DA == 2 || DA == 3, "ring depth 2 or 3");
-  constexpr int NBL = 4 / BN16, NI = 4, NS = 8;
-  constexpr int RECS = DA == 2 ? kBcscRecs / 2 : kBcscRecs, BLDS = DA == 2 ? 8192 : kBcscBLds, CPASS = DA == 2 ? 4 : 2, TILEW = 2048 / CPASS;     // C leaves in CPASS passes of 64 / CPASS columns
+  static_assert(!(F32 && DA == 2), "the f32 form has one LDS plan");
+  constexpr int NBL = 4 / BN16, NI = 4, NS = F32 ? 16 : 8;          // NS: stores of one tile
+  constexpr int RECS = DA == 2 ? kBcscRecs / 2 : kBcscRecs, BLDS = F32 ? 16384 : (DA == 2 ? 8192 : kBcscBLds), CPASS = DA == 2 ? 4 : 2, TILEW = F32 ? 512 : 2048 / CPASS;     // C leaves in CPASS passes of 64 / CPASS columns
   __shared__ __attribute__((aligned(16))) unsigned int recs_all[4][RECS][4];
   __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][DA][1024];
   __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][TILEW];             // 64 / CPASS columns x 128 bytes
@@ -1076,11 +1079,11 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
   const unsigned int tn = tt % tiles_n, ti = tt / tiles_n;
   const int i0 = (int)ti * 64, n0 = (int)tn * 64;
   const int nb0 = n0 / (16 * BN16);
-  const int nkb = p.K / p.bk, steps = p.bk / 32;
+  const int nkb = p.K / p.bk, steps = F32 ? p.bk / 16 : p.bk / 32, kw = F32 ? p.bk : p.bk / 2;          // kw: image rows (words per matrix row) of a k-block
   const int nmb = (live && (unsigned int)p.m_blocks > g0) ? (int)(((unsigned int)p.m_blocks - g0 + mbg - 1u) / mbg) : 0;
   // DMA source of LDS slot (lane + 64 x): row kp_l = slot >> 4, the 16-byte group that lands there = (slot & 15) rotated back
   GM const unsigned int* A2 = (GM const unsigned int*)p.a + i0;
-  const long long a_mb_words = (long long)(p.K / 2) * p.M;
+  const long long a_mb_words = (long long)(F32 ? p.K : p.K / 2) * p.M;
   unsigned int src_off[NI];
 #pragma unroll
   for (int x = 0; x < NI; ++x) {
@@ -1098,7 +1101,7 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
         unsigned long long m = p.kmask0;
         for (int z = 0; z < q; ++z) m &= m - 1ull;
         const unsigned int kb = (unsigned int)__builtin_ctzll(m);
-        first[f] = (long long)(g0 + (unsigned int)j * mbg) * a_mb_words + (long long)((kb * (unsigned int)(p.bk / 2) + 16u * (unsigned int)st_) * (unsigned int)p.M);
+        first[f] = (long long)(g0 + (unsigned int)j * mbg) * a_mb_words + (long long)((kb * (unsigned int)kw + 16u * (unsigned int)st_) * (unsigned int)p.M);
       }
     }
   }
@@ -1106,9 +1109,9 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
   // are written as instructions: a register the compiler knows to be loaded is waited for with s_waitcnt vmcnt(0) while LDS-DMA requests are pending, whatever their
   // place in the queue -- here that would be the first three chunks of A (the wait statement names the registers, so nothing reads them before it).
   GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb + (lane < nkb ? lane : 0);
-  constexpr int BP = 3;          // 16-byte pieces of B per thread
-  static_assert(BP * 256 * 16 >= BLDS, "the load statement below asks for three pieces per thread");
-  const unsigned int pieces = (unsigned int)p.nnzb * (unsigned int)(p.bn * p.bk) / 8u;
+  constexpr int BP = F32 ? 4 : 3;          // 16-byte pieces of B per thread
+  static_assert(BP * 256 * 16 >= BLDS, "the load statements below ask for three (f32: four) pieces per thread");
+  const unsigned int pieces = (unsigned int)p.nnzb * (unsigned int)(p.bn * p.bk) / (F32 ? 4u : 8u);
   unsigned int trow[4]; u32x4v bpiece[BP];
   {
     GM const unsigned int* tp[4]; GM const u32x4v* bp_[BP];
@@ -1116,10 +1119,16 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
     for (int nbl = 0; nbl < 4; ++nbl) tp[nbl] = gt + (nbl < NBL ? nbl : NBL - 1) * nkb;
 #pragma unroll
     for (int e = 0; e < BP; ++e) { const unsigned int x = threadIdx.x + 256u * e; bp_[e] = (GM const u32x4v*)p.bvals + (x < pieces ? x : 0u); }
-    asm volatile("global_load_dword %0, %7, off\n\tglobal_load_dword %1, %8, off\n\tglobal_load_dword %2, %9, off\n\tglobal_load_dword %3, %10, off\n\t"
-                 "global_load_dwordx4 %4, %11, off\n\tglobal_load_dwordx4 %5, %12, off\n\tglobal_load_dwordx4 %6, %13, off"
-                 : "=&v"(trow[0]), "=&v"(trow[1]), "=&v"(trow[2]), "=&v"(trow[3]), "=&v"(bpiece[0]), "=&v"(bpiece[1]), "=&v"(bpiece[2])
-                 : "v"(tp[0]), "v"(tp[1]), "v"(tp[2]), "v"(tp[3]), "v"(bp_[0]), "v"(bp_[1]), "v"(bp_[2]) : "memory");
+    if constexpr (BP == 3)
+      asm volatile("global_load_dword %0, %7, off\n\tglobal_load_dword %1, %8, off\n\tglobal_load_dword %2, %9, off\n\tglobal_load_dword %3, %10, off\n\t"
+                   "global_load_dwordx4 %4, %11, off\n\tglobal_load_dwordx4 %5, %12, off\n\tglobal_load_dwordx4 %6, %13, off"
+                   : "=&v"(trow[0]), "=&v"(trow[1]), "=&v"(trow[2]), "=&v"(trow[3]), "=&v"(bpiece[0]), "=&v"(bpiece[1]), "=&v"(bpiece[2])
+                   : "v"(tp[0]), "v"(tp[1]), "v"(tp[2]), "v"(tp[3]), "v"(bp_[0]), "v"(bp_[1]), "v"(bp_[2]) : "memory");
+    else
+      asm volatile("global_load_dword %0, %8, off\n\tglobal_load_dword %1, %9, off\n\tglobal_load_dword %2, %10, off\n\tglobal_load_dword %3, %11, off\n\t"
+                   "global_load_dwordx4 %4, %12, off\n\tglobal_load_dwordx4 %5, %13, off\n\tglobal_load_dwordx4 %6, %14, off\n\tglobal_load_dwordx4 %7, %15, off"
+                   : "=&v"(trow[0]), "=&v"(trow[1]), "=&v"(trow[2]), "=&v"(trow[3]), "=&v"(bpiece[0]), "=&v"(bpiece[1]), "=&v"(bpiece[2]), "=&v"(bpiece[BP - 1])
+                   : "v"(tp[0]), "v"(tp[1]), "v"(tp[2]), "v"(tp[3]), "v"(bp_[0]), "v"(bp_[1]), "v"(bp_[2]), "v"(bp_[BP - 1]) : "memory");
   }
   if constexpr (EARLY) {
 #pragma unroll
@@ -1128,9 +1137,12 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
       for (int x = 0; x < NI; ++x)
         __builtin_amdgcn_global_load_lds((GM const void*)(A2 + first[f] + src_off[x]), (lds_ptr_t)((char*)abuf + 4096 * f + 1024 * x), 16, 0, AUX_A);
     }
-    asm volatile("s_waitcnt vmcnt(%7)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]) : "n"(DA * NI) : "memory");
-  } else
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]) :: "memory");
+    if constexpr (BP == 3) asm volatile("s_waitcnt vmcnt(%7)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]) : "n"(DA * NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]), "+v"(bpiece[BP - 1]) : "n"(DA * NI) : "memory");
+  } else {
+    if constexpr (BP == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]) :: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]), "+v"(bpiece[2]), "+v"(bpiece[BP - 1]) :: "memory");
+  }
   if (lane >= nkb) { trow[0] = 0xffffffffu; trow[1] = 0xffffffffu; trow[2] = 0xffffffffu; trow[3] = 0xffffffffu; }
   // one record per chunk, lane c building chunk c's -- without a look at LDS the compiler can see (an LDS access it sees while requests are in flight gets its
   // s_waitcnt vmcnt(0)): the used k-blocks are bits of a mask, the table row of another lane comes through a cross-lane read, the record leaves as an instruction
@@ -1150,17 +1162,44 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
 #pragma unroll
     for (int nbl = 0; nbl < NBL; ++nbl) {
       const unsigned int blk = (unsigned int)__shfl((int)trow[nbl], (int)kb);
-      if (blk != 0xffffffffu) bo[nbl] = (blk * (unsigned int)(16 * BN16) * (unsigned int)p.bk + 32u * (unsigned int)st_) * 2u;
+      if (blk != 0xffffffffu) bo[nbl] = (blk * (unsigned int)(16 * BN16) * (unsigned int)p.bk + (F32 ? 16u : 32u) * (unsigned int)st_) * (F32 ? 4u : 2u);
     }
-    rec_mine[0] = (kb * (unsigned int)(p.bk / 2) + 16u * (unsigned int)st_) * (unsigned int)p.M; rec_mine[1] = bo[0] | (bo[1] << 16); rec_mine[2] = bo[2] | (bo[3] << 16); rec_mine[3] = 0u;
+    rec_mine[0] = (kb * (unsigned int)kw + 16u * (unsigned int)st_) * (unsigned int)p.M; rec_mine[1] = bo[0] | (bo[1] << 16); rec_mine[2] = bo[2] | (bo[3] << 16); rec_mine[3] = 0u;
     const unsigned int rad = recs_lds + 16u * (unsigned int)lane;
     if (lane < nch) asm volatile("ds_write_b128 %0, %1" :: "v"(rad), "v"(rec_mine) : "memory");
   }
-  const long long c_mb_bytes = (long long)p.N * p.M * 2;
+  const long long c_mb_bytes = (long long)p.N * p.M * (F32 ? 4 : 2);
   f32x4v acc[4][4];
   sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
   auto store_tile = [&](unsigned int mb) __attribute__((always_inline)) {        // C of M-block mb leaves; the accumulators restart at zero
     GM char* cbase = (GM char*)p.c + (long long)mb * c_mb_bytes;
+    if constexpr (F32) {
+      // A lane holds 16 bytes of a column in each of its four row tiles: 64-byte pieces of 16 different lines per store.  Through LDS instead, eight columns (2 KiB) at a
+      // time -- the lanes of one half of the sub-tile write their four pieces, every lane reads 16 bytes of the linear image back: two 1 KiB stores per pass, sixteen
+      // per tile (118 -> 110 us with the stores alone made contiguous, profiles/r06_bcsc_f32_full.jsonl).  The 16-byte slot of a column is XORed with the column number.
+      sfor<8>([&](auto pc) {
+        constexpr int nt = pc.value / 2, half = pc.value % 2;
+        if ((lx >> 3) == half) {
+          const unsigned int c = (unsigned int)lx & 7u;
+          sfor<4>([&](auto tc) {
+            constexpr int it = tc.value;
+            const unsigned int wad = tile_lds + c * 256u + 16u * ((unsigned int)(4 * it + kg) ^ c);
+            const f32x4v v = acc[nt][it];
+            asm volatile("ds_write_b128 %0, %1" :: "v"(wad), "v"(v) : "memory");
+          });
+        }
+        f32x4v w2[2]; unsigned int ad[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const unsigned int c = 4u * j + ((unsigned int)lane >> 4), sl = (unsigned int)lane & 15u; ad[j] = tile_lds + c * 256u + 16u * (sl ^ c); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w2[0]), "=&v"(w2[1]) : "v"(ad[0]), "v"(ad[1]) : "memory");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = 4 * j + (lane >> 4), sl = lane & 15;
+          GM f32x4v* dst = (GM f32x4v*)(cbase + ((long long)(n0 + 16 * nt + 8 * half + c) * p.M + i0) * 4 + 16 * sl);
+          if (AUX_A != 0) __builtin_nontemporal_store(w2[j], dst); else *dst = w2[j];
+        }
+      });
+    } else {
     constexpr int NTP = 4 / CPASS, RD = 8 / CPASS;      // 16-column sub-tiles and 1 KiB stores per pass
     sfor<CPASS>([&](auto hc) {
       constexpr int h = hc.value;
@@ -1192,6 +1231,7 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
         if (AUX_A != 0) __builtin_nontemporal_store(w, dst); else *dst = w;
       }
     });
+    }
     sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (f32x4v)0.0f; });
   };
   const int rot = 16 * (kg & 1);
@@ -1200,7 +1240,7 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
   for (int t = 0; t < 4; ++t) a_rd[t] = (unsigned int)((4 * kg) * 64 + ((16 * t + lx + rot) & 63));
   unsigned int b_rd[BN16];                    // byte offset of this lane's piece inside a block's fragment (sub-tile s2)
 #pragma unroll
-  for (int s2 = 0; s2 < BN16; ++s2) b_rd[s2] = (unsigned int)(((16 * s2 + lx) * p.bk + 8 * kg) * 2);
+  for (int s2 = 0; s2 < BN16; ++s2) b_rd[s2] = (unsigned int)(((16 * s2 + lx) * p.bk + (F32 ? 4 : 8) * kg) * (F32 ? 4 : 2));
   const int total_f = nmb * nch;             // (0 for a wave beyond the last one)
   int aj = 0, ac_ = 0;                        // the NEXT chunk whose A is to be requested
   unsigned int a_slot = 0;                    // ... and the ring slot it goes to
@@ -1297,7 +1337,13 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
           constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
           sfor<4>([&](auto tc) {
             constexpr int t = tc.value;
-            acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a_cur[t]), __builtin_bit_cast(bf16x8v, bf_c[nbl][s2]), acc[nt][t], 0, 0, 0);
+            if constexpr (F32) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {     // (through scalars: see the general kernel)
+                const unsigned int av = a_cur[t][e], bw = bf_c[nbl][s2][e];
+                acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av), __uint_as_float(bw), acc[nt][t], 0, 0, 0);
+              }
+            } else acc[nt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a_cur[t]), __builtin_bit_cast(bf16x8v, bf_c[nbl][s2]), acc[nt][t], 0, 0, 0);
           });
         });
       }
@@ -1583,6 +1629,18 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
           mbg = (a.m_blocks + per - 1) / per;
           const long long waves = mbg * tt_count;
           const dim3 sgrid((unsigned int)((waves + 3) / 4));
+          // host-resident / bound pattern, whole 64 x 64 tiles, B up to 16 KiB: the kernel with one record per chunk (see bcsc_mfma_bf16_stream_full_kernel)
+          if (a.nnzb > 0 && (long long)a.nnzb * a.bn * a.bk * 4 <= 16384 && ((size_t)a.bvals % 16 == 0) && a.M % 64 == 0 && a.N % 64 == 0 && nkb * (a.bk / 16) <= kBcscRecs) {
+            const bool early = tiles_n == 1;
+#define LAUNCH_FULL_F32_(B_) do { if (early) { if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 2, true, 3, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+                                               else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0, true, 3, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } \
+                                  else if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 2, false, 3, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+                                  else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, 0, false, 3, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
+            if (a.bn == 16) LAUNCH_FULL_F32_(1); else if (a.bn == 32) LAUNCH_FULL_F32_(2); else LAUNCH_FULL_F32_(4);
+#undef LAUNCH_FULL_F32_
+            if (name) *name = "bcsc_mfma_f32_stream_full_kernel";
+            return (int)hipGetLastError();
+          }
 #define LAUNCH_STREAM_F32_(B_) do { if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 2, 4, 2, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
                                     else hipLaunchKernelGGL((bcsc_mfma_bf16_stream_kernel<B_, 0, 4, 2, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
           if (a.bn == 16) LAUNCH_STREAM_F32_(1); else if (a.bn == 32) LAUNCH_STREAM_F32_(2); else LAUNCH_STREAM_F32_(4);

@@ -112,7 +112,8 @@ def test_config4_bcsc_full_batch():
     api.release_kernel(h)
 
 
-def test_config4_bcsc_full_batch_f32():
+@pytest.mark.parametrize("pattern_on", ["device", "host"])
+def test_config4_bcsc_full_batch_f32(pattern_on):
     """config #4's shape in f32 (`spmm_kernel F32 F32 F32 F32 64 64 256 8192 ...`) at full size on the waves streaming over M-blocks (round 3): every 127th M-block
     (and the last one) against the gold loop [ref: spmm_kernel.c:74-217], all blocks through linearity in A (eighths: sums stay exact in f32)."""
     import torch
@@ -132,10 +133,12 @@ def test_config4_bcsc_full_batch_f32():
         dA, dC = A.cuda(), torch.full((mb * N * M,), float("nan"), dtype=torch.float32, device="cuda")
         p = capi.GemmParam()
         p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = dA.data_ptr(), dBv.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), dC.data_ptr()
+        if pattern_on == "host":
+            p.b.secondary, p.b.tertiary = colptr.ctypes.data, rowidx.ctypes.data
         capi.Api.call(h, p); api.hip_sync(); api.check()
         return dC
     c1, c2, c12 = run(A1), run(A2), run(A1 + A2)
-    assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_f32_stream_kernel"
+    assert api.hip_kernel_name(h, 0).decode() == ("bcsc_mfma_f32_stream_full_kernel" if pattern_on == "host" else "bcsc_mfma_f32_stream_kernel")
     assert torch.equal(c12, c1 + c2)                                             # exact: every term is a multiple of 1/64 far below 2^24
     sample = sorted(set(list(range(0, mb, 127)) + [mb - 1]))
     As = A1[sample].numpy().reshape(-1).copy()

@@ -529,12 +529,15 @@ def test_bcsc_bf16_waves_streaming_over_m_blocks(c_type, M, N, K, mb, bk, bn, ke
 
 # the same scheme on f32 operands (round 3): a chunk is 16 k, four v_mfma_f32_16x16x4_f32 per tile pair; bk = 16 (one chunk per block) .. 64, ragged tiles,
 # an n-tile without blocks, every wave with a different number of M-blocks
-@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep", [(80, 96, 128, 1100, 32, 32, 0.34), (64, 64, 256, 4099, 32, 16, 0.25), (64, 128, 64, 2050, 64, 64, 0.5), (64, 64, 128, 4100, 16, 16, 0.3)])
-def test_bcsc_f32_waves_streaming_over_m_blocks(M, N, K, mb, bk, bn, keep):
+# host pattern, whole tiles, B up to 16 KiB: the kernel with one record per chunk in its f32 form ("bcsc_mfma_f32_stream_full_kernel")
+@pytest.mark.parametrize("pattern_on", ["device", "host"])
+@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep", [(80, 96, 128, 1100, 32, 32, 0.34), (64, 64, 256, 4099, 32, 16, 0.25), (64, 128, 64, 2050, 64, 64, 0.5), (64, 64, 128, 4100, 16, 16, 0.3),
+                                                 (128, 128, 96, 1100, 48, 32, 0.5), (64, 64, 16, 4101, 16, 64, 1.0)])
+def test_bcsc_f32_waves_streaming_over_m_blocks(M, N, K, mb, bk, bn, keep, pattern_on):
     api, orc = capi.load(), pyoracle.oracle()
     rng = np.random.default_rng(14)
     colptr, rowidx, bvals = make_bcsc(rng, K, N, bk, bn, keep, DT.F32)
-    if N == 128:
+    if N == 128 and bn == 64:
         keep_blocks = int(colptr[1])
         colptr = np.array([0, keep_blocks, keep_blocks], dtype=colptr.dtype); rowidx = rowidx[:keep_blocks].copy(); bvals = bvals[:keep_blocks * bn * bk].copy()
     A = rand_values(rng, mb * K * M, DT.F32)
@@ -547,15 +550,19 @@ def test_bcsc_f32_waves_streaming_over_m_blocks(M, N, K, mb, bk, bn, keep):
     nblk = C.c_ulonglong(N // bn)
     p = capi.GemmParam()
     p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = dA.data_ptr(), dB.data_ptr(), dcp.data_ptr(), dri.data_ptr(), C.addressof(nblk), dC.data_ptr()
-    capi.Api.call(h, p)
+    if pattern_on == "host":
+        p.b.secondary, p.b.tertiary = colptr.ctypes.data, rowidx.ctypes.data
+    for _ in range(2):
+        capi.Api.call(h, p)
     api.hip_sync(); api.check()
-    assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_f32_stream_kernel"
+    full = pattern_on == "host" and len(rowidx) * bn * bk * 4 <= 16384 and M % 64 == 0 and N % 64 == 0
+    assert api.hip_kernel_name(h, 0).decode() == ("bcsc_mfma_f32_stream_full_kernel" if full else "bcsc_mfma_f32_stream_kernel")
     got = _host(dC, np.float32)
     assert normf_rel(ref, got, DT.F32) <= 1e-5
     rb, gb = ref.reshape(mb, -1), got.reshape(mb, -1)
     worst = max(normf_rel(rb[b], gb[b], DT.F32) for b in list(range(0, mb, 97)) + [mb - 1, mb - 2, mb // 2])
     assert worst <= 1e-5
-    if N == 128:
+    if N == 128 and bn == 64:
         assert not np.any(gb.reshape(mb, N, M)[:, 64:, :])
     api.release_kernel(h)
 
