@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
 
 // The streaming kernel re-cut for the shape config #4 has: whole 64 x 64 tiles (M and N multiples of 64), bf16 C, the value array of B in LDS.  What bounded the
 // general kernel above was not its operand stream but the chain of dependent steps in front of every chunk -- two integer divisions, five table look-ups in LDS each
-// waited for, a branch around every MFMA for tiles that are not whole (tools: A served from cache it still took 38 of its 61 us, profiles/r06_bcsc_full.jsonl).  Here
+// waited for, a branch around every MFMA for tiles that are not whole (with A served from cache -- every M-block reading the first eight's -- it still took 38 of its 61 us: profiles/r06_bcsc_full.jsonl, tag a_alias).  Here
 // a wave writes ONE 16-byte record per chunk of its pattern before the loop -- the chunk's offset inside an M-block of A and the LDS offsets of its (up to four) blocks
 // of B, 0xffff for an absent one -- and a chunk is: wait for its A; one batch of LDS reads (A fragments, B fragments, the next chunk's record, the offset of the chunk
 // to request) and one wait; four LDS-DMA requests into the slot just read; the MFMAs.  The ring slot is a run-time index, so the loop is not unrolled over slots.
@@ -1245,11 +1245,7 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
   int aj = 0, ac_ = 0;                        // the NEXT chunk whose A is to be requested
   unsigned int a_slot = 0;                    // ... and the ring slot it goes to
   auto issue_a = [&](unsigned int a_off) __attribute__((always_inline)) {
-#if defined(XAMD_BCSC_A_ALIAS)      // experiment: every M-block reads one of the first eight's A (cache hits) -- what the kernel costs without its operand stream
-    GM const unsigned int* rowbase = A2 + (long long)((g0 + (unsigned int)aj * mbg) & 7u) * a_mb_words + a_off;
-#else
     GM const unsigned int* rowbase = A2 + (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + a_off;
-#endif
     char* dst = (char*)abuf + 4096u * a_slot;
 #pragma unroll
     for (int x = 0; x < NI; ++x)
