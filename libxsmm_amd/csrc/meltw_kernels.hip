@@ -1040,6 +1040,17 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
     const int jbeg = partial ? (int)blockIdx.z * chunk : 0, jend = partial ? ((jbeg + chunk < p.n) ? jbeg + chunk : p.n) : p.n;
     if (rg < m4 && sl < slices) {
       int j = jbeg + sl;
+      // sixteen columns in flight per thread first (a wave then has 16 KiB on its way: with four, 2048 waves of the two-pass form kept 8 MB in flight and ran at
+      // 4.2 TB/s -- the round trip, not the memory system), folded in column order like the loops below: the same sums
+      for (; j + 15 * slices < jend; j += 16 * slices) {
+        float x[16][4];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) red_load4<BF16IN>(x[u], in, 4ll * rg + (long long)(j + u * slices) * p.ldi);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sx[e] = combine(sx[e], x[u][e]); sx2[e] += x[u][e] * x[u][e]; }
+      }
       for (; j + 3 * slices < jend; j += 4 * slices) {       // four columns in flight, folded in column order
         float x[4][4];
 #pragma unroll
@@ -1068,7 +1079,7 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
     if (partial) {
       GM float* px = (GM float*)partial + ((long long)blockIdx.z * 2) * p.m + 4ll * rg;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { px[e] = sx[e]; px[p.m + e] = sx2[e]; }
+      for (int e = 0; e < 4; ++e) { px[e] = sx[e]; if (want_x2) px[p.m + e] = sx2[e]; }
       return;
     }
 #pragma unroll
@@ -1338,12 +1349,22 @@ __global__ __launch_bounds__(256) void reduce_combine_kernel(MeltwArgs p, const 
   const bool want_x2 = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X2_OP_ADD || type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_X2_OP_ADD;
   const bool is_add = type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_ADD || want_x2;
   GM const float* px = (GM const float*)partial + i;
-  float a = px[0], b = px[p.m];
-  for (int z = 1; z < nchunks; ++z) {
-    const float x = px[(long long)z * 2 * p.m], x2 = px[((long long)z * 2 + 1) * p.m];
+  float a = px[0], b = want_x2 ? px[p.m] : 0.0f;
+  auto fold = [&](float x, float x2) {
     if (is_add) a += x; else if (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MAX) a = (a < x) ? x : a; else if (type == LIBXSMM_MELTW_TYPE_UNARY_REDUCE_X_OP_MIN) a = (a > x) ? x : a; else a = fmaxf(fabsf(a), fabsf(x));
     b += x2;
+  };
+  // sixteen chunks' partial sums in flight per thread, folded in chunk order (the loop used to ask for one pair at a time: with 128 chunks the 16 workgroups of this
+  // kernel spent 30 us waiting for 256 dependent round trips each -- why "few, long-running blocks" won the first pass's block-count scan)
+  int z = 1;
+  for (; z + 15 < nchunks; z += 16) {
+    float x[16], x2[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { x[u] = px[(long long)(z + u) * 2 * p.m]; x2[u] = want_x2 ? px[((long long)(z + u) * 2 + 1) * p.m] : 0.0f; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) fold(x[u], x2[u]);
   }
+  for (; z < nchunks; ++z) fold(px[(long long)z * 2 * p.m], want_x2 ? px[((long long)z * 2 + 1) * p.m] : 0.0f);
   gptr out = (gptr)p.out;
   gptr out2 = (want_x && want_x2) ? out + (long long)p.ldo * mw_size(p.out_type) : out;
   if (is_add && init_acc) { if (want_x) a += mw_load(out, i, p.out_type); if (want_x2) b += mw_load(out2, i, p.out_type); }
@@ -1874,6 +1895,8 @@ int launch_meltw(const MeltwArgs& a, void* stream, const char** name) {
         // round 4: 256 row groups per block (one contiguous 4 KiB run of every column, eight columns in flight per thread, 32 - 512 column chunks): 54 - 66 us
         // (8192 x 8192: 52 -> 66 - 91 us; 1024 x 65536: 60 -> 138 - 392 us) -- the short pieces of many columns at once are what this memory system wants here
         if (!rows && a.ws && a.nbatch == 1 && gx < 512) {
+          // round 6, with the second pass no longer waiting for one chunk at a time: 512 blocks 33.1 us, 1024 34.9, 2048 34.2, 4096 35.5; whole 1 KiB row segments per wave
+          // (64 row groups x 4 slices) 38 us at 512 and at 2048 blocks (profiles/r06_reduce_cols_scan.jsonl) -- still the 16 x 16 form at 512 blocks
           nchunks = (int)std::min<long long>(128, std::min<long long>(a.n / 64, 512 / (gx ? gx : 1)));
           if ((size_t)nchunks * 2 * (size_t)a.m * sizeof(float) > a.ws_bytes) nchunks = 1;
         }
