@@ -1011,6 +1011,15 @@ __global__ __launch_bounds__(256) void reduce_vec_kernel(MeltwArgs p, int G, int
     if (j < p.n) {
       // four independent loads in flight per lane; the values are folded in the order of the plain loop (same rounding)
       int i4 = l;
+      for (; i4 + 15 * G < m4; i4 += 16 * G) {      // a long column: sixteen vectors (16 KiB per wave) in flight, folded in the same order as below
+        float x[16][4];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) red_load4<BF16IN>(x[u], in, 4ll * (i4 + u * G) + (long long)j * p.ldi);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { sx = combine(sx, x[u][e]); sx2 += x[u][e] * x[u][e]; }
+      }
       for (; i4 + 3 * G < m4; i4 += 4 * G) {
         float x[4][4];
 #pragma unroll
