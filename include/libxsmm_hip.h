@@ -67,14 +67,19 @@ LIBXSMM_API int libxsmm_hip_get_async(void);
  * What the calling thread's next launches should assume about their dense operands -- the read-side counterpart of the reference's
  * non-temporal-store hint for C [ref: include/libxsmm_typedefs.h LIBXSMM_GEMM_FLAG_ALIGN_C_NTS_HINT]:
  *   0 (default, also LIBXSMM_HIP_STREAMING=0): decide per launch -- operands of a launch that moves more than the 256 MiB Infinity Cache
- *     holds are loaded non-temporally (they cannot be resident), smaller launches keep their operands cacheable;
+ *     holds are loaded non-temporally (they cannot be resident); so are the operands of a smaller launch when the thread's recent launches on OTHER
+ *     operand sets (the last 32 sets, each forgotten after 96 launches) together with this one exceed the cache -- a caller that walks over more
+ *     input than the cache holds re-reads nothing from it either (round 6); a caller that keeps launching on the same resident set stays cacheable;
  *   1: operands are re-read by later launches or were just produced on the device (keep them cacheable, never non-temporal);
  *   2: operands are read once from HBM (a pass over a working set far larger than the cache): non-temporal loads at every size.
  * Measured on 4096 f32 32^3 problems: hint 2 is 7 % faster when the operands do come from HBM and 50 % slower when they were
- * resident in the Infinity Cache, which is why it is a declaration of the caller and not a default.
+ * resident in the Infinity Cache, which is why it is not a default; since round 6 mode 0 makes the same choice as the right
+ * declaration in both cases (one resident set 5.69 / 5.68 / 9.06 us for modes 0 / 1 / 2, twelve rotated sets 9.97 / 10.74 / 9.99 us).
+ * libxsmm_hip_streaming_window_verdict(): what mode 0's look at the recent launches said for the calling thread's last launch (1: they exceed the cache).
  */
 LIBXSMM_API void libxsmm_hip_set_streaming_hint(int mode);
 LIBXSMM_API int libxsmm_hip_get_streaming_hint(void);
+LIBXSMM_API int libxsmm_hip_streaming_window_verdict(void);
 /** Block until all work enqueued by the calling thread's stream has finished. */
 LIBXSMM_API void libxsmm_hip_sync(void);
 /** Pipeline section: the calling thread DECLARES that the kernel launches it issues between _begin and _end are mutually independent (no launch reads

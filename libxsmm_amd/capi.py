@@ -260,6 +260,7 @@ class Api:
             self.hip_get_async = f("hip_get_async", C.c_int, [])
             self.hip_set_streaming_hint = f("hip_set_streaming_hint", None, [C.c_int])
             self.hip_get_streaming_hint = f("hip_get_streaming_hint", C.c_int, [])
+            self.hip_streaming_window_verdict = f("hip_streaming_window_verdict", C.c_int, [])
             self.hip_sync = f("hip_sync", None, [])
             self.hip_get_last_error = f("hip_get_last_error", C.c_int, [])
             self.hip_get_last_error_string = f("hip_get_last_error_string", C.c_char_p, [])

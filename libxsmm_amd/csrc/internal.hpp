@@ -266,6 +266,12 @@ int launch_brchain_f32(const GemmArgs& args, float* partial, size_t partial_capa
 int launch_brsplit_reduce(const GemmArgs& args, const float* partial, int nsplit, void* stream);
 int launch_spmm(const SpmmArgs& args, void* stream, const char** kernel_name);
 int launch_bcsc(const BcscArgs& args, void* stream, const char** kernel_name);
+// Automatic streaming decision (libxsmm_hip_set_streaming_hint(0)): a launch whose own operands exceed the Infinity Cache streams -- and so does a launch whose operands
+// TOGETHER WITH those of the calling thread's recent launches on other operands do (a caller that walks over more input sets than the cache holds re-reads nothing
+// from it either).  `key` identifies the launch's operand set (its first operand's address), `bytes` is what the launch moves.  32 sets are remembered, each forgotten after
+// 96 decisions without being seen again, so a caller that settles on one resident set gets cacheable loads back.  (runtime.cpp, thread-local.)
+bool rt_recent_operands_exceed_cache(const void* key, unsigned long long bytes);
+int rt_window_verdict();
 int launch_bcsc_invert(const unsigned int* colptr, const unsigned int* rowidx, unsigned int* table, int nblk_n, int nkb, void* stream);
 int launch_csparse(const CsparseArgs& args, void* stream, const char** kernel_name);
 int launch_pgemm(const PgemmArgs& args, void* stream, const char** kernel_name);
