@@ -1030,7 +1030,7 @@ def main():
     # secondary measurement: the same set every step (Infinity-Cache resident), not the headline
     l3_us = auto_us = None
     if not args.no_l3:
-        # the same rotation without the declaration (hint 0: the library decides by launch size -> cacheable loads for 48 MiB)
+        # the same rotation without the declaration (hint 0: the library decides by launch size and, since round 6, by the thread's recent operand sets together)
         work.hint = 0
         _, _, auto_us = timed(work, args.steps, min(args.min_seconds, 0.2), label=work.label() + "_hint0")
         l3 = Workload(api, dev, args.dtype, args.m, args.batch, br=args.br, beta=args.beta, fused=args.fused, nsets=1)
@@ -1109,7 +1109,7 @@ def main():
             "l3_resident": None if l3_us is None else {"value": round(work.flops_per_step / (l3_us * 1e-6) / 1e9, 1), "unit": "GFLOP/s", "kernel_us": round(l3_us, 3),
                                                        "achieved_GBs": round(work.alg_bytes_per_step / (l3_us * 1e-6) / 1e9, 1)},
             "without_streaming_hint": None if auto_us is None else {"kernel_us": round(auto_us, 3), "frac": round(work.alg_bytes_per_step / (auto_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                                     "note": "same rotation, libxsmm_hip_set_streaming_hint(0): cacheable operand loads (what a caller whose 48 MiB working set may be cache resident gets)"},
+                                                                     "note": "same rotation, libxsmm_hip_set_streaming_hint(0): the library decides -- since round 6 also from the thread's recent operand sets, so an unmodified caller that rotates over more than the Infinity Cache streams like the declared run (round 5: cacheable loads, 10.7 us)"},
             "mfma_busy": busy, "mfma_busy_source": busy_src,
         }
         if l3_us is not None:
