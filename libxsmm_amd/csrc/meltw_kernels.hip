@@ -819,6 +819,8 @@ __global__ __launch_bounds__(256) void gs_offs_vec4_kernel(MeltwArgs p, unsigned
 // whole-column gather / scatter (GS_COLS) with 16-byte accesses: a thread moves 16 bytes of one column; the column index is
 // read once per thread (same address across the lanes of a column segment -> broadcast).  Needs (m * S) % 16 == 0, 16-byte
 // aligned bases and leading dimensions that keep every column 16-byte aligned.
+// (round 6, not adopted: a workgroup per 16 KiB run of one column, the index read once per thread and four loads in flight before the first store: 54.0 against 52.4 us
+//  on 8192 columns of 16 KiB out of 16 384, profiles/r06_gather_run.jsonl)
 __global__ __launch_bounds__(256) void gather_cols_vec_kernel(MeltwArgs p, int elem_size, unsigned int vpc, unsigned int total) {
   const unsigned int gid = blockIdx.x * 256u + threadIdx.x;
   if (gid >= total) return;
