@@ -1501,6 +1501,236 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_i8_dma_kernel(BcscArgs p, 
   });
 }
 
+// The full-tile streaming kernel (see bcsc_mfma_bf16_stream_full_kernel: records, B in LDS, every in-loop LDS access an instruction) for 8-bit integers:
+// u8 x i8 (UA) and i8 x u8 -> i32 on v_mfma_i32_16x16x32_i8 with the unsigned operand fed as u - 128 and 128 * sum(other) added at the end, as in
+// bcsc_mfma_i8_dma_kernel.  A chunk is 32 k of the wave's 64 rows in VNNI-4: 8 rows of 256 bytes = 2 KiB = two requests; the ring is six chunks deep; B up to
+// 8 KiB; the int32 tile leaves through LDS eight columns (2 KiB per wave) at a time like the f32 form.  68 KiB of LDS, two waves per SIMD (at three, 168 registers, every
+// variant spills: the 64 + 16 .. 64 accumulators).
+template <int BN16, bool UA, int AUX_A, bool EARLY>
+__global__ __launch_bounds__(256, 2) void bcsc_mfma_i8_stream_full_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
+  constexpr int NBL = 4 / BN16, DA = 6, NI = 2, NS = 16, BLDS = 8192, BP = 2;
+  __shared__ __attribute__((aligned(16))) unsigned int recs_all[4][kBcscRecs][4];
+  __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][DA][512];
+  __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][512];
+  __shared__ __attribute__((aligned(16))) unsigned int bimg[BLDS / 4];
+  const unsigned int wave = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int wid = blockIdx.x * 4u + wave;
+  const int lane = threadIdx.x & 63, lx = lane & 15, kg = lane >> 4;
+  const bool live = wid < total_waves;
+  unsigned int* abuf = abuf_all[wave][0];
+  const unsigned int tile_lds = (unsigned int)(unsigned long long)(lds_ptr_t)ctile_all[wave];
+  const unsigned int recs_lds = (unsigned int)(unsigned long long)(lds_ptr_t)&recs_all[wave][0][0], abuf_lds = (unsigned int)(unsigned long long)(lds_ptr_t)abuf;
+  const unsigned int bimg_lds = (unsigned int)(unsigned long long)(lds_ptr_t)bimg;
+  const unsigned int tt_count = tiles_i * tiles_n, tt = live ? wid % tt_count : 0u, g0 = live ? wid / tt_count : 0u;
+  const unsigned int tn = tt % tiles_n, ti = tt / tiles_n;
+  const int i0 = (int)ti * 64, n0 = (int)tn * 64;
+  const int nb0 = n0 / (16 * BN16);
+  const int nkb = p.K / p.bk, steps = p.bk / 32, kw = p.bk / 4;          // kw: image rows (k quads) of a k-block
+  const int nmb = (live && (unsigned int)p.m_blocks > g0) ? (int)(((unsigned int)p.m_blocks - g0 + mbg - 1u) / mbg) : 0;
+  GM const unsigned int* A4 = (GM const unsigned int*)p.a + i0;
+  const long long a_mb_words = (long long)(p.K / 4) * p.M;
+  unsigned int src_off[NI];
+#pragma unroll
+  for (int x = 0; x < NI; ++x) {
+    const unsigned int S = (unsigned int)lane + 64u * x, row = S >> 4, g = ((S & 15u) - 4u * ((row >> 1) & 1u)) & 15u;
+    src_off[x] = row * (unsigned int)p.M + 4u * g;
+  }
+  long long first[DA] = {};
+  if constexpr (EARLY) {
+    const int nch_e = __builtin_popcountll(p.kmask0) * steps, total_e = nmb * nch_e;
+#pragma unroll
+    for (int f = 0; f < DA; ++f) {
+      if (f < total_e) {
+        const int j = f / nch_e, c = f - j * nch_e, q = c / steps, st_ = c - q * steps;
+        unsigned long long m = p.kmask0;
+        for (int z = 0; z < q; ++z) m &= m - 1ull;
+        const unsigned int kb = (unsigned int)__builtin_ctzll(m);
+        first[f] = (long long)(g0 + (unsigned int)j * mbg) * a_mb_words + (long long)((kb * (unsigned int)kw + 8u * (unsigned int)st_) * (unsigned int)p.M);
+      }
+    }
+  }
+  GM const unsigned int* gt = (GM const unsigned int*)gtable + (long long)nb0 * nkb + (lane < nkb ? lane : 0);
+  const unsigned int pieces = (unsigned int)p.nnzb * (unsigned int)(p.bn * p.bk) / 16u;
+  unsigned int trow[4]; u32x4v bpiece[BP];
+  {
+    GM const unsigned int* tp[4]; GM const u32x4v* bp_[BP];
+#pragma unroll
+    for (int nbl = 0; nbl < 4; ++nbl) tp[nbl] = gt + (nbl < NBL ? nbl : NBL - 1) * nkb;
+#pragma unroll
+    for (int e = 0; e < BP; ++e) { const unsigned int x = threadIdx.x + 256u * e; bp_[e] = (GM const u32x4v*)p.bvals + (x < pieces ? x : 0u); }
+    asm volatile("global_load_dword %0, %6, off\n\tglobal_load_dword %1, %7, off\n\tglobal_load_dword %2, %8, off\n\tglobal_load_dword %3, %9, off\n\t"
+                 "global_load_dwordx4 %4, %10, off\n\tglobal_load_dwordx4 %5, %11, off"
+                 : "=&v"(trow[0]), "=&v"(trow[1]), "=&v"(trow[2]), "=&v"(trow[3]), "=&v"(bpiece[0]), "=&v"(bpiece[1])
+                 : "v"(tp[0]), "v"(tp[1]), "v"(tp[2]), "v"(tp[3]), "v"(bp_[0]), "v"(bp_[1]) : "memory");
+  }
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int f = 0; f < DA; ++f) {
+#pragma unroll
+      for (int x = 0; x < NI; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(A4 + first[f] + src_off[x]), (lds_ptr_t)((char*)abuf + 2048 * f + 1024 * x), 16, 0, AUX_A);
+    }
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]) : "n"(DA * NI) : "memory");
+  } else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(trow[0]), "+v"(trow[1]), "+v"(trow[2]), "+v"(trow[3]), "+v"(bpiece[0]), "+v"(bpiece[1]) :: "memory");
+  if (lane >= nkb) { trow[0] = 0xffffffffu; trow[1] = 0xffffffffu; trow[2] = 0xffffffffu; trow[3] = 0xffffffffu; }
+  bool used = false;
+#pragma unroll
+  for (int nbl = 0; nbl < NBL; ++nbl) used = used || (trow[nbl] != 0xffffffffu);
+  const unsigned long long mask = EARLY ? p.kmask0 : __ballot(used);
+  const int nch = __builtin_popcountll(mask) * steps;
+  u32x4v rec_mine;
+  {
+    const int q = lane / steps, st_ = lane - q * steps;
+    unsigned long long m = mask;
+    for (int z = 0; z < q; ++z) m &= m - 1ull;
+    const unsigned int kb = m ? (unsigned int)__builtin_ctzll(m) : 0u;
+    unsigned int bo[4] = {0xffffu, 0xffffu, 0xffffu, 0xffffu};
+#pragma unroll
+    for (int nbl = 0; nbl < NBL; ++nbl) {
+      const unsigned int blk = (unsigned int)__shfl((int)trow[nbl], (int)kb);
+      if (blk != 0xffffffffu) bo[nbl] = blk * (unsigned int)(16 * BN16) * (unsigned int)p.bk + 32u * (unsigned int)st_;
+    }
+    rec_mine[0] = (kb * (unsigned int)kw + 8u * (unsigned int)st_) * (unsigned int)p.M; rec_mine[1] = bo[0] | (bo[1] << 16); rec_mine[2] = bo[2] | (bo[3] << 16); rec_mine[3] = 0u;
+    const unsigned int rad = recs_lds + 16u * (unsigned int)lane;
+    if (lane < nch) asm volatile("ds_write_b128 %0, %1" :: "v"(rad), "v"(rec_mine) : "memory");
+  }
+  const long long c_mb_bytes = (long long)p.N * p.M * 4;
+  i32x4v acc[4][4], corr_b[4], corr_a[NBL][4];
+  sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (i32x4v)0; });
+  sfor<4>([&](auto c) { corr_b[c.value] = (i32x4v)0; });
+  sfor<NBL * 4>([&](auto c) { corr_a[c.value / 4][c.value % 4] = (i32x4v)0; });
+  const long long ones = 0x0101010101010101ll;
+  auto store_tile = [&](unsigned int mb) __attribute__((always_inline)) {
+    GM char* cbase = (GM char*)p.c + (long long)mb * c_mb_bytes;
+    sfor<8>([&](auto pc) {
+      constexpr int nt = pc.value / 2, half = pc.value % 2;
+      if ((lx >> 3) == half) {
+        const unsigned int c = (unsigned int)lx & 7u;
+        sfor<4>([&](auto tc) {
+          constexpr int it = tc.value;
+          i32x4v v = acc[nt][it];
+          if (UA) v += corr_b[nt] * 128; else v += corr_a[nt / BN16][it] * 128;
+          const unsigned int wad = tile_lds + c * 256u + 16u * ((unsigned int)(4 * it + kg) ^ c);
+          asm volatile("ds_write_b128 %0, %1" :: "v"(wad), "v"(v) : "memory");
+        });
+      }
+      u32x4v w2[2]; unsigned int ad[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { const unsigned int c = 4u * j + ((unsigned int)lane >> 4), sl = (unsigned int)lane & 15u; ad[j] = tile_lds + c * 256u + 16u * (sl ^ c); }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w2[0]), "=&v"(w2[1]) : "v"(ad[0]), "v"(ad[1]) : "memory");
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = 4 * j + (lane >> 4), sl = lane & 15;
+        GM u32x4v* dst = (GM u32x4v*)(cbase + ((long long)(n0 + 16 * nt + 8 * half + c) * p.M + i0) * 4 + 16 * sl);
+        if (AUX_A != 0) __builtin_nontemporal_store(w2[j], dst); else *dst = w2[j];
+      }
+    });
+    sfor<16>([&](auto ic) { acc[ic.value / 4][ic.value % 4] = (i32x4v)0; });
+    sfor<4>([&](auto c) { corr_b[c.value] = (i32x4v)0; });
+    sfor<NBL * 4>([&](auto c) { corr_a[c.value / 4][c.value % 4] = (i32x4v)0; });
+  };
+  const int rot = 16 * (kg & 1);
+  unsigned int a_rd[4];                       // word index of the low k quad (image row 2 kg) of this lane's row in tile t; the high one is a row (64 words) further
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a_rd[t] = (unsigned int)((2 * kg) * 64 + ((16 * t + lx + rot) & 63));
+  unsigned int b_rd[BN16];
+#pragma unroll
+  for (int s2 = 0; s2 < BN16; ++s2) b_rd[s2] = (unsigned int)((16 * s2 + lx) * p.bk + 8 * kg);
+  const int total_f = nmb * nch;
+  int aj = 0, ac_ = 0;
+  unsigned int a_slot = 0;
+  auto issue_a = [&](unsigned int a_off) __attribute__((always_inline)) {
+    GM const unsigned int* rowbase = A4 + (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + a_off;
+    char* dst = (char*)abuf + 2048u * a_slot;
+#pragma unroll
+    for (int x = 0; x < NI; ++x)
+      __builtin_amdgcn_global_load_lds((GM const void*)(rowbase + src_off[x]), (lds_ptr_t)(dst + 1024 * x), 16, 0, AUX_A);
+    a_slot = (a_slot == (unsigned int)(DA - 1)) ? 0u : a_slot + 1u;
+    if (++ac_ == nch) { ac_ = 0; ++aj; }
+  };
+#pragma unroll
+  for (int e = 0; e < BP; ++e) {
+    const unsigned int x = threadIdx.x + 256u * e, bad = bimg_lds + 16u * x;
+    if (x < pieces) asm volatile("ds_write_b128 %0, %1" :: "v"(bad), "v"(bpiece[e]) : "memory");
+  }
+  u32x4v rec_c;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) rec_c[e] = (unsigned int)__builtin_amdgcn_readlane((int)rec_mine[e], 0);
+#pragma unroll
+  for (int f = 0; f < DA; ++f) {
+    const bool real = f < total_f;
+    const unsigned int a_off = real ? (unsigned int)__builtin_amdgcn_readlane((int)rec_mine[0], ac_) : 0u;
+    if constexpr (!EARLY) first[f] = real ? (long long)(g0 + (unsigned int)aj * mbg) * a_mb_words + a_off : 0ll;
+    if (real && ++ac_ == nch) { ac_ = 0; ++aj; }
+  }
+  if constexpr (!EARLY) {
+#pragma unroll
+    for (int f = 0; f < DA; ++f) {
+#pragma unroll
+      for (int x = 0; x < NI; ++x)
+        __builtin_amdgcn_global_load_lds((GM const void*)(A4 + first[f] + src_off[x]), (lds_ptr_t)((char*)abuf + 2048 * f + 1024 * x), 16, 0, AUX_A);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (!live) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+  if (nch == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); for (int j = 0; j < nmb; ++j) store_tile(g0 + (unsigned int)j * mbg); return; }
+  int cj = 0, cc = 0;
+  unsigned int c_slot = 0;
+  for (int f = 0; f < total_f; ++f) {
+    // chunk f must have landed; behind it: A(f+1) .. A(f+DA-1) as far as they exist and the 16 stores of the previous tile while this chunk is one of the first DA of its tile
+    const int left = total_f - 1 - f;
+    const bool stored = cj > 0 && cc < DA;
+    const int behind = left < DA - 1 ? left : DA - 1;          // chunks requested behind this one
+    sfor<DA>([&](auto bc) {
+      if (behind == bc.value) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(bc.value * NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(bc.value * NI) : "memory"); }
+    });
+    const unsigned int r1 = (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_c[1]), r2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_c[2]);
+    const unsigned int bo[4] = {r1 & 0xffffu, r1 >> 16, r2 & 0xffffu, r2 >> 16};
+    unsigned int a_ad[4], b_ad[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a_ad[t] = abuf_lds + 2048u * c_slot + 4u * a_rd[t];
+    sfor<NBL>([&](auto nc) {
+      constexpr int nbl = nc.value;
+      const unsigned int b = bo[nbl] == 0xffffu ? 0u : bo[nbl];
+      sfor<BN16>([&](auto sc) { b_ad[nbl * BN16 + sc.value] = bimg_lds + b + b_rd[sc.value]; });
+    });
+    const int cn = (cc + 1 == nch) ? 0 : cc + 1;
+    const unsigned int rec_ad = recs_lds + 16u * (unsigned int)cn, aoff_ad = recs_lds + 16u * (unsigned int)ac_;
+    u32x2v ap[4], bq[4]; u32x4v rec_n; unsigned int a_off_v;
+    asm volatile("ds_read2_b32 %0, %10 offset1:64\n\tds_read2_b32 %1, %11 offset1:64\n\tds_read2_b32 %2, %12 offset1:64\n\tds_read2_b32 %3, %13 offset1:64\n\t"
+                 "ds_read_b64 %4, %14\n\tds_read_b64 %5, %15\n\tds_read_b64 %6, %16\n\tds_read_b64 %7, %17\n\t"
+                 "ds_read_b128 %8, %18\n\tds_read_b32 %9, %19\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(ap[0]), "=&v"(ap[1]), "=&v"(ap[2]), "=&v"(ap[3]), "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(rec_n), "=&v"(a_off_v)
+                 : "v"(a_ad[0]), "v"(a_ad[1]), "v"(a_ad[2]), "v"(a_ad[3]), "v"(b_ad[0]), "v"(b_ad[1]), "v"(b_ad[2]), "v"(b_ad[3]), "v"(rec_ad), "v"(aoff_ad)
+                 : "memory");
+    if (left >= DA) issue_a((unsigned int)__builtin_amdgcn_readfirstlane((int)a_off_v));        // into the slot just read
+    long long a_cur[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      unsigned int lo = ap[t][0], hi = ap[t][1];
+      if (UA) { lo ^= 0x80808080u; hi ^= 0x80808080u; }
+      a_cur[t] = (long long)(((unsigned long long)hi << 32) | lo);
+    }
+    sfor<NBL>([&](auto nc) {
+      constexpr int nbl = nc.value;
+      if (bo[nbl] != 0xffffu) {
+        sfor<BN16>([&](auto sc) {
+          constexpr int s2 = sc.value, nt = nbl * BN16 + s2;
+          long long bfrag = (long long)(((unsigned long long)bq[nt][1] << 32) | bq[nt][0]);
+          if (!UA) bfrag ^= (long long)0x8080808080808080ull;
+          sfor<4>([&](auto tc) { constexpr int t = tc.value; acc[nt][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_cur[t], bfrag, acc[nt][t], 0, 0, 0); });
+          if (UA) corr_b[nt] = __builtin_amdgcn_mfma_i32_16x16x32_i8(ones, bfrag, corr_b[nt], 0, 0, 0);
+        });
+        if (!UA) sfor<4>([&](auto tc) { constexpr int t = tc.value; corr_a[nbl][t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_cur[t], ones, corr_a[nbl][t], 0, 0, 0); });
+      }
+    });
+    rec_c = rec_n;
+    c_slot = (c_slot == (unsigned int)(DA - 1)) ? 0u : c_slot + 1u;
+    if (++cc == nch) { store_tile(g0 + (unsigned int)cj * mbg); cc = 0; ++cj; }
+  }
+}
+
 // What one launch moves: the k-blocks of A some block of B refers to (known from a host-resident pattern when one n-tile covers all columns: BcscArgs::kmask0;
 // all of A otherwise) and C.  A launch that moves more than the Infinity Cache holds cannot leave anything there for the next one: its A is requested non-temporal
 // (config #4: 7 of 8 k-blocks of 256 MiB + 64 MiB of C -- 52.6 against 56.7 us; the same shape with bn = 32 touches half of A: 192 MiB, cacheable, 34.6 against 36.6 us;
@@ -1669,6 +1899,25 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
           const int nkb = a.K / a.bk;
           const unsigned int* table = (const unsigned int*)a.table;
           if (!a.table_ready) hipLaunchKernelGGL(bcsc_invert_kernel, dim3((unsigned int)a.nblk_n), dim3(64), 0, st, a.colptr, a.rowidx, (unsigned int*)a.table, a.nblk_n, nkb);
+          // host-resident / bound pattern, whole 64 x 64 tiles, beta = 0, B up to 8 KiB, many M-blocks per tile: waves streaming over M-blocks with one record per chunk
+          const long long tt_count8 = (long long)tiles_i * tiles_n;
+          if (a.beta0 && a.nnzb > 0 && (long long)a.nnzb * a.bn * a.bk <= 8192 && ((size_t)a.bvals % 16 == 0) && a.M % 64 == 0 && a.N % 64 == 0 && nkb <= 64 && nkb * (a.bk / 32) <= kBcscRecs &&
+              tt_count8 <= 2048 && (long long)a.m_blocks * tt_count8 >= 4096) {
+            long long mbg = std::min<long long>(a.m_blocks, std::max<long long>(1, 2048 / tt_count8));          // two waves per SIMD
+            const long long per = (a.m_blocks + mbg - 1) / mbg;
+            mbg = (a.m_blocks + per - 1) / per;
+            const long long waves = mbg * tt_count8;
+            const dim3 sgrid((unsigned int)((waves + 3) / 4));
+            const bool early = tiles_n == 1;
+#define LAUNCH_I8F3_(B_, U_, X_) do { if (early) hipLaunchKernelGGL((bcsc_mfma_i8_stream_full_kernel<B_, U_, X_, true>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); \
+                                      else hipLaunchKernelGGL((bcsc_mfma_i8_stream_full_kernel<B_, U_, X_, false>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table); } while (0)
+#define LAUNCH_I8F_(B_) do { if (ua) { if (a.nt_a) LAUNCH_I8F3_(B_, true, 2); else LAUNCH_I8F3_(B_, true, 0); } else { if (a.nt_a) LAUNCH_I8F3_(B_, false, 2); else LAUNCH_I8F3_(B_, false, 0); } } while (0)
+            if (a.bn == 16) LAUNCH_I8F_(1); else if (a.bn == 32) LAUNCH_I8F_(2); else LAUNCH_I8F_(4);
+#undef LAUNCH_I8F_
+#undef LAUNCH_I8F3_
+            if (name) *name = "bcsc_mfma_i8_stream_full_kernel";
+            return (int)hipGetLastError();
+          }
 #define LAUNCH_I8D_(B_) do { \
     if (ua) { if (a.nt_a) hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, true, 2, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); \
               else hipLaunchKernelGGL((bcsc_mfma_i8_dma_kernel<B_, true, 0, 2, 3, 4>), grid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)total, table); } \

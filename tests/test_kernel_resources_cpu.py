@@ -31,6 +31,7 @@ OCCUPANCY = {
     r"xamd::bcsc_mfma_bf16_stream_kernel<.*>": 2,                # 2048 waves = one round at two waves per SIMD
     r"xamd::bcsc_mfma_bf16_stream_full_kernel<.*>": 2,           # round 6: the same 2048 waves, one record per chunk
     r"xamd::bcsc_mfma_bf16_dma_kernel<.*>": 3,
+    r"xamd::bcsc_mfma_i8_stream_full_kernel<.*>": 2,
     r"xamd::bcsc_mfma_i8_dma_kernel<., true, .*>": 3,
     r"xamd::bcsc_mfma_i8_dma_kernel<., false, .*>": 2,
     r"xamd::bcsc_mfma_f32_kernel<.*>": 4,

@@ -619,6 +619,43 @@ def test_bcsc_int8(a_type, M, N, K, mb, bk, bn, keep, beta0):
     assert not api.create_packed_spgemm_bcsc(shape, flags & ~GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
 
 
+# many M-blocks, host-resident pattern, whole tiles, beta = 0: the 8-bit form of the streaming kernel with one record per chunk (bcsc_mfma_i8_stream_full_kernel);
+# both signedness combinations, several tiles per M-block, two 32-deep steps per k-block, an n-tile without blocks, a wave with a single chunk
+@pytest.mark.parametrize("a_type", [DT.U8, DT.I8])
+@pytest.mark.parametrize("M,N,K,mb,bk,bn,keep", [(64, 64, 256, 4099, 32, 16, 0.25), (64, 128, 64, 2050, 64, 64, 0.5), (128, 64, 64, 2049, 32, 32, 0.5), (64, 64, 32, 4101, 32, 64, 1.0),
+                                                 (192, 128, 128, 700, 32, 32, 0.25)])
+def test_bcsc_int8_waves_streaming_over_m_blocks(a_type, M, N, K, mb, bk, bn, keep):
+    api, orc = capi.load(), pyoracle.oracle()
+    rng = np.random.default_rng(15)
+    b_type = DT.I8 if a_type == DT.U8 else DT.U8
+    colptr, rowidx, bvals = make_bcsc(rng, K, N, bk, bn, keep, b_type)
+    if N == 128 and bn == 64:                       # the second n-tile loses all its blocks: its C must become zero
+        keep_blocks = int(colptr[1])
+        colptr = np.array([0, keep_blocks, keep_blocks], dtype=colptr.dtype); rowidx = rowidx[:keep_blocks].copy(); bvals = bvals[:keep_blocks * bn * bk].copy()
+    A = rng.integers(0, 256, mb * K * M).astype(np.uint8) if a_type == DT.U8 else rng.integers(-128, 128, mb * K * M).astype(np.int8)
+    bvals = rng.integers(-128, 128, bvals.size).astype(np.int8) if b_type == DT.I8 else rng.integers(0, 256, bvals.size).astype(np.uint8)
+    A_run = pack_vnni4(A, mb, K, M)
+    C0 = rng.integers(-1000, 1000, mb * N * M).astype(np.int32)
+    ref = C0.copy()
+    orc.lib.oracle_packed_spgemm_bcsc(a_type, DT.I32, M, N, K, mb, bk, bn, 1, A_run.ctypes.data, bvals.ctypes.data, colptr.ctypes.data, rowidx.ctypes.data, ref.ctypes.data, 1)
+    h = api.create_packed_spgemm_bcsc(capi.gemm_shape(mb, 0, K, K, 0, N, a_type, b_type, DT.I32, DT.I32), GEMM_FLAG.BETA_0 | GEMM_FLAG.VNNI_A, 0, capi.SpgemmConfig(M, bk, bn))
+    assert h
+    dA, dB, dC = _dev(A_run), _dev(bvals), _dev(C0.copy())
+    nblk = C.c_ulonglong(N // bn)
+    p = capi.GemmParam()
+    p.a.primary, p.b.primary, p.b.secondary, p.b.tertiary, p.b.quaternary, p.c.primary = dA.data_ptr(), dB.data_ptr(), colptr.ctypes.data, rowidx.ctypes.data, C.addressof(nblk), dC.data_ptr()
+    for hint in (0, 2):                             # cacheable and non-temporal instance
+        api.hip_set_streaming_hint(hint)
+        capi.Api.call(h, p)
+        api.hip_sync(); api.check()
+        assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_i8_stream_full_kernel"
+        got = _host(dC, np.int32)
+        assert np.array_equal(got, ref)
+        dC.zero_()
+    api.hip_set_streaming_hint(0)
+    api.release_kernel(h)
+
+
 # ---- dense packed GEMMs --------------------------------------------------------------------
 @pytest.mark.parametrize("dt", [DT.F32, DT.F64])
 @pytest.mark.parametrize("kind", ["packed", "ac_rm", "bc_rm"])
