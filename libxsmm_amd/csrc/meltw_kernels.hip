@@ -322,6 +322,11 @@ __device__ __forceinline__ void ew8_load(float (&x)[E], gcptr base, int type, in
   }
   const long long idx = (kind == BC_COL) ? i : i + j * ld;
   if constexpr (E == 4) {
+    if (NT && kind == BC_COL) {          // a column every thread of the launch re-reads stays cacheable
+      const f32x4 a = *(GM const f32x4*)((GM const float*)base + idx);
+      x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
+      return;
+    }
     const f32x4 a = ld_pol<NT>((GM const f32x4*)((GM const float*)base + idx));
     x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
   } else
