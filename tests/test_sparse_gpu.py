@@ -651,7 +651,7 @@ def test_bcsc_int8_waves_streaming_over_m_blocks(a_type, M, N, K, mb, bk, bn, ke
         assert api.hip_kernel_name(h, 0).decode() == "bcsc_mfma_i8_stream_full_kernel"
         got = _host(dC, np.int32)
         assert np.array_equal(got, ref)
-        dC.zero_()
+        dC = _dev(C0.copy()); p.c.primary = dC.data_ptr()
     api.hip_set_streaming_hint(0)
     api.release_kernel(h)
 
