@@ -2023,7 +2023,7 @@ LIBXSMM_API int libxsmm_hip_bcsc_bind_pattern(libxsmm_gemmfunction kernel, const
   // pattern tells the launcher), unless the bind is being captured into a graph.  This waits for the stream, like the first call with a new host pattern does.
   int nnzb_read = 0; unsigned long long kmask_read = 0ull;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(cur_stream(), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+  if (tls().stream && hipStreamIsCapturing(cur_stream(), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }      // (the NULL stream cannot be captured and is not asked)
   if (cap == hipStreamCaptureStatusNone && nkb <= 64 && c->bn > 0 && n_block_columns <= 4096) {
     std::vector<unsigned int> hc((size_t)n_block_columns + 1);
     if (hipMemcpyAsync(hc.data(), colptr, hc.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, cur_stream()) == hipSuccess && hipStreamSynchronize(cur_stream()) == hipSuccess &&
