@@ -1052,6 +1052,8 @@ __global__ __launch_bounds__(256, WPS) void bcsc_mfma_bf16_stream_kernel(BcscArg
 constexpr int kBcscRecs = 64;        // chunk records per wave (ring depth 3; depth 2: half)
 // DA: depth of the A ring.  3: two workgroups per CU (78 KiB each).  2: THREE workgroups per CU -- ring 32 KiB, C leaving in quarters through 2 KiB per wave, B up to 8 KiB,
 // 32 records: 50 KiB -- the same 96 KiB of A in flight per CU spread over twelve waves instead of eight (what a wave does between its waits hides behind two others).
+// (EARLY stays a template parameter: as a run-time branch the two wait statements -- each naming the loaded registers -- made the compiler copy those registers at the
+//  branch, BEFORE the wait, i.e. before the loads had landed: wrong results, caught by the parity tests; profiles/r06_bcsc_full.jsonl has no entry for it.)
 // F32: f32 operands and f32 C on v_mfma_f32_16x16x4_f32 -- a chunk is 16 k of 64 rows (the same 4 KiB image, a row is one k instead of a k pair), B up to 16 KiB in LDS,
 // C leaves through LDS eight columns at a time (2 KiB per wave: what is left next to two workgroups' rings)
 template <int BN16, int AUX_A, bool EARLY, int DA, bool F32 = false>     // EARLY: one n-tile and the host's mask of its used k-blocks (BcscArgs::kmask0) -- the first three chunks are requested before anything is loaded

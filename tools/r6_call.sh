@@ -1,5 +1,4 @@
 #!/bin/bash
 # one GPU call of round 6 (scratch: edited per call, results copied to profiles/ by hand)
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_full_size_gpu.py tests/test_sparse_gpu.py tests/test_streaming_auto_gpu.py -x -q -k "bound or bind or config4 or streaming" 2>&1 | tail -3
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 1500 python -m pytest tests/test_sparse_gpu.py tests/test_full_size_gpu.py -x -q -k "bcsc" 2>&1 | tail -3 | tee gpurun_out/r6_call_tests.log
