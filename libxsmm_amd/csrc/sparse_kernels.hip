@@ -1058,10 +1058,11 @@ constexpr int kBcscRecs = 64;        // chunk records per wave (ring depth 3; de
 // C leaves through LDS eight columns at a time (2 KiB per wave: what is left next to two workgroups' rings)
 template <int BN16, int AUX_A, bool EARLY, int DA, bool F32 = false>     // EARLY: one n-tile and the host's mask of its used k-blocks (BcscArgs::kmask0) -- the first three chunks are requested before anything is loaded
 __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_full_kernel(BcscArgs p, unsigned int tiles_i, unsigned int tiles_n, unsigned int mbg, unsigned int total_waves, const unsigned int* gtable) {
-  static_assert(DA == 2 || DA == 3, "ring depth 2 or 3");
-  static_assert(!(F32 && DA == 2), "the f32 form has one LDS plan");
+  static_assert(DA >= 2 && DA <= 4, "ring depth 2, 3 or 4");
+  static_assert(!(F32 && DA != 3), "the f32 form has one LDS plan");
   constexpr int NBL = 4 / BN16, NI = 4, NS = F32 ? 16 : 8;          // NS: stores of one tile
-  constexpr int RECS = DA == 2 ? kBcscRecs / 2 : kBcscRecs, BLDS = F32 ? 16384 : (DA == 2 ? 8192 : kBcscBLds), CPASS = DA == 2 ? 4 : 2, TILEW = F32 ? 512 : 2048 / CPASS;     // C leaves in CPASS passes of 64 / CPASS columns
+  // DA = 4 (bf16): the ring takes 64 KiB of the workgroup's 78, so C leaves in eight passes of eight columns (1 KiB per wave), B up to 8 KiB, 32 records
+  constexpr int RECS = DA == 3 ? kBcscRecs : kBcscRecs / 2, BLDS = F32 ? 16384 : (DA == 3 ? kBcscBLds : 8192), CPASS = DA == 2 ? 4 : (DA == 4 ? 8 : 2), TILEW = F32 ? 512 : 2048 / CPASS;     // C leaves in CPASS passes of 64 / CPASS columns
   __shared__ __attribute__((aligned(16))) unsigned int recs_all[4][RECS][4];
   __shared__ __attribute__((aligned(16))) unsigned int abuf_all[4][DA][1024];
   __shared__ __attribute__((aligned(16))) unsigned int ctile_all[4][TILEW];             // 64 / CPASS columns x 128 bytes
@@ -1201,6 +1202,30 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
           if (AUX_A != 0) __builtin_nontemporal_store(w2[j], dst); else *dst = w2[j];
         }
       });
+    } else if constexpr (CPASS == 8) {
+      // eight columns (1 KiB) per pass: the lanes of one half of a sub-tile write their four 8-byte pieces, every lane reads 16 bytes back, one 1 KiB store
+      sfor<8>([&](auto pc) {
+        constexpr int nt = pc.value / 2, half = pc.value % 2;
+        if ((lx >> 3) == half) {
+          const int n = lx & 7;
+          sfor<4>([&](auto tc) {
+            constexpr int it = tc.value;
+            const float x4[4] = {acc[nt][it][0], acc[nt][it][1], acc[nt][it][2], acc[nt][it][3]};
+            unsigned int o2[2];
+            bf16_pk_exact_n<2>(x4, o2);
+            u32x2v v; v[0] = o2[0]; v[1] = o2[1];
+            const unsigned int wad = tile_lds + 4u * (unsigned int)(n * 32 + 2 * ((4 * it + kg) ^ n));
+            asm volatile("ds_write_b64 %0, %1" :: "v"(wad), "v"(v) : "memory");
+          });
+        }
+        const int n = lane >> 3, j = lane & 7;
+        const unsigned int ad = tile_lds + 4u * (unsigned int)(n * 32 + 4 * (j ^ (n >> 1)));
+        u32x4v w;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w) : "v"(ad) : "memory");
+        if (n & 1) { const unsigned int t0 = w[0], t1 = w[1]; w[0] = w[2]; w[1] = w[3]; w[2] = t0; w[3] = t1; }
+        GM u32x4v* dst = (GM u32x4v*)(cbase + ((long long)(n0 + 16 * nt + 8 * half + n) * p.M + i0) * 2 + 16 * j);
+        if (AUX_A != 0) __builtin_nontemporal_store(w, dst); else *dst = w;
+      });
     } else {
     constexpr int NTP = 4 / CPASS, RD = 8 / CPASS;      // 16-column sub-tiles and 1 KiB stores per pass
     sfor<CPASS>([&](auto hc) {
@@ -1292,10 +1317,10 @@ __global__ __launch_bounds__(256, DA == 2 ? 3 : 2) void bcsc_mfma_bf16_stream_fu
     // first DA of its tile (A(f) was requested DA chunks earlier, in front of them); loads and stores retire this counter in issue order on gfx9
     const int left = total_f - 1 - f;
     const bool stored = cj > 0 && cc < DA;
-    if (left >= DA - 1) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DA - 1) * NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DA - 1) * NI) : "memory"); }
-    else if (DA == 3 && left == 1) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory"); }
-    else if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int behind = left < DA - 1 ? left : DA - 1;          // chunks requested behind this one
+    sfor<DA>([&](auto bc) {
+      if (behind == bc.value) { if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(bc.value * NI + NS) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(bc.value * NI) : "memory"); }
+    });
     const unsigned int r1 = (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_c[1]), r2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_c[2]);
     const unsigned int bo[4] = {r1 & 0xffffu, r1 >> 16, r2 & 0xffffu, r2 >> 16};
     // the chunk's LDS reads in one statement, one wait behind them: the A fragments (lane (row, kg): k pairs 4 kg .. 4 kg + 3 of its row, four image rows), the B
@@ -1800,7 +1825,14 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
 #define XAMD_BCSC_AUX_NT 2          // cache-policy bits of the A requests of a launch that streams (A/B builds: 3, 16, 18: profiles/r06_bcsc_full.jsonl)
 #endif
 #define LAUNCH_FULL4_(B_, X_, E_, D_) hipLaunchKernelGGL((bcsc_mfma_bf16_stream_full_kernel<B_, X_, E_, D_>), sgrid, dim3(256), 0, st, a, tiles_i, tiles_n, (unsigned int)mbg, (unsigned int)waves, table)
-#define LAUNCH_FULL3_(B_, X_, E_) do { if constexpr (XAMD_BCSC_THREE != 0) { if (three) LAUNCH_FULL4_(B_, X_, E_, 2); else LAUNCH_FULL4_(B_, X_, E_, 3); } else LAUNCH_FULL4_(B_, X_, E_, 3); } while (0)
+#if !defined(XAMD_BCSC_DEEP)
+#define XAMD_BCSC_DEEP 0            // ring depth 4 where B (<= 8 KiB) and the record list (<= 32) leave room for it: built, verified (124 parity tests) and measured equal on
+                                    // config #4 (51.8-52.8 against 51.5-52.4 us), worse on short tiles (bn = 64: 30.5 against 26.7 us, the eight-pass epilogue): not instantiated
+                                    // unless built with -DXAMD_BCSC_DEEP=1 (profiles/r06_bcsc_deep.jsonl).  The copy floor with LDS-DMA reads equals the one with register loads.
+#endif
+              const bool deep = XAMD_BCSC_DEEP != 0 && (long long)a.nnzb * a.bn * a.bk * 2 <= 8192 && nkb * (a.bk / 32) <= kBcscRecs / 2;
+#define LAUNCH_FULL3_(B_, X_, E_) do { if constexpr (XAMD_BCSC_THREE != 0) { if (three) LAUNCH_FULL4_(B_, X_, E_, 2); else LAUNCH_FULL4_(B_, X_, E_, 3); } \
+                                       else if constexpr (XAMD_BCSC_DEEP != 0) { if (deep) LAUNCH_FULL4_(B_, X_, E_, 4); else LAUNCH_FULL4_(B_, X_, E_, 3); } else LAUNCH_FULL4_(B_, X_, E_, 3); } while (0)
 #define LAUNCH_FULL_(B_) do { if (early) { if (nta) LAUNCH_FULL3_(B_, XAMD_BCSC_AUX_NT, true); else LAUNCH_FULL3_(B_, 0, true); } \
                               else if (nta) LAUNCH_FULL3_(B_, XAMD_BCSC_AUX_NT, false); else LAUNCH_FULL3_(B_, 0, false); } while (0)
               if (a.bn == 16) LAUNCH_FULL_(1); else if (a.bn == 32) LAUNCH_FULL_(2); else LAUNCH_FULL_(4);

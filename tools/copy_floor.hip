@@ -97,6 +97,41 @@ __global__ __launch_bounds__(256) void bcsc_pattern_kernel(const u32x4* a, u32x4
   }
 }
 
+// the same pattern with the reads as LDS-DMA requests (global_load_lds, 16 bytes per lane, a ring of three 4 KiB chunks per wave in LDS; nothing reads the LDS: what
+// the requests themselves cost).  s_waitcnt counts in issue order: a chunk is waited for with the two younger chunks (and, on a tile's first chunks, the 8 stores) behind it.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int AUX, bool NTS>
+__global__ __launch_bounds__(256) void bcsc_pattern_dma_kernel(const u32x4* a, u32x4* c, unsigned int m_blocks, unsigned int waves) {
+  __shared__ __attribute__((aligned(16))) unsigned int ring[4][3][1024];
+  const unsigned int wv = threadIdx.x >> 6, w = blockIdx.x * 4u + wv, lane = threadIdx.x & 63u;
+  if (w >= waves) return;
+  unsigned int* r = ring[__builtin_amdgcn_readfirstlane((int)wv)][0];
+  const unsigned int tiles = (m_blocks - w + waves - 1u) / waves, total = tiles * 7u;
+  auto issue = [&](unsigned int f) __attribute__((always_inline)) {
+    const unsigned int t = f / 7u, ch = f - 7u * t;
+    GM const u32x4* src = (GM const u32x4*)a + (unsigned long long)(w + t * waves) * 2048ull + ch * 256u + lane;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) __builtin_amdgcn_global_load_lds((GM const void*)(src + 64 * x), (lds_ptr_t)((char*)r + 4096u * (f % 3u) + 1024 * x), 16, 0, AUX);
+  };
+  for (unsigned int f = 0; f < 3u && f < total; ++f) issue(f);
+  unsigned int cc = 0, cj = 0;
+  for (unsigned int f = 0; f < total; ++f) {
+    const unsigned int left = total - 1u - f;
+    const bool stored = cj > 0 && cc < 3;
+    if (left >= 2) { if (stored) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (left == 1) { if (stored) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else if (stored) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (left >= 3) issue(f + 3u);
+    if (++cc == 7u) {
+      GM u32x4* dst = (GM u32x4*)c + (unsigned long long)(w + cj * waves) * 512ull + lane;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) { u32x4 o = (u32x4){f, lane, (unsigned int)x, cj}; if (NTS) __builtin_nontemporal_store(o, dst + x * 64); else dst[x * 64] = o; }
+      cc = 0; ++cj;
+    }
+  }
+}
+
 template <int NR, int NW, bool NT> static void launch(const Streams& s, unsigned long long pieces, hipStream_t st) {
   constexpr int U = 4;
   hipLaunchKernelGGL((copy_kernel<NR, NW, U, NT>), dim3((unsigned int)((pieces + U - 1) / U)), dim3(256), 0, st, s, pieces);
@@ -122,13 +157,15 @@ int main(int argc, char** argv) {
       std::vector<void*> as_((size_t)ns), cs_((size_t)ns);
       for (int q = 0; q < ns; ++q) { CHECK(hipMalloc(&as_[(size_t)q], a_bytes)); CHECK(hipMemset(as_[(size_t)q], 0x31, a_bytes)); CHECK(hipMalloc(&cs_[(size_t)q], c_bytes)); }
       for (unsigned int waves = 2048; waves <= 2048; waves *= 2)      // (4096 and 8192 waves measure the same: profiles/r06_copy_floor.txt history)
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < 6; ++nt) {
           auto go = [&](int i) {
             const u32x4* ap = (const u32x4*)as_[(size_t)(i % ns)]; u32x4* cp = (u32x4*)cs_[(size_t)(i % ns)];
             if (nt == 0) hipLaunchKernelGGL((bcsc_pattern_kernel<0>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves);
             else if (nt == 1) hipLaunchKernelGGL((bcsc_pattern_kernel<1>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves);
             else if (nt == 2) hipLaunchKernelGGL((bcsc_pattern_kernel<2>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves);
-            else hipLaunchKernelGGL((bcsc_pattern_kernel<3>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves); };
+            else if (nt == 3) hipLaunchKernelGGL((bcsc_pattern_kernel<3>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves);
+            else if (nt == 4) hipLaunchKernelGGL((bcsc_pattern_dma_kernel<0, false>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves);
+            else hipLaunchKernelGGL((bcsc_pattern_dma_kernel<2, true>), dim3(waves / 4), dim3(256), 0, st, ap, cp, m_blocks, waves); };
           for (int i = 0; i < 2 * ns; ++i) go(i);
           CHECK(hipStreamSynchronize(st));
           const int reps = std::max(3 * ns, (int)(0.05 / (moved / 5e12)));
@@ -138,7 +175,7 @@ int main(int argc, char** argv) {
           float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
           const double us = ms * 1e3 / reps, tbs = moved / us / 1e6;
           printf("{\"copy_floor\": \"%s\", \"pattern\": \"bcsc 7 of 8 chunks in, 8 KiB out per M-block\", \"m_blocks\": %u, \"waves\": %u, \"sets\": %d, \"policy\": \"%s\", \"us\": %.2f, \"TB/s\": %.3f, \"frac_of_8TBs\": %.4f}\n",
-                 name, m_blocks, waves, ns, nt == 0 ? "default" : nt == 1 ? "nt loads" : nt == 2 ? "nt stores" : "nt", us, tbs, tbs / 8.0);
+                 name, m_blocks, waves, ns, nt == 0 ? "default" : nt == 1 ? "nt loads" : nt == 2 ? "nt stores" : nt == 3 ? "nt" : nt == 4 ? "LDS-DMA reads, default" : "LDS-DMA reads, nt", us, tbs, tbs / 8.0);
         }
       for (int q = 0; q < ns; ++q) { CHECK(hipFree(as_[(size_t)q])); CHECK(hipFree(cs_[(size_t)q])); }
       continue;
