@@ -69,7 +69,8 @@ LIBXSMM_API int libxsmm_hip_get_async(void);
  *   0 (default, also LIBXSMM_HIP_STREAMING=0): decide per launch -- operands of a launch that moves more than the 256 MiB Infinity Cache
  *     holds are loaded non-temporally (they cannot be resident); so are the operands of a smaller launch when the thread's recent launches on OTHER
  *     operand sets (the last 32 sets, each forgotten after 96 launches) together with this one exceed the cache -- a caller that walks over more
- *     input than the cache holds re-reads nothing from it either (round 6); a caller that keeps launching on the same resident set stays cacheable;
+ *     input than the cache holds re-reads nothing from it either (round 6); a caller that keeps launching on the same resident set stays cacheable,
+ *     and so does a launch whose first operand is what one of those recent launches wrote (a hand-over inside a chain: GEMM, then a TPP on its C);
  *   1: operands are re-read by later launches or were just produced on the device (keep them cacheable, never non-temporal);
  *   2: operands are read once from HBM (a pass over a working set far larger than the cache): non-temporal loads at every size.
  * Measured on 4096 f32 32^3 problems: hint 2 is 7 % faster when the operands do come from HBM and 50 % slower when they were

@@ -631,7 +631,7 @@ int launch_gemm_f64(const GemmArgs& a_in, void* stream, const char** kernel_name
   // cache policy as for the f32 kernels (DESIGN decision 8): non-temporal requests only when the operands cannot be cache resident -- one launch
   // moves more than the 256 MiB Infinity Cache holds -- or the caller declared a streaming pass (libxsmm_hip_set_streaming_hint(2)); never with hint 1
   const unsigned long long moved = (unsigned long long)a.nbatch * ((unsigned long long)a.br_count * (unsigned long long)a.k * (unsigned long long)(a.m + a.n) + (unsigned long long)a.m * a.n) * 8ull;
-  bool nt = a.stream_hint == 2 || (a.stream_hint == 0 && (moved > (256ull << 20) || rt_recent_operands_exceed_cache(a.a, moved)));
+  bool nt = a.stream_hint == 2 || (a.stream_hint == 0 && (moved > (256ull << 20) || rt_recent_operands_exceed_cache(a.a, moved, a.c)));
   if (pol_env == 0) nt = false; else if (pol_env == 1) nt = true;
   constexpr bool blocked_off = false;
   if (!blocked_off && f64_blocked_ok(a)) {

@@ -3928,7 +3928,7 @@ static bool stream_nt(const GemmArgs& a, int elem_bytes_ab, int elem_bytes_c) {
   if (a.batch_inner || a.list_a || a.bs_a == 0 || a.bs_b == 0 || a.stream_hint == 1) return false;
   if (a.stream_hint == 2) return true;
   const unsigned long long per = a.br_count * (unsigned long long)a.k * (unsigned long long)(a.m + a.n) * elem_bytes_ab + (unsigned long long)a.m * a.n * elem_bytes_c;
-  return per * a.nbatch > (256ull << 20) || rt_recent_operands_exceed_cache(a.a, per * a.nbatch);      // (round 6: ... or this thread's recent launches together)
+  return per * a.nbatch > (256ull << 20) || rt_recent_operands_exceed_cache(a.a, per * a.nbatch, a.c);      // (round 6: ... or this thread's recent launches together)
 }
 // the four-problems-per-wave kernel for 16 x 16 problems: m = n = 16, k % 16 == 0, no transposes, beta = 0, no fused epilogue, operands whose
 // vector loads are aligned (B columns and C columns 16 bytes for f32, 8 bytes for bf16; bf16 A in VNNI-2 with dword-aligned rows)

@@ -364,22 +364,25 @@ template <typename T> T* to_device(const T* host, size_t count) {
 
 namespace xamd {
 static thread_local int g_window_verdict = 0;          // libxsmm_hip_streaming_window_verdict
-bool rt_recent_operands_exceed_cache(const void* key, unsigned long long bytes) {
+bool rt_recent_operands_exceed_cache(const void* key, unsigned long long bytes, const void* out) {
   constexpr int kEntries = 32;                          // 32 operand sets, each forgotten after 96 decisions without being seen again
-  struct Entry { const void* key; unsigned long long bytes, gen; };
+  struct Entry { const void* key; const void* out; unsigned long long bytes, gen; };
   struct Window { Entry e[kEntries]; unsigned long long gen; };
   static thread_local Window w = {};
   ++w.gen;
   int slot = -1, oldest = 0;
+  bool handed_over = false;                             // the first operand is what a remembered launch wrote
   for (int i = 0; i < kEntries; ++i) {
+    const bool live = w.e[i].gen != 0 && w.gen - w.e[i].gen < 96ull;
     if (w.e[i].key == key && w.e[i].gen != 0) slot = i;
+    if (live && key != nullptr && w.e[i].out == key && w.e[i].key != key) handed_over = true;
     if (w.e[i].gen < w.e[oldest].gen) oldest = i;
   }
   if (slot < 0) slot = oldest;
-  w.e[slot] = Entry{key, bytes, w.gen};
+  w.e[slot] = Entry{key, out, bytes, w.gen};
   unsigned long long sum = 0;
   for (int i = 0; i < kEntries; ++i) if (w.e[i].gen != 0 && w.gen - w.e[i].gen < 96ull) sum += w.e[i].bytes;
-  g_window_verdict = sum > (256ull << 20) ? 1 : 0;
+  g_window_verdict = (!handed_over && sum > (256ull << 20)) ? 1 : 0;
   return g_window_verdict != 0;
 }
 int rt_window_verdict() { return g_window_verdict; }
@@ -930,7 +933,7 @@ void run_meltw(KernelCtx* k, const void* param, const BatchSpec& b) {
     const int hint = tls().stream_hint;
     const unsigned long long elems = (unsigned long long)std::max(a.m, 0) * (unsigned long long)std::max(a.n, 0) * (unsigned long long)std::max<size_t>(b.count, 1);
     const unsigned long long bytes = elems * (unsigned long long)(typesize(a.in0_type) + typesize(a.out_type));
-    a.nt = hint == 2 || (hint == 0 && (bytes >= (256ull << 20) || rt_recent_operands_exceed_cache(a.in0, bytes))) ? 1 : 0;
+    a.nt = hint == 2 || (hint == 0 && (bytes >= (256ull << 20) || rt_recent_operands_exceed_cache(a.in0, bytes, a.out))) ? 1 : 0;
   }
   const char* kname = nullptr;
   const bool stoch = a.out_type == LIBXSMM_DATATYPE_BF8 &&

@@ -1775,7 +1775,7 @@ int launch_bcsc(const BcscArgs& a_in, void* stream, const char** name) {
   {
     const unsigned long long es = a.a_type == LIBXSMM_DATATYPE_F32 ? 4ull : (a.a_type == LIBXSMM_DATATYPE_BF16 ? 2ull : 1ull);
     const unsigned long long moved = bcsc_launch_bytes(a, es, a.c_type == LIBXSMM_DATATYPE_BF16 ? 2ull : 4ull);
-    a.nt_a = (a.stream_hint == 2 || (a.stream_hint == 0 && (moved > (256ull << 20) || rt_recent_operands_exceed_cache(a.a, moved)))) ? 1 : 0;
+    a.nt_a = (a.stream_hint == 2 || (a.stream_hint == 0 && (moved > (256ull << 20) || rt_recent_operands_exceed_cache(a.a, moved, a.c)))) ? 1 : 0;
   }
   if (a.m_blocks <= 0 || a.M <= 0 || a.N <= 0) { if (name) *name = "(empty)"; return 0; }
   // matrix-core path: bf16 with VNNI-2 A, 32-deep k steps, 16-wide n sub-tiles, 16-row i tiles, 8-byte aligned C columns

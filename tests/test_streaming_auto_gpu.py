@@ -43,6 +43,23 @@ def test_walking_over_more_operand_sets_than_the_cache_holds_switches_to_streami
     assert verdicts.index(1) == 5
     api.hip_sync()
     assert torch.equal(Cs[0], cached)                        # the same numbers under either policy
+    # a hand-over inside a chain: a TPP whose input is what the GEMM just wrote stays cacheable although the walk still fills the window
+    from libxsmm_amd.capi import UNARY
+    verdicts = [launch(i % nsets) for i in range(nsets)]
+    assert verdicts[-1] == 1
+    ht = api.dispatch_meltw_unary(UNARY.RELU, capi.UnaryShape(m * m, batch, m * m, m * m, DT.F32, DT.F32, DT.F32), 0)
+    assert ht
+    out = torch.empty_like(Cs[0])
+    up = capi.UnaryParam(); up.in_.primary, up.out.primary = Cs[nsets - 1].data_ptr(), out.data_ptr()
+    capi.Api.call(ht, up)
+    api.check()
+    assert api.hip_streaming_window_verdict() == 0
+    up.in_.primary = As[2].data_ptr()                        # ... while the same TPP on an operand nobody just produced streams like the rest of the walk
+    capi.Api.call(ht, up)
+    api.check()
+    assert api.hip_streaming_window_verdict() == 1
+    api.hip_sync()
+    assert torch.equal(out, torch.relu(As[2]))
     for _ in range(200):
         v = launch(3)
     assert v == 0                                            # settled on one set again
