@@ -270,7 +270,7 @@ int launch_bcsc(const BcscArgs& args, void* stream, const char** kernel_name);
 // TOGETHER WITH those of the calling thread's recent launches on other operands do (a caller that walks over more input sets than the cache holds re-reads nothing
 // from it either).  `key` identifies the launch's operand set (its first operand's address), `bytes` is what the launch moves.  32 sets are remembered, each forgotten after
 // 96 decisions without being seen again, so a caller that settles on one resident set gets cacheable loads back.  (runtime.cpp, thread-local.)
-// `out`: what the launch writes.  A launch whose first operand IS what one of the remembered launches wrote is a hand-over inside a chain (GEMM -> TPP on its C): its
+// `out`: what the launch writes.  A launch whose first operand IS what one of the last eight decisions' launches wrote is a hand-over inside a chain (GEMM -> TPP on its C): its
 // operand may well still be cached, it stays cacheable whatever the sum says.
 bool rt_recent_operands_exceed_cache(const void* key, unsigned long long bytes, const void* out = nullptr);
 int rt_window_verdict();

@@ -322,11 +322,8 @@ __device__ __forceinline__ void ew8_load(float (&x)[E], gcptr base, int type, in
   }
   const long long idx = (kind == BC_COL) ? i : i + j * ld;
   if constexpr (E == 4) {
-    if (NT && kind == BC_COL) {          // a column every thread of the launch re-reads stays cacheable
-      const f32x4 a = *(GM const f32x4*)((GM const float*)base + idx);
-      x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
-      return;
-    }
+    // (a cacheable load for a broadcast column next to the non-temporal one was tried and taken back: the compiler folded the two loads of this function into ONE
+    //  without the non-temporal bit -- the f32 copy lost its 5 %, found in the round's last closing run)
     const f32x4 a = ld_pol<NT>((GM const f32x4*)((GM const float*)base + idx));
     x[0] = a[0]; x[1] = a[1]; x[2] = a[2]; x[3] = a[3];
   } else

@@ -375,7 +375,7 @@ bool rt_recent_operands_exceed_cache(const void* key, unsigned long long bytes, 
   for (int i = 0; i < kEntries; ++i) {
     const bool live = w.e[i].gen != 0 && w.gen - w.e[i].gen < 96ull;
     if (w.e[i].key == key && w.e[i].gen != 0) slot = i;
-    if (live && key != nullptr && w.e[i].out == key && w.e[i].key != key) handed_over = true;
+    if (live && key != nullptr && w.e[i].out == key && w.e[i].key != key && w.gen - w.e[i].gen <= 8ull) handed_over = true;      // (written within the last few launches: an address a finished phase of the caller wrote to and freed is not a hand-over)
     if (w.e[i].gen < w.e[oldest].gen) oldest = i;
   }
   if (slot < 0) slot = oldest;
