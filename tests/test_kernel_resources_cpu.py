@@ -85,3 +85,26 @@ def test_committed_table_is_current(table):
         committed[cols[8]] = (int(cols[3]), int(cols[4]))                 # static LDS and scratch; register counts may move with the compiler
     built = {t["name"]: (t["lds"], t["scratch"]) for t in table}
     assert committed == built
+
+
+def test_hand_written_waits_of_the_bcsc_full_tile_kernels_stay_the_only_ones():
+    """DESIGN.md section 4, decision 36: next to LDS-DMA requests in flight the compiler puts `s_waitcnt vmcnt(0)` in front of every LDS access it can see, which lands
+    the whole operand ring before every chunk.  The full-tile streaming kernels write their in-loop LDS traffic as instructions for that reason: no such wait may be
+    left in them (tools/dma_wait_scan.py, from the code objects of the built library)."""
+    import dma_wait_scan
+    table = dma_wait_scan.scan(LIB)
+    full = {k: v for k, v in table.items() if "stream_full_kernel" in k}
+    assert len(full) >= 36                                   # bf16 12, f32 12, 8-bit integers 24 instances (some share a symbol prefix cut by c++filt)
+    for fam in ("bcsc_mfma_bf16_stream_full_kernel", "bcsc_mfma_i8_stream_full_kernel"):
+        assert any(fam in k for k in full), fam
+    bad = {k: v for k, v in full.items() if v[1]}
+    assert not bad, bad
+
+
+def test_non_temporal_instance_of_the_elementwise_kernel_loads_non_temporally():
+    """The f32 copy's non-temporal instance lost the bit on its load once (a second, cacheable load in the same function made the compiler fold the two): 0.755 -> 0.716."""
+    import dma_wait_scan
+    ins = dma_wait_scan.instructions(LIB, "meltw_ew8_kernelILi1ELb1ELi4E")
+    assert ins, "meltw_ew8_kernel<1, true, 4> not found"
+    wide = [x for x in ins if x.startswith("global_load_dwordx4") or x.startswith("global_store_dwordx4")]
+    assert wide and all(x.endswith(" nt") for x in wide), wide
