@@ -172,7 +172,7 @@ def fsspmdm(api, N, density, dtype=DT.F64, beta=0.0):
     return w
 
 
-def bcsc(api, m_blocks=8192, M=64, K=256, N=64, bk=32, bn=16, dtype="bf16", host_pattern=False):
+def bcsc(api, m_blocks=8192, M=64, K=256, N=64, bk=32, bn=16, dtype="bf16", host_pattern=False, bind=False):
     """BASELINE config #4 (bf16) and its f32 / 8-bit integer siblings; host_pattern: colptr / rowidx in plain host memory like the
     reference's driver (inverted on the host once and cached with the kernel) instead of device arrays (inverted by a kernel per call)."""
     colptr, rowidx = structured_2_of_8(K, N, bk, bn)
@@ -195,13 +195,15 @@ def bcsc(api, m_blocks=8192, M=64, K=256, N=64, bk=32, bn=16, dtype="bf16", host
     Cs = [torch.zeros(m_blocks * N * M * sc, dtype=torch.uint8, device=DEV) for _ in range(ns)]
     bv, dcp, dri = operand(nnzb * bk * bn), dev(colptr), dev(rowidx)
     nblk = C.c_ulonglong(N // bn)
+    if bind:                                       # libxsmm_hip_bcsc_bind_pattern: the device-resident pattern is inverted (and read) once
+        assert not host_pattern and api.hip_bcsc_bind_pattern(h, dcp.data_ptr(), dri.data_ptr(), N // bn) == 0
     ps = []
     for s in range(ns):
         p = capi.GemmParam()
         p.a.primary, p.b.primary, p.b.quaternary, p.c.primary = As[s].data_ptr(), bv.data_ptr(), C.addressof(nblk), Cs[s].data_ptr()
         p.b.secondary, p.b.tertiary = (colptr.ctypes.data, rowidx.ctypes.data) if host_pattern else (dcp.data_ptr(), dri.data_ptr())
         ps.append(p)
-    w = Work(api, f"packed_spgemm_bcsc {dtype} 2:8 M={M} K={K} N={N} bk={bk} bn={bn} m_blocks={m_blocks} beta=0" + (" host pattern" if host_pattern else ""),
+    w = Work(api, f"packed_spgemm_bcsc {dtype} 2:8 M={M} K={K} N={N} bk={bk} bn={bn} m_blocks={m_blocks} beta=0" + (" host pattern" if host_pattern else (" bound pattern" if bind else "")),
              2.0 * M * m_blocks * bk * bn * nnzb, float(m_blocks * M * (kt * bk * sa + N * sc) + nnzb * bk * bn * sa), ns, lambda s: capi.Api.call(h, ps[s]),
              lambda: api.hip_kernel_name(h, 0).decode())
     w.dense_equiv_flops = 2.0 * M * m_blocks * N * K
